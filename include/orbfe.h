@@ -1,0 +1,173 @@
+/*
+ * orbfe.h -- C ABI of the MI355X-native per-frame front-end for ORB_SLAM2_aruco.
+ *
+ * One shared library (liborbfe.so, built by hipcc for gfx950) exports exactly the
+ * entry points below.  Plain pointers and sizes only: no C++ types, no torch
+ * types, nothing thrown across the boundary (status codes instead; the C++ shim
+ * classes in orb_slam2_aruco_amd/csrc/shims re-raise to keep reference behaviour).
+ *
+ * Each group names the reference interface it replaces (file:line in the
+ * reference tree, CarminLiu/ORB_SLAM2_aruco):
+ *
+ *   orbfe_extractor_*   ORB_SLAM2::ORBextractor            include/ORBextractor.h:45-113
+ *                       ctor                               src/ORBextractor.cc:410-470
+ *                       operator()(image, mask, kps, desc) src/ORBextractor.cc:1043-1105
+ *                       Get{Levels,ScaleFactor(s),...}     include/ORBextractor.h:63-83
+ *                       called from Frame::ExtractORB      src/Frame.cc:200-206
+ *   orbfe_aruco_*       aruco::MarkerDetector              Thirdparty/aruco/aruco/markerdetector.h:96-312
+ *                       setDictionary / setDetectionMode / setCornerRefinementMethod / detect
+ *                       configured + called at             src/Frame.cc:129-142
+ *   orbfe_hamming*,     ORBmatcher::DescriptorDistance     src/ORBmatcher.cc:1651-1667
+ *   orbfe_knn2*,        best/second-best inner loop of every SearchBy*  
+ *   orbfe_search_for_initialization   ORBmatcher::SearchForInitialization  src/ORBmatcher.cc:409-524
+ *
+ * Memory convention: functions without a suffix take HOST pointers (drop-in for
+ * the reference's call sites, which hand over cv::Mat / std::vector storage) and
+ * do their own H2D/D2H staging.  Functions ending in _device take DEVICE pointers
+ * (hipMalloc'd, e.g. torch CUDA tensors) and a hipStream_t passed as void*; they
+ * launch asynchronously on that stream and are the batched-video path.
+ *
+ * Threading: an extractor / detector handle is a stateful, non-re-entrant object
+ * like the classes it replaces (one handle per stream of frames).  The
+ * matching functions are thread-safe.
+ */
+#ifndef ORBFE_H
+#define ORBFE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* status codes (0 = ok, <0 = error; orbfe_last_error() holds the message of the calling thread) */
+#define ORBFE_OK 0
+#define ORBFE_ERR_INVALID (-1)   /* bad argument (null pointer, non-positive size, ...) */
+#define ORBFE_ERR_NO_DEVICE (-2) /* no gfx950 device / HIP runtime unusable: the product path has NO CPU fallback */
+#define ORBFE_ERR_HIP (-3)       /* a HIP call failed */
+#define ORBFE_ERR_CAPACITY (-4)  /* caller-provided output capacity too small */
+#define ORBFE_ERR_DICT (-5)      /* unknown dictionary name */
+
+/* cv::KeyPoint layout (pt.x, pt.y, size, angle, response, octave, class_id) = 28 bytes;
+ * fields are set as at src/ORBextractor.cc:822-846,:477 */
+typedef struct orbfe_keypoint {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} orbfe_keypoint;
+
+/* aruco::Marker essentials (marker.h:42-56): id + 4 refined corners (x,y) in detection order */
+typedef struct orbfe_marker {
+    int32_t id;
+    float corners[4][2];
+} orbfe_marker;
+
+const char* orbfe_last_error(void);
+const char* orbfe_version(void);
+int orbfe_device_count(void); /* number of usable HIP devices, 0 if none */
+
+/* ------------------------------------------------------------------ ORB extractor -- */
+typedef struct orbfe_extractor orbfe_extractor;
+
+/* ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST); device = HIP device ordinal. NULL on error. */
+orbfe_extractor* orbfe_extractor_create(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST,
+                                        int device);
+void orbfe_extractor_destroy(orbfe_extractor* h);
+
+int orbfe_extractor_get_levels(const orbfe_extractor* h);                                 /* GetLevels */
+float orbfe_extractor_get_scale_factor(const orbfe_extractor* h);                         /* GetScaleFactor */
+int orbfe_extractor_get_scale_factors(const orbfe_extractor* h, float* out);              /* GetScaleFactors */
+int orbfe_extractor_get_inverse_scale_factors(const orbfe_extractor* h, float* out);      /* GetInverseScaleFactors */
+int orbfe_extractor_get_scale_sigma_squares(const orbfe_extractor* h, float* out);        /* GetScaleSigmaSquares */
+int orbfe_extractor_get_inverse_scale_sigma_squares(const orbfe_extractor* h, float* out);/* GetInverseScaleSigmaSquares */
+int orbfe_extractor_get_features_per_level(const orbfe_extractor* h, int32_t* out);       /* mnFeaturesPerLevel */
+/* upper bound on keypoints per frame (the quadtree may overshoot a level quota by a few nodes,
+ * src/ORBextractor.cc:730): size kps/desc buffers with this */
+int orbfe_extractor_max_keypoints(const orbfe_extractor* h);
+
+/* operator()(image, mask(ignored), keypoints, descriptors) for one CV_8UC1 frame in host memory.
+ * img: rows x cols bytes with row stride `step`.  kps: capacity records; desc: capacity x 32 bytes, row i belongs to
+ * kps[i].  *n_out = number of keypoints.  Empty image (rows==0 || cols==0 || img==NULL) -> ORBFE_OK with *n_out
+ * untouched semantics of :1046 mapped to *n_out = 0. */
+int orbfe_extract(orbfe_extractor* h, const uint8_t* img, int rows, int cols, size_t step, orbfe_keypoint* kps,
+                  uint8_t* desc, int capacity, int32_t* n_out);
+
+/* Batched video mode, host buffers: nframes images `frame_stride` bytes apart; outputs are nframes blocks of
+ * `capacity` records; n_out[nframes]. */
+int orbfe_extract_batch(orbfe_extractor* h, const uint8_t* imgs, int nframes, size_t frame_stride, int rows, int cols,
+                        size_t step, orbfe_keypoint* kps, uint8_t* desc, int capacity, int32_t* n_out);
+
+/* Batched video mode, device buffers, asynchronous on `stream` (hipStream_t). d_n_out: int32[nframes] on device. */
+int orbfe_extract_batch_device(orbfe_extractor* h, const uint8_t* d_imgs, int nframes, size_t frame_stride, int rows,
+                               int cols, size_t step, orbfe_keypoint* d_kps, uint8_t* d_desc, int capacity,
+                               int32_t* d_n_out, void* stream);
+
+/* Stage read-back for parity tests (valid after an extract call; `frame` indexes the last batch).
+ * stage 0: pyramid level image, 1: blurred level image -> out must hold w*h bytes (tightly packed). */
+int orbfe_extractor_debug_level_size(orbfe_extractor* h, int level, int* w, int* hgt);
+int orbfe_extractor_debug_level_image(orbfe_extractor* h, int frame, int level, int stage, uint8_t* out);
+/* stage 0: FAST candidates handed to the quadtree (x,y relative to the 16-px border, response=score),
+ * stage 1: keypoints kept by the quadtree (level coordinates).  Returns count in *n (<= capacity copied). */
+int orbfe_extractor_debug_level_keypoints(orbfe_extractor* h, int frame, int level, int stage, orbfe_keypoint* out,
+                                          int capacity, int32_t* n);
+/* per-kernel timing of the last batch call on this handle, microseconds, in launch order; returns number written */
+int orbfe_extractor_debug_kernel_times(orbfe_extractor* h, float* out_us, int capacity);
+
+/* ------------------------------------------------------------------ descriptor matching -- */
+/* popcount(a XOR b) over 256 bits, host pointers (ORBmatcher::DescriptorDistance) */
+int orbfe_hamming(const uint8_t* a, const uint8_t* b);
+
+/* All-pairs best / second-best of nq query descriptors against nt train descriptors (32 B rows), rule of App. D:
+ *   if d<best {second=best; best=d; idx=t} else if d<second {second=d}   (first candidate wins ties)
+ * best and second start at `init` (256 or INT_MAX in the reference). idx = -1 when nt == 0. Host pointers. */
+int orbfe_knn2(const uint8_t* Q, int nq, const uint8_t* T, int nt, int init, int32_t* best_idx, int32_t* best_dist,
+               int32_t* second_dist, int device);
+
+/* Batched device variant: npairs independent (Q,T) problems. Q/T: device pointers to descriptor blocks,
+ * block p at Q + p*q_stride bytes with d_nq[p] valid rows (<= max_nq), same for T. Outputs blocks of max_nq. */
+int orbfe_knn2_batch_device(const uint8_t* d_Q, const int32_t* d_nq, size_t q_stride, int max_nq, const uint8_t* d_T,
+                            const int32_t* d_nt, size_t t_stride, int max_nt, int npairs, int init,
+                            int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second_dist, void* stream);
+
+/* ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) with an undistorted camera
+ * (grid bounds 0..cols, 0..rows; Frame.cc:440-446).  prev_matched: n1 x 2 floats, updated in place like
+ * vbPrevMatched; matches12: n1 ints (-1 = none).  Returns ORBFE_OK and the match count in *nmatches. */
+int orbfe_search_for_initialization(const orbfe_keypoint* kps1, const uint8_t* desc1, int n1,
+                                    const orbfe_keypoint* kps2, const uint8_t* desc2, int n2, int cols, int rows,
+                                    float* prev_matched, int32_t* matches12, int window_size, float nnratio,
+                                    int check_orientation, int32_t* nmatches, int device);
+
+/* Batched device variant over npairs frame pairs (frame t vs t-1 of a stream); all arrays are blocks of `capacity`
+ * records per frame; pair p matches frame p (as F1) against frame p+1 (as F2). prev_matched == NULL means
+ * "start from F1's own keypoint positions" (what Tracking does on the first call, src/Tracking.cc:520-523). */
+int orbfe_search_for_initialization_batch_device(const orbfe_keypoint* d_kps, const uint8_t* d_desc,
+                                                 const int32_t* d_n, int capacity, int npairs, int cols, int rows,
+                                                 int window_size, float nnratio, int check_orientation,
+                                                 int32_t* d_matches12, int32_t* d_nmatches, void* stream);
+
+/* ------------------------------------------------------------------ ArUco marker detector -- */
+typedef struct orbfe_aruco orbfe_aruco;
+
+/* MarkerDetector + setDictionary(dict) + setDetectionMode(DM_NORMAL) +
+ * setCornerRefinementMethod(CORNER_LINES): the configuration of src/Frame.cc:135-137. NULL on error. */
+orbfe_aruco* orbfe_aruco_create(const char* dictionary, int device);
+void orbfe_aruco_destroy(orbfe_aruco* h);
+int orbfe_aruco_set_dictionary(orbfe_aruco* h, const char* dictionary);
+int orbfe_aruco_max_markers(const orbfe_aruco* h);
+
+/* detect(image) -> markers sorted by id, corners refined by contour lines. Host pointers, one CV_8UC1 frame. */
+int orbfe_aruco_detect(orbfe_aruco* h, const uint8_t* img, int rows, int cols, size_t step, orbfe_marker* out,
+                       int capacity, int32_t* n_out);
+int orbfe_aruco_detect_batch(orbfe_aruco* h, const uint8_t* imgs, int nframes, size_t frame_stride, int rows, int cols,
+                             size_t step, orbfe_marker* out, int capacity, int32_t* n_out);
+int orbfe_aruco_detect_batch_device(orbfe_aruco* h, const uint8_t* d_imgs, int nframes, size_t frame_stride, int rows,
+                                    int cols, size_t step, orbfe_marker* d_out, int capacity, int32_t* d_n_out,
+                                    void* stream);
+/* stage read-back for parity tests: 0 = thresholded image (rows x cols bytes, 0/255) of `frame` */
+int orbfe_aruco_debug_image(orbfe_aruco* h, int frame, int stage, uint8_t* out);
+int orbfe_aruco_debug_kernel_times(orbfe_aruco* h, float* out_us, int capacity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBFE_H */

@@ -1,0 +1,239 @@
+/*
+ * match_oracle.cpp -- CPU restatement of the reference's descriptor matching primitives.
+ * TEST INFRASTRUCTURE ONLY (see orb_oracle.cpp header for the rules).
+ *
+ * Restates: ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1651-1667), the
+ * best / second-best update rule shared by every SearchBy* (App. D), the Frame
+ * keypoint grid (src/Frame.cc:183-198, 280-345), ORBmatcher::SearchForInitialization
+ * (src/ORBmatcher.cc:409-524) and ComputeThreeMaxima (:1605-1646).
+ * These are integer algorithms fully contained in the reference, so this part of
+ * the oracle is pinned by known-answer tests (popcount identity, hand-built cases).
+ */
+#include <climits>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+struct KeyPoint {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+};
+
+const int TH_HIGH = 100, TH_LOW = 50, HISTO_LENGTH = 30; /* ORBmatcher.cc:37-39 */
+const int FRAME_GRID_ROWS = 48, FRAME_GRID_COLS = 64;    /* Frame.h:40-41 */
+
+/* ORBmatcher.cc:1651-1667 (the bit-hack itself, not __builtin_popcount) */
+int DescriptorDistance(const uint8_t* a, const uint8_t* b)
+{
+    const int32_t* pa = (const int32_t*)a;
+    const int32_t* pb = (const int32_t*)b;
+    int dist = 0;
+    for (int i = 0; i < 8; i++, pa++, pb++) {
+        unsigned int v = *pa ^ *pb;
+        v = v - ((v >> 1) & 0x55555555);
+        v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+        dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+    }
+    return dist;
+}
+
+/* ORBmatcher.cc:1605-1646 */
+void ComputeThreeMaxima(const int* histo_sizes, int L, int& ind1, int& ind2, int& ind3)
+{
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < L; i++) {
+        const int s = histo_sizes[i];
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+
+/* Frame grid for an undistorted camera: mnMinX=0, mnMaxX=cols, mnMinY=0, mnMaxY=rows (Frame.cc:440-446) */
+struct FrameGrid {
+    float mnMinX, mnMinY, mnMaxX, mnMaxY, invW, invH;
+    const KeyPoint* kps;
+    int N;
+    std::vector<int> cell[FRAME_GRID_COLS][FRAME_GRID_ROWS];
+
+    FrameGrid(const KeyPoint* k, int n, int cols, int rows) : kps(k), N(n)
+    {
+        mnMinX = 0.f; mnMaxX = (float)cols; mnMinY = 0.f; mnMaxY = (float)rows;
+        invW = static_cast<float>(FRAME_GRID_COLS) / static_cast<float>(mnMaxX - mnMinX); /* Frame.cc:112 */
+        invH = static_cast<float>(FRAME_GRID_ROWS) / static_cast<float>(mnMaxY - mnMinY);
+        for (int i = 0; i < N; i++) { /* Frame.cc:183-198, :335-345 */
+            int px = (int)std::round((kps[i].x - mnMinX) * invW);
+            int py = (int)std::round((kps[i].y - mnMinY) * invH);
+            if (px < 0 || px >= FRAME_GRID_COLS || py < 0 || py >= FRAME_GRID_ROWS) continue;
+            cell[px][py].push_back(i);
+        }
+    }
+    /* Frame.cc:280-333 */
+    std::vector<int> GetFeaturesInArea(float x, float y, float r, int minLevel, int maxLevel) const
+    {
+        std::vector<int> v;
+        const int nMinCellX = std::max(0, (int)std::floor((x - mnMinX - r) * invW));
+        if (nMinCellX >= FRAME_GRID_COLS) return v;
+        const int nMaxCellX = std::min((int)FRAME_GRID_COLS - 1, (int)std::ceil((x - mnMinX + r) * invW));
+        if (nMaxCellX < 0) return v;
+        const int nMinCellY = std::max(0, (int)std::floor((y - mnMinY - r) * invH));
+        if (nMinCellY >= FRAME_GRID_ROWS) return v;
+        const int nMaxCellY = std::min((int)FRAME_GRID_ROWS - 1, (int)std::ceil((y - mnMinY + r) * invH));
+        if (nMaxCellY < 0) return v;
+        const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+        for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+            for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+                const std::vector<int>& vCell = cell[ix][iy];
+                for (size_t j = 0; j < vCell.size(); j++) {
+                    const KeyPoint& kp = kps[vCell[j]];
+                    if (bCheckLevels) {
+                        if (kp.octave < minLevel) continue;
+                        if (maxLevel >= 0 && kp.octave > maxLevel) continue;
+                    }
+                    const float distx = kp.x - x, disty = kp.y - y;
+                    if (std::fabs(distx) < r && std::fabs(disty) < r) v.push_back(vCell[j]);
+                }
+            }
+        return v;
+    }
+};
+
+} // namespace
+
+extern "C" {
+
+int oracle_descriptor_distance(const uint8_t* a, const uint8_t* b) { return DescriptorDistance(a, b); }
+
+/* All-pairs best / second-best with the reference update rule (strict '<', first candidate wins):
+ *   if d<best {second=best; best=d; idx=i} else if d<second {second=d}
+ * init = starting value of best and second (256 or INT_MAX in the reference, App. D). */
+void oracle_knn2(const uint8_t* Q, int nq, const uint8_t* T, int nt, int init, int32_t* best_idx, int32_t* best_dist,
+                 int32_t* second_dist)
+{
+    for (int q = 0; q < nq; q++) {
+        int best = init, second = init, idx = -1;
+        for (int t = 0; t < nt; t++) {
+            int d = DescriptorDistance(Q + (size_t)q * 32, T + (size_t)t * 32);
+            if (d < best) { second = best; best = d; idx = t; }
+            else if (d < second) second = d;
+        }
+        best_idx[q] = idx; best_dist[q] = best; second_dist[q] = second;
+    }
+}
+
+/* Candidate lists of Frame::GetFeaturesInArea for a batch of queries, CSR output.
+ * offsets has nq+1 entries; returns total count (idx may be NULL to size it). */
+int oracle_features_in_area(const void* kps2, int n2, int cols, int rows, const float* qx, const float* qy, int nq,
+                            float r, int minLevel, int maxLevel, int32_t* offsets, int32_t* idx, int capacity)
+{
+    FrameGrid g((const KeyPoint*)kps2, n2, cols, rows);
+    int total = 0;
+    for (int q = 0; q < nq; q++) {
+        offsets[q] = total;
+        std::vector<int> v = g.GetFeaturesInArea(qx[q], qy[q], r, minLevel, maxLevel);
+        for (int i : v) {
+            if (idx && total < capacity) idx[total] = i;
+            total++;
+        }
+    }
+    offsets[nq] = total;
+    return total;
+}
+
+/* Guided best/second-best over CSR candidate lists, plain rule (no cross-query state). */
+void oracle_knn2_csr(const uint8_t* Q, int nq, const uint8_t* T, const int32_t* offsets, const int32_t* idx, int init,
+                     int32_t* best_idx, int32_t* best_dist, int32_t* second_dist)
+{
+    for (int q = 0; q < nq; q++) {
+        int best = init, second = init, bi = -1;
+        for (int k = offsets[q]; k < offsets[q + 1]; k++) {
+            int d = DescriptorDistance(Q + (size_t)q * 32, T + (size_t)idx[k] * 32);
+            if (d < best) { second = best; best = d; bi = idx[k]; }
+            else if (d < second) second = d;
+        }
+        best_idx[q] = bi; best_dist[q] = best; second_dist[q] = second;
+    }
+}
+
+/* ORBmatcher::SearchForInitialization, ORBmatcher.cc:409-524.
+ * prevMatched (n1 x 2 floats) is updated in place like vbPrevMatched; matches12 gets n1 ints. */
+int oracle_search_for_initialization(const void* kps1_, const uint8_t* desc1, int n1, const void* kps2_,
+                                     const uint8_t* desc2, int n2, int cols, int rows, float* prevMatched,
+                                     int32_t* matches12, int windowSize, float nnratio, int checkOrientation)
+{
+    const KeyPoint* k1 = (const KeyPoint*)kps1_;
+    const KeyPoint* k2 = (const KeyPoint*)kps2_;
+    FrameGrid F2(k2, n2, cols, rows);
+    int nmatches = 0;
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    std::vector<int> vMatchedDistance(n2, INT_MAX);
+    std::vector<int> vnMatches21(n2, -1);
+    for (int i1 = 0; i1 < n1; i1++) {
+        int level1 = k1[i1].octave;
+        if (level1 > 0) continue;
+        std::vector<int> vIndices2 =
+            F2.GetFeaturesInArea(prevMatched[2 * i1], prevMatched[2 * i1 + 1], (float)windowSize, level1, level1);
+        if (vIndices2.empty()) continue;
+        const uint8_t* d1 = desc1 + (size_t)i1 * 32;
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+        for (int i2 : vIndices2) {
+            int dist = DescriptorDistance(d1, desc2 + (size_t)i2 * 32);
+            if (vMatchedDistance[i2] <= dist) continue;
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist <= TH_LOW) {
+            if (bestDist < (float)bestDist2 * nnratio) {
+                if (vnMatches21[bestIdx2] >= 0) {
+                    matches12[vnMatches21[bestIdx2]] = -1;
+                    nmatches--;
+                }
+                matches12[i1] = bestIdx2;
+                vnMatches21[bestIdx2] = i1;
+                vMatchedDistance[bestIdx2] = bestDist;
+                nmatches++;
+                if (checkOrientation) {
+                    float rot = k1[i1].angle - k2[bestIdx2].angle;
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)std::round(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    rotHist[bin].push_back(i1);
+                }
+            }
+        }
+    }
+    if (checkOrientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1, sizes[HISTO_LENGTH];
+        for (int i = 0; i < HISTO_LENGTH; i++) sizes[i] = (int)rotHist[i].size();
+        ComputeThreeMaxima(sizes, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int idx1 : rotHist[i])
+                if (matches12[idx1] >= 0) { matches12[idx1] = -1; nmatches--; }
+        }
+    }
+    for (int i1 = 0; i1 < n1; i1++)
+        if (matches12[i1] >= 0) {
+            prevMatched[2 * i1] = k2[matches12[i1]].x;
+            prevMatched[2 * i1 + 1] = k2[matches12[i1]].y;
+        }
+    return nmatches;
+}
+
+void oracle_three_maxima(const int* sizes, int L, int* out3)
+{
+    int a = -1, b = -1, c = -1;
+    ComputeThreeMaxima(sizes, L, a, b, c);
+    out3[0] = a; out3[1] = b; out3[2] = c;
+}
+
+int oracle_match_constants(int which) { return which == 0 ? TH_HIGH : which == 1 ? TH_LOW : HISTO_LENGTH; }
+
+} /* extern "C" */

@@ -1,0 +1,205 @@
+"""ctypes binding of liborbfe.so (the C ABI of include/orbfe.h).
+
+This is plumbing for tests and bench.py; the product is the shared library.  There is no Python or CPU
+implementation behind these classes: if the library is missing or no HIP device is usable, construction fails.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liborbfe.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+MARKER_DTYPE = np.dtype([("id", "<i4"), ("corners", "<f4", (4, 2))])
+assert KP_DTYPE.itemsize == 28 and MARKER_DTYPE.itemsize == 36
+
+# every symbol include/orbfe.h declares (tests/test_abi.py checks the header against this list and the .so)
+SYMBOLS = [
+    "orbfe_last_error", "orbfe_version", "orbfe_device_count",
+    "orbfe_extractor_create", "orbfe_extractor_destroy", "orbfe_extractor_get_levels",
+    "orbfe_extractor_get_scale_factor", "orbfe_extractor_get_scale_factors",
+    "orbfe_extractor_get_inverse_scale_factors", "orbfe_extractor_get_scale_sigma_squares",
+    "orbfe_extractor_get_inverse_scale_sigma_squares", "orbfe_extractor_get_features_per_level",
+    "orbfe_extractor_max_keypoints", "orbfe_extract", "orbfe_extract_batch", "orbfe_extract_batch_device",
+    "orbfe_extractor_debug_level_size", "orbfe_extractor_debug_level_image",
+    "orbfe_extractor_debug_level_keypoints", "orbfe_extractor_debug_kernel_times",
+    "orbfe_hamming", "orbfe_knn2", "orbfe_knn2_batch_device", "orbfe_search_for_initialization",
+    "orbfe_search_for_initialization_batch_device",
+    "orbfe_aruco_create", "orbfe_aruco_destroy", "orbfe_aruco_set_dictionary", "orbfe_aruco_max_markers",
+    "orbfe_aruco_detect", "orbfe_aruco_detect_batch", "orbfe_aruco_detect_batch_device", "orbfe_aruco_debug_image",
+    "orbfe_aruco_debug_kernel_times",
+]
+
+_lib = None
+
+
+class OrbfeError(RuntimeError):
+    pass
+
+
+def load():
+    """Load liborbfe.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OrbfeError("%s not found: build it with __graft_entry__.build() (hipcc --offload-arch=gfx950)"
+                         % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, f32, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+    L.orbfe_last_error.restype = C.c_char_p
+    L.orbfe_version.restype = C.c_char_p
+    L.orbfe_extractor_create.restype = vp
+    L.orbfe_extractor_create.argtypes = [i32, f32, i32, i32, i32, i32]
+    L.orbfe_extractor_destroy.argtypes = [vp]
+    L.orbfe_extractor_get_levels.argtypes = [vp]
+    L.orbfe_extractor_get_scale_factor.argtypes = [vp]
+    L.orbfe_extractor_get_scale_factor.restype = f32
+    for nm in ("scale_factors", "inverse_scale_factors", "scale_sigma_squares", "inverse_scale_sigma_squares",
+               "features_per_level"):
+        getattr(L, "orbfe_extractor_get_" + nm).argtypes = [vp, vp]
+    L.orbfe_extractor_max_keypoints.argtypes = [vp]
+    L.orbfe_extract.argtypes = [vp, vp, i32, i32, sz, vp, vp, i32, vp]
+    L.orbfe_extract_batch.argtypes = [vp, vp, i32, sz, i32, i32, sz, vp, vp, i32, vp]
+    L.orbfe_extract_batch_device.argtypes = [vp, vp, i32, sz, i32, i32, sz, vp, vp, i32, vp, vp]
+    L.orbfe_extractor_debug_level_size.argtypes = [vp, i32, vp, vp]
+    L.orbfe_extractor_debug_level_image.argtypes = [vp, i32, i32, i32, vp]
+    L.orbfe_extractor_debug_level_keypoints.argtypes = [vp, i32, i32, i32, vp, i32, vp]
+    L.orbfe_extractor_debug_kernel_times.argtypes = [vp, vp, i32]
+    if hasattr(L, "orbfe_knn2"):
+        L.orbfe_hamming.argtypes = [vp, vp]
+        L.orbfe_knn2.argtypes = [vp, i32, vp, i32, i32, vp, vp, vp, i32]
+        L.orbfe_knn2_batch_device.argtypes = [vp, vp, sz, i32, vp, vp, sz, i32, i32, i32, vp, vp, vp, vp]
+        L.orbfe_search_for_initialization.argtypes = [vp, vp, i32, vp, vp, i32, i32, i32, vp, vp, i32, f32, i32, vp,
+                                                      i32]
+        L.orbfe_search_for_initialization_batch_device.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp,
+                                                                   vp, vp]
+    if hasattr(L, "orbfe_aruco_create"):
+        L.orbfe_aruco_create.restype = vp
+        L.orbfe_aruco_create.argtypes = [C.c_char_p, i32]
+        L.orbfe_aruco_destroy.argtypes = [vp]
+        L.orbfe_aruco_set_dictionary.argtypes = [vp, C.c_char_p]
+        L.orbfe_aruco_max_markers.argtypes = [vp]
+        L.orbfe_aruco_detect.argtypes = [vp, vp, i32, i32, sz, vp, i32, vp]
+        L.orbfe_aruco_detect_batch.argtypes = [vp, vp, i32, sz, i32, i32, sz, vp, i32, vp]
+        L.orbfe_aruco_detect_batch_device.argtypes = [vp, vp, i32, sz, i32, i32, sz, vp, i32, vp, vp]
+        L.orbfe_aruco_debug_image.argtypes = [vp, i32, i32, vp]
+        L.orbfe_aruco_debug_kernel_times.argtypes = [vp, vp, i32]
+    _lib = L
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _check(L, rc, what):
+    if rc < 0:
+        raise OrbfeError("%s failed (%d): %s" % (what, rc, L.orbfe_last_error().decode()))
+    return rc
+
+
+class ORBextractor:
+    """Mirror of ORB_SLAM2::ORBextractor (reference include/ORBextractor.h:45-113) over the C ABI."""
+
+    def __init__(self, nfeatures=1000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7, device=0):
+        self.L = load()
+        self.nlevels = nlevels
+        self.h = self.L.orbfe_extractor_create(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device)
+        if not self.h:
+            raise OrbfeError("orbfe_extractor_create: " + self.L.orbfe_last_error().decode())
+        self.capacity = self.L.orbfe_extractor_max_keypoints(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orbfe_extractor_destroy(self.h)
+            self.h = None
+
+    # reference getters (ORBextractor.h:63-83)
+    def GetLevels(self):
+        return self.L.orbfe_extractor_get_levels(self.h)
+
+    def GetScaleFactor(self):
+        return self.L.orbfe_extractor_get_scale_factor(self.h)
+
+    def _vec(self, name, dtype=np.float32):
+        out = np.zeros(self.nlevels, dtype)
+        _check(self.L, getattr(self.L, "orbfe_extractor_get_" + name)(self.h, _p(out)), name)
+        return out
+
+    def GetScaleFactors(self):
+        return self._vec("scale_factors")
+
+    def GetInverseScaleFactors(self):
+        return self._vec("inverse_scale_factors")
+
+    def GetScaleSigmaSquares(self):
+        return self._vec("scale_sigma_squares")
+
+    def GetInverseScaleSigmaSquares(self):
+        return self._vec("inverse_scale_sigma_squares")
+
+    def features_per_level(self):
+        return self._vec("features_per_level", np.int32)
+
+    def __call__(self, image, mask=None):
+        """operator()(image, mask, keypoints, descriptors): returns (keypoints[KP_DTYPE], descriptors[n,32])."""
+        image = np.asarray(image)
+        if image.size == 0:
+            return np.zeros(0, KP_DTYPE), np.zeros((0, 32), np.uint8)
+        assert image.dtype == np.uint8 and image.ndim == 2, "CV_8UC1 expected (ORBextractor.cc:1050)"
+        if image.strides[1] != 1:
+            image = np.ascontiguousarray(image)
+        kps = np.zeros(self.capacity, KP_DTYPE)
+        desc = np.zeros((self.capacity, 32), np.uint8)
+        n = C.c_int32(0)
+        _check(self.L, self.L.orbfe_extract(self.h, _p(image), image.shape[0], image.shape[1], image.strides[0],
+                                            _p(kps), _p(desc), self.capacity, C.byref(n)), "orbfe_extract")
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def extract_batch(self, images):
+        """images: (B, rows, cols) uint8 host array. Returns list of (kps, desc)."""
+        images = np.ascontiguousarray(images, np.uint8)
+        B, rows, cols = images.shape
+        kps = np.zeros((B, self.capacity), KP_DTYPE)
+        desc = np.zeros((B, self.capacity, 32), np.uint8)
+        n = np.zeros(B, np.int32)
+        _check(self.L, self.L.orbfe_extract_batch(self.h, _p(images), B, images.strides[0], rows, cols,
+                                                  images.strides[1], _p(kps), _p(desc), self.capacity, _p(n)),
+               "orbfe_extract_batch")
+        return [(kps[f, :n[f]].copy(), desc[f, :n[f]].copy()) for f in range(B)]
+
+    def extract_batch_device(self, d_imgs_ptr, B, frame_stride, rows, cols, step, d_kps_ptr, d_desc_ptr, capacity,
+                             d_n_ptr, stream=0):
+        _check(self.L, self.L.orbfe_extract_batch_device(self.h, d_imgs_ptr, B, frame_stride, rows, cols, step,
+                                                         d_kps_ptr, d_desc_ptr, capacity, d_n_ptr, stream),
+               "orbfe_extract_batch_device")
+
+    # stage read-back for parity tests
+    def level_image(self, frame, level, blurred=False):
+        w, h = C.c_int(), C.c_int()
+        _check(self.L, self.L.orbfe_extractor_debug_level_size(self.h, level, C.byref(w), C.byref(h)), "level_size")
+        out = np.zeros((h.value, w.value), np.uint8)
+        _check(self.L, self.L.orbfe_extractor_debug_level_image(self.h, frame, level, int(blurred), _p(out)),
+               "level_image")
+        return out
+
+    def level_keypoints(self, frame, level, stage):
+        n = C.c_int32(0)
+        _check(self.L, self.L.orbfe_extractor_debug_level_keypoints(self.h, frame, level, stage, None, 0, C.byref(n)),
+               "level_keypoints")
+        out = np.zeros(max(n.value, 1), KP_DTYPE)
+        _check(self.L, self.L.orbfe_extractor_debug_level_keypoints(self.h, frame, level, stage, _p(out), n.value,
+                                                                    C.byref(n)), "level_keypoints")
+        return out[:n.value]
+
+    def enable_kernel_timing(self, on=True):
+        self.L.orbfe_extractor_debug_kernel_times(self.h, None, int(on))
+
+    def kernel_times_us(self):
+        out = np.zeros(32, np.float32)
+        n = self.L.orbfe_extractor_debug_kernel_times(self.h, _p(out), 32)
+        return out[:n]

@@ -1,0 +1,508 @@
+// orb_extractor.hip -- host side of the ORB extractor behind the C ABI (include/orbfe.h).
+//
+// Mirrors ORB_SLAM2::ORBextractor (include/ORBextractor.h:45-113): the constructor builds the same tables
+// (src/ORBextractor.cc:410-470) with the same float/double arithmetic, operator() becomes orbfe_extract*(), and
+// the image work runs as the gfx950 kernels of orb_kernels.hip on a batch of frames.  There is no CPU path: if
+// no HIP device is usable every entry point fails with ORBFE_ERR_NO_DEVICE.
+#include <algorithm>
+#include <cmath>
+
+#include "orb_kernels.hpp"
+#include "orbfe_common.hpp"
+#include "orbfe_tables.inc"
+
+namespace orbfe {
+
+thread_local char g_err[512] = "";
+
+int use_device(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(ORBFE_ERR_NO_DEVICE, "no usable HIP device (%s); liborbfe has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(ORBFE_ERR_INVALID, "device %d out of range (have %d)", device, n);
+    ORBFE_HIP(hipSetDevice(device));
+    return ORBFE_OK;
+}
+
+static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+} // namespace orbfe
+
+using namespace orbfe;
+
+struct orbfe_extractor {
+    // --- reference members (ORBextractor.h:92-112)
+    int nfeatures, nlevels, iniThFAST, minThFAST;
+    double scaleFactor;
+    std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
+    std::vector<int> mnFeaturesPerLevel, umax;
+    // --- device state
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    int rows = 0, cols = 0; // geometry currently built
+    int batch_cap = 0;
+    std::vector<LevelGeom> geom;
+    int ncells_total = 0, ntiles = 0, out_total = 0, max_out_cap = 0;
+    size_t pyr_fbytes = 0, blur_fbytes = 0, slots_fu32 = 0, keys_fu32 = 0;
+    int keycap_lds = 0, nodecap = 0, veccap = 0;
+    std::vector<size_t> tab_off; // per level >= 1: offsets (in ints) of xofs, xalpha, yofs, ybeta in d_tabs
+    DevBuf d_geom, d_cellinfo, d_tiles, d_tabs, d_pattern, d_umax;
+    DevBuf d_pyr, d_blur, d_slots, d_cellcnt, d_keys, d_lvlout, d_lvlcnt, d_lvloff, d_lvlncand, d_overflow;
+    DevBuf d_in, d_kps, d_desc, d_nout; // staging for the host-pointer entry points
+    KernelTimer timer;
+    int last_nframes = 0;
+    ImgView last_src0{};
+
+    ~orbfe_extractor()
+    {
+        for (DevBuf* b : {&d_geom, &d_cellinfo, &d_tiles, &d_tabs, &d_pattern, &d_umax, &d_pyr, &d_blur, &d_slots,
+                          &d_cellcnt, &d_keys, &d_lvlout, &d_lvlcnt, &d_lvloff, &d_lvlncand, &d_overflow, &d_in,
+                          &d_kps, &d_desc, &d_nout})
+            b->release();
+        if (own_stream) (void)hipStreamDestroy(own_stream);
+    }
+
+    // ORBextractor::ORBextractor, src/ORBextractor.cc:410-470
+    void build_tables()
+    {
+        mvScaleFactor.resize(nlevels);
+        mvLevelSigma2.resize(nlevels);
+        mvScaleFactor[0] = 1.0f;
+        mvLevelSigma2[0] = 1.0f;
+        for (int i = 1; i < nlevels; i++) {
+            mvScaleFactor[i] = (float)(mvScaleFactor[i - 1] * scaleFactor);
+            mvLevelSigma2[i] = mvScaleFactor[i] * mvScaleFactor[i];
+        }
+        mvInvScaleFactor.resize(nlevels);
+        mvInvLevelSigma2.resize(nlevels);
+        for (int i = 0; i < nlevels; i++) {
+            mvInvScaleFactor[i] = 1.0f / mvScaleFactor[i];
+            mvInvLevelSigma2[i] = 1.0f / mvLevelSigma2[i];
+        }
+        mnFeaturesPerLevel.resize(nlevels);
+        float factor = (float)(1.0f / scaleFactor);
+        float nDesired = nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nlevels));
+        int sum = 0;
+        for (int level = 0; level < nlevels - 1; level++) {
+            mnFeaturesPerLevel[level] = orbfe_round_f(nDesired);
+            sum += mnFeaturesPerLevel[level];
+            nDesired *= factor;
+        }
+        mnFeaturesPerLevel[nlevels - 1] = std::max(nfeatures - sum, 0);
+        const int HP = 15;
+        umax.assign(HP + 1, 0);
+        int v, v0, vmax = orbfe_floor_d(HP * std::sqrt(2.f) / 2 + 1);
+        int vmin = orbfe_ceil_d(HP * std::sqrt(2.f) / 2);
+        const double hp2 = HP * HP;
+        for (v = 0; v <= vmax; ++v) umax[v] = orbfe_round_d(std::sqrt(hp2 - v * v));
+        for (v = HP, v0 = 0; v >= vmin; --v) {
+            while (umax[v0] == umax[v0 + 1]) ++v0;
+            umax[v] = v0;
+            ++v0;
+        }
+    }
+
+    int max_keypoints() const
+    {
+        int t = 0;
+        for (int l = 0; l < nlevels; l++) t += mnFeaturesPerLevel[l] + 3;
+        return t + 8;
+    }
+
+    // Level geometry for a rows x cols input: pyramid sizes (:1112), cell grid (:767-787), quadtree roots (:543-558),
+    // plus the HBM layout of every per-frame block.
+    int build_geometry(int rows_, int cols_)
+    {
+        if (rows_ == rows && cols_ == cols && !geom.empty()) return ORBFE_OK;
+        geom.assign(nlevels, LevelGeom{});
+        std::vector<uint32_t> cellinfo, tiles;
+        std::vector<int> tabs;
+        tab_off.assign((size_t)nlevels * 4, 0);
+        size_t pyr = 0, blur = 0, slots = 0, cand = 0;
+        int out = 0, maxcap = 0;
+        for (int l = 0; l < nlevels; l++) {
+            LevelGeom& g = geom[l];
+            const float scale = mvInvScaleFactor[l];
+            g.w = orbfe_round_f((float)cols_ * scale);
+            g.h = orbfe_round_f((float)rows_ * scale);
+            if (g.w < 38 + 30 || g.h < 38 + 30)
+                return fail(ORBFE_ERR_INVALID, "level %d is %dx%d: too small for a FAST cell grid", l, g.w, g.h);
+            g.pitch = align_up(g.w, 64);
+            g.bpitch = align_up(g.w, 64);
+            g.img_off = (long long)pyr;
+            if (l > 0) pyr += (size_t)g.pitch * g.h;
+            g.blur_off = (long long)blur;
+            blur += (size_t)g.bpitch * g.h;
+            g.maxBX = g.w - 19 + 3;
+            g.maxBY = g.h - 19 + 3;
+            const float width = (float)(g.maxBX - 16), height = (float)(g.maxBY - 16);
+            g.nCols = (int)(width / 30.f);
+            g.nRows = (int)(height / 30.f);
+            g.wCell = (int)std::ceil(width / g.nCols);
+            g.hCell = (int)std::ceil(height / g.nRows);
+            if (g.wCell > 60 || g.hCell > 60) return fail(ORBFE_ERR_INVALID, "cell larger than 60 px");
+            g.cell_first = (int)cellinfo.size();
+            for (int i = 0; i < g.nRows; i++) {
+                const float iniY = (float)(16 + i * g.hCell);
+                if (iniY >= g.maxBY - 3) continue;
+                for (int j = 0; j < g.nCols; j++) {
+                    const float iniX = (float)(16 + j * g.wCell);
+                    if (iniX >= g.maxBX - 6) continue;
+                    cellinfo.push_back((uint32_t)l | ((uint32_t)i << 4) | ((uint32_t)j << 14));
+                }
+            }
+            g.ncells = (int)cellinfo.size() - g.cell_first;
+            g.cell_cap = ((g.wCell + 1) / 2) * ((g.hCell + 1) / 2);
+            g.slot_off = (long long)slots;
+            g.cand_cap = g.ncells * g.cell_cap;
+            slots += (size_t)g.cand_cap;
+            g.cand_off = (long long)cand;
+            cand += (size_t)g.cand_cap;
+            g.quota = mnFeaturesPerLevel[l];
+            g.nIni = (int)std::round(static_cast<float>(g.maxBX - 16) / (g.maxBY - 16));
+            if (g.nIni < 1 || g.nIni > 8)
+                return fail(ORBFE_ERR_INVALID, "aspect ratio gives %d quadtree roots (supported: 1..8)", g.nIni);
+            g.hX = static_cast<float>(g.maxBX - 16) / g.nIni;
+            g.out_cap = std::max(g.quota + 3, 4 * g.nIni) + 5;
+            g.out_off = out;
+            out += g.out_cap;
+            maxcap = std::max(maxcap, g.out_cap);
+            g.scale = mvScaleFactor[l];
+            g.kp_size = (float)(int)(31 * mvScaleFactor[l]);
+            for (int ty = 0; ty < (g.h + 15) / 16; ty++)
+                for (int tx = 0; tx < (g.w + 63) / 64; tx++)
+                    tiles.push_back((uint32_t)l | ((uint32_t)tx << 4) | ((uint32_t)ty << 18));
+            if (l > 0) {
+                // cv::resize(INTER_LINEAR) coefficient tables, OpenCV 3.4
+                const int sw = geom[l - 1].w, sh = geom[l - 1].h, dw = g.w, dh = g.h;
+                const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
+                const int dwp = align_up(dw, 4);
+                std::vector<int> xofs(dwp), xal(dwp), yofs(dh), ybe(dh);
+                for (int dx = 0; dx < dw; dx++) {
+                    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+                    int sx = orbfe_floor_d(fx);
+                    fx -= sx;
+                    if (sx < 0) { fx = 0; sx = 0; }
+                    if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+                    const int a0 = (short)orbfe_round_f((1.f - fx) * 2048.f), a1 = (short)orbfe_round_f(fx * 2048.f);
+                    xofs[dx] = sx;
+                    xal[dx] = (a0 & 0xffff) | (a1 << 16);
+                }
+                for (int dx = dw; dx < dwp; dx++) { xofs[dx] = xofs[dw - 1]; xal[dx] = xal[dw - 1]; }
+                for (int dy = 0; dy < dh; dy++) {
+                    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+                    int sy = orbfe_floor_d(fy);
+                    fy -= sy;
+                    const int b0 = (short)orbfe_round_f((1.f - fy) * 2048.f), b1 = (short)orbfe_round_f(fy * 2048.f);
+                    yofs[dy] = sy;
+                    ybe[dy] = (b0 & 0xffff) | (b1 << 16);
+                }
+                tab_off[l * 4 + 0] = tabs.size(); tabs.insert(tabs.end(), xofs.begin(), xofs.end());
+                tab_off[l * 4 + 1] = tabs.size(); tabs.insert(tabs.end(), xal.begin(), xal.end());
+                tab_off[l * 4 + 2] = tabs.size(); tabs.insert(tabs.end(), yofs.begin(), yofs.end());
+                tab_off[l * 4 + 3] = tabs.size(); tabs.insert(tabs.end(), ybe.begin(), ybe.end());
+            }
+        }
+        rows = rows_; cols = cols_;
+        ncells_total = (int)cellinfo.size();
+        ntiles = (int)tiles.size();
+        out_total = out;
+        max_out_cap = maxcap;
+        pyr_fbytes = pyr + 64;
+        blur_fbytes = blur + 64;
+        slots_fu32 = slots;
+        keys_fu32 = 2 * cand;
+        nodecap = maxcap + 8;
+        veccap = 1;
+        while (veccap < nodecap) veccap <<= 1;
+        keycap_lds = 6144;
+        batch_cap = 0; // force workspace re-allocation
+        if (tabs.empty()) tabs.push_back(0);
+        int rc;
+        if ((rc = d_geom.ensure(geom.size() * sizeof(LevelGeom)))) return rc;
+        if ((rc = d_cellinfo.ensure(cellinfo.size() * 4))) return rc;
+        if ((rc = d_tiles.ensure(tiles.size() * 4))) return rc;
+        if ((rc = d_tabs.ensure(tabs.size() * 4))) return rc;
+        ORBFE_HIP(hipMemcpy(d_geom.p, geom.data(), geom.size() * sizeof(LevelGeom), hipMemcpyHostToDevice));
+        ORBFE_HIP(hipMemcpy(d_cellinfo.p, cellinfo.data(), cellinfo.size() * 4, hipMemcpyHostToDevice));
+        ORBFE_HIP(hipMemcpy(d_tiles.p, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice));
+        ORBFE_HIP(hipMemcpy(d_tabs.p, tabs.data(), tabs.size() * 4, hipMemcpyHostToDevice));
+        return ORBFE_OK;
+    }
+
+    int ensure_workspace(int B)
+    {
+        if (B <= batch_cap) return ORBFE_OK;
+        int rc;
+        if ((rc = d_pyr.ensure(pyr_fbytes * B))) return rc;
+        if ((rc = d_blur.ensure(blur_fbytes * B))) return rc;
+        if ((rc = d_slots.ensure(slots_fu32 * 4 * B))) return rc;
+        if ((rc = d_cellcnt.ensure((size_t)ncells_total * 4 * B))) return rc;
+        if ((rc = d_keys.ensure(keys_fu32 * 4 * B))) return rc;
+        if ((rc = d_lvlout.ensure((size_t)out_total * 4 * B))) return rc;
+        if ((rc = d_lvlcnt.ensure((size_t)nlevels * 4 * B))) return rc;
+        if ((rc = d_lvloff.ensure((size_t)nlevels * 4 * B))) return rc;
+        if ((rc = d_lvlncand.ensure((size_t)nlevels * 4 * B))) return rc;
+        if ((rc = d_overflow.ensure(16))) return rc;
+        batch_cap = B;
+        return ORBFE_OK;
+    }
+
+    // The batched pipeline: every launch covers all frames.  Asynchronous on `s`.
+    int run_device(const uint8_t* d_imgs, int B, size_t frame_stride, int rows_, int cols_, size_t step,
+                   orbfe_keypoint* d_kps_out, uint8_t* d_desc_out, int capacity, int32_t* d_n, hipStream_t s)
+    {
+        int rc;
+        if ((rc = build_geometry(rows_, cols_))) return rc;
+        if ((rc = ensure_workspace(B))) return rc;
+        ImgView src0{d_imgs, nullptr, frame_stride, (int)step};
+        ImgView pyr{d_pyr.as<uint8_t>(), d_pyr.as<uint8_t>(), pyr_fbytes, 0};
+        ImgView blur{d_blur.as<uint8_t>(), d_blur.as<uint8_t>(), blur_fbytes, 0};
+        const LevelGeom* dg = d_geom.as<LevelGeom>();
+        last_nframes = B;
+        last_src0 = src0;
+        timer.begin();
+        timer.mark(s, "start");
+        ORBFE_HIP(hipMemsetAsync(d_overflow.p, 0, 4, s));
+        for (int l = 1; l < nlevels; l++) {
+            const LevelGeom& g = geom[l];
+            const LevelGeom& gp = geom[l - 1];
+            ImgView sv = (l == 1) ? src0 : ImgView{pyr.base + gp.img_off, nullptr, pyr_fbytes, gp.pitch};
+            ImgView dv{pyr.base + g.img_off, pyr.base_w + g.img_off, pyr_fbytes, g.pitch};
+            const int dw4 = (g.w + 3) / 4;
+            dim3 grid((dw4 + 63) / 64, (g.h + 3) / 4, B);
+            const int* tabs = d_tabs.as<int>();
+            hipLaunchKernelGGL(k_resize_level, grid, dim3(256), 0, s, sv, dv, gp.w, gp.h, dw4, g.h,
+                               tabs + tab_off[l * 4 + 0], tabs + tab_off[l * 4 + 1], tabs + tab_off[l * 4 + 2],
+                               tabs + tab_off[l * 4 + 3]);
+        }
+        timer.mark(s, "resize");
+        hipLaunchKernelGGL(k_fast_cells, dim3(ncells_total, B), dim3(256), 0, s, src0, pyr, dg,
+                           d_cellinfo.as<uint32_t>(), d_slots.as<uint32_t>(), slots_fu32, d_cellcnt.as<int32_t>(),
+                           ncells_total, iniThFAST, minThFAST);
+        timer.mark(s, "fast_cells");
+        const size_t lds = qt_lds_bytes(keycap_lds, nodecap, veccap);
+        hipLaunchKernelGGL(k_distribute, dim3(nlevels, B), dim3(64), lds, s, dg, d_slots.as<uint32_t>(), slots_fu32,
+                           d_cellcnt.as<int32_t>(), ncells_total, d_keys.as<uint32_t>(), keys_fu32,
+                           d_lvlout.as<uint32_t>(), out_total, d_lvlcnt.as<int32_t>(), nlevels,
+                           d_lvlncand.as<int32_t>(), keycap_lds, nodecap, veccap);
+        timer.mark(s, "distribute");
+        hipLaunchKernelGGL(k_level_offsets, dim3((B + 63) / 64), dim3(64), 0, s, d_lvlcnt.as<int32_t>(),
+                           d_lvloff.as<int32_t>(), d_n, nlevels, B, capacity, d_overflow.as<int32_t>());
+        hipLaunchKernelGGL(k_blur7, dim3(ntiles, B), dim3(256), 0, s, src0, pyr, blur, dg, d_tiles.as<uint32_t>());
+        timer.mark(s, "blur7");
+        hipLaunchKernelGGL(k_orient_describe, dim3((max_out_cap + 3) / 4, nlevels, B), dim3(256), 0, s, src0, pyr,
+                           blur, dg, d_lvlout.as<uint32_t>(), out_total, d_lvlcnt.as<int32_t>(),
+                           d_lvloff.as<int32_t>(), nlevels, d_pattern.as<uint32_t>(), d_umax.as<int>(), d_kps_out,
+                           d_desc_out, capacity);
+        timer.mark(s, "orient_describe");
+        ORBFE_HIP(hipGetLastError());
+        return ORBFE_OK;
+    }
+};
+
+extern "C" {
+
+const char* orbfe_last_error(void) { return g_err; }
+const char* orbfe_version(void) { return "orbfe 0.1 (gfx950)"; }
+int orbfe_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+orbfe_extractor* orbfe_extractor_create(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST,
+                                        int device)
+{
+    if (nfeatures <= 0 || nlevels < 1 || nlevels > 15 || !(scaleFactor > 1.0f) || iniThFAST < 1 || minThFAST < 1 ||
+        iniThFAST > 254 || minThFAST > 254) {
+        fail(ORBFE_ERR_INVALID, "invalid extractor parameters");
+        return nullptr;
+    }
+    if (use_device(device) != ORBFE_OK) return nullptr;
+    orbfe_extractor* h = new orbfe_extractor();
+    h->nfeatures = nfeatures; h->nlevels = nlevels; h->iniThFAST = iniThFAST; h->minThFAST = minThFAST;
+    h->scaleFactor = scaleFactor;
+    h->device = device;
+    h->build_tables();
+    if (hipStreamCreate(&h->own_stream) != hipSuccess || h->d_pattern.ensure(1024) != ORBFE_OK ||
+        h->d_umax.ensure(64) != ORBFE_OK ||
+        hipMemcpy(h->d_pattern.p, ORBFE_BIT_PATTERN_31, 1024, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(h->d_umax.p, h->umax.data(), 64, hipMemcpyHostToDevice) != hipSuccess) {
+        fail(ORBFE_ERR_HIP, "extractor device initialisation failed");
+        delete h;
+        return nullptr;
+    }
+    return h;
+}
+
+void orbfe_extractor_destroy(orbfe_extractor* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    delete h;
+}
+
+int orbfe_extractor_get_levels(const orbfe_extractor* h) { return h ? h->nlevels : ORBFE_ERR_INVALID; }
+float orbfe_extractor_get_scale_factor(const orbfe_extractor* h) { return h ? (float)h->scaleFactor : 0.f; }
+static int copy_vec(const orbfe_extractor* h, const std::vector<float>& v, float* out)
+{
+    if (!h || !out) return fail(ORBFE_ERR_INVALID, "null argument");
+    memcpy(out, v.data(), v.size() * sizeof(float));
+    return (int)v.size();
+}
+int orbfe_extractor_get_scale_factors(const orbfe_extractor* h, float* out) { return h ? copy_vec(h, h->mvScaleFactor, out) : ORBFE_ERR_INVALID; }
+int orbfe_extractor_get_inverse_scale_factors(const orbfe_extractor* h, float* out) { return h ? copy_vec(h, h->mvInvScaleFactor, out) : ORBFE_ERR_INVALID; }
+int orbfe_extractor_get_scale_sigma_squares(const orbfe_extractor* h, float* out) { return h ? copy_vec(h, h->mvLevelSigma2, out) : ORBFE_ERR_INVALID; }
+int orbfe_extractor_get_inverse_scale_sigma_squares(const orbfe_extractor* h, float* out) { return h ? copy_vec(h, h->mvInvLevelSigma2, out) : ORBFE_ERR_INVALID; }
+int orbfe_extractor_get_features_per_level(const orbfe_extractor* h, int32_t* out)
+{
+    if (!h || !out) return fail(ORBFE_ERR_INVALID, "null argument");
+    for (int i = 0; i < h->nlevels; i++) out[i] = h->mnFeaturesPerLevel[i];
+    return h->nlevels;
+}
+int orbfe_extractor_max_keypoints(const orbfe_extractor* h) { return h ? h->max_keypoints() : ORBFE_ERR_INVALID; }
+
+int orbfe_extract_batch_device(orbfe_extractor* h, const uint8_t* d_imgs, int nframes, size_t frame_stride, int rows,
+                               int cols, size_t step, orbfe_keypoint* d_kps, uint8_t* d_desc, int capacity,
+                               int32_t* d_n_out, void* stream)
+{
+    if (!h || !d_imgs || !d_kps || !d_desc || !d_n_out || nframes <= 0 || rows <= 0 || cols <= 0 ||
+        step < (size_t)cols || capacity <= 0)
+        return fail(ORBFE_ERR_INVALID, "orbfe_extract_batch_device: invalid argument");
+    int rc = use_device(h->device);
+    if (rc) return rc;
+    return h->run_device(d_imgs, nframes, frame_stride, rows, cols, step, d_kps, d_desc, capacity, d_n_out,
+                         (hipStream_t)stream);
+}
+
+int orbfe_extract_batch(orbfe_extractor* h, const uint8_t* imgs, int nframes, size_t frame_stride, int rows, int cols,
+                        size_t step, orbfe_keypoint* kps, uint8_t* desc, int capacity, int32_t* n_out)
+{
+    if (!h || !n_out) return fail(ORBFE_ERR_INVALID, "orbfe_extract_batch: null argument");
+    if (!imgs || rows <= 0 || cols <= 0 || nframes <= 0) { // empty image: ORBextractor.cc:1046
+        for (int f = 0; f < nframes; f++) n_out[f] = 0;
+        return ORBFE_OK;
+    }
+    if (!kps || !desc || step < (size_t)cols || capacity <= 0)
+        return fail(ORBFE_ERR_INVALID, "orbfe_extract_batch: invalid argument");
+    int rc = use_device(h->device);
+    if (rc) return rc;
+    const int cap = h->max_keypoints();
+    const size_t dpitch = (size_t)align_up(cols, 64), dframe = dpitch * rows;
+    if ((rc = h->d_in.ensure(dframe * nframes + 64))) return rc;
+    if ((rc = h->d_kps.ensure((size_t)cap * nframes * sizeof(orbfe_keypoint)))) return rc;
+    if ((rc = h->d_desc.ensure((size_t)cap * nframes * 32))) return rc;
+    if ((rc = h->d_nout.ensure((size_t)nframes * 4))) return rc;
+    hipStream_t s = h->own_stream;
+    for (int f = 0; f < nframes; f++)
+        ORBFE_HIP(hipMemcpy2DAsync((uint8_t*)h->d_in.p + f * dframe, dpitch, imgs + f * frame_stride, step, cols, rows,
+                                   hipMemcpyHostToDevice, s));
+    rc = h->run_device(h->d_in.as<uint8_t>(), nframes, dframe, rows, cols, dpitch, h->d_kps.as<orbfe_keypoint>(),
+                       h->d_desc.as<uint8_t>(), cap, h->d_nout.as<int32_t>(), s);
+    if (rc) return rc;
+    ORBFE_HIP(hipMemcpyAsync(n_out, h->d_nout.p, (size_t)nframes * 4, hipMemcpyDeviceToHost, s));
+    ORBFE_HIP(hipStreamSynchronize(s));
+    int32_t ovf = 0;
+    ORBFE_HIP(hipMemcpy(&ovf, h->d_overflow.p, 4, hipMemcpyDeviceToHost));
+    if (ovf) return fail(ORBFE_ERR_CAPACITY, "internal keypoint capacity exceeded (%d)", ovf);
+    for (int f = 0; f < nframes; f++) {
+        if (n_out[f] > capacity)
+            return fail(ORBFE_ERR_CAPACITY, "frame %d has %d keypoints, capacity is %d", f, n_out[f], capacity);
+        if (n_out[f] == 0) continue;
+        ORBFE_HIP(hipMemcpy(kps + (size_t)f * capacity, h->d_kps.as<orbfe_keypoint>() + (size_t)f * cap,
+                            (size_t)n_out[f] * sizeof(orbfe_keypoint), hipMemcpyDeviceToHost));
+        ORBFE_HIP(hipMemcpy(desc + (size_t)f * capacity * 32, h->d_desc.as<uint8_t>() + (size_t)f * cap * 32,
+                            (size_t)n_out[f] * 32, hipMemcpyDeviceToHost));
+    }
+    return ORBFE_OK;
+}
+
+int orbfe_extract(orbfe_extractor* h, const uint8_t* img, int rows, int cols, size_t step, orbfe_keypoint* kps,
+                  uint8_t* desc, int capacity, int32_t* n_out)
+{
+    return orbfe_extract_batch(h, img, 1, 0, rows, cols, step, kps, desc, capacity, n_out);
+}
+
+int orbfe_extractor_debug_level_size(orbfe_extractor* h, int level, int* w, int* hgt)
+{
+    if (!h || level < 0 || level >= h->nlevels || h->geom.empty()) return fail(ORBFE_ERR_INVALID, "no geometry");
+    *w = h->geom[level].w;
+    *hgt = h->geom[level].h;
+    return ORBFE_OK;
+}
+
+int orbfe_extractor_debug_level_image(orbfe_extractor* h, int frame, int level, int stage, uint8_t* out)
+{
+    if (!h || !out || level < 0 || level >= h->nlevels || frame < 0 || frame >= h->last_nframes)
+        return fail(ORBFE_ERR_INVALID, "debug_level_image: invalid argument");
+    int rc = use_device(h->device);
+    if (rc) return rc;
+    const LevelGeom& g = h->geom[level];
+    const uint8_t* src;
+    size_t pitch;
+    if (stage == 1) { src = h->d_blur.as<uint8_t>() + frame * h->blur_fbytes + g.blur_off; pitch = g.bpitch; }
+    else if (level == 0) { src = h->last_src0.base + frame * h->last_src0.fstride; pitch = h->last_src0.pitch; }
+    else { src = h->d_pyr.as<uint8_t>() + frame * h->pyr_fbytes + g.img_off; pitch = g.pitch; }
+    ORBFE_HIP(hipDeviceSynchronize());
+    ORBFE_HIP(hipMemcpy2D(out, g.w, src, pitch, g.w, g.h, hipMemcpyDeviceToHost));
+    return ORBFE_OK;
+}
+
+int orbfe_extractor_debug_level_keypoints(orbfe_extractor* h, int frame, int level, int stage, orbfe_keypoint* out,
+                                          int capacity, int32_t* n)
+{
+    if (!h || !n || level < 0 || level >= h->nlevels || frame < 0 || frame >= h->last_nframes)
+        return fail(ORBFE_ERR_INVALID, "debug_level_keypoints: invalid argument");
+    int rc = use_device(h->device);
+    if (rc) return rc;
+    ORBFE_HIP(hipDeviceSynchronize());
+    const LevelGeom& g = h->geom[level];
+    std::vector<uint32_t> keys;
+    if (stage == 0) {
+        std::vector<int32_t> cnt(g.ncells);
+        ORBFE_HIP(hipMemcpy(cnt.data(), h->d_cellcnt.as<int32_t>() + (size_t)frame * h->ncells_total + g.cell_first,
+                            (size_t)g.ncells * 4, hipMemcpyDeviceToHost));
+        std::vector<uint32_t> slots((size_t)g.cand_cap);
+        ORBFE_HIP(hipMemcpy(slots.data(), h->d_slots.as<uint32_t>() + (size_t)frame * h->slots_fu32 + g.slot_off,
+                            slots.size() * 4, hipMemcpyDeviceToHost));
+        for (int c = 0; c < g.ncells; c++)
+            for (int k = 0; k < cnt[c]; k++) keys.push_back(slots[(size_t)c * g.cell_cap + k]);
+    } else {
+        int32_t c = 0;
+        ORBFE_HIP(hipMemcpy(&c, h->d_lvlcnt.as<int32_t>() + frame * h->nlevels + level, 4, hipMemcpyDeviceToHost));
+        keys.resize(c);
+        if (c)
+            ORBFE_HIP(hipMemcpy(keys.data(), h->d_lvlout.as<uint32_t>() + (size_t)frame * h->out_total + g.out_off,
+                                (size_t)c * 4, hipMemcpyDeviceToHost));
+    }
+    *n = (int32_t)keys.size();
+    const int add = stage == 0 ? 0 : 16;
+    for (int i = 0; i < (int)keys.size() && i < capacity; i++) {
+        const uint32_t kv = keys[i];
+        out[i].x = (float)((int)(kv & 0xfff) + add);
+        out[i].y = (float)((int)((kv >> 12) & 0xfff) + add);
+        out[i].size = stage == 0 ? 7.f : g.kp_size;
+        out[i].angle = -1.f;
+        out[i].response = (float)(kv >> 24);
+        out[i].octave = stage == 0 ? 0 : level;
+        out[i].class_id = -1;
+    }
+    return ORBFE_OK;
+}
+
+int orbfe_extractor_debug_kernel_times(orbfe_extractor* h, float* out_us, int capacity)
+{
+    if (!h) return fail(ORBFE_ERR_INVALID, "null handle");
+    if (!out_us) { // toggle: capacity != 0 enables timing for subsequent calls
+        h->timer.enabled = capacity != 0;
+        return 0;
+    }
+    return h->timer.collect(out_us, capacity);
+}
+
+} // extern "C"

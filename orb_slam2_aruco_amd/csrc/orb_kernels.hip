@@ -1,0 +1,764 @@
+// orb_kernels.hip -- gfx950 kernels of the ORB extractor (wave64, LDS-staged; no MFMA: there is no dense contraction).
+//
+// Pipeline per batch of B same-sized frames (all launches cover every frame of the batch):
+//   k_resize_level      x (nlevels-1)  bilinear pyramid level l from level l-1     (ORBextractor.cc:1107-1132)
+//   k_fast_cells        x 1            per-cell FAST-9/16 score + 3x3 NMS + threshold fallback (:789-829)
+//   k_distribute        x 1            DistributeOctTree, one wave per (frame, level)           (:539-763)
+//   k_level_offsets     x 1            per-frame level prefix sums / keypoint totals            (:1059-1062)
+//   k_blur7             x 1            7x7 sigma-2 integer Gaussian of every level              (:1085-1086)
+//   k_orient_describe   x 1            IC_Angle + steered BRIEF, one wave per keypoint          (:77-147)
+//
+// Data layout in HBM (per extractor handle, frame-major): see DESIGN.md "ORB extractor: layout".
+#include "orb_kernels.hpp"
+
+namespace orbfe {
+
+// ------------------------------------------------------------------------------------------------ helpers --
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int lane_prefix(unsigned long long mask)
+{
+    // number of set bits below this lane
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+}
+
+// ------------------------------------------------------------------------------------------------ resize --
+// One thread = 4 horizontally adjacent output pixels (one aligned u32 store).  Coefficient tables are built on the
+// host exactly as cv::resize does (double/float arithmetic), so the kernel is pure integer work.
+__global__ __launch_bounds__(256) void k_resize_level(ImgView src, ImgView dst, int sw, int sh, int dw4 /*ceil(dw/4)*/,
+                                                      int dh, const int* __restrict__ xofs,
+                                                      const int* __restrict__ xalpha, const int* __restrict__ yofs,
+                                                      const int* __restrict__ ybeta)
+{
+    const int x4 = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int f = blockIdx.z;
+    if (x4 >= dw4 || dy >= dh) return;
+    const uint8_t* S = src.base + (size_t)f * src.fstride;
+    int sy0 = yofs[dy], sy1 = sy0 + 1;
+    sy0 = min(max(sy0, 0), sh - 1);
+    sy1 = min(max(sy1, 0), sh - 1);
+    const uint8_t* S0 = S + (size_t)sy0 * src.pitch;
+    const uint8_t* S1 = S + (size_t)sy1 * src.pitch;
+    const int bb = ybeta[dy];
+    const int b0 = (short)(bb & 0xffff), b1 = (short)(bb >> 16);
+    uint32_t packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int dx = x4 * 4 + k; // tables are padded to a multiple of 4 entries
+        const int sx = xofs[dx];
+        const int sx1 = min(sx + 1, sw - 1);
+        const int aa = xalpha[dx];
+        const int a0 = (short)(aa & 0xffff), a1 = (short)(aa >> 16);
+        const int h0 = S0[sx] * a0 + S0[sx1] * a1;
+        const int h1 = S1[sx] * a0 + S1[sx1] * a1;
+        const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+        packed |= (uint32_t)(v & 0xff) << (8 * k);
+    }
+    uint8_t* D = dst.base_w + (size_t)f * dst.fstride + (size_t)dy * dst.pitch;
+    *reinterpret_cast<uint32_t*>(D + x4 * 4) = packed;
+}
+
+// ------------------------------------------------------------------------------------------------ FAST ----
+// ring offsets of the 9-16 segment test (radius 3), k = 0..15
+__device__ __constant__ signed char c_ring_dx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+__device__ __constant__ signed char c_ring_dy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+
+#define FAST_MAXROI 66  // cell (<= 60) + 6
+#define FAST_SP 68      // LDS row pitch of the staged ROI
+#define FAST_MAXLIST 3600
+
+template <int PITCH> __device__ __forceinline__ void ring_diffs(const uint8_t* c, int v, int d[16])
+{
+    d[0] = v - c[3 * PITCH + 0];   d[1] = v - c[3 * PITCH + 1];   d[2] = v - c[2 * PITCH + 2];
+    d[3] = v - c[1 * PITCH + 3];   d[4] = v - c[0 * PITCH + 3];   d[5] = v - c[-1 * PITCH + 3];
+    d[6] = v - c[-2 * PITCH + 2];  d[7] = v - c[-3 * PITCH + 1];  d[8] = v - c[-3 * PITCH + 0];
+    d[9] = v - c[-3 * PITCH - 1];  d[10] = v - c[-2 * PITCH - 2]; d[11] = v - c[-1 * PITCH - 3];
+    d[12] = v - c[0 * PITCH - 3];  d[13] = v - c[1 * PITCH - 3];  d[14] = v - c[2 * PITCH - 2];
+    d[15] = v - c[3 * PITCH - 1];
+}
+
+// true iff 9 contiguous ring pixels are all brighter than v+t or all darker than v-t
+__device__ __forceinline__ bool fast_is_corner(const int d[16], int t)
+{
+    unsigned ma = 0, mb = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        ma |= (unsigned)(d[k] > t) << k;
+        mb |= (unsigned)(d[k] < -t) << k;
+    }
+    ma |= ma << 16;
+    mb |= mb << 16;
+    unsigned ra = ma & (ma >> 1); ra &= ra >> 2; ra &= ra >> 4; ra &= ma >> 8;
+    unsigned rb = mb & (mb >> 1); rb &= rb >> 2; rb &= rb >> 4; rb &= mb >> 8;
+    return ((ra | rb) & 0xffffu) != 0;
+}
+
+// cornerScore<16>: max over the 16 arcs of 9 of min(d) (and of min(-d)), minus 1
+__device__ __forceinline__ int fast_score16(const int d[16])
+{
+    int mn2[16], mx2[16], mn4[16], mx4[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        mn2[k] = min(d[k], d[(k + 1) & 15]);
+        mx2[k] = max(d[k], d[(k + 1) & 15]);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        mn4[k] = min(mn2[k], mn2[(k + 2) & 15]);
+        mx4[k] = max(mx2[k], mx2[(k + 2) & 15]);
+    }
+    int best = -255;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        int mn9 = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
+        int mx9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
+        best = max(best, max(mn9, -mx9));
+    }
+    return best - 1;
+}
+
+// One workgroup per (active cell, frame).  Stages the cell's ROI in LDS, finds corners at the lower threshold,
+// scores them, applies 3x3 strict-max NMS restricted to the cell (ORBextractor.cc:809 runs cv::FAST on the ROI,
+// so NMS never looks across cells), applies the iniThFAST -> minThFAST fallback (:812-816) and writes the
+// survivors in raster order to the cell's slot.
+__global__ __launch_bounds__(256) void k_fast_cells(ImgView src0, ImgView pyr, const LevelGeom* __restrict__ geom,
+                                                    const uint32_t* __restrict__ cellinfo, uint32_t* __restrict__ slots,
+                                                    size_t slots_fstride, int32_t* __restrict__ cellcnt,
+                                                    int ncells_total, int iniTh, int minTh)
+{
+    __shared__ uint8_t simg[FAST_MAXROI * FAST_SP];
+    __shared__ uint8_t smap[62 * 64];
+    __shared__ uint16_t slist[FAST_MAXLIST];
+    __shared__ uint8_t sscore[FAST_MAXLIST];
+    __shared__ uint8_t sflag[FAST_MAXLIST];
+    __shared__ int s_wcnt[4];
+    __shared__ int s_cnt_ini;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int cell = blockIdx.x, f = blockIdx.y;
+    const uint32_t ci = cellinfo[cell];
+    const int level = ci & 15, ci_i = (ci >> 4) & 1023, ci_j = (ci >> 14) & 1023;
+    const LevelGeom g = geom[level];
+
+    const int iniX = 16 + ci_j * g.wCell, iniY = 16 + ci_i * g.hCell;
+    const int maxX = min(iniX + g.wCell + 6, g.maxBX), maxY = min(iniY + g.hCell + 6, g.maxBY);
+    const int w = maxX - iniX, h = maxY - iniY;
+    const int aw = w - 6, ah = h - 6;
+    int32_t* cnt_out = cellcnt + (size_t)f * ncells_total + cell;
+    if (aw <= 0 || ah <= 0) {
+        if (tid == 0) *cnt_out = 0;
+        return;
+    }
+    const uint8_t* img = (level == 0) ? src0.base + (size_t)f * src0.fstride
+                                      : pyr.base + (size_t)f * pyr.fstride + g.img_off;
+    const int pitch = (level == 0) ? src0.pitch : g.pitch;
+
+    // stage ROI + clear score map
+    for (int y = wid; y < h; y += 4) {
+        const uint8_t* row = img + (size_t)(iniY + y) * pitch + iniX;
+        if (lane < w) simg[y * FAST_SP + lane] = row[lane];
+        if (lane + 64 < w) simg[y * FAST_SP + lane + 64] = row[lane + 64];
+    }
+    for (int i = tid; i < 62 * 64 / 4; i += 256) reinterpret_cast<uint32_t*>(smap)[i] = 0;
+    if (tid == 0) s_cnt_ini = 0;
+    __syncthreads();
+
+    // phase 1: segment test at the lower threshold, raster-ordered compaction
+    const int tlow = min(iniTh, minTh);
+    const int npix = aw * ah;
+    int nlist = 0;
+    for (int base = 0; base < npix; base += 256) {
+        const int p = base + tid;
+        bool corner = false;
+        int x = 0, y = 0;
+        if (p < npix) {
+            y = p / aw;
+            x = p - y * aw;
+            const uint8_t* c = simg + (y + 3) * FAST_SP + (x + 3);
+            int d[16];
+            ring_diffs<FAST_SP>(c, c[0], d);
+            corner = fast_is_corner(d, tlow);
+        }
+        const unsigned long long m = __ballot(corner);
+        if (lane == 0) s_wcnt[wid] = __popcll(m);
+        __syncthreads();
+        int off = nlist;
+        for (int k = 0; k < wid; k++) off += s_wcnt[k];
+        if (corner) slist[off + lane_prefix(m)] = (uint16_t)((y << 8) | x);
+        nlist += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+        __syncthreads();
+    }
+
+    // phase 2: exact score of every corner
+    for (int e = tid; e < nlist; e += 256) {
+        const int yx = slist[e], y = yx >> 8, x = yx & 255;
+        const uint8_t* c = simg + (y + 3) * FAST_SP + (x + 3);
+        int d[16];
+        ring_diffs<FAST_SP>(c, c[0], d);
+        const int s = fast_score16(d);
+        sscore[e] = (uint8_t)s;
+        smap[(y + 1) * 64 + (x + 1)] = (uint8_t)s;
+    }
+    __syncthreads();
+
+    // phase 3: strict 3x3 maximum inside the cell
+    int my_ini = 0;
+    for (int e = tid; e < nlist; e += 256) {
+        const int yx = slist[e], y = yx >> 8, x = yx & 255;
+        const int s = sscore[e];
+        const uint8_t* m = smap + (y + 1) * 64 + (x + 1);
+        const bool keep = s > m[-65] && s > m[-64] && s > m[-63] && s > m[-1] && s > m[1] && s > m[63] && s > m[64] &&
+                          s > m[65];
+        const int fl = (keep && s >= minTh ? 1 : 0) | (keep && s >= iniTh ? 2 : 0);
+        sflag[e] = (uint8_t)fl;
+        my_ini += (fl >> 1);
+    }
+    if (my_ini) atomicAdd(&s_cnt_ini, my_ini);
+    __syncthreads();
+
+    // phase 4: threshold fallback + ordered write-out
+    const int want = s_cnt_ini > 0 ? 2 : 1;
+    uint32_t* out = slots + (size_t)f * slots_fstride + g.slot_off + (size_t)(cell - g.cell_first) * g.cell_cap;
+    const int xrel = ci_j * g.wCell + 3, yrel = ci_i * g.hCell + 3; // (*vit).pt.x += j*wCell (:822-823)
+    int nout = 0;
+    for (int base = 0; base < nlist; base += 256) {
+        const int e = base + tid;
+        const bool take = e < nlist && (sflag[e] & want);
+        const unsigned long long m = __ballot(take);
+        if (lane == 0) s_wcnt[wid] = __popcll(m);
+        __syncthreads();
+        int off = nout;
+        for (int k = 0; k < wid; k++) off += s_wcnt[k];
+        if (take) {
+            const int yx = slist[e], y = yx >> 8, x = yx & 255;
+            out[off + lane_prefix(m)] = (uint32_t)(x + xrel) | ((uint32_t)(y + yrel) << 12) | ((uint32_t)sscore[e] << 24);
+        }
+        nout += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+        __syncthreads();
+    }
+    if (tid == 0) *cnt_out = nout;
+}
+
+// ------------------------------------------------------------------------------------------------ quadtree --
+// DistributeOctTree (ORBextractor.cc:539-763), one wave per (frame, level).  The std::list of nodes is a doubly
+// linked list in LDS; a node's keypoints are a contiguous, order-preserving range of a ping-pong key buffer
+// (LDS when the level's candidates fit, HBM scratch otherwise), so DivideNode (:481-537) is a stable 4-way
+// partition done with wave ballots.  Control flow is wave-uniform.  Tie-break of the (size, pointer) sort at :684:
+// creation sequence, as the oracle defines it.
+struct QtShared {
+    // sizes are set by the launch (dynamic LDS); see qt_lds_bytes()
+    uint32_t* keys[2];
+    short *x0, *y0, *x1, *y1;
+    int *begin, *count;
+    short *next, *prev;
+    uint8_t* flags; // bit0 = key buffer, bit1 = bNoMore
+    unsigned long long *vec, *vprev;
+};
+
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__global__ __launch_bounds__(64) void k_distribute(const LevelGeom* __restrict__ geom, const uint32_t* __restrict__ slots,
+                                                   size_t slots_fstride, const int32_t* __restrict__ cellcnt,
+                                                   int ncells_total, uint32_t* __restrict__ keyscratch,
+                                                   size_t keys_fstride, uint32_t* __restrict__ lvl_out,
+                                                   int out_fstride, int32_t* __restrict__ lvl_cnt, int nlevels,
+                                                   int32_t* __restrict__ lvl_ncand, int keycap_lds, int nodecap,
+                                                   int veccap)
+{
+    extern __shared__ __align__(16) unsigned char qt_smem[];
+    const int lane = threadIdx.x;
+    const int level = blockIdx.x, f = blockIdx.y;
+    const LevelGeom g = geom[level];
+
+    // carve LDS
+    unsigned char* sp = qt_smem;
+    unsigned long long* vec = (unsigned long long*)sp; sp += (size_t)veccap * 8;
+    unsigned long long* vprev = (unsigned long long*)sp; sp += (size_t)veccap * 8;
+    int* nbegin = (int*)sp; sp += (size_t)nodecap * 4;
+    int* ncount = (int*)sp; sp += (size_t)nodecap * 4;
+    int* nseq = (int*)sp; sp += (size_t)nodecap * 4;
+    short* nx0 = (short*)sp; sp += (size_t)nodecap * 2;
+    short* ny0 = (short*)sp; sp += (size_t)nodecap * 2;
+    short* nx1 = (short*)sp; sp += (size_t)nodecap * 2;
+    short* ny1 = (short*)sp; sp += (size_t)nodecap * 2;
+    short* nnext = (short*)sp; sp += (size_t)nodecap * 2;
+    short* nprev = (short*)sp; sp += (size_t)nodecap * 2;
+    short* nfree = (short*)sp; sp += (size_t)nodecap * 2;
+    uint8_t* nflag = (uint8_t*)sp; sp += ((size_t)nodecap + 15) & ~(size_t)15;
+    sp = qt_smem + (((size_t)(sp - qt_smem) + 15) & ~(size_t)15);
+    uint32_t* lkeys = (uint32_t*)sp; // 2 * keycap_lds
+
+    // ---- gather the level's candidates in cell row-major order (= vToDistributeKeys order, :819-826)
+    const int32_t* ccnt = cellcnt + (size_t)f * ncells_total + g.cell_first;
+    const uint32_t* cslots = slots + (size_t)f * slots_fstride + g.slot_off;
+    int n = 0;
+    for (int c0 = 0; c0 < g.ncells; c0 += 64) {
+        const int c = c0 + lane;
+        n += (c < g.ncells) ? ccnt[c] : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+    n = rfl(n);
+    uint32_t* kb0;
+    uint32_t* kb1;
+    if (n <= keycap_lds) {
+        kb0 = lkeys;
+        kb1 = lkeys + keycap_lds;
+    } else {
+        kb0 = keyscratch + (size_t)f * keys_fstride + 2 * g.cand_off;
+        kb1 = kb0 + g.cand_cap;
+    }
+    {
+        int base = 0;
+        for (int c0 = 0; c0 < g.ncells; c0 += 64) {
+            const int c = c0 + lane;
+            const int cnt = (c < g.ncells) ? ccnt[c] : 0;
+            int incl = cnt;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                int t = __shfl_up(incl, o);
+                if (lane >= o) incl += t;
+            }
+            const int off = base + incl - cnt;
+            int mx = cnt;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+            const uint32_t* s = cslots + (size_t)c * g.cell_cap;
+            for (int k = 0; k < mx; k++)
+                if (k < cnt) kb0[off + k] = s[k];
+            base += __shfl(incl, 63);
+        }
+    }
+    if (lane == 0) lvl_ncand[f * nlevels + level] = n;
+    __syncthreads();
+
+    uint32_t* outp = lvl_out + (size_t)f * out_fstride + g.out_off;
+    if (n == 0) {
+        if (lane == 0) lvl_cnt[f * nlevels + level] = 0;
+        return;
+    }
+
+    // ---- node list
+    int head = -1, tail = -1, size = 0, nfreecnt = 0, nalloc = 0, seq = 0, nvec = 0;
+    const int N = g.quota;
+    uint32_t* kbuf[2] = {kb0, kb1};
+
+    auto alloc_node = [&]() -> int {
+        int id;
+        if (nfreecnt > 0) id = nfree[--nfreecnt];
+        else id = nalloc++;
+        return id;
+    };
+    auto push_front = [&](int id) {
+        if (lane == 0) {
+            nprev[id] = -1;
+            nnext[id] = (short)head;
+            if (head >= 0) nprev[head] = (short)id;
+        }
+        if (head < 0) tail = id;
+        head = id;
+        size++;
+    };
+    auto push_back = [&](int id) {
+        if (lane == 0) {
+            nnext[id] = -1;
+            nprev[id] = (short)tail;
+            if (tail >= 0) nnext[tail] = (short)id;
+        }
+        if (tail < 0) head = id;
+        tail = id;
+        size++;
+    };
+    auto erase = [&](int id) {
+        const int p = nprev[id], q = nnext[id];
+        __syncthreads();
+        if (lane == 0) {
+            if (p >= 0) nnext[p] = (short)q;
+            if (q >= 0) nprev[q] = (short)p;
+            nfree[nfreecnt] = (short)id;
+        }
+        if (p < 0) head = q;
+        if (q < 0) tail = p;
+        nfreecnt++;
+        size--;
+        __syncthreads();
+    };
+
+    // root nodes (:546-570): nIni vertical strips, keys assigned by (int)(x / hX)
+    {
+        int cnt[8], beginq[8], run[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) cnt[q] = 0;
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            const int i = i0 + lane;
+            int r = -1;
+            if (i < n) r = (int)__fdiv_rn((float)(kb0[i] & 0xfff), g.hX);
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+                if (q < g.nIni) cnt[q] += __popcll(__ballot(r == q));
+        }
+        int acc = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) { beginq[q] = acc; run[q] = acc; acc += cnt[q]; }
+        if (g.nIni > 1) {
+            for (int i0 = 0; i0 < n; i0 += 64) {
+                const int i = i0 + lane;
+                int r = -1;
+                uint32_t kv = 0;
+                if (i < n) { kv = kb0[i]; r = (int)__fdiv_rn((float)(kv & 0xfff), g.hX); }
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                    if (q < g.nIni) {
+                        const unsigned long long m = __ballot(r == q);
+                        if (r == q) kb1[run[q] + lane_prefix(m)] = kv;
+                        run[q] += __popcll(m);
+                    }
+            }
+        }
+        __syncthreads();
+        const int rootbuf = (g.nIni == 1) ? 0 : 1;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            if (q >= g.nIni) continue;
+            // the reference creates every root, then erases the empty ones (:574-585); seq counts all of them
+            const int myseq = seq++;
+            if (cnt[q] == 0) continue;
+            const int id = alloc_node();
+            if (lane == 0) {
+                nx0[id] = (short)(int)(g.hX * (float)q);
+                nx1[id] = (short)(int)(g.hX * (float)(q + 1));
+                ny0[id] = 0;
+                ny1[id] = (short)(g.maxBY - 16);
+                nbegin[id] = beginq[q];
+                ncount[id] = cnt[q];
+                nseq[id] = myseq;
+                nflag[id] = (uint8_t)(rootbuf | (cnt[q] == 1 ? 2 : 0));
+            }
+            push_back(id);
+        }
+        __syncthreads();
+    }
+
+    // DivideNode + "add childs if they contain points" (:604-656 / :689-728); returns nothing, updates list + vec
+    auto split = [&](int id, int* nToExpand) {
+        const int x0 = nx0[id], y0 = ny0[id], x1 = nx1[id], y1 = ny1[id];
+        const int b = nbegin[id], cnt = ncount[id], buf = nflag[id] & 1;
+        const int halfX = (x1 - x0 + 1) >> 1, halfY = (y1 - y0 + 1) >> 1; // ceil(float(d)/2), d >= 0
+        const int xm = x0 + halfX, ym = y0 + halfY;
+        const uint32_t* srck = kbuf[buf] + b;
+        uint32_t* dstk = kbuf[buf ^ 1] + b;
+        int c[4] = {0, 0, 0, 0};
+        for (int i0 = 0; i0 < cnt; i0 += 64) {
+            const int i = i0 + lane;
+            int q = -1;
+            if (i < cnt) {
+                const uint32_t kv = srck[i];
+                const int kx = kv & 0xfff, ky = (kv >> 12) & 0xfff;
+                q = (kx < xm ? 0 : 1) + (ky < ym ? 0 : 2);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) c[k] += __popcll(__ballot(q == k));
+        }
+        int run[4] = {0, c[0], c[0] + c[1], c[0] + c[1] + c[2]};
+        const int cb[4] = {run[0], run[1], run[2], run[3]};
+        for (int i0 = 0; i0 < cnt; i0 += 64) {
+            const int i = i0 + lane;
+            int q = -1;
+            uint32_t kv = 0;
+            if (i < cnt) {
+                kv = srck[i];
+                const int kx = kv & 0xfff, ky = (kv >> 12) & 0xfff;
+                q = (kx < xm ? 0 : 1) + (ky < ym ? 0 : 2);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const unsigned long long m = __ballot(q == k);
+                if (q == k) dstk[run[k] + lane_prefix(m)] = kv;
+                run[k] += __popcll(m);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (c[k] == 0) continue;
+            const int cid = alloc_node();
+            const int myseq = seq++;
+            if (lane == 0) {
+                nx0[cid] = (short)((k & 1) ? xm : x0);
+                nx1[cid] = (short)((k & 1) ? x1 : xm);
+                ny0[cid] = (short)((k & 2) ? ym : y0);
+                ny1[cid] = (short)((k & 2) ? y1 : ym);
+                nbegin[cid] = b + cb[k];
+                ncount[cid] = c[k];
+                nseq[cid] = myseq;
+                nflag[cid] = (uint8_t)((buf ^ 1) | (c[k] == 1 ? 2 : 0));
+            }
+            push_front(cid);
+            if (c[k] > 1) {
+                if (nToExpand) (*nToExpand)++;
+                if (lane == 0)
+                    vec[nvec] = ((unsigned long long)c[k] << 40) | ((unsigned long long)myseq << 16) |
+                                (unsigned long long)cid;
+                nvec++;
+            }
+        }
+        __syncthreads();
+    };
+
+    bool finish = false;
+    while (!finish) {
+        const int prevSize = size;
+        int nToExpand = 0;
+        nvec = 0;
+        int cur = head;
+        while (cur >= 0) {
+            const int nxt = rfl(nnext[cur]);
+            const int fl = rfl(nflag[cur]);
+            if (!(fl & 2)) {
+                split(cur, &nToExpand);
+                erase(cur);
+            }
+            cur = nxt;
+        }
+        if (size >= N || size == prevSize) {
+            finish = true;
+        } else if (size + nToExpand * 3 > N) {
+            while (!finish) {
+                const int prevSize2 = size;
+                // vPrev = vSizeAndPointerToNode, sorted ascending by (size, seq); bitonic sort over a power of two
+                const int np = nvec;
+                int P = 1;
+                while (P < np) P <<= 1;
+                for (int i = lane; i < P; i += 64) vprev[i] = (i < np) ? vec[i] : 0ull;
+                __syncthreads();
+                for (int k = 2; k <= P; k <<= 1)
+                    for (int j = k >> 1; j > 0; j >>= 1) {
+                        for (int t = lane; t < (P >> 1); t += 64) {
+                            const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                            const int l = i | j;
+                            const unsigned long long a = vprev[i], bb = vprev[l];
+                            const bool up = ((i & k) == 0);
+                            if ((a > bb) == up) { vprev[i] = bb; vprev[l] = a; }
+                        }
+                        __syncthreads();
+                    }
+                nvec = 0;
+                for (int j = P - 1; j >= P - np; j--) {
+                    const unsigned long long e = vprev[j];
+                    const int id = rfl((int)(e & 0xffff));
+                    split(id, nullptr);
+                    erase(id);
+                    if (size >= N) break;
+                }
+                if (size >= N || size == prevSize2) finish = true;
+            }
+        }
+    }
+
+    // ---- retain the best point of each node (:741-760), in list order
+    // walk the list once (wave-uniform) recording node ids, then one lane per node
+    short* order = (short*)vprev; // reuse (veccap*8 bytes >= nodecap*2)
+    {
+        int cur = head, k = 0;
+        while (cur >= 0) {
+            if (lane == 0) order[k] = (short)cur;
+            k++;
+            cur = rfl(nnext[cur]);
+        }
+    }
+    __syncthreads();
+    for (int k0 = 0; k0 < size; k0 += 64) {
+        const int k = k0 + lane;
+        if (k < size) {
+            const int id = order[k];
+            const uint32_t* kk = kbuf[nflag[id] & 1] + nbegin[id];
+            const int cnt = ncount[id];
+            uint32_t best = kk[0];
+            for (int i = 1; i < cnt; i++) {
+                const uint32_t kv = kk[i];
+                if ((kv >> 24) > (best >> 24)) best = kv; // strict '>' : first one wins ties (:752)
+            }
+            outp[k] = best;
+        }
+    }
+    if (lane == 0) lvl_cnt[f * nlevels + level] = size;
+}
+
+// per-frame level offsets (ascending-level concatenation, :1076-1104) and totals
+__global__ void k_level_offsets(const int32_t* __restrict__ lvl_cnt, int32_t* __restrict__ lvl_off,
+                                int32_t* __restrict__ n_out, int nlevels, int nframes, int capacity,
+                                int32_t* __restrict__ overflow)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nframes) return;
+    int acc = 0;
+    for (int l = 0; l < nlevels; l++) {
+        lvl_off[f * nlevels + l] = acc;
+        acc += lvl_cnt[f * nlevels + l];
+    }
+    if (acc > capacity) {
+        atomicMax(overflow, acc);
+        acc = capacity;
+    }
+    n_out[f] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------ blur ----
+// GaussianBlur 7x7 sigma 2, taps 18 34 49 55 49 34 18 (x256, sum 257), BORDER_REFLECT_101,
+// out = sat_u8((sum + 32768) >> 16).  64x16 output tile per workgroup, separable through LDS.
+__device__ __forceinline__ int reflect101(int p, int n)
+{
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = (p < 0) ? -p : 2 * (n - 1) - p;
+    return p;
+}
+
+__global__ __launch_bounds__(256) void k_blur7(ImgView src0, ImgView pyr, ImgView blur,
+                                               const LevelGeom* __restrict__ geom, const uint32_t* __restrict__ tiles)
+{
+    __shared__ uint8_t sin[22][72];
+    __shared__ uint16_t sh[22][64];
+    const uint32_t t = tiles[blockIdx.x];
+    const int level = t & 15, tx0 = ((t >> 4) & 0x3fff) * 64, ty0 = (t >> 18) * 16;
+    const int f = blockIdx.y;
+    const LevelGeom g = geom[level];
+    const uint8_t* img = (level == 0) ? src0.base + (size_t)f * src0.fstride
+                                      : pyr.base + (size_t)f * pyr.fstride + g.img_off;
+    const int pitch = (level == 0) ? src0.pitch : g.pitch;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 22 * 70; i += 256) {
+        const int r = i / 70, c = i - r * 70;
+        const int y = reflect101(ty0 + r - 3, g.h), x = reflect101(tx0 + c - 3, g.w);
+        sin[r][c] = img[(size_t)y * pitch + x];
+    }
+    __syncthreads();
+    for (int i = tid; i < 22 * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        const uint8_t* p = &sin[r][c];
+        sh[r][c] = (uint16_t)(18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3]);
+    }
+    __syncthreads();
+    const int r = tid >> 4, c4 = (tid & 15) * 4;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int c = c4 + k;
+        const int s = 18 * (sh[r][c] + sh[r + 6][c]) + 34 * (sh[r + 1][c] + sh[r + 5][c]) +
+                      49 * (sh[r + 2][c] + sh[r + 4][c]) + 55 * sh[r + 3][c];
+        int v = (s + 32768) >> 16;
+        v = v > 255 ? 255 : v;
+        packed |= (uint32_t)v << (8 * k);
+    }
+    const int y = ty0 + r, x = tx0 + c4;
+    if (y < g.h && x < g.bpitch) {
+        uint8_t* D = blur.base_w + (size_t)f * blur.fstride + g.blur_off + (size_t)y * g.bpitch;
+        *reinterpret_cast<uint32_t*>(D + x) = packed;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ describe --
+// One wave per keypoint: IC_Angle on the un-blurred level (:77-104), then the 256 steered BRIEF tests on the
+// blurred level (:108-147), then the final record (octave, size, scaled coordinates; :837-847, :1095-1101).
+__global__ __launch_bounds__(256) void k_orient_describe(ImgView src0, ImgView pyr, ImgView blur,
+                                                         const LevelGeom* __restrict__ geom,
+                                                         const uint32_t* __restrict__ lvl_out, int out_fstride,
+                                                         const int32_t* __restrict__ lvl_cnt,
+                                                         const int32_t* __restrict__ lvl_off, int nlevels,
+                                                         const uint32_t* __restrict__ pattern32 /*256 x (x0,y0,x1,y1) i8*/,
+                                                         const int* __restrict__ umax, orbfe_keypoint* __restrict__ kps,
+                                                         uint8_t* __restrict__ desc, int capacity)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int level = blockIdx.y, f = blockIdx.z;
+    const int i = blockIdx.x * 4 + wid;
+    const int cnt = lvl_cnt[f * nlevels + level];
+    if (i >= cnt) return;
+    const int oidx = lvl_off[f * nlevels + level] + i;
+    if (oidx >= capacity) return;
+    const LevelGeom g = geom[level];
+    const uint32_t kv = lvl_out[(size_t)f * out_fstride + g.out_off + i];
+    const int kx = (int)(kv & 0xfff) + 16, ky = (int)((kv >> 12) & 0xfff) + 16; // += minBorder (:843-844)
+    const int score = kv >> 24;
+
+    const uint8_t* img = (level == 0) ? src0.base + (size_t)f * src0.fstride
+                                      : pyr.base + (size_t)f * pyr.fstride + g.img_off;
+    const int pitch = (level == 0) ? src0.pitch : g.pitch;
+
+    // ---- IC_Angle: lanes 0..30 <-> u = -15..15 of an even row, lanes 32..62 of the following row
+    int m10 = 0, m01 = 0;
+    {
+        const int half = lane >> 5, u = (lane & 31) - 15;
+        const uint8_t* center = img + (size_t)ky * pitch + kx;
+#pragma unroll
+        for (int it = 0; it < 16; it++) {
+            const int v = -15 + 2 * it + half; // rows -15..16 (16 is masked)
+            const int av = v < 0 ? -v : v;
+            if ((lane & 31) < 31 && v <= 15) {
+                const int um = umax[av];
+                if (u >= -um && u <= um) {
+                    const int val = center[v * pitch + u];
+                    m10 += u * val;
+                    m01 += v * val;
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            m10 += __shfl_xor(m10, o);
+            m01 += __shfl_xor(m01, o);
+        }
+    }
+    const float angle = orbfe_fast_atan2((float)m01, (float)m10);
+
+    // ---- steered BRIEF
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    const float arad = angle * factorPI;
+    float a, b;
+    orbfe_sincosf(arad, &b, &a); // a = cos, b = sin
+    const uint8_t* bimg = blur.base + (size_t)f * blur.fstride + g.blur_off;
+    const uint8_t* bc = bimg + (size_t)ky * g.bpitch + kx;
+    unsigned long long words[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t pp = pattern32[j * 64 + lane];
+        const float x0 = (float)(signed char)(pp & 0xff), y0 = (float)(signed char)((pp >> 8) & 0xff);
+        const float x1 = (float)(signed char)((pp >> 16) & 0xff), y1 = (float)(signed char)(pp >> 24);
+        const int r0 = orbfe_round_f(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
+        const int c0 = orbfe_round_f(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
+        const int r1 = orbfe_round_f(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
+        const int c1 = orbfe_round_f(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
+        const int t0 = bc[r0 * g.bpitch + c0], t1 = bc[r1 * g.bpitch + c1];
+        words[j] = __ballot(t0 < t1);
+    }
+    if (lane < 4) {
+        unsigned long long wv = lane == 0 ? words[0] : lane == 1 ? words[1] : lane == 2 ? words[2] : words[3];
+        reinterpret_cast<unsigned long long*>(desc + ((size_t)f * capacity + oidx) * 32)[lane] = wv;
+    }
+    if (lane == 0) {
+        orbfe_keypoint kp;
+        float px = (float)kx, py = (float)ky;
+        if (level != 0) { px = __fmul_rn(px, g.scale); py = __fmul_rn(py, g.scale); }
+        kp.x = px; kp.y = py;
+        kp.size = g.kp_size;
+        kp.angle = angle;
+        kp.response = (float)score;
+        kp.octave = level;
+        kp.class_id = -1;
+        kps[(size_t)f * capacity + oidx] = kp;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ debug ---
+__global__ void k_unpack_keys(const uint32_t* __restrict__ in, int n, int add, orbfe_keypoint* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t kv = in[i];
+    orbfe_keypoint kp;
+    kp.x = (float)((int)(kv & 0xfff) + add);
+    kp.y = (float)((int)((kv >> 12) & 0xfff) + add);
+    kp.size = 7.f; kp.angle = -1.f; kp.response = (float)(kv >> 24); kp.octave = 0; kp.class_id = -1;
+    out[i] = kp;
+}
+
+} // namespace orbfe

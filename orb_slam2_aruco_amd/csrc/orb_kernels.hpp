@@ -1,0 +1,73 @@
+// orb_kernels.hpp -- device-side structs and kernel declarations of the ORB extractor.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/orbfe.h"
+#include "../../include/orbfe_math.h"
+
+namespace orbfe {
+
+// A batch of same-sized images: frame f starts at base + f * fstride, rows are `pitch` bytes apart.
+struct ImgView {
+    const uint8_t* base;
+    uint8_t* base_w; // same memory, writable (null for read-only views)
+    size_t fstride;
+    int pitch;
+};
+
+// Geometry of one pyramid level, computed on the host with the reference's own float arithmetic
+// (ORBextractor.cc:767-787, :546-558) and read by every kernel.
+struct LevelGeom {
+    int w, h;            // level image size (:1112)
+    int pitch;           // row pitch of the level inside the pyramid block (levels >= 1)
+    int bpitch;          // row pitch inside the blurred block
+    long long img_off;   // byte offset of the level inside a frame's pyramid block (levels >= 1)
+    long long blur_off;  // byte offset inside a frame's blurred block
+    int nCols, nRows, wCell, hCell; // FAST cell grid (:784-787)
+    int maxBX, maxBY;    // maxBorderX/Y (:774-775); minBorder is 16
+    int cell_first;      // index of the level's first active cell in the frame's cell array
+    int ncells;          // active cells (rows/cols skipped at :795,:804 are not materialised)
+    int cell_cap;        // candidate slots per cell: ceil(wCell/2)*ceil(hCell/2) (no two NMS survivors are adjacent)
+    long long slot_off;  // u32 offset of the level's slots inside a frame's slot block
+    int cand_cap;        // ncells * cell_cap
+    long long cand_off;  // u32 offset (per ping-pong half) inside a frame's key scratch
+    int quota;           // mnFeaturesPerLevel[level] (:435-446)
+    int out_cap;         // slots for the level's distributed keypoints
+    int out_off;         // u32 offset inside a frame's lvl_out block
+    int nIni;            // root nodes (:543)
+    float hX;            // (:545)
+    float scale;         // mvScaleFactor[level]
+    float kp_size;       // (float)(int)(31 * scale) (:837)
+};
+
+__global__ void k_resize_level(ImgView src, ImgView dst, int sw, int sh, int dw4, int dh, const int* xofs,
+                               const int* xalpha, const int* yofs, const int* ybeta);
+__global__ void k_fast_cells(ImgView src0, ImgView pyr, const LevelGeom* geom, const uint32_t* cellinfo,
+                             uint32_t* slots, size_t slots_fstride, int32_t* cellcnt, int ncells_total, int iniTh,
+                             int minTh);
+__global__ void k_distribute(const LevelGeom* geom, const uint32_t* slots, size_t slots_fstride,
+                             const int32_t* cellcnt, int ncells_total, uint32_t* keyscratch, size_t keys_fstride,
+                             uint32_t* lvl_out, int out_fstride, int32_t* lvl_cnt, int nlevels, int32_t* lvl_ncand,
+                             int keycap_lds, int nodecap, int veccap);
+__global__ void k_level_offsets(const int32_t* lvl_cnt, int32_t* lvl_off, int32_t* n_out, int nlevels, int nframes,
+                                int capacity, int32_t* overflow);
+__global__ void k_blur7(ImgView src0, ImgView pyr, ImgView blur, const LevelGeom* geom, const uint32_t* tiles);
+__global__ void k_orient_describe(ImgView src0, ImgView pyr, ImgView blur, const LevelGeom* geom,
+                                  const uint32_t* lvl_out, int out_fstride, const int32_t* lvl_cnt,
+                                  const int32_t* lvl_off, int nlevels, const uint32_t* pattern32, const int* umax,
+                                  orbfe_keypoint* kps, uint8_t* desc, int capacity);
+__global__ void k_unpack_keys(const uint32_t* in, int n, int add, orbfe_keypoint* out);
+
+inline size_t qt_lds_bytes(int keycap_lds, int nodecap, int veccap)
+{
+    size_t b = (size_t)veccap * 16;                 // vec + vprev
+    b += (size_t)nodecap * 12;                      // begin, count, seq
+    b += (size_t)nodecap * 14;                      // x0,y0,x1,y1,next,prev,free
+    b += ((size_t)nodecap + 15) & ~(size_t)15;      // flags
+    b = (b + 15) & ~(size_t)15;
+    b += (size_t)keycap_lds * 8;                    // two key buffers
+    return b + 16;
+}
+
+} // namespace orbfe

@@ -1,0 +1,98 @@
+// orbfe_common.hpp -- shared host-side plumbing of liborbfe.so (error state, HIP checks, device buffers).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/orbfe.h"
+#include "../../include/orbfe_math.h"
+
+namespace orbfe {
+
+extern thread_local char g_err[512];
+
+inline int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define ORBFE_HIP(call)                                                                                  \
+    do {                                                                                                 \
+        hipError_t e_ = (call);                                                                          \
+        if (e_ != hipSuccess)                                                                            \
+            return ::orbfe::fail(ORBFE_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                                 __FILE__, __LINE__);                                                    \
+    } while (0)
+
+// Select the device, or report that there is none (no CPU fallback exists in this library).
+int use_device(int device);
+
+// Grow-only device allocation.
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need)
+    {
+        if (need <= bytes) return ORBFE_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        size_t want = need + need / 8 + 256;
+        ORBFE_HIP(hipMalloc(&p, want));
+        bytes = want;
+        return ORBFE_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+// Event-pair timing of individual launches (debug/profiling aid; off the hot path unless enabled).
+struct KernelTimer {
+    bool enabled = false;
+    std::vector<hipEvent_t> ev;
+    std::vector<std::string> names;
+    size_t used = 0;
+    void begin() { used = 0; names.clear(); }
+    void mark(hipStream_t s, const char* name)
+    {
+        if (!enabled) return;
+        if (used == ev.size()) {
+            hipEvent_t e;
+            (void)hipEventCreate(&e);
+            ev.push_back(e);
+        }
+        (void)hipEventRecord(ev[used++], s);
+        names.push_back(name);
+    }
+    int collect(float* out_us, int capacity)
+    {
+        if (!enabled || used < 2) return 0;
+        (void)hipEventSynchronize(ev[used - 1]);
+        int n = 0;
+        for (size_t i = 1; i < used && n < capacity; i++) {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, ev[i - 1], ev[i]);
+            out_us[n++] = ms * 1000.f;
+        }
+        return n;
+    }
+    ~KernelTimer()
+    {
+        for (auto e : ev) (void)hipEventDestroy(e);
+    }
+};
+
+} // namespace orbfe

@@ -1,0 +1,196 @@
+"""ctypes binding of oracle/liborbfe_oracle.so (the CPU restatement).  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "liborbfe_oracle.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+MARKER_DTYPE = np.dtype([("id", "<i4"), ("corners", "<f4", (4, 2))])
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(ORACLE_SO) or any(
+                os.path.getmtime(os.path.join(ORACLE_DIR, f)) > os.path.getmtime(ORACLE_SO)
+                for f in os.listdir(ORACLE_DIR) if f.endswith((".cpp", ".h"))):
+            build()
+        L = C.CDLL(ORACLE_SO)
+        L.oracle_orb_create.restype = C.c_void_p
+        L.oracle_orb_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        L.oracle_orb_destroy.argtypes = [C.c_void_p]
+        L.oracle_orb_set_trig_libm.argtypes = [C.c_void_p, C.c_int]
+        L.oracle_orb_extract.restype = C.c_int
+        L.oracle_orb_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p,
+                                         C.c_void_p, C.c_int]
+        L.oracle_orb_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+        L.oracle_orb_level_size.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.oracle_orb_level_image.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.oracle_orb_level_keypoints.restype = C.c_int
+        L.oracle_orb_level_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.oracle_resize_linear_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
+        L.oracle_gaussian_blur7.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.oracle_gaussian7_taps.argtypes = [C.c_void_p]
+        L.oracle_fast_score_map.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.oracle_fast_detect.restype = C.c_int
+        L.oracle_fast_detect.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.oracle_distribute.restype = C.c_int
+        L.oracle_distribute.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                        C.c_int]
+        L.oracle_fast_atan2.restype = C.c_float
+        L.oracle_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.oracle_sincosf.argtypes = [C.c_float, C.c_void_p, C.c_void_p]
+        L.oracle_cv_round.restype = C.c_int
+        L.oracle_cv_round.argtypes = [C.c_double]
+        L.oracle_descriptor_distance.restype = C.c_int
+        L.oracle_descriptor_distance.argtypes = [C.c_void_p, C.c_void_p]
+        L.oracle_knn2.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                  C.c_void_p]
+        L.oracle_features_in_area.restype = C.c_int
+        L.oracle_features_in_area.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                              C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.oracle_knn2_csr.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                      C.c_void_p, C.c_void_p]
+        L.oracle_search_for_initialization.restype = C.c_int
+        L.oracle_search_for_initialization.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                       C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                                       C.c_float, C.c_int]
+        L.oracle_three_maxima.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        if hasattr(L, "oracle_aruco_create"):
+            _bind_aruco(L)
+        _lib = L
+    return _lib
+
+
+def _bind_aruco(L):
+    L.oracle_aruco_create.restype = C.c_void_p
+    L.oracle_aruco_create.argtypes = [C.c_char_p]
+    L.oracle_aruco_destroy.argtypes = [C.c_void_p]
+    L.oracle_aruco_detect.restype = C.c_int
+    L.oracle_aruco_detect.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_int]
+    L.oracle_aruco_stage_image.restype = C.c_int
+    L.oracle_aruco_stage_image.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.oracle_aruco_stage_count.restype = C.c_int
+    L.oracle_aruco_stage_count.argtypes = [C.c_void_p, C.c_int]
+    L.oracle_aruco_candidates.restype = C.c_int
+    L.oracle_aruco_candidates.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    L.oracle_adaptive_threshold.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
+    L.oracle_find_contours.restype = C.c_int
+    L.oracle_find_contours.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    L.oracle_warp_perspective35.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    L.oracle_otsu_threshold.restype = C.c_int
+    L.oracle_otsu_threshold.argtypes = [C.c_void_p, C.c_int]
+    L.oracle_decode_marker.restype = C.c_int
+    L.oracle_decode_marker.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class OrbOracle:
+    def __init__(self, nfeatures=1000, scale=1.2, nlevels=8, ini=20, mn=7):
+        self.L = lib()
+        self.nlevels = nlevels
+        self.nfeatures = nfeatures
+        self.h = self.L.oracle_orb_create(nfeatures, scale, nlevels, ini, mn)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.oracle_orb_destroy(self.h)
+            self.h = None
+
+    def tables(self):
+        n = self.nlevels
+        f = [np.zeros(n, np.float32) for _ in range(4)]
+        per = np.zeros(n, np.int32)
+        um = np.zeros(16, np.int32)
+        self.L.oracle_orb_tables(self.h, _p(f[0]), _p(f[1]), _p(f[2]), _p(f[3]), _p(per), _p(um))
+        return dict(scale=f[0], inv_scale=f[1], sigma2=f[2], inv_sigma2=f[3], per_level=per, umax=um)
+
+    def extract(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        cap = self.nfeatures + 4 * self.nlevels + 16
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = self.L.oracle_orb_extract(self.h, _p(img), img.shape[0], img.shape[1], img.strides[0], _p(kps), _p(desc),
+                                      cap)
+        assert n >= 0, "oracle capacity too small"
+        return kps[:n].copy(), desc[:n].copy()
+
+    def level_image(self, level, blurred=False):
+        w, h = C.c_int(), C.c_int()
+        self.L.oracle_orb_level_size(self.h, level, C.byref(w), C.byref(h))
+        out = np.zeros((h.value, w.value), np.uint8)
+        self.L.oracle_orb_level_image(self.h, level, int(blurred), _p(out))
+        return out
+
+    def level_keypoints(self, level, stage):
+        n = self.L.oracle_orb_level_keypoints(self.h, level, stage, None, 0)
+        out = np.zeros(max(n, 1), KP_DTYPE)
+        self.L.oracle_orb_level_keypoints(self.h, level, stage, _p(out), n)
+        return out[:n]
+
+
+def knn2(Q, T, init=256):
+    L = lib()
+    Q = np.ascontiguousarray(Q, np.uint8)
+    T = np.ascontiguousarray(T, np.uint8)
+    bi = np.zeros(len(Q), np.int32)
+    bd = np.zeros(len(Q), np.int32)
+    sd = np.zeros(len(Q), np.int32)
+    L.oracle_knn2(_p(Q), len(Q), _p(T), len(T), init, _p(bi), _p(bd), _p(sd))
+    return bi, bd, sd
+
+
+def features_in_area(kps2, cols, rows, qx, qy, r, min_level, max_level):
+    L = lib()
+    kps2 = np.ascontiguousarray(kps2)
+    qx = np.ascontiguousarray(qx, np.float32)
+    qy = np.ascontiguousarray(qy, np.float32)
+    off = np.zeros(len(qx) + 1, np.int32)
+    total = L.oracle_features_in_area(_p(kps2), len(kps2), cols, rows, _p(qx), _p(qy), len(qx), r, min_level,
+                                      max_level, _p(off), None, 0)
+    idx = np.zeros(max(total, 1), np.int32)
+    L.oracle_features_in_area(_p(kps2), len(kps2), cols, rows, _p(qx), _p(qy), len(qx), r, min_level, max_level,
+                              _p(off), _p(idx), total)
+    return off, idx[:total]
+
+
+def knn2_csr(Q, T, off, idx, init=256):
+    L = lib()
+    Q = np.ascontiguousarray(Q, np.uint8)
+    T = np.ascontiguousarray(T, np.uint8)
+    bi = np.zeros(len(Q), np.int32)
+    bd = np.zeros(len(Q), np.int32)
+    sd = np.zeros(len(Q), np.int32)
+    idx = np.ascontiguousarray(idx, np.int32)
+    L.oracle_knn2_csr(_p(Q), len(Q), _p(T), _p(off), _p(idx), init, _p(bi), _p(bd), _p(sd))
+    return bi, bd, sd
+
+
+def search_for_initialization(k1, d1, k2, d2, cols, rows, prev=None, window=100, nnratio=0.9, check_ori=True):
+    L = lib()
+    k1 = np.ascontiguousarray(k1); k2 = np.ascontiguousarray(k2)
+    d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
+    if prev is None:
+        prev = np.stack([k1["x"], k1["y"]], 1)
+    prev = np.ascontiguousarray(prev, np.float32).copy()
+    m = np.zeros(len(k1), np.int32)
+    n = L.oracle_search_for_initialization(_p(k1), _p(d1), len(k1), _p(k2), _p(d2), len(k2), cols, rows, _p(prev),
+                                           _p(m), window, nnratio, int(check_ori))
+    return n, m, prev

@@ -1,0 +1,65 @@
+"""GPU parity: HIP ORB extractor (through the C ABI) vs the CPU oracle, stage by stage and end to end."""
+import numpy as np
+import pytest
+
+from orb_slam2_aruco_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # (rows, cols, nfeatures, nlevels, seed)
+    (240, 320, 500, 4, 11),
+    (480, 640, 1000, 8, 1),
+    (480, 640, 2000, 8, 2),   # the 2*nFeatures initialisation extractor (Tracking.cc:127)
+    (360, 636, 700, 6, 5),    # odd width, non-multiple-of-4 levels
+]
+
+
+def _cmp_kps(a, b, what):
+    assert len(a) == len(b), "%s: count %d vs %d" % (what, len(a), len(b))
+    for fld in ("x", "y", "response"):
+        assert np.array_equal(a[fld], b[fld]), "%s: field %s differs" % (what, fld)
+
+
+@pytest.mark.parametrize("rows,cols,nf,nl,seed", CASES)
+def test_stages_and_end_to_end(orbfe, oracle, rows, cols, nf, nl, seed):
+    img, _ = synth.scene(rows, cols, seed, n_markers=3, side_range=(40, 90))
+    ex = orbfe.ORBextractor(nf, 1.2, nl, 20, 7)
+    ora = oracle.OrbOracle(nf, 1.2, nl, 20, 7)
+    kps, desc = ex(img)
+    okps, odesc = ora.extract(img)
+    for l in range(nl):
+        assert np.array_equal(ex.level_image(0, l), ora.level_image(l)), "pyramid level %d" % l
+        _cmp_kps(ex.level_keypoints(0, l, 0), ora.level_keypoints(l, 0), "FAST candidates level %d" % l)
+        _cmp_kps(ex.level_keypoints(0, l, 1), ora.level_keypoints(l, 1), "quadtree level %d" % l)
+        if len(ora.level_keypoints(l, 1)):
+            assert np.array_equal(ex.level_image(0, l, True), ora.level_image(l, True)), "blur level %d" % l
+    assert len(kps) == len(okps)
+    for fld in ("x", "y", "size", "response", "octave", "class_id"):
+        assert np.array_equal(kps[fld], okps[fld]), fld
+    # orientation: shared integer moments + shared fastAtan2 -> expected bit-exact; contract is 1e-4
+    assert np.allclose(kps["angle"], okps["angle"], atol=1e-4)
+    assert np.array_equal(kps["angle"], okps["angle"])
+    assert np.array_equal(desc, odesc)
+
+
+def test_batch_equals_single(orbfe):
+    imgs = np.stack([synth.scene(240, 320, 100 + i, n_markers=2, side_range=(40, 70))[0] for i in range(5)])
+    ex = orbfe.ORBextractor(500, 1.2, 4, 20, 7)
+    batch = ex.extract_batch(imgs)
+    for i in range(5):
+        k, d = ex(imgs[i])
+        assert np.array_equal(k, batch[i][0]) and np.array_equal(d, batch[i][1])
+
+
+def test_empty_image(orbfe):
+    ex = orbfe.ORBextractor(500, 1.2, 4, 20, 7)
+    k, d = ex(np.zeros((0, 0), np.uint8))
+    assert len(k) == 0 and d.shape == (0, 32)
+
+
+def test_flat_image_no_keypoints(orbfe, oracle):
+    img = np.full((240, 320), 128, np.uint8)
+    k, d = orbfe.ORBextractor(500, 1.2, 4, 20, 7)(img)
+    ok, od = oracle.OrbOracle(500, 1.2, 4, 20, 7).extract(img)
+    assert len(k) == 0 and len(ok) == 0
