@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of the per-frame front-end (ORB extract + ArUco detect + Hamming match) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+One step = one pass of the hot path over one batch: a synthetic 640x480 mono stream (BASELINE.json configs[1]:
+nFeatures 1000, 8 levels, ARUCO dictionary) resident in HBM before the timed region.  Each rank owns an
+independent stream (frames/streams shard with no data-path collective, SURVEY 8e: weak scaling); the only collective
+is the final RCCL gather of the fixed-capacity result records to rank 0, inside the timed region.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=300, help="frames per step per GPU (the C2 stream length)")
+    ap.add_argument("--rows", type=int, default=480)
+    ap.add_argument("--cols", type=int, default=640)
+    ap.add_argument("--nfeatures", type=int, default=1000)
+    ap.add_argument("--nlevels", type=int, default=8)
+    ap.add_argument("--dictionary", default="ARUCO")
+    ap.add_argument("--cpu-frames", type=int, default=24, help="frames timed on the host for cpu_baseline (0 = skip)")
+    ap.add_argument("--no-aruco", action="store_true", help="diagnostic only: drop the ArUco leg (invalidates value)")
+    return ap.parse_args()
+
+
+def make_stream(args, rank):
+    """Synthetic stream of this rank (seed base differs per rank), cached under /tmp across runs on one box."""
+    from orb_slam2_aruco_amd import synth
+    seed = 1000 + 2000 * rank
+    path = "/tmp/orbfe_stream_%dx%d_%d_%d_%s.npy" % (args.cols, args.rows, args.frames, seed, args.dictionary)
+    if os.path.exists(path):
+        try:
+            return np.load(path)
+        except Exception:
+            pass
+    s = synth.stream(args.rows, args.cols, args.frames, seed, args.dictionary, n_markers=4)
+    try:
+        np.save(path + ".tmp.npy", s)
+        os.replace(path + ".tmp.npy", path)
+    except Exception:
+        pass
+    return s
+
+
+def cpu_baseline(args, frames_u8):
+    """The oracle (CPU port of the reference path) timed single-threaded on a bounded sample of the same stream."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    n = min(args.cpu_frames, len(frames_u8))
+    if n < 2:
+        return None
+    orb = O.OrbOracle(args.nfeatures, 1.2, args.nlevels, 20, 7)
+    aruco = O.ArucoOracle(args.dictionary) if (hasattr(O, "ArucoOracle") and not args.no_aruco) else None
+    res = []
+    t0 = time.perf_counter()
+    for i in range(n):
+        k, d = orb.extract(frames_u8[i])
+        if aruco is not None:
+            aruco.detect(frames_u8[i])
+        if res:
+            pk, pd = res[-1]
+            O.knn2(pd, d, 256)
+            O.search_for_initialization(pk, pd, k, d, args.cols, args.rows, None, 100, 0.9, True)
+        res.append((k, d))
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d frames of the same %dx%d stream, oracle/ single thread (ORB%s + knn2 + SearchForInitialization)"
+                      % (n, args.cols, args.rows, " + ArUco" if aruco is not None else "")}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from orb_slam2_aruco_amd import binding
+    L = binding.load()
+    B, rows, cols = args.frames, args.rows, args.cols
+
+    frames_np = make_stream(args, rank)
+    pitch = (cols + 63) // 64 * 64
+    d_imgs = torch.zeros((B, rows, pitch), dtype=torch.uint8, device=dev)
+    d_imgs[:, :, :cols] = torch.from_numpy(frames_np).to(dev)
+
+    ex = binding.ORBextractor(args.nfeatures, 1.2, args.nlevels, 20, 7, device=local_rank)
+    cap = ex.capacity
+    d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)     # 28-byte cv::KeyPoint records
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_bidx = torch.zeros((B - 1, cap), dtype=torch.int32, device=dev)
+    d_bdist = torch.zeros((B - 1, cap), dtype=torch.int32, device=dev)
+    d_sdist = torch.zeros((B - 1, cap), dtype=torch.int32, device=dev)
+    d_m12 = torch.zeros((B - 1, cap), dtype=torch.int32, device=dev)
+    d_nm = torch.zeros(B - 1, dtype=torch.int32, device=dev)
+    use_aruco = not args.no_aruco
+    if use_aruco:
+        det = binding.MarkerDetector(args.dictionary, device=local_rank)
+        mcap = det.capacity
+        d_mk = torch.zeros((B, mcap, 9), dtype=torch.int32, device=dev)   # 36-byte marker records
+        d_nmk = torch.zeros(B, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    sp = ctypes.c_void_p(stream.cuda_stream)
+
+    gathered = None
+    if world > 1:
+        rec = [d_n, d_kps, d_desc] + ([d_nmk, d_mk] if use_aruco else [])
+        gathered = [[torch.empty_like(t) for _ in range(world)] if rank == 0 else None for t in rec]
+
+    def step():
+        ex.extract_batch_device(d_imgs.data_ptr(), B, rows * pitch, rows, cols, pitch, d_kps.data_ptr(),
+                                d_desc.data_ptr(), cap, d_n.data_ptr(), sp)
+        if use_aruco:
+            det.detect_batch_device(d_imgs.data_ptr(), B, rows * pitch, rows, cols, pitch, d_mk.data_ptr(), mcap,
+                                    d_nmk.data_ptr(), sp)
+        # frame t vs t-1: all-pairs knn2 + one SearchForInitialization-style windowed pass
+        binding._check(L, L.orbfe_knn2_batch_device(d_desc.data_ptr(), d_n.data_ptr(), cap * 32, cap,
+                                                    d_desc.data_ptr() + cap * 32, d_n.data_ptr() + 4, cap * 32, cap,
+                                                    B - 1, 256, d_bidx.data_ptr(), d_bdist.data_ptr(),
+                                                    d_sdist.data_ptr(), sp), "knn2")
+        binding._check(L, L.orbfe_search_for_initialization_batch_device(
+            d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap, B - 1, cols, rows, 100, 0.9, 1,
+            d_m12.data_ptr(), d_nm.data_ptr(), sp), "sfi")
+        if world > 1:
+            for t, g in zip(rec, gathered):
+                dist.gather(t, g, dst=0)
+
+    ex.enable_kernel_timing(False)
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ex.enable_kernel_timing(True)
+    if use_aruco:
+        det.enable_kernel_timing(True)
+    ktimes = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        kt = {"orb": ex.kernel_times_us()} if False else None  # per-step collection would sync; done after the loop
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    # HIP-event timings of the LAST timed step's launches (events were recorded on the launch stream every step)
+    orb_us = ex.kernel_times_us()
+    aruco_us = det.kernel_times_us() if use_aruco else np.zeros(0, np.float32)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    total_frames = B * args.steps * world
+    n_host = d_n.cpu().numpy()
+
+    if rank == 0:
+        orb_names = ["resize", "fast_cells", "distribute", "blur7", "orient_describe"]
+        stages = {nm: float(v) for nm, v in zip(orb_names, orb_us)}
+        if use_aruco:
+            for nm, v in zip(binding.MarkerDetector.STAGES, aruco_us):
+                stages["aruco_" + nm] = float(v)
+        # algorithmic bytes per frame of each stage (DESIGN.md "roofline": terms of SURVEY 8d's B_orb / B_aruco)
+        sizes = ex.level_sizes()
+        P = [w * h for (w, h) in sizes]
+        sumP, P0 = sum(P), P[0]
+        N = float(n_host.mean())
+        alg = {"resize": (sumP - P[-1]) + (sumP - P0), "fast_cells": sumP, "blur7": 2 * sumP,
+               "orient_describe": N * (749 + 512 + 60), "distribute": 0}
+        if use_aruco:
+            alg.update(binding.MarkerDetector.algorithmic_bytes(rows, cols))
+        dom = max(stages, key=lambda k: stages[k]) if stages else None
+        roof = None
+        if dom is not None and stages[dom] > 0:
+            ach = alg.get(dom, 0) * B / (stages[dom] * 1e-6) / 1e9
+            traffic = None
+            tp = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tp):
+                try:
+                    traffic = json.load(open(tp)).get(dom)
+                except Exception:
+                    traffic = None
+            roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": 8000.0, "unit": "GB/s",
+                    "frac": ach / 8000.0, "traffic": traffic, "launch_us": stages[dom],
+                    "algorithmic_bytes_per_launch": alg.get(dom, 0) * B}
+        cpu = None
+        if world == 1 and args.cpu_frames > 0:
+            cpu = cpu_baseline(args, frames_np)
+        out = {
+            "metric": "frames/s (ORB+ArUco extract+match, 640x480 mono)" if (rows, cols) == (480, 640) else
+                      "frames/s (ORB+ArUco extract+match, %dx%d mono)" % (cols, rows),
+            "value": total_frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "C2: %d-frame %dx%d mono stream per GPU, nFeatures=%d, %d levels, %s dictionary; "
+                                   "per frame: ORB extract%s + knn2 all-pairs + SearchForInitialization vs previous frame"
+                                   % (B, cols, rows, args.nfeatures, args.nlevels, args.dictionary,
+                                      " + ArUco detect" if use_aruco else " (ArUco leg DISABLED: diagnostic run)"),
+                       "frames_per_step_per_gpu": B, "mean_keypoints_per_frame": N,
+                       "parallelism": "stream-per-gpu x%d, RCCL gather to rank 0" % world},
+            "roofline": roof, "cpu_baseline": cpu, "stage_us_last_step": stages,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

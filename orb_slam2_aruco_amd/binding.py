@@ -196,6 +196,14 @@ class ORBextractor:
                                                                     C.byref(n)), "level_keypoints")
         return out[:n.value]
 
+    def level_sizes(self):
+        out = []
+        for l in range(self.nlevels):
+            w, h = C.c_int(), C.c_int()
+            _check(self.L, self.L.orbfe_extractor_debug_level_size(self.h, l, C.byref(w), C.byref(h)), "level_size")
+            out.append((w.value, h.value))
+        return out
+
     def enable_kernel_timing(self, on=True):
         self.L.orbfe_extractor_debug_kernel_times(self.h, None, int(on))
 
@@ -203,3 +211,50 @@ class ORBextractor:
         out = np.zeros(32, np.float32)
         n = self.L.orbfe_extractor_debug_kernel_times(self.h, _p(out), 32)
         return out[:n]
+
+
+# ------------------------------------------------------------------------------------------ matching --
+def hamming(a, b):
+    L = load()
+    a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+    return L.orbfe_hamming(_p(a), _p(b))
+
+
+def knn2(Q, T, init=256, device=0):
+    """All-pairs best / second-best (ORBmatcher inner loop). Returns (best_idx, best_dist, second_dist)."""
+    L = load()
+    Q = np.ascontiguousarray(Q, np.uint8).reshape(-1, 32)
+    T = np.ascontiguousarray(T, np.uint8).reshape(-1, 32)
+    bi = np.full(len(Q), -1, np.int32); bd = np.full(len(Q), init, np.int32); sd = np.full(len(Q), init, np.int32)
+    _check(L, L.orbfe_knn2(_p(Q), len(Q), _p(T), len(T), init, _p(bi), _p(bd), _p(sd), device), "orbfe_knn2")
+    return bi, bd, sd
+
+
+class ORBmatcher:
+    """Mirror of ORB_SLAM2::ORBmatcher (reference include/ORBmatcher.h:41-83) for the rows built so far."""
+    TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30
+
+    def __init__(self, nnratio=0.6, checkOri=True, device=0):
+        self.mfNNratio = nnratio
+        self.mbCheckOrientation = checkOri
+        self.device = device
+        self.L = load()
+
+    @staticmethod
+    def DescriptorDistance(a, b):
+        return hamming(a, b)
+
+    def SearchForInitialization(self, kps1, desc1, kps2, desc2, cols, rows, vbPrevMatched=None, windowSize=10):
+        """Returns (nmatches, vnMatches12, vbPrevMatched'); frames are given as (keypoints, descriptors)."""
+        k1 = np.ascontiguousarray(kps1); k2 = np.ascontiguousarray(kps2)
+        d1 = np.ascontiguousarray(desc1, np.uint8); d2 = np.ascontiguousarray(desc2, np.uint8)
+        if vbPrevMatched is None:
+            vbPrevMatched = np.stack([k1["x"], k1["y"]], 1)
+        prev = np.ascontiguousarray(vbPrevMatched, np.float32).copy()
+        m12 = np.full(len(k1), -1, np.int32)
+        n = C.c_int32(0)
+        _check(self.L, self.L.orbfe_search_for_initialization(_p(k1), _p(d1), len(k1), _p(k2), _p(d2), len(k2), cols,
+                                                              rows, _p(prev), _p(m12), windowSize, self.mfNNratio,
+                                                              int(self.mbCheckOrientation), C.byref(n), self.device),
+               "orbfe_search_for_initialization")
+        return n.value, m12, prev

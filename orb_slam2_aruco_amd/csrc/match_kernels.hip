@@ -1,0 +1,560 @@
+// match_kernels.hip -- descriptor matching on gfx950 behind the C ABI (include/orbfe.h, "descriptor matching").
+//
+//   k_knn2_tiles / k_knn2_merge    all-pairs best / second-best Hamming with the reference update rule
+//                                  (inner loop of every ORBmatcher::SearchBy*)
+//   k_search_init                  ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:409-524) incl. the Frame
+//                                  grid (src/Frame.cc:183-198, 280-345), one workgroup per frame pair
+//
+// Bound: integer VALU issue (XOR + v_bcnt_u32_b32), not HBM: 1000 x 1000 descriptors are 64 KB of traffic for
+// 16 M lane-ops.  Train descriptors are staged through LDS and broadcast to all lanes of a wave.
+#include <climits>
+
+#include "orbfe_common.hpp"
+
+namespace orbfe {
+
+__device__ __forceinline__ int hamming256(const uint4& a0, const uint4& a1, const uint4& b0, const uint4& b1)
+{
+    int d = __popc(a0.x ^ b0.x);
+    d += __popc(a0.y ^ b0.y);
+    d += __popc(a0.z ^ b0.z);
+    d += __popc(a0.w ^ b0.w);
+    d += __popc(a1.x ^ b1.x);
+    d += __popc(a1.y ^ b1.y);
+    d += __popc(a1.z ^ b1.z);
+    d += __popc(a1.w ^ b1.w);
+    return d;
+}
+
+#define KNN_TILE 256
+
+// grid: (ceil(max_nq/256), npairs, nsplit).  Split s handles train rows [s*chunk, (s+1)*chunk).
+// Partial results go to part_* [pair][split][max_nq]; with nsplit == 1 they are the final arrays.
+__global__ __launch_bounds__(256) void k_knn2_tiles(const uint8_t* __restrict__ Q, const int32_t* __restrict__ nq_arr,
+                                                    size_t q_stride, int max_nq, const uint8_t* __restrict__ T,
+                                                    const int32_t* __restrict__ nt_arr, size_t t_stride, int chunk,
+                                                    int init, int32_t* __restrict__ best_idx,
+                                                    int32_t* __restrict__ best_dist, int32_t* __restrict__ second_dist)
+{
+    __shared__ uint4 st[KNN_TILE * 2];
+    const int pair = blockIdx.y, split = blockIdx.z, nsplit = gridDim.z;
+    const int nq = nq_arr ? nq_arr[pair] : max_nq;
+    const int nt = nt_arr[pair];
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x * 256 >= nq) return;
+    const uint4* Qp = reinterpret_cast<const uint4*>(Q + (size_t)pair * q_stride);
+    const uint4* Tp = reinterpret_cast<const uint4*>(T + (size_t)pair * t_stride);
+    uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
+    if (q < nq) { a0 = Qp[2 * q]; a1 = Qp[2 * q + 1]; }
+    int best = init, second = init, idx = -1;
+    const int t_begin = split * chunk, t_end = min(nt, t_begin + chunk);
+    for (int t0 = t_begin; t0 < t_end; t0 += KNN_TILE) {
+        const int m = min(KNN_TILE, t_end - t0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * m; i += 256) st[i] = Tp[2 * t0 + i];
+        __syncthreads();
+        for (int t = 0; t < m; t++) {
+            const int d = hamming256(a0, a1, st[2 * t], st[2 * t + 1]);
+            if (d < best) { second = best; best = d; idx = t0 + t; }
+            else if (d < second) second = d;
+        }
+    }
+    if (q < nq) {
+        const size_t o = ((size_t)pair * nsplit + split) * max_nq + q;
+        best_idx[o] = idx; best_dist[o] = best; second_dist[o] = second;
+    }
+}
+
+// Merge the per-split partials in ascending split order (earlier candidates win ties, as in the serial loop).
+__global__ void k_knn2_merge(const int32_t* __restrict__ pidx, const int32_t* __restrict__ pbest,
+                             const int32_t* __restrict__ psecond, int nsplit, int max_nq,
+                             const int32_t* __restrict__ nq_arr, int32_t* __restrict__ best_idx,
+                             int32_t* __restrict__ best_dist, int32_t* __restrict__ second_dist)
+{
+    const int pair = blockIdx.y;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nq = nq_arr ? nq_arr[pair] : max_nq;
+    if (q >= nq) return;
+    int best = INT_MAX, second = INT_MAX, idx = -1;
+    for (int s = 0; s < nsplit; s++) {
+        const size_t o = ((size_t)pair * nsplit + s) * max_nq + q;
+        const int b = pbest[o], sc = psecond[o], i = pidx[o];
+        if (s == 0) { best = b; second = sc; idx = i; continue; }
+        if (b < best) { second = min(best, sc); best = b; idx = i; }
+        else second = min(second, b);
+    }
+    const size_t o = (size_t)pair * max_nq + q;
+    best_idx[o] = idx; best_dist[o] = best; second_dist[o] = second;
+}
+
+// ---------------------------------------------------------------------------- SearchForInitialization ----------
+#define GRID_COLS 64
+#define GRID_ROWS 48
+#define SFI_MAXC 512 // candidates examined per query in one go (wave-strided)
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned long long t = __shfl_xor(v, o);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+
+// One workgroup (256 threads) per frame pair p: F1 = frame p, F2 = frame p+1 of a stream.
+// Phase A builds F2's 64x48 grid in LDS (cell lists in keypoint-index order, like AssignFeaturesToGrid).
+// Phase B (parallel): for every level-0 keypoint of F1, the candidate list of GetFeaturesInArea with its Hamming
+//   distances goes to a CSR scratch in HBM, in the reference's candidate order (ix outer, iy inner, cell order).
+// Phase C (wave 0, serial over i1 as in the reference because vMatchedDistance couples the queries): best /
+//   second-best with the "already matched better" skip, ratio + TH_LOW tests, mutual-uniqueness bookkeeping,
+//   rotation histogram, ComputeThreeMaxima, final vbPrevMatched update.
+__global__ __launch_bounds__(256) void k_search_init(const orbfe_keypoint* __restrict__ kps,
+                                                     const uint8_t* __restrict__ desc, const int32_t* __restrict__ nkp,
+                                                     int capacity, int cols, int rows, float window, float nnratio,
+                                                     int check_ori, const float* __restrict__ prev_in,
+                                                     float* __restrict__ prev_out, int32_t* __restrict__ matches12,
+                                                     int32_t* __restrict__ nmatches_out, int32_t* __restrict__ csr_off,
+                                                     int32_t* __restrict__ csr_idx, uint8_t* __restrict__ csr_dist,
+                                                     int csr_cap, int32_t* __restrict__ scratch /*3*capacity per pair*/,
+                                                     int32_t* __restrict__ overflow)
+{
+    __shared__ int s_cnt[GRID_COLS * GRID_ROWS];
+    __shared__ int s_off[GRID_COLS * GRID_ROWS + 1];
+    __shared__ int s_scan[256];
+    __shared__ int s_hist[30];
+    __shared__ int s_total;
+    extern __shared__ short s_cellidx[]; // capacity entries: F2 keypoint indices sorted by cell (stable)
+
+    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const orbfe_keypoint* k1 = kps + (size_t)p * capacity;
+    const orbfe_keypoint* k2 = kps + (size_t)(p + 1) * capacity;
+    const uint8_t* d1 = desc + (size_t)p * capacity * 32;
+    const uint8_t* d2 = desc + (size_t)(p + 1) * capacity * 32;
+    const int n1 = nkp[p], n2 = nkp[p + 1];
+    int32_t* m12 = matches12 + (size_t)p * capacity;
+    int32_t* coff = csr_off + (size_t)p * (capacity + 1);
+    int32_t* cidx = csr_idx + (size_t)p * csr_cap;
+    uint8_t* cdist = csr_dist + (size_t)p * csr_cap;
+    int32_t* vMatchedDistance = scratch + (size_t)p * 3 * capacity;
+    int32_t* vnMatches21 = vMatchedDistance + capacity;
+    int32_t* rotbin = vnMatches21 + capacity; // per i1: histogram bin or -1
+    const float* prev = prev_in ? prev_in + (size_t)p * capacity * 2 : nullptr;
+    float* prevo = prev_out ? prev_out + (size_t)p * capacity * 2 : nullptr;
+
+    const float mnMinX = 0.f, mnMinY = 0.f;
+    const float invW = __fdiv_rn((float)GRID_COLS, (float)cols - mnMinX);
+    const float invH = __fdiv_rn((float)GRID_ROWS, (float)rows - mnMinY);
+
+    // ---- phase A: grid of F2 (Frame.cc:183-198, :335-345)
+    for (int i = tid; i < GRID_COLS * GRID_ROWS; i += 256) s_cnt[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < n2; i += 256) {
+        const int px = (int)roundf(__fmul_rn(k2[i].x - mnMinX, invW));
+        const int py = (int)roundf(__fmul_rn(k2[i].y - mnMinY, invH));
+        if (px >= 0 && px < GRID_COLS && py >= 0 && py < GRID_ROWS) atomicAdd(&s_cnt[px * GRID_ROWS + py], 1);
+    }
+    __syncthreads();
+    { // exclusive scan of 3072 counts: 12 per thread
+        int loc[12], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 12; k++) { loc[k] = s_cnt[tid * 12 + k]; sum += loc[k]; }
+        s_scan[tid] = sum;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            int t = tid >= o ? s_scan[tid - o] : 0;
+            __syncthreads();
+            s_scan[tid] += t;
+            __syncthreads();
+        }
+        int base = s_scan[tid] - sum;
+#pragma unroll
+        for (int k = 0; k < 12; k++) { s_off[tid * 12 + k] = base; base += loc[k]; }
+        if (tid == 255) s_off[GRID_COLS * GRID_ROWS] = base;
+    }
+    __syncthreads();
+    for (int i = tid; i < GRID_COLS * GRID_ROWS; i += 256) s_cnt[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < n2; i += 256) {
+        const int px = (int)roundf(__fmul_rn(k2[i].x - mnMinX, invW));
+        const int py = (int)roundf(__fmul_rn(k2[i].y - mnMinY, invH));
+        if (px >= 0 && px < GRID_COLS && py >= 0 && py < GRID_ROWS) {
+            const int c = px * GRID_ROWS + py;
+            s_cellidx[s_off[c] + atomicAdd(&s_cnt[c], 1)] = (short)i;
+        }
+    }
+    __syncthreads();
+    // restore keypoint-index order inside each cell (push_back order of AssignFeaturesToGrid)
+    for (int c = tid; c < GRID_COLS * GRID_ROWS; c += 256) {
+        const int b = s_off[c], e = s_off[c + 1];
+        for (int i = b + 1; i < e; i++) {
+            const short v = s_cellidx[i];
+            int j = i - 1;
+            while (j >= b && s_cellidx[j] > v) { s_cellidx[j + 1] = s_cellidx[j]; j--; }
+            s_cellidx[j + 1] = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase B: candidate lists (Frame.cc:280-333) + distances.  One wave per query, lanes over cells' entries.
+    // pass 1 counts, pass 2 writes; counts are scanned by wave 0 in between.
+    for (int pass = 0; pass < 2; pass++) {
+        for (int i1 = wid; i1 < n1; i1 += 4) {
+            int count = 0;
+            const orbfe_keypoint kp1 = k1[i1];
+            if (kp1.octave <= 0) {
+                const float x = prev ? prev[2 * i1] : kp1.x, y = prev ? prev[2 * i1 + 1] : kp1.y;
+                const float r = window;
+                const int nMinCellX = max(0, (int)floorf(__fmul_rn(x - mnMinX - r, invW)));
+                const int nMaxCellX = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(x - mnMinX + r, invW)));
+                const int nMinCellY = max(0, (int)floorf(__fmul_rn(y - mnMinY - r, invH)));
+                const int nMaxCellY = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(y - mnMinY + r, invH)));
+                if (!(nMinCellX >= GRID_COLS || nMaxCellX < 0 || nMinCellY >= GRID_ROWS || nMaxCellY < 0)) {
+                    uint4 a0, a1;
+                    a0 = reinterpret_cast<const uint4*>(d1)[2 * i1];
+                    a1 = reinterpret_cast<const uint4*>(d1)[2 * i1 + 1];
+                    const int wbase = pass ? coff[i1] : 0;
+                    for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
+                        // cells (ix, nMinCellY..nMaxCellY) are contiguous in the sorted index array
+                        const int b = s_off[ix * GRID_ROWS + nMinCellY], e = s_off[ix * GRID_ROWS + nMaxCellY + 1];
+                        for (int j0 = b; j0 < e; j0 += 64) {
+                            const int j = j0 + lane;
+                            bool ok = false;
+                            int i2 = 0;
+                            if (j < e) {
+                                i2 = s_cellidx[j];
+                                const orbfe_keypoint kp2 = k2[i2];
+                                // bCheckLevels is true for (minLevel, maxLevel) = (0, 0)
+                                ok = !(kp2.octave < 0) && !(kp2.octave > 0) && fabsf(kp2.x - x) < r &&
+                                     fabsf(kp2.y - y) < r;
+                            }
+                            const unsigned long long m = __ballot(ok);
+                            if (pass && ok) {
+                                const int pos = wbase + count +
+                                                __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                                                          __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                                if (pos < csr_cap) {
+                                    const uint4 b0 = reinterpret_cast<const uint4*>(d2)[2 * i2];
+                                    const uint4 b1 = reinterpret_cast<const uint4*>(d2)[2 * i2 + 1];
+                                    cidx[pos] = i2;
+                                    const int d = hamming256(a0, a1, b0, b1);
+                                    cdist[pos] = (uint8_t)(d > 255 ? 255 : d); // 256 only for exact complements; > TH_LOW anyway
+                                }
+                            }
+                            count += __popcll(m);
+                        }
+                    }
+                }
+            }
+            if (!pass && lane == 0) coff[i1 + 1] = count; // counts first, scanned below
+        }
+        __syncthreads();
+        if (!pass) {
+            if (wid == 0) {
+                int run = 0;
+                if (lane == 0) coff[0] = 0;
+                for (int i0 = 0; i0 < n1; i0 += 64) {
+                    const int i = i0 + lane;
+                    int c = i < n1 ? coff[i + 1] : 0;
+                    int incl = c;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        int t = __shfl_up(incl, o);
+                        if (lane >= o) incl += t;
+                    }
+                    if (i < n1) coff[i + 1] = run + incl;
+                    run += __shfl(incl, 63);
+                }
+                if (lane == 0) {
+                    s_total = run;
+                    if (run > csr_cap) atomicMax(overflow, run);
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < n2; i += 256) { vMatchedDistance[i] = INT_MAX; vnMatches21[i] = -1; }
+    for (int i = tid; i < n1; i += 256) { m12[i] = -1; rotbin[i] = -1; }
+    if (tid < 30) s_hist[tid] = 0;
+    __threadfence_block();
+    __syncthreads();
+    if (wid != 0) return;
+
+    // ---- phase C: the serial matching loop (ORBmatcher.cc:423-490), wave 0
+    int nmatches = 0;
+    const float factor = 1.0f / 30; // HISTO_LENGTH; the upstream "1/30" quirk is kept (App. D)
+    for (int i1 = 0; i1 < n1; i1++) {
+        const int b = coff[i1], e = min(coff[i1 + 1], csr_cap);
+        if (e <= b) continue;
+        // best = first minimum among candidates with vMatchedDistance[i2] > dist; second = next smallest
+        unsigned long long bestk = ~0ull, secondk = ~0ull;
+        for (int j0 = b; j0 < e; j0 += 64) {
+            const int j = j0 + lane;
+            unsigned long long key = ~0ull;
+            if (j < e) {
+                const int i2 = cidx[j], d = cdist[j];
+                if (!(vMatchedDistance[i2] <= d)) key = ((unsigned long long)d << 32) | (unsigned)(j - b);
+            }
+            const unsigned long long m1 = wave_min_u64(key);
+            const unsigned long long k2nd = wave_min_u64(key == m1 ? ~0ull : key);
+            // merge (m1, k2nd) into (bestk, secondk); earlier chunks hold earlier candidates
+            if (m1 < bestk) { secondk = min(bestk, k2nd); bestk = m1; }
+            else secondk = min(secondk, m1);
+        }
+        if (bestk == ~0ull) continue;
+        const int bestDist = (int)(bestk >> 32);
+        const int bestDist2 = secondk == ~0ull ? INT_MAX : (int)(secondk >> 32);
+        const int bestIdx2 = cidx[b + (int)(bestk & 0xffffffffu)];
+        if (bestDist <= 50) { // TH_LOW
+            if ((float)bestDist < __fmul_rn((float)bestDist2, nnratio)) {
+                const int old = vnMatches21[bestIdx2];
+                if (old >= 0) {
+                    if (lane == 0) m12[old] = -1;
+                    nmatches--;
+                }
+                if (lane == 0) {
+                    m12[i1] = bestIdx2;
+                    vnMatches21[bestIdx2] = i1;
+                    vMatchedDistance[bestIdx2] = bestDist;
+                }
+                nmatches++;
+                if (check_ori) {
+                    float rot = k1[i1].angle - k2[bestIdx2].angle;
+                    if (rot < 0.0f) rot += 360.0f;
+                    int bin = (int)roundf(__fmul_rn(rot, factor));
+                    if (bin == 30) bin = 0;
+                    if (lane == 0) rotbin[i1] = bin; // rotHist[bin].push_back(i1): entries stay even if un-matched later
+                }
+                __threadfence_block();
+            }
+        }
+    }
+    __threadfence_block();
+    if (check_ori) {
+        // histogram sizes count every push_back, including i1 whose match was later stolen (as in the reference)
+        for (int i = lane; i < n1; i += 64)
+            if (rotbin[i] >= 0) atomicAdd(&s_hist[rotbin[i]], 1);
+        __threadfence_block();
+        int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+        for (int i = 0; i < 30; i++) { // ComputeThreeMaxima, ORBmatcher.cc:1605-1646
+            const int s = s_hist[i];
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+            else if (s > max3) { max3 = s; ind3 = i; }
+        }
+        if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+        int removed = 0;
+        for (int i0 = 0; i0 < n1; i0 += 64) {
+            const int i = i0 + lane;
+            bool rm = false;
+            if (i < n1) {
+                const int bin = rotbin[i];
+                rm = bin >= 0 && bin != ind1 && bin != ind2 && bin != ind3 && m12[i] >= 0;
+                if (rm) m12[i] = -1;
+            }
+            removed += __popcll(__ballot(rm));
+        }
+        nmatches -= removed;
+    }
+    __threadfence_block();
+    if (prevo)
+        for (int i = lane; i < n1; i += 64) {
+            float x = prev ? prev[2 * i] : k1[i].x, y = prev ? prev[2 * i + 1] : k1[i].y;
+            const int m = m12[i];
+            if (m >= 0) { x = k2[m].x; y = k2[m].y; }
+            prevo[2 * i] = x;
+            prevo[2 * i + 1] = y;
+        }
+    if (lane == 0) nmatches_out[p] = nmatches;
+}
+
+struct MatchWorkspace {
+    DevBuf pidx, pbest, psecond, csr_off, csr_idx, csr_dist, scratch, overflow, prev;
+    DevBuf q, t, nq, nt, oidx, obest, osecond, kps, desc, nk, m12, nm;
+    int csr_per_pair = 0; // CSR slots per frame pair (grown by the host wrapper on overflow)
+};
+static thread_local MatchWorkspace* tl_ws = nullptr;
+static MatchWorkspace& ws()
+{
+    if (!tl_ws) tl_ws = new MatchWorkspace();
+    return *tl_ws;
+}
+
+static int knn2_launch(const uint8_t* d_Q, const int32_t* d_nq, size_t q_stride, int max_nq, const uint8_t* d_T,
+                       const int32_t* d_nt, size_t t_stride, int max_nt, int npairs, int init, int32_t* d_best_idx,
+                       int32_t* d_best_dist, int32_t* d_second_dist, hipStream_t s)
+{
+    // split the train set when there are too few (query-tile, pair) workgroups to fill 256 CUs
+    const int qtiles = (max_nq + 255) / 256;
+    int nsplit = 1;
+    const long long wgs = (long long)qtiles * npairs;
+    if (wgs < 1024) {
+        nsplit = (int)std::min<long long>((1024 + wgs - 1) / wgs, (max_nt + KNN_TILE - 1) / KNN_TILE);
+        if (nsplit < 1) nsplit = 1;
+    }
+    int chunk = (max_nt + nsplit - 1) / nsplit;
+    chunk = std::max(KNN_TILE, (chunk + KNN_TILE - 1) / KNN_TILE * KNN_TILE);
+    nsplit = std::max(1, (max_nt + chunk - 1) / chunk);
+    if (nsplit == 1) {
+        hipLaunchKernelGGL(k_knn2_tiles, dim3(qtiles, npairs, 1), dim3(256), 0, s, d_Q, d_nq, q_stride, max_nq, d_T,
+                           d_nt, t_stride, chunk, init, d_best_idx, d_best_dist, d_second_dist);
+    } else {
+        MatchWorkspace& w = ws();
+        const size_t nb = (size_t)npairs * nsplit * max_nq * 4;
+        int rc;
+        if ((rc = w.pidx.ensure(nb)) || (rc = w.pbest.ensure(nb)) || (rc = w.psecond.ensure(nb))) return rc;
+        hipLaunchKernelGGL(k_knn2_tiles, dim3(qtiles, npairs, nsplit), dim3(256), 0, s, d_Q, d_nq, q_stride, max_nq,
+                           d_T, d_nt, t_stride, chunk, init, w.pidx.as<int32_t>(), w.pbest.as<int32_t>(),
+                           w.psecond.as<int32_t>());
+        hipLaunchKernelGGL(k_knn2_merge, dim3(qtiles, npairs), dim3(256), 0, s, w.pidx.as<int32_t>(),
+                           w.pbest.as<int32_t>(), w.psecond.as<int32_t>(), nsplit, max_nq, d_nq, d_best_idx,
+                           d_best_dist, d_second_dist);
+    }
+    ORBFE_HIP(hipGetLastError());
+    return ORBFE_OK;
+}
+
+static int sfi_launch(const orbfe_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n, int capacity, int npairs,
+                      int cols, int rows, int window, float nnratio, int check_ori, const float* d_prev_in,
+                      float* d_prev_out, int32_t* d_m12, int32_t* d_nm, hipStream_t s)
+{
+    if (capacity > 32767) return fail(ORBFE_ERR_INVALID, "capacity above 32767 keypoints per frame is unsupported");
+    MatchWorkspace& w = ws();
+    // CSR capacity: level-0 queries x their window candidates; the host wrapper grows it on overflow
+    const int want = std::max(w.csr_per_pair, capacity * 64);
+    w.csr_per_pair = want;
+    int rc;
+    if ((rc = w.csr_off.ensure((size_t)npairs * (capacity + 1) * 4)) || (rc = w.csr_idx.ensure((size_t)npairs * want * 4)) ||
+        (rc = w.csr_dist.ensure((size_t)npairs * want)) || (rc = w.scratch.ensure((size_t)npairs * 3 * capacity * 4)) ||
+        (rc = w.overflow.ensure(16)))
+        return rc;
+    ORBFE_HIP(hipMemsetAsync(w.overflow.p, 0, 4, s));
+    const size_t lds = (size_t)capacity * 2 + 16;
+    hipLaunchKernelGGL(k_search_init, dim3(npairs), dim3(256), lds, s, d_kps, d_desc, d_n, capacity, cols, rows,
+                       (float)window, nnratio, check_ori, d_prev_in, d_prev_out, d_m12, d_nm, w.csr_off.as<int32_t>(),
+                       w.csr_idx.as<int32_t>(), w.csr_dist.as<uint8_t>(), want, w.scratch.as<int32_t>(),
+                       w.overflow.as<int32_t>());
+    ORBFE_HIP(hipGetLastError());
+    return ORBFE_OK;
+}
+
+} // namespace orbfe
+
+using namespace orbfe;
+
+extern "C" {
+
+int orbfe_hamming(const uint8_t* a, const uint8_t* b)
+{
+    // host-side scalar helper with the reference's exact formulation (ORBmatcher.cc:1651-1667)
+    const int32_t* pa = (const int32_t*)a;
+    const int32_t* pb = (const int32_t*)b;
+    int dist = 0;
+    for (int i = 0; i < 8; i++, pa++, pb++) {
+        unsigned int v = *pa ^ *pb;
+        v = v - ((v >> 1) & 0x55555555);
+        v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+        dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+    }
+    return dist;
+}
+
+int orbfe_knn2_batch_device(const uint8_t* d_Q, const int32_t* d_nq, size_t q_stride, int max_nq, const uint8_t* d_T,
+                            const int32_t* d_nt, size_t t_stride, int max_nt, int npairs, int init,
+                            int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second_dist, void* stream)
+{
+    if (!d_Q || !d_T || !d_nt || !d_best_idx || !d_best_dist || !d_second_dist || max_nq <= 0 || max_nt < 0 ||
+        npairs <= 0)
+        return fail(ORBFE_ERR_INVALID, "orbfe_knn2_batch_device: invalid argument");
+    return knn2_launch(d_Q, d_nq, q_stride, max_nq, d_T, d_nt, t_stride, max_nt, npairs, init, d_best_idx,
+                       d_best_dist, d_second_dist, (hipStream_t)stream);
+}
+
+int orbfe_knn2(const uint8_t* Q, int nq, const uint8_t* T, int nt, int init, int32_t* best_idx, int32_t* best_dist,
+               int32_t* second_dist, int device)
+{
+    if (nq < 0 || nt < 0 || (nq && (!Q || !best_idx || !best_dist || !second_dist)) || (nt && !T))
+        return fail(ORBFE_ERR_INVALID, "orbfe_knn2: invalid argument");
+    int rc = use_device(device);
+    if (rc) return rc;
+    if (nq == 0) return ORBFE_OK;
+    MatchWorkspace& w = ws();
+    if ((rc = w.q.ensure((size_t)nq * 32)) || (rc = w.t.ensure((size_t)std::max(nt, 1) * 32)) ||
+        (rc = w.nt.ensure(16)) || (rc = w.oidx.ensure((size_t)nq * 4)) || (rc = w.obest.ensure((size_t)nq * 4)) ||
+        (rc = w.osecond.ensure((size_t)nq * 4)))
+        return rc;
+    ORBFE_HIP(hipMemcpy(w.q.p, Q, (size_t)nq * 32, hipMemcpyHostToDevice));
+    if (nt) ORBFE_HIP(hipMemcpy(w.t.p, T, (size_t)nt * 32, hipMemcpyHostToDevice));
+    ORBFE_HIP(hipMemcpy(w.nt.p, &nt, 4, hipMemcpyHostToDevice));
+    rc = knn2_launch(w.q.as<uint8_t>(), nullptr, 0, nq, w.t.as<uint8_t>(), w.nt.as<int32_t>(), 0, nt, 1, init,
+                     w.oidx.as<int32_t>(), w.obest.as<int32_t>(), w.osecond.as<int32_t>(), nullptr);
+    if (rc) return rc;
+    ORBFE_HIP(hipDeviceSynchronize());
+    ORBFE_HIP(hipMemcpy(best_idx, w.oidx.p, (size_t)nq * 4, hipMemcpyDeviceToHost));
+    ORBFE_HIP(hipMemcpy(best_dist, w.obest.p, (size_t)nq * 4, hipMemcpyDeviceToHost));
+    ORBFE_HIP(hipMemcpy(second_dist, w.osecond.p, (size_t)nq * 4, hipMemcpyDeviceToHost));
+    return ORBFE_OK;
+}
+
+int orbfe_search_for_initialization_batch_device(const orbfe_keypoint* d_kps, const uint8_t* d_desc,
+                                                 const int32_t* d_n, int capacity, int npairs, int cols, int rows,
+                                                 int window_size, float nnratio, int check_orientation,
+                                                 int32_t* d_matches12, int32_t* d_nmatches, void* stream)
+{
+    if (!d_kps || !d_desc || !d_n || !d_matches12 || !d_nmatches || capacity <= 0 || npairs <= 0 || cols <= 0 ||
+        rows <= 0)
+        return fail(ORBFE_ERR_INVALID, "orbfe_search_for_initialization_batch_device: invalid argument");
+    return sfi_launch(d_kps, d_desc, d_n, capacity, npairs, cols, rows, window_size, nnratio, check_orientation,
+                      nullptr, nullptr, d_matches12, d_nmatches, (hipStream_t)stream);
+}
+
+int orbfe_search_for_initialization(const orbfe_keypoint* kps1, const uint8_t* desc1, int n1,
+                                    const orbfe_keypoint* kps2, const uint8_t* desc2, int n2, int cols, int rows,
+                                    float* prev_matched, int32_t* matches12, int window_size, float nnratio,
+                                    int check_orientation, int32_t* nmatches, int device)
+{
+    if (n1 < 0 || n2 < 0 || !nmatches || (n1 && (!kps1 || !desc1 || !matches12 || !prev_matched)) ||
+        (n2 && (!kps2 || !desc2)) || cols <= 0 || rows <= 0)
+        return fail(ORBFE_ERR_INVALID, "orbfe_search_for_initialization: invalid argument");
+    int rc = use_device(device);
+    if (rc) return rc;
+    *nmatches = 0;
+    if (n1 == 0) return ORBFE_OK;
+    const int cap = std::max(std::max(n1, n2), 1);
+    MatchWorkspace& w = ws();
+    if ((rc = w.kps.ensure((size_t)2 * cap * sizeof(orbfe_keypoint))) || (rc = w.desc.ensure((size_t)2 * cap * 32)) ||
+        (rc = w.nk.ensure(16)) || (rc = w.m12.ensure((size_t)cap * 4)) || (rc = w.nm.ensure(16)) ||
+        (rc = w.prev.ensure((size_t)cap * 8)))
+        return rc;
+    ORBFE_HIP(hipMemcpy(w.kps.p, kps1, (size_t)n1 * sizeof(orbfe_keypoint), hipMemcpyHostToDevice));
+    ORBFE_HIP(hipMemcpy(w.desc.p, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice));
+    if (n2) {
+        ORBFE_HIP(hipMemcpy(w.kps.as<orbfe_keypoint>() + cap, kps2, (size_t)n2 * sizeof(orbfe_keypoint),
+                            hipMemcpyHostToDevice));
+        ORBFE_HIP(hipMemcpy(w.desc.as<uint8_t>() + (size_t)cap * 32, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice));
+    }
+    const int32_t nn[2] = {n1, n2};
+    ORBFE_HIP(hipMemcpy(w.nk.p, nn, 8, hipMemcpyHostToDevice));
+    for (int attempt = 0;; attempt++) {
+        // the device copy of prev_matched is only overwritten by a run that did not overflow
+        ORBFE_HIP(hipMemcpy(w.prev.p, prev_matched, (size_t)n1 * 8, hipMemcpyHostToDevice));
+        rc = sfi_launch(w.kps.as<orbfe_keypoint>(), w.desc.as<uint8_t>(), w.nk.as<int32_t>(), cap, 1, cols, rows,
+                        window_size, nnratio, check_orientation, w.prev.as<float>(), w.prev.as<float>(),
+                        w.m12.as<int32_t>(), w.nm.as<int32_t>(), nullptr);
+        if (rc) return rc;
+        ORBFE_HIP(hipDeviceSynchronize());
+        int32_t ovf = 0;
+        ORBFE_HIP(hipMemcpy(&ovf, w.overflow.p, 4, hipMemcpyDeviceToHost));
+        if (!ovf) break;
+        if (attempt) return fail(ORBFE_ERR_CAPACITY, "candidate list overflow (%d)", ovf);
+        w.csr_per_pair = ovf + 64;
+    }
+    ORBFE_HIP(hipMemcpy(matches12, w.m12.p, (size_t)n1 * 4, hipMemcpyDeviceToHost));
+    ORBFE_HIP(hipMemcpy(prev_matched, w.prev.p, (size_t)n1 * 8, hipMemcpyDeviceToHost));
+    ORBFE_HIP(hipMemcpy(nmatches, w.nm.p, 4, hipMemcpyDeviceToHost));
+    return ORBFE_OK;
+}
+
+} // extern "C"
