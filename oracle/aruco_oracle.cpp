@@ -1,0 +1,858 @@
+/*
+ * aruco_oracle.cpp -- CPU restatement of the reference ArUco detector as configured by
+ * src/Frame.cc:129-142 (dictionary by name, DM_NORMAL, CORNER_LINES).  TEST INFRASTRUCTURE ONLY.
+ *
+ * PARITY UNPINNED for the OpenCV primitives (adaptiveThreshold, findContours, approxPolyDP,
+ * getPerspectiveTransform/warpPerspective, threshold(OTSU), solve(SVD)): the reference ships no
+ * tests and OpenCV 3.4 is not available here, so these follow the OpenCV 3.4 generic code paths
+ * from knowledge of that source.  The detector logic itself follows the
+ * de-obfuscated Thirdparty/aruco/aruco/markerdetector_impl.cpp and dictionary_based.cpp
+ * (recipe in SURVEY.md App. C); cites use the line numbers of the shipped (obfuscated) files.
+ *
+ * Deliberate, documented deviations (also in DESIGN.md):
+ *  - getPerspectiveTransform / the line fits use double-precision Gaussian elimination / normal
+ *    equations where OpenCV 3.4 calls solve(DECOMP_SVD); results agree to ~1e-6 relative.
+ *  - pose (Marker::calculateExtrinsics, step 12 of App. C) is out of scope.
+ */
+#include <algorithm>
+#include <cfloat>
+#include <climits>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../include/orbfe_math.h"
+#include "../orb_slam2_aruco_amd/csrc/orbfe_tables.inc"
+
+namespace {
+
+struct Image {
+    int w = 0, h = 0;
+    std::vector<uint8_t> d;
+    Image() {}
+    Image(int w_, int h_) : w(w_), h(h_), d((size_t)w_ * h_) {}
+    uint8_t* row(int y) { return d.data() + (size_t)y * w; }
+    const uint8_t* row(int y) const { return d.data() + (size_t)y * w; }
+};
+struct Pt { int x, y; };
+struct Ptf { float x, y; };
+
+struct Candidate {
+    Ptf c[4];
+    std::vector<Pt> contour;
+    int id = -1;
+};
+
+/* ------------------------------------------------------- adaptiveThreshold -- */
+/* cv::adaptiveThreshold(src, dst, 255, ADAPTIVE_THRESH_MEAN_C, THRESH_BINARY_INV, win, C)
+ * (markerdetector_impl.cpp:2983): normalized box mean with BORDER_REPLICATE, mean rounded to
+ * nearest, dst = 255 where src - mean <= -floor(C). */
+void adaptive_threshold_inv(const Image& src, Image& dst, int win, int C)
+{
+    const int w = src.w, h = src.h, r = win / 2;
+    dst = Image(w, h);
+    const double scale = 1.0 / (win * win);
+    std::vector<int> colsum(w);
+    std::vector<int> rowsum((size_t)w * h);
+    for (int y = 0; y < h; y++) {
+        const uint8_t* S = src.row(y);
+        for (int x = 0; x < w; x++) {
+            int s = 0;
+            for (int k = -r; k <= r; k++) s += S[std::min(std::max(x + k, 0), w - 1)];
+            rowsum[(size_t)y * w + x] = s;
+        }
+    }
+    for (int y = 0; y < h; y++) {
+        const uint8_t* S = src.row(y);
+        uint8_t* D = dst.row(y);
+        for (int x = 0; x < w; x++) {
+            int s = 0;
+            for (int k = -r; k <= r; k++) s += rowsum[(size_t)std::min(std::max(y + k, 0), h - 1) * w + x];
+            int mean = orbfe_round_d(s * scale);
+            if (mean > 255) mean = 255;
+            D[x] = (S[x] - mean <= -C) ? 255 : 0;
+        }
+    }
+}
+
+/* ---------------------------------------------------------- findContours -- */
+/* cv::findContours(img, contours, RETR_LIST, CHAIN_APPROX_NONE) (markerdetector_impl.cpp:3104),
+ * OpenCV 3.4: the image is copied into a zero-padded buffer (offset -1,-1), binarised to 0/1,
+ * scanned in raster order (cvFindNextContour) and every border is followed by icvFetchContour
+ * with nbd = 2.  The output order is the REVERSE of discovery (cvInsertNodeIntoTree prepends). */
+void find_contours_list(const Image& img, std::vector<std::vector<Pt>>& out)
+{
+    const int W = img.w + 2, H = img.h + 2;
+    std::vector<signed char> buf((size_t)W * H, 0);
+    for (int y = 0; y < img.h; y++)
+        for (int x = 0; x < img.w; x++) buf[(size_t)(y + 1) * W + (x + 1)] = img.row(y)[x] ? 1 : 0;
+    const int step = W;
+    const int deltas[16] = {1, -step + 1, -step, -step - 1, -1, step - 1, step, step + 1,
+                            1, -step + 1, -step, -step - 1, -1, step - 1, step, step + 1};
+    static const int cdx[8] = {1, 1, 0, -1, -1, -1, 0, 1}, cdy[8] = {0, -1, -1, -1, 0, 1, 1, 1};
+    std::vector<std::vector<Pt>> found;
+    for (int y = 1; y < H - 1; y++) {
+        signed char* row = buf.data() + (size_t)y * W;
+        int prev = 0;
+        for (int x = 1; x < W - 1; x++) {
+            int p = row[x];
+            if (p == prev) continue;
+            int is_hole = 0;
+            bool trace = false;
+            if (prev == 0 && p == 1) trace = true;
+            else if (p == 0 && prev >= 1) { is_hole = 1; trace = true; }
+            if (trace) {
+                std::vector<Pt> c;
+                signed char* i0 = row + x - is_hole;
+                Pt pt{x - is_hole - 1, y - 1}; /* offset (-1,-1): back to image coordinates */
+                const signed char nbd = 2;
+                int s_end, s;
+                s_end = s = is_hole ? 0 : 4;
+                signed char* i1;
+                do {
+                    s = (s - 1) & 7;
+                    i1 = i0 + deltas[s];
+                } while (*i1 == 0 && s != s_end);
+                if (s == s_end) { /* single pixel domain */
+                    *i0 = (signed char)(nbd | -128);
+                    c.push_back(pt);
+                } else {
+                    signed char* i3 = i0;
+                    signed char* i4 = nullptr;
+                    for (;;) {
+                        s_end = s;
+                        while (s < 15) {
+                            i4 = i3 + deltas[++s];
+                            if (*i4 != 0) break;
+                        }
+                        s &= 7;
+                        if ((unsigned)(s - 1) < (unsigned)s_end) *i3 = (signed char)(nbd | -128);
+                        else if (*i3 == 1) *i3 = nbd;
+                        c.push_back(pt);
+                        pt.x += cdx[s];
+                        pt.y += cdy[s];
+                        if (i4 == i0 && i3 == i1) break;
+                        i3 = i4;
+                        s = (s + 4) & 7;
+                    }
+                }
+                found.push_back(std::move(c));
+                p = row[x];
+            }
+            prev = p;
+        }
+    }
+    out.assign(found.rbegin(), found.rend());
+}
+
+/* ---------------------------------------------------------- approxPolyDP -- */
+/* cv::approxPolyDP(contour, out, eps, closed=true) for integer points (approx.cpp approxPolyDP_<int>,
+ * OpenCV 3.4.2+ incl. the successive-inner-product guard in the clean-up pass). */
+int approx_poly_dp_closed(const std::vector<Pt>& src, double eps, std::vector<Pt>& dst)
+{
+    const int count = (int)src.size();
+    dst.clear();
+    if (count == 0) return 0;
+    struct Range { int start, end; };
+    std::vector<Range> stack;
+    std::vector<Pt> out;
+    Range slice{0, 0}, right_slice{0, 0};
+    Pt start_pt{-1000000, -1000000}, end_pt{0, 0}, pt{0, 0};
+    int pos = 0;
+    bool le_eps = false;
+    eps *= eps;
+    auto read_pt = [&](Pt& p, int& ps) { p = src[ps]; if (++ps >= count) ps = 0; };
+    right_slice.start = 0;
+    for (int i = 0; i < 3; i++) {
+        double max_dist = 0;
+        pos = (pos + right_slice.start) % count;
+        read_pt(start_pt, pos);
+        for (int j = 1; j < count; j++) {
+            read_pt(pt, pos);
+            double dx = pt.x - start_pt.x, dy = pt.y - start_pt.y;
+            double dist = dx * dx + dy * dy;
+            if (dist > max_dist) { max_dist = dist; right_slice.start = j; }
+        }
+        le_eps = max_dist <= eps;
+    }
+    if (!le_eps) {
+        right_slice.end = slice.start = pos % count;
+        slice.end = right_slice.start = (right_slice.start + slice.start) % count;
+        stack.push_back(right_slice);
+        stack.push_back(slice);
+    } else out.push_back(start_pt);
+    while (!stack.empty()) {
+        slice = stack.back();
+        stack.pop_back();
+        end_pt = src[slice.end];
+        pos = slice.start;
+        read_pt(start_pt, pos);
+        if (pos != slice.end) {
+            double max_dist = 0;
+            double dx = end_pt.x - start_pt.x, dy = end_pt.y - start_pt.y;
+            while (pos != slice.end) {
+                read_pt(pt, pos);
+                double dist = std::fabs((pt.y - start_pt.y) * dx - (pt.x - start_pt.x) * dy);
+                if (dist > max_dist) { max_dist = dist; right_slice.start = (pos + count - 1) % count; }
+            }
+            le_eps = max_dist * max_dist <= eps * (dx * dx + dy * dy);
+        } else {
+            le_eps = true;
+            start_pt = src[slice.start];
+        }
+        if (le_eps) out.push_back(start_pt);
+        else {
+            right_slice.end = slice.end;
+            slice.end = right_slice.start;
+            stack.push_back(right_slice);
+            stack.push_back(slice);
+        }
+    }
+    /* clean-up pass */
+    int new_count = (int)out.size();
+    const int cnt = new_count;
+    auto read_dst = [&](Pt& p, int& ps) { p = out[ps]; if (++ps >= cnt) ps = 0; };
+    pos = cnt - 1;
+    read_dst(start_pt, pos);
+    int wpos = pos;
+    read_dst(pt, pos);
+    for (int i = 0; i < cnt && new_count > 2; i++) {
+        read_dst(end_pt, pos);
+        double dx = end_pt.x - start_pt.x, dy = end_pt.y - start_pt.y;
+        double dist = std::fabs((pt.x - start_pt.x) * dy - (pt.y - start_pt.y) * dx);
+        double sip = (double)(pt.x - start_pt.x) * (end_pt.x - pt.x) + (double)(pt.y - start_pt.y) * (end_pt.y - pt.y);
+        if (dist * dist <= 0.5 * eps * (dx * dx + dy * dy) && dx != 0 && dy != 0 && sip >= 0) {
+            new_count--;
+            out[wpos] = start_pt = end_pt;
+            if (++wpos >= cnt) wpos = 0;
+            read_dst(pt, pos);
+            i++;
+            continue;
+        }
+        out[wpos] = start_pt = pt;
+        if (++wpos >= cnt) wpos = 0;
+        pt = end_pt;
+    }
+    dst.assign(out.begin(), out.begin() + new_count);
+    return new_count;
+}
+
+/* cv::isContourConvex for integer points (convhull.cpp isContourConvex_<int>) */
+bool is_contour_convex(const Pt* p, int n)
+{
+    Pt prev_pt = p[(n - 2 + n) % n], cur_pt = p[n - 1];
+    int dx0 = cur_pt.x - prev_pt.x, dy0 = cur_pt.y - prev_pt.y, orientation = 0;
+    for (int i = 0; i < n; i++) {
+        prev_pt = cur_pt;
+        cur_pt = p[i];
+        int dx = cur_pt.x - prev_pt.x, dy = cur_pt.y - prev_pt.y;
+        int dxdy0 = dx * dy0, dydx0 = dy * dx0;
+        orientation |= (dydx0 > dxdy0) ? 1 : ((dydx0 < dxdy0) ? 2 : 3);
+        if (orientation == 3) return false;
+        dx0 = dx;
+        dy0 = dy;
+    }
+    return true;
+}
+
+/* -------------------------------------------------------- warpPerspective -- */
+/* getPerspectiveTransform(src quad -> (0,0),(S-1,0),(S-1,S-1),(0,S-1)) followed by
+ * warpPerspective(INTER_LINEAR, BORDER_CONSTANT 0) to S x S (markerdetector_impl.cpp:10844-11111).
+ * The 8x8 system is solved by Gaussian elimination with partial pivoting in double (OpenCV 3.4:
+ * solve(DECOMP_SVD)); the map is inverted with the closed-form 3x3 inverse; coordinates are rounded
+ * to 1/32 px and blended with the 15-bit bilinear table exactly like remapBilinear. */
+bool solve_linear(double* A, double* b, int n) /* in place, row-major n x n; returns false if singular */
+{
+    for (int c = 0; c < n; c++) {
+        int piv = c;
+        for (int r = c + 1; r < n; r++)
+            if (std::fabs(A[r * n + c]) > std::fabs(A[piv * n + c])) piv = r;
+        if (A[piv * n + c] == 0.0) return false;
+        if (piv != c) {
+            for (int k = 0; k < n; k++) std::swap(A[c * n + k], A[piv * n + k]);
+            std::swap(b[c], b[piv]);
+        }
+        for (int r = c + 1; r < n; r++) {
+            double f = A[r * n + c] / A[c * n + c];
+            if (f == 0.0) continue;
+            for (int k = c; k < n; k++) A[r * n + k] -= f * A[c * n + k];
+            b[r] -= f * b[c];
+        }
+    }
+    for (int r = n - 1; r >= 0; r--) {
+        double s = b[r];
+        for (int k = r + 1; k < n; k++) s -= A[r * n + k] * b[k];
+        b[r] = s / A[r * n + r];
+    }
+    return true;
+}
+
+bool perspective_inverse_map(const Ptf q[4], int S, double Minv[9])
+{
+    const float dstx[4] = {0.f, (float)(S - 1), (float)(S - 1), 0.f};
+    const float dsty[4] = {0.f, 0.f, (float)(S - 1), (float)(S - 1)};
+    double a[64], b[8];
+    memset(a, 0, sizeof(a));
+    for (int i = 0; i < 4; i++) {
+        a[i * 8 + 0] = a[(i + 4) * 8 + 3] = q[i].x;
+        a[i * 8 + 1] = a[(i + 4) * 8 + 4] = q[i].y;
+        a[i * 8 + 2] = a[(i + 4) * 8 + 5] = 1;
+        a[i * 8 + 6] = -(double)q[i].x * dstx[i];
+        a[i * 8 + 7] = -(double)q[i].y * dstx[i];
+        a[(i + 4) * 8 + 6] = -(double)q[i].x * dsty[i];
+        a[(i + 4) * 8 + 7] = -(double)q[i].y * dsty[i];
+        b[i] = dstx[i];
+        b[i + 4] = dsty[i];
+    }
+    if (!solve_linear(a, b, 8)) return false;
+    const double M[9] = {b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], 1.0};
+    /* 3x3 inverse (cv::invert on 3x3 uses the closed form with d = 1/det) */
+    double det = M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) +
+                 M[2] * (M[3] * M[7] - M[4] * M[6]);
+    if (det == 0.0) return false;
+    double d = 1.0 / det;
+    Minv[0] = (M[4] * M[8] - M[5] * M[7]) * d;
+    Minv[1] = (M[2] * M[7] - M[1] * M[8]) * d;
+    Minv[2] = (M[1] * M[5] - M[2] * M[4]) * d;
+    Minv[3] = (M[5] * M[6] - M[3] * M[8]) * d;
+    Minv[4] = (M[0] * M[8] - M[2] * M[6]) * d;
+    Minv[5] = (M[2] * M[3] - M[0] * M[5]) * d;
+    Minv[6] = (M[3] * M[7] - M[4] * M[6]) * d;
+    Minv[7] = (M[1] * M[6] - M[0] * M[7]) * d;
+    Minv[8] = (M[0] * M[4] - M[1] * M[3]) * d;
+    return true;
+}
+
+inline int sat_int(double v)
+{
+    if (v <= (double)INT_MIN) return INT_MIN;
+    if (v >= (double)INT_MAX) return INT_MAX;
+    return orbfe_round_d(v);
+}
+inline int sat_short(int v) { return v < -32768 ? -32768 : v > 32767 ? 32767 : v; }
+
+void warp_perspective(const Image& src, const double M[9], int S, uint8_t* dst)
+{
+    for (int y = 0; y < S; y++) {
+        const double X0 = M[0] * 0 + M[1] * y + M[2];
+        const double Y0 = M[3] * 0 + M[4] * y + M[5];
+        const double W0 = M[6] * 0 + M[7] * y + M[8];
+        for (int x = 0; x < S; x++) {
+            double Wd = W0 + M[6] * x;
+            Wd = Wd ? 32.0 / Wd : 0;
+            double fX = std::max((double)INT_MIN, std::min((double)INT_MAX, (X0 + M[0] * x) * Wd));
+            double fY = std::max((double)INT_MIN, std::min((double)INT_MAX, (Y0 + M[3] * x) * Wd));
+            int X = sat_int(fX), Y = sat_int(fY);
+            int sx = sat_short(X >> 5), sy = sat_short(Y >> 5);
+            int ax = X & 31, ay = Y & 31;
+            int w00 = (32 - ax) * (32 - ay) * 32, w01 = ax * (32 - ay) * 32, w10 = (32 - ax) * ay * 32, w11 = ax * ay * 32;
+            auto px = [&](int xx, int yy) -> int {
+                if (xx < 0 || yy < 0 || xx >= src.w || yy >= src.h) return 0;
+                return src.row(yy)[xx];
+            };
+            int v = px(sx, sy) * w00 + px(sx + 1, sy) * w01 + px(sx, sy + 1) * w10 + px(sx + 1, sy + 1) * w11;
+            v = (v + (1 << 14)) >> 15;
+            dst[y * S + x] = (uint8_t)(v > 255 ? 255 : v);
+        }
+    }
+}
+
+/* --------------------------------------------------------------- Otsu ---- */
+/* cv::threshold(..., THRESH_BINARY | THRESH_OTSU) threshold value (thresh.cpp getThreshVal_Otsu_8u) */
+int otsu_threshold(const uint8_t* p, int n)
+{
+    int h[256] = {0};
+    for (int i = 0; i < n; i++) h[p[i]]++;
+    double mu = 0, scale = 1. / n;
+    for (int i = 0; i < 256; i++) mu += i * (double)h[i];
+    mu *= scale;
+    double mu1 = 0, q1 = 0, max_sigma = 0, max_val = 0;
+    for (int i = 0; i < 256; i++) {
+        double p_i = h[i] * scale;
+        mu1 *= q1;
+        q1 += p_i;
+        double q2 = 1. - q1;
+        if (std::min(q1, q2) < FLT_EPSILON || std::max(q1, q2) > 1. - FLT_EPSILON) continue;
+        mu1 = (mu1 + i * p_i) / q1;
+        double mu2 = (mu - q1 * mu1) / q2;
+        double sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2);
+        if (sigma > max_sigma) { max_sigma = sigma; max_val = i; }
+    }
+    return (int)max_val;
+}
+
+/* ------------------------------------------------------------ dictionary -- */
+struct Dict {
+    std::string name;
+    int nbits = 0, n = 0;
+    const unsigned long long* codes = nullptr;
+    /* Dictionary::fromVector (dictionary.cpp:99-103): map.insert keeps the FIRST id of a duplicated code */
+    int lookup(unsigned long long c) const
+    {
+        for (int i = 0; i < n; i++)
+            if (codes[i] == c) return i;
+        return -1;
+    }
+};
+
+bool load_dict(const char* name, Dict& d)
+{
+    for (int i = 0; i < ORBFE_NDICTS; i++)
+        if (!strcmp(ORBFE_DICTS[i].name, name)) {
+            d.name = name;
+            d.nbits = ORBFE_DICTS[i].nbits;
+            d.n = ORBFE_DICTS[i].ncodes;
+            d.codes = ORBFE_DICTS[i].codes;
+            return true;
+        }
+    return false;
+}
+
+/* DictionaryBased::detect (dictionary_based.cpp:1059-1628) with getInnerCode (:1635-2322), touulong (:2372-2499),
+ * rotate (:2501-2645).  in: S x S gray patch.  Returns id or -1; nRot = number of rotations. */
+int decode_marker(const uint8_t* patch, int S, const Dict& dict, int* nRot)
+{
+    std::vector<uint8_t> bin((size_t)S * S);
+    const int th = otsu_threshold(patch, S * S);
+    for (int i = 0; i < S * S; i++) bin[i] = patch[i] > th ? 255 : 0;
+    const int nb = (int)std::sqrt((double)dict.nbits);
+    const int n = nb + 2;
+    std::vector<int> ones(n * n, 0), tot(n * n, 0);
+    for (int y = 0; y < S; y++) {
+        const int my = (int)(float(n) * float(y) / float(S));
+        for (int x = 0; x < S; x++) {
+            const int mx = (int)(float(n) * float(x) / float(S));
+            if (bin[y * S + x] > 125) ones[my * n + mx]++;
+            tot[my * n + mx]++;
+        }
+    }
+    std::vector<uint8_t> bits(n * n);
+    for (int i = 0; i < n * n; i++) bits[i] = ones[i] > tot[i] / 2 ? 1 : 0;
+    for (int y = 0; y < n; y++) {
+        const int inc = (y == 0 || y == n - 1) ? 1 : n - 1;
+        for (int x = 0; x < n; x += inc)
+            if (bits[y * n + x] != 0) return -1;
+    }
+    std::vector<uint8_t> inner(nb * nb), tmp(nb * nb);
+    for (int y = 0; y < nb; y++)
+        for (int x = 0; x < nb; x++) inner[y * nb + x] = bits[(y + 1) * n + (x + 1)];
+    unsigned long long ids[4];
+    for (int r = 0; r < 4; r++) {
+        unsigned long long v = 0;
+        int b = 0;
+        for (int y = nb - 1; y >= 0; y--)
+            for (int x = nb - 1; x >= 0; x--) v |= (unsigned long long)inner[y * nb + x] << b++;
+        ids[r] = v;
+        for (int i = 0; i < nb; i++)
+            for (int j = 0; j < nb; j++) tmp[i * nb + j] = inner[(nb - j - 1) * nb + i];
+        inner = tmp;
+    }
+    if (ids[0] == 0) return -1; /* :1232 */
+    for (int r = 0; r < 4; r++) {
+        int id = dict.lookup(ids[r]);
+        if (id >= 0) { *nRot = r; return id; }
+    }
+    return -1;
+}
+
+/* ---------------------------------------------------------------- detector -- */
+float pt_norm(float dx, float dy) { return (float)std::sqrt((double)dx * dx + (double)dy * dy); }
+
+int perimeter(const Ptf c[4]) /* markerdetector_impl.cpp:11119-11296 */
+{
+    int sum = 0;
+    for (int i = 0; i < 4; i++) {
+        int i2 = (i + 1) % 4;
+        sum += static_cast<int>(std::sqrt((c[i].x - c[i2].x) * (c[i].x - c[i2].x) + (c[i].y - c[i2].y) * (c[i].y - c[i2].y)));
+    }
+    return sum;
+}
+
+float get_area(const Ptf c[4]) /* marker.cpp:405-416 */
+{
+    float v01x = c[1].x - c[0].x, v01y = c[1].y - c[0].y, v03x = c[3].x - c[0].x, v03y = c[3].y - c[0].y;
+    float area1 = std::fabs(v01x * v03y - v01y * v03x);
+    float v21x = c[1].x - c[2].x, v21y = c[1].y - c[2].y, v23x = c[3].x - c[2].x, v23y = c[3].y - c[2].y;
+    float area2 = std::fabs(v21x * v23y - v21y * v23x);
+    return (area2 + area1) / 2.f;
+}
+
+/* least-squares line through points (interpolate2Dline, :11301-11890); out = (a, b, c) with a x + b y + c = 0 */
+void interpolate2Dline(const std::vector<Ptf>& pts, float line[3])
+{
+    float minX, maxX, minY, maxY;
+    minX = maxX = pts[0].x;
+    minY = maxY = pts[0].y;
+    for (size_t i = 1; i < pts.size(); i++) {
+        minX = std::min(minX, pts[i].x); maxX = std::max(maxX, pts[i].x);
+        minY = std::min(minY, pts[i].y); maxY = std::max(maxY, pts[i].y);
+    }
+    const bool xdom = (maxX - minX > maxY - minY);
+    /* fit v = p*u + q */
+    double su = 0, sv = 0, suu = 0, suv = 0;
+    const double n = (double)pts.size();
+    for (const Ptf& p : pts) {
+        double u = xdom ? p.x : p.y, v = xdom ? p.y : p.x;
+        su += u; sv += v; suu += u * u; suv += u * v;
+    }
+    double det = n * suu - su * su, pa, qa;
+    if (std::fabs(det) > 1e-9 * std::max(1.0, n * suu)) {
+        pa = (n * suv - su * sv) / det;
+        qa = (sv * suu - su * suv) / det;
+    } else { /* rank deficient: minimum-norm solution, as the SVD solve would return */
+        double um = su / n, vm = sv / n;
+        pa = vm * um / (um * um + 1.0);
+        qa = vm / (um * um + 1.0);
+    }
+    if (xdom) { line[0] = (float)pa; line[1] = -1.f; line[2] = (float)qa; }
+    else { line[0] = -1.f; line[1] = (float)pa; line[2] = (float)qa; }
+}
+
+Ptf cross_point(const float l1[3], const float l2[3]) /* getCrossPoint, :11899-12073 */
+{
+    double a = l1[0], b = l1[1], c = l2[0], d = l2[1], e = -(double)l1[2], f = -(double)l2[2];
+    double det = a * d - b * c;
+    Ptf r{0.f, 0.f};
+    if (det != 0.0) { r.x = (float)((e * d - b * f) / det); r.y = (float)((a * f - e * c) / det); }
+    return r;
+}
+
+struct Detector {
+    Dict dict;
+    /* stage data of the last call (per-stage parity tests) */
+    Image thres;
+    std::vector<Image> pyramid;
+    std::vector<Candidate> rects, prefiltered;
+    int win = 0;
+
+    /* buildPyramid (:1299-1488): halve while width > maxsize; cv::resize default INTER_LINEAR, which the exact
+     * 2x case redirects to INTER_AREA (2x2 mean) */
+    void build_pyramid(const Image& gray, int maxsize)
+    {
+        pyramid.clear();
+        pyramid.push_back(gray);
+        int npyr = 1, w = gray.w, h = gray.h;
+        while (w > maxsize) { w /= 2; h /= 2; npyr++; }
+        for (int i = 1; i < npyr; i++) {
+            const Image& s = pyramid[i - 1];
+            Image d(s.w / 2, s.h / 2);
+            if (s.w == d.w * 2 && s.h == d.h * 2) {
+                for (int y = 0; y < d.h; y++)
+                    for (int x = 0; x < d.w; x++)
+                        d.row(y)[x] = (uint8_t)((s.row(2 * y)[2 * x] + s.row(2 * y)[2 * x + 1] + s.row(2 * y + 1)[2 * x] +
+                                                 s.row(2 * y + 1)[2 * x + 1] + 2) >> 2);
+            } else {
+                resize_generic(s, d);
+            }
+            pyramid.push_back(d);
+        }
+    }
+    /* generic INTER_LINEAR (same arithmetic as the ORB pyramid's resize) */
+    static void resize_generic(const Image& src, Image& dst)
+    {
+        const int sw = src.w, sh = src.h, dw = dst.w, dh = dst.h;
+        const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
+        std::vector<int> xofs(dw), yofs(dh), xa0(dw), xa1(dw), yb0(dh), yb1(dh);
+        for (int dx = 0; dx < dw; dx++) {
+            float fx = (float)((dx + 0.5) * scale_x - 0.5);
+            int sx = orbfe_floor_d(fx);
+            fx -= sx;
+            if (sx < 0) { fx = 0; sx = 0; }
+            if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+            xofs[dx] = sx;
+            xa0[dx] = (short)orbfe_round_f((1.f - fx) * 2048.f);
+            xa1[dx] = (short)orbfe_round_f(fx * 2048.f);
+        }
+        for (int dy = 0; dy < dh; dy++) {
+            float fy = (float)((dy + 0.5) * scale_y - 0.5);
+            int sy = orbfe_floor_d(fy);
+            fy -= sy;
+            yofs[dy] = sy;
+            yb0[dy] = (short)orbfe_round_f((1.f - fy) * 2048.f);
+            yb1[dy] = (short)orbfe_round_f(fy * 2048.f);
+        }
+        for (int dy = 0; dy < dh; dy++) {
+            const uint8_t* S0 = src.row(std::min(std::max(yofs[dy], 0), sh - 1));
+            const uint8_t* S1 = src.row(std::min(std::max(yofs[dy] + 1, 0), sh - 1));
+            for (int dx = 0; dx < dw; dx++) {
+                int sx = xofs[dx], sx1 = std::min(sx + 1, sw - 1);
+                int h0 = S0[sx] * xa0[dx] + S0[sx1] * xa1[dx], h1 = S1[sx] * xa0[dx] + S1[sx1] * xa1[dx];
+                dst.row(dy)[dx] = (uint8_t)((((yb0[dy] * (h0 >> 4)) >> 16) + ((yb1[dy] * (h1 >> 4)) >> 16) + 2) >> 2);
+            }
+        }
+    }
+
+    /* thresholdAndDetectRectangles (:2705-3607 and :3765-3895) */
+    void threshold_and_detect(const Image& gray)
+    {
+        int w = std::max(3, int(15 * float(gray.w) / 1920.));
+        if (w % 2 == 0) w++;
+        win = w; /* = _tooNearDistance */
+        adaptive_threshold_inv(gray, thres, w, 7);
+        std::vector<std::vector<Pt>> contours;
+        find_contours_list(thres, contours);
+        rects.clear();
+        const int thres_len = int(3.5 * float(20)); /* lowResMarkerSize = 20 */
+        std::vector<Pt> approx;
+        for (auto& c : contours) {
+            if (thres_len < (int)c.size()) {
+                approx_poly_dp_closed(c, double(c.size()) * 0.05, approx);
+                if (approx.size() == 4 && is_contour_convex(approx.data(), 4)) {
+                    Candidate cd;
+                    for (int j = 0; j < 4; j++) cd.c[j] = Ptf{(float)approx[j].x, (float)approx[j].y};
+                    cd.contour = c;
+                    rects.push_back(std::move(cd));
+                }
+            }
+        }
+    }
+
+    /* prefilterCandidates (:4347-5347) */
+    void prefilter(int W, int H)
+    {
+        std::vector<Candidate>& c = rects;
+        for (auto& cd : c) {
+            double dx1 = cd.c[1].x - cd.c[0].x, dy1 = cd.c[1].y - cd.c[0].y;
+            double dx2 = cd.c[2].x - cd.c[0].x, dy2 = cd.c[2].y - cd.c[0].y;
+            double o = (dx1 * dy2) - (dy1 * dx2);
+            if (o < 0.0) std::swap(cd.c[1], cd.c[3]);
+        }
+        std::vector<std::pair<int, int>> tooNear;
+        for (size_t i = 0; i < c.size(); i++)
+            for (size_t j = i + 1; j < c.size(); j++) {
+                float d[4];
+                for (int k = 0; k < 4; k++) d[k] = pt_norm(c[i].c[k].x - c[j].c[k].x, c[i].c[k].y - c[j].c[k].y);
+                if (d[0] < win && d[1] < win && d[2] < win && d[3] < win) tooNear.push_back({(int)i, (int)j});
+            }
+        std::vector<bool> rm(c.size(), false);
+        for (auto& pr : tooNear) {
+            if (perimeter(c[pr.first].c) > perimeter(c[pr.second].c)) rm[pr.second] = true;
+            else rm[pr.first] = true;
+        }
+        const int bx = static_cast<int>(0.015f * float(W)), by = static_cast<int>(0.015f * float(H));
+        for (size_t i = 0; i < c.size(); i++)
+            for (int k = 0; k < 4; k++)
+                if (c[i].c[k].x < bx || c[i].c[k].y < by || c[i].c[k].x > W - bx || c[i].c[k].y > H - by) rm[i] = true;
+        prefiltered.clear();
+        for (size_t i = 0; i < c.size(); i++)
+            if (!rm[i]) prefiltered.push_back(c[i]);
+    }
+
+    /* refineCornerWithContourLines (:8978-10044) with empty camera matrices */
+    static void refine_corners(Candidate& m)
+    {
+        const std::vector<Pt>& contour = m.contour;
+        int ci[4] = {-1, -1, -1, -1};
+        float dist[4] = {FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX};
+        for (unsigned j = 0; j < contour.size(); j++)
+            for (unsigned k = 0; k < 4; k++) {
+                float d = (contour[j].x - m.c[k].x) * (contour[j].x - m.c[k].x) +
+                          (contour[j].y - m.c[k].y) * (contour[j].y - m.c[k].y);
+                if (d < dist[k]) { ci[k] = j; dist[k] = d; }
+            }
+        bool inverse;
+        if ((ci[1] > ci[0]) && (ci[2] > ci[1] || ci[2] < ci[0])) inverse = false;
+        else if (ci[2] > ci[1] && ci[2] < ci[0]) inverse = false;
+        else inverse = true;
+        const int inc = inverse ? -1 : 1;
+        std::vector<Ptf> lines[4];
+        const int sz = (int)contour.size();
+        for (unsigned l = 0; l < 4; l++) {
+            /* bounded: the reference loop can only run away on degenerate index sets; cap at 2*sz iterations */
+            int guard = 0;
+            for (int j = ci[l]; j != ci[(l + 1) % 4] && guard < 2 * sz + 4; j += inc, guard++) {
+                if (j == sz && !inverse) j = 0;
+                else if (j == 0 && inverse) j = sz - 1;
+                lines[l].push_back(Ptf{(float)contour[j].x, (float)contour[j].y});
+                if (j == ci[(l + 1) % 4]) break;
+            }
+        }
+        float L[4][3];
+        for (int l = 0; l < 4; l++) {
+            if (lines[l].empty()) { L[l][0] = L[l][1] = L[l][2] = 0.f; continue; }
+            interpolate2Dline(lines[l], L[l]);
+        }
+        for (unsigned i = 0; i < 4; i++) m.c[i] = cross_point(L[(i - 1) % 4], L[i]); /* unsigned (i-1)%4: 3 for i=0 */
+    }
+
+    int detect(const Image& gray, std::vector<Candidate>& out)
+    {
+        out.clear();
+        const int nb = (int)std::sqrt((double)dict.nbits);
+        const int S = 5 * (nb + 2); /* getMarkerWarpSize (:1199-1292): markerWarpPixSize * nSubdivisions */
+        build_pyramid(gray, 2 * S);
+        threshold_and_detect(gray);
+        prefilter(gray.w, gray.h);
+        const float desiredarea = std::pow(static_cast<float>(S), 2.f);
+        std::vector<uint8_t> patch((size_t)S * S);
+        for (auto& cand : prefiltered) {
+            size_t lvl = 0;
+            for (size_t p = 1; p < pyramid.size(); p++) {
+                if (get_area(cand.c) / std::pow(4, p) >= desiredarea) lvl = p;
+                else break;
+            }
+            const Image& im = pyramid[lvl];
+            const float ratio = float(im.w) / float(gray.w);
+            Ptf q[4];
+            for (int k = 0; k < 4; k++) q[k] = Ptf{cand.c[k].x * ratio, cand.c[k].y * ratio};
+            double Minv[9];
+            if (!perspective_inverse_map(q, S, Minv)) continue;
+            warp_perspective(im, Minv, S, patch.data());
+            int nRot = 0;
+            int id = decode_marker(patch.data(), S, dict, &nRot);
+            if (id >= 0) {
+                Candidate m = cand;
+                m.id = id;
+                std::rotate(m.c, m.c + 4 - nRot, m.c + 4);
+                out.push_back(std::move(m));
+            }
+        }
+        /* sort by id; among equal ids keep the larger perimeter (:8153-8365) */
+        std::stable_sort(out.begin(), out.end(), [](const Candidate& a, const Candidate& b) { return a.id < b.id; });
+        std::vector<bool> rm(out.size(), false);
+        for (int i = 0; i < (int)out.size() - 1; i++)
+            for (int j = i + 1; j < (int)out.size() && !rm[i]; j++)
+                if (out[i].id == out[j].id) {
+                    if (perimeter(out[i].c) < perimeter(out[j].c)) rm[i] = true;
+                    else rm[j] = true;
+                }
+        std::vector<Candidate> kept;
+        for (size_t i = 0; i < out.size(); i++)
+            if (!rm[i]) kept.push_back(std::move(out[i]));
+        out.swap(kept);
+        for (auto& m : out) refine_corners(m);
+        return (int)out.size();
+    }
+};
+
+struct MarkerRec {
+    int32_t id;
+    float corners[4][2];
+};
+
+Image make_image(const uint8_t* img, int rows, int cols, size_t step)
+{
+    Image g(cols, rows);
+    for (int y = 0; y < rows; y++) memcpy(g.row(y), img + (size_t)y * step, cols);
+    return g;
+}
+
+} // namespace
+
+extern "C" {
+
+void* oracle_aruco_create(const char* dictionary)
+{
+    Detector* d = new Detector();
+    if (!load_dict(dictionary, d->dict)) { delete d; return nullptr; }
+    return d;
+}
+void oracle_aruco_destroy(void* h) { delete (Detector*)h; }
+
+int oracle_aruco_detect(void* h, const uint8_t* img, int rows, int cols, size_t step, void* out, int capacity)
+{
+    Detector* d = (Detector*)h;
+    std::vector<Candidate> m;
+    d->detect(make_image(img, rows, cols, step), m);
+    MarkerRec* o = (MarkerRec*)out;
+    for (int i = 0; i < (int)m.size() && i < capacity; i++) {
+        o[i].id = m[i].id;
+        for (int k = 0; k < 4; k++) { o[i].corners[k][0] = m[i].c[k].x; o[i].corners[k][1] = m[i].c[k].y; }
+    }
+    return (int)m.size();
+}
+
+/* stage 0: thresholded image; 1..: detector pyramid level (stage-1). Returns 0 on success. */
+int oracle_aruco_stage_image(void* h, int stage, uint8_t* out, int* w, int* hh)
+{
+    Detector* d = (Detector*)h;
+    const Image* im = nullptr;
+    if (stage == 0) im = &d->thres;
+    else if (stage - 1 < (int)d->pyramid.size()) im = &d->pyramid[stage - 1];
+    if (!im) return -1;
+    *w = im->w; *hh = im->h;
+    if (out) memcpy(out, im->d.data(), im->d.size());
+    return 0;
+}
+/* 0: rectangles after approxPolyDP/convexity, 1: after prefilterCandidates, 2: pyramid levels */
+int oracle_aruco_stage_count(void* h, int which)
+{
+    Detector* d = (Detector*)h;
+    return which == 0 ? (int)d->rects.size() : which == 1 ? (int)d->prefiltered.size() : (int)d->pyramid.size();
+}
+/* corners (float[4][2]) + contour length of stage-`which` candidates */
+int oracle_aruco_candidates(void* h, int which, float* out, int capacity)
+{
+    Detector* d = (Detector*)h;
+    const std::vector<Candidate>& v = which == 0 ? d->rects : d->prefiltered;
+    for (int i = 0; i < (int)v.size() && i < capacity; i++) {
+        for (int k = 0; k < 4; k++) { out[i * 9 + 2 * k] = v[i].c[k].x; out[i * 9 + 2 * k + 1] = v[i].c[k].y; }
+        out[i * 9 + 8] = (float)v[i].contour.size();
+    }
+    return (int)v.size();
+}
+
+void oracle_adaptive_threshold(const uint8_t* src, int w, int h, uint8_t* dst, int win, int C)
+{
+    Image s(w, h), d;
+    memcpy(s.d.data(), src, (size_t)w * h);
+    adaptive_threshold_inv(s, d, win, C);
+    memcpy(dst, d.d.data(), (size_t)w * h);
+}
+
+/* contours of a binary image: lengths[] per contour (in output order) and the concatenated points (x,y int32 pairs).
+ * Returns the number of contours; point capacity is in points. */
+int oracle_find_contours(const uint8_t* img, int w, int h, int32_t* lengths, int max_contours, int32_t* points,
+                         int max_points)
+{
+    Image s(w, h);
+    memcpy(s.d.data(), img, (size_t)w * h);
+    std::vector<std::vector<Pt>> c;
+    find_contours_list(s, c);
+    int np = 0;
+    for (int i = 0; i < (int)c.size(); i++) {
+        if (i < max_contours) lengths[i] = (int)c[i].size();
+        for (auto& p : c[i]) {
+            if (np < max_points) { points[2 * np] = p.x; points[2 * np + 1] = p.y; }
+            np++;
+        }
+    }
+    return (int)c.size();
+}
+
+/* quad: 8 floats; out: S*S bytes */
+void oracle_warp_perspective35(const uint8_t* img, int w, int h, const float* quad, uint8_t* out, int S)
+{
+    Image s(w, h);
+    memcpy(s.d.data(), img, (size_t)w * h);
+    Ptf q[4];
+    for (int k = 0; k < 4; k++) q[k] = Ptf{quad[2 * k], quad[2 * k + 1]};
+    double Minv[9];
+    memset(out, 0, (size_t)S * S);
+    if (perspective_inverse_map(q, S, Minv)) warp_perspective(s, Minv, S, out);
+}
+
+int oracle_otsu_threshold(const uint8_t* p, int n) { return otsu_threshold(p, n); }
+
+/* returns id or -1; rot gets the rotation count */
+int oracle_decode_marker(void* h, const uint8_t* patch, int S, int* rot)
+{
+    Detector* d = (Detector*)h;
+    int r = 0;
+    int id = decode_marker(patch, S, d->dict, &r);
+    if (rot) *rot = r;
+    return id;
+}
+
+int oracle_approx_poly(const int32_t* pts, int n, double eps, int32_t* out, int capacity)
+{
+    std::vector<Pt> s(n), d;
+    for (int i = 0; i < n; i++) s[i] = Pt{pts[2 * i], pts[2 * i + 1]};
+    approx_poly_dp_closed(s, eps, d);
+    for (int i = 0; i < (int)d.size() && i < capacity; i++) { out[2 * i] = d[i].x; out[2 * i + 1] = d[i].y; }
+    return (int)d.size();
+}
+
+} /* extern "C" */

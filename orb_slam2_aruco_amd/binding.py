@@ -258,3 +258,91 @@ class ORBmatcher:
                                                               int(self.mbCheckOrientation), C.byref(n), self.device),
                "orbfe_search_for_initialization")
         return n.value, m12, prev
+
+
+# ------------------------------------------------------------------------------------------ ArUco ----
+RECT_DTYPE = np.dtype([("corners", "<f4", (4, 2)), ("off", "<i4"), ("len", "<i4")])
+
+
+class MarkerDetector:
+    """Mirror of aruco::MarkerDetector as the reference configures it (src/Frame.cc:129-142):
+    setDictionary(name) + DM_NORMAL + CORNER_LINES; detect(image) -> markers sorted by id."""
+    STAGES = ["threshold", "pyramid", "contours", "decode", "finalize"]
+
+    def __init__(self, dictionary="ARUCO", device=0):
+        self.L = load()
+        self.h = self.L.orbfe_aruco_create(dictionary.encode(), device)
+        if not self.h:
+            raise OrbfeError("orbfe_aruco_create: " + self.L.orbfe_last_error().decode())
+        self.capacity = self.L.orbfe_aruco_max_markers(self.h)
+        self._shape = None
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orbfe_aruco_destroy(self.h)
+            self.h = None
+
+    def setDictionary(self, name):
+        _check(self.L, self.L.orbfe_aruco_set_dictionary(self.h, name.encode()), "orbfe_aruco_set_dictionary")
+
+    def detect(self, image):
+        image = np.asarray(image)
+        if image.size == 0:
+            return np.zeros(0, MARKER_DTYPE)
+        assert image.dtype == np.uint8 and image.ndim == 2
+        if image.strides[1] != 1:
+            image = np.ascontiguousarray(image)
+        out = np.zeros(self.capacity, MARKER_DTYPE)
+        n = C.c_int32(0)
+        _check(self.L, self.L.orbfe_aruco_detect(self.h, _p(image), image.shape[0], image.shape[1], image.strides[0],
+                                                 _p(out), self.capacity, C.byref(n)), "orbfe_aruco_detect")
+        self._shape = image.shape
+        return out[:n.value].copy()
+
+    def detect_batch(self, images):
+        images = np.ascontiguousarray(images, np.uint8)
+        B, rows, cols = images.shape
+        out = np.zeros((B, self.capacity), MARKER_DTYPE)
+        n = np.zeros(B, np.int32)
+        _check(self.L, self.L.orbfe_aruco_detect_batch(self.h, _p(images), B, images.strides[0], rows, cols,
+                                                       images.strides[1], _p(out), self.capacity, _p(n)),
+               "orbfe_aruco_detect_batch")
+        self._shape = (rows, cols)
+        return [out[f, :n[f]].copy() for f in range(B)]
+
+    def detect_batch_device(self, d_imgs_ptr, B, frame_stride, rows, cols, step, d_out_ptr, capacity, d_n_ptr,
+                            stream=0):
+        _check(self.L, self.L.orbfe_aruco_detect_batch_device(self.h, d_imgs_ptr, B, frame_stride, rows, cols, step,
+                                                              d_out_ptr, capacity, d_n_ptr, stream),
+               "orbfe_aruco_detect_batch_device")
+
+    # stage read-back for parity tests
+    def thresholded(self, frame=0):
+        out = np.zeros(self._shape, np.uint8)
+        _check(self.L, self.L.orbfe_aruco_debug_image(self.h, frame, 0, _p(out)), "debug_image")
+        return out
+
+    def counts(self, frame=0):
+        out = np.zeros(4, np.int32)
+        _check(self.L, self.L.orbfe_aruco_debug_image(self.h, frame, 100, _p(out)), "debug_image")
+        return dict(nkept=int(out[0]), nrect=int(out[1]), flags=int(out[2]), ncand=int(out[3]))
+
+    def rects(self, frame=0):
+        out = np.zeros(self.capacity, RECT_DTYPE)
+        _check(self.L, self.L.orbfe_aruco_debug_image(self.h, frame, 101, _p(out)), "debug_image")
+        return out[:self.counts(frame)["nrect"]]
+
+    def enable_kernel_timing(self, on=True):
+        self.L.orbfe_aruco_debug_kernel_times(self.h, None, int(on))
+
+    def kernel_times_us(self):
+        out = np.zeros(32, np.float32)
+        n = self.L.orbfe_aruco_debug_kernel_times(self.h, _p(out), 32)
+        return out[:n]
+
+    @staticmethod
+    def algorithmic_bytes(rows, cols):
+        """Per-frame algorithmic bytes of each ArUco stage (terms of SURVEY 8d's B_aruco ~ 3.33 W H)."""
+        wh = rows * cols
+        return {"aruco_threshold": wh + wh // 8, "aruco_pyramid": wh + wh // 3, "aruco_contours": wh // 8,
+                "aruco_decode": 0, "aruco_finalize": 0}

@@ -1,0 +1,345 @@
+// aruco_detector.hip -- host side of the ArUco marker detector behind the C ABI (include/orbfe.h).
+//
+// Mirrors aruco::MarkerDetector as configured by the reference at src/Frame.cc:129-142:
+//   setDictionary(name), setDetectionMode(DM_NORMAL), setCornerRefinementMethod(CORNER_LINES), detect(gray).
+// Effective parameters: adaptive threshold window max(3, 15*W/1920) made odd, C = 7, one
+// threshold image, contours longer than 70 points, approxPolyDP eps 5 %, markerWarpPixSize 5, pyrfactor 2,
+// borderDistThres 0.015, error correction off.  Pose estimation (step 12) is not part of this path yet.
+#include <algorithm>
+#include <cmath>
+
+#include "aruco_kernels.hpp"
+#include "orbfe_common.hpp"
+#include "orbfe_tables.inc"
+
+using namespace orbfe;
+
+struct orbfe_aruco {
+    int device = 0;
+    std::string dict_name;
+    int nbits = 0, nb = 0, S = 0, ncodes = 0;
+    hipStream_t own_stream = nullptr;
+    int rows = 0, cols = 0, batch_cap = 0;
+    int win = 0, wpr = 0, npyr = 0;
+    std::vector<ArLevel> levels;
+    std::vector<int> lvl_exact;           // 1 if level p is an exact 2x reduction of level p-1
+    std::vector<size_t> tab_off;          // resize tables for non-exact levels
+    size_t pyr_fbytes = 0, bits_fu32 = 0, candq_fu32 = 0, pool_fu32 = 0, gpad_fu32 = 0;
+    int lds_bits_words = 0;
+    DevBuf d_codes, d_levels, d_tabs, d_bits, d_pyr, d_candq, d_pool, d_kept, d_rects, d_counts, d_candidx, d_ncand,
+        d_result, d_gpad;
+    DevBuf d_in, d_out, d_nout;
+    KernelTimer timer;
+    int last_nframes = 0;
+
+    ~orbfe_aruco()
+    {
+        for (DevBuf* b : {&d_codes, &d_levels, &d_tabs, &d_bits, &d_pyr, &d_candq, &d_pool, &d_kept, &d_rects,
+                          &d_counts, &d_candidx, &d_ncand, &d_result, &d_gpad, &d_in, &d_out, &d_nout})
+            b->release();
+        if (own_stream) (void)hipStreamDestroy(own_stream);
+    }
+
+    int set_dictionary(const char* name)
+    {
+        for (int i = 0; i < ORBFE_NDICTS; i++)
+            if (!strcmp(ORBFE_DICTS[i].name, name)) {
+                const orbfe_dict_entry& d = ORBFE_DICTS[i];
+                if (d.nbits > 36) return fail(ORBFE_ERR_DICT, "dictionary %s: %d-bit codes are not supported", name, d.nbits);
+                dict_name = name;
+                nbits = d.nbits;
+                nb = (int)std::sqrt((double)nbits);
+                S = 5 * (nb + 2); // getMarkerWarpSize(): markerWarpPixSize * nSubdivisions (markerdetector_impl.cpp:1199-1292)
+                ncodes = d.ncodes;
+                int rc = d_codes.ensure((size_t)std::max(ncodes, 1) * 8);
+                if (rc) return rc;
+                if (ncodes) ORBFE_HIP(hipMemcpy(d_codes.p, d.codes, (size_t)ncodes * 8, hipMemcpyHostToDevice));
+                rows = cols = 0; // pyramid depth depends on S
+                return ORBFE_OK;
+            }
+        // the reference treats an unknown name as a file path and throws (dictionary.cpp:44-62)
+        return fail(ORBFE_ERR_DICT, "unknown dictionary '%s'", name);
+    }
+
+    int build_geometry(int rows_, int cols_)
+    {
+        if (rows_ == rows && cols_ == cols && !levels.empty()) return ORBFE_OK;
+        if (cols_ > 8000 || rows_ > 8000) return fail(ORBFE_ERR_INVALID, "image larger than 8000 px");
+        int w = std::max(3, int(15 * float(cols_) / 1920.)); // :3765-3809
+        if (w % 2 == 0) w++;
+        if (w > 2 * TH_MAXR_HOST + 1) return fail(ORBFE_ERR_INVALID, "threshold window %d too large", w);
+        win = w;
+        wpr = (cols_ + 31) / 32;
+        bits_fu32 = (size_t)wpr * rows_;
+        // buildPyramid (:1299-1488): halve while width > 2 * S
+        levels.clear();
+        lvl_exact.clear();
+        std::vector<int> tabs;
+        tab_off.clear();
+        int lw = cols_, lh = rows_;
+        size_t off = 0;
+        levels.push_back(ArLevel{lw, lh, 0, 0});
+        lvl_exact.push_back(1);
+        tab_off.resize(4, 0);
+        int n = 1, tw = cols_;
+        while (tw > 2 * S) { tw /= 2; n++; }
+        for (int p = 1; p < n; p++) {
+            const int sw = lw, sh = lh;
+            lw /= 2; lh /= 2;
+            if (lw < 1 || lh < 1) break;
+            ArLevel L{lw, lh, (lw + 63) / 64 * 64, (long long)off};
+            off += (size_t)L.pitch * lh;
+            levels.push_back(L);
+            const bool exact = (sw == 2 * lw && sh == 2 * lh);
+            lvl_exact.push_back(exact);
+            tab_off.resize((size_t)(p + 1) * 4, 0);
+            if (!exact) { // generic INTER_LINEAR tables, same format as the ORB pyramid's
+                const double scale_x = 1. / ((double)lw / sw), scale_y = 1. / ((double)lh / sh);
+                const int dwp = (lw + 3) / 4 * 4;
+                std::vector<int> xofs(dwp), xal(dwp), yofs(lh), ybe(lh);
+                for (int dx = 0; dx < lw; dx++) {
+                    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+                    int sx = orbfe_floor_d(fx);
+                    fx -= sx;
+                    if (sx < 0) { fx = 0; sx = 0; }
+                    if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+                    const int a0 = (short)orbfe_round_f((1.f - fx) * 2048.f), a1 = (short)orbfe_round_f(fx * 2048.f);
+                    xofs[dx] = sx;
+                    xal[dx] = (a0 & 0xffff) | (a1 << 16);
+                }
+                for (int dx = lw; dx < dwp; dx++) { xofs[dx] = xofs[lw - 1]; xal[dx] = xal[lw - 1]; }
+                for (int dy = 0; dy < lh; dy++) {
+                    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+                    int sy = orbfe_floor_d(fy);
+                    fy -= sy;
+                    const int b0 = (short)orbfe_round_f((1.f - fy) * 2048.f), b1 = (short)orbfe_round_f(fy * 2048.f);
+                    yofs[dy] = sy;
+                    ybe[dy] = (b0 & 0xffff) | (b1 << 16);
+                }
+                tab_off[p * 4 + 0] = tabs.size(); tabs.insert(tabs.end(), xofs.begin(), xofs.end());
+                tab_off[p * 4 + 1] = tabs.size(); tabs.insert(tabs.end(), xal.begin(), xal.end());
+                tab_off[p * 4 + 2] = tabs.size(); tabs.insert(tabs.end(), yofs.begin(), yofs.end());
+                tab_off[p * 4 + 3] = tabs.size(); tabs.insert(tabs.end(), ybe.begin(), ybe.end());
+            }
+        }
+        npyr = (int)levels.size();
+        pyr_fbytes = off + 64;
+        candq_fu32 = (size_t)rows_ * cols_ / 4 + 1024;
+        pool_fu32 = (size_t)rows_ * cols_ / 4 + 1024;
+        const int pw = (cols_ + 2 + 31) / 32;
+        const size_t padded_words = (size_t)pw * (rows_ + 2);
+        // the padded bit image goes to LDS when it fits next to the other arrays (160 KiB per workgroup)
+        lds_bits_words = (contours_lds_bytes((int)padded_words, AR_MAX_KEPT) <= 160 * 1024) ? (int)padded_words : 0;
+        gpad_fu32 = lds_bits_words ? 0 : padded_words;
+        rows = rows_; cols = cols_;
+        batch_cap = 0;
+        if (tabs.empty()) tabs.push_back(0);
+        int rc;
+        if ((rc = d_levels.ensure(levels.size() * sizeof(ArLevel))) || (rc = d_tabs.ensure(tabs.size() * 4))) return rc;
+        ORBFE_HIP(hipMemcpy(d_levels.p, levels.data(), levels.size() * sizeof(ArLevel), hipMemcpyHostToDevice));
+        ORBFE_HIP(hipMemcpy(d_tabs.p, tabs.data(), tabs.size() * 4, hipMemcpyHostToDevice));
+        return ORBFE_OK;
+    }
+    static const int TH_MAXR_HOST = 7;
+
+    int ensure_workspace(int B)
+    {
+        if (B <= batch_cap) return ORBFE_OK;
+        int rc;
+        if ((rc = d_bits.ensure(bits_fu32 * 4 * B)) || (rc = d_pyr.ensure(pyr_fbytes * B)) ||
+            (rc = d_candq.ensure(candq_fu32 * 4 * B)) || (rc = d_pool.ensure(pool_fu32 * 4 * B)) ||
+            (rc = d_kept.ensure((size_t)AR_MAX_KEPT * sizeof(ArKept) * B)) ||
+            (rc = d_rects.ensure((size_t)AR_MAX_RECTS * sizeof(ArRect) * B)) || (rc = d_counts.ensure((size_t)16 * B)) ||
+            (rc = d_candidx.ensure((size_t)AR_MAX_RECTS * 4 * B)) || (rc = d_ncand.ensure((size_t)4 * B)) ||
+            (rc = d_result.ensure((size_t)AR_MAX_RECTS * 8 * B)) ||
+            (rc = d_gpad.ensure(std::max<size_t>(gpad_fu32 * 4 * B, 16))))
+            return rc;
+        batch_cap = B;
+        return ORBFE_OK;
+    }
+
+    int run_device(const uint8_t* d_imgs, int B, size_t frame_stride, int rows_, int cols_, size_t step,
+                   orbfe_marker* d_out_m, int capacity, int32_t* d_n, hipStream_t s)
+    {
+        int rc;
+        if ((rc = build_geometry(rows_, cols_))) return rc;
+        if ((rc = ensure_workspace(B))) return rc;
+        last_nframes = B;
+        ImgView src0{d_imgs, nullptr, frame_stride, (int)step};
+        ImgView pyr{d_pyr.as<uint8_t>(), d_pyr.as<uint8_t>(), pyr_fbytes, 0};
+        timer.begin();
+        timer.mark(s, "start");
+        hipLaunchKernelGGL(k_adaptive_threshold, dim3((cols + 63) / 64, (rows + 15) / 16, B), dim3(256), 0, s, src0,
+                           cols, rows, win, 7, 1.0 / (win * win), d_bits.as<uint32_t>(), bits_fu32, wpr);
+        timer.mark(s, "threshold");
+        for (int p = 1; p < npyr; p++) {
+            const ArLevel& L = levels[p];
+            const ArLevel& Lp = levels[p - 1];
+            ImgView sv = (p == 1) ? src0 : ImgView{pyr.base + Lp.off, nullptr, pyr_fbytes, Lp.pitch};
+            ImgView dv{pyr.base + L.off, pyr.base_w + L.off, pyr_fbytes, L.pitch};
+            if (lvl_exact[p]) {
+                hipLaunchKernelGGL(k_half_area, dim3((L.w + 63) / 64, (L.h + 3) / 4, B), dim3(256), 0, s, sv, dv, L.w, L.h);
+            } else {
+                const int dw4 = (L.w + 3) / 4;
+                const int* tabs = d_tabs.as<int>();
+                hipLaunchKernelGGL(k_resize_level, dim3((dw4 + 63) / 64, (L.h + 3) / 4, B), dim3(256), 0, s, sv, dv,
+                                   Lp.w, Lp.h, dw4, L.h, tabs + tab_off[p * 4 + 0], tabs + tab_off[p * 4 + 1],
+                                   tabs + tab_off[p * 4 + 2], tabs + tab_off[p * 4 + 3]);
+            }
+        }
+        timer.mark(s, "pyramid");
+        const size_t lds = contours_lds_bytes(lds_bits_words, AR_MAX_KEPT);
+        ORBFE_HIP(hipGetLastError());
+        ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_contours),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_contours, dim3(B), dim3(CT_THREADS), lds, s, d_bits.as<uint32_t>(), bits_fu32, wpr, cols,
+                           rows, lds_bits_words, 70, d_candq.as<uint32_t>(), candq_fu32, (int)candq_fu32,
+                           d_pool.as<uint32_t>(), pool_fu32, (int)pool_fu32, d_kept.as<ArKept>(), AR_MAX_KEPT,
+                           d_rects.as<ArRect>(), AR_MAX_RECTS, d_counts.as<int32_t>(), d_gpad.as<uint32_t>(),
+                           gpad_fu32);
+        timer.mark(s, "contours");
+        ORBFE_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_prefilter, dim3(B), dim3(256), 0, s, d_rects.as<ArRect>(), AR_MAX_RECTS,
+                           d_counts.as<int32_t>(), cols, rows, win, d_candidx.as<int32_t>(), d_ncand.as<int32_t>());
+        hipLaunchKernelGGL(k_decode, dim3(32, B), dim3(256), 0, s, src0, pyr, d_levels.as<ArLevel>(), npyr,
+                           d_rects.as<ArRect>(), AR_MAX_RECTS, d_candidx.as<int32_t>(), d_ncand.as<int32_t>(), S, nb,
+                           d_codes.as<unsigned long long>(), ncodes, d_result.as<int32_t>(), cols);
+        timer.mark(s, "decode");
+        hipLaunchKernelGGL(k_finalize, dim3(B), dim3(256), 0, s, d_rects.as<ArRect>(), AR_MAX_RECTS,
+                           d_candidx.as<int32_t>(), d_ncand.as<int32_t>(), d_result.as<int32_t>(),
+                           d_pool.as<uint32_t>(), pool_fu32, d_out_m, capacity, d_n);
+        timer.mark(s, "finalize");
+        ORBFE_HIP(hipGetLastError());
+        return ORBFE_OK;
+    }
+};
+
+extern "C" {
+
+orbfe_aruco* orbfe_aruco_create(const char* dictionary, int device)
+{
+    if (!dictionary) { fail(ORBFE_ERR_INVALID, "null dictionary name"); return nullptr; }
+    if (use_device(device) != ORBFE_OK) return nullptr;
+    orbfe_aruco* h = new orbfe_aruco();
+    h->device = device;
+    if (hipStreamCreate(&h->own_stream) != hipSuccess) { fail(ORBFE_ERR_HIP, "hipStreamCreate failed"); delete h; return nullptr; }
+    if (h->set_dictionary(dictionary) != ORBFE_OK) { delete h; return nullptr; }
+    return h;
+}
+
+void orbfe_aruco_destroy(orbfe_aruco* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    delete h;
+}
+
+int orbfe_aruco_set_dictionary(orbfe_aruco* h, const char* dictionary)
+{
+    if (!h || !dictionary) return fail(ORBFE_ERR_INVALID, "null argument");
+    int rc = use_device(h->device);
+    if (rc) return rc;
+    return h->set_dictionary(dictionary);
+}
+
+int orbfe_aruco_max_markers(const orbfe_aruco* h) { return h ? AR_MAX_RECTS : ORBFE_ERR_INVALID; }
+
+int orbfe_aruco_detect_batch_device(orbfe_aruco* h, const uint8_t* d_imgs, int nframes, size_t frame_stride, int rows,
+                                    int cols, size_t step, orbfe_marker* d_out, int capacity, int32_t* d_n_out,
+                                    void* stream)
+{
+    if (!h || !d_imgs || !d_out || !d_n_out || nframes <= 0 || rows <= 0 || cols <= 0 || step < (size_t)cols ||
+        capacity <= 0)
+        return fail(ORBFE_ERR_INVALID, "orbfe_aruco_detect_batch_device: invalid argument");
+    int rc = use_device(h->device);
+    if (rc) return rc;
+    return h->run_device(d_imgs, nframes, frame_stride, rows, cols, step, d_out, capacity, d_n_out, (hipStream_t)stream);
+}
+
+int orbfe_aruco_detect_batch(orbfe_aruco* h, const uint8_t* imgs, int nframes, size_t frame_stride, int rows, int cols,
+                             size_t step, orbfe_marker* out, int capacity, int32_t* n_out)
+{
+    if (!h || !n_out) return fail(ORBFE_ERR_INVALID, "orbfe_aruco_detect_batch: null argument");
+    if (!imgs || rows <= 0 || cols <= 0 || nframes <= 0) {
+        for (int f = 0; f < nframes; f++) n_out[f] = 0;
+        return ORBFE_OK;
+    }
+    if (!out || step < (size_t)cols || capacity <= 0) return fail(ORBFE_ERR_INVALID, "orbfe_aruco_detect_batch: invalid argument");
+    int rc = use_device(h->device);
+    if (rc) return rc;
+    const size_t dpitch = (size_t)(cols + 63) / 64 * 64, dframe = dpitch * rows;
+    if ((rc = h->d_in.ensure(dframe * nframes + 64)) || (rc = h->d_out.ensure((size_t)AR_MAX_RECTS * nframes * sizeof(orbfe_marker))) ||
+        (rc = h->d_nout.ensure((size_t)nframes * 4)))
+        return rc;
+    hipStream_t s = h->own_stream;
+    for (int f = 0; f < nframes; f++)
+        ORBFE_HIP(hipMemcpy2DAsync((uint8_t*)h->d_in.p + f * dframe, dpitch, imgs + f * frame_stride, step, cols, rows,
+                                   hipMemcpyHostToDevice, s));
+    rc = h->run_device(h->d_in.as<uint8_t>(), nframes, dframe, rows, cols, dpitch, h->d_out.as<orbfe_marker>(),
+                       AR_MAX_RECTS, h->d_nout.as<int32_t>(), s);
+    if (rc) return rc;
+    ORBFE_HIP(hipMemcpyAsync(n_out, h->d_nout.p, (size_t)nframes * 4, hipMemcpyDeviceToHost, s));
+    ORBFE_HIP(hipStreamSynchronize(s));
+    std::vector<int32_t> counts((size_t)nframes * 4);
+    ORBFE_HIP(hipMemcpy(counts.data(), h->d_counts.p, counts.size() * 4, hipMemcpyDeviceToHost));
+    for (int f = 0; f < nframes; f++) {
+        if (counts[f * 4 + 2])
+            return fail(ORBFE_ERR_CAPACITY, "frame %d: internal detector capacity exceeded (flags 0x%x)", f, counts[f * 4 + 2]);
+        if (n_out[f] > capacity) return fail(ORBFE_ERR_CAPACITY, "frame %d has %d markers, capacity is %d", f, n_out[f], capacity);
+        if (n_out[f])
+            ORBFE_HIP(hipMemcpy(out + (size_t)f * capacity, h->d_out.as<orbfe_marker>() + (size_t)f * AR_MAX_RECTS,
+                                (size_t)n_out[f] * sizeof(orbfe_marker), hipMemcpyDeviceToHost));
+    }
+    return ORBFE_OK;
+}
+
+int orbfe_aruco_detect(orbfe_aruco* h, const uint8_t* img, int rows, int cols, size_t step, orbfe_marker* out,
+                       int capacity, int32_t* n_out)
+{
+    return orbfe_aruco_detect_batch(h, img, 1, 0, rows, cols, step, out, capacity, n_out);
+}
+
+int orbfe_aruco_debug_image(orbfe_aruco* h, int frame, int stage, uint8_t* out)
+{
+    if (!h || !out || frame < 0 || frame >= h->last_nframes) return fail(ORBFE_ERR_INVALID, "debug_image: invalid argument");
+    int rc = use_device(h->device);
+    if (rc) return rc;
+    ORBFE_HIP(hipDeviceSynchronize());
+    if (stage == 0) {
+        std::vector<uint32_t> bits(h->bits_fu32);
+        ORBFE_HIP(hipMemcpy(bits.data(), h->d_bits.as<uint32_t>() + (size_t)frame * h->bits_fu32, bits.size() * 4,
+                            hipMemcpyDeviceToHost));
+        for (int y = 0; y < h->rows; y++)
+            for (int x = 0; x < h->cols; x++)
+                out[(size_t)y * h->cols + x] = ((bits[(size_t)y * h->wpr + (x >> 5)] >> (x & 31)) & 1) ? 255 : 0;
+        return ORBFE_OK;
+    }
+    if (stage >= 1 && stage < h->npyr + 1 && stage - 1 >= 1) { // pyramid level stage-1 (>= 1)
+        const ArLevel& L = h->levels[stage - 1];
+        ORBFE_HIP(hipMemcpy2D(out, L.w, h->d_pyr.as<uint8_t>() + (size_t)frame * h->pyr_fbytes + L.off, L.pitch, L.w, L.h,
+                              hipMemcpyDeviceToHost));
+        return ORBFE_OK;
+    }
+    if (stage == 100) { // counts: nkept, nrect, flags, ncand as 4 int32
+        ORBFE_HIP(hipMemcpy(out, h->d_counts.as<int32_t>() + frame * 4, 16, hipMemcpyDeviceToHost));
+        return ORBFE_OK;
+    }
+    if (stage == 101) { // rectangle candidates: AR_MAX_RECTS x ArRect (40 B)
+        ORBFE_HIP(hipMemcpy(out, h->d_rects.as<ArRect>() + (size_t)frame * AR_MAX_RECTS, sizeof(ArRect) * AR_MAX_RECTS,
+                            hipMemcpyDeviceToHost));
+        return ORBFE_OK;
+    }
+    return fail(ORBFE_ERR_INVALID, "debug_image: unknown stage %d", stage);
+}
+
+int orbfe_aruco_debug_kernel_times(orbfe_aruco* h, float* out_us, int capacity)
+{
+    if (!h) return fail(ORBFE_ERR_INVALID, "null handle");
+    if (!out_us) {
+        h->timer.enabled = capacity != 0;
+        return 0;
+    }
+    return h->timer.collect(out_us, capacity);
+}
+
+} // extern "C"

@@ -1,0 +1,843 @@
+// aruco_kernels.hip -- gfx950 kernels of the ArUco marker detector (DM_NORMAL + CORNER_LINES, the configuration of
+// reference src/Frame.cc:129-142).  Pipeline per batch of B same-sized frames:
+//
+//   k_adaptive_threshold  box-mean adaptive threshold, writes a BIT image (1 bit/px)       (markerdetector_impl.cpp:2983)
+//   k_half_area / resize  the detector's /2 pyramid used by the 35x35 warps                 (:1299-1488)
+//   k_contours            one workgroup per frame: bit image -> LDS, border starts, read-only border following,
+//                         length gate (> 70), approxPolyDP, 4-gon + convexity               (:3104-3556)
+//   k_prefilter           per frame: CCW orientation, near-duplicate and image-border filters  (:4347-5347)
+//   k_decode              per (frame, candidate): level pick, homography, 35x35 warp, Otsu, cell vote, dictionary
+//                                                                                            (:6448-6900, dictionary_based.cpp)
+//   k_finalize            per frame: rotate corners, sort by id, de-duplicate, contour-line corner refinement
+//                                                                                            (:6723-6858, :8140-8377, :8978-10044)
+// HBM-bound part: threshold (reads W*H bytes, writes W*H/8).  Everything after it works on the bit image in LDS or
+// on a few hundred contour points, so it is latency- rather than bandwidth-bound; see DESIGN.md.
+#include "aruco_kernels.hpp"
+
+namespace orbfe {
+
+__device__ __forceinline__ int a_lane_prefix(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+}
+
+// ---------------------------------------------------------------------------------------- threshold -----------
+// cv::adaptiveThreshold(MEAN_C, BINARY_INV, win, C): mean = round(boxsum / win^2) with BORDER_REPLICATE,
+// out = (src - mean <= -C).  Tile 64 x 16 per workgroup; one wave = one row of 64 px -> one 64-bit ballot store.
+#define TH_MAXR 7
+__global__ __launch_bounds__(256) void k_adaptive_threshold(ImgView src, int W, int H, int win, int C, double scale,
+                                                            uint32_t* __restrict__ bits, size_t bits_fstride, int wpr)
+{
+    __shared__ uint8_t sin[16 + 2 * TH_MAXR][64 + 2 * TH_MAXR + 2];
+    __shared__ uint16_t sh[16 + 2 * TH_MAXR][64];
+    const int r = win >> 1;
+    const int tx0 = blockIdx.x * 64, ty0 = blockIdx.y * 16, f = blockIdx.z;
+    const int tid = threadIdx.x;
+    const uint8_t* img = src.base + (size_t)f * src.fstride;
+    const int rows = 16 + 2 * r, cols = 64 + 2 * r;
+    for (int i = tid; i < rows * cols; i += 256) {
+        const int rr = i / cols, cc = i - rr * cols;
+        const int y = min(max(ty0 + rr - r, 0), H - 1), x = min(max(tx0 + cc - r, 0), W - 1);
+        sin[rr][cc] = img[(size_t)y * src.pitch + x];
+    }
+    __syncthreads();
+    for (int i = tid; i < rows * 64; i += 256) {
+        const int rr = i >> 6, cc = i & 63;
+        int s = 0;
+        for (int k = 0; k < win; k++) s += sin[rr][cc + k];
+        sh[rr][cc] = (uint16_t)s;
+    }
+    __syncthreads();
+    const int lane = tid & 63, wid = tid >> 6;
+    for (int ry = wid; ry < 16; ry += 4) {
+        const int y = ty0 + ry, x = tx0 + lane;
+        int s = 0;
+        for (int k = 0; k < win; k++) s += sh[ry + k][lane];
+        int mean = orbfe_round_d((double)s * scale);
+        mean = mean > 255 ? 255 : mean;
+        const int v = sin[ry + r][lane + r];
+        const bool on = (x < W) && (y < H) && (v - mean <= -C);
+        const unsigned long long m = __ballot(on);
+        if (y < H && lane < 2) {
+            const int word = (tx0 >> 5) + lane;
+            if (word < wpr) bits[(size_t)f * bits_fstride + (size_t)y * wpr + word] = (uint32_t)(m >> (32 * lane));
+        }
+    }
+}
+
+// exact 2x downscale = INTER_AREA 2x2 mean (what cv::resize(INTER_LINEAR) does for an exact factor of two)
+__global__ __launch_bounds__(256) void k_half_area(ImgView src, ImgView dst, int dw, int dh)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), f = blockIdx.z;
+    if (x >= dw || y >= dh) return;
+    const uint8_t* s0 = src.base + (size_t)f * src.fstride + (size_t)(2 * y) * src.pitch + 2 * x;
+    const uint8_t* s1 = s0 + src.pitch;
+    dst.base_w[(size_t)f * dst.fstride + (size_t)y * dst.pitch + x] = (uint8_t)((s0[0] + s0[1] + s1[0] + s1[1] + 2) >> 2);
+}
+
+// ---------------------------------------------------------------------------------------- contours ------------
+struct ApPt { int x, y; };
+
+// approxPolyDP (closed curve) by one wave; P = contour points (x | y<<16), n > 0.  Returns the number of
+// vertices (<= AP_OUT, or AP_OUT+1 on overflow) in `out` (LDS).  Reductions keep the FIRST maximum like the
+// serial loops of cv::approxPolyDP_ ("dist > max_dist").
+__device__ int approx_poly_wave(const uint32_t* __restrict__ P, int n, ApPt* out, int2* stack, int lane)
+{
+    auto rd = [&](int i) -> ApPt { const uint32_t v = P[i]; return ApPt{(int)(v & 0xffff), (int)(v >> 16)}; };
+    double eps = (double)n * 0.05;
+    eps *= eps;
+    int nout = 0, top = 0;
+    int pos = 0, right_start = 0;
+    bool le_eps = false;
+    ApPt start_pt{0, 0};
+    for (int it = 0; it < 3; it++) {
+        pos = (pos + right_start) % n;
+        start_pt = rd(pos);
+        // farthest point from start_pt among j = 1..n-1 at index (pos + j) % n ; first maximum wins
+        long long best = 0; // (dist << 20) | (0xfffff - j): maximise dist, then minimise j
+        for (int j0 = 1; j0 < n; j0 += 64) {
+            const int j = j0 + lane;
+            if (j < n) {
+                int idx = pos + j;
+                if (idx >= n) idx -= n;
+                const ApPt p = rd(idx);
+                const long long dx = p.x - start_pt.x, dy = p.y - start_pt.y;
+                const long long d = dx * dx + dy * dy;
+                const long long key = (d << 20) | (long long)(0xfffff - j);
+                if (d > 0 && key > best) best = key;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const long long t = __shfl_xor(best, o);
+            best = t > best ? t : best;
+        }
+        const long long max_dist = best >> 20;
+        right_start = best ? (int)(0xfffff - (best & 0xfffff)) : right_start; // no dist > 0: index unchanged
+        le_eps = (double)max_dist <= eps;
+        // pos returns to the start index after the sweep (READ_PT wrapped n times)
+    }
+    if (!le_eps) {
+        const int A = pos % n, Bi = (right_start + A) % n;
+        stack[top++] = make_int2(Bi, A); // right_slice
+        stack[top++] = make_int2(A, Bi); // slice (popped first)
+    } else {
+        out[nout++] = start_pt;
+    }
+    while (top > 0) {
+        const int2 sl = stack[--top];
+        const ApPt end_pt = rd(sl.y);
+        const ApPt sp = rd(sl.x);
+        int p1 = sl.x + 1;
+        if (p1 >= n) p1 = 0;
+        bool le;
+        int split = 0;
+        if (p1 != sl.y) {
+            const long long dx = end_pt.x - sp.x, dy = end_pt.y - sp.y;
+            const int cnt = (sl.y - p1 + n) % n; // points strictly between
+            long long best = 0;
+            for (int j0 = 0; j0 < cnt; j0 += 64) {
+                const int j = j0 + lane;
+                if (j < cnt) {
+                    int idx = p1 + j;
+                    if (idx >= n) idx -= n;
+                    const ApPt p = rd(idx);
+                    long long d = (long long)(p.y - sp.y) * dx - (long long)(p.x - sp.x) * dy;
+                    d = d < 0 ? -d : d;
+                    const long long key = (d << 20) | (long long)(0xfffff - j);
+                    if (d > 0 && key > best) best = key;
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const long long t = __shfl_xor(best, o);
+                best = t > best ? t : best;
+            }
+            const double md = (double)(best >> 20);
+            le = md * md <= eps * (double)(dx * dx + dy * dy);
+            if (best) {
+                split = p1 + (int)(0xfffff - (best & 0xfffff));
+                if (split >= n) split -= n;
+            }
+        } else {
+            le = true;
+        }
+        if (le) {
+            if (nout < AP_OUT) out[nout] = sp;
+            nout++;
+            if (nout > AP_OUT) return AP_OUT + 1;
+        } else {
+            if (top + 2 > AP_STACK) return AP_OUT + 1;
+            stack[top++] = make_int2(split, sl.y);
+            stack[top++] = make_int2(sl.x, split);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // clean-up pass (serial, tiny)
+    int new_count = nout;
+    const int cnt = nout;
+    if (cnt > 0) {
+        int ps = cnt - 1;
+        ApPt s = out[ps]; if (++ps >= cnt) ps = 0;
+        int wpos = ps;
+        ApPt pt = out[ps]; if (++ps >= cnt) ps = 0;
+        for (int i = 0; i < cnt && new_count > 2; i++) {
+            ApPt e = out[ps]; if (++ps >= cnt) ps = 0;
+            const double dx = e.x - s.x, dy = e.y - s.y;
+            const double dist = fabs((pt.x - s.x) * dy - (pt.y - s.y) * dx);
+            const double sip = (double)(pt.x - s.x) * (e.x - pt.x) + (double)(pt.y - s.y) * (e.y - pt.y);
+            if (dist * dist <= 0.5 * eps * (dx * dx + dy * dy) && dx != 0 && dy != 0 && sip >= 0) {
+                new_count--;
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) out[wpos] = e;
+                __builtin_amdgcn_wave_barrier();
+                s = e;
+                if (++wpos >= cnt) wpos = 0;
+                pt = out[ps]; if (++ps >= cnt) ps = 0;
+                i++;
+                continue;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) out[wpos] = pt;
+            __builtin_amdgcn_wave_barrier();
+            s = pt;
+            if (++wpos >= cnt) wpos = 0;
+            pt = e;
+        }
+    }
+    return new_count;
+}
+
+__device__ bool convex4(const ApPt* p)
+{
+    const int n = 4;
+    ApPt prev_pt = p[(n - 2 + n) % n], cur_pt = p[n - 1];
+    int dx0 = cur_pt.x - prev_pt.x, dy0 = cur_pt.y - prev_pt.y, orientation = 0;
+    for (int i = 0; i < n; i++) {
+        prev_pt = cur_pt;
+        cur_pt = p[i];
+        const int dx = cur_pt.x - prev_pt.x, dy = cur_pt.y - prev_pt.y;
+        const int dxdy0 = dx * dy0, dydx0 = dy * dx0;
+        orientation |= (dydx0 > dxdy0) ? 1 : ((dydx0 < dxdy0) ? 2 : 3);
+        if (orientation == 3) return false;
+        dx0 = dx;
+        dy0 = dy;
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(CT_THREADS) void k_contours(const uint32_t* __restrict__ gbits, size_t bits_fstride,
+                                                         int wpr_g, int W, int H, int lds_bits_words, int min_len,
+                                                         uint32_t* __restrict__ candq, size_t candq_fstride,
+                                                         int candq_cap, uint32_t* __restrict__ pool,
+                                                         size_t pool_fstride, int pool_cap,
+                                                         ArKept* __restrict__ kept_out, int kept_cap,
+                                                         ArRect* __restrict__ rects_out, int rect_cap,
+                                                         int32_t* __restrict__ counts /*per frame: [nkept, nrect, flags, ncand]*/,
+                                                         uint32_t* __restrict__ gpadded, size_t gpadded_fstride)
+{
+    extern __shared__ __align__(16) unsigned char ct_smem[];
+    __shared__ int s_ncand, s_next, s_nkept, s_total, s_flags, s_nrect;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, f = blockIdx.x;
+    const int wpr = (W + 2 + 31) >> 5, prow = H + 2;
+    // LDS carve-up: [bits][kept keys (u64) kept_cap][per-wave approx scratch]
+    // the padded bit image lives in LDS when it fits (lds_bits_words > 0), else in an HBM scratch (L2-resident)
+    uint32_t* lbits = lds_bits_words ? (uint32_t*)ct_smem : gpadded + (size_t)f * gpadded_fstride;
+    unsigned long long* kkey = (unsigned long long*)(ct_smem + (((size_t)lds_bits_words * 4 + 15) & ~(size_t)15));
+    int* klen = (int*)(kkey + kept_cap);
+    int* koff = klen + kept_cap;
+    int* rectflag = koff + kept_cap;
+    ApPt* ap_out = (ApPt*)(rectflag + kept_cap);
+    int2* ap_stack = (int2*)(ap_out + CT_WAVES * AP_OUT);
+    const uint32_t* gb = gbits + (size_t)f * bits_fstride;
+    uint32_t* cq = candq + (size_t)f * candq_fstride;
+    uint32_t* pl = pool + (size_t)f * pool_fstride;
+
+    if (tid == 0) { s_ncand = 0; s_next = 0; s_nkept = 0; s_total = 0; s_flags = 0; s_nrect = 0; }
+    // ---- (a) padded bit image into LDS: pixel (x, y) -> bit x+1 of row y+1
+    for (int i = tid; i < wpr * prow; i += CT_THREADS) {
+        const int py = i / wpr, j = i - py * wpr;
+        uint32_t v = 0;
+        if (py >= 1 && py <= H) {
+            const uint32_t* row = gb + (size_t)(py - 1) * wpr_g;
+            const uint32_t cur = j < wpr_g ? row[j] : 0u;
+            const uint32_t prv = (j >= 1 && j - 1 < wpr_g) ? row[j - 1] : 0u;
+            v = (cur << 1) | (prv >> 31);
+        }
+        lbits[i] = v;
+    }
+    __threadfence_block();
+    __syncthreads();
+    const BitImage im{lbits, wpr, W, H};
+
+    // ---- (b) border start candidates (aruco_trace.hpp): bit tricks over whole words
+    for (int i = tid; i < wpr * H; i += CT_THREADS) {
+        const int py = 1 + i / wpr, j = i % wpr;
+        const uint32_t* row = lbits + py * wpr;
+        const uint32_t* up = row - wpr;
+        const uint32_t cur = row[j], upw = up[j];
+        const uint32_t cur_l = (cur << 1) | (j ? row[j - 1] >> 31 : 0u);
+        const uint32_t up_l = (upw << 1) | (j ? up[j - 1] >> 31 : 0u);
+        const uint32_t up_r = (upw >> 1) | (j + 1 < wpr ? up[j + 1] << 31 : 0u);
+        uint32_t outer = cur & ~cur_l & ~up_l & ~upw & ~up_r;
+        uint32_t hole = ~cur & cur_l & upw;
+        while (outer | hole) {
+            const int is_hole = outer ? 0 : 1;
+            uint32_t& m = outer ? outer : hole;
+            const int b = __ffs(m) - 1;
+            m &= m - 1;
+            const int px = j * 32 + b;
+            const int slot = atomicAdd(&s_ncand, 1);
+            if (slot < candq_cap) cq[slot] = (uint32_t)px | ((uint32_t)py << 13) | ((uint32_t)is_hole << 26);
+        }
+    }
+    __syncthreads();
+    if (tid == 0 && s_ncand > candq_cap) { s_flags |= 1; s_ncand = candq_cap; }
+    __syncthreads();
+    const int ncand = s_ncand;
+
+    // ---- (c) follow every candidate read-only; keep canonical borders longer than min_len
+    for (;;) {
+        const int c = atomicAdd(&s_next, 1);
+        if (c >= ncand) break;
+        const uint32_t q = cq[c];
+        const int px = q & 0x1fff, py = (q >> 13) & 0x1fff, is_hole = q >> 26;
+        const int n = trace_border(im, px - is_hole, py, is_hole, nullptr, 0, 1 << 24);
+        if (n > min_len) {
+            const int k = atomicAdd(&s_nkept, 1);
+            if (k < kept_cap) {
+                // discovery order = raster order of the transition pixel; findContours returns the reverse
+                kkey[k] = ((unsigned long long)(0xffffffffu - (uint32_t)(py * 65536 + px)) << 32) |
+                          ((unsigned long long)n << 8) | (unsigned)is_hole;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0 && s_nkept > kept_cap) { s_flags |= 2; s_nkept = kept_cap; }
+    __syncthreads();
+    const int nkept = s_nkept;
+    // ---- (d) sort kept ascending by (~raster key) = reverse discovery order; bitonic over a power of two
+    int Pn = 1;
+    while (Pn < nkept) Pn <<= 1;
+    for (int i = nkept + tid; i < Pn; i += CT_THREADS) kkey[i] = ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= Pn; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (Pn >> 1); t += CT_THREADS) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int l = i | j;
+                const unsigned long long a = kkey[i], b = kkey[l];
+                const bool up = ((i & k) == 0);
+                if ((a > b) == up) { kkey[i] = b; kkey[l] = a; }
+            }
+            __syncthreads();
+        }
+    if (tid == 0) { // exclusive scan of the lengths (nkept is small)
+        int acc = 0;
+        for (int k = 0; k < nkept; k++) {
+            const int n = (int)((kkey[k] >> 8) & 0xffffff);
+            klen[k] = n;
+            koff[k] = acc;
+            acc += n;
+            if (acc > pool_cap) { s_flags |= 4; klen[k] = 0; acc -= n; }
+        }
+        s_total = acc;
+        s_next = 0;
+    }
+    __syncthreads();
+    // ---- (e) follow the kept borders again, this time writing their points
+    for (;;) {
+        const int k = atomicAdd(&s_next, 1);
+        if (k >= nkept) break;
+        if (klen[k] == 0) continue;
+        const unsigned long long key = kkey[k];
+        const uint32_t pos = 0xffffffffu - (uint32_t)(key >> 32);
+        const int py = pos >> 16, px = pos & 0xffff, is_hole = (int)(key & 1);
+        trace_border(im, px - is_hole, py, is_hole, pl + koff[k], klen[k], 1 << 24);
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- (f) approxPolyDP(eps = 0.05 * len) -> 4 vertices and convex -> rectangle candidate
+    for (int k = wid; k < nkept; k += CT_WAVES) {
+        int ok = 0;
+        ApPt* o = ap_out + wid * AP_OUT;
+        if (klen[k] > 0) {
+            const int nv = approx_poly_wave(pl + koff[k], klen[k], o, ap_stack + wid * AP_STACK, lane);
+            __builtin_amdgcn_wave_barrier();
+            ok = (nv == 4) && convex4(o);
+        }
+        if (lane == 0) {
+            rectflag[k] = ok;
+            if (ok && k < kept_cap) {
+                ArKept kk;
+                kk.off = koff[k]; kk.len = klen[k];
+                for (int j = 0; j < 4; j++) { kk.vx[j] = (short)o[j].x; kk.vy[j] = (short)o[j].y; }
+                kept_out[(size_t)f * kept_cap + k] = kk;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) { // ordered compaction of the rectangles (a few dozen)
+        int nr = 0;
+        for (int k = 0; k < nkept; k++)
+            if (rectflag[k]) {
+                if (nr < rect_cap) {
+                    const ArKept kk = kept_out[(size_t)f * kept_cap + k];
+                    ArRect r;
+                    for (int j = 0; j < 4; j++) { r.c[j][0] = (float)kk.vx[j]; r.c[j][1] = (float)kk.vy[j]; }
+                    r.off = kk.off; r.len = kk.len;
+                    rects_out[(size_t)f * rect_cap + nr] = r;
+                } else s_flags |= 8;
+                nr++;
+            }
+        counts[f * 4 + 0] = nkept;
+        counts[f * 4 + 1] = min(nr, rect_cap);
+        counts[f * 4 + 2] = s_flags;
+        counts[f * 4 + 3] = ncand;
+    }
+}
+
+// ---------------------------------------------------------------------------------------- prefilter -----------
+__device__ __forceinline__ int ar_perimeter(const float c[4][2])
+{
+    int sum = 0;
+    for (int i = 0; i < 4; i++) {
+        const int i2 = (i + 1) & 3;
+        const float dx = c[i][0] - c[i2][0], dy = c[i][1] - c[i2][1];
+        sum += (int)__fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+    }
+    return sum;
+}
+
+// prefilterCandidates: one workgroup (256 threads) per frame
+__global__ __launch_bounds__(256) void k_prefilter(ArRect* __restrict__ rects, int rect_cap, const int32_t* __restrict__ counts,
+                                                   int W, int H, int too_near, int32_t* __restrict__ cand_idx,
+                                                   int32_t* __restrict__ ncand_out)
+{
+    __shared__ int s_rm[AR_MAX_RECTS];
+    __shared__ int s_per[AR_MAX_RECTS];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int n = counts[f * 4 + 1];
+    ArRect* R = rects + (size_t)f * rect_cap;
+    for (int i = tid; i < n; i += 256) {
+        ArRect r = R[i];
+        const double dx1 = r.c[1][0] - r.c[0][0], dy1 = r.c[1][1] - r.c[0][1];
+        const double dx2 = r.c[2][0] - r.c[0][0], dy2 = r.c[2][1] - r.c[0][1];
+        const double o = (dx1 * dy2) - (dy1 * dx2);
+        if (o < 0.0) {
+            const float tx = r.c[1][0], ty = r.c[1][1];
+            r.c[1][0] = r.c[3][0]; r.c[1][1] = r.c[3][1];
+            r.c[3][0] = tx; r.c[3][1] = ty;
+            R[i] = r;
+        }
+        s_per[i] = ar_perimeter(r.c);
+        s_rm[i] = 0;
+    }
+    __threadfence_block();
+    __syncthreads();
+    const float tn = (float)too_near;
+    for (int p = tid; p < n * n; p += 256) {
+        const int i = p / n, j = p - i * n;
+        if (j <= i) continue;
+        bool near = true;
+        for (int k = 0; k < 4; k++) {
+            const float dx = R[i].c[k][0] - R[j].c[k][0], dy = R[i].c[k][1] - R[j].c[k][1];
+            const float d = (float)sqrt((double)dx * dx + (double)dy * dy);
+            near = near && (d < tn);
+        }
+        if (near) {
+            if (s_per[i] > s_per[j]) atomicOr(&s_rm[j], 1);
+            else atomicOr(&s_rm[i], 1);
+        }
+    }
+    __syncthreads();
+    const int bx = (int)(0.015f * (float)W), by = (int)(0.015f * (float)H);
+    for (int i = tid; i < n; i += 256) {
+        bool rm = false;
+        for (int k = 0; k < 4; k++) {
+            const float x = R[i].c[k][0], y = R[i].c[k][1];
+            rm = rm || x < (float)bx || y < (float)by || x > (float)(W - bx) || y > (float)(H - by);
+        }
+        if (rm) s_rm[i] = 1;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int m = 0;
+        for (int i = 0; i < n; i++)
+            if (!s_rm[i]) cand_idx[(size_t)f * rect_cap + m++] = i;
+        ncand_out[f] = m;
+    }
+}
+
+// ---------------------------------------------------------------------------------------- decode --------------
+__device__ bool solve8(double* A, double* b)
+{
+    const int n = 8;
+    for (int c = 0; c < n; c++) {
+        int piv = c;
+        for (int r = c + 1; r < n; r++)
+            if (fabs(A[r * n + c]) > fabs(A[piv * n + c])) piv = r;
+        if (A[piv * n + c] == 0.0) return false;
+        if (piv != c) {
+            for (int k = 0; k < n; k++) { const double t = A[c * n + k]; A[c * n + k] = A[piv * n + k]; A[piv * n + k] = t; }
+            const double t = b[c]; b[c] = b[piv]; b[piv] = t;
+        }
+        for (int r = c + 1; r < n; r++) {
+            const double fct = A[r * n + c] / A[c * n + c];
+            if (fct == 0.0) continue;
+            for (int k = c; k < n; k++) A[r * n + k] -= fct * A[c * n + k];
+            b[r] -= fct * b[c];
+        }
+    }
+    for (int r = n - 1; r >= 0; r--) {
+        double s = b[r];
+        for (int k = r + 1; k < n; k++) s -= A[r * n + k] * b[k];
+        b[r] = s / A[r * n + r];
+    }
+    return true;
+}
+
+__device__ __forceinline__ int ar_sat_int(double v)
+{
+    if (v <= -2147483648.0) return (int)0x80000000;
+    if (v >= 2147483647.0) return 2147483647;
+    return orbfe_round_d(v);
+}
+
+// One workgroup (256 threads) per (candidate slot, frame).
+__global__ __launch_bounds__(256) void k_decode(ImgView src0, ImgView pyr, const ArLevel* __restrict__ levels,
+                                                int nlevels, const ArRect* __restrict__ rects, int rect_cap,
+                                                const int32_t* __restrict__ cand_idx,
+                                                const int32_t* __restrict__ ncand, int S, int nb,
+                                                const unsigned long long* __restrict__ codes, int ncodes,
+                                                int32_t* __restrict__ result /*per slot: id, nrot*/, int W0)
+{
+    __shared__ double sA[64], sB[8], sM[9];
+    __shared__ int s_ok, s_th, s_found;
+    __shared__ uint8_t spatch[40 * 40];
+    __shared__ int s_hist[256];
+    __shared__ int s_ones[64], s_tot[64];
+    __shared__ unsigned long long s_ids[4];
+    const int f = blockIdx.y, tid = threadIdx.x;
+    const int nc = ncand[f];
+    for (int slot = blockIdx.x; slot < nc; slot += gridDim.x) {
+    __syncthreads(); // previous iteration's LDS state is dead
+    int32_t* res = result + ((size_t)f * rect_cap + slot) * 2;
+    const ArRect r = rects[(size_t)f * rect_cap + cand_idx[(size_t)f * rect_cap + slot]];
+    // pyramid level: largest p with area / 4^p >= S^2 (markerdetector_impl.cpp:6507-6586)
+    const float v01x = r.c[1][0] - r.c[0][0], v01y = r.c[1][1] - r.c[0][1];
+    const float v03x = r.c[3][0] - r.c[0][0], v03y = r.c[3][1] - r.c[0][1];
+    const float area1 = fabsf(__fsub_rn(__fmul_rn(v01x, v03y), __fmul_rn(v01y, v03x)));
+    const float v21x = r.c[1][0] - r.c[2][0], v21y = r.c[1][1] - r.c[2][1];
+    const float v23x = r.c[3][0] - r.c[2][0], v23y = r.c[3][1] - r.c[2][1];
+    const float area2 = fabsf(__fsub_rn(__fmul_rn(v21x, v23y), __fmul_rn(v21y, v23x)));
+    const float area = __fdiv_rn(__fadd_rn(area2, area1), 2.f);
+    const float desired = __fmul_rn((float)S, (float)S);
+    int lvl = 0;
+    double p4 = 4.0;
+    for (int p = 1; p < nlevels; p++, p4 *= 4.0) {
+        if ((double)area / p4 >= (double)desired) lvl = p;
+        else break;
+    }
+    const ArLevel L = levels[lvl];
+    const float ratio = __fdiv_rn((float)L.w, (float)W0);
+    if (tid == 0) {
+        const float dstx[4] = {0.f, (float)(S - 1), (float)(S - 1), 0.f};
+        const float dsty[4] = {0.f, 0.f, (float)(S - 1), (float)(S - 1)};
+        for (int i = 0; i < 64; i++) sA[i] = 0.0;
+        for (int i = 0; i < 4; i++) {
+            const float qx = __fmul_rn(r.c[i][0], ratio), qy = __fmul_rn(r.c[i][1], ratio);
+            sA[i * 8 + 0] = sA[(i + 4) * 8 + 3] = qx;
+            sA[i * 8 + 1] = sA[(i + 4) * 8 + 4] = qy;
+            sA[i * 8 + 2] = sA[(i + 4) * 8 + 5] = 1;
+            sA[i * 8 + 6] = -(double)qx * dstx[i];
+            sA[i * 8 + 7] = -(double)qy * dstx[i];
+            sA[(i + 4) * 8 + 6] = -(double)qx * dsty[i];
+            sA[(i + 4) * 8 + 7] = -(double)qy * dsty[i];
+            sB[i] = dstx[i];
+            sB[i + 4] = dsty[i];
+        }
+        bool ok = solve8(sA, sB);
+        if (ok) {
+            const double M[9] = {sB[0], sB[1], sB[2], sB[3], sB[4], sB[5], sB[6], sB[7], 1.0};
+            const double det = M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) +
+                               M[2] * (M[3] * M[7] - M[4] * M[6]);
+            if (det == 0.0) ok = false;
+            else {
+                const double d = 1.0 / det;
+                sM[0] = (M[4] * M[8] - M[5] * M[7]) * d;
+                sM[1] = (M[2] * M[7] - M[1] * M[8]) * d;
+                sM[2] = (M[1] * M[5] - M[2] * M[4]) * d;
+                sM[3] = (M[5] * M[6] - M[3] * M[8]) * d;
+                sM[4] = (M[0] * M[8] - M[2] * M[6]) * d;
+                sM[5] = (M[2] * M[3] - M[0] * M[5]) * d;
+                sM[6] = (M[3] * M[7] - M[4] * M[6]) * d;
+                sM[7] = (M[1] * M[6] - M[0] * M[7]) * d;
+                sM[8] = (M[0] * M[4] - M[1] * M[3]) * d;
+            }
+        }
+        s_ok = ok;
+    }
+    for (int i = tid; i < 256; i += 256) s_hist[i] = 0;
+    if (tid < 64) { s_ones[tid] = 0; s_tot[tid] = 0; }
+    __syncthreads();
+    if (!s_ok) {
+        if (tid == 0) { res[0] = -1; res[1] = 0; }
+        continue;
+    }
+    const uint8_t* img = (lvl == 0) ? src0.base + (size_t)f * src0.fstride : pyr.base + (size_t)f * pyr.fstride + L.off;
+    const int pitch = (lvl == 0) ? src0.pitch : L.pitch;
+    // warpPerspective(INTER_LINEAR, BORDER_CONSTANT 0): 1/32-px coordinates, 15-bit bilinear weights
+    for (int i = tid; i < S * S; i += 256) {
+        const int y = i / S, x = i - y * S;
+        const double X0 = sM[0] * 0 + sM[1] * y + sM[2];
+        const double Y0 = sM[3] * 0 + sM[4] * y + sM[5];
+        const double W0d = sM[6] * 0 + sM[7] * y + sM[8];
+        double Wd = W0d + sM[6] * x;
+        Wd = Wd ? 32.0 / Wd : 0;
+        const double fX = fmax(-2147483648.0, fmin(2147483647.0, (X0 + sM[0] * x) * Wd));
+        const double fY = fmax(-2147483648.0, fmin(2147483647.0, (Y0 + sM[3] * x) * Wd));
+        const int X = ar_sat_int(fX), Y = ar_sat_int(fY);
+        int sx = X >> 5, sy = Y >> 5;
+        sx = sx < -32768 ? -32768 : sx > 32767 ? 32767 : sx;
+        sy = sy < -32768 ? -32768 : sy > 32767 ? 32767 : sy;
+        const int ax = X & 31, ay = Y & 31;
+        const int w00 = (32 - ax) * (32 - ay) * 32, w01 = ax * (32 - ay) * 32, w10 = (32 - ax) * ay * 32, w11 = ax * ay * 32;
+        auto px = [&](int xx, int yy) -> int {
+            if (xx < 0 || yy < 0 || xx >= L.w || yy >= L.h) return 0;
+            return img[(size_t)yy * pitch + xx];
+        };
+        int v = px(sx, sy) * w00 + px(sx + 1, sy) * w01 + px(sx, sy + 1) * w10 + px(sx + 1, sy + 1) * w11;
+        v = (v + (1 << 14)) >> 15;
+        v = v > 255 ? 255 : v;
+        spatch[i] = (uint8_t)v;
+        atomicAdd(&s_hist[v], 1);
+    }
+    __syncthreads();
+    if (tid == 0) { // getThreshVal_Otsu_8u (serial, 256 bins, double)
+        const int n = S * S;
+        double mu = 0, scale = 1. / n;
+        for (int i = 0; i < 256; i++) mu += i * (double)s_hist[i];
+        mu *= scale;
+        double mu1 = 0, q1 = 0, max_sigma = 0, max_val = 0;
+        for (int i = 0; i < 256; i++) {
+            const double p_i = s_hist[i] * scale;
+            mu1 *= q1;
+            q1 += p_i;
+            const double q2 = 1. - q1;
+            if (fmin(q1, q2) < 1.1920928955078125e-07 || fmax(q1, q2) > 1. - 1.1920928955078125e-07) continue;
+            mu1 = (mu1 + i * p_i) / q1;
+            const double mu2 = (mu - q1 * mu1) / q2;
+            const double sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2);
+            if (sigma > max_sigma) { max_sigma = sigma; max_val = i; }
+        }
+        s_th = (int)max_val;
+    }
+    __syncthreads();
+    const int th = s_th, n = nb + 2;
+    for (int i = tid; i < S * S; i += 256) {
+        const int y = i / S, x = i - y * S;
+        const int my = (int)__fdiv_rn(__fmul_rn((float)n, (float)y), (float)S);
+        const int mx = (int)__fdiv_rn(__fmul_rn((float)n, (float)x), (float)S);
+        if (spatch[i] > th) atomicAdd(&s_ones[my * n + mx], 1);
+        atomicAdd(&s_tot[my * n + mx], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint8_t bits[64], inner[36], tmp[36];
+        bool ok = true;
+        for (int i = 0; i < n * n; i++) bits[i] = s_ones[i] > s_tot[i] / 2 ? 1 : 0;
+        for (int y = 0; y < n && ok; y++) {
+            const int inc = (y == 0 || y == n - 1) ? 1 : n - 1;
+            for (int x = 0; x < n; x += inc)
+                if (bits[y * n + x] != 0) { ok = false; break; }
+        }
+        if (ok) {
+            for (int y = 0; y < nb; y++)
+                for (int x = 0; x < nb; x++) inner[y * nb + x] = bits[(y + 1) * n + (x + 1)];
+            for (int rr = 0; rr < 4; rr++) {
+                unsigned long long v = 0;
+                int b = 0;
+                for (int y = nb - 1; y >= 0; y--)
+                    for (int x = nb - 1; x >= 0; x--) v |= (unsigned long long)inner[y * nb + x] << b++;
+                s_ids[rr] = v;
+                for (int i = 0; i < nb; i++)
+                    for (int j = 0; j < nb; j++) tmp[i * nb + j] = inner[(nb - j - 1) * nb + i];
+                for (int i = 0; i < nb * nb; i++) inner[i] = tmp[i];
+            }
+            if (s_ids[0] == 0) ok = false;
+        }
+        s_ok = ok;
+    }
+    __syncthreads();
+    int id = -1, nrot = 0;
+    if (s_ok) {
+        // first rotation whose code is in the dictionary; id = first index holding that code (map.insert semantics)
+        for (int rr = 0; rr < 4; rr++) {
+            const unsigned long long want = s_ids[rr];
+            if (tid == 0) s_found = 0x7fffffff;
+            __syncthreads();
+            int best = 0x7fffffff;
+            for (int i = tid; i < ncodes; i += 256)
+                if (codes[i] == want) best = min(best, i);
+            if (best != 0x7fffffff) atomicMin(&s_found, best);
+            __syncthreads();
+            const int got = s_found;
+            __syncthreads();
+            if (got != 0x7fffffff) { id = got; nrot = rr; break; }
+        }
+    }
+    if (tid == 0) { res[0] = id; res[1] = nrot; }
+    } // slot loop
+}
+
+// ---------------------------------------------------------------------------------------- finalize ------------
+// interpolate2Dline + getCrossPoint in double (sums of integer coordinates are exact, so the reduction order is free)
+__device__ void fit_line(double n, double su, double sv, double suu, double suv, bool xdom, float line[3])
+{
+    const double det = n * suu - su * su;
+    double pa, qa;
+    if (fabs(det) > 1e-9 * fmax(1.0, n * suu)) {
+        pa = (n * suv - su * sv) / det;
+        qa = (sv * suu - su * suv) / det;
+    } else {
+        const double um = su / n, vm = sv / n;
+        pa = vm * um / (um * um + 1.0);
+        qa = vm / (um * um + 1.0);
+    }
+    if (xdom) { line[0] = (float)pa; line[1] = -1.f; line[2] = (float)qa; }
+    else { line[0] = -1.f; line[1] = (float)pa; line[2] = (float)qa; }
+}
+
+// One workgroup (256 threads) per frame.
+__global__ __launch_bounds__(256) void k_finalize(const ArRect* __restrict__ rects, int rect_cap,
+                                                  const int32_t* __restrict__ cand_idx,
+                                                  const int32_t* __restrict__ ncand, const int32_t* __restrict__ result,
+                                                  const uint32_t* __restrict__ pool, size_t pool_fstride,
+                                                  orbfe_marker* __restrict__ out, int out_cap,
+                                                  int32_t* __restrict__ n_out)
+{
+    __shared__ int s_id[AR_MAX_RECTS], s_src[AR_MAX_RECTS], s_rot[AR_MAX_RECTS], s_per[AR_MAX_RECTS], s_rm[AR_MAX_RECTS];
+    __shared__ float s_c[AR_MAX_RECTS][4][2];
+    __shared__ int s_n;
+    __shared__ unsigned long long s_best[4];
+    __shared__ double s_sum[4][5];
+    __shared__ float s_ext[4][4];
+    __shared__ float s_line[4][3];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int nc = ncand[f];
+    const ArRect* R = rects + (size_t)f * rect_cap;
+    if (tid == 0) {
+        // detected markers in candidate order, corners rotated by 4 - nRot (:6723-6823), then a stable sort by id
+        int m = 0;
+        for (int s = 0; s < nc; s++) {
+            const int id = result[((size_t)f * rect_cap + s) * 2], rot = result[((size_t)f * rect_cap + s) * 2 + 1];
+            if (id < 0) continue;
+            s_id[m] = id; s_src[m] = cand_idx[(size_t)f * rect_cap + s]; s_rot[m] = rot;
+            m++;
+        }
+        for (int i = 1; i < m; i++) { // insertion sort: stable
+            const int id = s_id[i], sr = s_src[i], ro = s_rot[i];
+            int j = i - 1;
+            while (j >= 0 && s_id[j] > id) { s_id[j + 1] = s_id[j]; s_src[j + 1] = s_src[j]; s_rot[j + 1] = s_rot[j]; j--; }
+            s_id[j + 1] = id; s_src[j + 1] = sr; s_rot[j + 1] = ro;
+        }
+        for (int i = 0; i < m; i++) {
+            const ArRect& r = R[s_src[i]];
+            // std::rotate(begin, begin + 4 - nRot, end): new[k] = old[(k + 4 - nRot) % 4]
+            for (int k = 0; k < 4; k++) {
+                const int o = (k + 4 - s_rot[i]) & 3;
+                s_c[i][k][0] = r.c[o][0];
+                s_c[i][k][1] = r.c[o][1];
+            }
+            s_per[i] = ar_perimeter(s_c[i]);
+            s_rm[i] = 0;
+        }
+        for (int i = 0; i < m - 1; i++) // same id: keep the larger perimeter (:8153-8365)
+            for (int j = i + 1; j < m && !s_rm[i]; j++)
+                if (s_id[i] == s_id[j]) {
+                    if (s_per[i] < s_per[j]) s_rm[i] = 1;
+                    else s_rm[j] = 1;
+                }
+        s_n = m;
+    }
+    __syncthreads();
+    const int m = s_n;
+    int written = 0;
+    for (int i = 0; i < m; i++) {
+        if (s_rm[i]) continue;
+        // ---- refineCornerWithContourLines (:8978-10044)
+        const ArRect& r = R[s_src[i]];
+        const uint32_t* P = pool + (size_t)f * pool_fstride + r.off;
+        const int len = r.len;
+        if (tid < 4) s_best[tid] = ~0ull;
+        __syncthreads();
+        // nearest contour point to each corner, first minimum wins
+        {
+            unsigned long long b[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+            for (int j = tid; j < len; j += 256) {
+                const uint32_t v = P[j];
+                const float x = (float)(v & 0xffff), y = (float)(v >> 16);
+                for (int k = 0; k < 4; k++) {
+                    const float dx = x - s_c[i][k][0], dy = y - s_c[i][k][1];
+                    const float d = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)j;
+                    b[k] = key < b[k] ? key : b[k];
+                }
+            }
+            for (int k = 0; k < 4; k++) atomicMin(&s_best[k], b[k]);
+        }
+        __syncthreads();
+        int ci[4];
+        for (int k = 0; k < 4; k++) ci[k] = (int)(s_best[k] & 0xffffffffu);
+        bool inverse;
+        if ((ci[1] > ci[0]) && (ci[2] > ci[1] || ci[2] < ci[0])) inverse = false;
+        else if (ci[2] > ci[1] && ci[2] < ci[0]) inverse = false;
+        else inverse = true;
+        // the four point runs; thread l < 4 walks run l exactly like the reference loop (a few hundred steps)
+        if (tid < 4) {
+            const int l = tid, inc = inverse ? -1 : 1, target = ci[(l + 1) & 3];
+            double su = 0, sv = 0, sxx = 0, syy = 0, sxy = 0, cnt = 0;
+            float minX = 0, maxX = 0, minY = 0, maxY = 0;
+            int guard = 0;
+            for (int j = ci[l]; j != target && guard < 2 * len + 4; j += inc, guard++) {
+                if (j == len && !inverse) j = 0;
+                else if (j == 0 && inverse) j = len - 1;
+                const uint32_t v = P[j];
+                const float x = (float)(v & 0xffff), y = (float)(v >> 16);
+                if (cnt == 0) { minX = maxX = x; minY = maxY = y; }
+                else { minX = fminf(minX, x); maxX = fmaxf(maxX, x); minY = fminf(minY, y); maxY = fmaxf(maxY, y); }
+                su += x; sv += y; sxx += (double)x * x; syy += (double)y * y; sxy += (double)x * y;
+                cnt += 1;
+                if (j == target) break;
+            }
+            if (cnt == 0) { s_line[l][0] = s_line[l][1] = s_line[l][2] = 0.f; }
+            else {
+                const bool xdom = (maxX - minX > maxY - minY);
+                if (xdom) fit_line(cnt, su, sv, sxx, sxy, true, s_line[l]);
+                else fit_line(cnt, sv, su, syy, sxy, false, s_line[l]);
+            }
+        }
+        __syncthreads();
+        if (tid == 0 && written < out_cap) {
+            orbfe_marker mk;
+            mk.id = s_id[i];
+            for (unsigned k = 0; k < 4; k++) {
+                const float* l1 = s_line[(k - 1) % 4];
+                const float* l2 = s_line[k];
+                const double a = l1[0], b = l1[1], c = l2[0], d = l2[1], e = -(double)l1[2], g = -(double)l2[2];
+                const double det = a * d - b * c;
+                float x = 0.f, y = 0.f;
+                if (det != 0.0) { x = (float)((e * d - b * g) / det); y = (float)((a * g - e * c) / det); }
+                mk.corners[k][0] = x;
+                mk.corners[k][1] = y;
+            }
+            out[(size_t)f * out_cap + written] = mk;
+        }
+        written++;
+        __syncthreads();
+    }
+    if (tid == 0) n_out[f] = written < out_cap ? written : out_cap;
+}
+
+} // namespace orbfe

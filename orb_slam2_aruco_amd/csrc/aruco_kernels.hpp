@@ -1,0 +1,61 @@
+// aruco_kernels.hpp -- device-side structs and kernel declarations of the ArUco detector.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "aruco_trace.hpp"
+#include "orb_kernels.hpp" // ImgView, k_resize_level
+
+namespace orbfe {
+
+#define AR_MAX_RECTS 256
+#define AR_MAX_KEPT 1024
+
+// a border that passed the length gate and the 4-gon/convexity test
+struct ArKept {
+    int off, len;     // its points inside the frame's point pool
+    short vx[4], vy[4];
+};
+// rectangle candidate (MarkerCandidate): corners + contour
+struct ArRect {
+    float c[4][2];
+    int off, len;
+};
+// one level of the detector's /2 pyramid
+struct ArLevel {
+    int w, h, pitch;
+    long long off; // byte offset inside a frame's pyramid block (level 0 is the input image)
+};
+
+__global__ void k_adaptive_threshold(ImgView src, int W, int H, int win, int C, double scale, uint32_t* bits,
+                                     size_t bits_fstride, int wpr);
+__global__ void k_half_area(ImgView src, ImgView dst, int dw, int dh);
+__global__ void k_contours(const uint32_t* gbits, size_t bits_fstride, int wpr_g, int W, int H, int lds_bits_words,
+                           int min_len, uint32_t* candq, size_t candq_fstride, int candq_cap, uint32_t* pool,
+                           size_t pool_fstride, int pool_cap, ArKept* kept_out, int kept_cap, ArRect* rects_out,
+                           int rect_cap, int32_t* counts, uint32_t* gpadded, size_t gpadded_fstride);
+__global__ void k_prefilter(ArRect* rects, int rect_cap, const int32_t* counts, int W, int H, int too_near,
+                            int32_t* cand_idx, int32_t* ncand_out);
+__global__ void k_decode(ImgView src0, ImgView pyr, const ArLevel* levels, int nlevels, const ArRect* rects,
+                         int rect_cap, const int32_t* cand_idx, const int32_t* ncand, int S, int nb,
+                         const unsigned long long* codes, int ncodes, int32_t* result, int W0);
+__global__ void k_finalize(const ArRect* rects, int rect_cap, const int32_t* cand_idx, const int32_t* ncand,
+                           const int32_t* result, const uint32_t* pool, size_t pool_fstride, orbfe_marker* out,
+                           int out_cap, int32_t* n_out);
+
+#define CT_THREADS 1024
+#define CT_WAVES (CT_THREADS / 64)
+#define AP_STACK 64
+#define AP_OUT 64
+
+inline size_t contours_lds_bytes(int lds_bits_words, int kept_cap)
+{
+    size_t b = ((size_t)lds_bits_words * 4 + 15) & ~(size_t)15;
+    b += (size_t)kept_cap * 8;      // keys
+    b += (size_t)kept_cap * 4 * 3;  // len, off, rect flag
+    b += (size_t)CT_WAVES * AP_OUT * 8;
+    b += (size_t)CT_WAVES * AP_STACK * 8;
+    return b + 16;
+}
+
+} // namespace orbfe

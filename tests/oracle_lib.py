@@ -194,3 +194,74 @@ def search_for_initialization(k1, d1, k2, d2, cols, rows, prev=None, window=100,
     n = L.oracle_search_for_initialization(_p(k1), _p(d1), len(k1), _p(k2), _p(d2), len(k2), cols, rows, _p(prev),
                                            _p(m), window, nnratio, int(check_ori))
     return n, m, prev
+
+
+class ArucoOracle:
+    def __init__(self, dictionary="ARUCO"):
+        self.L = lib()
+        self.h = self.L.oracle_aruco_create(dictionary.encode())
+        if not self.h:
+            raise ValueError("unknown dictionary " + dictionary)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.oracle_aruco_destroy(self.h)
+            self.h = None
+
+    def detect(self, img, capacity=256):
+        img = np.ascontiguousarray(img, np.uint8)
+        out = np.zeros(capacity, MARKER_DTYPE)
+        n = self.L.oracle_aruco_detect(self.h, _p(img), img.shape[0], img.shape[1], img.strides[0], _p(out), capacity)
+        return out[:min(n, capacity)].copy()
+
+    def stage_image(self, stage):
+        w, h = C.c_int(), C.c_int()
+        if self.L.oracle_aruco_stage_image(self.h, stage, None, C.byref(w), C.byref(h)) != 0:
+            return None
+        out = np.zeros((h.value, w.value), np.uint8)
+        self.L.oracle_aruco_stage_image(self.h, stage, _p(out), C.byref(w), C.byref(h))
+        return out
+
+    def stage_count(self, which):
+        return self.L.oracle_aruco_stage_count(self.h, which)
+
+    def candidates(self, which):
+        n = self.L.oracle_aruco_candidates(self.h, which, None, 0)
+        out = np.zeros((max(n, 1), 9), np.float32)
+        self.L.oracle_aruco_candidates(self.h, which, _p(out), n)
+        return out[:n]
+
+    def decode(self, patch):
+        patch = np.ascontiguousarray(patch, np.uint8)
+        rot = C.c_int(0)
+        i = self.L.oracle_decode_marker(self.h, _p(patch), patch.shape[0], C.byref(rot))
+        return i, rot.value
+
+
+def adaptive_threshold(img, win, Cc=7):
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.zeros_like(img)
+    lib().oracle_adaptive_threshold(_p(img), img.shape[1], img.shape[0], _p(out), win, Cc)
+    return out
+
+
+def find_contours(binimg, max_contours=200000, max_points=4000000):
+    binimg = np.ascontiguousarray(binimg, np.uint8)
+    lens = np.zeros(max_contours, np.int32)
+    pts = np.zeros((max_points, 2), np.int32)
+    n = lib().oracle_find_contours(_p(binimg), binimg.shape[1], binimg.shape[0], _p(lens), max_contours, _p(pts),
+                                   max_points)
+    lens = lens[:n]
+    out, o = [], 0
+    for l in lens:
+        out.append(pts[o:o + l].copy())
+        o += l
+    return out
+
+
+def warp35(img, quad, S=35):
+    img = np.ascontiguousarray(img, np.uint8)
+    quad = np.ascontiguousarray(quad, np.float32)
+    out = np.zeros((S, S), np.uint8)
+    lib().oracle_warp_perspective35(_p(img), img.shape[1], img.shape[0], _p(quad), _p(out), S)
+    return out
