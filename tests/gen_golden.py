@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the CPU oracle (committed, small).
+
+The reference ships no golden vectors and cannot be compiled here, so these fixtures are produced by
+the oracle on seeded synthetic inputs; they freeze the oracle's behaviour (any later edit of oracle/ that changes
+results is caught by tests/test_oracle_cpu.py) and give the GPU tests data that does not need the oracle at all.
+
+    python tests/gen_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as O  # noqa: E402
+from orb_slam2_aruco_amd import synth  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    # ORB: 240x320 crop-sized scene (image stored, ~77 KB) + 640x480 scene (only the seed is stored)
+    img, _ = synth.scene(240, 320, 7, "ARUCO", 2, side_range=(40, 70))
+    k, d = O.OrbOracle(500, 1.2, 4, 20, 7).extract(img)
+    np.savez_compressed(os.path.join(OUT, "orb_240x320.npz"), image=img, kps=k, desc=d,
+                        params=np.array([500, 4, 20, 7]))
+    img, _ = synth.scene(480, 640, 1, "ARUCO", 4)
+    o = O.OrbOracle(1000, 1.2, 8, 20, 7)
+    k, d = o.extract(img)
+    np.savez_compressed(os.path.join(OUT, "orb_640x480_seed1.npz"), kps=k, desc=d,
+                        image_sum=np.array([int(img.astype(np.int64).sum()), int((img.astype(np.int64) * np.arange(img.size).reshape(img.shape) % 65521).sum())]),
+                        ncand=np.array([len(o.level_keypoints(l, 0)) for l in range(8)]),
+                        nkept=np.array([len(o.level_keypoints(l, 1)) for l in range(8)]))
+    # ArUco
+    for name, (h, w, seed, dic, K) in {"aruco_640x480_seed1": (480, 640, 1, "ARUCO", 4),
+                                       "aruco_540x960_seed6": (540, 960, 6, "ARUCO_MIP_36h12", 5)}.items():
+        img, truth = synth.scene(h, w, seed, dic, K)
+        a = O.ArucoOracle(dic)
+        m = a.detect(img)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), markers=m, rects=a.candidates(0),
+                            thr_on=np.array([int((a.stage_image(0) > 0).sum())]),
+                            truth_ids=np.array(sorted(t[0] for t in truth)))
+    # matching
+    s = synth.stream(480, 640, 2, 1000)
+    o = O.OrbOracle(1000, 1.2, 8, 20, 7)
+    (k1, d1), (k2, d2) = o.extract(s[0]), o.extract(s[1])
+    bi, bd, sd = O.knn2(d1, d2, 256)
+    n, m12, prev = O.search_for_initialization(k1, d1, k2, d2, 640, 480, None, 100, 0.9, True)
+    np.savez_compressed(os.path.join(OUT, "match_stream1000.npz"), k1=k1, d1=d1, k2=k2, d2=d2, best_idx=bi,
+                        best_dist=bd, second_dist=sd, nmatches=np.array([n]), matches12=m12, prev=prev)
+    print("wrote", sorted(os.listdir(OUT)))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,289 @@
+"""CPU tests (no GPU): the oracle against the reference's source-embedded known answers and the
+committed golden vectors."""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import pytest
+
+from orb_slam2_aruco_amd import synth
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+# ---------------------------------------------------------------- ctor tables (ORBextractor.cc:410-470)
+def test_ctor_tables_match_reference_constants(oracle):
+    t = oracle.OrbOracle(1000, 1.2, 8, 20, 7).tables()
+    assert t["umax"].tolist() == [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+    assert t["per_level"].tolist() == [217, 181, 151, 126, 105, 87, 73, 60]
+    assert oracle.OrbOracle(2000, 1.2, 8, 20, 7).tables()["per_level"].tolist() == [434, 362, 302, 251, 209, 175, 145, 122]
+    assert oracle.OrbOracle(4000, 1.2, 12, 20, 7).tables()["per_level"].tolist() == \
+        [751, 626, 521, 435, 362, 302, 251, 210, 175, 146, 121, 100]
+    # float recurrence mvScaleFactor[i] = mvScaleFactor[i-1] * (double)1.2f, rounded to float each step
+    s = np.float32(1.0)
+    for i in range(1, 8):
+        s = np.float32(np.float64(s) * np.float64(np.float32(1.2)))
+        assert t["scale"][i] == s
+    assert np.all(t["inv_scale"] == np.float32(1.0) / t["scale"])
+
+
+def test_level_sizes_match_survey_appendix_e(oracle):
+    o = oracle.OrbOracle(1000, 1.2, 8, 20, 7)
+    o.extract(np.zeros((480, 640), np.uint8))
+    got = [o.level_image(l).shape[::-1] for l in range(8)]
+    assert got == [(640, 480), (533, 400), (444, 333), (370, 278), (309, 231), (257, 193), (214, 161), (179, 134)]
+
+
+# ---------------------------------------------------------------- numerics contract (include/orbfe_math.h)
+def test_cv_round_half_to_even(oracle):
+    L = oracle.lib()
+    for v, want in [(0.5, 0), (1.5, 2), (2.5, 2), (-0.5, 0), (-1.5, -2), (3.4999, 3), (-2.5, -2), (1e6 + 0.5, 1000000)]:
+        assert L.oracle_cv_round(v) == want
+
+
+def test_fast_atan2_properties(oracle):
+    L = oracle.lib()
+    assert L.oracle_fast_atan2(0.0, 0.0) == 0.0
+    rng = np.random.default_rng(0)
+    for _ in range(2000):
+        y, x = (float(v) for v in rng.integers(-3000000, 3000000, 2))
+        a = L.oracle_fast_atan2(y, x)
+        true = math.degrees(math.atan2(y, x)) % 360.0
+        d = abs(a - true)
+        assert min(d, 360 - d) < 0.02            # OpenCV documents ~0.3 deg; the polynomial is much better
+        assert 0.0 <= a <= 360.0
+
+
+def test_sincos_is_correctly_rounded(oracle):
+    """orbfe_sincosf == float32(round(sin/cos in double)) on a dense sweep of the angles the extractor can produce."""
+    L = oracle.lib()
+    s, c = C.c_float(), C.c_float()
+    deg = np.arange(0, 360, 0.0137, dtype=np.float32)
+    rad = (deg * np.float32(math.pi / 180.0)).astype(np.float32)
+    bad = 0
+    for r in rad[::3]:
+        L.oracle_sincosf(float(r), C.byref(s), C.byref(c))
+        if np.float32(math.sin(float(r))) != np.float32(s.value) or np.float32(math.cos(float(r))) != np.float32(c.value):
+            bad += 1
+    assert bad == 0
+
+
+# ---------------------------------------------------------------- OpenCV primitives restated (App. B)
+def test_gaussian_taps(oracle):
+    taps = np.zeros(7, np.int32)
+    oracle.lib().oracle_gaussian7_taps(taps.ctypes.data_as(C.c_void_p))
+    assert taps.tolist() == [18, 34, 49, 55, 49, 34, 18]
+
+
+def test_blur_constant_and_saturation(oracle):
+    L = oracle.lib()
+    for v in (0, 7, 128, 254, 255):
+        src = np.full((20, 31), v, np.uint8)
+        dst = np.zeros_like(src)
+        L.oracle_gaussian_blur7(src.ctypes.data_as(C.c_void_p), 31, 20, dst.ctypes.data_as(C.c_void_p))
+        want = min(255, (257 * 257 * v + 32768) >> 16)
+        assert np.all(dst == want)
+
+
+def test_resize_identity_and_constant(oracle):
+    L = oracle.lib()
+    rng = np.random.default_rng(1)
+    src = rng.integers(0, 256, (40, 60), dtype=np.uint8)
+    dst = np.zeros_like(src)
+    L.oracle_resize_linear_u8(src.ctypes.data_as(C.c_void_p), 60, 40, dst.ctypes.data_as(C.c_void_p), 60, 40)
+    assert np.array_equal(src, dst)
+    src = np.full((48, 64), 93, np.uint8)
+    dst = np.zeros((40, 53), np.uint8)
+    L.oracle_resize_linear_u8(src.ctypes.data_as(C.c_void_p), 64, 48, dst.ctypes.data_as(C.c_void_p), 53, 40)
+    assert np.all(dst == 93)
+
+
+def _ring():
+    return [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1),
+            (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+
+
+def test_fast_score_is_largest_threshold_still_a_corner(oracle):
+    """score(p) = max t such that p passes the 9-of-16 segment test at threshold t (definition of cornerScore)."""
+    L = oracle.lib()
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 256, (24, 24), dtype=np.uint8)
+    out = np.zeros((24, 24), np.int32)
+    L.oracle_fast_score_map(img.ctypes.data_as(C.c_void_p), 24, 24, out.ctypes.data_as(C.c_void_p))
+
+    def is_corner(y, x, t):
+        v = int(img[y, x])
+        r = [int(img[y + dy, x + dx]) for dx, dy in _ring()]
+        for s in range(16):
+            if all(r[(s + j) % 16] > v + t for j in range(9)) or all(r[(s + j) % 16] < v - t for j in range(9)):
+                return True
+        return False
+
+    for y in range(3, 21, 2):
+        for x in range(3, 21, 3):
+            s = out[y, x]
+            if s >= 0:
+                assert is_corner(y, x, s) and not is_corner(y, x, s + 1)
+            else:
+                assert not is_corner(y, x, 0)
+
+
+def test_quadtree_small_cases(oracle):
+    kp = np.zeros(6, oracle.KP_DTYPE)
+    kp["x"] = [10, 300, 20, 500, 310, 305]
+    kp["y"] = [10, 20, 300, 400, 25, 22]
+    kp["response"] = [5, 50, 7, 9, 50, 60]
+    out = np.zeros(16, oracle.KP_DTYPE)
+    L = oracle.lib()
+    n = L.oracle_distribute(kp.ctypes.data_as(C.c_void_p), 6, 16, 624, 16, 464, 3, out.ctypes.data_as(C.c_void_p), 16)
+    assert 3 <= n <= 6
+    # N larger than the candidates: splitting stops as soon as one pass leaves the node count unchanged (:661), which
+    # happens here while the three clustered points still share a node -> its best response (60) represents them
+    n = L.oracle_distribute(kp.ctypes.data_as(C.c_void_p), 6, 16, 624, 16, 464, 100, out.ctypes.data_as(C.c_void_p), 16)
+    assert n in (4, 5, 6) and 60 in out["response"][:n].tolist() and 5 in out["response"][:n].tolist()
+    # well separated points: every point ends up alone
+    kp["x"] = [10, 300, 20, 500, 100, 400]
+    kp["y"] = [10, 20, 300, 400, 200, 100]
+    n = L.oracle_distribute(kp.ctypes.data_as(C.c_void_p), 6, 16, 624, 16, 464, 100, out.ctypes.data_as(C.c_void_p), 16)
+    assert n == 6 and sorted(out["response"][:6].tolist()) == [5, 7, 9, 50, 50, 60]
+
+
+# ---------------------------------------------------------------- matching (App. D)
+def test_descriptor_distance_is_popcount(oracle):
+    L = oracle.lib()
+    rng = np.random.default_rng(3)
+    for _ in range(500):
+        a = rng.integers(0, 256, 32, dtype=np.uint8)
+        b = rng.integers(0, 256, 32, dtype=np.uint8)
+        want = int(np.unpackbits(a ^ b).sum())
+        assert L.oracle_descriptor_distance(a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)) == want
+    z = np.zeros(32, np.uint8)
+    f = np.full(32, 255, np.uint8)
+    assert L.oracle_descriptor_distance(z.ctypes.data_as(C.c_void_p), f.ctypes.data_as(C.c_void_p)) == 256
+
+
+def test_three_maxima(oracle):
+    L = oracle.lib()
+
+    def tm(h):
+        h = np.asarray(h, np.int32)
+        out = np.zeros(3, np.int32)
+        L.oracle_three_maxima(h.ctypes.data_as(C.c_void_p), len(h), out.ctypes.data_as(C.c_void_p))
+        return out.tolist()
+
+    h = [0] * 30
+    h[3], h[7], h[20] = 100, 50, 20
+    assert tm(h) == [3, 7, 20]
+    h[20] = 9                      # third < 10 % of first
+    assert tm(h) == [3, 7, -1]
+    h[7] = 9
+    assert tm(h) == [3, -1, -1]
+    assert tm([0] * 30) == [-1, -1, -1]
+
+
+def test_knn2_tie_rules(oracle):
+    T = np.zeros((5, 32), np.uint8)
+    T[1, 0] = 1; T[2, 0] = 1; T[3, 0] = 3
+    Q = np.zeros((1, 32), np.uint8); Q[0, 0] = 1
+    bi, bd, sd = oracle.knn2(Q, T, 256)
+    assert (bi[0], bd[0], sd[0]) == (1, 0, 0)      # first of the two exact matches wins; the duplicate is the runner-up
+    bi, bd, sd = oracle.knn2(Q, T[:1], 256)
+    assert (bi[0], bd[0], sd[0]) == (0, 1, 256)
+
+
+# ---------------------------------------------------------------- ArUco
+def test_marker_render_decode_roundtrip_all_rotations(oracle):
+    """getMarkerImage_id (dictionary.cpp:254-342) is the inverse of the decoder (dictionary_based.cpp:2372-2645)."""
+    for dic, ids in (("ARUCO", [0, 1, 77, 500, 1022]), ("ARUCO_MIP_25h7", [0, 42, 99]), ("ARUCO_MIP_36h12", [0, 249]),
+                     ("TAG16h5", [0, 29])):
+        a = oracle.ArucoOracle(dic)
+        nbits, _ = synth.dictionary_codes(dic)
+        n = int(round(nbits ** 0.5)) + 2
+        for i in ids:
+            m = synth.render_marker(dic, i, 5, quiet=0)      # exactly the 5 px/bit patch the detector warps to
+            assert m.shape == (5 * n, 5 * n)
+            for k in range(4):
+                got, rot = a.decode(np.ascontiguousarray(np.rot90(m, -k)))
+                assert got == i, (dic, i, k, got)
+                assert rot == (4 - k) % 4     # k clockwise quarter turns are undone by 4-k decoder rotations
+        assert a.decode(np.zeros((5 * n, 5 * n), np.uint8))[0] == -1          # all-black: code 0 is rejected
+        assert a.decode(np.full((5 * n, 5 * n), 255, np.uint8))[0] == -1      # white border cells: rejected
+
+
+def test_adaptive_threshold_definition(oracle):
+    rng = np.random.default_rng(4)
+    img = rng.integers(0, 256, (30, 41), dtype=np.uint8)
+    for win in (3, 5, 11):
+        got = oracle.adaptive_threshold(img, win, 7)
+        r = win // 2
+        p = np.pad(img.astype(np.int64), r, mode="edge")
+        s = sum(p[dy:dy + 30, dx:dx + 41] for dy in range(win) for dx in range(win))
+        mean = np.floor(s / (win * win) + 0.5).astype(np.int64)     # no exact ties: win*win is odd
+        want = np.where(img.astype(np.int64) - mean <= -7, 255, 0).astype(np.uint8)
+        assert np.array_equal(got, want)
+
+
+def test_find_contours_small_known_answers(oracle):
+    b = np.zeros((8, 8), np.uint8)
+    b[2:6, 2:6] = 255
+    c = oracle.find_contours(b)
+    assert len(c) == 1 and len(c[0]) == 12 and c[0][0].tolist() == [2, 2]
+    assert c[0][1].tolist() == [2, 3]                       # outer borders run counter-clockwise in image coordinates
+    b[3:5, 3:5] = 0
+    c = oracle.find_contours(b)
+    assert len(c) == 2
+    assert c[0][0].tolist() == [2, 3] and len(c[0]) == 8    # hole border found later, returned first (reverse order)
+    b = np.zeros((5, 5), np.uint8); b[2, 2] = 255
+    c = oracle.find_contours(b)
+    assert len(c) == 1 and c[0].tolist() == [[2, 2]]
+
+
+# ---------------------------------------------------------------- golden vectors
+def test_golden_orb(oracle):
+    g = np.load(os.path.join(GOLD, "orb_240x320.npz"))
+    nf, nl, ini, mn = g["params"]
+    k, d = oracle.OrbOracle(int(nf), 1.2, int(nl), int(ini), int(mn)).extract(g["image"])
+    assert np.array_equal(k, g["kps"]) and np.array_equal(d, g["desc"])
+    g = np.load(os.path.join(GOLD, "orb_640x480_seed1.npz"))
+    img, _ = synth.scene(480, 640, 1, "ARUCO", 4)
+    assert int(img.astype(np.int64).sum()) == int(g["image_sum"][0]), "synthetic generator changed"
+    o = oracle.OrbOracle(1000, 1.2, 8, 20, 7)
+    k, d = o.extract(img)
+    assert np.array_equal(k, g["kps"]) and np.array_equal(d, g["desc"])
+    assert [len(o.level_keypoints(l, 0)) for l in range(8)] == g["ncand"].tolist()
+
+
+def test_golden_aruco(oracle):
+    for name, (h, w, seed, dic, K) in {"aruco_640x480_seed1": (480, 640, 1, "ARUCO", 4),
+                                       "aruco_540x960_seed6": (540, 960, 6, "ARUCO_MIP_36h12", 5)}.items():
+        g = np.load(os.path.join(GOLD, name + ".npz"))
+        img, truth = synth.scene(h, w, seed, dic, K)
+        a = oracle.ArucoOracle(dic)
+        m = a.detect(img)
+        assert np.array_equal(m["id"], g["markers"]["id"])
+        assert np.array_equal(m["corners"], g["markers"]["corners"])
+        assert np.array_equal(a.candidates(0), g["rects"])
+        assert m["id"].tolist() == g["truth_ids"].tolist()      # every planted marker is found, nothing else
+
+
+def test_golden_match(oracle):
+    g = np.load(os.path.join(GOLD, "match_stream1000.npz"))
+    bi, bd, sd = oracle.knn2(g["d1"], g["d2"], 256)
+    assert np.array_equal(bi, g["best_idx"]) and np.array_equal(bd, g["best_dist"]) and np.array_equal(sd, g["second_dist"])
+    n, m12, prev = oracle.search_for_initialization(g["k1"], g["d1"], g["k2"], g["d2"], 640, 480, None, 100, 0.9, True)
+    assert n == int(g["nmatches"][0]) and np.array_equal(m12, g["matches12"]) and np.array_equal(prev, g["prev"])
+    assert n > 50
+
+
+def test_libm_trig_sensitivity_is_small(oracle):
+    """The reference calls libm cos/sin (ORBextractor.cc:112-113); the oracle uses correctly rounded values.
+    Quantify what that choice can change: a handful of descriptor BITS per frame at most."""
+    img, _ = synth.scene(240, 320, 7, "ARUCO", 2, side_range=(40, 70))
+    o = oracle.OrbOracle(500, 1.2, 4, 20, 7)
+    k1, d1 = o.extract(img)
+    oracle.lib().oracle_orb_set_trig_libm(o.h, 1)
+    k2, d2 = o.extract(img)
+    assert np.array_equal(k1, k2)
+    flipped = int(np.unpackbits(d1 ^ d2).sum())
+    assert flipped <= max(8, d1.size * 8 // 20000)
