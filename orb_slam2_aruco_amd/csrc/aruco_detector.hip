@@ -124,10 +124,10 @@ struct orbfe_aruco {
         }
         npyr = (int)levels.size();
         pyr_fbytes = off + 64;
-        candq_fu32 = (size_t)rows_ * cols_ / 4 + 1024;
-        pool_fu32 = (size_t)rows_ * cols_ / 4 + 1024;
+        candq_fu32 = 16; // (the candidate queue is gone: starts are found on the fly from the LDS bit image)
+        pool_fu32 = (size_t)CT_THREADS * std::max(4096, rows_ * cols_ / 48); // one private arena per lane of k_contours
         const int pw = (cols_ + 2 + 31) / 32;
-        const size_t padded_words = (size_t)pw * (rows_ + 2);
+        const size_t padded_words = (size_t)pw * (rows_ + 2) + 2; // + spare words for ring8()
         // the padded bit image goes to LDS when it fits next to the other arrays (160 KiB per workgroup)
         lds_bits_words = (contours_lds_bytes((int)padded_words, AR_MAX_KEPT) <= 160 * 1024) ? (int)padded_words : 0;
         gpad_fu32 = lds_bits_words ? 0 : padded_words;
@@ -190,10 +190,11 @@ struct orbfe_aruco {
         timer.mark(s, "pyramid");
         const size_t lds = contours_lds_bytes(lds_bits_words, AR_MAX_KEPT);
         ORBFE_HIP(hipGetLastError());
-        ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_contours),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_contours, dim3(B), dim3(CT_THREADS), lds, s, d_bits.as<uint32_t>(), bits_fu32, wpr, cols,
-                           rows, lds_bits_words, 70, d_candq.as<uint32_t>(), candq_fu32, (int)candq_fu32,
+        auto kfn = lds_bits_words ? k_contours_t<true> : k_contours_t<false>;
+        ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds));
+        hipLaunchKernelGGL(kfn, dim3(B), dim3(CT_THREADS), lds, s, d_bits.as<uint32_t>(), bits_fu32, wpr, cols, rows,
+                           lds_bits_words, 70, d_candq.as<uint32_t>(), candq_fu32, (int)candq_fu32,
                            d_pool.as<uint32_t>(), pool_fu32, (int)pool_fu32, d_kept.as<ArKept>(), AR_MAX_KEPT,
                            d_rects.as<ArRect>(), AR_MAX_RECTS, d_counts.as<int32_t>(), d_gpad.as<uint32_t>(),
                            gpad_fu32);
@@ -201,7 +202,7 @@ struct orbfe_aruco {
         ORBFE_HIP(hipGetLastError());
         hipLaunchKernelGGL(k_prefilter, dim3(B), dim3(256), 0, s, d_rects.as<ArRect>(), AR_MAX_RECTS,
                            d_counts.as<int32_t>(), cols, rows, win, d_candidx.as<int32_t>(), d_ncand.as<int32_t>());
-        hipLaunchKernelGGL(k_decode, dim3(32, B), dim3(256), 0, s, src0, pyr, d_levels.as<ArLevel>(), npyr,
+        hipLaunchKernelGGL(k_decode, dim3(32, B), dim3(64), 0, s, src0, pyr, d_levels.as<ArLevel>(), npyr,
                            d_rects.as<ArRect>(), AR_MAX_RECTS, d_candidx.as<int32_t>(), d_ncand.as<int32_t>(), S, nb,
                            d_codes.as<unsigned long long>(), ncodes, d_result.as<int32_t>(), cols);
         timer.mark(s, "decode");
@@ -326,6 +327,11 @@ int orbfe_aruco_debug_image(orbfe_aruco* h, int frame, int stage, uint8_t* out)
     }
     if (stage == 101) { // rectangle candidates: AR_MAX_RECTS x ArRect (40 B)
         ORBFE_HIP(hipMemcpy(out, h->d_rects.as<ArRect>() + (size_t)frame * AR_MAX_RECTS, sizeof(ArRect) * AR_MAX_RECTS,
+                            hipMemcpyDeviceToHost));
+        return ORBFE_OK;
+    }
+    if (stage == 102) { // tail of the kept array (phase timing words of instrumented builds), 96 bytes
+        ORBFE_HIP(hipMemcpy(out, h->d_kept.as<ArKept>() + (size_t)frame * AR_MAX_KEPT + AR_MAX_KEPT - 4, 96,
                             hipMemcpyDeviceToHost));
         return ORBFE_OK;
     }

@@ -226,7 +226,8 @@ __device__ bool convex4(const ApPt* p)
     return true;
 }
 
-__global__ __launch_bounds__(CT_THREADS) void k_contours(const uint32_t* __restrict__ gbits, size_t bits_fstride,
+template <bool LDS_BITS>
+__global__ __launch_bounds__(CT_THREADS) void k_contours_t(const uint32_t* __restrict__ gbits, size_t bits_fstride,
                                                          int wpr_g, int W, int H, int lds_bits_words, int min_len,
                                                          uint32_t* __restrict__ candq, size_t candq_fstride,
                                                          int candq_cap, uint32_t* __restrict__ pool,
@@ -237,23 +238,31 @@ __global__ __launch_bounds__(CT_THREADS) void k_contours(const uint32_t* __restr
                                                          uint32_t* __restrict__ gpadded, size_t gpadded_fstride)
 {
     extern __shared__ __align__(16) unsigned char ct_smem[];
-    __shared__ int s_ncand, s_next, s_nkept, s_total, s_flags, s_nrect;
+    __shared__ int s_ncand, s_next, s_nkept, s_nlong, s_flags;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, f = blockIdx.x;
     const int wpr = (W + 2 + 31) >> 5, prow = H + 2;
     // LDS carve-up: [bits][kept keys (u64) kept_cap][per-wave approx scratch]
     // the padded bit image lives in LDS when it fits (lds_bits_words > 0), else in an HBM scratch (L2-resident)
-    uint32_t* lbits = lds_bits_words ? (uint32_t*)ct_smem : gpadded + (size_t)f * gpadded_fstride;
+    uint32_t* lbits = LDS_BITS ? (uint32_t*)ct_smem : gpadded + (size_t)f * gpadded_fstride;
     unsigned long long* kkey = (unsigned long long*)(ct_smem + (((size_t)lds_bits_words * 4 + 15) & ~(size_t)15));
-    int* klen = (int*)(kkey + kept_cap);
+    int* off_u = (int*)(kkey + kept_cap);
+    int* klen = off_u + kept_cap;
     int* koff = klen + kept_cap;
     int* rectflag = koff + kept_cap;
+    uint32_t* longq = (uint32_t*)klen; // probe survivors; dead before klen/koff/rectflag are written
+    const int lq_cap = 3 * kept_cap;
     ApPt* ap_out = (ApPt*)(rectflag + kept_cap);
     int2* ap_stack = (int2*)(ap_out + CT_WAVES * AP_OUT);
     const uint32_t* gb = gbits + (size_t)f * bits_fstride;
-    uint32_t* cq = candq + (size_t)f * candq_fstride;
     uint32_t* pl = pool + (size_t)f * pool_fstride;
 
-    if (tid == 0) { s_ncand = 0; s_next = 0; s_nkept = 0; s_total = 0; s_flags = 0; s_nrect = 0; }
+    if (tid == 0) { s_ncand = 0; s_next = 0; s_nkept = 0; s_nlong = 0; s_flags = 0; }
+#ifdef ORBFE_CT_TIMING
+    long long t0 = clock64(), t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
+#define CT_STAMP(v) v = clock64()
+#else
+#define CT_STAMP(v)
+#endif
     // ---- (a) padded bit image into LDS: pixel (x, y) -> bit x+1 of row y+1
     for (int i = tid; i < wpr * prow; i += CT_THREADS) {
         const int py = i / wpr, j = i - py * wpr;
@@ -266,56 +275,117 @@ __global__ __launch_bounds__(CT_THREADS) void k_contours(const uint32_t* __restr
         }
         lbits[i] = v;
     }
+    if (tid < 2) lbits[wpr * prow + tid] = 0; // spare words read by ring8()'s funnel loads
     __threadfence_block();
     __syncthreads();
     const BitImage im{lbits, wpr, W, H};
+    CT_STAMP(t1);
 
-    // ---- (b) border start candidates (aruco_trace.hpp): bit tricks over whole words
-    for (int i = tid; i < wpr * H; i += CT_THREADS) {
-        const int py = 1 + i / wpr, j = i % wpr;
-        const uint32_t* row = lbits + py * wpr;
-        const uint32_t* up = row - wpr;
-        const uint32_t cur = row[j], upw = up[j];
-        const uint32_t cur_l = (cur << 1) | (j ? row[j - 1] >> 31 : 0u);
-        const uint32_t up_l = (upw << 1) | (j ? up[j - 1] >> 31 : 0u);
-        const uint32_t up_r = (upw >> 1) | (j + 1 < wpr ? up[j + 1] << 31 : 0u);
-        uint32_t outer = cur & ~cur_l & ~up_l & ~upw & ~up_r;
-        uint32_t hole = ~cur & cur_l & upw;
-        while (outer | hole) {
-            const int is_hole = outer ? 0 : 1;
-            uint32_t& m = outer ? outer : hole;
-            const int b = __ffs(m) - 1;
-            m &= m - 1;
-            const int px = j * 32 + b;
-            const int slot = atomicAdd(&s_ncand, 1);
-            if (slot < candq_cap) cq[slot] = (uint32_t)px | ((uint32_t)py << 13) | ((uint32_t)is_hole << 26);
-        }
-    }
-    __syncthreads();
-    if (tid == 0 && s_ncand > candq_cap) { s_flags |= 1; s_ncand = candq_cap; }
-    __syncthreads();
-    const int ncand = s_ncand;
-
-    // ---- (c) follow every candidate read-only; keep canonical borders longer than min_len
-    for (;;) {
-        const int c = atomicAdd(&s_next, 1);
-        if (c >= ncand) break;
-        const uint32_t q = cq[c];
-        const int px = q & 0x1fff, py = (q >> 13) & 0x1fff, is_hole = q >> 26;
-        const int n = trace_border(im, px - is_hole, py, is_hole, nullptr, 0, 1 << 24);
-        if (n > min_len) {
-            const int k = atomicAdd(&s_nkept, 1);
-            if (k < kept_cap) {
-                // discovery order = raster order of the transition pixel; findContours returns the reverse
-                kkey[k] = ((unsigned long long)(0xffffffffu - (uint32_t)(py * 65536 + px)) << 32) |
-                          ((unsigned long long)n << 8) | (unsigned)is_hole;
+    // ---- (b)+(c) border starts and border following, fused, in two flat phases.
+    // Start candidates come from word-wide bit tricks on the LDS image (aruco_trace.hpp: outer = foreground with
+    // background W, NW, N, NE; hole = background with foreground W and N); a lane takes one 32-pixel word at a time.
+    // Every loop iteration advances each busy lane's walk by ONE step and lets idle lanes take their next candidate,
+    // so no lane waits for the longest walk of its wave.
+    //   probe phase: walk at most CT_PROBE steps without storing anything; most candidates end here (abandoned as
+    //                non-canonical, or closed with fewer than min_len points).  Survivors go to an LDS queue.
+    //   long phase:  walk the survivors to the end, writing the points into the lane's private arena of the frame's
+    //                point pool; a closed canonical border longer than min_len keeps its arena space.
+    const int arena = pool_cap / CT_THREADS;
+    uint32_t* my_arena = pl + (size_t)tid * arena;
+    int wp = 0; // arena words owned by kept borders of this lane
+    for (int phase = 0; phase < 2; phase++) {
+        TraceState t;
+        bool busy = false, drained = false, storing = false;
+        uint32_t m_outer = 0, m_hole = 0;
+        int wj = 0, wy = 0, qx = 0, qy = 0, ncand_l = 0;
+        const int nwords = wpr * H;
+        __syncthreads();
+        const int nlong = min(s_nlong, lq_cap);
+        if (tid == 0) s_next = 0;
+        __syncthreads();
+        for (;;) {
+            if (!busy && !drained) {
+                if (phase == 0) {
+                    if (!(m_outer | m_hole)) {
+                        const int i = atomicAdd(&s_next, 1);
+                        if (i >= nwords) drained = true;
+                        else {
+                            wy = 1 + i / wpr;
+                            wj = i - (wy - 1) * wpr;
+                            const uint32_t* row = lbits + wy * wpr;
+                            const uint32_t* up = row - wpr;
+                            const uint32_t cur = row[wj], upw = up[wj];
+                            const uint32_t cur_l = (cur << 1) | (wj ? row[wj - 1] >> 31 : 0u);
+                            const uint32_t up_l = (upw << 1) | (wj ? up[wj - 1] >> 31 : 0u);
+                            const uint32_t up_r = (upw >> 1) | (wj + 1 < wpr ? up[wj + 1] << 31 : 0u);
+                            m_outer = cur & ~cur_l & ~up_l & ~upw & ~up_r;
+                            m_hole = ~cur & cur_l & upw;
+                        }
+                    }
+                    if (m_outer | m_hole) {
+                        const int is_hole = m_outer ? 0 : 1;
+                        uint32_t& mm = m_outer ? m_outer : m_hole;
+                        const int b = __ffs(mm) - 1;
+                        mm &= mm - 1;
+                        qx = wj * 32 + b;
+                        qy = wy;
+                        ncand_l++;
+                        storing = false;
+                        busy = !trace_init(im, t, qx - is_hole, qy, is_hole); // single-pixel borders are never kept
+                    }
+                } else {
+                    const int k = atomicAdd(&s_next, 1);
+                    if (k >= nlong) drained = true;
+                    else {
+                        const uint32_t q = longq[k];
+                        qx = q & 0x1fff; qy = (q >> 13) & 0x1fff;
+                        const int is_hole = q >> 26;
+                        storing = true;
+                        busy = !trace_init(im, t, qx - is_hole, qy, is_hole);
+                    }
+                }
+            }
+            if (!__any(busy || !drained)) break;
+            if (busy) {
+                uint32_t pt;
+                const int n0 = t.n;
+                const int st = trace_step(im, t, &pt);
+                if (storing && st >= 0 && wp + n0 < arena) my_arena[wp + n0] = pt;
+                if (st != 0) {
+                    busy = false;
+                    if (st == 1 && t.n > min_len) { // only reachable in the long phase (CT_PROBE < min_len)
+                        const int k = atomicAdd(&s_nkept, 1);
+                        if (wp + t.n > arena) atomicOr(&s_flags, 4);
+                        else if (k < kept_cap) {
+                            // discovery order = raster order of the transition pixel; findContours returns the reverse
+                            kkey[k] = ((unsigned long long)(0xffffffffu - (uint32_t)(qy * 65536 + qx)) << 32) |
+                                      ((unsigned long long)(t.n & 0xfffff) << 12) | ((unsigned)k << 1) | (unsigned)t.is_hole;
+                            off_u[k] = tid * arena + wp;
+                            wp += t.n;
+                        }
+                    }
+                } else if (!storing && t.n >= CT_PROBE) {
+                    const int k = atomicAdd(&s_nlong, 1);
+                    if (k < lq_cap) {
+                        busy = false;
+                        longq[k] = (uint32_t)qx | ((uint32_t)qy << 13) | ((uint32_t)t.is_hole << 26);
+                    } else { // queue full: this lane restarts the walk itself, now storing its points
+                        storing = true;
+                        trace_init(im, t, qx - t.is_hole, qy, t.is_hole);
+                    }
+                }
             }
         }
+        if (phase == 0) atomicAdd(&s_ncand, ncand_l);
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (tid == 0) {
+        if (s_nkept > kept_cap) { s_flags |= 2; s_nkept = kept_cap; }
     }
     __syncthreads();
-    if (tid == 0 && s_nkept > kept_cap) { s_flags |= 2; s_nkept = kept_cap; }
-    __syncthreads();
     const int nkept = s_nkept;
+    CT_STAMP(t3);
     // ---- (d) sort kept ascending by (~raster key) = reverse discovery order; bitonic over a power of two
     int Pn = 1;
     while (Pn < nkept) Pn <<= 1;
@@ -332,31 +402,13 @@ __global__ __launch_bounds__(CT_THREADS) void k_contours(const uint32_t* __restr
             }
             __syncthreads();
         }
-    if (tid == 0) { // exclusive scan of the lengths (nkept is small)
-        int acc = 0;
-        for (int k = 0; k < nkept; k++) {
-            const int n = (int)((kkey[k] >> 8) & 0xffffff);
-            klen[k] = n;
-            koff[k] = acc;
-            acc += n;
-            if (acc > pool_cap) { s_flags |= 4; klen[k] = 0; acc -= n; }
-        }
-        s_total = acc;
-        s_next = 0;
-    }
-    __syncthreads();
-    // ---- (e) follow the kept borders again, this time writing their points
-    for (;;) {
-        const int k = atomicAdd(&s_next, 1);
-        if (k >= nkept) break;
-        if (klen[k] == 0) continue;
+    for (int k = tid; k < nkept; k += CT_THREADS) { // (the long queue is dead: its space now holds klen/koff/rectflag)
         const unsigned long long key = kkey[k];
-        const uint32_t pos = 0xffffffffu - (uint32_t)(key >> 32);
-        const int py = pos >> 16, px = pos & 0xffff, is_hole = (int)(key & 1);
-        trace_border(im, px - is_hole, py, is_hole, pl + koff[k], klen[k], 1 << 24);
+        klen[k] = (int)((key >> 12) & 0xfffff);
+        koff[k] = off_u[(int)((key >> 1) & 0x7ff)];
     }
-    __threadfence_block();
     __syncthreads();
+    CT_STAMP(t4);
     // ---- (f) approxPolyDP(eps = 0.05 * len) -> 4 vertices and convex -> rectangle candidate
     for (int k = wid; k < nkept; k += CT_WAVES) {
         int ok = 0;
@@ -393,9 +445,19 @@ __global__ __launch_bounds__(CT_THREADS) void k_contours(const uint32_t* __restr
         counts[f * 4 + 0] = nkept;
         counts[f * 4 + 1] = min(nr, rect_cap);
         counts[f * 4 + 2] = s_flags;
-        counts[f * 4 + 3] = ncand;
+        counts[f * 4 + 3] = s_ncand;
+#ifdef ORBFE_CT_TIMING
+        t5 = clock64();
+        long long* dbg = (long long*)(kept_out + (size_t)f * kept_cap + kept_cap - 4);
+        dbg[0] = t1 - t0; dbg[1] = t2 - t1; dbg[2] = t3 - t2; dbg[3] = t4 - t3; dbg[4] = t5 - t4;
+#endif
     }
 }
+
+template __global__ void k_contours_t<true>(const uint32_t*, size_t, int, int, int, int, int, uint32_t*, size_t, int,
+                                            uint32_t*, size_t, int, ArKept*, int, ArRect*, int, int32_t*, uint32_t*, size_t);
+template __global__ void k_contours_t<false>(const uint32_t*, size_t, int, int, int, int, int, uint32_t*, size_t, int,
+                                             uint32_t*, size_t, int, ArKept*, int, ArRect*, int, int32_t*, uint32_t*, size_t);
 
 // ---------------------------------------------------------------------------------------- prefilter -----------
 __device__ __forceinline__ int ar_perimeter(const float c[4][2])
@@ -470,33 +532,6 @@ __global__ __launch_bounds__(256) void k_prefilter(ArRect* __restrict__ rects, i
 }
 
 // ---------------------------------------------------------------------------------------- decode --------------
-__device__ bool solve8(double* A, double* b)
-{
-    const int n = 8;
-    for (int c = 0; c < n; c++) {
-        int piv = c;
-        for (int r = c + 1; r < n; r++)
-            if (fabs(A[r * n + c]) > fabs(A[piv * n + c])) piv = r;
-        if (A[piv * n + c] == 0.0) return false;
-        if (piv != c) {
-            for (int k = 0; k < n; k++) { const double t = A[c * n + k]; A[c * n + k] = A[piv * n + k]; A[piv * n + k] = t; }
-            const double t = b[c]; b[c] = b[piv]; b[piv] = t;
-        }
-        for (int r = c + 1; r < n; r++) {
-            const double fct = A[r * n + c] / A[c * n + c];
-            if (fct == 0.0) continue;
-            for (int k = c; k < n; k++) A[r * n + k] -= fct * A[c * n + k];
-            b[r] -= fct * b[c];
-        }
-    }
-    for (int r = n - 1; r >= 0; r--) {
-        double s = b[r];
-        for (int k = r + 1; k < n; k++) s -= A[r * n + k] * b[k];
-        b[r] = s / A[r * n + r];
-    }
-    return true;
-}
-
 __device__ __forceinline__ int ar_sat_int(double v)
 {
     if (v <= -2147483648.0) return (int)0x80000000;
@@ -504,190 +539,239 @@ __device__ __forceinline__ int ar_sat_int(double v)
     return orbfe_round_d(v);
 }
 
-// One workgroup (256 threads) per (candidate slot, frame).
-__global__ __launch_bounds__(256) void k_decode(ImgView src0, ImgView pyr, const ArLevel* __restrict__ levels,
-                                                int nlevels, const ArRect* __restrict__ rects, int rect_cap,
-                                                const int32_t* __restrict__ cand_idx,
-                                                const int32_t* __restrict__ ncand, int S, int nb,
-                                                const unsigned long long* __restrict__ codes, int ncodes,
-                                                int32_t* __restrict__ result /*per slot: id, nrot*/, int W0)
+__device__ __forceinline__ double shfl_d(double v, int src)
 {
-    __shared__ double sA[64], sB[8], sM[9];
-    __shared__ int s_ok, s_th, s_found;
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl(lo, src);
+    hi = __shfl(hi, src);
+    return __hiloint2double(hi, lo);
+}
+
+// 8x8 linear system by Gaussian elimination with partial pivoting, one row per lane (lanes 0..7), same operation
+// order per element as the serial loop in the oracle (so the results are bit-identical).  Returns false if singular;
+// x[k] (all lanes) = solution.
+__device__ bool solve8_wave(double a[8], double b, int lane, double x[8])
+{
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        // pivot: first row r >= c with the largest |a[r][c]|
+        double v = (lane >= c && lane < 8) ? fabs(a[c]) : -1.0;
+        int piv = lane;
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) {
+            const double ov = shfl_d(v, lane ^ o);
+            const int op = __shfl(piv, lane ^ o);
+            if (ov > v || (ov == v && op < piv)) { v = ov; piv = op; }
+        }
+        v = shfl_d(v, 0);
+        piv = __shfl(piv, 0);
+        if (!(v > 0.0)) return false;
+        // swap rows c and piv
+        const int src = (lane == c) ? piv : (lane == piv) ? c : lane;
+#pragma unroll
+        for (int k = 0; k < 8; k++) a[k] = shfl_d(a[k], src);
+        b = shfl_d(b, src);
+        // eliminate below
+        const double pc = shfl_d(a[c], c);
+        const double pb = shfl_d(b, c);
+        const bool below = lane > c && lane < 8;
+        const double f = below ? a[c] / pc : 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const double pk = shfl_d(a[k], c);
+            if (k >= c && below && f != 0.0) a[k] -= f * pk;
+        }
+        if (below && f != 0.0) b -= f * pb;
+    }
+    // back substitution, r = 7..0; sums run over k = r+1..7 in ascending order like the serial loop
+#pragma unroll
+    for (int r = 7; r >= 0; r--) {
+        double s = b;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (k > r) s -= a[k] * x[k];
+        const double xr = s / a[r];
+        x[r] = shfl_d(xr, r);
+    }
+    return true;
+}
+
+// One wave per candidate; blockIdx.x strides over the frame's candidates.
+__global__ __launch_bounds__(64) void k_decode(ImgView src0, ImgView pyr, const ArLevel* __restrict__ levels,
+                                               int nlevels, const ArRect* __restrict__ rects, int rect_cap,
+                                               const int32_t* __restrict__ cand_idx,
+                                               const int32_t* __restrict__ ncand, int S, int nb,
+                                               const unsigned long long* __restrict__ codes, int ncodes,
+                                               int32_t* __restrict__ result /*per slot: id, nrot*/, int W0)
+{
     __shared__ uint8_t spatch[40 * 40];
     __shared__ int s_hist[256];
     __shared__ int s_ones[64], s_tot[64];
+    __shared__ uint8_t s_bits[64];
     __shared__ unsigned long long s_ids[4];
-    const int f = blockIdx.y, tid = threadIdx.x;
+    __shared__ int s_th;
+    const int f = blockIdx.y, lane = threadIdx.x;
     const int nc = ncand[f];
     for (int slot = blockIdx.x; slot < nc; slot += gridDim.x) {
-    __syncthreads(); // previous iteration's LDS state is dead
-    int32_t* res = result + ((size_t)f * rect_cap + slot) * 2;
-    const ArRect r = rects[(size_t)f * rect_cap + cand_idx[(size_t)f * rect_cap + slot]];
-    // pyramid level: largest p with area / 4^p >= S^2 (markerdetector_impl.cpp:6507-6586)
-    const float v01x = r.c[1][0] - r.c[0][0], v01y = r.c[1][1] - r.c[0][1];
-    const float v03x = r.c[3][0] - r.c[0][0], v03y = r.c[3][1] - r.c[0][1];
-    const float area1 = fabsf(__fsub_rn(__fmul_rn(v01x, v03y), __fmul_rn(v01y, v03x)));
-    const float v21x = r.c[1][0] - r.c[2][0], v21y = r.c[1][1] - r.c[2][1];
-    const float v23x = r.c[3][0] - r.c[2][0], v23y = r.c[3][1] - r.c[2][1];
-    const float area2 = fabsf(__fsub_rn(__fmul_rn(v21x, v23y), __fmul_rn(v21y, v23x)));
-    const float area = __fdiv_rn(__fadd_rn(area2, area1), 2.f);
-    const float desired = __fmul_rn((float)S, (float)S);
-    int lvl = 0;
-    double p4 = 4.0;
-    for (int p = 1; p < nlevels; p++, p4 *= 4.0) {
-        if ((double)area / p4 >= (double)desired) lvl = p;
-        else break;
-    }
-    const ArLevel L = levels[lvl];
-    const float ratio = __fdiv_rn((float)L.w, (float)W0);
-    if (tid == 0) {
-        const float dstx[4] = {0.f, (float)(S - 1), (float)(S - 1), 0.f};
-        const float dsty[4] = {0.f, 0.f, (float)(S - 1), (float)(S - 1)};
-        for (int i = 0; i < 64; i++) sA[i] = 0.0;
-        for (int i = 0; i < 4; i++) {
-            const float qx = __fmul_rn(r.c[i][0], ratio), qy = __fmul_rn(r.c[i][1], ratio);
-            sA[i * 8 + 0] = sA[(i + 4) * 8 + 3] = qx;
-            sA[i * 8 + 1] = sA[(i + 4) * 8 + 4] = qy;
-            sA[i * 8 + 2] = sA[(i + 4) * 8 + 5] = 1;
-            sA[i * 8 + 6] = -(double)qx * dstx[i];
-            sA[i * 8 + 7] = -(double)qy * dstx[i];
-            sA[(i + 4) * 8 + 6] = -(double)qx * dsty[i];
-            sA[(i + 4) * 8 + 7] = -(double)qy * dsty[i];
-            sB[i] = dstx[i];
-            sB[i + 4] = dsty[i];
+        __syncthreads();
+        int32_t* res = result + ((size_t)f * rect_cap + slot) * 2;
+        const ArRect r = rects[(size_t)f * rect_cap + cand_idx[(size_t)f * rect_cap + slot]];
+        // pyramid level: largest p with area / 4^p >= S^2 (markerdetector_impl.cpp:6507-6586)
+        const float v01x = r.c[1][0] - r.c[0][0], v01y = r.c[1][1] - r.c[0][1];
+        const float v03x = r.c[3][0] - r.c[0][0], v03y = r.c[3][1] - r.c[0][1];
+        const float area1 = fabsf(__fsub_rn(__fmul_rn(v01x, v03y), __fmul_rn(v01y, v03x)));
+        const float v21x = r.c[1][0] - r.c[2][0], v21y = r.c[1][1] - r.c[2][1];
+        const float v23x = r.c[3][0] - r.c[2][0], v23y = r.c[3][1] - r.c[2][1];
+        const float area2 = fabsf(__fsub_rn(__fmul_rn(v21x, v23y), __fmul_rn(v21y, v23x)));
+        const float area = __fdiv_rn(__fadd_rn(area2, area1), 2.f);
+        const float desired = __fmul_rn((float)S, (float)S);
+        int lvl = 0;
+        double p4 = 4.0;
+        for (int p = 1; p < nlevels; p++, p4 *= 4.0) {
+            if ((double)area / p4 >= (double)desired) lvl = p;
+            else break;
         }
-        bool ok = solve8(sA, sB);
+        const ArLevel L = levels[lvl];
+        const float ratio = __fdiv_rn((float)L.w, (float)W0);
+        // getPerspectiveTransform(quad -> (0,0),(S-1,0),(S-1,S-1),(0,S-1)): rows 0..3 = x equations, 4..7 = y equations
+        double a[8], bb = 0.0, x[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { a[k] = 0.0; x[k] = 0.0; }
+        if (lane < 8) {
+            const int i = lane & 3;
+            const float qx = __fmul_rn(r.c[i][0], ratio), qy = __fmul_rn(r.c[i][1], ratio);
+            const float dx = (i == 1 || i == 2) ? (float)(S - 1) : 0.f, dy = (i >= 2) ? (float)(S - 1) : 0.f;
+            if (lane < 4) {
+                a[0] = qx; a[1] = qy; a[2] = 1.0;
+                a[6] = -(double)qx * dx; a[7] = -(double)qy * dx;
+                bb = dx;
+            } else {
+                a[3] = qx; a[4] = qy; a[5] = 1.0;
+                a[6] = -(double)qx * dy; a[7] = -(double)qy * dy;
+                bb = dy;
+            }
+        }
+        bool ok = solve8_wave(a, bb, lane, x);
+        double Mi[9];
         if (ok) {
-            const double M[9] = {sB[0], sB[1], sB[2], sB[3], sB[4], sB[5], sB[6], sB[7], 1.0};
+            const double M[9] = {x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7], 1.0};
             const double det = M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) +
                                M[2] * (M[3] * M[7] - M[4] * M[6]);
             if (det == 0.0) ok = false;
             else {
                 const double d = 1.0 / det;
-                sM[0] = (M[4] * M[8] - M[5] * M[7]) * d;
-                sM[1] = (M[2] * M[7] - M[1] * M[8]) * d;
-                sM[2] = (M[1] * M[5] - M[2] * M[4]) * d;
-                sM[3] = (M[5] * M[6] - M[3] * M[8]) * d;
-                sM[4] = (M[0] * M[8] - M[2] * M[6]) * d;
-                sM[5] = (M[2] * M[3] - M[0] * M[5]) * d;
-                sM[6] = (M[3] * M[7] - M[4] * M[6]) * d;
-                sM[7] = (M[1] * M[6] - M[0] * M[7]) * d;
-                sM[8] = (M[0] * M[4] - M[1] * M[3]) * d;
+                Mi[0] = (M[4] * M[8] - M[5] * M[7]) * d;
+                Mi[1] = (M[2] * M[7] - M[1] * M[8]) * d;
+                Mi[2] = (M[1] * M[5] - M[2] * M[4]) * d;
+                Mi[3] = (M[5] * M[6] - M[3] * M[8]) * d;
+                Mi[4] = (M[0] * M[8] - M[2] * M[6]) * d;
+                Mi[5] = (M[2] * M[3] - M[0] * M[5]) * d;
+                Mi[6] = (M[3] * M[7] - M[4] * M[6]) * d;
+                Mi[7] = (M[1] * M[6] - M[0] * M[7]) * d;
+                Mi[8] = (M[0] * M[4] - M[1] * M[3]) * d;
             }
         }
-        s_ok = ok;
-    }
-    for (int i = tid; i < 256; i += 256) s_hist[i] = 0;
-    if (tid < 64) { s_ones[tid] = 0; s_tot[tid] = 0; }
-    __syncthreads();
-    if (!s_ok) {
-        if (tid == 0) { res[0] = -1; res[1] = 0; }
-        continue;
-    }
-    const uint8_t* img = (lvl == 0) ? src0.base + (size_t)f * src0.fstride : pyr.base + (size_t)f * pyr.fstride + L.off;
-    const int pitch = (lvl == 0) ? src0.pitch : L.pitch;
-    // warpPerspective(INTER_LINEAR, BORDER_CONSTANT 0): 1/32-px coordinates, 15-bit bilinear weights
-    for (int i = tid; i < S * S; i += 256) {
-        const int y = i / S, x = i - y * S;
-        const double X0 = sM[0] * 0 + sM[1] * y + sM[2];
-        const double Y0 = sM[3] * 0 + sM[4] * y + sM[5];
-        const double W0d = sM[6] * 0 + sM[7] * y + sM[8];
-        double Wd = W0d + sM[6] * x;
-        Wd = Wd ? 32.0 / Wd : 0;
-        const double fX = fmax(-2147483648.0, fmin(2147483647.0, (X0 + sM[0] * x) * Wd));
-        const double fY = fmax(-2147483648.0, fmin(2147483647.0, (Y0 + sM[3] * x) * Wd));
-        const int X = ar_sat_int(fX), Y = ar_sat_int(fY);
-        int sx = X >> 5, sy = Y >> 5;
-        sx = sx < -32768 ? -32768 : sx > 32767 ? 32767 : sx;
-        sy = sy < -32768 ? -32768 : sy > 32767 ? 32767 : sy;
-        const int ax = X & 31, ay = Y & 31;
-        const int w00 = (32 - ax) * (32 - ay) * 32, w01 = ax * (32 - ay) * 32, w10 = (32 - ax) * ay * 32, w11 = ax * ay * 32;
-        auto px = [&](int xx, int yy) -> int {
-            if (xx < 0 || yy < 0 || xx >= L.w || yy >= L.h) return 0;
-            return img[(size_t)yy * pitch + xx];
-        };
-        int v = px(sx, sy) * w00 + px(sx + 1, sy) * w01 + px(sx, sy + 1) * w10 + px(sx + 1, sy + 1) * w11;
-        v = (v + (1 << 14)) >> 15;
-        v = v > 255 ? 255 : v;
-        spatch[i] = (uint8_t)v;
-        atomicAdd(&s_hist[v], 1);
-    }
-    __syncthreads();
-    if (tid == 0) { // getThreshVal_Otsu_8u (serial, 256 bins, double)
-        const int n = S * S;
-        double mu = 0, scale = 1. / n;
-        for (int i = 0; i < 256; i++) mu += i * (double)s_hist[i];
-        mu *= scale;
-        double mu1 = 0, q1 = 0, max_sigma = 0, max_val = 0;
-        for (int i = 0; i < 256; i++) {
-            const double p_i = s_hist[i] * scale;
-            mu1 *= q1;
-            q1 += p_i;
-            const double q2 = 1. - q1;
-            if (fmin(q1, q2) < 1.1920928955078125e-07 || fmax(q1, q2) > 1. - 1.1920928955078125e-07) continue;
-            mu1 = (mu1 + i * p_i) / q1;
-            const double mu2 = (mu - q1 * mu1) / q2;
-            const double sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2);
-            if (sigma > max_sigma) { max_sigma = sigma; max_val = i; }
+        if (!ok) {
+            if (lane == 0) { res[0] = -1; res[1] = 0; }
+            continue;
         }
-        s_th = (int)max_val;
-    }
-    __syncthreads();
-    const int th = s_th, n = nb + 2;
-    for (int i = tid; i < S * S; i += 256) {
-        const int y = i / S, x = i - y * S;
-        const int my = (int)__fdiv_rn(__fmul_rn((float)n, (float)y), (float)S);
-        const int mx = (int)__fdiv_rn(__fmul_rn((float)n, (float)x), (float)S);
-        if (spatch[i] > th) atomicAdd(&s_ones[my * n + mx], 1);
-        atomicAdd(&s_tot[my * n + mx], 1);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        uint8_t bits[64], inner[36], tmp[36];
-        bool ok = true;
-        for (int i = 0; i < n * n; i++) bits[i] = s_ones[i] > s_tot[i] / 2 ? 1 : 0;
-        for (int y = 0; y < n && ok; y++) {
-            const int inc = (y == 0 || y == n - 1) ? 1 : n - 1;
-            for (int x = 0; x < n; x += inc)
-                if (bits[y * n + x] != 0) { ok = false; break; }
+        for (int i = lane; i < 256; i += 64) s_hist[i] = 0;
+        s_ones[lane] = 0;
+        s_tot[lane] = 0;
+        __syncthreads();
+        const uint8_t* img = (lvl == 0) ? src0.base + (size_t)f * src0.fstride : pyr.base + (size_t)f * pyr.fstride + L.off;
+        const int pitch = (lvl == 0) ? src0.pitch : L.pitch;
+        // warpPerspective(INTER_LINEAR, BORDER_CONSTANT 0): 1/32-px coordinates, 15-bit bilinear weights
+        for (int i = lane; i < S * S; i += 64) {
+            const int y = i / S, xx = i - y * S;
+            const double X0 = Mi[0] * 0 + Mi[1] * y + Mi[2];
+            const double Y0 = Mi[3] * 0 + Mi[4] * y + Mi[5];
+            const double W0d = Mi[6] * 0 + Mi[7] * y + Mi[8];
+            double Wd = W0d + Mi[6] * xx;
+            Wd = Wd ? 32.0 / Wd : 0;
+            const double fX = fmax(-2147483648.0, fmin(2147483647.0, (X0 + Mi[0] * xx) * Wd));
+            const double fY = fmax(-2147483648.0, fmin(2147483647.0, (Y0 + Mi[3] * xx) * Wd));
+            const int X = ar_sat_int(fX), Y = ar_sat_int(fY);
+            int sx = X >> 5, sy = Y >> 5;
+            sx = sx < -32768 ? -32768 : sx > 32767 ? 32767 : sx;
+            sy = sy < -32768 ? -32768 : sy > 32767 ? 32767 : sy;
+            const int ax = X & 31, ay = Y & 31;
+            const int w00 = (32 - ax) * (32 - ay) * 32, w01 = ax * (32 - ay) * 32, w10 = (32 - ax) * ay * 32, w11 = ax * ay * 32;
+            auto px = [&](int px_, int py_) -> int {
+                if (px_ < 0 || py_ < 0 || px_ >= L.w || py_ >= L.h) return 0;
+                return img[(size_t)py_ * pitch + px_];
+            };
+            int v = px(sx, sy) * w00 + px(sx + 1, sy) * w01 + px(sx, sy + 1) * w10 + px(sx + 1, sy + 1) * w11;
+            v = (v + (1 << 14)) >> 15;
+            v = v > 255 ? 255 : v;
+            spatch[i] = (uint8_t)v;
+            atomicAdd(&s_hist[v], 1);
         }
-        if (ok) {
-            for (int y = 0; y < nb; y++)
-                for (int x = 0; x < nb; x++) inner[y * nb + x] = bits[(y + 1) * n + (x + 1)];
+        __syncthreads();
+        if (lane == 0) { // getThreshVal_Otsu_8u: serial by definition (running double sums), 256 bins
+            const int n = S * S;
+            double mu = 0, scale = 1. / n;
+            for (int i = 0; i < 256; i++) mu += i * (double)s_hist[i];
+            mu *= scale;
+            double mu1 = 0, q1 = 0, max_sigma = 0, max_val = 0;
+            for (int i = 0; i < 256; i++) {
+                const double p_i = s_hist[i] * scale;
+                mu1 *= q1;
+                q1 += p_i;
+                const double q2 = 1. - q1;
+                if (fmin(q1, q2) < 1.1920928955078125e-07 || fmax(q1, q2) > 1. - 1.1920928955078125e-07) continue;
+                mu1 = (mu1 + i * p_i) / q1;
+                const double mu2 = (mu - q1 * mu1) / q2;
+                const double sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2);
+                if (sigma > max_sigma) { max_sigma = sigma; max_val = i; }
+            }
+            s_th = (int)max_val;
+        }
+        __syncthreads();
+        const int th = s_th, n = nb + 2;
+        for (int i = lane; i < S * S; i += 64) {
+            const int y = i / S, xx = i - y * S;
+            const int my = (int)__fdiv_rn(__fmul_rn((float)n, (float)y), (float)S);
+            const int mx = (int)__fdiv_rn(__fmul_rn((float)n, (float)xx), (float)S);
+            if (spatch[i] > th) atomicAdd(&s_ones[my * n + mx], 1);
+            atomicAdd(&s_tot[my * n + mx], 1);
+        }
+        __syncthreads();
+        // cell bits (n*n <= 64: one lane per cell), border must be black
+        const int cy = lane / n, cx = lane - cy * n;
+        const bool incell = lane < n * n;
+        const int bit = incell && (s_ones[lane] > s_tot[lane] / 2);
+        const bool border = incell && (cy == 0 || cy == n - 1 || cx == 0 || cx == n - 1);
+        s_bits[lane] = (uint8_t)bit;
+        const bool bad = __ballot(border && bit) != 0ull;
+        __syncthreads();
+        if (lane < 4) {
+            // code of the inner nb x nb matrix rotated `lane` times: rotate(out(i,j) = in(nb-1-j, i)) applied lane times
+            unsigned long long v = 0;
+            int bpos = 0;
+            for (int y = nb - 1; y >= 0; y--)
+                for (int xx = nb - 1; xx >= 0; xx--) {
+                    int yy = y, xc = xx;
+                    for (int t = 0; t < lane; t++) { const int ny = nb - 1 - xc, nx = yy; yy = ny; xc = nx; }
+                    v |= (unsigned long long)s_bits[(yy + 1) * n + (xc + 1)] << bpos++;
+                }
+            s_ids[lane] = v;
+        }
+        __syncthreads();
+        int id = -1, nrot = 0;
+        if (!bad && s_ids[0] != 0) {
+            // first rotation whose code is in the dictionary; id = first index holding that code (map.insert semantics)
             for (int rr = 0; rr < 4; rr++) {
-                unsigned long long v = 0;
-                int b = 0;
-                for (int y = nb - 1; y >= 0; y--)
-                    for (int x = nb - 1; x >= 0; x--) v |= (unsigned long long)inner[y * nb + x] << b++;
-                s_ids[rr] = v;
-                for (int i = 0; i < nb; i++)
-                    for (int j = 0; j < nb; j++) tmp[i * nb + j] = inner[(nb - j - 1) * nb + i];
-                for (int i = 0; i < nb * nb; i++) inner[i] = tmp[i];
+                const unsigned long long want = s_ids[rr];
+                int best = 0x7fffffff;
+                for (int i = lane; i < ncodes; i += 64)
+                    if (codes[i] == want) best = min(best, i);
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o));
+                if (best != 0x7fffffff) { id = best; nrot = rr; break; }
             }
-            if (s_ids[0] == 0) ok = false;
         }
-        s_ok = ok;
-    }
-    __syncthreads();
-    int id = -1, nrot = 0;
-    if (s_ok) {
-        // first rotation whose code is in the dictionary; id = first index holding that code (map.insert semantics)
-        for (int rr = 0; rr < 4; rr++) {
-            const unsigned long long want = s_ids[rr];
-            if (tid == 0) s_found = 0x7fffffff;
-            __syncthreads();
-            int best = 0x7fffffff;
-            for (int i = tid; i < ncodes; i += 256)
-                if (codes[i] == want) best = min(best, i);
-            if (best != 0x7fffffff) atomicMin(&s_found, best);
-            __syncthreads();
-            const int got = s_found;
-            __syncthreads();
-            if (got != 0x7fffffff) { id = got; nrot = rr; break; }
-        }
-    }
-    if (tid == 0) { res[0] = id; res[1] = nrot; }
+        if (lane == 0) { res[0] = id; res[1] = nrot; }
     } // slot loop
 }
 

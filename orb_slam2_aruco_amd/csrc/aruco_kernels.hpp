@@ -30,7 +30,8 @@ struct ArLevel {
 __global__ void k_adaptive_threshold(ImgView src, int W, int H, int win, int C, double scale, uint32_t* bits,
                                      size_t bits_fstride, int wpr);
 __global__ void k_half_area(ImgView src, ImgView dst, int dw, int dh);
-__global__ void k_contours(const uint32_t* gbits, size_t bits_fstride, int wpr_g, int W, int H, int lds_bits_words,
+template <bool LDS_BITS>
+__global__ void k_contours_t(const uint32_t* gbits, size_t bits_fstride, int wpr_g, int W, int H, int lds_bits_words,
                            int min_len, uint32_t* candq, size_t candq_fstride, int candq_cap, uint32_t* pool,
                            size_t pool_fstride, int pool_cap, ArKept* kept_out, int kept_cap, ArRect* rects_out,
                            int rect_cap, int32_t* counts, uint32_t* gpadded, size_t gpadded_fstride);
@@ -43,16 +44,17 @@ __global__ void k_finalize(const ArRect* rects, int rect_cap, const int32_t* can
                            const int32_t* result, const uint32_t* pool, size_t pool_fstride, orbfe_marker* out,
                            int out_cap, int32_t* n_out);
 
-#define CT_THREADS 1024
+#define CT_THREADS 256
 #define CT_WAVES (CT_THREADS / 64)
 #define AP_STACK 64
 #define AP_OUT 64
+#define CT_PROBE 24 // steps a border start is followed before it is queued as a long walk (< the 70-point gate)
 
 inline size_t contours_lds_bytes(int lds_bits_words, int kept_cap)
 {
     size_t b = ((size_t)lds_bits_words * 4 + 15) & ~(size_t)15;
     b += (size_t)kept_cap * 8;      // keys
-    b += (size_t)kept_cap * 4 * 3;  // len, off, rect flag
+    b += (size_t)kept_cap * 4 * 4;  // arena offsets, len, off, rect flag (the last three double as the long-walk queue)
     b += (size_t)CT_WAVES * AP_OUT * 8;
     b += (size_t)CT_WAVES * AP_STACK * 8;
     return b + 16;

@@ -32,51 +32,119 @@ struct BitImage {
 };
 
 // direction codes 0..7 = E, NE, N, NW, W, SW, S, SE (OpenCV icvCodeDeltas)
-ORBFE_HD int dir_dx(int s) { return (s == 0 || s == 1 || s == 7) ? 1 : (s == 3 || s == 4 || s == 5) ? -1 : 0; }
-ORBFE_HD int dir_dy(int s) { return (s == 1 || s == 2 || s == 3) ? -1 : (s == 5 || s == 6 || s == 7) ? 1 : 0; }
+// dx + 1 / dy + 1 of the 8 directions packed two bits each (dx: 1 1 0 -1 -1 -1 0 1; dy: 0 -1 -1 -1 0 1 1 1)
+ORBFE_HD int dir_dx(int s) { return (int)((((2u) | (2u << 2) | (1u << 4) | (0u << 6) | (0u << 8) | (0u << 10) | (1u << 12) | (2u << 14)) >> (2 * s)) & 3u) - 1; }
+ORBFE_HD int dir_dy(int s) { return (int)((((1u) | (0u << 2) | (0u << 4) | (0u << 6) | (1u << 8) | (2u << 10) | (2u << 12) | (2u << 14)) >> (2 * s)) & 3u) - 1; }
 
-// Follows one border.  (sx, sy): start pixel in PADDED coordinates; is_hole selects the hole start rule.
-// For holes (hx, hy) = (sx+1, sy) is the hole's candidate raster-first background pixel.
-// out (may be null): receives the points as (x | y << 16) in IMAGE coordinates, at most out_cap.
-// Returns the number of border points, or -1 if the walk met a raster-smaller pixel (= not the canonical start),
-// or -2 if max_steps was exceeded.
-ORBFE_HD int trace_border(const BitImage& im, int sx, int sy, int is_hole, uint32_t* out, int out_cap, int max_steps)
+// The 8 neighbours of padded pixel (x, y) as one byte, bit k = direction k (E, NE, N, NW, W, SW, S, SE).
+// Three 64-bit funnel reads; the bit array must have one spare word after the last row.
+ORBFE_HD unsigned ring8(const BitImage& im, int x, int y)
 {
-    const int start_key = is_hole ? (sy * 65536 + sx + 1) : (sy * 65536 + sx);
+    const int sh = (x - 1) & 31, w0 = (x - 1) >> 5;
+    const uint32_t* r0 = im.bits + (y - 1) * im.wpr + w0;
+    const uint32_t* r1 = r0 + im.wpr;
+    const uint32_t* r2 = r1 + im.wpr;
+    const unsigned a = (unsigned)((((unsigned long long)r0[1] << 32) | r0[0]) >> sh) & 7u; // row y-1: x-1, x, x+1
+    const unsigned b = (unsigned)((((unsigned long long)r1[1] << 32) | r1[0]) >> sh) & 7u; // row y
+    const unsigned c = (unsigned)((((unsigned long long)r2[1] << 32) | r2[0]) >> sh) & 7u; // row y+1
+    // E = b2; NE, N, NW = a2, a1, a0 (= bit-reversed a); W = b0; SW, S, SE = c0, c1, c2
+    const unsigned rev3 = (0x00ee9ca0u >> (3 * a)) & 7u; // 3-bit reversal table: 0 4 2 6 1 5 3 7
+    return (b >> 2) | (rev3 << 1) | ((b & 1u) << 4) | (c << 5);
+}
+
+ORBFE_HD int ctz8(unsigned v) // v != 0
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __ffs((int)v) - 1;
+#else
+    return __builtin_ctz(v);
+#endif
+}
+
+// Border following as an explicit state machine, so that a GPU lane can advance its walk by ONE step per loop
+// iteration and pick up a new candidate as soon as its walk ends (no lane waits for the longest walk of its wave).
+struct TraceState {
+    int sx, sy, is_hole, start_key;
+    int i1x, i1y; // first neighbour found from the start pixel (termination test)
+    int i3x, i3y; // current pixel
+    int s;        // direction from which the current pixel was entered (+4), OpenCV's `s`
+    int n;        // points emitted so far
+    unsigned ring;
+};
+
+// (sx, sy): start pixel in PADDED coordinates; is_hole selects the hole start rule; for holes (sx+1, sy) is the
+// hole's candidate raster-first background pixel.  Returns 1 if the border is a single pixel (n = 1, done), else 0.
+ORBFE_HD int trace_init(const BitImage& im, TraceState& t, int sx, int sy, int is_hole)
+{
+    t.sx = sx; t.sy = sy; t.is_hole = is_hole;
+    t.start_key = is_hole ? (sy * 65536 + sx + 1) : (sy * 65536 + sx);
     int s_end, s;
     s_end = s = is_hole ? 0 : 4;
-    int i1x, i1y;
+    t.ring = ring8(im, sx, sy);
     do {
         s = (s - 1) & 7;
-        i1x = sx + dir_dx(s);
-        i1y = sy + dir_dy(s);
-    } while (im.get(i1x, i1y) == 0 && s != s_end);
-    if (s == s_end) { // single pixel domain
+    } while (((t.ring >> s) & 1u) == 0 && s != s_end);
+    t.n = 0;
+    t.i3x = sx; t.i3y = sy;
+    if (s == s_end) { t.n = 1; return 1; }
+    t.i1x = sx + dir_dx(s); t.i1y = sy + dir_dy(s);
+    t.s = s;
+    return 0;
+}
+
+// One step.  *pt receives the emitted point (x | y << 16, image coordinates).  Returns 0 = continue,
+// 1 = border closed (t.n = length), -1 = met a raster-smaller pixel (not the canonical start).
+// "Search counter-clockwise from the direction after the previous pixel for the first foreground neighbour" is a
+// rotate + count-trailing-zeros on the 3x3 neighbourhood byte.
+ORBFE_HD int trace_step(const BitImage& im, TraceState& t, uint32_t* pt)
+{
+    const int rot = t.s + 1; // 1..8: first direction examined
+    const unsigned m = t.ring | (t.ring << 8) | (t.ring << 16);
+    const unsigned r = (m >> rot) & 0xffu; // bit i = direction (rot + i) & 7; the previous pixel guarantees r != 0
+    const int i = ctz8(r);
+    const int s = (rot + i) & 7;
+    const int key3 = t.i3y * 65536 + t.i3x;
+    if (t.is_hole) {
+        // examined background 4-neighbours belong to the hole being followed
+        const unsigned exr = (1u << i) - 1u;
+        const unsigned ex = ((exr << rot) | ((exr << rot) >> 8)) & 0xffu;
+        if (((ex & 0x04u) && key3 - 65536 < t.start_key) || // N
+            ((ex & 0x10u) && key3 - 1 < t.start_key) ||     // W
+            ((ex & 0x01u) && key3 + 1 < t.start_key) ||     // E
+            ((ex & 0x40u) && key3 + 65536 < t.start_key))   // S
+            return -1;
+    } else if (key3 < t.start_key) {
+        return -1;
+    }
+    *pt = (uint32_t)(t.i3x - 1) | ((uint32_t)(t.i3y - 1) << 16);
+    t.n++;
+    const int i4x = t.i3x + dir_dx(s), i4y = t.i3y + dir_dy(s);
+    if (i4x == t.sx && i4y == t.sy && t.i3x == t.i1x && t.i3y == t.i1y) return 1;
+    t.i3x = i4x;
+    t.i3y = i4y;
+    t.ring = ring8(im, i4x, i4y);
+    t.s = (s + 4) & 7;
+    return 0;
+}
+
+// Whole-border convenience wrapper (host prototype, and the point-emitting second pass on the GPU).
+// out (may be null) receives at most out_cap points.  Returns the length, -1 (not canonical) or -2 (max_steps).
+ORBFE_HD int trace_border(const BitImage& im, int sx, int sy, int is_hole, uint32_t* out, int out_cap, int max_steps)
+{
+    TraceState t;
+    if (trace_init(im, t, sx, sy, is_hole)) {
         if (out && out_cap > 0) out[0] = (uint32_t)(sx - 1) | ((uint32_t)(sy - 1) << 16);
         return 1;
     }
-    int i3x = sx, i3y = sy, i4x = 0, i4y = 0, n = 0;
     for (;;) {
-        s_end = s;
-        while (s < 15) {
-            ++s;
-            i4x = i3x + dir_dx(s & 7);
-            i4y = i3y + dir_dy(s & 7);
-            if (im.get(i4x, i4y)) break;
-            // an examined background pixel: for holes it belongs to the hole being followed (4-neighbours only)
-            if (is_hole && !(s & 1) && (i4y * 65536 + i4x) < start_key) return -1;
-        }
-        s &= 7;
-        if (!is_hole && (i3y * 65536 + i3x) < start_key) return -1;
-        if (out && n < out_cap) out[n] = (uint32_t)(i3x - 1) | ((uint32_t)(i3y - 1) << 16);
-        n++;
-        if (n > max_steps) return -2;
-        if (i4x == sx && i4y == sy && i3x == i1x && i3y == i1y) break;
-        i3x = i4x;
-        i3y = i4y;
-        s = (s + 4) & 7;
+        uint32_t pt;
+        const int n0 = t.n;
+        const int st = trace_step(im, t, &pt);
+        if (st < 0) return -1;
+        if (out && n0 < out_cap) out[n0] = pt;
+        if (st == 1) return t.n;
+        if (t.n > max_steps) return -2;
     }
-    return n;
 }
 
 // Candidate tests on the padded bit image (px, py in 1..W, 1..H).

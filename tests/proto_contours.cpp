@@ -14,7 +14,7 @@ extern "C" int proto_find_contours(const uint8_t* img, int w, int h, int32_t* le
                                    int32_t* points, int max_points, int64_t* work_steps)
 {
     const int wpr = (w + 2 + 31) / 32;
-    std::vector<uint32_t> bits((size_t)wpr * (h + 2), 0);
+    std::vector<uint32_t> bits((size_t)wpr * (h + 2) + 2, 0); // + spare word for ring8's funnel read
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++)
             if (img[(size_t)y * w + x]) bits[(size_t)(y + 1) * wpr + ((x + 1) >> 5)] |= 1u << ((x + 1) & 31);
