@@ -124,8 +124,12 @@ def main():
         mcap = det.capacity
         d_mk = torch.zeros((B, mcap, 9), dtype=torch.int32, device=dev)   # 36-byte marker records
         d_nmk = torch.zeros(B, dtype=torch.int32, device=dev)
+    # two HIP streams: the ORB extractor + matching on one, the ArUco detector on the other.  Both only read the
+    # resident frames, so the latency-bound ArUco kernels overlap with the bandwidth/VALU-bound ORB kernels.
     stream = torch.cuda.current_stream(dev)
     sp = ctypes.c_void_p(stream.cuda_stream)
+    stream2 = torch.cuda.Stream(dev)
+    sp2 = ctypes.c_void_p(stream2.cuda_stream)
 
     gathered = None
     if world > 1:
@@ -133,11 +137,12 @@ def main():
         gathered = [[torch.empty_like(t) for _ in range(world)] if rank == 0 else None for t in rec]
 
     def step():
+        if use_aruco:
+            stream2.wait_stream(stream)
+            det.detect_batch_device(d_imgs.data_ptr(), B, rows * pitch, rows, cols, pitch, d_mk.data_ptr(), mcap,
+                                    d_nmk.data_ptr(), sp2)
         ex.extract_batch_device(d_imgs.data_ptr(), B, rows * pitch, rows, cols, pitch, d_kps.data_ptr(),
                                 d_desc.data_ptr(), cap, d_n.data_ptr(), sp)
-        if use_aruco:
-            det.detect_batch_device(d_imgs.data_ptr(), B, rows * pitch, rows, cols, pitch, d_mk.data_ptr(), mcap,
-                                    d_nmk.data_ptr(), sp)
         # frame t vs t-1: all-pairs knn2 + one SearchForInitialization-style windowed pass
         binding._check(L, L.orbfe_knn2_batch_device(d_desc.data_ptr(), d_n.data_ptr(), cap * 32, cap,
                                                     d_desc.data_ptr() + cap * 32, d_n.data_ptr() + 4, cap * 32, cap,
@@ -146,6 +151,8 @@ def main():
         binding._check(L, L.orbfe_search_for_initialization_batch_device(
             d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap, B - 1, cols, rows, 100, 0.9, 1,
             d_m12.data_ptr(), d_nm.data_ptr(), sp), "sfi")
+        if use_aruco:
+            stream.wait_stream(stream2)
         if world > 1:
             for t, g in zip(rec, gathered):
                 dist.gather(t, g, dst=0)

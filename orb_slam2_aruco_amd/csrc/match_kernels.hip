@@ -90,7 +90,6 @@ __global__ void k_knn2_merge(const int32_t* __restrict__ pidx, const int32_t* __
 // ---------------------------------------------------------------------------- SearchForInitialization ----------
 #define GRID_COLS 64
 #define GRID_ROWS 48
-#define SFI_MAXC 512 // candidates examined per query in one go (wave-strided)
 
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 {
@@ -103,28 +102,28 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 }
 
 // One workgroup (256 threads) per frame pair p: F1 = frame p, F2 = frame p+1 of a stream.
-// Phase A builds F2's 64x48 grid in LDS (cell lists in keypoint-index order, like AssignFeaturesToGrid).
-// Phase B (parallel): for every level-0 keypoint of F1, the candidate list of GetFeaturesInArea with its Hamming
-//   distances goes to a CSR scratch in HBM, in the reference's candidate order (ix outer, iy inner, cell order).
+// Phase A: F2's level-0 keypoints sorted by (grid column, grid row, index) in LDS.  That is exactly the order in which
+//   Frame::GetFeaturesInArea walks the 64x48 grid (ix outer, iy inner, push_back order inside a cell), and
+//   SearchForInitialization only ever asks for level 0 (minLevel = maxLevel = 0), so a query's candidate list is the
+//   sub-sequence of this list whose cell lies in the query's cell rectangle and which passes the |dx|,|dy| < r test.
+// Phase B (parallel, one wave per query): candidate indices + Hamming distances into a fixed-stride scratch row.
 // Phase C (wave 0, serial over i1 as in the reference because vMatchedDistance couples the queries): best /
 //   second-best with the "already matched better" skip, ratio + TH_LOW tests, mutual-uniqueness bookkeeping,
 //   rotation histogram, ComputeThreeMaxima, final vbPrevMatched update.
+#define SFI_MAXL0 1024
 __global__ __launch_bounds__(256) void k_search_init(const orbfe_keypoint* __restrict__ kps,
                                                      const uint8_t* __restrict__ desc, const int32_t* __restrict__ nkp,
                                                      int capacity, int cols, int rows, float window, float nnratio,
                                                      int check_ori, const float* __restrict__ prev_in,
                                                      float* __restrict__ prev_out, int32_t* __restrict__ matches12,
-                                                     int32_t* __restrict__ nmatches_out, int32_t* __restrict__ csr_off,
-                                                     int32_t* __restrict__ csr_idx, uint8_t* __restrict__ csr_dist,
-                                                     int csr_cap, int32_t* __restrict__ scratch /*3*capacity per pair*/,
+                                                     int32_t* __restrict__ nmatches_out, int32_t* __restrict__ csr_cnt,
+                                                     uint16_t* __restrict__ csr_idx, uint8_t* __restrict__ csr_dist,
+                                                     int row_stride, int32_t* __restrict__ scratch /*3*capacity per pair*/,
                                                      int32_t* __restrict__ overflow)
 {
-    __shared__ int s_cnt[GRID_COLS * GRID_ROWS];
-    __shared__ int s_off[GRID_COLS * GRID_ROWS + 1];
-    __shared__ int s_scan[256];
+    __shared__ uint32_t s_sorted[SFI_MAXL0]; // (cell << 16) | index, ascending
     __shared__ int s_hist[30];
-    __shared__ int s_total;
-    extern __shared__ short s_cellidx[]; // capacity entries: F2 keypoint indices sorted by cell (stable)
+    __shared__ int s_nl0;
 
     const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const orbfe_keypoint* k1 = kps + (size_t)p * capacity;
@@ -133,9 +132,9 @@ __global__ __launch_bounds__(256) void k_search_init(const orbfe_keypoint* __res
     const uint8_t* d2 = desc + (size_t)(p + 1) * capacity * 32;
     const int n1 = nkp[p], n2 = nkp[p + 1];
     int32_t* m12 = matches12 + (size_t)p * capacity;
-    int32_t* coff = csr_off + (size_t)p * (capacity + 1);
-    int32_t* cidx = csr_idx + (size_t)p * csr_cap;
-    uint8_t* cdist = csr_dist + (size_t)p * csr_cap;
+    int32_t* ccnt = csr_cnt + (size_t)p * capacity;
+    uint16_t* cidx = csr_idx + (size_t)p * capacity * row_stride;
+    uint8_t* cdist = csr_dist + (size_t)p * capacity * row_stride;
     int32_t* vMatchedDistance = scratch + (size_t)p * 3 * capacity;
     int32_t* vnMatches21 = vMatchedDistance + capacity;
     int32_t* rotbin = vnMatches21 + capacity; // per i1: histogram bin or -1
@@ -146,133 +145,88 @@ __global__ __launch_bounds__(256) void k_search_init(const orbfe_keypoint* __res
     const float invW = __fdiv_rn((float)GRID_COLS, (float)cols - mnMinX);
     const float invH = __fdiv_rn((float)GRID_ROWS, (float)rows - mnMinY);
 
-    // ---- phase A: grid of F2 (Frame.cc:183-198, :335-345)
-    for (int i = tid; i < GRID_COLS * GRID_ROWS; i += 256) s_cnt[i] = 0;
+    // ---- phase A: level-0 keypoints of F2 that fall inside the grid (Frame.cc:183-198, :335-345), sorted
+    if (tid == 0) s_nl0 = 0;
     __syncthreads();
     for (int i = tid; i < n2; i += 256) {
-        const int px = (int)roundf(__fmul_rn(k2[i].x - mnMinX, invW));
-        const int py = (int)roundf(__fmul_rn(k2[i].y - mnMinY, invH));
-        if (px >= 0 && px < GRID_COLS && py >= 0 && py < GRID_ROWS) atomicAdd(&s_cnt[px * GRID_ROWS + py], 1);
-    }
-    __syncthreads();
-    { // exclusive scan of 3072 counts: 12 per thread
-        int loc[12], sum = 0;
-#pragma unroll
-        for (int k = 0; k < 12; k++) { loc[k] = s_cnt[tid * 12 + k]; sum += loc[k]; }
-        s_scan[tid] = sum;
-        __syncthreads();
-        for (int o = 1; o < 256; o <<= 1) {
-            int t = tid >= o ? s_scan[tid - o] : 0;
-            __syncthreads();
-            s_scan[tid] += t;
-            __syncthreads();
-        }
-        int base = s_scan[tid] - sum;
-#pragma unroll
-        for (int k = 0; k < 12; k++) { s_off[tid * 12 + k] = base; base += loc[k]; }
-        if (tid == 255) s_off[GRID_COLS * GRID_ROWS] = base;
-    }
-    __syncthreads();
-    for (int i = tid; i < GRID_COLS * GRID_ROWS; i += 256) s_cnt[i] = 0;
-    __syncthreads();
-    for (int i = tid; i < n2; i += 256) {
-        const int px = (int)roundf(__fmul_rn(k2[i].x - mnMinX, invW));
-        const int py = (int)roundf(__fmul_rn(k2[i].y - mnMinY, invH));
+        const orbfe_keypoint kp = k2[i];
+        if (kp.octave != 0) continue;
+        const int px = (int)roundf(__fmul_rn(kp.x - mnMinX, invW));
+        const int py = (int)roundf(__fmul_rn(kp.y - mnMinY, invH));
         if (px >= 0 && px < GRID_COLS && py >= 0 && py < GRID_ROWS) {
-            const int c = px * GRID_ROWS + py;
-            s_cellidx[s_off[c] + atomicAdd(&s_cnt[c], 1)] = (short)i;
+            const int k = atomicAdd(&s_nl0, 1);
+            if (k < SFI_MAXL0) s_sorted[k] = ((uint32_t)(px * GRID_ROWS + py) << 16) | (uint32_t)i;
         }
     }
     __syncthreads();
-    // restore keypoint-index order inside each cell (push_back order of AssignFeaturesToGrid)
-    for (int c = tid; c < GRID_COLS * GRID_ROWS; c += 256) {
-        const int b = s_off[c], e = s_off[c + 1];
-        for (int i = b + 1; i < e; i++) {
-            const short v = s_cellidx[i];
-            int j = i - 1;
-            while (j >= b && s_cellidx[j] > v) { s_cellidx[j + 1] = s_cellidx[j]; j--; }
-            s_cellidx[j + 1] = v;
-        }
-    }
+    if (tid == 0 && s_nl0 > SFI_MAXL0) { atomicMax(overflow, s_nl0); s_nl0 = SFI_MAXL0; }
     __syncthreads();
+    const int nl0 = s_nl0;
+    {
+        int P = 1;
+        while (P < nl0) P <<= 1;
+        for (int i = nl0 + tid; i < P; i += 256) s_sorted[i] = 0xffffffffu;
+        __syncthreads();
+        for (int k = 2; k <= P; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = tid; t < (P >> 1); t += 256) {
+                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    const int l = i | j;
+                    const uint32_t a = s_sorted[i], b = s_sorted[l];
+                    const bool up = ((i & k) == 0);
+                    if ((a > b) == up) { s_sorted[i] = b; s_sorted[l] = a; }
+                }
+                __syncthreads();
+            }
+    }
+    if (nl0 > row_stride && tid == 0) atomicMax(overflow, nl0);
 
-    // ---- phase B: candidate lists (Frame.cc:280-333) + distances.  One wave per query, lanes over cells' entries.
-    // pass 1 counts, pass 2 writes; counts are scanned by wave 0 in between.
-    for (int pass = 0; pass < 2; pass++) {
-        for (int i1 = wid; i1 < n1; i1 += 4) {
-            int count = 0;
-            const orbfe_keypoint kp1 = k1[i1];
-            if (kp1.octave <= 0) {
-                const float x = prev ? prev[2 * i1] : kp1.x, y = prev ? prev[2 * i1 + 1] : kp1.y;
-                const float r = window;
-                const int nMinCellX = max(0, (int)floorf(__fmul_rn(x - mnMinX - r, invW)));
-                const int nMaxCellX = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(x - mnMinX + r, invW)));
-                const int nMinCellY = max(0, (int)floorf(__fmul_rn(y - mnMinY - r, invH)));
-                const int nMaxCellY = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(y - mnMinY + r, invH)));
-                if (!(nMinCellX >= GRID_COLS || nMaxCellX < 0 || nMinCellY >= GRID_ROWS || nMaxCellY < 0)) {
-                    uint4 a0, a1;
-                    a0 = reinterpret_cast<const uint4*>(d1)[2 * i1];
-                    a1 = reinterpret_cast<const uint4*>(d1)[2 * i1 + 1];
-                    const int wbase = pass ? coff[i1] : 0;
-                    for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
-                        // cells (ix, nMinCellY..nMaxCellY) are contiguous in the sorted index array
-                        const int b = s_off[ix * GRID_ROWS + nMinCellY], e = s_off[ix * GRID_ROWS + nMaxCellY + 1];
-                        for (int j0 = b; j0 < e; j0 += 64) {
-                            const int j = j0 + lane;
-                            bool ok = false;
-                            int i2 = 0;
-                            if (j < e) {
-                                i2 = s_cellidx[j];
-                                const orbfe_keypoint kp2 = k2[i2];
-                                // bCheckLevels is true for (minLevel, maxLevel) = (0, 0)
-                                ok = !(kp2.octave < 0) && !(kp2.octave > 0) && fabsf(kp2.x - x) < r &&
-                                     fabsf(kp2.y - y) < r;
-                            }
-                            const unsigned long long m = __ballot(ok);
-                            if (pass && ok) {
-                                const int pos = wbase + count +
-                                                __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
-                                                                          __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-                                if (pos < csr_cap) {
-                                    const uint4 b0 = reinterpret_cast<const uint4*>(d2)[2 * i2];
-                                    const uint4 b1 = reinterpret_cast<const uint4*>(d2)[2 * i2 + 1];
-                                    cidx[pos] = i2;
-                                    const int d = hamming256(a0, a1, b0, b1);
-                                    cdist[pos] = (uint8_t)(d > 255 ? 255 : d); // 256 only for exact complements; > TH_LOW anyway
-                                }
-                            }
-                            count += __popcll(m);
+    // ---- phase B: candidate lists (Frame.cc:280-333) + distances.  One wave per query.
+    for (int i1 = wid; i1 < n1; i1 += 4) {
+        int count = 0;
+        const orbfe_keypoint kp1 = k1[i1];
+        if (kp1.octave <= 0) {
+            const float x = prev ? prev[2 * i1] : kp1.x, y = prev ? prev[2 * i1 + 1] : kp1.y;
+            const float r = window;
+            const int nMinCellX = max(0, (int)floorf(__fmul_rn(x - mnMinX - r, invW)));
+            const int nMaxCellX = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(x - mnMinX + r, invW)));
+            const int nMinCellY = max(0, (int)floorf(__fmul_rn(y - mnMinY - r, invH)));
+            const int nMaxCellY = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(y - mnMinY + r, invH)));
+            if (!(nMinCellX >= GRID_COLS || nMaxCellX < 0 || nMinCellY >= GRID_ROWS || nMaxCellY < 0)) {
+                const uint4 a0 = reinterpret_cast<const uint4*>(d1)[2 * i1];
+                const uint4 a1 = reinterpret_cast<const uint4*>(d1)[2 * i1 + 1];
+                uint16_t* ri = cidx + (size_t)i1 * row_stride;
+                uint8_t* rd = cdist + (size_t)i1 * row_stride;
+                for (int j0 = 0; j0 < nl0; j0 += 64) {
+                    const int j = j0 + lane;
+                    bool ok = false;
+                    int i2 = 0;
+                    if (j < nl0) {
+                        const uint32_t e = s_sorted[j];
+                        const int cell = e >> 16, cx = cell / GRID_ROWS, cy = cell - cx * GRID_ROWS;
+                        i2 = e & 0xffff;
+                        if (cx >= nMinCellX && cx <= nMaxCellX && cy >= nMinCellY && cy <= nMaxCellY) {
+                            const orbfe_keypoint kp2 = k2[i2];
+                            ok = fabsf(kp2.x - x) < r && fabsf(kp2.y - y) < r;
                         }
                     }
-                }
-            }
-            if (!pass && lane == 0) coff[i1 + 1] = count; // counts first, scanned below
-        }
-        __syncthreads();
-        if (!pass) {
-            if (wid == 0) {
-                int run = 0;
-                if (lane == 0) coff[0] = 0;
-                for (int i0 = 0; i0 < n1; i0 += 64) {
-                    const int i = i0 + lane;
-                    int c = i < n1 ? coff[i + 1] : 0;
-                    int incl = c;
-#pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) {
-                        int t = __shfl_up(incl, o);
-                        if (lane >= o) incl += t;
+                    const unsigned long long m = __ballot(ok);
+                    if (ok) {
+                        const int pos = count + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                                                         __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                        if (pos < row_stride) {
+                            const uint4 b0 = reinterpret_cast<const uint4*>(d2)[2 * i2];
+                            const uint4 b1 = reinterpret_cast<const uint4*>(d2)[2 * i2 + 1];
+                            ri[pos] = (uint16_t)i2;
+                            const int d = hamming256(a0, a1, b0, b1);
+                            rd[pos] = (uint8_t)(d > 255 ? 255 : d); // 256 only for exact complements; > TH_LOW anyway
+                        }
                     }
-                    if (i < n1) coff[i + 1] = run + incl;
-                    run += __shfl(incl, 63);
-                }
-                if (lane == 0) {
-                    s_total = run;
-                    if (run > csr_cap) atomicMax(overflow, run);
+                    count += __popcll(m);
                 }
             }
-            __threadfence_block();
-            __syncthreads();
         }
+        if (lane == 0) ccnt[i1] = min(count, row_stride);
     }
     for (int i = tid; i < n2; i += 256) { vMatchedDistance[i] = INT_MAX; vnMatches21[i] = -1; }
     for (int i = tid; i < n1; i += 256) { m12[i] = -1; rotbin[i] = -1; }
@@ -285,16 +239,18 @@ __global__ __launch_bounds__(256) void k_search_init(const orbfe_keypoint* __res
     int nmatches = 0;
     const float factor = 1.0f / 30; // HISTO_LENGTH; the upstream "1/30" quirk is kept (App. D)
     for (int i1 = 0; i1 < n1; i1++) {
-        const int b = coff[i1], e = min(coff[i1 + 1], csr_cap);
-        if (e <= b) continue;
+        const int e = ccnt[i1];
+        if (e <= 0) continue;
+        const uint16_t* ri = cidx + (size_t)i1 * row_stride;
+        const uint8_t* rd = cdist + (size_t)i1 * row_stride;
         // best = first minimum among candidates with vMatchedDistance[i2] > dist; second = next smallest
         unsigned long long bestk = ~0ull, secondk = ~0ull;
-        for (int j0 = b; j0 < e; j0 += 64) {
+        for (int j0 = 0; j0 < e; j0 += 64) {
             const int j = j0 + lane;
             unsigned long long key = ~0ull;
             if (j < e) {
-                const int i2 = cidx[j], d = cdist[j];
-                if (!(vMatchedDistance[i2] <= d)) key = ((unsigned long long)d << 32) | (unsigned)(j - b);
+                const int i2 = ri[j], d = rd[j];
+                if (!(vMatchedDistance[i2] <= d)) key = ((unsigned long long)d << 32) | (unsigned)j;
             }
             const unsigned long long m1 = wave_min_u64(key);
             const unsigned long long k2nd = wave_min_u64(key == m1 ? ~0ull : key);
@@ -305,7 +261,7 @@ __global__ __launch_bounds__(256) void k_search_init(const orbfe_keypoint* __res
         if (bestk == ~0ull) continue;
         const int bestDist = (int)(bestk >> 32);
         const int bestDist2 = secondk == ~0ull ? INT_MAX : (int)(secondk >> 32);
-        const int bestIdx2 = cidx[b + (int)(bestk & 0xffffffffu)];
+        const int bestIdx2 = ri[(int)(bestk & 0xffffffffu)];
         if (bestDist <= 50) { // TH_LOW
             if ((float)bestDist < __fmul_rn((float)bestDist2, nnratio)) {
                 const int old = vnMatches21[bestIdx2];
@@ -371,7 +327,7 @@ __global__ __launch_bounds__(256) void k_search_init(const orbfe_keypoint* __res
 }
 
 struct MatchWorkspace {
-    DevBuf pidx, pbest, psecond, csr_off, csr_idx, csr_dist, scratch, overflow, prev;
+    DevBuf pidx, pbest, psecond, csr_cnt, csr_idx, csr_dist, scratch, overflow, prev;
     DevBuf q, t, nq, nt, oidx, obest, osecond, kps, desc, nk, m12, nm;
     int csr_per_pair = 0; // CSR slots per frame pair (grown by the host wrapper on overflow)
 };
@@ -420,21 +376,22 @@ static int sfi_launch(const orbfe_keypoint* d_kps, const uint8_t* d_desc, const 
                       int cols, int rows, int window, float nnratio, int check_ori, const float* d_prev_in,
                       float* d_prev_out, int32_t* d_m12, int32_t* d_nm, hipStream_t s)
 {
-    if (capacity > 32767) return fail(ORBFE_ERR_INVALID, "capacity above 32767 keypoints per frame is unsupported");
+    if (capacity > 65535) return fail(ORBFE_ERR_INVALID, "capacity above 65535 keypoints per frame is unsupported");
     MatchWorkspace& w = ws();
-    // CSR capacity: level-0 queries x their window candidates; the host wrapper grows it on overflow
-    const int want = std::max(w.csr_per_pair, capacity * 64);
-    w.csr_per_pair = want;
+    // candidate rows have a fixed stride: at most every level-0 keypoint of F2 is a candidate; the host wrapper
+    // grows the stride when a frame reports more level-0 keypoints than that
+    const int stride = std::max(w.csr_per_pair, std::min(SFI_MAXL0, (capacity / 2 + 63) / 64 * 64));
+    w.csr_per_pair = stride;
     int rc;
-    if ((rc = w.csr_off.ensure((size_t)npairs * (capacity + 1) * 4)) || (rc = w.csr_idx.ensure((size_t)npairs * want * 4)) ||
-        (rc = w.csr_dist.ensure((size_t)npairs * want)) || (rc = w.scratch.ensure((size_t)npairs * 3 * capacity * 4)) ||
-        (rc = w.overflow.ensure(16)))
+    if ((rc = w.csr_cnt.ensure((size_t)npairs * capacity * 4)) ||
+        (rc = w.csr_idx.ensure((size_t)npairs * capacity * stride * 2)) ||
+        (rc = w.csr_dist.ensure((size_t)npairs * capacity * stride)) ||
+        (rc = w.scratch.ensure((size_t)npairs * 3 * capacity * 4)) || (rc = w.overflow.ensure(16)))
         return rc;
     ORBFE_HIP(hipMemsetAsync(w.overflow.p, 0, 4, s));
-    const size_t lds = (size_t)capacity * 2 + 16;
-    hipLaunchKernelGGL(k_search_init, dim3(npairs), dim3(256), lds, s, d_kps, d_desc, d_n, capacity, cols, rows,
-                       (float)window, nnratio, check_ori, d_prev_in, d_prev_out, d_m12, d_nm, w.csr_off.as<int32_t>(),
-                       w.csr_idx.as<int32_t>(), w.csr_dist.as<uint8_t>(), want, w.scratch.as<int32_t>(),
+    hipLaunchKernelGGL(k_search_init, dim3(npairs), dim3(256), 0, s, d_kps, d_desc, d_n, capacity, cols, rows,
+                       (float)window, nnratio, check_ori, d_prev_in, d_prev_out, d_m12, d_nm, w.csr_cnt.as<int32_t>(),
+                       w.csr_idx.as<uint16_t>(), w.csr_dist.as<uint8_t>(), stride, w.scratch.as<int32_t>(),
                        w.overflow.as<int32_t>());
     ORBFE_HIP(hipGetLastError());
     return ORBFE_OK;
@@ -549,7 +506,8 @@ int orbfe_search_for_initialization(const orbfe_keypoint* kps1, const uint8_t* d
         ORBFE_HIP(hipMemcpy(&ovf, w.overflow.p, 4, hipMemcpyDeviceToHost));
         if (!ovf) break;
         if (attempt) return fail(ORBFE_ERR_CAPACITY, "candidate list overflow (%d)", ovf);
-        w.csr_per_pair = ovf + 64;
+        if (ovf > SFI_MAXL0) return fail(ORBFE_ERR_CAPACITY, "%d level-0 keypoints exceed the supported %d", ovf, SFI_MAXL0);
+        w.csr_per_pair = ovf;
     }
     ORBFE_HIP(hipMemcpy(matches12, w.m12.p, (size_t)n1 * 4, hipMemcpyDeviceToHost));
     ORBFE_HIP(hipMemcpy(prev_matched, w.prev.p, (size_t)n1 * 8, hipMemcpyDeviceToHost));

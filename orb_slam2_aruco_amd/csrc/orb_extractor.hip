@@ -45,7 +45,7 @@ struct orbfe_extractor {
     int rows = 0, cols = 0; // geometry currently built
     int batch_cap = 0;
     std::vector<LevelGeom> geom;
-    int ncells_total = 0, ntiles = 0, out_total = 0, max_out_cap = 0;
+    int ncells_total = 0, ntiles = 0, out_total = 0, max_out_cap = 0, max_wcell = 0, max_hcell = 0;
     size_t pyr_fbytes = 0, blur_fbytes = 0, slots_fu32 = 0, keys_fu32 = 0;
     int keycap_lds = 0, nodecap = 0, veccap = 0;
     std::vector<size_t> tab_off; // per level >= 1: offsets (in ints) of xofs, xalpha, yofs, ybeta in d_tabs
@@ -122,7 +122,7 @@ struct orbfe_extractor {
         std::vector<int> tabs;
         tab_off.assign((size_t)nlevels * 4, 0);
         size_t pyr = 0, blur = 0, slots = 0, cand = 0;
-        int out = 0, maxcap = 0;
+        int out = 0, maxcap = 0, mwc = 0, mhc = 0;
         for (int l = 0; l < nlevels; l++) {
             LevelGeom& g = geom[l];
             const float scale = mvInvScaleFactor[l];
@@ -144,6 +144,7 @@ struct orbfe_extractor {
             g.wCell = (int)std::ceil(width / g.nCols);
             g.hCell = (int)std::ceil(height / g.nRows);
             if (g.wCell > 60 || g.hCell > 60) return fail(ORBFE_ERR_INVALID, "cell larger than 60 px");
+            mwc = std::max(mwc, g.wCell); mhc = std::max(mhc, g.hCell);
             g.cell_first = (int)cellinfo.size();
             for (int i = 0; i < g.nRows; i++) {
                 const float iniY = (float)(16 + i * g.hCell);
@@ -172,7 +173,7 @@ struct orbfe_extractor {
             maxcap = std::max(maxcap, g.out_cap);
             g.scale = mvScaleFactor[l];
             g.kp_size = (float)(int)(31 * mvScaleFactor[l]);
-            for (int ty = 0; ty < (g.h + 15) / 16; ty++)
+            for (int ty = 0; ty < (g.h + 63) / 64; ty++)
                 for (int tx = 0; tx < (g.w + 63) / 64; tx++)
                     tiles.push_back((uint32_t)l | ((uint32_t)tx << 4) | ((uint32_t)ty << 18));
             if (l > 0) {
@@ -211,6 +212,7 @@ struct orbfe_extractor {
         ntiles = (int)tiles.size();
         out_total = out;
         max_out_cap = maxcap;
+        max_wcell = mwc; max_hcell = mhc;
         pyr_fbytes = pyr + 64;
         blur_fbytes = blur + 64;
         slots_fu32 = slots;
@@ -280,9 +282,21 @@ struct orbfe_extractor {
                                tabs + tab_off[l * 4 + 3]);
         }
         timer.mark(s, "resize");
-        hipLaunchKernelGGL(k_fast_cells, dim3(ncells_total, B), dim3(256), 0, s, src0, pyr, dg,
-                           d_cellinfo.as<uint32_t>(), d_slots.as<uint32_t>(), slots_fu32, d_cellcnt.as<int32_t>(),
-                           ncells_total, iniThFAST, minThFAST);
+        {
+            // LDS per wave: ROI (cell + 6), score map (cell + 2), one u16 list of cell pixels
+            const int roi_pitch = align_up(max_wcell + 6, 4), roi_rows = max_hcell + 6;
+            const int map_pitch = max_wcell + 2, map_rows = max_hcell + 2;
+            const int list_cap = max_wcell * max_hcell;
+            auto a16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+            const size_t lds = 4 * (a16((size_t)roi_pitch * roi_rows) + a16((size_t)map_pitch * map_rows) +
+                                    a16((size_t)list_cap * 2));
+            ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fast_cells),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_fast_cells, dim3((ncells_total + 3) / 4, B), dim3(256), lds, s, src0, pyr, dg,
+                               d_cellinfo.as<uint32_t>(), d_slots.as<uint32_t>(), slots_fu32,
+                               d_cellcnt.as<int32_t>(), ncells_total, iniThFAST, minThFAST, roi_pitch, roi_rows,
+                               map_pitch, map_rows, list_cap);
+        }
         timer.mark(s, "fast_cells");
         const size_t lds = qt_lds_bytes(keycap_lds, nodecap, veccap);
         hipLaunchKernelGGL(k_distribute, dim3(nlevels, B), dim3(64), lds, s, dg, d_slots.as<uint32_t>(), slots_fu32,

@@ -117,126 +117,177 @@ __device__ __forceinline__ int fast_score16(const int d[16])
     return best - 1;
 }
 
-// One workgroup per (active cell, frame).  Stages the cell's ROI in LDS, finds corners at the lower threshold,
-// scores them, applies 3x3 strict-max NMS restricted to the cell (ORBextractor.cc:809 runs cv::FAST on the ROI,
-// so NMS never looks across cells), applies the iniThFAST -> minThFAST fallback (:812-816) and writes the
-// survivors in raster order to the cell's slot.
+// One WAVE per (active cell, frame), four cells per workgroup, no workgroup barriers: every step below is a
+// wave-level operation (ballot compaction, in-order LDS).  The wave stages the cell's ROI in LDS, runs the reference's
+// two-threshold sequence (cv::FAST at iniThFAST; only if the cell yields nothing, again at minThFAST -- :809-816),
+// and for each threshold: compass prefilter -> full 9-of-16 segment test -> exact cornerScore -> strict 3x3 NMS inside
+// the cell (cv::FAST runs on the ROI, so NMS never looks across cells) -> survivors written in raster order.
+// LDS per wave (dynamic, sized by the host from the largest cell of the pyramid): ROI bytes, score map, one list.
+__device__ __forceinline__ void ring_diffs_rt(const uint8_t* c, int P, int v, int d[16])
+{
+    d[0] = v - c[3 * P + 0];   d[1] = v - c[3 * P + 1];   d[2] = v - c[2 * P + 2];
+    d[3] = v - c[1 * P + 3];   d[4] = v - c[3];           d[5] = v - c[-1 * P + 3];
+    d[6] = v - c[-2 * P + 2];  d[7] = v - c[-3 * P + 1];  d[8] = v - c[-3 * P + 0];
+    d[9] = v - c[-3 * P - 1];  d[10] = v - c[-2 * P - 2]; d[11] = v - c[-1 * P - 3];
+    d[12] = v - c[-3];         d[13] = v - c[1 * P - 3];  d[14] = v - c[2 * P - 2];
+    d[15] = v - c[3 * P - 1];
+}
+
 __global__ __launch_bounds__(256) void k_fast_cells(ImgView src0, ImgView pyr, const LevelGeom* __restrict__ geom,
                                                     const uint32_t* __restrict__ cellinfo, uint32_t* __restrict__ slots,
                                                     size_t slots_fstride, int32_t* __restrict__ cellcnt,
-                                                    int ncells_total, int iniTh, int minTh)
+                                                    int ncells_total, int iniTh, int minTh, int roi_pitch, int roi_rows,
+                                                    int map_pitch, int map_rows, int list_cap)
 {
-    __shared__ uint8_t simg[FAST_MAXROI * FAST_SP];
-    __shared__ uint8_t smap[62 * 64];
-    __shared__ uint16_t slist[FAST_MAXLIST];
-    __shared__ uint8_t sscore[FAST_MAXLIST];
-    __shared__ uint8_t sflag[FAST_MAXLIST];
-    __shared__ int s_wcnt[4];
-    __shared__ int s_cnt_ini;
+    extern __shared__ __align__(16) unsigned char fc_smem[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int cell = blockIdx.x * 4 + wid, f = blockIdx.y;
+    if (cell >= ncells_total) return;
+    const size_t roi_bytes = ((size_t)roi_pitch * roi_rows + 15) & ~(size_t)15;
+    const size_t map_bytes = ((size_t)map_pitch * map_rows + 15) & ~(size_t)15;
+    const size_t per_wave = roi_bytes + map_bytes + (((size_t)list_cap * 2 + 15) & ~(size_t)15);
+    uint8_t* simg = fc_smem + per_wave * wid;
+    uint8_t* smap = simg + roi_bytes;
+    uint16_t* slist = (uint16_t*)(smap + map_bytes);
 
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int cell = blockIdx.x, f = blockIdx.y;
     const uint32_t ci = cellinfo[cell];
     const int level = ci & 15, ci_i = (ci >> 4) & 1023, ci_j = (ci >> 14) & 1023;
     const LevelGeom g = geom[level];
-
     const int iniX = 16 + ci_j * g.wCell, iniY = 16 + ci_i * g.hCell;
     const int maxX = min(iniX + g.wCell + 6, g.maxBX), maxY = min(iniY + g.hCell + 6, g.maxBY);
     const int w = maxX - iniX, h = maxY - iniY;
     const int aw = w - 6, ah = h - 6;
     int32_t* cnt_out = cellcnt + (size_t)f * ncells_total + cell;
     if (aw <= 0 || ah <= 0) {
-        if (tid == 0) *cnt_out = 0;
+        if (lane == 0) *cnt_out = 0;
         return;
     }
     const uint8_t* img = (level == 0) ? src0.base + (size_t)f * src0.fstride
                                       : pyr.base + (size_t)f * pyr.fstride + g.img_off;
     const int pitch = (level == 0) ? src0.pitch : g.pitch;
+    const int SP = roi_pitch, MP = map_pitch;
 
-    // stage ROI + clear score map
-    for (int y = wid; y < h; y += 4) {
-        const uint8_t* row = img + (size_t)(iniY + y) * pitch + iniX;
-        if (lane < w) simg[y * FAST_SP + lane] = row[lane];
-        if (lane + 64 < w) simg[y * FAST_SP + lane + 64] = row[lane + 64];
-    }
-    for (int i = tid; i < 62 * 64 / 4; i += 256) reinterpret_cast<uint32_t*>(smap)[i] = 0;
-    if (tid == 0) s_cnt_ini = 0;
-    __syncthreads();
-
-    // phase 1: segment test at the lower threshold, raster-ordered compaction
-    const int tlow = min(iniTh, minTh);
-    const int npix = aw * ah;
-    int nlist = 0;
-    for (int base = 0; base < npix; base += 256) {
-        const int p = base + tid;
-        bool corner = false;
-        int x = 0, y = 0;
-        if (p < npix) {
-            y = p / aw;
-            x = p - y * aw;
-            const uint8_t* c = simg + (y + 3) * FAST_SP + (x + 3);
-            int d[16];
-            ring_diffs<FAST_SP>(c, c[0], d);
-            corner = fast_is_corner(d, tlow);
+    // stage the ROI, 16 rows of loads in flight at a time; clear the score map
+    for (int y0 = 0; y0 < h; y0 += 16) {
+        uint8_t v0[16], v1[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int y = y0 + k;
+            const uint8_t* row = img + (size_t)(iniY + min(y, h - 1)) * pitch + iniX;
+            v0[k] = (lane < w) ? row[lane] : (uint8_t)0;
+            v1[k] = (lane + 64 < w) ? row[lane + 64] : (uint8_t)0;
         }
-        const unsigned long long m = __ballot(corner);
-        if (lane == 0) s_wcnt[wid] = __popcll(m);
-        __syncthreads();
-        int off = nlist;
-        for (int k = 0; k < wid; k++) off += s_wcnt[k];
-        if (corner) slist[off + lane_prefix(m)] = (uint16_t)((y << 8) | x);
-        nlist += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
-        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int y = y0 + k;
+            if (y < h) {
+                if (lane < w) simg[y * SP + lane] = v0[k];
+                if (lane + 64 < w) simg[y * SP + lane + 64] = v1[k];
+            }
+        }
+    }
+    for (int i = lane; i < (int)(map_bytes / 4); i += 64) reinterpret_cast<uint32_t*>(smap)[i] = 0;
+    __builtin_amdgcn_wave_barrier();
+
+    const int npix = aw * ah;
+    const float inv_aw = 1.0f / (float)aw;
+    int nlist = 0;
+    unsigned long long keepbits = 0; // bit k: list entry lane + 64 k survives NMS (list_cap <= 64 * 64)
+    for (int pass_no = 0; pass_no < 2; pass_no++) {
+        const int t = pass_no == 0 ? iniTh : minTh;
+        // 1a: cheap necessary condition on every pixel -- a 9-arc of the 16-ring always contains two ADJACENT compass
+        // points (ring positions 0, 4, 8, 12), so two adjacent compass pixels must both differ from the centre by more
+        // than the threshold with the same sign.  Survivors are compacted in raster order.
+        int n1 = 0;
+        for (int base = 0; base < npix; base += 64) {
+            const int p = base + lane;
+            bool pass = false;
+            int x = 0, y = 0;
+            if (p < npix) {
+                y = (int)(((float)p + 0.5f) * inv_aw); // exact: p < 4096, quotient >= 0.5/aw away from an integer
+                x = p - y * aw;
+                const uint8_t* c = simg + (y + 3) * SP + (x + 3);
+                const int v = c[0];
+                const int d0 = v - c[3 * SP], d4 = v - c[3], d8 = v - c[-3 * SP], d12 = v - c[-3];
+                const unsigned P = (d0 > t) | ((d4 > t) << 1) | ((d8 > t) << 2) | ((d12 > t) << 3);
+                const unsigned N = (d0 < -t) | ((d4 < -t) << 1) | ((d8 < -t) << 2) | ((d12 < -t) << 3);
+                const unsigned Pr = ((P << 1) | (P >> 3)) & 15u, Nr = ((N << 1) | (N >> 3)) & 15u;
+                pass = ((P & Pr) | (N & Nr)) != 0;
+            }
+            const unsigned long long m = __ballot(pass);
+            if (pass) slist[n1 + lane_prefix(m)] = (uint16_t)((y << 8) | x);
+            n1 += __popcll(m);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // 1b: full segment test on the survivors (dense); in-place order-preserving compaction (writes trail reads)
+        nlist = 0;
+        for (int base = 0; base < n1; base += 64) {
+            const int e = base + lane;
+            bool corner = false;
+            int yx = 0;
+            if (e < n1) {
+                yx = slist[e];
+                const uint8_t* c = simg + ((yx >> 8) + 3) * SP + ((yx & 255) + 3);
+                int d[16];
+                ring_diffs_rt(c, SP, c[0], d);
+                corner = fast_is_corner(d, t);
+            }
+            const unsigned long long m = __ballot(corner);
+            __builtin_amdgcn_wave_barrier();
+            if (corner) slist[nlist + lane_prefix(m)] = (uint16_t)yx;
+            nlist += __popcll(m);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // 2: exact score of every corner into the score map
+        for (int e = lane; e < nlist; e += 64) {
+            const int yx = slist[e], y = yx >> 8, x = yx & 255;
+            const uint8_t* c = simg + (y + 3) * SP + (x + 3);
+            int d[16];
+            ring_diffs_rt(c, SP, c[0], d);
+            smap[(y + 1) * MP + (x + 1)] = (uint8_t)fast_score16(d);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // 3: strict 3x3 maximum inside the cell
+        keepbits = 0;
+        int nkeep = 0;
+        for (int k = 0; k * 64 < nlist; k++) {
+            const int e = k * 64 + lane;
+            bool keep = false;
+            if (e < nlist) {
+                const int yx = slist[e], y = yx >> 8, x = yx & 255;
+                const uint8_t* m = smap + (y + 1) * MP + (x + 1);
+                const int s = m[0];
+                keep = s > m[-MP - 1] && s > m[-MP] && s > m[-MP + 1] && s > m[-1] && s > m[1] && s > m[MP - 1] &&
+                       s > m[MP] && s > m[MP + 1];
+            }
+            keepbits |= (unsigned long long)keep << k;
+            nkeep += __popcll(__ballot(keep));
+        }
+        if (nkeep > 0 || pass_no == 1) break;
+        // nothing at iniThFAST: wipe the scores and try again at minThFAST
+        for (int e = lane; e < nlist; e += 64) {
+            const int yx = slist[e];
+            smap[((yx >> 8) + 1) * MP + ((yx & 255) + 1)] = 0;
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 
-    // phase 2: exact score of every corner
-    for (int e = tid; e < nlist; e += 256) {
-        const int yx = slist[e], y = yx >> 8, x = yx & 255;
-        const uint8_t* c = simg + (y + 3) * FAST_SP + (x + 3);
-        int d[16];
-        ring_diffs<FAST_SP>(c, c[0], d);
-        const int s = fast_score16(d);
-        sscore[e] = (uint8_t)s;
-        smap[(y + 1) * 64 + (x + 1)] = (uint8_t)s;
-    }
-    __syncthreads();
-
-    // phase 3: strict 3x3 maximum inside the cell
-    int my_ini = 0;
-    for (int e = tid; e < nlist; e += 256) {
-        const int yx = slist[e], y = yx >> 8, x = yx & 255;
-        const int s = sscore[e];
-        const uint8_t* m = smap + (y + 1) * 64 + (x + 1);
-        const bool keep = s > m[-65] && s > m[-64] && s > m[-63] && s > m[-1] && s > m[1] && s > m[63] && s > m[64] &&
-                          s > m[65];
-        const int fl = (keep && s >= minTh ? 1 : 0) | (keep && s >= iniTh ? 2 : 0);
-        sflag[e] = (uint8_t)fl;
-        my_ini += (fl >> 1);
-    }
-    if (my_ini) atomicAdd(&s_cnt_ini, my_ini);
-    __syncthreads();
-
-    // phase 4: threshold fallback + ordered write-out
-    const int want = s_cnt_ini > 0 ? 2 : 1;
+    // 4: ordered write-out
     uint32_t* out = slots + (size_t)f * slots_fstride + g.slot_off + (size_t)(cell - g.cell_first) * g.cell_cap;
     const int xrel = ci_j * g.wCell + 3, yrel = ci_i * g.hCell + 3; // (*vit).pt.x += j*wCell (:822-823)
     int nout = 0;
-    for (int base = 0; base < nlist; base += 256) {
-        const int e = base + tid;
-        const bool take = e < nlist && (sflag[e] & want);
+    for (int k = 0; k * 64 < nlist; k++) {
+        const int e = k * 64 + lane;
+        const bool take = (keepbits >> k) & 1ull;
         const unsigned long long m = __ballot(take);
-        if (lane == 0) s_wcnt[wid] = __popcll(m);
-        __syncthreads();
-        int off = nout;
-        for (int k = 0; k < wid; k++) off += s_wcnt[k];
         if (take) {
             const int yx = slist[e], y = yx >> 8, x = yx & 255;
-            out[off + lane_prefix(m)] = (uint32_t)(x + xrel) | ((uint32_t)(y + yrel) << 12) | ((uint32_t)sscore[e] << 24);
+            out[nout + lane_prefix(m)] = (uint32_t)(x + xrel) | ((uint32_t)(y + yrel) << 12) |
+                                         ((uint32_t)smap[(y + 1) * MP + (x + 1)] << 24);
         }
-        nout += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
-        __syncthreads();
+        nout += __popcll(m);
     }
-    if (tid == 0) *cnt_out = nout;
+    if (lane == 0) *cnt_out = nout;
 }
 
 // ------------------------------------------------------------------------------------------------ quadtree --
@@ -605,7 +656,7 @@ __global__ void k_level_offsets(const int32_t* __restrict__ lvl_cnt, int32_t* __
 
 // ------------------------------------------------------------------------------------------------ blur ----
 // GaussianBlur 7x7 sigma 2, taps 18 34 49 55 49 34 18 (x256, sum 257), BORDER_REFLECT_101,
-// out = sat_u8((sum + 32768) >> 16).  64x16 output tile per workgroup, separable through LDS.
+// out = sat_u8((sum + 32768) >> 16).  64x64 output tile per workgroup (four 64x16 strips), separable through LDS.
 __device__ __forceinline__ int reflect101(int p, int n)
 {
     if (n == 1) return 0;
@@ -616,44 +667,79 @@ __device__ __forceinline__ int reflect101(int p, int n)
 __global__ __launch_bounds__(256) void k_blur7(ImgView src0, ImgView pyr, ImgView blur,
                                                const LevelGeom* __restrict__ geom, const uint32_t* __restrict__ tiles)
 {
-    __shared__ uint8_t sin[22][72];
-    __shared__ uint16_t sh[22][64];
+    __shared__ __align__(16) uint8_t sin[22][72];   // 64 + 6 columns, padded to a multiple of 4
+    __shared__ __align__(16) uint16_t sh[22][64];   // horizontal 7-tap sums (<= 257 * 255 fits 16 bits)
     const uint32_t t = tiles[blockIdx.x];
-    const int level = t & 15, tx0 = ((t >> 4) & 0x3fff) * 64, ty0 = (t >> 18) * 16;
+    const int level = t & 15, tx0 = ((t >> 4) & 0x3fff) * 64, tyb = (t >> 18) * 64;
     const int f = blockIdx.y;
     const LevelGeom g = geom[level];
     const uint8_t* img = (level == 0) ? src0.base + (size_t)f * src0.fstride
                                       : pyr.base + (size_t)f * pyr.fstride + g.img_off;
     const int pitch = (level == 0) ? src0.pitch : g.pitch;
-    const int tid = threadIdx.x;
-    for (int i = tid; i < 22 * 70; i += 256) {
-        const int r = i / 70, c = i - r * 70;
-        const int y = reflect101(ty0 + r - 3, g.h), x = reflect101(tx0 + c - 3, g.w);
-        sin[r][c] = img[(size_t)y * pitch + x];
-    }
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int ty0 = tyb; ty0 < tyb + 64 && ty0 < g.h; ty0 += 16) {
     __syncthreads();
-    for (int i = tid; i < 22 * 64; i += 256) {
-        const int r = i >> 6, c = i & 63;
-        const uint8_t* p = &sin[r][c];
-        sh[r][c] = (uint16_t)(18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3]);
-    }
-    __syncthreads();
-    const int r = tid >> 4, c4 = (tid & 15) * 4;
-    uint32_t packed = 0;
+    // stage the strip + 3-px halo: lane = column (reflected once per thread), wave = row; loads first, stores after
+    {
+        const int xa = reflect101(tx0 + lane - 3, g.w);
+        const int xb = reflect101(tx0 + 64 + (lane & 7) - 3, g.w);
+        uint8_t va[6], vb[6];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int c = c4 + k;
-        const int s = 18 * (sh[r][c] + sh[r + 6][c]) + 34 * (sh[r + 1][c] + sh[r + 5][c]) +
-                      49 * (sh[r + 2][c] + sh[r + 4][c]) + 55 * sh[r + 3][c];
-        int v = (s + 32768) >> 16;
-        v = v > 255 ? 255 : v;
-        packed |= (uint32_t)v << (8 * k);
+        for (int k = 0; k < 6; k++) {
+            const int r = wid + 4 * k;
+            const uint8_t* row = img + (size_t)reflect101(ty0 + min(r, 21) - 3, g.h) * pitch;
+            va[k] = row[xa];
+            vb[k] = row[xb];
+        }
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const int r = wid + 4 * k;
+            if (r < 22) {
+                sin[r][lane] = va[k];
+                if (lane < 6) sin[r][64 + lane] = vb[k];
+            }
+        }
     }
+    __syncthreads();
+    // horizontal pass: one item = 4 adjacent outputs of one row, from three aligned 32-bit LDS reads
+    for (int i = tid; i < 22 * 16; i += 256) {
+        const int r = i >> 4, c4 = (i & 15) * 4;
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(&sin[r][c4]);
+        const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+        const int b0 = w0 & 255, b1 = (w0 >> 8) & 255, b2 = (w0 >> 16) & 255, b3 = w0 >> 24;
+        const int b4 = w1 & 255, b5 = (w1 >> 8) & 255, b6 = (w1 >> 16) & 255, b7 = w1 >> 24;
+        const int b8 = w2 & 255, b9 = (w2 >> 8) & 255;
+        const uint32_t s0 = 18 * (b0 + b6) + 34 * (b1 + b5) + 49 * (b2 + b4) + 55 * b3;
+        const uint32_t s1 = 18 * (b1 + b7) + 34 * (b2 + b6) + 49 * (b3 + b5) + 55 * b4;
+        const uint32_t s2 = 18 * (b2 + b8) + 34 * (b3 + b7) + 49 * (b4 + b6) + 55 * b5;
+        const uint32_t s3 = 18 * (b3 + b9) + 34 * (b4 + b8) + 49 * (b5 + b7) + 55 * b6;
+        uint2 o;
+        o.x = s0 | (s1 << 16);
+        o.y = s2 | (s3 << 16);
+        *reinterpret_cast<uint2*>(&sh[r][c4]) = o;
+    }
+    __syncthreads();
+    // vertical pass: 4 outputs per thread from seven 64-bit LDS reads, one aligned 32-bit store
+    const int r = tid >> 4, c4 = (tid & 15) * 4;
+    int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        const int tap = (k == 0 || k == 6) ? 18 : (k == 1 || k == 5) ? 34 : (k == 2 || k == 4) ? 49 : 55;
+        const uint2 v = *reinterpret_cast<const uint2*>(&sh[r + k][c4]);
+        a0 += tap * (int)(v.x & 0xffff);
+        a1 += tap * (int)(v.x >> 16);
+        a2 += tap * (int)(v.y & 0xffff);
+        a3 += tap * (int)(v.y >> 16);
+    }
+    const int v0 = min((a0 + 32768) >> 16, 255), v1 = min((a1 + 32768) >> 16, 255);
+    const int v2 = min((a2 + 32768) >> 16, 255), v3 = min((a3 + 32768) >> 16, 255);
+    const uint32_t packed = (uint32_t)v0 | ((uint32_t)v1 << 8) | ((uint32_t)v2 << 16) | ((uint32_t)v3 << 24);
     const int y = ty0 + r, x = tx0 + c4;
     if (y < g.h && x < g.bpitch) {
         uint8_t* D = blur.base_w + (size_t)f * blur.fstride + g.blur_off + (size_t)y * g.bpitch;
         *reinterpret_cast<uint32_t*>(D + x) = packed;
     }
+    } // strips
 }
 
 // ------------------------------------------------------------------------------------------------ describe --
