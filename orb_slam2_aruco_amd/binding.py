@@ -207,6 +207,20 @@ class ORBextractor:
     def enable_kernel_timing(self, on=True):
         self.L.orbfe_extractor_debug_kernel_times(self.h, None, int(on))
 
+    def force_general_quadtree(self, on=True):
+        """Test hook: bypass the count-pyramid fast path of DistributeOctTree."""
+        self.L.orbfe_extractor_debug_kernel_times(self.h, None, 2 if on else 3)
+
+    def set_pyramid_depth(self, depth=0):
+        """Test hook: depth of the quadtree count pyramid (0 = default); shallow values force the fallback."""
+        self.L.orbfe_extractor_debug_kernel_times(self.h, None, 10 + depth)
+
+    def quadtree_fell_back(self, frame, level):
+        n = C.c_int32(0)
+        _check(self.L, self.L.orbfe_extractor_debug_level_keypoints(self.h, frame, level, 3, None, 0, C.byref(n)),
+               "level_keypoints")
+        return bool(n.value)
+
     def kernel_times_us(self):
         out = np.zeros(32, np.float32)
         n = self.L.orbfe_extractor_debug_kernel_times(self.h, _p(out), 32)

@@ -50,7 +50,9 @@ struct orbfe_extractor {
     int keycap_lds = 0, nodecap = 0, veccap = 0;
     std::vector<size_t> tab_off; // per level >= 1: offsets (in ints) of xofs, xalpha, yofs, ybeta in d_tabs
     DevBuf d_geom, d_cellinfo, d_tiles, d_tabs, d_pattern, d_umax;
-    DevBuf d_pyr, d_blur, d_slots, d_cellcnt, d_keys, d_lvlout, d_lvlcnt, d_lvloff, d_lvlncand, d_overflow;
+    DevBuf d_pyr, d_blur, d_slots, d_cellcnt, d_keys, d_lvlout, d_lvlcnt, d_lvloff, d_lvlncand, d_overflow, d_fallback;
+    bool force_general_quadtree = false; // test hook: run the general kernel for every level
+    int force_pyramid_depth = 0;         // test hook: shallow count pyramid so that levels fall back
     DevBuf d_in, d_kps, d_desc, d_nout; // staging for the host-pointer entry points
     KernelTimer timer;
     int last_nframes = 0;
@@ -59,7 +61,7 @@ struct orbfe_extractor {
     ~orbfe_extractor()
     {
         for (DevBuf* b : {&d_geom, &d_cellinfo, &d_tiles, &d_tabs, &d_pattern, &d_umax, &d_pyr, &d_blur, &d_slots,
-                          &d_cellcnt, &d_keys, &d_lvlout, &d_lvlcnt, &d_lvloff, &d_lvlncand, &d_overflow, &d_in,
+                          &d_cellcnt, &d_keys, &d_lvlout, &d_lvlcnt, &d_lvloff, &d_lvlncand, &d_overflow, &d_fallback, &d_in,
                           &d_kps, &d_desc, &d_nout})
             b->release();
         if (own_stream) (void)hipStreamDestroy(own_stream);
@@ -248,6 +250,7 @@ struct orbfe_extractor {
         if ((rc = d_lvlcnt.ensure((size_t)nlevels * 4 * B))) return rc;
         if ((rc = d_lvloff.ensure((size_t)nlevels * 4 * B))) return rc;
         if ((rc = d_lvlncand.ensure((size_t)nlevels * 4 * B))) return rc;
+        if ((rc = d_fallback.ensure((size_t)nlevels * 4 * B))) return rc;
         if ((rc = d_overflow.ensure(16))) return rc;
         batch_cap = B;
         return ORBFE_OK;
@@ -298,11 +301,27 @@ struct orbfe_extractor {
                                map_pitch, map_rows, list_cap);
         }
         timer.mark(s, "fast_cells");
-        const size_t lds = qt_lds_bytes(keycap_lds, nodecap, veccap);
-        hipLaunchKernelGGL(k_distribute, dim3(nlevels, B), dim3(64), lds, s, dg, d_slots.as<uint32_t>(), slots_fu32,
-                           d_cellcnt.as<int32_t>(), ncells_total, d_keys.as<uint32_t>(), keys_fu32,
-                           d_lvlout.as<uint32_t>(), out_total, d_lvlcnt.as<int32_t>(), nlevels,
-                           d_lvlncand.as<int32_t>(), keycap_lds, nodecap, veccap);
+        {
+            // fast path: count-pyramid quadtree (no keypoint movement); general kernel only for flagged levels
+            int max_ini = 1;
+            for (const LevelGeom& g : geom) max_ini = std::max(max_ini, g.nIni);
+            const int D = force_pyramid_depth ? force_pyramid_depth : max_ini == 1 ? 6 : max_ini <= 4 ? 5 : 4;
+            const size_t lds_p = qp_lds_bytes(max_ini, D, nodecap, veccap);
+            ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_distribute_pyr),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
+            hipLaunchKernelGGL(k_distribute_pyr, dim3(nlevels, B), dim3(64), lds_p, s, dg, d_slots.as<uint32_t>(),
+                               slots_fu32, d_cellcnt.as<int32_t>(), ncells_total, d_lvlout.as<uint32_t>(), out_total,
+                               d_lvlcnt.as<int32_t>(), nlevels, d_lvlncand.as<int32_t>(), d_fallback.as<int32_t>(), D,
+                               nodecap, veccap);
+            const size_t lds = qt_lds_bytes(keycap_lds, nodecap, veccap);
+            ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_distribute),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_distribute, dim3(nlevels, B), dim3(64), lds, s, dg, d_slots.as<uint32_t>(), slots_fu32,
+                               d_cellcnt.as<int32_t>(), ncells_total, d_keys.as<uint32_t>(), keys_fu32,
+                               d_lvlout.as<uint32_t>(), out_total, d_lvlcnt.as<int32_t>(), nlevels,
+                               d_lvlncand.as<int32_t>(), keycap_lds, nodecap, veccap,
+                               force_general_quadtree ? nullptr : d_fallback.as<int32_t>());
+        }
         timer.mark(s, "distribute");
         hipLaunchKernelGGL(k_level_offsets, dim3((B + 63) / 64), dim3(64), 0, s, d_lvlcnt.as<int32_t>(),
                            d_lvloff.as<int32_t>(), d_n, nlevels, B, capacity, d_overflow.as<int32_t>());
@@ -477,6 +496,14 @@ int orbfe_extractor_debug_level_keypoints(orbfe_extractor* h, int frame, int lev
     ORBFE_HIP(hipDeviceSynchronize());
     const LevelGeom& g = h->geom[level];
     std::vector<uint32_t> keys;
+    if (stage == 2) { // raw per-level candidate counter written by k_distribute (instrumented builds pack timings here)
+        ORBFE_HIP(hipMemcpy(n, h->d_lvlncand.as<int32_t>() + frame * h->nlevels + level, 4, hipMemcpyDeviceToHost));
+        return ORBFE_OK;
+    }
+    if (stage == 3) { // 1 if the level fell back from the count-pyramid quadtree to the general kernel
+        ORBFE_HIP(hipMemcpy(n, h->d_fallback.as<int32_t>() + frame * h->nlevels + level, 4, hipMemcpyDeviceToHost));
+        return ORBFE_OK;
+    }
     if (stage == 0) {
         std::vector<int32_t> cnt(g.ncells);
         ORBFE_HIP(hipMemcpy(cnt.data(), h->d_cellcnt.as<int32_t>() + (size_t)frame * h->ncells_total + g.cell_first,
@@ -512,8 +539,11 @@ int orbfe_extractor_debug_level_keypoints(orbfe_extractor* h, int frame, int lev
 int orbfe_extractor_debug_kernel_times(orbfe_extractor* h, float* out_us, int capacity)
 {
     if (!h) return fail(ORBFE_ERR_INVALID, "null handle");
-    if (!out_us) { // toggle: capacity != 0 enables timing for subsequent calls
-        h->timer.enabled = capacity != 0;
+    if (!out_us) { // toggles: 0/1 = kernel timing off/on; 2/3 = force the general quadtree kernel on/off (tests)
+        if (capacity == 2) h->force_general_quadtree = true;
+        else if (capacity == 3) h->force_general_quadtree = false;
+        else if (capacity >= 10 && capacity <= 16) h->force_pyramid_depth = capacity - 10; // 10 = default depth
+        else h->timer.enabled = capacity != 0;
         return 0;
     }
     return h->timer.collect(out_us, capacity);

@@ -308,17 +308,20 @@ struct QtShared {
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// The workgroup is a single wave: LDS operations of one wave execute in order, so a compiler-level barrier is enough.
+#define QT_SYNC() __builtin_amdgcn_wave_barrier()
 __global__ __launch_bounds__(64) void k_distribute(const LevelGeom* __restrict__ geom, const uint32_t* __restrict__ slots,
                                                    size_t slots_fstride, const int32_t* __restrict__ cellcnt,
                                                    int ncells_total, uint32_t* __restrict__ keyscratch,
                                                    size_t keys_fstride, uint32_t* __restrict__ lvl_out,
                                                    int out_fstride, int32_t* __restrict__ lvl_cnt, int nlevels,
                                                    int32_t* __restrict__ lvl_ncand, int keycap_lds, int nodecap,
-                                                   int veccap)
+                                                   int veccap, const int32_t* __restrict__ only_flagged)
 {
     extern __shared__ __align__(16) unsigned char qt_smem[];
     const int lane = threadIdx.x;
     const int level = blockIdx.x, f = blockIdx.y;
+    if (only_flagged && !only_flagged[f * nlevels + level]) return; // the pyramid fast path already did this level
     const LevelGeom g = geom[level];
 
     // carve LDS
@@ -339,6 +342,9 @@ __global__ __launch_bounds__(64) void k_distribute(const LevelGeom* __restrict__
     sp = qt_smem + (((size_t)(sp - qt_smem) + 15) & ~(size_t)15);
     uint32_t* lkeys = (uint32_t*)sp; // 2 * keycap_lds
 
+#ifdef ORBFE_QT_TIMING
+    const long long qt0 = clock64();
+#endif
     // ---- gather the level's candidates in cell row-major order (= vToDistributeKeys order, :819-826)
     const int32_t* ccnt = cellcnt + (size_t)f * ncells_total + g.cell_first;
     const uint32_t* cslots = slots + (size_t)f * slots_fstride + g.slot_off;
@@ -375,13 +381,22 @@ __global__ __launch_bounds__(64) void k_distribute(const LevelGeom* __restrict__
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
             const uint32_t* s = cslots + (size_t)c * g.cell_cap;
-            for (int k = 0; k < mx; k++)
-                if (k < cnt) kb0[off + k] = s[k];
+            for (int k0 = 0; k0 < mx; k0 += 8) { // 8 loads in flight per lane, then the 8 LDS stores
+                uint32_t v[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) v[k] = (k0 + k < cnt) ? s[k0 + k] : 0u;
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    if (k0 + k < cnt) kb0[off + k0 + k] = v[k];
+            }
             base += __shfl(incl, 63);
         }
     }
     if (lane == 0) lvl_ncand[f * nlevels + level] = n;
-    __syncthreads();
+    QT_SYNC();
+#ifdef ORBFE_QT_TIMING
+    const long long qt1 = clock64();
+#endif
 
     uint32_t* outp = lvl_out + (size_t)f * out_fstride + g.out_off;
     if (n == 0) {
@@ -422,7 +437,7 @@ __global__ __launch_bounds__(64) void k_distribute(const LevelGeom* __restrict__
     };
     auto erase = [&](int id) {
         const int p = nprev[id], q = nnext[id];
-        __syncthreads();
+        QT_SYNC();
         if (lane == 0) {
             if (p >= 0) nnext[p] = (short)q;
             if (q >= 0) nprev[q] = (short)p;
@@ -432,7 +447,7 @@ __global__ __launch_bounds__(64) void k_distribute(const LevelGeom* __restrict__
         if (q < 0) tail = p;
         nfreecnt++;
         size--;
-        __syncthreads();
+        QT_SYNC();
     };
 
     // root nodes (:546-570): nIni vertical strips, keys assigned by (int)(x / hX)
@@ -466,7 +481,7 @@ __global__ __launch_bounds__(64) void k_distribute(const LevelGeom* __restrict__
                     }
             }
         }
-        __syncthreads();
+        QT_SYNC();
         const int rootbuf = (g.nIni == 1) ? 0 : 1;
 #pragma unroll
         for (int q = 0; q < 8; q++) {
@@ -487,7 +502,7 @@ __global__ __launch_bounds__(64) void k_distribute(const LevelGeom* __restrict__
             }
             push_back(id);
         }
-        __syncthreads();
+        QT_SYNC();
     }
 
     // DivideNode + "add childs if they contain points" (:604-656 / :689-728); returns nothing, updates list + vec
@@ -499,36 +514,57 @@ __global__ __launch_bounds__(64) void k_distribute(const LevelGeom* __restrict__
         const uint32_t* srck = kbuf[buf] + b;
         uint32_t* dstk = kbuf[buf ^ 1] + b;
         int c[4] = {0, 0, 0, 0};
-        for (int i0 = 0; i0 < cnt; i0 += 64) {
-            const int i = i0 + lane;
-            int q = -1;
-            if (i < cnt) {
-                const uint32_t kv = srck[i];
-                const int kx = kv & 0xfff, ky = (kv >> 12) & 0xfff;
-                q = (kx < xm ? 0 : 1) + (ky < ym ? 0 : 2);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; k++) c[k] += __popcll(__ballot(q == k));
-        }
-        int run[4] = {0, c[0], c[0] + c[1], c[0] + c[1] + c[2]};
-        const int cb[4] = {run[0], run[1], run[2], run[3]};
-        for (int i0 = 0; i0 < cnt; i0 += 64) {
-            const int i = i0 + lane;
+        int cb[4];
+        if (cnt <= 64) {
+            // the whole node fits one wave: classify once, counts and positions straight from four ballots
             int q = -1;
             uint32_t kv = 0;
-            if (i < cnt) {
-                kv = srck[i];
+            if (lane < cnt) {
+                kv = srck[lane];
                 const int kx = kv & 0xfff, ky = (kv >> 12) & 0xfff;
                 q = (kx < xm ? 0 : 1) + (ky < ym ? 0 : 2);
             }
+            const unsigned long long m0 = __ballot(q == 0), m1 = __ballot(q == 1), m2 = __ballot(q == 2),
+                                     m3 = __ballot(q == 3);
+            c[0] = __popcll(m0); c[1] = __popcll(m1); c[2] = __popcll(m2); c[3] = __popcll(m3);
+            cb[0] = 0; cb[1] = c[0]; cb[2] = c[0] + c[1]; cb[3] = c[0] + c[1] + c[2];
+            if (q >= 0) {
+                const unsigned long long mq = q == 0 ? m0 : q == 1 ? m1 : q == 2 ? m2 : m3;
+                const int base = q == 0 ? cb[0] : q == 1 ? cb[1] : q == 2 ? cb[2] : cb[3];
+                dstk[base + lane_prefix(mq)] = kv;
+            }
+        } else {
+            for (int i0 = 0; i0 < cnt; i0 += 64) {
+                const int i = i0 + lane;
+                int q = -1;
+                if (i < cnt) {
+                    const uint32_t kv = srck[i];
+                    const int kx = kv & 0xfff, ky = (kv >> 12) & 0xfff;
+                    q = (kx < xm ? 0 : 1) + (ky < ym ? 0 : 2);
+                }
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const unsigned long long m = __ballot(q == k);
-                if (q == k) dstk[run[k] + lane_prefix(m)] = kv;
-                run[k] += __popcll(m);
+                for (int k = 0; k < 4; k++) c[k] += __popcll(__ballot(q == k));
+            }
+            int run[4] = {0, c[0], c[0] + c[1], c[0] + c[1] + c[2]};
+            cb[0] = run[0]; cb[1] = run[1]; cb[2] = run[2]; cb[3] = run[3];
+            for (int i0 = 0; i0 < cnt; i0 += 64) {
+                const int i = i0 + lane;
+                int q = -1;
+                uint32_t kv = 0;
+                if (i < cnt) {
+                    kv = srck[i];
+                    const int kx = kv & 0xfff, ky = (kv >> 12) & 0xfff;
+                    q = (kx < xm ? 0 : 1) + (ky < ym ? 0 : 2);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const unsigned long long m = __ballot(q == k);
+                    if (q == k) dstk[run[k] + lane_prefix(m)] = kv;
+                    run[k] += __popcll(m);
+                }
             }
         }
-        __syncthreads();
+        QT_SYNC();
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             if (c[k] == 0) continue;
@@ -553,7 +589,7 @@ __global__ __launch_bounds__(64) void k_distribute(const LevelGeom* __restrict__
                 nvec++;
             }
         }
-        __syncthreads();
+        QT_SYNC();
     };
 
     bool finish = false;
@@ -581,7 +617,7 @@ __global__ __launch_bounds__(64) void k_distribute(const LevelGeom* __restrict__
                 int P = 1;
                 while (P < np) P <<= 1;
                 for (int i = lane; i < P; i += 64) vprev[i] = (i < np) ? vec[i] : 0ull;
-                __syncthreads();
+                QT_SYNC();
                 for (int k = 2; k <= P; k <<= 1)
                     for (int j = k >> 1; j > 0; j >>= 1) {
                         for (int t = lane; t < (P >> 1); t += 64) {
@@ -591,7 +627,7 @@ __global__ __launch_bounds__(64) void k_distribute(const LevelGeom* __restrict__
                             const bool up = ((i & k) == 0);
                             if ((a > bb) == up) { vprev[i] = bb; vprev[l] = a; }
                         }
-                        __syncthreads();
+                        QT_SYNC();
                     }
                 nvec = 0;
                 for (int j = P - 1; j >= P - np; j--) {
@@ -606,6 +642,9 @@ __global__ __launch_bounds__(64) void k_distribute(const LevelGeom* __restrict__
         }
     }
 
+#ifdef ORBFE_QT_TIMING
+    const long long qt2 = clock64();
+#endif
     // ---- retain the best point of each node (:741-760), in list order
     // walk the list once (wave-uniform) recording node ids, then one lane per node
     short* order = (short*)vprev; // reuse (veccap*8 bytes >= nodecap*2)
@@ -617,7 +656,7 @@ __global__ __launch_bounds__(64) void k_distribute(const LevelGeom* __restrict__
             cur = rfl(nnext[cur]);
         }
     }
-    __syncthreads();
+    QT_SYNC();
     for (int k0 = 0; k0 < size; k0 += 64) {
         const int k = k0 + lane;
         if (k < size) {
@@ -633,6 +672,358 @@ __global__ __launch_bounds__(64) void k_distribute(const LevelGeom* __restrict__
         }
     }
     if (lane == 0) lvl_cnt[f * nlevels + level] = size;
+#ifdef ORBFE_QT_TIMING
+    if (lane == 0) lvl_ncand[f * nlevels + level] = (int)((qt1 - qt0) >> 8) | ((int)((qt2 - qt1) >> 8) << 10) | ((int)((clock64() - qt2) >> 8) << 20);
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------ quadtree, fast path
+// DistributeOctTree without moving keypoints.  A node's rectangle depends only on its path from the root (DivideNode
+// halves with ceil, :483-484), so every candidate has a fixed cell at every depth.  One pass over the candidates builds,
+// in LDS, a COUNT PYRAMID (keypoints per cell for depths 0..D, cell index = root * 4^d + path code) and, per depth-D
+// leaf, the best keypoint (max response, first in vToDistributeKeys order on ties, :745-757).  The node list logic of
+// :594-739 then runs on (cell, depth) records with O(1) child counts, lane-per-node:
+//   * a pass of the first loop (:598-657) splits every expandable node at once; the list after the pass is
+//     [children in reverse creation order] ++ [bNoMore nodes in their old order], which two prefix sums reproduce;
+//   * a round of the priority loop (:673-737) sorts (size, seq) and splits from the back until size >= N: the stopping
+//     point is the first prefix of "children - 1" gains that reaches N, found with a scan.
+// If the algorithm wants to split a depth-D cell (candidates concentrated in a tiny area) the pyramid is too shallow:
+// the workgroup raises `fallback[f, level]` and k_distribute (the general kernel) redoes that level.
+__device__ __forceinline__ int wave_excl_scan(int v, int lane, int& total)
+{
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    total = __shfl(incl, 63);
+    return incl - v;
+}
+
+__global__ __launch_bounds__(64) void k_distribute_pyr(const LevelGeom* __restrict__ geom, const uint32_t* __restrict__ slots,
+                                                       size_t slots_fstride, const int32_t* __restrict__ cellcnt,
+                                                       int ncells_total, uint32_t* __restrict__ lvl_out, int out_fstride,
+                                                       int32_t* __restrict__ lvl_cnt, int nlevels,
+                                                       int32_t* __restrict__ lvl_ncand, int32_t* __restrict__ fallback,
+                                                       int D, int nodecap, int veccap)
+{
+    extern __shared__ __align__(16) unsigned char qp_smem[];
+    const int lane = threadIdx.x;
+    const int level = blockIdx.x, f = blockIdx.y;
+    const LevelGeom g = geom[level];
+    const int nIni = g.nIni;
+    // depth d cells live at cnt[off(d) + root * 4^d + code]; off(d) = 4 * nIni * (4^d - 1) / 3 rounded so that every
+    // 4-child group is 8-byte aligned (u16 counts)
+    auto off = [&](int d) { return nIni * (((1 << (2 * d)) - 1) / 3) ; };
+    const int T = off(D + 1);                     // total cells, depths 0..D
+    const int nleaf = nIni << (2 * D);
+    unsigned char* sp = qp_smem;
+    unsigned long long* best = (unsigned long long*)sp; sp += (size_t)nleaf * 8;
+    unsigned long long* vec = (unsigned long long*)sp; sp += (size_t)veccap * 8;
+    unsigned long long* vprev = (unsigned long long*)sp; sp += (size_t)veccap * 8;
+    uint32_t* cellA = (uint32_t*)sp; sp += (size_t)nodecap * 4;
+    uint32_t* infoA = (uint32_t*)sp; sp += (size_t)nodecap * 4;
+    uint32_t* seqA = (uint32_t*)sp; sp += (size_t)nodecap * 4;
+    uint32_t* cellB = (uint32_t*)sp; sp += (size_t)nodecap * 4;
+    uint32_t* infoB = (uint32_t*)sp; sp += (size_t)nodecap * 4;
+    uint32_t* seqB = (uint32_t*)sp; sp += (size_t)nodecap * 4;
+    uint16_t* tpos = (uint16_t*)sp; sp += (((size_t)nodecap * 2 + 15) & ~(size_t)15);
+    uint16_t* smark = (uint16_t*)sp; sp += (((size_t)nodecap * 2 + 15) & ~(size_t)15);
+    uint32_t* cnt32 = (uint32_t*)sp;              // u16 counts, two per word; T rounded up
+    uint16_t* cnt = (uint16_t*)cnt32;
+    // info word: count (20 bits) | depth << 20 (4 bits) | nomore << 24
+
+    const int fl_idx = f * nlevels + level;
+    for (int i = lane; i < (T + 1) / 2 + 2; i += 64) cnt32[i] = 0;
+    for (int i = lane; i < nleaf; i += 64) best[i] = 0ull;
+    QT_SYNC();
+
+    // ---- one pass over the level's candidates (straight from the per-cell slots; order is carried as (cell, k))
+    const int32_t* ccnt = cellcnt + (size_t)f * ncells_total + g.cell_first;
+    const uint32_t* cslots = slots + (size_t)f * slots_fstride + g.slot_off;
+    const int H = g.maxBY - 16;
+    int n = 0;
+    for (int c0 = 0; c0 < g.ncells; c0 += 64) {
+        const int c = c0 + lane;
+        const int k_cnt = (c < g.ncells) ? ccnt[c] : 0;
+        n += k_cnt;
+        int mx = k_cnt;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+        const uint32_t* sl = cslots + (size_t)c * g.cell_cap;
+        for (int k0 = 0; k0 < mx; k0 += 4) {
+            uint32_t kv[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) kv[k] = (k0 + k < k_cnt) ? sl[k0 + k] : 0u;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (k0 + k >= k_cnt) continue;
+                const int x = kv[k] & 0xfff, y = (kv[k] >> 12) & 0xfff;
+                const int r = (int)__fdiv_rn((float)x, g.hX);
+                int x0 = (int)(g.hX * (float)r), x1 = (int)(g.hX * (float)(r + 1)), y0 = 0, y1 = H;
+                uint32_t code = 0;
+                for (int d = 0; d < D; d++) {
+                    const int xm = x0 + ((x1 - x0 + 1) >> 1), ym = y0 + ((y1 - y0 + 1) >> 1); // ceil(float(w)/2)
+                    const int qx = x >= xm, qy = y >= ym;
+                    code = (code << 2) | (uint32_t)(qx + 2 * qy);
+                    x0 = qx ? xm : x0; x1 = qx ? x1 : xm;
+                    y0 = qy ? ym : y0; y1 = qy ? y1 : ym;
+                }
+                const uint32_t leaf = ((uint32_t)r << (2 * D)) + code;
+                const uint32_t ci = (uint32_t)off(D) + leaf;
+                atomicAdd(&cnt32[ci >> 1], (ci & 1) ? 0x10000u : 1u);
+                const unsigned long long ord = ((unsigned long long)c << 10) | (unsigned)(k0 + k); // vToDistributeKeys order
+                const unsigned long long key = ((unsigned long long)(kv[k] >> 24) << 46) | ((0x3fffffull - ord) << 24) |
+                                               (kv[k] & 0xffffffu);
+                atomicMax(&best[leaf], key);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+    if (lane == 0) { lvl_ncand[fl_idx] = n; fallback[fl_idx] = 0; }
+    QT_SYNC();
+    if (n == 0) {
+        if (lane == 0) lvl_cnt[fl_idx] = 0;
+        return;
+    }
+    // ---- count pyramid, bottom-up
+    for (int d = D - 1; d >= 0; d--) {
+        const int nc = nIni << (2 * d);
+        for (int i = lane; i < nc; i += 64) {
+            const uint16_t* ch = cnt + off(d + 1) + 4 * i;
+            cnt[off(d) + i] = (uint16_t)(ch[0] + ch[1] + ch[2] + ch[3]);
+        }
+        QT_SYNC();
+    }
+
+    // ---- initial list: non-empty roots in order (:546-585); seq counts every root
+    int L = 0, seq = nIni;
+    const int N = g.quota;
+    for (int r = 0; r < nIni; r++) {
+        const int c = cnt[r];
+        if (c == 0) continue;
+        if (lane == 0) { cellA[L] = r; infoA[L] = (uint32_t)c | (c == 1 ? (1u << 24) : 0u); seqA[L] = r; }
+        L++;
+    }
+    QT_SYNC();
+    uint32_t *cA = cellA, *iA = infoA, *sA = seqA, *cB = cellB, *iB = infoB, *sB = seqB;
+    int nvec = 0;
+    bool finish = false, deep = false;
+
+    // children counts of node (cell, depth d): four u16 at cnt[off(d+1) + 4*cell .. +3]
+    auto child_counts = [&](uint32_t cell, int d, int c[4]) {
+        const uint16_t* ch = cnt + off(d + 1) + 4 * cell;
+        c[0] = ch[0]; c[1] = ch[1]; c[2] = ch[2]; c[3] = ch[3];
+    };
+
+    while (!finish && !deep) {
+        const int prevSize = L;
+        // ---------------- one pass of the first loop: split every expandable node
+        int total_ch = 0, nkeep = 0, nToExpand = 0;
+        for (int p0 = 0; p0 < L; p0 += 64) {
+            const int p = p0 + lane;
+            int nch = 0, nexp = 0, keep = 0;
+            if (p < L) {
+                const uint32_t info = iA[p];
+                if (info >> 24) keep = 1;
+                else {
+                    const int d = (info >> 20) & 15;
+                    if (d >= D) deep = true;
+                    else {
+                        int c[4];
+                        child_counts(cA[p], d, c);
+                        nch = (c[0] > 0) + (c[1] > 0) + (c[2] > 0) + (c[3] > 0);
+                        nexp = (c[0] > 1) + (c[1] > 1) + (c[2] > 1) + (c[3] > 1);
+                    }
+                }
+            }
+            int tch, tk, te;
+            const int pch = wave_excl_scan(nch, lane, tch);
+            const int pk = wave_excl_scan(keep, lane, tk);
+            const int pe = wave_excl_scan(nexp, lane, te);
+            if (p < L) { tpos[p] = (uint16_t)(keep ? nkeep + pk : total_ch + pch); smark[p] = (uint16_t)(nToExpand + pe); }
+            total_ch += tch; nkeep += tk; nToExpand += te;
+        }
+        deep = __any(deep);
+        if (deep) break;
+        if (total_ch + nkeep > nodecap) { deep = true; break; } // cannot happen (size <= N + 2), kept as a guard
+        QT_SYNC();
+        for (int p0 = 0; p0 < L; p0 += 64) {
+            const int p = p0 + lane;
+            if (p < L) {
+                const uint32_t info = iA[p];
+                if (info >> 24) {
+                    const int q = total_ch + tpos[p];
+                    cB[q] = cA[p]; iB[q] = info; sB[q] = sA[p];
+                } else {
+                    const int d = (info >> 20) & 15;
+                    int c[4];
+                    child_counts(cA[p], d, c);
+                    int ci = tpos[p], vi = smark[p];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        if (c[k] == 0) continue;
+                        const int q = total_ch - 1 - ci;
+                        cB[q] = cA[p] * 4 + k;
+                        iB[q] = (uint32_t)c[k] | ((uint32_t)(d + 1) << 20) | (c[k] == 1 ? (1u << 24) : 0u);
+                        sB[q] = (uint32_t)(seq + ci);
+                        if (c[k] > 1) {
+                            if (vi < veccap)
+                                vec[vi] = ((unsigned long long)c[k] << 40) | ((unsigned long long)(seq + ci) << 16) |
+                                          (unsigned long long)q;
+                            vi++;
+                        }
+                        ci++;
+                    }
+                }
+            }
+        }
+        seq += total_ch;
+        nvec = nToExpand;
+        L = total_ch + nkeep;
+        { uint32_t* t; t = cA; cA = cB; cB = t; t = iA; iA = iB; iB = t; t = sA; sA = sB; sB = t; }
+        QT_SYNC();
+        if (L >= N || L == prevSize) {
+            finish = true;
+        } else if (L + nToExpand * 3 > N) {
+            // ---------------- priority rounds (:673-737)
+            while (!finish && !deep) {
+                const int prevSize2 = L;
+                const int np = min(nvec, veccap);
+                int P = 1;
+                while (P < np) P <<= 1;
+                for (int i = lane; i < P; i += 64) vprev[i] = (i < np) ? vec[i] : 0ull;
+                QT_SYNC();
+                for (int k = 2; k <= P; k <<= 1)
+                    for (int j = k >> 1; j > 0; j >>= 1) {
+                        for (int t = lane; t < (P >> 1); t += 64) {
+                            const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                            const int l = i | j;
+                            const unsigned long long a = vprev[i], b = vprev[l];
+                            const bool up = ((i & k) == 0);
+                            if ((a > b) == up) { vprev[i] = b; vprev[l] = a; }
+                        }
+                        QT_SYNC();
+                    }
+                for (int p = lane; p < L; p += 64) smark[p] = 0;
+                QT_SYNC();
+                // scan in processing order (largest first); stop at the first prefix that reaches N
+                int cum = L, total_ch2 = 0, nsplit = np, nexp2 = 0;
+                bool cut = false;
+                for (int j0 = 0; j0 < np && !cut; j0 += 64) {
+                    const int j = j0 + lane;
+                    int nch = 0, nexp = 0, pos = 0;
+                    if (j < np) {
+                        pos = (int)(vprev[P - 1 - j] & 0xffff);
+                        const uint32_t info = iA[pos];
+                        const int d = (info >> 20) & 15;
+                        if (d >= D) deep = true;
+                        else {
+                            int c[4];
+                            child_counts(cA[pos], d, c);
+                            nch = (c[0] > 0) + (c[1] > 0) + (c[2] > 0) + (c[3] > 0);
+                            nexp = (c[0] > 1) + (c[1] > 1) + (c[2] > 1) + (c[3] > 1);
+                        }
+                    }
+                    int tg, tch, te;
+                    const int gain = (j < np) ? nch - 1 : 0;
+                    const int pg = wave_excl_scan(gain, lane, tg);
+                    const unsigned long long hit = __ballot(j < np && cum + pg + gain >= N);
+                    int upto = 64; // lanes of this chunk that are split
+                    if (hit) { upto = __ffsll((long long)hit); cut = true; nsplit = j0 + upto; }
+                    const bool sel = (j < np) && lane < upto;
+                    const int pch = wave_excl_scan(sel ? nch : 0, lane, tch);
+                    const int pe = wave_excl_scan(sel ? nexp : 0, lane, te);
+                    if (sel) { smark[pos] = (uint16_t)(j + 1); tpos[pos] = (uint16_t)(total_ch2 + pch); }
+                    if (sel) vec[j] = ((unsigned long long)(nexp2 + pe) << 32) | (unsigned)pos; // scratch: (vec slot, node position)
+                    total_ch2 += tch; nexp2 += te;
+                    cum += (hit ? 0 : tg);
+                }
+                deep = __any(deep);
+                if (deep) break;
+                if (total_ch2 + (L - nsplit) > nodecap) { deep = true; break; }
+                QT_SYNC();
+                // children of the split nodes, in reverse creation order at the front of the new list
+                // (vec[0..nsplit) currently holds (vec slot, node position) scratch; new vec entries go to vprev's tail-free
+                //  area: build them in cB-side scratch first)
+                for (int j0 = 0; j0 < nsplit; j0 += 64) {
+                    const int j = j0 + lane;
+                    if (j < nsplit) {
+                        const unsigned long long sc = vec[j];
+                        const int pos = (int)(sc & 0xffffffffu);
+                        int vi = (int)(sc >> 32);
+                        const uint32_t info = iA[pos];
+                        const int d = (info >> 20) & 15;
+                        int c[4];
+                        child_counts(cA[pos], d, c);
+                        int ci = tpos[pos];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            if (c[k] == 0) continue;
+                            const int q = total_ch2 - 1 - ci;
+                            cB[q] = cA[pos] * 4 + k;
+                            iB[q] = (uint32_t)c[k] | ((uint32_t)(d + 1) << 20) | (c[k] == 1 ? (1u << 24) : 0u);
+                            sB[q] = (uint32_t)(seq + ci);
+                            if (c[k] > 1) {
+                                if (vi < veccap)
+                                    vprev[vi] = ((unsigned long long)c[k] << 40) | ((unsigned long long)(seq + ci) << 16) |
+                                                (unsigned long long)q;
+                                vi++;
+                            }
+                            ci++;
+                        }
+                    }
+                }
+                // (vprev[0..nexp2) now holds the next round's vector; the sorted copy it overwrote is no longer needed
+                //  because every (vec slot, position) pair was taken from vec[] before this loop)
+                // survivors keep their relative order behind the new children
+                int kept = 0;
+                for (int p0 = 0; p0 < L; p0 += 64) {
+                    const int p = p0 + lane;
+                    const int keep = (p < L) && smark[p] == 0;
+                    int tk;
+                    const int pk = wave_excl_scan(keep, lane, tk);
+                    if (keep) {
+                        const int q = total_ch2 + kept + pk;
+                        cB[q] = cA[p]; iB[q] = iA[p]; sB[q] = sA[p];
+                    }
+                    kept += tk;
+                }
+                QT_SYNC();
+                for (int i = lane; i < min(nexp2, veccap); i += 64) vec[i] = vprev[i];
+                seq += total_ch2;
+                nvec = nexp2;
+                L = total_ch2 + kept;
+                { uint32_t* t; t = cA; cA = cB; cB = t; t = iA; iA = iB; iB = t; t = sA; sA = sB; sB = t; }
+                QT_SYNC();
+                if (L >= N || L == prevSize2) finish = true;
+            }
+        }
+    }
+    if (deep) {
+        if (lane == 0) fallback[fl_idx] = 1;
+        return;
+    }
+
+    // ---- best keypoint of every node, in list order (:741-760)
+    uint32_t* outp = lvl_out + (size_t)f * out_fstride + g.out_off;
+    for (int p0 = 0; p0 < L; p0 += 64) {
+        const int p = p0 + lane;
+        if (p < L) {
+            const int d = (iA[p] >> 20) & 15;
+            const int sh = 2 * (D - d);
+            const uint32_t l0 = cA[p] << sh, l1 = (cA[p] + 1) << sh;
+            unsigned long long b = 0;
+            for (uint32_t l = l0; l < l1; l++) {
+                const unsigned long long v = best[l];
+                b = v > b ? v : b;
+            }
+            outp[p] = (uint32_t)(b & 0xffffffu) | ((uint32_t)(b >> 46) << 24);
+        }
+    }
+    if (lane == 0) lvl_cnt[fl_idx] = L;
 }
 
 // per-frame level offsets (ascending-level concatenation, :1076-1104) and totals

@@ -49,7 +49,21 @@ __global__ void k_fast_cells(ImgView src0, ImgView pyr, const LevelGeom* geom, c
 __global__ void k_distribute(const LevelGeom* geom, const uint32_t* slots, size_t slots_fstride,
                              const int32_t* cellcnt, int ncells_total, uint32_t* keyscratch, size_t keys_fstride,
                              uint32_t* lvl_out, int out_fstride, int32_t* lvl_cnt, int nlevels, int32_t* lvl_ncand,
-                             int keycap_lds, int nodecap, int veccap);
+                             int keycap_lds, int nodecap, int veccap, const int32_t* only_flagged);
+__global__ void k_distribute_pyr(const LevelGeom* geom, const uint32_t* slots, size_t slots_fstride,
+                                 const int32_t* cellcnt, int ncells_total, uint32_t* lvl_out, int out_fstride,
+                                 int32_t* lvl_cnt, int nlevels, int32_t* lvl_ncand, int32_t* fallback, int D,
+                                 int nodecap, int veccap);
+
+inline size_t qp_lds_bytes(int nIni, int D, int nodecap, int veccap)
+{
+    const size_t nleaf = (size_t)nIni << (2 * D);
+    const size_t T = (size_t)nIni * (((1u << (2 * (D + 1))) - 1) / 3);
+    size_t b = nleaf * 8 + (size_t)veccap * 16 + (size_t)nodecap * 24;
+    b += 2 * (((size_t)nodecap * 2 + 15) & ~(size_t)15);
+    b += (T / 2 + 4) * 4;
+    return b + 32;
+}
 __global__ void k_level_offsets(const int32_t* lvl_cnt, int32_t* lvl_off, int32_t* n_out, int nlevels, int nframes,
                                 int capacity, int32_t* overflow);
 __global__ void k_blur7(ImgView src0, ImgView pyr, ImgView blur, const LevelGeom* geom, const uint32_t* tiles);

@@ -63,3 +63,40 @@ def test_flat_image_no_keypoints(orbfe, oracle):
     k, d = orbfe.ORBextractor(500, 1.2, 4, 20, 7)(img)
     ok, od = oracle.OrbOracle(500, 1.2, 4, 20, 7).extract(img)
     assert len(k) == 0 and len(ok) == 0
+
+
+def test_quadtree_fast_path_and_general_kernel_agree(orbfe, oracle):
+    """The count-pyramid quadtree and the general (key-moving) kernel are two implementations of DistributeOctTree."""
+    img, _ = synth.scene(480, 640, 21, n_markers=3)
+    ex = orbfe.ORBextractor(1000, 1.2, 8, 20, 7)
+    k1, d1 = ex(img)
+    assert not any(ex.quadtree_fell_back(0, l) for l in range(8))   # textured scene: the fast path handles every level
+    ex.force_general_quadtree(True)
+    k2, d2 = ex(img)
+    ok, od = oracle.OrbOracle(1000, 1.2, 8, 20, 7).extract(img)
+    assert np.array_equal(k1, k2) and np.array_equal(d1, d2)
+    assert np.array_equal(k1, ok) and np.array_equal(d1, od)
+
+
+def test_quadtree_fallback_to_general_kernel(orbfe, oracle):
+    """With a shallow count pyramid the tree wants to split leaf cells: those levels are redone by the general kernel."""
+    img, _ = synth.scene(480, 640, 22, n_markers=2)
+    ok, od = oracle.OrbOracle(1000, 1.2, 8, 20, 7).extract(img)
+    ex = orbfe.ORBextractor(1000, 1.2, 8, 20, 7)
+    for depth in (2, 3, 4):
+        ex.set_pyramid_depth(depth)
+        k, d = ex(img)
+        if depth <= 3:   # 1000 features need depth-4 nodes at level 0: a depth <= 3 pyramid must give up there
+            assert ex.quadtree_fell_back(0, 0), depth
+        assert np.array_equal(k, ok) and np.array_equal(d, od), depth
+
+
+def test_clustered_keypoints(orbfe, oracle):
+    """All texture in one small patch (the reference stops splitting as soon as a pass leaves the node count unchanged)."""
+    img = np.full((480, 640), 120, np.uint8)
+    rng = np.random.default_rng(3)
+    img[200:248, 300:348] = rng.integers(0, 256, (48, 48), dtype=np.uint8)
+    k, d = orbfe.ORBextractor(1000, 1.2, 8, 20, 7)(img)
+    ok, od = oracle.OrbOracle(1000, 1.2, 8, 20, 7).extract(img)
+    assert len(ok) > 10
+    assert np.array_equal(k, ok) and np.array_equal(d, od)
