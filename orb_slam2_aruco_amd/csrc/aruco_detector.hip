@@ -169,7 +169,7 @@ struct orbfe_aruco {
         ImgView pyr{d_pyr.as<uint8_t>(), d_pyr.as<uint8_t>(), pyr_fbytes, 0};
         timer.begin();
         timer.mark(s, "start");
-        hipLaunchKernelGGL(k_adaptive_threshold, dim3((cols + 63) / 64, (rows + 15) / 16, B), dim3(256), 0, s, src0,
+        hipLaunchKernelGGL(k_adaptive_threshold, dim3((cols + 63) / 64, (rows + 63) / 64, B), dim3(256), 0, s, src0,
                            cols, rows, win, 7, 1.0 / (win * win), d_bits.as<uint32_t>(), bits_fu32, wpr);
         timer.mark(s, "threshold");
         for (int p = 1; p < npyr; p++) {

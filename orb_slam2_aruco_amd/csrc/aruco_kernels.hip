@@ -31,36 +31,54 @@ __global__ __launch_bounds__(256) void k_adaptive_threshold(ImgView src, int W, 
     __shared__ uint8_t sin[16 + 2 * TH_MAXR][64 + 2 * TH_MAXR + 2];
     __shared__ uint16_t sh[16 + 2 * TH_MAXR][64];
     const int r = win >> 1;
-    const int tx0 = blockIdx.x * 64, ty0 = blockIdx.y * 16, f = blockIdx.z;
-    const int tid = threadIdx.x;
+    const int tx0 = blockIdx.x * 64, tyb = blockIdx.y * 64, f = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint8_t* img = src.base + (size_t)f * src.fstride;
-    const int rows = 16 + 2 * r, cols = 64 + 2 * r;
-    for (int i = tid; i < rows * cols; i += 256) {
-        const int rr = i / cols, cc = i - rr * cols;
-        const int y = min(max(ty0 + rr - r, 0), H - 1), x = min(max(tx0 + cc - r, 0), W - 1);
-        sin[rr][cc] = img[(size_t)y * src.pitch + x];
-    }
-    __syncthreads();
-    for (int i = tid; i < rows * 64; i += 256) {
-        const int rr = i >> 6, cc = i & 63;
-        int s = 0;
-        for (int k = 0; k < win; k++) s += sin[rr][cc + k];
-        sh[rr][cc] = (uint16_t)s;
-    }
-    __syncthreads();
-    const int lane = tid & 63, wid = tid >> 6;
-    for (int ry = wid; ry < 16; ry += 4) {
-        const int y = ty0 + ry, x = tx0 + lane;
-        int s = 0;
-        for (int k = 0; k < win; k++) s += sh[ry + k][lane];
-        int mean = orbfe_round_d((double)s * scale);
-        mean = mean > 255 ? 255 : mean;
-        const int v = sin[ry + r][lane + r];
-        const bool on = (x < W) && (y < H) && (v - mean <= -C);
-        const unsigned long long m = __ballot(on);
-        if (y < H && lane < 2) {
-            const int word = (tx0 >> 5) + lane;
-            if (word < wpr) bits[(size_t)f * bits_fstride + (size_t)y * wpr + word] = (uint32_t)(m >> (32 * lane));
+    // lane = column (clamped once per thread = BORDER_REPLICATE), wave = rows; 64 x 64 tile as four 16-row strips
+    const int xa = min(max(tx0 + lane - r, 0), W - 1);
+    const int xb = min(max(tx0 + 64 + (lane & 15) - r, 0), W - 1);
+    for (int ty0 = tyb; ty0 < tyb + 64 && ty0 < H; ty0 += 16) {
+        const int rows = 16 + 2 * r;
+        __syncthreads();
+        {
+            uint8_t va[8], vb[8]; // rows <= 30 -> at most 8 per wave; all loads issued before the LDS stores
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int rr = wid + 4 * k;
+                const uint8_t* row = img + (size_t)min(max(ty0 + min(rr, rows - 1) - r, 0), H - 1) * src.pitch;
+                va[k] = row[xa];
+                vb[k] = row[xb];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int rr = wid + 4 * k;
+                if (rr < rows) {
+                    sin[rr][lane] = va[k];
+                    if (lane < 2 * r) sin[rr][64 + lane] = vb[k];
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < rows * 64; i += 256) {
+            const int rr = i >> 6, cc = i & 63;
+            int s = 0;
+            for (int k = 0; k < win; k++) s += sin[rr][cc + k];
+            sh[rr][cc] = (uint16_t)s;
+        }
+        __syncthreads();
+        for (int ry = wid; ry < 16; ry += 4) {
+            const int y = ty0 + ry, x = tx0 + lane;
+            int s = 0;
+            for (int k = 0; k < win; k++) s += sh[ry + k][lane];
+            int mean = orbfe_round_d((double)s * scale);
+            mean = mean > 255 ? 255 : mean;
+            const int v = sin[ry + r][lane + r];
+            const bool on = (x < W) && (y < H) && (v - mean <= -C);
+            const unsigned long long m = __ballot(on);
+            if (y < H && lane < 2) {
+                const int word = (tx0 >> 5) + lane;
+                if (word < wpr) bits[(size_t)f * bits_fstride + (size_t)y * wpr + word] = (uint32_t)(m >> (32 * lane));
+            }
         }
     }
 }
@@ -299,6 +317,7 @@ __global__ __launch_bounds__(CT_THREADS) void k_contours_t(const uint32_t* __res
         uint32_t m_outer = 0, m_hole = 0;
         int wj = 0, wy = 0, qx = 0, qy = 0, ncand_l = 0;
         const int nwords = wpr * H;
+        const float inv_wpr = 1.0f / (float)wpr;
         __syncthreads();
         const int nlong = min(s_nlong, lq_cap);
         if (tid == 0) s_next = 0;
@@ -310,7 +329,7 @@ __global__ __launch_bounds__(CT_THREADS) void k_contours_t(const uint32_t* __res
                         const int i = atomicAdd(&s_next, 1);
                         if (i >= nwords) drained = true;
                         else {
-                            wy = 1 + i / wpr;
+                            wy = 1 + (int)(((float)i + 0.5f) * inv_wpr); // exact: i < 2^20, quotient >= 0.5/wpr off an integer
                             wj = i - (wy - 1) * wpr;
                             const uint32_t* row = lbits + wy * wpr;
                             const uint32_t* up = row - wpr;
@@ -376,7 +395,7 @@ __global__ __launch_bounds__(CT_THREADS) void k_contours_t(const uint32_t* __res
                 }
             }
         }
-        if (phase == 0) atomicAdd(&s_ncand, ncand_l);
+        if (phase == 0) { atomicAdd(&s_ncand, ncand_l); CT_STAMP(t2); }
     }
     __threadfence_block();
     __syncthreads();

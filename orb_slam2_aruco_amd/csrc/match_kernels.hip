@@ -123,7 +123,12 @@ __global__ __launch_bounds__(256) void k_search_init(const orbfe_keypoint* __res
 {
     __shared__ uint32_t s_sorted[SFI_MAXL0]; // (cell << 16) | index, ascending
     __shared__ int s_hist[30];
-    __shared__ int s_nl0;
+    __shared__ int s_nl0, s_nq;
+    __shared__ uint16_t s_query[SFI_MAXL0];  // level-0 keypoints of F1 in index order (the only ones that search)
+    __shared__ int s_vdist[SFI_MAXL0];       // vMatchedDistance / vnMatches21, indexed by the RANK of an F2 keypoint
+    __shared__ int s_v21[SFI_MAXL0];         //   in s_sorted (only level-0 keypoints of F2 can ever be matched)
+    __shared__ float s_ang1[SFI_MAXL0], s_ang2[SFI_MAXL0];
+    __shared__ signed char s_rotbin[SFI_MAXL0]; // per query: histogram bin or -1
 
     const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const orbfe_keypoint* k1 = kps + (size_t)p * capacity;
@@ -135,9 +140,6 @@ __global__ __launch_bounds__(256) void k_search_init(const orbfe_keypoint* __res
     int32_t* ccnt = csr_cnt + (size_t)p * capacity;
     uint16_t* cidx = csr_idx + (size_t)p * capacity * row_stride;
     uint8_t* cdist = csr_dist + (size_t)p * capacity * row_stride;
-    int32_t* vMatchedDistance = scratch + (size_t)p * 3 * capacity;
-    int32_t* vnMatches21 = vMatchedDistance + capacity;
-    int32_t* rotbin = vnMatches21 + capacity; // per i1: histogram bin or -1
     const float* prev = prev_in ? prev_in + (size_t)p * capacity * 2 : nullptr;
     float* prevo = prev_out ? prev_out + (size_t)p * capacity * 2 : nullptr;
 
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(256) void k_search_init(const orbfe_keypoint* __res
                         if (pos < row_stride) {
                             const uint4 b0 = reinterpret_cast<const uint4*>(d2)[2 * i2];
                             const uint4 b1 = reinterpret_cast<const uint4*>(d2)[2 * i2 + 1];
-                            ri[pos] = (uint16_t)i2;
+                            ri[pos] = (uint16_t)j; // rank in the sorted level-0 list (i2 = s_sorted[j] & 0xffff)
                             const int d = hamming256(a0, a1, b0, b1);
                             rd[pos] = (uint8_t)(d > 255 ? 255 : d); // 256 only for exact complements; > TH_LOW anyway
                         }
@@ -228,18 +230,51 @@ __global__ __launch_bounds__(256) void k_search_init(const orbfe_keypoint* __res
         }
         if (lane == 0) ccnt[i1] = min(count, row_stride);
     }
-    for (int i = tid; i < n2; i += 256) { vMatchedDistance[i] = INT_MAX; vnMatches21[i] = -1; }
-    for (int i = tid; i < n1; i += 256) { m12[i] = -1; rotbin[i] = -1; }
+    // level-0 queries in index order; per-rank state of F2 in LDS
+    if (tid == 0) s_nq = 0;
+    __syncthreads();
+    if (wid == 0) {
+        int nq = 0;
+        for (int i0 = 0; i0 < n1; i0 += 64) {
+            const int i = i0 + lane;
+            const bool isq = i < n1 && k1[i].octave <= 0;
+            const unsigned long long m = __ballot(isq);
+            const int pos = nq + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+            if (isq && pos < SFI_MAXL0) { s_query[pos] = (uint16_t)i; s_ang1[pos] = k1[i].angle; }
+            nq += __popcll(m);
+        }
+        if (lane == 0) {
+            if (nq > SFI_MAXL0) { atomicMax(overflow, nq); nq = SFI_MAXL0; }
+            s_nq = nq;
+        }
+    }
+    for (int i = tid; i < nl0; i += 256) { s_vdist[i] = INT_MAX; s_v21[i] = -1; s_ang2[i] = k2[s_sorted[i] & 0xffff].angle; }
+    for (int i = tid; i < SFI_MAXL0; i += 256) s_rotbin[i] = -1;
+    for (int i = tid; i < n1; i += 256) m12[i] = -1;
     if (tid < 30) s_hist[tid] = 0;
     __threadfence_block();
     __syncthreads();
     if (wid != 0) return;
 
-    // ---- phase C: the serial matching loop (ORBmatcher.cc:423-490), wave 0
+    // ---- phase C: the serial matching loop (ORBmatcher.cc:423-490), wave 0.  All loop-carried state is in LDS; the
+    // first 64 candidates of the NEXT query are prefetched while the current one is resolved.
+    const int nq = s_nq;
     int nmatches = 0;
     const float factor = 1.0f / 30; // HISTO_LENGTH; the upstream "1/30" quirk is kept (App. D)
-    for (int i1 = 0; i1 < n1; i1++) {
-        const int e = ccnt[i1];
+    int e_n = 0, r_n = 0, d_n = 0;
+    if (nq > 0) {
+        const int i1 = s_query[0];
+        e_n = ccnt[i1];
+        if (lane < e_n) { r_n = cidx[(size_t)i1 * row_stride + lane]; d_n = cdist[(size_t)i1 * row_stride + lane]; }
+    }
+    for (int q = 0; q < nq; q++) {
+        const int i1 = s_query[q];
+        const int e = e_n, r_c = r_n, d_c = d_n;
+        if (q + 1 < nq) {
+            const int i1n = s_query[q + 1];
+            e_n = ccnt[i1n];
+            if (lane < e_n) { r_n = cidx[(size_t)i1n * row_stride + lane]; d_n = cdist[(size_t)i1n * row_stride + lane]; }
+        }
         if (e <= 0) continue;
         const uint16_t* ri = cidx + (size_t)i1 * row_stride;
         const uint8_t* rd = cdist + (size_t)i1 * row_stride;
@@ -249,8 +284,8 @@ __global__ __launch_bounds__(256) void k_search_init(const orbfe_keypoint* __res
             const int j = j0 + lane;
             unsigned long long key = ~0ull;
             if (j < e) {
-                const int i2 = ri[j], d = rd[j];
-                if (!(vMatchedDistance[i2] <= d)) key = ((unsigned long long)d << 32) | (unsigned)j;
+                const int rk = j0 == 0 ? r_c : (int)ri[j], d = j0 == 0 ? d_c : (int)rd[j];
+                if (!(s_vdist[rk] <= d)) key = ((unsigned long long)d << 32) | ((unsigned long long)j << 16) | (unsigned)rk;
             }
             const unsigned long long m1 = wave_min_u64(key);
             const unsigned long long k2nd = wave_min_u64(key == m1 ? ~0ull : key);
@@ -261,37 +296,37 @@ __global__ __launch_bounds__(256) void k_search_init(const orbfe_keypoint* __res
         if (bestk == ~0ull) continue;
         const int bestDist = (int)(bestk >> 32);
         const int bestDist2 = secondk == ~0ull ? INT_MAX : (int)(secondk >> 32);
-        const int bestIdx2 = ri[(int)(bestk & 0xffffffffu)];
+        const int bestRank = (int)(bestk & 0xffffu);
         if (bestDist <= 50) { // TH_LOW
             if ((float)bestDist < __fmul_rn((float)bestDist2, nnratio)) {
-                const int old = vnMatches21[bestIdx2];
+                const int old = s_v21[bestRank];
                 if (old >= 0) {
                     if (lane == 0) m12[old] = -1;
                     nmatches--;
                 }
                 if (lane == 0) {
-                    m12[i1] = bestIdx2;
-                    vnMatches21[bestIdx2] = i1;
-                    vMatchedDistance[bestIdx2] = bestDist;
+                    m12[i1] = (int)(s_sorted[bestRank] & 0xffff);
+                    s_v21[bestRank] = i1;
+                    s_vdist[bestRank] = bestDist;
                 }
                 nmatches++;
                 if (check_ori) {
-                    float rot = k1[i1].angle - k2[bestIdx2].angle;
+                    float rot = s_ang1[q] - s_ang2[bestRank];
                     if (rot < 0.0f) rot += 360.0f;
                     int bin = (int)roundf(__fmul_rn(rot, factor));
                     if (bin == 30) bin = 0;
-                    if (lane == 0) rotbin[i1] = bin; // rotHist[bin].push_back(i1): entries stay even if un-matched later
+                    if (lane == 0) s_rotbin[q] = (signed char)bin; // rotHist[bin].push_back(i1): stays even if un-matched later
                 }
-                __threadfence_block();
+                __builtin_amdgcn_wave_barrier();
             }
         }
     }
     __threadfence_block();
     if (check_ori) {
         // histogram sizes count every push_back, including i1 whose match was later stolen (as in the reference)
-        for (int i = lane; i < n1; i += 64)
-            if (rotbin[i] >= 0) atomicAdd(&s_hist[rotbin[i]], 1);
-        __threadfence_block();
+        for (int i = lane; i < nq; i += 64)
+            if (s_rotbin[i] >= 0) atomicAdd(&s_hist[s_rotbin[i]], 1);
+        __builtin_amdgcn_wave_barrier();
         int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
         for (int i = 0; i < 30; i++) { // ComputeThreeMaxima, ORBmatcher.cc:1605-1646
             const int s = s_hist[i];
@@ -302,11 +337,11 @@ __global__ __launch_bounds__(256) void k_search_init(const orbfe_keypoint* __res
         if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
         else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
         int removed = 0;
-        for (int i0 = 0; i0 < n1; i0 += 64) {
-            const int i = i0 + lane;
+        for (int q0 = 0; q0 < nq; q0 += 64) {
+            const int q = q0 + lane;
             bool rm = false;
-            if (i < n1) {
-                const int bin = rotbin[i];
+            if (q < nq) {
+                const int bin = s_rotbin[q], i = s_query[q];
                 rm = bin >= 0 && bin != ind1 && bin != ind2 && bin != ind3 && m12[i] >= 0;
                 if (rm) m12[i] = -1;
             }

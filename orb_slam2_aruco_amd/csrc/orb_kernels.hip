@@ -1169,9 +1169,12 @@ __global__ __launch_bounds__(256) void k_orient_describe(ImgView src0, ImgView p
 #pragma unroll
         for (int it = 0; it < 16; it++) {
             const int v = -15 + 2 * it + half; // rows -15..16 (16 is masked)
-            const int av = v < 0 ? -v : v;
+            // umax of the r = 15 circular patch is a constant table (ORBextractor.cc:454-469); selecting between the
+            // two rows this lane can own keeps it an immediate instead of a dependent load
+            constexpr int UM[17] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3, 0};
+            const int v0 = -15 + 2 * it, a0 = v0 < 0 ? -v0 : v0, a1 = (v0 + 1) < 0 ? -(v0 + 1) : (v0 + 1);
             if ((lane & 31) < 31 && v <= 15) {
-                const int um = umax[av];
+                const int um = half ? UM[a1] : UM[a0];
                 if (u >= -um && u <= um) {
                     const int val = center[v * pitch + u];
                     m10 += u * val;

@@ -100,3 +100,43 @@ def test_clustered_keypoints(orbfe, oracle):
     ok, od = oracle.OrbOracle(1000, 1.2, 8, 20, 7).extract(img)
     assert len(ok) > 10
     assert np.array_equal(k, ok) and np.array_equal(d, od)
+
+
+@pytest.mark.parametrize("rows,cols,nf,nl,seed,dic,K", [
+    (720, 1280, 2000, 8, 3, "ARUCO_MIP_25h7", 6),      # BASELINE configs[2]
+    (1080, 1920, 4000, 12, 4, "ARUCO_MIP_36h12", 6),   # BASELINE configs[4] (extraction part)
+    (540, 960, 1000, 8, 8, "ARUCO", 4),                # what mono_cvcam really feeds (mono_cvcam.cc:124)
+])
+def test_baseline_configs_end_to_end(orbfe, oracle, rows, cols, nf, nl, seed, dic, K):
+    img, _ = synth.scene(rows, cols, seed, dic, K)
+    ex = orbfe.ORBextractor(nf, 1.2, nl, 20, 7)
+    kps, desc = ex(img)
+    okps, odesc = oracle.OrbOracle(nf, 1.2, nl, 20, 7).extract(img)
+    assert len(kps) == len(okps) and len(kps) >= nf * 0.9
+    assert np.array_equal(kps, okps)
+    assert np.array_equal(desc, odesc)
+    # a second call on the same handle (scratch reuse) and a 2-frame batch give the same answer
+    batch = ex.extract_batch(np.stack([img, img[::-1].copy()]))
+    assert np.array_equal(batch[0][0], okps) and np.array_equal(batch[0][1], odesc)
+
+
+def test_full_size_properties_without_oracle(orbfe):
+    """Size-independent properties at the bench batch size (64 frames of 640x480): determinism, level quotas,
+    keypoints inside the valid band, descriptors not degenerate."""
+    s = synth.stream(480, 640, 8, 4000)
+    frames = np.concatenate([s] * 8)
+    ex = orbfe.ORBextractor(1000, 1.2, 8, 20, 7)
+    a = ex.extract_batch(frames)
+    b = ex.extract_batch(frames)
+    scale = ex.GetScaleFactors()
+    quota = ex.features_per_level()
+    for i, ((k, d), (k2, d2)) in enumerate(zip(a, b)):
+        assert np.array_equal(k, k2) and np.array_equal(d, d2)                 # idempotent
+        assert np.array_equal(k, a[i % 8][0]) and np.array_equal(d, a[i % 8][1])  # same frame -> same result anywhere in the batch
+        assert np.all(np.diff(k["octave"]) >= 0)                                # levels concatenated in ascending order
+        for l in range(8):
+            m = k["octave"] == l
+            assert m.sum() <= quota[l] + 2                                      # ORBextractor.cc:730 overshoot bound
+            x, y = k["x"][m] / scale[l], k["y"][m] / scale[l]
+            assert x.min() >= 18.99 and y.min() >= 18.99                        # EDGE_THRESHOLD band
+        assert 100 < np.unpackbits(d, axis=1).sum(1).mean() < 156               # bits are balanced
