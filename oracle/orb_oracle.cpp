@@ -137,17 +137,24 @@ void gaussian_blur7(const Image& src, Image& dst)
     std::vector<int> tmp((size_t)w * h);
     for (int y = 0; y < h; y++) {
         const uint8_t* S = src.row(y);
+        int* T = tmp.data() + (size_t)y * w;
         for (int x = 0; x < w; x++) {
             int s = 0;
-            for (int k = -3; k <= 3; k++) s += taps[k + 3] * S[reflect101(x + k, w)];
-            tmp[(size_t)y * w + x] = s;
+            if (x >= 3 && x < w - 3) { /* interior: no border handling needed */
+                for (int k = -3; k <= 3; k++) s += taps[k + 3] * S[x + k];
+            } else {
+                for (int k = -3; k <= 3; k++) s += taps[k + 3] * S[reflect101(x + k, w)];
+            }
+            T[x] = s;
         }
     }
     for (int y = 0; y < h; y++) {
         uint8_t* D = dst.row(y);
+        const int* R[7];
+        for (int k = -3; k <= 3; k++) R[k + 3] = tmp.data() + (size_t)reflect101(y + k, h) * w;
         for (int x = 0; x < w; x++) {
             int s = 0;
-            for (int k = -3; k <= 3; k++) s += taps[k + 3] * tmp[(size_t)reflect101(y + k, h) * w + x];
+            for (int k = 0; k < 7; k++) s += taps[k] * R[k][x];
             int v = (s + 32768) >> 16;
             D[x] = (uint8_t)(v > 255 ? 255 : v);
         }
@@ -190,7 +197,15 @@ void fast_detect(const uint8_t* img, int stride, int w, int h, int threshold,
     std::vector<int> score((size_t)w * h, 0);
     for (int y = 3; y < h - 3; y++)
         for (int x = 3; x < w - 3; x++) {
-            int s = fast_score(img + (size_t)y * stride + x, stride);
+            const uint8_t* p = img + (size_t)y * stride + x;
+            /* early out, like cv::FAST's table test: a 9-arc always covers two ADJACENT compass points of the ring, so
+             * two adjacent ones must both be brighter / both darker than the centre by more than the threshold */
+            const int v = p[0], lo = v - threshold, hi = v + threshold;
+            const int r0 = p[3 * stride], r4 = p[3], r8 = p[-3 * stride], r12 = p[-3];
+            const bool dk = (r0 < lo && (r4 < lo || r12 < lo)) || (r8 < lo && (r4 < lo || r12 < lo));
+            const bool br = (r0 > hi && (r4 > hi || r12 > hi)) || (r8 > hi && (r4 > hi || r12 > hi));
+            if (!dk && !br) continue;
+            int s = fast_score(p, stride);
             score[(size_t)y * w + x] = s >= threshold ? s : 0;
         }
     for (int y = 3; y < h - 3; y++)
