@@ -136,26 +136,35 @@ def main():
         rec = [d_n, d_kps, d_desc] + ([d_nmk, d_mk] if use_aruco else [])
         gathered = [[torch.empty_like(t) for _ in range(world)] if rank == 0 else None for t in rec]
 
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]  # around the matching launches (same stream)
+
     def step():
         if use_aruco:
-            stream2.wait_stream(stream)
+            # the detector stream only depends on the (resident) input frames and on its own previous batch, so it is not
+            # joined with the ORB stream per step: consecutive batches of the two engines pipeline freely.  They are
+            # joined where their results meet: before the RCCL gather (N > 1) and before the clock stops.
             det.detect_batch_device(d_imgs.data_ptr(), B, rows * pitch, rows, cols, pitch, d_mk.data_ptr(), mcap,
                                     d_nmk.data_ptr(), sp2)
         ex.extract_batch_device(d_imgs.data_ptr(), B, rows * pitch, rows, cols, pitch, d_kps.data_ptr(),
                                 d_desc.data_ptr(), cap, d_n.data_ptr(), sp)
         # frame t vs t-1: all-pairs knn2 + one SearchForInitialization-style windowed pass
+        ev[0].record(stream)
         binding._check(L, L.orbfe_knn2_batch_device(d_desc.data_ptr(), d_n.data_ptr(), cap * 32, cap,
                                                     d_desc.data_ptr() + cap * 32, d_n.data_ptr() + 4, cap * 32, cap,
                                                     B - 1, 256, d_bidx.data_ptr(), d_bdist.data_ptr(),
                                                     d_sdist.data_ptr(), sp), "knn2")
+        ev[1].record(stream)
         binding._check(L, L.orbfe_search_for_initialization_batch_device(
             d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap, B - 1, cols, rows, 100, 0.9, 1,
             d_m12.data_ptr(), d_nm.data_ptr(), sp), "sfi")
-        if use_aruco:
-            stream.wait_stream(stream2)
+        ev[2].record(stream)
         if world > 1:
+            if use_aruco:
+                stream.wait_stream(stream2)
             for t, g in zip(rec, gathered):
                 dist.gather(t, g, dst=0)
+            if use_aruco:
+                stream2.wait_stream(stream)   # the next batch must not overwrite records that are still being gathered
 
     ex.enable_kernel_timing(False)
     for _ in range(args.warmup):
@@ -191,6 +200,8 @@ def main():
     if rank == 0:
         orb_names = ["resize", "fast_cells", "distribute", "blur7", "orient_describe"]
         stages = {nm: float(v) for nm, v in zip(orb_names, orb_us)}
+        stages["knn2"] = ev[0].elapsed_time(ev[1]) * 1000.0
+        stages["search_init"] = ev[1].elapsed_time(ev[2]) * 1000.0
         if use_aruco:
             for nm, v in zip(binding.MarkerDetector.STAGES, aruco_us):
                 stages["aruco_" + nm] = float(v)
@@ -200,7 +211,8 @@ def main():
         sumP, P0 = sum(P), P[0]
         N = float(n_host.mean())
         alg = {"resize": (sumP - P[-1]) + (sumP - P0), "fast_cells": sumP, "blur7": 2 * sumP,
-               "orient_describe": N * (749 + 512 + 60), "distribute": 0}
+               "orient_describe": N * (749 + 512 + 60), "distribute": 0,
+               "knn2": 2 * N * 32 + N * 12, "search_init": 2 * N * (32 + 28) + N * 4}
         if use_aruco:
             alg.update(binding.MarkerDetector.algorithmic_bytes(rows, cols))
         dom = max(stages, key=lambda k: stages[k]) if stages else None
@@ -216,7 +228,12 @@ def main():
                     traffic = None
             roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": 8000.0, "unit": "GB/s",
                     "frac": ach / 8000.0, "traffic": traffic, "launch_us": stages[dom],
-                    "algorithmic_bytes_per_launch": alg.get(dom, 0) * B}
+                    "algorithmic_bytes_per_launch": alg.get(dom, 0) * B,
+                    "note": "dominant launch of the last timed step (HIP events on its launch stream, the other engine "
+                            "running concurrently); k_contours is serial border following, latency- not HBM-bound",
+                    # the same figure for every stage, so the HBM-bound image kernels can be read off too
+                    "all_stages_GBps": {k: (alg.get(k, 0) * B / (v * 1e-6) / 1e9 if v > 0 else 0.0)
+                                        for k, v in stages.items()}}
         cpu = None
         if world == 1 and args.cpu_frames > 0:
             cpu = cpu_baseline(args, frames_np)

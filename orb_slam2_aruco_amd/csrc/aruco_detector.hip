@@ -181,10 +181,9 @@ struct orbfe_aruco {
                 hipLaunchKernelGGL(k_half_area, dim3((L.w + 63) / 64, (L.h + 3) / 4, B), dim3(256), 0, s, sv, dv, L.w, L.h);
             } else {
                 const int dw4 = (L.w + 3) / 4;
-                const int* tabs = d_tabs.as<int>();
-                hipLaunchKernelGGL(k_resize_level, dim3((dw4 + 63) / 64, (L.h + 3) / 4, B), dim3(256), 0, s, sv, dv,
-                                   Lp.w, Lp.h, dw4, L.h, tabs + tab_off[p * 4 + 0], tabs + tab_off[p * 4 + 1],
-                                   tabs + tab_off[p * 4 + 2], tabs + tab_off[p * 4 + 3]);
+                const double scale_x = 1. / ((double)L.w / Lp.w), scale_y = 1. / ((double)L.h / Lp.h);
+                hipLaunchKernelGGL(k_resize_level, dim3((dw4 + 63) / 64, (L.h + 7) / 8, B), dim3(256), 0, s, sv, dv,
+                                   Lp.w, Lp.h, dw4, L.h, scale_x, scale_y, L.w);
             }
         }
         timer.mark(s, "pyramid");

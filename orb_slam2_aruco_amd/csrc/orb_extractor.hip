@@ -278,11 +278,9 @@ struct orbfe_extractor {
             ImgView sv = (l == 1) ? src0 : ImgView{pyr.base + gp.img_off, nullptr, pyr_fbytes, gp.pitch};
             ImgView dv{pyr.base + g.img_off, pyr.base_w + g.img_off, pyr_fbytes, g.pitch};
             const int dw4 = (g.w + 3) / 4;
-            dim3 grid((dw4 + 63) / 64, (g.h + 3) / 4, B);
-            const int* tabs = d_tabs.as<int>();
-            hipLaunchKernelGGL(k_resize_level, grid, dim3(256), 0, s, sv, dv, gp.w, gp.h, dw4, g.h,
-                               tabs + tab_off[l * 4 + 0], tabs + tab_off[l * 4 + 1], tabs + tab_off[l * 4 + 2],
-                               tabs + tab_off[l * 4 + 3]);
+            dim3 grid((dw4 + 63) / 64, (g.h + 7) / 8, B);
+            const double scale_x = 1. / ((double)g.w / gp.w), scale_y = 1. / ((double)g.h / gp.h);
+            hipLaunchKernelGGL(k_resize_level, grid, dim3(256), 0, s, sv, dv, gp.w, gp.h, dw4, g.h, scale_x, scale_y, g.w);
         }
         timer.mark(s, "resize");
         {

@@ -22,40 +22,67 @@ __device__ __forceinline__ int lane_prefix(unsigned long long mask)
 }
 
 // ------------------------------------------------------------------------------------------------ resize --
-// One thread = 4 horizontally adjacent output pixels (one aligned u32 store).  Coefficient tables are built on the
-// host exactly as cv::resize does (double/float arithmetic), so the kernel is pure integer work.
+// One thread = 4 horizontally adjacent output pixels x 2 rows (two aligned u32 stores).  The cv::resize coefficient
+// arithmetic (double/float) is evaluated per thread with exactly the host formulas -- contraction is
+// off, so the values equal the host-built tables the first version of this kernel loaded -- which removes the
+// dependent table-load -> pixel-load chain.
+__device__ __forceinline__ void resize_coef(int d, double scale, int smax, int& s0, int& a0, int& a1)
+{
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int si = orbfe_floor_d((double)f);
+    f -= (float)si;
+    if (si < 0) { f = 0.f; si = 0; }
+    if (si >= smax - 1) { f = 0.f; si = smax - 1; }
+    s0 = si;
+    a0 = (short)orbfe_round_f((1.f - f) * 2048.f);
+    a1 = (short)orbfe_round_f(f * 2048.f);
+}
+
 __global__ __launch_bounds__(256) void k_resize_level(ImgView src, ImgView dst, int sw, int sh, int dw4 /*ceil(dw/4)*/,
-                                                      int dh, const int* __restrict__ xofs,
-                                                      const int* __restrict__ xalpha, const int* __restrict__ yofs,
-                                                      const int* __restrict__ ybeta)
+                                                      int dh, double scale_x, double scale_y, int dw)
 {
     const int x4 = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int dy0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 2;
     const int f = blockIdx.z;
-    if (x4 >= dw4 || dy >= dh) return;
+    if (x4 >= dw4 || dy0 >= dh) return;
     const uint8_t* S = src.base + (size_t)f * src.fstride;
-    int sy0 = yofs[dy], sy1 = sy0 + 1;
-    sy0 = min(max(sy0, 0), sh - 1);
-    sy1 = min(max(sy1, 0), sh - 1);
-    const uint8_t* S0 = S + (size_t)sy0 * src.pitch;
-    const uint8_t* S1 = S + (size_t)sy1 * src.pitch;
-    const int bb = ybeta[dy];
-    const int b0 = (short)(bb & 0xffff), b1 = (short)(bb >> 16);
-    uint32_t packed = 0;
+    int sx[4], ax0[4], ax1[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int dx = x4 * 4 + k; // tables are padded to a multiple of 4 entries
-        const int sx = xofs[dx];
-        const int sx1 = min(sx + 1, sw - 1);
-        const int aa = xalpha[dx];
-        const int a0 = (short)(aa & 0xffff), a1 = (short)(aa >> 16);
-        const int h0 = S0[sx] * a0 + S0[sx1] * a1;
-        const int h1 = S1[sx] * a0 + S1[sx1] * a1;
-        const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-        packed |= (uint32_t)(v & 0xff) << (8 * k);
+    for (int k = 0; k < 4; k++) resize_coef(min(x4 * 4 + k, dw - 1), scale_x, sw, sx[k], ax0[k], ax1[k]);
+    uint8_t px[2][2][4][2];
+    int b0[2], b1[2];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int dy = min(dy0 + r, dh - 1);
+        // rows are NOT clamped like columns: cv::resize keeps the fractional weight and clips the row index
+        float fy = (float)(((double)dy + 0.5) * scale_y - 0.5);
+        int sy = orbfe_floor_d((double)fy);
+        fy -= (float)sy;
+        b0[r] = (short)orbfe_round_f((1.f - fy) * 2048.f);
+        b1[r] = (short)orbfe_round_f(fy * 2048.f);
+        const uint8_t* S0 = S + (size_t)min(max(sy, 0), sh - 1) * src.pitch;
+        const uint8_t* S1 = S + (size_t)min(max(sy + 1, 0), sh - 1) * src.pitch;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int s1 = min(sx[k] + 1, sw - 1);
+            px[r][0][k][0] = S0[sx[k]]; px[r][0][k][1] = S0[s1];
+            px[r][1][k][0] = S1[sx[k]]; px[r][1][k][1] = S1[s1];
+        }
     }
-    uint8_t* D = dst.base_w + (size_t)f * dst.fstride + (size_t)dy * dst.pitch;
-    *reinterpret_cast<uint32_t*>(D + x4 * 4) = packed;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        if (dy0 + r >= dh) break;
+        uint32_t packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int h0 = px[r][0][k][0] * ax0[k] + px[r][0][k][1] * ax1[k];
+            const int h1 = px[r][1][k][0] * ax0[k] + px[r][1][k][1] * ax1[k];
+            const int v = (((b0[r] * (h0 >> 4)) >> 16) + ((b1[r] * (h1 >> 4)) >> 16) + 2) >> 2;
+            packed |= (uint32_t)(v & 0xff) << (8 * k);
+        }
+        uint8_t* D = dst.base_w + (size_t)f * dst.fstride + (size_t)(dy0 + r) * dst.pitch;
+        *reinterpret_cast<uint32_t*>(D + x4 * 4) = packed;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ FAST ----
