@@ -50,7 +50,8 @@ struct orbfe_extractor {
     int keycap_lds = 0, nodecap = 0, veccap = 0;
     std::vector<size_t> tab_off; // per level >= 1: offsets (in ints) of xofs, xalpha, yofs, ybeta in d_tabs
     DevBuf d_geom, d_cellinfo, d_tiles, d_tabs, d_pattern, d_umax;
-    DevBuf d_pyr, d_blur, d_slots, d_cellcnt, d_keys, d_lvlout, d_lvlcnt, d_lvloff, d_lvlncand, d_overflow, d_fallback;
+    DevBuf d_pyr, d_blur, d_slots, d_cellcnt, d_keys, d_lvlout, d_lvlcnt, d_lvloff, d_lvlncand, d_overflow, d_fallback,
+        d_flatkv, d_flatlvl;
     bool force_general_quadtree = false; // test hook: run the general kernel for every level
     int force_pyramid_depth = 0;         // test hook: shallow count pyramid so that levels fall back
     DevBuf d_in, d_kps, d_desc, d_nout; // staging for the host-pointer entry points
@@ -61,7 +62,8 @@ struct orbfe_extractor {
     ~orbfe_extractor()
     {
         for (DevBuf* b : {&d_geom, &d_cellinfo, &d_tiles, &d_tabs, &d_pattern, &d_umax, &d_pyr, &d_blur, &d_slots,
-                          &d_cellcnt, &d_keys, &d_lvlout, &d_lvlcnt, &d_lvloff, &d_lvlncand, &d_overflow, &d_fallback, &d_in,
+                          &d_cellcnt, &d_keys, &d_lvlout, &d_lvlcnt, &d_lvloff, &d_lvlncand, &d_overflow, &d_fallback, &d_flatkv,
+                          &d_flatlvl, &d_in,
                           &d_kps, &d_desc, &d_nout})
             b->release();
         if (own_stream) (void)hipStreamDestroy(own_stream);
@@ -321,14 +323,18 @@ struct orbfe_extractor {
                                force_general_quadtree ? nullptr : d_fallback.as<int32_t>());
         }
         timer.mark(s, "distribute");
-        hipLaunchKernelGGL(k_level_offsets, dim3((B + 63) / 64), dim3(64), 0, s, d_lvlcnt.as<int32_t>(),
-                           d_lvloff.as<int32_t>(), d_n, nlevels, B, capacity, d_overflow.as<int32_t>());
+        {
+            int rc2;
+            if ((rc2 = d_flatkv.ensure((size_t)B * capacity * 4)) || (rc2 = d_flatlvl.ensure((size_t)B * capacity))) return rc2;
+        }
+        hipLaunchKernelGGL(k_level_offsets, dim3(B), dim3(256), 0, s, d_lvlcnt.as<int32_t>(), d_lvloff.as<int32_t>(),
+                           d_n, nlevels, B, capacity, d_overflow.as<int32_t>(), dg, d_lvlout.as<uint32_t>(), out_total,
+                           d_flatkv.as<uint32_t>(), d_flatlvl.as<uint8_t>());
         hipLaunchKernelGGL(k_blur7, dim3(ntiles, B), dim3(256), 0, s, src0, pyr, blur, dg, d_tiles.as<uint32_t>());
         timer.mark(s, "blur7");
-        hipLaunchKernelGGL(k_orient_describe, dim3((max_out_cap + 3) / 4, nlevels, B), dim3(256), 0, s, src0, pyr,
-                           blur, dg, d_lvlout.as<uint32_t>(), out_total, d_lvlcnt.as<int32_t>(),
-                           d_lvloff.as<int32_t>(), nlevels, d_pattern.as<uint32_t>(), d_umax.as<int>(), d_kps_out,
-                           d_desc_out, capacity);
+        hipLaunchKernelGGL(k_orient_describe, dim3((std::min(capacity, max_keypoints()) + 3) / 4, B), dim3(256), 0, s, src0, pyr,
+                           blur, dg, d_flatkv.as<uint32_t>(), d_flatlvl.as<uint8_t>(), d_n, nlevels,
+                           d_pattern.as<uint32_t>(), d_umax.as<int>(), d_kps_out, d_desc_out, capacity);
         timer.mark(s, "orient_describe");
         ORBFE_HIP(hipGetLastError());
         return ORBFE_OK;

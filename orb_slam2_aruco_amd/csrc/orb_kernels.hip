@@ -1053,23 +1053,36 @@ __global__ __launch_bounds__(64) void k_distribute_pyr(const LevelGeom* __restri
     if (lane == 0) lvl_cnt[fl_idx] = L;
 }
 
-// per-frame level offsets (ascending-level concatenation, :1076-1104) and totals
-__global__ void k_level_offsets(const int32_t* __restrict__ lvl_cnt, int32_t* __restrict__ lvl_off,
-                                int32_t* __restrict__ n_out, int nlevels, int nframes, int capacity,
-                                int32_t* __restrict__ overflow)
+// per-frame level offsets (ascending-level concatenation, :1076-1104), totals, and a flat (keypoint, level) list so that
+// the per-keypoint kernel needs one record load instead of a chain of dependent lookups
+__global__ __launch_bounds__(256) void k_level_offsets(const int32_t* __restrict__ lvl_cnt, int32_t* __restrict__ lvl_off,
+                                                       int32_t* __restrict__ n_out, int nlevels, int nframes,
+                                                       int capacity, int32_t* __restrict__ overflow,
+                                                       const LevelGeom* __restrict__ geom,
+                                                       const uint32_t* __restrict__ lvl_out, int out_fstride,
+                                                       uint32_t* __restrict__ flat_kv, uint8_t* __restrict__ flat_lvl)
 {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.x, tid = threadIdx.x;
     if (f >= nframes) return;
     int acc = 0;
     for (int l = 0; l < nlevels; l++) {
-        lvl_off[f * nlevels + l] = acc;
-        acc += lvl_cnt[f * nlevels + l];
+        const int c = lvl_cnt[f * nlevels + l];
+        if (tid == 0) lvl_off[f * nlevels + l] = acc;
+        const uint32_t* src = lvl_out + (size_t)f * out_fstride + geom[l].out_off;
+        for (int i = tid; i < c; i += 256)
+            if (acc + i < capacity) {
+                flat_kv[(size_t)f * capacity + acc + i] = src[i];
+                flat_lvl[(size_t)f * capacity + acc + i] = (uint8_t)l;
+            }
+        acc += c;
     }
-    if (acc > capacity) {
-        atomicMax(overflow, acc);
-        acc = capacity;
+    if (tid == 0) {
+        if (acc > capacity) {
+            atomicMax(overflow, acc);
+            acc = capacity;
+        }
+        n_out[f] = acc;
     }
-    n_out[f] = acc;
 }
 
 // ------------------------------------------------------------------------------------------------ blur ----
@@ -1165,22 +1178,20 @@ __global__ __launch_bounds__(256) void k_blur7(ImgView src0, ImgView pyr, ImgVie
 // blurred level (:108-147), then the final record (octave, size, scaled coordinates; :837-847, :1095-1101).
 __global__ __launch_bounds__(256) void k_orient_describe(ImgView src0, ImgView pyr, ImgView blur,
                                                          const LevelGeom* __restrict__ geom,
-                                                         const uint32_t* __restrict__ lvl_out, int out_fstride,
-                                                         const int32_t* __restrict__ lvl_cnt,
-                                                         const int32_t* __restrict__ lvl_off, int nlevels,
+                                                         const uint32_t* __restrict__ flat_kv,
+                                                         const uint8_t* __restrict__ flat_lvl,
+                                                         const int32_t* __restrict__ n_out, int nlevels,
                                                          const uint32_t* __restrict__ pattern32 /*256 x (x0,y0,x1,y1) i8*/,
                                                          const int* __restrict__ umax, orbfe_keypoint* __restrict__ kps,
                                                          uint8_t* __restrict__ desc, int capacity)
 {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int level = blockIdx.y, f = blockIdx.z;
-    const int i = blockIdx.x * 4 + wid;
-    const int cnt = lvl_cnt[f * nlevels + level];
-    if (i >= cnt) return;
-    const int oidx = lvl_off[f * nlevels + level] + i;
-    if (oidx >= capacity) return;
+    const int f = blockIdx.y;
+    const int oidx = blockIdx.x * 4 + wid; // flat index over the frame's keypoints (levels concatenated ascending)
+    if (oidx >= n_out[f]) return;
+    const uint32_t kv = flat_kv[(size_t)f * capacity + oidx];
+    const int level = __builtin_amdgcn_readfirstlane((int)flat_lvl[(size_t)f * capacity + oidx]);
     const LevelGeom g = geom[level];
-    const uint32_t kv = lvl_out[(size_t)f * out_fstride + g.out_off + i];
     const int kx = (int)(kv & 0xfff) + 16, ky = (int)((kv >> 12) & 0xfff) + 16; // += minBorder (:843-844)
     const int score = kv >> 24;
 
@@ -1188,22 +1199,42 @@ __global__ __launch_bounds__(256) void k_orient_describe(ImgView src0, ImgView p
                                       : pyr.base + (size_t)f * pyr.fstride + g.img_off;
     const int pitch = (level == 0) ? src0.pitch : g.pitch;
 
-    // ---- IC_Angle: lanes 0..30 <-> u = -15..15 of an even row, lanes 32..62 of the following row
+    // ---- IC_Angle.  The 31 x 31 patch is staged in LDS with coalesced dword loads (rows of 36 bytes starting at the
+    // 4-byte-aligned column at or below kx - 15); then lanes 0..30 <-> u = -15..15 of an even row, lanes 32..62 of
+    // the following row.
+    __shared__ __align__(16) uint8_t s_pat[4][31 * 36 + 12];
     int m10 = 0, m01 = 0;
     {
+        const int axp = (kx - 15) & ~3, xo = (kx - 15) - axp;
+        const uint8_t* pimg = img + (size_t)(ky - 15) * pitch + axp;
+        uint32_t v[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int idx = min(k * 64 + lane, 278);
+            const int r = idx / 9, c = idx - r * 9;
+            const uint8_t* p = pimg + (size_t)r * pitch + 4 * c;
+            // level 0 is the caller's buffer: no alignment is assumed there (gfx950 global loads may be unaligned)
+            typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+            v[k] = *reinterpret_cast<const u32_unaligned*>(p);
+        }
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int idx = k * 64 + lane;
+            if (idx < 279) reinterpret_cast<uint32_t*>(s_pat[wid])[idx] = v[k];
+        }
+        __builtin_amdgcn_wave_barrier();
         const int half = lane >> 5, u = (lane & 31) - 15;
-        const uint8_t* center = img + (size_t)ky * pitch + kx;
+        const uint8_t* center = s_pat[wid] + 15 * 36 + 15 + xo;
 #pragma unroll
         for (int it = 0; it < 16; it++) {
             const int v = -15 + 2 * it + half; // rows -15..16 (16 is masked)
-            // umax of the r = 15 circular patch is a constant table (ORBextractor.cc:454-469); selecting between the
-            // two rows this lane can own keeps it an immediate instead of a dependent load
+            // umax of the r = 15 circular patch is a constant table (ORBextractor.cc:454-469)
             constexpr int UM[17] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3, 0};
             const int v0 = -15 + 2 * it, a0 = v0 < 0 ? -v0 : v0, a1 = (v0 + 1) < 0 ? -(v0 + 1) : (v0 + 1);
             if ((lane & 31) < 31 && v <= 15) {
                 const int um = half ? UM[a1] : UM[a0];
                 if (u >= -um && u <= um) {
-                    const int val = center[v * pitch + u];
+                    const int val = center[v * 36 + u];
                     m10 += u * val;
                     m01 += v * val;
                 }
@@ -1222,8 +1253,28 @@ __global__ __launch_bounds__(256) void k_orient_describe(ImgView src0, ImgView p
     const float arad = angle * factorPI;
     float a, b;
     orbfe_sincosf(arad, &b, &a); // a = cos, b = sin
+    // Stage the 37 x 37 blurred window (pattern reach <= 18 px) in LDS with coalesced dword loads: 6 wave loads touch
+    // ~60 cache lines, where 8 direct byte gathers would touch ~300.  Rows are 40 bytes: the window starts at the
+    // 4-byte-aligned column at or below kx - 18.
+    __shared__ __align__(16) uint8_t s_win[4][37 * 40 + 8];
     const uint8_t* bimg = blur.base + (size_t)f * blur.fstride + g.blur_off;
-    const uint8_t* bc = bimg + (size_t)ky * g.bpitch + kx;
+    const int ax = (kx - 18) & ~3, xoff = (kx - 18) - ax;
+    {
+        uint32_t v[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const int idx = min(k * 64 + lane, 369);
+            const int r = idx / 10, c = idx - r * 10;
+            v[k] = *reinterpret_cast<const uint32_t*>(bimg + (size_t)(ky - 18 + r) * g.bpitch + ax + 4 * c);
+        }
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const int idx = k * 64 + lane;
+            if (idx < 370) reinterpret_cast<uint32_t*>(s_win[wid])[idx] = v[k];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint8_t* bc = s_win[wid] + 18 * 40 + 18 + xoff;
     unsigned long long words[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -1234,7 +1285,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(ImgView src0, ImgView p
         const int c0 = orbfe_round_f(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
         const int r1 = orbfe_round_f(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
         const int c1 = orbfe_round_f(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-        const int t0 = bc[r0 * g.bpitch + c0], t1 = bc[r1 * g.bpitch + c1];
+        const int t0 = bc[r0 * 40 + c0], t1 = bc[r1 * 40 + c1];
         words[j] = __ballot(t0 < t1);
     }
     if (lane < 4) {

@@ -65,12 +65,13 @@ inline size_t qp_lds_bytes(int nIni, int D, int nodecap, int veccap)
     return b + 32;
 }
 __global__ void k_level_offsets(const int32_t* lvl_cnt, int32_t* lvl_off, int32_t* n_out, int nlevels, int nframes,
-                                int capacity, int32_t* overflow);
+                                int capacity, int32_t* overflow, const LevelGeom* geom, const uint32_t* lvl_out,
+                                int out_fstride, uint32_t* flat_kv, uint8_t* flat_lvl);
 __global__ void k_blur7(ImgView src0, ImgView pyr, ImgView blur, const LevelGeom* geom, const uint32_t* tiles);
 __global__ void k_orient_describe(ImgView src0, ImgView pyr, ImgView blur, const LevelGeom* geom,
-                                  const uint32_t* lvl_out, int out_fstride, const int32_t* lvl_cnt,
-                                  const int32_t* lvl_off, int nlevels, const uint32_t* pattern32, const int* umax,
-                                  orbfe_keypoint* kps, uint8_t* desc, int capacity);
+                                  const uint32_t* flat_kv, const uint8_t* flat_lvl, const int32_t* n_out, int nlevels,
+                                  const uint32_t* pattern32, const int* umax, orbfe_keypoint* kps, uint8_t* desc,
+                                  int capacity);
 __global__ void k_unpack_keys(const uint32_t* in, int n, int add, orbfe_keypoint* out);
 
 inline size_t qt_lds_bytes(int keycap_lds, int nodecap, int veccap)
