@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--dictionary", default="ARUCO")
     ap.add_argument("--cpu-frames", type=int, default=24, help="frames timed on the host for cpu_baseline (0 = skip)")
     ap.add_argument("--no-aruco", action="store_true", help="diagnostic only: drop the ArUco leg (invalidates value)")
+    ap.add_argument("--no-orb", action="store_true", help="diagnostic only: drop the ORB + matching legs (invalidates value)")
     return ap.parse_args()
 
 
@@ -145,6 +146,8 @@ def main():
             # joined where their results meet: before the RCCL gather (N > 1) and before the clock stops.
             det.detect_batch_device(d_imgs.data_ptr(), B, rows * pitch, rows, cols, pitch, d_mk.data_ptr(), mcap,
                                     d_nmk.data_ptr(), sp2)
+        if args.no_orb:
+            return
         ex.extract_batch_device(d_imgs.data_ptr(), B, rows * pitch, rows, cols, pitch, d_kps.data_ptr(),
                                 d_desc.data_ptr(), cap, d_n.data_ptr(), sp)
         # frame t vs t-1: all-pairs knn2 + one SearchForInitialization-style windowed pass
@@ -167,6 +170,9 @@ def main():
                 stream2.wait_stream(stream)   # the next batch must not overwrite records that are still being gathered
 
     ex.enable_kernel_timing(False)
+    if args.no_orb:  # diagnostics still want the level geometry
+        ex.extract_batch_device(d_imgs.data_ptr(), B, rows * pitch, rows, cols, pitch, d_kps.data_ptr(),
+                                d_desc.data_ptr(), cap, d_n.data_ptr(), sp)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -200,8 +206,9 @@ def main():
     if rank == 0:
         orb_names = ["resize", "fast_cells", "distribute", "blur7", "orient_describe"]
         stages = {nm: float(v) for nm, v in zip(orb_names, orb_us)}
-        stages["knn2"] = ev[0].elapsed_time(ev[1]) * 1000.0
-        stages["search_init"] = ev[1].elapsed_time(ev[2]) * 1000.0
+        if not args.no_orb:
+            stages["knn2"] = ev[0].elapsed_time(ev[1]) * 1000.0
+            stages["search_init"] = ev[1].elapsed_time(ev[2]) * 1000.0
         if use_aruco:
             for nm, v in zip(binding.MarkerDetector.STAGES, aruco_us):
                 stages["aruco_" + nm] = float(v)

@@ -124,7 +124,7 @@ struct orbfe_aruco {
         }
         npyr = (int)levels.size();
         pyr_fbytes = off + 64;
-        candq_fu32 = 16; // (the candidate queue is gone: starts are found on the fly from the LDS bit image)
+        candq_fu32 = (size_t)rows_ * cols_ / 16 + 64; // HBM overflow of the LDS long-walk queue
         pool_fu32 = (size_t)CT_THREADS * std::max(4096, rows_ * cols_ / 48); // one private arena per lane of k_contours
         const int pw = (cols_ + 2 + 31) / 32;
         const size_t padded_words = (size_t)pw * (rows_ + 2) + 2; // + spare words for ring8()
@@ -192,7 +192,7 @@ struct orbfe_aruco {
         auto kfn = lds_bits_words ? k_contours_t<true> : k_contours_t<false>;
         ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));
-        hipLaunchKernelGGL(kfn, dim3(B), dim3(CT_THREADS), lds, s, d_bits.as<uint32_t>(), bits_fu32, wpr, cols, rows,
+        hipLaunchKernelGGL(kfn, dim3(B), dim3(CT_PROBE_THREADS), lds, s, d_bits.as<uint32_t>(), bits_fu32, wpr, cols, rows,
                            lds_bits_words, 70, d_candq.as<uint32_t>(), candq_fu32, (int)candq_fu32,
                            d_pool.as<uint32_t>(), pool_fu32, (int)pool_fu32, d_kept.as<ArKept>(), AR_MAX_KEPT,
                            d_rects.as<ArRect>(), AR_MAX_RECTS, d_counts.as<int32_t>(), d_gpad.as<uint32_t>(),

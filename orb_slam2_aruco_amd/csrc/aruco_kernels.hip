@@ -245,7 +245,7 @@ __device__ bool convex4(const ApPt* p)
 }
 
 template <bool LDS_BITS>
-__global__ __launch_bounds__(CT_THREADS) void k_contours_t(const uint32_t* __restrict__ gbits, size_t bits_fstride,
+__global__ __launch_bounds__(CT_PROBE_THREADS) void k_contours_t(const uint32_t* __restrict__ gbits, size_t bits_fstride,
                                                          int wpr_g, int W, int H, int lds_bits_words, int min_len,
                                                          uint32_t* __restrict__ candq, size_t candq_fstride,
                                                          int candq_cap, uint32_t* __restrict__ pool,
@@ -272,6 +272,7 @@ __global__ __launch_bounds__(CT_THREADS) void k_contours_t(const uint32_t* __res
     ApPt* ap_out = (ApPt*)(rectflag + kept_cap);
     int2* ap_stack = (int2*)(ap_out + CT_WAVES * AP_OUT);
     const uint32_t* gb = gbits + (size_t)f * bits_fstride;
+    uint32_t* cq = candq + (size_t)f * candq_fstride; // overflow of the long-walk queue
     uint32_t* pl = pool + (size_t)f * pool_fstride;
 
     if (tid == 0) { s_ncand = 0; s_next = 0; s_nkept = 0; s_nlong = 0; s_flags = 0; }
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(CT_THREADS) void k_contours_t(const uint32_t* __res
 #define CT_STAMP(v)
 #endif
     // ---- (a) padded bit image into LDS: pixel (x, y) -> bit x+1 of row y+1
-    for (int i = tid; i < wpr * prow; i += CT_THREADS) {
+    for (int i = tid; i < wpr * prow; i += CT_PROBE_THREADS) {
         const int py = i / wpr, j = i - py * wpr;
         uint32_t v = 0;
         if (py >= 1 && py <= H) {
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(CT_THREADS) void k_contours_t(const uint32_t* __res
     //   long phase:  walk the survivors to the end, writing the points into the lane's private arena of the frame's
     //                point pool; a closed canonical border longer than min_len keeps its arena space.
     const int arena = pool_cap / CT_THREADS;
-    uint32_t* my_arena = pl + (size_t)tid * arena;
+    uint32_t* my_arena = pl + (size_t)(tid & (CT_THREADS - 1)) * arena;
     int wp = 0; // arena words owned by kept borders of this lane
     for (int phase = 0; phase < 2; phase++) {
         TraceState t;
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(CT_THREADS) void k_contours_t(const uint32_t* __res
         const int nwords = wpr * H;
         const float inv_wpr = 1.0f / (float)wpr;
         __syncthreads();
-        const int nlong = min(s_nlong, lq_cap);
+        const int nlong = min(s_nlong, lq_cap + candq_cap);
         if (tid == 0) s_next = 0;
         __syncthreads();
         for (;;) {
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(CT_THREADS) void k_contours_t(const uint32_t* __res
                     const int k = atomicAdd(&s_next, 1);
                     if (k >= nlong) drained = true;
                     else {
-                        const uint32_t q = longq[k];
+                        const uint32_t q = k < lq_cap ? longq[k] : cq[k - lq_cap];
                         qx = q & 0x1fff; qy = (q >> 13) & 0x1fff;
                         const int is_hole = q >> 26;
                         storing = true;
@@ -384,18 +385,23 @@ __global__ __launch_bounds__(CT_THREADS) void k_contours_t(const uint32_t* __res
                         }
                     }
                 } else if (!storing && t.n >= CT_PROBE) {
+                    // survivor of the probe: queue it for the long phase (LDS queue first, HBM overflow behind it)
+                    busy = false;
                     const int k = atomicAdd(&s_nlong, 1);
-                    if (k < lq_cap) {
-                        busy = false;
-                        longq[k] = (uint32_t)qx | ((uint32_t)qy << 13) | ((uint32_t)t.is_hole << 26);
-                    } else { // queue full: this lane restarts the walk itself, now storing its points
-                        storing = true;
-                        trace_init(im, t, qx - t.is_hole, qy, t.is_hole);
-                    }
+                    const uint32_t rec = (uint32_t)qx | ((uint32_t)qy << 13) | ((uint32_t)t.is_hole << 26);
+                    if (k < lq_cap) longq[k] = rec;
+                    else if (k - lq_cap < candq_cap) cq[k - lq_cap] = rec;
+                    else atomicOr(&s_flags, 16);
                 }
             }
         }
-        if (phase == 0) { atomicAdd(&s_ncand, ncand_l); CT_STAMP(t2); }
+        if (phase == 0) {
+            atomicAdd(&s_ncand, ncand_l);
+            CT_STAMP(t2);
+            // the probe phase is throughput-bound (one short walk per start candidate), the long phase is bound by the
+            // longest border: only CT_THREADS lanes stay, the rest free their wave slots for other kernels
+            if (tid >= CT_THREADS) return;
+        }
     }
     __threadfence_block();
     __syncthreads();

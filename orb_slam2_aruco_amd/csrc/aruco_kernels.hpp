@@ -44,8 +44,9 @@ __global__ void k_finalize(const ArRect* rects, int rect_cap, const int32_t* can
                            const int32_t* result, const uint32_t* pool, size_t pool_fstride, orbfe_marker* out,
                            int out_cap, int32_t* n_out);
 
-#define CT_THREADS 256
+#define CT_THREADS 256          // threads that run the whole kernel
 #define CT_WAVES (CT_THREADS / 64)
+#define CT_PROBE_THREADS 1024   // threads at launch: the extra ones help with the (throughput-bound) probe phase, then exit
 #define AP_STACK 64
 #define AP_OUT 64
 #define CT_PROBE 24 // steps a border start is followed before it is queued as a long walk (< the 70-point gate)
