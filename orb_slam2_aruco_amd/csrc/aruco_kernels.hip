@@ -62,14 +62,18 @@ __global__ __launch_bounds__(256) void k_adaptive_threshold(ImgView src, int W, 
         for (int i = tid; i < rows * 64; i += 256) {
             const int rr = i >> 6, cc = i & 63;
             int s = 0;
-            for (int k = 0; k < win; k++) s += sin[rr][cc + k];
+#pragma unroll
+            for (int k = 0; k < 2 * TH_MAXR + 1; k++) // fixed trip count: the LDS reads issue back to back
+                if (k < win) s += sin[rr][cc + k];
             sh[rr][cc] = (uint16_t)s;
         }
         __syncthreads();
         for (int ry = wid; ry < 16; ry += 4) {
             const int y = ty0 + ry, x = tx0 + lane;
             int s = 0;
-            for (int k = 0; k < win; k++) s += sh[ry + k][lane];
+#pragma unroll
+            for (int k = 0; k < 2 * TH_MAXR + 1; k++)
+                if (k < win) s += sh[ry + k][lane];
             int mean = orbfe_round_d((double)s * scale);
             mean = mean > 255 ? 255 : mean;
             const int v = sin[ry + r][lane + r];
@@ -635,6 +639,8 @@ __global__ __launch_bounds__(64) void k_decode(ImgView src0, ImgView pyr, const 
     __shared__ uint8_t s_bits[64];
     __shared__ unsigned long long s_ids[4];
     __shared__ int s_th;
+    __shared__ double s_q1[256], s_mu1[256];
+    __shared__ double s_mu;
     const int f = blockIdx.y, lane = threadIdx.x;
     const int nc = ncand[f];
     for (int slot = blockIdx.x; slot < nc; slot += gridDim.x) {
@@ -733,24 +739,52 @@ __global__ __launch_bounds__(64) void k_decode(ImgView src0, ImgView pyr, const 
             atomicAdd(&s_hist[v], 1);
         }
         __syncthreads();
-        if (lane == 0) { // getThreshVal_Otsu_8u: serial by definition (running double sums), 256 bins
+        // getThreshVal_Otsu_8u.  The running sums q1 / mu1 are serial by definition (each step rounds), so lane 0 walks
+        // the 256 bins with exactly the reference's operation sequence; mu2 and sigma of every bin are independent of
+        // the other bins and are evaluated by all lanes afterwards (first maximum wins, like the serial 'sigma > max').
+        if (lane == 0) {
             const int n = S * S;
             double mu = 0, scale = 1. / n;
             for (int i = 0; i < 256; i++) mu += i * (double)s_hist[i];
             mu *= scale;
-            double mu1 = 0, q1 = 0, max_sigma = 0, max_val = 0;
+            double mu1 = 0, q1 = 0;
             for (int i = 0; i < 256; i++) {
                 const double p_i = s_hist[i] * scale;
                 mu1 *= q1;
                 q1 += p_i;
                 const double q2 = 1. - q1;
-                if (fmin(q1, q2) < 1.1920928955078125e-07 || fmax(q1, q2) > 1. - 1.1920928955078125e-07) continue;
+                s_q1[i] = q1;
+                if (fmin(q1, q2) < 1.1920928955078125e-07 || fmax(q1, q2) > 1. - 1.1920928955078125e-07) {
+                    s_mu1[i] = -1.0; // skipped bin (mu1 keeps the un-normalised product, as in the reference)
+                    continue;
+                }
                 mu1 = (mu1 + i * p_i) / q1;
-                const double mu2 = (mu - q1 * mu1) / q2;
-                const double sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2);
-                if (sigma > max_sigma) { max_sigma = sigma; max_val = i; }
+                s_mu1[i] = mu1;
             }
-            s_th = (int)max_val;
+            s_mu = mu;
+        }
+        __syncthreads();
+        {
+            double best = 0.0;
+            int besti = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int i = k * 64 + lane;
+                const double mu1 = s_mu1[i], q1 = s_q1[i];
+                if (mu1 >= 0.0) {
+                    const double q2 = 1. - q1;
+                    const double mu2 = (s_mu - q1 * mu1) / q2;
+                    const double sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2);
+                    if (sigma > best) { best = sigma; besti = i; } // ascending i within the lane: first maximum
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const double ob = shfl_d(best, lane ^ o);
+                const int oi = __shfl(besti, lane ^ o);
+                if (ob > best || (ob == best && ob > 0.0 && oi < besti)) { best = ob; besti = oi; }
+            }
+            if (lane == 0) s_th = best > 0.0 ? besti : 0;
         }
         __syncthreads();
         const int th = s_th, n = nb + 2;
