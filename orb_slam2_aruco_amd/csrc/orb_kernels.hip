@@ -194,22 +194,27 @@ __global__ __launch_bounds__(256) void k_fast_cells(ImgView src0, ImgView pyr, c
     const int pitch = (level == 0) ? src0.pitch : g.pitch;
     const int SP = roi_pitch, MP = map_pitch;
 
-    // stage the ROI, 16 rows of loads in flight at a time; clear the score map
-    for (int y0 = 0; y0 < h; y0 += 16) {
-        uint8_t v0[16], v1[16];
+    // stage the ROI with (unaligned) dword loads, 8 in flight per lane; clear the score map
+    {
+        typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+        const int ndw = (w + 3) >> 2, items = ndw * h;
+        const float inv_ndw = 1.0f / (float)ndw;
+        const uint8_t* roi = img + (size_t)iniY * pitch + iniX;
+        for (int i0 = 0; i0 < items; i0 += 8 * 64) {
+            uint32_t v[8];
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int y = y0 + k;
-            const uint8_t* row = img + (size_t)(iniY + min(y, h - 1)) * pitch + iniX;
-            v0[k] = (lane < w) ? row[lane] : (uint8_t)0;
-            v1[k] = (lane + 64 < w) ? row[lane + 64] : (uint8_t)0;
-        }
+            for (int k = 0; k < 8; k++) {
+                const int i = min(i0 + k * 64 + lane, items - 1);
+                const int y = (int)(((float)i + 0.5f) * inv_ndw), c = i - y * ndw;
+                v[k] = *reinterpret_cast<const u32_unaligned*>(roi + (size_t)y * pitch + 4 * c);
+            }
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int y = y0 + k;
-            if (y < h) {
-                if (lane < w) simg[y * SP + lane] = v0[k];
-                if (lane + 64 < w) simg[y * SP + lane + 64] = v1[k];
+            for (int k = 0; k < 8; k++) {
+                const int i = i0 + k * 64 + lane;
+                if (i < items) {
+                    const int y = (int)(((float)i + 0.5f) * inv_ndw), c = i - y * ndw;
+                    *reinterpret_cast<uint32_t*>(simg + y * SP + 4 * c) = v[k];
+                }
             }
         }
     }
@@ -235,11 +240,11 @@ __global__ __launch_bounds__(256) void k_fast_cells(ImgView src0, ImgView pyr, c
                 x = p - y * aw;
                 const uint8_t* c = simg + (y + 3) * SP + (x + 3);
                 const int v = c[0];
-                const int d0 = v - c[3 * SP], d4 = v - c[3], d8 = v - c[-3 * SP], d12 = v - c[-3];
-                const unsigned P = (d0 > t) | ((d4 > t) << 1) | ((d8 > t) << 2) | ((d12 > t) << 3);
-                const unsigned N = (d0 < -t) | ((d4 < -t) << 1) | ((d8 < -t) << 2) | ((d12 < -t) << 3);
-                const unsigned Pr = ((P << 1) | (P >> 3)) & 15u, Nr = ((N << 1) | (N >> 3)) & 15u;
-                pass = ((P & Pr) | (N & Nr)) != 0;
+                const int r0 = c[3 * SP], r4 = c[3], r8 = c[-3 * SP], r12 = c[-3];
+                // two adjacent compass pixels both > v + t  <=>  max over the 4 adjacent pairs of min(pair) > v + t
+                const int hi = max(max(min(r0, r4), min(r4, r8)), max(min(r8, r12), min(r12, r0)));
+                const int lo = min(min(max(r0, r4), max(r4, r8)), min(max(r8, r12), max(r12, r0)));
+                pass = (hi > v + t) || (lo < v - t);
             }
             const unsigned long long m = __ballot(pass);
             if (pass) slist[n1 + lane_prefix(m)] = (uint16_t)((y << 8) | x);
