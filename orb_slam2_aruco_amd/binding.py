@@ -339,7 +339,12 @@ class MarkerDetector:
     def counts(self, frame=0):
         out = np.zeros(4, np.int32)
         _check(self.L, self.L.orbfe_aruco_debug_image(self.h, frame, 100, _p(out)), "debug_image")
-        return dict(nkept=int(out[0]), nrect=int(out[1]), flags=int(out[2]), ncand=int(out[3]))
+        return dict(nkept=int(out[0]), nrect=int(out[1]), flags=int(out[2]), ncand=int(out[3]) & 0x3fffffff,
+                    fell_back=bool(int(out[3]) >> 30))   # the relay contour kernel handed the frame to the legacy one
+
+    def force_legacy_contours(self, on=True):
+        """Debug: run every frame through the single-walker contour kernel (the relay kernel's fallback)."""
+        self.L.orbfe_aruco_debug_kernel_times(self.h, None, 2 if on else 3)
 
     def rects(self, frame=0):
         out = np.zeros(self.capacity, RECT_DTYPE)

@@ -26,6 +26,9 @@ struct orbfe_aruco {
     std::vector<size_t> tab_off;          // resize tables for non-exact levels
     size_t pyr_fbytes = 0, bits_fu32 = 0, candq_fu32 = 0, pool_fu32 = 0, gpad_fu32 = 0;
     int lds_bits_words = 0;
+    DevBuf d_segs;
+    int relay_tbits = 0;       // hash-table size of k_contours_relay (0: the kernel cannot run at this image size)
+    bool force_legacy = false; // debug: always use k_contours_t
     DevBuf d_codes, d_levels, d_tabs, d_bits, d_pyr, d_candq, d_pool, d_kept, d_rects, d_counts, d_candidx, d_ncand,
         d_result, d_gpad;
     DevBuf d_in, d_out, d_nout;
@@ -35,7 +38,7 @@ struct orbfe_aruco {
     ~orbfe_aruco()
     {
         for (DevBuf* b : {&d_codes, &d_levels, &d_tabs, &d_bits, &d_pyr, &d_candq, &d_pool, &d_kept, &d_rects,
-                          &d_counts, &d_candidx, &d_ncand, &d_result, &d_gpad, &d_in, &d_out, &d_nout})
+                          &d_counts, &d_candidx, &d_ncand, &d_result, &d_gpad, &d_in, &d_out, &d_nout, &d_segs})
             b->release();
         if (own_stream) (void)hipStreamDestroy(own_stream);
     }
@@ -131,6 +134,9 @@ struct orbfe_aruco {
         // the padded bit image goes to LDS when it fits next to the other arrays (160 KiB per workgroup)
         lds_bits_words = (contours_lds_bytes((int)padded_words, AR_MAX_KEPT) <= 160 * 1024) ? (int)padded_words : 0;
         gpad_fu32 = lds_bits_words ? 0 : padded_words;
+        // k_contours_relay needs the bit image AND its marker table in LDS; otherwise k_contours_t does all frames
+        relay_tbits = 0;
+        if (lds_bits_words && relay_lds_bytes(lds_bits_words, AR_MAX_KEPT, 12) + 2048 <= 160 * 1024) relay_tbits = 12;
         rows = rows_; cols = cols_;
         batch_cap = 0;
         if (tabs.empty()) tabs.push_back(0);
@@ -152,7 +158,8 @@ struct orbfe_aruco {
             (rc = d_rects.ensure((size_t)AR_MAX_RECTS * sizeof(ArRect) * B)) || (rc = d_counts.ensure((size_t)16 * B)) ||
             (rc = d_candidx.ensure((size_t)AR_MAX_RECTS * 4 * B)) || (rc = d_ncand.ensure((size_t)4 * B)) ||
             (rc = d_result.ensure((size_t)AR_MAX_RECTS * 8 * B)) ||
-            (rc = d_gpad.ensure(std::max<size_t>(gpad_fu32 * 4 * B, 16))))
+            (rc = d_gpad.ensure(std::max<size_t>(gpad_fu32 * 4 * B, 16))) ||
+            (rc = d_segs.ensure(std::max<size_t>(((size_t)sizeof(RelaySeg) << relay_tbits) * B, 16))))
             return rc;
         batch_cap = B;
         return ORBFE_OK;
@@ -192,11 +199,22 @@ struct orbfe_aruco {
         auto kfn = lds_bits_words ? k_contours_t<true> : k_contours_t<false>;
         ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));
+        const bool relay = relay_tbits && !force_legacy;
+        if (relay) {
+            const size_t rlds = relay_lds_bytes(lds_bits_words, AR_MAX_KEPT, relay_tbits);
+            ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_contours_relay),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
+            hipLaunchKernelGGL(k_contours_relay, dim3(B), dim3(RL_THREADS), rlds, s, d_bits.as<uint32_t>(), bits_fu32, wpr,
+                               cols, rows, lds_bits_words, 70, RL_KSHIFT, relay_tbits, d_segs.as<RelaySeg>(),
+                               d_pool.as<uint32_t>(), pool_fu32, (int)pool_fu32, d_kept.as<ArKept>(), AR_MAX_KEPT,
+                               d_rects.as<ArRect>(), AR_MAX_RECTS, d_counts.as<int32_t>());
+        }
+        // all frames, or (after the relay kernel) only the frames it flagged; unflagged workgroups exit at once
         hipLaunchKernelGGL(kfn, dim3(B), dim3(CT_PROBE_THREADS), lds, s, d_bits.as<uint32_t>(), bits_fu32, wpr, cols, rows,
                            lds_bits_words, 70, d_candq.as<uint32_t>(), candq_fu32, (int)candq_fu32,
                            d_pool.as<uint32_t>(), pool_fu32, (int)pool_fu32, d_kept.as<ArKept>(), AR_MAX_KEPT,
                            d_rects.as<ArRect>(), AR_MAX_RECTS, d_counts.as<int32_t>(), d_gpad.as<uint32_t>(),
-                           gpad_fu32);
+                           gpad_fu32, relay ? 1 : 0);
         timer.mark(s, "contours");
         ORBFE_HIP(hipGetLastError());
         hipLaunchKernelGGL(k_prefilter, dim3(B), dim3(256), 0, s, d_rects.as<ArRect>(), AR_MAX_RECTS,
@@ -340,8 +358,9 @@ int orbfe_aruco_debug_image(orbfe_aruco* h, int frame, int stage, uint8_t* out)
 int orbfe_aruco_debug_kernel_times(orbfe_aruco* h, float* out_us, int capacity)
 {
     if (!h) return fail(ORBFE_ERR_INVALID, "null handle");
-    if (!out_us) {
-        h->timer.enabled = capacity != 0;
+    if (!out_us) { // control codes: 0/1 kernel timing off/on, 2/3 force the legacy contour kernel on/off
+        if (capacity == 2 || capacity == 3) h->force_legacy = capacity == 2;
+        else h->timer.enabled = capacity != 0;
         return 0;
     }
     return h->timer.collect(out_us, capacity);

@@ -13,6 +13,7 @@
 // HBM-bound part: threshold (reads W*H bytes, writes W*H/8).  Everything after it works on the bit image in LDS or
 // on a few hundred contour points, so it is latency- rather than bandwidth-bound; see DESIGN.md.
 #include "aruco_kernels.hpp"
+#include "wave_dpp.hpp"
 
 namespace orbfe {
 
@@ -103,7 +104,7 @@ struct ApPt { int x, y; };
 // approxPolyDP (closed curve) by one wave; P = contour points (x | y<<16), n > 0.  Returns the number of
 // vertices (<= AP_OUT, or AP_OUT+1 on overflow) in `out` (LDS).  Reductions keep the FIRST maximum like the
 // serial loops of cv::approxPolyDP_ ("dist > max_dist").
-__device__ int approx_poly_wave(const uint32_t* __restrict__ P, int n, ApPt* out, int2* stack, int lane)
+__device__ __forceinline__ int approx_poly_wave(const uint32_t* __restrict__ P, int n, ApPt* out, int2* stack, int lane)
 {
     auto rd = [&](int i) -> ApPt { const uint32_t v = P[i]; return ApPt{(int)(v & 0xffff), (int)(v >> 16)}; };
     double eps = (double)n * 0.05;
@@ -129,11 +130,7 @@ __device__ int approx_poly_wave(const uint32_t* __restrict__ P, int n, ApPt* out
                 if (d > 0 && key > best) best = key;
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const long long t = __shfl_xor(best, o);
-            best = t > best ? t : best;
-        }
+        best = (long long)wave_max_u64((unsigned long long)best); // keys are >= 0
         const long long max_dist = best >> 20;
         right_start = best ? (int)(0xfffff - (best & 0xfffff)) : right_start; // no dist > 0: index unchanged
         le_eps = (double)max_dist <= eps;
@@ -170,11 +167,7 @@ __device__ int approx_poly_wave(const uint32_t* __restrict__ P, int n, ApPt* out
                     if (d > 0 && key > best) best = key;
                 }
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const long long t = __shfl_xor(best, o);
-                best = t > best ? t : best;
-            }
+            best = (long long)wave_max_u64((unsigned long long)best);
             const double md = (double)(best >> 20);
             le = md * md <= eps * (double)(dx * dx + dy * dy);
             if (best) {
@@ -248,6 +241,88 @@ __device__ bool convex4(const ApPt* p)
     return true;
 }
 
+// Last phases of both contour kernels: sort the kept borders into findContours' order (reverse discovery), run
+// approxPolyDP(eps = 0.05 * len) + the convexity test on each (one wave per border), compact the 4-gons in order and
+// write the per-frame counts.  All NT (a multiple of 64) remaining threads of the workgroup call it.
+__device__ void contours_tail(int f, int tid, int NT, int nkept, unsigned long long* kkey, const int* off_u, int* klen,
+                              int* koff, int* rectflag, ApPt* ap_out, int2* ap_stack, const uint32_t* pl,
+                              ArKept* __restrict__ kept_out, int kept_cap, ArRect* __restrict__ rects_out, int rect_cap,
+                              int32_t* __restrict__ counts, int* s_flags, const int* s_ncand, uint32_t* pbuf,
+                              int pbuf_pts)
+{
+    const int lane = tid & 63, wid = tid >> 6, nwaves = NT >> 6;
+    int Pn = 1;
+    while (Pn < nkept) Pn <<= 1;
+    for (int i = nkept + tid; i < Pn; i += NT) kkey[i] = ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= Pn; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (Pn >> 1); t += NT) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int l = i | j;
+                const unsigned long long a = kkey[i], b = kkey[l];
+                const bool up = ((i & k) == 0);
+                if ((a > b) == up) { kkey[i] = b; kkey[l] = a; }
+            }
+            __syncthreads();
+        }
+    for (int k = tid; k < nkept; k += NT) {
+        const unsigned long long key = kkey[k];
+        klen[k] = (int)((key >> 12) & 0xfffff);
+        koff[k] = off_u[(int)((key >> 1) & 0x7ff)];
+    }
+    __syncthreads();
+    for (int k = wid; k < nkept; k += nwaves) {
+        int ok = 0;
+        ApPt* o = ap_out + wid * AP_OUT;
+        if (klen[k] > 0) {
+            // approxPolyDP makes many dependent passes over the points: from LDS when the border fits the wave's
+            // buffer (pbuf: LDS that is dead by now, pbuf_pts points per wave), else from the pool (L2)
+            const int n = klen[k];
+            const uint32_t* src = pl + koff[k];
+            int nv;
+            if (n <= pbuf_pts) {
+                uint32_t* b = pbuf + wid * pbuf_pts;
+                for (int i = lane; i < n; i += 64) b[i] = src[i];
+                __builtin_amdgcn_wave_barrier();
+                nv = approx_poly_wave(b, n, o, ap_stack + wid * AP_STACK, lane);
+            } else {
+                nv = approx_poly_wave(src, n, o, ap_stack + wid * AP_STACK, lane);
+            }
+            __builtin_amdgcn_wave_barrier();
+            ok = (nv == 4) && convex4(o);
+        }
+        if (lane == 0) {
+            rectflag[k] = ok;
+            if (ok && k < kept_cap) {
+                ArKept kk;
+                kk.off = koff[k]; kk.len = klen[k];
+                for (int j = 0; j < 4; j++) { kk.vx[j] = (short)o[j].x; kk.vy[j] = (short)o[j].y; }
+                kept_out[(size_t)f * kept_cap + k] = kk;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) { // ordered compaction of the rectangles (a few dozen)
+        int nr = 0;
+        for (int k = 0; k < nkept; k++)
+            if (rectflag[k]) {
+                if (nr < rect_cap) {
+                    const ArKept kk = kept_out[(size_t)f * kept_cap + k];
+                    ArRect r;
+                    for (int j = 0; j < 4; j++) { r.c[j][0] = (float)kk.vx[j]; r.c[j][1] = (float)kk.vy[j]; }
+                    r.off = kk.off; r.len = kk.len;
+                    rects_out[(size_t)f * rect_cap + nr] = r;
+                } else *s_flags |= 8;
+                nr++;
+            }
+        counts[f * 4 + 0] = nkept;
+        counts[f * 4 + 1] = min(nr, rect_cap);
+        counts[f * 4 + 2] = *s_flags;
+        counts[f * 4 + 3] = *s_ncand;
+    }
+}
+
 template <bool LDS_BITS>
 __global__ __launch_bounds__(CT_PROBE_THREADS) void k_contours_t(const uint32_t* __restrict__ gbits, size_t bits_fstride,
                                                          int wpr_g, int W, int H, int lds_bits_words, int min_len,
@@ -257,11 +332,14 @@ __global__ __launch_bounds__(CT_PROBE_THREADS) void k_contours_t(const uint32_t*
                                                          ArKept* __restrict__ kept_out, int kept_cap,
                                                          ArRect* __restrict__ rects_out, int rect_cap,
                                                          int32_t* __restrict__ counts /*per frame: [nkept, nrect, flags, ncand]*/,
-                                                         uint32_t* __restrict__ gpadded, size_t gpadded_fstride)
+                                                         uint32_t* __restrict__ gpadded, size_t gpadded_fstride,
+                                                         int only_flagged)
 {
     extern __shared__ __align__(16) unsigned char ct_smem[];
     __shared__ int s_ncand, s_next, s_nkept, s_nlong, s_flags;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, f = blockIdx.x;
+    const int tid = threadIdx.x, f = blockIdx.x;
+    // as the fallback of k_contours_relay: only the frames that kernel gave up on
+    if (only_flagged && !(counts[f * 4 + 2] & RL_FALLBACK_FLAGS)) return;
     const int wpr = (W + 2 + 31) >> 5, prow = H + 2;
     // LDS carve-up: [bits][kept keys (u64) kept_cap][per-wave approx scratch]
     // the padded bit image lives in LDS when it fits (lds_bits_words > 0), else in an HBM scratch (L2-resident)
@@ -415,78 +493,550 @@ __global__ __launch_bounds__(CT_PROBE_THREADS) void k_contours_t(const uint32_t*
     __syncthreads();
     const int nkept = s_nkept;
     CT_STAMP(t3);
-    // ---- (d) sort kept ascending by (~raster key) = reverse discovery order; bitonic over a power of two
-    int Pn = 1;
-    while (Pn < nkept) Pn <<= 1;
-    for (int i = nkept + tid; i < Pn; i += CT_THREADS) kkey[i] = ~0ull;
-    __syncthreads();
-    for (int k = 2; k <= Pn; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < (Pn >> 1); t += CT_THREADS) {
-                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const int l = i | j;
-                const unsigned long long a = kkey[i], b = kkey[l];
-                const bool up = ((i & k) == 0);
-                if ((a > b) == up) { kkey[i] = b; kkey[l] = a; }
-            }
-            __syncthreads();
-        }
-    for (int k = tid; k < nkept; k += CT_THREADS) { // (the long queue is dead: its space now holds klen/koff/rectflag)
-        const unsigned long long key = kkey[k];
-        klen[k] = (int)((key >> 12) & 0xfffff);
-        koff[k] = off_u[(int)((key >> 1) & 0x7ff)];
-    }
-    __syncthreads();
-    CT_STAMP(t4);
-    // ---- (f) approxPolyDP(eps = 0.05 * len) -> 4 vertices and convex -> rectangle candidate
-    for (int k = wid; k < nkept; k += CT_WAVES) {
-        int ok = 0;
-        ApPt* o = ap_out + wid * AP_OUT;
-        if (klen[k] > 0) {
-            const int nv = approx_poly_wave(pl + koff[k], klen[k], o, ap_stack + wid * AP_STACK, lane);
-            __builtin_amdgcn_wave_barrier();
-            ok = (nv == 4) && convex4(o);
-        }
-        if (lane == 0) {
-            rectflag[k] = ok;
-            if (ok && k < kept_cap) {
-                ArKept kk;
-                kk.off = koff[k]; kk.len = klen[k];
-                for (int j = 0; j < 4; j++) { kk.vx[j] = (short)o[j].x; kk.vy[j] = (short)o[j].y; }
-                kept_out[(size_t)f * kept_cap + k] = kk;
-            }
-        }
-    }
-    __syncthreads();
-    if (tid == 0) { // ordered compaction of the rectangles (a few dozen)
-        int nr = 0;
-        for (int k = 0; k < nkept; k++)
-            if (rectflag[k]) {
-                if (nr < rect_cap) {
-                    const ArKept kk = kept_out[(size_t)f * kept_cap + k];
-                    ArRect r;
-                    for (int j = 0; j < 4; j++) { r.c[j][0] = (float)kk.vx[j]; r.c[j][1] = (float)kk.vy[j]; }
-                    r.off = kk.off; r.len = kk.len;
-                    rects_out[(size_t)f * rect_cap + nr] = r;
-                } else s_flags |= 8;
-                nr++;
-            }
-        counts[f * 4 + 0] = nkept;
-        counts[f * 4 + 1] = min(nr, rect_cap);
-        counts[f * 4 + 2] = s_flags;
-        counts[f * 4 + 3] = s_ncand;
+    if (only_flagged && tid == 0) s_ncand |= 1 << 30; // debug: this frame took the fallback (contours_tail syncs first)
+    const int pbuf_pts = LDS_BITS ? (lds_bits_words / CT_WAVES) & ~3 : 0; // the LDS bit image is dead: point buffers
+    contours_tail(f, tid, CT_THREADS, nkept, kkey, off_u, klen, koff, rectflag, ap_out, ap_stack, pl, kept_out, kept_cap,
+                  rects_out, rect_cap, counts, &s_flags, &s_ncand, (uint32_t*)ct_smem, pbuf_pts);
 #ifdef ORBFE_CT_TIMING
+    if (tid == 0) {
         t5 = clock64();
+        t4 = t3;
         long long* dbg = (long long*)(kept_out + (size_t)f * kept_cap + kept_cap - 4);
         dbg[0] = t1 - t0; dbg[1] = t2 - t1; dbg[2] = t3 - t2; dbg[3] = t4 - t3; dbg[4] = t5 - t4;
-#endif
     }
+#endif
 }
 
 template __global__ void k_contours_t<true>(const uint32_t*, size_t, int, int, int, int, int, uint32_t*, size_t, int,
-                                            uint32_t*, size_t, int, ArKept*, int, ArRect*, int, int32_t*, uint32_t*, size_t);
+                                            uint32_t*, size_t, int, ArKept*, int, ArRect*, int, int32_t*, uint32_t*, size_t,
+                                            int);
 template __global__ void k_contours_t<false>(const uint32_t*, size_t, int, int, int, int, int, uint32_t*, size_t, int,
-                                             uint32_t*, size_t, int, ArKept*, int, ArRect*, int, int32_t*, uint32_t*, size_t);
+                                             uint32_t*, size_t, int, ArKept*, int, ArRect*, int, int32_t*, uint32_t*, size_t,
+                                             int);
+
+// ---------------------------------------------------------------------------------------- contours, relay -----
+// findContours + approxPolyDP by relay segments (aruco_trace.hpp, second half).  One workgroup per frame; every phase
+// is parallel over all lanes and no lane ever follows a long border alone:
+//   (a) padded bit image -> LDS;  (b) grid markers -> hash table in LDS (the slot is the segment's id);
+//   (c) small borders (no grid marker on them) followed whole from their start candidates;
+//   (d) one segment per marker: walk to the next marker, remember the smallest start state passed;
+//   (e) cyclic lists: pointer doubling for the minimum (= the canonical start), list ranking for the offsets;
+//   (f) kept borders (> min_len points) get pool space, their segments are walked again and write their points
+//       straight to the final position;  (g) the common tail (sort, approxPolyDP, rectangles).
+// A frame whose markers do not fit the table is flagged (RL_FALLBACK_FLAGS) and redone by k_contours_t.
+__device__ __forceinline__ uint32_t rl_hash(uint32_t key, int tbits) { return (key * 0x9E3779B1u) >> (32 - tbits); }
+
+__device__ __forceinline__ int rl_find_or_insert(uint32_t* hkey, int tbits, uint32_t key, int* fresh)
+{
+    const uint32_t mask = (1u << tbits) - 1u;
+    uint32_t h = rl_hash(key, tbits);
+    for (uint32_t p = 0; p <= mask; p++) {
+        const uint32_t old = atomicCAS(&hkey[h], 0u, key);
+        if (old == 0u) { *fresh = 1; return (int)h; }
+        if (old == key) { *fresh = 0; return (int)h; }
+        h = (h + 1) & mask;
+    }
+    return -1;
+}
+
+__device__ __forceinline__ int rl_find(const uint32_t* hkey, int tbits, uint32_t key)
+{
+    const uint32_t mask = (1u << tbits) - 1u;
+    uint32_t h = rl_hash(key, tbits);
+    for (uint32_t p = 0; p <= mask; p++) {
+        const uint32_t v = hkey[h];
+        if (v == key) return (int)h;
+        if (v == 0u) return -1;
+        h = (h + 1) & mask;
+    }
+    return -1;
+}
+
+// One walk step as a table lookup: entry [(ring << 3) | s] of a 2048-entry LDS table built from the functions of
+// aruco_trace.hpp.  Bits: 0-2 direction of the next border pixel; 3 run has W or E; 4 run has N or S;
+// 5-6 start class; 7-10 run has N, W, E, S; 11-12 dx + 1; 13-14 dy + 1.
+__device__ __forceinline__ uint16_t rl_lut_entry(unsigned ring, int st)
+{
+    if (!ring) return 0;
+    unsigned run;
+    const int d = relay_examine(ring, st, &run);
+    unsigned e = (unsigned)d;
+    if (run & 0x11u) e |= 8u;
+    if (run & 0x44u) e |= 16u;
+    e |= (unsigned)relay_start_class(ring, run) << 5;
+    e |= ((run >> 2) & 1u) << 7;
+    e |= ((run >> 4) & 1u) << 8;
+    e |= (run & 1u) << 9;
+    e |= ((run >> 6) & 1u) << 10;
+    e |= (unsigned)(dir_dx(d) + 1) << 11;
+    e |= (unsigned)(dir_dy(d) + 1) << 13;
+    return (uint16_t)e;
+}
+// is the state a grid marker: its run has W/E on a relay row, or N/S on a relay column
+__device__ __forceinline__ bool rl_is_marker(unsigned e, int x, int y, int kmask)
+{
+    const unsigned g = ((y & kmask) == 0 ? 8u : 0u) | ((x & kmask) == 0 ? 16u : 0u);
+    return (e & g) != 0;
+}
+__device__ __forceinline__ void rl_advance(const BitImage& im, RelayWalk& w, unsigned e)
+{
+    w.x += (int)((e >> 11) & 3u) - 1;
+    w.y += (int)((e >> 13) & 3u) - 1;
+    w.s = (int)((e + 4u) & 7u);
+    w.n++;
+    w.ring = ring8(im, w.x, w.y);
+}
+
+__global__ __launch_bounds__(RL_THREADS) void k_contours_relay(
+    const uint32_t* __restrict__ gbits, size_t bits_fstride, int wpr_g, int W, int H, int lds_bits_words, int min_len,
+    int kshift, int tbits, RelaySeg* __restrict__ segs, uint32_t* __restrict__ pool, size_t pool_fstride, int pool_cap,
+    ArKept* __restrict__ kept_out, int kept_cap, ArRect* __restrict__ rects_out, int rect_cap,
+    int32_t* __restrict__ counts)
+{
+    extern __shared__ __align__(16) unsigned char ct_smem[];
+    __shared__ int s_next, s_nkept, s_flags, s_ncand, s_nmark, s_nsmall, s_pool, s_changed[2];
+    __shared__ uint4 s_small[RL_SMALL_CAP]; // state key, length, pool offset, discovery key * 2 + is_hole
+    __shared__ uint16_t s_lut[2048];
+    const int tid = threadIdx.x, f = blockIdx.x, NT = RL_THREADS;
+    const int wpr = (W + 2 + 31) >> 5, prow = H + 2;
+    const int T = 1 << tbits, kmask = (1 << kshift) - 1, K = 1 << kshift;
+    // LDS: [bits][kept keys u64][kept pool offsets][ table: hkey, cmin/val, jmp, arg | tail: klen, koff, rectflag, approx ]
+    uint32_t* lbits = (uint32_t*)ct_smem;
+    unsigned long long* kkey = (unsigned long long*)(ct_smem + (((size_t)lds_bits_words * 4 + 15) & ~(size_t)15));
+    int* off_u = (int*)(kkey + kept_cap);
+    unsigned char* uni = (unsigned char*)(off_u + kept_cap);
+    uint32_t* hkey = (uint32_t*)uni;
+    uint32_t* cmin = hkey + T; // smallest start state of the segment / of the border; later the ranking value
+    uint16_t* jmp = (uint16_t*)(cmin + T);
+    uint16_t* arg = jmp + T;   // slot of the segment that holds the border's smallest start state
+    int* klen = (int*)uni;
+    int* koff = klen + kept_cap;
+    int* rectflag = koff + kept_cap;
+    ApPt* ap_out = (ApPt*)(rectflag + kept_cap);
+    int2* ap_stack = (int2*)(ap_out + (RL_THREADS / 64) * AP_OUT);
+    const uint32_t* gb = gbits + (size_t)f * bits_fstride;
+    uint32_t* pl = pool + (size_t)f * pool_fstride;
+    RelaySeg* sg = segs + ((size_t)f << tbits);
+
+    if (tid == 0) {
+        s_next = 0; s_nkept = 0; s_flags = 0; s_ncand = 0; s_nmark = 0; s_nsmall = 0; s_pool = 0;
+        s_changed[0] = 0; s_changed[1] = 0;
+    }
+#ifdef ORBFE_CT_TIMING
+    long long tq[8];
+    int tqi = 0;
+#define RL_STAMP() tq[tqi++] = clock64()
+#else
+#define RL_STAMP()
+#endif
+    RL_STAMP();
+    // ---- (a) padded bit image into LDS: pixel (x, y) -> bit x+1 of row y+1
+    for (int i = tid; i < wpr * prow; i += NT) {
+        const int py = i / wpr, j = i - py * wpr;
+        uint32_t v = 0;
+        if (py >= 1 && py <= H) {
+            const uint32_t* row = gb + (size_t)(py - 1) * wpr_g;
+            const uint32_t cur = j < wpr_g ? row[j] : 0u;
+            const uint32_t prv = (j >= 1 && j - 1 < wpr_g) ? row[j - 1] : 0u;
+            v = (cur << 1) | (prv >> 31);
+        }
+        lbits[i] = v;
+    }
+    if (tid < 2) lbits[wpr * prow + tid] = 0; // spare words read by ring8()'s funnel loads
+    for (int i = tid; i < T; i += NT) hkey[i] = 0u;
+    for (int i = tid; i < 2048; i += NT) s_lut[i] = rl_lut_entry((unsigned)i >> 3, i & 7);
+    __syncthreads();
+    const BitImage im{lbits, wpr, W, H};
+    RL_STAMP();
+
+    // ---- (b) grid markers: relay rows word by word, relay columns in chunks of 32 rows
+    {
+        const int nrelrow = H >> kshift, nrelcol = W >> kshift, nchunk = (H + 31) >> 5;
+        const int nrow_items = nrelrow * wpr, nitems = nrow_items + nrelcol * nchunk;
+        int nm = 0;
+        auto add = [&](int x, int y) {
+            const unsigned ring = ring8(im, x, y);
+            if (!ring) return;
+            relay_states_of_pixel(ring, grid_active(ring, x, y, kmask), [&](int st) {
+                int fresh = 0;
+                if (rl_find_or_insert(hkey, tbits, relay_key(x, y, st), &fresh) < 0) atomicOr(&s_flags, RL_FLAG_TABLE);
+                nm += fresh;
+            });
+        };
+        for (int it = tid; it < nitems; it += NT) {
+            if (it < nrow_items) {
+                const int r = it / wpr, j = it - r * wpr, y = (r + 1) << kshift;
+                const uint32_t* row = lbits + y * wpr;
+                const uint32_t cur = row[j];
+                if (!cur) continue;
+                const uint32_t cur_l = (cur << 1) | (j ? row[j - 1] >> 31 : 0u);
+                const uint32_t cur_r = (cur >> 1) | (j + 1 < wpr ? row[j + 1] << 31 : 0u);
+                uint32_t colmask = 0;
+                for (int b = (-(j << 5)) & kmask; b < 32; b += K) colmask |= 1u << b;
+                uint32_t m = (cur & (~cur_l | ~cur_r)) | (cur & colmask & (~row[j - wpr] | ~row[j + wpr]));
+                while (m) {
+                    const int b = __ffs(m) - 1;
+                    m &= m - 1;
+                    add(j * 32 + b, y);
+                }
+            } else {
+                const int c = (it - nrow_items) / nchunk, ch = (it - nrow_items) - c * nchunk;
+                const int x = (c + 1) << kshift, j = x >> 5, b = x & 31, y0 = 1 + (ch << 5);
+                unsigned long long col = 0; // bit i = pixel (x, y0 - 1 + i)
+                for (int i = 0; i < 34; i++) {
+                    const int y = y0 - 1 + i;
+                    if (y <= H + 1) col |= (unsigned long long)((lbits[y * wpr + j] >> b) & 1u) << i;
+                }
+                uint32_t m = (uint32_t)(col >> 1) & (~(uint32_t)col | ~(uint32_t)(col >> 2));
+                while (m) {
+                    const int i = __ffs(m) - 1;
+                    m &= m - 1;
+                    const int y = y0 + i;
+                    if (y <= H && (y & kmask) != 0) add(x, y); // pixels on relay rows were taken above
+                }
+            }
+        }
+        if (nm) atomicAdd(&s_nmark, nm);
+    }
+    __syncthreads();
+    if ((s_flags & RL_FLAG_TABLE) || s_nmark > T - (T >> 3)) { // too many markers for the table: k_contours_t redoes the frame
+        if (tid == 0) {
+            counts[f * 4 + 0] = 0; counts[f * 4 + 1] = 0; counts[f * 4 + 2] = RL_FLAG_TABLE; counts[f * 4 + 3] = 0;
+        }
+        return;
+    }
+    RL_STAMP();
+
+    // ---- (c) small borders.  A lane takes one 32-pixel word of start candidates at a time; every loop iteration
+    // advances each busy lane by ONE step.  A walk stops at a grid marker (the border belongs to (d)), at a proof that
+    // the candidate is not canonical, or when the border closes; a closed border longer than min_len is queued.
+    {
+        RelayWalk wk;
+        bool busy = false, drained = false;
+        uint32_t m_outer = 0, m_hole = 0;
+        int wj = 0, wy = 0, sx = 0, sy = 0, s0 = 0, is_hole = 0, start_key = 0, ncand_l = 0;
+        const int nwords = wpr * H;
+        const float inv_wpr = 1.0f / (float)wpr;
+        for (;;) {
+            if (!busy && !drained) {
+                if (!(m_outer | m_hole)) {
+                    const int i = atomicAdd(&s_next, 1);
+                    if (i >= nwords) drained = true;
+                    else {
+                        wy = 1 + (int)(((float)i + 0.5f) * inv_wpr); // exact: i < 2^20
+                        wj = i - (wy - 1) * wpr;
+                        const uint32_t* row = lbits + wy * wpr;
+                        const uint32_t* up = row - wpr;
+                        const uint32_t cur = row[wj], upw = up[wj];
+                        const uint32_t cur_l = (cur << 1) | (wj ? row[wj - 1] >> 31 : 0u);
+                        const uint32_t up_l = (upw << 1) | (wj ? up[wj - 1] >> 31 : 0u);
+                        const uint32_t up_r = (upw >> 1) | (wj + 1 < wpr ? up[wj + 1] << 31 : 0u);
+                        m_outer = cur & ~cur_l & ~up_l & ~upw & ~up_r;
+                        m_hole = ~cur & cur_l & upw;
+                    }
+                }
+                if (m_outer | m_hole) {
+                    is_hole = m_outer ? 0 : 1;
+                    uint32_t& mm = m_outer ? m_outer : m_hole;
+                    const int b = __ffs(mm) - 1;
+                    mm &= mm - 1;
+                    const int qx = wj * 32 + b;
+                    ncand_l++;
+                    sx = qx - is_hole; sy = wy;
+                    start_key = wy * 65536 + qx;
+                    wk.x = sx; wk.y = sy; wk.n = 0;
+                    wk.ring = ring8(im, sx, sy);
+                    s0 = relay_start_dir(wk.ring, is_hole);
+                    wk.s = s0;
+                    busy = s0 >= 0; // single-pixel borders are never kept
+                }
+            }
+            if (!__any(busy || !drained)) break;
+#pragma unroll
+            for (int u = 0; u < RL_STEPS_PER_ITER; u++) {
+                if (busy) {
+                    const unsigned e = s_lut[(wk.ring << 3) | (unsigned)wk.s];
+                    const int key3 = wk.y * 65536 + wk.x;
+                    bool stop = rl_is_marker(e, wk.x, wk.y, kmask); // the border belongs to the segment walkers
+                    if (is_hole)                                      // relay_not_canonical() on the table's run bits
+                        stop |= ((e & 0x080u) && key3 - 65536 < start_key) || ((e & 0x100u) && key3 - 1 < start_key) ||
+                                ((e & 0x200u) && key3 + 1 < start_key) || ((e & 0x400u) && key3 + 65536 < start_key);
+                    else stop |= key3 < start_key;
+                    if (stop) busy = false;
+                    else {
+                        rl_advance(im, wk, e);
+                        if (wk.x == sx && wk.y == sy && wk.s == s0) {
+                            busy = false;
+                            if (wk.n > min_len) {
+                                const int q = atomicAdd(&s_nsmall, 1);
+                                if (q < RL_SMALL_CAP)
+                                    s_small[q] = make_uint4(relay_key(sx, sy, s0), (uint32_t)wk.n, 0xffffffffu,
+                                                            (uint32_t)start_key * 2u + (uint32_t)is_hole);
+                                else atomicOr(&s_flags, RL_FLAG_TABLE);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        atomicAdd(&s_ncand, ncand_l);
+    }
+    __syncthreads();
+    if (tid == 0) s_next = 0;
+    __syncthreads();
+    RL_STAMP();
+
+    // ---- (d) segments: table slot -> walk to the next grid marker.  The points go to the lane's staging arena (upper
+    // part of the frame's pool); (f2) copies the segments of kept borders to their final place.
+    const int stage0 = pool_cap >> 2, arena = (pool_cap - stage0) / NT;
+    {
+        RelayWalk wk;
+        bool busy = false, drained = false;
+        int slot = 0, mnoff = 0, wp = 0;
+        uint32_t mn = 0xffffffffu;
+        uint32_t* my_arena = pl + stage0 + tid * arena;
+        for (;;) {
+            if (!busy && !drained) {
+                const int i = atomicAdd(&s_next, 1);
+                if (i >= T) drained = true;
+                else {
+                    const uint32_t key = hkey[i];
+                    if (key) {
+                        slot = i;
+                        relay_walk_from_key(im, wk, key);
+                        mn = 0xffffffffu; mnoff = 0;
+                        busy = true;
+                    }
+                }
+            }
+            if (!__any(busy || !drained)) break;
+#pragma unroll
+            for (int u = 0; u < RL_STEPS_PER_ITER; u++) {
+                if (busy) {
+                    const unsigned e = s_lut[(wk.ring << 3) | (unsigned)wk.s];
+                    if (wk.n > 0 && rl_is_marker(e, wk.x, wk.y, kmask)) {
+                        int nx = rl_find(hkey, tbits, relay_key(wk.x, wk.y, wk.s));
+                        if (nx < 0) { atomicOr(&s_flags, RL_FLAG_BUG); nx = slot; }
+                        RelaySeg r;
+                        r.nxt = (uint32_t)nx; r.len = (uint32_t)wk.n; r.minoff = (uint32_t)mnoff;
+                        r.stg = (uint32_t)(stage0 + tid * arena + wp);
+                        sg[slot] = r;
+                        cmin[slot] = mn;
+                        arg[slot] = (uint16_t)slot;
+                        jmp[slot] = (uint16_t)nx;
+                        wp += wk.n;
+                        busy = false;
+                    } else {
+                        if (e & 0x60u) {
+                            const uint32_t k = relay_key(wk.x, wk.y, wk.s);
+                            if (k < mn) { mn = k; mnoff = wk.n; }
+                        }
+                        if (wp + wk.n < arena) my_arena[wp + wk.n] = relay_point(wk);
+                        else { atomicOr(&s_flags, RL_FLAG_TABLE); busy = false; } // staging full: legacy kernel
+                        rl_advance(im, wk, e);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (s_flags & RL_FALLBACK_FLAGS) {
+        if (tid == 0) {
+            counts[f * 4 + 0] = 0; counts[f * 4 + 1] = 0; counts[f * 4 + 2] = s_flags & RL_FALLBACK_FLAGS; counts[f * 4 + 3] = 0;
+        }
+        return;
+    }
+    RL_STAMP();
+
+    // ---- (e1) the border's smallest start state, by pointer doubling round the cyclic list.  When a round changes
+    // nothing, every window already covers its cycle (windows double; "no change" makes the minima periodic).
+    for (int round = 0; round < 24; round++) {
+        uint32_t m_[RL_SLOTS_PER_THREAD];
+        uint16_t a_[RL_SLOTS_PER_THREAD], j_[RL_SLOTS_PER_THREAD];
+#pragma unroll
+        for (int q = 0; q < RL_SLOTS_PER_THREAD; q++) {
+            const int i = tid + q * NT;
+            if (i < T && hkey[i]) {
+                const int j = jmp[i];
+                m_[q] = cmin[j]; a_[q] = arg[j]; j_[q] = jmp[j];
+            }
+        }
+        __syncthreads();
+        if (tid == 0) s_changed[(round + 1) & 1] = 0;
+        bool ch = false;
+#pragma unroll
+        for (int q = 0; q < RL_SLOTS_PER_THREAD; q++) {
+            const int i = tid + q * NT;
+            if (i < T && hkey[i]) {
+                if (m_[q] < cmin[i]) { cmin[i] = m_[q]; arg[i] = a_[q]; ch = true; }
+                jmp[i] = j_[q];
+            }
+        }
+        if (ch) s_changed[round & 1] = 1;
+        __syncthreads();
+        if (!s_changed[round & 1]) break;
+    }
+    // ---- (e2) list ranking: cut every cycle in front of the segment that holds the canonical start; val = points
+    // from the segment to the end of the list
+    uint32_t* val = cmin;
+    uint32_t canon_[RL_SLOTS_PER_THREAD]; // (head segments) the border's canonical start state
+#pragma unroll
+    for (int q = 0; q < RL_SLOTS_PER_THREAD; q++) {
+        const int i = tid + q * NT;
+        canon_[q] = (i < T && hkey[i]) ? cmin[i] : 0xffffffffu;
+    }
+    {
+        uint32_t l_[RL_SLOTS_PER_THREAD];
+        uint16_t n_[RL_SLOTS_PER_THREAD];
+#pragma unroll
+        for (int q = 0; q < RL_SLOTS_PER_THREAD; q++) {
+            const int i = tid + q * NT;
+            if (i < T && hkey[i]) {
+                const RelaySeg r = sg[i];
+                l_[q] = r.len;
+                n_[q] = (arg[r.nxt] == r.nxt) ? (uint16_t)RL_NIL : (uint16_t)r.nxt;
+            }
+        }
+        __syncthreads(); // all reads of cmin (as minimum) and of arg[nxt] done
+#pragma unroll
+        for (int q = 0; q < RL_SLOTS_PER_THREAD; q++) {
+            const int i = tid + q * NT;
+            if (i < T && hkey[i]) { val[i] = l_[q]; jmp[i] = n_[q]; }
+        }
+        if (tid == 0) { s_changed[0] = 0; s_changed[1] = 0; }
+        __syncthreads();
+    }
+    for (int round = 0; round < 24; round++) {
+        uint32_t v_[RL_SLOTS_PER_THREAD];
+        uint16_t j_[RL_SLOTS_PER_THREAD];
+#pragma unroll
+        for (int q = 0; q < RL_SLOTS_PER_THREAD; q++) {
+            const int i = tid + q * NT;
+            j_[q] = RL_NIL;
+            if (i < T && hkey[i]) {
+                const int j = jmp[i];
+                if (j != RL_NIL) { v_[q] = val[j]; j_[q] = jmp[j]; }
+                else v_[q] = 0xffffffffu; // marks "nothing to do"
+            } else v_[q] = 0xffffffffu;
+        }
+        __syncthreads();
+        if (tid == 0) s_changed[(round + 1) & 1] = 0;
+        bool ch = false;
+#pragma unroll
+        for (int q = 0; q < RL_SLOTS_PER_THREAD; q++) {
+            const int i = tid + q * NT;
+            if (v_[q] != 0xffffffffu) { val[i] += v_[q]; jmp[i] = j_[q]; ch = true; }
+        }
+        if (ch) s_changed[round & 1] = 1;
+        __syncthreads();
+        if (!s_changed[round & 1]) break;
+    }
+    RL_STAMP();
+
+    // ---- (f1) kept borders: pool space and sort key; jmp[root] = kept index or NIL
+#pragma unroll
+    for (int q = 0; q < RL_SLOTS_PER_THREAD; q++) {
+        const int i = tid + q * NT;
+        if (i < T && hkey[i] && arg[i] == i) {
+            const int n = (int)val[i];
+            const uint32_t canon = canon_[q];
+            uint16_t kk = RL_NIL;
+            if (canon == 0xffffffffu) atomicOr(&s_flags, RL_FLAG_BUG); // a border without a start state
+            else if (n > min_len) {
+                const int k = atomicAdd(&s_nkept, 1);
+                const int base = atomicAdd(&s_pool, n);
+                if (base + n > stage0) atomicOr(&s_flags, 4);
+                else if (k < kept_cap) {
+                    RelayWalk cs;
+                    relay_walk_from_key(im, cs, canon);
+                    unsigned run;
+                    relay_examine(cs.ring, cs.s, &run);
+                    const unsigned hole = relay_start_class(cs.ring, run) == 2 ? 1u : 0u;
+                    const uint32_t disc = (uint32_t)(cs.y * 65536 + cs.x) + hole;
+                    kkey[k] = ((unsigned long long)(0xffffffffu - disc) << 32) | ((unsigned long long)(n & 0xfffff) << 12) |
+                              ((unsigned)k << 1) | hole;
+                    off_u[k] = base;
+                    kk = (uint16_t)k;
+                }
+            }
+            jmp[i] = kk;
+        }
+    }
+    if (tid < min(s_nsmall, RL_SMALL_CAP)) {
+        const uint4 e = s_small[tid];
+        const int n = (int)e.y;
+        const int k = atomicAdd(&s_nkept, 1);
+        const int base = atomicAdd(&s_pool, n);
+        if (base + n > stage0) atomicOr(&s_flags, 4);
+        else if (k < kept_cap) {
+            kkey[k] = ((unsigned long long)(0xffffffffu - (e.w >> 1)) << 32) | ((unsigned long long)(n & 0xfffff) << 12) |
+                      ((unsigned)k << 1) | (e.w & 1u);
+            off_u[k] = base;
+            s_small[tid].z = (uint32_t)base;
+        }
+    }
+    __syncthreads();
+    // ---- (f2) the segments of kept borders move from the staging arenas to their final position, one wave per
+    // segment (coalesced).  Segment i starts (n - val[i]) points after the list head; the border starts `minoff`
+    // points into the head segment, so everything shifts down by minoff and the head's first points wrap to the end.
+    {
+        const int lane = tid & 63, wid = tid >> 6;
+        for (int i0 = wid * 64; i0 < T; i0 += (NT >> 6) * 64) {
+            const int i = i0 + lane;
+            int src = 0, dst = 0, len = 0, base = 0, n = 0;
+            if (hkey[i]) {
+                const int g = arg[i];
+                const int k = jmp[g];
+                if (k != RL_NIL) {
+                    const RelaySeg r = sg[i];
+                    n = (int)val[g]; base = off_u[k];
+                    dst = base + (n - (int)val[i]) - (int)sg[g].minoff;
+                    src = (int)r.stg; len = (int)r.len;
+                }
+            }
+            unsigned long long todo = __ballot(len > 0);
+            while (todo) {
+                const int L = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const int src_ = __shfl(src, L), dst_ = __shfl(dst, L), len_ = __shfl(len, L), base_ = __shfl(base, L),
+                          n_ = __shfl(n, L);
+                for (int o = lane; o < len_; o += 64) {
+                    int p = dst_ + o;
+                    if (p < base_) p += n_;
+                    pl[p] = pl[src_ + o];
+                }
+            }
+        }
+    }
+    if (tid < min(s_nsmall, RL_SMALL_CAP) && s_small[tid].z != 0xffffffffu) {
+        const uint4 e = s_small[tid];
+        RelayWalk wk;
+        relay_walk_from_key(im, wk, e.x);
+        for (int o = 0; o < (int)e.y; o++) {
+            unsigned run;
+            const int d = relay_examine(wk.ring, wk.s, &run);
+            pl[e.z + o] = relay_point(wk);
+            relay_advance(im, wk, d);
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (tid == 0) {
+        if (s_nkept > kept_cap) { s_flags |= 2; s_nkept = kept_cap; }
+    }
+    __syncthreads();
+    RL_STAMP();
+    // ---- (g) the table is dead; its space holds the tail's arrays
+    contours_tail(f, tid, NT, s_nkept, kkey, off_u, klen, koff, rectflag, ap_out, ap_stack, pl, kept_out, kept_cap,
+                  rects_out, rect_cap, counts, &s_flags, &s_ncand, lbits, (lds_bits_words / (RL_THREADS / 64)) & ~3);
+#ifdef ORBFE_CT_TIMING
+    if (tid == 0) {
+        RL_STAMP();
+        long long* dbg = (long long*)(kept_out + (size_t)f * kept_cap + kept_cap - 4);
+        for (int i = 0; i < 7; i++) dbg[i] = tq[i + 1] - tq[i];
+    }
+#endif
+}
 
 // ---------------------------------------------------------------------------------------- prefilter -----------
 __device__ __forceinline__ int ar_perimeter(const float c[4][2])
@@ -825,8 +1375,7 @@ __global__ __launch_bounds__(64) void k_decode(ImgView src0, ImgView pyr, const 
                 int best = 0x7fffffff;
                 for (int i = lane; i < ncodes; i += 64)
                     if (codes[i] == want) best = min(best, i);
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o));
+                best = wave_min(best);
                 if (best != 0x7fffffff) { id = best; nrot = rr; break; }
             }
         }

@@ -34,7 +34,19 @@ template <bool LDS_BITS>
 __global__ void k_contours_t(const uint32_t* gbits, size_t bits_fstride, int wpr_g, int W, int H, int lds_bits_words,
                            int min_len, uint32_t* candq, size_t candq_fstride, int candq_cap, uint32_t* pool,
                            size_t pool_fstride, int pool_cap, ArKept* kept_out, int kept_cap, ArRect* rects_out,
-                           int rect_cap, int32_t* counts, uint32_t* gpadded, size_t gpadded_fstride);
+                           int rect_cap, int32_t* counts, uint32_t* gpadded, size_t gpadded_fstride, int only_flagged);
+
+// HBM scratch of k_contours_relay, one per hash-table slot
+struct RelaySeg {
+    uint32_t nxt;    // slot of the next segment of the border
+    uint32_t len;    // points of this segment
+    uint32_t minoff; // offset of the segment's smallest start state
+    uint32_t stg;    // where the segment's points are staged inside the frame's pool
+};
+__global__ void k_contours_relay(const uint32_t* gbits, size_t bits_fstride, int wpr_g, int W, int H,
+                                 int lds_bits_words, int min_len, int kshift, int tbits, RelaySeg* segs, uint32_t* pool,
+                                 size_t pool_fstride, int pool_cap, ArKept* kept_out, int kept_cap, ArRect* rects_out,
+                                 int rect_cap, int32_t* counts);
 __global__ void k_prefilter(ArRect* rects, int rect_cap, const int32_t* counts, int W, int H, int too_near,
                             int32_t* cand_idx, int32_t* ncand_out);
 __global__ void k_decode(ImgView src0, ImgView pyr, const ArLevel* levels, int nlevels, const ArRect* rects,
@@ -50,6 +62,25 @@ __global__ void k_finalize(const ArRect* rects, int rect_cap, const int32_t* can
 #define AP_STACK 64
 #define AP_OUT 64
 #define CT_PROBE 24 // steps a border start is followed before it is queued as a long walk (< the 70-point gate)
+
+#define RL_THREADS 1024
+#define RL_SLOTS_PER_THREAD 8   // table slots <= RL_THREADS * RL_SLOTS_PER_THREAD
+#define RL_SMALL_CAP 64         // kept borders that touch no grid marker (rare: > 70 points between grid lines)
+#define RL_NIL 0xffff
+#define RL_FLAG_TABLE 32        // markers did not fit: the frame is redone by k_contours_t
+#define RL_FLAG_BUG 64          // an invariant of the relay formulation failed: redone by k_contours_t as well
+#define RL_FALLBACK_FLAGS (RL_FLAG_TABLE | RL_FLAG_BUG)
+#define RL_KSHIFT 5             // grid lines every 32 pixels
+#define RL_STEPS_PER_ITER 2      // walk steps between two looks at the work queue
+
+inline size_t relay_lds_bytes(int lds_bits_words, int kept_cap, int tbits)
+{
+    size_t b = ((size_t)lds_bits_words * 4 + 15) & ~(size_t)15;
+    b += (size_t)kept_cap * 8 + (size_t)kept_cap * 4; // keys, pool offsets
+    const size_t table = ((size_t)12 << tbits);
+    const size_t tail = (size_t)kept_cap * 12 + (size_t)(RL_THREADS / 64) * (AP_OUT + AP_STACK) * 8;
+    return b + (table > tail ? table : tail) + 16;
+}
 
 inline size_t contours_lds_bytes(int lds_bits_words, int kept_cap)
 {

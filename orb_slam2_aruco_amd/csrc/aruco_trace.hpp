@@ -159,4 +159,130 @@ ORBFE_HD bool hole_start_candidate(const BitImage& im, int px, int py)
     return !im.get(px, py) && im.get(px - 1, py) && im.get(px, py - 1);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Relay segments: the same borders, cut into short independent pieces (k_contours_relay, tests/proto_contours.cpp).
+//
+// A walk state is (pixel p, direction s of the previous border pixel).  One step searches counter-clockwise from s+1
+// for the first foreground neighbour; the background directions it examines before finding it are the state's RUN.
+// The step function is a bijection on states, so every state lies on exactly one cycle; a cycle that contains a state
+// whose run holds a 4-neighbour direction is a border Suzuki-Abe can follow (the border between the pixel's
+// component and the background region of that 4-neighbour).
+//
+// GRID MARKERS.  A state is a grid marker if its run contains W or E and its pixel lies on a relay row
+// (y % K == 0), or contains N or S and its pixel lies on a relay column (x % K == 0).  Grid markers are recognisable
+// from the 3x3 neighbourhood alone, both when enumerating them up front and when a walk arrives at one.  One lane walks
+// from its marker to the next marker (a SEGMENT, about K steps on straight edges); the segments of a border form a
+// cyclic list, and no lane ever walks a long border alone.
+//
+// CANONICAL START.  OpenCV's raster scan starts an outer border at the component's raster-first pixel (a "local top":
+// W, NW, N, NE background; the state whose run contains W) and a hole border at W(b), b the raster-first pixel of
+// the hole (E background, NE foreground; the state whose run contains E).  Call states of these two patterns START
+// states.  On every border cycle the canonical start is the start state with the smallest state key:
+//   * outer border: the component's raster-first pixel is a local top; hole-pattern start states on the cycle sit on
+//     other pixels of the component, hence are larger;
+//   * hole border of background region R with raster-first pixel b: a local top c on the cycle has N(c) in R, so
+//     b < N(c) and W(b) < c; another hole-pattern start W(b'), b' in R, has b' > b.
+// So each segment records the smallest start state it passes and where; the minimum over the cyclic list names the
+// canonical start, and its pattern says whether the border is an outer border or a hole border.
+//
+// Borders that touch no grid marker are small (they live between grid lines); they are followed whole from their
+// start candidates with the abandon rule of the first half of this file, and a walk that meets a grid marker stops
+// (that border belongs to the segment walkers).
+
+// Grid-marker directions (bit d = direction d; only background directions survive) of padded pixel (x, y).
+ORBFE_HD unsigned grid_active(unsigned ring, int x, int y, int kmask)
+{
+    unsigned a = 0;
+    if ((y & kmask) == 0) a |= 0x11u;
+    if ((x & kmask) == 0) a |= 0x44u;
+    return a & ~ring;
+}
+
+// One step's search from state (ring, s): direction of the next border pixel and the run of examined directions.
+ORBFE_HD int relay_examine(unsigned ring, int s, unsigned* run)
+{
+    const int rot = s + 1;
+    const unsigned m = ring | (ring << 8) | (ring << 16);
+    const unsigned r = (m >> rot) & 0xffu;
+    const int i = ctz8(r);
+    const unsigned exr = (1u << i) - 1u;
+    *run = ((exr << rot) | ((exr << rot) >> 8)) & 0xffu;
+    return (rot + i) & 7;
+}
+
+// Start pattern of a state with the given run: 1 = outer-border start, 2 = hole-border start, 0 = neither.
+ORBFE_HD int relay_start_class(unsigned ring, unsigned run)
+{
+    if ((run & 0x10u) && (ring & 0x1eu) == 0) return 1;
+    if ((run & 0x01u) && (ring & 0x02u)) return 2;
+    return 0;
+}
+
+// state key: y | x | s (padded coordinates), ordered like the raster key of the pixel; never 0
+ORBFE_HD uint32_t relay_key(int x, int y, int s) { return ((uint32_t)y << 16) | ((uint32_t)x << 3) | (uint32_t)s; }
+
+// Calls emit(s) for every state of a pixel whose run contains one of the directions in `a` (a subset of the pixel's
+// background directions).  ring != 0: isolated pixels have no states.
+template <class F>
+ORBFE_HD void relay_states_of_pixel(unsigned ring, unsigned a, F emit)
+{
+    while (a) {
+        const int d = ctz8(a);
+        const unsigned rr = ((ring | (ring << 8)) >> d) & 0xffu; // bit j = direction d + j; bit 0 is background
+        int j = 7;
+        while (!((rr >> j) & 1u)) j--;
+        const int s = (d + j) & 7; // first foreground direction clockwise from d
+        unsigned run;
+        relay_examine(ring, s, &run);
+        a &= ~run;
+        emit(s);
+    }
+}
+
+struct RelayWalk {
+    int x, y, s; // padded pixel, direction of the previous border pixel
+    int n;       // points emitted so far
+    unsigned ring;
+};
+
+ORBFE_HD void relay_walk_from_key(const BitImage& im, RelayWalk& w, uint32_t key)
+{
+    w.x = (int)((key >> 3) & 0x1fffu); w.y = (int)(key >> 16); w.s = (int)(key & 7u);
+    w.n = 0;
+    w.ring = ring8(im, w.x, w.y);
+}
+
+ORBFE_HD uint32_t relay_point(const RelayWalk& w) { return (uint32_t)(w.x - 1) | ((uint32_t)(w.y - 1) << 16); }
+
+ORBFE_HD void relay_advance(const BitImage& im, RelayWalk& w, int d)
+{
+    w.x += dir_dx(d); w.y += dir_dy(d);
+    w.s = (d + 4) & 7;
+    w.n++;
+    w.ring = ring8(im, w.x, w.y);
+}
+
+// The abandon rule of trace_step() in terms of a state's run: true if the walk from a start candidate with raster key
+// start_key proves that the candidate is not the canonical start.
+ORBFE_HD bool relay_not_canonical(int x, int y, unsigned run, int is_hole, int start_key)
+{
+    const int key3 = y * 65536 + x;
+    if (is_hole)
+        return ((run & 0x04u) && key3 - 65536 < start_key) || ((run & 0x10u) && key3 - 1 < start_key) ||
+               ((run & 0x01u) && key3 + 1 < start_key) || ((run & 0x40u) && key3 + 65536 < start_key);
+    return key3 < start_key;
+}
+
+// First state of a start candidate (the state trace_init() sets up): pixel (sx, sy), previous = first foreground
+// neighbour clockwise from W (outer) / from E (hole).  Returns -1 for an isolated pixel.
+ORBFE_HD int relay_start_dir(unsigned ring, int is_hole)
+{
+    if (!ring) return -1;
+    const int d0 = is_hole ? 0 : 4;
+    const unsigned rr = ((ring | (ring << 8)) >> d0) & 0xffu;
+    int j = 7; // direction d0 itself (bit 0) is background for a start candidate
+    while (!((rr >> j) & 1u)) j--;
+    return (d0 + j) & 7;
+}
+
 } // namespace orbfe

@@ -10,6 +10,7 @@
 #include <climits>
 
 #include "orbfe_common.hpp"
+#include "wave_dpp.hpp"
 
 namespace orbfe {
 
@@ -91,15 +92,6 @@ __global__ void k_knn2_merge(const int32_t* __restrict__ pidx, const int32_t* __
 #define GRID_COLS 64
 #define GRID_ROWS 48
 
-__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        unsigned long long t = __shfl_xor(v, o);
-        v = t < v ? t : v;
-    }
-    return v;
-}
 
 // One workgroup (256 threads) per frame pair p: F1 = frame p, F2 = frame p+1 of a stream.
 // Phase A: F2's level-0 keypoints sorted by (grid column, grid row, index) in LDS.  That is exactly the order in which

@@ -10,6 +10,7 @@
 //
 // Data layout in HBM (per extractor handle, frame-major): see DESIGN.md "ORB extractor: layout".
 #include "orb_kernels.hpp"
+#include "wave_dpp.hpp"
 
 namespace orbfe {
 
@@ -723,13 +724,9 @@ __global__ __launch_bounds__(64) void k_distribute(const LevelGeom* __restrict__
 // the workgroup raises `fallback[f, level]` and k_distribute (the general kernel) redoes that level.
 __device__ __forceinline__ int wave_excl_scan(int v, int lane, int& total)
 {
-    int incl = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(incl, o);
-        if (lane >= o) incl += t;
-    }
-    total = __shfl(incl, 63);
+    (void)lane;
+    const int incl = wave_incl_scan_add(v);
+    total = __builtin_amdgcn_readlane(incl, 63);
     return incl - v;
 }
 
@@ -780,9 +777,7 @@ __global__ __launch_bounds__(64) void k_distribute_pyr(const LevelGeom* __restri
         const int c = c0 + lane;
         const int k_cnt = (c < g.ncells) ? ccnt[c] : 0;
         n += k_cnt;
-        int mx = k_cnt;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+        const int mx = wave_max(k_cnt);
         const uint32_t* sl = cslots + (size_t)c * g.cell_cap;
         for (int k0 = 0; k0 < mx; k0 += 4) {
             uint32_t kv[4];
@@ -812,8 +807,7 @@ __global__ __launch_bounds__(64) void k_distribute_pyr(const LevelGeom* __restri
             }
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+    n = wave_sum(n);
     if (lane == 0) { lvl_ncand[fl_idx] = n; fallback[fl_idx] = 0; }
     QT_SYNC();
     if (n == 0) {
@@ -1245,11 +1239,8 @@ __global__ __launch_bounds__(256) void k_orient_describe(ImgView src0, ImgView p
                 }
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            m10 += __shfl_xor(m10, o);
-            m01 += __shfl_xor(m01, o);
-        }
+        m10 = wave_sum(m10);
+        m01 = wave_sum(m01);
     }
     const float angle = orbfe_fast_atan2((float)m01, (float)m10);
 

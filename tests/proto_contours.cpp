@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <unordered_map>
 #include <vector>
 
 #include "../orb_slam2_aruco_amd/csrc/aruco_trace.hpp"
@@ -45,5 +46,142 @@ extern "C" int proto_find_contours(const uint8_t* img, int w, int h, int32_t* le
         }
     }
     if (work_steps) *work_steps = steps;
+    return (int)found.size();
+}
+
+
+// The relay-segment formulation (aruco_trace.hpp, second half), phase by phase as k_contours_relay runs it:
+// grid markers -> small borders from start candidates -> segments -> cyclic lists -> canonical starts -> points.
+// stats: [grid markers, max segment length, total segment steps, max segments per cycle, borders, small-phase steps]
+extern "C" int proto_find_contours_relay(const uint8_t* img, int w, int h, int kshift, int32_t* lengths,
+                                         int max_contours, int32_t* points, int max_points, int64_t* stats)
+{
+    const int wpr = (w + 2 + 31) / 32, kmask = (1 << kshift) - 1;
+    std::vector<uint32_t> bits((size_t)wpr * (h + 2) + 2, 0);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+            if (img[(size_t)y * w + x]) bits[(size_t)(y + 1) * wpr + ((x + 1) >> 5)] |= 1u << ((x + 1) & 31);
+    BitImage im{bits.data(), wpr, w, h};
+    struct C { int key; std::vector<uint32_t> pts; };
+    std::vector<C> found;
+
+    // ---- grid markers
+    struct M { uint32_t key, cmin; int minoff, next, len; };
+    std::vector<M> mk;
+    std::unordered_map<uint32_t, int> idx;
+    for (int py = 1; py <= h; py++)
+        for (int px = 1; px <= w; px++) {
+            if (!im.get(px, py)) continue;
+            const unsigned ring = ring8(im, px, py);
+            if (!ring) continue;
+            relay_states_of_pixel(ring, grid_active(ring, px, py, kmask), [&](int s) {
+                idx[relay_key(px, py, s)] = (int)mk.size();
+                mk.push_back(M{relay_key(px, py, s), 0xffffffffu, 0, -1, 0});
+            });
+        }
+
+    // ---- small borders: followed whole from their start candidates
+    int64_t small_steps = 0;
+    for (int py = 1; py <= h; py++)
+        for (int px = 1; px <= w; px++) {
+            int is_hole = -1;
+            if (outer_start_candidate(im, px, py)) is_hole = 0;
+            else if (px >= 2 && hole_start_candidate(im, px, py)) is_hole = 1;
+            if (is_hole < 0) continue;
+            const int sx = px - is_hole, sy = py, start_key = py * 65536 + px;
+            RelayWalk wk;
+            wk.x = sx; wk.y = sy; wk.n = 0; wk.ring = ring8(im, sx, sy);
+            wk.s = relay_start_dir(wk.ring, is_hole);
+            if (wk.s < 0) { found.push_back(C{start_key, {relay_point(wk)}}); continue; } // single pixel
+            const int s0 = wk.s;
+            std::vector<uint32_t> pts;
+            bool ok = false;
+            for (;;) {
+                unsigned run;
+                const int d = relay_examine(wk.ring, wk.s, &run);
+                small_steps++;
+                if (run & grid_active(wk.ring, wk.x, wk.y, kmask)) break;          // a segment walker's border
+                if (relay_not_canonical(wk.x, wk.y, run, is_hole, start_key)) break;
+                pts.push_back(relay_point(wk));
+                relay_advance(im, wk, d);
+                if (wk.x == sx && wk.y == sy && wk.s == s0) { ok = true; break; }
+            }
+            if (ok) found.push_back(C{start_key, pts});
+        }
+
+    // ---- segments
+    int64_t total = 0, maxseg = 0;
+    std::vector<std::vector<uint32_t>> segpts(mk.size());
+    for (size_t i = 0; i < mk.size(); i++) {
+        M& m = mk[i];
+        RelayWalk wk;
+        relay_walk_from_key(im, wk, m.key);
+        for (;;) {
+            unsigned run;
+            const int d = relay_examine(wk.ring, wk.s, &run);
+            if (wk.n > 0 && (run & grid_active(wk.ring, wk.x, wk.y, kmask))) {
+                auto it = idx.find(relay_key(wk.x, wk.y, wk.s));
+                if (it == idx.end()) return -1;
+                m.next = it->second;
+                break;
+            }
+            if (relay_start_class(wk.ring, run)) {
+                const uint32_t k = relay_key(wk.x, wk.y, wk.s);
+                if (k < m.cmin) { m.cmin = k; m.minoff = wk.n; }
+            }
+            segpts[i].push_back(relay_point(wk));
+            relay_advance(im, wk, d);
+        }
+        m.len = wk.n;
+        total += m.len;
+        maxseg = std::max<int64_t>(maxseg, m.len);
+    }
+
+    // ---- cyclic lists: canonical start = smallest start state; rotate the concatenation to it
+    std::vector<char> seen(mk.size(), 0);
+    int64_t maxcyc = 0;
+    for (size_t i0 = 0; i0 < mk.size(); i0++) {
+        if (seen[i0]) continue;
+        int best = -1, cnt = 0;
+        for (int i = (int)i0;;) {
+            seen[i] = 1; cnt++;
+            if (best < 0 || mk[i].cmin < mk[best].cmin) best = i;
+            i = mk[i].next;
+            if (i == (int)i0) break;
+        }
+        maxcyc = std::max<int64_t>(maxcyc, cnt);
+        if (mk[best].cmin == 0xffffffffu) return -2; // a border without a start state: the theory would be wrong
+        RelayWalk cs;
+        relay_walk_from_key(im, cs, mk[best].cmin);
+        unsigned run;
+        relay_examine(cs.ring, cs.s, &run);
+        const int cls = relay_start_class(cs.ring, run);
+        if (!cls) return -3;
+        C c;
+        c.key = cs.y * 65536 + cs.x + (cls == 2 ? 1 : 0);
+        std::vector<uint32_t> all;
+        for (int i = best;;) {
+            all.insert(all.end(), segpts[i].begin(), segpts[i].end());
+            i = mk[i].next;
+            if (i == best) break;
+        }
+        const int j = mk[best].minoff, n = (int)all.size();
+        c.pts.resize(n);
+        for (int o = 0; o < n; o++) c.pts[(o - j + n) % n] = all[o];
+        found.push_back(std::move(c));
+    }
+    std::sort(found.begin(), found.end(), [](const C& a, const C& b) { return a.key > b.key; });
+    int np = 0;
+    for (int i = 0; i < (int)found.size(); i++) {
+        if (i < max_contours) lengths[i] = (int)found[i].pts.size();
+        for (uint32_t v : found[i].pts) {
+            if (np < max_points) { points[2 * np] = (int)(v & 0xffff); points[2 * np + 1] = (int)(v >> 16); }
+            np++;
+        }
+    }
+    if (stats) {
+        stats[0] = (int64_t)mk.size(); stats[1] = maxseg; stats[2] = total; stats[3] = maxcyc;
+        stats[4] = (int64_t)found.size(); stats[5] = small_steps;
+    }
     return (int)found.size();
 }

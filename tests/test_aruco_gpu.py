@@ -73,3 +73,83 @@ def test_rotated_markers_all_four_rotations(orbfe, oracle):
         got, want = det.detect(img), ora.detect(img)
         assert list(got["id"]) == [77] and list(want["id"]) == [77]
         assert np.allclose(got["corners"], want["corners"], atol=1e-3)
+
+
+def _rects_key(det, f=0):
+    r = det.rects(f)
+    return r["corners"].copy(), r["len"].copy()
+
+
+def test_relay_and_legacy_contour_kernels_agree(orbfe, oracle):
+    """The relay-segment kernel (default) and the single-walker kernel (its fallback) give the same rectangles,
+    markers and border counts on video-like frames."""
+    imgs = synth.stream(480, 640, 6, 321)
+    det = orbfe.MarkerDetector("ARUCO")
+    a = det.detect_batch(imgs)
+    ra = [(_rects_key(det, f), det.counts(f)) for f in range(len(imgs))]
+    assert not any(c["fell_back"] for _, c in ra)
+    det.force_legacy_contours(True)
+    b = det.detect_batch(imgs)
+    for f in range(len(imgs)):
+        (ca, la), cnt = ra[f]
+        cb, lb = _rects_key(det, f)
+        c2 = det.counts(f)
+        assert np.array_equal(ca, cb) and np.array_equal(la, lb)
+        assert (cnt["nkept"], cnt["nrect"], cnt["ncand"]) == (c2["nkept"], c2["nrect"], c2["ncand"])
+        assert np.array_equal(a[f], b[f])
+    ora = oracle.ArucoOracle("ARUCO")
+    assert np.array_equal(a[0]["id"], ora.detect(imgs[0])["id"])
+
+
+def test_dense_frame_falls_back_to_legacy_kernel(orbfe, oracle):
+    """A frame with more grid markers than the relay kernel's table holds is redone by the legacy kernel; a batch
+    may mix both kinds."""
+    rng = np.random.default_rng(5)
+    noisy, _ = synth.scene(480, 640, 11, "ARUCO", 3)
+    salt = rng.random(noisy.shape) < 0.35
+    noisy = np.where(salt, rng.integers(0, 256, noisy.shape), noisy).astype(np.uint8)
+    clean, _ = synth.scene(480, 640, 12, "ARUCO", 3)
+    det = orbfe.MarkerDetector("ARUCO")
+    got = det.detect_batch(np.stack([clean, noisy, clean]))
+    assert [det.counts(f)["fell_back"] for f in range(3)] == [False, True, False]
+    ora = oracle.ArucoOracle("ARUCO")
+    for f, img in enumerate([clean, noisy, clean]):
+        want = ora.detect(img)
+        orects = ora.candidates(0)
+        grects = det.rects(f)
+        assert det.counts(f)["flags"] == 0
+        assert np.array_equal(grects["corners"].reshape(-1, 8), orects[:, :8])
+        assert np.array_equal(got[f]["id"], want["id"])
+
+
+@pytest.mark.parametrize("pattern", ["spiral", "comb", "checker", "frame"])
+def test_structured_binary_patterns(orbfe, oracle, pattern):
+    """Long thin borders, borders between grid lines and one-pixel structures (the relay kernel's corner cases)."""
+    img = np.full((240, 320), 200, np.uint8)
+    if pattern == "spiral":        # one very long border
+        for k in range(0, 100, 8):
+            img[20 + k:220 - k, 20 + k:24 + k] = 20
+            img[20 + k:24 + k, 20 + k:300 - k] = 20
+            img[216 - k:220 - k, 28 + k:300 - k] = 20
+            img[28 + k:220 - k, 296 - k:300 - k] = 20
+    elif pattern == "comb":        # > 70 border points inside one 32 x 32 grid cell
+        for x in range(34, 62, 4):
+            img[35:62, x:x + 2] = 20
+        img[60:62, 34:60] = 20
+    elif pattern == "checker":
+        yy, xx = np.mgrid[0:240, 0:320]
+        img[((yy // 6 + xx // 6) % 2 == 0) & (yy > 30) & (yy < 200) & (xx > 40) & (xx < 280)] = 20
+    else:                          # border along the image frame
+        img[:] = 20
+        img[3:-3, 3:-3] = 200
+    det = orbfe.MarkerDetector("ARUCO")
+    ora = oracle.ArucoOracle("ARUCO")
+    got, want = det.detect(img), ora.detect(img)
+    assert np.array_equal(det.thresholded(0), ora.stage_image(0))
+    c = det.counts(0)
+    assert c["flags"] == 0 and not c["fell_back"], c
+    assert c["nkept"] == sum(len(b) > 70 for b in oracle.find_contours(ora.stage_image(0)))
+    orects, grects = ora.candidates(0), det.rects(0)
+    assert np.array_equal(grects["corners"].reshape(-1, 8), orects[:, :8])
+    assert np.array_equal(grects["len"], orects[:, 8].astype(np.int32))
+    assert np.array_equal(got["id"], want["id"])

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
-def proto(tmp_path_factory):
+def protos(tmp_path_factory):
     so = str(tmp_path_factory.mktemp("proto") / "libproto.so")
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so,
                            os.path.join(ROOT, "tests", "proto_contours.cpp")])
@@ -21,18 +21,36 @@ def proto(tmp_path_factory):
     P.proto_find_contours.restype = C.c_int
     P.proto_find_contours.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
 
-    def run(b):
-        b = np.ascontiguousarray(b, np.uint8)
-        lens = np.zeros(200000, np.int32)
-        pts = np.zeros((3000000, 2), np.int32)
-        n = P.proto_find_contours(b.ctypes.data, b.shape[1], b.shape[0], lens.ctypes.data, len(lens), pts.ctypes.data,
-                                  len(pts), None)
-        out, o = [], 0
-        for l in lens[:n]:
-            out.append(pts[o:o + l].copy())
-            o += l
-        return out
-    return run
+    P.proto_find_contours_relay.restype = C.c_int
+    P.proto_find_contours_relay.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                            C.c_int, C.c_void_p]
+
+    def make(fn, *extra):
+        def run(b, stats=None):
+            b = np.ascontiguousarray(b, np.uint8)
+            lens = np.zeros(200000, np.int32)
+            pts = np.zeros((3000000, 2), np.int32)
+            st = np.zeros(8, np.int64)
+            n = fn(b.ctypes.data, b.shape[1], b.shape[0], *extra, lens.ctypes.data, len(lens), pts.ctypes.data,
+                   len(pts), st.ctypes.data)
+            assert n >= 0, n
+            if stats is not None:
+                stats[:] = st
+            out, o = [], 0
+            for l in lens[:n]:
+                out.append(pts[o:o + l].copy())
+                o += l
+            return out
+        return run
+    # relay spacing K = 4, 8, 32: small K puts many grid markers on small test images (multi-segment borders),
+    # K = 32 is what the kernel uses (most borders of these images then take the small-border path)
+    return {"trace": make(P.proto_find_contours), "relay4": make(P.proto_find_contours_relay, 2),
+            "relay8": make(P.proto_find_contours_relay, 3), "relay32": make(P.proto_find_contours_relay, 5)}
+
+
+@pytest.fixture(params=["trace", "relay4", "relay8", "relay32"])
+def proto(request, protos):
+    return protos[request.param]
 
 
 def _same(a, b):

@@ -1,13 +1,20 @@
+"""Phase timers of the contour kernels (instrumented build: -DORBFE_CT_TIMING, ORBFE_LIB=build/liborbfe_timing.so).
+clock64() ticks at 100 MHz on gfx950 (s_memtime), so 1 tick = 10 ns."""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from orb_slam2_aruco_amd import binding, synth
-img, _ = synth.scene(480, 640, 1)
+imgs = synth.stream(480, 640, 300, 1000)[::38][:8].copy()
 det = binding.MarkerDetector("ARUCO")
-det.detect(img)
-imgs = np.stack([img] * 8)
-det.detect_batch(imgs)
-out = np.zeros(12, np.int64)
-binding._check(det.L, det.L.orbfe_aruco_debug_image(det.h, 0, 102, out.ctypes.data_as(C.c_void_p)), "dbg")
-print("cycles: load_bits %d, candidates %d, trace %d, sort+retrace %d, approx+compact %d" % tuple(out[:5]))
-print(det.counts(0))
+for legacy in (False, True):
+    det.force_legacy_contours(legacy)
+    det.detect_batch(imgs)
+    for f in (0, 5):
+        out = np.zeros(12, np.int64)
+        binding._check(det.L, det.L.orbfe_aruco_debug_image(det.h, f, 102, out.ctypes.data_as(C.c_void_p)), "dbg")
+        if legacy:
+            print("legacy frame %d ticks: load_bits %d, probe %d, long %d, - %d, sort+approx+compact %d" % ((f,) + tuple(out[:5])))
+        else:
+            print("relay frame %d ticks: load_bits %d, markers %d, small %d, segments %d, lists %d, points %d, tail %d"
+                  % ((f,) + tuple(out[:7])))
+        print("   ", det.counts(f))
