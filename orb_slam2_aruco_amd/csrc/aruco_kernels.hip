@@ -247,10 +247,14 @@ __device__ bool convex4(const ApPt* p)
 __device__ void contours_tail(int f, int tid, int NT, int nkept, unsigned long long* kkey, const int* off_u, int* klen,
                               int* koff, int* rectflag, ApPt* ap_out, int2* ap_stack, const uint32_t* pl,
                               ArKept* __restrict__ kept_out, int kept_cap, ArRect* __restrict__ rects_out, int rect_cap,
-                              int32_t* __restrict__ counts, int* s_flags, const int* s_ncand, uint32_t* pbuf,
-                              int pbuf_pts)
+                              int32_t* __restrict__ counts, int* s_flags, const int* s_ncand, uint16_t* rank_of,
+                              unsigned* tail_q, int nbig, uint32_t* pbuf, int pbuf_pts, uint32_t* pbuf2, int pbuf2_pts)
 {
     const int lane = tid & 63, wid = tid >> 6, nwaves = NT >> 6;
+#ifdef ORBFE_CT_TIMING
+    long long* tdbg = (long long*)(kept_out + (size_t)f * kept_cap + kept_cap - 4) + 8;
+    const long long tt0 = clock64();
+#endif
     int Pn = 1;
     while (Pn < nkept) Pn <<= 1;
     for (int i = nkept + tid; i < Pn; i += NT) kkey[i] = ~0ull;
@@ -272,37 +276,68 @@ __device__ void contours_tail(int f, int tid, int NT, int nkept, unsigned long l
         koff[k] = off_u[(int)((key >> 1) & 0x7ff)];
     }
     __syncthreads();
-    for (int k = wid; k < nkept; k += nwaves) {
-        int ok = 0;
+#ifdef ORBFE_CT_TIMING
+    const long long tt1 = clock64();
+#endif
+    // approxPolyDP makes many dependent passes over a border's points and its cost grows with the length; a frame has
+    // a few long borders and many short ones.  So: the points are staged in LDS that is dead by now (waves < nbig own a
+    // big buffer, the others a small one; a border that does not fit is read from the pool), and the borders are
+    // ranked by length -- big-buffer waves take them from the long end, the others from the short end, until the
+    // two meet (one packed ticket counter: front count | back count << 16).
+    for (int k = tid; k < nkept; k += NT) {
+        const int lk = klen[k];
+        int r = 0;
+        for (int j = 0; j < nkept; j++) {
+            const int lj = klen[j];
+            r += (lj > lk) || (lj == lk && j < k);
+        }
+        rank_of[r] = (uint16_t)k;
+    }
+    if (tid == 0) *tail_q = 0u;
+    __syncthreads();
+    {
+        const bool big = wid < nbig;
+        const int my_pts = big ? pbuf_pts : pbuf2_pts;
+        uint32_t* b = big ? pbuf + wid * pbuf_pts : pbuf2 + (wid - nbig) * pbuf2_pts;
         ApPt* o = ap_out + wid * AP_OUT;
-        if (klen[k] > 0) {
-            // approxPolyDP makes many dependent passes over the points: from LDS when the border fits the wave's
-            // buffer (pbuf: LDS that is dead by now, pbuf_pts points per wave), else from the pool (L2)
+        for (;;) {
+            unsigned tk = 0;
+            if (lane == 0) tk = atomicAdd(tail_q, big ? 1u : 0x10000u);
+            tk = (unsigned)__builtin_amdgcn_readfirstlane((int)tk);
+            const int fr = (int)(tk & 0xffffu), bk = (int)(tk >> 16);
+            if (fr + bk >= nkept) break; // the first nkept tickets are the valid ones: every border exactly once
+            const int k = rank_of[big ? fr : nkept - 1 - bk];
             const int n = klen[k];
-            const uint32_t* src = pl + koff[k];
-            int nv;
-            if (n <= pbuf_pts) {
-                uint32_t* b = pbuf + wid * pbuf_pts;
-                for (int i = lane; i < n; i += 64) b[i] = src[i];
+            int ok = 0;
+            if (n > 0) {
+                const uint32_t* src = pl + koff[k];
+                int nv;
+                if (n <= my_pts) {
+                    for (int i = lane; i < n; i += 64) b[i] = src[i];
+                    __builtin_amdgcn_wave_barrier();
+                    nv = approx_poly_wave(b, n, o, ap_stack + wid * AP_STACK, lane);
+                } else {
+                    nv = approx_poly_wave(src, n, o, ap_stack + wid * AP_STACK, lane);
+                }
                 __builtin_amdgcn_wave_barrier();
-                nv = approx_poly_wave(b, n, o, ap_stack + wid * AP_STACK, lane);
-            } else {
-                nv = approx_poly_wave(src, n, o, ap_stack + wid * AP_STACK, lane);
+                ok = (nv == 4) && convex4(o);
+            }
+            if (lane == 0) {
+                rectflag[k] = ok;
+                if (ok && k < kept_cap) {
+                    ArKept kk;
+                    kk.off = koff[k]; kk.len = n;
+                    for (int j = 0; j < 4; j++) { kk.vx[j] = (short)o[j].x; kk.vy[j] = (short)o[j].y; }
+                    kept_out[(size_t)f * kept_cap + k] = kk;
+                }
             }
             __builtin_amdgcn_wave_barrier();
-            ok = (nv == 4) && convex4(o);
-        }
-        if (lane == 0) {
-            rectflag[k] = ok;
-            if (ok && k < kept_cap) {
-                ArKept kk;
-                kk.off = koff[k]; kk.len = klen[k];
-                for (int j = 0; j < 4; j++) { kk.vx[j] = (short)o[j].x; kk.vy[j] = (short)o[j].y; }
-                kept_out[(size_t)f * kept_cap + k] = kk;
-            }
         }
     }
     __syncthreads();
+#ifdef ORBFE_CT_TIMING
+    if (tid == 0) { tdbg[0] = tt1 - tt0; tdbg[1] = clock64() - tt1; }
+#endif
     if (tid == 0) { // ordered compaction of the rectangles (a few dozen)
         int nr = 0;
         for (int k = 0; k < nkept; k++)
@@ -337,6 +372,7 @@ __global__ __launch_bounds__(CT_PROBE_THREADS) void k_contours_t(const uint32_t*
 {
     extern __shared__ __align__(16) unsigned char ct_smem[];
     __shared__ int s_ncand, s_next, s_nkept, s_nlong, s_flags;
+    __shared__ unsigned s_tailq;
     const int tid = threadIdx.x, f = blockIdx.x;
     // as the fallback of k_contours_relay: only the frames that kernel gave up on
     if (only_flagged && !(counts[f * 4 + 2] & RL_FALLBACK_FLAGS)) return;
@@ -496,7 +532,8 @@ __global__ __launch_bounds__(CT_PROBE_THREADS) void k_contours_t(const uint32_t*
     if (only_flagged && tid == 0) s_ncand |= 1 << 30; // debug: this frame took the fallback (contours_tail syncs first)
     const int pbuf_pts = LDS_BITS ? (lds_bits_words / CT_WAVES) & ~3 : 0; // the LDS bit image is dead: point buffers
     contours_tail(f, tid, CT_THREADS, nkept, kkey, off_u, klen, koff, rectflag, ap_out, ap_stack, pl, kept_out, kept_cap,
-                  rects_out, rect_cap, counts, &s_flags, &s_ncand, (uint32_t*)ct_smem, pbuf_pts);
+                  rects_out, rect_cap, counts, &s_flags, &s_ncand, (uint16_t*)(ap_stack + CT_WAVES * AP_STACK), &s_tailq,
+                  CT_WAVES, (uint32_t*)ct_smem, pbuf_pts, nullptr, 0);
 #ifdef ORBFE_CT_TIMING
     if (tid == 0) {
         t5 = clock64();
@@ -597,6 +634,7 @@ __global__ __launch_bounds__(RL_THREADS) void k_contours_relay(
     __shared__ int s_next, s_nkept, s_flags, s_ncand, s_nmark, s_nsmall, s_pool, s_changed[2];
     __shared__ uint4 s_small[RL_SMALL_CAP]; // state key, length, pool offset, discovery key * 2 + is_hole
     __shared__ uint16_t s_lut[2048];
+    __shared__ unsigned s_tailq;
     const int tid = threadIdx.x, f = blockIdx.x, NT = RL_THREADS;
     const int wpr = (W + 2 + 31) >> 5, prow = H + 2;
     const int T = 1 << tbits, kmask = (1 << kshift) - 1, K = 1 << kshift;
@@ -1027,8 +1065,13 @@ __global__ __launch_bounds__(RL_THREADS) void k_contours_relay(
     __syncthreads();
     RL_STAMP();
     // ---- (g) the table is dead; its space holds the tail's arrays
+    // point buffers: 8 big ones in the bit image's space, 8 small ones behind the tail's arrays in the table's space
+    uint16_t* rank_of = (uint16_t*)(ap_stack + (RL_THREADS / 64) * AP_STACK);
+    uint32_t* pbuf2 = (uint32_t*)(rank_of + kept_cap);
+    const int pbuf2_pts = (int)(((size_t)12 << tbits) - ((unsigned char*)pbuf2 - uni)) / 4 / 8;
     contours_tail(f, tid, NT, s_nkept, kkey, off_u, klen, koff, rectflag, ap_out, ap_stack, pl, kept_out, kept_cap,
-                  rects_out, rect_cap, counts, &s_flags, &s_ncand, lbits, (lds_bits_words / (RL_THREADS / 64)) & ~3);
+                  rects_out, rect_cap, counts, &s_flags, &s_ncand, rank_of, &s_tailq, 8, lbits,
+                  (lds_bits_words / 8) & ~3, pbuf2, pbuf2_pts > 0 ? pbuf2_pts & ~3 : 0);
 #ifdef ORBFE_CT_TIMING
     if (tid == 0) {
         RL_STAMP();

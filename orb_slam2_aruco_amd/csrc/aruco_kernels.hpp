@@ -78,7 +78,7 @@ inline size_t relay_lds_bytes(int lds_bits_words, int kept_cap, int tbits)
     size_t b = ((size_t)lds_bits_words * 4 + 15) & ~(size_t)15;
     b += (size_t)kept_cap * 8 + (size_t)kept_cap * 4; // keys, pool offsets
     const size_t table = ((size_t)12 << tbits);
-    const size_t tail = (size_t)kept_cap * 12 + (size_t)(RL_THREADS / 64) * (AP_OUT + AP_STACK) * 8;
+    const size_t tail = (size_t)kept_cap * 12 + (size_t)(RL_THREADS / 64) * (AP_OUT + AP_STACK) * 8 + (size_t)kept_cap * 2;
     return b + (table > tail ? table : tail) + 16;
 }
 
@@ -89,6 +89,7 @@ inline size_t contours_lds_bytes(int lds_bits_words, int kept_cap)
     b += (size_t)kept_cap * 4 * 4;  // arena offsets, len, off, rect flag (the last three double as the long-walk queue)
     b += (size_t)CT_WAVES * AP_OUT * 8;
     b += (size_t)CT_WAVES * AP_STACK * 8;
+    b += (size_t)kept_cap * 2; // length ranking
     return b + 16;
 }
 

@@ -17,4 +17,5 @@ for legacy in (False, True):
         else:
             print("relay frame %d ticks: load_bits %d, markers %d, small %d, segments %d, lists %d, points %d, tail %d"
                   % ((f,) + tuple(out[:7])))
+            print("    tail: sort %d, approx %d" % tuple(out[8:10]))
         print("   ", det.counts(f))
