@@ -48,6 +48,7 @@ struct orbfe_extractor {
     int ncells_total = 0, ntiles = 0, out_total = 0, max_out_cap = 0, max_wcell = 0, max_hcell = 0;
     size_t pyr_fbytes = 0, blur_fbytes = 0, slots_fu32 = 0, keys_fu32 = 0;
     int keycap_lds = 0, nodecap = 0, veccap = 0;
+    std::vector<char> resize_tab_ok; // per level >= 1: k_resize_tab's 8-byte windows fit
     std::vector<size_t> tab_off; // per level >= 1: offsets (in ints) of xofs, xalpha, yofs, ybeta in d_tabs
     DevBuf d_geom, d_cellinfo, d_tiles, d_tabs, d_pattern, d_umax;
     DevBuf d_pyr, d_blur, d_slots, d_cellcnt, d_keys, d_lvlout, d_lvlcnt, d_lvloff, d_lvlncand, d_overflow, d_fallback,
@@ -125,6 +126,7 @@ struct orbfe_extractor {
         std::vector<uint32_t> cellinfo, tiles;
         std::vector<int> tabs;
         tab_off.assign((size_t)nlevels * 4, 0);
+        resize_tab_ok.assign((size_t)nlevels, 0);
         size_t pyr = 0, blur = 0, slots = 0, cand = 0;
         int out = 0, maxcap = 0, mwc = 0, mhc = 0;
         for (int l = 0; l < nlevels; l++) {
@@ -197,6 +199,14 @@ struct orbfe_extractor {
                     xal[dx] = (a0 & 0xffff) | (a1 << 16);
                 }
                 for (int dx = dw; dx < dwp; dx++) { xofs[dx] = xofs[dw - 1]; xal[dx] = xal[dw - 1]; }
+                // k_resize_tab reads columns sx[0] .. sx[3]+1 of a source row with one 8-byte load
+                bool ok = sw >= 8;
+                for (int x4 = 0; ok && x4 < dwp / 4; x4++) {
+                    const int w0 = std::min(xofs[x4 * 4], sw - 8);
+                    for (int k = 0; k < 4; k++)
+                        ok = ok && xofs[x4 * 4 + k] >= w0 && std::min(xofs[x4 * 4 + k] + 1, sw - 1) - w0 <= 7;
+                }
+                resize_tab_ok[l] = ok;
                 for (int dy = 0; dy < dh; dy++) {
                     float fy = (float)((dy + 0.5) * scale_y - 0.5);
                     int sy = orbfe_floor_d(fy);
@@ -205,6 +215,7 @@ struct orbfe_extractor {
                     yofs[dy] = sy;
                     ybe[dy] = (b0 & 0xffff) | (b1 << 16);
                 }
+                while (tabs.size() % 4) tabs.push_back(0); // k_resize_tab loads xofs/xal as int4
                 tab_off[l * 4 + 0] = tabs.size(); tabs.insert(tabs.end(), xofs.begin(), xofs.end());
                 tab_off[l * 4 + 1] = tabs.size(); tabs.insert(tabs.end(), xal.begin(), xal.end());
                 tab_off[l * 4 + 2] = tabs.size(); tabs.insert(tabs.end(), yofs.begin(), yofs.end());
@@ -280,9 +291,18 @@ struct orbfe_extractor {
             ImgView sv = (l == 1) ? src0 : ImgView{pyr.base + gp.img_off, nullptr, pyr_fbytes, gp.pitch};
             ImgView dv{pyr.base + g.img_off, pyr.base_w + g.img_off, pyr_fbytes, g.pitch};
             const int dw4 = (g.w + 3) / 4;
-            dim3 grid((dw4 + 63) / 64, (g.h + 7) / 8, B);
-            const double scale_x = 1. / ((double)g.w / gp.w), scale_y = 1. / ((double)g.h / gp.h);
-            hipLaunchKernelGGL(k_resize_level, grid, dim3(256), 0, s, sv, dv, gp.w, gp.h, dw4, g.h, scale_x, scale_y, g.w);
+            if (resize_tab_ok[l]) {
+                const int nthreads = dw4 * ((g.h + RS_ROWS - 1) / RS_ROWS);
+                const int* tb = d_tabs.as<int>();
+                hipLaunchKernelGGL(k_resize_tab, dim3((nthreads + 255) / 256, B), dim3(256), 0, s, sv, dv, gp.w, gp.h, dw4,
+                                   g.h, nthreads, tb + tab_off[l * 4 + 0], tb + tab_off[l * 4 + 1], tb + tab_off[l * 4 + 2],
+                                   tb + tab_off[l * 4 + 3]);
+            } else {
+                dim3 grid((dw4 + 63) / 64, (g.h + 7) / 8, B);
+                const double scale_x = 1. / ((double)g.w / gp.w), scale_y = 1. / ((double)g.h / gp.h);
+                hipLaunchKernelGGL(k_resize_level, grid, dim3(256), 0, s, sv, dv, gp.w, gp.h, dw4, g.h, scale_x, scale_y,
+                                   g.w);
+            }
         }
         timer.mark(s, "resize");
         {

@@ -86,6 +86,75 @@ __global__ __launch_bounds__(256) void k_resize_level(ImgView src, ImgView dst, 
     }
 }
 
+// Table-driven variant for the ORB pyramid (scale 1.2 between levels).  One thread = 4 adjacent output pixels x
+// RS_ROWS consecutive rows, threads numbered flat over (row group, x) so that no lane idles at the right edge.
+//   * the 8 source bytes a thread needs per source row (columns sx[0] .. sx[3]+1, at most 6 apart at this scale) come
+//     from ONE unaligned 8-byte load instead of 8 byte loads;
+//   * v_perm_b32 picks each (left, right) pixel pair out of the window, v_dot2_u32_u16 does left*a0 + right*a1;
+//   * the x coefficients (host tables, the cv::resize arithmetic of SURVEY App. B.2) are loaded once per thread and
+//     reused for all rows; the y coefficients are two table words per row.
+// The host checks that every window fits (resize_tab_ok) and otherwise launches k_resize_level.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t hdot(uint32_t pair, uint32_t al)
+{
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pair), __builtin_bit_cast(u16x2, al), 0u, false);
+}
+
+__global__ __launch_bounds__(256) void k_resize_tab(ImgView src, ImgView dst, int sw, int sh, int dw4, int dh,
+                                                    int nthreads, const int* __restrict__ xofs,
+                                                    const int* __restrict__ xal, const int* __restrict__ yofs,
+                                                    const int* __restrict__ ybe)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
+    if (t >= nthreads) return;
+    const int rg = t / dw4, x4 = t - rg * dw4;
+    const uint8_t* S = src.base + (size_t)f * src.fstride;
+    uint8_t* D = dst.base_w + (size_t)f * dst.fstride + (size_t)x4 * 4;
+    const int4 sx = *reinterpret_cast<const int4*>(xofs + x4 * 4);
+    const int4 al = *reinterpret_cast<const int4*>(xal + x4 * 4);
+    const int w0 = min(sx.x, sw - 8);
+    uint32_t sel[4];
+    {
+        const int s[4] = {sx.x, sx.y, sx.z, sx.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            sel[k] = (uint32_t)(s[k] - w0) | ((uint32_t)(min(s[k] + 1, sw - 1) - w0) << 16) | 0x0c000c00u;
+    }
+    const uint32_t a[4] = {(uint32_t)al.x, (uint32_t)al.y, (uint32_t)al.z, (uint32_t)al.w};
+    typedef unsigned long long u64_unaligned __attribute__((aligned(1)));
+    const int dy0 = rg * RS_ROWS;
+#pragma unroll
+    for (int r0 = 0; r0 < RS_ROWS; r0 += 4) {
+        unsigned long long wt[4], wb[4];
+        int bb[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) { // all loads of four rows in flight before the first use
+            const int dy = min(dy0 + r0 + r, dh - 1);
+            const int sy = yofs[dy];
+            bb[r] = ybe[dy];
+            // rows are NOT clamped like columns: cv::resize keeps the fractional weight and clips the row index
+            wt[r] = *reinterpret_cast<const u64_unaligned*>(S + (size_t)min(max(sy, 0), sh - 1) * src.pitch + w0);
+            wb[r] = *reinterpret_cast<const u64_unaligned*>(S + (size_t)min(max(sy + 1, 0), sh - 1) * src.pitch + w0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int dy = dy0 + r0 + r;
+            if (dy >= dh) break;
+            const uint32_t b0 = (uint32_t)bb[r] & 0xffffu, b1 = (uint32_t)bb[r] >> 16;
+            const uint32_t tl = (uint32_t)wt[r], th = (uint32_t)(wt[r] >> 32), bl = (uint32_t)wb[r], bh = (uint32_t)(wb[r] >> 32);
+            uint32_t packed = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t h0 = hdot(__builtin_amdgcn_perm(th, tl, sel[k]), a[k]);
+                const uint32_t h1 = hdot(__builtin_amdgcn_perm(bh, bl, sel[k]), a[k]);
+                const uint32_t v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2u) >> 2;
+                packed |= (v & 0xffu) << (8 * k);
+            }
+            *reinterpret_cast<uint32_t*>(D + (size_t)dy * dst.pitch) = packed;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ FAST ----
 // ring offsets of the 9-16 segment test (radius 3), k = 0..15
 __device__ __constant__ signed char c_ring_dx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
