@@ -179,9 +179,8 @@ struct orbfe_extractor {
             maxcap = std::max(maxcap, g.out_cap);
             g.scale = mvScaleFactor[l];
             g.kp_size = (float)(int)(31 * mvScaleFactor[l]);
-            for (int ty = 0; ty < (g.h + 63) / 64; ty++)
-                for (int tx = 0; tx < (g.w + 63) / 64; tx++)
-                    tiles.push_back((uint32_t)l | ((uint32_t)tx << 4) | ((uint32_t)ty << 18));
+            for (int tx = 0; tx < (g.w + 63) / 64; tx++) // k_blur7: one workgroup per 64-column strip, long strips first
+                tiles.push_back((uint32_t)l | ((uint32_t)tx << 4));
             if (l > 0) {
                 // cv::resize(INTER_LINEAR) coefficient tables, OpenCV 3.4
                 const int sw = geom[l - 1].w, sh = geom[l - 1].h, dw = g.w, dh = g.h;

@@ -1163,82 +1163,133 @@ __device__ __forceinline__ int reflect101(int p, int n)
     return p;
 }
 
-__global__ __launch_bounds__(256) void k_blur7(ImgView src0, ImgView pyr, ImgView blur,
-                                               const LevelGeom* __restrict__ geom, const uint32_t* __restrict__ tiles)
+// Instruction count, not bandwidth, limits this kernel, so both passes run on the packed dot-product instructions:
+//   horizontal: a thread loads the 12 bytes around 4 adjacent outputs of one row as three dwords; every 7-tap sum is
+//               two v_dot4_u32_u8 on byte windows cut out with v_alignbyte (sums <= 257 * 255 fit 16 bits);
+//   transpose:  the sums go to LDS column-major (one column = 70 consecutive u16), so that
+//   vertical:   a thread takes one column and 4 consecutive rows, reads ten sums as five dwords and forms each output
+//               from four v_dot2_u32_u16 on (row, row+1) pairs; odd rows use pairs re-cut with v_alignbit.
+#define BL_CP 74 // u16 per LDS column: 70 rows + pad, an odd number of dwords (conflict-free across columns)
+
+__device__ __forceinline__ uint32_t bl_dot4(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_udot4(a, b, c, false); }
+__device__ __forceinline__ uint32_t bl_dot2(uint32_t a, uint32_t b, uint32_t c)
 {
-    __shared__ __align__(16) uint8_t sin[22][72];   // 64 + 6 columns, padded to a multiple of 4
-    __shared__ __align__(16) uint16_t sh[22][64];   // horizontal 7-tap sums (<= 257 * 255 fits 16 bits)
-    const uint32_t t = tiles[blockIdx.x];
-    const int level = t & 15, tx0 = ((t >> 4) & 0x3fff) * 64, tyb = (t >> 18) * 64;
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b), c, false);
+}
+
+// One workgroup = one 64-column strip of a level, walked top to bottom in 64-row tiles.  The loads of the next tile's
+// rows are in flight while the vertical pass of the current one runs, and the six rows of horizontal sums two tiles
+// share are carried over in LDS instead of being recomputed, so every source row is fetched once per strip.
+__device__ __forceinline__ void bl_load_rows(const uint8_t* img, int pitch, const LevelGeom& g, int tx0, int row0,
+                                             int first_rr, int nrr, int tid, int nitems, uint32_t (*w)[3])
+{
+    typedef uint32_t u32_unaligned __attribute__((aligned(1))); // level 0 is the caller's buffer
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        if (k >= nitems) break;
+        const int it = tid + 256 * k;
+        const int rr = first_rr + (it >> 4), x = tx0 + 4 * (it & 15);
+        w[k][0] = w[k][1] = w[k][2] = 0;
+        if (rr < nrr && x < g.bpitch) {
+            const uint8_t* row = img + (size_t)reflect101(row0 + rr, g.h) * pitch;
+            if (x >= 4 && x + 8 <= g.w) {
+                const u32_unaligned* p = reinterpret_cast<const u32_unaligned*>(row + x - 4);
+                w[k][0] = p[0]; w[k][1] = p[1]; w[k][2] = p[2];
+            } else { // the window crosses the left or right image border: BORDER_REFLECT_101 byte by byte
+#pragma unroll
+                for (int j = 1; j <= 10; j++)
+                    w[k][j >> 2] |= (uint32_t)row[reflect101(x - 4 + j, g.w)] << (8 * (j & 3));
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void bl_hsum_rows(uint16_t* sh, int first_rr, int nrr, int tid, int nitems, const uint32_t (*w)[3])
+{
+    constexpr uint32_t TA = 18u | (34u << 8) | (49u << 16) | (55u << 24); // taps 0..3
+    constexpr uint32_t TB = 49u | (34u << 8) | (18u << 16);               // taps 4..6
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        if (k >= nitems) break;
+        const int it = tid + 256 * k;
+        const int rr = first_rr + (it >> 4), c = 4 * (it & 15);
+        if (rr < nrr) {
+            // byte j of the 12-byte window is pixel x - 4 + j; output i uses bytes i+1 .. i+7
+            const uint32_t w0 = w[k][0], w1 = w[k][1], w2 = w[k][2];
+            const uint32_t s0 = bl_dot4(__builtin_amdgcn_alignbyte(w1, w0, 1), TA, bl_dot4(__builtin_amdgcn_alignbyte(w2, w1, 1), TB, 0));
+            const uint32_t s1 = bl_dot4(__builtin_amdgcn_alignbyte(w1, w0, 2), TA, bl_dot4(__builtin_amdgcn_alignbyte(w2, w1, 2), TB, 0));
+            const uint32_t s2 = bl_dot4(__builtin_amdgcn_alignbyte(w1, w0, 3), TA, bl_dot4(__builtin_amdgcn_alignbyte(w2, w1, 3), TB, 0));
+            const uint32_t s3 = bl_dot4(w1, TA, bl_dot4(w2, TB, 0));
+            sh[(c + 0) * BL_CP + rr] = (uint16_t)s0;
+            sh[(c + 1) * BL_CP + rr] = (uint16_t)s1;
+            sh[(c + 2) * BL_CP + rr] = (uint16_t)s2;
+            sh[(c + 3) * BL_CP + rr] = (uint16_t)s3;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_blur7(ImgView src0, ImgView pyr, ImgView blur,
+                                               const LevelGeom* __restrict__ geom, const uint32_t* __restrict__ strips)
+{
+    __shared__ __align__(16) uint16_t sh[64 * BL_CP];
+    const uint32_t t = strips[blockIdx.x];
+    const int level = t & 15, tx0 = (int)(t >> 4) * 64;
     const int f = blockIdx.y;
     const LevelGeom g = geom[level];
     const uint8_t* img = (level == 0) ? src0.base + (size_t)f * src0.fstride
                                       : pyr.base + (size_t)f * pyr.fstride + g.img_off;
     const int pitch = (level == 0) ? src0.pitch : g.pitch;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    for (int ty0 = tyb; ty0 < tyb + 64 && ty0 < g.h; ty0 += 16) {
-    __syncthreads();
-    // stage the strip + 3-px halo: lane = column (reflected once per thread), wave = row; loads first, stores after
+    const int tid = threadIdx.x;
+    uint8_t* D = blur.base_w + (size_t)f * blur.fstride + g.blur_off;
+    constexpr uint32_t V01 = 18u | (34u << 16), V23 = 49u | (55u << 16), V45 = 49u | (34u << 16), V6 = 18u, V6H = 18u << 16;
+    const int c4 = 4 * (tid & 15), q = tid >> 4;
+    const int x = tx0 + c4;
+
+    // LDS row rr of a tile that starts at image row tyb holds the horizontal sums of image row tyb - 3 + rr
+    uint32_t w[5][3];
     {
-        const int xa = reflect101(tx0 + lane - 3, g.w);
-        const int xb = reflect101(tx0 + 64 + (lane & 7) - 3, g.w);
-        uint8_t va[6], vb[6];
+        const int nrr = min(64, g.h) + 6;
+        bl_load_rows(img, pitch, g, tx0, -3, 0, nrr, tid, 5, w);
+        bl_hsum_rows(sh, 0, nrr, tid, 5, w);
+    }
+    for (int tyb = 0; tyb < g.h; tyb += 64) {
+        const int nrows_out = min(64, g.h - tyb);
+        const bool more = tyb + 64 < g.h;
+        const int nrr_next = more ? min(64, g.h - tyb - 64) + 6 : 0;
+        __syncthreads(); // sums of this tile complete
+        if (more) bl_load_rows(img, pitch, g, tx0, tyb + 64 - 3, 6, nrr_next, tid, 4, w); // rows 6.. of the next tile
+        // ---- vertical pass: one thread = 4 adjacent columns x 4 consecutive rows, stored as four aligned dwords
+        if (4 * q < nrows_out && x < g.bpitch) {
+            uint32_t out[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int k = 0; k < 6; k++) {
-            const int r = wid + 4 * k;
-            const uint8_t* row = img + (size_t)reflect101(ty0 + min(r, 21) - 3, g.h) * pitch;
-            va[k] = row[xa];
-            vb[k] = row[xb];
-        }
-#pragma unroll
-        for (int k = 0; k < 6; k++) {
-            const int r = wid + 4 * k;
-            if (r < 22) {
-                sin[r][lane] = va[k];
-                if (lane < 6) sin[r][64 + lane] = vb[k];
+            for (int j = 0; j < 4; j++) {
+                const uint32_t* hp = reinterpret_cast<const uint32_t*>(&sh[(c4 + j) * BL_CP + 4 * q]);
+                const uint32_t d0 = hp[0], d1 = hp[1], d2 = hp[2], d3 = hp[3], d4 = hp[4];
+                const uint32_t a01 = __builtin_amdgcn_alignbit(d1, d0, 16), a12 = __builtin_amdgcn_alignbit(d2, d1, 16);
+                const uint32_t a23 = __builtin_amdgcn_alignbit(d3, d2, 16), a34 = __builtin_amdgcn_alignbit(d4, d3, 16);
+                const uint32_t o0 = bl_dot2(d0, V01, bl_dot2(d1, V23, bl_dot2(d2, V45, bl_dot2(d3, V6, 32768u))));
+                const uint32_t o1 = bl_dot2(a01, V01, bl_dot2(a12, V23, bl_dot2(a23, V45, bl_dot2(a34, V6, 32768u))));
+                const uint32_t o2 = bl_dot2(d1, V01, bl_dot2(d2, V23, bl_dot2(d3, V45, bl_dot2(d4, V6, 32768u))));
+                const uint32_t o3 = bl_dot2(a12, V01, bl_dot2(a23, V23, bl_dot2(a34, V45, bl_dot2(d4, V6H, 32768u))));
+                out[0] |= min(o0 >> 16, 255u) << (8 * j);
+                out[1] |= min(o1 >> 16, 255u) << (8 * j);
+                out[2] |= min(o2 >> 16, 255u) << (8 * j);
+                out[3] |= min(o3 >> 16, 255u) << (8 * j);
             }
-        }
-    }
-    __syncthreads();
-    // horizontal pass: one item = 4 adjacent outputs of one row, from three aligned 32-bit LDS reads
-    for (int i = tid; i < 22 * 16; i += 256) {
-        const int r = i >> 4, c4 = (i & 15) * 4;
-        const uint32_t* w = reinterpret_cast<const uint32_t*>(&sin[r][c4]);
-        const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
-        const int b0 = w0 & 255, b1 = (w0 >> 8) & 255, b2 = (w0 >> 16) & 255, b3 = w0 >> 24;
-        const int b4 = w1 & 255, b5 = (w1 >> 8) & 255, b6 = (w1 >> 16) & 255, b7 = w1 >> 24;
-        const int b8 = w2 & 255, b9 = (w2 >> 8) & 255;
-        const uint32_t s0 = 18 * (b0 + b6) + 34 * (b1 + b5) + 49 * (b2 + b4) + 55 * b3;
-        const uint32_t s1 = 18 * (b1 + b7) + 34 * (b2 + b6) + 49 * (b3 + b5) + 55 * b4;
-        const uint32_t s2 = 18 * (b2 + b8) + 34 * (b3 + b7) + 49 * (b4 + b6) + 55 * b5;
-        const uint32_t s3 = 18 * (b3 + b9) + 34 * (b4 + b8) + 49 * (b5 + b7) + 55 * b6;
-        uint2 o;
-        o.x = s0 | (s1 << 16);
-        o.y = s2 | (s3 << 16);
-        *reinterpret_cast<uint2*>(&sh[r][c4]) = o;
-    }
-    __syncthreads();
-    // vertical pass: 4 outputs per thread from seven 64-bit LDS reads, one aligned 32-bit store
-    const int r = tid >> 4, c4 = (tid & 15) * 4;
-    int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+            const int y0 = tyb + 4 * q;
 #pragma unroll
-    for (int k = 0; k < 7; k++) {
-        const int tap = (k == 0 || k == 6) ? 18 : (k == 1 || k == 5) ? 34 : (k == 2 || k == 4) ? 49 : 55;
-        const uint2 v = *reinterpret_cast<const uint2*>(&sh[r + k][c4]);
-        a0 += tap * (int)(v.x & 0xffff);
-        a1 += tap * (int)(v.x >> 16);
-        a2 += tap * (int)(v.y & 0xffff);
-        a3 += tap * (int)(v.y >> 16);
+            for (int j = 0; j < 4; j++)
+                if (y0 + j < g.h) *reinterpret_cast<uint32_t*>(D + x + (size_t)(y0 + j) * g.bpitch) = out[j];
+        }
+        if (!more) break;
+        // ---- carry rows 64..69 (= rows 0..5 of the next tile) over: 3 dwords per column
+        uint32_t carry = 0;
+        const int cc = tid / 3, cd = tid - cc * 3;
+        if (tid < 192) carry = reinterpret_cast<const uint32_t*>(&sh[cc * BL_CP + 64])[cd];
+        __syncthreads(); // every read of this tile's sums done
+        if (tid < 192) reinterpret_cast<uint32_t*>(&sh[cc * BL_CP])[cd] = carry;
+        bl_hsum_rows(sh, 6, nrr_next, tid, 4, w);
     }
-    const int v0 = min((a0 + 32768) >> 16, 255), v1 = min((a1 + 32768) >> 16, 255);
-    const int v2 = min((a2 + 32768) >> 16, 255), v3 = min((a3 + 32768) >> 16, 255);
-    const uint32_t packed = (uint32_t)v0 | ((uint32_t)v1 << 8) | ((uint32_t)v2 << 16) | ((uint32_t)v3 << 24);
-    const int y = ty0 + r, x = tx0 + c4;
-    if (y < g.h && x < g.bpitch) {
-        uint8_t* D = blur.base_w + (size_t)f * blur.fstride + g.blur_off + (size_t)y * g.bpitch;
-        *reinterpret_cast<uint32_t*>(D + x) = packed;
-    }
-    } // strips
 }
 
 // ------------------------------------------------------------------------------------------------ describe --
