@@ -293,9 +293,10 @@ struct orbfe_extractor {
             if (resize_tab_ok[l]) {
                 const int nthreads = dw4 * ((g.h + RS_ROWS - 1) / RS_ROWS);
                 const int* tb = d_tabs.as<int>();
-                hipLaunchKernelGGL(k_resize_tab, dim3((nthreads + 255) / 256, B), dim3(256), 0, s, sv, dv, gp.w, gp.h, dw4,
+                const int nx = (nthreads + 255) / 256;
+                hipLaunchKernelGGL(k_resize_tab, dim3(xcd_grid(nx * B)), dim3(256), 0, s, sv, dv, gp.w, gp.h, dw4,
                                    g.h, nthreads, tb + tab_off[l * 4 + 0], tb + tab_off[l * 4 + 1], tb + tab_off[l * 4 + 2],
-                                   tb + tab_off[l * 4 + 3]);
+                                   tb + tab_off[l * 4 + 3], nx, nx * B);
             } else {
                 dim3 grid((dw4 + 63) / 64, (g.h + 7) / 8, B);
                 const double scale_x = 1. / ((double)g.w / gp.w), scale_y = 1. / ((double)g.h / gp.h);
@@ -314,10 +315,11 @@ struct orbfe_extractor {
                                     a16((size_t)list_cap * 2));
             ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fast_cells),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(k_fast_cells, dim3((ncells_total + 3) / 4, B), dim3(256), lds, s, src0, pyr, dg,
+            const int nx = (ncells_total + 3) / 4;
+            hipLaunchKernelGGL(k_fast_cells, dim3(xcd_grid(nx * B)), dim3(256), lds, s, src0, pyr, dg,
                                d_cellinfo.as<uint32_t>(), d_slots.as<uint32_t>(), slots_fu32,
                                d_cellcnt.as<int32_t>(), ncells_total, iniThFAST, minThFAST, roi_pitch, roi_rows,
-                               map_pitch, map_rows, list_cap);
+                               map_pitch, map_rows, list_cap, nx, nx * B);
         }
         timer.mark(s, "fast_cells");
         {
@@ -328,7 +330,7 @@ struct orbfe_extractor {
             const size_t lds_p = qp_lds_bytes(max_ini, D, nodecap, veccap);
             ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_distribute_pyr),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
-            hipLaunchKernelGGL(k_distribute_pyr, dim3(nlevels, B), dim3(64), lds_p, s, dg, d_slots.as<uint32_t>(),
+            hipLaunchKernelGGL(k_distribute_pyr, dim3(nlevels, B), dim3(QP_THREADS), lds_p, s, dg, d_slots.as<uint32_t>(),
                                slots_fu32, d_cellcnt.as<int32_t>(), ncells_total, d_lvlout.as<uint32_t>(), out_total,
                                d_lvlcnt.as<int32_t>(), nlevels, d_lvlncand.as<int32_t>(), d_fallback.as<int32_t>(), D,
                                nodecap, veccap);
@@ -349,11 +351,13 @@ struct orbfe_extractor {
         hipLaunchKernelGGL(k_level_offsets, dim3(B), dim3(256), 0, s, d_lvlcnt.as<int32_t>(), d_lvloff.as<int32_t>(),
                            d_n, nlevels, B, capacity, d_overflow.as<int32_t>(), dg, d_lvlout.as<uint32_t>(), out_total,
                            d_flatkv.as<uint32_t>(), d_flatlvl.as<uint8_t>());
-        hipLaunchKernelGGL(k_blur7, dim3(ntiles, B), dim3(256), 0, s, src0, pyr, blur, dg, d_tiles.as<uint32_t>());
+        hipLaunchKernelGGL(k_blur7, dim3(xcd_grid(ntiles * B)), dim3(256), 0, s, src0, pyr, blur, dg,
+                           d_tiles.as<uint32_t>(), ntiles, ntiles * B);
         timer.mark(s, "blur7");
-        hipLaunchKernelGGL(k_orient_describe, dim3((std::min(capacity, max_keypoints()) + 3) / 4, B), dim3(256), 0, s, src0, pyr,
-                           blur, dg, d_flatkv.as<uint32_t>(), d_flatlvl.as<uint8_t>(), d_n, nlevels,
-                           d_pattern.as<uint32_t>(), d_umax.as<int>(), d_kps_out, d_desc_out, capacity);
+        const int okx = (std::min(capacity, max_keypoints()) + 3) / 4;
+        hipLaunchKernelGGL(k_orient_describe, dim3(xcd_grid(okx * B)), dim3(256), 0, s, src0, pyr, blur, dg,
+                           d_flatkv.as<uint32_t>(), d_flatlvl.as<uint8_t>(), d_n, nlevels, d_pattern.as<uint32_t>(),
+                           d_umax.as<int>(), d_kps_out, d_desc_out, capacity, okx, okx * B);
         timer.mark(s, "orient_describe");
         ORBFE_HIP(hipGetLastError());
         return ORBFE_OK;

@@ -103,9 +103,11 @@ __device__ __forceinline__ uint32_t hdot(uint32_t pair, uint32_t al)
 __global__ __launch_bounds__(256) void k_resize_tab(ImgView src, ImgView dst, int sw, int sh, int dw4, int dh,
                                                     int nthreads, const int* __restrict__ xofs,
                                                     const int* __restrict__ xal, const int* __restrict__ yofs,
-                                                    const int* __restrict__ ybe)
+                                                    const int* __restrict__ ybe, int nx, int total)
 {
-    const int t = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
+    int bx, f;
+    if (!xcd_remap(nx, total, bx, f)) return;
+    const int t = bx * 256 + threadIdx.x;
     if (t >= nthreads) return;
     const int rg = t / dw4, x4 = t - rg * dw4;
     const uint8_t* S = src.base + (size_t)f * src.fstride;
@@ -234,11 +236,13 @@ __global__ __launch_bounds__(256) void k_fast_cells(ImgView src0, ImgView pyr, c
                                                     const uint32_t* __restrict__ cellinfo, uint32_t* __restrict__ slots,
                                                     size_t slots_fstride, int32_t* __restrict__ cellcnt,
                                                     int ncells_total, int iniTh, int minTh, int roi_pitch, int roi_rows,
-                                                    int map_pitch, int map_rows, int list_cap)
+                                                    int map_pitch, int map_rows, int list_cap, int nx, int total)
 {
     extern __shared__ __align__(16) unsigned char fc_smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int cell = blockIdx.x * 4 + wid, f = blockIdx.y;
+    int bx, f;
+    if (!xcd_remap(nx, total, bx, f)) return;
+    const int cell = bx * 4 + wid;
     if (cell >= ncells_total) return;
     const size_t roi_bytes = ((size_t)roi_pitch * roi_rows + 15) & ~(size_t)15;
     const size_t map_bytes = ((size_t)map_pitch * map_rows + 15) & ~(size_t)15;
@@ -799,7 +803,7 @@ __device__ __forceinline__ int wave_excl_scan(int v, int lane, int& total)
     return incl - v;
 }
 
-__global__ __launch_bounds__(64) void k_distribute_pyr(const LevelGeom* __restrict__ geom, const uint32_t* __restrict__ slots,
+__global__ __launch_bounds__(QP_THREADS) void k_distribute_pyr(const LevelGeom* __restrict__ geom, const uint32_t* __restrict__ slots,
                                                        size_t slots_fstride, const int32_t* __restrict__ cellcnt,
                                                        int ncells_total, uint32_t* __restrict__ lvl_out, int out_fstride,
                                                        int32_t* __restrict__ lvl_cnt, int nlevels,
@@ -807,7 +811,10 @@ __global__ __launch_bounds__(64) void k_distribute_pyr(const LevelGeom* __restri
                                                        int D, int nodecap, int veccap)
 {
     extern __shared__ __align__(16) unsigned char qp_smem[];
-    const int lane = threadIdx.x;
+    __shared__ int s_ncand;
+    // QP_THREADS threads build the leaf counts (the only part that is parallel over candidates), then one wave runs the
+    // tree logic
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int level = blockIdx.x, f = blockIdx.y;
     const LevelGeom g = geom[level];
     const int nIni = g.nIni;
@@ -833,16 +840,17 @@ __global__ __launch_bounds__(64) void k_distribute_pyr(const LevelGeom* __restri
     // info word: count (20 bits) | depth << 20 (4 bits) | nomore << 24
 
     const int fl_idx = f * nlevels + level;
-    for (int i = lane; i < (T + 1) / 2 + 2; i += 64) cnt32[i] = 0;
-    for (int i = lane; i < nleaf; i += 64) best[i] = 0ull;
-    QT_SYNC();
+    for (int i = tid; i < (T + 1) / 2 + 2; i += QP_THREADS) cnt32[i] = 0;
+    for (int i = tid; i < nleaf; i += QP_THREADS) best[i] = 0ull;
+    if (tid == 0) s_ncand = 0;
+    __syncthreads();
 
     // ---- one pass over the level's candidates (straight from the per-cell slots; order is carried as (cell, k))
     const int32_t* ccnt = cellcnt + (size_t)f * ncells_total + g.cell_first;
     const uint32_t* cslots = slots + (size_t)f * slots_fstride + g.slot_off;
     const int H = g.maxBY - 16;
     int n = 0;
-    for (int c0 = 0; c0 < g.ncells; c0 += 64) {
+    for (int c0 = wid * 64; c0 < g.ncells; c0 += QP_THREADS) {
         const int c = c0 + lane;
         const int k_cnt = (c < g.ncells) ? ccnt[c] : 0;
         n += k_cnt;
@@ -877,8 +885,11 @@ __global__ __launch_bounds__(64) void k_distribute_pyr(const LevelGeom* __restri
         }
     }
     n = wave_sum(n);
+    if (lane == 0) atomicAdd(&s_ncand, n);
+    __syncthreads();
+    if (wid != 0) return;
+    n = s_ncand;
     if (lane == 0) { lvl_ncand[fl_idx] = n; fallback[fl_idx] = 0; }
-    QT_SYNC();
     if (n == 0) {
         if (lane == 0) lvl_cnt[fl_idx] = 0;
         return;
@@ -1229,12 +1240,14 @@ __device__ __forceinline__ void bl_hsum_rows(uint16_t* sh, int first_rr, int nrr
 }
 
 __global__ __launch_bounds__(256) void k_blur7(ImgView src0, ImgView pyr, ImgView blur,
-                                               const LevelGeom* __restrict__ geom, const uint32_t* __restrict__ strips)
+                                               const LevelGeom* __restrict__ geom, const uint32_t* __restrict__ strips,
+                                               int nx, int total)
 {
     __shared__ __align__(16) uint16_t sh[64 * BL_CP];
-    const uint32_t t = strips[blockIdx.x];
+    int bx, f;
+    if (!xcd_remap(nx, total, bx, f)) return;
+    const uint32_t t = strips[bx];
     const int level = t & 15, tx0 = (int)(t >> 4) * 64;
-    const int f = blockIdx.y;
     const LevelGeom g = geom[level];
     const uint8_t* img = (level == 0) ? src0.base + (size_t)f * src0.fstride
                                       : pyr.base + (size_t)f * pyr.fstride + g.img_off;
@@ -1302,11 +1315,12 @@ __global__ __launch_bounds__(256) void k_orient_describe(ImgView src0, ImgView p
                                                          const int32_t* __restrict__ n_out, int nlevels,
                                                          const uint32_t* __restrict__ pattern32 /*256 x (x0,y0,x1,y1) i8*/,
                                                          const int* __restrict__ umax, orbfe_keypoint* __restrict__ kps,
-                                                         uint8_t* __restrict__ desc, int capacity)
+                                                         uint8_t* __restrict__ desc, int capacity, int nx, int total)
 {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int f = blockIdx.y;
-    const int oidx = blockIdx.x * 4 + wid; // flat index over the frame's keypoints (levels concatenated ascending)
+    int bx, f;
+    if (!xcd_remap(nx, total, bx, f)) return;
+    const int oidx = bx * 4 + wid; // flat index over the frame's keypoints (levels concatenated ascending)
     if (oidx >= n_out[f]) return;
     const uint32_t kv = flat_kv[(size_t)f * capacity + oidx];
     const int level = __builtin_amdgcn_readfirstlane((int)flat_lvl[(size_t)f * capacity + oidx]);

@@ -41,18 +41,36 @@ struct LevelGeom {
     float kp_size;       // (float)(int)(31 * scale) (:837)
 };
 
+// The hardware hands workgroups to the 8 XCDs round-robin by linear workgroup id, and every XCD has its own L2.
+// Kernels whose workgroups of one frame read overlapping image regions are launched as a 1-D grid of
+// xcd_grid(nx * nframes) workgroups and call xcd_remap() for (bx, f): consecutive logical ids -- a frame's nx
+// workgroups -- then run on the same XCD and share its L2 instead of fetching the same lines into all eight.
+inline int xcd_grid(int total) { return ((total + 7) / 8) * 8; }
+#if defined(__HIPCC__)
+__device__ __forceinline__ bool xcd_remap(int nx, int total, int& bx, int& f)
+{
+    const int wg = blockIdx.x, per = (total + 7) >> 3;
+    const int logical = (wg & 7) * per + (wg >> 3);
+    if (logical >= total) return false;
+    f = logical / nx;
+    bx = logical - f * nx;
+    return true;
+}
+#endif
+
 __global__ void k_resize_level(ImgView src, ImgView dst, int sw, int sh, int dw4, int dh, double scale_x,
                                double scale_y, int dw);
 #define RS_ROWS 8
 __global__ void k_resize_tab(ImgView src, ImgView dst, int sw, int sh, int dw4, int dh, int nthreads, const int* xofs,
-                             const int* xal, const int* yofs, const int* ybe);
+                             const int* xal, const int* yofs, const int* ybe, int nx, int total);
 __global__ void k_fast_cells(ImgView src0, ImgView pyr, const LevelGeom* geom, const uint32_t* cellinfo,
                              uint32_t* slots, size_t slots_fstride, int32_t* cellcnt, int ncells_total, int iniTh,
-                             int minTh, int roi_pitch, int roi_rows, int map_pitch, int map_rows, int list_cap);
+                             int minTh, int roi_pitch, int roi_rows, int map_pitch, int map_rows, int list_cap, int nx, int total);
 __global__ void k_distribute(const LevelGeom* geom, const uint32_t* slots, size_t slots_fstride,
                              const int32_t* cellcnt, int ncells_total, uint32_t* keyscratch, size_t keys_fstride,
                              uint32_t* lvl_out, int out_fstride, int32_t* lvl_cnt, int nlevels, int32_t* lvl_ncand,
                              int keycap_lds, int nodecap, int veccap, const int32_t* only_flagged);
+#define QP_THREADS 256
 __global__ void k_distribute_pyr(const LevelGeom* geom, const uint32_t* slots, size_t slots_fstride,
                                  const int32_t* cellcnt, int ncells_total, uint32_t* lvl_out, int out_fstride,
                                  int32_t* lvl_cnt, int nlevels, int32_t* lvl_ncand, int32_t* fallback, int D,
@@ -70,11 +88,12 @@ inline size_t qp_lds_bytes(int nIni, int D, int nodecap, int veccap)
 __global__ void k_level_offsets(const int32_t* lvl_cnt, int32_t* lvl_off, int32_t* n_out, int nlevels, int nframes,
                                 int capacity, int32_t* overflow, const LevelGeom* geom, const uint32_t* lvl_out,
                                 int out_fstride, uint32_t* flat_kv, uint8_t* flat_lvl);
-__global__ void k_blur7(ImgView src0, ImgView pyr, ImgView blur, const LevelGeom* geom, const uint32_t* tiles);
+__global__ void k_blur7(ImgView src0, ImgView pyr, ImgView blur, const LevelGeom* geom, const uint32_t* strips, int nx,
+                        int total);
 __global__ void k_orient_describe(ImgView src0, ImgView pyr, ImgView blur, const LevelGeom* geom,
                                   const uint32_t* flat_kv, const uint8_t* flat_lvl, const int32_t* n_out, int nlevels,
                                   const uint32_t* pattern32, const int* umax, orbfe_keypoint* kps, uint8_t* desc,
-                                  int capacity);
+                                  int capacity, int nx, int total);
 __global__ void k_unpack_keys(const uint32_t* in, int n, int add, orbfe_keypoint* out);
 
 inline size_t qt_lds_bytes(int keycap_lds, int nodecap, int veccap)
