@@ -103,7 +103,14 @@ __global__ void k_knn2_merge(const int32_t* __restrict__ pidx, const int32_t* __
 //   second-best with the "already matched better" skip, ratio + TH_LOW tests, mutual-uniqueness bookkeeping,
 //   rotation histogram, ComputeThreeMaxima, final vbPrevMatched update.
 #define SFI_MAXL0 1024
-__global__ __launch_bounds__(256) void k_search_init(const orbfe_keypoint* __restrict__ kps,
+#define SFI_THREADS 1024
+#define SFI_ROW 64       // candidates of a query that live in LDS; later ones go to the query's global row
+#define SFI_L0_LDS 256   // level-0 keypoints of F2 (by rank) whose position and descriptor are cached in LDS
+#define SFI_ROWQ 224     // queries whose first SFI_ROW candidates live in LDS
+// dynamic LDS: F2 positions, F2 descriptors, per-query candidate counts, candidate rows (rank u16, distance u8)
+inline size_t sfi_lds_bytes() { return (size_t)SFI_L0_LDS * 8 + (size_t)SFI_L0_LDS * 32 + SFI_MAXL0 * 2 + (size_t)SFI_ROWQ * SFI_ROW * 3; }
+
+__global__ __launch_bounds__(SFI_THREADS) void k_search_init(const orbfe_keypoint* __restrict__ kps,
                                                      const uint8_t* __restrict__ desc, const int32_t* __restrict__ nkp,
                                                      int capacity, int cols, int rows, float window, float nnratio,
                                                      int check_ori, const float* __restrict__ prev_in,
@@ -113,6 +120,7 @@ __global__ __launch_bounds__(256) void k_search_init(const orbfe_keypoint* __res
                                                      int row_stride, int32_t* __restrict__ scratch /*3*capacity per pair*/,
                                                      int32_t* __restrict__ overflow)
 {
+    extern __shared__ __align__(16) unsigned char sfi_smem[];
     __shared__ uint32_t s_sorted[SFI_MAXL0]; // (cell << 16) | index, ascending
     __shared__ int s_hist[30];
     __shared__ int s_nl0, s_nq;
@@ -121,6 +129,11 @@ __global__ __launch_bounds__(256) void k_search_init(const orbfe_keypoint* __res
     __shared__ int s_v21[SFI_MAXL0];         //   in s_sorted (only level-0 keypoints of F2 can ever be matched)
     __shared__ float s_ang1[SFI_MAXL0], s_ang2[SFI_MAXL0];
     __shared__ signed char s_rotbin[SFI_MAXL0]; // per query: histogram bin or -1
+    float2* s2xy = (float2*)sfi_smem;
+    uint4* s2d = (uint4*)(s2xy + SFI_L0_LDS);
+    uint16_t* s_cnt = (uint16_t*)(s2d + 2 * SFI_L0_LDS);
+    uint16_t* s_ridx = s_cnt + SFI_MAXL0;
+    uint8_t* s_rdist = (uint8_t*)(s_ridx + SFI_ROWQ * SFI_ROW);
 
     const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const orbfe_keypoint* k1 = kps + (size_t)p * capacity;
@@ -129,20 +142,21 @@ __global__ __launch_bounds__(256) void k_search_init(const orbfe_keypoint* __res
     const uint8_t* d2 = desc + (size_t)(p + 1) * capacity * 32;
     const int n1 = nkp[p], n2 = nkp[p + 1];
     int32_t* m12 = matches12 + (size_t)p * capacity;
-    int32_t* ccnt = csr_cnt + (size_t)p * capacity;
     uint16_t* cidx = csr_idx + (size_t)p * capacity * row_stride;
     uint8_t* cdist = csr_dist + (size_t)p * capacity * row_stride;
     const float* prev = prev_in ? prev_in + (size_t)p * capacity * 2 : nullptr;
     float* prevo = prev_out ? prev_out + (size_t)p * capacity * 2 : nullptr;
+    (void)csr_cnt;
 
     const float mnMinX = 0.f, mnMinY = 0.f;
     const float invW = __fdiv_rn((float)GRID_COLS, (float)cols - mnMinX);
     const float invH = __fdiv_rn((float)GRID_ROWS, (float)rows - mnMinY);
 
-    // ---- phase A: level-0 keypoints of F2 that fall inside the grid (Frame.cc:183-198, :335-345), sorted
-    if (tid == 0) s_nl0 = 0;
+    // ---- phase A: level-0 keypoints of F2 that fall inside the grid (Frame.cc:183-198, :335-345), sorted;
+    // level-0 keypoints of F1 (the queries) in index order
+    if (tid == 0) { s_nl0 = 0; s_nq = 0; }
     __syncthreads();
-    for (int i = tid; i < n2; i += 256) {
+    for (int i = tid; i < n2; i += SFI_THREADS) {
         const orbfe_keypoint kp = k2[i];
         if (kp.octave != 0) continue;
         const int px = (int)roundf(__fmul_rn(kp.x - mnMinX, invW));
@@ -152,79 +166,6 @@ __global__ __launch_bounds__(256) void k_search_init(const orbfe_keypoint* __res
             if (k < SFI_MAXL0) s_sorted[k] = ((uint32_t)(px * GRID_ROWS + py) << 16) | (uint32_t)i;
         }
     }
-    __syncthreads();
-    if (tid == 0 && s_nl0 > SFI_MAXL0) { atomicMax(overflow, s_nl0); s_nl0 = SFI_MAXL0; }
-    __syncthreads();
-    const int nl0 = s_nl0;
-    {
-        int P = 1;
-        while (P < nl0) P <<= 1;
-        for (int i = nl0 + tid; i < P; i += 256) s_sorted[i] = 0xffffffffu;
-        __syncthreads();
-        for (int k = 2; k <= P; k <<= 1)
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int t = tid; t < (P >> 1); t += 256) {
-                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                    const int l = i | j;
-                    const uint32_t a = s_sorted[i], b = s_sorted[l];
-                    const bool up = ((i & k) == 0);
-                    if ((a > b) == up) { s_sorted[i] = b; s_sorted[l] = a; }
-                }
-                __syncthreads();
-            }
-    }
-    if (nl0 > row_stride && tid == 0) atomicMax(overflow, nl0);
-
-    // ---- phase B: candidate lists (Frame.cc:280-333) + distances.  One wave per query.
-    for (int i1 = wid; i1 < n1; i1 += 4) {
-        int count = 0;
-        const orbfe_keypoint kp1 = k1[i1];
-        if (kp1.octave <= 0) {
-            const float x = prev ? prev[2 * i1] : kp1.x, y = prev ? prev[2 * i1 + 1] : kp1.y;
-            const float r = window;
-            const int nMinCellX = max(0, (int)floorf(__fmul_rn(x - mnMinX - r, invW)));
-            const int nMaxCellX = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(x - mnMinX + r, invW)));
-            const int nMinCellY = max(0, (int)floorf(__fmul_rn(y - mnMinY - r, invH)));
-            const int nMaxCellY = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(y - mnMinY + r, invH)));
-            if (!(nMinCellX >= GRID_COLS || nMaxCellX < 0 || nMinCellY >= GRID_ROWS || nMaxCellY < 0)) {
-                const uint4 a0 = reinterpret_cast<const uint4*>(d1)[2 * i1];
-                const uint4 a1 = reinterpret_cast<const uint4*>(d1)[2 * i1 + 1];
-                uint16_t* ri = cidx + (size_t)i1 * row_stride;
-                uint8_t* rd = cdist + (size_t)i1 * row_stride;
-                for (int j0 = 0; j0 < nl0; j0 += 64) {
-                    const int j = j0 + lane;
-                    bool ok = false;
-                    int i2 = 0;
-                    if (j < nl0) {
-                        const uint32_t e = s_sorted[j];
-                        const int cell = e >> 16, cx = cell / GRID_ROWS, cy = cell - cx * GRID_ROWS;
-                        i2 = e & 0xffff;
-                        if (cx >= nMinCellX && cx <= nMaxCellX && cy >= nMinCellY && cy <= nMaxCellY) {
-                            const orbfe_keypoint kp2 = k2[i2];
-                            ok = fabsf(kp2.x - x) < r && fabsf(kp2.y - y) < r;
-                        }
-                    }
-                    const unsigned long long m = __ballot(ok);
-                    if (ok) {
-                        const int pos = count + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
-                                                                         __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-                        if (pos < row_stride) {
-                            const uint4 b0 = reinterpret_cast<const uint4*>(d2)[2 * i2];
-                            const uint4 b1 = reinterpret_cast<const uint4*>(d2)[2 * i2 + 1];
-                            ri[pos] = (uint16_t)j; // rank in the sorted level-0 list (i2 = s_sorted[j] & 0xffff)
-                            const int d = hamming256(a0, a1, b0, b1);
-                            rd[pos] = (uint8_t)(d > 255 ? 255 : d); // 256 only for exact complements; > TH_LOW anyway
-                        }
-                    }
-                    count += __popcll(m);
-                }
-            }
-        }
-        if (lane == 0) ccnt[i1] = min(count, row_stride);
-    }
-    // level-0 queries in index order; per-rank state of F2 in LDS
-    if (tid == 0) s_nq = 0;
-    __syncthreads();
     if (wid == 0) {
         int nq = 0;
         for (int i0 = 0; i0 < n1; i0 += 64) {
@@ -240,34 +181,113 @@ __global__ __launch_bounds__(256) void k_search_init(const orbfe_keypoint* __res
             s_nq = nq;
         }
     }
-    for (int i = tid; i < nl0; i += 256) { s_vdist[i] = INT_MAX; s_v21[i] = -1; s_ang2[i] = k2[s_sorted[i] & 0xffff].angle; }
-    for (int i = tid; i < SFI_MAXL0; i += 256) s_rotbin[i] = -1;
-    for (int i = tid; i < n1; i += 256) m12[i] = -1;
+    __syncthreads();
+    if (tid == 0 && s_nl0 > SFI_MAXL0) { atomicMax(overflow, s_nl0); s_nl0 = SFI_MAXL0; }
+    __syncthreads();
+    const int nl0 = s_nl0, nq = s_nq;
+    {
+        int P = 1;
+        while (P < nl0) P <<= 1;
+        for (int i = nl0 + tid; i < P; i += SFI_THREADS) s_sorted[i] = 0xffffffffu;
+        __syncthreads();
+        for (int k = 2; k <= P; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = tid; t < (P >> 1); t += SFI_THREADS) {
+                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    const int l = i | j;
+                    const uint32_t a = s_sorted[i], b = s_sorted[l];
+                    const bool up = ((i & k) == 0);
+                    if ((a > b) == up) { s_sorted[i] = b; s_sorted[l] = a; }
+                }
+                __syncthreads();
+            }
+    }
+    if (nl0 > row_stride && tid == 0) atomicMax(overflow, nl0);
+    // per-rank state of F2 in LDS: position + descriptor (first SFI_L0_LDS ranks), matching state (all ranks)
+    for (int i = tid; i < nl0; i += SFI_THREADS) {
+        const int i2 = s_sorted[i] & 0xffff;
+        const orbfe_keypoint kp2 = k2[i2];
+        s_vdist[i] = INT_MAX; s_v21[i] = -1; s_ang2[i] = kp2.angle;
+        if (i < SFI_L0_LDS) {
+            s2xy[i] = make_float2(kp2.x, kp2.y);
+            s2d[2 * i] = reinterpret_cast<const uint4*>(d2)[2 * i2];
+            s2d[2 * i + 1] = reinterpret_cast<const uint4*>(d2)[2 * i2 + 1];
+        }
+    }
+    for (int i = tid; i < SFI_MAXL0; i += SFI_THREADS) s_rotbin[i] = -1;
+    for (int i = tid; i < n1; i += SFI_THREADS) m12[i] = -1;
     if (tid < 30) s_hist[tid] = 0;
+    __syncthreads();
+
+    // ---- phase B: candidate lists (Frame.cc:280-333) + distances, one wave per query.  The first SFI_ROW candidates
+    // of the first SFI_ROWQ queries stay in LDS, the rest goes to the query's global row.
+    for (int q = wid; q < nq; q += SFI_THREADS / 64) {
+        const int i1 = s_query[q];
+        int count = 0;
+        const orbfe_keypoint kp1 = k1[i1];
+        const float x = prev ? prev[2 * i1] : kp1.x, y = prev ? prev[2 * i1 + 1] : kp1.y;
+        const float r = window;
+        const int nMinCellX = max(0, (int)floorf(__fmul_rn(x - mnMinX - r, invW)));
+        const int nMaxCellX = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(x - mnMinX + r, invW)));
+        const int nMinCellY = max(0, (int)floorf(__fmul_rn(y - mnMinY - r, invH)));
+        const int nMaxCellY = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(y - mnMinY + r, invH)));
+        if (!(nMinCellX >= GRID_COLS || nMaxCellX < 0 || nMinCellY >= GRID_ROWS || nMaxCellY < 0)) {
+            const uint4 a0 = reinterpret_cast<const uint4*>(d1)[2 * i1];
+            const uint4 a1 = reinterpret_cast<const uint4*>(d1)[2 * i1 + 1];
+            uint16_t* ri = cidx + (size_t)i1 * row_stride;
+            uint8_t* rd = cdist + (size_t)i1 * row_stride;
+            for (int j0 = 0; j0 < nl0; j0 += 64) {
+                const int j = j0 + lane;
+                bool ok = false;
+                int i2 = 0;
+                if (j < nl0) {
+                    const uint32_t e = s_sorted[j];
+                    const int cell = e >> 16, cx = cell / GRID_ROWS, cy = cell - cx * GRID_ROWS;
+                    i2 = e & 0xffff;
+                    if (cx >= nMinCellX && cx <= nMaxCellX && cy >= nMinCellY && cy <= nMaxCellY) {
+                        float x2, y2;
+                        if (j < SFI_L0_LDS) { const float2 v = s2xy[j]; x2 = v.x; y2 = v.y; }
+                        else { x2 = k2[i2].x; y2 = k2[i2].y; }
+                        ok = fabsf(x2 - x) < r && fabsf(y2 - y) < r;
+                    }
+                }
+                const unsigned long long m = __ballot(ok);
+                if (ok) {
+                    const int pos = count + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                                                     __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                    if (pos < row_stride) {
+                        uint4 b0, b1;
+                        if (j < SFI_L0_LDS) { b0 = s2d[2 * j]; b1 = s2d[2 * j + 1]; }
+                        else { b0 = reinterpret_cast<const uint4*>(d2)[2 * i2]; b1 = reinterpret_cast<const uint4*>(d2)[2 * i2 + 1]; }
+                        const int d = hamming256(a0, a1, b0, b1);
+                        const uint8_t d8 = (uint8_t)(d > 255 ? 255 : d); // 256 only for exact complements; > TH_LOW anyway
+                        if (pos < SFI_ROW && q < SFI_ROWQ) { // rank in the sorted level-0 list (i2 = s_sorted[j] & 0xffff)
+                            s_ridx[q * SFI_ROW + pos] = (uint16_t)j;
+                            s_rdist[q * SFI_ROW + pos] = d8;
+                        } else {
+                            ri[pos] = (uint16_t)j;
+                            rd[pos] = d8;
+                        }
+                    }
+                }
+                count += __popcll(m);
+            }
+        }
+        if (lane == 0) s_cnt[q] = (uint16_t)min(count, row_stride);
+    }
     __threadfence_block();
     __syncthreads();
     if (wid != 0) return;
 
-    // ---- phase C: the serial matching loop (ORBmatcher.cc:423-490), wave 0.  All loop-carried state is in LDS; the
-    // first 64 candidates of the NEXT query are prefetched while the current one is resolved.
-    const int nq = s_nq;
+    // ---- phase C: the serial matching loop (ORBmatcher.cc:423-490), wave 0.  All loop-carried state and (normally)
+    // all candidate rows are in LDS.
     int nmatches = 0;
     const float factor = 1.0f / 30; // HISTO_LENGTH; the upstream "1/30" quirk is kept (App. D)
-    int e_n = 0, r_n = 0, d_n = 0;
-    if (nq > 0) {
-        const int i1 = s_query[0];
-        e_n = ccnt[i1];
-        if (lane < e_n) { r_n = cidx[(size_t)i1 * row_stride + lane]; d_n = cdist[(size_t)i1 * row_stride + lane]; }
-    }
     for (int q = 0; q < nq; q++) {
         const int i1 = s_query[q];
-        const int e = e_n, r_c = r_n, d_c = d_n;
-        if (q + 1 < nq) {
-            const int i1n = s_query[q + 1];
-            e_n = ccnt[i1n];
-            if (lane < e_n) { r_n = cidx[(size_t)i1n * row_stride + lane]; d_n = cdist[(size_t)i1n * row_stride + lane]; }
-        }
+        const int e = s_cnt[q];
         if (e <= 0) continue;
+        const bool in_lds = q < SFI_ROWQ;
         const uint16_t* ri = cidx + (size_t)i1 * row_stride;
         const uint8_t* rd = cdist + (size_t)i1 * row_stride;
         // best = first minimum among candidates with vMatchedDistance[i2] > dist; second = next smallest
@@ -276,7 +296,8 @@ __global__ __launch_bounds__(256) void k_search_init(const orbfe_keypoint* __res
             const int j = j0 + lane;
             unsigned long long key = ~0ull;
             if (j < e) {
-                const int rk = j0 == 0 ? r_c : (int)ri[j], d = j0 == 0 ? d_c : (int)rd[j];
+                const bool l = in_lds && j0 == 0;
+                const int rk = l ? (int)s_ridx[q * SFI_ROW + j] : (int)ri[j], d = l ? (int)s_rdist[q * SFI_ROW + j] : (int)rd[j];
                 if (!(s_vdist[rk] <= d)) key = ((unsigned long long)d << 32) | ((unsigned long long)j << 16) | (unsigned)rk;
             }
             const unsigned long long m1 = wave_min_u64(key);
@@ -416,7 +437,9 @@ static int sfi_launch(const orbfe_keypoint* d_kps, const uint8_t* d_desc, const 
         (rc = w.scratch.ensure((size_t)npairs * 3 * capacity * 4)) || (rc = w.overflow.ensure(16)))
         return rc;
     ORBFE_HIP(hipMemsetAsync(w.overflow.p, 0, 4, s));
-    hipLaunchKernelGGL(k_search_init, dim3(npairs), dim3(256), 0, s, d_kps, d_desc, d_n, capacity, cols, rows,
+    ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_init), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)sfi_lds_bytes()));
+    hipLaunchKernelGGL(k_search_init, dim3(npairs), dim3(SFI_THREADS), sfi_lds_bytes(), s, d_kps, d_desc, d_n, capacity, cols, rows,
                        (float)window, nnratio, check_ori, d_prev_in, d_prev_out, d_m12, d_nm, w.csr_cnt.as<int32_t>(),
                        w.csr_idx.as<uint16_t>(), w.csr_dist.as<uint8_t>(), stride, w.scratch.as<int32_t>(),
                        w.overflow.as<int32_t>());
