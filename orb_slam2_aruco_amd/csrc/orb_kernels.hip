@@ -217,19 +217,72 @@ __device__ __forceinline__ int fast_score16(const int d[16])
 }
 
 // One WAVE per (active cell, frame), four cells per workgroup, no workgroup barriers: every step below is a
-// wave-level operation (ballot compaction, in-order LDS).  The wave stages the cell's ROI in LDS, runs the reference's
-// two-threshold sequence (cv::FAST at iniThFAST; only if the cell yields nothing, again at minThFAST -- :809-816),
-// and for each threshold: compass prefilter -> full 9-of-16 segment test -> exact cornerScore -> strict 3x3 NMS inside
-// the cell (cv::FAST runs on the ROI, so NMS never looks across cells) -> survivors written in raster order.
+// wave-level operation (ballot / DPP-scan compaction, in-order LDS).  The wave stages the cell's ROI in LDS and runs the
+// reference's two-threshold sequence (cv::FAST at iniThFAST; only if the cell yields nothing, again at minThFAST --
+// :809-816).  The kernel is bound by VALU issue, so both stages run on packed 16-bit math (two values per op):
+//   1. compass prefilter on every pixel, FOUR ADJACENT PIXELS PER LANE from five aligned LDS dwords: a 9-arc of the
+//      16-ring always contains two adjacent compass points (ring positions 0, 4, 8, 12), so two adjacent compass pixels
+//      must both differ from the centre by more than t with the same sign.  Survivors are compacted in raster order.
+//   2. exact cornerScore of every survivor on (d[k], d[k+8]) pairs; "corner at t" <=> score >= t (the score is the
+//      largest threshold at which the pixel is still a corner), so no separate segment test is needed.
+//   3. strict 3x3 maximum inside the cell (cv::FAST runs on the ROI, so NMS never looks across cells), ordered write.
 // LDS per wave (dynamic, sized by the host from the largest cell of the pyramid): ROI bytes, score map, one list.
-__device__ __forceinline__ void ring_diffs_rt(const uint8_t* c, int P, int v, int d[16])
+// ROI pixel (x, y) lives at byte y * SP + x + 1: the +1 makes every 4-pixel group of step 1 one aligned dword.
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 as_u16x2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
+__device__ __forceinline__ i16x2 as_i16x2(uint32_t v) { return __builtin_bit_cast(i16x2, v); }
+__device__ __forceinline__ uint32_t as_u32(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ uint32_t as_u32(i16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ i16x2 pk_swap(i16x2 v) { const uint32_t u = as_u32(v); return as_i16x2(__builtin_amdgcn_alignbit(u, u, 16)); }
+__device__ __forceinline__ i16x2 pk_min(i16x2 a, i16x2 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ i16x2 pk_max(i16x2 a, i16x2 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ u16x2 pk_minu(u16x2 a, u16x2 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ u16x2 pk_maxu(u16x2 a, u16x2 b) { return __builtin_elementwise_max(a, b); }
+
+// compass test of two pixels at once (16-bit lanes); result lanes are non-zero where the pixel passes
+__device__ __forceinline__ uint32_t compass_pass2(u16x2 v, u16x2 r0, u16x2 r4, u16x2 r8, u16x2 r12, u16x2 t2)
 {
-    d[0] = v - c[3 * P + 0];   d[1] = v - c[3 * P + 1];   d[2] = v - c[2 * P + 2];
-    d[3] = v - c[1 * P + 3];   d[4] = v - c[3];           d[5] = v - c[-1 * P + 3];
-    d[6] = v - c[-2 * P + 2];  d[7] = v - c[-3 * P + 1];  d[8] = v - c[-3 * P + 0];
-    d[9] = v - c[-3 * P - 1];  d[10] = v - c[-2 * P - 2]; d[11] = v - c[-1 * P - 3];
-    d[12] = v - c[-3];         d[13] = v - c[1 * P - 3];  d[14] = v - c[2 * P - 2];
-    d[15] = v - c[3 * P - 1];
+    // two adjacent compass pixels both > v + t  <=>  max over the 4 adjacent pairs of min(pair) > v + t
+    const u16x2 hi = pk_maxu(pk_maxu(pk_minu(r0, r4), pk_minu(r4, r8)), pk_maxu(pk_minu(r8, r12), pk_minu(r12, r0)));
+    const u16x2 lo = pk_minu(pk_minu(pk_maxu(r0, r4), pk_maxu(r4, r8)), pk_minu(pk_maxu(r8, r12), pk_maxu(r12, r0)));
+    const u16x2 ph = __builtin_elementwise_sub_sat(hi, (u16x2)(v + t2));                           // hi > v + t
+    const u16x2 pl = __builtin_elementwise_sub_sat(__builtin_elementwise_sub_sat(v, t2), lo);      // lo < v - t
+    return as_u32(ph) | as_u32(pl);
+}
+
+// cornerScore<16> on pairs D[k] = (d[k], d[k+8]): max over the 16 arcs of 9 of min(d) (and of min(-d)), minus 1
+__device__ __forceinline__ int fast_score16_pk(const i16x2 D[8])
+{
+    i16x2 S[8]; // S[k] = (d[k+8], d[k])
+#pragma unroll
+    for (int k = 0; k < 8; k++) S[k] = pk_swap(D[k]);
+    i16x2 mn2[8], mx2[8]; // (m2[k], m2[k+8]),  m2[k] = min(d[k], d[k+1])
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const i16x2 nxt = k < 7 ? D[k + 1] : S[0];
+        mn2[k] = pk_min(D[k], nxt);
+        mx2[k] = pk_max(D[k], nxt);
+    }
+    i16x2 mn4[8], mx4[8]; // m4[k] = min(m2[k], m2[k+2])
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const i16x2 an = k < 6 ? mn2[k + 2] : pk_swap(mn2[k - 6]);
+        const i16x2 ax = k < 6 ? mx2[k + 2] : pk_swap(mx2[k - 6]);
+        mn4[k] = pk_min(mn2[k], an);
+        mx4[k] = pk_max(mx2[k], ax);
+    }
+    i16x2 bn, bx; // running max of mn9 / min of mx9;  m9[k] = min(m4[k], m4[k+4], d[k+8])
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const i16x2 an = k < 4 ? mn4[k + 4] : pk_swap(mn4[k - 4]);
+        const i16x2 ax = k < 4 ? mx4[k + 4] : pk_swap(mx4[k - 4]);
+        const i16x2 mn9 = pk_min(pk_min(mn4[k], an), S[k]);
+        const i16x2 mx9 = pk_max(pk_max(mx4[k], ax), S[k]);
+        bn = k == 0 ? mn9 : pk_max(bn, mn9);
+        bx = k == 0 ? mx9 : pk_min(bx, mx9);
+    }
+    const i16x2 m = pk_max(bn, (i16x2)(-bx));
+    return max((int)m.x, (int)m.y) - 1;
 }
 
 __global__ __launch_bounds__(256) void k_fast_cells(ImgView src0, ImgView pyr, const LevelGeom* __restrict__ geom,
@@ -268,92 +321,109 @@ __global__ __launch_bounds__(256) void k_fast_cells(ImgView src0, ImgView pyr, c
     const int pitch = (level == 0) ? src0.pitch : g.pitch;
     const int SP = roi_pitch, MP = map_pitch;
 
-    // stage the ROI with (unaligned) dword loads, 8 in flight per lane; clear the score map
+    // stage the ROI (columns -1 .. w-1: the one-byte shift) with unaligned dword loads, 8 in flight per lane; a lane's
+    // items are 64 apart, so (row, dword) advances by a constant step instead of a division per item
     {
         typedef uint32_t u32_unaligned __attribute__((aligned(1)));
-        const int ndw = (w + 3) >> 2, items = ndw * h;
-        const float inv_ndw = 1.0f / (float)ndw;
-        const uint8_t* roi = img + (size_t)iniY * pitch + iniX;
+        const int ndw = (w + 4) >> 2, items = ndw * h;
+        const int qstep = 64 / ndw, rstep = 64 - qstep * ndw;
+        int y = lane / ndw, c = lane - y * ndw;
+        const uint8_t* roi = img + (size_t)iniY * pitch + iniX - 1;
         for (int i0 = 0; i0 < items; i0 += 8 * 64) {
             uint32_t v[8];
+            int so[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                const int i = min(i0 + k * 64 + lane, items - 1);
-                const int y = (int)(((float)i + 0.5f) * inv_ndw), c = i - y * ndw;
-                v[k] = *reinterpret_cast<const u32_unaligned*>(roi + (size_t)y * pitch + 4 * c);
+                const bool in = i0 + k * 64 + lane < items;
+                so[k] = in ? y * SP + 4 * c : -1;
+                v[k] = in ? *reinterpret_cast<const u32_unaligned*>(roi + (size_t)y * pitch + 4 * c) : 0u;
+                y += qstep; c += rstep;
+                if (c >= ndw) { c -= ndw; y++; }
             }
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int i = i0 + k * 64 + lane;
-                if (i < items) {
-                    const int y = (int)(((float)i + 0.5f) * inv_ndw), c = i - y * ndw;
-                    *reinterpret_cast<uint32_t*>(simg + y * SP + 4 * c) = v[k];
-                }
-            }
+            for (int k = 0; k < 8; k++)
+                if (so[k] >= 0) *reinterpret_cast<uint32_t*>(simg + so[k]) = v[k];
         }
     }
     for (int i = lane; i < (int)(map_bytes / 4); i += 64) reinterpret_cast<uint32_t*>(smap)[i] = 0;
     __builtin_amdgcn_wave_barrier();
 
-    const int npix = aw * ah;
-    const float inv_aw = 1.0f / (float)aw;
+    const int G = (aw + 3) >> 2, nitems = G * ah; // 4-pixel groups per active row
+    const float inv_G = 1.0f / (float)G;
     int nlist = 0;
     unsigned long long keepbits = 0; // bit k: list entry lane + 64 k survives NMS (list_cap <= 64 * 64)
     for (int pass_no = 0; pass_no < 2; pass_no++) {
         const int t = pass_no == 0 ? iniTh : minTh;
-        // 1a: cheap necessary condition on every pixel -- a 9-arc of the 16-ring always contains two ADJACENT compass
-        // points (ring positions 0, 4, 8, 12), so two adjacent compass pixels must both differ from the centre by more
-        // than the threshold with the same sign.  Survivors are compacted in raster order.
+        const u16x2 t2 = as_u16x2((uint32_t)t | ((uint32_t)t << 16));
+        // ---- 1: compass prefilter, 4 adjacent pixels per lane
         int n1 = 0;
-        for (int base = 0; base < npix; base += 64) {
-            const int p = base + lane;
-            bool pass = false;
+        for (int base = 0; base < nitems; base += 64) {
+            const int it = base + lane;
+            unsigned mask4 = 0;
             int x = 0, y = 0;
-            if (p < npix) {
-                y = (int)(((float)p + 0.5f) * inv_aw); // exact: p < 4096, quotient >= 0.5/aw away from an integer
-                x = p - y * aw;
-                const uint8_t* c = simg + (y + 3) * SP + (x + 3);
-                const int v = c[0];
-                const int r0 = c[3 * SP], r4 = c[3], r8 = c[-3 * SP], r12 = c[-3];
-                // two adjacent compass pixels both > v + t  <=>  max over the 4 adjacent pairs of min(pair) > v + t
-                const int hi = max(max(min(r0, r4), min(r4, r8)), max(min(r8, r12), min(r12, r0)));
-                const int lo = min(min(max(r0, r4), max(r4, r8)), min(max(r8, r12), max(r12, r0)));
-                pass = (hi > v + t) || (lo < v - t);
+            if (it < nitems) {
+                y = (int)(((float)it + 0.5f) * inv_G); // exact: it < 4096, quotient >= 0.5/G away from an integer
+                x = 4 * (it - y * G);
+                // pixels x .. x+3 of active row y = ROI pixels (x+3 .. x+6, y+3) = bytes x+4 .. x+7 of ROI row y+3
+                const uint32_t* cr = reinterpret_cast<const uint32_t*>(simg + (y + 3) * SP + x + 4);
+                const uint32_t C = cr[0], Wd = cr[-1], Ed = cr[1];
+                const uint32_t N = *reinterpret_cast<const uint32_t*>(simg + y * SP + x + 4);
+                const uint32_t S = *reinterpret_cast<const uint32_t*>(simg + (y + 6) * SP + x + 4);
+                const uint32_t E = __builtin_amdgcn_alignbyte(Ed, C, 3), W = __builtin_amdgcn_alignbyte(C, Wd, 1);
+                // ring positions: 0 = (x, y+3) = S row, 4 = (x+3, y) = E, 8 = (x, y-3) = N row, 12 = (x-3, y) = W
+                constexpr uint32_t LO = 0x0c010c00u, HI = 0x0c030c02u; // bytes (0, 1) / (2, 3) -> 16-bit lanes
+                const uint32_t p01 = compass_pass2(as_u16x2(__builtin_amdgcn_perm(0, C, LO)), as_u16x2(__builtin_amdgcn_perm(0, S, LO)),
+                                                   as_u16x2(__builtin_amdgcn_perm(0, E, LO)), as_u16x2(__builtin_amdgcn_perm(0, N, LO)),
+                                                   as_u16x2(__builtin_amdgcn_perm(0, W, LO)), t2);
+                const uint32_t p23 = compass_pass2(as_u16x2(__builtin_amdgcn_perm(0, C, HI)), as_u16x2(__builtin_amdgcn_perm(0, S, HI)),
+                                                   as_u16x2(__builtin_amdgcn_perm(0, E, HI)), as_u16x2(__builtin_amdgcn_perm(0, N, HI)),
+                                                   as_u16x2(__builtin_amdgcn_perm(0, W, HI)), t2);
+                mask4 = ((p01 & 0xffffu) ? 1u : 0u) | ((p01 >> 16) ? 2u : 0u) | ((p23 & 0xffffu) ? 4u : 0u) | ((p23 >> 16) ? 8u : 0u);
+                mask4 &= (1u << min(4, aw - x)) - 1u; // the last group of a row may be partial
             }
-            const unsigned long long m = __ballot(pass);
-            if (pass) slist[n1 + lane_prefix(m)] = (uint16_t)((y << 8) | x);
-            n1 += __popcll(m);
+            const int cnt = __popc(mask4);
+            const int incl = wave_incl_scan_add(cnt);
+            int off = n1 + incl - cnt;
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+                if (mask4 & (1u << b)) slist[off++] = (uint16_t)((y << 8) | (x + b));
+            n1 += __builtin_amdgcn_readlane(incl, 63);
         }
         __builtin_amdgcn_wave_barrier();
-        // 1b: full segment test on the survivors (dense); in-place order-preserving compaction (writes trail reads)
+        // ---- 2: exact score of the survivors; corners (score >= t) into the score map, list compacted in place
+        // (order-preserving; writes trail reads)
         nlist = 0;
         for (int base = 0; base < n1; base += 64) {
             const int e = base + lane;
             bool corner = false;
-            int yx = 0;
+            int yx = 0, score = 0;
             if (e < n1) {
                 yx = slist[e];
-                const uint8_t* c = simg + ((yx >> 8) + 3) * SP + ((yx & 255) + 3);
-                int d[16];
-                ring_diffs_rt(c, SP, c[0], d);
-                corner = fast_is_corner(d, t);
+                const uint8_t* c = simg + ((yx >> 8) + 3) * SP + ((yx & 255) + 3) + 1;
+                const uint32_t v = c[0];
+                const i16x2 v2 = as_i16x2(v | (v << 16));
+                i16x2 D[8]; // (d[k], d[k+8]), d = v - ring pixel; ring offsets as in ring_diffs_rt()
+                D[0] = v2 - as_i16x2((uint32_t)c[3 * SP + 0] | ((uint32_t)c[-3 * SP + 0] << 16));
+                D[1] = v2 - as_i16x2((uint32_t)c[3 * SP + 1] | ((uint32_t)c[-3 * SP - 1] << 16));
+                D[2] = v2 - as_i16x2((uint32_t)c[2 * SP + 2] | ((uint32_t)c[-2 * SP - 2] << 16));
+                D[3] = v2 - as_i16x2((uint32_t)c[1 * SP + 3] | ((uint32_t)c[-1 * SP - 3] << 16));
+                D[4] = v2 - as_i16x2((uint32_t)c[3] | ((uint32_t)c[-3] << 16));
+                D[5] = v2 - as_i16x2((uint32_t)c[-1 * SP + 3] | ((uint32_t)c[1 * SP - 3] << 16));
+                D[6] = v2 - as_i16x2((uint32_t)c[-2 * SP + 2] | ((uint32_t)c[2 * SP - 2] << 16));
+                D[7] = v2 - as_i16x2((uint32_t)c[-3 * SP + 1] | ((uint32_t)c[3 * SP - 1] << 16));
+                score = fast_score16_pk(D);
+                corner = score >= t;
             }
             const unsigned long long m = __ballot(corner);
             __builtin_amdgcn_wave_barrier();
-            if (corner) slist[nlist + lane_prefix(m)] = (uint16_t)yx;
+            if (corner) {
+                slist[nlist + lane_prefix(m)] = (uint16_t)yx;
+                smap[((yx >> 8) + 1) * MP + ((yx & 255) + 1)] = (uint8_t)score;
+            }
             nlist += __popcll(m);
         }
         __builtin_amdgcn_wave_barrier();
-        // 2: exact score of every corner into the score map
-        for (int e = lane; e < nlist; e += 64) {
-            const int yx = slist[e], y = yx >> 8, x = yx & 255;
-            const uint8_t* c = simg + (y + 3) * SP + (x + 3);
-            int d[16];
-            ring_diffs_rt(c, SP, c[0], d);
-            smap[(y + 1) * MP + (x + 1)] = (uint8_t)fast_score16(d);
-        }
-        __builtin_amdgcn_wave_barrier();
-        // 3: strict 3x3 maximum inside the cell
+        // ---- 3: strict 3x3 maximum inside the cell
         keepbits = 0;
         int nkeep = 0;
         for (int k = 0; k * 64 < nlist; k++) {
@@ -378,7 +448,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(ImgView src0, ImgView pyr, c
         __builtin_amdgcn_wave_barrier();
     }
 
-    // 4: ordered write-out
+    // ---- 4: ordered write-out
     uint32_t* out = slots + (size_t)f * slots_fstride + g.slot_off + (size_t)(cell - g.cell_first) * g.cell_cap;
     const int xrel = ci_j * g.wCell + 3, yrel = ci_i * g.hCell + 3; // (*vit).pt.x += j*wCell (:822-823)
     int nout = 0;

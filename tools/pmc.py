@@ -33,13 +33,15 @@ for k, cs in agg.items():
     summary[k] = {c: sum(v) / len(v) for c, v in cs.items()}
     summary[k]["dispatches"] = max(len(v) for v in cs.values())
 json.dump(summary, open(os.path.join(root, "gpurun_out", "pmc_summary.json"), "w"), indent=1)
-print("%-28s %9s %9s %9s %7s %7s %7s %7s %9s %9s" % ("kernel", "VALU/wv", "SALU/wv", "VMEM/wv", "LDS/wv", "lane%", "busy%", "wait%", "fetchMB", "writeMB"))
+print("VALUus = VALU wave-instructions x 4 cycles / (1024 SIMDs x 2.4 GHz): the time the kernel needs if it only issued VALU")
+print("%-28s %5s %9s %9s %9s %7s %7s %7s %7s %9s %9s %8s" % ("kernel", "n", "VALU/wv", "SALU/wv", "VMEM/wv", "LDS/wv", "lane%", "busy%", "wait%", "fetchMB", "writeMB", "VALUus"))
 for k, s in sorted(summary.items(), key=lambda kv: -kv[1].get("SQ_BUSY_CYCLES", 0)):
     wv = max(s.get("SQ_WAVES", 1), 1)
     g = lambda n: s.get(n, 0.0)
     lane = 100 * g("SQ_THREAD_CYCLES_VALU") / max(64 * g("SQ_ACTIVE_INST_VALU"), 1) if g("SQ_ACTIVE_INST_VALU") else 0
     busy = 100 * g("SQ_ACTIVE_INST_ANY") / max(g("SQ_WAVE_CYCLES"), 1)
     wait = 100 * g("SQ_WAIT_INST_ANY") / max(g("SQ_WAVE_CYCLES"), 1)
-    print("%-28s %9.0f %9.0f %9.1f %7.1f %7.1f %7.1f %7.1f %9.1f %9.1f" % (
-        k[:28], g("SQ_INSTS_VALU") / wv, g("SQ_INSTS_SALU") / wv, (g("SQ_INSTS_VMEM_RD") + g("SQ_INSTS_VMEM_WR")) / wv,
-        g("SQ_INSTS_LDS") / wv, lane, busy, wait, g("FETCH_SIZE") / 1024, g("WRITE_SIZE") / 1024))
+    print("%-28s %5d %9.0f %9.0f %9.1f %7.1f %7.1f %7.1f %7.1f %9.1f %9.1f %8.1f" % (
+        k[:28], s["dispatches"] // 3, g("SQ_INSTS_VALU") / wv, g("SQ_INSTS_SALU") / wv, (g("SQ_INSTS_VMEM_RD") + g("SQ_INSTS_VMEM_WR")) / wv,
+        g("SQ_INSTS_LDS") / wv, lane, busy, wait, g("FETCH_SIZE") / 1024, g("WRITE_SIZE") / 1024,
+        g("SQ_INSTS_VALU") * 4 / 1024 / 2400))
