@@ -204,7 +204,7 @@ def main():
     n_host = d_n.cpu().numpy()
 
     if rank == 0:
-        orb_names = ["resize", "fast_cells", "distribute", "blur7", "orient_describe"]
+        orb_names = binding.ORBextractor.STAGES  # blur7 runs on a second stream next to fast_cells + distribute
         stages = {nm: float(v) for nm, v in zip(orb_names, orb_us)}
         if not args.no_orb:
             stages["knn2"] = ev[0].elapsed_time(ev[1]) * 1000.0

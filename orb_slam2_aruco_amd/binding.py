@@ -221,6 +221,9 @@ class ORBextractor:
                "level_keypoints")
         return bool(n.value)
 
+    # order of kernel_times_us(); blur7 runs on the extractor's second stream, concurrently with fast_cells + distribute
+    STAGES = ["resize", "blur7", "fast_cells", "distribute", "orient_describe"]
+
     def kernel_times_us(self):
         out = np.zeros(32, np.float32)
         n = self.L.orbfe_extractor_debug_kernel_times(self.h, _p(out), 32)
@@ -281,7 +284,8 @@ RECT_DTYPE = np.dtype([("corners", "<f4", (4, 2)), ("off", "<i4"), ("len", "<i4"
 class MarkerDetector:
     """Mirror of aruco::MarkerDetector as the reference configures it (src/Frame.cc:129-142):
     setDictionary(name) + DM_NORMAL + CORNER_LINES; detect(image) -> markers sorted by id."""
-    STAGES = ["threshold", "pyramid", "contours", "decode", "finalize"]
+    # order of kernel_times_us(); the pyramid runs on the detector's second stream, concurrently with threshold + contours
+    STAGES = ["pyramid", "threshold", "contours", "decode", "finalize"]
 
     def __init__(self, dictionary="ARUCO", device=0):
         self.L = load()

@@ -18,7 +18,8 @@ struct orbfe_aruco {
     int device = 0;
     std::string dict_name;
     int nbits = 0, nb = 0, S = 0, ncodes = 0;
-    hipStream_t own_stream = nullptr;
+    hipStream_t own_stream = nullptr, aux_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int rows = 0, cols = 0, batch_cap = 0;
     int win = 0, wpr = 0, npyr = 0;
     std::vector<ArLevel> levels;
@@ -41,6 +42,9 @@ struct orbfe_aruco {
                           &d_counts, &d_candidx, &d_ncand, &d_result, &d_gpad, &d_in, &d_out, &d_nout, &d_segs})
             b->release();
         if (own_stream) (void)hipStreamDestroy(own_stream);
+        if (aux_stream) (void)hipStreamDestroy(aux_stream);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
     }
 
     int set_dictionary(const char* name)
@@ -176,24 +180,29 @@ struct orbfe_aruco {
         ImgView pyr{d_pyr.as<uint8_t>(), d_pyr.as<uint8_t>(), pyr_fbytes, 0};
         timer.begin();
         timer.mark(s, "start");
-        hipLaunchKernelGGL(k_adaptive_threshold, dim3((cols + 63) / 64, (rows + 63) / 64, B), dim3(256), 0, s, src0,
-                           cols, rows, win, 7, 1.0 / (win * win), d_bits.as<uint32_t>(), bits_fu32, wpr);
-        timer.mark(s, "threshold");
+        // the /2 pyramid is only needed by k_decode: it runs on a second stream next to threshold + contours
+        ORBFE_HIP(hipEventRecord(ev_fork, s));
+        ORBFE_HIP(hipStreamWaitEvent(aux_stream, ev_fork, 0));
+        timer.mark(aux_stream, "pyramid starts", true);
         for (int p = 1; p < npyr; p++) {
             const ArLevel& L = levels[p];
             const ArLevel& Lp = levels[p - 1];
             ImgView sv = (p == 1) ? src0 : ImgView{pyr.base + Lp.off, nullptr, pyr_fbytes, Lp.pitch};
             ImgView dv{pyr.base + L.off, pyr.base_w + L.off, pyr_fbytes, L.pitch};
             if (lvl_exact[p]) {
-                hipLaunchKernelGGL(k_half_area, dim3((L.w + 63) / 64, (L.h + 3) / 4, B), dim3(256), 0, s, sv, dv, L.w, L.h);
+                hipLaunchKernelGGL(k_half_area, dim3((L.w + 63) / 64, (L.h + 3) / 4, B), dim3(256), 0, aux_stream, sv, dv, L.w, L.h);
             } else {
                 const int dw4 = (L.w + 3) / 4;
                 const double scale_x = 1. / ((double)L.w / Lp.w), scale_y = 1. / ((double)L.h / Lp.h);
-                hipLaunchKernelGGL(k_resize_level, dim3((dw4 + 63) / 64, (L.h + 7) / 8, B), dim3(256), 0, s, sv, dv,
+                hipLaunchKernelGGL(k_resize_level, dim3((dw4 + 63) / 64, (L.h + 7) / 8, B), dim3(256), 0, aux_stream, sv, dv,
                                    Lp.w, Lp.h, dw4, L.h, scale_x, scale_y, L.w);
             }
         }
-        timer.mark(s, "pyramid");
+        timer.mark(aux_stream, "pyramid");
+        ORBFE_HIP(hipEventRecord(ev_join, aux_stream));
+        hipLaunchKernelGGL(k_adaptive_threshold, dim3((cols + 63) / 64, (rows + 63) / 64, B), dim3(256), 0, s, src0,
+                           cols, rows, win, 7, 1.0 / (win * win), d_bits.as<uint32_t>(), bits_fu32, wpr);
+        timer.mark(s, "threshold");
         const size_t lds = contours_lds_bytes(lds_bits_words, AR_MAX_KEPT);
         ORBFE_HIP(hipGetLastError());
         auto kfn = lds_bits_words ? k_contours_t<true> : k_contours_t<false>;
@@ -219,6 +228,7 @@ struct orbfe_aruco {
         ORBFE_HIP(hipGetLastError());
         hipLaunchKernelGGL(k_prefilter, dim3(B), dim3(256), 0, s, d_rects.as<ArRect>(), AR_MAX_RECTS,
                            d_counts.as<int32_t>(), cols, rows, win, d_candidx.as<int32_t>(), d_ncand.as<int32_t>());
+        ORBFE_HIP(hipStreamWaitEvent(s, ev_join, 0));
         hipLaunchKernelGGL(k_decode, dim3(32, B), dim3(64), 0, s, src0, pyr, d_levels.as<ArLevel>(), npyr,
                            d_rects.as<ArRect>(), AR_MAX_RECTS, d_candidx.as<int32_t>(), d_ncand.as<int32_t>(), S, nb,
                            d_codes.as<unsigned long long>(), ncodes, d_result.as<int32_t>(), cols);
@@ -240,7 +250,14 @@ orbfe_aruco* orbfe_aruco_create(const char* dictionary, int device)
     if (use_device(device) != ORBFE_OK) return nullptr;
     orbfe_aruco* h = new orbfe_aruco();
     h->device = device;
-    if (hipStreamCreate(&h->own_stream) != hipSuccess) { fail(ORBFE_ERR_HIP, "hipStreamCreate failed"); delete h; return nullptr; }
+    if (hipStreamCreate(&h->own_stream) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+        fail(ORBFE_ERR_HIP, "hipStreamCreate failed");
+        delete h;
+        return nullptr;
+    }
     if (h->set_dictionary(dictionary) != ORBFE_OK) { delete h; return nullptr; }
     return h;
 }

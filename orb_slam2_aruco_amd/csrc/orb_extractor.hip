@@ -41,7 +41,8 @@ struct orbfe_extractor {
     std::vector<int> mnFeaturesPerLevel, umax;
     // --- device state
     int device = 0;
-    hipStream_t own_stream = nullptr;
+    hipStream_t own_stream = nullptr, aux_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int rows = 0, cols = 0; // geometry currently built
     int batch_cap = 0;
     std::vector<LevelGeom> geom;
@@ -68,6 +69,9 @@ struct orbfe_extractor {
                           &d_kps, &d_desc, &d_nout})
             b->release();
         if (own_stream) (void)hipStreamDestroy(own_stream);
+        if (aux_stream) (void)hipStreamDestroy(aux_stream);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
     }
 
     // ORBextractor::ORBextractor, src/ORBextractor.cc:410-470
@@ -305,6 +309,14 @@ struct orbfe_extractor {
             }
         }
         timer.mark(s, "resize");
+        // The blur only needs the pyramid: it runs on a second stream next to FAST and the (latency-bound) quadtree
+        ORBFE_HIP(hipEventRecord(ev_fork, s));
+        ORBFE_HIP(hipStreamWaitEvent(aux_stream, ev_fork, 0));
+        timer.mark(aux_stream, "blur7 starts", true);
+        hipLaunchKernelGGL(k_blur7, dim3(xcd_grid(ntiles * B)), dim3(256), 0, aux_stream, src0, pyr, blur, dg,
+                           d_tiles.as<uint32_t>(), ntiles, ntiles * B);
+        timer.mark(aux_stream, "blur7");
+        ORBFE_HIP(hipEventRecord(ev_join, aux_stream));
         {
             // LDS per wave: ROI (cell + 6), score map (cell + 2), one u16 list of cell pixels
             const int roi_pitch = align_up(max_wcell + 6 + 4, 4) + 4, roi_rows = max_hcell + 6; // +1 byte shift, +1 dword read past a row
@@ -351,9 +363,7 @@ struct orbfe_extractor {
         hipLaunchKernelGGL(k_level_offsets, dim3(B), dim3(256), 0, s, d_lvlcnt.as<int32_t>(), d_lvloff.as<int32_t>(),
                            d_n, nlevels, B, capacity, d_overflow.as<int32_t>(), dg, d_lvlout.as<uint32_t>(), out_total,
                            d_flatkv.as<uint32_t>(), d_flatlvl.as<uint8_t>());
-        hipLaunchKernelGGL(k_blur7, dim3(xcd_grid(ntiles * B)), dim3(256), 0, s, src0, pyr, blur, dg,
-                           d_tiles.as<uint32_t>(), ntiles, ntiles * B);
-        timer.mark(s, "blur7");
+        ORBFE_HIP(hipStreamWaitEvent(s, ev_join, 0));
         const int okx = (std::min(capacity, max_keypoints()) + 3) / 4;
         hipLaunchKernelGGL(k_orient_describe, dim3(xcd_grid(okx * B)), dim3(256), 0, s, src0, pyr, blur, dg,
                            d_flatkv.as<uint32_t>(), d_flatlvl.as<uint8_t>(), d_n, nlevels, d_pattern.as<uint32_t>(),
@@ -389,7 +399,9 @@ orbfe_extractor* orbfe_extractor_create(int nfeatures, float scaleFactor, int nl
     h->scaleFactor = scaleFactor;
     h->device = device;
     h->build_tables();
-    if (hipStreamCreate(&h->own_stream) != hipSuccess || h->d_pattern.ensure(1024) != ORBFE_OK ||
+    if (hipStreamCreate(&h->own_stream) != hipSuccess || hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess || h->d_pattern.ensure(1024) != ORBFE_OK ||
         h->d_umax.ensure(64) != ORBFE_OK ||
         hipMemcpy(h->d_pattern.p, ORBFE_BIT_PATTERN_31, 1024, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(h->d_umax.p, h->umax.data(), 64, hipMemcpyHostToDevice) != hipSuccess) {

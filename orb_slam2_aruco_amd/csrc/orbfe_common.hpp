@@ -59,14 +59,16 @@ struct DevBuf {
     template <class T> T* as() const { return (T*)p; }
 };
 
-// Event-pair timing of individual launches (debug/profiling aid; off the hot path unless enabled).
+// Event timing of individual launches (profiling aid; no events are recorded unless enabled).  A mark closes the
+// interval that the previous mark ON THE SAME STREAM opened; `opens_only` marks (the first one of a stream) report nothing.
 struct KernelTimer {
     bool enabled = false;
     std::vector<hipEvent_t> ev;
-    std::vector<std::string> names;
+    std::vector<hipStream_t> streams;
+    std::vector<char> opens;
     size_t used = 0;
-    void begin() { used = 0; names.clear(); }
-    void mark(hipStream_t s, const char* name)
+    void begin() { used = 0; streams.clear(); opens.clear(); }
+    void mark(hipStream_t s, const char* /*name: documentation at the call site*/, bool opens_only = false)
     {
         if (!enabled) return;
         if (used == ev.size()) {
@@ -75,16 +77,21 @@ struct KernelTimer {
             ev.push_back(e);
         }
         (void)hipEventRecord(ev[used++], s);
-        names.push_back(name);
+        streams.push_back(s);
+        opens.push_back(opens_only || streams.size() == 1);
     }
     int collect(float* out_us, int capacity)
     {
         if (!enabled || used < 2) return 0;
-        (void)hipEventSynchronize(ev[used - 1]);
+        for (size_t i = 0; i < used; i++) (void)hipEventSynchronize(ev[i]);
         int n = 0;
         for (size_t i = 1; i < used && n < capacity; i++) {
+            if (opens[i]) continue;
+            size_t j = i;
+            while (j-- > 0)
+                if (streams[j] == streams[i]) break;
             float ms = 0;
-            (void)hipEventElapsedTime(&ms, ev[i - 1], ev[i]);
+            if (j < i) (void)hipEventElapsedTime(&ms, ev[j], ev[i]);
             out_us[n++] = ms * 1000.f;
         }
         return n;
