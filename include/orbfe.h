@@ -114,6 +114,9 @@ int orbfe_extractor_debug_level_keypoints(orbfe_extractor* h, int frame, int lev
 int orbfe_extractor_debug_kernel_times(orbfe_extractor* h, float* out_us, int capacity);
 
 /* ------------------------------------------------------------------ descriptor matching -- */
+/* Debug/test switch.  "knn2_path": 0 = pick by problem size (default), 1 = VALU tile kernel, 2 = matrix-core kernel. */
+int orbfe_debug_control(const char* key, int value);
+
 /* popcount(a XOR b) over 256 bits, host pointers (ORBmatcher::DescriptorDistance) */
 int orbfe_hamming(const uint8_t* a, const uint8_t* b);
 

@@ -26,7 +26,7 @@ SYMBOLS = [
     "orbfe_extractor_max_keypoints", "orbfe_extract", "orbfe_extract_batch", "orbfe_extract_batch_device",
     "orbfe_extractor_debug_level_size", "orbfe_extractor_debug_level_image",
     "orbfe_extractor_debug_level_keypoints", "orbfe_extractor_debug_kernel_times",
-    "orbfe_hamming", "orbfe_knn2", "orbfe_knn2_batch_device", "orbfe_search_for_initialization",
+    "orbfe_debug_control", "orbfe_hamming", "orbfe_knn2", "orbfe_knn2_batch_device", "orbfe_search_for_initialization",
     "orbfe_search_for_initialization_batch_device",
     "orbfe_aruco_create", "orbfe_aruco_destroy", "orbfe_aruco_set_dictionary", "orbfe_aruco_max_markers",
     "orbfe_aruco_detect", "orbfe_aruco_detect_batch", "orbfe_aruco_detect_batch_device", "orbfe_aruco_debug_image",
@@ -70,6 +70,7 @@ def load():
     L.orbfe_extractor_debug_level_keypoints.argtypes = [vp, i32, i32, i32, vp, i32, vp]
     L.orbfe_extractor_debug_kernel_times.argtypes = [vp, vp, i32]
     if hasattr(L, "orbfe_knn2"):
+        L.orbfe_debug_control.argtypes = [C.c_char_p, i32]
         L.orbfe_hamming.argtypes = [vp, vp]
         L.orbfe_knn2.argtypes = [vp, i32, vp, i32, i32, vp, vp, vp, i32]
         L.orbfe_knn2_batch_device.argtypes = [vp, vp, sz, i32, vp, vp, sz, i32, i32, i32, vp, vp, vp, vp]
@@ -235,6 +236,11 @@ def hamming(a, b):
     L = load()
     a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
     return L.orbfe_hamming(_p(a), _p(b))
+
+
+def debug_control(key, value):
+    L = load()
+    _check(L, L.orbfe_debug_control(key.encode(), int(value)), "orbfe_debug_control")
 
 
 def knn2(Q, T, init=256, device=0):

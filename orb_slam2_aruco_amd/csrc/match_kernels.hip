@@ -66,6 +66,152 @@ __global__ __launch_bounds__(256) void k_knn2_tiles(const uint8_t* __restrict__ 
     }
 }
 
+// ---- all-pairs Hamming distances on the matrix cores.
+// For bit vectors a, b:  |a ^ b| = |a| + |b| - 2 a.b, and a.b over 256 bits is an int8 dot product of the bits spread to
+// bytes -- an (nq x 256) x (256 x nt) GEMM, which is what MFMA is for.  v_mfma_i32_32x32x32_i8 does a 32 x 32 tile of
+// dot products over 32 bits per instruction; eight of them finish a tile.  Per pair the VALU only has to fold the
+// result into the running (best, second) keys: one mad, one med3, one min.
+//   workgroup = KM_WAVES waves x 32 queries; the train descriptors are spread to bytes once per workgroup and chunk
+//   (KM_CHUNK descriptors) in LDS and shared by all waves; the queries' A fragments stay in registers.
+// Operand layout: lane l supplies row/column l & 31 and the 16 k-values of half l >> 5; A and B are loaded with the
+// same rule, so the order of the k-values inside the instruction does not matter (a.b is a sum over k).
+// C layout (cdna4 ISA, 32 x 32): column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+#define KM_WAVES 8
+#define KM_CHUNK 128
+#define KM_ROWB 272 // bytes per spread descriptor in LDS: 256 + 16 keeps the 16-byte reads of adjacent rows on distinct banks
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+// middle value of three (the compiler emits v_med3_i32)
+__device__ __forceinline__ int med3i(int a, int b, int c) { return max(min(a, b), min(max(a, b), c)); }
+// 4 bits -> 4 bytes (bit i -> byte i)
+__device__ __forceinline__ int spread4(uint32_t x) { return (int)(((x & 15u) * 0x00204081u) & 0x01010101u); }
+__device__ __forceinline__ v4i spread16(uint32_t bits)
+{
+    v4i r;
+    r.x = spread4(bits); r.y = spread4(bits >> 4); r.z = spread4(bits >> 8); r.w = spread4(bits >> 12);
+    return r;
+}
+
+__global__ __launch_bounds__(KM_WAVES * 64) void k_knn2_mfma(const uint8_t* __restrict__ Q, const int32_t* __restrict__ nq_arr,
+                                                             size_t q_stride, int max_nq, const uint8_t* __restrict__ T,
+                                                             const int32_t* __restrict__ nt_arr, size_t t_stride,
+                                                             int init, int32_t* __restrict__ best_idx,
+                                                             int32_t* __restrict__ best_dist,
+                                                             int32_t* __restrict__ second_dist)
+{
+    __shared__ __align__(16) unsigned char s_t[KM_CHUNK * KM_ROWB]; // spread train descriptors of the current chunk
+    __shared__ int s_pt[KM_CHUNK];                                  // their popcounts
+    __shared__ int s_red[KM_WAVES][32][33];                         // final cross-lane merge (keys)
+    const int pair = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int nq = nq_arr ? nq_arr[pair] : max_nq;
+    const int nt = nt_arr[pair];
+    const int q0 = blockIdx.x * (KM_WAVES * 32);
+    if (q0 >= nq) return;
+    const uint32_t* Qp = reinterpret_cast<const uint32_t*>(Q + (size_t)pair * q_stride);
+    const uint32_t* Tp = reinterpret_cast<const uint32_t*>(T + (size_t)pair * t_stride);
+    const int col = lane & 31, half = lane >> 5;
+    const int ie = min(init, 257); // distances are <= 256: any larger start value behaves like 257
+
+    // A fragments: query row (q0 + 32 wid + col), k-step s = dword s of the descriptor, this lane's 16-bit half
+    const int qa = q0 + 32 * wid + col;
+    v4i a[8];
+#pragma unroll
+    for (int s2 = 0; s2 < 8; s2++) {
+        const uint32_t w = qa < nq ? Qp[(size_t)qa * 8 + s2] : 0u;
+        a[s2] = spread16(w >> (16 * half));
+    }
+    // the 16 rows this lane accumulates: row(reg) = (reg & 3) + 8 * (reg >> 2) + 4 * half; keys start at "init":
+    // a candidate is accepted iff d < init  <=>  |t| - 2 q.t < init - |q|
+    int bestk[16], secondk[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int qr = q0 + 32 * wid + (r & 3) + 8 * (r >> 2) + 4 * half;
+        int pq = 0;
+        if (qr < nq) {
+            const uint4 d0 = reinterpret_cast<const uint4*>(Qp)[(size_t)qr * 2], d1 = reinterpret_cast<const uint4*>(Qp)[(size_t)qr * 2 + 1];
+            pq = __popc(d0.x) + __popc(d0.y) + __popc(d0.z) + __popc(d0.w) + __popc(d1.x) + __popc(d1.y) + __popc(d1.z) + __popc(d1.w);
+        }
+        bestk[r] = secondk[r] = (ie - pq) * 65536;
+    }
+
+    for (int t0 = 0; t0 < nt; t0 += KM_CHUNK) {
+        const int m = min(KM_CHUNK, nt - t0);
+        __syncthreads();
+        // spread the chunk: item = (train, dword) -> 32 bytes
+        for (int i = tid; i < KM_CHUNK * 8; i += KM_WAVES * 64) {
+            const int tr = i >> 3, dw = i & 7;
+            const uint32_t w = tr < m ? Tp[(size_t)(t0 + tr) * 8 + dw] : 0u;
+            v4i* dst = reinterpret_cast<v4i*>(s_t + tr * KM_ROWB + dw * 32);
+            dst[0] = spread16(w);
+            dst[1] = spread16(w >> 16);
+        }
+        for (int tr = tid; tr < KM_CHUNK; tr += KM_WAVES * 64) {
+            int pt = 0;
+            if (tr < m) {
+                const uint4 d0 = reinterpret_cast<const uint4*>(Tp)[(size_t)(t0 + tr) * 2], d1 = reinterpret_cast<const uint4*>(Tp)[(size_t)(t0 + tr) * 2 + 1];
+                pt = __popc(d0.x) + __popc(d0.y) + __popc(d0.z) + __popc(d0.w) + __popc(d1.x) + __popc(d1.y) + __popc(d1.z) + __popc(d1.w);
+            }
+            s_pt[tr] = pt;
+        }
+        __syncthreads();
+        for (int tt = 0; tt < m; tt += 32) {
+            v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            const unsigned char* brow = s_t + (tt + col) * KM_ROWB + 16 * half;
+#pragma unroll
+            for (int s2 = 0; s2 < 8; s2++) {
+                const v4i b = *reinterpret_cast<const v4i*>(brow + 32 * s2);
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s2], b, acc, 0, 0, 0);
+            }
+            // this lane's column is train t0 + tt + col; columns past the end get a key above every init key
+            const int j = t0 + tt + col;
+            const int cj = (tt + col < m) ? ((s_pt[tt + col] << 16) | j) : 0x7fffffff;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int key = (tt + col < m) ? cj - (acc[r] << 17) : 0x7fffffff; // ((|t| - 2 q.t) << 16) | j
+                secondk[r] = med3i(bestk[r], secondk[r], key);     // middle of the three
+                bestk[r] = min(bestk[r], key);
+            }
+        }
+    }
+    // merge the 32 column classes of every row through LDS: s_red[wave][row][column class]
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 16; r++) s_red[wid][(r & 3) + 8 * (r >> 2) + 4 * half][col] = pass == 0 ? bestk[r] : secondk[r];
+        __builtin_amdgcn_wave_barrier();
+        // lane = (row = col, half h): scans 16 column classes
+        int b1 = 0x7fffffff, b2 = 0x7fffffff; // two smallest keys of the scanned entries
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+            const int key = s_red[wid][col][16 * half + c];
+            b2 = med3i(b1, b2, key);
+            b1 = min(b1, key);
+        }
+        // combine the two halves of the row (lanes l and l ^ 32)
+        const int o1 = __shfl_xor(b1, 32), o2 = __shfl_xor(b2, 32);
+        const int n1 = min(b1, o1);
+        const int n2 = min(max(b1, o1), min(b2, o2));
+        if (pass == 0) { bestk[0] = n1; bestk[1] = n2; }       // two smallest "best" keys of the row
+        else { secondk[0] = n1; }                              // smallest "second" key of the row
+    }
+    // row's best = smallest best key; row's second = min(second smallest best key, smallest second key)
+    if (half == 0) {
+        const int qr = q0 + 32 * wid + col;
+        if (qr < nq) {
+            uint4 d0 = reinterpret_cast<const uint4*>(Qp)[(size_t)qr * 2], d1 = reinterpret_cast<const uint4*>(Qp)[(size_t)qr * 2 + 1];
+            const int pq = __popc(d0.x) + __popc(d0.y) + __popc(d0.z) + __popc(d0.w) + __popc(d1.x) + __popc(d1.y) + __popc(d1.z) + __popc(d1.w);
+            const int kb = bestk[0], ks = min(bestk[1], secondk[0]);
+            int bd = (kb >> 16) + pq, sd = (ks >> 16) + pq, bi = kb & 0xffff;
+            if (bd >= ie) { bd = init; bi = -1; }
+            if (sd >= ie) sd = init;
+            const size_t o = (size_t)pair * max_nq + qr;
+            best_idx[o] = bi; best_dist[o] = bd; second_dist[o] = sd;
+        }
+    }
+}
+
 // Merge the per-split partials in ascending split order (earlier candidates win ties, as in the serial loop).
 __global__ void k_knn2_merge(const int32_t* __restrict__ pidx, const int32_t* __restrict__ pbest,
                              const int32_t* __restrict__ psecond, int nsplit, int max_nq,
@@ -386,6 +532,9 @@ static MatchWorkspace& ws()
     return *tl_ws;
 }
 
+// debug: 0 = choose by problem size, 1 = VALU tiles (+ split/merge), 2 = matrix cores (orbfe_debug_control "knn2_path")
+static int g_knn2_path = 0;
+
 static int knn2_launch(const uint8_t* d_Q, const int32_t* d_nq, size_t q_stride, int max_nq, const uint8_t* d_T,
                        const int32_t* d_nt, size_t t_stride, int max_nt, int npairs, int init, int32_t* d_best_idx,
                        int32_t* d_best_dist, int32_t* d_second_dist, hipStream_t s)
@@ -401,7 +550,12 @@ static int knn2_launch(const uint8_t* d_Q, const int32_t* d_nq, size_t q_stride,
     int chunk = (max_nt + nsplit - 1) / nsplit;
     chunk = std::max(KNN_TILE, (chunk + KNN_TILE - 1) / KNN_TILE * KNN_TILE);
     nsplit = std::max(1, (max_nt + chunk - 1) / chunk);
-    if (nsplit == 1) {
+    const bool mfma_ok = max_nt <= 65535 && init > 0;
+    if (mfma_ok && (g_knn2_path == 2 || (g_knn2_path == 0 && nsplit == 1))) {
+        // enough (query tile, pair) workgroups to fill the GPU: distances on the matrix cores
+        hipLaunchKernelGGL(k_knn2_mfma, dim3((max_nq + KM_WAVES * 32 - 1) / (KM_WAVES * 32), npairs), dim3(KM_WAVES * 64), 0, s, d_Q,
+                           d_nq, q_stride, max_nq, d_T, d_nt, t_stride, init, d_best_idx, d_best_dist, d_second_dist);
+    } else if (nsplit == 1) {
         hipLaunchKernelGGL(k_knn2_tiles, dim3(qtiles, npairs, 1), dim3(256), 0, s, d_Q, d_nq, q_stride, max_nq, d_T,
                            d_nt, t_stride, chunk, init, d_best_idx, d_best_dist, d_second_dist);
     } else {
@@ -452,6 +606,12 @@ static int sfi_launch(const orbfe_keypoint* d_kps, const uint8_t* d_desc, const 
 using namespace orbfe;
 
 extern "C" {
+
+int orbfe_debug_control(const char* key, int value)
+{
+    if (key && !strcmp(key, "knn2_path") && value >= 0 && value <= 2) { g_knn2_path = value; return ORBFE_OK; }
+    return fail(ORBFE_ERR_INVALID, "orbfe_debug_control: unknown key or value");
+}
 
 int orbfe_hamming(const uint8_t* a, const uint8_t* b)
 {

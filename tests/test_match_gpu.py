@@ -21,6 +21,26 @@ def test_knn2_all_pairs(orbfe, oracle, nq, nt, init):
         assert np.array_equal(g, w), nm
 
 
+@pytest.mark.parametrize("path", [1, 2])
+@pytest.mark.parametrize("nq,nt,init", [(1, 1, 256), (33, 65, 256), (1000, 1000, 256), (1030, 999, 2**31 - 1),
+                                        (300, 257, 60), (5, 0, 256)])
+def test_knn2_both_kernels(orbfe, oracle, path, nq, nt, init):
+    """The VALU tile kernel (1) and the matrix-core kernel (2) implement the same rule, ties and `init` included."""
+    Q = synth.random_descriptors(nq, nq * 1000 + nt)
+    T = synth.random_descriptors(max(nt, 1), nq * 1000 + nt + 1)[:nt]
+    if nt > 40:   # duplicates and near-duplicates: ties in best and in second
+        T[7] = T[3]; T[40] = T[3]; Q[0] = T[3]
+        if nq > 2: Q[2] = T[3] ^ np.uint8(1)
+    orbfe.debug_control("knn2_path", path)
+    try:
+        got = orbfe.knn2(Q, T, init)
+    finally:
+        orbfe.debug_control("knn2_path", 0)
+    want = oracle.knn2(Q, T, init)
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+
+
 def test_knn2_large_property(orbfe):
     """10k x 10k (config C5): checked through size-independent properties instead of the (slow) oracle."""
     n = 10000
