@@ -28,6 +28,7 @@ struct orbfe_aruco {
     size_t pyr_fbytes = 0, bits_fu32 = 0, candq_fu32 = 0, pool_fu32 = 0, gpad_fu32 = 0;
     int lds_bits_words = 0;
     DevBuf d_segs;
+    int relay_kshift = 5;      // initial grid spacing (log2) of k_contours_relay
     int relay_tbits = 0;       // hash-table size of k_contours_relay (0: the kernel cannot run at this image size)
     bool force_legacy = false; // debug: always use k_contours_t
     DevBuf d_codes, d_levels, d_tabs, d_bits, d_pyr, d_candq, d_pool, d_kept, d_rects, d_counts, d_candidx, d_ncand,
@@ -139,8 +140,11 @@ struct orbfe_aruco {
         lds_bits_words = (contours_lds_bytes((int)padded_words, AR_MAX_KEPT) <= 160 * 1024) ? (int)padded_words : 0;
         gpad_fu32 = lds_bits_words ? 0 : padded_words;
         // k_contours_relay needs the bit image AND its marker table in LDS; otherwise k_contours_t does all frames
+        // 4096 marker slots on a 32-pixel grid (one workgroup per CU).  A 2048-slot table on a 64-pixel grid would let two
+        // workgroups share a CU, but its longer segments cost more than the sharing wins (measured: 857 vs 726 us).
         relay_tbits = 0;
-        if (lds_bits_words && relay_lds_bytes(lds_bits_words, AR_MAX_KEPT, 12) + 2048 <= 160 * 1024) relay_tbits = 12;
+        const size_t rl_static = 6 * 1024;
+        if (lds_bits_words && relay_lds_bytes(lds_bits_words, RL_KCAP, 12) + rl_static <= 160 * 1024) { relay_tbits = 12; relay_kshift = 5; }
         rows = rows_; cols = cols_;
         batch_cap = 0;
         if (tabs.empty()) tabs.push_back(0);
@@ -210,12 +214,12 @@ struct orbfe_aruco {
                                       (int)lds));
         const bool relay = relay_tbits && !force_legacy;
         if (relay) {
-            const size_t rlds = relay_lds_bytes(lds_bits_words, AR_MAX_KEPT, relay_tbits);
+            const size_t rlds = relay_lds_bytes(lds_bits_words, RL_KCAP, relay_tbits);
             ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_contours_relay),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
             hipLaunchKernelGGL(k_contours_relay, dim3(B), dim3(RL_THREADS), rlds, s, d_bits.as<uint32_t>(), bits_fu32, wpr,
-                               cols, rows, lds_bits_words, 70, RL_KSHIFT, relay_tbits, d_segs.as<RelaySeg>(),
-                               d_pool.as<uint32_t>(), pool_fu32, (int)pool_fu32, d_kept.as<ArKept>(), AR_MAX_KEPT,
+                               cols, rows, lds_bits_words, 70, relay_kshift, relay_tbits, d_segs.as<RelaySeg>(),
+                               d_pool.as<uint32_t>(), pool_fu32, (int)pool_fu32, d_kept.as<ArKept>(), AR_MAX_KEPT, RL_KCAP,
                                d_rects.as<ArRect>(), AR_MAX_RECTS, d_counts.as<int32_t>());
         }
         // all frames, or (after the relay kernel) only the frames it flagged; unflagged workgroups exit at once

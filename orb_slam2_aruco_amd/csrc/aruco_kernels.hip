@@ -627,8 +627,8 @@ __device__ __forceinline__ void rl_advance(const BitImage& im, RelayWalk& w, uns
 __global__ __launch_bounds__(RL_THREADS) void k_contours_relay(
     const uint32_t* __restrict__ gbits, size_t bits_fstride, int wpr_g, int W, int H, int lds_bits_words, int min_len,
     int kshift, int tbits, RelaySeg* __restrict__ segs, uint32_t* __restrict__ pool, size_t pool_fstride, int pool_cap,
-    ArKept* __restrict__ kept_out, int kept_cap, ArRect* __restrict__ rects_out, int rect_cap,
-    int32_t* __restrict__ counts)
+    ArKept* __restrict__ kept_out, int kept_cap, int kcap /*kept borders this kernel's LDS holds*/,
+    ArRect* __restrict__ rects_out, int rect_cap, int32_t* __restrict__ counts)
 {
     extern __shared__ __align__(16) unsigned char ct_smem[];
     __shared__ int s_next, s_nkept, s_flags, s_ncand, s_nmark, s_nsmall, s_pool, s_changed[2];
@@ -637,20 +637,21 @@ __global__ __launch_bounds__(RL_THREADS) void k_contours_relay(
     __shared__ unsigned s_tailq;
     const int tid = threadIdx.x, f = blockIdx.x, NT = RL_THREADS;
     const int wpr = (W + 2 + 31) >> 5, prow = H + 2;
-    const int T = 1 << tbits, kmask = (1 << kshift) - 1, K = 1 << kshift;
+    const int T = 1 << tbits;
+    int kmask = (1 << kshift) - 1, K = 1 << kshift;
     // LDS: [bits][kept keys u64][kept pool offsets][ table: hkey, cmin/val, jmp, arg | tail: klen, koff, rectflag, approx ]
     uint32_t* lbits = (uint32_t*)ct_smem;
     unsigned long long* kkey = (unsigned long long*)(ct_smem + (((size_t)lds_bits_words * 4 + 15) & ~(size_t)15));
-    int* off_u = (int*)(kkey + kept_cap);
-    unsigned char* uni = (unsigned char*)(off_u + kept_cap);
+    int* off_u = (int*)(kkey + kcap);
+    unsigned char* uni = (unsigned char*)(off_u + kcap);
     uint32_t* hkey = (uint32_t*)uni;
     uint32_t* cmin = hkey + T; // smallest start state of the segment / of the border; later the ranking value
     uint16_t* jmp = (uint16_t*)(cmin + T);
     uint16_t* arg = jmp + T;   // slot of the segment that holds the border's smallest start state
     int* klen = (int*)uni;
-    int* koff = klen + kept_cap;
-    int* rectflag = koff + kept_cap;
-    ApPt* ap_out = (ApPt*)(rectflag + kept_cap);
+    int* koff = klen + kcap;
+    int* rectflag = koff + kcap;
+    ApPt* ap_out = (ApPt*)(rectflag + kcap);
     int2* ap_stack = (int2*)(ap_out + (RL_THREADS / 64) * AP_OUT);
     const uint32_t* gb = gbits + (size_t)f * bits_fstride;
     uint32_t* pl = pool + (size_t)f * pool_fstride;
@@ -687,7 +688,9 @@ __global__ __launch_bounds__(RL_THREADS) void k_contours_relay(
     const BitImage im{lbits, wpr, W, H};
     RL_STAMP();
 
-    // ---- (b) grid markers: relay rows word by word, relay columns in chunks of 32 rows
+    // ---- (b) grid markers: relay rows word by word, relay columns in chunks of 32 rows.  If they do not fit the table
+    // the grid is coarsened (K doubles) and the enumeration repeated.
+    for (;;) {
     {
         const int nrelrow = H >> kshift, nrelcol = W >> kshift, nchunk = (H + 31) >> 5;
         const int nrow_items = nrelrow * wpr, nitems = nrow_items + nrelcol * nchunk;
@@ -737,11 +740,20 @@ __global__ __launch_bounds__(RL_THREADS) void k_contours_relay(
         if (nm) atomicAdd(&s_nmark, nm);
     }
     __syncthreads();
-    if ((s_flags & RL_FLAG_TABLE) || s_nmark > T - (T >> 3)) { // too many markers for the table: k_contours_t redoes the frame
+    const bool full = (s_flags & RL_FLAG_TABLE) || s_nmark > T - (T >> 3);
+    if (!full) break;
+    if (kshift >= 7) { // even a 128-pixel grid has too many markers: k_contours_t redoes the frame
         if (tid == 0) {
             counts[f * 4 + 0] = 0; counts[f * 4 + 1] = 0; counts[f * 4 + 2] = RL_FLAG_TABLE; counts[f * 4 + 3] = 0;
         }
         return;
+    }
+    __syncthreads();
+    for (int i = tid; i < T; i += NT) hkey[i] = 0u;
+    if (tid == 0) { s_flags &= ~RL_FLAG_TABLE; s_nmark = 0; }
+    kshift++;
+    kmask = (1 << kshift) - 1; K = 1 << kshift;
+    __syncthreads();
     }
     RL_STAMP();
 
@@ -984,7 +996,7 @@ __global__ __launch_bounds__(RL_THREADS) void k_contours_relay(
                 const int k = atomicAdd(&s_nkept, 1);
                 const int base = atomicAdd(&s_pool, n);
                 if (base + n > stage0) atomicOr(&s_flags, 4);
-                else if (k < kept_cap) {
+                else if (k < kcap) {
                     RelayWalk cs;
                     relay_walk_from_key(im, cs, canon);
                     unsigned run;
@@ -1006,7 +1018,7 @@ __global__ __launch_bounds__(RL_THREADS) void k_contours_relay(
         const int k = atomicAdd(&s_nkept, 1);
         const int base = atomicAdd(&s_pool, n);
         if (base + n > stage0) atomicOr(&s_flags, 4);
-        else if (k < kept_cap) {
+        else if (k < kcap) {
             kkey[k] = ((unsigned long long)(0xffffffffu - (e.w >> 1)) << 32) | ((unsigned long long)(n & 0xfffff) << 12) |
                       ((unsigned)k << 1) | (e.w & 1u);
             off_u[k] = base;
@@ -1014,6 +1026,12 @@ __global__ __launch_bounds__(RL_THREADS) void k_contours_relay(
         }
     }
     __syncthreads();
+    if (s_nkept > kcap) { // more kept borders than this kernel's LDS arrays hold: k_contours_t redoes the frame
+        if (tid == 0) {
+            counts[f * 4 + 0] = 0; counts[f * 4 + 1] = 0; counts[f * 4 + 2] = RL_FLAG_TABLE; counts[f * 4 + 3] = 0;
+        }
+        return;
+    }
     // ---- (f2) the segments of kept borders move from the staging arenas to their final position, one wave per
     // segment (coalesced).  Segment i starts (n - val[i]) points after the list head; the border starts `minoff`
     // points into the head segment, so everything shifts down by minoff and the head's first points wrap to the end.
@@ -1060,18 +1078,15 @@ __global__ __launch_bounds__(RL_THREADS) void k_contours_relay(
     __threadfence_block();
     __syncthreads();
     if (tid == 0) {
-        if (s_nkept > kept_cap) { s_flags |= 2; s_nkept = kept_cap; }
     }
     __syncthreads();
     RL_STAMP();
     // ---- (g) the table is dead; its space holds the tail's arrays
-    // point buffers: 8 big ones in the bit image's space, 8 small ones behind the tail's arrays in the table's space
+    // point buffers: one per wave in the bit image's space; borders are handed out longest first
     uint16_t* rank_of = (uint16_t*)(ap_stack + (RL_THREADS / 64) * AP_STACK);
-    uint32_t* pbuf2 = (uint32_t*)(rank_of + kept_cap);
-    const int pbuf2_pts = (int)(((size_t)12 << tbits) - ((unsigned char*)pbuf2 - uni)) / 4 / 8;
     contours_tail(f, tid, NT, s_nkept, kkey, off_u, klen, koff, rectflag, ap_out, ap_stack, pl, kept_out, kept_cap,
-                  rects_out, rect_cap, counts, &s_flags, &s_ncand, rank_of, &s_tailq, 8, lbits,
-                  (lds_bits_words / 8) & ~3, pbuf2, pbuf2_pts > 0 ? pbuf2_pts & ~3 : 0);
+                  rects_out, rect_cap, counts, &s_flags, &s_ncand, rank_of, &s_tailq, RL_THREADS / 64, lbits,
+                  (lds_bits_words / (RL_THREADS / 64)) & ~3, nullptr, 0);
 #ifdef ORBFE_CT_TIMING
     if (tid == 0) {
         RL_STAMP();

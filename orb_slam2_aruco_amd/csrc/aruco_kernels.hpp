@@ -45,8 +45,8 @@ struct RelaySeg {
 };
 __global__ void k_contours_relay(const uint32_t* gbits, size_t bits_fstride, int wpr_g, int W, int H,
                                  int lds_bits_words, int min_len, int kshift, int tbits, RelaySeg* segs, uint32_t* pool,
-                                 size_t pool_fstride, int pool_cap, ArKept* kept_out, int kept_cap, ArRect* rects_out,
-                                 int rect_cap, int32_t* counts);
+                                 size_t pool_fstride, int pool_cap, ArKept* kept_out, int kept_cap, int kcap,
+                                 ArRect* rects_out, int rect_cap, int32_t* counts);
 __global__ void k_prefilter(ArRect* rects, int rect_cap, const int32_t* counts, int W, int H, int too_near,
                             int32_t* cand_idx, int32_t* ncand_out);
 __global__ void k_decode(ImgView src0, ImgView pyr, const ArLevel* levels, int nlevels, const ArRect* rects,
@@ -70,7 +70,7 @@ __global__ void k_finalize(const ArRect* rects, int rect_cap, const int32_t* can
 #define RL_FLAG_TABLE 32        // markers did not fit: the frame is redone by k_contours_t
 #define RL_FLAG_BUG 64          // an invariant of the relay formulation failed: redone by k_contours_t as well
 #define RL_FALLBACK_FLAGS (RL_FLAG_TABLE | RL_FLAG_BUG)
-#define RL_KSHIFT 5             // grid lines every 32 pixels
+#define RL_KCAP 512              // kept borders per frame the relay kernel holds (more: legacy kernel)
 #define RL_STEPS_PER_ITER 2      // walk steps between two looks at the work queue
 
 inline size_t relay_lds_bytes(int lds_bits_words, int kept_cap, int tbits)
