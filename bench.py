@@ -111,9 +111,11 @@ def main():
 
     ex = binding.ORBextractor(args.nfeatures, 1.2, args.nlevels, 20, 7, device=local_rank)
     cap = ex.capacity
-    d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)     # 28-byte cv::KeyPoint records
-    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
-    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+    # two sets of extractor outputs: the matching of batch i (third stream) overlaps with the extraction of batch i+1
+    sets = [(torch.zeros((B, cap, 7), dtype=torch.float32, device=dev),     # 28-byte cv::KeyPoint records
+             torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev),
+             torch.zeros(B, dtype=torch.int32, device=dev)) for _ in range(2)]
+    d_kps, d_desc, d_n = sets[0]
     d_bidx = torch.zeros((B - 1, cap), dtype=torch.int32, device=dev)
     d_bdist = torch.zeros((B - 1, cap), dtype=torch.int32, device=dev)
     d_sdist = torch.zeros((B - 1, cap), dtype=torch.int32, device=dev)
@@ -125,19 +127,25 @@ def main():
         mcap = det.capacity
         d_mk = torch.zeros((B, mcap, 9), dtype=torch.int32, device=dev)   # 36-byte marker records
         d_nmk = torch.zeros(B, dtype=torch.int32, device=dev)
-    # two HIP streams: the ORB extractor + matching on one, the ArUco detector on the other.  Both only read the
-    # resident frames, so the latency-bound ArUco kernels overlap with the bandwidth/VALU-bound ORB kernels.
+    # three HIP streams: the ORB extractor, the ArUco detector, the matching.  The first two only read the resident
+    # frames; the matching of batch i reads extractor output set i % 2 while batch i+1 is extracted into the other set.
+    # So the latency-bound kernels (contours, quadtree, SearchForInitialization) overlap with the VALU-bound ones.
     stream = torch.cuda.current_stream(dev)
     sp = ctypes.c_void_p(stream.cuda_stream)
     stream2 = torch.cuda.Stream(dev)
     sp2 = ctypes.c_void_p(stream2.cuda_stream)
+    stream3 = torch.cuda.Stream(dev)
+    sp3 = ctypes.c_void_p(stream3.cuda_stream)
+    ex_done = [torch.cuda.Event() for _ in range(2)]
+    match_done = [torch.cuda.Event() for _ in range(2)]
+    step_no = [0]
 
     gathered = None
     if world > 1:
-        rec = [d_n, d_kps, d_desc] + ([d_nmk, d_mk] if use_aruco else [])
-        gathered = [[torch.empty_like(t) for _ in range(world)] if rank == 0 else None for t in rec]
+        rec0 = [d_n, d_kps, d_desc] + ([d_nmk, d_mk] if use_aruco else [])
+        gathered = [[torch.empty_like(t) for _ in range(world)] if rank == 0 else None for t in rec0]
 
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]  # around the matching launches (same stream)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]  # around the matching launches (their stream)
 
     def step():
         if use_aruco:
@@ -148,27 +156,40 @@ def main():
                                     d_nmk.data_ptr(), sp2)
         if args.no_orb:
             return
-        ex.extract_batch_device(d_imgs.data_ptr(), B, rows * pitch, rows, cols, pitch, d_kps.data_ptr(),
-                                d_desc.data_ptr(), cap, d_n.data_ptr(), sp)
+        i = step_no[0]
+        step_no[0] += 1
+        k_kps, k_desc, k_n = sets[i % 2]
+        if i >= 2:
+            stream.wait_event(match_done[i % 2])   # the matching of batch i-2 has finished reading this output set
+        ex.extract_batch_device(d_imgs.data_ptr(), B, rows * pitch, rows, cols, pitch, k_kps.data_ptr(),
+                                k_desc.data_ptr(), cap, k_n.data_ptr(), sp)
+        ex_done[i % 2].record(stream)
         # frame t vs t-1: all-pairs knn2 + one SearchForInitialization-style windowed pass
-        ev[0].record(stream)
-        binding._check(L, L.orbfe_knn2_batch_device(d_desc.data_ptr(), d_n.data_ptr(), cap * 32, cap,
-                                                    d_desc.data_ptr() + cap * 32, d_n.data_ptr() + 4, cap * 32, cap,
+        stream3.wait_event(ex_done[i % 2])
+        ev[0].record(stream3)
+        binding._check(L, L.orbfe_knn2_batch_device(k_desc.data_ptr(), k_n.data_ptr(), cap * 32, cap,
+                                                    k_desc.data_ptr() + cap * 32, k_n.data_ptr() + 4, cap * 32, cap,
                                                     B - 1, 256, d_bidx.data_ptr(), d_bdist.data_ptr(),
-                                                    d_sdist.data_ptr(), sp), "knn2")
-        ev[1].record(stream)
+                                                    d_sdist.data_ptr(), sp3), "knn2")
+        ev[1].record(stream3)
         binding._check(L, L.orbfe_search_for_initialization_batch_device(
-            d_kps.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap, B - 1, cols, rows, 100, 0.9, 1,
-            d_m12.data_ptr(), d_nm.data_ptr(), sp), "sfi")
-        ev[2].record(stream)
+            k_kps.data_ptr(), k_desc.data_ptr(), k_n.data_ptr(), cap, B - 1, cols, rows, 100, 0.9, 1,
+            d_m12.data_ptr(), d_nm.data_ptr(), sp3), "sfi")
+        ev[2].record(stream3)
+        match_done[i % 2].record(stream3)
         if world > 1:
             if use_aruco:
                 stream.wait_stream(stream2)
+            rec = [k_n, k_kps, k_desc] + ([d_nmk, d_mk] if use_aruco else [])
             for t, g in zip(rec, gathered):
                 dist.gather(t, g, dst=0)
             if use_aruco:
                 stream2.wait_stream(stream)   # the next batch must not overwrite records that are still being gathered
 
+    if os.environ.get("ORBFE_ORB_SKIP"):    # diagnosis: what does a kernel cost the concurrent pipeline (results invalid)
+        binding.debug_control("orb_skip", int(os.environ["ORBFE_ORB_SKIP"]))
+    if os.environ.get("ORBFE_ARUCO_SKIP"):
+        binding.debug_control("aruco_skip", int(os.environ["ORBFE_ARUCO_SKIP"]))
     ex.enable_kernel_timing(False)
     if args.no_orb:  # diagnostics still want the level geometry
         ex.extract_batch_device(d_imgs.data_ptr(), B, rows * pitch, rows, cols, pitch, d_kps.data_ptr(),

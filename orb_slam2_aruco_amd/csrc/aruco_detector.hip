@@ -204,7 +204,7 @@ struct orbfe_aruco {
         }
         timer.mark(aux_stream, "pyramid");
         ORBFE_HIP(hipEventRecord(ev_join, aux_stream));
-        hipLaunchKernelGGL(k_adaptive_threshold, dim3((cols + 63) / 64, (rows + 63) / 64, B), dim3(256), 0, s, src0,
+        if (!(g_aruco_skip & 8)) hipLaunchKernelGGL(k_adaptive_threshold, dim3((cols + 63) / 64, (rows + 63) / 64, B), dim3(256), 0, s, src0,
                            cols, rows, win, 7, 1.0 / (win * win), d_bits.as<uint32_t>(), bits_fu32, wpr);
         timer.mark(s, "threshold");
         const size_t lds = contours_lds_bytes(lds_bits_words, AR_MAX_KEPT);
@@ -213,7 +213,7 @@ struct orbfe_aruco {
         ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));
         const bool relay = relay_tbits && !force_legacy;
-        if (relay) {
+        if (relay && !(g_aruco_skip & 1)) {
             const size_t rlds = relay_lds_bytes(lds_bits_words, RL_KCAP, relay_tbits);
             ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_contours_relay),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
@@ -223,7 +223,7 @@ struct orbfe_aruco {
                                d_rects.as<ArRect>(), AR_MAX_RECTS, d_counts.as<int32_t>());
         }
         // all frames, or (after the relay kernel) only the frames it flagged; unflagged workgroups exit at once
-        hipLaunchKernelGGL(kfn, dim3(B), dim3(CT_PROBE_THREADS), lds, s, d_bits.as<uint32_t>(), bits_fu32, wpr, cols, rows,
+        if (!(g_aruco_skip & 1)) hipLaunchKernelGGL(kfn, dim3(B), dim3(CT_PROBE_THREADS), lds, s, d_bits.as<uint32_t>(), bits_fu32, wpr, cols, rows,
                            lds_bits_words, 70, d_candq.as<uint32_t>(), candq_fu32, (int)candq_fu32,
                            d_pool.as<uint32_t>(), pool_fu32, (int)pool_fu32, d_kept.as<ArKept>(), AR_MAX_KEPT,
                            d_rects.as<ArRect>(), AR_MAX_RECTS, d_counts.as<int32_t>(), d_gpad.as<uint32_t>(),
@@ -233,11 +233,11 @@ struct orbfe_aruco {
         hipLaunchKernelGGL(k_prefilter, dim3(B), dim3(256), 0, s, d_rects.as<ArRect>(), AR_MAX_RECTS,
                            d_counts.as<int32_t>(), cols, rows, win, d_candidx.as<int32_t>(), d_ncand.as<int32_t>());
         ORBFE_HIP(hipStreamWaitEvent(s, ev_join, 0));
-        hipLaunchKernelGGL(k_decode, dim3(32, B), dim3(64), 0, s, src0, pyr, d_levels.as<ArLevel>(), npyr,
+        if (!(g_aruco_skip & 2)) hipLaunchKernelGGL(k_decode, dim3(32, B), dim3(64), 0, s, src0, pyr, d_levels.as<ArLevel>(), npyr,
                            d_rects.as<ArRect>(), AR_MAX_RECTS, d_candidx.as<int32_t>(), d_ncand.as<int32_t>(), S, nb,
                            d_codes.as<unsigned long long>(), ncodes, d_result.as<int32_t>(), cols);
         timer.mark(s, "decode");
-        hipLaunchKernelGGL(k_finalize, dim3(B), dim3(256), 0, s, d_rects.as<ArRect>(), AR_MAX_RECTS,
+        if (!(g_aruco_skip & 4)) hipLaunchKernelGGL(k_finalize, dim3(B), dim3(256), 0, s, d_rects.as<ArRect>(), AR_MAX_RECTS,
                            d_candidx.as<int32_t>(), d_ncand.as<int32_t>(), d_result.as<int32_t>(),
                            d_pool.as<uint32_t>(), pool_fu32, d_out_m, capacity, d_n);
         timer.mark(s, "finalize");
@@ -370,6 +370,11 @@ int orbfe_aruco_debug_image(orbfe_aruco* h, int frame, int stage, uint8_t* out)
     }
     if (stage == 102) { // tail of the kept array (phase timing words of instrumented builds), 96 bytes
         ORBFE_HIP(hipMemcpy(out, h->d_kept.as<ArKept>() + (size_t)frame * AR_MAX_KEPT + AR_MAX_KEPT - 4, 96,
+                            hipMemcpyDeviceToHost));
+        return ORBFE_OK;
+    }
+    if (stage == 103) { // decode results of the frame, raw (instrumented builds keep phase timers of slot 0 at entry 200)
+        ORBFE_HIP(hipMemcpy(out, h->d_result.as<int32_t>() + (size_t)frame * AR_MAX_RECTS * 2, (size_t)AR_MAX_RECTS * 8,
                             hipMemcpyDeviceToHost));
         return ORBFE_OK;
     }

@@ -1254,6 +1254,13 @@ __global__ __launch_bounds__(64) void k_decode(ImgView src0, ImgView pyr, const 
     for (int slot = blockIdx.x; slot < nc; slot += gridDim.x) {
         __syncthreads();
         int32_t* res = result + ((size_t)f * rect_cap + slot) * 2;
+#ifdef ORBFE_CT_TIMING
+        long long dq[8]; int dqi = 0;
+#define DC_STAMP() dq[dqi++] = clock64()
+#else
+#define DC_STAMP()
+#endif
+        DC_STAMP();
         const ArRect r = rects[(size_t)f * rect_cap + cand_idx[(size_t)f * rect_cap + slot]];
         // pyramid level: largest p with area / 4^p >= S^2 (markerdetector_impl.cpp:6507-6586)
         const float v01x = r.c[1][0] - r.c[0][0], v01y = r.c[1][1] - r.c[0][1];
@@ -1314,6 +1321,7 @@ __global__ __launch_bounds__(64) void k_decode(ImgView src0, ImgView pyr, const 
             if (lane == 0) { res[0] = -1; res[1] = 0; }
             continue;
         }
+        DC_STAMP();
         for (int i = lane; i < 256; i += 64) s_hist[i] = 0;
         s_ones[lane] = 0;
         s_tot[lane] = 0;
@@ -1347,6 +1355,7 @@ __global__ __launch_bounds__(64) void k_decode(ImgView src0, ImgView pyr, const 
             atomicAdd(&s_hist[v], 1);
         }
         __syncthreads();
+        DC_STAMP();
         // getThreshVal_Otsu_8u.  The running sums q1 / mu1 are serial by definition (each step rounds), so lane 0 walks
         // the 256 bins with exactly the reference's operation sequence; mu2 and sigma of every bin are independent of
         // the other bins and are evaluated by all lanes afterwards (first maximum wins, like the serial 'sigma > max').
@@ -1425,6 +1434,7 @@ __global__ __launch_bounds__(64) void k_decode(ImgView src0, ImgView pyr, const 
             s_ids[lane] = v;
         }
         __syncthreads();
+        DC_STAMP();
         int id = -1, nrot = 0;
         if (!bad && s_ids[0] != 0) {
             // first rotation whose code is in the dictionary; id = first index holding that code (map.insert semantics)
@@ -1438,6 +1448,14 @@ __global__ __launch_bounds__(64) void k_decode(ImgView src0, ImgView pyr, const 
             }
         }
         if (lane == 0) { res[0] = id; res[1] = nrot; }
+#ifdef ORBFE_CT_TIMING
+        DC_STAMP();
+        if (lane == 0 && slot < 32) { // (instrumented builds only; entries 64.. of the frame's result block are unused)
+            long long* dbg = (long long*)(result + ((size_t)f * rect_cap + 64) * 2) + slot * 6;
+            for (int i = 0; i + 1 < dqi; i++) dbg[i] = dq[i + 1] - dq[i];
+            dbg[5] = id;
+        }
+#endif
     } // slot loop
 }
 

@@ -534,6 +534,7 @@ static MatchWorkspace& ws()
 
 // debug: 0 = choose by problem size, 1 = VALU tiles (+ split/merge), 2 = matrix cores (orbfe_debug_control "knn2_path")
 static int g_knn2_path = 0;
+int g_orb_skip = 0, g_aruco_skip = 0;
 
 static int knn2_launch(const uint8_t* d_Q, const int32_t* d_nq, size_t q_stride, int max_nq, const uint8_t* d_T,
                        const int32_t* d_nt, size_t t_stride, int max_nt, int npairs, int init, int32_t* d_best_idx,
@@ -610,6 +611,8 @@ extern "C" {
 int orbfe_debug_control(const char* key, int value)
 {
     if (key && !strcmp(key, "knn2_path") && value >= 0 && value <= 2) { g_knn2_path = value; return ORBFE_OK; }
+    if (key && !strcmp(key, "orb_skip")) { orbfe::g_orb_skip = value; return ORBFE_OK; }
+    if (key && !strcmp(key, "aruco_skip")) { orbfe::g_aruco_skip = value; return ORBFE_OK; }
     return fail(ORBFE_ERR_INVALID, "orbfe_debug_control: unknown key or value");
 }
 

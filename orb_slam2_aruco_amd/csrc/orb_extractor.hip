@@ -288,7 +288,7 @@ struct orbfe_extractor {
         timer.begin();
         timer.mark(s, "start");
         ORBFE_HIP(hipMemsetAsync(d_overflow.p, 0, 4, s));
-        for (int l = 1; l < nlevels; l++) {
+        for (int l = 1; l < nlevels && !(g_orb_skip & 16); l++) {
             const LevelGeom& g = geom[l];
             const LevelGeom& gp = geom[l - 1];
             ImgView sv = (l == 1) ? src0 : ImgView{pyr.base + gp.img_off, nullptr, pyr_fbytes, gp.pitch};
@@ -313,7 +313,7 @@ struct orbfe_extractor {
         ORBFE_HIP(hipEventRecord(ev_fork, s));
         ORBFE_HIP(hipStreamWaitEvent(aux_stream, ev_fork, 0));
         timer.mark(aux_stream, "blur7 starts", true);
-        hipLaunchKernelGGL(k_blur7, dim3(xcd_grid(ntiles * B)), dim3(256), 0, aux_stream, src0, pyr, blur, dg,
+        if (!(g_orb_skip & 8)) hipLaunchKernelGGL(k_blur7, dim3(xcd_grid(ntiles * B)), dim3(256), 0, aux_stream, src0, pyr, blur, dg,
                            d_tiles.as<uint32_t>(), ntiles, ntiles * B);
         timer.mark(aux_stream, "blur7");
         ORBFE_HIP(hipEventRecord(ev_join, aux_stream));
@@ -328,7 +328,7 @@ struct orbfe_extractor {
             ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fast_cells),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             const int nx = (ncells_total + 3) / 4;
-            hipLaunchKernelGGL(k_fast_cells, dim3(xcd_grid(nx * B)), dim3(256), lds, s, src0, pyr, dg,
+            if (!(g_orb_skip & 1)) hipLaunchKernelGGL(k_fast_cells, dim3(xcd_grid(nx * B)), dim3(256), lds, s, src0, pyr, dg,
                                d_cellinfo.as<uint32_t>(), d_slots.as<uint32_t>(), slots_fu32,
                                d_cellcnt.as<int32_t>(), ncells_total, iniThFAST, minThFAST, roi_pitch, roi_rows,
                                map_pitch, map_rows, list_cap, nx, nx * B);
@@ -342,7 +342,7 @@ struct orbfe_extractor {
             const size_t lds_p = qp_lds_bytes(max_ini, D, nodecap, veccap);
             ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_distribute_pyr),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
-            hipLaunchKernelGGL(k_distribute_pyr, dim3(nlevels, B), dim3(QP_THREADS), lds_p, s, dg, d_slots.as<uint32_t>(),
+            if (!(g_orb_skip & 2)) hipLaunchKernelGGL(k_distribute_pyr, dim3(nlevels, B), dim3(QP_THREADS), lds_p, s, dg, d_slots.as<uint32_t>(),
                                slots_fu32, d_cellcnt.as<int32_t>(), ncells_total, d_lvlout.as<uint32_t>(), out_total,
                                d_lvlcnt.as<int32_t>(), nlevels, d_lvlncand.as<int32_t>(), d_fallback.as<int32_t>(), D,
                                nodecap, veccap);
@@ -365,7 +365,7 @@ struct orbfe_extractor {
                            d_flatkv.as<uint32_t>(), d_flatlvl.as<uint8_t>());
         ORBFE_HIP(hipStreamWaitEvent(s, ev_join, 0));
         const int okx = (std::min(capacity, max_keypoints()) + 3) / 4;
-        hipLaunchKernelGGL(k_orient_describe, dim3(xcd_grid(okx * B)), dim3(256), 0, s, src0, pyr, blur, dg,
+        if (!(g_orb_skip & 4)) hipLaunchKernelGGL(k_orient_describe, dim3(xcd_grid(okx * B)), dim3(256), 0, s, src0, pyr, blur, dg,
                            d_flatkv.as<uint32_t>(), d_flatlvl.as<uint8_t>(), d_n, nlevels, d_pattern.as<uint32_t>(),
                            d_umax.as<int>(), d_kps_out, d_desc_out, capacity, okx, okx * B);
         timer.mark(s, "orient_describe");

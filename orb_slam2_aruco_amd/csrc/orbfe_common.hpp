@@ -14,6 +14,9 @@
 namespace orbfe {
 
 extern thread_local char g_err[512];
+// diagnosis only (orbfe_debug_control "orb_skip" / "aruco_skip"): bit masks of launches to leave out when measuring what a
+// kernel costs the concurrent pipeline; results are garbage while a bit is set
+extern int g_orb_skip, g_aruco_skip;
 
 inline int fail(int code, const char* fmt, ...)
 {
