@@ -27,7 +27,7 @@ struct orbfe_aruco {
     std::vector<size_t> tab_off;          // resize tables for non-exact levels
     size_t pyr_fbytes = 0, bits_fu32 = 0, candq_fu32 = 0, pool_fu32 = 0, gpad_fu32 = 0;
     int lds_bits_words = 0;
-    DevBuf d_segs;
+    DevBuf d_segs, d_tailkeys, d_tailoff;
     int relay_kshift = 5;      // initial grid spacing (log2) of k_contours_relay
     int relay_tbits = 0;       // hash-table size of k_contours_relay (0: the kernel cannot run at this image size)
     bool force_legacy = false; // debug: always use k_contours_t
@@ -40,7 +40,7 @@ struct orbfe_aruco {
     ~orbfe_aruco()
     {
         for (DevBuf* b : {&d_codes, &d_levels, &d_tabs, &d_bits, &d_pyr, &d_candq, &d_pool, &d_kept, &d_rects,
-                          &d_counts, &d_candidx, &d_ncand, &d_result, &d_gpad, &d_in, &d_out, &d_nout, &d_segs})
+                          &d_counts, &d_candidx, &d_ncand, &d_result, &d_gpad, &d_in, &d_out, &d_nout, &d_segs, &d_tailkeys, &d_tailoff})
             b->release();
         if (own_stream) (void)hipStreamDestroy(own_stream);
         if (aux_stream) (void)hipStreamDestroy(aux_stream);
@@ -167,7 +167,8 @@ struct orbfe_aruco {
             (rc = d_candidx.ensure((size_t)AR_MAX_RECTS * 4 * B)) || (rc = d_ncand.ensure((size_t)4 * B)) ||
             (rc = d_result.ensure((size_t)AR_MAX_RECTS * 8 * B)) ||
             (rc = d_gpad.ensure(std::max<size_t>(gpad_fu32 * 4 * B, 16))) ||
-            (rc = d_segs.ensure(std::max<size_t>(((size_t)sizeof(RelaySeg) << relay_tbits) * B, 16))))
+            (rc = d_segs.ensure(std::max<size_t>(((size_t)sizeof(RelaySeg) << relay_tbits) * B, 16))) ||
+            (rc = d_tailkeys.ensure((size_t)RL_KCAP * 8 * B)) || (rc = d_tailoff.ensure((size_t)RL_KCAP * 4 * B)))
             return rc;
         batch_cap = B;
         return ORBFE_OK;
@@ -220,7 +221,13 @@ struct orbfe_aruco {
             hipLaunchKernelGGL(k_contours_relay, dim3(B), dim3(RL_THREADS), rlds, s, d_bits.as<uint32_t>(), bits_fu32, wpr,
                                cols, rows, lds_bits_words, 70, relay_kshift, relay_tbits, d_segs.as<RelaySeg>(),
                                d_pool.as<uint32_t>(), pool_fu32, (int)pool_fu32, d_kept.as<ArKept>(), AR_MAX_KEPT, RL_KCAP,
-                               d_rects.as<ArRect>(), AR_MAX_RECTS, d_counts.as<int32_t>());
+                               d_tailkeys.as<unsigned long long>(), d_tailoff.as<int32_t>(), d_counts.as<int32_t>());
+            const size_t tlds = tail_lds_bytes(RL_KCAP, 1280);
+            ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_contours_tail),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
+            hipLaunchKernelGGL(k_contours_tail, dim3(B), dim3(RT_THREADS), tlds, s, d_tailkeys.as<unsigned long long>(),
+                               d_tailoff.as<int32_t>(), RL_KCAP, d_pool.as<uint32_t>(), pool_fu32, d_kept.as<ArKept>(),
+                               AR_MAX_KEPT, d_rects.as<ArRect>(), AR_MAX_RECTS, d_counts.as<int32_t>(), (int)tlds);
         }
         // all frames, or (after the relay kernel) only the frames it flagged; unflagged workgroups exit at once
         if (!(g_aruco_skip & 1)) hipLaunchKernelGGL(kfn, dim3(B), dim3(CT_PROBE_THREADS), lds, s, d_bits.as<uint32_t>(), bits_fu32, wpr, cols, rows,

@@ -624,11 +624,11 @@ __device__ __forceinline__ void rl_advance(const BitImage& im, RelayWalk& w, uns
     w.ring = ring8(im, w.x, w.y);
 }
 
-__global__ __launch_bounds__(RL_THREADS) void k_contours_relay(
+__global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_num_vgpr(64))) void k_contours_relay(
     const uint32_t* __restrict__ gbits, size_t bits_fstride, int wpr_g, int W, int H, int lds_bits_words, int min_len,
     int kshift, int tbits, RelaySeg* __restrict__ segs, uint32_t* __restrict__ pool, size_t pool_fstride, int pool_cap,
     ArKept* __restrict__ kept_out, int kept_cap, int kcap /*kept borders this kernel's LDS holds*/,
-    ArRect* __restrict__ rects_out, int rect_cap, int32_t* __restrict__ counts)
+    unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off, int32_t* __restrict__ counts)
 {
     extern __shared__ __align__(16) unsigned char ct_smem[];
     __shared__ int s_next, s_nkept, s_flags, s_ncand, s_nmark, s_nsmall, s_pool, s_changed[2];
@@ -639,15 +639,20 @@ __global__ __launch_bounds__(RL_THREADS) void k_contours_relay(
     const int wpr = (W + 2 + 31) >> 5, prow = H + 2;
     const int T = 1 << tbits;
     int kmask = (1 << kshift) - 1, K = 1 << kshift;
-    // LDS: [bits][kept keys u64][kept pool offsets][ table: hkey, cmin/val, jmp, arg | tail: klen, koff, rectflag, approx ]
+    // LDS: one region R seen three ways, then the marker keys (so that the tail's point buffers can run on into them):
+    //   walks (a-d):  R = the padded bit image
+    //   lists (e-f):  R = kept keys u64, kept pool offsets, cmin/val, jmp, arg      (the bit image is dead)
+    //   tail  (g):    R = kept keys, offsets | klen, koff, rectflag, approx scratch, length ranks, point buffers ...
+    //   [hkey: T marker state keys] lives until (f2)
     uint32_t* lbits = (uint32_t*)ct_smem;
-    unsigned long long* kkey = (unsigned long long*)(ct_smem + (((size_t)lds_bits_words * 4 + 15) & ~(size_t)15));
+    unsigned long long* kkey = (unsigned long long*)ct_smem;
     int* off_u = (int*)(kkey + kcap);
     unsigned char* uni = (unsigned char*)(off_u + kcap);
-    uint32_t* hkey = (uint32_t*)uni;
-    uint32_t* cmin = hkey + T; // smallest start state of the segment / of the border; later the ranking value
+    uint32_t* cmin = (uint32_t*)uni; // smallest start state of the segment / of the border; later the ranking value
     uint16_t* jmp = (uint16_t*)(cmin + T);
     uint16_t* arg = jmp + T;   // slot of the segment that holds the border's smallest start state
+    const size_t r_bytes = relay_region_bytes(lds_bits_words, kcap, tbits);
+    uint32_t* hkey = (uint32_t*)(ct_smem + r_bytes);
     int* klen = (int*)uni;
     int* koff = klen + kcap;
     int* rectflag = koff + kcap;
@@ -757,6 +762,11 @@ __global__ __launch_bounds__(RL_THREADS) void k_contours_relay(
     }
     RL_STAMP();
 
+    // every lane owns a staging arena in the upper part of the frame's pool: the points of its segments (d) and of the
+    // small borders it keeps (c) wait there until (f2) knows their final place
+    const int stage0 = pool_cap >> 2, arena = (pool_cap - stage0) / NT;
+    uint32_t* my_arena = pl + stage0 + tid * arena;
+    int wp = 0;
     // ---- (c) small borders.  A lane takes one 32-pixel word of start candidates at a time; every loop iteration
     // advances each busy lane by ONE step.  A walk stops at a grid marker (the border belongs to (d)), at a proof that
     // the candidate is not canonical, or when the border closes; a closed border longer than min_len is queued.
@@ -818,11 +828,19 @@ __global__ __launch_bounds__(RL_THREADS) void k_contours_relay(
                         if (wk.x == sx && wk.y == sy && wk.s == s0) {
                             busy = false;
                             if (wk.n > min_len) {
-                                const int q = atomicAdd(&s_nsmall, 1);
-                                if (q < RL_SMALL_CAP)
-                                    s_small[q] = make_uint4(relay_key(sx, sy, s0), (uint32_t)wk.n, 0xffffffffu,
+                                // rare (> min_len points between grid lines): walk it once more, into the staging arena
+                                const int q = atomicAdd(&s_nsmall, 1), n = wk.n;
+                                if (q < RL_SMALL_CAP && wp + n <= arena) {
+                                    RelayWalk w2;
+                                    relay_walk_from_key(im, w2, relay_key(sx, sy, s0));
+                                    for (int o = 0; o < n; o++) {
+                                        my_arena[wp + o] = relay_point(w2);
+                                        rl_advance(im, w2, s_lut[(w2.ring << 3) | (unsigned)w2.s]);
+                                    }
+                                    s_small[q] = make_uint4((uint32_t)(stage0 + tid * arena + wp), (uint32_t)n, 0xffffffffu,
                                                             (uint32_t)start_key * 2u + (uint32_t)is_hole);
-                                else atomicOr(&s_flags, RL_FLAG_TABLE);
+                                    wp += n;
+                                } else atomicOr(&s_flags, RL_FLAG_TABLE);
                             }
                         }
                     }
@@ -838,13 +856,11 @@ __global__ __launch_bounds__(RL_THREADS) void k_contours_relay(
 
     // ---- (d) segments: table slot -> walk to the next grid marker.  The points go to the lane's staging arena (upper
     // part of the frame's pool); (f2) copies the segments of kept borders to their final place.
-    const int stage0 = pool_cap >> 2, arena = (pool_cap - stage0) / NT;
     {
         RelayWalk wk;
         bool busy = false, drained = false;
-        int slot = 0, mnoff = 0, wp = 0;
-        uint32_t mn = 0xffffffffu;
-        uint32_t* my_arena = pl + stage0 + tid * arena;
+        int slot = 0, mnoff = 0;
+        uint32_t mn = 0xffffffffu, mnhole = 0;
         for (;;) {
             if (!busy && !drained) {
                 const int i = atomicAdd(&s_next, 1);
@@ -854,7 +870,7 @@ __global__ __launch_bounds__(RL_THREADS) void k_contours_relay(
                     if (key) {
                         slot = i;
                         relay_walk_from_key(im, wk, key);
-                        mn = 0xffffffffu; mnoff = 0;
+                        mn = 0xffffffffu; mnoff = 0; mnhole = 0;
                         busy = true;
                     }
                 }
@@ -868,18 +884,16 @@ __global__ __launch_bounds__(RL_THREADS) void k_contours_relay(
                         int nx = rl_find(hkey, tbits, relay_key(wk.x, wk.y, wk.s));
                         if (nx < 0) { atomicOr(&s_flags, RL_FLAG_BUG); nx = slot; }
                         RelaySeg r;
-                        r.nxt = (uint32_t)nx; r.len = (uint32_t)wk.n; r.minoff = (uint32_t)mnoff;
+                        r.nxt = (uint32_t)nx; r.len = (uint32_t)wk.n; r.minoff = (uint32_t)mnoff | (mnhole << 31);
                         r.stg = (uint32_t)(stage0 + tid * arena + wp);
+                        r.mn = mn;
                         sg[slot] = r;
-                        cmin[slot] = mn;
-                        arg[slot] = (uint16_t)slot;
-                        jmp[slot] = (uint16_t)nx;
                         wp += wk.n;
                         busy = false;
                     } else {
                         if (e & 0x60u) {
                             const uint32_t k = relay_key(wk.x, wk.y, wk.s);
-                            if (k < mn) { mn = k; mnoff = wk.n; }
+                            if (k < mn) { mn = k; mnoff = wk.n; mnhole = ((e >> 5) & 3u) == 2u ? 1u : 0u; }
                         }
                         if (wp + wk.n < arena) my_arena[wp + wk.n] = relay_point(wk);
                         else { atomicOr(&s_flags, RL_FLAG_TABLE); busy = false; } // staging full: legacy kernel
@@ -898,6 +912,16 @@ __global__ __launch_bounds__(RL_THREADS) void k_contours_relay(
     }
     RL_STAMP();
 
+    // the bit image is dead: its space now holds the list arrays, loaded from the segment records
+#pragma unroll
+    for (int q = 0; q < RL_SLOTS_PER_THREAD; q++) {
+        const int i = tid + q * NT;
+        if (i < T && hkey[i]) {
+            const RelaySeg r = sg[i];
+            cmin[i] = r.mn; jmp[i] = (uint16_t)r.nxt; arg[i] = (uint16_t)i;
+        }
+    }
+    __syncthreads();
     // ---- (e1) the border's smallest start state, by pointer doubling round the cyclic list.  When a round changes
     // nothing, every window already covers its cycle (windows double; "no change" makes the minima periodic).
     for (int round = 0; round < 24; round++) {
@@ -997,12 +1021,8 @@ __global__ __launch_bounds__(RL_THREADS) void k_contours_relay(
                 const int base = atomicAdd(&s_pool, n);
                 if (base + n > stage0) atomicOr(&s_flags, 4);
                 else if (k < kcap) {
-                    RelayWalk cs;
-                    relay_walk_from_key(im, cs, canon);
-                    unsigned run;
-                    relay_examine(cs.ring, cs.s, &run);
-                    const unsigned hole = relay_start_class(cs.ring, run) == 2 ? 1u : 0u;
-                    const uint32_t disc = (uint32_t)(cs.y * 65536 + cs.x) + hole;
+                    const unsigned hole = sg[i].minoff >> 31; // pattern of the canonical start (this segment holds it)
+                    const uint32_t disc = (canon >> 16) * 65536u + ((canon >> 3) & 0x1fffu) + hole;
                     kkey[k] = ((unsigned long long)(0xffffffffu - disc) << 32) | ((unsigned long long)(n & 0xfffff) << 12) |
                               ((unsigned)k << 1) | hole;
                     off_u[k] = base;
@@ -1032,48 +1052,96 @@ __global__ __launch_bounds__(RL_THREADS) void k_contours_relay(
         }
         return;
     }
-    // ---- (f2) the segments of kept borders move from the staging arenas to their final position, one wave per
-    // segment (coalesced).  Segment i starts (n - val[i]) points after the list head; the border starts `minoff`
-    // points into the head segment, so everything shifts down by minoff and the head's first points wrap to the end.
+    // ---- (f2) the segments of kept borders move from the staging arenas to their final position.  Segment i starts
+    // (n - val[i]) points after the list head; the border starts `minoff` points into the head segment, so everything
+    // shifts down by minoff and the head's first points wrap to the end.  The copy runs flat over all points: the kept
+    // segments are listed (in the marker keys' space, dead after this point) with a running point count, and every
+    // lane finds the segment of its point by binary search.
     {
-        const int lane = tid & 63, wid = tid >> 6;
-        for (int i0 = wid * 64; i0 < T; i0 += (NT >> 6) * 64) {
-            const int i = i0 + lane;
-            int src = 0, dst = 0, len = 0, base = 0, n = 0;
-            if (hkey[i]) {
+        int e_dst[RL_SLOTS_PER_THREAD], e_src[RL_SLOTS_PER_THREAD], e_len[RL_SLOTS_PER_THREAD], e_k[RL_SLOTS_PER_THREAD];
+        int mine = 0;
+#pragma unroll
+        for (int q = 0; q < RL_SLOTS_PER_THREAD; q++) {
+            const int i = tid + q * NT;
+            e_len[q] = 0;
+            if (i < T && hkey[i]) {
                 const int g = arg[i];
                 const int k = jmp[g];
                 if (k != RL_NIL) {
                     const RelaySeg r = sg[i];
-                    n = (int)val[g]; base = off_u[k];
-                    dst = base + (n - (int)val[i]) - (int)sg[g].minoff;
-                    src = (int)r.stg; len = (int)r.len;
+                    const int n = (int)val[g];
+                    e_dst[q] = off_u[k] + (n - (int)val[i]) - (int)(sg[g].minoff & 0x7fffffffu);
+                    e_src[q] = (int)r.stg; e_len[q] = (int)r.len; e_k[q] = k;
+                    mine++;
                 }
             }
-            unsigned long long todo = __ballot(len > 0);
-            while (todo) {
-                const int L = __ffsll((long long)todo) - 1;
-                todo &= todo - 1;
-                const int src_ = __shfl(src, L), dst_ = __shfl(dst, L), len_ = __shfl(len, L), base_ = __shfl(base, L),
-                          n_ = __shfl(n, L);
-                for (int o = lane; o < len_; o += 64) {
-                    int p = dst_ + o;
-                    if (p < base_) p += n_;
-                    pl[p] = pl[src_ + o];
+        }
+        if (tid == 0) s_next = 0;
+        __syncthreads(); // every read of the marker keys done
+        int* c_pre = (int*)hkey;            // points before the entry (exclusive running count), RL_COPY_CAP + 1
+        int* c_dst = c_pre + RL_COPY_CAP + 1;
+        int* c_src = c_dst + RL_COPY_CAP;
+        uint16_t* c_k = (uint16_t*)(c_src + RL_COPY_CAP);
+        int e0 = mine ? atomicAdd(&s_next, mine) : 0;
+#pragma unroll
+        for (int q = 0; q < RL_SLOTS_PER_THREAD; q++)
+            if (e_len[q] > 0) {
+                if (e0 < RL_COPY_CAP) { c_pre[e0] = e_len[q]; c_dst[e0] = e_dst[q]; c_src[e0] = e_src[q]; c_k[e0] = (uint16_t)e_k[q]; }
+                e0++;
+            }
+        __syncthreads();
+        const int E = s_next;
+        if (E > RL_COPY_CAP) { // more kept segments than the copy list holds: k_contours_t redoes the frame
+            if (tid == 0) {
+                counts[f * 4 + 0] = 0; counts[f * 4 + 1] = 0; counts[f * 4 + 2] = RL_FLAG_TABLE; counts[f * 4 + 3] = 0;
+            }
+            return;
+        }
+        // exclusive scan of the lengths (one entry per thread; RL_COPY_CAP == RL_THREADS)
+        {
+            const int lane = tid & 63, wid = tid >> 6;
+            const int len = tid < E ? c_pre[tid] : 0;
+            const int incl = wave_incl_scan_add(len);
+            __syncthreads();
+            if (lane == 63) c_pre[RL_COPY_CAP - 16 + wid] = incl; // wave totals parked at the end (entries there are read above)
+            __syncthreads();
+            int wbase = 0;
+            for (int w = 0; w < wid; w++) wbase += c_pre[RL_COPY_CAP - 16 + w];
+            __syncthreads();
+            c_pre[tid] = wbase + incl - len;
+            if (tid == NT - 1) c_pre[RL_COPY_CAP] = wbase + incl;
+            __syncthreads();
+        }
+        const int total = c_pre[RL_COPY_CAP];
+        for (int q0 = tid; q0 < total; q0 += 4 * NT) { // four independent points per lane: their latencies overlap
+            int pdst[4];
+            uint32_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int q = q0 + u * NT;
+                pdst[u] = -1;
+                if (q < total) {
+                    int lo = 0, hi = E - 1; // largest entry with c_pre <= q
+                    while (lo < hi) {
+                        const int mid = (lo + hi + 1) >> 1;
+                        if (c_pre[mid] <= q) lo = mid; else hi = mid - 1;
+                    }
+                    const int o = q - c_pre[lo], k = c_k[lo];
+                    const int base = off_u[k], n = (int)((kkey[k] >> 12) & 0xfffff);
+                    int p = c_dst[lo] + o;
+                    if (p < base) p += n;
+                    pdst[u] = p;
+                    v[u] = pl[c_src[lo] + o];
                 }
             }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (pdst[u] >= 0) pl[pdst[u]] = v[u];
         }
     }
     if (tid < min(s_nsmall, RL_SMALL_CAP) && s_small[tid].z != 0xffffffffu) {
-        const uint4 e = s_small[tid];
-        RelayWalk wk;
-        relay_walk_from_key(im, wk, e.x);
-        for (int o = 0; o < (int)e.y; o++) {
-            unsigned run;
-            const int d = relay_examine(wk.ring, wk.s, &run);
-            pl[e.z + o] = relay_point(wk);
-            relay_advance(im, wk, d);
-        }
+        const uint4 e = s_small[tid]; // staged points -> final place
+        for (int o = 0; o < (int)e.y; o++) pl[e.z + o] = pl[e.x + o];
     }
     __threadfence_block();
     __syncthreads();
@@ -1081,19 +1149,63 @@ __global__ __launch_bounds__(RL_THREADS) void k_contours_relay(
     }
     __syncthreads();
     RL_STAMP();
-    // ---- (g) the table is dead; its space holds the tail's arrays
-    // point buffers: one per wave in the bit image's space; borders are handed out longest first
-    uint16_t* rank_of = (uint16_t*)(ap_stack + (RL_THREADS / 64) * AP_STACK);
-    contours_tail(f, tid, NT, s_nkept, kkey, off_u, klen, koff, rectflag, ap_out, ap_stack, pl, kept_out, kept_cap,
-                  rects_out, rect_cap, counts, &s_flags, &s_ncand, rank_of, &s_tailq, RL_THREADS / 64, lbits,
-                  (lds_bits_words / (RL_THREADS / 64)) & ~3, nullptr, 0);
+    // ---- hand the kept borders (sort key, pool offset) to k_contours_tail
+    {
+        const int nk = s_nkept;
+        for (int k = tid; k < nk; k += NT) {
+            tail_keys[(size_t)f * kcap + k] = kkey[k];
+            tail_off[(size_t)f * kcap + k] = off_u[k];
+        }
+        if (tid == 0) {
+            counts[f * 4 + 0] = nk; counts[f * 4 + 1] = 0; counts[f * 4 + 2] = s_flags; counts[f * 4 + 3] = s_ncand;
+        }
+    }
 #ifdef ORBFE_CT_TIMING
     if (tid == 0) {
         RL_STAMP();
         long long* dbg = (long long*)(kept_out + (size_t)f * kept_cap + kept_cap - 4);
-        for (int i = 0; i < 7; i++) dbg[i] = tq[i + 1] - tq[i];
+        for (int i = 0; i < 6; i++) dbg[i] = tq[i + 1] - tq[i];
+        dbg[6] = 0;
     }
 #endif
+}
+
+// ---- (g) of the relay formulation as its own kernel: sort, approxPolyDP, rectangles for the borders k_contours_relay
+// kept.  (Separate because approxPolyDP needs twice the registers of the walks: the relay kernel stays at 64 VGPRs, so
+// two of its workgroups share a CU.)  Frames the relay kernel gave up on are skipped; k_contours_t redoes them.
+__global__ __launch_bounds__(RT_THREADS) void k_contours_tail(const unsigned long long* __restrict__ tail_keys,
+                                                               const int32_t* __restrict__ tail_off, int kcap,
+                                                               const uint32_t* __restrict__ pool, size_t pool_fstride,
+                                                               ArKept* __restrict__ kept_out, int kept_cap,
+                                                               ArRect* __restrict__ rects_out, int rect_cap,
+                                                               int32_t* __restrict__ counts, int lds_bytes)
+{
+    extern __shared__ __align__(16) unsigned char ct_smem[];
+    __shared__ int s_flags, s_ncand;
+    __shared__ unsigned s_tailq;
+    const int tid = threadIdx.x, f = blockIdx.x;
+    const int flags = counts[f * 4 + 2];
+    if (flags & RL_FALLBACK_FLAGS) return;
+    const int nkept = counts[f * 4 + 0];
+    unsigned long long* kkey = (unsigned long long*)ct_smem;
+    int* off_u = (int*)(kkey + kcap);
+    int* klen = off_u + kcap;
+    int* koff = klen + kcap;
+    int* rectflag = koff + kcap;
+    ApPt* ap_out = (ApPt*)(rectflag + kcap);
+    int2* ap_stack = (int2*)(ap_out + (RT_THREADS / 64) * AP_OUT);
+    uint16_t* rank_of = (uint16_t*)(ap_stack + (RT_THREADS / 64) * AP_STACK);
+    uint32_t* pb = (uint32_t*)(rank_of + kcap);
+    const int pb_pts = ((int)((lds_bytes - (int)((unsigned char*)pb - ct_smem)) / 4) / (RT_THREADS / 64)) & ~3;
+    for (int k = tid; k < nkept; k += RT_THREADS) {
+        kkey[k] = tail_keys[(size_t)f * kcap + k];
+        off_u[k] = tail_off[(size_t)f * kcap + k];
+    }
+    if (tid == 0) { s_flags = flags; s_ncand = counts[f * 4 + 3]; }
+    __syncthreads();
+    contours_tail(f, tid, RT_THREADS, nkept, kkey, off_u, klen, koff, rectflag, ap_out, ap_stack,
+                  pool + (size_t)f * pool_fstride, kept_out, kept_cap, rects_out, rect_cap, counts, &s_flags, &s_ncand, rank_of,
+                  &s_tailq, RT_THREADS / 64, pb, pb_pts, nullptr, 0);
 }
 
 // ---------------------------------------------------------------------------------------- prefilter -----------

@@ -40,13 +40,17 @@ __global__ void k_contours_t(const uint32_t* gbits, size_t bits_fstride, int wpr
 struct RelaySeg {
     uint32_t nxt;    // slot of the next segment of the border
     uint32_t len;    // points of this segment
-    uint32_t minoff; // offset of the segment's smallest start state
+    uint32_t minoff; // offset of the segment's smallest start state; bit 31: that state is a hole-border start
     uint32_t stg;    // where the segment's points are staged inside the frame's pool
+    uint32_t mn;     // the smallest start state the segment passes (0xffffffff: none)
 };
 __global__ void k_contours_relay(const uint32_t* gbits, size_t bits_fstride, int wpr_g, int W, int H,
                                  int lds_bits_words, int min_len, int kshift, int tbits, RelaySeg* segs, uint32_t* pool,
                                  size_t pool_fstride, int pool_cap, ArKept* kept_out, int kept_cap, int kcap,
-                                 ArRect* rects_out, int rect_cap, int32_t* counts);
+                                 unsigned long long* tail_keys, int32_t* tail_off, int32_t* counts);
+__global__ void k_contours_tail(const unsigned long long* tail_keys, const int32_t* tail_off, int kcap,
+                                const uint32_t* pool, size_t pool_fstride, ArKept* kept_out, int kept_cap,
+                                ArRect* rects_out, int rect_cap, int32_t* counts, int lds_bytes);
 __global__ void k_prefilter(ArRect* rects, int rect_cap, const int32_t* counts, int W, int H, int too_near,
                             int32_t* cand_idx, int32_t* ncand_out);
 __global__ void k_decode(ImgView src0, ImgView pyr, const ArLevel* levels, int nlevels, const ArRect* rects,
@@ -64,22 +68,34 @@ __global__ void k_finalize(const ArRect* rects, int rect_cap, const int32_t* can
 #define CT_PROBE 24 // steps a border start is followed before it is queued as a long walk (< the 70-point gate)
 
 #define RL_THREADS 1024
+#define RT_THREADS 512           // k_contours_tail: 8 waves, one approxPolyDP each at a time
 #define RL_SLOTS_PER_THREAD 8   // table slots <= RL_THREADS * RL_SLOTS_PER_THREAD
 #define RL_SMALL_CAP 64         // kept borders that touch no grid marker (rare: > 70 points between grid lines)
 #define RL_NIL 0xffff
+#define RL_COPY_CAP 1024        // kept segments per frame the flat copy lists (== RL_THREADS; 14 bytes each <= the key table)
 #define RL_FLAG_TABLE 32        // markers did not fit: the frame is redone by k_contours_t
 #define RL_FLAG_BUG 64          // an invariant of the relay formulation failed: redone by k_contours_t as well
 #define RL_FALLBACK_FLAGS (RL_FLAG_TABLE | RL_FLAG_BUG)
 #define RL_KCAP 512              // kept borders per frame the relay kernel holds (more: legacy kernel)
 #define RL_STEPS_PER_ITER 2      // walk steps between two looks at the work queue
 
-inline size_t relay_lds_bytes(int lds_bits_words, int kept_cap, int tbits)
+// LDS of k_contours_relay: region R (bit image | list arrays) followed by the marker keys
+__host__ __device__ inline size_t relay_region_bytes(int lds_bits_words, int kcap, int tbits)
 {
-    size_t b = ((size_t)lds_bits_words * 4 + 15) & ~(size_t)15;
-    b += (size_t)kept_cap * 8 + (size_t)kept_cap * 4; // keys, pool offsets
-    const size_t table = ((size_t)12 << tbits);
-    const size_t tail = (size_t)kept_cap * 12 + (size_t)(RL_THREADS / 64) * (AP_OUT + AP_STACK) * 8 + (size_t)kept_cap * 2;
-    return b + (table > tail ? table : tail) + 16;
+    const size_t bits = ((size_t)lds_bits_words * 4 + 15) & ~(size_t)15;
+    const size_t lists = (size_t)kcap * 12 + ((size_t)8 << tbits);
+    size_t r = bits > lists ? bits : lists;
+    return (r + 15) & ~(size_t)15;
+}
+inline size_t relay_lds_bytes(int lds_bits_words, int kcap, int tbits)
+{
+    return relay_region_bytes(lds_bits_words, kcap, tbits) + ((size_t)4 << tbits);
+}
+
+// LDS of k_contours_tail: per-border arrays, approx scratch, length ranks, one point buffer of `pts` points per wave
+inline size_t tail_lds_bytes(int kcap, int pts)
+{
+    return (size_t)kcap * (8 + 4 * 4 + 2) + (size_t)(RT_THREADS / 64) * ((AP_OUT + AP_STACK) * 8 + (size_t)pts * 4) + 64;
 }
 
 inline size_t contours_lds_bytes(int lds_bits_words, int kept_cap)
