@@ -240,7 +240,7 @@ struct orbfe_aruco {
         hipLaunchKernelGGL(k_prefilter, dim3(B), dim3(256), 0, s, d_rects.as<ArRect>(), AR_MAX_RECTS,
                            d_counts.as<int32_t>(), cols, rows, win, d_candidx.as<int32_t>(), d_ncand.as<int32_t>());
         ORBFE_HIP(hipStreamWaitEvent(s, ev_join, 0));
-        if (!(g_aruco_skip & 2)) hipLaunchKernelGGL(k_decode, dim3(32, B), dim3(64), 0, s, src0, pyr, d_levels.as<ArLevel>(), npyr,
+        if (!(g_aruco_skip & 2)) hipLaunchKernelGGL(k_decode, dim3(B), dim3(512), 0, s, src0, pyr, d_levels.as<ArLevel>(), npyr,
                            d_rects.as<ArRect>(), AR_MAX_RECTS, d_candidx.as<int32_t>(), d_ncand.as<int32_t>(), S, nb,
                            d_codes.as<unsigned long long>(), ncodes, d_result.as<int32_t>(), cols);
         timer.mark(s, "decode");
@@ -380,7 +380,7 @@ int orbfe_aruco_debug_image(orbfe_aruco* h, int frame, int stage, uint8_t* out)
                             hipMemcpyDeviceToHost));
         return ORBFE_OK;
     }
-    if (stage == 103) { // decode results of the frame, raw (instrumented builds keep phase timers of slot 0 at entry 200)
+    if (stage == 103) { // decode results of the frame, raw: AR_MAX_RECTS x (id, rotations)
         ORBFE_HIP(hipMemcpy(out, h->d_result.as<int32_t>() + (size_t)frame * AR_MAX_RECTS * 2, (size_t)AR_MAX_RECTS * 8,
                             hipMemcpyDeviceToHost));
         return ORBFE_OK;

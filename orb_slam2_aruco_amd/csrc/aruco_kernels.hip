@@ -1345,230 +1345,229 @@ __device__ bool solve8_wave(double a[8], double b, int lane, double x[8])
     return true;
 }
 
-// One wave per candidate; blockIdx.x strides over the frame's candidates.
-__global__ __launch_bounds__(64) void k_decode(ImgView src0, ImgView pyr, const ArLevel* __restrict__ levels,
+// One workgroup per frame, DC_WAVES waves; a wave takes the frame's candidates w, w + DC_WAVES, ...
+//   A (wave per candidate): pyramid level, homography (wave-parallel 8x8 elimination), warp -> histogram
+//   B (ONE LANE per candidate, all candidates of the frame in lockstep): getThreshVal_Otsu_8u.  Its running sums are
+//     serial by definition (every step rounds, and the gaps between the two clusters of a marker histogram are exact
+//     ties that the rounding noise decides), so each candidate needs ~256 dependent double divisions; side by side in
+//     the lanes of one wave they cost one candidate's latency for the whole frame.
+//   C (wave per candidate): warp again against the threshold -> cell votes, border check, 4 rotations, dictionary.
+#define DC_WAVES 8
+#define DC_MAXC 32 // candidates handled per pass (the workgroup loops if a frame has more)
+
+struct DcCand {
+    double Mi[9];
+    int lvl, ok;
+};
+
+__device__ __forceinline__ int dc_warp_pixel(const double* Mi, int y, int xx, const uint8_t* img, int pitch, int LW, int LH)
+{
+    // warpPerspective(INTER_LINEAR, BORDER_CONSTANT 0): 1/32-px coordinates, 15-bit bilinear weights
+    const double X0 = Mi[0] * 0 + Mi[1] * y + Mi[2];
+    const double Y0 = Mi[3] * 0 + Mi[4] * y + Mi[5];
+    const double W0d = Mi[6] * 0 + Mi[7] * y + Mi[8];
+    double Wd = W0d + Mi[6] * xx;
+    Wd = Wd ? 32.0 / Wd : 0;
+    const double fX = fmax(-2147483648.0, fmin(2147483647.0, (X0 + Mi[0] * xx) * Wd));
+    const double fY = fmax(-2147483648.0, fmin(2147483647.0, (Y0 + Mi[3] * xx) * Wd));
+    const int X = ar_sat_int(fX), Y = ar_sat_int(fY);
+    int sx = X >> 5, sy = Y >> 5;
+    sx = sx < -32768 ? -32768 : sx > 32767 ? 32767 : sx;
+    sy = sy < -32768 ? -32768 : sy > 32767 ? 32767 : sy;
+    const int ax = X & 31, ay = Y & 31;
+    const int w00 = (32 - ax) * (32 - ay) * 32, w01 = ax * (32 - ay) * 32, w10 = (32 - ax) * ay * 32, w11 = ax * ay * 32;
+    auto px = [&](int px_, int py_) -> int {
+        if (px_ < 0 || py_ < 0 || px_ >= LW || py_ >= LH) return 0;
+        return img[(size_t)py_ * pitch + px_];
+    };
+    int v = px(sx, sy) * w00 + px(sx + 1, sy) * w01 + px(sx, sy + 1) * w10 + px(sx + 1, sy + 1) * w11;
+    v = (v + (1 << 14)) >> 15;
+    return v > 255 ? 255 : v;
+}
+
+__global__ __launch_bounds__(DC_WAVES * 64) void k_decode(ImgView src0, ImgView pyr, const ArLevel* __restrict__ levels,
                                                int nlevels, const ArRect* __restrict__ rects, int rect_cap,
                                                const int32_t* __restrict__ cand_idx,
                                                const int32_t* __restrict__ ncand, int S, int nb,
                                                const unsigned long long* __restrict__ codes, int ncodes,
                                                int32_t* __restrict__ result /*per slot: id, nrot*/, int W0)
 {
-    __shared__ uint8_t spatch[40 * 40];
-    __shared__ int s_hist[256];
-    __shared__ int s_ones[64], s_tot[64];
-    __shared__ uint8_t s_bits[64];
-    __shared__ unsigned long long s_ids[4];
-    __shared__ int s_th;
-    __shared__ double s_q1[256], s_mu1[256];
-    __shared__ double s_mu;
-    const int f = blockIdx.y, lane = threadIdx.x;
+    __shared__ uint32_t s_hist[DC_MAXC][257]; // 257: the Otsu lanes read their rows conflict-free
+    __shared__ DcCand s_cand[DC_MAXC];
+    __shared__ int s_th[DC_MAXC];
+    __shared__ int s_ones[DC_WAVES][64], s_tot[DC_WAVES][64];
+    __shared__ uint8_t s_bits[DC_WAVES][64];
+    __shared__ unsigned long long s_ids[DC_WAVES][4];
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int nc = ncand[f];
-    for (int slot = blockIdx.x; slot < nc; slot += gridDim.x) {
+    for (int c0 = 0; c0 < nc; c0 += DC_MAXC) {
+        const int ncp = min(DC_MAXC, nc - c0);
         __syncthreads();
-        int32_t* res = result + ((size_t)f * rect_cap + slot) * 2;
-#ifdef ORBFE_CT_TIMING
-        long long dq[8]; int dqi = 0;
-#define DC_STAMP() dq[dqi++] = clock64()
-#else
-#define DC_STAMP()
-#endif
-        DC_STAMP();
-        const ArRect r = rects[(size_t)f * rect_cap + cand_idx[(size_t)f * rect_cap + slot]];
-        // pyramid level: largest p with area / 4^p >= S^2 (markerdetector_impl.cpp:6507-6586)
-        const float v01x = r.c[1][0] - r.c[0][0], v01y = r.c[1][1] - r.c[0][1];
-        const float v03x = r.c[3][0] - r.c[0][0], v03y = r.c[3][1] - r.c[0][1];
-        const float area1 = fabsf(__fsub_rn(__fmul_rn(v01x, v03y), __fmul_rn(v01y, v03x)));
-        const float v21x = r.c[1][0] - r.c[2][0], v21y = r.c[1][1] - r.c[2][1];
-        const float v23x = r.c[3][0] - r.c[2][0], v23y = r.c[3][1] - r.c[2][1];
-        const float area2 = fabsf(__fsub_rn(__fmul_rn(v21x, v23y), __fmul_rn(v21y, v23x)));
-        const float area = __fdiv_rn(__fadd_rn(area2, area1), 2.f);
-        const float desired = __fmul_rn((float)S, (float)S);
-        int lvl = 0;
-        double p4 = 4.0;
-        for (int p = 1; p < nlevels; p++, p4 *= 4.0) {
-            if ((double)area / p4 >= (double)desired) lvl = p;
-            else break;
-        }
-        const ArLevel L = levels[lvl];
-        const float ratio = __fdiv_rn((float)L.w, (float)W0);
-        // getPerspectiveTransform(quad -> (0,0),(S-1,0),(S-1,S-1),(0,S-1)): rows 0..3 = x equations, 4..7 = y equations
-        double a[8], bb = 0.0, x[8];
+        for (int i = tid; i < ncp * 257; i += DC_WAVES * 64) (&s_hist[0][0])[i] = 0;
+        __syncthreads();
+        // ---- A
+        for (int c = wid; c < ncp; c += DC_WAVES) {
+            const int slot = c0 + c;
+            const ArRect r = rects[(size_t)f * rect_cap + cand_idx[(size_t)f * rect_cap + slot]];
+            // pyramid level: largest p with area / 4^p >= S^2 (markerdetector_impl.cpp:6507-6586)
+            const float v01x = r.c[1][0] - r.c[0][0], v01y = r.c[1][1] - r.c[0][1];
+            const float v03x = r.c[3][0] - r.c[0][0], v03y = r.c[3][1] - r.c[0][1];
+            const float area1 = fabsf(__fsub_rn(__fmul_rn(v01x, v03y), __fmul_rn(v01y, v03x)));
+            const float v21x = r.c[1][0] - r.c[2][0], v21y = r.c[1][1] - r.c[2][1];
+            const float v23x = r.c[3][0] - r.c[2][0], v23y = r.c[3][1] - r.c[2][1];
+            const float area2 = fabsf(__fsub_rn(__fmul_rn(v21x, v23y), __fmul_rn(v21y, v23x)));
+            const float area = __fdiv_rn(__fadd_rn(area2, area1), 2.f);
+            const float desired = __fmul_rn((float)S, (float)S);
+            int lvl = 0;
+            double p4 = 4.0;
+            for (int p = 1; p < nlevels; p++, p4 *= 4.0) {
+                if ((double)area / p4 >= (double)desired) lvl = p;
+                else break;
+            }
+            const ArLevel L = levels[lvl];
+            const float ratio = __fdiv_rn((float)L.w, (float)W0);
+            // getPerspectiveTransform(quad -> (0,0),(S-1,0),(S-1,S-1),(0,S-1)): rows 0..3 = x equations, 4..7 = y equations
+            double a[8], bb = 0.0, x[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) { a[k] = 0.0; x[k] = 0.0; }
-        if (lane < 8) {
-            const int i = lane & 3;
-            const float qx = __fmul_rn(r.c[i][0], ratio), qy = __fmul_rn(r.c[i][1], ratio);
-            const float dx = (i == 1 || i == 2) ? (float)(S - 1) : 0.f, dy = (i >= 2) ? (float)(S - 1) : 0.f;
-            if (lane < 4) {
-                a[0] = qx; a[1] = qy; a[2] = 1.0;
-                a[6] = -(double)qx * dx; a[7] = -(double)qy * dx;
-                bb = dx;
-            } else {
-                a[3] = qx; a[4] = qy; a[5] = 1.0;
-                a[6] = -(double)qx * dy; a[7] = -(double)qy * dy;
-                bb = dy;
-            }
-        }
-        bool ok = solve8_wave(a, bb, lane, x);
-        double Mi[9];
-        if (ok) {
-            const double M[9] = {x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7], 1.0};
-            const double det = M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) +
-                               M[2] * (M[3] * M[7] - M[4] * M[6]);
-            if (det == 0.0) ok = false;
-            else {
-                const double d = 1.0 / det;
-                Mi[0] = (M[4] * M[8] - M[5] * M[7]) * d;
-                Mi[1] = (M[2] * M[7] - M[1] * M[8]) * d;
-                Mi[2] = (M[1] * M[5] - M[2] * M[4]) * d;
-                Mi[3] = (M[5] * M[6] - M[3] * M[8]) * d;
-                Mi[4] = (M[0] * M[8] - M[2] * M[6]) * d;
-                Mi[5] = (M[2] * M[3] - M[0] * M[5]) * d;
-                Mi[6] = (M[3] * M[7] - M[4] * M[6]) * d;
-                Mi[7] = (M[1] * M[6] - M[0] * M[7]) * d;
-                Mi[8] = (M[0] * M[4] - M[1] * M[3]) * d;
-            }
-        }
-        if (!ok) {
-            if (lane == 0) { res[0] = -1; res[1] = 0; }
-            continue;
-        }
-        DC_STAMP();
-        for (int i = lane; i < 256; i += 64) s_hist[i] = 0;
-        s_ones[lane] = 0;
-        s_tot[lane] = 0;
-        __syncthreads();
-        const uint8_t* img = (lvl == 0) ? src0.base + (size_t)f * src0.fstride : pyr.base + (size_t)f * pyr.fstride + L.off;
-        const int pitch = (lvl == 0) ? src0.pitch : L.pitch;
-        // warpPerspective(INTER_LINEAR, BORDER_CONSTANT 0): 1/32-px coordinates, 15-bit bilinear weights
-        for (int i = lane; i < S * S; i += 64) {
-            const int y = i / S, xx = i - y * S;
-            const double X0 = Mi[0] * 0 + Mi[1] * y + Mi[2];
-            const double Y0 = Mi[3] * 0 + Mi[4] * y + Mi[5];
-            const double W0d = Mi[6] * 0 + Mi[7] * y + Mi[8];
-            double Wd = W0d + Mi[6] * xx;
-            Wd = Wd ? 32.0 / Wd : 0;
-            const double fX = fmax(-2147483648.0, fmin(2147483647.0, (X0 + Mi[0] * xx) * Wd));
-            const double fY = fmax(-2147483648.0, fmin(2147483647.0, (Y0 + Mi[3] * xx) * Wd));
-            const int X = ar_sat_int(fX), Y = ar_sat_int(fY);
-            int sx = X >> 5, sy = Y >> 5;
-            sx = sx < -32768 ? -32768 : sx > 32767 ? 32767 : sx;
-            sy = sy < -32768 ? -32768 : sy > 32767 ? 32767 : sy;
-            const int ax = X & 31, ay = Y & 31;
-            const int w00 = (32 - ax) * (32 - ay) * 32, w01 = ax * (32 - ay) * 32, w10 = (32 - ax) * ay * 32, w11 = ax * ay * 32;
-            auto px = [&](int px_, int py_) -> int {
-                if (px_ < 0 || py_ < 0 || px_ >= L.w || py_ >= L.h) return 0;
-                return img[(size_t)py_ * pitch + px_];
-            };
-            int v = px(sx, sy) * w00 + px(sx + 1, sy) * w01 + px(sx, sy + 1) * w10 + px(sx + 1, sy + 1) * w11;
-            v = (v + (1 << 14)) >> 15;
-            v = v > 255 ? 255 : v;
-            spatch[i] = (uint8_t)v;
-            atomicAdd(&s_hist[v], 1);
-        }
-        __syncthreads();
-        DC_STAMP();
-        // getThreshVal_Otsu_8u.  The running sums q1 / mu1 are serial by definition (each step rounds), so lane 0 walks
-        // the 256 bins with exactly the reference's operation sequence; mu2 and sigma of every bin are independent of
-        // the other bins and are evaluated by all lanes afterwards (first maximum wins, like the serial 'sigma > max').
-        if (lane == 0) {
-            const int n = S * S;
-            double mu = 0, scale = 1. / n;
-            for (int i = 0; i < 256; i++) mu += i * (double)s_hist[i];
-            mu *= scale;
-            double mu1 = 0, q1 = 0;
-            for (int i = 0; i < 256; i++) {
-                const double p_i = s_hist[i] * scale;
-                mu1 *= q1;
-                q1 += p_i;
-                const double q2 = 1. - q1;
-                s_q1[i] = q1;
-                if (fmin(q1, q2) < 1.1920928955078125e-07 || fmax(q1, q2) > 1. - 1.1920928955078125e-07) {
-                    s_mu1[i] = -1.0; // skipped bin (mu1 keeps the un-normalised product, as in the reference)
-                    continue;
+            for (int k = 0; k < 8; k++) { a[k] = 0.0; x[k] = 0.0; }
+            if (lane < 8) {
+                const int i = lane & 3;
+                const float qx = __fmul_rn(r.c[i][0], ratio), qy = __fmul_rn(r.c[i][1], ratio);
+                const float dx = (i == 1 || i == 2) ? (float)(S - 1) : 0.f, dy = (i >= 2) ? (float)(S - 1) : 0.f;
+                if (lane < 4) {
+                    a[0] = qx; a[1] = qy; a[2] = 1.0;
+                    a[6] = -(double)qx * dx; a[7] = -(double)qy * dx;
+                    bb = dx;
+                } else {
+                    a[3] = qx; a[4] = qy; a[5] = 1.0;
+                    a[6] = -(double)qx * dy; a[7] = -(double)qy * dy;
+                    bb = dy;
                 }
-                mu1 = (mu1 + i * p_i) / q1;
-                s_mu1[i] = mu1;
             }
-            s_mu = mu;
+            bool ok = solve8_wave(a, bb, lane, x);
+            double Mi[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            if (ok) {
+                const double M[9] = {x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7], 1.0};
+                const double det = M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) +
+                                   M[2] * (M[3] * M[7] - M[4] * M[6]);
+                if (det == 0.0) ok = false;
+                else {
+                    const double d = 1.0 / det;
+                    Mi[0] = (M[4] * M[8] - M[5] * M[7]) * d;
+                    Mi[1] = (M[2] * M[7] - M[1] * M[8]) * d;
+                    Mi[2] = (M[1] * M[5] - M[2] * M[4]) * d;
+                    Mi[3] = (M[5] * M[6] - M[3] * M[8]) * d;
+                    Mi[4] = (M[0] * M[8] - M[2] * M[6]) * d;
+                    Mi[5] = (M[2] * M[3] - M[0] * M[5]) * d;
+                    Mi[6] = (M[3] * M[7] - M[4] * M[6]) * d;
+                    Mi[7] = (M[1] * M[6] - M[0] * M[7]) * d;
+                    Mi[8] = (M[0] * M[4] - M[1] * M[3]) * d;
+                }
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < 9; k++) s_cand[c].Mi[k] = Mi[k];
+                s_cand[c].lvl = lvl; s_cand[c].ok = ok ? 1 : 0;
+            }
+            if (ok) {
+                const uint8_t* img = (lvl == 0) ? src0.base + (size_t)f * src0.fstride : pyr.base + (size_t)f * pyr.fstride + L.off;
+                const int pitch = (lvl == 0) ? src0.pitch : L.pitch;
+                for (int i = lane; i < S * S; i += 64) {
+                    const int y = i / S, xx = i - y * S;
+                    atomicAdd(&s_hist[c][dc_warp_pixel(Mi, y, xx, img, pitch, L.w, L.h)], 1u);
+                }
+            }
         }
         __syncthreads();
-        {
-            double best = 0.0;
-            int besti = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int i = k * 64 + lane;
-                const double mu1 = s_mu1[i], q1 = s_q1[i];
-                if (mu1 >= 0.0) {
+        // ---- B: getThreshVal_Otsu_8u with exactly the reference's operation sequence, one lane per candidate
+        if (wid == 0 && lane < ncp) {
+            int max_val = 0;
+            if (s_cand[lane].ok) {
+                const uint32_t* h = s_hist[lane];
+                const int n = S * S;
+                double mu = 0, scale = 1. / n;
+                for (int i = 0; i < 256; i++) mu += i * (double)h[i];
+                mu *= scale;
+                double mu1 = 0, q1 = 0, max_sigma = 0;
+                for (int i = 0; i < 256; i++) {
+                    const double p_i = h[i] * scale;
+                    mu1 *= q1;
+                    q1 += p_i;
                     const double q2 = 1. - q1;
-                    const double mu2 = (s_mu - q1 * mu1) / q2;
+                    if (fmin(q1, q2) < 1.1920928955078125e-07 || fmax(q1, q2) > 1. - 1.1920928955078125e-07) continue;
+                    mu1 = (mu1 + i * p_i) / q1;
+                    const double mu2 = (mu - q1 * mu1) / q2;
                     const double sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2);
-                    if (sigma > best) { best = sigma; besti = i; } // ascending i within the lane: first maximum
+                    if (sigma > max_sigma) { max_sigma = sigma; max_val = i; }
                 }
             }
+            s_th[lane] = max_val;
+        }
+        __syncthreads();
+        // ---- C
+        for (int c = wid; c < ncp; c += DC_WAVES) {
+            const int slot = c0 + c;
+            int32_t* res = result + ((size_t)f * rect_cap + slot) * 2;
+            if (!s_cand[c].ok) {
+                if (lane == 0) { res[0] = -1; res[1] = 0; }
+                continue;
+            }
+            double Mi[9];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const double ob = shfl_d(best, lane ^ o);
-                const int oi = __shfl(besti, lane ^ o);
-                if (ob > best || (ob == best && ob > 0.0 && oi < besti)) { best = ob; besti = oi; }
+            for (int k = 0; k < 9; k++) Mi[k] = s_cand[c].Mi[k];
+            const int lvl = s_cand[c].lvl;
+            const ArLevel L = levels[lvl];
+            const uint8_t* img = (lvl == 0) ? src0.base + (size_t)f * src0.fstride : pyr.base + (size_t)f * pyr.fstride + L.off;
+            const int pitch = (lvl == 0) ? src0.pitch : L.pitch;
+            s_ones[wid][lane] = 0;
+            s_tot[wid][lane] = 0;
+            __builtin_amdgcn_wave_barrier();
+            const int th = s_th[c], n = nb + 2;
+            for (int i = lane; i < S * S; i += 64) {
+                const int y = i / S, xx = i - y * S;
+                const int my = (int)__fdiv_rn(__fmul_rn((float)n, (float)y), (float)S);
+                const int mx = (int)__fdiv_rn(__fmul_rn((float)n, (float)xx), (float)S);
+                if (dc_warp_pixel(Mi, y, xx, img, pitch, L.w, L.h) > th) atomicAdd(&s_ones[wid][my * n + mx], 1);
+                atomicAdd(&s_tot[wid][my * n + mx], 1);
             }
-            if (lane == 0) s_th = best > 0.0 ? besti : 0;
-        }
-        __syncthreads();
-        const int th = s_th, n = nb + 2;
-        for (int i = lane; i < S * S; i += 64) {
-            const int y = i / S, xx = i - y * S;
-            const int my = (int)__fdiv_rn(__fmul_rn((float)n, (float)y), (float)S);
-            const int mx = (int)__fdiv_rn(__fmul_rn((float)n, (float)xx), (float)S);
-            if (spatch[i] > th) atomicAdd(&s_ones[my * n + mx], 1);
-            atomicAdd(&s_tot[my * n + mx], 1);
-        }
-        __syncthreads();
-        // cell bits (n*n <= 64: one lane per cell), border must be black
-        const int cy = lane / n, cx = lane - cy * n;
-        const bool incell = lane < n * n;
-        const int bit = incell && (s_ones[lane] > s_tot[lane] / 2);
-        const bool border = incell && (cy == 0 || cy == n - 1 || cx == 0 || cx == n - 1);
-        s_bits[lane] = (uint8_t)bit;
-        const bool bad = __ballot(border && bit) != 0ull;
-        __syncthreads();
-        if (lane < 4) {
-            // code of the inner nb x nb matrix rotated `lane` times: rotate(out(i,j) = in(nb-1-j, i)) applied lane times
-            unsigned long long v = 0;
-            int bpos = 0;
-            for (int y = nb - 1; y >= 0; y--)
-                for (int xx = nb - 1; xx >= 0; xx--) {
-                    int yy = y, xc = xx;
-                    for (int t = 0; t < lane; t++) { const int ny = nb - 1 - xc, nx = yy; yy = ny; xc = nx; }
-                    v |= (unsigned long long)s_bits[(yy + 1) * n + (xc + 1)] << bpos++;
+            __builtin_amdgcn_wave_barrier();
+            // cell bits (n*n <= 64: one lane per cell), border must be black
+            const int cy = lane / n, cx = lane - cy * n;
+            const bool incell = lane < n * n;
+            const int bit = incell && (s_ones[wid][lane] > s_tot[wid][lane] / 2);
+            const bool border = incell && (cy == 0 || cy == n - 1 || cx == 0 || cx == n - 1);
+            s_bits[wid][lane] = (uint8_t)bit;
+            const bool bad = __ballot(border && bit) != 0ull;
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 4) {
+                // code of the inner nb x nb matrix rotated `lane` times: rotate(out(i,j) = in(nb-1-j, i)) applied lane times
+                unsigned long long v = 0;
+                int bpos = 0;
+                for (int y = nb - 1; y >= 0; y--)
+                    for (int xx = nb - 1; xx >= 0; xx--) {
+                        int yy = y, xc = xx;
+                        for (int t = 0; t < lane; t++) { const int ny = nb - 1 - xc, nx = yy; yy = ny; xc = nx; }
+                        v |= (unsigned long long)s_bits[wid][(yy + 1) * n + (xc + 1)] << bpos++;
+                    }
+                s_ids[wid][lane] = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+            int id = -1, nrot = 0;
+            if (!bad && s_ids[wid][0] != 0) {
+                // first rotation whose code is in the dictionary; id = first index holding that code (map.insert semantics)
+                for (int rr = 0; rr < 4; rr++) {
+                    const unsigned long long want = s_ids[wid][rr];
+                    int best = 0x7fffffff;
+                    for (int i = lane; i < ncodes; i += 64)
+                        if (codes[i] == want) best = min(best, i);
+                    best = wave_min(best);
+                    if (best != 0x7fffffff) { id = best; nrot = rr; break; }
                 }
-            s_ids[lane] = v;
-        }
-        __syncthreads();
-        DC_STAMP();
-        int id = -1, nrot = 0;
-        if (!bad && s_ids[0] != 0) {
-            // first rotation whose code is in the dictionary; id = first index holding that code (map.insert semantics)
-            for (int rr = 0; rr < 4; rr++) {
-                const unsigned long long want = s_ids[rr];
-                int best = 0x7fffffff;
-                for (int i = lane; i < ncodes; i += 64)
-                    if (codes[i] == want) best = min(best, i);
-                best = wave_min(best);
-                if (best != 0x7fffffff) { id = best; nrot = rr; break; }
             }
+            if (lane == 0) { res[0] = id; res[1] = nrot; }
+            __builtin_amdgcn_wave_barrier();
         }
-        if (lane == 0) { res[0] = id; res[1] = nrot; }
-#ifdef ORBFE_CT_TIMING
-        DC_STAMP();
-        if (lane == 0 && slot < 32) { // (instrumented builds only; entries 64.. of the frame's result block are unused)
-            long long* dbg = (long long*)(result + ((size_t)f * rect_cap + 64) * 2) + slot * 6;
-            for (int i = 0; i + 1 < dqi; i++) dbg[i] = dq[i + 1] - dq[i];
-            dbg[5] = id;
-        }
-#endif
-    } // slot loop
+    }
 }
 
 // ---------------------------------------------------------------------------------------- finalize ------------

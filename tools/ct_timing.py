@@ -22,9 +22,3 @@ for legacy in (False, True):
 
 det.force_legacy_contours(False)
 det.detect_batch(imgs)
-raw = np.zeros(512, np.int32)
-binding._check(det.L, det.L.orbfe_aruco_debug_image(det.h, 0, 103, raw.ctypes.data_as(C.c_void_p)), "dbg")
-t = raw[128:512].view(np.int64).reshape(32, 6)
-print("decode ticks per slot: solve+inverse, warp+hist, otsu+binarize+bits+rotations, dictionary, id")
-for i in range(min(32, det.counts(0)["nrect"])):
-    print("  slot %2d: %7d %7d %7d %7d  id %d" % (i, t[i][0], t[i][1], t[i][2], t[i][3], t[i][5]))
