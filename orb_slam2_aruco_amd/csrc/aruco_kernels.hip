@@ -370,6 +370,7 @@ __global__ __launch_bounds__(CT_PROBE_THREADS) void k_contours_t(const uint32_t*
                                                          uint32_t* __restrict__ gpadded, size_t gpadded_fstride,
                                                          int only_flagged)
 {
+    __builtin_amdgcn_s_setprio(2); // latency-bound: its few waves go first when a VALU-bound kernel shares the CU
     extern __shared__ __align__(16) unsigned char ct_smem[];
     __shared__ int s_ncand, s_next, s_nkept, s_nlong, s_flags;
     __shared__ unsigned s_tailq;
@@ -630,6 +631,7 @@ __global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_num_vgpr(64))) vo
     ArKept* __restrict__ kept_out, int kept_cap, int kcap /*kept borders this kernel's LDS holds*/,
     unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off, int32_t* __restrict__ counts)
 {
+    __builtin_amdgcn_s_setprio(2); // latency-bound: its few waves go first when a VALU-bound kernel shares the CU
     extern __shared__ __align__(16) unsigned char ct_smem[];
     __shared__ int s_next, s_nkept, s_flags, s_ncand, s_nmark, s_nsmall, s_pool, s_changed[2];
     __shared__ uint4 s_small[RL_SMALL_CAP]; // state key, length, pool offset, discovery key * 2 + is_hole
@@ -1180,6 +1182,7 @@ __global__ __launch_bounds__(RT_THREADS) void k_contours_tail(const unsigned lon
                                                                ArRect* __restrict__ rects_out, int rect_cap,
                                                                int32_t* __restrict__ counts, int lds_bytes)
 {
+    __builtin_amdgcn_s_setprio(2); // latency-bound: its few waves go first when a VALU-bound kernel shares the CU
     extern __shared__ __align__(16) unsigned char ct_smem[];
     __shared__ int s_flags, s_ncand;
     __shared__ unsigned s_tailq;
@@ -1225,6 +1228,7 @@ __global__ __launch_bounds__(256) void k_prefilter(ArRect* __restrict__ rects, i
                                                    int W, int H, int too_near, int32_t* __restrict__ cand_idx,
                                                    int32_t* __restrict__ ncand_out)
 {
+    __builtin_amdgcn_s_setprio(2); // latency-bound: its few waves go first when a VALU-bound kernel shares the CU
     __shared__ int s_rm[AR_MAX_RECTS];
     __shared__ int s_per[AR_MAX_RECTS];
     const int f = blockIdx.x, tid = threadIdx.x;
@@ -1392,6 +1396,7 @@ __global__ __launch_bounds__(DC_WAVES * 64) void k_decode(ImgView src0, ImgView 
                                                const unsigned long long* __restrict__ codes, int ncodes,
                                                int32_t* __restrict__ result /*per slot: id, nrot*/, int W0)
 {
+    __builtin_amdgcn_s_setprio(2); // latency-bound: its few waves go first when a VALU-bound kernel shares the CU
     __shared__ uint32_t s_hist[DC_MAXC][257]; // 257: the Otsu lanes read their rows conflict-free
     __shared__ DcCand s_cand[DC_MAXC];
     __shared__ int s_th[DC_MAXC];
@@ -1596,6 +1601,7 @@ __global__ __launch_bounds__(256) void k_finalize(const ArRect* __restrict__ rec
                                                   orbfe_marker* __restrict__ out, int out_cap,
                                                   int32_t* __restrict__ n_out)
 {
+    __builtin_amdgcn_s_setprio(2); // latency-bound: its few waves go first when a VALU-bound kernel shares the CU
     __shared__ int s_id[AR_MAX_RECTS], s_src[AR_MAX_RECTS], s_rot[AR_MAX_RECTS], s_per[AR_MAX_RECTS], s_rm[AR_MAX_RECTS];
     __shared__ float s_c[AR_MAX_RECTS][4][2];
     __shared__ int s_n;

@@ -68,7 +68,7 @@ __global__ void k_finalize(const ArRect* rects, int rect_cap, const int32_t* can
 #define CT_PROBE 24 // steps a border start is followed before it is queued as a long walk (< the 70-point gate)
 
 #define RL_THREADS 1024
-#define RT_THREADS 512           // k_contours_tail: 8 waves, one approxPolyDP each at a time
+#define RT_THREADS 256           // k_contours_tail: 4 waves, one approxPolyDP each at a time (small workgroups place easily next to other kernels)
 #define RL_SLOTS_PER_THREAD 8   // table slots <= RL_THREADS * RL_SLOTS_PER_THREAD
 #define RL_SMALL_CAP 64         // kept borders that touch no grid marker (rare: > 70 points between grid lines)
 #define RL_NIL 0xffff

@@ -266,6 +266,7 @@ __global__ __launch_bounds__(SFI_THREADS) void k_search_init(const orbfe_keypoin
                                                      int row_stride, int32_t* __restrict__ scratch /*3*capacity per pair*/,
                                                      int32_t* __restrict__ overflow)
 {
+    __builtin_amdgcn_s_setprio(2); // latency-bound: its few waves go first when a VALU-bound kernel shares the CU
     extern __shared__ __align__(16) unsigned char sfi_smem[];
     __shared__ uint32_t s_sorted[SFI_MAXL0]; // (cell << 16) | index, ascending
     __shared__ int s_hist[30];

@@ -880,6 +880,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_distribute_pyr(const LevelGeom* 
                                                        int32_t* __restrict__ lvl_ncand, int32_t* __restrict__ fallback,
                                                        int D, int nodecap, int veccap)
 {
+    __builtin_amdgcn_s_setprio(2); // latency-bound: its few waves go first when a VALU-bound kernel shares the CU
     extern __shared__ __align__(16) unsigned char qp_smem[];
     __shared__ int s_ncand;
     // QP_THREADS threads build the leaf counts (the only part that is parallel over candidates), then one wave runs the
@@ -1211,6 +1212,7 @@ __global__ __launch_bounds__(256) void k_level_offsets(const int32_t* __restrict
                                                        const uint32_t* __restrict__ lvl_out, int out_fstride,
                                                        uint32_t* __restrict__ flat_kv, uint8_t* __restrict__ flat_lvl)
 {
+    __builtin_amdgcn_s_setprio(2); // latency-bound: its few waves go first when a VALU-bound kernel shares the CU
     const int f = blockIdx.x, tid = threadIdx.x;
     if (f >= nframes) return;
     int acc = 0;
