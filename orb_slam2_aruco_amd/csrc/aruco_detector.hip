@@ -229,12 +229,12 @@ struct orbfe_aruco {
                                d_tailoff.as<int32_t>(), RL_KCAP, d_pool.as<uint32_t>(), pool_fu32, d_kept.as<ArKept>(),
                                AR_MAX_KEPT, d_rects.as<ArRect>(), AR_MAX_RECTS, d_counts.as<int32_t>(), (int)tlds);
         }
-        // all frames, or (after the relay kernel) only the frames it flagged; unflagged workgroups exit at once
-        if (!(g_aruco_skip & 1)) hipLaunchKernelGGL(kfn, dim3(B), dim3(CT_PROBE_THREADS), lds, s, d_bits.as<uint32_t>(), bits_fu32, wpr, cols, rows,
+        // the single-walker kernel: images whose bit image does not fit LDS next to the relay kernel's tables, or forced
+        if (!relay && !(g_aruco_skip & 1)) hipLaunchKernelGGL(kfn, dim3(B), dim3(CT_PROBE_THREADS), lds, s, d_bits.as<uint32_t>(), bits_fu32, wpr, cols, rows,
                            lds_bits_words, 70, d_candq.as<uint32_t>(), candq_fu32, (int)candq_fu32,
                            d_pool.as<uint32_t>(), pool_fu32, (int)pool_fu32, d_kept.as<ArKept>(), AR_MAX_KEPT,
                            d_rects.as<ArRect>(), AR_MAX_RECTS, d_counts.as<int32_t>(), d_gpad.as<uint32_t>(),
-                           gpad_fu32, relay ? 1 : 0);
+                           gpad_fu32, 0);
         timer.mark(s, "contours");
         ORBFE_HIP(hipGetLastError());
         hipLaunchKernelGGL(k_prefilter, dim3(B), dim3(256), 0, s, d_rects.as<ArRect>(), AR_MAX_RECTS,

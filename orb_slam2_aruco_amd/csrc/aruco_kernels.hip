@@ -375,8 +375,7 @@ __global__ __launch_bounds__(CT_PROBE_THREADS) void k_contours_t(const uint32_t*
     __shared__ int s_ncand, s_next, s_nkept, s_nlong, s_flags;
     __shared__ unsigned s_tailq;
     const int tid = threadIdx.x, f = blockIdx.x;
-    // as the fallback of k_contours_relay: only the frames that kernel gave up on
-    if (only_flagged && !(counts[f * 4 + 2] & RL_FALLBACK_FLAGS)) return;
+    if (only_flagged && !(counts[f * 4 + 2] & RL_FLAG_BUG)) return; // (debug builds: redo frames the relay kernel flagged)
     const int wpr = (W + 2 + 31) >> 5, prow = H + 2;
     // LDS carve-up: [bits][kept keys (u64) kept_cap][per-wave approx scratch]
     // the padded bit image lives in LDS when it fits (lds_bits_words > 0), else in an HBM scratch (L2-resident)
@@ -561,7 +560,7 @@ template __global__ void k_contours_t<false>(const uint32_t*, size_t, int, int, 
 //   (e) cyclic lists: pointer doubling for the minimum (= the canonical start), list ranking for the offsets;
 //   (f) kept borders (> min_len points) get pool space, their segments are walked again and write their points
 //       straight to the final position;  (g) the common tail (sort, approxPolyDP, rectangles).
-// A frame whose markers do not fit the table is flagged (RL_FALLBACK_FLAGS) and redone by k_contours_t.
+// If the markers do not fit the table the grid is coarsened, down to no grid at all (then (c) follows every border whole).
 __device__ __forceinline__ uint32_t rl_hash(uint32_t key, int tbits) { return (key * 0x9E3779B1u) >> (32 - tbits); }
 
 __device__ __forceinline__ int rl_find_or_insert(uint32_t* hkey, int tbits, uint32_t key, int* fresh)
@@ -625,16 +624,16 @@ __device__ __forceinline__ void rl_advance(const BitImage& im, RelayWalk& w, uns
     w.ring = ring8(im, w.x, w.y);
 }
 
-__global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_num_vgpr(64))) void k_contours_relay(
+// returns 1 if the frame has to be done again without a grid (force_nogrid), else 0
+template <bool force_nogrid>
+__device__ __forceinline__ int relay_frame(
     const uint32_t* __restrict__ gbits, size_t bits_fstride, int wpr_g, int W, int H, int lds_bits_words, int min_len,
     int kshift, int tbits, RelaySeg* __restrict__ segs, uint32_t* __restrict__ pool, size_t pool_fstride, int pool_cap,
     ArKept* __restrict__ kept_out, int kept_cap, int kcap /*kept borders this kernel's LDS holds*/,
     unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off, int32_t* __restrict__ counts)
 {
-    __builtin_amdgcn_s_setprio(2); // latency-bound: its few waves go first when a VALU-bound kernel shares the CU
     extern __shared__ __align__(16) unsigned char ct_smem[];
     __shared__ int s_next, s_nkept, s_flags, s_ncand, s_nmark, s_nsmall, s_pool, s_changed[2];
-    __shared__ uint4 s_small[RL_SMALL_CAP]; // state key, length, pool offset, discovery key * 2 + is_hole
     __shared__ uint16_t s_lut[2048];
     __shared__ unsigned s_tailq;
     const int tid = threadIdx.x, f = blockIdx.x, NT = RL_THREADS;
@@ -655,6 +654,8 @@ __global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_num_vgpr(64))) vo
     uint16_t* arg = jmp + T;   // slot of the segment that holds the border's smallest start state
     const size_t r_bytes = relay_region_bytes(lds_bits_words, kcap, tbits);
     uint32_t* hkey = (uint32_t*)(ct_smem + r_bytes);
+    // whole borders kept by phase (c): pool offset, length, -, discovery key * 2 + is_hole (kcap entries, behind the keys)
+    uint4* s_small = (uint4*)(hkey + T);
     int* klen = (int*)uni;
     int* koff = klen + kcap;
     int* rectflag = koff + kcap;
@@ -664,10 +665,6 @@ __global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_num_vgpr(64))) vo
     uint32_t* pl = pool + (size_t)f * pool_fstride;
     RelaySeg* sg = segs + ((size_t)f << tbits);
 
-    if (tid == 0) {
-        s_next = 0; s_nkept = 0; s_flags = 0; s_ncand = 0; s_nmark = 0; s_nsmall = 0; s_pool = 0;
-        s_changed[0] = 0; s_changed[1] = 0;
-    }
 #ifdef ORBFE_CT_TIMING
     long long tq[8];
     int tqi = 0;
@@ -675,6 +672,12 @@ __global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_num_vgpr(64))) vo
 #else
 #define RL_STAMP()
 #endif
+    // A frame whose segments overflow the staging arenas or the copy list (one giant noisy component) is done again
+    // from (a) without a grid: every border is then followed whole, straight into the pool.
+    if (tid == 0) {
+        s_next = 0; s_nkept = 0; s_flags = 0; s_ncand = 0; s_nmark = 0; s_nsmall = 0; s_pool = 0;
+        s_changed[0] = 0; s_changed[1] = 0;
+    }
     RL_STAMP();
     // ---- (a) padded bit image into LDS: pixel (x, y) -> bit x+1 of row y+1
     for (int i = tid; i < wpr * prow; i += NT) {
@@ -697,7 +700,8 @@ __global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_num_vgpr(64))) vo
 
     // ---- (b) grid markers: relay rows word by word, relay columns in chunks of 32 rows.  If they do not fit the table
     // the grid is coarsened (K doubles) and the enumeration repeated.
-    for (;;) {
+    if (force_nogrid) { kshift = 30; kmask = (1 << kshift) - 1; K = 1 << kshift; }
+    else for (;;) {
     {
         const int nrelrow = H >> kshift, nrelcol = W >> kshift, nchunk = (H + 31) >> 5;
         const int nrow_items = nrelrow * wpr, nitems = nrow_items + nrelcol * nchunk;
@@ -749,18 +753,16 @@ __global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_num_vgpr(64))) vo
     __syncthreads();
     const bool full = (s_flags & RL_FLAG_TABLE) || s_nmark > T - (T >> 3);
     if (!full) break;
-    if (kshift >= 7) { // even a 128-pixel grid has too many markers: k_contours_t redoes the frame
-        if (tid == 0) {
-            counts[f * 4 + 0] = 0; counts[f * 4 + 1] = 0; counts[f * 4 + 2] = RL_FLAG_TABLE; counts[f * 4 + 3] = 0;
-        }
-        return;
-    }
     __syncthreads();
     for (int i = tid; i < T; i += NT) hkey[i] = 0u;
     if (tid == 0) { s_flags &= ~RL_FLAG_TABLE; s_nmark = 0; }
-    kshift++;
+    // even a 128-pixel grid has too many markers (noise): no grid at all -- every border is then "small" and phase (c)
+    // follows it whole from its start candidate, which is the single-walker formulation of k_contours_t
+    const bool nogrid = kshift >= 7;
+    kshift = nogrid ? 30 : kshift + 1;
     kmask = (1 << kshift) - 1; K = 1 << kshift;
     __syncthreads();
+    if (nogrid) break;
     }
     RL_STAMP();
 
@@ -830,19 +832,21 @@ __global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_num_vgpr(64))) vo
                         if (wk.x == sx && wk.y == sy && wk.s == s0) {
                             busy = false;
                             if (wk.n > min_len) {
-                                // rare (> min_len points between grid lines): walk it once more, into the staging arena
+                                // rare with a grid (> min_len points between grid lines), every kept border without one: the
+                                // border is whole, so its final place is known -- walk it once more, straight into the pool
                                 const int q = atomicAdd(&s_nsmall, 1), n = wk.n;
-                                if (q < RL_SMALL_CAP && wp + n <= arena) {
+                                const int base = atomicAdd(&s_pool, n);
+                                if (q >= kcap) atomicOr(&s_flags, 2);
+                                else if (base + n > stage0) atomicOr(&s_flags, 4);
+                                else {
                                     RelayWalk w2;
                                     relay_walk_from_key(im, w2, relay_key(sx, sy, s0));
                                     for (int o = 0; o < n; o++) {
-                                        my_arena[wp + o] = relay_point(w2);
+                                        pl[base + o] = relay_point(w2);
                                         rl_advance(im, w2, s_lut[(w2.ring << 3) | (unsigned)w2.s]);
                                     }
-                                    s_small[q] = make_uint4((uint32_t)(stage0 + tid * arena + wp), (uint32_t)n, 0xffffffffu,
-                                                            (uint32_t)start_key * 2u + (uint32_t)is_hole);
-                                    wp += n;
-                                } else atomicOr(&s_flags, RL_FLAG_TABLE);
+                                    s_small[q] = make_uint4((uint32_t)base, (uint32_t)n, 0u, (uint32_t)start_key * 2u + (uint32_t)is_hole);
+                                }
                             }
                         }
                     }
@@ -898,7 +902,7 @@ __global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_num_vgpr(64))) vo
                             if (k < mn) { mn = k; mnoff = wk.n; mnhole = ((e >> 5) & 3u) == 2u ? 1u : 0u; }
                         }
                         if (wp + wk.n < arena) my_arena[wp + wk.n] = relay_point(wk);
-                        else { atomicOr(&s_flags, RL_FLAG_TABLE); busy = false; } // staging full: legacy kernel
+                        else { atomicOr(&s_flags, 4); busy = false; } // staging arena full: capacity error
                         rl_advance(im, wk, e);
                     }
                 }
@@ -906,11 +910,10 @@ __global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_num_vgpr(64))) vo
         }
     }
     __syncthreads();
-    if (s_flags & RL_FALLBACK_FLAGS) {
-        if (tid == 0) {
-            counts[f * 4 + 0] = 0; counts[f * 4 + 1] = 0; counts[f * 4 + 2] = s_flags & RL_FALLBACK_FLAGS; counts[f * 4 + 3] = 0;
-        }
-        return;
+    if ((s_flags & 4) && kshift < 30) return 1; // staging arena full: again without a grid
+    if (s_flags) { // capacity exceeded or an invariant broken: the frame is reported as failed (flags != 0)
+        if (tid == 0) { counts[f * 4 + 0] = 0; counts[f * 4 + 1] = 0; counts[f * 4 + 2] = s_flags; counts[f * 4 + 3] = 0; }
+        return 0;
     }
     RL_STAMP();
 
@@ -1034,25 +1037,20 @@ __global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_num_vgpr(64))) vo
             jmp[i] = kk;
         }
     }
-    if (tid < min(s_nsmall, RL_SMALL_CAP)) {
-        const uint4 e = s_small[tid];
+    for (int q = tid; q < min(s_nsmall, kcap); q += NT) { // whole borders of phase (c): already in the pool
+        const uint4 e = s_small[q];
         const int n = (int)e.y;
         const int k = atomicAdd(&s_nkept, 1);
-        const int base = atomicAdd(&s_pool, n);
-        if (base + n > stage0) atomicOr(&s_flags, 4);
-        else if (k < kcap) {
+        if (k < kcap) {
             kkey[k] = ((unsigned long long)(0xffffffffu - (e.w >> 1)) << 32) | ((unsigned long long)(n & 0xfffff) << 12) |
                       ((unsigned)k << 1) | (e.w & 1u);
-            off_u[k] = base;
-            s_small[tid].z = (uint32_t)base;
+            off_u[k] = (int)e.x;
         }
     }
     __syncthreads();
-    if (s_nkept > kcap) { // more kept borders than this kernel's LDS arrays hold: k_contours_t redoes the frame
-        if (tid == 0) {
-            counts[f * 4 + 0] = 0; counts[f * 4 + 1] = 0; counts[f * 4 + 2] = RL_FLAG_TABLE; counts[f * 4 + 3] = 0;
-        }
-        return;
+    if (s_nkept > kcap) { // more kept borders than this kernel's arrays hold: capacity error
+        if (tid == 0) { counts[f * 4 + 0] = 0; counts[f * 4 + 1] = 0; counts[f * 4 + 2] = s_flags | 2; counts[f * 4 + 3] = 0; }
+        return 0;
     }
     // ---- (f2) the segments of kept borders move from the staging arenas to their final position.  Segment i starts
     // (n - val[i]) points after the list head; the border starts `minoff` points into the head segment, so everything
@@ -1093,11 +1091,10 @@ __global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_num_vgpr(64))) vo
             }
         __syncthreads();
         const int E = s_next;
-        if (E > RL_COPY_CAP) { // more kept segments than the copy list holds: k_contours_t redoes the frame
-            if (tid == 0) {
-                counts[f * 4 + 0] = 0; counts[f * 4 + 1] = 0; counts[f * 4 + 2] = RL_FLAG_TABLE; counts[f * 4 + 3] = 0;
-            }
-            return;
+        if (E > RL_COPY_CAP && kshift < 30) return 1; // again without a grid
+        if (E > RL_COPY_CAP) { // more kept segments than the copy list holds: capacity error
+            if (tid == 0) { counts[f * 4 + 0] = 0; counts[f * 4 + 1] = 0; counts[f * 4 + 2] = s_flags | 4; counts[f * 4 + 3] = 0; }
+            return 0;
         }
         // exclusive scan of the lengths (one entry per thread; RL_COPY_CAP == RL_THREADS)
         {
@@ -1141,10 +1138,6 @@ __global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_num_vgpr(64))) vo
                 if (pdst[u] >= 0) pl[pdst[u]] = v[u];
         }
     }
-    if (tid < min(s_nsmall, RL_SMALL_CAP) && s_small[tid].z != 0xffffffffu) {
-        const uint4 e = s_small[tid]; // staged points -> final place
-        for (int o = 0; o < (int)e.y; o++) pl[e.z + o] = pl[e.x + o];
-    }
     __threadfence_block();
     __syncthreads();
     if (tid == 0) {
@@ -1170,6 +1163,22 @@ __global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_num_vgpr(64))) vo
         dbg[6] = 0;
     }
 #endif
+    return 0;
+}
+
+__global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_num_vgpr(64))) void k_contours_relay(
+    const uint32_t* __restrict__ gbits, size_t bits_fstride, int wpr_g, int W, int H, int lds_bits_words, int min_len,
+    int kshift, int tbits, RelaySeg* __restrict__ segs, uint32_t* __restrict__ pool, size_t pool_fstride, int pool_cap,
+    ArKept* __restrict__ kept_out, int kept_cap, int kcap /*kept borders this kernel's LDS holds*/,
+    unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off, int32_t* __restrict__ counts)
+{
+    __builtin_amdgcn_s_setprio(2); // latency-bound: its few waves go first when a VALU-bound kernel shares the CU
+    if (relay_frame<false>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool, pool_fstride,
+                           pool_cap, kept_out, kept_cap, kcap, tail_keys, tail_off, counts)) {
+        __syncthreads();
+        relay_frame<true>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool, pool_fstride,
+                          pool_cap, kept_out, kept_cap, kcap, tail_keys, tail_off, counts);
+    }
 }
 
 // ---- (g) of the relay formulation as its own kernel: sort, approxPolyDP, rectangles for the borders k_contours_relay
@@ -1188,7 +1197,7 @@ __global__ __launch_bounds__(RT_THREADS) void k_contours_tail(const unsigned lon
     __shared__ unsigned s_tailq;
     const int tid = threadIdx.x, f = blockIdx.x;
     const int flags = counts[f * 4 + 2];
-    if (flags & RL_FALLBACK_FLAGS) return;
+    if (flags) return; // the relay kernel reported the frame as failed
     const int nkept = counts[f * 4 + 0];
     unsigned long long* kkey = (unsigned long long*)ct_smem;
     int* off_u = (int*)(kkey + kcap);

@@ -69,14 +69,13 @@ __global__ void k_finalize(const ArRect* rects, int rect_cap, const int32_t* can
 
 #define RL_THREADS 1024
 #define RT_THREADS 256           // k_contours_tail: 4 waves, one approxPolyDP each at a time (small workgroups place easily next to other kernels)
-#define RL_SLOTS_PER_THREAD 8   // table slots <= RL_THREADS * RL_SLOTS_PER_THREAD
-#define RL_SMALL_CAP 64         // kept borders that touch no grid marker (rare: > 70 points between grid lines)
+#define RL_SLOTS_PER_THREAD 4   // table slots <= RL_THREADS * RL_SLOTS_PER_THREAD (tbits <= 12)
 #define RL_NIL 0xffff
 #define RL_COPY_CAP 1024        // kept segments per frame the flat copy lists (== RL_THREADS; 14 bytes each <= the key table)
-#define RL_FLAG_TABLE 32        // markers did not fit: the frame is redone by k_contours_t
+#define RL_FLAG_TABLE 32        // (kernel-internal) markers did not fit: coarsen the grid
 #define RL_FLAG_BUG 64          // an invariant of the relay formulation failed: redone by k_contours_t as well
 #define RL_FALLBACK_FLAGS (RL_FLAG_TABLE | RL_FLAG_BUG)
-#define RL_KCAP 512              // kept borders per frame the relay kernel holds (more: legacy kernel)
+#define RL_KCAP AR_MAX_KEPT      // kept borders per frame (k_contours_relay + k_contours_tail)
 #define RL_STEPS_PER_ITER 2      // walk steps between two looks at the work queue
 
 // LDS of k_contours_relay: region R (bit image | list arrays) followed by the marker keys
@@ -89,7 +88,7 @@ __host__ __device__ inline size_t relay_region_bytes(int lds_bits_words, int kca
 }
 inline size_t relay_lds_bytes(int lds_bits_words, int kcap, int tbits)
 {
-    return relay_region_bytes(lds_bits_words, kcap, tbits) + ((size_t)4 << tbits);
+    return relay_region_bytes(lds_bits_words, kcap, tbits) + ((size_t)4 << tbits) + (size_t)kcap * 16;
 }
 
 // LDS of k_contours_tail: per-border arrays, approx scratch, length ranks, one point buffer of `pts` points per wave
