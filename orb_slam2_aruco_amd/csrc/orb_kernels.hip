@@ -1408,6 +1408,21 @@ __global__ __launch_bounds__(256) void k_orient_describe(ImgView src0, ImgView p
     // 4-byte-aligned column at or below kx - 15); then lanes 0..30 <-> u = -15..15 of an even row, lanes 32..62 of
     // the following row.
     __shared__ __align__(16) uint8_t s_pat[4][31 * 36 + 12];
+    // The 37 x 37 blurred window of the descriptor (pattern reach <= 18 px; rows of 40 bytes from the 4-byte-aligned
+    // column at or below kx - 18) and the lane's four pattern words do not depend on the angle: their loads are issued
+    // here, together with the patch loads, so that a keypoint costs ONE global round trip instead of two.
+    __shared__ __align__(16) uint8_t s_win[4][37 * 40 + 8];
+    const uint8_t* bimg = blur.base + (size_t)f * blur.fstride + g.blur_off;
+    const int ax = (kx - 18) & ~3, xoff = (kx - 18) - ax;
+    uint32_t wv[6], pat[4];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const int idx = min(k * 64 + lane, 369);
+        const int r = idx / 10, c = idx - r * 10;
+        wv[k] = *reinterpret_cast<const uint32_t*>(bimg + (size_t)(ky - 18 + r) * g.bpitch + ax + 4 * c);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) pat[j] = pattern32[j * 64 + lane];
     int m10 = 0, m01 = 0;
     {
         const int axp = (kx - 15) & ~3, xo = (kx - 15) - axp;
@@ -1458,21 +1473,11 @@ __global__ __launch_bounds__(256) void k_orient_describe(ImgView src0, ImgView p
     // Stage the 37 x 37 blurred window (pattern reach <= 18 px) in LDS with coalesced dword loads: 6 wave loads touch
     // ~60 cache lines, where 8 direct byte gathers would touch ~300.  Rows are 40 bytes: the window starts at the
     // 4-byte-aligned column at or below kx - 18.
-    __shared__ __align__(16) uint8_t s_win[4][37 * 40 + 8];
-    const uint8_t* bimg = blur.base + (size_t)f * blur.fstride + g.blur_off;
-    const int ax = (kx - 18) & ~3, xoff = (kx - 18) - ax;
     {
-        uint32_t v[6];
-#pragma unroll
-        for (int k = 0; k < 6; k++) {
-            const int idx = min(k * 64 + lane, 369);
-            const int r = idx / 10, c = idx - r * 10;
-            v[k] = *reinterpret_cast<const uint32_t*>(bimg + (size_t)(ky - 18 + r) * g.bpitch + ax + 4 * c);
-        }
 #pragma unroll
         for (int k = 0; k < 6; k++) {
             const int idx = k * 64 + lane;
-            if (idx < 370) reinterpret_cast<uint32_t*>(s_win[wid])[idx] = v[k];
+            if (idx < 370) reinterpret_cast<uint32_t*>(s_win[wid])[idx] = wv[k];
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -1480,7 +1485,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(ImgView src0, ImgView p
     unsigned long long words[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const uint32_t pp = pattern32[j * 64 + lane];
+        const uint32_t pp = pat[j];
         const float x0 = (float)(signed char)(pp & 0xff), y0 = (float)(signed char)((pp >> 8) & 0xff);
         const float x1 = (float)(signed char)((pp >> 16) & 0xff), y1 = (float)(signed char)(pp >> 24);
         const int r0 = orbfe_round_f(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
