@@ -1392,6 +1392,25 @@ __global__ __launch_bounds__(256) void k_orient_describe(ImgView src0, ImgView p
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     int bx, f;
     if (!xcd_remap(nx, total, bx, f)) return;
+    // IC_Angle weights of the 31 rows of the r = 15 circular patch: [row][0..7] = byte index i = u + 15 of the bytes inside
+    // |u| <= umax(|v|), [row][8..15] = 1 for the same bytes (umax: ORBextractor.cc:454-469, a constant table for r = 15)
+    __shared__ __align__(16) uint32_t s_icw[31][16];
+    if (threadIdx.x < 248) {
+        constexpr int UM[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+        const int row = threadIdx.x >> 3, j = threadIdx.x & 7, av = row < 15 ? 15 - row : row - 15;
+        int um = 0;
+#pragma unroll
+        for (int q = 0; q < 16; q++) um = av == q ? UM[q] : um;
+        uint32_t wi = 0, on = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = 4 * j + k, u = i - 15;
+            if (i <= 30 && u >= -um && u <= um) { wi |= (uint32_t)i << (8 * k); on |= 1u << (8 * k); }
+        }
+        s_icw[row][j] = wi;
+        s_icw[row][8 + j] = on;
+    }
+    __syncthreads();
     const int oidx = bx * 4 + wid; // flat index over the frame's keypoints (levels concatenated ascending)
     if (oidx >= n_out[f]) return;
     const uint32_t kv = flat_kv[(size_t)f * capacity + oidx];
@@ -1443,22 +1462,26 @@ __global__ __launch_bounds__(256) void k_orient_describe(ImgView src0, ImgView p
             if (idx < 279) reinterpret_cast<uint32_t*>(s_pat[wid])[idx] = v[k];
         }
         __builtin_amdgcn_wave_barrier();
-        const int half = lane >> 5, u = (lane & 31) - 15;
-        const uint8_t* center = s_pat[wid] + 15 * 36 + 15 + xo;
+        // lane = patch row v = lane - 15 (lanes 0..30): the row's 31 bytes as eight dwords re-cut at the byte offset xo,
+        // m10 = sum (i - 15) I = dot(I, i) - 15 dot(I, 1) and m01 = v dot(I, 1) over the row's part of the circular patch,
+        // with the two weight vectors (byte index i, ones; zero outside |u| <= umax(|v|)) from a per-workgroup LDS table
+        if (lane < 31) {
+            const uint32_t* rw = reinterpret_cast<const uint32_t*>(s_pat[wid] + lane * 36);
+            const uint4 wa = *reinterpret_cast<const uint4*>(&s_icw[lane][0]), wb = *reinterpret_cast<const uint4*>(&s_icw[lane][4]);
+            const uint4 oa = *reinterpret_cast<const uint4*>(&s_icw[lane][8]), ob = *reinterpret_cast<const uint4*>(&s_icw[lane][12]);
+            uint32_t d[9];
 #pragma unroll
-        for (int it = 0; it < 16; it++) {
-            const int v = -15 + 2 * it + half; // rows -15..16 (16 is masked)
-            // umax of the r = 15 circular patch is a constant table (ORBextractor.cc:454-469)
-            constexpr int UM[17] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3, 0};
-            const int v0 = -15 + 2 * it, a0 = v0 < 0 ? -v0 : v0, a1 = (v0 + 1) < 0 ? -(v0 + 1) : (v0 + 1);
-            if ((lane & 31) < 31 && v <= 15) {
-                const int um = half ? UM[a1] : UM[a0];
-                if (u >= -um && u <= um) {
-                    const int val = center[v * 36 + u];
-                    m10 += u * val;
-                    m01 += v * val;
-                }
-            }
+            for (int j = 0; j < 9; j++) d[j] = rw[j];
+            uint32_t e[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) e[j] = __builtin_amdgcn_alignbyte(d[j + 1], d[j], xo);
+            uint32_t A = 0, B = 0;
+            A = bl_dot4(e[0], wa.x, A); A = bl_dot4(e[1], wa.y, A); A = bl_dot4(e[2], wa.z, A); A = bl_dot4(e[3], wa.w, A);
+            A = bl_dot4(e[4], wb.x, A); A = bl_dot4(e[5], wb.y, A); A = bl_dot4(e[6], wb.z, A); A = bl_dot4(e[7], wb.w, A);
+            B = bl_dot4(e[0], oa.x, B); B = bl_dot4(e[1], oa.y, B); B = bl_dot4(e[2], oa.z, B); B = bl_dot4(e[3], oa.w, B);
+            B = bl_dot4(e[4], ob.x, B); B = bl_dot4(e[5], ob.y, B); B = bl_dot4(e[6], ob.z, B); B = bl_dot4(e[7], ob.w, B);
+            m10 = (int)A - 15 * (int)B;
+            m01 = (lane - 15) * (int)B;
         }
         m10 = wave_sum(m10);
         m01 = wave_sum(m01);
