@@ -22,6 +22,7 @@ struct orbfe_aruco {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int rows = 0, cols = 0, batch_cap = 0;
     int win = 0, wpr = 0, npyr = 0;
+    uint32_t th_magic = 0; // multiply-high constant of the box mean (0: use the generic threshold kernel)
     std::vector<ArLevel> levels;
     std::vector<int> lvl_exact;           // 1 if level p is an exact 2x reduction of level p-1
     std::vector<size_t> tab_off;          // resize tables for non-exact levels
@@ -77,6 +78,17 @@ struct orbfe_aruco {
         if (w % 2 == 0) w++;
         if (w > 2 * TH_MAXR_HOST + 1) return fail(ORBFE_ERR_INVALID, "threshold window %d too large", w);
         win = w;
+        // k_adaptive_threshold_t computes the mean as (s + n/2) * magic >> 32, n = win^2: use it only if that equals the
+        // reference's rint(s * (1.0 / n)) for every possible box sum
+        th_magic = 0;
+        {
+            const int n = w * w;
+            const uint32_t mg = (uint32_t)((0x100000000ull + n - 1) / n);
+            bool same = (n & 1) != 0;
+            for (int sum = 0; same && sum <= 255 * n; sum++)
+                same = (int)(((unsigned long long)(sum + n / 2) * mg) >> 32) == orbfe_round_d((double)sum * (1.0 / n));
+            if (same) th_magic = mg;
+        }
         wpr = (cols_ + 31) / 32;
         bits_fu32 = (size_t)wpr * rows_;
         // buildPyramid (:1299-1488): halve while width > 2 * S
@@ -205,8 +217,15 @@ struct orbfe_aruco {
         }
         timer.mark(aux_stream, "pyramid");
         ORBFE_HIP(hipEventRecord(ev_join, aux_stream));
-        if (!(g_aruco_skip & 8)) hipLaunchKernelGGL(k_adaptive_threshold, dim3((cols + 63) / 64, (rows + 63) / 64, B), dim3(256), 0, s, src0,
-                           cols, rows, win, 7, 1.0 / (win * win), d_bits.as<uint32_t>(), bits_fu32, wpr);
+        if (!(g_aruco_skip & 8)) {
+            const dim3 tg((cols + 63) / 64, (rows + 63) / 64, B);
+            uint32_t* bp = d_bits.as<uint32_t>();
+            if (th_magic && win == 5) hipLaunchKernelGGL(k_adaptive_threshold_t<5>, tg, dim3(256), 0, s, src0, cols, rows, 7, th_magic, bp, bits_fu32, wpr);
+            else if (th_magic && win == 7) hipLaunchKernelGGL(k_adaptive_threshold_t<7>, tg, dim3(256), 0, s, src0, cols, rows, 7, th_magic, bp, bits_fu32, wpr);
+            else if (th_magic && win == 11) hipLaunchKernelGGL(k_adaptive_threshold_t<11>, tg, dim3(256), 0, s, src0, cols, rows, 7, th_magic, bp, bits_fu32, wpr);
+            else if (th_magic && win == 15) hipLaunchKernelGGL(k_adaptive_threshold_t<15>, tg, dim3(256), 0, s, src0, cols, rows, 7, th_magic, bp, bits_fu32, wpr);
+            else hipLaunchKernelGGL(k_adaptive_threshold, tg, dim3(256), 0, s, src0, cols, rows, win, 7, 1.0 / (win * win), bp, bits_fu32, wpr);
+        }
         timer.mark(s, "threshold");
         const size_t lds = contours_lds_bytes(lds_bits_words, AR_MAX_KEPT);
         ORBFE_HIP(hipGetLastError());

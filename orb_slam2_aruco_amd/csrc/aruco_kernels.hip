@@ -22,6 +22,8 @@ __device__ __forceinline__ int a_lane_prefix(unsigned long long mask)
     return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
 }
 
+__device__ __forceinline__ uint32_t bl_dot4_a(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_udot4(a, b, c, false); }
+
 // ---------------------------------------------------------------------------------------- threshold -----------
 // cv::adaptiveThreshold(MEAN_C, BINARY_INV, win, C): mean = round(boxsum / win^2) with BORDER_REPLICATE,
 // out = (src - mean <= -C).  Tile 64 x 16 per workgroup; one wave = one row of 64 px -> one 64-bit ballot store.
@@ -87,6 +89,105 @@ __global__ __launch_bounds__(256) void k_adaptive_threshold(ImgView src, int W, 
         }
     }
 }
+
+// The same threshold on the packed dot-product instructions (the generic kernel above issues 2 * 15 predicated LDS reads
+// and adds per pixel and an fp64 multiply for the mean).  64 x 64 tile per workgroup, WIN = 2 R + 1 a template parameter:
+//   horizontal: a thread loads the bytes around 4 adjacent outputs of one row as 3 (R <= 3) or 5 dwords; a box sum of WIN
+//               bytes is ceil(WIN / 4) v_dot4_u32_u8 with all-ones weights on windows cut out with v_alignbyte; the sums
+//               go to LDS column-major, the tile's own pixels row-major;
+//   vertical:   a lane owns one column and 16 consecutive rows: 16 + 2 R sums as dwords, sliding window down the column;
+//               mean = (s + WIN^2 / 2) / WIN^2 as a multiply-high (WIN^2 is odd, so the rounding has no ties and equals
+//               rint(s * (1.0 / WIN^2)) -- verified exhaustively by the host before this kernel is chosen);
+//               one 64-bit ballot per row = 64 bits of the bit image.
+typedef uint32_t u32_unaligned_t __attribute__((aligned(1)));
+template <int WIN>
+__global__ __launch_bounds__(256) void k_adaptive_threshold_t(ImgView src, int W, int H, int C, uint32_t magic,
+                                                              uint32_t* __restrict__ bits, size_t bits_fstride, int wpr)
+{
+    constexpr int R = WIN / 2, NDW = R <= 3 ? 3 : 5, LEAD = R <= 3 ? 4 : 8; // window = bytes x - LEAD .. x - LEAD + 4 NDW - 1
+    constexpr int ROWS = 64 + 2 * R, P0 = (ROWS + 1) & ~1, PITCH = ((P0 / 2) & 1) ? P0 : P0 + 2; // u16 per LDS column:
+    __shared__ __align__(16) uint16_t sh[64 * PITCH];                                           // an odd number of dwords
+    __shared__ __align__(16) uint32_t spx[64][16];
+    const int tx0 = blockIdx.x * 64, ty0 = blockIdx.y * 64, f = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint8_t* img = src.base + (size_t)f * src.fstride;
+    constexpr int NIT = (ROWS * 16 + 255) / 256;
+    uint32_t w[NIT][NDW];
+#pragma unroll
+    for (int k = 0; k < NIT; k++) {
+        const int it = tid + 256 * k;
+        const int rr = it >> 4, x = tx0 + 4 * (it & 15);
+#pragma unroll
+        for (int j = 0; j < NDW; j++) w[k][j] = 0;
+        if (rr < ROWS) {
+            const uint8_t* row = img + (size_t)min(max(ty0 + rr - R, 0), H - 1) * src.pitch; // BORDER_REPLICATE
+            if (x >= LEAD && x - LEAD + 4 * NDW <= W) {
+#pragma unroll
+                for (int j = 0; j < NDW; j++) w[k][j] = reinterpret_cast<const u32_unaligned_t*>(row + x - LEAD)[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4 * NDW; j++)
+                    w[k][j >> 2] |= (uint32_t)row[min(max(x - LEAD + j, 0), W - 1)] << (8 * (j & 3));
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NIT; k++) {
+        const int it = tid + 256 * k;
+        const int rr = it >> 4, c = 4 * (it & 15);
+        if (rr < ROWS) {
+            uint32_t sum[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                // output i sums window bytes a .. a + WIN - 1, a = LEAD + i - R
+                constexpr uint32_t ONES = 0x01010101u;
+                const int a = LEAD + i - R;
+                uint32_t acc = 0;
+#pragma unroll
+                for (int q = 0; q < (WIN + 3) / 4; q++) {
+                    const int b = a + 4 * q, j = b >> 2, sft = b & 3;                 // window bytes b .. b+3
+                    const uint32_t hi = j + 1 < NDW ? w[k][j + 1] : 0u;
+                    const uint32_t v = sft ? __builtin_amdgcn_alignbyte(hi, w[k][j], sft) : w[k][j];
+                    const int left = WIN - 4 * q;                                       // bytes still to add
+                    acc = bl_dot4_a(v, left >= 4 ? ONES : (ONES >> (8 * (4 - left))), acc);
+                }
+                sum[i] = acc;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) sh[(c + i) * PITCH + rr] = (uint16_t)sum[i];
+            if (rr >= R && rr < 64 + R) spx[rr - R][it & 15] = w[k][LEAD / 4]; // the tile's own pixels x .. x+3
+        }
+    }
+    __syncthreads();
+    // vertical: lane = column, wave = 16 rows
+    {
+        const int c = lane, r0 = 16 * wid;
+        const uint16_t* hp = &sh[c * PITCH + r0];
+        int s = 0;
+#pragma unroll
+        for (int k = 0; k < WIN; k++) s += hp[k];
+        const int x = tx0 + c;
+        const uint8_t* px = reinterpret_cast<const uint8_t*>(&spx[r0][0]) + c;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int y = ty0 + r0 + k;
+            int mean = (int)__umulhi((uint32_t)(s + WIN * WIN / 2), magic);
+            mean = mean > 255 ? 255 : mean;
+            const int v = px[k * 64];
+            const bool on = (x < W) && (y < H) && (v - mean <= -C);
+            const unsigned long long m = __ballot(on);
+            if (y < H && lane < 2) {
+                const int word = (tx0 >> 5) + lane;
+                if (word < wpr) bits[(size_t)f * bits_fstride + (size_t)y * wpr + word] = (uint32_t)(m >> (32 * lane));
+            }
+            if (k < 15) s += (int)hp[k + WIN] - (int)hp[k];
+        }
+    }
+}
+template __global__ void k_adaptive_threshold_t<5>(ImgView, int, int, int, uint32_t, uint32_t*, size_t, int);
+template __global__ void k_adaptive_threshold_t<7>(ImgView, int, int, int, uint32_t, uint32_t*, size_t, int);
+template __global__ void k_adaptive_threshold_t<11>(ImgView, int, int, int, uint32_t, uint32_t*, size_t, int);
+template __global__ void k_adaptive_threshold_t<15>(ImgView, int, int, int, uint32_t, uint32_t*, size_t, int);
 
 // exact 2x downscale = INTER_AREA 2x2 mean (what cv::resize(INTER_LINEAR) does for an exact factor of two)
 __global__ __launch_bounds__(256) void k_half_area(ImgView src, ImgView dst, int dw, int dh)
