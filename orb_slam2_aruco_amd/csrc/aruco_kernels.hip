@@ -1714,11 +1714,8 @@ __global__ __launch_bounds__(256) void k_finalize(const ArRect* __restrict__ rec
     __builtin_amdgcn_s_setprio(2); // latency-bound: its few waves go first when a VALU-bound kernel shares the CU
     __shared__ int s_id[AR_MAX_RECTS], s_src[AR_MAX_RECTS], s_rot[AR_MAX_RECTS], s_per[AR_MAX_RECTS], s_rm[AR_MAX_RECTS];
     __shared__ float s_c[AR_MAX_RECTS][4][2];
-    __shared__ int s_n;
-    __shared__ unsigned long long s_best[4];
-    __shared__ double s_sum[4][5];
-    __shared__ float s_ext[4][4];
-    __shared__ float s_line[4][3];
+    __shared__ int s_n, s_written;
+    __shared__ int s_slot[AR_MAX_RECTS];
     const int f = blockIdx.x, tid = threadIdx.x;
     const int nc = ncand[f];
     const ArRect* R = rects + (size_t)f * rect_cap;
@@ -1754,25 +1751,30 @@ __global__ __launch_bounds__(256) void k_finalize(const ArRect* __restrict__ rec
                     if (s_per[i] < s_per[j]) s_rm[i] = 1;
                     else s_rm[j] = 1;
                 }
+        int w = 0;
+        for (int i = 0; i < m; i++) { s_slot[i] = w; w += s_rm[i] ? 0 : 1; } // output order = id order, removed ones skipped
+        s_written = w;
         s_n = m;
     }
     __syncthreads();
     const int m = s_n;
-    int written = 0;
-    for (int i = 0; i < m; i++) {
+    // ---- refineCornerWithContourLines (:8978-10044), one WAVE per marker.  The reference walks the four point runs
+    // between the contour points nearest to the corners and accumulates sums of integer coordinates in double: those
+    // sums are exact, so they are formed in parallel over the run and reduced on the DPP network.
+    const int lane = tid & 63, wid = tid >> 6;
+    for (int i = wid; i < m; i += 4) {
         if (s_rm[i]) continue;
-        // ---- refineCornerWithContourLines (:8978-10044)
         const ArRect& r = R[s_src[i]];
         const uint32_t* P = pool + (size_t)f * pool_fstride + r.off;
         const int len = r.len;
-        if (tid < 4) s_best[tid] = ~0ull;
-        __syncthreads();
         // nearest contour point to each corner, first minimum wins
+        int ci[4];
         {
             unsigned long long b[4] = {~0ull, ~0ull, ~0ull, ~0ull};
-            for (int j = tid; j < len; j += 256) {
+            for (int j = lane; j < len; j += 64) {
                 const uint32_t v = P[j];
                 const float x = (float)(v & 0xffff), y = (float)(v >> 16);
+#pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const float dx = x - s_c[i][k][0], dy = y - s_c[i][k][1];
                     const float d = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
@@ -1780,46 +1782,66 @@ __global__ __launch_bounds__(256) void k_finalize(const ArRect* __restrict__ rec
                     b[k] = key < b[k] ? key : b[k];
                 }
             }
-            for (int k = 0; k < 4; k++) atomicMin(&s_best[k], b[k]);
+#pragma unroll
+            for (int k = 0; k < 4; k++) ci[k] = (int)(wave_min_u64(b[k]) & 0xffffffffu);
         }
-        __syncthreads();
-        int ci[4];
-        for (int k = 0; k < 4; k++) ci[k] = (int)(s_best[k] & 0xffffffffu);
         bool inverse;
         if ((ci[1] > ci[0]) && (ci[2] > ci[1] || ci[2] < ci[0])) inverse = false;
         else if (ci[2] > ci[1] && ci[2] < ci[0]) inverse = false;
         else inverse = true;
-        // the four point runs; thread l < 4 walks run l exactly like the reference loop (a few hundred steps)
-        if (tid < 4) {
-            const int l = tid, inc = inverse ? -1 : 1, target = ci[(l + 1) & 3];
-            double su = 0, sv = 0, sxx = 0, syy = 0, sxy = 0, cnt = 0;
-            float minX = 0, maxX = 0, minY = 0, maxY = 0;
-            int guard = 0;
-            for (int j = ci[l]; j != target && guard < 2 * len + 4; j += inc, guard++) {
-                if (j == len && !inverse) j = 0;
-                else if (j == 0 && inverse) j = len - 1;
-                const uint32_t v = P[j];
-                const float x = (float)(v & 0xffff), y = (float)(v >> 16);
-                if (cnt == 0) { minX = maxX = x; minY = maxY = y; }
-                else { minX = fminf(minX, x); maxX = fmaxf(maxX, x); minY = fminf(minY, y); maxY = fmaxf(maxY, y); }
-                su += x; sv += y; sxx += (double)x * x; syy += (double)y * y; sxy += (double)x * y;
-                cnt += 1;
-                if (j == target) break;
+        float line[4][3];
+#pragma unroll
+        for (int l = 0; l < 4; l++) {
+            // The points the reference loop visits (for (j = ci[l]; j != target; j += inc) with its wrap rules, incl. the
+            // quirks: going forward a wrap that lands on target == 0 still takes point 0; going backward index 0 is
+            // replaced by len-1 before it is read, and a wrap that lands on target == len-1 still takes that point):
+            // up to two index ranges [a0, a1) and [b0, b1) plus at most one extra point.
+            const int j0 = ci[l], target = ci[(l + 1) & 3];
+            int a0 = 0, a1 = 0, b0 = 0, b1 = 0, extra = -1;
+            if (j0 != target) {
+                if (!inverse) {
+                    if (target > j0) { a0 = j0; a1 = target; }
+                    else { a0 = j0; a1 = len; b0 = 0; b1 = target; if (target == 0) extra = 0; }
+                } else {
+                    if (target < j0) { a0 = target + 1; a1 = j0 + 1; }
+                    else {
+                        a0 = 1; a1 = j0 + 1; // (empty when j0 == 0)
+                        if (target == len - 1) extra = len - 1;
+                        else { b0 = target + 1; b1 = len; }
+                    }
+                }
             }
-            if (cnt == 0) { s_line[l][0] = s_line[l][1] = s_line[l][2] = 0.f; }
+            double su = 0, sv = 0, sxx = 0, syy = 0, sxy = 0;
+            int cnt = 0, minX = 0x7fffffff, maxX = -1, minY = 0x7fffffff, maxY = -1;
+            auto take = [&](int j) {
+                const uint32_t v = P[j];
+                const int xi = (int)(v & 0xffff), yi = (int)(v >> 16);
+                const double x = xi, y = yi;
+                minX = min(minX, xi); maxX = max(maxX, xi); minY = min(minY, yi); maxY = max(maxY, yi);
+                su += x; sv += y; sxx += x * x; syy += y * y; sxy += x * y;
+                cnt++;
+            };
+            for (int j = a0 + lane; j < a1; j += 64) take(j);
+            for (int j = b0 + lane; j < b1; j += 64) take(j);
+            if (extra >= 0 && lane == 0) take(extra);
+            cnt = wave_sum(cnt);
+            if (cnt == 0) { line[l][0] = line[l][1] = line[l][2] = 0.f; }
             else {
-                const bool xdom = (maxX - minX > maxY - minY);
-                if (xdom) fit_line(cnt, su, sv, sxx, sxy, true, s_line[l]);
-                else fit_line(cnt, sv, su, syy, sxy, false, s_line[l]);
+                su = wave_sum_f64(su); sv = wave_sum_f64(sv); sxx = wave_sum_f64(sxx); syy = wave_sum_f64(syy); sxy = wave_sum_f64(sxy);
+                minX = wave_min(minX); maxX = wave_max(maxX); minY = wave_min(minY); maxY = wave_max(maxY);
+                const bool xdom = ((float)maxX - (float)minX > (float)maxY - (float)minY);
+                if (xdom) fit_line((double)cnt, su, sv, sxx, sxy, true, line[l]);
+                else fit_line((double)cnt, sv, su, syy, sxy, false, line[l]);
             }
         }
-        __syncthreads();
-        if (tid == 0 && written < out_cap) {
+        const int slot = s_slot[i];
+        if (lane == 0 && slot < out_cap) {
             orbfe_marker mk;
             mk.id = s_id[i];
+#pragma unroll
             for (unsigned k = 0; k < 4; k++) {
-                const float* l1 = s_line[(k - 1) % 4];
-                const float* l2 = s_line[k];
+                const float* l1 = line[(k - 1) % 4];
+                const float* l2 = line[k];
                 const double a = l1[0], b = l1[1], c = l2[0], d = l2[1], e = -(double)l1[2], g = -(double)l2[2];
                 const double det = a * d - b * c;
                 float x = 0.f, y = 0.f;
@@ -1827,12 +1849,10 @@ __global__ __launch_bounds__(256) void k_finalize(const ArRect* __restrict__ rec
                 mk.corners[k][0] = x;
                 mk.corners[k][1] = y;
             }
-            out[(size_t)f * out_cap + written] = mk;
+            out[(size_t)f * out_cap + slot] = mk;
         }
-        written++;
-        __syncthreads();
     }
-    if (tid == 0) n_out[f] = written < out_cap ? written : out_cap;
+    if (tid == 0) n_out[f] = s_written < out_cap ? s_written : out_cap;
 }
 
 } // namespace orbfe

@@ -61,4 +61,18 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 }
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) { return ~wave_max_u64(~v); }
 
+// sum of doubles (exact, hence order-free, when every partial sum is an integer below 2^53)
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+#define ORBFE_STEP(ctrl, rmask)                                                                              \
+    {                                                                                                        \
+        const int lo = ORBFE_DPP(0, __double2loint(v), ctrl, rmask);                                         \
+        const int hi = ORBFE_DPP(0, __double2hiint(v), ctrl, rmask);                                         \
+        v += __hiloint2double(hi, lo);                                                                       \
+    }
+    ORBFE_DPP_STEPS(ORBFE_STEP)
+#undef ORBFE_STEP
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
 } // namespace orbfe
