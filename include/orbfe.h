@@ -140,6 +140,28 @@ int orbfe_search_for_initialization(const orbfe_keypoint* kps1, const uint8_t* d
                                     float* prev_matched, int32_t* matches12, int window_size, float nnratio,
                                     int check_orientation, int32_t* nmatches, int device);
 
+/* The matching loop of ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) (ORBmatcher.cc:45-129) on
+ * flat arrays; the projection of the map points, the viewing-cosine radius and the MapPoint bookkeeping stay with the
+ * caller.  Query q = a map point in view: window centre (x, y), radius r (already times the scale factor of the predicted
+ * level, :71), octave range [min_level, max_level] (:71 passes predicted-1 .. predicted; max_level < 0 = no upper bound,
+ * both <= 0 / < 0 = no octave test, as Frame::GetFeaturesInArea, Frame.cc:280-333), 32-byte descriptor.  Candidates are
+ * GetFeaturesInArea's, in its order.  taken[i] != 0: keypoint i already carries a map point with observations (:91-93).
+ *   mode 0: best / second-best distance and octave per query (:84-118), no state between queries -- also the inner loop
+ *           of the (CurrentFrame, LastFrame) and (CurrentFrame, KeyFrame) variants (:1413-1433, :1551-1571);
+ *           best_idx = -1, distances 256, levels -1 when there is no candidate.  match / nmatches may be NULL.
+ *   mode 1: the whole loop: accept when best <= th_high (TH_HIGH = 100) and not (same octave and best > nnratio*second)
+ *           (:121-128); an accepted keypoint is taken for the queries after it.  match[q] = keypoint index or -1,
+ *           *nmatches = accepted count, taken[] updated in place.  The raw outputs may be NULL.
+ * Host pointers.  undistorted camera (grid bounds 0..cols, 0..rows), mono (no right-image test). */
+typedef struct orbfe_window_query {
+    float x, y, r;
+    int32_t min_level, max_level;
+} orbfe_window_query;
+int orbfe_search_by_projection(const orbfe_keypoint* kps, const uint8_t* desc, int n, int cols, int rows,
+                               const orbfe_window_query* queries, const uint8_t* qdesc, int nq, uint8_t* taken, int mode,
+                               int th_high, float nnratio, int32_t* best_idx, int32_t* best_dist, int32_t* best_level,
+                               int32_t* second_dist, int32_t* second_level, int32_t* match, int32_t* nmatches, int device);
+
 /* Batched device variant over npairs frame pairs (frame t vs t-1 of a stream); all arrays are blocks of `capacity`
  * records per frame; pair p matches frame p (as F1) against frame p+1 (as F2). prev_matched == NULL means
  * "start from F1's own keypoint positions" (what Tracking does on the first call, src/Tracking.cc:520-523). */

@@ -160,6 +160,57 @@ void oracle_knn2_csr(const uint8_t* Q, int nq, const uint8_t* T, const int32_t* 
     }
 }
 
+/* The matching loop of ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th), ORBmatcher.cc:45-129, with
+ * the MapPoint / Frame objects flattened to arrays (the projection, the viewing-cosine radius and the bookkeeping of map
+ * points stay with the caller).  Per query q (a map point in view): window centre (x, y), radius r (already multiplied by
+ * the scale factor of the predicted level, :71), level range [min_level, max_level] (:71: predicted-1 .. predicted),
+ * descriptor.  Candidates = Frame::GetFeaturesInArea (Frame.cc:280-333).  taken[i] != 0 marks keypoints that already
+ * carry a map point with observations (:91-93).
+ *   mode 0: raw -- best / second-best and their octaves per query (:84-118), no cross-query state; this is also the inner
+ *           loop of the (CurrentFrame, LastFrame) and (CurrentFrame, KeyFrame) variants (:1413-1433, :1551-1571).
+ *   mode 1: the whole loop -- accept if best <= th_high and not (same octave and best > nnratio * second) (:121-128), and
+ *           the accepted keypoint becomes taken for the following queries (F.mvpMapPoints[bestIdx] = pMP; map points in
+ *           view have observations).  match[q] = keypoint index or -1.  taken[] is updated in place.  Returns nmatches. */
+struct WindowQuery { float x, y, r; int32_t min_level, max_level; };
+
+int oracle_search_by_projection(const void* kps_, const uint8_t* desc, int n, int cols, int rows, const void* queries_,
+                                const uint8_t* qdesc, int nq, uint8_t* taken, int mode, int th_high, float nnratio,
+                                int32_t* best_idx, int32_t* best_dist, int32_t* best_level, int32_t* second_dist,
+                                int32_t* second_level, int32_t* match)
+{
+    const KeyPoint* k = (const KeyPoint*)kps_;
+    const WindowQuery* Q = (const WindowQuery*)queries_;
+    FrameGrid F(k, n, cols, rows);
+    int nmatches = 0;
+    for (int q = 0; q < nq; q++) {
+        const std::vector<int> vIndices = F.GetFeaturesInArea(Q[q].x, Q[q].y, Q[q].r, Q[q].min_level, Q[q].max_level);
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int idx : vIndices) {
+            if (taken && taken[idx]) continue;
+            const int dist = DescriptorDistance(qdesc + (size_t)q * 32, desc + (size_t)idx * 32);
+            if (dist < bestDist) {
+                bestDist2 = bestDist; bestDist = dist;
+                bestLevel2 = bestLevel; bestLevel = k[idx].octave;
+                bestIdx = idx;
+            } else if (dist < bestDist2) {
+                bestLevel2 = k[idx].octave;
+                bestDist2 = dist;
+            }
+        }
+        if (best_idx) { best_idx[q] = bestIdx; best_dist[q] = bestDist; best_level[q] = bestLevel; second_dist[q] = bestDist2; second_level[q] = bestLevel2; }
+        if (mode == 1) {
+            match[q] = -1;
+            if (bestIdx >= 0 && bestDist <= th_high) {
+                if (bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) continue;
+                match[q] = bestIdx;
+                if (taken) taken[bestIdx] = 1;
+                nmatches++;
+            }
+        }
+    }
+    return nmatches;
+}
+
 /* ORBmatcher::SearchForInitialization, ORBmatcher.cc:409-524.
  * prevMatched (n1 x 2 floats) is updated in place like vbPrevMatched; matches12 gets n1 ints. */
 int oracle_search_for_initialization(const void* kps1_, const uint8_t* desc1, int n1, const void* kps2_,

@@ -27,7 +27,7 @@ SYMBOLS = [
     "orbfe_extractor_debug_level_size", "orbfe_extractor_debug_level_image",
     "orbfe_extractor_debug_level_keypoints", "orbfe_extractor_debug_kernel_times",
     "orbfe_debug_control", "orbfe_hamming", "orbfe_knn2", "orbfe_knn2_batch_device", "orbfe_search_for_initialization",
-    "orbfe_search_for_initialization_batch_device",
+    "orbfe_search_for_initialization_batch_device", "orbfe_search_by_projection",
     "orbfe_aruco_create", "orbfe_aruco_destroy", "orbfe_aruco_set_dictionary", "orbfe_aruco_max_markers",
     "orbfe_aruco_detect", "orbfe_aruco_detect_batch", "orbfe_aruco_detect_batch_device", "orbfe_aruco_debug_image",
     "orbfe_aruco_debug_kernel_times",
@@ -71,6 +71,7 @@ def load():
     L.orbfe_extractor_debug_kernel_times.argtypes = [vp, vp, i32]
     if hasattr(L, "orbfe_knn2"):
         L.orbfe_debug_control.argtypes = [C.c_char_p, i32]
+        L.orbfe_search_by_projection.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, vp, i32, i32, C.c_float] + [vp] * 7 + [i32]
         L.orbfe_hamming.argtypes = [vp, vp]
         L.orbfe_knn2.argtypes = [vp, i32, vp, i32, i32, vp, vp, vp, i32]
         L.orbfe_knn2_batch_device.argtypes = [vp, vp, sz, i32, vp, vp, sz, i32, i32, i32, vp, vp, vp, vp]
@@ -251,6 +252,27 @@ def knn2(Q, T, init=256, device=0):
     bi = np.full(len(Q), -1, np.int32); bd = np.full(len(Q), init, np.int32); sd = np.full(len(Q), init, np.int32)
     _check(L, L.orbfe_knn2(_p(Q), len(Q), _p(T), len(T), init, _p(bi), _p(bd), _p(sd), device), "orbfe_knn2")
     return bi, bd, sd
+
+
+WINDOW_QUERY_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("r", "<f4"), ("min_level", "<i4"), ("max_level", "<i4")])
+
+
+def search_by_projection(kps, desc, cols, rows, queries, qdesc, taken=None, mode=0, th_high=100, nnratio=0.8, device=0):
+    """The matching loop of ORBmatcher::SearchByProjection(Frame&, vpMapPoints, th) (ORBmatcher.cc:45-129) on flat arrays:
+    queries = WINDOW_QUERY_DTYPE records (projected position, radius, octave range), qdesc = their descriptors.
+    mode 0: best / second-best + octaves per query; mode 1: the whole loop (accept rule, taken keypoints)."""
+    L = load()
+    kps = np.ascontiguousarray(kps, KP_DTYPE); desc = np.ascontiguousarray(desc, np.uint8)
+    queries = np.ascontiguousarray(queries, WINDOW_QUERY_DTYPE); qdesc = np.ascontiguousarray(qdesc, np.uint8)
+    nq = len(queries)
+    tk = None if taken is None else np.ascontiguousarray(taken, np.uint8).copy()
+    out = [np.zeros(max(nq, 1), np.int32) for _ in range(6)]
+    nm = C.c_int32(0)
+    _check(L, L.orbfe_search_by_projection(_p(kps), _p(desc), len(kps), cols, rows, _p(queries), _p(qdesc), nq,
+                                           None if tk is None else _p(tk), mode, th_high, nnratio, *[_p(o) for o in out],
+                                           C.byref(nm), device), "orbfe_search_by_projection")
+    return dict(best_idx=out[0][:nq], best_dist=out[1][:nq], best_level=out[2][:nq], second_dist=out[3][:nq],
+                second_level=out[4][:nq], match=out[5][:nq], nmatches=nm.value, taken=tk)
 
 
 class ORBmatcher:

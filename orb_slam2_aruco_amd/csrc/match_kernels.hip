@@ -521,10 +521,207 @@ __global__ __launch_bounds__(SFI_THREADS) void k_search_init(const orbfe_keypoin
     if (lane == 0) nmatches_out[p] = nmatches;
 }
 
+// ---------------------------------------------------------------------------- SearchByProjection ---------------
+// The matching loop of ORBmatcher::SearchByProjection (ORBmatcher.cc:45-129) on flat arrays; see include/orbfe.h.
+// One workgroup (16 waves) per call.
+//   A  the Frame grid (Frame.cc:183-198, :335-345): keypoints sorted by (cell, index); cell start offsets; per-rank
+//      position / octave / taken flag in LDS.  Sorted order inside a run of cells of one grid column IS the order in
+//      which GetFeaturesInArea (Frame.cc:280-333) walks them, so a query's candidates are one contiguous range per column.
+//   B  one wave per query: candidates that pass the octave and window tests, with their Hamming distances, as a row
+//      (rank u16, distance u8) in scratch, in candidate order.
+//   C  mode 0: one wave per query resolves best / second-best over the row (strict '<', first candidate wins);
+//      mode 1: ONE wave walks the queries in order, because an accepted keypoint is taken for the queries after it.
+#define SBP_THREADS 1024
+#define SBP_CELLS (GRID_COLS * GRID_ROWS)
+struct SbpQuery { float x, y, r; int32_t min_level, max_level; };
+
+__global__ __launch_bounds__(SBP_THREADS) void k_search_by_projection(
+    const orbfe_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc, int n, int ncap /*pow2 >= n*/, int cols, int rows,
+    const SbpQuery* __restrict__ queries, const uint8_t* __restrict__ qdesc, int nq, uint8_t* __restrict__ taken, int mode,
+    int th_high, float nnratio, uint16_t* __restrict__ row_rank, uint8_t* __restrict__ row_dist, int32_t* __restrict__ row_cnt,
+    int row_stride, int32_t* __restrict__ best_idx, int32_t* __restrict__ best_dist, int32_t* __restrict__ best_level,
+    int32_t* __restrict__ second_dist, int32_t* __restrict__ second_level, int32_t* __restrict__ match,
+    int32_t* __restrict__ nmatches_out, int32_t* __restrict__ overflow)
+{
+    extern __shared__ __align__(16) unsigned char sbp_smem[];
+    __shared__ int s_nin;
+    uint32_t* s_sorted = (uint32_t*)sbp_smem;                  // (cell << 16) | index, ascending; ncap entries
+    float2* s_xy = (float2*)(s_sorted + ncap);                 // by rank
+    uint16_t* s_cell0 = (uint16_t*)(s_xy + ncap);              // first rank of every cell, SBP_CELLS + 1 entries
+    uint8_t* s_lvl = (uint8_t*)(s_cell0 + SBP_CELLS + 2);      // by rank
+    uint8_t* s_taken = s_lvl + ncap;                           // by rank
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const float mnMinX = 0.f, mnMinY = 0.f;
+    const float invW = __fdiv_rn((float)GRID_COLS, (float)cols - mnMinX);
+    const float invH = __fdiv_rn((float)GRID_ROWS, (float)rows - mnMinY);
+
+    // ---- A
+    if (tid == 0) s_nin = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += SBP_THREADS) {
+        const orbfe_keypoint kp = kps[i];
+        const int px = (int)roundf(__fmul_rn(kp.x - mnMinX, invW));
+        const int py = (int)roundf(__fmul_rn(kp.y - mnMinY, invH));
+        if (px >= 0 && px < GRID_COLS && py >= 0 && py < GRID_ROWS) {
+            const int k = atomicAdd(&s_nin, 1);
+            s_sorted[k] = ((uint32_t)(px * GRID_ROWS + py) << 16) | (uint32_t)i;
+        }
+    }
+    __syncthreads();
+    const int nin = s_nin;
+    {
+        int P = 1;
+        while (P < nin) P <<= 1;
+        for (int i = nin + tid; i < P; i += SBP_THREADS) s_sorted[i] = 0xffffffffu;
+        __syncthreads();
+        for (int k = 2; k <= P; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = tid; t < (P >> 1); t += SBP_THREADS) {
+                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    const int l = i | j;
+                    const uint32_t a = s_sorted[i], b = s_sorted[l];
+                    const bool up = ((i & k) == 0);
+                    if ((a > b) == up) { s_sorted[i] = b; s_sorted[l] = a; }
+                }
+                __syncthreads();
+            }
+    }
+    for (int c = tid; c <= SBP_CELLS; c += SBP_THREADS) { // lower bound of (c << 16)
+        const uint32_t key = (uint32_t)c << 16;
+        int lo = 0, hi = nin;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (s_sorted[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        s_cell0[c] = (uint16_t)lo;
+    }
+    for (int i = tid; i < nin; i += SBP_THREADS) {
+        const int idx = s_sorted[i] & 0xffff;
+        const orbfe_keypoint kp = kps[idx];
+        s_xy[i] = make_float2(kp.x, kp.y);
+        s_lvl[i] = (uint8_t)kp.octave;
+        s_taken[i] = taken ? taken[idx] : 0;
+    }
+    __syncthreads();
+
+    // ---- B
+    for (int q = wid; q < nq; q += SBP_THREADS / 64) {
+        const SbpQuery Q = queries[q];
+        const float x = Q.x, y = Q.y, r = Q.r;
+        int count = 0;
+        const int nMinCellX = max(0, (int)floorf(__fmul_rn(x - mnMinX - r, invW)));
+        const int nMaxCellX = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(x - mnMinX + r, invW)));
+        const int nMinCellY = max(0, (int)floorf(__fmul_rn(y - mnMinY - r, invH)));
+        const int nMaxCellY = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(y - mnMinY + r, invH)));
+        if (!(nMinCellX >= GRID_COLS || nMaxCellX < 0 || nMinCellY >= GRID_ROWS || nMaxCellY < 0)) {
+            const bool check_levels = (Q.min_level > 0) || (Q.max_level >= 0);
+            const uint4 a0 = reinterpret_cast<const uint4*>(qdesc)[2 * q];
+            const uint4 a1 = reinterpret_cast<const uint4*>(qdesc)[2 * q + 1];
+            uint16_t* rr = row_rank + (size_t)q * row_stride;
+            uint8_t* rd = row_dist + (size_t)q * row_stride;
+            for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
+                const int j_begin = s_cell0[ix * GRID_ROWS + nMinCellY], j_end = s_cell0[ix * GRID_ROWS + nMaxCellY + 1];
+                for (int j0 = j_begin; j0 < j_end; j0 += 64) {
+                    const int j = j0 + lane;
+                    bool ok = false;
+                    if (j < j_end) {
+                        const int lv = s_lvl[j];
+                        ok = !check_levels || (lv >= Q.min_level && (Q.max_level < 0 || lv <= Q.max_level));
+                        if (ok) {
+                            const float2 p = s_xy[j];
+                            ok = fabsf(p.x - x) < r && fabsf(p.y - y) < r;
+                        }
+                    }
+                    const unsigned long long m = __ballot(ok);
+                    if (ok) {
+                        const int pos = count + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                        if (pos < row_stride) {
+                            const int i2 = s_sorted[j] & 0xffff;
+                            const uint4 b0 = reinterpret_cast<const uint4*>(desc)[2 * i2];
+                            const uint4 b1 = reinterpret_cast<const uint4*>(desc)[2 * i2 + 1];
+                            const int d = hamming256(a0, a1, b0, b1);
+                            rr[pos] = (uint16_t)j;
+                            rd[pos] = (uint8_t)(d > 255 ? 255 : d); // 256 only for exact complements: never accepted
+                        }
+                    }
+                    count += __popcll(m);
+                }
+            }
+        }
+        if (lane == 0) {
+            if (count > row_stride) atomicMax(overflow, count);
+            row_cnt[q] = min(count, row_stride);
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    // ---- C: best / second-best over a row; returns keys (d << 32 | position << 16 | rank), ~0 = none
+    auto resolve = [&](int q, unsigned long long& bestk, unsigned long long& secondk) {
+        const int e = row_cnt[q];
+        const uint16_t* rr = row_rank + (size_t)q * row_stride;
+        const uint8_t* rd = row_dist + (size_t)q * row_stride;
+        bestk = ~0ull; secondk = ~0ull;
+        for (int j0 = 0; j0 < e; j0 += 64) {
+            const int j = j0 + lane;
+            unsigned long long key = ~0ull;
+            if (j < e) {
+                const int rk = rr[j];
+                if (!s_taken[rk]) key = ((unsigned long long)rd[j] << 32) | ((unsigned long long)j << 16) | (unsigned)rk;
+            }
+            const unsigned long long m1 = wave_min_u64(key);
+            const unsigned long long k2 = wave_min_u64(key == m1 ? ~0ull : key);
+            if (m1 < bestk) { secondk = min(bestk, k2); bestk = m1; }
+            else secondk = min(secondk, m1);
+        }
+    };
+    auto write_raw = [&](int q, unsigned long long bestk, unsigned long long secondk) {
+        if (lane == 0 && best_idx) {
+            const bool hb = bestk != ~0ull, hs = secondk != ~0ull;
+            best_idx[q] = hb ? (int)(s_sorted[bestk & 0xffff] & 0xffff) : -1;
+            best_dist[q] = hb ? (int)(bestk >> 32) : 256;
+            best_level[q] = hb ? (int)s_lvl[bestk & 0xffff] : -1;
+            second_dist[q] = hs ? (int)(secondk >> 32) : 256;
+            second_level[q] = hs ? (int)s_lvl[secondk & 0xffff] : -1;
+        }
+    };
+    if (mode == 0) {
+        for (int q = wid; q < nq; q += SBP_THREADS / 64) {
+            unsigned long long bk, sk;
+            resolve(q, bk, sk);
+            write_raw(q, bk, sk);
+        }
+        return;
+    }
+    if (wid != 0) return;
+    int nmatches = 0;
+    for (int q = 0; q < nq; q++) {
+        unsigned long long bk, sk;
+        resolve(q, bk, sk);
+        write_raw(q, bk, sk);
+        int m = -1;
+        if (bk != ~0ull) {
+            const int bestDist = (int)(bk >> 32), bestRank = (int)(bk & 0xffff);
+            // a second-best of 256 (none) has level -1, which never equals the best's level
+            const int bestDist2 = sk != ~0ull ? (int)(sk >> 32) : 256;
+            const int bestLevel = s_lvl[bestRank], bestLevel2 = sk != ~0ull ? (int)s_lvl[sk & 0xffff] : -1;
+            if (bestDist <= th_high && !(bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(nnratio, (float)bestDist2))) {
+                m = (int)(s_sorted[bestRank] & 0xffff);
+                if (lane == 0) { s_taken[bestRank] = 1; if (taken) taken[m] = 1; }
+                nmatches++;
+            }
+        }
+        if (lane == 0) match[q] = m;
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) *nmatches_out = nmatches;
+}
+
 struct MatchWorkspace {
     DevBuf pidx, pbest, psecond, csr_cnt, csr_idx, csr_dist, scratch, overflow, prev;
     DevBuf q, t, nq, nt, oidx, obest, osecond, kps, desc, nk, m12, nm;
     int csr_per_pair = 0; // CSR slots per frame pair (grown by the host wrapper on overflow)
+    int sbp_stride = 0;   // candidate row stride of k_search_by_projection (grown on overflow)
 };
 static thread_local MatchWorkspace* tl_ws = nullptr;
 static MatchWorkspace& ws()
@@ -726,6 +923,75 @@ int orbfe_search_for_initialization(const orbfe_keypoint* kps1, const uint8_t* d
     ORBFE_HIP(hipMemcpy(matches12, w.m12.p, (size_t)n1 * 4, hipMemcpyDeviceToHost));
     ORBFE_HIP(hipMemcpy(prev_matched, w.prev.p, (size_t)n1 * 8, hipMemcpyDeviceToHost));
     ORBFE_HIP(hipMemcpy(nmatches, w.nm.p, 4, hipMemcpyDeviceToHost));
+    return ORBFE_OK;
+}
+
+int orbfe_search_by_projection(const orbfe_keypoint* kps, const uint8_t* desc, int n, int cols, int rows,
+                               const orbfe_window_query* queries, const uint8_t* qdesc, int nq, uint8_t* taken, int mode,
+                               int th_high, float nnratio, int32_t* best_idx, int32_t* best_dist, int32_t* best_level,
+                               int32_t* second_dist, int32_t* second_level, int32_t* match, int32_t* nmatches, int device)
+{
+    if (n < 0 || nq < 0 || cols <= 0 || rows <= 0 || (mode != 0 && mode != 1) || (n && (!kps || !desc)) ||
+        (nq && (!queries || !qdesc)) || (mode == 1 && nq && (!match || !nmatches)) ||
+        (best_idx && (!best_dist || !best_level || !second_dist || !second_level)))
+        return fail(ORBFE_ERR_INVALID, "orbfe_search_by_projection: invalid argument");
+    if (n > 65535) return fail(ORBFE_ERR_INVALID, "more than 65535 keypoints per frame are unsupported");
+    int rc = use_device(device);
+    if (rc) return rc;
+    if (nmatches) *nmatches = 0;
+    if (nq == 0) return ORBFE_OK;
+    int ncap = 64;
+    while (ncap < n) ncap <<= 1;
+    const size_t lds = (size_t)ncap * (4 + 8 + 1 + 1) + (SBP_CELLS + 2) * 2 + 64;
+    if (lds > 150 * 1024) return fail(ORBFE_ERR_CAPACITY, "%d keypoints do not fit the grid kernel's LDS", n);
+    MatchWorkspace& w = ws();
+    const size_t qo = (size_t)nq * 4;
+    for (int attempt = 0;; attempt++) {
+        const int stride = std::max(w.sbp_stride, 128);
+        if ((rc = w.kps.ensure((size_t)std::max(n, 1) * sizeof(orbfe_keypoint))) || (rc = w.desc.ensure((size_t)std::max(n, 1) * 32)) ||
+            (rc = w.q.ensure((size_t)nq * sizeof(orbfe_window_query))) || (rc = w.t.ensure((size_t)nq * 32)) ||
+            (rc = w.prev.ensure((size_t)std::max(n, 1))) || (rc = w.csr_idx.ensure((size_t)nq * stride * 2)) ||
+            (rc = w.csr_dist.ensure((size_t)nq * stride)) || (rc = w.csr_cnt.ensure(qo)) || (rc = w.obest.ensure(qo * 6)) ||
+            (rc = w.nm.ensure(16)) || (rc = w.overflow.ensure(16)))
+            return rc;
+        if (n) {
+            ORBFE_HIP(hipMemcpy(w.kps.p, kps, (size_t)n * sizeof(orbfe_keypoint), hipMemcpyHostToDevice));
+            ORBFE_HIP(hipMemcpy(w.desc.p, desc, (size_t)n * 32, hipMemcpyHostToDevice));
+            if (taken) ORBFE_HIP(hipMemcpy(w.prev.p, taken, (size_t)n, hipMemcpyHostToDevice));
+        }
+        ORBFE_HIP(hipMemcpy(w.q.p, queries, (size_t)nq * sizeof(orbfe_window_query), hipMemcpyHostToDevice));
+        ORBFE_HIP(hipMemcpy(w.t.p, qdesc, (size_t)nq * 32, hipMemcpyHostToDevice));
+        ORBFE_HIP(hipMemset(w.overflow.p, 0, 4));
+        ORBFE_HIP(hipMemset(w.nm.p, 0, 4));
+        int32_t* o = w.obest.as<int32_t>();
+        ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_by_projection),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_search_by_projection, dim3(1), dim3(SBP_THREADS), lds, 0, w.kps.as<orbfe_keypoint>(),
+                           w.desc.as<uint8_t>(), n, ncap, cols, rows, w.q.as<SbpQuery>(), w.t.as<uint8_t>(), nq,
+                           taken ? w.prev.as<uint8_t>() : nullptr, mode, th_high, nnratio, w.csr_idx.as<uint16_t>(),
+                           w.csr_dist.as<uint8_t>(), w.csr_cnt.as<int32_t>(), stride, o, o + nq, o + 2 * nq, o + 3 * nq,
+                           o + 4 * nq, o + 5 * nq, w.nm.as<int32_t>(), w.overflow.as<int32_t>());
+        ORBFE_HIP(hipGetLastError());
+        ORBFE_HIP(hipDeviceSynchronize());
+        int32_t ovf = 0;
+        ORBFE_HIP(hipMemcpy(&ovf, w.overflow.p, 4, hipMemcpyDeviceToHost));
+        if (!ovf) break;
+        if (attempt) return fail(ORBFE_ERR_CAPACITY, "candidate row overflow (%d)", ovf);
+        w.sbp_stride = (ovf + 63) / 64 * 64; // the longest candidate list decides the row stride; run again
+    }
+    const int32_t* o = w.obest.as<int32_t>();
+    if (best_idx) {
+        ORBFE_HIP(hipMemcpy(best_idx, o, qo, hipMemcpyDeviceToHost));
+        ORBFE_HIP(hipMemcpy(best_dist, o + nq, qo, hipMemcpyDeviceToHost));
+        ORBFE_HIP(hipMemcpy(best_level, o + 2 * nq, qo, hipMemcpyDeviceToHost));
+        ORBFE_HIP(hipMemcpy(second_dist, o + 3 * nq, qo, hipMemcpyDeviceToHost));
+        ORBFE_HIP(hipMemcpy(second_level, o + 4 * nq, qo, hipMemcpyDeviceToHost));
+    }
+    if (mode == 1) {
+        ORBFE_HIP(hipMemcpy(match, o + 5 * nq, qo, hipMemcpyDeviceToHost));
+        ORBFE_HIP(hipMemcpy(nmatches, w.nm.p, 4, hipMemcpyDeviceToHost));
+        if (taken && n) ORBFE_HIP(hipMemcpy(taken, w.prev.p, (size_t)n, hipMemcpyDeviceToHost));
+    }
     return ORBFE_OK;
 }
 

@@ -183,6 +183,26 @@ def knn2_csr(Q, T, off, idx, init=256):
     return bi, bd, sd
 
 
+WINDOW_QUERY_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("r", "<f4"), ("min_level", "<i4"), ("max_level", "<i4")])
+
+
+def search_by_projection(kps, desc, cols, rows, queries, qdesc, taken=None, mode=0, th_high=100, nnratio=0.8):
+    """ORBmatcher::SearchByProjection(Frame, MapPoints) matching loop on flat arrays; see oracle/match_oracle.cpp."""
+    L = lib()
+    kps = np.ascontiguousarray(kps); desc = np.ascontiguousarray(desc, np.uint8)
+    queries = np.ascontiguousarray(queries, WINDOW_QUERY_DTYPE); qdesc = np.ascontiguousarray(qdesc, np.uint8)
+    nq = len(queries)
+    tk = None if taken is None else np.ascontiguousarray(taken, np.uint8).copy()
+    out = [np.zeros(nq, np.int32) for _ in range(6)]
+    L.oracle_search_by_projection.restype = C.c_int
+    L.oracle_search_by_projection.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                              C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float] + [C.c_void_p] * 6
+    nm = L.oracle_search_by_projection(_p(kps), _p(desc), len(kps), cols, rows, _p(queries), _p(qdesc), nq,
+                                       None if tk is None else _p(tk), mode, th_high, nnratio, *[_p(o) for o in out])
+    return dict(best_idx=out[0], best_dist=out[1], best_level=out[2], second_dist=out[3], second_level=out[4],
+                match=out[5], nmatches=nm, taken=tk)
+
+
 def search_for_initialization(k1, d1, k2, d2, cols, rows, prev=None, window=100, nnratio=0.9, check_ori=True):
     L = lib()
     k1 = np.ascontiguousarray(k1); k2 = np.ascontiguousarray(k2)

@@ -80,3 +80,62 @@ def test_search_for_initialization_second_call_uses_prev(orbfe, oracle):
     n2, m12b, prev2 = m.SearchForInitialization(k1, d1, k2, d2, 640, 480, prev, 100)
     on2, om12b, oprev2 = oracle.search_for_initialization(k1, d1, k2, d2, 640, 480, prev, 100, 0.9, True)
     assert n2 == on2 and np.array_equal(m12b, om12b) and np.array_equal(prev2, oprev2)
+
+
+def _projection_case(oracle_mod, seed, nq, jitter):
+    """A frame's keypoints + queries placed near real keypoints (as projected map points are), descriptors = the
+    keypoint's with a few flipped bits, so that best / second-best, octave ties and taken keypoints all occur."""
+    rng = np.random.default_rng(seed)
+    img, _ = synth.scene(480, 640, seed % 7 + 1, n_markers=3, side_range=(40, 90))
+    kps, desc = oracle_mod.OrbOracle(1000, 1.2, 8, 20, 7).extract(img)
+    pick = rng.integers(0, len(kps), nq)
+    q = np.zeros(nq, oracle_mod.WINDOW_QUERY_DTYPE)
+    q["x"] = kps["x"][pick] + rng.normal(0, jitter, nq).astype(np.float32)
+    q["y"] = kps["y"][pick] + rng.normal(0, jitter, nq).astype(np.float32)
+    lvl = kps["octave"][pick]
+    q["r"] = (rng.choice([2.5, 4.0], nq) * 1.2 ** lvl).astype(np.float32) * rng.choice([1.0, 3.0], nq).astype(np.float32)
+    q["min_level"] = lvl - 1
+    q["max_level"] = lvl
+    special = rng.random(nq)
+    q["min_level"][special < 0.05] = 0; q["max_level"][special < 0.05] = -1      # no octave test
+    q["x"][special > 0.97] = -500.0                                                  # window outside the image
+    qd = desc[pick].copy()
+    flips = rng.integers(0, 256, (nq, 6))
+    for i in range(nq):
+        for b in flips[i][: rng.integers(0, 7)]:
+            qd[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    taken = (rng.random(len(kps)) < 0.15).astype(np.uint8)
+    return kps, desc, q, qd, taken
+
+
+@pytest.mark.parametrize("seed,nq,jitter", [(1, 600, 1.0), (2, 1500, 3.0), (3, 64, 0.5)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_search_by_projection(orbfe, oracle, seed, nq, jitter, mode):
+    kps, desc, q, qd, taken = _projection_case(oracle, seed, nq, jitter)
+    want = oracle.search_by_projection(kps, desc, 640, 480, q, qd, taken, mode, 100, 0.8)
+    got = orbfe.search_by_projection(kps, desc, 640, 480, q, qd, taken, mode, 100, 0.8)
+    for f in ("best_idx", "best_dist", "best_level", "second_dist", "second_level"):
+        assert np.array_equal(got[f], want[f]), f
+    if mode == 1:
+        assert got["nmatches"] == want["nmatches"] and got["nmatches"] > nq // 4
+        assert np.array_equal(got["match"], want["match"])
+        assert np.array_equal(got["taken"], want["taken"])
+        m = got["match"][got["match"] >= 0]
+        assert len(np.unique(m)) == len(m)          # a keypoint is matched at most once
+
+
+def test_search_by_projection_edge_cases(orbfe, oracle):
+    kps, desc, q, qd, taken = _projection_case(oracle, 5, 40, 1.0)
+    # no queries, no keypoints, no taken array
+    assert orbfe.search_by_projection(kps, desc, 640, 480, q[:0], qd[:0], None, 1)["nmatches"] == 0
+    got = orbfe.search_by_projection(kps[:0], desc[:0], 640, 480, q, qd, None, 0)
+    assert (got["best_idx"] == -1).all() and (got["best_dist"] == 256).all() and (got["second_level"] == -1).all()
+    want = oracle.search_by_projection(kps, desc, 640, 480, q, qd, None, 1, 100, 0.8)
+    got = orbfe.search_by_projection(kps, desc, 640, 480, q, qd, None, 1, 100, 0.8)
+    assert np.array_equal(got["match"], want["match"])
+    # a huge window: every keypoint is a candidate of every query (row stride grows)
+    q["r"] = 2000.0; q["min_level"] = 0; q["max_level"] = -1
+    want = oracle.search_by_projection(kps, desc, 640, 480, q, qd, None, 0)
+    got = orbfe.search_by_projection(kps, desc, 640, 480, q, qd, None, 0)
+    for f in ("best_idx", "best_dist", "second_dist", "best_level", "second_level"):
+        assert np.array_equal(got[f], want[f]), f
