@@ -126,6 +126,12 @@ int orbfe_hamming(const uint8_t* a, const uint8_t* b);
 int orbfe_knn2(const uint8_t* Q, int nq, const uint8_t* T, int nt, int init, int32_t* best_idx, int32_t* best_dist,
                int32_t* second_dist, int device);
 
+/* The same rule over per-query candidate lists in CSR form (offsets[nq + 1] starting at 0, idx[offsets[nq]] rows of T):
+ * the inner loop of the guided searches whose candidates the caller builds (SearchByBoW node lists, ORBmatcher.cc:159-292;
+ * Fuse; SearchForTriangulation).  Candidates are visited in list order.  Host pointers. */
+int orbfe_knn2_csr(const uint8_t* Q, int nq, const uint8_t* T, int nt, const int32_t* offsets, const int32_t* idx, int init,
+                   int32_t* best_idx, int32_t* best_dist, int32_t* second_dist, int device);
+
 /* Batched device variant: npairs independent (Q,T) problems. Q/T: device pointers to descriptor blocks,
  * block p at Q + p*q_stride bytes with d_nq[p] valid rows (<= max_nq), same for T. Outputs blocks of max_nq. */
 int orbfe_knn2_batch_device(const uint8_t* d_Q, const int32_t* d_nq, size_t q_stride, int max_nq, const uint8_t* d_T,

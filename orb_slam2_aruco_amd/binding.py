@@ -26,7 +26,7 @@ SYMBOLS = [
     "orbfe_extractor_max_keypoints", "orbfe_extract", "orbfe_extract_batch", "orbfe_extract_batch_device",
     "orbfe_extractor_debug_level_size", "orbfe_extractor_debug_level_image",
     "orbfe_extractor_debug_level_keypoints", "orbfe_extractor_debug_kernel_times",
-    "orbfe_debug_control", "orbfe_hamming", "orbfe_knn2", "orbfe_knn2_batch_device", "orbfe_search_for_initialization",
+    "orbfe_debug_control", "orbfe_hamming", "orbfe_knn2", "orbfe_knn2_csr", "orbfe_knn2_batch_device", "orbfe_search_for_initialization",
     "orbfe_search_for_initialization_batch_device", "orbfe_search_by_projection",
     "orbfe_aruco_create", "orbfe_aruco_destroy", "orbfe_aruco_set_dictionary", "orbfe_aruco_max_markers",
     "orbfe_aruco_detect", "orbfe_aruco_detect_batch", "orbfe_aruco_detect_batch_device", "orbfe_aruco_debug_image",
@@ -74,6 +74,7 @@ def load():
         L.orbfe_search_by_projection.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, vp, i32, i32, C.c_float] + [vp] * 7 + [i32]
         L.orbfe_hamming.argtypes = [vp, vp]
         L.orbfe_knn2.argtypes = [vp, i32, vp, i32, i32, vp, vp, vp, i32]
+        L.orbfe_knn2_csr.argtypes = [vp, i32, vp, i32, vp, vp, i32, vp, vp, vp, i32]
         L.orbfe_knn2_batch_device.argtypes = [vp, vp, sz, i32, vp, vp, sz, i32, i32, i32, vp, vp, vp, vp]
         L.orbfe_search_for_initialization.argtypes = [vp, vp, i32, vp, vp, i32, i32, i32, vp, vp, i32, f32, i32, vp,
                                                       i32]
@@ -237,6 +238,18 @@ def hamming(a, b):
     L = load()
     a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
     return L.orbfe_hamming(_p(a), _p(b))
+
+
+def knn2_csr(Q, T, offsets, idx, init=256, device=0):
+    """Best / second-best of every query over its own candidate list (CSR)."""
+    L = load()
+    Q = np.ascontiguousarray(Q, np.uint8).reshape(-1, 32)
+    T = np.ascontiguousarray(T, np.uint8).reshape(-1, 32)
+    offsets = np.ascontiguousarray(offsets, np.int32); idx = np.ascontiguousarray(idx, np.int32)
+    bi = np.full(len(Q), -1, np.int32); bd = np.full(len(Q), init, np.int32); sd = np.full(len(Q), init, np.int32)
+    _check(L, L.orbfe_knn2_csr(_p(Q), len(Q), _p(T), len(T), _p(offsets), _p(idx), init, _p(bi), _p(bd), _p(sd), device),
+           "orbfe_knn2_csr")
+    return bi, bd, sd
 
 
 def debug_control(key, value):

@@ -521,6 +521,40 @@ __global__ __launch_bounds__(SFI_THREADS) void k_search_init(const orbfe_keypoin
     if (lane == 0) nmatches_out[p] = nmatches;
 }
 
+// ---------------------------------------------------------------------------- guided knn2 (CSR) ----------------
+// Best / second-best of every query over ITS candidate list (CSR: offsets[nq + 1], idx[]) -- the inner loop of the guided
+// searches whose candidates the caller builds (SearchByBoW node lists ORBmatcher.cc:159-292, Fuse, SearchForTriangulation).
+// One wave per query; strict '<', the first candidate in list order wins ties.
+__global__ __launch_bounds__(256) void k_knn2_csr(const uint8_t* __restrict__ Q, int nq, const uint8_t* __restrict__ T,
+                                                  const int32_t* __restrict__ offsets, const int32_t* __restrict__ idx,
+                                                  int init, int32_t* __restrict__ best_idx, int32_t* __restrict__ best_dist,
+                                                  int32_t* __restrict__ second_dist)
+{
+    const int lane = threadIdx.x & 63, q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const uint4 a0 = reinterpret_cast<const uint4*>(Q)[2 * q], a1 = reinterpret_cast<const uint4*>(Q)[2 * q + 1];
+    const int b = offsets[q], e = offsets[q + 1];
+    unsigned long long bestk = ~0ull, secondk = ~0ull; // (distance << 32) | position in the list
+    for (int j0 = b; j0 < e; j0 += 64) {
+        const int j = j0 + lane;
+        unsigned long long key = ~0ull;
+        if (j < e) {
+            const int t = idx[j];
+            const int d = hamming256(a0, a1, reinterpret_cast<const uint4*>(T)[2 * t], reinterpret_cast<const uint4*>(T)[2 * t + 1]);
+            if (d < init) key = ((unsigned long long)d << 32) | (unsigned)(j - b);
+        }
+        const unsigned long long m1 = wave_min_u64(key);
+        const unsigned long long k2 = wave_min_u64(key == m1 ? ~0ull : key);
+        if (m1 < bestk) { secondk = min(bestk, k2); bestk = m1; }
+        else secondk = min(secondk, m1);
+    }
+    if (lane == 0) {
+        best_idx[q] = bestk != ~0ull ? idx[b + (int)(bestk & 0xffffffffu)] : -1;
+        best_dist[q] = bestk != ~0ull ? (int)(bestk >> 32) : init;
+        second_dist[q] = secondk != ~0ull ? (int)(secondk >> 32) : init;
+    }
+}
+
 // ---------------------------------------------------------------------------- SearchByProjection ---------------
 // The matching loop of ORBmatcher::SearchByProjection (ORBmatcher.cc:45-129) on flat arrays; see include/orbfe.h.
 // One workgroup (16 waves) per call.
@@ -992,6 +1026,39 @@ int orbfe_search_by_projection(const orbfe_keypoint* kps, const uint8_t* desc, i
         ORBFE_HIP(hipMemcpy(nmatches, w.nm.p, 4, hipMemcpyDeviceToHost));
         if (taken && n) ORBFE_HIP(hipMemcpy(taken, w.prev.p, (size_t)n, hipMemcpyDeviceToHost));
     }
+    return ORBFE_OK;
+}
+
+int orbfe_knn2_csr(const uint8_t* Q, int nq, const uint8_t* T, int nt, const int32_t* offsets, const int32_t* idx, int init,
+                   int32_t* best_idx, int32_t* best_dist, int32_t* second_dist, int device)
+{
+    if (nq < 0 || nt < 0 || (nq && (!Q || !offsets || !best_idx || !best_dist || !second_dist)))
+        return fail(ORBFE_ERR_INVALID, "orbfe_knn2_csr: invalid argument");
+    int rc = use_device(device);
+    if (rc) return rc;
+    if (nq == 0) return ORBFE_OK;
+    const int total = offsets[nq];
+    if (offsets[0] != 0 || total < 0 || (total && (!idx || !T))) return fail(ORBFE_ERR_INVALID, "orbfe_knn2_csr: bad candidate lists");
+    for (int q = 0; q < nq; q++)
+        if (offsets[q + 1] < offsets[q]) return fail(ORBFE_ERR_INVALID, "orbfe_knn2_csr: offsets must be non-decreasing");
+    for (int k = 0; k < total; k++)
+        if (idx[k] < 0 || idx[k] >= nt) return fail(ORBFE_ERR_INVALID, "orbfe_knn2_csr: candidate %d out of range", idx[k]);
+    MatchWorkspace& w = ws();
+    if ((rc = w.q.ensure((size_t)nq * 32)) || (rc = w.t.ensure((size_t)std::max(nt, 1) * 32)) ||
+        (rc = w.csr_cnt.ensure((size_t)(nq + 1) * 4)) || (rc = w.scratch.ensure((size_t)std::max(total, 1) * 4)) ||
+        (rc = w.oidx.ensure((size_t)nq * 4)) || (rc = w.obest.ensure((size_t)nq * 4)) || (rc = w.osecond.ensure((size_t)nq * 4)))
+        return rc;
+    ORBFE_HIP(hipMemcpy(w.q.p, Q, (size_t)nq * 32, hipMemcpyHostToDevice));
+    if (nt) ORBFE_HIP(hipMemcpy(w.t.p, T, (size_t)nt * 32, hipMemcpyHostToDevice));
+    ORBFE_HIP(hipMemcpy(w.csr_cnt.p, offsets, (size_t)(nq + 1) * 4, hipMemcpyHostToDevice));
+    if (total) ORBFE_HIP(hipMemcpy(w.scratch.p, idx, (size_t)total * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_knn2_csr, dim3((nq + 3) / 4), dim3(256), 0, 0, w.q.as<uint8_t>(), nq, w.t.as<uint8_t>(),
+                       w.csr_cnt.as<int32_t>(), w.scratch.as<int32_t>(), init, w.oidx.as<int32_t>(), w.obest.as<int32_t>(),
+                       w.osecond.as<int32_t>());
+    ORBFE_HIP(hipGetLastError());
+    ORBFE_HIP(hipMemcpy(best_idx, w.oidx.p, (size_t)nq * 4, hipMemcpyDeviceToHost));
+    ORBFE_HIP(hipMemcpy(best_dist, w.obest.p, (size_t)nq * 4, hipMemcpyDeviceToHost));
+    ORBFE_HIP(hipMemcpy(second_dist, w.osecond.p, (size_t)nq * 4, hipMemcpyDeviceToHost));
     return ORBFE_OK;
 }
 

@@ -139,3 +139,22 @@ def test_search_by_projection_edge_cases(orbfe, oracle):
     got = orbfe.search_by_projection(kps, desc, 640, 480, q, qd, None, 0)
     for f in ("best_idx", "best_dist", "second_dist", "best_level", "second_level"):
         assert np.array_equal(got[f], want[f]), f
+
+
+@pytest.mark.parametrize("init", [256, 60, 2**31 - 1])
+def test_knn2_csr_guided(orbfe, oracle, init):
+    """Guided best / second-best over candidate lists built by GetFeaturesInArea (what SearchByBoW / Fuse feed it)."""
+    img, _ = synth.scene(480, 640, 3, n_markers=3, side_range=(40, 90))
+    kps, desc = oracle.OrbOracle(1000, 1.2, 8, 20, 7).extract(img)
+    rng = np.random.default_rng(8)
+    nq = 700
+    pick = rng.integers(0, len(kps), nq)
+    off, idx = oracle.features_in_area(kps, 640, 480, kps["x"][pick] + 2, kps["y"][pick] - 1, 25.0, 0, -1)
+    Q = desc[pick] ^ np.uint8(3)
+    off[5] = off[4]                      # an empty list in the middle stays legal
+    got = orbfe.knn2_csr(Q, desc, off, idx, init)
+    want = oracle.knn2_csr(Q, desc, off, idx, init)
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    with pytest.raises(orbfe.OrbfeError):
+        orbfe.knn2_csr(Q, desc, off, np.where(idx == idx[0], len(desc), idx), init)   # candidate out of range
