@@ -28,6 +28,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--splits", type=int, default=1, help="process a batch as this many sub-batches on separate handles and "
+                    "streams (their latency-bound and VALU-bound kernels overlap)")
     ap.add_argument("--frames", type=int, default=300, help="frames per step per GPU (the C2 stream length)")
     ap.add_argument("--rows", type=int, default=480)
     ap.add_argument("--cols", type=int, default=640)
@@ -109,7 +111,10 @@ def main():
     d_imgs = torch.zeros((B, rows, pitch), dtype=torch.uint8, device=dev)
     d_imgs[:, :, :cols] = torch.from_numpy(frames_np).to(dev)
 
-    ex = binding.ORBextractor(args.nfeatures, 1.2, args.nlevels, 20, 7, device=local_rank)
+    S = max(1, min(args.splits, B // 2))
+    bounds = [B * k // S for k in range(S + 1)]          # sub-batch k = frames bounds[k] .. bounds[k+1]
+    exs = [binding.ORBextractor(args.nfeatures, 1.2, args.nlevels, 20, 7, device=local_rank) for _ in range(S)]
+    ex = exs[0]
     cap = ex.capacity
     # two sets of extractor outputs: the matching of batch i (third stream) overlaps with the extraction of batch i+1
     sets = [(torch.zeros((B, cap, 7), dtype=torch.float32, device=dev),     # 28-byte cv::KeyPoint records
@@ -123,7 +128,8 @@ def main():
     d_nm = torch.zeros(B - 1, dtype=torch.int32, device=dev)
     use_aruco = not args.no_aruco
     if use_aruco:
-        det = binding.MarkerDetector(args.dictionary, device=local_rank)
+        dets = [binding.MarkerDetector(args.dictionary, device=local_rank) for _ in range(S)]
+        det = dets[0]
         mcap = det.capacity
         d_mk = torch.zeros((B, mcap, 9), dtype=torch.int32, device=dev)   # 36-byte marker records
         d_nmk = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -136,7 +142,10 @@ def main():
     sp2 = ctypes.c_void_p(stream2.cuda_stream)
     stream3 = torch.cuda.Stream(dev)
     sp3 = ctypes.c_void_p(stream3.cuda_stream)
-    ex_done = [torch.cuda.Event() for _ in range(2)]
+    # with --splits S > 1: sub-batch k of the extractor / detector runs on its own handle and stream
+    orb_streams = [stream] + [torch.cuda.Stream(dev) for _ in range(S - 1)]
+    aru_streams = [stream2] + [torch.cuda.Stream(dev) for _ in range(S - 1)]
+    ex_done = [[torch.cuda.Event() for _ in range(S)] for _ in range(2)]
     match_done = [torch.cuda.Event() for _ in range(2)]
     step_no = [0]
 
@@ -149,23 +158,29 @@ def main():
 
     def step():
         if use_aruco:
-            # the detector stream only depends on the (resident) input frames and on its own previous batch, so it is not
-            # joined with the ORB stream per step: consecutive batches of the two engines pipeline freely.  They are
+            # the detector streams only depend on the (resident) input frames and on their own previous batch, so they are
+            # not joined with the ORB streams per step: consecutive batches of the two engines pipeline freely.  They are
             # joined where their results meet: before the RCCL gather (N > 1) and before the clock stops.
-            det.detect_batch_device(d_imgs.data_ptr(), B, rows * pitch, rows, cols, pitch, d_mk.data_ptr(), mcap,
-                                    d_nmk.data_ptr(), sp2)
+            for k in range(S):
+                f0, nf = bounds[k], bounds[k + 1] - bounds[k]
+                dets[k].detect_batch_device(d_imgs.data_ptr() + f0 * rows * pitch, nf, rows * pitch, rows, cols, pitch,
+                                            d_mk.data_ptr() + f0 * mcap * 36, mcap, d_nmk.data_ptr() + f0 * 4,
+                                            ctypes.c_void_p(aru_streams[k].cuda_stream))
         if args.no_orb:
             return
         i = step_no[0]
         step_no[0] += 1
         k_kps, k_desc, k_n = sets[i % 2]
-        if i >= 2:
-            stream.wait_event(match_done[i % 2])   # the matching of batch i-2 has finished reading this output set
-        ex.extract_batch_device(d_imgs.data_ptr(), B, rows * pitch, rows, cols, pitch, k_kps.data_ptr(),
-                                k_desc.data_ptr(), cap, k_n.data_ptr(), sp)
-        ex_done[i % 2].record(stream)
+        for k in range(S):
+            f0, nf = bounds[k], bounds[k + 1] - bounds[k]
+            if i >= 2:
+                orb_streams[k].wait_event(match_done[i % 2])   # the matching of batch i-2 has finished reading this output set
+            exs[k].extract_batch_device(d_imgs.data_ptr() + f0 * rows * pitch, nf, rows * pitch, rows, cols, pitch,
+                                        k_kps.data_ptr() + f0 * cap * 28, k_desc.data_ptr() + f0 * cap * 32, cap,
+                                        k_n.data_ptr() + f0 * 4, ctypes.c_void_p(orb_streams[k].cuda_stream))
+            ex_done[i % 2][k].record(orb_streams[k])
+            stream3.wait_event(ex_done[i % 2][k])
         # frame t vs t-1: all-pairs knn2 + one SearchForInitialization-style windowed pass
-        stream3.wait_event(ex_done[i % 2])
         ev[0].record(stream3)
         binding._check(L, L.orbfe_knn2_batch_device(k_desc.data_ptr(), k_n.data_ptr(), cap * 32, cap,
                                                     k_desc.data_ptr() + cap * 32, k_n.data_ptr() + 4, cap * 32, cap,
@@ -178,13 +193,17 @@ def main():
         ev[2].record(stream3)
         match_done[i % 2].record(stream3)
         if world > 1:
+            for k in range(1, S):
+                stream.wait_stream(orb_streams[k])
             if use_aruco:
-                stream.wait_stream(stream2)
+                for k in range(S):
+                    stream.wait_stream(aru_streams[k])
             rec = [k_n, k_kps, k_desc] + ([d_nmk, d_mk] if use_aruco else [])
             for t, g in zip(rec, gathered):
                 dist.gather(t, g, dst=0)
             if use_aruco:
-                stream2.wait_stream(stream)   # the next batch must not overwrite records that are still being gathered
+                for k in range(S):
+                    aru_streams[k].wait_stream(stream)   # the next batch must not overwrite records still being gathered
 
     if os.environ.get("ORBFE_ORB_SKIP"):    # diagnosis: what does a kernel cost the concurrent pipeline (results invalid)
         binding.debug_control("orb_skip", int(os.environ["ORBFE_ORB_SKIP"]))
@@ -243,10 +262,12 @@ def main():
                "knn2": 2 * N * 32 + N * 12, "search_init": 2 * N * (32 + 28) + N * 4}
         if use_aruco:
             alg.update(binding.MarkerDetector.algorithmic_bytes(rows, cols))
+        # frames one launch of a stage covers: the matching runs over the whole batch, the engines per sub-batch (--splits)
+        fl = lambda k: B if k in ("knn2", "search_init") else bounds[1] - bounds[0]
         dom = max(stages, key=lambda k: stages[k]) if stages else None
         roof = None
         if dom is not None and stages[dom] > 0:
-            ach = alg.get(dom, 0) * B / (stages[dom] * 1e-6) / 1e9
+            ach = alg.get(dom, 0) * fl(dom) / (stages[dom] * 1e-6) / 1e9
             traffic = None
             tp = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tp):
@@ -256,11 +277,11 @@ def main():
                     traffic = None
             roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": 8000.0, "unit": "GB/s",
                     "frac": ach / 8000.0, "traffic": traffic, "launch_us": stages[dom],
-                    "algorithmic_bytes_per_launch": alg.get(dom, 0) * B,
+                    "algorithmic_bytes_per_launch": alg.get(dom, 0) * fl(dom), "frames_per_launch": fl(dom),
                     "note": "dominant launch of the last timed step (HIP events on its launch stream, the other engine "
                             "running concurrently); k_contours is serial border following, latency- not HBM-bound",
                     # the same figure for every stage, so the HBM-bound image kernels can be read off too
-                    "all_stages_GBps": {k: (alg.get(k, 0) * B / (v * 1e-6) / 1e9 if v > 0 else 0.0)
+                    "all_stages_GBps": {k: (alg.get(k, 0) * fl(k) / (v * 1e-6) / 1e9 if v > 0 else 0.0)
                                         for k, v in stages.items()}}
         cpu = None
         if world == 1 and args.cpu_frames > 0:
@@ -276,6 +297,7 @@ def main():
                                    % (B, cols, rows, args.nfeatures, args.nlevels, args.dictionary,
                                       " + ArUco detect" if use_aruco else " (ArUco leg DISABLED: diagnostic run)"),
                        "frames_per_step_per_gpu": B, "mean_keypoints_per_frame": N,
+                       "sub_batches": S,
                        "parallelism": "stream-per-gpu x%d, RCCL gather to rank 0" % world},
             "roofline": roof, "cpu_baseline": cpu, "stage_us_last_step": stages,
         }
