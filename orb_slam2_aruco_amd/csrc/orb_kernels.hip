@@ -158,63 +158,9 @@ __global__ __launch_bounds__(256) void k_resize_tab(ImgView src, ImgView dst, in
 }
 
 // ------------------------------------------------------------------------------------------------ FAST ----
-// ring offsets of the 9-16 segment test (radius 3), k = 0..15
-__device__ __constant__ signed char c_ring_dx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
-__device__ __constant__ signed char c_ring_dy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
-
-#define FAST_MAXROI 66  // cell (<= 60) + 6
-#define FAST_SP 68      // LDS row pitch of the staged ROI
-#define FAST_MAXLIST 3600
-
-template <int PITCH> __device__ __forceinline__ void ring_diffs(const uint8_t* c, int v, int d[16])
-{
-    d[0] = v - c[3 * PITCH + 0];   d[1] = v - c[3 * PITCH + 1];   d[2] = v - c[2 * PITCH + 2];
-    d[3] = v - c[1 * PITCH + 3];   d[4] = v - c[0 * PITCH + 3];   d[5] = v - c[-1 * PITCH + 3];
-    d[6] = v - c[-2 * PITCH + 2];  d[7] = v - c[-3 * PITCH + 1];  d[8] = v - c[-3 * PITCH + 0];
-    d[9] = v - c[-3 * PITCH - 1];  d[10] = v - c[-2 * PITCH - 2]; d[11] = v - c[-1 * PITCH - 3];
-    d[12] = v - c[0 * PITCH - 3];  d[13] = v - c[1 * PITCH - 3];  d[14] = v - c[2 * PITCH - 2];
-    d[15] = v - c[3 * PITCH - 1];
-}
-
-// true iff 9 contiguous ring pixels are all brighter than v+t or all darker than v-t
-__device__ __forceinline__ bool fast_is_corner(const int d[16], int t)
-{
-    unsigned ma = 0, mb = 0;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        ma |= (unsigned)(d[k] > t) << k;
-        mb |= (unsigned)(d[k] < -t) << k;
-    }
-    ma |= ma << 16;
-    mb |= mb << 16;
-    unsigned ra = ma & (ma >> 1); ra &= ra >> 2; ra &= ra >> 4; ra &= ma >> 8;
-    unsigned rb = mb & (mb >> 1); rb &= rb >> 2; rb &= rb >> 4; rb &= mb >> 8;
-    return ((ra | rb) & 0xffffu) != 0;
-}
-
-// cornerScore<16>: max over the 16 arcs of 9 of min(d) (and of min(-d)), minus 1
-__device__ __forceinline__ int fast_score16(const int d[16])
-{
-    int mn2[16], mx2[16], mn4[16], mx4[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        mn2[k] = min(d[k], d[(k + 1) & 15]);
-        mx2[k] = max(d[k], d[(k + 1) & 15]);
-    }
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        mn4[k] = min(mn2[k], mn2[(k + 2) & 15]);
-        mx4[k] = max(mx2[k], mx2[(k + 2) & 15]);
-    }
-    int best = -255;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        int mn9 = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
-        int mx9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
-        best = max(best, max(mn9, -mx9));
-    }
-    return best - 1;
-}
+// Ring of the 9-16 segment test (radius 3), position k = 0..15:
+//   dx = 0 1 2 3 3 3 2 1 0 -1 -2 -3 -3 -3 -2 -1,  dy = 3 3 2 1 0 -1 -2 -3 -3 -3 -2 -1 0 1 2 3
+// (position k + 8 is the point opposite to k; the kernel below loads the ring as eight (k, k + 8) pairs).
 
 // One WAVE per (active cell, frame), four cells per workgroup, no workgroup barriers: every step below is a
 // wave-level operation (ballot / DPP-scan compaction, in-order LDS).  The wave stages the cell's ROI in LDS and runs the
@@ -402,7 +348,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(ImgView src0, ImgView pyr, c
                 const uint8_t* c = simg + ((yx >> 8) + 3) * SP + ((yx & 255) + 3) + 1;
                 const uint32_t v = c[0];
                 const i16x2 v2 = as_i16x2(v | (v << 16));
-                i16x2 D[8]; // (d[k], d[k+8]), d = v - ring pixel; ring offsets as in ring_diffs_rt()
+                i16x2 D[8]; // (d[k], d[k+8]), d = v - ring pixel
                 D[0] = v2 - as_i16x2((uint32_t)c[3 * SP + 0] | ((uint32_t)c[-3 * SP + 0] << 16));
                 D[1] = v2 - as_i16x2((uint32_t)c[3 * SP + 1] | ((uint32_t)c[-3 * SP - 1] << 16));
                 D[2] = v2 - as_i16x2((uint32_t)c[2 * SP + 2] | ((uint32_t)c[-2 * SP - 2] << 16));
