@@ -95,12 +95,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks (single-GPU box): ORBFE_BENCH_DEVICE pins every rank to one device, ORBFE_BENCH_BACKEND=gloo replaces RCCL
+    if os.environ.get("ORBFE_BENCH_DEVICE"):
+        local_rank = int(os.environ["ORBFE_BENCH_DEVICE"])
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if os.environ.get("ORBFE_BENCH_BACKEND"):
+            dist.init_process_group(os.environ["ORBFE_BENCH_BACKEND"])
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from orb_slam2_aruco_amd import binding
     L = binding.load()
@@ -116,23 +122,28 @@ def main():
     exs = [binding.ORBextractor(args.nfeatures, 1.2, args.nlevels, 20, 7, device=local_rank) for _ in range(S)]
     ex = exs[0]
     cap = ex.capacity
-    # two sets of extractor outputs: the matching of batch i (third stream) overlaps with the extraction of batch i+1
-    sets = [(torch.zeros((B, cap, 7), dtype=torch.float32, device=dev),     # 28-byte cv::KeyPoint records
-             torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev),
-             torch.zeros(B, dtype=torch.int32, device=dev)) for _ in range(2)]
-    d_kps, d_desc, d_n = sets[0]
+    # Two sets of result records: the matching (third stream) and, on N > 1, the gather of batch i (communication stream)
+    # overlap with batch i+1, which writes the other set.  A set is ONE contiguous buffer -- the record SURVEY 8e gathers:
+    # {n_kp, kp[cap] x 28 B, desc[cap] x 32 B, n_mk, markers[mcap] x 36 B} per frame -- so a batch is one collective.
+    use_aruco = not args.no_aruco
+    mcap = binding.MarkerDetector(args.dictionary, device=local_rank).capacity if use_aruco else 0
+    up = lambda v: (v + 255) // 256 * 256
+    off_kps, off_desc = 0, up(B * cap * 28)
+    off_n = off_desc + up(B * cap * 32)
+    off_mk = off_n + up(B * 4)
+    off_nmk = off_mk + up(B * mcap * 36)
+    rec_bytes = off_nmk + up(B * 4)
+    recs = [torch.zeros(rec_bytes, dtype=torch.uint8, device=dev) for _ in range(2)]
+    rec_ptr = [r.data_ptr() for r in recs]
+    d_n = recs[0][off_n:off_n + B * 4].view(torch.int32)
     d_bidx = torch.zeros((B - 1, cap), dtype=torch.int32, device=dev)
     d_bdist = torch.zeros((B - 1, cap), dtype=torch.int32, device=dev)
     d_sdist = torch.zeros((B - 1, cap), dtype=torch.int32, device=dev)
     d_m12 = torch.zeros((B - 1, cap), dtype=torch.int32, device=dev)
     d_nm = torch.zeros(B - 1, dtype=torch.int32, device=dev)
-    use_aruco = not args.no_aruco
     if use_aruco:
         dets = [binding.MarkerDetector(args.dictionary, device=local_rank) for _ in range(S)]
         det = dets[0]
-        mcap = det.capacity
-        d_mk = torch.zeros((B, mcap, 9), dtype=torch.int32, device=dev)   # 36-byte marker records
-        d_nmk = torch.zeros(B, dtype=torch.int32, device=dev)
     # three HIP streams: the ORB extractor, the ArUco detector, the matching.  The first two only read the resident
     # frames; the matching of batch i reads extractor output set i % 2 while batch i+1 is extracted into the other set.
     # So the latency-bound kernels (contours, quadtree, SearchForInitialization) overlap with the VALU-bound ones.
@@ -147,63 +158,68 @@ def main():
     aru_streams = [stream2] + [torch.cuda.Stream(dev) for _ in range(S - 1)]
     ex_done = [[torch.cuda.Event() for _ in range(S)] for _ in range(2)]
     match_done = [torch.cuda.Event() for _ in range(2)]
+    comm_stream = torch.cuda.Stream(dev)
+    det_done = [[torch.cuda.Event() for _ in range(S)] for _ in range(2)]
+    gather_done = [torch.cuda.Event() for _ in range(2)]
     step_no = [0]
 
     gathered = None
     if world > 1:
-        rec0 = [d_n, d_kps, d_desc] + ([d_nmk, d_mk] if use_aruco else [])
-        gathered = [[torch.empty_like(t) for _ in range(world)] if rank == 0 else None for t in rec0]
+        gathered = [torch.empty_like(recs[0]) for _ in range(world)] if rank == 0 else None
 
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]  # around the matching launches (their stream)
 
     def step():
+        i = step_no[0]
+        step_no[0] += 1
+        base = rec_ptr[i % 2]
         if use_aruco:
             # the detector streams only depend on the (resident) input frames and on their own previous batch, so they are
             # not joined with the ORB streams per step: consecutive batches of the two engines pipeline freely.  They are
             # joined where their results meet: before the RCCL gather (N > 1) and before the clock stops.
             for k in range(S):
                 f0, nf = bounds[k], bounds[k + 1] - bounds[k]
+                if world > 1 and i >= 2:
+                    aru_streams[k].wait_event(gather_done[i % 2])   # batch i-2 has left this record set
                 dets[k].detect_batch_device(d_imgs.data_ptr() + f0 * rows * pitch, nf, rows * pitch, rows, cols, pitch,
-                                            d_mk.data_ptr() + f0 * mcap * 36, mcap, d_nmk.data_ptr() + f0 * 4,
+                                            base + off_mk + f0 * mcap * 36, mcap, base + off_nmk + f0 * 4,
                                             ctypes.c_void_p(aru_streams[k].cuda_stream))
-        if args.no_orb:
-            return
-        i = step_no[0]
-        step_no[0] += 1
-        k_kps, k_desc, k_n = sets[i % 2]
-        for k in range(S):
-            f0, nf = bounds[k], bounds[k + 1] - bounds[k]
-            if i >= 2:
-                orb_streams[k].wait_event(match_done[i % 2])   # the matching of batch i-2 has finished reading this output set
-            exs[k].extract_batch_device(d_imgs.data_ptr() + f0 * rows * pitch, nf, rows * pitch, rows, cols, pitch,
-                                        k_kps.data_ptr() + f0 * cap * 28, k_desc.data_ptr() + f0 * cap * 32, cap,
-                                        k_n.data_ptr() + f0 * 4, ctypes.c_void_p(orb_streams[k].cuda_stream))
-            ex_done[i % 2][k].record(orb_streams[k])
-            stream3.wait_event(ex_done[i % 2][k])
-        # frame t vs t-1: all-pairs knn2 + one SearchForInitialization-style windowed pass
-        ev[0].record(stream3)
-        binding._check(L, L.orbfe_knn2_batch_device(k_desc.data_ptr(), k_n.data_ptr(), cap * 32, cap,
-                                                    k_desc.data_ptr() + cap * 32, k_n.data_ptr() + 4, cap * 32, cap,
-                                                    B - 1, 256, d_bidx.data_ptr(), d_bdist.data_ptr(),
-                                                    d_sdist.data_ptr(), sp3), "knn2")
-        ev[1].record(stream3)
-        binding._check(L, L.orbfe_search_for_initialization_batch_device(
-            k_kps.data_ptr(), k_desc.data_ptr(), k_n.data_ptr(), cap, B - 1, cols, rows, 100, 0.9, 1,
-            d_m12.data_ptr(), d_nm.data_ptr(), sp3), "sfi")
-        ev[2].record(stream3)
-        match_done[i % 2].record(stream3)
+                det_done[i % 2][k].record(aru_streams[k])
+        if not args.no_orb:
+            for k in range(S):
+                f0, nf = bounds[k], bounds[k + 1] - bounds[k]
+                if i >= 2:
+                    orb_streams[k].wait_event(match_done[i % 2])    # the matching of batch i-2 has read this record set
+                    if world > 1:
+                        orb_streams[k].wait_event(gather_done[i % 2])
+                exs[k].extract_batch_device(d_imgs.data_ptr() + f0 * rows * pitch, nf, rows * pitch, rows, cols, pitch,
+                                            base + off_kps + f0 * cap * 28, base + off_desc + f0 * cap * 32, cap,
+                                            base + off_n + f0 * 4, ctypes.c_void_p(orb_streams[k].cuda_stream))
+                ex_done[i % 2][k].record(orb_streams[k])
+                stream3.wait_event(ex_done[i % 2][k])
+            # frame t vs t-1: all-pairs knn2 + one SearchForInitialization-style windowed pass
+            ev[0].record(stream3)
+            binding._check(L, L.orbfe_knn2_batch_device(base + off_desc, base + off_n, cap * 32, cap,
+                                                        base + off_desc + cap * 32, base + off_n + 4, cap * 32, cap,
+                                                        B - 1, 256, d_bidx.data_ptr(), d_bdist.data_ptr(),
+                                                        d_sdist.data_ptr(), sp3), "knn2")
+            ev[1].record(stream3)
+            binding._check(L, L.orbfe_search_for_initialization_batch_device(
+                base + off_kps, base + off_desc, base + off_n, cap, B - 1, cols, rows, 100, 0.9, 1,
+                d_m12.data_ptr(), d_nm.data_ptr(), sp3), "sfi")
+            ev[2].record(stream3)
+            match_done[i % 2].record(stream3)
         if world > 1:
-            for k in range(1, S):
-                stream.wait_stream(orb_streams[k])
-            if use_aruco:
+            # the batch's one collective, on its own stream: it waits for the engines of THIS batch and runs
+            # while the next batch is computed into the other record set
+            with torch.cuda.stream(comm_stream):
                 for k in range(S):
-                    stream.wait_stream(aru_streams[k])
-            rec = [k_n, k_kps, k_desc] + ([d_nmk, d_mk] if use_aruco else [])
-            for t, g in zip(rec, gathered):
-                dist.gather(t, g, dst=0)
-            if use_aruco:
-                for k in range(S):
-                    aru_streams[k].wait_stream(stream)   # the next batch must not overwrite records still being gathered
+                    if not args.no_orb:
+                        comm_stream.wait_event(ex_done[i % 2][k])
+                    if use_aruco:
+                        comm_stream.wait_event(det_done[i % 2][k])
+                dist.gather(recs[i % 2], gathered, dst=0)
+                gather_done[i % 2].record(comm_stream)
 
     if os.environ.get("ORBFE_ORB_SKIP"):    # diagnosis: what does a kernel cost the concurrent pipeline (results invalid)
         binding.debug_control("orb_skip", int(os.environ["ORBFE_ORB_SKIP"]))
@@ -211,8 +227,8 @@ def main():
         binding.debug_control("aruco_skip", int(os.environ["ORBFE_ARUCO_SKIP"]))
     ex.enable_kernel_timing(False)
     if args.no_orb:  # diagnostics still want the level geometry
-        ex.extract_batch_device(d_imgs.data_ptr(), B, rows * pitch, rows, cols, pitch, d_kps.data_ptr(),
-                                d_desc.data_ptr(), cap, d_n.data_ptr(), sp)
+        ex.extract_batch_device(d_imgs.data_ptr(), B, rows * pitch, rows, cols, pitch, rec_ptr[0] + off_kps,
+                                rec_ptr[0] + off_desc, cap, rec_ptr[0] + off_n, sp)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
