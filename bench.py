@@ -156,6 +156,8 @@ def main():
     # with --splits S > 1: sub-batch k of the extractor / detector runs on its own handle and stream
     orb_streams = [stream] + [torch.cuda.Stream(dev) for _ in range(S - 1)]
     aru_streams = [stream2] + [torch.cuda.Stream(dev) for _ in range(S - 1)]
+    if S == 1:
+        ex.set_aux_stream(sp3)   # the blur shares the matching stream's hardware queue instead of the detector's
     ex_done = [[torch.cuda.Event() for _ in range(S)] for _ in range(2)]
     match_done = [torch.cuda.Event() for _ in range(2)]
     comm_stream = torch.cuda.Stream(dev)

@@ -111,6 +111,11 @@ int orbfe_extractor_debug_level_image(orbfe_extractor* h, int frame, int level, 
 int orbfe_extractor_debug_level_keypoints(orbfe_extractor* h, int frame, int level, int stage, orbfe_keypoint* out,
                                           int capacity, int32_t* n);
 /* per-kernel timing of the last batch call on this handle, microseconds, in launch order; returns number written */
+/* The extractor forks one launch (the blur, which only needs the pyramid) onto a second stream so that it overlaps with
+ * FAST and the quadtree.  By default that is a stream the handle owns; an application that already has a lightly
+ * loaded stream (bench.py: the matching stream) can lend it instead -- ROCm maps streams onto a few hardware queues, and
+ * two busy streams on one queue serialise.  NULL restores the internal stream.  Ordering is by events either way. */
+int orbfe_extractor_set_aux_stream(orbfe_extractor* h, void* stream);
 int orbfe_extractor_debug_kernel_times(orbfe_extractor* h, float* out_us, int capacity);
 
 /* ------------------------------------------------------------------ descriptor matching -- */
@@ -196,6 +201,8 @@ int orbfe_aruco_detect_batch_device(orbfe_aruco* h, const uint8_t* d_imgs, int n
                                     void* stream);
 /* stage read-back for parity tests: 0 = thresholded image (rows x cols bytes, 0/255) of `frame` */
 int orbfe_aruco_debug_image(orbfe_aruco* h, int frame, int stage, uint8_t* out);
+/* As orbfe_extractor_set_aux_stream, for the detector's forked launches (the /2 pyramid). */
+int orbfe_aruco_set_aux_stream(orbfe_aruco* h, void* stream);
 int orbfe_aruco_debug_kernel_times(orbfe_aruco* h, float* out_us, int capacity);
 
 #ifdef __cplusplus

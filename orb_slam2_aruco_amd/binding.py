@@ -25,12 +25,12 @@ SYMBOLS = [
     "orbfe_extractor_get_inverse_scale_sigma_squares", "orbfe_extractor_get_features_per_level",
     "orbfe_extractor_max_keypoints", "orbfe_extract", "orbfe_extract_batch", "orbfe_extract_batch_device",
     "orbfe_extractor_debug_level_size", "orbfe_extractor_debug_level_image",
-    "orbfe_extractor_debug_level_keypoints", "orbfe_extractor_debug_kernel_times",
+    "orbfe_extractor_debug_level_keypoints", "orbfe_extractor_debug_kernel_times", "orbfe_extractor_set_aux_stream",
     "orbfe_debug_control", "orbfe_hamming", "orbfe_knn2", "orbfe_knn2_csr", "orbfe_knn2_batch_device", "orbfe_search_for_initialization",
     "orbfe_search_for_initialization_batch_device", "orbfe_search_by_projection",
     "orbfe_aruco_create", "orbfe_aruco_destroy", "orbfe_aruco_set_dictionary", "orbfe_aruco_max_markers",
     "orbfe_aruco_detect", "orbfe_aruco_detect_batch", "orbfe_aruco_detect_batch_device", "orbfe_aruco_debug_image",
-    "orbfe_aruco_debug_kernel_times",
+    "orbfe_aruco_debug_kernel_times", "orbfe_aruco_set_aux_stream",
 ]
 
 _lib = None
@@ -69,6 +69,7 @@ def load():
     L.orbfe_extractor_debug_level_image.argtypes = [vp, i32, i32, i32, vp]
     L.orbfe_extractor_debug_level_keypoints.argtypes = [vp, i32, i32, i32, vp, i32, vp]
     L.orbfe_extractor_debug_kernel_times.argtypes = [vp, vp, i32]
+    L.orbfe_extractor_set_aux_stream.argtypes = [vp, vp]
     if hasattr(L, "orbfe_knn2"):
         L.orbfe_debug_control.argtypes = [C.c_char_p, i32]
         L.orbfe_search_by_projection.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, vp, i32, i32, C.c_float] + [vp] * 7 + [i32]
@@ -91,6 +92,7 @@ def load():
         L.orbfe_aruco_detect_batch_device.argtypes = [vp, vp, i32, sz, i32, i32, sz, vp, i32, vp, vp]
         L.orbfe_aruco_debug_image.argtypes = [vp, i32, i32, vp]
         L.orbfe_aruco_debug_kernel_times.argtypes = [vp, vp, i32]
+        L.orbfe_aruco_set_aux_stream.argtypes = [vp, vp]
     _lib = L
     return L
 
@@ -206,6 +208,10 @@ class ORBextractor:
             _check(self.L, self.L.orbfe_extractor_debug_level_size(self.h, l, C.byref(w), C.byref(h)), "level_size")
             out.append((w.value, h.value))
         return out
+
+    def set_aux_stream(self, stream_ptr):
+        """Run the extractor's forked launch (blur) on the caller's stream (None: the handle's own)."""
+        _check(self.L, self.L.orbfe_extractor_set_aux_stream(self.h, stream_ptr), "set_aux_stream")
 
     def enable_kernel_timing(self, on=True):
         self.L.orbfe_extractor_debug_kernel_times(self.h, None, int(on))
@@ -395,6 +401,10 @@ class MarkerDetector:
         out = np.zeros(self.capacity, RECT_DTYPE)
         _check(self.L, self.L.orbfe_aruco_debug_image(self.h, frame, 101, _p(out)), "debug_image")
         return out[:self.counts(frame)["nrect"]]
+
+    def set_aux_stream(self, stream_ptr):
+        """Run the detector's forked launches (pyramid) on the caller's stream (None: the handle's own)."""
+        _check(self.L, self.L.orbfe_aruco_set_aux_stream(self.h, stream_ptr), "set_aux_stream")
 
     def enable_kernel_timing(self, on=True):
         self.L.orbfe_aruco_debug_kernel_times(self.h, None, int(on))

@@ -19,6 +19,7 @@ struct orbfe_aruco {
     std::string dict_name;
     int nbits = 0, nb = 0, S = 0, ncodes = 0;
     hipStream_t own_stream = nullptr, aux_stream = nullptr;
+    hipStream_t user_aux = nullptr; // orbfe_aruco_set_aux_stream: run the pyramid there instead of on aux_stream
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int rows = 0, cols = 0, batch_cap = 0;
     int win = 0, wpr = 0, npyr = 0;
@@ -198,6 +199,7 @@ struct orbfe_aruco {
         timer.begin();
         timer.mark(s, "start");
         // the /2 pyramid is only needed by k_decode: it runs on a second stream next to threshold + contours
+        hipStream_t aux_stream = user_aux ? user_aux : this->aux_stream;
         ORBFE_HIP(hipEventRecord(ev_fork, s));
         ORBFE_HIP(hipStreamWaitEvent(aux_stream, ev_fork, 0));
         timer.mark(aux_stream, "pyramid starts", true);
@@ -405,6 +407,13 @@ int orbfe_aruco_debug_image(orbfe_aruco* h, int frame, int stage, uint8_t* out)
         return ORBFE_OK;
     }
     return fail(ORBFE_ERR_INVALID, "debug_image: unknown stage %d", stage);
+}
+
+int orbfe_aruco_set_aux_stream(orbfe_aruco* h, void* stream)
+{
+    if (!h) return fail(ORBFE_ERR_INVALID, "null handle");
+    h->user_aux = (hipStream_t)stream;
+    return ORBFE_OK;
 }
 
 int orbfe_aruco_debug_kernel_times(orbfe_aruco* h, float* out_us, int capacity)

@@ -42,6 +42,7 @@ struct orbfe_extractor {
     // --- device state
     int device = 0;
     hipStream_t own_stream = nullptr, aux_stream = nullptr;
+    hipStream_t user_aux = nullptr; // orbfe_extractor_set_aux_stream: run the blur there instead of on aux_stream
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int rows = 0, cols = 0; // geometry currently built
     int batch_cap = 0;
@@ -310,6 +311,7 @@ struct orbfe_extractor {
         }
         timer.mark(s, "resize");
         // The blur only needs the pyramid: it runs on a second stream next to FAST and the (latency-bound) quadtree
+        hipStream_t aux_stream = user_aux ? user_aux : this->aux_stream;
         ORBFE_HIP(hipEventRecord(ev_fork, s));
         ORBFE_HIP(hipStreamWaitEvent(aux_stream, ev_fork, 0));
         timer.mark(aux_stream, "blur7 starts", true);
@@ -572,6 +574,13 @@ int orbfe_extractor_debug_level_keypoints(orbfe_extractor* h, int frame, int lev
         out[i].octave = stage == 0 ? 0 : level;
         out[i].class_id = -1;
     }
+    return ORBFE_OK;
+}
+
+int orbfe_extractor_set_aux_stream(orbfe_extractor* h, void* stream)
+{
+    if (!h) return fail(ORBFE_ERR_INVALID, "null handle");
+    h->user_aux = (hipStream_t)stream;
     return ORBFE_OK;
 }
 
