@@ -52,6 +52,23 @@ def main():
     n, m12, prev = O.search_for_initialization(k1, d1, k2, d2, 640, 480, None, 100, 0.9, True)
     np.savez_compressed(os.path.join(OUT, "match_stream1000.npz"), k1=k1, d1=d1, k2=k2, d2=d2, best_idx=bi,
                         best_dist=bd, second_dist=sd, nmatches=np.array([n]), matches12=m12, prev=prev)
+    # SearchByProjection matching loop: map points = the keypoints of frame 1 "projected" into frame 2 at their matched
+    # position (or their own position), predicted octave = their octave; descriptors = frame 1's
+    rng = np.random.default_rng(77)
+    sel = rng.permutation(len(k1))[:600]
+    q = np.zeros(len(sel), O.WINDOW_QUERY_DTYPE)
+    q["x"] = np.where(m12[sel] >= 0, k2["x"][np.maximum(m12[sel], 0)], k1["x"][sel]) + rng.normal(0, 1.0, len(sel)).astype(np.float32)
+    q["y"] = np.where(m12[sel] >= 0, k2["y"][np.maximum(m12[sel], 0)], k1["y"][sel]) + rng.normal(0, 1.0, len(sel)).astype(np.float32)
+    q["r"] = (4.0 * 1.2 ** k1["octave"][sel]).astype(np.float32)
+    q["min_level"] = k1["octave"][sel] - 1
+    q["max_level"] = k1["octave"][sel]
+    taken = (rng.random(len(k2)) < 0.1).astype(np.uint8)
+    r0 = O.search_by_projection(k2, d2, 640, 480, q, d1[sel], taken, 0, 100, 0.8)
+    r1 = O.search_by_projection(k2, d2, 640, 480, q, d1[sel], taken, 1, 100, 0.8)
+    np.savez_compressed(os.path.join(OUT, "projection_stream1000.npz"), sel=sel.astype(np.int32), queries=q, taken=taken,
+                        best_idx=r0["best_idx"], best_dist=r0["best_dist"], best_level=r0["best_level"],
+                        second_dist=r0["second_dist"], second_level=r0["second_level"], match=r1["match"],
+                        nmatches=np.array([r1["nmatches"]]), taken_after=r1["taken"])
     print("wrote", sorted(os.listdir(OUT)))
 
 

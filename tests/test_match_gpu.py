@@ -158,3 +158,18 @@ def test_knn2_csr_guided(orbfe, oracle, init):
         assert np.array_equal(g, w)
     with pytest.raises(orbfe.OrbfeError):
         orbfe.knn2_csr(Q, desc, off, np.where(idx == idx[0], len(desc), idx), init)   # candidate out of range
+
+
+def test_search_by_projection_golden(orbfe):
+    """Against the committed vectors (no oracle needed): tests/golden/projection_stream1000.npz."""
+    import os
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    g = np.load(os.path.join(gold, "match_stream1000.npz"))
+    p = np.load(os.path.join(gold, "projection_stream1000.npz"))
+    q = p["queries"].view(orbfe.WINDOW_QUERY_DTYPE).reshape(-1)
+    r0 = orbfe.search_by_projection(g["k2"], g["d2"], 640, 480, q, g["d1"][p["sel"]], p["taken"], 0, 100, 0.8)
+    for f in ("best_idx", "best_dist", "best_level", "second_dist", "second_level"):
+        assert np.array_equal(r0[f], p[f]), f
+    r1 = orbfe.search_by_projection(g["k2"], g["d2"], 640, 480, q, g["d1"][p["sel"]], p["taken"], 1, 100, 0.8)
+    assert r1["nmatches"] == int(p["nmatches"][0])
+    assert np.array_equal(r1["match"], p["match"]) and np.array_equal(r1["taken"], p["taken_after"])

@@ -276,6 +276,23 @@ def test_golden_match(oracle):
     assert n > 50
 
 
+def _projection_golden(mod):
+    g = np.load(os.path.join(GOLD, "match_stream1000.npz"))
+    p = np.load(os.path.join(GOLD, "projection_stream1000.npz"))
+    q = p["queries"].view(mod.WINDOW_QUERY_DTYPE).reshape(-1)
+    return g, p, q
+
+
+def test_golden_search_by_projection(oracle):
+    g, p, q = _projection_golden(oracle)
+    r0 = oracle.search_by_projection(g["k2"], g["d2"], 640, 480, q, g["d1"][p["sel"]], p["taken"], 0, 100, 0.8)
+    for f in ("best_idx", "best_dist", "best_level", "second_dist", "second_level"):
+        assert np.array_equal(r0[f], p[f]), f
+    r1 = oracle.search_by_projection(g["k2"], g["d2"], 640, 480, q, g["d1"][p["sel"]], p["taken"], 1, 100, 0.8)
+    assert r1["nmatches"] == int(p["nmatches"][0]) > 20
+    assert np.array_equal(r1["match"], p["match"]) and np.array_equal(r1["taken"], p["taken_after"])
+
+
 def test_libm_trig_sensitivity_is_small(oracle):
     """The reference calls libm cos/sin (ORBextractor.cc:112-113); the oracle uses correctly rounded values.
     Quantify what that choice can change: a handful of descriptor BITS per frame at most."""
