@@ -210,7 +210,7 @@ def main():
                                                         d_sdist.data_ptr(), sp3), "knn2")
             ev[1].record(stream3)
             binding._check(L, L.orbfe_search_for_initialization_batch_device(
-                base + off_kps, base + off_desc, base + off_n, cap, B - 1, cols, rows, 100, 0.9, 1,
+                base + off_kps, base + off_desc, base + off_n, cap, B - 1, cols, rows, None, 100, 0.9, 1,
                 d_m12.data_ptr(), d_nm.data_ptr(), sp3), "sfi")
             ev[2].record(stream3)
             match_done[i % 2].record(stream3)

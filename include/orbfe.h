@@ -143,12 +143,14 @@ int orbfe_knn2_batch_device(const uint8_t* d_Q, const int32_t* d_nq, size_t q_st
                             const int32_t* d_nt, size_t t_stride, int max_nt, int npairs, int init,
                             int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second_dist, void* stream);
 
-/* ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) with an undistorted camera
- * (grid bounds 0..cols, 0..rows; Frame.cc:440-446).  prev_matched: n1 x 2 floats, updated in place like
+/* ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize).  The keypoints are the
+ * UNDISTORTED ones (mvKeysUn).  bounds = {mnMinX, mnMinY, mnMaxX, mnMaxY} of the undistorted image
+ * (Frame::ComputeImageBounds, Frame.cc:418-451): the 64 x 48 Frame grid spans them (Frame.cc:112-113); NULL = a camera
+ * without distortion, 0, 0, cols, rows (Frame.cc:440-446).  prev_matched: n1 x 2 floats, updated in place like
  * vbPrevMatched; matches12: n1 ints (-1 = none).  Returns ORBFE_OK and the match count in *nmatches. */
 int orbfe_search_for_initialization(const orbfe_keypoint* kps1, const uint8_t* desc1, int n1,
                                     const orbfe_keypoint* kps2, const uint8_t* desc2, int n2, int cols, int rows,
-                                    float* prev_matched, int32_t* matches12, int window_size, float nnratio,
+                                    const float* bounds, float* prev_matched, int32_t* matches12, int window_size, float nnratio,
                                     int check_orientation, int32_t* nmatches, int device);
 
 /* The matching loop of ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) (ORBmatcher.cc:45-129) on
@@ -163,12 +165,12 @@ int orbfe_search_for_initialization(const orbfe_keypoint* kps1, const uint8_t* d
  *   mode 1: the whole loop: accept when best <= th_high (TH_HIGH = 100) and not (same octave and best > nnratio*second)
  *           (:121-128); an accepted keypoint is taken for the queries after it.  match[q] = keypoint index or -1,
  *           *nmatches = accepted count, taken[] updated in place.  The raw outputs may be NULL.
- * Host pointers.  undistorted camera (grid bounds 0..cols, 0..rows), mono (no right-image test). */
+ * Host pointers.  bounds as for orbfe_search_for_initialization; mono (no right-image test). */
 typedef struct orbfe_window_query {
     float x, y, r;
     int32_t min_level, max_level;
 } orbfe_window_query;
-int orbfe_search_by_projection(const orbfe_keypoint* kps, const uint8_t* desc, int n, int cols, int rows,
+int orbfe_search_by_projection(const orbfe_keypoint* kps, const uint8_t* desc, int n, int cols, int rows, const float* bounds,
                                const orbfe_window_query* queries, const uint8_t* qdesc, int nq, uint8_t* taken, int mode,
                                int th_high, float nnratio, int32_t* best_idx, int32_t* best_dist, int32_t* best_level,
                                int32_t* second_dist, int32_t* second_level, int32_t* match, int32_t* nmatches, int device);
@@ -177,7 +179,7 @@ int orbfe_search_by_projection(const orbfe_keypoint* kps, const uint8_t* desc, i
  * records per frame; pair p matches frame p (as F1) against frame p+1 (as F2). prev_matched == NULL means
  * "start from F1's own keypoint positions" (what Tracking does on the first call, src/Tracking.cc:520-523). */
 int orbfe_search_for_initialization_batch_device(const orbfe_keypoint* d_kps, const uint8_t* d_desc,
-                                                 const int32_t* d_n, int capacity, int npairs, int cols, int rows,
+                                                 const int32_t* d_n, int capacity, int npairs, int cols, int rows, const float* bounds,
                                                  int window_size, float nnratio, int check_orientation,
                                                  int32_t* d_matches12, int32_t* d_nmatches, void* stream);
 

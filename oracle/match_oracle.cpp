@@ -61,9 +61,12 @@ struct FrameGrid {
     int N;
     std::vector<int> cell[FRAME_GRID_COLS][FRAME_GRID_ROWS];
 
-    FrameGrid(const KeyPoint* k, int n, int cols, int rows) : kps(k), N(n)
+    /* bounds = {mnMinX, mnMinY, mnMaxX, mnMaxY} of the undistorted image (Frame::ComputeImageBounds, Frame.cc:418-451);
+     * NULL = no distortion: 0, 0, cols, rows (Frame.cc:440-446) */
+    FrameGrid(const KeyPoint* k, int n, int cols, int rows, const float* bounds = nullptr) : kps(k), N(n)
     {
         mnMinX = 0.f; mnMaxX = (float)cols; mnMinY = 0.f; mnMaxY = (float)rows;
+        if (bounds) { mnMinX = bounds[0]; mnMinY = bounds[1]; mnMaxX = bounds[2]; mnMaxY = bounds[3]; }
         invW = static_cast<float>(FRAME_GRID_COLS) / static_cast<float>(mnMaxX - mnMinX); /* Frame.cc:112 */
         invH = static_cast<float>(FRAME_GRID_ROWS) / static_cast<float>(mnMaxY - mnMinY);
         for (int i = 0; i < N; i++) { /* Frame.cc:183-198, :335-345 */
@@ -129,9 +132,10 @@ void oracle_knn2(const uint8_t* Q, int nq, const uint8_t* T, int nt, int init, i
 /* Candidate lists of Frame::GetFeaturesInArea for a batch of queries, CSR output.
  * offsets has nq+1 entries; returns total count (idx may be NULL to size it). */
 int oracle_features_in_area(const void* kps2, int n2, int cols, int rows, const float* qx, const float* qy, int nq,
-                            float r, int minLevel, int maxLevel, int32_t* offsets, int32_t* idx, int capacity)
+                            float r, int minLevel, int maxLevel, int32_t* offsets, int32_t* idx, int capacity,
+                            const float* bounds)
 {
-    FrameGrid g((const KeyPoint*)kps2, n2, cols, rows);
+    FrameGrid g((const KeyPoint*)kps2, n2, cols, rows, bounds);
     int total = 0;
     for (int q = 0; q < nq; q++) {
         offsets[q] = total;
@@ -176,11 +180,11 @@ struct WindowQuery { float x, y, r; int32_t min_level, max_level; };
 int oracle_search_by_projection(const void* kps_, const uint8_t* desc, int n, int cols, int rows, const void* queries_,
                                 const uint8_t* qdesc, int nq, uint8_t* taken, int mode, int th_high, float nnratio,
                                 int32_t* best_idx, int32_t* best_dist, int32_t* best_level, int32_t* second_dist,
-                                int32_t* second_level, int32_t* match)
+                                int32_t* second_level, int32_t* match, const float* bounds)
 {
     const KeyPoint* k = (const KeyPoint*)kps_;
     const WindowQuery* Q = (const WindowQuery*)queries_;
-    FrameGrid F(k, n, cols, rows);
+    FrameGrid F(k, n, cols, rows, bounds);
     int nmatches = 0;
     for (int q = 0; q < nq; q++) {
         const std::vector<int> vIndices = F.GetFeaturesInArea(Q[q].x, Q[q].y, Q[q].r, Q[q].min_level, Q[q].max_level);
@@ -215,11 +219,12 @@ int oracle_search_by_projection(const void* kps_, const uint8_t* desc, int n, in
  * prevMatched (n1 x 2 floats) is updated in place like vbPrevMatched; matches12 gets n1 ints. */
 int oracle_search_for_initialization(const void* kps1_, const uint8_t* desc1, int n1, const void* kps2_,
                                      const uint8_t* desc2, int n2, int cols, int rows, float* prevMatched,
-                                     int32_t* matches12, int windowSize, float nnratio, int checkOrientation)
+                                     int32_t* matches12, int windowSize, float nnratio, int checkOrientation,
+                                     const float* bounds)
 {
     const KeyPoint* k1 = (const KeyPoint*)kps1_;
     const KeyPoint* k2 = (const KeyPoint*)kps2_;
-    FrameGrid F2(k2, n2, cols, rows);
+    FrameGrid F2(k2, n2, cols, rows, bounds);
     int nmatches = 0;
     for (int i = 0; i < n1; i++) matches12[i] = -1;
     std::vector<int> rotHist[HISTO_LENGTH];

@@ -72,14 +72,14 @@ def load():
     L.orbfe_extractor_set_aux_stream.argtypes = [vp, vp]
     if hasattr(L, "orbfe_knn2"):
         L.orbfe_debug_control.argtypes = [C.c_char_p, i32]
-        L.orbfe_search_by_projection.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, vp, i32, i32, C.c_float] + [vp] * 7 + [i32]
+        L.orbfe_search_by_projection.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, i32, vp, i32, i32, C.c_float] + [vp] * 7 + [i32]
         L.orbfe_hamming.argtypes = [vp, vp]
         L.orbfe_knn2.argtypes = [vp, i32, vp, i32, i32, vp, vp, vp, i32]
         L.orbfe_knn2_csr.argtypes = [vp, i32, vp, i32, vp, vp, i32, vp, vp, vp, i32]
         L.orbfe_knn2_batch_device.argtypes = [vp, vp, sz, i32, vp, vp, sz, i32, i32, i32, vp, vp, vp, vp]
-        L.orbfe_search_for_initialization.argtypes = [vp, vp, i32, vp, vp, i32, i32, i32, vp, vp, i32, f32, i32, vp,
+        L.orbfe_search_for_initialization.argtypes = [vp, vp, i32, vp, vp, i32, i32, i32, vp, vp, vp, i32, f32, i32, vp,
                                                       i32]
-        L.orbfe_search_for_initialization_batch_device.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp,
+        L.orbfe_search_for_initialization_batch_device.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, i32, f32, i32, vp,
                                                                    vp, vp]
     if hasattr(L, "orbfe_aruco_create"):
         L.orbfe_aruco_create.restype = vp
@@ -276,7 +276,8 @@ def knn2(Q, T, init=256, device=0):
 WINDOW_QUERY_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("r", "<f4"), ("min_level", "<i4"), ("max_level", "<i4")])
 
 
-def search_by_projection(kps, desc, cols, rows, queries, qdesc, taken=None, mode=0, th_high=100, nnratio=0.8, device=0):
+def search_by_projection(kps, desc, cols, rows, queries, qdesc, taken=None, mode=0, th_high=100, nnratio=0.8, device=0,
+                         bounds=None):
     """The matching loop of ORBmatcher::SearchByProjection(Frame&, vpMapPoints, th) (ORBmatcher.cc:45-129) on flat arrays:
     queries = WINDOW_QUERY_DTYPE records (projected position, radius, octave range), qdesc = their descriptors.
     mode 0: best / second-best + octaves per query; mode 1: the whole loop (accept rule, taken keypoints)."""
@@ -287,7 +288,9 @@ def search_by_projection(kps, desc, cols, rows, queries, qdesc, taken=None, mode
     tk = None if taken is None else np.ascontiguousarray(taken, np.uint8).copy()
     out = [np.zeros(max(nq, 1), np.int32) for _ in range(6)]
     nm = C.c_int32(0)
-    _check(L, L.orbfe_search_by_projection(_p(kps), _p(desc), len(kps), cols, rows, _p(queries), _p(qdesc), nq,
+    bnd = None if bounds is None else np.ascontiguousarray(bounds, np.float32)
+    _check(L, L.orbfe_search_by_projection(_p(kps), _p(desc), len(kps), cols, rows, None if bnd is None else _p(bnd),
+                                           _p(queries), _p(qdesc), nq,
                                            None if tk is None else _p(tk), mode, th_high, nnratio, *[_p(o) for o in out],
                                            C.byref(nm), device), "orbfe_search_by_projection")
     return dict(best_idx=out[0][:nq], best_dist=out[1][:nq], best_level=out[2][:nq], second_dist=out[3][:nq],
@@ -308,7 +311,7 @@ class ORBmatcher:
     def DescriptorDistance(a, b):
         return hamming(a, b)
 
-    def SearchForInitialization(self, kps1, desc1, kps2, desc2, cols, rows, vbPrevMatched=None, windowSize=10):
+    def SearchForInitialization(self, kps1, desc1, kps2, desc2, cols, rows, vbPrevMatched=None, windowSize=10, bounds=None):
         """Returns (nmatches, vnMatches12, vbPrevMatched'); frames are given as (keypoints, descriptors)."""
         k1 = np.ascontiguousarray(kps1); k2 = np.ascontiguousarray(kps2)
         d1 = np.ascontiguousarray(desc1, np.uint8); d2 = np.ascontiguousarray(desc2, np.uint8)
@@ -317,8 +320,9 @@ class ORBmatcher:
         prev = np.ascontiguousarray(vbPrevMatched, np.float32).copy()
         m12 = np.full(len(k1), -1, np.int32)
         n = C.c_int32(0)
+        bnd = None if bounds is None else np.ascontiguousarray(bounds, np.float32)
         _check(self.L, self.L.orbfe_search_for_initialization(_p(k1), _p(d1), len(k1), _p(k2), _p(d2), len(k2), cols,
-                                                              rows, _p(prev), _p(m12), windowSize, self.mfNNratio,
+                                                              rows, None if bnd is None else _p(bnd), _p(prev), _p(m12), windowSize, self.mfNNratio,
                                                               int(self.mbCheckOrientation), C.byref(n), self.device),
                "orbfe_search_for_initialization")
         return n.value, m12, prev

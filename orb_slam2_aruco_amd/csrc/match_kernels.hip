@@ -258,7 +258,7 @@ inline size_t sfi_lds_bytes() { return (size_t)SFI_L0_LDS * 8 + (size_t)SFI_L0_L
 
 __global__ __launch_bounds__(SFI_THREADS) void k_search_init(const orbfe_keypoint* __restrict__ kps,
                                                      const uint8_t* __restrict__ desc, const int32_t* __restrict__ nkp,
-                                                     int capacity, int cols, int rows, float window, float nnratio,
+                                                     int capacity, float4 bnd, float window, float nnratio,
                                                      int check_ori, const float* __restrict__ prev_in,
                                                      float* __restrict__ prev_out, int32_t* __restrict__ matches12,
                                                      int32_t* __restrict__ nmatches_out, int32_t* __restrict__ csr_cnt,
@@ -295,9 +295,10 @@ __global__ __launch_bounds__(SFI_THREADS) void k_search_init(const orbfe_keypoin
     float* prevo = prev_out ? prev_out + (size_t)p * capacity * 2 : nullptr;
     (void)csr_cnt;
 
-    const float mnMinX = 0.f, mnMinY = 0.f;
-    const float invW = __fdiv_rn((float)GRID_COLS, (float)cols - mnMinX);
-    const float invH = __fdiv_rn((float)GRID_ROWS, (float)rows - mnMinY);
+    // bounds of the undistorted image (Frame::ComputeImageBounds; 0, 0, cols, rows without distortion) and Frame.cc:112-113
+    const float mnMinX = bnd.x, mnMinY = bnd.y;
+    const float invW = __fdiv_rn((float)GRID_COLS, bnd.z - bnd.x);
+    const float invH = __fdiv_rn((float)GRID_ROWS, bnd.w - bnd.y);
 
     // ---- phase A: level-0 keypoints of F2 that fall inside the grid (Frame.cc:183-198, :335-345), sorted;
     // level-0 keypoints of F1 (the queries) in index order
@@ -570,7 +571,7 @@ __global__ __launch_bounds__(256) void k_knn2_csr(const uint8_t* __restrict__ Q,
 struct SbpQuery { float x, y, r; int32_t min_level, max_level; };
 
 __global__ __launch_bounds__(SBP_THREADS) void k_search_by_projection(
-    const orbfe_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc, int n, int ncap /*pow2 >= n*/, int cols, int rows,
+    const orbfe_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc, int n, int ncap /*pow2 >= n*/, float4 bnd,
     const SbpQuery* __restrict__ queries, const uint8_t* __restrict__ qdesc, int nq, uint8_t* __restrict__ taken, int mode,
     int th_high, float nnratio, uint16_t* __restrict__ row_rank, uint8_t* __restrict__ row_dist, int32_t* __restrict__ row_cnt,
     int row_stride, int32_t* __restrict__ best_idx, int32_t* __restrict__ best_dist, int32_t* __restrict__ best_level,
@@ -585,9 +586,10 @@ __global__ __launch_bounds__(SBP_THREADS) void k_search_by_projection(
     uint8_t* s_lvl = (uint8_t*)(s_cell0 + SBP_CELLS + 2);      // by rank
     uint8_t* s_taken = s_lvl + ncap;                           // by rank
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const float mnMinX = 0.f, mnMinY = 0.f;
-    const float invW = __fdiv_rn((float)GRID_COLS, (float)cols - mnMinX);
-    const float invH = __fdiv_rn((float)GRID_ROWS, (float)rows - mnMinY);
+    // bounds of the undistorted image (Frame::ComputeImageBounds; 0, 0, cols, rows without distortion) and Frame.cc:112-113
+    const float mnMinX = bnd.x, mnMinY = bnd.y;
+    const float invW = __fdiv_rn((float)GRID_COLS, bnd.z - bnd.x);
+    const float invH = __fdiv_rn((float)GRID_ROWS, bnd.w - bnd.y);
 
     // ---- A
     if (tid == 0) s_nin = 0;
@@ -807,8 +809,13 @@ static int knn2_launch(const uint8_t* d_Q, const int32_t* d_nq, size_t q_stride,
     return ORBFE_OK;
 }
 
+static float4 frame_bounds(int cols, int rows, const float* bounds)
+{
+    return bounds ? make_float4(bounds[0], bounds[1], bounds[2], bounds[3]) : make_float4(0.f, 0.f, (float)cols, (float)rows);
+}
+
 static int sfi_launch(const orbfe_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n, int capacity, int npairs,
-                      int cols, int rows, int window, float nnratio, int check_ori, const float* d_prev_in,
+                      float4 bnd, int window, float nnratio, int check_ori, const float* d_prev_in,
                       float* d_prev_out, int32_t* d_m12, int32_t* d_nm, hipStream_t s)
 {
     if (capacity > 65535) return fail(ORBFE_ERR_INVALID, "capacity above 65535 keypoints per frame is unsupported");
@@ -826,7 +833,7 @@ static int sfi_launch(const orbfe_keypoint* d_kps, const uint8_t* d_desc, const 
     ORBFE_HIP(hipMemsetAsync(w.overflow.p, 0, 4, s));
     ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_init), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)sfi_lds_bytes()));
-    hipLaunchKernelGGL(k_search_init, dim3(npairs), dim3(SFI_THREADS), sfi_lds_bytes(), s, d_kps, d_desc, d_n, capacity, cols, rows,
+    hipLaunchKernelGGL(k_search_init, dim3(npairs), dim3(SFI_THREADS), sfi_lds_bytes(), s, d_kps, d_desc, d_n, capacity, bnd,
                        (float)window, nnratio, check_ori, d_prev_in, d_prev_out, d_m12, d_nm, w.csr_cnt.as<int32_t>(),
                        w.csr_idx.as<uint16_t>(), w.csr_dist.as<uint8_t>(), stride, w.scratch.as<int32_t>(),
                        w.overflow.as<int32_t>());
@@ -902,19 +909,19 @@ int orbfe_knn2(const uint8_t* Q, int nq, const uint8_t* T, int nt, int init, int
 
 int orbfe_search_for_initialization_batch_device(const orbfe_keypoint* d_kps, const uint8_t* d_desc,
                                                  const int32_t* d_n, int capacity, int npairs, int cols, int rows,
-                                                 int window_size, float nnratio, int check_orientation,
+                                                 const float* bounds, int window_size, float nnratio, int check_orientation,
                                                  int32_t* d_matches12, int32_t* d_nmatches, void* stream)
 {
     if (!d_kps || !d_desc || !d_n || !d_matches12 || !d_nmatches || capacity <= 0 || npairs <= 0 || cols <= 0 ||
         rows <= 0)
         return fail(ORBFE_ERR_INVALID, "orbfe_search_for_initialization_batch_device: invalid argument");
-    return sfi_launch(d_kps, d_desc, d_n, capacity, npairs, cols, rows, window_size, nnratio, check_orientation,
+    return sfi_launch(d_kps, d_desc, d_n, capacity, npairs, frame_bounds(cols, rows, bounds), window_size, nnratio, check_orientation,
                       nullptr, nullptr, d_matches12, d_nmatches, (hipStream_t)stream);
 }
 
 int orbfe_search_for_initialization(const orbfe_keypoint* kps1, const uint8_t* desc1, int n1,
                                     const orbfe_keypoint* kps2, const uint8_t* desc2, int n2, int cols, int rows,
-                                    float* prev_matched, int32_t* matches12, int window_size, float nnratio,
+                                    const float* bounds, float* prev_matched, int32_t* matches12, int window_size, float nnratio,
                                     int check_orientation, int32_t* nmatches, int device)
 {
     if (n1 < 0 || n2 < 0 || !nmatches || (n1 && (!kps1 || !desc1 || !matches12 || !prev_matched)) ||
@@ -942,7 +949,7 @@ int orbfe_search_for_initialization(const orbfe_keypoint* kps1, const uint8_t* d
     for (int attempt = 0;; attempt++) {
         // the device copy of prev_matched is only overwritten by a run that did not overflow
         ORBFE_HIP(hipMemcpy(w.prev.p, prev_matched, (size_t)n1 * 8, hipMemcpyHostToDevice));
-        rc = sfi_launch(w.kps.as<orbfe_keypoint>(), w.desc.as<uint8_t>(), w.nk.as<int32_t>(), cap, 1, cols, rows,
+        rc = sfi_launch(w.kps.as<orbfe_keypoint>(), w.desc.as<uint8_t>(), w.nk.as<int32_t>(), cap, 1, frame_bounds(cols, rows, bounds),
                         window_size, nnratio, check_orientation, w.prev.as<float>(), w.prev.as<float>(),
                         w.m12.as<int32_t>(), w.nm.as<int32_t>(), nullptr);
         if (rc) return rc;
@@ -960,7 +967,7 @@ int orbfe_search_for_initialization(const orbfe_keypoint* kps1, const uint8_t* d
     return ORBFE_OK;
 }
 
-int orbfe_search_by_projection(const orbfe_keypoint* kps, const uint8_t* desc, int n, int cols, int rows,
+int orbfe_search_by_projection(const orbfe_keypoint* kps, const uint8_t* desc, int n, int cols, int rows, const float* bounds,
                                const orbfe_window_query* queries, const uint8_t* qdesc, int nq, uint8_t* taken, int mode,
                                int th_high, float nnratio, int32_t* best_idx, int32_t* best_dist, int32_t* best_level,
                                int32_t* second_dist, int32_t* second_level, int32_t* match, int32_t* nmatches, int device)
@@ -1001,7 +1008,7 @@ int orbfe_search_by_projection(const orbfe_keypoint* kps, const uint8_t* desc, i
         ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_by_projection),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_search_by_projection, dim3(1), dim3(SBP_THREADS), lds, 0, w.kps.as<orbfe_keypoint>(),
-                           w.desc.as<uint8_t>(), n, ncap, cols, rows, w.q.as<SbpQuery>(), w.t.as<uint8_t>(), nq,
+                           w.desc.as<uint8_t>(), n, ncap, frame_bounds(cols, rows, bounds), w.q.as<SbpQuery>(), w.t.as<uint8_t>(), nq,
                            taken ? w.prev.as<uint8_t>() : nullptr, mode, th_high, nnratio, w.csr_idx.as<uint16_t>(),
                            w.csr_dist.as<uint8_t>(), w.csr_cnt.as<int32_t>(), stride, o, o + nq, o + 2 * nq, o + 3 * nq,
                            o + 4 * nq, o + 5 * nq, w.nm.as<int32_t>(), w.overflow.as<int32_t>());

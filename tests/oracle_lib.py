@@ -62,13 +62,13 @@ def lib():
                                   C.c_void_p]
         L.oracle_features_in_area.restype = C.c_int
         L.oracle_features_in_area.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
-                                              C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+                                              C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.oracle_knn2_csr.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                       C.c_void_p, C.c_void_p]
         L.oracle_search_for_initialization.restype = C.c_int
         L.oracle_search_for_initialization.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                                        C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
-                                                       C.c_float, C.c_int]
+                                                       C.c_float, C.c_int, C.c_void_p]
         L.oracle_three_maxima.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         if hasattr(L, "oracle_aruco_create"):
             _bind_aruco(L)
@@ -157,17 +157,23 @@ def knn2(Q, T, init=256):
     return bi, bd, sd
 
 
-def features_in_area(kps2, cols, rows, qx, qy, r, min_level, max_level):
+def _bounds(b):
+    return None if b is None else np.ascontiguousarray(b, np.float32)
+
+
+def features_in_area(kps2, cols, rows, qx, qy, r, min_level, max_level, bounds=None):
     L = lib()
+    bounds = _bounds(bounds)
+    bp = None if bounds is None else _p(bounds)
     kps2 = np.ascontiguousarray(kps2)
     qx = np.ascontiguousarray(qx, np.float32)
     qy = np.ascontiguousarray(qy, np.float32)
     off = np.zeros(len(qx) + 1, np.int32)
     total = L.oracle_features_in_area(_p(kps2), len(kps2), cols, rows, _p(qx), _p(qy), len(qx), r, min_level,
-                                      max_level, _p(off), None, 0)
+                                      max_level, _p(off), None, 0, bp)
     idx = np.zeros(max(total, 1), np.int32)
     L.oracle_features_in_area(_p(kps2), len(kps2), cols, rows, _p(qx), _p(qy), len(qx), r, min_level, max_level,
-                              _p(off), _p(idx), total)
+                              _p(off), _p(idx), total, bp)
     return off, idx[:total]
 
 
@@ -186,7 +192,7 @@ def knn2_csr(Q, T, off, idx, init=256):
 WINDOW_QUERY_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("r", "<f4"), ("min_level", "<i4"), ("max_level", "<i4")])
 
 
-def search_by_projection(kps, desc, cols, rows, queries, qdesc, taken=None, mode=0, th_high=100, nnratio=0.8):
+def search_by_projection(kps, desc, cols, rows, queries, qdesc, taken=None, mode=0, th_high=100, nnratio=0.8, bounds=None):
     """ORBmatcher::SearchByProjection(Frame, MapPoints) matching loop on flat arrays; see oracle/match_oracle.cpp."""
     L = lib()
     kps = np.ascontiguousarray(kps); desc = np.ascontiguousarray(desc, np.uint8)
@@ -196,14 +202,15 @@ def search_by_projection(kps, desc, cols, rows, queries, qdesc, taken=None, mode
     out = [np.zeros(nq, np.int32) for _ in range(6)]
     L.oracle_search_by_projection.restype = C.c_int
     L.oracle_search_by_projection.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
-                                              C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float] + [C.c_void_p] * 6
+                                              C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float] + [C.c_void_p] * 7
     nm = L.oracle_search_by_projection(_p(kps), _p(desc), len(kps), cols, rows, _p(queries), _p(qdesc), nq,
-                                       None if tk is None else _p(tk), mode, th_high, nnratio, *[_p(o) for o in out])
+                                       None if tk is None else _p(tk), mode, th_high, nnratio, *[_p(o) for o in out],
+                                       None if bounds is None else _p(_bounds(bounds)))
     return dict(best_idx=out[0], best_dist=out[1], best_level=out[2], second_dist=out[3], second_level=out[4],
                 match=out[5], nmatches=nm, taken=tk)
 
 
-def search_for_initialization(k1, d1, k2, d2, cols, rows, prev=None, window=100, nnratio=0.9, check_ori=True):
+def search_for_initialization(k1, d1, k2, d2, cols, rows, prev=None, window=100, nnratio=0.9, check_ori=True, bounds=None):
     L = lib()
     k1 = np.ascontiguousarray(k1); k2 = np.ascontiguousarray(k2)
     d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
@@ -212,7 +219,8 @@ def search_for_initialization(k1, d1, k2, d2, cols, rows, prev=None, window=100,
     prev = np.ascontiguousarray(prev, np.float32).copy()
     m = np.zeros(len(k1), np.int32)
     n = L.oracle_search_for_initialization(_p(k1), _p(d1), len(k1), _p(k2), _p(d2), len(k2), cols, rows, _p(prev),
-                                           _p(m), window, nnratio, int(check_ori))
+                                           _p(m), window, nnratio, int(check_ori),
+                                           None if bounds is None else _p(_bounds(bounds)))
     return n, m, prev
 
 

@@ -173,3 +173,26 @@ def test_search_by_projection_golden(orbfe):
     r1 = orbfe.search_by_projection(g["k2"], g["d2"], 640, 480, q, g["d1"][p["sel"]], p["taken"], 1, 100, 0.8)
     assert r1["nmatches"] == int(p["nmatches"][0])
     assert np.array_equal(r1["match"], p["match"]) and np.array_equal(r1["taken"], p["taken_after"])
+
+
+def test_grid_bounds_of_a_distorted_camera(orbfe, oracle):
+    """With lens distortion the Frame grid spans the undistorted image bounds (Frame.cc:418-451), not 0..cols."""
+    bounds = np.array([-14.25, -9.5, 655.75, 489.0], np.float32)
+    kps, desc, q, qd, taken = _projection_case(oracle, 4, 500, 2.0)
+    kps = kps.copy()
+    kps["x"] = kps["x"] * 1.04 - 13.0          # "undistorted" positions reaching beyond the sensor
+    kps["y"] = kps["y"] * 1.03 - 8.0
+    q = q.copy(); q["x"] = q["x"] * 1.04 - 13.0; q["y"] = q["y"] * 1.03 - 8.0
+    for mode in (0, 1):
+        want = oracle.search_by_projection(kps, desc, 640, 480, q, qd, taken, mode, 100, 0.8, bounds)
+        got = orbfe.search_by_projection(kps, desc, 640, 480, q, qd, taken, mode, 100, 0.8, bounds=bounds)
+        for f in ("best_idx", "best_dist", "best_level", "second_dist", "second_level") + (("match",) if mode else ()):
+            assert np.array_equal(got[f], want[f]), (mode, f)
+    s = synth.stream(480, 640, 2, 1000)
+    o = oracle.OrbOracle(1000, 1.2, 8, 20, 7)
+    (k1, d1), (k2, d2) = o.extract(s[0]), o.extract(s[1])
+    for k in (k1, k2):
+        k["x"] = k["x"] * 1.04 - 13.0; k["y"] = k["y"] * 1.03 - 8.0
+    wn, wm, wp = oracle.search_for_initialization(k1, d1, k2, d2, 640, 480, None, 100, 0.9, True, bounds)
+    gn, gm, gp = orbfe.ORBmatcher(0.9, True).SearchForInitialization(k1, d1, k2, d2, 640, 480, None, 100, bounds=bounds)
+    assert gn == wn and np.array_equal(gm, wm) and np.array_equal(gp, wp)
