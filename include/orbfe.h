@@ -183,6 +183,24 @@ int orbfe_search_for_initialization_batch_device(const orbfe_keypoint* d_kps, co
                                                  int window_size, float nnratio, int check_orientation,
                                                  int32_t* d_matches12, int32_t* d_nmatches, void* stream);
 
+/* ------------------------------------------------------------------ Frame glue: undistortion -- */
+/* cv::undistortPoints(src, dst, K, distCoeffs, noArray(), K) (OpenCV 3.4: 5 fixed-point iterations in double) on n
+ * (x, y) float pairs -- what Frame::UndistortKeyPoints (src/Frame.cc:357-387) and Frame::UndistortArucoCorners
+ * (:389-416) run over mvKeys / the 4*NA marker corners.  K4 = {fx, fy, cx, cy}; dist = k1 k2 p1 p2 [k3 [k4 k5 k6
+ * [s1 s2 s3 s4]]] (ORB_SLAM2's mDistCoef has 4 or 5).  Always undistorts (the callers' "mDistCoef[0] == 0 -> copy"
+ * shortcut is the caller's, see the batch variant).  Host pointers; src may equal dst. */
+int orbfe_undistort_points(const float* src, int n, const float* K4, const float* dist, int ndist, float* dst, int device);
+
+/* Frame::UndistortKeyPoints over a batch of extractor outputs on the device: frame f's first min(d_n[f], capacity)
+ * records get undistorted (x, y), every other field is kept (Frame.cc:379-386); with ndist == 0 or dist[0] == 0 the
+ * records are copied unchanged (:359-363).  d_kps_un may equal d_kps. */
+int orbfe_undistort_keypoints_batch_device(const orbfe_keypoint* d_kps, const int32_t* d_n, int capacity, int nframes,
+                                           const float* K4, const float* dist, int ndist, orbfe_keypoint* d_kps_un, void* stream);
+
+/* Frame::ComputeImageBounds (src/Frame.cc:418-451): bounds = {mnMinX, mnMinY, mnMaxX, mnMaxY}, the `bounds` argument
+ * of the search entry points above.  {0, 0, cols, rows} when dist[0] == 0. */
+int orbfe_compute_image_bounds(int cols, int rows, const float* K4, const float* dist, int ndist, float* bounds, int device);
+
 /* ------------------------------------------------------------------ ArUco marker detector -- */
 typedef struct orbfe_aruco orbfe_aruco;
 

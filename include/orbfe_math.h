@@ -100,4 +100,29 @@ ORBFE_HD void orbfe_sincosf(float xf, float* s, float* c)
     *c = (float)rc;
 }
 
+
+/* cv::undistortPoints(src, dst, K, distCoeffs, noArray(), K) of OpenCV 3.4 for one point, as Frame::UndistortKeyPoints
+ * (Frame.cc:357-387), UndistortArucoCorners (:389-416) and ComputeImageBounds (:418-451) call it: normalise with K,
+ * five fixed-point iterations of the inverse Brown model (radial k1 k2 k3 [k4 k5 k6], tangential p1 p2, thin prism
+ * s1..s4 -- ORB_SLAM2 passes 4 or 5 coefficients, the rest are 0), re-project with P = K.  All arithmetic in double, the
+ * result rounded to float once per coordinate.  k[] = the 12 coefficients in OpenCV's order k1 k2 p1 p2 k3 k4 k5 k6 s1..s4. */
+ORBFE_HD void orbfe_undistort_point(float u, float v, double fx, double fy, double cx, double cy, const double k[12], float* ou,
+                                    float* ov)
+{
+    const double ifx = 1. / fx, ify = 1. / fy;
+    double x = ((double)u - cx) * ifx, y = ((double)v - cy) * ify;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; j++) {
+        const double r2 = x * x + y * y;
+        const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+        const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2;
+        const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    const double xx = fx * x + 0. * y + cx, yy = 0. * x + fy * y + cy, ww = 1. / (0. * x + 0. * y + 1.);
+    *ou = (float)(xx * ww);
+    *ov = (float)(yy * ww);
+}
+
 #endif /* ORBFE_MATH_H */

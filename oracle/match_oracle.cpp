@@ -283,6 +283,57 @@ int oracle_search_for_initialization(const void* kps1_, const uint8_t* desc1, in
     return nmatches;
 }
 
+/* cv::undistortPoints(mat, mat, mK, mDistCoef, cv::Mat(), mK) as Frame::UndistortKeyPoints (src/Frame.cc:357-387),
+ * Frame::UndistortArucoCorners (:389-416) and Frame::ComputeImageBounds (:418-451) call it.  OpenCV is not in this image;
+ * this restates the published OpenCV 3.4 algorithm (imgproc/src/undistort.cpp, cvUndistortPointsInternal with the default
+ * criteria MAX_ITER 5): the matrices are converted to double, each point is normalised by K, the distortion is inverted
+ * by five fixed-point iterations, and the point is re-projected through the 3x3 product P*R = K. */
+void oracle_undistort_points(const float* src, int n, const float* K4, const float* dist, int ndist, float* dst)
+{
+    double A[3][3] = {{K4[0], 0, K4[2]}, {0, K4[1], K4[3]}, {0, 0, 1}};
+    double RR[3][3] = {{K4[0], 0, K4[2]}, {0, K4[1], K4[3]}, {0, 0, 1}};
+    double k[14] = {0};
+    for (int i = 0; i < ndist && i < 14; i++) k[i] = dist[i];
+    const double fx = A[0][0], fy = A[1][1], ifx = 1. / fx, ify = 1. / fy, cx = A[0][2], cy = A[1][2];
+    for (int i = 0; i < n; i++) {
+        double x = src[2 * i], y = src[2 * i + 1];
+        x = (x - cx) * ifx;
+        y = (y - cy) * ify;
+        if (ndist > 0) {
+            double x0 = x, y0 = y;
+            for (int j = 0; j < 5; j++) {
+                double r2 = x * x + y * y;
+                double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+                double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2;
+                double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
+                x = (x0 - deltaX) * icdist;
+                y = (y0 - deltaY) * icdist;
+            }
+        }
+        double xx = RR[0][0] * x + RR[0][1] * y + RR[0][2];
+        double yy = RR[1][0] * x + RR[1][1] * y + RR[1][2];
+        double ww = 1. / (RR[2][0] * x + RR[2][1] * y + RR[2][2]);
+        dst[2 * i] = (float)(xx * ww);
+        dst[2 * i + 1] = (float)(yy * ww);
+    }
+}
+
+/* Frame::ComputeImageBounds (src/Frame.cc:418-451): the four image corners undistorted when mDistCoef[0] != 0;
+ * out = {mnMinX, mnMinY, mnMaxX, mnMaxY}. */
+void oracle_compute_image_bounds(int cols, int rows, const float* K4, const float* dist, int ndist, float* out)
+{
+    if (ndist > 0 && dist[0] != 0.0f) {
+        float c[8] = {0, 0, (float)cols, 0, 0, (float)rows, (float)cols, (float)rows}, u[8];
+        oracle_undistort_points(c, 4, K4, dist, ndist, u);
+        out[0] = std::min(u[0], u[4]);
+        out[2] = std::max(u[2], u[6]);
+        out[1] = std::min(u[1], u[3]);
+        out[3] = std::max(u[5], u[7]);
+    } else {
+        out[0] = 0.0f; out[1] = 0.0f; out[2] = (float)cols; out[3] = (float)rows;
+    }
+}
+
 void oracle_three_maxima(const int* sizes, int L, int* out3)
 {
     int a = -1, b = -1, c = -1;

@@ -28,6 +28,7 @@ SYMBOLS = [
     "orbfe_extractor_debug_level_keypoints", "orbfe_extractor_debug_kernel_times", "orbfe_extractor_set_aux_stream",
     "orbfe_debug_control", "orbfe_hamming", "orbfe_knn2", "orbfe_knn2_csr", "orbfe_knn2_batch_device", "orbfe_search_for_initialization",
     "orbfe_search_for_initialization_batch_device", "orbfe_search_by_projection",
+    "orbfe_undistort_points", "orbfe_undistort_keypoints_batch_device", "orbfe_compute_image_bounds",
     "orbfe_aruco_create", "orbfe_aruco_destroy", "orbfe_aruco_set_dictionary", "orbfe_aruco_max_markers",
     "orbfe_aruco_detect", "orbfe_aruco_detect_batch", "orbfe_aruco_detect_batch_device", "orbfe_aruco_debug_image",
     "orbfe_aruco_debug_kernel_times", "orbfe_aruco_set_aux_stream",
@@ -74,6 +75,9 @@ def load():
         L.orbfe_debug_control.argtypes = [C.c_char_p, i32]
         L.orbfe_search_by_projection.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, i32, vp, i32, i32, C.c_float] + [vp] * 7 + [i32]
         L.orbfe_hamming.argtypes = [vp, vp]
+        L.orbfe_undistort_points.argtypes = [vp, i32, vp, vp, i32, vp, i32]
+        L.orbfe_undistort_keypoints_batch_device.argtypes = [vp, vp, i32, i32, vp, vp, i32, vp, vp]
+        L.orbfe_compute_image_bounds.argtypes = [i32, i32, vp, vp, i32, vp, i32]
         L.orbfe_knn2.argtypes = [vp, i32, vp, i32, i32, vp, vp, vp, i32]
         L.orbfe_knn2_csr.argtypes = [vp, i32, vp, i32, vp, vp, i32, vp, vp, vp, i32]
         L.orbfe_knn2_batch_device.argtypes = [vp, vp, sz, i32, vp, vp, sz, i32, i32, i32, vp, vp, vp, vp]
@@ -295,6 +299,47 @@ def search_by_projection(kps, desc, cols, rows, queries, qdesc, taken=None, mode
                                            C.byref(nm), device), "orbfe_search_by_projection")
     return dict(best_idx=out[0][:nq], best_dist=out[1][:nq], best_level=out[2][:nq], second_dist=out[3][:nq],
                 second_level=out[4][:nq], match=out[5][:nq], nmatches=nm.value, taken=tk)
+
+
+def _camera(K, dist):
+    """K: 3x3 matrix or (fx, fy, cx, cy); dist: mDistCoef (4 or 5 values, up to 12)."""
+    K = np.asarray(K, np.float32)
+    K4 = np.ascontiguousarray([K[0, 0], K[1, 1], K[0, 2], K[1, 2]] if K.ndim == 2 else K.reshape(4), np.float32)
+    d = np.ascontiguousarray(np.asarray([] if dist is None else dist, np.float32).reshape(-1))
+    return K4, d
+
+
+def undistort_points(pts, K, dist, device=0):
+    """cv::undistortPoints(pts, K, dist, R=I, P=K) on an (n, 2) float array (Frame.cc:357-416)."""
+    L = load()
+    K4, d = _camera(K, dist)
+    src = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+    dst = np.empty_like(src)
+    _check(L, L.orbfe_undistort_points(_p(src), len(src), _p(K4), _p(d) if len(d) else None, len(d), _p(dst), device),
+           "orbfe_undistort_points")
+    return dst
+
+
+def UndistortKeyPoints(kps, K, dist, device=0):
+    """Frame::UndistortKeyPoints (Frame.cc:357-387): mvKeysUn = mvKeys with (x, y) undistorted; unchanged when dist[0] == 0."""
+    kps = np.ascontiguousarray(kps, KP_DTYPE)
+    K4, d = _camera(K, dist)
+    if len(d) == 0 or d[0] == 0.0 or len(kps) == 0:
+        return kps.copy()
+    un = kps.copy()
+    xy = undistort_points(np.stack([kps["x"], kps["y"]], 1), K4, d, device)
+    un["x"] = xy[:, 0]; un["y"] = xy[:, 1]
+    return un
+
+
+def ComputeImageBounds(cols, rows, K, dist, device=0):
+    """Frame::ComputeImageBounds (Frame.cc:418-451) -> float32 [mnMinX, mnMinY, mnMaxX, mnMaxY] (the `bounds` of the searches)."""
+    L = load()
+    K4, d = _camera(K, dist)
+    out = np.zeros(4, np.float32)
+    _check(L, L.orbfe_compute_image_bounds(cols, rows, _p(K4), _p(d) if len(d) else None, len(d), _p(out), device),
+           "orbfe_compute_image_bounds")
+    return out
 
 
 class ORBmatcher:

@@ -753,6 +753,46 @@ __global__ __launch_bounds__(SBP_THREADS) void k_search_by_projection(
     if (lane == 0) *nmatches_out = nmatches;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Frame glue: cv::undistortPoints with P = K (Frame.cc:357-451).  One point per lane, double arithmetic
+// (orbfe_undistort_point in include/orbfe_math.h is the numerics contract); the 12 coefficients come by value.
+struct UndistortParams {
+    double fx, fy, cx, cy;
+    double k[12];
+};
+
+// points: n (x, y) float pairs, src -> dst (may alias)
+__global__ __launch_bounds__(256) void k_undistort_points(const float2* __restrict__ src, int n, UndistortParams P,
+                                                          float2* __restrict__ dst)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float2 p = src[i];
+    float2 o;
+    orbfe_undistort_point(p.x, p.y, P.fx, P.fy, P.cx, P.cy, P.k, &o.x, &o.y);
+    dst[i] = o;
+}
+
+// keypoint records of a batch: frame = blockIdx.y, in place on (x, y) (mvKeysUn keeps the other fields, Frame.cc:379-386)
+__global__ __launch_bounds__(256) void k_undistort_keypoints(const orbfe_keypoint* __restrict__ kin, const int32_t* __restrict__ d_n,
+                                                             int capacity, UndistortParams P, orbfe_keypoint* __restrict__ kout)
+{
+    const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= min(d_n[f], capacity)) return;
+    orbfe_keypoint kp = kin[(size_t)f * capacity + i];
+    orbfe_undistort_point(kp.x, kp.y, P.fx, P.fy, P.cx, P.cy, P.k, &kp.x, &kp.y);
+    kout[(size_t)f * capacity + i] = kp;
+}
+
+static int undistort_params(const float* K4, const float* dist, int ndist, UndistortParams& P, const char* who)
+{
+    if (!K4 || ndist < 0 || ndist > 12 || (ndist && !dist) || !(K4[0] != 0.0f) || !(K4[1] != 0.0f))
+        return fail(ORBFE_ERR_INVALID, "%s: invalid camera (K = {fx, fy, cx, cy} with fx, fy != 0; at most 12 coefficients)", who);
+    P.fx = K4[0]; P.fy = K4[1]; P.cx = K4[2]; P.cy = K4[3];
+    for (int i = 0; i < 12; i++) P.k[i] = i < ndist ? (double)dist[i] : 0.0;
+    return ORBFE_OK;
+}
+
 struct MatchWorkspace {
     DevBuf pidx, pbest, psecond, csr_cnt, csr_idx, csr_dist, scratch, overflow, prev;
     DevBuf q, t, nq, nt, oidx, obest, osecond, kps, desc, nk, m12, nm;
@@ -1066,6 +1106,60 @@ int orbfe_knn2_csr(const uint8_t* Q, int nq, const uint8_t* T, int nt, const int
     ORBFE_HIP(hipMemcpy(best_idx, w.oidx.p, (size_t)nq * 4, hipMemcpyDeviceToHost));
     ORBFE_HIP(hipMemcpy(best_dist, w.obest.p, (size_t)nq * 4, hipMemcpyDeviceToHost));
     ORBFE_HIP(hipMemcpy(second_dist, w.osecond.p, (size_t)nq * 4, hipMemcpyDeviceToHost));
+    return ORBFE_OK;
+}
+
+int orbfe_undistort_points(const float* src, int n, const float* K4, const float* dist, int ndist, float* dst, int device)
+{
+    if (n < 0 || (n && (!src || !dst))) return fail(ORBFE_ERR_INVALID, "orbfe_undistort_points: invalid argument");
+    UndistortParams P;
+    int rc = undistort_params(K4, dist, ndist, P, "orbfe_undistort_points");
+    if (rc || (rc = use_device(device))) return rc;
+    if (n == 0) return ORBFE_OK;
+    MatchWorkspace& w = ws();
+    if ((rc = w.prev.ensure((size_t)n * 8))) return rc;
+    ORBFE_HIP(hipMemcpy(w.prev.p, src, (size_t)n * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_undistort_points, dim3((n + 255) / 256), dim3(256), 0, 0, w.prev.as<float2>(), n, P, w.prev.as<float2>());
+    ORBFE_HIP(hipGetLastError());
+    ORBFE_HIP(hipMemcpy(dst, w.prev.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+    return ORBFE_OK;
+}
+
+int orbfe_undistort_keypoints_batch_device(const orbfe_keypoint* d_kps, const int32_t* d_n, int capacity, int nframes,
+                                           const float* K4, const float* dist, int ndist, orbfe_keypoint* d_kps_un, void* stream)
+{
+    if (nframes < 0 || capacity < 0 || (nframes && capacity && (!d_kps || !d_n || !d_kps_un)))
+        return fail(ORBFE_ERR_INVALID, "orbfe_undistort_keypoints_batch_device: invalid argument");
+    UndistortParams P;
+    int rc = undistort_params(K4, dist, ndist, P, "orbfe_undistort_keypoints_batch_device");
+    if (rc) return rc;
+    if (nframes == 0 || capacity == 0) return ORBFE_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (ndist == 0 || dist[0] == 0.0f) { // Frame.cc:359-363: mvKeysUn = mvKeys
+        if (d_kps_un != d_kps)
+            ORBFE_HIP(hipMemcpyAsync(d_kps_un, d_kps, (size_t)nframes * capacity * sizeof(orbfe_keypoint), hipMemcpyDeviceToDevice, s));
+        return ORBFE_OK;
+    }
+    hipLaunchKernelGGL(k_undistort_keypoints, dim3((capacity + 255) / 256, nframes), dim3(256), 0, s, d_kps, d_n, capacity, P, d_kps_un);
+    ORBFE_HIP(hipGetLastError());
+    return ORBFE_OK;
+}
+
+int orbfe_compute_image_bounds(int cols, int rows, const float* K4, const float* dist, int ndist, float* bounds, int device)
+{
+    if (cols <= 0 || rows <= 0 || !bounds) return fail(ORBFE_ERR_INVALID, "orbfe_compute_image_bounds: invalid argument");
+    if (ndist == 0 || (dist && dist[0] == 0.0f)) { // Frame.cc:444-450
+        bounds[0] = 0.0f; bounds[1] = 0.0f; bounds[2] = (float)cols; bounds[3] = (float)rows;
+        return ORBFE_OK;
+    }
+    const float c[8] = {0.0f, 0.0f, (float)cols, 0.0f, 0.0f, (float)rows, (float)cols, (float)rows};
+    float u[8];
+    int rc = orbfe_undistort_points(c, 4, K4, dist, ndist, u, device);
+    if (rc) return rc;
+    bounds[0] = std::min(u[0], u[4]); // mnMinX = min(top-left.x, bottom-left.x)   (Frame.cc:437)
+    bounds[2] = std::max(u[2], u[6]); // mnMaxX = max(top-right.x, bottom-right.x) (:438)
+    bounds[1] = std::min(u[1], u[3]); // mnMinY = min(top-left.y, top-right.y)     (:439)
+    bounds[3] = std::max(u[5], u[7]); // mnMaxY = max(bottom-left.y, bottom-right.y) (:440)
     return ORBFE_OK;
 }
 

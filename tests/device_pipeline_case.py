@@ -1,0 +1,51 @@
+"""Device-resident Frame glue case run by tests/test_match_gpu.py::test_undistort_keypoints_batch_device in its own
+process (torch first, then the HIP library): extract_batch_device -> undistort_keypoints_batch_device -> matching over
+the undistorted image bounds, against the oracle."""
+import os, sys
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, HERE)
+import numpy as np
+import torch, ctypes as C
+torch.cuda.init()
+from orb_slam2_aruco_amd import binding as orbfe, synth
+import oracle_lib as oracle
+
+TUM1_K = np.array([517.306408, 516.469215, 318.643040, 255.313989], np.float32)
+TUM1_DIST = np.array([0.262383, -0.953104, -0.005358, 0.002628, 1.163314], np.float32)
+
+s = synth.stream(480, 640, 3, 1000)
+ex = orbfe.ORBextractor(1000, 1.2, 8, 20, 7)
+cap = ex.capacity
+dev = torch.device("cuda:0")
+imgs = torch.from_numpy(s).to(dev)
+kps = torch.zeros(3 * cap * orbfe.KP_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+desc = torch.zeros(3 * cap * 32, dtype=torch.uint8, device=dev)
+n = torch.zeros(3, dtype=torch.int32, device=dev)
+ex.extract_batch_device(imgs.data_ptr(), 3, 480 * 640, 480, 640, 640, kps.data_ptr(), desc.data_ptr(), cap, n.data_ptr(), 0)
+L = ex.L
+d = np.ascontiguousarray(TUM1_DIST)
+rc = L.orbfe_undistort_keypoints_batch_device(kps.data_ptr(), n.data_ptr(), cap, 3, TUM1_K.ctypes.data_as(C.c_void_p),
+                                              d.ctypes.data_as(C.c_void_p), 5, kps.data_ptr(), None)
+assert rc == 0
+torch.cuda.synchronize()
+nh = n.cpu().numpy()
+kh = kps.cpu().numpy().view(orbfe.KP_DTYPE).reshape(3, cap)
+dh = desc.cpu().numpy().reshape(3, cap, 32)
+o = oracle.OrbOracle(1000, 1.2, 8, 20, 7)
+frames = []
+for f in range(3):
+    k, dd = o.extract(s[f])
+    xy = oracle.undistort_points(np.stack([k["x"], k["y"]], 1), TUM1_K, TUM1_DIST)
+    k = k.copy(); k["x"] = xy[:, 0]; k["y"] = xy[:, 1]
+    assert nh[f] == len(k)
+    for fld in ("x", "y", "size", "octave"):
+        assert np.array_equal(kh[f, :nh[f]][fld], k[fld]), (f, fld)
+    assert np.array_equal(dh[f, :nh[f]], dd)
+    frames.append((k, dd))
+bounds = orbfe.ComputeImageBounds(640, 480, TUM1_K, TUM1_DIST)
+(k1, d1), (k2, d2) = frames[0], frames[1]
+wn, wm, wp = oracle.search_for_initialization(k1, d1, k2, d2, 640, 480, None, 100, 0.9, True, bounds)
+gn, gm, gp = orbfe.ORBmatcher(0.9, True).SearchForInitialization(kh[0, :nh[0]], dh[0, :nh[0]], kh[1, :nh[1]], dh[1, :nh[1]],
+                                                                 640, 480, None, 100, bounds=bounds)
+assert gn == wn and np.array_equal(gm, wm) and np.array_equal(gp, wp)
+print("ok")

@@ -210,6 +210,27 @@ def search_by_projection(kps, desc, cols, rows, queries, qdesc, taken=None, mode
                 match=out[5], nmatches=nm, taken=tk)
 
 
+def undistort_points(pts, K4, dist):
+    L = lib()
+    src = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+    K4 = np.ascontiguousarray(K4, np.float32); d = np.ascontiguousarray(dist, np.float32).reshape(-1)
+    dst = np.empty_like(src)
+    L.oracle_undistort_points.restype = None
+    L.oracle_undistort_points.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.oracle_undistort_points(_p(src), len(src), _p(K4), _p(d) if len(d) else None, len(d), _p(dst))
+    return dst
+
+
+def compute_image_bounds(cols, rows, K4, dist):
+    L = lib()
+    K4 = np.ascontiguousarray(K4, np.float32); d = np.ascontiguousarray(dist, np.float32).reshape(-1)
+    out = np.zeros(4, np.float32)
+    L.oracle_compute_image_bounds.restype = None
+    L.oracle_compute_image_bounds.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.oracle_compute_image_bounds(cols, rows, _p(K4), _p(d) if len(d) else None, len(d), _p(out))
+    return out
+
+
 def search_for_initialization(k1, d1, k2, d2, cols, rows, prev=None, window=100, nnratio=0.9, check_ori=True, bounds=None):
     L = lib()
     k1 = np.ascontiguousarray(k1); k2 = np.ascontiguousarray(k2)

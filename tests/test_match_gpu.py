@@ -196,3 +196,56 @@ def test_grid_bounds_of_a_distorted_camera(orbfe, oracle):
     wn, wm, wp = oracle.search_for_initialization(k1, d1, k2, d2, 640, 480, None, 100, 0.9, True, bounds)
     gn, gm, gp = orbfe.ORBmatcher(0.9, True).SearchForInitialization(k1, d1, k2, d2, 640, 480, None, 100, bounds=bounds)
     assert gn == wn and np.array_equal(gm, wm) and np.array_equal(gp, wp)
+
+
+# TUM1.yaml of the reference (Examples/Monocular/TUM1.yaml): the camera the reference's monocular example is run with
+TUM1_K = np.array([517.306408, 516.469215, 318.643040, 255.313989], np.float32)
+TUM1_DIST = np.array([0.262383, -0.953104, -0.005358, 0.002628, 1.163314], np.float32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ndist", [4, 5, 8, 12])
+def test_undistort_points(orbfe, oracle, ndist):
+    """cv::undistortPoints with P = K (Frame.cc:357-416): bit-exact float results (double arithmetic on both sides)."""
+    rng = np.random.default_rng(ndist)
+    pts = np.concatenate([rng.uniform([-5, -5], [645, 485], (5000, 2)),
+                          [[0, 0], [640, 0], [0, 480], [640, 480], [318.643040, 255.313989]]]).astype(np.float32)
+    dist = np.concatenate([TUM1_DIST, [0.01, -0.02, 0.005, 1e-3, -2e-3, 5e-4, 1e-4]]).astype(np.float32)[:ndist]
+    want = oracle.undistort_points(pts, TUM1_K, dist)
+    got = orbfe.undistort_points(pts, TUM1_K, dist)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert orbfe.undistort_points(np.zeros((0, 2), np.float32), TUM1_K, dist).shape == (0, 2)
+    Kmat = np.array([[TUM1_K[0], 0, TUM1_K[2]], [0, TUM1_K[1], TUM1_K[3]], [0, 0, 1]], np.float32)
+    assert np.array_equal(orbfe.undistort_points(pts, Kmat, dist), got)      # 3x3 K accepted like mK
+
+
+@pytest.mark.gpu
+def test_compute_image_bounds_and_keypoints(orbfe, oracle):
+    want = oracle.compute_image_bounds(640, 480, TUM1_K, TUM1_DIST)
+    got = orbfe.ComputeImageBounds(640, 480, TUM1_K, TUM1_DIST)
+    assert np.array_equal(got, want)
+    assert not np.array_equal(got, [0, 0, 640, 480])
+    assert np.array_equal(orbfe.ComputeImageBounds(640, 480, TUM1_K, np.zeros(5, np.float32)), [0, 0, 640, 480])
+    assert np.array_equal(orbfe.ComputeImageBounds(640, 480, TUM1_K, None), [0, 0, 640, 480])
+    s = synth.stream(480, 640, 1, 1000)
+    k, d = oracle.OrbOracle(1000, 1.2, 8, 20, 7).extract(s[0])
+    un = orbfe.UndistortKeyPoints(k, TUM1_K, TUM1_DIST)
+    xy = oracle.undistort_points(np.stack([k["x"], k["y"]], 1), TUM1_K, TUM1_DIST)
+    assert np.array_equal(un["x"], xy[:, 0]) and np.array_equal(un["y"], xy[:, 1])
+    for f in ("size", "angle", "response", "octave"):
+        assert np.array_equal(un[f], k[f])
+    same = orbfe.UndistortKeyPoints(k, TUM1_K, np.zeros(5, np.float32))       # Frame.cc:359-363
+    assert np.array_equal(same, k)
+    with pytest.raises(RuntimeError):
+        orbfe.undistort_points(np.zeros((3, 2), np.float32), [0, 1, 2, 3], TUM1_DIST)
+
+
+@pytest.mark.gpu
+def test_undistort_keypoints_batch_device():
+    """Extractor records undistorted in place on the device, then matched over the undistorted bounds: the Frame
+    constructor's order (Frame.cc:204-233) for a distorted camera, against the oracle end to end.  Runs in its own
+    process because torch (device memory) has to initialise HIP before the library does."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "device_pipeline_case.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr

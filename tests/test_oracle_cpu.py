@@ -327,3 +327,45 @@ def test_search_by_projection_oracle_against_brute_force(oracle):
         assert got["best_dist"][i] == (d.min() if len(d) else 256)
         if len(d) > 1:
             assert got["second_dist"][i] == np.sort(d)[1]
+
+
+# ---------------------------------------------------------------- Frame glue: undistortion (Frame.cc:357-451)
+TUM1_K = np.array([517.306408, 516.469215, 318.643040, 255.313989], np.float32)
+TUM1_DIST = np.array([0.262383, -0.953104, -0.005358, 0.002628, 1.163314], np.float32)
+
+
+def _distort(xy, K, d):
+    """Forward Brown model in float64 (the model cv::undistortPoints inverts)."""
+    d = np.concatenate([d.astype(np.float64), np.zeros(12 - len(d))])
+    fx, fy, cx, cy = K.astype(np.float64)
+    x = (xy[:, 0].astype(np.float64) - cx) / fx; y = (xy[:, 1].astype(np.float64) - cy) / fy
+    r2 = x * x + y * y
+    cd = (1 + ((d[4] * r2 + d[1]) * r2 + d[0]) * r2) / (1 + ((d[7] * r2 + d[6]) * r2 + d[5]) * r2)
+    xd = x * cd + 2 * d[2] * x * y + d[3] * (r2 + 2 * x * x) + d[8] * r2 + d[9] * r2 * r2
+    yd = y * cd + d[2] * (r2 + 2 * y * y) + 2 * d[3] * x * y + d[10] * r2 + d[11] * r2 * r2
+    return np.stack([xd * fx + cx, yd * fy + cy], 1)
+
+
+def test_undistort_points_inverts_the_brown_model(oracle):
+    rng = np.random.default_rng(0)
+    pts = rng.uniform([0, 0], [640, 480], (2000, 2)).astype(np.float32)
+    un = oracle.undistort_points(pts, TUM1_K, TUM1_DIST)
+    back = _distort(un, TUM1_K, TUM1_DIST)
+    # five iterations converge to well under a pixel over the TUM1 image (OpenCV's fixed iteration count)
+    assert np.abs(back - pts).max() < 0.05
+    assert np.abs(un - pts).max() > 1.0                       # the distortion is not a no-op on this camera
+    # no coefficients: normalise + re-project only
+    same = oracle.undistort_points(pts, TUM1_K, np.zeros(0, np.float32))
+    assert np.abs(same - pts).max() < 1e-4
+    # the principal point is a fixed point
+    pp = oracle.undistort_points(TUM1_K[None, 2:4], TUM1_K, TUM1_DIST)
+    assert np.allclose(pp, TUM1_K[None, 2:4], atol=1e-4)
+
+
+def test_compute_image_bounds(oracle):
+    b = oracle.compute_image_bounds(640, 480, TUM1_K, TUM1_DIST)
+    c = oracle.undistort_points(np.array([[0, 0], [640, 0], [0, 480], [640, 480]], np.float32), TUM1_K, TUM1_DIST)
+    assert b[0] == min(c[0, 0], c[2, 0]) and b[2] == max(c[1, 0], c[3, 0])
+    assert b[1] == min(c[0, 1], c[1, 1]) and b[3] == max(c[2, 1], c[3, 1])
+    assert np.array_equal(oracle.compute_image_bounds(640, 480, TUM1_K, np.zeros(5, np.float32)), [0, 0, 640, 480])
+    assert np.array_equal(oracle.compute_image_bounds(640, 480, TUM1_K, np.zeros(0, np.float32)), [0, 0, 640, 480])
