@@ -225,6 +225,34 @@ int orbfe_aruco_debug_image(orbfe_aruco* h, int frame, int stage, uint8_t* out);
 int orbfe_aruco_set_aux_stream(orbfe_aruco* h, void* stream);
 int orbfe_aruco_debug_kernel_times(orbfe_aruco* h, float* out_us, int capacity);
 
+/* ------------------------------------------------------------------ marker pose (IPPE) -- */
+/* Marker pose: what MarkerDetector::detect adds to every marker when it is given camera parameters and a marker size
+ * (markerdetector_impl.cpp:8720-8780 -> Marker::calculateExtrinsics, marker.cpp:322-344 -> aruco::solvePnP, ippe.cpp:91-100)
+ * and what Frame.cc:170-174 asks for again to judge the ambiguity (aruco::solvePnP returning both IPPE solutions,
+ * ippe.cpp:72-89): rvec/tvec = the solution with the lower reprojection error (Marker::Rvec / Tvec as CV_32F), rvec2/tvec2
+ * the other one, err = their reprojection errors in pixels (Frame.cc:172: mvbArucoGood = err[0] / err[1] < 0.7).
+ * Object frame: marker centre, corners (-s/2, s/2, 0) (s/2, s/2, 0) (s/2, -s/2, 0) (-s/2, -s/2, 0) (marker.cpp:358-369). */
+typedef struct orbfe_marker_pose {
+    float rvec[3], tvec[3];
+    float rvec2[3], tvec2[3];
+    float err[2];
+} orbfe_marker_pose;
+
+/* CameraParameters::resize (cameraparameters.cpp:158-173): detect() rescales the camera matrix when the image size is not
+ * CamSize (markerdetector_impl.cpp:1110-1172; Frame.cc:132 fixes CamSize = 1280x720).  K4 = {fx, fy, cx, cy}. Host only. */
+int orbfe_camera_resize(const float* K4, int cam_width, int cam_height, int img_width, int img_height, float* K4_out);
+
+/* Poses of n markers (host pointers).  marker_size in metres (Frame.cc:131: 0.187); marker_size <= 0 or an empty camera
+ * matrix is ORBFE_ERR_INVALID (the reference throws cv::Exception 9004, marker.cpp:325-331).  dist as orbfe_undistort_points. */
+int orbfe_marker_poses(const orbfe_marker* markers, int n, float marker_size, const float* K4, const float* dist, int ndist,
+                       orbfe_marker_pose* poses, int device);
+
+/* The same over the detector's batch output on the device: frame f's first min(d_n[f], capacity) records of d_markers get
+ * a pose in the same slot of d_poses.  d_n == NULL: all `capacity` records of every frame. */
+int orbfe_marker_poses_batch_device(const orbfe_marker* d_markers, const int32_t* d_n, int capacity, int nframes,
+                                    float marker_size, const float* K4, const float* dist, int ndist,
+                                    orbfe_marker_pose* d_poses, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

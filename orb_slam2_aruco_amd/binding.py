@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("ORBFE_LIB", os.path.join(_HERE, "liborbfe.so"))
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
                      ("octave", "<i4"), ("class_id", "<i4")])
 MARKER_DTYPE = np.dtype([("id", "<i4"), ("corners", "<f4", (4, 2))])
+POSE_DTYPE = np.dtype([("rvec", "<f4", 3), ("tvec", "<f4", 3), ("rvec2", "<f4", 3), ("tvec2", "<f4", 3), ("err", "<f4", 2)])
 assert KP_DTYPE.itemsize == 28 and MARKER_DTYPE.itemsize == 36
 
 # every symbol include/orbfe.h declares (tests/test_abi.py checks the header against this list and the .so)
@@ -32,6 +33,7 @@ SYMBOLS = [
     "orbfe_aruco_create", "orbfe_aruco_destroy", "orbfe_aruco_set_dictionary", "orbfe_aruco_max_markers",
     "orbfe_aruco_detect", "orbfe_aruco_detect_batch", "orbfe_aruco_detect_batch_device", "orbfe_aruco_debug_image",
     "orbfe_aruco_debug_kernel_times", "orbfe_aruco_set_aux_stream",
+    "orbfe_camera_resize", "orbfe_marker_poses", "orbfe_marker_poses_batch_device",
 ]
 
 _lib = None
@@ -97,6 +99,9 @@ def load():
         L.orbfe_aruco_debug_image.argtypes = [vp, i32, i32, vp]
         L.orbfe_aruco_debug_kernel_times.argtypes = [vp, vp, i32]
         L.orbfe_aruco_set_aux_stream.argtypes = [vp, vp]
+        L.orbfe_camera_resize.argtypes = [vp, i32, i32, i32, i32, vp]
+        L.orbfe_marker_poses.argtypes = [vp, i32, f32, vp, vp, i32, vp, i32]
+        L.orbfe_marker_poses_batch_device.argtypes = [vp, vp, i32, i32, f32, vp, vp, i32, vp, vp]
     _lib = L
     return L
 
@@ -377,6 +382,27 @@ class ORBmatcher:
 RECT_DTYPE = np.dtype([("corners", "<f4", (4, 2)), ("off", "<i4"), ("len", "<i4")])
 
 
+def camera_resize(K, cam_size, img_size):
+    """CameraParameters::resize (cameraparameters.cpp:158-173); sizes are (width, height)."""
+    L = load()
+    K4, _ = _camera(K, None)
+    out = np.zeros(4, np.float32)
+    _check(L, L.orbfe_camera_resize(_p(K4), int(cam_size[0]), int(cam_size[1]), int(img_size[0]), int(img_size[1]), _p(out)),
+           "orbfe_camera_resize")
+    return out
+
+
+def marker_poses(markers, marker_size, K, dist, device=0):
+    """Both IPPE poses + reprojection errors of every marker (marker.cpp:322-344, ippe.cpp:72-100, Frame.cc:170-174)."""
+    L = load()
+    K4, d = _camera(K, dist)
+    mk = np.ascontiguousarray(markers, MARKER_DTYPE)
+    out = np.zeros(len(mk), POSE_DTYPE)
+    _check(L, L.orbfe_marker_poses(_p(mk), len(mk), marker_size, _p(K4), _p(d) if len(d) else None, len(d), _p(out), device),
+           "orbfe_marker_poses")
+    return out
+
+
 class MarkerDetector:
     """Mirror of aruco::MarkerDetector as the reference configures it (src/Frame.cc:129-142):
     setDictionary(name) + DM_NORMAL + CORNER_LINES; detect(image) -> markers sorted by id."""
@@ -399,7 +425,16 @@ class MarkerDetector:
     def setDictionary(self, name):
         _check(self.L, self.L.orbfe_aruco_set_dictionary(self.h, name.encode()), "orbfe_aruco_set_dictionary")
 
-    def detect(self, image):
+    def detect(self, image, camera=None, markerSizeMeters=-1.0):
+        """detect(image) -> MARKER_DTYPE records.  With camera = (K, dist, (cam_width, cam_height)) and a marker size
+        (markerdetector.h:276-312; Frame.cc:142 passes 0.187) -> (markers, POSE_DTYPE poses): the camera matrix is
+        rescaled to the image size first (markerdetector_impl.cpp:1110-1172), then every marker gets its IPPE pose."""
+        if camera is not None and markerSizeMeters > 0:
+            mk = self.detect(image)
+            K, dist, cam_size = camera
+            K4, d = _camera(K, dist)
+            rows, cols = np.asarray(image).shape[:2]
+            return mk, marker_poses(mk, markerSizeMeters, camera_resize(K4, cam_size, (cols, rows)), d)
         image = np.asarray(image)
         if image.size == 0:
             return np.zeros(0, MARKER_DTYPE)

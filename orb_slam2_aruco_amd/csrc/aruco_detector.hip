@@ -9,6 +9,7 @@
 #include <cmath>
 
 #include "aruco_kernels.hpp"
+#include "aruco_pose.hpp"
 #include "orbfe_common.hpp"
 #include "orbfe_tables.inc"
 
@@ -274,6 +275,37 @@ struct orbfe_aruco {
     }
 };
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Marker pose (reference detect :8720-8780 -> Marker::calculateExtrinsics, and Frame.cc:170): one lane per marker record.
+__global__ __launch_bounds__(64) void k_marker_poses(const orbfe_marker* __restrict__ markers, const int32_t* __restrict__ d_n,
+                                                    int capacity, float marker_size, PoseCamera cam,
+                                                    orbfe_marker_pose* __restrict__ poses)
+{
+    const int f = blockIdx.y, i = blockIdx.x * 64 + threadIdx.x;
+    const int n = d_n ? min(d_n[f], capacity) : capacity;
+    if (i >= n) return;
+    const orbfe_marker m = markers[(size_t)f * capacity + i];
+    orbfe_marker_pose out;
+    pose::solve_marker(m.corners, marker_size, cam, &out);
+    poses[(size_t)f * capacity + i] = out;
+}
+
+static int pose_camera(const float* K4, const float* dist, int ndist, float marker_size, PoseCamera& c, const char* who)
+{
+    if (!(marker_size > 0.0f)) return fail(ORBFE_ERR_INVALID, "%s: markerSize<=0: invalid markerSize", who); // marker.cpp:328-329
+    if (!K4 || ndist < 0 || ndist > 12 || (ndist && !dist) || !(K4[0] != 0.0f) || !(K4[1] != 0.0f))
+        return fail(ORBFE_ERR_INVALID, "%s: invalid camera (K = {fx, fy, cx, cy} with fx, fy != 0; at most 12 coefficients)", who);
+    c.fx = K4[0]; c.fy = K4[1]; c.cx = K4[2]; c.cy = K4[3];
+    for (int i = 0; i < 12; i++) c.k[i] = i < ndist ? (double)dist[i] : 0.0;
+    c.has_dist = ndist > 0;
+    return ORBFE_OK;
+}
+
+struct PoseWorkspace {
+    DevBuf markers, poses;
+};
+static thread_local PoseWorkspace* tl_pose_ws = nullptr;
+
 extern "C" {
 
 orbfe_aruco* orbfe_aruco_create(const char* dictionary, int device)
@@ -425,6 +457,55 @@ int orbfe_aruco_debug_kernel_times(orbfe_aruco* h, float* out_us, int capacity)
         return 0;
     }
     return h->timer.collect(out_us, capacity);
+}
+
+int orbfe_camera_resize(const float* K4, int cam_width, int cam_height, int img_width, int img_height, float* K4_out)
+{
+    if (!K4 || !K4_out || cam_width <= 0 || cam_height <= 0 || img_width <= 0 || img_height <= 0)
+        return fail(ORBFE_ERR_INVALID, "orbfe_camera_resize: invalid argument");
+    float k[4] = {K4[0], K4[1], K4[2], K4[3]};
+    if (!(img_width == cam_width && img_height == cam_height)) { // cameraparameters.cpp:162-172
+        const float ax = float(img_width) / float(cam_width), ay = float(img_height) / float(cam_height);
+        k[0] *= ax; k[2] *= ax; k[1] *= ay; k[3] *= ay;
+    }
+    for (int i = 0; i < 4; i++) K4_out[i] = k[i];
+    return ORBFE_OK;
+}
+
+int orbfe_marker_poses_batch_device(const orbfe_marker* d_markers, const int32_t* d_n, int capacity, int nframes,
+                                    float marker_size, const float* K4, const float* dist, int ndist,
+                                    orbfe_marker_pose* d_poses, void* stream)
+{
+    if (nframes < 0 || capacity < 0 || (nframes && capacity && (!d_markers || !d_poses)))
+        return fail(ORBFE_ERR_INVALID, "orbfe_marker_poses_batch_device: invalid argument");
+    PoseCamera c;
+    int rc = pose_camera(K4, dist, ndist, marker_size, c, "orbfe_marker_poses_batch_device");
+    if (rc) return rc;
+    if (nframes == 0 || capacity == 0) return ORBFE_OK;
+    hipLaunchKernelGGL(k_marker_poses, dim3((capacity + 63) / 64, nframes), dim3(64), 0, (hipStream_t)stream, d_markers, d_n,
+                       capacity, marker_size, c, d_poses);
+    ORBFE_HIP(hipGetLastError());
+    return ORBFE_OK;
+}
+
+int orbfe_marker_poses(const orbfe_marker* markers, int n, float marker_size, const float* K4, const float* dist, int ndist,
+                       orbfe_marker_pose* poses, int device)
+{
+    if (n < 0 || (n && (!markers || !poses))) return fail(ORBFE_ERR_INVALID, "orbfe_marker_poses: invalid argument");
+    PoseCamera c;
+    int rc = pose_camera(K4, dist, ndist, marker_size, c, "orbfe_marker_poses");
+    if (rc || (rc = use_device(device))) return rc;
+    if (n == 0) return ORBFE_OK;
+    if (!tl_pose_ws) tl_pose_ws = new PoseWorkspace();
+    PoseWorkspace& w = *tl_pose_ws;
+    if ((rc = w.markers.ensure((size_t)n * sizeof(orbfe_marker))) || (rc = w.poses.ensure((size_t)n * sizeof(orbfe_marker_pose))))
+        return rc;
+    ORBFE_HIP(hipMemcpy(w.markers.p, markers, (size_t)n * sizeof(orbfe_marker), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_marker_poses, dim3((n + 63) / 64, 1), dim3(64), 0, 0, w.markers.as<orbfe_marker>(), (const int32_t*)nullptr,
+                       n, marker_size, c, w.poses.as<orbfe_marker_pose>());
+    ORBFE_HIP(hipGetLastError());
+    ORBFE_HIP(hipMemcpy(poses, w.poses.p, (size_t)n * sizeof(orbfe_marker_pose), hipMemcpyDeviceToHost));
+    return ORBFE_OK;
 }
 
 } // extern "C"

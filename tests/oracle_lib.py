@@ -231,6 +231,27 @@ def compute_image_bounds(cols, rows, K4, dist):
     return out
 
 
+def marker_pose(corners, marker_size, K4, dist):
+    """-> (rvec1, tvec1, rvec2, tvec2) float64, err float32[2]"""
+    L = lib()
+    c = np.ascontiguousarray(corners, np.float32).reshape(4, 2)
+    K4 = np.ascontiguousarray(K4, np.float32); d = np.ascontiguousarray(dist, np.float32).reshape(-1)
+    out = np.zeros(12, np.float64); err = np.zeros(2, np.float32)
+    L.oracle_marker_pose.restype = None
+    L.oracle_marker_pose.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.oracle_marker_pose(_p(c), marker_size, _p(K4), _p(d) if len(d) else None, len(d), _p(out), _p(err))
+    return out[0:3], out[3:6], out[6:9], out[9:12], err
+
+
+def camera_resize(K4, cam_size, img_size):
+    L = lib()
+    K4 = np.ascontiguousarray(K4, np.float32); out = np.zeros(4, np.float32)
+    L.oracle_camera_resize.restype = None
+    L.oracle_camera_resize.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.oracle_camera_resize(_p(K4), cam_size[0], cam_size[1], img_size[0], img_size[1], _p(out))
+    return out
+
+
 def search_for_initialization(k1, d1, k2, d2, cols, rows, prev=None, window=100, nnratio=0.9, check_ori=True, bounds=None):
     L = lib()
     k1 = np.ascontiguousarray(k1); k2 = np.ascontiguousarray(k2)

@@ -369,3 +369,35 @@ def test_compute_image_bounds(oracle):
     assert b[1] == min(c[0, 1], c[1, 1]) and b[3] == max(c[2, 1], c[3, 1])
     assert np.array_equal(oracle.compute_image_bounds(640, 480, TUM1_K, np.zeros(5, np.float32)), [0, 0, 640, 480])
     assert np.array_equal(oracle.compute_image_bounds(640, 480, TUM1_K, np.zeros(0, np.float32)), [0, 0, 640, 480])
+
+
+# ---------------------------------------------------------------- marker pose (IPPE; marker.cpp:322-344, ippe.cpp)
+def test_marker_pose_recovers_synthetic_poses(oracle):
+    """The restated solver is pinned by geometry: corners projected from a known pose give that pose back (to the accuracy
+    of five undistortion iterations and float corners), and the second IPPE solution reprojects worse."""
+    import pose_cases as pc
+    for R, t, c in pc.random_cases(200, 7):
+        r1, t1, r2, t2, err = oracle.marker_pose(c, 0.187, pc.K4, pc.DIST)
+        assert err[0] <= err[1]
+        assert err[0] < 0.05, err
+        assert np.abs(pc.rodrigues(r1) - R).max() < 2e-2 and np.abs(t1 - t).max() < 5e-3 * t[2] + 1e-3
+        # both solutions are rotations and keep the marker in front of the camera
+        for r, tt in ((r1, t1), (r2, t2)):
+            Rm = pc.rodrigues(r)
+            assert np.allclose(Rm @ Rm.T, np.eye(3), atol=1e-9) and tt[2] > 0
+        # reported errors are what the poses reproject to
+        for r, tt, e in ((r1, t1, err[0]), (r2, t2, err[1])):
+            d = pc.project(pc.object_points(0.187), pc.rodrigues(r), tt).astype(np.float32) - c
+            assert abs(np.sqrt((d.astype(np.float64) ** 2).sum() / 8) - e) < 1e-3 + 1e-3 * e
+
+
+def test_marker_pose_scale_and_camera_resize(oracle):
+    import pose_cases as pc
+    R, t, c = pc.random_cases(1, 11)[0]
+    _, t1, _, _, _ = oracle.marker_pose(c, 0.187, pc.K4, pc.DIST)
+    _, t2, _, _, _ = oracle.marker_pose(c, 0.374, pc.K4, pc.DIST)
+    assert np.allclose(t2, 2 * t1, rtol=1e-6)                        # translation scales with the marker size
+    assert np.array_equal(oracle.camera_resize(pc.K4, (640, 480), (640, 480)), pc.K4)
+    k = oracle.camera_resize(pc.K4, (1280, 720), (640, 480))        # Frame.cc:132 hard-codes CamSize 1280x720
+    ax, ay = np.float32(640) / np.float32(1280), np.float32(480) / np.float32(720)
+    assert np.array_equal(k, np.array([pc.K4[0] * ax, pc.K4[1] * ay, pc.K4[2] * ax, pc.K4[3] * ay], np.float32))
