@@ -61,6 +61,11 @@ def make_stream(args, rank):
     return s
 
 
+TUM1_K = [517.306408, 516.469215, 318.643040, 255.313989]
+TUM1_DIST = [0.262383, -0.953104, -0.005358, 0.002628, 1.163314]
+MARKER_SIZE = 0.187   # Frame.cc:131
+
+
 def cpu_baseline(args, frames_u8):
     """The oracle (CPU port of the reference path) timed single-threaded on a bounded sample of the same stream."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -75,7 +80,9 @@ def cpu_baseline(args, frames_u8):
     for i in range(n):
         k, d = orb.extract(frames_u8[i])
         if aruco is not None:
-            aruco.detect(frames_u8[i])
+            K = O.camera_resize(np.array(TUM1_K, np.float32), (1280, 720), (args.cols, args.rows))
+            for m in aruco.detect(frames_u8[i]):
+                O.marker_pose(m["corners"], MARKER_SIZE, K, np.array(TUM1_DIST, np.float32))
         if res:
             pk, pd = res[-1]
             O.knn2(pd, d, 256)
@@ -84,7 +91,7 @@ def cpu_baseline(args, frames_u8):
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": "%d frames of the same %dx%d stream, oracle/ single thread (ORB%s + knn2 + SearchForInitialization)"
-                      % (n, args.cols, args.rows, " + ArUco" if aruco is not None else "")}
+                      % (n, args.cols, args.rows, " + ArUco incl. marker poses" if aruco is not None else "")}
 
 
 def main():
@@ -124,7 +131,7 @@ def main():
     cap = ex.capacity
     # Two sets of result records: the matching (third stream) and, on N > 1, the gather of batch i (communication stream)
     # overlap with batch i+1, which writes the other set.  A set is ONE contiguous buffer -- the record SURVEY 8e gathers:
-    # {n_kp, kp[cap] x 28 B, desc[cap] x 32 B, n_mk, markers[mcap] x 36 B} per frame -- so a batch is one collective.
+    # {n_kp, kp[cap] x 28 B, desc[cap] x 32 B, n_mk, markers[mcap] x 36 B, poses[mcap] x 56 B} per frame -- so a batch is one collective.
     use_aruco = not args.no_aruco
     mcap = binding.MarkerDetector(args.dictionary, device=local_rank).capacity if use_aruco else 0
     up = lambda v: (v + 255) // 256 * 256
@@ -132,7 +139,12 @@ def main():
     off_n = off_desc + up(B * cap * 32)
     off_mk = off_n + up(B * 4)
     off_nmk = off_mk + up(B * mcap * 36)
-    rec_bytes = off_nmk + up(B * 4)
+    off_pose = off_nmk + up(B * 4)
+    rec_bytes = off_pose + up(B * mcap * 56)
+    # camera of the reference's monocular example (Examples/Monocular/TUM1.yaml); the detector is handed CamSize 1280x720
+    # (Frame.cc:132), so the matrix is rescaled to the frame size before the marker poses (markerdetector_impl.cpp:1110-1172)
+    cam_K = binding.camera_resize(np.array(TUM1_K, np.float32), (1280, 720), (cols, rows)) if use_aruco else None
+    cam_D = np.array(TUM1_DIST, np.float32)
     recs = [torch.zeros(rec_bytes, dtype=torch.uint8, device=dev) for _ in range(2)]
     rec_ptr = [r.data_ptr() for r in recs]
     d_n = recs[0][off_n:off_n + B * 4].view(torch.int32)
@@ -189,6 +201,11 @@ def main():
                 dets[k].detect_batch_device(d_imgs.data_ptr() + f0 * rows * pitch, nf, rows * pitch, rows, cols, pitch,
                                             base + off_mk + f0 * mcap * 36, mcap, base + off_nmk + f0 * 4,
                                             ctypes.c_void_p(aru_streams[k].cuda_stream))
+                # detect(image, CameraParameters, 0.187): every marker gets its IPPE pose (markerdetector_impl.cpp:8720-8780)
+                binding._check(L, L.orbfe_marker_poses_batch_device(
+                    base + off_mk + f0 * mcap * 36, base + off_nmk + f0 * 4, mcap, nf, MARKER_SIZE,
+                    cam_K.ctypes.data_as(ctypes.c_void_p), cam_D.ctypes.data_as(ctypes.c_void_p), len(cam_D),
+                    base + off_pose + f0 * mcap * 56, ctypes.c_void_p(aru_streams[k].cuda_stream)), "orbfe_marker_poses_batch_device")
                 det_done[i % 2][k].record(aru_streams[k])
         if not args.no_orb:
             for k in range(S):
@@ -316,7 +333,7 @@ def main():
             "config": {"workload": "C2: %d-frame %dx%d mono stream per GPU, nFeatures=%d, %d levels, %s dictionary; "
                                    "per frame: ORB extract%s + knn2 all-pairs + SearchForInitialization vs previous frame"
                                    % (B, cols, rows, args.nfeatures, args.nlevels, args.dictionary,
-                                      " + ArUco detect" if use_aruco else " (ArUco leg DISABLED: diagnostic run)"),
+                                      " + ArUco detect incl. IPPE marker poses" if use_aruco else " (ArUco leg DISABLED: diagnostic run)"),
                        "frames_per_step_per_gpu": B, "mean_keypoints_per_frame": N,
                        "sub_batches": S,
                        "parallelism": "stream-per-gpu x%d, RCCL gather to rank 0" % world},
