@@ -183,6 +183,41 @@ int orbfe_search_for_initialization_batch_device(const orbfe_keypoint* d_kps, co
                                                  int window_size, float nnratio, int check_orientation,
                                                  int32_t* d_matches12, int32_t* d_nmatches, void* stream);
 
+/* ------------------------------------------------------------------ DBoW2 vocabulary transform -- */
+/* ORBVocabulary (= DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>, include/ORBVocabulary.h) as Frame::ComputeBoW and
+ * KeyFrame::ComputeBoW use it (src/Frame.cc:348-355, src/KeyFrame.cc): transform(descriptors, BowVector, FeatureVector, 4).
+ * The handle owns the tree in HBM.  scoring / weighting are DBoW2's enums (BowVector.h:37-55): weighting 0 TF_IDF, 1 TF,
+ * 2 IDF, 3 BINARY; scoring 0 L1_NORM .. 5 DOT_PRODUCT (decides the normalisation, ScoringObject.h:74-91). */
+typedef struct orbfe_vocabulary orbfe_vocabulary;
+
+/* TemplatedVocabulary::loadFromTextFile (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1338-1425; System.cc loads
+ * ORBvoc.txt with it): "k L scoring weighting" then one line per node "parent isLeaf d0..d31 weight".  An empty line --
+ * the one the reference's `while(!f.eof())` reads after the file's last newline -- becomes a node exactly as there (child of
+ * the root, no word, weight 0; its descriptor, left unset by the reference, is zero here).  NULL + orbfe_last_error() on failure. */
+orbfe_vocabulary* orbfe_vocabulary_load_text(const char* filename, int device);
+/* The same tree from arrays: nodes 1..nnodes in file order (the root, node 0, is implicit; parent[i] refers to node ids, so
+ * parent[i] <= i); descriptors nnodes x 32 bytes; weights as parsed. */
+orbfe_vocabulary* orbfe_vocabulary_create(int k, int L, int scoring, int weighting, int nnodes, const int32_t* parent,
+                                          const uint8_t* is_leaf, const uint8_t* descriptors, const double* weights, int device);
+void orbfe_vocabulary_destroy(orbfe_vocabulary* v);
+int orbfe_vocabulary_info(const orbfe_vocabulary* v, int32_t* out6); /* k, L, scoring, weighting, nodes (incl. root), words */
+
+/* transform(features, v, fv, levelsup) (TemplatedVocabulary.h:1127-1194) for one frame, host pointers.  Per feature
+ * (each may be NULL): word_id, node_id (the ancestor at level L - levelsup, :1218-1259), weight.  The two vectors (all
+ * seven pointers or none): BowVector as *nbow (word id ascending, value) pairs; FeatureVector as *nfv node ids ascending
+ * with fv_offset[0..*nfv] into fv_feature (feature indices ascending within a node).  Capacity of every array: n
+ * (fv_offset: n + 1).  Bit-exact doubles: weights are added and normalised in the reference's map order.
+ * n > 4096 with vectors is ORBFE_ERR_CAPACITY. */
+int orbfe_vocabulary_transform(orbfe_vocabulary* v, const uint8_t* desc, int n, int levelsup, int32_t* word_id, int32_t* node_id,
+                               double* weight, uint32_t* bow_word, double* bow_value, int32_t* nbow, uint32_t* fv_node,
+                               int32_t* fv_offset, uint32_t* fv_feature, int32_t* nfv);
+/* Batch on the device over the extractor's output (blocks of `capacity` records per frame, d_n[f] valid; fv_offset
+ * blocks are capacity + 1).  d_word / d_node / d_weight are required (scratch for the vector kernel). */
+int orbfe_vocabulary_transform_batch_device(orbfe_vocabulary* v, const uint8_t* d_desc, const int32_t* d_n, int capacity, int nframes,
+                                            int levelsup, int32_t* d_word, int32_t* d_node, double* d_weight, uint32_t* d_bow_word,
+                                            double* d_bow_value, int32_t* d_nbow, uint32_t* d_fv_node, int32_t* d_fv_offset,
+                                            uint32_t* d_fv_feature, int32_t* d_nfv, void* stream);
+
 /* ------------------------------------------------------------------ Frame glue: undistortion -- */
 /* cv::undistortPoints(src, dst, K, distCoeffs, noArray(), K) (OpenCV 3.4: 5 fixed-point iterations in double) on n
  * (x, y) float pairs -- what Frame::UndistortKeyPoints (src/Frame.cc:357-387) and Frame::UndistortArucoCorners

@@ -34,6 +34,8 @@ SYMBOLS = [
     "orbfe_aruco_detect", "orbfe_aruco_detect_batch", "orbfe_aruco_detect_batch_device", "orbfe_aruco_debug_image",
     "orbfe_aruco_debug_kernel_times", "orbfe_aruco_set_aux_stream",
     "orbfe_camera_resize", "orbfe_marker_poses", "orbfe_marker_poses_batch_device",
+    "orbfe_vocabulary_load_text", "orbfe_vocabulary_create", "orbfe_vocabulary_destroy", "orbfe_vocabulary_info",
+    "orbfe_vocabulary_transform", "orbfe_vocabulary_transform_batch_device",
 ]
 
 _lib = None
@@ -100,6 +102,16 @@ def load():
         L.orbfe_aruco_debug_kernel_times.argtypes = [vp, vp, i32]
         L.orbfe_aruco_set_aux_stream.argtypes = [vp, vp]
         L.orbfe_camera_resize.argtypes = [vp, i32, i32, i32, i32, vp]
+    if hasattr(L, "orbfe_vocabulary_create"):
+        L.orbfe_vocabulary_load_text.restype = vp
+        L.orbfe_vocabulary_load_text.argtypes = [C.c_char_p, i32]
+        L.orbfe_vocabulary_create.restype = vp
+        L.orbfe_vocabulary_create.argtypes = [i32, i32, i32, i32, i32, vp, vp, vp, vp, i32]
+        L.orbfe_vocabulary_destroy.restype = None
+        L.orbfe_vocabulary_destroy.argtypes = [vp]
+        L.orbfe_vocabulary_info.argtypes = [vp, vp]
+        L.orbfe_vocabulary_transform.argtypes = [vp, vp, i32, i32] + [vp] * 10
+        L.orbfe_vocabulary_transform_batch_device.argtypes = [vp, vp, vp, i32, i32, i32] + [vp] * 11
         L.orbfe_marker_poses.argtypes = [vp, i32, f32, vp, vp, i32, vp, i32]
         L.orbfe_marker_poses_batch_device.argtypes = [vp, vp, i32, i32, f32, vp, vp, i32, vp, vp]
     _lib = L
@@ -401,6 +413,61 @@ def marker_poses(markers, marker_size, K, dist, device=0):
     _check(L, L.orbfe_marker_poses(_p(mk), len(mk), marker_size, _p(K4), _p(d) if len(d) else None, len(d), _p(out), device),
            "orbfe_marker_poses")
     return out
+
+
+class ORBVocabulary:
+    """Mirror of ORB_SLAM2::ORBVocabulary (include/ORBVocabulary.h: DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>) for
+    the per-frame path: loadFromTextFile + transform(features, BowVector, FeatureVector, levelsup)."""
+
+    def __init__(self, device=0):
+        self.L = load()
+        self.h = None
+        self.device = device
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orbfe_vocabulary_destroy(self.h)
+            self.h = None
+
+    def loadFromTextFile(self, filename):
+        if self.h:
+            self.L.orbfe_vocabulary_destroy(self.h)
+        self.h = self.L.orbfe_vocabulary_load_text(os.fsencode(filename), self.device)
+        if not self.h:
+            raise OrbfeError("orbfe_vocabulary_load_text: " + self.L.orbfe_last_error().decode())
+        return True
+
+    @classmethod
+    def from_arrays(cls, k, L, scoring, weighting, parent, is_leaf, descriptors, weights, device=0):
+        self = cls(device)
+        parent = np.ascontiguousarray(parent, np.int32); is_leaf = np.ascontiguousarray(is_leaf, np.uint8)
+        descriptors = np.ascontiguousarray(descriptors, np.uint8).reshape(-1, 32)
+        weights = np.ascontiguousarray(weights, np.float64)
+        self.h = self.L.orbfe_vocabulary_create(k, L, scoring, weighting, len(parent), _p(parent), _p(is_leaf), _p(descriptors),
+                                                _p(weights), device)
+        if not self.h:
+            raise OrbfeError("orbfe_vocabulary_create: " + self.L.orbfe_last_error().decode())
+        return self
+
+    def info(self):
+        out = np.zeros(6, np.int32)
+        _check(self.L, self.L.orbfe_vocabulary_info(self.h, _p(out)), "orbfe_vocabulary_info")
+        return dict(zip(("k", "L", "scoring", "weighting", "nodes", "words"), out.tolist()))
+
+    def transform(self, descriptors, levelsup=4):
+        """-> dict(word, node, weight per feature; bow = (word ids, values); fv = (node ids, offsets, feature indices))"""
+        d = np.ascontiguousarray(descriptors, np.uint8).reshape(-1, 32)
+        n = len(d)
+        word = np.zeros(n, np.int32); node = np.zeros(n, np.int32); weight = np.zeros(n, np.float64)
+        bw = np.zeros(n, np.uint32); bv = np.zeros(n, np.float64); fn = np.zeros(n, np.uint32)
+        fo = np.zeros(n + 1, np.int32); ff = np.zeros(n, np.uint32)
+        nb, nf = C.c_int32(0), C.c_int32(0)
+        _check(self.L, self.L.orbfe_vocabulary_transform(self.h, _p(d), n, levelsup, _p(word), _p(node), _p(weight), _p(bw), _p(bv),
+                                                         C.byref(nb), _p(fn), _p(fo), _p(ff), C.byref(nf)),
+               "orbfe_vocabulary_transform")
+        nb, nf = nb.value, nf.value
+        return dict(word=word, node=node, weight=weight, bow=(bw[:nb].copy(), bv[:nb].copy()),
+                    fv=(fn[:nf].copy(), fo[:nf + 1].copy(), ff[:fo[nf]].copy()))
 
 
 class MarkerDetector:

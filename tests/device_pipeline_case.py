@@ -48,4 +48,29 @@ wn, wm, wp = oracle.search_for_initialization(k1, d1, k2, d2, 640, 480, None, 10
 gn, gm, gp = orbfe.ORBmatcher(0.9, True).SearchForInitialization(kh[0, :nh[0]], dh[0, :nh[0]], kh[1, :nh[1]], dh[1, :nh[1]],
                                                                  640, 480, None, 100, bounds=bounds)
 assert gn == wn and np.array_equal(gm, wm) and np.array_equal(gp, wp)
+
+# ---- ComputeBoW over the batch on the device (Frame.cc:348-355): per-frame vectors against the oracle
+import voc_cases as vc
+voc = vc.make(10, 4, 41, irregular=False)
+ovoc = oracle.VocabularyOracle.from_arrays(10, 4, 0, 0, voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"])
+gvoc = orbfe.ORBVocabulary.from_arrays(10, 4, 0, 0, voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"])
+i32 = lambda *shape: torch.zeros(*shape, dtype=torch.int32, device=dev)
+word, node, weight = i32(3 * cap), i32(3 * cap), torch.zeros(3 * cap, dtype=torch.float64, device=dev)
+bw, bv, nb = i32(3 * cap), torch.zeros(3 * cap, dtype=torch.float64, device=dev), i32(3)
+fn, fo, ff, nf = i32(3 * cap), i32(3 * (cap + 1)), i32(3 * cap), i32(3)
+rc = L.orbfe_vocabulary_transform_batch_device(gvoc.h, desc.data_ptr(), n.data_ptr(), cap, 3, 4, word.data_ptr(), node.data_ptr(),
+                                               weight.data_ptr(), bw.data_ptr(), bv.data_ptr(), nb.data_ptr(), fn.data_ptr(),
+                                               fo.data_ptr(), ff.data_ptr(), nf.data_ptr(), None)
+assert rc == 0, L.orbfe_last_error()
+torch.cuda.synchronize()
+for f in range(3):
+    want = ovoc.transform(frames[f][1], 4)
+    k = int(nb[f]); j = int(nf[f])
+    assert np.array_equal(bw[f * cap:f * cap + k].cpu().numpy().view(np.uint32), want["bow"][0])
+    assert np.array_equal(bv[f * cap:f * cap + k].cpu().numpy().view(np.uint64), want["bow"][1].view(np.uint64))
+    assert np.array_equal(fn[f * cap:f * cap + j].cpu().numpy().view(np.uint32), want["fv"][0])
+    off = fo[f * (cap + 1):f * (cap + 1) + j + 1].cpu().numpy()
+    assert np.array_equal(off, want["fv"][1])
+    assert np.array_equal(ff[f * cap:f * cap + off[-1]].cpu().numpy().view(np.uint32), want["fv"][2])
+print("bow ok")
 print("ok")

@@ -252,6 +252,65 @@ def camera_resize(K4, cam_size, img_size):
     return out
 
 
+class VocabularyOracle:
+    def __init__(self, handle):
+        self.L = lib()
+        self.h = handle
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.oracle_voc_destroy.argtypes = [C.c_void_p]
+            self.L.oracle_voc_destroy(self.h)
+            self.h = None
+
+    @classmethod
+    def load_text(cls, filename):
+        L = lib()
+        L.oracle_voc_load_text.restype = C.c_void_p
+        L.oracle_voc_load_text.argtypes = [C.c_char_p]
+        h = L.oracle_voc_load_text(os.fsencode(filename))
+        if not h:
+            raise RuntimeError("oracle_voc_load_text failed")
+        return cls(h)
+
+    @classmethod
+    def from_arrays(cls, k, Lv, scoring, weighting, parent, is_leaf, descriptors, weights):
+        L = lib()
+        L.oracle_voc_create.restype = C.c_void_p
+        L.oracle_voc_create.argtypes = [C.c_int] * 4
+        L.oracle_voc_add_node.restype = None
+        L.oracle_voc_add_node.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_double]
+        h = L.oracle_voc_create(k, Lv, scoring, weighting)
+        d = np.ascontiguousarray(descriptors, np.uint8).reshape(-1, 32)
+        for i in range(len(parent)):
+            L.oracle_voc_add_node(h, int(parent[i]), int(is_leaf[i]), _p(d[i]), float(weights[i]))
+        return cls(h)
+
+    def info(self):
+        out = np.zeros(6, np.int32)
+        self.L.oracle_voc_info.restype = None
+        self.L.oracle_voc_info.argtypes = [C.c_void_p, C.c_void_p]
+        self.L.oracle_voc_info(self.h, _p(out))
+        return dict(zip(("k", "L", "scoring", "weighting", "nodes", "words"), out.tolist()))
+
+    def transform(self, descriptors, levelsup=4):
+        d = np.ascontiguousarray(descriptors, np.uint8).reshape(-1, 32)
+        n = len(d)
+        word = np.zeros(n, np.int32); node = np.zeros(n, np.int32); weight = np.zeros(n, np.float64)
+        self.L.oracle_voc_transform_features.restype = None
+        self.L.oracle_voc_transform_features.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        self.L.oracle_voc_transform_features(self.h, _p(d), n, levelsup, _p(word), _p(node), _p(weight))
+        bw = np.zeros(max(n, 1), np.uint32); bv = np.zeros(max(n, 1), np.float64); fn = np.zeros(max(n, 1), np.uint32)
+        fo = np.zeros(n + 1, np.int32); ff = np.zeros(max(n, 1), np.uint32)
+        nb, nf = C.c_int32(0), C.c_int32(0)
+        self.L.oracle_voc_transform.restype = None
+        self.L.oracle_voc_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7
+        self.L.oracle_voc_transform(self.h, _p(d), n, levelsup, _p(bw), _p(bv), C.byref(nb), _p(fn), _p(fo), _p(ff), C.byref(nf))
+        nb, nf = nb.value, nf.value
+        return dict(word=word, node=node, weight=weight, bow=(bw[:nb].copy(), bv[:nb].copy()),
+                    fv=(fn[:nf].copy(), fo[:nf + 1].copy(), ff[:fo[nf]].copy()))
+
+
 def search_for_initialization(k1, d1, k2, d2, cols, rows, prev=None, window=100, nnratio=0.9, check_ori=True, bounds=None):
     L = lib()
     k1 = np.ascontiguousarray(k1); k2 = np.ascontiguousarray(k2)

@@ -1,0 +1,86 @@
+"""GPU parity: DBoW2 vocabulary transform through the C ABI vs the CPU oracle -- bit-exact, doubles included (the weights
+are added and normalised in the reference's map order on both sides)."""
+import numpy as np
+import pytest
+
+import voc_cases as vc
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(got, want):
+    for f in ("word", "node", "weight"):
+        assert np.array_equal(got[f], want[f]), f
+    assert np.array_equal(got["bow"][0], want["bow"][0])
+    assert np.array_equal(got["bow"][1].view(np.uint64), want["bow"][1].view(np.uint64))
+    for a, b in zip(got["fv"], want["fv"]):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("k,L,seed,levelsup,nfeat", [(10, 3, 1, 1, 1000), (4, 5, 2, 4, 2000), (10, 4, 3, 2, 4096), (3, 2, 4, 4, 7),
+                                                     (10, 5, 5, 4, 1000)])
+def test_transform_matches_oracle(orbfe, oracle, k, L, seed, levelsup, nfeat):
+    voc = vc.make(k, L, seed)
+    o = oracle.VocabularyOracle.from_arrays(k, L, 0, 0, voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"])
+    g = orbfe.ORBVocabulary.from_arrays(k, L, 0, 0, voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"])
+    assert g.info() == o.info()
+    feats = vc.features(voc, nfeat, seed)
+    _same(g.transform(feats, levelsup), o.transform(feats, levelsup))
+    empty = g.transform(np.zeros((0, 32), np.uint8), levelsup)
+    assert len(empty["bow"][0]) == 0 and len(empty["fv"][0]) == 0
+
+
+@pytest.mark.parametrize("weighting,scoring", [(0, 0), (1, 0), (2, 1), (3, 2), (0, 5), (1, 5), (2, 5)])
+def test_weighting_and_scoring_types(orbfe, oracle, weighting, scoring):
+    """TF_IDF / TF / IDF / BINARY x (L1 | L2 | no normalisation): TemplatedVocabulary.h:1145-1193, ScoringObject.h:74-91."""
+    voc = vc.make(8, 3, 11, weighting=weighting, scoring=scoring)
+    o = oracle.VocabularyOracle.from_arrays(8, 3, scoring, weighting, voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"])
+    g = orbfe.ORBVocabulary.from_arrays(8, 3, scoring, weighting, voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"])
+    feats = vc.features(voc, 1500, 12)
+    _same(g.transform(feats, 1), o.transform(feats, 1))
+
+
+def test_text_loader_and_phantom_node(orbfe, oracle, tmp_path):
+    voc = vc.make(10, 3, 21)
+    feats = vc.features(voc, 800, 22)
+    p = tmp_path / "voc.txt"
+    for trailing in (False, True):
+        vc.write_text(voc, p, trailing_newline=trailing)
+        o = oracle.VocabularyOracle.load_text(str(p))
+        g = orbfe.ORBVocabulary()
+        assert g.loadFromTextFile(str(p))
+        assert g.info() == o.info()
+        assert g.info()["nodes"] == len(voc["parent"]) + 1 + (1 if trailing else 0)
+        _same(g.transform(feats, 2), o.transform(feats, 2))
+    with pytest.raises(RuntimeError):
+        orbfe.ORBVocabulary().loadFromTextFile(str(tmp_path / "missing.txt"))
+    (tmp_path / "bad.txt").write_text("30 3 0 0\n")
+    with pytest.raises(RuntimeError):                     # k > 20: "This is not a correct text file!"
+        orbfe.ORBVocabulary().loadFromTextFile(str(tmp_path / "bad.txt"))
+    (tmp_path / "bad2.txt").write_text("10 3 0 0\n0 1 1 2 3\n")
+    with pytest.raises(RuntimeError):
+        orbfe.ORBVocabulary().loadFromTextFile(str(tmp_path / "bad2.txt"))
+
+
+def test_empty_vocabulary_and_capacity(orbfe):
+    g = orbfe.ORBVocabulary.from_arrays(10, 3, 0, 0, np.zeros(0, np.int32), np.zeros(0, np.uint8), np.zeros((0, 32), np.uint8),
+                                        np.zeros(0))
+    r = g.transform(np.zeros((5, 32), np.uint8), 4)       # empty(): both vectors stay empty (:1134-1137)
+    assert len(r["bow"][0]) == 0 and len(r["fv"][0]) == 0
+    voc = vc.make(4, 2, 1)
+    g = orbfe.ORBVocabulary.from_arrays(4, 2, 0, 0, voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"])
+    with pytest.raises(RuntimeError):
+        g.transform(np.zeros((4097, 32), np.uint8), 4)
+
+
+def test_extracted_frame_descriptors(orbfe, oracle):
+    """Real extractor output through a vocabulary at the reference's levelsup = 4 (Frame.cc:353)."""
+    from orb_slam2_aruco_amd import synth
+    voc = vc.make(10, 5, 31, irregular=False)
+    o = oracle.VocabularyOracle.from_arrays(10, 5, 0, 0, voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"])
+    g = orbfe.ORBVocabulary.from_arrays(10, 5, 0, 0, voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"])
+    img = synth.stream(480, 640, 1, 1000)[0]
+    _, d = orbfe.ORBextractor(1000, 1.2, 8, 20, 7)(img)
+    got = g.transform(d, 4)
+    _same(got, o.transform(d, 4))
+    assert abs(got["bow"][1].sum() - 1.0) < 1e-12 and len(got["fv"][0]) <= 10

@@ -401,3 +401,67 @@ def test_marker_pose_scale_and_camera_resize(oracle):
     k = oracle.camera_resize(pc.K4, (1280, 720), (640, 480))        # Frame.cc:132 hard-codes CamSize 1280x720
     ax, ay = np.float32(640) / np.float32(1280), np.float32(480) / np.float32(720)
     assert np.array_equal(k, np.array([pc.K4[0] * ax, pc.K4[1] * ay, pc.K4[2] * ax, pc.K4[3] * ay], np.float32))
+
+
+# ---------------------------------------------------------------- DBoW2 vocabulary transform (TemplatedVocabulary.h)
+def _brute_transform(voc, feats, levelsup):
+    """Independent numpy restatement of the tree descent (no shared code with oracle/bow_oracle.cpp)."""
+    parent = np.concatenate([[0], voc["parent"]]); n = len(parent)
+    children = [[] for _ in range(n)]
+    for i in range(1, n):
+        children[parent[i]].append(i)
+    desc = np.concatenate([np.zeros((1, 32), np.uint8), voc["desc"]])
+    wid = np.zeros(n, np.int64); wid[1:][voc["is_leaf"] > 0] = np.arange(int((voc["is_leaf"] > 0).sum()))
+    weight = np.concatenate([[0.0], voc["weight"]])
+    out = []
+    for f in feats:
+        node, level, nid, nid_level = 0, 0, None, voc["L"] - levelsup
+        if nid_level <= 0:
+            nid = 0
+        while children[node]:
+            ch = children[node]
+            d = np.unpackbits(desc[ch] ^ f, axis=1).sum(1)
+            node = ch[int(np.argmin(d))]                  # argmin = first minimum, like the strict '<'
+            level += 1
+            if level == nid_level:
+                nid = node
+        out.append((wid[node], node if nid is None else nid, weight[node]))
+    return out
+
+
+@pytest.mark.parametrize("k,L,seed,levelsup", [(10, 3, 1, 1), (4, 5, 2, 4), (10, 4, 3, 2), (3, 2, 4, 4)])
+def test_vocabulary_transform_oracle(oracle, k, L, seed, levelsup, tmp_path):
+    import voc_cases as vc
+    voc = vc.make(k, L, seed)
+    o = oracle.VocabularyOracle.from_arrays(k, L, 0, 0, voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"])
+    feats = vc.features(voc, 400, seed)
+    got = o.transform(feats, levelsup)
+    want = _brute_transform(voc, feats, levelsup)
+    assert np.array_equal(got["word"], [w[0] for w in want])
+    assert np.array_equal(got["node"], [w[1] for w in want])
+    assert np.array_equal(got["weight"], [w[2] for w in want])
+    # BowVector = per-word sums, L1-normalised; FeatureVector = features grouped by node, both over weight > 0 only
+    keep = got["weight"] > 0
+    assert 0 < keep.sum() < len(feats)                    # the stop words drop some
+    words, vals = got["bow"]
+    assert np.array_equal(words, np.unique(got["word"][keep])) and abs(vals.sum() - 1.0) < 1e-12
+    raw = np.array([got["weight"][keep][got["word"][keep] == w].sum() for w in words])
+    assert np.allclose(vals, raw / raw.sum(), rtol=1e-12)
+    nodes, off, feat = got["fv"]
+    assert np.array_equal(nodes, np.unique(got["node"][keep])) and off[0] == 0 and off[-1] == keep.sum()
+    for j, nd in enumerate(nodes):
+        assert np.array_equal(feat[off[j]:off[j + 1]], np.flatnonzero(keep & (got["node"] == nd)))
+    # the text loader builds the same tree; a trailing newline adds the reference's phantom root child
+    p = tmp_path / "voc.txt"
+    vc.write_text(voc, p, trailing_newline=False)
+    t = oracle.VocabularyOracle.load_text(str(p))
+    assert t.info() == o.info()
+    g2 = t.transform(feats, levelsup)
+    assert all(np.array_equal(g2[f], got[f]) for f in ("word", "node", "weight"))
+    vc.write_text(voc, p, trailing_newline=True)
+    t2 = oracle.VocabularyOracle.load_text(str(p))
+    assert t2.info()["nodes"] == o.info()["nodes"] + 1 and t2.info()["words"] == o.info()["words"]
+    g3 = t2.transform(feats, levelsup)
+    sparse = np.unpackbits(feats, axis=1).sum(1) == 1
+    assert np.all(g3["weight"][sparse] == 0)              # one-bit descriptors sit closest to the all-zero phantom: dropped
+    assert np.array_equal(g3["word"][~sparse], got["word"][~sparse])
