@@ -218,6 +218,29 @@ int orbfe_vocabulary_transform_batch_device(orbfe_vocabulary* v, const uint8_t* 
                                             double* d_bow_value, int32_t* d_nbow, uint32_t* d_fv_node, int32_t* d_fv_offset,
                                             uint32_t* d_fv_feature, int32_t* d_nfv, void* stream);
 
+/* ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (src/ORBmatcher.cc:159-292) and SearchByBoW(KeyFrame*,
+ * KeyFrame*, vpMatches12) (:526-659) on flat arrays: side 1 = the keyframe whose map points are looked for, side 2 = the
+ * frame / second keyframe, each with the FeatureVector orbfe_vocabulary_transform returned.  valid1[i] != 0 = "feature i has
+ * a map point that is not bad" (:196-201; NULL = all); valid2 the same for side 2 (the KF-KF variant, :583-590; NULL = the
+ * KF-Frame variant).  The variants also differ in accept_max (best <= TH_LOW = 50, :233, vs best < TH_LOW, :608 -> 49) and
+ * factor (this fork's HISTO_LENGTH / 360.0f, :174, vs 1.0f / HISTO_LENGTH, :546).  match12[i1] = i2 or -1 and match21[i2] =
+ * i1 or -1 (vpMapPointMatches[i2] = map point of match21[i2]; vpMatches12[i1] = map point of match12[i1]); *nmatches is the
+ * return value.  At most 4096 features per side.  Host pointers. */
+int orbfe_search_by_bow(const orbfe_keypoint* kps1, const uint8_t* desc1, const uint8_t* valid1, int n1, const uint32_t* fv_node1,
+                        const int32_t* fv_offset1, const uint32_t* fv_feature1, int nfv1, const orbfe_keypoint* kps2,
+                        const uint8_t* desc2, const uint8_t* valid2, int n2, const uint32_t* fv_node2, const int32_t* fv_offset2,
+                        const uint32_t* fv_feature2, int nfv2, float nnratio, int check_orientation, int accept_max, float factor,
+                        int32_t* match12, int32_t* match21, int32_t* nmatches, int device);
+/* Batch over npairs pairs of frames of one set of per-frame blocks (the layouts of orbfe_extract_batch_device and
+ * orbfe_vocabulary_transform_batch_device; d_valid may be NULL): pair p matches frame d_pair1[p] (side 1) with frame
+ * d_pair2[p] (side 2); NULL index arrays mean p and p + 1.  use_valid2 != 0 applies d_valid to side 2 as well.
+ * d_match12 / d_match21 are blocks of `capacity` per pair. */
+int orbfe_search_by_bow_batch_device(const orbfe_keypoint* d_kps, const uint8_t* d_desc, const uint8_t* d_valid, const int32_t* d_n,
+                                     const uint32_t* d_fv_node, const int32_t* d_fv_offset, const uint32_t* d_fv_feature,
+                                     const int32_t* d_nfv, int capacity, const int32_t* d_pair1, const int32_t* d_pair2, int npairs,
+                                     int use_valid2, float nnratio, int check_orientation, int accept_max, float factor,
+                                     int32_t* d_match12, int32_t* d_match21, int32_t* d_nmatches, void* stream);
+
 /* ------------------------------------------------------------------ Frame glue: undistortion -- */
 /* cv::undistortPoints(src, dst, K, distCoeffs, noArray(), K) (OpenCV 3.4: 5 fixed-point iterations in double) on n
  * (x, y) float pairs -- what Frame::UndistortKeyPoints (src/Frame.cc:357-387) and Frame::UndistortArucoCorners

@@ -334,6 +334,85 @@ void oracle_compute_image_bounds(int cols, int rows, const float* K4, const floa
     }
 }
 
+/* ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (src/ORBmatcher.cc:159-292) and
+ * SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12) (:526-659) on flat arrays.  Side 1 = the keyframe whose map points are
+ * looked for, side 2 = the frame / second keyframe.  valid1[i] = "has a map point that is not bad" (:196-201, :564-568),
+ * valid2 likewise for the KF-KF variant (:583-590; NULL = every feature, the KF-Frame variant).  The two variants differ
+ * in the accept test (best <= TH_LOW :233 vs best < TH_LOW :608: pass accept_max = 50 or 49) and in the histogram factor
+ * (HISTO_LENGTH/360.0f :174 in this fork vs 1.0f/HISTO_LENGTH :546).  Outputs: match12[i1] = i2 or -1, match21[i2] = i1 or
+ * -1 (the reference's vpMapPointMatches[i2] = map point of match21[i2]; vpMatches12[i1] = map point of match12[i1]). */
+int oracle_search_by_bow(const void* kps1_, const uint8_t* desc1, const uint8_t* valid1, int n1, const uint32_t* fv_node1,
+                         const int32_t* fv_off1, const uint32_t* fv_feat1, int nfv1, const void* kps2_, const uint8_t* desc2,
+                         const uint8_t* valid2, int n2, const uint32_t* fv_node2, const int32_t* fv_off2, const uint32_t* fv_feat2,
+                         int nfv2, float nnratio, int check_orientation, int accept_max, float factor, int32_t* match12,
+                         int32_t* match21)
+{
+    const KeyPoint* k1 = (const KeyPoint*)kps1_;
+    const KeyPoint* k2 = (const KeyPoint*)kps2_;
+    for (int i = 0; i < n1; i++) match12[i] = -1;
+    for (int i = 0; i < n2; i++) match21[i] = -1;
+    int nmatches = 0;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    int a = 0, b = 0;
+    while (a != nfv1 && b != nfv2) {
+        if (fv_node1[a] == fv_node2[b]) {
+            for (int p1 = fv_off1[a]; p1 < fv_off1[a + 1]; p1++) {
+                const int idx1 = (int)fv_feat1[p1];
+                if (valid1 && !valid1[idx1]) continue;
+                const uint8_t* d1 = desc1 + 32 * (size_t)idx1;
+                int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+                for (int p2 = fv_off2[b]; p2 < fv_off2[b + 1]; p2++) {
+                    const int idx2 = (int)fv_feat2[p2];
+                    if (match21[idx2] >= 0 || (valid2 && !valid2[idx2])) continue;
+                    const int dist = DescriptorDistance(d1, desc2 + 32 * (size_t)idx2);
+                    if (dist < bestDist1) {
+                        bestDist2 = bestDist1;
+                        bestDist1 = dist;
+                        bestIdx2 = idx2;
+                    } else if (dist < bestDist2) {
+                        bestDist2 = dist;
+                    }
+                }
+                if (bestDist1 <= accept_max) {
+                    if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+                        match12[idx1] = bestIdx2;
+                        match21[bestIdx2] = idx1;
+                        if (check_orientation) {
+                            float rot = k1[idx1].angle - k2[bestIdx2].angle;
+                            if (rot < 0.0) rot += 360.0f;
+                            int bin = (int)std::round(rot * factor);
+                            if (bin == HISTO_LENGTH) bin = 0;
+                            rotHist[bin].push_back(idx1);
+                        }
+                        nmatches++;
+                    }
+                }
+            }
+            a++;
+            b++;
+        } else if (fv_node1[a] < fv_node2[b]) {
+            a = (int)(std::lower_bound(fv_node1, fv_node1 + nfv1, fv_node2[b]) - fv_node1);
+        } else {
+            b = (int)(std::lower_bound(fv_node2, fv_node2 + nfv2, fv_node1[a]) - fv_node2);
+        }
+    }
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1, sizes[HISTO_LENGTH];
+        for (int i = 0; i < HISTO_LENGTH; i++) sizes[i] = (int)rotHist[i].size();
+        ComputeThreeMaxima(sizes, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0; j < rotHist[i].size(); j++) {
+                const int idx1 = rotHist[i][j];
+                match21[match12[idx1]] = -1;
+                match12[idx1] = -1;
+                nmatches--;
+            }
+        }
+    }
+    return nmatches;
+}
+
 void oracle_three_maxima(const int* sizes, int L, int* out3)
 {
     int a = -1, b = -1, c = -1;

@@ -36,6 +36,7 @@ SYMBOLS = [
     "orbfe_camera_resize", "orbfe_marker_poses", "orbfe_marker_poses_batch_device",
     "orbfe_vocabulary_load_text", "orbfe_vocabulary_create", "orbfe_vocabulary_destroy", "orbfe_vocabulary_info",
     "orbfe_vocabulary_transform", "orbfe_vocabulary_transform_batch_device",
+    "orbfe_search_by_bow", "orbfe_search_by_bow_batch_device",
 ]
 
 _lib = None
@@ -112,6 +113,9 @@ def load():
         L.orbfe_vocabulary_info.argtypes = [vp, vp]
         L.orbfe_vocabulary_transform.argtypes = [vp, vp, i32, i32] + [vp] * 10
         L.orbfe_vocabulary_transform_batch_device.argtypes = [vp, vp, vp, i32, i32, i32] + [vp] * 11
+        side = [vp, vp, vp, i32, vp, vp, vp, i32]
+        L.orbfe_search_by_bow.argtypes = side + side + [f32, i32, i32, f32, vp, vp, vp, i32]
+        L.orbfe_search_by_bow_batch_device.argtypes = [vp] * 8 + [i32, vp, vp, i32, i32, f32, i32, i32, f32, vp, vp, vp, vp]
         L.orbfe_marker_poses.argtypes = [vp, i32, f32, vp, vp, i32, vp, i32]
         L.orbfe_marker_poses_batch_device.argtypes = [vp, vp, i32, i32, f32, vp, vp, i32, vp, vp]
     _lib = L
@@ -413,6 +417,25 @@ def marker_poses(markers, marker_size, K, dist, device=0):
     _check(L, L.orbfe_marker_poses(_p(mk), len(mk), marker_size, _p(K4), _p(d) if len(d) else None, len(d), _p(out), device),
            "orbfe_marker_poses")
     return out
+
+
+def search_by_bow(kps1, desc1, fv1, kps2, desc2, fv2, valid1=None, valid2=None, nnratio=0.7, check_orientation=True,
+                  accept_max=50, factor=30 / 360.0, device=0):
+    """ORBmatcher::SearchByBoW on flat arrays (ORBmatcher.cc:159-292; :526-659 with valid2, accept_max=49, factor=1/30).
+    fv = (node ids, offsets, feature indices) as ORBVocabulary.transform returns.  -> (nmatches, match12, match21)."""
+    L = load()
+    k1 = np.ascontiguousarray(kps1, KP_DTYPE); k2 = np.ascontiguousarray(kps2, KP_DTYPE)
+    d1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32); d2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
+    a = [np.ascontiguousarray(fv1[0], np.uint32), np.ascontiguousarray(fv1[1], np.int32), np.ascontiguousarray(fv1[2], np.uint32)]
+    b = [np.ascontiguousarray(fv2[0], np.uint32), np.ascontiguousarray(fv2[1], np.int32), np.ascontiguousarray(fv2[2], np.uint32)]
+    v1 = None if valid1 is None else np.ascontiguousarray(valid1, np.uint8)
+    v2 = None if valid2 is None else np.ascontiguousarray(valid2, np.uint8)
+    m12 = np.full(len(k1), -1, np.int32); m21 = np.full(len(k2), -1, np.int32); nm = C.c_int32(0)
+    _check(L, L.orbfe_search_by_bow(_p(k1), _p(d1), None if v1 is None else _p(v1), len(k1), _p(a[0]), _p(a[1]), _p(a[2]), len(a[0]),
+                                    _p(k2), _p(d2), None if v2 is None else _p(v2), len(k2), _p(b[0]), _p(b[1]), _p(b[2]), len(b[0]),
+                                    nnratio, int(check_orientation), accept_max, np.float32(factor), _p(m12), _p(m21), C.byref(nm),
+                                    device), "orbfe_search_by_bow")
+    return nm.value, m12, m21
 
 
 class ORBVocabulary:

@@ -211,6 +211,137 @@ __global__ __launch_bounds__(BV_THREADS) void k_bow_vectors(const int32_t* __res
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// ORBmatcher::SearchByBoW (reference src/ORBmatcher.cc:159-292 KeyFrame-Frame, :526-659 KeyFrame-KeyFrame) over the
+// FeatureVectors the transform above produced.  One workgroup per pair of frames.  Features of side 2 belong to exactly one
+// node, so the "already matched" coupling of the reference's loop (:213-214, :586) never crosses nodes: a wave owns a common
+// node, walks side 1's features of that node in order and spreads side 2's over its lanes; best / second-best follow the
+// sequential scan (first minimum wins, the second counts duplicates).  The rotation histogram is LDS counters.
+#define SB_THREADS 256
+#define SB_MAX 4096 // features per frame (LDS match tables)
+
+struct BowFrames {
+    const orbfe_keypoint* kps;
+    const uint8_t* desc;
+    const uint8_t* valid; // "has a map point that is not bad"; may be NULL
+    const int32_t* n;
+    const uint32_t* fv_node;
+    const int32_t* fv_off; // blocks of capacity + 1
+    const uint32_t* fv_feat;
+    const int32_t* nfv;
+    int capacity;
+};
+
+__global__ __launch_bounds__(SB_THREADS) void k_search_by_bow(BowFrames F, const int32_t* __restrict__ pair1, const int32_t* __restrict__ pair2,
+                                                             int use_valid2, float nnratio, int check_ori, int accept_max, float factor,
+                                                             int32_t* __restrict__ match12, int32_t* __restrict__ match21,
+                                                             int32_t* __restrict__ nmatches)
+{
+    __shared__ short s_m12[SB_MAX], s_m21[SB_MAX];
+    __shared__ signed char s_bin[SB_MAX];
+    __shared__ int s_hist[30], s_nm, s_ind[3];
+    const int p = blockIdx.x, f1 = pair1 ? pair1[p] : p, f2 = pair2 ? pair2[p] : p + 1;
+    const int cap = F.capacity;
+    const int n1 = min(min(F.n[f1], cap), SB_MAX), n2 = min(min(F.n[f2], cap), SB_MAX);
+    for (int i = threadIdx.x; i < SB_MAX; i += SB_THREADS) { s_m12[i] = -1; s_m21[i] = -1; s_bin[i] = -1; }
+    if (threadIdx.x < 30) s_hist[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_nm = 0;
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nfv1 = F.nfv[f1], nfv2 = F.nfv[f2];
+    const uint32_t *node1 = F.fv_node + (size_t)f1 * cap, *node2 = F.fv_node + (size_t)f2 * cap;
+    const int32_t *off1 = F.fv_off + (size_t)f1 * (cap + 1), *off2 = F.fv_off + (size_t)f2 * (cap + 1);
+    const uint32_t *feat1 = F.fv_feat + (size_t)f1 * cap, *feat2 = F.fv_feat + (size_t)f2 * cap;
+    const uint4 *d1v = (const uint4*)(F.desc + (size_t)f1 * cap * 32), *d2v = (const uint4*)(F.desc + (size_t)f2 * cap * 32);
+    const uint8_t *valid1 = F.valid ? F.valid + (size_t)f1 * cap : nullptr, *valid2 = (F.valid && use_valid2) ? F.valid + (size_t)f2 * cap : nullptr;
+    const orbfe_keypoint *k1 = F.kps + (size_t)f1 * cap, *k2 = F.kps + (size_t)f2 * cap;
+    int nm = 0;
+    for (int a = wave; a < nfv1; a += SB_THREADS / 64) {
+        const uint32_t node = node1[a];
+        int lo = 0, hi = nfv2; // lower_bound in side 2's node list (:279-286)
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (node2[mid] < node) lo = mid + 1; else hi = mid;
+        }
+        if (lo >= nfv2 || node2[lo] != node) continue;
+        const int o1 = off1[a], e1 = off1[a + 1], o2 = off2[lo], e2 = off2[lo + 1];
+        for (int p1 = o1; p1 < e1; p1++) {
+            const int idx1 = (int)feat1[p1];
+            if (idx1 >= n1 || (valid1 && !valid1[idx1])) continue;
+            const uint4 qa = d1v[2 * idx1], qb = d1v[2 * idx1 + 1];
+            int bestd = 256, second = 256, key = (256 << 16) | 0xffff;
+            for (int p2 = o2 + lane; p2 < e2; p2 += 64) {
+                const int idx2 = (int)feat2[p2];
+                if (idx2 >= n2 || s_m21[idx2] >= 0 || (valid2 && !valid2[idx2])) continue;
+                const uint4 ta = d2v[2 * idx2], tb = d2v[2 * idx2 + 1];
+                const int dist = __popc(ta.x ^ qa.x) + __popc(ta.y ^ qa.y) + __popc(ta.z ^ qa.z) + __popc(ta.w ^ qa.w) +
+                                 __popc(tb.x ^ qb.x) + __popc(tb.y ^ qb.y) + __popc(tb.z ^ qb.z) + __popc(tb.w ^ qb.w);
+                if (dist < bestd) { second = bestd; bestd = dist; key = (dist << 16) | (p2 - o2); }
+                else if (dist < second) second = dist;
+            }
+            const int B = wave_min(key);
+            const int S = wave_min(key == B ? second : bestd);
+            const int bestDist1 = B >> 16;
+            if (bestDist1 <= accept_max && (float)bestDist1 < __fmul_rn(nnratio, (float)S)) {
+                const int idx2 = (int)feat2[o2 + (B & 0xffff)];
+                if (lane == 0) {
+                    s_m12[idx1] = (short)idx2;
+                    s_m21[idx2] = (short)idx1;
+                    if (check_ori) {
+                        float rot = k1[idx1].angle - k2[idx2].angle;
+                        if (rot < 0.0f) rot += 360.0f;
+                        int bin = (int)roundf(__fmul_rn(rot, factor));
+                        if (bin == 30) bin = 0;
+                        bin = min(max(bin, 0), 29); // the reference asserts this range
+                        s_bin[idx1] = (signed char)bin;
+                        atomicAdd(&s_hist[bin], 1);
+                    }
+                }
+                nm++;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (lane == 0 && nm) atomicAdd(&s_nm, nm);
+    __syncthreads();
+    if (check_ori) {
+        if (threadIdx.x == 0) {
+            int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+            for (int i = 0; i < 30; i++) { // ComputeThreeMaxima, ORBmatcher.cc:1605-1646
+                const int s = s_hist[i];
+                if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+                else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+                else if (s > max3) { max3 = s; ind3 = i; }
+            }
+            if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+            else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+            s_ind[0] = ind1; s_ind[1] = ind2; s_ind[2] = ind3;
+        }
+        __syncthreads();
+        int removed = 0;
+        for (int i = threadIdx.x; i < n1; i += SB_THREADS) {
+            const int bin = s_bin[i];
+            if (bin >= 0 && bin != s_ind[0] && bin != s_ind[1] && bin != s_ind[2]) {
+                s_m21[s_m12[i]] = -1;
+                s_m12[i] = -1;
+                removed++;
+            }
+        }
+        removed = wave_sum(removed);
+        if (lane == 0 && removed) atomicSub(&s_nm, removed);
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < n1; i += SB_THREADS) match12[(size_t)p * cap + i] = s_m12[i];
+    for (int i = threadIdx.x; i < n2; i += SB_THREADS) match21[(size_t)p * cap + i] = s_m21[i];
+    if (threadIdx.x == 0) nmatches[p] = s_nm;
+}
+
+struct BowMatchWorkspace {
+    DevBuf kps, desc, valid, n, fn, fo, ff, nf, m12, m21, nm;
+};
+thread_local BowMatchWorkspace* tl_bow_ws = nullptr;
+
 int norm_of(int scoring) { return scoring == 5 ? 0 : scoring == 1 ? 2 : 1; } // ScoringObject.h:74-91
 
 // builds the device tree from nodes given in file order (node 0 = root, implicit)
@@ -455,6 +586,80 @@ int orbfe_vocabulary_transform(orbfe_vocabulary* v, const uint8_t* desc, int n, 
             ORBFE_HIP(hipMemcpy(fv_feature, v->w_ff.p, (size_t)fv_offset[*nfv] * 4, hipMemcpyDeviceToHost));
         }
     }
+    return ORBFE_OK;
+}
+
+int orbfe_search_by_bow_batch_device(const orbfe_keypoint* d_kps, const uint8_t* d_desc, const uint8_t* d_valid, const int32_t* d_n,
+                                     const uint32_t* d_fv_node, const int32_t* d_fv_offset, const uint32_t* d_fv_feature,
+                                     const int32_t* d_nfv, int capacity, const int32_t* d_pair1, const int32_t* d_pair2, int npairs,
+                                     int use_valid2, float nnratio, int check_orientation, int accept_max, float factor,
+                                     int32_t* d_match12, int32_t* d_match21, int32_t* d_nmatches, void* stream)
+{
+    if (npairs < 0 || capacity <= 0 || !d_kps || !d_desc || !d_n || !d_fv_node || !d_fv_offset || !d_fv_feature || !d_nfv || !d_match12 ||
+        !d_match21 || !d_nmatches)
+        return fail(ORBFE_ERR_INVALID, "orbfe_search_by_bow_batch_device: invalid argument");
+    if (capacity > SB_MAX) return fail(ORBFE_ERR_CAPACITY, "orbfe_search_by_bow: at most %d features per frame", SB_MAX);
+    if (npairs == 0) return ORBFE_OK;
+    BowFrames F{d_kps, d_desc, d_valid, d_n, d_fv_node, d_fv_offset, d_fv_feature, d_nfv, capacity};
+    hipLaunchKernelGGL(k_search_by_bow, dim3(npairs), dim3(SB_THREADS), 0, (hipStream_t)stream, F, d_pair1, d_pair2, use_valid2, nnratio,
+                       check_orientation, accept_max, factor, d_match12, d_match21, d_nmatches);
+    ORBFE_HIP(hipGetLastError());
+    return ORBFE_OK;
+}
+
+int orbfe_search_by_bow(const orbfe_keypoint* kps1, const uint8_t* desc1, const uint8_t* valid1, int n1, const uint32_t* fv_node1,
+                        const int32_t* fv_offset1, const uint32_t* fv_feature1, int nfv1, const orbfe_keypoint* kps2,
+                        const uint8_t* desc2, const uint8_t* valid2, int n2, const uint32_t* fv_node2, const int32_t* fv_offset2,
+                        const uint32_t* fv_feature2, int nfv2, float nnratio, int check_orientation, int accept_max, float factor,
+                        int32_t* match12, int32_t* match21, int32_t* nmatches, int device)
+{
+    if (n1 < 0 || n2 < 0 || nfv1 < 0 || nfv2 < 0 || nfv1 > n1 || nfv2 > n2 || !nmatches || (n1 && (!kps1 || !desc1 || !match12)) ||
+        (n2 && (!kps2 || !desc2 || !match21)) || (nfv1 && (!fv_node1 || !fv_offset1 || !fv_feature1)) ||
+        (nfv2 && (!fv_node2 || !fv_offset2 || !fv_feature2)))
+        return fail(ORBFE_ERR_INVALID, "orbfe_search_by_bow: invalid argument");
+    if (nfv1 && (fv_offset1[0] != 0 || fv_offset1[nfv1] > n1)) return fail(ORBFE_ERR_INVALID, "orbfe_search_by_bow: bad FeatureVector 1");
+    if (nfv2 && (fv_offset2[0] != 0 || fv_offset2[nfv2] > n2)) return fail(ORBFE_ERR_INVALID, "orbfe_search_by_bow: bad FeatureVector 2");
+    int rc = use_device(device);
+    if (rc) return rc;
+    *nmatches = 0;
+    for (int i = 0; i < n1; i++) match12[i] = -1;
+    for (int i = 0; i < n2; i++) match21[i] = -1;
+    if (n1 == 0 || n2 == 0 || nfv1 == 0 || nfv2 == 0) return ORBFE_OK;
+    const int cap = std::max(n1, n2);
+    if (cap > SB_MAX) return fail(ORBFE_ERR_CAPACITY, "orbfe_search_by_bow: at most %d features per frame", SB_MAX);
+    if (!tl_bow_ws) tl_bow_ws = new BowMatchWorkspace();
+    BowMatchWorkspace& w = *tl_bow_ws;
+    const size_t C = (size_t)cap;
+    if ((rc = w.kps.ensure(2 * C * sizeof(orbfe_keypoint))) || (rc = w.desc.ensure(2 * C * 32)) || (rc = w.valid.ensure(2 * C)) ||
+        (rc = w.n.ensure(16)) || (rc = w.fn.ensure(2 * C * 4)) || (rc = w.fo.ensure(2 * (C + 1) * 4)) || (rc = w.ff.ensure(2 * C * 4)) ||
+        (rc = w.nf.ensure(16)) || (rc = w.m12.ensure(C * 4)) || (rc = w.m21.ensure(C * 4)) || (rc = w.nm.ensure(16)))
+        return rc;
+    const bool any_valid = valid1 || valid2;
+    std::vector<uint8_t> valid(2 * C, 1);
+    if (valid1) memcpy(valid.data(), valid1, n1);
+    if (valid2) memcpy(valid.data() + C, valid2, n2);
+    const int32_t nn[2] = {n1, n2}, nf[2] = {nfv1, nfv2};
+    ORBFE_HIP(hipMemcpy(w.kps.p, kps1, (size_t)n1 * sizeof(orbfe_keypoint), hipMemcpyHostToDevice));
+    ORBFE_HIP(hipMemcpy(w.kps.as<orbfe_keypoint>() + C, kps2, (size_t)n2 * sizeof(orbfe_keypoint), hipMemcpyHostToDevice));
+    ORBFE_HIP(hipMemcpy(w.desc.p, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice));
+    ORBFE_HIP(hipMemcpy(w.desc.as<uint8_t>() + C * 32, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice));
+    ORBFE_HIP(hipMemcpy(w.valid.p, valid.data(), 2 * C, hipMemcpyHostToDevice));
+    ORBFE_HIP(hipMemcpy(w.n.p, nn, 8, hipMemcpyHostToDevice));
+    ORBFE_HIP(hipMemcpy(w.nf.p, nf, 8, hipMemcpyHostToDevice));
+    ORBFE_HIP(hipMemcpy(w.fn.p, fv_node1, (size_t)nfv1 * 4, hipMemcpyHostToDevice));
+    ORBFE_HIP(hipMemcpy(w.fn.as<uint32_t>() + C, fv_node2, (size_t)nfv2 * 4, hipMemcpyHostToDevice));
+    ORBFE_HIP(hipMemcpy(w.fo.p, fv_offset1, (size_t)(nfv1 + 1) * 4, hipMemcpyHostToDevice));
+    ORBFE_HIP(hipMemcpy(w.fo.as<int32_t>() + C + 1, fv_offset2, (size_t)(nfv2 + 1) * 4, hipMemcpyHostToDevice));
+    ORBFE_HIP(hipMemcpy(w.ff.p, fv_feature1, (size_t)fv_offset1[nfv1] * 4, hipMemcpyHostToDevice));
+    ORBFE_HIP(hipMemcpy(w.ff.as<uint32_t>() + C, fv_feature2, (size_t)fv_offset2[nfv2] * 4, hipMemcpyHostToDevice));
+    rc = orbfe_search_by_bow_batch_device(w.kps.as<orbfe_keypoint>(), w.desc.as<uint8_t>(), any_valid ? w.valid.as<uint8_t>() : nullptr,
+                                          w.n.as<int32_t>(), w.fn.as<uint32_t>(), w.fo.as<int32_t>(), w.ff.as<uint32_t>(), w.nf.as<int32_t>(),
+                                          cap, nullptr, nullptr, 1, valid2 != nullptr, nnratio, check_orientation, accept_max, factor,
+                                          w.m12.as<int32_t>(), w.m21.as<int32_t>(), w.nm.as<int32_t>(), nullptr);
+    if (rc) return rc;
+    ORBFE_HIP(hipMemcpy(match12, w.m12.p, (size_t)n1 * 4, hipMemcpyDeviceToHost));
+    ORBFE_HIP(hipMemcpy(match21, w.m21.p, (size_t)n2 * 4, hipMemcpyDeviceToHost));
+    ORBFE_HIP(hipMemcpy(nmatches, w.nm.p, 4, hipMemcpyDeviceToHost));
     return ORBFE_OK;
 }
 

@@ -311,6 +311,25 @@ class VocabularyOracle:
                     fv=(fn[:nf].copy(), fo[:nf + 1].copy(), ff[:fo[nf]].copy()))
 
 
+def search_by_bow(kps1, desc1, fv1, kps2, desc2, fv2, valid1=None, valid2=None, nnratio=0.7, check_orientation=True,
+                  accept_max=50, factor=30 / 360.0):
+    L = lib()
+    k1 = np.ascontiguousarray(kps1, KP_DTYPE); k2 = np.ascontiguousarray(kps2, KP_DTYPE)
+    d1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32); d2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
+    a = [np.ascontiguousarray(fv1[0], np.uint32), np.ascontiguousarray(fv1[1], np.int32), np.ascontiguousarray(fv1[2], np.uint32)]
+    b = [np.ascontiguousarray(fv2[0], np.uint32), np.ascontiguousarray(fv2[1], np.int32), np.ascontiguousarray(fv2[2], np.uint32)]
+    v1 = None if valid1 is None else np.ascontiguousarray(valid1, np.uint8)
+    v2 = None if valid2 is None else np.ascontiguousarray(valid2, np.uint8)
+    m12 = np.full(max(len(k1), 1), -1, np.int32); m21 = np.full(max(len(k2), 1), -1, np.int32)
+    side = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.oracle_search_by_bow.restype = C.c_int
+    L.oracle_search_by_bow.argtypes = side + side + [C.c_float, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+    nm = L.oracle_search_by_bow(_p(k1), _p(d1), None if v1 is None else _p(v1), len(k1), _p(a[0]), _p(a[1]), _p(a[2]), len(a[0]),
+                                _p(k2), _p(d2), None if v2 is None else _p(v2), len(k2), _p(b[0]), _p(b[1]), _p(b[2]), len(b[0]),
+                                nnratio, int(check_orientation), accept_max, np.float32(factor), _p(m12), _p(m21))
+    return nm, m12[:len(k1)], m21[:len(k2)]
+
+
 def search_for_initialization(k1, d1, k2, d2, cols, rows, prev=None, window=100, nnratio=0.9, check_ori=True, bounds=None):
     L = lib()
     k1 = np.ascontiguousarray(k1); k2 = np.ascontiguousarray(k2)

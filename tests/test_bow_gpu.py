@@ -84,3 +84,59 @@ def test_extracted_frame_descriptors(orbfe, oracle):
     got = g.transform(d, 4)
     _same(got, o.transform(d, 4))
     assert abs(got["bow"][1].sum() - 1.0) < 1e-12 and len(got["fv"][0]) <= 10
+
+
+def _two_frames(orbfe, oracle, seed, L=4, levelsup=2):
+    from orb_slam2_aruco_amd import synth
+    voc = vc.make(10, L, seed, irregular=False)
+    o = oracle.VocabularyOracle.from_arrays(10, L, 0, 0, voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"])
+    s = synth.stream(480, 640, 2, 1000 + seed)
+    ex = oracle.OrbOracle(1000, 1.2, 8, 20, 7)
+    (k1, d1), (k2, d2) = ex.extract(s[0]), ex.extract(s[1])
+    return k1, d1, o.transform(d1, levelsup)["fv"], k2, d2, o.transform(d2, levelsup)["fv"]
+
+
+@pytest.mark.parametrize("seed,levelsup,ratio,ori", [(1, 2, 0.7, True), (2, 3, 0.9, True), (3, 4, 0.75, False), (4, 1, 0.7, True)])
+def test_search_by_bow_keyframe_frame(orbfe, oracle, seed, levelsup, ratio, ori):
+    """SearchByBoW(KeyFrame, Frame) (ORBmatcher.cc:159-292): bit-exact matches, incl. the taken-feature coupling inside a node."""
+    k1, d1, fv1, k2, d2, fv2 = _two_frames(orbfe, oracle, seed, 4, levelsup)
+    rng = np.random.default_rng(seed)
+    valid1 = (rng.random(len(k1)) < 0.8).astype(np.uint8)            # keyframe features with a (good) map point
+    want = oracle.search_by_bow(k1, d1, fv1, k2, d2, fv2, valid1, None, ratio, ori, 50, 30 / 360.0)
+    got = orbfe.search_by_bow(k1, d1, fv1, k2, d2, fv2, valid1, None, ratio, ori, 50, 30 / 360.0)
+    assert got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+    assert got[0] > 30 and np.all(valid1[got[1] >= 0] == 1)
+    assert got[0] == (got[1] >= 0).sum() == (got[2] >= 0).sum()
+
+
+@pytest.mark.parametrize("seed", [5, 6])
+def test_search_by_bow_keyframe_keyframe(orbfe, oracle, seed):
+    """SearchByBoW(KeyFrame, KeyFrame) (:526-659): map points required on both sides, best < TH_LOW, factor 1/HISTO_LENGTH."""
+    k1, d1, fv1, k2, d2, fv2 = _two_frames(orbfe, oracle, seed, 4, 2)
+    rng = np.random.default_rng(seed)
+    valid1 = (rng.random(len(k1)) < 0.7).astype(np.uint8); valid2 = (rng.random(len(k2)) < 0.7).astype(np.uint8)
+    want = oracle.search_by_bow(k1, d1, fv1, k2, d2, fv2, valid1, valid2, 0.75, True, 49, 1.0 / 30)
+    got = orbfe.search_by_bow(k1, d1, fv1, k2, d2, fv2, valid1, valid2, 0.75, True, 49, 1.0 / 30)
+    assert got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+    assert got[0] > 10 and np.all(valid2[got[1][got[1] >= 0]] == 1)
+
+
+def test_search_by_bow_edge_cases(orbfe, oracle):
+    k1, d1, fv1, k2, d2, fv2 = _two_frames(orbfe, oracle, 7, 3, 1)
+    e = (np.zeros(0, np.uint32), np.zeros(1, np.int32), np.zeros(0, np.uint32))
+    nm, m12, m21 = orbfe.search_by_bow(k1, d1, fv1, k2[:0], d2[:0], e)
+    assert nm == 0 and np.all(m12 == -1) and len(m21) == 0
+    nm, m12, m21 = orbfe.search_by_bow(k1, d1, e, k2, d2, fv2)
+    assert nm == 0 and np.all(m21 == -1)
+    # identical frames: every valid feature finds itself at distance 0 unless a twin took it
+    want = oracle.search_by_bow(k1, d1, fv1, k1, d1, fv1, None, None, 0.7, True, 50, 30 / 360.0)
+    got = orbfe.search_by_bow(k1, d1, fv1, k1, d1, fv1, None, None, 0.7, True, 50, 30 / 360.0)
+    assert got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+    # one big node (levelsup >= L: everything under the root): the lanes of one wave cover > 64 candidates
+    voc = vc.make(10, 3, 9, irregular=False)
+    o = oracle.VocabularyOracle.from_arrays(10, 3, 0, 0, voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"])
+    f1, f2 = o.transform(d1, 3)["fv"], o.transform(d2, 3)["fv"]
+    assert len(f1[0]) == 1
+    want = oracle.search_by_bow(k1, d1, f1, k2, d2, f2, None, None, 0.9, True, 50, 30 / 360.0)
+    got = orbfe.search_by_bow(k1, d1, f1, k2, d2, f2, None, None, 0.9, True, 50, 30 / 360.0)
+    assert got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
