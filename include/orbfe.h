@@ -259,6 +259,28 @@ int orbfe_undistort_keypoints_batch_device(const orbfe_keypoint* d_kps, const in
  * of the search entry points above.  {0, 0, cols, rows} when dist[0] == 0. */
 int orbfe_compute_image_bounds(int cols, int rows, const float* K4, const float* dist, int ndist, float* bounds, int device);
 
+/* ------------------------------------------------------------------ on-disk keyframe features -- */
+/* The feature records of the reference's binary map files (src/Map.cc:297-321 SaveKeyFrame, :478-511 LoadKeyFrame): per
+ * feature pt.x pt.y size angle response (f32) octave (i32) | mDescriptors.cols (i32 = 32) | 32 descriptor bytes | map
+ * point index (u64, ULONG_MAX = none) = 68 bytes, packed back to back after each keyframe header (id u64, timestamp f64,
+ * quaternion 4 x f32, translation 3 x f32, N i32).  class_id is not stored; unpack sets -1 (cv::KeyPoint's default). */
+#define ORBFE_KF_FEATURE_BYTES 68
+/* n records <-> arrays, host pointers.  mp_index may be NULL (pack: ULONG_MAX everywhere; unpack: not returned).
+ * unpack fails with ORBFE_ERR_INVALID when a record's descriptor length is not 32 (LoadKeyFrame would read a
+ * different number of bytes there, Map.cc:492-495). */
+int orbfe_keyframe_features_pack(const orbfe_keypoint* kps, const uint8_t* desc, const uint64_t* mp_index, int n, uint8_t* out, int device);
+int orbfe_keyframe_features_unpack(const uint8_t* in, int n, orbfe_keypoint* kps, uint8_t* desc, uint64_t* mp_index, int device);
+/* A whole map file image resident on the device: segment s = the features of one keyframe, starting at byte
+ * d_seg_offset[s] of d_file (4-byte aligned, as every offset of the format is) and occupying output indices
+ * d_seg_first[s] .. d_seg_first[s + 1].  NULL offsets = one segment at offset 0 of max_records_per_segment records.
+ * *d_bad counts records whose descriptor length is not 32 (zero it first). */
+int orbfe_keyframe_features_unpack_device(const uint8_t* d_file, const uint64_t* d_seg_offset, const int32_t* d_seg_first, int nsegments,
+                                          int max_records_per_segment, orbfe_keypoint* d_kps, uint8_t* d_desc, uint64_t* d_mp_index,
+                                          int32_t* d_bad, void* stream);
+int orbfe_keyframe_features_pack_device(const orbfe_keypoint* d_kps, const uint8_t* d_desc, const uint64_t* d_mp_index,
+                                        const uint64_t* d_seg_offset, const int32_t* d_seg_first, int nsegments,
+                                        int max_records_per_segment, uint8_t* d_file, void* stream);
+
 /* ------------------------------------------------------------------ ArUco marker detector -- */
 typedef struct orbfe_aruco orbfe_aruco;
 

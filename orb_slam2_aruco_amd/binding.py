@@ -37,6 +37,8 @@ SYMBOLS = [
     "orbfe_vocabulary_load_text", "orbfe_vocabulary_create", "orbfe_vocabulary_destroy", "orbfe_vocabulary_info",
     "orbfe_vocabulary_transform", "orbfe_vocabulary_transform_batch_device",
     "orbfe_search_by_bow", "orbfe_search_by_bow_batch_device",
+    "orbfe_keyframe_features_pack", "orbfe_keyframe_features_unpack", "orbfe_keyframe_features_pack_device",
+    "orbfe_keyframe_features_unpack_device",
 ]
 
 _lib = None
@@ -113,6 +115,10 @@ def load():
         L.orbfe_vocabulary_info.argtypes = [vp, vp]
         L.orbfe_vocabulary_transform.argtypes = [vp, vp, i32, i32] + [vp] * 10
         L.orbfe_vocabulary_transform_batch_device.argtypes = [vp, vp, vp, i32, i32, i32] + [vp] * 11
+        L.orbfe_keyframe_features_pack.argtypes = [vp, vp, vp, i32, vp, i32]
+        L.orbfe_keyframe_features_unpack.argtypes = [vp, i32, vp, vp, vp, i32]
+        L.orbfe_keyframe_features_unpack_device.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]
+        L.orbfe_keyframe_features_pack_device.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, vp]
         side = [vp, vp, vp, i32, vp, vp, vp, i32]
         L.orbfe_search_by_bow.argtypes = side + side + [f32, i32, i32, f32, vp, vp, vp, i32]
         L.orbfe_search_by_bow_batch_device.argtypes = [vp] * 8 + [i32, vp, vp, i32, i32, f32, i32, i32, f32, vp, vp, vp, vp]
@@ -436,6 +442,30 @@ def search_by_bow(kps1, desc1, fv1, kps2, desc2, fv2, valid1=None, valid2=None, 
                                     nnratio, int(check_orientation), accept_max, np.float32(factor), _p(m12), _p(m21), C.byref(nm),
                                     device), "orbfe_search_by_bow")
     return nm.value, m12, m21
+
+
+KF_FEATURE_BYTES = 68
+
+
+def keyframe_features_pack(kps, desc, mp_index=None, device=0):
+    """Feature records of Map::SaveKeyFrame (Map.cc:297-321) -> bytes (n x 68)."""
+    L = load()
+    k = np.ascontiguousarray(kps, KP_DTYPE); d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    m = None if mp_index is None else np.ascontiguousarray(mp_index, np.uint64)
+    out = np.zeros(len(k) * KF_FEATURE_BYTES, np.uint8)
+    _check(L, L.orbfe_keyframe_features_pack(_p(k), _p(d), None if m is None else _p(m), len(k), _p(out), device),
+           "orbfe_keyframe_features_pack")
+    return out
+
+
+def keyframe_features_unpack(buf, n, device=0):
+    """The read side (Map::LoadKeyFrame, Map.cc:478-511) -> (keypoints, descriptors, map point indices)."""
+    L = load()
+    b = np.ascontiguousarray(buf, np.uint8)
+    assert len(b) >= n * KF_FEATURE_BYTES
+    k = np.zeros(n, KP_DTYPE); d = np.zeros((n, 32), np.uint8); m = np.zeros(n, np.uint64)
+    _check(L, L.orbfe_keyframe_features_unpack(_p(b), n, _p(k), _p(d), _p(m), device), "orbfe_keyframe_features_unpack")
+    return k, d, m
 
 
 class ORBVocabulary:

@@ -330,6 +330,29 @@ def search_by_bow(kps1, desc1, fv1, kps2, desc2, fv2, valid1=None, valid2=None, 
     return nm, m12[:len(k1)], m21[:len(k2)]
 
 
+def keyframe_features_pack(kps, desc, mp_index=None):
+    L = lib()
+    k = np.ascontiguousarray(kps, KP_DTYPE); d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    m = None if mp_index is None else np.ascontiguousarray(mp_index, np.uint64)
+    out = np.zeros(len(k) * 68 + 8, np.uint8)
+    L.oracle_keyframe_features_pack.restype = C.c_long
+    L.oracle_keyframe_features_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    nb = L.oracle_keyframe_features_pack(_p(k), _p(d), None if m is None else _p(m), len(k), _p(out))
+    return out[:nb].copy()
+
+
+def keyframe_features_unpack(buf, n):
+    L = lib()
+    b = np.ascontiguousarray(buf, np.uint8)
+    k = np.zeros(max(n, 1), KP_DTYPE); d = np.zeros((max(n, 1), 32), np.uint8); m = np.zeros(max(n, 1), np.uint64)
+    L.oracle_keyframe_features_unpack.restype = C.c_long
+    L.oracle_keyframe_features_unpack.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = L.oracle_keyframe_features_unpack(_p(b), n, _p(k), _p(d), _p(m))
+    if rc < 0:
+        raise ValueError("record %d: descriptor length is not 32" % (-rc - 1))
+    return k[:n], d[:n], m[:n]
+
+
 def search_for_initialization(k1, d1, k2, d2, cols, rows, prev=None, window=100, nnratio=0.9, check_ori=True, bounds=None):
     L = lib()
     k1 = np.ascontiguousarray(k1); k2 = np.ascontiguousarray(k2)

@@ -465,3 +465,30 @@ def test_vocabulary_transform_oracle(oracle, k, L, seed, levelsup, tmp_path):
     sparse = np.unpackbits(feats, axis=1).sum(1) == 1
     assert np.all(g3["weight"][sparse] == 0)              # one-bit descriptors sit closest to the all-zero phantom: dropped
     assert np.array_equal(g3["word"][~sparse], got["word"][~sparse])
+
+
+# ---------------------------------------------------------------- on-disk keyframe features (Map.cc:297-321, :478-511)
+KF_REC = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"),
+                   ("cols", "<i4"), ("desc", "u1", 32), ("mp", "<u8")])
+
+
+def test_keyframe_feature_records(oracle):
+    assert KF_REC.itemsize == 68
+    k, d = oracle.OrbOracle(500, 1.2, 4, 20, 7).extract(synth.scene(240, 320, 7, n_markers=2, side_range=(40, 70))[0])
+    rng = np.random.default_rng(0)
+    mp = rng.integers(0, 10000, len(k)).astype(np.uint64); mp[rng.random(len(k)) < 0.3] = np.uint64(2**64 - 1)
+    buf = oracle.keyframe_features_pack(k, d, mp)
+    rec = buf.view(KF_REC)                               # the packed layout, field by field
+    assert len(rec) == len(k) and np.all(rec["cols"] == 32)
+    for f in ("x", "y", "size", "angle", "response", "octave"):
+        assert np.array_equal(rec[f], k[f])
+    assert np.array_equal(rec["desc"], d) and np.array_equal(rec["mp"], mp)
+    k2, d2, m2 = oracle.keyframe_features_unpack(buf, len(k))
+    assert np.array_equal(d2, d) and np.array_equal(m2, mp) and np.all(k2["class_id"] == -1)
+    for f in ("x", "y", "size", "angle", "response", "octave"):
+        assert np.array_equal(k2[f], k[f])
+    none = oracle.keyframe_features_pack(k, d, None).view(KF_REC)
+    assert np.all(none["mp"] == np.uint64(2**64 - 1))    # ULONG_MAX = no map point
+    bad = buf.copy(); bad.view(KF_REC)["cols"][3] = 31
+    with pytest.raises(ValueError):
+        oracle.keyframe_features_unpack(bad, len(k))
