@@ -175,6 +175,30 @@ int orbfe_search_by_projection(const orbfe_keypoint* kps, const uint8_t* desc, i
                                int th_high, float nnratio, int32_t* best_idx, int32_t* best_dist, int32_t* best_level,
                                int32_t* second_dist, int32_t* second_level, int32_t* match, int32_t* nmatches, int device);
 
+/* ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono) (src/ORBmatcher.cc:1332-1474; what
+ * TrackWithMotionModel runs every frame), monocular, whole on the device: the projection of the last frame's map points
+ * with the current pose (:1362-1389), the window search on the Frame grid (levels octave +- 1, :1396), best match <= th_high
+ * (TH_HIGH = 100, :1421), the blocking of keypoints that received an observed map point (:1397-1399), the rotation
+ * histogram (factor 1/HISTO_LENGTH, :1341) and ComputeThreeMaxima (:1440-1471).
+ * Per feature i of the last frame: valid_last[i] = has a map point and is not an outlier (NULL = all); x3Dw = its world
+ * position (n_last x 3); mp_desc = MapPoint::GetDescriptor() (n_last x 32); mp_observed[i] = Observations() > 0 (NULL = all).
+ * taken_cur[i2] = the keypoint already holds an observed map point (NULL = none).  Tcw = 3x4 row-major [Rcw | tcw]
+ * (CurrentFrame.mTcw), K4 = fx fy cx cy, scale_factors = mvScaleFactors.  match_cur[i2] = i (the keypoint receives the
+ * map point of last-frame feature i) or -1; *nmatches = the return value.  Host pointers. */
+int orbfe_search_by_projection_last_frame(const orbfe_keypoint* kps_cur, const uint8_t* desc_cur, int n_cur, const uint8_t* taken_cur,
+                                          int cols, int rows, const float* bounds, const orbfe_keypoint* kps_last, int n_last,
+                                          const uint8_t* valid_last, const float* x3Dw, const uint8_t* mp_desc, const uint8_t* mp_observed,
+                                          const float* Tcw, const float* K4, const float* scale_factors, int nlevels, float th, int th_high,
+                                          int check_orientation, int32_t* match_cur, int32_t* nmatches, int device);
+/* The same loop for queries projected by the caller -- SearchByProjection(CurrentFrame, KeyFrame, sAlreadyFound, th, ORBdist)
+ * (:1476-1603: th_high = ORBdist, levels nPredictedLevel +- 1 from MapPoint::PredictScale, q_blocks = NULL) and the other
+ * best-only variants: queries (r < 0 = skip) with their descriptors, q_angle = the source keypoints' angles, factor = the
+ * histogram factor of the variant. */
+int orbfe_search_by_projection_best(const orbfe_keypoint* kps, const uint8_t* desc, int n, int cols, int rows, const float* bounds,
+                                    const orbfe_window_query* queries, const float* q_angle, const uint8_t* qdesc, const uint8_t* q_blocks,
+                                    int nq, const uint8_t* taken, int th_high, int check_orientation, float factor, int32_t* match_cur,
+                                    int32_t* nmatches, int device);
+
 /* Batched device variant over npairs frame pairs (frame t vs t-1 of a stream); all arrays are blocks of `capacity`
  * records per frame; pair p matches frame p (as F1) against frame p+1 (as F2). prev_matched == NULL means
  * "start from F1's own keypoint positions" (what Tracking does on the first call, src/Tracking.cc:520-523). */

@@ -413,6 +413,84 @@ int oracle_search_by_bow(const void* kps1_, const uint8_t* desc1, const uint8_t*
     return nmatches;
 }
 
+/* ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono = true) (src/ORBmatcher.cc:1332-1474)
+ * on flat arrays.  Per feature i of the last frame: valid_last[i] = "has a map point and is not an outlier" (:1358-1362),
+ * x3Dw = the map point's world position, mp_desc = its descriptor (:1391), mp_observed[i] = its Observations() > 0 -- what
+ * makes CurrentFrame.mvpMapPoints[i2] block later queries (:1397-1399; NULL = all observed).  taken_cur = keypoints of the
+ * current frame that already hold an observed map point.  Tcw = 3x4 row-major [Rcw | tcw], K4 = fx fy cx cy.  The stereo
+ * branches (bForward / bBackward, mvuRight) do not exist in the monocular system.  OpenCV's `Rcw*x3Dw+tcw` on 3x3 * 3x1
+ * floats: each row is a float sum left to right, then the float translation is added.
+ * match_cur[i2] = i (last-frame feature whose map point the keypoint received) or -1; returns nmatches. */
+int oracle_search_by_projection_last_frame(const void* kps_cur_, const uint8_t* desc_cur, int n_cur, const uint8_t* taken_cur, int cols,
+                                           int rows, const float* bounds, const void* kps_last_, int n_last, const uint8_t* valid_last,
+                                           const float* x3Dw, const uint8_t* mp_desc, const uint8_t* mp_observed, const float* Tcw,
+                                           const float* K4, const float* scale_factors, float th, int th_high, int check_orientation,
+                                           int32_t* match_cur)
+{
+    const KeyPoint* kc = (const KeyPoint*)kps_cur_;
+    const KeyPoint* kl = (const KeyPoint*)kps_last_;
+    FrameGrid grid(kc, n_cur, cols, rows, bounds);
+    const float fx = K4[0], fy = K4[1], cx = K4[2], cy = K4[3];
+    int nmatches = 0;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    std::vector<uint8_t> blocked(n_cur, 0); /* CurrentFrame.mvpMapPoints[i2] && Observations() > 0 */
+    for (int i = 0; i < n_cur; i++) { match_cur[i] = -1; blocked[i] = taken_cur ? taken_cur[i] : 0; }
+    for (int i = 0; i < n_last; i++) {
+        if (valid_last && !valid_last[i]) continue;
+        const float X = x3Dw[3 * i], Y = x3Dw[3 * i + 1], Z = x3Dw[3 * i + 2];
+        float t0 = Tcw[0] * X + Tcw[1] * Y + Tcw[2] * Z;
+        float t1 = Tcw[4] * X + Tcw[5] * Y + Tcw[6] * Z;
+        float t2 = Tcw[8] * X + Tcw[9] * Y + Tcw[10] * Z;
+        const float xc = (float)(t0 * 1.0 + 1.0 * Tcw[3]);
+        const float yc = (float)(t1 * 1.0 + 1.0 * Tcw[7]);
+        const float zc = (float)(t2 * 1.0 + 1.0 * Tcw[11]);
+        const float invzc = 1.0 / zc;
+        if (invzc < 0) continue;
+        float u = fx * xc * invzc + cx;
+        float v = fy * yc * invzc + cy;
+        if (u < grid.mnMinX || u > grid.mnMaxX) continue;
+        if (v < grid.mnMinY || v > grid.mnMaxY) continue;
+        if (u != u || v != v) continue; /* NaN: undefined in the reference (grid indices from NaN); dropped */
+        int nLastOctave = kl[i].octave;
+        float radius = th * scale_factors[nLastOctave];
+        std::vector<int> vIndices2 = grid.GetFeaturesInArea(u, v, radius, nLastOctave - 1, nLastOctave + 1);
+        if (vIndices2.empty()) continue;
+        const uint8_t* dMP = mp_desc + 32 * (size_t)i;
+        int bestDist = 256, bestIdx2 = -1;
+        for (size_t k = 0; k < vIndices2.size(); k++) {
+            const int i2 = vIndices2[k];
+            if (blocked[i2]) continue;
+            const int dist = DescriptorDistance(dMP, desc_cur + 32 * (size_t)i2);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= th_high) {
+            match_cur[bestIdx2] = i;
+            blocked[bestIdx2] = mp_observed ? mp_observed[i] : 1;
+            nmatches++;
+            if (check_orientation) {
+                float rot = kl[i].angle - kc[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)std::round(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(bestIdx2);
+            }
+        }
+    }
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1, sizes[HISTO_LENGTH];
+        for (int i = 0; i < HISTO_LENGTH; i++) sizes[i] = (int)rotHist[i].size();
+        ComputeThreeMaxima(sizes, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (size_t j = 0; j < rotHist[i].size(); j++) {
+                    match_cur[rotHist[i][j]] = -1;
+                    nmatches--;
+                }
+    }
+    return nmatches;
+}
+
 void oracle_three_maxima(const int* sizes, int L, int* out3)
 {
     int a = -1, b = -1, c = -1;

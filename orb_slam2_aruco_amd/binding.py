@@ -37,6 +37,7 @@ SYMBOLS = [
     "orbfe_vocabulary_load_text", "orbfe_vocabulary_create", "orbfe_vocabulary_destroy", "orbfe_vocabulary_info",
     "orbfe_vocabulary_transform", "orbfe_vocabulary_transform_batch_device",
     "orbfe_search_by_bow", "orbfe_search_by_bow_batch_device",
+    "orbfe_search_by_projection_last_frame", "orbfe_search_by_projection_best",
     "orbfe_keyframe_features_pack", "orbfe_keyframe_features_unpack", "orbfe_keyframe_features_pack_device",
     "orbfe_keyframe_features_unpack_device",
 ]
@@ -82,6 +83,9 @@ def load():
         L.orbfe_debug_control.argtypes = [C.c_char_p, i32]
         L.orbfe_search_by_projection.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, i32, vp, i32, i32, C.c_float] + [vp] * 7 + [i32]
         L.orbfe_hamming.argtypes = [vp, vp]
+        L.orbfe_search_by_projection_last_frame.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, f32,
+                                                            i32, i32, vp, vp, i32]
+        L.orbfe_search_by_projection_best.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp, i32, i32, f32, vp, vp, i32]
         L.orbfe_undistort_points.argtypes = [vp, i32, vp, vp, i32, vp, i32]
         L.orbfe_undistort_keypoints_batch_device.argtypes = [vp, vp, i32, i32, vp, vp, i32, vp, vp]
         L.orbfe_compute_image_bounds.argtypes = [i32, i32, vp, vp, i32, vp, i32]
@@ -367,6 +371,42 @@ def ComputeImageBounds(cols, rows, K, dist, device=0):
     _check(L, L.orbfe_compute_image_bounds(cols, rows, _p(K4), _p(d) if len(d) else None, len(d), _p(out), device),
            "orbfe_compute_image_bounds")
     return out
+
+
+def search_by_projection_last_frame(kps_cur, desc_cur, cols, rows, kps_last, valid_last, x3Dw, mp_desc, Tcw, K4, scale_factors, th,
+                                    taken_cur=None, mp_observed=None, th_high=100, check_orientation=True, bounds=None, device=0):
+    """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, mono) (ORBmatcher.cc:1332-1474) -> (nmatches, match_cur)."""
+    L = load()
+    kc = np.ascontiguousarray(kps_cur, KP_DTYPE); dc = np.ascontiguousarray(desc_cur, np.uint8).reshape(-1, 32)
+    kl = np.ascontiguousarray(kps_last, KP_DTYPE)
+    opt = lambda a, t: None if a is None else np.ascontiguousarray(a, t)
+    vl, tc, ob, bnd = opt(valid_last, np.uint8), opt(taken_cur, np.uint8), opt(mp_observed, np.uint8), opt(bounds, np.float32)
+    x = np.ascontiguousarray(x3Dw, np.float32).reshape(-1, 3); md = np.ascontiguousarray(mp_desc, np.uint8).reshape(-1, 32)
+    T = np.ascontiguousarray(Tcw, np.float32).reshape(-1)[:12].copy(); K = np.ascontiguousarray(K4, np.float32)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    m = np.full(len(kc), -1, np.int32); nm = C.c_int32(0)
+    pp = lambda a: None if a is None else _p(a)
+    _check(L, L.orbfe_search_by_projection_last_frame(_p(kc), _p(dc), len(kc), pp(tc), cols, rows, pp(bnd), _p(kl), len(kl), pp(vl), _p(x),
+                                                      _p(md), pp(ob), _p(T), _p(K), _p(sf), len(sf), th, th_high, int(check_orientation),
+                                                      _p(m), C.byref(nm), device), "orbfe_search_by_projection_last_frame")
+    return nm.value, m
+
+
+def search_by_projection_best(kps, desc, cols, rows, queries, q_angle, qdesc, th_high, factor, q_blocks=None, taken=None,
+                              check_orientation=True, bounds=None, device=0):
+    """Best-only guided search with rotation consistency (ORBmatcher.cc:1476-1603 and relatives) -> (nmatches, match_cur)."""
+    L = load()
+    k = np.ascontiguousarray(kps, KP_DTYPE); d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    q = np.ascontiguousarray(queries, WINDOW_QUERY_DTYPE); qa = np.ascontiguousarray(q_angle, np.float32)
+    qd = np.ascontiguousarray(qdesc, np.uint8).reshape(-1, 32)
+    opt = lambda a, t: None if a is None else np.ascontiguousarray(a, t)
+    qb, tk, bnd = opt(q_blocks, np.uint8), opt(taken, np.uint8), opt(bounds, np.float32)
+    pp = lambda a: None if a is None else _p(a)
+    m = np.full(len(k), -1, np.int32); nm = C.c_int32(0)
+    _check(L, L.orbfe_search_by_projection_best(_p(k), _p(d), len(k), cols, rows, pp(bnd), _p(q), _p(qa), _p(qd), pp(qb), len(q), pp(tk),
+                                                th_high, int(check_orientation), np.float32(factor), _p(m), C.byref(nm), device),
+           "orbfe_search_by_projection_best")
+    return nm.value, m
 
 
 class ORBmatcher:

@@ -566,9 +566,20 @@ __global__ __launch_bounds__(256) void k_knn2_csr(const uint8_t* __restrict__ Q,
 //      (rank u16, distance u8) in scratch, in candidate order.
 //   C  mode 0: one wave per query resolves best / second-best over the row (strict '<', first candidate wins);
 //      mode 1: ONE wave walks the queries in order, because an accepted keypoint is taken for the queries after it.
+//      mode 2: the loop of SearchByProjection(CurrentFrame, LastFrame, th, mono) (ORBmatcher.cc:1355-1471): best only,
+//              accept best <= th_high, the accepted keypoint is taken when the query's map point has observations, rotation
+//              histogram + ComputeThreeMaxima; the result is per keypoint of the frame (match_cur[i2] = query or -1).
 #define SBP_THREADS 1024
 #define SBP_CELLS (GRID_COLS * GRID_ROWS)
-struct SbpQuery { float x, y, r; int32_t min_level, max_level; };
+struct SbpQuery { float x, y, r; int32_t min_level, max_level; }; // r < 0: no search (the point did not project into the frame)
+struct SbpBest { // mode 2 only
+    const float* q_angle;     // LastFrame.mvKeysUn[i].angle per query
+    const uint8_t* q_blocks;  // "the query's map point has Observations() > 0" (:1397-1399); NULL = all
+    float factor;             // rotation histogram factor (:1341)
+    int check_ori;
+    int32_t* match_cur;       // n entries
+    int32_t* qbin;            // nq entries of scratch
+};
 
 __global__ __launch_bounds__(SBP_THREADS) void k_search_by_projection(
     const orbfe_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc, int n, int ncap /*pow2 >= n*/, float4 bnd,
@@ -576,10 +587,11 @@ __global__ __launch_bounds__(SBP_THREADS) void k_search_by_projection(
     int th_high, float nnratio, uint16_t* __restrict__ row_rank, uint8_t* __restrict__ row_dist, int32_t* __restrict__ row_cnt,
     int row_stride, int32_t* __restrict__ best_idx, int32_t* __restrict__ best_dist, int32_t* __restrict__ best_level,
     int32_t* __restrict__ second_dist, int32_t* __restrict__ second_level, int32_t* __restrict__ match,
-    int32_t* __restrict__ nmatches_out, int32_t* __restrict__ overflow)
+    int32_t* __restrict__ nmatches_out, int32_t* __restrict__ overflow, SbpBest bo)
 {
     extern __shared__ __align__(16) unsigned char sbp_smem[];
     __shared__ int s_nin;
+    __shared__ int s_hist[30];
     uint32_t* s_sorted = (uint32_t*)sbp_smem;                  // (cell << 16) | index, ascending; ncap entries
     float2* s_xy = (float2*)(s_sorted + ncap);                 // by rank
     uint16_t* s_cell0 = (uint16_t*)(s_xy + ncap);              // first rank of every cell, SBP_CELLS + 1 entries
@@ -593,6 +605,9 @@ __global__ __launch_bounds__(SBP_THREADS) void k_search_by_projection(
 
     // ---- A
     if (tid == 0) s_nin = 0;
+    if (tid < 30) s_hist[tid] = 0;
+    if (mode == 2)
+        for (int i = tid; i < n; i += SBP_THREADS) bo.match_cur[i] = -1;
     __syncthreads();
     for (int i = tid; i < n; i += SBP_THREADS) {
         const orbfe_keypoint kp = kps[i];
@@ -649,7 +664,7 @@ __global__ __launch_bounds__(SBP_THREADS) void k_search_by_projection(
         const int nMaxCellX = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(x - mnMinX + r, invW)));
         const int nMinCellY = max(0, (int)floorf(__fmul_rn(y - mnMinY - r, invH)));
         const int nMaxCellY = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(y - mnMinY + r, invH)));
-        if (!(nMinCellX >= GRID_COLS || nMaxCellX < 0 || nMinCellY >= GRID_ROWS || nMaxCellY < 0)) {
+        if (!(r < 0.0f) && !(nMinCellX >= GRID_COLS || nMaxCellX < 0 || nMinCellY >= GRID_ROWS || nMaxCellY < 0)) {
             const bool check_levels = (Q.min_level > 0) || (Q.max_level >= 0);
             const uint4 a0 = reinterpret_cast<const uint4*>(qdesc)[2 * q];
             const uint4 a1 = reinterpret_cast<const uint4*>(qdesc)[2 * q + 1];
@@ -731,6 +746,63 @@ __global__ __launch_bounds__(SBP_THREADS) void k_search_by_projection(
     }
     if (wid != 0) return;
     int nmatches = 0;
+    if (mode == 2) {
+        for (int q = 0; q < nq; q++) {
+            unsigned long long bk, sk;
+            resolve(q, bk, sk);
+            write_raw(q, bk, sk);
+            int m = -1, bin = -1;
+            if (bk != ~0ull && (int)(bk >> 32) <= th_high) { // :1421
+                const int bestRank = (int)(bk & 0xffff);
+                m = (int)(s_sorted[bestRank] & 0xffff);
+                if (bo.check_ori) {
+                    float rot = bo.q_angle[q] - kps[m].angle;
+                    if (rot < 0.0f) rot += 360.0f;
+                    bin = (int)roundf(__fmul_rn(rot, bo.factor));
+                    if (bin == 30) bin = 0;
+                    bin = min(max(bin, 0), 29);
+                }
+                if (lane == 0) {
+                    bo.match_cur[m] = q; // CurrentFrame.mvpMapPoints[bestIdx2] = pMP (:1423)
+                    if (!bo.q_blocks || bo.q_blocks[q]) { s_taken[bestRank] = 1; if (taken) taken[m] = 1; }
+                }
+                nmatches++;
+            }
+            if (lane == 0) { match[q] = m; bo.qbin[q] = bin; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (bo.check_ori) { // :1440-1471: every push_back counts, also for a keypoint that was assigned twice
+            __threadfence_block();
+            for (int q = lane; q < nq; q += 64)
+                if (match[q] >= 0) atomicAdd(&s_hist[bo.qbin[q]], 1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+            for (int i = 0; i < 30; i++) { // ComputeThreeMaxima, ORBmatcher.cc:1605-1646
+                const int sz = s_hist[i];
+                if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; ind3 = ind2; ind2 = ind1; ind1 = i; }
+                else if (sz > max2) { max3 = max2; max2 = sz; ind3 = ind2; ind2 = i; }
+                else if (sz > max3) { max3 = sz; ind3 = i; }
+            }
+            if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+            else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+            int removed = 0;
+            for (int q0 = 0; q0 < nq; q0 += 64) {
+                const int q = q0 + lane;
+                bool rm = false;
+                if (q < nq && match[q] >= 0) {
+                    const int bin = bo.qbin[q];
+                    rm = bin != ind1 && bin != ind2 && bin != ind3;
+                    if (rm) bo.match_cur[match[q]] = -1;
+                }
+                removed += __popcll(__ballot(rm));
+            }
+            nmatches -= removed;
+        }
+        if (lane == 0) *nmatches_out = nmatches;
+        return;
+    }
     for (int q = 0; q < nq; q++) {
         unsigned long long bk, sk;
         resolve(q, bk, sk);
@@ -791,6 +863,38 @@ static int undistort_params(const float* K4, const float* dist, int ndist, Undis
     P.fx = K4[0]; P.fy = K4[1]; P.cx = K4[2]; P.cy = K4[3];
     for (int i = 0; i < 12; i++) P.k[i] = i < ndist ? (double)dist[i] : 0.0;
     return ORBFE_OK;
+}
+
+// The projection of SearchByProjection(CurrentFrame, LastFrame) (ORBmatcher.cc:1362-1389): one lane per feature of the last
+// frame.  x3Dc = Rcw * x3Dw + tcw is OpenCV's 3x3 float product (a row is summed left to right in float) plus the float
+// translation; invzc is a double division rounded to float (:1371).  A query that is skipped gets r = -1.
+__global__ __launch_bounds__(256) void k_project_last_frame(const float* __restrict__ x3Dw, const uint8_t* __restrict__ valid,
+                                                            const orbfe_keypoint* __restrict__ kps_last, int n, const float* __restrict__ Tcw,
+                                                            float4 K, float4 bnd, const float* __restrict__ scale, int nlevels, float th,
+                                                            SbpQuery* __restrict__ queries, float* __restrict__ q_angle)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    SbpQuery Q{0.0f, 0.0f, -1.0f, 0, 0};
+    const orbfe_keypoint kp = kps_last[i];
+    q_angle[i] = kp.angle;
+    if (!valid || valid[i]) {
+        const float X = x3Dw[3 * i], Y = x3Dw[3 * i + 1], Z = x3Dw[3 * i + 2];
+        const float xc = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(Tcw[0], X), __fmul_rn(Tcw[1], Y)), __fmul_rn(Tcw[2], Z)), Tcw[3]);
+        const float yc = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(Tcw[4], X), __fmul_rn(Tcw[5], Y)), __fmul_rn(Tcw[6], Z)), Tcw[7]);
+        const float zc = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(Tcw[8], X), __fmul_rn(Tcw[9], Y)), __fmul_rn(Tcw[10], Z)), Tcw[11]);
+        const float invzc = (float)(1.0 / (double)zc);
+        if (!(invzc < 0)) {
+            const float u = __fadd_rn(__fmul_rn(__fmul_rn(K.x, xc), invzc), K.z);
+            const float v = __fadd_rn(__fmul_rn(__fmul_rn(K.y, yc), invzc), K.w);
+            // NaN coordinates (zc == 0 with xc == 0) are dropped here; the reference would index the grid with them
+            if (u >= bnd.x && u <= bnd.z && v >= bnd.y && v <= bnd.w) {
+                const int oct = min(max(kp.octave, 0), nlevels - 1);
+                Q = SbpQuery{u, v, __fmul_rn(th, scale[oct]), kp.octave - 1, kp.octave + 1}; // mono: :1396
+            }
+        }
+    }
+    queries[i] = Q;
 }
 
 struct MatchWorkspace {
@@ -1051,7 +1155,7 @@ int orbfe_search_by_projection(const orbfe_keypoint* kps, const uint8_t* desc, i
                            w.desc.as<uint8_t>(), n, ncap, frame_bounds(cols, rows, bounds), w.q.as<SbpQuery>(), w.t.as<uint8_t>(), nq,
                            taken ? w.prev.as<uint8_t>() : nullptr, mode, th_high, nnratio, w.csr_idx.as<uint16_t>(),
                            w.csr_dist.as<uint8_t>(), w.csr_cnt.as<int32_t>(), stride, o, o + nq, o + 2 * nq, o + 3 * nq,
-                           o + 4 * nq, o + 5 * nq, w.nm.as<int32_t>(), w.overflow.as<int32_t>());
+                           o + 4 * nq, o + 5 * nq, w.nm.as<int32_t>(), w.overflow.as<int32_t>(), SbpBest{});
         ORBFE_HIP(hipGetLastError());
         ORBFE_HIP(hipDeviceSynchronize());
         int32_t ovf = 0;
@@ -1074,6 +1178,117 @@ int orbfe_search_by_projection(const orbfe_keypoint* kps, const uint8_t* desc, i
         if (taken && n) ORBFE_HIP(hipMemcpy(taken, w.prev.p, (size_t)n, hipMemcpyDeviceToHost));
     }
     return ORBFE_OK;
+}
+
+// shared plumbing of the two "best only" entry points: queries either come from the host or are projected on the device
+static int sbp_best_run(const orbfe_keypoint* kps, const uint8_t* desc, int n, int cols, int rows, const float* bounds,
+                        const orbfe_window_query* queries, const float* q_angle, const uint8_t* qdesc, const uint8_t* q_blocks, int nq,
+                        const uint8_t* taken, int th_high, int check_ori, float factor, int32_t* match_cur, int32_t* nmatches,
+                        // projection request (x3Dw != NULL): the queries are built on the device
+                        const float* x3Dw, const uint8_t* valid, const orbfe_keypoint* kps_last, const float* Tcw, const float* K4,
+                        const float* scale, int nlevels, float th)
+{
+    if (n > 65535) return fail(ORBFE_ERR_INVALID, "more than 65535 keypoints per frame are unsupported");
+    *nmatches = 0;
+    for (int i = 0; i < n; i++) match_cur[i] = -1;
+    if (nq == 0 || n == 0) return ORBFE_OK;
+    int ncap = 64;
+    while (ncap < n) ncap <<= 1;
+    const size_t lds = (size_t)ncap * (4 + 8 + 1 + 1) + (SBP_CELLS + 2) * 2 + 64;
+    if (lds > 150 * 1024) return fail(ORBFE_ERR_CAPACITY, "%d keypoints do not fit the grid kernel's LDS", n);
+    MatchWorkspace& w = ws();
+    const size_t qo = (size_t)nq * 4;
+    int rc;
+    for (int attempt = 0;; attempt++) {
+        const int stride = std::max(w.sbp_stride, 128);
+        if ((rc = w.kps.ensure((size_t)n * sizeof(orbfe_keypoint))) || (rc = w.desc.ensure((size_t)n * 32)) ||
+            (rc = w.q.ensure((size_t)nq * sizeof(orbfe_window_query))) || (rc = w.t.ensure((size_t)nq * 32)) ||
+            (rc = w.prev.ensure((size_t)n)) || (rc = w.csr_idx.ensure((size_t)nq * stride * 2)) ||
+            (rc = w.csr_dist.ensure((size_t)nq * stride)) || (rc = w.csr_cnt.ensure(qo)) || (rc = w.obest.ensure(qo * 3)) ||
+            (rc = w.nm.ensure(16)) || (rc = w.overflow.ensure(16)) || (rc = w.m12.ensure((size_t)n * 4)) ||
+            (rc = w.scratch.ensure((size_t)nq * 16 + 256)) || (rc = w.pidx.ensure((size_t)nq * sizeof(orbfe_keypoint) + nq + 256)))
+            return rc;
+        ORBFE_HIP(hipMemcpy(w.kps.p, kps, (size_t)n * sizeof(orbfe_keypoint), hipMemcpyHostToDevice));
+        ORBFE_HIP(hipMemcpy(w.desc.p, desc, (size_t)n * 32, hipMemcpyHostToDevice));
+        if (taken) ORBFE_HIP(hipMemcpy(w.prev.p, taken, (size_t)n, hipMemcpyHostToDevice));
+        ORBFE_HIP(hipMemcpy(w.t.p, qdesc, (size_t)nq * 32, hipMemcpyHostToDevice));
+        // scratch: [q_angle f32 x nq | x3Dw f32 x 3nq]; pidx: [kps_last | valid / blocks bytes]
+        float* d_angle = w.scratch.as<float>();
+        uint8_t* d_flags = w.pidx.as<uint8_t>() + (size_t)nq * sizeof(orbfe_keypoint);
+        if (x3Dw) {
+            float* d_x = d_angle + nq;
+            ORBFE_HIP(hipMemcpy(d_x, x3Dw, (size_t)nq * 12, hipMemcpyHostToDevice));
+            ORBFE_HIP(hipMemcpy(w.pidx.p, kps_last, (size_t)nq * sizeof(orbfe_keypoint), hipMemcpyHostToDevice));
+            if (valid) ORBFE_HIP(hipMemcpy(d_flags, valid, (size_t)nq, hipMemcpyHostToDevice));
+            float h[12 + 16];
+            memcpy(h, Tcw, 48);
+            for (int l = 0; l < 16; l++) h[12 + l] = l < nlevels ? scale[l] : 0.0f;
+            if ((rc = w.pbest.ensure(sizeof h))) return rc;
+            ORBFE_HIP(hipMemcpy(w.pbest.p, h, sizeof h, hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(k_project_last_frame, dim3((nq + 255) / 256), dim3(256), 0, 0, d_x, valid ? d_flags : nullptr,
+                               w.pidx.as<orbfe_keypoint>(), nq, w.pbest.as<float>(), make_float4(K4[0], K4[1], K4[2], K4[3]),
+                               frame_bounds(cols, rows, bounds), w.pbest.as<float>() + 12, nlevels, th, w.q.as<SbpQuery>(), d_angle);
+            ORBFE_HIP(hipGetLastError());
+            ORBFE_HIP(hipDeviceSynchronize()); // d_flags is reused for the blocks flags below
+        } else {
+            ORBFE_HIP(hipMemcpy(w.q.p, queries, (size_t)nq * sizeof(orbfe_window_query), hipMemcpyHostToDevice));
+            ORBFE_HIP(hipMemcpy(d_angle, q_angle, (size_t)nq * 4, hipMemcpyHostToDevice));
+        }
+        if (q_blocks) ORBFE_HIP(hipMemcpy(d_flags, q_blocks, (size_t)nq, hipMemcpyHostToDevice));
+        ORBFE_HIP(hipMemset(w.overflow.p, 0, 4));
+        ORBFE_HIP(hipMemset(w.nm.p, 0, 4));
+        int32_t* o = w.obest.as<int32_t>();
+        SbpBest bo{d_angle, q_blocks ? d_flags : nullptr, factor, check_ori, w.m12.as<int32_t>(), o + nq};
+        ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_by_projection),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_search_by_projection, dim3(1), dim3(SBP_THREADS), lds, 0, w.kps.as<orbfe_keypoint>(), w.desc.as<uint8_t>(), n,
+                           ncap, frame_bounds(cols, rows, bounds), w.q.as<SbpQuery>(), w.t.as<uint8_t>(), nq,
+                           taken ? w.prev.as<uint8_t>() : nullptr, 2, th_high, 0.0f, w.csr_idx.as<uint16_t>(), w.csr_dist.as<uint8_t>(),
+                           w.csr_cnt.as<int32_t>(), stride, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr,
+                           (int32_t*)nullptr, o, w.nm.as<int32_t>(), w.overflow.as<int32_t>(), bo);
+        ORBFE_HIP(hipGetLastError());
+        ORBFE_HIP(hipDeviceSynchronize());
+        int32_t ovf = 0;
+        ORBFE_HIP(hipMemcpy(&ovf, w.overflow.p, 4, hipMemcpyDeviceToHost));
+        if (!ovf) break;
+        if (attempt) return fail(ORBFE_ERR_CAPACITY, "candidate row overflow (%d)", ovf);
+        w.sbp_stride = (ovf + 63) / 64 * 64;
+    }
+    ORBFE_HIP(hipMemcpy(match_cur, w.m12.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    ORBFE_HIP(hipMemcpy(nmatches, w.nm.p, 4, hipMemcpyDeviceToHost));
+    return ORBFE_OK;
+}
+
+int orbfe_search_by_projection_best(const orbfe_keypoint* kps, const uint8_t* desc, int n, int cols, int rows, const float* bounds,
+                                    const orbfe_window_query* queries, const float* q_angle, const uint8_t* qdesc, const uint8_t* q_blocks,
+                                    int nq, const uint8_t* taken, int th_high, int check_orientation, float factor, int32_t* match_cur,
+                                    int32_t* nmatches, int device)
+{
+    if (n < 0 || nq < 0 || cols <= 0 || rows <= 0 || !nmatches || (n && (!kps || !desc || !match_cur)) ||
+        (nq && (!queries || !qdesc || (check_orientation && !q_angle))))
+        return fail(ORBFE_ERR_INVALID, "orbfe_search_by_projection_best: invalid argument");
+    int rc = use_device(device);
+    if (rc) return rc;
+    std::vector<float> zero;
+    if (!q_angle) { zero.assign(std::max(nq, 1), 0.0f); q_angle = zero.data(); }
+    return sbp_best_run(kps, desc, n, cols, rows, bounds, queries, q_angle, qdesc, q_blocks, nq, taken, th_high, check_orientation, factor,
+                        match_cur, nmatches, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.0f);
+}
+
+int orbfe_search_by_projection_last_frame(const orbfe_keypoint* kps_cur, const uint8_t* desc_cur, int n_cur, const uint8_t* taken_cur,
+                                          int cols, int rows, const float* bounds, const orbfe_keypoint* kps_last, int n_last,
+                                          const uint8_t* valid_last, const float* x3Dw, const uint8_t* mp_desc, const uint8_t* mp_observed,
+                                          const float* Tcw, const float* K4, const float* scale_factors, int nlevels, float th, int th_high,
+                                          int check_orientation, int32_t* match_cur, int32_t* nmatches, int device)
+{
+    if (n_cur < 0 || n_last < 0 || cols <= 0 || rows <= 0 || !nmatches || (n_cur && (!kps_cur || !desc_cur || !match_cur)) ||
+        (n_last && (!kps_last || !x3Dw || !mp_desc)) || !Tcw || !K4 || !scale_factors || nlevels < 1 || nlevels > 16)
+        return fail(ORBFE_ERR_INVALID, "orbfe_search_by_projection_last_frame: invalid argument");
+    int rc = use_device(device);
+    if (rc) return rc;
+    return sbp_best_run(kps_cur, desc_cur, n_cur, cols, rows, bounds, nullptr, nullptr, mp_desc, mp_observed, n_last, taken_cur, th_high,
+                        check_orientation, 1.0f / 30 /* :1341 */, match_cur, nmatches, x3Dw, valid_last, kps_last, Tcw, K4, scale_factors,
+                        nlevels, th);
 }
 
 int orbfe_knn2_csr(const uint8_t* Q, int nq, const uint8_t* T, int nt, const int32_t* offsets, const int32_t* idx, int init,

@@ -353,6 +353,27 @@ def keyframe_features_unpack(buf, n):
     return k[:n], d[:n], m[:n]
 
 
+def search_by_projection_last_frame(kps_cur, desc_cur, cols, rows, kps_last, valid_last, x3Dw, mp_desc, Tcw, K4, scale_factors, th,
+                                    taken_cur=None, mp_observed=None, th_high=100, check_orientation=True, bounds=None):
+    L = lib()
+    kc = np.ascontiguousarray(kps_cur, KP_DTYPE); dc = np.ascontiguousarray(desc_cur, np.uint8).reshape(-1, 32)
+    kl = np.ascontiguousarray(kps_last, KP_DTYPE)
+    opt = lambda a, t: None if a is None else np.ascontiguousarray(a, t)
+    vl, tc, ob, bnd = opt(valid_last, np.uint8), opt(taken_cur, np.uint8), opt(mp_observed, np.uint8), opt(bounds, np.float32)
+    x = np.ascontiguousarray(x3Dw, np.float32).reshape(-1, 3); md = np.ascontiguousarray(mp_desc, np.uint8).reshape(-1, 32)
+    T = np.ascontiguousarray(Tcw, np.float32).reshape(-1)[:12].copy(); K = np.ascontiguousarray(K4, np.float32)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    m = np.full(max(len(kc), 1), -1, np.int32)
+    pp = lambda a: None if a is None else _p(a)
+    vp = C.c_void_p
+    L.oracle_search_by_projection_last_frame.restype = C.c_int
+    L.oracle_search_by_projection_last_frame.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp,
+                                                         C.c_float, C.c_int, C.c_int, vp]
+    nm = L.oracle_search_by_projection_last_frame(_p(kc), _p(dc), len(kc), pp(tc), cols, rows, pp(bnd), _p(kl), len(kl), pp(vl), _p(x),
+                                                  _p(md), pp(ob), _p(T), _p(K), _p(sf), th, th_high, int(check_orientation), _p(m))
+    return nm, m[:len(kc)]
+
+
 def search_for_initialization(k1, d1, k2, d2, cols, rows, prev=None, window=100, nnratio=0.9, check_ori=True, bounds=None):
     L = lib()
     k1 = np.ascontiguousarray(k1); k2 = np.ascontiguousarray(k2)

@@ -249,3 +249,73 @@ def test_undistort_keypoints_batch_device():
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, os.path.join(here, "device_pipeline_case.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def _motion_case(oracle, seed, depth_lo=1.0, depth_hi=6.0):
+    """Two consecutive stream frames; the last frame's keypoints get map points by back-projection at random depths (last
+    pose = identity) and the current pose is a small motion, so the projections land near the keypoints' new positions."""
+    s = synth.stream(480, 640, 2, 1000 + seed)
+    ex = oracle.OrbOracle(1000, 1.2, 8, 20, 7)
+    (kl, dl), (kc, dc) = ex.extract(s[0]), ex.extract(s[1])
+    rng = np.random.default_rng(seed)
+    K4 = np.array([517.3, 516.5, 318.6, 255.3], np.float32)
+    z = rng.uniform(depth_lo, depth_hi, len(kl)).astype(np.float32)
+    x3 = np.stack([(kl["x"] - K4[2]) / K4[0] * z, (kl["y"] - K4[3]) / K4[1] * z, z], 1).astype(np.float32)
+    a = 0.004 * rng.normal(size=3)
+    Rx = np.array([[1, -a[2], a[1]], [a[2], 1, -a[0]], [-a[1], a[0], 1]])
+    U, _, Vt = np.linalg.svd(Rx)
+    Tcw = np.concatenate([U @ Vt, (0.01 * rng.normal(size=3))[:, None]], 1).astype(np.float32)
+    x3[rng.random(len(kl)) < 0.02, 2] *= -1                           # a few points behind the camera (invzc < 0)
+    sf = np.array([1.2 ** i for i in range(8)], np.float32)
+    return kc, dc, kl, dl, x3, Tcw, K4, sf, rng
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,th,ori", [(1, 15.0, True), (2, 7.0, True), (3, 15.0, False), (4, 30.0, True)])
+def test_search_by_projection_last_frame(orbfe, oracle, seed, th, ori):
+    """SearchByProjection(CurrentFrame, LastFrame, th, mono) (ORBmatcher.cc:1332-1474), projection included: bit-exact."""
+    kc, dc, kl, dl, x3, Tcw, K4, sf, rng = _motion_case(oracle, seed)
+    valid = (rng.random(len(kl)) < 0.85).astype(np.uint8)
+    taken = (rng.random(len(kc)) < 0.05).astype(np.uint8)
+    observed = (rng.random(len(kl)) < 0.9).astype(np.uint8)              # unobserved map points do not block their keypoint
+    for tk, ob in ((None, None), (taken, observed)):
+        want = oracle.search_by_projection_last_frame(kc, dc, 640, 480, kl, valid, x3, dl, Tcw, K4, sf, th, tk, ob, 100, ori)
+        got = orbfe.search_by_projection_last_frame(kc, dc, 640, 480, kl, valid, x3, dl, Tcw, K4, sf, th, tk, ob, 100, ori)
+        assert got[0] == want[0] and np.array_equal(got[1], want[1])
+        assert got[0] > 10
+        m = got[1]
+        assert np.all(valid[m[m >= 0]] == 1)
+        if tk is not None:
+            assert np.all(m[taken == 1] == -1)
+
+
+@pytest.mark.gpu
+def test_search_by_projection_last_frame_edges(orbfe, oracle):
+    kc, dc, kl, dl, x3, Tcw, K4, sf, rng = _motion_case(oracle, 9)
+    nm, m = orbfe.search_by_projection_last_frame(kc, dc, 640, 480, kl[:0], None, x3[:0], dl[:0], Tcw, K4, sf, 15.0)
+    assert nm == 0 and np.all(m == -1)
+    nm, m = orbfe.search_by_projection_last_frame(kc[:0], dc[:0], 640, 480, kl, None, x3, dl, Tcw, K4, sf, 15.0)
+    assert nm == 0 and len(m) == 0
+    none = np.zeros(len(kl), np.uint8)
+    nm, m = orbfe.search_by_projection_last_frame(kc, dc, 640, 480, kl, none, x3, dl, Tcw, K4, sf, 15.0)
+    assert nm == 0 and np.all(m == -1)
+    # distorted-camera bounds are honoured by the projection test and the grid
+    b = np.array([-14.25, -9.5, 655.75, 489.0], np.float32)
+    want = oracle.search_by_projection_last_frame(kc, dc, 640, 480, kl, None, x3, dl, Tcw, K4, sf, 15.0, bounds=b)
+    got = orbfe.search_by_projection_last_frame(kc, dc, 640, 480, kl, None, x3, dl, Tcw, K4, sf, 15.0, bounds=b)
+    assert got[0] == want[0] and np.array_equal(got[1], want[1])
+    # the caller-projected variant with the same queries gives the same result
+    X = x3.astype(np.float32)
+    t0 = (Tcw[:, 0] * X[:, 0:1] + Tcw[:, 1] * X[:, 1:2]).astype(np.float32)
+    pc = ((t0 + Tcw[:, 2] * X[:, 2:3]).astype(np.float32) + Tcw[:, 3]).astype(np.float32)
+    inv = (1.0 / pc[:, 2].astype(np.float64)).astype(np.float32)
+    u = ((K4[0] * pc[:, 0]).astype(np.float32) * inv).astype(np.float32) + K4[2]
+    v = ((K4[1] * pc[:, 1]).astype(np.float32) * inv).astype(np.float32) + K4[3]
+    q = np.zeros(len(kl), orbfe.WINDOW_QUERY_DTYPE)
+    ok = ~(inv < 0) & (u >= 0) & (u <= 640) & (v >= 0) & (v <= 480)
+    q["x"], q["y"] = u, v
+    q["r"] = np.where(ok, np.float32(15.0) * sf[kl["octave"]], np.float32(-1))
+    q["min_level"], q["max_level"] = kl["octave"] - 1, kl["octave"] + 1
+    want = oracle.search_by_projection_last_frame(kc, dc, 640, 480, kl, None, x3, dl, Tcw, K4, sf, 15.0)
+    got = orbfe.search_by_projection_best(kc, dc, 640, 480, q, kl["angle"], dl, 100, 1.0 / 30)
+    assert got[0] == want[0] and np.array_equal(got[1], want[1])
