@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--nfeatures", type=int, default=1000)
     ap.add_argument("--nlevels", type=int, default=8)
     ap.add_argument("--dictionary", default="ARUCO")
-    ap.add_argument("--cpu-frames", type=int, default=24, help="frames timed on the host for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=300, help="frames timed on the host for cpu_baseline (0 = skip)")
     ap.add_argument("--no-aruco", action="store_true", help="diagnostic only: drop the ArUco leg (invalidates value)")
     ap.add_argument("--no-orb", action="store_true", help="diagnostic only: drop the ORB + matching legs (invalidates value)")
     return ap.parse_args()
@@ -67,31 +67,51 @@ MARKER_SIZE = 0.187   # Frame.cc:131
 
 
 def cpu_baseline(args, frames_u8):
-    """The oracle (CPU port of the reference path) timed single-threaded on a bounded sample of the same stream."""
+    """The oracle (CPU port of the reference path) on the same stream: single thread -- the reference runs extractor and
+    detector serially on the Tracking thread (Frame.cc:91,142) -- after 10 warm-up frames; and, as a second row, all host
+    cores with the frames sharded into contiguous blocks."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
+    from concurrent.futures import ThreadPoolExecutor
     n = min(args.cpu_frames, len(frames_u8))
     if n < 2:
         return None
-    orb = O.OrbOracle(args.nfeatures, 1.2, args.nlevels, 20, 7)
-    aruco = O.ArucoOracle(args.dictionary) if (hasattr(O, "ArucoOracle") and not args.no_aruco) else None
-    res = []
+    K = O.camera_resize(np.array(TUM1_K, np.float32), (1280, 720), (args.cols, args.rows))
+    D = np.array(TUM1_DIST, np.float32)
+    use_aruco = hasattr(O, "ArucoOracle") and not args.no_aruco
+
+    def run(frames):                       # ctypes releases the GIL inside the oracle calls
+        orb = O.OrbOracle(args.nfeatures, 1.2, args.nlevels, 20, 7)
+        aruco = O.ArucoOracle(args.dictionary) if use_aruco else None
+        prev = None
+        for img in frames:
+            k, d = orb.extract(img)
+            if aruco is not None:
+                for m in aruco.detect(img):
+                    O.marker_pose(m["corners"], MARKER_SIZE, K, D)
+            if prev is not None:
+                O.knn2(prev[1], d, 256)
+                O.search_for_initialization(prev[0], prev[1], k, d, args.cols, args.rows, None, 100, 0.9, True)
+            prev = (k, d)
+
+    run(frames_u8[:min(10, n)])            # warm-up
     t0 = time.perf_counter()
-    for i in range(n):
-        k, d = orb.extract(frames_u8[i])
-        if aruco is not None:
-            K = O.camera_resize(np.array(TUM1_K, np.float32), (1280, 720), (args.cols, args.rows))
-            for m in aruco.detect(frames_u8[i]):
-                O.marker_pose(m["corners"], MARKER_SIZE, K, np.array(TUM1_DIST, np.float32))
-        if res:
-            pk, pd = res[-1]
-            O.knn2(pd, d, 256)
-            O.search_for_initialization(pk, pd, k, d, args.cols, args.rows, None, 100, 0.9, True)
-        res.append((k, d))
+    run(frames_u8[:n])
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d frames of the same %dx%d stream, oracle/ single thread (ORB%s + knn2 + SearchForInitialization)"
-                      % (n, args.cols, args.rows, " + ArUco incl. marker poses" if aruco is not None else "")}
+    what = "ORB%s + knn2 + SearchForInitialization" % (" + ArUco incl. marker poses" if use_aruco else "")
+    out = {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": "%d frames of the same %dx%d stream after 10 warm-up frames, oracle/ single thread (%s)"
+                     % (n, args.cols, args.rows, what)}
+    cores = min(os.cpu_count() or 1, n // 4)      # blocks of >= 4 frames; `cores` = the threads actually used
+    if cores > 1:
+        blocks = [frames_u8[n * c // cores:n * (c + 1) // cores] for c in range(cores)]
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as pool:
+            list(pool.map(run, blocks))
+        dt = time.perf_counter() - t0
+        out["all_cores"] = {"value": n / dt, "unit": "frames/s", "cores": cores,
+                            "sample": "the same %d frames in %d contiguous blocks, one thread each" % (n, cores)}
+    return out
 
 
 def main():
@@ -133,6 +153,7 @@ def main():
     # overlap with batch i+1, which writes the other set.  A set is ONE contiguous buffer -- the record SURVEY 8e gathers:
     # {n_kp, kp[cap] x 28 B, desc[cap] x 32 B, n_mk, markers[mcap] x 36 B, poses[mcap] x 56 B} per frame -- so a batch is one collective.
     use_aruco = not args.no_aruco
+    big_frames = False
     mcap = binding.MarkerDetector(args.dictionary, device=local_rank).capacity if use_aruco else 0
     up = lambda v: (v + 255) // 256 * 256
     off_kps, off_desc = 0, up(B * cap * 28)
@@ -254,6 +275,18 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    if use_aruco:
+        # the device-pointer entry point cannot return a capacity error: ask once after the warm-up and once after the run.
+        # Frames with more long contours than the LDS-resident kernels hold (large, busy images) need the big-frame kernel.
+        if any(d.batch_status()[0] for d in dets):
+            for d in dets:
+                d.set_big_frames(True)
+            big_frames = True
+            for _ in range(max(args.warmup, 1)):
+                step()
+            torch.cuda.synchronize()
+            if any(d.batch_status()[0] for d in dets):
+                raise SystemExit("ArUco detector capacity exceeded at this frame size (flags 0x%x)" % dets[0].batch_status()[1])
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -270,6 +303,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if use_aruco and any(d.batch_status()[0] for d in dets):
+        raise SystemExit("ArUco detector capacity exceeded during the timed run: results incomplete, no number reported")
     # HIP-event timings of the LAST timed step's launches (events were recorded on the launch stream every step)
     orb_us = ex.kernel_times_us()
     aruco_us = det.kernel_times_us() if use_aruco else np.zeros(0, np.float32)
@@ -330,12 +365,13 @@ def main():
             "value": total_frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "C2: %d-frame %dx%d mono stream per GPU, nFeatures=%d, %d levels, %s dictionary; "
+            "config": {"workload": "%s: %d-frame %dx%d mono stream per GPU, nFeatures=%d, %d levels, %s dictionary; "
                                    "per frame: ORB extract%s + knn2 all-pairs + SearchForInitialization vs previous frame"
-                                   % (B, cols, rows, args.nfeatures, args.nlevels, args.dictionary,
+                                   % ({(480, 640, 300, 1000): "C2", (720, 1280, 300, 2000): "C3", (1080, 1920, 100, 4000): "C5 frames"}
+                                      .get((rows, cols, B, args.nfeatures), "custom"), B, cols, rows, args.nfeatures, args.nlevels, args.dictionary,
                                       " + ArUco detect incl. IPPE marker poses" if use_aruco else " (ArUco leg DISABLED: diagnostic run)"),
                        "frames_per_step_per_gpu": B, "mean_keypoints_per_frame": N,
-                       "sub_batches": S,
+                       "sub_batches": S, "aruco_big_frame_kernel": big_frames,
                        "parallelism": "stream-per-gpu x%d, RCCL gather to rank 0" % world},
             "roofline": roof, "cpu_baseline": cpu, "stage_us_last_step": stages,
         }

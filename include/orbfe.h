@@ -323,6 +323,14 @@ int orbfe_aruco_detect_batch(orbfe_aruco* h, const uint8_t* imgs, int nframes, s
 int orbfe_aruco_detect_batch_device(orbfe_aruco* h, const uint8_t* d_imgs, int nframes, size_t frame_stride, int rows,
                                     int cols, size_t step, orbfe_marker* d_out, int capacity, int32_t* d_n_out,
                                     void* stream);
+/* The batch entry point on device pointers cannot report a frame that exceeded the detector's internal capacities (more
+ * than 1024 contours longer than 70 points in a frame that the LDS-resident contour kernels handle; the host-pointer
+ * entry points retry such a batch with the big-frame kernel themselves).  After the batch: *nflagged = frames of the last
+ * batch whose results are incomplete, *flags_or = the union of their capacity flags (synchronises the device).
+ * orbfe_aruco_set_big_frames(h, 1) selects the big-frame contour kernel (bit image in HBM, 4096 kept contours) for all
+ * following batches. */
+int orbfe_aruco_batch_status(orbfe_aruco* h, int32_t* nflagged, int32_t* flags_or);
+int orbfe_aruco_set_big_frames(orbfe_aruco* h, int on);
 /* stage read-back for parity tests: 0 = thresholded image (rows x cols bytes, 0/255) of `frame` */
 int orbfe_aruco_debug_image(orbfe_aruco* h, int frame, int stage, uint8_t* out);
 /* As orbfe_extractor_set_aux_stream, for the detector's forked launches (the /2 pyramid). */

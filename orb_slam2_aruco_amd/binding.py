@@ -33,6 +33,7 @@ SYMBOLS = [
     "orbfe_aruco_create", "orbfe_aruco_destroy", "orbfe_aruco_set_dictionary", "orbfe_aruco_max_markers",
     "orbfe_aruco_detect", "orbfe_aruco_detect_batch", "orbfe_aruco_detect_batch_device", "orbfe_aruco_debug_image",
     "orbfe_aruco_debug_kernel_times", "orbfe_aruco_set_aux_stream",
+    "orbfe_aruco_batch_status", "orbfe_aruco_set_big_frames",
     "orbfe_camera_resize", "orbfe_marker_poses", "orbfe_marker_poses_batch_device",
     "orbfe_vocabulary_load_text", "orbfe_vocabulary_create", "orbfe_vocabulary_destroy", "orbfe_vocabulary_info",
     "orbfe_vocabulary_transform", "orbfe_vocabulary_transform_batch_device",
@@ -108,6 +109,8 @@ def load():
         L.orbfe_aruco_debug_image.argtypes = [vp, i32, i32, vp]
         L.orbfe_aruco_debug_kernel_times.argtypes = [vp, vp, i32]
         L.orbfe_aruco_set_aux_stream.argtypes = [vp, vp]
+        L.orbfe_aruco_batch_status.argtypes = [vp, vp, vp]
+        L.orbfe_aruco_set_big_frames.argtypes = [vp, i32]
         L.orbfe_camera_resize.argtypes = [vp, i32, i32, i32, i32, vp]
     if hasattr(L, "orbfe_vocabulary_create"):
         L.orbfe_vocabulary_load_text.restype = vp
@@ -624,6 +627,15 @@ class MarkerDetector:
         _check(self.L, self.L.orbfe_aruco_detect_batch_device(self.h, d_imgs_ptr, B, frame_stride, rows, cols, step,
                                                               d_out_ptr, capacity, d_n_ptr, stream),
                "orbfe_aruco_detect_batch_device")
+
+    def batch_status(self):
+        """(frames of the last device batch with incomplete results, union of their capacity flags)"""
+        n, fl = C.c_int32(0), C.c_int32(0)
+        _check(self.L, self.L.orbfe_aruco_batch_status(self.h, C.byref(n), C.byref(fl)), "orbfe_aruco_batch_status")
+        return n.value, fl.value
+
+    def set_big_frames(self, on=True):
+        _check(self.L, self.L.orbfe_aruco_set_big_frames(self.h, int(on)), "orbfe_aruco_set_big_frames")
 
     # stage read-back for parity tests
     def thresholded(self, frame=0):

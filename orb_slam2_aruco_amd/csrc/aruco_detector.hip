@@ -34,6 +34,7 @@ struct orbfe_aruco {
     int relay_kshift = 5;      // initial grid spacing (log2) of k_contours_relay
     int relay_tbits = 0;       // hash-table size of k_contours_relay (0: the kernel cannot run at this image size)
     bool force_legacy = false; // debug: always use k_contours_t
+    bool big_mode = false;     // frames with more kept borders than the LDS-resident kernels hold: bit image in HBM, AR_MAX_KEPT_BIG
     DevBuf d_codes, d_levels, d_tabs, d_bits, d_pyr, d_candq, d_pool, d_kept, d_rects, d_counts, d_candidx, d_ncand,
         d_result, d_gpad;
     DevBuf d_in, d_out, d_nout;
@@ -152,7 +153,7 @@ struct orbfe_aruco {
         const size_t padded_words = (size_t)pw * (rows_ + 2) + 2; // + spare words for ring8()
         // the padded bit image goes to LDS when it fits next to the other arrays (160 KiB per workgroup)
         lds_bits_words = (contours_lds_bytes((int)padded_words, AR_MAX_KEPT) <= 160 * 1024) ? (int)padded_words : 0;
-        gpad_fu32 = lds_bits_words ? 0 : padded_words;
+        gpad_fu32 = padded_words; // always there: big_mode uses the HBM variant at any size
         // k_contours_relay needs the bit image AND its marker table in LDS; otherwise k_contours_t does all frames
         // 4096 marker slots on a 32-pixel grid (one workgroup per CU).  A 2048-slot table on a 64-pixel grid would let two
         // workgroups share a CU, but its longer segments cost more than the sharing wins (measured: 857 vs 726 us).
@@ -176,7 +177,7 @@ struct orbfe_aruco {
         int rc;
         if ((rc = d_bits.ensure(bits_fu32 * 4 * B)) || (rc = d_pyr.ensure(pyr_fbytes * B)) ||
             (rc = d_candq.ensure(candq_fu32 * 4 * B)) || (rc = d_pool.ensure(pool_fu32 * 4 * B)) ||
-            (rc = d_kept.ensure((size_t)AR_MAX_KEPT * sizeof(ArKept) * B)) ||
+            (rc = d_kept.ensure((size_t)AR_MAX_KEPT_BIG * sizeof(ArKept) * B)) ||
             (rc = d_rects.ensure((size_t)AR_MAX_RECTS * sizeof(ArRect) * B)) || (rc = d_counts.ensure((size_t)16 * B)) ||
             (rc = d_candidx.ensure((size_t)AR_MAX_RECTS * 4 * B)) || (rc = d_ncand.ensure((size_t)4 * B)) ||
             (rc = d_result.ensure((size_t)AR_MAX_RECTS * 8 * B)) ||
@@ -230,12 +231,14 @@ struct orbfe_aruco {
             else hipLaunchKernelGGL(k_adaptive_threshold, tg, dim3(256), 0, s, src0, cols, rows, win, 7, 1.0 / (win * win), bp, bits_fu32, wpr);
         }
         timer.mark(s, "threshold");
-        const size_t lds = contours_lds_bytes(lds_bits_words, AR_MAX_KEPT);
+        const bool big = big_mode || !lds_bits_words;
+        const int legacy_kcap = big ? AR_MAX_KEPT_BIG : AR_MAX_KEPT, legacy_ldsw = big ? 0 : lds_bits_words;
+        const size_t lds = contours_lds_bytes(legacy_ldsw, legacy_kcap);
         ORBFE_HIP(hipGetLastError());
-        auto kfn = lds_bits_words ? k_contours_t<true> : k_contours_t<false>;
+        auto kfn = big ? k_contours_t<false> : k_contours_t<true>;
         ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));
-        const bool relay = relay_tbits && !force_legacy;
+        const bool relay = relay_tbits && !force_legacy && !big_mode;
         if (relay && !(g_aruco_skip & 1)) {
             const size_t rlds = relay_lds_bytes(lds_bits_words, RL_KCAP, relay_tbits);
             ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_contours_relay),
@@ -253,8 +256,8 @@ struct orbfe_aruco {
         }
         // the single-walker kernel: images whose bit image does not fit LDS next to the relay kernel's tables, or forced
         if (!relay && !(g_aruco_skip & 1)) hipLaunchKernelGGL(kfn, dim3(B), dim3(CT_PROBE_THREADS), lds, s, d_bits.as<uint32_t>(), bits_fu32, wpr, cols, rows,
-                           lds_bits_words, 70, d_candq.as<uint32_t>(), candq_fu32, (int)candq_fu32,
-                           d_pool.as<uint32_t>(), pool_fu32, (int)pool_fu32, d_kept.as<ArKept>(), AR_MAX_KEPT,
+                           legacy_ldsw, 70, d_candq.as<uint32_t>(), candq_fu32, (int)candq_fu32,
+                           d_pool.as<uint32_t>(), pool_fu32, (int)pool_fu32, d_kept.as<ArKept>(), legacy_kcap,
                            d_rects.as<ArRect>(), AR_MAX_RECTS, d_counts.as<int32_t>(), d_gpad.as<uint32_t>(),
                            gpad_fu32, 0);
         timer.mark(s, "contours");
@@ -374,13 +377,22 @@ int orbfe_aruco_detect_batch(orbfe_aruco* h, const uint8_t* imgs, int nframes, s
     for (int f = 0; f < nframes; f++)
         ORBFE_HIP(hipMemcpy2DAsync((uint8_t*)h->d_in.p + f * dframe, dpitch, imgs + f * frame_stride, step, cols, rows,
                                    hipMemcpyHostToDevice, s));
-    rc = h->run_device(h->d_in.as<uint8_t>(), nframes, dframe, rows, cols, dpitch, h->d_out.as<orbfe_marker>(),
-                       AR_MAX_RECTS, h->d_nout.as<int32_t>(), s);
-    if (rc) return rc;
-    ORBFE_HIP(hipMemcpyAsync(n_out, h->d_nout.p, (size_t)nframes * 4, hipMemcpyDeviceToHost, s));
-    ORBFE_HIP(hipStreamSynchronize(s));
     std::vector<int32_t> counts((size_t)nframes * 4);
-    ORBFE_HIP(hipMemcpy(counts.data(), h->d_counts.p, counts.size() * 4, hipMemcpyDeviceToHost));
+    for (int attempt = 0; attempt < 2; attempt++) {
+        rc = h->run_device(h->d_in.as<uint8_t>(), nframes, dframe, rows, cols, dpitch, h->d_out.as<orbfe_marker>(),
+                           AR_MAX_RECTS, h->d_nout.as<int32_t>(), s);
+        if (rc) { h->big_mode = false; return rc; }
+        ORBFE_HIP(hipMemcpyAsync(n_out, h->d_nout.p, (size_t)nframes * 4, hipMemcpyDeviceToHost, s));
+        ORBFE_HIP(hipStreamSynchronize(s));
+        ORBFE_HIP(hipMemcpy(counts.data(), h->d_counts.p, counts.size() * 4, hipMemcpyDeviceToHost));
+        bool retry = false;
+        for (int f = 0; f < nframes; f++) retry = retry || (counts[f * 4 + 2] & (2 | 4));
+        // a frame with more kept borders (or border points) than the LDS-resident kernels hold: the batch is done again
+        // by the single-walker kernel with its tables sized for AR_MAX_KEPT_BIG
+        if (!retry || h->big_mode) break;
+        h->big_mode = true;
+    }
+    h->big_mode = false;
     for (int f = 0; f < nframes; f++) {
         if (counts[f * 4 + 2])
             return fail(ORBFE_ERR_CAPACITY, "frame %d: internal detector capacity exceeded (flags 0x%x)", f, counts[f * 4 + 2]);
@@ -439,6 +451,29 @@ int orbfe_aruco_debug_image(orbfe_aruco* h, int frame, int stage, uint8_t* out)
         return ORBFE_OK;
     }
     return fail(ORBFE_ERR_INVALID, "debug_image: unknown stage %d", stage);
+}
+
+int orbfe_aruco_batch_status(orbfe_aruco* h, int32_t* nflagged, int32_t* flags_or)
+{
+    if (!h || !nflagged) return fail(ORBFE_ERR_INVALID, "orbfe_aruco_batch_status: null argument");
+    int rc = use_device(h->device);
+    if (rc) return rc;
+    *nflagged = 0;
+    if (flags_or) *flags_or = 0;
+    if (h->last_nframes <= 0) return ORBFE_OK;
+    ORBFE_HIP(hipDeviceSynchronize());
+    std::vector<int32_t> counts((size_t)h->last_nframes * 4);
+    ORBFE_HIP(hipMemcpy(counts.data(), h->d_counts.p, counts.size() * 4, hipMemcpyDeviceToHost));
+    for (int f = 0; f < h->last_nframes; f++)
+        if (counts[f * 4 + 2]) { (*nflagged)++; if (flags_or) *flags_or |= counts[f * 4 + 2]; }
+    return ORBFE_OK;
+}
+
+int orbfe_aruco_set_big_frames(orbfe_aruco* h, int on)
+{
+    if (!h) return fail(ORBFE_ERR_INVALID, "null handle");
+    h->big_mode = on != 0;
+    return ORBFE_OK;
 }
 
 int orbfe_aruco_set_aux_stream(orbfe_aruco* h, void* stream)

@@ -668,7 +668,9 @@ __device__ __forceinline__ int rl_find_or_insert(uint32_t* hkey, int tbits, uint
 {
     const uint32_t mask = (1u << tbits) - 1u;
     uint32_t h = rl_hash(key, tbits);
-    for (uint32_t p = 0; p <= mask; p++) {
+    // a probe sequence this long means the table is (nearly) full: the caller coarsens the grid.  Without the bound every
+    // insert into a full table walks all of it with atomics (1280x720 frames: 400x the time of the whole phase).
+    for (uint32_t p = 0; p <= min(mask, 255u); p++) {
         const uint32_t old = atomicCAS(&hkey[h], 0u, key);
         if (old == 0u) { *fresh = 1; return (int)h; }
         if (old == key) { *fresh = 0; return (int)h; }
@@ -810,6 +812,7 @@ __device__ __forceinline__ int relay_frame(
         auto add = [&](int x, int y) {
             const unsigned ring = ring8(im, x, y);
             if (!ring) return;
+            if (*(volatile int*)&s_flags & RL_FLAG_TABLE) return; // the table overflowed already: this pass is void
             relay_states_of_pixel(ring, grid_active(ring, x, y, kmask), [&](int st) {
                 int fresh = 0;
                 if (rl_find_or_insert(hkey, tbits, relay_key(x, y, st), &fresh) < 0) atomicOr(&s_flags, RL_FLAG_TABLE);
@@ -1183,60 +1186,62 @@ __device__ __forceinline__ int relay_frame(
         int* c_dst = c_pre + RL_COPY_CAP + 1;
         int* c_src = c_dst + RL_COPY_CAP;
         uint16_t* c_k = (uint16_t*)(c_src + RL_COPY_CAP);
-        int e0 = mine ? atomicAdd(&s_next, mine) : 0;
-#pragma unroll
-        for (int q = 0; q < RL_SLOTS_PER_THREAD; q++)
-            if (e_len[q] > 0) {
-                if (e0 < RL_COPY_CAP) { c_pre[e0] = e_len[q]; c_dst[e0] = e_dst[q]; c_src[e0] = e_src[q]; c_k[e0] = (uint16_t)e_k[q]; }
-                e0++;
-            }
+        const int ebase = mine ? atomicAdd(&s_next, mine) : 0;
         __syncthreads();
         const int E = s_next;
-        if (E > RL_COPY_CAP && kshift < 30) return 1; // again without a grid
-        if (E > RL_COPY_CAP) { // more kept segments than the copy list holds: capacity error
-            if (tid == 0) { counts[f * 4 + 0] = 0; counts[f * 4 + 1] = 0; counts[f * 4 + 2] = s_flags | 4; counts[f * 4 + 3] = 0; }
-            return 0;
-        }
-        // exclusive scan of the lengths (one entry per thread; RL_COPY_CAP == RL_THREADS)
-        {
-            const int lane = tid & 63, wid = tid >> 6;
-            const int len = tid < E ? c_pre[tid] : 0;
-            const int incl = wave_incl_scan_add(len);
-            __syncthreads();
-            if (lane == 63) c_pre[RL_COPY_CAP - 16 + wid] = incl; // wave totals parked at the end (entries there are read above)
-            __syncthreads();
-            int wbase = 0;
-            for (int w = 0; w < wid; w++) wbase += c_pre[RL_COPY_CAP - 16 + w];
-            __syncthreads();
-            c_pre[tid] = wbase + incl - len;
-            if (tid == NT - 1) c_pre[RL_COPY_CAP] = wbase + incl;
-            __syncthreads();
-        }
-        const int total = c_pre[RL_COPY_CAP];
-        for (int q0 = tid; q0 < total; q0 += 4 * NT) { // four independent points per lane: their latencies overlap
-            int pdst[4];
-            uint32_t v[4];
+        // the list holds RL_COPY_CAP entries; frames with more kept segments (large images) take several rounds
+        for (int r0 = 0; r0 < E; r0 += RL_COPY_CAP) {
+            const int Er = min(RL_COPY_CAP, E - r0);
+            int e0 = ebase - r0;
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int q = q0 + u * NT;
-                pdst[u] = -1;
-                if (q < total) {
-                    int lo = 0, hi = E - 1; // largest entry with c_pre <= q
-                    while (lo < hi) {
-                        const int mid = (lo + hi + 1) >> 1;
-                        if (c_pre[mid] <= q) lo = mid; else hi = mid - 1;
-                    }
-                    const int o = q - c_pre[lo], k = c_k[lo];
-                    const int base = off_u[k], n = (int)((kkey[k] >> 12) & 0xfffff);
-                    int p = c_dst[lo] + o;
-                    if (p < base) p += n;
-                    pdst[u] = p;
-                    v[u] = pl[c_src[lo] + o];
+            for (int q = 0; q < RL_SLOTS_PER_THREAD; q++)
+                if (e_len[q] > 0) {
+                    if (e0 >= 0 && e0 < RL_COPY_CAP) { c_pre[e0] = e_len[q]; c_dst[e0] = e_dst[q]; c_src[e0] = e_src[q]; c_k[e0] = (uint16_t)e_k[q]; }
+                    e0++;
                 }
+            __syncthreads();
+            // exclusive scan of the lengths (one entry per thread; RL_COPY_CAP == RL_THREADS)
+            {
+                const int lane = tid & 63, wid = tid >> 6;
+                const int len = tid < Er ? c_pre[tid] : 0;
+                const int incl = wave_incl_scan_add(len);
+                __syncthreads();
+                if (lane == 63) c_pre[RL_COPY_CAP - 16 + wid] = incl; // wave totals parked at the end (entries there are read above)
+                __syncthreads();
+                int wbase = 0;
+                for (int w = 0; w < wid; w++) wbase += c_pre[RL_COPY_CAP - 16 + w];
+                __syncthreads();
+                c_pre[tid] = wbase + incl - len;
+                if (tid == NT - 1) c_pre[RL_COPY_CAP] = wbase + incl;
+                __syncthreads();
             }
+            const int total = c_pre[RL_COPY_CAP];
+            for (int q0 = tid; q0 < total; q0 += 4 * NT) { // four independent points per lane: their latencies overlap
+                int pdst[4];
+                uint32_t v[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++)
-                if (pdst[u] >= 0) pl[pdst[u]] = v[u];
+                for (int u = 0; u < 4; u++) {
+                    const int q = q0 + u * NT;
+                    pdst[u] = -1;
+                    if (q < total) {
+                        int lo = 0, hi = Er - 1; // largest entry with c_pre <= q
+                        while (lo < hi) {
+                            const int mid = (lo + hi + 1) >> 1;
+                            if (c_pre[mid] <= q) lo = mid; else hi = mid - 1;
+                        }
+                        const int o = q - c_pre[lo], k = c_k[lo];
+                        const int base = off_u[k], n = (int)((kkey[k] >> 12) & 0xfffff);
+                        int p = c_dst[lo] + o;
+                        if (p < base) p += n;
+                        pdst[u] = p;
+                        v[u] = pl[c_src[lo] + o];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (pdst[u] >= 0) pl[pdst[u]] = v[u];
+            }
+            __syncthreads(); // the list is rewritten by the next round
         }
     }
     __threadfence_block();

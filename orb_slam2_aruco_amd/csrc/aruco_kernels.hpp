@@ -10,6 +10,7 @@ namespace orbfe {
 
 #define AR_MAX_RECTS 256
 #define AR_MAX_KEPT 1024
+#define AR_MAX_KEPT_BIG 4096 // the single-walker kernel with the bit image in HBM: LDS has room for this many kept borders
 
 // a border that passed the length gate and the 4-gon/convexity test
 struct ArKept {

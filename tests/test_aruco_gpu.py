@@ -152,3 +152,26 @@ def test_structured_binary_patterns(orbfe, oracle, pattern):
     assert np.array_equal(grects["corners"].reshape(-1, 8), orects[:, :8])
     assert np.array_equal(grects["len"], orects[:, 8].astype(np.int32))
     assert np.array_equal(got["id"], want["id"])
+
+
+def test_big_frame_kernel_same_results(orbfe, oracle):
+    """The big-frame contour kernel (bit image in HBM, 4096 kept contours) gives the same markers at an ordinary size."""
+    img, _ = synth.scene(480, 640, 2, "ARUCO", 4)
+    det = orbfe.MarkerDetector("ARUCO")
+    want = det.detect(img)
+    det.set_big_frames(True)
+    got = det.detect(img)
+    det.set_big_frames(False)
+    assert len(want) > 0 and np.array_equal(got["id"], want["id"]) and np.array_equal(got["corners"], want["corners"])
+
+
+def test_full_hd_frame_with_many_contours(orbfe, oracle):
+    """1920x1080 (config C5): more than 1024 contours longer than 70 points in a frame -> the host entry point redoes the batch
+    with the big-frame kernel instead of failing; markers equal the oracle's."""
+    img = synth.stream(1080, 1920, 1, 1000, "ARUCO", n_markers=4)[0]
+    det = orbfe.MarkerDetector("ARUCO")
+    got = det.detect(img)
+    want = oracle.ArucoOracle("ARUCO").detect(img)
+    assert len(want) > 0 and np.array_equal(got["id"], want["id"])
+    assert np.allclose(got["corners"], want["corners"], atol=1e-3)
+    assert det.counts(0)["nkept"] > 1024

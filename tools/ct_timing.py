@@ -4,8 +4,10 @@ import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from orb_slam2_aruco_amd import binding, synth
-imgs = synth.stream(480, 640, 300, 1000)[::38][:8].copy()
-det = binding.MarkerDetector("ARUCO")
+rows, cols = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (480, 640)
+dic = sys.argv[3] if len(sys.argv) > 3 else "ARUCO"
+imgs = synth.stream(rows, cols, 300 if rows == 480 else 40, 1000, dic)[::38 if rows == 480 else 5][:8].copy()
+det = binding.MarkerDetector(dic)
 for legacy in (False, True):
     det.force_legacy_contours(legacy)
     det.detect_batch(imgs)
