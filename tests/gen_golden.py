@@ -69,6 +69,39 @@ def main():
                         best_idx=r0["best_idx"], best_dist=r0["best_dist"], best_level=r0["best_level"],
                         second_dist=r0["second_dist"], second_level=r0["second_level"], match=r1["match"],
                         nmatches=np.array([r1["nmatches"]]), taken_after=r1["taken"])
+    # the rows built after the first three: pose, undistortion, vocabulary transform, SearchByBoW, last-frame projection
+    # search, on-disk keyframe records -- inputs are the seeded generators in tests/ and match_stream1000's two frames
+    import hashlib
+    import pose_cases as pc
+    import voc_cases as vc
+    cases = pc.random_cases(30, 123, 0.187, 0.2)
+    corners = np.stack([c for _, _, c in cases])
+    poses = np.zeros((len(cases), 12)); errs = np.zeros((len(cases), 2), np.float32)
+    for i, c in enumerate(corners):
+        r1, t1, r2, t2, e = O.marker_pose(c, 0.187, pc.K4, pc.DIST)
+        poses[i] = np.concatenate([r1, t1, r2, t2]); errs[i] = e
+    pts = np.random.default_rng(5).uniform([0, 0], [640, 480], (200, 2)).astype(np.float32)
+    und = O.undistort_points(pts, pc.K4, pc.DIST)
+    bnd = O.compute_image_bounds(640, 480, pc.K4, pc.DIST)
+    voc = vc.make(10, 4, 41, irregular=False)
+    ov = O.VocabularyOracle.from_arrays(10, 4, 0, 0, voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"])
+    t1, t2 = ov.transform(d1, 2), ov.transform(d2, 2)
+    valid1 = (np.random.default_rng(6).random(len(k1)) < 0.8).astype(np.uint8)
+    nb, b12, b21 = O.search_by_bow(k1, d1, t1["fv"], k2, d2, t2["fv"], valid1, None, 0.7, True, 50, 30 / 360.0)
+    rng = np.random.default_rng(8)
+    z = rng.uniform(1.0, 6.0, len(k1)).astype(np.float32)
+    K4 = np.array([517.3, 516.5, 318.6, 255.3], np.float32)
+    x3 = np.stack([(k1["x"] - K4[2]) / K4[0] * z, (k1["y"] - K4[3]) / K4[1] * z, z], 1).astype(np.float32)
+    Tcw = np.array([[1, -0.002, 0.001, 0.004], [0.002, 1, -0.003, -0.006], [-0.001, 0.003, 1, 0.01]], np.float32)
+    sf = np.array([1.2 ** i for i in range(8)], np.float32)
+    nl, ml = O.search_by_projection_last_frame(k2, d2, 640, 480, k1, valid1, x3, d1, Tcw, K4, sf, 15.0)
+    rec = O.keyframe_features_pack(k1, d1, np.arange(len(k1), dtype=np.uint64))
+    np.savez_compressed(os.path.join(OUT, "extras_stream1000.npz"), corners=corners, poses=poses, pose_err=errs, pts=pts, undistorted=und,
+                        bounds=bnd, word1=t1["word"], node1=t1["node"], bow1_words=t1["bow"][0], bow1_values=t1["bow"][1],
+                        fv1_nodes=t1["fv"][0], fv1_offsets=t1["fv"][1], fv1_features=t1["fv"][2], fv2_nodes=t2["fv"][0],
+                        fv2_offsets=t2["fv"][1], fv2_features=t2["fv"][2], valid1=valid1, bow_nmatches=np.array([nb]), bow_match12=b12,
+                        x3Dw=x3, Tcw=Tcw, last_nmatches=np.array([nl]), last_match_cur=ml,
+                        kf_sha256=np.frombuffer(hashlib.sha256(rec.tobytes()).digest(), np.uint8))
     print("wrote", sorted(os.listdir(OUT)))
 
 

@@ -492,3 +492,37 @@ def test_keyframe_feature_records(oracle):
     bad = buf.copy(); bad.view(KF_REC)["cols"][3] = 31
     with pytest.raises(ValueError):
         oracle.keyframe_features_unpack(bad, len(k))
+
+
+def _extras():
+    g = np.load(os.path.join(GOLD, "extras_stream1000.npz"))
+    m = np.load(os.path.join(GOLD, "match_stream1000.npz"))
+    return g, m
+
+
+def test_golden_extras(oracle):
+    """Pose, undistortion, vocabulary transform, SearchByBoW, last-frame projection search and keyframe records against the
+    committed vectors (tests/golden/extras_stream1000.npz; inputs: tests/pose_cases.py, tests/voc_cases.py, match_stream1000)."""
+    import hashlib
+    import pose_cases as pc
+    import voc_cases as vc
+    g, m = _extras()
+    for c, want, e in zip(g["corners"], g["poses"], g["pose_err"]):
+        r1, t1, r2, t2, err = oracle.marker_pose(c, 0.187, pc.K4, pc.DIST)
+        assert np.allclose(np.concatenate([r1, t1, r2, t2]), want, rtol=1e-9, atol=1e-12) and np.allclose(err, e, atol=1e-5)
+    assert np.array_equal(oracle.undistort_points(g["pts"], pc.K4, pc.DIST), g["undistorted"])
+    assert np.array_equal(oracle.compute_image_bounds(640, 480, pc.K4, pc.DIST), g["bounds"])
+    voc = vc.make(10, 4, 41, irregular=False)
+    ov = oracle.VocabularyOracle.from_arrays(10, 4, 0, 0, voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"])
+    t1 = ov.transform(m["d1"], 2)
+    assert np.array_equal(t1["word"], g["word1"]) and np.array_equal(t1["node"], g["node1"])
+    assert np.array_equal(t1["bow"][0], g["bow1_words"]) and np.array_equal(t1["bow"][1], g["bow1_values"])
+    fv1 = (g["fv1_nodes"], g["fv1_offsets"], g["fv1_features"]); fv2 = (g["fv2_nodes"], g["fv2_offsets"], g["fv2_features"])
+    assert all(np.array_equal(a, b) for a, b in zip(t1["fv"], fv1))
+    nb, b12, _ = oracle.search_by_bow(m["k1"], m["d1"], fv1, m["k2"], m["d2"], fv2, g["valid1"], None, 0.7, True, 50, 30 / 360.0)
+    assert nb == int(g["bow_nmatches"][0]) and np.array_equal(b12, g["bow_match12"])
+    K4 = np.array([517.3, 516.5, 318.6, 255.3], np.float32); sf = np.array([1.2 ** i for i in range(8)], np.float32)
+    nl, ml = oracle.search_by_projection_last_frame(m["k2"], m["d2"], 640, 480, m["k1"], g["valid1"], g["x3Dw"], m["d1"], g["Tcw"], K4, sf, 15.0)
+    assert nl == int(g["last_nmatches"][0]) and np.array_equal(ml, g["last_match_cur"])
+    rec = oracle.keyframe_features_pack(m["k1"], m["d1"], np.arange(len(m["k1"]), dtype=np.uint64))
+    assert np.array_equal(np.frombuffer(hashlib.sha256(rec.tobytes()).digest(), np.uint8), g["kf_sha256"])
