@@ -265,6 +265,27 @@ int orbfe_search_by_bow_batch_device(const orbfe_keypoint* d_kps, const uint8_t*
                                      int use_valid2, float nnratio, int check_orientation, int accept_max, float factor,
                                      int32_t* d_match12, int32_t* d_match21, int32_t* d_nmatches, void* stream);
 
+/* ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo = false) (src/ORBmatcher.cc:661-827),
+ * monocular: features of the two keyframes without a map point (has_mp* != 0 = skip, :710-714, :731-735; NULL = none has
+ * one), paired per vocabulary node, distance <= TH_LOW, not within 10 px * sqrt(scale) of the epipole (ex, ey) (:752-757,
+ * the caller computes it, :669-675), within the 3.84 sigma^2 band of the epipolar line x1' F12 (CheckDistEpipolarLine,
+ * :139-157; F12 3x3 row-major), rotation histogram with factor 1/HISTO_LENGTH.  scale_factors2 / level_sigma2_2 =
+ * pKF2->mvScaleFactors / mvLevelSigma2.  match12[i1] = i2 or -1: vMatchedPairs = the pairs in ascending i1. */
+int orbfe_search_for_triangulation(const orbfe_keypoint* kps1, const uint8_t* desc1, const uint8_t* has_mp1, int n1, const uint32_t* fv_node1,
+                                   const int32_t* fv_offset1, const uint32_t* fv_feature1, int nfv1, const orbfe_keypoint* kps2,
+                                   const uint8_t* desc2, const uint8_t* has_mp2, int n2, const uint32_t* fv_node2, const int32_t* fv_offset2,
+                                   const uint32_t* fv_feature2, int nfv2, const float* F12, float ex, float ey, const float* scale_factors2,
+                                   const float* level_sigma2_2, int nlevels, int check_orientation, int32_t* match12, int32_t* nmatches,
+                                   int device);
+/* Batch over pairs of frames as orbfe_search_by_bow_batch_device; d_free[i] != 0 = "feature i has no map point" (NULL = all),
+ * d_F12 npairs x 9 and d_epipole npairs x 2 on the device, the level tables on the host; d_scratch21 = capacity ints per pair. */
+int orbfe_search_for_triangulation_batch_device(const orbfe_keypoint* d_kps, const uint8_t* d_desc, const uint8_t* d_free, const int32_t* d_n,
+                                                const uint32_t* d_fv_node, const int32_t* d_fv_offset, const uint32_t* d_fv_feature,
+                                                const int32_t* d_nfv, int capacity, const int32_t* d_pair1, const int32_t* d_pair2, int npairs,
+                                                const float* d_F12, const float* d_epipole, const float* scale_factors,
+                                                const float* level_sigma2, int nlevels, int check_orientation, int32_t* d_match12,
+                                                int32_t* d_scratch21, int32_t* d_nmatches, void* stream);
+
 /* ------------------------------------------------------------------ Frame glue: undistortion -- */
 /* cv::undistortPoints(src, dst, K, distCoeffs, noArray(), K) (OpenCV 3.4: 5 fixed-point iterations in double) on n
  * (x, y) float pairs -- what Frame::UndistortKeyPoints (src/Frame.cc:357-387) and Frame::UndistortArucoCorners

@@ -491,6 +491,97 @@ int oracle_search_by_projection_last_frame(const void* kps_cur_, const uint8_t* 
     return nmatches;
 }
 
+/* ORBmatcher::CheckDistEpipolarLine (src/ORBmatcher.cc:139-157) */
+static bool CheckDistEpipolarLine(const KeyPoint& kp1, const KeyPoint& kp2, const float* F12, const float* mvLevelSigma2)
+{
+    const float a = kp1.x * F12[0] + kp1.y * F12[3] + F12[6];
+    const float b = kp1.x * F12[1] + kp1.y * F12[4] + F12[7];
+    const float c = kp1.x * F12[2] + kp1.y * F12[5] + F12[8];
+    const float num = a * kp2.x + b * kp2.y + c;
+    const float den = a * a + b * b;
+    if (den == 0) return false;
+    const float dsqr = num * num / den;
+    return dsqr < 3.84 * mvLevelSigma2[kp2.octave];
+}
+
+/* ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:661-827), monocular (bOnlyStereo = false, no right coordinates), on
+ * flat arrays.  has_mp1 / has_mp2 = "the feature already has a map point" (:710-714, :731-735).  F12 3x3 row-major, (ex, ey)
+ * the epipole in the second image (:669-675).  vbMatched2 is never set in the reference, so candidates are not consumed.
+ * match12[i1] = i2 or -1 (vMatchedPairs = the pairs in ascending i1); returns nmatches. */
+int oracle_search_for_triangulation(const void* kps1_, const uint8_t* desc1, const uint8_t* has_mp1, int n1, const uint32_t* fv_node1,
+                                    const int32_t* fv_off1, const uint32_t* fv_feat1, int nfv1, const void* kps2_, const uint8_t* desc2,
+                                    const uint8_t* has_mp2, int n2, const uint32_t* fv_node2, const int32_t* fv_off2,
+                                    const uint32_t* fv_feat2, int nfv2, const float* F12, float ex, float ey, const float* mvScaleFactors,
+                                    const float* mvLevelSigma2, int check_orientation, int32_t* vMatches12)
+{
+    const KeyPoint* k1 = (const KeyPoint*)kps1_;
+    const KeyPoint* k2 = (const KeyPoint*)kps2_;
+    int nmatches = 0;
+    std::vector<bool> vbMatched2(n2, false);
+    for (int i = 0; i < n1; i++) vMatches12[i] = -1;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    int a = 0, b = 0;
+    while (a != nfv1 && b != nfv2) {
+        if (fv_node1[a] == fv_node2[b]) {
+            for (int p1 = fv_off1[a]; p1 < fv_off1[a + 1]; p1++) {
+                const int idx1 = (int)fv_feat1[p1];
+                if (has_mp1 && has_mp1[idx1]) continue;
+                const KeyPoint& kp1 = k1[idx1];
+                const uint8_t* d1 = desc1 + 32 * (size_t)idx1;
+                int bestDist = TH_LOW, bestIdx2 = -1;
+                for (int p2 = fv_off2[b]; p2 < fv_off2[b + 1]; p2++) {
+                    const int idx2 = (int)fv_feat2[p2];
+                    if (vbMatched2[idx2] || (has_mp2 && has_mp2[idx2])) continue;
+                    const int dist = DescriptorDistance(d1, desc2 + 32 * (size_t)idx2);
+                    if (dist > TH_LOW || dist > bestDist) continue;
+                    const KeyPoint& kp2 = k2[idx2];
+                    {
+                        const float distex = ex - kp2.x;
+                        const float distey = ey - kp2.y;
+                        if (distex * distex + distey * distey < 100 * mvScaleFactors[kp2.octave]) continue;
+                    }
+                    if (CheckDistEpipolarLine(kp1, kp2, F12, mvLevelSigma2)) {
+                        bestIdx2 = idx2;
+                        bestDist = dist;
+                    }
+                }
+                if (bestIdx2 >= 0) {
+                    const KeyPoint& kp2 = k2[bestIdx2];
+                    vMatches12[idx1] = bestIdx2;
+                    nmatches++;
+                    if (check_orientation) {
+                        float rot = kp1.angle - kp2.angle;
+                        if (rot < 0.0) rot += 360.0f;
+                        int bin = (int)std::round(rot * factor);
+                        if (bin == HISTO_LENGTH) bin = 0;
+                        rotHist[bin].push_back(idx1);
+                    }
+                }
+            }
+            a++;
+            b++;
+        } else if (fv_node1[a] < fv_node2[b]) {
+            a = (int)(std::lower_bound(fv_node1, fv_node1 + nfv1, fv_node2[b]) - fv_node1);
+        } else {
+            b = (int)(std::lower_bound(fv_node2, fv_node2 + nfv2, fv_node1[a]) - fv_node2);
+        }
+    }
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1, sizes[HISTO_LENGTH];
+        for (int i = 0; i < HISTO_LENGTH; i++) sizes[i] = (int)rotHist[i].size();
+        ComputeThreeMaxima(sizes, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0; j < rotHist[i].size(); j++) {
+                vMatches12[rotHist[i][j]] = -1;
+                nmatches--;
+            }
+        }
+    }
+    return nmatches;
+}
+
 void oracle_three_maxima(const int* sizes, int L, int* out3)
 {
     int a = -1, b = -1, c = -1;

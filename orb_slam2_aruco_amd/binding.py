@@ -38,6 +38,7 @@ SYMBOLS = [
     "orbfe_vocabulary_load_text", "orbfe_vocabulary_create", "orbfe_vocabulary_destroy", "orbfe_vocabulary_info",
     "orbfe_vocabulary_transform", "orbfe_vocabulary_transform_batch_device",
     "orbfe_search_by_bow", "orbfe_search_by_bow_batch_device",
+    "orbfe_search_for_triangulation", "orbfe_search_for_triangulation_batch_device",
     "orbfe_search_by_projection_last_frame", "orbfe_search_by_projection_best",
     "orbfe_keyframe_features_pack", "orbfe_keyframe_features_unpack", "orbfe_keyframe_features_pack_device",
     "orbfe_keyframe_features_unpack_device",
@@ -128,6 +129,8 @@ def load():
         L.orbfe_keyframe_features_pack_device.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, vp]
         side = [vp, vp, vp, i32, vp, vp, vp, i32]
         L.orbfe_search_by_bow.argtypes = side + side + [f32, i32, i32, f32, vp, vp, vp, i32]
+        L.orbfe_search_for_triangulation.argtypes = side + side + [vp, f32, f32, vp, vp, i32, i32, vp, vp, i32]
+        L.orbfe_search_for_triangulation_batch_device.argtypes = [vp] * 8 + [i32, vp, vp, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]
         L.orbfe_search_by_bow_batch_device.argtypes = [vp] * 8 + [i32, vp, vp, i32, i32, f32, i32, i32, f32, vp, vp, vp, vp]
         L.orbfe_marker_poses.argtypes = [vp, i32, f32, vp, vp, i32, vp, i32]
         L.orbfe_marker_poses_batch_device.argtypes = [vp, vp, i32, i32, f32, vp, vp, i32, vp, vp]
@@ -509,6 +512,26 @@ def keyframe_features_unpack(buf, n, device=0):
     k = np.zeros(n, KP_DTYPE); d = np.zeros((n, 32), np.uint8); m = np.zeros(n, np.uint64)
     _check(L, L.orbfe_keyframe_features_unpack(_p(b), n, _p(k), _p(d), _p(m), device), "orbfe_keyframe_features_unpack")
     return k, d, m
+
+
+def search_for_triangulation(kps1, desc1, fv1, kps2, desc2, fv2, F12, epipole, scale_factors, level_sigma2, has_mp1=None, has_mp2=None,
+                             check_orientation=True, device=0):
+    """ORBmatcher::SearchForTriangulation (ORBmatcher.cc:661-827, mono) -> (nmatches, match12)."""
+    L = load()
+    k1 = np.ascontiguousarray(kps1, KP_DTYPE); k2 = np.ascontiguousarray(kps2, KP_DTYPE)
+    d1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32); d2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
+    a = [np.ascontiguousarray(fv1[0], np.uint32), np.ascontiguousarray(fv1[1], np.int32), np.ascontiguousarray(fv1[2], np.uint32)]
+    b = [np.ascontiguousarray(fv2[0], np.uint32), np.ascontiguousarray(fv2[1], np.int32), np.ascontiguousarray(fv2[2], np.uint32)]
+    h1 = None if has_mp1 is None else np.ascontiguousarray(has_mp1, np.uint8)
+    h2 = None if has_mp2 is None else np.ascontiguousarray(has_mp2, np.uint8)
+    F = np.ascontiguousarray(F12, np.float32).reshape(9); sf = np.ascontiguousarray(scale_factors, np.float32)
+    sg = np.ascontiguousarray(level_sigma2, np.float32)
+    m12 = np.full(len(k1), -1, np.int32); nm = C.c_int32(0)
+    _check(L, L.orbfe_search_for_triangulation(_p(k1), _p(d1), None if h1 is None else _p(h1), len(k1), _p(a[0]), _p(a[1]), _p(a[2]), len(a[0]),
+                                               _p(k2), _p(d2), None if h2 is None else _p(h2), len(k2), _p(b[0]), _p(b[1]), _p(b[2]), len(b[0]),
+                                               _p(F), np.float32(epipole[0]), np.float32(epipole[1]), _p(sf), _p(sg), len(sf),
+                                               int(check_orientation), _p(m12), C.byref(nm), device), "orbfe_search_for_triangulation")
+    return nm.value, m12
 
 
 class ORBVocabulary:

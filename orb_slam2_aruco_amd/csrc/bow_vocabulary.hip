@@ -232,11 +232,21 @@ struct BowFrames {
     int capacity;
 };
 
+// SearchForTriangulation (ORBmatcher.cc:661-827, monocular) shares the node pairing and the histogram: tri.F12 != NULL selects
+// its candidate rule -- no taken-feature coupling (the reference never sets vbMatched2), candidates pass dist <= TH_LOW, the
+// epipole distance gate (:752-757) and CheckDistEpipolarLine (:139-157); the last of the equally near candidates wins (:749).
+struct TriParams {
+    const float* F12;      // npairs x 9, row major
+    const float* epipole;  // npairs x 2 (ex, ey), :669-675
+    float scale[16], sigma2[16]; // pKF2->mvScaleFactors, mvLevelSigma2
+};
+
 __global__ __launch_bounds__(SB_THREADS) void k_search_by_bow(BowFrames F, const int32_t* __restrict__ pair1, const int32_t* __restrict__ pair2,
                                                              int use_valid2, float nnratio, int check_ori, int accept_max, float factor,
                                                              int32_t* __restrict__ match12, int32_t* __restrict__ match21,
-                                                             int32_t* __restrict__ nmatches)
+                                                             int32_t* __restrict__ nmatches, TriParams tri)
 {
+    const bool tri_mode = tri.F12 != nullptr;
     __shared__ short s_m12[SB_MAX], s_m21[SB_MAX];
     __shared__ signed char s_bin[SB_MAX];
     __shared__ int s_hist[30], s_nm, s_ind[3];
@@ -270,23 +280,47 @@ __global__ __launch_bounds__(SB_THREADS) void k_search_by_bow(BowFrames F, const
             if (idx1 >= n1 || (valid1 && !valid1[idx1])) continue;
             const uint4 qa = d1v[2 * idx1], qb = d1v[2 * idx1 + 1];
             int bestd = 256, second = 256, key = (256 << 16) | 0xffff;
+            float la = 0.0f, lb = 0.0f, lc = 0.0f, lden = 0.0f, ex = 0.0f, ey = 0.0f;
+            if (tri_mode) { // epipolar line of kp1 in the second image, l = x1' F12 (:142-145)
+                const float* Fm = tri.F12 + 9 * (size_t)p;
+                const float x1 = k1[idx1].x, y1 = k1[idx1].y;
+                la = __fadd_rn(__fadd_rn(__fmul_rn(x1, Fm[0]), __fmul_rn(y1, Fm[3])), Fm[6]);
+                lb = __fadd_rn(__fadd_rn(__fmul_rn(x1, Fm[1]), __fmul_rn(y1, Fm[4])), Fm[7]);
+                lc = __fadd_rn(__fadd_rn(__fmul_rn(x1, Fm[2]), __fmul_rn(y1, Fm[5])), Fm[8]);
+                lden = __fadd_rn(__fmul_rn(la, la), __fmul_rn(lb, lb));
+                ex = tri.epipole[2 * p]; ey = tri.epipole[2 * p + 1];
+            }
             for (int p2 = o2 + lane; p2 < e2; p2 += 64) {
                 const int idx2 = (int)feat2[p2];
-                if (idx2 >= n2 || s_m21[idx2] >= 0 || (valid2 && !valid2[idx2])) continue;
+                if (idx2 >= n2 || (!tri_mode && s_m21[idx2] >= 0) || (valid2 && !valid2[idx2])) continue;
                 const uint4 ta = d2v[2 * idx2], tb = d2v[2 * idx2 + 1];
                 const int dist = __popc(ta.x ^ qa.x) + __popc(ta.y ^ qa.y) + __popc(ta.z ^ qa.z) + __popc(ta.w ^ qa.w) +
                                  __popc(tb.x ^ qb.x) + __popc(tb.y ^ qb.y) + __popc(tb.z ^ qb.z) + __popc(tb.w ^ qb.w);
+                if (tri_mode) {
+                    if (dist > accept_max) continue; // :749
+                    const orbfe_keypoint kp2 = k2[idx2];
+                    const int oct = min(max(kp2.octave, 0), 15);
+                    const float dex = ex - kp2.x, dey = ey - kp2.y;
+                    if (__fadd_rn(__fmul_rn(dex, dex), __fmul_rn(dey, dey)) < __fmul_rn(100.0f, tri.scale[oct])) continue; // :752-757
+                    const float num = __fadd_rn(__fadd_rn(__fmul_rn(la, kp2.x), __fmul_rn(lb, kp2.y)), lc);
+                    if (lden == 0.0f) continue;
+                    const float dsqr = __fdiv_rn(__fmul_rn(num, num), lden);
+                    if (!((double)dsqr < 3.84 * (double)tri.sigma2[oct])) continue; // :156
+                    const int k = (dist << 16) | (0xffff - (p2 - o2)); // "dist > bestDist" skips: of equal distances the last stays
+                    if (k < key) { key = k; bestd = dist; }
+                    continue;
+                }
                 if (dist < bestd) { second = bestd; bestd = dist; key = (dist << 16) | (p2 - o2); }
                 else if (dist < second) second = dist;
             }
             const int B = wave_min(key);
             const int S = wave_min(key == B ? second : bestd);
             const int bestDist1 = B >> 16;
-            if (bestDist1 <= accept_max && (float)bestDist1 < __fmul_rn(nnratio, (float)S)) {
-                const int idx2 = (int)feat2[o2 + (B & 0xffff)];
+            if (tri_mode ? (B >> 16) <= accept_max : (bestDist1 <= accept_max && (float)bestDist1 < __fmul_rn(nnratio, (float)S))) {
+                const int idx2 = (int)feat2[o2 + (tri_mode ? 0xffff - (B & 0xffff) : (B & 0xffff))];
                 if (lane == 0) {
                     s_m12[idx1] = (short)idx2;
-                    s_m21[idx2] = (short)idx1;
+                    if (!tri_mode) s_m21[idx2] = (short)idx1;
                     if (check_ori) {
                         float rot = k1[idx1].angle - k2[idx2].angle;
                         if (rot < 0.0f) rot += 360.0f;
@@ -323,7 +357,7 @@ __global__ __launch_bounds__(SB_THREADS) void k_search_by_bow(BowFrames F, const
         for (int i = threadIdx.x; i < n1; i += SB_THREADS) {
             const int bin = s_bin[i];
             if (bin >= 0 && bin != s_ind[0] && bin != s_ind[1] && bin != s_ind[2]) {
-                s_m21[s_m12[i]] = -1;
+                if (!tri_mode) s_m21[s_m12[i]] = -1;
                 s_m12[i] = -1;
                 removed++;
             }
@@ -602,8 +636,87 @@ int orbfe_search_by_bow_batch_device(const orbfe_keypoint* d_kps, const uint8_t*
     if (npairs == 0) return ORBFE_OK;
     BowFrames F{d_kps, d_desc, d_valid, d_n, d_fv_node, d_fv_offset, d_fv_feature, d_nfv, capacity};
     hipLaunchKernelGGL(k_search_by_bow, dim3(npairs), dim3(SB_THREADS), 0, (hipStream_t)stream, F, d_pair1, d_pair2, use_valid2, nnratio,
-                       check_orientation, accept_max, factor, d_match12, d_match21, d_nmatches);
+                       check_orientation, accept_max, factor, d_match12, d_match21, d_nmatches, TriParams{});
     ORBFE_HIP(hipGetLastError());
+    return ORBFE_OK;
+}
+
+int orbfe_search_for_triangulation_batch_device(const orbfe_keypoint* d_kps, const uint8_t* d_desc, const uint8_t* d_free, const int32_t* d_n,
+                                                const uint32_t* d_fv_node, const int32_t* d_fv_offset, const uint32_t* d_fv_feature,
+                                                const int32_t* d_nfv, int capacity, const int32_t* d_pair1, const int32_t* d_pair2, int npairs,
+                                                const float* d_F12, const float* d_epipole, const float* scale_factors,
+                                                const float* level_sigma2, int nlevels, int check_orientation, int32_t* d_match12,
+                                                int32_t* d_scratch21, int32_t* d_nmatches, void* stream)
+{
+    if (npairs < 0 || capacity <= 0 || !d_kps || !d_desc || !d_n || !d_fv_node || !d_fv_offset || !d_fv_feature || !d_nfv || !d_match12 ||
+        !d_scratch21 || !d_nmatches || !d_F12 || !d_epipole || !scale_factors || !level_sigma2 || nlevels < 1 || nlevels > 16)
+        return fail(ORBFE_ERR_INVALID, "orbfe_search_for_triangulation_batch_device: invalid argument");
+    if (capacity > SB_MAX) return fail(ORBFE_ERR_CAPACITY, "orbfe_search_for_triangulation: at most %d features per frame", SB_MAX);
+    if (npairs == 0) return ORBFE_OK;
+    TriParams tri{};
+    tri.F12 = d_F12; tri.epipole = d_epipole;
+    for (int l = 0; l < 16; l++) { tri.scale[l] = scale_factors[std::min(l, nlevels - 1)]; tri.sigma2[l] = level_sigma2[std::min(l, nlevels - 1)]; }
+    BowFrames F{d_kps, d_desc, d_free, d_n, d_fv_node, d_fv_offset, d_fv_feature, d_nfv, capacity};
+    hipLaunchKernelGGL(k_search_by_bow, dim3(npairs), dim3(SB_THREADS), 0, (hipStream_t)stream, F, d_pair1, d_pair2, 1, 0.0f,
+                       check_orientation, 50 /* TH_LOW */, 1.0f / 30 /* :693 */, d_match12, d_scratch21, d_nmatches, tri);
+    ORBFE_HIP(hipGetLastError());
+    return ORBFE_OK;
+}
+
+int orbfe_search_for_triangulation(const orbfe_keypoint* kps1, const uint8_t* desc1, const uint8_t* has_mp1, int n1, const uint32_t* fv_node1,
+                                   const int32_t* fv_offset1, const uint32_t* fv_feature1, int nfv1, const orbfe_keypoint* kps2,
+                                   const uint8_t* desc2, const uint8_t* has_mp2, int n2, const uint32_t* fv_node2, const int32_t* fv_offset2,
+                                   const uint32_t* fv_feature2, int nfv2, const float* F12, float ex, float ey, const float* scale_factors2,
+                                   const float* level_sigma2_2, int nlevels, int check_orientation, int32_t* match12, int32_t* nmatches,
+                                   int device)
+{
+    if (n1 < 0 || n2 < 0 || nfv1 < 0 || nfv2 < 0 || nfv1 > n1 || nfv2 > n2 || !nmatches || !F12 || !scale_factors2 || !level_sigma2_2 ||
+        nlevels < 1 || nlevels > 16 || (n1 && (!kps1 || !desc1 || !match12)) || (n2 && (!kps2 || !desc2)) ||
+        (nfv1 && (!fv_node1 || !fv_offset1 || !fv_feature1)) || (nfv2 && (!fv_node2 || !fv_offset2 || !fv_feature2)))
+        return fail(ORBFE_ERR_INVALID, "orbfe_search_for_triangulation: invalid argument");
+    if (nfv1 && (fv_offset1[0] != 0 || fv_offset1[nfv1] > n1)) return fail(ORBFE_ERR_INVALID, "orbfe_search_for_triangulation: bad FeatureVector 1");
+    if (nfv2 && (fv_offset2[0] != 0 || fv_offset2[nfv2] > n2)) return fail(ORBFE_ERR_INVALID, "orbfe_search_for_triangulation: bad FeatureVector 2");
+    int rc = use_device(device);
+    if (rc) return rc;
+    *nmatches = 0;
+    for (int i = 0; i < n1; i++) match12[i] = -1;
+    if (n1 == 0 || n2 == 0 || nfv1 == 0 || nfv2 == 0) return ORBFE_OK;
+    const int cap = std::max(n1, n2);
+    if (cap > SB_MAX) return fail(ORBFE_ERR_CAPACITY, "orbfe_search_for_triangulation: at most %d features per frame", SB_MAX);
+    if (!tl_bow_ws) tl_bow_ws = new BowMatchWorkspace();
+    BowMatchWorkspace& w = *tl_bow_ws;
+    const size_t C = (size_t)cap;
+    if ((rc = w.kps.ensure(2 * C * sizeof(orbfe_keypoint))) || (rc = w.desc.ensure(2 * C * 32)) || (rc = w.valid.ensure(2 * C)) ||
+        (rc = w.n.ensure(16)) || (rc = w.fn.ensure(2 * C * 4)) || (rc = w.fo.ensure(2 * (C + 1) * 4)) || (rc = w.ff.ensure(2 * C * 4)) ||
+        (rc = w.nf.ensure(64)) || (rc = w.m12.ensure(C * 4)) || (rc = w.m21.ensure(C * 4)) || (rc = w.nm.ensure(64)))
+        return rc;
+    std::vector<uint8_t> freef(2 * C, 1); // "no map point yet" (:710-714, :731-735)
+    if (has_mp1) for (int i = 0; i < n1; i++) freef[i] = !has_mp1[i];
+    if (has_mp2) for (int i = 0; i < n2; i++) freef[C + i] = !has_mp2[i];
+    const int32_t nn[2] = {n1, n2}, nf[2] = {nfv1, nfv2};
+    const float fe[11] = {F12[0], F12[1], F12[2], F12[3], F12[4], F12[5], F12[6], F12[7], F12[8], ex, ey};
+    ORBFE_HIP(hipMemcpy(w.kps.p, kps1, (size_t)n1 * sizeof(orbfe_keypoint), hipMemcpyHostToDevice));
+    ORBFE_HIP(hipMemcpy(w.kps.as<orbfe_keypoint>() + C, kps2, (size_t)n2 * sizeof(orbfe_keypoint), hipMemcpyHostToDevice));
+    ORBFE_HIP(hipMemcpy(w.desc.p, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice));
+    ORBFE_HIP(hipMemcpy(w.desc.as<uint8_t>() + C * 32, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice));
+    ORBFE_HIP(hipMemcpy(w.valid.p, freef.data(), 2 * C, hipMemcpyHostToDevice));
+    ORBFE_HIP(hipMemcpy(w.n.p, nn, 8, hipMemcpyHostToDevice));
+    ORBFE_HIP(hipMemcpy(w.nf.p, nf, 8, hipMemcpyHostToDevice));
+    ORBFE_HIP(hipMemcpy(w.nm.as<float>() + 4, fe, sizeof fe, hipMemcpyHostToDevice));
+    ORBFE_HIP(hipMemcpy(w.fn.p, fv_node1, (size_t)nfv1 * 4, hipMemcpyHostToDevice));
+    ORBFE_HIP(hipMemcpy(w.fn.as<uint32_t>() + C, fv_node2, (size_t)nfv2 * 4, hipMemcpyHostToDevice));
+    ORBFE_HIP(hipMemcpy(w.fo.p, fv_offset1, (size_t)(nfv1 + 1) * 4, hipMemcpyHostToDevice));
+    ORBFE_HIP(hipMemcpy(w.fo.as<int32_t>() + C + 1, fv_offset2, (size_t)(nfv2 + 1) * 4, hipMemcpyHostToDevice));
+    ORBFE_HIP(hipMemcpy(w.ff.p, fv_feature1, (size_t)fv_offset1[nfv1] * 4, hipMemcpyHostToDevice));
+    ORBFE_HIP(hipMemcpy(w.ff.as<uint32_t>() + C, fv_feature2, (size_t)fv_offset2[nfv2] * 4, hipMemcpyHostToDevice));
+    rc = orbfe_search_for_triangulation_batch_device(w.kps.as<orbfe_keypoint>(), w.desc.as<uint8_t>(), w.valid.as<uint8_t>(), w.n.as<int32_t>(),
+                                                     w.fn.as<uint32_t>(), w.fo.as<int32_t>(), w.ff.as<uint32_t>(), w.nf.as<int32_t>(), cap, nullptr,
+                                                     nullptr, 1, w.nm.as<float>() + 4, w.nm.as<float>() + 13, scale_factors2, level_sigma2_2,
+                                                     nlevels, check_orientation, w.m12.as<int32_t>(), w.m21.as<int32_t>(), w.nm.as<int32_t>(),
+                                                     nullptr);
+    if (rc) return rc;
+    ORBFE_HIP(hipMemcpy(match12, w.m12.p, (size_t)n1 * 4, hipMemcpyDeviceToHost));
+    ORBFE_HIP(hipMemcpy(nmatches, w.nm.p, 4, hipMemcpyDeviceToHost));
     return ORBFE_OK;
 }
 

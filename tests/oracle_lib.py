@@ -374,6 +374,27 @@ def search_by_projection_last_frame(kps_cur, desc_cur, cols, rows, kps_last, val
     return nm, m[:len(kc)]
 
 
+def search_for_triangulation(kps1, desc1, fv1, kps2, desc2, fv2, F12, epipole, scale_factors, level_sigma2, has_mp1=None, has_mp2=None,
+                             check_orientation=True):
+    L = lib()
+    k1 = np.ascontiguousarray(kps1, KP_DTYPE); k2 = np.ascontiguousarray(kps2, KP_DTYPE)
+    d1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32); d2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
+    a = [np.ascontiguousarray(fv1[0], np.uint32), np.ascontiguousarray(fv1[1], np.int32), np.ascontiguousarray(fv1[2], np.uint32)]
+    b = [np.ascontiguousarray(fv2[0], np.uint32), np.ascontiguousarray(fv2[1], np.int32), np.ascontiguousarray(fv2[2], np.uint32)]
+    h1 = None if has_mp1 is None else np.ascontiguousarray(has_mp1, np.uint8)
+    h2 = None if has_mp2 is None else np.ascontiguousarray(has_mp2, np.uint8)
+    F = np.ascontiguousarray(F12, np.float32).reshape(9); sf = np.ascontiguousarray(scale_factors, np.float32)
+    sg = np.ascontiguousarray(level_sigma2, np.float32)
+    m12 = np.full(max(len(k1), 1), -1, np.int32)
+    side = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.oracle_search_for_triangulation.restype = C.c_int
+    L.oracle_search_for_triangulation.argtypes = side + side + [C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    nm = L.oracle_search_for_triangulation(_p(k1), _p(d1), None if h1 is None else _p(h1), len(k1), _p(a[0]), _p(a[1]), _p(a[2]), len(a[0]),
+                                           _p(k2), _p(d2), None if h2 is None else _p(h2), len(k2), _p(b[0]), _p(b[1]), _p(b[2]), len(b[0]),
+                                           _p(F), np.float32(epipole[0]), np.float32(epipole[1]), _p(sf), _p(sg), int(check_orientation), _p(m12))
+    return nm, m12[:len(k1)]
+
+
 def search_for_initialization(k1, d1, k2, d2, cols, rows, prev=None, window=100, nnratio=0.9, check_ori=True, bounds=None):
     L = lib()
     k1 = np.ascontiguousarray(k1); k2 = np.ascontiguousarray(k2)

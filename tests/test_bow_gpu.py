@@ -140,3 +140,27 @@ def test_search_by_bow_edge_cases(orbfe, oracle):
     want = oracle.search_by_bow(k1, d1, f1, k2, d2, f2, None, None, 0.9, True, 50, 30 / 360.0)
     got = orbfe.search_by_bow(k1, d1, f1, k2, d2, f2, None, None, 0.9, True, 50, 30 / 360.0)
     assert got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+
+
+@pytest.mark.parametrize("seed,levelsup,ori", [(1, 2, True), (2, 3, True), (3, 4, False), (4, 1, True)])
+def test_search_for_triangulation(orbfe, oracle, seed, levelsup, ori):
+    """SearchForTriangulation (ORBmatcher.cc:661-827): node pairing, map-point skips, epipole gate, epipolar band, the
+    last-of-equals rule and the rotation histogram, bit-exact.  F12 = horizontal epipolar lines (y2 = y1)."""
+    k1, d1, fv1, k2, d2, fv2 = _two_frames(orbfe, oracle, seed, 4, levelsup)
+    rng = np.random.default_rng(seed)
+    has1 = (rng.random(len(k1)) < 0.3).astype(np.uint8); has2 = (rng.random(len(k2)) < 0.3).astype(np.uint8)
+    F12 = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32)
+    sf = np.array([1.2 ** i for i in range(8)], np.float32); sg = (sf * sf).astype(np.float32)
+    for F, ep in ((F12, (320.0, 240.0)), (F12 * np.float32(0.37), (-1e4, 240.0)), (np.zeros((3, 3), np.float32), (0.0, 0.0))):
+        want = oracle.search_for_triangulation(k1, d1, fv1, k2, d2, fv2, F, ep, sf, sg, has1, has2, ori)
+        got = orbfe.search_for_triangulation(k1, d1, fv1, k2, d2, fv2, F, ep, sf, sg, has1, has2, ori)
+        assert got[0] == want[0] and np.array_equal(got[1], want[1])
+        assert got[0] == (got[1] >= 0).sum()
+        if F.any():
+            assert got[0] > 0 and np.all(has1[got[1] >= 0] == 0) and np.all(has2[got[1][got[1] >= 0]] == 0)
+        else:
+            assert got[0] == 0                              # den == 0: CheckDistEpipolarLine is false (:151-152)
+    # the same frame on both sides: every free feature has several candidates at distance 0 only if descriptors repeat
+    want = oracle.search_for_triangulation(k1, d1, fv1, k1, d1, fv1, F12, (1e5, 1e5), sf, sg, None, None, True)
+    got = orbfe.search_for_triangulation(k1, d1, fv1, k1, d1, fv1, F12, (1e5, 1e5), sf, sg, None, None, True)
+    assert got[0] == want[0] and np.array_equal(got[1], want[1]) and got[0] > 500
