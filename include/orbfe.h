@@ -199,6 +199,27 @@ int orbfe_search_by_projection_best(const orbfe_keypoint* kps, const uint8_t* de
                                     int nq, const uint8_t* taken, int th_high, int check_orientation, float factor, int32_t* match_cur,
                                     int32_t* nmatches, int device);
 
+/* The matching part of ORBmatcher::Fuse(pKF, vpMapPoints, th) (src/ORBmatcher.cc:829-970; chi2 = 5.99) and of Fuse(pKF, Scw,
+ * vpPoints, th, vpReplacePoint) (:972-1104; chi2 = 0, Tcw / Ow from the decomposed Scw) on the device: per map point the
+ * projection and gates (positive depth, KeyFrame::IsInImage, scale-invariance range, viewing angle < 60 deg), PredictScale,
+ * the window search on the keyframe grid at levels [predicted - 1, predicted], the reprojection gate and the best
+ * descriptor distance.  valid[i] = "pMP && !isBad() && !IsInKeyFrame(pKF)" resp. "!isBad() && !alreadyFound" (NULL = all);
+ * min_dist / max_dist = Get{Min,Max}DistanceInvariance(), normal = GetNormal() (nmp x 3), mp_desc = GetDescriptor().
+ * Tcw = 3x4 row-major [Rcw | tcw], Ow = camera centre (3).  best_idx[i] = keypoint or -1, best_dist[i] = its distance (256
+ * if none); the caller applies bestDist <= TH_LOW and does the map bookkeeping (Replace / AddObservation, :943-964). */
+int orbfe_fuse_search(const orbfe_keypoint* kps, const uint8_t* desc, int n, int cols, int rows, const float* bounds, const float* p3Dw,
+                      const uint8_t* valid, const float* min_dist, const float* max_dist, const float* normal, const uint8_t* mp_desc, int nmp,
+                      const float* Tcw, const float* Ow, const float* K4, const float* scale_factors, const float* inv_level_sigma2, int nlevels,
+                      float log_scale_factor, float th, double chi2, int32_t* best_idx, int32_t* best_dist, int device);
+/* Only the projection + gates + PredictScale, as window queries for orbfe_search_by_projection / _best (the keyframe variants of
+ * SearchByProjection, :294-407 and :1476-1603, project the same way with other level ranges): r < 0 = not searched,
+ * min_level = predicted - level_below, max_level = predicted + level_above.  normal == NULL: no viewing-angle gate;
+ * strict_max != 0: KeyFrame::IsInImage (x < mnMaxX), else the Frame test (u <= mnMaxX). */
+int orbfe_project_map_points(const float* p3Dw, const uint8_t* valid, const float* min_dist, const float* max_dist, const float* normal, int n,
+                             const float* Tcw, const float* Ow, const float* K4, int cols, int rows, const float* bounds, int strict_max,
+                             const float* scale_factors, int nlevels, float log_scale_factor, float th, int level_below, int level_above,
+                             orbfe_window_query* queries, int device);
+
 /* Batched device variant over npairs frame pairs (frame t vs t-1 of a stream); all arrays are blocks of `capacity`
  * records per frame; pair p matches frame p (as F1) against frame p+1 (as F2). prev_matched == NULL means
  * "start from F1's own keypoint positions" (what Tracking does on the first call, src/Tracking.cc:520-523). */

@@ -582,6 +582,68 @@ int oracle_search_for_triangulation(const void* kps1_, const uint8_t* desc1, con
     return nmatches;
 }
 
+/* The matching part of ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th) (src/ORBmatcher.cc:829-970) and of Fuse(KeyFrame*, Scw,
+ * vpPoints, th, vpReplacePoint) (:972-1104) on flat arrays: per map point the projection and gates (:848-893 / :1008-1049),
+ * MapPoint::PredictScale (MapPoint.cc:414-429; `log` evaluated in double), KeyFrame::GetFeaturesInArea (KeyFrame.cc:672-711,
+ * the Frame grid), levels [predicted - 1, predicted], the mono reprojection gate e2 * invSigma2 > chi2 (:920-931; chi2 = 0:
+ * the Scw variant has none), best distance.  What is done with (bestIdx, bestDist <= TH_LOW) -- Replace / AddObservation --
+ * is map bookkeeping and stays with the caller.  valid[i] = pMP && !isBad() && !IsInKeyFrame / !alreadyFound.
+ * Tcw = 3x4 row-major [Rcw | tcw], Ow = camera centre.  best_idx[i] = keypoint or -1, best_dist[i] (256 if none). */
+void oracle_fuse_search(const void* kps_, const uint8_t* desc, int n, int cols, int rows, const float* bounds, const float* p3Dw,
+                        const uint8_t* valid, const float* min_dist, const float* max_dist, const float* normal, const uint8_t* mp_desc,
+                        int nmp, const float* Tcw, const float* Ow, const float* K4, const float* mvScaleFactors,
+                        const float* mvInvLevelSigma2, int nlevels, float mfLogScaleFactor, float th, double chi2, int32_t* best_idx,
+                        int32_t* best_dist)
+{
+    const KeyPoint* kps = (const KeyPoint*)kps_;
+    FrameGrid grid(kps, n, cols, rows, bounds);
+    const float fx = K4[0], fy = K4[1], cx = K4[2], cy = K4[3];
+    for (int i = 0; i < nmp; i++) {
+        best_idx[i] = -1; best_dist[i] = 256;
+        if (valid && !valid[i]) continue;
+        const float X = p3Dw[3 * i], Y = p3Dw[3 * i + 1], Z = p3Dw[3 * i + 2];
+        float t0 = Tcw[0] * X + Tcw[1] * Y + Tcw[2] * Z, t1 = Tcw[4] * X + Tcw[5] * Y + Tcw[6] * Z, t2 = Tcw[8] * X + Tcw[9] * Y + Tcw[10] * Z;
+        const float p3Dc[3] = {(float)(t0 * 1.0 + 1.0 * Tcw[3]), (float)(t1 * 1.0 + 1.0 * Tcw[7]), (float)(t2 * 1.0 + 1.0 * Tcw[11])};
+        if (p3Dc[2] < 0.0f) continue;
+        const float invz = 1 / p3Dc[2];
+        const float x = p3Dc[0] * invz;
+        const float y = p3Dc[1] * invz;
+        const float u = fx * x + cx;
+        const float v = fy * y + cy;
+        if (!(u >= grid.mnMinX && u < grid.mnMaxX && v >= grid.mnMinY && v < grid.mnMaxY)) continue; /* KeyFrame::IsInImage */
+        const float maxDistance = max_dist[i], minDistance = min_dist[i];
+        const float PO[3] = {X - Ow[0], Y - Ow[1], Z - Ow[2]};
+        const float dist3D = std::sqrt((double)PO[0] * PO[0] + (double)PO[1] * PO[1] + (double)PO[2] * PO[2]); /* cv::norm */
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        const double dot = (double)PO[0] * normal[3 * i] + (double)PO[1] * normal[3 * i + 1] + (double)PO[2] * normal[3 * i + 2];
+        if (dot < 0.5 * dist3D) continue;
+        float ratio = maxDistance / dist3D;
+        int nPredictedLevel = (int)std::ceil(std::log((double)ratio) / mfLogScaleFactor);
+        if (nPredictedLevel < 0) nPredictedLevel = 0;
+        else if (nPredictedLevel >= nlevels) nPredictedLevel = nlevels - 1;
+        const float radius = th * mvScaleFactors[nPredictedLevel];
+        const std::vector<int> vIndices = grid.GetFeaturesInArea(u, v, radius, -1, -1);
+        if (vIndices.empty()) continue;
+        const uint8_t* dMP = mp_desc + 32 * (size_t)i;
+        int bestDist = 256, bestIdx = -1;
+        for (size_t k = 0; k < vIndices.size(); k++) {
+            const int idx = vIndices[k];
+            const KeyPoint& kp = kps[idx];
+            const int kpLevel = kp.octave;
+            if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+            if (chi2 > 0) {
+                const float ex = u - kp.x;
+                const float ey = v - kp.y;
+                const float e2 = ex * ex + ey * ey;
+                if (e2 * mvInvLevelSigma2[kpLevel] > chi2) continue;
+            }
+            const int dist = DescriptorDistance(dMP, desc + 32 * (size_t)idx);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        best_idx[i] = bestIdx; best_dist[i] = bestDist;
+    }
+}
+
 void oracle_three_maxima(const int* sizes, int L, int* out3)
 {
     int a = -1, b = -1, c = -1;

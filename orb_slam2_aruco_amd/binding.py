@@ -39,7 +39,7 @@ SYMBOLS = [
     "orbfe_vocabulary_transform", "orbfe_vocabulary_transform_batch_device",
     "orbfe_search_by_bow", "orbfe_search_by_bow_batch_device",
     "orbfe_search_for_triangulation", "orbfe_search_for_triangulation_batch_device",
-    "orbfe_search_by_projection_last_frame", "orbfe_search_by_projection_best",
+    "orbfe_search_by_projection_last_frame", "orbfe_search_by_projection_best", "orbfe_fuse_search", "orbfe_project_map_points",
     "orbfe_keyframe_features_pack", "orbfe_keyframe_features_unpack", "orbfe_keyframe_features_pack_device",
     "orbfe_keyframe_features_unpack_device",
 ]
@@ -87,6 +87,9 @@ def load():
         L.orbfe_hamming.argtypes = [vp, vp]
         L.orbfe_search_by_projection_last_frame.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, f32,
                                                             i32, i32, vp, vp, i32]
+        L.orbfe_fuse_search.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, f32, f32, C.c_double,
+                                        vp, vp, i32]
+        L.orbfe_project_map_points.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp, i32, vp, i32, f32, f32, i32, i32, vp, i32]
         L.orbfe_search_by_projection_best.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp, i32, i32, f32, vp, vp, i32]
         L.orbfe_undistort_points.argtypes = [vp, i32, vp, vp, i32, vp, i32]
         L.orbfe_undistort_keypoints_batch_device.argtypes = [vp, vp, i32, i32, vp, vp, i32, vp, vp]
@@ -413,6 +416,38 @@ def search_by_projection_best(kps, desc, cols, rows, queries, q_angle, qdesc, th
                                                 th_high, int(check_orientation), np.float32(factor), _p(m), C.byref(nm), device),
            "orbfe_search_by_projection_best")
     return nm.value, m
+
+
+def fuse_search(kps, desc, cols, rows, p3Dw, valid, min_dist, max_dist, normal, mp_desc, Tcw, Ow, K4, scale_factors, inv_level_sigma2,
+                log_scale_factor, th, chi2=5.99, bounds=None, device=0):
+    """Matching part of ORBmatcher::Fuse (ORBmatcher.cc:829-970; chi2=0: the Scw variant :972-1104) -> (best_idx, best_dist)."""
+    L = load()
+    k = np.ascontiguousarray(kps, KP_DTYPE); d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    f = lambda a, t=np.float32: np.ascontiguousarray(a, t)
+    x, mn, mx, nr, md = f(p3Dw).reshape(-1, 3), f(min_dist), f(max_dist), f(normal).reshape(-1, 3), f(mp_desc, np.uint8).reshape(-1, 32)
+    v = None if valid is None else f(valid, np.uint8); bnd = None if bounds is None else f(bounds)
+    T, O, K, sf, isg = f(Tcw).reshape(-1)[:12].copy(), f(Ow), f(K4), f(scale_factors), f(inv_level_sigma2)
+    bi = np.full(len(x), -1, np.int32); bd = np.full(len(x), 256, np.int32)
+    pp = lambda a: None if a is None else _p(a)
+    _check(L, L.orbfe_fuse_search(_p(k), _p(d), len(k), cols, rows, pp(bnd), _p(x), pp(v), _p(mn), _p(mx), _p(nr), _p(md), len(x), _p(T), _p(O),
+                                  _p(K), _p(sf), _p(isg), len(sf), log_scale_factor, th, float(chi2), _p(bi), _p(bd), device), "orbfe_fuse_search")
+    return bi, bd
+
+
+def project_map_points(p3Dw, valid, min_dist, max_dist, normal, Tcw, Ow, K4, cols, rows, scale_factors, log_scale_factor, th, level_below,
+                       level_above, strict_max=True, bounds=None, device=0):
+    """Projection + gates + PredictScale -> WINDOW_QUERY_DTYPE records (r < 0 = not searched)."""
+    L = load()
+    f = lambda a, t=np.float32: np.ascontiguousarray(a, t)
+    x, mn, mx = f(p3Dw).reshape(-1, 3), f(min_dist), f(max_dist)
+    nr = None if normal is None else f(normal).reshape(-1, 3)
+    v = None if valid is None else f(valid, np.uint8); bnd = None if bounds is None else f(bounds)
+    T, O, K, sf = f(Tcw).reshape(-1)[:12].copy(), f(Ow), f(K4), f(scale_factors)
+    q = np.zeros(len(x), WINDOW_QUERY_DTYPE)
+    pp = lambda a: None if a is None else _p(a)
+    _check(L, L.orbfe_project_map_points(_p(x), pp(v), _p(mn), _p(mx), pp(nr), len(x), _p(T), _p(O), _p(K), cols, rows, pp(bnd), int(strict_max),
+                                         _p(sf), len(sf), log_scale_factor, th, level_below, level_above, _p(q), device), "orbfe_project_map_points")
+    return q
 
 
 class ORBmatcher:

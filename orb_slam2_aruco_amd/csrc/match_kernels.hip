@@ -579,6 +579,9 @@ struct SbpBest { // mode 2 only
     int check_ori;
     int32_t* match_cur;       // n entries
     int32_t* qbin;            // nq entries of scratch
+    // any mode: the reprojection gate of Fuse (ORBmatcher.cc:925-931): skip a candidate when e2 * inv_sigma2[level] > chi2
+    double chi2;              // 0 = no gate
+    float inv_sigma2[16];
 };
 
 __global__ __launch_bounds__(SBP_THREADS) void k_search_by_projection(
@@ -681,6 +684,11 @@ __global__ __launch_bounds__(SBP_THREADS) void k_search_by_projection(
                         if (ok) {
                             const float2 p = s_xy[j];
                             ok = fabsf(p.x - x) < r && fabsf(p.y - y) < r;
+                            if (ok && bo.chi2 > 0.0) {
+                                const float ex = x - p.x, ey = y - p.y;
+                                const float e2 = __fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey));
+                                ok = !((double)__fmul_rn(e2, bo.inv_sigma2[min(lv, 15)]) > bo.chi2);
+                            }
                         }
                     }
                     const unsigned long long m = __ballot(ok);
@@ -891,6 +899,57 @@ __global__ __launch_bounds__(256) void k_project_last_frame(const float* __restr
             if (u >= bnd.x && u <= bnd.z && v >= bnd.y && v <= bnd.w) {
                 const int oct = min(max(kp.octave, 0), nlevels - 1);
                 Q = SbpQuery{u, v, __fmul_rn(th, scale[oct]), kp.octave - 1, kp.octave + 1}; // mono: :1396
+            }
+        }
+    }
+    queries[i] = Q;
+}
+
+// The projection and visibility gates shared by Fuse (ORBmatcher.cc:848-893 and :1008-1049) and the keyframe variants of
+// SearchByProjection (:321-358, :1497-1530): camera coordinates (OpenCV's 3x3 float product + float translation), positive
+// depth, inside the image, distance inside the scale-invariance range, optional viewing-angle gate (P - Ow) . n >= 0.5 d
+// (cv::Mat::dot and cv::norm accumulate in double), MapPoint::PredictScale (MapPoint.cc:414-429, evaluated in double), search
+// radius th * scale[level].  One lane per map point; a point that is not searched gets r = -1.
+struct ProjectParams {
+    float T[12], Ow[3], K[4], bnd[4], scale[16];
+    int nlevels, strict_max, level_below, level_above;
+    float log_scale, th;
+};
+
+__global__ __launch_bounds__(256) void k_project_map_points(const float* __restrict__ p3Dw, const uint8_t* __restrict__ valid,
+                                                            const float* __restrict__ min_dist, const float* __restrict__ max_dist,
+                                                            const float* __restrict__ normal, int n, ProjectParams P,
+                                                            SbpQuery* __restrict__ queries)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    SbpQuery Q{0.0f, 0.0f, -1.0f, 0, 0};
+    if (!valid || valid[i]) {
+        const float X = p3Dw[3 * i], Y = p3Dw[3 * i + 1], Z = p3Dw[3 * i + 2];
+        const float xc = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(P.T[0], X), __fmul_rn(P.T[1], Y)), __fmul_rn(P.T[2], Z)), P.T[3]);
+        const float yc = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(P.T[4], X), __fmul_rn(P.T[5], Y)), __fmul_rn(P.T[6], Z)), P.T[7]);
+        const float zc = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(P.T[8], X), __fmul_rn(P.T[9], Y)), __fmul_rn(P.T[10], Z)), P.T[11]);
+        if (!(zc < 0.0f)) {
+            const float invz = __fdiv_rn(1.0f, zc);
+            const float u = __fadd_rn(__fmul_rn(P.K[0], __fmul_rn(xc, invz)), P.K[2]);
+            const float v = __fadd_rn(__fmul_rn(P.K[1], __fmul_rn(yc, invz)), P.K[3]);
+            const bool inside = P.strict_max ? (u >= P.bnd[0] && u < P.bnd[2] && v >= P.bnd[1] && v < P.bnd[3])  // KeyFrame::IsInImage
+                                             : (u >= P.bnd[0] && u <= P.bnd[2] && v >= P.bnd[1] && v <= P.bnd[3]);
+            if (inside) {
+                const float px = X - P.Ow[0], py = Y - P.Ow[1], pz = Z - P.Ow[2];
+                const float dist3D = (float)sqrt((double)px * px + (double)py * py + (double)pz * pz);
+                bool ok = !(dist3D < min_dist[i] || dist3D > max_dist[i]);
+                if (ok && normal) {
+                    const double dot = (double)px * normal[3 * i] + (double)py * normal[3 * i + 1] + (double)pz * normal[3 * i + 2];
+                    ok = !(dot < 0.5 * (double)dist3D);
+                }
+                if (ok) {
+                    const float ratio = __fdiv_rn(max_dist[i], dist3D);
+                    int lvl = (int)ceil(log((double)ratio) / (double)P.log_scale);
+                    if (lvl < 0) lvl = 0;
+                    else if (lvl >= P.nlevels) lvl = P.nlevels - 1;
+                    Q = SbpQuery{u, v, __fmul_rn(P.th, P.scale[lvl]), lvl - P.level_below, lvl + P.level_above};
+                }
             }
         }
     }
@@ -1289,6 +1348,113 @@ int orbfe_search_by_projection_last_frame(const orbfe_keypoint* kps_cur, const u
     return sbp_best_run(kps_cur, desc_cur, n_cur, cols, rows, bounds, nullptr, nullptr, mp_desc, mp_observed, n_last, taken_cur, th_high,
                         check_orientation, 1.0f / 30 /* :1341 */, match_cur, nmatches, x3Dw, valid_last, kps_last, Tcw, K4, scale_factors,
                         nlevels, th);
+}
+
+static int project_params(ProjectParams& P, const float* Tcw, const float* Ow, const float* K4, int cols, int rows, const float* bounds,
+                          int strict_max, const float* scale, int nlevels, float log_scale, float th, int below, int above, const char* who)
+{
+    if (!Tcw || !Ow || !K4 || !scale || nlevels < 1 || nlevels > 16 || cols <= 0 || rows <= 0 || !(log_scale > 0.0f))
+        return fail(ORBFE_ERR_INVALID, "%s: invalid camera / pyramid argument", who);
+    memcpy(P.T, Tcw, 48); memcpy(P.Ow, Ow, 12); memcpy(P.K, K4, 16);
+    const float4 b = frame_bounds(cols, rows, bounds);
+    P.bnd[0] = b.x; P.bnd[1] = b.y; P.bnd[2] = b.z; P.bnd[3] = b.w;
+    for (int l = 0; l < 16; l++) P.scale[l] = scale[std::min(l, nlevels - 1)];
+    P.nlevels = nlevels; P.strict_max = strict_max; P.level_below = below; P.level_above = above; P.log_scale = log_scale; P.th = th;
+    return ORBFE_OK;
+}
+
+// uploads the map points and leaves their queries in w.q
+static int project_run(MatchWorkspace& w, const float* p3Dw, const uint8_t* valid, const float* min_dist, const float* max_dist,
+                       const float* normal, int n, const ProjectParams& P)
+{
+    int rc;
+    const size_t N = (size_t)n;
+    if ((rc = w.q.ensure(N * sizeof(orbfe_window_query))) || (rc = w.scratch.ensure(N * (12 + 4 + 4 + 12) + 256)) || (rc = w.pidx.ensure(N + 256)))
+        return rc;
+    float* d_p = w.scratch.as<float>();
+    float *d_min = d_p + 3 * N, *d_max = d_min + N, *d_nrm = d_max + N;
+    ORBFE_HIP(hipMemcpy(d_p, p3Dw, N * 12, hipMemcpyHostToDevice));
+    ORBFE_HIP(hipMemcpy(d_min, min_dist, N * 4, hipMemcpyHostToDevice));
+    ORBFE_HIP(hipMemcpy(d_max, max_dist, N * 4, hipMemcpyHostToDevice));
+    if (normal) ORBFE_HIP(hipMemcpy(d_nrm, normal, N * 12, hipMemcpyHostToDevice));
+    if (valid) ORBFE_HIP(hipMemcpy(w.pidx.p, valid, N, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_project_map_points, dim3((n + 255) / 256), dim3(256), 0, 0, d_p, valid ? w.pidx.as<uint8_t>() : nullptr, d_min, d_max,
+                       normal ? d_nrm : nullptr, n, P, w.q.as<SbpQuery>());
+    ORBFE_HIP(hipGetLastError());
+    return ORBFE_OK;
+}
+
+int orbfe_project_map_points(const float* p3Dw, const uint8_t* valid, const float* min_dist, const float* max_dist, const float* normal, int n,
+                             const float* Tcw, const float* Ow, const float* K4, int cols, int rows, const float* bounds, int strict_max,
+                             const float* scale_factors, int nlevels, float log_scale_factor, float th, int level_below, int level_above,
+                             orbfe_window_query* queries, int device)
+{
+    if (n < 0 || (n && (!p3Dw || !min_dist || !max_dist || !queries)))
+        return fail(ORBFE_ERR_INVALID, "orbfe_project_map_points: invalid argument");
+    ProjectParams P;
+    int rc = project_params(P, Tcw, Ow, K4, cols, rows, bounds, strict_max, scale_factors, nlevels, log_scale_factor, th, level_below, level_above,
+                            "orbfe_project_map_points");
+    if (rc || (rc = use_device(device)) || n == 0) return rc;
+    MatchWorkspace& w = ws();
+    if ((rc = project_run(w, p3Dw, valid, min_dist, max_dist, normal, n, P))) return rc;
+    ORBFE_HIP(hipMemcpy(queries, w.q.p, (size_t)n * sizeof(orbfe_window_query), hipMemcpyDeviceToHost));
+    return ORBFE_OK;
+}
+
+int orbfe_fuse_search(const orbfe_keypoint* kps, const uint8_t* desc, int n, int cols, int rows, const float* bounds, const float* p3Dw,
+                      const uint8_t* valid, const float* min_dist, const float* max_dist, const float* normal, const uint8_t* mp_desc, int nmp,
+                      const float* Tcw, const float* Ow, const float* K4, const float* scale_factors, const float* inv_level_sigma2, int nlevels,
+                      float log_scale_factor, float th, double chi2, int32_t* best_idx, int32_t* best_dist, int device)
+{
+    if (n < 0 || nmp < 0 || (n && (!kps || !desc)) || (nmp && (!p3Dw || !min_dist || !max_dist || !normal || !mp_desc || !best_idx || !best_dist)) ||
+        (chi2 > 0.0 && !inv_level_sigma2))
+        return fail(ORBFE_ERR_INVALID, "orbfe_fuse_search: invalid argument");
+    if (n > 65535) return fail(ORBFE_ERR_INVALID, "more than 65535 keypoints per frame are unsupported");
+    ProjectParams P;
+    int rc = project_params(P, Tcw, Ow, K4, cols, rows, bounds, 1, scale_factors, nlevels, log_scale_factor, th, 1, 0, "orbfe_fuse_search");
+    if (rc || (rc = use_device(device))) return rc;
+    for (int i = 0; i < nmp; i++) { best_idx[i] = -1; best_dist[i] = 256; }
+    if (nmp == 0 || n == 0) return ORBFE_OK;
+    int ncap = 64;
+    while (ncap < n) ncap <<= 1;
+    const size_t lds = (size_t)ncap * (4 + 8 + 1 + 1) + (SBP_CELLS + 2) * 2 + 64;
+    if (lds > 150 * 1024) return fail(ORBFE_ERR_CAPACITY, "%d keypoints do not fit the grid kernel's LDS", n);
+    MatchWorkspace& w = ws();
+    const size_t qo = (size_t)nmp * 4;
+    SbpBest bo{};
+    bo.chi2 = chi2 > 0.0 ? chi2 : 0.0;
+    if (chi2 > 0.0) {
+        for (int l = 0; l < 16; l++) bo.inv_sigma2[l] = inv_level_sigma2[std::min(l, nlevels - 1)];
+    }
+    for (int attempt = 0;; attempt++) {
+        const int stride = std::max(w.sbp_stride, 128);
+        if ((rc = w.kps.ensure((size_t)n * sizeof(orbfe_keypoint))) || (rc = w.desc.ensure((size_t)n * 32)) || (rc = w.t.ensure((size_t)nmp * 32)) ||
+            (rc = w.csr_idx.ensure((size_t)nmp * stride * 2)) || (rc = w.csr_dist.ensure((size_t)nmp * stride)) || (rc = w.csr_cnt.ensure(qo)) ||
+            (rc = w.obest.ensure(qo * 6)) || (rc = w.nm.ensure(16)) || (rc = w.overflow.ensure(16)))
+            return rc;
+        ORBFE_HIP(hipMemcpy(w.kps.p, kps, (size_t)n * sizeof(orbfe_keypoint), hipMemcpyHostToDevice));
+        ORBFE_HIP(hipMemcpy(w.desc.p, desc, (size_t)n * 32, hipMemcpyHostToDevice));
+        ORBFE_HIP(hipMemcpy(w.t.p, mp_desc, (size_t)nmp * 32, hipMemcpyHostToDevice));
+        if ((rc = project_run(w, p3Dw, valid, min_dist, max_dist, normal, nmp, P))) return rc;
+        ORBFE_HIP(hipMemset(w.overflow.p, 0, 4));
+        int32_t* o = w.obest.as<int32_t>();
+        ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_by_projection),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_search_by_projection, dim3(1), dim3(SBP_THREADS), lds, 0, w.kps.as<orbfe_keypoint>(), w.desc.as<uint8_t>(), n,
+                           ncap, frame_bounds(cols, rows, bounds), w.q.as<SbpQuery>(), w.t.as<uint8_t>(), nmp, (uint8_t*)nullptr, 0, 256, 0.0f,
+                           w.csr_idx.as<uint16_t>(), w.csr_dist.as<uint8_t>(), w.csr_cnt.as<int32_t>(), stride, o, o + nmp, o + 2 * nmp,
+                           o + 3 * nmp, o + 4 * nmp, o + 5 * nmp, w.nm.as<int32_t>(), w.overflow.as<int32_t>(), bo);
+        ORBFE_HIP(hipGetLastError());
+        ORBFE_HIP(hipDeviceSynchronize());
+        int32_t ovf = 0;
+        ORBFE_HIP(hipMemcpy(&ovf, w.overflow.p, 4, hipMemcpyDeviceToHost));
+        if (!ovf) break;
+        if (attempt) return fail(ORBFE_ERR_CAPACITY, "candidate row overflow (%d)", ovf);
+        w.sbp_stride = (ovf + 63) / 64 * 64;
+    }
+    ORBFE_HIP(hipMemcpy(best_idx, w.obest.p, qo, hipMemcpyDeviceToHost));
+    ORBFE_HIP(hipMemcpy(best_dist, w.obest.as<int32_t>() + nmp, qo, hipMemcpyDeviceToHost));
+    return ORBFE_OK;
 }
 
 int orbfe_knn2_csr(const uint8_t* Q, int nq, const uint8_t* T, int nt, const int32_t* offsets, const int32_t* idx, int init,

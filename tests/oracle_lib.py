@@ -395,6 +395,25 @@ def search_for_triangulation(kps1, desc1, fv1, kps2, desc2, fv2, F12, epipole, s
     return nm, m12[:len(k1)]
 
 
+def fuse_search(kps, desc, cols, rows, p3Dw, valid, min_dist, max_dist, normal, mp_desc, Tcw, Ow, K4, scale_factors, inv_level_sigma2,
+                log_scale_factor, th, chi2=5.99, bounds=None):
+    L = lib()
+    k = np.ascontiguousarray(kps, KP_DTYPE); d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    f = lambda a, t=np.float32: np.ascontiguousarray(a, t)
+    x, mn, mx, nr, md = f(p3Dw).reshape(-1, 3), f(min_dist), f(max_dist), f(normal).reshape(-1, 3), f(mp_desc, np.uint8).reshape(-1, 32)
+    v = None if valid is None else f(valid, np.uint8); bnd = None if bounds is None else f(bounds)
+    T, O, K, sf, isg = f(Tcw).reshape(-1)[:12].copy(), f(Ow), f(K4), f(scale_factors), f(inv_level_sigma2)
+    bi = np.full(max(len(x), 1), -1, np.int32); bd = np.full(max(len(x), 1), 256, np.int32)
+    pp = lambda a: None if a is None else _p(a)
+    vp = C.c_void_p
+    L.oracle_fuse_search.restype = None
+    L.oracle_fuse_search.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int,
+                                     C.c_float, C.c_float, C.c_double, vp, vp]
+    L.oracle_fuse_search(_p(k), _p(d), len(k), cols, rows, pp(bnd), _p(x), pp(v), _p(mn), _p(mx), _p(nr), _p(md), len(x), _p(T), _p(O), _p(K),
+                         _p(sf), _p(isg), len(sf), log_scale_factor, th, float(chi2), _p(bi), _p(bd))
+    return bi[:len(x)], bd[:len(x)]
+
+
 def search_for_initialization(k1, d1, k2, d2, cols, rows, prev=None, window=100, nnratio=0.9, check_ori=True, bounds=None):
     L = lib()
     k1 = np.ascontiguousarray(k1); k2 = np.ascontiguousarray(k2)

@@ -319,3 +319,45 @@ def test_search_by_projection_last_frame_edges(orbfe, oracle):
     want = oracle.search_by_projection_last_frame(kc, dc, 640, 480, kl, None, x3, dl, Tcw, K4, sf, 15.0)
     got = orbfe.search_by_projection_best(kc, dc, 640, 480, q, kl["angle"], dl, 100, 1.0 / 30)
     assert got[0] == want[0] and np.array_equal(got[1], want[1])
+
+
+def _map_points_for(kl, x3, Tcw, rng, sf):
+    """Scale-invariance range, normal and camera centre for map points observed at octave kl.octave from the identity pose."""
+    d0 = np.linalg.norm(x3.astype(np.float64), axis=1)
+    max_d = (d0 * sf[kl["octave"]] * rng.uniform(0.9, 1.3, len(kl))).astype(np.float32)
+    min_d = (max_d / sf[-1] * rng.uniform(0.8, 1.0, len(kl))).astype(np.float32)
+    nrm = x3 / np.maximum(d0, 1e-9)[:, None] + 0.3 * rng.normal(size=x3.shape)
+    nrm = (nrm / np.linalg.norm(nrm, axis=1)[:, None]).astype(np.float32)
+    flip = rng.random(len(kl)) < 0.05
+    nrm[flip] *= -1                                                   # seen from behind: viewing-angle gate
+    R, t = Tcw[:, :3].astype(np.float64), Tcw[:, 3].astype(np.float64)
+    Ow = (-R.T @ t).astype(np.float32)
+    return min_d, max_d, nrm, Ow
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,th,chi2", [(1, 3.0, 5.99), (2, 2.5, 5.99), (3, 4.0, 0.0), (4, 10.0, 0.0)])
+def test_fuse_search(orbfe, oracle, seed, th, chi2):
+    """Matching part of Fuse (ORBmatcher.cc:829-970; chi2 = 0: :972-1104): projection, gates, PredictScale, window, levels,
+    reprojection gate, best distance -- bit-exact."""
+    kc, dc, kl, dl, x3, Tcw, K4, sf, rng = _motion_case(oracle, seed)
+    # the keyframe the points are fused into sees them almost where the source keyframe did: same keypoints, a fifth of the motion
+    kc, dc = kl, dl
+    Tcw = (np.eye(3, 4) + 0.2 * (Tcw.astype(np.float64) - np.eye(3, 4))).astype(np.float32)
+    min_d, max_d, nrm, Ow = _map_points_for(kl, x3, Tcw, rng, sf)
+    valid = (rng.random(len(kl)) < 0.9).astype(np.uint8)
+    isg = (1.0 / (sf * sf)).astype(np.float32)
+    logsf = np.float32(np.log(np.float32(1.2)))
+    want = oracle.fuse_search(kc, dc, 640, 480, x3, valid, min_d, max_d, nrm, dl, Tcw, Ow, K4, sf, isg, logsf, th, chi2)
+    got = orbfe.fuse_search(kc, dc, 640, 480, x3, valid, min_d, max_d, nrm, dl, Tcw, Ow, K4, sf, isg, logsf, th, chi2)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    fused = (got[1] <= 50).sum()
+    assert fused > 20 and np.all(got[0][valid == 0] == -1)
+    # the projection alone, as window queries: searched points are exactly the ones Fuse searched
+    q = orbfe.project_map_points(x3, valid, min_d, max_d, nrm, Tcw, Ow, K4, 640, 480, sf, logsf, th, 1, 0)
+    assert np.all(q["r"][got[0] >= 0] > 0) and np.all(q["r"][valid == 0] < 0)
+    assert np.all(q["max_level"][q["r"] > 0] - q["min_level"][q["r"] > 0] == 1)
+    # SearchByProjection(CurrentFrame, KeyFrame, ...) (:1476-1603) = this projection (levels +-1, no viewing gate, Frame bounds) + the best-only loop
+    q2 = orbfe.project_map_points(x3, valid, min_d, max_d, None, Tcw, Ow, K4, 640, 480, sf, logsf, th, 1, 1, strict_max=False)
+    nm, mc = orbfe.search_by_projection_best(kc, dc, 640, 480, q2, kl["angle"], dl, 100, 1.0 / 30)
+    assert nm == (mc >= 0).sum() and nm > 20
