@@ -211,6 +211,21 @@ int orbfe_fuse_search(const orbfe_keypoint* kps, const uint8_t* desc, int n, int
                       const uint8_t* valid, const float* min_dist, const float* max_dist, const float* normal, const uint8_t* mp_desc, int nmp,
                       const float* Tcw, const float* Ow, const float* K4, const float* scale_factors, const float* inv_level_sigma2, int nlevels,
                       float log_scale_factor, float th, double chi2, int32_t* best_idx, int32_t* best_dist, int device);
+/* ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th) (src/ORBmatcher.cc:1106-1330): the map points of
+ * each keyframe are carried into the other camera (world -> own camera -> sR | t of the similarity, each stage rounded to
+ * float), gated (positive depth, IsInImage, distance in the scale-invariance range of the FINAL camera coordinates),
+ * PredictScale, window search at levels [predicted - 1, predicted], best distance <= th_high (TH_HIGH = 100); pairs that
+ * agree in both directions are returned.  Feature i of keyframe k carries p3Dw_k[i], min/max_dist_k[i], mp_desc_k[i];
+ * valid_k[i] = "map point exists, is not bad, is not already matched" (:1148-1155, :1230-1236; NULL = all).  T1w / T2w =
+ * 3x4 row-major [R | t]; sT12 = [s12 R12 | t12], sT21 = [(1/s12) R12' | t21] as the caller computes them (:1123-1126).
+ * match12[i1] = i2 or -1 (vpMatches12[i1] = vpMapPoints2[i2]); *nfound = the return value. */
+int orbfe_search_by_sim3(const orbfe_keypoint* kps1, const uint8_t* desc1, int n1, const orbfe_keypoint* kps2, const uint8_t* desc2, int n2,
+                         int cols, int rows, const float* bounds, const float* p3Dw1, const uint8_t* valid1, const float* min_dist1,
+                         const float* max_dist1, const uint8_t* mp_desc1, const float* p3Dw2, const uint8_t* valid2, const float* min_dist2,
+                         const float* max_dist2, const uint8_t* mp_desc2, const float* T1w, const float* T2w, const float* sT12,
+                         const float* sT21, const float* K4, const float* scale_factors, int nlevels, float log_scale_factor, float th,
+                         int th_high, int32_t* match12, int32_t* nfound, int device);
+
 /* Only the projection + gates + PredictScale, as window queries for orbfe_search_by_projection / _best (the keyframe variants of
  * SearchByProjection, :294-407 and :1476-1603, project the same way with other level ranges): r < 0 = not searched,
  * min_level = predicted - level_below, max_level = predicted + level_above.  normal == NULL: no viewing-angle gate;

@@ -644,6 +644,76 @@ void oracle_fuse_search(const void* kps_, const uint8_t* desc, int n, int cols, 
     }
 }
 
+/* ORBmatcher::SearchBySim3 (src/ORBmatcher.cc:1106-1330) on flat arrays.  Feature i of a keyframe carries its map point's world
+ * position, scale-invariance range and descriptor; valid*[i] = "has a map point that is not bad and is not already matched"
+ * (:1148-1155, :1230-1236).  T1w / T2w = 3x4 row-major [R | t] of the keyframes; sT12 = [sR12 | t12], sT21 = [sR21 | t21]
+ * as computed at :1123-1126.  Both cameras share K.  vnMatch = best keypoint at levels [predicted - 1, predicted] with
+ * distance <= TH_HIGH; a pair is kept when both directions agree (:1302-1318).  match12[i1] = i2 or -1; returns nFound. */
+int oracle_search_by_sim3(const void* kps1_, const uint8_t* desc1, int n1, const void* kps2_, const uint8_t* desc2, int n2, int cols, int rows,
+                          const float* bounds, const float* p3Dw1, const uint8_t* valid1, const float* min1, const float* max1,
+                          const uint8_t* mpd1, const float* p3Dw2, const uint8_t* valid2, const float* min2, const float* max2,
+                          const uint8_t* mpd2, const float* T1w, const float* T2w, const float* sT12, const float* sT21, const float* K4,
+                          const float* mvScaleFactors, int nlevels, float mfLogScaleFactor, float th, int32_t* match12)
+{
+    const KeyPoint* k1 = (const KeyPoint*)kps1_;
+    const KeyPoint* k2 = (const KeyPoint*)kps2_;
+    FrameGrid grid1(k1, n1, cols, rows, bounds), grid2(k2, n2, cols, rows, bounds);
+    const float fx = K4[0], fy = K4[1], cx = K4[2], cy = K4[3];
+    auto mul = [](const float* T, const float* p, float* o) { /* cv: 3x3 * 3x1 float rows, then + t */
+        for (int r = 0; r < 3; r++) {
+            float t = T[4 * r] * p[0] + T[4 * r + 1] * p[1] + T[4 * r + 2] * p[2];
+            o[r] = (float)(t * 1.0 + 1.0 * T[4 * r + 3]);
+        }
+    };
+    auto direction = [&](int nA, const float* pw, const uint8_t* valid, const float* mind, const float* maxd, const uint8_t* mpd,
+                         const float* TAw, const float* sTBA, const FrameGrid& gridB, const KeyPoint* kB, const uint8_t* descB,
+                         std::vector<int>& vnMatch) {
+        for (int i = 0; i < nA; i++) {
+            if (valid && !valid[i]) continue;
+            float cA[3], cB[3];
+            mul(TAw, pw + 3 * i, cA);
+            mul(sTBA, cA, cB);
+            if (cB[2] < 0.0) continue;
+            const float invz = 1.0 / cB[2];
+            const float x = cB[0] * invz;
+            const float y = cB[1] * invz;
+            const float u = fx * x + cx;
+            const float v = fy * y + cy;
+            if (!(u >= gridB.mnMinX && u < gridB.mnMaxX && v >= gridB.mnMinY && v < gridB.mnMaxY)) continue;
+            const float dist3D = std::sqrt((double)cB[0] * cB[0] + (double)cB[1] * cB[1] + (double)cB[2] * cB[2]);
+            if (dist3D < mind[i] || dist3D > maxd[i]) continue;
+            float ratio = maxd[i] / dist3D;
+            int nPredictedLevel = (int)std::ceil(std::log((double)ratio) / mfLogScaleFactor);
+            if (nPredictedLevel < 0) nPredictedLevel = 0;
+            else if (nPredictedLevel >= nlevels) nPredictedLevel = nlevels - 1;
+            const float radius = th * mvScaleFactors[nPredictedLevel];
+            const std::vector<int> vIndices = gridB.GetFeaturesInArea(u, v, radius, -1, -1);
+            if (vIndices.empty()) continue;
+            int bestDist = INT_MAX, bestIdx = -1;
+            for (size_t k = 0; k < vIndices.size(); k++) {
+                const int idx = vIndices[k];
+                if (kB[idx].octave < nPredictedLevel - 1 || kB[idx].octave > nPredictedLevel) continue;
+                const int dist = DescriptorDistance(mpd + 32 * (size_t)i, descB + 32 * (size_t)idx);
+                if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+            }
+            if (bestDist <= TH_HIGH) vnMatch[i] = bestIdx;
+        }
+    };
+    std::vector<int> vnMatch1(n1, -1), vnMatch2(n2, -1);
+    direction(n1, p3Dw1, valid1, min1, max1, mpd1, T1w, sT21, grid2, k2, desc2, vnMatch1);
+    direction(n2, p3Dw2, valid2, min2, max2, mpd2, T2w, sT12, grid1, k1, desc1, vnMatch2);
+    int nFound = 0;
+    for (int i1 = 0; i1 < n1; i1++) {
+        match12[i1] = -1;
+        int idx2 = vnMatch1[i1];
+        if (idx2 >= 0) {
+            int idx1 = vnMatch2[idx2];
+            if (idx1 == i1) { match12[i1] = idx2; nFound++; }
+        }
+    }
+    return nFound;
+}
+
 void oracle_three_maxima(const int* sizes, int L, int* out3)
 {
     int a = -1, b = -1, c = -1;

@@ -39,7 +39,7 @@ SYMBOLS = [
     "orbfe_vocabulary_transform", "orbfe_vocabulary_transform_batch_device",
     "orbfe_search_by_bow", "orbfe_search_by_bow_batch_device",
     "orbfe_search_for_triangulation", "orbfe_search_for_triangulation_batch_device",
-    "orbfe_search_by_projection_last_frame", "orbfe_search_by_projection_best", "orbfe_fuse_search", "orbfe_project_map_points",
+    "orbfe_search_by_projection_last_frame", "orbfe_search_by_projection_best", "orbfe_fuse_search", "orbfe_project_map_points", "orbfe_search_by_sim3",
     "orbfe_keyframe_features_pack", "orbfe_keyframe_features_unpack", "orbfe_keyframe_features_pack_device",
     "orbfe_keyframe_features_unpack_device",
 ]
@@ -89,6 +89,7 @@ def load():
                                                             i32, i32, vp, vp, i32]
         L.orbfe_fuse_search.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, f32, f32, C.c_double,
                                         vp, vp, i32]
+        L.orbfe_search_by_sim3.argtypes = [vp, vp, i32, vp, vp, i32, i32, i32, vp] + [vp] * 10 + [vp] * 6 + [i32, f32, f32, i32, vp, vp, i32]
         L.orbfe_project_map_points.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp, i32, vp, i32, f32, f32, i32, i32, vp, i32]
         L.orbfe_search_by_projection_best.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp, i32, i32, f32, vp, vp, i32]
         L.orbfe_undistort_points.argtypes = [vp, i32, vp, vp, i32, vp, i32]
@@ -448,6 +449,27 @@ def project_map_points(p3Dw, valid, min_dist, max_dist, normal, Tcw, Ow, K4, col
     _check(L, L.orbfe_project_map_points(_p(x), pp(v), _p(mn), _p(mx), pp(nr), len(x), _p(T), _p(O), _p(K), cols, rows, pp(bnd), int(strict_max),
                                          _p(sf), len(sf), log_scale_factor, th, level_below, level_above, _p(q), device), "orbfe_project_map_points")
     return q
+
+
+def search_by_sim3(kf1, kf2, cols, rows, T1w, T2w, sT12, sT21, K4, scale_factors, log_scale_factor, th, th_high=100, bounds=None, device=0):
+    """ORBmatcher::SearchBySim3 (ORBmatcher.cc:1106-1330).  kf = dict(kps, desc, p3Dw, valid, min_dist, max_dist, mp_desc) -> (nFound, match12)."""
+    L = load()
+    f = lambda a, t=np.float32: np.ascontiguousarray(a, t)
+    def side(kf):
+        v = None if kf.get("valid") is None else f(kf["valid"], np.uint8)
+        return [np.ascontiguousarray(kf["kps"], KP_DTYPE), f(kf["desc"], np.uint8).reshape(-1, 32), f(kf["p3Dw"]).reshape(-1, 3), v,
+                f(kf["min_dist"]), f(kf["max_dist"]), f(kf["mp_desc"], np.uint8).reshape(-1, 32)]
+    a, b = side(kf1), side(kf2)
+    pp = lambda x: None if x is None else _p(x)
+    bnd = None if bounds is None else f(bounds)
+    Ts = [f(T).reshape(-1)[:12].copy() for T in (T1w, T2w, sT12, sT21)]
+    K, sf = f(K4), f(scale_factors)
+    m12 = np.full(len(a[0]), -1, np.int32); nf = C.c_int32(0)
+    _check(L, L.orbfe_search_by_sim3(_p(a[0]), _p(a[1]), len(a[0]), _p(b[0]), _p(b[1]), len(b[0]), cols, rows, pp(bnd),
+                                     _p(a[2]), pp(a[3]), _p(a[4]), _p(a[5]), _p(a[6]), _p(b[2]), pp(b[3]), _p(b[4]), _p(b[5]), _p(b[6]),
+                                     _p(Ts[0]), _p(Ts[1]), _p(Ts[2]), _p(Ts[3]), _p(K), _p(sf), len(sf), log_scale_factor, th, th_high,
+                                     _p(m12), C.byref(nf), device), "orbfe_search_by_sim3")
+    return nf.value, m12
 
 
 class ORBmatcher:

@@ -914,6 +914,10 @@ struct ProjectParams {
     float T[12], Ow[3], K[4], bnd[4], scale[16];
     int nlevels, strict_max, level_below, level_above;
     float log_scale, th;
+    // SearchBySim3 (ORBmatcher.cc:1158-1159, :1238-1239): a second transform applied to the camera coordinates of the first, each
+    // stage rounded to float as the two cv::Mat expressions are; the distance is then the norm of the final camera coordinates
+    int use_T2;
+    float T2[12];
 };
 
 __global__ __launch_bounds__(256) void k_project_map_points(const float* __restrict__ p3Dw, const uint8_t* __restrict__ valid,
@@ -926,9 +930,15 @@ __global__ __launch_bounds__(256) void k_project_map_points(const float* __restr
     SbpQuery Q{0.0f, 0.0f, -1.0f, 0, 0};
     if (!valid || valid[i]) {
         const float X = p3Dw[3 * i], Y = p3Dw[3 * i + 1], Z = p3Dw[3 * i + 2];
-        const float xc = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(P.T[0], X), __fmul_rn(P.T[1], Y)), __fmul_rn(P.T[2], Z)), P.T[3]);
-        const float yc = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(P.T[4], X), __fmul_rn(P.T[5], Y)), __fmul_rn(P.T[6], Z)), P.T[7]);
-        const float zc = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(P.T[8], X), __fmul_rn(P.T[9], Y)), __fmul_rn(P.T[10], Z)), P.T[11]);
+        float xc = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(P.T[0], X), __fmul_rn(P.T[1], Y)), __fmul_rn(P.T[2], Z)), P.T[3]);
+        float yc = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(P.T[4], X), __fmul_rn(P.T[5], Y)), __fmul_rn(P.T[6], Z)), P.T[7]);
+        float zc = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(P.T[8], X), __fmul_rn(P.T[9], Y)), __fmul_rn(P.T[10], Z)), P.T[11]);
+        if (P.use_T2) {
+            const float a = xc, b = yc, c = zc;
+            xc = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(P.T2[0], a), __fmul_rn(P.T2[1], b)), __fmul_rn(P.T2[2], c)), P.T2[3]);
+            yc = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(P.T2[4], a), __fmul_rn(P.T2[5], b)), __fmul_rn(P.T2[6], c)), P.T2[7]);
+            zc = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(P.T2[8], a), __fmul_rn(P.T2[9], b)), __fmul_rn(P.T2[10], c)), P.T2[11]);
+        }
         if (!(zc < 0.0f)) {
             const float invz = __fdiv_rn(1.0f, zc);
             const float u = __fadd_rn(__fmul_rn(P.K[0], __fmul_rn(xc, invz)), P.K[2]);
@@ -936,7 +946,7 @@ __global__ __launch_bounds__(256) void k_project_map_points(const float* __restr
             const bool inside = P.strict_max ? (u >= P.bnd[0] && u < P.bnd[2] && v >= P.bnd[1] && v < P.bnd[3])  // KeyFrame::IsInImage
                                              : (u >= P.bnd[0] && u <= P.bnd[2] && v >= P.bnd[1] && v <= P.bnd[3]);
             if (inside) {
-                const float px = X - P.Ow[0], py = Y - P.Ow[1], pz = Z - P.Ow[2];
+                const float px = P.use_T2 ? xc : X - P.Ow[0], py = P.use_T2 ? yc : Y - P.Ow[1], pz = P.use_T2 ? zc : Z - P.Ow[2];
                 const float dist3D = (float)sqrt((double)px * px + (double)py * py + (double)pz * pz);
                 bool ok = !(dist3D < min_dist[i] || dist3D > max_dist[i]);
                 if (ok && normal) {
@@ -1360,6 +1370,8 @@ static int project_params(ProjectParams& P, const float* Tcw, const float* Ow, c
     P.bnd[0] = b.x; P.bnd[1] = b.y; P.bnd[2] = b.z; P.bnd[3] = b.w;
     for (int l = 0; l < 16; l++) P.scale[l] = scale[std::min(l, nlevels - 1)];
     P.nlevels = nlevels; P.strict_max = strict_max; P.level_below = below; P.level_above = above; P.log_scale = log_scale; P.th = th;
+    P.use_T2 = 0;
+    for (int i = 0; i < 12; i++) P.T2[i] = 0.0f;
     return ORBFE_OK;
 }
 
@@ -1401,18 +1413,12 @@ int orbfe_project_map_points(const float* p3Dw, const uint8_t* valid, const floa
     return ORBFE_OK;
 }
 
-int orbfe_fuse_search(const orbfe_keypoint* kps, const uint8_t* desc, int n, int cols, int rows, const float* bounds, const float* p3Dw,
-                      const uint8_t* valid, const float* min_dist, const float* max_dist, const float* normal, const uint8_t* mp_desc, int nmp,
-                      const float* Tcw, const float* Ow, const float* K4, const float* scale_factors, const float* inv_level_sigma2, int nlevels,
-                      float log_scale_factor, float th, double chi2, int32_t* best_idx, int32_t* best_dist, int device)
+// projection + grid search + best distance for nmp map points against one keyframe (Fuse, SearchBySim3)
+static int guided_best(const orbfe_keypoint* kps, const uint8_t* desc, int n, int cols, int rows, const float* bounds, const float* p3Dw,
+                       const uint8_t* valid, const float* min_dist, const float* max_dist, const float* normal, const uint8_t* mp_desc, int nmp,
+                       const ProjectParams& P, double chi2, const float* inv_level_sigma2, int nlevels, int32_t* best_idx, int32_t* best_dist)
 {
-    if (n < 0 || nmp < 0 || (n && (!kps || !desc)) || (nmp && (!p3Dw || !min_dist || !max_dist || !normal || !mp_desc || !best_idx || !best_dist)) ||
-        (chi2 > 0.0 && !inv_level_sigma2))
-        return fail(ORBFE_ERR_INVALID, "orbfe_fuse_search: invalid argument");
     if (n > 65535) return fail(ORBFE_ERR_INVALID, "more than 65535 keypoints per frame are unsupported");
-    ProjectParams P;
-    int rc = project_params(P, Tcw, Ow, K4, cols, rows, bounds, 1, scale_factors, nlevels, log_scale_factor, th, 1, 0, "orbfe_fuse_search");
-    if (rc || (rc = use_device(device))) return rc;
     for (int i = 0; i < nmp; i++) { best_idx[i] = -1; best_dist[i] = 256; }
     if (nmp == 0 || n == 0) return ORBFE_OK;
     int ncap = 64;
@@ -1423,9 +1429,9 @@ int orbfe_fuse_search(const orbfe_keypoint* kps, const uint8_t* desc, int n, int
     const size_t qo = (size_t)nmp * 4;
     SbpBest bo{};
     bo.chi2 = chi2 > 0.0 ? chi2 : 0.0;
-    if (chi2 > 0.0) {
+    if (chi2 > 0.0)
         for (int l = 0; l < 16; l++) bo.inv_sigma2[l] = inv_level_sigma2[std::min(l, nlevels - 1)];
-    }
+    int rc;
     for (int attempt = 0;; attempt++) {
         const int stride = std::max(w.sbp_stride, 128);
         if ((rc = w.kps.ensure((size_t)n * sizeof(orbfe_keypoint))) || (rc = w.desc.ensure((size_t)n * 32)) || (rc = w.t.ensure((size_t)nmp * 32)) ||
@@ -1454,6 +1460,61 @@ int orbfe_fuse_search(const orbfe_keypoint* kps, const uint8_t* desc, int n, int
     }
     ORBFE_HIP(hipMemcpy(best_idx, w.obest.p, qo, hipMemcpyDeviceToHost));
     ORBFE_HIP(hipMemcpy(best_dist, w.obest.as<int32_t>() + nmp, qo, hipMemcpyDeviceToHost));
+    return ORBFE_OK;
+}
+
+int orbfe_fuse_search(const orbfe_keypoint* kps, const uint8_t* desc, int n, int cols, int rows, const float* bounds, const float* p3Dw,
+                      const uint8_t* valid, const float* min_dist, const float* max_dist, const float* normal, const uint8_t* mp_desc, int nmp,
+                      const float* Tcw, const float* Ow, const float* K4, const float* scale_factors, const float* inv_level_sigma2, int nlevels,
+                      float log_scale_factor, float th, double chi2, int32_t* best_idx, int32_t* best_dist, int device)
+{
+    if (n < 0 || nmp < 0 || (n && (!kps || !desc)) || (nmp && (!p3Dw || !min_dist || !max_dist || !normal || !mp_desc || !best_idx || !best_dist)) ||
+        (chi2 > 0.0 && !inv_level_sigma2))
+        return fail(ORBFE_ERR_INVALID, "orbfe_fuse_search: invalid argument");
+    ProjectParams P;
+    int rc = project_params(P, Tcw, Ow, K4, cols, rows, bounds, 1, scale_factors, nlevels, log_scale_factor, th, 1, 0, "orbfe_fuse_search");
+    if (rc || (rc = use_device(device))) return rc;
+    return guided_best(kps, desc, n, cols, rows, bounds, p3Dw, valid, min_dist, max_dist, normal, mp_desc, nmp, P, chi2, inv_level_sigma2, nlevels,
+                       best_idx, best_dist);
+}
+
+int orbfe_search_by_sim3(const orbfe_keypoint* kps1, const uint8_t* desc1, int n1, const orbfe_keypoint* kps2, const uint8_t* desc2, int n2,
+                         int cols, int rows, const float* bounds, const float* p3Dw1, const uint8_t* valid1, const float* min_dist1,
+                         const float* max_dist1, const uint8_t* mp_desc1, const float* p3Dw2, const uint8_t* valid2, const float* min_dist2,
+                         const float* max_dist2, const uint8_t* mp_desc2, const float* T1w, const float* T2w, const float* sT12,
+                         const float* sT21, const float* K4, const float* scale_factors, int nlevels, float log_scale_factor, float th,
+                         int th_high, int32_t* match12, int32_t* nfound, int device)
+{
+    if (n1 < 0 || n2 < 0 || !nfound || (n1 && (!kps1 || !desc1 || !p3Dw1 || !min_dist1 || !max_dist1 || !mp_desc1 || !match12)) ||
+        (n2 && (!kps2 || !desc2 || !p3Dw2 || !min_dist2 || !max_dist2 || !mp_desc2)) || !T1w || !T2w || !sT12 || !sT21)
+        return fail(ORBFE_ERR_INVALID, "orbfe_search_by_sim3: invalid argument");
+    const float zero3[3] = {0.0f, 0.0f, 0.0f};
+    ProjectParams P12, P21;
+    // KF1's points: camera 1, then sR21 | t21 into camera 2, searched in KF2 (:1148-1219); KF2's points the other way (:1228-1299)
+    int rc = project_params(P12, T1w, zero3, K4, cols, rows, bounds, 1, scale_factors, nlevels, log_scale_factor, th, 1, 0, "orbfe_search_by_sim3");
+    if (rc || (rc = project_params(P21, T2w, zero3, K4, cols, rows, bounds, 1, scale_factors, nlevels, log_scale_factor, th, 1, 0,
+                                   "orbfe_search_by_sim3")) || (rc = use_device(device)))
+        return rc;
+    P12.use_T2 = 1; memcpy(P12.T2, sT21, 48);
+    P21.use_T2 = 1; memcpy(P21.T2, sT12, 48);
+    *nfound = 0;
+    for (int i = 0; i < n1; i++) match12[i] = -1;
+    if (n1 == 0 || n2 == 0) return ORBFE_OK;
+    std::vector<int32_t> m1(n1), d1(n1), m2(n2), d2(n2);
+    if ((rc = guided_best(kps2, desc2, n2, cols, rows, bounds, p3Dw1, valid1, min_dist1, max_dist1, nullptr, mp_desc1, n1, P12, 0.0, nullptr,
+                          nlevels, m1.data(), d1.data())) ||
+        (rc = guided_best(kps1, desc1, n1, cols, rows, bounds, p3Dw2, valid2, min_dist2, max_dist2, nullptr, mp_desc2, n2, P21, 0.0, nullptr,
+                          nlevels, m2.data(), d2.data())))
+        return rc;
+    int found = 0;
+    for (int i1 = 0; i1 < n1; i1++) { // check agreement (:1302-1318)
+        const int idx2 = d1[i1] <= th_high ? m1[i1] : -1;
+        if (idx2 >= 0) {
+            const int idx1 = d2[idx2] <= th_high ? m2[idx2] : -1;
+            if (idx1 == i1) { match12[i1] = idx2; found++; }
+        }
+    }
+    *nfound = found;
     return ORBFE_OK;
 }
 

@@ -414,6 +414,28 @@ def fuse_search(kps, desc, cols, rows, p3Dw, valid, min_dist, max_dist, normal, 
     return bi[:len(x)], bd[:len(x)]
 
 
+def search_by_sim3(kf1, kf2, cols, rows, T1w, T2w, sT12, sT21, K4, scale_factors, log_scale_factor, th, bounds=None):
+    L = lib()
+    f = lambda a, t=np.float32: np.ascontiguousarray(a, t)
+    def side(kf):
+        v = None if kf.get("valid") is None else f(kf["valid"], np.uint8)
+        return [np.ascontiguousarray(kf["kps"], KP_DTYPE), f(kf["desc"], np.uint8).reshape(-1, 32), f(kf["p3Dw"]).reshape(-1, 3), v,
+                f(kf["min_dist"]), f(kf["max_dist"]), f(kf["mp_desc"], np.uint8).reshape(-1, 32)]
+    a, b = side(kf1), side(kf2)
+    pp = lambda x: None if x is None else _p(x)
+    bnd = None if bounds is None else f(bounds)
+    Ts = [f(T).reshape(-1)[:12].copy() for T in (T1w, T2w, sT12, sT21)]
+    K, sf = f(K4), f(scale_factors)
+    m12 = np.full(max(len(a[0]), 1), -1, np.int32)
+    vp = C.c_void_p
+    L.oracle_search_by_sim3.restype = C.c_int
+    L.oracle_search_by_sim3.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp] + [vp] * 10 + [vp] * 6 + [C.c_int, C.c_float, C.c_float, vp]
+    nf = L.oracle_search_by_sim3(_p(a[0]), _p(a[1]), len(a[0]), _p(b[0]), _p(b[1]), len(b[0]), cols, rows, pp(bnd),
+                                 _p(a[2]), pp(a[3]), _p(a[4]), _p(a[5]), _p(a[6]), _p(b[2]), pp(b[3]), _p(b[4]), _p(b[5]), _p(b[6]),
+                                 _p(Ts[0]), _p(Ts[1]), _p(Ts[2]), _p(Ts[3]), _p(K), _p(sf), len(sf), log_scale_factor, th, _p(m12))
+    return nf, m12[:len(a[0])]
+
+
 def search_for_initialization(k1, d1, k2, d2, cols, rows, prev=None, window=100, nnratio=0.9, check_ori=True, bounds=None):
     L = lib()
     k1 = np.ascontiguousarray(k1); k2 = np.ascontiguousarray(k2)

@@ -361,3 +361,37 @@ def test_fuse_search(orbfe, oracle, seed, th, chi2):
     q2 = orbfe.project_map_points(x3, valid, min_d, max_d, None, Tcw, Ow, K4, 640, 480, sf, logsf, th, 1, 1, strict_max=False)
     nm, mc = orbfe.search_by_projection_best(kc, dc, 640, 480, q2, kl["angle"], dl, 100, 1.0 / 30)
     assert nm == (mc >= 0).sum() and nm > 20
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,th,s12", [(1, 7.5, 1.0), (2, 7.5, 1.03), (3, 4.0, 0.97)])
+def test_search_by_sim3(orbfe, oracle, seed, th, s12):
+    """SearchBySim3 (ORBmatcher.cc:1106-1330): two-stage transforms, gates, PredictScale, both directions and the agreement pass."""
+    _, _, kl, dl, x1, Tm, K4, sf, rng = _motion_case(oracle, seed)
+    T2w = (np.eye(3, 4) + 0.2 * (Tm.astype(np.float64) - np.eye(3, 4)))
+    T1w = np.eye(3, 4)
+    R2, t2 = T2w[:, :3], T2w[:, 3]
+    z2 = rng.uniform(1.0, 6.0, len(kl))
+    c2 = np.stack([(kl["x"] - K4[2]) / K4[0] * z2, (kl["y"] - K4[3]) / K4[1] * z2, z2], 1)
+    x2 = ((c2 - t2) @ R2).astype(np.float32)                         # world points seen by keyframe 2 at its keypoints
+    # similarity camera 2 -> camera 1: the true relative pose (T1w = I) with a scale and a small error
+    R12 = R2.T; t12 = -R2.T @ t2 + 0.003 * rng.normal(size=3)
+    sR12 = (np.float32(s12) * R12.astype(np.float32)).astype(np.float32)
+    sR21 = ((1.0 / np.float64(np.float32(s12))) * R12.T.astype(np.float32).astype(np.float64)).astype(np.float32)
+    t12f = t12.astype(np.float32)
+    t21 = -(sR21 @ t12f).astype(np.float32)
+    sT12 = np.concatenate([sR12, t12f[:, None]], 1); sT21 = np.concatenate([sR21, t21[:, None]], 1)
+    logsf = np.float32(np.log(np.float32(1.2)))
+
+    def kf(x3, cam_T):
+        d0 = np.linalg.norm((x3.astype(np.float64) @ cam_T[:, :3].T + cam_T[:, 3]), axis=1)
+        mx = (d0 * sf[kl["octave"]] * rng.uniform(0.9, 1.3, len(kl))).astype(np.float32)
+        mn = (mx / sf[-1] * rng.uniform(0.8, 1.0, len(kl))).astype(np.float32)
+        return dict(kps=kl, desc=dl, p3Dw=x3, valid=(rng.random(len(kl)) < 0.85).astype(np.uint8), min_dist=mn, max_dist=mx, mp_desc=dl)
+    kf1, kf2 = kf(x1, T1w), kf(x2, T2w)
+    want = oracle.search_by_sim3(kf1, kf2, 640, 480, T1w, T2w, sT12, sT21, K4, sf, logsf, th)
+    got = orbfe.search_by_sim3(kf1, kf2, 640, 480, T1w, T2w, sT12, sT21, K4, sf, logsf, th)
+    assert got[0] == want[0] and np.array_equal(got[1], want[1])
+    assert got[0] > 30 and got[0] == (got[1] >= 0).sum()
+    m = got[1]
+    assert np.all(kf1["valid"][m >= 0] == 1) and np.all(kf2["valid"][m[m >= 0]] == 1)
