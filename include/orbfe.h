@@ -226,6 +226,17 @@ int orbfe_search_by_sim3(const orbfe_keypoint* kps1, const uint8_t* desc1, int n
                          const float* sT21, const float* K4, const float* scale_factors, int nlevels, float log_scale_factor, float th,
                          int th_high, int32_t* match12, int32_t* nfound, int device);
 
+/* ORBmatcher::SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) (src/ORBmatcher.cc:294-407, loop closing): map points
+ * projected with the similarity's rigid part (Tcw = [Rcw | tcw], Ow as computed at :303-308), gated as in Fuse incl. the viewing
+ * angle, searched at levels [predicted - 1, predicted] among keypoints not yet matched (matched[i] = vpMatched[i] != NULL; a
+ * keypoint that receives a point is matched for the points after it), best distance <= TH_LOW.  valid[i] = "!isBad() && not
+ * in vpMatched".  match_kf[i] = index of the map point the keypoint received or -1; *nmatches = the return value. */
+int orbfe_search_by_projection_sim3(const orbfe_keypoint* kps, const uint8_t* desc, int n, int cols, int rows, const float* bounds,
+                                    const uint8_t* matched, const float* p3Dw, const uint8_t* valid, const float* min_dist,
+                                    const float* max_dist, const float* normal, const uint8_t* mp_desc, int nmp, const float* Tcw,
+                                    const float* Ow, const float* K4, const float* scale_factors, int nlevels, float log_scale_factor, int th,
+                                    int32_t* match_kf, int32_t* nmatches, int device);
+
 /* Only the projection + gates + PredictScale, as window queries for orbfe_search_by_projection / _best (the keyframe variants of
  * SearchByProjection, :294-407 and :1476-1603, project the same way with other level ranges): r < 0 = not searched,
  * min_level = predicted - level_below, max_level = predicted + level_above.  normal == NULL: no viewing-angle gate;

@@ -714,6 +714,62 @@ int oracle_search_by_sim3(const void* kps1_, const uint8_t* desc1, int n1, const
     return nFound;
 }
 
+/* ORBmatcher::SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th) (src/ORBmatcher.cc:294-407) on flat arrays; see
+ * oracle_fuse_search for the per-point inputs.  matched[i] = vpMatched[i] != NULL on entry.  match_kf[idx] = iMP or -1. */
+int oracle_search_by_projection_sim3(const void* kps_, const uint8_t* desc, int n, int cols, int rows, const float* bounds,
+                                     const uint8_t* matched, const float* p3Dw, const uint8_t* valid, const float* min_dist,
+                                     const float* max_dist, const float* normal, const uint8_t* mp_desc, int nmp, const float* Tcw,
+                                     const float* Ow, const float* K4, const float* mvScaleFactors, int nlevels, float mfLogScaleFactor, int th,
+                                     int32_t* match_kf)
+{
+    const KeyPoint* kps = (const KeyPoint*)kps_;
+    FrameGrid grid(kps, n, cols, rows, bounds);
+    const float fx = K4[0], fy = K4[1], cx = K4[2], cy = K4[3];
+    std::vector<uint8_t> vpMatched(n, 0);
+    for (int i = 0; i < n; i++) { match_kf[i] = -1; vpMatched[i] = matched ? matched[i] : 0; }
+    int nmatches = 0;
+    for (int iMP = 0; iMP < nmp; iMP++) {
+        if (valid && !valid[iMP]) continue;
+        const float X = p3Dw[3 * iMP], Y = p3Dw[3 * iMP + 1], Z = p3Dw[3 * iMP + 2];
+        float t0 = Tcw[0] * X + Tcw[1] * Y + Tcw[2] * Z, t1 = Tcw[4] * X + Tcw[5] * Y + Tcw[6] * Z, t2 = Tcw[8] * X + Tcw[9] * Y + Tcw[10] * Z;
+        const float p3Dc[3] = {(float)(t0 * 1.0 + 1.0 * Tcw[3]), (float)(t1 * 1.0 + 1.0 * Tcw[7]), (float)(t2 * 1.0 + 1.0 * Tcw[11])};
+        if (p3Dc[2] < 0.0) continue;
+        const float invz = 1 / p3Dc[2];
+        const float x = p3Dc[0] * invz;
+        const float y = p3Dc[1] * invz;
+        const float u = fx * x + cx;
+        const float v = fy * y + cy;
+        if (!(u >= grid.mnMinX && u < grid.mnMaxX && v >= grid.mnMinY && v < grid.mnMaxY)) continue;
+        const float PO[3] = {X - Ow[0], Y - Ow[1], Z - Ow[2]};
+        const float dist = std::sqrt((double)PO[0] * PO[0] + (double)PO[1] * PO[1] + (double)PO[2] * PO[2]);
+        if (dist < min_dist[iMP] || dist > max_dist[iMP]) continue;
+        const double dot = (double)PO[0] * normal[3 * iMP] + (double)PO[1] * normal[3 * iMP + 1] + (double)PO[2] * normal[3 * iMP + 2];
+        if (dot < 0.5 * dist) continue;
+        float ratio = max_dist[iMP] / dist;
+        int nPredictedLevel = (int)std::ceil(std::log((double)ratio) / mfLogScaleFactor);
+        if (nPredictedLevel < 0) nPredictedLevel = 0;
+        else if (nPredictedLevel >= nlevels) nPredictedLevel = nlevels - 1;
+        const float radius = th * mvScaleFactors[nPredictedLevel];
+        const std::vector<int> vIndices = grid.GetFeaturesInArea(u, v, radius, -1, -1);
+        if (vIndices.empty()) continue;
+        int bestDist = 256, bestIdx = -1;
+        for (size_t k = 0; k < vIndices.size(); k++) {
+            const int idx = vIndices[k];
+            if (vpMatched[idx]) continue;
+            const int kpLevel = kps[idx].octave;
+            if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+            const int d = DescriptorDistance(mp_desc + 32 * (size_t)iMP, desc + 32 * (size_t)idx);
+            if (d < bestDist) { bestDist = d; bestIdx = idx; }
+        }
+        if (bestDist <= TH_LOW) {
+            vpMatched[bestIdx] = 1;
+            match_kf[bestIdx] = iMP;
+            nmatches++;
+        }
+    }
+    return nmatches;
+}
+
 void oracle_three_maxima(const int* sizes, int L, int* out3)
 {
     int a = -1, b = -1, c = -1;

@@ -39,7 +39,7 @@ SYMBOLS = [
     "orbfe_vocabulary_transform", "orbfe_vocabulary_transform_batch_device",
     "orbfe_search_by_bow", "orbfe_search_by_bow_batch_device",
     "orbfe_search_for_triangulation", "orbfe_search_for_triangulation_batch_device",
-    "orbfe_search_by_projection_last_frame", "orbfe_search_by_projection_best", "orbfe_fuse_search", "orbfe_project_map_points", "orbfe_search_by_sim3",
+    "orbfe_search_by_projection_last_frame", "orbfe_search_by_projection_best", "orbfe_fuse_search", "orbfe_project_map_points", "orbfe_search_by_sim3", "orbfe_search_by_projection_sim3",
     "orbfe_keyframe_features_pack", "orbfe_keyframe_features_unpack", "orbfe_keyframe_features_pack_device",
     "orbfe_keyframe_features_unpack_device",
 ]
@@ -90,6 +90,8 @@ def load():
         L.orbfe_fuse_search.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, f32, f32, C.c_double,
                                         vp, vp, i32]
         L.orbfe_search_by_sim3.argtypes = [vp, vp, i32, vp, vp, i32, i32, i32, vp] + [vp] * 10 + [vp] * 6 + [i32, f32, f32, i32, vp, vp, i32]
+        L.orbfe_search_by_projection_sim3.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, f32, i32,
+                                                      vp, vp, i32]
         L.orbfe_project_map_points.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp, i32, vp, i32, f32, f32, i32, i32, vp, i32]
         L.orbfe_search_by_projection_best.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp, i32, i32, f32, vp, vp, i32]
         L.orbfe_undistort_points.argtypes = [vp, i32, vp, vp, i32, vp, i32]
@@ -470,6 +472,24 @@ def search_by_sim3(kf1, kf2, cols, rows, T1w, T2w, sT12, sT21, K4, scale_factors
                                      _p(Ts[0]), _p(Ts[1]), _p(Ts[2]), _p(Ts[3]), _p(K), _p(sf), len(sf), log_scale_factor, th, th_high,
                                      _p(m12), C.byref(nf), device), "orbfe_search_by_sim3")
     return nf.value, m12
+
+
+def search_by_projection_sim3(kps, desc, cols, rows, matched, p3Dw, valid, min_dist, max_dist, normal, mp_desc, Tcw, Ow, K4, scale_factors,
+                              log_scale_factor, th, bounds=None, device=0):
+    """ORBmatcher::SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) (ORBmatcher.cc:294-407) -> (nmatches, match_kf)."""
+    L = load()
+    k = np.ascontiguousarray(kps, KP_DTYPE); d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    f = lambda a, t=np.float32: np.ascontiguousarray(a, t)
+    x, mn, mx, nr, md = f(p3Dw).reshape(-1, 3), f(min_dist), f(max_dist), f(normal).reshape(-1, 3), f(mp_desc, np.uint8).reshape(-1, 32)
+    v = None if valid is None else f(valid, np.uint8); bnd = None if bounds is None else f(bounds)
+    mt = None if matched is None else f(matched, np.uint8)
+    T, O, K, sf = f(Tcw).reshape(-1)[:12].copy(), f(Ow), f(K4), f(scale_factors)
+    m = np.full(len(k), -1, np.int32); nm = C.c_int32(0)
+    pp = lambda a: None if a is None else _p(a)
+    _check(L, L.orbfe_search_by_projection_sim3(_p(k), _p(d), len(k), cols, rows, pp(bnd), pp(mt), _p(x), pp(v), _p(mn), _p(mx), _p(nr), _p(md),
+                                                len(x), _p(T), _p(O), _p(K), _p(sf), len(sf), log_scale_factor, int(th), _p(m), C.byref(nm),
+                                                device), "orbfe_search_by_projection_sim3")
+    return nm.value, m
 
 
 class ORBmatcher:

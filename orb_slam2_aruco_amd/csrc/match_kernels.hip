@@ -1518,6 +1518,23 @@ int orbfe_search_by_sim3(const orbfe_keypoint* kps1, const uint8_t* desc1, int n
     return ORBFE_OK;
 }
 
+int orbfe_search_by_projection_sim3(const orbfe_keypoint* kps, const uint8_t* desc, int n, int cols, int rows, const float* bounds,
+                                    const uint8_t* matched, const float* p3Dw, const uint8_t* valid, const float* min_dist,
+                                    const float* max_dist, const float* normal, const uint8_t* mp_desc, int nmp, const float* Tcw,
+                                    const float* Ow, const float* K4, const float* scale_factors, int nlevels, float log_scale_factor, int th,
+                                    int32_t* match_kf, int32_t* nmatches, int device)
+{
+    if (nmp < 0 || (nmp && (!p3Dw || !min_dist || !max_dist || !normal || !mp_desc)) || !nmatches)
+        return fail(ORBFE_ERR_INVALID, "orbfe_search_by_projection_sim3: invalid argument");
+    std::vector<orbfe_window_query> q(std::max(nmp, 1));
+    // :321-358 projection and gates, then the loop of :360-401: best only, <= TH_LOW, a matched keypoint is taken, no rotation check
+    int rc = orbfe_project_map_points(p3Dw, valid, min_dist, max_dist, normal, nmp, Tcw, Ow, K4, cols, rows, bounds, 1, scale_factors, nlevels,
+                                      log_scale_factor, (float)th, 1, 0, q.data(), device);
+    if (rc) return rc;
+    return orbfe_search_by_projection_best(kps, desc, n, cols, rows, bounds, q.data(), nullptr, mp_desc, nullptr, nmp, matched, 50, 0, 0.0f,
+                                           match_kf, nmatches, device);
+}
+
 int orbfe_knn2_csr(const uint8_t* Q, int nq, const uint8_t* T, int nt, const int32_t* offsets, const int32_t* idx, int init,
                    int32_t* best_idx, int32_t* best_dist, int32_t* second_dist, int device)
 {

@@ -436,6 +436,26 @@ def search_by_sim3(kf1, kf2, cols, rows, T1w, T2w, sT12, sT21, K4, scale_factors
     return nf, m12[:len(a[0])]
 
 
+def search_by_projection_sim3(kps, desc, cols, rows, matched, p3Dw, valid, min_dist, max_dist, normal, mp_desc, Tcw, Ow, K4, scale_factors,
+                              log_scale_factor, th, bounds=None):
+    L = lib()
+    k = np.ascontiguousarray(kps, KP_DTYPE); d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    f = lambda a, t=np.float32: np.ascontiguousarray(a, t)
+    x, mn, mx, nr, md = f(p3Dw).reshape(-1, 3), f(min_dist), f(max_dist), f(normal).reshape(-1, 3), f(mp_desc, np.uint8).reshape(-1, 32)
+    v = None if valid is None else f(valid, np.uint8); bnd = None if bounds is None else f(bounds)
+    mt = None if matched is None else f(matched, np.uint8)
+    T, O, K, sf = f(Tcw).reshape(-1)[:12].copy(), f(Ow), f(K4), f(scale_factors)
+    m = np.full(max(len(k), 1), -1, np.int32)
+    pp = lambda a: None if a is None else _p(a)
+    vp = C.c_void_p
+    L.oracle_search_by_projection_sim3.restype = C.c_int
+    L.oracle_search_by_projection_sim3.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp,
+                                                   C.c_int, C.c_float, C.c_int, vp]
+    nm = L.oracle_search_by_projection_sim3(_p(k), _p(d), len(k), cols, rows, pp(bnd), pp(mt), _p(x), pp(v), _p(mn), _p(mx), _p(nr), _p(md),
+                                            len(x), _p(T), _p(O), _p(K), _p(sf), len(sf), log_scale_factor, int(th), _p(m))
+    return nm, m[:len(k)]
+
+
 def search_for_initialization(k1, d1, k2, d2, cols, rows, prev=None, window=100, nnratio=0.9, check_ori=True, bounds=None):
     L = lib()
     k1 = np.ascontiguousarray(k1); k2 = np.ascontiguousarray(k2)

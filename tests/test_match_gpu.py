@@ -395,3 +395,23 @@ def test_search_by_sim3(orbfe, oracle, seed, th, s12):
     assert got[0] > 30 and got[0] == (got[1] >= 0).sum()
     m = got[1]
     assert np.all(kf1["valid"][m >= 0] == 1) and np.all(kf2["valid"][m[m >= 0]] == 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,th", [(1, 10), (2, 4), (3, 15)])
+def test_search_by_projection_sim3(orbfe, oracle, seed, th):
+    """SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) (ORBmatcher.cc:294-407): the loop-closing variant, bit-exact incl. the
+    matched-keypoint coupling."""
+    _, _, kl, dl, x3, Tcw, K4, sf, rng = _motion_case(oracle, seed)
+    Tcw = (np.eye(3, 4) + 0.2 * (Tcw.astype(np.float64) - np.eye(3, 4))).astype(np.float32)
+    min_d, max_d, nrm, Ow = _map_points_for(kl, x3, Tcw, rng, sf)
+    valid = (rng.random(len(kl)) < 0.9).astype(np.uint8)
+    matched = (rng.random(len(kl)) < 0.2).astype(np.uint8)
+    logsf = np.float32(np.log(np.float32(1.2)))
+    # the candidate points come in another order than the keypoints, and every point twice: the second copy finds its keypoint taken
+    order = np.concatenate([rng.permutation(len(kl)), rng.permutation(len(kl))])
+    args = (x3[order], valid[order], min_d[order], max_d[order], nrm[order], dl[order], Tcw, Ow, K4, sf, logsf, th)
+    want = oracle.search_by_projection_sim3(kl, dl, 640, 480, matched, *args)
+    got = orbfe.search_by_projection_sim3(kl, dl, 640, 480, matched, *args)
+    assert got[0] == want[0] and np.array_equal(got[1], want[1])
+    assert got[0] > 50 and np.all(got[1][matched == 1] == -1)
