@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--nfeatures", type=int, default=1000)
     ap.add_argument("--nlevels", type=int, default=8)
     ap.add_argument("--dictionary", default="ARUCO")
+    ap.add_argument("--marker-capacity", type=int, default=64, help="marker (+ pose) records per frame in the gathered result set")
     ap.add_argument("--cpu-frames", type=int, default=300, help="frames timed on the host for cpu_baseline (0 = skip)")
     ap.add_argument("--no-aruco", action="store_true", help="diagnostic only: drop the ArUco leg (invalidates value)")
     ap.add_argument("--no-orb", action="store_true", help="diagnostic only: drop the ORB + matching legs (invalidates value)")
@@ -154,7 +155,8 @@ def main():
     # {n_kp, kp[cap] x 28 B, desc[cap] x 32 B, n_mk, markers[mcap] x 36 B, poses[mcap] x 56 B} per frame -- so a batch is one collective.
     use_aruco = not args.no_aruco
     big_frames = False
-    mcap = binding.MarkerDetector(args.dictionary, device=local_rank).capacity if use_aruco else 0
+    # marker records per frame in the result set (the detector clamps a frame's count to it; its own limit is 256 candidates)
+    mcap = min(binding.MarkerDetector(args.dictionary, device=local_rank).capacity, args.marker_capacity) if use_aruco else 0
     up = lambda v: (v + 255) // 256 * 256
     off_kps, off_desc = 0, up(B * cap * 28)
     off_n = off_desc + up(B * cap * 32)
@@ -370,7 +372,8 @@ def main():
                                    % ({(480, 640, 300, 1000): "C2", (720, 1280, 300, 2000): "C3", (1080, 1920, 100, 4000): "C5 frames"}
                                       .get((rows, cols, B, args.nfeatures), "custom"), B, cols, rows, args.nfeatures, args.nlevels, args.dictionary,
                                       " + ArUco detect incl. IPPE marker poses" if use_aruco else " (ArUco leg DISABLED: diagnostic run)"),
-                       "frames_per_step_per_gpu": B, "mean_keypoints_per_frame": N,
+                       "frames_per_step_per_gpu": B, "mean_keypoints_per_frame": N, "marker_records_per_frame": mcap,
+                       "result_record_bytes_per_step_per_gpu": rec_bytes,
                        "sub_batches": S, "aruco_big_frame_kernel": big_frames,
                        "parallelism": "stream-per-gpu x%d, RCCL gather to rank 0" % world},
             "roofline": roof, "cpu_baseline": cpu, "stage_us_last_step": stages,
