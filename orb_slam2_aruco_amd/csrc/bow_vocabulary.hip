@@ -217,7 +217,7 @@ __global__ __launch_bounds__(BV_THREADS) void k_bow_vectors(const int32_t* __res
 // node, so the "already matched" coupling of the reference's loop (:213-214, :586) never crosses nodes: a wave owns a common
 // node, walks side 1's features of that node in order and spreads side 2's over its lanes; best / second-best follow the
 // sequential scan (first minimum wins, the second counts duplicates).  The rotation histogram is LDS counters.
-#define SB_THREADS 256
+#define SB_THREADS 1024
 #define SB_MAX 4096 // features per frame (LDS match tables)
 
 struct BowFrames {

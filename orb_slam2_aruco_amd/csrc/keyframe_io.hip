@@ -29,7 +29,19 @@ __global__ __launch_bounds__(KF_THREADS) void k_kf_unpack(const uint32_t* __rest
     if (r0 >= nrec) return;
     const int cnt = min(KF_THREADS, nrec - r0);
     const uint32_t* src = file + src0 + (size_t)r0 * KF_REC_DWORDS;
-    for (int j = threadIdx.x; j < cnt * KF_REC_DWORDS; j += KF_THREADS) s_rec[j] = src[j];
+    {
+        uint32_t v[KF_REC_DWORDS]; // all loads of the tile in flight before the first LDS store
+#pragma unroll
+        for (int k = 0; k < KF_REC_DWORDS; k++) {
+            const int j = threadIdx.x + k * KF_THREADS;
+            v[k] = j < cnt * KF_REC_DWORDS ? src[j] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < KF_REC_DWORDS; k++) {
+            const int j = threadIdx.x + k * KF_THREADS;
+            if (j < cnt * KF_REC_DWORDS) s_rec[j] = v[k];
+        }
+    }
     __syncthreads();
     const size_t o = (size_t)first + r0;
     for (int j = threadIdx.x; j < cnt * 7; j += KF_THREADS) { // cv::KeyPoint: 6 stored fields + class_id (not stored: -1)
@@ -55,13 +67,31 @@ __global__ __launch_bounds__(KF_THREADS) void k_kf_pack(const uint32_t* __restri
     if (r0 >= nrec) return;
     const int cnt = min(KF_THREADS, nrec - r0);
     const size_t o = (size_t)first + r0;
-    for (int j = threadIdx.x; j < cnt * 7; j += KF_THREADS) {
-        const int r = j / 7, c = j - r * 7;
-        if (c < 6) s_rec[r * KF_REC_DWORDS + c] = kps[o * 7 + j];
+    {
+        uint32_t a[7], b[8], c2[2]; // the tile's 17 loads per thread in flight together
+#pragma unroll
+        for (int k = 0; k < 7; k++) { const int j = threadIdx.x + k * KF_THREADS; a[k] = j < cnt * 7 ? kps[o * 7 + j] : 0u; }
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const int j = threadIdx.x + k * KF_THREADS; b[k] = j < cnt * 8 ? desc[o * 8 + j] : 0u; }
+#pragma unroll
+        for (int k = 0; k < 2; k++) { const int j = threadIdx.x + k * KF_THREADS; c2[k] = (mp && j < cnt * 2) ? mp[o * 2 + j] : 0xffffffffu; } // ULONG_MAX = no map point (Map.cc:316-317)
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            const int j = threadIdx.x + k * KF_THREADS;
+            const int r = j / 7, c = j - r * 7;
+            if (j < cnt * 7 && c < 6) s_rec[r * KF_REC_DWORDS + c] = a[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int j = threadIdx.x + k * KF_THREADS;
+            if (j < cnt * 8) s_rec[(j >> 3) * KF_REC_DWORDS + 7 + (j & 7)] = b[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int j = threadIdx.x + k * KF_THREADS;
+            if (j < cnt * 2) s_rec[(j >> 1) * KF_REC_DWORDS + 15 + (j & 1)] = c2[k];
+        }
     }
-    for (int j = threadIdx.x; j < cnt * 8; j += KF_THREADS) s_rec[(j >> 3) * KF_REC_DWORDS + 7 + (j & 7)] = desc[o * 8 + j];
-    for (int j = threadIdx.x; j < cnt * 2; j += KF_THREADS)
-        s_rec[(j >> 1) * KF_REC_DWORDS + 15 + (j & 1)] = mp ? mp[o * 2 + j] : 0xffffffffu; // ULONG_MAX = no map point (Map.cc:316-317)
     if (threadIdx.x < cnt) s_rec[threadIdx.x * KF_REC_DWORDS + 6] = 32u; // mDescriptors.cols
     __syncthreads();
     uint32_t* dst = file + dst0 + (size_t)r0 * KF_REC_DWORDS;
