@@ -29,7 +29,8 @@
  *
  * Threading: an extractor / detector handle is a stateful, non-re-entrant object
  * like the classes it replaces (one handle per stream of frames).  The
- * matching functions are thread-safe.
+ * matching functions are thread-safe (per-thread device workspaces); so is orbfe_vocabulary_transform on one shared
+ * vocabulary handle (ComputeBoW runs on the Tracking, LocalMapping and LoopClosing threads).
  */
 #ifndef ORBFE_H
 #define ORBFE_H

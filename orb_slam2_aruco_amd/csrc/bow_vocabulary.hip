@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -31,6 +32,7 @@ struct orbfe_vocabulary {
     DevBuf info, child_node, child_desc, word_id, weight;                     // the tree
     DevBuf w_desc, w_n, w_word, w_nid, w_weight;                              // host-pointer calls: staging
     DevBuf w_bw, w_bv, w_nb, w_fn, w_fo, w_ff, w_nf;
+    std::mutex staging; // ComputeBoW is called from the Tracking, LocalMapping and LoopClosing threads on ONE vocabulary
 };
 
 namespace {
@@ -592,6 +594,7 @@ int orbfe_vocabulary_transform(orbfe_vocabulary* v, const uint8_t* desc, int n, 
     if (rc) return rc;
     if (vectors) { *nbow = 0; *nfv = 0; fv_offset[0] = 0; }
     if (n == 0) return ORBFE_OK;
+    std::lock_guard<std::mutex> lock(v->staging); // the handle's staging buffers are shared by the calling threads
     const size_t N = (size_t)n;
     if ((rc = v->w_desc.ensure(N * 32)) || (rc = v->w_word.ensure(N * 4)) || (rc = v->w_nid.ensure(N * 4)) || (rc = v->w_weight.ensure(N * 8)) ||
         (rc = v->w_bw.ensure(N * 4)) || (rc = v->w_bv.ensure(N * 8)) || (rc = v->w_nb.ensure(16)) || (rc = v->w_fn.ensure(N * 4)) ||

@@ -415,3 +415,43 @@ def test_search_by_projection_sim3(orbfe, oracle, seed, th):
     got = orbfe.search_by_projection_sim3(kl, dl, 640, 480, matched, *args)
     assert got[0] == want[0] and np.array_equal(got[1], want[1])
     assert got[0] > 50 and np.all(got[1][matched == 1] == -1)
+
+
+@pytest.mark.gpu
+def test_matching_entry_points_are_thread_safe(orbfe, oracle):
+    """ORBmatcher members and ComputeBoW are called from the Tracking, LocalMapping and LoopClosing threads at once:
+    three threads hammer knn2, the projection search and one shared vocabulary; every result equals the serial one."""
+    import threading
+    import voc_cases as vc
+    kps, desc, q, qd, taken = _projection_case(oracle, 5, 600, 2.0)
+    voc = vc.make(10, 3, 3, irregular=False)
+    v = orbfe.ORBVocabulary.from_arrays(10, 3, 0, 0, voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"])
+    rng = np.random.default_rng(0)
+    Q = rng.integers(0, 256, (700, 32), dtype=np.uint8); T = rng.integers(0, 256, (900, 32), dtype=np.uint8)
+    ref_knn = orbfe.knn2(Q, T)
+    ref_sbp = orbfe.search_by_projection(kps, desc, 640, 480, q, qd, taken, 1, 100, 0.8)
+    ref_bow = v.transform(desc, 2)
+    errors = []
+
+    def work(kind):
+        try:
+            for _ in range(25):
+                if kind == 0:
+                    got = orbfe.knn2(Q, T)
+                    assert all(np.array_equal(a, b) for a, b in zip(got, ref_knn))
+                elif kind == 1:
+                    got = orbfe.search_by_projection(kps, desc, 640, 480, q, qd, taken, 1, 100, 0.8)
+                    assert got["nmatches"] == ref_sbp["nmatches"] and np.array_equal(got["match"], ref_sbp["match"])
+                else:
+                    got = v.transform(desc, 2)
+                    assert np.array_equal(got["bow"][1].view(np.uint64), ref_bow["bow"][1].view(np.uint64))
+                    assert all(np.array_equal(a, b) for a, b in zip(got["fv"], ref_bow["fv"]))
+        except Exception as e:  # noqa: BLE001
+            errors.append((kind, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(k % 3,)) for k in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
