@@ -30,7 +30,7 @@ struct orbfe_aruco {
     std::vector<size_t> tab_off;          // resize tables for non-exact levels
     size_t pyr_fbytes = 0, bits_fu32 = 0, candq_fu32 = 0, pool_fu32 = 0, gpad_fu32 = 0;
     int lds_bits_words = 0;
-    DevBuf d_segs, d_tailkeys, d_tailoff;
+    DevBuf d_segs, d_tailkeys, d_tailoff, d_hint; // d_hint: the relay kernel's grid spacing of the previous batch
     int relay_kshift = 5;      // initial grid spacing (log2) of k_contours_relay
     int relay_tbits = 0;       // hash-table size of k_contours_relay (0: the kernel cannot run at this image size)
     bool force_legacy = false; // debug: always use k_contours_t
@@ -44,7 +44,7 @@ struct orbfe_aruco {
     ~orbfe_aruco()
     {
         for (DevBuf* b : {&d_codes, &d_levels, &d_tabs, &d_bits, &d_pyr, &d_candq, &d_pool, &d_kept, &d_rects,
-                          &d_counts, &d_candidx, &d_ncand, &d_result, &d_gpad, &d_in, &d_out, &d_nout, &d_segs, &d_tailkeys, &d_tailoff})
+                          &d_counts, &d_candidx, &d_ncand, &d_result, &d_gpad, &d_in, &d_out, &d_nout, &d_segs, &d_tailkeys, &d_tailoff, &d_hint})
             b->release();
         if (own_stream) (void)hipStreamDestroy(own_stream);
         if (aux_stream) (void)hipStreamDestroy(aux_stream);
@@ -185,6 +185,10 @@ struct orbfe_aruco {
             (rc = d_segs.ensure(std::max<size_t>(((size_t)sizeof(RelaySeg) << relay_tbits) * B, 16))) ||
             (rc = d_tailkeys.ensure((size_t)RL_KCAP * 8 * B)) || (rc = d_tailoff.ensure((size_t)RL_KCAP * 4 * B)))
             return rc;
+        if (!d_hint.p) {
+            if ((rc = d_hint.ensure(16))) return rc;
+            ORBFE_HIP(hipMemset(d_hint.p, 0, 16));
+        }
         batch_cap = B;
         return ORBFE_OK;
     }
@@ -246,7 +250,7 @@ struct orbfe_aruco {
             hipLaunchKernelGGL(k_contours_relay, dim3(B), dim3(RL_THREADS), rlds, s, d_bits.as<uint32_t>(), bits_fu32, wpr,
                                cols, rows, lds_bits_words, 70, relay_kshift, relay_tbits, d_segs.as<RelaySeg>(),
                                d_pool.as<uint32_t>(), pool_fu32, (int)pool_fu32, d_kept.as<ArKept>(), AR_MAX_KEPT, RL_KCAP,
-                               d_tailkeys.as<unsigned long long>(), d_tailoff.as<int32_t>(), d_counts.as<int32_t>());
+                               d_tailkeys.as<unsigned long long>(), d_tailoff.as<int32_t>(), d_counts.as<int32_t>(), d_hint.as<int32_t>());
             const size_t tlds = tail_lds_bytes(RL_KCAP, 1280);
             ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_contours_tail),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));

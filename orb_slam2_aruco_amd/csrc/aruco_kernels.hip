@@ -733,10 +733,13 @@ __device__ __forceinline__ int relay_frame(
     const uint32_t* __restrict__ gbits, size_t bits_fstride, int wpr_g, int W, int H, int lds_bits_words, int min_len,
     int kshift, int tbits, RelaySeg* __restrict__ segs, uint32_t* __restrict__ pool, size_t pool_fstride, int pool_cap,
     ArKept* __restrict__ kept_out, int kept_cap, int kcap /*kept borders this kernel's LDS holds*/,
-    unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off, int32_t* __restrict__ counts)
+    unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off, int32_t* __restrict__ counts, int32_t* __restrict__ hint)
 {
     extern __shared__ __align__(16) unsigned char ct_smem[];
     __shared__ int s_next, s_nkept, s_flags, s_ncand, s_nmark, s_nsmall, s_pool, s_changed[2];
+    // grid spacing that fitted the marker table in the previous batch of this handle (video: it will fit again); saves the
+    // enumeration passes that overflow at finer spacings.  The result does not depend on the spacing.
+    if (!force_nogrid && hint) kshift = max(kshift, min(*hint, 7));
     __shared__ uint16_t s_lut[2048];
     __shared__ unsigned s_tailq;
     const int tid = threadIdx.x, f = blockIdx.x, NT = RL_THREADS;
@@ -868,6 +871,8 @@ __device__ __forceinline__ int relay_frame(
     __syncthreads();
     if (nogrid) break;
     }
+    if (!force_nogrid && hint && f == 0 && tid == 0)
+        *hint = kshift >= 30 ? 7 : (s_nmark < (T >> 2) && kshift > 5) ? kshift - 1 : kshift;
     RL_STAMP();
 
     // every lane owns a staging arena in the upper part of the frame's pool: the points of its segments (d) and of the
@@ -1276,14 +1281,14 @@ __global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_num_vgpr(64))) vo
     const uint32_t* __restrict__ gbits, size_t bits_fstride, int wpr_g, int W, int H, int lds_bits_words, int min_len,
     int kshift, int tbits, RelaySeg* __restrict__ segs, uint32_t* __restrict__ pool, size_t pool_fstride, int pool_cap,
     ArKept* __restrict__ kept_out, int kept_cap, int kcap /*kept borders this kernel's LDS holds*/,
-    unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off, int32_t* __restrict__ counts)
+    unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off, int32_t* __restrict__ counts, int32_t* __restrict__ hint)
 {
     __builtin_amdgcn_s_setprio(2); // latency-bound: its few waves go first when a VALU-bound kernel shares the CU
     if (relay_frame<false>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool, pool_fstride,
-                           pool_cap, kept_out, kept_cap, kcap, tail_keys, tail_off, counts)) {
+                           pool_cap, kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint)) {
         __syncthreads();
         relay_frame<true>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool, pool_fstride,
-                          pool_cap, kept_out, kept_cap, kcap, tail_keys, tail_off, counts);
+                          pool_cap, kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint);
     }
 }
 

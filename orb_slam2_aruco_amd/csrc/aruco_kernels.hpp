@@ -51,7 +51,7 @@ struct RelaySeg {
 __global__ void k_contours_relay(const uint32_t* gbits, size_t bits_fstride, int wpr_g, int W, int H,
                                  int lds_bits_words, int min_len, int kshift, int tbits, RelaySeg* segs, uint32_t* pool,
                                  size_t pool_fstride, int pool_cap, ArKept* kept_out, int kept_cap, int kcap,
-                                 unsigned long long* tail_keys, int32_t* tail_off, int32_t* counts);
+                                 unsigned long long* tail_keys, int32_t* tail_off, int32_t* counts, int32_t* hint);
 __global__ void k_contours_tail(const unsigned long long* tail_keys, const int32_t* tail_off, int kcap,
                                 const uint32_t* pool, size_t pool_fstride, ArKept* kept_out, int kept_cap,
                                 ArRect* rects_out, int rect_cap, int32_t* counts, int lds_bytes);
