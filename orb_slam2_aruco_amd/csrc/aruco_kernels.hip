@@ -774,6 +774,8 @@ __device__ __forceinline__ int relay_frame(
 #ifdef ORBFE_CT_TIMING
     long long tq[8];
     int tqi = 0;
+    __shared__ unsigned s_dbg_steps[6]; // phase (c): steps of closed / marker-stopped / non-canonical walks; max and sum of a wave's loop iterations; longest closed border
+    if (threadIdx.x < 6) s_dbg_steps[threadIdx.x] = 0;
 #define RL_STAMP() tq[tqi++] = clock64()
 #else
 #define RL_STAMP()
@@ -890,7 +892,13 @@ __device__ __forceinline__ int relay_frame(
         int wj = 0, wy = 0, sx = 0, sy = 0, s0 = 0, is_hole = 0, start_key = 0, ncand_l = 0;
         const int nwords = wpr * H;
         const float inv_wpr = 1.0f / (float)wpr;
+#ifdef ORBFE_CT_TIMING
+        unsigned dbg_iters = 0;
+#endif
         for (;;) {
+#ifdef ORBFE_CT_TIMING
+            dbg_iters++;
+#endif
             if (!busy && !drained) {
                 if (!(m_outer | m_hole)) {
                     const int i = atomicAdd(&s_next, 1);
@@ -935,11 +943,18 @@ __device__ __forceinline__ int relay_frame(
                         stop |= ((e & 0x080u) && key3 - 65536 < start_key) || ((e & 0x100u) && key3 - 1 < start_key) ||
                                 ((e & 0x200u) && key3 + 1 < start_key) || ((e & 0x400u) && key3 + 65536 < start_key);
                     else stop |= key3 < start_key;
+#ifdef ORBFE_CT_TIMING
+                    if (stop) atomicAdd(&s_dbg_steps[rl_is_marker(e, wk.x, wk.y, kmask) ? 1 : 2], (unsigned)wk.n + 1);
+#endif
                     if (stop) busy = false;
                     else {
                         rl_advance(im, wk, e);
                         if (wk.x == sx && wk.y == sy && wk.s == s0) {
                             busy = false;
+#ifdef ORBFE_CT_TIMING
+                            atomicAdd(&s_dbg_steps[0], (unsigned)wk.n);
+                            atomicMax(&s_dbg_steps[5], (unsigned)wk.n);
+#endif
                             if (wk.n > min_len) {
                                 // rare with a grid (> min_len points between grid lines), every kept border without one: the
                                 // border is whole, so its final place is known -- walk it once more, straight into the pool
@@ -963,6 +978,9 @@ __device__ __forceinline__ int relay_frame(
             }
         }
         atomicAdd(&s_ncand, ncand_l);
+#ifdef ORBFE_CT_TIMING
+        if ((tid & 63) == 0) { atomicMax(&s_dbg_steps[3], dbg_iters); atomicAdd(&s_dbg_steps[4], dbg_iters); }
+#endif
     }
     __syncthreads();
     if (tid == 0) s_next = 0;
@@ -1271,7 +1289,8 @@ __device__ __forceinline__ int relay_frame(
         RL_STAMP();
         long long* dbg = (long long*)(kept_out + (size_t)f * kept_cap + kept_cap - 4);
         for (int i = 0; i < 6; i++) dbg[i] = tq[i + 1] - tq[i];
-        dbg[6] = 0;
+        dbg[6] = ((long long)s_dbg_steps[3] << 40) | ((long long)s_dbg_steps[4] << 16) | s_dbg_steps[5];
+        dbg[7] = s_dbg_steps[0]; dbg[10] = s_dbg_steps[1]; dbg[11] = s_dbg_steps[2];
     }
 #endif
     return 0;
