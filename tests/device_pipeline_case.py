@@ -73,4 +73,35 @@ for f in range(3):
     assert np.array_equal(off, want["fv"][1])
     assert np.array_equal(ff[f * cap:f * cap + off[-1]].cpu().numpy().view(np.uint32), want["fv"][2])
 print("bow ok")
+
+# ---- SearchByBoW / SearchForTriangulation over explicit frame pairs of the batch (device pointers end to end)
+pairs = [(0, 1), (2, 0)]
+p1 = torch.tensor([a for a, _ in pairs], dtype=torch.int32, device=dev); p2 = torch.tensor([b for _, b in pairs], dtype=torch.int32, device=dev)
+m12, m21, nmm = i32(2 * cap), i32(2 * cap), i32(2)
+rc = L.orbfe_search_by_bow_batch_device(kps.data_ptr(), desc.data_ptr(), None, n.data_ptr(), fn.data_ptr(), fo.data_ptr(), ff.data_ptr(),
+                                        nf.data_ptr(), cap, p1.data_ptr(), p2.data_ptr(), 2, 0, 0.7, 1, 50, np.float32(30 / 360.0),
+                                        m12.data_ptr(), m21.data_ptr(), nmm.data_ptr(), None)
+assert rc == 0, L.orbfe_last_error()
+torch.cuda.synchronize()
+fvs = [ovoc.transform(frames[f][1], 4)["fv"] for f in range(3)]
+for p, (a, b) in enumerate(pairs):
+    (ka, da), (kb, db) = frames[a], frames[b]
+    wn, w12, w21 = oracle.search_by_bow(ka, da, fvs[a], kb, db, fvs[b], None, None, 0.7, True, 50, 30 / 360.0)
+    assert int(nmm[p]) == wn and wn > 0
+    assert np.array_equal(m12[p * cap:p * cap + len(ka)].cpu().numpy(), w12) and np.array_equal(m21[p * cap:p * cap + len(kb)].cpu().numpy(), w21)
+F12 = torch.tensor(np.tile(np.array([0, 0, 0, 0, 0, -1, 0, 1, 0], np.float32), 2), device=dev)
+epi = torch.tensor(np.array([320, 240, -1e4, 240], np.float32), device=dev)
+sfh = np.array([1.2 ** i for i in range(8)], np.float32); sgh = (sfh * sfh).astype(np.float32)
+rc = L.orbfe_search_for_triangulation_batch_device(kps.data_ptr(), desc.data_ptr(), None, n.data_ptr(), fn.data_ptr(), fo.data_ptr(), ff.data_ptr(),
+                                                   nf.data_ptr(), cap, p1.data_ptr(), p2.data_ptr(), 2, F12.data_ptr(), epi.data_ptr(),
+                                                   sfh.ctypes.data_as(C.c_void_p), sgh.ctypes.data_as(C.c_void_p), 8, 1, m12.data_ptr(),
+                                                   m21.data_ptr(), nmm.data_ptr(), None)
+assert rc == 0, L.orbfe_last_error()
+torch.cuda.synchronize()
+for p, (a, b) in enumerate(pairs):
+    (ka, da), (kb, db) = frames[a], frames[b]
+    ep = (320.0, 240.0) if p == 0 else (-1e4, 240.0)
+    wn, w12 = oracle.search_for_triangulation(ka, da, fvs[a], kb, db, fvs[b], np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32), ep, sfh, sgh)
+    assert int(nmm[p]) == wn and np.array_equal(m12[p * cap:p * cap + len(ka)].cpu().numpy(), w12)
+print("pairs ok")
 print("ok")

@@ -258,10 +258,13 @@ class VocabularyOracle:
         self.h = handle
 
     def __del__(self):
-        if getattr(self, "h", None):
-            self.L.oracle_voc_destroy.argtypes = [C.c_void_p]
-            self.L.oracle_voc_destroy(self.h)
-            self.h = None
+        try:
+            if getattr(self, "h", None):
+                self.L.oracle_voc_destroy.argtypes = [C.c_void_p]
+                self.L.oracle_voc_destroy(self.h)
+                self.h = None
+        except Exception:  # interpreter shutdown: module globals may be gone
+            pass
 
     @classmethod
     def load_text(cls, filename):
