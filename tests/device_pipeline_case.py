@@ -104,4 +104,27 @@ for p, (a, b) in enumerate(pairs):
     wn, w12 = oracle.search_for_triangulation(ka, da, fvs[a], kb, db, fvs[b], np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32), ep, sfh, sgh)
     assert int(nmm[p]) == wn and np.array_equal(m12[p * cap:p * cap + len(ka)].cpu().numpy(), w12)
 print("pairs ok")
+
+# ---- detector batch on device pointers + marker poses (MarkerDetector::detect with camera parameters, Frame.cc:142)
+import pose_cases as pc
+det = orbfe.MarkerDetector("ARUCO")
+mcap = 32
+mk = torch.zeros(3 * mcap * 36, dtype=torch.uint8, device=dev); nmk = i32(3)
+poses = torch.zeros(3 * mcap * 56, dtype=torch.uint8, device=dev)
+det.detect_batch_device(imgs.data_ptr(), 3, 480 * 640, 480, 640, 640, mk.data_ptr(), mcap, nmk.data_ptr(), 0)
+Kc = orbfe.camera_resize(pc.K4, (1280, 720), (640, 480)); Dc = np.ascontiguousarray(pc.DIST)
+rc = L.orbfe_marker_poses_batch_device(mk.data_ptr(), nmk.data_ptr(), mcap, 3, np.float32(0.187), Kc.ctypes.data_as(C.c_void_p),
+                                       Dc.ctypes.data_as(C.c_void_p), 5, poses.data_ptr(), None)
+assert rc == 0, L.orbfe_last_error()
+torch.cuda.synchronize()
+assert det.batch_status() == (0, 0)
+mkh = mk.cpu().numpy().view(orbfe.MARKER_DTYPE).reshape(3, mcap); ph = poses.cpu().numpy().view(orbfe.POSE_DTYPE).reshape(3, mcap)
+odet = oracle.ArucoOracle("ARUCO")
+for f in range(3):
+    want = odet.detect(s[f])
+    assert int(nmk[f]) == len(want) > 0 and np.array_equal(mkh[f, :len(want)]["id"], want["id"])
+    for j, w in enumerate(want):
+        r1, t1, r2, t2, err = oracle.marker_pose(w["corners"], 0.187, Kc, Dc)
+        assert np.allclose(ph[f, j]["rvec"], r1, rtol=1e-5, atol=1e-6) and np.allclose(ph[f, j]["tvec"], t1, rtol=1e-5, atol=1e-6)
+print("markers ok")
 print("ok")
