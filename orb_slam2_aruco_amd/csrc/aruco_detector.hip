@@ -30,7 +30,7 @@ struct orbfe_aruco {
     std::vector<size_t> tab_off;          // resize tables for non-exact levels
     size_t pyr_fbytes = 0, bits_fu32 = 0, candq_fu32 = 0, pool_fu32 = 0, gpad_fu32 = 0;
     int lds_bits_words = 0;
-    DevBuf d_segs, d_tailkeys, d_tailoff, d_hint; // d_hint: the relay kernel's grid spacing of the previous batch
+    DevBuf d_segs, d_tailkeys, d_tailoff, d_small, d_hint; // d_hint: the relay kernel's grid spacing of the previous batch
     int relay_kshift = 5;      // initial grid spacing (log2) of k_contours_relay
     int relay_tbits = 0;       // hash-table size of k_contours_relay (0: the kernel cannot run at this image size)
     bool force_legacy = false; // debug: always use k_contours_t
@@ -44,7 +44,7 @@ struct orbfe_aruco {
     ~orbfe_aruco()
     {
         for (DevBuf* b : {&d_codes, &d_levels, &d_tabs, &d_bits, &d_pyr, &d_candq, &d_pool, &d_kept, &d_rects,
-                          &d_counts, &d_candidx, &d_ncand, &d_result, &d_gpad, &d_in, &d_out, &d_nout, &d_segs, &d_tailkeys, &d_tailoff, &d_hint})
+                          &d_counts, &d_candidx, &d_ncand, &d_result, &d_gpad, &d_in, &d_out, &d_nout, &d_segs, &d_tailkeys, &d_tailoff, &d_small, &d_hint})
             b->release();
         if (own_stream) (void)hipStreamDestroy(own_stream);
         if (aux_stream) (void)hipStreamDestroy(aux_stream);
@@ -154,12 +154,16 @@ struct orbfe_aruco {
         // the padded bit image goes to LDS when it fits next to the other arrays (160 KiB per workgroup)
         lds_bits_words = (contours_lds_bytes((int)padded_words, AR_MAX_KEPT) <= 160 * 1024) ? (int)padded_words : 0;
         gpad_fu32 = padded_words; // always there: big_mode uses the HBM variant at any size
-        // k_contours_relay needs the bit image AND its marker table in LDS; otherwise k_contours_t does all frames
-        // 4096 marker slots on a 32-pixel grid (one workgroup per CU).  A 2048-slot table on a 64-pixel grid would let two
-        // workgroups share a CU, but its longer segments cost more than the sharing wins (measured: 857 vs 726 us).
+        // k_contours_relay needs the bit image AND its marker table in LDS; otherwise k_contours_t does all frames.
+        // 4096 marker slots on a 32-pixel grid for ordinary frames (a 2048-slot table on a 64-pixel grid would let two workgroups
+        // share a CU, but its longer segments cost more than the sharing wins: 857 vs 726 us).  Large frames have more grid
+        // crossings than 4096 slots hold and would be coarsened to a 128-pixel grid, which doubles the kernel's time (640 x 480:
+        // 463 / 592 / 949 us at 32 / 64 / 128 pixels): they get 8192 slots (k_contours_relay8) when the LDS allows.
         relay_tbits = 0;
         const size_t rl_static = 6 * 1024;
-        if (lds_bits_words && relay_lds_bytes(lds_bits_words, RL_KCAP, 12) + rl_static <= 160 * 1024) { relay_tbits = 12; relay_kshift = 5; }
+        const bool large = (size_t)rows_ * cols_ > (size_t)640 * 480 * 3 / 2;
+        if (lds_bits_words && large && relay_lds_bytes(lds_bits_words, RL_KCAP, 13) + rl_static <= 160 * 1024) { relay_tbits = 13; relay_kshift = 5; }
+        else if (lds_bits_words && relay_lds_bytes(lds_bits_words, RL_KCAP, 12) + rl_static <= 160 * 1024) { relay_tbits = 12; relay_kshift = 5; }
         rows = rows_; cols = cols_;
         batch_cap = 0;
         if (tabs.empty()) tabs.push_back(0);
@@ -183,7 +187,8 @@ struct orbfe_aruco {
             (rc = d_result.ensure((size_t)AR_MAX_RECTS * 8 * B)) ||
             (rc = d_gpad.ensure(std::max<size_t>(gpad_fu32 * 4 * B, 16))) ||
             (rc = d_segs.ensure(std::max<size_t>(((size_t)sizeof(RelaySeg) << relay_tbits) * B, 16))) ||
-            (rc = d_tailkeys.ensure((size_t)RL_KCAP * 8 * B)) || (rc = d_tailoff.ensure((size_t)RL_KCAP * 4 * B)))
+            (rc = d_tailkeys.ensure((size_t)RL_KCAP * 8 * B)) || (rc = d_tailoff.ensure((size_t)RL_KCAP * 4 * B)) ||
+            (rc = d_small.ensure((size_t)RL_KCAP * 16 * B)))
             return rc;
         if (!d_hint.p) {
             if ((rc = d_hint.ensure(16))) return rc;
@@ -245,12 +250,13 @@ struct orbfe_aruco {
         const bool relay = relay_tbits && !force_legacy && !big_mode;
         if (relay && !(g_aruco_skip & 1)) {
             const size_t rlds = relay_lds_bytes(lds_bits_words, RL_KCAP, relay_tbits);
-            ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_contours_relay),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
-            hipLaunchKernelGGL(k_contours_relay, dim3(B), dim3(RL_THREADS), rlds, s, d_bits.as<uint32_t>(), bits_fu32, wpr,
+            auto rfn = relay_tbits > 12 ? k_contours_relay8 : k_contours_relay;
+            ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
+            hipLaunchKernelGGL(rfn, dim3(B), dim3(RL_THREADS), rlds, s, d_bits.as<uint32_t>(), bits_fu32, wpr,
                                cols, rows, lds_bits_words, 70, relay_kshift, relay_tbits, d_segs.as<RelaySeg>(),
                                d_pool.as<uint32_t>(), pool_fu32, (int)pool_fu32, d_kept.as<ArKept>(), AR_MAX_KEPT, RL_KCAP,
-                               d_tailkeys.as<unsigned long long>(), d_tailoff.as<int32_t>(), d_counts.as<int32_t>(), d_hint.as<int32_t>());
+                               d_tailkeys.as<unsigned long long>(), d_tailoff.as<int32_t>(), d_counts.as<int32_t>(), d_hint.as<int32_t>(),
+                               d_small.as<uint4>());
             const size_t tlds = tail_lds_bytes(RL_KCAP, 1280);
             ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_contours_tail),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));

@@ -728,12 +728,12 @@ __device__ __forceinline__ void rl_advance(const BitImage& im, RelayWalk& w, uns
 }
 
 // returns 1 if the frame has to be done again without a grid (force_nogrid), else 0
-template <bool force_nogrid>
+template <bool force_nogrid, int RL_SLOTS>
 __device__ __forceinline__ int relay_frame(
     const uint32_t* __restrict__ gbits, size_t bits_fstride, int wpr_g, int W, int H, int lds_bits_words, int min_len,
     int kshift, int tbits, RelaySeg* __restrict__ segs, uint32_t* __restrict__ pool, size_t pool_fstride, int pool_cap,
     ArKept* __restrict__ kept_out, int kept_cap, int kcap /*kept borders this kernel's LDS holds*/,
-    unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off, int32_t* __restrict__ counts, int32_t* __restrict__ hint)
+    unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off, int32_t* __restrict__ counts, int32_t* __restrict__ hint, uint4* __restrict__ small_g)
 {
     extern __shared__ __align__(16) unsigned char ct_smem[];
     __shared__ int s_next, s_nkept, s_flags, s_ncand, s_nmark, s_nsmall, s_pool, s_changed[2];
@@ -760,8 +760,9 @@ __device__ __forceinline__ int relay_frame(
     uint16_t* arg = jmp + T;   // slot of the segment that holds the border's smallest start state
     const size_t r_bytes = relay_region_bytes(lds_bits_words, kcap, tbits);
     uint32_t* hkey = (uint32_t*)(ct_smem + r_bytes);
-    // whole borders kept by phase (c): pool offset, length, -, discovery key * 2 + is_hole (kcap entries, behind the keys)
-    uint4* s_small = (uint4*)(hkey + T);
+    // whole borders kept by phase (c): pool offset, length, -, discovery key * 2 + is_hole (kcap entries).  Rarely touched, so they
+    // live in HBM: their 16 KB of LDS are what lets a 1280 x 720 frame have an 8192-slot marker table.
+    uint4* s_small = small_g + (size_t)f * kcap;
     int* klen = (int*)uni;
     int* koff = klen + kcap;
     int* rectflag = koff + kcap;
@@ -1046,7 +1047,7 @@ __device__ __forceinline__ int relay_frame(
 
     // the bit image is dead: its space now holds the list arrays, loaded from the segment records
 #pragma unroll
-    for (int q = 0; q < RL_SLOTS_PER_THREAD; q++) {
+    for (int q = 0; q < RL_SLOTS; q++) {
         const int i = tid + q * NT;
         if (i < T && hkey[i]) {
             const RelaySeg r = sg[i];
@@ -1057,10 +1058,10 @@ __device__ __forceinline__ int relay_frame(
     // ---- (e1) the border's smallest start state, by pointer doubling round the cyclic list.  When a round changes
     // nothing, every window already covers its cycle (windows double; "no change" makes the minima periodic).
     for (int round = 0; round < 24; round++) {
-        uint32_t m_[RL_SLOTS_PER_THREAD];
-        uint16_t a_[RL_SLOTS_PER_THREAD], j_[RL_SLOTS_PER_THREAD];
+        uint32_t m_[RL_SLOTS];
+        uint16_t a_[RL_SLOTS], j_[RL_SLOTS];
 #pragma unroll
-        for (int q = 0; q < RL_SLOTS_PER_THREAD; q++) {
+        for (int q = 0; q < RL_SLOTS; q++) {
             const int i = tid + q * NT;
             if (i < T && hkey[i]) {
                 const int j = jmp[i];
@@ -1071,7 +1072,7 @@ __device__ __forceinline__ int relay_frame(
         if (tid == 0) s_changed[(round + 1) & 1] = 0;
         bool ch = false;
 #pragma unroll
-        for (int q = 0; q < RL_SLOTS_PER_THREAD; q++) {
+        for (int q = 0; q < RL_SLOTS; q++) {
             const int i = tid + q * NT;
             if (i < T && hkey[i]) {
                 if (m_[q] < cmin[i]) { cmin[i] = m_[q]; arg[i] = a_[q]; ch = true; }
@@ -1085,17 +1086,17 @@ __device__ __forceinline__ int relay_frame(
     // ---- (e2) list ranking: cut every cycle in front of the segment that holds the canonical start; val = points
     // from the segment to the end of the list
     uint32_t* val = cmin;
-    uint32_t canon_[RL_SLOTS_PER_THREAD]; // (head segments) the border's canonical start state
+    uint32_t canon_[RL_SLOTS]; // (head segments) the border's canonical start state
 #pragma unroll
-    for (int q = 0; q < RL_SLOTS_PER_THREAD; q++) {
+    for (int q = 0; q < RL_SLOTS; q++) {
         const int i = tid + q * NT;
         canon_[q] = (i < T && hkey[i]) ? cmin[i] : 0xffffffffu;
     }
     {
-        uint32_t l_[RL_SLOTS_PER_THREAD];
-        uint16_t n_[RL_SLOTS_PER_THREAD];
+        uint32_t l_[RL_SLOTS];
+        uint16_t n_[RL_SLOTS];
 #pragma unroll
-        for (int q = 0; q < RL_SLOTS_PER_THREAD; q++) {
+        for (int q = 0; q < RL_SLOTS; q++) {
             const int i = tid + q * NT;
             if (i < T && hkey[i]) {
                 const RelaySeg r = sg[i];
@@ -1105,7 +1106,7 @@ __device__ __forceinline__ int relay_frame(
         }
         __syncthreads(); // all reads of cmin (as minimum) and of arg[nxt] done
 #pragma unroll
-        for (int q = 0; q < RL_SLOTS_PER_THREAD; q++) {
+        for (int q = 0; q < RL_SLOTS; q++) {
             const int i = tid + q * NT;
             if (i < T && hkey[i]) { val[i] = l_[q]; jmp[i] = n_[q]; }
         }
@@ -1113,10 +1114,10 @@ __device__ __forceinline__ int relay_frame(
         __syncthreads();
     }
     for (int round = 0; round < 24; round++) {
-        uint32_t v_[RL_SLOTS_PER_THREAD];
-        uint16_t j_[RL_SLOTS_PER_THREAD];
+        uint32_t v_[RL_SLOTS];
+        uint16_t j_[RL_SLOTS];
 #pragma unroll
-        for (int q = 0; q < RL_SLOTS_PER_THREAD; q++) {
+        for (int q = 0; q < RL_SLOTS; q++) {
             const int i = tid + q * NT;
             j_[q] = RL_NIL;
             if (i < T && hkey[i]) {
@@ -1129,7 +1130,7 @@ __device__ __forceinline__ int relay_frame(
         if (tid == 0) s_changed[(round + 1) & 1] = 0;
         bool ch = false;
 #pragma unroll
-        for (int q = 0; q < RL_SLOTS_PER_THREAD; q++) {
+        for (int q = 0; q < RL_SLOTS; q++) {
             const int i = tid + q * NT;
             if (v_[q] != 0xffffffffu) { val[i] += v_[q]; jmp[i] = j_[q]; ch = true; }
         }
@@ -1141,7 +1142,7 @@ __device__ __forceinline__ int relay_frame(
 
     // ---- (f1) kept borders: pool space and sort key; jmp[root] = kept index or NIL
 #pragma unroll
-    for (int q = 0; q < RL_SLOTS_PER_THREAD; q++) {
+    for (int q = 0; q < RL_SLOTS; q++) {
         const int i = tid + q * NT;
         if (i < T && hkey[i] && arg[i] == i) {
             const int n = (int)val[i];
@@ -1185,10 +1186,10 @@ __device__ __forceinline__ int relay_frame(
     // segments are listed (in the marker keys' space, dead after this point) with a running point count, and every
     // lane finds the segment of its point by binary search.
     {
-        int e_dst[RL_SLOTS_PER_THREAD], e_src[RL_SLOTS_PER_THREAD], e_len[RL_SLOTS_PER_THREAD], e_k[RL_SLOTS_PER_THREAD];
+        int e_dst[RL_SLOTS], e_src[RL_SLOTS], e_len[RL_SLOTS], e_k[RL_SLOTS];
         int mine = 0;
 #pragma unroll
-        for (int q = 0; q < RL_SLOTS_PER_THREAD; q++) {
+        for (int q = 0; q < RL_SLOTS; q++) {
             const int i = tid + q * NT;
             e_len[q] = 0;
             if (i < T && hkey[i]) {
@@ -1217,7 +1218,7 @@ __device__ __forceinline__ int relay_frame(
             const int Er = min(RL_COPY_CAP, E - r0);
             int e0 = ebase - r0;
 #pragma unroll
-            for (int q = 0; q < RL_SLOTS_PER_THREAD; q++)
+            for (int q = 0; q < RL_SLOTS; q++)
                 if (e_len[q] > 0) {
                     if (e0 >= 0 && e0 < RL_COPY_CAP) { c_pre[e0] = e_len[q]; c_dst[e0] = e_dst[q]; c_src[e0] = e_src[q]; c_k[e0] = (uint16_t)e_k[q]; }
                     e0++;
@@ -1300,14 +1301,32 @@ __global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_num_vgpr(64))) vo
     const uint32_t* __restrict__ gbits, size_t bits_fstride, int wpr_g, int W, int H, int lds_bits_words, int min_len,
     int kshift, int tbits, RelaySeg* __restrict__ segs, uint32_t* __restrict__ pool, size_t pool_fstride, int pool_cap,
     ArKept* __restrict__ kept_out, int kept_cap, int kcap /*kept borders this kernel's LDS holds*/,
-    unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off, int32_t* __restrict__ counts, int32_t* __restrict__ hint)
+    unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off, int32_t* __restrict__ counts, int32_t* __restrict__ hint,
+    uint4* __restrict__ small_g)
 {
     __builtin_amdgcn_s_setprio(2); // latency-bound: its few waves go first when a VALU-bound kernel shares the CU
-    if (relay_frame<false>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool, pool_fstride,
-                           pool_cap, kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint)) {
+    if (relay_frame<false, RL_SLOTS_PER_THREAD>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool,
+                                                pool_fstride, pool_cap, kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g)) {
         __syncthreads();
-        relay_frame<true>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool, pool_fstride,
-                          pool_cap, kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint);
+        relay_frame<true, RL_SLOTS_PER_THREAD>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool,
+                                               pool_fstride, pool_cap, kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g);
+    }
+}
+
+// The same with eight table slots per thread (tbits = 13): large frames, whose workgroup owns a CU anyway (LDS), so the
+// register budget of two resident workgroups does not apply.
+__global__ __launch_bounds__(RL_THREADS) void k_contours_relay8(
+    const uint32_t* __restrict__ gbits, size_t bits_fstride, int wpr_g, int W, int H, int lds_bits_words, int min_len,
+    int kshift, int tbits, RelaySeg* __restrict__ segs, uint32_t* __restrict__ pool, size_t pool_fstride, int pool_cap,
+    ArKept* __restrict__ kept_out, int kept_cap, int kcap, unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off,
+    int32_t* __restrict__ counts, int32_t* __restrict__ hint, uint4* __restrict__ small_g)
+{
+    __builtin_amdgcn_s_setprio(2);
+    if (relay_frame<false, 8>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool, pool_fstride, pool_cap,
+                              kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g)) {
+        __syncthreads();
+        relay_frame<true, 8>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool, pool_fstride, pool_cap,
+                             kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g);
     }
 }
 

@@ -51,7 +51,11 @@ struct RelaySeg {
 __global__ void k_contours_relay(const uint32_t* gbits, size_t bits_fstride, int wpr_g, int W, int H,
                                  int lds_bits_words, int min_len, int kshift, int tbits, RelaySeg* segs, uint32_t* pool,
                                  size_t pool_fstride, int pool_cap, ArKept* kept_out, int kept_cap, int kcap,
-                                 unsigned long long* tail_keys, int32_t* tail_off, int32_t* counts, int32_t* hint);
+                                 unsigned long long* tail_keys, int32_t* tail_off, int32_t* counts, int32_t* hint, uint4* small_g);
+__global__ void k_contours_relay8(const uint32_t* gbits, size_t bits_fstride, int wpr_g, int W, int H,
+                                 int lds_bits_words, int min_len, int kshift, int tbits, RelaySeg* segs, uint32_t* pool,
+                                 size_t pool_fstride, int pool_cap, ArKept* kept_out, int kept_cap, int kcap,
+                                 unsigned long long* tail_keys, int32_t* tail_off, int32_t* counts, int32_t* hint, uint4* small_g);
 __global__ void k_contours_tail(const unsigned long long* tail_keys, const int32_t* tail_off, int kcap,
                                 const uint32_t* pool, size_t pool_fstride, ArKept* kept_out, int kept_cap,
                                 ArRect* rects_out, int rect_cap, int32_t* counts, int lds_bytes);
@@ -92,7 +96,7 @@ __host__ __device__ inline size_t relay_region_bytes(int lds_bits_words, int kca
 }
 inline size_t relay_lds_bytes(int lds_bits_words, int kcap, int tbits)
 {
-    return relay_region_bytes(lds_bits_words, kcap, tbits) + ((size_t)4 << tbits) + (size_t)kcap * 16;
+    return relay_region_bytes(lds_bits_words, kcap, tbits) + ((size_t)4 << tbits);
 }
 
 // LDS of k_contours_tail: per-border arrays, approx scratch, length ranks, one point buffer of `pts` points per wave
