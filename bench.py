@@ -1,14 +1,17 @@
 #!/usr/bin/env python3
 """bench.py -- frames/s of the per-frame front-end (ORB extract + ArUco detect + Hamming match) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config C2|C3|C4|C5]
     (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-One step = one pass of the hot path over one batch: a synthetic 640x480 mono stream (BASELINE.json configs[1]:
-nFeatures 1000, 8 levels, ARUCO dictionary) resident in HBM before the timed region.  Each rank owns an
-independent stream (frames/streams shard with no data-path collective, SURVEY 8e: weak scaling); the only collective
-is the final RCCL gather of the fixed-capacity result records to rank 0, inside the timed region.
-Prints ONE JSON line on rank 0.
+One step = one pass of the hot path (orb_slam2_aruco_amd/pipeline.py: FrontEndPipeline.step) over one batch: a synthetic
+mono stream resident in HBM before the timed region.  Default = BASELINE.json configs[1] (C2: 300 frames 640x480,
+nFeatures 1000, 8 levels, ARUCO dictionary).  Each rank owns an independent stream (frames / streams shard with no
+data-path collective, SURVEY 8e: weak scaling); the only collective is the RCCL gather of the fixed-capacity result records
+to rank 0, once per batch, inside the timed region.  After the clock stops rank 0 checks sampled frames of the last timed
+step against the CPU oracle ("verified_frames").  Prints ONE JSON line on rank 0.
+
+    python bench.py --latency        drop-in latency of one frame through the host-pointer ABI (one JSON line, separate metric)
 """
 import argparse
 import ctypes
@@ -22,38 +25,68 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# SURVEY 8d configurations: frames per step, rows, cols, nFeatures, levels, dictionary
+CONFIGS = {
+    "C2": dict(frames=300, rows=480, cols=640, nfeatures=1000, nlevels=8, dictionary="ARUCO", n_markers=4),
+    "C3": dict(frames=300, rows=720, cols=1280, nfeatures=2000, nlevels=8, dictionary="ARUCO_MIP_25h7", n_markers=6),
+    # C4 = one C3-like stream per GPU (seed base 2000 * rank) + the RCCL gather: run with --gpus 8
+    "C4": dict(frames=300, rows=720, cols=1280, nfeatures=2000, nlevels=8, dictionary="ARUCO_MIP_25h7", n_markers=6),
+    # C5 = 100 frames 1920x1080 + the 10k x 10k all-pairs knn2 ("c5_match" in the JSON line)
+    "C5": dict(frames=100, rows=1080, cols=1920, nfeatures=4000, nlevels=12, dictionary="ARUCO", n_markers=6),
+}
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+# integer VALU issue: 4 cycles per wave64 instruction per SIMD (what tools/pmc.py's VALUus assumes and r01's FAST launch
+# confirmed: 526 us of issue in a 529 us launch) = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 3.9e13 lane-ops/s
+VALU_LANE_OPS = 256 * 4 * 16 * 2.4e9
+I8_MFMA_PEAK_TOPS = 5000.0      # dense i8 = 2x the bf16 rate (guide: >= 3944 TOPS measured with 16x16x64)
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C2", choices=sorted(CONFIGS), help="SURVEY 8d configuration (default: the one "
+                    "BASELINE.json's metric is quoted on)")
     ap.add_argument("--splits", type=int, default=1, help="process a batch as this many sub-batches on separate handles and "
                     "streams (their latency-bound and VALU-bound kernels overlap)")
-    ap.add_argument("--frames", type=int, default=300, help="frames per step per GPU (the C2 stream length)")
-    ap.add_argument("--rows", type=int, default=480)
-    ap.add_argument("--cols", type=int, default=640)
-    ap.add_argument("--nfeatures", type=int, default=1000)
-    ap.add_argument("--nlevels", type=int, default=8)
-    ap.add_argument("--dictionary", default="ARUCO")
+    ap.add_argument("--frames", type=int, default=None, help="frames per step per GPU (overrides the configuration)")
+    ap.add_argument("--rows", type=int, default=None)
+    ap.add_argument("--cols", type=int, default=None)
+    ap.add_argument("--nfeatures", type=int, default=None)
+    ap.add_argument("--nlevels", type=int, default=None)
+    ap.add_argument("--dictionary", default=None)
     ap.add_argument("--marker-capacity", type=int, default=64, help="marker (+ pose) records per frame in the gathered result set")
-    ap.add_argument("--cpu-frames", type=int, default=300, help="frames timed on the host for cpu_baseline (0 = skip)")
-    ap.add_argument("--no-aruco", action="store_true", help="diagnostic only: drop the ArUco leg (invalidates value)")
-    ap.add_argument("--no-orb", action="store_true", help="diagnostic only: drop the ORB + matching legs (invalidates value)")
-    return ap.parse_args()
+    ap.add_argument("--resident-batches", type=int, default=0, help="copies of the stream resident in HBM (different time "
+                    "offsets), one per step in rotation; 0 = as many as exceed the 256 MiB Infinity Cache (at most 8)")
+    ap.add_argument("--cpu-frames", type=int, default=None, help="frames timed on the host for cpu_baseline (0 = skip)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the post-run check against the oracle")
+    ap.add_argument("--no-aruco", action="store_true", help="diagnostic only: drop the ArUco leg (value becomes null)")
+    ap.add_argument("--no-orb", action="store_true", help="diagnostic only: drop the ORB + matching legs (value becomes null)")
+    ap.add_argument("--latency", action="store_true", help="single-frame latency through the host-pointer ABI instead")
+    ap.add_argument("--out", default=None, help="also write the JSON line to this file")
+    args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    for k, v in cfg.items():
+        if getattr(args, k, None) is None:
+            setattr(args, k, v)
+    args.custom = any(getattr(args, k) != v for k, v in cfg.items())
+    if args.cpu_frames is None:     # ~10-30 s of single-thread oracle work
+        args.cpu_frames = {"C2": 300, "C3": 100, "C4": 100, "C5": 40}[args.config]
+    return args
 
 
 def make_stream(args, rank):
     """Synthetic stream of this rank (seed base differs per rank), cached under /tmp across runs on one box."""
-    from orb_slam2_aruco_amd import synth
-    seed = 1000 + 2000 * rank
+    from orb_slam2_aruco_amd import synth, sharding
+    seed = sharding.stream_seed(rank)
     path = "/tmp/orbfe_stream_%dx%d_%d_%d_%s.npy" % (args.cols, args.rows, args.frames, seed, args.dictionary)
     if os.path.exists(path):
         try:
             return np.load(path)
         except Exception:
             pass
-    s = synth.stream(args.rows, args.cols, args.frames, seed, args.dictionary, n_markers=4)
+    s = synth.stream(args.rows, args.cols, args.frames, seed, args.dictionary, n_markers=args.n_markers)
     try:
         np.save(path + ".tmp.npy", s)
         os.replace(path + ".tmp.npy", path)
@@ -62,34 +95,38 @@ def make_stream(args, rank):
     return s
 
 
-TUM1_K = [517.306408, 516.469215, 318.643040, 255.313989]
-TUM1_DIST = [0.262383, -0.953104, -0.005358, 0.002628, 1.163314]
-MARKER_SIZE = 0.187   # Frame.cc:131
+def oracle_module():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    return oracle_lib
 
 
 def cpu_baseline(args, frames_u8):
     """The oracle (CPU port of the reference path) on the same stream: single thread -- the reference runs extractor and
     detector serially on the Tracking thread (Frame.cc:91,142) -- after 10 warm-up frames; and, as a second row, all host
     cores with the frames sharded into contiguous blocks."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_lib as O
+    O = oracle_module()
+    from orb_slam2_aruco_amd.pipeline import TUM1_K, TUM1_DIST, MARKER_SIZE
     from concurrent.futures import ThreadPoolExecutor
     n = min(args.cpu_frames, len(frames_u8))
     if n < 2:
         return None
     K = O.camera_resize(np.array(TUM1_K, np.float32), (1280, 720), (args.cols, args.rows))
     D = np.array(TUM1_DIST, np.float32)
-    use_aruco = hasattr(O, "ArucoOracle") and not args.no_aruco
+    use_aruco = not args.no_aruco
+    use_orb = not args.no_orb
 
     def run(frames):                       # ctypes releases the GIL inside the oracle calls
         orb = O.OrbOracle(args.nfeatures, 1.2, args.nlevels, 20, 7)
         aruco = O.ArucoOracle(args.dictionary) if use_aruco else None
         prev = None
         for img in frames:
-            k, d = orb.extract(img)
             if aruco is not None:
                 for m in aruco.detect(img):
                     O.marker_pose(m["corners"], MARKER_SIZE, K, D)
+            if not use_orb:
+                continue
+            k, d = orb.extract(img)
             if prev is not None:
                 O.knn2(prev[1], d, 256)
                 O.search_for_initialization(prev[0], prev[1], k, d, args.cols, args.rows, None, 100, 0.9, True)
@@ -99,10 +136,11 @@ def cpu_baseline(args, frames_u8):
     t0 = time.perf_counter()
     run(frames_u8[:n])
     dt = time.perf_counter() - t0
-    what = "ORB%s + knn2 + SearchForInitialization" % (" + ArUco incl. marker poses" if use_aruco else "")
+    what = "%s%s" % ("ORB + knn2 + SearchForInitialization" if use_orb else "", " + ArUco incl. marker poses" if use_aruco else "")
     out = {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-           "sample": "%d frames of the same %dx%d stream after 10 warm-up frames, oracle/ single thread (%s)"
-                     % (n, args.cols, args.rows, what)}
+           "sample": "%d frames of the same %dx%d stream after 10 warm-up frames, oracle/ single thread (%s); the port is scalar "
+                     "C++ at -O3 (no SIMD intrinsics): the reference's OpenCV runs SSE2 FAST / resize / blur and would be faster "
+                     "by a small integer factor" % (n, args.cols, args.rows, what)}
     cores = min(os.cpu_count() or 1, n // 4)      # blocks of >= 4 frames; `cores` = the threads actually used
     if cores > 1:
         blocks = [frames_u8[n * c // cores:n * (c + 1) // cores] for c in range(cores)]
@@ -115,8 +153,146 @@ def cpu_baseline(args, frames_u8):
     return out
 
 
+def load_profile(name, config):
+    """A committed profile of THIS configuration (profiles/<name>_<config>.json), or None: counters measured on another
+    frame size are never reported."""
+    p = os.path.join(ROOT, "profiles", "%s_%s.json" % (name, config))
+    if os.path.exists(p):
+        try:
+            return json.load(open(p))
+        except Exception:
+            return None
+    return None
+
+
+# what bounds each stage (DESIGN.md section 6; from the PMC counters of tools/pmc.py): "hbm" = streaming, traffic ~ algorithmic
+# bytes; "valu" = the launch needs (almost) its whole duration just to issue its VALU instructions; "latency" = serial
+# dependent chains (border following, quadtree rounds, the coupled accept loops) that neither bandwidth nor issue bounds
+STAGE_BOUND = {"resize": "hbm", "blur7": "valu", "fast_cells": "valu", "distribute": "latency", "orient_describe": "valu",
+               "knn2": "mfma", "search_init": "latency", "aruco_pyramid": "hbm", "aruco_threshold": "valu",
+               "aruco_contours": "latency", "aruco_decode": "latency", "aruco_finalize": "latency"}
+
+
+def c5_match_leg(binding, torch, dev, O):
+    """C5's matching leg: D = u8[10000 x 32] i.i.d. uniform bits (seed 5) matched 10k x 10k all-pairs,
+    best + second-best, resident on the device; both kernels, each against its own bound."""
+    from orb_slam2_aruco_amd import synth
+    L = binding.load()
+    n = 10000
+    D = synth.random_descriptors(n, 5)
+    d_D = torch.from_numpy(D).to(dev)
+    d_n = torch.tensor([n], dtype=torch.int32, device=dev)
+    outs = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(3)]
+    st = torch.cuda.current_stream(dev)
+    sp = ctypes.c_void_p(st.cuda_stream)
+    res = {"workload": "10000 x 10000 all-pairs Hamming best + second-best, 256-bit descriptors (seed 5), resident in HBM",
+           "pairs": n * n}
+    want = None
+    for name, path in (("valu", 1), ("mfma_i8", 2)):
+        binding.debug_control("knn2_path", path)
+        call = lambda: binding._check(L, L.orbfe_knn2_batch_device(d_D.data_ptr(), d_n.data_ptr(), 0, n, d_D.data_ptr(), d_n.data_ptr(),
+                                                                   0, n, 1, 256, outs[0].data_ptr(), outs[1].data_ptr(),
+                                                                   outs[2].data_ptr(), sp), "orbfe_knn2_batch_device")
+        for _ in range(3):
+            call()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 20
+        e0.record(st)
+        for _ in range(reps):
+            call()
+        e1.record(st)
+        torch.cuda.synchronize(dev)
+        us = e0.elapsed_time(e1) * 1000.0 / reps
+        got = [o.cpu().numpy() for o in outs]
+        if want is None:            # oracle on a sample of the queries (the full 10^8 pairs take the scalar port ~1 s per 200 queries)
+            sample = np.r_[0:64, n // 2:n // 2 + 64, n - 64:n]
+            want = (sample, O.knn2(D[sample], D, 256))
+        sample, (bi, bd, sd) = want
+        assert np.array_equal(got[0][sample], bi) and np.array_equal(got[1][sample], bd) and np.array_equal(got[2][sample], sd), name
+        # self-match: the best of query i is i itself at distance 0 (first index wins ties)
+        assert np.array_equal(got[0], np.arange(n)) and not got[1].any(), name
+        if name == "valu":      # 8 XOR + 8 BCNT lane-ops per pair (SURVEY 8d)
+            ops = n * n * 16.0
+            res[name] = {"launch_us": us, "bound": "valu", "achieved": ops / (us * 1e-6) / 1e12, "peak": VALU_LANE_OPS / 1e12,
+                         "unit": "T lane-ops/s", "frac": ops / (us * 1e-6) / VALU_LANE_OPS}
+        else:                   # |a ^ b| = |a| + |b| - 2 a.b: a (nq x 256) . (256 x nt) int8 GEMM, 2 * 256 ops per pair
+            ops = n * n * 512.0
+            res[name] = {"launch_us": us, "bound": "mfma", "achieved": ops / (us * 1e-6) / 1e12, "peak": I8_MFMA_PEAK_TOPS,
+                         "unit": "TOP/s", "frac": ops / (us * 1e-6) / 1e12 / I8_MFMA_PEAK_TOPS}
+    binding.debug_control("knn2_path", 0)
+    res["verified_queries"] = int(len(want[0]))
+    return res
+
+
+def latency_mode(args):
+    """The drop-in mode the reference's sequential Tracking thread uses (Frame.cc:91,142; Tracking.cc:531): ONE frame per
+    call through the host-pointer ABI (H2D + kernels + D2H + sync inside each call), median of 200 calls."""
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    from orb_slam2_aruco_amd import binding
+    from orb_slam2_aruco_amd.pipeline import TUM1_K, TUM1_DIST, MARKER_SIZE
+    frames = make_stream(args, 0)[:max(16, min(64, args.frames))]
+    ex = binding.ORBextractor(args.nfeatures, 1.2, args.nlevels, 20, 7)
+    det = binding.MarkerDetector(args.dictionary)
+    mt = binding.ORBmatcher(0.9, True)
+    K = binding.camera_resize(np.array(TUM1_K, np.float32), (1280, 720), (args.cols, args.rows))
+    D = np.array(TUM1_DIST, np.float32)
+    cam = (K, D, (args.cols, args.rows))
+    t_ex, t_det, t_sfi, t_all = [], [], [], []
+    prev = None
+    calls = 200
+    for i in range(calls + 20):
+        img = frames[i % len(frames)]
+        t0 = time.perf_counter()
+        k, d = ex(img)
+        t1 = time.perf_counter()
+        det.detect(img, cam, MARKER_SIZE)
+        t2 = time.perf_counter()
+        if prev is not None:
+            mt.SearchForInitialization(prev[0], prev[1], k, d, args.cols, args.rows, None, 100)
+        t3 = time.perf_counter()
+        prev = (k, d)
+        if i >= 20:
+            t_ex.append(t1 - t0); t_det.append(t2 - t1); t_sfi.append(t3 - t2); t_all.append(t3 - t0)
+    med = lambda v: float(np.median(v) * 1e3)
+    out = {"metric": "ms per frame, single-frame drop-in calls through the host-pointer ABI (%dx%d mono)" % (args.cols, args.rows),
+           "value": med(t_all), "unit": "ms", "higher_is_better": False, "n_gpus": 1, "calls": calls, "dtype": "u8", "data": "synthetic",
+           "config": {"workload": "%s frames one at a time: orbfe_extract + orbfe_aruco_detect + orbfe_marker_poses + "
+                                  "orbfe_search_for_initialization, host pointers (H2D, kernels, D2H and sync inside every call; "
+                                  "includes the ctypes marshalling of the test binding)" % args.config},
+           "median_ms": {"orbfe_extract": med(t_ex), "orbfe_aruco_detect+poses": med(t_det),
+                         "orbfe_search_for_initialization": med(t_sfi)}}
+    if args.cpu_frames > 0:
+        O = oracle_module()
+        orb, aru = O.OrbOracle(args.nfeatures, 1.2, args.nlevels, 20, 7), O.ArucoOracle(args.dictionary)
+        c_ex, c_det, c_sfi = [], [], []
+        prev = None
+        for i in range(min(30, len(frames))):
+            img = frames[i]
+            t0 = time.perf_counter(); k, d = orb.extract(img)
+            t1 = time.perf_counter()
+            for m in aru.detect(img):
+                O.marker_pose(m["corners"], MARKER_SIZE, K, D)
+            t2 = time.perf_counter()
+            if prev is not None:
+                O.search_for_initialization(prev[0], prev[1], k, d, args.cols, args.rows, None, 100, 0.9, True)
+            t3 = time.perf_counter()
+            prev = (k, d)
+            if i >= 2:
+                c_ex.append(t1 - t0); c_det.append(t2 - t1); c_sfi.append(t3 - t2)
+        out["cpu_baseline"] = {"value": med(c_ex) + med(c_det) + med(c_sfi), "unit": "ms", "cores": 1, "kind": "port",
+                               "sample": "%d frames, oracle/ single thread" % len(c_ex),
+                               "median_ms": {"extract": med(c_ex), "aruco_detect+poses": med(c_det), "search_for_initialization": med(c_sfi)}}
+    print(json.dumps(out))
+    if args.out:
+        open(args.out, "w").write(json.dumps(out) + "\n")
+
+
 def main():
     args = parse()
+    if args.latency:
+        return latency_mode(args)
     import torch
     import torch.distributed as dist
 
@@ -130,256 +306,217 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    backend = os.environ.get("ORBFE_BENCH_BACKEND") or "nccl"
     if world > 1:
-        if os.environ.get("ORBFE_BENCH_BACKEND"):
-            dist.init_process_group(os.environ["ORBFE_BENCH_BACKEND"])
-        else:
+        if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
-    from orb_slam2_aruco_amd import binding
+    from orb_slam2_aruco_amd import binding, sharding
+    from orb_slam2_aruco_amd.pipeline import FrontEndPipeline, RecordLayout, valid_records
     L = binding.load()
+    version = L.orbfe_version().decode()
+    # launch ablation needs the diagnosis build (tools/ablate.sh); its numbers are never a result
+    skips = {}
+    for key, env in (("orb_skip", "ORBFE_ORB_SKIP"), ("aruco_skip", "ORBFE_ARUCO_SKIP")):
+        if os.environ.get(env):
+            binding.debug_control(key, int(os.environ[env]))     # ORBFE_ERR_INVALID in the shipped library
+            skips[key] = int(os.environ[env])
+    if "+ablation" in version:
+        skips["library"] = version
     B, rows, cols = args.frames, args.rows, args.cols
+    use_aruco, use_orb = not args.no_aruco, not args.no_orb
 
     frames_np = make_stream(args, rank)
-    pitch = (cols + 63) // 64 * 64
-    d_imgs = torch.zeros((B, rows, pitch), dtype=torch.uint8, device=dev)
-    d_imgs[:, :, :cols] = torch.from_numpy(frames_np).to(dev)
-
-    S = max(1, min(args.splits, B // 2))
-    bounds = [B * k // S for k in range(S + 1)]          # sub-batch k = frames bounds[k] .. bounds[k+1]
-    exs = [binding.ORBextractor(args.nfeatures, 1.2, args.nlevels, 20, 7, device=local_rank) for _ in range(S)]
-    ex = exs[0]
-    cap = ex.capacity
-    # Two sets of result records: the matching (third stream) and, on N > 1, the gather of batch i (communication stream)
-    # overlap with batch i+1, which writes the other set.  A set is ONE contiguous buffer -- the record SURVEY 8e gathers:
-    # {n_kp, kp[cap] x 28 B, desc[cap] x 32 B, n_mk, markers[mcap] x 36 B, poses[mcap] x 56 B} per frame -- so a batch is one collective.
-    use_aruco = not args.no_aruco
-    big_frames = False
-    # marker records per frame in the result set (the detector clamps a frame's count to it; its own limit is 256 candidates)
-    mcap = min(binding.MarkerDetector(args.dictionary, device=local_rank).capacity, args.marker_capacity) if use_aruco else 0
-    up = lambda v: (v + 255) // 256 * 256
-    off_kps, off_desc = 0, up(B * cap * 28)
-    off_n = off_desc + up(B * cap * 32)
-    off_mk = off_n + up(B * 4)
-    off_nmk = off_mk + up(B * mcap * 36)
-    off_pose = off_nmk + up(B * 4)
-    rec_bytes = off_pose + up(B * mcap * 56)
-    # camera of the reference's monocular example (Examples/Monocular/TUM1.yaml); the detector is handed CamSize 1280x720
-    # (Frame.cc:132), so the matrix is rescaled to the frame size before the marker poses (markerdetector_impl.cpp:1110-1172)
-    cam_K = binding.camera_resize(np.array(TUM1_K, np.float32), (1280, 720), (cols, rows)) if use_aruco else None
-    cam_D = np.array(TUM1_DIST, np.float32)
-    recs = [torch.zeros(rec_bytes, dtype=torch.uint8, device=dev) for _ in range(2)]
-    rec_ptr = [r.data_ptr() for r in recs]
-    d_n = recs[0][off_n:off_n + B * 4].view(torch.int32)
-    d_bidx = torch.zeros((B - 1, cap), dtype=torch.int32, device=dev)
-    d_bdist = torch.zeros((B - 1, cap), dtype=torch.int32, device=dev)
-    d_sdist = torch.zeros((B - 1, cap), dtype=torch.int32, device=dev)
-    d_m12 = torch.zeros((B - 1, cap), dtype=torch.int32, device=dev)
-    d_nm = torch.zeros(B - 1, dtype=torch.int32, device=dev)
-    if use_aruco:
-        dets = [binding.MarkerDetector(args.dictionary, device=local_rank) for _ in range(S)]
-        det = dets[0]
-    # three HIP streams: the ORB extractor, the ArUco detector, the matching.  The first two only read the resident
-    # frames; the matching of batch i reads extractor output set i % 2 while batch i+1 is extracted into the other set.
-    # So the latency-bound kernels (contours, quadtree, SearchForInitialization) overlap with the VALU-bound ones.
-    stream = torch.cuda.current_stream(dev)
-    sp = ctypes.c_void_p(stream.cuda_stream)
-    stream2 = torch.cuda.Stream(dev)
-    sp2 = ctypes.c_void_p(stream2.cuda_stream)
-    stream3 = torch.cuda.Stream(dev)
-    sp3 = ctypes.c_void_p(stream3.cuda_stream)
-    # with --splits S > 1: sub-batch k of the extractor / detector runs on its own handle and stream
-    orb_streams = [stream] + [torch.cuda.Stream(dev) for _ in range(S - 1)]
-    aru_streams = [stream2] + [torch.cuda.Stream(dev) for _ in range(S - 1)]
-    if S == 1:
-        # ROCm maps streams onto 4 hardware queues, and two busy streams on one queue serialise.  The extractor's forked
-        # launch (the blur) is lent the matching stream; measured against the handle's own fork stream and against one
-        # shared fork stream for both engines: 2.02 vs 2.12 vs 2.14 ms per step.
-        ex.set_aux_stream(sp3)
-    ex_done = [[torch.cuda.Event() for _ in range(S)] for _ in range(2)]
-    match_done = [torch.cuda.Event() for _ in range(2)]
-    comm_stream = torch.cuda.Stream(dev)
-    det_done = [[torch.cuda.Event() for _ in range(S)] for _ in range(2)]
-    gather_done = [torch.cuda.Event() for _ in range(2)]
-    step_no = [0]
-
-    gathered = None
+    gather = None
+    pipe = FrontEndPipeline(B, rows, cols, args.nfeatures, args.nlevels, args.dictionary, device=local_rank,
+                            marker_capacity=args.marker_capacity, use_orb=use_orb, use_aruco=use_aruco, splits=args.splits)
     if world > 1:
-        gathered = [torch.empty_like(recs[0]) for _ in range(world)] if rank == 0 else None
-
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]  # around the matching launches (their stream)
-
-    def step():
-        i = step_no[0]
-        step_no[0] += 1
-        base = rec_ptr[i % 2]
-        if use_aruco:
-            # the detector streams only depend on the (resident) input frames and on their own previous batch, so they are
-            # not joined with the ORB streams per step: consecutive batches of the two engines pipeline freely.  They are
-            # joined where their results meet: before the RCCL gather (N > 1) and before the clock stops.
-            for k in range(S):
-                f0, nf = bounds[k], bounds[k + 1] - bounds[k]
-                if world > 1 and i >= 2:
-                    aru_streams[k].wait_event(gather_done[i % 2])   # batch i-2 has left this record set
-                dets[k].detect_batch_device(d_imgs.data_ptr() + f0 * rows * pitch, nf, rows * pitch, rows, cols, pitch,
-                                            base + off_mk + f0 * mcap * 36, mcap, base + off_nmk + f0 * 4,
-                                            ctypes.c_void_p(aru_streams[k].cuda_stream))
-                # detect(image, CameraParameters, 0.187): every marker gets its IPPE pose (markerdetector_impl.cpp:8720-8780)
-                binding._check(L, L.orbfe_marker_poses_batch_device(
-                    base + off_mk + f0 * mcap * 36, base + off_nmk + f0 * 4, mcap, nf, MARKER_SIZE,
-                    cam_K.ctypes.data_as(ctypes.c_void_p), cam_D.ctypes.data_as(ctypes.c_void_p), len(cam_D),
-                    base + off_pose + f0 * mcap * 56, ctypes.c_void_p(aru_streams[k].cuda_stream)), "orbfe_marker_poses_batch_device")
-                det_done[i % 2][k].record(aru_streams[k])
-        if not args.no_orb:
-            for k in range(S):
-                f0, nf = bounds[k], bounds[k + 1] - bounds[k]
-                if i >= 2:
-                    orb_streams[k].wait_event(match_done[i % 2])    # the matching of batch i-2 has read this record set
-                    if world > 1:
-                        orb_streams[k].wait_event(gather_done[i % 2])
-                exs[k].extract_batch_device(d_imgs.data_ptr() + f0 * rows * pitch, nf, rows * pitch, rows, cols, pitch,
-                                            base + off_kps + f0 * cap * 28, base + off_desc + f0 * cap * 32, cap,
-                                            base + off_n + f0 * 4, ctypes.c_void_p(orb_streams[k].cuda_stream))
-                ex_done[i % 2][k].record(orb_streams[k])
-                stream3.wait_event(ex_done[i % 2][k])
-            # frame t vs t-1: all-pairs knn2 + one SearchForInitialization-style windowed pass
-            ev[0].record(stream3)
-            binding._check(L, L.orbfe_knn2_batch_device(base + off_desc, base + off_n, cap * 32, cap,
-                                                        base + off_desc + cap * 32, base + off_n + 4, cap * 32, cap,
-                                                        B - 1, 256, d_bidx.data_ptr(), d_bdist.data_ptr(),
-                                                        d_sdist.data_ptr(), sp3), "knn2")
-            ev[1].record(stream3)
-            binding._check(L, L.orbfe_search_for_initialization_batch_device(
-                base + off_kps, base + off_desc, base + off_n, cap, B - 1, cols, rows, None, 100, 0.9, 1,
-                d_m12.data_ptr(), d_nm.data_ptr(), sp3), "sfi")
-            ev[2].record(stream3)
-            match_done[i % 2].record(stream3)
-        if world > 1:
-            # the batch's one collective, on its own stream: it waits for the engines of THIS batch and runs
-            # while the next batch is computed into the other record set
-            with torch.cuda.stream(comm_stream):
-                for k in range(S):
-                    if not args.no_orb:
-                        comm_stream.wait_event(ex_done[i % 2][k])
-                    if use_aruco:
-                        comm_stream.wait_event(det_done[i % 2][k])
-                dist.gather(recs[i % 2], gathered, dst=0)
-                gather_done[i % 2].record(comm_stream)
-
-    if os.environ.get("ORBFE_ORB_SKIP"):    # diagnosis: what does a kernel cost the concurrent pipeline (results invalid)
-        binding.debug_control("orb_skip", int(os.environ["ORBFE_ORB_SKIP"]))
-    if os.environ.get("ORBFE_ARUCO_SKIP"):
-        binding.debug_control("aruco_skip", int(os.environ["ORBFE_ARUCO_SKIP"]))
+        # gloo moves CPU tensors: the test hook stages the record set through the host (the RCCL path gathers in place)
+        gather = sharding.RecordGather(pipe.recs[0] if backend == "nccl" else pipe.recs[0].cpu())
+        if backend == "nccl":
+            pipe.gather = gather
+        else:
+            pipe.gather = lambda t: gather(t.cpu())
+    # resident input: R copies of the stream at different time offsets, one per step in rotation, so that no step finds its
+    # frames in the 256 MiB Infinity Cache (copy r = the stream rolled by r * B / R frames)
+    pitch = pipe.pitch
+    R = args.resident_batches or max(1, min(8, (256 << 20) // (B * rows * pitch) + 2))
+    shifts = [(r * B) // R for r in range(R)]
+    d_batches = [pipe.upload(np.roll(frames_np, -s, axis=0)) for s in shifts]
+    ex, det = pipe.ex, pipe.det
     ex.enable_kernel_timing(False)
     if args.no_orb:  # diagnostics still want the level geometry
-        ex.extract_batch_device(d_imgs.data_ptr(), B, rows * pitch, rows, cols, pitch, rec_ptr[0] + off_kps,
-                                rec_ptr[0] + off_desc, cap, rec_ptr[0] + off_n, sp)
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if use_aruco:
-        # the device-pointer entry point cannot return a capacity error: ask once after the warm-up and once after the run.
-        # Frames with more long contours than the LDS-resident kernels hold (large, busy images) need the big-frame kernel.
-        if any(d.batch_status()[0] for d in dets):
-            for d in dets:
-                d.set_big_frames(True)
-            big_frames = True
-            for _ in range(max(args.warmup, 1)):
-                step()
-            torch.cuda.synchronize()
-            if any(d.batch_status()[0] for d in dets):
-                raise SystemExit("ArUco detector capacity exceeded at this frame size (flags 0x%x)" % dets[0].batch_status()[1])
+        lay = pipe.layout
+        ex.extract_batch_device(d_batches[0].data_ptr(), B, rows * pitch, rows, cols, pitch, pipe.rec_ptr[0] + lay.kps,
+                                pipe.rec_ptr[0] + lay.desc, pipe.cap, pipe.rec_ptr[0] + lay.n, ctypes.c_void_p(pipe.stream.cuda_stream))
+
+    pipe.warmup(d_batches[0], args.warmup)
+    for r in range(1, R):           # touch every resident copy once
+        pipe.step(d_batches[r])
+    pipe.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     ex.enable_kernel_timing(True)
     if use_aruco:
         det.enable_kernel_timing(True)
-    ktimes = []
+    last = (0, 0)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        kt = {"orb": ex.kernel_times_us()} if False else None  # per-step collection would sync; done after the loop
+    for i in range(args.steps):
+        r = i % R
+        last = (pipe.step(d_batches[r]), r)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if use_aruco and any(d.batch_status()[0] for d in dets):
-        raise SystemExit("ArUco detector capacity exceeded during the timed run: results incomplete, no number reported")
+    status = pipe.status()
+    if any(status.values()):
+        raise SystemExit("front-end capacity exceeded during the timed run: results incomplete, no number reported (%r)" % (status,))
     # HIP-event timings of the LAST timed step's launches (events were recorded on the launch stream every step)
     orb_us = ex.kernel_times_us()
     aruco_us = det.kernel_times_us() if use_aruco else np.zeros(0, np.float32)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if backend == "nccl":
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        else:
+            tc = t.cpu(); dist.all_reduce(tc, op=dist.ReduceOp.MAX); t = tc
     elapsed = float(t.item())
     total_frames = B * args.steps * world
-    n_host = d_n.cpu().numpy()
+    cur, r_last = last
+    rec = pipe.read_records(cur)
+    matches = pipe.read_matches() if use_orb else None
+    last_frames = np.roll(frames_np, -shifts[r_last], axis=0)       # host images of the last timed step's batch
+
+    # ---- multi-GPU: rank 0 checks every gathered block of the last step against that rank's own stream, recomputed here
+    gather_check = None
+    if world > 1 and rank == 0:
+        blocks = gather.blocks
+        lay = pipe.layout
+        checked = []
+        for r in range(world):
+            got = valid_records(lay.unpack(blocks[r].cpu().numpy()), use_orb)
+            if r == 0:
+                want = valid_records(rec, use_orb)
+            else:
+                other = np.roll(make_stream(args, r), -shifts[r_last], axis=0)
+                d_other = pipe.upload(other)
+                pipe.gather = None
+                c2 = pipe.step(d_other)
+                pipe.synchronize()
+                want = valid_records(pipe.read_records(c2), use_orb)
+                del d_other
+            assert got == want, "gathered records of rank %d differ from that rank's stream recomputed on rank 0" % r
+            checked.append(r)
+        gather_check = {"ranks": checked, "frames_per_rank": B, "what": "n, keypoints, descriptors, marker ids / corners / poses of "
+                        "every frame, byte for byte"}
 
     if rank == 0:
-        orb_names = binding.ORBextractor.STAGES  # blur7 runs on a second stream next to fast_cells + distribute
-        stages = {nm: float(v) for nm, v in zip(orb_names, orb_us)}
-        if not args.no_orb:
-            stages["knn2"] = ev[0].elapsed_time(ev[1]) * 1000.0
-            stages["search_init"] = ev[1].elapsed_time(ev[2]) * 1000.0
+        stages = {nm: float(v) for nm, v in zip(binding.ORBextractor.STAGES, orb_us)}   # blur7 runs on a second stream
+        if use_orb:
+            stages["knn2"], stages["search_init"] = pipe.matching_times_us()
         if use_aruco:
             for nm, v in zip(binding.MarkerDetector.STAGES, aruco_us):
                 stages["aruco_" + nm] = float(v)
-        # algorithmic bytes per frame of each stage (DESIGN.md "roofline": terms of SURVEY 8d's B_orb / B_aruco)
+        # algorithmic bytes per frame of each stage (DESIGN.md "roofline": the terms of SURVEY 8d's B_orb / B_aruco)
         sizes = ex.level_sizes()
         P = [w * h for (w, h) in sizes]
         sumP, P0 = sum(P), P[0]
-        N = float(n_host.mean())
+        N = float(rec["n"].mean()) if use_orb else 0.0
+        Ncand = 24.0          # rectangle candidates decoded per frame, upper end of what the synthetic streams produce
         alg = {"resize": (sumP - P[-1]) + (sumP - P0), "fast_cells": sumP, "blur7": 2 * sumP,
-               "orient_describe": N * (749 + 512 + 60), "distribute": 0,
+               "orient_describe": N * (749 + 512 + 60), "distribute": N * 8,
                "knn2": 2 * N * 32 + N * 12, "search_init": 2 * N * (32 + 28) + N * 4}
         if use_aruco:
             alg.update(binding.MarkerDetector.algorithmic_bytes(rows, cols))
-        # frames one launch of a stage covers: the matching runs over the whole batch, the engines per sub-batch (--splits)
-        fl = lambda k: B if k in ("knn2", "search_init") else bounds[1] - bounds[0]
+            alg["aruco_decode"] = Ncand * 2 * 35 * 35
+            alg["aruco_finalize"] = Ncand * 36
+        fl = lambda k: B if k in ("knn2", "search_init") else pipe.bounds[1] - pipe.bounds[0]   # frames one launch covers
+        pmc = load_profile("pmc_stage", args.config) if not args.custom else None      # tools/pmc.py + tools/make_traffic.py
+        traffic = load_profile("traffic", args.config) if not args.custom else None
+        per_stage = {}
+        for k, us in stages.items():
+            ab = alg.get(k, 0) * fl(k)
+            ent = {"bound": STAGE_BOUND.get(k, "latency"), "launch_us": us, "algorithmic_bytes_per_launch": ab,
+                   "GBps": ab / (us * 1e-6) / 1e9 if us > 0 else 0.0}
+            ent["hbm_frac"] = ent["GBps"] / HBM_PEAK_GBPS
+            ent["traffic"] = traffic.get(k) if traffic else None
+            if pmc and k in pmc:    # VALU issue time of the stage's launches (instruction counts x 4 cycles / 1024 SIMDs / 2.4 GHz)
+                ent["valu_us"] = pmc[k].get("valu_us")
+                ent["valu_frac"] = pmc[k]["valu_us"] / us if us > 0 and pmc[k].get("valu_us") is not None else None
+                ent["lane_utilisation"] = pmc[k].get("lane_utilisation")
+            per_stage[k] = ent
         dom = max(stages, key=lambda k: stages[k]) if stages else None
         roof = None
         if dom is not None and stages[dom] > 0:
-            ach = alg.get(dom, 0) * fl(dom) / (stages[dom] * 1e-6) / 1e9
-            traffic = None
-            tp = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tp):
-                try:
-                    traffic = json.load(open(tp)).get(dom)
-                except Exception:
-                    traffic = None
-            roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": 8000.0, "unit": "GB/s",
-                    "frac": ach / 8000.0, "traffic": traffic, "launch_us": stages[dom],
-                    "algorithmic_bytes_per_launch": alg.get(dom, 0) * fl(dom), "frames_per_launch": fl(dom),
-                    "note": "dominant launch of the last timed step (HIP events on its launch stream, the other engine "
-                            "running concurrently); k_contours is serial border following, latency- not HBM-bound",
-                    # the same figure for every stage, so the HBM-bound image kernels can be read off too
-                    "all_stages_GBps": {k: (alg.get(k, 0) * fl(k) / (v * 1e-6) / 1e9 if v > 0 else 0.0)
-                                        for k, v in stages.items()}}
+            d = per_stage[dom]
+            roof = {"bound": d["bound"], "kernel": dom, "achieved": d["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": d["hbm_frac"], "traffic": d["traffic"], "launch_us": d["launch_us"],
+                    "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"], "frames_per_launch": fl(dom),
+                    "note": "dominant launch of the last timed step; launch_us = HIP events on the stream the stage is launched "
+                            "on, the other engines running concurrently (standalone times: DESIGN.md section 6); achieved = "
+                            "algorithmic bytes / launch time against the HBM peak also where the stage's bound is not HBM -- "
+                            "'stages' carries every stage's bound, and valu_us / valu_frac where the committed PMC profile of "
+                            "this configuration has them",
+                    "stages": per_stage}
+            step_bytes = sum(alg.get(k, 0) * B for k in stages)
+            roof["step"] = {"algorithmic_bytes_per_step": step_bytes, "GBps": step_bytes / (elapsed / args.steps) / 1e9,
+                            "frac": step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBPS,
+                            "note": "sum of the stages' algorithmic bytes over the measured step time: the whole pipeline against HBM"}
+
+        invalid = bool(skips) or args.no_aruco or args.no_orb
+        verified = None
+        if not args.no_verify and not skips:
+            # outside the clock: frames {0, B/2, B-1} and pairs {0, B/2, B-2} of the LAST timed step against the oracle
+            O = oracle_module()
+            import pipeline_check  # tests/
+            fids = sorted({0, B // 2, B - 1})
+            pairs = sorted({0, B // 2, B - 2}) if B >= 2 else []
+            verified = pipeline_check.check_against_oracle(O, last_frames, fids, rec, matches, args.nfeatures, args.nlevels,
+                                                           args.dictionary, cols, rows, pipe.cam_K, pipe.cam_D,
+                                                           use_orb=use_orb, use_aruco=use_aruco, pairs=pairs)
         cpu = None
-        if world == 1 and args.cpu_frames > 0:
+        if world == 1 and args.cpu_frames > 0 and not skips:
             cpu = cpu_baseline(args, frames_np)
+        c5 = None
+        if args.config == "C5" and world == 1 and use_orb and not args.custom:
+            c5 = c5_match_leg(binding, torch, dev, oracle_module())
+        cfg_name = "custom" if args.custom else args.config
         out = {
             "metric": "frames/s (ORB+ArUco extract+match, 640x480 mono)" if (rows, cols) == (480, 640) else
                       "frames/s (ORB+ArUco extract+match, %dx%d mono)" % (cols, rows),
-            "value": total_frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "value": None if invalid else total_frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%s: %d-frame %dx%d mono stream per GPU, nFeatures=%d, %d levels, %s dictionary; "
-                                   "per frame: ORB extract%s + knn2 all-pairs + SearchForInitialization vs previous frame"
-                                   % ({(480, 640, 300, 1000): "C2", (720, 1280, 300, 2000): "C3", (1080, 1920, 100, 4000): "C5 frames"}
-                                      .get((rows, cols, B, args.nfeatures), "custom"), B, cols, rows, args.nfeatures, args.nlevels, args.dictionary,
+                                   "per frame: %s%s"
+                                   % (cfg_name, B, cols, rows, args.nfeatures, args.nlevels, args.dictionary,
+                                      "ORB extract + knn2 all-pairs + SearchForInitialization vs previous frame" if use_orb
+                                      else "(ORB + matching legs DISABLED: diagnostic run)",
                                       " + ArUco detect incl. IPPE marker poses" if use_aruco else " (ArUco leg DISABLED: diagnostic run)"),
-                       "frames_per_step_per_gpu": B, "mean_keypoints_per_frame": N, "marker_records_per_frame": mcap,
-                       "result_record_bytes_per_step_per_gpu": rec_bytes,
-                       "sub_batches": S, "aruco_big_frame_kernel": big_frames,
-                       "parallelism": "stream-per-gpu x%d, RCCL gather to rank 0" % world},
-            "roofline": roof, "cpu_baseline": cpu, "stage_us_last_step": stages,
+                       "frames_per_step_per_gpu": B, "mean_keypoints_per_frame": N, "marker_records_per_frame": pipe.mcap,
+                       "result_record_bytes_per_step_per_gpu": pipe.layout.nbytes, "resident_batches": R,
+                       "sub_batches": pipe.S, "aruco_big_frame_kernel": pipe.big_frames, "library": version,
+                       "parallelism": "stream-per-gpu x%d, %s gather to rank 0" % (world, "RCCL" if backend == "nccl" else backend)},
+            "roofline": roof, "cpu_baseline": cpu, "verified_frames": verified, "skips": skips or None,
+            "stage_us_last_step": stages,
         }
-        print(json.dumps(out))
+        if invalid:
+            out["diagnostic_frames_per_s"] = total_frames / elapsed
+        if gather_check:
+            out["gather_check"] = gather_check
+        if c5:
+            out["c5_match"] = c5
+        line = json.dumps(out)
+        print(line)
+        if args.out:
+            open(args.out, "w").write(line + "\n")
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -4,7 +4,7 @@
  * One shared library (liborbfe.so, built by hipcc for gfx950) exports exactly the
  * entry points below.  Plain pointers and sizes only: no C++ types, no torch
  * types, nothing thrown across the boundary (status codes instead; the C++ shim
- * classes in orb_slam2_aruco_amd/csrc/shims re-raise to keep reference behaviour).
+ * classes in include/shims/ re-raise to keep reference behaviour).
  *
  * Each group names the reference interface it replaces (file:line in the
  * reference tree, CarminLiu/ORB_SLAM2_aruco):
@@ -29,7 +29,8 @@
  *
  * Threading: an extractor / detector handle is a stateful, non-re-entrant object
  * like the classes it replaces (one handle per stream of frames).  The
- * matching functions are thread-safe (per-thread device workspaces); so is orbfe_vocabulary_transform on one shared
+ * matching functions are thread-safe (device scratch per calling thread, device and stream, released when the thread
+ * exits); so is orbfe_vocabulary_transform on one shared
  * vocabulary handle (ComputeBoW runs on the Tracking, LocalMapping and LoopClosing threads).
  */
 #ifndef ORBFE_H
@@ -102,6 +103,11 @@ int orbfe_extract_batch(orbfe_extractor* h, const uint8_t* imgs, int nframes, si
 int orbfe_extract_batch_device(orbfe_extractor* h, const uint8_t* d_imgs, int nframes, size_t frame_stride, int rows,
                                int cols, size_t step, orbfe_keypoint* d_kps, uint8_t* d_desc, int capacity,
                                int32_t* d_n_out, void* stream);
+/* The device-pointer entry point is asynchronous and cannot return a capacity error: a frame whose keypoint total exceeds
+ * `capacity` is clamped to it.  After the batch (synchronises the device): *overflow = 0, or the largest per-frame total
+ * that did not fit -- the batch's records are then incomplete and the call must be repeated with capacity >= *overflow
+ * (orbfe_extractor_max_keypoints() always suffices). */
+int orbfe_extractor_batch_status(orbfe_extractor* h, int32_t* overflow);
 
 /* Stage read-back for parity tests (valid after an extract call; `frame` indexes the last batch).
  * stage 0: pyramid level image, 1: blurred level image -> out must hold w*h bytes (tightly packed). */
@@ -120,7 +126,9 @@ int orbfe_extractor_set_aux_stream(orbfe_extractor* h, void* stream);
 int orbfe_extractor_debug_kernel_times(orbfe_extractor* h, float* out_us, int capacity);
 
 /* ------------------------------------------------------------------ descriptor matching -- */
-/* Debug/test switch.  "knn2_path": 0 = pick by problem size (default), 1 = VALU tile kernel, 2 = matrix-core kernel. */
+/* Debug/test switch.  "knn2_path": 0 = pick by problem size (default), 1 = VALU tile kernel, 2 = matrix-core kernel.
+ * Both kernels give identical results.  No key of the shipped library skips work ("orb_skip" / "aruco_skip" exist only in
+ * the -DORBFE_ABLATION diagnosis build, whose orbfe_version() says "+ablation"; here they are ORBFE_ERR_INVALID). */
 int orbfe_debug_control(const char* key, int value);
 
 /* popcount(a XOR b) over 256 bits, host pointers (ORBmatcher::DescriptorDistance) */
@@ -254,6 +262,12 @@ int orbfe_search_for_initialization_batch_device(const orbfe_keypoint* d_kps, co
                                                  const int32_t* d_n, int capacity, int npairs, int cols, int rows, const float* bounds,
                                                  int window_size, float nnratio, int check_orientation,
                                                  int32_t* d_matches12, int32_t* d_nmatches, void* stream);
+/* The batch entry point cannot return a capacity error either (the host-pointer one retries by itself): a frame with more
+ * level-0 keypoints than the candidate rows were sized for is truncated.  After a batch issued by THIS thread on `stream`
+ * (synchronises the stream): *overflow = 0, or the level-0 keypoint count that did not fit -- the batch's matches are then
+ * incomplete; the per-stream scratch has been grown, so repeating the batch call succeeds.  More than 1024 level-0
+ * keypoints in a frame: ORBFE_ERR_CAPACITY. */
+int orbfe_search_for_initialization_batch_status(void* stream, int32_t* overflow);
 
 /* ------------------------------------------------------------------ DBoW2 vocabulary transform -- */
 /* ORBVocabulary (= DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>, include/ORBVocabulary.h) as Frame::ComputeBoW and

@@ -25,6 +25,7 @@ SYMBOLS = [
     "orbfe_extractor_get_inverse_scale_factors", "orbfe_extractor_get_scale_sigma_squares",
     "orbfe_extractor_get_inverse_scale_sigma_squares", "orbfe_extractor_get_features_per_level",
     "orbfe_extractor_max_keypoints", "orbfe_extract", "orbfe_extract_batch", "orbfe_extract_batch_device",
+    "orbfe_extractor_batch_status", "orbfe_search_for_initialization_batch_status",
     "orbfe_extractor_debug_level_size", "orbfe_extractor_debug_level_image",
     "orbfe_extractor_debug_level_keypoints", "orbfe_extractor_debug_kernel_times", "orbfe_extractor_set_aux_stream",
     "orbfe_debug_control", "orbfe_hamming", "orbfe_knn2", "orbfe_knn2_csr", "orbfe_knn2_batch_device", "orbfe_search_for_initialization",
@@ -76,6 +77,7 @@ def load():
     L.orbfe_extract.argtypes = [vp, vp, i32, i32, sz, vp, vp, i32, vp]
     L.orbfe_extract_batch.argtypes = [vp, vp, i32, sz, i32, i32, sz, vp, vp, i32, vp]
     L.orbfe_extract_batch_device.argtypes = [vp, vp, i32, sz, i32, i32, sz, vp, vp, i32, vp, vp]
+    L.orbfe_extractor_batch_status.argtypes = [vp, vp]
     L.orbfe_extractor_debug_level_size.argtypes = [vp, i32, vp, vp]
     L.orbfe_extractor_debug_level_image.argtypes = [vp, i32, i32, i32, vp]
     L.orbfe_extractor_debug_level_keypoints.argtypes = [vp, i32, i32, i32, vp, i32, vp]
@@ -104,6 +106,7 @@ def load():
                                                       i32]
         L.orbfe_search_for_initialization_batch_device.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, i32, f32, i32, vp,
                                                                    vp, vp]
+        L.orbfe_search_for_initialization_batch_status.argtypes = [vp, vp]
     if hasattr(L, "orbfe_aruco_create"):
         L.orbfe_aruco_create.restype = vp
         L.orbfe_aruco_create.argtypes = [C.c_char_p, i32]
@@ -229,6 +232,12 @@ class ORBextractor:
         _check(self.L, self.L.orbfe_extract_batch_device(self.h, d_imgs_ptr, B, frame_stride, rows, cols, step,
                                                          d_kps_ptr, d_desc_ptr, capacity, d_n_ptr, stream),
                "orbfe_extract_batch_device")
+
+    def batch_status(self):
+        """0, or the largest per-frame keypoint total of the last device batch that did not fit its capacity."""
+        ovf = C.c_int32(0)
+        _check(self.L, self.L.orbfe_extractor_batch_status(self.h, C.byref(ovf)), "orbfe_extractor_batch_status")
+        return ovf.value
 
     # stage read-back for parity tests
     def level_image(self, frame, level, blurred=False):

@@ -230,7 +230,7 @@ struct orbfe_aruco {
         }
         timer.mark(aux_stream, "pyramid");
         ORBFE_HIP(hipEventRecord(ev_join, aux_stream));
-        if (!(g_aruco_skip & 8)) {
+        if (!ORBFE_SKIP_ARUCO(8)) {
             const dim3 tg((cols + 63) / 64, (rows + 63) / 64, B);
             uint32_t* bp = d_bits.as<uint32_t>();
             if (th_magic && win == 5) hipLaunchKernelGGL(k_adaptive_threshold_t<5>, tg, dim3(256), 0, s, src0, cols, rows, 7, th_magic, bp, bits_fu32, wpr);
@@ -248,7 +248,7 @@ struct orbfe_aruco {
         ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));
         const bool relay = relay_tbits && !force_legacy && !big_mode;
-        if (relay && !(g_aruco_skip & 1)) {
+        if (relay && !ORBFE_SKIP_ARUCO(1)) {
             const size_t rlds = relay_lds_bytes(lds_bits_words, RL_KCAP, relay_tbits);
             auto rfn = relay_tbits > 12 ? k_contours_relay8 : k_contours_relay;
             ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
@@ -265,7 +265,7 @@ struct orbfe_aruco {
                                AR_MAX_KEPT, d_rects.as<ArRect>(), AR_MAX_RECTS, d_counts.as<int32_t>(), (int)tlds);
         }
         // the single-walker kernel: images whose bit image does not fit LDS next to the relay kernel's tables, or forced
-        if (!relay && !(g_aruco_skip & 1)) hipLaunchKernelGGL(kfn, dim3(B), dim3(CT_PROBE_THREADS), lds, s, d_bits.as<uint32_t>(), bits_fu32, wpr, cols, rows,
+        if (!relay && !ORBFE_SKIP_ARUCO(1)) hipLaunchKernelGGL(kfn, dim3(B), dim3(CT_PROBE_THREADS), lds, s, d_bits.as<uint32_t>(), bits_fu32, wpr, cols, rows,
                            legacy_ldsw, 70, d_candq.as<uint32_t>(), candq_fu32, (int)candq_fu32,
                            d_pool.as<uint32_t>(), pool_fu32, (int)pool_fu32, d_kept.as<ArKept>(), legacy_kcap,
                            d_rects.as<ArRect>(), AR_MAX_RECTS, d_counts.as<int32_t>(), d_gpad.as<uint32_t>(),
@@ -275,11 +275,11 @@ struct orbfe_aruco {
         hipLaunchKernelGGL(k_prefilter, dim3(B), dim3(256), 0, s, d_rects.as<ArRect>(), AR_MAX_RECTS,
                            d_counts.as<int32_t>(), cols, rows, win, d_candidx.as<int32_t>(), d_ncand.as<int32_t>());
         ORBFE_HIP(hipStreamWaitEvent(s, ev_join, 0));
-        if (!(g_aruco_skip & 2)) hipLaunchKernelGGL(k_decode, dim3(B), dim3(512), 0, s, src0, pyr, d_levels.as<ArLevel>(), npyr,
+        if (!ORBFE_SKIP_ARUCO(2)) hipLaunchKernelGGL(k_decode, dim3(B), dim3(512), 0, s, src0, pyr, d_levels.as<ArLevel>(), npyr,
                            d_rects.as<ArRect>(), AR_MAX_RECTS, d_candidx.as<int32_t>(), d_ncand.as<int32_t>(), S, nb,
                            d_codes.as<unsigned long long>(), ncodes, d_result.as<int32_t>(), cols);
         timer.mark(s, "decode");
-        if (!(g_aruco_skip & 4)) hipLaunchKernelGGL(k_finalize, dim3(B), dim3(256), 0, s, d_rects.as<ArRect>(), AR_MAX_RECTS,
+        if (!ORBFE_SKIP_ARUCO(4)) hipLaunchKernelGGL(k_finalize, dim3(B), dim3(256), 0, s, d_rects.as<ArRect>(), AR_MAX_RECTS,
                            d_candidx.as<int32_t>(), d_ncand.as<int32_t>(), d_result.as<int32_t>(),
                            d_pool.as<uint32_t>(), pool_fu32, d_out_m, capacity, d_n);
         timer.mark(s, "finalize");
@@ -317,7 +317,7 @@ static int pose_camera(const float* K4, const float* dist, int ndist, float mark
 struct PoseWorkspace {
     DevBuf markers, poses;
 };
-static thread_local PoseWorkspace* tl_pose_ws = nullptr;
+static thread_local ThreadWorkspaces<PoseWorkspace> tl_pose_ws; // per (thread, device)
 
 extern "C" {
 
@@ -388,10 +388,11 @@ int orbfe_aruco_detect_batch(orbfe_aruco* h, const uint8_t* imgs, int nframes, s
         ORBFE_HIP(hipMemcpy2DAsync((uint8_t*)h->d_in.p + f * dframe, dpitch, imgs + f * frame_stride, step, cols, rows,
                                    hipMemcpyHostToDevice, s));
     std::vector<int32_t> counts((size_t)nframes * 4);
+    const bool user_big_mode = h->big_mode; // orbfe_aruco_set_big_frames applies to all following batches: keep it
     for (int attempt = 0; attempt < 2; attempt++) {
         rc = h->run_device(h->d_in.as<uint8_t>(), nframes, dframe, rows, cols, dpitch, h->d_out.as<orbfe_marker>(),
                            AR_MAX_RECTS, h->d_nout.as<int32_t>(), s);
-        if (rc) { h->big_mode = false; return rc; }
+        if (rc) { h->big_mode = user_big_mode; return rc; }
         ORBFE_HIP(hipMemcpyAsync(n_out, h->d_nout.p, (size_t)nframes * 4, hipMemcpyDeviceToHost, s));
         ORBFE_HIP(hipStreamSynchronize(s));
         ORBFE_HIP(hipMemcpy(counts.data(), h->d_counts.p, counts.size() * 4, hipMemcpyDeviceToHost));
@@ -402,7 +403,7 @@ int orbfe_aruco_detect_batch(orbfe_aruco* h, const uint8_t* imgs, int nframes, s
         if (!retry || h->big_mode) break;
         h->big_mode = true;
     }
-    h->big_mode = false;
+    h->big_mode = user_big_mode;
     for (int f = 0; f < nframes; f++) {
         if (counts[f * 4 + 2])
             return fail(ORBFE_ERR_CAPACITY, "frame %d: internal detector capacity exceeded (flags 0x%x)", f, counts[f * 4 + 2]);
@@ -541,8 +542,7 @@ int orbfe_marker_poses(const orbfe_marker* markers, int n, float marker_size, co
     int rc = pose_camera(K4, dist, ndist, marker_size, c, "orbfe_marker_poses");
     if (rc || (rc = use_device(device))) return rc;
     if (n == 0) return ORBFE_OK;
-    if (!tl_pose_ws) tl_pose_ws = new PoseWorkspace();
-    PoseWorkspace& w = *tl_pose_ws;
+    PoseWorkspace& w = tl_pose_ws.get();
     if ((rc = w.markers.ensure((size_t)n * sizeof(orbfe_marker))) || (rc = w.poses.ensure((size_t)n * sizeof(orbfe_marker_pose))))
         return rc;
     ORBFE_HIP(hipMemcpy(w.markers.p, markers, (size_t)n * sizeof(orbfe_marker), hipMemcpyHostToDevice));

@@ -376,7 +376,7 @@ __global__ __launch_bounds__(SB_THREADS) void k_search_by_bow(BowFrames F, const
 struct BowMatchWorkspace {
     DevBuf kps, desc, valid, n, fn, fo, ff, nf, m12, m21, nm;
 };
-thread_local BowMatchWorkspace* tl_bow_ws = nullptr;
+thread_local ThreadWorkspaces<BowMatchWorkspace> tl_bow_ws; // per (thread, device): host-pointer entry points only
 
 int norm_of(int scoring) { return scoring == 5 ? 0 : scoring == 1 ? 2 : 1; } // ScoringObject.h:74-91
 
@@ -686,8 +686,7 @@ int orbfe_search_for_triangulation(const orbfe_keypoint* kps1, const uint8_t* de
     if (n1 == 0 || n2 == 0 || nfv1 == 0 || nfv2 == 0) return ORBFE_OK;
     const int cap = std::max(n1, n2);
     if (cap > SB_MAX) return fail(ORBFE_ERR_CAPACITY, "orbfe_search_for_triangulation: at most %d features per frame", SB_MAX);
-    if (!tl_bow_ws) tl_bow_ws = new BowMatchWorkspace();
-    BowMatchWorkspace& w = *tl_bow_ws;
+    BowMatchWorkspace& w = tl_bow_ws.get();
     const size_t C = (size_t)cap;
     if ((rc = w.kps.ensure(2 * C * sizeof(orbfe_keypoint))) || (rc = w.desc.ensure(2 * C * 32)) || (rc = w.valid.ensure(2 * C)) ||
         (rc = w.n.ensure(16)) || (rc = w.fn.ensure(2 * C * 4)) || (rc = w.fo.ensure(2 * (C + 1) * 4)) || (rc = w.ff.ensure(2 * C * 4)) ||
@@ -743,8 +742,7 @@ int orbfe_search_by_bow(const orbfe_keypoint* kps1, const uint8_t* desc1, const 
     if (n1 == 0 || n2 == 0 || nfv1 == 0 || nfv2 == 0) return ORBFE_OK;
     const int cap = std::max(n1, n2);
     if (cap > SB_MAX) return fail(ORBFE_ERR_CAPACITY, "orbfe_search_by_bow: at most %d features per frame", SB_MAX);
-    if (!tl_bow_ws) tl_bow_ws = new BowMatchWorkspace();
-    BowMatchWorkspace& w = *tl_bow_ws;
+    BowMatchWorkspace& w = tl_bow_ws.get();
     const size_t C = (size_t)cap;
     if ((rc = w.kps.ensure(2 * C * sizeof(orbfe_keypoint))) || (rc = w.desc.ensure(2 * C * 32)) || (rc = w.valid.ensure(2 * C)) ||
         (rc = w.n.ensure(16)) || (rc = w.fn.ensure(2 * C * 4)) || (rc = w.fo.ensure(2 * (C + 1) * 4)) || (rc = w.ff.ensure(2 * C * 4)) ||

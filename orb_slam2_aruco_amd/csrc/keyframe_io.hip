@@ -101,12 +101,8 @@ __global__ __launch_bounds__(KF_THREADS) void k_kf_pack(const uint32_t* __restri
 struct KfWorkspace {
     DevBuf file, kps, desc, mp, bad;
 };
-thread_local KfWorkspace* tl_kf_ws = nullptr;
-KfWorkspace& kf_ws()
-{
-    if (!tl_kf_ws) tl_kf_ws = new KfWorkspace();
-    return *tl_kf_ws;
-}
+thread_local ThreadWorkspaces<KfWorkspace> tl_kf_ws; // per (thread, device): host-pointer entry points only
+KfWorkspace& kf_ws() { return tl_kf_ws.get(); }
 
 } // namespace
 

@@ -907,9 +907,14 @@ __global__ __launch_bounds__(256) void k_project_last_frame(const float* __restr
 
 // The projection and visibility gates shared by Fuse (ORBmatcher.cc:848-893 and :1008-1049) and the keyframe variants of
 // SearchByProjection (:321-358, :1497-1530): camera coordinates (OpenCV's 3x3 float product + float translation), positive
-// depth, inside the image, distance inside the scale-invariance range, optional viewing-angle gate (P - Ow) . n >= 0.5 d
-// (cv::Mat::dot and cv::norm accumulate in double), MapPoint::PredictScale (MapPoint.cc:414-429, evaluated in double), search
-// radius th * scale[level].  One lane per map point; a point that is not searched gets r = -1.
+// depth, inside the image, distance inside the scale-invariance range [0.8f * mfMinDistance, 1.2f * mfMaxDistance]
+// (MapPoint::Get{Min,Max}DistanceInvariance, MapPoint.cc:402-412), optional viewing-angle gate (P - Ow) . n >= 0.5 d
+// (cv::Mat::dot and cv::norm accumulate in double), MapPoint::PredictScale (MapPoint.cc:414-446: mfMaxDistance / dist, and --
+// TemplatedVocabulary.h:36 puts `using namespace std` in front of MapPoint.cc -- std::log(float), float division, std::ceil(float);
+// the float log here is the correctly rounded one), search radius th * scale[level].  One lane per map point; a point that is
+// not searched gets r = -1.
+// frame_variant: the relocalisation search SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) projects with other
+// arithmetic (:1503-1512): NO depth gate, invzc = 1.0 / zc evaluated in double, u = (fx * xc) * invzc + cx, Frame bounds (<=).
 struct ProjectParams {
     float T[12], Ow[3], K[4], bnd[4], scale[16];
     int nlevels, strict_max, level_below, level_above;
@@ -918,6 +923,7 @@ struct ProjectParams {
     // stage rounded to float as the two cv::Mat expressions are; the distance is then the norm of the final camera coordinates
     int use_T2;
     float T2[12];
+    int frame_variant;
 };
 
 __global__ __launch_bounds__(256) void k_project_map_points(const float* __restrict__ p3Dw, const uint8_t* __restrict__ valid,
@@ -939,27 +945,36 @@ __global__ __launch_bounds__(256) void k_project_map_points(const float* __restr
             yc = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(P.T2[4], a), __fmul_rn(P.T2[5], b)), __fmul_rn(P.T2[6], c)), P.T2[7]);
             zc = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(P.T2[8], a), __fmul_rn(P.T2[9], b)), __fmul_rn(P.T2[10], c)), P.T2[11]);
         }
-        if (!(zc < 0.0f)) {
+        float u = 0.0f, v = 0.0f;
+        bool inside = false;
+        if (P.frame_variant) {
+            const float invzc = (float)(1.0 / (double)zc);
+            u = __fadd_rn(__fmul_rn(__fmul_rn(P.K[0], xc), invzc), P.K[2]);
+            v = __fadd_rn(__fmul_rn(__fmul_rn(P.K[1], yc), invzc), P.K[3]);
+            // NaN coordinates (zc == 0 with xc == 0) fail every comparison and are dropped; the reference would index the grid with them
+            inside = u >= P.bnd[0] && u <= P.bnd[2] && v >= P.bnd[1] && v <= P.bnd[3];
+        } else if (!(zc < 0.0f)) {
             const float invz = __fdiv_rn(1.0f, zc);
-            const float u = __fadd_rn(__fmul_rn(P.K[0], __fmul_rn(xc, invz)), P.K[2]);
-            const float v = __fadd_rn(__fmul_rn(P.K[1], __fmul_rn(yc, invz)), P.K[3]);
-            const bool inside = P.strict_max ? (u >= P.bnd[0] && u < P.bnd[2] && v >= P.bnd[1] && v < P.bnd[3])  // KeyFrame::IsInImage
-                                             : (u >= P.bnd[0] && u <= P.bnd[2] && v >= P.bnd[1] && v <= P.bnd[3]);
-            if (inside) {
-                const float px = P.use_T2 ? xc : X - P.Ow[0], py = P.use_T2 ? yc : Y - P.Ow[1], pz = P.use_T2 ? zc : Z - P.Ow[2];
-                const float dist3D = (float)sqrt((double)px * px + (double)py * py + (double)pz * pz);
-                bool ok = !(dist3D < min_dist[i] || dist3D > max_dist[i]);
-                if (ok && normal) {
-                    const double dot = (double)px * normal[3 * i] + (double)py * normal[3 * i + 1] + (double)pz * normal[3 * i + 2];
-                    ok = !(dot < 0.5 * (double)dist3D);
-                }
-                if (ok) {
-                    const float ratio = __fdiv_rn(max_dist[i], dist3D);
-                    int lvl = (int)ceil(log((double)ratio) / (double)P.log_scale);
-                    if (lvl < 0) lvl = 0;
-                    else if (lvl >= P.nlevels) lvl = P.nlevels - 1;
-                    Q = SbpQuery{u, v, __fmul_rn(P.th, P.scale[lvl]), lvl - P.level_below, lvl + P.level_above};
-                }
+            u = __fadd_rn(__fmul_rn(P.K[0], __fmul_rn(xc, invz)), P.K[2]);
+            v = __fadd_rn(__fmul_rn(P.K[1], __fmul_rn(yc, invz)), P.K[3]);
+            inside = P.strict_max ? (u >= P.bnd[0] && u < P.bnd[2] && v >= P.bnd[1] && v < P.bnd[3])  // KeyFrame::IsInImage
+                                  : (u >= P.bnd[0] && u <= P.bnd[2] && v >= P.bnd[1] && v <= P.bnd[3]);
+        }
+        if (inside) {
+            const float px = P.use_T2 ? xc : X - P.Ow[0], py = P.use_T2 ? yc : Y - P.Ow[1], pz = P.use_T2 ? zc : Z - P.Ow[2];
+            const float dist3D = (float)sqrt((double)px * px + (double)py * py + (double)pz * pz);
+            const float mfMax = max_dist[i];
+            bool ok = !(dist3D < __fmul_rn(0.8f, min_dist[i]) || dist3D > __fmul_rn(1.2f, mfMax));
+            if (ok && normal) {
+                const double dot = (double)px * normal[3 * i] + (double)py * normal[3 * i + 1] + (double)pz * normal[3 * i + 2];
+                ok = !(dot < 0.5 * (double)dist3D);
+            }
+            if (ok) {
+                const float ratio = __fdiv_rn(mfMax, dist3D);
+                int lvl = (int)ceilf(__fdiv_rn((float)log((double)ratio), P.log_scale));
+                if (lvl < 0) lvl = 0;
+                else if (lvl >= P.nlevels) lvl = P.nlevels - 1;
+                Q = SbpQuery{u, v, __fmul_rn(P.th, P.scale[lvl]), lvl - P.level_below, lvl + P.level_above};
             }
         }
     }
@@ -972,16 +987,15 @@ struct MatchWorkspace {
     int csr_per_pair = 0; // CSR slots per frame pair (grown by the host wrapper on overflow)
     int sbp_stride = 0;   // candidate row stride of k_search_by_projection (grown on overflow)
 };
-static thread_local MatchWorkspace* tl_ws = nullptr;
-static MatchWorkspace& ws()
-{
-    if (!tl_ws) tl_ws = new MatchWorkspace();
-    return *tl_ws;
-}
+// one workspace per (thread, device, stream): see ThreadWorkspaces.  The host-pointer entry points run on the null stream.
+static thread_local ThreadWorkspaces<MatchWorkspace> tl_ws;
+static MatchWorkspace& ws(hipStream_t s = nullptr) { return tl_ws.get(s); }
 
 // debug: 0 = choose by problem size, 1 = VALU tiles (+ split/merge), 2 = matrix cores (orbfe_debug_control "knn2_path")
 static int g_knn2_path = 0;
+#ifdef ORBFE_ABLATION
 int g_orb_skip = 0, g_aruco_skip = 0;
+#endif
 
 static int knn2_launch(const uint8_t* d_Q, const int32_t* d_nq, size_t q_stride, int max_nq, const uint8_t* d_T,
                        const int32_t* d_nt, size_t t_stride, int max_nt, int npairs, int init, int32_t* d_best_idx,
@@ -1007,7 +1021,7 @@ static int knn2_launch(const uint8_t* d_Q, const int32_t* d_nq, size_t q_stride,
         hipLaunchKernelGGL(k_knn2_tiles, dim3(qtiles, npairs, 1), dim3(256), 0, s, d_Q, d_nq, q_stride, max_nq, d_T,
                            d_nt, t_stride, chunk, init, d_best_idx, d_best_dist, d_second_dist);
     } else {
-        MatchWorkspace& w = ws();
+        MatchWorkspace& w = ws(s);
         const size_t nb = (size_t)npairs * nsplit * max_nq * 4;
         int rc;
         if ((rc = w.pidx.ensure(nb)) || (rc = w.pbest.ensure(nb)) || (rc = w.psecond.ensure(nb))) return rc;
@@ -1032,7 +1046,7 @@ static int sfi_launch(const orbfe_keypoint* d_kps, const uint8_t* d_desc, const 
                       float* d_prev_out, int32_t* d_m12, int32_t* d_nm, hipStream_t s)
 {
     if (capacity > 65535) return fail(ORBFE_ERR_INVALID, "capacity above 65535 keypoints per frame is unsupported");
-    MatchWorkspace& w = ws();
+    MatchWorkspace& w = ws(s);
     // candidate rows have a fixed stride: at most every level-0 keypoint of F2 is a candidate; the host wrapper
     // grows the stride when a frame reports more level-0 keypoints than that
     const int stride = std::max(w.csr_per_pair, std::min(SFI_MAXL0, (capacity / 2 + 63) / 64 * 64));
@@ -1063,23 +1077,21 @@ extern "C" {
 int orbfe_debug_control(const char* key, int value)
 {
     if (key && !strcmp(key, "knn2_path") && value >= 0 && value <= 2) { g_knn2_path = value; return ORBFE_OK; }
+#ifdef ORBFE_ABLATION // diagnosis build only; the shipped library cannot skip work
     if (key && !strcmp(key, "orb_skip")) { orbfe::g_orb_skip = value; return ORBFE_OK; }
     if (key && !strcmp(key, "aruco_skip")) { orbfe::g_aruco_skip = value; return ORBFE_OK; }
+#endif
     return fail(ORBFE_ERR_INVALID, "orbfe_debug_control: unknown key or value");
 }
 
 int orbfe_hamming(const uint8_t* a, const uint8_t* b)
 {
-    // host-side scalar helper with the reference's exact formulation (ORBmatcher.cc:1651-1667)
-    const int32_t* pa = (const int32_t*)a;
-    const int32_t* pb = (const int32_t*)b;
+    // host-side scalar helper: the 256-bit Hamming distance of ORBmatcher::DescriptorDistance (ORBmatcher.cc:1651-1667)
+    uint64_t x[4], y[4];
+    memcpy(x, a, 32);
+    memcpy(y, b, 32);
     int dist = 0;
-    for (int i = 0; i < 8; i++, pa++, pb++) {
-        unsigned int v = *pa ^ *pb;
-        v = v - ((v >> 1) & 0x55555555);
-        v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
-        dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
-    }
+    for (int i = 0; i < 4; i++) dist += __builtin_popcountll(x[i] ^ y[i]);
     return dist;
 }
 
@@ -1130,6 +1142,21 @@ int orbfe_search_for_initialization_batch_device(const orbfe_keypoint* d_kps, co
         return fail(ORBFE_ERR_INVALID, "orbfe_search_for_initialization_batch_device: invalid argument");
     return sfi_launch(d_kps, d_desc, d_n, capacity, npairs, frame_bounds(cols, rows, bounds), window_size, nnratio, check_orientation,
                       nullptr, nullptr, d_matches12, d_nmatches, (hipStream_t)stream);
+}
+
+int orbfe_search_for_initialization_batch_status(void* stream, int32_t* overflow)
+{
+    if (!overflow) return fail(ORBFE_ERR_INVALID, "orbfe_search_for_initialization_batch_status: null argument");
+    *overflow = 0;
+    hipStream_t s = (hipStream_t)stream;
+    MatchWorkspace& w = ws(s);
+    if (!w.overflow.p) return ORBFE_OK; // no batch on this (thread, device, stream) yet
+    ORBFE_HIP(hipStreamSynchronize(s));
+    ORBFE_HIP(hipMemcpy(overflow, w.overflow.p, 4, hipMemcpyDeviceToHost));
+    if (*overflow > SFI_MAXL0)
+        return fail(ORBFE_ERR_CAPACITY, "%d level-0 keypoints in a frame exceed the supported %d", *overflow, SFI_MAXL0);
+    if (*overflow > w.csr_per_pair) w.csr_per_pair = (*overflow + 63) / 64 * 64; // the next batch on this stream has the room
+    return ORBFE_OK;
 }
 
 int orbfe_search_for_initialization(const orbfe_keypoint* kps1, const uint8_t* desc1, int n1,
@@ -1372,6 +1399,7 @@ static int project_params(ProjectParams& P, const float* Tcw, const float* Ow, c
     P.nlevels = nlevels; P.strict_max = strict_max; P.level_below = below; P.level_above = above; P.log_scale = log_scale; P.th = th;
     P.use_T2 = 0;
     for (int i = 0; i < 12; i++) P.T2[i] = 0.0f;
+    P.frame_variant = 0;
     return ORBFE_OK;
 }
 
@@ -1397,15 +1425,16 @@ static int project_run(MatchWorkspace& w, const float* p3Dw, const uint8_t* vali
 }
 
 int orbfe_project_map_points(const float* p3Dw, const uint8_t* valid, const float* min_dist, const float* max_dist, const float* normal, int n,
-                             const float* Tcw, const float* Ow, const float* K4, int cols, int rows, const float* bounds, int strict_max,
+                             const float* Tcw, const float* Ow, const float* K4, int cols, int rows, const float* bounds, int keyframe_variant,
                              const float* scale_factors, int nlevels, float log_scale_factor, float th, int level_below, int level_above,
                              orbfe_window_query* queries, int device)
 {
     if (n < 0 || (n && (!p3Dw || !min_dist || !max_dist || !queries)))
         return fail(ORBFE_ERR_INVALID, "orbfe_project_map_points: invalid argument");
     ProjectParams P;
-    int rc = project_params(P, Tcw, Ow, K4, cols, rows, bounds, strict_max, scale_factors, nlevels, log_scale_factor, th, level_below, level_above,
-                            "orbfe_project_map_points");
+    int rc = project_params(P, Tcw, Ow, K4, cols, rows, bounds, keyframe_variant, scale_factors, nlevels, log_scale_factor, th, level_below,
+                            level_above, "orbfe_project_map_points");
+    P.frame_variant = !keyframe_variant;
     if (rc || (rc = use_device(device)) || n == 0) return rc;
     MatchWorkspace& w = ws();
     if ((rc = project_run(w, p3Dw, valid, min_dist, max_dist, normal, n, P))) return rc;

@@ -141,6 +141,9 @@ struct orbfe_extractor {
             g.h = orbfe_round_f((float)rows_ * scale);
             if (g.w < 38 + 30 || g.h < 38 + 30)
                 return fail(ORBFE_ERR_INVALID, "level %d is %dx%d: too small for a FAST cell grid", l, g.w, g.h);
+            // a keypoint travels as x | y << 12 | score << 24 relative to the 16-px border
+            if (g.w - 32 > 4095 || g.h - 32 > 4095)
+                return fail(ORBFE_ERR_INVALID, "level %d is %dx%d: images above 4127 px a side are unsupported", l, g.w, g.h);
             g.pitch = align_up(g.w, 64);
             g.bpitch = align_up(g.w, 64);
             g.img_off = (long long)pyr;
@@ -289,7 +292,7 @@ struct orbfe_extractor {
         timer.begin();
         timer.mark(s, "start");
         ORBFE_HIP(hipMemsetAsync(d_overflow.p, 0, 4, s));
-        for (int l = 1; l < nlevels && !(g_orb_skip & 16); l++) {
+        for (int l = 1; l < nlevels && !ORBFE_SKIP_ORB(16); l++) {
             const LevelGeom& g = geom[l];
             const LevelGeom& gp = geom[l - 1];
             ImgView sv = (l == 1) ? src0 : ImgView{pyr.base + gp.img_off, nullptr, pyr_fbytes, gp.pitch};
@@ -315,7 +318,7 @@ struct orbfe_extractor {
         ORBFE_HIP(hipEventRecord(ev_fork, s));
         ORBFE_HIP(hipStreamWaitEvent(aux_stream, ev_fork, 0));
         timer.mark(aux_stream, "blur7 starts", true);
-        if (!(g_orb_skip & 8)) hipLaunchKernelGGL(k_blur7, dim3(xcd_grid(ntiles * B)), dim3(256), 0, aux_stream, src0, pyr, blur, dg,
+        if (!ORBFE_SKIP_ORB(8)) hipLaunchKernelGGL(k_blur7, dim3(xcd_grid(ntiles * B)), dim3(256), 0, aux_stream, src0, pyr, blur, dg,
                            d_tiles.as<uint32_t>(), ntiles, ntiles * B);
         timer.mark(aux_stream, "blur7");
         ORBFE_HIP(hipEventRecord(ev_join, aux_stream));
@@ -330,7 +333,7 @@ struct orbfe_extractor {
             ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fast_cells),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             const int nx = (ncells_total + 3) / 4;
-            if (!(g_orb_skip & 1)) hipLaunchKernelGGL(k_fast_cells, dim3(xcd_grid(nx * B)), dim3(256), lds, s, src0, pyr, dg,
+            if (!ORBFE_SKIP_ORB(1)) hipLaunchKernelGGL(k_fast_cells, dim3(xcd_grid(nx * B)), dim3(256), lds, s, src0, pyr, dg,
                                d_cellinfo.as<uint32_t>(), d_slots.as<uint32_t>(), slots_fu32,
                                d_cellcnt.as<int32_t>(), ncells_total, iniThFAST, minThFAST, roi_pitch, roi_rows,
                                map_pitch, map_rows, list_cap, nx, nx * B);
@@ -344,7 +347,7 @@ struct orbfe_extractor {
             const size_t lds_p = qp_lds_bytes(max_ini, D, nodecap, veccap);
             ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_distribute_pyr),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
-            if (!(g_orb_skip & 2)) hipLaunchKernelGGL(k_distribute_pyr, dim3(nlevels, B), dim3(QP_THREADS), lds_p, s, dg, d_slots.as<uint32_t>(),
+            if (!ORBFE_SKIP_ORB(2)) hipLaunchKernelGGL(k_distribute_pyr, dim3(nlevels, B), dim3(QP_THREADS), lds_p, s, dg, d_slots.as<uint32_t>(),
                                slots_fu32, d_cellcnt.as<int32_t>(), ncells_total, d_lvlout.as<uint32_t>(), out_total,
                                d_lvlcnt.as<int32_t>(), nlevels, d_lvlncand.as<int32_t>(), d_fallback.as<int32_t>(), D,
                                nodecap, veccap);
@@ -367,7 +370,7 @@ struct orbfe_extractor {
                            d_flatkv.as<uint32_t>(), d_flatlvl.as<uint8_t>());
         ORBFE_HIP(hipStreamWaitEvent(s, ev_join, 0));
         const int okx = (std::min(capacity, max_keypoints()) + 3) / 4;
-        if (!(g_orb_skip & 4)) hipLaunchKernelGGL(k_orient_describe, dim3(xcd_grid(okx * B)), dim3(256), 0, s, src0, pyr, blur, dg,
+        if (!ORBFE_SKIP_ORB(4)) hipLaunchKernelGGL(k_orient_describe, dim3(xcd_grid(okx * B)), dim3(256), 0, s, src0, pyr, blur, dg,
                            d_flatkv.as<uint32_t>(), d_flatlvl.as<uint8_t>(), d_n, nlevels, d_pattern.as<uint32_t>(),
                            d_umax.as<int>(), d_kps_out, d_desc_out, capacity, okx, okx * B);
         timer.mark(s, "orient_describe");
@@ -379,7 +382,11 @@ struct orbfe_extractor {
 extern "C" {
 
 const char* orbfe_last_error(void) { return g_err; }
-const char* orbfe_version(void) { return "orbfe 0.1 (gfx950)"; }
+#ifdef ORBFE_ABLATION
+const char* orbfe_version(void) { return "orbfe 0.2 (gfx950) +ablation"; } // diagnosis build: launches can be skipped
+#else
+const char* orbfe_version(void) { return "orbfe 0.2 (gfx950)"; }
+#endif
 int orbfe_device_count(void)
 {
     int n = 0;
@@ -452,6 +459,18 @@ int orbfe_extract_batch_device(orbfe_extractor* h, const uint8_t* d_imgs, int nf
     if (rc) return rc;
     return h->run_device(d_imgs, nframes, frame_stride, rows, cols, step, d_kps, d_desc, capacity, d_n_out,
                          (hipStream_t)stream);
+}
+
+int orbfe_extractor_batch_status(orbfe_extractor* h, int32_t* overflow)
+{
+    if (!h || !overflow) return fail(ORBFE_ERR_INVALID, "orbfe_extractor_batch_status: null argument");
+    *overflow = 0;
+    if (!h->d_overflow.p) return ORBFE_OK; // no batch yet
+    int rc = use_device(h->device);
+    if (rc) return rc;
+    ORBFE_HIP(hipDeviceSynchronize());
+    ORBFE_HIP(hipMemcpy(overflow, h->d_overflow.p, 4, hipMemcpyDeviceToHost));
+    return ORBFE_OK;
 }
 
 int orbfe_extract_batch(orbfe_extractor* h, const uint8_t* imgs, int nframes, size_t frame_stride, int rows, int cols,

@@ -14,9 +14,18 @@
 namespace orbfe {
 
 extern thread_local char g_err[512];
-// diagnosis only (orbfe_debug_control "orb_skip" / "aruco_skip"): bit masks of launches to leave out when measuring what a
-// kernel costs the concurrent pipeline; results are garbage while a bit is set
+// Launch ablation ("what does this kernel cost the concurrent pipeline") exists only in the diagnosis build
+// (-DORBFE_ABLATION, tools/ablate.sh -> build/liborbfe_ablate.so): bit masks of launches to leave out, set with
+// orbfe_debug_control "orb_skip" / "aruco_skip"; results are garbage while a bit is set.  The shipped library has no
+// switch that skips work: there the macros are the constant 0 and orbfe_debug_control rejects the keys.
+#ifdef ORBFE_ABLATION
 extern int g_orb_skip, g_aruco_skip;
+#define ORBFE_SKIP_ORB(bit) (::orbfe::g_orb_skip & (bit))
+#define ORBFE_SKIP_ARUCO(bit) (::orbfe::g_aruco_skip & (bit))
+#else
+#define ORBFE_SKIP_ORB(bit) 0
+#define ORBFE_SKIP_ARUCO(bit) 0
+#endif
 
 inline int fail(int code, const char* fmt, ...)
 {
@@ -42,6 +51,10 @@ int use_device(int device);
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
     int ensure(size_t need)
     {
         if (need <= bytes) return ORBFE_OK;
@@ -60,6 +73,40 @@ struct DevBuf {
         bytes = 0;
     }
     template <class T> T* as() const { return (T*)p; }
+};
+
+// Scratch of the entry points that have no handle (matching, poses, keyframe records): one workspace per calling thread,
+// HIP device and stream.  A buffer allocated on one GPU is never handed to a kernel on another, two asynchronous calls
+// of one thread on different streams never share scratch, and the buffers are released when the thread exits.
+template <class W> class ThreadWorkspaces {
+    struct Slot {
+        int device;
+        hipStream_t stream;
+        W* w;
+    };
+    std::vector<Slot> slots;
+
+public:
+    // workspace of (this thread, the current device, stream); the caller has selected the device already
+    W& get(hipStream_t stream = nullptr)
+    {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        for (auto& s : slots)
+            if (s.device == dev && s.stream == stream) return *s.w;
+        slots.push_back(Slot{dev, stream, new W()});
+        return *slots.back().w;
+    }
+    ~ThreadWorkspaces()
+    {
+        int cur = 0;
+        const bool have = hipGetDevice(&cur) == hipSuccess;
+        for (auto& s : slots) {
+            (void)hipSetDevice(s.device);
+            delete s.w;
+        }
+        if (have) (void)hipSetDevice(cur);
+    }
 };
 
 // Event timing of individual launches (profiling aid; no events are recorded unless enabled).  A mark closes the

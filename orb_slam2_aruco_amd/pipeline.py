@@ -1,0 +1,265 @@
+"""Host side of the batched-video mode (BASELINE north_star): one B-frame batch resident in HBM goes through
+
+    ORBextractor::operator()          (Frame.cc:200-206)  -> orbfe_extract_batch_device
+    MarkerDetector::detect(img, cam, 0.187) (Frame.cc:142) -> orbfe_aruco_detect_batch_device + orbfe_marker_poses_batch_device
+    frame t vs t-1 descriptor matching (ORBmatcher)        -> orbfe_knn2_batch_device + orbfe_search_for_initialization_batch_device
+
+on three HIP streams, into fixed-capacity result records.  bench.py times exactly this class and the GPU tests check exactly
+this class against the oracle, so the tested code is the benchmarked code.  torch is plumbing here (device buffers, streams,
+events, torch.distributed); every computation is a call into liborbfe.so.
+"""
+import ctypes
+
+import numpy as np
+
+from . import binding
+
+TUM1_K = [517.306408, 516.469215, 318.643040, 255.313989]       # Examples/Monocular/TUM1.yaml
+TUM1_DIST = [0.262383, -0.953104, -0.005358, 0.002628, 1.163314]
+MARKER_SIZE = 0.187                                             # Frame.cc:131
+
+
+def _up(v):
+    return (v + 255) // 256 * 256
+
+
+class RecordLayout:
+    """One result set = ONE contiguous buffer, the record SURVEY 8e gathers, array by array over the B frames:
+    {kp[B][cap] x 28 B | desc[B][cap] x 32 B | n_kp[B] | markers[B][mcap] x 36 B | n_mk[B] | poses[B][mcap] x 56 B}."""
+
+    def __init__(self, B, cap, mcap):
+        self.B, self.cap, self.mcap = B, cap, mcap
+        self.kps = 0
+        self.desc = _up(B * cap * 28)
+        self.n = self.desc + _up(B * cap * 32)
+        self.mk = self.n + _up(B * 4)
+        self.nmk = self.mk + _up(B * mcap * 36)
+        self.pose = self.nmk + _up(B * 4)
+        self.nbytes = self.pose + _up(B * mcap * 56)
+
+    def unpack(self, buf):
+        """bytes of one record set (numpy uint8) -> dict of per-frame arrays (views)."""
+        B, cap, mcap = self.B, self.cap, self.mcap
+        out = {"n": buf[self.n:self.n + B * 4].view(np.int32),
+               "kps": buf[self.kps:self.kps + B * cap * 28].view(binding.KP_DTYPE).reshape(B, cap),
+               "desc": buf[self.desc:self.desc + B * cap * 32].reshape(B, cap, 32)}
+        if mcap:
+            out["nmk"] = buf[self.nmk:self.nmk + B * 4].view(np.int32)
+            out["markers"] = buf[self.mk:self.mk + B * mcap * 36].view(binding.MARKER_DTYPE).reshape(B, mcap)
+            out["poses"] = buf[self.pose:self.pose + B * mcap * 56].view(binding.POSE_DTYPE).reshape(B, mcap)
+        return out
+
+
+def valid_records(rec, use_orb=True):
+    """The defined part of an unpacked record set (entries past a frame's count are unspecified): a list of per-frame tuples."""
+    out = []
+    for f in range(len(rec["n"])):
+        n = int(rec["n"][f]) if use_orb else 0
+        item = [n, rec["kps"][f, :n].tobytes(), rec["desc"][f, :n].tobytes()]
+        if "nmk" in rec:
+            m = min(int(rec["nmk"][f]), rec["markers"].shape[1])
+            item += [int(rec["nmk"][f]), rec["markers"][f, :m].tobytes(), rec["poses"][f, :m].tobytes()]
+        out.append(tuple(item))
+    return out
+
+
+class FrontEndPipeline:
+    """Extractor, detector and matching of one stream of frames on one GPU.
+
+    step(d_imgs) enqueues one batch (B frames, rows x pitch bytes each, resident on the device) and returns at once; result
+    set i % 2 receives batch i, so the matching of batch i (third stream) -- and on N > 1 its gather (communication
+    stream) -- overlap with the engines of batch i + 1.  The engines are joined where their results meet: before the
+    gather and in synchronize()."""
+
+    def __init__(self, frames, rows, cols, nfeatures=1000, nlevels=8, dictionary="ARUCO", device=0, marker_capacity=64,
+                 use_orb=True, use_aruco=True, splits=1, gather=None, lend_aux_stream=True):
+        import torch
+        self.torch = torch
+        self.L = binding.load()
+        self.B, self.rows, self.cols = frames, rows, cols
+        self.pitch = (cols + 63) // 64 * 64
+        self.use_orb, self.use_aruco = use_orb, use_aruco
+        self.device = device
+        self.dev = dev = torch.device("cuda", device)
+        B = frames
+        S = self.S = max(1, min(splits, B // 2))
+        self.bounds = [B * k // S for k in range(S + 1)]          # sub-batch k = frames bounds[k] .. bounds[k+1]
+        self.exs = [binding.ORBextractor(nfeatures, 1.2, nlevels, 20, 7, device=device) for _ in range(S)]
+        self.ex = self.exs[0]
+        self.cap = cap = self.ex.capacity
+        self.dets = [binding.MarkerDetector(dictionary, device=device) for _ in range(S)] if use_aruco else []
+        self.det = self.dets[0] if use_aruco else None
+        # marker records per frame in the result set (the detector clamps a frame's count to it; its own limit is 256 candidates)
+        self.mcap = mcap = min(self.det.capacity, marker_capacity) if use_aruco else 0
+        self.layout = lay = RecordLayout(B, cap, mcap)
+        # camera of the reference's monocular example; the detector is handed CamSize 1280x720 (Frame.cc:132), so the matrix
+        # is rescaled to the frame size before the marker poses (markerdetector_impl.cpp:1110-1172)
+        self.cam_K = binding.camera_resize(np.array(TUM1_K, np.float32), (1280, 720), (cols, rows)) if use_aruco else None
+        self.cam_D = np.array(TUM1_DIST, np.float32)
+        self.recs = [torch.zeros(lay.nbytes, dtype=torch.uint8, device=dev) for _ in range(2)]
+        self.rec_ptr = [r.data_ptr() for r in self.recs]
+        z = lambda *shape: torch.zeros(shape, dtype=torch.int32, device=dev)
+        # matching outputs of the newest batch: pair p = frame p (queries / F1) against frame p + 1 (train / F2)
+        self.d_bidx, self.d_bdist, self.d_sdist, self.d_m12 = z(B - 1, cap), z(B - 1, cap), z(B - 1, cap), z(B - 1, cap)
+        self.d_nm = z(B - 1)
+        # three HIP streams: the ORB extractor, the ArUco detector, the matching.  The first two only read the resident
+        # frames; the matching of batch i reads result set i % 2 while batch i+1 is extracted into the other set.
+        # So the latency-bound kernels (contours, quadtree, SearchForInitialization) overlap with the VALU-bound ones.
+        self.stream = torch.cuda.current_stream(dev)
+        self.stream2 = torch.cuda.Stream(dev)
+        self.stream3 = torch.cuda.Stream(dev)
+        self.sp3 = ctypes.c_void_p(self.stream3.cuda_stream)
+        self.orb_streams = [self.stream] + [torch.cuda.Stream(dev) for _ in range(S - 1)]
+        self.aru_streams = [self.stream2] + [torch.cuda.Stream(dev) for _ in range(S - 1)]
+        if S == 1 and lend_aux_stream:
+            # ROCm maps streams onto 4 hardware queues, and two busy streams on one queue serialise.  The extractor's forked
+            # launch (the blur) is lent the matching stream; measured against the handle's own fork stream and against one
+            # shared fork stream for both engines: 2.02 vs 2.12 vs 2.14 ms per step.
+            self.ex.set_aux_stream(self.sp3)
+        ev = lambda **kw: torch.cuda.Event(**kw)
+        self.ex_done = [[ev() for _ in range(S)] for _ in range(2)]
+        self.det_done = [[ev() for _ in range(S)] for _ in range(2)]
+        self.match_done = [ev() for _ in range(2)]
+        self.gather_done = [ev() for _ in range(2)]
+        self.match_ev = [ev(enable_timing=True) for _ in range(3)]   # around the matching launches (their stream)
+        self.comm_stream = torch.cuda.Stream(dev)
+        self.gather = gather            # sharding.RecordGather or None (single GPU)
+        self.step_no = 0
+        self.big_frames = False
+
+    # ------------------------------------------------------------------------------------------------------------
+    def upload(self, frames_u8):
+        """(B, rows, cols) uint8 host frames -> resident device batch with 64-byte aligned rows."""
+        torch = self.torch
+        d = torch.zeros((len(frames_u8), self.rows, self.pitch), dtype=torch.uint8, device=self.dev)
+        d[:, :, :self.cols] = torch.from_numpy(np.ascontiguousarray(frames_u8)).to(self.dev)
+        return d
+
+    def step(self, d_imgs):
+        """Enqueue one batch; returns the result-set index (0 / 1) it writes."""
+        L, lay, S, B = self.L, self.layout, self.S, self.B
+        rows, cols, pitch, cap, mcap = self.rows, self.cols, self.pitch, self.cap, self.mcap
+        i = self.step_no
+        self.step_no += 1
+        cur = i % 2
+        base = self.rec_ptr[cur]
+        img0 = d_imgs.data_ptr()
+        multi = self.gather is not None
+        if self.use_aruco:
+            # the detector streams only depend on the (resident) input frames and on their own previous batch, so they are
+            # not joined with the ORB streams per step: consecutive batches of the two engines pipeline freely.
+            for k in range(S):
+                f0, nf = self.bounds[k], self.bounds[k + 1] - self.bounds[k]
+                st = self.aru_streams[k]
+                if multi and i >= 2:
+                    st.wait_event(self.gather_done[cur])         # batch i-2 has left this record set
+                sp = ctypes.c_void_p(st.cuda_stream)
+                self.dets[k].detect_batch_device(img0 + f0 * rows * pitch, nf, rows * pitch, rows, cols, pitch,
+                                                 base + lay.mk + f0 * mcap * 36, mcap, base + lay.nmk + f0 * 4, sp)
+                # detect(image, CameraParameters, 0.187): every marker gets its IPPE pose (markerdetector_impl.cpp:8720-8780)
+                binding._check(L, L.orbfe_marker_poses_batch_device(
+                    base + lay.mk + f0 * mcap * 36, base + lay.nmk + f0 * 4, mcap, nf, MARKER_SIZE,
+                    self.cam_K.ctypes.data_as(ctypes.c_void_p), self.cam_D.ctypes.data_as(ctypes.c_void_p), len(self.cam_D),
+                    base + lay.pose + f0 * mcap * 56, sp), "orbfe_marker_poses_batch_device")
+                self.det_done[cur][k].record(st)
+        if self.use_orb:
+            for k in range(S):
+                f0, nf = self.bounds[k], self.bounds[k + 1] - self.bounds[k]
+                st = self.orb_streams[k]
+                if i >= 2:
+                    st.wait_event(self.match_done[cur])          # the matching of batch i-2 has read this record set
+                    if multi:
+                        st.wait_event(self.gather_done[cur])
+                self.exs[k].extract_batch_device(img0 + f0 * rows * pitch, nf, rows * pitch, rows, cols, pitch,
+                                                 base + lay.kps + f0 * cap * 28, base + lay.desc + f0 * cap * 32, cap,
+                                                 base + lay.n + f0 * 4, ctypes.c_void_p(st.cuda_stream))
+                self.ex_done[cur][k].record(st)
+                self.stream3.wait_event(self.ex_done[cur][k])
+            self.enqueue_matching(cur)
+        if multi:
+            # the batch's one collective, on its own stream: it waits for the engines of THIS batch and runs
+            # while the next batch is computed into the other record set
+            with self.torch.cuda.stream(self.comm_stream):
+                for k in range(S):
+                    if self.use_orb:
+                        self.comm_stream.wait_event(self.ex_done[cur][k])
+                    if self.use_aruco:
+                        self.comm_stream.wait_event(self.det_done[cur][k])
+                self.gather(self.recs[cur])
+                self.gather_done[cur].record(self.comm_stream)
+        return cur
+
+    def enqueue_matching(self, cur):
+        """Frame t vs t-1 over result set `cur` on the matching stream: all-pairs knn2 + one SearchForInitialization-style
+        windowed pass."""
+        L, lay, B, cap = self.L, self.layout, self.B, self.cap
+        base = self.rec_ptr[cur]
+        e = self.match_ev
+        e[0].record(self.stream3)
+        binding._check(L, L.orbfe_knn2_batch_device(base + lay.desc, base + lay.n, cap * 32, cap,
+                                                    base + lay.desc + cap * 32, base + lay.n + 4, cap * 32, cap,
+                                                    B - 1, 256, self.d_bidx.data_ptr(), self.d_bdist.data_ptr(),
+                                                    self.d_sdist.data_ptr(), self.sp3), "orbfe_knn2_batch_device")
+        e[1].record(self.stream3)
+        binding._check(L, L.orbfe_search_for_initialization_batch_device(
+            base + lay.kps, base + lay.desc, base + lay.n, cap, B - 1, self.cols, self.rows, None, 100, 0.9, 1,
+            self.d_m12.data_ptr(), self.d_nm.data_ptr(), self.sp3), "orbfe_search_for_initialization_batch_device")
+        e[2].record(self.stream3)
+        self.match_done[cur].record(self.stream3)
+
+    def synchronize(self):
+        self.torch.cuda.synchronize(self.dev)
+
+    # ------------------------------------------------------------------------------------------------------------
+    def status(self):
+        """Capacity flags of the last batch of every engine (synchronises): dict, all zero = results complete."""
+        out = {"extractor_overflow": 0, "search_init_overflow": 0, "aruco_flagged_frames": 0, "aruco_flags": 0}
+        if self.use_orb:
+            out["extractor_overflow"] = max(e.batch_status() for e in self.exs)
+            ovf = ctypes.c_int32(0)
+            binding._check(self.L, self.L.orbfe_search_for_initialization_batch_status(self.sp3, ctypes.byref(ovf)),
+                           "orbfe_search_for_initialization_batch_status")
+            out["search_init_overflow"] = ovf.value
+        for d in self.dets:
+            n, fl = d.batch_status()
+            out["aruco_flagged_frames"] += n
+            out["aruco_flags"] |= fl
+        return out
+
+    def warmup(self, d_imgs, steps):
+        """Untimed steps; afterwards the capacity flags are asked once: frames with more long contours than the LDS-resident
+        contour kernels hold (large, busy images) switch the detector to its big-frame kernel, and a SearchForInitialization
+        candidate overflow has grown the scratch, so the steps are repeated once."""
+        for _ in range(max(steps, 1)):
+            self.step(d_imgs)
+        self.synchronize()
+        st = self.status()
+        again = False
+        if st["aruco_flagged_frames"]:
+            for d in self.dets:
+                d.set_big_frames(True)
+            self.big_frames = again = True
+        if st["search_init_overflow"]:
+            again = True
+        if again:
+            for _ in range(max(steps, 1)):
+                self.step(d_imgs)
+            self.synchronize()
+            st = self.status()
+        if any(st.values()):
+            raise binding.OrbfeError("front-end capacity exceeded at this frame size: %r" % (st,))
+
+    # ------------------------------------------------------------------------------------------------------------
+    def read_records(self, cur):
+        """Result set `cur` as host arrays (after synchronize())."""
+        return self.layout.unpack(self.recs[cur].cpu().numpy())
+
+    def read_matches(self):
+        """Matching outputs of the newest batch: dict of (B-1, cap) arrays + nmatches (B-1)."""
+        g = lambda t: t.cpu().numpy()
+        return {"best_idx": g(self.d_bidx), "best_dist": g(self.d_bdist), "second_dist": g(self.d_sdist),
+                "matches12": g(self.d_m12), "nmatches": g(self.d_nm)}
+
+    def matching_times_us(self):
+        e = self.match_ev
+        return e[0].elapsed_time(e[1]) * 1000.0, e[1].elapsed_time(e[2]) * 1000.0

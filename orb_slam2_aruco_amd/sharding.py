@@ -1,6 +1,9 @@
 """Multi-GPU plumbing: frames / streams are independent, so they shard across ranks with no data-path
 collective; the single collective is the gather of fixed-capacity result records to rank 0 (RCCL on GPU tensors,
-gloo in the CPU tests).  torch.distributed is plumbing here, not part of the product library."""
+gloo in the CPU tests).  torch.distributed is plumbing here, not part of the product library.
+
+bench.py and pipeline.FrontEndPipeline gather through RecordGather, tests/test_multigpu_cpu.py runs the same class (and
+gather_records, which is built on it) with gloo on the CPU."""
 import torch
 import torch.distributed as dist
 
@@ -12,18 +15,35 @@ def frames_of_rank(total, rank, world):
     return list(range(start, start + base + (1 if rank < rem else 0)))
 
 
+def stream_seed(rank, base=1000, stride=2000):
+    """Seed of the synthetic stream rank `rank` owns (seed base 2000 * s)."""
+    return base + stride * rank
+
+
+class RecordGather:
+    """The batch's one collective: gather one record buffer per rank to `dst`.
+
+    The receive buffers are allocated once (rank dst only) and reused by every batch; a record set is ONE contiguous
+    buffer (pipeline.RecordLayout), so a batch is one dist.gather -- RCCL send/recv over xGMI on the GPU, 7 peers -> rank 0.
+    Issued on whatever stream is current (FrontEndPipeline: its communication stream)."""
+
+    def __init__(self, like, dst=0):
+        self.dst = dst
+        self.world = dist.get_world_size()
+        self.rank = dist.get_rank()
+        self.blocks = [torch.empty_like(like) for _ in range(self.world)] if self.rank == dst else None
+
+    def __call__(self, tensor):
+        dist.gather(tensor, self.blocks, dst=self.dst)
+        return self.blocks
+
+
 def gather_records(tensors, dst=0):
     """Gather each tensor of `tensors` (same shape on every rank) to rank `dst`.
 
-    Returns, on dst, a list over ranks of lists of tensors; elsewhere None.  One dist.gather per record array per
+    Returns, on dst, a list over ranks of lists of tensors; elsewhere None.  One gather per record array per
     batch of frames (never per frame): the records are a few hundred KB, so the gather is latency-bound."""
-    world = dist.get_world_size()
-    rank = dist.get_rank()
-    out = []
-    for t in tensors:
-        buf = [torch.empty_like(t) for _ in range(world)] if rank == dst else None
-        dist.gather(t, buf, dst=dst)
-        out.append(buf)
-    if rank != dst:
+    out = [RecordGather(t, dst)(t) for t in tensors]
+    if dist.get_rank() != dst:
         return None
-    return [[out[k][r] for k in range(len(tensors))] for r in range(world)]
+    return [[out[k][r] for k in range(len(tensors))] for r in range(dist.get_world_size())]
