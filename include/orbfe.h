@@ -213,7 +213,10 @@ int orbfe_search_by_projection_best(const orbfe_keypoint* kps, const uint8_t* de
  * projection and gates (positive depth, KeyFrame::IsInImage, scale-invariance range, viewing angle < 60 deg), PredictScale,
  * the window search on the keyframe grid at levels [predicted - 1, predicted], the reprojection gate and the best
  * descriptor distance.  valid[i] = "pMP && !isBad() && !IsInKeyFrame(pKF)" resp. "!isBad() && !alreadyFound" (NULL = all);
- * min_dist / max_dist = Get{Min,Max}DistanceInvariance(), normal = GetNormal() (nmp x 3), mp_desc = GetDescriptor().
+ * min_dist / max_dist = the map point's mfMinDistance / mfMaxDistance: the range gate applies the 0.8f / 1.2f of
+ * Get{Min,Max}DistanceInvariance() (MapPoint.cc:402-412) and MapPoint::PredictScale divides mfMaxDistance itself (:419) -- the
+ * two are not recoverable from the getters' values bit-exactly, so the members are what every guided search here takes;
+ * normal = GetNormal() (nmp x 3), mp_desc = GetDescriptor().
  * Tcw = 3x4 row-major [Rcw | tcw], Ow = camera centre (3).  best_idx[i] = keypoint or -1, best_dist[i] = its distance (256
  * if none); the caller applies bestDist <= TH_LOW and does the map bookkeeping (Replace / AddObservation, :943-964). */
 int orbfe_fuse_search(const orbfe_keypoint* kps, const uint8_t* desc, int n, int cols, int rows, const float* bounds, const float* p3Dw,
@@ -246,14 +249,30 @@ int orbfe_search_by_projection_sim3(const orbfe_keypoint* kps, const uint8_t* de
                                     const float* Ow, const float* K4, const float* scale_factors, int nlevels, float log_scale_factor, int th,
                                     int32_t* match_kf, int32_t* nmatches, int device);
 
-/* Only the projection + gates + PredictScale, as window queries for orbfe_search_by_projection / _best (the keyframe variants of
- * SearchByProjection, :294-407 and :1476-1603, project the same way with other level ranges): r < 0 = not searched,
- * min_level = predicted - level_below, max_level = predicted + level_above.  normal == NULL: no viewing-angle gate;
- * strict_max != 0: KeyFrame::IsInImage (x < mnMaxX), else the Frame test (u <= mnMaxX). */
+/* Only the projection + gates + PredictScale, as window queries for orbfe_search_by_projection / _best: r < 0 = not searched,
+ * min_level = predicted - level_below, max_level = predicted + level_above.  normal == NULL: no viewing-angle gate.
+ * keyframe_variant != 0: the projection of Fuse / SearchBySim3 / SearchByProjection(pKF, Scw, ...) (:321-358, :848-893): positive
+ * depth, invz = 1 / z in float, u = fx * (xc * invz) + cx, KeyFrame::IsInImage (u < mnMaxX).  keyframe_variant == 0: the
+ * projection of SearchByProjection(CurrentFrame, pKF, ...) (:1503-1512): NO depth gate, invzc = 1.0 / z in double,
+ * u = (fx * xc) * invzc + cx, the Frame bounds test (u <= mnMaxX). */
 int orbfe_project_map_points(const float* p3Dw, const uint8_t* valid, const float* min_dist, const float* max_dist, const float* normal, int n,
-                             const float* Tcw, const float* Ow, const float* K4, int cols, int rows, const float* bounds, int strict_max,
+                             const float* Tcw, const float* Ow, const float* K4, int cols, int rows, const float* bounds, int keyframe_variant,
                              const float* scale_factors, int nlevels, float log_scale_factor, float th, int level_below, int level_above,
                              orbfe_window_query* queries, int device);
+
+/* ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, th, ORBdist)
+ * (src/ORBmatcher.cc:1476-1603; Tracking::Relocalization calls it with (10, 100) and (3, 64), Tracking.cc:1858, :1875), whole on
+ * the device: the projection above (keyframe_variant = 0), the distance gate, PredictScale, the window search at levels
+ * predicted - 1 .. predicted + 1 among keypoints without a map point (taken_cur[i2] = CurrentFrame.mvpMapPoints[i2] != NULL; a
+ * keypoint that receives a point is taken for the points after it), best distance <= orb_dist, rotation histogram (factor
+ * 1 / HISTO_LENGTH) and ComputeThreeMaxima.  Per feature i of the keyframe: valid[i] = "has a map point that is not bad and
+ * not in sAlreadyFound" (NULL = all), p3Dw, min_dist / max_dist, mp_desc as below, kf_angle[i] = pKF->mvKeysUn[i].angle.
+ * Ow = -Rcw' tcw (:1482).  match_cur[i2] = i or -1; *nmatches = the return value. */
+int orbfe_search_by_projection_keyframe(const orbfe_keypoint* kps_cur, const uint8_t* desc_cur, int n_cur, const uint8_t* taken_cur, int cols,
+                                        int rows, const float* bounds, int n_kf, const float* kf_angle, const uint8_t* valid, const float* p3Dw,
+                                        const float* min_dist, const float* max_dist, const uint8_t* mp_desc, const float* Tcw, const float* Ow,
+                                        const float* K4, const float* scale_factors, int nlevels, float log_scale_factor, float th, int orb_dist,
+                                        int check_orientation, int32_t* match_cur, int32_t* nmatches, int device);
 
 /* Batched device variant over npairs frame pairs (frame t vs t-1 of a stream); all arrays are blocks of `capacity`
  * records per frame; pair p matches frame p (as F1) against frame p+1 (as F2). prev_matched == NULL means

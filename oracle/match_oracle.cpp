@@ -25,6 +25,23 @@ struct KeyPoint {
 const int TH_HIGH = 100, TH_LOW = 50, HISTO_LENGTH = 30; /* ORBmatcher.cc:37-39 */
 const int FRAME_GRID_ROWS = 48, FRAME_GRID_COLS = 64;    /* Frame.h:40-41 */
 
+/* MapPoint::GetMinDistanceInvariance / GetMaxDistanceInvariance (src/MapPoint.cc:402-412): the per-point arrays of the guided
+ * searches carry the members mfMinDistance / mfMaxDistance themselves. */
+inline float GetMinDistanceInvariance(float mfMinDistance) { return 0.8f * mfMinDistance; }
+inline float GetMaxDistanceInvariance(float mfMaxDistance) { return 1.2f * mfMaxDistance; }
+
+/* MapPoint::PredictScale (src/MapPoint.cc:414-446).  It divides mfMaxDistance -- not the 1.2f * mfMaxDistance of the range gate.
+ * MapPoint.cc sees `using namespace std` (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:36, included through KeyFrame.h), so
+ * log(ratio) and ceil(...) on a float resolve to the float overloads: logf, a float division by mfLogScaleFactor, ceilf. */
+inline int PredictScale(float mfMaxDistance, float currentDist, float mfLogScaleFactor, int mnScaleLevels)
+{
+    float ratio = mfMaxDistance / currentDist;
+    int nScale = (int)std::ceil(std::log(ratio) / mfLogScaleFactor);
+    if (nScale < 0) nScale = 0;
+    else if (nScale >= mnScaleLevels) nScale = mnScaleLevels - 1;
+    return nScale;
+}
+
 /* ORBmatcher.cc:1651-1667 (the bit-hack itself, not __builtin_popcount) */
 int DescriptorDistance(const uint8_t* a, const uint8_t* b)
 {
@@ -611,16 +628,13 @@ void oracle_fuse_search(const void* kps_, const uint8_t* desc, int n, int cols, 
         const float u = fx * x + cx;
         const float v = fy * y + cy;
         if (!(u >= grid.mnMinX && u < grid.mnMaxX && v >= grid.mnMinY && v < grid.mnMaxY)) continue; /* KeyFrame::IsInImage */
-        const float maxDistance = max_dist[i], minDistance = min_dist[i];
+        const float maxDistance = GetMaxDistanceInvariance(max_dist[i]), minDistance = GetMinDistanceInvariance(min_dist[i]);
         const float PO[3] = {X - Ow[0], Y - Ow[1], Z - Ow[2]};
         const float dist3D = std::sqrt((double)PO[0] * PO[0] + (double)PO[1] * PO[1] + (double)PO[2] * PO[2]); /* cv::norm */
         if (dist3D < minDistance || dist3D > maxDistance) continue;
         const double dot = (double)PO[0] * normal[3 * i] + (double)PO[1] * normal[3 * i + 1] + (double)PO[2] * normal[3 * i + 2];
         if (dot < 0.5 * dist3D) continue;
-        float ratio = maxDistance / dist3D;
-        int nPredictedLevel = (int)std::ceil(std::log((double)ratio) / mfLogScaleFactor);
-        if (nPredictedLevel < 0) nPredictedLevel = 0;
-        else if (nPredictedLevel >= nlevels) nPredictedLevel = nlevels - 1;
+        const int nPredictedLevel = PredictScale(max_dist[i], dist3D, mfLogScaleFactor, nlevels);
         const float radius = th * mvScaleFactors[nPredictedLevel];
         const std::vector<int> vIndices = grid.GetFeaturesInArea(u, v, radius, -1, -1);
         if (vIndices.empty()) continue;
@@ -681,11 +695,8 @@ int oracle_search_by_sim3(const void* kps1_, const uint8_t* desc1, int n1, const
             const float v = fy * y + cy;
             if (!(u >= gridB.mnMinX && u < gridB.mnMaxX && v >= gridB.mnMinY && v < gridB.mnMaxY)) continue;
             const float dist3D = std::sqrt((double)cB[0] * cB[0] + (double)cB[1] * cB[1] + (double)cB[2] * cB[2]);
-            if (dist3D < mind[i] || dist3D > maxd[i]) continue;
-            float ratio = maxd[i] / dist3D;
-            int nPredictedLevel = (int)std::ceil(std::log((double)ratio) / mfLogScaleFactor);
-            if (nPredictedLevel < 0) nPredictedLevel = 0;
-            else if (nPredictedLevel >= nlevels) nPredictedLevel = nlevels - 1;
+            if (dist3D < GetMinDistanceInvariance(mind[i]) || dist3D > GetMaxDistanceInvariance(maxd[i])) continue;
+            const int nPredictedLevel = PredictScale(maxd[i], dist3D, mfLogScaleFactor, nlevels);
             const float radius = th * mvScaleFactors[nPredictedLevel];
             const std::vector<int> vIndices = gridB.GetFeaturesInArea(u, v, radius, -1, -1);
             if (vIndices.empty()) continue;
@@ -742,13 +753,10 @@ int oracle_search_by_projection_sim3(const void* kps_, const uint8_t* desc, int 
         if (!(u >= grid.mnMinX && u < grid.mnMaxX && v >= grid.mnMinY && v < grid.mnMaxY)) continue;
         const float PO[3] = {X - Ow[0], Y - Ow[1], Z - Ow[2]};
         const float dist = std::sqrt((double)PO[0] * PO[0] + (double)PO[1] * PO[1] + (double)PO[2] * PO[2]);
-        if (dist < min_dist[iMP] || dist > max_dist[iMP]) continue;
+        if (dist < GetMinDistanceInvariance(min_dist[iMP]) || dist > GetMaxDistanceInvariance(max_dist[iMP])) continue;
         const double dot = (double)PO[0] * normal[3 * iMP] + (double)PO[1] * normal[3 * iMP + 1] + (double)PO[2] * normal[3 * iMP + 2];
         if (dot < 0.5 * dist) continue;
-        float ratio = max_dist[iMP] / dist;
-        int nPredictedLevel = (int)std::ceil(std::log((double)ratio) / mfLogScaleFactor);
-        if (nPredictedLevel < 0) nPredictedLevel = 0;
-        else if (nPredictedLevel >= nlevels) nPredictedLevel = nlevels - 1;
+        const int nPredictedLevel = PredictScale(max_dist[iMP], dist, mfLogScaleFactor, nlevels);
         const float radius = th * mvScaleFactors[nPredictedLevel];
         const std::vector<int> vIndices = grid.GetFeaturesInArea(u, v, radius, -1, -1);
         if (vIndices.empty()) continue;
@@ -768,6 +776,91 @@ int oracle_search_by_projection_sim3(const void* kps_, const uint8_t* desc, int 
         }
     }
     return nmatches;
+}
+
+/* ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, th, ORBdist)
+ * (src/ORBmatcher.cc:1476-1603; what Tracking::Relocalization runs with (th, ORBdist) = (10, 100) and (3, 64), Tracking.cc:1858,
+ * :1875) on flat arrays.  Per feature i of the keyframe: valid[i] = "pMP && !pMP->isBad() && !sAlreadyFound.count(pMP)" (:1494-1498),
+ * p3Dw = GetWorldPos(), min_dist / max_dist = mfMinDistance / mfMaxDistance, mp_desc = GetDescriptor(), kf_angle[i] =
+ * pKF->mvKeysUn[i].angle.  taken_cur[i2] = CurrentFrame.mvpMapPoints[i2] != NULL on entry; a keypoint that receives a point is
+ * taken for the points after it (:1547-1548, :1561).  The projection has NO positive-depth gate here (:1503-1512), invzc is
+ * `1.0 / z` evaluated in double, u = fx * xc * invzc + cx left to right, Frame bounds (<=).  Ow = -Rcw' * tcw is the caller's
+ * (:1482).  match_cur[i2] = i (the keypoint received the map point of keyframe feature i) or -1; returns nmatches. */
+int oracle_search_by_projection_keyframe(const void* kps_cur_, const uint8_t* desc_cur, int n_cur, const uint8_t* taken_cur, int cols,
+                                         int rows, const float* bounds, int n_kf, const float* kf_angle, const uint8_t* valid,
+                                         const float* p3Dw, const float* min_dist, const float* max_dist, const uint8_t* mp_desc,
+                                         const float* Tcw, const float* Ow, const float* K4, const float* mvScaleFactors, int nlevels,
+                                         float mfLogScaleFactor, float th, int ORBdist, int check_orientation, int32_t* match_cur)
+{
+    const KeyPoint* kc = (const KeyPoint*)kps_cur_;
+    FrameGrid grid(kc, n_cur, cols, rows, bounds);
+    const float fx = K4[0], fy = K4[1], cx = K4[2], cy = K4[3];
+    int nmatches = 0;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    std::vector<uint8_t> mvpMapPoints(n_cur, 0);
+    for (int i = 0; i < n_cur; i++) { match_cur[i] = -1; mvpMapPoints[i] = taken_cur ? taken_cur[i] : 0; }
+    for (int i = 0; i < n_kf; i++) {
+        if (valid && !valid[i]) continue;
+        const float X = p3Dw[3 * i], Y = p3Dw[3 * i + 1], Z = p3Dw[3 * i + 2];
+        float t0 = Tcw[0] * X + Tcw[1] * Y + Tcw[2] * Z, t1 = Tcw[4] * X + Tcw[5] * Y + Tcw[6] * Z, t2 = Tcw[8] * X + Tcw[9] * Y + Tcw[10] * Z;
+        const float xc = (float)(t0 * 1.0 + 1.0 * Tcw[3]);
+        const float yc = (float)(t1 * 1.0 + 1.0 * Tcw[7]);
+        const float zc = (float)(t2 * 1.0 + 1.0 * Tcw[11]);
+        const float invzc = 1.0 / zc;
+        const float u = fx * xc * invzc + cx;
+        const float v = fy * yc * invzc + cy;
+        if (u < grid.mnMinX || u > grid.mnMaxX) continue;
+        if (v < grid.mnMinY || v > grid.mnMaxY) continue;
+        if (u != u || v != v) continue; /* NaN: undefined in the reference (grid indices from NaN); dropped */
+        const float PO[3] = {X - Ow[0], Y - Ow[1], Z - Ow[2]};
+        float dist3D = std::sqrt((double)PO[0] * PO[0] + (double)PO[1] * PO[1] + (double)PO[2] * PO[2]); /* cv::norm */
+        const float maxDistance = GetMaxDistanceInvariance(max_dist[i]);
+        const float minDistance = GetMinDistanceInvariance(min_dist[i]);
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        int nPredictedLevel = PredictScale(max_dist[i], dist3D, mfLogScaleFactor, nlevels);
+        const float radius = th * mvScaleFactors[nPredictedLevel];
+        const std::vector<int> vIndices2 = grid.GetFeaturesInArea(u, v, radius, nPredictedLevel - 1, nPredictedLevel + 1);
+        if (vIndices2.empty()) continue;
+        const uint8_t* dMP = mp_desc + 32 * (size_t)i;
+        int bestDist = 256, bestIdx2 = -1;
+        for (size_t k = 0; k < vIndices2.size(); k++) {
+            const int i2 = vIndices2[k];
+            if (mvpMapPoints[i2]) continue;
+            const int dist = DescriptorDistance(dMP, desc_cur + 32 * (size_t)i2);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= ORBdist) {
+            mvpMapPoints[bestIdx2] = 1;
+            match_cur[bestIdx2] = i;
+            nmatches++;
+            if (check_orientation) {
+                float rot = kf_angle[i] - kc[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)std::round(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(bestIdx2);
+            }
+        }
+    }
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1, sizes[HISTO_LENGTH];
+        for (int i = 0; i < HISTO_LENGTH; i++) sizes[i] = (int)rotHist[i].size();
+        ComputeThreeMaxima(sizes, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (size_t j = 0; j < rotHist[i].size(); j++) {
+                    match_cur[rotHist[i][j]] = -1; /* CurrentFrame.mvpMapPoints[...] = NULL */
+                    nmatches--;
+                }
+    }
+    return nmatches;
+}
+
+/* MapPoint::PredictScale alone, for the known-answer tests */
+int oracle_predict_scale(float mfMaxDistance, float currentDist, float mfLogScaleFactor, int mnScaleLevels)
+{
+    return PredictScale(mfMaxDistance, currentDist, mfLogScaleFactor, mnScaleLevels);
 }
 
 void oracle_three_maxima(const int* sizes, int L, int* out3)

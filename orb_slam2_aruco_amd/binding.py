@@ -40,7 +40,7 @@ SYMBOLS = [
     "orbfe_vocabulary_transform", "orbfe_vocabulary_transform_batch_device",
     "orbfe_search_by_bow", "orbfe_search_by_bow_batch_device",
     "orbfe_search_for_triangulation", "orbfe_search_for_triangulation_batch_device",
-    "orbfe_search_by_projection_last_frame", "orbfe_search_by_projection_best", "orbfe_fuse_search", "orbfe_project_map_points", "orbfe_search_by_sim3", "orbfe_search_by_projection_sim3",
+    "orbfe_search_by_projection_last_frame", "orbfe_search_by_projection_best", "orbfe_search_by_projection_keyframe", "orbfe_fuse_search", "orbfe_project_map_points", "orbfe_search_by_sim3", "orbfe_search_by_projection_sim3",
     "orbfe_keyframe_features_pack", "orbfe_keyframe_features_unpack", "orbfe_keyframe_features_pack_device",
     "orbfe_keyframe_features_unpack_device",
 ]
@@ -95,6 +95,8 @@ def load():
         L.orbfe_search_by_projection_sim3.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, f32, i32,
                                                       vp, vp, i32]
         L.orbfe_project_map_points.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp, i32, vp, i32, f32, f32, i32, i32, vp, i32]
+        L.orbfe_search_by_projection_keyframe.argtypes = [vp, vp, i32, vp, i32, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32,
+                                                          i32, i32, vp, vp, i32]
         L.orbfe_search_by_projection_best.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp, i32, i32, f32, vp, vp, i32]
         L.orbfe_undistort_points.argtypes = [vp, i32, vp, vp, i32, vp, i32]
         L.orbfe_undistort_keypoints_batch_device.argtypes = [vp, vp, i32, i32, vp, vp, i32, vp, vp]
@@ -446,9 +448,28 @@ def fuse_search(kps, desc, cols, rows, p3Dw, valid, min_dist, max_dist, normal, 
     return bi, bd
 
 
+def search_by_projection_keyframe(kps_cur, desc_cur, cols, rows, kf_angle, valid, p3Dw, min_dist, max_dist, mp_desc, Tcw, Ow, K4, scale_factors,
+                                  log_scale_factor, th, orb_dist, taken_cur=None, check_orientation=True, bounds=None, device=0):
+    """ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:1476-1603) -> (nmatches, match_cur)."""
+    L = load()
+    kc = np.ascontiguousarray(kps_cur, KP_DTYPE); dc = np.ascontiguousarray(desc_cur, np.uint8).reshape(-1, 32)
+    f = lambda a, t=np.float32: np.ascontiguousarray(a, t)
+    x, mn, mx, md, ang = f(p3Dw).reshape(-1, 3), f(min_dist), f(max_dist), f(mp_desc, np.uint8).reshape(-1, 32), f(kf_angle)
+    opt = lambda a, t: None if a is None else np.ascontiguousarray(a, t)
+    v, tc, bnd = opt(valid, np.uint8), opt(taken_cur, np.uint8), opt(bounds, np.float32)
+    T, O, K, sf = f(Tcw).reshape(-1)[:12].copy(), f(Ow), f(K4), f(scale_factors)
+    m = np.full(len(kc), -1, np.int32); nm = C.c_int32(0)
+    pp = lambda a: None if a is None else _p(a)
+    _check(L, L.orbfe_search_by_projection_keyframe(_p(kc), _p(dc), len(kc), pp(tc), cols, rows, pp(bnd), len(x), _p(ang), pp(v), _p(x), _p(mn),
+                                                    _p(mx), _p(md), _p(T), _p(O), _p(K), _p(sf), len(sf), log_scale_factor, th, int(orb_dist),
+                                                    int(check_orientation), _p(m), C.byref(nm), device), "orbfe_search_by_projection_keyframe")
+    return nm.value, m
+
+
 def project_map_points(p3Dw, valid, min_dist, max_dist, normal, Tcw, Ow, K4, cols, rows, scale_factors, log_scale_factor, th, level_below,
                        level_above, strict_max=True, bounds=None, device=0):
-    """Projection + gates + PredictScale -> WINDOW_QUERY_DTYPE records (r < 0 = not searched)."""
+    """Projection + gates + PredictScale -> WINDOW_QUERY_DTYPE records (r < 0 = not searched).  strict_max=False selects the
+    projection of SearchByProjection(CurrentFrame, pKF, ...) (ORBmatcher.cc:1503-1512), see orbfe.h."""
     L = load()
     f = lambda a, t=np.float32: np.ascontiguousarray(a, t)
     x, mn, mx = f(p3Dw).reshape(-1, 3), f(min_dist), f(max_dist)

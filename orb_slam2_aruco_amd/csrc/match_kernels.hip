@@ -1276,13 +1276,18 @@ int orbfe_search_by_projection(const orbfe_keypoint* kps, const uint8_t* desc, i
     return ORBFE_OK;
 }
 
-// shared plumbing of the two "best only" entry points: queries either come from the host or are projected on the device
+static int project_run(MatchWorkspace& w, const float* p3Dw, const uint8_t* valid, const float* min_dist, const float* max_dist,
+                       const float* normal, int n, const ProjectParams& P);
+
+// shared plumbing of the "best only" entry points: queries either come from the host or are projected on the device
 static int sbp_best_run(const orbfe_keypoint* kps, const uint8_t* desc, int n, int cols, int rows, const float* bounds,
                         const orbfe_window_query* queries, const float* q_angle, const uint8_t* qdesc, const uint8_t* q_blocks, int nq,
                         const uint8_t* taken, int th_high, int check_ori, float factor, int32_t* match_cur, int32_t* nmatches,
                         // projection request (x3Dw != NULL): the queries are built on the device
                         const float* x3Dw, const uint8_t* valid, const orbfe_keypoint* kps_last, const float* Tcw, const float* K4,
-                        const float* scale, int nlevels, float th)
+                        const float* scale, int nlevels, float th,
+                        // map-point projection request (PP != NULL): k_project_map_points builds the queries from x3Dw / valid / the distances
+                        const ProjectParams* PP = nullptr, const float* min_dist = nullptr, const float* max_dist = nullptr)
 {
     if (n > 65535) return fail(ORBFE_ERR_INVALID, "more than 65535 keypoints per frame are unsupported");
     *nmatches = 0;
@@ -1302,7 +1307,7 @@ static int sbp_best_run(const orbfe_keypoint* kps, const uint8_t* desc, int n, i
             (rc = w.prev.ensure((size_t)n)) || (rc = w.csr_idx.ensure((size_t)nq * stride * 2)) ||
             (rc = w.csr_dist.ensure((size_t)nq * stride)) || (rc = w.csr_cnt.ensure(qo)) || (rc = w.obest.ensure(qo * 3)) ||
             (rc = w.nm.ensure(16)) || (rc = w.overflow.ensure(16)) || (rc = w.m12.ensure((size_t)n * 4)) ||
-            (rc = w.scratch.ensure((size_t)nq * 16 + 256)) || (rc = w.pidx.ensure((size_t)nq * sizeof(orbfe_keypoint) + nq + 256)))
+            (rc = w.scratch.ensure((size_t)nq * 32 + 256)) || (rc = w.pidx.ensure((size_t)nq * sizeof(orbfe_keypoint) + nq + 256)))
             return rc;
         ORBFE_HIP(hipMemcpy(w.kps.p, kps, (size_t)n * sizeof(orbfe_keypoint), hipMemcpyHostToDevice));
         ORBFE_HIP(hipMemcpy(w.desc.p, desc, (size_t)n * 32, hipMemcpyHostToDevice));
@@ -1311,7 +1316,12 @@ static int sbp_best_run(const orbfe_keypoint* kps, const uint8_t* desc, int n, i
         // scratch: [q_angle f32 x nq | x3Dw f32 x 3nq]; pidx: [kps_last | valid / blocks bytes]
         float* d_angle = w.scratch.as<float>();
         uint8_t* d_flags = w.pidx.as<uint8_t>() + (size_t)nq * sizeof(orbfe_keypoint);
-        if (x3Dw) {
+        if (PP) {
+            // the staging of project_run shares w.scratch / w.pidx (already large enough: no reallocation) with the arrays below
+            if ((rc = project_run(w, x3Dw, valid, min_dist, max_dist, nullptr, nq, *PP))) return rc;
+            ORBFE_HIP(hipDeviceSynchronize());
+            ORBFE_HIP(hipMemcpy(d_angle, q_angle, (size_t)nq * 4, hipMemcpyHostToDevice));
+        } else if (x3Dw) {
             float* d_x = d_angle + nq;
             ORBFE_HIP(hipMemcpy(d_x, x3Dw, (size_t)nq * 12, hipMemcpyHostToDevice));
             ORBFE_HIP(hipMemcpy(w.pidx.p, kps_last, (size_t)nq * sizeof(orbfe_keypoint), hipMemcpyHostToDevice));
@@ -1562,6 +1572,28 @@ int orbfe_search_by_projection_sim3(const orbfe_keypoint* kps, const uint8_t* de
     if (rc) return rc;
     return orbfe_search_by_projection_best(kps, desc, n, cols, rows, bounds, q.data(), nullptr, mp_desc, nullptr, nmp, matched, 50, 0, 0.0f,
                                            match_kf, nmatches, device);
+}
+
+int orbfe_search_by_projection_keyframe(const orbfe_keypoint* kps_cur, const uint8_t* desc_cur, int n_cur, const uint8_t* taken_cur, int cols,
+                                        int rows, const float* bounds, int n_kf, const float* kf_angle, const uint8_t* valid, const float* p3Dw,
+                                        const float* min_dist, const float* max_dist, const uint8_t* mp_desc, const float* Tcw, const float* Ow,
+                                        const float* K4, const float* scale_factors, int nlevels, float log_scale_factor, float th, int orb_dist,
+                                        int check_orientation, int32_t* match_cur, int32_t* nmatches, int device)
+{
+    if (n_cur < 0 || n_kf < 0 || !nmatches || (n_cur && (!kps_cur || !desc_cur || !match_cur)) ||
+        (n_kf && (!p3Dw || !min_dist || !max_dist || !mp_desc || (check_orientation && !kf_angle))))
+        return fail(ORBFE_ERR_INVALID, "orbfe_search_by_projection_keyframe: invalid argument");
+    ProjectParams P;
+    // :1497-1530: Frame arithmetic and bounds, no viewing-angle gate, levels predicted - 1 .. predicted + 1 (:1532)
+    int rc = project_params(P, Tcw, Ow, K4, cols, rows, bounds, 0, scale_factors, nlevels, log_scale_factor, th, 1, 1,
+                            "orbfe_search_by_projection_keyframe");
+    P.frame_variant = 1;
+    if (rc || (rc = use_device(device))) return rc;
+    std::vector<float> zero;
+    if (!kf_angle) { zero.assign(std::max(n_kf, 1), 0.0f); kf_angle = zero.data(); }
+    return sbp_best_run(kps_cur, desc_cur, n_cur, cols, rows, bounds, nullptr, kf_angle, mp_desc, nullptr, n_kf, taken_cur, orb_dist,
+                        check_orientation, 1.0f / 30 /* :1488 */, match_cur, nmatches, p3Dw, valid, nullptr, nullptr, nullptr, nullptr, 0, 0.0f,
+                        &P, min_dist, max_dist);
 }
 
 int orbfe_knn2_csr(const uint8_t* Q, int nq, const uint8_t* T, int nt, const int32_t* offsets, const int32_t* idx, int init,

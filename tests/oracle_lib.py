@@ -377,6 +377,36 @@ def search_by_projection_last_frame(kps_cur, desc_cur, cols, rows, kps_last, val
     return nm, m[:len(kc)]
 
 
+def search_by_projection_keyframe(kps_cur, desc_cur, cols, rows, kf_angle, valid, p3Dw, min_dist, max_dist, mp_desc, Tcw, Ow, K4, scale_factors,
+                                  log_scale_factor, th, orb_dist, taken_cur=None, check_orientation=True, bounds=None):
+    """ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:1476-1603) -> (nmatches, match_cur)."""
+    L = lib()
+    kc = np.ascontiguousarray(kps_cur, KP_DTYPE); dc = np.ascontiguousarray(desc_cur, np.uint8).reshape(-1, 32)
+    f = lambda a, t=np.float32: np.ascontiguousarray(a, t)
+    x, mn, mx, md, ang = f(p3Dw).reshape(-1, 3), f(min_dist), f(max_dist), f(mp_desc, np.uint8).reshape(-1, 32), f(kf_angle)
+    opt = lambda a, t: None if a is None else np.ascontiguousarray(a, t)
+    v, tc, bnd = opt(valid, np.uint8), opt(taken_cur, np.uint8), opt(bounds, np.float32)
+    T, O, K, sf = f(Tcw).reshape(-1)[:12].copy(), f(Ow), f(K4), f(scale_factors)
+    m = np.full(max(len(kc), 1), -1, np.int32)
+    pp = lambda a: None if a is None else _p(a)
+    vp = C.c_void_p
+    L.oracle_search_by_projection_keyframe.restype = C.c_int
+    L.oracle_search_by_projection_keyframe.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                                       C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, vp]
+    nm = L.oracle_search_by_projection_keyframe(_p(kc), _p(dc), len(kc), pp(tc), cols, rows, pp(bnd), len(x), _p(ang), pp(v), _p(x), _p(mn),
+                                                _p(mx), _p(md), _p(T), _p(O), _p(K), _p(sf), len(sf), log_scale_factor, th, int(orb_dist),
+                                                int(check_orientation), _p(m))
+    return nm, m[:len(kc)]
+
+
+def predict_scale(max_distance, dist, log_scale_factor, nlevels):
+    """MapPoint::PredictScale (MapPoint.cc:414-446)."""
+    L = lib()
+    L.oracle_predict_scale.restype = C.c_int
+    L.oracle_predict_scale.argtypes = [C.c_float, C.c_float, C.c_float, C.c_int]
+    return L.oracle_predict_scale(max_distance, dist, log_scale_factor, nlevels)
+
+
 def search_for_triangulation(kps1, desc1, fv1, kps2, desc2, fv2, F12, epipole, scale_factors, level_sigma2, has_mp1=None, has_mp2=None,
                              check_orientation=True):
     L = lib()

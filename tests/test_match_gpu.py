@@ -324,8 +324,9 @@ def test_search_by_projection_last_frame_edges(orbfe, oracle):
 def _map_points_for(kl, x3, Tcw, rng, sf):
     """Scale-invariance range, normal and camera centre for map points observed at octave kl.octave from the identity pose."""
     d0 = np.linalg.norm(x3.astype(np.float64), axis=1)
-    max_d = (d0 * sf[kl["octave"]] * rng.uniform(0.9, 1.3, len(kl))).astype(np.float32)
-    min_d = (max_d / sf[-1] * rng.uniform(0.8, 1.0, len(kl))).astype(np.float32)
+    # mfMaxDistance / mfMinDistance as MapPoint::UpdateNormalAndDepth sets them (MapPoint.cc:395-397), with some spread
+    max_d = (d0 * sf[kl["octave"]] * rng.uniform(0.8, 1.15, len(kl))).astype(np.float32)
+    min_d = (max_d / sf[-1] * rng.uniform(0.95, 1.2, len(kl))).astype(np.float32)
     nrm = x3 / np.maximum(d0, 1e-9)[:, None] + 0.3 * rng.normal(size=x3.shape)
     nrm = (nrm / np.linalg.norm(nrm, axis=1)[:, None]).astype(np.float32)
     flip = rng.random(len(kl)) < 0.05
@@ -357,10 +358,51 @@ def test_fuse_search(orbfe, oracle, seed, th, chi2):
     q = orbfe.project_map_points(x3, valid, min_d, max_d, nrm, Tcw, Ow, K4, 640, 480, sf, logsf, th, 1, 0)
     assert np.all(q["r"][got[0] >= 0] > 0) and np.all(q["r"][valid == 0] < 0)
     assert np.all(q["max_level"][q["r"] > 0] - q["min_level"][q["r"] > 0] == 1)
-    # SearchByProjection(CurrentFrame, KeyFrame, ...) (:1476-1603) = this projection (levels +-1, no viewing gate, Frame bounds) + the best-only loop
-    q2 = orbfe.project_map_points(x3, valid, min_d, max_d, None, Tcw, Ow, K4, 640, 480, sf, logsf, th, 1, 1, strict_max=False)
-    nm, mc = orbfe.search_by_projection_best(kc, dc, 640, 480, q2, kl["angle"], dl, 100, 1.0 / 30)
-    assert nm == (mc >= 0).sum() and nm > 20
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,th,orb_dist", [(1, 10.0, 100), (2, 3.0, 64), (3, 10.0, 64), (4, 3.0, 100)])
+def test_search_by_projection_keyframe(orbfe, oracle, seed, th, orb_dist):
+    """SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:1476-1603; Relocalization calls it with
+    (10, 100) and (3, 64), Tracking.cc:1858, :1875) against its restatement: the dist3D range gate, PredictScale on mfMaxDistance,
+    radius th * scale[level], levels +-1, bestDist <= ORBdist, the taken-keypoint coupling, the rotation histogram -- bit-exact,
+    through the dedicated entry point AND as orbfe_project_map_points(keyframe_variant = 0, normal = NULL, levels +-1) +
+    orbfe_search_by_projection_best."""
+    kc, dc, kl, dl, x3, Tcw, K4, sf, rng = _motion_case(oracle, seed)
+    if th < 5 or orb_dist < 100:  # the narrow second pass runs on an optimised pose (Tracking.cc:1875): the keyframe's own keypoints, a tenth of the motion
+        kc, dc = kl, dl
+        Tcw = (np.eye(3, 4) + 0.1 * (Tcw.astype(np.float64) - np.eye(3, 4))).astype(np.float32)
+    min_d, max_d, _, Ow = _map_points_for(kl, x3, Tcw, rng, sf)
+    # some points lie BEHIND the camera: this variant has no depth gate (:1503-1512) and still projects them
+    behind = rng.random(len(kl)) < 0.05
+    x3 = x3.copy(); x3[behind, 2] *= -1
+    valid = (rng.random(len(kl)) < 0.85).astype(np.uint8)                # has a map point, not bad, not in sAlreadyFound
+    taken = (rng.random(len(kc)) < 0.15).astype(np.uint8)                # CurrentFrame.mvpMapPoints[i2] != NULL
+    logsf = np.float32(np.log(np.float32(1.2)))
+    want = oracle.search_by_projection_keyframe(kc, dc, 640, 480, kl["angle"], valid, x3, min_d, max_d, dl, Tcw, Ow, K4, sf, logsf, th, orb_dist,
+                                                taken_cur=taken)
+    got = orbfe.search_by_projection_keyframe(kc, dc, 640, 480, kl["angle"], valid, x3, min_d, max_d, dl, Tcw, Ow, K4, sf, logsf, th, orb_dist,
+                                              taken_cur=taken)
+    assert got[0] == want[0] and np.array_equal(got[1], want[1])
+    assert got[0] > 20 and got[0] == (got[1] >= 0).sum() and np.all(got[1][taken == 1] == -1)
+    assert np.all(valid[got[1][got[1] >= 0]] == 1)
+    # the composition the header documents
+    q = orbfe.project_map_points(x3, valid, min_d, max_d, None, Tcw, Ow, K4, 640, 480, sf, logsf, th, 1, 1, strict_max=False)
+    nm, mc = orbfe.search_by_projection_best(kc, dc, 640, 480, q, kl["angle"], dl, orb_dist, 1.0 / 30, taken=taken)
+    assert nm == want[0] and np.array_equal(mc, want[1])
+    assert np.all(q["max_level"][q["r"] > 0] - q["min_level"][q["r"] > 0] == 2)
+    # without the orientation check and with distorted-camera bounds
+    b = np.array([-14.25, -9.5, 655.75, 489.0], np.float32)
+    want = oracle.search_by_projection_keyframe(kc, dc, 640, 480, kl["angle"], None, x3, min_d, max_d, dl, Tcw, Ow, K4, sf, logsf, th, orb_dist,
+                                                check_orientation=False, bounds=b)
+    got = orbfe.search_by_projection_keyframe(kc, dc, 640, 480, kl["angle"], None, x3, min_d, max_d, dl, Tcw, Ow, K4, sf, logsf, th, orb_dist,
+                                              check_orientation=False, bounds=b)
+    assert got[0] == want[0] and np.array_equal(got[1], want[1])
+    # nothing valid, empty sides
+    none = np.zeros(len(kl), np.uint8)
+    assert orbfe.search_by_projection_keyframe(kc, dc, 640, 480, kl["angle"], none, x3, min_d, max_d, dl, Tcw, Ow, K4, sf, logsf, th, orb_dist)[0] == 0
+    assert orbfe.search_by_projection_keyframe(kc[:0], dc[:0], 640, 480, kl["angle"], None, x3, min_d, max_d, dl, Tcw, Ow, K4, sf, logsf, th,
+                                               orb_dist)[0] == 0
 
 
 @pytest.mark.gpu
@@ -385,8 +427,8 @@ def test_search_by_sim3(orbfe, oracle, seed, th, s12):
 
     def kf(x3, cam_T):
         d0 = np.linalg.norm((x3.astype(np.float64) @ cam_T[:, :3].T + cam_T[:, 3]), axis=1)
-        mx = (d0 * sf[kl["octave"]] * rng.uniform(0.9, 1.3, len(kl))).astype(np.float32)
-        mn = (mx / sf[-1] * rng.uniform(0.8, 1.0, len(kl))).astype(np.float32)
+        mx = (d0 * sf[kl["octave"]] * rng.uniform(0.8, 1.15, len(kl))).astype(np.float32)
+        mn = (mx / sf[-1] * rng.uniform(0.95, 1.2, len(kl))).astype(np.float32)
         return dict(kps=kl, desc=dl, p3Dw=x3, valid=(rng.random(len(kl)) < 0.85).astype(np.uint8), min_dist=mn, max_dist=mx, mp_desc=dl)
     kf1, kf2 = kf(x1, T1w), kf(x2, T2w)
     want = oracle.search_by_sim3(kf1, kf2, 640, 480, T1w, T2w, sT12, sT21, K4, sf, logsf, th)

@@ -526,3 +526,61 @@ def test_golden_extras(oracle):
     assert nl == int(g["last_nmatches"][0]) and np.array_equal(ml, g["last_match_cur"])
     rec = oracle.keyframe_features_pack(m["k1"], m["d1"], np.arange(len(m["k1"]), dtype=np.uint64))
     assert np.array_equal(np.frombuffer(hashlib.sha256(rec.tobytes()).digest(), np.uint8), g["kf_sha256"])
+
+
+# ---------------------------------------------------------------- PredictScale / relocalisation search (a13)
+def test_predict_scale_known_answers(oracle):
+    """MapPoint::PredictScale (MapPoint.cc:414-446): ceil(logf(mfMaxDistance / dist) / mfLogScaleFactor), clamped to [0, nlevels - 1]."""
+    L = float(np.log(np.float32(1.2)))
+    assert oracle.predict_scale(1.5, 1.0, L, 8) == 3          # log(1.5) / log(1.2) = 2.22
+    assert oracle.predict_scale(1.0, 1.0, L, 8) == 0          # ratio 1
+    assert oracle.predict_scale(1.0, 2.0, L, 8) == 0          # ratio < 1: negative -> 0
+    assert oracle.predict_scale(100.0, 1.0, L, 8) == 7        # 25.3 -> nlevels - 1
+    assert oracle.predict_scale(1.25, 1.0, L, 8) == 2         # just above one level
+    assert oracle.predict_scale(2.0, 1.0, L, 12) == 4         # 3.80
+
+
+def test_float_log_choice_is_immaterial():
+    """The reference evaluates PredictScale's log as logf (float overload); the device uses the correctly rounded float log.
+    glibc's logf differs from it on a small share of inputs, and the predicted level never changes on 10^6 random ratios."""
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6")
+    libm.logf.restype = ctypes.c_float; libm.logf.argtypes = [ctypes.c_float]
+    r = np.random.default_rng(3).uniform(0.3, 6.0, 1_000_000).astype(np.float32)
+    cr = np.log(r.astype(np.float64)).astype(np.float32)
+    sample = r[:20000]
+    lm = np.array([libm.logf(float(x)) for x in sample], np.float32)
+    differ = float((lm != cr[:20000]).mean())
+    assert differ < 0.02, differ
+    L = np.float32(np.log(np.float32(1.2)))
+    lv_cr = np.ceil(cr[:20000] / L)
+    lv_lm = np.ceil(lm / L)
+    assert np.array_equal(lv_cr, lv_lm)
+
+
+def test_search_by_projection_keyframe_hand_case(oracle):
+    """ORBmatcher.cc:1476-1603 on a hand-built frame: a point straight ahead is matched at its keypoint; a point BEHIND the
+    camera is projected all the same (this variant has no depth gate, :1503-1512) and takes the keypoint at its mirror image;
+    a point outside [0.8 mfMin, 1.2 mfMax] is skipped; ORBdist is honoured; a taken keypoint is not reused."""
+    K4 = np.array([500.0, 500.0, 320.0, 240.0], np.float32)
+    sf = np.array([1.2 ** i for i in range(8)], np.float32)
+    L = np.float32(np.log(np.float32(1.2)))
+    kps = np.zeros(3, oracle.KP_DTYPE)
+    kps["x"] = [320.0, 420.0, 100.0]; kps["y"] = [240.0, 240.0, 100.0]; kps["octave"] = [0, 1, 0]; kps["angle"] = [10.0, 10.0, 10.0]
+    d = np.zeros((3, 32), np.uint8); d[1, 0] = 0xFF; d[2, :4] = 0xFF
+    T = np.eye(3, 4, dtype=np.float32); Ow = np.zeros(3, np.float32)
+    p = np.array([[0, 0, 2.0], [-0.4, 0, -2.0], [0, 0, 2.0], [0, 0, 50.0]], np.float32)   # ahead; behind -> u = 420; duplicate; too far
+    mfmax = np.array([2.0, 2.3, 2.0, 2.0], np.float32); mfmin = mfmax / sf[-1]
+    md = np.zeros((4, 32), np.uint8); md[1, 0] = 0xFF
+    ang = np.array([10.0, 10.0, 10.0, 10.0], np.float32)
+    n, m = oracle.search_by_projection_keyframe(kps, d, 640, 480, ang, None, p, mfmin, mfmax, md, T, Ow, K4, sf, L, 10.0, 100, check_orientation=False)
+    assert n == 2 and m.tolist() == [0, 1, -1]
+    # ORBdist: keypoint 1's descriptor is 8 bits away from a zero descriptor
+    md2 = md.copy(); md2[1, 0] = 0
+    assert oracle.search_by_projection_keyframe(kps, d, 640, 480, ang, None, p, mfmin, mfmax, md2, T, Ow, K4, sf, L, 10.0, 7, check_orientation=False)[0] == 1
+    assert oracle.search_by_projection_keyframe(kps, d, 640, 480, ang, None, p, mfmin, mfmax, md2, T, Ow, K4, sf, L, 10.0, 8, check_orientation=False)[0] == 2
+    # taken keypoint 0: nothing else lies in the window of the points ahead
+    tk = np.array([1, 0, 0], np.uint8)
+    n, m = oracle.search_by_projection_keyframe(kps, d, 640, 480, ang, None, p, mfmin, mfmax, md, T, Ow, K4, sf, L, 10.0, 100, taken_cur=tk,
+                                                check_orientation=False)
+    assert n == 1 and m.tolist() == [-1, 1, -1]
