@@ -95,17 +95,20 @@ __device__ __forceinline__ v4i spread16(uint32_t bits)
 
 __global__ __launch_bounds__(KM_WAVES * 64) void k_knn2_mfma(const uint8_t* __restrict__ Q, const int32_t* __restrict__ nq_arr,
                                                              size_t q_stride, int max_nq, const uint8_t* __restrict__ T,
-                                                             const int32_t* __restrict__ nt_arr, size_t t_stride,
+                                                             const int32_t* __restrict__ nt_arr, size_t t_stride, int chunk,
                                                              int init, int32_t* __restrict__ best_idx,
                                                              int32_t* __restrict__ best_dist,
                                                              int32_t* __restrict__ second_dist)
 {
+    // grid: (query tiles, pairs, nsplit).  Split z handles train rows [z * chunk, (z + 1) * chunk) and writes partials
+    // [pair][split][max_nq] for k_knn2_merge, exactly as k_knn2_tiles does; with one split they are the final arrays.
     __shared__ __align__(16) unsigned char s_t[KM_CHUNK * KM_ROWB]; // spread train descriptors of the current chunk
     __shared__ int s_pt[KM_CHUNK];                                  // their popcounts
     __shared__ int s_red[KM_WAVES][32][33];                         // final cross-lane merge (keys)
     const int pair = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int nq = nq_arr ? nq_arr[pair] : max_nq;
-    const int nt = nt_arr[pair];
+    const int split = blockIdx.z, nsplit = gridDim.z;
+    const int t_begin = split * chunk, nt = min(nt_arr[pair], t_begin + chunk);
     const int q0 = blockIdx.x * (KM_WAVES * 32);
     if (q0 >= nq) return;
     const uint32_t* Qp = reinterpret_cast<const uint32_t*>(Q + (size_t)pair * q_stride);
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(KM_WAVES * 64) void k_knn2_mfma(const uint8_t* __re
         bestk[r] = secondk[r] = (ie - pq) * 65536;
     }
 
-    for (int t0 = 0; t0 < nt; t0 += KM_CHUNK) {
+    for (int t0 = t_begin; t0 < nt; t0 += KM_CHUNK) {
         const int m = min(KM_CHUNK, nt - t0);
         __syncthreads();
         // spread the chunk: item = (train, dword) -> 32 bytes
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(KM_WAVES * 64) void k_knn2_mfma(const uint8_t* __re
             int bd = (kb >> 16) + pq, sd = (ks >> 16) + pq, bi = kb & 0xffff;
             if (bd >= ie) { bd = init; bi = -1; }
             if (sd >= ie) sd = init;
-            const size_t o = (size_t)pair * max_nq + qr;
+            const size_t o = ((size_t)pair * nsplit + split) * max_nq + qr;
             best_idx[o] = bi; best_dist[o] = bd; second_dist[o] = sd;
         }
     }
@@ -1013,21 +1016,28 @@ static int knn2_launch(const uint8_t* d_Q, const int32_t* d_nq, size_t q_stride,
     chunk = std::max(KNN_TILE, (chunk + KNN_TILE - 1) / KNN_TILE * KNN_TILE);
     nsplit = std::max(1, (max_nt + chunk - 1) / chunk);
     const bool mfma_ok = max_nt <= 65535 && init > 0;
-    if (mfma_ok && (g_knn2_path == 2 || (g_knn2_path == 0 && nsplit == 1))) {
-        // enough (query tile, pair) workgroups to fill the GPU: distances on the matrix cores
-        hipLaunchKernelGGL(k_knn2_mfma, dim3((max_nq + KM_WAVES * 32 - 1) / (KM_WAVES * 32), npairs), dim3(KM_WAVES * 64), 0, s, d_Q,
-                           d_nq, q_stride, max_nq, d_T, d_nt, t_stride, init, d_best_idx, d_best_dist, d_second_dist);
-    } else if (nsplit == 1) {
-        hipLaunchKernelGGL(k_knn2_tiles, dim3(qtiles, npairs, 1), dim3(256), 0, s, d_Q, d_nq, q_stride, max_nq, d_T,
-                           d_nt, t_stride, chunk, init, d_best_idx, d_best_dist, d_second_dist);
+    const bool use_mfma = mfma_ok && g_knn2_path != 1;   // distances on the matrix cores unless the VALU kernel is forced
+    const dim3 mgrid((max_nq + KM_WAVES * 32 - 1) / (KM_WAVES * 32), npairs, nsplit);
+    if (nsplit == 1) {
+        if (use_mfma)
+            hipLaunchKernelGGL(k_knn2_mfma, mgrid, dim3(KM_WAVES * 64), 0, s, d_Q, d_nq, q_stride, max_nq, d_T, d_nt, t_stride, chunk, init,
+                               d_best_idx, d_best_dist, d_second_dist);
+        else
+            hipLaunchKernelGGL(k_knn2_tiles, dim3(qtiles, npairs, 1), dim3(256), 0, s, d_Q, d_nq, q_stride, max_nq, d_T,
+                               d_nt, t_stride, chunk, init, d_best_idx, d_best_dist, d_second_dist);
     } else {
+        // too few (query tile, pair) workgroups to fill 256 CUs: the train set is split, partials merged in split order
         MatchWorkspace& w = ws(s);
         const size_t nb = (size_t)npairs * nsplit * max_nq * 4;
         int rc;
         if ((rc = w.pidx.ensure(nb)) || (rc = w.pbest.ensure(nb)) || (rc = w.psecond.ensure(nb))) return rc;
-        hipLaunchKernelGGL(k_knn2_tiles, dim3(qtiles, npairs, nsplit), dim3(256), 0, s, d_Q, d_nq, q_stride, max_nq,
-                           d_T, d_nt, t_stride, chunk, init, w.pidx.as<int32_t>(), w.pbest.as<int32_t>(),
-                           w.psecond.as<int32_t>());
+        if (use_mfma)
+            hipLaunchKernelGGL(k_knn2_mfma, mgrid, dim3(KM_WAVES * 64), 0, s, d_Q, d_nq, q_stride, max_nq, d_T, d_nt, t_stride, chunk, init,
+                               w.pidx.as<int32_t>(), w.pbest.as<int32_t>(), w.psecond.as<int32_t>());
+        else
+            hipLaunchKernelGGL(k_knn2_tiles, dim3(qtiles, npairs, nsplit), dim3(256), 0, s, d_Q, d_nq, q_stride, max_nq,
+                               d_T, d_nt, t_stride, chunk, init, w.pidx.as<int32_t>(), w.pbest.as<int32_t>(),
+                               w.psecond.as<int32_t>());
         hipLaunchKernelGGL(k_knn2_merge, dim3(qtiles, npairs), dim3(256), 0, s, w.pidx.as<int32_t>(),
                            w.pbest.as<int32_t>(), w.psecond.as<int32_t>(), nsplit, max_nq, d_nq, d_best_idx,
                            d_best_dist, d_second_dist);

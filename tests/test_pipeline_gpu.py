@@ -42,3 +42,23 @@ def test_bench_line_is_self_checking(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--frames", "8", "--steps", "1", "--warmup", "1", "--cpu-frames", "0"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode != 0 and "orbfe_debug_control" in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu_gather_is_verified(tmp_path):
+    """bench.py's N > 1 branch end to end on a single-GPU box: two ranks pinned to device 0, gloo instead of RCCL (the test
+    hooks of bench.py), double-buffered communication stream included.  Rank 0 compares the gathered record block of each rank,
+    byte for byte, with that rank's stream recomputed locally ("gather_check")."""
+    import json
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = tmp_path / "b2.json"
+    env = dict(os.environ, ORBFE_BENCH_DEVICE="0", ORBFE_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--frames", "16", "--steps", "4",
+                        "--warmup", "2", "--cpu-frames", "0", "--out", str(out)],
+                       capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = json.loads(out.read_text())
+    assert d["n_gpus"] == 2 and d["gather_check"]["ranks"] == [0, 1] and d["value"] > 0
+    assert d["verified_frames"]["frames"] == [0, 8, 15]

@@ -1,0 +1,65 @@
+"""profiles/traffic_<config>.json and profiles/pmc_stage_<config>.json from a tools/pmc.py run:
+    python tools/make_profiles.py gpurun_out/pmc_summary.json gpurun_out/pmc_calibration.json <config> <tag>
+traffic: HBM-side bytes per launch of every bench stage = sum over the stage's kernels of (FETCH_SIZE / f_r + WRITE_SIZE / f_w) *
+1024 * launches per step, with the correction factors f measured by tools/fetch_calib.hip for the kernel's access width (the
+gfx950 FETCH_SIZE under-count, MI355X_MICROARCH.md HBM section).  pmc_stage: VALU issue time (SQ_INSTS_VALU x 4 cycles / 1024 SIMDs
+/ 2.4 GHz) and lane utilisation per stage.  bench.py reads both only for the configuration they were measured on."""
+import json, os, sys
+src, cal, config, tag = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+s = json.load(open(src))
+calib = json.load(open(cal)) if os.path.exists(cal) else {}
+# dominant global access width of each kernel (bytes per lane): reads, writes -- from the kernel sources
+WIDTH = {"k_resize_tab": (8, 4), "k_resize_level": (1, 4), "k_fast_cells": (4, 4), "k_blur7": (4, 4), "k_orient_describe": (4, 16),
+         "k_adaptive_threshold": (4, 8), "k_half_area": (8, 4), "k_knn2_mfma": (16, 4), "k_search_init": (16, 4), "k_contours_relay": (4, 4),
+         "k_contours_tail": (4, 4), "k_decode": (1, 4), "k_distribute_pyr": (4, 4)}
+names = {1: "unsigned char", 4: "unsigned int", 8: "HIP_vector_type<unsigned int, 2u>", 16: "HIP_vector_type<unsigned int, 4u>"}
+
+
+def factor(kind, ctr, width):
+    for k, v in calib.items():
+        if k.startswith("calib_" + kind) and names[width] in k and ctr in v and v[ctr] > 0.1:
+            return v[ctr]
+    return 1.0
+
+
+def kb(k):
+    if k not in s:
+        return 0.0
+    base = next((b for b in WIDTH if k.startswith(b)), None)
+    wr, ww = WIDTH.get(base, (4, 4))
+    return (s[k].get("FETCH_SIZE", 0.0) / factor("read", "FETCH_SIZE", wr) + s[k].get("WRITE_SIZE", 0.0) / factor("write", "WRITE_SIZE", ww)) * 1024.0
+
+
+steps = min(v["dispatches"] for k, v in s.items() if k in ("k_fast_cells", "k_blur7")) if "k_fast_cells" in s else \
+    min(v["dispatches"] for k, v in s.items() if k.startswith("k_adaptive_threshold"))
+per_step = lambda k: s[k]["dispatches"] / steps if k in s else 0
+stage = {
+    "resize": ["k_resize_tab", "k_resize_level"], "fast_cells": ["k_fast_cells"],
+    "distribute": ["k_distribute_pyr", "k_distribute", "k_level_offsets"], "blur7": ["k_blur7"],
+    "orient_describe": ["k_orient_describe"], "knn2": ["k_knn2_mfma", "k_knn2_tiles", "k_knn2_merge"], "search_init": ["k_search_init"],
+    "aruco_threshold": [k for k in s if k.startswith("k_adaptive_threshold")], "aruco_pyramid": ["k_half_area"],
+    "aruco_contours": [k for k in s if k.startswith("k_contours")],
+    "aruco_decode": ["k_prefilter", "k_decode"], "aruco_finalize": ["k_finalize", "k_marker_poses"],
+}
+traffic = {"_note": "HBM-side bytes per launch (%s batch) = (FETCH_SIZE / f_read + WRITE_SIZE / f_write) * 1024 from separate rocprofv3 --pmc "
+                    "passes (tools/pmc.py; --kernel-trace only), per-dispatch mean x launches per step (profiles/%s_pmc_summary.json), summed "
+                    "over the kernels of a bench stage; f = the counter's value per byte really moved for the kernel's access width, "
+                    "measured in the same run by tools/fetch_calib.hip (profiles/%s_pmc_calibration.json)" % (config, tag, tag)}
+pmc = {"_note": "per bench stage: valu_us = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz), the time the stage's launches need if they "
+                "only issued VALU instructions; lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) of the stage's "
+                "largest kernel; instruction counts are properties of kernel + input, not of the run (profiles/%s_pmc_summary.json)" % tag}
+for st, ks in stage.items():
+    ks = [k for k in ks if k in s]
+    if not ks:
+        continue
+    traffic[st] = int(round(sum(kb(k) * per_step(k) for k in ks)))
+    big = max(ks, key=lambda k: s[k].get("SQ_INSTS_VALU", 0) * per_step(k))
+    g = lambda n: s[big].get(n, 0.0)
+    pmc[st] = {"valu_us": sum(s[k].get("SQ_INSTS_VALU", 0.0) * per_step(k) for k in ks) * 4 / 1024 / 2400,
+               "lane_utilisation": g("SQ_THREAD_CYCLES_VALU") / max(64 * g("SQ_ACTIVE_INST_VALU"), 1) if g("SQ_ACTIVE_INST_VALU") else None,
+               "valu_per_wave": g("SQ_INSTS_VALU") / max(g("SQ_WAVES"), 1), "kernels": ks}
+json.dump(traffic, open(os.path.join(root, "profiles", "traffic_%s.json" % config), "w"), indent=1)
+json.dump(pmc, open(os.path.join(root, "profiles", "pmc_stage_%s.json" % config), "w"), indent=1)
+print({k: v for k, v in traffic.items() if k != "_note"})
+print({k: round(v["valu_us"], 1) for k, v in pmc.items() if k != "_note"})

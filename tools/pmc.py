@@ -19,7 +19,7 @@ env = dict(os.environ, TMPDIR="/tmp")
 for gi, grp in enumerate(GROUPS):
     d = os.path.join(out, "g%d" % gi)
     cmd = ["rocprofv3", "--pmc", *grp, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
-           sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-frames", "0", *args]
+           sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-frames", "0", "--no-verify", *args]
     r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True)
     if r.returncode:
         print("group", grp, "failed:", r.stderr[-400:])
@@ -28,6 +28,31 @@ for gi, grp in enumerate(GROUPS):
         for row in csv.DictReader(open(fn)):
             k = row["Kernel_Name"].split("(")[0].replace("orbfe::", "").replace("void ", "")
             agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+# FETCH_SIZE / WRITE_SIZE calibration on known byte counts (tools/fetch_calib.hip; MI355X_MICROARCH.md, HBM section)
+calib = {}
+exe = os.path.join(root, "build", "fetch_calib")
+if not os.path.exists(exe):
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-o", exe, os.path.join(root, "tools", "fetch_calib.hip")], capture_output=True)
+if os.path.exists(exe):
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = os.path.join(out, "calib_" + ctr)
+        r = subprocess.run(["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "--", exe], cwd="/tmp", env=env,
+                           capture_output=True, text=True)
+        if r.returncode:
+            print("calibration", ctr, "failed:", r.stderr[-300:])
+            continue
+        acc = collections.defaultdict(list)
+        for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(fn)):
+                if "calib_" in row["Kernel_Name"]:
+                    acc[row["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(row["Counter_Value"]))
+        for k, v in acc.items():
+            calib.setdefault(k, {})[ctr] = (sum(v) / len(v)) * 1024.0 / float(1 << 30)   # counted bytes per real byte
+    json.dump(calib, open(os.path.join(root, "gpurun_out", "pmc_calibration.json"), "w"), indent=1)
+    print("FETCH_SIZE / WRITE_SIZE x 1024 per byte really moved (1 GiB streamed once per kernel):")
+    for k, v in sorted(calib.items()):
+        print("  %-40s %s" % (k, {c: round(x, 3) for c, x in v.items()}))
 summary = {}
 for k, cs in agg.items():
     summary[k] = {c: sum(v) / len(v) for c, v in cs.items()}

@@ -1,0 +1,23 @@
+# One round's measurements on the GPU box:  bash tools/profile_round.sh <tag>   (e.g. r02)
+# bench lines of C2 / C3 / C5, the rocprofv3 kernel-trace summary of the default bench command, the PMC passes (separate runs,
+# --kernel-trace only) with the FETCH_SIZE / WRITE_SIZE calibration, and the per-configuration profiles bench.py reads.
+# Everything lands in gpurun_out/<tag>/; copy what should be judged into profiles/.
+set -x
+TAG=${1:-r02}
+cd "$(dirname "$0")/.."
+O=gpurun_out/$TAG
+mkdir -p $O
+export TMPDIR=/tmp
+python bench.py --out $O/${TAG}_bench.json > $O/bench_c2.log 2>&1
+python bench.py --config C3 --out $O/${TAG}_bench_c3.json > $O/bench_c3.log 2>&1
+python bench.py --config C5 --steps 10 --out $O/${TAG}_bench_c5.json > $O/bench_c5.log 2>&1
+python bench.py --latency --out $O/${TAG}_latency.json > $O/latency.log 2>&1
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$O/prof -- python $OLDPWD/bench.py --cpu-frames 0 --no-verify > $OLDPWD/$O/prof.log 2>&1 )
+cp $(find $O/prof -name '*kernel_stats.csv' | head -1) $O/${TAG}_kernel_stats.csv
+python tools/pmc.py > $O/${TAG}_pmc_table.txt 2>&1
+cp gpurun_out/pmc_summary.json $O/${TAG}_pmc_summary.json
+cp gpurun_out/pmc_calibration.json $O/${TAG}_pmc_calibration.json
+python tools/make_profiles.py $O/${TAG}_pmc_summary.json $O/${TAG}_pmc_calibration.json C2 $TAG > $O/make_profiles_c2.log 2>&1
+cp profiles/traffic_C2.json profiles/pmc_stage_C2.json $O/
+rm -rf $O/prof gpurun_out/pmc
+tail -c 400 $O/bench_c2.log
