@@ -103,6 +103,13 @@ int orbfe_extract_batch(orbfe_extractor* h, const uint8_t* imgs, int nframes, si
 int orbfe_extract_batch_device(orbfe_extractor* h, const uint8_t* d_imgs, int nframes, size_t frame_stride, int rows,
                                int cols, size_t step, orbfe_keypoint* d_kps, uint8_t* d_desc, int capacity,
                                int32_t* d_n_out, void* stream);
+/* The 8-bit taps of the extractor's GaussianBlur(7x7, sigma 2) (ORBextractor.cc:1086) depend on the OpenCV release the
+ * reference is built against.  mode 0 (default): every tap rounded on its own, 18 34 49 55 49 34 18 (sum 257) -- OpenCV 2.4 / 3.2
+ * (what CMakeLists.txt:32-38 asks for) and the first fixed-point GaussianBlur of 3.4.  mode 1: the later bit-exact kernel
+ * (rounding error carried from tap to tap, the centre tap takes the remainder), 18 34 48 56 48 34 18 (sum 256) -- late 3.4.x, 4.x.
+ * Output is sat_u8((sum + 2^15) >> 16) either way. */
+int orbfe_extractor_set_gaussian_taps(orbfe_extractor* h, int mode);
+
 /* The device-pointer entry point is asynchronous and cannot return a capacity error: a frame whose keypoint total exceeds
  * `capacity` is clamped to it.  After the batch (synchronises the device): *overflow = 0, or the largest per-frame total
  * that did not fit -- the batch's records are then incomplete and the call must be repeated with capacity >= *overflow

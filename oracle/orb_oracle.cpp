@@ -114,10 +114,14 @@ inline int reflect101(int p, int n)
     return p;
 }
 
-/* GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) on 8U (ORBextractor.cc:1086).
- * Taps = round(256 * normalised exp(-x^2/8)) = 18 34 49 55 49 34 18 (sum 257,
- * not renormalised in 3.4); out = sat_u8((sum + 2^15) >> 16).  App. B.3. */
-void gaussian7_taps(int taps[7])
+/* GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) on 8U (ORBextractor.cc:1086); out = sat_u8((sum + 2^15) >> 16).  App. B.3.
+ * The 8-bit taps depend on the OpenCV release -- a stated, switchable choice (the reference binary's 3.4 patch level is unknown):
+ *   mode 0 (default): every tap rounded on its own, round(256 * normalised exp(-x^2/8)) = 18 34 49 55 49 34 18 (sum 257, not
+ *           renormalised): the 8U path of sepFilter2D in 2.4 / 3.2 (CMakeLists.txt:32-38 asks for 3.2.0) and the first fixed-point
+ *           GaussianBlur of 3.4 (ufixedpoint16 taps, each rounded to nearest);
+ *   mode 1: the later "bit-exact" kernel (late 3.4.x, 4.x): the taps go to 8.8 fixed point left to right with the rounding error
+ *           carried into the next tap, mirrored, and the centre tap takes what is left of 256: 18 34 48 56 48 34 18 (sum 256). */
+void gaussian7_taps(int taps[7], int mode)
 {
     double k[7], sum = 0;
     for (int i = 0; i < 7; i++) {
@@ -125,13 +129,26 @@ void gaussian7_taps(int taps[7])
         k[i] = std::exp(-0.5 * x * x / 4.0);
         sum += k[i];
     }
-    for (int i = 0; i < 7; i++) taps[i] = orbfe_round_d(k[i] / sum * 256.0);
+    if (mode == 0) {
+        for (int i = 0; i < 7; i++) taps[i] = orbfe_round_d(k[i] / sum * 256.0);
+        return;
+    }
+    double err = 0;
+    int acc = 0;
+    for (int i = 0; i < 3; i++) {
+        const double adj = k[i] / sum * 256.0 + err;
+        const int v = orbfe_round_d(adj);
+        err = adj - v;
+        taps[i] = taps[6 - i] = v;
+        acc += v;
+    }
+    taps[3] = 256 - 2 * acc;
 }
 
-void gaussian_blur7(const Image& src, Image& dst)
+void gaussian_blur7(const Image& src, Image& dst, int mode = 0)
 {
     int taps[7];
-    gaussian7_taps(taps);
+    gaussian7_taps(taps, mode);
     const int w = src.w, h = src.h;
     dst = Image(w, h);
     std::vector<int> tmp((size_t)w * h);
@@ -372,6 +389,7 @@ struct Extractor {
     double scaleFactor; /* double member initialised from a float (ORBextractor.h:98) */
     std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
     std::vector<int> mnFeaturesPerLevel, umax;
+    int gaussian_mode = 0; /* gaussian7_taps: 0 = taps rounded one by one (sum 257), 1 = bit-exact kernel (sum 256) */
     int trig_libm = 0; /* diagnostic: use host libm cosf/sinf like the reference binary would */
     /* kept for per-stage parity tests */
     std::vector<Image> pyramid, blurred;
@@ -554,7 +572,7 @@ struct Extractor {
             std::vector<KeyPoint>& keypoints = allKeypoints[level];
             int n = (int)keypoints.size();
             if (n == 0) continue;
-            gaussian_blur7(pyramid[level], blurred[level]);
+            gaussian_blur7(pyramid[level], blurred[level], gaussian_mode);
             for (int i = 0; i < n; i++)
                 computeOrbDescriptor(keypoints[i], blurred[level], desc.data() + (size_t)(offset + i) * 32);
             offset += n;
@@ -579,6 +597,7 @@ void* oracle_orb_create(int nfeatures, float scaleFactor, int nlevels, int iniTh
 }
 void oracle_orb_destroy(void* h) { delete (Extractor*)h; }
 void oracle_orb_set_trig_libm(void* h, int on) { ((Extractor*)h)->trig_libm = on; }
+void oracle_orb_set_gaussian_taps(void* h, int mode) { ((Extractor*)h)->gaussian_mode = mode; }
 
 /* kps: capacity x 28 B (cv::KeyPoint layout), desc: capacity x 32 B. Returns n (or -n if capacity too small). */
 int oracle_orb_extract(void* h, const uint8_t* img, int rows, int cols, size_t step, void* kps, uint8_t* desc,
@@ -648,7 +667,8 @@ void oracle_gaussian_blur7(const uint8_t* src, int w, int h, uint8_t* dst)
     gaussian_blur7(s, d);
     memcpy(dst, d.d.data(), (size_t)w * h);
 }
-void oracle_gaussian7_taps(int* taps) { gaussian7_taps(taps); }
+void oracle_gaussian7_taps(int* taps) { gaussian7_taps(taps, 0); }
+void oracle_gaussian7_taps_mode(int* taps, int mode) { gaussian7_taps(taps, mode); }
 /* score map of an image (0 in the 3-px frame); used to test the FAST kernel in isolation */
 void oracle_fast_score_map(const uint8_t* img, int w, int h, int* out)
 {

@@ -25,7 +25,7 @@ SYMBOLS = [
     "orbfe_extractor_get_inverse_scale_factors", "orbfe_extractor_get_scale_sigma_squares",
     "orbfe_extractor_get_inverse_scale_sigma_squares", "orbfe_extractor_get_features_per_level",
     "orbfe_extractor_max_keypoints", "orbfe_extract", "orbfe_extract_batch", "orbfe_extract_batch_device",
-    "orbfe_extractor_batch_status", "orbfe_search_for_initialization_batch_status",
+    "orbfe_extractor_batch_status", "orbfe_search_for_initialization_batch_status", "orbfe_extractor_set_gaussian_taps",
     "orbfe_extractor_debug_level_size", "orbfe_extractor_debug_level_image",
     "orbfe_extractor_debug_level_keypoints", "orbfe_extractor_debug_kernel_times", "orbfe_extractor_set_aux_stream",
     "orbfe_debug_control", "orbfe_hamming", "orbfe_knn2", "orbfe_knn2_csr", "orbfe_knn2_batch_device", "orbfe_search_for_initialization",
@@ -78,6 +78,7 @@ def load():
     L.orbfe_extract_batch.argtypes = [vp, vp, i32, sz, i32, i32, sz, vp, vp, i32, vp]
     L.orbfe_extract_batch_device.argtypes = [vp, vp, i32, sz, i32, i32, sz, vp, vp, i32, vp, vp]
     L.orbfe_extractor_batch_status.argtypes = [vp, vp]
+    L.orbfe_extractor_set_gaussian_taps.argtypes = [vp, i32]
     L.orbfe_extractor_debug_level_size.argtypes = [vp, i32, vp, vp]
     L.orbfe_extractor_debug_level_image.argtypes = [vp, i32, i32, i32, vp]
     L.orbfe_extractor_debug_level_keypoints.argtypes = [vp, i32, i32, i32, vp, i32, vp]
@@ -234,6 +235,10 @@ class ORBextractor:
         _check(self.L, self.L.orbfe_extract_batch_device(self.h, d_imgs_ptr, B, frame_stride, rows, cols, step,
                                                          d_kps_ptr, d_desc_ptr, capacity, d_n_ptr, stream),
                "orbfe_extract_batch_device")
+
+    def set_gaussian_taps(self, mode):
+        """0: taps 18 34 49 55 49 34 18 (OpenCV 2.4 / 3.2 / early 3.4); 1: 18 34 48 56 48 34 18 (late 3.4.x / 4.x)."""
+        _check(self.L, self.L.orbfe_extractor_set_gaussian_taps(self.h, int(mode)), "orbfe_extractor_set_gaussian_taps")
 
     def batch_status(self):
         """0, or the largest per-frame keypoint total of the last device batch that did not fit its capacity."""

@@ -55,6 +55,7 @@ struct orbfe_extractor {
     DevBuf d_geom, d_cellinfo, d_tiles, d_tabs, d_pattern, d_umax;
     DevBuf d_pyr, d_blur, d_slots, d_cellcnt, d_keys, d_lvlout, d_lvlcnt, d_lvloff, d_lvlncand, d_overflow, d_fallback,
         d_flatkv, d_flatlvl;
+    bool gaussian_ed = false;            // orbfe_extractor_set_gaussian_taps: 18 34 48 56 48 34 18 instead of 18 34 49 55 49 34 18
     bool force_general_quadtree = false; // test hook: run the general kernel for every level
     int force_pyramid_depth = 0;         // test hook: shallow count pyramid so that levels fall back
     DevBuf d_in, d_kps, d_desc, d_nout; // staging for the host-pointer entry points
@@ -318,8 +319,14 @@ struct orbfe_extractor {
         ORBFE_HIP(hipEventRecord(ev_fork, s));
         ORBFE_HIP(hipStreamWaitEvent(aux_stream, ev_fork, 0));
         timer.mark(aux_stream, "blur7 starts", true);
-        if (!ORBFE_SKIP_ORB(8)) hipLaunchKernelGGL(k_blur7, dim3(xcd_grid(ntiles * B)), dim3(256), 0, aux_stream, src0, pyr, blur, dg,
-                           d_tiles.as<uint32_t>(), ntiles, ntiles * B);
+        if (!ORBFE_SKIP_ORB(8)) {
+            if (gaussian_ed)
+                hipLaunchKernelGGL(k_blur7<true>, dim3(xcd_grid(ntiles * B)), dim3(256), 0, aux_stream, src0, pyr, blur, dg,
+                                   d_tiles.as<uint32_t>(), ntiles, ntiles * B);
+            else
+                hipLaunchKernelGGL(k_blur7<false>, dim3(xcd_grid(ntiles * B)), dim3(256), 0, aux_stream, src0, pyr, blur, dg,
+                                   d_tiles.as<uint32_t>(), ntiles, ntiles * B);
+        }
         timer.mark(aux_stream, "blur7");
         ORBFE_HIP(hipEventRecord(ev_join, aux_stream));
         {
@@ -593,6 +600,13 @@ int orbfe_extractor_debug_level_keypoints(orbfe_extractor* h, int frame, int lev
         out[i].octave = stage == 0 ? 0 : level;
         out[i].class_id = -1;
     }
+    return ORBFE_OK;
+}
+
+int orbfe_extractor_set_gaussian_taps(orbfe_extractor* h, int mode)
+{
+    if (!h || (mode != 0 && mode != 1)) return fail(ORBFE_ERR_INVALID, "orbfe_extractor_set_gaussian_taps: mode is 0 or 1");
+    h->gaussian_ed = mode == 1;
     return ORBFE_OK;
 }
 

@@ -1233,10 +1233,17 @@ __device__ __forceinline__ void bl_load_rows(const uint8_t* img, int pitch, cons
     }
 }
 
+// The 8-bit taps of GaussianBlur(7x7, sigma 2) depend on the OpenCV release (orbfe_extractor_set_gaussian_taps):
+//   ED = false: every tap rounded on its own, 18 34 49 55 49 34 18 (sum 257) -- 2.4 / 3.2 (the version CMakeLists.txt:32-38 asks
+//               for) and the first fixed-point implementation of 3.4
+//   ED = true:  the bit-exact kernel with the rounding error carried tap to tap and the centre taking the rest, 18 34 48 56 48 34 18
+//               (sum 256) -- late 3.4.x and 4.x
+template <bool ED>
 __device__ __forceinline__ void bl_hsum_rows(uint16_t* sh, int first_rr, int nrr, int tid, int nitems, const uint32_t (*w)[3])
 {
-    constexpr uint32_t TA = 18u | (34u << 8) | (49u << 16) | (55u << 24); // taps 0..3
-    constexpr uint32_t TB = 49u | (34u << 8) | (18u << 16);               // taps 4..6
+    constexpr uint32_t T2 = ED ? 48u : 49u, T3 = ED ? 56u : 55u;
+    constexpr uint32_t TA = 18u | (34u << 8) | (T2 << 16) | (T3 << 24); // taps 0..3
+    constexpr uint32_t TB = T2 | (34u << 8) | (18u << 16);              // taps 4..6
 #pragma unroll
     for (int k = 0; k < 5; k++) {
         if (k >= nitems) break;
@@ -1257,6 +1264,7 @@ __device__ __forceinline__ void bl_hsum_rows(uint16_t* sh, int first_rr, int nrr
     }
 }
 
+template <bool ED>
 __global__ __launch_bounds__(256) void k_blur7(ImgView src0, ImgView pyr, ImgView blur,
                                                const LevelGeom* __restrict__ geom, const uint32_t* __restrict__ strips,
                                                int nx, int total)
@@ -1272,7 +1280,8 @@ __global__ __launch_bounds__(256) void k_blur7(ImgView src0, ImgView pyr, ImgVie
     const int pitch = (level == 0) ? src0.pitch : g.pitch;
     const int tid = threadIdx.x;
     uint8_t* D = blur.base_w + (size_t)f * blur.fstride + g.blur_off;
-    constexpr uint32_t V01 = 18u | (34u << 16), V23 = 49u | (55u << 16), V45 = 49u | (34u << 16), V6 = 18u, V6H = 18u << 16;
+    constexpr uint32_t T2 = ED ? 48u : 49u, T3 = ED ? 56u : 55u;
+    constexpr uint32_t V01 = 18u | (34u << 16), V23 = T2 | (T3 << 16), V45 = T2 | (34u << 16), V6 = 18u, V6H = 18u << 16;
     const int c4 = 4 * (tid & 15), q = tid >> 4;
     const int x = tx0 + c4;
 
@@ -1281,7 +1290,7 @@ __global__ __launch_bounds__(256) void k_blur7(ImgView src0, ImgView pyr, ImgVie
     {
         const int nrr = min(64, g.h) + 6;
         bl_load_rows(img, pitch, g, tx0, -3, 0, nrr, tid, 5, w);
-        bl_hsum_rows(sh, 0, nrr, tid, 5, w);
+        bl_hsum_rows<ED>(sh, 0, nrr, tid, 5, w);
     }
     for (int tyb = 0; tyb < g.h; tyb += 64) {
         const int nrows_out = min(64, g.h - tyb);
@@ -1319,9 +1328,12 @@ __global__ __launch_bounds__(256) void k_blur7(ImgView src0, ImgView pyr, ImgVie
         if (tid < 192) carry = reinterpret_cast<const uint32_t*>(&sh[cc * BL_CP + 64])[cd];
         __syncthreads(); // every read of this tile's sums done
         if (tid < 192) reinterpret_cast<uint32_t*>(&sh[cc * BL_CP])[cd] = carry;
-        bl_hsum_rows(sh, 6, nrr_next, tid, 4, w);
+        bl_hsum_rows<ED>(sh, 6, nrr_next, tid, 4, w);
     }
 }
+
+template __global__ void k_blur7<false>(ImgView, ImgView, ImgView, const LevelGeom*, const uint32_t*, int, int);
+template __global__ void k_blur7<true>(ImgView, ImgView, ImgView, const LevelGeom*, const uint32_t*, int, int);
 
 // ------------------------------------------------------------------------------------------------ describe --
 // One wave per keypoint: IC_Angle on the un-blurred level (:77-104), then the 256 steered BRIEF tests on the

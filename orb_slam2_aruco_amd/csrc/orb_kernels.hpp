@@ -88,7 +88,7 @@ inline size_t qp_lds_bytes(int nIni, int D, int nodecap, int veccap)
 __global__ void k_level_offsets(const int32_t* lvl_cnt, int32_t* lvl_off, int32_t* n_out, int nlevels, int nframes,
                                 int capacity, int32_t* overflow, const LevelGeom* geom, const uint32_t* lvl_out,
                                 int out_fstride, uint32_t* flat_kv, uint8_t* flat_lvl);
-__global__ void k_blur7(ImgView src0, ImgView pyr, ImgView blur, const LevelGeom* geom, const uint32_t* strips, int nx,
+template <bool ED> __global__ void k_blur7(ImgView src0, ImgView pyr, ImgView blur, const LevelGeom* geom, const uint32_t* strips, int nx,
                         int total);
 __global__ void k_orient_describe(ImgView src0, ImgView pyr, ImgView blur, const LevelGeom* geom,
                                   const uint32_t* flat_kv, const uint8_t* flat_lvl, const int32_t* n_out, int nlevels,

@@ -34,6 +34,8 @@ def lib():
         L.oracle_orb_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
         L.oracle_orb_destroy.argtypes = [C.c_void_p]
         L.oracle_orb_set_trig_libm.argtypes = [C.c_void_p, C.c_int]
+        L.oracle_orb_set_gaussian_taps.argtypes = [C.c_void_p, C.c_int]
+        L.oracle_gaussian7_taps_mode.argtypes = [C.c_void_p, C.c_int]
         L.oracle_orb_extract.restype = C.c_int
         L.oracle_orb_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p,
                                          C.c_void_p, C.c_int]
@@ -114,6 +116,10 @@ class OrbOracle:
             self.L.oracle_orb_destroy(self.h)
             self.h = None
 
+    def set_gaussian_taps(self, mode):
+        """0: 18 34 49 55 49 34 18 (OpenCV 2.4 / 3.2 / early 3.4); 1: 18 34 48 56 48 34 18 (late 3.4.x / 4.x)."""
+        self.L.oracle_orb_set_gaussian_taps(self.h, int(mode))
+
     def tables(self):
         n = self.nlevels
         f = [np.zeros(n, np.float32) for _ in range(4)]
@@ -144,6 +150,25 @@ class OrbOracle:
         out = np.zeros(max(n, 1), KP_DTYPE)
         self.L.oracle_orb_level_keypoints(self.h, level, stage, _p(out), n)
         return out[:n]
+
+
+def resize_linear_u8(src, dw, dh):
+    """cv::resize(INTER_LINEAR) on 8U as restated (App. B.2)."""
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().oracle_resize_linear_u8(_p(src), src.shape[1], src.shape[0], _p(dst), dw, dh)
+    return dst
+
+
+def gaussian7_taps(mode=0):
+    t = np.zeros(7, np.int32)
+    lib().oracle_gaussian7_taps_mode(_p(t), int(mode))
+    return t
+
+
+def otsu_threshold(values):
+    v = np.ascontiguousarray(values, np.uint8).reshape(-1)
+    return lib().oracle_otsu_threshold(_p(v), len(v))
 
 
 def knn2(Q, T, init=256):

@@ -584,3 +584,48 @@ def test_search_by_projection_keyframe_hand_case(oracle):
     n, m = oracle.search_by_projection_keyframe(kps, d, 640, 480, ang, None, p, mfmin, mfmax, md, T, Ow, K4, sf, L, 10.0, 100, taken_cur=tk,
                                                 check_orientation=False)
     assert n == 1 and m.tolist() == [-1, 1, -1]
+
+
+# ---------------------------------------------------------------- the reference's own BowVector / FeatureVector (oracle/_ref)
+def _dbow2_ref():
+    import ctypes as C
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libdbow2_ref.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/libdbow2_ref.so not built (make -C oracle ref needs /root/reference)")
+    L = C.CDLL(so)
+    L.dbow2_ref_bowvector.restype = C.c_int
+    L.dbow2_ref_bowvector.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.dbow2_ref_featurevector.restype = C.c_int
+    L.dbow2_ref_featurevector.argtypes = [C.c_void_p] * 2 + [C.c_int] + [C.c_void_p] * 3
+    return L
+
+
+@pytest.mark.parametrize("weighting,scoring", [(0, 0), (1, 0), (2, 0), (3, 0), (0, 1), (0, 5), (1, 5), (0, 2)])
+def test_bow_vectors_pinned_by_reference_classes(oracle, weighting, scoring):
+    """The oracle's BowVector / FeatureVector (oracle/bow_oracle.cpp restating BowVector.cpp:32-89, FeatureVector.cpp:30-45 and the
+    accumulation / normalisation switch of TemplatedVocabulary.h:1143-1191, ScoringObject.h:74-91) against the REFERENCE's own
+    classes compiled from /root/reference (oracle/_ref/libdbow2_ref.so): the per-feature (word, weight, node) stream of the
+    oracle's tree descent goes through the real addWeight / addIfNotExist / normalize / addFeature -- doubles bit-exact."""
+    import voc_cases as vc
+    R = _dbow2_ref()
+    voc = vc.make(9, 3, 17 + weighting + 10 * scoring, irregular=True)
+    ov = oracle.VocabularyOracle.from_arrays(9, 3, scoring, weighting, voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"])
+    desc = np.random.default_rng(weighting * 7 + scoring).integers(0, 256, (700, 32), dtype=np.uint8)
+    desc[100:140] = desc[0:40]                     # repeated words: accumulation order matters
+    t = ov.transform(desc, 2)
+    keep = t["weight"] > 0                          # "not stopped" (TemplatedVocabulary.h:1159,1183)
+    word = np.ascontiguousarray(t["word"][keep], np.uint32); w = np.ascontiguousarray(t["weight"][keep], np.float64)
+    n = len(word)
+    assert n > 300
+    mode = 0 if weighting in (0, 1) else 1
+    norm = {0: 1, 1: 2, 2: 1, 3: 1, 4: 1, 5: 0}[scoring]     # ScoringObject.h:74-91: L1 / L2 / none (DOT_PRODUCT)
+    ow = np.zeros(n, np.uint32); ov_ = np.zeros(n, np.float64)
+    k = R.dbow2_ref_bowvector(word.ctypes.data, w.ctypes.data, n, mode, norm, ow.ctypes.data, ov_.ctypes.data)
+    if mode == 0 and norm == 0:                     # TF / TF_IDF without normalisation: divided by the vector size (:1168-1174)
+        ov_[:k] = ov_[:k] / float(k)
+    assert np.array_equal(ow[:k], t["bow"][0])
+    assert np.array_equal(ov_[:k].view(np.uint64), t["bow"][1].view(np.uint64))
+    node = np.ascontiguousarray(t["node"][keep], np.uint32); feat = np.ascontiguousarray(np.nonzero(keep)[0], np.uint32)
+    on = np.zeros(n, np.uint32); oo = np.zeros(n + 1, np.int32); of = np.zeros(n, np.uint32)
+    kf = R.dbow2_ref_featurevector(node.ctypes.data, feat.ctypes.data, n, on.ctypes.data, oo.ctypes.data, of.ctypes.data)
+    assert np.array_equal(on[:kf], t["fv"][0]) and np.array_equal(oo[:kf + 1], t["fv"][1]) and np.array_equal(of[:oo[kf]], t["fv"][2])

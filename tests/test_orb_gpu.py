@@ -140,3 +140,24 @@ def test_full_size_properties_without_oracle(orbfe):
             x, y = k["x"][m] / scale[l], k["y"][m] / scale[l]
             assert x.min() >= 18.99 and y.min() >= 18.99                        # EDGE_THRESHOLD band
         assert 100 < np.unpackbits(d, axis=1).sum(1).mean() < 156               # bits are balanced
+
+
+def test_gaussian_tap_variants(orbfe, oracle):
+    """The GaussianBlur taps are a stated, switchable choice (OpenCV release dependent, orbfe_extractor_set_gaussian_taps): both
+    variants are bit-exact against the oracle, blurred levels and descriptors."""
+    img, _ = synth.scene(480, 640, 11, n_markers=3, side_range=(40, 90))
+    ex = orbfe.ORBextractor(1000, 1.2, 8, 20, 7)
+    ora = oracle.OrbOracle(1000, 1.2, 8, 20, 7)
+    out = []
+    for mode in (1, 0):
+        ex.set_gaussian_taps(mode); ora.set_gaussian_taps(mode)
+        kps, desc = ex(img)
+        okps, odesc = ora.extract(img)
+        for l in range(8):
+            if len(ora.level_keypoints(l, 1)):
+                assert np.array_equal(ex.level_image(0, l, True), ora.level_image(l, True)), "blur level %d, taps mode %d" % (l, mode)
+        assert np.array_equal(kps, okps) and np.array_equal(desc, odesc)
+        out.append(desc)
+    assert not np.array_equal(out[0], out[1])
+    with pytest.raises(orbfe.OrbfeError):
+        ex.set_gaussian_taps(2)
