@@ -423,6 +423,19 @@ orbfe_aruco* orbfe_aruco_create(const char* dictionary, int device);
 void orbfe_aruco_destroy(orbfe_aruco* h);
 int orbfe_aruco_set_dictionary(orbfe_aruco* h, const char* dictionary);
 int orbfe_aruco_max_markers(const orbfe_aruco* h);
+/* MarkerDetector::Params the shim forwards (markerdetector.h:96-214).
+ *   setDictionary(name, error_correction_rate) / MarkerDetector(dict, rate): rate in [0, 1]; > 0 enables the error-correction pass
+ *     of DictionaryBased::detect (a code closer than int(tau * rate) bits to a dictionary entry is accepted; default 0 = exact).
+ *   setDetectionMode(dm, minMarkerSize): DM_NORMAL (0) with minMarkerSize 0 is what is built (Frame.cc:136); DM_FAST (1) and
+ *     DM_VIDEO_FAST (2) -- THRES_AUTO_FIXED with its rand() retries and frame-to-frame state -- are refused with ORBFE_ERR_INVALID.
+ *   setCornerRefinementMethod(m): CORNER_LINES (1, default, Frame.cc:137) and CORNER_NONE (2); CORNER_SUBPIX (0) is refused. */
+int orbfe_aruco_set_error_correction_rate(orbfe_aruco* h, float rate);
+int orbfe_aruco_set_detection_mode(orbfe_aruco* h, int mode, float min_marker_size);
+int orbfe_aruco_set_corner_refinement(orbfe_aruco* h, int method);
+/* aruco::Marker::contourPoints (marker.h:56) of marker `marker` (index into the output of the last detect / batch call) of frame
+ * `frame`: the full border the rectangle came from, (x, y) int32 pairs.  *n = its length; min(*n, capacity) points are written.
+ * Host pointers; synchronises the device. */
+int orbfe_aruco_marker_contour(orbfe_aruco* h, int frame, int marker, int32_t* xy, int capacity, int32_t* n);
 
 /* detect(image) -> markers sorted by id, corners refined by contour lines. Host pointers, one CV_8UC1 frame. */
 int orbfe_aruco_detect(orbfe_aruco* h, const uint8_t* img, int rows, int cols, size_t step, orbfe_marker* out,

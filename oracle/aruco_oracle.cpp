@@ -20,6 +20,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -386,8 +387,9 @@ int otsu_threshold(const uint8_t* p, int n)
 /* ------------------------------------------------------------ dictionary -- */
 struct Dict {
     std::string name;
-    int nbits = 0, n = 0;
+    int nbits = 0, n = 0, tau = 0;
     const unsigned long long* codes = nullptr;
+    float error_correction_rate = 0; /* MarkerDetector::Params::error_correction_rate (markerdetector.h:171); 0 in the reference's setup */
     /* Dictionary::fromVector (dictionary.cpp:99-103): map.insert keeps the FIRST id of a duplicated code */
     int lookup(unsigned long long c) const
     {
@@ -405,6 +407,7 @@ bool load_dict(const char* name, Dict& d)
             d.nbits = ORBFE_DICTS[i].nbits;
             d.n = ORBFE_DICTS[i].ncodes;
             d.codes = ORBFE_DICTS[i].codes;
+            d.tau = ORBFE_DICTS[i].tau; /* Dictionary::tau(), dictionary.cpp:108-248 */
             return true;
         }
     return false;
@@ -453,6 +456,17 @@ int decode_marker(const uint8_t* patch, int S, const Dict& dict, int* nRot)
     for (int r = 0; r < 4; r++) {
         int id = dict.lookup(ids[r]);
         if (id >= 0) { *nRot = r; return id; }
+    }
+    /* error correction (dictionary_based.cpp:1423-1560): maxCorrection = int(float(tau) * rate); the dictionary's code map
+     * (std::map<uint64_t, uint16_t>: ascending code, first id of a duplicated code) is walked entry by entry, the four rotations
+     * inside; the first entry with hamm_distance < maxCorrection wins */
+    const int maxCorrection = static_cast<int>(static_cast<float>(dict.tau) * dict.error_correction_rate);
+    if (maxCorrection > 0) {
+        std::map<unsigned long long, int> code_id;
+        for (int i = 0; i < dict.n; i++) code_id.insert(std::make_pair(dict.codes[i], i));
+        for (const auto& ci : code_id)
+            for (int r = 0; r < 4; r++)
+                if (__builtin_popcountll(ci.first ^ ids[r]) < maxCorrection) { *nRot = r; return ci.second; }
     }
     return -1;
 }
@@ -521,6 +535,7 @@ Ptf cross_point(const float l1[3], const float l2[3]) /* getCrossPoint, :11899-1
 
 struct Detector {
     Dict dict;
+    bool corner_lines = true; /* Params::cornerRefinementM == CORNER_LINES (Frame.cc:137) */
     /* stage data of the last call (per-stage parity tests) */
     Image thres;
     std::vector<Image> pyramid;
@@ -722,7 +737,8 @@ struct Detector {
         for (size_t i = 0; i < out.size(); i++)
             if (!rm[i]) kept.push_back(std::move(out[i]));
         out.swap(kept);
-        for (auto& m : out) refine_corners(m);
+        if (corner_lines) /* cornerRefinementM == CORNER_LINES (:8634-8701); CORNER_NONE leaves the approxPolyDP corners */
+            for (auto& m : out) refine_corners(m);
         return (int)out.size();
     }
 };
@@ -750,6 +766,11 @@ void* oracle_aruco_create(const char* dictionary)
     return d;
 }
 void oracle_aruco_destroy(void* h) { delete (Detector*)h; }
+void oracle_aruco_set_params(void* h, float error_correction_rate, int corner_lines)
+{
+    ((Detector*)h)->dict.error_correction_rate = error_correction_rate;
+    ((Detector*)h)->corner_lines = corner_lines != 0;
+}
 
 int oracle_aruco_detect(void* h, const uint8_t* img, int rows, int cols, size_t step, void* out, int capacity)
 {

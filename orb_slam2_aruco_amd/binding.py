@@ -34,7 +34,8 @@ SYMBOLS = [
     "orbfe_aruco_create", "orbfe_aruco_destroy", "orbfe_aruco_set_dictionary", "orbfe_aruco_max_markers",
     "orbfe_aruco_detect", "orbfe_aruco_detect_batch", "orbfe_aruco_detect_batch_device", "orbfe_aruco_debug_image",
     "orbfe_aruco_debug_kernel_times", "orbfe_aruco_set_aux_stream",
-    "orbfe_aruco_batch_status", "orbfe_aruco_set_big_frames",
+    "orbfe_aruco_batch_status", "orbfe_aruco_set_big_frames", "orbfe_aruco_set_error_correction_rate",
+    "orbfe_aruco_set_detection_mode", "orbfe_aruco_set_corner_refinement", "orbfe_aruco_marker_contour",
     "orbfe_camera_resize", "orbfe_marker_poses", "orbfe_marker_poses_batch_device",
     "orbfe_vocabulary_load_text", "orbfe_vocabulary_create", "orbfe_vocabulary_destroy", "orbfe_vocabulary_info",
     "orbfe_vocabulary_transform", "orbfe_vocabulary_transform_batch_device",
@@ -124,6 +125,10 @@ def load():
         L.orbfe_aruco_set_aux_stream.argtypes = [vp, vp]
         L.orbfe_aruco_batch_status.argtypes = [vp, vp, vp]
         L.orbfe_aruco_set_big_frames.argtypes = [vp, i32]
+        L.orbfe_aruco_set_error_correction_rate.argtypes = [vp, f32]
+        L.orbfe_aruco_set_detection_mode.argtypes = [vp, i32, f32]
+        L.orbfe_aruco_set_corner_refinement.argtypes = [vp, i32]
+        L.orbfe_aruco_marker_contour.argtypes = [vp, i32, i32, vp, i32, vp]
         L.orbfe_camera_resize.argtypes = [vp, i32, i32, i32, i32, vp]
     if hasattr(L, "orbfe_vocabulary_create"):
         L.orbfe_vocabulary_load_text.restype = vp
@@ -720,8 +725,26 @@ class MarkerDetector:
             self.L.orbfe_aruco_destroy(self.h)
             self.h = None
 
-    def setDictionary(self, name):
+    DM_NORMAL, DM_FAST, DM_VIDEO_FAST = 0, 1, 2              # aruco::DetectionMode (markerdetector.h:60)
+    CORNER_SUBPIX, CORNER_LINES, CORNER_NONE = 0, 1, 2       # aruco::CornerRefinementMethod (:62)
+
+    def setDictionary(self, name, error_correction_rate=0.0):
         _check(self.L, self.L.orbfe_aruco_set_dictionary(self.h, name.encode()), "orbfe_aruco_set_dictionary")
+        _check(self.L, self.L.orbfe_aruco_set_error_correction_rate(self.h, error_correction_rate), "orbfe_aruco_set_error_correction_rate")
+
+    def setDetectionMode(self, dm, minMarkerSize=0.0):
+        _check(self.L, self.L.orbfe_aruco_set_detection_mode(self.h, int(dm), minMarkerSize), "orbfe_aruco_set_detection_mode")
+
+    def setCornerRefinementMethod(self, method):
+        _check(self.L, self.L.orbfe_aruco_set_corner_refinement(self.h, int(method)), "orbfe_aruco_set_corner_refinement")
+
+    def contour(self, marker, frame=0):
+        """aruco::Marker::contourPoints of output marker `marker` of the last call -> (n, 2) int32."""
+        n = C.c_int32(0)
+        _check(self.L, self.L.orbfe_aruco_marker_contour(self.h, frame, marker, None, 0, C.byref(n)), "orbfe_aruco_marker_contour")
+        xy = np.zeros((max(n.value, 1), 2), np.int32)
+        _check(self.L, self.L.orbfe_aruco_marker_contour(self.h, frame, marker, _p(xy), n.value, C.byref(n)), "orbfe_aruco_marker_contour")
+        return xy[:n.value]
 
     def detect(self, image, camera=None, markerSizeMeters=-1.0):
         """detect(image) -> MARKER_DTYPE records.  With camera = (K, dist, (cam_width, cam_height)) and a marker size

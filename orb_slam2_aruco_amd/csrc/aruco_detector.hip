@@ -38,13 +38,19 @@ struct orbfe_aruco {
     DevBuf d_codes, d_levels, d_tabs, d_bits, d_pyr, d_candq, d_pool, d_kept, d_rects, d_counts, d_candidx, d_ncand,
         d_result, d_gpad;
     DevBuf d_in, d_out, d_nout;
+    // MarkerDetector::Params the ABI exposes (markerdetector.h:96-214): error_correction_rate, cornerRefinementM
+    float error_rate = 0.0f;
+    int max_corr = 0, tau = 0, nsorted = 0; // int(tau * error_rate); the dictionary's code map in std::map order
+    int corner_method = 1;                  // aruco::CornerRefinementMethod: 0 CORNER_SUBPIX, 1 CORNER_LINES, 2 CORNER_NONE
+    DevBuf d_scodes, d_sids, d_msrc;        // d_msrc: rectangle (= contour) of every output marker of the last batch
     KernelTimer timer;
     int last_nframes = 0;
 
     ~orbfe_aruco()
     {
         for (DevBuf* b : {&d_codes, &d_levels, &d_tabs, &d_bits, &d_pyr, &d_candq, &d_pool, &d_kept, &d_rects,
-                          &d_counts, &d_candidx, &d_ncand, &d_result, &d_gpad, &d_in, &d_out, &d_nout, &d_segs, &d_tailkeys, &d_tailoff, &d_small, &d_hint})
+                          &d_counts, &d_candidx, &d_ncand, &d_result, &d_gpad, &d_in, &d_out, &d_nout, &d_segs, &d_tailkeys, &d_tailoff, &d_small, &d_hint, &d_scodes, &d_sids,
+                          &d_msrc})
             b->release();
         if (own_stream) (void)hipStreamDestroy(own_stream);
         if (aux_stream) (void)hipStreamDestroy(aux_stream);
@@ -66,6 +72,23 @@ struct orbfe_aruco {
                 int rc = d_codes.ensure((size_t)std::max(ncodes, 1) * 8);
                 if (rc) return rc;
                 if (ncodes) ORBFE_HIP(hipMemcpy(d_codes.p, d.codes, (size_t)ncodes * 8, hipMemcpyHostToDevice));
+                // Dictionary::getMapCode() for the error-correction pass: std::map<uint64_t, uint16_t> = codes ascending, the FIRST id of
+                // a duplicated code (map.insert does not overwrite, dictionary.cpp:99-103)
+                std::vector<std::pair<unsigned long long, int>> m;
+                for (int k = 0; k < ncodes; k++) m.push_back({d.codes[k], k});
+                std::stable_sort(m.begin(), m.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+                std::vector<unsigned long long> sc;
+                std::vector<int32_t> si;
+                for (size_t k = 0; k < m.size(); k++)
+                    if (k == 0 || m[k].first != m[k - 1].first) { sc.push_back(m[k].first); si.push_back(m[k].second); }
+                nsorted = (int)sc.size();
+                if ((rc = d_scodes.ensure((size_t)std::max(nsorted, 1) * 8)) || (rc = d_sids.ensure((size_t)std::max(nsorted, 1) * 4))) return rc;
+                if (nsorted) {
+                    ORBFE_HIP(hipMemcpy(d_scodes.p, sc.data(), (size_t)nsorted * 8, hipMemcpyHostToDevice));
+                    ORBFE_HIP(hipMemcpy(d_sids.p, si.data(), (size_t)nsorted * 4, hipMemcpyHostToDevice));
+                }
+                tau = d.tau;
+                max_corr = (int)((float)tau * error_rate); // dictionary_based.cpp: static_cast<int>(static_cast<float>(tau()) * rate)
                 rows = cols = 0; // pyramid depth depends on S
                 return ORBFE_OK;
             }
@@ -184,7 +207,7 @@ struct orbfe_aruco {
             (rc = d_kept.ensure((size_t)AR_MAX_KEPT_BIG * sizeof(ArKept) * B)) ||
             (rc = d_rects.ensure((size_t)AR_MAX_RECTS * sizeof(ArRect) * B)) || (rc = d_counts.ensure((size_t)16 * B)) ||
             (rc = d_candidx.ensure((size_t)AR_MAX_RECTS * 4 * B)) || (rc = d_ncand.ensure((size_t)4 * B)) ||
-            (rc = d_result.ensure((size_t)AR_MAX_RECTS * 8 * B)) ||
+            (rc = d_result.ensure((size_t)AR_MAX_RECTS * 8 * B)) || (rc = d_msrc.ensure((size_t)AR_MAX_RECTS * 4 * B)) ||
             (rc = d_gpad.ensure(std::max<size_t>(gpad_fu32 * 4 * B, 16))) ||
             (rc = d_segs.ensure(std::max<size_t>(((size_t)sizeof(RelaySeg) << relay_tbits) * B, 16))) ||
             (rc = d_tailkeys.ensure((size_t)RL_KCAP * 8 * B)) || (rc = d_tailoff.ensure((size_t)RL_KCAP * 4 * B)) ||
@@ -277,11 +300,13 @@ struct orbfe_aruco {
         ORBFE_HIP(hipStreamWaitEvent(s, ev_join, 0));
         if (!ORBFE_SKIP_ARUCO(2)) hipLaunchKernelGGL(k_decode, dim3(B), dim3(512), 0, s, src0, pyr, d_levels.as<ArLevel>(), npyr,
                            d_rects.as<ArRect>(), AR_MAX_RECTS, d_candidx.as<int32_t>(), d_ncand.as<int32_t>(), S, nb,
-                           d_codes.as<unsigned long long>(), ncodes, d_result.as<int32_t>(), cols);
+                           d_codes.as<unsigned long long>(), ncodes, d_scodes.as<unsigned long long>(), d_sids.as<int32_t>(), nsorted,
+                           max_corr, d_result.as<int32_t>(), cols);
         timer.mark(s, "decode");
+        ORBFE_HIP(hipMemsetAsync(d_msrc.p, 0xff, (size_t)AR_MAX_RECTS * 4 * B, s)); // -1: slot holds no marker
         if (!ORBFE_SKIP_ARUCO(4)) hipLaunchKernelGGL(k_finalize, dim3(B), dim3(256), 0, s, d_rects.as<ArRect>(), AR_MAX_RECTS,
                            d_candidx.as<int32_t>(), d_ncand.as<int32_t>(), d_result.as<int32_t>(),
-                           d_pool.as<uint32_t>(), pool_fu32, d_out_m, capacity, d_n);
+                           d_pool.as<uint32_t>(), pool_fu32, d_out_m, capacity, d_n, corner_method == 1 ? 1 : 0, d_msrc.as<int32_t>());
         timer.mark(s, "finalize");
         ORBFE_HIP(hipGetLastError());
         return ORBFE_OK;
@@ -355,6 +380,58 @@ int orbfe_aruco_set_dictionary(orbfe_aruco* h, const char* dictionary)
 }
 
 int orbfe_aruco_max_markers(const orbfe_aruco* h) { return h ? AR_MAX_RECTS : ORBFE_ERR_INVALID; }
+
+int orbfe_aruco_set_error_correction_rate(orbfe_aruco* h, float rate)
+{
+    if (!h || !(rate >= 0.0f && rate <= 1.0f)) return fail(ORBFE_ERR_INVALID, "orbfe_aruco_set_error_correction_rate: rate must be in [0, 1]");
+    h->error_rate = rate;
+    h->max_corr = (int)((float)h->tau * rate);
+    return ORBFE_OK;
+}
+
+int orbfe_aruco_set_detection_mode(orbfe_aruco* h, int mode, float min_marker_size)
+{
+    if (!h) return fail(ORBFE_ERR_INVALID, "null handle");
+    // DM_NORMAL = 0 (markerdetector.h:60): full-resolution image + adaptive threshold, the mode of Frame.cc:136.  DM_FAST (1) and
+    // DM_VIDEO_FAST (2) switch to THRES_AUTO_FIXED (markerdetector.cpp:380-397): a global threshold retried with rand() and
+    // carried from frame to frame -- not built; refusing loudly beats detecting with another mode silently.
+    if (mode != 0) return fail(ORBFE_ERR_INVALID, "detection mode %d (DM_FAST / DM_VIDEO_FAST: THRES_AUTO_FIXED) is not implemented", mode);
+    if (min_marker_size != 0.0f && h->corner_method == 0)
+        return fail(ORBFE_ERR_INVALID, "minMarkerSize %g: only 0 is implemented (CORNER_LINES / CORNER_NONE reset it to 0 anyway)",
+                    (double)min_marker_size);
+    return ORBFE_OK; // setCornerRefinementMethod(!= CORNER_SUBPIX) sets minSize = 0 (markerdetector.cpp:399-402)
+}
+
+int orbfe_aruco_set_corner_refinement(orbfe_aruco* h, int method)
+{
+    if (!h) return fail(ORBFE_ERR_INVALID, "null handle");
+    // aruco::CornerRefinementMethod (markerdetector.h:62): CORNER_SUBPIX = 0 (cv::cornerSubPix, not built), CORNER_LINES = 1, CORNER_NONE = 2
+    if (method != 1 && method != 2) return fail(ORBFE_ERR_INVALID, "corner refinement method %d (CORNER_SUBPIX) is not implemented", method);
+    h->corner_method = method;
+    return ORBFE_OK;
+}
+
+int orbfe_aruco_marker_contour(orbfe_aruco* h, int frame, int marker, int32_t* xy, int capacity, int32_t* n)
+{
+    if (!h || !n || frame < 0 || frame >= h->last_nframes || marker < 0 || marker >= AR_MAX_RECTS || (capacity > 0 && !xy))
+        return fail(ORBFE_ERR_INVALID, "orbfe_aruco_marker_contour: invalid argument");
+    int rc = use_device(h->device);
+    if (rc) return rc;
+    ORBFE_HIP(hipDeviceSynchronize());
+    int32_t src = -1;
+    ORBFE_HIP(hipMemcpy(&src, h->d_msrc.as<int32_t>() + (size_t)frame * AR_MAX_RECTS + marker, 4, hipMemcpyDeviceToHost));
+    if (src < 0 || src >= AR_MAX_RECTS) return fail(ORBFE_ERR_INVALID, "orbfe_aruco_marker_contour: no such marker in the last batch");
+    ArRect r;
+    ORBFE_HIP(hipMemcpy(&r, h->d_rects.as<ArRect>() + (size_t)frame * AR_MAX_RECTS + src, sizeof r, hipMemcpyDeviceToHost));
+    *n = r.len;
+    const int m = std::min(r.len, capacity);
+    if (m > 0) {
+        std::vector<uint32_t> p(m);
+        ORBFE_HIP(hipMemcpy(p.data(), h->d_pool.as<uint32_t>() + (size_t)frame * h->pool_fu32 + r.off, (size_t)m * 4, hipMemcpyDeviceToHost));
+        for (int i = 0; i < m; i++) { xy[2 * i] = (int32_t)(p[i] & 0xffff); xy[2 * i + 1] = (int32_t)(p[i] >> 16); }
+    }
+    return ORBFE_OK;
+}
 
 int orbfe_aruco_detect_batch_device(orbfe_aruco* h, const uint8_t* d_imgs, int nframes, size_t frame_stride, int rows,
                                     int cols, size_t step, orbfe_marker* d_out, int capacity, int32_t* d_n_out,

@@ -1552,6 +1552,8 @@ __global__ __launch_bounds__(DC_WAVES * 64) void k_decode(ImgView src0, ImgView 
                                                const int32_t* __restrict__ cand_idx,
                                                const int32_t* __restrict__ ncand, int S, int nb,
                                                const unsigned long long* __restrict__ codes, int ncodes,
+                                               const unsigned long long* __restrict__ scodes, const int32_t* __restrict__ sids,
+                                               int nsorted, int max_corr,
                                                int32_t* __restrict__ result /*per slot: id, nrot*/, int W0)
 {
     __builtin_amdgcn_s_setprio(2); // latency-bound: its few waves go first when a VALU-bound kernel shares the CU
@@ -1726,6 +1728,18 @@ __global__ __launch_bounds__(DC_WAVES * 64) void k_decode(ImgView src0, ImgView 
                     best = wave_min(best);
                     if (best != 0x7fffffff) { id = best; nrot = rr; break; }
                 }
+                if (id < 0 && max_corr > 0) {
+                    // error correction (dictionary_based.cpp:1423-1560): the dictionary's code map in ascending code order, the four
+                    // rotations inside, first entry closer than int(tau * error_correction_rate) bits wins.  scodes / sids = that map.
+                    int best = 0x7fffffff;
+                    for (int i = lane; i < nsorted && best == 0x7fffffff; i += 64) {
+                        const unsigned long long c = scodes[i];
+                        for (int rr = 0; rr < 4; rr++)
+                            if (__popcll(c ^ s_ids[wid][rr]) < max_corr) { best = i * 4 + rr; break; }
+                    }
+                    best = wave_min(best);
+                    if (best != 0x7fffffff) { id = sids[best >> 2]; nrot = best & 3; }
+                }
             }
             if (lane == 0) { res[0] = id; res[1] = nrot; }
             __builtin_amdgcn_wave_barrier();
@@ -1757,7 +1771,8 @@ __global__ __launch_bounds__(256) void k_finalize(const ArRect* __restrict__ rec
                                                   const int32_t* __restrict__ ncand, const int32_t* __restrict__ result,
                                                   const uint32_t* __restrict__ pool, size_t pool_fstride,
                                                   orbfe_marker* __restrict__ out, int out_cap,
-                                                  int32_t* __restrict__ n_out)
+                                                  int32_t* __restrict__ n_out, int refine_lines,
+                                                  int32_t* __restrict__ out_src /*per output slot: its rectangle (contour)*/)
 {
     __builtin_amdgcn_s_setprio(2); // latency-bound: its few waves go first when a VALU-bound kernel shares the CU
     __shared__ int s_id[AR_MAX_RECTS], s_src[AR_MAX_RECTS], s_rot[AR_MAX_RECTS], s_per[AR_MAX_RECTS], s_rm[AR_MAX_RECTS];
@@ -1812,6 +1827,17 @@ __global__ __launch_bounds__(256) void k_finalize(const ArRect* __restrict__ rec
     const int lane = tid & 63, wid = tid >> 6;
     for (int i = wid; i < m; i += 4) {
         if (s_rm[i]) continue;
+        if (lane == 0 && s_slot[i] < AR_MAX_RECTS) out_src[(size_t)f * AR_MAX_RECTS + s_slot[i]] = s_src[i];
+        if (!refine_lines) { // CORNER_NONE: the rotated approxPolyDP corners as they are (:8634-8701 does nothing)
+            const int slot = s_slot[i];
+            if (lane == 0 && slot < out_cap) {
+                orbfe_marker mk;
+                mk.id = s_id[i];
+                for (int k = 0; k < 4; k++) { mk.corners[k][0] = s_c[i][k][0]; mk.corners[k][1] = s_c[i][k][1]; }
+                out[(size_t)f * out_cap + slot] = mk;
+            }
+            continue;
+        }
         const ArRect& r = R[s_src[i]];
         const uint32_t* P = pool + (size_t)f * pool_fstride + r.off;
         const int len = r.len;

@@ -63,10 +63,10 @@ __global__ void k_prefilter(ArRect* rects, int rect_cap, const int32_t* counts, 
                             int32_t* cand_idx, int32_t* ncand_out);
 __global__ void k_decode(ImgView src0, ImgView pyr, const ArLevel* levels, int nlevels, const ArRect* rects,
                          int rect_cap, const int32_t* cand_idx, const int32_t* ncand, int S, int nb,
-                         const unsigned long long* codes, int ncodes, int32_t* result, int W0);
+                         const unsigned long long* codes, int ncodes, const unsigned long long* scodes, const int32_t* sids, int nsorted, int max_corr, int32_t* result, int W0);
 __global__ void k_finalize(const ArRect* rects, int rect_cap, const int32_t* cand_idx, const int32_t* ncand,
                            const int32_t* result, const uint32_t* pool, size_t pool_fstride, orbfe_marker* out,
-                           int out_cap, int32_t* n_out);
+                           int out_cap, int32_t* n_out, int refine_lines, int32_t* out_src);
 
 #define CT_THREADS 256          // threads that run the whole kernel
 #define CT_WAVES (CT_THREADS / 64)

@@ -540,6 +540,11 @@ class ArucoOracle:
             self.L.oracle_aruco_destroy(self.h)
             self.h = None
 
+    def set_params(self, error_correction_rate=0.0, corner_lines=True):
+        """MarkerDetector::Params::error_correction_rate and cornerRefinementM == CORNER_LINES (False: CORNER_NONE)."""
+        self.L.oracle_aruco_set_params.argtypes = [C.c_void_p, C.c_float, C.c_int]
+        self.L.oracle_aruco_set_params(self.h, error_correction_rate, int(corner_lines))
+
     def detect(self, img, capacity=256):
         img = np.ascontiguousarray(img, np.uint8)
         out = np.zeros(capacity, MARKER_DTYPE)

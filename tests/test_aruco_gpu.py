@@ -175,3 +175,74 @@ def test_full_hd_frame_with_many_contours(orbfe, oracle):
     assert len(want) > 0 and np.array_equal(got["id"], want["id"])
     assert np.allclose(got["corners"], want["corners"], atol=1e-3)
     assert det.counts(0)["nkept"] > 1024
+
+
+def _damaged_markers_image(dic, ids, flips, bit=8):
+    """White 480x640 frame with axis-aligned markers; marker k has flips[k] inner cells inverted."""
+    img = np.full((480, 640), 235, np.uint8)
+    rng = np.random.default_rng(3)
+    x = 30
+    for mid, nf in zip(ids, flips):
+        m = synth.render_marker(dic, mid, bit, quiet=1).copy()
+        nb = m.shape[0] // bit - 4
+        cells = rng.permutation(nb * nb)[:nf]
+        for c in cells:
+            cy, cx = 2 + c // nb, 2 + c % nb
+            blk = m[cy * bit:(cy + 1) * bit, cx * bit:(cx + 1) * bit]
+            m[cy * bit:(cy + 1) * bit, cx * bit:(cx + 1) * bit] = 255 - blk
+        s = m.shape[0]
+        img[200:200 + s, x:x + s] = m
+        x += s + 20
+    noise = np.random.default_rng(4).normal(0, 2.0, img.shape)
+    return np.clip(np.rint(img + noise), 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("dic,rate", [("ARUCO_MIP_36h12", 0.5), ("ARUCO_MIP_36h12", 0.0), ("TAG36h11", 0.3), ("ARUCO_MIP_25h7", 1.0)])
+def test_error_correction_rate(orbfe, oracle, dic, rate):
+    """MarkerDetector(dict, error_correction_rate) (markerdetector.h:222-229 -> dictionary_based.cpp:1423-1560): damaged markers are
+    accepted when closer than int(tau * rate) bits to a dictionary code; ids, order and corners equal the oracle's."""
+    ids, flips = [3, 17, 42, 60], [0, 2, 5, 9]
+    img = _damaged_markers_image(dic, ids, flips)
+    det = orbfe.MarkerDetector(dic)
+    det.setDictionary(dic, rate)
+    ora = oracle.ArucoOracle(dic)
+    ora.set_params(rate, True)
+    got, want = det.detect(img), ora.detect(img)
+    assert np.array_equal(got["id"], want["id"]) and np.allclose(got["corners"], want["corners"], atol=1e-3)
+    tau = {"ARUCO_MIP_36h12": 12, "TAG36h11": 11, "ARUCO_MIP_25h7": 7}[dic]
+    maxc = int(np.float32(tau) * np.float32(rate))
+    expect = sorted(i for i, f in zip(ids, flips) if f == 0 or f < maxc)
+    if 2 * (maxc - 1) < tau:    # correction radius below half the dictionary distance: the accepted code is the damaged marker's own
+        assert sorted(got["id"].tolist()) == expect, (got["id"], expect)
+    else:                       # beyond it the FIRST close entry in code order wins, not the nearest (as in the reference)
+        assert len(got) >= len(expect) - 1
+
+
+def test_corner_none_modes_and_contours(orbfe, oracle):
+    """setCornerRefinementMethod(CORNER_NONE) returns the rotated approxPolyDP corners; aruco::Marker::contourPoints are the border
+    the rectangle came from; the modes that are not built are refused loudly."""
+    img, truth = synth.scene(480, 640, 2, "ARUCO", 4)
+    det = orbfe.MarkerDetector("ARUCO")
+    ora = oracle.ArucoOracle("ARUCO")
+    lines = det.detect(img)
+    det.setCornerRefinementMethod(det.CORNER_NONE); ora.set_params(0.0, False)
+    got, want = det.detect(img), ora.detect(img)
+    assert np.array_equal(got["id"], want["id"]) and np.array_equal(got["corners"], want["corners"])
+    assert np.array_equal(got["corners"], np.rint(got["corners"])) and not np.array_equal(got["corners"], lines["corners"])
+    for i in range(len(got)):
+        c = det.contour(i)
+        assert len(c) > 70                                     # only borders longer than 70 points become candidates
+        # every corner of the unrefined marker is a point of its contour, and the contour is a closed 8-connected chain
+        for k in range(4):
+            assert np.any(np.all(c == got["corners"][i, k].astype(np.int32), axis=1))
+        step = np.abs(np.diff(np.vstack([c, c[:1]]), axis=0)).max(axis=1)
+        assert step.max() == 1 and step.min() == 1
+    with pytest.raises(orbfe.OrbfeError):
+        det.contour(len(got))
+    det.setCornerRefinementMethod(det.CORNER_LINES)
+    assert np.array_equal(det.detect(img)["corners"], lines["corners"])
+    det.setDetectionMode(det.DM_NORMAL)
+    for bad in (lambda: det.setDetectionMode(det.DM_FAST), lambda: det.setDetectionMode(det.DM_VIDEO_FAST, 0.1),
+                lambda: det.setCornerRefinementMethod(det.CORNER_SUBPIX), lambda: det.setDictionary("ARUCO", 1.5)):
+        with pytest.raises(orbfe.OrbfeError):
+            bad()
