@@ -179,16 +179,18 @@ int orbfe_search_for_initialization(const orbfe_keypoint* kps1, const uint8_t* d
  *           of the (CurrentFrame, LastFrame) and (CurrentFrame, KeyFrame) variants (:1413-1433, :1551-1571);
  *           best_idx = -1, distances 256, levels -1 when there is no candidate.  match / nmatches may be NULL.
  *   mode 1: the whole loop: accept when best <= th_high (TH_HIGH = 100) and not (same octave and best > nnratio*second)
- *           (:121-128); an accepted keypoint is taken for the queries after it.  match[q] = keypoint index or -1,
- *           *nmatches = accepted count, taken[] updated in place.  The raw outputs may be NULL.
+ *           (:121-128); an accepted keypoint is taken for the queries after it when the map point it received is observed
+ *           (q_observed[q] = pMP->Observations() > 0, the test of :91-93; NULL = all observed).  match[q] = keypoint index or
+ *           -1 (a keypoint assigned twice keeps the later query, as F.mvpMapPoints[bestIdx] = pMP does), *nmatches =
+ *           accepted count, taken[] updated in place.  The raw outputs may be NULL.
  * Host pointers.  bounds as for orbfe_search_for_initialization; mono (no right-image test). */
 typedef struct orbfe_window_query {
     float x, y, r;
     int32_t min_level, max_level;
 } orbfe_window_query;
 int orbfe_search_by_projection(const orbfe_keypoint* kps, const uint8_t* desc, int n, int cols, int rows, const float* bounds,
-                               const orbfe_window_query* queries, const uint8_t* qdesc, int nq, uint8_t* taken, int mode,
-                               int th_high, float nnratio, int32_t* best_idx, int32_t* best_dist, int32_t* best_level,
+                               const orbfe_window_query* queries, const uint8_t* qdesc, int nq, uint8_t* taken, const uint8_t* q_observed,
+                               int mode, int th_high, float nnratio, int32_t* best_idx, int32_t* best_dist, int32_t* best_level,
                                int32_t* second_dist, int32_t* second_level, int32_t* match, int32_t* nmatches, int device);
 
 /* ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono) (src/ORBmatcher.cc:1332-1474; what

@@ -19,7 +19,7 @@
  * minimax kernels, error < 1e-16) and rounds once to float. That equals the
  * correctly rounded float result except when the true value lies within
  * ~1e-16 relative of a float rounding boundary; glibc's cosf/sinf have the same
- * property, and tests/test_oracle_math.py checks agreement with the host libm
+ * property, and tests/test_oracle_cpu.py checks agreement with the host libm
  * over a dense angle sweep.
  */
 #ifndef ORBFE_MATH_H

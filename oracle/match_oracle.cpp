@@ -197,17 +197,21 @@ struct WindowQuery { float x, y, r; int32_t min_level, max_level; };
 int oracle_search_by_projection(const void* kps_, const uint8_t* desc, int n, int cols, int rows, const void* queries_,
                                 const uint8_t* qdesc, int nq, uint8_t* taken, int mode, int th_high, float nnratio,
                                 int32_t* best_idx, int32_t* best_dist, int32_t* best_level, int32_t* second_dist,
-                                int32_t* second_level, int32_t* match, const float* bounds)
+                                int32_t* second_level, int32_t* match, const float* bounds, const uint8_t* q_observed)
 {
+    /* q_observed[q] = the query's map point has Observations() > 0: only then does the keypoint it is assigned to block the
+     * queries after it (:91-93 test F.mvpMapPoints[idx]->Observations() > 0); NULL = every map point is observed */
     const KeyPoint* k = (const KeyPoint*)kps_;
     const WindowQuery* Q = (const WindowQuery*)queries_;
     FrameGrid F(k, n, cols, rows, bounds);
     int nmatches = 0;
+    std::vector<uint8_t> blocked(n, 0); /* F.mvpMapPoints[idx] && F.mvpMapPoints[idx]->Observations() > 0; taken == NULL: none yet */
+    for (int i = 0; i < n; i++) blocked[i] = taken ? taken[i] : 0;
     for (int q = 0; q < nq; q++) {
         const std::vector<int> vIndices = F.GetFeaturesInArea(Q[q].x, Q[q].y, Q[q].r, Q[q].min_level, Q[q].max_level);
         int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
         for (int idx : vIndices) {
-            if (taken && taken[idx]) continue;
+            if (blocked[idx]) continue;
             const int dist = DescriptorDistance(qdesc + (size_t)q * 32, desc + (size_t)idx * 32);
             if (dist < bestDist) {
                 bestDist2 = bestDist; bestDist = dist;
@@ -224,7 +228,7 @@ int oracle_search_by_projection(const void* kps_, const uint8_t* desc, int n, in
             if (bestIdx >= 0 && bestDist <= th_high) {
                 if (bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) continue;
                 match[q] = bestIdx;
-                if (taken) taken[bestIdx] = 1;
+                if (!q_observed || q_observed[q]) { blocked[bestIdx] = 1; if (taken) taken[bestIdx] = 1; }
                 nmatches++;
             }
         }

@@ -87,7 +87,7 @@ def load():
     L.orbfe_extractor_set_aux_stream.argtypes = [vp, vp]
     if hasattr(L, "orbfe_knn2"):
         L.orbfe_debug_control.argtypes = [C.c_char_p, i32]
-        L.orbfe_search_by_projection.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, i32, vp, i32, i32, C.c_float] + [vp] * 7 + [i32]
+        L.orbfe_search_by_projection.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, i32, vp, vp, i32, i32, C.c_float] + [vp] * 7 + [i32]
         L.orbfe_hamming.argtypes = [vp, vp]
         L.orbfe_search_by_projection_last_frame.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, f32,
                                                             i32, i32, vp, vp, i32]
@@ -345,7 +345,7 @@ WINDOW_QUERY_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("r", "<f4"), ("min_l
 
 
 def search_by_projection(kps, desc, cols, rows, queries, qdesc, taken=None, mode=0, th_high=100, nnratio=0.8, device=0,
-                         bounds=None):
+                         bounds=None, q_observed=None):
     """The matching loop of ORBmatcher::SearchByProjection(Frame&, vpMapPoints, th) (ORBmatcher.cc:45-129) on flat arrays:
     queries = WINDOW_QUERY_DTYPE records (projected position, radius, octave range), qdesc = their descriptors.
     mode 0: best / second-best + octaves per query; mode 1: the whole loop (accept rule, taken keypoints)."""
@@ -359,7 +359,9 @@ def search_by_projection(kps, desc, cols, rows, queries, qdesc, taken=None, mode
     bnd = None if bounds is None else np.ascontiguousarray(bounds, np.float32)
     _check(L, L.orbfe_search_by_projection(_p(kps), _p(desc), len(kps), cols, rows, None if bnd is None else _p(bnd),
                                            _p(queries), _p(qdesc), nq,
-                                           None if tk is None else _p(tk), mode, th_high, nnratio, *[_p(o) for o in out],
+                                           None if tk is None else _p(tk),
+                                           None if q_observed is None else _p(np.ascontiguousarray(q_observed, np.uint8)),
+                                           mode, th_high, nnratio, *[_p(o) for o in out],
                                            C.byref(nm), device), "orbfe_search_by_projection")
     return dict(best_idx=out[0][:nq], best_dist=out[1][:nq], best_level=out[2][:nq], second_dist=out[3][:nq],
                 second_level=out[4][:nq], match=out[5][:nq], nmatches=nm.value, taken=tk)

@@ -575,9 +575,9 @@ __global__ __launch_bounds__(256) void k_knn2_csr(const uint8_t* __restrict__ Q,
 #define SBP_THREADS 1024
 #define SBP_CELLS (GRID_COLS * GRID_ROWS)
 struct SbpQuery { float x, y, r; int32_t min_level, max_level; }; // r < 0: no search (the point did not project into the frame)
-struct SbpBest { // mode 2 only
+struct SbpBest { // mode 2 only (q_blocks: modes 1 and 2)
     const float* q_angle;     // LastFrame.mvKeysUn[i].angle per query
-    const uint8_t* q_blocks;  // "the query's map point has Observations() > 0" (:1397-1399); NULL = all
+    const uint8_t* q_blocks;  // "the query's map point has Observations() > 0" (:91-93, :1397-1399); NULL = all
     float factor;             // rotation histogram factor (:1341)
     int check_ori;
     int32_t* match_cur;       // n entries
@@ -826,7 +826,8 @@ __global__ __launch_bounds__(SBP_THREADS) void k_search_by_projection(
             const int bestLevel = s_lvl[bestRank], bestLevel2 = sk != ~0ull ? (int)s_lvl[sk & 0xffff] : -1;
             if (bestDist <= th_high && !(bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(nnratio, (float)bestDist2))) {
                 m = (int)(s_sorted[bestRank] & 0xffff);
-                if (lane == 0) { s_taken[bestRank] = 1; if (taken) taken[m] = 1; }
+                // the keypoint blocks later queries only if the map point it received is observed (:91-93)
+                if (lane == 0 && (!bo.q_blocks || bo.q_blocks[q])) { s_taken[bestRank] = 1; if (taken) taken[m] = 1; }
                 nmatches++;
             }
         }
@@ -1218,8 +1219,8 @@ int orbfe_search_for_initialization(const orbfe_keypoint* kps1, const uint8_t* d
 }
 
 int orbfe_search_by_projection(const orbfe_keypoint* kps, const uint8_t* desc, int n, int cols, int rows, const float* bounds,
-                               const orbfe_window_query* queries, const uint8_t* qdesc, int nq, uint8_t* taken, int mode,
-                               int th_high, float nnratio, int32_t* best_idx, int32_t* best_dist, int32_t* best_level,
+                               const orbfe_window_query* queries, const uint8_t* qdesc, int nq, uint8_t* taken, const uint8_t* q_observed,
+                               int mode, int th_high, float nnratio, int32_t* best_idx, int32_t* best_dist, int32_t* best_level,
                                int32_t* second_dist, int32_t* second_level, int32_t* match, int32_t* nmatches, int device)
 {
     if (n < 0 || nq < 0 || cols <= 0 || rows <= 0 || (mode != 0 && mode != 1) || (n && (!kps || !desc)) ||
@@ -1243,8 +1244,9 @@ int orbfe_search_by_projection(const orbfe_keypoint* kps, const uint8_t* desc, i
             (rc = w.q.ensure((size_t)nq * sizeof(orbfe_window_query))) || (rc = w.t.ensure((size_t)nq * 32)) ||
             (rc = w.prev.ensure((size_t)std::max(n, 1))) || (rc = w.csr_idx.ensure((size_t)nq * stride * 2)) ||
             (rc = w.csr_dist.ensure((size_t)nq * stride)) || (rc = w.csr_cnt.ensure(qo)) || (rc = w.obest.ensure(qo * 6)) ||
-            (rc = w.nm.ensure(16)) || (rc = w.overflow.ensure(16)))
+            (rc = w.nm.ensure(16)) || (rc = w.overflow.ensure(16)) || (rc = w.pidx.ensure((size_t)nq + 16)))
             return rc;
+        if (q_observed) ORBFE_HIP(hipMemcpy(w.pidx.p, q_observed, (size_t)nq, hipMemcpyHostToDevice));
         if (n) {
             ORBFE_HIP(hipMemcpy(w.kps.p, kps, (size_t)n * sizeof(orbfe_keypoint), hipMemcpyHostToDevice));
             ORBFE_HIP(hipMemcpy(w.desc.p, desc, (size_t)n * 32, hipMemcpyHostToDevice));
@@ -1255,13 +1257,15 @@ int orbfe_search_by_projection(const orbfe_keypoint* kps, const uint8_t* desc, i
         ORBFE_HIP(hipMemset(w.overflow.p, 0, 4));
         ORBFE_HIP(hipMemset(w.nm.p, 0, 4));
         int32_t* o = w.obest.as<int32_t>();
+        SbpBest sb{};
+        sb.q_blocks = q_observed ? w.pidx.as<uint8_t>() : nullptr;
         ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_by_projection),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_search_by_projection, dim3(1), dim3(SBP_THREADS), lds, 0, w.kps.as<orbfe_keypoint>(),
                            w.desc.as<uint8_t>(), n, ncap, frame_bounds(cols, rows, bounds), w.q.as<SbpQuery>(), w.t.as<uint8_t>(), nq,
                            taken ? w.prev.as<uint8_t>() : nullptr, mode, th_high, nnratio, w.csr_idx.as<uint16_t>(),
                            w.csr_dist.as<uint8_t>(), w.csr_cnt.as<int32_t>(), stride, o, o + nq, o + 2 * nq, o + 3 * nq,
-                           o + 4 * nq, o + 5 * nq, w.nm.as<int32_t>(), w.overflow.as<int32_t>(), SbpBest{});
+                           o + 4 * nq, o + 5 * nq, w.nm.as<int32_t>(), w.overflow.as<int32_t>(), sb);
         ORBFE_HIP(hipGetLastError());
         ORBFE_HIP(hipDeviceSynchronize());
         int32_t ovf = 0;

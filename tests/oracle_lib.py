@@ -217,7 +217,7 @@ def knn2_csr(Q, T, off, idx, init=256):
 WINDOW_QUERY_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("r", "<f4"), ("min_level", "<i4"), ("max_level", "<i4")])
 
 
-def search_by_projection(kps, desc, cols, rows, queries, qdesc, taken=None, mode=0, th_high=100, nnratio=0.8, bounds=None):
+def search_by_projection(kps, desc, cols, rows, queries, qdesc, taken=None, mode=0, th_high=100, nnratio=0.8, bounds=None, q_observed=None):
     """ORBmatcher::SearchByProjection(Frame, MapPoints) matching loop on flat arrays; see oracle/match_oracle.cpp."""
     L = lib()
     kps = np.ascontiguousarray(kps); desc = np.ascontiguousarray(desc, np.uint8)
@@ -227,10 +227,11 @@ def search_by_projection(kps, desc, cols, rows, queries, qdesc, taken=None, mode
     out = [np.zeros(nq, np.int32) for _ in range(6)]
     L.oracle_search_by_projection.restype = C.c_int
     L.oracle_search_by_projection.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
-                                              C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float] + [C.c_void_p] * 7
+                                              C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float] + [C.c_void_p] * 8
+    qo = None if q_observed is None else np.ascontiguousarray(q_observed, np.uint8)
     nm = L.oracle_search_by_projection(_p(kps), _p(desc), len(kps), cols, rows, _p(queries), _p(qdesc), nq,
                                        None if tk is None else _p(tk), mode, th_high, nnratio, *[_p(o) for o in out],
-                                       None if bounds is None else _p(_bounds(bounds)))
+                                       None if bounds is None else _p(_bounds(bounds)), None if qo is None else _p(qo))
     return dict(best_idx=out[0], best_dist=out[1], best_level=out[2], second_dist=out[3], second_level=out[4],
                 match=out[5], nmatches=nm, taken=tk)
 

@@ -1,0 +1,205 @@
+// TEST INFRASTRUCTURE ONLY -- drives the C++ shims of include/shims/ (ORBextractor, aruco::MarkerDetector, ORBmatcher) the way the
+// reference's Frame / Tracking code does, against the mock OpenCV / SLAM headers of tests/mock_cv/, and dumps inputs and results as
+// raw arrays; tests/test_shims_gpu.py repeats every call through the ctypes binding and compares.
+//   shim_driver <frames.raw> <rows> <cols> <nframes> <out prefix>          exit 3 = no GPU (the library has no CPU fallback)
+#include <cstdio>
+#include <cstdlib>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "ORBextractor.h"
+#include "MarkerDetector.h"
+#include "ORBmatcher.h"
+
+using namespace ORB_SLAM2;
+
+float Frame::fx, Frame::fy, Frame::cx, Frame::cy, Frame::invfx, Frame::invfy;
+float Frame::mnMinX, Frame::mnMaxX, Frame::mnMinY, Frame::mnMaxY;
+
+static std::string g_prefix;
+template <class T> static void dump(const char* name, const T* p, size_t n)
+{
+    FILE* f = fopen((g_prefix + "_" + name + ".bin").c_str(), "wb");
+    if (n) fwrite(p, sizeof(T), n, f);
+    fclose(f);
+}
+template <class T> static void dump(const char* name, const std::vector<T>& v) { dump(name, v.data(), v.size()); }
+
+static cv::Mat mat32(int r, int c, std::initializer_list<float> v)
+{
+    cv::Mat m(r, c, CV_32F);
+    int i = 0;
+    for (float x : v) { m.at<float>(i / c, i % c) = x; i++; }
+    return m;
+}
+
+static void make_frame(Frame& F, ORBextractor& ex, const cv::Mat& im)
+{
+    // Frame::Frame (Frame.cc:74-127) as far as the matcher needs it
+    ex(im, cv::Mat(), F.mvKeys, F.mDescriptors);
+    F.N = (int)F.mvKeys.size();
+    F.mvKeysUn = F.mvKeys; // no distortion
+    F.mvpMapPoints.assign(F.N, (MapPoint*)NULL);
+    F.mvbOutlier.assign(F.N, false);
+    F.mnScaleLevels = ex.GetLevels();
+    F.mfScaleFactor = ex.GetScaleFactor();
+    F.mfLogScaleFactor = log(F.mfScaleFactor);
+    F.mvScaleFactors = ex.GetScaleFactors();
+    F.mvInvScaleFactors = ex.GetInverseScaleFactors();
+    F.mvLevelSigma2 = ex.GetScaleSigmaSquares();
+    F.mvInvLevelSigma2 = ex.GetInverseScaleSigmaSquares();
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 6) return 2;
+    const int rows = atoi(argv[2]), cols = atoi(argv[3]), nframes = atoi(argv[4]);
+    g_prefix = argv[5];
+    if (orbfe_device_count() == 0) { fprintf(stderr, "no HIP device: %s\n", orbfe_last_error()); return 3; }
+    std::vector<unsigned char> raw((size_t)rows * cols * nframes);
+    FILE* f = fopen(argv[1], "rb");
+    if (!f || fread(raw.data(), 1, raw.size(), f) != raw.size()) return 2;
+    fclose(f);
+    Frame::fx = 517.3f; Frame::fy = 516.5f; Frame::cx = 318.6f; Frame::cy = 255.3f;
+    Frame::mnMinX = 0; Frame::mnMinY = 0; Frame::mnMaxX = (float)cols; Frame::mnMaxY = (float)rows;
+
+    // ---- ORBextractor through operator() (Frame::ExtractORB, Frame.cc:200-206)
+    ORBextractor ex(1000, 1.2f, 8, 20, 7);
+    std::vector<Frame> F(nframes);
+    std::vector<int> nk;
+    for (int i = 0; i < nframes; i++) {
+        cv::Mat im(rows, cols, CV_8UC1, raw.data() + (size_t)i * rows * cols, (size_t)cols);
+        make_frame(F[i], ex, im);
+        nk.push_back(F[i].N);
+        dump(("kps" + std::to_string(i)).c_str(), F[i].mvKeys);
+        dump(("desc" + std::to_string(i)).c_str(), F[i].mDescriptors.data, (size_t)F[i].N * 32);
+    }
+    dump("nk", nk);
+    {   // empty image: outputs untouched (ORBextractor.cc:1046)
+        std::vector<cv::KeyPoint> k(3);
+        cv::Mat d;
+        ex(cv::Mat(), cv::Mat(), k, d);
+        if (k.size() != 3) return 10;
+    }
+
+    // ---- aruco::MarkerDetector as Frame.cc:129-142 configures and calls it
+    aruco::MarkerDetector det;
+    det.setDictionary("ARUCO");
+    det.setDetectionMode(aruco::DM_NORMAL);
+    det.getParameters().setCornerRefinementMethod(aruco::CORNER_LINES);
+    aruco::CameraParameters cam;
+    cam.CameraMatrix = mat32(3, 3, {517.306408f, 0, 318.643040f, 0, 516.469215f, 255.313989f, 0, 0, 1});
+    cam.Distorsion = mat32(1, 5, {0.262383f, -0.953104f, -0.005358f, 0.002628f, 1.163314f});
+    cam.CamSize = cv::Size(1280, 720);
+    {
+        cv::Mat im(rows, cols, CV_8UC1, raw.data(), (size_t)cols);
+        std::vector<aruco::Marker> mk = det.detect(im, cam, 0.187f);
+        std::vector<float> rec; // id, 8 corner coordinates, rvec, tvec, contour length
+        for (auto& m : mk) {
+            rec.push_back((float)m.id);
+            for (int k = 0; k < 4; k++) { rec.push_back(m[k].x); rec.push_back(m[k].y); }
+            for (int k = 0; k < 3; k++) rec.push_back(m.Rvec.at<float>(k, 0));
+            for (int k = 0; k < 3; k++) rec.push_back(m.Tvec.at<float>(k, 0));
+            rec.push_back((float)m.contourPoints.size());
+            if (m.ssize != 0.187f || m.dict_info != "ARUCO") return 11;
+        }
+        dump("markers", rec);
+        bool threw = false;
+        try { det.setDetectionMode(aruco::DM_FAST); } catch (const cv::Exception&) { threw = true; }
+        if (!threw) return 12;
+        threw = false;
+        try { det.setDictionary("NO_SUCH_DICTIONARY"); } catch (const std::runtime_error&) { threw = true; }
+        if (!threw) return 13;
+    }
+
+    // ---- ORBmatcher members
+    std::vector<int> res;
+    ORBmatcher matcher(0.9f, true);
+    {   // Tracking::MonocularInitialization (Tracking.cc:520-532)
+        std::vector<cv::Point2f> prev(F[0].mvKeysUn.size());
+        for (size_t i = 0; i < prev.size(); i++) prev[i] = F[0].mvKeysUn[i].pt;
+        std::vector<int> m12;
+        res.push_back(matcher.SearchForInitialization(F[0], F[1], prev, m12, 100));
+        dump("sfi_m12", m12);
+        dump("sfi_prev", (const float*)prev.data(), prev.size() * 2);
+        res.push_back(ORBmatcher::DescriptorDistance(F[0].mDescriptors.row(0), F[1].mDescriptors.row(0)));
+    }
+    // map points of frame 0: back-projection at a depth that depends on the index; frame 1 sees them from a small motion
+    Frame& L = F[0];
+    Frame& C = F[1];
+    std::vector<MapPoint> mps(L.N);
+    std::vector<float> x3(3 * (size_t)L.N), dmin(L.N), dmax(L.N);
+    for (int i = 0; i < L.N; i++) {
+        const float z = 1.0f + 0.1f * (float)(i % 50);
+        const float X = (L.mvKeysUn[i].pt.x - Frame::cx) / Frame::fx * z, Y = (L.mvKeysUn[i].pt.y - Frame::cy) / Frame::fy * z;
+        mps[i].mWorldPos = mat32(3, 1, {X, Y, z});
+        const float d = sqrt(X * X + Y * Y + z * z);
+        mps[i].mNormal = mat32(3, 1, {X / d, Y / d, z / d});
+        mps[i].mDescriptor = L.mDescriptors.row(i);
+        mps[i].mfMaxDistance = d * L.mvScaleFactors[L.mvKeysUn[i].octave];
+        mps[i].mfMinDistance = mps[i].mfMaxDistance / L.mvScaleFactors[L.mnScaleLevels - 1];
+        mps[i].nObs = (i % 7 == 0) ? 0 : 2;
+        x3[3 * i] = X; x3[3 * i + 1] = Y; x3[3 * i + 2] = z;
+        dmin[i] = mps[i].mfMinDistance; dmax[i] = mps[i].mfMaxDistance;
+        if (i % 9 != 0) L.mvpMapPoints[i] = &mps[i];
+    }
+    dump("x3", x3); dump("dmin", dmin); dump("dmax", dmax);
+    C.mTcw = mat32(4, 4, {1, -0.002f, 0.001f, 0.004f, 0.002f, 1, -0.003f, -0.006f, -0.001f, 0.003f, 1, 0.01f, 0, 0, 0, 1});
+    {   // Tracking::TrackWithMotionModel (Tracking.cc:1011)
+        res.push_back(matcher.SearchByProjection(C, L, 15.0f, true));
+        std::vector<int> got(C.N, -1);
+        for (int i = 0; i < C.N; i++) got[i] = C.mvpMapPoints[i] ? (int)(C.mvpMapPoints[i] - mps.data()) : -1;
+        dump("last_frame", got);
+        C.mvpMapPoints.assign(C.N, (MapPoint*)NULL);
+    }
+    KeyFrame KF; // frame 0 as a keyframe
+    KF.N = L.N; KF.mvKeys = L.mvKeys; KF.mvKeysUn = L.mvKeysUn; KF.mDescriptors = L.mDescriptors; KF.mvpMapPoints = L.mvpMapPoints;
+    KF.fx = Frame::fx; KF.fy = Frame::fy; KF.cx = Frame::cx; KF.cy = Frame::cy;
+    KF.mnMinX = 0; KF.mnMinY = 0; KF.mnMaxX = cols; KF.mnMaxY = rows;
+    KF.mnScaleLevels = L.mnScaleLevels; KF.mfScaleFactor = L.mfScaleFactor; KF.mfLogScaleFactor = L.mfLogScaleFactor;
+    KF.mvScaleFactors = L.mvScaleFactors; KF.mvLevelSigma2 = L.mvLevelSigma2; KF.mvInvLevelSigma2 = L.mvInvLevelSigma2;
+    KF.Rcw = mat32(3, 3, {1, 0, 0, 0, 1, 0, 0, 0, 1}); KF.tcw = mat32(3, 1, {0, 0, 0}); KF.Ow = mat32(3, 1, {0, 0, 0});
+    {   // Tracking::Relocalization (Tracking.cc:1858): SearchByProjection(CurrentFrame, pKF, sFound, 10, 100)
+        std::set<MapPoint*> sFound;
+        for (int i = 0; i < L.N; i += 5) sFound.insert(&mps[i]);
+        for (int i = 0; i < C.N; i += 11) C.mvpMapPoints[i] = &mps[0]; // keypoints that already carry a point
+        std::vector<int> before(C.N);
+        for (int i = 0; i < C.N; i++) before[i] = C.mvpMapPoints[i] != NULL;
+        res.push_back(matcher.SearchByProjection(C, &KF, sFound, 10.0f, 100));
+        std::vector<int> got(C.N, -1);
+        for (int i = 0; i < C.N; i++) got[i] = (C.mvpMapPoints[i] && !before[i]) ? (int)(C.mvpMapPoints[i] - mps.data()) : -1;
+        dump("keyframe", got);
+        C.mvpMapPoints.assign(C.N, (MapPoint*)NULL);
+    }
+    {   // Tracking::SearchLocalPoints (Tracking.cc:1515): SearchByProjection(F, vpMapPoints, th)
+        std::vector<MapPoint*> local;
+        std::vector<float> proj;
+        for (int i = 0; i < L.N; i += 2) {
+            MapPoint* p = &mps[i];
+            p->mbTrackInView = true;
+            p->mTrackProjX = L.mvKeysUn[i].pt.x + 1.5f; p->mTrackProjY = L.mvKeysUn[i].pt.y - 1.0f;
+            p->mnTrackScaleLevel = L.mvKeysUn[i].octave;
+            p->mTrackViewCos = (i % 3) ? 0.9f : 0.999f;
+            local.push_back(p);
+        }
+        res.push_back(matcher.SearchByProjection(L, local, 3.0f)); // frame 0's own keypoints: every other one already holds its point
+        std::vector<int> got(L.N, -1);
+        for (int i = 0; i < L.N; i++) got[i] = L.mvpMapPoints[i] ? (int)(L.mvpMapPoints[i] - mps.data()) : -1;
+        dump("local_points", got);
+    }
+    {   // LocalMapping::SearchInNeighbors: Fuse(pKF, vpMapPoints)
+        std::vector<MapPoint> dup(mps.begin(), mps.end()); // a second set of points at the same places: they fuse with the keyframe's
+        std::vector<MapPoint*> cand;
+        for (auto& m : dup) { m.mObservations.clear(); m.nObs = 1; cand.push_back(&m); }
+        res.push_back(matcher.Fuse(&KF, cand, 3.0f));
+        int replaced = 0, added = 0;
+        for (auto& m : dup) replaced += m.mbBad ? 1 : 0;
+        for (auto& m : dup) added += m.mObservations.count(&KF) ? 1 : 0;
+        res.push_back(replaced);
+        res.push_back(added);
+    }
+    dump("results", res);
+    printf("ok %d frames, %d keypoints in frame 0\n", nframes, F[0].N);
+    return 0;
+}

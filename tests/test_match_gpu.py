@@ -122,6 +122,12 @@ def test_search_by_projection(orbfe, oracle, seed, nq, jitter, mode):
         assert np.array_equal(got["taken"], want["taken"])
         m = got["match"][got["match"] >= 0]
         assert len(np.unique(m)) == len(m)          # a keypoint is matched at most once
+        # map points without observations do not block the keypoint they receive (:91-93): it can be assigned again
+        obs = (np.random.default_rng(seed).random(len(q)) < 0.5).astype(np.uint8)
+        want = oracle.search_by_projection(kps, desc, 640, 480, q, qd, taken, 1, 100, 0.8, q_observed=obs)
+        got = orbfe.search_by_projection(kps, desc, 640, 480, q, qd, taken, 1, 100, 0.8, q_observed=obs)
+        assert got["nmatches"] == want["nmatches"] and np.array_equal(got["match"], want["match"])
+        assert np.array_equal(got["taken"], want["taken"])
 
 
 def test_search_by_projection_edge_cases(orbfe, oracle):
