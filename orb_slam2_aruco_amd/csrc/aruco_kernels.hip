@@ -728,6 +728,11 @@ __device__ __forceinline__ void rl_advance(const BitImage& im, RelayWalk& w, uns
 }
 
 // returns 1 if the frame has to be done again without a grid (force_nogrid), else 0
+#if RL_THREADS == 1024
+#define RL_VGPR_ATTR __attribute__((amdgpu_num_vgpr(64))) // two workgroups (32 waves) share a CU
+#else
+#define RL_VGPR_ATTR
+#endif
 template <bool force_nogrid, int RL_SLOTS>
 __device__ __forceinline__ int relay_frame(
     const uint32_t* __restrict__ gbits, size_t bits_fstride, int wpr_g, int W, int H, int lds_bits_words, int min_len,
@@ -1297,7 +1302,7 @@ __device__ __forceinline__ int relay_frame(
     return 0;
 }
 
-__global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_num_vgpr(64))) void k_contours_relay(
+__global__ __launch_bounds__(RL_THREADS) RL_VGPR_ATTR void k_contours_relay(
     const uint32_t* __restrict__ gbits, size_t bits_fstride, int wpr_g, int W, int H, int lds_bits_words, int min_len,
     int kshift, int tbits, RelaySeg* __restrict__ segs, uint32_t* __restrict__ pool, size_t pool_fstride, int pool_cap,
     ArKept* __restrict__ kept_out, int kept_cap, int kcap /*kept borders this kernel's LDS holds*/,
@@ -1322,10 +1327,10 @@ __global__ __launch_bounds__(RL_THREADS) void k_contours_relay8(
     int32_t* __restrict__ counts, int32_t* __restrict__ hint, uint4* __restrict__ small_g)
 {
     __builtin_amdgcn_s_setprio(2);
-    if (relay_frame<false, 8>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool, pool_fstride, pool_cap,
+    if (relay_frame<false, 2 * RL_SLOTS_PER_THREAD>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool, pool_fstride, pool_cap,
                               kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g)) {
         __syncthreads();
-        relay_frame<true, 8>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool, pool_fstride, pool_cap,
+        relay_frame<true, 2 * RL_SLOTS_PER_THREAD>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool, pool_fstride, pool_cap,
                              kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g);
     }
 }

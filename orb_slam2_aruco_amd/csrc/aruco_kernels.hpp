@@ -75,11 +75,13 @@ __global__ void k_finalize(const ArRect* rects, int rect_cap, const int32_t* can
 #define AP_OUT 64
 #define CT_PROBE 24 // steps a border start is followed before it is queued as a long walk (< the 70-point gate)
 
-#define RL_THREADS 1024
+#ifndef RL_THREADS
+#define RL_THREADS 512   // 8 waves per frame: measured against 1024 (contours alone 713 -> 640 us per 300 frames, step 2.00 -> 1.95 ms) and 256 (893 us)
+#endif
 #define RT_THREADS 256           // k_contours_tail: 4 waves, one approxPolyDP each at a time (small workgroups place easily next to other kernels)
-#define RL_SLOTS_PER_THREAD 4   // table slots <= RL_THREADS * RL_SLOTS_PER_THREAD (tbits <= 12)
+#define RL_SLOTS_PER_THREAD (4096 / RL_THREADS)   // table slots <= RL_THREADS * RL_SLOTS_PER_THREAD (tbits <= 12)
 #define RL_NIL 0xffff
-#define RL_COPY_CAP 1024        // kept segments per frame the flat copy lists (== RL_THREADS; 14 bytes each <= the key table)
+#define RL_COPY_CAP RL_THREADS  // kept segments per frame the flat copy lists (== RL_THREADS; 14 bytes each <= the key table)
 #define RL_FLAG_TABLE 32        // (kernel-internal) markers did not fit: coarsen the grid
 #define RL_FLAG_BUG 64          // an invariant of the relay formulation failed: redone by k_contours_t as well
 #define RL_FALLBACK_FLAGS (RL_FLAG_TABLE | RL_FLAG_BUG)

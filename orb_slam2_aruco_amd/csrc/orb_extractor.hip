@@ -331,7 +331,7 @@ struct orbfe_extractor {
         ORBFE_HIP(hipEventRecord(ev_join, aux_stream));
         {
             // LDS per wave: ROI (cell + 6), score map (cell + 2), one u16 list of cell pixels
-            const int roi_pitch = align_up(max_wcell + 6 + 4, 4) + 4, roi_rows = max_hcell + 6; // +1 byte shift, +1 dword read past a row
+            const int roi_pitch = align_up(max_wcell + 6 + 4, 4) + 8, roi_rows = max_hcell + 6; // +1 byte shift, +2 dwords read past a row (8-pixel groups)
             const int map_pitch = max_wcell + 2, map_rows = max_hcell + 2;
             const int list_cap = max_wcell * max_hcell;
             auto a16 = [](size_t v) { return (v + 15) & ~(size_t)15; };

@@ -166,11 +166,12 @@ __global__ __launch_bounds__(256) void k_resize_tab(ImgView src, ImgView dst, in
 // wave-level operation (ballot / DPP-scan compaction, in-order LDS).  The wave stages the cell's ROI in LDS and runs the
 // reference's two-threshold sequence (cv::FAST at iniThFAST; only if the cell yields nothing, again at minThFAST --
 // :809-816).  The kernel is bound by VALU issue, so both stages run on packed 16-bit math (two values per op):
-//   1. compass prefilter on every pixel, FOUR ADJACENT PIXELS PER LANE from five aligned LDS dwords: a 9-arc of the
+//   1. compass prefilter on every pixel, EIGHT ADJACENT PIXELS PER LANE from eight aligned LDS dwords: a 9-arc of the
 //      16-ring always contains two adjacent compass points (ring positions 0, 4, 8, 12), so two adjacent compass pixels
 //      must both differ from the centre by more than t with the same sign.  Survivors are compacted in raster order.
-//   2. exact cornerScore of every survivor on (d[k], d[k+8]) pairs; "corner at t" <=> score >= t (the score is the
-//      largest threshold at which the pixel is still a corner), so no separate segment test is needed.
+//   2. exact cornerScore of every survivor on (d[k], d[k+8]) pairs with three-input packed minimum / maximum (fast_score16_h);
+//      "corner at t" <=> score >= t (the score is the largest threshold at which the pixel is still a corner), so no
+//      separate segment test is needed.
 //   3. strict 3x3 maximum inside the cell (cv::FAST runs on the ROI, so NMS never looks across cells), ordered write.
 // LDS per wave (dynamic, sized by the host from the largest cell of the pyramid): ROI bytes, score map, one list.
 // ROI pixel (x, y) lives at byte y * SP + x + 1: the +1 makes every 4-pixel group of step 1 one aligned dword.
@@ -179,9 +180,6 @@ __device__ __forceinline__ u16x2 as_u16x2(uint32_t v) { return __builtin_bit_cas
 __device__ __forceinline__ i16x2 as_i16x2(uint32_t v) { return __builtin_bit_cast(i16x2, v); }
 __device__ __forceinline__ uint32_t as_u32(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
 __device__ __forceinline__ uint32_t as_u32(i16x2 v) { return __builtin_bit_cast(uint32_t, v); }
-__device__ __forceinline__ i16x2 pk_swap(i16x2 v) { const uint32_t u = as_u32(v); return as_i16x2(__builtin_amdgcn_alignbit(u, u, 16)); }
-__device__ __forceinline__ i16x2 pk_min(i16x2 a, i16x2 b) { return __builtin_elementwise_min(a, b); }
-__device__ __forceinline__ i16x2 pk_max(i16x2 a, i16x2 b) { return __builtin_elementwise_max(a, b); }
 __device__ __forceinline__ u16x2 pk_minu(u16x2 a, u16x2 b) { return __builtin_elementwise_min(a, b); }
 __device__ __forceinline__ u16x2 pk_maxu(u16x2 a, u16x2 b) { return __builtin_elementwise_max(a, b); }
 
@@ -196,39 +194,61 @@ __device__ __forceinline__ uint32_t compass_pass2(u16x2 v, u16x2 r0, u16x2 r4, u
     return as_u32(ph) | as_u32(pl);
 }
 
-// cornerScore<16> on pairs D[k] = (d[k], d[k+8]): max over the 16 arcs of 9 of min(d) (and of min(-d)), minus 1
-__device__ __forceinline__ int fast_score16_pk(const i16x2 D[8])
+// cornerScore<16> on pairs P[k] = (d[k], d[k+8]): max over the 16 arcs of 9 of min(d) (and of min(-d)), minus 1.
+// The differences are 9-bit integers, and gfx950 has three-input packed f16 minimum / maximum (v_pk_minimum3_f16,
+// v_pk_maximum3_f16) but no three-input packed integer ones.  An integer |d| <= 255 read as f16 BITS is the denormal d * 2^-24:
+// differences of two such values are exact, their order is the order of the integers, and the bits of a positive result are
+// the integer again -- so the whole network runs on packed f16 without a single conversion (the kernel's f16 denormal
+// mode is the default "preserve").  min over 9 consecutive = min3 of (min3 of 3) at offsets 0, 3, 6: 16 + 16 instructions
+// for all 16 arcs of both polarities, and the half swaps a wrapped index needs are operand selects of the instruction.
+//   SW bit i: operand i is taken with its halves swapped
+template <int SW> __device__ __forceinline__ uint32_t hmin3(uint32_t a, uint32_t b, uint32_t c)
 {
-    i16x2 S[8]; // S[k] = (d[k+8], d[k])
+    uint32_t r;
+    if constexpr (SW == 0) asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    else if constexpr (SW == 4) asm("v_pk_minimum3_f16 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    else asm("v_pk_minimum3_f16 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+template <int SW> __device__ __forceinline__ uint32_t hmax3(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    if constexpr (SW == 0) asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    else if constexpr (SW == 4) asm("v_pk_maximum3_f16 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    else asm("v_pk_maximum3_f16 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// (a.lo - b.lo, a.hi - b.hi) on f16 bits
+__device__ __forceinline__ uint32_t hsub2(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ int fast_score16_h(const uint32_t P[8])
+{
+    uint32_t n3[8], x3[8]; // (m3[k], m3[k+8]),  m3[k] = min / max of d[k], d[k+1], d[k+2]
 #pragma unroll
-    for (int k = 0; k < 8; k++) S[k] = pk_swap(D[k]);
-    i16x2 mn2[8], mx2[8]; // (m2[k], m2[k+8]),  m2[k] = min(d[k], d[k+1])
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const i16x2 nxt = k < 7 ? D[k + 1] : S[0];
-        mn2[k] = pk_min(D[k], nxt);
-        mx2[k] = pk_max(D[k], nxt);
-    }
-    i16x2 mn4[8], mx4[8]; // m4[k] = min(m2[k], m2[k+2])
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const i16x2 an = k < 6 ? mn2[k + 2] : pk_swap(mn2[k - 6]);
-        const i16x2 ax = k < 6 ? mx2[k + 2] : pk_swap(mx2[k - 6]);
-        mn4[k] = pk_min(mn2[k], an);
-        mx4[k] = pk_max(mx2[k], ax);
-    }
-    i16x2 bn, bx; // running max of mn9 / min of mx9;  m9[k] = min(m4[k], m4[k+4], d[k+8])
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const i16x2 an = k < 4 ? mn4[k + 4] : pk_swap(mn4[k - 4]);
-        const i16x2 ax = k < 4 ? mx4[k + 4] : pk_swap(mx4[k - 4]);
-        const i16x2 mn9 = pk_min(pk_min(mn4[k], an), S[k]);
-        const i16x2 mx9 = pk_max(pk_max(mx4[k], ax), S[k]);
-        bn = k == 0 ? mn9 : pk_max(bn, mn9);
-        bx = k == 0 ? mx9 : pk_min(bx, mx9);
-    }
-    const i16x2 m = pk_max(bn, (i16x2)(-bx));
-    return max((int)m.x, (int)m.y) - 1;
+    for (int k = 0; k < 6; k++) { n3[k] = hmin3<0>(P[k], P[k + 1], P[k + 2]); x3[k] = hmax3<0>(P[k], P[k + 1], P[k + 2]); }
+    n3[6] = hmin3<4>(P[6], P[7], P[0]); x3[6] = hmax3<4>(P[6], P[7], P[0]);
+    n3[7] = hmin3<6>(P[7], P[0], P[1]); x3[7] = hmax3<6>(P[7], P[0], P[1]);
+    uint32_t n9[8], x9[8]; // m9[k] = min / max of m3[k], m3[k+3], m3[k+6] = of d[k] .. d[k+8]
+    n9[0] = hmin3<0>(n3[0], n3[3], n3[6]); x9[0] = hmax3<0>(x3[0], x3[3], x3[6]);
+    n9[1] = hmin3<0>(n3[1], n3[4], n3[7]); x9[1] = hmax3<0>(x3[1], x3[4], x3[7]);
+    n9[2] = hmin3<4>(n3[2], n3[5], n3[0]); x9[2] = hmax3<4>(x3[2], x3[5], x3[0]);
+    n9[3] = hmin3<4>(n3[3], n3[6], n3[1]); x9[3] = hmax3<4>(x3[3], x3[6], x3[1]);
+    n9[4] = hmin3<4>(n3[4], n3[7], n3[2]); x9[4] = hmax3<4>(x3[4], x3[7], x3[2]);
+    n9[5] = hmin3<6>(n3[5], n3[0], n3[3]); x9[5] = hmax3<6>(x3[5], x3[0], x3[3]);
+    n9[6] = hmin3<6>(n3[6], n3[1], n3[4]); x9[6] = hmax3<6>(x3[6], x3[1], x3[4]);
+    n9[7] = hmin3<6>(n3[7], n3[2], n3[5]); x9[7] = hmax3<6>(x3[7], x3[2], x3[5]);
+    // brightest arc = max of the 16 minima; darkest arc = min of the 16 maxima
+    const uint32_t bn = hmax3<0>(hmax3<0>(n9[0], n9[1], n9[2]), hmax3<0>(n9[3], n9[4], n9[5]), hmax3<0>(n9[6], n9[7], n9[7]));
+    const uint32_t bx = hmin3<0>(hmin3<0>(x9[0], x9[1], x9[2]), hmin3<0>(x9[3], x9[4], x9[5]), hmin3<0>(x9[6], x9[7], x9[7]));
+    uint32_t m;
+    asm("v_pk_max_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(m) : "v"(bn), "v"(bx)); // (max(bn, -bx)) per half
+    uint32_t sres;
+    asm("v_pk_max_f16 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(sres) : "v"(m));    // low half: max of the two halves
+    return (int)(short)(sres & 0xffffu) - 1; // the bits of a positive denormal are the integer; anything else is far below any threshold
 }
 
 __global__ __launch_bounds__(256) void k_fast_cells(ImgView src0, ImgView pyr, const LevelGeom* __restrict__ geom,
@@ -294,45 +314,52 @@ __global__ __launch_bounds__(256) void k_fast_cells(ImgView src0, ImgView pyr, c
     for (int i = lane; i < (int)(map_bytes / 4); i += 64) reinterpret_cast<uint32_t*>(smap)[i] = 0;
     __builtin_amdgcn_wave_barrier();
 
-    const int G = (aw + 3) >> 2, nitems = G * ah; // 4-pixel groups per active row
+    const int G = (aw + 7) >> 3, nitems = G * ah; // 8-pixel groups per active row
     const float inv_G = 1.0f / (float)G;
     int nlist = 0;
     unsigned long long keepbits = 0; // bit k: list entry lane + 64 k survives NMS (list_cap <= 64 * 64)
     for (int pass_no = 0; pass_no < 2; pass_no++) {
         const int t = pass_no == 0 ? iniTh : minTh;
         const u16x2 t2 = as_u16x2((uint32_t)t | ((uint32_t)t << 16));
-        // ---- 1: compass prefilter, 4 adjacent pixels per lane
+        // ---- 1: compass prefilter, 8 adjacent pixels per lane (two aligned dwords of the centre row and their neighbours)
         int n1 = 0;
         for (int base = 0; base < nitems; base += 64) {
             const int it = base + lane;
-            unsigned mask4 = 0;
+            unsigned mask8 = 0;
             int x = 0, y = 0;
             if (it < nitems) {
                 y = (int)(((float)it + 0.5f) * inv_G); // exact: it < 4096, quotient >= 0.5/G away from an integer
-                x = 4 * (it - y * G);
-                // pixels x .. x+3 of active row y = ROI pixels (x+3 .. x+6, y+3) = bytes x+4 .. x+7 of ROI row y+3
+                x = 8 * (it - y * G);
+                // pixels x .. x+7 of active row y = ROI pixels (x+3 .. x+10, y+3) = bytes x+4 .. x+11 of ROI row y+3
                 const uint32_t* cr = reinterpret_cast<const uint32_t*>(simg + (y + 3) * SP + x + 4);
-                const uint32_t C = cr[0], Wd = cr[-1], Ed = cr[1];
-                const uint32_t N = *reinterpret_cast<const uint32_t*>(simg + y * SP + x + 4);
-                const uint32_t S = *reinterpret_cast<const uint32_t*>(simg + (y + 6) * SP + x + 4);
-                const uint32_t E = __builtin_amdgcn_alignbyte(Ed, C, 3), W = __builtin_amdgcn_alignbyte(C, Wd, 1);
+                const uint32_t* nr = reinterpret_cast<const uint32_t*>(simg + y * SP + x + 4);
+                const uint32_t* sr = reinterpret_cast<const uint32_t*>(simg + (y + 6) * SP + x + 4);
+                const uint32_t Wd = cr[-1], C0 = cr[0], C1 = cr[1], Ed = cr[2];
+                const uint32_t N0 = nr[0], N1 = nr[1], S0 = sr[0], S1 = sr[1];
+                const uint32_t E0 = __builtin_amdgcn_alignbyte(C1, C0, 3), W0 = __builtin_amdgcn_alignbyte(C0, Wd, 1);
+                const uint32_t E1 = __builtin_amdgcn_alignbyte(Ed, C1, 3), W1 = __builtin_amdgcn_alignbyte(C1, C0, 1);
                 // ring positions: 0 = (x, y+3) = S row, 4 = (x+3, y) = E, 8 = (x, y-3) = N row, 12 = (x-3, y) = W
                 constexpr uint32_t LO = 0x0c010c00u, HI = 0x0c030c02u; // bytes (0, 1) / (2, 3) -> 16-bit lanes
-                const uint32_t p01 = compass_pass2(as_u16x2(__builtin_amdgcn_perm(0, C, LO)), as_u16x2(__builtin_amdgcn_perm(0, S, LO)),
-                                                   as_u16x2(__builtin_amdgcn_perm(0, E, LO)), as_u16x2(__builtin_amdgcn_perm(0, N, LO)),
-                                                   as_u16x2(__builtin_amdgcn_perm(0, W, LO)), t2);
-                const uint32_t p23 = compass_pass2(as_u16x2(__builtin_amdgcn_perm(0, C, HI)), as_u16x2(__builtin_amdgcn_perm(0, S, HI)),
-                                                   as_u16x2(__builtin_amdgcn_perm(0, E, HI)), as_u16x2(__builtin_amdgcn_perm(0, N, HI)),
-                                                   as_u16x2(__builtin_amdgcn_perm(0, W, HI)), t2);
-                mask4 = ((p01 & 0xffffu) ? 1u : 0u) | ((p01 >> 16) ? 2u : 0u) | ((p23 & 0xffffu) ? 4u : 0u) | ((p23 >> 16) ? 8u : 0u);
-                mask4 &= (1u << min(4, aw - x)) - 1u; // the last group of a row may be partial
+#define FC_PASS2(C, S, E, N, W, SEL)                                                                                             \
+    compass_pass2(as_u16x2(__builtin_amdgcn_perm(0, C, SEL)), as_u16x2(__builtin_amdgcn_perm(0, S, SEL)),                       \
+                  as_u16x2(__builtin_amdgcn_perm(0, E, SEL)), as_u16x2(__builtin_amdgcn_perm(0, N, SEL)),                       \
+                  as_u16x2(__builtin_amdgcn_perm(0, W, SEL)), t2)
+                const uint32_t p01 = FC_PASS2(C0, S0, E0, N0, W0, LO), p23 = FC_PASS2(C0, S0, E0, N0, W0, HI);
+                const uint32_t p45 = FC_PASS2(C1, S1, E1, N1, W1, LO), p67 = FC_PASS2(C1, S1, E1, N1, W1, HI);
+#undef FC_PASS2
+                mask8 = ((p01 & 0xffffu) ? 1u : 0u) | ((p01 >> 16) ? 2u : 0u) | ((p23 & 0xffffu) ? 4u : 0u) | ((p23 >> 16) ? 8u : 0u) |
+                        ((p45 & 0xffffu) ? 16u : 0u) | ((p45 >> 16) ? 32u : 0u) | ((p67 & 0xffffu) ? 64u : 0u) | ((p67 >> 16) ? 128u : 0u);
+                mask8 &= (1u << min(8, aw - x)) - 1u; // the last group of a row may be partial
             }
-            const int cnt = __popc(mask4);
+            const int cnt = __popc(mask8);
             const int incl = wave_incl_scan_add(cnt);
             int off = n1 + incl - cnt;
-#pragma unroll
-            for (int b = 0; b < 4; b++)
-                if (mask4 & (1u << b)) slist[off++] = (uint16_t)((y << 8) | (x + b));
+            const int yx0 = (y << 8) | x;
+            while (mask8) { // raster order inside the group
+                const int b = __ffs(mask8) - 1;
+                mask8 &= mask8 - 1;
+                slist[off++] = (uint16_t)(yx0 + b);
+            }
             n1 += __builtin_amdgcn_readlane(incl, 63);
         }
         __builtin_amdgcn_wave_barrier();
@@ -347,17 +374,17 @@ __global__ __launch_bounds__(256) void k_fast_cells(ImgView src0, ImgView pyr, c
                 yx = slist[e];
                 const uint8_t* c = simg + ((yx >> 8) + 3) * SP + ((yx & 255) + 3) + 1;
                 const uint32_t v = c[0];
-                const i16x2 v2 = as_i16x2(v | (v << 16));
-                i16x2 D[8]; // (d[k], d[k+8]), d = v - ring pixel
-                D[0] = v2 - as_i16x2((uint32_t)c[3 * SP + 0] | ((uint32_t)c[-3 * SP + 0] << 16));
-                D[1] = v2 - as_i16x2((uint32_t)c[3 * SP + 1] | ((uint32_t)c[-3 * SP - 1] << 16));
-                D[2] = v2 - as_i16x2((uint32_t)c[2 * SP + 2] | ((uint32_t)c[-2 * SP - 2] << 16));
-                D[3] = v2 - as_i16x2((uint32_t)c[1 * SP + 3] | ((uint32_t)c[-1 * SP - 3] << 16));
-                D[4] = v2 - as_i16x2((uint32_t)c[3] | ((uint32_t)c[-3] << 16));
-                D[5] = v2 - as_i16x2((uint32_t)c[-1 * SP + 3] | ((uint32_t)c[1 * SP - 3] << 16));
-                D[6] = v2 - as_i16x2((uint32_t)c[-2 * SP + 2] | ((uint32_t)c[2 * SP - 2] << 16));
-                D[7] = v2 - as_i16x2((uint32_t)c[-3 * SP + 1] | ((uint32_t)c[3 * SP - 1] << 16));
-                score = fast_score16_pk(D);
+                const uint32_t v2 = v | (v << 16);
+                uint32_t P[8]; // (d[k], d[k+8]) as f16 bits, d = v - ring pixel
+                P[0] = hsub2(v2, (uint32_t)c[3 * SP + 0] | ((uint32_t)c[-3 * SP + 0] << 16));
+                P[1] = hsub2(v2, (uint32_t)c[3 * SP + 1] | ((uint32_t)c[-3 * SP - 1] << 16));
+                P[2] = hsub2(v2, (uint32_t)c[2 * SP + 2] | ((uint32_t)c[-2 * SP - 2] << 16));
+                P[3] = hsub2(v2, (uint32_t)c[1 * SP + 3] | ((uint32_t)c[-1 * SP - 3] << 16));
+                P[4] = hsub2(v2, (uint32_t)c[3] | ((uint32_t)c[-3] << 16));
+                P[5] = hsub2(v2, (uint32_t)c[-1 * SP + 3] | ((uint32_t)c[1 * SP - 3] << 16));
+                P[6] = hsub2(v2, (uint32_t)c[-2 * SP + 2] | ((uint32_t)c[2 * SP - 2] << 16));
+                P[7] = hsub2(v2, (uint32_t)c[-3 * SP + 1] | ((uint32_t)c[3 * SP - 1] << 16));
+                score = fast_score16_h(P);
                 corner = score >= t;
             }
             const unsigned long long m = __ballot(corner);
