@@ -275,7 +275,7 @@ struct orbfe_aruco {
             const size_t rlds = relay_lds_bytes(lds_bits_words, RL_KCAP, relay_tbits);
             auto rfn = relay_tbits > 12 ? k_contours_relay8 : k_contours_relay;
             ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
-            hipLaunchKernelGGL(rfn, dim3(B), dim3(RL_THREADS), rlds, s, d_bits.as<uint32_t>(), bits_fu32, wpr,
+            hipLaunchKernelGGL(rfn, dim3(B), dim3(relay_tbits > 12 ? RL_THREADS_BIG : RL_THREADS), rlds, s, d_bits.as<uint32_t>(), bits_fu32, wpr,
                                cols, rows, lds_bits_words, 70, relay_kshift, relay_tbits, d_segs.as<RelaySeg>(),
                                d_pool.as<uint32_t>(), pool_fu32, (int)pool_fu32, d_kept.as<ArKept>(), AR_MAX_KEPT, RL_KCAP,
                                d_tailkeys.as<unsigned long long>(), d_tailoff.as<int32_t>(), d_counts.as<int32_t>(), d_hint.as<int32_t>(),

@@ -733,7 +733,7 @@ __device__ __forceinline__ void rl_advance(const BitImage& im, RelayWalk& w, uns
 #else
 #define RL_VGPR_ATTR
 #endif
-template <bool force_nogrid, int RL_SLOTS>
+template <bool force_nogrid, int RL_SLOTS, int RL_NT>
 __device__ __forceinline__ int relay_frame(
     const uint32_t* __restrict__ gbits, size_t bits_fstride, int wpr_g, int W, int H, int lds_bits_words, int min_len,
     int kshift, int tbits, RelaySeg* __restrict__ segs, uint32_t* __restrict__ pool, size_t pool_fstride, int pool_cap,
@@ -747,7 +747,7 @@ __device__ __forceinline__ int relay_frame(
     if (!force_nogrid && hint) kshift = max(kshift, min(*hint, 7));
     __shared__ uint16_t s_lut[2048];
     __shared__ unsigned s_tailq;
-    const int tid = threadIdx.x, f = blockIdx.x, NT = RL_THREADS;
+    const int tid = threadIdx.x, f = blockIdx.x, NT = RL_NT;
     const int wpr = (W + 2 + 31) >> 5, prow = H + 2;
     const int T = 1 << tbits;
     int kmask = (1 << kshift) - 1, K = 1 << kshift;
@@ -772,7 +772,7 @@ __device__ __forceinline__ int relay_frame(
     int* koff = klen + kcap;
     int* rectflag = koff + kcap;
     ApPt* ap_out = (ApPt*)(rectflag + kcap);
-    int2* ap_stack = (int2*)(ap_out + (RL_THREADS / 64) * AP_OUT);
+    int2* ap_stack = (int2*)(ap_out + (RL_NT / 64) * AP_OUT);
     const uint32_t* gb = gbits + (size_t)f * bits_fstride;
     uint32_t* pl = pool + (size_t)f * pool_fstride;
     RelaySeg* sg = segs + ((size_t)f << tbits);
@@ -1211,40 +1211,40 @@ __device__ __forceinline__ int relay_frame(
         }
         if (tid == 0) s_next = 0;
         __syncthreads(); // every read of the marker keys done
-        int* c_pre = (int*)hkey;            // points before the entry (exclusive running count), RL_COPY_CAP + 1
-        int* c_dst = c_pre + RL_COPY_CAP + 1;
-        int* c_src = c_dst + RL_COPY_CAP;
-        uint16_t* c_k = (uint16_t*)(c_src + RL_COPY_CAP);
+        int* c_pre = (int*)hkey;            // points before the entry (exclusive running count), RL_NT + 1
+        int* c_dst = c_pre + RL_NT + 1;
+        int* c_src = c_dst + RL_NT;
+        uint16_t* c_k = (uint16_t*)(c_src + RL_NT);
         const int ebase = mine ? atomicAdd(&s_next, mine) : 0;
         __syncthreads();
         const int E = s_next;
-        // the list holds RL_COPY_CAP entries; frames with more kept segments (large images) take several rounds
-        for (int r0 = 0; r0 < E; r0 += RL_COPY_CAP) {
-            const int Er = min(RL_COPY_CAP, E - r0);
+        // the list holds RL_NT entries; frames with more kept segments (large images) take several rounds
+        for (int r0 = 0; r0 < E; r0 += RL_NT) {
+            const int Er = min(RL_NT, E - r0);
             int e0 = ebase - r0;
 #pragma unroll
             for (int q = 0; q < RL_SLOTS; q++)
                 if (e_len[q] > 0) {
-                    if (e0 >= 0 && e0 < RL_COPY_CAP) { c_pre[e0] = e_len[q]; c_dst[e0] = e_dst[q]; c_src[e0] = e_src[q]; c_k[e0] = (uint16_t)e_k[q]; }
+                    if (e0 >= 0 && e0 < RL_NT) { c_pre[e0] = e_len[q]; c_dst[e0] = e_dst[q]; c_src[e0] = e_src[q]; c_k[e0] = (uint16_t)e_k[q]; }
                     e0++;
                 }
             __syncthreads();
-            // exclusive scan of the lengths (one entry per thread; RL_COPY_CAP == RL_THREADS)
+            // exclusive scan of the lengths (one entry per thread; RL_NT == RL_THREADS)
             {
                 const int lane = tid & 63, wid = tid >> 6;
                 const int len = tid < Er ? c_pre[tid] : 0;
                 const int incl = wave_incl_scan_add(len);
                 __syncthreads();
-                if (lane == 63) c_pre[RL_COPY_CAP - 16 + wid] = incl; // wave totals parked at the end (entries there are read above)
+                if (lane == 63) c_pre[RL_NT - 16 + wid] = incl; // wave totals parked at the end (entries there are read above)
                 __syncthreads();
                 int wbase = 0;
-                for (int w = 0; w < wid; w++) wbase += c_pre[RL_COPY_CAP - 16 + w];
+                for (int w = 0; w < wid; w++) wbase += c_pre[RL_NT - 16 + w];
                 __syncthreads();
                 c_pre[tid] = wbase + incl - len;
-                if (tid == NT - 1) c_pre[RL_COPY_CAP] = wbase + incl;
+                if (tid == NT - 1) c_pre[RL_NT] = wbase + incl;
                 __syncthreads();
             }
-            const int total = c_pre[RL_COPY_CAP];
+            const int total = c_pre[RL_NT];
             for (int q0 = tid; q0 < total; q0 += 4 * NT) { // four independent points per lane: their latencies overlap
                 int pdst[4];
                 uint32_t v[4];
@@ -1310,27 +1310,27 @@ __global__ __launch_bounds__(RL_THREADS) RL_VGPR_ATTR void k_contours_relay(
     uint4* __restrict__ small_g)
 {
     __builtin_amdgcn_s_setprio(2); // latency-bound: its few waves go first when a VALU-bound kernel shares the CU
-    if (relay_frame<false, RL_SLOTS_PER_THREAD>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool,
+    if (relay_frame<false, RL_SLOTS_PER_THREAD, RL_THREADS>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool,
                                                 pool_fstride, pool_cap, kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g)) {
         __syncthreads();
-        relay_frame<true, RL_SLOTS_PER_THREAD>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool,
+        relay_frame<true, RL_SLOTS_PER_THREAD, RL_THREADS>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool,
                                                pool_fstride, pool_cap, kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g);
     }
 }
 
 // The same with eight table slots per thread (tbits = 13): large frames, whose workgroup owns a CU anyway (LDS), so the
 // register budget of two resident workgroups does not apply.
-__global__ __launch_bounds__(RL_THREADS) void k_contours_relay8(
+__global__ __launch_bounds__(RL_THREADS_BIG) void k_contours_relay8(
     const uint32_t* __restrict__ gbits, size_t bits_fstride, int wpr_g, int W, int H, int lds_bits_words, int min_len,
     int kshift, int tbits, RelaySeg* __restrict__ segs, uint32_t* __restrict__ pool, size_t pool_fstride, int pool_cap,
     ArKept* __restrict__ kept_out, int kept_cap, int kcap, unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off,
     int32_t* __restrict__ counts, int32_t* __restrict__ hint, uint4* __restrict__ small_g)
 {
     __builtin_amdgcn_s_setprio(2);
-    if (relay_frame<false, 2 * RL_SLOTS_PER_THREAD>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool, pool_fstride, pool_cap,
+    if (relay_frame<false, 8192 / RL_THREADS_BIG, RL_THREADS_BIG>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool, pool_fstride, pool_cap,
                               kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g)) {
         __syncthreads();
-        relay_frame<true, 2 * RL_SLOTS_PER_THREAD>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool, pool_fstride, pool_cap,
+        relay_frame<true, 8192 / RL_THREADS_BIG, RL_THREADS_BIG>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool, pool_fstride, pool_cap,
                              kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g);
     }
 }

@@ -79,9 +79,12 @@ __global__ void k_finalize(const ArRect* rects, int rect_cap, const int32_t* can
 #define RL_THREADS 512   // 8 waves per frame: measured against 1024 (contours alone 713 -> 640 us per 300 frames, step 2.00 -> 1.95 ms) and 256 (893 us)
 #endif
 #define RT_THREADS 256           // k_contours_tail: 4 waves, one approxPolyDP each at a time (small workgroups place easily next to other kernels)
+#ifndef RL_THREADS_BIG
+#define RL_THREADS_BIG 1024     // k_contours_relay8 (large frames): its workgroup owns the CU (LDS), so it brings 16 waves
+#endif
 #define RL_SLOTS_PER_THREAD (4096 / RL_THREADS)   // table slots <= RL_THREADS * RL_SLOTS_PER_THREAD (tbits <= 12)
 #define RL_NIL 0xffff
-#define RL_COPY_CAP RL_THREADS  // kept segments per frame the flat copy lists (== RL_THREADS; 14 bytes each <= the key table)
+#define RL_COPY_CAP RL_THREADS  // (documentation) kept segments per frame the flat copy lists (== RL_THREADS; 14 bytes each <= the key table)
 #define RL_FLAG_TABLE 32        // (kernel-internal) markers did not fit: coarsen the grid
 #define RL_FLAG_BUG 64          // an invariant of the relay formulation failed: redone by k_contours_t as well
 #define RL_FALLBACK_FLAGS (RL_FLAG_TABLE | RL_FLAG_BUG)
