@@ -268,21 +268,19 @@ struct orbfe_aruco {
         const size_t lds = contours_lds_bytes(legacy_ldsw, legacy_kcap);
         ORBFE_HIP(hipGetLastError());
         auto kfn = big ? k_contours_t<false> : k_contours_t<true>;
-        ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)lds));
+        { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(kfn), (size_t)(lds)); if (rc_lds_) return rc_lds_; }
         const bool relay = relay_tbits && !force_legacy && !big_mode;
         if (relay && !ORBFE_SKIP_ARUCO(1)) {
             const size_t rlds = relay_lds_bytes(lds_bits_words, RL_KCAP, relay_tbits);
             auto rfn = relay_tbits > 12 ? k_contours_relay8 : k_contours_relay;
-            ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
+            { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(rfn), (size_t)(rlds)); if (rc_lds_) return rc_lds_; }
             hipLaunchKernelGGL(rfn, dim3(B), dim3(relay_tbits > 12 ? RL_THREADS_BIG : RL_THREADS), rlds, s, d_bits.as<uint32_t>(), bits_fu32, wpr,
                                cols, rows, lds_bits_words, 70, relay_kshift, relay_tbits, d_segs.as<RelaySeg>(),
                                d_pool.as<uint32_t>(), pool_fu32, (int)pool_fu32, d_kept.as<ArKept>(), AR_MAX_KEPT, RL_KCAP,
                                d_tailkeys.as<unsigned long long>(), d_tailoff.as<int32_t>(), d_counts.as<int32_t>(), d_hint.as<int32_t>(),
                                d_small.as<uint4>());
             const size_t tlds = tail_lds_bytes(RL_KCAP, 1280);
-            ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_contours_tail),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
+            { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(k_contours_tail), (size_t)(tlds)); if (rc_lds_) return rc_lds_; }
             hipLaunchKernelGGL(k_contours_tail, dim3(B), dim3(RT_THREADS), tlds, s, d_tailkeys.as<unsigned long long>(),
                                d_tailoff.as<int32_t>(), RL_KCAP, d_pool.as<uint32_t>(), pool_fu32, d_kept.as<ArKept>(),
                                AR_MAX_KEPT, d_rects.as<ArRect>(), AR_MAX_RECTS, d_counts.as<int32_t>(), (int)tlds);

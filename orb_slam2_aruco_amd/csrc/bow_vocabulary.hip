@@ -573,8 +573,7 @@ int orbfe_vocabulary_transform_batch_device(orbfe_vocabulary* v, const uint8_t* 
                        d_word, d_node, d_weight);
     ORBFE_HIP(hipGetLastError());
     if (vectors) {
-        ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bow_vectors), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      BV_LDS_BYTES));
+        { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(&k_bow_vectors), (size_t)BV_LDS_BYTES); if (rc_lds_) return rc_lds_; }
         hipLaunchKernelGGL(k_bow_vectors, dim3(nframes), dim3(BV_THREADS), BV_LDS_BYTES, s, d_word, d_node, d_weight, d_n, capacity, v->weighting,
                            norm_of(v->scoring), d_bow_word, d_bow_value, d_nbow, d_fv_node, d_fv_offset, d_fv_feature, d_nfv);
         ORBFE_HIP(hipGetLastError());

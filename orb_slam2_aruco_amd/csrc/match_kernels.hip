@@ -1069,8 +1069,7 @@ static int sfi_launch(const orbfe_keypoint* d_kps, const uint8_t* d_desc, const 
         (rc = w.scratch.ensure((size_t)npairs * 3 * capacity * 4)) || (rc = w.overflow.ensure(16)))
         return rc;
     ORBFE_HIP(hipMemsetAsync(w.overflow.p, 0, 4, s));
-    ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_init), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)sfi_lds_bytes()));
+    { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(&k_search_init), (size_t)(sfi_lds_bytes())); if (rc_lds_) return rc_lds_; }
     hipLaunchKernelGGL(k_search_init, dim3(npairs), dim3(SFI_THREADS), sfi_lds_bytes(), s, d_kps, d_desc, d_n, capacity, bnd,
                        (float)window, nnratio, check_ori, d_prev_in, d_prev_out, d_m12, d_nm, w.csr_cnt.as<int32_t>(),
                        w.csr_idx.as<uint16_t>(), w.csr_dist.as<uint8_t>(), stride, w.scratch.as<int32_t>(),
@@ -1259,8 +1258,7 @@ int orbfe_search_by_projection(const orbfe_keypoint* kps, const uint8_t* desc, i
         int32_t* o = w.obest.as<int32_t>();
         SbpBest sb{};
         sb.q_blocks = q_observed ? w.pidx.as<uint8_t>() : nullptr;
-        ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_by_projection),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(&k_search_by_projection), (size_t)(lds)); if (rc_lds_) return rc_lds_; }
         hipLaunchKernelGGL(k_search_by_projection, dim3(1), dim3(SBP_THREADS), lds, 0, w.kps.as<orbfe_keypoint>(),
                            w.desc.as<uint8_t>(), n, ncap, frame_bounds(cols, rows, bounds), w.q.as<SbpQuery>(), w.t.as<uint8_t>(), nq,
                            taken ? w.prev.as<uint8_t>() : nullptr, mode, th_high, nnratio, w.csr_idx.as<uint16_t>(),
@@ -1359,8 +1357,7 @@ static int sbp_best_run(const orbfe_keypoint* kps, const uint8_t* desc, int n, i
         ORBFE_HIP(hipMemset(w.nm.p, 0, 4));
         int32_t* o = w.obest.as<int32_t>();
         SbpBest bo{d_angle, q_blocks ? d_flags : nullptr, factor, check_ori, w.m12.as<int32_t>(), o + nq};
-        ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_by_projection),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(&k_search_by_projection), (size_t)(lds)); if (rc_lds_) return rc_lds_; }
         hipLaunchKernelGGL(k_search_by_projection, dim3(1), dim3(SBP_THREADS), lds, 0, w.kps.as<orbfe_keypoint>(), w.desc.as<uint8_t>(), n,
                            ncap, frame_bounds(cols, rows, bounds), w.q.as<SbpQuery>(), w.t.as<uint8_t>(), nq,
                            taken ? w.prev.as<uint8_t>() : nullptr, 2, th_high, 0.0f, w.csr_idx.as<uint16_t>(), w.csr_dist.as<uint8_t>(),
@@ -1497,8 +1494,7 @@ static int guided_best(const orbfe_keypoint* kps, const uint8_t* desc, int n, in
         if ((rc = project_run(w, p3Dw, valid, min_dist, max_dist, normal, nmp, P))) return rc;
         ORBFE_HIP(hipMemset(w.overflow.p, 0, 4));
         int32_t* o = w.obest.as<int32_t>();
-        ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_search_by_projection),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(&k_search_by_projection), (size_t)(lds)); if (rc_lds_) return rc_lds_; }
         hipLaunchKernelGGL(k_search_by_projection, dim3(1), dim3(SBP_THREADS), lds, 0, w.kps.as<orbfe_keypoint>(), w.desc.as<uint8_t>(), n,
                            ncap, frame_bounds(cols, rows, bounds), w.q.as<SbpQuery>(), w.t.as<uint8_t>(), nmp, (uint8_t*)nullptr, 0, 256, 0.0f,
                            w.csr_idx.as<uint16_t>(), w.csr_dist.as<uint8_t>(), w.csr_cnt.as<int32_t>(), stride, o, o + nmp, o + 2 * nmp,

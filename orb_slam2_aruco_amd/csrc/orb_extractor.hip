@@ -8,6 +8,9 @@
 #include <cmath>
 
 #include "orb_kernels.hpp"
+#include <map>
+#include <mutex>
+
 #include "orbfe_common.hpp"
 #include "orbfe_tables.inc"
 
@@ -24,6 +27,21 @@ int use_device(int device)
                     e == hipSuccess ? "device count 0" : hipGetErrorString(e));
     if (device < 0 || device >= n) return fail(ORBFE_ERR_INVALID, "device %d out of range (have %d)", device, n);
     ORBFE_HIP(hipSetDevice(device));
+    return ORBFE_OK;
+}
+
+int ensure_dyn_lds(const void* fn, size_t bytes)
+{
+    // per device: the attribute belongs to the function object of the current device's code object
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, size_t> done;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& have = done[std::make_pair(dev, fn)];
+    if (have >= bytes && have != 0) return ORBFE_OK;
+    ORBFE_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    have = bytes;
     return ORBFE_OK;
 }
 
@@ -337,8 +355,7 @@ struct orbfe_extractor {
             auto a16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
             const size_t lds = 4 * (a16((size_t)roi_pitch * roi_rows) + a16((size_t)map_pitch * map_rows) +
                                     a16((size_t)list_cap * 2));
-            ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fast_cells),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(&k_fast_cells), (size_t)(lds)); if (rc_lds_) return rc_lds_; }
             const int nx = (ncells_total + 3) / 4;
             if (!ORBFE_SKIP_ORB(1)) hipLaunchKernelGGL(k_fast_cells, dim3(xcd_grid(nx * B)), dim3(256), lds, s, src0, pyr, dg,
                                d_cellinfo.as<uint32_t>(), d_slots.as<uint32_t>(), slots_fu32,
@@ -352,15 +369,13 @@ struct orbfe_extractor {
             for (const LevelGeom& g : geom) max_ini = std::max(max_ini, g.nIni);
             const int D = force_pyramid_depth ? force_pyramid_depth : max_ini == 1 ? 6 : max_ini <= 4 ? 5 : 4;
             const size_t lds_p = qp_lds_bytes(max_ini, D, nodecap, veccap);
-            ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_distribute_pyr),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
+            { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(&k_distribute_pyr), (size_t)(lds_p)); if (rc_lds_) return rc_lds_; }
             if (!ORBFE_SKIP_ORB(2)) hipLaunchKernelGGL(k_distribute_pyr, dim3(nlevels, B), dim3(QP_THREADS), lds_p, s, dg, d_slots.as<uint32_t>(),
                                slots_fu32, d_cellcnt.as<int32_t>(), ncells_total, d_lvlout.as<uint32_t>(), out_total,
                                d_lvlcnt.as<int32_t>(), nlevels, d_lvlncand.as<int32_t>(), d_fallback.as<int32_t>(), D,
                                nodecap, veccap);
             const size_t lds = qt_lds_bytes(keycap_lds, nodecap, veccap);
-            ORBFE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_distribute),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(&k_distribute), (size_t)(lds)); if (rc_lds_) return rc_lds_; }
             hipLaunchKernelGGL(k_distribute, dim3(nlevels, B), dim3(64), lds, s, dg, d_slots.as<uint32_t>(), slots_fu32,
                                d_cellcnt.as<int32_t>(), ncells_total, d_keys.as<uint32_t>(), keys_fu32,
                                d_lvlout.as<uint32_t>(), out_total, d_lvlcnt.as<int32_t>(), nlevels,

@@ -44,6 +44,10 @@ inline int fail(int code, const char* fmt, ...)
                                  __FILE__, __LINE__);                                                    \
     } while (0)
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, size) instead of before every launch: it is a driver call of
+// a few microseconds, and it is not a stream operation (nothing for a captured graph to replay).
+int ensure_dyn_lds(const void* fn, size_t bytes);
+
 // Select the device, or report that there is none (no CPU fallback exists in this library).
 int use_device(int device);
 
