@@ -255,11 +255,13 @@ struct orbfe_aruco {
         ORBFE_HIP(hipEventRecord(ev_join, aux_stream));
         if (!ORBFE_SKIP_ARUCO(8)) {
             const dim3 tg((cols + 63) / 64, (rows + 63) / 64, B);
+            const int ntx = (cols + 63) / 64, ntl = ntx * ((rows + 63) / 64);
+            const dim3 tg1(xcd_grid(ntl * B));
             uint32_t* bp = d_bits.as<uint32_t>();
-            if (th_magic && win == 5) hipLaunchKernelGGL(k_adaptive_threshold_t<5>, tg, dim3(256), 0, s, src0, cols, rows, 7, th_magic, bp, bits_fu32, wpr);
-            else if (th_magic && win == 7) hipLaunchKernelGGL(k_adaptive_threshold_t<7>, tg, dim3(256), 0, s, src0, cols, rows, 7, th_magic, bp, bits_fu32, wpr);
-            else if (th_magic && win == 11) hipLaunchKernelGGL(k_adaptive_threshold_t<11>, tg, dim3(256), 0, s, src0, cols, rows, 7, th_magic, bp, bits_fu32, wpr);
-            else if (th_magic && win == 15) hipLaunchKernelGGL(k_adaptive_threshold_t<15>, tg, dim3(256), 0, s, src0, cols, rows, 7, th_magic, bp, bits_fu32, wpr);
+            if (th_magic && win == 5) hipLaunchKernelGGL(k_adaptive_threshold_t<5>, tg1, dim3(256), 0, s, src0, cols, rows, 7, th_magic, bp, bits_fu32, wpr, ntx, ntl, ntl * B);
+            else if (th_magic && win == 7) hipLaunchKernelGGL(k_adaptive_threshold_t<7>, tg1, dim3(256), 0, s, src0, cols, rows, 7, th_magic, bp, bits_fu32, wpr, ntx, ntl, ntl * B);
+            else if (th_magic && win == 11) hipLaunchKernelGGL(k_adaptive_threshold_t<11>, tg1, dim3(256), 0, s, src0, cols, rows, 7, th_magic, bp, bits_fu32, wpr, ntx, ntl, ntl * B);
+            else if (th_magic && win == 15) hipLaunchKernelGGL(k_adaptive_threshold_t<15>, tg1, dim3(256), 0, s, src0, cols, rows, 7, th_magic, bp, bits_fu32, wpr, ntx, ntl, ntl * B);
             else hipLaunchKernelGGL(k_adaptive_threshold, tg, dim3(256), 0, s, src0, cols, rows, win, 7, 1.0 / (win * win), bp, bits_fu32, wpr);
         }
         timer.mark(s, "threshold");

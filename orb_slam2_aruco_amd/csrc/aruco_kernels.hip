@@ -102,13 +102,19 @@ __global__ __launch_bounds__(256) void k_adaptive_threshold(ImgView src, int W, 
 typedef uint32_t u32_unaligned_t __attribute__((aligned(1)));
 template <int WIN>
 __global__ __launch_bounds__(256) void k_adaptive_threshold_t(ImgView src, int W, int H, int C, uint32_t magic,
-                                                              uint32_t* __restrict__ bits, size_t bits_fstride, int wpr)
+                                                              uint32_t* __restrict__ bits, size_t bits_fstride, int wpr, int ntx, int ntiles,
+                                                              int total)
 {
     constexpr int R = WIN / 2, NDW = R <= 3 ? 3 : 5, LEAD = R <= 3 ? 4 : 8; // window = bytes x - LEAD .. x - LEAD + 4 NDW - 1
     constexpr int ROWS = 64 + 2 * R, P0 = (ROWS + 1) & ~1, PITCH = ((P0 / 2) & 1) ? P0 : P0 + 2; // u16 per LDS column:
     __shared__ __align__(16) uint16_t sh[64 * PITCH];                                           // an odd number of dwords
     __shared__ __align__(16) uint32_t spx[64][16];
-    const int tx0 = blockIdx.x * 64, ty0 = blockIdx.y * 64, f = blockIdx.z;
+    // 1-D grid renumbered so that the tiles of a frame run on one XCD (xcd_remap): neighbouring tiles share the 128-byte lines
+    // their 64-byte rows lie in and their halo rows; on eight different L2s every line was fetched 3.5 times
+    int tile, f;
+    if (!xcd_remap(ntiles, total, tile, f)) return;
+    const int tyi = tile / ntx;
+    const int tx0 = (tile - tyi * ntx) * 64, ty0 = tyi * 64;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint8_t* img = src.base + (size_t)f * src.fstride;
     constexpr int NIT = (ROWS * 16 + 255) / 256;
@@ -184,10 +190,10 @@ __global__ __launch_bounds__(256) void k_adaptive_threshold_t(ImgView src, int W
         }
     }
 }
-template __global__ void k_adaptive_threshold_t<5>(ImgView, int, int, int, uint32_t, uint32_t*, size_t, int);
-template __global__ void k_adaptive_threshold_t<7>(ImgView, int, int, int, uint32_t, uint32_t*, size_t, int);
-template __global__ void k_adaptive_threshold_t<11>(ImgView, int, int, int, uint32_t, uint32_t*, size_t, int);
-template __global__ void k_adaptive_threshold_t<15>(ImgView, int, int, int, uint32_t, uint32_t*, size_t, int);
+template __global__ void k_adaptive_threshold_t<5>(ImgView, int, int, int, uint32_t, uint32_t*, size_t, int, int, int, int);
+template __global__ void k_adaptive_threshold_t<7>(ImgView, int, int, int, uint32_t, uint32_t*, size_t, int, int, int, int);
+template __global__ void k_adaptive_threshold_t<11>(ImgView, int, int, int, uint32_t, uint32_t*, size_t, int, int, int, int);
+template __global__ void k_adaptive_threshold_t<15>(ImgView, int, int, int, uint32_t, uint32_t*, size_t, int, int, int, int);
 
 // exact 2x downscale = INTER_AREA 2x2 mean (what cv::resize(INTER_LINEAR) does for an exact factor of two)
 __global__ __launch_bounds__(256) void k_half_area(ImgView src, ImgView dst, int dw, int dh)

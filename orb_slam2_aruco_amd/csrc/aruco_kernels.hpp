@@ -32,7 +32,7 @@ __global__ void k_adaptive_threshold(ImgView src, int W, int H, int win, int C, 
                                      size_t bits_fstride, int wpr);
 template <int WIN>
 __global__ void k_adaptive_threshold_t(ImgView src, int W, int H, int C, uint32_t magic, uint32_t* bits,
-                                       size_t bits_fstride, int wpr);
+                                       size_t bits_fstride, int wpr, int ntx, int ntiles, int total);
 __global__ void k_half_area(ImgView src, ImgView dst, int dw, int dh);
 template <bool LDS_BITS>
 __global__ void k_contours_t(const uint32_t* gbits, size_t bits_fstride, int wpr_g, int W, int H, int lds_bits_words,
