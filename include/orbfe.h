@@ -297,6 +297,16 @@ int orbfe_search_for_initialization_batch_device(const orbfe_keypoint* d_kps, co
  * keypoints in a frame: ORBFE_ERR_CAPACITY. */
 int orbfe_search_for_initialization_batch_status(void* stream, int32_t* overflow);
 
+/* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:270-333; called after every new observation by Tracking,
+ * LocalMapping and LoopClosing): for every map point, among the descriptors it was observed with (CSR: point p owns rows
+ * offsets[p] .. offsets[p + 1] of desc, in the order of its observation map), the one with the least median Hamming distance
+ * to the others -- median = sorted row[(int)(0.5 * (N - 1))], first row wins ties.  best_idx[p] = its index inside the point's
+ * list (-1 for a point without descriptors, which the reference leaves untouched); best_desc (may be NULL) receives the chosen
+ * descriptor (npoints x 32).  At most 256 observations per point.  Host pointers / device pointers + stream. */
+int orbfe_distinctive_descriptors(const uint8_t* desc, const int32_t* offsets, int npoints, int32_t* best_idx, uint8_t* best_desc, int device);
+int orbfe_distinctive_descriptors_device(const uint8_t* d_desc, const int32_t* d_offsets, int npoints, int32_t* d_best_idx, uint8_t* d_best_desc,
+                                         void* stream);
+
 /* ------------------------------------------------------------------ DBoW2 vocabulary transform -- */
 /* ORBVocabulary (= DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>, include/ORBVocabulary.h) as Frame::ComputeBoW and
  * KeyFrame::ComputeBoW use it (src/Frame.cc:348-355, src/KeyFrame.cc): transform(descriptors, BowVector, FeatureVector, 4).

@@ -9,6 +9,7 @@
  * These are integer algorithms fully contained in the reference, so this part of
  * the oracle is pinned by known-answer tests (popcount identity, hand-built cases).
  */
+#include <algorithm>
 #include <climits>
 #include <cmath>
 #include <cstdint>
@@ -865,6 +866,37 @@ int oracle_search_by_projection_keyframe(const void* kps_cur_, const uint8_t* de
 int oracle_predict_scale(float mfMaxDistance, float currentDist, float mfLogScaleFactor, int mnScaleLevels)
 {
     return PredictScale(mfMaxDistance, currentDist, mfLogScaleFactor, mnScaleLevels);
+}
+
+/* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:270-333) on flat arrays: point p owns descriptors offsets[p] ..
+ * offsets[p + 1] (the observations of non-bad keyframes, in the order of the std::map mObservations).  best_idx[p] = index inside
+ * the point's list of the descriptor with the least median distance to the others, -1 for a point without descriptors (the
+ * reference returns before touching mDescriptor). */
+void oracle_distinctive_descriptors(const uint8_t* desc, const int32_t* offsets, int npoints, int32_t* best_idx)
+{
+    for (int p = 0; p < npoints; p++) {
+        const uint8_t* vDescriptors = desc + 32 * (size_t)offsets[p];
+        const size_t N = (size_t)(offsets[p + 1] - offsets[p]);
+        if (N == 0) { best_idx[p] = -1; continue; }
+        std::vector<std::vector<float>> Distances(N, std::vector<float>(N));
+        for (size_t i = 0; i < N; i++) {
+            Distances[i][i] = 0;
+            for (size_t j = i + 1; j < N; j++) {
+                int distij = DescriptorDistance(vDescriptors + 32 * i, vDescriptors + 32 * j);
+                Distances[i][j] = distij;
+                Distances[j][i] = distij;
+            }
+        }
+        int BestMedian = INT_MAX;
+        int BestIdx = 0;
+        for (size_t i = 0; i < N; i++) {
+            std::vector<int> vDists(Distances[i].begin(), Distances[i].end());
+            std::sort(vDists.begin(), vDists.end());
+            int median = vDists[0.5 * (N - 1)];
+            if (median < BestMedian) { BestMedian = median; BestIdx = i; }
+        }
+        best_idx[p] = BestIdx;
+    }
 }
 
 void oracle_three_maxima(const int* sizes, int L, int* out3)

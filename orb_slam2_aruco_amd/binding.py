@@ -41,7 +41,7 @@ SYMBOLS = [
     "orbfe_vocabulary_transform", "orbfe_vocabulary_transform_batch_device",
     "orbfe_search_by_bow", "orbfe_search_by_bow_batch_device",
     "orbfe_search_for_triangulation", "orbfe_search_for_triangulation_batch_device",
-    "orbfe_search_by_projection_last_frame", "orbfe_search_by_projection_best", "orbfe_search_by_projection_keyframe", "orbfe_fuse_search", "orbfe_project_map_points", "orbfe_search_by_sim3", "orbfe_search_by_projection_sim3",
+    "orbfe_distinctive_descriptors", "orbfe_distinctive_descriptors_device", "orbfe_search_by_projection_last_frame", "orbfe_search_by_projection_best", "orbfe_search_by_projection_keyframe", "orbfe_fuse_search", "orbfe_project_map_points", "orbfe_search_by_sim3", "orbfe_search_by_projection_sim3",
     "orbfe_keyframe_features_pack", "orbfe_keyframe_features_unpack", "orbfe_keyframe_features_pack_device",
     "orbfe_keyframe_features_unpack_device",
 ]
@@ -100,6 +100,8 @@ def load():
         L.orbfe_search_by_projection_keyframe.argtypes = [vp, vp, i32, vp, i32, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, f32,
                                                           i32, i32, vp, vp, i32]
         L.orbfe_search_by_projection_best.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp, i32, i32, f32, vp, vp, i32]
+        L.orbfe_distinctive_descriptors.argtypes = [vp, vp, i32, vp, vp, i32]
+        L.orbfe_distinctive_descriptors_device.argtypes = [vp, vp, i32, vp, vp, vp]
         L.orbfe_undistort_points.argtypes = [vp, i32, vp, vp, i32, vp, i32]
         L.orbfe_undistort_keypoints_batch_device.argtypes = [vp, vp, i32, i32, vp, vp, i32, vp, vp]
         L.orbfe_compute_image_bounds.argtypes = [i32, i32, vp, vp, i32, vp, i32]
@@ -329,6 +331,17 @@ def knn2_csr(Q, T, offsets, idx, init=256, device=0):
 def debug_control(key, value):
     L = load()
     _check(L, L.orbfe_debug_control(key.encode(), int(value)), "orbfe_debug_control")
+
+
+def distinctive_descriptors(desc, offsets, device=0):
+    """MapPoint::ComputeDistinctiveDescriptors over many map points (MapPoint.cc:270-333) -> (best index per point, chosen descriptors)."""
+    L = load()
+    d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    o = np.ascontiguousarray(offsets, np.int32)
+    n = len(o) - 1
+    bi = np.full(max(n, 1), -1, np.int32); bd = np.zeros((max(n, 1), 32), np.uint8)
+    _check(L, L.orbfe_distinctive_descriptors(_p(d) if len(d) else None, _p(o), n, _p(bi), _p(bd), device), "orbfe_distinctive_descriptors")
+    return bi[:n], bd[:n]
 
 
 def knn2(Q, T, init=256, device=0):

@@ -985,6 +985,64 @@ __global__ __launch_bounds__(256) void k_project_map_points(const float* __restr
     queries[i] = Q;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:270-333): among the N descriptors a map point was observed with,
+// the one with the least MEDIAN Hamming distance to the others -- median = sorted row[(int)(0.5 * (N - 1))], the first row wins
+// ties (`median < BestMedian`).  One wave per map point, N <= 256: lane l keeps descriptors l, l + 64, l + 128, l + 192 in
+// registers; row i's descriptor comes by v_readlane from the lane that owns it; the k-th smallest of a row's distances (all in
+// 0 .. 256) is found by bisection on the VALUE with one ballot + popcount per chunk and step -- no sort, no LDS.
+#define DD_MAXN 256
+__global__ __launch_bounds__(256) void k_distinctive(const uint8_t* __restrict__ desc, const int32_t* __restrict__ offsets, int npoints,
+                                                     int32_t* __restrict__ best_idx, uint8_t* __restrict__ best_desc)
+{
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (p >= npoints) return;
+    const int o0 = offsets[p], N = min(offsets[p + 1] - o0, DD_MAXN);
+    if (N <= 0) {
+        if (lane == 0) best_idx[p] = -1;
+        return;
+    }
+    const uint4* D = reinterpret_cast<const uint4*>(desc) + (size_t)o0 * 2;
+    uint32_t w[4][8];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int j = lane + 64 * c;
+        uint4 a = make_uint4(0, 0, 0, 0), b = a;
+        if (j < N) { a = D[2 * j]; b = D[2 * j + 1]; }
+        w[c][0] = a.x; w[c][1] = a.y; w[c][2] = a.z; w[c][3] = a.w; w[c][4] = b.x; w[c][5] = b.y; w[c][6] = b.z; w[c][7] = b.w;
+    }
+    const int k = (int)(0.5 * (double)(N - 1)); // index of the median in the sorted row
+    int best_median = 0x7fffffff, best = 0;
+    for (int i = 0; i < N; i++) {
+        uint32_t r[8];
+        const int src_lane = i & 63, src_c = i >> 6;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const uint32_t v = src_c == 0 ? w[0][q] : src_c == 1 ? w[1][q] : src_c == 2 ? w[2][q] : w[3][q];
+            r[q] = (uint32_t)__builtin_amdgcn_readlane((int)v, src_lane);
+        }
+        int d[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            int s_ = 0;
+#pragma unroll
+            for (int q = 0; q < 8; q++) s_ += __popc(w[c][q] ^ r[q]);
+            d[c] = s_;
+        }
+        int lo = 0, hi = 256; // smallest m with #(d <= m) >= k + 1
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            int cnt = 0;
+#pragma unroll
+            for (int c = 0; c < 4; c++) cnt += __popcll(__ballot(lane + 64 * c < N && d[c] <= mid));
+            if (cnt >= k + 1) hi = mid; else lo = mid + 1;
+        }
+        if (lo < best_median) { best_median = lo; best = i; }
+    }
+    if (lane == 0) best_idx[p] = best;
+    if (best_desc && lane < 8) reinterpret_cast<uint32_t*>(best_desc)[(size_t)p * 8 + lane] = reinterpret_cast<const uint32_t*>(D)[(size_t)best * 8 + lane];
+}
+
 struct MatchWorkspace {
     DevBuf pidx, pbest, psecond, csr_cnt, csr_idx, csr_dist, scratch, overflow, prev;
     DevBuf q, t, nq, nt, oidx, obest, osecond, kps, desc, nk, m12, nm;
@@ -1636,6 +1694,45 @@ int orbfe_knn2_csr(const uint8_t* Q, int nq, const uint8_t* T, int nt, const int
     ORBFE_HIP(hipMemcpy(best_idx, w.oidx.p, (size_t)nq * 4, hipMemcpyDeviceToHost));
     ORBFE_HIP(hipMemcpy(best_dist, w.obest.p, (size_t)nq * 4, hipMemcpyDeviceToHost));
     ORBFE_HIP(hipMemcpy(second_dist, w.osecond.p, (size_t)nq * 4, hipMemcpyDeviceToHost));
+    return ORBFE_OK;
+}
+
+int orbfe_distinctive_descriptors_device(const uint8_t* d_desc, const int32_t* d_offsets, int npoints, int32_t* d_best_idx, uint8_t* d_best_desc,
+                                         void* stream)
+{
+    if (npoints < 0 || (npoints && (!d_desc || !d_offsets || !d_best_idx)))
+        return fail(ORBFE_ERR_INVALID, "orbfe_distinctive_descriptors_device: invalid argument");
+    if (npoints == 0) return ORBFE_OK;
+    hipLaunchKernelGGL(k_distinctive, dim3((npoints + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_desc, d_offsets, npoints, d_best_idx, d_best_desc);
+    ORBFE_HIP(hipGetLastError());
+    return ORBFE_OK;
+}
+
+int orbfe_distinctive_descriptors(const uint8_t* desc, const int32_t* offsets, int npoints, int32_t* best_idx, uint8_t* best_desc, int device)
+{
+    if (npoints < 0 || (npoints && (!offsets || !best_idx))) return fail(ORBFE_ERR_INVALID, "orbfe_distinctive_descriptors: invalid argument");
+    if (npoints == 0) return ORBFE_OK;
+    if (offsets[0] != 0) return fail(ORBFE_ERR_INVALID, "orbfe_distinctive_descriptors: offsets must start at 0");
+    for (int p = 0; p < npoints; p++) {
+        if (offsets[p + 1] < offsets[p]) return fail(ORBFE_ERR_INVALID, "orbfe_distinctive_descriptors: offsets must be non-decreasing");
+        if (offsets[p + 1] - offsets[p] > DD_MAXN)
+            return fail(ORBFE_ERR_CAPACITY, "map point %d has %d observations, at most %d are supported", p, offsets[p + 1] - offsets[p], DD_MAXN);
+    }
+    const int total = offsets[npoints];
+    if (total && !desc) return fail(ORBFE_ERR_INVALID, "orbfe_distinctive_descriptors: null descriptors");
+    int rc = use_device(device);
+    if (rc) return rc;
+    MatchWorkspace& w = ws();
+    if ((rc = w.t.ensure((size_t)std::max(total, 1) * 32)) || (rc = w.csr_cnt.ensure((size_t)(npoints + 1) * 4)) ||
+        (rc = w.oidx.ensure((size_t)npoints * 4)) || (rc = w.q.ensure((size_t)npoints * 32)))
+        return rc;
+    if (total) ORBFE_HIP(hipMemcpy(w.t.p, desc, (size_t)total * 32, hipMemcpyHostToDevice));
+    ORBFE_HIP(hipMemcpy(w.csr_cnt.p, offsets, (size_t)(npoints + 1) * 4, hipMemcpyHostToDevice));
+    if ((rc = orbfe_distinctive_descriptors_device(w.t.as<uint8_t>(), w.csr_cnt.as<int32_t>(), npoints, w.oidx.as<int32_t>(),
+                                                   best_desc ? w.q.as<uint8_t>() : nullptr, nullptr)))
+        return rc;
+    ORBFE_HIP(hipMemcpy(best_idx, w.oidx.p, (size_t)npoints * 4, hipMemcpyDeviceToHost));
+    if (best_desc) ORBFE_HIP(hipMemcpy(best_desc, w.q.p, (size_t)npoints * 32, hipMemcpyDeviceToHost));
     return ORBFE_OK;
 }
 

@@ -425,6 +425,18 @@ def search_by_projection_keyframe(kps_cur, desc_cur, cols, rows, kf_angle, valid
     return nm, m[:len(kc)]
 
 
+def distinctive_descriptors(desc, offsets):
+    """MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:270-333) over CSR lists -> best index per point."""
+    L = lib()
+    d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32); o = np.ascontiguousarray(offsets, np.int32)
+    n = len(o) - 1
+    bi = np.zeros(max(n, 1), np.int32)
+    L.oracle_distinctive_descriptors.restype = None
+    L.oracle_distinctive_descriptors.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.oracle_distinctive_descriptors(_p(d) if len(d) else None, _p(o), n, _p(bi))
+    return bi[:n]
+
+
 def predict_scale(max_distance, dist, log_scale_factor, nlevels):
     """MapPoint::PredictScale (MapPoint.cc:414-446)."""
     L = lib()

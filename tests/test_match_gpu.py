@@ -503,3 +503,31 @@ def test_matching_entry_points_are_thread_safe(orbfe, oracle):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+@pytest.mark.gpu
+def test_distinctive_descriptors(orbfe, oracle):
+    """MapPoint::ComputeDistinctiveDescriptors over a whole map at once: bit-exact against the oracle, N from 0 to 256, clusters of
+    near-duplicates (ties in the medians), chosen descriptors returned."""
+    rng = np.random.default_rng(11)
+    sizes = [0, 1, 2, 3, 4, 5, 7, 16, 33, 63, 64, 65, 127, 128, 129, 200, 256] + rng.integers(1, 40, 400).tolist()
+    rng.shuffle(sizes)
+    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    desc = np.zeros((offsets[-1], 32), np.uint8)
+    for p, n in enumerate(sizes):            # observations of one point: a base descriptor with a few bits flipped
+        base = rng.integers(0, 256, 32, dtype=np.uint8)
+        blk = np.tile(base, (n, 1))
+        flips = rng.integers(0, 256, (n, 3))
+        for i in range(n):
+            for b in flips[i][:rng.integers(0, 4)]:
+                blk[i, b >> 3] ^= np.uint8(1 << (b & 7))
+        desc[offsets[p]:offsets[p + 1]] = blk
+    want = oracle.distinctive_descriptors(desc, offsets)
+    got, chosen = orbfe.distinctive_descriptors(desc, offsets)
+    assert np.array_equal(got, want)
+    for p, n in enumerate(sizes):
+        if n:
+            assert np.array_equal(chosen[p], desc[offsets[p] + got[p]])
+    assert len(orbfe.distinctive_descriptors(desc[:0], np.zeros(1, np.int32))[0]) == 0
+    with pytest.raises(orbfe.OrbfeError):
+        orbfe.distinctive_descriptors(np.zeros((300, 32), np.uint8), np.array([0, 300], np.int32))

@@ -629,3 +629,22 @@ def test_bow_vectors_pinned_by_reference_classes(oracle, weighting, scoring):
     on = np.zeros(n, np.uint32); oo = np.zeros(n + 1, np.int32); of = np.zeros(n, np.uint32)
     kf = R.dbow2_ref_featurevector(node.ctypes.data, feat.ctypes.data, n, on.ctypes.data, oo.ctypes.data, of.ctypes.data)
     assert np.array_equal(on[:kf], t["fv"][0]) and np.array_equal(oo[:kf + 1], t["fv"][1]) and np.array_equal(of[:oo[kf]], t["fv"][2])
+
+
+def test_distinctive_descriptor_known_answers(oracle):
+    """MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:270-333): least median distance, median = sorted[(int)(0.5 (N - 1))],
+    first row wins ties; a point without observations is left alone (-1)."""
+    z = np.zeros((1, 32), np.uint8)
+    a = z.copy(); a[0, 0] = 0x0F            # 4 bits from z
+    b = z.copy(); b[0, :2] = 0xFF           # 16 bits from z, 12 from a
+    # N = 3: rows sorted (0,4,16) (0,4,12) (0,12,16): medians 4, 4, 12 -> first of the tie = 0
+    d = np.concatenate([z, a, b])
+    assert oracle.distinctive_descriptors(d, [0, 3]).tolist() == [0]
+    # N = 2: median index (int)(0.5) = 0 -> every row's median is its own 0 distance -> index 0
+    assert oracle.distinctive_descriptors(np.concatenate([b, z]), [0, 2]).tolist() == [0]
+    # N = 4, index (int)1.5 = 1: rows z:(0,0,4,16)->0  z:(0,0,4,16)->0  a:(0,4,4,12)->4  b -> 12
+    d = np.concatenate([b, a, z, z])
+    assert oracle.distinctive_descriptors(d, [0, 4]).tolist() == [2]
+    # several points, one of them empty, one with a single observation
+    d = np.concatenate([z, a, b, a])
+    assert oracle.distinctive_descriptors(d, [0, 3, 3, 4]).tolist() == [0, -1, 0]
