@@ -193,6 +193,22 @@ int orbfe_search_by_projection(const orbfe_keypoint* kps, const uint8_t* desc, i
                                int mode, int th_high, float nnratio, int32_t* best_idx, int32_t* best_dist, int32_t* best_level,
                                int32_t* second_dist, int32_t* second_level, int32_t* match, int32_t* nmatches, int device);
 
+/* The same loop over the frames of a batch resident on the device (no host round trip per call): frame f owns block f of
+ * `capacity` keypoint records (d_n[f] valid, the layout of orbfe_extract_batch_device) and block f of `qcapacity` queries
+ * (d_nq[f] valid) with their descriptors, flags and outputs.  mode 0 / 1 as above; mode 2 = the best-only loop of
+ * orbfe_search_by_projection_best (d_q_angle, factor, check_orientation, d_match_cur[f][keypoint] = query or -1; d_q_observed
+ * plays q_blocks).  d_taken (may be NULL) is updated in place.  Asynchronous on `stream`; a candidate row that overflowed the
+ * per-stream scratch truncates silently, so ask orbfe_search_by_projection_batch_status afterwards: *overflow = 0, or the
+ * longest candidate list -- the scratch has then been grown and repeating the call succeeds. */
+int orbfe_search_by_projection_batch_device(const orbfe_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n, int capacity, int nframes,
+                                            int cols, int rows, const float* bounds, const orbfe_window_query* d_queries,
+                                            const uint8_t* d_qdesc, const int32_t* d_nq, int qcapacity, uint8_t* d_taken,
+                                            const uint8_t* d_q_observed, const float* d_q_angle, int mode, int th_high, float nnratio,
+                                            float factor, int check_orientation, int32_t* d_best_idx, int32_t* d_best_dist,
+                                            int32_t* d_best_level, int32_t* d_second_dist, int32_t* d_second_level, int32_t* d_match,
+                                            int32_t* d_match_cur, int32_t* d_nmatches, void* stream);
+int orbfe_search_by_projection_batch_status(void* stream, int32_t* overflow);
+
 /* ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono) (src/ORBmatcher.cc:1332-1474; what
  * TrackWithMotionModel runs every frame), monocular, whole on the device: the projection of the last frame's map points
  * with the current pose (:1362-1389), the window search on the Frame grid (levels octave +- 1, :1396), best match <= th_high

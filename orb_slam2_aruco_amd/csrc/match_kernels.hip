@@ -587,7 +587,7 @@ struct SbpBest { // mode 2 only (q_blocks: modes 1 and 2)
     float inv_sigma2[16];
 };
 
-__global__ __launch_bounds__(SBP_THREADS) void k_search_by_projection(
+__device__ __forceinline__ void sbp_frame(
     const orbfe_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc, int n, int ncap /*pow2 >= n*/, float4 bnd,
     const SbpQuery* __restrict__ queries, const uint8_t* __restrict__ qdesc, int nq, uint8_t* __restrict__ taken, int mode,
     int th_high, float nnratio, uint16_t* __restrict__ row_rank, uint8_t* __restrict__ row_dist, int32_t* __restrict__ row_cnt,
@@ -835,6 +835,46 @@ __global__ __launch_bounds__(SBP_THREADS) void k_search_by_projection(
         __builtin_amdgcn_wave_barrier();
     }
     if (lane == 0) *nmatches_out = nmatches;
+}
+
+__global__ __launch_bounds__(SBP_THREADS) void k_search_by_projection(
+    const orbfe_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc, int n, int ncap /*pow2 >= n*/, float4 bnd,
+    const SbpQuery* __restrict__ queries, const uint8_t* __restrict__ qdesc, int nq, uint8_t* __restrict__ taken, int mode,
+    int th_high, float nnratio, uint16_t* __restrict__ row_rank, uint8_t* __restrict__ row_dist, int32_t* __restrict__ row_cnt,
+    int row_stride, int32_t* __restrict__ best_idx, int32_t* __restrict__ best_dist, int32_t* __restrict__ best_level,
+    int32_t* __restrict__ second_dist, int32_t* __restrict__ second_level, int32_t* __restrict__ match,
+    int32_t* __restrict__ nmatches_out, int32_t* __restrict__ overflow, SbpBest bo)
+{
+    sbp_frame(kps, desc, n, ncap, bnd, queries, qdesc, nq, taken, mode, th_high, nnratio, row_rank, row_dist, row_cnt, row_stride, best_idx,
+              best_dist, best_level, second_dist, second_level, match, nmatches_out, overflow, bo);
+}
+
+// The same search over the frames of a batch resident on the device: workgroup f = frame f of blocks of `capacity` keypoint
+// records and `qcapacity` query records (the layouts of orbfe_extract_batch_device).
+struct SbpBatch {
+    const orbfe_keypoint* kps; const uint8_t* desc; const int32_t* n; int capacity;
+    const SbpQuery* queries; const uint8_t* qdesc; const int32_t* nq; int qcapacity;
+    uint8_t* taken; const uint8_t* q_observed; const float* q_angle;
+    uint16_t* row_rank; uint8_t* row_dist; int32_t* row_cnt; int row_stride;
+    int32_t *best_idx, *best_dist, *best_level, *second_dist, *second_level, *match, *nmatches, *overflow;
+    int32_t *match_cur, *qbin;
+};
+__global__ __launch_bounds__(SBP_THREADS) void k_search_by_projection_batch(SbpBatch B, int ncap, float4 bnd, int mode, int th_high,
+                                                                            float nnratio, float factor, int check_ori)
+{
+    const size_t f = blockIdx.x, ko = f * B.capacity, qo = f * B.qcapacity;
+    const int n = min(B.n[f], B.capacity), nq = min(B.nq[f], B.qcapacity);
+    SbpBest bo{};
+    bo.q_angle = B.q_angle ? B.q_angle + qo : nullptr;
+    bo.q_blocks = B.q_observed ? B.q_observed + qo : nullptr;
+    bo.factor = factor; bo.check_ori = check_ori;
+    bo.match_cur = B.match_cur ? B.match_cur + ko : nullptr;
+    bo.qbin = B.qbin ? B.qbin + qo : nullptr;
+    sbp_frame(B.kps + ko, B.desc + ko * 32, n, ncap, bnd, B.queries + qo, B.qdesc + qo * 32, nq, B.taken ? B.taken + ko : nullptr, mode, th_high,
+              nnratio, B.row_rank + qo * B.row_stride, B.row_dist + qo * B.row_stride, B.row_cnt + qo, B.row_stride,
+              B.best_idx ? B.best_idx + qo : nullptr, B.best_dist ? B.best_dist + qo : nullptr, B.best_level ? B.best_level + qo : nullptr,
+              B.second_dist ? B.second_dist + qo : nullptr, B.second_level ? B.second_level + qo : nullptr, B.match + qo, B.nmatches + f,
+              B.overflow, bo);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1662,6 +1702,61 @@ int orbfe_search_by_projection_keyframe(const orbfe_keypoint* kps_cur, const uin
     return sbp_best_run(kps_cur, desc_cur, n_cur, cols, rows, bounds, nullptr, kf_angle, mp_desc, nullptr, n_kf, taken_cur, orb_dist,
                         check_orientation, 1.0f / 30 /* :1488 */, match_cur, nmatches, p3Dw, valid, nullptr, nullptr, nullptr, nullptr, 0, 0.0f,
                         &P, min_dist, max_dist);
+}
+
+int orbfe_search_by_projection_batch_device(const orbfe_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n, int capacity, int nframes,
+                                            int cols, int rows, const float* bounds, const orbfe_window_query* d_queries,
+                                            const uint8_t* d_qdesc, const int32_t* d_nq, int qcapacity, uint8_t* d_taken,
+                                            const uint8_t* d_q_observed, const float* d_q_angle, int mode, int th_high, float nnratio,
+                                            float factor, int check_orientation, int32_t* d_best_idx, int32_t* d_best_dist,
+                                            int32_t* d_best_level, int32_t* d_second_dist, int32_t* d_second_level, int32_t* d_match,
+                                            int32_t* d_match_cur, int32_t* d_nmatches, void* stream)
+{
+    if (!d_kps || !d_desc || !d_n || !d_queries || !d_qdesc || !d_nq || !d_match || !d_nmatches || capacity <= 0 || qcapacity <= 0 ||
+        nframes <= 0 || cols <= 0 || rows <= 0 || mode < 0 || mode > 2 || (mode == 2 && (!d_match_cur || (check_orientation && !d_q_angle))) ||
+        (d_best_idx && (!d_best_dist || !d_best_level || !d_second_dist || !d_second_level)))
+        return fail(ORBFE_ERR_INVALID, "orbfe_search_by_projection_batch_device: invalid argument");
+    if (capacity > 65535) return fail(ORBFE_ERR_INVALID, "more than 65535 keypoints per frame are unsupported");
+    int ncap = 64;
+    while (ncap < capacity) ncap <<= 1;
+    const size_t lds = (size_t)ncap * (4 + 8 + 1 + 1) + (SBP_CELLS + 2) * 2 + 64;
+    if (lds > 150 * 1024) return fail(ORBFE_ERR_CAPACITY, "%d keypoints do not fit the grid kernel's LDS", capacity);
+    hipStream_t s = (hipStream_t)stream;
+    MatchWorkspace& w = ws(s);
+    const int stride = std::max(w.sbp_stride, 128);
+    w.sbp_stride = stride;
+    const size_t NQ = (size_t)nframes * qcapacity;
+    int rc;
+    if ((rc = w.csr_idx.ensure(NQ * stride * 2)) || (rc = w.csr_dist.ensure(NQ * stride)) || (rc = w.csr_cnt.ensure(NQ * 4)) ||
+        (rc = w.scratch.ensure(NQ * 4 + 256)) || (rc = w.overflow.ensure(16)))
+        return rc;
+    ORBFE_HIP(hipMemsetAsync(w.overflow.p, 0, 4, s));
+    SbpBatch B{};
+    B.kps = d_kps; B.desc = d_desc; B.n = d_n; B.capacity = capacity;
+    B.queries = reinterpret_cast<const SbpQuery*>(d_queries); B.qdesc = d_qdesc; B.nq = d_nq; B.qcapacity = qcapacity;
+    B.taken = d_taken; B.q_observed = d_q_observed; B.q_angle = d_q_angle;
+    B.row_rank = w.csr_idx.as<uint16_t>(); B.row_dist = w.csr_dist.as<uint8_t>(); B.row_cnt = w.csr_cnt.as<int32_t>(); B.row_stride = stride;
+    B.best_idx = d_best_idx; B.best_dist = d_best_dist; B.best_level = d_best_level; B.second_dist = d_second_dist; B.second_level = d_second_level;
+    B.match = d_match; B.nmatches = d_nmatches; B.overflow = w.overflow.as<int32_t>();
+    B.match_cur = d_match_cur; B.qbin = w.scratch.as<int32_t>();
+    if ((rc = ensure_dyn_lds(reinterpret_cast<const void*>(&k_search_by_projection_batch), lds))) return rc;
+    hipLaunchKernelGGL(k_search_by_projection_batch, dim3(nframes), dim3(SBP_THREADS), lds, s, B, ncap, frame_bounds(cols, rows, bounds), mode,
+                       th_high, nnratio, factor, check_orientation);
+    ORBFE_HIP(hipGetLastError());
+    return ORBFE_OK;
+}
+
+int orbfe_search_by_projection_batch_status(void* stream, int32_t* overflow)
+{
+    if (!overflow) return fail(ORBFE_ERR_INVALID, "orbfe_search_by_projection_batch_status: null argument");
+    *overflow = 0;
+    hipStream_t s = (hipStream_t)stream;
+    MatchWorkspace& w = ws(s);
+    if (!w.overflow.p) return ORBFE_OK;
+    ORBFE_HIP(hipStreamSynchronize(s));
+    ORBFE_HIP(hipMemcpy(overflow, w.overflow.p, 4, hipMemcpyDeviceToHost));
+    if (*overflow > w.sbp_stride) w.sbp_stride = (*overflow + 63) / 64 * 64; // the next batch on this stream has the room
+    return ORBFE_OK;
 }
 
 int orbfe_knn2_csr(const uint8_t* Q, int nq, const uint8_t* T, int nt, const int32_t* offsets, const int32_t* idx, int init,

@@ -105,6 +105,65 @@ for p, (a, b) in enumerate(pairs):
     assert int(nmm[p]) == wn and np.array_equal(m12[p * cap:p * cap + len(ka)].cpu().numpy(), w12)
 print("pairs ok")
 
+# ---- the projection searches over a resident batch (orbfe_search_by_projection_batch_device): frame f is searched with queries
+# built from frame (f + 1) % 3's keypoints; every mode against the per-frame host-pointer entry points and the oracle
+rng = np.random.default_rng(3)
+QC = 700
+qs = np.zeros((3, QC), orbfe.WINDOW_QUERY_DTYPE); qd = np.zeros((3, QC, 32), np.uint8); nq = np.zeros(3, np.int32)
+qobs = np.zeros((3, QC), np.uint8); qang = np.zeros((3, QC), np.float32); tk = np.zeros((3, cap), np.uint8)
+for f in range(3):
+    ks, ds = frames[(f + 1) % 3]
+    sel = rng.permutation(len(ks))[:QC - 50 * f]
+    nq[f] = len(sel)
+    qs[f, :len(sel)]["x"] = ks["x"][sel] + rng.normal(0, 1.5, len(sel)).astype(np.float32)
+    qs[f, :len(sel)]["y"] = ks["y"][sel] + rng.normal(0, 1.5, len(sel)).astype(np.float32)
+    qs[f, :len(sel)]["r"] = (6.0 * 1.2 ** ks["octave"][sel]).astype(np.float32)
+    qs[f, :len(sel)]["min_level"] = ks["octave"][sel] - 1
+    qs[f, :len(sel)]["max_level"] = ks["octave"][sel] + (f % 2)
+    qd[f, :len(sel)] = ds[sel]
+    qang[f, :len(sel)] = ks["angle"][sel]
+    qobs[f, :len(sel)] = rng.random(len(sel)) < 0.7
+    tk[f, :nh[f]] = rng.random(nh[f]) < 0.1
+tdev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).to(dev)
+d_qs, d_qd, d_nq, d_qobs, d_qang = tdev(qs), tdev(qd), torch.from_numpy(nq).to(dev), tdev(qobs), tdev(qang)
+outs = [i32(3 * QC) for _ in range(6)]
+d_mc, d_nm3 = i32(3 * cap), i32(3)
+kun = kps  # the (undistorted) keypoint records of the batch, still on the device
+bnd_p = bounds.ctypes.data_as(C.c_void_p)
+for mode in (0, 1, 2):
+    d_tk = tdev(tk)
+    for attempt in range(2):
+        rc = L.orbfe_search_by_projection_batch_device(kun.data_ptr(), desc.data_ptr(), n.data_ptr(), cap, 3, 640, 480, bnd_p, d_qs.data_ptr(),
+                                                       d_qd.data_ptr(), d_nq.data_ptr(), QC, d_tk.data_ptr(), d_qobs.data_ptr(), d_qang.data_ptr(),
+                                                       mode, 100, np.float32(0.8), np.float32(1.0 / 30), 1, *[o.data_ptr() for o in outs[:5]],
+                                                       outs[5].data_ptr(), d_mc.data_ptr(), d_nm3.data_ptr(), None)
+        assert rc == 0, L.orbfe_last_error()
+        ovf = C.c_int32(0)
+        assert L.orbfe_search_by_projection_batch_status(None, C.byref(ovf)) == 0
+        if not ovf.value:
+            break
+        d_tk = tdev(tk)
+    assert ovf.value == 0
+    torch.cuda.synchronize()
+    got = [o.cpu().numpy().reshape(3, QC) for o in outs]
+    gmc = d_mc.cpu().numpy().reshape(3, cap); gnm = d_nm3.cpu().numpy(); gtk = d_tk.cpu().numpy().reshape(3, cap)
+    for f in range(3):
+        kf, df = kh[f, :nh[f]], dh[f, :nh[f]]
+        q, m = qs[f, :nq[f]], int(nq[f])
+        if mode < 2:
+            want = orbfe.search_by_projection(kf, df, 640, 480, q, qd[f, :m], tk[f, :nh[f]], mode, 100, 0.8, bounds=bounds, q_observed=qobs[f, :m])
+            ora = oracle.search_by_projection(kf, df, 640, 480, q, qd[f, :m], tk[f, :nh[f]], mode, 100, 0.8, bounds=bounds, q_observed=qobs[f, :m])
+            for j, name in enumerate(("best_idx", "best_dist", "best_level", "second_dist", "second_level")):
+                assert np.array_equal(got[j][f, :m], want[name]) and np.array_equal(want[name], ora[name]), (mode, f, name)
+            if mode == 1:
+                assert gnm[f] == want["nmatches"] == ora["nmatches"] and np.array_equal(got[5][f, :m], want["match"])
+                assert np.array_equal(gtk[f, :nh[f]], want["taken"]) and np.array_equal(want["match"], ora["match"])
+        else:
+            wn, wm = orbfe.search_by_projection_best(kf, df, 640, 480, q, qang[f, :m], qd[f, :m], 100, 1.0 / 30, q_blocks=qobs[f, :m],
+                                                     taken=tk[f, :nh[f]], bounds=bounds)
+            assert gnm[f] == wn and wn > 5 and np.array_equal(gmc[f, :nh[f]], wm), (f, gnm[f], wn)
+print("projection batch ok")
+
 # ---- detector batch on device pointers + marker poses (MarkerDetector::detect with camera parameters, Frame.cc:142)
 import pose_cases as pc
 det = orbfe.MarkerDetector("ARUCO")
