@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(ImgView src0, ImgView pyr, c
                                                     int map_pitch, int map_rows, int list_cap, int nx, int total)
 {
     extern __shared__ __align__(16) unsigned char fc_smem[];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wid = wave_id();
     int bx, f;
     if (!xcd_remap(nx, total, bx, f)) return;
     const int cell = bx * 4 + wid;
@@ -1374,7 +1374,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(ImgView src0, ImgView p
                                                          const int* __restrict__ umax, orbfe_keypoint* __restrict__ kps,
                                                          uint8_t* __restrict__ desc, int capacity, int nx, int total)
 {
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wid = wave_id();
     int bx, f;
     if (!xcd_remap(nx, total, bx, f)) return;
     // IC_Angle weights of the 31 rows of the r = 15 circular patch: [row][0..7] = byte index i = u + 15 of the bytes inside

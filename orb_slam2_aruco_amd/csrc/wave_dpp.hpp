@@ -15,6 +15,12 @@
 
 namespace orbfe {
 
+// Index of the wave inside its workgroup as a SCALAR.  threadIdx.x >> 6 is the same in all lanes, but the compiler only knows
+// that it derives from a per-lane value: everything computed from it (which cell / keypoint / candidate the wave owns, its
+// geometry, loop bounds) is then kept in vector registers, addressed with vector arithmetic, and every loop and branch on it
+// is compiled as a divergent one with exec-mask bookkeeping.  v_readfirstlane moves it -- and all that follows -- to the scalar unit.
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
 #define ORBFE_DPP(old_, v_, ctrl_, rmask_) __builtin_amdgcn_update_dpp((old_), (v_), (ctrl_), (rmask_), 0xf, false)
 #define ORBFE_DPP_STEPS(STEP)                                                                  \
     STEP(0x111, 0xf) STEP(0x112, 0xf) STEP(0x114, 0xf) STEP(0x118, 0xf) /* row_shr 1 2 4 8 */ \
