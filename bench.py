@@ -359,9 +359,10 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ex.enable_kernel_timing(True)
-    if use_aruco:
-        det.enable_kernel_timing(True)
+    for e in pipe.exs:
+        e.enable_kernel_timing(True)
+    for d in pipe.dets:
+        d.enable_kernel_timing(True)
     last = (0, 0)
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -376,8 +377,9 @@ def main():
     if any(status.values()):
         raise SystemExit("front-end capacity exceeded during the timed run: results incomplete, no number reported (%r)" % (status,))
     # HIP-event timings of the LAST timed step's launches (events were recorded on the launch stream every step)
-    orb_us = ex.kernel_times_us()
-    aruco_us = det.kernel_times_us() if use_aruco else np.zeros(0, np.float32)
+    ex_last, det_last = pipe.last_engines()
+    orb_us = ex_last.kernel_times_us()
+    aruco_us = det_last.kernel_times_us() if use_aruco else np.zeros(0, np.float32)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -500,7 +502,7 @@ def main():
                                       " + ArUco detect incl. IPPE marker poses" if use_aruco else " (ArUco leg DISABLED: diagnostic run)"),
                        "frames_per_step_per_gpu": B, "mean_keypoints_per_frame": N, "marker_records_per_frame": pipe.mcap,
                        "result_record_bytes_per_step_per_gpu": pipe.layout.nbytes, "resident_batches": R,
-                       "sub_batches": pipe.S, "aruco_big_frame_kernel": pipe.big_frames, "library": version,
+                       "sub_batches": pipe.S, "engine_sets": pipe.D, "aruco_big_frame_kernel": pipe.big_frames, "library": version,
                        "parallelism": "stream-per-gpu x%d, %s gather to rank 0" % (world, "RCCL" if backend == "nccl" else backend)},
             "roofline": roof, "cpu_baseline": cpu, "verified_frames": verified, "skips": skips or None,
             "stage_us_last_step": stages,

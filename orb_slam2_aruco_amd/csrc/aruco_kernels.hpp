@@ -78,7 +78,9 @@ __global__ void k_finalize(const ArRect* rects, int rect_cap, const int32_t* can
 #ifndef RL_THREADS
 #define RL_THREADS 512   // 8 waves per frame: measured against 1024 (contours alone 713 -> 640 us per 300 frames, step 2.00 -> 1.95 ms) and 256 (893 us)
 #endif
+#ifndef RT_THREADS
 #define RT_THREADS 256           // k_contours_tail: 4 waves, one approxPolyDP each at a time (small workgroups place easily next to other kernels)
+#endif
 #ifndef RL_THREADS_BIG
 #define RL_THREADS_BIG 1024     // k_contours_relay8 (large frames): its workgroup owns the CU (LDS), so it brings 16 waves
 #endif

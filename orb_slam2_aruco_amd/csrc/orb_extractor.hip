@@ -73,6 +73,7 @@ struct orbfe_extractor {
     DevBuf d_geom, d_cellinfo, d_tiles, d_tabs, d_pattern, d_umax;
     DevBuf d_pyr, d_blur, d_slots, d_cellcnt, d_keys, d_lvlout, d_lvlcnt, d_lvloff, d_lvlncand, d_overflow, d_fallback,
         d_flatkv, d_flatlvl;
+    int blur_place = 1;                  // where the blur is forked: 1 in front of FAST (default), 0 after FAST, 2 no fork (main stream, before orient)
     bool gaussian_ed = false;            // orbfe_extractor_set_gaussian_taps: 18 34 48 56 48 34 18 instead of 18 34 49 55 49 34 18
     bool force_general_quadtree = false; // test hook: run the general kernel for every level
     int force_pyramid_depth = 0;         // test hook: shallow count pyramid so that levels fall back
@@ -132,6 +133,28 @@ struct orbfe_extractor {
             umax[v] = v0;
             ++v0;
         }
+    }
+
+    // Tables of k_orient_describe: the 256 rBRIEF tests (x0, y0, x1, y1 as int8 -- the pattern copied at ORBextractor.cc:448-450),
+    // and per row v = -15 .. 15 of the r = 15 patch of IC_Angle the weights of its 32 bytes: byte index i = u + 15 inside
+    // |u| <= umax[|v|] (:454-469), and ones for the same bytes (d_umax keeps its name: it holds umax in this form).
+    int upload_describe_tables()
+    {
+        std::vector<uint32_t> w(31 * 16, 0u);
+        for (int row = 0; row < 31; row++) {
+            const int um = umax[row < 15 ? 15 - row : row - 15];
+            for (int i = 0; i <= 30; i++) {
+                const int u = i - 15;
+                if (u < -um || u > um) continue;
+                w[row * 16 + i / 4] |= (uint32_t)i << (8 * (i & 3));
+                w[row * 16 + 8 + i / 4] |= 1u << (8 * (i & 3));
+            }
+        }
+        int rc;
+        if ((rc = d_pattern.ensure(1024)) || (rc = d_umax.ensure(w.size() * 4))) return rc;
+        ORBFE_HIP(hipMemcpy(d_pattern.p, ORBFE_BIT_PATTERN_31, 1024, hipMemcpyHostToDevice));
+        ORBFE_HIP(hipMemcpy(d_umax.p, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+        return ORBFE_OK;
     }
 
     int max_keypoints() const
@@ -332,21 +355,29 @@ struct orbfe_extractor {
             }
         }
         timer.mark(s, "resize");
-        // The blur only needs the pyramid: it runs on a second stream next to FAST and the (latency-bound) quadtree
+        // The blur only needs the pyramid, and only k_orient_describe needs the blur: it runs on a second stream, forked in front of
+        // FAST.  Measured on the C2 batch (step time with the detector running / extractor alone, ms): fork in front of FAST 1.83 /
+        // 1.76, fork after FAST (blur next to the quadtree) 1.88 / 1.76, no fork 1.97 / 1.75 -- orbfe_extractor_debug_kernel_times
+        // codes 20..22 switch, ORBFE_BLUR_PLACE in the bench.
         hipStream_t aux_stream = user_aux ? user_aux : this->aux_stream;
-        ORBFE_HIP(hipEventRecord(ev_fork, s));
-        ORBFE_HIP(hipStreamWaitEvent(aux_stream, ev_fork, 0));
-        timer.mark(aux_stream, "blur7 starts", true);
-        if (!ORBFE_SKIP_ORB(8)) {
-            if (gaussian_ed)
-                hipLaunchKernelGGL(k_blur7<true>, dim3(xcd_grid(ntiles * B)), dim3(256), 0, aux_stream, src0, pyr, blur, dg,
-                                   d_tiles.as<uint32_t>(), ntiles, ntiles * B);
-            else
-                hipLaunchKernelGGL(k_blur7<false>, dim3(xcd_grid(ntiles * B)), dim3(256), 0, aux_stream, src0, pyr, blur, dg,
-                                   d_tiles.as<uint32_t>(), ntiles, ntiles * B);
-        }
-        timer.mark(aux_stream, "blur7");
-        ORBFE_HIP(hipEventRecord(ev_join, aux_stream));
+        if (blur_place == 2) aux_stream = s;
+        auto launch_blur = [&]() -> int {
+            ORBFE_HIP(hipEventRecord(ev_fork, s));
+            ORBFE_HIP(hipStreamWaitEvent(aux_stream, ev_fork, 0));
+            timer.mark(aux_stream, "blur7 starts", true);
+            if (!ORBFE_SKIP_ORB(8)) {
+                if (gaussian_ed)
+                    hipLaunchKernelGGL(k_blur7<true>, dim3(xcd_grid(ntiles * B)), dim3(256), 0, aux_stream, src0, pyr, blur, dg,
+                                       d_tiles.as<uint32_t>(), ntiles, ntiles * B);
+                else
+                    hipLaunchKernelGGL(k_blur7<false>, dim3(xcd_grid(ntiles * B)), dim3(256), 0, aux_stream, src0, pyr, blur, dg,
+                                       d_tiles.as<uint32_t>(), ntiles, ntiles * B);
+            }
+            timer.mark(aux_stream, "blur7");
+            ORBFE_HIP(hipEventRecord(ev_join, aux_stream));
+            return ORBFE_OK;
+        };
+        if (blur_place == 1) { int rcb = launch_blur(); if (rcb) return rcb; }
         {
             // LDS per wave: ROI (cell + 6), score map (cell + 2), one u16 list of cell pixels
             const int roi_pitch = align_up(max_wcell + 6 + 4, 4) + 8, roi_rows = max_hcell + 6; // +1 byte shift, +2 dwords read past a row (8-pixel groups)
@@ -363,6 +394,7 @@ struct orbfe_extractor {
                                map_pitch, map_rows, list_cap, nx, nx * B);
         }
         timer.mark(s, "fast_cells");
+        if (blur_place == 0) { int rcb = launch_blur(); if (rcb) return rcb; }
         {
             // fast path: count-pyramid quadtree (no keypoint movement); general kernel only for flagged levels
             int max_ini = 1;
@@ -390,11 +422,18 @@ struct orbfe_extractor {
         hipLaunchKernelGGL(k_level_offsets, dim3(B), dim3(256), 0, s, d_lvlcnt.as<int32_t>(), d_lvloff.as<int32_t>(),
                            d_n, nlevels, B, capacity, d_overflow.as<int32_t>(), dg, d_lvlout.as<uint32_t>(), out_total,
                            d_flatkv.as<uint32_t>(), d_flatlvl.as<uint8_t>());
-        ORBFE_HIP(hipStreamWaitEvent(s, ev_join, 0));
+        if (blur_place == 2) { // no fork: the blur runs in the main stream between the quadtree and the descriptors
+            hipStream_t keep = aux_stream;
+            aux_stream = s;
+            int rcb = launch_blur();
+            aux_stream = keep;
+            if (rcb) return rcb;
+        } else
+            ORBFE_HIP(hipStreamWaitEvent(s, ev_join, 0));
         const int okx = (std::min(capacity, max_keypoints()) + 3) / 4;
         if (!ORBFE_SKIP_ORB(4)) hipLaunchKernelGGL(k_orient_describe, dim3(xcd_grid(okx * B)), dim3(256), 0, s, src0, pyr, blur, dg,
                            d_flatkv.as<uint32_t>(), d_flatlvl.as<uint8_t>(), d_n, nlevels, d_pattern.as<uint32_t>(),
-                           d_umax.as<int>(), d_kps_out, d_desc_out, capacity, okx, okx * B);
+                           d_umax.as<uint4>(), d_kps_out, d_desc_out, capacity, okx, okx * B);
         timer.mark(s, "orient_describe");
         ORBFE_HIP(hipGetLastError());
         return ORBFE_OK;
@@ -432,10 +471,7 @@ orbfe_extractor* orbfe_extractor_create(int nfeatures, float scaleFactor, int nl
     h->build_tables();
     if (hipStreamCreate(&h->own_stream) != hipSuccess || hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess || h->d_pattern.ensure(1024) != ORBFE_OK ||
-        h->d_umax.ensure(64) != ORBFE_OK ||
-        hipMemcpy(h->d_pattern.p, ORBFE_BIT_PATTERN_31, 1024, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(h->d_umax.p, h->umax.data(), 64, hipMemcpyHostToDevice) != hipSuccess) {
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess || h->upload_describe_tables() != ORBFE_OK) {
         fail(ORBFE_ERR_HIP, "extractor device initialisation failed");
         delete h;
         return nullptr;
@@ -639,6 +675,7 @@ int orbfe_extractor_debug_kernel_times(orbfe_extractor* h, float* out_us, int ca
         if (capacity == 2) h->force_general_quadtree = true;
         else if (capacity == 3) h->force_general_quadtree = false;
         else if (capacity >= 10 && capacity <= 16) h->force_pyramid_depth = capacity - 10; // 10 = default depth
+        else if (capacity >= 20 && capacity <= 22) h->blur_place = capacity - 20;
         else h->timer.enabled = capacity != 0;
         return 0;
     }

@@ -1371,75 +1371,68 @@ __global__ __launch_bounds__(256) void k_orient_describe(ImgView src0, ImgView p
                                                          const uint8_t* __restrict__ flat_lvl,
                                                          const int32_t* __restrict__ n_out, int nlevels,
                                                          const uint32_t* __restrict__ pattern32 /*256 x (x0,y0,x1,y1) i8*/,
-                                                         const int* __restrict__ umax, orbfe_keypoint* __restrict__ kps,
+                                                         const uint4* __restrict__ icw /*31 rows x 4 uint4: IC_Angle weights*/,
+                                                         orbfe_keypoint* __restrict__ kps,
                                                          uint8_t* __restrict__ desc, int capacity, int nx, int total)
 {
+    // The kernel is bound by VALU issue, so everything that is the same for the whole wave sits in scalar registers (the
+    // keypoint, its level, every base address), the IC_Angle row weights come precomputed from the host and index arithmetic is incremental.  (The pattern as a float4
+    // table saves 32 conversions per lane but quadruples the table traffic of every wave: slower.)  (Letting four lanes of one wave do fastAtan2 + sin / cos for the four
+    // keypoints of the workgroup removes another 25 % of the instructions but costs two workgroup barriers around a serial
+    // f64 chain: measured 290 instead of 265 us.)
     const int lane = threadIdx.x & 63, wid = wave_id();
     int bx, f;
     if (!xcd_remap(nx, total, bx, f)) return;
-    // IC_Angle weights of the 31 rows of the r = 15 circular patch: [row][0..7] = byte index i = u + 15 of the bytes inside
-    // |u| <= umax(|v|), [row][8..15] = 1 for the same bytes (umax: ORBextractor.cc:454-469, a constant table for r = 15)
-    __shared__ __align__(16) uint32_t s_icw[31][16];
-    if (threadIdx.x < 248) {
-        constexpr int UM[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
-        const int row = threadIdx.x >> 3, j = threadIdx.x & 7, av = row < 15 ? 15 - row : row - 15;
-        int um = 0;
-#pragma unroll
-        for (int q = 0; q < 16; q++) um = av == q ? UM[q] : um;
-        uint32_t wi = 0, on = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int i = 4 * j + k, u = i - 15;
-            if (i <= 30 && u >= -um && u <= um) { wi |= (uint32_t)i << (8 * k); on |= 1u << (8 * k); }
-        }
-        s_icw[row][j] = wi;
-        s_icw[row][8 + j] = on;
-    }
-    __syncthreads();
+    __shared__ __align__(16) uint8_t s_pat[4][31 * 36 + 12];
+    __shared__ __align__(16) uint8_t s_win[4][37 * 40 + 8];
     const int oidx = bx * 4 + wid; // flat index over the frame's keypoints (levels concatenated ascending)
     if (oidx >= n_out[f]) return;
-    const uint32_t kv = flat_kv[(size_t)f * capacity + oidx];
+    const uint32_t kv = (uint32_t)__builtin_amdgcn_readfirstlane((int)flat_kv[(size_t)f * capacity + oidx]);
     const int level = __builtin_amdgcn_readfirstlane((int)flat_lvl[(size_t)f * capacity + oidx]);
     const LevelGeom g = geom[level];
     const int kx = (int)(kv & 0xfff) + 16, ky = (int)((kv >> 12) & 0xfff) + 16; // += minBorder (:843-844)
     const int score = kv >> 24;
-
-    const uint8_t* img = (level == 0) ? src0.base + (size_t)f * src0.fstride
-                                      : pyr.base + (size_t)f * pyr.fstride + g.img_off;
-    const int pitch = (level == 0) ? src0.pitch : g.pitch;
-
-    // ---- IC_Angle.  The 31 x 31 patch is staged in LDS with coalesced dword loads (rows of 36 bytes starting at the
-    // 4-byte-aligned column at or below kx - 15); then lanes 0..30 <-> u = -15..15 of an even row, lanes 32..62 of
-    // the following row.
-    __shared__ __align__(16) uint8_t s_pat[4][31 * 36 + 12];
-    // The 37 x 37 blurred window of the descriptor (pattern reach <= 18 px; rows of 40 bytes from the 4-byte-aligned
-    // column at or below kx - 18) and the lane's four pattern words do not depend on the angle: their loads are issued
-    // here, together with the patch loads, so that a keypoint costs ONE global round trip instead of two.
-    __shared__ __align__(16) uint8_t s_win[4][37 * 40 + 8];
-    const uint8_t* bimg = blur.base + (size_t)f * blur.fstride + g.blur_off;
     const int ax = (kx - 18) & ~3, xoff = (kx - 18) - ax;
     uint32_t wv[6], pat[4];
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-        const int idx = min(k * 64 + lane, 369);
-        const int r = idx / 10, c = idx - r * 10;
-        wv[k] = *reinterpret_cast<const uint32_t*>(bimg + (size_t)(ky - 18 + r) * g.bpitch + ax + 4 * c);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) pat[j] = pattern32[j * 64 + lane];
     int m10 = 0, m01 = 0;
     {
+        const uint8_t* img = (level == 0) ? src0.base + (size_t)f * src0.fstride
+                                          : pyr.base + (size_t)f * pyr.fstride + g.img_off;
+        const int pitch = (level == 0) ? src0.pitch : g.pitch;
+        // ---- all global loads of the keypoint up front (one round trip): the 37 x 37 blurred window of the descriptor (rows of
+        // 40 bytes from the 4-byte-aligned column at or below kx - 18), the lane's four pattern tests, the 31 x 31 patch of
+        // IC_Angle (rows of 36 bytes from the aligned column at or below kx - 15).  (row, dword) of a lane's item advance by a
+        // constant step per item (64 = 6 * 10 + 4 = 7 * 9 + 1), so there is one division per lane, not one per item.
+        const uint8_t* bimg = blur.base + (size_t)f * blur.fstride + g.blur_off + (size_t)(ky - 18) * g.bpitch + ax;
+        {
+            int r = lane / 10, c = lane - r * 10;
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                const bool in = k * 64 + lane < 370;
+                wv[k] = *reinterpret_cast<const uint32_t*>(bimg + (size_t)(in ? r : 36) * g.bpitch + 4 * (in ? c : 9));
+                r += 6; c += 4;
+                if (c >= 10) { c -= 10; r++; }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) pat[j] = pattern32[j * 64 + lane];
+        // the row weights of IC_Angle (lane = patch row) come with the same round trip
+        const int wrow = min(lane, 30);
+        const uint4 wa = icw[wrow * 4 + 0], wb = icw[wrow * 4 + 1], oa = icw[wrow * 4 + 2], ob = icw[wrow * 4 + 3];
         const int axp = (kx - 15) & ~3, xo = (kx - 15) - axp;
         const uint8_t* pimg = img + (size_t)(ky - 15) * pitch + axp;
         uint32_t v[5];
+        {
+            int r = lane / 9, c = lane - r * 9;
 #pragma unroll
-        for (int k = 0; k < 5; k++) {
-            const int idx = min(k * 64 + lane, 278);
-            const int r = idx / 9, c = idx - r * 9;
-            const uint8_t* p = pimg + (size_t)r * pitch + 4 * c;
-            // level 0 is the caller's buffer: no alignment is assumed there (gfx950 global loads may be unaligned)
-            typedef uint32_t u32_unaligned __attribute__((aligned(1)));
-            v[k] = *reinterpret_cast<const u32_unaligned*>(p);
+            for (int k = 0; k < 5; k++) {
+                const bool in = k * 64 + lane < 279;
+                // level 0 is the caller's buffer: no alignment is assumed there (gfx950 global loads may be unaligned)
+                typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+                v[k] = *reinterpret_cast<const u32_unaligned*>(pimg + (size_t)(in ? r : 30) * pitch + 4 * (in ? c : 8));
+                r += 7; c += 1;
+                if (c >= 9) { c -= 9; r++; }
+            }
         }
 #pragma unroll
         for (int k = 0; k < 5; k++) {
@@ -1447,19 +1440,17 @@ __global__ __launch_bounds__(256) void k_orient_describe(ImgView src0, ImgView p
             if (idx < 279) reinterpret_cast<uint32_t*>(s_pat[wid])[idx] = v[k];
         }
         __builtin_amdgcn_wave_barrier();
-        // lane = patch row v = lane - 15 (lanes 0..30): the row's 31 bytes as eight dwords re-cut at the byte offset xo,
-        // m10 = sum (i - 15) I = dot(I, i) - 15 dot(I, 1) and m01 = v dot(I, 1) over the row's part of the circular patch,
-        // with the two weight vectors (byte index i, ones; zero outside |u| <= umax(|v|)) from a per-workgroup LDS table
+        // ---- IC_Angle: lane = patch row v = lane - 15 (lanes 0..30): the row's 31 bytes as eight dwords re-cut at the byte offset
+        // xo, m10 = sum (i - 15) I = dot(I, i) - 15 dot(I, 1) and m01 = v dot(I, 1) over the row's part of the circular patch
+        // (umax, ORBextractor.cc:454-469), with the two weight vectors of the row (byte index i, ones; zero outside |u| <= umax(|v|))
         if (lane < 31) {
             const uint32_t* rw = reinterpret_cast<const uint32_t*>(s_pat[wid] + lane * 36);
-            const uint4 wa = *reinterpret_cast<const uint4*>(&s_icw[lane][0]), wb = *reinterpret_cast<const uint4*>(&s_icw[lane][4]);
-            const uint4 oa = *reinterpret_cast<const uint4*>(&s_icw[lane][8]), ob = *reinterpret_cast<const uint4*>(&s_icw[lane][12]);
             uint32_t d[9];
 #pragma unroll
-            for (int j = 0; j < 9; j++) d[j] = rw[j];
+            for (int q = 0; q < 9; q++) d[q] = rw[q];
             uint32_t e[8];
 #pragma unroll
-            for (int j = 0; j < 8; j++) e[j] = __builtin_amdgcn_alignbyte(d[j + 1], d[j], xo);
+            for (int q = 0; q < 8; q++) e[q] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], xo);
             uint32_t A = 0, B = 0;
             A = bl_dot4(e[0], wa.x, A); A = bl_dot4(e[1], wa.y, A); A = bl_dot4(e[2], wa.z, A); A = bl_dot4(e[3], wa.w, A);
             A = bl_dot4(e[4], wb.x, A); A = bl_dot4(e[5], wb.y, A); A = bl_dot4(e[6], wb.z, A); A = bl_dot4(e[7], wb.w, A);
@@ -1470,25 +1461,19 @@ __global__ __launch_bounds__(256) void k_orient_describe(ImgView src0, ImgView p
         }
         m10 = wave_sum(m10);
         m01 = wave_sum(m01);
-    }
-    const float angle = orbfe_fast_atan2((float)m01, (float)m10);
-
-    // ---- steered BRIEF
-    const float factorPI = (float)(3.14159265358979323846 / 180.f);
-    const float arad = angle * factorPI;
-    float a, b;
-    orbfe_sincosf(arad, &b, &a); // a = cos, b = sin
-    // Stage the 37 x 37 blurred window (pattern reach <= 18 px) in LDS with coalesced dword loads: 6 wave loads touch
-    // ~60 cache lines, where 8 direct byte gathers would touch ~300.  Rows are 40 bytes: the window starts at the
-    // 4-byte-aligned column at or below kx - 18.
-    {
 #pragma unroll
         for (int k = 0; k < 6; k++) {
             const int idx = k * 64 + lane;
             if (idx < 370) reinterpret_cast<uint32_t*>(s_win[wid])[idx] = wv[k];
         }
     }
+    const float angle = orbfe_fast_atan2((float)m01, (float)m10);
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    float a, b;
+    orbfe_sincosf(angle * factorPI, &b, &a); // a = cos, b = sin
     __builtin_amdgcn_wave_barrier();
+
+    // ---- steered BRIEF on the staged window
     const uint8_t* bc = s_win[wid] + 18 * 40 + 18 + xoff;
     unsigned long long words[4];
 #pragma unroll
@@ -1504,8 +1489,8 @@ __global__ __launch_bounds__(256) void k_orient_describe(ImgView src0, ImgView p
         words[j] = __ballot(t0 < t1);
     }
     if (lane < 4) {
-        unsigned long long wv = lane == 0 ? words[0] : lane == 1 ? words[1] : lane == 2 ? words[2] : words[3];
-        reinterpret_cast<unsigned long long*>(desc + ((size_t)f * capacity + oidx) * 32)[lane] = wv;
+        unsigned long long wd = lane == 0 ? words[0] : lane == 1 ? words[1] : lane == 2 ? words[2] : words[3];
+        reinterpret_cast<unsigned long long*>(desc + ((size_t)f * capacity + oidx) * 32)[lane] = wd;
     }
     if (lane == 0) {
         orbfe_keypoint kp;

@@ -92,7 +92,7 @@ template <bool ED> __global__ void k_blur7(ImgView src0, ImgView pyr, ImgView bl
                         int total);
 __global__ void k_orient_describe(ImgView src0, ImgView pyr, ImgView blur, const LevelGeom* geom,
                                   const uint32_t* flat_kv, const uint8_t* flat_lvl, const int32_t* n_out, int nlevels,
-                                  const uint32_t* pattern32, const int* umax, orbfe_keypoint* kps, uint8_t* desc,
+                                  const uint32_t* pattern32, const uint4* icw, orbfe_keypoint* kps, uint8_t* desc,
                                   int capacity, int nx, int total);
 __global__ void k_unpack_keys(const uint32_t* in, int n, int add, orbfe_keypoint* out);
 

@@ -72,7 +72,7 @@ class FrontEndPipeline:
     gather and in synchronize()."""
 
     def __init__(self, frames, rows, cols, nfeatures=1000, nlevels=8, dictionary="ARUCO", device=0, marker_capacity=64,
-                 use_orb=True, use_aruco=True, splits=1, gather=None, lend_aux_stream=True):
+                 use_orb=True, use_aruco=True, splits=1, gather=None, lend_aux_stream=True, engine_sets=1):
         import torch
         self.torch = torch
         self.L = binding.load()
@@ -84,10 +84,23 @@ class FrontEndPipeline:
         B = frames
         S = self.S = max(1, min(splits, B // 2))
         self.bounds = [B * k // S for k in range(S + 1)]          # sub-batch k = frames bounds[k] .. bounds[k+1]
-        self.exs = [binding.ORBextractor(nfeatures, 1.2, nlevels, 20, 7, device=device) for _ in range(S)]
+        import os
+        # Engine sets (experiment, ORBFE_ENGINE_SETS): consecutive batches alternate between D sets of handles and streams (a set
+        # owns its pyramid, candidate and contour workspaces), so that batch i + 1's resize / FAST run next to batch i's quadtree /
+        # descriptors instead of queueing behind them.  Measured on the C2 batch: 1.89 ms with one set, 2.02 (4 hardware queues)
+        # and 2.14 ms (8) with two -- the detector alone gains (1.02 -> 0.79 ms), the whole pipeline loses: D = 1 is the default.
+        D = self.D = max(1, int(os.environ.get("ORBFE_ENGINE_SETS", engine_sets)))
+        self.ex_sets = [[binding.ORBextractor(nfeatures, 1.2, nlevels, 20, 7, device=device) for _ in range(S)] for _ in range(D)]
+        self.exs = [e for es in self.ex_sets for e in es]
         self.ex = self.exs[0]
+        if os.environ.get("ORBFE_BLUR_PLACE"):            # A/B of the blur's fork point: 0 after FAST, 1 before FAST, 2 no fork
+            for e in self.exs:
+                e.L.orbfe_extractor_debug_kernel_times(e.h, None, 20 + int(os.environ["ORBFE_BLUR_PLACE"]))
+        if os.environ.get("ORBFE_NO_LEND"):
+            lend_aux_stream = False
         self.cap = cap = self.ex.capacity
-        self.dets = [binding.MarkerDetector(dictionary, device=device) for _ in range(S)] if use_aruco else []
+        self.det_sets = [[binding.MarkerDetector(dictionary, device=device) for _ in range(S)] for _ in range(D)] if use_aruco else []
+        self.dets = [d for ds in self.det_sets for d in ds]
         self.det = self.dets[0] if use_aruco else None
         # marker records per frame in the result set (the detector clamps a frame's count to it; its own limit is 256 candidates)
         self.mcap = mcap = min(self.det.capacity, marker_capacity) if use_aruco else 0
@@ -111,9 +124,13 @@ class FrontEndPipeline:
         self.stream2 = torch.cuda.Stream(dev)
         self.stream3 = torch.cuda.Stream(dev)
         self.sp3 = ctypes.c_void_p(self.stream3.cuda_stream)
-        self.orb_streams = [self.stream] + [torch.cuda.Stream(dev) for _ in range(S - 1)]
-        self.aru_streams = [self.stream2] + [torch.cuda.Stream(dev) for _ in range(S - 1)]
-        if S == 1 and lend_aux_stream:
+        self.orb_stream_sets = [[self.stream] + [torch.cuda.Stream(dev) for _ in range(S - 1)]] + \
+                               [[torch.cuda.Stream(dev) for _ in range(S)] for _ in range(D - 1)]
+        self.aru_stream_sets = [[self.stream2] + [torch.cuda.Stream(dev) for _ in range(S - 1)]] + \
+                               [[torch.cuda.Stream(dev) for _ in range(S)] for _ in range(D - 1)]
+        self.orb_streams, self.aru_streams = self.orb_stream_sets[0], self.aru_stream_sets[0]
+        self.last_set = 0
+        if S == 1 and D == 1 and lend_aux_stream:
             # ROCm maps streams onto 4 hardware queues, and two busy streams on one queue serialise.  The extractor's forked
             # launch (the blur) is lent the matching stream; measured against the handle's own fork stream and against one
             # shared fork stream for both engines: 2.02 vs 2.12 vs 2.14 ms per step.
@@ -145,6 +162,9 @@ class FrontEndPipeline:
         i = self.step_no
         self.step_no += 1
         cur = i % 2
+        eset = self.last_set = i % self.D
+        exs, dets = self.ex_sets[eset], (self.det_sets[eset] if self.use_aruco else [])
+        orb_streams, aru_streams = self.orb_stream_sets[eset], self.aru_stream_sets[eset]
         base = self.rec_ptr[cur]
         img0 = d_imgs.data_ptr()
         multi = self.gather is not None
@@ -153,11 +173,11 @@ class FrontEndPipeline:
             # not joined with the ORB streams per step: consecutive batches of the two engines pipeline freely.
             for k in range(S):
                 f0, nf = self.bounds[k], self.bounds[k + 1] - self.bounds[k]
-                st = self.aru_streams[k]
+                st = aru_streams[k]
                 if multi and i >= 2:
                     st.wait_event(self.gather_done[cur])         # batch i-2 has left this record set
                 sp = ctypes.c_void_p(st.cuda_stream)
-                self.dets[k].detect_batch_device(img0 + f0 * rows * pitch, nf, rows * pitch, rows, cols, pitch,
+                dets[k].detect_batch_device(img0 + f0 * rows * pitch, nf, rows * pitch, rows, cols, pitch,
                                                  base + lay.mk + f0 * mcap * 36, mcap, base + lay.nmk + f0 * 4, sp)
                 # detect(image, CameraParameters, 0.187): every marker gets its IPPE pose (markerdetector_impl.cpp:8720-8780)
                 binding._check(L, L.orbfe_marker_poses_batch_device(
@@ -168,12 +188,12 @@ class FrontEndPipeline:
         if self.use_orb:
             for k in range(S):
                 f0, nf = self.bounds[k], self.bounds[k + 1] - self.bounds[k]
-                st = self.orb_streams[k]
+                st = orb_streams[k]
                 if i >= 2:
                     st.wait_event(self.match_done[cur])          # the matching of batch i-2 has read this record set
                     if multi:
                         st.wait_event(self.gather_done[cur])
-                self.exs[k].extract_batch_device(img0 + f0 * rows * pitch, nf, rows * pitch, rows, cols, pitch,
+                exs[k].extract_batch_device(img0 + f0 * rows * pitch, nf, rows * pitch, rows, cols, pitch,
                                                  base + lay.kps + f0 * cap * 28, base + lay.desc + f0 * cap * 32, cap,
                                                  base + lay.n + f0 * 4, ctypes.c_void_p(st.cuda_stream))
                 self.ex_done[cur][k].record(st)
@@ -209,6 +229,10 @@ class FrontEndPipeline:
             self.d_m12.data_ptr(), self.d_nm.data_ptr(), self.sp3), "orbfe_search_for_initialization_batch_device")
         e[2].record(self.stream3)
         self.match_done[cur].record(self.stream3)
+
+    def last_engines(self):
+        """(extractor, detector) handles that ran the most recent step (their launch timers describe that step)."""
+        return self.ex_sets[self.last_set][0], (self.det_sets[self.last_set][0] if self.use_aruco else None)
 
     def synchronize(self):
         self.torch.cuda.synchronize(self.dev)
