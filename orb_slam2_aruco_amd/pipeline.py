@@ -90,6 +90,7 @@ class FrontEndPipeline:
         # descriptors instead of queueing behind them.  Measured on the C2 batch: 1.89 ms with one set, 2.02 (4 hardware queues)
         # and 2.14 ms (8) with two -- the detector alone gains (1.02 -> 0.79 ms), the whole pipeline loses: D = 1 is the default.
         D = self.D = max(1, int(os.environ.get("ORBFE_ENGINE_SETS", engine_sets)))
+        DA = self.DA = max(1, int(os.environ.get("ORBFE_ENGINE_SETS_ARUCO", D)))
         self.ex_sets = [[binding.ORBextractor(nfeatures, 1.2, nlevels, 20, 7, device=device) for _ in range(S)] for _ in range(D)]
         self.exs = [e for es in self.ex_sets for e in es]
         self.ex = self.exs[0]
@@ -99,7 +100,7 @@ class FrontEndPipeline:
         if os.environ.get("ORBFE_NO_LEND"):
             lend_aux_stream = False
         self.cap = cap = self.ex.capacity
-        self.det_sets = [[binding.MarkerDetector(dictionary, device=device) for _ in range(S)] for _ in range(D)] if use_aruco else []
+        self.det_sets = [[binding.MarkerDetector(dictionary, device=device) for _ in range(S)] for _ in range(DA)] if use_aruco else []
         self.dets = [d for ds in self.det_sets for d in ds]
         self.det = self.dets[0] if use_aruco else None
         # marker records per frame in the result set (the detector clamps a frame's count to it; its own limit is 256 candidates)
@@ -127,9 +128,9 @@ class FrontEndPipeline:
         self.orb_stream_sets = [[self.stream] + [torch.cuda.Stream(dev) for _ in range(S - 1)]] + \
                                [[torch.cuda.Stream(dev) for _ in range(S)] for _ in range(D - 1)]
         self.aru_stream_sets = [[self.stream2] + [torch.cuda.Stream(dev) for _ in range(S - 1)]] + \
-                               [[torch.cuda.Stream(dev) for _ in range(S)] for _ in range(D - 1)]
+                               [[torch.cuda.Stream(dev) for _ in range(S)] for _ in range(DA - 1)]
         self.orb_streams, self.aru_streams = self.orb_stream_sets[0], self.aru_stream_sets[0]
-        self.last_set = 0
+        self.last_set = self.last_aset = 0
         if S == 1 and D == 1 and lend_aux_stream:
             # ROCm maps streams onto 4 hardware queues, and two busy streams on one queue serialise.  The extractor's forked
             # launch (the blur) is lent the matching stream; measured against the handle's own fork stream and against one
@@ -163,8 +164,9 @@ class FrontEndPipeline:
         self.step_no += 1
         cur = i % 2
         eset = self.last_set = i % self.D
-        exs, dets = self.ex_sets[eset], (self.det_sets[eset] if self.use_aruco else [])
-        orb_streams, aru_streams = self.orb_stream_sets[eset], self.aru_stream_sets[eset]
+        aset = self.last_aset = i % self.DA
+        exs, dets = self.ex_sets[eset], (self.det_sets[aset] if self.use_aruco else [])
+        orb_streams, aru_streams = self.orb_stream_sets[eset], self.aru_stream_sets[aset]
         base = self.rec_ptr[cur]
         img0 = d_imgs.data_ptr()
         multi = self.gather is not None
@@ -232,7 +234,7 @@ class FrontEndPipeline:
 
     def last_engines(self):
         """(extractor, detector) handles that ran the most recent step (their launch timers describe that step)."""
-        return self.ex_sets[self.last_set][0], (self.det_sets[self.last_set][0] if self.use_aruco else None)
+        return self.ex_sets[self.last_set][0], (self.det_sets[self.last_aset][0] if self.use_aruco else None)
 
     def synchronize(self):
         self.torch.cuda.synchronize(self.dev)

@@ -31,16 +31,22 @@ def kb(k):
     return (s[k].get("FETCH_SIZE", 0.0) / factor("read", "FETCH_SIZE", wr) + s[k].get("WRITE_SIZE", 0.0) / factor("write", "WRITE_SIZE", ww)) * 1024.0
 
 
-steps = min(v["dispatches"] for k, v in s.items() if k in ("k_fast_cells", "k_blur7")) if "k_fast_cells" in s else \
-    min(v["dispatches"] for k, v in s.items() if k.startswith("k_adaptive_threshold"))
+def named(*bases):
+    """kernels of the summary called `base` or an instantiation `base<...>` of it"""
+    return [k for k in s if any(k == b or k.startswith(b + "<") for b in bases)]
+
+
+steps = min(s[k]["dispatches"] for k in named("k_fast_cells", "k_blur7")) if "k_fast_cells" in s else \
+    min(s[k]["dispatches"] for k in named("k_adaptive_threshold_t", "k_adaptive_threshold"))
 per_step = lambda k: s[k]["dispatches"] / steps if k in s else 0
 stage = {
-    "resize": ["k_resize_tab", "k_resize_level"], "fast_cells": ["k_fast_cells"],
-    "distribute": ["k_distribute_pyr", "k_distribute", "k_level_offsets"], "blur7": ["k_blur7"],
-    "orient_describe": ["k_orient_describe"], "knn2": ["k_knn2_mfma", "k_knn2_tiles", "k_knn2_merge"], "search_init": ["k_search_init"],
-    "aruco_threshold": [k for k in s if k.startswith("k_adaptive_threshold")], "aruco_pyramid": ["k_half_area"],
+    "resize": named("k_resize_tab", "k_resize_level"), "fast_cells": named("k_fast_cells"),
+    "distribute": named("k_distribute_pyr", "k_distribute", "k_level_offsets"), "blur7": named("k_blur7"),
+    "orient_describe": named("k_orient_describe"), "knn2": named("k_knn2_mfma", "k_knn2_tiles", "k_knn2_merge"),
+    "search_init": named("k_search_init"),
+    "aruco_threshold": named("k_adaptive_threshold_t", "k_adaptive_threshold"), "aruco_pyramid": named("k_half_area"),
     "aruco_contours": [k for k in s if k.startswith("k_contours")],
-    "aruco_decode": ["k_prefilter", "k_decode"], "aruco_finalize": ["k_finalize", "k_marker_poses"],
+    "aruco_decode": named("k_prefilter", "k_decode"), "aruco_finalize": named("k_finalize", "k_marker_poses"),
 }
 traffic = {"_note": "HBM-side bytes per launch (%s batch) = (FETCH_SIZE / f_read + WRITE_SIZE / f_write) * 1024 from separate rocprofv3 --pmc "
                     "passes (tools/pmc.py; --kernel-trace only), per-dispatch mean x launches per step (profiles/%s_pmc_summary.json), summed "

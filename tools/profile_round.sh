@@ -18,6 +18,15 @@ python tools/pmc.py > $O/${TAG}_pmc_table.txt 2>&1
 cp gpurun_out/pmc_summary.json $O/${TAG}_pmc_summary.json
 cp gpurun_out/pmc_calibration.json $O/${TAG}_pmc_calibration.json
 python tools/make_profiles.py $O/${TAG}_pmc_summary.json $O/${TAG}_pmc_calibration.json C2 $TAG > $O/make_profiles_c2.log 2>&1
-cp profiles/traffic_C2.json profiles/pmc_stage_C2.json $O/
+python tools/pmc.py --config C3 > $O/${TAG}_pmc_table_c3.txt 2>&1
+cp gpurun_out/pmc_summary.json $O/${TAG}_pmc_summary_c3.json
+python tools/make_profiles.py $O/${TAG}_pmc_summary_c3.json $O/${TAG}_pmc_calibration.json C3 ${TAG}_c3 > $O/make_profiles_c3.log 2>&1
+cp profiles/traffic_C2.json profiles/pmc_stage_C2.json profiles/traffic_C3.json profiles/pmc_stage_C3.json $O/
+# second pass of the bench lines: now with the freshly written per-configuration traffic / PMC profiles in the roofline record
+python bench.py --out $O/${TAG}_bench.json > $O/bench_c2.log 2>&1
+python bench.py --config C3 --out $O/${TAG}_bench_c3.json > $O/bench_c3.log 2>&1
+PORT=$((20000 + RANDOM % 20000))
+ORBFE_BENCH_DEVICE=0 ORBFE_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port $PORT \
+    bench.py --gpus 2 --steps 6 --warmup 2 --cpu-frames 0 --out $O/${TAG}_bench_2ranks_gloo_one_gpu.json > $O/bench_2ranks.log 2>&1
 rm -rf $O/prof gpurun_out/pmc
 tail -c 400 $O/bench_c2.log
