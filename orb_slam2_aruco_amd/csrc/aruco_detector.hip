@@ -30,8 +30,11 @@ struct orbfe_aruco {
     std::vector<size_t> tab_off;          // resize tables for non-exact levels
     size_t pyr_fbytes = 0, bits_fu32 = 0, candq_fu32 = 0, pool_fu32 = 0, gpad_fu32 = 0;
     int lds_bits_words = 0;
+    DevBuf d_rstate, d_lut; // k_contours_relay -> k_contours_small: per-frame grid shift and pool fill; the walks' step table
     DevBuf d_segs, d_tailkeys, d_tailoff, d_small, d_hint; // d_hint: the relay kernel's grid spacing of the previous batch
     int relay_kshift = 5;      // initial grid spacing (log2) of k_contours_relay
+    int relay_kcap = RL_KCAP;  // kept borders per frame the relay kernels and their tail hold
+    bool relay_global = false; // k_contours_relay8g: the bit image stays in HBM (it does not fit LDS)
     int relay_tbits = 0;       // hash-table size of k_contours_relay (0: the kernel cannot run at this image size)
     bool force_legacy = false; // debug: always use k_contours_t
     bool big_mode = false;     // frames with more kept borders than the LDS-resident kernels hold: bit image in HBM, AR_MAX_KEPT_BIG
@@ -49,7 +52,7 @@ struct orbfe_aruco {
     ~orbfe_aruco()
     {
         for (DevBuf* b : {&d_codes, &d_levels, &d_tabs, &d_bits, &d_pyr, &d_candq, &d_pool, &d_kept, &d_rects,
-                          &d_counts, &d_candidx, &d_ncand, &d_result, &d_gpad, &d_in, &d_out, &d_nout, &d_segs, &d_tailkeys, &d_tailoff, &d_small, &d_hint, &d_scodes, &d_sids,
+                          &d_counts, &d_candidx, &d_ncand, &d_result, &d_gpad, &d_in, &d_out, &d_nout, &d_segs, &d_tailkeys, &d_tailoff, &d_small, &d_hint, &d_rstate, &d_lut, &d_scodes, &d_sids,
                           &d_msrc})
             b->release();
         if (own_stream) (void)hipStreamDestroy(own_stream);
@@ -187,6 +190,11 @@ struct orbfe_aruco {
         const bool large = (size_t)rows_ * cols_ > (size_t)640 * 480 * 3 / 2;
         if (lds_bits_words && large && relay_lds_bytes(lds_bits_words, RL_KCAP, 13) + rl_static <= 160 * 1024) { relay_tbits = 13; relay_kshift = 5; }
         else if (lds_bits_words && relay_lds_bytes(lds_bits_words, RL_KCAP, 12) + rl_static <= 160 * 1024) { relay_tbits = 12; relay_kshift = 5; }
+        // frames whose bit image does not fit LDS: the relay formulation with the bit image in HBM (k_contours_relay8g)
+        // (and room for as many kept borders as the single-walker kernel's big-frame mode: busy 1920 x 1080 frames have > 1024)
+        relay_global = !lds_bits_words && relay_lds_bytes(0, AR_MAX_KEPT_BIG, 13) + rl_static <= 160 * 1024;
+        relay_kcap = RL_KCAP;
+        if (relay_global) { relay_tbits = 13; relay_kshift = 5; relay_kcap = AR_MAX_KEPT_BIG; }
         rows = rows_; cols = cols_;
         batch_cap = 0;
         if (tabs.empty()) tabs.push_back(0);
@@ -210,12 +218,17 @@ struct orbfe_aruco {
             (rc = d_result.ensure((size_t)AR_MAX_RECTS * 8 * B)) || (rc = d_msrc.ensure((size_t)AR_MAX_RECTS * 4 * B)) ||
             (rc = d_gpad.ensure(std::max<size_t>(gpad_fu32 * 4 * B, 16))) ||
             (rc = d_segs.ensure(std::max<size_t>(((size_t)sizeof(RelaySeg) << relay_tbits) * B, 16))) ||
-            (rc = d_tailkeys.ensure((size_t)RL_KCAP * 8 * B)) || (rc = d_tailoff.ensure((size_t)RL_KCAP * 4 * B)) ||
-            (rc = d_small.ensure((size_t)RL_KCAP * 16 * B)))
+            (rc = d_tailkeys.ensure((size_t)relay_kcap * 8 * B)) || (rc = d_tailoff.ensure((size_t)relay_kcap * 4 * B)) ||
+            (rc = d_small.ensure((size_t)relay_kcap * 16 * B)) || (rc = d_rstate.ensure((size_t)8 * B)))
             return rc;
         if (!d_hint.p) {
             if ((rc = d_hint.ensure(16))) return rc;
             ORBFE_HIP(hipMemset(d_hint.p, 0, 16));
+        }
+        if (!d_lut.p) {
+            if ((rc = d_lut.ensure(2048 * 2))) return rc;
+            hipLaunchKernelGGL(k_relay_lut, dim3(8), dim3(256), 0, 0, d_lut.as<uint16_t>());
+            ORBFE_HIP(hipDeviceSynchronize());
         }
         batch_cap = B;
         return ORBFE_OK;
@@ -273,19 +286,47 @@ struct orbfe_aruco {
         { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(kfn), (size_t)(lds)); if (rc_lds_) return rc_lds_; }
         const bool relay = relay_tbits && !force_legacy && !big_mode;
         if (relay && !ORBFE_SKIP_ARUCO(1)) {
-            const size_t rlds = relay_lds_bytes(lds_bits_words, RL_KCAP, relay_tbits);
+            const size_t rlds = relay_lds_bytes(lds_bits_words, relay_kcap, relay_tbits);
+            if (relay_global) {
+                { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(k_contours_relay8g), (size_t)(rlds)); if (rc_lds_) return rc_lds_; }
+                hipLaunchKernelGGL(k_contours_relay8g, dim3(B), dim3(RL_THREADS_BIG), rlds, s, d_bits.as<uint32_t>(), bits_fu32, wpr,
+                                   cols, rows, 0, 70, relay_kshift, relay_tbits, d_segs.as<RelaySeg>(),
+                                   d_pool.as<uint32_t>(), pool_fu32, (int)pool_fu32, d_kept.as<ArKept>(), relay_kcap, relay_kcap,
+                                   d_tailkeys.as<unsigned long long>(), d_tailoff.as<int32_t>(), d_counts.as<int32_t>(), d_hint.as<int32_t>(),
+                                   d_small.as<uint4>(), d_rstate.as<int32_t>(), d_gpad.as<uint32_t>(), gpad_fu32);
+            } else {
             auto rfn = relay_tbits > 12 ? k_contours_relay8 : k_contours_relay;
             { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(rfn), (size_t)(rlds)); if (rc_lds_) return rc_lds_; }
             hipLaunchKernelGGL(rfn, dim3(B), dim3(relay_tbits > 12 ? RL_THREADS_BIG : RL_THREADS), rlds, s, d_bits.as<uint32_t>(), bits_fu32, wpr,
                                cols, rows, lds_bits_words, 70, relay_kshift, relay_tbits, d_segs.as<RelaySeg>(),
-                               d_pool.as<uint32_t>(), pool_fu32, (int)pool_fu32, d_kept.as<ArKept>(), AR_MAX_KEPT, RL_KCAP,
+                               d_pool.as<uint32_t>(), pool_fu32, (int)pool_fu32, d_kept.as<ArKept>(), relay_kcap, relay_kcap,
                                d_tailkeys.as<unsigned long long>(), d_tailoff.as<int32_t>(), d_counts.as<int32_t>(), d_hint.as<int32_t>(),
-                               d_small.as<uint4>());
-            const size_t tlds = tail_lds_bytes(RL_KCAP, 1280);
-            { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(k_contours_tail), (size_t)(tlds)); if (rc_lds_) return rc_lds_; }
-            hipLaunchKernelGGL(k_contours_tail, dim3(B), dim3(RT_THREADS), tlds, s, d_tailkeys.as<unsigned long long>(),
-                               d_tailoff.as<int32_t>(), RL_KCAP, d_pool.as<uint32_t>(), pool_fu32, d_kept.as<ArKept>(),
-                               AR_MAX_KEPT, d_rects.as<ArRect>(), AR_MAX_RECTS, d_counts.as<int32_t>(), (int)tlds);
+                               d_small.as<uint4>(), d_rstate.as<int32_t>());
+            }
+            // the borders that touch no grid line, for frames done with a grid by a relay kernel that leaves them out (the
+            // HBM-resident one: its bands fit LDS here; for LDS-resident frames the separate launch halves the relay kernel's time
+            // but issues twice the instructions of the in-kernel phase -- measured 1.85 -> 1.98 ms per C2 step -- so those keep
+            // phase (c) inside): bands of K rows, K >= 2^relay_kshift
+            if (relay_global) {
+                const int nwaves = ((cols >> RS_BLOCK_SHIFT) + 1) * ((rows >> relay_kshift) + 1); // blocks of the finest grid
+                hipLaunchKernelGGL(k_contours_small, dim3((nwaves + RS_THREADS / 64 - 1) / (RS_THREADS / 64), B), dim3(RS_THREADS), 0, s,
+                                   d_bits.as<uint32_t>(), bits_fu32, wpr, cols, rows, 70, d_lut.as<uint16_t>(), d_rstate.as<int32_t>(),
+                                   d_pool.as<uint32_t>(), pool_fu32, (int)pool_fu32, relay_kcap, d_tailkeys.as<unsigned long long>(),
+                                   d_tailoff.as<int32_t>(), d_counts.as<int32_t>());
+            }
+            if (relay_global) {
+                const size_t tlds = tail_lds_bytes(relay_kcap, 384, RT_THREADS_BIG);
+                { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(k_contours_tail_t<RT_THREADS_BIG>), (size_t)(tlds)); if (rc_lds_) return rc_lds_; }
+                hipLaunchKernelGGL(k_contours_tail_t<RT_THREADS_BIG>, dim3(B), dim3(RT_THREADS_BIG), tlds, s, d_tailkeys.as<unsigned long long>(),
+                                   d_tailoff.as<int32_t>(), relay_kcap, d_pool.as<uint32_t>(), pool_fu32, d_kept.as<ArKept>(),
+                                   relay_kcap, d_rects.as<ArRect>(), AR_MAX_RECTS, d_counts.as<int32_t>(), (int)tlds);
+            } else {
+                const size_t tlds = tail_lds_bytes(relay_kcap, 1280);
+                { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(k_contours_tail_t<RT_THREADS>), (size_t)(tlds)); if (rc_lds_) return rc_lds_; }
+                hipLaunchKernelGGL(k_contours_tail_t<RT_THREADS>, dim3(B), dim3(RT_THREADS), tlds, s, d_tailkeys.as<unsigned long long>(),
+                                   d_tailoff.as<int32_t>(), relay_kcap, d_pool.as<uint32_t>(), pool_fu32, d_kept.as<ArKept>(),
+                                   relay_kcap, d_rects.as<ArRect>(), AR_MAX_RECTS, d_counts.as<int32_t>(), (int)tlds);
+            }
         }
         // the single-walker kernel: images whose bit image does not fit LDS next to the relay kernel's tables, or forced
         if (!relay && !ORBFE_SKIP_ARUCO(1)) hipLaunchKernelGGL(kfn, dim3(B), dim3(CT_PROBE_THREADS), lds, s, d_bits.as<uint32_t>(), bits_fu32, wpr, cols, rows,

@@ -379,8 +379,8 @@ __device__ void contours_tail(int f, int tid, int NT, int nkept, unsigned long l
         }
     for (int k = tid; k < nkept; k += NT) {
         const unsigned long long key = kkey[k];
-        klen[k] = (int)((key >> 12) & 0xfffff);
-        koff[k] = off_u[(int)((key >> 1) & 0x7ff)];
+        klen[k] = (int)((key >> 13) & 0x7ffff);
+        koff[k] = off_u[(int)((key >> 1) & 0xfff)]; // kept index: AR_MAX_KEPT_BIG = 4096 borders at most
     }
     __syncthreads();
 #ifdef ORBFE_CT_TIMING
@@ -604,7 +604,7 @@ __global__ __launch_bounds__(CT_PROBE_THREADS) void k_contours_t(const uint32_t*
                         else if (k < kept_cap) {
                             // discovery order = raster order of the transition pixel; findContours returns the reverse
                             kkey[k] = ((unsigned long long)(0xffffffffu - (uint32_t)(qy * 65536 + qx)) << 32) |
-                                      ((unsigned long long)(t.n & 0xfffff) << 12) | ((unsigned)k << 1) | (unsigned)t.is_hole;
+                                      ((unsigned long long)(t.n & 0x7ffff) << 13) | ((unsigned)k << 1) | (unsigned)t.is_hole;
                             off_u[k] = tid * arena + wp;
                             wp += t.n;
                         }
@@ -739,12 +739,15 @@ __device__ __forceinline__ void rl_advance(const BitImage& im, RelayWalk& w, uns
 #else
 #define RL_VGPR_ATTR
 #endif
-template <bool force_nogrid, int RL_SLOTS, int RL_NT>
+template <bool force_nogrid, int RL_SLOTS, int RL_NT, bool GBITS = false>
 __device__ __forceinline__ int relay_frame(
     const uint32_t* __restrict__ gbits, size_t bits_fstride, int wpr_g, int W, int H, int lds_bits_words, int min_len,
     int kshift, int tbits, RelaySeg* __restrict__ segs, uint32_t* __restrict__ pool, size_t pool_fstride, int pool_cap,
     ArKept* __restrict__ kept_out, int kept_cap, int kcap /*kept borders this kernel's LDS holds*/,
-    unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off, int32_t* __restrict__ counts, int32_t* __restrict__ hint, uint4* __restrict__ small_g)
+    unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off, int32_t* __restrict__ counts, int32_t* __restrict__ hint, uint4* __restrict__ small_g,
+    int32_t* __restrict__ rstate /* per frame: grid shift the frame was done with, final pool words in use (k_contours_small goes on from there) */,
+    uint32_t* __restrict__ gpad = nullptr /* GBITS: the padded bit image lives here (HBM / L2) instead of LDS */, size_t gpad_fstride = 0,
+    int small_elsewhere = 0 /* phase (c) of gridded frames is k_contours_small's */)
 {
     extern __shared__ __align__(16) unsigned char ct_smem[];
     __shared__ int s_next, s_nkept, s_flags, s_ncand, s_nmark, s_nsmall, s_pool, s_changed[2];
@@ -762,7 +765,7 @@ __device__ __forceinline__ int relay_frame(
     //   lists (e-f):  R = kept keys u64, kept pool offsets, cmin/val, jmp, arg      (the bit image is dead)
     //   tail  (g):    R = kept keys, offsets | klen, koff, rectflag, approx scratch, length ranks, point buffers ...
     //   [hkey: T marker state keys] lives until (f2)
-    uint32_t* lbits = (uint32_t*)ct_smem;
+    uint32_t* lbits = GBITS ? gpad + (size_t)blockIdx.x * gpad_fstride : (uint32_t*)ct_smem;
     unsigned long long* kkey = (unsigned long long*)ct_smem;
     int* off_u = (int*)(kkey + kcap);
     unsigned char* uni = (unsigned char*)(off_u + kcap);
@@ -814,6 +817,7 @@ __device__ __forceinline__ int relay_frame(
     if (tid < 2) lbits[wpr * prow + tid] = 0; // spare words read by ring8()'s funnel loads
     for (int i = tid; i < T; i += NT) hkey[i] = 0u;
     for (int i = tid; i < 2048; i += NT) s_lut[i] = rl_lut_entry((unsigned)i >> 3, i & 7);
+    if (GBITS) __threadfence_block(); // the padded image was written to HBM: visible to the workgroup's other waves
     __syncthreads();
     const BitImage im{lbits, wpr, W, H};
     RL_STAMP();
@@ -894,10 +898,12 @@ __device__ __forceinline__ int relay_frame(
     const int stage0 = pool_cap >> 2, arena = (pool_cap - stage0) / NT;
     uint32_t* my_arena = pl + stage0 + tid * arena;
     int wp = 0;
-    // ---- (c) small borders.  A lane takes one 32-pixel word of start candidates at a time; every loop iteration
-    // advances each busy lane by ONE step.  A walk stops at a grid marker (the border belongs to (d)), at a proof that
+    // ---- (c) small borders.  With a grid they are k_contours_small's (the next launch: one small workgroup per band of K rows,
+    // because such walks never leave their grid cell -- the chip is full instead of one workgroup per frame waiting on LDS round
+    // trips).  Without a grid every border is "small" and is followed whole here: a lane takes one 32-pixel word of start
+    // candidates at a time; every loop iteration advances each busy lane by ONE step.  A walk stops at a proof that
     // the candidate is not canonical, or when the border closes; a closed border longer than min_len is queued.
-    {
+    if (kshift >= 30 || !small_elsewhere) {
         RelayWalk wk;
         bool busy = false, drained = false;
         uint32_t m_outer = 0, m_hole = 0;
@@ -1167,7 +1173,7 @@ __device__ __forceinline__ int relay_frame(
                 else if (k < kcap) {
                     const unsigned hole = sg[i].minoff >> 31; // pattern of the canonical start (this segment holds it)
                     const uint32_t disc = (canon >> 16) * 65536u + ((canon >> 3) & 0x1fffu) + hole;
-                    kkey[k] = ((unsigned long long)(0xffffffffu - disc) << 32) | ((unsigned long long)(n & 0xfffff) << 12) |
+                    kkey[k] = ((unsigned long long)(0xffffffffu - disc) << 32) | ((unsigned long long)(n & 0x7ffff) << 13) |
                               ((unsigned)k << 1) | hole;
                     off_u[k] = base;
                     kk = (uint16_t)k;
@@ -1181,7 +1187,7 @@ __device__ __forceinline__ int relay_frame(
         const int n = (int)e.y;
         const int k = atomicAdd(&s_nkept, 1);
         if (k < kcap) {
-            kkey[k] = ((unsigned long long)(0xffffffffu - (e.w >> 1)) << 32) | ((unsigned long long)(n & 0xfffff) << 12) |
+            kkey[k] = ((unsigned long long)(0xffffffffu - (e.w >> 1)) << 32) | ((unsigned long long)(n & 0x7ffff) << 13) |
                       ((unsigned)k << 1) | (e.w & 1u);
             off_u[k] = (int)e.x;
         }
@@ -1265,7 +1271,7 @@ __device__ __forceinline__ int relay_frame(
                             if (c_pre[mid] <= q) lo = mid; else hi = mid - 1;
                         }
                         const int o = q - c_pre[lo], k = c_k[lo];
-                        const int base = off_u[k], n = (int)((kkey[k] >> 12) & 0xfffff);
+                        const int base = off_u[k], n = (int)((kkey[k] >> 13) & 0x7ffff);
                         int p = c_dst[lo] + o;
                         if (p < base) p += n;
                         pdst[u] = p;
@@ -1294,6 +1300,7 @@ __device__ __forceinline__ int relay_frame(
         }
         if (tid == 0) {
             counts[f * 4 + 0] = nk; counts[f * 4 + 1] = 0; counts[f * 4 + 2] = s_flags; counts[f * 4 + 3] = s_ncand;
+            rstate[f * 2 + 0] = small_elsewhere ? kshift : 30; rstate[f * 2 + 1] = s_pool;
         }
     }
 #ifdef ORBFE_CT_TIMING
@@ -1313,14 +1320,14 @@ __global__ __launch_bounds__(RL_THREADS) RL_VGPR_ATTR void k_contours_relay(
     int kshift, int tbits, RelaySeg* __restrict__ segs, uint32_t* __restrict__ pool, size_t pool_fstride, int pool_cap,
     ArKept* __restrict__ kept_out, int kept_cap, int kcap /*kept borders this kernel's LDS holds*/,
     unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off, int32_t* __restrict__ counts, int32_t* __restrict__ hint,
-    uint4* __restrict__ small_g)
+    uint4* __restrict__ small_g, int32_t* __restrict__ rstate)
 {
     __builtin_amdgcn_s_setprio(2); // latency-bound: its few waves go first when a VALU-bound kernel shares the CU
     if (relay_frame<false, RL_SLOTS_PER_THREAD, RL_THREADS>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool,
-                                                pool_fstride, pool_cap, kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g)) {
+                                                pool_fstride, pool_cap, kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate)) {
         __syncthreads();
         relay_frame<true, RL_SLOTS_PER_THREAD, RL_THREADS>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool,
-                                               pool_fstride, pool_cap, kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g);
+                                               pool_fstride, pool_cap, kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate);
     }
 }
 
@@ -1330,21 +1337,247 @@ __global__ __launch_bounds__(RL_THREADS_BIG) void k_contours_relay8(
     const uint32_t* __restrict__ gbits, size_t bits_fstride, int wpr_g, int W, int H, int lds_bits_words, int min_len,
     int kshift, int tbits, RelaySeg* __restrict__ segs, uint32_t* __restrict__ pool, size_t pool_fstride, int pool_cap,
     ArKept* __restrict__ kept_out, int kept_cap, int kcap, unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off,
-    int32_t* __restrict__ counts, int32_t* __restrict__ hint, uint4* __restrict__ small_g)
+    int32_t* __restrict__ counts, int32_t* __restrict__ hint, uint4* __restrict__ small_g, int32_t* __restrict__ rstate)
 {
     __builtin_amdgcn_s_setprio(2);
     if (relay_frame<false, 8192 / RL_THREADS_BIG, RL_THREADS_BIG>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool, pool_fstride, pool_cap,
-                              kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g)) {
+                              kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate)) {
         __syncthreads();
         relay_frame<true, 8192 / RL_THREADS_BIG, RL_THREADS_BIG>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool, pool_fstride, pool_cap,
-                             kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g);
+                             kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate);
     }
+}
+
+// Frames whose bit image does not fit LDS (1920 x 1080: 264 KB): the same formulation with the padded bit image in HBM -- it stays
+// in L2 -- and only the lists and the 8192-slot marker table in LDS.  A step costs an L2 round trip instead of an LDS one, but the
+// segments are as short as ever (the single-walker kernel follows a 5000-point border in one lane), and the small borders are
+// k_contours_small's, whose bands do fit LDS.
+__global__ __launch_bounds__(RL_THREADS_BIG) void k_contours_relay8g(
+    const uint32_t* __restrict__ gbits, size_t bits_fstride, int wpr_g, int W, int H, int lds_bits_words, int min_len,
+    int kshift, int tbits, RelaySeg* __restrict__ segs, uint32_t* __restrict__ pool, size_t pool_fstride, int pool_cap,
+    ArKept* __restrict__ kept_out, int kept_cap, int kcap, unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off,
+    int32_t* __restrict__ counts, int32_t* __restrict__ hint, uint4* __restrict__ small_g, int32_t* __restrict__ rstate,
+    uint32_t* __restrict__ gpad, size_t gpad_fstride)
+{
+    __builtin_amdgcn_s_setprio(2);
+    if (relay_frame<false, 8192 / RL_THREADS_BIG, RL_THREADS_BIG, true>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool,
+                              pool_fstride, pool_cap, kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate, gpad, gpad_fstride, 1)) {
+        __syncthreads();
+        relay_frame<true, 8192 / RL_THREADS_BIG, RL_THREADS_BIG, true>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool,
+                             pool_fstride, pool_cap, kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate, gpad, gpad_fstride, 1);
+    }
+}
+
+// The step table of the relay walks (rl_lut_entry) in HBM, built once per detector: k_contours_small's workgroups are small and
+// many, so they copy it instead of computing it.
+__global__ void k_relay_lut(uint16_t* __restrict__ lut)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 2048) lut[i] = rl_lut_entry((unsigned)i >> 3, i & 7);
+}
+
+// ---- (c) of the relay formulation for frames that have a grid, as its own launch between the relay kernel and k_contours_tail.
+// A walk that starts at a border's start candidate stops at the first grid marker it meets, and a border cannot get past a relay
+// row or column without one (aruco_trace.hpp), so the walk stays between the grid lines around its start.  One WAVE per block of
+// K rows x RS_BLOCK_COLS columns of start pixels, four independent waves per workgroup, no workgroup barrier and no atomics on
+// LDS: the block's part of the bit image in a wave-private LDS tile (K + 4 rows x 11 words), the start candidates of a round of
+// rows compacted into a wave-private queue with ballots and scans, then every free lane takes the next candidate off the queue
+// (lane prefix of the ballot of free lanes) and follows it.  Thousands of such waves fill the chip where phase (c) inside a
+// relay kernel is one workgroup per frame waiting on dependent round trips -- to HBM / L2 when the bit image is not in LDS.
+// The result is almost always "nothing": a border longer than min_len that touches no grid line is rare.  If there is one it is
+// appended to the frame's kept list behind the relay kernel's borders (the tail sorts by discovery key).
+__global__ __launch_bounds__(RS_THREADS) void k_contours_small(
+    const uint32_t* __restrict__ gbits, size_t bits_fstride, int wpr_g, int W, int H, int min_len,
+    const uint16_t* __restrict__ lut_g, int32_t* __restrict__ rstate, uint32_t* __restrict__ pool, size_t pool_fstride, int pool_cap,
+    int kcap, unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off, int32_t* __restrict__ counts)
+{
+    __shared__ __align__(16) uint16_t s_lut[2048];
+    __shared__ uint32_t s_tile[RS_THREADS / 64][RS_TILE_ROWS * RS_TW + 2];
+    __shared__ uint16_t s_q[RS_THREADS / 64][RS_QCAP];
+    const int tid = threadIdx.x, lane = tid & 63, wid = wave_id(), f = blockIdx.y;
+    if (counts[f * 4 + 2]) return;              // the relay kernel gave the frame up
+    const int kshift = rstate[f * 2 + 0];
+    if (kshift >= 30) return;                   // no grid (or phase (c) done inside the relay kernel)
+    reinterpret_cast<uint4*>(s_lut)[tid] = reinterpret_cast<const uint4*>(lut_g)[tid]; // 2048 x 2 B = RS_THREADS x 16 B
+    __syncthreads();                            // the only workgroup barrier: the step table
+    const int kmask = (1 << kshift) - 1;
+    // padded coordinates throughout (pixel (x, y) = bit x + 1 of row y + 1); relay rows / columns are the multiples of K
+    const int ncb = (W >> RS_BLOCK_SHIFT) + 1, nbands = (H >> kshift) + 1;
+    const int w = blockIdx.x * (RS_THREADS / 64) + wid;
+    if (w >= ncb * nbands) return;
+    const int band = w / ncb, cb = w - band * ncb;
+    const int ys0 = max(1, band << kshift), ys1 = min(H, ((band + 1) << kshift) - 1);     // start rows of this block
+    const int xs0 = max(1, cb << RS_BLOCK_SHIFT), xs1 = min(W, ((cb + 1) << RS_BLOCK_SHIFT) - 1); // start columns
+    if (ys0 > ys1 || xs0 > xs1) return;
+    const int j0 = cb << (RS_BLOCK_SHIFT - 5);  // first word of the block's columns; the tile holds words j0 - 1 .. j0 + RS_TW - 2
+    const int ty0 = max(0, ys0 - 2), ty1 = min(H + 1, ys1 + 2);
+    uint32_t* tile = s_tile[wid];
+    uint16_t* queue = s_q[wid];
+    const uint32_t* gb = gbits + (size_t)f * bits_fstride;
+    uint32_t* pl = pool + (size_t)f * pool_fstride;
+    {
+        const int nw = RS_TW * (ty1 - ty0 + 1);
+        for (int i = lane; i < nw; i += 64) {
+            const int r = i / RS_TW, j = j0 - 1 + (i - r * RS_TW), py = ty0 + r; // word j of the padded image
+            uint32_t v = 0;
+            if (py >= 1 && py <= H && j >= 0) {
+                const uint32_t* row = gb + (size_t)(py - 1) * wpr_g;
+                const uint32_t cur = j < wpr_g ? row[j] : 0u;
+                const uint32_t prv = (j >= 1 && j - 1 < wpr_g) ? row[j - 1] : 0u;
+                v = (cur << 1) | (prv >> 31);
+            }
+            tile[i] = v;
+        }
+        if (lane < 2) tile[nw + lane] = 0; // spare words read by ring8()'s funnel loads
+    }
+    __builtin_amdgcn_wave_barrier();
+    // the tile under the image's row and word numbers (nothing outside it is touched through this view, see ring_at)
+    const BitImage im{tile - ty0 * RS_TW - (j0 - 1), RS_TW, W, H};
+    // 3 x 3 neighbourhood of a padded pixel: from the tile, or -- a walk that left it: one that started on a relay column and went
+    // more than a word to the left -- bit by bit from HBM
+    auto ring_at = [&](int x, int y) -> unsigned {
+        const int w0 = (x - 1) >> 5;
+        if (y - 1 >= ty0 && y + 1 <= ty1 && w0 >= j0 - 1 && w0 + 1 <= j0 + RS_TW - 2) return ring8(im, x, y);
+        auto px = [&](int qx, int qy) -> unsigned {
+            if (qx < 1 || qx > W || qy < 1 || qy > H) return 0u;
+            return (gb[(size_t)(qy - 1) * wpr_g + ((qx - 1) >> 5)] >> ((qx - 1) & 31)) & 1u;
+        };
+        return px(x + 1, y) | (px(x + 1, y - 1) << 1) | (px(x, y - 1) << 2) | (px(x - 1, y - 1) << 3) | (px(x - 1, y) << 4) |
+               (px(x - 1, y + 1) << 5) | (px(x, y + 1) << 6) | (px(x + 1, y + 1) << 7);
+    };
+    auto step_from = [&](RelayWalk& wk, unsigned e) {
+        wk.x += (int)((e >> 11) & 3u) - 1;
+        wk.y += (int)((e >> 13) & 3u) - 1;
+        wk.s = (int)((e + 4u) & 7u);
+        wk.n++;
+        wk.ring = ring_at(wk.x, wk.y);
+    };
+    const int stage0 = pool_cap >> 2; // the final part of the frame's pool (the relay kernel's staging arenas lie above it)
+    // start candidates of word j0 + k of row wy that belong to this block: bit b = padded pixel (32 (j0 + k) + b, wy).  Candidates
+    // are owned by their START pixel: a hole candidate's start is the pixel to its left, so the hole bits are the block's shifted by one
+    constexpr int NWB = (1 << (RS_BLOCK_SHIFT - 5)) + 1; // words per row looked at: the block's and bit 0 of the next
+    auto cand_masks = [&](int wy, int k, uint32_t& m_outer, uint32_t& m_hole) {
+        const int wj = j0 + k;
+        const uint32_t* row = im.bits + wy * RS_TW + wj;
+        const uint32_t* up = row - RS_TW;
+        const uint32_t cur = row[0], upw = up[0];
+        const uint32_t cur_l = (cur << 1) | (row[-1] >> 31);
+        const uint32_t up_l = (upw << 1) | (up[-1] >> 31);
+        const uint32_t up_r = (upw >> 1) | (up[1] << 31);
+        m_outer = (k < NWB - 1) ? cur & ~cur_l & ~up_l & ~upw & ~up_r : 0u;
+        m_hole = ~cur & cur_l & upw;
+        if (k == 0) m_hole &= ~1u;
+        if (k == NWB - 1) m_hole &= 1u;
+        if (wj == 0) { m_outer &= ~1u; m_hole &= ~3u; } // column 0 is the frame; a hole candidate at column 1 has no start pixel
+    };
+    int ncand_w = 0;
+    // One loop for everything: when the queue is empty the wave (all lanes, walking or not) enumerates the next round of rows into
+    // it; free lanes take candidates; busy lanes step.  Walks carry on across rounds, so a long walk delays nothing but its own lane.
+    RelayWalk wk;
+    bool busy = false;
+    int head = 0, total = 0, q_r0 = ys0, r_next = ys0, R = RS_ROUND_ROWS;
+    int sx = 0, sy = 0, s0 = 0, is_hole = 0, start_key = 0;
+    for (;;) {
+        if (head >= total && r_next <= ys1) {
+            const int r0 = r_next, r1 = min(ys1, r0 + R - 1), nitems = (r1 - r0 + 1) * NWB;
+            int cnt = 0;
+            for (int i0 = 0; i0 < nitems; i0 += 64) {
+                const int it = i0 + lane;
+                uint32_t mo = 0, mh = 0;
+                if (it < nitems) { const int r = it / NWB; cand_masks(r0 + r, it - r * NWB, mo, mh); }
+                cnt += wave_sum(__popc(mo) + __popc(mh));
+            }
+            if (cnt > RS_QCAP) { R = max(1, R >> 1); continue; } // one row of a block has at most RS_BLOCK_COLS + 1 <= RS_QCAP candidates
+            int qbase = 0;
+            for (int i0 = 0; i0 < nitems; i0 += 64) {
+                const int it = i0 + lane;
+                uint32_t mo = 0, mh = 0;
+                int r = 0, k = 0;
+                if (it < nitems) { r = it / NWB; k = it - r * NWB; cand_masks(r0 + r, k, mo, mh); }
+                const int c = __popc(mo) + __popc(mh);
+                const int incl = wave_incl_scan_add(c);
+                int q = qbase + incl - c;
+                const uint32_t hi = ((uint32_t)r << 10) | ((uint32_t)k << 5); // row in the round (5 bits) | word (4) | bit (5) | hole << 15
+                while (mo) { const int b = __ffs(mo) - 1; mo &= mo - 1; queue[q++] = (uint16_t)(hi | (uint32_t)b); }
+                while (mh) { const int b = __ffs(mh) - 1; mh &= mh - 1; queue[q++] = (uint16_t)(hi | (uint32_t)b | 0x8000u); }
+                qbase += __builtin_amdgcn_readlane(incl, 63);
+            }
+            __builtin_amdgcn_wave_barrier();
+            ncand_w += cnt;
+            head = 0; total = cnt; q_r0 = r0; r_next = r1 + 1;
+        }
+        if (head < total) {
+            const unsigned long long fm = __ballot(!busy);
+            const int q = head + a_lane_prefix(fm);
+            if (!busy && q < total) {
+                const uint32_t c = queue[q];
+                is_hole = (int)(c >> 15);
+                const int qx = ((j0 + (int)((c >> 5) & 15u)) << 5) + (int)(c & 31u), wy = q_r0 + (int)((c >> 10) & 31u);
+                sx = qx - is_hole; sy = wy;
+                start_key = wy * 65536 + qx;
+                wk.x = sx; wk.y = sy; wk.n = 0;
+                wk.ring = ring_at(sx, sy);
+                s0 = relay_start_dir(wk.ring, is_hole);
+                wk.s = s0;
+                busy = s0 >= 0; // single-pixel borders are never kept
+            }
+            head = min(total, head + (int)__popcll(fm));
+            __builtin_amdgcn_wave_barrier(); // reads of the queue stay in front of the next round's writes
+        }
+        if (!__any(busy)) {
+            if (head >= total && r_next > ys1) break;
+            continue;
+        }
+#pragma unroll
+        for (int u = 0; u < RS_STEPS; u++) {
+            if (busy) {
+                const unsigned e = s_lut[(wk.ring << 3) | (unsigned)wk.s];
+                const int key3 = wk.y * 65536 + wk.x;
+                bool stop = rl_is_marker(e, wk.x, wk.y, kmask); // the border belongs to the segment walkers
+                if (is_hole)                                      // relay_not_canonical() on the table's run bits
+                    stop |= ((e & 0x080u) && key3 - 65536 < start_key) || ((e & 0x100u) && key3 - 1 < start_key) ||
+                            ((e & 0x200u) && key3 + 1 < start_key) || ((e & 0x400u) && key3 + 65536 < start_key);
+                else stop |= key3 < start_key;
+                if (stop) busy = false;
+                else {
+                    step_from(wk, e);
+                    if (wk.x == sx && wk.y == sy && wk.s == s0) {
+                        busy = false;
+                        if (wk.n > min_len) {
+                            // rare: more than min_len points between grid lines.  The border is whole, so its final place
+                            // is known -- walk it once more, straight into the pool
+                            const int n = wk.n;
+                            const int k = atomicAdd(&counts[f * 4 + 0], 1);
+                            const int base = atomicAdd(&rstate[f * 2 + 1], n);
+                            if (k >= kcap) { atomicSub(&counts[f * 4 + 0], 1); atomicOr(&counts[f * 4 + 2], 2); }
+                            else if (base + n > stage0) atomicOr(&counts[f * 4 + 2], 4);
+                            else {
+                                RelayWalk w2;
+                                w2.x = sx; w2.y = sy; w2.s = s0; w2.n = 0;
+                                w2.ring = ring_at(sx, sy);
+                                for (int o = 0; o < n; o++) {
+                                    pl[base + o] = relay_point(w2);
+                                    step_from(w2, s_lut[(w2.ring << 3) | (unsigned)w2.s]);
+                                }
+                                tail_keys[(size_t)f * kcap + k] =
+                                    ((unsigned long long)(0xffffffffu - (uint32_t)start_key) << 32) |
+                                    ((unsigned long long)(n & 0x7ffff) << 13) | ((unsigned)k << 1) | (unsigned)is_hole;
+                                tail_off[(size_t)f * kcap + k] = base;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0 && ncand_w) atomicAdd(&counts[f * 4 + 3], ncand_w);
 }
 
 // ---- (g) of the relay formulation as its own kernel: sort, approxPolyDP, rectangles for the borders k_contours_relay
 // kept.  (Separate because approxPolyDP needs twice the registers of the walks: the relay kernel stays at 64 VGPRs, so
 // two of its workgroups share a CU.)  Frames the relay kernel gave up on are skipped; k_contours_t redoes them.
-__global__ __launch_bounds__(RT_THREADS) void k_contours_tail(const unsigned long long* __restrict__ tail_keys,
+template <int NT>
+__global__ __launch_bounds__(NT) void k_contours_tail_t(const unsigned long long* __restrict__ tail_keys,
                                                                const int32_t* __restrict__ tail_off, int kcap,
                                                                const uint32_t* __restrict__ pool, size_t pool_fstride,
                                                                ArKept* __restrict__ kept_out, int kept_cap,
@@ -1365,20 +1598,26 @@ __global__ __launch_bounds__(RT_THREADS) void k_contours_tail(const unsigned lon
     int* koff = klen + kcap;
     int* rectflag = koff + kcap;
     ApPt* ap_out = (ApPt*)(rectflag + kcap);
-    int2* ap_stack = (int2*)(ap_out + (RT_THREADS / 64) * AP_OUT);
-    uint16_t* rank_of = (uint16_t*)(ap_stack + (RT_THREADS / 64) * AP_STACK);
+    int2* ap_stack = (int2*)(ap_out + (NT / 64) * AP_OUT);
+    uint16_t* rank_of = (uint16_t*)(ap_stack + (NT / 64) * AP_STACK);
     uint32_t* pb = (uint32_t*)(rank_of + kcap);
-    const int pb_pts = ((int)((lds_bytes - (int)((unsigned char*)pb - ct_smem)) / 4) / (RT_THREADS / 64)) & ~3;
-    for (int k = tid; k < nkept; k += RT_THREADS) {
+    const int pb_pts = ((int)((lds_bytes - (int)((unsigned char*)pb - ct_smem)) / 4) / (NT / 64)) & ~3;
+    for (int k = tid; k < nkept; k += NT) {
         kkey[k] = tail_keys[(size_t)f * kcap + k];
         off_u[k] = tail_off[(size_t)f * kcap + k];
     }
     if (tid == 0) { s_flags = flags; s_ncand = counts[f * 4 + 3]; }
     __syncthreads();
-    contours_tail(f, tid, RT_THREADS, nkept, kkey, off_u, klen, koff, rectflag, ap_out, ap_stack,
+    contours_tail(f, tid, NT, nkept, kkey, off_u, klen, koff, rectflag, ap_out, ap_stack,
                   pool + (size_t)f * pool_fstride, kept_out, kept_cap, rects_out, rect_cap, counts, &s_flags, &s_ncand, rank_of,
-                  &s_tailq, RT_THREADS / 64, pb, pb_pts, nullptr, 0);
+                  &s_tailq, NT / 64, pb, pb_pts, nullptr, 0);
 }
+
+template __global__ void k_contours_tail_t<RT_THREADS>(const unsigned long long*, const int32_t*, int, const uint32_t*, size_t, ArKept*, int, ArRect*, int,
+                                                       int32_t*, int);
+// busy large frames have a few thousand kept borders: sixteen waves per frame instead of four (the frames are few, the CUs many)
+template __global__ void k_contours_tail_t<RT_THREADS_BIG>(const unsigned long long*, const int32_t*, int, const uint32_t*, size_t, ArKept*, int, ArRect*, int,
+                                                           int32_t*, int);
 
 // ---------------------------------------------------------------------------------------- prefilter -----------
 __device__ __forceinline__ int ar_perimeter(const float c[4][2])

@@ -51,14 +51,24 @@ struct RelaySeg {
 __global__ void k_contours_relay(const uint32_t* gbits, size_t bits_fstride, int wpr_g, int W, int H,
                                  int lds_bits_words, int min_len, int kshift, int tbits, RelaySeg* segs, uint32_t* pool,
                                  size_t pool_fstride, int pool_cap, ArKept* kept_out, int kept_cap, int kcap,
-                                 unsigned long long* tail_keys, int32_t* tail_off, int32_t* counts, int32_t* hint, uint4* small_g);
+                                 unsigned long long* tail_keys, int32_t* tail_off, int32_t* counts, int32_t* hint, uint4* small_g, int32_t* rstate);
 __global__ void k_contours_relay8(const uint32_t* gbits, size_t bits_fstride, int wpr_g, int W, int H,
                                  int lds_bits_words, int min_len, int kshift, int tbits, RelaySeg* segs, uint32_t* pool,
                                  size_t pool_fstride, int pool_cap, ArKept* kept_out, int kept_cap, int kcap,
-                                 unsigned long long* tail_keys, int32_t* tail_off, int32_t* counts, int32_t* hint, uint4* small_g);
-__global__ void k_contours_tail(const unsigned long long* tail_keys, const int32_t* tail_off, int kcap,
-                                const uint32_t* pool, size_t pool_fstride, ArKept* kept_out, int kept_cap,
-                                ArRect* rects_out, int rect_cap, int32_t* counts, int lds_bytes);
+                                 unsigned long long* tail_keys, int32_t* tail_off, int32_t* counts, int32_t* hint, uint4* small_g, int32_t* rstate);
+__global__ void k_contours_relay8g(const uint32_t* gbits, size_t bits_fstride, int wpr_g, int W, int H,
+                                 int lds_bits_words, int min_len, int kshift, int tbits, RelaySeg* segs, uint32_t* pool,
+                                 size_t pool_fstride, int pool_cap, ArKept* kept_out, int kept_cap, int kcap,
+                                 unsigned long long* tail_keys, int32_t* tail_off, int32_t* counts, int32_t* hint, uint4* small_g, int32_t* rstate,
+                                 uint32_t* gpad, size_t gpad_fstride);
+__global__ void k_relay_lut(uint16_t* lut);
+__global__ void k_contours_small(const uint32_t* gbits, size_t bits_fstride, int wpr_g, int W, int H, int min_len, const uint16_t* lut_g,
+                                 int32_t* rstate, uint32_t* pool, size_t pool_fstride, int pool_cap, int kcap, unsigned long long* tail_keys,
+                                 int32_t* tail_off, int32_t* counts);
+template <int NT>
+__global__ void k_contours_tail_t(const unsigned long long* tail_keys, const int32_t* tail_off, int kcap,
+                                  const uint32_t* pool, size_t pool_fstride, ArKept* kept_out, int kept_cap,
+                                  ArRect* rects_out, int rect_cap, int32_t* counts, int lds_bytes);
 __global__ void k_prefilter(ArRect* rects, int rect_cap, const int32_t* counts, int W, int H, int too_near,
                             int32_t* cand_idx, int32_t* ncand_out);
 __global__ void k_decode(ImgView src0, ImgView pyr, const ArLevel* levels, int nlevels, const ArRect* rects,
@@ -81,6 +91,7 @@ __global__ void k_finalize(const ArRect* rects, int rect_cap, const int32_t* can
 #ifndef RT_THREADS
 #define RT_THREADS 256           // k_contours_tail: 4 waves, one approxPolyDP each at a time (small workgroups place easily next to other kernels)
 #endif
+#define RT_THREADS_BIG 1024      // k_contours_tail for frames with thousands of kept borders (k_contours_relay8g)
 #ifndef RL_THREADS_BIG
 #define RL_THREADS_BIG 1024     // k_contours_relay8 (large frames): its workgroup owns the CU (LDS), so it brings 16 waves
 #endif
@@ -92,6 +103,19 @@ __global__ void k_finalize(const ArRect* rects, int rect_cap, const int32_t* can
 #define RL_FALLBACK_FLAGS (RL_FLAG_TABLE | RL_FLAG_BUG)
 #define RL_KCAP AR_MAX_KEPT      // kept borders per frame (k_contours_relay + k_contours_tail)
 #define RL_STEPS_PER_ITER 2      // walk steps between two looks at the work queue
+// k_contours_small (phase (c) of frames with a grid, one wave per block of K rows x 256 columns): threads per workgroup, columns
+// per block (log2), tile words per row (the block's 8 + one to the left + one to the right + ring8()'s funnel word), tile rows
+// (K <= 128: K + 4), queue entries per wave (>= the start candidates one row of a block can have), rows per round, steps per
+// look at the queue
+#define RS_THREADS 256
+#define RS_BLOCK_SHIFT 8
+#define RS_TW 11
+#define RS_TILE_ROWS (128 + 4)
+#define RS_QCAP 1024
+#define RS_ROUND_ROWS 32
+#ifndef RS_STEPS
+#define RS_STEPS 2
+#endif
 
 // LDS of k_contours_relay: region R (bit image | list arrays) followed by the marker keys
 __host__ __device__ inline size_t relay_region_bytes(int lds_bits_words, int kcap, int tbits)
@@ -107,9 +131,9 @@ inline size_t relay_lds_bytes(int lds_bits_words, int kcap, int tbits)
 }
 
 // LDS of k_contours_tail: per-border arrays, approx scratch, length ranks, one point buffer of `pts` points per wave
-inline size_t tail_lds_bytes(int kcap, int pts)
+inline size_t tail_lds_bytes(int kcap, int pts, int nthreads = RT_THREADS)
 {
-    return (size_t)kcap * (8 + 4 * 4 + 2) + (size_t)(RT_THREADS / 64) * ((AP_OUT + AP_STACK) * 8 + (size_t)pts * 4) + 64;
+    return (size_t)kcap * (8 + 4 * 4 + 2) + (size_t)(nthreads / 64) * ((AP_OUT + AP_STACK) * 8 + (size_t)pts * 4) + 64;
 }
 
 inline size_t contours_lds_bytes(int lds_bits_words, int kept_cap)

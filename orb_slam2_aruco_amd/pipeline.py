@@ -23,6 +23,19 @@ def _up(v):
     return (v + 255) // 256 * 256
 
 
+def _stream(torch, dev, priority=0):
+    """A non-blocking HIP stream of the given priority (-1 high, 0 normal, 1 low; torch's pool only has 0 and -1) as a torch stream."""
+    if priority == 0:
+        return torch.cuda.Stream(dev)
+    hip = ctypes.CDLL("libamdhip64.so")
+    h = ctypes.c_void_p()
+    with torch.cuda.device(dev):
+        rc = hip.hipStreamCreateWithPriority(ctypes.byref(h), ctypes.c_uint(1), ctypes.c_int(priority))   # hipStreamNonBlocking
+    if rc != 0:
+        raise RuntimeError("hipStreamCreateWithPriority: %d" % rc)
+    return torch.cuda.ExternalStream(h.value, device=dev)
+
+
 class RecordLayout:
     """One result set = ONE contiguous buffer, the record SURVEY 8e gathers, array by array over the B frames:
     {kp[B][cap] x 28 B | desc[B][cap] x 32 B | n_kp[B] | markers[B][mcap] x 36 B | n_mk[B] | poses[B][mcap] x 56 B}."""
@@ -121,9 +134,8 @@ class FrontEndPipeline:
         # So the latency-bound kernels (contours, quadtree, SearchForInitialization) overlap with the VALU-bound ones.
         # None of them is the null stream: work on the legacy default stream synchronises implicitly with every blocking
         # stream of the process (measured: 2.30 ms per C2 step with the extractor on the null stream, 2.01 ms on its own).
-        self.stream = torch.cuda.Stream(dev)
-        self.stream2 = torch.cuda.Stream(dev)
-        self.stream3 = torch.cuda.Stream(dev)
+        prio = [int(v) for v in os.environ.get("ORBFE_STREAM_PRIO", "0,0,0").split(",")]   # experiment: extractor, detector, matching
+        self.stream, self.stream2, self.stream3 = (_stream(torch, dev, p) for p in prio)
         self.sp3 = ctypes.c_void_p(self.stream3.cuda_stream)
         self.orb_stream_sets = [[self.stream] + [torch.cuda.Stream(dev) for _ in range(S - 1)]] + \
                                [[torch.cuda.Stream(dev) for _ in range(S)] for _ in range(D - 1)]

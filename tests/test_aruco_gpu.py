@@ -177,6 +177,51 @@ def test_full_hd_frame_with_many_contours(orbfe, oracle):
     assert det.counts(0)["nkept"] > 1024
 
 
+def test_full_hd_structured_borders_between_grid_lines(orbfe, oracle):
+    """1920x1080: the bit image does not fit LDS, so the relay kernel walks it in HBM (k_contours_relay8g) and the borders that touch
+    no grid line are k_contours_small's.  Hollow and filled squares and a comb, each with more than 70 border points, placed strictly
+    inside 32-pixel grid cells (kept by the small-border kernel), at block and band seams, next to long borders that cross many grid
+    lines and rendered markers: kept-contour count, rectangle candidates (order and corners) and markers equal the oracle's, and equal
+    the single-walker big-frame kernel's."""
+    img = np.full((1080, 1920), 200, np.uint8)
+    rng = np.random.default_rng(11)
+    for (y0, x0) in [(35, 35), (35, 259), (227, 1027), (515, 1859), (1027, 35), (995, 1795), (259, 515)]:   # cells of the 32-px grid
+        img[y0:y0 + 25, x0:x0 + 25] = 20                      # outer border 96 points
+    for (y0, x0) in [(99, 99), (547, 771), (803, 1283)]:
+        img[y0:y0 + 26, x0:x0 + 26] = 20
+        img[y0 + 2:y0 + 24, x0 + 2:x0 + 24] = 200             # hollow: hole border > 70 points as well
+    for x in range(1573, 1597, 4):                            # comb inside one cell
+        img[163:188, x:x + 2] = 20
+    img[186:188, 1573:1595] = 20
+    img[300:304, 100:1800] = 20                               # long thin borders across many grid lines
+    img[300:900, 100:104] = 20
+    img[400:700, 900:1300] = 20
+    img[450:650, 950:1250] = 200
+    for k, (y0, x0) in enumerate([(720, 300), (60, 1300), (760, 1500)]):
+        m = synth.render_marker("ARUCO", 7 + 31 * k, 14, quiet=1)
+        img[y0:y0 + m.shape[0], x0:x0 + m.shape[1]] = m
+    img = np.clip(img.astype(np.int32) + rng.integers(-3, 4, img.shape), 0, 255).astype(np.uint8)
+    det = orbfe.MarkerDetector("ARUCO")
+    ora = oracle.ArucoOracle("ARUCO")
+    got, want = det.detect(img), ora.detect(img)
+    assert np.array_equal(det.thresholded(0), ora.stage_image(0))
+    c = det.counts(0)
+    assert c["flags"] == 0 and not c["fell_back"], c
+    assert c["nkept"] == sum(len(b) > 70 for b in oracle.find_contours(ora.stage_image(0)))
+    orects, grects = ora.candidates(0), det.rects(0)
+    assert len(orects) >= 10
+    assert np.array_equal(grects["corners"].reshape(-1, 8), orects[:, :8])
+    assert np.array_equal(grects["len"], orects[:, 8].astype(np.int32))
+    assert len(want) == 3 and np.array_equal(got["id"], want["id"]) and np.allclose(got["corners"], want["corners"], atol=1e-3)
+    relay_rects = _rects_key(det)
+    det.set_big_frames(True)
+    got_big = det.detect(img)
+    det.set_big_frames(False)
+    big_rects = _rects_key(det)                     # (rects of the last run: the big-frame kernel's)
+    assert np.array_equal(big_rects[0], relay_rects[0]) and np.array_equal(big_rects[1], relay_rects[1])
+    assert np.array_equal(got_big["id"], got["id"]) and np.array_equal(got_big["corners"], got["corners"])
+
+
 def _damaged_markers_image(dic, ids, flips, bit=8):
     """White 480x640 frame with axis-aligned markers; marker k has flips[k] inner cells inverted."""
     img = np.full((480, 640), 235, np.uint8)
