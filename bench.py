@@ -452,14 +452,23 @@ def main():
                 ent["valu_frac"] = pmc[k]["valu_us"] / us if us > 0 and pmc[k].get("valu_us") is not None else None
                 ent["lane_utilisation"] = pmc[k].get("lane_utilisation")
             per_stage[k] = ent
-        dom = max(stages, key=lambda k: stages[k]) if stages else None
+        # The dominant kernel.  The step is bound by VALU issue with all engines overlapped, so where the
+        # committed PMC profile of this configuration is available it is the stage that takes most of that resource -- the same
+        # stage whose removal shortens the step most in the ablation study (profiles/r02_ablation.txt: FAST) -- else the longest
+        # launch.  "longest_launch" names the latter in any case.
+        longest = max(stages, key=lambda k: stages[k]) if stages else None
+        with_valu = [k for k in stages if per_stage[k].get("valu_us") is not None]
+        dom = max(with_valu, key=lambda k: per_stage[k]["valu_us"]) if with_valu else longest
         roof = None
         if dom is not None and stages[dom] > 0:
             d = per_stage[dom]
             roof = {"bound": d["bound"], "kernel": dom, "achieved": d["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": d["hbm_frac"], "traffic": d["traffic"], "launch_us": d["launch_us"],
                     "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"], "frames_per_launch": fl(dom),
-                    "note": "dominant launch of the last timed step; launch_us = HIP events on the stream the stage is launched "
+                    "longest_launch": longest,
+                    "valu_us": d.get("valu_us"), "valu_frac": d.get("valu_frac"),
+                    "note": "dominant kernel of the last timed step = the stage with the largest VALU issue time (the resource that "
+                            "bounds the step; without a PMC profile of this configuration: the longest launch); launch_us = HIP events on the stream the stage is launched "
                             "on, the other engines running concurrently (standalone times: DESIGN.md section 6); achieved = "
                             "algorithmic bytes / launch time against the HBM peak also where the stage's bound is not HBM -- "
                             "'stages' carries every stage's bound, and valu_us / valu_frac where the committed PMC profile of "

@@ -34,6 +34,8 @@ struct orbfe_aruco {
     DevBuf d_segs, d_tailkeys, d_tailoff, d_small, d_hint; // d_hint: the relay kernel's grid spacing of the previous batch
     int relay_kshift = 5;      // initial grid spacing (log2) of k_contours_relay
     int relay_kcap = RL_KCAP;  // kept borders per frame the relay kernels and their tail hold
+    // experiment (ORBFE_ARUCO_SMALL_SEPARATE=1): k_contours_small also for frames whose bit image is in LDS
+    bool small_separate = getenv("ORBFE_ARUCO_SMALL_SEPARATE") && atoi(getenv("ORBFE_ARUCO_SMALL_SEPARATE")) != 0;
     bool relay_global = false; // k_contours_relay8g: the bit image stays in HBM (it does not fit LDS)
     int relay_tbits = 0;       // hash-table size of k_contours_relay (0: the kernel cannot run at this image size)
     bool force_legacy = false; // debug: always use k_contours_t
@@ -301,13 +303,13 @@ struct orbfe_aruco {
                                cols, rows, lds_bits_words, 70, relay_kshift, relay_tbits, d_segs.as<RelaySeg>(),
                                d_pool.as<uint32_t>(), pool_fu32, (int)pool_fu32, d_kept.as<ArKept>(), relay_kcap, relay_kcap,
                                d_tailkeys.as<unsigned long long>(), d_tailoff.as<int32_t>(), d_counts.as<int32_t>(), d_hint.as<int32_t>(),
-                               d_small.as<uint4>(), d_rstate.as<int32_t>());
+                               d_small.as<uint4>(), d_rstate.as<int32_t>(), small_separate ? 1 : 0);
             }
             // the borders that touch no grid line, for frames done with a grid by a relay kernel that leaves them out (the
             // HBM-resident one: its bands fit LDS here; for LDS-resident frames the separate launch halves the relay kernel's time
             // but issues twice the instructions of the in-kernel phase -- measured 1.85 -> 1.98 ms per C2 step -- so those keep
             // phase (c) inside): bands of K rows, K >= 2^relay_kshift
-            if (relay_global) {
+            if (relay_global || small_separate) {
                 const int nwaves = ((cols >> RS_BLOCK_SHIFT) + 1) * ((rows >> relay_kshift) + 1); // blocks of the finest grid
                 hipLaunchKernelGGL(k_contours_small, dim3((nwaves + RS_THREADS / 64 - 1) / (RS_THREADS / 64), B), dim3(RS_THREADS), 0, s,
                                    d_bits.as<uint32_t>(), bits_fu32, wpr, cols, rows, 70, d_lut.as<uint16_t>(), d_rstate.as<int32_t>(),

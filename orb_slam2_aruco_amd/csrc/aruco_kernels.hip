@@ -1320,14 +1320,16 @@ __global__ __launch_bounds__(RL_THREADS) RL_VGPR_ATTR void k_contours_relay(
     int kshift, int tbits, RelaySeg* __restrict__ segs, uint32_t* __restrict__ pool, size_t pool_fstride, int pool_cap,
     ArKept* __restrict__ kept_out, int kept_cap, int kcap /*kept borders this kernel's LDS holds*/,
     unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off, int32_t* __restrict__ counts, int32_t* __restrict__ hint,
-    uint4* __restrict__ small_g, int32_t* __restrict__ rstate)
+    uint4* __restrict__ small_g, int32_t* __restrict__ rstate, int small_elsewhere)
 {
     __builtin_amdgcn_s_setprio(2); // latency-bound: its few waves go first when a VALU-bound kernel shares the CU
     if (relay_frame<false, RL_SLOTS_PER_THREAD, RL_THREADS>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool,
-                                                pool_fstride, pool_cap, kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate)) {
+                                                pool_fstride, pool_cap, kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate,
+                                                nullptr, 0, small_elsewhere)) {
         __syncthreads();
         relay_frame<true, RL_SLOTS_PER_THREAD, RL_THREADS>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool,
-                                               pool_fstride, pool_cap, kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate);
+                                               pool_fstride, pool_cap, kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate,
+                                               nullptr, 0, small_elsewhere);
     }
 }
 
@@ -1337,14 +1339,14 @@ __global__ __launch_bounds__(RL_THREADS_BIG) void k_contours_relay8(
     const uint32_t* __restrict__ gbits, size_t bits_fstride, int wpr_g, int W, int H, int lds_bits_words, int min_len,
     int kshift, int tbits, RelaySeg* __restrict__ segs, uint32_t* __restrict__ pool, size_t pool_fstride, int pool_cap,
     ArKept* __restrict__ kept_out, int kept_cap, int kcap, unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off,
-    int32_t* __restrict__ counts, int32_t* __restrict__ hint, uint4* __restrict__ small_g, int32_t* __restrict__ rstate)
+    int32_t* __restrict__ counts, int32_t* __restrict__ hint, uint4* __restrict__ small_g, int32_t* __restrict__ rstate, int small_elsewhere)
 {
     __builtin_amdgcn_s_setprio(2);
     if (relay_frame<false, 8192 / RL_THREADS_BIG, RL_THREADS_BIG>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool, pool_fstride, pool_cap,
-                              kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate)) {
+                              kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate, nullptr, 0, small_elsewhere)) {
         __syncthreads();
         relay_frame<true, 8192 / RL_THREADS_BIG, RL_THREADS_BIG>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool, pool_fstride, pool_cap,
-                             kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate);
+                             kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate, nullptr, 0, small_elsewhere);
     }
 }
 
