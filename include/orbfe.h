@@ -248,6 +248,19 @@ int orbfe_fuse_search(const orbfe_keypoint* kps, const uint8_t* desc, int n, int
                       const uint8_t* valid, const float* min_dist, const float* max_dist, const float* normal, const uint8_t* mp_desc, int nmp,
                       const float* Tcw, const float* Ow, const float* K4, const float* scale_factors, const float* inv_level_sigma2, int nlevels,
                       float log_scale_factor, float th, double chi2, int32_t* best_idx, int32_t* best_dist, int device);
+
+/* The same over several keyframes resident on the device: LocalMapping::SearchInNeighbors fuses the current keyframe's map points
+ * into every neighbour (`matcher.Fuse(pKFi, vpMapPointMatches)` in a loop, src/LocalMapping.cc:850-858) -- one call instead of a
+ * host round trip per keyframe.  Keyframe k owns block k of `capacity` keypoint records / descriptors (d_n[k] valid; the layout of
+ * orbfe_extract_batch_device); the nmp map points (device arrays) are shared, d_valid (may be NULL) is [nkf][nmp] because
+ * IsInKeyFrame(pKF) depends on the keyframe; Tcw / Ow are HOST arrays of nkf poses (12 / 3 floats each).  Outputs [nkf][nmp].
+ * Asynchronous on `stream`; a candidate row that overflowed the per-stream scratch truncates silently:
+ * orbfe_search_by_projection_batch_status(stream) reports it (and grows the scratch for a repeat). */
+int orbfe_fuse_search_batch_device(const orbfe_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n, int capacity, int nkf, int cols, int rows,
+                                   const float* bounds, const float* d_p3Dw, const uint8_t* d_valid, const float* d_min_dist,
+                                   const float* d_max_dist, const float* d_normal, const uint8_t* d_mp_desc, int nmp, const float* Tcw,
+                                   const float* Ow, const float* K4, const float* scale_factors, const float* inv_level_sigma2, int nlevels,
+                                   float log_scale_factor, float th, double chi2, int32_t* d_best_idx, int32_t* d_best_dist, void* stream);
 /* ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th) (src/ORBmatcher.cc:1106-1330): the map points of
  * each keyframe are carried into the other camera (world -> own camera -> sR | t of the similarity, each stage rounded to
  * float), gated (positive depth, IsInImage, distance in the scale-invariance range of the FINAL camera coordinates),

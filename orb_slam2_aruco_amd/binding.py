@@ -42,7 +42,7 @@ SYMBOLS = [
     "orbfe_search_by_bow", "orbfe_search_by_bow_batch_device",
     "orbfe_search_for_triangulation", "orbfe_search_for_triangulation_batch_device",
     "orbfe_distinctive_descriptors", "orbfe_distinctive_descriptors_device", "orbfe_search_by_projection_batch_device",
-    "orbfe_search_by_projection_batch_status", "orbfe_search_by_projection_last_frame", "orbfe_search_by_projection_best", "orbfe_search_by_projection_keyframe", "orbfe_fuse_search", "orbfe_project_map_points", "orbfe_search_by_sim3", "orbfe_search_by_projection_sim3",
+    "orbfe_search_by_projection_batch_status", "orbfe_search_by_projection_last_frame", "orbfe_search_by_projection_best", "orbfe_search_by_projection_keyframe", "orbfe_fuse_search", "orbfe_fuse_search_batch_device", "orbfe_project_map_points", "orbfe_search_by_sim3", "orbfe_search_by_projection_sim3",
     "orbfe_keyframe_features_pack", "orbfe_keyframe_features_unpack", "orbfe_keyframe_features_pack_device",
     "orbfe_keyframe_features_unpack_device",
 ]
@@ -103,6 +103,8 @@ def load():
         L.orbfe_search_by_projection_best.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp, i32, i32, f32, vp, vp, i32]
         L.orbfe_search_by_projection_batch_device.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, f32, f32, i32] + [vp] * 9
         L.orbfe_search_by_projection_batch_status.argtypes = [vp, vp]
+        L.orbfe_fuse_search_batch_device.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, f32, f32,
+                                                     C.c_double, vp, vp, vp]
         L.orbfe_distinctive_descriptors.argtypes = [vp, vp, i32, vp, vp, i32]
         L.orbfe_distinctive_descriptors_device.argtypes = [vp, vp, i32, vp, vp, vp]
         L.orbfe_undistort_points.argtypes = [vp, i32, vp, vp, i32, vp, i32]

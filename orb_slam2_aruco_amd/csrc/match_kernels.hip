@@ -858,6 +858,9 @@ struct SbpBatch {
     uint16_t* row_rank; uint8_t* row_dist; int32_t* row_cnt; int row_stride;
     int32_t *best_idx, *best_dist, *best_level, *second_dist, *second_level, *match, *nmatches, *overflow;
     int32_t *match_cur, *qbin;
+    int qdesc_shared;     // every frame's queries use the same descriptor block (the same map points into several keyframes: Fuse)
+    double chi2;          // > 0: reprojection gate of Fuse (SbpBest::chi2)
+    float inv_sigma2[16];
 };
 __global__ __launch_bounds__(SBP_THREADS) void k_search_by_projection_batch(SbpBatch B, int ncap, float4 bnd, int mode, int th_high,
                                                                             float nnratio, float factor, int check_ori)
@@ -870,7 +873,10 @@ __global__ __launch_bounds__(SBP_THREADS) void k_search_by_projection_batch(SbpB
     bo.factor = factor; bo.check_ori = check_ori;
     bo.match_cur = B.match_cur ? B.match_cur + ko : nullptr;
     bo.qbin = B.qbin ? B.qbin + qo : nullptr;
-    sbp_frame(B.kps + ko, B.desc + ko * 32, n, ncap, bnd, B.queries + qo, B.qdesc + qo * 32, nq, B.taken ? B.taken + ko : nullptr, mode, th_high,
+    bo.chi2 = B.chi2;
+#pragma unroll
+    for (int l = 0; l < 16; l++) bo.inv_sigma2[l] = B.inv_sigma2[l];
+    sbp_frame(B.kps + ko, B.desc + ko * 32, n, ncap, bnd, B.queries + qo, B.qdesc + (B.qdesc_shared ? 0 : qo * 32), nq, B.taken ? B.taken + ko : nullptr, mode, th_high,
               nnratio, B.row_rank + qo * B.row_stride, B.row_dist + qo * B.row_stride, B.row_cnt + qo, B.row_stride,
               B.best_idx ? B.best_idx + qo : nullptr, B.best_dist ? B.best_dist + qo : nullptr, B.best_level ? B.best_level + qo : nullptr,
               B.second_dist ? B.second_dist + qo : nullptr, B.second_level ? B.second_level + qo : nullptr, B.match + qo, B.nmatches + f,
@@ -1742,6 +1748,58 @@ int orbfe_search_by_projection_batch_device(const orbfe_keypoint* d_kps, const u
     if ((rc = ensure_dyn_lds(reinterpret_cast<const void*>(&k_search_by_projection_batch), lds))) return rc;
     hipLaunchKernelGGL(k_search_by_projection_batch, dim3(nframes), dim3(SBP_THREADS), lds, s, B, ncap, frame_bounds(cols, rows, bounds), mode,
                        th_high, nnratio, factor, check_orientation);
+    ORBFE_HIP(hipGetLastError());
+    return ORBFE_OK;
+}
+
+int orbfe_fuse_search_batch_device(const orbfe_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n, int capacity, int nkf, int cols, int rows,
+                                   const float* bounds, const float* d_p3Dw, const uint8_t* d_valid, const float* d_min_dist,
+                                   const float* d_max_dist, const float* d_normal, const uint8_t* d_mp_desc, int nmp, const float* Tcw,
+                                   const float* Ow, const float* K4, const float* scale_factors, const float* inv_level_sigma2, int nlevels,
+                                   float log_scale_factor, float th, double chi2, int32_t* d_best_idx, int32_t* d_best_dist, void* stream)
+{
+    if (!d_kps || !d_desc || !d_n || capacity <= 0 || nkf <= 0 || nmp <= 0 || !d_p3Dw || !d_min_dist || !d_max_dist || !d_normal || !d_mp_desc ||
+        !Tcw || !Ow || !d_best_idx || !d_best_dist || (chi2 > 0.0 && !inv_level_sigma2))
+        return fail(ORBFE_ERR_INVALID, "orbfe_fuse_search_batch_device: invalid argument");
+    if (capacity > 65535) return fail(ORBFE_ERR_INVALID, "more than 65535 keypoints per frame are unsupported");
+    int ncap = 64;
+    while (ncap < capacity) ncap <<= 1;
+    const size_t lds = (size_t)ncap * (4 + 8 + 1 + 1) + (SBP_CELLS + 2) * 2 + 64;
+    if (lds > 150 * 1024) return fail(ORBFE_ERR_CAPACITY, "%d keypoints do not fit the grid kernel's LDS", capacity);
+    hipStream_t s = (hipStream_t)stream;
+    MatchWorkspace& w = ws(s);
+    const int stride = std::max(w.sbp_stride, 128);
+    w.sbp_stride = stride;
+    const size_t NQ = (size_t)nkf * nmp;
+    int rc;
+    // obest: [best_level | second_dist | second_level | match] x NQ, then nq[nkf], nmatches[nkf]
+    if ((rc = w.q.ensure(NQ * sizeof(orbfe_window_query))) || (rc = w.csr_idx.ensure(NQ * stride * 2)) || (rc = w.csr_dist.ensure(NQ * stride)) ||
+        (rc = w.csr_cnt.ensure(NQ * 4)) || (rc = w.obest.ensure((NQ * 4 + 2 * (size_t)nkf) * 4 + 256)) || (rc = w.overflow.ensure(16)))
+        return rc;
+    ORBFE_HIP(hipMemsetAsync(w.overflow.p, 0, 4, s));
+    for (int k = 0; k < nkf; k++) { // the projection and the gates of :848-915, one small launch per keyframe pose
+        ProjectParams P;
+        if ((rc = project_params(P, Tcw + 12 * k, Ow + 3 * k, K4, cols, rows, bounds, 1, scale_factors, nlevels, log_scale_factor, th, 1, 0,
+                                 "orbfe_fuse_search_batch_device")))
+            return rc;
+        hipLaunchKernelGGL(k_project_map_points, dim3((nmp + 255) / 256), dim3(256), 0, s, d_p3Dw, d_valid ? d_valid + (size_t)k * nmp : nullptr,
+                           d_min_dist, d_max_dist, d_normal, nmp, P, w.q.as<SbpQuery>() + (size_t)k * nmp);
+    }
+    int32_t* o = w.obest.as<int32_t>();
+    int32_t* d_nq = o + 4 * NQ;
+    ORBFE_HIP(hipMemsetD32Async((hipDeviceptr_t)d_nq, nmp, nkf, s));
+    SbpBatch B{};
+    B.kps = d_kps; B.desc = d_desc; B.n = d_n; B.capacity = capacity;
+    B.queries = w.q.as<SbpQuery>(); B.qdesc = d_mp_desc; B.qdesc_shared = 1; B.nq = d_nq; B.qcapacity = nmp;
+    B.row_rank = w.csr_idx.as<uint16_t>(); B.row_dist = w.csr_dist.as<uint8_t>(); B.row_cnt = w.csr_cnt.as<int32_t>(); B.row_stride = stride;
+    B.best_idx = d_best_idx; B.best_dist = d_best_dist; B.best_level = o; B.second_dist = o + NQ; B.second_level = o + 2 * NQ;
+    B.match = o + 3 * NQ; B.nmatches = d_nq + nkf; B.overflow = w.overflow.as<int32_t>();
+    B.chi2 = chi2 > 0.0 ? chi2 : 0.0;
+    if (chi2 > 0.0)
+        for (int l = 0; l < 16; l++) B.inv_sigma2[l] = inv_level_sigma2[std::min(l, nlevels - 1)];
+    if ((rc = ensure_dyn_lds(reinterpret_cast<const void*>(&k_search_by_projection_batch), lds))) return rc;
+    hipLaunchKernelGGL(k_search_by_projection_batch, dim3(nkf), dim3(SBP_THREADS), lds, s, B, ncap, frame_bounds(cols, rows, bounds), 0, 256, 0.0f,
+                       0.0f, 0);
     ORBFE_HIP(hipGetLastError());
     return ORBFE_OK;
 }

@@ -164,6 +164,54 @@ for mode in (0, 1, 2):
             assert gnm[f] == wn and wn > 5 and np.array_equal(gmc[f, :nh[f]], wm), (f, gnm[f], wn)
 print("projection batch ok")
 
+# ---- Fuse over several resident keyframes (orbfe_fuse_search_batch_device; LocalMapping::SearchInNeighbors, LocalMapping.cc:850-858):
+# the map points seen by frame 0 fused into the three frames under three poses, against the per-keyframe entry point and the oracle
+sf = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
+for l in range(1, 8):
+    sf[l] = np.float32(sf[l - 1] * np.float32(1.2))
+isg = (1.0 / (sf * sf)).astype(np.float32)
+logsf = np.float32(np.log(np.float32(1.2)))
+k0, d0 = kh[0, :nh[0]], dh[0, :nh[0]]
+nmp = len(k0)
+z = rng.uniform(2.0, 6.0, nmp).astype(np.float32)
+x3 = np.stack([(k0["x"] - TUM1_K[2]) / TUM1_K[0] * z, (k0["y"] - TUM1_K[3]) / TUM1_K[1] * z, z], 1).astype(np.float32)
+dist3 = np.linalg.norm(x3, axis=1).astype(np.float32)
+max_d = (dist3 * sf[k0["octave"]]).astype(np.float32)
+min_d = (max_d / sf[7]).astype(np.float32)
+nrm = (x3 / dist3[:, None]).astype(np.float32)
+Tcws = np.zeros((3, 12), np.float32); Ows = np.zeros((3, 3), np.float32)
+for k in range(3):
+    T = np.eye(3, 4, dtype=np.float32); T[:, 3] = [0.02 * k, -0.01 * k, 0.01 * k]
+    Tcws[k] = T.reshape(-1); Ows[k] = -T[:, 3]
+fvalid = (rng.random((3, nmp)) < 0.9).astype(np.uint8)
+d_x3, d_min, d_max, d_nrm, d_mpd, d_fv = tdev(x3), tdev(min_d), tdev(max_d), tdev(nrm), tdev(d0), tdev(fvalid)
+d_bi, d_bd = i32(3 * nmp), i32(3 * nmp)
+cp = lambda a: a.ctypes.data_as(C.c_void_p)
+for chi2 in (5.99, 0.0):
+    for attempt in range(2):
+        rc = L.orbfe_fuse_search_batch_device(kun.data_ptr(), desc.data_ptr(), n.data_ptr(), cap, 3, 640, 480, bnd_p, d_x3.data_ptr(), d_fv.data_ptr(),
+                                              d_min.data_ptr(), d_max.data_ptr(), d_nrm.data_ptr(), d_mpd.data_ptr(), nmp, cp(Tcws), cp(Ows),
+                                              cp(TUM1_K), cp(sf), cp(isg), 8, logsf, np.float32(3.0), chi2, d_bi.data_ptr(), d_bd.data_ptr(), None)
+        assert rc == 0, L.orbfe_last_error()
+        ovf = C.c_int32(0)
+        assert L.orbfe_search_by_projection_batch_status(None, C.byref(ovf)) == 0
+        if not ovf.value:
+            break
+    assert ovf.value == 0
+    torch.cuda.synchronize()
+    gbi, gbd = d_bi.cpu().numpy().reshape(3, nmp), d_bd.cpu().numpy().reshape(3, nmp)
+    for k in range(3):
+        kf, df = kh[k, :nh[k]], dh[k, :nh[k]]
+        want = oracle.fuse_search(kf, df, 640, 480, x3, fvalid[k], min_d, max_d, nrm, d0, Tcws[k].reshape(3, 4), Ows[k], TUM1_K, sf, isg, logsf, 3.0, chi2,
+                                  bounds=bounds)
+        host = orbfe.fuse_search(kf, df, 640, 480, x3, fvalid[k], min_d, max_d, nrm, d0, Tcws[k].reshape(3, 4), Ows[k], TUM1_K, sf, isg, logsf, 3.0, chi2,
+                                 bounds=bounds)
+        assert np.array_equal(gbi[k], want[0]) and np.array_equal(gbd[k], want[1]), (chi2, k)
+        assert np.array_equal(host[0], want[0]) and np.array_equal(host[1], want[1])
+        if k == 0:
+            assert (gbd[0] == 0).sum() > 0.5 * nmp      # frame 0 under its own pose finds its own keypoints
+print("fuse batch ok")
+
 # ---- detector batch on device pointers + marker poses (MarkerDetector::detect with camera parameters, Frame.cc:142)
 import pose_cases as pc
 det = orbfe.MarkerDetector("ARUCO")
