@@ -268,7 +268,7 @@ struct orbfe_aruco {
         }
         timer.mark(aux_stream, "pyramid");
         ORBFE_HIP(hipEventRecord(ev_join, aux_stream));
-        if (!ORBFE_SKIP_ARUCO(8)) {
+        for (int r_ = 0; r_ < ORBFE_REPS_ARUCO(8); r_++) {
             const dim3 tg((cols + 63) / 64, (rows + 63) / 64, B);
             const int ntx = (cols + 63) / 64, ntl = ntx * ((rows + 63) / 64);
             const dim3 tg1(xcd_grid(ntl * B));
@@ -287,7 +287,7 @@ struct orbfe_aruco {
         auto kfn = big ? k_contours_t<false> : k_contours_t<true>;
         { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(kfn), (size_t)(lds)); if (rc_lds_) return rc_lds_; }
         const bool relay = relay_tbits && !force_legacy && !big_mode;
-        if (relay && !ORBFE_SKIP_ARUCO(1)) {
+        for (int r_ = 0; relay && r_ < ORBFE_REPS_ARUCO(1); r_++) {
             const size_t rlds = relay_lds_bytes(lds_bits_words, relay_kcap, relay_tbits);
             if (relay_global) {
                 { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(k_contours_relay8g), (size_t)(rlds)); if (rc_lds_) return rc_lds_; }
@@ -341,13 +341,13 @@ struct orbfe_aruco {
         hipLaunchKernelGGL(k_prefilter, dim3(B), dim3(256), 0, s, d_rects.as<ArRect>(), AR_MAX_RECTS,
                            d_counts.as<int32_t>(), cols, rows, win, d_candidx.as<int32_t>(), d_ncand.as<int32_t>());
         ORBFE_HIP(hipStreamWaitEvent(s, ev_join, 0));
-        if (!ORBFE_SKIP_ARUCO(2)) hipLaunchKernelGGL(k_decode, dim3(B), dim3(512), 0, s, src0, pyr, d_levels.as<ArLevel>(), npyr,
+        for (int r_ = 0; r_ < ORBFE_REPS_ARUCO(2); r_++) hipLaunchKernelGGL(k_decode, dim3(B), dim3(512), 0, s, src0, pyr, d_levels.as<ArLevel>(), npyr,
                            d_rects.as<ArRect>(), AR_MAX_RECTS, d_candidx.as<int32_t>(), d_ncand.as<int32_t>(), S, nb,
                            d_codes.as<unsigned long long>(), ncodes, d_scodes.as<unsigned long long>(), d_sids.as<int32_t>(), nsorted,
                            max_corr, d_result.as<int32_t>(), cols);
         timer.mark(s, "decode");
         ORBFE_HIP(hipMemsetAsync(d_msrc.p, 0xff, (size_t)AR_MAX_RECTS * 4 * B, s)); // -1: slot holds no marker
-        if (!ORBFE_SKIP_ARUCO(4)) hipLaunchKernelGGL(k_finalize, dim3(B), dim3(256), 0, s, d_rects.as<ArRect>(), AR_MAX_RECTS,
+        for (int r_ = 0; r_ < ORBFE_REPS_ARUCO(4); r_++) hipLaunchKernelGGL(k_finalize, dim3(B), dim3(256), 0, s, d_rects.as<ArRect>(), AR_MAX_RECTS,
                            d_candidx.as<int32_t>(), d_ncand.as<int32_t>(), d_result.as<int32_t>(),
                            d_pool.as<uint32_t>(), pool_fu32, d_out_m, capacity, d_n, corner_method == 1 ? 1 : 0, d_msrc.as<int32_t>());
         timer.mark(s, "finalize");

@@ -75,6 +75,17 @@ struct orbfe_extractor {
         d_flatkv, d_flatlvl;
     int blur_place = 1;                  // where the blur is forked: 1 in front of FAST (default), 0 after FAST, 2 no fork (main stream, before orient)
     bool gaussian_ed = false;            // orbfe_extractor_set_gaussian_taps: 18 34 48 56 48 34 18 instead of 18 34 49 55 49 34 18
+    // workgroups per CU the VALU-bound kernels may occupy (0 = what the hardware allows): the launch asks for LDS it does not use
+    // so that the other engine's latency-bound kernels (8 waves and 50-77 KB of LDS per workgroup) always find room on every CU
+    int occ_fast = env_int("ORBFE_OCC_FAST", 0), occ_blur = env_int("ORBFE_OCC_BLUR", 0), occ_orient = env_int("ORBFE_OCC_ORIENT", 0);
+    static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+    static size_t occ_lds(int per_cu, size_t static_bytes, size_t needed)
+    {
+        if (per_cu <= 0) return needed;
+        const size_t want = (size_t)160 * 1024 / per_cu;
+        const size_t dyn = want > static_bytes + 256 ? want - static_bytes - 256 : 0;
+        return dyn > needed ? dyn : needed;
+    }
     bool force_general_quadtree = false; // test hook: run the general kernel for every level
     int force_pyramid_depth = 0;         // test hook: shallow count pyramid so that levels fall back
     DevBuf d_in, d_kps, d_desc, d_nout; // staging for the host-pointer entry points
@@ -365,12 +376,18 @@ struct orbfe_extractor {
             ORBFE_HIP(hipEventRecord(ev_fork, s));
             ORBFE_HIP(hipStreamWaitEvent(aux_stream, ev_fork, 0));
             timer.mark(aux_stream, "blur7 starts", true);
-            if (!ORBFE_SKIP_ORB(8)) {
+            const size_t lds_blur = occ_lds(occ_blur, 64 * 74 * 2 /* k_blur7: 64 columns x BL_CP u16 */, 0);
+            if (lds_blur) {
+                int rc_lds_ = gaussian_ed ? ensure_dyn_lds(reinterpret_cast<const void*>(&k_blur7<true>), lds_blur)
+                                          : ensure_dyn_lds(reinterpret_cast<const void*>(&k_blur7<false>), lds_blur);
+                if (rc_lds_) return rc_lds_;
+            }
+            for (int r_ = 0; r_ < ORBFE_REPS_ORB(8); r_++) {
                 if (gaussian_ed)
-                    hipLaunchKernelGGL(k_blur7<true>, dim3(xcd_grid(ntiles * B)), dim3(256), 0, aux_stream, src0, pyr, blur, dg,
+                    hipLaunchKernelGGL(k_blur7<true>, dim3(xcd_grid(ntiles * B)), dim3(256), lds_blur, aux_stream, src0, pyr, blur, dg,
                                        d_tiles.as<uint32_t>(), ntiles, ntiles * B);
                 else
-                    hipLaunchKernelGGL(k_blur7<false>, dim3(xcd_grid(ntiles * B)), dim3(256), 0, aux_stream, src0, pyr, blur, dg,
+                    hipLaunchKernelGGL(k_blur7<false>, dim3(xcd_grid(ntiles * B)), dim3(256), lds_blur, aux_stream, src0, pyr, blur, dg,
                                        d_tiles.as<uint32_t>(), ntiles, ntiles * B);
             }
             timer.mark(aux_stream, "blur7");
@@ -386,9 +403,12 @@ struct orbfe_extractor {
             auto a16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
             const size_t lds = 4 * (a16((size_t)roi_pitch * roi_rows) + a16((size_t)map_pitch * map_rows) +
                                     a16((size_t)list_cap * 2));
-            { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(&k_fast_cells), (size_t)(lds)); if (rc_lds_) return rc_lds_; }
+            const size_t lds_need = lds;
+            (void)lds_need;
+            const size_t lds_fast = occ_lds(occ_fast, 0, lds);
+            { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(&k_fast_cells), (size_t)(lds_fast)); if (rc_lds_) return rc_lds_; }
             const int nx = (ncells_total + 3) / 4;
-            if (!ORBFE_SKIP_ORB(1)) hipLaunchKernelGGL(k_fast_cells, dim3(xcd_grid(nx * B)), dim3(256), lds, s, src0, pyr, dg,
+            for (int r_ = 0; r_ < ORBFE_REPS_ORB(1); r_++) hipLaunchKernelGGL(k_fast_cells, dim3(xcd_grid(nx * B)), dim3(256), lds_fast, s, src0, pyr, dg,
                                d_cellinfo.as<uint32_t>(), d_slots.as<uint32_t>(), slots_fu32,
                                d_cellcnt.as<int32_t>(), ncells_total, iniThFAST, minThFAST, roi_pitch, roi_rows,
                                map_pitch, map_rows, list_cap, nx, nx * B);
@@ -399,10 +419,14 @@ struct orbfe_extractor {
             // fast path: count-pyramid quadtree (no keypoint movement); general kernel only for flagged levels
             int max_ini = 1;
             for (const LevelGeom& g : geom) max_ini = std::max(max_ini, g.nIni);
-            const int D = force_pyramid_depth ? force_pyramid_depth : max_ini == 1 ? 6 : max_ini <= 4 ? 5 : 4;
+            // depth of the count pyramid: 1024 (2048) leaves for a level's 217 (434) nodes.  Its LDS decides how many of the
+            // nlevels x B workgroups are resident at once, and this kernel sits alone on the extractor's critical path: with six
+            // levels (4096 leaves, 54 KB, two workgroups per CU) the 2400 workgroups of a C2 batch ran in five rounds, 225 us;
+            // a level that needs more depth is flagged and redone by the general kernel
+            const int D = force_pyramid_depth ? force_pyramid_depth : max_ini <= 4 ? 5 : 4;
             const size_t lds_p = qp_lds_bytes(max_ini, D, nodecap, veccap);
             { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(&k_distribute_pyr), (size_t)(lds_p)); if (rc_lds_) return rc_lds_; }
-            if (!ORBFE_SKIP_ORB(2)) hipLaunchKernelGGL(k_distribute_pyr, dim3(nlevels, B), dim3(QP_THREADS), lds_p, s, dg, d_slots.as<uint32_t>(),
+            for (int r_ = 0; r_ < ORBFE_REPS_ORB(2); r_++) hipLaunchKernelGGL(k_distribute_pyr, dim3(nlevels, B), dim3(QP_THREADS), lds_p, s, dg, d_slots.as<uint32_t>(),
                                slots_fu32, d_cellcnt.as<int32_t>(), ncells_total, d_lvlout.as<uint32_t>(), out_total,
                                d_lvlcnt.as<int32_t>(), nlevels, d_lvlncand.as<int32_t>(), d_fallback.as<int32_t>(), D,
                                nodecap, veccap);
@@ -431,7 +455,9 @@ struct orbfe_extractor {
         } else
             ORBFE_HIP(hipStreamWaitEvent(s, ev_join, 0));
         const int okx = (std::min(capacity, max_keypoints()) + 3) / 4;
-        if (!ORBFE_SKIP_ORB(4)) hipLaunchKernelGGL(k_orient_describe, dim3(xcd_grid(okx * B)), dim3(256), 0, s, src0, pyr, blur, dg,
+        const size_t lds_orient = occ_lds(occ_orient, 4 * (31 * 36 + 12 + 37 * 40 + 8), 0);
+        if (lds_orient) { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(&k_orient_describe), lds_orient); if (rc_lds_) return rc_lds_; }
+        for (int r_ = 0; r_ < ORBFE_REPS_ORB(4); r_++) hipLaunchKernelGGL(k_orient_describe, dim3(xcd_grid(okx * B)), dim3(256), lds_orient, s, src0, pyr, blur, dg,
                            d_flatkv.as<uint32_t>(), d_flatlvl.as<uint8_t>(), d_n, nlevels, d_pattern.as<uint32_t>(),
                            d_umax.as<uint4>(), d_kps_out, d_desc_out, capacity, okx, okx * B);
         timer.mark(s, "orient_describe");

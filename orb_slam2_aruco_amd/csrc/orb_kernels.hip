@@ -868,7 +868,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_distribute_pyr(const LevelGeom* 
     const int T = off(D + 1);                     // total cells, depths 0..D
     const int nleaf = nIni << (2 * D);
     unsigned char* sp = qp_smem;
-    unsigned long long* best = (unsigned long long*)sp; sp += (size_t)nleaf * 8;
+    uint32_t* best = (uint32_t*)sp; sp += (size_t)nleaf * 4; // per leaf: response << 22 | (0x3fffff - order): max = best response, first in order
     unsigned long long* vec = (unsigned long long*)sp; sp += (size_t)veccap * 8;
     unsigned long long* vprev = (unsigned long long*)sp; sp += (size_t)veccap * 8;
     uint32_t* cellA = (uint32_t*)sp; sp += (size_t)nodecap * 4;
@@ -885,7 +885,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_distribute_pyr(const LevelGeom* 
 
     const int fl_idx = f * nlevels + level;
     for (int i = tid; i < (T + 1) / 2 + 2; i += QP_THREADS) cnt32[i] = 0;
-    for (int i = tid; i < nleaf; i += QP_THREADS) best[i] = 0ull;
+    for (int i = tid; i < nleaf; i += QP_THREADS) best[i] = 0u;
     if (tid == 0) s_ncand = 0;
     __syncthreads();
 
@@ -921,10 +921,8 @@ __global__ __launch_bounds__(QP_THREADS) void k_distribute_pyr(const LevelGeom* 
                 const uint32_t leaf = ((uint32_t)r << (2 * D)) + code;
                 const uint32_t ci = (uint32_t)off(D) + leaf;
                 atomicAdd(&cnt32[ci >> 1], (ci & 1) ? 0x10000u : 1u);
-                const unsigned long long ord = ((unsigned long long)c << 10) | (unsigned)(k0 + k); // vToDistributeKeys order
-                const unsigned long long key = ((unsigned long long)(kv[k] >> 24) << 46) | ((0x3fffffull - ord) << 24) |
-                                               (kv[k] & 0xffffffu);
-                atomicMax(&best[leaf], key);
+                const uint32_t ord = ((uint32_t)c << 10) | (uint32_t)(k0 + k); // vToDistributeKeys order = (cell, slot): the keypoint itself
+                atomicMax(&best[leaf], ((kv[k] >> 24) << 22) | (0x3fffffu - ord)); // is read back from its slot at the end
             }
         }
     }
@@ -1165,12 +1163,10 @@ __global__ __launch_bounds__(QP_THREADS) void k_distribute_pyr(const LevelGeom* 
             const int d = (iA[p] >> 20) & 15;
             const int sh = 2 * (D - d);
             const uint32_t l0 = cA[p] << sh, l1 = (cA[p] + 1) << sh;
-            unsigned long long b = 0;
-            for (uint32_t l = l0; l < l1; l++) {
-                const unsigned long long v = best[l];
-                b = v > b ? v : b;
-            }
-            outp[p] = (uint32_t)(b & 0xffffffu) | ((uint32_t)(b >> 46) << 24);
+            uint32_t b = 0;
+            for (uint32_t l = l0; l < l1; l++) b = max(b, best[l]);
+            const uint32_t ord = 0x3fffffu - (b & 0x3fffffu);
+            outp[p] = cslots[(size_t)(ord >> 10) * g.cell_cap + (ord & 1023u)];
         }
     }
     if (lane == 0) lvl_cnt[fl_idx] = L;

@@ -80,7 +80,7 @@ inline size_t qp_lds_bytes(int nIni, int D, int nodecap, int veccap)
 {
     const size_t nleaf = (size_t)nIni << (2 * D);
     const size_t T = (size_t)nIni * (((1u << (2 * (D + 1))) - 1) / 3);
-    size_t b = nleaf * 8 + (size_t)veccap * 16 + (size_t)nodecap * 24;
+    size_t b = nleaf * 4 + (size_t)veccap * 16 + (size_t)nodecap * 24;
     b += 2 * (((size_t)nodecap * 2 + 15) & ~(size_t)15);
     b += (T / 2 + 4) * 4;
     return b + 32;

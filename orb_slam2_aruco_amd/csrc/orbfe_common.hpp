@@ -22,9 +22,15 @@ extern thread_local char g_err[512];
 extern int g_orb_skip, g_aruco_skip;
 #define ORBFE_SKIP_ORB(bit) (::orbfe::g_orb_skip & (bit))
 #define ORBFE_SKIP_ARUCO(bit) (::orbfe::g_aruco_skip & (bit))
+// sensitivity instead of ablation: mask bit << 8 launches the kernel TWICE (same results; removing a kernel also removes the work of
+// everything downstream of it, doubling one does not) -- "how much does the step grow per microsecond of this kernel's work"
+#define ORBFE_REPS_ORB(bit) (ORBFE_SKIP_ORB(bit) ? 0 : (::orbfe::g_orb_skip & ((bit) << 8)) ? 2 : 1)
+#define ORBFE_REPS_ARUCO(bit) (ORBFE_SKIP_ARUCO(bit) ? 0 : (::orbfe::g_aruco_skip & ((bit) << 8)) ? 2 : 1)
 #else
 #define ORBFE_SKIP_ORB(bit) 0
 #define ORBFE_SKIP_ARUCO(bit) 0
+#define ORBFE_REPS_ORB(bit) 1
+#define ORBFE_REPS_ARUCO(bit) 1
 #endif
 
 inline int fail(int code, const char* fmt, ...)
