@@ -821,6 +821,16 @@ class MarkerDetector:
         _check(self.L, self.L.orbfe_aruco_debug_image(self.h, frame, 0, _p(out)), "debug_image")
         return out
 
+    def pyramid_level(self, level, frame=0):
+        """Debug: level >= 1 of the detector's /2 pyramid of the last batch (None past the last level)."""
+        out = np.zeros(self._shape, np.uint8)
+        if self.L.orbfe_aruco_debug_image(self.h, frame, level + 1, _p(out)) != 0:
+            return None
+        h, w = self._shape
+        for _ in range(level):
+            w, h = w // 2, h // 2        # exact halves only (the levels this accessor is for)
+        return out.reshape(-1)[:w * h].reshape(h, w).copy()
+
     def counts(self, frame=0):
         out = np.zeros(4, np.int32)
         _check(self.L, self.L.orbfe_aruco_debug_image(self.h, frame, 100, _p(out)), "debug_image")

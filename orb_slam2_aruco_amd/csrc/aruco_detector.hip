@@ -257,7 +257,10 @@ struct orbfe_aruco {
             const ArLevel& Lp = levels[p - 1];
             ImgView sv = (p == 1) ? src0 : ImgView{pyr.base + Lp.off, nullptr, pyr_fbytes, Lp.pitch};
             ImgView dv{pyr.base + L.off, pyr.base_w + L.off, pyr_fbytes, L.pitch};
-            if (lvl_exact[p]) {
+            if (lvl_exact[p] && sv.pitch % 8 == 0 && sv.fstride % 8 == 0 && ((uintptr_t)sv.base & 7) == 0 && dv.pitch % 4 == 0 && dv.pitch >= 4 * ((L.w + 3) / 4)) {
+                const int dw4 = (L.w + 3) / 4, nthreads = dw4 * ((L.h + 1) / 2);   // reads up to 2 * L.w + 6 < the source pitch (64-byte rows)
+                hipLaunchKernelGGL(k_half_area4, dim3((nthreads + 255) / 256, B), dim3(256), 0, aux_stream, sv, dv, dw4, L.h);
+            } else if (lvl_exact[p]) {
                 hipLaunchKernelGGL(k_half_area, dim3((L.w + 63) / 64, (L.h + 3) / 4, B), dim3(256), 0, aux_stream, sv, dv, L.w, L.h);
             } else {
                 const int dw4 = (L.w + 3) / 4;

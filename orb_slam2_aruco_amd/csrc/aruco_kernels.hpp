@@ -34,6 +34,7 @@ template <int WIN>
 __global__ void k_adaptive_threshold_t(ImgView src, int W, int H, int C, uint32_t magic, uint32_t* bits,
                                        size_t bits_fstride, int wpr, int ntx, int ntiles, int total);
 __global__ void k_half_area(ImgView src, ImgView dst, int dw, int dh);
+__global__ void k_half_area4(ImgView src, ImgView dst, int dw4, int dh);
 template <bool LDS_BITS>
 __global__ void k_contours_t(const uint32_t* gbits, size_t bits_fstride, int wpr_g, int W, int H, int lds_bits_words,
                            int min_len, uint32_t* candq, size_t candq_fstride, int candq_cap, uint32_t* pool,

@@ -154,6 +154,23 @@ def test_structured_binary_patterns(orbfe, oracle, pattern):
     assert np.array_equal(got["id"], want["id"])
 
 
+@pytest.mark.parametrize("rows,cols", [(480, 640), (472, 632), (240, 320)])
+def test_detector_pyramid_is_the_2x2_mean(orbfe, rows, cols):
+    """buildPyramid's exact /2 levels (markerdetector_impl.cpp:1299-1488: resize by exactly 1/2 = 2 x 2 mean, rounded): the
+    four-pixels-per-thread kernel against numpy, for row pitches with and without slack behind the last pixel."""
+    img = np.random.default_rng(rows).integers(0, 256, (rows, cols), dtype=np.uint8)
+    det = orbfe.MarkerDetector("ARUCO")
+    det.detect(img)
+    ref, level = img, 1
+    while ref.shape[1] % 2 == 0 and ref.shape[0] % 2 == 0 and ref.shape[1] // 2 > 70:
+        a = ref.astype(np.uint16)
+        ref = ((a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+        got = det.pyramid_level(level)
+        assert got is not None and got.shape == ref.shape and np.array_equal(got, ref), (level, ref.shape)
+        level += 1
+    assert level >= 3
+
+
 def test_big_frame_kernel_same_results(orbfe, oracle):
     """The big-frame contour kernel (bit image in HBM, 4096 kept contours) gives the same markers at an ordinary size."""
     img, _ = synth.scene(480, 640, 2, "ARUCO", 4)
