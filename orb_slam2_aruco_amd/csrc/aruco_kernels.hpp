@@ -103,7 +103,9 @@ __global__ void k_finalize(const ArRect* rects, int rect_cap, const int32_t* can
 #define RL_FLAG_BUG 64          // an invariant of the relay formulation failed: redone by k_contours_t as well
 #define RL_FALLBACK_FLAGS (RL_FLAG_TABLE | RL_FLAG_BUG)
 #define RL_KCAP AR_MAX_KEPT      // kept borders per frame (k_contours_relay + k_contours_tail)
+#ifndef RL_STEPS_PER_ITER
 #define RL_STEPS_PER_ITER 2      // walk steps between two looks at the work queue
+#endif
 // k_contours_small (phase (c) of frames with a grid, one wave per block of K rows x 256 columns): threads per workgroup, columns
 // per block (log2), tile words per row (the block's 8 + one to the left + one to the right + ring8()'s funnel word), tile rows
 // (K <= 128: K + 4), queue entries per wave (>= the start candidates one row of a block can have), rows per round, steps per

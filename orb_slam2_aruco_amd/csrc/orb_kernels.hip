@@ -1229,6 +1229,19 @@ __device__ __forceinline__ uint32_t bl_dot2(uint32_t a, uint32_t b, uint32_t c)
     return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b), c, false);
 }
 
+// right-border windows of bl_load_rows: v_perm selectors of the three window dwords and which dword pair each takes ({l1, l0} = 0,
+// {l2, l1} = 1; bits 0..2), indexed by r = w - x
+__device__ const uint4 bl_right_tab[8] = {
+    {0x00000000u, 0x00000000u, 0x00000000u, 0u},
+    {0x06050403u, 0x04050607u, 0x04050607u, 3u}, // r = 1
+    {0x05040302u, 0x05060706u, 0x01020304u, 7u}, // r = 2
+    {0x04030201u, 0x06070605u, 0x02030405u, 7u}, // r = 3
+    {0x07060504u, 0x07060504u, 0x03040506u, 6u}, // r = 4
+    {0x06050403u, 0x06050403u, 0x04050607u, 6u}, // r = 5
+    {0x05040302u, 0x05040302u, 0x05060706u, 6u}, // r = 6
+    {0x04030201u, 0x04030201u, 0x06070605u, 6u}, // r = 7
+};
+
 // One workgroup = one 64-column strip of a level, walked top to bottom in 64-row tiles.  The loads of the next tile's
 // rows are in flight while the vertical pass of the current one runs, and the six rows of horizontal sums two tiles
 // share are carried over in LDS instead of being recomputed, so every source row is fetched once per strip.
@@ -1247,7 +1260,24 @@ __device__ __forceinline__ void bl_load_rows(const uint8_t* img, int pitch, cons
             if (x >= 4 && x + 8 <= g.w) {
                 const u32_unaligned* p = reinterpret_cast<const u32_unaligned*>(row + x - 4);
                 w[k][0] = p[0]; w[k][1] = p[1]; w[k][2] = p[2];
-            } else { // the window crosses the left or right image border: BORDER_REFLECT_101 byte by byte
+            } else if (g.w >= 16 && x == 0) {
+                // left border, BORDER_REFLECT_101: pixels -4 .. -1 are pixels 4 .. 1 -- one v_perm on the two dwords the window has anyway
+                const u32_unaligned* p = reinterpret_cast<const u32_unaligned*>(row);
+                const uint32_t d0 = p[0], d1 = p[1];
+                w[k][0] = __builtin_amdgcn_perm(d1, d0, 0x01020304u); w[k][1] = d0; w[k][2] = d1;
+            } else if (g.w >= 16 && x < g.w) {
+                // right border: r = w - x (1 .. 7) pixels of the window's centre dword are inside.  Every window byte, reflected or not,
+                // is one of the row's last 12 pixels: three dwords, and per window dword one v_perm on two of them with a selector
+                // that depends only on r (bl_right_tab: byte j <- pixel index 8 - r + j inside, 14 + r - j reflected)
+                const u32_unaligned* p = reinterpret_cast<const u32_unaligned*>(row + g.w - 12);
+                const uint32_t l0 = p[0], l1 = p[1], l2 = p[2];
+                const uint4 s = bl_right_tab[g.w - x];
+                w[k][0] = (s.w & 1u) ? __builtin_amdgcn_perm(l2, l1, s.x) : __builtin_amdgcn_perm(l1, l0, s.x);
+                w[k][1] = (s.w & 2u) ? __builtin_amdgcn_perm(l2, l1, s.y) : __builtin_amdgcn_perm(l1, l0, s.y);
+                w[k][2] = (s.w & 4u) ? __builtin_amdgcn_perm(l2, l1, s.z) : __builtin_amdgcn_perm(l1, l0, s.z);
+            } else if (g.w >= 16) {
+                // columns of the blurred row's padding (x >= w): nobody reads them
+            } else { // levels narrower than 16 pixels: BORDER_REFLECT_101 byte by byte
 #pragma unroll
                 for (int j = 1; j <= 10; j++)
                     w[k][j >> 2] |= (uint32_t)row[reflect101(x - 4 + j, g.w)] << (8 * (j & 3));
