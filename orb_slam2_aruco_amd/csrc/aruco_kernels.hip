@@ -131,9 +131,18 @@ __global__ __launch_bounds__(256) void k_adaptive_threshold_t(ImgView src, int W
 #pragma unroll
                 for (int j = 0; j < NDW; j++) w[k][j] = reinterpret_cast<const u32_unaligned_t*>(row + x - LEAD)[j];
             } else {
+                // the window crosses the left or right image border (BORDER_REPLICATE).  Its dwords start at multiples of four, so
+                // a dword is either inside (loaded), left of the image (pixel 0 four times) or at / beyond the right edge: its
+                // pixels then come out of the row's last four with one v_perm (n_in = 3, 2, 1, <= 0 pixels of it are inside)
+                const uint32_t first = reinterpret_cast<const u32_unaligned_t*>(row)[0];
+                const uint32_t last = reinterpret_cast<const u32_unaligned_t*>(row + W - 4)[0];
 #pragma unroll
-                for (int j = 0; j < 4 * NDW; j++)
-                    w[k][j >> 2] |= (uint32_t)row[min(max(x - LEAD + j, 0), W - 1)] << (8 * (j & 3));
+                for (int j = 0; j < NDW; j++) {
+                    const int q = x - LEAD + 4 * j, n_in = W - q;
+                    if (q < 0) w[k][j] = __builtin_amdgcn_perm(0u, first, 0x00000000u);
+                    else if (n_in >= 4) w[k][j] = reinterpret_cast<const u32_unaligned_t*>(row + q)[0];
+                    else w[k][j] = __builtin_amdgcn_perm(0u, last, n_in <= 1 ? 0x03030303u : n_in == 2 ? 0x03030302u : 0x03030201u);
+                }
             }
         }
     }

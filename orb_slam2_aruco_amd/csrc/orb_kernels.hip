@@ -1260,12 +1260,13 @@ __device__ __forceinline__ void bl_load_rows(const uint8_t* img, int pitch, cons
             if (x >= 4 && x + 8 <= g.w) {
                 const u32_unaligned* p = reinterpret_cast<const u32_unaligned*>(row + x - 4);
                 w[k][0] = p[0]; w[k][1] = p[1]; w[k][2] = p[2];
-            } else if (g.w >= 16 && x == 0) {
+            } else if (x == 0) {
                 // left border, BORDER_REFLECT_101: pixels -4 .. -1 are pixels 4 .. 1 -- one v_perm on the two dwords the window has anyway
+                // (a level is at least 68 pixels wide, orb_extractor.hip build_geometry)
                 const u32_unaligned* p = reinterpret_cast<const u32_unaligned*>(row);
                 const uint32_t d0 = p[0], d1 = p[1];
                 w[k][0] = __builtin_amdgcn_perm(d1, d0, 0x01020304u); w[k][1] = d0; w[k][2] = d1;
-            } else if (g.w >= 16 && x < g.w) {
+            } else if (x < g.w) {
                 // right border: r = w - x (1 .. 7) pixels of the window's centre dword are inside.  Every window byte, reflected or not,
                 // is one of the row's last 12 pixels: three dwords, and per window dword one v_perm on two of them with a selector
                 // that depends only on r (bl_right_tab: byte j <- pixel index 8 - r + j inside, 14 + r - j reflected)
@@ -1275,13 +1276,7 @@ __device__ __forceinline__ void bl_load_rows(const uint8_t* img, int pitch, cons
                 w[k][0] = (s.w & 1u) ? __builtin_amdgcn_perm(l2, l1, s.x) : __builtin_amdgcn_perm(l1, l0, s.x);
                 w[k][1] = (s.w & 2u) ? __builtin_amdgcn_perm(l2, l1, s.y) : __builtin_amdgcn_perm(l1, l0, s.y);
                 w[k][2] = (s.w & 4u) ? __builtin_amdgcn_perm(l2, l1, s.z) : __builtin_amdgcn_perm(l1, l0, s.z);
-            } else if (g.w >= 16) {
-                // columns of the blurred row's padding (x >= w): nobody reads them
-            } else { // levels narrower than 16 pixels: BORDER_REFLECT_101 byte by byte
-#pragma unroll
-                for (int j = 1; j <= 10; j++)
-                    w[k][j >> 2] |= (uint32_t)row[reflect101(x - 4 + j, g.w)] << (8 * (j & 3));
-            }
+            } // else: columns of the blurred row's padding (x >= w): nobody reads them
         }
     }
 }
