@@ -383,7 +383,7 @@ __device__ bool convex4(const ApPt* p)
 // Last phases of both contour kernels: sort the kept borders into findContours' order (reverse discovery), run
 // approxPolyDP(eps = 0.05 * len) + the convexity test on each (one wave per border), compact the 4-gons in order and
 // write the per-frame counts.  All NT (a multiple of 64) remaining threads of the workgroup call it.
-__device__ void contours_tail(int f, int tid, int NT, int nkept, unsigned long long* kkey, const int* off_u, int* klen,
+__device__ __forceinline__ void contours_tail(int f, int tid, int NT, int nkept, unsigned long long* kkey, const int* off_u, int* klen,
                               int* koff, int* rectflag, ApPt* ap_out, int2* ap_stack, const uint32_t* pl,
                               ArKept* __restrict__ kept_out, int kept_cap, ArRect* __restrict__ rects_out, int rect_cap,
                               int32_t* __restrict__ counts, int* s_flags, const int* s_ncand, uint16_t* rank_of,

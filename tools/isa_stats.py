@@ -5,7 +5,7 @@ for ln in open(sys.argv[1]):
     m = re.match(r'^(_Z\w+):', ln)
     if m: cur = m.group(1); stats[cur] = collections.Counter(); continue
     if cur and re.match(r'^\s+(v_|s_|ds_|global_|buffer_|flat_|scratch_)', ln): stats[cur][ln.split()[0]] += 1
-    if 's_endpgm' in ln: cur = None
+    if ln.startswith('.Lfunc_end'): cur = None
 for k, c in stats.items():
     if not c: continue
     g = lambda pre: sum(n for o, n in c.items() if o.startswith(pre))
