@@ -1800,6 +1800,7 @@ __device__ bool solve8_wave(double a[8], double b, int lane, double x[8])
 //   C (wave per candidate): warp again against the threshold -> cell votes, border check, 4 rotations, dictionary.
 #define DC_WAVES 8
 #define DC_MAXC 32 // candidates handled per pass (the workgroup loops if a frame has more)
+#define DC_PXCAP 1232 // bytes per kept patch: 35 x 35, the warp size of every configuration the detector is used in here
 
 struct DcCand {
     double Mi[9];
@@ -1847,6 +1848,10 @@ __global__ __launch_bounds__(DC_WAVES * 64) void k_decode(ImgView src0, ImgView 
     __shared__ int s_ones[DC_WAVES][64], s_tot[DC_WAVES][64];
     __shared__ uint8_t s_bits[DC_WAVES][64];
     __shared__ unsigned long long s_ids[DC_WAVES][4];
+    // the warped S x S patch of every candidate of the pass: phase C reads it back instead of warping again (per pixel three f64
+    // multiply-adds, an f64 division and four dependent byte loads); a warp size whose patch does not fit is warped twice as before
+    __shared__ uint8_t s_px[DC_MAXC][DC_PXCAP];
+    const bool keep_px = S * S <= DC_PXCAP;
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int nc = ncand[f];
     for (int c0 = 0; c0 < nc; c0 += DC_MAXC) {
@@ -1923,7 +1928,9 @@ __global__ __launch_bounds__(DC_WAVES * 64) void k_decode(ImgView src0, ImgView 
                 const int pitch = (lvl == 0) ? src0.pitch : L.pitch;
                 for (int i = lane; i < S * S; i += 64) {
                     const int y = i / S, xx = i - y * S;
-                    atomicAdd(&s_hist[c][dc_warp_pixel(Mi, y, xx, img, pitch, L.w, L.h)], 1u);
+                    const int v = dc_warp_pixel(Mi, y, xx, img, pitch, L.w, L.h);
+                    atomicAdd(&s_hist[c][v], 1u);
+                    if (keep_px) s_px[c][i] = (uint8_t)v;
                 }
             }
         }
@@ -1976,7 +1983,8 @@ __global__ __launch_bounds__(DC_WAVES * 64) void k_decode(ImgView src0, ImgView 
                 const int y = i / S, xx = i - y * S;
                 const int my = (int)__fdiv_rn(__fmul_rn((float)n, (float)y), (float)S);
                 const int mx = (int)__fdiv_rn(__fmul_rn((float)n, (float)xx), (float)S);
-                if (dc_warp_pixel(Mi, y, xx, img, pitch, L.w, L.h) > th) atomicAdd(&s_ones[wid][my * n + mx], 1);
+                const int v = keep_px ? (int)s_px[c][i] : dc_warp_pixel(Mi, y, xx, img, pitch, L.w, L.h);
+                if (v > th) atomicAdd(&s_ones[wid][my * n + mx], 1);
                 atomicAdd(&s_tot[wid][my * n + mx], 1);
             }
             __builtin_amdgcn_wave_barrier();
