@@ -344,7 +344,7 @@ struct orbfe_aruco {
         hipLaunchKernelGGL(k_prefilter, dim3(B), dim3(256), 0, s, d_rects.as<ArRect>(), AR_MAX_RECTS,
                            d_counts.as<int32_t>(), cols, rows, win, d_candidx.as<int32_t>(), d_ncand.as<int32_t>());
         ORBFE_HIP(hipStreamWaitEvent(s, ev_join, 0));
-        for (int r_ = 0; r_ < ORBFE_REPS_ARUCO(2); r_++) hipLaunchKernelGGL(k_decode, dim3(B), dim3(512), 0, s, src0, pyr, d_levels.as<ArLevel>(), npyr,
+        for (int r_ = 0; r_ < ORBFE_REPS_ARUCO(2); r_++) hipLaunchKernelGGL(k_decode, dim3(B), dim3(DC_WAVES * 64), 0, s, src0, pyr, d_levels.as<ArLevel>(), npyr,
                            d_rects.as<ArRect>(), AR_MAX_RECTS, d_candidx.as<int32_t>(), d_ncand.as<int32_t>(), S, nb,
                            d_codes.as<unsigned long long>(), ncodes, d_scodes.as<unsigned long long>(), d_sids.as<int32_t>(), nsorted,
                            max_corr, d_result.as<int32_t>(), cols);

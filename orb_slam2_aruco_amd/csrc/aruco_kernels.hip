@@ -1798,7 +1798,6 @@ __device__ bool solve8_wave(double a[8], double b, int lane, double x[8])
 //     ties that the rounding noise decides), so each candidate needs ~256 dependent double divisions; side by side in
 //     the lanes of one wave they cost one candidate's latency for the whole frame.
 //   C (wave per candidate): warp again against the threshold -> cell votes, border check, 4 rotations, dictionary.
-#define DC_WAVES 8
 #define DC_MAXC 32 // candidates handled per pass (the workgroup loops if a frame has more)
 #define DC_PXCAP 1232 // bytes per kept patch: 35 x 35, the warp size of every configuration the detector is used in here
 

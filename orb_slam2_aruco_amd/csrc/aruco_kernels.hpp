@@ -86,6 +86,9 @@ __global__ void k_finalize(const ArRect* rects, int rect_cap, const int32_t* can
 #define AP_OUT 64
 #define CT_PROBE 24 // steps a border start is followed before it is queued as a long walk (< the 70-point gate)
 
+#ifndef DC_WAVES
+#define DC_WAVES 8   // k_decode: waves per frame (one candidate per wave at a time)
+#endif
 #ifndef RL_THREADS
 #define RL_THREADS 512   // 8 waves per frame: measured against 1024 (contours alone 713 -> 640 us per 300 frames, step 2.00 -> 1.95 ms) and 256 (893 us)
 #endif
