@@ -442,25 +442,28 @@ __global__ __launch_bounds__(SFI_THREADS) void k_search_init(const orbfe_keypoin
         const uint16_t* ri = cidx + (size_t)i1 * row_stride;
         const uint8_t* rd = cdist + (size_t)i1 * row_stride;
         // best = first minimum among candidates with vMatchedDistance[i2] > dist; second = next smallest
-        unsigned long long bestk = ~0ull, secondk = ~0ull;
+        // key = distance (8 bits; 255 = "255 or 256", far above TH_LOW) | candidate position (10) | rank (10): the order of the
+        // keys is (distance, position), so the wave minimum is the first minimum -- on 32-bit DPP reductions
+        constexpr int NONE = 0x7fffffff;
+        int bestk = NONE, secondk = NONE;
         for (int j0 = 0; j0 < e; j0 += 64) {
             const int j = j0 + lane;
-            unsigned long long key = ~0ull;
+            int key = NONE;
             if (j < e) {
                 const bool l = in_lds && j0 == 0;
                 const int rk = l ? (int)s_ridx[q * SFI_ROW + j] : (int)ri[j], d = l ? (int)s_rdist[q * SFI_ROW + j] : (int)rd[j];
-                if (!(s_vdist[rk] <= d)) key = ((unsigned long long)d << 32) | ((unsigned long long)j << 16) | (unsigned)rk;
+                if (!(s_vdist[rk] <= d)) key = (d << 20) | (j << 10) | rk;
             }
-            const unsigned long long m1 = wave_min_u64(key);
-            const unsigned long long k2nd = wave_min_u64(key == m1 ? ~0ull : key);
+            const int m1 = wave_min(key);
+            const int k2nd = wave_min(key == m1 ? NONE : key);
             // merge (m1, k2nd) into (bestk, secondk); earlier chunks hold earlier candidates
             if (m1 < bestk) { secondk = min(bestk, k2nd); bestk = m1; }
             else secondk = min(secondk, m1);
         }
-        if (bestk == ~0ull) continue;
-        const int bestDist = (int)(bestk >> 32);
-        const int bestDist2 = secondk == ~0ull ? INT_MAX : (int)(secondk >> 32);
-        const int bestRank = (int)(bestk & 0xffffu);
+        if (bestk == NONE) continue;
+        const int bestDist = bestk >> 20;
+        const int bestDist2 = secondk == NONE ? INT_MAX : secondk >> 20;
+        const int bestRank = bestk & 0x3ff;
         if (bestDist <= 50) { // TH_LOW
             if ((float)bestDist < __fmul_rn((float)bestDist2, nnratio)) {
                 const int old = s_v21[bestRank];
