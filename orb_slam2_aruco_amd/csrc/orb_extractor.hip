@@ -345,7 +345,8 @@ struct orbfe_extractor {
         timer.begin();
         timer.mark(s, "start");
         ORBFE_HIP(hipMemsetAsync(d_overflow.p, 0, 4, s));
-        for (int l = 1; l < nlevels && !ORBFE_SKIP_ORB(16); l++) {
+        for (int r16_ = 0; r16_ < ORBFE_REPS_ORB(16); r16_++)
+        for (int l = 1; l < nlevels; l++) {
             const LevelGeom& g = geom[l];
             const LevelGeom& gp = geom[l - 1];
             ImgView sv = (l == 1) ? src0 : ImgView{pyr.base + gp.img_off, nullptr, pyr_fbytes, gp.pitch};

@@ -9,6 +9,7 @@ this class against the oracle, so the tested code is the benchmarked code.  torc
 events, torch.distributed); every computation is a call into liborbfe.so.
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -97,7 +98,6 @@ class FrontEndPipeline:
         B = frames
         S = self.S = max(1, min(splits, B // 2))
         self.bounds = [B * k // S for k in range(S + 1)]          # sub-batch k = frames bounds[k] .. bounds[k+1]
-        import os
         # Engine sets (experiment, ORBFE_ENGINE_SETS): consecutive batches alternate between D sets of handles and streams (a set
         # owns its pyramid, candidate and contour workspaces), so that batch i + 1's resize / FAST run next to batch i's quadtree /
         # descriptors instead of queueing behind them.  Measured on the C2 batch: 1.89 ms with one set, 2.02 (4 hardware queues)
@@ -213,6 +213,8 @@ class FrontEndPipeline:
                 self.ex_done[cur][k].record(st)
                 self.stream3.wait_event(self.ex_done[cur][k])
             self.enqueue_matching(cur)
+            if os.environ.get("ORBFE_MATCH_TWICE"):      # sensitivity study only (tools/sensitivity.sh): the matching launched twice
+                self.enqueue_matching(cur)
         if multi:
             # the batch's one collective, on its own stream: it waits for the engines of THIS batch and runs
             # while the next batch is computed into the other record set

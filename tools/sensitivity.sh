@@ -17,4 +17,6 @@ ORBFE_ORB_SKIP=$((2<<8)) run "quadtree twice (+85)"
 ORBFE_ARUCO_SKIP=$((1<<8)) run "contours twice (+670)"
 ORBFE_ARUCO_SKIP=$((2<<8)) run "decode twice (+170)"
 ORBFE_ARUCO_SKIP=$((8<<8)) run "threshold twice (+100)"
+ORBFE_ORB_SKIP=$((16<<8)) run "resize chain twice (+190)"
+ORBFE_MATCH_TWICE=1 run "knn2 + search_init twice (+290)"
 done
