@@ -1745,35 +1745,49 @@ __device__ __forceinline__ double shfl_d(double v, int src)
 // 8x8 linear system by Gaussian elimination with partial pivoting, one row per lane (lanes 0..7), same operation
 // order per element as the serial loop in the oracle (so the results are bit-identical).  Returns false if singular;
 // x[k] (all lanes) = solution.
-__device__ bool solve8_wave(double a[8], double b, int lane, double x[8])
+// value of lane `src` (wave-uniform) in every lane: v_readlane_b32 through a scalar register -- a few cycles, where ds_bpermute
+// (__shfl) is an LDS round trip; the elimination below makes ~400 such broadcasts per candidate, one after the other
+__device__ __forceinline__ double rl_d(double v, int src)
+{
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, src);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), src);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+__device__ __forceinline__ bool solve8_wave(double a[8], double b, int lane, double x[8])
 {
 #pragma unroll
     for (int c = 0; c < 8; c++) {
-        // pivot: first row r >= c with the largest |a[r][c]|
-        double v = (lane >= c && lane < 8) ? fabs(a[c]) : -1.0;
-        int piv = lane;
+        // pivot: first row r >= c with the largest |a[r][c]| (rows live in lanes 0..7; everything here is wave-uniform)
+        const double mine = fabs(a[c]);
+        double v = rl_d(mine, c);
+        int piv = c;
 #pragma unroll
-        for (int o = 4; o > 0; o >>= 1) {
-            const double ov = shfl_d(v, lane ^ o);
-            const int op = __shfl(piv, lane ^ o);
-            if (ov > v || (ov == v && op < piv)) { v = ov; piv = op; }
+        for (int r = c + 1; r < 8; r++) {
+            const double ov = rl_d(mine, r);
+            if (ov > v) { v = ov; piv = r; }
         }
-        v = shfl_d(v, 0);
-        piv = __shfl(piv, 0);
         if (!(v > 0.0)) return false;
+        piv = __builtin_amdgcn_readfirstlane(piv);
         // swap rows c and piv
-        const int src = (lane == c) ? piv : (lane == piv) ? c : lane;
+        if (piv != c) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) a[k] = shfl_d(a[k], src);
-        b = shfl_d(b, src);
+            for (int k = 0; k < 8; k++) {
+                const double rc = rl_d(a[k], c), rp = rl_d(a[k], piv);
+                a[k] = lane == c ? rp : lane == piv ? rc : a[k];
+            }
+            const double bc = rl_d(b, c), bp = rl_d(b, piv);
+            b = lane == c ? bp : lane == piv ? bc : b;
+        }
         // eliminate below
-        const double pc = shfl_d(a[c], c);
-        const double pb = shfl_d(b, c);
+        const double pc = rl_d(a[c], c);
+        const double pb = rl_d(b, c);
         const bool below = lane > c && lane < 8;
         const double f = below ? a[c] / pc : 0.0;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            const double pk = shfl_d(a[k], c);
+            const double pk = rl_d(a[k], c);
             if (k >= c && below && f != 0.0) a[k] -= f * pk;
         }
         if (below && f != 0.0) b -= f * pb;
@@ -1786,7 +1800,7 @@ __device__ bool solve8_wave(double a[8], double b, int lane, double x[8])
         for (int k = 0; k < 8; k++)
             if (k > r) s -= a[k] * x[k];
         const double xr = s / a[r];
-        x[r] = shfl_d(xr, r);
+        x[r] = rl_d(xr, r);
     }
     return true;
 }
@@ -2011,13 +2025,18 @@ __global__ __launch_bounds__(DC_WAVES * 64) void k_decode(ImgView src0, ImgView 
             int id = -1, nrot = 0;
             if (!bad && s_ids[wid][0] != 0) {
                 // first rotation whose code is in the dictionary; id = first index holding that code (map.insert semantics)
-                for (int rr = 0; rr < 4; rr++) {
-                    const unsigned long long want = s_ids[wid][rr];
+                // one pass over the dictionary for all four rotations (four passes, each a chain of cache round trips and a wave
+                // reduction, were a third of this kernel's time): key = rotation << 24 | index, the minimum is the answer
+                {
+                    const unsigned long long w0 = s_ids[wid][0], w1 = s_ids[wid][1], w2 = s_ids[wid][2], w3 = s_ids[wid][3];
                     int best = 0x7fffffff;
-                    for (int i = lane; i < ncodes; i += 64)
-                        if (codes[i] == want) best = min(best, i);
+                    for (int i = lane; i < ncodes; i += 64) {
+                        const unsigned long long c = codes[i];
+                        const int k = c == w0 ? i : c == w1 ? (1 << 24) | i : c == w2 ? (2 << 24) | i : c == w3 ? (3 << 24) | i : 0x7fffffff;
+                        best = min(best, k);
+                    }
                     best = wave_min(best);
-                    if (best != 0x7fffffff) { id = best; nrot = rr; break; }
+                    if (best != 0x7fffffff) { id = best & 0xffffff; nrot = best >> 24; }
                 }
                 if (id < 0 && max_corr > 0) {
                     // error correction (dictionary_based.cpp:1423-1560): the dictionary's code map in ascending code order, the four
