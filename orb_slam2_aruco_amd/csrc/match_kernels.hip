@@ -275,8 +275,8 @@ __global__ __launch_bounds__(SFI_THREADS) void k_search_init(const orbfe_keypoin
     __shared__ int s_hist[30];
     __shared__ int s_nl0, s_nq;
     __shared__ uint16_t s_query[SFI_MAXL0];  // level-0 keypoints of F1 in index order (the only ones that search)
-    __shared__ int s_vdist[SFI_MAXL0];       // vMatchedDistance / vnMatches21, indexed by the RANK of an F2 keypoint
-    __shared__ int s_v21[SFI_MAXL0];         //   in s_sorted (only level-0 keypoints of F2 can ever be matched)
+    __shared__ uint32_t s_state[SFI_MAXL0];  // vMatchedDistance << 16 | (position of the query in vnMatches21 + 1), indexed by the RANK of
+                                             //   an F2 keypoint in s_sorted (only level-0 keypoints of F2 can ever be matched)
     __shared__ float s_ang1[SFI_MAXL0], s_ang2[SFI_MAXL0];
     __shared__ signed char s_rotbin[SFI_MAXL0]; // per query: histogram bin or -1
     float2* s2xy = (float2*)sfi_smem;
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(SFI_THREADS) void k_search_init(const orbfe_keypoin
     for (int i = tid; i < nl0; i += SFI_THREADS) {
         const int i2 = s_sorted[i] & 0xffff;
         const orbfe_keypoint kp2 = k2[i2];
-        s_vdist[i] = INT_MAX; s_v21[i] = -1; s_ang2[i] = kp2.angle;
+        s_state[i] = 0xffff0000u; s_ang2[i] = kp2.angle;
         if (i < SFI_L0_LDS) {
             s2xy[i] = make_float2(kp2.x, kp2.y);
             s2d[2 * i] = reinterpret_cast<const uint4*>(d2)[2 * i2];
@@ -431,62 +431,90 @@ __global__ __launch_bounds__(SFI_THREADS) void k_search_init(const orbfe_keypoin
     if (wid != 0) return;
 
     // ---- phase C: the serial matching loop (ORBmatcher.cc:423-490), wave 0.  All loop-carried state and (normally)
-    // all candidate rows are in LDS.
-    int nmatches = 0;
+    // all candidate rows are in LDS.  The loop carries only what couples the queries -- vMatchedDistance / vnMatches21 per F2
+    // keypoint and which query currently holds it; everything else (vnMatches12 in HBM, the rotation bins) is written by all
+    // lanes after the loop from two per-query records: the rank a query was accepted with (rotHist keeps it even if the match
+    // is stolen later, :470-488) and the rank it still holds.  The per-keypoint word holds query POSITIONS.
+    uint16_t* s_acc = reinterpret_cast<uint16_t*>(s_ang1);      // per query: rank accepted with, or NIL (s_ang1 is re-read from HBM below)
+    uint16_t* s_held = s_acc + SFI_MAXL0;                       // per query: rank still held, or NIL
+    constexpr int NIL = 0xffff;
+    for (int i = lane; i < nq; i += 64) { s_acc[i] = NIL; s_held[i] = NIL; }
+    __builtin_amdgcn_wave_barrier();
     const float factor = 1.0f / 30; // HISTO_LENGTH; the upstream "1/30" quirk is kept (App. D)
+    // The loop is a chain of dependent LDS round trips and wave reductions, 217 times; so (1) the first 64 candidates of query
+    // q + 1 are fetched while query q is reduced, (2) vMatchedDistance and vnMatches21 of a keypoint are one word, read once per
+    // candidate, and the lane that holds the winning candidate does the bookkeeping with the word it already has.
+    auto row0 = [&](int q, int& e, int& rk, int& d) {
+        e = __builtin_amdgcn_readfirstlane((int)s_cnt[q]);
+        rk = 0; d = 0;
+        if (lane < e) {
+            if (q < SFI_ROWQ) { rk = s_ridx[q * SFI_ROW + lane]; d = s_rdist[q * SFI_ROW + lane]; }
+            else { const size_t o = (size_t)s_query[q] * row_stride + lane; rk = cidx[o]; d = cdist[o]; }
+        }
+    };
+    constexpr int NONE = 0x7fffffff;
+    int e_n = 0, rk_n = 0, d_n = 0;
+    if (nq > 0) row0(0, e_n, rk_n, d_n);
     for (int q = 0; q < nq; q++) {
-        const int i1 = s_query[q];
-        const int e = s_cnt[q];
+        const int e = e_n, rk0 = rk_n, d0 = d_n;
+        if (q + 1 < nq) row0(q + 1, e_n, rk_n, d_n);
         if (e <= 0) continue;
-        const bool in_lds = q < SFI_ROWQ;
-        const uint16_t* ri = cidx + (size_t)i1 * row_stride;
-        const uint8_t* rd = cdist + (size_t)i1 * row_stride;
-        // best = first minimum among candidates with vMatchedDistance[i2] > dist; second = next smallest
+        // best = first minimum among candidates with vMatchedDistance[i2] > dist; second = next smallest.
         // key = distance (8 bits; 255 = "255 or 256", far above TH_LOW) | candidate position (10) | rank (10): the order of the
         // keys is (distance, position), so the wave minimum is the first minimum -- on 32-bit DPP reductions
-        constexpr int NONE = 0x7fffffff;
-        int bestk = NONE, secondk = NONE;
-        for (int j0 = 0; j0 < e; j0 += 64) {
-            const int j = j0 + lane;
-            int key = NONE;
-            if (j < e) {
-                const bool l = in_lds && j0 == 0;
-                const int rk = l ? (int)s_ridx[q * SFI_ROW + j] : (int)ri[j], d = l ? (int)s_rdist[q * SFI_ROW + j] : (int)rd[j];
-                if (!(s_vdist[rk] <= d)) key = (d << 20) | (j << 10) | rk;
+        const uint32_t st0 = lane < e ? s_state[rk0] : 0u;
+        int key = (lane < e && (int)(st0 >> 16) > d0) ? (d0 << 20) | (lane << 10) | rk0 : NONE;
+        int bestk = wave_min(key);
+        int secondk = wave_min(key == bestk ? NONE : key);
+        if (e > 64) { // rows longer than one wave: the later candidates from the query's global row
+            const size_t o = (size_t)s_query[q] * row_stride;
+            for (int j0 = 64; j0 < e; j0 += 64) {
+                const int j = j0 + lane;
+                int k2 = NONE;
+                if (j < e) {
+                    const int rk = cidx[o + j], d = cdist[o + j];
+                    if ((int)(s_state[rk] >> 16) > d) k2 = (d << 20) | (j << 10) | rk;
+                }
+                const int m1 = wave_min(k2);
+                const int k2nd = wave_min(k2 == m1 ? NONE : k2);
+                if (m1 < bestk) { secondk = min(bestk, k2nd); bestk = m1; }
+                else secondk = min(secondk, m1);
             }
-            const int m1 = wave_min(key);
-            const int k2nd = wave_min(key == m1 ? NONE : key);
-            // merge (m1, k2nd) into (bestk, secondk); earlier chunks hold earlier candidates
-            if (m1 < bestk) { secondk = min(bestk, k2nd); bestk = m1; }
-            else secondk = min(secondk, m1);
         }
         if (bestk == NONE) continue;
         const int bestDist = bestk >> 20;
         const int bestDist2 = secondk == NONE ? INT_MAX : secondk >> 20;
-        const int bestRank = bestk & 0x3ff;
-        if (bestDist <= 50) { // TH_LOW
-            if ((float)bestDist < __fmul_rn((float)bestDist2, nnratio)) {
-                const int old = s_v21[bestRank];
-                if (old >= 0) {
-                    if (lane == 0) m12[old] = -1;
-                    nmatches--;
-                }
-                if (lane == 0) {
-                    m12[i1] = (int)(s_sorted[bestRank] & 0xffff);
-                    s_v21[bestRank] = i1;
-                    s_vdist[bestRank] = bestDist;
-                }
-                nmatches++;
-                if (check_ori) {
-                    float rot = s_ang1[q] - s_ang2[bestRank];
-                    if (rot < 0.0f) rot += 360.0f;
-                    int bin = (int)roundf(__fmul_rn(rot, factor));
-                    if (bin == 30) bin = 0;
-                    if (lane == 0) s_rotbin[q] = (signed char)bin; // rotHist[bin].push_back(i1): stays even if un-matched later
-                }
-                __builtin_amdgcn_wave_barrier();
+        const int bestRank = bestk & 0x3ff, bestPos = (bestk >> 10) & 0x3ff;
+        if (bestDist <= 50 && (float)bestDist < __fmul_rn((float)bestDist2, nnratio)) { // TH_LOW, ratio test
+            if (lane == (bestPos & 63)) {
+                const uint32_t st = bestPos < 64 ? st0 : s_state[bestRank];
+                const int old = (int)(st & 0xffffu) - 1;
+                if (old >= 0) s_held[old] = NIL;      // the earlier query loses the keypoint (:467-471)
+                s_state[bestRank] = ((uint32_t)bestDist << 16) | (uint32_t)(q + 1);
+                s_held[q] = (uint16_t)bestRank;
+                s_acc[q] = (uint16_t)bestRank;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    int nmatches = 0;
+    for (int q0 = 0; q0 < nq; q0 += 64) {
+        const int q = q0 + lane;
+        bool held = false;
+        if (q < nq) {
+            const int r = s_held[q];
+            held = r != NIL;
+            if (held) m12[s_query[q]] = (int)(s_sorted[r] & 0xffff);
+            if (check_ori && s_acc[q] != NIL) {
+                float rot = k1[s_query[q]].angle - s_ang2[s_acc[q]];
+                if (rot < 0.0f) rot += 360.0f;
+                int bin = (int)roundf(__fmul_rn(rot, factor));
+                if (bin == 30) bin = 0;
+                s_rotbin[q] = (signed char)bin; // rotHist[bin].push_back(i1): stays even if un-matched later
             }
         }
+        nmatches += (int)__popcll(__ballot(held));
     }
     __threadfence_block();
     if (check_ori) {
@@ -509,7 +537,7 @@ __global__ __launch_bounds__(SFI_THREADS) void k_search_init(const orbfe_keypoin
             bool rm = false;
             if (q < nq) {
                 const int bin = s_rotbin[q], i = s_query[q];
-                rm = bin >= 0 && bin != ind1 && bin != ind2 && bin != ind3 && m12[i] >= 0;
+                rm = bin >= 0 && bin != ind1 && bin != ind2 && bin != ind3 && s_held[q] != NIL;
                 if (rm) m12[i] = -1;
             }
             removed += __popcll(__ballot(rm));
