@@ -349,7 +349,6 @@ struct orbfe_aruco {
                            d_codes.as<unsigned long long>(), ncodes, d_scodes.as<unsigned long long>(), d_sids.as<int32_t>(), nsorted,
                            max_corr, d_result.as<int32_t>(), cols);
         timer.mark(s, "decode");
-        ORBFE_HIP(hipMemsetAsync(d_msrc.p, 0xff, (size_t)AR_MAX_RECTS * 4 * B, s)); // -1: slot holds no marker
         for (int r_ = 0; r_ < ORBFE_REPS_ARUCO(4); r_++) hipLaunchKernelGGL(k_finalize, dim3(B), dim3(256), 0, s, d_rects.as<ArRect>(), AR_MAX_RECTS,
                            d_candidx.as<int32_t>(), d_ncand.as<int32_t>(), d_result.as<int32_t>(),
                            d_pool.as<uint32_t>(), pool_fu32, d_out_m, capacity, d_n, corner_method == 1 ? 1 : 0, d_msrc.as<int32_t>());

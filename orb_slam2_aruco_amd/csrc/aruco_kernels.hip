@@ -2092,7 +2092,8 @@ __global__ __launch_bounds__(256) void k_finalize(const ArRect* __restrict__ rec
     const int f = blockIdx.x, tid = threadIdx.x;
     const int nc = ncand[f];
     const ArRect* R = rects + (size_t)f * rect_cap;
-    if (tid == 0) {
+    for (int i = tid; i < AR_MAX_RECTS; i += blockDim.x) out_src[(size_t)f * AR_MAX_RECTS + i] = -1; // slot holds no marker (the
+    if (tid == 0) {                                                                                    // workgroup barriers below order it)
         // detected markers in candidate order, corners rotated by 4 - nRot (:6723-6823), then a stable sort by id
         int m = 0;
         for (int s = 0; s < nc; s++) {

@@ -1122,6 +1122,7 @@ __global__ __launch_bounds__(256) void k_distinctive(const uint8_t* __restrict__
 
 struct MatchWorkspace {
     DevBuf pidx, pbest, psecond, csr_cnt, csr_idx, csr_dist, scratch, overflow, prev;
+    DevBuf sfi_overflow;  // k_search_init's flag: zeroed when allocated and whenever it is read (no memset launch per batch)
     DevBuf q, t, nq, nt, oidx, obest, osecond, kps, desc, nk, m12, nm;
     int csr_per_pair = 0; // CSR slots per frame pair (grown by the host wrapper on overflow)
     int sbp_stride = 0;   // candidate row stride of k_search_by_projection (grown on overflow)
@@ -1201,14 +1202,17 @@ static int sfi_launch(const orbfe_keypoint* d_kps, const uint8_t* d_desc, const 
     if ((rc = w.csr_cnt.ensure((size_t)npairs * capacity * 4)) ||
         (rc = w.csr_idx.ensure((size_t)npairs * capacity * stride * 2)) ||
         (rc = w.csr_dist.ensure((size_t)npairs * capacity * stride)) ||
-        (rc = w.scratch.ensure((size_t)npairs * 3 * capacity * 4)) || (rc = w.overflow.ensure(16)))
+        (rc = w.scratch.ensure((size_t)npairs * 3 * capacity * 4)))
         return rc;
-    ORBFE_HIP(hipMemsetAsync(w.overflow.p, 0, 4, s));
+    if (!w.sfi_overflow.p) {
+        if ((rc = w.sfi_overflow.ensure(16))) return rc;
+        ORBFE_HIP(hipMemset(w.sfi_overflow.p, 0, 16));
+    }
     { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(&k_search_init), (size_t)(sfi_lds_bytes())); if (rc_lds_) return rc_lds_; }
     hipLaunchKernelGGL(k_search_init, dim3(npairs), dim3(SFI_THREADS), sfi_lds_bytes(), s, d_kps, d_desc, d_n, capacity, bnd,
                        (float)window, nnratio, check_ori, d_prev_in, d_prev_out, d_m12, d_nm, w.csr_cnt.as<int32_t>(),
                        w.csr_idx.as<uint16_t>(), w.csr_dist.as<uint8_t>(), stride, w.scratch.as<int32_t>(),
-                       w.overflow.as<int32_t>());
+                       w.sfi_overflow.as<int32_t>());
     ORBFE_HIP(hipGetLastError());
     return ORBFE_OK;
 }
@@ -1295,9 +1299,10 @@ int orbfe_search_for_initialization_batch_status(void* stream, int32_t* overflow
     *overflow = 0;
     hipStream_t s = (hipStream_t)stream;
     MatchWorkspace& w = ws(s);
-    if (!w.overflow.p) return ORBFE_OK; // no batch on this (thread, device, stream) yet
+    if (!w.sfi_overflow.p) return ORBFE_OK; // no batch on this (thread, device, stream) yet
     ORBFE_HIP(hipStreamSynchronize(s));
-    ORBFE_HIP(hipMemcpy(overflow, w.overflow.p, 4, hipMemcpyDeviceToHost));
+    ORBFE_HIP(hipMemcpy(overflow, w.sfi_overflow.p, 4, hipMemcpyDeviceToHost));
+    if (*overflow) ORBFE_HIP(hipMemset(w.sfi_overflow.p, 0, 4)); // the flag is sticky until it has been read
     if (*overflow > SFI_MAXL0)
         return fail(ORBFE_ERR_CAPACITY, "%d level-0 keypoints in a frame exceed the supported %d", *overflow, SFI_MAXL0);
     if (*overflow > w.csr_per_pair) w.csr_per_pair = (*overflow + 63) / 64 * 64; // the next batch on this stream has the room
@@ -1340,8 +1345,9 @@ int orbfe_search_for_initialization(const orbfe_keypoint* kps1, const uint8_t* d
         if (rc) return rc;
         ORBFE_HIP(hipDeviceSynchronize());
         int32_t ovf = 0;
-        ORBFE_HIP(hipMemcpy(&ovf, w.overflow.p, 4, hipMemcpyDeviceToHost));
+        ORBFE_HIP(hipMemcpy(&ovf, w.sfi_overflow.p, 4, hipMemcpyDeviceToHost));
         if (!ovf) break;
+        ORBFE_HIP(hipMemset(w.sfi_overflow.p, 0, 4));
         if (attempt) return fail(ORBFE_ERR_CAPACITY, "candidate list overflow (%d)", ovf);
         if (ovf > SFI_MAXL0) return fail(ORBFE_ERR_CAPACITY, "%d level-0 keypoints exceed the supported %d", ovf, SFI_MAXL0);
         w.csr_per_pair = ovf;

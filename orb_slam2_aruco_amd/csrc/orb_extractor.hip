@@ -324,7 +324,10 @@ struct orbfe_extractor {
         if ((rc = d_lvloff.ensure((size_t)nlevels * 4 * B))) return rc;
         if ((rc = d_lvlncand.ensure((size_t)nlevels * 4 * B))) return rc;
         if ((rc = d_fallback.ensure((size_t)nlevels * 4 * B))) return rc;
-        if ((rc = d_overflow.ensure(16))) return rc;
+        if (!d_overflow.p) { // zeroed here and whenever it is read: no memset launch per batch
+            if ((rc = d_overflow.ensure(16))) return rc;
+            ORBFE_HIP(hipMemset(d_overflow.p, 0, 16));
+        }
         batch_cap = B;
         return ORBFE_OK;
     }
@@ -344,7 +347,6 @@ struct orbfe_extractor {
         last_src0 = src0;
         timer.begin();
         timer.mark(s, "start");
-        ORBFE_HIP(hipMemsetAsync(d_overflow.p, 0, 4, s));
         for (int r16_ = 0; r16_ < ORBFE_REPS_ORB(16); r16_++)
         for (int l = 1; l < nlevels; l++) {
             const LevelGeom& g = geom[l];
@@ -555,6 +557,7 @@ int orbfe_extractor_batch_status(orbfe_extractor* h, int32_t* overflow)
     if (rc) return rc;
     ORBFE_HIP(hipDeviceSynchronize());
     ORBFE_HIP(hipMemcpy(overflow, h->d_overflow.p, 4, hipMemcpyDeviceToHost));
+    if (*overflow) ORBFE_HIP(hipMemset(h->d_overflow.p, 0, 4)); // sticky until read
     return ORBFE_OK;
 }
 
@@ -587,6 +590,7 @@ int orbfe_extract_batch(orbfe_extractor* h, const uint8_t* imgs, int nframes, si
     ORBFE_HIP(hipStreamSynchronize(s));
     int32_t ovf = 0;
     ORBFE_HIP(hipMemcpy(&ovf, h->d_overflow.p, 4, hipMemcpyDeviceToHost));
+    if (ovf) ORBFE_HIP(hipMemset(h->d_overflow.p, 0, 4));
     if (ovf) return fail(ORBFE_ERR_CAPACITY, "internal keypoint capacity exceeded (%d)", ovf);
     for (int f = 0; f < nframes; f++) {
         if (n_out[f] > capacity)
