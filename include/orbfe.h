@@ -113,7 +113,7 @@ int orbfe_extractor_set_gaussian_taps(orbfe_extractor* h, int mode);
 /* The device-pointer entry point is asynchronous and cannot return a capacity error: a frame whose keypoint total exceeds
  * `capacity` is clamped to it.  After the batch (synchronises the device): *overflow = 0, or the largest per-frame total
  * that did not fit -- the batch's records are then incomplete and the call must be repeated with capacity >= *overflow
- * (orbfe_extractor_max_keypoints() always suffices). */
+ * (orbfe_extractor_max_keypoints() always suffices).  The flag covers every batch since it was last read (reading clears it). */
 int orbfe_extractor_batch_status(orbfe_extractor* h, int32_t* overflow);
 
 /* Stage read-back for parity tests (valid after an extract call; `frame` indexes the last batch).
@@ -323,7 +323,7 @@ int orbfe_search_for_initialization_batch_device(const orbfe_keypoint* d_kps, co
  * level-0 keypoints than the candidate rows were sized for is truncated.  After a batch issued by THIS thread on `stream`
  * (synchronises the stream): *overflow = 0, or the level-0 keypoint count that did not fit -- the batch's matches are then
  * incomplete; the per-stream scratch has been grown, so repeating the batch call succeeds.  More than 1024 level-0
- * keypoints in a frame: ORBFE_ERR_CAPACITY. */
+ * keypoints in a frame: ORBFE_ERR_CAPACITY.  The flag covers every batch since it was last read (reading clears it). */
 int orbfe_search_for_initialization_batch_status(void* stream, int32_t* overflow);
 
 /* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:270-333; called after every new observation by Tracking,
