@@ -186,9 +186,10 @@ __device__ __forceinline__ u16x2 pk_maxu(u16x2 a, u16x2 b) { return __builtin_el
 // compass test of two pixels at once (16-bit lanes); result lanes are non-zero where the pixel passes
 __device__ __forceinline__ uint32_t compass_pass2(u16x2 v, u16x2 r0, u16x2 r4, u16x2 r8, u16x2 r12, u16x2 t2)
 {
-    // two adjacent compass pixels both > v + t  <=>  max over the 4 adjacent pairs of min(pair) > v + t
-    const u16x2 hi = pk_maxu(pk_maxu(pk_minu(r0, r4), pk_minu(r4, r8)), pk_maxu(pk_minu(r8, r12), pk_minu(r12, r0)));
-    const u16x2 lo = pk_minu(pk_minu(pk_maxu(r0, r4), pk_maxu(r4, r8)), pk_minu(pk_maxu(r8, r12), pk_maxu(r12, r0)));
+    // two adjacent compass pixels both > v + t  <=>  max over the 4 adjacent pairs of min(pair) > v + t.  The four adjacent pairs of
+    // the cycle 0 - 4 - 8 - 12 are exactly {r0, r8} x {r4, r12}, so that maximum is min(max(r0, r8), max(r4, r12)): 3 operations, not 7
+    const u16x2 hi = pk_minu(pk_maxu(r0, r8), pk_maxu(r4, r12));
+    const u16x2 lo = pk_maxu(pk_minu(r0, r8), pk_minu(r4, r12));
     const u16x2 ph = __builtin_elementwise_sub_sat(hi, (u16x2)(v + t2));                           // hi > v + t
     const u16x2 pl = __builtin_elementwise_sub_sat(__builtin_elementwise_sub_sat(v, t2), lo);      // lo < v - t
     return as_u32(ph) | as_u32(pl);
@@ -347,8 +348,11 @@ __global__ __launch_bounds__(256) void k_fast_cells(ImgView src0, ImgView pyr, c
                 const uint32_t p01 = FC_PASS2(C0, S0, E0, N0, W0, LO), p23 = FC_PASS2(C0, S0, E0, N0, W0, HI);
                 const uint32_t p45 = FC_PASS2(C1, S1, E1, N1, W1, LO), p67 = FC_PASS2(C1, S1, E1, N1, W1, HI);
 #undef FC_PASS2
-                mask8 = ((p01 & 0xffffu) ? 1u : 0u) | ((p01 >> 16) ? 2u : 0u) | ((p23 & 0xffffu) ? 4u : 0u) | ((p23 >> 16) ? 8u : 0u) |
-                        ((p45 & 0xffffu) ? 16u : 0u) | ((p45 >> 16) ? 32u : 0u) | ((p67 & 0xffffu) ? 64u : 0u) | ((p67 >> 16) ? 128u : 0u);
+                // non-zero 16-bit lanes -> bits 0 .. 7: clamp every lane to 0 / 1, interleave the four words, fold the high halves in
+                const u16x2 one2 = as_u16x2(0x00010001u);
+                const uint32_t b = as_u32(pk_minu(as_u16x2(p01), one2)) | (as_u32(pk_minu(as_u16x2(p23), one2)) << 2) |
+                                   (as_u32(pk_minu(as_u16x2(p45), one2)) << 4) | (as_u32(pk_minu(as_u16x2(p67), one2)) << 6);
+                mask8 = (b & 0x55u) | ((b >> 15) & 0xaau);
                 mask8 &= (1u << min(8, aw - x)) - 1u; // the last group of a row may be partial
             }
             const int cnt = __popc(mask8);
