@@ -308,3 +308,16 @@ def test_corner_none_modes_and_contours(orbfe, oracle):
                 lambda: det.setCornerRefinementMethod(det.CORNER_SUBPIX), lambda: det.setDictionary("ARUCO", 1.5)):
         with pytest.raises(orbfe.OrbfeError):
             bad()
+
+
+def test_small_border_kernel_on_lds_resident_frames():
+    """k_contours_small (the borders between grid lines as their own launch) is the default only where the bit image lives in HBM
+    (1920x1080); ORBFE_ARUCO_SMALL_SEPARATE=1 switches it on for LDS-resident frames too.  The contour tests must pass either way:
+    run them in a process with the switch set."""
+    import os, subprocess, sys
+    env = dict(os.environ, ORBFE_ARUCO_SMALL_SEPARATE="1")
+    here = os.path.abspath(__file__)
+    r = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-k",
+                        "structured_binary or relay_and_legacy or dense_frame or detect_matches_oracle"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
