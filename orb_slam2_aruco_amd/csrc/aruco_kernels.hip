@@ -782,7 +782,7 @@ __device__ __forceinline__ int relay_frame(
     int small_elsewhere = 0 /* phase (c) of gridded frames is k_contours_small's */)
 {
     extern __shared__ __align__(16) unsigned char ct_smem[];
-    __shared__ int s_next, s_nkept, s_flags, s_ncand, s_nmark, s_nsmall, s_pool, s_changed[2];
+    __shared__ int s_next, s_next_d, s_nkept, s_flags, s_ncand, s_nmark, s_nsmall, s_pool, s_changed[2];
     // grid spacing that fitted the marker table in the previous batch of this handle (video: it will fit again); saves the
     // enumeration passes that overflow at finer spacings.  The result does not depend on the spacing.
     if (!force_nogrid && hint) kshift = max(kshift, min(*hint, 7));
@@ -830,7 +830,7 @@ __device__ __forceinline__ int relay_frame(
     // A frame whose segments overflow the staging arenas or the copy list (one giant noisy component) is done again
     // from (a) without a grid: every border is then followed whole, straight into the pool.
     if (tid == 0) {
-        s_next = 0; s_nkept = 0; s_flags = 0; s_ncand = 0; s_nmark = 0; s_nsmall = 0; s_pool = 0;
+        s_next = 0; s_next_d = 0; s_nkept = 0; s_flags = 0; s_ncand = 0; s_nmark = 0; s_nsmall = 0; s_pool = 0;
         s_changed[0] = 0; s_changed[1] = 0;
     }
     RL_STAMP();
@@ -1032,9 +1032,9 @@ __device__ __forceinline__ int relay_frame(
         if ((tid & 63) == 0) { atomicMax(&s_dbg_steps[3], dbg_iters); atomicAdd(&s_dbg_steps[4], dbg_iters); }
 #endif
     }
-    __syncthreads();
-    if (tid == 0) s_next = 0;
-    __syncthreads();
+    // no barrier here: (d) depends on nothing (c) writes, and has its own ticket counter -- a wave that has drained the small
+    // borders goes straight on to the segments instead of waiting for the wave that was handed the last long walk (the waves'
+    // loop counts in (c) spread 92 +- 30: a quarter of the phase was waiting at this point)
     RL_STAMP();
 
     // ---- (d) segments: table slot -> walk to the next grid marker.  The points go to the lane's staging arena (upper
@@ -1046,7 +1046,7 @@ __device__ __forceinline__ int relay_frame(
         uint32_t mn = 0xffffffffu, mnhole = 0;
         for (;;) {
             if (!busy && !drained) {
-                const int i = atomicAdd(&s_next, 1);
+                const int i = atomicAdd(&s_next_d, 1);
                 if (i >= T) drained = true;
                 else {
                     const uint32_t key = hkey[i];
