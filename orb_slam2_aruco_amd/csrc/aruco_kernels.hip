@@ -255,23 +255,24 @@ __device__ __forceinline__ int approx_poly_wave(const uint32_t* __restrict__ P, 
     for (int it = 0; it < 3; it++) {
         pos = (pos + right_start) % n;
         start_pt = rd(pos);
-        // farthest point from start_pt among j = 1..n-1 at index (pos + j) % n ; first maximum wins
-        long long best = 0; // (dist << 20) | (0xfffff - j): maximise dist, then minimise j
+        // farthest point from start_pt among j = 1..n-1 at index (pos + j) % n ; first maximum wins.  Coordinates are below 2^14
+        // (far above any frame here), so squared distances and cross products fit 32 bits: the maximum is two 32-bit DPP reductions
+        // (largest distance, then smallest j among the lanes that hold it) instead of one on 64-bit keys
+        int bd = 0, bj = 0x7fffffff; // this lane: largest distance so far and the first j it occurred at (j grows chunk by chunk)
         for (int j0 = 1; j0 < n; j0 += 64) {
             const int j = j0 + lane;
             if (j < n) {
                 int idx = pos + j;
                 if (idx >= n) idx -= n;
                 const ApPt p = rd(idx);
-                const long long dx = p.x - start_pt.x, dy = p.y - start_pt.y;
-                const long long d = dx * dx + dy * dy;
-                const long long key = (d << 20) | (long long)(0xfffff - j);
-                if (d > 0 && key > best) best = key;
+                const int dx = p.x - start_pt.x, dy = p.y - start_pt.y;
+                const int d = dx * dx + dy * dy;
+                if (d > bd) { bd = d; bj = j; }
             }
         }
-        best = (long long)wave_max_u64((unsigned long long)best); // keys are >= 0
-        const long long max_dist = best >> 20;
-        right_start = best ? (int)(0xfffff - (best & 0xfffff)) : right_start; // no dist > 0: index unchanged
+        const int max_dist = wave_max(bd);
+        const int first_j = wave_min(bd == max_dist ? bj : 0x7fffffff);
+        right_start = max_dist > 0 ? first_j : right_start; // no dist > 0: index unchanged
         le_eps = (double)max_dist <= eps;
         // pos returns to the start index after the sweep (READ_PT wrapped n times)
     }
@@ -291,26 +292,27 @@ __device__ __forceinline__ int approx_poly_wave(const uint32_t* __restrict__ P, 
         bool le;
         int split = 0;
         if (p1 != sl.y) {
-            const long long dx = end_pt.x - sp.x, dy = end_pt.y - sp.y;
-            const int cnt = (sl.y - p1 + n) % n; // points strictly between
-            long long best = 0;
+            const int dx = end_pt.x - sp.x, dy = end_pt.y - sp.y;
+            int cnt = sl.y - p1; // points strictly between
+            if (cnt < 0) cnt += n;
+            int bd = 0, bj = 0x7fffffff;
             for (int j0 = 0; j0 < cnt; j0 += 64) {
                 const int j = j0 + lane;
                 if (j < cnt) {
                     int idx = p1 + j;
                     if (idx >= n) idx -= n;
                     const ApPt p = rd(idx);
-                    long long d = (long long)(p.y - sp.y) * dx - (long long)(p.x - sp.x) * dy;
+                    int d = (p.y - sp.y) * dx - (p.x - sp.x) * dy;
                     d = d < 0 ? -d : d;
-                    const long long key = (d << 20) | (long long)(0xfffff - j);
-                    if (d > 0 && key > best) best = key;
+                    if (d > bd) { bd = d; bj = j; }
                 }
             }
-            best = (long long)wave_max_u64((unsigned long long)best);
-            const double md = (double)(best >> 20);
-            le = md * md <= eps * (double)(dx * dx + dy * dy);
-            if (best) {
-                split = p1 + (int)(0xfffff - (best & 0xfffff));
+            const int maxd = wave_max(bd);
+            const int first_j = wave_min(bd == maxd ? bj : 0x7fffffff);
+            const double md = (double)maxd;
+            le = md * md <= eps * (double)((long long)dx * dx + (long long)dy * dy);
+            if (maxd > 0) {
+                split = p1 + first_j;
                 if (split >= n) split -= n;
             }
         } else {
