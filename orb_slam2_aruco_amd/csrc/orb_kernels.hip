@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(ImgView src0, ImgView pyr, c
             for (int k = 0; k < 8; k++) {
                 const bool in = i0 + k * 64 + lane < items;
                 so[k] = in ? y * SP + 4 * c : -1;
-                v[k] = in ? *reinterpret_cast<const u32_unaligned*>(roi + (size_t)y * pitch + 4 * c) : 0u;
+                v[k] = in ? *reinterpret_cast<const u32_unaligned*>(roi + (uint32_t)(y * pitch + 4 * c)) : 0u; // 32-bit offset off a uniform base
                 y += qstep; c += rstep;
                 if (c >= ndw) { c -= ndw; y++; }
             }
