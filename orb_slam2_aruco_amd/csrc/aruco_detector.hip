@@ -298,7 +298,7 @@ struct orbfe_aruco {
                                    cols, rows, 0, 70, relay_kshift, relay_tbits, d_segs.as<RelaySeg>(),
                                    d_pool.as<uint32_t>(), pool_fu32, (int)pool_fu32, d_kept.as<ArKept>(), relay_kcap, relay_kcap,
                                    d_tailkeys.as<unsigned long long>(), d_tailoff.as<int32_t>(), d_counts.as<int32_t>(), d_hint.as<int32_t>(),
-                                   d_small.as<uint4>(), d_rstate.as<int32_t>(), d_gpad.as<uint32_t>(), gpad_fu32);
+                                   d_small.as<uint4>(), d_rstate.as<int32_t>(), d_gpad.as<uint32_t>(), gpad_fu32, d_lut.as<uint16_t>());
             } else {
             auto rfn = relay_tbits > 12 ? k_contours_relay8 : k_contours_relay;
             { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(rfn), (size_t)(rlds)); if (rc_lds_) return rc_lds_; }
@@ -306,7 +306,7 @@ struct orbfe_aruco {
                                cols, rows, lds_bits_words, 70, relay_kshift, relay_tbits, d_segs.as<RelaySeg>(),
                                d_pool.as<uint32_t>(), pool_fu32, (int)pool_fu32, d_kept.as<ArKept>(), relay_kcap, relay_kcap,
                                d_tailkeys.as<unsigned long long>(), d_tailoff.as<int32_t>(), d_counts.as<int32_t>(), d_hint.as<int32_t>(),
-                               d_small.as<uint4>(), d_rstate.as<int32_t>(), small_separate ? 1 : 0);
+                               d_small.as<uint4>(), d_rstate.as<int32_t>(), small_separate ? 1 : 0, d_lut.as<uint16_t>());
             }
             // the borders that touch no grid line, for frames done with a grid by a relay kernel that leaves them out (the
             // HBM-resident one: its bands fit LDS here; for LDS-resident frames the separate launch halves the relay kernel's time

@@ -781,7 +781,8 @@ __device__ __forceinline__ int relay_frame(
     unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off, int32_t* __restrict__ counts, int32_t* __restrict__ hint, uint4* __restrict__ small_g,
     int32_t* __restrict__ rstate /* per frame: grid shift the frame was done with, final pool words in use (k_contours_small goes on from there) */,
     uint32_t* __restrict__ gpad = nullptr /* GBITS: the padded bit image lives here (HBM / L2) instead of LDS */, size_t gpad_fstride = 0,
-    int small_elsewhere = 0 /* phase (c) of gridded frames is k_contours_small's */)
+    int small_elsewhere = 0 /* phase (c) of gridded frames is k_contours_small's */,
+    const uint16_t* __restrict__ lut_g = nullptr /* the step table, built once per detector (k_relay_lut) */)
 {
     extern __shared__ __align__(16) unsigned char ct_smem[];
     __shared__ int s_next, s_next_d, s_nkept, s_flags, s_ncand, s_nmark, s_nsmall, s_pool, s_changed[2];
@@ -850,7 +851,8 @@ __device__ __forceinline__ int relay_frame(
     }
     if (tid < 2) lbits[wpr * prow + tid] = 0; // spare words read by ring8()'s funnel loads
     for (int i = tid; i < T; i += NT) hkey[i] = 0u;
-    for (int i = tid; i < 2048; i += NT) s_lut[i] = rl_lut_entry((unsigned)i >> 3, i & 7);
+    if (lut_g) for (int i = tid; i < 1024; i += NT) reinterpret_cast<uint32_t*>(s_lut)[i] = reinterpret_cast<const uint32_t*>(lut_g)[i];
+    else for (int i = tid; i < 2048; i += NT) s_lut[i] = rl_lut_entry((unsigned)i >> 3, i & 7);
     if (GBITS) __threadfence_block(); // the padded image was written to HBM: visible to the workgroup's other waves
     __syncthreads();
     const BitImage im{lbits, wpr, W, H};
@@ -1354,16 +1356,16 @@ __global__ __launch_bounds__(RL_THREADS) RL_VGPR_ATTR void k_contours_relay(
     int kshift, int tbits, RelaySeg* __restrict__ segs, uint32_t* __restrict__ pool, size_t pool_fstride, int pool_cap,
     ArKept* __restrict__ kept_out, int kept_cap, int kcap /*kept borders this kernel's LDS holds*/,
     unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off, int32_t* __restrict__ counts, int32_t* __restrict__ hint,
-    uint4* __restrict__ small_g, int32_t* __restrict__ rstate, int small_elsewhere)
+    uint4* __restrict__ small_g, int32_t* __restrict__ rstate, int small_elsewhere, const uint16_t* __restrict__ lut_g)
 {
     __builtin_amdgcn_s_setprio(2); // latency-bound: its few waves go first when a VALU-bound kernel shares the CU
     if (relay_frame<false, RL_SLOTS_PER_THREAD, RL_THREADS>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool,
                                                 pool_fstride, pool_cap, kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate,
-                                                nullptr, 0, small_elsewhere)) {
+                                                nullptr, 0, small_elsewhere, lut_g)) {
         __syncthreads();
         relay_frame<true, RL_SLOTS_PER_THREAD, RL_THREADS>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool,
                                                pool_fstride, pool_cap, kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate,
-                                               nullptr, 0, small_elsewhere);
+                                               nullptr, 0, small_elsewhere, lut_g);
     }
 }
 
@@ -1373,14 +1375,15 @@ __global__ __launch_bounds__(RL_THREADS_BIG) void k_contours_relay8(
     const uint32_t* __restrict__ gbits, size_t bits_fstride, int wpr_g, int W, int H, int lds_bits_words, int min_len,
     int kshift, int tbits, RelaySeg* __restrict__ segs, uint32_t* __restrict__ pool, size_t pool_fstride, int pool_cap,
     ArKept* __restrict__ kept_out, int kept_cap, int kcap, unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off,
-    int32_t* __restrict__ counts, int32_t* __restrict__ hint, uint4* __restrict__ small_g, int32_t* __restrict__ rstate, int small_elsewhere)
+    int32_t* __restrict__ counts, int32_t* __restrict__ hint, uint4* __restrict__ small_g, int32_t* __restrict__ rstate, int small_elsewhere,
+    const uint16_t* __restrict__ lut_g)
 {
     __builtin_amdgcn_s_setprio(2);
     if (relay_frame<false, 8192 / RL_THREADS_BIG, RL_THREADS_BIG>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool, pool_fstride, pool_cap,
-                              kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate, nullptr, 0, small_elsewhere)) {
+                              kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate, nullptr, 0, small_elsewhere, lut_g)) {
         __syncthreads();
         relay_frame<true, 8192 / RL_THREADS_BIG, RL_THREADS_BIG>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool, pool_fstride, pool_cap,
-                             kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate, nullptr, 0, small_elsewhere);
+                             kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate, nullptr, 0, small_elsewhere, lut_g);
     }
 }
 
@@ -1393,14 +1396,14 @@ __global__ __launch_bounds__(RL_THREADS_BIG) void k_contours_relay8g(
     int kshift, int tbits, RelaySeg* __restrict__ segs, uint32_t* __restrict__ pool, size_t pool_fstride, int pool_cap,
     ArKept* __restrict__ kept_out, int kept_cap, int kcap, unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off,
     int32_t* __restrict__ counts, int32_t* __restrict__ hint, uint4* __restrict__ small_g, int32_t* __restrict__ rstate,
-    uint32_t* __restrict__ gpad, size_t gpad_fstride)
+    uint32_t* __restrict__ gpad, size_t gpad_fstride, const uint16_t* __restrict__ lut_g)
 {
     __builtin_amdgcn_s_setprio(2);
     if (relay_frame<false, 8192 / RL_THREADS_BIG, RL_THREADS_BIG, true>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool,
-                              pool_fstride, pool_cap, kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate, gpad, gpad_fstride, 1)) {
+                              pool_fstride, pool_cap, kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate, gpad, gpad_fstride, 1, lut_g)) {
         __syncthreads();
         relay_frame<true, 8192 / RL_THREADS_BIG, RL_THREADS_BIG, true>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool,
-                             pool_fstride, pool_cap, kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate, gpad, gpad_fstride, 1);
+                             pool_fstride, pool_cap, kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate, gpad, gpad_fstride, 1, lut_g);
     }
 }
 
