@@ -229,8 +229,7 @@ ORBFE_HD void relay_states_of_pixel(unsigned ring, unsigned a, F emit)
     while (a) {
         const int d = ctz8(a);
         const unsigned rr = ((ring | (ring << 8)) >> d) & 0xffu; // bit j = direction d + j; bit 0 is background
-        int j = 7;
-        while (!((rr >> j) & 1u)) j--;
+        const int j = 31 - __builtin_clz(rr);                     // highest set bit (ring != 0)
         const int s = (d + j) & 7; // first foreground direction clockwise from d
         unsigned run;
         relay_examine(ring, s, &run);
@@ -280,8 +279,7 @@ ORBFE_HD int relay_start_dir(unsigned ring, int is_hole)
     if (!ring) return -1;
     const int d0 = is_hole ? 0 : 4;
     const unsigned rr = ((ring | (ring << 8)) >> d0) & 0xffu;
-    int j = 7; // direction d0 itself (bit 0) is background for a start candidate
-    while (!((rr >> j) & 1u)) j--;
+    const int j = 31 - __builtin_clz(rr); // highest set bit; direction d0 itself (bit 0) is background for a start candidate
     return (d0 + j) & 7;
 }
 
