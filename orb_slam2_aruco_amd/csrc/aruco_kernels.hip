@@ -785,6 +785,7 @@ __device__ __forceinline__ int relay_frame(
     const uint16_t* __restrict__ lut_g = nullptr /* the step table, built once per detector (k_relay_lut) */)
 {
     extern __shared__ __align__(16) unsigned char ct_smem[];
+    __shared__ int s_nmpix;
     __shared__ int s_next, s_next_d, s_nkept, s_flags, s_ncand, s_nmark, s_nsmall, s_pool, s_changed[2];
     // grid spacing that fitted the marker table in the previous batch of this handle (video: it will fit again); saves the
     // enumeration passes that overflow at finer spacings.  The result does not depend on the spacing.
@@ -876,6 +877,17 @@ __device__ __forceinline__ int relay_frame(
                 nm += fresh;
             });
         };
+        // two passes: the pixels that carry markers are listed first (a textured word has sixteen of them, most have none: with one
+        // lane doing a word's inserts the phase waited for the unluckiest lane), then every lane inserts the states of listed pixels.
+        // The list lives in the segment records' HBM (unused until (d)): 5 T words.
+        uint32_t* mlist = reinterpret_cast<uint32_t*>(sg);
+        const int mcap = 5 * T;
+        if (tid == 0) s_nmpix = 0;
+        __syncthreads();
+        auto push = [&](int x, int y) {
+            const int q = atomicAdd(&s_nmpix, 1);
+            if (q < mcap) mlist[q] = (uint32_t)x | ((uint32_t)y << 16);
+        };
         for (int it = tid; it < nitems; it += NT) {
             if (it < nrow_items) {
                 const int r = it / wpr, j = it - r * wpr, y = (r + 1) << kshift;
@@ -890,7 +902,7 @@ __device__ __forceinline__ int relay_frame(
                 while (m) {
                     const int b = __ffs(m) - 1;
                     m &= m - 1;
-                    add(j * 32 + b, y);
+                    push(j * 32 + b, y);
                 }
             } else {
                 const int c = (it - nrow_items) / nchunk, ch = (it - nrow_items) - c * nchunk;
@@ -905,9 +917,17 @@ __device__ __forceinline__ int relay_frame(
                     const int i = __ffs(m) - 1;
                     m &= m - 1;
                     const int y = y0 + i;
-                    if (y <= H && (y & kmask) != 0) add(x, y); // pixels on relay rows were taken above
+                    if (y <= H && (y & kmask) != 0) push(x, y); // pixels on relay rows were taken above
                 }
             }
+        }
+        __threadfence_block();
+        __syncthreads();
+        if (s_nmpix > mcap && tid == 0) atomicOr(&s_flags, RL_FLAG_TABLE); // cannot fit the table either
+        const int npx = min(s_nmpix, mcap);
+        for (int i = tid; i < npx; i += NT) {
+            const uint32_t v = mlist[i];
+            add((int)(v & 0xffffu), (int)(v >> 16));
         }
         if (nm) atomicAdd(&s_nmark, nm);
     }
