@@ -337,21 +337,18 @@ __global__ __launch_bounds__(SFI_THREADS) void k_search_init(const orbfe_keypoin
     __syncthreads();
     const int nl0 = s_nl0, nq = s_nq;
     {
-        int P = 1;
-        while (P < nl0) P <<= 1;
-        for (int i = nl0 + tid; i < P; i += SFI_THREADS) s_sorted[i] = 0xffffffffu;
+        // sort by counting: the keys are distinct (the index is part of them), so an entry's place is the number of smaller keys --
+        // one pass of broadcast LDS reads and two barriers instead of the 36+ barrier stages of a bitonic network
+        uint32_t key = 0xffffffffu;
+        int r = 0;
+        if (tid < nl0) {
+            key = s_sorted[tid];
+            for (int k = 0; k < nl0; k++) r += s_sorted[k] < key;
+            s_state[r] = key;
+        }
         __syncthreads();
-        for (int k = 2; k <= P; k <<= 1)
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int t = tid; t < (P >> 1); t += SFI_THREADS) {
-                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                    const int l = i | j;
-                    const uint32_t a = s_sorted[i], b = s_sorted[l];
-                    const bool up = ((i & k) == 0);
-                    if ((a > b) == up) { s_sorted[i] = b; s_sorted[l] = a; }
-                }
-                __syncthreads();
-            }
+        if (tid < nl0) s_sorted[tid] = s_state[tid];
+        __syncthreads();
     }
     if (nl0 > row_stride && tid == 0) atomicMax(overflow, nl0);
     // per-rank state of F2 in LDS: position + descriptor (first SFI_L0_LDS ranks), matching state (all ranks)
