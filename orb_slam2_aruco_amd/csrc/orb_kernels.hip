@@ -1434,7 +1434,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(ImgView src0, ImgView p
 #pragma unroll
             for (int k = 0; k < 6; k++) {
                 const bool in = k * 64 + lane < 370;
-                wv[k] = *reinterpret_cast<const uint32_t*>(bimg + (size_t)(in ? r : 36) * g.bpitch + 4 * (in ? c : 9));
+                wv[k] = *reinterpret_cast<const uint32_t*>(bimg + (uint32_t)((in ? r : 36) * g.bpitch + 4 * (in ? c : 9))); // 32-bit offset off a uniform base
                 r += 6; c += 4;
                 if (c >= 10) { c -= 10; r++; }
             }
@@ -1454,7 +1454,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(ImgView src0, ImgView p
                 const bool in = k * 64 + lane < 279;
                 // level 0 is the caller's buffer: no alignment is assumed there (gfx950 global loads may be unaligned)
                 typedef uint32_t u32_unaligned __attribute__((aligned(1)));
-                v[k] = *reinterpret_cast<const u32_unaligned*>(pimg + (size_t)(in ? r : 30) * pitch + 4 * (in ? c : 8));
+                v[k] = *reinterpret_cast<const u32_unaligned*>(pimg + (uint32_t)((in ? r : 30) * pitch + 4 * (in ? c : 8)));
                 r += 7; c += 1;
                 if (c >= 9) { c -= 9; r++; }
             }
