@@ -90,7 +90,12 @@ int orbfe_extractor_max_keypoints(const orbfe_extractor* h);
 /* operator()(image, mask(ignored), keypoints, descriptors) for one CV_8UC1 frame in host memory.
  * img: rows x cols bytes with row stride `step`.  kps: capacity records; desc: capacity x 32 bytes, row i belongs to
  * kps[i].  *n_out = number of keypoints.  Empty image (rows==0 || cols==0 || img==NULL) -> ORBFE_OK with *n_out
- * untouched semantics of :1046 mapped to *n_out = 0. */
+ * untouched semantics of :1046 mapped to *n_out = 0.
+ * Frame geometry this implementation accepts (ORBFE_ERR_INVALID otherwise): every pyramid level at least 68 pixels in both
+ * directions (below that it has no FAST cell); levels up to 4127 pixels (a keypoint travels as 12 + 12 bits inside the kernels);
+ * 1 to 8 quadtree roots per level, nIni = round(width / height) of the border-less level (ORBextractor.cc:544): portrait frames give
+ * nIni = 0, on which the reference divides by zero and indexes an empty vector; frames wider than 8.5 : 1 are a capacity limit of
+ * the quadtree kernels. */
 int orbfe_extract(orbfe_extractor* h, const uint8_t* img, int rows, int cols, size_t step, orbfe_keypoint* kps,
                   uint8_t* desc, int capacity, int32_t* n_out);
 
