@@ -93,8 +93,8 @@ int orbfe_extractor_max_keypoints(const orbfe_extractor* h);
  * untouched semantics of :1046 mapped to *n_out = 0.
  * Frame geometry this implementation accepts (ORBFE_ERR_INVALID otherwise): every pyramid level at least 68 pixels in both
  * directions (below that it has no FAST cell); levels up to 4127 pixels (a keypoint travels as 12 + 12 bits inside the kernels);
- * 1 to 8 quadtree roots per level, nIni = round(width / height) of the border-less level (ORBextractor.cc:544): portrait frames give
- * nIni = 0, on which the reference divides by zero and indexes an empty vector; frames wider than 8.5 : 1 are a capacity limit of
+ * 1 to 16 quadtree roots per level, nIni = round(width / height) of the border-less level (ORBextractor.cc:544): portrait frames give
+ * nIni = 0, on which the reference divides by zero and indexes an empty vector; frames wider than 16.5 : 1 are a capacity limit of
  * the quadtree kernels. */
 int orbfe_extract(orbfe_extractor* h, const uint8_t* img, int rows, int cols, size_t step, orbfe_keypoint* kps,
                   uint8_t* desc, int capacity, int32_t* n_out);

@@ -231,8 +231,8 @@ struct orbfe_extractor {
             cand += (size_t)g.cand_cap;
             g.quota = mnFeaturesPerLevel[l];
             g.nIni = (int)std::round(static_cast<float>(g.maxBX - 16) / (g.maxBY - 16));
-            if (g.nIni < 1 || g.nIni > 8)
-                return fail(ORBFE_ERR_INVALID, "aspect ratio gives %d quadtree roots (supported: 1..8)", g.nIni);
+            if (g.nIni < 1 || g.nIni > QT_MAXROOTS)
+                return fail(ORBFE_ERR_INVALID, "aspect ratio gives %d quadtree roots (supported: 1..%d)", g.nIni, QT_MAXROOTS);
             g.hX = static_cast<float>(g.maxBX - 16) / g.nIni;
             g.out_cap = std::max(g.quota + 3, 4 * g.nIni) + 5;
             g.out_off = out;

@@ -605,20 +605,20 @@ __global__ __launch_bounds__(64) void k_distribute(const LevelGeom* __restrict__
 
     // root nodes (:546-570): nIni vertical strips, keys assigned by (int)(x / hX)
     {
-        int cnt[8], beginq[8], run[8];
+        int cnt[QT_MAXROOTS], beginq[QT_MAXROOTS], run[QT_MAXROOTS];
 #pragma unroll
-        for (int q = 0; q < 8; q++) cnt[q] = 0;
+        for (int q = 0; q < QT_MAXROOTS; q++) cnt[q] = 0;
         for (int i0 = 0; i0 < n; i0 += 64) {
             const int i = i0 + lane;
             int r = -1;
             if (i < n) r = (int)__fdiv_rn((float)(kb0[i] & 0xfff), g.hX);
 #pragma unroll
-            for (int q = 0; q < 8; q++)
+            for (int q = 0; q < QT_MAXROOTS; q++)
                 if (q < g.nIni) cnt[q] += __popcll(__ballot(r == q));
         }
         int acc = 0;
 #pragma unroll
-        for (int q = 0; q < 8; q++) { beginq[q] = acc; run[q] = acc; acc += cnt[q]; }
+        for (int q = 0; q < QT_MAXROOTS; q++) { beginq[q] = acc; run[q] = acc; acc += cnt[q]; }
         if (g.nIni > 1) {
             for (int i0 = 0; i0 < n; i0 += 64) {
                 const int i = i0 + lane;
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(64) void k_distribute(const LevelGeom* __restrict__
                 uint32_t kv = 0;
                 if (i < n) { kv = kb0[i]; r = (int)__fdiv_rn((float)(kv & 0xfff), g.hX); }
 #pragma unroll
-                for (int q = 0; q < 8; q++)
+                for (int q = 0; q < QT_MAXROOTS; q++)
                     if (q < g.nIni) {
                         const unsigned long long m = __ballot(r == q);
                         if (r == q) kb1[run[q] + lane_prefix(m)] = kv;
@@ -637,7 +637,7 @@ __global__ __launch_bounds__(64) void k_distribute(const LevelGeom* __restrict__
         QT_SYNC();
         const int rootbuf = (g.nIni == 1) ? 0 : 1;
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
+        for (int q = 0; q < QT_MAXROOTS; q++) {
             if (q >= g.nIni) continue;
             // the reference creates every root, then erases the empty ones (:574-585); seq counts all of them
             const int myseq = seq++;

@@ -12,6 +12,7 @@ CASES = [
     (480, 640, 1000, 8, 1),
     (480, 640, 2000, 8, 2),   # the 2*nFeatures initialisation extractor (Tracking.cc:127)
     (360, 636, 700, 6, 5),    # odd width, non-multiple-of-4 levels
+    (196, 1641, 500, 5, 6),   # panorama: ten quadtree roots
 ]
 
 

@@ -12,7 +12,7 @@ bad = 0
 for case in range(n):
     big = case % 7 == 3
     cols, rows = int(rng.integers(200, 1700 if big else 1000)), int(rng.integers(160, 1100 if big else 760))
-    rows = max(rows, cols // 6)                # more than 8 roots (aspect ratio above 8.5) is a capacity limit of the quadtree kernels
+    rows = max(rows, cols // 12)               # more than 16 roots is a capacity limit of the quadtree kernels
     if rows > cols: cols, rows = rows, cols   # portrait frames give nIni = 0 in DistributeOctTree: undefined in the reference, rejected here
     nf, nl = int(rng.integers(200, 2500)), int(rng.integers(3, 9))
     while min(cols, rows) / 1.2 ** (nl - 1) < 70:
