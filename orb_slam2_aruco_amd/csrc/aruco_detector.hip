@@ -180,7 +180,7 @@ struct orbfe_aruco {
         const int pw = (cols_ + 2 + 31) / 32;
         const size_t padded_words = (size_t)pw * (rows_ + 2) + 2; // + spare words for ring8()
         // the padded bit image goes to LDS when it fits next to the other arrays (160 KiB per workgroup)
-        lds_bits_words = (contours_lds_bytes((int)padded_words, AR_MAX_KEPT) <= 160 * 1024) ? (int)padded_words : 0;
+        lds_bits_words = (contours_lds_bytes((int)padded_words, AR_MAX_KEPT) + 256 <= 160 * 1024) ? (int)padded_words : 0;
         gpad_fu32 = padded_words; // always there: big_mode uses the HBM variant at any size
         // k_contours_relay needs the bit image AND its marker table in LDS; otherwise k_contours_t does all frames.
         // 4096 marker slots on a 32-pixel grid for ordinary frames (a 2048-slot table on a 64-pixel grid would let two workgroups
@@ -188,13 +188,26 @@ struct orbfe_aruco {
         // crossings than 4096 slots hold and would be coarsened to a 128-pixel grid, which doubles the kernel's time (640 x 480:
         // 463 / 592 / 949 us at 32 / 64 / 128 pixels): they get 8192 slots (k_contours_relay8) when the LDS allows.
         relay_tbits = 0;
-        const size_t rl_static = 6 * 1024;
+        // static LDS of the relay kernels (step table, counters), asked from the runtime: a constant here once fell behind the kernels
+        // and frames whose tables only just fitted (1582 x 619: 156,976 B dynamic) failed at launch
+        size_t rl_static = 0;
+        {
+            const void* fns[3] = {reinterpret_cast<const void*>(k_contours_relay), reinterpret_cast<const void*>(k_contours_relay8),
+                                  reinterpret_cast<const void*>(k_contours_relay8g)};
+            for (const void* fn : fns) {
+                hipFuncAttributes fa{};
+                ORBFE_HIP(hipFuncGetAttributes(&fa, fn));
+                rl_static = std::max(rl_static, (size_t)fa.sharedSizeBytes);
+            }
+            rl_static += 256;
+        }
         const bool large = (size_t)rows_ * cols_ > (size_t)640 * 480 * 3 / 2;
         if (lds_bits_words && large && relay_lds_bytes(lds_bits_words, RL_KCAP, 13) + rl_static <= 160 * 1024) { relay_tbits = 13; relay_kshift = 5; }
         else if (lds_bits_words && relay_lds_bytes(lds_bits_words, RL_KCAP, 12) + rl_static <= 160 * 1024) { relay_tbits = 12; relay_kshift = 5; }
         // frames whose bit image does not fit LDS: the relay formulation with the bit image in HBM (k_contours_relay8g)
         // (and room for as many kept borders as the single-walker kernel's big-frame mode: busy 1920 x 1080 frames have > 1024)
-        relay_global = !lds_bits_words && relay_lds_bytes(0, AR_MAX_KEPT_BIG, 13) + rl_static <= 160 * 1024;
+        // (also frames whose bit image fits LDS for the single-walker kernel but not next to a marker table)
+        relay_global = !relay_tbits && relay_lds_bytes(0, AR_MAX_KEPT_BIG, 13) + rl_static <= 160 * 1024;
         relay_kcap = RL_KCAP;
         if (relay_global) { relay_tbits = 13; relay_kshift = 5; relay_kcap = AR_MAX_KEPT_BIG; }
         rows = rows_; cols = cols_;
@@ -291,7 +304,7 @@ struct orbfe_aruco {
         { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(kfn), (size_t)(lds)); if (rc_lds_) return rc_lds_; }
         const bool relay = relay_tbits && !force_legacy && !big_mode;
         for (int r_ = 0; relay && r_ < ORBFE_REPS_ARUCO(1); r_++) {
-            const size_t rlds = relay_lds_bytes(lds_bits_words, relay_kcap, relay_tbits);
+            const size_t rlds = relay_lds_bytes(relay_global ? 0 : lds_bits_words, relay_kcap, relay_tbits);
             if (relay_global) {
                 { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(k_contours_relay8g), (size_t)(rlds)); if (rc_lds_) return rc_lds_; }
                 hipLaunchKernelGGL(k_contours_relay8g, dim3(B), dim3(RL_THREADS_BIG), rlds, s, d_bits.as<uint32_t>(), bits_fu32, wpr,

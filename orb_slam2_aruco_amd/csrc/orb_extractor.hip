@@ -40,7 +40,12 @@ int ensure_dyn_lds(const void* fn, size_t bytes)
     std::lock_guard<std::mutex> lock(mu);
     size_t& have = done[std::make_pair(dev, fn)];
     if (have >= bytes && have != 0) return ORBFE_OK;
-    ORBFE_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError(); // do not leave the error for the next call to trip over
+        return fail(ORBFE_ERR_CAPACITY, "a kernel needs %zu bytes of dynamic LDS (plus its static LDS): more than a workgroup can have (%s)",
+                    bytes, hipGetErrorString(e));
+    }
     have = bytes;
     return ORBFE_OK;
 }

@@ -310,6 +310,21 @@ def test_corner_none_modes_and_contours(orbfe, oracle):
             bad()
 
 
+@pytest.mark.parametrize("rows,cols", [(619, 1582), (700, 1400), (760, 1500), (655, 1599)])
+def test_frames_at_the_lds_boundary_of_the_relay_kernels(orbfe, oracle, rows, cols):
+    """Frame sizes whose bit image only just fits (or just does not fit) LDS next to the marker table: the kernel variant is chosen
+    from the kernels' real static LDS (a constant once fell behind: 1582 x 619 and 1400 x 700 failed at launch).  Found by
+    tools/stress_aruco.py."""
+    img, _ = synth.scene(rows, cols, rows + cols, "ARUCO", 4, side_range=(50, 150))
+    det = orbfe.MarkerDetector("ARUCO")
+    ora = oracle.ArucoOracle("ARUCO")
+    got, want = det.detect(img), ora.detect(img)
+    assert det.counts(0)["flags"] == 0
+    assert np.array_equal(det.thresholded(0), ora.stage_image(0))
+    assert np.array_equal(got["id"], want["id"]) and np.allclose(got["corners"], want["corners"], atol=1e-3)
+    assert len(want) > 0
+
+
 def test_small_border_kernel_on_lds_resident_frames():
     """k_contours_small (the borders between grid lines as their own launch) is the default only where the bit image lives in HBM
     (1920x1080); ORBFE_ARUCO_SMALL_SEPARATE=1 switches it on for LDS-resident frames too.  The contour tests must pass either way:
