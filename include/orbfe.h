@@ -483,7 +483,8 @@ int orbfe_aruco_set_corner_refinement(orbfe_aruco* h, int method);
  * Host pointers; synchronises the device. */
 int orbfe_aruco_marker_contour(orbfe_aruco* h, int frame, int marker, int32_t* xy, int capacity, int32_t* n);
 
-/* detect(image) -> markers sorted by id, corners refined by contour lines. Host pointers, one CV_8UC1 frame. */
+/* detect(image) -> markers sorted by id, corners refined by contour lines. Host pointers, one CV_8UC1 frame.
+ * Frames up to 4095 pixels wide (adaptive-threshold windows up to 31, markerdetector_impl.cpp:3765-3809). */
 int orbfe_aruco_detect(orbfe_aruco* h, const uint8_t* img, int rows, int cols, size_t step, orbfe_marker* out,
                        int capacity, int32_t* n_out);
 int orbfe_aruco_detect_batch(orbfe_aruco* h, const uint8_t* imgs, int nframes, size_t frame_stride, int rows, int cols,

@@ -219,7 +219,7 @@ struct orbfe_aruco {
         ORBFE_HIP(hipMemcpy(d_tabs.p, tabs.data(), tabs.size() * 4, hipMemcpyHostToDevice));
         return ORBFE_OK;
     }
-    static const int TH_MAXR_HOST = 7;
+    static const int TH_MAXR_HOST = 15; // windows up to 31 (k_adaptive_threshold<15>): frames up to 4095 pixels wide
 
     int ensure_workspace(int B)
     {
@@ -293,7 +293,8 @@ struct orbfe_aruco {
             else if (th_magic && win == 7) hipLaunchKernelGGL(k_adaptive_threshold_t<7>, tg1, dim3(256), 0, s, src0, cols, rows, 7, th_magic, bp, bits_fu32, wpr, ntx, ntl, ntl * B);
             else if (th_magic && win == 11) hipLaunchKernelGGL(k_adaptive_threshold_t<11>, tg1, dim3(256), 0, s, src0, cols, rows, 7, th_magic, bp, bits_fu32, wpr, ntx, ntl, ntl * B);
             else if (th_magic && win == 15) hipLaunchKernelGGL(k_adaptive_threshold_t<15>, tg1, dim3(256), 0, s, src0, cols, rows, 7, th_magic, bp, bits_fu32, wpr, ntx, ntl, ntl * B);
-            else hipLaunchKernelGGL(k_adaptive_threshold, tg, dim3(256), 0, s, src0, cols, rows, win, 7, 1.0 / (win * win), bp, bits_fu32, wpr);
+            else if (win <= 15) hipLaunchKernelGGL(k_adaptive_threshold<7>, tg, dim3(256), 0, s, src0, cols, rows, win, 7, 1.0 / (win * win), bp, bits_fu32, wpr);
+            else hipLaunchKernelGGL(k_adaptive_threshold<15>, tg, dim3(256), 0, s, src0, cols, rows, win, 7, 1.0 / (win * win), bp, bits_fu32, wpr);
         }
         timer.mark(s, "threshold");
         const bool big = big_mode || !lds_bits_words;

@@ -27,10 +27,13 @@ __device__ __forceinline__ uint32_t bl_dot4_a(uint32_t a, uint32_t b, uint32_t c
 // ---------------------------------------------------------------------------------------- threshold -----------
 // cv::adaptiveThreshold(MEAN_C, BINARY_INV, win, C): mean = round(boxsum / win^2) with BORDER_REPLICATE,
 // out = (src - mean <= -C).  Tile 64 x 16 per workgroup; one wave = one row of 64 px -> one 64-bit ballot store.
-#define TH_MAXR 7
+// TH_MAXR = largest window radius the instantiation holds: 7 (windows up to 15: frames up to 2047 pixels wide, where the
+// specialised kernels below do not apply) and 15 (windows up to 31: frames up to 4095 pixels wide)
+template <int TH_MAXR>
 __global__ __launch_bounds__(256) void k_adaptive_threshold(ImgView src, int W, int H, int win, int C, double scale,
                                                             uint32_t* __restrict__ bits, size_t bits_fstride, int wpr)
 {
+    constexpr int TH_NLD = (16 + 2 * TH_MAXR + 3) / 4; // rows of a strip per wave
     __shared__ uint8_t sin[16 + 2 * TH_MAXR][64 + 2 * TH_MAXR + 2];
     __shared__ uint16_t sh[16 + 2 * TH_MAXR][64];
     const int r = win >> 1;
@@ -39,21 +42,21 @@ __global__ __launch_bounds__(256) void k_adaptive_threshold(ImgView src, int W, 
     const uint8_t* img = src.base + (size_t)f * src.fstride;
     // lane = column (clamped once per thread = BORDER_REPLICATE), wave = rows; 64 x 64 tile as four 16-row strips
     const int xa = min(max(tx0 + lane - r, 0), W - 1);
-    const int xb = min(max(tx0 + 64 + (lane & 15) - r, 0), W - 1);
+    const int xb = min(max(tx0 + 64 + (lane & (TH_MAXR > 7 ? 31 : 15)) - r, 0), W - 1); // halo column 64 + lane, lane < 2 r
     for (int ty0 = tyb; ty0 < tyb + 64 && ty0 < H; ty0 += 16) {
         const int rows = 16 + 2 * r;
         __syncthreads();
         {
-            uint8_t va[8], vb[8]; // rows <= 30 -> at most 8 per wave; all loads issued before the LDS stores
+            uint8_t va[TH_NLD], vb[TH_NLD]; // all loads issued before the LDS stores
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
+            for (int k = 0; k < TH_NLD; k++) {
                 const int rr = wid + 4 * k;
                 const uint8_t* row = img + (size_t)min(max(ty0 + min(rr, rows - 1) - r, 0), H - 1) * src.pitch;
                 va[k] = row[xa];
                 vb[k] = row[xb];
             }
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
+            for (int k = 0; k < TH_NLD; k++) {
                 const int rr = wid + 4 * k;
                 if (rr < rows) {
                     sin[rr][lane] = va[k];
@@ -89,6 +92,9 @@ __global__ __launch_bounds__(256) void k_adaptive_threshold(ImgView src, int W, 
         }
     }
 }
+
+template __global__ void k_adaptive_threshold<7>(ImgView, int, int, int, int, double, uint32_t*, size_t, int);
+template __global__ void k_adaptive_threshold<15>(ImgView, int, int, int, int, double, uint32_t*, size_t, int);
 
 // The same threshold on the packed dot-product instructions (the generic kernel above issues 2 * 15 predicated LDS reads
 // and adds per pixel and an fp64 multiply for the mean).  64 x 64 tile per workgroup, WIN = 2 R + 1 a template parameter:

@@ -28,6 +28,7 @@ struct ArLevel {
     long long off; // byte offset inside a frame's pyramid block (level 0 is the input image)
 };
 
+template <int TH_MAXR>
 __global__ void k_adaptive_threshold(ImgView src, int W, int H, int win, int C, double scale, uint32_t* bits,
                                      size_t bits_fstride, int wpr);
 template <int WIN>

@@ -310,11 +310,11 @@ def test_corner_none_modes_and_contours(orbfe, oracle):
             bad()
 
 
-@pytest.mark.parametrize("rows,cols", [(619, 1582), (700, 1400), (760, 1500), (655, 1599)])
+@pytest.mark.parametrize("rows,cols", [(619, 1582), (700, 1400), (760, 1500), (655, 1599), (820, 2341), (603, 2172)])
 def test_frames_at_the_lds_boundary_of_the_relay_kernels(orbfe, oracle, rows, cols):
     """Frame sizes whose bit image only just fits (or just does not fit) LDS next to the marker table: the kernel variant is chosen
-    from the kernels' real static LDS (a constant once fell behind: 1582 x 619 and 1400 x 700 failed at launch).  Found by
-    tools/stress_aruco.py."""
+    from the kernels' real static LDS (a constant once fell behind: 1582 x 619 and 1400 x 700 failed at launch); frames wider than
+    2047 pixels have threshold windows of 17 and more (k_adaptive_threshold<15>).  Found by tools/stress_aruco.py / stress.py."""
     img, _ = synth.scene(rows, cols, rows + cols, "ARUCO", 4, side_range=(50, 150))
     det = orbfe.MarkerDetector("ARUCO")
     ora = oracle.ArucoOracle("ARUCO")

@@ -11,7 +11,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad = 0
 for case in range(n):
     big = case % 7 == 3
-    cols, rows = int(rng.integers(200, 1700 if big else 1000)), int(rng.integers(160, 1100 if big else 760))
+    cols, rows = int(rng.integers(200, 2600 if big else 1000)), int(rng.integers(160, 1500 if big else 760))
     rows = max(rows, cols // 12)               # more than 16 roots is a capacity limit of the quadtree kernels
     if rows > cols: cols, rows = rows, cols   # portrait frames give nIni = 0 in DistributeOctTree: undefined in the reference, rejected here
     nf, nl = int(rng.integers(200, 2500)), int(rng.integers(3, 9))
