@@ -95,7 +95,8 @@ int orbfe_extractor_max_keypoints(const orbfe_extractor* h);
  * directions (below that it has no FAST cell); levels up to 4127 pixels (a keypoint travels as 12 + 12 bits inside the kernels);
  * 1 to 16 quadtree roots per level, nIni = round(width / height) of the border-less level (ORBextractor.cc:544): portrait frames give
  * nIni = 0, on which the reference divides by zero and indexes an empty vector; frames wider than 16.5 : 1 are a capacity limit of
- * the quadtree kernels. */
+ * the quadtree kernels; a level's keypoint quota (mnFeaturesPerLevel) up to about 2700 -- its node lists live in LDS -- i.e.
+ * nfeatures up to ~12000 at 8 levels and scale 1.2 (ORBFE_ERR_CAPACITY beyond). */
 int orbfe_extract(orbfe_extractor* h, const uint8_t* img, int rows, int cols, size_t step, orbfe_keypoint* kps,
                   uint8_t* desc, int capacity, int32_t* n_out);
 

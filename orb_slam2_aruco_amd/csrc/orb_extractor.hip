@@ -301,6 +301,21 @@ struct orbfe_extractor {
         veccap = 1;
         while (veccap < nodecap) veccap <<= 1;
         keycap_lds = 6144;
+        {   // the general kernel's key buffers share LDS with the node lists: large quotas leave less room (levels whose candidates do
+            // not fit work out of the HBM key scratch)
+            const long long room = (long long)160 * 1024 - 3072 - (long long)qt_lds_bytes(0, nodecap, veccap);
+            keycap_lds = (int)std::max<long long>(0, std::min<long long>(6144, room / 8)) & ~63;
+        }
+        {
+            // the node lists of DistributeOctTree live in LDS, sized by the largest per-level quota: say so here, not at launch
+            int max_ini = 1;
+            for (const LevelGeom& g : geom) max_ini = std::max(max_ini, g.nIni);
+            const size_t need = std::max(qp_lds_bytes(max_ini, max_ini <= 4 ? 5 : 4, nodecap, veccap), qt_lds_bytes(keycap_lds, nodecap, veccap));
+            if (need + 2048 > (size_t)160 * 1024)
+                return fail(ORBFE_ERR_CAPACITY, "a pyramid level's quota of %d keypoints (nfeatures %d over %d levels at scale %.3f) needs %zu bytes "
+                            "of LDS for the quadtree: more than a workgroup has (about 2700 keypoints per level fit)", maxcap, nfeatures, nlevels,
+                            (double)scaleFactor, need);
+        }
         batch_cap = 0; // force workspace re-allocation
         if (tabs.empty()) tabs.push_back(0);
         int rc;

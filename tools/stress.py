@@ -14,8 +14,10 @@ for case in range(n):
     cols, rows = int(rng.integers(200, 2600 if big else 1000)), int(rng.integers(160, 1500 if big else 760))
     rows = max(rows, cols // 12)               # more than 16 roots is a capacity limit of the quadtree kernels
     if rows > cols: cols, rows = rows, cols   # portrait frames give nIni = 0 in DistributeOctTree: undefined in the reference, rejected here
-    nf, nl = int(rng.integers(200, 2500)), int(rng.integers(3, 9))
-    while min(cols, rows) / 1.2 ** (nl - 1) < 70:
+    nf, nl = int(rng.integers(50, 6000)), int(rng.integers(1, 13))
+    sc = [1.2, 1.2, 1.1, 1.44, 2.0][int(rng.integers(0, 5))]
+    ini, mn = [(20, 7), (20, 7), (30, 10), (12, 5), (7, 7)][int(rng.integers(0, 5))]
+    while min(cols, rows) / sc ** (nl - 1) < 70:
         nl -= 1
     dic = ["ARUCO", "ARUCO_MIP_36h12", "ARUCO_MIP_25h7", "TAG36h11"][case % 4]
     img, _ = synth.scene(rows, cols, int(rng.integers(1, 10 ** 6)), dic, int(rng.integers(0, 5)), side_range=(30, max(31, min(rows, cols) // 4)))
@@ -23,7 +25,7 @@ for case in range(n):
         salt = rng.random(img.shape) < 0.1
         img = np.where(salt, rng.integers(0, 256, img.shape), img).astype(np.uint8)
     try:
-        ex = binding.ORBextractor(nf, 1.2, nl, 20, 7); ora = O.OrbOracle(nf, 1.2, nl, 20, 7)
+        ex = binding.ORBextractor(nf, sc, nl, ini, mn); ora = O.OrbOracle(nf, sc, nl, ini, mn)
         k, d = ex(img); ok_, od = ora.extract(img)
         why = []
         if not (len(k) == len(ok_) and all(np.array_equal(k[f], ok_[f]) for f in ("x", "y", "octave", "response", "angle", "size"))): why.append("keypoints %d vs %d" % (len(k), len(ok_)))
@@ -38,8 +40,8 @@ for case in range(n):
         if why: print("   ", why)
     except Exception as e:
         good = False
-        print("case %d %dx%d nf %d nl %d %s: exception %r" % (case, cols, rows, nf, nl, dic, e))
+        print("case %d %dx%d nf %d nl %d sc %.2f th %d/%d %s: exception %r" % (case, cols, rows, nf, nl, sc, ini, mn, dic, e))
     if not good:
         bad += 1
-        print("case %d %dx%d nf %d nl %d %s: MISMATCH" % (case, cols, rows, nf, nl, dic))
+        print("case %d %dx%d nf %d nl %d sc %.2f th %d/%d %s: MISMATCH" % (case, cols, rows, nf, nl, sc, ini, mn, dic))
 print("%d cases, %d mismatches" % (n, bad))
