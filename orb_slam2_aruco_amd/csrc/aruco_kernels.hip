@@ -1445,7 +1445,7 @@ __global__ void k_relay_lut(uint16_t* __restrict__ lut)
 // A walk that starts at a border's start candidate stops at the first grid marker it meets, and a border cannot get past a relay
 // row or column without one (aruco_trace.hpp), so the walk stays between the grid lines around its start.  One WAVE per block of
 // K rows x RS_BLOCK_COLS columns of start pixels, four independent waves per workgroup, no workgroup barrier and no atomics on
-// LDS: the block's part of the bit image in a wave-private LDS tile (K + 4 rows x 11 words), the start candidates of a round of
+// LDS: the block's part of the bit image in a wave-private LDS tile (K + 4 rows x 7 words), the start candidates of a round of
 // rows compacted into a wave-private queue with ballots and scans, then every free lane takes the next candidate off the queue
 // (lane prefix of the ballot of free lanes) and follows it.  Thousands of such waves fill the chip where phase (c) inside a
 // relay kernel is one workgroup per frame waiting on dependent round trips -- to HBM / L2 when the bit image is not in LDS.

@@ -110,15 +110,19 @@ __global__ void k_finalize(const ArRect* rects, int rect_cap, const int32_t* can
 #ifndef RL_STEPS_PER_ITER
 #define RL_STEPS_PER_ITER 2      // walk steps between two looks at the work queue
 #endif
-// k_contours_small (phase (c) of frames with a grid, one wave per block of K rows x 256 columns): threads per workgroup, columns
+// k_contours_small (phase (c) of frames with a grid, one wave per block of K rows x 128 columns): threads per workgroup, columns
 // per block (log2), tile words per row (the block's 8 + one to the left + one to the right + ring8()'s funnel word), tile rows
 // (K <= 128: K + 4), queue entries per wave (>= the start candidates one row of a block can have), rows per round, steps per
 // look at the queue
 #define RS_THREADS 256
-#define RS_BLOCK_SHIFT 8
-#define RS_TW 11
+#ifndef RS_BLOCK_SHIFT
+#define RS_BLOCK_SHIFT 7   // 128 columns: measured against 256 and 64 on the 1920 x 1080 batch (1.32 / 1.47 / 1.78 ms)
+#endif
+#define RS_TW ((1 << (RS_BLOCK_SHIFT - 5)) + 3)
 #define RS_TILE_ROWS (128 + 4)
-#define RS_QCAP 1024
+#ifndef RS_QCAP
+#define RS_QCAP 512
+#endif
 #define RS_ROUND_ROWS 32
 #ifndef RS_STEPS
 #define RS_STEPS 2
