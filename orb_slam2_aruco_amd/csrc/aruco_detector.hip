@@ -30,6 +30,7 @@ struct orbfe_aruco {
     std::vector<size_t> tab_off;          // resize tables for non-exact levels
     size_t pyr_fbytes = 0, bits_fu32 = 0, candq_fu32 = 0, pool_fu32 = 0, gpad_fu32 = 0;
     int lds_bits_words = 0;
+    DevBuf d_twork, d_trect, d_tctr; // k_tail_prep -> k_tail_approx -> k_tail_finish: work list, 4-gon flags, list length
     DevBuf d_rstate, d_lut; // k_contours_relay -> k_contours_small: per-frame grid shift and pool fill; the walks' step table
     DevBuf d_segs, d_tailkeys, d_tailoff, d_small, d_hint; // d_hint: the relay kernel's grid spacing of the previous batch
     int relay_kshift = 5;      // initial grid spacing (log2) of k_contours_relay
@@ -54,7 +55,7 @@ struct orbfe_aruco {
     ~orbfe_aruco()
     {
         for (DevBuf* b : {&d_codes, &d_levels, &d_tabs, &d_bits, &d_pyr, &d_candq, &d_pool, &d_kept, &d_rects,
-                          &d_counts, &d_candidx, &d_ncand, &d_result, &d_gpad, &d_in, &d_out, &d_nout, &d_segs, &d_tailkeys, &d_tailoff, &d_small, &d_hint, &d_rstate, &d_lut, &d_scodes, &d_sids,
+                          &d_counts, &d_candidx, &d_ncand, &d_result, &d_gpad, &d_in, &d_out, &d_nout, &d_segs, &d_tailkeys, &d_tailoff, &d_small, &d_hint, &d_rstate, &d_lut, &d_twork, &d_trect, &d_tctr, &d_scodes, &d_sids,
                           &d_msrc})
             b->release();
         if (own_stream) (void)hipStreamDestroy(own_stream);
@@ -234,11 +235,16 @@ struct orbfe_aruco {
             (rc = d_gpad.ensure(std::max<size_t>(gpad_fu32 * 4 * B, 16))) ||
             (rc = d_segs.ensure(std::max<size_t>(((size_t)sizeof(RelaySeg) << relay_tbits) * B, 16))) ||
             (rc = d_tailkeys.ensure((size_t)relay_kcap * 8 * B)) || (rc = d_tailoff.ensure((size_t)relay_kcap * 4 * B)) ||
-            (rc = d_small.ensure((size_t)relay_kcap * 16 * B)) || (rc = d_rstate.ensure((size_t)8 * B)))
+            (rc = d_small.ensure((size_t)relay_kcap * 16 * B)) || (rc = d_rstate.ensure((size_t)8 * B)) ||
+            (rc = d_twork.ensure((size_t)relay_kcap * 32 * B)) || (rc = d_trect.ensure((size_t)relay_kcap * B)))
             return rc;
         if (!d_hint.p) {
             if ((rc = d_hint.ensure(16))) return rc;
             ORBFE_HIP(hipMemset(d_hint.p, 0, 16));
+        }
+        if (!d_tctr.p) {   // k_tail_finish leaves the two counters at zero for the next batch
+            if ((rc = d_tctr.ensure(16))) return rc;
+            ORBFE_HIP(hipMemset(d_tctr.p, 0, 16));
         }
         if (!d_lut.p) {
             if ((rc = d_lut.ensure(2048 * 2))) return rc;
@@ -333,18 +339,20 @@ struct orbfe_aruco {
                                    d_pool.as<uint32_t>(), pool_fu32, (int)pool_fu32, relay_kcap, d_tailkeys.as<unsigned long long>(),
                                    d_tailoff.as<int32_t>(), d_counts.as<int32_t>());
             }
-            if (relay_global) {
-                const size_t tlds = tail_lds_bytes(relay_kcap, 384, RT_THREADS_BIG);
-                { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(k_contours_tail_t<RT_THREADS_BIG>), (size_t)(tlds)); if (rc_lds_) return rc_lds_; }
-                hipLaunchKernelGGL(k_contours_tail_t<RT_THREADS_BIG>, dim3(B), dim3(RT_THREADS_BIG), tlds, s, d_tailkeys.as<unsigned long long>(),
-                                   d_tailoff.as<int32_t>(), relay_kcap, d_pool.as<uint32_t>(), pool_fu32, d_kept.as<ArKept>(),
-                                   relay_kcap, d_rects.as<ArRect>(), AR_MAX_RECTS, d_counts.as<int32_t>(), (int)tlds);
-            } else {
-                const size_t tlds = tail_lds_bytes(relay_kcap, 1280);
-                { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(k_contours_tail_t<RT_THREADS>), (size_t)(tlds)); if (rc_lds_) return rc_lds_; }
-                hipLaunchKernelGGL(k_contours_tail_t<RT_THREADS>, dim3(B), dim3(RT_THREADS), tlds, s, d_tailkeys.as<unsigned long long>(),
-                                   d_tailoff.as<int32_t>(), relay_kcap, d_pool.as<uint32_t>(), pool_fu32, d_kept.as<ArKept>(),
-                                   relay_kcap, d_rects.as<ArRect>(), AR_MAX_RECTS, d_counts.as<int32_t>(), (int)tlds);
+            // (g): sort + rank per frame, approxPolyDP by persistent waves over the whole batch's borders, rectangles per frame
+            {
+                const int pts = 1024;   // LDS point buffer per wave; longer borders are read from the pool
+                const size_t alds = tail_approx_lds_bytes(pts);
+                const int tail_wgs = std::min(RT_WGS, B * 128);
+                { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(k_tail_prep), tail_prep_lds_bytes(relay_kcap)); if (rc_lds_) return rc_lds_; }
+                { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(k_tail_approx), alds); if (rc_lds_) return rc_lds_; }
+                hipLaunchKernelGGL(k_tail_prep, dim3(B), dim3(relay_global ? 1024 : 256), tail_prep_lds_bytes(relay_kcap), s,
+                                   d_tailkeys.as<unsigned long long>(), d_tailoff.as<int32_t>(), relay_kcap, d_counts.as<int32_t>(),
+                                   d_twork.as<uint4>(), (size_t)relay_kcap * B, d_tctr.as<int32_t>());
+                hipLaunchKernelGGL(k_tail_approx, dim3(tail_wgs), dim3(256), alds, s, relay_kcap, d_twork.as<uint4>(), (size_t)relay_kcap * B, d_tctr.as<int32_t>(),
+                                   d_pool.as<uint32_t>(), pool_fu32, d_kept.as<ArKept>(), relay_kcap, d_trect.as<uint8_t>(), pts);
+                hipLaunchKernelGGL(k_tail_finish, dim3(B), dim3(64), 0, s, relay_kcap, d_trect.as<uint8_t>(), d_kept.as<ArKept>(), relay_kcap,
+                                   d_rects.as<ArRect>(), AR_MAX_RECTS, d_counts.as<int32_t>(), d_tctr.as<int32_t>());
             }
         }
         // the single-walker kernel: images whose bit image does not fit LDS next to the relay kernel's tables, or forced

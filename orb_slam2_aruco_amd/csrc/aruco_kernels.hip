@@ -246,12 +246,59 @@ __global__ __launch_bounds__(256) void k_half_area4(ImgView src, ImgView dst, in
 // ---------------------------------------------------------------------------------------- contours ------------
 struct ApPt { int x, y; };
 
-// approxPolyDP (closed curve) by one wave; P = contour points (x | y<<16), n > 0.  Returns the number of
-// vertices (<= AP_OUT, or AP_OUT+1 on overflow) in `out` (LDS).  Reductions keep the FIRST maximum like the
-// serial loops of cv::approxPolyDP_ ("dist > max_dist").
-__device__ __forceinline__ int approx_poly_wave(const uint32_t* __restrict__ P, int n, ApPt* out, int2* stack, int lane)
+// Maximum / minimum over the G lanes of a group (G = 64: the wave; G = 16: a DPP row, every lane of the row gets the result:
+// xor 1, xor 2 as quad permutations, then row_half_mirror and row_mirror -- the groups of a wave may have diverged, a row has not).
+template <int G> __device__ __forceinline__ int group_max(int v)
+{
+    if (G == 64) return wave_max(v);
+    v = max(v, ORBFE_DPP(v, v, 0xB1, 0xf)); v = max(v, ORBFE_DPP(v, v, 0x4E, 0xf));
+    v = max(v, ORBFE_DPP(v, v, 0x141, 0xf)); v = max(v, ORBFE_DPP(v, v, 0x140, 0xf));
+    return v;
+}
+template <int G> __device__ __forceinline__ int group_min(int v)
+{
+    if (G == 64) return wave_min(v);
+    v = min(v, ORBFE_DPP(v, v, 0xB1, 0xf)); v = min(v, ORBFE_DPP(v, v, 0x4E, 0xf));
+    v = min(v, ORBFE_DPP(v, v, 0x141, 0xf)); v = min(v, ORBFE_DPP(v, v, 0x140, 0xf));
+    return v;
+}
+
+// approxPolyDP (closed curve) by a group of G lanes (`lane`: 0 .. G-1); P = contour points (x | y<<16), n > 0.  Returns the number
+// of vertices (<= OUTCAP, or OUTCAP+1 on overflow) in `out` (LDS).  Reductions keep the FIRST maximum like the serial loops of
+// cv::approxPolyDP_ ("dist > max_dist").  The callers only ask "is it 4?": an overflow of `out` (or of the stack: every pending
+// slice ends as at least one vertex) means more than the capacity before the clean-up pass, which at most halves the count --
+// so any capacity of 10 or more answers exactly.
+template <int G, int OUTCAP, int STACKCAP>
+__device__ __forceinline__ int approx_poly_g(const uint32_t* __restrict__ P, int n, ApPt* out, int2* stack, int lane)
 {
     auto rd = [&](int i) -> ApPt { const uint32_t v = P[i]; return ApPt{(int)(v & 0xffff), (int)(v >> 16)}; };
+    // Largest metric(point (i0 + j) mod n) over j in [j_begin, j_end) and the first j it occurs at, per lane (lane l looks at
+    // j = j_begin + l, + G, ...; ">" keeps the earliest).  Four chunks per trip while more than one is left: the loads of a long
+    // border (LDS, or the pool in L2 when it does not fit) are in flight together instead of one latency per chunk.
+    auto scan = [&](int i0, int j_begin, int j_end, auto metric, int& bd, int& bj) {
+        int j0 = j_begin;
+        for (; j_end - j0 > G; j0 += 4 * G) {
+            uint32_t w[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                int idx = i0 + min(j0 + u * G + lane, j_end - 1);
+                if (idx >= n) idx -= n;
+                w[u] = P[idx];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int j = j0 + u * G + lane, d = metric(w[u]);
+                if (j < j_end && d > bd) { bd = d; bj = j; }
+            }
+        }
+        const int j = j0 + lane;
+        if (j < j_end) {
+            int idx = i0 + j;
+            if (idx >= n) idx -= n;
+            const int d = metric(P[idx]);
+            if (d > bd) { bd = d; bj = j; }
+        }
+    };
     double eps = (double)n * 0.05;
     eps *= eps;
     int nout = 0, top = 0;
@@ -265,19 +312,9 @@ __device__ __forceinline__ int approx_poly_wave(const uint32_t* __restrict__ P, 
         // (far above any frame here), so squared distances and cross products fit 32 bits: the maximum is two 32-bit DPP reductions
         // (largest distance, then smallest j among the lanes that hold it) instead of one on 64-bit keys
         int bd = 0, bj = 0x7fffffff; // this lane: largest distance so far and the first j it occurred at (j grows chunk by chunk)
-        for (int j0 = 1; j0 < n; j0 += 64) {
-            const int j = j0 + lane;
-            if (j < n) {
-                int idx = pos + j;
-                if (idx >= n) idx -= n;
-                const ApPt p = rd(idx);
-                const int dx = p.x - start_pt.x, dy = p.y - start_pt.y;
-                const int d = dx * dx + dy * dy;
-                if (d > bd) { bd = d; bj = j; }
-            }
-        }
-        const int max_dist = wave_max(bd);
-        const int first_j = wave_min(bd == max_dist ? bj : 0x7fffffff);
+        scan(pos, 1, n, [&](uint32_t w) { const int dx = (int)(w & 0xffff) - start_pt.x, dy = (int)(w >> 16) - start_pt.y; return dx * dx + dy * dy; }, bd, bj);
+        const int max_dist = group_max<G>(bd);
+        const int first_j = group_min<G>(bd == max_dist ? bj : 0x7fffffff);
         right_start = max_dist > 0 ? first_j : right_start; // no dist > 0: index unchanged
         le_eps = (double)max_dist <= eps;
         // pos returns to the start index after the sweep (READ_PT wrapped n times)
@@ -302,19 +339,9 @@ __device__ __forceinline__ int approx_poly_wave(const uint32_t* __restrict__ P, 
             int cnt = sl.y - p1; // points strictly between
             if (cnt < 0) cnt += n;
             int bd = 0, bj = 0x7fffffff;
-            for (int j0 = 0; j0 < cnt; j0 += 64) {
-                const int j = j0 + lane;
-                if (j < cnt) {
-                    int idx = p1 + j;
-                    if (idx >= n) idx -= n;
-                    const ApPt p = rd(idx);
-                    int d = (p.y - sp.y) * dx - (p.x - sp.x) * dy;
-                    d = d < 0 ? -d : d;
-                    if (d > bd) { bd = d; bj = j; }
-                }
-            }
-            const int maxd = wave_max(bd);
-            const int first_j = wave_min(bd == maxd ? bj : 0x7fffffff);
+            scan(p1, 0, cnt, [&](uint32_t w) { const int d = ((int)(w >> 16) - sp.y) * dx - ((int)(w & 0xffff) - sp.x) * dy; return d < 0 ? -d : d; }, bd, bj);
+            const int maxd = group_max<G>(bd);
+            const int first_j = group_min<G>(bd == maxd ? bj : 0x7fffffff);
             const double md = (double)maxd;
             le = md * md <= eps * (double)((long long)dx * dx + (long long)dy * dy);
             if (maxd > 0) {
@@ -325,11 +352,11 @@ __device__ __forceinline__ int approx_poly_wave(const uint32_t* __restrict__ P, 
             le = true;
         }
         if (le) {
-            if (nout < AP_OUT) out[nout] = sp;
+            if (nout < OUTCAP) out[nout] = sp;
             nout++;
-            if (nout > AP_OUT) return AP_OUT + 1;
+            if (nout > OUTCAP) return OUTCAP + 1;
         } else {
-            if (top + 2 > AP_STACK) return AP_OUT + 1;
+            if (top + 2 > STACKCAP) return OUTCAP + 1;
             stack[top++] = make_int2(split, sl.y);
             stack[top++] = make_int2(sl.x, split);
         }
@@ -368,6 +395,11 @@ __device__ __forceinline__ int approx_poly_wave(const uint32_t* __restrict__ P, 
         }
     }
     return new_count;
+}
+
+__device__ __forceinline__ int approx_poly_wave(const uint32_t* __restrict__ P, int n, ApPt* out, int2* stack, int lane)
+{
+    return approx_poly_g<64, AP_OUT, AP_STACK>(P, n, out, stack, lane);
 }
 
 __device__ bool convex4(const ApPt* p)
@@ -1638,51 +1670,201 @@ __global__ __launch_bounds__(RS_THREADS) void k_contours_small(
     if (lane == 0 && ncand_w) atomicAdd(&counts[f * 4 + 3], ncand_w);
 }
 
-// ---- (g) of the relay formulation as its own kernel: sort, approxPolyDP, rectangles for the borders k_contours_relay
-// kept.  (Separate because approxPolyDP needs twice the registers of the walks: the relay kernel stays at 64 VGPRs, so
-// two of its workgroups share a CU.)  Frames the relay kernel gave up on are skipped; k_contours_t redoes them.
-template <int NT>
-__global__ __launch_bounds__(NT) void k_contours_tail_t(const unsigned long long* __restrict__ tail_keys,
-                                                               const int32_t* __restrict__ tail_off, int kcap,
-                                                               const uint32_t* __restrict__ pool, size_t pool_fstride,
-                                                               ArKept* __restrict__ kept_out, int kept_cap,
-                                                               ArRect* __restrict__ rects_out, int rect_cap,
-                                                               int32_t* __restrict__ counts, int lds_bytes)
+// ---- (g) of the relay formulation: sort, approxPolyDP, rectangles for the borders the relay kernel (and k_contours_small) kept.
+// Three launches, because approxPolyDP is one wave per border and a frame has 60 (640 x 480) to 2000 (1920 x 1080) of them: as one
+// workgroup of four waves per frame it kept a fifth of the chip busy (and 1280 x 720 frames waited 0.8 ms for it).
+//   k_tail_prep    (workgroup per frame)  sort the kept borders into findContours' order (reverse discovery), rank them by length,
+//                                         append (frame, border) work items, longest first, to one list for the whole batch
+//   k_tail_approx  (persistent waves)     a wave takes the next work item off the list: approxPolyDP(eps = 0.05 len) + convexity test
+//   k_tail_finish  (wave per frame)       ordered compaction of the 4-gons into the frame's rectangle list, per-frame counts
+// Frames the relay kernel gave up on (flags != 0) contribute nothing; the host entry points redo them.
+__global__ __launch_bounds__(1024) void k_tail_prep(const unsigned long long* __restrict__ tail_keys, const int32_t* __restrict__ tail_off,
+                                                    int kcap, const int32_t* __restrict__ counts, uint4* __restrict__ work,
+                                                    size_t work_half, int32_t* __restrict__ ctr)
 {
-    __builtin_amdgcn_s_setprio(2); // latency-bound: its few waves go first when a VALU-bound kernel shares the CU
-    extern __shared__ __align__(16) unsigned char ct_smem[];
-    __shared__ int s_flags, s_ncand;
-    __shared__ unsigned s_tailq;
-    const int tid = threadIdx.x, f = blockIdx.x;
+    __builtin_amdgcn_s_setprio(2);
+    extern __shared__ __align__(16) unsigned char tp_smem[];
+    __shared__ int s_base, s_base2, s_hist[RT_BUCKETS];
+    const int tid = threadIdx.x, f = blockIdx.x, NT = (int)blockDim.x;
+    const int nkept = counts[f * 4 + 2] ? 0 : min(counts[f * 4 + 0], kcap);
+    if (nkept <= 0) return;
+    unsigned long long* kkey = (unsigned long long*)tp_smem;
+    int* off_u = (int*)(kkey + kcap);
+    for (int k = tid; k < nkept; k += NT) { kkey[k] = tail_keys[(size_t)f * kcap + k]; off_u[k] = tail_off[(size_t)f * kcap + k]; }
+    int Pn = 1;
+    while (Pn < nkept) Pn <<= 1;
+    for (int i = nkept + tid; i < Pn; i += NT) kkey[i] = ~0ull;
+    for (int i = tid; i < RT_BUCKETS; i += NT) s_hist[i] = 0;
+    __syncthreads();
+    for (int k = 2; k <= Pn; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (Pn >> 1); t += NT) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int l = i | j;
+                const unsigned long long a = kkey[i], b = kkey[l];
+                const bool up = ((i & k) == 0);
+                if ((a > b) == up) { kkey[i] = b; kkey[l] = a; }
+            }
+            __syncthreads();
+        }
+    // the frame's part of the work list, long borders first: a counting sort on length classes of 8 points (the order only spreads
+    // the work -- every border's result lands in its own slot -- so the order inside a class may vary from run to run)
+    auto bucket_of = [](int len) { return RT_BUCKETS - 1 - (min(len, RT_BUCKETS * 8 - 1) >> 3); };
+    for (int k = tid; k < nkept; k += NT) atomicAdd(&s_hist[bucket_of((int)((kkey[k] >> 13) & 0x7ffff))], 1);
+    __syncthreads();
+    if (tid < 64) { // exclusive scan of the class counts by one wave
+        int v[RT_BUCKETS / 64], sum = 0;
+        for (int i = 0; i < RT_BUCKETS / 64; i++) { v[i] = s_hist[tid * (RT_BUCKETS / 64) + i]; sum += v[i]; }
+        int incl = sum;
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (tid >= d) incl += o; }
+        int run = incl - sum;
+        for (int i = 0; i < RT_BUCKETS / 64; i++) { s_hist[tid * (RT_BUCKETS / 64) + i] = run; run += v[i]; }
+    }
+    __syncthreads();
+    // borders of fewer than RT_QUAD_MAX points go to the second list (k_tail_approx does four of them at a time)
+    const int nlong = s_hist[bucket_of(RT_QUAD_MAX - 1)];
+    __syncthreads();
+    if (tid == 0) { s_base = atomicAdd(&ctr[0], nlong); s_base2 = atomicAdd(&ctr[1], nkept - nlong); }
+    __syncthreads();
+    const int base = s_base, base2 = s_base2 - nlong;
+    uint4* work2 = work + work_half;
+    for (int k = tid; k < nkept; k += NT) {
+        const unsigned long long key = kkey[k];
+        const int len = (int)((key >> 13) & 0x7ffff);
+        const int r = atomicAdd(&s_hist[bucket_of(len)], 1);
+        const uint4 e = make_uint4(((uint32_t)f << 12) | (uint32_t)k, (uint32_t)len, (uint32_t)off_u[(int)((key >> 1) & 0xfff)], 0u);
+        if (r < nlong) work[base + r] = e;
+        else work2[base2 + r] = e;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_tail_approx(int kcap, const uint4* __restrict__ work, size_t work_half, const int32_t* __restrict__ ctr,
+                                                     const uint32_t* __restrict__ pool, size_t pool_fstride, ArKept* __restrict__ kept_out,
+                                                     int kept_cap, uint8_t* __restrict__ rectflag, int pts)
+{
+    extern __shared__ __align__(16) unsigned char ta_smem[];
+    const int lane = threadIdx.x & 63, wid = wave_id();
+    ApPt* o = (ApPt*)ta_smem + wid * AP_OUT;
+    int2* stack = (int2*)((ApPt*)ta_smem + 4 * AP_OUT) + wid * AP_STACK;
+    uint32_t* b = (uint32_t*)((int2*)((ApPt*)ta_smem + 4 * AP_OUT) + 4 * AP_STACK) + (size_t)wid * pts;
+    // The list is sorted by length frame by frame, so dealing it out round-robin balances the waves (a ticket counter shared by
+    // 4096 waves was measured slower than the whole of approxPolyDP: 247 us against the 148 us of the per-frame kernel).  A border
+    // costs a wave three dependent trips to memory (work item, points, result) next to a few microseconds of arithmetic: the item
+    // after the next and the first 128 points of the next border are fetched while the current one is worked on.
+    const int total = ctr[0], nw = (int)gridDim.x * 4;
+    int t = (int)blockIdx.x + wid * (int)gridDim.x;
+    const uint4 none = make_uint4(0u, 0u, 0u, 0u);
+    auto src_of = [&](const uint4& e) { return pool + (size_t)(e.x >> 12) * pool_fstride + e.z; };
+    uint4 e = t < total ? work[t] : none;
+    uint4 e1 = t + nw < total ? work[t + nw] : none;
+    uint32_t p0 = 0, p1 = 0;
+    if (lane < (int)e.y) p0 = src_of(e)[lane];
+    if (lane + 64 < (int)e.y) p1 = src_of(e)[lane + 64];
+    for (; t < total; t += nw) {
+        const uint4 e2 = t + 2 * nw < total ? work[t + 2 * nw] : none;
+        uint32_t q0 = 0, q1 = 0;
+        if (lane < (int)e1.y) q0 = src_of(e1)[lane];
+        if (lane + 64 < (int)e1.y) q1 = src_of(e1)[lane + 64];
+        const int f = (int)(e.x >> 12), k = (int)(e.x & 0xfffu), off = (int)e.z;
+        int n = (int)e.y;
+#ifdef RT_SKIP_LONG
+        if (n > RT_SKIP_LONG) n = 0;
+#endif
+        int ok = 0;
+        if (n > 0) {
+            const uint32_t* src = src_of(e);
+            int nv;
+            if (n <= pts) {
+                b[lane] = p0;         // pts >= 128
+                b[lane + 64] = p1;
+                for (int i = lane + 128; i < n; i += 64) b[i] = src[i];
+                __builtin_amdgcn_wave_barrier();
+                nv = approx_poly_wave(b, n, o, stack, lane);
+            } else {
+                nv = approx_poly_wave(src, n, o, stack, lane);
+            }
+            __builtin_amdgcn_wave_barrier();
+            ok = (nv == 4) && convex4(o);
+        }
+        if (lane == 0) {
+            rectflag[(size_t)f * kcap + k] = (uint8_t)ok;
+            if (ok && k < kept_cap) {
+                ArKept kk;
+                kk.off = off; kk.len = n;
+                for (int j = 0; j < 4; j++) { kk.vx[j] = (short)o[j].x; kk.vy[j] = (short)o[j].y; }
+                kept_out[(size_t)f * kept_cap + k] = kk;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        e = e1; e1 = e2; p0 = q0; p1 = q1;
+    }
+    // The short borders (most of them: a 1280 x 720 frame keeps hundreds of 70 .. 160 points), four per wave, a DPP row of 16 lanes
+    // each: a slice of a short border has a handful of points, so what a border costs is the chain of dependent steps per slice
+    // (pop, two point reads, the sweep, two reductions, the f64 test, push) -- four such chains now overlap in one wave.
+    {
+        const uint4* work2 = work + work_half;
+        const int nshort = ctr[1], g = lane >> 4, gl = lane & 15;
+        ApPt* og = o + g * 16;       // per group: 16 vertices and 16 stack entries, a quarter of the wave's
+        int2* sg = stack + g * 16;
+        uint32_t* bg = b + g * RT_QUAD_MAX;
+        for (int q = (int)blockIdx.x + wid * (int)gridDim.x; q * 4 < nshort; q += nw) {
+            const int idx = q * 4 + g;
+            const uint4 it = idx < nshort ? work2[idx] : none;
+            const int n = (int)it.y;
+            const uint32_t* src = src_of(it);
+            for (int i = gl; i < n; i += 16) bg[i] = src[i];
+            __builtin_amdgcn_wave_barrier();
+            if (n > 0) {
+                const int nv = approx_poly_g<16, 16, 16>(bg, n, og, sg, gl);
+                __builtin_amdgcn_wave_barrier();
+                const int ok = (nv == 4) && convex4(og);
+                if (gl == 0) {
+                    const int f = (int)(it.x >> 12), k = (int)(it.x & 0xfffu);
+                    rectflag[(size_t)f * kcap + k] = (uint8_t)ok;
+                    if (ok && k < kept_cap) {
+                        ArKept kk;
+                        kk.off = (int)it.z; kk.len = n;
+                        for (int j = 0; j < 4; j++) { kk.vx[j] = (short)og[j].x; kk.vy[j] = (short)og[j].y; }
+                        kept_out[(size_t)f * kept_cap + k] = kk;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_tail_finish(int kcap, const uint8_t* __restrict__ rectflag, const ArKept* __restrict__ kept_out,
+                                                    int kept_cap, ArRect* __restrict__ rects_out, int rect_cap, int32_t* __restrict__ counts,
+                                                    int32_t* __restrict__ ctr)
+{
+    const int f = blockIdx.x, lane = threadIdx.x;
+    if (f == 0 && lane == 0) { ctr[0] = 0; ctr[1] = 0; } // every consumer of this batch's work list is done: ready for the next batch
     const int flags = counts[f * 4 + 2];
     if (flags) return; // the relay kernel reported the frame as failed
     const int nkept = counts[f * 4 + 0];
-    unsigned long long* kkey = (unsigned long long*)ct_smem;
-    int* off_u = (int*)(kkey + kcap);
-    int* klen = off_u + kcap;
-    int* koff = klen + kcap;
-    int* rectflag = koff + kcap;
-    ApPt* ap_out = (ApPt*)(rectflag + kcap);
-    int2* ap_stack = (int2*)(ap_out + (NT / 64) * AP_OUT);
-    uint16_t* rank_of = (uint16_t*)(ap_stack + (NT / 64) * AP_STACK);
-    uint32_t* pb = (uint32_t*)(rank_of + kcap);
-    const int pb_pts = ((int)((lds_bytes - (int)((unsigned char*)pb - ct_smem)) / 4) / (NT / 64)) & ~3;
-    for (int k = tid; k < nkept; k += NT) {
-        kkey[k] = tail_keys[(size_t)f * kcap + k];
-        off_u[k] = tail_off[(size_t)f * kcap + k];
+    int nr = 0;
+    for (int k0 = 0; k0 < nkept; k0 += 64) {
+        const int k = k0 + lane;
+        const bool is = k < nkept && k < kept_cap && rectflag[(size_t)f * kcap + k];
+        const unsigned long long m = __ballot(is);
+        if (is) {
+            const int q = nr + a_lane_prefix(m);
+            if (q < rect_cap) {
+                const ArKept kk = kept_out[(size_t)f * kept_cap + k];
+                ArRect r;
+                for (int j = 0; j < 4; j++) { r.c[j][0] = (float)kk.vx[j]; r.c[j][1] = (float)kk.vy[j]; }
+                r.off = kk.off; r.len = kk.len;
+                rects_out[(size_t)f * rect_cap + q] = r;
+            }
+        }
+        nr += (int)__popcll(m);
     }
-    if (tid == 0) { s_flags = flags; s_ncand = counts[f * 4 + 3]; }
-    __syncthreads();
-    contours_tail(f, tid, NT, nkept, kkey, off_u, klen, koff, rectflag, ap_out, ap_stack,
-                  pool + (size_t)f * pool_fstride, kept_out, kept_cap, rects_out, rect_cap, counts, &s_flags, &s_ncand, rank_of,
-                  &s_tailq, NT / 64, pb, pb_pts, nullptr, 0);
+    if (lane == 0) {
+        counts[f * 4 + 1] = min(nr, rect_cap);
+        if (nr > rect_cap) counts[f * 4 + 2] = flags | 8;
+    }
 }
-
-template __global__ void k_contours_tail_t<RT_THREADS>(const unsigned long long*, const int32_t*, int, const uint32_t*, size_t, ArKept*, int, ArRect*, int,
-                                                       int32_t*, int);
-// busy large frames have a few thousand kept borders: sixteen waves per frame instead of four (the frames are few, the CUs many)
-template __global__ void k_contours_tail_t<RT_THREADS_BIG>(const unsigned long long*, const int32_t*, int, const uint32_t*, size_t, ArKept*, int, ArRect*, int,
-                                                           int32_t*, int);
 
 // ---------------------------------------------------------------------------------------- prefilter -----------
 __device__ __forceinline__ int ar_perimeter(const float c[4][2])

@@ -67,10 +67,12 @@ __global__ void k_relay_lut(uint16_t* lut);
 __global__ void k_contours_small(const uint32_t* gbits, size_t bits_fstride, int wpr_g, int W, int H, int min_len, const uint16_t* lut_g,
                                  int32_t* rstate, uint32_t* pool, size_t pool_fstride, int pool_cap, int kcap, unsigned long long* tail_keys,
                                  int32_t* tail_off, int32_t* counts);
-template <int NT>
-__global__ void k_contours_tail_t(const unsigned long long* tail_keys, const int32_t* tail_off, int kcap,
-                                  const uint32_t* pool, size_t pool_fstride, ArKept* kept_out, int kept_cap,
-                                  ArRect* rects_out, int rect_cap, int32_t* counts, int lds_bytes);
+__global__ void k_tail_prep(const unsigned long long* tail_keys, const int32_t* tail_off, int kcap, const int32_t* counts, uint4* work, size_t work_half,
+                            int32_t* ctr);
+__global__ void k_tail_approx(int kcap, const uint4* work, size_t work_half, const int32_t* ctr, const uint32_t* pool, size_t pool_fstride, ArKept* kept_out,
+                              int kept_cap, uint8_t* rectflag, int pts);
+__global__ void k_tail_finish(int kcap, const uint8_t* rectflag, const ArKept* kept_out, int kept_cap, ArRect* rects_out, int rect_cap,
+                              int32_t* counts, int32_t* ctr);
 __global__ void k_prefilter(ArRect* rects, int rect_cap, const int32_t* counts, int W, int H, int too_near,
                             int32_t* cand_idx, int32_t* ncand_out);
 __global__ void k_decode(ImgView src0, ImgView pyr, const ArLevel* levels, int nlevels, const ArRect* rects,
@@ -93,10 +95,11 @@ __global__ void k_finalize(const ArRect* rects, int rect_cap, const int32_t* can
 #ifndef RL_THREADS
 #define RL_THREADS 512   // 8 waves per frame: measured against 1024 (contours alone 713 -> 640 us per 300 frames, step 2.00 -> 1.95 ms) and 256 (893 us)
 #endif
-#ifndef RT_THREADS
-#define RT_THREADS 256           // k_contours_tail: 4 waves, one approxPolyDP each at a time (small workgroups place easily next to other kernels)
+#define RT_QUAD_MAX 160           // k_tail_approx: borders of fewer points are done by 16 lanes, four to a wave (a multiple of 8)
+#define RT_BUCKETS 256           // k_tail_prep: length classes of the work list's counting sort
+#ifndef RT_WGS
+#define RT_WGS 1536              // k_tail_approx: persistent workgroups of 4 waves (16 waves per CU at its ~128 VGPRs)
 #endif
-#define RT_THREADS_BIG 1024      // k_contours_tail for frames with thousands of kept borders (k_contours_relay8g)
 #ifndef RL_THREADS_BIG
 #define RL_THREADS_BIG 1024     // k_contours_relay8 (large frames): its workgroup owns the CU (LDS), so it brings 16 waves
 #endif
@@ -141,11 +144,9 @@ inline size_t relay_lds_bytes(int lds_bits_words, int kcap, int tbits)
     return relay_region_bytes(lds_bits_words, kcap, tbits) + ((size_t)4 << tbits);
 }
 
-// LDS of k_contours_tail: per-border arrays, approx scratch, length ranks, one point buffer of `pts` points per wave
-inline size_t tail_lds_bytes(int kcap, int pts, int nthreads = RT_THREADS)
-{
-    return (size_t)kcap * (8 + 4 * 4 + 2) + (size_t)(nthreads / 64) * ((AP_OUT + AP_STACK) * 8 + (size_t)pts * 4) + 64;
-}
+// LDS of k_tail_prep (keys, pool offsets, lengths per kept border) and of k_tail_approx (per wave: approx output + stack + `pts` points)
+inline size_t tail_prep_lds_bytes(int kcap) { return (size_t)kcap * (8 + 4) + 16; }
+inline size_t tail_approx_lds_bytes(int pts) { return (size_t)4 * ((AP_OUT + AP_STACK) * 8 + (size_t)pts * 4) + 16; }
 
 inline size_t contours_lds_bytes(int lds_bits_words, int kept_cap)
 {
