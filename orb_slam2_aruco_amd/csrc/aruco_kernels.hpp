@@ -95,10 +95,12 @@ __global__ void k_finalize(const ArRect* rects, int rect_cap, const int32_t* can
 #ifndef RL_THREADS
 #define RL_THREADS 512   // 8 waves per frame: measured against 1024 (contours alone 713 -> 640 us per 300 frames, step 2.00 -> 1.95 ms) and 256 (893 us)
 #endif
-#define RT_QUAD_MAX 160           // k_tail_approx: borders of fewer points are done by 16 lanes, four to a wave (a multiple of 8)
+#ifndef RT_QUAD_MAX
+#define RT_QUAD_MAX 256           // k_tail_approx: borders of fewer points are done by 16 lanes, four to a wave (a multiple of 8)
+#endif
 #define RT_BUCKETS 256           // k_tail_prep: length classes of the work list's counting sort
 #ifndef RT_WGS
-#define RT_WGS 1536              // k_tail_approx: persistent workgroups of 4 waves (16 waves per CU at its ~128 VGPRs)
+#define RT_WGS 2048              // k_tail_approx: persistent workgroups of 4 waves (16 waves per CU at its ~128 VGPRs)
 #endif
 #ifndef RL_THREADS_BIG
 #define RL_THREADS_BIG 1024     // k_contours_relay8 (large frames): its workgroup owns the CU (LDS), so it brings 16 waves

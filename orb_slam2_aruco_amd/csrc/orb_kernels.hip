@@ -1499,18 +1499,27 @@ __global__ __launch_bounds__(256) void k_orient_describe(ImgView src0, ImgView p
     __builtin_amdgcn_wave_barrier();
 
     // ---- steered BRIEF on the staged window
+    // The rotation is separate multiplies and adds (the reference is compiled without fused multiply-add) on packed f32: the two
+    // points of a test side by side, (x0, x1) (b, b) + (y0, y1) (a, a), six v_pk_* instead of twelve scalar operations.  cvRound
+    // is "add 1.5 * 2^23": the sum is rounded to an integer by the adder (to nearest even, like cvRound), and its low mantissa
+    // bits are that integer plus 2^22; row * 40 + column is then one 24-bit multiply-add on the raw bits, the constants folded
+    // into the window's base address.
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    constexpr uint32_t MAGIC_BITS = 0x4B400000u;                                      // 12582912.0f = 1.5 * 2^23
+    constexpr uint32_t IDX_BIAS = (MAGIC_BITS & 0xffffffu) * 40u + MAGIC_BITS;         // what the raw-bit multiply-add carries along
     const uint8_t* bc = s_win[wid] + 18 * 40 + 18 + xoff;
+    const v2f aa = {a, a}, bb = {b, b}, magic = {12582912.0f, 12582912.0f};
     unsigned long long words[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const uint32_t pp = pat[j];
-        const float x0 = (float)(signed char)(pp & 0xff), y0 = (float)(signed char)((pp >> 8) & 0xff);
-        const float x1 = (float)(signed char)((pp >> 16) & 0xff), y1 = (float)(signed char)(pp >> 24);
-        const int r0 = orbfe_round_f(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
-        const int c0 = orbfe_round_f(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
-        const int r1 = orbfe_round_f(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
-        const int c1 = orbfe_round_f(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-        const int t0 = bc[r0 * 40 + c0], t1 = bc[r1 * 40 + c1];
+        const v2f X = {(float)(signed char)(pp & 0xff), (float)(signed char)((pp >> 16) & 0xff)};
+        const v2f Y = {(float)(signed char)((pp >> 8) & 0xff), (float)(signed char)(pp >> 24)};
+        const v2f R = (X * bb + Y * aa) + magic;   // rows of the two points (-ffp-contract=off: no fused multiply-add)
+        const v2f C = (X * aa - Y * bb) + magic;   // columns
+        const uint32_t i0 = __umul24(__float_as_uint(R.x), 40u) + __float_as_uint(C.x) - IDX_BIAS;
+        const uint32_t i1 = __umul24(__float_as_uint(R.y), 40u) + __float_as_uint(C.y) - IDX_BIAS;
+        const int t0 = bc[(int)i0], t1 = bc[(int)i1];
         words[j] = __ballot(t0 < t1);
     }
     if (lane < 4) {

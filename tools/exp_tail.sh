@@ -1,4 +1,8 @@
+# k_tail_approx: persistent workgroups, the length below which borders go four to a wave, and (debug build) the share of long borders
 mkdir -p gpurun_out/t1
-python -m pytest tests/test_aruco_gpu.py tests/test_pipeline_gpu.py -x -q 2>&1 | tail -2; python tools/stress_aruco.py 2>&1 | tail -1
-for cfg in C2 C3 C5; do echo "$cfg:"; bash tools/kstats.sh gpurun_out/t1/x.csv --no-orb --config $cfg 2>&1 | grep "k_tail_"; done
-python bench.py 2>&1 | tail -1 | cut -c1-200
+for cfg in C2 C3; do
+for v in base w1024 w2048 q96 q256 s600; do
+  lib=build/liborbfe_$v.so; [ $v = base ] && lib=orb_slam2_aruco_amd/liborbfe.so
+  echo -n "$cfg $v: "; ORBFE_LIB=$PWD/$lib bash tools/kstats.sh gpurun_out/t1/x.csv --no-orb --config $cfg 2>&1 | grep "k_tail_approx"
+done
+done

@@ -8,7 +8,7 @@ import oracle_lib as O
 from orb_slam2_aruco_amd import binding, synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-bad = 0
+bad = 0; refused = 0
 for case in range(n):
     big = case % 7 == 3
     cols, rows = int(rng.integers(200, 2600 if big else 1000)), int(rng.integers(160, 1500 if big else 760))
@@ -38,10 +38,17 @@ for case in range(n):
         if c["flags"]: why.append("flags %d" % c["flags"])
         good = not why
         if why: print("   ", why)
+    except binding.OrbfeError as e:
+        if "(-4)" in str(e):   # ORBFE_ERR_CAPACITY: a documented limit (include/orbfe.h), refused loudly -- not a wrong result
+            refused += 1
+            print("case %d %dx%d nf %d nl %d sc %.2f: refused (capacity): %s" % (case, cols, rows, nf, nl, sc, str(e)[:90]))
+            continue
+        good = False
+        print("case %d: exception %r" % (case, e))
     except Exception as e:
         good = False
         print("case %d %dx%d nf %d nl %d sc %.2f th %d/%d %s: exception %r" % (case, cols, rows, nf, nl, sc, ini, mn, dic, e))
     if not good:
         bad += 1
         print("case %d %dx%d nf %d nl %d sc %.2f th %d/%d %s: MISMATCH" % (case, cols, rows, nf, nl, sc, ini, mn, dic))
-print("%d cases, %d mismatches" % (n, bad))
+print("%d cases, %d mismatches, %d refused with ORBFE_ERR_CAPACITY" % (n, bad, refused))
