@@ -34,6 +34,7 @@ struct orbfe_aruco {
     DevBuf d_rstate, d_lut; // k_contours_relay -> k_contours_small: per-frame grid shift and pool fill; the walks' step table
     DevBuf d_segs, d_tailkeys, d_tailoff, d_small, d_hint; // d_hint: the relay kernel's grid spacing of the previous batch
     int relay_kshift = 5;      // initial grid spacing (log2) of k_contours_relay
+    bool tail_dirty = false;   // the work-list counters may be non-zero (set while the tail's three launches are being enqueued)
     int relay_kcap = RL_KCAP;  // kept borders per frame the relay kernels and their tail hold
     // experiment (ORBFE_ARUCO_SMALL_SEPARATE=1): k_contours_small also for frames whose bit image is in LDS
     bool small_separate = getenv("ORBFE_ARUCO_SMALL_SEPARATE") && atoi(getenv("ORBFE_ARUCO_SMALL_SEPARATE")) != 0;
@@ -346,6 +347,8 @@ struct orbfe_aruco {
                 const int tail_wgs = std::min(RT_WGS, B * 128);
                 { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(k_tail_prep), tail_prep_lds_bytes(relay_kcap)); if (rc_lds_) return rc_lds_; }
                 { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(k_tail_approx), alds); if (rc_lds_) return rc_lds_; }
+                if (tail_dirty) ORBFE_HIP(hipMemsetAsync(d_tctr.p, 0, 16, s));   // a previous batch was abandoned between prep and finish
+                tail_dirty = true;
                 hipLaunchKernelGGL(k_tail_prep, dim3(B), dim3(relay_global ? 1024 : 256), tail_prep_lds_bytes(relay_kcap), s,
                                    d_tailkeys.as<unsigned long long>(), d_tailoff.as<int32_t>(), relay_kcap, d_counts.as<int32_t>(),
                                    d_twork.as<uint4>(), (size_t)relay_kcap * B, d_tctr.as<int32_t>());
@@ -353,6 +356,7 @@ struct orbfe_aruco {
                                    d_pool.as<uint32_t>(), pool_fu32, d_kept.as<ArKept>(), relay_kcap, d_trect.as<uint8_t>(), pts);
                 hipLaunchKernelGGL(k_tail_finish, dim3(B), dim3(64), 0, s, relay_kcap, d_trect.as<uint8_t>(), d_kept.as<ArKept>(), relay_kcap,
                                    d_rects.as<ArRect>(), AR_MAX_RECTS, d_counts.as<int32_t>(), d_tctr.as<int32_t>());
+                if (hipPeekAtLastError() == hipSuccess) tail_dirty = false;   // k_tail_finish leaves the list lengths at zero
             }
         }
         // the single-walker kernel: images whose bit image does not fit LDS next to the relay kernel's tables, or forced

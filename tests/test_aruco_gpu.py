@@ -239,6 +239,47 @@ def test_full_hd_structured_borders_between_grid_lines(orbfe, oracle):
     assert np.array_equal(got_big["id"], got["id"]) and np.array_equal(got_big["corners"], got["corners"])
 
 
+@pytest.mark.parametrize("rows,cols", [(720, 1280), (1080, 1920)])
+def test_border_lengths_around_the_tail_kernel_thresholds(orbfe, oracle, rows, cols):
+    """k_tail_approx does borders below 256 points four to a wave on 16-lane rows, longer ones one per wave out of a 1024-point LDS
+    buffer and still longer ones out of the pool: rectangles (some with a corner cut off: five vertices) whose border lengths step
+    through 240 .. 272 and 1000 .. 1050 points, next to a frame-sized border, give the oracle's rectangle candidates in its order."""
+    img = np.full((rows, cols), 210, np.uint8)
+    k = 0
+    for i in range(16):                                   # outer border of a w x h block: 2 (w + h) - 4 points
+        w, h = 60 + i, 64
+        y0, x0 = 20 + 90 * (i // 8), 20 + 150 * (i % 8)
+        img[y0:y0 + h, x0:x0 + w] = 30
+        if i % 3 == 2:
+            for d in range(14): img[y0 + d, x0 + w - 14 + d:x0 + w] = 210
+    for i in range(6):
+        w, h = 252 + i * 4, 256
+        y0, x0 = 220 + 270 * (i // 4), 20 + 300 * (i % 4)
+        if y0 + h + 10 > rows: break
+        img[y0:y0 + h, x0:x0 + w] = 30
+        img[y0 + 20:y0 + h - 20, x0 + 20:x0 + w - 20] = 210
+        if i % 2 == 0:
+            for d in range(40): img[y0 + d, x0:x0 + 40 - d] = 210
+        k += 1
+    img[4:8, 4:cols - 4] = 30; img[rows - 8:rows - 4, 4:cols - 4] = 30       # a border of ~2 (rows + cols) points
+    img[4:rows - 4, 4:8] = 30; img[4:rows - 4, cols - 8:cols - 4] = 30
+    rng = np.random.default_rng(3)
+    img = np.clip(img.astype(np.int32) + rng.integers(-2, 3, img.shape), 0, 255).astype(np.uint8)
+    det, ora = orbfe.MarkerDetector("ARUCO"), oracle.ArucoOracle("ARUCO")
+    det.detect(img); ora.detect(img)
+    assert np.array_equal(det.thresholded(0), ora.stage_image(0))
+    c = det.counts(0)
+    assert c["flags"] == 0 and not c["fell_back"], c
+    lens = np.array([len(b) for b in oracle.find_contours(ora.stage_image(0))])
+    assert ((lens >= 230) & (lens < 256)).any() and ((lens >= 256) & (lens < 290)).any(), sorted(lens)
+    assert ((lens > 900) & (lens <= 1024)).any() and ((lens > 1024) & (lens < 1200)).any() and (lens > 3000).any(), sorted(lens)
+    assert c["nkept"] == (lens > 70).sum()
+    orects, grects = ora.candidates(0), det.rects(0)
+    assert len(orects) >= 12
+    assert np.array_equal(grects["corners"].reshape(-1, 8), orects[:, :8])
+    assert np.array_equal(grects["len"], orects[:, 8].astype(np.int32))
+
+
 def _damaged_markers_image(dic, ids, flips, bit=8):
     """White 480x640 frame with axis-aligned markers; marker k has flips[k] inner cells inverted."""
     img = np.full((480, 640), 235, np.uint8)

@@ -17,9 +17,8 @@ for legacy in (False, True):
         if legacy:
             print("legacy frame %d ticks: load_bits %d, probe %d, long %d, - %d, sort+approx+compact %d" % ((f,) + tuple(out[:5])))
         else:
-            print("relay frame %d ticks: load_bits %d, markers %d, small %d, segments %d, lists %d, points %d, tail %d"
-                  % ((f,) + tuple(out[:7])))
-            print("    tail: sort %d, approx %d" % tuple(out[8:10]))
+            print("relay frame %d ticks: load_bits %d, markers %d, small %d, segments %d, lists %d, points %d"
+                  % ((f,) + tuple(out[:6])))   # (the tail is three kernels of its own: k_tail_prep / _approx / _finish in the kernel trace)
             print("    phase (c) loop iterations of a wave: max %d, mean %.0f; longest closed small border %d" % (out[6] >> 40, ((out[6] >> 16) & 0xffffff) / 16.0, out[6] & 0xffff))
             print("    phase (c) steps: closed small borders %d, stopped at a grid marker %d, stopped as not canonical %d" % (out[7], out[10], out[11]))
         print("   ", det.counts(f))

@@ -12,7 +12,7 @@ calib = json.load(open(cal)) if os.path.exists(cal) else {}
 # dominant global access width of each kernel (bytes per lane): reads, writes -- from the kernel sources
 WIDTH = {"k_resize_tab": (8, 4), "k_resize_level": (1, 4), "k_fast_cells": (4, 4), "k_blur7": (4, 4), "k_orient_describe": (4, 16),
          "k_adaptive_threshold": (4, 8), "k_half_area4": (8, 4), "k_half_area": (1, 1), "k_knn2_mfma": (16, 4), "k_search_init": (16, 4), "k_contours_relay": (4, 4),
-         "k_contours_tail": (4, 4), "k_decode": (1, 4), "k_distribute_pyr": (4, 4)}
+         "k_contours_small": (4, 4), "k_tail_prep": (8, 16), "k_tail_approx": (4, 4), "k_tail_finish": (4, 4), "k_decode": (1, 4), "k_distribute_pyr": (4, 4)}
 names = {1: "unsigned char", 4: "unsigned int", 8: "HIP_vector_type<unsigned int, 2u>", 16: "HIP_vector_type<unsigned int, 4u>"}
 
 
@@ -45,7 +45,7 @@ stage = {
     "orient_describe": named("k_orient_describe"), "knn2": named("k_knn2_mfma", "k_knn2_tiles", "k_knn2_merge"),
     "search_init": named("k_search_init"),
     "aruco_threshold": named("k_adaptive_threshold_t", "k_adaptive_threshold"), "aruco_pyramid": named("k_half_area", "k_half_area4", "k_resize_level"),
-    "aruco_contours": [k for k in s if k.startswith("k_contours")],
+    "aruco_contours": [k for k in s if k.startswith("k_contours") or k.startswith("k_tail_")],
     "aruco_decode": named("k_prefilter", "k_decode"), "aruco_finalize": named("k_finalize", "k_marker_poses"),
 }
 traffic = {"_note": "HBM-side bytes per launch (%s batch) = (FETCH_SIZE / f_read + WRITE_SIZE / f_write) * 1024 from separate rocprofv3 --pmc "
