@@ -34,6 +34,7 @@ struct orbfe_aruco {
     DevBuf d_rstate, d_lut; // k_contours_relay -> k_contours_small: per-frame grid shift and pool fill; the walks' step table
     DevBuf d_segs, d_tailkeys, d_tailoff, d_small, d_hint; // d_hint: the relay kernel's grid spacing of the previous batch
     int relay_kshift = 5;      // initial grid spacing (log2) of k_contours_relay
+    int relay_chunk = getenv("ORBFE_ARUCO_RELAY_CHUNK") ? atoi(getenv("ORBFE_ARUCO_RELAY_CHUNK")) : 1 << 30;   // frames per launch of the large-frame relay kernels
     bool tail_dirty = false;   // the work-list counters may be non-zero (set while the tail's three launches are being enqueued)
     int relay_kcap = RL_KCAP;  // kept borders per frame the relay kernels and their tail hold
     // experiment (ORBFE_ARUCO_SMALL_SEPARATE=1): k_contours_small also for frames whose bit image is in LDS
@@ -313,21 +314,27 @@ struct orbfe_aruco {
         const bool relay = relay_tbits && !force_legacy && !big_mode;
         for (int r_ = 0; relay && r_ < ORBFE_REPS_ARUCO(1); r_++) {
             const size_t rlds = relay_lds_bytes(relay_global ? 0 : lds_bits_words, relay_kcap, relay_tbits);
+            // A workgroup of the large-frame kernels takes a CU's whole LDS, so a launch of >= 256 frames shuts every kernel that
+            // needs LDS (FAST, the descriptors) out of the chip for as long as it runs: such batches go in chunks of relay_chunk frames
+            const int chunk = (relay_global || relay_tbits > 12) ? std::max(1, std::min(B, relay_chunk)) : B;
+            for (int f0 = 0; f0 < B; f0 += chunk) {
+            const int nb_ = std::min(chunk, B - f0);
             if (relay_global) {
                 { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(k_contours_relay8g), (size_t)(rlds)); if (rc_lds_) return rc_lds_; }
-                hipLaunchKernelGGL(k_contours_relay8g, dim3(B), dim3(RL_THREADS_BIG), rlds, s, d_bits.as<uint32_t>(), bits_fu32, wpr,
+                hipLaunchKernelGGL(k_contours_relay8g, dim3(nb_), dim3(RL_THREADS_BIG), rlds, s, d_bits.as<uint32_t>(), bits_fu32, wpr,
                                    cols, rows, 0, 70, relay_kshift, relay_tbits, d_segs.as<RelaySeg>(),
                                    d_pool.as<uint32_t>(), pool_fu32, (int)pool_fu32, d_kept.as<ArKept>(), relay_kcap, relay_kcap,
                                    d_tailkeys.as<unsigned long long>(), d_tailoff.as<int32_t>(), d_counts.as<int32_t>(), d_hint.as<int32_t>(),
-                                   d_small.as<uint4>(), d_rstate.as<int32_t>(), d_gpad.as<uint32_t>(), gpad_fu32, d_lut.as<uint16_t>());
+                                   d_small.as<uint4>(), d_rstate.as<int32_t>(), d_gpad.as<uint32_t>(), gpad_fu32, d_lut.as<uint16_t>(), f0);
             } else {
             auto rfn = relay_tbits > 12 ? k_contours_relay8 : k_contours_relay;
             { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(rfn), (size_t)(rlds)); if (rc_lds_) return rc_lds_; }
-            hipLaunchKernelGGL(rfn, dim3(B), dim3(relay_tbits > 12 ? RL_THREADS_BIG : RL_THREADS), rlds, s, d_bits.as<uint32_t>(), bits_fu32, wpr,
+            hipLaunchKernelGGL(rfn, dim3(nb_), dim3(relay_tbits > 12 ? RL_THREADS_BIG : RL_THREADS), rlds, s, d_bits.as<uint32_t>(), bits_fu32, wpr,
                                cols, rows, lds_bits_words, 70, relay_kshift, relay_tbits, d_segs.as<RelaySeg>(),
                                d_pool.as<uint32_t>(), pool_fu32, (int)pool_fu32, d_kept.as<ArKept>(), relay_kcap, relay_kcap,
                                d_tailkeys.as<unsigned long long>(), d_tailoff.as<int32_t>(), d_counts.as<int32_t>(), d_hint.as<int32_t>(),
-                               d_small.as<uint4>(), d_rstate.as<int32_t>(), small_separate ? 1 : 0, d_lut.as<uint16_t>());
+                               d_small.as<uint4>(), d_rstate.as<int32_t>(), small_separate ? 1 : 0, d_lut.as<uint16_t>(), f0);
+            }
             }
             // the borders that touch no grid line, for frames done with a grid by a relay kernel that leaves them out (the
             // HBM-resident one: its bands fit LDS here; for LDS-resident frames the separate launch halves the relay kernel's time

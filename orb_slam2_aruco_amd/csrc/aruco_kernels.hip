@@ -820,7 +820,8 @@ __device__ __forceinline__ int relay_frame(
     int32_t* __restrict__ rstate /* per frame: grid shift the frame was done with, final pool words in use (k_contours_small goes on from there) */,
     uint32_t* __restrict__ gpad = nullptr /* GBITS: the padded bit image lives here (HBM / L2) instead of LDS */, size_t gpad_fstride = 0,
     int small_elsewhere = 0 /* phase (c) of gridded frames is k_contours_small's */,
-    const uint16_t* __restrict__ lut_g = nullptr /* the step table, built once per detector (k_relay_lut) */)
+    const uint16_t* __restrict__ lut_g = nullptr /* the step table, built once per detector (k_relay_lut) */,
+    int f0 = 0 /* first frame of this launch (a batch may be launched in chunks) */)
 {
     extern __shared__ __align__(16) unsigned char ct_smem[];
     __shared__ int s_nmpix;
@@ -830,7 +831,7 @@ __device__ __forceinline__ int relay_frame(
     if (!force_nogrid && hint) kshift = max(kshift, min(*hint, 7));
     __shared__ uint16_t s_lut[2048];
     __shared__ unsigned s_tailq;
-    const int tid = threadIdx.x, f = blockIdx.x, NT = RL_NT;
+    const int tid = threadIdx.x, f = blockIdx.x + f0, NT = RL_NT;
     const int wpr = (W + 2 + 31) >> 5, prow = H + 2;
     const int T = 1 << tbits;
     int kmask = (1 << kshift) - 1, K = 1 << kshift;
@@ -839,7 +840,7 @@ __device__ __forceinline__ int relay_frame(
     //   lists (e-f):  R = kept keys u64, kept pool offsets, cmin/val, jmp, arg      (the bit image is dead)
     //   tail  (g):    R = kept keys, offsets | klen, koff, rectflag, approx scratch, length ranks, point buffers ...
     //   [hkey: T marker state keys] lives until (f2)
-    uint32_t* lbits = GBITS ? gpad + (size_t)blockIdx.x * gpad_fstride : (uint32_t*)ct_smem;
+    uint32_t* lbits = GBITS ? gpad + (size_t)(blockIdx.x + f0) * gpad_fstride : (uint32_t*)ct_smem;
     unsigned long long* kkey = (unsigned long long*)ct_smem;
     int* off_u = (int*)(kkey + kcap);
     unsigned char* uni = (unsigned char*)(off_u + kcap);
@@ -1414,16 +1415,16 @@ __global__ __launch_bounds__(RL_THREADS) RL_VGPR_ATTR void k_contours_relay(
     int kshift, int tbits, RelaySeg* __restrict__ segs, uint32_t* __restrict__ pool, size_t pool_fstride, int pool_cap,
     ArKept* __restrict__ kept_out, int kept_cap, int kcap /*kept borders this kernel's LDS holds*/,
     unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off, int32_t* __restrict__ counts, int32_t* __restrict__ hint,
-    uint4* __restrict__ small_g, int32_t* __restrict__ rstate, int small_elsewhere, const uint16_t* __restrict__ lut_g)
+    uint4* __restrict__ small_g, int32_t* __restrict__ rstate, int small_elsewhere, const uint16_t* __restrict__ lut_g, int f0)
 {
     __builtin_amdgcn_s_setprio(2); // latency-bound: its few waves go first when a VALU-bound kernel shares the CU
     if (relay_frame<false, RL_SLOTS_PER_THREAD, RL_THREADS>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool,
                                                 pool_fstride, pool_cap, kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate,
-                                                nullptr, 0, small_elsewhere, lut_g)) {
+                                                nullptr, 0, small_elsewhere, lut_g, f0)) {
         __syncthreads();
         relay_frame<true, RL_SLOTS_PER_THREAD, RL_THREADS>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool,
                                                pool_fstride, pool_cap, kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate,
-                                               nullptr, 0, small_elsewhere, lut_g);
+                                               nullptr, 0, small_elsewhere, lut_g, f0);
     }
 }
 
@@ -1434,14 +1435,14 @@ __global__ __launch_bounds__(RL_THREADS_BIG) void k_contours_relay8(
     int kshift, int tbits, RelaySeg* __restrict__ segs, uint32_t* __restrict__ pool, size_t pool_fstride, int pool_cap,
     ArKept* __restrict__ kept_out, int kept_cap, int kcap, unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off,
     int32_t* __restrict__ counts, int32_t* __restrict__ hint, uint4* __restrict__ small_g, int32_t* __restrict__ rstate, int small_elsewhere,
-    const uint16_t* __restrict__ lut_g)
+    const uint16_t* __restrict__ lut_g, int f0)
 {
     __builtin_amdgcn_s_setprio(2);
     if (relay_frame<false, 8192 / RL_THREADS_BIG, RL_THREADS_BIG>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool, pool_fstride, pool_cap,
-                              kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate, nullptr, 0, small_elsewhere, lut_g)) {
+                              kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate, nullptr, 0, small_elsewhere, lut_g, f0)) {
         __syncthreads();
         relay_frame<true, 8192 / RL_THREADS_BIG, RL_THREADS_BIG>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool, pool_fstride, pool_cap,
-                             kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate, nullptr, 0, small_elsewhere, lut_g);
+                             kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate, nullptr, 0, small_elsewhere, lut_g, f0);
     }
 }
 
@@ -1454,14 +1455,14 @@ __global__ __launch_bounds__(RL_THREADS_BIG) void k_contours_relay8g(
     int kshift, int tbits, RelaySeg* __restrict__ segs, uint32_t* __restrict__ pool, size_t pool_fstride, int pool_cap,
     ArKept* __restrict__ kept_out, int kept_cap, int kcap, unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off,
     int32_t* __restrict__ counts, int32_t* __restrict__ hint, uint4* __restrict__ small_g, int32_t* __restrict__ rstate,
-    uint32_t* __restrict__ gpad, size_t gpad_fstride, const uint16_t* __restrict__ lut_g)
+    uint32_t* __restrict__ gpad, size_t gpad_fstride, const uint16_t* __restrict__ lut_g, int f0)
 {
     __builtin_amdgcn_s_setprio(2);
     if (relay_frame<false, 8192 / RL_THREADS_BIG, RL_THREADS_BIG, true>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool,
-                              pool_fstride, pool_cap, kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate, gpad, gpad_fstride, 1, lut_g)) {
+                              pool_fstride, pool_cap, kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate, gpad, gpad_fstride, 1, lut_g, f0)) {
         __syncthreads();
         relay_frame<true, 8192 / RL_THREADS_BIG, RL_THREADS_BIG, true>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool,
-                             pool_fstride, pool_cap, kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate, gpad, gpad_fstride, 1, lut_g);
+                             pool_fstride, pool_cap, kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate, gpad, gpad_fstride, 1, lut_g, f0);
     }
 }
 
