@@ -38,7 +38,10 @@ struct orbfe_aruco {
     bool tail_dirty = false;   // the work-list counters may be non-zero (set while the tail's three launches are being enqueued)
     int relay_kcap = RL_KCAP;  // kept borders per frame the relay kernels and their tail hold
     // experiment (ORBFE_ARUCO_SMALL_SEPARATE=1): k_contours_small also for frames whose bit image is in LDS
-    bool small_separate = getenv("ORBFE_ARUCO_SMALL_SEPARATE") && atoi(getenv("ORBFE_ARUCO_SMALL_SEPARATE")) != 0;
+    // phase (c) of LDS-resident frames as its own launch (k_contours_small): -1 = by batch size (a few frames leave most of the chip
+    // idle, so the many small workgroups of the separate kernel shorten the call: 0.62 -> 0.57 ms for one 640 x 480 frame; a full
+    // batch issues more instructions that way and the pipeline is bound by those: 1.85 -> 1.98 ms per C2 step), 0 / 1 = forced
+    int small_separate_mode = getenv("ORBFE_ARUCO_SMALL_SEPARATE") ? atoi(getenv("ORBFE_ARUCO_SMALL_SEPARATE")) : -1;
     bool relay_global = false; // k_contours_relay8g: the bit image stays in HBM (it does not fit LDS)
     int relay_tbits = 0;       // hash-table size of k_contours_relay (0: the kernel cannot run at this image size)
     bool force_legacy = false; // debug: always use k_contours_t
@@ -316,6 +319,7 @@ struct orbfe_aruco {
             const size_t rlds = relay_lds_bytes(relay_global ? 0 : lds_bits_words, relay_kcap, relay_tbits);
             // A workgroup of the large-frame kernels takes a CU's whole LDS, so a launch of >= 256 frames shuts every kernel that
             // needs LDS (FAST, the descriptors) out of the chip for as long as it runs: such batches go in chunks of relay_chunk frames
+            const bool small_separate = small_separate_mode < 0 ? B <= 32 : small_separate_mode != 0;
             const int chunk = (relay_global || relay_tbits > 12) ? std::max(1, std::min(B, relay_chunk)) : B;
             for (int f0 = 0; f0 < B; f0 += chunk) {
             const int nb_ = std::min(chunk, B - f0);

@@ -366,14 +366,16 @@ def test_frames_at_the_lds_boundary_of_the_relay_kernels(orbfe, oracle, rows, co
     assert len(want) > 0
 
 
-def test_small_border_kernel_on_lds_resident_frames():
-    """k_contours_small (the borders between grid lines as their own launch) is the default only where the bit image lives in HBM
-    (1920x1080); ORBFE_ARUCO_SMALL_SEPARATE=1 switches it on for LDS-resident frames too.  The contour tests must pass either way:
-    run them in a process with the switch set."""
+@pytest.mark.parametrize("mode", ["0", "1"])
+def test_small_border_phase_inside_and_outside_the_relay_kernel(mode):
+    """The borders between grid lines are followed inside the relay kernel (phase (c): what a full batch of LDS-resident frames
+    runs) or by k_contours_small as its own launch (frames whose bit image lives in HBM, and batches of up to 32 frames, where it
+    shortens the call).  ORBFE_ARUCO_SMALL_SEPARATE=0 / 1 forces one or the other for every batch size: the contour tests must
+    pass both ways, so they are run in a process with the switch set."""
     import os, subprocess, sys
-    env = dict(os.environ, ORBFE_ARUCO_SMALL_SEPARATE="1")
+    env = dict(os.environ, ORBFE_ARUCO_SMALL_SEPARATE=mode)
     here = os.path.abspath(__file__)
     r = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-k",
-                        "structured_binary or relay_and_legacy or dense_frame or detect_matches_oracle"],
+                        "structured_binary or relay_and_legacy or dense_frame or detect_matches_oracle or lds_boundary or tail_kernel"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
