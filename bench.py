@@ -325,6 +325,8 @@ def main():
             skips[key] = int(os.environ[env])
     if "+ablation" in version:
         skips["library"] = version
+    if os.environ.get("ORBFE_MATCH_TWICE"):      # sensitivity study: the matching launched twice (more work, but not the workload)
+        skips["match_twice"] = 1
     B, rows, cols = args.frames, args.rows, args.cols
     use_aruco, use_orb = not args.no_aruco, not args.no_orb
 
