@@ -91,8 +91,8 @@ int orbfe_extractor_max_keypoints(const orbfe_extractor* h);
  * img: rows x cols bytes with row stride `step`.  kps: capacity records; desc: capacity x 32 bytes, row i belongs to
  * kps[i].  *n_out = number of keypoints.  Empty image (rows==0 || cols==0 || img==NULL) -> ORBFE_OK with *n_out
  * untouched semantics of :1046 mapped to *n_out = 0.
- * Frame geometry this implementation accepts (ORBFE_ERR_INVALID otherwise): every pyramid level at least 68 pixels in both
- * directions (below that it has no FAST cell); levels up to 4127 pixels (a keypoint travels as 12 + 12 bits inside the kernels);
+ * Frame geometry this implementation accepts (ORBFE_ERR_INVALID otherwise): every pyramid level at least 62 pixels in both
+ * directions (below that the reference's cell grid has no column, ORBextractor.cc:780-784); levels up to 4127 pixels (a keypoint travels as 12 + 12 bits inside the kernels);
  * 1 to 16 quadtree roots per level, nIni = round(width / height) of the border-less level (ORBextractor.cc:544): portrait frames give
  * nIni = 0, on which the reference divides by zero and indexes an empty vector; frames wider than 16.5 : 1 are a capacity limit of
  * the quadtree kernels; a level's keypoint quota (mnFeaturesPerLevel) up to about 2700 -- its node lists live in LDS -- i.e.

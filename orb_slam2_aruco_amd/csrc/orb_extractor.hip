@@ -197,8 +197,9 @@ struct orbfe_extractor {
             const float scale = mvInvScaleFactor[l];
             g.w = orbfe_round_f((float)cols_ * scale);
             g.h = orbfe_round_f((float)rows_ * scale);
-            if (g.w < 38 + 30 || g.h < 38 + 30)
-                return fail(ORBFE_ERR_INVALID, "level %d is %dx%d: too small for a FAST cell grid", l, g.w, g.h);
+            // the reference's own limit: its cell grid needs nCols = (w - 32) / 30 >= 1 (ORBextractor.cc:780-784; below that it divides by zero)
+            if (g.w < 32 + 30 || g.h < 32 + 30)
+                return fail(ORBFE_ERR_INVALID, "level %d is %dx%d: too small for a FAST cell grid (62 pixels a side)", l, g.w, g.h);
             // a keypoint travels as x | y << 12 | score << 24 relative to the 16-px border
             if (g.w - 32 > 4095 || g.h - 32 > 4095)
                 return fail(ORBFE_ERR_INVALID, "level %d is %dx%d: images above 4127 px a side are unsupported", l, g.w, g.h);

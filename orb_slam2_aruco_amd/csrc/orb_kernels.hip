@@ -1266,7 +1266,7 @@ __device__ __forceinline__ void bl_load_rows(const uint8_t* img, int pitch, cons
                 w[k][0] = p[0]; w[k][1] = p[1]; w[k][2] = p[2];
             } else if (x == 0) {
                 // left border, BORDER_REFLECT_101: pixels -4 .. -1 are pixels 4 .. 1 -- one v_perm on the two dwords the window has anyway
-                // (a level is at least 68 pixels wide, orb_extractor.hip build_geometry)
+                // (a level is at least 62 pixels wide, orb_extractor.hip build_geometry)
                 const u32_unaligned* p = reinterpret_cast<const u32_unaligned*>(row);
                 const uint32_t d0 = p[0], d1 = p[1];
                 w[k][0] = __builtin_amdgcn_perm(d1, d0, 0x01020304u); w[k][1] = d0; w[k][2] = d1;

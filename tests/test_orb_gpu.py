@@ -13,6 +13,8 @@ CASES = [
     (480, 640, 2000, 8, 2),   # the 2*nFeatures initialisation extractor (Tracking.cc:127)
     (360, 636, 700, 6, 5),    # odd width, non-multiple-of-4 levels
     (196, 1641, 500, 5, 6),   # panorama: ten quadtree roots
+    (240, 320, 500, 8, 12),   # QVGA with the default 8 levels: level 7 is 89 x 67, one row of FAST cells
+    (222, 222, 300, 8, 13),   # level 7 is 62 x 62: the smallest level the reference's cell grid allows
 ]
 
 
