@@ -1767,10 +1767,7 @@ __global__ __launch_bounds__(256) void k_tail_approx(int kcap, const uint4* __re
         if (lane < (int)e1.y) q0 = src_of(e1)[lane];
         if (lane + 64 < (int)e1.y) q1 = src_of(e1)[lane + 64];
         const int f = (int)(e.x >> 12), k = (int)(e.x & 0xfffu), off = (int)e.z;
-        int n = (int)e.y;
-#ifdef RT_SKIP_LONG
-        if (n > RT_SKIP_LONG) n = 0;
-#endif
+        const int n = (int)e.y;
         int ok = 0;
         if (n > 0) {
             const uint32_t* src = src_of(e);
