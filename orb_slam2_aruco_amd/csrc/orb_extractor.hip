@@ -82,6 +82,9 @@ struct orbfe_extractor {
     bool gaussian_ed = false;            // orbfe_extractor_set_gaussian_taps: 18 34 48 56 48 34 18 instead of 18 34 49 55 49 34 18
     // workgroups per CU the VALU-bound kernels may occupy (0 = what the hardware allows): the launch asks for LDS it does not use
     // so that the other engine's latency-bound kernels (8 waves and 50-77 KB of LDS per workgroup) always find room on every CU
+    // k_orient_describe2 (two keypoints per wave: 227 instead of 342 VALU instructions per keypoint, 238 instead of 256 us alone at C2)
+    // is NOT the default: with the detector running the C2 step was 1.62 ms with it and 1.61 without (four interleaved runs each)
+    bool orient_pair = env_int("ORBFE_ORIENT_PAIR", 0) != 0;
     int occ_fast = env_int("ORBFE_OCC_FAST", 0), occ_blur = env_int("ORBFE_OCC_BLUR", 0), occ_orient = env_int("ORBFE_OCC_ORIENT", 0);
     static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
     static size_t occ_lds(int per_cu, size_t static_bytes, size_t needed)
@@ -478,10 +481,12 @@ struct orbfe_extractor {
             if (rcb) return rcb;
         } else
             ORBFE_HIP(hipStreamWaitEvent(s, ev_join, 0));
-        const int okx = (std::min(capacity, max_keypoints()) + 3) / 4;
-        const size_t lds_orient = occ_lds(occ_orient, 4 * (31 * 36 + 12 + 37 * 40 + 8), 0);
-        if (lds_orient) { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(&k_orient_describe), lds_orient); if (rc_lds_) return rc_lds_; }
-        for (int r_ = 0; r_ < ORBFE_REPS_ORB(4); r_++) hipLaunchKernelGGL(k_orient_describe, dim3(xcd_grid(okx * B)), dim3(256), lds_orient, s, src0, pyr, blur, dg,
+        const int kcap_ = std::min(capacity, max_keypoints());
+        const int okx = orient_pair ? (kcap_ + 7) / 8 : (kcap_ + 3) / 4;   // workgroups per frame: 4 waves of one or two keypoints
+        auto ofn = orient_pair ? k_orient_describe2 : k_orient_describe;
+        const size_t lds_orient = occ_lds(occ_orient, orient_pair ? 8 * (31 * 36 + 12) : 4 * (31 * 36 + 12 + 37 * 40 + 8), 0);
+        if (lds_orient) { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(ofn), lds_orient); if (rc_lds_) return rc_lds_; }
+        for (int r_ = 0; r_ < ORBFE_REPS_ORB(4); r_++) hipLaunchKernelGGL(ofn, dim3(xcd_grid(okx * B)), dim3(256), lds_orient, s, src0, pyr, blur, dg,
                            d_flatkv.as<uint32_t>(), d_flatlvl.as<uint8_t>(), d_n, nlevels, d_pattern.as<uint32_t>(),
                            d_umax.as<uint4>(), d_kps_out, d_desc_out, capacity, okx, okx * B);
         timer.mark(s, "orient_describe");

@@ -259,6 +259,11 @@ __global__ __launch_bounds__(256) void k_fast_cells(ImgView src0, ImgView pyr, c
                                                     int map_pitch, int map_rows, int list_cap, int nx, int total)
 {
     extern __shared__ __align__(16) unsigned char fc_smem[];
+#ifdef FC_VGPR_TOP
+    // Occupancy cap without an LDS request: claiming a high register makes the allocation FC_VGPR_TOP + 1 registers per lane, so fewer
+    // waves (and with them fewer of this kernel's LDS-holding workgroups) fit a CU, and the detector's 65 - 77 KB workgroups find room
+    asm volatile("" ::: FC_VGPR_TOP);
+#endif
     const int lane = threadIdx.x & 63, wid = wave_id();
     int bx, f;
     if (!xcd_remap(nx, total, bx, f)) return;
@@ -1537,6 +1542,167 @@ __global__ __launch_bounds__(256) void k_orient_describe(ImgView src0, ImgView p
         kp.octave = level;
         kp.class_id = -1;
         kps[(size_t)f * capacity + oidx] = kp;
+    }
+}
+
+// Two keypoints per wave.  A third of k_orient_describe's instructions do not depend on the lane: fastAtan2 and sin / cos of the one
+// angle, and IC_Angle uses 31 lanes.  Here lanes 0..31 belong to keypoint A and 32..63 to keypoint B for those parts -- the patch rows
+// of both in one pass, the two moment sums out of one scan (lanes 31 and 63), one fastAtan2 / sincos sequence for both angles -- and
+// the loads and the 256 tests run per keypoint on all 64 lanes as before.  An odd last keypoint is paired with itself.
+__global__ __launch_bounds__(256) void k_orient_describe2(ImgView src0, ImgView pyr, ImgView blur,
+                                                          const LevelGeom* __restrict__ geom,
+                                                          const uint32_t* __restrict__ flat_kv,
+                                                          const uint8_t* __restrict__ flat_lvl,
+                                                          const int32_t* __restrict__ n_out, int nlevels,
+                                                          const uint32_t* __restrict__ pattern32, const uint4* __restrict__ icw,
+                                                          orbfe_keypoint* __restrict__ kps,
+                                                          uint8_t* __restrict__ desc, int capacity, int nx, int total)
+{
+    const int lane = threadIdx.x & 63, wid = wave_id();
+    int bx, f;
+    if (!xcd_remap(nx, total, bx, f)) return;
+    constexpr int PATB = 31 * 36 + 12, WINB = 37 * 40 + 8;
+    // LDS per wave: the two IC_Angle patches; once the moments are summed the same bytes hold one descriptor window at a time
+    // (9 KB per workgroup: the footprint matters, an LDS request of 23 KB on k_orient_describe cost the C2 step 50 us)
+    static_assert(2 * PATB >= WINB, "the window overlays the patches");
+    __shared__ __align__(16) uint8_t s_pat[4][2][PATB];
+    const int nk = n_out[f];
+    const int o0 = (bx * 4 + wid) * 2;
+    if (o0 >= nk) return;
+    const bool two = o0 + 1 < nk;
+    const int half = lane >> 5, r = lane & 31;
+    typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+    int kx[2], ky[2], level[2], score[2], xoff[2], xo[2];
+    uint32_t wv[2][6], v[2][5], pat[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) pat[j] = pattern32[j * 64 + lane];
+    const int wrow = min(r, 30);
+    const uint4 wa = icw[wrow * 4 + 0], wb = icw[wrow * 4 + 1], oa = icw[wrow * 4 + 2], ob = icw[wrow * 4 + 3];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int oidx = (h == 1 && two) ? o0 + 1 : o0;
+        const uint32_t kv = (uint32_t)__builtin_amdgcn_readfirstlane((int)flat_kv[(size_t)f * capacity + oidx]);
+        level[h] = __builtin_amdgcn_readfirstlane((int)flat_lvl[(size_t)f * capacity + oidx]);
+        const LevelGeom& g = geom[level[h]];
+        kx[h] = (int)(kv & 0xfff) + 16; ky[h] = (int)((kv >> 12) & 0xfff) + 16;
+        score[h] = kv >> 24;
+        const int ax = (kx[h] - 18) & ~3;
+        xoff[h] = (kx[h] - 18) - ax;
+        const uint8_t* img = (level[h] == 0) ? src0.base + (size_t)f * src0.fstride : pyr.base + (size_t)f * pyr.fstride + g.img_off;
+        const int pitch = (level[h] == 0) ? src0.pitch : g.pitch;
+        const int bpitch = g.bpitch;
+        const uint8_t* bimg = blur.base + (size_t)f * blur.fstride + g.blur_off + (size_t)(ky[h] - 18) * bpitch + ax;
+        {
+            int rr = lane / 10, c = lane - rr * 10;
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                const bool in = k * 64 + lane < 370;
+                wv[h][k] = *reinterpret_cast<const uint32_t*>(bimg + (uint32_t)((in ? rr : 36) * bpitch + 4 * (in ? c : 9)));
+                rr += 6; c += 4;
+                if (c >= 10) { c -= 10; rr++; }
+            }
+        }
+        const int axp = (kx[h] - 15) & ~3;
+        xo[h] = (kx[h] - 15) - axp;
+        const uint8_t* pimg = img + (size_t)(ky[h] - 15) * pitch + axp;
+        {
+            int rr = lane / 9, c = lane - rr * 9;
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const bool in = k * 64 + lane < 279;
+                v[h][k] = *reinterpret_cast<const u32_unaligned*>(pimg + (uint32_t)((in ? rr : 30) * pitch + 4 * (in ? c : 8)));
+                rr += 7; c += 1;
+                if (c >= 9) { c -= 9; rr++; }
+            }
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int idx = k * 64 + lane;
+            if (idx < 279) reinterpret_cast<uint32_t*>(s_pat[wid][h])[idx] = v[h][k];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- IC_Angle of both keypoints: lane = (keypoint, patch row)
+    int m10 = 0, m01 = 0;
+    if (r < 31) {
+        const uint32_t* rw = reinterpret_cast<const uint32_t*>(&s_pat[wid][0][0] + half * PATB + r * 36);
+        const int sh = half ? xo[1] : xo[0];
+        uint32_t d[9];
+#pragma unroll
+        for (int q = 0; q < 9; q++) d[q] = rw[q];
+        uint32_t e[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) e[q] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], sh);
+        uint32_t A = 0, B = 0;
+        A = bl_dot4(e[0], wa.x, A); A = bl_dot4(e[1], wa.y, A); A = bl_dot4(e[2], wa.z, A); A = bl_dot4(e[3], wa.w, A);
+        A = bl_dot4(e[4], wb.x, A); A = bl_dot4(e[5], wb.y, A); A = bl_dot4(e[6], wb.z, A); A = bl_dot4(e[7], wb.w, A);
+        B = bl_dot4(e[0], oa.x, B); B = bl_dot4(e[1], oa.y, B); B = bl_dot4(e[2], oa.z, B); B = bl_dot4(e[3], oa.w, B);
+        B = bl_dot4(e[4], ob.x, B); B = bl_dot4(e[5], ob.y, B); B = bl_dot4(e[6], ob.z, B); B = bl_dot4(e[7], ob.w, B);
+        m10 = (int)A - 15 * (int)B;
+        m01 = (r - 15) * (int)B;
+    }
+    const int s10 = wave_incl_scan_add(m10), s01 = wave_incl_scan_add(m01);
+    const int m10a = __builtin_amdgcn_readlane(s10, 31), m10t = __builtin_amdgcn_readlane(s10, 63);
+    const int m01a = __builtin_amdgcn_readlane(s01, 31), m01t = __builtin_amdgcn_readlane(s01, 63);
+    const float fm10 = (float)(half ? m10t - m10a : m10a), fm01 = (float)(half ? m01t - m01a : m01a);
+    const float angle = orbfe_fast_atan2(fm01, fm10);     // lanes 0..31: keypoint A's, lanes 32..63: keypoint B's
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    float a, b;
+    orbfe_sincosf(angle * factorPI, &b, &a); // a = cos, b = sin
+    // ---- steered BRIEF, one keypoint after the other on all lanes (see k_orient_describe for the arithmetic)
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    constexpr uint32_t MAGIC_BITS = 0x4B400000u;
+    constexpr uint32_t IDX_BIAS = (MAGIC_BITS & 0xffffffu) * 40u + MAGIC_BITS;
+    const v2f magic = {12582912.0f, 12582912.0f};
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const float ah = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), h * 32));
+        const float bh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, b), h * 32));
+        const v2f aa = {ah, ah}, bb = {bh, bh};
+        uint8_t* win = &s_pat[wid][0][0];
+        __builtin_amdgcn_wave_barrier();   // the patches (h = 0) / the first window (h = 1) have been read
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const int idx = k * 64 + lane;
+            if (idx < 370) reinterpret_cast<uint32_t*>(win)[idx] = wv[h][k];
+        }
+        __builtin_amdgcn_wave_barrier();
+        const uint8_t* bc = win + 18 * 40 + 18 + xoff[h];
+        unsigned long long words[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t pp = pat[j];
+            const v2f X = {(float)(signed char)(pp & 0xff), (float)(signed char)((pp >> 16) & 0xff)};
+            const v2f Y = {(float)(signed char)((pp >> 8) & 0xff), (float)(signed char)(pp >> 24)};
+            const v2f R = (X * bb + Y * aa) + magic;
+            const v2f C = (X * aa - Y * bb) + magic;
+            const uint32_t i0 = __umul24(__float_as_uint(R.x), 40u) + __float_as_uint(C.x) - IDX_BIAS;
+            const uint32_t i1 = __umul24(__float_as_uint(R.y), 40u) + __float_as_uint(C.y) - IDX_BIAS;
+            const int t0 = bc[(int)i0], t1 = bc[(int)i1];
+            words[j] = __ballot(t0 < t1);
+        }
+        if (h == 0 || two) {
+            if (lane < 4) {
+                unsigned long long wd = lane == 0 ? words[0] : lane == 1 ? words[1] : lane == 2 ? words[2] : words[3];
+                reinterpret_cast<unsigned long long*>(desc + ((size_t)f * capacity + o0 + h) * 32)[lane] = wd;
+            }
+            if (lane == h * 32) {
+                const LevelGeom& g = geom[level[h]];
+                orbfe_keypoint kp;
+                float px = (float)kx[h], py = (float)ky[h];
+                if (level[h] != 0) { px = __fmul_rn(px, g.scale); py = __fmul_rn(py, g.scale); }
+                kp.x = px; kp.y = py;
+                kp.size = g.kp_size;
+                kp.angle = angle;
+                kp.response = (float)score[h];
+                kp.octave = level[h];
+                kp.class_id = -1;
+                kps[(size_t)f * capacity + o0 + h] = kp;
+            }
+        }
     }
 }
 

@@ -95,6 +95,10 @@ __global__ void k_orient_describe(ImgView src0, ImgView pyr, ImgView blur, const
                                   const uint32_t* flat_kv, const uint8_t* flat_lvl, const int32_t* n_out, int nlevels,
                                   const uint32_t* pattern32, const uint4* icw, orbfe_keypoint* kps, uint8_t* desc,
                                   int capacity, int nx, int total);
+__global__ void k_orient_describe2(ImgView src0, ImgView pyr, ImgView blur, const LevelGeom* geom,
+                                  const uint32_t* flat_kv, const uint8_t* flat_lvl, const int32_t* n_out, int nlevels,
+                                  const uint32_t* pattern32, const uint4* icw, orbfe_keypoint* kps, uint8_t* desc,
+                                  int capacity, int nx, int total);
 __global__ void k_unpack_keys(const uint32_t* in, int n, int add, orbfe_keypoint* out);
 
 inline size_t qt_lds_bytes(int keycap_lds, int nodecap, int veccap)
