@@ -353,7 +353,7 @@ struct orbfe_aruco {
             }
             // (g): sort + rank per frame, approxPolyDP by persistent waves over the whole batch's borders, rectangles per frame
             {
-                const int pts = 1024;   // LDS point buffer per wave; longer borders are read from the pool
+                const int pts = RT_PTS;   // LDS point buffer per wave; longer borders are read from the pool
                 const size_t alds = tail_approx_lds_bytes(pts);
                 const int tail_wgs = std::min(RT_WGS, B * 128);
                 { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(k_tail_prep), tail_prep_lds_bytes(relay_kcap)); if (rc_lds_) return rc_lds_; }

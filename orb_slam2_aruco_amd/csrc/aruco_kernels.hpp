@@ -98,6 +98,9 @@ __global__ void k_finalize(const ArRect* rects, int rect_cap, const int32_t* can
 #ifndef RT_QUAD_MAX
 #define RT_QUAD_MAX 256           // k_tail_approx: borders of fewer points are done by 16 lanes, four to a wave (a multiple of 8)
 #endif
+#ifndef RT_PTS
+#define RT_PTS 1024                // k_tail_approx: points of a long border kept in LDS per wave (>= 4 * RT_QUAD_MAX: the four short ones share it)
+#endif
 #define RT_BUCKETS 256           // k_tail_prep: length classes of the work list's counting sort
 #ifndef RT_WGS
 #define RT_WGS 2048              // k_tail_approx: persistent workgroups of 4 waves (16 waves per CU at its ~128 VGPRs)
