@@ -63,6 +63,8 @@ def parse():
     ap.add_argument("--no-verify", action="store_true", help="skip the post-run check against the oracle")
     ap.add_argument("--no-aruco", action="store_true", help="diagnostic only: drop the ArUco leg (value becomes null)")
     ap.add_argument("--no-orb", action="store_true", help="diagnostic only: drop the ORB + matching legs (value becomes null)")
+    ap.add_argument("--force-gather", action="store_true", help="with --gpus 1: still initialise the RCCL process group (world size 1) "
+                    "and run the batch's device-tensor gather on the communication stream, so the N > 1 branch executes on a one-GPU box")
     ap.add_argument("--latency", action="store_true", help="single-frame latency through the host-pointer ABI instead")
     ap.add_argument("--out", default=None, help="also write the JSON line to this file")
     args = ap.parse_args()
@@ -70,7 +72,8 @@ def parse():
     for k, v in cfg.items():
         if getattr(args, k, None) is None:
             setattr(args, k, v)
-    args.custom = any(getattr(args, k) != v for k, v in cfg.items())
+    args.custom = any(getattr(args, k) != v for k, v in cfg.items() if k != "frames")
+    args.reduced = args.frames != cfg["frames"]        # the named configuration at another batch length (tests, quick runs)
     if args.cpu_frames is None:     # ~10-30 s of single-thread oracle work
         args.cpu_frames = {"C2": 300, "C3": 100, "C4": 100, "C5": 40}[args.config]
     return args
@@ -307,7 +310,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     backend = os.environ.get("ORBFE_BENCH_BACKEND") or "nccl"
-    if world > 1:
+    multi = world > 1 or args.force_gather          # the gather branch runs (RCCL with world size 1 under --force-gather)
+    if multi and "RANK" not in os.environ:          # --force-gather started without torchrun
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK=str(local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            sk = socket.socket(); sk.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(sk.getsockname()[1]); sk.close()
+    if multi:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -317,6 +327,8 @@ def main():
     from orb_slam2_aruco_amd.pipeline import FrontEndPipeline, RecordLayout, valid_records
     L = binding.load()
     version = L.orbfe_version().decode()
+    import hashlib
+    lib_sha16 = hashlib.sha256(open(binding.LIB_PATH, "rb").read()).hexdigest()[:16]
     # launch ablation needs the diagnosis build (tools/ablate.sh); its numbers are never a result
     skips = {}
     for key, env in (("orb_skip", "ORBFE_ORB_SKIP"), ("aruco_skip", "ORBFE_ARUCO_SKIP")):
@@ -327,6 +339,14 @@ def main():
         skips["library"] = version
     if os.environ.get("ORBFE_MATCH_TWICE"):      # sensitivity study: the matching launched twice (more work, but not the workload)
         skips["match_twice"] = 1
+    # every ORBFE_* variable that is set is recorded; the ones that change which kernels run or how they are scheduled make the
+    # line a diagnostic (value null) unless they spell the default
+    env_set = {k: v for k, v in sorted(os.environ.items()) if k.startswith("ORBFE_")}
+    harmless = {"ORBFE_BENCH_DEVICE", "ORBFE_BENCH_BACKEND", "ORBFE_LIB"}
+    defaults = {"ORBFE_ORIENT_PAIR": "0", "ORBFE_STREAM_PRIO": "0,0,0", "ORBFE_ENGINE_SETS": "1", "ORBFE_ENGINE_SETS_ARUCO": "1",
+                "ORBFE_BLUR_PLACE": "1", "ORBFE_ARUCO_RELAY_CHUNK": "0", "ORBFE_OCC_FAST": "0", "ORBFE_OCC_BLUR": "0",
+                "ORBFE_OCC_ORIENT": "0"}
+    env_nondefault = {k: v for k, v in env_set.items() if k not in harmless and defaults.get(k) != v}
     B, rows, cols = args.frames, args.rows, args.cols
     use_aruco, use_orb = not args.no_aruco, not args.no_orb
 
@@ -334,7 +354,7 @@ def main():
     gather = None
     pipe = FrontEndPipeline(B, rows, cols, args.nfeatures, args.nlevels, args.dictionary, device=local_rank,
                             marker_capacity=args.marker_capacity, use_orb=use_orb, use_aruco=use_aruco, splits=args.splits)
-    if world > 1:
+    if multi:
         # gloo moves CPU tensors: the test hook stages the record set through the host (the RCCL path gathers in place)
         gather = sharding.RecordGather(pipe.recs[0] if backend == "nccl" else pipe.recs[0].cpu())
         if backend == "nccl":
@@ -358,33 +378,37 @@ def main():
     for r in range(1, R):           # touch every resident copy once
         pipe.step(d_batches[r])
     pipe.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     for e in pipe.exs:
         e.enable_kernel_timing(True)
     for d in pipe.dets:
         d.enable_kernel_timing(True)
+    pipe.reset_timing_history()
     last = (0, 0)
     t0 = time.perf_counter()
     for i in range(args.steps):
         r = i % R
         last = (pipe.step(d_batches[r]), r)
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     status = pipe.status()
     if any(status.values()):
         raise SystemExit("front-end capacity exceeded during the timed run: results incomplete, no number reported (%r)" % (status,))
-    # HIP-event timings of the LAST timed step's launches (events were recorded on the launch stream every step)
+    # HIP-event timings of the timed steps' launches (events recorded on the launch stream every step, no synchronisation in
+    # between): the per-stage MEDIAN over the timed steps (the newest 64), not one step's events
     ex_last, det_last = pipe.last_engines()
-    orb_us = ex_last.kernel_times_us()
-    aruco_us = det_last.kernel_times_us() if use_aruco else np.zeros(0, np.float32)
+    orb_us = ex_last.kernel_times_us(median=True)
+    aruco_us = det_last.kernel_times_us(median=True) if use_aruco else np.zeros(0, np.float32)
+    orb_us_last = ex_last.kernel_times_us()
+    aruco_us_last = det_last.kernel_times_us() if use_aruco else np.zeros(0, np.float32)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if multi:
         if backend == "nccl":
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         else:
@@ -398,7 +422,7 @@ def main():
 
     # ---- multi-GPU: rank 0 checks every gathered block of the last step against that rank's own stream, recomputed here
     gather_check = None
-    if world > 1 and rank == 0:
+    if multi and rank == 0:
         blocks = gather.blocks
         lay = pipe.layout
         checked = []
@@ -421,11 +445,15 @@ def main():
 
     if rank == 0:
         stages = {nm: float(v) for nm, v in zip(binding.ORBextractor.STAGES, orb_us)}   # blur7 runs on a second stream
+        stages_last = {nm: float(v) for nm, v in zip(binding.ORBextractor.STAGES, orb_us_last)}
         if use_orb:
-            stages["knn2"], stages["search_init"] = pipe.matching_times_us()
+            stages["knn2"], stages["search_init"] = pipe.matching_times_us(median=True)
+            stages_last["knn2"], stages_last["search_init"] = pipe.matching_times_us()
         if use_aruco:
             for nm, v in zip(binding.MarkerDetector.STAGES, aruco_us):
                 stages["aruco_" + nm] = float(v)
+            for nm, v in zip(binding.MarkerDetector.STAGES, aruco_us_last):
+                stages_last["aruco_" + nm] = float(v)
         # algorithmic bytes per frame of each stage (DESIGN.md "roofline": the terms of SURVEY 8d's B_orb / B_aruco)
         sizes = ex.level_sizes()
         P = [w * h for (w, h) in sizes]
@@ -440,8 +468,12 @@ def main():
             alg["aruco_decode"] = Ncand * 2 * 35 * 35
             alg["aruco_finalize"] = Ncand * 36
         fl = lambda k: B if k in ("knn2", "search_init") else pipe.bounds[1] - pipe.bounds[0]   # frames one launch covers
-        pmc = load_profile("pmc_stage", args.config) if not args.custom else None      # tools/pmc.py + tools/make_traffic.py
-        traffic = load_profile("traffic", args.config) if not args.custom else None
+        # counters are NOT measured in this run: they come from the committed rocprofv3 --pmc profile of this configuration
+        # (tools/pmc.py + tools/make_profiles.py) and carry that profile's id; a custom size reports none
+        pmc = load_profile("pmc_stage", args.config) if not (args.custom or args.reduced) else None
+        traffic = load_profile("traffic", args.config) if not (args.custom or args.reduced) else None
+        prof_id = lambda d: ({"file": d.get("_file"), "profile": d.get("_profile"), "library_commit": d.get("_commit"),
+                              "library_sha16": d.get("_library_sha16")} if d else None)
         per_stage = {}
         for k, us in stages.items():
             ab = alg.get(k, 0) * fl(k)
@@ -451,6 +483,7 @@ def main():
             ent["traffic"] = traffic.get(k) if traffic else None
             if pmc and k in pmc:    # VALU issue time of the stage's launches (instruction counts x 4 cycles / 1024 SIMDs / 2.4 GHz)
                 ent["valu_us"] = pmc[k].get("valu_us")
+                # profile-run numerator over this run's denominator: an estimate, valid while the kernels are the profiled ones
                 ent["valu_frac"] = pmc[k]["valu_us"] / us if us > 0 and pmc[k].get("valu_us") is not None else None
                 ent["lane_utilisation"] = pmc[k].get("lane_utilisation")
             per_stage[k] = ent
@@ -476,12 +509,36 @@ def main():
                             "'stages' carries every stage's bound, and valu_us / valu_frac where the committed PMC profile of "
                             "this configuration has them",
                     "stages": per_stage}
+            step_s = elapsed / args.steps
+            # SURVEY 8d's contract: the compulsory traffic of a FUSED pipeline, per frame
+            #   B_orb = 3 * sumP - P0 + 1321 * N,   B_aruco = 3.33 * W * H,   B_match = (Q + T) * 32 + Q * 12 (frame t vs t-1)
+            b_orb = (3 * sumP - P0 + 1321 * N) if use_orb else 0.0
+            b_aruco = (10.0 / 3.0) * rows * cols if use_aruco else 0.0
+            b_match = (2 * N * 32 + N * 12) if use_orb else 0.0
+            fused_bytes = (b_orb + b_aruco) * B
+            fused_bytes_m = fused_bytes + b_match * (B - 1)
             step_bytes = sum(alg.get(k, 0) * B for k in stages)
-            roof["step"] = {"algorithmic_bytes_per_step": step_bytes, "GBps": step_bytes / (elapsed / args.steps) / 1e9,
-                            "frac": step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBPS,
-                            "note": "sum of the stages' algorithmic bytes over the measured step time: the whole pipeline against HBM"}
+            mk = lambda nbytes: {"algorithmic_bytes_per_step": nbytes, "GBps": nbytes / step_s / 1e9,
+                                 "frac": nbytes / step_s / 1e9 / HBM_PEAK_GBPS}
+            roof["step"] = {
+                "fused": dict(mk(fused_bytes), bytes_per_frame={"B_orb": b_orb, "B_aruco": b_aruco},
+                              note="SURVEY 8d / BASELINE.md section 4 contract bytes: (3*sumP - P0 + 1321*N) + 3.33*W*H per frame, "
+                                   "x frames per step, over the measured step time against the 8 TB/s HBM peak"),
+                "fused_with_match": dict(mk(fused_bytes_m), bytes_per_pair=b_match),
+                "per_stage": dict(mk(step_bytes), note="sum of the UNFUSED stages' algorithmic bytes (every pyramid level counted "
+                                  "once per kernel that reads or writes it): what the kernels as built must move, 1.4x the contract"),
+                "frac": fused_bytes / step_s / 1e9 / HBM_PEAK_GBPS,
+                "ms_per_step": 1000.0 * step_s}
+            if traffic:
+                tsum = sum(v for k, v in traffic.items() if not k.startswith("_") and isinstance(v, (int, float)) and k in stages)
+                roof["step"]["counter_traffic"] = {"bytes_per_step": tsum, "over_fused": tsum / fused_bytes if fused_bytes else None,
+                                                   "source": prof_id(traffic)}
+            roof["counters_from"] = {"pmc_stage": prof_id(pmc), "traffic": prof_id(traffic),
+                                     "note": "traffic / valu_us / lane_utilisation are read from committed profiles of this "
+                                             "configuration, not measured in this run; launch_us and ms_per_step are this run's"}
+            roof["launch_us_is"] = "median over the %d timed steps (newest 64)" % args.steps
 
-        invalid = bool(skips) or args.no_aruco or args.no_orb
+        invalid = bool(skips) or args.no_aruco or args.no_orb or bool(env_nondefault)
         verified = None
         if not args.no_verify and not skips:
             # outside the clock: frames {0, B/2, B-1} and pairs {0, B/2, B-2} of the LAST timed step against the oracle
@@ -496,9 +553,9 @@ def main():
         if world == 1 and args.cpu_frames > 0 and not skips:
             cpu = cpu_baseline(args, frames_np)
         c5 = None
-        if args.config == "C5" and world == 1 and use_orb and not args.custom:
+        if args.config == "C5" and world == 1 and use_orb and not args.custom and not args.reduced:
             c5 = c5_match_leg(binding, torch, dev, oracle_module())
-        cfg_name = "custom" if args.custom else args.config
+        cfg_name = "custom" if args.custom else args.config + (" at %d frames per step" % B if args.reduced else "")
         out = {
             "metric": "frames/s (ORB+ArUco extract+match, 640x480 mono)" if (rows, cols) == (480, 640) else
                       "frames/s (ORB+ArUco extract+match, %dx%d mono)" % (cols, rows),
@@ -514,21 +571,24 @@ def main():
                        "frames_per_step_per_gpu": B, "mean_keypoints_per_frame": N, "marker_records_per_frame": pipe.mcap,
                        "result_record_bytes_per_step_per_gpu": pipe.layout.nbytes, "resident_batches": R,
                        "sub_batches": pipe.S, "engine_sets": pipe.D, "aruco_big_frame_kernel": pipe.big_frames, "library": version,
-                       "parallelism": "stream-per-gpu x%d, %s gather to rank 0" % (world, "RCCL" if backend == "nccl" else backend)},
+                       "library_sha16": lib_sha16, "env": env_set, "env_nondefault": env_nondefault or None,
+                       "parallelism": "stream-per-gpu x%d, %s" % (world, ("%s gather to rank 0" % ("RCCL" if backend == "nccl" else backend))
+                                                                  if multi else "no collective (one rank)")},
             "roofline": roof, "cpu_baseline": cpu, "verified_frames": verified, "skips": skips or None,
-            "stage_us_last_step": stages,
+            "stage_us": stages, "stage_us_last_step": stages_last,
         }
         if invalid:
             out["diagnostic_frames_per_s"] = total_frames / elapsed
         if gather_check:
             out["gather_check"] = gather_check
+            out["gather_us"] = pipe.gather_times_us()
         if c5:
             out["c5_match"] = c5
         line = json.dumps(out)
         print(line)
         if args.out:
             open(args.out, "w").write(line + "\n")
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -130,7 +130,10 @@ int orbfe_extractor_debug_level_image(orbfe_extractor* h, int frame, int level, 
  * stage 1: keypoints kept by the quadtree (level coordinates).  Returns count in *n (<= capacity copied). */
 int orbfe_extractor_debug_level_keypoints(orbfe_extractor* h, int frame, int level, int stage, orbfe_keypoint* out,
                                           int capacity, int32_t* n);
-/* per-kernel timing of the last batch call on this handle, microseconds, in launch order; returns number written */
+/* per-kernel timing of the last batch call on this handle, microseconds, in launch order; returns number written.
+ * out_us == NULL: `capacity` is a control code (0 / 1 = event timing off / on, which also clears the history).  capacity < 0:
+ * the per-interval MEDIAN over the batches recorded since timing was switched on (the newest 64 at most), -capacity slots --
+ * what bench.py reports, because one batch's events are not the steady state of a pipelined run. */
 /* The extractor forks one launch (the blur, which only needs the pyramid) onto a second stream so that it overlaps with
  * FAST and the quadtree.  By default that is a stream the handle owns; an application that already has a lightly
  * loaded stream (bench.py: the matching stream) can lend it instead -- ROCm maps streams onto a few hardware queues, and
@@ -146,6 +149,12 @@ int orbfe_debug_control(const char* key, int value);
 
 /* popcount(a XOR b) over 256 bits, host pointers (ORBmatcher::DescriptorDistance) */
 int orbfe_hamming(const uint8_t* a, const uint8_t* b);
+/* Two more host-side scalar helpers for the reference's protected members (the device searches carry their own copies):
+ * ComputeThreeMaxima (ORBmatcher.cc:1605-1646) on L bin populations -> ind3[0..2], -1 where the 10 % rule drops a runner-up;
+ * CheckDistEpipolarLine (ORBmatcher.cc:139-157): 1 if keypoint 2 lies within 3.84 sigma^2 of the epipolar line of keypoint 1
+ * (F12 row-major 3 x 3, level_sigma2 = mvLevelSigma2[kp2.octave]). */
+void orbfe_three_maxima(const int32_t* counts, int L, int32_t* ind3);
+int orbfe_epipolar_distance_ok(float x1, float y1, float x2, float y2, const float* F12, float level_sigma2);
 
 /* All-pairs best / second-best of nq query descriptors against nt train descriptors (32 B rows), rule of App. D:
  *   if d<best {second=best; best=d; idx=t} else if d<second {second=d}   (first candidate wins ties)
@@ -205,7 +214,9 @@ int orbfe_search_by_projection(const orbfe_keypoint* kps, const uint8_t* desc, i
  * orbfe_search_by_projection_best (d_q_angle, factor, check_orientation, d_match_cur[f][keypoint] = query or -1; d_q_observed
  * plays q_blocks).  d_taken (may be NULL) is updated in place.  Asynchronous on `stream`; a candidate row that overflowed the
  * per-stream scratch truncates silently, so ask orbfe_search_by_projection_batch_status afterwards: *overflow = 0, or the
- * longest candidate list -- the scratch has then been grown and repeating the call succeeds. */
+ * longest candidate list -- the scratch has then been grown and repeating the call succeeds.  The flag is sticky like the extractor's
+ * and SearchForInitialization's: it covers every _batch_device search / fuse call on this stream since it was last read (reading
+ * clears it), so two batches may be enqueued before one status call. */
 int orbfe_search_by_projection_batch_device(const orbfe_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n, int capacity, int nframes,
                                             int cols, int rows, const float* bounds, const orbfe_window_query* d_queries,
                                             const uint8_t* d_qdesc, const int32_t* d_nq, int qcapacity, uint8_t* d_taken,
@@ -214,6 +225,12 @@ int orbfe_search_by_projection_batch_device(const orbfe_keypoint* d_kps, const u
                                             int32_t* d_best_level, int32_t* d_second_dist, int32_t* d_second_level, int32_t* d_match,
                                             int32_t* d_match_cur, int32_t* d_nmatches, void* stream);
 int orbfe_search_by_projection_batch_status(void* stream, int32_t* overflow);
+
+/* Scratch of the matching entry points is kept per (calling thread, device, stream) so that Tracking / LocalMapping / LoopClosing
+ * calls do not serialise on each other.  Reuse a small fixed set of streams: at most 16 (device, stream) slots are kept per thread,
+ * least recently used first out.  Before destroying a stream that was handed to a `_device` matching call, release its scratch
+ * (grown candidate strides, unread overflow flags) so that a new stream at the same address starts clean.  Synchronises `stream`. */
+int orbfe_release_stream_scratch(void* stream);
 
 /* ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono) (src/ORBmatcher.cc:1332-1474; what
  * TrackWithMotionModel runs every frame), monocular, whole on the device: the projection of the last frame's map points
@@ -475,6 +492,7 @@ int orbfe_aruco_max_markers(const orbfe_aruco* h);
  *     of DictionaryBased::detect (a code closer than int(tau * rate) bits to a dictionary entry is accepted; default 0 = exact).
  *   setDetectionMode(dm, minMarkerSize): DM_NORMAL (0) with minMarkerSize 0 is what is built (Frame.cc:136); DM_FAST (1) and
  *     DM_VIDEO_FAST (2) -- THRES_AUTO_FIXED with its rand() retries and frame-to-frame state -- are refused with ORBFE_ERR_INVALID.
+ *     min_marker_size must be 0 (Params::minSize > 0 detects on a reduced image: not built; refused, never ignored).
  *   setCornerRefinementMethod(m): CORNER_LINES (1, default, Frame.cc:137) and CORNER_NONE (2); CORNER_SUBPIX (0) is refused. */
 int orbfe_aruco_set_error_correction_rate(orbfe_aruco* h, float rate);
 int orbfe_aruco_set_detection_mode(orbfe_aruco* h, int mode, float min_marker_size);
@@ -483,6 +501,10 @@ int orbfe_aruco_set_corner_refinement(orbfe_aruco* h, int method);
  * `frame`: the full border the rectangle came from, (x, y) int32 pairs.  *n = its length; min(*n, capacity) points are written.
  * Host pointers; synchronises the device. */
 int orbfe_aruco_marker_contour(orbfe_aruco* h, int frame, int marker, int32_t* xy, int capacity, int32_t* n);
+/* The same for the first `nmarkers` markers of the frame in ONE round trip: offsets[0 .. nmarkers] are filled in any case (marker i owns
+ * points offsets[i] .. offsets[i+1]); the (x, y) pairs are written only when offsets[nmarkers] <= capacity (points), so a caller
+ * asks once with capacity 0 for the total or, simply, passes a generous buffer. */
+int orbfe_aruco_marker_contours(orbfe_aruco* h, int frame, int nmarkers, int32_t* xy, int capacity, int32_t* offsets);
 
 /* detect(image) -> markers sorted by id, corners refined by contour lines. Host pointers, one CV_8UC1 frame.
  * Frames up to 4095 pixels wide (adaptive-threshold windows up to 31, markerdetector_impl.cpp:3765-3809). */

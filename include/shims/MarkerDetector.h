@@ -34,7 +34,9 @@ public:
     {
         void setDetectionMode(DetectionMode dm, float minMarkerSize)
         {
-            check(orbfe_aruco_set_detection_mode(owner->handle(), (int)dm, minMarkerSize));
+            // the mode is checked now; minSize is bookkeeping until detect() (a following setCornerRefinementMethod(CORNER_LINES /
+            // CORNER_NONE) resets it to 0 as in the reference, markerdetector.cpp:374-393), where a value still in force is refused
+            check(orbfe_aruco_set_detection_mode(owner->handle(), (int)dm, 0.f));
             detectMode = dm;
             minSize = minMarkerSize;
         }
@@ -120,6 +122,8 @@ public:
         if (!h_) setDictionary(_params.dictionary, _params.error_correction_rate);
         if (input.type() != CV_8UC1)
             throw cv::Exception(9001, "the orbfe detector takes the grey image Frame.cc:142 passes (CV_8UC1)", "MarkerDetector::detect", __FILE__, __LINE__);
+        if (orbfe_aruco_set_detection_mode(h_, (int)_params.detectMode, _params.minSize) != ORBFE_OK)   // minSize != 0 in force: refused
+            throw cv::Exception(9001, orbfe_last_error(), "MarkerDetector::detect", __FILE__, __LINE__);
         const int cap = orbfe_aruco_max_markers(h_);
         std::vector<orbfe_marker> m(cap);
         int32_t n = 0;
@@ -127,19 +131,24 @@ public:
             throw cv::Exception(9001, orbfe_last_error(), "MarkerDetector::detect", __FILE__, __LINE__);
         detectedMarkers.clear();
         detectedMarkers.resize(n);
+        // Marker::contourPoints (marker.h:56) of all markers of the frame in one round trip
+        std::vector<int32_t> off((size_t)n + 1, 0), xy;
+        if (n > 0 && orbfe_aruco_marker_contours(h_, 0, n, nullptr, 0, off.data()) == ORBFE_OK && off[n] > 0)
+        {
+            xy.resize((size_t)off[n] * 2);
+            if (orbfe_aruco_marker_contours(h_, 0, n, xy.data(), off[n], off.data()) != ORBFE_OK) xy.clear();
+        }
         for (int i = 0; i < n; i++)
         {
             Marker& M = detectedMarkers[i];
             M.id = m[i].id;
             M.dict_info = _params.dictionary;
             for (int k = 0; k < 4; k++) M.push_back(cv::Point2f(m[i].corners[k][0], m[i].corners[k][1]));
-            int32_t len = 0;                                   // Marker::contourPoints (marker.h:56)
-            if (orbfe_aruco_marker_contour(h_, 0, i, nullptr, 0, &len) == ORBFE_OK && len > 0)
+            if (!xy.empty())
             {
-                std::vector<int32_t> xy((size_t)len * 2);
-                orbfe_aruco_marker_contour(h_, 0, i, xy.data(), len, &len);
+                const int len = off[i + 1] - off[i];
                 M.contourPoints.resize(len);
-                for (int j = 0; j < len; j++) M.contourPoints[j] = cv::Point(xy[2 * j], xy[2 * j + 1]);
+                for (int j = 0; j < len; j++) M.contourPoints[j] = cv::Point(xy[2 * (off[i] + j)], xy[2 * (off[i] + j) + 1]);
             }
         }
         // detect the position of detected markers if desired (markerdetector_impl.cpp:8720-8780 -> Marker::calculateExtrinsics)

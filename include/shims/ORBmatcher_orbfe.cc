@@ -401,6 +401,9 @@ int ORBmatcher::Fuse(KeyFrame* pKF, const vector<MapPoint*>& vpMapPoints, const 
     for (int i = 0; i < nMPs; i++) { // :943-964
         if (!A.valid[i] || bestDist[i] > TH_LOW) continue;
         MapPoint* pMP = vpMapPoints[i];
+        // the reference evaluates :850-856 inside this sequential loop, after earlier iterations' Replace / AddObservation: a point
+        // that occurs twice in vpMapPoints, or was replaced a moment ago, is skipped there -- so the gates are asked again here
+        if (pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;
         MapPoint* pMPinKF = pKF->GetMapPoint(bestIdx[i]);
         if (pMPinKF) {
             if (!pMPinKF->isBad()) {
@@ -443,6 +446,7 @@ int ORBmatcher::Fuse(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*>& vpPoin
     for (int i = 0; i < nPoints; i++) { // :1085-1099
         if (!A.valid[i] || bestDist[i] > TH_LOW) continue;
         MapPoint* pMP = vpPoints[i];
+        if (pMP->isBad()) continue; // :1003 is evaluated per iteration in the reference (spAlreadyFound is a snapshot there too)
         MapPoint* pMPinKF = pKF->GetMapPoint(bestIdx[i]);
         if (pMPinKF) {
             if (!pMPinKF->isBad()) vpReplacePoint[i] = pMPinKF;
@@ -458,29 +462,22 @@ int ORBmatcher::Fuse(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*>& vpPoin
 // the two protected helpers stay callable for code that derives from ORBmatcher
 bool ORBmatcher::CheckDistEpipolarLine(const cv::KeyPoint& kp1, const cv::KeyPoint& kp2, const cv::Mat& F12, const KeyFrame* pKF2)
 {
-    // src/ORBmatcher.cc:139-157
-    const float a = kp1.pt.x * F12.at<float>(0, 0) + kp1.pt.y * F12.at<float>(1, 0) + F12.at<float>(2, 0);
-    const float b = kp1.pt.x * F12.at<float>(0, 1) + kp1.pt.y * F12.at<float>(1, 1) + F12.at<float>(2, 1);
-    const float c = kp1.pt.x * F12.at<float>(0, 2) + kp1.pt.y * F12.at<float>(1, 2) + F12.at<float>(2, 2);
-    const float num = a * kp2.pt.x + b * kp2.pt.y + c;
-    const float den = a * a + b * b;
-    if (den == 0) return false;
-    const float dsqr = num * num / den;
-    return dsqr < 3.84 * pKF2->mvLevelSigma2[kp2.octave];
+    float F[9];
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) F[3 * r + c] = F12.at<float>(r, c);
+    return orbfe_epipolar_distance_ok(kp1.pt.x, kp1.pt.y, kp2.pt.x, kp2.pt.y, F, pKF2->mvLevelSigma2[kp2.octave]) != 0;
 }
 
 void ORBmatcher::ComputeThreeMaxima(vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3)
 {
-    // src/ORBmatcher.cc:1605-1646
-    int max1 = 0, max2 = 0, max3 = 0;
-    for (int i = 0; i < L; i++) {
-        const int s = (int)histo[i].size();
-        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
-        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
-        else if (s > max3) { max3 = s; ind3 = i; }
-    }
-    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
-    else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+    vector<int32_t> counts(L);
+    for (int i = 0; i < L; i++) counts[i] = (int32_t)histo[i].size();
+    int32_t ind[3];
+    orbfe_three_maxima(counts.data(), L, ind);
+    // the reference leaves an index it never assigned untouched (callers initialise all three to -1)
+    if (ind[0] >= 0) ind1 = ind[0];
+    if (ind[1] >= 0 || ind[0] >= 0) ind2 = ind[1];
+    if (ind[2] >= 0 || ind[0] >= 0) ind3 = ind[2];
 }
 
 } // namespace ORB_SLAM2

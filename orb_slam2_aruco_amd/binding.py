@@ -28,21 +28,21 @@ SYMBOLS = [
     "orbfe_extractor_batch_status", "orbfe_search_for_initialization_batch_status", "orbfe_extractor_set_gaussian_taps",
     "orbfe_extractor_debug_level_size", "orbfe_extractor_debug_level_image",
     "orbfe_extractor_debug_level_keypoints", "orbfe_extractor_debug_kernel_times", "orbfe_extractor_set_aux_stream",
-    "orbfe_debug_control", "orbfe_hamming", "orbfe_knn2", "orbfe_knn2_csr", "orbfe_knn2_batch_device", "orbfe_search_for_initialization",
+    "orbfe_debug_control", "orbfe_hamming", "orbfe_three_maxima", "orbfe_epipolar_distance_ok", "orbfe_knn2", "orbfe_knn2_csr", "orbfe_knn2_batch_device", "orbfe_search_for_initialization",
     "orbfe_search_for_initialization_batch_device", "orbfe_search_by_projection",
     "orbfe_undistort_points", "orbfe_undistort_keypoints_batch_device", "orbfe_compute_image_bounds",
     "orbfe_aruco_create", "orbfe_aruco_destroy", "orbfe_aruco_set_dictionary", "orbfe_aruco_max_markers",
     "orbfe_aruco_detect", "orbfe_aruco_detect_batch", "orbfe_aruco_detect_batch_device", "orbfe_aruco_debug_image",
     "orbfe_aruco_debug_kernel_times", "orbfe_aruco_set_aux_stream",
     "orbfe_aruco_batch_status", "orbfe_aruco_set_big_frames", "orbfe_aruco_set_error_correction_rate",
-    "orbfe_aruco_set_detection_mode", "orbfe_aruco_set_corner_refinement", "orbfe_aruco_marker_contour",
+    "orbfe_aruco_set_detection_mode", "orbfe_aruco_set_corner_refinement", "orbfe_aruco_marker_contour", "orbfe_aruco_marker_contours",
     "orbfe_camera_resize", "orbfe_marker_poses", "orbfe_marker_poses_batch_device",
     "orbfe_vocabulary_load_text", "orbfe_vocabulary_create", "orbfe_vocabulary_destroy", "orbfe_vocabulary_info",
     "orbfe_vocabulary_transform", "orbfe_vocabulary_transform_batch_device",
     "orbfe_search_by_bow", "orbfe_search_by_bow_batch_device",
     "orbfe_search_for_triangulation", "orbfe_search_for_triangulation_batch_device",
     "orbfe_distinctive_descriptors", "orbfe_distinctive_descriptors_device", "orbfe_search_by_projection_batch_device",
-    "orbfe_search_by_projection_batch_status", "orbfe_search_by_projection_last_frame", "orbfe_search_by_projection_best", "orbfe_search_by_projection_keyframe", "orbfe_fuse_search", "orbfe_fuse_search_batch_device", "orbfe_project_map_points", "orbfe_search_by_sim3", "orbfe_search_by_projection_sim3",
+    "orbfe_search_by_projection_batch_status", "orbfe_release_stream_scratch", "orbfe_search_by_projection_last_frame", "orbfe_search_by_projection_best", "orbfe_search_by_projection_keyframe", "orbfe_fuse_search", "orbfe_fuse_search_batch_device", "orbfe_project_map_points", "orbfe_search_by_sim3", "orbfe_search_by_projection_sim3",
     "orbfe_keyframe_features_pack", "orbfe_keyframe_features_unpack", "orbfe_keyframe_features_pack_device",
     "orbfe_keyframe_features_unpack_device",
 ]
@@ -136,6 +136,7 @@ def load():
         L.orbfe_aruco_set_detection_mode.argtypes = [vp, i32, f32]
         L.orbfe_aruco_set_corner_refinement.argtypes = [vp, i32]
         L.orbfe_aruco_marker_contour.argtypes = [vp, i32, i32, vp, i32, vp]
+        L.orbfe_aruco_marker_contours.argtypes = [vp, i32, i32, vp, i32, vp]
         L.orbfe_camera_resize.argtypes = [vp, i32, i32, i32, i32, vp]
     if hasattr(L, "orbfe_vocabulary_create"):
         L.orbfe_vocabulary_load_text.restype = vp
@@ -308,9 +309,10 @@ class ORBextractor:
     # order of kernel_times_us(); blur7 runs on the extractor's second stream, concurrently with fast_cells + distribute
     STAGES = ["resize", "blur7", "fast_cells", "distribute", "orient_describe"]
 
-    def kernel_times_us(self):
+    def kernel_times_us(self, median=False):
+        """Stage times of the last batch, or (median=True) the per-stage median over the batches since timing was enabled."""
         out = np.zeros(32, np.float32)
-        n = self.L.orbfe_extractor_debug_kernel_times(self.h, _p(out), 32)
+        n = self.L.orbfe_extractor_debug_kernel_times(self.h, _p(out), -32 if median else 32)
         return out[:n]
 
 
@@ -766,6 +768,14 @@ class MarkerDetector:
         _check(self.L, self.L.orbfe_aruco_marker_contour(self.h, frame, marker, _p(xy), n.value, C.byref(n)), "orbfe_aruco_marker_contour")
         return xy[:n.value]
 
+    def contours(self, nmarkers, frame=0):
+        """contourPoints of the first `nmarkers` output markers of `frame` in one round trip -> list of (n, 2) int32."""
+        off = np.zeros(nmarkers + 1, np.int32)
+        _check(self.L, self.L.orbfe_aruco_marker_contours(self.h, frame, nmarkers, None, 0, _p(off)), "orbfe_aruco_marker_contours")
+        xy = np.zeros((max(int(off[-1]), 1), 2), np.int32)
+        _check(self.L, self.L.orbfe_aruco_marker_contours(self.h, frame, nmarkers, _p(xy), int(off[-1]), _p(off)), "orbfe_aruco_marker_contours")
+        return [xy[off[i]:off[i + 1]] for i in range(nmarkers)]
+
     def detect(self, image, camera=None, markerSizeMeters=-1.0):
         """detect(image) -> MARKER_DTYPE records.  With camera = (K, dist, (cam_width, cam_height)) and a marker size
         (markerdetector.h:276-312; Frame.cc:142 passes 0.187) -> (markers, POSE_DTYPE poses): the camera matrix is
@@ -853,9 +863,10 @@ class MarkerDetector:
     def enable_kernel_timing(self, on=True):
         self.L.orbfe_aruco_debug_kernel_times(self.h, None, int(on))
 
-    def kernel_times_us(self):
+    def kernel_times_us(self, median=False):
+        """Stage times of the last batch, or (median=True) the per-stage median over the batches since timing was enabled."""
         out = np.zeros(32, np.float32)
-        n = self.L.orbfe_aruco_debug_kernel_times(self.h, _p(out), 32)
+        n = self.L.orbfe_aruco_debug_kernel_times(self.h, _p(out), -32 if median else 32)
         return out[:n]
 
     @staticmethod

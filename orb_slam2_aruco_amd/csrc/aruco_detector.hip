@@ -478,10 +478,12 @@ int orbfe_aruco_set_detection_mode(orbfe_aruco* h, int mode, float min_marker_si
     // DM_VIDEO_FAST (2) switch to THRES_AUTO_FIXED (markerdetector.cpp:380-397): a global threshold retried with rand() and
     // carried from frame to frame -- not built; refusing loudly beats detecting with another mode silently.
     if (mode != 0) return fail(ORBFE_ERR_INVALID, "detection mode %d (DM_FAST / DM_VIDEO_FAST: THRES_AUTO_FIXED) is not implemented", mode);
-    if (min_marker_size != 0.0f && h->corner_method == 0)
-        return fail(ORBFE_ERR_INVALID, "minMarkerSize %g: only 0 is implemented (CORNER_LINES / CORNER_NONE reset it to 0 anyway)",
-                    (double)min_marker_size);
-    return ORBFE_OK; // setCornerRefinementMethod(!= CORNER_SUBPIX) sets minSize = 0 (markerdetector.cpp:399-402)
+    // Params::minSize (markerdetector.cpp:376) makes the reference detect on a reduced image and drop short contours: not built, and
+    // a size that would be ignored silently is refused.  (The reference's setCornerRefinementMethod(!= CORNER_SUBPIX) resets minSize to
+    // 0, markerdetector.cpp:390-393: the shim keeps that bookkeeping and only ever passes the value in force at detect time.)
+    if (min_marker_size != 0.0f)
+        return fail(ORBFE_ERR_INVALID, "minMarkerSize %g: only 0 is implemented", (double)min_marker_size);
+    return ORBFE_OK;
 }
 
 int orbfe_aruco_set_corner_refinement(orbfe_aruco* h, int method)
@@ -511,6 +513,38 @@ int orbfe_aruco_marker_contour(orbfe_aruco* h, int frame, int marker, int32_t* x
         std::vector<uint32_t> p(m);
         ORBFE_HIP(hipMemcpy(p.data(), h->d_pool.as<uint32_t>() + (size_t)frame * h->pool_fu32 + r.off, (size_t)m * 4, hipMemcpyDeviceToHost));
         for (int i = 0; i < m; i++) { xy[2 * i] = (int32_t)(p[i] & 0xffff); xy[2 * i + 1] = (int32_t)(p[i] >> 16); }
+    }
+    return ORBFE_OK;
+}
+
+int orbfe_aruco_marker_contours(orbfe_aruco* h, int frame, int nmarkers, int32_t* xy, int capacity, int32_t* offsets)
+{
+    if (!h || !offsets || frame < 0 || frame >= h->last_nframes || nmarkers < 0 || nmarkers > AR_MAX_RECTS || (capacity > 0 && !xy))
+        return fail(ORBFE_ERR_INVALID, "orbfe_aruco_marker_contours: invalid argument");
+    int rc = use_device(h->device);
+    if (rc) return rc;
+    offsets[0] = 0;
+    if (nmarkers == 0) return ORBFE_OK;
+    ORBFE_HIP(hipDeviceSynchronize());
+    std::vector<int32_t> src((size_t)nmarkers);
+    std::vector<ArRect> rects(AR_MAX_RECTS);
+    ORBFE_HIP(hipMemcpy(src.data(), h->d_msrc.as<int32_t>() + (size_t)frame * AR_MAX_RECTS, (size_t)nmarkers * 4, hipMemcpyDeviceToHost));
+    ORBFE_HIP(hipMemcpy(rects.data(), h->d_rects.as<ArRect>() + (size_t)frame * AR_MAX_RECTS, sizeof(ArRect) * AR_MAX_RECTS, hipMemcpyDeviceToHost));
+    // the borders of a frame's markers lie in one pool: fetch the span that covers them once, then cut it up
+    uint32_t lo = ~0u, hi = 0;
+    for (int i = 0; i < nmarkers; i++) {
+        if (src[i] < 0 || src[i] >= AR_MAX_RECTS) return fail(ORBFE_ERR_INVALID, "orbfe_aruco_marker_contours: no marker %d in the last batch", i);
+        const ArRect& r = rects[(size_t)src[i]];
+        offsets[i + 1] = offsets[i] + r.len;
+        if (r.len > 0) { lo = std::min(lo, (uint32_t)r.off); hi = std::max(hi, (uint32_t)(r.off + r.len)); }
+    }
+    if (offsets[nmarkers] > capacity || hi <= lo) return ORBFE_OK; // the caller reads the total from offsets and comes back with room
+    std::vector<uint32_t> p((size_t)(hi - lo));
+    ORBFE_HIP(hipMemcpy(p.data(), h->d_pool.as<uint32_t>() + (size_t)frame * h->pool_fu32 + lo, p.size() * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < nmarkers; i++) {
+        const ArRect& r = rects[(size_t)src[i]];
+        int32_t* o = xy + 2 * (size_t)offsets[i];
+        for (int k = 0; k < r.len; k++) { const uint32_t v = p[(size_t)(r.off - lo) + k]; o[2 * k] = (int32_t)(v & 0xffff); o[2 * k + 1] = (int32_t)(v >> 16); }
     }
     return ORBFE_OK;
 }
@@ -658,9 +692,10 @@ int orbfe_aruco_debug_kernel_times(orbfe_aruco* h, float* out_us, int capacity)
     if (!h) return fail(ORBFE_ERR_INVALID, "null handle");
     if (!out_us) { // control codes: 0/1 kernel timing off/on, 2/3 force the legacy contour kernel on/off
         if (capacity == 2 || capacity == 3) h->force_legacy = capacity == 2;
-        else h->timer.enabled = capacity != 0;
+        else { h->timer.enabled = capacity != 0; h->timer.reset_history(); }
         return 0;
     }
+    if (capacity < 0) return h->timer.collect_median(out_us, -capacity, nullptr);
     return h->timer.collect(out_us, capacity);
 }
 

@@ -1119,6 +1119,7 @@ __global__ __launch_bounds__(256) void k_distinctive(const uint8_t* __restrict__
 
 struct MatchWorkspace {
     DevBuf pidx, pbest, psecond, csr_cnt, csr_idx, csr_dist, scratch, overflow, prev;
+    DevBuf sbp_batch_overflow; // flag of the _batch_device searches: sticky until orbfe_search_by_projection_batch_status reads it
     DevBuf sfi_overflow;  // k_search_init's flag: zeroed when allocated and whenever it is read (no memset launch per batch)
     DevBuf q, t, nq, nt, oidx, obest, osecond, kps, desc, nk, m12, nm;
     int csr_per_pair = 0; // CSR slots per frame pair (grown by the host wrapper on overflow)
@@ -1127,6 +1128,15 @@ struct MatchWorkspace {
 // one workspace per (thread, device, stream): see ThreadWorkspaces.  The host-pointer entry points run on the null stream.
 static thread_local ThreadWorkspaces<MatchWorkspace> tl_ws;
 static MatchWorkspace& ws(hipStream_t s = nullptr) { return tl_ws.get(s); }
+// a capacity flag that is zeroed once, when it is allocated, and again only by the status call that reads it
+static int ensure_sticky_flag(DevBuf& b)
+{
+    if (b.p) return ORBFE_OK;
+    int rc = b.ensure(16);
+    if (rc) return rc;
+    ORBFE_HIP(hipMemset(b.p, 0, 16));
+    return ORBFE_OK;
+}
 
 // debug: 0 = choose by problem size, 1 = VALU tiles (+ split/merge), 2 = matrix cores (orbfe_debug_control "knn2_path")
 static int g_knn2_path = 0;
@@ -1239,6 +1249,38 @@ int orbfe_hamming(const uint8_t* a, const uint8_t* b)
     int dist = 0;
     for (int i = 0; i < 4; i++) dist += __builtin_popcountll(x[i] ^ y[i]);
     return dist;
+}
+
+void orbfe_three_maxima(const int32_t* counts, int L, int32_t* ind3)
+{
+    // host-side scalar helper: ORBmatcher::ComputeThreeMaxima (ORBmatcher.cc:1605-1646) on the bin populations; the device
+    // searches carry their own copy (rot_hist_maxima).  A running top three with strict '>' (the earliest bin wins ties), then the
+    // 10 % rule on the runner-ups.
+    int top[3] = {0, 0, 0};
+    ind3[0] = ind3[1] = ind3[2] = -1;
+    for (int i = 0; i < L; i++) {
+        const int c = counts[i];
+        int k = 0;
+        while (k < 3 && c <= top[k]) k++;
+        if (k == 3) continue;
+        for (int j = 2; j > k; j--) { top[j] = top[j - 1]; ind3[j] = ind3[j - 1]; }
+        top[k] = c;
+        ind3[k] = i;
+    }
+    const float floor_ = 0.1f * (float)top[0];
+    if ((float)top[1] < floor_) ind3[1] = ind3[2] = -1;
+    else if ((float)top[2] < floor_) ind3[2] = -1;
+}
+
+int orbfe_epipolar_distance_ok(float x1, float y1, float x2, float y2, const float* F12, float level_sigma2)
+{
+    // host-side scalar helper: ORBmatcher::CheckDistEpipolarLine (ORBmatcher.cc:139-157); l = x1' F12, row-major 3 x 3
+    float l[3];
+    for (int j = 0; j < 3; j++) l[j] = x1 * F12[j] + y1 * F12[3 + j] + F12[6 + j];
+    const float num = l[0] * x2 + l[1] * y2 + l[2];
+    const float den = l[0] * l[0] + l[1] * l[1];
+    if (den == 0) return 0;
+    return num * num / den < 3.84 * level_sigma2; // the comparison is in double, as in the reference
 }
 
 int orbfe_knn2_batch_device(const uint8_t* d_Q, const int32_t* d_nq, size_t q_stride, int max_nq, const uint8_t* d_T,
@@ -1768,16 +1810,15 @@ int orbfe_search_by_projection_batch_device(const orbfe_keypoint* d_kps, const u
     const size_t NQ = (size_t)nframes * qcapacity;
     int rc;
     if ((rc = w.csr_idx.ensure(NQ * stride * 2)) || (rc = w.csr_dist.ensure(NQ * stride)) || (rc = w.csr_cnt.ensure(NQ * 4)) ||
-        (rc = w.scratch.ensure(NQ * 4 + 256)) || (rc = w.overflow.ensure(16)))
+        (rc = w.scratch.ensure(NQ * 4 + 256)) || (rc = ensure_sticky_flag(w.sbp_batch_overflow)))
         return rc;
-    ORBFE_HIP(hipMemsetAsync(w.overflow.p, 0, 4, s));
     SbpBatch B{};
     B.kps = d_kps; B.desc = d_desc; B.n = d_n; B.capacity = capacity;
     B.queries = reinterpret_cast<const SbpQuery*>(d_queries); B.qdesc = d_qdesc; B.nq = d_nq; B.qcapacity = qcapacity;
     B.taken = d_taken; B.q_observed = d_q_observed; B.q_angle = d_q_angle;
     B.row_rank = w.csr_idx.as<uint16_t>(); B.row_dist = w.csr_dist.as<uint8_t>(); B.row_cnt = w.csr_cnt.as<int32_t>(); B.row_stride = stride;
     B.best_idx = d_best_idx; B.best_dist = d_best_dist; B.best_level = d_best_level; B.second_dist = d_second_dist; B.second_level = d_second_level;
-    B.match = d_match; B.nmatches = d_nmatches; B.overflow = w.overflow.as<int32_t>();
+    B.match = d_match; B.nmatches = d_nmatches; B.overflow = w.sbp_batch_overflow.as<int32_t>();
     B.match_cur = d_match_cur; B.qbin = w.scratch.as<int32_t>();
     if ((rc = ensure_dyn_lds(reinterpret_cast<const void*>(&k_search_by_projection_batch), lds))) return rc;
     hipLaunchKernelGGL(k_search_by_projection_batch, dim3(nframes), dim3(SBP_THREADS), lds, s, B, ncap, frame_bounds(cols, rows, bounds), mode,
@@ -1808,9 +1849,8 @@ int orbfe_fuse_search_batch_device(const orbfe_keypoint* d_kps, const uint8_t* d
     int rc;
     // obest: [best_level | second_dist | second_level | match] x NQ, then nq[nkf], nmatches[nkf]
     if ((rc = w.q.ensure(NQ * sizeof(orbfe_window_query))) || (rc = w.csr_idx.ensure(NQ * stride * 2)) || (rc = w.csr_dist.ensure(NQ * stride)) ||
-        (rc = w.csr_cnt.ensure(NQ * 4)) || (rc = w.obest.ensure((NQ * 4 + 2 * (size_t)nkf) * 4 + 256)) || (rc = w.overflow.ensure(16)))
+        (rc = w.csr_cnt.ensure(NQ * 4)) || (rc = w.obest.ensure((NQ * 4 + 2 * (size_t)nkf) * 4 + 256)) || (rc = ensure_sticky_flag(w.sbp_batch_overflow)))
         return rc;
-    ORBFE_HIP(hipMemsetAsync(w.overflow.p, 0, 4, s));
     for (int k = 0; k < nkf; k++) { // the projection and the gates of :848-915, one small launch per keyframe pose
         ProjectParams P;
         if ((rc = project_params(P, Tcw + 12 * k, Ow + 3 * k, K4, cols, rows, bounds, 1, scale_factors, nlevels, log_scale_factor, th, 1, 0,
@@ -1827,7 +1867,7 @@ int orbfe_fuse_search_batch_device(const orbfe_keypoint* d_kps, const uint8_t* d
     B.queries = w.q.as<SbpQuery>(); B.qdesc = d_mp_desc; B.qdesc_shared = 1; B.nq = d_nq; B.qcapacity = nmp;
     B.row_rank = w.csr_idx.as<uint16_t>(); B.row_dist = w.csr_dist.as<uint8_t>(); B.row_cnt = w.csr_cnt.as<int32_t>(); B.row_stride = stride;
     B.best_idx = d_best_idx; B.best_dist = d_best_dist; B.best_level = o; B.second_dist = o + NQ; B.second_level = o + 2 * NQ;
-    B.match = o + 3 * NQ; B.nmatches = d_nq + nkf; B.overflow = w.overflow.as<int32_t>();
+    B.match = o + 3 * NQ; B.nmatches = d_nq + nkf; B.overflow = w.sbp_batch_overflow.as<int32_t>();
     B.chi2 = chi2 > 0.0 ? chi2 : 0.0;
     if (chi2 > 0.0)
         for (int l = 0; l < 16; l++) B.inv_sigma2[l] = inv_level_sigma2[std::min(l, nlevels - 1)];
@@ -1844,10 +1884,21 @@ int orbfe_search_by_projection_batch_status(void* stream, int32_t* overflow)
     *overflow = 0;
     hipStream_t s = (hipStream_t)stream;
     MatchWorkspace& w = ws(s);
-    if (!w.overflow.p) return ORBFE_OK;
+    if (!w.sbp_batch_overflow.p) return ORBFE_OK; // no batch on this (thread, device, stream) yet
     ORBFE_HIP(hipStreamSynchronize(s));
-    ORBFE_HIP(hipMemcpy(overflow, w.overflow.p, 4, hipMemcpyDeviceToHost));
+    ORBFE_HIP(hipMemcpy(overflow, w.sbp_batch_overflow.p, 4, hipMemcpyDeviceToHost));
+    if (*overflow) ORBFE_HIP(hipMemset(w.sbp_batch_overflow.p, 0, 4)); // covers every batch since it was last read
     if (*overflow > w.sbp_stride) w.sbp_stride = (*overflow + 63) / 64 * 64; // the next batch on this stream has the room
+    return ORBFE_OK;
+}
+
+int orbfe_release_stream_scratch(void* stream)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return fail(ORBFE_ERR_NO_DEVICE, "orbfe_release_stream_scratch: no HIP device (this library has no CPU fallback)");
+    hipStream_t s = (hipStream_t)stream;
+    ORBFE_HIP(hipStreamSynchronize(s));
+    tl_ws.release(s);
     return ORBFE_OK;
 }
 

@@ -358,8 +358,10 @@ struct orbfe_extractor {
 
     // The batched pipeline: every launch covers all frames.  Asynchronous on `s`.
     int run_device(const uint8_t* d_imgs, int B, size_t frame_stride, int rows_, int cols_, size_t step,
-                   orbfe_keypoint* d_kps_out, uint8_t* d_desc_out, int capacity, int32_t* d_n, hipStream_t s)
+                   orbfe_keypoint* d_kps_out, uint8_t* d_desc_out, int capacity, int32_t* d_n, hipStream_t s, int flag_word = 0)
     {
+        // flag_word: 0 = the sticky flag of the device-pointer batches (orbfe_extractor_batch_status), 1 = the host-pointer entry
+        // points' own word (they own their whole call, so a device batch's unread flag must not fail them)
         int rc;
         if ((rc = build_geometry(rows_, cols_))) return rc;
         if ((rc = ensure_workspace(B))) return rc;
@@ -471,7 +473,7 @@ struct orbfe_extractor {
             if ((rc2 = d_flatkv.ensure((size_t)B * capacity * 4)) || (rc2 = d_flatlvl.ensure((size_t)B * capacity))) return rc2;
         }
         hipLaunchKernelGGL(k_level_offsets, dim3(B), dim3(256), 0, s, d_lvlcnt.as<int32_t>(), d_lvloff.as<int32_t>(),
-                           d_n, nlevels, B, capacity, d_overflow.as<int32_t>(), dg, d_lvlout.as<uint32_t>(), out_total,
+                           d_n, nlevels, B, capacity, d_overflow.as<int32_t>() + flag_word, dg, d_lvlout.as<uint32_t>(), out_total,
                            d_flatkv.as<uint32_t>(), d_flatlvl.as<uint8_t>());
         if (blur_place == 2) { // no fork: the blur runs in the main stream between the quadtree and the descriptors
             hipStream_t keep = aux_stream;
@@ -610,13 +612,13 @@ int orbfe_extract_batch(orbfe_extractor* h, const uint8_t* imgs, int nframes, si
         ORBFE_HIP(hipMemcpy2DAsync((uint8_t*)h->d_in.p + f * dframe, dpitch, imgs + f * frame_stride, step, cols, rows,
                                    hipMemcpyHostToDevice, s));
     rc = h->run_device(h->d_in.as<uint8_t>(), nframes, dframe, rows, cols, dpitch, h->d_kps.as<orbfe_keypoint>(),
-                       h->d_desc.as<uint8_t>(), cap, h->d_nout.as<int32_t>(), s);
+                       h->d_desc.as<uint8_t>(), cap, h->d_nout.as<int32_t>(), s, /*flag_word*/ 1);
     if (rc) return rc;
     ORBFE_HIP(hipMemcpyAsync(n_out, h->d_nout.p, (size_t)nframes * 4, hipMemcpyDeviceToHost, s));
     ORBFE_HIP(hipStreamSynchronize(s));
     int32_t ovf = 0;
-    ORBFE_HIP(hipMemcpy(&ovf, h->d_overflow.p, 4, hipMemcpyDeviceToHost));
-    if (ovf) ORBFE_HIP(hipMemset(h->d_overflow.p, 0, 4));
+    ORBFE_HIP(hipMemcpy(&ovf, h->d_overflow.as<int32_t>() + 1, 4, hipMemcpyDeviceToHost));
+    if (ovf) ORBFE_HIP(hipMemset(h->d_overflow.as<int32_t>() + 1, 0, 4));
     if (ovf) return fail(ORBFE_ERR_CAPACITY, "internal keypoint capacity exceeded (%d)", ovf);
     for (int f = 0; f < nframes; f++) {
         if (n_out[f] > capacity)
@@ -733,9 +735,10 @@ int orbfe_extractor_debug_kernel_times(orbfe_extractor* h, float* out_us, int ca
         else if (capacity == 3) h->force_general_quadtree = false;
         else if (capacity >= 10 && capacity <= 16) h->force_pyramid_depth = capacity - 10; // 10 = default depth
         else if (capacity >= 20 && capacity <= 22) h->blur_place = capacity - 20;
-        else h->timer.enabled = capacity != 0;
+        else { h->timer.enabled = capacity != 0; h->timer.reset_history(); }
         return 0;
     }
+    if (capacity < 0) return h->timer.collect_median(out_us, -capacity, nullptr);
     return h->timer.collect(out_us, capacity);
 }
 

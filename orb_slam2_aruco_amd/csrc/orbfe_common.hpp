@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -97,15 +98,42 @@ template <class W> class ThreadWorkspaces {
     std::vector<Slot> slots;
 
 public:
-    // workspace of (this thread, the current device, stream); the caller has selected the device already
+    // workspace of (this thread, the current device, stream); the caller has selected the device already.  Slots are kept in
+    // most-recently-used order and capped: a thread that keeps creating streams does not grow scratch without bound (the least
+    // recently used slot is freed -- hipFree waits for the device, so work still in flight on that stream is safe), and a
+    // destroyed stream whose address is recycled should be dropped with release() so that it does not inherit stale state.
+    static constexpr size_t MAX_SLOTS = 16;
     W& get(hipStream_t stream = nullptr)
     {
         int dev = 0;
         (void)hipGetDevice(&dev);
-        for (auto& s : slots)
-            if (s.device == dev && s.stream == stream) return *s.w;
+        for (size_t i = 0; i < slots.size(); i++)
+            if (slots[i].device == dev && slots[i].stream == stream) {
+                if (i + 1 != slots.size()) std::rotate(slots.begin() + (long)i, slots.begin() + (long)i + 1, slots.end());
+                return *slots.back().w;
+            }
+        if (slots.size() >= MAX_SLOTS) {
+            int cur = dev;
+            (void)hipSetDevice(slots.front().device);
+            delete slots.front().w;
+            (void)hipSetDevice(cur);
+            slots.erase(slots.begin());
+        }
         slots.push_back(Slot{dev, stream, new W()});
         return *slots.back().w;
+    }
+    // drop the workspace of (this thread, the current device, stream), if any; returns whether there was one
+    bool release(hipStream_t stream)
+    {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        for (size_t i = 0; i < slots.size(); i++)
+            if (slots[i].device == dev && slots[i].stream == stream) {
+                delete slots[i].w;
+                slots.erase(slots.begin() + (long)i);
+                return true;
+            }
+        return false;
     }
     ~ThreadWorkspaces()
     {
@@ -121,44 +149,100 @@ public:
 
 // Event timing of individual launches (profiling aid; no events are recorded unless enabled).  A mark closes the
 // interval that the previous mark ON THE SAME STREAM opened; `opens_only` marks (the first one of a stream) report nothing.
+// The last HISTORY batches keep their own event sets, so a caller that times K batches without synchronising in between
+// can ask for the per-interval MEDIAN over them afterwards (bench.py: one step's events are not the steady state).
 struct KernelTimer {
+    static constexpr int HISTORY = 64;
+    struct Set {
+        std::vector<hipEvent_t> ev;
+        std::vector<hipStream_t> streams;
+        std::vector<char> opens;
+        size_t used = 0;
+    };
     bool enabled = false;
-    std::vector<hipEvent_t> ev;
-    std::vector<hipStream_t> streams;
-    std::vector<char> opens;
-    size_t used = 0;
-    void begin() { used = 0; streams.clear(); opens.clear(); }
+    Set sets[HISTORY];
+    int cur = 0;
+    long batches = 0; // begin() calls while enabled
+    void begin()
+    {
+        if (!enabled) return;
+        cur = (int)(batches++ % HISTORY);
+        Set& t = sets[cur];
+        t.used = 0;
+        t.streams.clear();
+        t.opens.clear();
+    }
+    void reset_history()
+    {
+        batches = 0;
+        for (auto& t : sets) t.used = 0;
+    }
     void mark(hipStream_t s, const char* /*name: documentation at the call site*/, bool opens_only = false)
     {
         if (!enabled) return;
-        if (used == ev.size()) {
+        Set& t = sets[cur];
+        if (t.used == t.ev.size()) {
             hipEvent_t e;
             (void)hipEventCreate(&e);
-            ev.push_back(e);
+            t.ev.push_back(e);
         }
-        (void)hipEventRecord(ev[used++], s);
-        streams.push_back(s);
-        opens.push_back(opens_only || streams.size() == 1);
+        (void)hipEventRecord(t.ev[t.used++], s);
+        t.streams.push_back(s);
+        t.opens.push_back(opens_only || t.streams.size() == 1);
     }
-    int collect(float* out_us, int capacity)
+    static int collect_set(Set& t, float* out_us, int capacity)
     {
-        if (!enabled || used < 2) return 0;
-        for (size_t i = 0; i < used; i++) (void)hipEventSynchronize(ev[i]);
+        if (t.used < 2) return 0;
+        for (size_t i = 0; i < t.used; i++) (void)hipEventSynchronize(t.ev[i]);
         int n = 0;
-        for (size_t i = 1; i < used && n < capacity; i++) {
-            if (opens[i]) continue;
+        for (size_t i = 1; i < t.used && n < capacity; i++) {
+            if (t.opens[i]) continue;
             size_t j = i;
             while (j-- > 0)
-                if (streams[j] == streams[i]) break;
+                if (t.streams[j] == t.streams[i]) break;
             float ms = 0;
-            if (j < i) (void)hipEventElapsedTime(&ms, ev[j], ev[i]);
+            if (j < i) (void)hipEventElapsedTime(&ms, t.ev[j], t.ev[i]);
             out_us[n++] = ms * 1000.f;
         }
         return n;
     }
+    // intervals of the most recent batch
+    int collect(float* out_us, int capacity)
+    {
+        if (!enabled) return 0;
+        return collect_set(sets[cur], out_us, capacity);
+    }
+    // per-interval median over the recorded batches (at most HISTORY, the newest ones); *nbatches = how many went in
+    int collect_median(float* out_us, int capacity, int* nbatches)
+    {
+        if (nbatches) *nbatches = 0;
+        if (!enabled || capacity <= 0) return 0;
+        std::vector<std::vector<float>> cols;
+        std::vector<float> row((size_t)capacity);
+        int n0 = -1, nb = 0;
+        const long have = batches < HISTORY ? batches : HISTORY;
+        for (long k = 0; k < have; k++) {
+            const int n = collect_set(sets[k], row.data(), capacity);
+            if (n <= 0) continue;
+            if (n0 < 0) { n0 = n; cols.assign((size_t)n, {}); }
+            if (n != n0) continue; // a batch that took another launch path (fallback kernels) is not mixed in
+            for (int i = 0; i < n; i++) cols[(size_t)i].push_back(row[(size_t)i]);
+            nb++;
+        }
+        if (n0 < 0) return 0;
+        for (int i = 0; i < n0; i++) {
+            auto& c = cols[(size_t)i];
+            std::sort(c.begin(), c.end());
+            const size_t m = c.size();
+            out_us[i] = (m & 1) ? c[m / 2] : 0.5f * (c[m / 2 - 1] + c[m / 2]);
+        }
+        if (nbatches) *nbatches = nb;
+        return n0;
+    }
     ~KernelTimer()
     {
-        for (auto e : ev) (void)hipEventDestroy(e);
+        for (auto& t : sets)
+            for (auto e : t.ev) (void)hipEventDestroy(e);
     }
 };
 

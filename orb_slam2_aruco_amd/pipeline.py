@@ -153,7 +153,12 @@ class FrontEndPipeline:
         self.det_done = [[ev() for _ in range(S)] for _ in range(2)]
         self.match_done = [ev() for _ in range(2)]
         self.gather_done = [ev() for _ in range(2)]
-        self.match_ev = [ev(enable_timing=True) for _ in range(3)]   # around the matching launches (their stream)
+        # around the matching launches (their stream); one event triple per step, the newest 64 steps kept for the median
+        self.match_evs = [[ev(enable_timing=True) for _ in range(3)] for _ in range(64)]
+        self.match_ev = self.match_evs[0]
+        self.match_steps = 0
+        self.gather_evs = [[ev(enable_timing=True) for _ in range(2)] for _ in range(64)]
+        self.gather_steps = 0
         self.comm_stream = torch.cuda.Stream(dev)
         self.gather = gather            # sharding.RecordGather or None (single GPU)
         self.step_no = 0
@@ -224,7 +229,11 @@ class FrontEndPipeline:
                         self.comm_stream.wait_event(self.ex_done[cur][k])
                     if self.use_aruco:
                         self.comm_stream.wait_event(self.det_done[cur][k])
+                ge = self.gather_evs[self.gather_steps % len(self.gather_evs)]
+                self.gather_steps += 1
+                ge[0].record(self.comm_stream)
                 self.gather(self.recs[cur])
+                ge[1].record(self.comm_stream)
                 self.gather_done[cur].record(self.comm_stream)
         return cur
 
@@ -233,7 +242,8 @@ class FrontEndPipeline:
         windowed pass."""
         L, lay, B, cap = self.L, self.layout, self.B, self.cap
         base = self.rec_ptr[cur]
-        e = self.match_ev
+        e = self.match_ev = self.match_evs[self.match_steps % len(self.match_evs)]
+        self.match_steps += 1
         e[0].record(self.stream3)
         binding._check(L, L.orbfe_knn2_batch_device(base + lay.desc, base + lay.n, cap * 32, cap,
                                                     base + lay.desc + cap * 32, base + lay.n + 4, cap * 32, cap,
@@ -303,6 +313,23 @@ class FrontEndPipeline:
         return {"best_idx": g(self.d_bidx), "best_dist": g(self.d_bdist), "second_dist": g(self.d_sdist),
                 "matches12": g(self.d_m12), "nmatches": g(self.d_nm)}
 
-    def matching_times_us(self):
-        e = self.match_ev
-        return e[0].elapsed_time(e[1]) * 1000.0, e[1].elapsed_time(e[2]) * 1000.0
+    def reset_timing_history(self):
+        self.match_steps = 0
+        self.gather_steps = 0
+
+    def matching_times_us(self, median=False):
+        """(knn2, SearchForInitialization) launch times of the newest step, or their medians over the steps since
+        reset_timing_history() (the newest 64); after synchronize()."""
+        if not median:
+            e = self.match_ev
+            return e[0].elapsed_time(e[1]) * 1000.0, e[1].elapsed_time(e[2]) * 1000.0
+        n = min(self.match_steps, len(self.match_evs))
+        t = np.array([[e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2])] for e in self.match_evs[:n]]) * 1000.0
+        return float(np.median(t[:, 0])), float(np.median(t[:, 1]))
+
+    def gather_times_us(self):
+        """Median duration of the batch gather on the communication stream over the steps since reset_timing_history()."""
+        n = min(self.gather_steps, len(self.gather_evs))
+        if n == 0:
+            return None
+        return float(np.median([e[0].elapsed_time(e[1]) for e in self.gather_evs[:n]]) * 1000.0)

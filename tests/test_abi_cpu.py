@@ -52,3 +52,33 @@ def test_product_sources_never_touch_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "oracle_" not in txt and "liborbfe_oracle" not in txt and "oracle/" not in txt, f
+
+
+def test_host_scalar_helpers_need_no_device():
+    """orbfe_hamming / orbfe_three_maxima / orbfe_epipolar_distance_ok are plain host functions (the reference's static and
+    protected ORBmatcher helpers, ORBmatcher.cc:1651-1667, :1605-1646, :139-157): checked against the oracle's restatement and
+    known answers here, without a GPU."""
+    import numpy as np
+    import oracle_lib
+    from orb_slam2_aruco_amd import binding
+    L = ctypes.CDLL(binding.LIB_PATH)
+    O = oracle_lib.lib()
+    vp = ctypes.c_void_p
+    L.orbfe_three_maxima.argtypes = [vp, ctypes.c_int, vp]; L.orbfe_three_maxima.restype = None
+    L.orbfe_epipolar_distance_ok.argtypes = [ctypes.c_float] * 4 + [vp, ctypes.c_float]
+    rng = np.random.default_rng(3)
+    for trial in range(400):
+        kind = trial % 4
+        h = (rng.integers(0, 4, 30) if kind == 0 else rng.integers(0, 200, 30) if kind == 1 else
+             rng.integers(0, 2, 30) * rng.integers(0, 50, 30) if kind == 2 else np.zeros(30, np.int64)).astype(np.int32)
+        if kind == 1 and trial % 8 == 1:
+            h[5] = h[17] = h[29] = 150         # ties: the earliest bin wins
+        got, want = np.zeros(3, np.int32), np.full(3, -1, np.int32)
+        L.orbfe_three_maxima(h.ctypes.data_as(vp), 30, got.ctypes.data_as(vp))
+        O.oracle_three_maxima(h.ctypes.data_as(vp), 30, want.ctypes.data_as(vp))
+        assert got.tolist() == want.tolist(), (h, got, want)
+    # epipolar band: F12 of a pure x translation -> epipolar lines are the rows y2 = y1; 3.84 * sigma2 is the gate on dy^2
+    F = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32)
+    ok = lambda y2, s2: L.orbfe_epipolar_distance_ok(10.0, 20.0, 55.0, y2, F.ctypes.data_as(vp), s2)
+    assert ok(20.0, 1.0) == 1 and ok(21.9, 1.0) == 1 and ok(22.0, 1.0) == 0 and ok(23.0, 1.44) == 0 and ok(22.3, 1.44) == 1
+    assert L.orbfe_epipolar_distance_ok(1.0, 2.0, 3.0, 4.0, np.zeros(9, np.float32).ctypes.data_as(vp), 1.0) == 0   # den == 0

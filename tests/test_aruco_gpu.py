@@ -340,12 +340,18 @@ def test_corner_none_modes_and_contours(orbfe, oracle):
             assert np.any(np.all(c == got["corners"][i, k].astype(np.int32), axis=1))
         step = np.abs(np.diff(np.vstack([c, c[:1]]), axis=0)).max(axis=1)
         assert step.max() == 1 and step.min() == 1
+    allc = det.contours(len(got))                              # the one-round-trip variant the MarkerDetector shim uses
+    assert len(allc) == len(got) and all(np.array_equal(a, det.contour(i)) for i, a in enumerate(allc))
+    assert det.contours(0) == []
     with pytest.raises(orbfe.OrbfeError):
         det.contour(len(got))
+    with pytest.raises(orbfe.OrbfeError):
+        det.contours(len(got) + 1)
     det.setCornerRefinementMethod(det.CORNER_LINES)
     assert np.array_equal(det.detect(img)["corners"], lines["corners"])
     det.setDetectionMode(det.DM_NORMAL)
     for bad in (lambda: det.setDetectionMode(det.DM_FAST), lambda: det.setDetectionMode(det.DM_VIDEO_FAST, 0.1),
+                lambda: det.setDetectionMode(det.DM_NORMAL, 0.05),        # Params::minSize: not built, refused (never ignored)
                 lambda: det.setCornerRefinementMethod(det.CORNER_SUBPIX), lambda: det.setDictionary("ARUCO", 1.5)):
         with pytest.raises(orbfe.OrbfeError):
             bad()

@@ -55,6 +55,19 @@ def test_knn2_large_property(orbfe):
     assert np.array_equal(sd[idx], x.min(1))
 
 
+def test_knn2_c5_oracle_sample_both_kernels(orbfe, oracle):
+    """bench.py's C5 matching leg (10k x 10k, seed 5, resident): 192 queries of the full-size problem against the oracle, for the
+    VALU kernel and the matrix-core kernel, plus the self-match property over all 10^4 queries -- so the driver's GPU test
+    record holds an oracle check of the full-size configuration, not only `bench.py --config C5`."""
+    import sys, os
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    res = bench.c5_match_leg(orbfe, torch, torch.device("cuda", 0), oracle)
+    assert res["verified_queries"] == 192 and res["pairs"] == 10**8
+    assert res["valu"]["launch_us"] > 0 and res["mfma_i8"]["launch_us"] > 0
+
+
 def _frame_pair(orbfe, seed):
     s = synth.stream(480, 640, 2, seed)
     ex = orbfe.ORBextractor(1000, 1.2, 8, 20, 7)

@@ -62,3 +62,50 @@ def test_bench_two_ranks_on_one_gpu_gather_is_verified(tmp_path):
     d = json.loads(out.read_text())
     assert d["n_gpus"] == 2 and d["gather_check"]["ranks"] == [0, 1] and d["value"] > 0
     assert d["verified_frames"]["frames"] == [0, 8, 15]
+
+
+def _free_port():
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    return port
+
+
+@pytest.mark.gpu
+def test_bench_rccl_gather_branch_world_size_1(tmp_path):
+    """The RCCL branch of bench.py / FrontEndPipeline on the hardware that is there: `--gpus 1 --force-gather` initialises the
+    nccl (= RCCL) process group with world size 1 and runs the batch's gather on the DEVICE record buffer, on the communication
+    stream, with the gather_done waits of the double-buffered record sets -- the code path N > 1 takes, minus the peers.
+    gather_check compares the gathered block with the records byte for byte."""
+    import json
+    out = tmp_path / "bg.json"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "ORBFE_BENCH_BACKEND", "ORBFE_BENCH_DEVICE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-gather", "--frames", "24", "--steps", "6",
+                        "--warmup", "2", "--cpu-frames", "0", "--out", str(out)], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = json.loads(out.read_text())
+    assert d["n_gpus"] == 1 and d["gather_check"]["ranks"] == [0] and d["value"] > 0 and d["gather_us"] > 0
+    assert "RCCL gather" in d["config"]["parallelism"]
+    assert d["verified_frames"]["frames"] == [0, 12, 23]
+
+
+@pytest.mark.gpu
+def test_bench_c4_eight_ranks_on_one_gpu(tmp_path):
+    """BASELINE configs[3] (C4: 8 independent 1280x720 / nFeatures 2000 / ARUCO_MIP_25h7 streams, one per rank, seeds 1000 + 2000 r) as far
+    as a one-GPU box can run it: 8 ranks pinned to device 0, gloo instead of RCCL, 8 frames per step.  Rank 0 receives 8 blocks and
+    recomputes every rank's stream (gather_check.ranks == [0..7])."""
+    import json
+    from orb_slam2_aruco_amd import sharding
+    assert [sharding.stream_seed(r) for r in range(8)] == [1000 + 2000 * r for r in range(8)]
+    out = tmp_path / "c4.json"
+    env = dict(os.environ, ORBFE_BENCH_DEVICE="0", ORBFE_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--config", "C4", "--frames", "8",
+                        "--steps", "3", "--warmup", "1", "--cpu-frames", "0", "--out", str(out)],
+                       capture_output=True, text=True, timeout=1800, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = json.loads(out.read_text())
+    assert d["n_gpus"] == 8 and d["gather_check"]["ranks"] == list(range(8)) and d["gather_check"]["frames_per_rank"] == 8
+    assert d["config"]["workload"].startswith("C4 at 8 frames per step: 8-frame 1280x720") and "ARUCO_MIP_25h7" in d["config"]["workload"]
+    assert d["value"] > 0 and d["verified_frames"]["frames"] == [0, 4, 7]

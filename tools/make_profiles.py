@@ -55,6 +55,14 @@ traffic = {"_note": "HBM-side bytes per launch (%s batch) = (FETCH_SIZE / f_read
 pmc = {"_note": "per bench stage: valu_us = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz), the time the stage's launches need if they "
                 "only issued VALU instructions; lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) of the stage's "
                 "largest kernel; instruction counts are properties of kernel + input, not of the run (profiles/%s_pmc_summary.json)" % tag}
+# provenance: bench.py copies these into roofline.counters_from (the counters are not re-measured in a bench run)
+import hashlib
+lib = os.path.join(root, "orb_slam2_aruco_amd", "liborbfe.so")
+commit_file = os.path.join(root, "build", "COMMIT")       # written by tools/gpu.sh before the snapshot leaves (no .git on the GPU box)
+ident = {"_profile": tag, "_commit": open(commit_file).read().strip() if os.path.exists(commit_file) else None,
+         "_library_sha16": hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16] if os.path.exists(lib) else None}
+traffic.update(ident, _file="profiles/traffic_%s.json" % config)
+pmc.update(ident, _file="profiles/pmc_stage_%s.json" % config)
 for st, ks in stage.items():
     ks = [k for k in ks if k in s]
     if not ks:
@@ -67,5 +75,5 @@ for st, ks in stage.items():
                "valu_per_wave": g("SQ_INSTS_VALU") / max(g("SQ_WAVES"), 1), "kernels": ks}
 json.dump(traffic, open(os.path.join(root, "profiles", "traffic_%s.json" % config), "w"), indent=1)
 json.dump(pmc, open(os.path.join(root, "profiles", "pmc_stage_%s.json" % config), "w"), indent=1)
-print({k: v for k, v in traffic.items() if k != "_note"})
-print({k: round(v["valu_us"], 1) for k, v in pmc.items() if k != "_note"})
+print({k: v for k, v in traffic.items() if not k.startswith("_")})
+print({k: round(v["valu_us"], 1) for k, v in pmc.items() if not k.startswith("_")})
