@@ -342,11 +342,12 @@ int orbfe_search_for_initialization_batch_device(const orbfe_keypoint* d_kps, co
                                                  const int32_t* d_n, int capacity, int npairs, int cols, int rows, const float* bounds,
                                                  int window_size, float nnratio, int check_orientation,
                                                  int32_t* d_matches12, int32_t* d_nmatches, void* stream);
-/* The batch entry point cannot return a capacity error either (the host-pointer one retries by itself): a frame with more
- * level-0 keypoints than the candidate rows were sized for is truncated.  After a batch issued by THIS thread on `stream`
- * (synchronises the stream): *overflow = 0, or the level-0 keypoint count that did not fit -- the batch's matches are then
- * incomplete; the per-stream scratch has been grown, so repeating the batch call succeeds.  More than 1024 level-0
- * keypoints in a frame: ORBFE_ERR_CAPACITY.  The flag covers every batch since it was last read (reading clears it). */
+/* The batch entry point cannot return a capacity error either (the host-pointer one retries by itself): the candidate rows of a
+ * frame pair live in one pool, and a pair that needs more entries than the pool holds loses rows.  After a batch issued by THIS
+ * thread on `stream` (synchronises the stream): *overflow = 0, or the number of pool entries the fullest pair needed -- the batch's
+ * matches are then incomplete; the per-stream pool has been grown, so repeating the batch call succeeds.  More than 1024 level-0
+ * keypoints in a frame: ORBFE_ERR_CAPACITY (*overflow = that count).  The flag covers every batch since it was last read (reading
+ * clears it). */
 int orbfe_search_for_initialization_batch_status(void* stream, int32_t* overflow);
 
 /* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:270-333; called after every new observation by Tracking,

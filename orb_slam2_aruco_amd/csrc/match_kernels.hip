@@ -2,8 +2,9 @@
 //
 //   k_knn2_tiles / k_knn2_merge    all-pairs best / second-best Hamming with the reference update rule
 //                                  (inner loop of every ORBmatcher::SearchBy*)
-//   k_search_init                  ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:409-524) incl. the Frame
-//                                  grid (src/Frame.cc:183-198, 280-345), one workgroup per frame pair
+//   k_sfi_grid / _rows / _accept   ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:409-524) incl. the Frame
+//                                  grid (src/Frame.cc:183-198, 280-345): a sort per frame, a wave per query for the candidate
+//                                  rows, one wave per frame pair for the coupled accept loop
 //
 // Bound: integer VALU issue (XOR + v_bcnt_u32_b32), not HBM: 1000 x 1000 descriptors are 64 KB of traffic for
 // 16 M lane-ops.  Train descriptors are staged through LDS and broadcast to all lanes of a wave.
@@ -252,209 +253,236 @@ __global__ void k_knn2_merge(const int32_t* __restrict__ pidx, const int32_t* __
 //   second-best with the "already matched better" skip, ratio + TH_LOW tests, mutual-uniqueness bookkeeping,
 //   rotation histogram, ComputeThreeMaxima, final vbPrevMatched update.
 #define SFI_MAXL0 1024
-#define SFI_THREADS 1024
-#define SFI_ROW 64       // candidates of a query that live in LDS; later ones go to the query's global row
-#define SFI_L0_LDS 256   // level-0 keypoints of F2 (by rank) whose position and descriptor are cached in LDS
-#define SFI_ROWQ 224     // queries whose first SFI_ROW candidates live in LDS
-// dynamic LDS: F2 positions, F2 descriptors, per-query candidate counts, candidate rows (rank u16, distance u8)
-inline size_t sfi_lds_bytes() { return (size_t)SFI_L0_LDS * 8 + (size_t)SFI_L0_LDS * 32 + SFI_MAXL0 * 2 + (size_t)SFI_ROWQ * SFI_ROW * 3; }
+// Three launches (round 3; before: one 1024-thread workgroup + 55 KB of LDS per frame pair, fifteen of its sixteen waves parked
+// while one wave ran the serial loop -- 146 us alone, 640 us next to the other engines' kernels):
+//   k_sfi_grid    workgroup per FRAME: what a frame contributes in either role.  As F2: its level-0 keypoints inside the Frame
+//                 grid sorted by (grid column, grid row, index) -- the order in which GetFeaturesInArea walks the 64 x 48 grid
+//                 (Frame.cc:183-198, :280-345) -- with position, angle and descriptor laid out by rank; as F1: its level-0
+//                 keypoints in index order (the queries).  A frame of a batch is F2 of one pair and F1 of the next.
+//   k_sfi_rows    wave per query, all pairs of the batch in one grid (a throughput kernel): window test against F2's sorted
+//                 list, Hamming distance of every candidate, one contiguous row (distance << 16 | rank, candidate order) per
+//                 query in the pair's pool; rows are placed by an atomic cursor, so a pool is dense and any order.
+//   k_sfi_accept  ONE WAVE per pair (64-thread workgroups): the reference's serial loop -- the "already matched better" skip and
+//                 the mutual-uniqueness bookkeeping couple the queries (ORBmatcher.cc:448-449, :467-475) -- out of LDS, then the
+//                 rotation histogram, ComputeThreeMaxima and the vbPrevMatched update.
+struct SfiGrid { // [frame][SFI_MAXL0] arrays in HBM, written by k_sfi_grid
+    int32_t* nl0;     // [frames] level-0 keypoints inside the grid (role F2), clamped to SFI_MAXL0
+    int32_t* nq;      // [frames] level-0 keypoints (role F1), clamped to SFI_MAXL0
+    uint32_t* sorted; // (cell << 16) | index, ascending
+    float2* xy;       // by rank
+    float* ang;       // by rank
+    uint4* desc;      // by rank, two per keypoint
+    uint16_t* query;  // by query position: keypoint index
+    int32_t* cursor;  // [pairs] next free pool entry (zeroed here, advanced by k_sfi_rows)
+};
+#define SFI_GRID_THREADS 256
+#define SFI_ROWS_BX 16         // workgroups per pair in k_sfi_rows (4 waves each)
+#define SFI_POOL_LDS 6144      // pool entries k_sfi_accept stages in LDS (24 KB); later ones are read from the pool in HBM
+#define SFI_ROW_BITS 11        // row record = offset << 11 | count (count <= SFI_MAXL0 = 1024)
 
-__global__ __launch_bounds__(SFI_THREADS) void k_search_init(const orbfe_keypoint* __restrict__ kps,
-                                                     const uint8_t* __restrict__ desc, const int32_t* __restrict__ nkp,
-                                                     int capacity, float4 bnd, float window, float nnratio,
-                                                     int check_ori, const float* __restrict__ prev_in,
-                                                     float* __restrict__ prev_out, int32_t* __restrict__ matches12,
-                                                     int32_t* __restrict__ nmatches_out, int32_t* __restrict__ csr_cnt,
-                                                     uint16_t* __restrict__ csr_idx, uint8_t* __restrict__ csr_dist,
-                                                     int row_stride, int32_t* __restrict__ scratch /*3*capacity per pair*/,
-                                                     int32_t* __restrict__ overflow)
+__global__ __launch_bounds__(SFI_GRID_THREADS) void k_sfi_grid(const orbfe_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc,
+                                                               const int32_t* __restrict__ nkp, int capacity, int nframes, float4 bnd,
+                                                               SfiGrid G, int32_t* __restrict__ overflow)
 {
-    __builtin_amdgcn_s_setprio(2); // latency-bound: its few waves go first when a VALU-bound kernel shares the CU
-    extern __shared__ __align__(16) unsigned char sfi_smem[];
-    __shared__ uint32_t s_sorted[SFI_MAXL0]; // (cell << 16) | index, ascending
-    __shared__ int s_hist[30];
-    __shared__ int s_nl0, s_nq;
-    __shared__ uint16_t s_query[SFI_MAXL0];  // level-0 keypoints of F1 in index order (the only ones that search)
-    __shared__ uint32_t s_state[SFI_MAXL0];  // vMatchedDistance << 16 | (position of the query in vnMatches21 + 1), indexed by the RANK of
-                                             //   an F2 keypoint in s_sorted (only level-0 keypoints of F2 can ever be matched)
-    __shared__ float s_ang1[SFI_MAXL0], s_ang2[SFI_MAXL0];
-    __shared__ signed char s_rotbin[SFI_MAXL0]; // per query: histogram bin or -1
-    float2* s2xy = (float2*)sfi_smem;
-    uint4* s2d = (uint4*)(s2xy + SFI_L0_LDS);
-    uint16_t* s_cnt = (uint16_t*)(s2d + 2 * SFI_L0_LDS);
-    uint16_t* s_ridx = s_cnt + SFI_MAXL0;
-    uint8_t* s_rdist = (uint8_t*)(s_ridx + SFI_ROWQ * SFI_ROW);
-
-    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const orbfe_keypoint* k1 = kps + (size_t)p * capacity;
-    const orbfe_keypoint* k2 = kps + (size_t)(p + 1) * capacity;
-    const uint8_t* d1 = desc + (size_t)p * capacity * 32;
-    const uint8_t* d2 = desc + (size_t)(p + 1) * capacity * 32;
-    const int n1 = nkp[p], n2 = nkp[p + 1];
-    int32_t* m12 = matches12 + (size_t)p * capacity;
-    uint16_t* cidx = csr_idx + (size_t)p * capacity * row_stride;
-    uint8_t* cdist = csr_dist + (size_t)p * capacity * row_stride;
-    const float* prev = prev_in ? prev_in + (size_t)p * capacity * 2 : nullptr;
-    float* prevo = prev_out ? prev_out + (size_t)p * capacity * 2 : nullptr;
-    (void)csr_cnt;
-
+    __shared__ __align__(16) uint32_t s_key[SFI_MAXL0 + 4];
+    __shared__ int s_nl0;
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const orbfe_keypoint* k = kps + (size_t)f * capacity;
+    const uint8_t* d = desc + (size_t)f * capacity * 32;
+    const int n = nkp[f];
     // bounds of the undistorted image (Frame::ComputeImageBounds; 0, 0, cols, rows without distortion) and Frame.cc:112-113
     const float mnMinX = bnd.x, mnMinY = bnd.y;
     const float invW = __fdiv_rn((float)GRID_COLS, bnd.z - bnd.x);
     const float invH = __fdiv_rn((float)GRID_ROWS, bnd.w - bnd.y);
-
-    // ---- phase A: level-0 keypoints of F2 that fall inside the grid (Frame.cc:183-198, :335-345), sorted;
-    // level-0 keypoints of F1 (the queries) in index order
-    if (tid == 0) { s_nl0 = 0; s_nq = 0; }
+    if (tid == 0) { s_nl0 = 0; if (f < nframes - 1) G.cursor[f] = 0; }
     __syncthreads();
-    for (int i = tid; i < n2; i += SFI_THREADS) {
-        const orbfe_keypoint kp = k2[i];
+    // role F2: level-0 keypoints that fall inside the grid (Frame.cc:183-198, :335-345)
+    for (int i = tid; i < n; i += SFI_GRID_THREADS) {
+        const orbfe_keypoint kp = k[i];
         if (kp.octave != 0) continue;
         const int px = (int)roundf(__fmul_rn(kp.x - mnMinX, invW));
         const int py = (int)roundf(__fmul_rn(kp.y - mnMinY, invH));
         if (px >= 0 && px < GRID_COLS && py >= 0 && py < GRID_ROWS) {
-            const int k = atomicAdd(&s_nl0, 1);
-            if (k < SFI_MAXL0) s_sorted[k] = ((uint32_t)(px * GRID_ROWS + py) << 16) | (uint32_t)i;
+            const int e = atomicAdd(&s_nl0, 1);
+            if (e < SFI_MAXL0) s_key[e] = ((uint32_t)(px * GRID_ROWS + py) << 16) | (uint32_t)i;
         }
     }
+    // role F1: level-0 keypoints in index order (ORBmatcher.cc:425-428), wave 0 by ballots
     if (wid == 0) {
         int nq = 0;
-        for (int i0 = 0; i0 < n1; i0 += 64) {
+        uint16_t* qo = G.query + (size_t)f * SFI_MAXL0;
+        for (int i0 = 0; i0 < n; i0 += 64) {
             const int i = i0 + lane;
-            const bool isq = i < n1 && k1[i].octave <= 0;
+            const bool isq = i < n && k[i].octave <= 0;
             const unsigned long long m = __ballot(isq);
             const int pos = nq + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-            if (isq && pos < SFI_MAXL0) { s_query[pos] = (uint16_t)i; s_ang1[pos] = k1[i].angle; }
+            if (isq && pos < SFI_MAXL0) qo[pos] = (uint16_t)i;
             nq += __popcll(m);
         }
         if (lane == 0) {
             if (nq > SFI_MAXL0) { atomicMax(overflow, nq); nq = SFI_MAXL0; }
-            s_nq = nq;
+            G.nq[f] = nq;
         }
     }
     __syncthreads();
-    if (tid == 0 && s_nl0 > SFI_MAXL0) { atomicMax(overflow, s_nl0); s_nl0 = SFI_MAXL0; }
+    int nl0 = s_nl0;
+    if (nl0 > SFI_MAXL0) { if (tid == 0) atomicMax(overflow, nl0); nl0 = SFI_MAXL0; }
+    if (tid == 0) G.nl0[f] = nl0;
+    if (tid < 4) s_key[nl0 + tid] = 0xffffffffu; // the counting loop reads whole uint4s
     __syncthreads();
-    const int nl0 = s_nl0, nq = s_nq;
-    {
-        // sort by counting: the keys are distinct (the index is part of them), so an entry's place is the number of smaller keys --
-        // one pass of broadcast LDS reads and two barriers instead of the 36+ barrier stages of a bitonic network
-        uint32_t key = 0xffffffffu;
+    // sort by counting: the keys are distinct (the index is part of them), so an entry's rank is the number of smaller keys --
+    // broadcast LDS reads, no barrier; the rank-ordered record goes straight to HBM
+    const uint4* k4 = reinterpret_cast<const uint4*>(s_key);
+    for (int e = tid; e < nl0; e += SFI_GRID_THREADS) {
+        const uint32_t key = s_key[e];
         int r = 0;
-        if (tid < nl0) {
-            key = s_sorted[tid];
-            for (int k = 0; k < nl0; k++) r += s_sorted[k] < key;
-            s_state[r] = key;
+        for (int j = 0; j < (nl0 + 3) / 4; j++) {
+            const uint4 v = k4[j];
+            r += (v.x < key) + (v.y < key) + (v.z < key) + (v.w < key);
         }
-        __syncthreads();
-        if (tid < nl0) s_sorted[tid] = s_state[tid];
-        __syncthreads();
+        const int i2 = key & 0xffff;
+        const orbfe_keypoint kp = k[i2];
+        const size_t o = (size_t)f * SFI_MAXL0 + r;
+        G.sorted[o] = key;
+        G.xy[o] = make_float2(kp.x, kp.y);
+        G.ang[o] = kp.angle;
+        G.desc[2 * o] = reinterpret_cast<const uint4*>(d)[2 * i2];
+        G.desc[2 * o + 1] = reinterpret_cast<const uint4*>(d)[2 * i2 + 1];
     }
-    if (nl0 > row_stride && tid == 0) atomicMax(overflow, nl0);
-    // per-rank state of F2 in LDS: position + descriptor (first SFI_L0_LDS ranks), matching state (all ranks)
-    for (int i = tid; i < nl0; i += SFI_THREADS) {
-        const int i2 = s_sorted[i] & 0xffff;
-        const orbfe_keypoint kp2 = k2[i2];
-        s_state[i] = 0xffff0000u; s_ang2[i] = kp2.angle;
-        if (i < SFI_L0_LDS) {
-            s2xy[i] = make_float2(kp2.x, kp2.y);
-            s2d[2 * i] = reinterpret_cast<const uint4*>(d2)[2 * i2];
-            s2d[2 * i + 1] = reinterpret_cast<const uint4*>(d2)[2 * i2 + 1];
-        }
-    }
-    for (int i = tid; i < SFI_MAXL0; i += SFI_THREADS) s_rotbin[i] = -1;
-    for (int i = tid; i < n1; i += SFI_THREADS) m12[i] = -1;
-    if (tid < 30) s_hist[tid] = 0;
-    __syncthreads();
+}
 
-    // ---- phase B: candidate lists (Frame.cc:280-333) + distances, one wave per query.  The first SFI_ROW candidates
-    // of the first SFI_ROWQ queries stay in LDS, the rest goes to the query's global row.
-    for (int q = wid; q < nq; q += SFI_THREADS / 64) {
-        const int i1 = s_query[q];
-        int count = 0;
-        const orbfe_keypoint kp1 = k1[i1];
-        const float x = prev ? prev[2 * i1] : kp1.x, y = prev ? prev[2 * i1 + 1] : kp1.y;
-        const float r = window;
+__global__ __launch_bounds__(256) void k_sfi_rows(const orbfe_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc, int capacity,
+                                                  float4 bnd, float window, const float* __restrict__ prev_in, SfiGrid G,
+                                                  uint32_t* __restrict__ pool, int pool_cap, uint32_t* __restrict__ rowrec,
+                                                  int32_t* __restrict__ overflow)
+{
+    __shared__ uint16_t s_cell[SFI_MAXL0];
+    __shared__ float2 s_xy[SFI_MAXL0];
+    const int p = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = wave_id();
+    const int nq = G.nq[p], nl0 = G.nl0[p + 1];
+    if ((int)blockIdx.x * 4 >= nq) return;
+    const size_t g2 = (size_t)(p + 1) * SFI_MAXL0;
+    for (int i = tid; i < nl0; i += 256) { s_cell[i] = (uint16_t)(G.sorted[g2 + i] >> 16); s_xy[i] = G.xy[g2 + i]; }
+    __syncthreads();
+    const orbfe_keypoint* k1 = kps + (size_t)p * capacity;
+    const uint8_t* d1 = desc + (size_t)p * capacity * 32;
+    const float* prev = prev_in ? prev_in + (size_t)p * capacity * 2 : nullptr;
+    const uint16_t* qi = G.query + (size_t)p * SFI_MAXL0;
+    uint32_t* pl = pool + (size_t)p * pool_cap;
+    const float mnMinX = bnd.x, mnMinY = bnd.y;
+    const float invW = __fdiv_rn((float)GRID_COLS, bnd.z - bnd.x);
+    const float invH = __fdiv_rn((float)GRID_ROWS, bnd.w - bnd.y);
+    const float r = window;
+    for (int q = blockIdx.x * 4 + wid; q < nq; q += SFI_ROWS_BX * 4) {
+        const int i1 = __builtin_amdgcn_readfirstlane((int)qi[q]);
+        const float x = prev ? prev[2 * i1] : k1[i1].x, y = prev ? prev[2 * i1 + 1] : k1[i1].y;
+        // Frame::GetFeaturesInArea (Frame.cc:280-333): the cell range of the window, then |dx| < r and |dy| < r
         const int nMinCellX = max(0, (int)floorf(__fmul_rn(x - mnMinX - r, invW)));
         const int nMaxCellX = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(x - mnMinX + r, invW)));
         const int nMinCellY = max(0, (int)floorf(__fmul_rn(y - mnMinY - r, invH)));
         const int nMaxCellY = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(y - mnMinY + r, invH)));
-        if (!(nMinCellX >= GRID_COLS || nMaxCellX < 0 || nMinCellY >= GRID_ROWS || nMaxCellY < 0)) {
-            const uint4 a0 = reinterpret_cast<const uint4*>(d1)[2 * i1];
-            const uint4 a1 = reinterpret_cast<const uint4*>(d1)[2 * i1 + 1];
-            uint16_t* ri = cidx + (size_t)i1 * row_stride;
-            uint8_t* rd = cdist + (size_t)i1 * row_stride;
-            for (int j0 = 0; j0 < nl0; j0 += 64) {
-                const int j = j0 + lane;
-                bool ok = false;
-                int i2 = 0;
-                if (j < nl0) {
-                    const uint32_t e = s_sorted[j];
-                    const int cell = e >> 16, cx = cell / GRID_ROWS, cy = cell - cx * GRID_ROWS;
-                    i2 = e & 0xffff;
-                    if (cx >= nMinCellX && cx <= nMaxCellX && cy >= nMinCellY && cy <= nMaxCellY) {
-                        float x2, y2;
-                        if (j < SFI_L0_LDS) { const float2 v = s2xy[j]; x2 = v.x; y2 = v.y; }
-                        else { x2 = k2[i2].x; y2 = k2[i2].y; }
-                        ok = fabsf(x2 - x) < r && fabsf(y2 - y) < r;
-                    }
-                }
-                const unsigned long long m = __ballot(ok);
-                if (ok) {
-                    const int pos = count + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
-                                                                     __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-                    if (pos < row_stride) {
-                        uint4 b0, b1;
-                        if (j < SFI_L0_LDS) { b0 = s2d[2 * j]; b1 = s2d[2 * j + 1]; }
-                        else { b0 = reinterpret_cast<const uint4*>(d2)[2 * i2]; b1 = reinterpret_cast<const uint4*>(d2)[2 * i2 + 1]; }
-                        const int d = hamming256(a0, a1, b0, b1);
-                        const uint8_t d8 = (uint8_t)(d > 255 ? 255 : d); // 256 only for exact complements; > TH_LOW anyway
-                        if (pos < SFI_ROW && q < SFI_ROWQ) { // rank in the sorted level-0 list (i2 = s_sorted[j] & 0xffff)
-                            s_ridx[q * SFI_ROW + pos] = (uint16_t)j;
-                            s_rdist[q * SFI_ROW + pos] = d8;
-                        } else {
-                            ri[pos] = (uint16_t)j;
-                            rd[pos] = d8;
-                        }
-                    }
-                }
-                count += __popcll(m);
+        const bool any = !(nMinCellX >= GRID_COLS || nMaxCellX < 0 || nMinCellY >= GRID_ROWS || nMaxCellY < 0);
+        auto inside = [&](int j) {
+            if (j >= nl0) return false;
+            const int cell = s_cell[j], cx = cell / GRID_ROWS, cy = cell - cx * GRID_ROWS;
+            if (cx < nMinCellX || cx > nMaxCellX || cy < nMinCellY || cy > nMaxCellY) return false;
+            const float2 v = s_xy[j];
+            return fabsf(v.x - x) < r && fabsf(v.y - y) < r;
+        };
+        int count = 0;
+        if (any)
+            for (int j0 = 0; j0 < nl0; j0 += 64) count += (int)__popcll(__ballot(inside(j0 + lane)));
+        int off = 0;
+        if (lane == 0 && count > 0) off = atomicAdd(&G.cursor[p], count);
+        off = __builtin_amdgcn_readfirstlane(off);
+        bool fits = true;
+        if (count > 0 && off + count > pool_cap) { // the pool is too small: flagged, the host grows it and the batch is repeated
+            if (lane == 0) atomicMax(overflow + 1, off + count);
+            fits = false;
+        }
+        if (lane == 0) rowrec[(size_t)p * SFI_MAXL0 + q] = fits ? ((uint32_t)off << SFI_ROW_BITS) | (uint32_t)count : 0u;
+        if (count == 0 || !fits) continue;
+        const uint4 a0 = reinterpret_cast<const uint4*>(d1)[2 * i1];
+        const uint4 a1 = reinterpret_cast<const uint4*>(d1)[2 * i1 + 1];
+        int done = 0;
+        for (int j0 = 0; j0 < nl0; j0 += 64) {
+            const int j = j0 + lane;
+            const bool ok = inside(j);
+            const unsigned long long m = __ballot(ok);
+            if (ok) {
+                const int pos = done + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                const int dd = hamming256(a0, a1, G.desc[2 * (g2 + j)], G.desc[2 * (g2 + j) + 1]);
+                // 256 only for exact complements; 255 is far above TH_LOW as well
+                pl[off + pos] = ((uint32_t)(dd > 255 ? 255 : dd) << 16) | (uint32_t)j;
             }
+            done += (int)__popcll(m);
         }
-        if (lane == 0) s_cnt[q] = (uint16_t)min(count, row_stride);
     }
-    __threadfence_block();
-    __syncthreads();
-    if (wid != 0) return;
+}
 
-    // ---- phase C: the serial matching loop (ORBmatcher.cc:423-490), wave 0.  All loop-carried state and (normally)
-    // all candidate rows are in LDS.  The loop carries only what couples the queries -- vMatchedDistance / vnMatches21 per F2
-    // keypoint and which query currently holds it; everything else (vnMatches12 in HBM, the rotation bins) is written by all
-    // lanes after the loop from two per-query records: the rank a query was accepted with (rotHist keeps it even if the match
-    // is stolen later, :470-488) and the rank it still holds.  The per-keypoint word holds query POSITIONS.
-    uint16_t* s_acc = reinterpret_cast<uint16_t*>(s_ang1);      // per query: rank accepted with, or NIL (s_ang1 is re-read from HBM below)
-    uint16_t* s_held = s_acc + SFI_MAXL0;                       // per query: rank still held, or NIL
+__global__ __launch_bounds__(64) void k_sfi_accept(const orbfe_keypoint* __restrict__ kps, const int32_t* __restrict__ nkp, int capacity,
+                                                   float nnratio, int check_ori, const float* __restrict__ prev_in,
+                                                   float* __restrict__ prev_out, int32_t* __restrict__ matches12,
+                                                   int32_t* __restrict__ nmatches_out, SfiGrid G, const uint32_t* __restrict__ pool,
+                                                   int pool_cap, const uint32_t* __restrict__ rowrec)
+{
+    __builtin_amdgcn_s_setprio(2); // latency-bound: one wave per pair goes first when a VALU-bound kernel shares the CU
+    __shared__ __align__(16) uint32_t s_pool[SFI_POOL_LDS];
+    __shared__ uint32_t s_state[SFI_MAXL0]; // vMatchedDistance << 16 | (position of the query in vnMatches21 + 1), indexed by the RANK
+                                            //   of an F2 keypoint (only level-0 keypoints of F2 inside the grid can ever be matched)
+    __shared__ uint32_t s_row[SFI_MAXL0];   // per query: pool offset << 11 | candidates
+    __shared__ uint16_t s_acc[SFI_MAXL0];   // per query: rank accepted with, or NIL
+    __shared__ uint16_t s_held[SFI_MAXL0];  // per query: rank still held, or NIL
+    __shared__ signed char s_rotbin[SFI_MAXL0]; // per query: histogram bin or -1
+    __shared__ int s_hist[30];
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const orbfe_keypoint* k1 = kps + (size_t)p * capacity;
+    const orbfe_keypoint* k2 = kps + (size_t)(p + 1) * capacity;
+    const int n1 = nkp[p];
+    const int nq = G.nq[p], nl0 = G.nl0[p + 1];
+    const size_t g1 = (size_t)p * SFI_MAXL0, g2 = (size_t)(p + 1) * SFI_MAXL0;
+    const uint16_t* qi = G.query + g1;
+    int32_t* m12 = matches12 + (size_t)p * capacity;
+    const float* prev = prev_in ? prev_in + (size_t)p * capacity * 2 : nullptr;
+    float* prevo = prev_out ? prev_out + (size_t)p * capacity * 2 : nullptr;
+    const uint32_t* pl = pool + (size_t)p * pool_cap;
     constexpr int NIL = 0xffff;
-    for (int i = lane; i < nq; i += 64) { s_acc[i] = NIL; s_held[i] = NIL; }
+
+    // the pair's candidate rows -> LDS (dense pool: a flat copy, all loads in flight), the per-query and per-keypoint state
+    {
+        const int used = min(min(G.cursor[p], pool_cap), SFI_POOL_LDS);
+        const uint4* src = reinterpret_cast<const uint4*>(pl); // pool_cap is a multiple of 4
+        uint4* dst = reinterpret_cast<uint4*>(s_pool);
+        for (int i = lane; i < (used + 3) / 4; i += 64) dst[i] = src[i];
+    }
+    for (int i = lane; i < nq; i += 64) { s_row[i] = rowrec[g1 + i]; s_acc[i] = NIL; s_held[i] = NIL; s_rotbin[i] = -1; }
+    for (int i = lane; i < nl0; i += 64) s_state[i] = 0xffff0000u;
+    if (lane < 30) s_hist[lane] = 0;
+    for (int i = lane; i < n1; i += 64) m12[i] = -1;
     __builtin_amdgcn_wave_barrier();
+
+    // ---- the serial matching loop (ORBmatcher.cc:423-490).  It carries only what couples the queries -- vMatchedDistance /
+    // vnMatches21 per F2 keypoint and which query currently holds it; everything else (vnMatches12 in HBM, the rotation bins) is
+    // written by all lanes after the loop from two per-query records: the rank a query was accepted with (rotHist keeps it even
+    // if the match is stolen later, :470-488) and the rank it still holds.  The loop is a chain of dependent LDS round trips and
+    // wave reductions, once per query; so (1) the first 64 candidates of query q + 1 are fetched while query q is reduced, (2)
+    // vMatchedDistance and vnMatches21 of a keypoint are one word, read once per candidate, and the lane that holds the winning
+    // candidate does the bookkeeping with the word it already has.
     const float factor = 1.0f / 30; // HISTO_LENGTH; the upstream "1/30" quirk is kept (App. D)
-    // The loop is a chain of dependent LDS round trips and wave reductions, 217 times; so (1) the first 64 candidates of query
-    // q + 1 are fetched while query q is reduced, (2) vMatchedDistance and vnMatches21 of a keypoint are one word, read once per
-    // candidate, and the lane that holds the winning candidate does the bookkeeping with the word it already has.
-    auto row0 = [&](int q, int& e, int& rk, int& d) {
-        e = __builtin_amdgcn_readfirstlane((int)s_cnt[q]);
-        rk = 0; d = 0;
-        if (lane < e) {
-            if (q < SFI_ROWQ) { rk = s_ridx[q * SFI_ROW + lane]; d = s_rdist[q * SFI_ROW + lane]; }
-            else { const size_t o = (size_t)s_query[q] * row_stride + lane; rk = cidx[o]; d = cdist[o]; }
-        }
+    auto entry = [&](int o) { return o < SFI_POOL_LDS ? s_pool[o] : pl[o]; };
+    auto row0 = [&](int q, int& e, int& off, uint32_t& ent) {
+        const uint32_t rr = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_row[q]);
+        e = (int)(rr & ((1u << SFI_ROW_BITS) - 1));
+        off = (int)(rr >> SFI_ROW_BITS);
+        ent = lane < e ? entry(off + lane) : 0u;
     };
     constexpr int NONE = 0x7fffffff;
-    int e_n = 0, rk_n = 0, d_n = 0;
-    if (nq > 0) row0(0, e_n, rk_n, d_n);
+    int e_n = 0, off_n = 0;
+    uint32_t ent_n = 0;
+    if (nq > 0) row0(0, e_n, off_n, ent_n);
     for (int q = 0; q < nq; q++) {
-        const int e = e_n, rk0 = rk_n, d0 = d_n;
-        if (q + 1 < nq) row0(q + 1, e_n, rk_n, d_n);
+        const int e = e_n, off = off_n, rk0 = (int)(ent_n & 0xffffu), d0 = (int)(ent_n >> 16);
+        if (q + 1 < nq) row0(q + 1, e_n, off_n, ent_n);
         if (e <= 0) continue;
         // best = first minimum among candidates with vMatchedDistance[i2] > dist; second = next smallest.
         // key = distance (8 bits; 255 = "255 or 256", far above TH_LOW) | candidate position (10) | rank (10): the order of the
@@ -463,17 +491,17 @@ __global__ __launch_bounds__(SFI_THREADS) void k_search_init(const orbfe_keypoin
         int key = (lane < e && (int)(st0 >> 16) > d0) ? (d0 << 20) | (lane << 10) | rk0 : NONE;
         int bestk = wave_min(key);
         int secondk = wave_min(key == bestk ? NONE : key);
-        if (e > 64) { // rows longer than one wave: the later candidates from the query's global row
-            const size_t o = (size_t)s_query[q] * row_stride;
+        if (e > 64) { // rows longer than one wave
             for (int j0 = 64; j0 < e; j0 += 64) {
                 const int j = j0 + lane;
-                int k2 = NONE;
+                int kk = NONE;
                 if (j < e) {
-                    const int rk = cidx[o + j], d = cdist[o + j];
-                    if ((int)(s_state[rk] >> 16) > d) k2 = (d << 20) | (j << 10) | rk;
+                    const uint32_t en = entry(off + j);
+                    const int rk = (int)(en & 0xffffu), dd = (int)(en >> 16);
+                    if ((int)(s_state[rk] >> 16) > dd) kk = (dd << 20) | (j << 10) | rk;
                 }
-                const int m1 = wave_min(k2);
-                const int k2nd = wave_min(k2 == m1 ? NONE : k2);
+                const int m1 = wave_min(kk);
+                const int k2nd = wave_min(kk == m1 ? NONE : kk);
                 if (m1 < bestk) { secondk = min(bestk, k2nd); bestk = m1; }
                 else secondk = min(secondk, m1);
             }
@@ -502,9 +530,9 @@ __global__ __launch_bounds__(SFI_THREADS) void k_search_init(const orbfe_keypoin
         if (q < nq) {
             const int r = s_held[q];
             held = r != NIL;
-            if (held) m12[s_query[q]] = (int)(s_sorted[r] & 0xffff);
+            if (held) m12[qi[q]] = (int)(G.sorted[g2 + r] & 0xffff);
             if (check_ori && s_acc[q] != NIL) {
-                float rot = k1[s_query[q]].angle - s_ang2[s_acc[q]];
+                float rot = k1[qi[q]].angle - G.ang[g2 + s_acc[q]];
                 if (rot < 0.0f) rot += 360.0f;
                 int bin = (int)roundf(__fmul_rn(rot, factor));
                 if (bin == 30) bin = 0;
@@ -521,10 +549,10 @@ __global__ __launch_bounds__(SFI_THREADS) void k_search_init(const orbfe_keypoin
         __builtin_amdgcn_wave_barrier();
         int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
         for (int i = 0; i < 30; i++) { // ComputeThreeMaxima, ORBmatcher.cc:1605-1646
-            const int s = s_hist[i];
-            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
-            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
-            else if (s > max3) { max3 = s; ind3 = i; }
+            const int sz = s_hist[i];
+            if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (sz > max2) { max3 = max2; max2 = sz; ind3 = ind2; ind2 = i; }
+            else if (sz > max3) { max3 = sz; ind3 = i; }
         }
         if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
         else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
@@ -533,11 +561,11 @@ __global__ __launch_bounds__(SFI_THREADS) void k_search_init(const orbfe_keypoin
             const int q = q0 + lane;
             bool rm = false;
             if (q < nq) {
-                const int bin = s_rotbin[q], i = s_query[q];
+                const int bin = s_rotbin[q];
                 rm = bin >= 0 && bin != ind1 && bin != ind2 && bin != ind3 && s_held[q] != NIL;
-                if (rm) m12[i] = -1;
+                if (rm) m12[qi[q]] = -1;
             }
-            removed += __popcll(__ballot(rm));
+            removed += (int)__popcll(__ballot(rm));
         }
         nmatches -= removed;
     }
@@ -1120,9 +1148,9 @@ __global__ __launch_bounds__(256) void k_distinctive(const uint8_t* __restrict__
 struct MatchWorkspace {
     DevBuf pidx, pbest, psecond, csr_cnt, csr_idx, csr_dist, scratch, overflow, prev;
     DevBuf sbp_batch_overflow; // flag of the _batch_device searches: sticky until orbfe_search_by_projection_batch_status reads it
-    DevBuf sfi_overflow;  // k_search_init's flag: zeroed when allocated and whenever it is read (no memset launch per batch)
+    DevBuf sfi_overflow;  // SearchForInitialization's two flag words: zeroed when allocated and whenever they are read (no memset launch per batch)
     DevBuf q, t, nq, nt, oidx, obest, osecond, kps, desc, nk, m12, nm;
-    int csr_per_pair = 0; // CSR slots per frame pair (grown by the host wrapper on overflow)
+    int csr_per_pair = 0; // candidate pool entries per frame pair of SearchForInitialization (grown on overflow)
     int sbp_stride = 0;   // candidate row stride of k_search_by_projection (grown on overflow)
 };
 // one workspace per (thread, device, stream): see ThreadWorkspaces.  The host-pointer entry points run on the null stream.
@@ -1201,26 +1229,51 @@ static int sfi_launch(const orbfe_keypoint* d_kps, const uint8_t* d_desc, const 
 {
     if (capacity > 65535) return fail(ORBFE_ERR_INVALID, "capacity above 65535 keypoints per frame is unsupported");
     MatchWorkspace& w = ws(s);
-    // candidate rows have a fixed stride: at most every level-0 keypoint of F2 is a candidate; the host wrapper
-    // grows the stride when a frame reports more level-0 keypoints than that
-    const int stride = std::max(w.csr_per_pair, std::min(SFI_MAXL0, (capacity / 2 + 63) / 64 * 64));
-    w.csr_per_pair = stride;
+    // a pair's candidate rows share one dense pool; a pool that turns out too small is flagged, grown by the status call (or the
+    // host wrapper) and the batch repeated.  16 K entries hold a 640 x 480 / 1000-feature pair at window 100 more than twice.
+    const int pool_cap = std::max((w.csr_per_pair + 3) / 4 * 4, 16384);
+    w.csr_per_pair = pool_cap;
+    const int nframes = npairs + 1;
+    const size_t F = (size_t)nframes * SFI_MAXL0;
     int rc;
-    if ((rc = w.csr_cnt.ensure((size_t)npairs * capacity * 4)) ||
-        (rc = w.csr_idx.ensure((size_t)npairs * capacity * stride * 2)) ||
-        (rc = w.csr_dist.ensure((size_t)npairs * capacity * stride)) ||
-        (rc = w.scratch.ensure((size_t)npairs * 3 * capacity * 4)))
+    // grid records: nl0 | nq | cursor (ints), then sorted, xy, ang, desc, query per frame
+    if ((rc = w.csr_cnt.ensure((size_t)nframes * 3 * 4 + 64)) || (rc = w.csr_idx.ensure(F * (4 + 8 + 4 + 32 + 2) + 256)) ||
+        (rc = w.csr_dist.ensure((size_t)npairs * pool_cap * 4 + 64)) || (rc = w.scratch.ensure((size_t)npairs * SFI_MAXL0 * 4)))
         return rc;
     if (!w.sfi_overflow.p) {
         if ((rc = w.sfi_overflow.ensure(16))) return rc;
         ORBFE_HIP(hipMemset(w.sfi_overflow.p, 0, 16));
     }
-    { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(&k_search_init), (size_t)(sfi_lds_bytes())); if (rc_lds_) return rc_lds_; }
-    hipLaunchKernelGGL(k_search_init, dim3(npairs), dim3(SFI_THREADS), sfi_lds_bytes(), s, d_kps, d_desc, d_n, capacity, bnd,
-                       (float)window, nnratio, check_ori, d_prev_in, d_prev_out, d_m12, d_nm, w.csr_cnt.as<int32_t>(),
-                       w.csr_idx.as<uint16_t>(), w.csr_dist.as<uint8_t>(), stride, w.scratch.as<int32_t>(),
-                       w.sfi_overflow.as<int32_t>());
+    SfiGrid G;
+    G.nl0 = w.csr_cnt.as<int32_t>();
+    G.nq = G.nl0 + nframes;
+    G.cursor = G.nq + nframes;
+    uint8_t* b = w.csr_idx.as<uint8_t>();
+    G.desc = reinterpret_cast<uint4*>(b); b += F * 32;
+    G.xy = reinterpret_cast<float2*>(b); b += F * 8;
+    G.sorted = reinterpret_cast<uint32_t*>(b); b += F * 4;
+    G.ang = reinterpret_cast<float*>(b); b += F * 4;
+    G.query = reinterpret_cast<uint16_t*>(b);
+    int32_t* ovf = w.sfi_overflow.as<int32_t>(); // [0]: level-0 keypoints beyond SFI_MAXL0, [1]: pool entries a pair needed
+    hipLaunchKernelGGL(k_sfi_grid, dim3(nframes), dim3(SFI_GRID_THREADS), 0, s, d_kps, d_desc, d_n, capacity, nframes, bnd, G, ovf);
+    hipLaunchKernelGGL(k_sfi_rows, dim3(SFI_ROWS_BX, npairs), dim3(256), 0, s, d_kps, d_desc, capacity, bnd, (float)window, d_prev_in, G,
+                       w.csr_dist.as<uint32_t>(), pool_cap, w.scratch.as<uint32_t>(), ovf);
+    hipLaunchKernelGGL(k_sfi_accept, dim3(npairs), dim3(64), 0, s, d_kps, d_n, capacity, nnratio, check_ori, d_prev_in, d_prev_out, d_m12,
+                       d_nm, G, w.csr_dist.as<uint32_t>(), pool_cap, w.scratch.as<uint32_t>());
     ORBFE_HIP(hipGetLastError());
+    return ORBFE_OK;
+}
+
+// reads and clears the two flag words after the stream has drained; *need = 0, the level-0 count that does not fit (an error), or
+// the pool size a pair needed (the pool is grown: repeat the call)
+static int sfi_read_flags(MatchWorkspace& w, int32_t* need)
+{
+    int32_t f[2] = {0, 0};
+    ORBFE_HIP(hipMemcpy(f, w.sfi_overflow.p, 8, hipMemcpyDeviceToHost));
+    if (f[0] || f[1]) ORBFE_HIP(hipMemset(w.sfi_overflow.p, 0, 8)); // sticky until read
+    *need = std::max(f[0], f[1]);
+    if (f[0] > SFI_MAXL0) return fail(ORBFE_ERR_CAPACITY, "%d level-0 keypoints in a frame exceed the supported %d", f[0], SFI_MAXL0);
+    if (f[1] > w.csr_per_pair) w.csr_per_pair = (f[1] + 1023) / 1024 * 1024; // the next batch on this stream has the room
     return ORBFE_OK;
 }
 
@@ -1340,12 +1393,7 @@ int orbfe_search_for_initialization_batch_status(void* stream, int32_t* overflow
     MatchWorkspace& w = ws(s);
     if (!w.sfi_overflow.p) return ORBFE_OK; // no batch on this (thread, device, stream) yet
     ORBFE_HIP(hipStreamSynchronize(s));
-    ORBFE_HIP(hipMemcpy(overflow, w.sfi_overflow.p, 4, hipMemcpyDeviceToHost));
-    if (*overflow) ORBFE_HIP(hipMemset(w.sfi_overflow.p, 0, 4)); // the flag is sticky until it has been read
-    if (*overflow > SFI_MAXL0)
-        return fail(ORBFE_ERR_CAPACITY, "%d level-0 keypoints in a frame exceed the supported %d", *overflow, SFI_MAXL0);
-    if (*overflow > w.csr_per_pair) w.csr_per_pair = (*overflow + 63) / 64 * 64; // the next batch on this stream has the room
-    return ORBFE_OK;
+    return sfi_read_flags(w, overflow);
 }
 
 int orbfe_search_for_initialization(const orbfe_keypoint* kps1, const uint8_t* desc1, int n1,
@@ -1384,12 +1432,9 @@ int orbfe_search_for_initialization(const orbfe_keypoint* kps1, const uint8_t* d
         if (rc) return rc;
         ORBFE_HIP(hipDeviceSynchronize());
         int32_t ovf = 0;
-        ORBFE_HIP(hipMemcpy(&ovf, w.sfi_overflow.p, 4, hipMemcpyDeviceToHost));
+        if ((rc = sfi_read_flags(w, &ovf))) return rc;
         if (!ovf) break;
-        ORBFE_HIP(hipMemset(w.sfi_overflow.p, 0, 4));
-        if (attempt) return fail(ORBFE_ERR_CAPACITY, "candidate list overflow (%d)", ovf);
-        if (ovf > SFI_MAXL0) return fail(ORBFE_ERR_CAPACITY, "%d level-0 keypoints exceed the supported %d", ovf, SFI_MAXL0);
-        w.csr_per_pair = ovf;
+        if (attempt) return fail(ORBFE_ERR_CAPACITY, "candidate pool overflow (%d)", ovf);
     }
     ORBFE_HIP(hipMemcpy(matches12, w.m12.p, (size_t)n1 * 4, hipMemcpyDeviceToHost));
     ORBFE_HIP(hipMemcpy(prev_matched, w.prev.p, (size_t)n1 * 8, hipMemcpyDeviceToHost));
