@@ -273,10 +273,13 @@ struct SfiGrid { // [frame][SFI_MAXL0] arrays in HBM, written by k_sfi_grid
     float* ang;       // by rank
     uint4* desc;      // by rank, two per keypoint
     uint16_t* query;  // by query position: keypoint index
-    int32_t* cursor;  // [pairs] next free pool entry (zeroed here, advanced by k_sfi_rows)
+    float2* qxy;      // by query position: the keypoint's own position (the window centre unless vbPrevMatched is given)
+    int32_t* cursor;  // [pairs * SFI_CURSOR_PAD] next free pool entry (zeroed here, advanced by k_sfi_rows); one per 256 bytes, so that
+                      //   the 65 k atomics of a batch do not queue on a handful of cache lines of one L2 channel
 };
 #define SFI_GRID_THREADS 256
-#define SFI_ROWS_BX 16         // workgroups per pair in k_sfi_rows (4 waves each)
+#define SFI_CURSOR_PAD 64
+#define SFI_ROWS_BX 64         // workgroups per pair in k_sfi_rows (4 waves each, one query per wave and trip)
 #define SFI_POOL_LDS 6144      // pool entries k_sfi_accept stages in LDS (24 KB); later ones are read from the pool in HBM
 #define SFI_ROW_BITS 11        // row record = offset << 11 | count (count <= SFI_MAXL0 = 1024)
 
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(SFI_GRID_THREADS) void k_sfi_grid(const orbfe_keypo
     const float mnMinX = bnd.x, mnMinY = bnd.y;
     const float invW = __fdiv_rn((float)GRID_COLS, bnd.z - bnd.x);
     const float invH = __fdiv_rn((float)GRID_ROWS, bnd.w - bnd.y);
-    if (tid == 0) { s_nl0 = 0; if (f < nframes - 1) G.cursor[f] = 0; }
+    if (tid == 0) { s_nl0 = 0; if (f < nframes - 1) G.cursor[(size_t)f * SFI_CURSOR_PAD] = 0; }
     __syncthreads();
     // role F2: level-0 keypoints that fall inside the grid (Frame.cc:183-198, :335-345)
     for (int i = tid; i < n; i += SFI_GRID_THREADS) {
@@ -311,12 +314,16 @@ __global__ __launch_bounds__(SFI_GRID_THREADS) void k_sfi_grid(const orbfe_keypo
     if (wid == 0) {
         int nq = 0;
         uint16_t* qo = G.query + (size_t)f * SFI_MAXL0;
+        float2* qp = G.qxy + (size_t)f * SFI_MAXL0;
         for (int i0 = 0; i0 < n; i0 += 64) {
             const int i = i0 + lane;
-            const bool isq = i < n && k[i].octave <= 0;
+            orbfe_keypoint kp;
+            kp.octave = 1;
+            if (i < n) kp = k[i];
+            const bool isq = i < n && kp.octave <= 0;
             const unsigned long long m = __ballot(isq);
             const int pos = nq + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-            if (isq && pos < SFI_MAXL0) qo[pos] = (uint16_t)i;
+            if (isq && pos < SFI_MAXL0) { qo[pos] = (uint16_t)i; qp[pos] = make_float2(kp.x, kp.y); }
             nq += __popcll(m);
         }
         if (lane == 0) {
@@ -351,72 +358,175 @@ __global__ __launch_bounds__(SFI_GRID_THREADS) void k_sfi_grid(const orbfe_keypo
     }
 }
 
-__global__ __launch_bounds__(256) void k_sfi_rows(const orbfe_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc, int capacity,
-                                                  float4 bnd, float window, const float* __restrict__ prev_in, SfiGrid G,
-                                                  uint32_t* __restrict__ pool, int pool_cap, uint32_t* __restrict__ rowrec,
-                                                  int32_t* __restrict__ overflow)
+// Candidates of one query among four 64-entry chunks (c0 .. c0 + 3) of F2's sorted list: window test, then the Hamming distances
+// with all loads of the four chunks in flight together.  keys[k] = distance << 20 | position in the row << 10 | rank (0x7fffffff:
+// no candidate); returns the number of candidates found (wave-uniform).
+struct SfiWindow { float x, y, r; int minx, maxx, miny, maxy; };
+__device__ __forceinline__ int sfi_chunks4(const SfiGrid& G, size_t g2, int nl0, int c0, int lane, const SfiWindow& W, const uint4& a0,
+                                           const uint4& a1, int base, int* keys)
 {
-    __shared__ uint16_t s_cell[SFI_MAXL0];
-    __shared__ float2 s_xy[SFI_MAXL0];
-    const int p = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = wave_id();
+    uint32_t cell[4];
+    float2 xy[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int j = (c0 + k) * 64 + lane;
+        cell[k] = 0xffffffffu; xy[k] = make_float2(0.f, 0.f);
+        if (j < nl0) { cell[k] = G.sorted[g2 + j] >> 16; xy[k] = G.xy[g2 + j]; }
+    }
+    bool ok[4];
+    uint4 b0[4], b1[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        // Frame::GetFeaturesInArea (Frame.cc:280-333): the cell range of the window, then |dx| < r and |dy| < r
+        const int cx = (int)(cell[k] / GRID_ROWS), cy = (int)(cell[k] - (uint32_t)cx * GRID_ROWS);
+        ok[k] = cell[k] != 0xffffffffu && cx >= W.minx && cx <= W.maxx && cy >= W.miny && cy <= W.maxy && fabsf(xy[k].x - W.x) < W.r &&
+                fabsf(xy[k].y - W.y) < W.r;
+        if (ok[k]) { const size_t o = 2 * (g2 + (size_t)((c0 + k) * 64 + lane)); b0[k] = G.desc[o]; b1[k] = G.desc[o + 1]; }
+    }
+    int n = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const unsigned long long m = __ballot(ok[k]);
+        keys[k] = 0x7fffffff;
+        if (ok[k]) {
+            const int pos = base + n + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+            const int dd = hamming256(a0, a1, b0[k], b1[k]); // 256 only for exact complements; 255 is far above TH_LOW as well
+            keys[k] = (min(dd, 255) << 20) | (pos << 10) | ((c0 + k) * 64 + lane);
+        }
+        n += (int)__popcll(m);
+    }
+    return n;
+}
+
+#define SFI_ROWS_WAVES 4
+__global__ __launch_bounds__(SFI_ROWS_WAVES * 64) void k_sfi_rows(const orbfe_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc,
+                                                                  int capacity, float4 bnd, float window, const float* __restrict__ prev_in,
+                                                                  SfiGrid G, uint32_t* __restrict__ pool, int pool_cap,
+                                                                  uint32_t* __restrict__ rowrec, int32_t* __restrict__ overflow)
+{
+    __shared__ int s_keys[SFI_ROWS_WAVES][SFI_MAXL0]; // the wave's row, by candidate position, for the rank-by-counting sort
+    const int p = blockIdx.y, lane = threadIdx.x & 63, wid = wave_id();
     const int nq = G.nq[p], nl0 = G.nl0[p + 1];
-    if ((int)blockIdx.x * 4 >= nq) return;
-    const size_t g2 = (size_t)(p + 1) * SFI_MAXL0;
-    for (int i = tid; i < nl0; i += 256) { s_cell[i] = (uint16_t)(G.sorted[g2 + i] >> 16); s_xy[i] = G.xy[g2 + i]; }
-    __syncthreads();
-    const orbfe_keypoint* k1 = kps + (size_t)p * capacity;
+    const size_t g1 = (size_t)p * SFI_MAXL0, g2 = (size_t)(p + 1) * SFI_MAXL0;
     const uint8_t* d1 = desc + (size_t)p * capacity * 32;
     const float* prev = prev_in ? prev_in + (size_t)p * capacity * 2 : nullptr;
-    const uint16_t* qi = G.query + (size_t)p * SFI_MAXL0;
     uint32_t* pl = pool + (size_t)p * pool_cap;
     const float mnMinX = bnd.x, mnMinY = bnd.y;
     const float invW = __fdiv_rn((float)GRID_COLS, bnd.z - bnd.x);
     const float invH = __fdiv_rn((float)GRID_ROWS, bnd.w - bnd.y);
-    const float r = window;
-    for (int q = blockIdx.x * 4 + wid; q < nq; q += SFI_ROWS_BX * 4) {
-        const int i1 = __builtin_amdgcn_readfirstlane((int)qi[q]);
-        const float x = prev ? prev[2 * i1] : k1[i1].x, y = prev ? prev[2 * i1 + 1] : k1[i1].y;
-        // Frame::GetFeaturesInArea (Frame.cc:280-333): the cell range of the window, then |dx| < r and |dy| < r
-        const int nMinCellX = max(0, (int)floorf(__fmul_rn(x - mnMinX - r, invW)));
-        const int nMaxCellX = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(x - mnMinX + r, invW)));
-        const int nMinCellY = max(0, (int)floorf(__fmul_rn(y - mnMinY - r, invH)));
-        const int nMaxCellY = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(y - mnMinY + r, invH)));
-        const bool any = !(nMinCellX >= GRID_COLS || nMaxCellX < 0 || nMinCellY >= GRID_ROWS || nMaxCellY < 0);
-        auto inside = [&](int j) {
-            if (j >= nl0) return false;
-            const int cell = s_cell[j], cx = cell / GRID_ROWS, cy = cell - cx * GRID_ROWS;
-            if (cx < nMinCellX || cx > nMaxCellX || cy < nMinCellY || cy > nMaxCellY) return false;
-            const float2 v = s_xy[j];
-            return fabsf(v.x - x) < r && fabsf(v.y - y) < r;
-        };
+    int* row = s_keys[wid];
+    (void)kps;
+    for (int q = blockIdx.x * SFI_ROWS_WAVES + wid; q < nq; q += gridDim.x * SFI_ROWS_WAVES) {
+        const int i1 = __builtin_amdgcn_readfirstlane((int)G.query[g1 + q]);
+        float2 c = G.qxy[g1 + q];
+        if (prev) c = make_float2(prev[2 * i1], prev[2 * i1 + 1]);
+        SfiWindow W;
+        W.x = c.x; W.y = c.y; W.r = window;
+        W.minx = max(0, (int)floorf(__fmul_rn(c.x - mnMinX - W.r, invW)));
+        W.maxx = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(c.x - mnMinX + W.r, invW)));
+        W.miny = max(0, (int)floorf(__fmul_rn(c.y - mnMinY - W.r, invH)));
+        W.maxy = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(c.y - mnMinY + W.r, invH)));
+        const bool any = !(W.minx >= GRID_COLS || W.maxx < 0 || W.miny >= GRID_ROWS || W.maxy < 0);
+        const uint4 a0 = reinterpret_cast<const uint4*>(d1)[2 * i1];
+        const uint4 a1 = reinterpret_cast<const uint4*>(d1)[2 * i1 + 1];
         int count = 0;
         if (any)
-            for (int j0 = 0; j0 < nl0; j0 += 64) count += (int)__popcll(__ballot(inside(j0 + lane)));
+            for (int c0 = 0; c0 * 64 < nl0; c0 += 4) { // the row in candidate order, wave-private LDS
+                int keys[4];
+                const int n = sfi_chunks4(G, g2, nl0, c0, lane, W, a0, a1, count, keys);
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (keys[k] != 0x7fffffff) row[(keys[k] >> 10) & 0x3ff] = keys[k];
+                count += n;
+            }
         int off = 0;
-        if (lane == 0 && count > 0) off = atomicAdd(&G.cursor[p], count);
+        if (lane == 0 && count > 0) off = atomicAdd(&G.cursor[(size_t)p * SFI_CURSOR_PAD], count);
+        // sorted by (distance, position): the accept loop then takes the first two candidates that are not skipped instead of
+        // reducing the row.  Rank by counting (the keys are distinct), broadcast LDS reads; the first 64 entries are ranked while
+        // the cursor's atomic is in flight.
+        auto rank_of = [&](int e, int& key) {
+            key = e < count ? row[e] : 0x7fffffff;
+            int r = 0;
+            for (int t = 0; t < count; t++) r += row[t] < key;
+            return r;
+        };
+        int key0 = 0x7fffffff;
+        const int r0 = count > 0 ? rank_of(lane, key0) : 0;
         off = __builtin_amdgcn_readfirstlane(off);
         bool fits = true;
         if (count > 0 && off + count > pool_cap) { // the pool is too small: flagged, the host grows it and the batch is repeated
             if (lane == 0) atomicMax(overflow + 1, off + count);
             fits = false;
         }
-        if (lane == 0) rowrec[(size_t)p * SFI_MAXL0 + q] = fits ? ((uint32_t)off << SFI_ROW_BITS) | (uint32_t)count : 0u;
+        if (lane == 0) rowrec[g1 + q] = fits ? ((uint32_t)off << SFI_ROW_BITS) | (uint32_t)count : 0u;
         if (count == 0 || !fits) continue;
-        const uint4 a0 = reinterpret_cast<const uint4*>(d1)[2 * i1];
-        const uint4 a1 = reinterpret_cast<const uint4*>(d1)[2 * i1 + 1];
-        int done = 0;
-        for (int j0 = 0; j0 < nl0; j0 += 64) {
-            const int j = j0 + lane;
-            const bool ok = inside(j);
-            const unsigned long long m = __ballot(ok);
-            if (ok) {
-                const int pos = done + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-                const int dd = hamming256(a0, a1, G.desc[2 * (g2 + j)], G.desc[2 * (g2 + j) + 1]);
-                // 256 only for exact complements; 255 is far above TH_LOW as well
-                pl[off + pos] = ((uint32_t)(dd > 255 ? 255 : dd) << 16) | (uint32_t)j;
-            }
-            done += (int)__popcll(m);
+        if (lane < count) pl[off + r0] = ((uint32_t)(key0 >> 20) << 16) | (uint32_t)(key0 & 0x3ff);
+        for (int e0 = 64; e0 < count; e0 += 64) {
+            int key;
+            const int r = rank_of(e0 + lane, key);
+            if (e0 + lane < count) pl[off + r] = ((uint32_t)(key >> 20) << 16) | (uint32_t)(key & 0x3ff);
         }
+    }
+}
+
+// The serial loop of k_sfi_accept (see there).  IN_LDS: the pair's whole pool is staged in LDS -- no global path, hence no
+// branch and no vmcnt wait inside the loop.
+template <bool IN_LDS>
+__device__ __forceinline__ void sfi_accept_loop(int nq, int lane, float nnratio, const uint32_t* s_pool, uint32_t* s_state,
+                                                const uint32_t* s_row, uint16_t* s_acc, uint16_t* s_held, const uint32_t* __restrict__ pl)
+{
+    constexpr int NIL = 0xffff;
+    auto rfl = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    constexpr uint32_t CNT = (1u << SFI_ROW_BITS) - 1;
+    auto entry = [&](int o) { return IN_LDS || o < SFI_POOL_LDS ? s_pool[min(o, SFI_POOL_LDS - 1)] : pl[o]; };
+    // rows longer than a wave whose first 64 entries did not settle best and second: the later chunks, in order
+    auto long_row = [&](int e, int off, int& bestDist, int& bestRank, uint32_t& bestState, int& bestDist2) {
+        for (int j0 = 64; j0 < e; j0 += 64) {
+            const uint32_t en = j0 + lane < e ? entry(off + j0 + lane) : 0u;
+            const int rk = (int)(en & 0x3ffu), dd = (int)(en >> 16);
+            const uint32_t st = s_state[rk];
+            unsigned long long open = __ballot(j0 + lane < e && (int)(st >> 16) > dd);
+            if (open && bestDist < 0) {
+                const int b = __builtin_ctzll(open);
+                bestDist = __builtin_amdgcn_readlane(dd, b);
+                bestRank = __builtin_amdgcn_readlane(rk, b);
+                bestState = (uint32_t)__builtin_amdgcn_readlane((int)st, b);
+                open &= open - 1;
+            }
+            if (open) { bestDist2 = __builtin_amdgcn_readlane(dd, __builtin_ctzll(open)); return; }
+        }
+    };
+    uint32_t rr = nq > 0 ? rfl(s_row[0]) : 0u, rr1 = nq > 1 ? rfl(s_row[1]) : 0u;
+    uint32_t ent = entry((int)(rr >> SFI_ROW_BITS) + lane);
+    for (int q = 0; q < nq; q++) {
+        const int e = (int)(rr & CNT), off = (int)(rr >> SFI_ROW_BITS);
+        const int rk = (int)(ent & 0x3ffu), dd = (int)(ent >> 16);
+        const uint32_t st = s_state[rk];                                        // the loop-carried read
+        const uint32_t ent1 = entry((int)(rr1 >> SFI_ROW_BITS) + lane);         // row q + 1
+        const uint32_t rr2 = s_row[min(q + 2, SFI_MAXL0 - 1)];                  // record of row q + 2
+        unsigned long long open = __ballot(lane < e && (int)(st >> 16) > dd);
+        int bestDist = -1, bestRank = 0, bestDist2 = INT_MAX;
+        uint32_t bestState = 0;
+        if (open) {
+            const int b = __builtin_ctzll(open);
+            bestDist = __builtin_amdgcn_readlane(dd, b);
+            bestRank = __builtin_amdgcn_readlane(rk, b);
+            bestState = (uint32_t)__builtin_amdgcn_readlane((int)st, b);
+            open &= open - 1;
+            if (open) bestDist2 = __builtin_amdgcn_readlane(dd, __builtin_ctzll(open));
+        }
+        if (e > 64 && !open) long_row(e, off, bestDist, bestRank, bestState, bestDist2);
+        if (bestDist >= 0 && bestDist <= 50 && (float)bestDist < __fmul_rn((float)bestDist2, nnratio)) { // TH_LOW, ratio test
+            if (lane == 0) {
+                const int old = (int)(bestState & 0xffffu) - 1;
+                if (old >= 0) s_held[old] = NIL;      // the earlier query loses the keypoint (:467-471)
+                s_state[bestRank] = ((uint32_t)bestDist << 16) | (uint32_t)(q + 1);
+                s_held[q] = (uint16_t)bestRank;
+                s_acc[q] = (uint16_t)bestRank;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        rr = rr1; rr1 = q + 2 < nq ? rfl(rr2) : 0u; ent = ent1;
     }
 }
 
@@ -448,15 +558,38 @@ __global__ __launch_bounds__(64) void k_sfi_accept(const orbfe_keypoint* __restr
     const uint32_t* pl = pool + (size_t)p * pool_cap;
     constexpr int NIL = 0xffff;
 
-    // the pair's candidate rows -> LDS (dense pool: a flat copy, all loads in flight), the per-query and per-keypoint state
+    // the pair's candidate rows -> LDS (dense pool: a flat copy), the per-query and per-keypoint state.  All of it without
+    // predicated loads -- a load under `if (i < n)` becomes a branch with a full wait behind it, one L2 round trip per trip -- the
+    // buffers are sized so that whole batches may be read: the pool holds >= 16 K entries per pair (SFI_POOL_LDS are copied), the
+    // row records SFI_MAXL0 per pair.
+#ifdef ORBFE_SFI_TIMING // diagnosis build (tools/build_timing.sh): phase clocks of one pair, s_memrealtime ticks of 10 ns
+    const unsigned long long t_0 = wall_clock64();
+#endif
+    const int total = min(G.cursor[(size_t)p * SFI_CURSOR_PAD], pool_cap);
     {
-        const int used = min(min(G.cursor[p], pool_cap), SFI_POOL_LDS);
         const uint4* src = reinterpret_cast<const uint4*>(pl); // pool_cap is a multiple of 4
         uint4* dst = reinterpret_cast<uint4*>(s_pool);
-        for (int i = lane; i < (used + 3) / 4; i += 64) dst[i] = src[i];
+        const int n4 = (min(total, SFI_POOL_LDS) + 3) / 4;
+        static_assert(SFI_POOL_LDS % (4 * 64 * 8) == 0, "whole batches");
+        for (int i0 = 0; i0 < n4; i0 += 64 * 8) { // eight loads in flight per lane
+            uint4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = src[i0 + k * 64 + lane];
+#pragma unroll
+            for (int k = 0; k < 8; k++) dst[i0 + k * 64 + lane] = v[k];
+        }
+        for (int i0 = 0; i0 < nq; i0 += 64 * 4) {
+            uint32_t v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = rowrec[g1 + i0 + k * 64 + lane];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int i = i0 + k * 64 + lane;
+                s_row[i] = i < nq ? v[k] : 0u; s_acc[i] = NIL; s_held[i] = NIL; s_rotbin[i] = -1;
+            }
+        }
     }
-    for (int i = lane; i < nq; i += 64) { s_row[i] = rowrec[g1 + i]; s_acc[i] = NIL; s_held[i] = NIL; s_rotbin[i] = -1; }
-    for (int i = lane; i < nl0; i += 64) s_state[i] = 0xffff0000u;
+    for (int i = lane; i < SFI_MAXL0; i += 64) s_state[i] = 0xffff0000u;
     if (lane < 30) s_hist[lane] = 0;
     for (int i = lane; i < n1; i += 64) m12[i] = -1;
     __builtin_amdgcn_wave_barrier();
@@ -464,65 +597,23 @@ __global__ __launch_bounds__(64) void k_sfi_accept(const orbfe_keypoint* __restr
     // ---- the serial matching loop (ORBmatcher.cc:423-490).  It carries only what couples the queries -- vMatchedDistance /
     // vnMatches21 per F2 keypoint and which query currently holds it; everything else (vnMatches12 in HBM, the rotation bins) is
     // written by all lanes after the loop from two per-query records: the rank a query was accepted with (rotHist keeps it even
-    // if the match is stolen later, :470-488) and the rank it still holds.  The loop is a chain of dependent LDS round trips and
-    // wave reductions, once per query; so (1) the first 64 candidates of query q + 1 are fetched while query q is reduced, (2)
-    // vMatchedDistance and vnMatches21 of a keypoint are one word, read once per candidate, and the lane that holds the winning
-    // candidate does the bookkeeping with the word it already has.
+    // if the match is stolen later, :470-488) and the rank it still holds.
+    // A query's row is sorted by (distance, candidate position), so "best = first minimum among the candidates whose
+    // vMatchedDistance exceeds their distance (:448-449), second = the next smallest" is: the first two candidates of the row that
+    // are not skipped -- one gather of the keypoints' state words, one ballot, two scalar bit scans; no wave reduction on the
+    // loop-carried chain.  One LDS round trip on that chain per query: the gather is issued first, the row of query q + 1 and the
+    // row record of query q + 2 behind it (LDS answers in order, so the wait for the gather does not wait for them); every LDS
+    // read of the loop is unconditional (clamped addresses), only the ballot looks at the row length.
     const float factor = 1.0f / 30; // HISTO_LENGTH; the upstream "1/30" quirk is kept (App. D)
-    auto entry = [&](int o) { return o < SFI_POOL_LDS ? s_pool[o] : pl[o]; };
-    auto row0 = [&](int q, int& e, int& off, uint32_t& ent) {
-        const uint32_t rr = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_row[q]);
-        e = (int)(rr & ((1u << SFI_ROW_BITS) - 1));
-        off = (int)(rr >> SFI_ROW_BITS);
-        ent = lane < e ? entry(off + lane) : 0u;
-    };
-    constexpr int NONE = 0x7fffffff;
-    int e_n = 0, off_n = 0;
-    uint32_t ent_n = 0;
-    if (nq > 0) row0(0, e_n, off_n, ent_n);
-    for (int q = 0; q < nq; q++) {
-        const int e = e_n, off = off_n, rk0 = (int)(ent_n & 0xffffu), d0 = (int)(ent_n >> 16);
-        if (q + 1 < nq) row0(q + 1, e_n, off_n, ent_n);
-        if (e <= 0) continue;
-        // best = first minimum among candidates with vMatchedDistance[i2] > dist; second = next smallest.
-        // key = distance (8 bits; 255 = "255 or 256", far above TH_LOW) | candidate position (10) | rank (10): the order of the
-        // keys is (distance, position), so the wave minimum is the first minimum -- on 32-bit DPP reductions
-        const uint32_t st0 = lane < e ? s_state[rk0] : 0u;
-        int key = (lane < e && (int)(st0 >> 16) > d0) ? (d0 << 20) | (lane << 10) | rk0 : NONE;
-        int bestk = wave_min(key);
-        int secondk = wave_min(key == bestk ? NONE : key);
-        if (e > 64) { // rows longer than one wave
-            for (int j0 = 64; j0 < e; j0 += 64) {
-                const int j = j0 + lane;
-                int kk = NONE;
-                if (j < e) {
-                    const uint32_t en = entry(off + j);
-                    const int rk = (int)(en & 0xffffu), dd = (int)(en >> 16);
-                    if ((int)(s_state[rk] >> 16) > dd) kk = (dd << 20) | (j << 10) | rk;
-                }
-                const int m1 = wave_min(kk);
-                const int k2nd = wave_min(kk == m1 ? NONE : kk);
-                if (m1 < bestk) { secondk = min(bestk, k2nd); bestk = m1; }
-                else secondk = min(secondk, m1);
-            }
-        }
-        if (bestk == NONE) continue;
-        const int bestDist = bestk >> 20;
-        const int bestDist2 = secondk == NONE ? INT_MAX : secondk >> 20;
-        const int bestRank = bestk & 0x3ff, bestPos = (bestk >> 10) & 0x3ff;
-        if (bestDist <= 50 && (float)bestDist < __fmul_rn((float)bestDist2, nnratio)) { // TH_LOW, ratio test
-            if (lane == (bestPos & 63)) {
-                const uint32_t st = bestPos < 64 ? st0 : s_state[bestRank];
-                const int old = (int)(st & 0xffffu) - 1;
-                if (old >= 0) s_held[old] = NIL;      // the earlier query loses the keypoint (:467-471)
-                s_state[bestRank] = ((uint32_t)bestDist << 16) | (uint32_t)(q + 1);
-                s_held[q] = (uint16_t)bestRank;
-                s_acc[q] = (uint16_t)bestRank;
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
+#ifdef ORBFE_SFI_TIMING
+    const unsigned long long t_1 = wall_clock64();
+#endif
+    if (total <= SFI_POOL_LDS) sfi_accept_loop<true>(nq, lane, nnratio, s_pool, s_state, s_row, s_acc, s_held, pl);
+    else sfi_accept_loop<false>(nq, lane, nnratio, s_pool, s_state, s_row, s_acc, s_held, pl); // rows beyond the staged part of the pool
     __builtin_amdgcn_wave_barrier();
+#ifdef ORBFE_SFI_TIMING
+    const unsigned long long t_2 = wall_clock64();
+#endif
     int nmatches = 0;
     for (int q0 = 0; q0 < nq; q0 += 64) {
         const int q = q0 + lane;
@@ -579,6 +670,11 @@ __global__ __launch_bounds__(64) void k_sfi_accept(const orbfe_keypoint* __restr
             prevo[2 * i + 1] = y;
         }
     if (lane == 0) nmatches_out[p] = nmatches;
+#ifdef ORBFE_SFI_TIMING
+    if (lane == 0 && (p == 7 || p == 150))
+        printf("k_sfi_accept pair %d: nq %d nl0 %d pool %d | stage %llu loop %llu epilogue %llu (x 10 ns)\n", p, nq, nl0, total, t_1 - t_0,
+               t_2 - t_1, wall_clock64() - t_2);
+#endif
 }
 
 // ---------------------------------------------------------------------------- guided knn2 (CSR) ----------------
@@ -1237,7 +1333,7 @@ static int sfi_launch(const orbfe_keypoint* d_kps, const uint8_t* d_desc, const 
     const size_t F = (size_t)nframes * SFI_MAXL0;
     int rc;
     // grid records: nl0 | nq | cursor (ints), then sorted, xy, ang, desc, query per frame
-    if ((rc = w.csr_cnt.ensure((size_t)nframes * 3 * 4 + 64)) || (rc = w.csr_idx.ensure(F * (4 + 8 + 4 + 32 + 2) + 256)) ||
+    if ((rc = w.csr_cnt.ensure((size_t)nframes * (2 + SFI_CURSOR_PAD) * 4 + 64)) || (rc = w.csr_idx.ensure(F * (4 + 8 + 4 + 32 + 8 + 2) + 256)) ||
         (rc = w.csr_dist.ensure((size_t)npairs * pool_cap * 4 + 64)) || (rc = w.scratch.ensure((size_t)npairs * SFI_MAXL0 * 4)))
         return rc;
     if (!w.sfi_overflow.p) {
@@ -1252,11 +1348,13 @@ static int sfi_launch(const orbfe_keypoint* d_kps, const uint8_t* d_desc, const 
     G.desc = reinterpret_cast<uint4*>(b); b += F * 32;
     G.xy = reinterpret_cast<float2*>(b); b += F * 8;
     G.sorted = reinterpret_cast<uint32_t*>(b); b += F * 4;
+    G.qxy = reinterpret_cast<float2*>(b); b += F * 8;
     G.ang = reinterpret_cast<float*>(b); b += F * 4;
     G.query = reinterpret_cast<uint16_t*>(b);
     int32_t* ovf = w.sfi_overflow.as<int32_t>(); // [0]: level-0 keypoints beyond SFI_MAXL0, [1]: pool entries a pair needed
     hipLaunchKernelGGL(k_sfi_grid, dim3(nframes), dim3(SFI_GRID_THREADS), 0, s, d_kps, d_desc, d_n, capacity, nframes, bnd, G, ovf);
-    hipLaunchKernelGGL(k_sfi_rows, dim3(SFI_ROWS_BX, npairs), dim3(256), 0, s, d_kps, d_desc, capacity, bnd, (float)window, d_prev_in, G,
+    // a wave per query for frames of up to 256 level-0 keypoints (ORB-SLAM's 1000 features at 640 x 480 have ~217), more per wave above
+    hipLaunchKernelGGL(k_sfi_rows, dim3(SFI_ROWS_BX, npairs), dim3(SFI_ROWS_WAVES * 64), 0, s, d_kps, d_desc, capacity, bnd, (float)window, d_prev_in, G,
                        w.csr_dist.as<uint32_t>(), pool_cap, w.scratch.as<uint32_t>(), ovf);
     hipLaunchKernelGGL(k_sfi_accept, dim3(npairs), dim3(64), 0, s, d_kps, d_n, capacity, nnratio, check_ori, d_prev_in, d_prev_out, d_m12,
                        d_nm, G, w.csr_dist.as<uint32_t>(), pool_cap, w.scratch.as<uint32_t>());

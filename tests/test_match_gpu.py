@@ -55,15 +55,20 @@ def test_knn2_large_property(orbfe):
     assert np.array_equal(sd[idx], x.min(1))
 
 
-def test_knn2_c5_oracle_sample_both_kernels(orbfe, oracle):
+def test_knn2_c5_oracle_sample_both_kernels():
     """bench.py's C5 matching leg (10k x 10k, seed 5, resident): 192 queries of the full-size problem against the oracle, for the
     VALU kernel and the matrix-core kernel, plus the self-match property over all 10^4 queries -- so the driver's GPU test
-    record holds an oracle check of the full-size configuration, not only `bench.py --config C5`."""
-    import sys, os
-    import torch
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    import bench
-    res = bench.c5_match_leg(orbfe, torch, torch.device("cuda", 0), oracle)
+    record holds an oracle check of the full-size configuration, not only `bench.py --config C5`.  In its own process, torch
+    imported first (torch brings its own HIP runtime; a process that has already initialised the system one through liborbfe.so
+    may find no device through torch afterwards)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, json, torch; sys.path[:0] = [%r, %r]; import bench, oracle_lib; from orb_slam2_aruco_amd import binding; "
+            "print(json.dumps(bench.c5_match_leg(binding, torch, torch.device('cuda', 0), oracle_lib)))" % (root, os.path.join(root, "tests")))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    import json
+    res = json.loads(r.stdout.strip().splitlines()[-1])
     assert res["verified_queries"] == 192 and res["pairs"] == 10**8
     assert res["valu"]["launch_us"] > 0 and res["mfma_i8"]["launch_us"] > 0
 
