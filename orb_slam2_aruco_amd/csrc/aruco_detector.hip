@@ -35,6 +35,8 @@ struct orbfe_aruco {
     DevBuf d_segs, d_tailkeys, d_tailoff, d_small, d_hint; // d_hint: the relay kernel's grid spacing of the previous batch
     int relay_kshift = 5;      // initial grid spacing (log2) of k_contours_relay
     int relay_chunk = getenv("ORBFE_ARUCO_RELAY_CHUNK") ? atoi(getenv("ORBFE_ARUCO_RELAY_CHUNK")) : 1 << 30;   // frames per launch of the large-frame relay kernels
+    DevBuf d_dwork, d_dctr, d_ditems, d_dhist, d_dpatch; // k_prefilter -> k_decode_warp / _otsu / _vote: the batch's candidates
+    bool decode_dirty = false; // the decode work-list counter may be non-zero
     bool tail_dirty = false;   // the work-list counters may be non-zero (set while the tail's three launches are being enqueued)
     int relay_kcap = RL_KCAP;  // kept borders per frame the relay kernels and their tail hold
     // experiment (ORBFE_ARUCO_SMALL_SEPARATE=1): k_contours_small also for frames whose bit image is in LDS
@@ -60,7 +62,7 @@ struct orbfe_aruco {
     ~orbfe_aruco()
     {
         for (DevBuf* b : {&d_codes, &d_levels, &d_tabs, &d_bits, &d_pyr, &d_candq, &d_pool, &d_kept, &d_rects,
-                          &d_counts, &d_candidx, &d_ncand, &d_result, &d_gpad, &d_in, &d_out, &d_nout, &d_segs, &d_tailkeys, &d_tailoff, &d_small, &d_hint, &d_rstate, &d_lut, &d_twork, &d_trect, &d_tctr, &d_scodes, &d_sids,
+                          &d_counts, &d_candidx, &d_ncand, &d_result, &d_gpad, &d_in, &d_out, &d_nout, &d_segs, &d_tailkeys, &d_tailoff, &d_small, &d_hint, &d_rstate, &d_lut, &d_twork, &d_trect, &d_tctr, &d_dwork, &d_dctr, &d_ditems, &d_dhist, &d_dpatch, &d_scodes, &d_sids,
                           &d_msrc})
             b->release();
         if (own_stream) (void)hipStreamDestroy(own_stream);
@@ -247,6 +249,16 @@ struct orbfe_aruco {
             if ((rc = d_hint.ensure(16))) return rc;
             ORBFE_HIP(hipMemset(d_hint.p, 0, 16));
         }
+        {
+            const size_t items = (size_t)B * AR_MAX_RECTS;
+            if ((rc = d_dwork.ensure(items * 4)) || (rc = d_ditems.ensure(items * sizeof(DcItem))) || (rc = d_dhist.ensure(items * 512)) ||
+                (rc = d_dpatch.ensure(items * DC_PATCH_BYTES)))
+                return rc;
+        }
+        if (!d_dctr.p) {   // k_finalize leaves the counter at zero for the next batch
+            if ((rc = d_dctr.ensure(16))) return rc;
+            ORBFE_HIP(hipMemset(d_dctr.p, 0, 16));
+        }
         if (!d_tctr.p) {   // k_tail_finish leaves the two counters at zero for the next batch
             if ((rc = d_tctr.ensure(16))) return rc;
             ORBFE_HIP(hipMemset(d_tctr.p, 0, 16));
@@ -378,19 +390,37 @@ struct orbfe_aruco {
                            gpad_fu32, 0);
         timer.mark(s, "contours");
         ORBFE_HIP(hipGetLastError());
+        if (decode_dirty) ORBFE_HIP(hipMemsetAsync(d_dctr.p, 0, 16, s));   // a previous batch was abandoned between prefilter and finalize
+        decode_dirty = true;
         hipLaunchKernelGGL(k_prefilter, dim3(B), dim3(256), 0, s, d_rects.as<ArRect>(), AR_MAX_RECTS,
-                           d_counts.as<int32_t>(), cols, rows, win, d_candidx.as<int32_t>(), d_ncand.as<int32_t>());
+                           d_counts.as<int32_t>(), cols, rows, win, d_candidx.as<int32_t>(), d_ncand.as<int32_t>(),
+                           d_dwork.as<uint32_t>(), d_dctr.as<int32_t>());
         ORBFE_HIP(hipStreamWaitEvent(s, ev_join, 0));
-        for (int r_ = 0; r_ < ORBFE_REPS_ARUCO(2); r_++) hipLaunchKernelGGL(k_decode, dim3(B), dim3(DC_WAVES * 64), 0, s, src0, pyr, d_levels.as<ArLevel>(), npyr,
-                           d_rects.as<ArRect>(), AR_MAX_RECTS, d_candidx.as<int32_t>(), d_ncand.as<int32_t>(), S, nb,
-                           d_codes.as<unsigned long long>(), ncodes, d_scodes.as<unsigned long long>(), d_sids.as<int32_t>(), nsorted,
-                           max_corr, d_result.as<int32_t>(), cols);
+        {
+            // the batch's candidates as one work list: a wave per candidate (persistent: 32 candidates per frame is more than the
+            // streams here produce, a busier batch loops), 64 candidates per Otsu wave
+            const int max_items = B * AR_MAX_RECTS;
+            const int wgs = std::max(1, std::min((B * 32 + DC_WAVES - 1) / DC_WAVES, 4096));
+            for (int r_ = 0; r_ < ORBFE_REPS_ARUCO(2); r_++) {
+                hipLaunchKernelGGL(k_decode_warp, dim3(wgs), dim3(DC_WAVES * 64), 0, s, src0, pyr, d_levels.as<ArLevel>(), npyr,
+                                   d_rects.as<ArRect>(), AR_MAX_RECTS, d_candidx.as<int32_t>(), S, cols, d_dwork.as<uint32_t>(),
+                                   d_dctr.as<int32_t>(), d_ditems.as<DcItem>(), d_dhist.as<uint16_t>(), d_dpatch.as<uint8_t>());
+                hipLaunchKernelGGL(k_decode_otsu, dim3((max_items + 63) / 64), dim3(64), 0, s, d_dctr.as<int32_t>(), d_ditems.as<DcItem>(),
+                                   d_dhist.as<uint16_t>(), S);
+                hipLaunchKernelGGL(k_decode_vote, dim3(wgs), dim3(DC_WAVES * 64), 0, s, src0, pyr, d_levels.as<ArLevel>(), AR_MAX_RECTS, S, nb,
+                                   d_codes.as<unsigned long long>(), ncodes, d_scodes.as<unsigned long long>(), d_sids.as<int32_t>(),
+                                   nsorted, max_corr, d_dwork.as<uint32_t>(), d_dctr.as<int32_t>(), d_ditems.as<DcItem>(),
+                                   d_dpatch.as<uint8_t>(), d_result.as<int32_t>());
+            }
+        }
         timer.mark(s, "decode");
         for (int r_ = 0; r_ < ORBFE_REPS_ARUCO(4); r_++) hipLaunchKernelGGL(k_finalize, dim3(B), dim3(256), 0, s, d_rects.as<ArRect>(), AR_MAX_RECTS,
                            d_candidx.as<int32_t>(), d_ncand.as<int32_t>(), d_result.as<int32_t>(),
-                           d_pool.as<uint32_t>(), pool_fu32, d_out_m, capacity, d_n, corner_method == 1 ? 1 : 0, d_msrc.as<int32_t>());
+                           d_pool.as<uint32_t>(), pool_fu32, d_out_m, capacity, d_n, corner_method == 1 ? 1 : 0, d_msrc.as<int32_t>(),
+                           d_dctr.as<int32_t>());
         timer.mark(s, "finalize");
         ORBFE_HIP(hipGetLastError());
+        decode_dirty = false;   // k_finalize leaves the work-list length at zero
         return ORBFE_OK;
     }
 };

@@ -6,7 +6,7 @@
 //   k_contours            one workgroup per frame: bit image -> LDS, border starts, read-only border following,
 //                         length gate (> 70), approxPolyDP, 4-gon + convexity               (:3104-3556)
 //   k_prefilter           per frame: CCW orientation, near-duplicate and image-border filters  (:4347-5347)
-//   k_decode              per (frame, candidate): level pick, homography, 35x35 warp, Otsu, cell vote, dictionary
+//   k_decode_warp / _otsu / _vote   per candidate of the batch's work list: level pick, homography, 35x35 warp | Otsu | cell vote, dictionary
 //                                                                                            (:6448-6900, dictionary_based.cpp)
 //   k_finalize            per frame: rotate corners, sort by id, de-duplicate, contour-line corner refinement
 //                                                                                            (:6723-6858, :8140-8377, :8978-10044)
@@ -1879,7 +1879,7 @@ __device__ __forceinline__ int ar_perimeter(const float c[4][2])
 // prefilterCandidates: one workgroup (256 threads) per frame
 __global__ __launch_bounds__(256) void k_prefilter(ArRect* __restrict__ rects, int rect_cap, const int32_t* __restrict__ counts,
                                                    int W, int H, int too_near, int32_t* __restrict__ cand_idx,
-                                                   int32_t* __restrict__ ncand_out)
+                                                   int32_t* __restrict__ ncand_out, uint32_t* __restrict__ work, int32_t* __restrict__ wctr)
 {
     __builtin_amdgcn_s_setprio(2); // latency-bound: its few waves go first when a VALU-bound kernel shares the CU
     __shared__ int s_rm[AR_MAX_RECTS];
@@ -1934,6 +1934,12 @@ __global__ __launch_bounds__(256) void k_prefilter(ArRect* __restrict__ rects, i
         for (int i = 0; i < n; i++)
             if (!s_rm[i]) cand_idx[(size_t)f * rect_cap + m++] = i;
         ncand_out[f] = m;
+        // the batch's candidates as ONE work list for the decode kernels (frame << 16 | slot; any order: results go to
+        // (frame, slot)); k_finalize leaves the counter at zero for the next batch
+        if (m > 0) {
+            const int base = atomicAdd(wctr, m);
+            for (int i = 0; i < m; i++) work[base + i] = ((uint32_t)f << 16) | (uint32_t)i;
+        }
     }
 }
 
@@ -2016,20 +2022,16 @@ __device__ __forceinline__ bool solve8_wave(double a[8], double b, int lane, dou
     return true;
 }
 
-// One workgroup per frame, DC_WAVES waves; a wave takes the frame's candidates w, w + DC_WAVES, ...
-//   A (wave per candidate): pyramid level, homography (wave-parallel 8x8 elimination), warp -> histogram
-//   B (ONE LANE per candidate, all candidates of the frame in lockstep): getThreshVal_Otsu_8u.  Its running sums are
-//     serial by definition (every step rounds, and the gaps between the two clusters of a marker histogram are exact
-//     ties that the rounding noise decides), so each candidate needs ~256 dependent double divisions; side by side in
-//     the lanes of one wave they cost one candidate's latency for the whole frame.
-//   C (wave per candidate): warp again against the threshold -> cell votes, border check, 4 rotations, dictionary.
-#define DC_MAXC 32 // candidates handled per pass (the workgroup loops if a frame has more)
-#define DC_PXCAP 1232 // bytes per kept patch: 35 x 35, the warp size of every configuration the detector is used in here
-
-struct DcCand {
-    double Mi[9];
-    int lvl, ok;
-};
+// Decoding the rectangle candidates: three launches over ONE work list for the whole batch (k_prefilter builds it).  Until round 3
+// this was one workgroup of 8 waves and 76 KB of LDS per frame -- 136 us alone, 420 - 670 us next to the other engines' kernels,
+// most of it eight waves parked on a CU while one of them ran the serial Otsu recurrence.
+//   k_decode_warp  (wave per candidate, persistent waves): pyramid level, homography (wave-parallel 8x8 elimination), 1/32-px
+//                  fixed-point warp -> the S x S patch and its 256-bin histogram, both to HBM (they stay in L2)
+//   k_decode_otsu  (ONE LANE per candidate, 64 candidates of the batch side by side): getThreshVal_Otsu_8u.  Its running sums are
+//                  serial by definition (every step rounds, and the gaps between the two clusters of a marker histogram are
+//                  exact ties that the rounding noise decides): ~256 dependent double divisions per candidate
+//   k_decode_vote  (wave per candidate): the patch against the threshold -> cell votes, border check, 4 rotations, dictionary
+#define DC_PXCAP DC_PATCH_BYTES // bytes per kept patch: 35 x 35, the warp size of every configuration the detector is used in here
 
 __device__ __forceinline__ int dc_warp_pixel(const double* Mi, int y, int xx, const uint8_t* img, int pitch, int LW, int LH)
 {
@@ -2056,121 +2058,134 @@ __device__ __forceinline__ int dc_warp_pixel(const double* Mi, int y, int xx, co
     return v > 255 ? 255 : v;
 }
 
-__global__ __launch_bounds__(DC_WAVES * 64) void k_decode(ImgView src0, ImgView pyr, const ArLevel* __restrict__ levels,
-                                               int nlevels, const ArRect* __restrict__ rects, int rect_cap,
-                                               const int32_t* __restrict__ cand_idx,
-                                               const int32_t* __restrict__ ncand, int S, int nb,
-                                               const unsigned long long* __restrict__ codes, int ncodes,
-                                               const unsigned long long* __restrict__ scodes, const int32_t* __restrict__ sids,
-                                               int nsorted, int max_corr,
-                                               int32_t* __restrict__ result /*per slot: id, nrot*/, int W0)
+
+__global__ __launch_bounds__(DC_WAVES * 64) void k_decode_warp(ImgView src0, ImgView pyr, const ArLevel* __restrict__ levels, int nlevels,
+                                                               const ArRect* __restrict__ rects, int rect_cap,
+                                                               const int32_t* __restrict__ cand_idx, int S, int W0,
+                                                               const uint32_t* __restrict__ work, const int32_t* __restrict__ wctr,
+                                                               DcItem* __restrict__ items, uint16_t* __restrict__ hist,
+                                                               uint8_t* __restrict__ patch)
 {
-    __builtin_amdgcn_s_setprio(2); // latency-bound: its few waves go first when a VALU-bound kernel shares the CU
-    __shared__ uint32_t s_hist[DC_MAXC][257]; // 257: the Otsu lanes read their rows conflict-free
-    __shared__ DcCand s_cand[DC_MAXC];
-    __shared__ int s_th[DC_MAXC];
-    __shared__ int s_ones[DC_WAVES][64], s_tot[DC_WAVES][64];
-    __shared__ uint8_t s_bits[DC_WAVES][64];
-    __shared__ unsigned long long s_ids[DC_WAVES][4];
-    // the warped S x S patch of every candidate of the pass: phase C reads it back instead of warping again (per pixel three f64
-    // multiply-adds, an f64 division and four dependent byte loads); a warp size whose patch does not fit is warped twice as before
-    __shared__ uint8_t s_px[DC_MAXC][DC_PXCAP];
+    __shared__ uint32_t s_hist[DC_WAVES][256];
+    const int lane = threadIdx.x & 63, wid = wave_id();
+    const int nitems = wctr[0];
     const bool keep_px = S * S <= DC_PXCAP;
-    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int nc = ncand[f];
-    for (int c0 = 0; c0 < nc; c0 += DC_MAXC) {
-        const int ncp = min(DC_MAXC, nc - c0);
-        __syncthreads();
-        for (int i = tid; i < ncp * 257; i += DC_WAVES * 64) (&s_hist[0][0])[i] = 0;
-        __syncthreads();
-        // ---- A
-        for (int c = wid; c < ncp; c += DC_WAVES) {
-            const int slot = c0 + c;
-            const ArRect r = rects[(size_t)f * rect_cap + cand_idx[(size_t)f * rect_cap + slot]];
-            // pyramid level: largest p with area / 4^p >= S^2 (markerdetector_impl.cpp:6507-6586)
-            const float v01x = r.c[1][0] - r.c[0][0], v01y = r.c[1][1] - r.c[0][1];
-            const float v03x = r.c[3][0] - r.c[0][0], v03y = r.c[3][1] - r.c[0][1];
-            const float area1 = fabsf(__fsub_rn(__fmul_rn(v01x, v03y), __fmul_rn(v01y, v03x)));
-            const float v21x = r.c[1][0] - r.c[2][0], v21y = r.c[1][1] - r.c[2][1];
-            const float v23x = r.c[3][0] - r.c[2][0], v23y = r.c[3][1] - r.c[2][1];
-            const float area2 = fabsf(__fsub_rn(__fmul_rn(v21x, v23y), __fmul_rn(v21y, v23x)));
-            const float area = __fdiv_rn(__fadd_rn(area2, area1), 2.f);
-            const float desired = __fmul_rn((float)S, (float)S);
-            int lvl = 0;
-            double p4 = 4.0;
-            for (int p = 1; p < nlevels; p++, p4 *= 4.0) {
-                if ((double)area / p4 >= (double)desired) lvl = p;
-                else break;
-            }
-            const ArLevel L = levels[lvl];
-            const float ratio = __fdiv_rn((float)L.w, (float)W0);
-            // getPerspectiveTransform(quad -> (0,0),(S-1,0),(S-1,S-1),(0,S-1)): rows 0..3 = x equations, 4..7 = y equations
-            double a[8], bb = 0.0, x[8];
+    for (int it = blockIdx.x * DC_WAVES + wid; it < nitems; it += gridDim.x * DC_WAVES) {
+        const uint32_t wi = work[it];
+        const int f = (int)(wi >> 16), slot = (int)(wi & 0xffffu);
+        uint32_t* h = s_hist[wid];
+        h[lane] = 0; h[lane + 64] = 0; h[lane + 128] = 0; h[lane + 192] = 0;
+        const ArRect r = rects[(size_t)f * rect_cap + cand_idx[(size_t)f * rect_cap + slot]];
+        // pyramid level: largest p with area / 4^p >= S^2 (markerdetector_impl.cpp:6507-6586)
+        const float v01x = r.c[1][0] - r.c[0][0], v01y = r.c[1][1] - r.c[0][1];
+        const float v03x = r.c[3][0] - r.c[0][0], v03y = r.c[3][1] - r.c[0][1];
+        const float area1 = fabsf(__fsub_rn(__fmul_rn(v01x, v03y), __fmul_rn(v01y, v03x)));
+        const float v21x = r.c[1][0] - r.c[2][0], v21y = r.c[1][1] - r.c[2][1];
+        const float v23x = r.c[3][0] - r.c[2][0], v23y = r.c[3][1] - r.c[2][1];
+        const float area2 = fabsf(__fsub_rn(__fmul_rn(v21x, v23y), __fmul_rn(v21y, v23x)));
+        const float area = __fdiv_rn(__fadd_rn(area2, area1), 2.f);
+        const float desired = __fmul_rn((float)S, (float)S);
+        int lvl = 0;
+        double p4 = 4.0;
+        for (int p = 1; p < nlevels; p++, p4 *= 4.0) {
+            if ((double)area / p4 >= (double)desired) lvl = p;
+            else break;
+        }
+        const ArLevel L = levels[lvl];
+        const float ratio = __fdiv_rn((float)L.w, (float)W0);
+        // getPerspectiveTransform(quad -> (0,0),(S-1,0),(S-1,S-1),(0,S-1)): rows 0..3 = x equations, 4..7 = y equations
+        double a[8], bb = 0.0, x[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++) { a[k] = 0.0; x[k] = 0.0; }
-            if (lane < 8) {
-                const int i = lane & 3;
-                const float qx = __fmul_rn(r.c[i][0], ratio), qy = __fmul_rn(r.c[i][1], ratio);
-                const float dx = (i == 1 || i == 2) ? (float)(S - 1) : 0.f, dy = (i >= 2) ? (float)(S - 1) : 0.f;
-                if (lane < 4) {
-                    a[0] = qx; a[1] = qy; a[2] = 1.0;
-                    a[6] = -(double)qx * dx; a[7] = -(double)qy * dx;
-                    bb = dx;
-                } else {
-                    a[3] = qx; a[4] = qy; a[5] = 1.0;
-                    a[6] = -(double)qx * dy; a[7] = -(double)qy * dy;
-                    bb = dy;
-                }
-            }
-            bool ok = solve8_wave(a, bb, lane, x);
-            double Mi[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-            if (ok) {
-                const double M[9] = {x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7], 1.0};
-                const double det = M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) +
-                                   M[2] * (M[3] * M[7] - M[4] * M[6]);
-                if (det == 0.0) ok = false;
-                else {
-                    const double d = 1.0 / det;
-                    Mi[0] = (M[4] * M[8] - M[5] * M[7]) * d;
-                    Mi[1] = (M[2] * M[7] - M[1] * M[8]) * d;
-                    Mi[2] = (M[1] * M[5] - M[2] * M[4]) * d;
-                    Mi[3] = (M[5] * M[6] - M[3] * M[8]) * d;
-                    Mi[4] = (M[0] * M[8] - M[2] * M[6]) * d;
-                    Mi[5] = (M[2] * M[3] - M[0] * M[5]) * d;
-                    Mi[6] = (M[3] * M[7] - M[4] * M[6]) * d;
-                    Mi[7] = (M[1] * M[6] - M[0] * M[7]) * d;
-                    Mi[8] = (M[0] * M[4] - M[1] * M[3]) * d;
-                }
-            }
-            if (lane == 0) {
-#pragma unroll
-                for (int k = 0; k < 9; k++) s_cand[c].Mi[k] = Mi[k];
-                s_cand[c].lvl = lvl; s_cand[c].ok = ok ? 1 : 0;
-            }
-            if (ok) {
-                const uint8_t* img = (lvl == 0) ? src0.base + (size_t)f * src0.fstride : pyr.base + (size_t)f * pyr.fstride + L.off;
-                const int pitch = (lvl == 0) ? src0.pitch : L.pitch;
-                for (int i = lane; i < S * S; i += 64) {
-                    const int y = i / S, xx = i - y * S;
-                    const int v = dc_warp_pixel(Mi, y, xx, img, pitch, L.w, L.h);
-                    atomicAdd(&s_hist[c][v], 1u);
-                    if (keep_px) s_px[c][i] = (uint8_t)v;
-                }
+        for (int k = 0; k < 8; k++) { a[k] = 0.0; x[k] = 0.0; }
+        if (lane < 8) {
+            const int i = lane & 3;
+            const float qx = __fmul_rn(r.c[i][0], ratio), qy = __fmul_rn(r.c[i][1], ratio);
+            const float dx = (i == 1 || i == 2) ? (float)(S - 1) : 0.f, dy = (i >= 2) ? (float)(S - 1) : 0.f;
+            if (lane < 4) {
+                a[0] = qx; a[1] = qy; a[2] = 1.0;
+                a[6] = -(double)qx * dx; a[7] = -(double)qy * dx;
+                bb = dx;
+            } else {
+                a[3] = qx; a[4] = qy; a[5] = 1.0;
+                a[6] = -(double)qx * dy; a[7] = -(double)qy * dy;
+                bb = dy;
             }
         }
-        __syncthreads();
-        // ---- B: getThreshVal_Otsu_8u with exactly the reference's operation sequence, one lane per candidate
-        if (wid == 0 && lane < ncp) {
-            int max_val = 0;
-            if (s_cand[lane].ok) {
-                const uint32_t* h = s_hist[lane];
-                const int n = S * S;
-                double mu = 0, scale = 1. / n;
-                for (int i = 0; i < 256; i++) mu += i * (double)h[i];
-                mu *= scale;
-                double mu1 = 0, q1 = 0, max_sigma = 0;
-                for (int i = 0; i < 256; i++) {
-                    const double p_i = h[i] * scale;
+        bool ok = solve8_wave(a, bb, lane, x);
+        double Mi[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (ok) {
+            const double M[9] = {x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7], 1.0};
+            const double det = M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) +
+                               M[2] * (M[3] * M[7] - M[4] * M[6]);
+            if (det == 0.0) ok = false;
+            else {
+                const double d = 1.0 / det;
+                Mi[0] = (M[4] * M[8] - M[5] * M[7]) * d;
+                Mi[1] = (M[2] * M[7] - M[1] * M[8]) * d;
+                Mi[2] = (M[1] * M[5] - M[2] * M[4]) * d;
+                Mi[3] = (M[5] * M[6] - M[3] * M[8]) * d;
+                Mi[4] = (M[0] * M[8] - M[2] * M[6]) * d;
+                Mi[5] = (M[2] * M[3] - M[0] * M[5]) * d;
+                Mi[6] = (M[3] * M[7] - M[4] * M[6]) * d;
+                Mi[7] = (M[1] * M[6] - M[0] * M[7]) * d;
+                Mi[8] = (M[0] * M[4] - M[1] * M[3]) * d;
+            }
+        }
+        int isum = 0;
+        if (ok) {
+            const uint8_t* img = (lvl == 0) ? src0.base + (size_t)f * src0.fstride : pyr.base + (size_t)f * pyr.fstride + L.off;
+            const int pitch = (lvl == 0) ? src0.pitch : L.pitch;
+            uint8_t* po = patch + (size_t)it * DC_PXCAP;
+            for (int i = lane; i < S * S; i += 64) {
+                const int y = i / S, xx = i - y * S;
+                const int v = dc_warp_pixel(Mi, y, xx, img, pitch, L.w, L.h);
+                atomicAdd(&h[v], 1u);
+                if (keep_px) po[i] = (uint8_t)v;
+            }
+            __builtin_amdgcn_wave_barrier();
+            // the histogram as u16 (a bin holds at most S * S pixels; the host refuses S > 255) and its first moment, which is a sum
+            // of integers -- exact in double in any order, so the Otsu lane starts from it instead of walking the bins twice
+            const uint32_t h0 = h[4 * lane], h1 = h[4 * lane + 1], h2 = h[4 * lane + 2], h3 = h[4 * lane + 3];
+            reinterpret_cast<uint2*>(hist + (size_t)it * 256)[lane] = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+            isum = wave_sum((int)(h0 * (4 * lane) + h1 * (4 * lane + 1) + h2 * (4 * lane + 2) + h3 * (4 * lane + 3)));
+        }
+        if (lane == 0) {
+            DcItem* o = items + it;
+#pragma unroll
+            for (int k = 0; k < 9; k++) o->Mi[k] = Mi[k];
+            o->lvl = lvl; o->ok = ok ? 1 : 0; o->isum = isum; o->th = 0;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// getThreshVal_Otsu_8u with exactly the reference's operation sequence, one lane per candidate of the batch
+__global__ __launch_bounds__(64) void k_decode_otsu(const int32_t* __restrict__ wctr, DcItem* __restrict__ items,
+                                                    const uint16_t* __restrict__ hist, int S)
+{
+    __builtin_amdgcn_s_setprio(2); // latency-bound: one wave of serial f64 chains goes first when a VALU-bound kernel shares the CU
+    const int nitems = wctr[0];
+    const int it = blockIdx.x * 64 + threadIdx.x;
+    if (it >= nitems) return;
+    int max_val = 0;
+    if (items[it].ok) {
+        const uint4* hp = reinterpret_cast<const uint4*>(hist + (size_t)it * 256);
+        const int n = S * S;
+        const double scale = 1. / n;
+        const double mu = (double)items[it].isum * scale;
+        double mu1 = 0, q1 = 0, max_sigma = 0;
+        for (int i0 = 0; i0 < 256; i0 += 32) { // four 16-byte loads (32 bins) in flight per lane
+            uint4 hv[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) hv[k] = hp[i0 / 8 + k];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t w[4] = {hv[k].x, hv[k].y, hv[k].z, hv[k].w};
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int i = i0 + k * 8 + j;
+                    const uint32_t hi = (w[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
+                    const double p_i = hi * scale;
                     mu1 *= q1;
                     q1 += p_i;
                     const double q2 = 1. - q1;
@@ -2181,90 +2196,108 @@ __global__ __launch_bounds__(DC_WAVES * 64) void k_decode(ImgView src0, ImgView 
                     if (sigma > max_sigma) { max_sigma = sigma; max_val = i; }
                 }
             }
-            s_th[lane] = max_val;
         }
-        __syncthreads();
-        // ---- C
-        for (int c = wid; c < ncp; c += DC_WAVES) {
-            const int slot = c0 + c;
-            int32_t* res = result + ((size_t)f * rect_cap + slot) * 2;
-            if (!s_cand[c].ok) {
-                if (lane == 0) { res[0] = -1; res[1] = 0; }
-                continue;
-            }
-            double Mi[9];
+    }
+    items[it].th = max_val;
+}
+
+__global__ __launch_bounds__(DC_WAVES * 64) void k_decode_vote(ImgView src0, ImgView pyr, const ArLevel* __restrict__ levels, int rect_cap,
+                                                               int S, int nb, const unsigned long long* __restrict__ codes, int ncodes,
+                                                               const unsigned long long* __restrict__ scodes,
+                                                               const int32_t* __restrict__ sids, int nsorted, int max_corr,
+                                                               const uint32_t* __restrict__ work, const int32_t* __restrict__ wctr,
+                                                               const DcItem* __restrict__ items, const uint8_t* __restrict__ patch,
+                                                               int32_t* __restrict__ result /*per slot: id, nrot*/)
+{
+    __shared__ int s_ones[DC_WAVES][64], s_tot[DC_WAVES][64];
+    __shared__ uint8_t s_bits[DC_WAVES][64];
+    __shared__ unsigned long long s_ids[DC_WAVES][4];
+    const int lane = threadIdx.x & 63, wid = wave_id();
+    const int nitems = wctr[0];
+    const bool keep_px = S * S <= DC_PXCAP;
+    for (int it = blockIdx.x * DC_WAVES + wid; it < nitems; it += gridDim.x * DC_WAVES) {
+        const uint32_t wi = work[it];
+        const int f = (int)(wi >> 16), slot = (int)(wi & 0xffffu);
+        int32_t* res = result + ((size_t)f * rect_cap + slot) * 2;
+        const DcItem* ci = items + it;
+        if (!ci->ok) {
+            if (lane == 0) { res[0] = -1; res[1] = 0; }
+            continue;
+        }
+        double Mi[9];
 #pragma unroll
-            for (int k = 0; k < 9; k++) Mi[k] = s_cand[c].Mi[k];
-            const int lvl = s_cand[c].lvl;
-            const ArLevel L = levels[lvl];
-            const uint8_t* img = (lvl == 0) ? src0.base + (size_t)f * src0.fstride : pyr.base + (size_t)f * pyr.fstride + L.off;
-            const int pitch = (lvl == 0) ? src0.pitch : L.pitch;
-            s_ones[wid][lane] = 0;
-            s_tot[wid][lane] = 0;
-            __builtin_amdgcn_wave_barrier();
-            const int th = s_th[c], n = nb + 2;
-            for (int i = lane; i < S * S; i += 64) {
-                const int y = i / S, xx = i - y * S;
-                const int my = (int)__fdiv_rn(__fmul_rn((float)n, (float)y), (float)S);
-                const int mx = (int)__fdiv_rn(__fmul_rn((float)n, (float)xx), (float)S);
-                const int v = keep_px ? (int)s_px[c][i] : dc_warp_pixel(Mi, y, xx, img, pitch, L.w, L.h);
-                if (v > th) atomicAdd(&s_ones[wid][my * n + mx], 1);
-                atomicAdd(&s_tot[wid][my * n + mx], 1);
-            }
-            __builtin_amdgcn_wave_barrier();
-            // cell bits (n*n <= 64: one lane per cell), border must be black
-            const int cy = lane / n, cx = lane - cy * n;
-            const bool incell = lane < n * n;
-            const int bit = incell && (s_ones[wid][lane] > s_tot[wid][lane] / 2);
-            const bool border = incell && (cy == 0 || cy == n - 1 || cx == 0 || cx == n - 1);
-            s_bits[wid][lane] = (uint8_t)bit;
-            const bool bad = __ballot(border && bit) != 0ull;
-            __builtin_amdgcn_wave_barrier();
-            if (lane < 4) {
-                // code of the inner nb x nb matrix rotated `lane` times: rotate(out(i,j) = in(nb-1-j, i)) applied lane times
-                unsigned long long v = 0;
-                int bpos = 0;
-                for (int y = nb - 1; y >= 0; y--)
-                    for (int xx = nb - 1; xx >= 0; xx--) {
-                        int yy = y, xc = xx;
-                        for (int t = 0; t < lane; t++) { const int ny = nb - 1 - xc, nx = yy; yy = ny; xc = nx; }
-                        v |= (unsigned long long)s_bits[wid][(yy + 1) * n + (xc + 1)] << bpos++;
-                    }
-                s_ids[wid][lane] = v;
-            }
-            __builtin_amdgcn_wave_barrier();
-            int id = -1, nrot = 0;
-            if (!bad && s_ids[wid][0] != 0) {
-                // first rotation whose code is in the dictionary; id = first index holding that code (map.insert semantics)
-                // one pass over the dictionary for all four rotations (four passes, each a chain of cache round trips and a wave
-                // reduction, were a third of this kernel's time): key = rotation << 24 | index, the minimum is the answer
-                {
-                    const unsigned long long w0 = s_ids[wid][0], w1 = s_ids[wid][1], w2 = s_ids[wid][2], w3 = s_ids[wid][3];
-                    int best = 0x7fffffff;
-                    for (int i = lane; i < ncodes; i += 64) {
-                        const unsigned long long c = codes[i];
-                        const int k = c == w0 ? i : c == w1 ? (1 << 24) | i : c == w2 ? (2 << 24) | i : c == w3 ? (3 << 24) | i : 0x7fffffff;
-                        best = min(best, k);
-                    }
-                    best = wave_min(best);
-                    if (best != 0x7fffffff) { id = best & 0xffffff; nrot = best >> 24; }
-                }
-                if (id < 0 && max_corr > 0) {
-                    // error correction (dictionary_based.cpp:1423-1560): the dictionary's code map in ascending code order, the four
-                    // rotations inside, first entry closer than int(tau * error_correction_rate) bits wins.  scodes / sids = that map.
-                    int best = 0x7fffffff;
-                    for (int i = lane; i < nsorted && best == 0x7fffffff; i += 64) {
-                        const unsigned long long c = scodes[i];
-                        for (int rr = 0; rr < 4; rr++)
-                            if (__popcll(c ^ s_ids[wid][rr]) < max_corr) { best = i * 4 + rr; break; }
-                    }
-                    best = wave_min(best);
-                    if (best != 0x7fffffff) { id = sids[best >> 2]; nrot = best & 3; }
-                }
-            }
-            if (lane == 0) { res[0] = id; res[1] = nrot; }
-            __builtin_amdgcn_wave_barrier();
+        for (int k = 0; k < 9; k++) Mi[k] = ci->Mi[k];
+        const int lvl = ci->lvl;
+        const ArLevel L = levels[lvl];
+        const uint8_t* img = (lvl == 0) ? src0.base + (size_t)f * src0.fstride : pyr.base + (size_t)f * pyr.fstride + L.off;
+        const int pitch = (lvl == 0) ? src0.pitch : L.pitch;
+        const uint8_t* px = patch + (size_t)it * DC_PXCAP;
+        s_ones[wid][lane] = 0;
+        s_tot[wid][lane] = 0;
+        __builtin_amdgcn_wave_barrier();
+        const int th = ci->th, n = nb + 2;
+        for (int i = lane; i < S * S; i += 64) {
+            const int y = i / S, xx = i - y * S;
+            const int my = (int)__fdiv_rn(__fmul_rn((float)n, (float)y), (float)S);
+            const int mx = (int)__fdiv_rn(__fmul_rn((float)n, (float)xx), (float)S);
+            // the patch k_decode_warp kept; a warp size whose patch does not fit is warped again (per pixel three f64 multiply-adds,
+            // an f64 division and four dependent byte loads)
+            const int v = keep_px ? (int)px[i] : dc_warp_pixel(Mi, y, xx, img, pitch, L.w, L.h);
+            if (v > th) atomicAdd(&s_ones[wid][my * n + mx], 1);
+            atomicAdd(&s_tot[wid][my * n + mx], 1);
         }
+        __builtin_amdgcn_wave_barrier();
+        // cell bits (n*n <= 64: one lane per cell), border must be black
+        const int cy = lane / n, cx = lane - cy * n;
+        const bool incell = lane < n * n;
+        const int bit = incell && (s_ones[wid][lane] > s_tot[wid][lane] / 2);
+        const bool border = incell && (cy == 0 || cy == n - 1 || cx == 0 || cx == n - 1);
+        s_bits[wid][lane] = (uint8_t)bit;
+        const bool bad = __ballot(border && bit) != 0ull;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 4) {
+            // code of the inner nb x nb matrix rotated `lane` times: rotate(out(i,j) = in(nb-1-j, i)) applied lane times
+            unsigned long long v = 0;
+            int bpos = 0;
+            for (int y = nb - 1; y >= 0; y--)
+                for (int xx = nb - 1; xx >= 0; xx--) {
+                    int yy = y, xc = xx;
+                    for (int t = 0; t < lane; t++) { const int ny = nb - 1 - xc, nx = yy; yy = ny; xc = nx; }
+                    v |= (unsigned long long)s_bits[wid][(yy + 1) * n + (xc + 1)] << bpos++;
+                }
+            s_ids[wid][lane] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        int id = -1, nrot = 0;
+        if (!bad && s_ids[wid][0] != 0) {
+            // first rotation whose code is in the dictionary; id = first index holding that code (map.insert semantics)
+            // one pass over the dictionary for all four rotations: key = rotation << 24 | index, the minimum is the answer
+            {
+                const unsigned long long w0 = s_ids[wid][0], w1 = s_ids[wid][1], w2 = s_ids[wid][2], w3 = s_ids[wid][3];
+                int best = 0x7fffffff;
+                for (int i = lane; i < ncodes; i += 64) {
+                    const unsigned long long c = codes[i];
+                    const int k = c == w0 ? i : c == w1 ? (1 << 24) | i : c == w2 ? (2 << 24) | i : c == w3 ? (3 << 24) | i : 0x7fffffff;
+                    best = min(best, k);
+                }
+                best = wave_min(best);
+                if (best != 0x7fffffff) { id = best & 0xffffff; nrot = best >> 24; }
+            }
+            if (id < 0 && max_corr > 0) {
+                // error correction (dictionary_based.cpp:1423-1560): the dictionary's code map in ascending code order, the four
+                // rotations inside, first entry closer than int(tau * error_correction_rate) bits wins.  scodes / sids = that map.
+                int best = 0x7fffffff;
+                for (int i = lane; i < nsorted && best == 0x7fffffff; i += 64) {
+                    const unsigned long long c = scodes[i];
+                    for (int rr = 0; rr < 4; rr++)
+                        if (__popcll(c ^ s_ids[wid][rr]) < max_corr) { best = i * 4 + rr; break; }
+                }
+                best = wave_min(best);
+                if (best != 0x7fffffff) { id = sids[best >> 2]; nrot = best & 3; }
+            }
+        }
+        if (lane == 0) { res[0] = id; res[1] = nrot; }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -2293,7 +2326,8 @@ __global__ __launch_bounds__(256) void k_finalize(const ArRect* __restrict__ rec
                                                   const uint32_t* __restrict__ pool, size_t pool_fstride,
                                                   orbfe_marker* __restrict__ out, int out_cap,
                                                   int32_t* __restrict__ n_out, int refine_lines,
-                                                  int32_t* __restrict__ out_src /*per output slot: its rectangle (contour)*/)
+                                                  int32_t* __restrict__ out_src /*per output slot: its rectangle (contour)*/,
+                                                  int32_t* __restrict__ wctr)
 {
     __builtin_amdgcn_s_setprio(2); // latency-bound: its few waves go first when a VALU-bound kernel shares the CU
     __shared__ int s_id[AR_MAX_RECTS], s_src[AR_MAX_RECTS], s_rot[AR_MAX_RECTS], s_per[AR_MAX_RECTS], s_rm[AR_MAX_RECTS];
@@ -2303,6 +2337,7 @@ __global__ __launch_bounds__(256) void k_finalize(const ArRect* __restrict__ rec
     const int f = blockIdx.x, tid = threadIdx.x;
     const int nc = ncand[f];
     const ArRect* R = rects + (size_t)f * rect_cap;
+    if (f == 0 && tid == 0) wctr[0] = 0; // every consumer of this batch's decode work list is done: ready for the next batch
     for (int i = tid; i < AR_MAX_RECTS; i += blockDim.x) out_src[(size_t)f * AR_MAX_RECTS + i] = -1; // slot holds no marker (the
     if (tid == 0) {                                                                                    // workgroup barriers below order it)
         // detected markers in candidate order, corners rotated by 4 - nRot (:6723-6823), then a stable sort by id

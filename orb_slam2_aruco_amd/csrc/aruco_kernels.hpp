@@ -74,13 +74,24 @@ __global__ void k_tail_approx(int kcap, const uint4* work, size_t work_half, con
 __global__ void k_tail_finish(int kcap, const uint8_t* rectflag, const ArKept* kept_out, int kept_cap, ArRect* rects_out, int rect_cap,
                               int32_t* counts, int32_t* ctr);
 __global__ void k_prefilter(ArRect* rects, int rect_cap, const int32_t* counts, int W, int H, int too_near,
-                            int32_t* cand_idx, int32_t* ncand_out);
-__global__ void k_decode(ImgView src0, ImgView pyr, const ArLevel* levels, int nlevels, const ArRect* rects,
-                         int rect_cap, const int32_t* cand_idx, const int32_t* ncand, int S, int nb,
-                         const unsigned long long* codes, int ncodes, const unsigned long long* scodes, const int32_t* sids, int nsorted, int max_corr, int32_t* result, int W0);
+                            int32_t* cand_idx, int32_t* ncand_out, uint32_t* work, int32_t* wctr);
+struct DcItem { // one rectangle candidate between the decode kernels
+    double Mi[9]; // inverse homography of the warp
+    int lvl, ok;  // pyramid level; 0 = singular system
+    int isum, th; // first moment of the patch histogram; Otsu threshold
+};
+__global__ void k_decode_warp(ImgView src0, ImgView pyr, const ArLevel* levels, int nlevels, const ArRect* rects, int rect_cap,
+                              const int32_t* cand_idx, int S, int W0, const uint32_t* work, const int32_t* wctr, DcItem* items,
+                              uint16_t* hist, uint8_t* patch);
+__global__ void k_decode_otsu(const int32_t* wctr, DcItem* items, const uint16_t* hist, int S);
+__global__ void k_decode_vote(ImgView src0, ImgView pyr, const ArLevel* levels, int rect_cap, int S, int nb,
+                              const unsigned long long* codes, int ncodes, const unsigned long long* scodes, const int32_t* sids,
+                              int nsorted, int max_corr, const uint32_t* work, const int32_t* wctr, const DcItem* items,
+                              const uint8_t* patch, int32_t* result);
 __global__ void k_finalize(const ArRect* rects, int rect_cap, const int32_t* cand_idx, const int32_t* ncand,
                            const int32_t* result, const uint32_t* pool, size_t pool_fstride, orbfe_marker* out,
-                           int out_cap, int32_t* n_out, int refine_lines, int32_t* out_src);
+                           int out_cap, int32_t* n_out, int refine_lines, int32_t* out_src, int32_t* wctr);
+#define DC_PATCH_BYTES 1232   // = DC_PXCAP of aruco_kernels.hip: bytes per kept patch
 
 #define CT_THREADS 256          // threads that run the whole kernel
 #define CT_WAVES (CT_THREADS / 64)
@@ -90,7 +101,7 @@ __global__ void k_finalize(const ArRect* rects, int rect_cap, const int32_t* can
 #define CT_PROBE 24 // steps a border start is followed before it is queued as a long walk (< the 70-point gate)
 
 #ifndef DC_WAVES
-#define DC_WAVES 8   // k_decode: waves per frame (one candidate per wave at a time)
+#define DC_WAVES 4   // k_decode_warp / _vote: waves per workgroup (a candidate per wave)
 #endif
 #ifndef RL_THREADS
 #define RL_THREADS 512   // 8 waves per frame: measured against 1024 (contours alone 713 -> 640 us per 300 frames, step 2.00 -> 1.95 ms) and 256 (893 us)

@@ -43,10 +43,10 @@ stage = {
     "resize": named("k_resize_tab"), "fast_cells": named("k_fast_cells"),
     "distribute": named("k_distribute_pyr", "k_distribute", "k_level_offsets"), "blur7": named("k_blur7"),
     "orient_describe": named("k_orient_describe"), "knn2": named("k_knn2_mfma", "k_knn2_tiles", "k_knn2_merge"),
-    "search_init": named("k_search_init"),
+    "search_init": named("k_search_init", "k_sfi_grid", "k_sfi_rows", "k_sfi_accept"),
     "aruco_threshold": named("k_adaptive_threshold_t", "k_adaptive_threshold"), "aruco_pyramid": named("k_half_area", "k_half_area4", "k_resize_level"),
     "aruco_contours": [k for k in s if k.startswith("k_contours") or k.startswith("k_tail_")],
-    "aruco_decode": named("k_prefilter", "k_decode"), "aruco_finalize": named("k_finalize", "k_marker_poses"),
+    "aruco_decode": named("k_prefilter", "k_decode", "k_decode_warp", "k_decode_otsu", "k_decode_vote"), "aruco_finalize": named("k_finalize", "k_marker_poses"),
 }
 traffic = {"_note": "HBM-side bytes per launch (%s batch) = (FETCH_SIZE / f_read + WRITE_SIZE / f_write) * 1024 from separate rocprofv3 --pmc "
                     "passes (tools/pmc.py; --kernel-trace only), per-dispatch mean x launches per step (profiles/%s_pmc_summary.json), summed "
