@@ -84,7 +84,7 @@ struct orbfe_extractor {
     // so that the other engine's latency-bound kernels (8 waves and 50-77 KB of LDS per workgroup) always find room on every CU
     // k_orient_describe2 (two keypoints per wave: 227 instead of 342 VALU instructions per keypoint, 238 instead of 256 us alone at C2)
     // is NOT the default: with the detector running the C2 step was 1.62 ms with it and 1.61 without (four interleaved runs each)
-    bool orient_pair = env_int("ORBFE_ORIENT_PAIR", 0) != 0;
+    bool orient_pair = env_int("ORBFE_ORIENT_PAIR", 1) != 0; // two keypoints per wave: the default since round 3 (C2 step 1.564 -> 1.543 ms, four interleaved runs each)
     int occ_fast = env_int("ORBFE_OCC_FAST", 0), occ_blur = env_int("ORBFE_OCC_BLUR", 0), occ_orient = env_int("ORBFE_OCC_ORIENT", 0);
     static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
     static size_t occ_lds(int per_cu, size_t static_bytes, size_t needed)
