@@ -171,7 +171,7 @@ def load_profile(name, config):
 # what bounds each stage (from the PMC counters of tools/pmc.py): "hbm" = streaming, traffic ~ algorithmic
 # bytes; "valu" = the launch needs (almost) its whole duration just to issue its VALU instructions; "latency" = serial
 # dependent chains (border following, quadtree rounds, the coupled accept loops) that neither bandwidth nor issue bounds
-STAGE_BOUND = {"resize": "hbm", "blur7": "valu", "fast_cells": "valu", "distribute": "latency", "orient_describe": "valu",
+STAGE_BOUND = {"resize": "hbm", "blur7": "valu", "fast_cells": "valu", "fast_cells_l0": "valu", "distribute": "latency", "orient_describe": "valu",
                "knn2": "mfma", "search_init": "latency", "aruco_pyramid": "hbm", "aruco_threshold": "valu",
                "aruco_contours": "latency", "aruco_decode": "latency", "aruco_finalize": "latency"}
 
@@ -343,7 +343,7 @@ def main():
     # line a diagnostic (value null) unless they spell the default
     env_set = {k: v for k, v in sorted(os.environ.items()) if k.startswith("ORBFE_")}
     harmless = {"ORBFE_BENCH_DEVICE", "ORBFE_BENCH_BACKEND", "ORBFE_LIB"}
-    defaults = {"ORBFE_ORIENT_PAIR": "1", "ORBFE_STREAM_PRIO": "0,0,0", "ORBFE_ENGINE_SETS": "1", "ORBFE_ENGINE_SETS_ARUCO": "1",
+    defaults = {"ORBFE_ORIENT_PAIR": "1", "ORBFE_FAST0": "0", "ORBFE_EARLY_SHARED": "0", "ORBFE_STREAM_PRIO": "0,0,0", "ORBFE_ENGINE_SETS": "1", "ORBFE_ENGINE_SETS_ARUCO": "1",
                 "ORBFE_BLUR_PLACE": "1", "ORBFE_ARUCO_RELAY_CHUNK": "0", "ORBFE_OCC_FAST": "0", "ORBFE_OCC_BLUR": "0",
                 "ORBFE_OCC_ORIENT": "0"}
     env_nondefault = {k: v for k, v in env_set.items() if k not in harmless and defaults.get(k) != v}
@@ -444,8 +444,8 @@ def main():
                         "every frame, byte for byte"}
 
     if rank == 0:
-        stages = {nm: float(v) for nm, v in zip(binding.ORBextractor.STAGES, orb_us)}   # blur7 runs on a second stream
-        stages_last = {nm: float(v) for nm, v in zip(binding.ORBextractor.STAGES, orb_us_last)}
+        stages = {nm: float(v) for nm, v in zip(binding.ORBextractor.stage_names(len(orb_us)), orb_us)}   # blur7 runs on a second stream
+        stages_last = {nm: float(v) for nm, v in zip(binding.ORBextractor.stage_names(len(orb_us_last)), orb_us_last)}
         if use_orb:
             stages["knn2"], stages["search_init"] = pipe.matching_times_us(median=True)
             stages_last["knn2"], stages_last["search_init"] = pipe.matching_times_us()
@@ -460,7 +460,8 @@ def main():
         sumP, P0 = sum(P), P[0]
         N = float(rec["n"].mean()) if use_orb else 0.0
         Ncand = 24.0          # rectangle candidates decoded per frame, upper end of what the synthetic streams produce
-        alg = {"resize": (sumP - P[-1]) + (sumP - P0), "fast_cells": sumP, "blur7": 2 * sumP,
+        l0_split = "fast_cells_l0" in stages
+        alg = {"resize": (sumP - P[-1]) + (sumP - P0), "fast_cells": sumP - P0 if l0_split else sumP, "fast_cells_l0": P0, "blur7": 2 * sumP,
                "orient_describe": N * (749 + 512 + 60), "distribute": N * 8,
                "knn2": 2 * N * 32 + N * 12, "search_init": 2 * N * (32 + 28) + N * 4}
         if use_aruco:
@@ -475,17 +476,22 @@ def main():
         prof_id = lambda d: ({"file": d.get("_file"), "profile": d.get("_profile"), "library_commit": d.get("_commit"),
                               "library_sha16": d.get("_library_sha16")} if d else None)
         per_stage = {}
+        # the two FAST launches (level 0 early, levels >= 1 after the resize chain) are one kernel in the profiles: its counters are
+        # shared out by pixels
+        share = {"fast_cells_l0": ("fast_cells", P0 / float(sumP)), "fast_cells": ("fast_cells", 1.0 - P0 / float(sumP))} if l0_split else {}
         for k, us in stages.items():
             ab = alg.get(k, 0) * fl(k)
             ent = {"bound": STAGE_BOUND.get(k, "latency"), "launch_us": us, "algorithmic_bytes_per_launch": ab,
                    "GBps": ab / (us * 1e-6) / 1e9 if us > 0 else 0.0}
             ent["hbm_frac"] = ent["GBps"] / HBM_PEAK_GBPS
-            ent["traffic"] = traffic.get(k) if traffic else None
-            if pmc and k in pmc:    # VALU issue time of the stage's launches (instruction counts x 4 cycles / 1024 SIMDs / 2.4 GHz)
-                ent["valu_us"] = pmc[k].get("valu_us")
+            pk, frac_of = share.get(k, (k, 1.0))
+            ent["traffic"] = (traffic.get(pk) * frac_of if traffic.get(pk) is not None else None) if traffic else None
+            if pmc and pk in pmc:    # VALU issue time of the stage's launches (instruction counts x 4 cycles / 1024 SIMDs / 2.4 GHz)
+                vu = pmc[pk].get("valu_us")
+                ent["valu_us"] = vu * frac_of if vu is not None else None
                 # profile-run numerator over this run's denominator: an estimate, valid while the kernels are the profiled ones
-                ent["valu_frac"] = pmc[k]["valu_us"] / us if us > 0 and pmc[k].get("valu_us") is not None else None
-                ent["lane_utilisation"] = pmc[k].get("lane_utilisation")
+                ent["valu_frac"] = ent["valu_us"] / us if us > 0 and vu is not None else None
+                ent["lane_utilisation"] = pmc[pk].get("lane_utilisation")
             per_stage[k] = ent
         # The dominant kernel.  The step is bound by VALU issue with all engines overlapped, so where the
         # committed PMC profile of this configuration is available it is the stage that takes most of that resource -- the same

@@ -27,7 +27,7 @@ SYMBOLS = [
     "orbfe_extractor_max_keypoints", "orbfe_extract", "orbfe_extract_batch", "orbfe_extract_batch_device",
     "orbfe_extractor_batch_status", "orbfe_search_for_initialization_batch_status", "orbfe_extractor_set_gaussian_taps",
     "orbfe_extractor_debug_level_size", "orbfe_extractor_debug_level_image",
-    "orbfe_extractor_debug_level_keypoints", "orbfe_extractor_debug_kernel_times", "orbfe_extractor_set_aux_stream",
+    "orbfe_extractor_debug_level_keypoints", "orbfe_extractor_debug_kernel_times", "orbfe_extractor_set_aux_stream", "orbfe_extractor_set_early_stream",
     "orbfe_debug_control", "orbfe_hamming", "orbfe_three_maxima", "orbfe_epipolar_distance_ok", "orbfe_knn2", "orbfe_knn2_csr", "orbfe_knn2_batch_device", "orbfe_search_for_initialization",
     "orbfe_search_for_initialization_batch_device", "orbfe_search_by_projection",
     "orbfe_undistort_points", "orbfe_undistort_keypoints_batch_device", "orbfe_compute_image_bounds",
@@ -85,6 +85,7 @@ def load():
     L.orbfe_extractor_debug_level_image.argtypes = [vp, i32, i32, i32, vp]
     L.orbfe_extractor_debug_level_keypoints.argtypes = [vp, i32, i32, i32, vp, i32, vp]
     L.orbfe_extractor_debug_kernel_times.argtypes = [vp, vp, i32]
+    L.orbfe_extractor_set_early_stream.argtypes = [vp, vp]
     L.orbfe_extractor_set_aux_stream.argtypes = [vp, vp]
     if hasattr(L, "orbfe_knn2"):
         L.orbfe_debug_control.argtypes = [C.c_char_p, i32]
@@ -289,6 +290,10 @@ class ORBextractor:
         """Run the extractor's forked launch (blur) on the caller's stream (None: the handle's own)."""
         _check(self.L, self.L.orbfe_extractor_set_aux_stream(self.h, stream_ptr), "set_aux_stream")
 
+    def set_early_stream(self, stream_ptr):
+        """Run the extractor's launch that needs no pyramid (FAST of level 0) on the caller's stream (None: the handle's own)."""
+        _check(self.L, self.L.orbfe_extractor_set_early_stream(self.h, stream_ptr), "set_early_stream")
+
     def enable_kernel_timing(self, on=True):
         self.L.orbfe_extractor_debug_kernel_times(self.h, None, int(on))
 
@@ -308,6 +313,13 @@ class ORBextractor:
 
     # order of kernel_times_us(); blur7 runs on the extractor's second stream, concurrently with fast_cells + distribute
     STAGES = ["resize", "blur7", "fast_cells", "distribute", "orient_describe"]
+    # with FAST of level 0 on its own stream from the start of the batch (the default): its interval comes first, and
+    # "fast_cells" is the launch over levels >= 1
+    STAGES_L0 = ["fast_cells_l0"] + STAGES
+
+    @classmethod
+    def stage_names(cls, n):
+        return cls.STAGES_L0 if n == len(cls.STAGES_L0) else cls.STAGES
 
     def kernel_times_us(self, median=False):
         """Stage times of the last batch, or (median=True) the per-stage median over the batches since timing was enabled."""

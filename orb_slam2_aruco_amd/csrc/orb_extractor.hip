@@ -66,7 +66,12 @@ struct orbfe_extractor {
     int device = 0;
     hipStream_t own_stream = nullptr, aux_stream = nullptr;
     hipStream_t user_aux = nullptr; // orbfe_extractor_set_aux_stream: run the blur there instead of on aux_stream
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t user_early = nullptr; // orbfe_extractor_set_early_stream: FAST of level 0 there instead of on aux_stream
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork0 = nullptr, ev_join0 = nullptr;
+    // FAST of level 0 from the start of the batch, next to the resize chain: 0 off (default), 1 on the handle's second stream (or the one
+    // named by orbfe_extractor_set_early_stream), 2 on the lent one.  Measured in round 3 (profiles/r03_fast0_early.txt): the launch
+    // does overlap the resize chain, but the C2 step does not move (1.5365 ms either way) -- the chip was issue-bound there already
+    int fast0_mode = env_int("ORBFE_FAST0", 0);
     int rows = 0, cols = 0; // geometry currently built
     int batch_cap = 0;
     std::vector<LevelGeom> geom;
@@ -112,6 +117,8 @@ struct orbfe_extractor {
         if (aux_stream) (void)hipStreamDestroy(aux_stream);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
+        if (ev_fork0) (void)hipEventDestroy(ev_fork0);
+        if (ev_join0) (void)hipEventDestroy(ev_join0);
     }
 
     // ORBextractor::ORBextractor, src/ORBextractor.cc:410-470
@@ -373,6 +380,37 @@ struct orbfe_extractor {
         last_src0 = src0;
         timer.begin();
         timer.mark(s, "start");
+        auto launch_fast = [&](hipStream_t st, int cell_base, int cell_end) -> int {
+            if (cell_end <= cell_base) return ORBFE_OK;
+            // LDS per wave: ROI (cell + 6), score map (cell + 2), one u16 list of cell pixels
+            const int roi_pitch = align_up(max_wcell + 6 + 4, 4) + 8, roi_rows = max_hcell + 6; // +1 byte shift, +2 dwords read past a row (8-pixel groups)
+            const int map_pitch = max_wcell + 2, map_rows = max_hcell + 2;
+            const int list_cap = max_wcell * max_hcell;
+            auto a16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+            const size_t lds = 4 * (a16((size_t)roi_pitch * roi_rows) + a16((size_t)map_pitch * map_rows) +
+                                    a16((size_t)list_cap * 2));
+            const size_t lds_fast = occ_lds(occ_fast, 0, lds);
+            { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(&k_fast_cells), (size_t)(lds_fast)); if (rc_lds_) return rc_lds_; }
+            const int nx = (cell_end - cell_base + 3) / 4;
+            for (int r_ = 0; r_ < ORBFE_REPS_ORB(1); r_++) hipLaunchKernelGGL(k_fast_cells, dim3(xcd_grid(nx * B)), dim3(256), lds_fast, st, src0, pyr, dg,
+                               d_cellinfo.as<uint32_t>(), d_slots.as<uint32_t>(), slots_fu32,
+                               d_cellcnt.as<int32_t>(), ncells_total, iniThFAST, minThFAST, roi_pitch, roi_rows,
+                               map_pitch, map_rows, list_cap, nx, nx * B, cell_base, cell_end);
+            return ORBFE_OK;
+        };
+        // Level 0 needs no resize: its cells (a third of all pixels) can be searched on a stream of their own from the start of the
+        // batch, next to the resize chain instead of behind it (fast0_mode; off by default, see there).
+        const int ncells_l0 = nlevels > 1 ? geom[1].cell_first : ncells_total;
+        const bool fast0 = fast0_mode != 0 && nlevels > 1 && blur_place != 2;
+        hipStream_t fast0_stream = user_early ? user_early : fast0_mode == 2 && user_aux ? user_aux : this->aux_stream;
+        if (fast0) {
+            ORBFE_HIP(hipEventRecord(ev_fork0, s));
+            ORBFE_HIP(hipStreamWaitEvent(fast0_stream, ev_fork0, 0));
+            timer.mark(fast0_stream, "fast_cells level 0 starts", true);
+            if ((rc = launch_fast(fast0_stream, 0, ncells_l0))) return rc;
+            timer.mark(fast0_stream, "fast_cells_l0");
+            ORBFE_HIP(hipEventRecord(ev_join0, fast0_stream));
+        }
         for (int r16_ = 0; r16_ < ORBFE_REPS_ORB(16); r16_++)
         for (int l = 1; l < nlevels; l++) {
             const LevelGeom& g = geom[l];
@@ -424,25 +462,9 @@ struct orbfe_extractor {
             return ORBFE_OK;
         };
         if (blur_place == 1) { int rcb = launch_blur(); if (rcb) return rcb; }
-        {
-            // LDS per wave: ROI (cell + 6), score map (cell + 2), one u16 list of cell pixels
-            const int roi_pitch = align_up(max_wcell + 6 + 4, 4) + 8, roi_rows = max_hcell + 6; // +1 byte shift, +2 dwords read past a row (8-pixel groups)
-            const int map_pitch = max_wcell + 2, map_rows = max_hcell + 2;
-            const int list_cap = max_wcell * max_hcell;
-            auto a16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
-            const size_t lds = 4 * (a16((size_t)roi_pitch * roi_rows) + a16((size_t)map_pitch * map_rows) +
-                                    a16((size_t)list_cap * 2));
-            const size_t lds_need = lds;
-            (void)lds_need;
-            const size_t lds_fast = occ_lds(occ_fast, 0, lds);
-            { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(&k_fast_cells), (size_t)(lds_fast)); if (rc_lds_) return rc_lds_; }
-            const int nx = (ncells_total + 3) / 4;
-            for (int r_ = 0; r_ < ORBFE_REPS_ORB(1); r_++) hipLaunchKernelGGL(k_fast_cells, dim3(xcd_grid(nx * B)), dim3(256), lds_fast, s, src0, pyr, dg,
-                               d_cellinfo.as<uint32_t>(), d_slots.as<uint32_t>(), slots_fu32,
-                               d_cellcnt.as<int32_t>(), ncells_total, iniThFAST, minThFAST, roi_pitch, roi_rows,
-                               map_pitch, map_rows, list_cap, nx, nx * B);
-        }
+        if ((rc = launch_fast(s, fast0 ? ncells_l0 : 0, ncells_total))) return rc;
         timer.mark(s, "fast_cells");
+        if (fast0) ORBFE_HIP(hipStreamWaitEvent(s, ev_join0, 0));
         if (blur_place == 0) { int rcb = launch_blur(); if (rcb) return rcb; }
         {
             // fast path: count-pyramid quadtree (no keypoint movement); general kernel only for flagged levels
@@ -528,7 +550,9 @@ orbfe_extractor* orbfe_extractor_create(int nfeatures, float scaleFactor, int nl
     h->build_tables();
     if (hipStreamCreate(&h->own_stream) != hipSuccess || hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess || h->upload_describe_tables() != ORBFE_OK) {
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fork0, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join0, hipEventDisableTiming) != hipSuccess || h->upload_describe_tables() != ORBFE_OK) {
         fail(ORBFE_ERR_HIP, "extractor device initialisation failed");
         delete h;
         return nullptr;
@@ -724,6 +748,13 @@ int orbfe_extractor_set_aux_stream(orbfe_extractor* h, void* stream)
 {
     if (!h) return fail(ORBFE_ERR_INVALID, "null handle");
     h->user_aux = (hipStream_t)stream;
+    return ORBFE_OK;
+}
+
+int orbfe_extractor_set_early_stream(orbfe_extractor* h, void* stream)
+{
+    if (!h) return fail(ORBFE_ERR_INVALID, "null handle");
+    h->user_early = (hipStream_t)stream;
     return ORBFE_OK;
 }
 

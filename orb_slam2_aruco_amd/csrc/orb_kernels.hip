@@ -256,7 +256,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(ImgView src0, ImgView pyr, c
                                                     const uint32_t* __restrict__ cellinfo, uint32_t* __restrict__ slots,
                                                     size_t slots_fstride, int32_t* __restrict__ cellcnt,
                                                     int ncells_total, int iniTh, int minTh, int roi_pitch, int roi_rows,
-                                                    int map_pitch, int map_rows, int list_cap, int nx, int total)
+                                                    int map_pitch, int map_rows, int list_cap, int nx, int total,
+                                                    int cell_base, int cell_end /* this launch covers cells [cell_base, cell_end) */)
 {
     extern __shared__ __align__(16) unsigned char fc_smem[];
 #ifdef FC_VGPR_TOP
@@ -267,8 +268,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(ImgView src0, ImgView pyr, c
     const int lane = threadIdx.x & 63, wid = wave_id();
     int bx, f;
     if (!xcd_remap(nx, total, bx, f)) return;
-    const int cell = bx * 4 + wid;
-    if (cell >= ncells_total) return;
+    const int cell = cell_base + bx * 4 + wid;
+    if (cell >= cell_end) return;
     const size_t roi_bytes = ((size_t)roi_pitch * roi_rows + 15) & ~(size_t)15;
     const size_t map_bytes = ((size_t)map_pitch * map_rows + 15) & ~(size_t)15;
     const size_t per_wave = roi_bytes + map_bytes + (((size_t)list_cap * 2 + 15) & ~(size_t)15);

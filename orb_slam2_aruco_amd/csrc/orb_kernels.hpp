@@ -65,7 +65,8 @@ __global__ void k_resize_tab(ImgView src, ImgView dst, int sw, int sh, int dw4, 
                              const int* xal, const int* yofs, const int* ybe, int nx, int total);
 __global__ void k_fast_cells(ImgView src0, ImgView pyr, const LevelGeom* geom, const uint32_t* cellinfo,
                              uint32_t* slots, size_t slots_fstride, int32_t* cellcnt, int ncells_total, int iniTh,
-                             int minTh, int roi_pitch, int roi_rows, int map_pitch, int map_rows, int list_cap, int nx, int total);
+                             int minTh, int roi_pitch, int roi_rows, int map_pitch, int map_rows, int list_cap, int nx, int total,
+                             int cell_base, int cell_end);
 __global__ void k_distribute(const LevelGeom* geom, const uint32_t* slots, size_t slots_fstride,
                              const int32_t* cellcnt, int ncells_total, uint32_t* keyscratch, size_t keys_fstride,
                              uint32_t* lvl_out, int out_fstride, int32_t* lvl_cnt, int nlevels, int32_t* lvl_ncand,

@@ -148,6 +148,15 @@ class FrontEndPipeline:
             # launch (the blur) is lent the matching stream; measured against the handle's own fork stream and against one
             # shared fork stream for both engines: 2.02 vs 2.12 vs 2.14 ms per step.
             self.ex.set_aux_stream(self.sp3)
+            # The fourth queue: the detector's /2 pyramid (~100 us per batch) and the extractor's FAST of level 0 (~120 us), both
+            # wanted at the start of a batch and both independent of everything else, share one stream -- a fifth stream would
+            # share a hardware queue with a busy one (measured: FAST of level 0 ran behind the whole detector chain).
+            # Experiment (ORBFE_FAST0=1 ORBFE_EARLY_SHARED=1): no gain, off by default.
+            if use_aruco and use_orb and os.environ.get("ORBFE_EARLY_SHARED", "0") != "0":
+                self.stream4 = torch.cuda.Stream(dev)
+                self.sp4 = ctypes.c_void_p(self.stream4.cuda_stream)
+                self.det.set_aux_stream(self.sp4)
+                self.ex.set_early_stream(self.sp4)
         ev = lambda **kw: torch.cuda.Event(**kw)
         self.ex_done = [[ev() for _ in range(S)] for _ in range(2)]
         self.det_done = [[ev() for _ in range(S)] for _ in range(2)]
