@@ -35,6 +35,7 @@ struct orbfe_aruco {
     DevBuf d_segs, d_tailkeys, d_tailoff, d_small, d_hint; // d_hint: the relay kernel's grid spacing of the previous batch
     int relay_kshift = 5;      // initial grid spacing (log2) of k_contours_relay
     int relay_chunk = getenv("ORBFE_ARUCO_RELAY_CHUNK") ? atoi(getenv("ORBFE_ARUCO_RELAY_CHUNK")) : 1 << 30;   // frames per launch of the large-frame relay kernels
+    PinnedBuf pinned; // staging of the host-pointer entry points
     DevBuf d_dwork, d_dctr, d_ditems, d_dhist, d_dpatch; // k_prefilter -> k_decode_warp / _otsu / _vote: the batch's candidates
     bool decode_dirty = false; // the decode work-list counter may be non-zero
     bool tail_dirty = false;   // the work-list counters may be non-zero (set while the tail's three launches are being enqueued)
@@ -452,6 +453,9 @@ static int pose_camera(const float* K4, const float* dist, int ndist, float mark
 }
 
 struct PoseWorkspace {
+    hipStream_t stream = nullptr; // not the null stream: that one synchronises with every blocking stream of the process
+    PinnedBuf pinned;
+    ~PoseWorkspace() { if (stream) (void)hipStreamDestroy(stream); }
     DevBuf markers, poses;
 };
 static thread_local ThreadWorkspaces<PoseWorkspace> tl_pose_ws; // per (thread, device)
@@ -606,19 +610,26 @@ int orbfe_aruco_detect_batch(orbfe_aruco* h, const uint8_t* imgs, int nframes, s
     if ((rc = h->d_in.ensure(dframe * nframes + 64)) || (rc = h->d_out.ensure((size_t)AR_MAX_RECTS * nframes * sizeof(orbfe_marker))) ||
         (rc = h->d_nout.ensure((size_t)nframes * 4)))
         return rc;
+    // page-locked staging: [frames in] then [n per frame | counts (4 per frame) | marker records] out -- three copies queued behind
+    // the kernels and one wait instead of a blocking copy per array
+    const size_t o_n = (dframe * nframes + 255) / 256 * 256, o_cnt = o_n + ((size_t)nframes * 4 + 63) / 64 * 64;
+    const size_t o_mk = o_cnt + ((size_t)nframes * 16 + 63) / 64 * 64, o_end = o_mk + (size_t)AR_MAX_RECTS * nframes * sizeof(orbfe_marker);
+    if ((rc = h->pinned.ensure(o_end))) return rc;
+    uint8_t* hp = h->pinned.as<uint8_t>();
     hipStream_t s = h->own_stream;
     for (int f = 0; f < nframes; f++)
-        ORBFE_HIP(hipMemcpy2DAsync((uint8_t*)h->d_in.p + f * dframe, dpitch, imgs + f * frame_stride, step, cols, rows,
-                                   hipMemcpyHostToDevice, s));
-    std::vector<int32_t> counts((size_t)nframes * 4);
+        for (int y = 0; y < rows; y++) memcpy(hp + f * dframe + (size_t)y * dpitch, imgs + f * frame_stride + (size_t)y * step, (size_t)cols);
+    ORBFE_HIP(hipMemcpyAsync(h->d_in.p, hp, dframe * nframes, hipMemcpyHostToDevice, s));
+    const int32_t* counts = reinterpret_cast<const int32_t*>(hp + o_cnt);
     const bool user_big_mode = h->big_mode; // orbfe_aruco_set_big_frames applies to all following batches: keep it
     for (int attempt = 0; attempt < 2; attempt++) {
         rc = h->run_device(h->d_in.as<uint8_t>(), nframes, dframe, rows, cols, dpitch, h->d_out.as<orbfe_marker>(),
                            AR_MAX_RECTS, h->d_nout.as<int32_t>(), s);
         if (rc) { h->big_mode = user_big_mode; return rc; }
-        ORBFE_HIP(hipMemcpyAsync(n_out, h->d_nout.p, (size_t)nframes * 4, hipMemcpyDeviceToHost, s));
+        ORBFE_HIP(hipMemcpyAsync(hp + o_n, h->d_nout.p, (size_t)nframes * 4, hipMemcpyDeviceToHost, s));
+        ORBFE_HIP(hipMemcpyAsync(hp + o_cnt, h->d_counts.p, (size_t)nframes * 16, hipMemcpyDeviceToHost, s));
+        ORBFE_HIP(hipMemcpyAsync(hp + o_mk, h->d_out.p, (size_t)AR_MAX_RECTS * nframes * sizeof(orbfe_marker), hipMemcpyDeviceToHost, s));
         ORBFE_HIP(hipStreamSynchronize(s));
-        ORBFE_HIP(hipMemcpy(counts.data(), h->d_counts.p, counts.size() * 4, hipMemcpyDeviceToHost));
         bool retry = false;
         for (int f = 0; f < nframes; f++) retry = retry || (counts[f * 4 + 2] & (2 | 4));
         // a frame with more kept borders (or border points) than the LDS-resident kernels hold: the batch is done again
@@ -627,13 +638,13 @@ int orbfe_aruco_detect_batch(orbfe_aruco* h, const uint8_t* imgs, int nframes, s
         h->big_mode = true;
     }
     h->big_mode = user_big_mode;
+    memcpy(n_out, hp + o_n, (size_t)nframes * 4);
     for (int f = 0; f < nframes; f++) {
         if (counts[f * 4 + 2])
             return fail(ORBFE_ERR_CAPACITY, "frame %d: internal detector capacity exceeded (flags 0x%x)", f, counts[f * 4 + 2]);
         if (n_out[f] > capacity) return fail(ORBFE_ERR_CAPACITY, "frame %d has %d markers, capacity is %d", f, n_out[f], capacity);
         if (n_out[f])
-            ORBFE_HIP(hipMemcpy(out + (size_t)f * capacity, h->d_out.as<orbfe_marker>() + (size_t)f * AR_MAX_RECTS,
-                                (size_t)n_out[f] * sizeof(orbfe_marker), hipMemcpyDeviceToHost));
+            memcpy(out + (size_t)f * capacity, hp + o_mk + (size_t)f * AR_MAX_RECTS * sizeof(orbfe_marker), (size_t)n_out[f] * sizeof(orbfe_marker));
     }
     return ORBFE_OK;
 }
@@ -767,13 +778,19 @@ int orbfe_marker_poses(const orbfe_marker* markers, int n, float marker_size, co
     if (rc || (rc = use_device(device))) return rc;
     if (n == 0) return ORBFE_OK;
     PoseWorkspace& w = tl_pose_ws.get();
-    if ((rc = w.markers.ensure((size_t)n * sizeof(orbfe_marker))) || (rc = w.poses.ensure((size_t)n * sizeof(orbfe_marker_pose))))
-        return rc;
-    ORBFE_HIP(hipMemcpy(w.markers.p, markers, (size_t)n * sizeof(orbfe_marker), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_marker_poses, dim3((n + 63) / 64, 1), dim3(64), 0, 0, w.markers.as<orbfe_marker>(), (const int32_t*)nullptr,
+    const size_t mb = (size_t)n * sizeof(orbfe_marker), pb = (size_t)n * sizeof(orbfe_marker_pose);
+    if ((rc = w.markers.ensure(mb)) || (rc = w.poses.ensure(pb)) || (rc = w.pinned.ensure(mb + pb + 64))) return rc;
+    if (!w.stream) ORBFE_HIP(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+    uint8_t* hp = w.pinned.as<uint8_t>();
+    const size_t o_p = (mb + 63) / 64 * 64;
+    memcpy(hp, markers, mb);
+    ORBFE_HIP(hipMemcpyAsync(w.markers.p, hp, mb, hipMemcpyHostToDevice, w.stream));
+    hipLaunchKernelGGL(k_marker_poses, dim3((n + 63) / 64, 1), dim3(64), 0, w.stream, w.markers.as<orbfe_marker>(), (const int32_t*)nullptr,
                        n, marker_size, c, w.poses.as<orbfe_marker_pose>());
     ORBFE_HIP(hipGetLastError());
-    ORBFE_HIP(hipMemcpy(poses, w.poses.p, (size_t)n * sizeof(orbfe_marker_pose), hipMemcpyDeviceToHost));
+    ORBFE_HIP(hipMemcpyAsync(hp + o_p, w.poses.p, pb, hipMemcpyDeviceToHost, w.stream));
+    ORBFE_HIP(hipStreamSynchronize(w.stream));
+    memcpy(poses, hp + o_p, pb);
     return ORBFE_OK;
 }
 

@@ -1248,6 +1248,11 @@ struct MatchWorkspace {
     DevBuf q, t, nq, nt, oidx, obest, osecond, kps, desc, nk, m12, nm;
     int csr_per_pair = 0; // candidate pool entries per frame pair of SearchForInitialization (grown on overflow)
     int sbp_stride = 0;   // candidate row stride of k_search_by_projection (grown on overflow)
+    // host-pointer SearchForInitialization: a stream of its own (the null stream synchronises with every blocking stream of the
+    // process) and page-locked staging, so that a call is a few queued copies and one wait
+    hipStream_t host_stream = nullptr;
+    PinnedBuf pinned;
+    ~MatchWorkspace() { if (host_stream) (void)hipStreamDestroy(host_stream); }
 };
 // one workspace per (thread, device, stream): see ThreadWorkspaces.  The host-pointer entry points run on the null stream.
 static thread_local ThreadWorkspaces<MatchWorkspace> tl_ws;
@@ -1321,10 +1326,9 @@ static float4 frame_bounds(int cols, int rows, const float* bounds)
 
 static int sfi_launch(const orbfe_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n, int capacity, int npairs,
                       float4 bnd, int window, float nnratio, int check_ori, const float* d_prev_in,
-                      float* d_prev_out, int32_t* d_m12, int32_t* d_nm, hipStream_t s)
+                      float* d_prev_out, int32_t* d_m12, int32_t* d_nm, hipStream_t s, MatchWorkspace& w)
 {
     if (capacity > 65535) return fail(ORBFE_ERR_INVALID, "capacity above 65535 keypoints per frame is unsupported");
-    MatchWorkspace& w = ws(s);
     // a pair's candidate rows share one dense pool; a pool that turns out too small is flagged, grown by the status call (or the
     // host wrapper) and the batch repeated.  16 K entries hold a 640 x 480 / 1000-feature pair at window 100 more than twice.
     const int pool_cap = std::max((w.csr_per_pair + 3) / 4 * 4, 16384);
@@ -1480,7 +1484,7 @@ int orbfe_search_for_initialization_batch_device(const orbfe_keypoint* d_kps, co
         rows <= 0)
         return fail(ORBFE_ERR_INVALID, "orbfe_search_for_initialization_batch_device: invalid argument");
     return sfi_launch(d_kps, d_desc, d_n, capacity, npairs, frame_bounds(cols, rows, bounds), window_size, nnratio, check_orientation,
-                      nullptr, nullptr, d_matches12, d_nmatches, (hipStream_t)stream);
+                      nullptr, nullptr, d_matches12, d_nmatches, (hipStream_t)stream, ws((hipStream_t)stream));
 }
 
 int orbfe_search_for_initialization_batch_status(void* stream, int32_t* overflow)
@@ -1512,31 +1516,48 @@ int orbfe_search_for_initialization(const orbfe_keypoint* kps1, const uint8_t* d
         (rc = w.nk.ensure(16)) || (rc = w.m12.ensure((size_t)cap * 4)) || (rc = w.nm.ensure(16)) ||
         (rc = w.prev.ensure((size_t)cap * 8)))
         return rc;
-    ORBFE_HIP(hipMemcpy(w.kps.p, kps1, (size_t)n1 * sizeof(orbfe_keypoint), hipMemcpyHostToDevice));
-    ORBFE_HIP(hipMemcpy(w.desc.p, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice));
+    if (!w.host_stream) ORBFE_HIP(hipStreamCreateWithFlags(&w.host_stream, hipStreamNonBlocking));
+    hipStream_t s = w.host_stream;
+    // page-locked staging: in [kps1 | kps2 | desc1 | desc2 | n1, n2 | prev], out [m12 | prev | nmatches | 2 flag words]
+    const size_t kb = (size_t)cap * sizeof(orbfe_keypoint), db = (size_t)cap * 32;
+    const size_t i_kps = 0, i_desc = 2 * kb, i_nk = i_desc + 2 * db, i_prev = i_nk + 64, o_m12 = i_prev + (size_t)cap * 8;
+    const size_t o_prev = o_m12 + (size_t)cap * 4, o_nm = o_prev + (size_t)cap * 8, o_flags = o_nm + 16, o_end = o_flags + 16;
+    if ((rc = w.pinned.ensure(o_end))) return rc;
+    uint8_t* hp = w.pinned.as<uint8_t>();
+    memcpy(hp + i_kps, kps1, (size_t)n1 * sizeof(orbfe_keypoint));
+    memcpy(hp + i_desc, desc1, (size_t)n1 * 32);
     if (n2) {
-        ORBFE_HIP(hipMemcpy(w.kps.as<orbfe_keypoint>() + cap, kps2, (size_t)n2 * sizeof(orbfe_keypoint),
-                            hipMemcpyHostToDevice));
-        ORBFE_HIP(hipMemcpy(w.desc.as<uint8_t>() + (size_t)cap * 32, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice));
+        memcpy(hp + i_kps + kb, kps2, (size_t)n2 * sizeof(orbfe_keypoint));
+        memcpy(hp + i_desc + db, desc2, (size_t)n2 * 32);
     }
     const int32_t nn[2] = {n1, n2};
-    ORBFE_HIP(hipMemcpy(w.nk.p, nn, 8, hipMemcpyHostToDevice));
+    memcpy(hp + i_nk, nn, 8);
+    memcpy(hp + i_prev, prev_matched, (size_t)n1 * 8);
+    ORBFE_HIP(hipMemcpyAsync(w.kps.p, hp + i_kps, 2 * kb, hipMemcpyHostToDevice, s));
+    ORBFE_HIP(hipMemcpyAsync(w.desc.p, hp + i_desc, 2 * db, hipMemcpyHostToDevice, s));
+    ORBFE_HIP(hipMemcpyAsync(w.nk.p, hp + i_nk, 8, hipMemcpyHostToDevice, s));
     for (int attempt = 0;; attempt++) {
         // the device copy of prev_matched is only overwritten by a run that did not overflow
-        ORBFE_HIP(hipMemcpy(w.prev.p, prev_matched, (size_t)n1 * 8, hipMemcpyHostToDevice));
+        ORBFE_HIP(hipMemcpyAsync(w.prev.p, hp + i_prev, (size_t)n1 * 8, hipMemcpyHostToDevice, s));
         rc = sfi_launch(w.kps.as<orbfe_keypoint>(), w.desc.as<uint8_t>(), w.nk.as<int32_t>(), cap, 1, frame_bounds(cols, rows, bounds),
                         window_size, nnratio, check_orientation, w.prev.as<float>(), w.prev.as<float>(),
-                        w.m12.as<int32_t>(), w.nm.as<int32_t>(), nullptr);
+                        w.m12.as<int32_t>(), w.nm.as<int32_t>(), s, w);
         if (rc) return rc;
-        ORBFE_HIP(hipDeviceSynchronize());
+        // results and flags: copies queued behind the kernels, one wait
+        ORBFE_HIP(hipMemcpyAsync(hp + o_m12, w.m12.p, (size_t)n1 * 4, hipMemcpyDeviceToHost, s));
+        ORBFE_HIP(hipMemcpyAsync(hp + o_prev, w.prev.p, (size_t)n1 * 8, hipMemcpyDeviceToHost, s));
+        ORBFE_HIP(hipMemcpyAsync(hp + o_nm, w.nm.p, 4, hipMemcpyDeviceToHost, s));
+        ORBFE_HIP(hipMemcpyAsync(hp + o_flags, w.sfi_overflow.p, 8, hipMemcpyDeviceToHost, s));
+        ORBFE_HIP(hipStreamSynchronize(s));
+        const int32_t* fl = reinterpret_cast<const int32_t*>(hp + o_flags);
+        if (!fl[0] && !fl[1]) break;
         int32_t ovf = 0;
-        if ((rc = sfi_read_flags(w, &ovf))) return rc;
-        if (!ovf) break;
+        if ((rc = sfi_read_flags(w, &ovf))) return rc; // clears the flags, grows the pool
         if (attempt) return fail(ORBFE_ERR_CAPACITY, "candidate pool overflow (%d)", ovf);
     }
-    ORBFE_HIP(hipMemcpy(matches12, w.m12.p, (size_t)n1 * 4, hipMemcpyDeviceToHost));
-    ORBFE_HIP(hipMemcpy(prev_matched, w.prev.p, (size_t)n1 * 8, hipMemcpyDeviceToHost));
-    ORBFE_HIP(hipMemcpy(nmatches, w.nm.p, 4, hipMemcpyDeviceToHost));
+    memcpy(matches12, hp + o_m12, (size_t)n1 * 4);
+    memcpy(prev_matched, hp + o_prev, (size_t)n1 * 8);
+    memcpy(nmatches, hp + o_nm, 4);
     return ORBFE_OK;
 }
 

@@ -65,6 +65,7 @@ struct orbfe_extractor {
     // --- device state
     int device = 0;
     hipStream_t own_stream = nullptr, aux_stream = nullptr;
+    PinnedBuf pinned;               // staging of the host-pointer entry points
     hipStream_t user_aux = nullptr; // orbfe_extractor_set_aux_stream: run the blur there instead of on aux_stream
     hipStream_t user_early = nullptr; // orbfe_extractor_set_early_stream: FAST of level 0 there instead of on aux_stream
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork0 = nullptr, ev_join0 = nullptr;
@@ -631,27 +632,34 @@ int orbfe_extract_batch(orbfe_extractor* h, const uint8_t* imgs, int nframes, si
     if ((rc = h->d_kps.ensure((size_t)cap * nframes * sizeof(orbfe_keypoint)))) return rc;
     if ((rc = h->d_desc.ensure((size_t)cap * nframes * 32))) return rc;
     if ((rc = h->d_nout.ensure((size_t)nframes * 4))) return rc;
+    // page-locked staging: [frames in, row pitch dpitch] then [n per frame | flag | keypoints | descriptors] out
+    const size_t o_n = align_up((int)(dframe * nframes), 256), o_flag = o_n + (size_t)align_up(nframes * 4, 64), o_kps = o_flag + 64;
+    const size_t o_desc = o_kps + (size_t)cap * nframes * sizeof(orbfe_keypoint), o_end = o_desc + (size_t)cap * nframes * 32;
+    if ((rc = h->pinned.ensure(o_end))) return rc;
+    uint8_t* hp = h->pinned.as<uint8_t>();
     hipStream_t s = h->own_stream;
     for (int f = 0; f < nframes; f++)
-        ORBFE_HIP(hipMemcpy2DAsync((uint8_t*)h->d_in.p + f * dframe, dpitch, imgs + f * frame_stride, step, cols, rows,
-                                   hipMemcpyHostToDevice, s));
+        for (int y = 0; y < rows; y++) memcpy(hp + f * dframe + (size_t)y * dpitch, imgs + f * frame_stride + (size_t)y * step, (size_t)cols);
+    ORBFE_HIP(hipMemcpyAsync(h->d_in.p, hp, dframe * nframes, hipMemcpyHostToDevice, s));
     rc = h->run_device(h->d_in.as<uint8_t>(), nframes, dframe, rows, cols, dpitch, h->d_kps.as<orbfe_keypoint>(),
                        h->d_desc.as<uint8_t>(), cap, h->d_nout.as<int32_t>(), s, /*flag_word*/ 1);
     if (rc) return rc;
-    ORBFE_HIP(hipMemcpyAsync(n_out, h->d_nout.p, (size_t)nframes * 4, hipMemcpyDeviceToHost, s));
+    // the results: four copies queued behind the kernels, one wait (blocking copies cost a round trip each: 4 x ~40 us per frame)
+    ORBFE_HIP(hipMemcpyAsync(hp + o_n, h->d_nout.p, (size_t)nframes * 4, hipMemcpyDeviceToHost, s));
+    ORBFE_HIP(hipMemcpyAsync(hp + o_flag, h->d_overflow.as<int32_t>() + 1, 4, hipMemcpyDeviceToHost, s));
+    ORBFE_HIP(hipMemcpyAsync(hp + o_kps, h->d_kps.p, (size_t)cap * nframes * sizeof(orbfe_keypoint), hipMemcpyDeviceToHost, s));
+    ORBFE_HIP(hipMemcpyAsync(hp + o_desc, h->d_desc.p, (size_t)cap * nframes * 32, hipMemcpyDeviceToHost, s));
     ORBFE_HIP(hipStreamSynchronize(s));
-    int32_t ovf = 0;
-    ORBFE_HIP(hipMemcpy(&ovf, h->d_overflow.as<int32_t>() + 1, 4, hipMemcpyDeviceToHost));
+    const int32_t ovf = *reinterpret_cast<const int32_t*>(hp + o_flag);
     if (ovf) ORBFE_HIP(hipMemset(h->d_overflow.as<int32_t>() + 1, 0, 4));
+    memcpy(n_out, hp + o_n, (size_t)nframes * 4);
     if (ovf) return fail(ORBFE_ERR_CAPACITY, "internal keypoint capacity exceeded (%d)", ovf);
     for (int f = 0; f < nframes; f++) {
         if (n_out[f] > capacity)
             return fail(ORBFE_ERR_CAPACITY, "frame %d has %d keypoints, capacity is %d", f, n_out[f], capacity);
         if (n_out[f] == 0) continue;
-        ORBFE_HIP(hipMemcpy(kps + (size_t)f * capacity, h->d_kps.as<orbfe_keypoint>() + (size_t)f * cap,
-                            (size_t)n_out[f] * sizeof(orbfe_keypoint), hipMemcpyDeviceToHost));
-        ORBFE_HIP(hipMemcpy(desc + (size_t)f * capacity * 32, h->d_desc.as<uint8_t>() + (size_t)f * cap * 32,
-                            (size_t)n_out[f] * 32, hipMemcpyDeviceToHost));
+        memcpy(kps + (size_t)f * capacity, hp + o_kps + (size_t)f * cap * sizeof(orbfe_keypoint), (size_t)n_out[f] * sizeof(orbfe_keypoint));
+        memcpy(desc + (size_t)f * capacity * 32, hp + o_desc + (size_t)f * cap * 32, (size_t)n_out[f] * 32);
     }
     return ORBFE_OK;
 }
