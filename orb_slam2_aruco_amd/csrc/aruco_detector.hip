@@ -36,6 +36,9 @@ struct orbfe_aruco {
     int relay_kshift = 5;      // initial grid spacing (log2) of k_contours_relay
     int relay_chunk = getenv("ORBFE_ARUCO_RELAY_CHUNK") ? atoi(getenv("ORBFE_ARUCO_RELAY_CHUNK")) : 1 << 30;   // frames per launch of the large-frame relay kernels
     PinnedBuf pinned; // staging of the host-pointer entry points
+    DevBuf d_vis;        // per frame: one bit per start candidate on a gridded border (relay kernels, phase (d) -> (c))
+    size_t vis_fu32 = 0;
+    int vis_mode = getenv("ORBFE_ARUCO_VIS") ? atoi(getenv("ORBFE_ARUCO_VIS")) : 0; // experiment, slower: see relay_frame
     DevBuf d_dwork, d_dctr, d_ditems, d_dhist, d_dpatch; // k_prefilter -> k_decode_warp / _otsu / _vote: the batch's candidates
     bool decode_dirty = false; // the decode work-list counter may be non-zero
     bool tail_dirty = false;   // the work-list counters may be non-zero (set while the tail's three launches are being enqueued)
@@ -63,7 +66,7 @@ struct orbfe_aruco {
     ~orbfe_aruco()
     {
         for (DevBuf* b : {&d_codes, &d_levels, &d_tabs, &d_bits, &d_pyr, &d_candq, &d_pool, &d_kept, &d_rects,
-                          &d_counts, &d_candidx, &d_ncand, &d_result, &d_gpad, &d_in, &d_out, &d_nout, &d_segs, &d_tailkeys, &d_tailoff, &d_small, &d_hint, &d_rstate, &d_lut, &d_twork, &d_trect, &d_tctr, &d_dwork, &d_dctr, &d_ditems, &d_dhist, &d_dpatch, &d_scodes, &d_sids,
+                          &d_counts, &d_candidx, &d_ncand, &d_result, &d_gpad, &d_in, &d_out, &d_nout, &d_segs, &d_tailkeys, &d_tailoff, &d_small, &d_hint, &d_rstate, &d_lut, &d_twork, &d_trect, &d_tctr, &d_dwork, &d_dctr, &d_ditems, &d_dhist, &d_dpatch, &d_vis, &d_scodes, &d_sids,
                           &d_msrc})
             b->release();
         if (own_stream) (void)hipStreamDestroy(own_stream);
@@ -256,6 +259,8 @@ struct orbfe_aruco {
                 (rc = d_dpatch.ensure(items * DC_PATCH_BYTES)))
                 return rc;
         }
+        vis_fu32 = (size_t)((cols + 2 + 31) >> 5) * (rows + 2) + 4;
+        if (vis_mode && (rc = d_vis.ensure(vis_fu32 * 4 * B))) return rc;
         if (!d_dctr.p) {   // k_finalize leaves the counter at zero for the next batch
             if ((rc = d_dctr.ensure(16))) return rc;
             ORBFE_HIP(hipMemset(d_dctr.p, 0, 16));
@@ -350,7 +355,8 @@ struct orbfe_aruco {
                                cols, rows, lds_bits_words, 70, relay_kshift, relay_tbits, d_segs.as<RelaySeg>(),
                                d_pool.as<uint32_t>(), pool_fu32, (int)pool_fu32, d_kept.as<ArKept>(), relay_kcap, relay_kcap,
                                d_tailkeys.as<unsigned long long>(), d_tailoff.as<int32_t>(), d_counts.as<int32_t>(), d_hint.as<int32_t>(),
-                               d_small.as<uint4>(), d_rstate.as<int32_t>(), small_separate ? 1 : 0, d_lut.as<uint16_t>(), f0);
+                               d_small.as<uint4>(), d_rstate.as<int32_t>(), small_separate ? 1 : 0, d_lut.as<uint16_t>(), f0,
+                               vis_mode ? d_vis.as<uint32_t>() : nullptr, vis_fu32);
             }
             }
             // the borders that touch no grid line, for frames done with a grid by a relay kernel that leaves them out (the

@@ -821,7 +821,9 @@ __device__ __forceinline__ int relay_frame(
     uint32_t* __restrict__ gpad = nullptr /* GBITS: the padded bit image lives here (HBM / L2) instead of LDS */, size_t gpad_fstride = 0,
     int small_elsewhere = 0 /* phase (c) of gridded frames is k_contours_small's */,
     const uint16_t* __restrict__ lut_g = nullptr /* the step table, built once per detector (k_relay_lut) */,
-    int f0 = 0 /* first frame of this launch (a batch may be launched in chunks) */)
+    int f0 = 0 /* first frame of this launch (a batch may be launched in chunks) */,
+    uint32_t* __restrict__ vis_g = nullptr /* per frame: one bit per start candidate that lies on a gridded border (see (d)) */,
+    size_t vis_fstride = 0)
 {
     extern __shared__ __align__(16) unsigned char ct_smem[];
     __shared__ int s_nmpix;
@@ -888,6 +890,11 @@ __device__ __forceinline__ int relay_frame(
             v = (cur << 1) | (prv >> 31);
         }
         lbits[i] = v;
+    }
+    uint32_t* vis = vis_g ? vis_g + (size_t)f * vis_fstride : nullptr;
+    if (vis) {
+        for (int i = tid; i < wpr * prow; i += NT) vis[i] = 0u;
+        __threadfence(); // ahead of the atomics of (d), which execute in L2
     }
     if (tid < 2) lbits[wpr * prow + tid] = 0; // spare words read by ring8()'s funnel loads
     for (int i = tid; i < T; i += NT) hkey[i] = 0u;
@@ -998,6 +1005,7 @@ __device__ __forceinline__ int relay_frame(
     // trips).  Without a grid every border is "small" and is followed whole here: a lane takes one 32-pixel word of start
     // candidates at a time; every loop iteration advances each busy lane by ONE step.  A walk stops at a proof that
     // the candidate is not canonical, or when the border closes; a closed border longer than min_len is queued.
+    auto phase_c = [&](const bool use_vis) {
     if (kshift >= 30 || !small_elsewhere) {
         RelayWalk wk;
         bool busy = false, drained = false;
@@ -1027,6 +1035,11 @@ __device__ __forceinline__ int relay_frame(
                         const uint32_t up_r = (upw >> 1) | (wj + 1 < wpr ? up[wj + 1] << 31 : 0u);
                         m_outer = cur & ~cur_l & ~up_l & ~upw & ~up_r;
                         m_hole = ~cur & cur_l & upw;
+                        if (use_vis) { // candidates on gridded borders: the segment walkers of (d) have been there
+                            const uint32_t seen = __hip_atomic_load(vis + i + wpr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ncand_l += __popc((m_outer | m_hole) & seen); // the statistic counts every start candidate of the frame
+                            m_outer &= ~seen; m_hole &= ~seen;
+                        }
                     }
                 }
                 if (m_outer | m_hole) {
@@ -1051,7 +1064,9 @@ __device__ __forceinline__ int relay_frame(
                 if (busy) {
                     const unsigned e = s_lut[(wk.ring << 3) | (unsigned)wk.s];
                     const int key3 = wk.y * 65536 + wk.x;
-                    bool stop = rl_is_marker(e, wk.x, wk.y, kmask); // the border belongs to the segment walkers
+                    // a walk that meets a grid marker: the border belongs to the segment walkers (with the candidate bits of (d)
+                    // no such walk is started, but a marker test costs three instructions and keeps the two modes one code path)
+                    bool stop = rl_is_marker(e, wk.x, wk.y, kmask);
                     if (is_hole)                                      // relay_not_canonical() on the table's run bits
                         stop |= ((e & 0x080u) && key3 - 65536 < start_key) || ((e & 0x100u) && key3 - 1 < start_key) ||
                                 ((e & 0x200u) && key3 + 1 < start_key) || ((e & 0x400u) && key3 + 65536 < start_key);
@@ -1095,13 +1110,12 @@ __device__ __forceinline__ int relay_frame(
         if ((tid & 63) == 0) { atomicMax(&s_dbg_steps[3], dbg_iters); atomicAdd(&s_dbg_steps[4], dbg_iters); }
 #endif
     }
-    // no barrier here: (d) depends on nothing (c) writes, and has its own ticket counter -- a wave that has drained the small
-    // borders goes straight on to the segments instead of waiting for the wave that was handed the last long walk (the waves'
-    // loop counts in (c) spread 92 +- 30: a quarter of the phase was waiting at this point)
+    };
     RL_STAMP();
 
     // ---- (d) segments: table slot -> walk to the next grid marker.  The points go to the lane's staging arena (upper
     // part of the frame's pool); (f2) copies the segments of kept borders to their final place.
+    auto phase_d = [&](const bool mark) {
     {
         RelayWalk wk;
         bool busy = false, drained = false;
@@ -1139,7 +1153,14 @@ __device__ __forceinline__ int relay_frame(
                     } else {
                         if (e & 0x60u) {
                             const uint32_t k = relay_key(wk.x, wk.y, wk.s);
-                            if (k < mn) { mn = k; mnoff = wk.n; mnhole = ((e >> 5) & 3u) == 2u ? 1u : 0u; }
+                            const uint32_t hole = ((e >> 5) & 3u) == 2u ? 1u : 0u;
+                            if (k < mn) { mn = k; mnoff = wk.n; mnhole = hole; }
+                            // a start state = exactly one start candidate of the raster scan: the pixel itself (outer pattern) or
+                            // its E neighbour (hole pattern).  It lies on a gridded border, so phase (c) need not walk from it.
+                            if (mark) {
+                                const int qx = wk.x + (int)hole;
+                                __hip_atomic_fetch_or(vis + wk.y * wpr + (qx >> 5), 1u << (qx & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
                         }
                         if (wp + wk.n < arena) my_arena[wp + wk.n] = relay_point(wk);
                         else { atomicOr(&s_flags, 4); busy = false; } // staging arena full: capacity error
@@ -1148,6 +1169,24 @@ __device__ __forceinline__ int relay_frame(
                 }
             }
         }
+    }
+    };
+    // Order of (c) and (d).  Default: (c) then (d) with no barrier between them ((d) depends on nothing (c) writes and has its own
+    // ticket counter; a wave that has drained the small borders goes straight on to the segments).  Experiment of round 3
+    // (ORBFE_ARUCO_VIS=1, profiles/r03_contour_candidate_plane.txt): (d) first, its walkers setting a bit in an HBM plane for every
+    // start candidate they pass, then (c) on the candidates that are left.  It removes a quarter of the candidates (11.8 k of
+    // 15.9 k remain on a 640 x 480 frame) and the 14 k steps of walks that end at a grid marker -- and is SLOWER: 553 against
+    // 399 us alone, C2 step 1.74 against 1.56 ms: every word fetch of (c) now waits for an L2 round trip, the two phases no longer
+    // overlap, and (c)'s time is set by its slowest wave (123 loop trips against a mean of 46), not by the number of walks.
+    const bool vis_mode = vis != nullptr && kshift < 30 && !small_elsewhere;
+    if (vis_mode) {
+        phase_d(true);
+        __threadfence();
+        __syncthreads();
+        phase_c(true);
+    } else {
+        phase_c(false);
+        phase_d(false);
     }
     __syncthreads();
     if ((s_flags & 4) && kshift < 30) return 1; // staging arena full: again without a grid
@@ -1415,16 +1454,16 @@ __global__ __launch_bounds__(RL_THREADS) RL_VGPR_ATTR void k_contours_relay(
     int kshift, int tbits, RelaySeg* __restrict__ segs, uint32_t* __restrict__ pool, size_t pool_fstride, int pool_cap,
     ArKept* __restrict__ kept_out, int kept_cap, int kcap /*kept borders this kernel's LDS holds*/,
     unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off, int32_t* __restrict__ counts, int32_t* __restrict__ hint,
-    uint4* __restrict__ small_g, int32_t* __restrict__ rstate, int small_elsewhere, const uint16_t* __restrict__ lut_g, int f0)
+    uint4* __restrict__ small_g, int32_t* __restrict__ rstate, int small_elsewhere, const uint16_t* __restrict__ lut_g, int f0, uint32_t* __restrict__ vis_g, size_t vis_fstride)
 {
     __builtin_amdgcn_s_setprio(2); // latency-bound: its few waves go first when a VALU-bound kernel shares the CU
     if (relay_frame<false, RL_SLOTS_PER_THREAD, RL_THREADS>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool,
                                                 pool_fstride, pool_cap, kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate,
-                                                nullptr, 0, small_elsewhere, lut_g, f0)) {
+                                                nullptr, 0, small_elsewhere, lut_g, f0, vis_g, vis_fstride)) {
         __syncthreads();
         relay_frame<true, RL_SLOTS_PER_THREAD, RL_THREADS>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool,
                                                pool_fstride, pool_cap, kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate,
-                                               nullptr, 0, small_elsewhere, lut_g, f0);
+                                               nullptr, 0, small_elsewhere, lut_g, f0, vis_g, vis_fstride);
     }
 }
 
@@ -1435,14 +1474,14 @@ __global__ __launch_bounds__(RL_THREADS_BIG) void k_contours_relay8(
     int kshift, int tbits, RelaySeg* __restrict__ segs, uint32_t* __restrict__ pool, size_t pool_fstride, int pool_cap,
     ArKept* __restrict__ kept_out, int kept_cap, int kcap, unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off,
     int32_t* __restrict__ counts, int32_t* __restrict__ hint, uint4* __restrict__ small_g, int32_t* __restrict__ rstate, int small_elsewhere,
-    const uint16_t* __restrict__ lut_g, int f0)
+    const uint16_t* __restrict__ lut_g, int f0, uint32_t* __restrict__ vis_g, size_t vis_fstride)
 {
     __builtin_amdgcn_s_setprio(2);
     if (relay_frame<false, 8192 / RL_THREADS_BIG, RL_THREADS_BIG>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool, pool_fstride, pool_cap,
-                              kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate, nullptr, 0, small_elsewhere, lut_g, f0)) {
+                              kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate, nullptr, 0, small_elsewhere, lut_g, f0, vis_g, vis_fstride)) {
         __syncthreads();
         relay_frame<true, 8192 / RL_THREADS_BIG, RL_THREADS_BIG>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool, pool_fstride, pool_cap,
-                             kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate, nullptr, 0, small_elsewhere, lut_g, f0);
+                             kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate, nullptr, 0, small_elsewhere, lut_g, f0, vis_g, vis_fstride);
     }
 }
 
@@ -2173,7 +2212,23 @@ __global__ __launch_bounds__(64) void k_decode_otsu(const int32_t* __restrict__ 
         const int n = S * S;
         const double scale = 1. / n;
         const double mu = (double)items[it].isum * scale;
+        // The recurrence mu1, q1 is the serial part; mu2 and sigma of a bin do not feed back.  They are evaluated ONE BIN LATE, from
+        // the saved (q1, mu1) of the previous bin, and without branches, so that the two dependent chains of a trip -- this bin's
+        // recurrence (multiply, add, divide) and the previous bin's variance (divide, four multiplies, compare) -- are independent
+        // instruction streams the in-order wave can interleave.  Same operations on the same values in the same order of bins.
         double mu1 = 0, q1 = 0, max_sigma = 0;
+        double pq1 = 0, pmu1 = 0;
+        bool pvalid = false;
+        auto variance_of_previous = [&](int i_prev) {
+            const double q2p = 1. - pq1;
+            const double mu2 = __ddiv_rn(mu - pq1 * pmu1, q2p);
+            const double dm = pmu1 - mu2;
+            double sigma = pq1 * q2p * dm * dm;
+            sigma = pvalid ? sigma : -1.0; // a skipped bin never wins (max_sigma >= 0)
+            const bool better = sigma > max_sigma;
+            max_sigma = better ? sigma : max_sigma;
+            max_val = better ? i_prev : max_val;
+        };
         for (int i0 = 0; i0 < 256; i0 += 32) { // four 16-byte loads (32 bins) in flight per lane
             uint4 hv[4];
 #pragma unroll
@@ -2184,19 +2239,20 @@ __global__ __launch_bounds__(64) void k_decode_otsu(const int32_t* __restrict__ 
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     const int i = i0 + k * 8 + j;
+                    variance_of_previous(i - 1);
                     const uint32_t hi = (w[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
                     const double p_i = hi * scale;
                     mu1 *= q1;
                     q1 += p_i;
                     const double q2 = 1. - q1;
-                    if (fmin(q1, q2) < 1.1920928955078125e-07 || fmax(q1, q2) > 1. - 1.1920928955078125e-07) continue;
-                    mu1 = (mu1 + i * p_i) / q1;
-                    const double mu2 = (mu - q1 * mu1) / q2;
-                    const double sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2);
-                    if (sigma > max_sigma) { max_sigma = sigma; max_val = i; }
+                    const bool skip = fmin(q1, q2) < 1.1920928955078125e-07 || fmax(q1, q2) > 1. - 1.1920928955078125e-07;
+                    const double upd = __ddiv_rn(mu1 + i * p_i, q1);
+                    mu1 = skip ? mu1 : upd;
+                    pvalid = !skip; pq1 = q1; pmu1 = mu1;
                 }
             }
         }
+        variance_of_previous(255);
     }
     items[it].th = max_val;
 }

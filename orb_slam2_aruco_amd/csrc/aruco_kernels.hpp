@@ -53,11 +53,11 @@ struct RelaySeg {
 __global__ void k_contours_relay(const uint32_t* gbits, size_t bits_fstride, int wpr_g, int W, int H,
                                  int lds_bits_words, int min_len, int kshift, int tbits, RelaySeg* segs, uint32_t* pool,
                                  size_t pool_fstride, int pool_cap, ArKept* kept_out, int kept_cap, int kcap,
-                                 unsigned long long* tail_keys, int32_t* tail_off, int32_t* counts, int32_t* hint, uint4* small_g, int32_t* rstate, int small_elsewhere, const uint16_t* lut_g, int f0);
+                                 unsigned long long* tail_keys, int32_t* tail_off, int32_t* counts, int32_t* hint, uint4* small_g, int32_t* rstate, int small_elsewhere, const uint16_t* lut_g, int f0, uint32_t* vis_g, size_t vis_fstride);
 __global__ void k_contours_relay8(const uint32_t* gbits, size_t bits_fstride, int wpr_g, int W, int H,
                                  int lds_bits_words, int min_len, int kshift, int tbits, RelaySeg* segs, uint32_t* pool,
                                  size_t pool_fstride, int pool_cap, ArKept* kept_out, int kept_cap, int kcap,
-                                 unsigned long long* tail_keys, int32_t* tail_off, int32_t* counts, int32_t* hint, uint4* small_g, int32_t* rstate, int small_elsewhere, const uint16_t* lut_g, int f0);
+                                 unsigned long long* tail_keys, int32_t* tail_off, int32_t* counts, int32_t* hint, uint4* small_g, int32_t* rstate, int small_elsewhere, const uint16_t* lut_g, int f0, uint32_t* vis_g, size_t vis_fstride);
 __global__ void k_contours_relay8g(const uint32_t* gbits, size_t bits_fstride, int wpr_g, int W, int H,
                                  int lds_bits_words, int min_len, int kshift, int tbits, RelaySeg* segs, uint32_t* pool,
                                  size_t pool_fstride, int pool_cap, ArKept* kept_out, int kept_cap, int kcap,
