@@ -28,5 +28,11 @@ python bench.py --config C3 --out $O/${TAG}_bench_c3.json > $O/bench_c3.log 2>&1
 PORT=$((20000 + RANDOM % 20000))
 ORBFE_BENCH_DEVICE=0 ORBFE_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port $PORT \
     bench.py --gpus 2 --steps 6 --warmup 2 --cpu-frames 0 --out $O/${TAG}_bench_2ranks_gloo_one_gpu.json > $O/bench_2ranks.log 2>&1
-rm -rf $O/prof gpurun_out/pmc
+# the RCCL branch on the hardware that is there (world size 1), and C4 as far as one GPU runs it (8 gloo ranks on device 0, 8 frames each)
+python bench.py --gpus 1 --force-gather --cpu-frames 0 --out $O/${TAG}_bench_rccl_world1_force_gather.json > $O/bench_fg.log 2>&1
+PORT=$((20000 + RANDOM % 20000))
+ORBFE_BENCH_DEVICE=0 ORBFE_BENCH_BACKEND=gloo OMP_NUM_THREADS=2 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port $PORT \
+    bench.py --gpus 8 --config C4 --frames 8 --steps 3 --warmup 1 --cpu-frames 0 --out $O/${TAG}_bench_c4_8ranks_gloo_one_gpu.json > $O/bench_c4.log 2>&1
+python tools/timeline.py > $O/${TAG}_timeline_full.txt 2>&1
+rm -rf $O/prof gpurun_out/pmc gpurun_out/tl
 tail -c 400 $O/bench_c2.log
