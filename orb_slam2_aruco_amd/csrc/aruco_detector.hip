@@ -219,6 +219,9 @@ struct orbfe_aruco {
         // frames whose bit image does not fit LDS: the relay formulation with the bit image in HBM (k_contours_relay8g)
         // (and room for as many kept borders as the single-walker kernel's big-frame mode: busy 1920 x 1080 frames have > 1024)
         // (also frames whose bit image fits LDS for the single-walker kernel but not next to a marker table)
+        // experiment (ORBFE_ARUCO_FORCE_GLOBAL=1): the HBM-image formulation also for frames that would fit LDS -- its workgroups are
+        // 45 KB instead of 151 KB (1280 x 720), so the extractor's kernels can share their CUs
+        if (getenv("ORBFE_ARUCO_FORCE_GLOBAL") && atoi(getenv("ORBFE_ARUCO_FORCE_GLOBAL")) && large) relay_tbits = 0;
         relay_global = !relay_tbits && relay_lds_bytes(0, AR_MAX_KEPT_BIG, 13) + rl_static <= 160 * 1024;
         relay_kcap = RL_KCAP;
         if (relay_global) { relay_tbits = 13; relay_kshift = 5; relay_kcap = AR_MAX_KEPT_BIG; }
