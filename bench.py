@@ -331,9 +331,14 @@ def main():
     lib_sha16 = hashlib.sha256(open(binding.LIB_PATH, "rb").read()).hexdigest()[:16]
     # launch ablation needs the diagnosis build (tools/ablate.sh); its numbers are never a result
     skips = {}
+    late_skips = []      # ORBFE_SKIP_AFTER_WARMUP=1: the launches are left out only after the warm-up steps have filled every buffer
     for key, env in (("orb_skip", "ORBFE_ORB_SKIP"), ("aruco_skip", "ORBFE_ARUCO_SKIP")):
         if os.environ.get(env):
-            binding.debug_control(key, int(os.environ[env]))     # ORBFE_ERR_INVALID in the shipped library
+            if os.environ.get("ORBFE_SKIP_AFTER_WARMUP"):
+                binding.debug_control(key, 0)                    # ORBFE_ERR_INVALID in the shipped library
+                late_skips.append((key, int(os.environ[env])))
+            else:
+                binding.debug_control(key, int(os.environ[env]))
             skips[key] = int(os.environ[env])
     if "+ablation" in version:
         skips["library"] = version
@@ -378,6 +383,8 @@ def main():
     for r in range(1, R):           # touch every resident copy once
         pipe.step(d_batches[r])
     pipe.synchronize()
+    for key, v in late_skips:
+        binding.debug_control(key, v)
     if multi:
         dist.barrier()
     torch.cuda.synchronize()

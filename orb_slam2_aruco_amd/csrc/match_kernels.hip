@@ -103,9 +103,13 @@ __global__ __launch_bounds__(KM_WAVES * 64) void k_knn2_mfma(const uint8_t* __re
 {
     // grid: (query tiles, pairs, nsplit).  Split z handles train rows [z * chunk, (z + 1) * chunk) and writes partials
     // [pair][split][max_nq] for k_knn2_merge, exactly as k_knn2_tiles does; with one split they are the final arrays.
-    __shared__ __align__(16) unsigned char s_t[KM_CHUNK * KM_ROWB]; // spread train descriptors of the current chunk
+    // the spread train descriptors of the current chunk and, after the loop, the cross-lane merge of the keys share one region:
+    // 35 KB per workgroup instead of 69 (the footprint is a cost of its own: it decides what else fits on the CU)
+    constexpr int KM_LDS = KM_CHUNK * KM_ROWB > KM_WAVES * 32 * 33 * 4 ? KM_CHUNK * KM_ROWB : KM_WAVES * 32 * 33 * 4;
+    __shared__ __align__(16) unsigned char s_u[KM_LDS];
+    unsigned char* s_t = s_u;
+    int (*s_red)[32][33] = reinterpret_cast<int (*)[32][33]>(s_u);
     __shared__ int s_pt[KM_CHUNK];                                  // their popcounts
-    __shared__ int s_red[KM_WAVES][32][33];                         // final cross-lane merge (keys)
     const int pair = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int nq = nq_arr ? nq_arr[pair] : max_nq;
     const int split = blockIdx.z, nsplit = gridDim.z;
@@ -179,6 +183,7 @@ __global__ __launch_bounds__(KM_WAVES * 64) void k_knn2_mfma(const uint8_t* __re
         }
     }
     // merge the 32 column classes of every row through LDS: s_red[wave][row][column class]
+    __syncthreads(); // every wave has read the last chunk: the region changes hands
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
         __builtin_amdgcn_wave_barrier();

@@ -1322,8 +1322,11 @@ __device__ __forceinline__ void bl_hsum_rows(uint16_t* sh, int first_rr, int nrr
     }
 }
 
+#ifndef BL_ATTR
+#define BL_ATTR
+#endif
 template <bool ED>
-__global__ __launch_bounds__(256) void k_blur7(ImgView src0, ImgView pyr, ImgView blur,
+__global__ __launch_bounds__(256) BL_ATTR void k_blur7(ImgView src0, ImgView pyr, ImgView blur,
                                                const LevelGeom* __restrict__ geom, const uint32_t* __restrict__ strips,
                                                int nx, int total)
 {
@@ -1550,7 +1553,12 @@ __global__ __launch_bounds__(256) void k_orient_describe(ImgView src0, ImgView p
 // angle, and IC_Angle uses 31 lanes.  Here lanes 0..31 belong to keypoint A and 32..63 to keypoint B for those parts -- the patch rows
 // of both in one pass, the two moment sums out of one scan (lanes 31 and 63), one fastAtan2 / sincos sequence for both angles -- and
 // the loads and the 256 tests run per keypoint on all 64 lanes as before.  An odd last keypoint is paired with itself.
-__global__ __launch_bounds__(256) void k_orient_describe2(ImgView src0, ImgView pyr, ImgView blur,
+// 66 registers would cost the eighth wave per SIMD: the kernel waits on three dependent global round trips per keypoint pair, so
+// occupancy is what hides them (C2 step 1.531 -> 1.519 ms, three interleaved runs each)
+#ifndef OD2_ATTR
+#define OD2_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))
+#endif
+__global__ __launch_bounds__(256) OD2_ATTR void k_orient_describe2(ImgView src0, ImgView pyr, ImgView blur,
                                                           const LevelGeom* __restrict__ geom,
                                                           const uint32_t* __restrict__ flat_kv,
                                                           const uint8_t* __restrict__ flat_lvl,
