@@ -86,7 +86,7 @@ class FrontEndPipeline:
     gather and in synchronize()."""
 
     def __init__(self, frames, rows, cols, nfeatures=1000, nlevels=8, dictionary="ARUCO", device=0, marker_capacity=64,
-                 use_orb=True, use_aruco=True, splits=1, gather=None, lend_aux_stream=True, engine_sets=1):
+                 use_orb=True, use_aruco=True, splits=1, gather=None, lend_aux_stream=True, engine_sets=None):
         import torch
         self.torch = torch
         self.L = binding.load()
@@ -98,12 +98,18 @@ class FrontEndPipeline:
         B = frames
         S = self.S = max(1, min(splits, B // 2))
         self.bounds = [B * k // S for k in range(S + 1)]          # sub-batch k = frames bounds[k] .. bounds[k+1]
-        # Engine sets (experiment, ORBFE_ENGINE_SETS): consecutive batches alternate between D sets of handles and streams (a set
-        # owns its pyramid, candidate and contour workspaces), so that batch i + 1's resize / FAST run next to batch i's quadtree /
-        # descriptors instead of queueing behind them.  Measured on the C2 batch: 1.89 ms with one set, 2.02 (4 hardware queues)
-        # and 2.14 ms (8) with two -- the detector alone gains (1.02 -> 0.79 ms), the whole pipeline loses: D = 1 is the default.
+        # Engine sets: consecutive batches alternate between D sets of extractor handles and streams (a set owns its pyramid, candidate
+        # and keypoint workspaces), so that batch i + 1's resize / FAST run next to batch i's quadtree / descriptors -- the tail of the
+        # extractor chain is latency-bound (quadtree 116 us + descriptors 350 us in the pipeline for 140 us of VALU issue) and leaves
+        # issue slots free.  Round 2 measured two sets as a loss (2.02 against 1.89 ms, when the detector chain with its 540 us
+        # k_decode and the 640 us k_search_init set the step); with those split up (round 3) two EXTRACTOR sets win: 1.4955 against
+        # 1.5288 ms per C2 step (four interleaved runs each), a second detector set still loses (1.628).  Default: 2 / 1.
+        # Frames of more than a megapixel (1920 x 1080: 4.84 against 5.00 ms per 100-frame step) keep one set: a single batch of
+        # them keeps the chip busy through the extractor's tail, and the second set's workspace traffic costs more than it hides.
+        if engine_sets is None:
+            engine_sets = 2 if rows * cols <= 1280 * 720 else 1
         D = self.D = max(1, int(os.environ.get("ORBFE_ENGINE_SETS", engine_sets)))
-        DA = self.DA = max(1, int(os.environ.get("ORBFE_ENGINE_SETS_ARUCO", D)))
+        DA = self.DA = max(1, int(os.environ.get("ORBFE_ENGINE_SETS_ARUCO", 1)))
         self.ex_sets = [[binding.ORBextractor(nfeatures, 1.2, nlevels, 20, 7, device=device) for _ in range(S)] for _ in range(D)]
         self.exs = [e for es in self.ex_sets for e in es]
         self.ex = self.exs[0]
@@ -143,6 +149,11 @@ class FrontEndPipeline:
                                [[torch.cuda.Stream(dev) for _ in range(S)] for _ in range(DA - 1)]
         self.orb_streams, self.aru_streams = self.orb_stream_sets[0], self.aru_stream_sets[0]
         self.last_set = self.last_aset = 0
+        if S == 1 and D > 1 and lend_aux_stream and os.environ.get("ORBFE_LEND_ALL", "1") != "0":
+            # every set's blur on the matching stream (1.4466 against 1.4873 ms with the handles' own fork streams, which share
+            # hardware queues with the busy ones)
+            for e in self.exs:
+                e.set_aux_stream(self.sp3)
         if S == 1 and D == 1 and lend_aux_stream:
             # ROCm maps streams onto 4 hardware queues, and two busy streams on one queue serialise.  The extractor's forked
             # launch (the blur) is lent the matching stream; measured against the handle's own fork stream and against one
