@@ -427,6 +427,39 @@ def main():
     matches = pipe.read_matches() if use_orb else None
     last_frames = np.roll(frames_np, -shifts[r_last], axis=0)       # host images of the last timed step's batch
 
+    # ---- the stages ALONE on the GPU (outside the clock): each engine by itself, three batches, median of its HIP events.  In the
+    # timed pipeline a stage's launch time is stretched by whatever else shares the chip -- two extractor batches, the detector and
+    # the matching are in flight together -- so the in-pipeline figure says how long the launch was resident, this one what it costs.
+    match_med = pipe.matching_times_us(median=True) if use_orb else (0.0, 0.0)      # in the pipeline: before the history is reset below
+    match_last = pipe.matching_times_us() if use_orb else (0.0, 0.0)
+    alone = {}
+    if not multi and not skips:
+        lay = pipe.layout
+        torch.cuda.synchronize()
+        if use_orb:
+            ex0 = pipe.ex
+            ex0.enable_kernel_timing(True)          # clears the history
+            for _ in range(3):
+                ex0.extract_batch_device(d_batches[r_last].data_ptr(), B, rows * pitch, rows, cols, pitch, pipe.rec_ptr[cur] + lay.kps,
+                                         pipe.rec_ptr[cur] + lay.desc, pipe.cap, pipe.rec_ptr[cur] + lay.n, ctypes.c_void_p(pipe.stream.cuda_stream))
+                torch.cuda.synchronize()
+            t = ex0.kernel_times_us(median=True)
+            alone.update({nm: float(v) for nm, v in zip(binding.ORBextractor.stage_names(len(t)), t)})
+            pipe.reset_timing_history()
+            for _ in range(3):
+                pipe.enqueue_matching(cur)
+                torch.cuda.synchronize()
+            alone["knn2"], alone["search_init"] = pipe.matching_times_us(median=True)
+        if use_aruco:
+            det0 = pipe.det
+            det0.enable_kernel_timing(True)
+            for _ in range(3):
+                det0.detect_batch_device(d_batches[r_last].data_ptr(), B, rows * pitch, rows, cols, pitch, pipe.rec_ptr[cur] + lay.mk,
+                                         pipe.mcap, pipe.rec_ptr[cur] + lay.nmk, ctypes.c_void_p(pipe.stream2.cuda_stream))
+                torch.cuda.synchronize()
+            t = det0.kernel_times_us(median=True)
+            alone.update({"aruco_" + nm: float(v) for nm, v in zip(binding.MarkerDetector.STAGES, t)})
+
     # ---- multi-GPU: rank 0 checks every gathered block of the last step against that rank's own stream, recomputed here
     gather_check = None
     if multi and rank == 0:
@@ -454,8 +487,8 @@ def main():
         stages = {nm: float(v) for nm, v in zip(binding.ORBextractor.stage_names(len(orb_us)), orb_us)}   # blur7 runs on a second stream
         stages_last = {nm: float(v) for nm, v in zip(binding.ORBextractor.stage_names(len(orb_us_last)), orb_us_last)}
         if use_orb:
-            stages["knn2"], stages["search_init"] = pipe.matching_times_us(median=True)
-            stages_last["knn2"], stages_last["search_init"] = pipe.matching_times_us()
+            stages["knn2"], stages["search_init"] = match_med
+            stages_last["knn2"], stages_last["search_init"] = match_last
         if use_aruco:
             for nm, v in zip(binding.MarkerDetector.STAGES, aruco_us):
                 stages["aruco_" + nm] = float(v)
@@ -491,6 +524,9 @@ def main():
             ent = {"bound": STAGE_BOUND.get(k, "latency"), "launch_us": us, "algorithmic_bytes_per_launch": ab,
                    "GBps": ab / (us * 1e-6) / 1e9 if us > 0 else 0.0}
             ent["hbm_frac"] = ent["GBps"] / HBM_PEAK_GBPS
+            if alone.get(k):
+                ent["launch_us_alone"] = alone[k]
+                ent["hbm_frac_alone"] = ab / (alone[k] * 1e-6) / 1e9 / HBM_PEAK_GBPS
             pk, frac_of = share.get(k, (k, 1.0))
             ent["traffic"] = (traffic.get(pk) * frac_of if traffic.get(pk) is not None else None) if traffic else None
             if pmc and pk in pmc:    # VALU issue time of the stage's launches (instruction counts x 4 cycles / 1024 SIMDs / 2.4 GHz)
@@ -514,6 +550,8 @@ def main():
                     "frac": d["hbm_frac"], "traffic": d["traffic"], "launch_us": d["launch_us"],
                     "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"], "frames_per_launch": fl(dom),
                     "longest_launch": longest,
+                    "alone": {"launch_us": d.get("launch_us_alone"), "frac": d.get("hbm_frac_alone"),
+                              "note": "the same stage with nothing else on the GPU (three batches after the clock, median)"} if d.get("launch_us_alone") else None,
                     "valu_us": d.get("valu_us"), "valu_frac": d.get("valu_frac"),
                     "note": "dominant kernel of the last timed step = the stage with the largest VALU issue time (the resource that "
                             "bounds the step; without a PMC profile of this configuration: the longest launch); launch_us = HIP events on the stream the stage is launched "
