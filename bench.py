@@ -347,8 +347,8 @@ def main():
     # every ORBFE_* variable that is set is recorded; the ones that change which kernels run or how they are scheduled make the
     # line a diagnostic (value null) unless they spell the default
     env_set = {k: v for k, v in sorted(os.environ.items()) if k.startswith("ORBFE_")}
-    harmless = {"ORBFE_BENCH_DEVICE", "ORBFE_BENCH_BACKEND", "ORBFE_LIB"}
-    defaults = {"ORBFE_ORIENT_PAIR": "1", "ORBFE_FAST0": "0", "ORBFE_EARLY_SHARED": "0", "ORBFE_ARUCO_VIS": "0", "ORBFE_ARUCO_FORCE_GLOBAL": "0", "ORBFE_STREAM_PRIO": "0,0,0", "ORBFE_ENGINE_SETS_ARUCO": "1", "ORBFE_LEND_ALL": "1",
+    harmless = {"ORBFE_BENCH_DEVICE", "ORBFE_BENCH_BACKEND", "ORBFE_LIB"}   # (ORBFE_GATHER_NOOP is not: it makes the line a diagnostic)
+    defaults = {"ORBFE_ORIENT_PAIR": "1", "ORBFE_FAST0": "0", "ORBFE_EARLY_SHARED": "0", "ORBFE_ARUCO_VIS": "0", "ORBFE_ARUCO_FORCE_GLOBAL": "0", "ORBFE_STREAM_PRIO": "0,0,0", "ORBFE_ENGINE_SETS_ARUCO": "1", "ORBFE_LEND_ALL": "1", "ORBFE_RECORD_SETS": "4", "ORBFE_GATHER_STREAM": "match",
                 "ORBFE_BLUR_PLACE": "1", "ORBFE_ARUCO_RELAY_CHUNK": "0", "ORBFE_OCC_FAST": "0", "ORBFE_OCC_BLUR": "0",
                 "ORBFE_OCC_ORIENT": "0"}
     env_nondefault = {k: v for k, v in env_set.items() if k not in harmless and defaults.get(k) != v}
@@ -359,10 +359,16 @@ def main():
     gather = None
     pipe = FrontEndPipeline(B, rows, cols, args.nfeatures, args.nlevels, args.dictionary, device=local_rank,
                             marker_capacity=args.marker_capacity, use_orb=use_orb, use_aruco=use_aruco, splits=args.splits)
-    if multi:
+    if os.environ.get("ORBFE_PG_ONLY"):      # diagnostic: the process group is initialised, the pipeline runs without its gather branch
+        gather_off = True
+    else:
+        gather_off = False
+    if multi and not gather_off:
         # gloo moves CPU tensors: the test hook stages the record set through the host (the RCCL path gathers in place)
         gather = sharding.RecordGather(pipe.recs[0] if backend == "nccl" else pipe.recs[0].cpu())
-        if backend == "nccl":
+        if os.environ.get("ORBFE_GATHER_NOOP"):       # diagnostic: the gather branch's events and waits without the collective
+            pipe.gather = lambda t: None
+        elif backend == "nccl":
             pipe.gather = gather
         else:
             pipe.gather = lambda t: gather(t.cpu())
@@ -398,6 +404,7 @@ def main():
     for i in range(args.steps):
         r = i % R
         last = (pipe.step(d_batches[r]), r)
+    t_enq = time.perf_counter() - t0           # host time to enqueue all steps (the GPU runs behind it)
     torch.cuda.synchronize()
     if multi:
         dist.barrier()
@@ -462,7 +469,7 @@ def main():
 
     # ---- multi-GPU: rank 0 checks every gathered block of the last step against that rank's own stream, recomputed here
     gather_check = None
-    if multi and rank == 0:
+    if multi and rank == 0 and not os.environ.get("ORBFE_GATHER_NOOP") and not gather_off:
         blocks = gather.blocks
         lay = pipe.layout
         checked = []
@@ -626,7 +633,7 @@ def main():
                        "parallelism": "stream-per-gpu x%d, %s" % (world, ("%s gather to rank 0" % ("RCCL" if backend == "nccl" else backend))
                                                                   if multi else "no collective (one rank)")},
             "roofline": roof, "cpu_baseline": cpu, "verified_frames": verified, "skips": skips or None,
-            "stage_us": stages, "stage_us_last_step": stages_last,
+            "stage_us": stages, "stage_us_last_step": stages_last, "host_enqueue_ms_per_step": 1000.0 * t_enq / args.steps,
         }
         if invalid:
             out["diagnostic_frames_per_s"] = total_frames / elapsed

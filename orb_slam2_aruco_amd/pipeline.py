@@ -81,12 +81,12 @@ class FrontEndPipeline:
     """Extractor, detector and matching of one stream of frames on one GPU.
 
     step(d_imgs) enqueues one batch (B frames, rows x pitch bytes each, resident on the device) and returns at once; result
-    set i % 2 receives batch i, so the matching of batch i (third stream) -- and on N > 1 its gather (communication
+    set i % R (R = 4) receives batch i, so the matching of batch i (third stream) -- and on N > 1 its gather (communication
     stream) -- overlap with the engines of batch i + 1.  The engines are joined where their results meet: before the
     gather and in synchronize()."""
 
     def __init__(self, frames, rows, cols, nfeatures=1000, nlevels=8, dictionary="ARUCO", device=0, marker_capacity=64,
-                 use_orb=True, use_aruco=True, splits=1, gather=None, lend_aux_stream=True, engine_sets=None):
+                 use_orb=True, use_aruco=True, splits=1, gather=None, lend_aux_stream=True, engine_sets=None, record_sets=4, gather_stream="match"):
         import torch
         self.torch = torch
         self.L = binding.load()
@@ -129,7 +129,12 @@ class FrontEndPipeline:
         # is rescaled to the frame size before the marker poses (markerdetector_impl.cpp:1110-1172)
         self.cam_K = binding.camera_resize(np.array(TUM1_K, np.float32), (1280, 720), (cols, rows)) if use_aruco else None
         self.cam_D = np.array(TUM1_DIST, np.float32)
-        self.recs = [torch.zeros(lay.nbytes, dtype=torch.uint8, device=dev) for _ in range(2)]
+        # Result sets in rotation: batch i writes set i % R.  A set is reused only when the matching (and, on N > 1, the gather) of the
+        # batch that last wrote it is done, which ties every engine to the slowest one R batches back.  With two sets the gather
+        # branch cost 12 % (the detector, 1.05 ms per batch, may run ahead of the extractor chain, 1.47 ms, by less than two
+        # batches); four sets (80 MB per rank) take the coupling out: 1.65 -> see profiles/r03_record_sets.txt.
+        R = self.R = max(2, int(os.environ.get("ORBFE_RECORD_SETS", record_sets)))
+        self.recs = [torch.zeros(lay.nbytes, dtype=torch.uint8, device=dev) for _ in range(R)]
         self.rec_ptr = [r.data_ptr() for r in self.recs]
         z = lambda *shape: torch.zeros(shape, dtype=torch.int32, device=dev)
         # matching outputs of the newest batch: pair p = frame p (queries / F1) against frame p + 1 (train / F2)
@@ -169,17 +174,25 @@ class FrontEndPipeline:
                 self.det.set_aux_stream(self.sp4)
                 self.ex.set_early_stream(self.sp4)
         ev = lambda **kw: torch.cuda.Event(**kw)
-        self.ex_done = [[ev() for _ in range(S)] for _ in range(2)]
-        self.det_done = [[ev() for _ in range(S)] for _ in range(2)]
-        self.match_done = [ev() for _ in range(2)]
-        self.gather_done = [ev() for _ in range(2)]
+        self.ex_done = [[ev() for _ in range(S)] for _ in range(R)]
+        self.det_done = [[ev() for _ in range(S)] for _ in range(R)]
+        self.match_done = [ev() for _ in range(R)]
+        self.gather_done = [ev() for _ in range(R)]
         # around the matching launches (their stream); one event triple per step, the newest 64 steps kept for the median
         self.match_evs = [[ev(enable_timing=True) for _ in range(3)] for _ in range(64)]
         self.match_ev = self.match_evs[0]
         self.match_steps = 0
         self.gather_evs = [[ev(enable_timing=True) for _ in range(2)] for _ in range(64)]
         self.gather_steps = 0
-        self.comm_stream = torch.cuda.Stream(dev)
+        # The batch's gather needs a stream.  ROCm runs the process's streams on four hardware queues and the engines use four
+        # (extractor sets, detector, matching + blur, the detector's /2 pyramid): a stream of its own for the collective is a fifth
+        # ACTIVE one, and that alone -- one event record per batch on it, the collective replaced by a no-op, no waits -- costs the
+        # C2 step 9 % (1.50 -> 1.63 ms; profiles/r03_gather_stream.txt).  So the gather is issued on a stream that exists anyway:
+        # "match" (default): behind this batch's matching, which has waited for the extractor already; "det": behind the
+        # detector's poses; "comm": the separate stream (the round-2 arrangement).
+        which = os.environ.get("ORBFE_GATHER_STREAM", gather_stream)
+        self.comm_stream = {"match": self.stream3, "det": self.stream2}.get(which) or torch.cuda.Stream(dev)
+        self.gather_stream_name = which
         self.gather = gather            # sharding.RecordGather or None (single GPU)
         self.step_no = 0
         self.big_frames = False
@@ -199,7 +212,7 @@ class FrontEndPipeline:
         rows, cols, pitch, cap, mcap = self.rows, self.cols, self.pitch, self.cap, self.mcap
         i = self.step_no
         self.step_no += 1
-        cur = i % 2
+        cur = i % self.R
         eset = self.last_set = i % self.D
         aset = self.last_aset = i % self.DA
         exs, dets = self.ex_sets[eset], (self.det_sets[aset] if self.use_aruco else [])
@@ -213,8 +226,8 @@ class FrontEndPipeline:
             for k in range(S):
                 f0, nf = self.bounds[k], self.bounds[k + 1] - self.bounds[k]
                 st = aru_streams[k]
-                if multi and i >= 2:
-                    st.wait_event(self.gather_done[cur])         # batch i-2 has left this record set
+                if multi and i >= self.R:
+                    st.wait_event(self.gather_done[cur])         # batch i-R has left this record set
                 sp = ctypes.c_void_p(st.cuda_stream)
                 dets[k].detect_batch_device(img0 + f0 * rows * pitch, nf, rows * pitch, rows, cols, pitch,
                                                  base + lay.mk + f0 * mcap * 36, mcap, base + lay.nmk + f0 * 4, sp)
@@ -228,7 +241,7 @@ class FrontEndPipeline:
             for k in range(S):
                 f0, nf = self.bounds[k], self.bounds[k + 1] - self.bounds[k]
                 st = orb_streams[k]
-                if i >= 2:
+                if i >= self.R:
                     st.wait_event(self.match_done[cur])          # the matching of batch i-2 has read this record set
                     if multi:
                         st.wait_event(self.gather_done[cur])
@@ -241,8 +254,8 @@ class FrontEndPipeline:
             if os.environ.get("ORBFE_MATCH_TWICE"):      # sensitivity study only (tools/sensitivity.sh): the matching launched twice
                 self.enqueue_matching(cur)
         if multi:
-            # the batch's one collective, on its own stream: it waits for the engines of THIS batch and runs
-            # while the next batch is computed into the other record set
+            # the batch's one collective: it waits for the engines of THIS batch and runs while the next batches are
+            # computed into the other record sets (on which stream: see __init__)
             with self.torch.cuda.stream(self.comm_stream):
                 for k in range(S):
                     if self.use_orb:
