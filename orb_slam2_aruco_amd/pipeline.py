@@ -173,6 +173,10 @@ class FrontEndPipeline:
                 self.sp4 = ctypes.c_void_p(self.stream4.cuda_stream)
                 self.det.set_aux_stream(self.sp4)
                 self.ex.set_early_stream(self.sp4)
+        if use_aruco and S == 1 and os.environ.get("ORBFE_DET_NOFORK", "0") != "0":
+            # experiment: the detector's /2 pyramid in line on the detector's stream (one active stream fewer)
+            for dset, sset in zip(self.det_sets, self.aru_stream_sets):
+                dset[0].set_aux_stream(ctypes.c_void_p(sset[0].cuda_stream))
         ev = lambda **kw: torch.cuda.Event(**kw)
         self.ex_done = [[ev() for _ in range(S)] for _ in range(R)]
         self.det_done = [[ev() for _ in range(S)] for _ in range(R)]
