@@ -404,6 +404,7 @@ def main():
     for i in range(args.steps):
         r = i % R
         last = (pipe.step(d_batches[r]), r)
+    pipe.flush()                               # the last batch's matching / gather (held back one step, see FrontEndPipeline.step)
     t_enq = time.perf_counter() - t0           # host time to enqueue all steps (the GPU runs behind it)
     torch.cuda.synchronize()
     if multi:

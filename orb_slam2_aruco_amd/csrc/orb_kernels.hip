@@ -294,28 +294,33 @@ __global__ __launch_bounds__(256) void k_fast_cells(ImgView src0, ImgView pyr, c
     const int pitch = (level == 0) ? src0.pitch : g.pitch;
     const int SP = roi_pitch, MP = map_pitch;
 
-    // stage the ROI (columns -1 .. w-1: the one-byte shift) with unaligned dword loads, 8 in flight per lane; a lane's
-    // items are 64 apart, so (row, dword) advances by a constant step instead of a division per item
+    // stage the ROI (columns -1 .. w-1: the one-byte shift) with unaligned dword loads, 8 in flight per lane.  A lane keeps its
+    // dword column and takes every (64 / ndw)-th row: its image and LDS offsets advance by constants (uniform base + 32-bit lane
+    // offset, one addition each per load -- the flat (row, dword) numbering cost a wrap test, three selects and a 64-bit
+    // multiply-add per item: 115 of the kernel's ~890 VALU instructions per wave); the 64 % ndw lanes left over idle here.
     {
         typedef uint32_t u32_unaligned __attribute__((aligned(1)));
-        const int ndw = (w + 4) >> 2, items = ndw * h;
-        const int qstep = 64 / ndw, rstep = 64 - qstep * ndw;
-        int y = lane / ndw, c = lane - y * ndw;
+        const int ndw = (w + 4) >> 2;
+        const int rpi = 64 / ndw;                      // rows per trip of the wave
+        const int y0 = lane / ndw, c = lane - y0 * ndw;
         const uint8_t* roi = img + (size_t)iniY * pitch + iniX - 1;
-        for (int i0 = 0; i0 < items; i0 += 8 * 64) {
-            uint32_t v[8];
-            int so[8];
+        uint32_t go = (uint32_t)(y0 * pitch + 4 * c), so_ = (uint32_t)(y0 * SP + 4 * c);
+        const uint32_t gstep = (uint32_t)(rpi * pitch), sstep = (uint32_t)(rpi * SP);
+        // no predicates (a load under a condition becomes a branch with a wait behind it): a row past the end -- and with it the
+        // lanes left over -- takes the ROI's last row, i.e. loads and stores that row's dword once more
+        const uint32_t go_last = (uint32_t)((h - 1) * pitch + 4 * c), so_last = (uint32_t)((h - 1) * SP + 4 * c);
+        for (int r0 = 0; r0 < h; r0 += 8 * rpi) {
+            uint32_t v[8], so[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                const bool in = i0 + k * 64 + lane < items;
-                so[k] = in ? y * SP + 4 * c : -1;
-                v[k] = in ? *reinterpret_cast<const u32_unaligned*>(roi + (uint32_t)(y * pitch + 4 * c)) : 0u; // 32-bit offset off a uniform base
-                y += qstep; c += rstep;
-                if (c >= ndw) { c -= ndw; y++; }
+                const bool in = r0 + k * rpi + y0 < h;
+                const uint32_t g_ = in ? go + (uint32_t)k * gstep : go_last;
+                so[k] = in ? so_ + (uint32_t)k * sstep : so_last;
+                v[k] = *reinterpret_cast<const u32_unaligned*>(roi + g_);
             }
 #pragma unroll
-            for (int k = 0; k < 8; k++)
-                if (so[k] >= 0) *reinterpret_cast<uint32_t*>(simg + so[k]) = v[k];
+            for (int k = 0; k < 8; k++) *reinterpret_cast<uint32_t*>(simg + so[k]) = v[k];
+            go += 8 * gstep; so_ += 8 * sstep;
         }
     }
     for (int i = lane; i < (int)(map_bytes / 4); i += 64) reinterpret_cast<uint32_t*>(smap)[i] = 0;
