@@ -36,6 +36,7 @@ struct orbfe_aruco {
     int relay_kshift = 5;      // initial grid spacing (log2) of k_contours_relay
     int relay_chunk = getenv("ORBFE_ARUCO_RELAY_CHUNK") ? atoi(getenv("ORBFE_ARUCO_RELAY_CHUNK")) : 1 << 30;   // frames per launch of the large-frame relay kernels
     PinnedBuf pinned; // staging of the host-pointer entry points
+    bool relay_wide = !(getenv("ORBFE_ARUCO_RELAY_WIDE") && !atoi(getenv("ORBFE_ARUCO_RELAY_WIDE")));
     DevBuf d_vis;        // per frame: one bit per start candidate on a gridded border (relay kernels, phase (d) -> (c))
     size_t vis_fu32 = 0;
     int vis_mode = getenv("ORBFE_ARUCO_VIS") ? atoi(getenv("ORBFE_ARUCO_VIS")) : 0; // experiment, slower: see relay_frame
@@ -204,8 +205,8 @@ struct orbfe_aruco {
         // and frames whose tables only just fitted (1582 x 619: 156,976 B dynamic) failed at launch
         size_t rl_static = 0;
         {
-            const void* fns[3] = {reinterpret_cast<const void*>(k_contours_relay), reinterpret_cast<const void*>(k_contours_relay8),
-                                  reinterpret_cast<const void*>(k_contours_relay8g)};
+            const void* fns[4] = {reinterpret_cast<const void*>(k_contours_relay), reinterpret_cast<const void*>(k_contours_relay8),
+                                  reinterpret_cast<const void*>(k_contours_relay8g), reinterpret_cast<const void*>(k_contours_relay_wide)};
             for (const void* fn : fns) {
                 hipFuncAttributes fa{};
                 ORBFE_HIP(hipFuncGetAttributes(&fa, fn));
@@ -352,9 +353,10 @@ struct orbfe_aruco {
                                    d_tailkeys.as<unsigned long long>(), d_tailoff.as<int32_t>(), d_counts.as<int32_t>(), d_hint.as<int32_t>(),
                                    d_small.as<uint4>(), d_rstate.as<int32_t>(), d_gpad.as<uint32_t>(), gpad_fu32, d_lut.as<uint16_t>(), f0);
             } else {
-            auto rfn = relay_tbits > 12 ? k_contours_relay8 : k_contours_relay;
+            const bool wide = relay_tbits <= 12 && B <= 32 && relay_wide;   // few frames: 16 waves per frame (see k_contours_relay_wide)
+            auto rfn = relay_tbits > 12 ? k_contours_relay8 : wide ? k_contours_relay_wide : k_contours_relay;
             { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(rfn), (size_t)(rlds)); if (rc_lds_) return rc_lds_; }
-            hipLaunchKernelGGL(rfn, dim3(nb_), dim3(relay_tbits > 12 ? RL_THREADS_BIG : RL_THREADS), rlds, s, d_bits.as<uint32_t>(), bits_fu32, wpr,
+            hipLaunchKernelGGL(rfn, dim3(nb_), dim3(relay_tbits > 12 || wide ? RL_THREADS_BIG : RL_THREADS), rlds, s, d_bits.as<uint32_t>(), bits_fu32, wpr,
                                cols, rows, lds_bits_words, 70, relay_kshift, relay_tbits, d_segs.as<RelaySeg>(),
                                d_pool.as<uint32_t>(), pool_fu32, (int)pool_fu32, d_kept.as<ArKept>(), relay_kcap, relay_kcap,
                                d_tailkeys.as<unsigned long long>(), d_tailoff.as<int32_t>(), d_counts.as<int32_t>(), d_hint.as<int32_t>(),

@@ -1485,6 +1485,26 @@ __global__ __launch_bounds__(RL_THREADS_BIG) void k_contours_relay8(
     }
 }
 
+// Small batches (a single frame of the drop-in path, up to 32): twice the waves per frame on the same 4096-slot table.  On an empty
+// chip the walks are bound by their dependent LDS round trips, and sixteen waves hide them better (phase clocks of one 640 x 480
+// frame: 833 k -> 572 k cycles); a full batch is bound by instruction issue over all its workgroups, where the 8-wave version
+// wins (387 against 446 us per 300 frames).
+__global__ __launch_bounds__(RL_THREADS_BIG) void k_contours_relay_wide(
+    const uint32_t* __restrict__ gbits, size_t bits_fstride, int wpr_g, int W, int H, int lds_bits_words, int min_len,
+    int kshift, int tbits, RelaySeg* __restrict__ segs, uint32_t* __restrict__ pool, size_t pool_fstride, int pool_cap,
+    ArKept* __restrict__ kept_out, int kept_cap, int kcap, unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off,
+    int32_t* __restrict__ counts, int32_t* __restrict__ hint, uint4* __restrict__ small_g, int32_t* __restrict__ rstate, int small_elsewhere,
+    const uint16_t* __restrict__ lut_g, int f0, uint32_t* __restrict__ vis_g, size_t vis_fstride)
+{
+    __builtin_amdgcn_s_setprio(2);
+    if (relay_frame<false, 4096 / RL_THREADS_BIG, RL_THREADS_BIG>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool, pool_fstride, pool_cap,
+                              kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate, nullptr, 0, small_elsewhere, lut_g, f0, vis_g, vis_fstride)) {
+        __syncthreads();
+        relay_frame<true, 4096 / RL_THREADS_BIG, RL_THREADS_BIG>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool, pool_fstride, pool_cap,
+                             kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate, nullptr, 0, small_elsewhere, lut_g, f0, vis_g, vis_fstride);
+    }
+}
+
 // Frames whose bit image does not fit LDS (1920 x 1080: 264 KB): the same formulation with the padded bit image in HBM -- it stays
 // in L2 -- and only the lists and the 8192-slot marker table in LDS.  A step costs an L2 round trip instead of an LDS one, but the
 // segments are as short as ever (the single-walker kernel follows a 5000-point border in one lane), and the small borders are
@@ -2170,7 +2190,7 @@ __global__ __launch_bounds__(DC_WAVES * 64) void k_decode_warp(ImgView src0, Img
                 Mi[8] = (M[0] * M[4] - M[1] * M[3]) * d;
             }
         }
-        int isum = 0;
+        int isum = 0, blo = 0, bhi = 0;
         if (ok) {
             const uint8_t* img = (lvl == 0) ? src0.base + (size_t)f * src0.fstride : pyr.base + (size_t)f * pyr.fstride + L.off;
             const int pitch = (lvl == 0) ? src0.pitch : L.pitch;
@@ -2187,12 +2207,16 @@ __global__ __launch_bounds__(DC_WAVES * 64) void k_decode_warp(ImgView src0, Img
             const uint32_t h0 = h[4 * lane], h1 = h[4 * lane + 1], h2 = h[4 * lane + 2], h3 = h[4 * lane + 3];
             reinterpret_cast<uint2*>(hist + (size_t)it * 256)[lane] = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
             isum = wave_sum((int)(h0 * (4 * lane) + h1 * (4 * lane + 1) + h2 * (4 * lane + 2) + h3 * (4 * lane + 3)));
+            // first and last non-empty bin (in units of this lane's four bins): the Otsu recurrence does nothing outside them
+            const unsigned long long ne = __ballot((h0 | h1 | h2 | h3) != 0u);
+            blo = ne ? 4 * __builtin_ctzll(ne) : 0;
+            bhi = ne ? 4 * (63 - __builtin_clzll(ne)) + 3 : 0;
         }
         if (lane == 0) {
             DcItem* o = items + it;
 #pragma unroll
             for (int k = 0; k < 9; k++) o->Mi[k] = Mi[k];
-            o->lvl = lvl; o->ok = ok ? 1 : 0; o->isum = isum; o->th = 0;
+            o->lvl = lvl; o->ok = ok ? 1 : 0; o->isum = isum; o->th = 0; o->bin_lo = blo; o->bin_hi = bhi;
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -2229,7 +2253,10 @@ __global__ __launch_bounds__(64) void k_decode_otsu(const int32_t* __restrict__ 
             max_sigma = better ? sigma : max_sigma;
             max_val = better ? i_prev : max_val;
         };
-        for (int i0 = 0; i0 < 256; i0 += 32) { // four 16-byte loads (32 bins) in flight per lane
+        // Bins below the first non-empty one leave mu1 = q1 = 0, bins above the last one are all skipped (q2 = 1 - q1 is below the
+        // tolerance once every pixel is counted): the loop runs over the groups of 32 bins in between -- same values, fewer trips
+        const int i_begin = items[it].bin_lo & ~31, i_end = min(256, (items[it].bin_hi | 31) + 1);
+        for (int i0 = i_begin; i0 < i_end; i0 += 32) { // four 16-byte loads (32 bins) in flight per lane
             uint4 hv[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) hv[k] = hp[i0 / 8 + k];
@@ -2252,7 +2279,7 @@ __global__ __launch_bounds__(64) void k_decode_otsu(const int32_t* __restrict__ 
                 }
             }
         }
-        variance_of_previous(255);
+        variance_of_previous(i_end - 1);
     }
     items[it].th = max_val;
 }

@@ -58,6 +58,10 @@ __global__ void k_contours_relay8(const uint32_t* gbits, size_t bits_fstride, in
                                  int lds_bits_words, int min_len, int kshift, int tbits, RelaySeg* segs, uint32_t* pool,
                                  size_t pool_fstride, int pool_cap, ArKept* kept_out, int kept_cap, int kcap,
                                  unsigned long long* tail_keys, int32_t* tail_off, int32_t* counts, int32_t* hint, uint4* small_g, int32_t* rstate, int small_elsewhere, const uint16_t* lut_g, int f0, uint32_t* vis_g, size_t vis_fstride);
+__global__ void k_contours_relay_wide(const uint32_t* gbits, size_t bits_fstride, int wpr_g, int W, int H,
+                                 int lds_bits_words, int min_len, int kshift, int tbits, RelaySeg* segs, uint32_t* pool,
+                                 size_t pool_fstride, int pool_cap, ArKept* kept_out, int kept_cap, int kcap,
+                                 unsigned long long* tail_keys, int32_t* tail_off, int32_t* counts, int32_t* hint, uint4* small_g, int32_t* rstate, int small_elsewhere, const uint16_t* lut_g, int f0, uint32_t* vis_g, size_t vis_fstride);
 __global__ void k_contours_relay8g(const uint32_t* gbits, size_t bits_fstride, int wpr_g, int W, int H,
                                  int lds_bits_words, int min_len, int kshift, int tbits, RelaySeg* segs, uint32_t* pool,
                                  size_t pool_fstride, int pool_cap, ArKept* kept_out, int kept_cap, int kcap,
@@ -79,6 +83,7 @@ struct DcItem { // one rectangle candidate between the decode kernels
     double Mi[9]; // inverse homography of the warp
     int lvl, ok;  // pyramid level; 0 = singular system
     int isum, th; // first moment of the patch histogram; Otsu threshold
+    int bin_lo, bin_hi; // first / last non-empty histogram bin
 };
 __global__ void k_decode_warp(ImgView src0, ImgView pyr, const ArLevel* levels, int nlevels, const ArRect* rects, int rect_cap,
                               const int32_t* cand_idx, int S, int W0, const uint32_t* work, const int32_t* wctr, DcItem* items,
