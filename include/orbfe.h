@@ -564,6 +564,13 @@ int orbfe_marker_poses(const orbfe_marker* markers, int n, float marker_size, co
 int orbfe_marker_poses_batch_device(const orbfe_marker* d_markers, const int32_t* d_n, int capacity, int nframes,
                                     float marker_size, const float* K4, const float* dist, int ndist,
                                     orbfe_marker_pose* d_poses, void* stream);
+/* detect(image, CameraParameters, markerSize) in ONE call (markerdetector.h:276-283: what Frame.cc:142 calls): the markers of
+ * orbfe_aruco_detect plus poses[i] of markers[i] as orbfe_marker_poses would give them, with one upload, one wait and one set of
+ * result copies instead of two of each.  K4 = {fx, fy, cx, cy} for THIS image size (orbfe_camera_resize when CamSize differs). */
+int orbfe_aruco_detect_poses(orbfe_aruco* h, const uint8_t* img, int rows, int cols, size_t step, orbfe_marker* out,
+                             orbfe_marker_pose* poses, int capacity, int32_t* n_out, float marker_size, const float* K4,
+                             const float* dist, int ndist);
+
 
 #ifdef __cplusplus
 }

@@ -126,8 +126,22 @@ public:
             throw cv::Exception(9001, orbfe_last_error(), "MarkerDetector::detect", __FILE__, __LINE__);
         const int cap = orbfe_aruco_max_markers(h_);
         std::vector<orbfe_marker> m(cap);
+        std::vector<orbfe_marker_pose> poses;
         int32_t n = 0;
-        if (orbfe_aruco_detect(h_, input.data, input.rows, input.cols, input.step, m.data(), cap, &n) != ORBFE_OK)
+        // with a camera and a marker size (what Frame.cc:142 passes) detection and the IPPE poses are one library call
+        const bool want_pose = camMatrix.rows != 0 && markerSizeMeters > 0;
+        if (want_pose)
+        {
+            cv::Mat K32, D32;
+            camMatrix.convertTo(K32, CV_32F);
+            distCoeff.convertTo(D32, CV_32F);
+            const float K4[4] = {K32.at<float>(0, 0), K32.at<float>(1, 1), K32.at<float>(0, 2), K32.at<float>(1, 2)};
+            poses.resize(cap);
+            if (orbfe_aruco_detect_poses(h_, input.data, input.rows, input.cols, input.step, m.data(), poses.data(), cap, &n, markerSizeMeters,
+                                         K4, D32.empty() ? nullptr : D32.ptr<float>(), (int)D32.total()) != ORBFE_OK)
+                throw cv::Exception(9001, orbfe_last_error(), "MarkerDetector::detect", __FILE__, __LINE__);
+        }
+        else if (orbfe_aruco_detect(h_, input.data, input.rows, input.cols, input.step, m.data(), cap, &n) != ORBFE_OK)
             throw cv::Exception(9001, orbfe_last_error(), "MarkerDetector::detect", __FILE__, __LINE__);
         detectedMarkers.clear();
         detectedMarkers.resize(n);
@@ -152,16 +166,8 @@ public:
             }
         }
         // detect the position of detected markers if desired (markerdetector_impl.cpp:8720-8780 -> Marker::calculateExtrinsics)
-        if (camMatrix.rows != 0 && markerSizeMeters > 0 && n > 0)
+        if (want_pose && n > 0)
         {
-            cv::Mat K32, D32;
-            camMatrix.convertTo(K32, CV_32F);
-            distCoeff.convertTo(D32, CV_32F);
-            const float K4[4] = {K32.at<float>(0, 0), K32.at<float>(1, 1), K32.at<float>(0, 2), K32.at<float>(1, 2)};
-            std::vector<orbfe_marker_pose> poses(n);
-            if (orbfe_marker_poses(m.data(), n, markerSizeMeters, K4, D32.empty() ? nullptr : D32.ptr<float>(), (int)D32.total(), poses.data(), 0) !=
-                ORBFE_OK)
-                throw cv::Exception(9004, orbfe_last_error(), "calculateExtrinsics", __FILE__, __LINE__); // marker.cpp:325-331
             for (int i = 0; i < n; i++)
             {
                 Marker& M = detectedMarkers[i];

@@ -36,7 +36,7 @@ SYMBOLS = [
     "orbfe_aruco_debug_kernel_times", "orbfe_aruco_set_aux_stream",
     "orbfe_aruco_batch_status", "orbfe_aruco_set_big_frames", "orbfe_aruco_set_error_correction_rate",
     "orbfe_aruco_set_detection_mode", "orbfe_aruco_set_corner_refinement", "orbfe_aruco_marker_contour", "orbfe_aruco_marker_contours",
-    "orbfe_camera_resize", "orbfe_marker_poses", "orbfe_marker_poses_batch_device",
+    "orbfe_camera_resize", "orbfe_marker_poses", "orbfe_marker_poses_batch_device", "orbfe_aruco_detect_poses",
     "orbfe_vocabulary_load_text", "orbfe_vocabulary_create", "orbfe_vocabulary_destroy", "orbfe_vocabulary_info",
     "orbfe_vocabulary_transform", "orbfe_vocabulary_transform_batch_device",
     "orbfe_search_by_bow", "orbfe_search_by_bow_batch_device",
@@ -126,6 +126,7 @@ def load():
         L.orbfe_aruco_set_dictionary.argtypes = [vp, C.c_char_p]
         L.orbfe_aruco_max_markers.argtypes = [vp]
         L.orbfe_aruco_detect.argtypes = [vp, vp, i32, i32, sz, vp, i32, vp]
+        L.orbfe_aruco_detect_poses.argtypes = [vp, vp, i32, i32, sz, vp, vp, i32, vp, f32, vp, vp, i32]
         L.orbfe_aruco_detect_batch.argtypes = [vp, vp, i32, sz, i32, i32, sz, vp, i32, vp]
         L.orbfe_aruco_detect_batch_device.argtypes = [vp, vp, i32, sz, i32, i32, sz, vp, i32, vp, vp]
         L.orbfe_aruco_debug_image.argtypes = [vp, i32, i32, vp]
@@ -793,11 +794,24 @@ class MarkerDetector:
         (markerdetector.h:276-312; Frame.cc:142 passes 0.187) -> (markers, POSE_DTYPE poses): the camera matrix is
         rescaled to the image size first (markerdetector_impl.cpp:1110-1172), then every marker gets its IPPE pose."""
         if camera is not None and markerSizeMeters > 0:
-            mk = self.detect(image)
             K, dist, cam_size = camera
             K4, d = _camera(K, dist)
-            rows, cols = np.asarray(image).shape[:2]
-            return mk, marker_poses(mk, markerSizeMeters, camera_resize(K4, cam_size, (cols, rows)), d)
+            image = np.asarray(image)
+            if image.size == 0:
+                return np.zeros(0, MARKER_DTYPE), np.zeros(0, POSE_DTYPE)
+            assert image.dtype == np.uint8 and image.ndim == 2
+            if image.strides[1] != 1:
+                image = np.ascontiguousarray(image)
+            rows, cols = image.shape
+            K4 = np.ascontiguousarray(camera_resize(K4, cam_size, (cols, rows)), np.float32)
+            out = np.zeros(self.capacity, MARKER_DTYPE)
+            poses = np.zeros(self.capacity, POSE_DTYPE)
+            n = C.c_int32(0)
+            _check(self.L, self.L.orbfe_aruco_detect_poses(self.h, _p(image), rows, cols, image.strides[0], _p(out), _p(poses), self.capacity,
+                                                           C.byref(n), markerSizeMeters, _p(K4), _p(d) if d is not None and len(d) else None,
+                                                           0 if d is None else len(d)), "orbfe_aruco_detect_poses")
+            self._shape = image.shape
+            return out[:n.value].copy(), poses[:n.value].copy()
         image = np.asarray(image)
         if image.size == 0:
             return np.zeros(0, MARKER_DTYPE)

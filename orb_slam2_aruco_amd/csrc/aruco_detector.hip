@@ -36,6 +36,7 @@ struct orbfe_aruco {
     int relay_kshift = 5;      // initial grid spacing (log2) of k_contours_relay
     int relay_chunk = getenv("ORBFE_ARUCO_RELAY_CHUNK") ? atoi(getenv("ORBFE_ARUCO_RELAY_CHUNK")) : 1 << 30;   // frames per launch of the large-frame relay kernels
     PinnedBuf pinned; // staging of the host-pointer entry points
+    DevBuf d_poses;   // orbfe_aruco_detect_poses
     bool relay_wide = !(getenv("ORBFE_ARUCO_RELAY_WIDE") && !atoi(getenv("ORBFE_ARUCO_RELAY_WIDE")));
     DevBuf d_vis;        // per frame: one bit per start candidate on a gridded border (relay kernels, phase (d) -> (c))
     size_t vis_fu32 = 0;
@@ -67,7 +68,7 @@ struct orbfe_aruco {
     ~orbfe_aruco()
     {
         for (DevBuf* b : {&d_codes, &d_levels, &d_tabs, &d_bits, &d_pyr, &d_candq, &d_pool, &d_kept, &d_rects,
-                          &d_counts, &d_candidx, &d_ncand, &d_result, &d_gpad, &d_in, &d_out, &d_nout, &d_segs, &d_tailkeys, &d_tailoff, &d_small, &d_hint, &d_rstate, &d_lut, &d_twork, &d_trect, &d_tctr, &d_dwork, &d_dctr, &d_ditems, &d_dhist, &d_dpatch, &d_vis, &d_scodes, &d_sids,
+                          &d_counts, &d_candidx, &d_ncand, &d_result, &d_gpad, &d_in, &d_out, &d_nout, &d_segs, &d_tailkeys, &d_tailoff, &d_small, &d_hint, &d_rstate, &d_lut, &d_twork, &d_trect, &d_tctr, &d_dwork, &d_dctr, &d_ditems, &d_dhist, &d_dpatch, &d_vis, &d_poses, &d_scodes, &d_sids,
                           &d_msrc})
             b->release();
         if (own_stream) (void)hipStreamDestroy(own_stream);
@@ -606,8 +607,12 @@ int orbfe_aruco_detect_batch_device(orbfe_aruco* h, const uint8_t* d_imgs, int n
     return h->run_device(d_imgs, nframes, frame_stride, rows, cols, step, d_out, capacity, d_n_out, (hipStream_t)stream);
 }
 
-int orbfe_aruco_detect_batch(orbfe_aruco* h, const uint8_t* imgs, int nframes, size_t frame_stride, int rows, int cols,
-                             size_t step, orbfe_marker* out, int capacity, int32_t* n_out)
+} // extern "C"
+
+// detect (+ the IPPE pose of every marker when a camera is given: one call, one wait, instead of a detect call and a pose call)
+static int detect_batch_impl(orbfe_aruco* h, const uint8_t* imgs, int nframes, size_t frame_stride, int rows, int cols,
+                             size_t step, orbfe_marker* out, int capacity, int32_t* n_out, const PoseCamera* cam, float marker_size,
+                             orbfe_marker_pose* poses_out)
 {
     if (!h || !n_out) return fail(ORBFE_ERR_INVALID, "orbfe_aruco_detect_batch: null argument");
     if (!imgs || rows <= 0 || cols <= 0 || nframes <= 0) {
@@ -624,8 +629,10 @@ int orbfe_aruco_detect_batch(orbfe_aruco* h, const uint8_t* imgs, int nframes, s
     // page-locked staging: [frames in] then [n per frame | counts (4 per frame) | marker records] out -- three copies queued behind
     // the kernels and one wait instead of a blocking copy per array
     const size_t o_n = (dframe * nframes + 255) / 256 * 256, o_cnt = o_n + ((size_t)nframes * 4 + 63) / 64 * 64;
-    const size_t o_mk = o_cnt + ((size_t)nframes * 16 + 63) / 64 * 64, o_end = o_mk + (size_t)AR_MAX_RECTS * nframes * sizeof(orbfe_marker);
+    const size_t o_mk = o_cnt + ((size_t)nframes * 16 + 63) / 64 * 64, o_ps = o_mk + (size_t)AR_MAX_RECTS * nframes * sizeof(orbfe_marker);
+    const size_t o_end = o_ps + (cam ? (size_t)AR_MAX_RECTS * nframes * sizeof(orbfe_marker_pose) : 0);
     if ((rc = h->pinned.ensure(o_end))) return rc;
+    if (cam && (rc = h->d_poses.ensure((size_t)AR_MAX_RECTS * nframes * sizeof(orbfe_marker_pose)))) return rc;
     uint8_t* hp = h->pinned.as<uint8_t>();
     hipStream_t s = h->own_stream;
     for (int f = 0; f < nframes; f++)
@@ -640,6 +647,11 @@ int orbfe_aruco_detect_batch(orbfe_aruco* h, const uint8_t* imgs, int nframes, s
         ORBFE_HIP(hipMemcpyAsync(hp + o_n, h->d_nout.p, (size_t)nframes * 4, hipMemcpyDeviceToHost, s));
         ORBFE_HIP(hipMemcpyAsync(hp + o_cnt, h->d_counts.p, (size_t)nframes * 16, hipMemcpyDeviceToHost, s));
         ORBFE_HIP(hipMemcpyAsync(hp + o_mk, h->d_out.p, (size_t)AR_MAX_RECTS * nframes * sizeof(orbfe_marker), hipMemcpyDeviceToHost, s));
+        if (cam) {
+            hipLaunchKernelGGL(k_marker_poses, dim3((AR_MAX_RECTS + 63) / 64, nframes), dim3(64), 0, s, h->d_out.as<orbfe_marker>(),
+                               h->d_nout.as<int32_t>(), AR_MAX_RECTS, marker_size, *cam, h->d_poses.as<orbfe_marker_pose>());
+            ORBFE_HIP(hipMemcpyAsync(hp + o_ps, h->d_poses.p, (size_t)AR_MAX_RECTS * nframes * sizeof(orbfe_marker_pose), hipMemcpyDeviceToHost, s));
+        }
         ORBFE_HIP(hipStreamSynchronize(s));
         bool retry = false;
         for (int f = 0; f < nframes; f++) retry = retry || (counts[f * 4 + 2] & (2 | 4));
@@ -656,8 +668,30 @@ int orbfe_aruco_detect_batch(orbfe_aruco* h, const uint8_t* imgs, int nframes, s
         if (n_out[f] > capacity) return fail(ORBFE_ERR_CAPACITY, "frame %d has %d markers, capacity is %d", f, n_out[f], capacity);
         if (n_out[f])
             memcpy(out + (size_t)f * capacity, hp + o_mk + (size_t)f * AR_MAX_RECTS * sizeof(orbfe_marker), (size_t)n_out[f] * sizeof(orbfe_marker));
+        if (n_out[f] && cam)
+            memcpy(poses_out + (size_t)f * capacity, hp + o_ps + (size_t)f * AR_MAX_RECTS * sizeof(orbfe_marker_pose),
+                   (size_t)n_out[f] * sizeof(orbfe_marker_pose));
     }
     return ORBFE_OK;
+}
+
+extern "C" {
+
+int orbfe_aruco_detect_batch(orbfe_aruco* h, const uint8_t* imgs, int nframes, size_t frame_stride, int rows, int cols,
+                             size_t step, orbfe_marker* out, int capacity, int32_t* n_out)
+{
+    return detect_batch_impl(h, imgs, nframes, frame_stride, rows, cols, step, out, capacity, n_out, nullptr, 0.f, nullptr);
+}
+
+int orbfe_aruco_detect_poses(orbfe_aruco* h, const uint8_t* img, int rows, int cols, size_t step, orbfe_marker* out,
+                             orbfe_marker_pose* poses, int capacity, int32_t* n_out, float marker_size, const float* K4,
+                             const float* dist, int ndist)
+{
+    if (!poses) return fail(ORBFE_ERR_INVALID, "orbfe_aruco_detect_poses: null argument");
+    PoseCamera c;
+    int rc = pose_camera(K4, dist, ndist, marker_size, c, "orbfe_aruco_detect_poses");
+    if (rc) return rc;
+    return detect_batch_impl(h, img, 1, 0, rows, cols, step, out, capacity, n_out, &c, marker_size, poses);
 }
 
 int orbfe_aruco_detect(orbfe_aruco* h, const uint8_t* img, int rows, int cols, size_t step, orbfe_marker* out,
