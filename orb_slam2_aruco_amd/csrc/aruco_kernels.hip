@@ -737,8 +737,8 @@ template __global__ void k_contours_t<false>(const uint32_t*, size_t, int, int, 
 //   (c) small borders (no grid marker on them) followed whole from their start candidates;
 //   (d) one segment per marker: walk to the next marker, remember the smallest start state passed;
 //   (e) cyclic lists: pointer doubling for the minimum (= the canonical start), list ranking for the offsets;
-//   (f) kept borders (> min_len points) get pool space, their segments are walked again and write their points
-//       straight to the final position;  (g) the common tail (sort, approxPolyDP, rectangles).
+//   (f) kept borders (> min_len points) get pool space, their segments are walked again (nothing is staged in (d)) and write
+//       their points straight to the final position;  (g) the common tail (sort, approxPolyDP, rectangles).
 // If the markers do not fit the table the grid is coarsened, down to no grid at all (then (c) follows every border whole).
 __device__ __forceinline__ uint32_t rl_hash(uint32_t key, int tbits) { return (key * 0x9E3779B1u) >> (32 - tbits); }
 
@@ -995,11 +995,9 @@ __device__ __forceinline__ int relay_frame(
         *hint = kshift >= 30 ? 7 : (s_nmark < (T >> 2) && kshift > 5) ? kshift - 1 : kshift;
     RL_STAMP();
 
-    // every lane owns a staging arena in the upper part of the frame's pool: the points of its segments (d) and of the
-    // small borders it keeps (c) wait there until (f2) knows their final place
-    const int stage0 = pool_cap >> 2, arena = (pool_cap - stage0) / NT;
-    uint32_t* my_arena = pl + stage0 + tid * arena;
-    int wp = 0;
+    // the part of the frame's pool the kept borders may fill (the rest was the staging arenas of rounds 1 - 2; the single-walker
+    // kernel still uses it that way)
+    const int stage0 = pool_cap >> 2;
     // ---- (c) small borders.  With a grid they are k_contours_small's (the next launch: one small workgroup per band of K rows,
     // because such walks never leave their grid cell -- the chip is full instead of one workgroup per frame waiting on LDS round
     // trips).  Without a grid every border is "small" and is followed whole here: a lane takes one 32-pixel word of start
@@ -1145,10 +1143,9 @@ __device__ __forceinline__ int relay_frame(
                         if (nx < 0) { atomicOr(&s_flags, RL_FLAG_BUG); nx = slot; }
                         RelaySeg r;
                         r.nxt = (uint32_t)nx; r.len = (uint32_t)wk.n; r.minoff = (uint32_t)mnoff | (mnhole << 31);
-                        r.stg = (uint32_t)(stage0 + tid * arena + wp);
+                        r.stg = 0u; // (no staging since round 3: kept segments are walked again in (f2))
                         r.mn = mn;
                         sg[slot] = r;
-                        wp += wk.n;
                         busy = false;
                     } else {
                         if (e & 0x60u) {
@@ -1162,8 +1159,6 @@ __device__ __forceinline__ int relay_frame(
                                 __hip_atomic_fetch_or(vis + wk.y * wpr + (qx >> 5), 1u << (qx & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             }
                         }
-                        if (wp + wk.n < arena) my_arena[wp + wk.n] = relay_point(wk);
-                        else { atomicOr(&s_flags, 4); busy = false; } // staging arena full: capacity error
                         rl_advance(im, wk, e);
                     }
                 }
@@ -1331,13 +1326,16 @@ __device__ __forceinline__ int relay_frame(
         if (tid == 0) { counts[f * 4 + 0] = 0; counts[f * 4 + 1] = 0; counts[f * 4 + 2] = s_flags | 2; counts[f * 4 + 3] = 0; }
         return 0;
     }
-    // ---- (f2) the segments of kept borders move from the staging arenas to their final position.  Segment i starts
-    // (n - val[i]) points after the list head; the border starts `minoff` points into the head segment, so everything
-    // shifts down by minoff and the head's first points wrap to the end.  The copy runs flat over all points: the kept
-    // segments are listed (in the marker keys' space, dead after this point) with a running point count, and every
-    // lane finds the segment of its point by binary search.
+    // ---- (f2) the points of the kept borders.  Until round 3 every walked point of (d) was staged in a per-lane arena in HBM (57 k
+    // uncoalesced 4-byte stores per 640 x 480 frame, 133 MB per 300-frame launch) and the segments of kept borders were copied from
+    // there; but only ~60 borders (~9 k points, ~280 segments) per frame are kept.  Now (d) stores nothing: the kept segments are
+    // listed (in the marker keys' space, dead after this point), the bit image is loaded into LDS once more (the list arrays that
+    // overlaid it are done), and one lane per listed segment walks it AGAIN, straight into its final place.  Segment i starts
+    // (n - val[i]) points after the list head; the border starts `minoff` points into the head segment, so everything shifts down
+    // by minoff and the head's first points wrap to the end.
     {
-        int e_dst[RL_SLOTS], e_src[RL_SLOTS], e_len[RL_SLOTS], e_k[RL_SLOTS];
+        int e_dst[RL_SLOTS], e_len[RL_SLOTS], e_base[RL_SLOTS], e_n[RL_SLOTS];
+        uint32_t e_key[RL_SLOTS];
         int mine = 0;
 #pragma unroll
         for (int q = 0; q < RL_SLOTS; q++) {
@@ -1349,91 +1347,78 @@ __device__ __forceinline__ int relay_frame(
                 if (k != RL_NIL) {
                     const RelaySeg r = sg[i];
                     const int n = (int)val[g];
+                    e_base[q] = off_u[k];
                     e_dst[q] = off_u[k] + (n - (int)val[i]) - (int)(sg[g].minoff & 0x7fffffffu);
-                    e_src[q] = (int)r.stg; e_len[q] = (int)r.len; e_k[q] = k;
+                    e_len[q] = (int)r.len; e_n[q] = n; e_key[q] = hkey[i];
                     mine++;
                 }
             }
         }
+        // the kept borders (sort key, pool offset) go to k_tail_prep now: their arrays are about to be overwritten by the bit image
+        {
+            const int nk = s_nkept;
+            for (int k = tid; k < nk; k += NT) {
+                tail_keys[(size_t)f * kcap + k] = kkey[k];
+                tail_off[(size_t)f * kcap + k] = off_u[k];
+            }
+        }
         if (tid == 0) s_next = 0;
-        __syncthreads(); // every read of the marker keys done
-        int* c_pre = (int*)hkey;            // points before the entry (exclusive running count), RL_NT + 1
-        int* c_dst = c_pre + RL_NT + 1;
-        int* c_src = c_dst + RL_NT;
-        uint16_t* c_k = (uint16_t*)(c_src + RL_NT);
+        __syncthreads(); // every read of the marker keys and of the list arrays done
         const int ebase = mine ? atomicAdd(&s_next, mine) : 0;
+        if (!GBITS) { // (a) again: the padded bit image
+            for (int i = tid; i < wpr * prow; i += NT) {
+                const int py = i / wpr, j = i - py * wpr;
+                uint32_t v = 0;
+                if (py >= 1 && py <= H) {
+                    const uint32_t* row = gb + (size_t)(py - 1) * wpr_g;
+                    const uint32_t cur = j < wpr_g ? row[j] : 0u;
+                    const uint32_t prv = (j >= 1 && j - 1 < wpr_g) ? row[j - 1] : 0u;
+                    v = (cur << 1) | (prv >> 31);
+                }
+                lbits[i] = v;
+            }
+            if (tid < 2) lbits[wpr * prow + tid] = 0;
+        }
         __syncthreads();
         const int E = s_next;
-        // the list holds RL_NT entries; frames with more kept segments (large images) take several rounds
-        for (int r0 = 0; r0 < E; r0 += RL_NT) {
-            const int Er = min(RL_NT, E - r0);
+        // the list: key, first destination, length, border base, border length -- five words per entry in the marker keys' space
+        const int ECAP = min(NT, T / 5);
+        int* c_key = (int*)hkey;
+        int* c_dst = c_key + ECAP;
+        int* c_len = c_dst + ECAP;
+        int* c_base = c_len + ECAP;
+        int* c_n = c_base + ECAP;
+        for (int r0 = 0; r0 < E; r0 += ECAP) { // frames with more kept segments than the list holds (large images) take several rounds
+            const int Er = min(ECAP, E - r0);
             int e0 = ebase - r0;
 #pragma unroll
             for (int q = 0; q < RL_SLOTS; q++)
                 if (e_len[q] > 0) {
-                    if (e0 >= 0 && e0 < RL_NT) { c_pre[e0] = e_len[q]; c_dst[e0] = e_dst[q]; c_src[e0] = e_src[q]; c_k[e0] = (uint16_t)e_k[q]; }
+                    if (e0 >= 0 && e0 < ECAP) {
+                        c_key[e0] = (int)e_key[q]; c_dst[e0] = e_dst[q]; c_len[e0] = e_len[q]; c_base[e0] = e_base[q]; c_n[e0] = e_n[q];
+                    }
                     e0++;
                 }
             __syncthreads();
-            // exclusive scan of the lengths (one entry per thread; RL_NT == RL_THREADS)
-            {
-                const int lane = tid & 63, wid = tid >> 6;
-                const int len = tid < Er ? c_pre[tid] : 0;
-                const int incl = wave_incl_scan_add(len);
-                __syncthreads();
-                if (lane == 63) c_pre[RL_NT - 16 + wid] = incl; // wave totals parked at the end (entries there are read above)
-                __syncthreads();
-                int wbase = 0;
-                for (int w = 0; w < wid; w++) wbase += c_pre[RL_NT - 16 + w];
-                __syncthreads();
-                c_pre[tid] = wbase + incl - len;
-                if (tid == NT - 1) c_pre[RL_NT] = wbase + incl;
-                __syncthreads();
-            }
-            const int total = c_pre[RL_NT];
-            for (int q0 = tid; q0 < total; q0 += 4 * NT) { // four independent points per lane: their latencies overlap
-                int pdst[4];
-                uint32_t v[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int q = q0 + u * NT;
-                    pdst[u] = -1;
-                    if (q < total) {
-                        int lo = 0, hi = Er - 1; // largest entry with c_pre <= q
-                        while (lo < hi) {
-                            const int mid = (lo + hi + 1) >> 1;
-                            if (c_pre[mid] <= q) lo = mid; else hi = mid - 1;
-                        }
-                        const int o = q - c_pre[lo], k = c_k[lo];
-                        const int base = off_u[k], n = (int)((kkey[k] >> 13) & 0x7ffff);
-                        int p = c_dst[lo] + o;
-                        if (p < base) p += n;
-                        pdst[u] = p;
-                        v[u] = pl[c_src[lo] + o];
-                    }
+            if (tid < Er) {
+                RelayWalk w2;
+                relay_walk_from_key(im, w2, (uint32_t)c_key[tid]);
+                const int len = c_len[tid], base = c_base[tid], n = c_n[tid];
+                int pdst = c_dst[tid];
+                for (int o = 0; o < len; o++, pdst++) {
+                    pl[pdst < base ? pdst + n : pdst] = relay_point(w2);
+                    rl_advance(im, w2, s_lut[(w2.ring << 3) | (unsigned)w2.s]);
                 }
-#pragma unroll
-                for (int u = 0; u < 4; u++)
-                    if (pdst[u] >= 0) pl[pdst[u]] = v[u];
             }
             __syncthreads(); // the list is rewritten by the next round
         }
     }
     __threadfence_block();
     __syncthreads();
-    if (tid == 0) {
-    }
-    __syncthreads();
     RL_STAMP();
-    // ---- hand the kept borders (sort key, pool offset) to k_contours_tail
     {
-        const int nk = s_nkept;
-        for (int k = tid; k < nk; k += NT) {
-            tail_keys[(size_t)f * kcap + k] = kkey[k];
-            tail_off[(size_t)f * kcap + k] = off_u[k];
-        }
         if (tid == 0) {
-            counts[f * 4 + 0] = nk; counts[f * 4 + 1] = 0; counts[f * 4 + 2] = s_flags; counts[f * 4 + 3] = s_ncand;
+            counts[f * 4 + 0] = s_nkept; counts[f * 4 + 1] = 0; counts[f * 4 + 2] = s_flags; counts[f * 4 + 3] = s_ncand;
             rstate[f * 2 + 0] = small_elsewhere ? kshift : 30; rstate[f * 2 + 1] = s_pool;
         }
     }
