@@ -66,6 +66,32 @@ struct orbfe_extractor {
     int device = 0;
     hipStream_t own_stream = nullptr, aux_stream = nullptr;
     PinnedBuf pinned;               // staging of the host-pointer entry points
+    // hipGraph replay of the host-pointer call (orbfe_extract_batch).  Built for VERDICT item 7 and measured: the capture works (inside
+    // the library, on its own streams; torch's capture API had segfaulted in round 2), the results are identical -- and the call is
+    // no faster (0.207 against 0.206 ms per 640 x 480 frame, profiles/r03_latency_graph.txt): the 13 launches of a frame are back to
+    // back on the GPU already, what a graph saves is host time that is not on the critical path.  Off by default (ORBFE_GRAPH=1).
+    bool use_graph = env_int("ORBFE_GRAPH", 0) != 0;
+    hipGraphExec_t g_exec = nullptr;
+    uint64_t g_key = 0;
+    int g_seen = 0;
+    void drop_graph()
+    {
+        if (g_exec) (void)hipGraphExecDestroy(g_exec);
+        g_exec = nullptr;
+    }
+    // everything that decides a launch parameter or a buffer address of the host-pointer call
+    uint64_t graph_key(int nframes, int rows_, int cols_, const void* hp) const
+    {
+        uint64_t k = 1469598103934665603ull;
+        auto mix = [&](uint64_t v) { k = (k ^ v) * 1099511628211ull; };
+        mix((uint64_t)nframes); mix((uint64_t)rows_); mix((uint64_t)cols_); mix((uint64_t)(uintptr_t)hp);
+        mix((uint64_t)(uintptr_t)d_in.p); mix((uint64_t)(uintptr_t)d_kps.p); mix((uint64_t)(uintptr_t)d_desc.p); mix((uint64_t)(uintptr_t)d_nout.p);
+        mix((uint64_t)(uintptr_t)d_pyr.p); mix((uint64_t)(uintptr_t)d_blur.p); mix((uint64_t)(uintptr_t)d_slots.p); mix((uint64_t)(uintptr_t)d_keys.p);
+        mix((uint64_t)(uintptr_t)d_flatkv.p); mix((uint64_t)(uintptr_t)d_lvlout.p); mix((uint64_t)(uintptr_t)user_aux); mix((uint64_t)(uintptr_t)user_early);
+        mix((uint64_t)gaussian_ed); mix((uint64_t)force_general_quadtree); mix((uint64_t)force_pyramid_depth); mix((uint64_t)blur_place);
+        mix((uint64_t)fast0_mode); mix((uint64_t)orient_pair); mix((uint64_t)batch_cap);
+        return k | 1ull;
+    }
     hipStream_t user_aux = nullptr; // orbfe_extractor_set_aux_stream: run the blur there instead of on aux_stream
     hipStream_t user_early = nullptr; // orbfe_extractor_set_early_stream: FAST of level 0 there instead of on aux_stream
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork0 = nullptr, ev_join0 = nullptr;
@@ -118,6 +144,7 @@ struct orbfe_extractor {
         if (aux_stream) (void)hipStreamDestroy(aux_stream);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
+        drop_graph();
         if (ev_fork0) (void)hipEventDestroy(ev_fork0);
         if (ev_join0) (void)hipEventDestroy(ev_join0);
     }
@@ -640,15 +667,45 @@ int orbfe_extract_batch(orbfe_extractor* h, const uint8_t* imgs, int nframes, si
     hipStream_t s = h->own_stream;
     for (int f = 0; f < nframes; f++)
         for (int y = 0; y < rows; y++) memcpy(hp + f * dframe + (size_t)y * dpitch, imgs + f * frame_stride + (size_t)y * step, (size_t)cols);
-    ORBFE_HIP(hipMemcpyAsync(h->d_in.p, hp, dframe * nframes, hipMemcpyHostToDevice, s));
-    rc = h->run_device(h->d_in.as<uint8_t>(), nframes, dframe, rows, cols, dpitch, h->d_kps.as<orbfe_keypoint>(),
-                       h->d_desc.as<uint8_t>(), cap, h->d_nout.as<int32_t>(), s, /*flag_word*/ 1);
-    if (rc) return rc;
-    // the results: four copies queued behind the kernels, one wait (blocking copies cost a round trip each: 4 x ~40 us per frame)
-    ORBFE_HIP(hipMemcpyAsync(hp + o_n, h->d_nout.p, (size_t)nframes * 4, hipMemcpyDeviceToHost, s));
-    ORBFE_HIP(hipMemcpyAsync(hp + o_flag, h->d_overflow.as<int32_t>() + 1, 4, hipMemcpyDeviceToHost, s));
-    ORBFE_HIP(hipMemcpyAsync(hp + o_kps, h->d_kps.p, (size_t)cap * nframes * sizeof(orbfe_keypoint), hipMemcpyDeviceToHost, s));
-    ORBFE_HIP(hipMemcpyAsync(hp + o_desc, h->d_desc.p, (size_t)cap * nframes * 32, hipMemcpyDeviceToHost, s));
+    // The call's stream work -- upload, ~13 launches on two streams, four result copies -- is the same every time a caller feeds
+    // frames of one size (the drop-in path: Frame.cc:200-206 once per frame): with ORBFE_GRAPH=1 it is replayed from the third such
+    // call on as one hipGraph, captured inside the library on its own stream (everything that decides a launch parameter is part of
+    // the key).
+    auto enqueue = [&]() -> int {
+        ORBFE_HIP(hipMemcpyAsync(h->d_in.p, hp, dframe * nframes, hipMemcpyHostToDevice, s));
+        int rc2 = h->run_device(h->d_in.as<uint8_t>(), nframes, dframe, rows, cols, dpitch, h->d_kps.as<orbfe_keypoint>(),
+                                h->d_desc.as<uint8_t>(), cap, h->d_nout.as<int32_t>(), s, /*flag_word*/ 1);
+        if (rc2) return rc2;
+        // the results: four copies queued behind the kernels, one wait (blocking copies cost a round trip each: 4 x ~40 us per frame)
+        ORBFE_HIP(hipMemcpyAsync(hp + o_n, h->d_nout.p, (size_t)nframes * 4, hipMemcpyDeviceToHost, s));
+        ORBFE_HIP(hipMemcpyAsync(hp + o_flag, h->d_overflow.as<int32_t>() + 1, 4, hipMemcpyDeviceToHost, s));
+        ORBFE_HIP(hipMemcpyAsync(hp + o_kps, h->d_kps.p, (size_t)cap * nframes * sizeof(orbfe_keypoint), hipMemcpyDeviceToHost, s));
+        ORBFE_HIP(hipMemcpyAsync(hp + o_desc, h->d_desc.p, (size_t)cap * nframes * 32, hipMemcpyDeviceToHost, s));
+        return ORBFE_OK;
+    };
+    const uint64_t key = h->graph_key(nframes, rows, cols, hp);
+    bool replayed = false;
+    if (h->use_graph && !h->timer.enabled && key == h->g_key && h->g_exec) {
+        if (hipGraphLaunch(h->g_exec, s) == hipSuccess) replayed = true;
+        else h->drop_graph();
+    }
+    if (!replayed) {
+        const bool capture = h->use_graph && !h->timer.enabled && key == h->g_key && !h->g_exec && ++h->g_seen >= 2;
+        if (key != h->g_key) { h->drop_graph(); h->g_key = key; h->g_seen = 0; }
+        bool captured = false;
+        if (capture && hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            rc = enqueue();
+            hipGraph_t g = nullptr;
+            const hipError_t e = hipStreamEndCapture(s, &g);
+            if (rc == ORBFE_OK && e == hipSuccess && g && hipGraphInstantiate(&h->g_exec, g, nullptr, nullptr, 0) == hipSuccess &&
+                hipGraphLaunch(h->g_exec, s) == hipSuccess)
+                captured = true;
+            else { h->drop_graph(); h->use_graph = false; (void)hipGetLastError(); } // capture is not available here: never again
+            if (getenv("ORBFE_GRAPH_VERBOSE")) fprintf(stderr, "orbfe_extract: hipGraph capture %s (rc %d, end %d)\n", captured ? "ok" : "FAILED", rc, (int)e);
+            if (g) (void)hipGraphDestroy(g);
+        }
+        if (!captured && (rc = enqueue())) return rc;
+    }
     ORBFE_HIP(hipStreamSynchronize(s));
     const int32_t ovf = *reinterpret_cast<const int32_t*>(hp + o_flag);
     if (ovf) ORBFE_HIP(hipMemset(h->d_overflow.as<int32_t>() + 1, 0, 4));

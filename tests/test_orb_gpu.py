@@ -176,3 +176,21 @@ def test_both_descriptor_kernels(pair):
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "stages_and_end_to_end"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_hipgraph_replay_of_the_host_pointer_call():
+    """ORBFE_GRAPH=1: from the third call with one frame size on, orbfe_extract replays its upload, launches and result copies as a
+    hipGraph captured inside the library.  The end-to-end cases (several frames of one size through one handle) in a process with the
+    switch set: replayed calls must give the oracle's keypoints and descriptors like direct ones."""
+    import os, subprocess, sys
+    env = dict(os.environ, ORBFE_GRAPH="1", ORBFE_GRAPH_VERBOSE="1")
+    code = ("import sys, numpy as np; sys.path[:0] = [%r, %r]; from orb_slam2_aruco_amd import binding, synth; import oracle_lib\n"
+            "s = synth.stream(480, 640, 6, 4242)\n"
+            "ex = binding.ORBextractor(1000, 1.2, 8, 20, 7); ora = oracle_lib.OrbOracle(1000, 1.2, 8, 20, 7)\n"
+            "for img in list(s) + [s[0], s[3]]:\n"
+            "    k, d = ex(img); ok, od = ora.extract(img)\n"
+            "    assert np.array_equal(k, ok) and np.array_equal(d, od)\n"
+            "print('replays ok')\n" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "replays ok" in r.stdout, r.stdout[-1000:] + r.stderr[-2000:]
+    assert "hipGraph capture ok" in r.stderr, r.stderr[-1000:]
