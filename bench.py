@@ -242,22 +242,30 @@ def latency_mode(args):
     K = binding.camera_resize(np.array(TUM1_K, np.float32), (1280, 720), (args.cols, args.rows))
     D = np.array(TUM1_DIST, np.float32)
     cam = (K, D, (args.cols, args.rows))
-    t_ex, t_det, t_sfi, t_all = [], [], [], []
-    prev = None
     calls = 200
-    for i in range(calls + 20):
-        img = frames[i % len(frames)]
-        t0 = time.perf_counter()
-        k, d = ex(img)
-        t1 = time.perf_counter()
-        det.detect(img, cam, MARKER_SIZE)
-        t2 = time.perf_counter()
-        if prev is not None:
-            mt.SearchForInitialization(prev[0], prev[1], k, d, args.cols, args.rows, None, 100)
-        t3 = time.perf_counter()
-        prev = (k, d)
-        if i >= 20:
-            t_ex.append(t1 - t0); t_det.append(t2 - t1); t_sfi.append(t3 - t2); t_all.append(t3 - t0)
+
+    def run(paired):
+        ex.pair_detector(det if paired else None)
+        t_ex, t_det, t_sfi, t_all = [], [], [], []
+        prev = None
+        for i in range(calls + 20):
+            img = frames[i % len(frames)]
+            t0 = time.perf_counter()
+            k, d = ex(img)
+            t1 = time.perf_counter()
+            det.detect(img, cam, MARKER_SIZE)
+            t2 = time.perf_counter()
+            if prev is not None:
+                mt.SearchForInitialization(prev[0], prev[1], k, d, args.cols, args.rows, None, 100)
+            t3 = time.perf_counter()
+            prev = (k, d)
+            if i >= 20:
+                t_ex.append(t1 - t0); t_det.append(t2 - t1); t_sfi.append(t3 - t2); t_all.append(t3 - t0)
+        ex.pair_detector(None)
+        return t_ex, t_det, t_sfi, t_all
+
+    t_ex, t_det, t_sfi, t_all = run(False)
+    p_ex, p_det, p_sfi, p_all = run(True)
     med = lambda v: float(np.median(v) * 1e3)
     out = {"metric": "ms per frame, single-frame drop-in calls through the host-pointer ABI (%dx%d mono)" % (args.cols, args.rows),
            "value": med(t_all), "unit": "ms", "higher_is_better": False, "n_gpus": 1, "calls": calls, "dtype": "u8", "data": "synthetic",
@@ -265,7 +273,12 @@ def latency_mode(args):
                                   "orbfe_search_for_initialization, host pointers (H2D, kernels, D2H and sync inside every call; "
                                   "includes the ctypes marshalling of the test binding)" % args.config},
            "median_ms": {"orbfe_extract": med(t_ex), "orbfe_aruco_detect+poses": med(t_det),
-                         "orbfe_search_for_initialization": med(t_sfi)}}
+                         "orbfe_search_for_initialization": med(t_sfi)},
+           # the same call sequence with the detector paired to the extractor (orbfe_extractor_pair_detector: one line added where the
+           # reference creates the two objects): the extractor's call starts the detector on the image it uploads, the detector's call
+           # -- same image -- finds its work done.  Identical results (tests/test_shims_gpu.py, test_aruco_gpu.py)
+           "paired": {"value": med(p_all), "median_ms": {"orbfe_extract": med(p_ex), "orbfe_aruco_detect+poses": med(p_det),
+                                                          "orbfe_search_for_initialization": med(p_sfi)}}}
     if args.cpu_frames > 0:
         O = oracle_module()
         orb, aru = O.OrbOracle(args.nfeatures, 1.2, args.nlevels, 20, 7), O.ArucoOracle(args.dictionary)

@@ -146,6 +146,16 @@ int orbfe_extractor_set_aux_stream(orbfe_extractor* h, void* stream);
  * a stream with little work at the start of a batch instead -- bench.py: the one that carries the detector's /2 pyramid.  NULL
  * restores the default.  Ordering is by events either way. */
 int orbfe_extractor_set_early_stream(orbfe_extractor* h, void* stream);
+
+/* Pairing for the drop-in path.  The reference builds a Frame by calling ORBextractor::operator() and then
+ * MarkerDetector::detect on the SAME grey image (Frame.cc:91 / :200-206, then :142), one after the other on the Tracking thread; the
+ * two are independent.  With a detector paired to an extractor, a one-frame orbfe_extract uploads the image once and starts the
+ * detector on that device copy on the detector's own stream, next to its own launches; the following orbfe_aruco_detect /
+ * orbfe_aruco_detect_poses call, if it is handed the same image (rows, cols and a 64-bit hash of the pixels), waits for that
+ * work and returns its results -- poses included when camera and marker size are those of the detector's previous call.  Any
+ * other image, a batch call, or a capacity flag: the call runs as if nothing had been started.  Results are identical either way.
+ * detector == NULL unpairs; unpair (or destroy the extractor) before destroying the detector.  Both handles on one device. */
+int orbfe_extractor_pair_detector(orbfe_extractor* h, struct orbfe_aruco* detector);
 int orbfe_extractor_debug_kernel_times(orbfe_extractor* h, float* out_us, int capacity);
 
 /* ------------------------------------------------------------------ descriptor matching -- */

@@ -37,6 +37,17 @@ struct orbfe_aruco {
     int relay_chunk = getenv("ORBFE_ARUCO_RELAY_CHUNK") ? atoi(getenv("ORBFE_ARUCO_RELAY_CHUNK")) : 1 << 30;   // frames per launch of the large-frame relay kernels
     PinnedBuf pinned; // staging of the host-pointer entry points
     DevBuf d_poses;   // orbfe_aruco_detect_poses
+    // speculation for a paired extractor (orbfe_extractor_pair_detector; orbfe_common.hpp)
+    struct Spec {
+        bool pending = false, has_pose = false; // work enqueued and not consumed yet; poses were computed with `cam` / `size`
+        int rows = 0, cols = 0;
+        uint64_t hash = 0;
+        PoseCamera cam{};
+        float size = 0.f;
+    } spec;
+    bool last_cam_valid = false; // camera and marker size of the last detect-with-poses call: what the speculation assumes
+    PoseCamera last_cam{};
+    float last_size = 0.f;
     bool relay_wide = !(getenv("ORBFE_ARUCO_RELAY_WIDE") && !atoi(getenv("ORBFE_ARUCO_RELAY_WIDE")));
     DevBuf d_vis;        // per frame: one bit per start candidate on a gridded border (relay kernels, phase (d) -> (c))
     size_t vis_fu32 = 0;
@@ -496,6 +507,7 @@ void orbfe_aruco_destroy(orbfe_aruco* h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    if (h->spec.pending) (void)hipStreamSynchronize(h->own_stream); // work started for a paired extractor (unpair before destroying)
     delete h;
 }
 
@@ -604,10 +616,88 @@ int orbfe_aruco_detect_batch_device(orbfe_aruco* h, const uint8_t* d_imgs, int n
         return fail(ORBFE_ERR_INVALID, "orbfe_aruco_detect_batch_device: invalid argument");
     int rc = use_device(h->device);
     if (rc) return rc;
+    if (h->spec.pending) { ORBFE_HIP(hipStreamSynchronize(h->own_stream)); h->spec.pending = false; } // the handle's buffers are in use
     return h->run_device(d_imgs, nframes, frame_stride, rows, cols, step, d_out, capacity, d_n_out, (hipStream_t)stream);
 }
 
 } // extern "C"
+
+// staging layout of a one-frame host call (page-locked): [frame in] [n] [counts x 4] [marker records] [poses]
+struct DetOffsets { size_t n, cnt, mk, ps, end; };
+static DetOffsets det_offsets(size_t dframe, int nframes, bool with_pose)
+{
+    DetOffsets o;
+    o.n = (dframe * nframes + 255) / 256 * 256;
+    o.cnt = o.n + ((size_t)nframes * 4 + 63) / 64 * 64;
+    o.mk = o.cnt + ((size_t)nframes * 16 + 63) / 64 * 64;
+    o.ps = o.mk + (size_t)AR_MAX_RECTS * nframes * sizeof(orbfe_marker);
+    o.end = o.ps + (with_pose ? (size_t)AR_MAX_RECTS * nframes * sizeof(orbfe_marker_pose) : 0);
+    return o;
+}
+
+static bool same_camera(const PoseCamera& a, const PoseCamera& b) { return memcmp(&a, &b, sizeof(PoseCamera)) == 0; }
+
+namespace orbfe {
+
+uint64_t image_hash(const uint8_t* img, int rows, int cols, size_t step)
+{
+    // four independent multiply-xor lanes over the rows' 8-byte words (the tail bytes of a row go in as one more word)
+    uint64_t h[4] = {0x9E3779B97F4A7C15ull, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull, 0x27D4EB2F165667C5ull};
+    const uint64_t M = 0x100000001B3ull * 0x9E3779B1ull | 1ull;
+    for (int y = 0; y < rows; y++) {
+        const uint8_t* r = img + (size_t)y * step;
+        int x = 0;
+        for (; x + 32 <= cols; x += 32) {
+            uint64_t w[4];
+            memcpy(w, r + x, 32);
+            for (int k = 0; k < 4; k++) h[k] = (h[k] ^ w[k]) * M;
+        }
+        uint64_t t[4] = {0, 0, 0, 0};
+        memcpy(t, r + x, (size_t)(cols - x));
+        for (int k = 0; k < 4; k++) h[k] = (h[k] ^ t[k]) * M;
+    }
+    uint64_t out = (uint64_t)rows * 0x9E3779B97F4A7C15ull ^ (uint64_t)cols;
+    for (int k = 0; k < 4; k++) out = (out ^ (h[k] >> 29) ^ h[k]) * M;
+    return out;
+}
+
+int aruco_speculate(orbfe_aruco* h, const uint8_t* d_img, size_t dframe, int rows, int cols, size_t dpitch, hipEvent_t uploaded, uint64_t hash)
+{
+    h->spec.pending = false;
+    if (h->big_mode) return ORBFE_OK; // the rare big-frame mode is left to the detector's own call
+    int rc;
+    if ((rc = h->d_out.ensure((size_t)AR_MAX_RECTS * sizeof(orbfe_marker))) || (rc = h->d_nout.ensure(4))) return rc;
+    const bool pose = h->last_cam_valid;
+    const DetOffsets o = det_offsets(dframe, 1, true);
+    if ((rc = h->pinned.ensure(o.end)) || (rc = h->d_poses.ensure((size_t)AR_MAX_RECTS * sizeof(orbfe_marker_pose)))) return rc;
+    uint8_t* hp = h->pinned.as<uint8_t>();
+    hipStream_t s = h->own_stream;
+    ORBFE_HIP(hipStreamWaitEvent(s, uploaded, 0));
+    if ((rc = h->run_device(d_img, 1, dframe, rows, cols, dpitch, h->d_out.as<orbfe_marker>(), AR_MAX_RECTS, h->d_nout.as<int32_t>(), s))) return rc;
+    ORBFE_HIP(hipMemcpyAsync(hp + o.n, h->d_nout.p, 4, hipMemcpyDeviceToHost, s));
+    ORBFE_HIP(hipMemcpyAsync(hp + o.cnt, h->d_counts.p, 16, hipMemcpyDeviceToHost, s));
+    ORBFE_HIP(hipMemcpyAsync(hp + o.mk, h->d_out.p, (size_t)AR_MAX_RECTS * sizeof(orbfe_marker), hipMemcpyDeviceToHost, s));
+    if (pose) {
+        hipLaunchKernelGGL(k_marker_poses, dim3((AR_MAX_RECTS + 63) / 64, 1), dim3(64), 0, s, h->d_out.as<orbfe_marker>(), h->d_nout.as<int32_t>(),
+                           AR_MAX_RECTS, h->last_size, h->last_cam, h->d_poses.as<orbfe_marker_pose>());
+        ORBFE_HIP(hipMemcpyAsync(hp + o.ps, h->d_poses.p, (size_t)AR_MAX_RECTS * sizeof(orbfe_marker_pose), hipMemcpyDeviceToHost, s));
+    }
+    h->spec.pending = true; h->spec.rows = rows; h->spec.cols = cols; h->spec.hash = hash;
+    h->spec.has_pose = pose; h->spec.cam = h->last_cam; h->spec.size = h->last_size;
+    return ORBFE_OK;
+}
+
+void aruco_speculation_wait(orbfe_aruco* h)
+{
+    if (h && h->spec.pending) { (void)hipStreamSynchronize(h->own_stream); h->spec.pending = false; }
+}
+
+void aruco_unpair_notice(orbfe_aruco* h)
+{
+    if (h) h->spec.pending = false;
+}
+
+} // namespace orbfe
 
 // detect (+ the IPPE pose of every marker when a camera is given: one call, one wait, instead of a detect call and a pose call)
 static int detect_batch_impl(orbfe_aruco* h, const uint8_t* imgs, int nframes, size_t frame_stride, int rows, int cols,
@@ -623,14 +713,43 @@ static int detect_batch_impl(orbfe_aruco* h, const uint8_t* imgs, int nframes, s
     int rc = use_device(h->device);
     if (rc) return rc;
     const size_t dpitch = (size_t)(cols + 63) / 64 * 64, dframe = dpitch * rows;
+    if (cam) { h->last_cam = *cam; h->last_size = marker_size; h->last_cam_valid = true; } // what a paired extractor's speculation assumes
+    // A paired extractor has started this detector on the image it was given (aruco_speculate): if this call is handed the same
+    // image, the work is done or under way on the device -- wait for it and take the results (and the poses, when the camera is the
+    // one of the last call); anything else -- another image, a capacity flag -- and the call runs as if nothing had happened.
+    if (h->spec.pending && nframes != 1) { ORBFE_HIP(hipStreamSynchronize(h->own_stream)); h->spec.pending = false; }
+    if (h->spec.pending && nframes == 1) {
+        h->spec.pending = false;
+        const bool match = h->spec.rows == rows && h->spec.cols == cols && h->spec.hash == image_hash(imgs, rows, cols, step);
+        hipStream_t s = h->own_stream;
+        if (!match) ORBFE_HIP(hipStreamSynchronize(s)); // its buffers are about to be reused
+        else {
+            const DetOffsets o = det_offsets(dframe, 1, true);
+            uint8_t* hp = h->pinned.as<uint8_t>();
+            const bool pose_ready = cam && h->spec.has_pose && h->spec.size == marker_size && same_camera(h->spec.cam, *cam);
+            if (cam && !pose_ready) { // same markers, another camera: only the poses are still to do
+                hipLaunchKernelGGL(k_marker_poses, dim3((AR_MAX_RECTS + 63) / 64, 1), dim3(64), 0, s, h->d_out.as<orbfe_marker>(),
+                                   h->d_nout.as<int32_t>(), AR_MAX_RECTS, marker_size, *cam, h->d_poses.as<orbfe_marker_pose>());
+                ORBFE_HIP(hipMemcpyAsync(hp + o.ps, h->d_poses.p, (size_t)AR_MAX_RECTS * sizeof(orbfe_marker_pose), hipMemcpyDeviceToHost, s));
+            }
+            ORBFE_HIP(hipStreamSynchronize(s));
+            const int32_t* counts = reinterpret_cast<const int32_t*>(hp + o.cnt);
+            const int32_t n = *reinterpret_cast<const int32_t*>(hp + o.n);
+            if (!counts[2] && n <= capacity) { // no capacity flag: the speculated run is the result
+                n_out[0] = n;
+                if (n) memcpy(out, hp + o.mk, (size_t)n * sizeof(orbfe_marker));
+                if (n && cam) memcpy(poses_out, hp + o.ps, (size_t)n * sizeof(orbfe_marker_pose));
+                return ORBFE_OK;
+            }
+        }
+    }
     if ((rc = h->d_in.ensure(dframe * nframes + 64)) || (rc = h->d_out.ensure((size_t)AR_MAX_RECTS * nframes * sizeof(orbfe_marker))) ||
         (rc = h->d_nout.ensure((size_t)nframes * 4)))
         return rc;
     // page-locked staging: [frames in] then [n per frame | counts (4 per frame) | marker records] out -- three copies queued behind
     // the kernels and one wait instead of a blocking copy per array
-    const size_t o_n = (dframe * nframes + 255) / 256 * 256, o_cnt = o_n + ((size_t)nframes * 4 + 63) / 64 * 64;
-    const size_t o_mk = o_cnt + ((size_t)nframes * 16 + 63) / 64 * 64, o_ps = o_mk + (size_t)AR_MAX_RECTS * nframes * sizeof(orbfe_marker);
-    const size_t o_end = o_ps + (cam ? (size_t)AR_MAX_RECTS * nframes * sizeof(orbfe_marker_pose) : 0);
+    const DetOffsets o_ = det_offsets(dframe, nframes, cam != nullptr);
+    const size_t o_n = o_.n, o_cnt = o_.cnt, o_mk = o_.mk, o_ps = o_.ps, o_end = o_.end;
     if ((rc = h->pinned.ensure(o_end))) return rc;
     if (cam && (rc = h->d_poses.ensure((size_t)AR_MAX_RECTS * nframes * sizeof(orbfe_marker_pose)))) return rc;
     uint8_t* hp = h->pinned.as<uint8_t>();

@@ -116,6 +116,16 @@ struct PinnedBuf {
     template <class T> T* as() const { return (T*)p; }
 };
 
+// ---- a detector paired with an extractor (orbfe_extractor_pair_detector): the drop-in path calls ORBextractor::operator() and
+// MarkerDetector::detect on the SAME image one after the other (Frame.cc:91 -> :142); the extractor's call uploads the image once
+// and starts the detector on it on the detector's own stream, next to its own launches; the detector's call finds its work done if
+// it is handed the same image (64-bit content hash), else it runs as if nothing had happened.
+uint64_t image_hash(const uint8_t* img, int rows, int cols, size_t step);
+int aruco_speculate(orbfe_aruco* a, const uint8_t* d_img, size_t dframe, int rows, int cols, size_t dpitch, hipEvent_t uploaded,
+                    uint64_t hash);
+void aruco_speculation_wait(orbfe_aruco* a); // until the detector no longer reads the extractor's copy of the image
+void aruco_unpair_notice(orbfe_aruco* a);
+
 // Scratch of the entry points that have no handle (matching, poses, keyframe records): one workspace per calling thread,
 // HIP device and stream.  A buffer allocated on one GPU is never handed to a kernel on another, two asynchronous calls
 // of one thread on different streams never share scratch, and the buffers are released when the thread exits.

@@ -385,3 +385,39 @@ def test_small_border_phase_inside_and_outside_the_relay_kernel(mode):
                         "structured_binary or relay_and_legacy or dense_frame or detect_matches_oracle or lds_boundary or tail_kernel"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_detector_paired_with_an_extractor(orbfe, oracle):
+    """orbfe_extractor_pair_detector: the extractor's one-frame call starts the paired detector on the image it uploads; the detector's
+    call takes that work if it is handed the same image and runs normally otherwise.  Same results in every case: same image (with
+    and without poses, with the camera of the previous call and with another one), another image, detect without a preceding extract,
+    a batch call in between, unpairing."""
+    K = np.array([517.3, 516.5, 318.6, 255.3], np.float32); D = np.array([0.26, -0.95, -0.005, 0.003, 1.16], np.float32)
+    K2 = K * np.float32(1.01)
+    imgs = synth.stream(480, 640, 5, 77, "ARUCO", n_markers=4)
+    ex = orbfe.ORBextractor(1000, 1.2, 8, 20, 7)
+    det = orbfe.MarkerDetector("ARUCO")
+    ref = orbfe.MarkerDetector("ARUCO")                                  # never paired
+    ora = oracle.ArucoOracle("ARUCO")
+    want = [ref.detect(im, (K, D, (640, 480)), 0.187) for im in imgs]
+    want2 = ref.detect(imgs[1], (K2, D, (640, 480)), 0.187)
+    okps = [oracle.OrbOracle(1000, 1.2, 8, 20, 7).extract(im) for im in imgs[:2]]
+    ex.pair_detector(det)
+    same = lambda a, b: np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    for rep in range(2):                                                 # second round: the speculation knows the camera
+        for i, im in enumerate(imgs):
+            k, d = ex(im)
+            if i < 2:
+                assert np.array_equal(k, okps[i][0]) and np.array_equal(d, okps[i][1])
+            assert same(det.detect(im, (K, D, (640, 480)), 0.187), want[i]), (rep, i)
+    assert np.array_equal(det.detect(imgs[0])["id"], ora.detect(imgs[0])["id"])
+    ex(imgs[1]); assert same(det.detect(imgs[1], (K2, D, (640, 480)), 0.187), want2)         # same image, another camera
+    ex(imgs[2]); assert same(det.detect(imgs[3], (K, D, (640, 480)), 0.187), want[3])         # another image than the extractor saw
+    assert same(det.detect(imgs[4], (K, D, (640, 480)), 0.187), want[4])                      # no extract in between
+    ex(imgs[0]); b = det.detect_batch(imgs[:3])                                               # a batch while work is pending
+    assert all(np.array_equal(b[f]["id"], want[f][0]["id"]) for f in range(3))
+    ex(imgs[1]); ex(imgs[2]); assert same(det.detect(imgs[2], (K, D, (640, 480)), 0.187), want[2])   # two extracts in a row
+    c = det.contours(len(want[2][0]))
+    assert len(c) == len(want[2][0]) and all(len(x) > 70 for x in c)
+    ex.pair_detector(None)
+    ex(imgs[0]); assert same(det.detect(imgs[0], (K, D, (640, 480)), 0.187), want[0])
