@@ -94,7 +94,7 @@ __device__ __forceinline__ v4i spread16(uint32_t bits)
     return r;
 }
 
-__global__ __launch_bounds__(KM_WAVES * 64) void k_knn2_mfma(const uint8_t* __restrict__ Q, const int32_t* __restrict__ nq_arr,
+__global__ __launch_bounds__(KM_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_knn2_mfma(const uint8_t* __restrict__ Q, const int32_t* __restrict__ nq_arr,
                                                              size_t q_stride, int max_nq, const uint8_t* __restrict__ T,
                                                              const int32_t* __restrict__ nt_arr, size_t t_stride, int chunk,
                                                              int init, int32_t* __restrict__ best_idx,
@@ -121,63 +121,71 @@ __global__ __launch_bounds__(KM_WAVES * 64) void k_knn2_mfma(const uint8_t* __re
     const int col = lane & 31, half = lane >> 5;
     const int ie = min(init, 257); // distances are <= 256: any larger start value behaves like 257
 
-    // A fragments: query row (q0 + 32 wid + col), k-step s = dword s of the descriptor, this lane's 16-bit half
+    // A fragments: query row (q0 + 32 wid + col), k-step s = dword s of the descriptor, this lane's 16-bit half.  A set bit is
+    // the byte -1, so the accumulator holds -(q.t) and a pair's key is ONE v_lshl_add_u32 (with +1 bytes the compiler needs a
+    // shift and a subtraction)
     const int qa = q0 + 32 * wid + col;
     v4i a[8];
+    {
+        const uint4* qrow = reinterpret_cast<const uint4*>(Qp) + (size_t)min(qa, nq - 1) * 2; // clamped, not predicated
+        const uint4 d0 = qrow[0], d1 = qrow[1];
+        const uint32_t w[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
 #pragma unroll
-    for (int s2 = 0; s2 < 8; s2++) {
-        const uint32_t w = qa < nq ? Qp[(size_t)qa * 8 + s2] : 0u;
-        a[s2] = spread16(w >> (16 * half));
+        for (int s2 = 0; s2 < 8; s2++) {
+            const v4i p = spread16((qa < nq ? w[s2] : 0u) >> (16 * half));
+            a[s2] = p * 255; // 0x01 -> 0xff per byte, no carries
+        }
     }
-    // the 16 rows this lane accumulates: row(reg) = (reg & 3) + 8 * (reg >> 2) + 4 * half; keys start at "init":
-    // a candidate is accepted iff d < init  <=>  |t| - 2 q.t < init - |q|
+    // the 16 rows this lane accumulates: row(reg) = (reg & 3) + 8 * (reg >> 2) + 4 * half.  Keys are ((|t| - 2 q.t) << 16) | j: the
+    // order of a row's candidates by (distance, index) without the row's own |q|; "accepted iff d < init" is applied when the
+    // row is written, so the running keys simply start above every real key
     int bestk[16], secondk[16];
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int qr = q0 + 32 * wid + (r & 3) + 8 * (r >> 2) + 4 * half;
-        int pq = 0;
-        if (qr < nq) {
-            const uint4 d0 = reinterpret_cast<const uint4*>(Qp)[(size_t)qr * 2], d1 = reinterpret_cast<const uint4*>(Qp)[(size_t)qr * 2 + 1];
-            pq = __popc(d0.x) + __popc(d0.y) + __popc(d0.z) + __popc(d0.w) + __popc(d1.x) + __popc(d1.y) + __popc(d1.z) + __popc(d1.w);
-        }
-        bestk[r] = secondk[r] = (ie - pq) * 65536;
-    }
+    for (int r = 0; r < 16; r++) bestk[r] = secondk[r] = 0x7fffffff;
 
+    // A thread's part of a chunk: dwords 2 p, 2 p + 1 of train row (tid >> 2), p = tid & 3.  The NEXT chunk's part is loaded
+    // before the current chunk's tiles are computed and waited for after them: global latency (and with two workgroups per CU
+    // in the same rhythm there is nothing else to hide it) is off the chunk's critical path.
+    const int ctr = tid >> 2, cpart = tid & 3;
+    const uint2* Tp2 = reinterpret_cast<const uint2*>(Tp);
+    uint2 nxt = make_uint2(0u, 0u);
+    if (t_begin < nt) nxt = Tp2[(size_t)min(t_begin + ctr, nt - 1) * 4 + cpart];
     for (int t0 = t_begin; t0 < nt; t0 += KM_CHUNK) {
         const int m = min(KM_CHUNK, nt - t0);
-        __syncthreads();
-        // spread the chunk: item = (train, dword) -> 32 bytes
-        for (int i = tid; i < KM_CHUNK * 8; i += KM_WAVES * 64) {
-            const int tr = i >> 3, dw = i & 7;
-            const uint32_t w = tr < m ? Tp[(size_t)(t0 + tr) * 8 + dw] : 0u;
-            v4i* dst = reinterpret_cast<v4i*>(s_t + tr * KM_ROWB + dw * 32);
-            dst[0] = spread16(w);
-            dst[1] = spread16(w >> 16);
+        uint2 w = nxt;
+        if (ctr >= m) w = make_uint2(0u, 0u); // rows past the end: zero bytes, popcount 0
+        __syncthreads();                      // every wave is done with the previous chunk
+        {
+            v4i* dst = reinterpret_cast<v4i*>(s_t + ctr * KM_ROWB + cpart * 64);
+            dst[0] = spread16(w.x);
+            dst[1] = spread16(w.x >> 16);
+            dst[2] = spread16(w.y);
+            dst[3] = spread16(w.y >> 16);
+            int pc = __popc(w.x) + __popc(w.y);                // |t|: sum over the row's four threads (one quad)
+            pc += ORBFE_DPP(0, pc, 0xb1, 0xf);                 // quad_perm [1, 0, 3, 2]
+            pc += ORBFE_DPP(0, pc, 0x4e, 0xf);                 // quad_perm [2, 3, 0, 1]
+            if (cpart == 0) s_pt[ctr] = pc;
         }
-        for (int tr = tid; tr < KM_CHUNK; tr += KM_WAVES * 64) {
-            int pt = 0;
-            if (tr < m) {
-                const uint4 d0 = reinterpret_cast<const uint4*>(Tp)[(size_t)(t0 + tr) * 2], d1 = reinterpret_cast<const uint4*>(Tp)[(size_t)(t0 + tr) * 2 + 1];
-                pt = __popc(d0.x) + __popc(d0.y) + __popc(d0.z) + __popc(d0.w) + __popc(d1.x) + __popc(d1.y) + __popc(d1.z) + __popc(d1.w);
-            }
-            s_pt[tr] = pt;
-        }
+        if (t0 + KM_CHUNK < nt) nxt = Tp2[(size_t)min(t0 + KM_CHUNK + ctr, nt - 1) * 4 + cpart];
         __syncthreads();
-        for (int tt = 0; tt < m; tt += 32) {
+        // all four tiles of the chunk, straight-line (rows past the end are zero bytes and get the never-accepted key): one basic
+        // block, so that a tile's matrix instructions can be scheduled under the previous tile's key updates
+#pragma unroll
+        for (int tt = 0; tt < KM_CHUNK; tt += 32) {
             v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             const unsigned char* brow = s_t + (tt + col) * KM_ROWB + 16 * half;
+            v4i b[8];
 #pragma unroll
-            for (int s2 = 0; s2 < 8; s2++) {
-                const v4i b = *reinterpret_cast<const v4i*>(brow + 32 * s2);
-                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s2], b, acc, 0, 0, 0);
-            }
-            // this lane's column is train t0 + tt + col; columns past the end get a key above every init key
-            const int j = t0 + tt + col;
-            const int cj = (tt + col < m) ? ((s_pt[tt + col] << 16) | j) : 0x7fffffff;
+            for (int s2 = 0; s2 < 8; s2++) b[s2] = *reinterpret_cast<const v4i*>(brow + 32 * s2); // all eight reads in flight
+            const int pt = s_pt[tt + col];
+#pragma unroll
+            for (int s2 = 0; s2 < 8; s2++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s2], b[s2], acc, 0, 0, 0);
+            // this lane's column is train t0 + tt + col; a column past the end has zero bytes (acc = 0) and a key above every real one
+            const uint32_t cj = (tt + col < m) ? (((uint32_t)pt << 16) | (uint32_t)(t0 + tt + col)) : 0x7fffffffu;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int key = (tt + col < m) ? cj - (acc[r] << 17) : 0x7fffffff; // ((|t| - 2 q.t) << 16) | j
-                secondk[r] = med3i(bestk[r], secondk[r], key);     // middle of the three
+                const int key = (int)(((uint32_t)acc[r] << 17) + cj); // ((|t| - 2 q.t) << 16) | j
+                secondk[r] = med3i(bestk[r], secondk[r], key);       // middle of the three
                 bestk[r] = min(bestk[r], key);
             }
         }
@@ -1282,19 +1290,28 @@ static int knn2_launch(const uint8_t* d_Q, const int32_t* d_nq, size_t q_stride,
                        const int32_t* d_nt, size_t t_stride, int max_nt, int npairs, int init, int32_t* d_best_idx,
                        int32_t* d_best_dist, int32_t* d_second_dist, hipStream_t s)
 {
-    // split the train set when there are too few (query-tile, pair) workgroups to fill 256 CUs
-    const int qtiles = (max_nq + 255) / 256;
-    int nsplit = 1;
-    const long long wgs = (long long)qtiles * npairs;
-    if (wgs < 1024) {
-        nsplit = (int)std::min<long long>((1024 + wgs - 1) / wgs, (max_nt + KNN_TILE - 1) / KNN_TILE);
-        if (nsplit < 1) nsplit = 1;
-    }
-    int chunk = (max_nt + nsplit - 1) / nsplit;
-    chunk = std::max(KNN_TILE, (chunk + KNN_TILE - 1) / KNN_TILE * KNN_TILE);
-    nsplit = std::max(1, (max_nt + chunk - 1) / chunk);
     const bool mfma_ok = max_nt <= 65535 && init > 0;
     const bool use_mfma = mfma_ok && g_knn2_path != 1;   // distances on the matrix cores unless the VALU kernel is forced
+    // split the train set when there are too few (query-tile, pair) workgroups to fill 256 CUs
+    const int qtiles = (max_nq + 255) / 256;
+    int nsplit = 1, chunk;
+    const long long wgs = (long long)qtiles * npairs;
+    if (use_mfma) {
+        // k_knn2_mfma: 8 waves of ~110 registers -> two workgroups per CU, 512 resident; the split aims at ONE round of them (a second,
+        // half-empty round costs as much as a full one), in whole 128-descriptor chunks
+        const int max_split = (max_nt + KM_CHUNK - 1) / KM_CHUNK;
+        if (wgs < 512) nsplit = (int)std::max<long long>(1, std::min<long long>(512 / wgs, max_split));
+        chunk = (max_nt + nsplit - 1) / nsplit;
+        chunk = std::max(KM_CHUNK, (chunk + KM_CHUNK - 1) / KM_CHUNK * KM_CHUNK);
+    } else {
+        if (wgs < 1024) {
+            nsplit = (int)std::min<long long>((1024 + wgs - 1) / wgs, (max_nt + KNN_TILE - 1) / KNN_TILE);
+            if (nsplit < 1) nsplit = 1;
+        }
+        chunk = (max_nt + nsplit - 1) / nsplit;
+        chunk = std::max(KNN_TILE, (chunk + KNN_TILE - 1) / KNN_TILE * KNN_TILE);
+    }
+    nsplit = std::max(1, (max_nt + chunk - 1) / chunk);
     const dim3 mgrid((max_nq + KM_WAVES * 32 - 1) / (KM_WAVES * 32), npairs, nsplit);
     if (nsplit == 1) {
         if (use_mfma)
