@@ -183,6 +183,13 @@ __device__ __forceinline__ uint32_t as_u32(i16x2 v) { return __builtin_bit_cast(
 __device__ __forceinline__ u16x2 pk_minu(u16x2 a, u16x2 b) { return __builtin_elementwise_min(a, b); }
 __device__ __forceinline__ u16x2 pk_maxu(u16x2 a, u16x2 b) { return __builtin_elementwise_max(a, b); }
 
+// min(x, 1) per 16-bit lane: non-zero lanes -> 1
+__device__ __forceinline__ uint32_t pk_min1(uint32_t x)
+{
+    uint32_t r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(x), "s"(0x00010001u));
+    return r;
+}
 // compass test of two pixels at once (16-bit lanes); result lanes are non-zero where the pixel passes
 __device__ __forceinline__ uint32_t compass_pass2(u16x2 v, u16x2 r0, u16x2 r4, u16x2 r8, u16x2 r12, u16x2 t2)
 {
@@ -302,9 +309,10 @@ __global__ __launch_bounds__(256) void k_fast_cells(ImgView src0, ImgView pyr, c
         typedef uint32_t u32_unaligned __attribute__((aligned(1)));
         const int ndw = (w + 4) >> 2;
         const int rpi = 64 / ndw;                      // rows per trip of the wave
-        const int y0 = lane / ndw, c = lane - y0 * ndw;
+        const int y0 = (int)(((float)lane + 0.5f) * (1.0f / (float)ndw)), c = lane - __mul24(y0, ndw); // exact: lane < 64
         const uint8_t* roi = img + (size_t)iniY * pitch + iniX - 1;
-        uint32_t go = (uint32_t)(y0 * pitch + 4 * c), so_ = (uint32_t)(y0 * SP + 4 * c);
+        // (24-bit multiplies: v_mul_lo_u32 runs at a quarter of the rate)
+        uint32_t go = (uint32_t)(__mul24(y0, pitch) + 4 * c), so_ = (uint32_t)(__mul24(y0, SP) + 4 * c);
         const uint32_t gstep = (uint32_t)(rpi * pitch), sstep = (uint32_t)(rpi * SP);
         // no predicates (a load under a condition becomes a branch with a wait behind it): a row past the end -- and with it the
         // lanes left over -- takes the ROI's last row, i.e. loads and stores that row's dword once more
@@ -341,11 +349,12 @@ __global__ __launch_bounds__(256) void k_fast_cells(ImgView src0, ImgView pyr, c
             int x = 0, y = 0;
             if (it < nitems) {
                 y = (int)(((float)it + 0.5f) * inv_G); // exact: it < 4096, quotient >= 0.5/G away from an integer
-                x = 8 * (it - y * G);
+                x = 8 * (it - __mul24(y, G));
                 // pixels x .. x+7 of active row y = ROI pixels (x+3 .. x+10, y+3) = bytes x+4 .. x+11 of ROI row y+3
-                const uint32_t* cr = reinterpret_cast<const uint32_t*>(simg + (y + 3) * SP + x + 4);
-                const uint32_t* nr = reinterpret_cast<const uint32_t*>(simg + y * SP + x + 4);
-                const uint32_t* sr = reinterpret_cast<const uint32_t*>(simg + (y + 6) * SP + x + 4);
+                const uint8_t* rb = simg + __mul24(y, SP) + x + 4;
+                const uint32_t* cr = reinterpret_cast<const uint32_t*>(rb + 3 * SP);
+                const uint32_t* nr = reinterpret_cast<const uint32_t*>(rb);
+                const uint32_t* sr = reinterpret_cast<const uint32_t*>(rb + 6 * SP);
                 const uint32_t Wd = cr[-1], C0 = cr[0], C1 = cr[1], Ed = cr[2];
                 const uint32_t N0 = nr[0], N1 = nr[1], S0 = sr[0], S1 = sr[1];
                 const uint32_t E0 = __builtin_amdgcn_alignbyte(C1, C0, 3), W0 = __builtin_amdgcn_alignbyte(C0, Wd, 1);
@@ -360,9 +369,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(ImgView src0, ImgView pyr, c
                 const uint32_t p45 = FC_PASS2(C1, S1, E1, N1, W1, LO), p67 = FC_PASS2(C1, S1, E1, N1, W1, HI);
 #undef FC_PASS2
                 // non-zero 16-bit lanes -> bits 0 .. 7: clamp every lane to 0 / 1, interleave the four words, fold the high halves in
-                const u16x2 one2 = as_u16x2(0x00010001u);
-                const uint32_t b = as_u32(pk_minu(as_u16x2(p01), one2)) | (as_u32(pk_minu(as_u16x2(p23), one2)) << 2) |
-                                   (as_u32(pk_minu(as_u16x2(p45), one2)) << 4) | (as_u32(pk_minu(as_u16x2(p67), one2)) << 6);
+                // (written as the instruction: from the builtin the compiler makes two compares, two selects and a v_perm per word)
+                const uint32_t b = pk_min1(p01) | (pk_min1(p23) << 2) | (pk_min1(p45) << 4) | (pk_min1(p67) << 6);
                 mask8 = (b & 0x55u) | ((b >> 15) & 0xaau);
                 mask8 &= (1u << min(8, aw - x)) - 1u; // the last group of a row may be partial
             }
@@ -387,7 +395,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(ImgView src0, ImgView pyr, c
             int yx = 0, score = 0;
             if (e < n1) {
                 yx = slist[e];
-                const uint8_t* c = simg + ((yx >> 8) + 3) * SP + ((yx & 255) + 3) + 1;
+                const uint8_t* c = simg + __mul24(yx >> 8, SP) + (yx & 255) + (3 * SP + 4);
                 const uint32_t v = c[0];
                 const uint32_t v2 = v | (v << 16);
                 uint32_t P[8]; // (d[k], d[k+8]) as f16 bits, d = v - ring pixel
@@ -406,7 +414,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(ImgView src0, ImgView pyr, c
             __builtin_amdgcn_wave_barrier();
             if (corner) {
                 slist[nlist + lane_prefix(m)] = (uint16_t)yx;
-                smap[((yx >> 8) + 1) * MP + ((yx & 255) + 1)] = (uint8_t)score;
+                smap[__mul24(yx >> 8, MP) + (yx & 255) + (MP + 1)] = (uint8_t)score;
             }
             nlist += __popcll(m);
         }
@@ -419,7 +427,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(ImgView src0, ImgView pyr, c
             bool keep = false;
             if (e < nlist) {
                 const int yx = slist[e], y = yx >> 8, x = yx & 255;
-                const uint8_t* m = smap + (y + 1) * MP + (x + 1);
+                const uint8_t* m = smap + __mul24(y, MP) + x + (MP + 1);
                 const int s = m[0];
                 keep = s > m[-MP - 1] && s > m[-MP] && s > m[-MP + 1] && s > m[-1] && s > m[1] && s > m[MP - 1] &&
                        s > m[MP] && s > m[MP + 1];
@@ -431,7 +439,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(ImgView src0, ImgView pyr, c
         // nothing at iniThFAST: wipe the scores and try again at minThFAST
         for (int e = lane; e < nlist; e += 64) {
             const int yx = slist[e];
-            smap[((yx >> 8) + 1) * MP + ((yx & 255) + 1)] = 0;
+            smap[__mul24(yx >> 8, MP) + (yx & 255) + (MP + 1)] = 0;
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -447,7 +455,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(ImgView src0, ImgView pyr, c
         if (take) {
             const int yx = slist[e], y = yx >> 8, x = yx & 255;
             out[nout + lane_prefix(m)] = (uint32_t)(x + xrel) | ((uint32_t)(y + yrel) << 12) |
-                                         ((uint32_t)smap[(y + 1) * MP + (x + 1)] << 24);
+                                         ((uint32_t)smap[__mul24(y, MP) + x + (MP + 1)] << 24);
         }
         nout += __popcll(m);
     }
