@@ -508,13 +508,26 @@ int orbfe_aruco_max_markers(const orbfe_aruco* h);
 /* MarkerDetector::Params the shim forwards (markerdetector.h:96-214).
  *   setDictionary(name, error_correction_rate) / MarkerDetector(dict, rate): rate in [0, 1]; > 0 enables the error-correction pass
  *     of DictionaryBased::detect (a code closer than int(tau * rate) bits to a dictionary entry is accepted; default 0 = exact).
- *   setDetectionMode(dm, minMarkerSize): DM_NORMAL (0) with minMarkerSize 0 is what is built (Frame.cc:136); DM_FAST (1) and
- *     DM_VIDEO_FAST (2) -- THRES_AUTO_FIXED with its rand() retries and frame-to-frame state -- are refused with ORBFE_ERR_INVALID.
- *     min_marker_size must be 0 (Params::minSize > 0 detects on a reduced image: not built; refused, never ignored).
- *   setCornerRefinementMethod(m): CORNER_LINES (1, default, Frame.cc:137) and CORNER_NONE (2); CORNER_SUBPIX (0) is refused. */
+ *   setDetectionMode(dm, minMarkerSize) (markerdetector.cpp:374-391): DM_NORMAL (0, Frame.cc:136), DM_FAST (1) and DM_VIDEO_FAST (2).
+ *     The fast modes threshold with THRES_AUTO_FIXED: one global threshold, carried from frame to frame (Otsu over the pixels of the
+ *     markers just found, markerdetector_impl.cpp:7003-7040) and replaced by 10 + rand() % 230 -- the process's own rand() sequence,
+ *     as in the reference -- when a frame yields nothing (:6903-6990); DM_VIDEO_FAST also derives the next frame's minMarkerSize from
+ *     the smallest marker of this one (:8790-8880).  Such a handle is frame-sequential: the host-pointer entry points take its frames
+ *     one at a time in order, orbfe_aruco_detect_batch_device refuses it.  minMarkerSize in [0, 1] (Params::minSize, a fraction of
+ *     the larger image side) > 0 detects on an INTER_NEAREST reduction of the frame and brings the corners back through the /2
+ *     pyramid with cv::cornerSubPix (cornerUpsample, :14028-14220); reductions below 64 x 48 pixels are refused.
+ *   setCornerRefinementMethod(m): CORNER_SUBPIX (0: cv::cornerSubPix, window 4, 12 iterations, eps 0.005, :8511), CORNER_LINES
+ *     (1, default here, Frame.cc:137) and CORNER_NONE (2); anything but CORNER_SUBPIX resets minMarkerSize to 0 (markerdetector.cpp:392-395).
+ *   orbfe_aruco_get_state: Params::ThresHold and Params::minSize as the last call left them, the threshold passes of the last call
+ *     and the size of the image it worked on (any pointer may be NULL). */
 int orbfe_aruco_set_error_correction_rate(orbfe_aruco* h, float rate);
 int orbfe_aruco_set_detection_mode(orbfe_aruco* h, int mode, float min_marker_size);
 int orbfe_aruco_set_corner_refinement(orbfe_aruco* h, int method);
+int orbfe_aruco_get_state(const orbfe_aruco* h, int32_t* threshold, float* min_size, int32_t* attempts, int32_t* work_rows,
+                          int32_t* work_cols);
+/* cvtColor(BGR2GRAY) of the CV_8UC3 entry points: 14 fractional bits (OpenCV <= 3.4.1: B 1868, G 9617, R 4899; default) or 15
+ * (3.4.2 and later: 3735, 19235, 9798). */
+int orbfe_aruco_set_gray_conversion(orbfe_aruco* h, int fractional_bits);
 /* aruco::Marker::contourPoints (marker.h:56) of marker `marker` (index into the output of the last detect / batch call) of frame
  * `frame`: the full border the rectangle came from, (x, y) int32 pairs.  *n = its length; min(*n, capacity) points are written.
  * Host pointers; synchronises the device. */
@@ -528,6 +541,9 @@ int orbfe_aruco_marker_contours(orbfe_aruco* h, int frame, int nmarkers, int32_t
  * Frames up to 4095 pixels wide (adaptive-threshold windows up to 31, markerdetector_impl.cpp:3765-3809). */
 int orbfe_aruco_detect(orbfe_aruco* h, const uint8_t* img, int rows, int cols, size_t step, orbfe_marker* out,
                        int capacity, int32_t* n_out);
+/* detect() on a CV_8UC3 (BGR) frame (markerdetector_impl.cpp:5892: cvtColor(BGR2GRAY) first); `step` in bytes, >= 3 * cols. */
+int orbfe_aruco_detect_bgr(orbfe_aruco* h, const uint8_t* bgr, int rows, int cols, size_t step, orbfe_marker* out, int capacity,
+                           int32_t* n_out);
 int orbfe_aruco_detect_batch(orbfe_aruco* h, const uint8_t* imgs, int nframes, size_t frame_stride, int rows, int cols,
                              size_t step, orbfe_marker* out, int capacity, int32_t* n_out);
 int orbfe_aruco_detect_batch_device(orbfe_aruco* h, const uint8_t* d_imgs, int nframes, size_t frame_stride, int rows,
@@ -580,6 +596,15 @@ int orbfe_marker_poses_batch_device(const orbfe_marker* d_markers, const int32_t
 int orbfe_aruco_detect_poses(orbfe_aruco* h, const uint8_t* img, int rows, int cols, size_t step, orbfe_marker* out,
                              orbfe_marker_pose* poses, int capacity, int32_t* n_out, float marker_size, const float* K4,
                              const float* dist, int ndist);
+/* The same on a CV_8UC3 (BGR) frame. */
+int orbfe_aruco_detect_poses_bgr(orbfe_aruco* h, const uint8_t* bgr, int rows, int cols, size_t step, orbfe_marker* out,
+                                 orbfe_marker_pose* poses, int capacity, int32_t* n_out, float marker_size, const float* K4,
+                                 const float* dist, int ndist);
+/* cv::cornerSubPix(image, corners, Size(win, win), Size(-1, -1), TermCriteria(MAX_ITER | EPS, max_iters, eps)) on a CV_8UC1 image
+ * (what the detector's CORNER_SUBPIX mode and its cornerUpsample run, markerdetector_impl.cpp:8511, :14182): pts = n (x, y) pairs,
+ * refined in place; window half size 1 .. 8.  Host pointers. */
+int orbfe_corner_subpix(const uint8_t* img, int rows, int cols, size_t step, float* pts, int n, int win, int max_iters, double eps,
+                        int device);
 
 
 #ifdef __cplusplus

@@ -34,9 +34,10 @@ public:
     {
         void setDetectionMode(DetectionMode dm, float minMarkerSize)
         {
-            // the mode is checked now; minSize is bookkeeping until detect() (a following setCornerRefinementMethod(CORNER_LINES /
-            // CORNER_NONE) resets it to 0 as in the reference, markerdetector.cpp:374-393), where a value still in force is refused
-            check(orbfe_aruco_set_detection_mode(owner->handle(), (int)dm, 0.f));
+            // the library keeps the parameters and their frame-to-frame state (THRES_AUTO_FIXED threshold, automatic minSize); the
+            // members below are the caller-visible copy (a following setCornerRefinementMethod(CORNER_LINES / CORNER_NONE) resets
+            // minSize to 0 on both sides as in the reference, markerdetector.cpp:374-395)
+            check(orbfe_aruco_set_detection_mode(owner->handle(), (int)dm, minMarkerSize));
             detectMode = dm;
             minSize = minMarkerSize;
         }
@@ -120,10 +121,10 @@ public:
                 float markerSizeMeters = -1, bool setYPerperdicular = false)
     {
         if (!h_) setDictionary(_params.dictionary, _params.error_correction_rate);
-        if (input.type() != CV_8UC1)
-            throw cv::Exception(9001, "the orbfe detector takes the grey image Frame.cc:142 passes (CV_8UC1)", "MarkerDetector::detect", __FILE__, __LINE__);
-        if (orbfe_aruco_set_detection_mode(h_, (int)_params.detectMode, _params.minSize) != ORBFE_OK)   // minSize != 0 in force: refused
-            throw cv::Exception(9001, orbfe_last_error(), "MarkerDetector::detect", __FILE__, __LINE__);
+        // CV_8UC1 (what Frame.cc:142 passes) or CV_8UC3, converted with BGR2GRAY on the device (markerdetector_impl.cpp:5892)
+        if (input.type() != CV_8UC1 && input.type() != CV_8UC3)
+            throw cv::Exception(9001, "MarkerDetector::detect takes CV_8UC1 or CV_8UC3 images", "MarkerDetector::detect", __FILE__, __LINE__);
+        const bool bgr = input.type() == CV_8UC3;
         const int cap = orbfe_aruco_max_markers(h_);
         std::vector<orbfe_marker> m(cap);
         std::vector<orbfe_marker_pose> poses;
@@ -137,11 +138,11 @@ public:
             distCoeff.convertTo(D32, CV_32F);
             const float K4[4] = {K32.at<float>(0, 0), K32.at<float>(1, 1), K32.at<float>(0, 2), K32.at<float>(1, 2)};
             poses.resize(cap);
-            if (orbfe_aruco_detect_poses(h_, input.data, input.rows, input.cols, input.step, m.data(), poses.data(), cap, &n, markerSizeMeters,
+            if ((bgr ? orbfe_aruco_detect_poses_bgr : orbfe_aruco_detect_poses)(h_, input.data, input.rows, input.cols, input.step, m.data(), poses.data(), cap, &n, markerSizeMeters,
                                          K4, D32.empty() ? nullptr : D32.ptr<float>(), (int)D32.total()) != ORBFE_OK)
                 throw cv::Exception(9001, orbfe_last_error(), "MarkerDetector::detect", __FILE__, __LINE__);
         }
-        else if (orbfe_aruco_detect(h_, input.data, input.rows, input.cols, input.step, m.data(), cap, &n) != ORBFE_OK)
+        else if ((bgr ? orbfe_aruco_detect_bgr : orbfe_aruco_detect)(h_, input.data, input.rows, input.cols, input.step, m.data(), cap, &n) != ORBFE_OK)
             throw cv::Exception(9001, orbfe_last_error(), "MarkerDetector::detect", __FILE__, __LINE__);
         detectedMarkers.clear();
         detectedMarkers.resize(n);

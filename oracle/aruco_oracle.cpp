@@ -1,9 +1,13 @@
 /*
  * aruco_oracle.cpp -- CPU restatement of the reference ArUco detector as configured by
- * src/Frame.cc:129-142 (dictionary by name, DM_NORMAL, CORNER_LINES).  TEST INFRASTRUCTURE ONLY.
+ * src/Frame.cc:129-142 (dictionary by name, DM_NORMAL, CORNER_LINES), and of the rest of its parameter
+ * surface (markerdetector.cpp:364-402: DM_FAST / DM_VIDEO_FAST = THRES_AUTO_FIXED with rand() retries and
+ * frame-to-frame state, Params::minSize > 0 with cornerUpsample, CORNER_SUBPIX, CV_8UC3 input).
+ * TEST INFRASTRUCTURE ONLY.
  *
  * PARITY UNPINNED for the OpenCV primitives (adaptiveThreshold, findContours, approxPolyDP,
- * getPerspectiveTransform/warpPerspective, threshold(OTSU), solve(SVD)): the reference ships no
+ * getPerspectiveTransform/warpPerspective, threshold(OTSU), solve(SVD), threshold, resize(INTER_NEAREST),
+ * cornerSubPix / getRectSubPix, cvtColor(BGR2GRAY)): the reference ships no
  * tests and OpenCV 3.4 is not available here, so these follow the OpenCV 3.4 generic code paths
  * from knowledge of that source.  The detector logic itself follows the
  * de-obfuscated Thirdparty/aruco/aruco/markerdetector_impl.cpp and dictionary_based.cpp
@@ -18,6 +22,8 @@
 #include <cfloat>
 #include <climits>
 #include <cmath>
+#include <cstdlib>
+#include <limits>
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -384,6 +390,162 @@ int otsu_threshold(const uint8_t* p, int n)
     return (int)max_val;
 }
 
+
+/* ---------------------------------------------------------------- primitives of the modes outside Frame.cc:135-137 ----
+ * (DM_FAST / DM_VIDEO_FAST = THRES_AUTO_FIXED, Params::minSize > 0, CORNER_SUBPIX, CV_8UC3 input).  PARITY UNPINNED like the
+ * rest of the image path: cv::threshold, cv::resize(INTER_NEAREST), cv::cornerSubPix / getRectSubPix and cvtColor(BGR2GRAY)
+ * follow the OpenCV 3.x generic code paths from knowledge of that source. */
+
+/* cv::threshold(src, dst, int(thr), 255, THRESH_BINARY_INV) (markerdetector_impl.cpp:2833-2870) */
+void threshold_fixed_inv(const Image& src, Image& dst, int thr)
+{
+    dst = Image(src.w, src.h);
+    for (size_t i = 0; i < src.d.size(); i++) dst.d[i] = src.d[i] > thr ? 0 : 255;
+}
+
+/* cv::resize(src, dst, dsize, 0, 0, INTER_NEAREST) (resize.cpp resizeNN): sx = min(floor(x * ifx), sw - 1), ifx = 1 / (dw / sw) */
+void resize_nearest(const Image& src, Image& dst)
+{
+    const double inv_fx = (double)dst.w / src.w, inv_fy = (double)dst.h / src.h;
+    const double ifx = 1. / inv_fx, ify = 1. / inv_fy;
+    std::vector<int> xo(dst.w);
+    for (int x = 0; x < dst.w; x++) xo[x] = std::min(orbfe_floor_d(x * ifx), src.w - 1);
+    for (int y = 0; y < dst.h; y++) {
+        const uint8_t* S = src.row(std::min(orbfe_floor_d(y * ify), src.h - 1));
+        uint8_t* D = dst.row(y);
+        for (int x = 0; x < dst.w; x++) D[x] = S[xo[x]];
+    }
+}
+
+/* cvtColor(BGR2GRAY) on CV_8UC3 (markerdetector_impl.cpp:5892): OpenCV <= 3.4.1 tables with 14 fractional bits
+ * (B 1868, G 9617, R 4899); 3.4.2+ / 4.x use 15 bits (B 3735, G 19235, R 9798): `bits15` selects. */
+void bgr_to_gray(const uint8_t* bgr, size_t step, int w, int h, Image& dst, int bits15)
+{
+    dst = Image(w, h);
+    for (int y = 0; y < h; y++) {
+        const uint8_t* s = bgr + (size_t)y * step;
+        for (int x = 0; x < w; x++, s += 3)
+            dst.row(y)[x] = bits15 ? (uint8_t)((s[0] * 3735 + s[1] * 19235 + s[2] * 9798 + (1 << 14)) >> 15)
+                                   : (uint8_t)((s[0] * 1868 + s[1] * 9617 + s[2] * 4899 + (1 << 13)) >> 14);
+    }
+}
+
+/* getRectSubPix(src 8u, Size(ww, wh), center, dst 32f) (samplers.cpp getRectSubPix_Cn_<uchar, float, float>), dst row-major ww x wh */
+void get_rect_subpix(const Image& src, int ww, int wh, float cx, float cy, float* dst)
+{
+    cx -= (ww - 1) * 0.5f;
+    cy -= (wh - 1) * 0.5f;
+    const int ipx = orbfe_floor_d(cx), ipy = orbfe_floor_d(cy);
+    const float a = cx - ipx, b = cy - ipy;
+    const float a11 = (1.f - a) * (1.f - b), a12 = a * (1.f - b), a21 = (1.f - a) * b, a22 = a * b, b1 = 1.f - b, b2 = b;
+    if (0 <= ipx && ipx < src.w - ww && 0 <= ipy && ipy < src.h - wh) {
+        for (int i = 0; i < wh; i++) {
+            const uint8_t* s = src.row(ipy + i) + ipx;
+            const uint8_t* s2 = s + src.w;
+            for (int j = 0; j < ww; j++) dst[i * ww + j] = s[j] * a11 + s[j + 1] * a12 + s2[j] * a21 + s2[j + 1] * a22;
+        }
+        return;
+    }
+    /* adjustRect(): the part of the window inside the image is [rx, rw) x [ry, rh); outside it the border is replicated */
+    long so = 0; /* offset of `src` (in pixels) from the image origin */
+    int rx, rw, ry, rh;
+    if (ipx >= 0) { so += ipx; rx = 0; }
+    else { rx = -ipx; if (rx > ww) rx = ww; }
+    if (ipx < src.w - ww) rw = ww;
+    else { rw = src.w - ipx - 1; if (rw < 0) { so += rw; rw = 0; } }
+    if (ipy >= 0) { so += (long)ipy * src.w; ry = 0; }
+    else ry = -ipy;
+    if (ipy < src.h - wh) rh = wh;
+    else { rh = src.h - ipy - 1; if (rh < 0) { so += (long)rh * src.w; rh = 0; } }
+    const uint8_t* s = src.d.data() + so - rx;
+    for (int i = 0; i < wh; i++) {
+        const uint8_t* s2 = s + src.w;
+        if (i < ry || i >= rh) s2 -= src.w;
+        int j = 0;
+        for (; j < rx; j++) dst[i * ww + j] = s[rx] * b1 + s2[rx] * b2;
+        for (; j < rw; j++) dst[i * ww + j] = s[j] * a11 + s[j + 1] * a12 + s2[j] * a21 + s2[j + 1] * a22;
+        for (; j < ww; j++) dst[i * ww + j] = s[rw] * b1 + s2[rw] * b2;
+        if (i < rh) s = s2;
+    }
+}
+
+/* cv::cornerSubPix(src, corners, Size(win, win), Size(-1, -1), criteria) (cornersubpix.cpp): max_iters = criteria.maxCount clamped to
+ * [1, 100] (100 without MAX_ITER), eps = criteria.epsilon (0 without EPS) */
+void corner_subpix(const Image& src, std::vector<Ptf>& corners, int win, int max_iters, double eps)
+{
+    if (corners.empty()) return;
+    const int ww = 2 * win + 1;
+    eps *= eps;
+    std::vector<float> mask((size_t)ww * ww), buf((size_t)(ww + 2) * (ww + 2));
+    for (int i = 0; i < ww; i++) {
+        const float y = (float)(i - win) / win;
+        const float vy = std::exp(-y * y);
+        for (int j = 0; j < ww; j++) {
+            const float x = (float)(j - win) / win;
+            mask[(size_t)i * ww + j] = (float)(vy * std::exp(-x * x));
+        }
+    }
+    for (auto& cr : corners) {
+        const Ptf cT = cr;
+        Ptf cI = cT;
+        int iter = 0;
+        double err = 0;
+        do {
+            double a = 0, b = 0, c = 0, bb1 = 0, bb2 = 0;
+            get_rect_subpix(src, ww + 2, ww + 2, cI.x, cI.y, buf.data());
+            const float* sp = buf.data() + (ww + 2) + 1;
+            for (int i = 0, k = 0; i < ww; i++, sp += ww + 2) {
+                const double py = i - win;
+                for (int j = 0; j < ww; j++, k++) {
+                    const double m = mask[k];
+                    const double tgx = sp[j + 1] - sp[j - 1];
+                    const double tgy = sp[j + ww + 2] - sp[j - ww - 2];
+                    const double gxx = tgx * tgx * m, gxy = tgx * tgy * m, gyy = tgy * tgy * m;
+                    const double px = j - win;
+                    a += gxx; b += gxy; c += gyy;
+                    bb1 += gxx * px + gxy * py;
+                    bb2 += gxy * px + gyy * py;
+                }
+            }
+            const double det = a * c - b * b;
+            if (std::fabs(det) <= DBL_EPSILON * DBL_EPSILON) break;
+            const double scale = 1.0 / det;
+            Ptf cI2;
+            cI2.x = (float)(cI.x + c * scale * bb1 - b * scale * bb2);
+            cI2.y = (float)(cI.y - b * scale * bb1 + a * scale * bb2);
+            err = (cI2.x - cI.x) * (cI2.x - cI.x) + (cI2.y - cI.y) * (cI2.y - cI.y);
+            cI = cI2;
+            if (cI.x < 0 || cI.x >= src.w || cI.y < 0 || cI.y >= src.h) break;
+        } while (++iter < max_iters && err > eps);
+        if (std::fabs(cI.x - cT.x) > win || std::fabs(cI.y - cT.y) > win) cI = cT;
+        cr = cI;
+    }
+}
+
+/* Otsu over the float histogram accumulated from the warped patches of the detected markers (markerdetector_impl.cpp:6121-6380):
+ * normalises the histogram in place; -1 when no split has both classes above 1e-4 (an empty histogram gives NaNs and -1) */
+int otsu_of_histogram(std::vector<float>& hist)
+{
+    float sum = 0, invsum;
+    for (auto c : hist) sum += c;
+    invsum = 1. / sum;
+    for (auto& c : hist) c *= invsum;
+    float maxVar = 0;
+    int bestT = -1;
+    for (int t = 1; t < 256; t++) {
+        float w0 = 0, w1 = 0, mean0 = 0, mean1 = 0;
+        for (int v = 0; v < t; v++) { w0 += hist[v]; mean0 += float(v) * hist[v]; }
+        for (int v = t; v < 256; v++) { w1 += hist[v]; mean1 += hist[v] * float(v); }
+        if (w0 > 1e-4 && w1 > 1e-4) {
+            mean0 /= w0;
+            mean1 /= w1;
+            const float var = w0 * w1 * (mean0 - mean1) * (mean0 - mean1);
+            if (var > maxVar) { maxVar = var; bestT = t; }
+        }
+    }
+    return bestT;
+}
+
 /* ------------------------------------------------------------ dictionary -- */
 struct Dict {
     std::string name;
@@ -536,6 +698,16 @@ Ptf cross_point(const float l1[3], const float l2[3]) /* getCrossPoint, :11899-1
 struct Detector {
     Dict dict;
     bool corner_lines = true; /* Params::cornerRefinementM == CORNER_LINES (Frame.cc:137) */
+    /* MarkerDetector::Params outside the configuration of Frame.cc:135-137 (markerdetector.h:158-196, markerdetector.cpp:364-402) */
+    int corner_method = 1;     /* CORNER_SUBPIX 0, CORNER_LINES 1, CORNER_NONE 2 (kept in step with corner_lines) */
+    int thres_method = 0;      /* THRES_ADAPTIVE 0, THRES_AUTO_FIXED 1 */
+    int ThresHold = 7;         /* adaptive: the constant C; AUTO_FIXED: the global threshold carried from frame to frame */
+    int NAttemptsAutoThresFix = 3;
+    float minSize = 0.f;       /* what setDetectionMode(dm, minMarkerSize) leaves (the default -1 behaves like 0) */
+    bool autoSize = false;
+    float ts = 0.25f;
+    int last_attempts = 0;     /* threshold passes of the last call (test read-back) */
+    int last_work_w = 0, last_work_h = 0;
     /* stage data of the last call (per-stage parity tests) */
     Image thres;
     std::vector<Image> pyramid;
@@ -605,7 +777,8 @@ struct Detector {
         int w = std::max(3, int(15 * float(gray.w) / 1920.));
         if (w % 2 == 0) w++;
         win = w; /* = _tooNearDistance */
-        adaptive_threshold_inv(gray, thres, w, 7);
+        if (thres_method == 1) threshold_fixed_inv(gray, thres, ThresHold); /* THRES_AUTO_FIXED (:2833-2870) */
+        else adaptive_threshold_inv(gray, thres, w, ThresHold);
         std::vector<std::vector<Pt>> contours;
         find_contours_list(thres, contours);
         rects.clear();
@@ -692,38 +865,125 @@ struct Detector {
         for (unsigned i = 0; i < 4; i++) m.c[i] = cross_point(L[(i - 1) % 4], L[i]); /* unsigned (i-1)%4: 3 for i=0 */
     }
 
-    int detect(const Image& gray, std::vector<Candidate>& out)
+    /* setDetectionMode (markerdetector.cpp:374-391) */
+    void set_detection_mode(int dm, float minMarkerSize)
+    {
+        minSize = minMarkerSize;
+        if (dm == 0) { autoSize = false; ts = 0.25f; thres_method = 0; ThresHold = 7; }
+        else if (dm == 1) { autoSize = false; ts = 0.25f; thres_method = 1; ThresHold = 100; }
+        else { thres_method = 1; ThresHold = 100; autoSize = true; ts = 0.3f; }
+    }
+    /* setCornerRefinementMethod (:392-395) */
+    void set_corner_method(int m)
+    {
+        corner_method = m;
+        corner_lines = m == 1;
+        if (m != 0) minSize = 0;
+    }
+    /* getMinMarkerSizePix (:10690-10760) with minSize_pix == -1 */
+    int min_marker_size_pix(int w, int h) const
+    {
+        const int maxDim = std::max(w, h);
+        return (int)(static_cast<float>(minSize) * static_cast<float>(maxDim));
+    }
+    /* cornerUpsample (:14028-14220): from the level of the pyramid just above the working size down to the input, scale the corners
+     * and refine them with cornerSubPix(TermCriteria(MAX_ITER, 4, 0.5)) */
+    void corner_upsample(std::vector<Candidate>& ms, int work_w)
+    {
+        if (ms.empty()) return;
+        int start = 0;
+        for (size_t i = 0; i < pyramid.size(); i++) {
+            if (work_w < pyramid[i].w) start = (int)i;
+            else break;
+        }
+        int prev_w = work_w;
+        for (int l = start; l >= 0; l--) {
+            const float factor = float(pyramid[l].w) / float(prev_w);
+            std::vector<Ptf> pts;
+            for (auto& m : ms)
+                for (int k = 0; k < 4; k++) {
+                    m.c[k].x *= factor; m.c[k].y *= factor;
+                    pts.push_back(m.c[k]);
+                }
+            const int halfw = (int)(0.5 + 2.5 * factor);
+            corner_subpix(pyramid[l], pts, halfw, 4, 0.0);
+            size_t q = 0;
+            for (auto& m : ms)
+                for (int k = 0; k < 4; k++) m.c[k] = pts[q++];
+            prev_w = pyramid[l].w;
+        }
+    }
+
+    /* MarkerDetector_Impl::detect (:5870-8800) */
+    int detect(const Image& input, std::vector<Candidate>& out)
     {
         out.clear();
         const int nb = (int)std::sqrt((double)dict.nbits);
         const int S = 5 * (nb + 2); /* getMarkerWarpSize (:1199-1292): markerWarpPixSize * nSubdivisions */
-        build_pyramid(gray, 2 * S);
-        threshold_and_detect(gray);
-        prefilter(gray.w, gray.h);
-        const float desiredarea = std::pow(static_cast<float>(S), 2.f);
-        std::vector<uint8_t> patch((size_t)S * S);
-        for (auto& cand : prefiltered) {
-            size_t lvl = 0;
-            for (size_t p = 1; p < pyramid.size(); p++) {
-                if (get_area(cand.c) / std::pow(4, p) >= desiredarea) lvl = p;
-                else break;
-            }
-            const Image& im = pyramid[lvl];
-            const float ratio = float(im.w) / float(gray.w);
-            Ptf q[4];
-            for (int k = 0; k < 4; k++) q[k] = Ptf{cand.c[k].x * ratio, cand.c[k].y * ratio};
-            double Minv[9];
-            if (!perspective_inverse_map(q, S, Minv)) continue;
-            warp_perspective(im, Minv, S, patch.data());
-            int nRot = 0;
-            int id = decode_marker(patch.data(), S, dict, &nRot);
-            if (id >= 0) {
-                Candidate m = cand;
-                m.id = id;
-                std::rotate(m.c, m.c + 4 - nRot, m.c + 4);
-                out.push_back(std::move(m));
+        /* the working image: reduced with INTER_NEAREST when markers below minSize need not be found (:5990-6090) */
+        Image reduced;
+        const Image* work = &input;
+        const int minpix = min_marker_size_pix(input.w, input.h);
+        if (20 < minpix) { /* lowResMarkerSize = 20 */
+            const float scale = float(20) / float(minpix);
+            if (scale < 0.9) {
+                int rw = float(input.w) * scale + 0.5, rh = float(input.h) * scale + 0.5;
+                if (rw % 2 != 0) rw++;
+                if (rh % 2 != 0) rh++;
+                reduced = Image(rw, rh);
+                resize_nearest(input, reduced);
+                work = &reduced;
             }
         }
+        last_work_w = work->w; last_work_h = work->h;
+        build_pyramid(input, 2 * S);
+        const float desiredarea = std::pow(static_cast<float>(S), 2.f);
+        std::vector<uint8_t> patch((size_t)S * S);
+        std::vector<float> hist(256, 0.f);
+        int nattempts = 0;
+        bool again;
+        last_attempts = 0;
+        do {
+            last_attempts++;
+            threshold_and_detect(*work);
+            prefilter(work->w, work->h);
+            out.clear();
+            for (auto& v : hist) v = 0;
+            for (auto& cand : prefiltered) {
+                size_t lvl = 0;
+                for (size_t p = 1; p < pyramid.size(); p++) {
+                    if (get_area(cand.c) / std::pow(4, p) >= desiredarea) lvl = p;
+                    else break;
+                }
+                const Image& im = pyramid[lvl];
+                const float ratio = float(im.w) / float(work->w);
+                Ptf q[4];
+                for (int k = 0; k < 4; k++) q[k] = Ptf{cand.c[k].x * ratio, cand.c[k].y * ratio};
+                double Minv[9];
+                if (!perspective_inverse_map(q, S, Minv)) continue;
+                warp_perspective(im, Minv, S, patch.data());
+                int nRot = 0;
+                int id = decode_marker(patch.data(), S, dict, &nRot);
+                if (id >= 0) {
+                    Candidate m = cand;
+                    m.id = id;
+                    std::rotate(m.c, m.c + 4 - nRot, m.c + 4);
+                    out.push_back(std::move(m));
+                    if (thres_method == 1) /* addToImageHist (:6121-6190): the warped patch, before the labeler thresholds its copy */
+                        for (size_t i = 0; i < patch.size(); i++) hist[patch[i]]++;
+                }
+            }
+            /* nothing found with the carried-over threshold: try a random one (:6903-6990) */
+            if (out.size() == 0 && thres_method == 1 && ++nattempts < NAttemptsAutoThresFix) {
+                ThresHold = 10 + rand() % 230;
+                again = true;
+            } else again = false;
+        } while (again);
+        if (thres_method == 1) { /* the threshold for the next call: Otsu over the detected markers' pixels (:7003-7040) */
+            const int t = otsu_of_histogram(hist);
+            if (t > 0) ThresHold = float(t);
+        }
+        if (input.w != work->w) corner_upsample(out, work->w); /* :7046-7071 */
         /* sort by id; among equal ids keep the larger perimeter (:8153-8365) */
         std::stable_sort(out.begin(), out.end(), [](const Candidate& a, const Candidate& b) { return a.id < b.id; });
         std::vector<bool> rm(out.size(), false);
@@ -737,8 +997,33 @@ struct Detector {
         for (size_t i = 0; i < out.size(); i++)
             if (!rm[i]) kept.push_back(std::move(out[i]));
         out.swap(kept);
-        if (corner_lines) /* cornerRefinementM == CORNER_LINES (:8634-8701); CORNER_NONE leaves the approxPolyDP corners */
-            for (auto& m : out) refine_corners(m);
+        if (out.size() > 0 && input.w == work->w && input.h == work->h) { /* :8420-8701 */
+            if (corner_method == 0) {
+                const int halfw = 4 * float(input.w) / float(work->w) + 0.5;
+                std::vector<Ptf> pts;
+                for (auto& m : out)
+                    for (int k = 0; k < 4; k++) pts.push_back(m.c[k]);
+                corner_subpix(input, pts, halfw, 12, 0.005);
+                size_t q = 0;
+                for (auto& m : out)
+                    for (int k = 0; k < 4; k++) m.c[k] = pts[q++];
+            } else if (corner_method == 1) /* CORNER_LINES (:8634-8701); CORNER_NONE leaves the approxPolyDP corners */
+                for (auto& m : out) refine_corners(m);
+        }
+        /* the smallest marker of this frame sets the next frame's minSize (:8790-8880) */
+        float mlength = std::numeric_limits<float>::max();
+        for (const auto& m : out) {
+            float l = 0;
+            for (int c = 0; c < 4; c++) {
+                const float dx = m.c[c].x - m.c[(c + 1) % 4].x, dy = m.c[c].y - m.c[(c + 1) % 4].y;
+                l += std::sqrt((double)dx * dx + (double)dy * dy); /* float += cv::norm (double) */
+            }
+            if (mlength > l) mlength = l;
+        }
+        float markerMinSize;
+        if (mlength != std::numeric_limits<float>::max()) markerMinSize = mlength / (4 * std::max(input.w, input.h));
+        else markerMinSize = 0;
+        if (autoSize) minSize = markerMinSize * (1 - ts);
         return (int)out.size();
     }
 };
@@ -770,6 +1055,46 @@ void oracle_aruco_set_params(void* h, float error_correction_rate, int corner_li
 {
     ((Detector*)h)->dict.error_correction_rate = error_correction_rate;
     ((Detector*)h)->corner_lines = corner_lines != 0;
+    ((Detector*)h)->corner_method = corner_lines ? 1 : 2;
+}
+
+/* setDetectionMode(dm, minMarkerSize) then setCornerRefinementMethod(corner_method), in the order a caller of the reference uses */
+void oracle_aruco_set_detection_mode(void* h, int dm, float min_marker_size) { ((Detector*)h)->set_detection_mode(dm, min_marker_size); }
+void oracle_aruco_set_corner_method(void* h, int m) { ((Detector*)h)->set_corner_method(m); }
+/* state read-back: 0 ThresHold, 1 threshold passes of the last call, 2 / 3 working width / height of the last call */
+int oracle_aruco_state(void* h, int which)
+{
+    Detector* d = (Detector*)h;
+    return which == 0 ? d->ThresHold : which == 1 ? d->last_attempts : which == 2 ? d->last_work_w : d->last_work_h;
+}
+float oracle_aruco_min_size(void* h) { return ((Detector*)h)->minSize; }
+void oracle_bgr_to_gray(const uint8_t* bgr, int rows, int cols, size_t step, uint8_t* out, int bits15)
+{
+    Image g;
+    bgr_to_gray(bgr, step, cols, rows, g, bits15);
+    memcpy(out, g.d.data(), g.d.size());
+}
+void oracle_resize_nearest(const uint8_t* src, int w, int h, uint8_t* dst, int dw, int dh)
+{
+    Image s(w, h), d(dw, dh);
+    memcpy(s.d.data(), src, (size_t)w * h);
+    resize_nearest(s, d);
+    memcpy(dst, d.d.data(), d.d.size());
+}
+/* pts: n (x, y) float pairs, refined in place */
+void oracle_corner_subpix(const uint8_t* src, int w, int h, float* pts, int n, int win, int max_iters, double eps)
+{
+    Image s(w, h);
+    memcpy(s.d.data(), src, (size_t)w * h);
+    std::vector<Ptf> c(n);
+    for (int i = 0; i < n; i++) c[i] = Ptf{pts[2 * i], pts[2 * i + 1]};
+    corner_subpix(s, c, win, max_iters, eps);
+    for (int i = 0; i < n; i++) { pts[2 * i] = c[i].x; pts[2 * i + 1] = c[i].y; }
+}
+int oracle_otsu_of_histogram(const float* hist256)
+{
+    std::vector<float> h(hist256, hist256 + 256);
+    return otsu_of_histogram(h);
 }
 
 int oracle_aruco_detect(void* h, const uint8_t* img, int rows, int cols, size_t step, void* out, int capacity)

@@ -37,6 +37,7 @@ SYMBOLS = [
     "orbfe_aruco_batch_status", "orbfe_aruco_set_big_frames", "orbfe_aruco_set_error_correction_rate",
     "orbfe_aruco_set_detection_mode", "orbfe_aruco_set_corner_refinement", "orbfe_aruco_marker_contour", "orbfe_aruco_marker_contours",
     "orbfe_camera_resize", "orbfe_marker_poses", "orbfe_marker_poses_batch_device", "orbfe_aruco_detect_poses",
+    "orbfe_aruco_detect_bgr", "orbfe_aruco_detect_poses_bgr", "orbfe_aruco_get_state", "orbfe_aruco_set_gray_conversion", "orbfe_corner_subpix",
     "orbfe_vocabulary_load_text", "orbfe_vocabulary_create", "orbfe_vocabulary_destroy", "orbfe_vocabulary_info",
     "orbfe_vocabulary_transform", "orbfe_vocabulary_transform_batch_device",
     "orbfe_search_by_bow", "orbfe_search_by_bow_batch_device",
@@ -138,6 +139,11 @@ def load():
         L.orbfe_aruco_set_error_correction_rate.argtypes = [vp, f32]
         L.orbfe_aruco_set_detection_mode.argtypes = [vp, i32, f32]
         L.orbfe_aruco_set_corner_refinement.argtypes = [vp, i32]
+        L.orbfe_aruco_detect_bgr.argtypes = [vp, vp, i32, i32, sz, vp, i32, vp]
+        L.orbfe_aruco_detect_poses_bgr.argtypes = [vp, vp, i32, i32, sz, vp, vp, i32, vp, f32, vp, vp, i32]
+        L.orbfe_aruco_get_state.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.orbfe_aruco_set_gray_conversion.argtypes = [vp, i32]
+        L.orbfe_corner_subpix.argtypes = [vp, i32, i32, sz, vp, i32, i32, i32, C.c_double, i32]
         L.orbfe_aruco_marker_contour.argtypes = [vp, i32, i32, vp, i32, vp]
         L.orbfe_aruco_marker_contours.argtypes = [vp, i32, i32, vp, i32, vp]
         L.orbfe_camera_resize.argtypes = [vp, i32, i32, i32, i32, vp]
@@ -748,6 +754,16 @@ class ORBVocabulary:
                     fv=(fn[:nf].copy(), fo[:nf + 1].copy(), ff[:fo[nf]].copy()))
 
 
+def corner_subpix(image, pts, win, max_iters, eps, device=0):
+    """cv::cornerSubPix(image, pts, Size(win, win), Size(-1, -1), TermCriteria(MAX_ITER | EPS, max_iters, eps)) -> refined (n, 2) float32."""
+    L = load()
+    image = np.ascontiguousarray(image, np.uint8)
+    out = np.ascontiguousarray(pts, np.float32).reshape(-1, 2).copy()
+    _check(L, L.orbfe_corner_subpix(_p(image), image.shape[0], image.shape[1], image.strides[0], _p(out), len(out), int(win), int(max_iters),
+                                    float(eps), device), "orbfe_corner_subpix")
+    return out
+
+
 class MarkerDetector:
     """Mirror of aruco::MarkerDetector as the reference configures it (src/Frame.cc:129-142):
     setDictionary(name) + DM_NORMAL + CORNER_LINES; detect(image) -> markers sorted by id."""
@@ -780,6 +796,16 @@ class MarkerDetector:
     def setCornerRefinementMethod(self, method):
         _check(self.L, self.L.orbfe_aruco_set_corner_refinement(self.h, int(method)), "orbfe_aruco_set_corner_refinement")
 
+    def setGrayConversion(self, fractional_bits):
+        """cvtColor(BGR2GRAY) of CV_8UC3 frames: 14 fractional bits (OpenCV <= 3.4.1, default) or 15 (3.4.2 and later)."""
+        _check(self.L, self.L.orbfe_aruco_set_gray_conversion(self.h, int(fractional_bits)), "orbfe_aruco_set_gray_conversion")
+
+    def state(self):
+        """Params::ThresHold and Params::minSize as the last call left them, its threshold passes and working image size."""
+        t, a, r, c, m = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_float(0)
+        _check(self.L, self.L.orbfe_aruco_get_state(self.h, C.byref(t), C.byref(m), C.byref(a), C.byref(r), C.byref(c)), "orbfe_aruco_get_state")
+        return {"threshold": t.value, "min_size": m.value, "attempts": a.value, "work_shape": (r.value, c.value)}
+
     def contour(self, marker, frame=0):
         """aruco::Marker::contourPoints of output marker `marker` of the last call -> (n, 2) int32."""
         n = C.c_int32(0)
@@ -806,30 +832,34 @@ class MarkerDetector:
             image = np.asarray(image)
             if image.size == 0:
                 return np.zeros(0, MARKER_DTYPE), np.zeros(0, POSE_DTYPE)
-            assert image.dtype == np.uint8 and image.ndim == 2
-            if image.strides[1] != 1:
+            bgr = image.ndim == 3 and image.shape[2] == 3   # CV_8UC3: cvtColor(BGR2GRAY) first (markerdetector_impl.cpp:5892)
+            assert image.dtype == np.uint8 and (image.ndim == 2 or bgr)
+            if image.strides[1] != (3 if bgr else 1) or (bgr and image.strides[2] != 1):
                 image = np.ascontiguousarray(image)
-            rows, cols = image.shape
+            rows, cols = image.shape[:2]
             K4 = np.ascontiguousarray(camera_resize(K4, cam_size, (cols, rows)), np.float32)
             out = np.zeros(self.capacity, MARKER_DTYPE)
             poses = np.zeros(self.capacity, POSE_DTYPE)
             n = C.c_int32(0)
-            _check(self.L, self.L.orbfe_aruco_detect_poses(self.h, _p(image), rows, cols, image.strides[0], _p(out), _p(poses), self.capacity,
+            fn = self.L.orbfe_aruco_detect_poses_bgr if bgr else self.L.orbfe_aruco_detect_poses
+            _check(self.L, fn(self.h, _p(image), rows, cols, image.strides[0], _p(out), _p(poses), self.capacity,
                                                            C.byref(n), markerSizeMeters, _p(K4), _p(d) if d is not None and len(d) else None,
                                                            0 if d is None else len(d)), "orbfe_aruco_detect_poses")
-            self._shape = image.shape
+            self._shape = image.shape[:2]
             return out[:n.value].copy(), poses[:n.value].copy()
         image = np.asarray(image)
         if image.size == 0:
             return np.zeros(0, MARKER_DTYPE)
-        assert image.dtype == np.uint8 and image.ndim == 2
-        if image.strides[1] != 1:
+        bgr = image.ndim == 3 and image.shape[2] == 3
+        assert image.dtype == np.uint8 and (image.ndim == 2 or bgr)
+        if image.strides[1] != (3 if bgr else 1) or (bgr and image.strides[2] != 1):
             image = np.ascontiguousarray(image)
         out = np.zeros(self.capacity, MARKER_DTYPE)
         n = C.c_int32(0)
-        _check(self.L, self.L.orbfe_aruco_detect(self.h, _p(image), image.shape[0], image.shape[1], image.strides[0],
-                                                 _p(out), self.capacity, C.byref(n)), "orbfe_aruco_detect")
-        self._shape = image.shape
+        fn = self.L.orbfe_aruco_detect_bgr if bgr else self.L.orbfe_aruco_detect
+        _check(self.L, fn(self.h, _p(image), image.shape[0], image.shape[1], image.strides[0],
+                          _p(out), self.capacity, C.byref(n)), "orbfe_aruco_detect")
+        self._shape = image.shape[:2]
         return out[:n.value].copy()
 
     def detect_batch(self, images):

@@ -7,6 +7,8 @@
 // borderDistThres 0.015, error correction off.  Pose estimation (step 12) is not part of this path yet.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <limits>
 
 #include "aruco_kernels.hpp"
 #include "aruco_pose.hpp"
@@ -14,6 +16,15 @@
 #include "orbfe_tables.inc"
 
 using namespace orbfe;
+
+// What a run of the device pipeline does differently from the configuration of Frame.cc:135-137 (aruco_modes.hip)
+struct ModeRun {
+    const uint8_t* d_full = nullptr; // minSize > 0: the full-resolution frames (pyramid, warps, cornerUpsample); d_imgs is the reduction
+    size_t full_fstride = 0, full_step = 0;
+    int full_rows = 0, full_cols = 0;
+    int fixed_thr = -1;              // THRES_AUTO_FIXED: the global threshold (-1: adaptive)
+    uint32_t* d_hist = nullptr;      // THRES_AUTO_FIXED: per frame, 256 bins over the accepted candidates' patches
+};
 
 struct orbfe_aruco {
     int device = 0;
@@ -73,6 +84,20 @@ struct orbfe_aruco {
     int max_corr = 0, tau = 0, nsorted = 0; // int(tau * error_rate); the dictionary's code map in std::map order
     int corner_method = 1;                  // aruco::CornerRefinementMethod: 0 CORNER_SUBPIX, 1 CORNER_LINES, 2 CORNER_NONE
     DevBuf d_scodes, d_sids, d_msrc;        // d_msrc: rectangle (= contour) of every output marker of the last batch
+    // MarkerDetector::Params outside the configuration of Frame.cc:135-137 (markerdetector.h:158-196; kernels in aruco_modes.hip)
+    int detect_mode = 0;         // DM_NORMAL 0, DM_FAST 1, DM_VIDEO_FAST 2
+    int thres_method = 0;        // THRES_ADAPTIVE 0, THRES_AUTO_FIXED 1
+    int thres_value = 7;         // Params::ThresHold: the adaptive constant C, or the global threshold carried from frame to frame
+    int n_attempts_auto_fix = 3; // Params::NAttemptsAutoThresFix
+    float min_size = 0.f;        // Params::minSize as setDetectionMode / the automatic size estimation leave it
+    bool auto_size = false;      // Params::autoSize (DM_VIDEO_FAST)
+    float ts = 0.25f;
+    int gray_bits15 = 0;         // BGR2GRAY with 15 fractional bits (OpenCV 3.4.2+) instead of 14
+    int pyr_rows = 0, pyr_cols = 0;   // the frame the /2 pyramid starts from (the working image is smaller when minSize > 0)
+    int last_attempts = 0, last_work_rows = 0, last_work_cols = 0;
+    size_t rl_static = 0;
+    DevBuf d_red, d_mhist, d_masks, d_bgr;
+    bool stateful() const { return thres_method == 1 || auto_size; } // a frame's result depends on the frames before it
     KernelTimer timer;
     int last_nframes = 0;
 
@@ -80,7 +105,7 @@ struct orbfe_aruco {
     {
         for (DevBuf* b : {&d_codes, &d_levels, &d_tabs, &d_bits, &d_pyr, &d_candq, &d_pool, &d_kept, &d_rects,
                           &d_counts, &d_candidx, &d_ncand, &d_result, &d_gpad, &d_in, &d_out, &d_nout, &d_segs, &d_tailkeys, &d_tailoff, &d_small, &d_hint, &d_rstate, &d_lut, &d_twork, &d_trect, &d_tctr, &d_dwork, &d_dctr, &d_ditems, &d_dhist, &d_dpatch, &d_vis, &d_poses, &d_scodes, &d_sids,
-                          &d_msrc})
+                          &d_msrc, &d_red, &d_mhist, &d_masks, &d_bgr})
             b->release();
         if (own_stream) (void)hipStreamDestroy(own_stream);
         if (aux_stream) (void)hipStreamDestroy(aux_stream);
@@ -126,9 +151,10 @@ struct orbfe_aruco {
         return fail(ORBFE_ERR_DICT, "unknown dictionary '%s'", name);
     }
 
-    int build_geometry(int rows_, int cols_)
+    // rows_ x cols_: the image that is thresholded and traced; prows x pcols: the frame the /2 pyramid is built from
+    int build_geometry(int rows_, int cols_, int prows, int pcols)
     {
-        if (rows_ == rows && cols_ == cols && !levels.empty()) return ORBFE_OK;
+        if (rows_ == rows && cols_ == cols && prows == pyr_rows && pcols == pyr_cols && !levels.empty()) return ORBFE_OK;
         if (cols_ > 8000 || rows_ > 8000) return fail(ORBFE_ERR_INVALID, "image larger than 8000 px");
         int w = std::max(3, int(15 * float(cols_) / 1920.)); // :3765-3809
         if (w % 2 == 0) w++;
@@ -152,12 +178,12 @@ struct orbfe_aruco {
         lvl_exact.clear();
         std::vector<int> tabs;
         tab_off.clear();
-        int lw = cols_, lh = rows_;
+        int lw = pcols, lh = prows;
         size_t off = 0;
         levels.push_back(ArLevel{lw, lh, 0, 0});
         lvl_exact.push_back(1);
         tab_off.resize(4, 0);
-        int n = 1, tw = cols_;
+        int n = 1, tw = pcols;
         while (tw > 2 * S) { tw /= 2; n++; }
         for (int p = 1; p < n; p++) {
             const int sw = lw, sh = lh;
@@ -215,8 +241,7 @@ struct orbfe_aruco {
         relay_tbits = 0;
         // static LDS of the relay kernels (step table, counters), asked from the runtime: a constant here once fell behind the kernels
         // and frames whose tables only just fitted (1582 x 619: 156,976 B dynamic) failed at launch
-        size_t rl_static = 0;
-        {
+        if (!rl_static) {
             const void* fns[4] = {reinterpret_cast<const void*>(k_contours_relay), reinterpret_cast<const void*>(k_contours_relay8),
                                   reinterpret_cast<const void*>(k_contours_relay8g), reinterpret_cast<const void*>(k_contours_relay_wide)};
             for (const void* fn : fns) {
@@ -239,6 +264,7 @@ struct orbfe_aruco {
         relay_kcap = RL_KCAP;
         if (relay_global) { relay_tbits = 13; relay_kshift = 5; relay_kcap = AR_MAX_KEPT_BIG; }
         rows = rows_; cols = cols_;
+        pyr_rows = prows; pyr_cols = pcols;
         batch_cap = 0;
         if (tabs.empty()) tabs.push_back(0);
         int rc;
@@ -294,14 +320,41 @@ struct orbfe_aruco {
         return ORBFE_OK;
     }
 
+    // window tables of cv::cornerSubPix for half sizes 1 .. 8: exp(-y^2) exp(-x^2) in float, by the host's expf like the reference
+    int ensure_subpix_masks()
+    {
+        if (d_masks.p) return ORBFE_OK;
+        std::vector<float> m((size_t)8 * 17 * 17, 0.f);
+        for (int w = 1; w <= 8; w++) {
+            const int ww = 2 * w + 1;
+            float* mk = m.data() + (size_t)(w - 1) * 17 * 17;
+            for (int i = 0; i < ww; i++) {
+                const float y = (float)(i - w) / w;
+                const float vy = std::exp(-y * y);
+                for (int j = 0; j < ww; j++) {
+                    const float x = (float)(j - w) / w;
+                    mk[i * ww + j] = (float)(vy * std::exp(-x * x));
+                }
+            }
+        }
+        int rc = d_masks.ensure(m.size() * 4);
+        if (rc) return rc;
+        ORBFE_HIP(hipMemcpy(d_masks.p, m.data(), m.size() * 4, hipMemcpyHostToDevice));
+        return ORBFE_OK;
+    }
+
     int run_device(const uint8_t* d_imgs, int B, size_t frame_stride, int rows_, int cols_, size_t step,
-                   orbfe_marker* d_out_m, int capacity, int32_t* d_n, hipStream_t s)
+                   orbfe_marker* d_out_m, int capacity, int32_t* d_n, hipStream_t s, const ModeRun* mr = nullptr)
     {
         int rc;
-        if ((rc = build_geometry(rows_, cols_))) return rc;
+        const bool reduced = mr && mr->d_full;
+        if ((rc = build_geometry(rows_, cols_, reduced ? mr->full_rows : rows_, reduced ? mr->full_cols : cols_))) return rc;
         if ((rc = ensure_workspace(B))) return rc;
+        if ((reduced || corner_method == 0) && (rc = ensure_subpix_masks())) return rc;
         last_nframes = B;
-        ImgView src0{d_imgs, nullptr, frame_stride, (int)step};
+        const ImgView srcW{d_imgs, nullptr, frame_stride, (int)step}; // what is thresholded and traced
+        // the frame the pyramid starts from and the patches are warped from (level 0)
+        const ImgView src0 = reduced ? ImgView{mr->d_full, nullptr, mr->full_fstride, (int)mr->full_step} : srcW;
         ImgView pyr{d_pyr.as<uint8_t>(), d_pyr.as<uint8_t>(), pyr_fbytes, 0};
         timer.begin();
         timer.mark(s, "start");
@@ -334,12 +387,14 @@ struct orbfe_aruco {
             const int ntx = (cols + 63) / 64, ntl = ntx * ((rows + 63) / 64);
             const dim3 tg1(xcd_grid(ntl * B));
             uint32_t* bp = d_bits.as<uint32_t>();
-            if (th_magic && win == 5) hipLaunchKernelGGL(k_adaptive_threshold_t<5>, tg1, dim3(256), 0, s, src0, cols, rows, 7, th_magic, bp, bits_fu32, wpr, ntx, ntl, ntl * B);
-            else if (th_magic && win == 7) hipLaunchKernelGGL(k_adaptive_threshold_t<7>, tg1, dim3(256), 0, s, src0, cols, rows, 7, th_magic, bp, bits_fu32, wpr, ntx, ntl, ntl * B);
-            else if (th_magic && win == 11) hipLaunchKernelGGL(k_adaptive_threshold_t<11>, tg1, dim3(256), 0, s, src0, cols, rows, 7, th_magic, bp, bits_fu32, wpr, ntx, ntl, ntl * B);
-            else if (th_magic && win == 15) hipLaunchKernelGGL(k_adaptive_threshold_t<15>, tg1, dim3(256), 0, s, src0, cols, rows, 7, th_magic, bp, bits_fu32, wpr, ntx, ntl, ntl * B);
-            else if (win <= 15) hipLaunchKernelGGL(k_adaptive_threshold<7>, tg, dim3(256), 0, s, src0, cols, rows, win, 7, 1.0 / (win * win), bp, bits_fu32, wpr);
-            else hipLaunchKernelGGL(k_adaptive_threshold<15>, tg, dim3(256), 0, s, src0, cols, rows, win, 7, 1.0 / (win * win), bp, bits_fu32, wpr);
+            if (mr && mr->fixed_thr >= 0)   // THRES_AUTO_FIXED: cv::threshold(THRESH_BINARY_INV) at the carried-over threshold
+                hipLaunchKernelGGL(k_fixed_threshold, dim3((wpr * rows + 255) / 256, B), dim3(256), 0, s, srcW, cols, rows, mr->fixed_thr, bp, bits_fu32, wpr);
+            else if (th_magic && win == 5) hipLaunchKernelGGL(k_adaptive_threshold_t<5>, tg1, dim3(256), 0, s, srcW, cols, rows, thres_value, th_magic, bp, bits_fu32, wpr, ntx, ntl, ntl * B);
+            else if (th_magic && win == 7) hipLaunchKernelGGL(k_adaptive_threshold_t<7>, tg1, dim3(256), 0, s, srcW, cols, rows, thres_value, th_magic, bp, bits_fu32, wpr, ntx, ntl, ntl * B);
+            else if (th_magic && win == 11) hipLaunchKernelGGL(k_adaptive_threshold_t<11>, tg1, dim3(256), 0, s, srcW, cols, rows, thres_value, th_magic, bp, bits_fu32, wpr, ntx, ntl, ntl * B);
+            else if (th_magic && win == 15) hipLaunchKernelGGL(k_adaptive_threshold_t<15>, tg1, dim3(256), 0, s, srcW, cols, rows, thres_value, th_magic, bp, bits_fu32, wpr, ntx, ntl, ntl * B);
+            else if (win <= 15) hipLaunchKernelGGL(k_adaptive_threshold<7>, tg, dim3(256), 0, s, srcW, cols, rows, win, thres_value, 1.0 / (win * win), bp, bits_fu32, wpr);
+            else hipLaunchKernelGGL(k_adaptive_threshold<15>, tg, dim3(256), 0, s, srcW, cols, rows, win, thres_value, 1.0 / (win * win), bp, bits_fu32, wpr);
         }
         timer.mark(s, "threshold");
         const bool big = big_mode || !lds_bits_words;
@@ -438,10 +493,28 @@ struct orbfe_aruco {
             }
         }
         timer.mark(s, "decode");
+        if (mr && mr->d_hist)   // the pixels of the accepted candidates: the next frame's threshold is Otsu over them
+            hipLaunchKernelGGL(k_marker_hist, dim3(B), dim3(256), 0, s, d_dwork.as<uint32_t>(), d_dctr.as<int32_t>(), d_result.as<int32_t>(),
+                               AR_MAX_RECTS, d_dhist.as<uint16_t>(), mr->d_hist);
+        if (reduced) {   // cornerUpsample: before sort / dedupe, whose perimeters are those of the upsampled corners
+            int start = 0;
+            for (int i = 0; i < npyr; i++) {
+                if (cols < levels[i].w) start = i;
+                else break;
+            }
+            const int wgs = std::max(1, std::min((B * 32 * 4 + 3) / 4, 2048));
+            hipLaunchKernelGGL(k_upsample_corners, dim3(wgs), dim3(256), 0, s, src0, pyr, d_levels.as<ArLevel>(), start, cols,
+                               d_rects.as<ArRect>(), AR_MAX_RECTS, d_candidx.as<int32_t>(), d_dwork.as<uint32_t>(), d_dctr.as<int32_t>(),
+                               d_result.as<int32_t>(), d_masks.as<float>());
+        }
+        // corner refinement applies only when the input was not reduced (:8420): CORNER_LINES inside k_finalize, CORNER_SUBPIX after it
         for (int r_ = 0; r_ < ORBFE_REPS_ARUCO(4); r_++) hipLaunchKernelGGL(k_finalize, dim3(B), dim3(256), 0, s, d_rects.as<ArRect>(), AR_MAX_RECTS,
                            d_candidx.as<int32_t>(), d_ncand.as<int32_t>(), d_result.as<int32_t>(),
-                           d_pool.as<uint32_t>(), pool_fu32, d_out_m, capacity, d_n, corner_method == 1 ? 1 : 0, d_msrc.as<int32_t>(),
+                           d_pool.as<uint32_t>(), pool_fu32, d_out_m, capacity, d_n, (corner_method == 1 && !reduced) ? 1 : 0, d_msrc.as<int32_t>(),
                            d_dctr.as<int32_t>());
+        if (corner_method == 0 && !reduced)   // cornerSubPix(grey, Size(4, 4), TermCriteria(MAX_ITER | EPS, 12, 0.005)) (:8511)
+            hipLaunchKernelGGL(k_corner_subpix_markers, dim3(16, B), dim3(256), 0, s, src0, cols, rows, d_out_m, d_n, capacity, 4, 12,
+                               0.005 * 0.005, d_masks.as<float>() + (size_t)3 * 17 * 17);
         timer.mark(s, "finalize");
         ORBFE_HIP(hipGetLastError());
         decode_dirty = false;   // k_finalize leaves the work-list length at zero
@@ -482,6 +555,70 @@ struct PoseWorkspace {
     DevBuf markers, poses;
 };
 static thread_local ThreadWorkspaces<PoseWorkspace> tl_pose_ws; // per (thread, device)
+
+// The image detect() works on (markerdetector_impl.cpp:5990-6090): with Params::minSize > 0 markers smaller than minSize * max(cols,
+// rows) need not be found, so the frame is reduced until such a marker would be lowResMarkerSize = 20 pixels.
+static int work_size(const orbfe_aruco* h, int rows, int cols, int* wr, int* wc)
+{
+    *wr = rows; *wc = cols;
+    const int maxdim = std::max(cols, rows);
+    const int minpix = (int)(static_cast<float>(h->min_size) * static_cast<float>(maxdim)); // getMinMarkerSizePix, minSize_pix = -1
+    if (20 < minpix) {
+        const float scale = float(20) / float(minpix);
+        if (scale < 0.9) {
+            int w = float(cols) * scale + 0.5, hh = float(rows) * scale + 0.5;
+            if (w % 2 != 0) w++;
+            if (hh % 2 != 0) hh++;
+            // cornerUpsample's cornerSubPix window is int(0.5 + 2.5 * width ratio to the pyramid level above): tables up to 8
+            if (w < 64 || hh < 48)
+                return fail(ORBFE_ERR_INVALID, "minMarkerSize %g reduces a %d x %d frame to %d x %d: working images below 64 x 48 are not supported",
+                            (double)h->min_size, cols, rows, w, hh);
+            *wr = hh; *wc = w;
+        }
+    }
+    return ORBFE_OK;
+}
+
+// a batch on a reduced working image: INTER_NEAREST into the handle's buffer, then the pipeline with the full frames for the
+// pyramid, the warps and cornerUpsample
+static int reduced_batch(orbfe_aruco* h, const uint8_t* d_imgs, int B, size_t frame_stride, int rows, int cols, size_t step, int wr, int wc,
+                         orbfe_marker* d_out, int capacity, int32_t* d_n, hipStream_t s, int fixed_thr, uint32_t* d_hist)
+{
+    const size_t rpitch = (size_t)(wc + 63) / 64 * 64, rframe = rpitch * wr;
+    int rc = h->d_red.ensure(rframe * B + 64);
+    if (rc) return rc;
+    const double ifx = 1. / ((double)wc / cols), ify = 1. / ((double)wr / rows);
+    hipLaunchKernelGGL(k_resize_nearest, dim3((wc + 63) / 64, (wr + 3) / 4, B), dim3(256), 0, s, ImgView{d_imgs, nullptr, frame_stride, (int)step},
+                       ImgView{h->d_red.as<uint8_t>(), h->d_red.as<uint8_t>(), rframe, (int)rpitch}, cols, rows, wc, wr, ifx, ify);
+    ModeRun mr;
+    mr.d_full = d_imgs; mr.full_fstride = frame_stride; mr.full_step = step; mr.full_rows = rows; mr.full_cols = cols;
+    mr.fixed_thr = fixed_thr; mr.d_hist = d_hist;
+    return h->run_device(h->d_red.as<uint8_t>(), B, rframe, wr, wc, rpitch, d_out, capacity, d_n, s, &mr);
+}
+
+// The threshold of the next frame: Otsu's criterion over the normalised float histogram of the detected markers' pixels, every
+// split evaluated from scratch in single precision as markerdetector_impl.cpp:6121-6380 does (host logic there as here: 2 x 256 x 255
+// additions).  -1: no split has both classes above 1e-4 (an empty histogram turns into NaNs and ends here too).
+static int otsu_of_marker_histogram(const uint32_t* counts)
+{
+    float hist[256], total = 0;
+    for (int v = 0; v < 256; v++) { hist[v] = (float)counts[v]; total += hist[v]; } // counts < 2^24: exact, like the reference's ++
+    const float inv = 1. / total;
+    for (int v = 0; v < 256; v++) hist[v] *= inv;
+    float best = 0;
+    int best_t = -1;
+    for (int t = 1; t < 256; t++) {
+        float wlo = 0, whi = 0, mlo = 0, mhi = 0;
+        for (int v = 0; v < t; v++) { wlo += hist[v]; mlo += float(v) * hist[v]; }
+        for (int v = t; v < 256; v++) { whi += hist[v]; mhi += hist[v] * float(v); }
+        if (!(wlo > 1e-4 && whi > 1e-4)) continue;
+        mlo /= wlo;
+        mhi /= whi;
+        const float between = wlo * whi * (mlo - mhi) * (mlo - mhi);
+        if (between > best) { best = between; best_t = t; }
+    }
+    return best_t;
+}
 
 extern "C" {
 
@@ -532,24 +669,47 @@ int orbfe_aruco_set_error_correction_rate(orbfe_aruco* h, float rate)
 int orbfe_aruco_set_detection_mode(orbfe_aruco* h, int mode, float min_marker_size)
 {
     if (!h) return fail(ORBFE_ERR_INVALID, "null handle");
-    // DM_NORMAL = 0 (markerdetector.h:60): full-resolution image + adaptive threshold, the mode of Frame.cc:136.  DM_FAST (1) and
-    // DM_VIDEO_FAST (2) switch to THRES_AUTO_FIXED (markerdetector.cpp:380-397): a global threshold retried with rand() and
-    // carried from frame to frame -- not built; refusing loudly beats detecting with another mode silently.
-    if (mode != 0) return fail(ORBFE_ERR_INVALID, "detection mode %d (DM_FAST / DM_VIDEO_FAST: THRES_AUTO_FIXED) is not implemented", mode);
-    // Params::minSize (markerdetector.cpp:376) makes the reference detect on a reduced image and drop short contours: not built, and
-    // a size that would be ignored silently is refused.  (The reference's setCornerRefinementMethod(!= CORNER_SUBPIX) resets minSize to
-    // 0, markerdetector.cpp:390-393: the shim keeps that bookkeeping and only ever passes the value in force at detect time.)
-    if (min_marker_size != 0.0f)
-        return fail(ORBFE_ERR_INVALID, "minMarkerSize %g: only 0 is implemented", (double)min_marker_size);
+    // Params::setDetectionMode (markerdetector.cpp:374-391).  DM_NORMAL = 0: adaptive threshold, C = 7 (Frame.cc:136); DM_FAST = 1:
+    // THRES_AUTO_FIXED, the global threshold starts at 100; DM_VIDEO_FAST = 2: the same plus the automatic size estimation with
+    // ts = 0.3.  minMarkerSize (Params::minSize, a fraction of the larger image side) > 0 makes detect() work on a reduced frame.
+    if (mode < 0 || mode > 2) return fail(ORBFE_ERR_INVALID, "detection mode %d: DM_NORMAL 0, DM_FAST 1, DM_VIDEO_FAST 2", mode);
+    if (!(min_marker_size >= 0.0f && min_marker_size <= 1.0f))
+        return fail(ORBFE_ERR_INVALID, "minMarkerSize %g: a fraction of the image size in [0, 1]", (double)min_marker_size);
+    h->detect_mode = mode;
+    h->min_size = min_marker_size;
+    if (mode == 0) { h->auto_size = false; h->ts = 0.25f; h->thres_method = 0; h->thres_value = 7; }
+    else if (mode == 1) { h->auto_size = false; h->ts = 0.25f; h->thres_method = 1; h->thres_value = 100; }
+    else { h->thres_method = 1; h->thres_value = 100; h->auto_size = true; h->ts = 0.3f; }
     return ORBFE_OK;
 }
 
 int orbfe_aruco_set_corner_refinement(orbfe_aruco* h, int method)
 {
     if (!h) return fail(ORBFE_ERR_INVALID, "null handle");
-    // aruco::CornerRefinementMethod (markerdetector.h:62): CORNER_SUBPIX = 0 (cv::cornerSubPix, not built), CORNER_LINES = 1, CORNER_NONE = 2
-    if (method != 1 && method != 2) return fail(ORBFE_ERR_INVALID, "corner refinement method %d (CORNER_SUBPIX) is not implemented", method);
+    // aruco::CornerRefinementMethod (markerdetector.h:62): CORNER_SUBPIX = 0 (cv::cornerSubPix), CORNER_LINES = 1, CORNER_NONE = 2.
+    // Params::setCornerRefinementMethod (markerdetector.cpp:392-395): anything but CORNER_SUBPIX resets minSize to 0.
+    if (method < 0 || method > 2) return fail(ORBFE_ERR_INVALID, "corner refinement method %d: CORNER_SUBPIX 0, CORNER_LINES 1, CORNER_NONE 2", method);
     h->corner_method = method;
+    if (method != 0) h->min_size = 0.f;
+    return ORBFE_OK;
+}
+
+int orbfe_aruco_set_gray_conversion(orbfe_aruco* h, int fractional_bits)
+{
+    if (!h || (fractional_bits != 14 && fractional_bits != 15))
+        return fail(ORBFE_ERR_INVALID, "orbfe_aruco_set_gray_conversion: 14 (OpenCV <= 3.4.1) or 15 (3.4.2 and later) fractional bits");
+    h->gray_bits15 = fractional_bits == 15;
+    return ORBFE_OK;
+}
+
+int orbfe_aruco_get_state(const orbfe_aruco* h, int32_t* threshold, float* min_size, int32_t* attempts, int32_t* work_rows, int32_t* work_cols)
+{
+    if (!h) return fail(ORBFE_ERR_INVALID, "null handle");
+    if (threshold) *threshold = h->thres_value;
+    if (min_size) *min_size = h->min_size;
+    if (attempts) *attempts = h->last_attempts;
+    if (work_rows) *work_rows = h->last_work_rows;
+    if (work_cols) *work_cols = h->last_work_cols;
     return ORBFE_OK;
 }
 
@@ -617,6 +777,13 @@ int orbfe_aruco_detect_batch_device(orbfe_aruco* h, const uint8_t* d_imgs, int n
     int rc = use_device(h->device);
     if (rc) return rc;
     if (h->spec.pending) { ORBFE_HIP(hipStreamSynchronize(h->own_stream)); h->spec.pending = false; } // the handle's buffers are in use
+    // THRES_AUTO_FIXED and the automatic size estimation carry state from one frame to the next and decide on the host (retry with
+    // a random threshold): frames must go one at a time through the host-pointer entry points
+    if (h->stateful())
+        return fail(ORBFE_ERR_INVALID, "orbfe_aruco_detect_batch_device: DM_FAST / DM_VIDEO_FAST are frame-sequential (use orbfe_aruco_detect)");
+    int wr, wc;
+    if ((rc = work_size(h, rows, cols, &wr, &wc))) return rc;
+    if (wc != cols) return reduced_batch(h, d_imgs, nframes, frame_stride, rows, cols, step, wr, wc, d_out, capacity, d_n_out, (hipStream_t)stream, -1, nullptr);
     return h->run_device(d_imgs, nframes, frame_stride, rows, cols, step, d_out, capacity, d_n_out, (hipStream_t)stream);
 }
 
@@ -665,6 +832,7 @@ int aruco_speculate(orbfe_aruco* h, const uint8_t* d_img, size_t dframe, int row
 {
     h->spec.pending = false;
     if (h->big_mode) return ORBFE_OK; // the rare big-frame mode is left to the detector's own call
+    if (h->stateful() || h->min_size > 0.f) return ORBFE_OK; // frame-sequential modes (aruco_modes.hip): the detector's own call too
     int rc;
     if ((rc = h->d_out.ensure((size_t)AR_MAX_RECTS * sizeof(orbfe_marker))) || (rc = h->d_nout.ensure(4))) return rc;
     const bool pose = h->last_cam_valid;
@@ -699,19 +867,128 @@ void aruco_unpair_notice(orbfe_aruco* h)
 
 } // namespace orbfe
 
+// The modes whose frames go one at a time (THRES_AUTO_FIXED and the automatic size estimation carry state from frame to frame and
+// decide on the host; a reduced working image or a BGR frame just take this path too): upload, BGR -> grey, the pipeline -- again
+// with a random threshold when nothing was found (markerdetector_impl.cpp:6903-6990; rand() is the process's own sequence, as in
+// the reference) --, the next frame's threshold and minimum size (:7003-7040, :8790-8880), the poses.
+static int detect_frames_modes(orbfe_aruco* h, const uint8_t* imgs, int nframes, size_t frame_stride, int rows, int cols, size_t step,
+                               int channels, orbfe_marker* out, int capacity, int32_t* n_out, const PoseCamera* cam, float marker_size,
+                               orbfe_marker_pose* poses_out)
+{
+    int rc;
+    if (h->spec.pending) { ORBFE_HIP(hipStreamSynchronize(h->own_stream)); h->spec.pending = false; }
+    const size_t dpitch = (size_t)(cols + 63) / 64 * 64, dframe = dpitch * rows;
+    const size_t in_bytes = channels == 3 ? (size_t)cols * 3 * rows : dframe;
+    // page-locked: [frame in] [n | counts | histogram | markers | poses] out
+    const size_t o_n = (in_bytes + 255) / 256 * 256, o_cnt = o_n + 64, o_h = o_cnt + 64, o_mk = o_h + 1024,
+                 o_ps = o_mk + (size_t)AR_MAX_RECTS * sizeof(orbfe_marker), o_end = o_ps + (size_t)AR_MAX_RECTS * sizeof(orbfe_marker_pose);
+    if ((rc = h->pinned.ensure(o_end)) || (rc = h->d_in.ensure(dframe + 64)) || (rc = h->d_out.ensure((size_t)AR_MAX_RECTS * sizeof(orbfe_marker))) ||
+        (rc = h->d_nout.ensure(4)) || (rc = h->d_mhist.ensure(1024)) || (cam && (rc = h->d_poses.ensure((size_t)AR_MAX_RECTS * sizeof(orbfe_marker_pose)))) ||
+        (channels == 3 && (rc = h->d_bgr.ensure(in_bytes + 64))))
+        return rc;
+    uint8_t* hp = h->pinned.as<uint8_t>();
+    hipStream_t s = h->own_stream;
+    const int32_t* counts = reinterpret_cast<const int32_t*>(hp + o_cnt);
+    const int32_t* np = reinterpret_cast<const int32_t*>(hp + o_n);
+    const orbfe_marker* mk = reinterpret_cast<const orbfe_marker*>(hp + o_mk);
+    const bool user_big_mode = h->big_mode;
+    for (int f = 0; f < nframes; f++) {
+        const uint8_t* img = imgs + (size_t)f * frame_stride;
+        if (channels == 3) {
+            for (int y = 0; y < rows; y++) memcpy(hp + (size_t)y * cols * 3, img + (size_t)y * step, (size_t)cols * 3);
+            ORBFE_HIP(hipMemcpyAsync(h->d_bgr.p, hp, in_bytes, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_bgr_to_gray, dim3((cols + 63) / 64, (rows + 3) / 4, 1), dim3(256), 0, s, h->d_bgr.as<uint8_t>(), (size_t)0, (size_t)cols * 3,
+                               ImgView{h->d_in.as<uint8_t>(), h->d_in.as<uint8_t>(), dframe, (int)dpitch}, cols, rows, h->gray_bits15);
+        } else {
+            for (int y = 0; y < rows; y++) memcpy(hp + (size_t)y * dpitch, img + (size_t)y * step, (size_t)cols);
+            ORBFE_HIP(hipMemcpyAsync(h->d_in.p, hp, dframe, hipMemcpyHostToDevice, s));
+        }
+        int wr, wc;
+        if ((rc = work_size(h, rows, cols, &wr, &wc))) return rc;
+        h->last_work_rows = wr; h->last_work_cols = wc;
+        int attempts = 0;
+        h->last_attempts = 0;
+        for (;;) {
+            h->last_attempts++;
+            const int thr = h->thres_method == 1 ? h->thres_value : -1;
+            uint32_t* d_hist = h->thres_method == 1 ? h->d_mhist.as<uint32_t>() : nullptr;
+            for (int pass = 0; pass < 2; pass++) { // a frame that exceeds the LDS-resident kernels' capacities is done again in big-frame mode
+                if (wc != cols) rc = reduced_batch(h, h->d_in.as<uint8_t>(), 1, dframe, rows, cols, dpitch, wr, wc, h->d_out.as<orbfe_marker>(), AR_MAX_RECTS,
+                                                   h->d_nout.as<int32_t>(), s, thr, d_hist);
+                else {
+                    ModeRun mr;
+                    mr.fixed_thr = thr; mr.d_hist = d_hist;
+                    rc = h->run_device(h->d_in.as<uint8_t>(), 1, dframe, rows, cols, dpitch, h->d_out.as<orbfe_marker>(), AR_MAX_RECTS,
+                                       h->d_nout.as<int32_t>(), s, &mr);
+                }
+                if (rc) { h->big_mode = user_big_mode; return rc; }
+                ORBFE_HIP(hipMemcpyAsync(hp + o_n, h->d_nout.p, 4, hipMemcpyDeviceToHost, s));
+                ORBFE_HIP(hipMemcpyAsync(hp + o_cnt, h->d_counts.p, 16, hipMemcpyDeviceToHost, s));
+                if (d_hist) ORBFE_HIP(hipMemcpyAsync(hp + o_h, d_hist, 1024, hipMemcpyDeviceToHost, s));
+                ORBFE_HIP(hipMemcpyAsync(hp + o_mk, h->d_out.p, (size_t)AR_MAX_RECTS * sizeof(orbfe_marker), hipMemcpyDeviceToHost, s));
+                ORBFE_HIP(hipStreamSynchronize(s));
+                if (!(counts[2] & (2 | 4)) || h->big_mode) break;
+                h->big_mode = true;
+            }
+            h->big_mode = user_big_mode;
+            if (counts[2]) return fail(ORBFE_ERR_CAPACITY, "frame %d: internal detector capacity exceeded (flags 0x%x)", f, counts[2]);
+            if (np[0] == 0 && h->thres_method == 1 && ++attempts < h->n_attempts_auto_fix) {
+                h->thres_value = 10 + rand() % 230;
+                continue;
+            }
+            break;
+        }
+        const int n = np[0];
+        if (h->thres_method == 1) {
+            const int t = otsu_of_marker_histogram(reinterpret_cast<const uint32_t*>(hp + o_h));
+            if (t > 0) h->thres_value = t;
+        }
+        // the smallest marker of this frame sets the minimum size the next frame looks for (:8790-8880)
+        float shortest = std::numeric_limits<float>::max();
+        for (int i = 0; i < n && i < AR_MAX_RECTS; i++) {
+            float per = 0;
+            for (int c = 0; c < 4; c++) {
+                const float dx = mk[i].corners[c][0] - mk[i].corners[(c + 1) % 4][0], dy = mk[i].corners[c][1] - mk[i].corners[(c + 1) % 4][1];
+                per += std::sqrt((double)dx * dx + (double)dy * dy);
+            }
+            if (shortest > per) shortest = per;
+        }
+        const float marker_min = shortest != std::numeric_limits<float>::max() ? shortest / (4 * std::max(cols, rows)) : 0.f;
+        if (h->auto_size) h->min_size = marker_min * (1 - h->ts);
+        n_out[f] = n;
+        if (n > capacity) return fail(ORBFE_ERR_CAPACITY, "frame %d has %d markers, capacity is %d", f, n, capacity);
+        if (n) memcpy(out + (size_t)f * capacity, mk, (size_t)n * sizeof(orbfe_marker));
+        if (n && cam) {
+            hipLaunchKernelGGL(k_marker_poses, dim3((AR_MAX_RECTS + 63) / 64, 1), dim3(64), 0, s, h->d_out.as<orbfe_marker>(), h->d_nout.as<int32_t>(),
+                               AR_MAX_RECTS, marker_size, *cam, h->d_poses.as<orbfe_marker_pose>());
+            ORBFE_HIP(hipMemcpyAsync(hp + o_ps, h->d_poses.p, (size_t)n * sizeof(orbfe_marker_pose), hipMemcpyDeviceToHost, s));
+            ORBFE_HIP(hipStreamSynchronize(s));
+            memcpy(poses_out + (size_t)f * capacity, hp + o_ps, (size_t)n * sizeof(orbfe_marker_pose));
+        }
+    }
+    return ORBFE_OK;
+}
+
 // detect (+ the IPPE pose of every marker when a camera is given: one call, one wait, instead of a detect call and a pose call)
 static int detect_batch_impl(orbfe_aruco* h, const uint8_t* imgs, int nframes, size_t frame_stride, int rows, int cols,
                              size_t step, orbfe_marker* out, int capacity, int32_t* n_out, const PoseCamera* cam, float marker_size,
-                             orbfe_marker_pose* poses_out)
+                             orbfe_marker_pose* poses_out, int channels = 1)
 {
     if (!h || !n_out) return fail(ORBFE_ERR_INVALID, "orbfe_aruco_detect_batch: null argument");
     if (!imgs || rows <= 0 || cols <= 0 || nframes <= 0) {
         for (int f = 0; f < nframes; f++) n_out[f] = 0;
         return ORBFE_OK;
     }
-    if (!out || step < (size_t)cols || capacity <= 0) return fail(ORBFE_ERR_INVALID, "orbfe_aruco_detect_batch: invalid argument");
+    if (!out || step < (size_t)cols * channels || capacity <= 0) return fail(ORBFE_ERR_INVALID, "orbfe_aruco_detect_batch: invalid argument");
     int rc = use_device(h->device);
     if (rc) return rc;
+    {
+        int wr, wc;
+        if ((rc = work_size(h, rows, cols, &wr, &wc))) return rc;
+        if (h->stateful() || wc != cols || channels == 3)
+            return detect_frames_modes(h, imgs, nframes, frame_stride, rows, cols, step, channels, out, capacity, n_out, cam, marker_size, poses_out);
+        h->last_attempts = 1; h->last_work_rows = rows; h->last_work_cols = cols;
+    }
     const size_t dpitch = (size_t)(cols + 63) / 64 * 64, dframe = dpitch * rows;
     if (cam) { h->last_cam = *cam; h->last_size = marker_size; h->last_cam_valid = true; } // what a paired extractor's speculation assumes
     // A paired extractor has started this detector on the image it was given (aruco_speculate): if this call is handed the same
@@ -817,6 +1094,62 @@ int orbfe_aruco_detect(orbfe_aruco* h, const uint8_t* img, int rows, int cols, s
                        int capacity, int32_t* n_out)
 {
     return orbfe_aruco_detect_batch(h, img, 1, 0, rows, cols, step, out, capacity, n_out);
+}
+
+int orbfe_aruco_detect_bgr(orbfe_aruco* h, const uint8_t* bgr, int rows, int cols, size_t step, orbfe_marker* out, int capacity, int32_t* n_out)
+{
+    return detect_batch_impl(h, bgr, 1, 0, rows, cols, step, out, capacity, n_out, nullptr, 0.f, nullptr, 3);
+}
+
+int orbfe_aruco_detect_poses_bgr(orbfe_aruco* h, const uint8_t* bgr, int rows, int cols, size_t step, orbfe_marker* out,
+                                 orbfe_marker_pose* poses, int capacity, int32_t* n_out, float marker_size, const float* K4,
+                                 const float* dist, int ndist)
+{
+    if (!poses) return fail(ORBFE_ERR_INVALID, "orbfe_aruco_detect_poses_bgr: null argument");
+    PoseCamera c;
+    int rc = pose_camera(K4, dist, ndist, marker_size, c, "orbfe_aruco_detect_poses_bgr");
+    if (rc) return rc;
+    return detect_batch_impl(h, bgr, 1, 0, rows, cols, step, out, capacity, n_out, &c, marker_size, poses, 3);
+}
+
+int orbfe_corner_subpix(const uint8_t* img, int rows, int cols, size_t step, float* pts, int n, int win, int max_iters, double eps, int device)
+{
+    if (!img || rows <= 0 || cols <= 0 || step < (size_t)cols || n < 0 || (n && !pts) || win < 1 || win > 8 || max_iters < 1 || !(eps >= 0.0))
+        return fail(ORBFE_ERR_INVALID, "orbfe_corner_subpix: invalid argument (window half size 1 .. 8, max_iters >= 1, eps >= 0)");
+    if (n == 0) return ORBFE_OK;
+    int rc = use_device(device);
+    if (rc) return rc;
+    // the markers kernel on a scratch detector-free path: corners as n / 4 "markers" (padded), one frame
+    const int nm = (n + 3) / 4;
+    DevBuf d_img, d_mk, d_n, d_mask;
+    const size_t pitch = (size_t)(cols + 63) / 64 * 64;
+    if ((rc = d_img.ensure(pitch * rows + 64)) || (rc = d_mk.ensure((size_t)nm * sizeof(orbfe_marker))) || (rc = d_n.ensure(4)) || (rc = d_mask.ensure(17 * 17 * 4))) return rc;
+    std::vector<orbfe_marker> mk((size_t)nm);
+    memset(mk.data(), 0, mk.size() * sizeof(orbfe_marker));
+    for (int i = 0; i < n; i++) { mk[i >> 2].corners[i & 3][0] = pts[2 * i]; mk[i >> 2].corners[i & 3][1] = pts[2 * i + 1]; }
+    for (int i = n; i < 4 * nm; i++) { mk[i >> 2].corners[i & 3][0] = pts[0]; mk[i >> 2].corners[i & 3][1] = pts[1]; }
+    std::vector<float> mask((size_t)17 * 17, 0.f);
+    {
+        const int ww = 2 * win + 1;
+        for (int i = 0; i < ww; i++) {
+            const float y = (float)(i - win) / win;
+            const float vy = std::exp(-y * y);
+            for (int j = 0; j < ww; j++) {
+                const float x = (float)(j - win) / win;
+                mask[(size_t)i * ww + j] = (float)(vy * std::exp(-x * x));
+            }
+        }
+    }
+    ORBFE_HIP(hipMemcpy2D(d_img.p, pitch, img, step, (size_t)cols, (size_t)rows, hipMemcpyHostToDevice));
+    ORBFE_HIP(hipMemcpy(d_mk.p, mk.data(), mk.size() * sizeof(orbfe_marker), hipMemcpyHostToDevice));
+    ORBFE_HIP(hipMemcpy(d_n.p, &nm, 4, hipMemcpyHostToDevice));
+    ORBFE_HIP(hipMemcpy(d_mask.p, mask.data(), mask.size() * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_corner_subpix_markers, dim3(std::max(1, std::min(nm, 256)), 1), dim3(256), 0, 0, ImgView{d_img.as<uint8_t>(), nullptr, 0, (int)pitch}, cols, rows,
+                       d_mk.as<orbfe_marker>(), d_n.as<int32_t>(), nm, win, std::min(max_iters, 100), eps * eps, d_mask.as<float>());
+    ORBFE_HIP(hipGetLastError());
+    ORBFE_HIP(hipMemcpy(mk.data(), d_mk.p, mk.size() * sizeof(orbfe_marker), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++) { pts[2 * i] = mk[i >> 2].corners[i & 3][0]; pts[2 * i + 1] = mk[i >> 2].corners[i & 3][1]; }
+    return ORBFE_OK;
 }
 
 int orbfe_aruco_debug_image(orbfe_aruco* h, int frame, int stage, uint8_t* out)

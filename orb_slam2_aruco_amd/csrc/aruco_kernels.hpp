@@ -96,6 +96,18 @@ __global__ void k_decode_vote(ImgView src0, ImgView pyr, const ArLevel* levels, 
 __global__ void k_finalize(const ArRect* rects, int rect_cap, const int32_t* cand_idx, const int32_t* ncand,
                            const int32_t* result, const uint32_t* pool, size_t pool_fstride, orbfe_marker* out,
                            int out_cap, int32_t* n_out, int refine_lines, int32_t* out_src, int32_t* wctr);
+// aruco_modes.hip: THRES_AUTO_FIXED, Params::minSize > 0, CORNER_SUBPIX, CV_8UC3 input
+__global__ void k_fixed_threshold(ImgView src, int W, int H, int thr, uint32_t* bits, size_t bits_fstride, int wpr);
+__global__ void k_resize_nearest(ImgView src, ImgView dst, int sw, int sh, int dw, int dh, double ifx, double ify);
+__global__ void k_bgr_to_gray(const uint8_t* bgr, size_t bgr_fstride, size_t step, ImgView dst, int W, int H, int bits15);
+__global__ void k_marker_hist(const uint32_t* work, const int32_t* wctr, const int32_t* result, int rect_cap, const uint16_t* hist,
+                              uint32_t* out);
+__global__ void k_corner_subpix_markers(ImgView src, int W, int H, orbfe_marker* markers, const int32_t* n_out, int capacity, int win,
+                                        int max_iters, double eps2, const float* mask);
+__global__ void k_upsample_corners(ImgView src0, ImgView pyr, const ArLevel* levels, int start, int work_w, ArRect* rects, int rect_cap,
+                                   const int32_t* cand_idx, const uint32_t* work, const int32_t* wctr, const int32_t* result,
+                                   const float* masks);
+
 #define DC_PATCH_BYTES 1232   // = DC_PXCAP of aruco_kernels.hip: bytes per kept patch
 
 #define CT_THREADS 256          // threads that run the whole kernel

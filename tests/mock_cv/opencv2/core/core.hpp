@@ -15,6 +15,7 @@
 #define CV_8U 0
 #define CV_32F 5
 #define CV_8UC1 0
+#define CV_8UC3 16
 
 namespace cv
 {
@@ -94,7 +95,7 @@ public:
     }
     void copyTo(Mat& dst) const { dst = clone(); }
 private:
-    size_t esz() const { return type_ == CV_32F ? 4 : 1; }
+    size_t esz() const { return type_ == CV_32F ? 4 : type_ == CV_8UC3 ? 3 : 1; }
     std::shared_ptr<std::vector<unsigned char>> buf;
 };
 inline Mat operator*(const Mat& a, const Mat& b)

@@ -90,6 +90,15 @@ def _bind_aruco(L):
     L.oracle_aruco_stage_count.argtypes = [C.c_void_p, C.c_int]
     L.oracle_aruco_candidates.restype = C.c_int
     L.oracle_aruco_candidates.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    L.oracle_aruco_set_detection_mode.argtypes = [C.c_void_p, C.c_int, C.c_float]
+    L.oracle_aruco_set_corner_method.argtypes = [C.c_void_p, C.c_int]
+    L.oracle_aruco_state.argtypes = [C.c_void_p, C.c_int]
+    L.oracle_aruco_min_size.restype = C.c_float
+    L.oracle_aruco_min_size.argtypes = [C.c_void_p]
+    L.oracle_bgr_to_gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_int]
+    L.oracle_resize_nearest.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
+    L.oracle_corner_subpix.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double]
+    L.oracle_otsu_of_histogram.argtypes = [C.c_void_p]
     L.oracle_adaptive_threshold.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
     L.oracle_find_contours.restype = C.c_int
     L.oracle_find_contours.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
@@ -558,8 +567,23 @@ class ArucoOracle:
         self.L.oracle_aruco_set_params.argtypes = [C.c_void_p, C.c_float, C.c_int]
         self.L.oracle_aruco_set_params(self.h, error_correction_rate, int(corner_lines))
 
-    def detect(self, img, capacity=256):
+    def set_detection_mode(self, dm, min_marker_size=0.0):
+        """Params::setDetectionMode (markerdetector.cpp:374-391): 0 DM_NORMAL, 1 DM_FAST, 2 DM_VIDEO_FAST."""
+        self.L.oracle_aruco_set_detection_mode(self.h, int(dm), float(min_marker_size))
+
+    def set_corner_method(self, m):
+        """Params::setCornerRefinementMethod (:392-395): 0 CORNER_SUBPIX, 1 CORNER_LINES, 2 CORNER_NONE."""
+        self.L.oracle_aruco_set_corner_method(self.h, int(m))
+
+    def state(self):
+        return {"threshold": self.L.oracle_aruco_state(self.h, 0), "min_size": self.L.oracle_aruco_min_size(self.h),
+                "attempts": self.L.oracle_aruco_state(self.h, 1),
+                "work_shape": (self.L.oracle_aruco_state(self.h, 3), self.L.oracle_aruco_state(self.h, 2))}
+
+    def detect(self, img, capacity=256, bits15=0):
         img = np.ascontiguousarray(img, np.uint8)
+        if img.ndim == 3:   # CV_8UC3: cvtColor(BGR2GRAY) first
+            img = bgr_to_gray(img, bits15)
         out = np.zeros(capacity, MARKER_DTYPE)
         n = self.L.oracle_aruco_detect(self.h, _p(img), img.shape[0], img.shape[1], img.strides[0], _p(out), capacity)
         return out[:min(n, capacity)].copy()
@@ -586,6 +610,32 @@ class ArucoOracle:
         rot = C.c_int(0)
         i = self.L.oracle_decode_marker(self.h, _p(patch), patch.shape[0], C.byref(rot))
         return i, rot.value
+
+
+def bgr_to_gray(bgr, bits15=0):
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    out = np.zeros(bgr.shape[:2], np.uint8)
+    lib().oracle_bgr_to_gray(_p(bgr), bgr.shape[0], bgr.shape[1], bgr.strides[0], _p(out), int(bits15))
+    return out
+
+
+def resize_nearest(img, dw, dh):
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.zeros((dh, dw), np.uint8)
+    lib().oracle_resize_nearest(_p(img), img.shape[1], img.shape[0], _p(out), dw, dh)
+    return out
+
+
+def corner_subpix(img, pts, win, max_iters, eps):
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.ascontiguousarray(pts, np.float32).reshape(-1, 2).copy()
+    lib().oracle_corner_subpix(_p(img), img.shape[1], img.shape[0], _p(out), len(out), int(win), int(max_iters), float(eps))
+    return out
+
+
+def otsu_of_histogram(hist):
+    hist = np.ascontiguousarray(hist, np.float32)
+    return lib().oracle_otsu_of_histogram(_p(hist))
 
 
 def adaptive_threshold(img, win, Cc=7):

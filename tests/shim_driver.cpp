@@ -2,6 +2,7 @@
 // reference's Frame / Tracking code does, against the mock OpenCV / SLAM headers of tests/mock_cv/, and dumps inputs and results as
 // raw arrays; tests/test_shims_gpu.py repeats every call through the ctypes binding and compares.
 //   shim_driver <frames.raw> <rows> <cols> <nframes> <out prefix>          exit 3 = no GPU (the library has no CPU fallback)
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <set>
@@ -105,8 +106,28 @@ int main(int argc, char** argv)
             if (m.ssize != 0.187f || m.dict_info != "ARUCO") return 11;
         }
         dump("markers", rec);
+        // the other modes through the shim: a CV_8UC3 frame with three equal channels is its grey image (same markers, bit for bit);
+        // DM_FAST + CORNER_SUBPIX (the reference's default corner method) finds the same ids; a value outside the enums throws
+        {
+            std::vector<unsigned char> raw3((size_t)rows * cols * 3);
+            for (size_t i = 0; i < (size_t)rows * cols; i++) raw3[3 * i] = raw3[3 * i + 1] = raw3[3 * i + 2] = raw[i];
+            cv::Mat im3(rows, cols, CV_8UC3, raw3.data(), (size_t)cols * 3);
+            std::vector<aruco::Marker> mk3 = det.detect(im3, cam, 0.187f);
+            if (mk3.size() != mk.size()) return 14;
+            for (size_t i = 0; i < mk.size(); i++)
+                for (int k = 0; k < 4; k++)
+                    if (mk3[i].id != mk[i].id || mk3[i][k].x != mk[i][k].x || mk3[i][k].y != mk[i][k].y) return 14;
+            det.getParameters().setCornerRefinementMethod(aruco::CORNER_SUBPIX);
+            det.setDetectionMode(aruco::DM_FAST, 0.f);
+            std::vector<aruco::Marker> mkf = det.detect(im);
+            if (mkf.size() != mk.size()) return 15;
+            for (size_t i = 0; i < mk.size(); i++)
+                if (mkf[i].id != mk[i].id || std::fabs(mkf[i][0].x - mk[i][0].x) > 2.f) return 15;
+            det.setDetectionMode(aruco::DM_NORMAL);
+            det.getParameters().setCornerRefinementMethod(aruco::CORNER_LINES);
+        }
         bool threw = false;
-        try { det.setDetectionMode(aruco::DM_FAST); } catch (const cv::Exception&) { threw = true; }
+        try { det.setDetectionMode((aruco::DetectionMode)7); } catch (const cv::Exception&) { threw = true; }
         if (!threw) return 12;
         threw = false;
         try { det.setDictionary("NO_SUCH_DICTIONARY"); } catch (const std::runtime_error&) { threw = true; }

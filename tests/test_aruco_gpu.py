@@ -323,7 +323,7 @@ def test_error_correction_rate(orbfe, oracle, dic, rate):
 
 def test_corner_none_modes_and_contours(orbfe, oracle):
     """setCornerRefinementMethod(CORNER_NONE) returns the rotated approxPolyDP corners; aruco::Marker::contourPoints are the border
-    the rectangle came from; the modes that are not built are refused loudly."""
+    the rectangle came from; parameters outside their range are refused loudly (the other modes: tests/test_aruco_modes_gpu.py)."""
     img, truth = synth.scene(480, 640, 2, "ARUCO", 4)
     det = orbfe.MarkerDetector("ARUCO")
     ora = oracle.ArucoOracle("ARUCO")
@@ -350,9 +350,8 @@ def test_corner_none_modes_and_contours(orbfe, oracle):
     det.setCornerRefinementMethod(det.CORNER_LINES)
     assert np.array_equal(det.detect(img)["corners"], lines["corners"])
     det.setDetectionMode(det.DM_NORMAL)
-    for bad in (lambda: det.setDetectionMode(det.DM_FAST), lambda: det.setDetectionMode(det.DM_VIDEO_FAST, 0.1),
-                lambda: det.setDetectionMode(det.DM_NORMAL, 0.05),        # Params::minSize: not built, refused (never ignored)
-                lambda: det.setCornerRefinementMethod(det.CORNER_SUBPIX), lambda: det.setDictionary("ARUCO", 1.5)):
+    for bad in (lambda: det.setDetectionMode(7), lambda: det.setDetectionMode(det.DM_VIDEO_FAST, 1.1),
+                lambda: det.setCornerRefinementMethod(5), lambda: det.setDictionary("ARUCO", 1.5)):
         with pytest.raises(orbfe.OrbfeError):
             bad()
 

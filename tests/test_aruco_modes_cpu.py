@@ -1,0 +1,134 @@
+"""CPU checks of the oracle's restatement of the detector modes outside src/Frame.cc:135-137 (oracle/aruco_oracle.cpp: THRES_AUTO_FIXED,
+Params::minSize, CORNER_SUBPIX, CV_8UC3 input).  Like the rest of the image path these primitives are PARITY UNPINNED (no OpenCV in the
+image, the reference ships no vectors): what can be checked here is that each restatement agrees with an independent formulation
+of the same published algorithm -- second opinions with a stated tolerance, not pins."""
+import ctypes
+
+import numpy as np
+
+import oracle_lib
+from orb_slam2_aruco_amd import synth
+
+LIBC = ctypes.CDLL(None)
+
+
+def test_bgr_to_gray_against_the_integer_and_the_float_definition():
+    rng = np.random.default_rng(1)
+    bgr = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    b, g, r = (bgr[..., k].astype(np.int64) for k in range(3))
+    assert np.array_equal(oracle_lib.bgr_to_gray(bgr, 0), ((b * 1868 + g * 9617 + r * 4899 + 8192) >> 14).astype(np.uint8))
+    assert np.array_equal(oracle_lib.bgr_to_gray(bgr, 1), ((b * 3735 + g * 19235 + r * 9798 + 16384) >> 15).astype(np.uint8))
+    y = 0.114 * b + 0.587 * g + 0.299 * r                       # the ITU-R 601 weights both tables quantise
+    for bits in (0, 1):
+        assert np.abs(oracle_lib.bgr_to_gray(bgr, bits).astype(np.float64) - y).max() <= 0.51
+    grey = rng.integers(0, 256, (9, 11), dtype=np.uint8)        # equal channels come back unchanged (the weights sum to one)
+    assert np.array_equal(oracle_lib.bgr_to_gray(np.repeat(grey[..., None], 3, 2), 0), grey)
+    assert np.array_equal(oracle_lib.bgr_to_gray(np.repeat(grey[..., None], 3, 2), 1), grey)
+
+
+def test_resize_nearest_is_the_floor_of_the_scaled_index():
+    rng = np.random.default_rng(2)
+    for (h, w, dh, dw) in [(480, 640, 300, 400), (480, 640, 188, 252), (720, 1280, 282, 502), (33, 47, 12, 20), (10, 10, 10, 10)]:
+        img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        sx = np.minimum(np.floor(np.arange(dw) * (1.0 / (dw / w))).astype(int), w - 1)
+        sy = np.minimum(np.floor(np.arange(dh) * (1.0 / (dh / h))).astype(int), h - 1)
+        assert np.array_equal(oracle_lib.resize_nearest(img, dw, dh), img[sy][:, sx])
+
+
+def test_otsu_of_the_marker_histogram():
+    rng = np.random.default_rng(3)
+    # two well separated classes: every formulation of Otsu's criterion lands between them, on the same bin
+    for lo, hi, nlo, nhi in [(40, 200, 3000, 2000), (10, 90, 500, 4000), (120, 135, 1000, 1000)]:
+        px = np.concatenate([rng.normal(lo, 4, nlo), rng.normal(hi, 4, nhi)]).clip(0, 255).astype(np.uint8)
+        hist = np.bincount(px, minlength=256).astype(np.float32)
+        t = oracle_lib.otsu_of_histogram(hist)
+        p = hist.astype(np.float64) / hist.sum()
+        w0 = np.cumsum(p)[:-1]; w1 = 1 - w0                         # split "v < t" for t = 1 .. 255
+        m0 = np.cumsum(p * np.arange(256))[:-1]
+        mt = (p * np.arange(256)).sum()
+        with np.errstate(divide="ignore", invalid="ignore"):
+            var = w0 * w1 * (m0 / w0 - (mt - m0) / w1) ** 2
+        var[~((w0 > 1e-4) & (w1 > 1e-4))] = -1
+        best = var.max()
+        assert var[t - 1] >= best * (1 - 1e-5) and lo < t < hi, (t, int(np.argmax(var)) + 1)
+    assert oracle_lib.otsu_of_histogram(np.zeros(256, np.float32)) == -1        # no marker found: the threshold is kept
+    one = np.zeros(256, np.float32); one[77] = 1225
+    assert oracle_lib.otsu_of_histogram(one) == -1                              # a single grey level has no split
+
+
+def _corner_image(cx, cy, n=64, ss=8):
+    """An X-corner (two dark quadrants) at sub-pixel (cx, cy), area-sampled."""
+    ys, xs = np.mgrid[0:n * ss, 0:n * ss]
+    u, v = (xs + 0.5) / ss - 0.5 - cx, (ys + 0.5) / ss - 0.5 - cy
+    hi = ((u > 0) ^ (v > 0)).astype(np.float64) * 180 + 40
+    return np.rint(hi.reshape(n, ss, n, ss).mean(axis=(1, 3))).astype(np.uint8)
+
+
+def test_corner_subpix_finds_a_rendered_corner():
+    for cx, cy in [(31.3, 30.8), (28.55, 33.1), (32.0, 32.5)]:
+        img = _corner_image(cx, cy)
+        for win, iters, eps in [(4, 12, 0.005), (5, 30, 0.001), (3, 30, 0.001)]:
+            start = np.array([[cx + 1.1, cy - 0.9], [cx - 0.7, cy + 1.2]], np.float32)
+            got = oracle_lib.corner_subpix(img, start, win, iters, eps)
+            # an area-sampled step edge is one pixel wide: the gradient-orthogonality estimate sits within ~0.15 px of the true corner,
+            # and both starts arrive at the same point
+            assert np.abs(got - np.array([cx, cy], np.float32)).max() < 0.2, (cx, cy, win, got)
+            assert np.abs(got[0] - got[1]).max() < 0.01, (cx, cy, win, got)
+            again = oracle_lib.corner_subpix(img, got, win, iters, eps)             # a converged corner stays (within eps)
+            assert np.abs(again - got).max() < 0.02
+    # flat image: singular system, the point stays; too far a jump is rejected (the start is kept)
+    flat = np.full((40, 40), 9, np.uint8)
+    p = np.array([[20.25, 19.5]], np.float32)
+    assert np.array_equal(oracle_lib.corner_subpix(flat, p, 4, 12, 0.005), p)
+    # near the border the window is the replicated border: the result stays finite and inside the image
+    img = _corner_image(3.2, 2.7)
+    got = oracle_lib.corner_subpix(img, np.array([[3.9, 2.1], [0.5, 0.5], [63.4, 63.2]], np.float32), 4, 12, 0.005)
+    assert np.all(np.isfinite(got)) and got.min() >= 0 and got.max() < 64
+    assert np.abs(got[0] - np.array([3.2, 2.7], np.float32)).max() < 0.3
+
+
+def test_dm_fast_oracle_retries_with_the_process_rand_and_carries_the_threshold():
+    img, truth = synth.scene(480, 640, 72, "ARUCO", 4, side_range=(60, 130))
+    dark = (img.astype(np.float32) * 0.22).astype(np.uint8)
+
+    def run(seed):
+        ora = oracle_lib.ArucoOracle("ARUCO")
+        ora.set_detection_mode(1, 0.0)
+        LIBC.srand(seed)
+        out = []
+        for im in (img, dark, dark, img):
+            m = ora.detect(im)
+            out.append((m["id"].tolist(), ora.state()["threshold"], ora.state()["attempts"]))
+        return out
+    a, b, c = run(5), run(5), run(6)
+    assert a == b                                                  # same rand() sequence, same run
+    assert a[0][2] == 1 and a[0][0] == sorted(t[0] for t in truth) and a[0][1] != 100   # Otsu over the markers moved the threshold
+    assert a[1][2] >= 2                                            # nothing at the carried-over threshold on the dark frame
+    assert c[0] == a[0]                                            # no rand() before the first retry
+    # the adaptive mode is what it was: one pass, C = 7
+    ora = oracle_lib.ArucoOracle("ARUCO")
+    ora.set_detection_mode(0, 0.0)
+    assert ora.detect(img)["id"].tolist() == a[0][0] and ora.state() == {"threshold": 7, "min_size": 0.0, "attempts": 1, "work_shape": (480, 640)}
+
+
+def test_min_size_reduces_the_working_image_as_the_reference_computes_it():
+    img, _ = synth.scene(480, 640, 70, "ARUCO", 4, side_range=(60, 130))
+    for ms, shape in [(0.0, (480, 640)), (0.03, (480, 640)), (0.04, (384, 512)), (0.05, (300, 400)), (0.08, (188, 252)), (0.12, (126, 168))]:
+        ora = oracle_lib.ArucoOracle("ARUCO")
+        ora.set_corner_method(0)
+        ora.set_detection_mode(0, ms)
+        ora.detect(img)
+        # minpix = int(ms * 640); scale = 20 / minpix, used below 0.9; sides rounded and made even
+        minpix = int(np.float32(ms) * np.float32(640))
+        want = (480, 640)
+        if 20 < minpix and np.float32(20) / np.float32(minpix) < 0.9:
+            sc = np.float32(20) / np.float32(minpix)
+            w, h = int(np.float32(640) * sc + 0.5), int(np.float32(480) * sc + 0.5)
+            want = (h + h % 2, w + w % 2)
+        assert ora.state()["work_shape"] == want == shape, (ms, ora.state(), want)
+    # CORNER_LINES / CORNER_NONE reset minSize (markerdetector.cpp:392-395)
+    ora = oracle_lib.ArucoOracle("ARUCO")
+    ora.set_detection_mode(0, 0.1)
+    ora.set_corner_method(1)
+    ora.detect(img)
+    assert ora.state()["work_shape"] == (480, 640) and ora.state()["min_size"] == 0.0

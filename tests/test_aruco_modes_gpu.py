@@ -1,0 +1,186 @@
+"""GPU parity of the detector's parameter surface outside src/Frame.cc:135-137 (csrc/aruco_modes.hip) against the CPU oracle:
+DM_FAST / DM_VIDEO_FAST (THRES_AUTO_FIXED with its rand() retries and frame-to-frame threshold, the automatic size estimation),
+Params::minSize > 0 (reduced working image + cornerUpsample), CORNER_SUBPIX, CV_8UC3 input, cv::cornerSubPix by itself.
+rand() is the process's sequence on both sides: every sequence is run once per side behind the same srand()."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from orb_slam2_aruco_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+LIBC = ctypes.CDLL(None)
+CORNER_TOL = 1e-3   # px; ids, thresholds, attempts, working sizes and minSize are compared exactly
+
+
+def frames(n, rows=480, cols=640, dic="ARUCO", seed0=70):
+    """A video-like sequence: scenes with markers, a dark one (every marker pixel below the start threshold: THRES_AUTO_FIXED has
+    to retry with random thresholds), one without markers, a bright one."""
+    out = []
+    for i in range(n):
+        img, _ = synth.scene(rows, cols, seed0 + i, dic, 3 + i % 3, side_range=(60, 130))
+        if i % 5 == 2:
+            img = (img.astype(np.float32) * 0.22).astype(np.uint8)          # max ~56: nothing at threshold 100+
+        elif i % 5 == 3:
+            img, _ = synth.scene(rows, cols, seed0 + i, dic, 0)
+        elif i % 5 == 4:
+            img = np.clip(img.astype(np.int32) + 70, 0, 255).astype(np.uint8)
+        out.append(img)
+    return out
+
+
+def run_both(orbfe, oracle, seq, dic, mode, min_size, corner, seed=11):
+    det, ora = orbfe.MarkerDetector(dic), oracle.ArucoOracle(dic)
+    # the order a caller of the reference uses with CORNER_SUBPIX: the corner method first, else it resets minSize (markerdetector.cpp:392-395)
+    det.setCornerRefinementMethod(corner); ora.set_corner_method(corner)
+    det.setDetectionMode(mode, min_size); ora.set_detection_mode(mode, min_size)
+    LIBC.srand(seed)
+    want = [(ora.detect(im), ora.state()) for im in seq]
+    LIBC.srand(seed)
+    got = [(det.detect(im), det.state()) for im in seq]
+    return got, want
+
+
+def compare(got, want):
+    nretry = 0
+    for i, ((g, gs), (w, ws)) in enumerate(zip(got, want)):
+        assert gs["attempts"] == ws["attempts"] and gs["threshold"] == ws["threshold"], (i, gs, ws)
+        assert tuple(gs["work_shape"]) == tuple(ws["work_shape"]), (i, gs, ws)
+        assert np.float32(gs["min_size"]) == np.float32(ws["min_size"]), (i, gs, ws)
+        assert np.array_equal(g["id"], w["id"]), (i, g["id"], w["id"])
+        assert np.allclose(g["corners"], w["corners"], atol=CORNER_TOL), (i, np.abs(g["corners"] - w["corners"]).max())
+        nretry += ws["attempts"] > 1
+    return nretry
+
+
+def test_dm_fast_sequence_with_random_retries(orbfe, oracle):
+    seq = frames(10)
+    got, want = run_both(orbfe, oracle, seq, "ARUCO", 1, 0.0, 1)
+    assert compare(got, want) >= 2                                  # the dark and the empty frames went through the retries
+    assert sum(len(w) for w, _ in want) >= 15
+    assert len({ws["threshold"] for _, ws in want}) >= 3            # the threshold follows the markers' pixels
+    # same sequence, another seed: the retries draw other thresholds
+    got2, want2 = run_both(orbfe, oracle, seq, "ARUCO", 1, 0.0, 1, seed=12345)
+    compare(got2, want2)
+
+
+@pytest.mark.parametrize("dic,rows,cols", [("ARUCO", 480, 640), ("ARUCO_MIP_36h12", 540, 960)])
+def test_corner_subpix_mode(orbfe, oracle, dic, rows, cols):
+    seq = frames(4, rows, cols, dic)
+    got, want = run_both(orbfe, oracle, seq, dic, 0, 0.0, 0)
+    compare(got, want)
+    lines = orbfe.MarkerDetector(dic).detect(seq[0])
+    assert len(lines) == len(got[0][0]) and not np.array_equal(lines["corners"], got[0][0]["corners"])
+    # the batch entry point runs the same kernel
+    det = orbfe.MarkerDetector(dic)
+    det.setCornerRefinementMethod(det.CORNER_SUBPIX)
+    batch = det.detect_batch(np.stack(seq))
+    for i in range(len(seq)):
+        assert np.array_equal(batch[i], got[i][0])
+
+
+@pytest.mark.parametrize("mode,min_size", [(0, 0.05), (0, 0.08), (1, 0.05), (0, 0.12)])
+def test_min_marker_size_reduced_working_image(orbfe, oracle, mode, min_size):
+    seq = frames(5)
+    got, want = run_both(orbfe, oracle, seq, "ARUCO", mode, min_size, 0)
+    compare(got, want)
+    assert all(ws["work_shape"][1] < 640 for _, ws in want)
+    assert sum(len(w) for w, _ in want) >= 4
+
+
+def test_min_marker_size_other_frame_sizes(orbfe, oracle):
+    for rows, cols, ms in [(720, 1280, 0.04), (540, 960, 0.06), (480, 752, 0.1)]:
+        seq = frames(2, rows, cols, "ARUCO_MIP_25h7", seed0=31)
+        got, want = run_both(orbfe, oracle, seq, "ARUCO_MIP_25h7", 0, ms, 0)
+        compare(got, want)
+        assert want[0][1]["work_shape"][1] < cols
+
+
+def test_dm_video_fast_follows_the_marker_size(orbfe, oracle):
+    seq = frames(10, seed0=120)
+    got, want = run_both(orbfe, oracle, seq, "ARUCO", 2, 0.0, 0)
+    compare(got, want)
+    shapes = {tuple(ws["work_shape"]) for _, ws in want}
+    assert len(shapes) >= 3 and (480, 640) in shapes               # reduced after frames with markers, full size after empty ones
+    # with CORNER_LINES set AFTER the mode the reference resets minSize to 0: only the automatic size is left
+    det, ora = orbfe.MarkerDetector("ARUCO"), oracle.ArucoOracle("ARUCO")
+    det.setDetectionMode(det.DM_VIDEO_FAST, 0.1); ora.set_detection_mode(2, 0.1)
+    det.setCornerRefinementMethod(det.CORNER_LINES); ora.set_corner_method(1)
+    assert det.state()["min_size"] == 0.0 and ora.state()["min_size"] == 0.0
+    LIBC.srand(3)
+    want = [(ora.detect(im), ora.state()) for im in seq[:4]]
+    LIBC.srand(3)
+    got = [(det.detect(im), det.state()) for im in seq[:4]]
+    compare(got, want)
+
+
+def test_bgr_input(orbfe, oracle):
+    rng = np.random.default_rng(5)
+    img, truth = synth.scene(480, 640, 3, "ARUCO", 4)
+    bgr = np.stack([np.clip(img.astype(np.int32) + rng.integers(-12, 13, img.shape), 0, 255).astype(np.uint8) for _ in range(3)], axis=2)
+    for bits in (14, 15):
+        det, ora = orbfe.MarkerDetector("ARUCO"), oracle.ArucoOracle("ARUCO")
+        det.setGrayConversion(bits)
+        got, want = det.detect(bgr), ora.detect(bgr, bits15=int(bits == 15))
+        assert np.array_equal(got["id"], want["id"]) and len(got) == len(truth)
+        assert np.allclose(got["corners"], want["corners"], atol=CORNER_TOL)
+        assert np.array_equal(det.thresholded(0), ora.stage_image(0))       # the grey image itself was the same
+    # with a camera: the poses entry point takes BGR too
+    K = np.array([[520., 0, 320], [0, 520., 240], [0, 0, 1]], np.float32)
+    det = orbfe.MarkerDetector("ARUCO")
+    mk, poses = det.detect(bgr, (K, np.zeros(5, np.float32), (640, 480)), 0.187)
+    mk_g, poses_g = det.detect(oracle.bgr_to_gray(bgr), (K, np.zeros(5, np.float32), (640, 480)), 0.187)
+    assert np.array_equal(mk, mk_g) and np.array_equal(poses, poses_g)
+    # a strided view (a ROI of a larger frame)
+    big = np.zeros((500, 700, 3), np.uint8)
+    big[10:490, 20:660] = bgr
+    assert np.array_equal(det.detect(big[10:490, 20:660]), det.detect(bgr))
+
+
+@pytest.mark.parametrize("win,iters,eps", [(4, 12, 0.005), (3, 4, 0.0), (5, 4, 0.0), (2, 30, 0.001), (8, 6, 0.01)])
+def test_corner_subpix_primitive(orbfe, oracle, win, iters, eps):
+    img, truth = synth.scene(480, 640, 8, "ARUCO", 5)
+    rng = np.random.default_rng(win)
+    pts = [c for t in truth for c in np.asarray(t[1], np.float32).reshape(4, 2)]
+    pts = np.array(pts, np.float32) + rng.uniform(-1.5, 1.5, (len(pts), 2)).astype(np.float32)
+    # corners whose window leaves the image on every side, and one in a flat region (singular system: stays)
+    edge = np.array([[1.2, 1.7], [638.4, 2.2], [2.5, 477.9], [637.1, 478.3], [320.3, 0.4], [0.3, 240.6], [639.0, 200.0], [100.0, 479.0]], np.float32)
+    pts = np.vstack([pts, edge])
+    got = orbfe.corner_subpix(img, pts, win, iters, eps)
+    want = oracle.corner_subpix(img, pts, win, iters, eps)
+    assert np.array_equal(got, want), np.abs(got - want).max()
+    assert np.abs(got[:len(pts) - len(edge)] - pts[:len(pts) - len(edge)]).max() > 0.05       # something moved
+    flat = np.full((64, 64), 77, np.uint8)
+    p = np.array([[30.5, 31.25]], np.float32)
+    assert np.array_equal(orbfe.corner_subpix(flat, p, win, iters, eps), p)
+
+
+def test_mode_setters_and_the_batch_entry_points(orbfe, oracle):
+    det = orbfe.MarkerDetector("ARUCO")
+    for bad in (lambda: det.setDetectionMode(3), lambda: det.setDetectionMode(det.DM_FAST, 1.5), lambda: det.setDetectionMode(det.DM_NORMAL, -0.1),
+                lambda: det.setCornerRefinementMethod(3), lambda: det.setGrayConversion(16)):
+        with pytest.raises(orbfe.OrbfeError):
+            bad()
+    # a reduction below 64 x 48 is refused at detect time, never ignored
+    det.setCornerRefinementMethod(det.CORNER_SUBPIX); det.setDetectionMode(det.DM_NORMAL, 0.5)
+    with pytest.raises(orbfe.OrbfeError):
+        det.detect(synth.scene(480, 640, 1, "ARUCO", 2)[0])
+    # host batches of a frame-sequential handle are taken frame by frame, in order
+    seq = frames(5)
+    a, b = orbfe.MarkerDetector("ARUCO"), orbfe.MarkerDetector("ARUCO")
+    a.setDetectionMode(a.DM_FAST); b.setDetectionMode(b.DM_FAST)
+    LIBC.srand(9)
+    one = [a.detect(im) for im in seq]
+    LIBC.srand(9)
+    batch = b.detect_batch(np.stack(seq))
+    for i in range(len(seq)):
+        assert np.array_equal(one[i], batch[i])
+    assert a.state() == b.state()
+    # the device-pointer batch entry point refuses such a handle and takes a reduced working image (stateless) as it is: in its own
+    # process, torch (device memory) has to initialise HIP before the library does
+    import os, subprocess, sys
+    case = os.path.join(os.path.dirname(os.path.abspath(__file__)), "aruco_modes_device_case.py")
+    r = subprocess.run([sys.executable, case], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "device case ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
