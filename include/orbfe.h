@@ -151,7 +151,8 @@ int orbfe_extractor_set_early_stream(orbfe_extractor* h, void* stream);
  * MarkerDetector::detect on the SAME grey image (Frame.cc:91 / :200-206, then :142), one after the other on the Tracking thread; the
  * two are independent.  With a detector paired to an extractor, a one-frame orbfe_extract uploads the image once and starts the
  * detector on that device copy on the detector's own stream, next to its own launches; the following orbfe_aruco_detect /
- * orbfe_aruco_detect_poses call, if it is handed the same image (rows, cols and a 64-bit hash of the pixels), waits for that
+ * orbfe_aruco_detect_poses call, if it is handed the same image (rows, cols and every pixel, compared with the copy the extractor
+ * staged), waits for that
  * work and returns its results -- poses included when camera and marker size are those of the detector's previous call.  Any
  * other image, a batch call, or a capacity flag: the call runs as if nothing had been started.  Results are identical either way.
  * detector == NULL unpairs; unpair (or destroy the extractor) before destroying the detector.  Both handles on one device. */

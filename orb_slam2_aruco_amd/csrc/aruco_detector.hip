@@ -52,7 +52,8 @@ struct orbfe_aruco {
     struct Spec {
         bool pending = false, has_pose = false; // work enqueued and not consumed yet; poses were computed with `cam` / `size`
         int rows = 0, cols = 0;
-        uint64_t hash = 0;
+        const uint8_t* host_copy = nullptr; // the extractor's staged frame (orbfe_common.hpp)
+        size_t host_pitch = 0;
         PoseCamera cam{};
         float size = 0.f;
     } spec;
@@ -806,29 +807,17 @@ static bool same_camera(const PoseCamera& a, const PoseCamera& b) { return memcm
 
 namespace orbfe {
 
-uint64_t image_hash(const uint8_t* img, int rows, int cols, size_t step)
+// is `img` byte for byte the frame the paired extractor staged?
+static bool same_frame(const uint8_t* img, size_t step, const uint8_t* copy, size_t pitch, int rows, int cols)
 {
-    // four independent multiply-xor lanes over the rows' 8-byte words (the tail bytes of a row go in as one more word)
-    uint64_t h[4] = {0x9E3779B97F4A7C15ull, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull, 0x27D4EB2F165667C5ull};
-    const uint64_t M = 0x100000001B3ull * 0x9E3779B1ull | 1ull;
-    for (int y = 0; y < rows; y++) {
-        const uint8_t* r = img + (size_t)y * step;
-        int x = 0;
-        for (; x + 32 <= cols; x += 32) {
-            uint64_t w[4];
-            memcpy(w, r + x, 32);
-            for (int k = 0; k < 4; k++) h[k] = (h[k] ^ w[k]) * M;
-        }
-        uint64_t t[4] = {0, 0, 0, 0};
-        memcpy(t, r + x, (size_t)(cols - x));
-        for (int k = 0; k < 4; k++) h[k] = (h[k] ^ t[k]) * M;
-    }
-    uint64_t out = (uint64_t)rows * 0x9E3779B97F4A7C15ull ^ (uint64_t)cols;
-    for (int k = 0; k < 4; k++) out = (out ^ (h[k] >> 29) ^ h[k]) * M;
-    return out;
+    if (!copy) return false;
+    for (int y = 0; y < rows; y++)
+        if (memcmp(img + (size_t)y * step, copy + (size_t)y * pitch, (size_t)cols) != 0) return false;
+    return true;
 }
 
-int aruco_speculate(orbfe_aruco* h, const uint8_t* d_img, size_t dframe, int rows, int cols, size_t dpitch, hipEvent_t uploaded, uint64_t hash)
+int aruco_speculate(orbfe_aruco* h, const uint8_t* d_img, size_t dframe, int rows, int cols, size_t dpitch, hipEvent_t uploaded,
+                    const uint8_t* host_copy, size_t host_pitch)
 {
     h->spec.pending = false;
     if (h->big_mode) return ORBFE_OK; // the rare big-frame mode is left to the detector's own call
@@ -850,7 +839,7 @@ int aruco_speculate(orbfe_aruco* h, const uint8_t* d_img, size_t dframe, int row
                            AR_MAX_RECTS, h->last_size, h->last_cam, h->d_poses.as<orbfe_marker_pose>());
         ORBFE_HIP(hipMemcpyAsync(hp + o.ps, h->d_poses.p, (size_t)AR_MAX_RECTS * sizeof(orbfe_marker_pose), hipMemcpyDeviceToHost, s));
     }
-    h->spec.pending = true; h->spec.rows = rows; h->spec.cols = cols; h->spec.hash = hash;
+    h->spec.pending = true; h->spec.rows = rows; h->spec.cols = cols; h->spec.host_copy = host_copy; h->spec.host_pitch = host_pitch;
     h->spec.has_pose = pose; h->spec.cam = h->last_cam; h->spec.size = h->last_size;
     return ORBFE_OK;
 }
@@ -997,7 +986,7 @@ static int detect_batch_impl(orbfe_aruco* h, const uint8_t* imgs, int nframes, s
     if (h->spec.pending && nframes != 1) { ORBFE_HIP(hipStreamSynchronize(h->own_stream)); h->spec.pending = false; }
     if (h->spec.pending && nframes == 1) {
         h->spec.pending = false;
-        const bool match = h->spec.rows == rows && h->spec.cols == cols && h->spec.hash == image_hash(imgs, rows, cols, step);
+        const bool match = h->spec.rows == rows && h->spec.cols == cols && same_frame(imgs, step, h->spec.host_copy, h->spec.host_pitch, rows, cols);
         hipStream_t s = h->own_stream;
         if (!match) ORBFE_HIP(hipStreamSynchronize(s)); // its buffers are about to be reused
         else {

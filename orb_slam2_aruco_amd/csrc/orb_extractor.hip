@@ -595,6 +595,7 @@ void orbfe_extractor_destroy(orbfe_extractor* h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    if (h->paired) { aruco_speculation_wait(h->paired); aruco_unpair_notice(h->paired); } // it reads this handle's buffers (a paired detector outlives the pairing: orbfe.h)
     delete h;
 }
 
@@ -681,7 +682,7 @@ int orbfe_extract_batch(orbfe_extractor* h, const uint8_t* imgs, int nframes, si
         if (spec) { // the paired detector starts on the same device copy, on its own stream, next to the launches below
             if (!h->ev_up) ORBFE_HIP(hipEventCreateWithFlags(&h->ev_up, hipEventDisableTiming));
             ORBFE_HIP(hipEventRecord(h->ev_up, s));
-            int rcs = aruco_speculate(h->paired, h->d_in.as<uint8_t>(), dframe, rows, cols, dpitch, h->ev_up, image_hash(hp, rows, cols, dpitch));
+            int rcs = aruco_speculate(h->paired, h->d_in.as<uint8_t>(), dframe, rows, cols, dpitch, h->ev_up, hp, dpitch);
             if (rcs) return rcs;
         }
         int rc2 = h->run_device(h->d_in.as<uint8_t>(), nframes, dframe, rows, cols, dpitch, h->d_kps.as<orbfe_keypoint>(),

@@ -119,10 +119,12 @@ struct PinnedBuf {
 // ---- a detector paired with an extractor (orbfe_extractor_pair_detector): the drop-in path calls ORBextractor::operator() and
 // MarkerDetector::detect on the SAME image one after the other (Frame.cc:91 -> :142); the extractor's call uploads the image once
 // and starts the detector on it on the detector's own stream, next to its own launches; the detector's call finds its work done if
-// it is handed the same image (64-bit content hash), else it runs as if nothing had happened.
-uint64_t image_hash(const uint8_t* img, int rows, int cols, size_t step);
+// it is handed the same image, else it runs as if nothing had happened.  "The same image" = byte for byte what the extractor
+// staged in its page-locked buffer (`host_copy`, rows of `host_pitch` bytes: valid until the extractor's next call or its
+// destruction, both of which end the speculation first).  Until the end of round 3 both calls hashed the frame instead (two passes
+// of ~30 us over a 640 x 480 frame; one memcmp is ~12 us and stops at the first difference).
 int aruco_speculate(orbfe_aruco* a, const uint8_t* d_img, size_t dframe, int rows, int cols, size_t dpitch, hipEvent_t uploaded,
-                    uint64_t hash);
+                    const uint8_t* host_copy, size_t host_pitch);
 void aruco_speculation_wait(orbfe_aruco* a); // until the detector no longer reads the extractor's copy of the image
 void aruco_unpair_notice(orbfe_aruco* a);
 
