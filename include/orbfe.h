@@ -146,6 +146,11 @@ int orbfe_extractor_set_aux_stream(orbfe_extractor* h, void* stream);
  * a stream with little work at the start of a batch instead -- bench.py: the one that carries the detector's /2 pyramid.  NULL
  * restores the default.  Ordering is by events either way. */
 int orbfe_extractor_set_early_stream(orbfe_extractor* h, void* stream);
+/* Phase lock between the extractor handles of a pipeline (device-pointer batches): every batch of `h` starts behind a stage of the
+ * latest batch enqueued on `other` -- stage 1 = its FAST, 2 = its quadtree, 3 = its descriptors; 0 or other == NULL: free running.
+ * Two engine sets that follow each other run a fixed half-period apart instead of in whatever phase contention leaves them
+ * (bench.py: measured).  `other` must outlive the relation.  Results do not depend on it. */
+int orbfe_extractor_follow(orbfe_extractor* h, orbfe_extractor* other, int stage);
 
 /* Pairing for the drop-in path.  The reference builds a Frame by calling ORBextractor::operator() and then
  * MarkerDetector::detect on the SAME grey image (Frame.cc:91 / :200-206, then :142), one after the other on the Tracking thread; the

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void k_adaptive_threshold(ImgView src, int W, 
             const unsigned long long m = __ballot(on);
             if (y < H && lane < 2) {
                 const int word = (tx0 >> 5) + lane;
-                if (word < wpr) bits[(size_t)f * bits_fstride + (size_t)y * wpr + word] = (uint32_t)(m >> (32 * lane));
+                if (word < wpr) bits[(size_t)f * bits_fstride + (uint32_t)(__mul24(y, wpr) + word)] = (uint32_t)(m >> (32 * lane));
             }
         }
     }
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void k_adaptive_threshold_t(ImgView src, int W
 #pragma unroll
         for (int j = 0; j < NDW; j++) w[k][j] = 0;
         if (rr < ROWS) {
-            const uint8_t* row = img + (size_t)min(max(ty0 + rr - R, 0), H - 1) * src.pitch; // BORDER_REPLICATE
+            const uint8_t* row = img + (uint32_t)__mul24(min(max(ty0 + rr - R, 0), H - 1), src.pitch); // BORDER_REPLICATE (24-bit multiply: full rate)
             if (x >= LEAD && x - LEAD + 4 * NDW <= W) {
 #pragma unroll
                 for (int j = 0; j < NDW; j++) w[k][j] = reinterpret_cast<const u32_unaligned_t*>(row + x - LEAD)[j];
@@ -195,11 +195,11 @@ __global__ __launch_bounds__(256) void k_adaptive_threshold_t(ImgView src, int W
             // mean = floor((s + WIN^2 / 2) / WIN^2) (<= 255: no saturation) and "v - mean <= -C" is "mean >= v + C", i.e.
             // s + WIN^2 / 2 >= WIN^2 (v + C): one 24-bit multiply-add and a compare instead of the division (a quarter-rate v_mul_hi)
             const int v = px[k * 64];
-            const bool on = (x < W) && (y < H) && (s + WIN * WIN / 2 >= WIN * WIN * (v + C));
+            const bool on = (x < W) && (y < H) && (s + WIN * WIN / 2 >= __mul24(WIN * WIN, v + C));   // (v_mul_lo_u32 without the hint)
             const unsigned long long m = __ballot(on);
             if (y < H && lane < 2) {
                 const int word = (tx0 >> 5) + lane;
-                if (word < wpr) bits[(size_t)f * bits_fstride + (size_t)y * wpr + word] = (uint32_t)(m >> (32 * lane));
+                if (word < wpr) bits[(size_t)f * bits_fstride + (uint32_t)(__mul24(y, wpr) + word)] = (uint32_t)(m >> (32 * lane));
             }
             if (k < 15) s += (int)hp[k + WIN] - (int)hp[k];
         }
@@ -880,11 +880,12 @@ __device__ __forceinline__ int relay_frame(
     }
     RL_STAMP();
     // ---- (a) padded bit image into LDS: pixel (x, y) -> bit x+1 of row y+1
+    const float inv_wpr_a = 1.0f / (float)wpr;
     for (int i = tid; i < wpr * prow; i += NT) {
-        const int py = i / wpr, j = i - py * wpr;
+        const int py = (int)(((float)i + 0.5f) * inv_wpr_a), j = i - __mul24(py, wpr); // exact: i < 2^20 (an integer division costs ~25 instructions)
         uint32_t v = 0;
         if (py >= 1 && py <= H) {
-            const uint32_t* row = gb + (size_t)(py - 1) * wpr_g;
+            const uint32_t* row = gb + (uint32_t)__mul24(py - 1, wpr_g);
             const uint32_t cur = j < wpr_g ? row[j] : 0u;
             const uint32_t prv = (j >= 1 && j - 1 < wpr_g) ? row[j - 1] : 0u;
             v = (cur << 1) | (prv >> 31);
@@ -936,8 +937,8 @@ __device__ __forceinline__ int relay_frame(
         };
         for (int it = tid; it < nitems; it += NT) {
             if (it < nrow_items) {
-                const int r = it / wpr, j = it - r * wpr, y = (r + 1) << kshift;
-                const uint32_t* row = lbits + y * wpr;
+                const int r = (int)(((float)it + 0.5f) * inv_wpr_a), j = it - __mul24(r, wpr), y = (r + 1) << kshift;
+                const uint32_t* row = lbits + __mul24(y, wpr);
                 const uint32_t cur = row[j];
                 if (!cur) continue;
                 const uint32_t cur_l = (cur << 1) | (j ? row[j - 1] >> 31 : 0u);
@@ -956,7 +957,7 @@ __device__ __forceinline__ int relay_frame(
                 unsigned long long col = 0; // bit i = pixel (x, y0 - 1 + i)
                 for (int i = 0; i < 34; i++) {
                     const int y = y0 - 1 + i;
-                    if (y <= H + 1) col |= (unsigned long long)((lbits[y * wpr + j] >> b) & 1u) << i;
+                    if (y <= H + 1) col |= (unsigned long long)((lbits[__mul24(y, wpr) + j] >> b) & 1u) << i;
                 }
                 uint32_t m = (uint32_t)(col >> 1) & (~(uint32_t)col | ~(uint32_t)(col >> 2));
                 while (m) {
@@ -1024,8 +1025,8 @@ __device__ __forceinline__ int relay_frame(
                     if (i >= nwords) drained = true;
                     else {
                         wy = 1 + (int)(((float)i + 0.5f) * inv_wpr); // exact: i < 2^20
-                        wj = i - (wy - 1) * wpr;
-                        const uint32_t* row = lbits + wy * wpr;
+                        wj = i - __mul24(wy - 1, wpr);
+                        const uint32_t* row = lbits + __mul24(wy, wpr);
                         const uint32_t* up = row - wpr;
                         const uint32_t cur = row[wj], upw = up[wj];
                         const uint32_t cur_l = (cur << 1) | (wj ? row[wj - 1] >> 31 : 0u);
@@ -1367,10 +1368,10 @@ __device__ __forceinline__ int relay_frame(
         const int ebase = mine ? atomicAdd(&s_next, mine) : 0;
         if (!GBITS) { // (a) again: the padded bit image
             for (int i = tid; i < wpr * prow; i += NT) {
-                const int py = i / wpr, j = i - py * wpr;
+                const int py = (int)(((float)i + 0.5f) * inv_wpr_a), j = i - __mul24(py, wpr);
                 uint32_t v = 0;
                 if (py >= 1 && py <= H) {
-                    const uint32_t* row = gb + (size_t)(py - 1) * wpr_g;
+                    const uint32_t* row = gb + (uint32_t)__mul24(py - 1, wpr_g);
                     const uint32_t cur = j < wpr_g ? row[j] : 0u;
                     const uint32_t prv = (j >= 1 && j - 1 < wpr_g) ? row[j - 1] : 0u;
                     v = (cur << 1) | (prv >> 31);

@@ -20,6 +20,14 @@
 
 namespace orbfe {
 
+// row * words-per-row on the device: a 24-bit multiply issues at the full rate, the 32-bit one (what `y * wpr` compiles to: the
+// compiler cannot bound the operands) at a quarter of it -- and ring8() runs once per walk step
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ORBFE_ROWMUL(y, wpr) __mul24((y), (wpr))
+#else
+#define ORBFE_ROWMUL(y, wpr) ((y) * (wpr))
+#endif
+
 // Bit image with a one-pixel zero frame: pixel (x, y) of the W x H image is bit (x+1) of row (y+1).
 struct BitImage {
     const uint32_t* bits;
@@ -27,7 +35,7 @@ struct BitImage {
     int W, H;
     ORBFE_HD int get(int px, int py) const // padded coordinates, 0 <= px < W+2, 0 <= py < H+2
     {
-        return (bits[py * wpr + (px >> 5)] >> (px & 31)) & 1;
+        return (bits[ORBFE_ROWMUL(py, wpr) + (px >> 5)] >> (px & 31)) & 1;
     }
 };
 
@@ -41,7 +49,7 @@ ORBFE_HD int dir_dy(int s) { return (int)((((1u) | (0u << 2) | (0u << 4) | (0u <
 ORBFE_HD unsigned ring8(const BitImage& im, int x, int y)
 {
     const int sh = (x - 1) & 31, w0 = (x - 1) >> 5;
-    const uint32_t* r0 = im.bits + (y - 1) * im.wpr + w0;
+    const uint32_t* r0 = im.bits + (ORBFE_ROWMUL(y - 1, im.wpr) + w0);
     const uint32_t* r1 = r0 + im.wpr;
     const uint32_t* r2 = r1 + im.wpr;
     const unsigned a = (unsigned)((((unsigned long long)r0[1] << 32) | r0[0]) >> sh) & 7u; // row y-1: x-1, x, x+1

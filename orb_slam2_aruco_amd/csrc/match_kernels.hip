@@ -133,7 +133,9 @@ __global__ __launch_bounds__(KM_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4
 #pragma unroll
         for (int s2 = 0; s2 < 8; s2++) {
             const v4i p = spread16((qa < nq ? w[s2] : 0u) >> (16 * half));
-            a[s2] = p * 255; // 0x01 -> 0xff per byte, no carries
+            v4i x = p | (p << 1); // 0x01 -> 0xff per byte with three shift-ors (x 255 is a 32-bit multiply: a quarter of the issue rate,
+            x |= x << 2;          // and the compiler turns (p << 8) - p back into one)
+            a[s2] = x | (x << 4);
         }
     }
     // the 16 rows this lane accumulates: row(reg) = (reg & 3) + 8 * (reg >> 2) + 4 * half.  Keys are ((|t| - 2 q.t) << 16) | j: the

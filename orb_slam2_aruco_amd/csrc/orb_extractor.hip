@@ -97,6 +97,12 @@ struct orbfe_extractor {
     hipStream_t user_aux = nullptr; // orbfe_extractor_set_aux_stream: run the blur there instead of on aux_stream
     hipStream_t user_early = nullptr; // orbfe_extractor_set_early_stream: FAST of level 0 there instead of on aux_stream
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork0 = nullptr, ev_join0 = nullptr;
+    // orbfe_extractor_follow: this handle's batches start behind a stage of ANOTHER handle's latest batch (two engine sets of a
+    // pipeline hold a fixed phase that way instead of whatever the contention of the moment settles on)
+    orbfe_extractor* follow = nullptr;
+    int follow_stage = 0;                // 1 = the other's FAST, 2 = its quadtree, 3 = its descriptors (the whole batch)
+    hipEvent_t ev_stage[3] = {nullptr, nullptr, nullptr};
+    bool stage_recorded = false;
     // FAST of level 0 from the start of the batch, next to the resize chain: 0 off (default), 1 on the handle's second stream (or the one
     // named by orbfe_extractor_set_early_stream), 2 on the lent one.  Measured in round 3 (profiles/r03_fast0_early.txt): the launch
     // does overlap the resize chain, but the C2 step does not move (1.5365 ms either way) -- the chip was issue-bound there already
@@ -148,6 +154,7 @@ struct orbfe_extractor {
         if (ev_join) (void)hipEventDestroy(ev_join);
         drop_graph();
         if (ev_up) (void)hipEventDestroy(ev_up);
+        for (hipEvent_t e : ev_stage) if (e) (void)hipEventDestroy(e);
         if (ev_fork0) (void)hipEventDestroy(ev_fork0);
         if (ev_join0) (void)hipEventDestroy(ev_join0);
     }
@@ -410,6 +417,8 @@ struct orbfe_extractor {
         last_nframes = B;
         last_src0 = src0;
         timer.begin();
+        if (follow && follow != this && follow->stage_recorded && follow_stage >= 1 && follow_stage <= 3)
+            ORBFE_HIP(hipStreamWaitEvent(s, follow->ev_stage[follow_stage - 1], 0));
         timer.mark(s, "start");
         auto launch_fast = [&](hipStream_t st, int cell_base, int cell_end) -> int {
             if (cell_end <= cell_base) return ORBFE_OK;
@@ -496,6 +505,12 @@ struct orbfe_extractor {
         if ((rc = launch_fast(s, fast0 ? ncells_l0 : 0, ncells_total))) return rc;
         timer.mark(s, "fast_cells");
         if (fast0) ORBFE_HIP(hipStreamWaitEvent(s, ev_join0, 0));
+        auto stage_event = [&](int k) -> int {
+            if (!ev_stage[k]) ORBFE_HIP(hipEventCreateWithFlags(&ev_stage[k], hipEventDisableTiming));
+            ORBFE_HIP(hipEventRecord(ev_stage[k], s));
+            return ORBFE_OK;
+        };
+        if ((rc = stage_event(0))) return rc;
         if (blur_place == 0) { int rcb = launch_blur(); if (rcb) return rcb; }
         {
             // fast path: count-pyramid quadtree (no keypoint movement); general kernel only for flagged levels
@@ -521,6 +536,7 @@ struct orbfe_extractor {
                                force_general_quadtree ? nullptr : d_fallback.as<int32_t>());
         }
         timer.mark(s, "distribute");
+        if ((rc = stage_event(1))) return rc;
         {
             int rc2;
             if ((rc2 = d_flatkv.ensure((size_t)B * capacity * 4)) || (rc2 = d_flatlvl.ensure((size_t)B * capacity))) return rc2;
@@ -545,6 +561,8 @@ struct orbfe_extractor {
                            d_flatkv.as<uint32_t>(), d_flatlvl.as<uint8_t>(), d_n, nlevels, d_pattern.as<uint32_t>(),
                            d_umax.as<uint4>(), d_kps_out, d_desc_out, capacity, okx, okx * B);
         timer.mark(s, "orient_describe");
+        if ((rc = stage_event(2))) return rc;
+        stage_recorded = true;
         ORBFE_HIP(hipGetLastError());
         return ORBFE_OK;
     }
@@ -833,6 +851,14 @@ int orbfe_extractor_pair_detector(orbfe_extractor* h, orbfe_aruco* detector)
     if (!h) return fail(ORBFE_ERR_INVALID, "null handle");
     if (h->paired) { aruco_speculation_wait(h->paired); aruco_unpair_notice(h->paired); }
     h->paired = detector;
+    return ORBFE_OK;
+}
+
+int orbfe_extractor_follow(orbfe_extractor* h, orbfe_extractor* other, int stage)
+{
+    if (!h || stage < 0 || stage > 3 || (other && other->device != h->device)) return fail(ORBFE_ERR_INVALID, "orbfe_extractor_follow: invalid argument");
+    h->follow = stage ? other : nullptr;
+    h->follow_stage = stage;
     return ORBFE_OK;
 }
 

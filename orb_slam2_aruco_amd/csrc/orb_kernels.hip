@@ -13,6 +13,11 @@
 #include "wave_dpp.hpp"
 
 namespace orbfe {
+// row * pitch as a 32-bit byte offset, for rows and pitches below 2^23 (any frame here): v_mul_i32_i24 issues at the full rate;
+// written as (size_t)row * pitch the product is a v_mad_u64_u32 (or a v_mul_lo_u32), which issue at a quarter of it -- and which
+// the instruction counters count as one VALU instruction like any other, so they hid in the "VALU us" of every kernel.
+__device__ __forceinline__ uint32_t off24(int row, int pitch) { return (uint32_t)__mul24(row, pitch); }
+
 
 // ------------------------------------------------------------------------------------------------ helpers --
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
@@ -100,6 +105,17 @@ __device__ __forceinline__ uint32_t hdot(uint32_t pair, uint32_t al)
     return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pair), __builtin_bit_cast(u16x2, al), 0u, false);
 }
 
+// (b * (h >> 4)) >> 16 for a weight b <= 2048 and a row sum h <= 2048 * 255 as ONE full-rate instruction: with bs = b << 12 and
+// hm = h & ~15 (both below 2^24), bs * hm = b * (h >> 4) * 2^16, and v_mul_hi_u32_u24 returns bits 32.. of that 48-bit product.
+// (Written as b * (h >> 4) the compiler cannot bound the operands and emits v_mul_lo_u32, which issues at a quarter of the rate:
+// 64 of them per thread were a third of this kernel's issue time while counting as 11 % of its instructions.)
+__device__ __forceinline__ uint32_t rs_wmul(uint32_t bs, uint32_t hm)
+{
+    uint32_t r;
+    asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(r) : "v"(bs), "v"(hm));
+    return r;
+}
+
 __global__ __launch_bounds__(256) void k_resize_tab(ImgView src, ImgView dst, int sw, int sh, int dw4, int dh,
                                                     int nthreads, const int* __restrict__ xofs,
                                                     const int* __restrict__ xal, const int* __restrict__ yofs,
@@ -135,24 +151,25 @@ __global__ __launch_bounds__(256) void k_resize_tab(ImgView src, ImgView dst, in
             const int sy = yofs[dy];
             bb[r] = ybe[dy];
             // rows are NOT clamped like columns: cv::resize keeps the fractional weight and clips the row index
-            wt[r] = *reinterpret_cast<const u64_unaligned*>(S + (size_t)min(max(sy, 0), sh - 1) * src.pitch + w0);
-            wb[r] = *reinterpret_cast<const u64_unaligned*>(S + (size_t)min(max(sy + 1, 0), sh - 1) * src.pitch + w0);
+            wt[r] = *reinterpret_cast<const u64_unaligned*>(S + (off24(min(max(sy, 0), sh - 1), src.pitch) + (uint32_t)w0));
+            wb[r] = *reinterpret_cast<const u64_unaligned*>(S + (off24(min(max(sy + 1, 0), sh - 1), src.pitch) + (uint32_t)w0));
         }
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int dy = dy0 + r0 + r;
             if (dy >= dh) break;
-            const uint32_t b0 = (uint32_t)bb[r] & 0xffffu, b1 = (uint32_t)bb[r] >> 16;
+            const uint32_t b0s = ((uint32_t)bb[r] & 0xffffu) << 12, b1s = ((uint32_t)bb[r] >> 16) << 12;
             const uint32_t tl = (uint32_t)wt[r], th = (uint32_t)(wt[r] >> 32), bl = (uint32_t)wb[r], bh = (uint32_t)(wb[r] >> 32);
             uint32_t packed = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const uint32_t h0 = hdot(__builtin_amdgcn_perm(th, tl, sel[k]), a[k]);
                 const uint32_t h1 = hdot(__builtin_amdgcn_perm(bh, bl, sel[k]), a[k]);
-                const uint32_t v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2u) >> 2;
+                // (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2
+                const uint32_t v = (rs_wmul(b0s, h0 & ~15u) + rs_wmul(b1s, h1 & ~15u) + 2u) >> 2;
                 packed |= (v & 0xffu) << (8 * k);
             }
-            *reinterpret_cast<uint32_t*>(D + (size_t)dy * dst.pitch) = packed;
+            *reinterpret_cast<uint32_t*>(D + off24(dy, dst.pitch)) = packed;
         }
     }
 }
@@ -1279,7 +1296,7 @@ __device__ __forceinline__ void bl_load_rows(const uint8_t* img, int pitch, cons
         const int rr = first_rr + (it >> 4), x = tx0 + 4 * (it & 15);
         w[k][0] = w[k][1] = w[k][2] = 0;
         if (rr < nrr && x < g.bpitch) {
-            const uint8_t* row = img + (size_t)reflect101(row0 + rr, g.h) * pitch;
+            const uint8_t* row = img + off24(reflect101(row0 + rr, g.h), pitch);
             if (x >= 4 && x + 8 <= g.w) {
                 const u32_unaligned* p = reinterpret_cast<const u32_unaligned*>(row + x - 4);
                 w[k][0] = p[0]; w[k][1] = p[1]; w[k][2] = p[2];
@@ -1393,7 +1410,7 @@ __global__ __launch_bounds__(256) BL_ATTR void k_blur7(ImgView src0, ImgView pyr
             const int y0 = tyb + 4 * q;
 #pragma unroll
             for (int j = 0; j < 4; j++)
-                if (y0 + j < g.h) *reinterpret_cast<uint32_t*>(D + x + (size_t)(y0 + j) * g.bpitch) = out[j];
+                if (y0 + j < g.h) *reinterpret_cast<uint32_t*>(D + (off24(y0 + j, g.bpitch) + (uint32_t)x)) = out[j];
         }
         if (!more) break;
         // ---- carry rows 64..69 (= rows 0..5 of the next tile) over: 3 dwords per column
@@ -1450,13 +1467,13 @@ __global__ __launch_bounds__(256) void k_orient_describe(ImgView src0, ImgView p
         // 40 bytes from the 4-byte-aligned column at or below kx - 18), the lane's four pattern tests, the 31 x 31 patch of
         // IC_Angle (rows of 36 bytes from the aligned column at or below kx - 15).  (row, dword) of a lane's item advance by a
         // constant step per item (64 = 6 * 10 + 4 = 7 * 9 + 1), so there is one division per lane, not one per item.
-        const uint8_t* bimg = blur.base + (size_t)f * blur.fstride + g.blur_off + (size_t)(ky - 18) * g.bpitch + ax;
+        const uint8_t* bimg = blur.base + (size_t)f * blur.fstride + g.blur_off + (off24(ky - 18, g.bpitch) + (uint32_t)ax);
         {
             int r = lane / 10, c = lane - r * 10;
 #pragma unroll
             for (int k = 0; k < 6; k++) {
                 const bool in = k * 64 + lane < 370;
-                wv[k] = *reinterpret_cast<const uint32_t*>(bimg + (uint32_t)((in ? r : 36) * g.bpitch + 4 * (in ? c : 9))); // 32-bit offset off a uniform base
+                wv[k] = *reinterpret_cast<const uint32_t*>(bimg + (off24(in ? r : 36, g.bpitch) + (uint32_t)(4 * (in ? c : 9)))); // 32-bit offset off a uniform base
                 r += 6; c += 4;
                 if (c >= 10) { c -= 10; r++; }
             }
@@ -1467,7 +1484,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(ImgView src0, ImgView p
         const int wrow = min(lane, 30);
         const uint4 wa = icw[wrow * 4 + 0], wb = icw[wrow * 4 + 1], oa = icw[wrow * 4 + 2], ob = icw[wrow * 4 + 3];
         const int axp = (kx - 15) & ~3, xo = (kx - 15) - axp;
-        const uint8_t* pimg = img + (size_t)(ky - 15) * pitch + axp;
+        const uint8_t* pimg = img + (off24(ky - 15, pitch) + (uint32_t)axp);
         uint32_t v[5];
         {
             int r = lane / 9, c = lane - r * 9;
@@ -1476,7 +1493,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(ImgView src0, ImgView p
                 const bool in = k * 64 + lane < 279;
                 // level 0 is the caller's buffer: no alignment is assumed there (gfx950 global loads may be unaligned)
                 typedef uint32_t u32_unaligned __attribute__((aligned(1)));
-                v[k] = *reinterpret_cast<const u32_unaligned*>(pimg + (uint32_t)((in ? r : 30) * pitch + 4 * (in ? c : 8)));
+                v[k] = *reinterpret_cast<const u32_unaligned*>(pimg + (off24(in ? r : 30, pitch) + (uint32_t)(4 * (in ? c : 8))));
                 r += 7; c += 1;
                 if (c >= 9) { c -= 9; r++; }
             }
@@ -1613,26 +1630,26 @@ __global__ __launch_bounds__(256) OD2_ATTR void k_orient_describe2(ImgView src0,
         const uint8_t* img = (level[h] == 0) ? src0.base + (size_t)f * src0.fstride : pyr.base + (size_t)f * pyr.fstride + g.img_off;
         const int pitch = (level[h] == 0) ? src0.pitch : g.pitch;
         const int bpitch = g.bpitch;
-        const uint8_t* bimg = blur.base + (size_t)f * blur.fstride + g.blur_off + (size_t)(ky[h] - 18) * bpitch + ax;
+        const uint8_t* bimg = blur.base + (size_t)f * blur.fstride + g.blur_off + (off24(ky[h] - 18, bpitch) + (uint32_t)ax);
         {
             int rr = lane / 10, c = lane - rr * 10;
 #pragma unroll
             for (int k = 0; k < 6; k++) {
                 const bool in = k * 64 + lane < 370;
-                wv[h][k] = *reinterpret_cast<const uint32_t*>(bimg + (uint32_t)((in ? rr : 36) * bpitch + 4 * (in ? c : 9)));
+                wv[h][k] = *reinterpret_cast<const uint32_t*>(bimg + (off24(in ? rr : 36, bpitch) + (uint32_t)(4 * (in ? c : 9))));
                 rr += 6; c += 4;
                 if (c >= 10) { c -= 10; rr++; }
             }
         }
         const int axp = (kx[h] - 15) & ~3;
         xo[h] = (kx[h] - 15) - axp;
-        const uint8_t* pimg = img + (size_t)(ky[h] - 15) * pitch + axp;
+        const uint8_t* pimg = img + (off24(ky[h] - 15, pitch) + (uint32_t)axp);
         {
             int rr = lane / 9, c = lane - rr * 9;
 #pragma unroll
             for (int k = 0; k < 5; k++) {
                 const bool in = k * 64 + lane < 279;
-                v[h][k] = *reinterpret_cast<const u32_unaligned*>(pimg + (uint32_t)((in ? rr : 30) * pitch + 4 * (in ? c : 8)));
+                v[h][k] = *reinterpret_cast<const u32_unaligned*>(pimg + (off24(in ? rr : 30, pitch) + (uint32_t)(4 * (in ? c : 8))));
                 rr += 7; c += 1;
                 if (c >= 9) { c -= 9; rr++; }
             }

@@ -86,7 +86,7 @@ class FrontEndPipeline:
     gather and in synchronize()."""
 
     def __init__(self, frames, rows, cols, nfeatures=1000, nlevels=8, dictionary="ARUCO", device=0, marker_capacity=64,
-                 use_orb=True, use_aruco=True, splits=1, gather=None, lend_aux_stream=True, engine_sets=None, record_sets=4, gather_stream="match"):
+                 use_orb=True, use_aruco=True, splits=1, gather=None, lend_aux_stream=True, engine_sets=None, record_sets=4, gather_stream="match", phase_pin=2):
         import torch
         self.torch = torch
         self.L = binding.load()
@@ -113,6 +113,17 @@ class FrontEndPipeline:
         self.ex_sets = [[binding.ORBextractor(nfeatures, 1.2, nlevels, 20, 7, device=device) for _ in range(S)] for _ in range(D)]
         self.exs = [e for es in self.ex_sets for e in es]
         self.ex = self.exs[0]
+        # Phase lock of the engine sets (ORBFE_PHASE_PIN = stage 1 .. 3, 0 = free running): set d's batches start behind that stage of
+        # set d - 1's latest batch, round the ring.  Free running, the two sets' chains drift into whatever phase the contention of
+        # the moment leaves them in -- the step time was bimodal from run to run (1.38 / 1.52 ms with the blur on the sets' own
+        # streams) and got LONGER when a kernel at the head of the chain got shorter (the 24-bit address arithmetic of round 3 cut
+        # the resize chain's issue time by a third and the free-running step went 1.44 -> 1.49 ms).  Behind the other set's QUADTREE
+        # (stage 2) batch i + 1's resize / FAST run next to batch i's blur join and descriptors, every step: C2 1.487 -> 1.354 ms
+        # (eight interleaved runs, 1.33 - 1.39), C3 4.19 -> 3.95; behind FAST (1) 1.45, behind the descriptors (3) 1.47.
+        self.phase_pin = int(os.environ.get("ORBFE_PHASE_PIN", phase_pin))
+        if self.phase_pin and D > 1 and S == 1:
+            for d in range(D):
+                self.ex_sets[d][0].follow(self.ex_sets[(d - 1) % D][0], self.phase_pin)
         if os.environ.get("ORBFE_BLUR_PLACE"):            # A/B of the blur's fork point: 0 after FAST, 1 before FAST, 2 no fork
             for e in self.exs:
                 e.L.orbfe_extractor_debug_kernel_times(e.h, None, 20 + int(os.environ["ORBFE_BLUR_PLACE"]))
