@@ -151,6 +151,9 @@ int orbfe_extractor_set_early_stream(orbfe_extractor* h, void* stream);
  * Two engine sets that follow each other run a fixed half-period apart instead of in whatever phase contention leaves them
  * (bench.py: measured).  `other` must outlive the relation.  Results do not depend on it. */
 int orbfe_extractor_follow(orbfe_extractor* h, orbfe_extractor* other, int stage);
+/* The same relation for any other work of the pipeline: whatever is enqueued on `stream` after this call starts behind stage 1 .. 3
+ * of the latest batch enqueued on `h` (nothing to wait for before its first batch). */
+int orbfe_extractor_stage_wait(orbfe_extractor* h, int stage, void* stream);
 
 /* Pairing for the drop-in path.  The reference builds a Frame by calling ORBextractor::operator() and then
  * MarkerDetector::detect on the SAME grey image (Frame.cc:91 / :200-206, then :142), one after the other on the Tracking thread; the

@@ -27,7 +27,7 @@ SYMBOLS = [
     "orbfe_extractor_max_keypoints", "orbfe_extract", "orbfe_extract_batch", "orbfe_extract_batch_device",
     "orbfe_extractor_batch_status", "orbfe_search_for_initialization_batch_status", "orbfe_extractor_set_gaussian_taps",
     "orbfe_extractor_debug_level_size", "orbfe_extractor_debug_level_image",
-    "orbfe_extractor_debug_level_keypoints", "orbfe_extractor_debug_kernel_times", "orbfe_extractor_set_aux_stream", "orbfe_extractor_set_early_stream", "orbfe_extractor_follow", "orbfe_extractor_pair_detector",
+    "orbfe_extractor_debug_level_keypoints", "orbfe_extractor_debug_kernel_times", "orbfe_extractor_set_aux_stream", "orbfe_extractor_set_early_stream", "orbfe_extractor_follow", "orbfe_extractor_stage_wait", "orbfe_extractor_pair_detector",
     "orbfe_debug_control", "orbfe_hamming", "orbfe_three_maxima", "orbfe_epipolar_distance_ok", "orbfe_knn2", "orbfe_knn2_csr", "orbfe_knn2_batch_device", "orbfe_search_for_initialization",
     "orbfe_search_for_initialization_batch_device", "orbfe_search_by_projection",
     "orbfe_undistort_points", "orbfe_undistort_keypoints_batch_device", "orbfe_compute_image_bounds",
@@ -88,6 +88,7 @@ def load():
     L.orbfe_extractor_debug_kernel_times.argtypes = [vp, vp, i32]
     L.orbfe_extractor_set_early_stream.argtypes = [vp, vp]
     L.orbfe_extractor_follow.argtypes = [vp, vp, i32]
+    L.orbfe_extractor_stage_wait.argtypes = [vp, i32, vp]
     L.orbfe_extractor_pair_detector.argtypes = [vp, vp]
     L.orbfe_extractor_set_aux_stream.argtypes = [vp, vp]
     if hasattr(L, "orbfe_knn2"):

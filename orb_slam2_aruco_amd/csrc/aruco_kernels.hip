@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void k_adaptive_threshold_t(ImgView src, int W
 #pragma unroll
         for (int j = 0; j < NDW; j++) w[k][j] = 0;
         if (rr < ROWS) {
-            const uint8_t* row = img + (uint32_t)__mul24(min(max(ty0 + rr - R, 0), H - 1), src.pitch); // BORDER_REPLICATE (24-bit multiply: full rate)
+            const uint8_t* row = img + (uint32_t)__mul24(min(max(ty0 + rr - R, 0), H - 1), src.pitch); // BORDER_REPLICATE (24-bit multiply: a 32-bit offset off the uniform base instead of a 64-bit v_mad_i64_i32)
             if (x >= LEAD && x - LEAD + 4 * NDW <= W) {
 #pragma unroll
                 for (int j = 0; j < NDW; j++) w[k][j] = reinterpret_cast<const u32_unaligned_t*>(row + x - LEAD)[j];
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void k_adaptive_threshold_t(ImgView src, int W
             // mean = floor((s + WIN^2 / 2) / WIN^2) (<= 255: no saturation) and "v - mean <= -C" is "mean >= v + C", i.e.
             // s + WIN^2 / 2 >= WIN^2 (v + C): one 24-bit multiply-add and a compare instead of the division (a quarter-rate v_mul_hi)
             const int v = px[k * 64];
-            const bool on = (x < W) && (y < H) && (s + WIN * WIN / 2 >= __mul24(WIN * WIN, v + C));   // (v_mul_lo_u32 without the hint)
+            const bool on = (x < W) && (y < H) && (s + WIN * WIN / 2 >= __mul24(WIN * WIN, v + C));   // (v_mul_u32_u24; v_mul_lo_u32 without the hint)
             const unsigned long long m = __ballot(on);
             if (y < H && lane < 2) {
                 const int word = (tx0 >> 5) + lane;
@@ -882,7 +882,7 @@ __device__ __forceinline__ int relay_frame(
     // ---- (a) padded bit image into LDS: pixel (x, y) -> bit x+1 of row y+1
     const float inv_wpr_a = 1.0f / (float)wpr;
     for (int i = tid; i < wpr * prow; i += NT) {
-        const int py = (int)(((float)i + 0.5f) * inv_wpr_a), j = i - __mul24(py, wpr); // exact: i < 2^20 (an integer division costs ~25 instructions)
+        const int py = (int)(((float)i + 0.5f) * inv_wpr_a), j = i - __mul24(py, wpr); // exact: i < 2^20 (an integer division by a runtime value is ~25 instructions)
         uint32_t v = 0;
         if (py >= 1 && py <= H) {
             const uint32_t* row = gb + (uint32_t)__mul24(py - 1, wpr_g);

@@ -20,8 +20,8 @@
 
 namespace orbfe {
 
-// row * words-per-row on the device: a 24-bit multiply issues at the full rate, the 32-bit one (what `y * wpr` compiles to: the
-// compiler cannot bound the operands) at a quarter of it -- and ring8() runs once per walk step
+// row * words-per-row on the device as a 24-bit multiply: it folds with the word index into one v_mad_u32_u24 (the 32-bit product
+// the compiler emits for `y * wpr` -- it cannot bound the operands -- needs a separate addition); ring8() runs once per walk step
 #if defined(__HIP_DEVICE_COMPILE__)
 #define ORBFE_ROWMUL(y, wpr) __mul24((y), (wpr))
 #else

@@ -86,7 +86,21 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 // middle value of three (the compiler emits v_med3_i32)
 __device__ __forceinline__ int med3i(int a, int b, int c) { return max(min(a, b), min(max(a, b), c)); }
 // 4 bits -> 4 bytes (bit i -> byte i)
-__device__ __forceinline__ int spread4(uint32_t x) { return (int)(((x & 15u) * 0x00204081u) & 0x01010101u); }
+__device__ __forceinline__ int spread4(uint32_t x) { return (int)(__umul24(x & 15u, 0x00204081u) & 0x01010101u); }
+// x * 255 for words of 0 / 1 bytes as (x << 8) - x, the shift written as the instruction (the compiler folds the pair back into a
+// v_mul_lo_u32 by 255: 5.3 cycles per wave against 2 x 3.4 - 4.5 for the pair, tools/valu_rate.hip -- a wash, kept for the shorter chain).
+__device__ __forceinline__ int x255_1(int x)
+{
+    int t;
+    asm("v_lshlrev_b32 %0, 8, %1" : "=v"(t) : "v"(x));
+    return t - x;
+}
+__device__ __forceinline__ v4i x255(v4i p)
+{
+    v4i r;
+    r.x = x255_1(p.x); r.y = x255_1(p.y); r.z = x255_1(p.z); r.w = x255_1(p.w);
+    return r;
+}
 __device__ __forceinline__ v4i spread16(uint32_t bits)
 {
     v4i r;
@@ -133,9 +147,7 @@ __global__ __launch_bounds__(KM_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4
 #pragma unroll
         for (int s2 = 0; s2 < 8; s2++) {
             const v4i p = spread16((qa < nq ? w[s2] : 0u) >> (16 * half));
-            v4i x = p | (p << 1); // 0x01 -> 0xff per byte with three shift-ors (x 255 is a 32-bit multiply: a quarter of the issue rate,
-            x |= x << 2;          // and the compiler turns (p << 8) - p back into one)
-            a[s2] = x | (x << 4);
+            a[s2] = x255(p); // 0x01 -> 0xff per byte, no carries
         }
     }
     // the 16 rows this lane accumulates: row(reg) = (reg & 3) + 8 * (reg >> 2) + 4 * half.  Keys are ((|t| - 2 q.t) << 16) | j: the

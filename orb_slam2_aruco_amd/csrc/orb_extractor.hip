@@ -862,6 +862,15 @@ int orbfe_extractor_follow(orbfe_extractor* h, orbfe_extractor* other, int stage
     return ORBFE_OK;
 }
 
+int orbfe_extractor_stage_wait(orbfe_extractor* h, int stage, void* stream)
+{
+    if (!h || stage < 1 || stage > 3) return fail(ORBFE_ERR_INVALID, "orbfe_extractor_stage_wait: invalid argument");
+    int rc = use_device(h->device);
+    if (rc) return rc;
+    if (h->stage_recorded) ORBFE_HIP(hipStreamWaitEvent((hipStream_t)stream, h->ev_stage[stage - 1], 0));
+    return ORBFE_OK;
+}
+
 int orbfe_extractor_set_early_stream(orbfe_extractor* h, void* stream)
 {
     if (!h) return fail(ORBFE_ERR_INVALID, "null handle");

@@ -13,9 +13,11 @@
 #include "wave_dpp.hpp"
 
 namespace orbfe {
-// row * pitch as a 32-bit byte offset, for rows and pitches below 2^23 (any frame here): v_mul_i32_i24 issues at the full rate;
-// written as (size_t)row * pitch the product is a v_mad_u64_u32 (or a v_mul_lo_u32), which issue at a quarter of it -- and which
-// the instruction counters count as one VALU instruction like any other, so they hid in the "VALU us" of every kernel.
+// row * pitch as a 32-bit byte offset, for rows and pitches below 2^23 (any frame here).  Written as (size_t)row * pitch the product
+// is a v_mad_u64_u32 into a register PAIR followed by a 64-bit pointer addition; as a 32-bit offset off a uniform base it is one
+// v_mul_i32_i24 (or v_mad_u32_u24 with the column) and the load takes the base from scalar registers: fewer instructions and
+// registers (k_blur7 68 -> 64, k_orient_describe2 64 -> 58), not a faster multiply -- 32-bit multiplies are NOT quarter-rate on
+// gfx950 (tools/valu_rate.hip: 5.3 against 4.9 cycles per wave).
 __device__ __forceinline__ uint32_t off24(int row, int pitch) { return (uint32_t)__mul24(row, pitch); }
 
 
@@ -107,8 +109,7 @@ __device__ __forceinline__ uint32_t hdot(uint32_t pair, uint32_t al)
 
 // (b * (h >> 4)) >> 16 for a weight b <= 2048 and a row sum h <= 2048 * 255 as ONE full-rate instruction: with bs = b << 12 and
 // hm = h & ~15 (both below 2^24), bs * hm = b * (h >> 4) * 2^16, and v_mul_hi_u32_u24 returns bits 32.. of that 48-bit product.
-// (Written as b * (h >> 4) the compiler cannot bound the operands and emits v_mul_lo_u32, which issues at a quarter of the rate:
-// 64 of them per thread were a third of this kernel's issue time while counting as 11 % of its instructions.)
+// (Written as (b * (h >> 4)) >> 16 it is three: shift, v_mul_lo_u32, shift -- 192 of the thread's ~570 instructions.)
 __device__ __forceinline__ uint32_t rs_wmul(uint32_t bs, uint32_t hm)
 {
     uint32_t r;
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(ImgView src0, ImgView pyr, c
         const int rpi = 64 / ndw;                      // rows per trip of the wave
         const int y0 = (int)(((float)lane + 0.5f) * (1.0f / (float)ndw)), c = lane - __mul24(y0, ndw); // exact: lane < 64
         const uint8_t* roi = img + (size_t)iniY * pitch + iniX - 1;
-        // (24-bit multiplies: v_mul_lo_u32 runs at a quarter of the rate)
+        // (24-bit multiplies fold into v_mad_u32_u24 with the column offset)
         uint32_t go = (uint32_t)(__mul24(y0, pitch) + 4 * c), so_ = (uint32_t)(__mul24(y0, SP) + 4 * c);
         const uint32_t gstep = (uint32_t)(rpi * pitch), sstep = (uint32_t)(rpi * SP);
         // no predicates (a load under a condition becomes a branch with a wait behind it): a row past the end -- and with it the

@@ -115,12 +115,14 @@ class FrontEndPipeline:
         self.ex = self.exs[0]
         # Phase lock of the engine sets (ORBFE_PHASE_PIN = stage 1 .. 3, 0 = free running): set d's batches start behind that stage of
         # set d - 1's latest batch, round the ring.  Free running, the two sets' chains drift into whatever phase the contention of
-        # the moment leaves them in -- the step time was bimodal from run to run (1.38 / 1.52 ms with the blur on the sets' own
-        # streams) and got LONGER when a kernel at the head of the chain got shorter (the 24-bit address arithmetic of round 3 cut
-        # the resize chain's issue time by a third and the free-running step went 1.44 -> 1.49 ms).  Behind the other set's QUADTREE
-        # (stage 2) batch i + 1's resize / FAST run next to batch i's blur join and descriptors, every step: C2 1.487 -> 1.354 ms
-        # (eight interleaved runs, 1.33 - 1.39), C3 4.19 -> 3.95; behind FAST (1) 1.45, behind the descriptors (3) 1.47.
+        # the moment leaves them in: the step time was bimodal from run to run (1.38 / 1.52 ms with the blur on the sets' own
+        # streams) and got LONGER when kernels got cheaper (the address-arithmetic rewrite of round 3 -- fewer instructions, k_blur7
+        # at 64 registers -- took the free-running step 1.42 -> 1.49 ms).  Behind the other set's QUADTREE (stage 2) batch i + 1's
+        # resize / FAST run next to batch i's blur join and descriptors, every step: C2 1.49 -> 1.355 ms (1.33 - 1.39 over eight
+        # interleaved runs; the old kernels under the same lock: 1.40), C3 4.19 -> 3.95; behind FAST (1) 1.45, behind the
+        # descriptors (3) 1.47.
         self.phase_pin = int(os.environ.get("ORBFE_PHASE_PIN", phase_pin))
+        self.det_pin = int(os.environ.get("ORBFE_DET_PIN", 0))
         if self.phase_pin and D > 1 and S == 1:
             for d in range(D):
                 self.ex_sets[d][0].follow(self.ex_sets[(d - 1) % D][0], self.phase_pin)
@@ -247,6 +249,8 @@ class FrontEndPipeline:
                 if multi and i >= self.R:
                     st.wait_event(self.gather_done[cur])         # batch i-R has left this record set
                 sp = ctypes.c_void_p(st.cuda_stream)
+                if self.det_pin and self.use_orb and i > 0:   # experiment: the detector's batch behind a stage of the extractor's previous one
+                    binding._check(L, L.orbfe_extractor_stage_wait(self.ex_sets[(i - 1) % self.D][k].h, self.det_pin, sp), "stage_wait")
                 dets[k].detect_batch_device(img0 + f0 * rows * pitch, nf, rows * pitch, rows, cols, pitch,
                                                  base + lay.mk + f0 * mcap * 36, mcap, base + lay.nmk + f0 * 4, sp)
                 # detect(image, CameraParameters, 0.187): every marker gets its IPPE pose (markerdetector_impl.cpp:8720-8780)
