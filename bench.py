@@ -364,6 +364,7 @@ def main():
     defaults = {"ORBFE_ORIENT_PAIR": "1", "ORBFE_FAST0": "0", "ORBFE_EARLY_SHARED": "0", "ORBFE_ARUCO_VIS": "0", "ORBFE_ARUCO_FORCE_GLOBAL": "0", "ORBFE_STREAM_PRIO": "0,0,0", "ORBFE_ENGINE_SETS_ARUCO": "1", "ORBFE_PHASE_PIN": "2", "ORBFE_DET_PIN": "0", "ORBFE_LEND_ALL": "1", "ORBFE_RECORD_SETS": "4", "ORBFE_GATHER_STREAM": "match", "ORBFE_DET_NOFORK": "0",
                 "ORBFE_BLUR_PLACE": "1", "ORBFE_ARUCO_RELAY_CHUNK": "0", "ORBFE_OCC_FAST": "0", "ORBFE_OCC_BLUR": "0",
                 "ORBFE_OCC_ORIENT": "0"}
+    defaults["ORBFE_DET_NOFORK"] = "1" if args.rows * args.cols <= 640 * 480 else "0"    # pipeline.py: by frame size
     env_nondefault = {k: v for k, v in env_set.items() if k not in harmless and defaults.get(k) != v}
     B, rows, cols = args.frames, args.rows, args.cols
     use_aruco, use_orb = not args.no_aruco, not args.no_orb

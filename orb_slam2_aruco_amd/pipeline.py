@@ -186,8 +186,12 @@ class FrontEndPipeline:
                 self.sp4 = ctypes.c_void_p(self.stream4.cuda_stream)
                 self.det.set_aux_stream(self.sp4)
                 self.ex.set_early_stream(self.sp4)
-        if use_aruco and S == 1 and os.environ.get("ORBFE_DET_NOFORK", "0") != "0":
-            # experiment: the detector's /2 pyramid in line on the detector's stream (one active stream fewer)
+        # The detector's /2 pyramid in line on the detector's stream instead of forked onto the handle's second stream: one active
+        # stream fewer.  Measured as "no gain" while the engine sets were free-running; under the phase lock, frames up to VGA size:
+        # C2 1.360 -> 1.320 ms (six interleaved runs each, 1.305 - 1.335), the gather branch 1.393 -> 1.364; 1280 x 720 loses (3.99 ->
+        # 4.05: the pyramid there is 0.3 ms of HBM-bound work worth hiding), 1920 x 1080 does not care.
+        self.det_nofork = os.environ.get("ORBFE_DET_NOFORK", "1" if rows * cols <= 640 * 480 else "0") != "0"
+        if use_aruco and S == 1 and self.det_nofork:
             for dset, sset in zip(self.det_sets, self.aru_stream_sets):
                 dset[0].set_aux_stream(ctypes.c_void_p(sset[0].cuda_stream))
         ev = lambda **kw: torch.cuda.Event(**kw)

@@ -194,3 +194,26 @@ def test_hipgraph_replay_of_the_host_pointer_call():
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "replays ok" in r.stdout, r.stdout[-1000:] + r.stderr[-2000:]
     assert "hipGraph capture ok" in r.stderr, r.stderr[-1000:]
+
+
+def test_phase_lock_between_handles_changes_no_result(orbfe, oracle):
+    """orbfe_extractor_follow: a handle's batches start behind a stage of another handle's latest batch (the engine sets of the
+    batched pipeline).  Ordering only: results are those of the free-running handles; arguments outside the ranges are refused."""
+    imgs = [synth.scene(480, 640, 300 + i, "ARUCO", 2)[0] for i in range(4)]
+    free = orbfe.ORBextractor(1000, 1.2, 8, 20, 7)
+    want = [free(im) for im in imgs]
+    a, b = orbfe.ORBextractor(1000, 1.2, 8, 20, 7), orbfe.ORBextractor(1000, 1.2, 8, 20, 7)
+    for stage in (1, 2, 3):
+        a.follow(b, stage); b.follow(a, stage)
+        for i, im in enumerate(imgs):
+            kps, desc = (a if i % 2 == 0 else b)(im)
+            assert np.array_equal(kps, want[i][0]) and np.array_equal(desc, want[i][1])
+    a.follow(None, 0); b.follow(a, 0)
+    kps, desc = a(imgs[0])
+    assert np.array_equal(kps, want[0][0])
+    with pytest.raises(orbfe.OrbfeError):
+        a.follow(b, 4)
+    L = a.L
+    assert L.orbfe_extractor_stage_wait(a.h, 0, None) != 0 and L.orbfe_extractor_stage_wait(a.h, 4, None) != 0
+    assert L.orbfe_extractor_stage_wait(a.h, 2, None) == 0      # the null stream waits for a's latest quadtree: harmless
+    assert np.array_equal(b(imgs[1])[0], want[1][0])
