@@ -805,6 +805,16 @@ __device__ __forceinline__ void rl_advance(const BitImage& im, RelayWalk& w, uns
     w.ring = ring8(im, w.x, w.y);
 }
 
+#ifndef RL_FETCH_GATE
+#define RL_FETCH_GATE 1
+#endif
+// RL_FETCH_GATE > 1 (experiment, build parameter): a walk loop refills its idle lanes only when at least that many lanes of the wave
+// are idle (or none is walking), so that the refill block is issued for many lanes at a time instead of a few on every trip
+#if RL_FETCH_GATE > 1
+#define RL_GATE_OPEN(busy, drained) (__popcll(__ballot(!(busy) && !(drained))) >= RL_FETCH_GATE || !__any(busy))
+#else
+#define RL_GATE_OPEN(busy, drained) true
+#endif
 // returns 1 if the frame has to be done again without a grid (force_nogrid), else 0
 #if RL_THREADS == 1024
 #define RL_VGPR_ATTR __attribute__((amdgpu_num_vgpr(64))) // two workgroups (32 waves) share a CU
@@ -1019,7 +1029,7 @@ __device__ __forceinline__ int relay_frame(
 #ifdef ORBFE_CT_TIMING
             dbg_iters++;
 #endif
-            if (!busy && !drained) {
+            if (!busy && !drained && RL_GATE_OPEN(busy, drained)) {
                 if (!(m_outer | m_hole)) {
                     const int i = atomicAdd(&s_next, 1);
                     if (i >= nwords) drained = true;
@@ -1121,7 +1131,7 @@ __device__ __forceinline__ int relay_frame(
         int slot = 0, mnoff = 0;
         uint32_t mn = 0xffffffffu, mnhole = 0;
         for (;;) {
-            if (!busy && !drained) {
+            if (!busy && !drained && RL_GATE_OPEN(busy, drained)) {
                 const int i = atomicAdd(&s_next_d, 1);
                 if (i >= T) drained = true;
                 else {

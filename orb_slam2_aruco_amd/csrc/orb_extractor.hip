@@ -715,12 +715,12 @@ int orbfe_extract_batch(orbfe_extractor* h, const uint8_t* imgs, int nframes, si
     };
     const uint64_t key = h->graph_key(nframes, rows, cols, hp);
     bool replayed = false;
-    if (h->use_graph && !spec && !h->timer.enabled && key == h->g_key && h->g_exec) {
+    if (h->use_graph && !spec && !h->follow && !h->timer.enabled && key == h->g_key && h->g_exec) {
         if (hipGraphLaunch(h->g_exec, s) == hipSuccess) replayed = true;
         else h->drop_graph();
     }
     if (!replayed) {
-        const bool capture = h->use_graph && !spec && !h->timer.enabled && key == h->g_key && !h->g_exec && ++h->g_seen >= 2;
+        const bool capture = h->use_graph && !spec && !h->follow && !h->timer.enabled && key == h->g_key && !h->g_exec && ++h->g_seen >= 2; // (a followed handle waits for an event recorded outside the capture)
         if (key != h->g_key) { h->drop_graph(); h->g_key = key; h->g_seen = 0; }
         bool captured = false;
         if (capture && hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
