@@ -532,6 +532,10 @@ int orbfe_aruco_max_markers(const orbfe_aruco* h);
 int orbfe_aruco_set_error_correction_rate(orbfe_aruco* h, float rate);
 int orbfe_aruco_set_detection_mode(orbfe_aruco* h, int mode, float min_marker_size);
 int orbfe_aruco_set_corner_refinement(orbfe_aruco* h, int method);
+/* Params::detectEnclosedMarkers (markerdetector.h:126): markers whose corners touch other dark squares (chessboard-like boards).
+ * With THRES_AUTO_FIXED the thresholded image is replaced by its inner edge band (erode with a cross, xor); in every mode each
+ * rectangle candidate is enlarged by half the threshold window along its diagonals (markerdetector_impl.cpp:2871-2950, :10620-10690). */
+int orbfe_aruco_set_enclosed_markers(orbfe_aruco* h, int on);
 int orbfe_aruco_get_state(const orbfe_aruco* h, int32_t* threshold, float* min_size, int32_t* attempts, int32_t* work_rows,
                           int32_t* work_cols);
 /* cvtColor(BGR2GRAY) of the CV_8UC3 entry points: 14 fractional bits (OpenCV <= 3.4.1: B 1868, G 9617, R 4899; default) or 15

@@ -41,6 +41,11 @@ public:
             detectMode = dm;
             minSize = minMarkerSize;
         }
+        void detectEnclosedMarkers(bool do_) // markerdetector.h:126
+        {
+            check(orbfe_aruco_set_enclosed_markers(owner->handle(), do_ ? 1 : 0));
+            enclosedMarker = do_;
+        }
         void setCornerRefinementMethod(CornerRefinementMethod method)
         {
             check(orbfe_aruco_set_corner_refinement(owner->handle(), (int)method));
@@ -50,6 +55,7 @@ public:
         DetectionMode detectMode = DM_NORMAL;
         CornerRefinementMethod cornerRefinementM = CORNER_LINES;
         float minSize = 0;
+        bool enclosedMarker = false;
         float error_correction_rate = 0;
         std::string dictionary = "ARUCO";
         int maxThreads = 1;

@@ -403,6 +403,25 @@ void threshold_fixed_inv(const Image& src, Image& dst, int thr)
     for (size_t i = 0; i < src.d.size(); i++) dst.d[i] = src.d[i] > thr ? 0 : 255;
 }
 
+/* Params::detectEnclosedMarkers with THRES_AUTO_FIXED (markerdetector_impl.cpp:2871-2950): erode with a MORPH_CROSS element of
+ * size k (anchor at its centre; pixels outside the image do not constrain the minimum: morphologyDefaultBorderValue), then
+ * bitwise_xor with the thresholded image -- the inner edge band of every thresholded region */
+void erode_cross_xor(Image& thres, int k)
+{
+    const int r = k / 2, w = thres.w, h = thres.h;
+    Image er(w, h);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            uint8_t m = 255;
+            for (int d = -r; d <= r; d++) {
+                if (x + d >= 0 && x + d < w) m = std::min(m, thres.row(y)[x + d]);
+                if (y + d >= 0 && y + d < h) m = std::min(m, thres.row(y + d)[x]);
+            }
+            er.row(y)[x] = m;
+        }
+    for (size_t i = 0; i < thres.d.size(); i++) thres.d[i] ^= er.d[i];
+}
+
 /* cv::resize(src, dst, dsize, 0, 0, INTER_NEAREST) (resize.cpp resizeNN): sx = min(floor(x * ifx), sw - 1), ifx = 1 / (dw / sw) */
 void resize_nearest(const Image& src, Image& dst)
 {
@@ -706,6 +725,7 @@ struct Detector {
     float minSize = 0.f;       /* what setDetectionMode(dm, minMarkerSize) leaves (the default -1 behaves like 0) */
     bool autoSize = false;
     float ts = 0.25f;
+    bool enclosed = false;     /* Params::enclosedMarker (detectEnclosedMarkers) */
     int last_attempts = 0;     /* threshold passes of the last call (test read-back) */
     int last_work_w = 0, last_work_h = 0;
     /* stage data of the last call (per-stage parity tests) */
@@ -777,8 +797,15 @@ struct Detector {
         int w = std::max(3, int(15 * float(gray.w) / 1920.));
         if (w % 2 == 0) w++;
         win = w; /* = _tooNearDistance */
-        if (thres_method == 1) threshold_fixed_inv(gray, thres, ThresHold); /* THRES_AUTO_FIXED (:2833-2870) */
-        else adaptive_threshold_inv(gray, thres, w, ThresHold);
+        int enlarge_k = w; /* the adaptive window; the erosion size with THRES_AUTO_FIXED (:2871-2990) */
+        if (thres_method == 1) { /* THRES_AUTO_FIXED (:2833-2870) */
+            threshold_fixed_inv(gray, thres, ThresHold);
+            if (enclosed) {
+                enlarge_k = int(std::max(3.0, 3. / 1920. * float(thres.w)));
+                if (enlarge_k % 2 == 0) enlarge_k++;
+                erode_cross_xor(thres, enlarge_k);
+            }
+        } else adaptive_threshold_inv(gray, thres, w, ThresHold);
         std::vector<std::vector<Pt>> contours;
         find_contours_list(thres, contours);
         rects.clear();
@@ -790,10 +817,38 @@ struct Detector {
                 if (approx.size() == 4 && is_contour_convex(approx.data(), 4)) {
                     Candidate cd;
                     for (int j = 0; j < 4; j++) cd.c[j] = Ptf{(float)approx[j].x, (float)approx[j].y};
+                    if (enclosed) enlarge_candidate(cd, float(enlarge_k) / 2.);
                     cd.contour = c;
                     rects.push_back(std::move(cd));
                 }
             }
+        }
+    }
+
+    /* enlargeMarkerCandidate (:10620-10690): both diagonals pushed outwards by `fact` pixels along the octant of their direction */
+    static void enlarge_candidate(Candidate& cand, int fact)
+    {
+        for (int j = 0; j < 2; j++) {
+            int startp = j, endp = (j + 2) % 4;
+            if (cand.c[startp].x > cand.c[endp].x) std::swap(startp, endp);
+            const float _180 = 3.14159f;
+            const float _22 = 3.14159 / 8.f;
+            const float _3_22 = 3. * 3.14159f / 8.f;
+            const float _5_22 = 5.f * 3.14159f / 8.f;
+            const float _7_22 = 7.f * 3.14159f / 8.f;
+            int incx = 0, incy = 0;
+            const float vx = cand.c[endp].x - cand.c[startp].x, vy = cand.c[endp].y - cand.c[startp].y;
+            const float angle = std::atan2(vy, vx);
+            if (_22 < angle && angle < 3 * _22) incx = incy = fact;
+            else if (-_22 < angle && angle < _22) { incx = fact; incy = 0; }
+            else if (-_3_22 < angle && angle < -_22) { incx = fact; incy = -fact; }
+            else if (-_5_22 < angle && angle < -_3_22) { incx = 0; incy = -fact; }
+            else if (-_7_22 < angle && angle < -_5_22) { incx = -fact; incy = -fact; }
+            else if ((-_180 < angle && angle < -_7_22) || (_7_22 < angle && angle < _180)) { incx = -fact; incy = 0; }
+            else if (_5_22 < angle && angle < _7_22) { incx = -fact; incy = fact; }
+            else if (_3_22 < angle && angle < _5_22) { incx = fact; incy = fact; }
+            cand.c[endp].x += incx; cand.c[endp].y += incy;
+            cand.c[startp].x -= incx; cand.c[startp].y -= incy;
         }
     }
 
@@ -1061,6 +1116,7 @@ void oracle_aruco_set_params(void* h, float error_correction_rate, int corner_li
 /* setDetectionMode(dm, minMarkerSize) then setCornerRefinementMethod(corner_method), in the order a caller of the reference uses */
 void oracle_aruco_set_detection_mode(void* h, int dm, float min_marker_size) { ((Detector*)h)->set_detection_mode(dm, min_marker_size); }
 void oracle_aruco_set_corner_method(void* h, int m) { ((Detector*)h)->set_corner_method(m); }
+void oracle_aruco_set_enclosed(void* h, int on) { ((Detector*)h)->enclosed = on != 0; }
 /* state read-back: 0 ThresHold, 1 threshold passes of the last call, 2 / 3 working width / height of the last call */
 int oracle_aruco_state(void* h, int which)
 {

@@ -93,11 +93,12 @@ struct orbfe_aruco {
     float min_size = 0.f;        // Params::minSize as setDetectionMode / the automatic size estimation leave it
     bool auto_size = false;      // Params::autoSize (DM_VIDEO_FAST)
     float ts = 0.25f;
+    bool enclosed = false;       // Params::enclosedMarker (detectEnclosedMarkers, markerdetector.h:126)
     int gray_bits15 = 0;         // BGR2GRAY with 15 fractional bits (OpenCV 3.4.2+) instead of 14
     int pyr_rows = 0, pyr_cols = 0;   // the frame the /2 pyramid starts from (the working image is smaller when minSize > 0)
     int last_attempts = 0, last_work_rows = 0, last_work_cols = 0;
     size_t rl_static = 0;
-    DevBuf d_red, d_mhist, d_masks, d_bgr;
+    DevBuf d_red, d_mhist, d_masks, d_bgr, d_bits2;
     bool stateful() const { return thres_method == 1 || auto_size; } // a frame's result depends on the frames before it
     KernelTimer timer;
     int last_nframes = 0;
@@ -106,7 +107,7 @@ struct orbfe_aruco {
     {
         for (DevBuf* b : {&d_codes, &d_levels, &d_tabs, &d_bits, &d_pyr, &d_candq, &d_pool, &d_kept, &d_rects,
                           &d_counts, &d_candidx, &d_ncand, &d_result, &d_gpad, &d_in, &d_out, &d_nout, &d_segs, &d_tailkeys, &d_tailoff, &d_small, &d_hint, &d_rstate, &d_lut, &d_twork, &d_trect, &d_tctr, &d_dwork, &d_dctr, &d_ditems, &d_dhist, &d_dpatch, &d_vis, &d_poses, &d_scodes, &d_sids,
-                          &d_msrc, &d_red, &d_mhist, &d_masks, &d_bgr})
+                          &d_msrc, &d_red, &d_mhist, &d_masks, &d_bgr, &d_bits2})
             b->release();
         if (own_stream) (void)hipStreamDestroy(own_stream);
         if (aux_stream) (void)hipStreamDestroy(aux_stream);
@@ -383,14 +384,24 @@ struct orbfe_aruco {
         }
         timer.mark(aux_stream, "pyramid");
         ORBFE_HIP(hipEventRecord(ev_join, aux_stream));
+        int enlarge_k = win;   // detectEnclosedMarkers: the candidates grow by half the adaptive window, or half the erosion size
         for (int r_ = 0; r_ < ORBFE_REPS_ARUCO(8); r_++) {
             const dim3 tg((cols + 63) / 64, (rows + 63) / 64, B);
             const int ntx = (cols + 63) / 64, ntl = ntx * ((rows + 63) / 64);
             const dim3 tg1(xcd_grid(ntl * B));
             uint32_t* bp = d_bits.as<uint32_t>();
-            if (mr && mr->fixed_thr >= 0)   // THRES_AUTO_FIXED: cv::threshold(THRESH_BINARY_INV) at the carried-over threshold
-                hipLaunchKernelGGL(k_fixed_threshold, dim3((wpr * rows + 255) / 256, B), dim3(256), 0, s, srcW, cols, rows, mr->fixed_thr, bp, bits_fu32, wpr);
-            else if (th_magic && win == 5) hipLaunchKernelGGL(k_adaptive_threshold_t<5>, tg1, dim3(256), 0, s, srcW, cols, rows, thres_value, th_magic, bp, bits_fu32, wpr, ntx, ntl, ntl * B);
+            if (mr && mr->fixed_thr >= 0) {   // THRES_AUTO_FIXED: cv::threshold(THRESH_BINARY_INV) at the carried-over threshold
+                if (enclosed) {               // detectEnclosedMarkers: the inner edge band of the thresholded regions (erode + xor)
+                    if ((rc = d_bits2.ensure(bits_fu32 * 4 * B))) return rc;
+                    int k = int(std::max(3.0, 3. / 1920. * float(cols)));
+                    if (k % 2 == 0) k++;
+                    enlarge_k = k;
+                    if (k / 2 > 15) return fail(ORBFE_ERR_INVALID, "detectEnclosedMarkers: frame too wide (erosion size %d)", k);
+                    hipLaunchKernelGGL(k_fixed_threshold, dim3((wpr * rows + 255) / 256, B), dim3(256), 0, s, srcW, cols, rows, mr->fixed_thr, d_bits2.as<uint32_t>(), bits_fu32, wpr);
+                    hipLaunchKernelGGL(k_erode_cross_xor, dim3((wpr * rows + 255) / 256, B), dim3(256), 0, s, d_bits2.as<uint32_t>(), bp, bits_fu32, wpr, cols, rows, k / 2);
+                } else
+                    hipLaunchKernelGGL(k_fixed_threshold, dim3((wpr * rows + 255) / 256, B), dim3(256), 0, s, srcW, cols, rows, mr->fixed_thr, bp, bits_fu32, wpr);
+            } else if (th_magic && win == 5) hipLaunchKernelGGL(k_adaptive_threshold_t<5>, tg1, dim3(256), 0, s, srcW, cols, rows, thres_value, th_magic, bp, bits_fu32, wpr, ntx, ntl, ntl * B);
             else if (th_magic && win == 7) hipLaunchKernelGGL(k_adaptive_threshold_t<7>, tg1, dim3(256), 0, s, srcW, cols, rows, thres_value, th_magic, bp, bits_fu32, wpr, ntx, ntl, ntl * B);
             else if (th_magic && win == 11) hipLaunchKernelGGL(k_adaptive_threshold_t<11>, tg1, dim3(256), 0, s, srcW, cols, rows, thres_value, th_magic, bp, bits_fu32, wpr, ntx, ntl, ntl * B);
             else if (th_magic && win == 15) hipLaunchKernelGGL(k_adaptive_threshold_t<15>, tg1, dim3(256), 0, s, srcW, cols, rows, thres_value, th_magic, bp, bits_fu32, wpr, ntx, ntl, ntl * B);
@@ -470,6 +481,9 @@ struct orbfe_aruco {
                            gpad_fu32, 0);
         timer.mark(s, "contours");
         ORBFE_HIP(hipGetLastError());
+        if (enclosed)   // enlargeMarkerCandidate on every rectangle, before prefilterCandidates sees them (:3560-3590)
+            hipLaunchKernelGGL(k_enlarge_candidates, dim3(B), dim3(AR_MAX_RECTS), 0, s, d_rects.as<ArRect>(), AR_MAX_RECTS, d_counts.as<int32_t>(),
+                               (int)(float(enlarge_k) / 2.));
         if (decode_dirty) ORBFE_HIP(hipMemsetAsync(d_dctr.p, 0, 16, s));   // a previous batch was abandoned between prefilter and finalize
         decode_dirty = true;
         hipLaunchKernelGGL(k_prefilter, dim3(B), dim3(256), 0, s, d_rects.as<ArRect>(), AR_MAX_RECTS,
@@ -692,6 +706,13 @@ int orbfe_aruco_set_corner_refinement(orbfe_aruco* h, int method)
     if (method < 0 || method > 2) return fail(ORBFE_ERR_INVALID, "corner refinement method %d: CORNER_SUBPIX 0, CORNER_LINES 1, CORNER_NONE 2", method);
     h->corner_method = method;
     if (method != 0) h->min_size = 0.f;
+    return ORBFE_OK;
+}
+
+int orbfe_aruco_set_enclosed_markers(orbfe_aruco* h, int on)
+{
+    if (!h) return fail(ORBFE_ERR_INVALID, "null handle");
+    h->enclosed = on != 0;
     return ORBFE_OK;
 }
 

@@ -98,6 +98,8 @@ __global__ void k_finalize(const ArRect* rects, int rect_cap, const int32_t* can
                            int out_cap, int32_t* n_out, int refine_lines, int32_t* out_src, int32_t* wctr);
 // aruco_modes.hip: THRES_AUTO_FIXED, Params::minSize > 0, CORNER_SUBPIX, CV_8UC3 input
 __global__ void k_fixed_threshold(ImgView src, int W, int H, int thr, uint32_t* bits, size_t bits_fstride, int wpr);
+__global__ void k_erode_cross_xor(const uint32_t* in, uint32_t* out, size_t bits_fstride, int wpr, int W, int H, int r);
+__global__ void k_enlarge_candidates(ArRect* rects, int rect_cap, const int32_t* counts, int fact);
 __global__ void k_resize_nearest(ImgView src, ImgView dst, int sw, int sh, int dw, int dh, double ifx, double ify);
 __global__ void k_bgr_to_gray(const uint8_t* bgr, size_t bgr_fstride, size_t step, ImgView dst, int W, int H, int bits15);
 __global__ void k_marker_hist(const uint32_t* work, const int32_t* wctr, const int32_t* result, int rect_cap, const uint16_t* hist,

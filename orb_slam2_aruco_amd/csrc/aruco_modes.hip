@@ -40,6 +40,64 @@ __global__ __launch_bounds__(256) void k_fixed_threshold(ImgView src, int W, int
     bits[(size_t)f * bits_fstride + i] = word;
 }
 
+// Params::detectEnclosedMarkers with THRES_AUTO_FIXED (markerdetector_impl.cpp:2871-2950): cv::erode with a MORPH_CROSS element of
+// size 2 r + 1 (pixels outside the image do not constrain the minimum) and bitwise_xor with the thresholded image, on the bit
+// image: out = b & ~(AND over the row run & AND over the column run).  One 32-pixel word per thread; r <= 15.
+__global__ __launch_bounds__(256) void k_erode_cross_xor(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t bits_fstride,
+                                                         int wpr, int W, int H, int r)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
+    if (i >= wpr * H) return;
+    const int y = i / wpr, j = i - y * wpr;
+    const uint32_t* b = in + (size_t)f * bits_fstride;
+    // a word with the pixels outside the image set (they must not clear anything): bits >= W of the last word, words outside the row
+    auto ext = [&](int yy, int jj) -> uint32_t {
+        if (yy < 0 || yy >= H || jj < 0 || jj >= wpr) return 0xffffffffu;
+        const int nvalid = W - 32 * jj;
+        const uint32_t v = b[(size_t)yy * wpr + jj];
+        return nvalid >= 32 ? v : v | ~((1u << nvalid) - 1u);
+    };
+    const uint32_t cur = ext(y, j), prv = ext(y, j - 1), nxt = ext(y, j + 1);
+    uint32_t hand = cur, vand = cur;
+    for (int d = 1; d <= r; d++) {
+        hand &= (cur >> d) | (nxt << (32 - d));   // pixel x + d
+        hand &= (cur << d) | (prv >> (32 - d));   // pixel x - d
+        vand &= ext(y - d, j) & ext(y + d, j);
+    }
+    out[(size_t)f * bits_fstride + i] = b[(size_t)y * wpr + j] & ~(hand & vand);
+}
+
+// enlargeMarkerCandidate (markerdetector_impl.cpp:10620-10690, Params::detectEnclosedMarkers): both diagonals of every rectangle
+// candidate pushed outwards by `fact` pixels along the octant of their direction (the reference's own octant limits, 3.14159 / 8 ...)
+__global__ __launch_bounds__(256) void k_enlarge_candidates(ArRect* __restrict__ rects, int rect_cap, const int32_t* __restrict__ counts, int fact)
+{
+    const int f = blockIdx.x, i = threadIdx.x;
+    if (i >= min(counts[f * 4 + 1], rect_cap)) return;
+    ArRect* R = rects + (size_t)f * rect_cap + i;
+    for (int j = 0; j < 2; j++) {
+        int startp = j, endp = (j + 2) % 4;
+        if (R->c[startp][0] > R->c[endp][0]) { const int t = startp; startp = endp; endp = t; }
+        const float _180 = 3.14159f;
+        const float _22 = 3.14159 / 8.f;
+        const float _3_22 = 3. * 3.14159f / 8.f;
+        const float _5_22 = 5.f * 3.14159f / 8.f;
+        const float _7_22 = 7.f * 3.14159f / 8.f;
+        int incx = 0, incy = 0;
+        const float vx = R->c[endp][0] - R->c[startp][0], vy = R->c[endp][1] - R->c[startp][1];
+        const float angle = atan2f(vy, vx);
+        if (_22 < angle && angle < 3 * _22) incx = incy = fact;
+        else if (-_22 < angle && angle < _22) { incx = fact; incy = 0; }
+        else if (-_3_22 < angle && angle < -_22) { incx = fact; incy = -fact; }
+        else if (-_5_22 < angle && angle < -_3_22) { incx = 0; incy = -fact; }
+        else if (-_7_22 < angle && angle < -_5_22) { incx = -fact; incy = -fact; }
+        else if ((-_180 < angle && angle < -_7_22) || (_7_22 < angle && angle < _180)) { incx = -fact; incy = 0; }
+        else if (_5_22 < angle && angle < _7_22) { incx = -fact; incy = fact; }
+        else if (_3_22 < angle && angle < _5_22) { incx = fact; incy = fact; }
+        R->c[endp][0] += (float)incx; R->c[endp][1] += (float)incy;
+        R->c[startp][0] -= (float)incx; R->c[startp][1] -= (float)incy;
+    }
+}
+
 // cv::resize(INTER_NEAREST): sx = min(floor(x * ifx), sw - 1) with ifx = 1 / (dw / sw) in double (resize.cpp resizeNN)
 __global__ __launch_bounds__(256) void k_resize_nearest(ImgView src, ImgView dst, int sw, int sh, int dw, int dh, double ifx, double ify)
 {

@@ -92,6 +92,7 @@ def _bind_aruco(L):
     L.oracle_aruco_candidates.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
     L.oracle_aruco_set_detection_mode.argtypes = [C.c_void_p, C.c_int, C.c_float]
     L.oracle_aruco_set_corner_method.argtypes = [C.c_void_p, C.c_int]
+    L.oracle_aruco_set_enclosed.argtypes = [C.c_void_p, C.c_int]
     L.oracle_aruco_state.argtypes = [C.c_void_p, C.c_int]
     L.oracle_aruco_min_size.restype = C.c_float
     L.oracle_aruco_min_size.argtypes = [C.c_void_p]
@@ -574,6 +575,10 @@ class ArucoOracle:
     def set_corner_method(self, m):
         """Params::setCornerRefinementMethod (:392-395): 0 CORNER_SUBPIX, 1 CORNER_LINES, 2 CORNER_NONE."""
         self.L.oracle_aruco_set_corner_method(self.h, int(m))
+
+    def detect_enclosed_markers(self, on=True):
+        """Params::detectEnclosedMarkers (markerdetector.h:126)."""
+        self.L.oracle_aruco_set_enclosed(self.h, int(on))
 
     def state(self):
         return {"threshold": self.L.oracle_aruco_state(self.h, 0), "min_size": self.L.oracle_aruco_min_size(self.h),

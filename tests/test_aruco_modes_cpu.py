@@ -132,3 +132,35 @@ def test_min_size_reduces_the_working_image_as_the_reference_computes_it():
     ora.set_corner_method(1)
     ora.detect(img)
     assert ora.state()["work_shape"] == (480, 640) and ora.state()["min_size"] == 0.0
+
+
+def test_enclosed_markers_edge_band_is_erosion_xor():
+    """detectEnclosedMarkers + THRES_AUTO_FIXED: the thresholded image becomes thres XOR erode(thres, cross) -- second opinion:
+    scipy's binary erosion with the same cross and a border that does not constrain (border_value=1)."""
+    import scipy.ndimage as ndi
+    img, _ = synth.scene(300, 420, 9, "ARUCO", 3, side_range=(50, 90))
+    for k_expected, cols in ((3, 420),):
+        ora = oracle_lib.ArucoOracle("ARUCO")
+        ora.set_detection_mode(1, 0.0)
+        ora.detect_enclosed_markers(True)
+        LIBC.srand(1)
+        ora.detect(img)                       # first pass at threshold 100 (markers are found: one pass)
+        assert ora.state()["attempts"] == 1
+        th = (img <= 100)
+        cross = np.zeros((k_expected, k_expected), bool); cross[k_expected // 2, :] = True; cross[:, k_expected // 2] = True
+        er = ndi.binary_erosion(th, structure=cross, border_value=1)
+        assert np.array_equal(ora.stage_image(0) > 0, th ^ er)
+    # every rectangle candidate is its plain counterpart moved outwards by int(k / 2.) = 1 pixel per axis at most, both diagonals
+    plain = oracle_lib.ArucoOracle("ARUCO"); plain.set_detection_mode(0, 0.0)
+    enc = oracle_lib.ArucoOracle("ARUCO"); enc.set_detection_mode(0, 0.0); enc.detect_enclosed_markers(True)
+    plain.detect(img); enc.detect(img)
+    a, b = plain.candidates(0), enc.candidates(0)
+    assert len(a) == len(b) and len(a) > 3
+    d = np.abs(a[:, :8] - b[:, :8])
+    fact = int(5 / 2.)                        # adaptive window of a 420-pixel frame: max(3, int(15 * 420 / 1920)) = 3 -> odd 3 ... see below
+    win = max(3, int(15 * 420 / 1920.)); win += (win % 2 == 0)
+    fact = int(win / 2.)
+    assert d.max() == fact and set(np.unique(d)) <= {0.0, float(fact)}
+    # outwards: the enlarged quadrilateral contains the plain one's centroid and has the larger area
+    def area(q): x, y = q[0::2], q[1::2]; return 0.5 * abs(np.dot(x, np.roll(y, -1)) - np.dot(y, np.roll(x, -1)))
+    assert all(area(b[i, :8]) > area(a[i, :8]) for i in range(len(a)))

@@ -31,8 +31,9 @@ def frames(n, rows=480, cols=640, dic="ARUCO", seed0=70):
     return out
 
 
-def run_both(orbfe, oracle, seq, dic, mode, min_size, corner, seed=11):
+def run_both(orbfe, oracle, seq, dic, mode, min_size, corner, seed=11, enclosed=False):
     det, ora = orbfe.MarkerDetector(dic), oracle.ArucoOracle(dic)
+    det.detectEnclosedMarkers(enclosed); ora.detect_enclosed_markers(enclosed)
     # the order a caller of the reference uses with CORNER_SUBPIX: the corner method first, else it resets minSize (markerdetector.cpp:392-395)
     det.setCornerRefinementMethod(corner); ora.set_corner_method(corner)
     det.setDetectionMode(mode, min_size); ora.set_detection_mode(mode, min_size)
@@ -114,6 +115,27 @@ def test_dm_video_fast_follows_the_marker_size(orbfe, oracle):
     LIBC.srand(3)
     got = [(det.detect(im), det.state()) for im in seq[:4]]
     compare(got, want)
+
+
+@pytest.mark.parametrize("mode,min_size,corner", [(0, 0.0, 1), (1, 0.0, 1), (1, 0.0, 0), (2, 0.0, 0), (0, 0.06, 0)])
+def test_detect_enclosed_markers(orbfe, oracle, mode, min_size, corner):
+    """Params::detectEnclosedMarkers: every rectangle candidate enlarged along its diagonals; with THRES_AUTO_FIXED the thresholded
+    image is its own inner edge band (erode with a cross + xor)."""
+    seq = frames(6, seed0=210)
+    got, want = run_both(orbfe, oracle, seq, "ARUCO", mode, min_size, corner, enclosed=True)
+    compare(got, want)
+    assert sum(len(w) for w, _ in want) >= 6
+    det, ora = orbfe.MarkerDetector("ARUCO"), oracle.ArucoOracle("ARUCO")
+    det.detectEnclosedMarkers(True); ora.detect_enclosed_markers(True)
+    det.setDetectionMode(mode, 0.0); ora.set_detection_mode(mode, 0.0)
+    LIBC.srand(1); w = ora.detect(seq[0]); LIBC.srand(1); g = det.detect(seq[0])
+    assert np.array_equal(det.thresholded(0), ora.stage_image(0))
+    orects, grects = ora.candidates(0), det.rects(0)
+    assert len(grects) == len(orects) and np.array_equal(grects["corners"].reshape(-1, 8), orects[:, :8])   # enlarged, integer-valued
+    plain = orbfe.MarkerDetector("ARUCO")
+    plain.setDetectionMode(mode, 0.0)
+    LIBC.srand(1); plain.detect(seq[0])
+    assert not np.array_equal(plain.rects(0)["corners"][:len(grects)], grects["corners"][:len(plain.rects(0))])
 
 
 def test_bgr_input(orbfe, oracle):

@@ -22,6 +22,7 @@ for case in range(n):
     ms = [0.0, 0.0, 0.03, 0.05, 0.08, 0.15][int(rng.integers(0, 6))]
     bgr = bool(rng.integers(0, 4) == 0)
     bits = 14 if rng.integers(0, 2) else 15
+    enclosed = bool(rng.integers(0, 3) == 0)
     seq = []
     for i in range(int(rng.integers(2, 6))):
         try:
@@ -41,6 +42,7 @@ for case in range(n):
     try:
         det, ora = binding.MarkerDetector(dic), O.ArucoOracle(dic)
         det.setGrayConversion(bits)
+        det.detectEnclosedMarkers(enclosed); ora.detect_enclosed_markers(enclosed)
         det.setCornerRefinementMethod(corner); ora.set_corner_method(corner)
         det.setDetectionMode(mode, ms); ora.set_detection_mode(mode, ms)
         seed = int(rng.integers(1, 10 ** 6))
@@ -65,6 +67,6 @@ for case in range(n):
         why.append("exception %r" % (e,))
     if why:
         bad += 1
-        print("case %d %dx%d %s mode %d minSize %.2f corner %d bgr %d/%d: %s" % (case, cols, rows, dic, mode, ms, corner, bgr, bits, why))
+        print("case %d %dx%d %s mode %d minSize %.2f corner %d bgr %d/%d enclosed %d: %s" % (case, cols, rows, dic, mode, ms, corner, bgr, bits, enclosed, why))
 print("%d cases, %d frames (%d markers, %d with retries, %d on a reduced image, %d sequences refused as documented), %d mismatches" %
       (n, frames, markers, retries, reduced, refused, bad))
