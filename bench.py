@@ -643,7 +643,8 @@ def main():
                                       " + ArUco detect incl. IPPE marker poses" if use_aruco else " (ArUco leg DISABLED: diagnostic run)"),
                        "frames_per_step_per_gpu": B, "mean_keypoints_per_frame": N, "marker_records_per_frame": pipe.mcap,
                        "result_record_bytes_per_step_per_gpu": pipe.layout.nbytes, "resident_batches": R,
-                       "sub_batches": pipe.S, "engine_sets": pipe.D, "aruco_big_frame_kernel": pipe.big_frames, "library": version,
+                       "sub_batches": pipe.S, "engine_sets": pipe.D, "engine_phase_lock_stage": pipe.phase_pin if pipe.D > 1 else 0,
+                       "detector_pyramid_in_line": bool(getattr(pipe, "det_nofork", False)), "aruco_big_frame_kernel": pipe.big_frames, "library": version,
                        "library_sha16": lib_sha16, "env": env_set, "env_nondefault": env_nondefault or None,
                        "parallelism": "stream-per-gpu x%d, %s" % (world, ("%s gather to rank 0" % ("RCCL" if backend == "nccl" else backend))
                                                                   if multi else "no collective (one rank)")},
