@@ -536,6 +536,13 @@ int orbfe_aruco_set_corner_refinement(orbfe_aruco* h, int method);
  * With THRES_AUTO_FIXED the thresholded image is replaced by its inner edge band (erode with a cross, xor); in every mode each
  * rectangle candidate is enlarged by half the threshold window along its diagonals (markerdetector_impl.cpp:2871-2950, :10620-10690). */
 int orbfe_aruco_set_enclosed_markers(orbfe_aruco* h, int on);
+/* Params::trackingMinDetections (markerdetector.h:187; 0 = off, the default): a marker that was found in that many calls and is
+ * missing from this one is looked for among the rectangle candidates the dictionary rejected -- centre inside its last outline,
+ * area within 30 %, nearest centre -- and returned with its id and the corner order that continues its previous orientation
+ * (markerdetector_impl.cpp:7107-7890).  Host logic over two short lists, as in the reference; the handle becomes frame-sequential.
+ * Setting it resets the history.  orbfe_aruco_last_tracked: markers the last call recovered that way. */
+int orbfe_aruco_set_tracking(orbfe_aruco* h, int min_detections);
+int orbfe_aruco_last_tracked(const orbfe_aruco* h);
 int orbfe_aruco_get_state(const orbfe_aruco* h, int32_t* threshold, float* min_size, int32_t* attempts, int32_t* work_rows,
                           int32_t* work_cols);
 /* cvtColor(BGR2GRAY) of the CV_8UC3 entry points: 14 fractional bits (OpenCV <= 3.4.1: B 1868, G 9617, R 4899; default) or 15

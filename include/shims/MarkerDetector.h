@@ -46,6 +46,11 @@ public:
             check(orbfe_aruco_set_enclosed_markers(owner->handle(), do_ ? 1 : 0));
             enclosedMarker = do_;
         }
+        void setTrackingMinDetections(int n) // the reference assigns Params::trackingMinDetections directly (markerdetector.h:187): call this instead
+        {
+            check(orbfe_aruco_set_tracking(owner->handle(), n));
+            trackingMinDetections = n;
+        }
         void setCornerRefinementMethod(CornerRefinementMethod method)
         {
             check(orbfe_aruco_set_corner_refinement(owner->handle(), (int)method));
@@ -56,6 +61,7 @@ public:
         CornerRefinementMethod cornerRefinementM = CORNER_LINES;
         float minSize = 0;
         bool enclosedMarker = false;
+        int trackingMinDetections = 0;
         float error_correction_rate = 0;
         std::string dictionary = "ARUCO";
         int maxThreads = 1;

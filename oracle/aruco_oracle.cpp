@@ -726,6 +726,12 @@ struct Detector {
     bool autoSize = false;
     float ts = 0.25f;
     bool enclosed = false;     /* Params::enclosedMarker (detectEnclosedMarkers) */
+    /* Params::trackingMinDetections (markerdetector.h:187): a marker seen in that many calls and missing now is looked for among the
+     * candidates the dictionary rejected, near its last position (markerdetector_impl.cpp:7107-7890) */
+    int trackingMinDetections = 0;
+    std::map<int, int> markerCounts;      /* id -> calls it was found in (decays by one per call without it) */
+    std::vector<Candidate> prevMarkers;   /* the markers the previous call returned */
+    int last_tracked = 0;                 /* markers the last call recovered that way (test read-back) */
     int last_attempts = 0;     /* threshold passes of the last call (test read-back) */
     int last_work_w = 0, last_work_h = 0;
     /* stage data of the last call (per-stage parity tests) */
@@ -920,6 +926,96 @@ struct Detector {
         for (unsigned i = 0; i < 4; i++) m.c[i] = cross_point(L[(i - 1) % 4], L[i]); /* unsigned (i-1)%4: 3 for i=0 */
     }
 
+    /* marker_analyzer (markerdetector_impl.h:2460-2530): centre, area and the inside test of a quadrilateral */
+    struct Quad {
+        Ptf c[4], center;
+        float area;
+        void set(const Ptf q[4])
+        {
+            for (int k = 0; k < 4; k++) c[k] = q[k];
+            const float ax = c[1].x - c[0].x, ay = c[1].y - c[0].y, bx = c[3].x - c[0].x, by = c[3].y - c[0].y;
+            const float a1 = std::fabs(ax * by - ay * bx);
+            const float cx = c[1].x - c[2].x, cy = c[1].y - c[2].y, dx = c[3].x - c[2].x, dy = c[3].y - c[2].y;
+            const float a2 = std::fabs(cx * dy - cy * dx);
+            area = (a2 + a1) / 2.f;
+            center = Ptf{0, 0};
+            for (int k = 0; k < 4; k++) { center.x += c[k].x; center.y += c[k].y; }
+            center.x = (float)(center.x * (1. / 4.)); center.y = (float)(center.y * (1. / 4.));
+        }
+        static float signed_dist(Ptf p1, Ptf p2, Ptf p)
+        {
+            return ((p1.y - p2.y) * p.x + (p2.x - p1.x) * p.y + (p1.x * p2.y - p2.x * p1.y)) /
+                   std::sqrt((p2.x - p1.x) * (p2.x - p1.x) + (p2.y - p1.y) * (p2.y - p1.y));
+        }
+        bool is_into(Ptf p) const
+        {
+            for (int k = 0; k < 4; k++)
+                if (signed_dist(c[k], c[(k + 1) % 4], p) < 0) return false;
+            return true;
+        }
+    };
+    /* direction agreement of the first sides (the lambda at :7700-7760): unit vectors in float, scaled by a double reciprocal norm */
+    static float side_agreement(const Ptf a[4], const Ptf b[4])
+    {
+        Ptf u{a[1].x - a[0].x, a[1].y - a[0].y}, v{b[1].x - b[0].x, b[1].y - b[0].y};
+        const double nu = 1. / std::sqrt((double)u.x * u.x + (double)u.y * u.y), nv = 1. / std::sqrt((double)v.x * v.x + (double)v.y * v.y);
+        u.x = (float)(u.x * nu); u.y = (float)(u.y * nu);
+        v.x = (float)(v.x * nv); v.y = (float)(v.y * nv);
+        return u.x * v.x + u.y * v.y;
+    }
+    /* the tracking block of detect() (:7107-7890); `rejected` = the candidates the dictionary did not accept, in candidate order */
+    void track_missing(std::vector<Candidate>& detected, std::vector<Candidate>& rejected)
+    {
+        last_tracked = 0;
+        if (trackingMinDetections <= 0) return;
+        auto found = [&](int id) { for (auto& m : detected) if (m.id == id) return true; return false; };
+        for (auto& mc : markerCounts)
+            if (!found(mc.first)) mc.second = std::max(mc.second - 1, 0);
+        struct Info { Quad q; int best = -1; double dist = std::numeric_limits<double>::max(); const Candidate* prev = nullptr; };
+        std::map<int, Info> need;
+        for (auto& m : prevMarkers)
+            if (!found(m.id) && markerCounts.count(m.id) != 0 && markerCounts.at(m.id) >= trackingMinDetections && !need.count(m.id)) {
+                Info in; in.q.set(m.c); in.prev = &m;
+                need.insert({m.id, in});
+            }
+        if (!need.empty()) {
+            for (size_t ci = 0; ci < rejected.size(); ci++) {
+                Quad qc; qc.set(rejected[ci].c);
+                for (auto& kv : need) {
+                    Info& in = kv.second;
+                    if (!in.q.is_into(qc.center)) continue;
+                    const float dx = in.q.center.x - qc.center.x, dy = in.q.center.y - qc.center.y;
+                    const double dist = std::sqrt((double)dx * dx + (double)dy * dy);
+                    const float sizeDiff = std::fabs(in.q.area - qc.area) / in.q.area;
+                    if (sizeDiff < 0.3f && dist < in.dist) { in.best = (int)ci; in.dist = dist; }
+                }
+            }
+            std::vector<bool> used(rejected.size(), false);
+            for (auto& kv : need) {
+                Info& in = kv.second;
+                if (in.best == -1 || used[in.best]) continue; /* (the reference hands a candidate claimed twice on as an empty marker: undefined; first claim wins here) */
+                Candidate m = rejected[in.best];
+                m.id = kv.first;
+                int best_r = -1;
+                double best_s = -1;
+                for (int r = 0; r < 4; r++) {
+                    Ptf rot[4];
+                    for (int k = 0; k < 4; k++) rot[k] = m.c[(k + r) % 4];
+                    const float sc = side_agreement(in.prev->c, rot);
+                    if (sc > best_s) { best_r = r; best_s = sc; }
+                }
+                if (best_r > 0) std::rotate(m.c, m.c + best_r, m.c + 4);
+                detected.push_back(std::move(m));
+                used[in.best] = true;
+                last_tracked++;
+            }
+        }
+        for (auto& m : detected) {
+            if (markerCounts.count(m.id) == 0) markerCounts[m.id] = 1;
+            else markerCounts[m.id]++;
+        }
+    }
+
     /* setDetectionMode (markerdetector.cpp:374-391) */
     void set_detection_mode(int dm, float minMarkerSize)
     {
@@ -995,6 +1091,7 @@ struct Detector {
         const float desiredarea = std::pow(static_cast<float>(S), 2.f);
         std::vector<uint8_t> patch((size_t)S * S);
         std::vector<float> hist(256, 0.f);
+        std::vector<Candidate> rejected;
         int nattempts = 0;
         bool again;
         last_attempts = 0;
@@ -1003,6 +1100,7 @@ struct Detector {
             threshold_and_detect(*work);
             prefilter(work->w, work->h);
             out.clear();
+            rejected.clear();
             for (auto& v : hist) v = 0;
             for (auto& cand : prefiltered) {
                 size_t lvl = 0;
@@ -1015,10 +1113,12 @@ struct Detector {
                 Ptf q[4];
                 for (int k = 0; k < 4; k++) q[k] = Ptf{cand.c[k].x * ratio, cand.c[k].y * ratio};
                 double Minv[9];
-                if (!perspective_inverse_map(q, S, Minv)) continue;
-                warp_perspective(im, Minv, S, patch.data());
-                int nRot = 0;
-                int id = decode_marker(patch.data(), S, dict, &nRot);
+                int nRot = 0, id = -1;
+                if (perspective_inverse_map(q, S, Minv)) {
+                    warp_perspective(im, Minv, S, patch.data());
+                    id = decode_marker(patch.data(), S, dict, &nRot);
+                }
+                if (id < 0) rejected.push_back(cand);
                 if (id >= 0) {
                     Candidate m = cand;
                     m.id = id;
@@ -1039,6 +1139,7 @@ struct Detector {
             if (t > 0) ThresHold = float(t);
         }
         if (input.w != work->w) corner_upsample(out, work->w); /* :7046-7071 */
+        track_missing(out, rejected);                           /* :7107-7890 (rejected candidates keep the working image's coordinates) */
         /* sort by id; among equal ids keep the larger perimeter (:8153-8365) */
         std::stable_sort(out.begin(), out.end(), [](const Candidate& a, const Candidate& b) { return a.id < b.id; });
         std::vector<bool> rm(out.size(), false);
@@ -1079,6 +1180,7 @@ struct Detector {
         if (mlength != std::numeric_limits<float>::max()) markerMinSize = mlength / (4 * std::max(input.w, input.h));
         else markerMinSize = 0;
         if (autoSize) minSize = markerMinSize * (1 - ts);
+        prevMarkers = out;
         return (int)out.size();
     }
 };
@@ -1117,11 +1219,12 @@ void oracle_aruco_set_params(void* h, float error_correction_rate, int corner_li
 void oracle_aruco_set_detection_mode(void* h, int dm, float min_marker_size) { ((Detector*)h)->set_detection_mode(dm, min_marker_size); }
 void oracle_aruco_set_corner_method(void* h, int m) { ((Detector*)h)->set_corner_method(m); }
 void oracle_aruco_set_enclosed(void* h, int on) { ((Detector*)h)->enclosed = on != 0; }
+void oracle_aruco_set_tracking(void* h, int min_detections) { ((Detector*)h)->trackingMinDetections = min_detections; }
 /* state read-back: 0 ThresHold, 1 threshold passes of the last call, 2 / 3 working width / height of the last call */
 int oracle_aruco_state(void* h, int which)
 {
     Detector* d = (Detector*)h;
-    return which == 0 ? d->ThresHold : which == 1 ? d->last_attempts : which == 2 ? d->last_work_w : d->last_work_h;
+    return which == 0 ? d->ThresHold : which == 1 ? d->last_attempts : which == 2 ? d->last_work_w : which == 3 ? d->last_work_h : d->last_tracked;
 }
 float oracle_aruco_min_size(void* h) { return ((Detector*)h)->minSize; }
 void oracle_bgr_to_gray(const uint8_t* bgr, int rows, int cols, size_t step, uint8_t* out, int bits15)

@@ -37,7 +37,7 @@ SYMBOLS = [
     "orbfe_aruco_batch_status", "orbfe_aruco_set_big_frames", "orbfe_aruco_set_error_correction_rate",
     "orbfe_aruco_set_detection_mode", "orbfe_aruco_set_corner_refinement", "orbfe_aruco_marker_contour", "orbfe_aruco_marker_contours",
     "orbfe_camera_resize", "orbfe_marker_poses", "orbfe_marker_poses_batch_device", "orbfe_aruco_detect_poses",
-    "orbfe_aruco_detect_bgr", "orbfe_aruco_detect_poses_bgr", "orbfe_aruco_get_state", "orbfe_aruco_set_gray_conversion", "orbfe_aruco_set_enclosed_markers", "orbfe_corner_subpix",
+    "orbfe_aruco_detect_bgr", "orbfe_aruco_detect_poses_bgr", "orbfe_aruco_get_state", "orbfe_aruco_set_gray_conversion", "orbfe_aruco_set_enclosed_markers", "orbfe_aruco_set_tracking", "orbfe_aruco_last_tracked", "orbfe_corner_subpix",
     "orbfe_vocabulary_load_text", "orbfe_vocabulary_create", "orbfe_vocabulary_destroy", "orbfe_vocabulary_info",
     "orbfe_vocabulary_transform", "orbfe_vocabulary_transform_batch_device",
     "orbfe_search_by_bow", "orbfe_search_by_bow_batch_device",
@@ -146,6 +146,8 @@ def load():
         L.orbfe_aruco_get_state.argtypes = [vp, vp, vp, vp, vp, vp]
         L.orbfe_aruco_set_gray_conversion.argtypes = [vp, i32]
         L.orbfe_aruco_set_enclosed_markers.argtypes = [vp, i32]
+        L.orbfe_aruco_set_tracking.argtypes = [vp, i32]
+        L.orbfe_aruco_last_tracked.argtypes = [vp]
         L.orbfe_corner_subpix.argtypes = [vp, i32, i32, sz, vp, i32, i32, i32, C.c_double, i32]
         L.orbfe_aruco_marker_contour.argtypes = [vp, i32, i32, vp, i32, vp]
         L.orbfe_aruco_marker_contours.argtypes = [vp, i32, i32, vp, i32, vp]
@@ -807,6 +809,13 @@ class MarkerDetector:
     def detectEnclosedMarkers(self, on=True):
         """Params::detectEnclosedMarkers (markerdetector.h:126)."""
         _check(self.L, self.L.orbfe_aruco_set_enclosed_markers(self.h, int(on)), "orbfe_aruco_set_enclosed_markers")
+
+    def setTracking(self, min_detections):
+        """Params::trackingMinDetections (markerdetector.h:187); resets the history."""
+        _check(self.L, self.L.orbfe_aruco_set_tracking(self.h, int(min_detections)), "orbfe_aruco_set_tracking")
+
+    def tracked(self):
+        return self.L.orbfe_aruco_last_tracked(self.h)
 
     def setGrayConversion(self, fractional_bits):
         """cvtColor(BGR2GRAY) of CV_8UC3 frames: 14 fractional bits (OpenCV <= 3.4.1, default) or 15 (3.4.2 and later)."""

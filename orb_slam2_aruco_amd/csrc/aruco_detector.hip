@@ -6,9 +6,12 @@
 // threshold image, contours longer than 70 points, approxPolyDP eps 5 %, markerWarpPixSize 5, pyrfactor 2,
 // borderDistThres 0.015, error correction off.  Pose estimation (step 12) is not part of this path yet.
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdlib>
+#include <functional>
 #include <limits>
+#include <map>
 
 #include "aruco_kernels.hpp"
 #include "aruco_pose.hpp"
@@ -24,6 +27,7 @@ struct ModeRun {
     int full_rows = 0, full_cols = 0;
     int fixed_thr = -1;              // THRES_AUTO_FIXED: the global threshold (-1: adaptive)
     uint32_t* d_hist = nullptr;      // THRES_AUTO_FIXED: per frame, 256 bins over the accepted candidates' patches
+    std::function<int(hipStream_t)> before_finalize; // trackingMinDetections: the host looks at the decode results and may adopt rejected candidates
 };
 
 struct orbfe_aruco {
@@ -94,12 +98,18 @@ struct orbfe_aruco {
     bool auto_size = false;      // Params::autoSize (DM_VIDEO_FAST)
     float ts = 0.25f;
     bool enclosed = false;       // Params::enclosedMarker (detectEnclosedMarkers, markerdetector.h:126)
+    // Params::trackingMinDetections (markerdetector.h:187; markerdetector_impl.cpp:7107-7890): a marker found in that many calls and
+    // missing now is looked for among the candidates the dictionary rejected, inside its last outline
+    int tracking_min = 0;
+    std::map<int, int> marker_counts;         // id -> calls it was found in (one less per call without it)
+    std::vector<orbfe_marker> prev_markers;   // what the previous call returned
+    int last_tracked = 0;
     int gray_bits15 = 0;         // BGR2GRAY with 15 fractional bits (OpenCV 3.4.2+) instead of 14
     int pyr_rows = 0, pyr_cols = 0;   // the frame the /2 pyramid starts from (the working image is smaller when minSize > 0)
     int last_attempts = 0, last_work_rows = 0, last_work_cols = 0;
     size_t rl_static = 0;
     DevBuf d_red, d_mhist, d_masks, d_bgr, d_bits2;
-    bool stateful() const { return thres_method == 1 || auto_size; } // a frame's result depends on the frames before it
+    bool stateful() const { return thres_method == 1 || auto_size || tracking_min > 0; } // a frame's result depends on the frames before it
     KernelTimer timer;
     int last_nframes = 0;
 
@@ -522,6 +532,7 @@ struct orbfe_aruco {
                                d_rects.as<ArRect>(), AR_MAX_RECTS, d_candidx.as<int32_t>(), d_dwork.as<uint32_t>(), d_dctr.as<int32_t>(),
                                d_result.as<int32_t>(), d_masks.as<float>());
         }
+        if (mr && mr->before_finalize && (rc = mr->before_finalize(s))) return rc;
         // corner refinement applies only when the input was not reduced (:8420): CORNER_LINES inside k_finalize, CORNER_SUBPIX after it
         for (int r_ = 0; r_ < ORBFE_REPS_ARUCO(4); r_++) hipLaunchKernelGGL(k_finalize, dim3(B), dim3(256), 0, s, d_rects.as<ArRect>(), AR_MAX_RECTS,
                            d_candidx.as<int32_t>(), d_ncand.as<int32_t>(), d_result.as<int32_t>(),
@@ -571,6 +582,101 @@ struct PoseWorkspace {
 };
 static thread_local ThreadWorkspaces<PoseWorkspace> tl_pose_ws; // per (thread, device)
 
+// ---- trackingMinDetections: host logic, as in the reference (it walks two short lists; the device supplies the candidates) ----
+namespace {
+struct TrackQuad { // marker_analyzer (markerdetector_impl.h:2460-2530): centre, area, inside test
+    float c[4][2], cx, cy, area;
+    void set(const float q[4][2])
+    {
+        memcpy(c, q, sizeof c);
+        const float a1 = std::fabs((c[1][0] - c[0][0]) * (c[3][1] - c[0][1]) - (c[1][1] - c[0][1]) * (c[3][0] - c[0][0]));
+        const float a2 = std::fabs((c[1][0] - c[2][0]) * (c[3][1] - c[2][1]) - (c[1][1] - c[2][1]) * (c[3][0] - c[2][0]));
+        area = (a2 + a1) / 2.f;
+        float sx = 0, sy = 0;
+        for (int k = 0; k < 4; k++) { sx += c[k][0]; sy += c[k][1]; }
+        cx = (float)(sx * (1. / 4.)); cy = (float)(sy * (1. / 4.));
+    }
+    bool is_into(float px, float py) const
+    {
+        for (int k = 0; k < 4; k++) {
+            const float* p1 = c[k];
+            const float* p2 = c[(k + 1) % 4];
+            const float d = ((p1[1] - p2[1]) * px + (p2[0] - p1[0]) * py + (p1[0] * p2[1] - p2[0] * p1[1])) /
+                            std::sqrt((p2[0] - p1[0]) * (p2[0] - p1[0]) + (p2[1] - p1[1]) * (p2[1] - p1[1]));
+            if (d < 0) return false;
+        }
+        return true;
+    }
+};
+// agreement of the first sides' directions (:7700-7760)
+float track_side_agreement(const float a[4][2], const float b[4][2])
+{
+    float ux = a[1][0] - a[0][0], uy = a[1][1] - a[0][1], vx = b[1][0] - b[0][0], vy = b[1][1] - b[0][1];
+    const double nu = 1. / std::sqrt((double)ux * ux + (double)uy * uy), nv = 1. / std::sqrt((double)vx * vx + (double)vy * vy);
+    ux = (float)(ux * nu); uy = (float)(uy * nu);
+    vx = (float)(vx * nv); vy = (float)(vy * nv);
+    return ux * vx + uy * vy;
+}
+} // namespace
+
+// The tracking block of detect() on the decode results of one frame: `ids[slot]` (-1 = rejected) and the candidates' corners.  Adopted
+// candidates get the missing marker's id and the corner rotation that best continues its previous orientation (written back as
+// the (id, nRot) pair k_finalize understands).  Returns the number of adopted candidates.
+static int track_missing_markers(orbfe_aruco* h, int ncand, int32_t* result /* ncand x (id, nRot) */, const float (*corners)[4][2])
+{
+    auto found = [&](int id) { for (int s = 0; s < ncand; s++) if (result[2 * s] == id) return true; return false; };
+    for (auto& mc : h->marker_counts)
+        if (!found(mc.first)) mc.second = std::max(mc.second - 1, 0);
+    struct Info { TrackQuad q; int best = -1; double dist = std::numeric_limits<double>::max(); const orbfe_marker* prev = nullptr; };
+    std::map<int, Info> need;
+    for (const orbfe_marker& m : h->prev_markers)
+        if (!found(m.id) && h->marker_counts.count(m.id) != 0 && h->marker_counts.at(m.id) >= h->tracking_min && !need.count(m.id)) {
+            Info in; in.q.set(m.corners); in.prev = &m;
+            need.insert({m.id, in});
+        }
+    struct Adopt { int slot, id, nrot; };
+    std::vector<Adopt> adopt;
+    if (!need.empty()) {
+        for (int s = 0; s < ncand; s++) {
+            if (result[2 * s] >= 0) continue; // only what the dictionary rejected
+            TrackQuad qc; qc.set(corners[s]);
+            for (auto& kv : need) {
+                Info& in = kv.second;
+                if (!in.q.is_into(qc.cx, qc.cy)) continue;
+                const float dx = in.q.cx - qc.cx, dy = in.q.cy - qc.cy;
+                const double dist = std::sqrt((double)dx * dx + (double)dy * dy);
+                const float size_diff = std::fabs(in.q.area - qc.area) / in.q.area;
+                if (size_diff < 0.3f && dist < in.dist) { in.best = s; in.dist = dist; }
+            }
+        }
+        std::vector<char> used((size_t)std::max(ncand, 1), 0);
+        for (auto& kv : need) {
+            Info& in = kv.second;
+            if (in.best == -1 || used[in.best]) continue; // (a candidate claimed twice: undefined in the reference; the first claim wins)
+            int best_r = 0;
+            double best_s = -1;
+            for (int r = 0; r < 4; r++) {
+                float rot[4][2];
+                for (int k = 0; k < 4; k++) { rot[k][0] = corners[in.best][(k + r) % 4][0]; rot[k][1] = corners[in.best][(k + r) % 4][1]; }
+                const float sc = track_side_agreement(in.prev->corners, rot);
+                if (sc > best_s) { best_r = r; best_s = sc; }
+            }
+            used[in.best] = 1;
+            // k_finalize rotates the corners by 4 - nRot: a left rotation by r is nRot = (4 - r) % 4
+            adopt.push_back(Adopt{in.best, kv.first, (4 - best_r) % 4});
+        }
+        for (const Adopt& a : adopt) { result[2 * a.slot] = a.id; result[2 * a.slot + 1] = a.nrot; } // (after the loop: found() above saw the dictionary's results only)
+    }
+    const int adopted = (int)adopt.size();
+    for (int s = 0; s < ncand; s++)
+        if (result[2 * s] >= 0) {
+            const int id = result[2 * s];
+            if (h->marker_counts.count(id) == 0) h->marker_counts[id] = 1;
+            else h->marker_counts[id]++;
+        }
+    return adopted;
+}
+
 // The image detect() works on (markerdetector_impl.cpp:5990-6090): with Params::minSize > 0 markers smaller than minSize * max(cols,
 // rows) need not be found, so the frame is reduced until such a marker would be lowResMarkerSize = 20 pixels.
 static int work_size(const orbfe_aruco* h, int rows, int cols, int* wr, int* wc)
@@ -597,7 +703,8 @@ static int work_size(const orbfe_aruco* h, int rows, int cols, int* wr, int* wc)
 // a batch on a reduced working image: INTER_NEAREST into the handle's buffer, then the pipeline with the full frames for the
 // pyramid, the warps and cornerUpsample
 static int reduced_batch(orbfe_aruco* h, const uint8_t* d_imgs, int B, size_t frame_stride, int rows, int cols, size_t step, int wr, int wc,
-                         orbfe_marker* d_out, int capacity, int32_t* d_n, hipStream_t s, int fixed_thr, uint32_t* d_hist)
+                         orbfe_marker* d_out, int capacity, int32_t* d_n, hipStream_t s, int fixed_thr, uint32_t* d_hist,
+                         std::function<int(hipStream_t)> before_finalize = nullptr)
 {
     const size_t rpitch = (size_t)(wc + 63) / 64 * 64, rframe = rpitch * wr;
     int rc = h->d_red.ensure(rframe * B + 64);
@@ -607,7 +714,7 @@ static int reduced_batch(orbfe_aruco* h, const uint8_t* d_imgs, int B, size_t fr
                        ImgView{h->d_red.as<uint8_t>(), h->d_red.as<uint8_t>(), rframe, (int)rpitch}, cols, rows, wc, wr, ifx, ify);
     ModeRun mr;
     mr.d_full = d_imgs; mr.full_fstride = frame_stride; mr.full_step = step; mr.full_rows = rows; mr.full_cols = cols;
-    mr.fixed_thr = fixed_thr; mr.d_hist = d_hist;
+    mr.fixed_thr = fixed_thr; mr.d_hist = d_hist; mr.before_finalize = before_finalize;
     return h->run_device(h->d_red.as<uint8_t>(), B, rframe, wr, wc, rpitch, d_out, capacity, d_n, s, &mr);
 }
 
@@ -715,6 +822,18 @@ int orbfe_aruco_set_enclosed_markers(orbfe_aruco* h, int on)
     h->enclosed = on != 0;
     return ORBFE_OK;
 }
+
+int orbfe_aruco_set_tracking(orbfe_aruco* h, int min_detections)
+{
+    if (!h || min_detections < 0) return fail(ORBFE_ERR_INVALID, "orbfe_aruco_set_tracking: trackingMinDetections >= 0");
+    h->tracking_min = min_detections;
+    h->marker_counts.clear();
+    h->prev_markers.clear();
+    h->last_tracked = 0;
+    return ORBFE_OK;
+}
+
+int orbfe_aruco_last_tracked(const orbfe_aruco* h) { return h ? h->last_tracked : ORBFE_ERR_INVALID; }
 
 int orbfe_aruco_set_gray_conversion(orbfe_aruco* h, int fractional_bits)
 {
@@ -891,7 +1010,9 @@ static int detect_frames_modes(orbfe_aruco* h, const uint8_t* imgs, int nframes,
     const size_t in_bytes = channels == 3 ? (size_t)cols * 3 * rows : dframe;
     // page-locked: [frame in] [n | counts | histogram | markers | poses] out
     const size_t o_n = (in_bytes + 255) / 256 * 256, o_cnt = o_n + 64, o_h = o_cnt + 64, o_mk = o_h + 1024,
-                 o_ps = o_mk + (size_t)AR_MAX_RECTS * sizeof(orbfe_marker), o_end = o_ps + (size_t)AR_MAX_RECTS * sizeof(orbfe_marker_pose);
+                 o_ps = o_mk + (size_t)AR_MAX_RECTS * sizeof(orbfe_marker), o_tk = o_ps + (size_t)AR_MAX_RECTS * sizeof(orbfe_marker_pose),
+                 o_tci = o_tk + 64, o_trc = o_tci + (size_t)AR_MAX_RECTS * 4, o_trs = o_trc + (size_t)AR_MAX_RECTS * sizeof(ArRect),
+                 o_end = o_trs + (size_t)AR_MAX_RECTS * 8; // trackingMinDetections: candidate count, indices, rectangles, decode results
     if ((rc = h->pinned.ensure(o_end)) || (rc = h->d_in.ensure(dframe + 64)) || (rc = h->d_out.ensure((size_t)AR_MAX_RECTS * sizeof(orbfe_marker))) ||
         (rc = h->d_nout.ensure(4)) || (rc = h->d_mhist.ensure(1024)) || (cam && (rc = h->d_poses.ensure((size_t)AR_MAX_RECTS * sizeof(orbfe_marker_pose)))) ||
         (channels == 3 && (rc = h->d_bgr.ensure(in_bytes + 64))))
@@ -918,16 +1039,44 @@ static int detect_frames_modes(orbfe_aruco* h, const uint8_t* imgs, int nframes,
         h->last_work_rows = wr; h->last_work_cols = wc;
         int attempts = 0;
         h->last_attempts = 0;
+        h->last_tracked = 0;
+        // trackingMinDetections (:7107-7890): between the dictionary's verdicts and sort / dedupe the host looks at the frame's
+        // candidates (2 KB of results, 10 KB of rectangles) and may hand a rejected one the id of a marker that has gone missing
+        int pre_detected = -1;
+        const std::map<int, int> counts_at_start = h->marker_counts;
+        std::function<int(hipStream_t)> track_hook;
+        if (h->tracking_min > 0)
+            track_hook = [&](hipStream_t st) -> int {
+                ORBFE_HIP(hipMemcpyAsync(hp + o_tk, h->d_ncand.p, 4, hipMemcpyDeviceToHost, st));
+                ORBFE_HIP(hipMemcpyAsync(hp + o_tci, h->d_candidx.p, (size_t)AR_MAX_RECTS * 4, hipMemcpyDeviceToHost, st));
+                ORBFE_HIP(hipMemcpyAsync(hp + o_trc, h->d_rects.p, (size_t)AR_MAX_RECTS * sizeof(ArRect), hipMemcpyDeviceToHost, st));
+                ORBFE_HIP(hipMemcpyAsync(hp + o_trs, h->d_result.p, (size_t)AR_MAX_RECTS * 8, hipMemcpyDeviceToHost, st));
+                ORBFE_HIP(hipStreamSynchronize(st));
+                const int ncand = std::min(*reinterpret_cast<const int32_t*>(hp + o_tk), (int32_t)AR_MAX_RECTS);
+                const int32_t* cidx = reinterpret_cast<const int32_t*>(hp + o_tci);
+                const ArRect* rc_ = reinterpret_cast<const ArRect*>(hp + o_trc);
+                int32_t* res = reinterpret_cast<int32_t*>(hp + o_trs);
+                pre_detected = 0;
+                for (int q = 0; q < ncand; q++) pre_detected += res[2 * q] >= 0;
+                // a pass that will be repeated with another threshold: the tracking block runs once, after the last pass
+                if (pre_detected == 0 && h->thres_method == 1 && attempts + 1 < h->n_attempts_auto_fix) return ORBFE_OK;
+                h->marker_counts = counts_at_start;
+                std::vector<std::array<std::array<float, 2>, 4>> cs((size_t)std::max(ncand, 1));
+                for (int q = 0; q < ncand; q++) memcpy(&cs[q], rc_[cidx[q]].c, sizeof(float) * 8);
+                h->last_tracked = track_missing_markers(h, ncand, res, reinterpret_cast<const float (*)[4][2]>(cs.data()));
+                if (h->last_tracked) ORBFE_HIP(hipMemcpyAsync(h->d_result.p, res, (size_t)AR_MAX_RECTS * 8, hipMemcpyHostToDevice, st));
+                return ORBFE_OK;
+            };
         for (;;) {
             h->last_attempts++;
             const int thr = h->thres_method == 1 ? h->thres_value : -1;
             uint32_t* d_hist = h->thres_method == 1 ? h->d_mhist.as<uint32_t>() : nullptr;
             for (int pass = 0; pass < 2; pass++) { // a frame that exceeds the LDS-resident kernels' capacities is done again in big-frame mode
                 if (wc != cols) rc = reduced_batch(h, h->d_in.as<uint8_t>(), 1, dframe, rows, cols, dpitch, wr, wc, h->d_out.as<orbfe_marker>(), AR_MAX_RECTS,
-                                                   h->d_nout.as<int32_t>(), s, thr, d_hist);
+                                                   h->d_nout.as<int32_t>(), s, thr, d_hist, track_hook);
                 else {
                     ModeRun mr;
-                    mr.fixed_thr = thr; mr.d_hist = d_hist;
+                    mr.fixed_thr = thr; mr.d_hist = d_hist; mr.before_finalize = track_hook;
                     rc = h->run_device(h->d_in.as<uint8_t>(), 1, dframe, rows, cols, dpitch, h->d_out.as<orbfe_marker>(), AR_MAX_RECTS,
                                        h->d_nout.as<int32_t>(), s, &mr);
                 }
@@ -942,7 +1091,8 @@ static int detect_frames_modes(orbfe_aruco* h, const uint8_t* imgs, int nframes,
             }
             h->big_mode = user_big_mode;
             if (counts[2]) return fail(ORBFE_ERR_CAPACITY, "frame %d: internal detector capacity exceeded (flags 0x%x)", f, counts[2]);
-            if (np[0] == 0 && h->thres_method == 1 && ++attempts < h->n_attempts_auto_fix) {
+            // (the retry is decided on what the dictionary found, before the tracking block adds anything: :6903)
+            if ((h->tracking_min > 0 ? pre_detected : np[0]) == 0 && h->thres_method == 1 && ++attempts < h->n_attempts_auto_fix) {
                 h->thres_value = 10 + rand() % 230;
                 continue;
             }
@@ -965,6 +1115,7 @@ static int detect_frames_modes(orbfe_aruco* h, const uint8_t* imgs, int nframes,
         }
         const float marker_min = shortest != std::numeric_limits<float>::max() ? shortest / (4 * std::max(cols, rows)) : 0.f;
         if (h->auto_size) h->min_size = marker_min * (1 - h->ts);
+        if (h->tracking_min > 0) h->prev_markers.assign(mk, mk + std::min(n, (int)AR_MAX_RECTS));
         n_out[f] = n;
         if (n > capacity) return fail(ORBFE_ERR_CAPACITY, "frame %d has %d markers, capacity is %d", f, n, capacity);
         if (n) memcpy(out + (size_t)f * capacity, mk, (size_t)n * sizeof(orbfe_marker));

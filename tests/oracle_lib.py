@@ -93,6 +93,7 @@ def _bind_aruco(L):
     L.oracle_aruco_set_detection_mode.argtypes = [C.c_void_p, C.c_int, C.c_float]
     L.oracle_aruco_set_corner_method.argtypes = [C.c_void_p, C.c_int]
     L.oracle_aruco_set_enclosed.argtypes = [C.c_void_p, C.c_int]
+    L.oracle_aruco_set_tracking.argtypes = [C.c_void_p, C.c_int]
     L.oracle_aruco_state.argtypes = [C.c_void_p, C.c_int]
     L.oracle_aruco_min_size.restype = C.c_float
     L.oracle_aruco_min_size.argtypes = [C.c_void_p]
@@ -579,6 +580,13 @@ class ArucoOracle:
     def detect_enclosed_markers(self, on=True):
         """Params::detectEnclosedMarkers (markerdetector.h:126)."""
         self.L.oracle_aruco_set_enclosed(self.h, int(on))
+
+    def set_tracking(self, min_detections):
+        """Params::trackingMinDetections (markerdetector.h:187)."""
+        self.L.oracle_aruco_set_tracking(self.h, int(min_detections))
+
+    def tracked(self):
+        return self.L.oracle_aruco_state(self.h, 4)
 
     def state(self):
         return {"threshold": self.L.oracle_aruco_state(self.h, 0), "min_size": self.L.oracle_aruco_min_size(self.h),

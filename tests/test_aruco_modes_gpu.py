@@ -138,6 +138,54 @@ def test_detect_enclosed_markers(orbfe, oracle, mode, min_size, corner):
     assert not np.array_equal(plain.rects(0)["corners"][:len(grects)], grects["corners"][:len(plain.rects(0))])
 
 
+def _damaged(img, quad, frac=0.45, val=128):
+    """The marker's code painted over with a flat grey (its black border stays): the rectangle is still found, the dictionary rejects it."""
+    q = np.asarray(quad, np.float64); c = q.mean(0)
+    inner = c + (q - c) * frac
+    ys, xs = np.mgrid[0:img.shape[0], 0:img.shape[1]]
+    inside = np.ones(img.shape, bool)
+    sign = None
+    for k in range(4):
+        a, b = inner[k], inner[(k + 1) % 4]
+        cr = (b[0] - a[0]) * (ys - a[1]) - (b[1] - a[1]) * (xs - a[0])
+        sign = np.sign(cr[int(c[1]), int(c[0])]) if sign is None else sign
+        inside &= (cr * sign) >= 0
+    out = img.copy(); out[inside] = val
+    return out
+
+
+@pytest.mark.parametrize("mode,min_size,corner,nmin", [(0, 0.0, 1, 1), (0, 0.0, 1, 2), (1, 0.0, 0, 1), (2, 0.0, 0, 1), (0, 0.05, 0, 1)])
+def test_marker_tracking_adopts_rejected_candidates(orbfe, oracle, mode, min_size, corner, nmin):
+    """Params::trackingMinDetections: a marker found in enough calls and missing now is recovered from the candidates the dictionary
+    rejected (centre inside its last outline, similar area), with its id and the corner order of its previous orientation."""
+    img, truth = synth.scene(480, 640, 72, "ARUCO", 4, side_range=(60, 130))
+    d0, d1 = _damaged(img, truth[0][1]), _damaged(_damaged(img, truth[0][1]), truth[1][1])
+    shifted = np.roll(d0, 3, axis=1)                         # the scene moved by three pixels: still inside the last outline
+    seq = [img, img, img, d0, shifted, img, d1, d1, np.full_like(img, 90), img]
+    det, ora = orbfe.MarkerDetector("ARUCO"), oracle.ArucoOracle("ARUCO")
+    det.setCornerRefinementMethod(corner); ora.set_corner_method(corner)
+    det.setDetectionMode(mode, min_size); ora.set_detection_mode(mode, min_size)
+    det.setTracking(nmin); ora.set_tracking(nmin)
+    LIBC.srand(5)
+    want = [(ora.detect(im), ora.state(), ora.tracked()) for im in seq]
+    LIBC.srand(5)
+    got = [(det.detect(im), det.state(), det.tracked()) for im in seq]
+    compare([(g, s) for g, s, _ in got], [(w, s) for w, s, _ in want])
+    assert [t for _, _, t in got] == [t for _, _, t in want]
+    if mode != 2 and min_size == 0.0:
+        assert sum(t for _, _, t in want) >= 2                 # something was recovered
+    else:                                                      # on a reduced working image the rejected candidates keep ITS coordinates
+        assert sum(t for _, _, t in want) == 0                 # (the reference compares them with full-size outlines: nothing matches)
+    if mode == 0 and min_size == 0.0:
+        ids = want[3][0]["id"].tolist()
+        assert truth[0][0] in ids and want[3][2] == 1            # the painted-over marker is back, under its id
+    det.setTracking(0)                                        # off: the history is gone, plain detection again
+    LIBC.srand(5)
+    assert det.tracked() == 0 and truth[0][0] not in det.detect(d0)["id"].tolist()
+    with pytest.raises(orbfe.OrbfeError):
+        det.setTracking(-1)
+
+
 def test_bgr_input(orbfe, oracle):
     rng = np.random.default_rng(5)
     img, truth = synth.scene(480, 640, 3, "ARUCO", 4)

@@ -12,7 +12,7 @@ LIBC = ctypes.CDLL(None)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 dics = ["ARUCO", "ARUCO_MIP_36h12", "ARUCO_MIP_25h7", "ARUCO_MIP_16h3", "TAG36h11"]
-bad = refused = frames = markers = retries = reduced = 0
+bad = refused = frames = markers = retries = reduced = tracked = 0
 for case in range(n):
     cols, rows = int(rng.integers(200, 1400)), int(rng.integers(150, 800))
     if case % 5 == 0: cols, rows = 640, 480
@@ -23,8 +23,18 @@ for case in range(n):
     bgr = bool(rng.integers(0, 4) == 0)
     bits = 14 if rng.integers(0, 2) else 15
     enclosed = bool(rng.integers(0, 3) == 0)
+    track = int(rng.integers(0, 3))                # trackingMinDetections
+    video = bool(rng.integers(0, 3) == 0)          # one scene, markers painted over at random: what the tracking block is for
     seq = []
-    for i in range(int(rng.integers(2, 6))):
+    if video:
+        from test_aruco_modes_gpu import _damaged
+        base, truth = synth.scene(rows, cols, int(rng.integers(1, 10 ** 6)), dic, int(rng.integers(2, 6)), side_range=(40, max(41, min(rows, cols) // 3)))
+        for i in range(int(rng.integers(4, 9))):
+            img = base
+            for t in truth:
+                if i >= 2 and rng.random() < 0.4: img = _damaged(img, t[1])
+            seq.append(np.roll(img, int(rng.integers(-2, 3)), axis=1))
+    for i in range(0 if video else int(rng.integers(2, 6))):
         try:
             img, _ = synth.scene(rows, cols, int(rng.integers(1, 10 ** 6)), dic, int(rng.integers(0, 5)), side_range=(30, max(31, min(rows, cols) // 3)))
         except Exception:
@@ -43,11 +53,14 @@ for case in range(n):
         det, ora = binding.MarkerDetector(dic), O.ArucoOracle(dic)
         det.setGrayConversion(bits)
         det.detectEnclosedMarkers(enclosed); ora.detect_enclosed_markers(enclosed)
+        det.setTracking(track); ora.set_tracking(track)
         det.setCornerRefinementMethod(corner); ora.set_corner_method(corner)
         det.setDetectionMode(mode, ms); ora.set_detection_mode(mode, ms)
         seed = int(rng.integers(1, 10 ** 6))
         LIBC.srand(seed)
-        want = [(ora.detect(im, bits15=int(bits == 15)), ora.state()) for im in seq]
+        want, ora_tracked = [], []
+        for im in seq:
+            want.append((ora.detect(im, bits15=int(bits == 15)), ora.state())); ora_tracked.append(ora.tracked())
         LIBC.srand(seed)
         for i, im in enumerate(seq):
             try:
@@ -60,6 +73,9 @@ for case in range(n):
             if (gs["attempts"], gs["threshold"], tuple(gs["work_shape"])) != (ws["attempts"], ws["threshold"], tuple(ws["work_shape"])) or \
                     np.float32(gs["min_size"]) != np.float32(ws["min_size"]):
                 why.append("frame %d state %s vs %s" % (i, gs, ws)); break
+            tracked += ora_tracked[i]
+            if det.tracked() != ora_tracked[i]:
+                why.append("frame %d tracked %d vs %d" % (i, det.tracked(), ora_tracked[i])); break
             if not (np.array_equal(g["id"], w["id"]) and np.allclose(g["corners"], w["corners"], atol=1e-3)):
                 why.append("frame %d markers %s vs %s (max corner diff %s)" % (i, g["id"].tolist(), w["id"].tolist(),
                                                                           np.abs(g["corners"] - w["corners"]).max() if len(g) == len(w) and len(g) else None)); break
@@ -67,6 +83,6 @@ for case in range(n):
         why.append("exception %r" % (e,))
     if why:
         bad += 1
-        print("case %d %dx%d %s mode %d minSize %.2f corner %d bgr %d/%d enclosed %d: %s" % (case, cols, rows, dic, mode, ms, corner, bgr, bits, enclosed, why))
-print("%d cases, %d frames (%d markers, %d with retries, %d on a reduced image, %d sequences refused as documented), %d mismatches" %
-      (n, frames, markers, retries, reduced, refused, bad))
+        print("case %d %dx%d %s mode %d minSize %.2f corner %d bgr %d/%d enclosed %d track %d video %d: %s" % (case, cols, rows, dic, mode, ms, corner, bgr, bits, enclosed, track, video, why))
+print("%d cases, %d frames (%d markers, %d recovered by tracking, %d frames with retries, %d on a reduced image, %d sequences refused as documented), %d mismatches" %
+      (n, frames, markers, tracked, retries, reduced, refused, bad))
