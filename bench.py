@@ -361,7 +361,7 @@ def main():
     # line a diagnostic (value null) unless they spell the default
     env_set = {k: v for k, v in sorted(os.environ.items()) if k.startswith("ORBFE_")}
     harmless = {"ORBFE_BENCH_DEVICE", "ORBFE_BENCH_BACKEND", "ORBFE_LIB"}   # (ORBFE_GATHER_NOOP is not: it makes the line a diagnostic)
-    defaults = {"ORBFE_ORIENT_PAIR": "1", "ORBFE_FAST0": "0", "ORBFE_EARLY_SHARED": "0", "ORBFE_ARUCO_VIS": "0", "ORBFE_ARUCO_FORCE_GLOBAL": "0", "ORBFE_STREAM_PRIO": "0,0,0", "ORBFE_ENGINE_SETS_ARUCO": "1", "ORBFE_PHASE_PIN": "2", "ORBFE_DET_PIN": "0", "ORBFE_LEND_ALL": "1", "ORBFE_RECORD_SETS": "4", "ORBFE_GATHER_STREAM": "match", "ORBFE_DET_NOFORK": "0",
+    defaults = {"ORBFE_ORIENT_PAIR": "1", "ORBFE_FAST0": "0", "ORBFE_EARLY_SHARED": "0", "ORBFE_ARUCO_VIS": "0", "ORBFE_ARUCO_FORCE_GLOBAL": "0", "ORBFE_STREAM_PRIO": "0,0,0", "ORBFE_ENGINE_SETS_ARUCO": "1", "ORBFE_PHASE_PIN": "2", "ORBFE_DET_PIN": "4", "ORBFE_LEND_ALL": "1", "ORBFE_RECORD_SETS": "4", "ORBFE_GATHER_STREAM": "match", "ORBFE_DET_NOFORK": "0",
                 "ORBFE_BLUR_PLACE": "1", "ORBFE_ARUCO_RELAY_CHUNK": "0", "ORBFE_OCC_FAST": "0", "ORBFE_OCC_BLUR": "0",
                 "ORBFE_OCC_ORIENT": "0"}
     defaults["ORBFE_DET_NOFORK"] = "1" if args.rows * args.cols <= 640 * 480 else "0"    # pipeline.py: by frame size
@@ -644,7 +644,7 @@ def main():
                        "frames_per_step_per_gpu": B, "mean_keypoints_per_frame": N, "marker_records_per_frame": pipe.mcap,
                        "result_record_bytes_per_step_per_gpu": pipe.layout.nbytes, "resident_batches": R,
                        "sub_batches": pipe.S, "engine_sets": pipe.D, "engine_phase_lock_stage": pipe.phase_pin if pipe.D > 1 else 0,
-                       "detector_pyramid_in_line": bool(getattr(pipe, "det_nofork", False)), "aruco_big_frame_kernel": pipe.big_frames, "library": version,
+                       "detector_pyramid_in_line": bool(getattr(pipe, "det_nofork", False)), "detector_phase_stage": getattr(pipe, "det_pin", 0), "aruco_big_frame_kernel": pipe.big_frames, "library": version,
                        "library_sha16": lib_sha16, "env": env_set, "env_nondefault": env_nondefault or None,
                        "parallelism": "stream-per-gpu x%d, %s" % (world, ("%s gather to rank 0" % ("RCCL" if backend == "nccl" else backend))
                                                                   if multi else "no collective (one rank)")},

@@ -147,11 +147,12 @@ int orbfe_extractor_set_aux_stream(orbfe_extractor* h, void* stream);
  * restores the default.  Ordering is by events either way. */
 int orbfe_extractor_set_early_stream(orbfe_extractor* h, void* stream);
 /* Phase lock between the extractor handles of a pipeline (device-pointer batches): every batch of `h` starts behind a stage of the
- * latest batch enqueued on `other` -- stage 1 = its FAST, 2 = its quadtree, 3 = its descriptors; 0 or other == NULL: free running.
+ * latest batch enqueued on `other` -- stage 1 = its FAST, 2 = its quadtree, 3 = its descriptors, 4 = its resize chain (FAST starts); 0 or
+ * other == NULL: free running.
  * Two engine sets that follow each other run a fixed half-period apart instead of in whatever phase contention leaves them
  * (bench.py: measured).  `other` must outlive the relation.  Results do not depend on it. */
 int orbfe_extractor_follow(orbfe_extractor* h, orbfe_extractor* other, int stage);
-/* The same relation for any other work of the pipeline: whatever is enqueued on `stream` after this call starts behind stage 1 .. 3
+/* The same relation for any other work of the pipeline: whatever is enqueued on `stream` after this call starts behind stage 1 .. 4
  * of the latest batch enqueued on `h` (nothing to wait for before its first batch). */
 int orbfe_extractor_stage_wait(orbfe_extractor* h, int stage, void* stream);
 

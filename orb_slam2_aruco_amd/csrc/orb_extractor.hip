@@ -100,8 +100,8 @@ struct orbfe_extractor {
     // orbfe_extractor_follow: this handle's batches start behind a stage of ANOTHER handle's latest batch (two engine sets of a
     // pipeline hold a fixed phase that way instead of whatever the contention of the moment settles on)
     orbfe_extractor* follow = nullptr;
-    int follow_stage = 0;                // 1 = the other's FAST, 2 = its quadtree, 3 = its descriptors (the whole batch)
-    hipEvent_t ev_stage[3] = {nullptr, nullptr, nullptr};
+    int follow_stage = 0;                // 1 = the other's FAST, 2 = its quadtree, 3 = its descriptors (the whole batch), 4 = its resize chain
+    hipEvent_t ev_stage[4] = {nullptr, nullptr, nullptr, nullptr};   // after FAST, the quadtree, the descriptors; [3] = after the resize chain (FAST starts)
     bool stage_recorded = false;
     // FAST of level 0 from the start of the batch, next to the resize chain: 0 off (default), 1 on the handle's second stream (or the one
     // named by orbfe_extractor_set_early_stream), 2 on the lent one.  Measured in round 3 (profiles/r03_fast0_early.txt): the launch
@@ -417,7 +417,7 @@ struct orbfe_extractor {
         last_nframes = B;
         last_src0 = src0;
         timer.begin();
-        if (follow && follow != this && follow->stage_recorded && follow_stage >= 1 && follow_stage <= 3)
+        if (follow && follow != this && follow->stage_recorded && follow_stage >= 1 && follow_stage <= 4)
             ORBFE_HIP(hipStreamWaitEvent(s, follow->ev_stage[follow_stage - 1], 0));
         timer.mark(s, "start");
         auto launch_fast = [&](hipStream_t st, int cell_base, int cell_end) -> int {
@@ -473,6 +473,10 @@ struct orbfe_extractor {
             }
         }
         timer.mark(s, "resize");
+        {   // stage 4: the pyramid is there, FAST starts
+            if (!ev_stage[3]) ORBFE_HIP(hipEventCreateWithFlags(&ev_stage[3], hipEventDisableTiming));
+            ORBFE_HIP(hipEventRecord(ev_stage[3], s));
+        }
         // The blur only needs the pyramid, and only k_orient_describe needs the blur: it runs on a second stream, forked in front of
         // FAST.  Measured on the C2 batch (step time with the detector running / extractor alone, ms): fork in front of FAST 1.83 /
         // 1.76, fork after FAST (blur next to the quadtree) 1.88 / 1.76, no fork 1.97 / 1.75 -- orbfe_extractor_debug_kernel_times
@@ -856,7 +860,7 @@ int orbfe_extractor_pair_detector(orbfe_extractor* h, orbfe_aruco* detector)
 
 int orbfe_extractor_follow(orbfe_extractor* h, orbfe_extractor* other, int stage)
 {
-    if (!h || stage < 0 || stage > 3 || (other && other->device != h->device)) return fail(ORBFE_ERR_INVALID, "orbfe_extractor_follow: invalid argument");
+    if (!h || stage < 0 || stage > 4 || (other && other->device != h->device)) return fail(ORBFE_ERR_INVALID, "orbfe_extractor_follow: invalid argument");
     h->follow = stage ? other : nullptr;
     h->follow_stage = stage;
     return ORBFE_OK;
@@ -864,7 +868,7 @@ int orbfe_extractor_follow(orbfe_extractor* h, orbfe_extractor* other, int stage
 
 int orbfe_extractor_stage_wait(orbfe_extractor* h, int stage, void* stream)
 {
-    if (!h || stage < 1 || stage > 3) return fail(ORBFE_ERR_INVALID, "orbfe_extractor_stage_wait: invalid argument");
+    if (!h || stage < 1 || stage > 4) return fail(ORBFE_ERR_INVALID, "orbfe_extractor_stage_wait: invalid argument");
     int rc = use_device(h->device);
     if (rc) return rc;
     if (h->stage_recorded) ORBFE_HIP(hipStreamWaitEvent((hipStream_t)stream, h->ev_stage[stage - 1], 0));

@@ -122,7 +122,12 @@ class FrontEndPipeline:
         # interleaved runs; the old kernels under the same lock: 1.40), C3 4.19 -> 3.95; behind FAST (1) 1.45, behind the
         # descriptors (3) 1.47.
         self.phase_pin = int(os.environ.get("ORBFE_PHASE_PIN", phase_pin))
-        self.det_pin = int(os.environ.get("ORBFE_DET_PIN", 0))
+        # The detector's phase (ORBFE_DET_PIN = stage of the extractor's PREVIOUS batch its batch starts behind; + 10: of the current
+        # batch; 0 = free running).  Free running the C2 step spread over 1.31 - 1.39 ms from run to run (two attractors); behind the
+        # previous batch's RESIZE CHAIN (4) 1.329 - 1.367 with the mean a little lower (1.3435 against 1.3495, twelve interleaved runs
+        # each; C3 3.98 against 4.00, gather branch 1.375 against 1.392).  Behind its FAST (1) 1.357, behind the current batch's
+        # stages (11 / 12 / 14) 1.348 / 1.381 / 1.365.
+        self.det_pin = int(os.environ.get("ORBFE_DET_PIN", 4))
         if self.phase_pin and D > 1 and S == 1:
             for d in range(D):
                 self.ex_sets[d][0].follow(self.ex_sets[(d - 1) % D][0], self.phase_pin)
@@ -244,37 +249,49 @@ class FrontEndPipeline:
         base = self.rec_ptr[cur]
         img0 = d_imgs.data_ptr()
         multi = self.gather is not None
-        if self.use_aruco:
-            # the detector streams only depend on the (resident) input frames and on their own previous batch, so they are
-            # not joined with the ORB streams per step: consecutive batches of the two engines pipeline freely.
-            for k in range(S):
-                f0, nf = self.bounds[k], self.bounds[k + 1] - self.bounds[k]
-                st = aru_streams[k]
-                if multi and i >= self.R:
-                    st.wait_event(self.gather_done[cur])         # batch i-R has left this record set
-                sp = ctypes.c_void_p(st.cuda_stream)
-                if self.det_pin and self.use_orb and i > 0:   # experiment: the detector's batch behind a stage of the extractor's previous one
-                    binding._check(L, L.orbfe_extractor_stage_wait(self.ex_sets[(i - 1) % self.D][k].h, self.det_pin, sp), "stage_wait")
-                dets[k].detect_batch_device(img0 + f0 * rows * pitch, nf, rows * pitch, rows, cols, pitch,
-                                                 base + lay.mk + f0 * mcap * 36, mcap, base + lay.nmk + f0 * 4, sp)
-                # detect(image, CameraParameters, 0.187): every marker gets its IPPE pose (markerdetector_impl.cpp:8720-8780)
-                binding._check(L, L.orbfe_marker_poses_batch_device(
-                    base + lay.mk + f0 * mcap * 36, base + lay.nmk + f0 * 4, mcap, nf, MARKER_SIZE,
-                    self.cam_K.ctypes.data_as(ctypes.c_void_p), self.cam_D.ctypes.data_as(ctypes.c_void_p), len(self.cam_D),
-                    base + lay.pose + f0 * mcap * 56, sp), "orbfe_marker_poses_batch_device")
-                self.det_done[cur][k].record(st)
-        if self.use_orb:
-            for k in range(S):
-                f0, nf = self.bounds[k], self.bounds[k + 1] - self.bounds[k]
-                st = orb_streams[k]
-                if i >= self.R:
-                    st.wait_event(self.match_done[cur])          # the matching of batch i-2 has read this record set
-                    if multi:
-                        st.wait_event(self.gather_done[cur])
-                exs[k].extract_batch_device(img0 + f0 * rows * pitch, nf, rows * pitch, rows, cols, pitch,
-                                                 base + lay.kps + f0 * cap * 28, base + lay.desc + f0 * cap * 32, cap,
-                                                 base + lay.n + f0 * 4, ctypes.c_void_p(st.cuda_stream))
-                self.ex_done[cur][k].record(st)
+        def enqueue_detector():
+            if self.use_aruco:
+                # the detector streams only depend on the (resident) input frames and on their own previous batch, so they are
+                # not joined with the ORB streams per step: consecutive batches of the two engines pipeline freely.
+                for k in range(S):
+                    f0, nf = self.bounds[k], self.bounds[k + 1] - self.bounds[k]
+                    st = aru_streams[k]
+                    if multi and i >= self.R:
+                        st.wait_event(self.gather_done[cur])         # batch i-R has left this record set
+                    sp = ctypes.c_void_p(st.cuda_stream)
+                    if self.det_pin and self.use_orb:
+                        # experiment (ORBFE_DET_PIN = stage, + 10: of THIS batch's extractor, which is then enqueued first): the detector's
+                        # batch starts behind a stage of the extractor's previous / current batch
+                        j = i if self.det_pin >= 10 else i - 1
+                        if j >= 0:
+                            binding._check(L, L.orbfe_extractor_stage_wait(self.ex_sets[j % self.D][k].h, self.det_pin % 10, sp), "stage_wait")
+                    dets[k].detect_batch_device(img0 + f0 * rows * pitch, nf, rows * pitch, rows, cols, pitch,
+                                                     base + lay.mk + f0 * mcap * 36, mcap, base + lay.nmk + f0 * 4, sp)
+                    # detect(image, CameraParameters, 0.187): every marker gets its IPPE pose (markerdetector_impl.cpp:8720-8780)
+                    binding._check(L, L.orbfe_marker_poses_batch_device(
+                        base + lay.mk + f0 * mcap * 36, base + lay.nmk + f0 * 4, mcap, nf, MARKER_SIZE,
+                        self.cam_K.ctypes.data_as(ctypes.c_void_p), self.cam_D.ctypes.data_as(ctypes.c_void_p), len(self.cam_D),
+                        base + lay.pose + f0 * mcap * 56, sp), "orbfe_marker_poses_batch_device")
+                    self.det_done[cur][k].record(st)
+
+        def enqueue_extractor():
+            if self.use_orb:
+                for k in range(S):
+                    f0, nf = self.bounds[k], self.bounds[k + 1] - self.bounds[k]
+                    st = orb_streams[k]
+                    if i >= self.R:
+                        st.wait_event(self.match_done[cur])          # the matching of batch i-2 has read this record set
+                        if multi:
+                            st.wait_event(self.gather_done[cur])
+                    exs[k].extract_batch_device(img0 + f0 * rows * pitch, nf, rows * pitch, rows, cols, pitch,
+                                                     base + lay.kps + f0 * cap * 28, base + lay.desc + f0 * cap * 32, cap,
+                                                     base + lay.n + f0 * 4, ctypes.c_void_p(st.cuda_stream))
+                    self.ex_done[cur][k].record(st)
+
+        if self.det_pin >= 10:
+            enqueue_extractor(); enqueue_detector()
+        else:
+            enqueue_detector(); enqueue_extractor()
         # What follows a batch's engines -- its matching and, on N > 1, its gather -- goes onto the matching stream, which also
         # carries the extractor's blur (lent).  Enqueued right away, the matching of batch i (which waits for the whole extractor
         # chain of batch i) would sit IN FRONT of the blur of batch i + 1 on that stream, and the descriptors of batch i + 1 wait
