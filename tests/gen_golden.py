@@ -21,7 +21,36 @@ from orb_slam2_aruco_amd import synth  # noqa: E402
 OUT = os.path.join(ROOT, "tests", "golden")
 
 
+def modes():
+    """The detector's other modes (oracle/aruco_oracle.cpp, csrc/aruco_modes.hip): one ten-frame sequence per configuration through ONE
+    detector behind srand(5) -- ids, corners, Params::ThresHold, threshold passes, working sizes, minSize and tracked markers per frame.
+    The frames are regenerated from their seeds by tests/test_aruco_modes_gpu.py::golden_sequence (checksum stored)."""
+    import ctypes
+    import test_aruco_modes_gpu as T
+    libc = ctypes.CDLL(None)
+    seq = T.golden_sequence()
+    out = {"frames_sum": np.array([int(sum(int(f.astype(np.int64).sum()) for f in seq))])}
+    for name, (mode, ms, corner, enclosed, track) in T.GOLDEN_CONFIGS.items():
+        o = O.ArucoOracle("ARUCO")
+        o.detect_enclosed_markers(enclosed); o.set_corner_method(corner); o.set_detection_mode(mode, ms); o.set_tracking(track)
+        libc.srand(5)
+        ids, corners, state = [], [], []
+        for im in seq:
+            m = o.detect(im)
+            st = o.state()
+            ids.append(np.pad(m["id"], (0, 8 - len(m)), constant_values=-1)[:8])
+            c = np.zeros((8, 4, 2), np.float32); c[:min(len(m), 8)] = m["corners"][:8]; corners.append(c)
+            state.append([st["threshold"], st["attempts"], st["work_shape"][0], st["work_shape"][1], o.tracked(), len(m)])
+        out[name + "_ids"] = np.array(ids, np.int32); out[name + "_corners"] = np.array(corners)
+        out[name + "_state"] = np.array(state, np.int32)
+    np.savez_compressed(os.path.join(OUT, "aruco_modes_seq.npz"), **out)
+    print("wrote aruco_modes_seq.npz")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "modes":   # only the fixture of the detector modes (the others stay byte for byte)
+        os.makedirs(OUT, exist_ok=True)
+        return modes()
     os.makedirs(OUT, exist_ok=True)
     # ORB: 240x320 crop-sized scene (image stored, ~77 KB) + 640x480 scene (only the seed is stored)
     img, _ = synth.scene(240, 320, 7, "ARUCO", 2, side_range=(40, 70))
@@ -102,6 +131,7 @@ def main():
                         fv2_offsets=t2["fv"][1], fv2_features=t2["fv"][2], valid1=valid1, bow_nmatches=np.array([nb]), bow_match12=b12,
                         x3Dw=x3, Tcw=Tcw, last_nmatches=np.array([nl]), last_match_cur=ml,
                         kf_sha256=np.frombuffer(hashlib.sha256(rec.tobytes()).digest(), np.uint8))
+    modes()
     print("wrote", sorted(os.listdir(OUT)))
 
 

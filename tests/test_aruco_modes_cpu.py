@@ -164,3 +164,26 @@ def test_enclosed_markers_edge_band_is_erosion_xor():
     # outwards: the enlarged quadrilateral contains the plain one's centroid and has the larger area
     def area(q): x, y = q[0::2], q[1::2]; return 0.5 * abs(np.dot(x, np.roll(y, -1)) - np.dot(y, np.roll(x, -1)))
     assert all(area(b[i, :8]) > area(a[i, :8]) for i in range(len(a)))
+
+
+def test_oracle_against_the_committed_mode_sequences():
+    """tests/golden/aruco_modes_seq.npz freezes the oracle's behaviour in the detector's other modes (any edit of oracle/ that changes
+    ids, thresholds, retries, working sizes, tracked markers or corners of these sequences is caught here)."""
+    import os
+    import test_aruco_modes_gpu as T
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "aruco_modes_seq.npz"))
+    seq = T.golden_sequence()
+    assert int(sum(int(f.astype(np.int64).sum()) for f in seq)) == int(g["frames_sum"][0])
+    for name, (mode, ms, corner, enclosed, track) in T.GOLDEN_CONFIGS.items():
+        o = oracle_lib.ArucoOracle("ARUCO")
+        o.detect_enclosed_markers(enclosed); o.set_corner_method(corner); o.set_detection_mode(mode, ms); o.set_tracking(track)
+        LIBC.srand(5)
+        for i, im in enumerate(seq):
+            m = o.detect(im); st = o.state()
+            assert [st["threshold"], st["attempts"], st["work_shape"][0], st["work_shape"][1], o.tracked(), len(m)] == g[name + "_state"][i].tolist(), (name, i)
+            n = min(len(m), 8)
+            assert np.array_equal(m["id"][:n], g[name + "_ids"][i][:n])
+            assert np.array_equal(m["corners"][:n], g[name + "_corners"][i][:n])
+    # the sequences do exercise what they are for
+    assert g["fast_lines_state"][:, 1].max() >= 2 and g["fast_enclosed_track_state"][:, 4].sum() + g["normal_track2_none_state"][:, 4].sum() >= 1
+    assert (g["video_subpix_state"][:, 3] < 640).any() and (g["normal_min06_subpix_state"][:, 3] < 640).all()

@@ -31,6 +31,39 @@ def frames(n, rows=480, cols=640, dic="ARUCO", seed0=70):
     return out
 
 
+# tests/golden/aruco_modes_seq.npz (tests/gen_golden.py modes): name -> (mode, minMarkerSize, corner method, enclosed, trackingMinDetections)
+GOLDEN_CONFIGS = {"fast_lines": (1, 0.0, 1, False, 0), "video_subpix": (2, 0.0, 0, False, 0), "normal_min06_subpix": (0, 0.06, 0, False, 0),
+                  "fast_enclosed_track": (1, 0.0, 1, True, 1), "normal_track2_none": (0, 0.0, 2, False, 2)}
+
+
+def golden_sequence():
+    """Ten frames: one scene, two of its markers painted over in some frames, a dark, an empty and a shifted frame."""
+    img, truth = synth.scene(480, 640, 72, "ARUCO", 4, side_range=(60, 130))
+    d0 = _damaged(img, truth[0][1]); d1 = _damaged(d0, truth[1][1])
+    dark = (img.astype(np.float32) * 0.22).astype(np.uint8)
+    return [img, img, d0, np.roll(d0, 2, axis=1), dark, img, d1, np.full_like(img, 90), img, d0]
+
+
+def test_golden_sequences_without_the_oracle(orbfe):
+    """The library against the committed fixture (generated from the oracle, tests/gen_golden.py modes): no oracle at run time."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "aruco_modes_seq.npz"))
+    seq = golden_sequence()
+    assert int(sum(int(f.astype(np.int64).sum()) for f in seq)) == int(g["frames_sum"][0])
+    for name, (mode, ms, corner, enclosed, track) in GOLDEN_CONFIGS.items():
+        det = orbfe.MarkerDetector("ARUCO")
+        det.detectEnclosedMarkers(enclosed); det.setCornerRefinementMethod(corner); det.setDetectionMode(mode, ms); det.setTracking(track)
+        LIBC.srand(5)
+        for i, im in enumerate(seq):
+            m = det.detect(im)
+            st = det.state()
+            want = g[name + "_state"][i]
+            assert [st["threshold"], st["attempts"], st["work_shape"][0], st["work_shape"][1], det.tracked(), len(m)] == want.tolist(), (name, i)
+            n = min(len(m), 8)
+            assert np.array_equal(m["id"][:n], g[name + "_ids"][i][:n]) and np.all(g[name + "_ids"][i][n:] == -1), (name, i)
+            assert np.allclose(m["corners"][:n], g[name + "_corners"][i][:n], atol=CORNER_TOL), (name, i)
+
+
 def run_both(orbfe, oracle, seq, dic, mode, min_size, corner, seed=11, enclosed=False):
     det, ora = orbfe.MarkerDetector(dic), oracle.ArucoOracle(dic)
     det.detectEnclosedMarkers(enclosed); ora.detect_enclosed_markers(enclosed)
