@@ -150,7 +150,9 @@ int orbfe_extractor_set_early_stream(orbfe_extractor* h, void* stream);
  * latest batch enqueued on `other` -- stage 1 = its FAST, 2 = its quadtree, 3 = its descriptors, 4 = its resize chain (FAST starts); 0 or
  * other == NULL: free running.
  * Two engine sets that follow each other run a fixed half-period apart instead of in whatever phase contention leaves them
- * (bench.py: measured).  `other` must outlive the relation.  Results do not depend on it. */
+ * (bench.py: measured).  stage + 10 * g adds a second gate: the handle's FAST waits for stage g of `other` (with stage
+ * % 10 == 0 the resize chain starts freely; measured slower in every combination).  `other` must outlive the
+ * relation.  Results do not depend on it. */
 int orbfe_extractor_follow(orbfe_extractor* h, orbfe_extractor* other, int stage);
 /* The same relation for any other work of the pipeline: whatever is enqueued on `stream` after this call starts behind stage 1 .. 4
  * of the latest batch enqueued on `h` (nothing to wait for before its first batch). */

@@ -101,6 +101,7 @@ struct orbfe_extractor {
     // pipeline hold a fixed phase that way instead of whatever the contention of the moment settles on)
     orbfe_extractor* follow = nullptr;
     int follow_stage = 0;                // 1 = the other's FAST, 2 = its quadtree, 3 = its descriptors (the whole batch), 4 = its resize chain
+    int follow_fast_stage = 0;           // a second gate in front of this handle's FAST (0 = none): the resize chain may run earlier
     hipEvent_t ev_stage[4] = {nullptr, nullptr, nullptr, nullptr};   // after FAST, the quadtree, the descriptors; [3] = after the resize chain (FAST starts)
     bool stage_recorded = false;
     // FAST of level 0 from the start of the batch, next to the resize chain: 0 off (default), 1 on the handle's second stream (or the one
@@ -506,6 +507,8 @@ struct orbfe_extractor {
             return ORBFE_OK;
         };
         if (blur_place == 1) { int rcb = launch_blur(); if (rcb) return rcb; }
+        if (follow && follow != this && follow->stage_recorded && follow_fast_stage >= 1 && follow_fast_stage <= 4)
+            ORBFE_HIP(hipStreamWaitEvent(s, follow->ev_stage[follow_fast_stage - 1], 0));
         if ((rc = launch_fast(s, fast0 ? ncells_l0 : 0, ncells_total))) return rc;
         timer.mark(s, "fast_cells");
         if (fast0) ORBFE_HIP(hipStreamWaitEvent(s, ev_join0, 0));
@@ -860,9 +863,11 @@ int orbfe_extractor_pair_detector(orbfe_extractor* h, orbfe_aruco* detector)
 
 int orbfe_extractor_follow(orbfe_extractor* h, orbfe_extractor* other, int stage)
 {
-    if (!h || stage < 0 || stage > 4 || (other && other->device != h->device)) return fail(ORBFE_ERR_INVALID, "orbfe_extractor_follow: invalid argument");
+    if (!h || stage < 0 || stage % 10 > 4 || stage / 10 > 4 || (other && other->device != h->device)) return fail(ORBFE_ERR_INVALID, "orbfe_extractor_follow: invalid argument");
+    // stage = start gate + 10 * gate in front of FAST (either may be 0)
     h->follow = stage ? other : nullptr;
-    h->follow_stage = stage;
+    h->follow_stage = stage % 10;
+    h->follow_fast_stage = stage / 10;
     return ORBFE_OK;
 }
 
