@@ -122,6 +122,14 @@ __global__ __launch_bounds__(256) void k_resize_tab(ImgView src, ImgView dst, in
                                                     const int* __restrict__ xal, const int* __restrict__ yofs,
                                                     const int* __restrict__ ybe, int nx, int total)
 {
+#ifndef ORBFE_PRIO_RESIZE
+#define ORBFE_PRIO_RESIZE 2
+#endif
+    // Under the phase lock the step is the extractor chain resize -> FAST -> quadtree, and the resize chain's seven small launches are
+    // stretched 2.4x by whatever shares their CUs (469 us in the pipeline, 194 alone): their waves go first.  Twelve interleaved runs
+    // each: 1.3450 against 1.3607 ms per C2 step at priority 2 (medians 1.340 / 1.361); priority 3 loses (1.42: it starves the
+    // detector's latency-bound kernels, which run at 2), FAST at priority 1 loses more (1.53).
+    __builtin_amdgcn_s_setprio(ORBFE_PRIO_RESIZE);
     int bx, f;
     if (!xcd_remap(nx, total, bx, f)) return;
     const int t = bx * 256 + threadIdx.x;
@@ -289,6 +297,9 @@ __global__ __launch_bounds__(256) void k_fast_cells(ImgView src0, ImgView pyr, c
     // Occupancy cap without an LDS request: claiming a high register makes the allocation FC_VGPR_TOP + 1 registers per lane, so fewer
     // waves (and with them fewer of this kernel's LDS-holding workgroups) fit a CU, and the detector's 65 - 77 KB workgroups find room
     asm volatile("" ::: FC_VGPR_TOP);
+#endif
+#ifdef ORBFE_PRIO_FAST
+    __builtin_amdgcn_s_setprio(ORBFE_PRIO_FAST); // (experiment: 1.53 against 1.36 ms per C2 step at priority 1)
 #endif
     const int lane = threadIdx.x & 63, wid = wave_id();
     int bx, f;
