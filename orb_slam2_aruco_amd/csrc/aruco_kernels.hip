@@ -808,6 +808,9 @@ __device__ __forceinline__ void rl_advance(const BitImage& im, RelayWalk& w, uns
 #ifndef RL_FETCH_GATE
 #define RL_FETCH_GATE 1
 #endif
+#ifndef RL_FETCH_TRIES
+#define RL_FETCH_TRIES 1   // experiment (build parameter): refill attempts of phase (c) per loop trip
+#endif
 // RL_FETCH_GATE > 1 (experiment, build parameter): a walk loop refills its idle lanes only when at least that many lanes of the wave
 // are idle (or none is walking), so that the refill block is issued for many lanes at a time instead of a few on every trip
 #if RL_FETCH_GATE > 1
@@ -1029,6 +1032,7 @@ __device__ __forceinline__ int relay_frame(
 #ifdef ORBFE_CT_TIMING
             dbg_iters++;
 #endif
+            for (int tries_ = 0; tries_ < RL_FETCH_TRIES; tries_++)   // (a lane that drew an empty word, or a one-pixel border, tries again at once)
             if (!busy && !drained && RL_GATE_OPEN(busy, drained)) {
                 if (!(m_outer | m_hole)) {
                     const int i = atomicAdd(&s_next, 1);

@@ -905,7 +905,10 @@ __global__ __launch_bounds__(QP_THREADS) void k_distribute_pyr(const LevelGeom* 
                                                        int32_t* __restrict__ lvl_ncand, int32_t* __restrict__ fallback,
                                                        int D, int nodecap, int veccap)
 {
-    __builtin_amdgcn_s_setprio(2); // latency-bound: its few waves go first when a VALU-bound kernel shares the CU
+#ifndef ORBFE_PRIO_QT
+#define ORBFE_PRIO_QT 2
+#endif
+    __builtin_amdgcn_s_setprio(ORBFE_PRIO_QT); // latency-bound: its few waves go first when a VALU-bound kernel shares the CU
     extern __shared__ __align__(16) unsigned char qp_smem[];
     __shared__ int s_ncand;
     // QP_THREADS threads build the leaf counts (the only part that is parallel over candidates), then one wave runs the
