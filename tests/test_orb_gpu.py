@@ -203,7 +203,7 @@ def test_phase_lock_between_handles_changes_no_result(orbfe, oracle):
     free = orbfe.ORBextractor(1000, 1.2, 8, 20, 7)
     want = [free(im) for im in imgs]
     a, b = orbfe.ORBextractor(1000, 1.2, 8, 20, 7), orbfe.ORBextractor(1000, 1.2, 8, 20, 7)
-    for stage in (1, 2, 3, 4):
+    for stage in (1, 2, 3, 4, 21, 20, 14):   # (+ 10 g: a second gate in front of the follower's FAST)
         a.follow(b, stage); b.follow(a, stage)
         for i, im in enumerate(imgs):
             kps, desc = (a if i % 2 == 0 else b)(im)
@@ -213,6 +213,8 @@ def test_phase_lock_between_handles_changes_no_result(orbfe, oracle):
     assert np.array_equal(kps, want[0][0])
     with pytest.raises(orbfe.OrbfeError):
         a.follow(b, 5)
+    with pytest.raises(orbfe.OrbfeError):
+        a.follow(b, 52)
     L = a.L
     assert L.orbfe_extractor_stage_wait(a.h, 0, None) != 0 and L.orbfe_extractor_stage_wait(a.h, 5, None) != 0
     assert L.orbfe_extractor_stage_wait(a.h, 2, None) == 0      # the null stream waits for a's latest quadtree: harmless
