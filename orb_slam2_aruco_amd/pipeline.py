@@ -175,8 +175,16 @@ class FrontEndPipeline:
         if S == 1 and D > 1 and lend_aux_stream and os.environ.get("ORBFE_LEND_ALL", "1") != "0":
             # every set's blur on the matching stream (1.4466 against 1.4873 ms with the handles' own fork streams, which share
             # hardware queues with the busy ones)
-            for e in self.exs:
-                e.set_aux_stream(self.sp3)
+            # (experiment ORBFE_BLUR_LEND = det / other: the blur on the detector's stream / on the OTHER extractor set's stream)
+            lend = os.environ.get("ORBFE_BLUR_LEND", "match")
+            for d, es in enumerate(self.ex_sets):
+                for e in es:
+                    if lend == "det" and use_aruco:
+                        e.set_aux_stream(ctypes.c_void_p(self.aru_stream_sets[0][0].cuda_stream))
+                    elif lend == "other":
+                        e.set_aux_stream(ctypes.c_void_p(self.orb_stream_sets[(d + 1) % D][0].cuda_stream))
+                    else:
+                        e.set_aux_stream(self.sp3)
         if S == 1 and D == 1 and lend_aux_stream:
             # ROCm maps streams onto 4 hardware queues, and two busy streams on one queue serialise.  The extractor's forked
             # launch (the blur) is lent the matching stream; measured against the handle's own fork stream and against one
