@@ -2,7 +2,8 @@
 """bench.py -- frames/s of the per-frame front-end (ORB extract + ArUco detect + Hamming match) on MI355X.
 
     python bench.py --gpus N --steps K --warmup W [--config C2|C3|C4|C5]
-    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: either as above -- bench.py then starts the N ranks itself through torch.distributed.run -- or under a launcher:
+     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...; WORLD_SIZE must equal N)
 
 One step = one pass of the hot path (orb_slam2_aruco_amd/pipeline.py: FrontEndPipeline.step) over one batch: a synthetic
 mono stream resident in HBM before the timed region.  Default = BASELINE.json configs[1] (C2: 300 frames 640x480,
@@ -65,6 +66,8 @@ def parse():
     ap.add_argument("--no-orb", action="store_true", help="diagnostic only: drop the ORB + matching legs (value becomes null)")
     ap.add_argument("--force-gather", action="store_true", help="with --gpus 1: still initialise the RCCL process group (world size 1) "
                     "and run the batch's device-tensor gather on the communication stream, so the N > 1 branch executes on a one-GPU box")
+    ap.add_argument("--launch-check", action="store_true", help="only start the ranks, count them over gloo and print n_gpus (no GPU "
+                    "needed: the CPU test of the --gpus N launcher)")
     ap.add_argument("--latency", action="store_true", help="single-frame latency through the host-pointer ABI instead")
     ap.add_argument("--out", default=None, help="also write the JSON line to this file")
     args = ap.parse_args()
@@ -305,16 +308,72 @@ def latency_mode(args):
         open(args.out, "w").write(json.dumps(out) + "\n")
 
 
+def free_port():
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` started WITHOUT torchrun (the form the driver uses for N = 1): become the launcher of N ranks on
+    this node -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>
+    bench.py <the same arguments>` -- and pass its exit code on.  Rank 0 of the children prints the JSON line."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def launch_check(args, world, rank):
+    """--launch-check: the N-rank launch of `--gpus N` without a GPU (CPU test of the launcher): every rank joins a gloo group,
+    the ranks are counted with an all-reduce and listed with an all-gather, rank 0 prints a line with n_gpus and no value."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+        one = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(one)
+        ranks = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(ranks, torch.tensor([rank], dtype=torch.int64))
+        counted, ranks = int(one.item()), [int(r.item()) for r in ranks]
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        counted, ranks = 1, [0]
+    if rank == 0:
+        line = json.dumps({"metric": "launch check (no GPU work)", "value": None, "n_gpus": world, "ranks_counted": counted, "ranks": ranks,
+                           "launched_by": "bench.py --gpus %d" % args.gpus if os.environ.get("ORBFE_BENCH_SELF_LAUNCHED") else "torchrun"})
+        print(line)
+        if args.out:
+            open(args.out, "w").write(line + "\n")
+
+
 def main():
     args = parse()
     if args.latency:
         return latency_mode(args)
-    import torch
-    import torch.distributed as dist
-
+    # --gpus N is the number of ranks.  Under torchrun (WORLD_SIZE set) it must agree with the launcher; without it and N > 1 this
+    # process launches the N ranks itself, so that the plain command `python bench.py --gpus N` measures N GPUs.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        os.environ["ORBFE_BENCH_SELF_LAUNCHED"] = "1"
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE): start it as `python bench.py --gpus N` "
+                         "or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (args.gpus, world))
+    if args.launch_check:
+        return launch_check(args, world, rank)
+    import torch
+    import torch.distributed as dist
+
     # test hooks (single-GPU box): ORBFE_BENCH_DEVICE pins every rank to one device, ORBFE_BENCH_BACKEND=gloo replaces RCCL
     if os.environ.get("ORBFE_BENCH_DEVICE"):
         local_rank = int(os.environ["ORBFE_BENCH_DEVICE"])
@@ -328,8 +387,7 @@ def main():
         os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK=str(local_rank))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:
-            import socket
-            sk = socket.socket(); sk.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(sk.getsockname()[1]); sk.close()
+            os.environ["MASTER_PORT"] = str(free_port())
     if multi:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)

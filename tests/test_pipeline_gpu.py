@@ -64,6 +64,23 @@ def test_bench_two_ranks_on_one_gpu_gather_is_verified(tmp_path):
     assert d["verified_frames"]["frames"] == [0, 8, 15]
 
 
+@pytest.mark.gpu
+def test_bench_gpus_2_plain_command_launches_two_ranks(tmp_path):
+    """The driver's plain command, `python bench.py --gpus 2`, with no launcher around it: bench.py starts the two ranks itself
+    (both pinned to device 0 over gloo here, the one-GPU box's test hooks) and the line says n_gpus 2 with both ranks' records
+    gathered and checked."""
+    import json
+    out = tmp_path / "b2p.json"
+    env = dict(os.environ, ORBFE_BENCH_DEVICE="0", ORBFE_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--frames", "16", "--steps", "3", "--warmup", "1",
+                        "--cpu-frames", "0", "--out", str(out)], capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = json.loads(out.read_text())
+    assert d["n_gpus"] == 2 and d["gather_check"]["ranks"] == [0, 1] and d["value"] > 0
+
+
 def _free_port():
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
