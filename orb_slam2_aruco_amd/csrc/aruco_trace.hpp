@@ -291,4 +291,38 @@ ORBFE_HD int relay_start_dir(unsigned ring, int is_hole)
     return (d0 + j) & 7;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// TILES: the relay formulation cut into independent pieces of the frame (k_ct_walk, tests/proto_contours.cpp).
+//
+// A segment -- the states from one grid marker up to the next -- never crosses a relay row or column: passing from one side of
+// a relay row to the other turns counter-clockwise through W or E on a pixel of that row, which makes that state a marker (the
+// same with N / S on a relay column).  So the pixels of a segment, its end marker included, lie in one CLOSED grid cell (the
+// cell with its four grid lines), and the same holds for a border that touches no marker at all.  A tile is a closed rectangle
+// of whole cells, [x0, x1] x [y0, y1] in padded coordinates with all four numbers multiples of K; a workgroup that holds the
+// tile and one more pixel on every side can therefore do, without looking at anything else,
+//   * every segment whose pixels lie in the tile, and
+//   * every small border whose pixels lie in the tile.
+// A walk that leaves the tile is abandoned: it is a neighbour's.  Pixels on the grid line between two tiles belong to both, so
+// a segment (at least two pixels) that lies entirely on a shared line is seen by both: it goes to the tile below / to the right
+// of the line (the one for which the line is y0 / x0), i.e. a tile skips what lies entirely on its bottom row or right column
+// when a neighbour exists there.  A small border cannot lie entirely on a grid line (its ends would be markers); its start
+// candidate may lie on a shared COLUMN, then both tiles try and the one on whose side the border runs completes it.  Start
+// candidates on relay ROWS are never small borders: the start state's run holds W (outer) or E (hole).
+struct RelayTile {
+    int x0, y0, x1, y1; // closed rectangle, padded coordinates
+    int right, lower;   // a neighbour tile exists beyond x1 / beyond y1
+};
+// tile (band, col) of a W x H image: bands of K rows, cw columns per tile (a multiple of K); ceil(H / K) x ceil(W / cw) tiles
+ORBFE_HD RelayTile relay_tile(int W, int H, int K, int cw, int band, int col)
+{
+    RelayTile t;
+    t.x0 = col * cw; t.y0 = band * K; t.x1 = t.x0 + cw; t.y1 = t.y0 + K;
+    t.right = t.x1 < W ? 1 : 0;
+    t.lower = t.y1 < H ? 1 : 0;
+    return t;
+}
+ORBFE_HD bool relay_tile_has(const RelayTile& t, int x, int y) { return x >= t.x0 && x <= t.x1 && y >= t.y0 && y <= t.y1; }
+// a finished segment all of whose pixels had y == y1 (allbot) / x == x1 (allright): does this tile keep it?
+ORBFE_HD bool relay_tile_owns(const RelayTile& t, bool allbot, bool allright) { return !((t.lower && allbot) || (t.right && allright)); }
+
 } // namespace orbfe

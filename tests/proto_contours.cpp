@@ -185,3 +185,187 @@ extern "C" int proto_find_contours_relay(const uint8_t* img, int w, int h, int k
     }
     return (int)found.size();
 }
+
+
+// The TILED relay formulation (aruco_trace.hpp, "TILES"; k_ct_walk / k_ct_lists on the GPU): every tile of whole grid cells finds
+// its segments and its small borders from its own pixels plus one pixel on every side -- the rest of the image is filled with
+// noise in the tile's copy, so a read outside that window shows up as a wrong result -- and only the cyclic lists are global.
+// cells = tile width in grid cells.  stats: [segments, tiles, abandoned segment walks, skipped (neighbour's) segments, borders, abandoned small walks]
+extern "C" int proto_find_contours_tiled(const uint8_t* img, int w, int h, int kshift, int cells, int32_t* lengths,
+                                         int max_contours, int32_t* points, int max_points, int64_t* stats)
+{
+    const int wpr = (w + 2 + 31) / 32, K = 1 << kshift, kmask = K - 1, cw = cells * K;
+    std::vector<uint32_t> bits((size_t)wpr * (h + 2) + 2, 0);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+            if (img[(size_t)y * w + x]) bits[(size_t)(y + 1) * wpr + ((x + 1) >> 5)] |= 1u << ((x + 1) & 31);
+    struct C { int key; std::vector<uint32_t> pts; };
+    std::vector<C> found;
+    struct M { uint32_t key, next_key, cmin; int minoff, len, next; std::vector<uint32_t> pts; };
+    std::vector<M> mk;
+    std::unordered_map<uint32_t, int> idx;
+    int64_t n_abandoned = 0, n_skipped = 0, n_small_abandoned = 0, ntiles = 0;
+    const int nbands = (h + K - 1) / K, ncols = (w + cw - 1) / cw;
+    uint32_t lcg = 12345u;
+    for (int band = 0; band < nbands; band++)
+        for (int col = 0; col < ncols; col++) {
+            ntiles++;
+            const RelayTile t = relay_tile(w, h, K, cw, band, col);
+            // the tile's view: noise outside [x0 - 1, x1 + 1] x [y0 - 1, y1 + 1]
+            std::vector<uint32_t> tb(bits.size());
+            for (auto& v : tb) { lcg = lcg * 1664525u + 1013904223u; v = lcg; }
+            for (int y = std::max(0, t.y0 - 1); y <= std::min(h + 1, t.y1 + 1); y++)
+                for (int x = std::max(0, t.x0 - 1); x <= std::min(w + 1, t.x1 + 1); x++) {
+                    const uint32_t b = (bits[(size_t)y * wpr + (x >> 5)] >> (x & 31)) & 1u;
+                    uint32_t& v = tb[(size_t)y * wpr + (x >> 5)];
+                    v = (v & ~(1u << (x & 31))) | (b << (x & 31));
+                }
+            BitImage im{tb.data(), wpr, w, h};
+            // ---- segments from every marker state of the closed tile
+            for (int py = std::max(1, t.y0); py <= std::min(h, t.y1); py++)
+                for (int px = std::max(1, t.x0); px <= std::min(w, t.x1); px++) {
+                    if (!im.get(px, py)) continue;
+                    const unsigned ring = ring8(im, px, py);
+                    if (!ring) continue;
+                    relay_states_of_pixel(ring, grid_active(ring, px, py, kmask), [&](int s0) {
+                        M m{relay_key(px, py, s0), 0u, 0xffffffffu, 0, 0, -1, {}};
+                        RelayWalk wk;
+                        relay_walk_from_key(im, wk, m.key);
+                        bool allbot = py == t.y1, allright = px == t.x1, inside = true;
+                        for (;;) {
+                            unsigned run;
+                            const int d = relay_examine(wk.ring, wk.s, &run);
+                            if (wk.n > 0 && (run & grid_active(wk.ring, wk.x, wk.y, kmask))) { m.next_key = relay_key(wk.x, wk.y, wk.s); break; }
+                            if (relay_start_class(wk.ring, run)) {
+                                const uint32_t k = relay_key(wk.x, wk.y, wk.s);
+                                if (k < m.cmin) { m.cmin = k; m.minoff = wk.n; }
+                            }
+                            m.pts.push_back(relay_point(wk));
+                            const int nx = wk.x + dir_dx(d), ny = wk.y + dir_dy(d);
+                            if (!relay_tile_has(t, nx, ny)) { inside = false; break; } // a neighbour's segment
+                            relay_advance(im, wk, d);
+                            allbot = allbot && wk.y == t.y1; allright = allright && wk.x == t.x1;
+                        }
+                        if (!inside) { n_abandoned++; return; }
+                        if (!relay_tile_owns(t, allbot, allright)) { n_skipped++; return; }
+                        m.len = wk.n;
+                        if (idx.count(m.key)) { idx[m.key] = -1; return; } // owned twice: reported below
+                        idx[m.key] = (int)mk.size();
+                        mk.push_back(std::move(m));
+                    });
+                }
+            // ---- small borders from the start candidates strictly between the tile's relay rows
+            for (int py = std::max(1, t.y0 + 1); py <= std::min(h, t.y1 - 1); py++)
+                for (int px = std::max(1, t.x0); px <= std::min(w, t.x1 + 1); px++) { // px: the candidate pixel; the start pixel is px - is_hole
+                    int is_hole = -1;
+                    if (px <= t.x1 && outer_start_candidate(im, px, py)) is_hole = 0;
+                    else if (px >= 2 && px - 1 >= t.x0 && hole_start_candidate(im, px, py)) is_hole = 1;
+                    if (is_hole < 0) continue;
+                    const int sx = px - is_hole, sy = py, start_key = py * 65536 + px;
+                    RelayWalk wk;
+                    wk.x = sx; wk.y = sy; wk.n = 0; wk.ring = ring8(im, sx, sy);
+                    wk.s = relay_start_dir(wk.ring, is_hole);
+                    if (wk.s < 0) continue; // isolated pixel: below
+                    const int s0 = wk.s;
+                    std::vector<uint32_t> pts;
+                    bool ok = false;
+                    for (;;) {
+                        unsigned run;
+                        const int d = relay_examine(wk.ring, wk.s, &run);
+                        if (run & grid_active(wk.ring, wk.x, wk.y, kmask)) break;
+                        if (relay_not_canonical(wk.x, wk.y, run, is_hole, start_key)) break;
+                        pts.push_back(relay_point(wk));
+                        const int nx = wk.x + dir_dx(d), ny = wk.y + dir_dy(d);
+                        if (!relay_tile_has(t, nx, ny)) { n_small_abandoned++; break; }
+                        relay_advance(im, wk, d);
+                        if (wk.x == sx && wk.y == sy && wk.s == s0) { ok = true; break; }
+                    }
+                    if (ok) found.push_back(C{start_key, pts});
+                }
+        }
+    // isolated pixels have no states: no tile logic applies (and no kernel keeps a one-point border)
+    {
+        BitImage im{bits.data(), wpr, w, h};
+        for (int py = 1; py <= h; py++)
+            for (int px = 1; px <= w; px++)
+                if (im.get(px, py) && !ring8(im, px, py)) found.push_back(C{py * 65536 + px, {(uint32_t)(px - 1) | ((uint32_t)(py - 1) << 16)}});
+    }
+    // every marker state of the frame must have exactly one owner
+    {
+        BitImage im{bits.data(), wpr, w, h};
+        size_t nstates = 0;
+        int bad = 0;
+        for (int py = 1; py <= h; py++)
+            for (int px = 1; px <= w; px++) {
+                if (!im.get(px, py)) continue;
+                const unsigned ring = ring8(im, px, py);
+                if (!ring) continue;
+                relay_states_of_pixel(ring, grid_active(ring, px, py, kmask), [&](int s) {
+                    nstates++;
+                    auto it = idx.find(relay_key(px, py, s));
+                    if (it == idx.end() || it->second < 0) bad++;
+                });
+            }
+        if (bad) return -10;
+        if (nstates != mk.size()) return -11;
+    }
+    for (auto& m : mk) {
+        auto it = idx.find(m.next_key);
+        if (it == idx.end()) return -1;
+        m.next = it->second;
+    }
+    // no small border twice (a start candidate on a shared column is tried by both tiles)
+    {
+        std::vector<int> keys;
+        for (auto& c : found) keys.push_back(c.key);
+        std::sort(keys.begin(), keys.end());
+        if (std::adjacent_find(keys.begin(), keys.end()) != keys.end()) return -12;
+    }
+    // ---- cyclic lists, as in proto_find_contours_relay
+    BitImage im{bits.data(), wpr, w, h};
+    std::vector<char> seen(mk.size(), 0);
+    for (size_t i0 = 0; i0 < mk.size(); i0++) {
+        if (seen[i0]) continue;
+        int best = -1;
+        for (int i = (int)i0;;) {
+            seen[i] = 1;
+            if (best < 0 || mk[i].cmin < mk[best].cmin) best = i;
+            i = mk[i].next;
+            if (i == (int)i0) break;
+            if (seen[i]) return -4; // not a cycle
+        }
+        if (mk[best].cmin == 0xffffffffu) return -2;
+        RelayWalk cs;
+        relay_walk_from_key(im, cs, mk[best].cmin);
+        unsigned run;
+        relay_examine(cs.ring, cs.s, &run);
+        const int cls = relay_start_class(cs.ring, run);
+        if (!cls) return -3;
+        C c;
+        c.key = cs.y * 65536 + cs.x + (cls == 2 ? 1 : 0);
+        std::vector<uint32_t> all;
+        for (int i = best;;) {
+            all.insert(all.end(), mk[i].pts.begin(), mk[i].pts.end());
+            i = mk[i].next;
+            if (i == best) break;
+        }
+        const int j = mk[best].minoff, n = (int)all.size();
+        c.pts.resize(n);
+        for (int o = 0; o < n; o++) c.pts[(o - j + n) % n] = all[o];
+        found.push_back(std::move(c));
+    }
+    std::sort(found.begin(), found.end(), [](const C& a, const C& b) { return a.key > b.key; });
+    int np = 0;
+    for (int i = 0; i < (int)found.size(); i++) {
+        if (i < max_contours) lengths[i] = (int)found[i].pts.size();
+        for (uint32_t v : found[i].pts) {
+            if (np < max_points) { points[2 * np] = (int)(v & 0xffff); points[2 * np + 1] = (int)(v >> 16); }
+            np++;
+        }
+    }
+    if (stats) {
+        stats[0] = (int64_t)mk.size(); stats[1] = ntiles; stats[2] = n_abandoned; stats[3] = n_skipped;
+        stats[4] = (int64_t)found.size(); stats[5] = n_small_abandoned;
+    }
+    return (int)found.size();
+}

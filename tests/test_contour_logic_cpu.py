@@ -25,6 +25,10 @@ def protos(tmp_path_factory):
     P.proto_find_contours_relay.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                             C.c_int, C.c_void_p]
 
+    P.proto_find_contours_tiled.restype = C.c_int
+    P.proto_find_contours_tiled.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                            C.c_int, C.c_void_p]
+
     def make(fn, *extra):
         def run(b, stats=None):
             b = np.ascontiguousarray(b, np.uint8)
@@ -44,11 +48,16 @@ def protos(tmp_path_factory):
         return run
     # relay spacing K = 4, 8, 32: small K puts many grid markers on small test images (multi-segment borders),
     # K = 32 is what the kernel uses (most borders of these images then take the small-border path)
+    # tiled: (grid spacing, tile width in cells): many tiles per test image at K = 4 / 8 (segments on shared grid lines, start
+    # candidates on shared columns), one band x several column tiles and whole-width tiles at K = 16 / 32
     return {"trace": make(P.proto_find_contours), "relay4": make(P.proto_find_contours_relay, 2),
-            "relay8": make(P.proto_find_contours_relay, 3), "relay32": make(P.proto_find_contours_relay, 5)}
+            "relay8": make(P.proto_find_contours_relay, 3), "relay32": make(P.proto_find_contours_relay, 5),
+            "tiled4x1": make(P.proto_find_contours_tiled, 2, 1), "tiled4x3": make(P.proto_find_contours_tiled, 2, 3),
+            "tiled8x2": make(P.proto_find_contours_tiled, 3, 2), "tiled16x1": make(P.proto_find_contours_tiled, 4, 1),
+            "tiled32x1": make(P.proto_find_contours_tiled, 5, 1), "tiled32x20": make(P.proto_find_contours_tiled, 5, 20)}
 
 
-@pytest.fixture(params=["trace", "relay4", "relay8", "relay32"])
+@pytest.fixture(params=["trace", "relay4", "relay8", "relay32", "tiled4x1", "tiled4x3", "tiled8x2", "tiled16x1", "tiled32x1", "tiled32x20"])
 def proto(request, protos):
     return protos[request.param]
 
@@ -82,3 +91,26 @@ def test_thresholded_scene(proto, oracle):
     img, _ = synth.scene(240, 320, 3, "ARUCO", 2, side_range=(40, 70))
     b = oracle.adaptive_threshold(img, 3, 7)
     assert _same(oracle.find_contours(b), proto(b))
+
+
+def test_tiles_see_shared_grid_lines_once(protos, oracle):
+    """Lines and blobs ON the grid lines between tiles (segments that lie entirely on a shared row / column, corners on grid
+    crossings, sizes that are exact multiples of the spacing): every marker state has exactly one owner (the prototype returns
+    an error otherwise) and the contours equal the sequential scan's."""
+    st = np.zeros(8, np.int64)
+    for K, name in ((4, "tiled4x1"), (4, "tiled4x3"), (8, "tiled8x2")):
+        for H, W in ((4 * K, 6 * K), (4 * K + 1, 6 * K - 1), (3 * K - 1, 5 * K + 3)):
+            b = np.zeros((H, W), np.uint8)
+            # padded coordinate = image coordinate + 1: image row K - 1 is the relay row K
+            b[K - 1, 1:W - 1] = 255                      # a line along a relay row, across several tiles
+            b[2:H - 1, 2 * K - 1] = 255                  # a line along a relay column
+            b[2 * K - 1:2 * K + 1, 3 * K - 1:3 * K + 1] = 255   # a 2 x 2 blob on a grid crossing
+            b[K + 1:2 * K - 2, K + 1:2 * K - 2] = 255    # a blob strictly inside a cell (small border)
+            b[2 * K:3 * K - 1, 4 * K - 1] = 255          # a piece that starts on a crossing and runs down a column
+            assert _same(oracle.find_contours(b), protos[name](b, st)), (K, name, H, W)
+            assert st[3] > 0        # segments on shared lines were met by two tiles and skipped by one
+    rng = np.random.default_rng(77)
+    for k in range(6):                                    # images whose sizes are multiples of the spacing, dense and sparse
+        b = (rng.random((32, 48)) < (0.2 + 0.12 * k)).astype(np.uint8) * 255
+        for name in ("tiled4x1", "tiled4x3", "tiled8x2", "tiled16x1"):
+            assert _same(oracle.find_contours(b), protos[name](b)), (k, name)
