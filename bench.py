@@ -418,10 +418,10 @@ def main():
     # every ORBFE_* variable that is set is recorded; the ones that change which kernels run or how they are scheduled make the
     # line a diagnostic (value null) unless they spell the default
     env_set = {k: v for k, v in sorted(os.environ.items()) if k.startswith("ORBFE_")}
-    harmless = {"ORBFE_BENCH_DEVICE", "ORBFE_BENCH_BACKEND", "ORBFE_LIB"}   # (ORBFE_GATHER_NOOP is not: it makes the line a diagnostic)
+    harmless = {"ORBFE_BENCH_DEVICE", "ORBFE_BENCH_BACKEND", "ORBFE_LIB", "ORBFE_BENCH_SELF_LAUNCHED"}   # (ORBFE_GATHER_NOOP is not: it makes the line a diagnostic)
     defaults = {"ORBFE_ORIENT_PAIR": "1", "ORBFE_FAST0": "0", "ORBFE_EARLY_SHARED": "0", "ORBFE_ARUCO_VIS": "0", "ORBFE_ARUCO_FORCE_GLOBAL": "0", "ORBFE_STREAM_PRIO": "0,0,0", "ORBFE_ENGINE_SETS_ARUCO": "1", "ORBFE_PHASE_PIN": "2", "ORBFE_DET_PIN": "4", "ORBFE_BLUR_LEND": "match", "ORBFE_LEND_ALL": "1", "ORBFE_RECORD_SETS": "4", "ORBFE_GATHER_STREAM": "match", "ORBFE_DET_NOFORK": "0",
                 "ORBFE_BLUR_PLACE": "1", "ORBFE_ARUCO_RELAY_CHUNK": "0", "ORBFE_OCC_FAST": "0", "ORBFE_OCC_BLUR": "0",
-                "ORBFE_OCC_ORIENT": "0"}
+                "ORBFE_OCC_ORIENT": "0", "ORBFE_ARUCO_TILED": "auto", "ORBFE_ARUCO_TILE_W": "0", "ORBFE_ARUCO_TPW": "0"}
     defaults["ORBFE_DET_NOFORK"] = "1" if args.rows * args.cols <= 640 * 480 else "0"    # pipeline.py: by frame size
     env_nondefault = {k: v for k, v in env_set.items() if k not in harmless and defaults.get(k) != v}
     B, rows, cols = args.frames, args.rows, args.cols

@@ -935,6 +935,10 @@ class MarkerDetector:
         """Debug: run every frame through the single-walker contour kernel (the relay kernel's fallback)."""
         self.L.orbfe_aruco_debug_kernel_times(self.h, None, 2 if on else 3)
 
+    def set_tiled_contours(self, mode):
+        """Debug: the tiled contour path (aruco_tiles.hip) None = by frame / batch size (default), True = every batch, False = never."""
+        self.L.orbfe_aruco_debug_kernel_times(self.h, None, 4 if mode is None else 5 if mode else 6)
+
     def rects(self, frame=0):
         out = np.zeros(self.capacity, RECT_DTYPE)
         _check(self.L, self.L.orbfe_aruco_debug_image(self.h, frame, 101, _p(out)), "debug_image")

@@ -77,6 +77,20 @@ struct orbfe_aruco {
     // idle, so the many small workgroups of the separate kernel shorten the call: 0.62 -> 0.57 ms for one 640 x 480 frame; a full
     // batch issues more instructions that way and the pipeline is bound by those: 1.85 -> 1.98 ms per C2 step), 0 / 1 = forced
     int small_separate_mode = getenv("ORBFE_ARUCO_SMALL_SEPARATE") ? atoi(getenv("ORBFE_ARUCO_SMALL_SEPARATE")) : -1;
+    // the tiled relay formulation (aruco_tiles.hip: k_ct_walk / k_ct_lists / k_ct_points).  -1 = by frame and batch size: frames whose
+    // bit image does not fit LDS next to the relay kernel's tables (1920 x 1080: 100-frame step 4.88 -> 3.75 ms) and batches of up to
+    // 32 frames (a frame's walks spread over ~40 CUs instead of one); full batches of LDS-resident frames keep the one-workgroup relay
+    // kernels, which issue a third fewer instructions for the same borders (640 x 480: 1.32 against 1.50 ms per step, 1280 x 720: 4.0
+    // against 4.2).  ORBFE_ARUCO_TILED = 0 / 1 forces it off / on for every batch (tests, A/B); ORBFE_ARUCO_TILE_W = tile width in
+    // pixels, ORBFE_ARUCO_TPW = tiles per wave: measurement switches.
+    int tiled = getenv("ORBFE_ARUCO_TILED") ? (atoi(getenv("ORBFE_ARUCO_TILED")) ? 1 : 0) : -1;
+    bool tiled_off = false;    // set while a batch is redone by the relay kernels
+    bool tiled_ran = false;    // the last batch took the tiled path
+    int tile_w_env = getenv("ORBFE_ARUCO_TILE_W") ? atoi(getenv("ORBFE_ARUCO_TILE_W")) : 0;
+    int tpw_env = getenv("ORBFE_ARUCO_TPW") ? atoi(getenv("ORBFE_ARUCO_TPW")) : 0;
+    int ct_segcap = 0, ct_hbits = 0, ct_lcap = 0, ct_items_per_frame = 0, ct_tiles_max = 0;
+    bool ct_dirty = true;      // the per-frame counters of k_ct_walk may be non-zero (first use; a batch abandoned before k_ct_lists)
+    DevBuf d_ctseg, d_cthtab, d_ctelem, d_ctstate, d_ctitemsA, d_ctitemsB, d_cttiles;
     bool relay_global = false; // k_contours_relay8g: the bit image stays in HBM (it does not fit LDS)
     int relay_tbits = 0;       // hash-table size of k_contours_relay (0: the kernel cannot run at this image size)
     bool force_legacy = false; // debug: always use k_contours_t
@@ -109,6 +123,17 @@ struct orbfe_aruco {
     int last_attempts = 0, last_work_rows = 0, last_work_cols = 0;
     size_t rl_static = 0;
     DevBuf d_red, d_mhist, d_masks, d_bgr, d_bits2;
+    // A batch with a frame that exceeded a capacity of the contour path it ran on is done again on the next one: tiled -> (its
+    // segment lists full: noise) the one-workgroup relay kernels, which coarsen their grid -> (kept borders / pool) the single-walker
+    // kernel in big-frame mode.  The callers restore tiled_off / big_mode afterwards.
+    bool escalate(int flags_or)
+    {
+        if (big_mode || force_legacy) return false;
+        const bool was_tiled = tiled_ran;
+        if (was_tiled && (flags_or & RL_FALLBACK_FLAGS) && relay_tbits) { tiled_off = true; return true; }
+        if (flags_or & (2 | 4 | (was_tiled ? RL_FALLBACK_FLAGS : 0))) { big_mode = true; return true; }
+        return false;
+    }
     bool stateful() const { return thres_method == 1 || auto_size || tracking_min > 0; } // a frame's result depends on the frames before it
     KernelTimer timer;
     int last_nframes = 0;
@@ -117,7 +142,7 @@ struct orbfe_aruco {
     {
         for (DevBuf* b : {&d_codes, &d_levels, &d_tabs, &d_bits, &d_pyr, &d_candq, &d_pool, &d_kept, &d_rects,
                           &d_counts, &d_candidx, &d_ncand, &d_result, &d_gpad, &d_in, &d_out, &d_nout, &d_segs, &d_tailkeys, &d_tailoff, &d_small, &d_hint, &d_rstate, &d_lut, &d_twork, &d_trect, &d_tctr, &d_dwork, &d_dctr, &d_ditems, &d_dhist, &d_dpatch, &d_vis, &d_poses, &d_scodes, &d_sids,
-                          &d_msrc, &d_red, &d_mhist, &d_masks, &d_bgr, &d_bits2})
+                          &d_msrc, &d_red, &d_mhist, &d_masks, &d_bgr, &d_bits2, &d_ctseg, &d_cthtab, &d_ctelem, &d_ctstate, &d_ctitemsA, &d_ctitemsB, &d_cttiles})
             b->release();
         if (own_stream) (void)hipStreamDestroy(own_stream);
         if (aux_stream) (void)hipStreamDestroy(aux_stream);
@@ -275,6 +300,18 @@ struct orbfe_aruco {
         relay_global = !relay_tbits && relay_lds_bytes(0, AR_MAX_KEPT_BIG, 13) + rl_static <= 160 * 1024;
         relay_kcap = RL_KCAP;
         if (relay_global) { relay_tbits = 13; relay_kshift = 5; relay_kcap = AR_MAX_KEPT_BIG; }
+        // tiled path: segments per frame the lists hold (a 640 x 480 frame of the synthetic streams has ~2000, salt noise ~15 k; ids
+        // are 16 bits), hash slots (twice that), segments whose list arrays k_ct_lists keeps in LDS (more: the same arrays in HBM)
+        {
+            int sc = 4096;
+            while (sc < rows_ * cols_ / 32 && sc < 65536) sc <<= 1;
+            ct_segcap = std::min(sc, 65535);
+            ct_hbits = 1;
+            while ((1 << ct_hbits) < 2 * sc) ct_hbits++;
+            ct_lcap = std::min(ct_segcap, large ? 8192 : 4096);
+            ct_items_per_frame = std::max(4096, ct_segcap / 4);
+            ct_tiles_max = ((rows_ + 31) / 32) * ((cols_ + 31) / 32);
+        }
         rows = rows_; cols = cols_;
         pyr_rows = prows; pyr_cols = pcols;
         batch_cap = 0;
@@ -303,6 +340,15 @@ struct orbfe_aruco {
             (rc = d_small.ensure((size_t)relay_kcap * 16 * B)) || (rc = d_rstate.ensure((size_t)8 * B)) ||
             (rc = d_twork.ensure((size_t)relay_kcap * 32 * B)) || (rc = d_trect.ensure((size_t)relay_kcap * B)))
             return rc;
+        if (tiled != 0) {
+            const size_t elem_words = (size_t)ct_segcap + ((size_t)ct_segcap + 3) / 4; // u64 elements + u16 next ids, per frame
+            if ((rc = d_ctseg.ensure((size_t)5 * ct_segcap * 4 * B)) || (rc = d_cthtab.ensure(((size_t)8 << ct_hbits) * B)) ||
+                (rc = d_ctelem.ensure(elem_words * 8 * B)) || (rc = d_ctstate.ensure((size_t)CT_STATE_INTS * 4 * B)) ||
+                (rc = d_ctitemsA.ensure((size_t)ct_items_per_frame * 16 * B)) || (rc = d_ctitemsB.ensure((size_t)ct_items_per_frame * 8 * B)) ||
+                (rc = d_cttiles.ensure((size_t)ct_tiles_max * 8 * B)))
+                return rc;
+            ct_dirty = true;
+        }
         if (!d_hint.p) {
             if ((rc = d_hint.ensure(16))) return rc;
             ORBFE_HIP(hipMemset(d_hint.p, 0, 16));
@@ -425,8 +471,48 @@ struct orbfe_aruco {
         ORBFE_HIP(hipGetLastError());
         auto kfn = big ? k_contours_t<false> : k_contours_t<true>;
         { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(kfn), (size_t)(lds)); if (rc_lds_) return rc_lds_; }
-        const bool relay = relay_tbits && !force_legacy && !big_mode;
+        const bool use_tiled = (tiled > 0 || (tiled < 0 && (relay_global || !relay_tbits || B <= 32))) && !tiled_off && !force_legacy && !big_mode;
+        tiled_ran = use_tiled;
+        const bool relay = (relay_tbits || use_tiled) && !force_legacy && !big_mode;
         for (int r_ = 0; relay && r_ < ORBFE_REPS_ARUCO(1); r_++) {
+            if (use_tiled) {
+                // Tile width and waves.  k_ct_walk's waves are persistent and overlap their tiles, so a wave wants several tiles (its
+                // lanes always find work) and a SIMD wants several waves (a step is a chain of dependent LDS reads): narrow tiles for a
+                // batch -- ORBFE_ARUCO_TILE_W / ORBFE_ARUCO_TPW (tiles per wave) are measurement switches --, and for a few frames as many
+                // waves as there are tiles.
+                const int target = tile_w_env > 0 ? tile_w_env : (B <= 32 ? 192 : 480);
+                const int ncols0 = std::max(1, (cols + target - 1) / target);
+                const int cw = std::min(CTW_MAX_CW, std::max(32, ((cols + ncols0 - 1) / ncols0 + 31) / 32 * 32));
+                const int ncols = (cols + cw - 1) / cw, nbands = (rows + 31) / 32;
+                const int wave_bytes = ctw_wave_lds_bytes(cw), wlds = wave_bytes * (CTW_THREADS / 64);
+                const int pwave_bytes = ctp_wave_lds_bytes(cw), plds = pwave_bytes * (CTW_THREADS / 64);
+                const int wgs_pf = (ncols * nbands + CTW_THREADS / 64 - 1) / (CTW_THREADS / 64);
+                const int total_tiles = ncols * nbands * B;
+                const int tpw = tpw_env > 0 ? tpw_env : (B <= 32 ? 1 : 2);
+                const int walk_wgs = std::max(1, std::min((total_tiles / tpw + CTW_THREADS / 64 - 1) / (CTW_THREADS / 64), 256 * 8));
+                const int ntiles = ncols * nbands;
+                const size_t llds = (((size_t)ntiles + 1) * 4 + 15) / 16 * 16 + (size_t)ct_lcap * 10 + 16;
+                { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(k_ct_walk), (size_t)wlds); if (rc_lds_) return rc_lds_; }
+                { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(k_ct_points), (size_t)plds); if (rc_lds_) return rc_lds_; }
+                { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(k_ct_lists), llds); if (rc_lds_) return rc_lds_; }
+                if (ct_dirty) {   // first use, or a batch abandoned between k_ct_walk and k_ct_lists (which leaves both empty)
+                    ORBFE_HIP(hipMemsetAsync(d_ctstate.p, 0, (size_t)CT_STATE_INTS * 4 * B, s));
+                    ORBFE_HIP(hipMemsetAsync(d_cthtab.p, 0, ((size_t)8 << ct_hbits) * B, s));
+                }
+                ct_dirty = true;
+                hipLaunchKernelGGL(k_ct_walk, dim3(walk_wgs), dim3(CTW_THREADS), wlds, s, d_bits.as<uint32_t>(), bits_fu32, wpr, cols, rows, 70,
+                                   d_lut.as<uint16_t>(), cw, ncols, nbands, total_tiles, d_cthtab.as<unsigned long long>(), ct_hbits,
+                                   d_ctseg.as<uint32_t>(), (size_t)5 * ct_segcap, ct_segcap, d_ctstate.as<int32_t>(), d_pool.as<uint32_t>(), pool_fu32,
+                                   (int)pool_fu32, relay_kcap, d_tailkeys.as<unsigned long long>(), d_tailoff.as<int32_t>(), wave_bytes);
+                hipLaunchKernelGGL(k_ct_lists, dim3(B), dim3(ct_lcap > 4096 ? 1024 : 512), llds, s, d_ctseg.as<uint32_t>(), (size_t)5 * ct_segcap, ct_segcap,
+                                   d_ctstate.as<int32_t>(), d_cthtab.as<unsigned long long>(), ct_hbits, d_ctelem.as<unsigned long long>(), ct_lcap, 70,
+                                   (int)pool_fu32, relay_kcap, d_tailkeys.as<unsigned long long>(), d_tailoff.as<int32_t>(), d_counts.as<int32_t>(),
+                                   d_rstate.as<int32_t>(), d_ctitemsA.as<uint4>(), d_ctitemsB.as<uint2>(), ct_items_per_frame, d_cttiles.as<int2>(), ntiles);
+                if (hipPeekAtLastError() == hipSuccess) ct_dirty = false;
+                hipLaunchKernelGGL(k_ct_points, dim3(xcd_grid(wgs_pf * B)), dim3(CTW_THREADS), plds, s, d_bits.as<uint32_t>(), bits_fu32, wpr, cols, rows,
+                                   d_lut.as<uint16_t>(), cw, ncols, nbands, wgs_pf, wgs_pf * B, d_counts.as<int32_t>(), d_ctitemsA.as<uint4>(),
+                                   d_ctitemsB.as<uint2>(), ct_items_per_frame, d_cttiles.as<int2>(), d_pool.as<uint32_t>(), pool_fu32, pwave_bytes);
+            } else {
             const size_t rlds = relay_lds_bytes(relay_global ? 0 : lds_bits_words, relay_kcap, relay_tbits);
             // A workgroup of the large-frame kernels takes a CU's whole LDS, so a launch of >= 256 frames shuts every kernel that
             // needs LDS (FAST, the descriptors) out of the chip for as long as it runs: such batches go in chunks of relay_chunk frames
@@ -464,6 +550,7 @@ struct orbfe_aruco {
                                    d_pool.as<uint32_t>(), pool_fu32, (int)pool_fu32, relay_kcap, d_tailkeys.as<unsigned long long>(),
                                    d_tailoff.as<int32_t>(), d_counts.as<int32_t>());
             }
+            } // (the relay kernels)
             // (g): sort + rank per frame, approxPolyDP by persistent waves over the whole batch's borders, rectangles per frame
             {
                 const int pts = RT_PTS;   // LDS point buffer per wave; longer borders are read from the pool
@@ -770,11 +857,19 @@ void orbfe_aruco_destroy(orbfe_aruco* h)
     delete h;
 }
 
+// A setter that changes what detect() returns ends a speculation started with the old parameters (orbfe_extractor_pair_detector:
+// the extractor's call may have run this detector on its frame already): the detector's next call then runs by itself.
+static void end_speculation(orbfe_aruco* h)
+{
+    if (h->spec.pending) { (void)hipStreamSynchronize(h->own_stream); h->spec.pending = false; }
+}
+
 int orbfe_aruco_set_dictionary(orbfe_aruco* h, const char* dictionary)
 {
     if (!h || !dictionary) return fail(ORBFE_ERR_INVALID, "null argument");
     int rc = use_device(h->device);
     if (rc) return rc;
+    end_speculation(h);
     return h->set_dictionary(dictionary);
 }
 
@@ -783,6 +878,7 @@ int orbfe_aruco_max_markers(const orbfe_aruco* h) { return h ? AR_MAX_RECTS : OR
 int orbfe_aruco_set_error_correction_rate(orbfe_aruco* h, float rate)
 {
     if (!h || !(rate >= 0.0f && rate <= 1.0f)) return fail(ORBFE_ERR_INVALID, "orbfe_aruco_set_error_correction_rate: rate must be in [0, 1]");
+    end_speculation(h);
     h->error_rate = rate;
     h->max_corr = (int)((float)h->tau * rate);
     return ORBFE_OK;
@@ -797,6 +893,7 @@ int orbfe_aruco_set_detection_mode(orbfe_aruco* h, int mode, float min_marker_si
     if (mode < 0 || mode > 2) return fail(ORBFE_ERR_INVALID, "detection mode %d: DM_NORMAL 0, DM_FAST 1, DM_VIDEO_FAST 2", mode);
     if (!(min_marker_size >= 0.0f && min_marker_size <= 1.0f))
         return fail(ORBFE_ERR_INVALID, "minMarkerSize %g: a fraction of the image size in [0, 1]", (double)min_marker_size);
+    end_speculation(h);
     h->detect_mode = mode;
     h->min_size = min_marker_size;
     if (mode == 0) { h->auto_size = false; h->ts = 0.25f; h->thres_method = 0; h->thres_value = 7; }
@@ -811,6 +908,7 @@ int orbfe_aruco_set_corner_refinement(orbfe_aruco* h, int method)
     // aruco::CornerRefinementMethod (markerdetector.h:62): CORNER_SUBPIX = 0 (cv::cornerSubPix), CORNER_LINES = 1, CORNER_NONE = 2.
     // Params::setCornerRefinementMethod (markerdetector.cpp:392-395): anything but CORNER_SUBPIX resets minSize to 0.
     if (method < 0 || method > 2) return fail(ORBFE_ERR_INVALID, "corner refinement method %d: CORNER_SUBPIX 0, CORNER_LINES 1, CORNER_NONE 2", method);
+    end_speculation(h);
     h->corner_method = method;
     if (method != 0) h->min_size = 0.f;
     return ORBFE_OK;
@@ -819,6 +917,7 @@ int orbfe_aruco_set_corner_refinement(orbfe_aruco* h, int method)
 int orbfe_aruco_set_enclosed_markers(orbfe_aruco* h, int on)
 {
     if (!h) return fail(ORBFE_ERR_INVALID, "null handle");
+    end_speculation(h);
     h->enclosed = on != 0;
     return ORBFE_OK;
 }
@@ -826,6 +925,7 @@ int orbfe_aruco_set_enclosed_markers(orbfe_aruco* h, int on)
 int orbfe_aruco_set_tracking(orbfe_aruco* h, int min_detections)
 {
     if (!h || min_detections < 0) return fail(ORBFE_ERR_INVALID, "orbfe_aruco_set_tracking: trackingMinDetections >= 0");
+    end_speculation(h);
     h->tracking_min = min_detections;
     h->marker_counts.clear();
     h->prev_markers.clear();
@@ -839,6 +939,7 @@ int orbfe_aruco_set_gray_conversion(orbfe_aruco* h, int fractional_bits)
 {
     if (!h || (fractional_bits != 14 && fractional_bits != 15))
         return fail(ORBFE_ERR_INVALID, "orbfe_aruco_set_gray_conversion: 14 (OpenCV <= 3.4.1) or 15 (3.4.2 and later) fractional bits");
+    end_speculation(h);
     h->gray_bits15 = fractional_bits == 15;
     return ORBFE_OK;
 }
@@ -1071,7 +1172,7 @@ static int detect_frames_modes(orbfe_aruco* h, const uint8_t* imgs, int nframes,
             h->last_attempts++;
             const int thr = h->thres_method == 1 ? h->thres_value : -1;
             uint32_t* d_hist = h->thres_method == 1 ? h->d_mhist.as<uint32_t>() : nullptr;
-            for (int pass = 0; pass < 2; pass++) { // a frame that exceeds the LDS-resident kernels' capacities is done again in big-frame mode
+            for (int pass = 0; pass < 3; pass++) { // a frame that exceeds the capacities of the contour path it ran on is done again on the next one (escalate())
                 if (wc != cols) rc = reduced_batch(h, h->d_in.as<uint8_t>(), 1, dframe, rows, cols, dpitch, wr, wc, h->d_out.as<orbfe_marker>(), AR_MAX_RECTS,
                                                    h->d_nout.as<int32_t>(), s, thr, d_hist, track_hook);
                 else {
@@ -1080,16 +1181,15 @@ static int detect_frames_modes(orbfe_aruco* h, const uint8_t* imgs, int nframes,
                     rc = h->run_device(h->d_in.as<uint8_t>(), 1, dframe, rows, cols, dpitch, h->d_out.as<orbfe_marker>(), AR_MAX_RECTS,
                                        h->d_nout.as<int32_t>(), s, &mr);
                 }
-                if (rc) { h->big_mode = user_big_mode; return rc; }
+                if (rc) { h->big_mode = user_big_mode; h->tiled_off = false; return rc; }
                 ORBFE_HIP(hipMemcpyAsync(hp + o_n, h->d_nout.p, 4, hipMemcpyDeviceToHost, s));
                 ORBFE_HIP(hipMemcpyAsync(hp + o_cnt, h->d_counts.p, 16, hipMemcpyDeviceToHost, s));
                 if (d_hist) ORBFE_HIP(hipMemcpyAsync(hp + o_h, d_hist, 1024, hipMemcpyDeviceToHost, s));
                 ORBFE_HIP(hipMemcpyAsync(hp + o_mk, h->d_out.p, (size_t)AR_MAX_RECTS * sizeof(orbfe_marker), hipMemcpyDeviceToHost, s));
                 ORBFE_HIP(hipStreamSynchronize(s));
-                if (!(counts[2] & (2 | 4)) || h->big_mode) break;
-                h->big_mode = true;
+                if (!h->escalate(counts[2])) break;
             }
-            h->big_mode = user_big_mode;
+            h->big_mode = user_big_mode; h->tiled_off = false;
             if (counts[2]) return fail(ORBFE_ERR_CAPACITY, "frame %d: internal detector capacity exceeded (flags 0x%x)", f, counts[2]);
             // (the retry is decided on what the dictionary found, before the tracking block adds anything: :6903)
             if ((h->tracking_min > 0 ? pre_detected : np[0]) == 0 && h->thres_method == 1 && ++attempts < h->n_attempts_auto_fix) {
@@ -1197,10 +1297,10 @@ static int detect_batch_impl(orbfe_aruco* h, const uint8_t* imgs, int nframes, s
     ORBFE_HIP(hipMemcpyAsync(h->d_in.p, hp, dframe * nframes, hipMemcpyHostToDevice, s));
     const int32_t* counts = reinterpret_cast<const int32_t*>(hp + o_cnt);
     const bool user_big_mode = h->big_mode; // orbfe_aruco_set_big_frames applies to all following batches: keep it
-    for (int attempt = 0; attempt < 2; attempt++) {
+    for (int attempt = 0; attempt < 3; attempt++) {
         rc = h->run_device(h->d_in.as<uint8_t>(), nframes, dframe, rows, cols, dpitch, h->d_out.as<orbfe_marker>(),
                            AR_MAX_RECTS, h->d_nout.as<int32_t>(), s);
-        if (rc) { h->big_mode = user_big_mode; return rc; }
+        if (rc) { h->big_mode = user_big_mode; h->tiled_off = false; return rc; }
         ORBFE_HIP(hipMemcpyAsync(hp + o_n, h->d_nout.p, (size_t)nframes * 4, hipMemcpyDeviceToHost, s));
         ORBFE_HIP(hipMemcpyAsync(hp + o_cnt, h->d_counts.p, (size_t)nframes * 16, hipMemcpyDeviceToHost, s));
         ORBFE_HIP(hipMemcpyAsync(hp + o_mk, h->d_out.p, (size_t)AR_MAX_RECTS * nframes * sizeof(orbfe_marker), hipMemcpyDeviceToHost, s));
@@ -1210,14 +1310,13 @@ static int detect_batch_impl(orbfe_aruco* h, const uint8_t* imgs, int nframes, s
             ORBFE_HIP(hipMemcpyAsync(hp + o_ps, h->d_poses.p, (size_t)AR_MAX_RECTS * nframes * sizeof(orbfe_marker_pose), hipMemcpyDeviceToHost, s));
         }
         ORBFE_HIP(hipStreamSynchronize(s));
-        bool retry = false;
-        for (int f = 0; f < nframes; f++) retry = retry || (counts[f * 4 + 2] & (2 | 4));
-        // a frame with more kept borders (or border points) than the LDS-resident kernels hold: the batch is done again
-        // by the single-walker kernel with its tables sized for AR_MAX_KEPT_BIG
-        if (!retry || h->big_mode) break;
-        h->big_mode = true;
+        int flags_or = 0;
+        for (int f = 0; f < nframes; f++) flags_or |= counts[f * 4 + 2];
+        // a frame with more segments than the tiled path's lists hold: the batch is done again by the relay kernels; one with more kept
+        // borders (or border points) than those hold: by the single-walker kernel with its tables sized for AR_MAX_KEPT_BIG
+        if (!h->escalate(flags_or)) break;
     }
-    h->big_mode = user_big_mode;
+    h->big_mode = user_big_mode; h->tiled_off = false;
     memcpy(n_out, hp + o_n, (size_t)nframes * 4);
     for (int f = 0; f < nframes; f++) {
         if (counts[f * 4 + 2])
@@ -1375,6 +1474,7 @@ int orbfe_aruco_batch_status(orbfe_aruco* h, int32_t* nflagged, int32_t* flags_o
 int orbfe_aruco_set_big_frames(orbfe_aruco* h, int on)
 {
     if (!h) return fail(ORBFE_ERR_INVALID, "null handle");
+    end_speculation(h);
     h->big_mode = on != 0;
     return ORBFE_OK;
 }
@@ -1389,8 +1489,9 @@ int orbfe_aruco_set_aux_stream(orbfe_aruco* h, void* stream)
 int orbfe_aruco_debug_kernel_times(orbfe_aruco* h, float* out_us, int capacity)
 {
     if (!h) return fail(ORBFE_ERR_INVALID, "null handle");
-    if (!out_us) { // control codes: 0/1 kernel timing off/on, 2/3 force the legacy contour kernel on/off
+    if (!out_us) { // control codes: 0/1 kernel timing off/on, 2/3 force the legacy contour kernel on/off, 4/5/6 tiled contour path by size / always / never
         if (capacity == 2 || capacity == 3) h->force_legacy = capacity == 2;
+        else if (capacity >= 4 && capacity <= 6) h->tiled = capacity == 4 ? -1 : capacity == 5 ? 1 : 0; // (the workspace of the tiled path exists unless ORBFE_ARUCO_TILED=0)
         else { h->timer.enabled = capacity != 0; h->timer.reset_history(); }
         return 0;
     }

@@ -166,6 +166,35 @@ __global__ void k_upsample_corners(ImgView src0, ImgView pyr, const ArLevel* lev
 #define RS_STEPS 2
 #endif
 
+// ---- the tiled relay formulation (aruco_tiles.hip)
+#define CTW_THREADS 256          // k_ct_walk: four independent waves per workgroup, a tile each
+#define CTW_ROWS 35              // tile rows in LDS: the closed band of 33 rows + one above + one below
+#ifndef CTW_QCAP
+#define CTW_QCAP 512             // queue entries per wave (>= 64: what one enumeration item can yield)
+#endif
+#define CTW_FCAP 64              // finished segments a wave collects before it appends them to the frame's list
+#ifndef CTW_STEPS
+#define CTW_STEPS 2              // walk steps between two looks at the queue
+#endif
+#ifndef CTW_TAKE
+#define CTW_TAKE 256             // enumeration items per refill of the queue (halved while they do not fit)
+#endif
+#define CTW_MAX_CW 480           // tile width limit: the marker pixels of all relay columns of a tile (31 x (cw / 32 + 1)) fit the queue
+#define CT_STATE_INTS 8          // per frame: segments, kept small borders, pool words in use, flags, start candidates
+#define CTL_THREADS 1024
+inline int ctw_wave_lds_bytes(int cw) { return (2 * (CTW_ROWS * ((cw >> 5) + 2) + 2) * 4 + CTW_QCAP * 2 + CTW_FCAP * 24 + 15) & ~15; }   // two tile slots, queue, finished segments
+inline int ctp_wave_lds_bytes(int cw) { return ((CTW_ROWS * ((cw >> 5) + 2) + 2) * 4 + 15) & ~15; }                                           // k_ct_points: one tile
+__global__ void k_ct_walk(const uint32_t* gbits, size_t bits_fstride, int wpr_g, int W, int H, int min_len, const uint16_t* lut_g, int cw, int ncols,
+                          int nbands, int total_tiles, unsigned long long* htab, int hbits, uint32_t* seg, size_t seg_fstride,
+                          int segcap, int32_t* ctstate, uint32_t* pool, size_t pool_fstride, int pool_cap, int kcap, unsigned long long* tail_keys,
+                          int32_t* tail_off, int wave_bytes);
+__global__ void k_ct_lists(const uint32_t* seg, size_t seg_fstride, int segcap, int32_t* ctstate, unsigned long long* htab, int hbits,
+                           unsigned long long* gelem, int lcap, int min_len, int pool_cap, int kcap, unsigned long long* tail_keys, int32_t* tail_off,
+                           int32_t* counts, int32_t* rstate, uint4* itemsA, uint2* itemsB, int ipf, int2* tile_items, int ntiles);
+__global__ void k_ct_points(const uint32_t* gbits, size_t bits_fstride, int wpr_g, int W, int H, const uint16_t* lut_g, int cw, int ncols, int nbands,
+                            int wgs_per_frame, int total_wgs, const int32_t* counts, const uint4* itemsA, const uint2* itemsB, int ipf,
+                            const int2* tile_items, uint32_t* pool, size_t pool_fstride, int wave_bytes);
+
 // LDS of k_contours_relay: region R (bit image | list arrays) followed by the marker keys
 __host__ __device__ inline size_t relay_region_bytes(int lds_bits_words, int kcap, int tbits)
 {

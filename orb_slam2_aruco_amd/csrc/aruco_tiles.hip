@@ -1,0 +1,696 @@
+// aruco_tiles.hip -- findContours(RETR_LIST, CHAIN_APPROX_NONE) by relay segments (aruco_trace.hpp), TILED: the frame is cut into
+// closed rectangles of whole 32 x 32 grid cells and every walk of the relay formulation -- segments from grid marker to grid marker,
+// small borders from their start candidates -- is done by the wave that holds the tile (aruco_trace.hpp, "TILES": no such walk
+// leaves its closed cell).  Reference behaviour: cv::findContours as called at Thirdparty/aruco/aruco/markerdetector_impl.cpp:3104.
+//
+//   k_ct_walk    a WAVE per tile, thousands per batch, no workgroup barrier after the step table is loaded: tile of the bit image
+//                (+ 1 pixel) in wave-private LDS, grid markers and start candidates enumerated into a wave-private queue with
+//                ballots and scans, every free lane takes the next entry and follows it one step per trip.  Finished segments
+//                {start state, end state, length, smallest start state passed} are collected in LDS and appended to the frame's
+//                segment list 64 at a time (one atomic per flush), their start states entered into the frame's hash table in L2.
+//   k_ct_lists   a workgroup per frame: end states -> segment ids (the hash table, read-only now), the border's smallest start
+//                state by pointer doubling round the cyclic lists, list ranking for the offsets, pool space + sort keys of the kept
+//                borders, one copy item per segment of a kept border, grouped by the tile that walked it.
+//   k_ct_points  a wave per tile again: the tile back in LDS, a lane per copy item walks its segment once more, straight into its
+//                final place (about one segment in seven belongs to a kept border).
+// then the common tail (k_tail_prep / k_tail_approx / k_tail_finish: sort, approxPolyDP, rectangles).
+//
+// Against k_contours_relay (one workgroup per frame doing all of this out of one LDS image): the walks of a 640 x 480 batch are
+// 9000 independent waves instead of 300 workgroups of eight, a workgroup needs 20 KB of LDS whatever the frame size (1280 x 720:
+// 151 KB before, a CU to itself; 1920 x 1080: the bit image did not fit and every step was an L2 round trip), and a single frame
+// of the drop-in path spreads over 30 CUs instead of one.
+#include "aruco_kernels.hpp"
+#include "wave_dpp.hpp"
+
+namespace orbfe {
+
+__device__ __forceinline__ int ctl_lane_prefix(unsigned long long mask)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+// is the state a grid marker (K = 32): its run has W / E on a relay row, or N / S on a relay column (step-table bits 3, 4)
+__device__ __forceinline__ bool ct_is_marker(unsigned e, int x, int y)
+{
+    const unsigned g = ((y & 31) == 0 ? 8u : 0u) | ((x & 31) == 0 ? 16u : 0u);
+    return (e & g) != 0;
+}
+
+// A tile of the padded bit image (pixel (x, y) = bit x + 1 of row y + 1) into wave-private LDS: words j0 - 1 .. j0 + TW - 2 of the
+// rows y0 - 1 .. y0 + 33, + two spare words for ring8()'s funnel loads.
+__device__ __forceinline__ void ct_load_tile(uint32_t* tile, const uint32_t* __restrict__ gb, int wpr_g, int H, int y0, int j0, int TW, int lane)
+{
+    const int nwords = CTW_ROWS * TW;
+    for (int i = lane; i < nwords; i += 64) {
+        const int r = i / TW, k = i - r * TW, py = y0 - 1 + r, j = j0 - 1 + k; // word j of padded row py
+        uint32_t v = 0;
+        if (py >= 1 && py <= H && j >= 0) {
+            const uint32_t* row = gb + (size_t)(py - 1) * wpr_g;
+            const uint32_t cur = j < wpr_g ? row[j] : 0u;
+            const uint32_t prv = (j >= 1 && j - 1 < wpr_g) ? row[j - 1] : 0u;
+            v = (cur << 1) | (prv >> 31);
+        }
+        tile[i] = v;
+    }
+    if (lane < 2) tile[nwords + lane] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_ct_walk.  PERSISTENT waves: wave w does tiles w, w + nwaves, w + 2 nwaves ... of the batch, and the tiles OVERLAP in time -- two
+// tile slots in LDS, the lanes still walking in tile k carry on while the wave enumerates tile k + 1 and its free lanes start on
+// it.  (One tile per wave was measured first: every wave ends with its longest walks running alone, and with tiles small enough to
+// fill the chip that tail was half of all loop trips -- the 640 x 480 batch took 717 / 548 / 520 us with tiles of 128 / 320 / 640
+// columns.)  A lane works in TILE coordinates: xr = x - x0 + 32 is the pixel's bit number in the tile's LDS rows, yr = y - y0 + 1 its
+// row, so relay columns are xr % 32 == 0, relay rows yr == 1 and 33, the tile is [32, cw + 32] x [1, 33], and all a walk needs of
+// its tile is the LDS offset of the slot; states and start keys only differ from the frame's by a constant per tile, which is
+// added when a result leaves the wave.
+__global__ __launch_bounds__(CTW_THREADS) void k_ct_walk(
+    const uint32_t* __restrict__ gbits, size_t bits_fstride, int wpr_g, int W, int H, int min_len, const uint16_t* __restrict__ lut_g,
+    int cw /* tile width in pixels: a multiple of 32, <= CTW_MAX_CW */, int ncols, int nbands, int total_tiles /* of the batch */,
+    unsigned long long* __restrict__ htab, int hbits, uint32_t* __restrict__ seg, size_t seg_fstride, int segcap,
+    int32_t* __restrict__ ctstate, uint32_t* __restrict__ pool, size_t pool_fstride, int pool_cap, int kcap,
+    unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off, int wave_bytes)
+{
+    extern __shared__ __align__(16) unsigned char ctw_smem[];
+    __shared__ __align__(16) uint16_t s_lut[2048];
+    __builtin_amdgcn_s_setprio(2); // latency-bound: its waves go first when a VALU-bound kernel shares the SIMD
+    const int tid = threadIdx.x, lane = tid & 63, wid = wave_id();
+    reinterpret_cast<uint4*>(s_lut)[tid] = reinterpret_cast<const uint4*>(lut_g)[tid]; // 2048 x 2 B = CTW_THREADS x 16 B
+    __syncthreads();                                                                  // the only workgroup barrier
+    const int nwaves = (int)gridDim.x * (CTW_THREADS / 64), tpf = nbands * ncols;
+    int next_tile = (int)blockIdx.x * (CTW_THREADS / 64) + wid;
+    if (next_tile >= total_tiles) return;
+    const int nw = cw >> 5, TW = nw + 2, slot_words = CTW_ROWS * TW + 2;
+    uint32_t* tiles = reinterpret_cast<uint32_t*>(ctw_smem + (size_t)wid * wave_bytes);
+    uint16_t* queue = reinterpret_cast<uint16_t*>(tiles + 2 * slot_words);
+    uint32_t* fin = reinterpret_cast<uint32_t*>(queue + CTW_QCAP);
+    uint32_t* f_key = fin;
+    uint32_t* f_nxt = fin + CTW_FCAP;
+    uint32_t* f_len = fin + 2 * CTW_FCAP;
+    uint32_t* f_mn = fin + 3 * CTW_FCAP;
+    uint32_t* f_off = fin + 4 * CTW_FCAP;
+    uint32_t* f_frm = fin + 5 * CTW_FCAP;
+    const int stage0 = pool_cap >> 2;
+    const uint32_t hmask = (1u << hbits) - 1u;
+
+    // the two tile slots (wave-uniform): frame, tile number inside the frame, what to add to tile coordinates, neighbours
+    int sl_f0 = 0, sl_f1 = 0, sl_tile0 = 0, sl_tile1 = 0, sl_ox0 = 0, sl_ox1 = 0, sl_oy0 = 0, sl_oy1 = 0, sl_right0 = 0, sl_right1 = 0, sl_lower0 = 0, sl_lower1 = 0;
+#define CT_SLOT(name, sl) ((sl) ? name##1 : name##0)
+    int cur = 1;               // slot of the tile being enumerated (the first tile goes to slot 0)
+    int phase = 3, it0 = 0;    // enumeration state of the current tile: phases 0 .. 2, 3 = done
+    int head = 0, total = 0, qphase = 0, fcnt = 0, ncand_w = 0;
+    bool more = true;
+
+    // per lane
+    int x = 0, y = 0, s = 0, n = 0;   // walk state, tile coordinates
+    unsigned ring = 0;
+    bool busy = false;
+    int kind = 0;               // 0 segment, 1 small outer, 2 small hole
+    unsigned a = 0;             // grid-active directions of the lane's marker pixel whose states are still to be walked
+    int sx = 0, sy = 0, s0 = 0; // start pixel and state of the walk (the marker pixel of a segment)
+    uint32_t mn = 0xffffffffu, mnoff = 0;
+    bool allbot = false, allright = false;
+    int lslot = 0;              // the slot of the lane's tile
+    const uint32_t* lbits = tiles; // = tiles + lslot * slot_words
+
+    auto flush = [&]() {
+        // the list may hold segments of two frames: one atomic per frame
+        const bool my = lane < fcnt;
+        const int fr = my ? (int)f_frm[lane] : -1;
+        unsigned long long rem = __ballot(my);
+        while (rem) {
+            const int leader = (int)__builtin_ctzll(rem);
+            const int lf = __builtin_amdgcn_readlane(fr, leader);
+            const unsigned long long grp = __ballot(my && fr == lf);
+            int32_t* st = ctstate + (size_t)lf * CT_STATE_INTS;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&st[0], (int)__popcll(grp));
+            base = __builtin_amdgcn_readlane(base, leader);
+            if (my && fr == lf) {
+                const int id = base + ctl_lane_prefix(grp);
+                if (id < segcap) {
+                    uint32_t* sg = seg + (size_t)lf * seg_fstride;
+                    const uint32_t key = f_key[lane];
+                    sg[id] = key; sg[segcap + id] = f_nxt[lane]; sg[2 * segcap + id] = f_len[lane];
+                    sg[3 * segcap + id] = f_mn[lane]; sg[4 * segcap + id] = f_off[lane];
+                    // start state -> id: the frame's hash table (k_ct_lists resolves the end states with it, then empties it again)
+                    unsigned long long* ht = htab + ((size_t)lf << hbits);
+                    uint32_t h = (key * 0x9E3779B1u) >> (32 - hbits);
+                    const unsigned long long ent = (unsigned long long)key | ((unsigned long long)(uint32_t)id << 32);
+                    int p = 0;
+                    for (; p < 128; p++) {
+                        const unsigned long long old = atomicCAS(&ht[h], 0ull, ent);
+                        if (old == 0ull) break;
+                        if ((uint32_t)old == key) { atomicOr(&st[3], RL_FLAG_BUG); break; } // a state owned twice
+                        h = (h + 1) & hmask;
+                    }
+                    if (p == 128) atomicOr(&st[3], RL_FLAG_TABLE);
+                }
+            }
+            rem &= ~grp;
+        }
+        __builtin_amdgcn_wave_barrier();
+        fcnt = 0;
+    };
+
+    for (;;) {
+        // ---- the next tile, once the current one is enumerated and its queue is empty -- into the other slot, which must be free of
+        // walks (it held the tile before the current one: a whole tile's work ago)
+        if (head >= total && phase >= 3 && more) {
+            const int o = cur ^ 1;
+            if (!__any((busy || a != 0) && lslot == o)) {
+                if (ncand_w) { if (lane == 0) atomicAdd(&ctstate[(size_t)CT_SLOT(sl_f, cur) * CT_STATE_INTS + 4], ncand_w); ncand_w = 0; }
+                if (next_tile >= total_tiles) more = false;
+                else {
+                    const int fno = next_tile / tpf, tno = next_tile - fno * tpf, band = tno / ncols, col = tno - band * ncols;
+                    next_tile += nwaves;
+                    if (o) { sl_f1 = fno; sl_tile1 = tno; sl_ox1 = col * cw - 32; sl_oy1 = band * 32 - 1; sl_right1 = (col + 1) * cw < W; sl_lower1 = (band + 1) * 32 < H; }
+                    else { sl_f0 = fno; sl_tile0 = tno; sl_ox0 = col * cw - 32; sl_oy0 = band * 32 - 1; sl_right0 = (col + 1) * cw < W; sl_lower0 = (band + 1) * 32 < H; }
+                    ct_load_tile(tiles + o * slot_words, gbits + (size_t)fno * bits_fstride, wpr_g, H, band * 32, (col * cw) >> 5, TW, lane);
+                    __builtin_amdgcn_wave_barrier();
+                    cur = o; phase = 0; it0 = 0;
+                }
+            }
+        }
+        // ---- refill: when the queue is empty, all lanes (walking or not) enumerate the next items of the current tile into it.
+        //   phase 0  marker pixels on the tile's two relay rows: item = (row, word)
+        //   phase 1  marker pixels on its relay columns, rows strictly between: ONE item, a lane per row        entry = xr | yr << 10
+        //   phase 2  start candidates of small borders, rows yr = 2 .. 33 (the relay row 33 is only counted: a start state on a relay
+        //            row is a grid marker): item = (row, word)                           entry = start xr | (yr - 2) << 10 | hole << 15
+        // One pass: the entries are written as they are found; if they do not fit, the pass is repeated with fewer items.
+        while (head >= total && phase < 3) {
+            const uint32_t* tb = tiles + cur * slot_words;
+            const int y_last = H - CT_SLOT(sl_oy, cur); // tile row of the image's last row (rows beyond it are empty in LDS anyway)
+            const int NI = phase == 0 ? 2 * (nw + 1) : phase == 1 ? 1 : 32 * (nw + 1);
+            int take = min(CTW_TAKE, NI - it0), qbase = 0, stsum = 0;
+            for (;;) {
+                qbase = 0; stsum = 0;
+                for (int i0 = 0; i0 < take; i0 += 64) {
+                    const int it = it0 + i0 + lane;
+                    uint32_t m0 = 0, m1 = 0, hi = 0;
+                    int stc = 0;
+                    if (phase == 1) { // lane r < 31: row yr = 2 + r; bit c of the masks = the pixel on relay column xr = 32 (c + 1)
+                        if (lane < 31) {
+                            const uint32_t* row = tb + (2 + lane) * TW + 1;
+                            uint32_t curb = 0, nb = 0; // the pixel; its N or S neighbour is background
+                            for (int c = 0; c <= nw; c++) {
+                                curb |= (row[c] & 1u) << c;
+                                nb |= (~(row[c - TW] & row[c + TW]) & 1u) << c;
+                            }
+                            m0 = curb & nb;
+                            hi = (uint32_t)(2 + lane) << 10;
+                        }
+                    } else if (i0 + lane < take) {
+                        const int r = it / (nw + 1), k = it - r * (nw + 1);
+                        if (phase == 0) {
+                            const int yr = r ? 33 : 1;
+                            const uint32_t* row = tb + yr * TW + 1 + k;
+                            const uint32_t curw = row[0];
+                            const uint32_t cur_l = (curw << 1) | (row[-1] >> 31), cur_r = (curw >> 1) | (row[1] << 31);
+                            m0 = (curw & (~cur_l | ~cur_r)) | (curw & 1u & (~row[-TW] | ~row[TW]));
+                            if (k == nw) m0 &= 1u;
+                            hi = (uint32_t)(32 * (k + 1)) | ((uint32_t)yr << 10);
+                        } else if (2 + r <= y_last) {
+                            const uint32_t* row = tb + (2 + r) * TW + 1 + k;
+                            const uint32_t* up = row - TW;
+                            const uint32_t curw = row[0], upw = up[0];
+                            const uint32_t cur_l = (curw << 1) | (row[-1] >> 31);
+                            const uint32_t up_l = (upw << 1) | (up[-1] >> 31);
+                            const uint32_t up_r = (upw >> 1) | (up[1] << 31);
+                            const uint32_t mo = curw & ~cur_l & ~up_l & ~upw & ~up_r; // bit = the start pixel
+                            const uint32_t mh = ~curw & cur_l & upw;                  // bit = the hole's background pixel; the start pixel is one to the left
+                            // the statistic counts every start candidate of the frame once: candidate pixels in (x0, x1]
+                            stc = __popc((mo | mh) & (k == 0 ? ~1u : k == nw ? 1u : ~0u));
+                            if (r < 31) { // walked here: start pixels in [x0, x1] (a candidate on a shared column is tried by both tiles)
+                                m0 = k == nw ? mo & 1u : mo;
+                                m1 = k == 0 ? mh & ~1u : k == nw ? mh & 3u : mh;
+                            }
+                            hi = (uint32_t)(32 * (k + 1)) | ((uint32_t)r << 10);
+                        }
+                    }
+                    stsum += stc;
+                    const int c = __popc(m0) + __popc(m1);
+                    const int incl = wave_incl_scan_add(c);
+                    int q = qbase + incl - c;
+                    if (phase == 1) {
+                        while (m0) { const int b = __ffs(m0) - 1; m0 &= m0 - 1; if (q < CTW_QCAP) queue[q] = (uint16_t)(hi | (uint32_t)(32 * (b + 1))); q++; }
+                    } else {
+                        while (m0) { const int b = __ffs(m0) - 1; m0 &= m0 - 1; if (q < CTW_QCAP) queue[q] = (uint16_t)(hi + (uint32_t)b); q++; }
+                        while (m1) { const int b = __ffs(m1) - 1; m1 &= m1 - 1; if (q < CTW_QCAP) queue[q] = (uint16_t)((hi + (uint32_t)b - 1u) | 0x8000u); q++; }
+                    }
+                    qbase += __builtin_amdgcn_readlane(incl, 63);
+                }
+                if (qbase <= CTW_QCAP) break;
+                take = max(1, take >> 1); // (one item has at most 32 entries, phase 1 at most 31 * 31)
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (phase == 2) ncand_w += wave_sum(stsum);
+            __builtin_amdgcn_wave_barrier();
+            head = 0; total = qbase; qphase = phase;
+            it0 += take;
+            if (it0 >= NI) { phase++; it0 = 0; }
+        }
+        // ---- free lanes take the next entries
+        if (head < total) {
+            const bool idle = !busy && a == 0;
+            const unsigned long long fm = __ballot(idle);
+            const int q = head + ctl_lane_prefix(fm);
+            if (idle && q < total) {
+                const uint32_t c = queue[q];
+                lslot = cur; lbits = tiles + cur * slot_words;
+                const BitImage im{lbits, TW, 0, 0};
+                if (qphase < 2) { // a marker pixel: its states are walked one after the other
+                    sx = (int)(c & 1023u); sy = (int)(c >> 10);
+                    const unsigned ring0 = ring8(im, sx, sy);
+                    // grid-active directions: W / E on a relay row, N / S on a relay column, where the neighbour is background
+                    a = ring0 ? ((((sy & 31) == 1 ? 0x11u : 0u) | ((sx & 31) == 0 ? 0x44u : 0u)) & ~ring0) : 0u; // an isolated pixel has no states
+                } else {
+                    const int is_hole = (int)(c >> 15);
+                    sx = (int)(c & 1023u); sy = 2 + (int)((c >> 10) & 31u);
+                    kind = 1 + is_hole;
+                    x = sx; y = sy; n = 0;
+                    ring = ring8(im, sx, sy);
+                    s0 = relay_start_dir(ring, is_hole);
+                    s = s0;
+                    busy = s0 >= 0; // single-pixel borders are never kept
+                }
+            }
+            head = min(total, head + (int)__popcll(fm));
+            __builtin_amdgcn_wave_barrier(); // reads of the queue stay in front of the next refill's writes
+        }
+        // ---- the next state of a lane's marker pixel: the first foreground direction clockwise from a grid-active direction
+        if (!busy && a) {
+            const BitImage im{lbits, TW, 0, 0};
+            const unsigned ring0 = ring8(im, sx, sy);
+            const int d = __ffs((int)a) - 1;
+            const unsigned rr = ((ring0 | (ring0 << 8)) >> d) & 0xffu;
+            s0 = (d + 31 - __clz((int)rr)) & 7;
+            const unsigned e = s_lut[(ring0 << 3) | (unsigned)s0];
+            // the state's run, its 4-neighbour directions E, N, W, S (table bits 9, 7, 8, 10): all of them are this state's
+            a &= ~(((e >> 9) & 1u) | (((e >> 7) & 1u) << 2) | (((e >> 8) & 1u) << 4) | (((e >> 10) & 1u) << 6) | (1u << d));
+            kind = 0;
+            x = sx; y = sy; s = s0; n = 0; ring = ring0;
+            mn = 0xffffffffu; mnoff = 0;
+            allbot = sy == 33; allright = sx == cw + 32;
+            busy = true;
+        }
+        if (!__any(busy)) {
+            if (head >= total && phase >= 3 && !more && !__any(a != 0)) break;
+            continue;
+        }
+        // ---- every busy lane advances
+        bool finished = false;
+        uint32_t endkey = 0;
+        const BitImage im{lbits, TW, 0, 0};
+#pragma unroll
+        for (int u = 0; u < CTW_STEPS; u++) {
+            if (busy) {
+                const unsigned e = s_lut[(ring << 3) | (unsigned)s];
+                const bool at_marker = (e & (((y & 31) == 1 ? 8u : 0u) | ((x & 31) == 0 ? 16u : 0u))) != 0;
+                bool stop;
+                if (kind == 0) {
+                    stop = n > 0 && at_marker;
+                    if (stop) { finished = true; endkey = relay_key(x, y, s); }
+                    else if (e & 0x60u) {
+                        const uint32_t k = relay_key(x, y, s);
+                        if (k < mn) { mn = k; mnoff = (uint32_t)n | ((((e >> 5) & 3u) == 2u ? 1u : 0u) << 31); }
+                    }
+                } else {
+                    // a walk that meets a grid marker: the border is the segment walkers'; or a proof that the candidate is not the
+                    // border's canonical start (relay_not_canonical() on the table's run bits)
+                    const int key3 = y * 65536 + x, start_key = sy * 65536 + sx + (kind - 1);
+                    stop = at_marker;
+                    if (kind == 2)
+                        stop |= ((e & 0x080u) && key3 - 65536 < start_key) || ((e & 0x100u) && key3 - 1 < start_key) ||
+                                ((e & 0x200u) && key3 + 1 < start_key) || ((e & 0x400u) && key3 + 65536 < start_key);
+                    else stop |= key3 < start_key;
+                }
+                if (stop) busy = false;
+                else {
+                    const int nx = x + (int)((e >> 11) & 3u) - 1, ny = y + (int)((e >> 13) & 3u) - 1;
+                    if (nx < 32 || nx > cw + 32 || ny < 1 || ny > 33) busy = false; // a neighbour tile's walk
+                    else {
+                        x = nx; y = ny; s = (int)((e + 4u) & 7u); n++;
+                        ring = ring8(im, nx, ny);
+                        if (kind == 0) { allbot = allbot && ny == 33; allright = allright && nx == cw + 32; }
+                        else if (nx == sx && ny == sy && s == s0) {
+                            busy = false;
+                            if (n > min_len) {
+                                // rare: more than min_len points between grid lines.  The border is whole, so its final place is
+                                // known -- walk it once more, straight into the pool
+                                const int fl = CT_SLOT(sl_f, lslot), ox = CT_SLOT(sl_ox, lslot), oy = CT_SLOT(sl_oy, lslot);
+                                int32_t* st = ctstate + (size_t)fl * CT_STATE_INTS;
+                                uint32_t* pl = pool + (size_t)fl * pool_fstride;
+                                const int is_hole = kind - 1, start_key = (sy + oy) * 65536 + sx + ox + is_hole;
+                                const int k = atomicAdd(&st[1], 1);
+                                const int base = atomicAdd(&st[2], n);
+                                if (k >= kcap) atomicOr(&st[3], 2);
+                                else if (base + n > stage0) atomicOr(&st[3], 4);
+                                else {
+                                    int wx = sx, wy = sy, ws = s0;
+                                    unsigned wr = ring8(im, sx, sy);
+                                    for (int o = 0; o < n; o++) {
+                                        pl[base + o] = (uint32_t)(wx + ox - 1) | ((uint32_t)(wy + oy - 1) << 16);
+                                        const unsigned e2 = s_lut[(wr << 3) | (unsigned)ws];
+                                        wx += (int)((e2 >> 11) & 3u) - 1; wy += (int)((e2 >> 13) & 3u) - 1;
+                                        ws = (int)((e2 + 4u) & 7u);
+                                        wr = ring8(im, wx, wy);
+                                    }
+                                    tail_keys[(size_t)fl * kcap + k] = ((unsigned long long)(0xffffffffu - (uint32_t)start_key) << 32) |
+                                                                       ((unsigned long long)(n & 0x7ffff) << 13) | ((unsigned)k << 1) | (unsigned)is_hole;
+                                    tail_off[(size_t)fl * kcap + k] = base;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        // ---- finished segments this tile owns (not entirely on its bottom row / right column when a neighbour is there): into the
+        // wave's list with the frame's coordinates, appended to the frames' lists 64 at a time
+        const bool mine = finished && !((CT_SLOT(sl_lower, lslot) && allbot) || (CT_SLOT(sl_right, lslot) && allright));
+        const unsigned long long om = __ballot(mine);
+        if (om) {
+            const int nf = (int)__popcll(om);
+            if (fcnt + nf > CTW_FCAP) flush();
+            if (mine) {
+                const int i = fcnt + ctl_lane_prefix(om);
+                const uint32_t koff = ((uint32_t)CT_SLOT(sl_oy, lslot) << 16) + ((uint32_t)CT_SLOT(sl_ox, lslot) << 3); // tile -> frame, for a state key
+                f_key[i] = relay_key(sx, sy, s0) + koff; f_nxt[i] = endkey + koff; f_len[i] = (uint32_t)n | ((uint32_t)CT_SLOT(sl_tile, lslot) << 16);
+                f_mn[i] = mn == 0xffffffffu ? mn : mn + koff; f_off[i] = mnoff; f_frm[i] = (uint32_t)CT_SLOT(sl_f, lslot);
+            }
+            fcnt += nf;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (fcnt) flush();
+    if (ncand_w && lane == 0) atomicAdd(&ctstate[(size_t)CT_SLOT(sl_f, cur) * CT_STATE_INTS + 4], ncand_w);
+#undef CT_SLOT
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// One list element: value (the smallest start state of a window of the cyclic list; later the points from the segment to the end
+// of its list) | jump | id of the segment that holds the value.  64 bits, read and written whole, so that the rounds below need
+// no barrier between reading and writing: an element always describes a window [i, jump) truthfully, whatever the progress of
+// the elements it was combined from.
+struct CtElem {
+    uint32_t v;
+    uint16_t jmp, arg;
+};
+__device__ __forceinline__ unsigned long long ct_pack(CtElem e) { return (unsigned long long)e.v | ((unsigned long long)e.jmp << 32) | ((unsigned long long)e.arg << 48); }
+__device__ __forceinline__ CtElem ct_unpack(unsigned long long u) { return CtElem{(uint32_t)u, (uint16_t)(u >> 32), (uint16_t)(u >> 48)}; }
+
+template <bool LDSL> struct CtStore;
+template <> struct CtStore<true> {
+    unsigned long long* e;
+    uint16_t* nx;
+    __device__ __forceinline__ CtElem ld(int i) const { return ct_unpack(e[i]); }
+    __device__ __forceinline__ void st(int i, CtElem v) const { e[i] = ct_pack(v); }
+    __device__ __forceinline__ int ldn(int i) const { return nx[i]; }
+    __device__ __forceinline__ void stn(int i, int v) const { nx[i] = (uint16_t)v; }
+};
+// a frame with more segments than the LDS arrays hold (noise): the same lists in HBM / L2.  Only this workgroup touches them, and
+// its waves share one CU's vector cache, so workgroup scope is enough (an agent-scope release is an L2 write-back on this part)
+template <> struct CtStore<false> {
+    unsigned long long* e;
+    uint16_t* nx;
+    __device__ __forceinline__ CtElem ld(int i) const { return ct_unpack(__hip_atomic_load(e + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); }
+    __device__ __forceinline__ void st(int i, CtElem v) const { __hip_atomic_store(e + i, ct_pack(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    __device__ __forceinline__ int ldn(int i) const { return __hip_atomic_load(nx + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    __device__ __forceinline__ void stn(int i, int v) const { __hip_atomic_store(nx + i, (uint16_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+};
+
+#define CT_NIL 0xffff
+
+template <bool LDSL>
+__device__ __forceinline__ void ct_lists_frame(const CtStore<LDSL> S, int f, int nseg, int nk0, int pool0, int ncand, const uint32_t* __restrict__ sg,
+                                               int segcap, unsigned long long* __restrict__ ht, int hbits, int min_len, int pool_cap,
+                                               int kcap, unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off,
+                                               int32_t* __restrict__ counts, int32_t* __restrict__ rstate, uint4* __restrict__ itA,
+                                               uint2* __restrict__ itB, int ipf, int2* __restrict__ tile_items, int ntiles,
+                                               int* s_sh /* 8 ints of LDS */, int* s_tcur /* ntiles + 1 ints of LDS */)
+{
+    const int tid = threadIdx.x, NT = (int)blockDim.x;
+    const uint32_t* g_key = sg;
+    const uint32_t* g_nxt = sg + segcap;
+    const uint32_t* g_len = sg + 2 * (size_t)segcap; // length | tile << 16
+    const uint32_t* g_mn = sg + 3 * (size_t)segcap;
+    const uint32_t* g_off = sg + 4 * (size_t)segcap;
+    int* s_flags = s_sh + 0;
+    int* s_nkept = s_sh + 1;
+    int* s_pool = s_sh + 2;
+    int* s_ch = s_sh + 3; // three flags in rotation
+    if (tid == 0) { *s_flags = 0; *s_nkept = nk0; *s_pool = pool0; s_ch[0] = s_ch[1] = s_ch[2] = 0; }
+    for (int i = tid; i <= ntiles; i += NT) s_tcur[i] = 0;
+    __syncthreads();
+    // ---- end states -> segment ids: k_ct_walk entered every segment's start state into the frame's hash table
+    const uint32_t hmask = (1u << hbits) - 1u;
+    for (int i = tid; i < nseg; i += NT) {
+        const uint32_t key = g_nxt[i];
+        uint32_t h = (key * 0x9E3779B1u) >> (32 - hbits);
+        int nx = -1;
+        for (int p = 0; p < 128; p++) {
+            const unsigned long long v = ht[h];
+            if ((uint32_t)v == key) { nx = (int)(v >> 32); break; }
+            if (v == 0ull) break;
+            h = (h + 1) & hmask;
+        }
+        if (nx < 0 || nx >= nseg) { atomicOr(s_flags, RL_FLAG_BUG); nx = i; } // a segment that ends at a state nobody owns
+        S.stn(i, nx);
+        S.st(i, CtElem{g_mn[i], (uint16_t)nx, (uint16_t)i});
+    }
+    __threadfence_block();
+    __syncthreads();
+    // the table is left empty for the next batch: every segment takes its own entry out again (all lookups are done)
+    for (int i = tid; i < nseg; i += NT) {
+        const uint32_t key = g_key[i];
+        uint32_t h = (key * 0x9E3779B1u) >> (32 - hbits);
+        for (int p = 0; p < 128; p++) {
+            const unsigned long long v = ht[h];
+            if ((uint32_t)v == key) { ht[h] = 0ull; break; }
+            h = (h + 1) & hmask; // (an emptied slot in between does not end the search: the entry is there)
+        }
+    }
+    // ---- (e1) the border's smallest start state by pointer doubling round the cyclic list.  A round in which no value changes
+    // ends it: values then do not decrease along the jumps, the jumps of any element lead into a loop whose windows tile the whole
+    // cycle, so the loop's common value is the cycle's minimum and every value on the way to it is squeezed between.
+    for (int round = 0; round < 40; round++) {
+        if (tid == 0) s_ch[(round + 1) % 3] = 0; // last read two rounds ago, with a barrier in between
+        bool ch = false;
+        for (int i = tid; i < nseg; i += NT) {
+            CtElem E = S.ld(i);
+            const CtElem J = S.ld(E.jmp);
+            if (J.v < E.v) { E.v = J.v; E.arg = J.arg; ch = true; }
+            E.jmp = J.jmp;
+            S.st(i, E);
+        }
+        if (ch) s_ch[round % 3] = 1;
+        __threadfence_block();
+        __syncthreads();
+        if (!s_ch[round % 3]) break;
+    }
+    // ---- (e2) list ranking: every cycle is cut in front of the segment that holds the canonical start (arg == own id); the value
+    // becomes the number of points from the segment to the end of its list
+    for (int i = tid; i < nseg; i += NT) {
+        CtElem E = S.ld(i);
+        const int nx = S.ldn(i);
+        const CtElem N = S.ld(nx); // (its arg is final, whatever else the element holds by now)
+        E.v = g_len[i] & 0xffffu;
+        E.jmp = (N.arg == nx) ? (uint16_t)CT_NIL : (uint16_t)nx;
+        S.st(i, E);
+    }
+    if (tid == 0) s_ch[0] = s_ch[1] = s_ch[2] = 0;
+    __threadfence_block();
+    __syncthreads();
+    for (int round = 0; round < 40; round++) {
+        if (tid == 0) s_ch[(round + 1) % 3] = 0;
+        bool ch = false;
+        for (int i = tid; i < nseg; i += NT) {
+            CtElem E = S.ld(i);
+            if (E.jmp != CT_NIL) {
+                const CtElem J = S.ld(E.jmp);
+                E.v += J.v; E.jmp = J.jmp;
+                S.st(i, E);
+                ch = true;
+            }
+        }
+        if (ch) s_ch[round % 3] = 1;
+        __threadfence_block();
+        __syncthreads();
+        if (!s_ch[round % 3]) break;
+    }
+    // ---- (f1) kept borders: pool space and sort key; jmp of a head segment = the border's kept index or NIL
+    const int stage0 = pool_cap >> 2;
+    for (int i = tid; i < nseg; i += NT) {
+        CtElem E = S.ld(i);
+        if (E.arg != i) continue;
+        const int n = (int)E.v;
+        const uint32_t canon = g_mn[i]; // the head segment holds the border's smallest start state
+        uint16_t kk = CT_NIL;
+        if (canon == 0xffffffffu) atomicOr(s_flags, RL_FLAG_BUG); // a border without a start state
+        else if (n > min_len) {
+            const int k = atomicAdd(s_nkept, 1);
+            const int base = atomicAdd(s_pool, n);
+            if (base + n > stage0) atomicOr(s_flags, 4);
+            else if (k < kcap) {
+                const unsigned hole = g_off[i] >> 31; // pattern of the canonical start
+                const uint32_t disc = (canon >> 16) * 65536u + ((canon >> 3) & 0x1fffu) + hole;
+                tail_keys[(size_t)f * kcap + k] = ((unsigned long long)(0xffffffffu - disc) << 32) | ((unsigned long long)(n & 0x7ffff) << 13) |
+                                                  ((unsigned)k << 1) | hole;
+                __hip_atomic_store(tail_off + (size_t)f * kcap + k, base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                kk = (uint16_t)k;
+            }
+        }
+        E.jmp = kk;
+        S.st(i, E);
+    }
+    __threadfence_block();
+    __syncthreads();
+    int flags = *s_flags;
+    if (*s_nkept > kcap) flags |= 2;
+    if (flags) {
+        if (tid == 0) { counts[f * 4 + 0] = 0; counts[f * 4 + 1] = 0; counts[f * 4 + 2] = flags; counts[f * 4 + 3] = 0; }
+        return;
+    }
+    // ---- (f2) one copy item per segment of a kept border, grouped by the tile that walked the segment (k_ct_points: a wave per
+    // tile).  Counting sort: segments per tile, exclusive scan, scatter.  Segment i starts (n - val[i]) points after the list head;
+    // the border starts `minoff` points into the head segment, so everything shifts down by minoff and the head's first points
+    // wrap to the end.
+    for (int i = tid; i < nseg; i += NT) {
+        const CtElem E = S.ld(i);
+        if (S.ld(E.arg).jmp != CT_NIL) atomicAdd(&s_tcur[g_len[i] >> 16], 1);
+    }
+    __syncthreads();
+    if (tid < 64) { // exclusive scan over the tiles by one wave; s_tcur[t] becomes the tile's write cursor
+        int run = 0;
+        for (int t0 = 0; t0 < ntiles; t0 += 64) {
+            const int t = t0 + tid;
+            const int c = t < ntiles ? s_tcur[t] : 0;
+            const int incl = wave_incl_scan_add(c);
+            if (t < ntiles) {
+                s_tcur[t] = run + incl - c;
+                tile_items[(size_t)f * ntiles + t] = make_int2(run + incl - c, (run + incl <= ipf) ? c : 0);
+            }
+            run += __builtin_amdgcn_readlane(incl, 63);
+        }
+        if (tid == 0) { s_tcur[ntiles] = run; if (run > ipf) atomicOr(s_flags, 4); } // more kept segments than the frame's item list holds: reported like a full pool
+    }
+    __syncthreads();
+    if (s_tcur[ntiles] <= ipf) {
+        uint4* A = itA + (size_t)f * ipf;
+        uint2* B2 = itB + (size_t)f * ipf;
+        for (int i = tid; i < nseg; i += NT) {
+            const CtElem E = S.ld(i);
+            const CtElem G = S.ld(E.arg);
+            if (G.jmp == CT_NIL) continue;
+            const int k = G.jmp, n = (int)G.v;
+            const int base = __hip_atomic_load(tail_off + (size_t)f * kcap + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const int dst = base + (n - (int)E.v) - (int)(g_off[E.arg] & 0x7fffffffu);
+            const uint32_t lt = g_len[i];
+            const int q = atomicAdd(&s_tcur[lt >> 16], 1);
+            A[q] = make_uint4(g_key[i], (uint32_t)dst, lt & 0xffffu, (uint32_t)base);
+            B2[q] = make_uint2((uint32_t)n, 0u);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        counts[f * 4 + 0] = *s_nkept; counts[f * 4 + 1] = 0; counts[f * 4 + 2] = *s_flags; counts[f * 4 + 3] = ncand;
+        rstate[f * 2 + 0] = 30; rstate[f * 2 + 1] = *s_pool;
+    }
+}
+
+__global__ __launch_bounds__(CTL_THREADS) void k_ct_lists(const uint32_t* __restrict__ seg, size_t seg_fstride, int segcap, int32_t* __restrict__ ctstate,
+                                                          unsigned long long* __restrict__ htab, int hbits, unsigned long long* __restrict__ gelem,
+                                                          int lcap, int min_len, int pool_cap, int kcap, unsigned long long* __restrict__ tail_keys,
+                                                          int32_t* __restrict__ tail_off, int32_t* __restrict__ counts, int32_t* __restrict__ rstate,
+                                                          uint4* __restrict__ itemsA, uint2* __restrict__ itemsB, int ipf,
+                                                          int2* __restrict__ tile_items, int ntiles)
+{
+    extern __shared__ __align__(16) unsigned char ctl_smem[];
+    __shared__ int s_sh[8];
+    __shared__ int s_in[6];
+    __builtin_amdgcn_s_setprio(2);
+    const int tid = threadIdx.x, f = blockIdx.x;
+    int32_t* st = ctstate + (size_t)f * CT_STATE_INTS;
+    if (tid < 5) s_in[tid] = st[tid];
+    __syncthreads();
+    if (tid < 5) st[tid] = 0; // the counters of k_ct_walk are left at zero for the next batch
+    const int nseg = s_in[0], nk0 = s_in[1], pool0 = s_in[2], ncand = s_in[4];
+    int flags = s_in[3];
+    if (nseg > segcap) flags |= RL_FLAG_TABLE; // more segments than the frame's list holds: the host redoes the frame on a coarser grid
+    unsigned long long* ht = htab + ((size_t)f << hbits);
+    if (flags) {
+        // (the hash table may hold anything now: emptied whole)
+        for (int i = tid; i < (1 << hbits); i += (int)blockDim.x) ht[i] = 0ull;
+        if (tid == 0) { counts[f * 4 + 0] = 0; counts[f * 4 + 1] = 0; counts[f * 4 + 2] = flags; counts[f * 4 + 3] = 0; }
+        return;
+    }
+    const uint32_t* sg = seg + (size_t)f * seg_fstride;
+    int* s_tcur = reinterpret_cast<int*>(ctl_smem);
+    unsigned char* lists = ctl_smem + (((size_t)ntiles + 1) * 4 + 15) / 16 * 16;
+    if (nseg <= lcap) {
+        CtStore<true> S{reinterpret_cast<unsigned long long*>(lists), reinterpret_cast<uint16_t*>(lists + (size_t)lcap * 8)};
+        ct_lists_frame<true>(S, f, nseg, nk0, pool0, ncand, sg, segcap, ht, hbits, min_len, pool_cap, kcap, tail_keys, tail_off, counts, rstate, itemsA,
+                             itemsB, ipf, tile_items, ntiles, s_sh, s_tcur);
+    } else {
+        unsigned long long* ge = gelem + (size_t)f * ((size_t)segcap + ((size_t)segcap + 3) / 4);
+        CtStore<false> S{ge, reinterpret_cast<uint16_t*>(ge + segcap)};
+        ct_lists_frame<false>(S, f, nseg, nk0, pool0, ncand, sg, segcap, ht, hbits, min_len, pool_cap, kcap, tail_keys, tail_off, counts, rstate, itemsA,
+                              itemsB, ipf, tile_items, ntiles, s_sh, s_tcur);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// (f2): a wave per tile, the grid of k_ct_walk again.  The tile's copy items -- the segments of kept borders it walked -- are walked
+// once more out of LDS, a lane each, their points going straight to their final place.
+__global__ __launch_bounds__(CTW_THREADS) void k_ct_points(
+    const uint32_t* __restrict__ gbits, size_t bits_fstride, int wpr_g, int W, int H, const uint16_t* __restrict__ lut_g, int cw, int ncols,
+    int nbands, int wgs_per_frame, int total_wgs, const int32_t* __restrict__ counts, const uint4* __restrict__ itemsA,
+    const uint2* __restrict__ itemsB, int ipf, const int2* __restrict__ tile_items, uint32_t* __restrict__ pool, size_t pool_fstride, int wave_bytes)
+{
+    extern __shared__ __align__(16) unsigned char ctw_smem[];
+    __shared__ __align__(16) uint16_t s_lut[2048];
+    __builtin_amdgcn_s_setprio(2);
+    const int tid = threadIdx.x, lane = tid & 63, wid = wave_id();
+    int bx, f;
+    if (!xcd_remap(wgs_per_frame, total_wgs, bx, f)) return;
+    const int ntiles = nbands * ncols, tile0 = bx * (CTW_THREADS / 64);
+    if (counts[f * 4 + 2]) return; // the frame was given up
+    // (a workgroup none of whose tiles has an item -- most of them on a quiet frame -- leaves before the step table is loaded)
+    int any = 0;
+    if (tid < CTW_THREADS / 64 && tile0 + tid < ntiles) any = tile_items[(size_t)f * ntiles + tile0 + tid].y;
+    if (!__syncthreads_or(any)) return;
+    reinterpret_cast<uint4*>(s_lut)[tid] = reinterpret_cast<const uint4*>(lut_g)[tid];
+    __syncthreads();
+    const int tile_id = tile0 + wid;
+    if (tile_id >= ntiles) return;
+    const int2 ti = tile_items[(size_t)f * ntiles + tile_id];
+    if (ti.y <= 0) return;
+    const int band = tile_id / ncols, col = tile_id - band * ncols;
+    const RelayTile t = relay_tile(W, H, 32, cw, band, col);
+    const int nw = cw >> 5, TW = nw + 2, j0 = t.x0 >> 5;
+    uint32_t* tile = reinterpret_cast<uint32_t*>(ctw_smem + (size_t)wid * wave_bytes);
+    ct_load_tile(tile, gbits + (size_t)f * bits_fstride, wpr_g, H, t.y0, j0, TW, lane);
+    __builtin_amdgcn_wave_barrier();
+    const BitImage im{tile - (t.y0 - 1) * TW - (j0 - 1), TW, W, H};
+    uint32_t* pl = pool + (size_t)f * pool_fstride;
+    const uint4* A = itemsA + (size_t)f * ipf + ti.x;
+    const uint2* B2 = itemsB + (size_t)f * ipf + ti.x;
+    for (int i = lane; i < ti.y; i += 64) {
+        const uint4 a = A[i];
+        const int n = (int)B2[i].x;
+        RelayWalk w2;
+        relay_walk_from_key(im, w2, a.x);
+        const int len = (int)a.z, base = (int)a.w;
+        int pdst = (int)a.y;
+        for (int o = 0; o < len; o++, pdst++) {
+            pl[pdst < base ? pdst + n : pdst] = relay_point(w2);
+            const unsigned e = s_lut[(w2.ring << 3) | (unsigned)w2.s];
+            w2.x += (int)((e >> 11) & 3u) - 1; w2.y += (int)((e >> 13) & 3u) - 1;
+            w2.s = (int)((e + 4u) & 7u);
+            w2.ring = ring8(im, w2.x, w2.y);
+        }
+    }
+}
+
+} // namespace orbfe

@@ -386,6 +386,23 @@ def test_small_border_phase_inside_and_outside_the_relay_kernel(mode):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("mode,tile_w,tpw", [("0", "0", "0"), ("1", "0", "0"), ("1", "64", "4"), ("1", "480", "1")])
+def test_tiled_and_one_workgroup_contour_paths(mode, tile_w, tpw):
+    """The contour stage has two formulations of the same relay segments: one workgroup per frame out of one LDS image
+    (k_contours_relay*: what full batches of frames up to 1280 x 720 run) and tiles of whole grid cells, a wave each
+    (aruco_tiles.hip: 1920 x 1080 and batches of up to 32 frames by default).  ORBFE_ARUCO_TILED=0 / 1 forces one or the other for
+    every batch; narrow tiles with four tiles per wave (the waves are persistent and overlap their tiles) and the widest tiles are run
+    too.  The contour, detector-mode and full-HD tests must pass every way."""
+    import os, subprocess, sys
+    env = dict(os.environ, ORBFE_ARUCO_TILED=mode, ORBFE_ARUCO_TILE_W=tile_w, ORBFE_ARUCO_TPW=tpw)
+    here = os.path.abspath(__file__)
+    r = subprocess.run([sys.executable, "-m", "pytest", here, os.path.join(os.path.dirname(here), "test_aruco_modes_gpu.py"), "-q", "-x", "-k",
+                        "structured_binary or relay_and_legacy or dense_frame or detect_matches_oracle or lds_boundary or tail_kernel or full_hd "
+                        "or sequence or enclosed or min_marker"],
+                       env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_detector_paired_with_an_extractor(orbfe, oracle):
     """orbfe_extractor_pair_detector: the extractor's one-frame call starts the paired detector on the image it uploads; the detector's
     call takes that work if it is handed the same image and runs normally otherwise.  Same results in every case: same image (with
@@ -418,5 +435,17 @@ def test_detector_paired_with_an_extractor(orbfe, oracle):
     ex(imgs[1]); ex(imgs[2]); assert same(det.detect(imgs[2], (K, D, (640, 480)), 0.187), want[2])   # two extracts in a row
     c = det.contours(len(want[2][0]))
     assert len(c) == len(want[2][0]) and all(len(x) > 70 for x in c)
+    # a setter between the extractor's call and the detector's ends the work started with the old parameters: the
+    # detector's call must answer with the new dictionary / corner method / error-correction rate, not with what was speculated
+    other = orbfe.MarkerDetector("ARUCO_MIP_36h12")
+    mip = synth.stream(480, 640, 2, 78, "ARUCO_MIP_36h12", n_markers=4)[1]
+    want_mip = other.detect(mip, (K, D, (640, 480)), 0.187)
+    assert len(want_mip[0]) > 0
+    ex(mip); det.setDictionary("ARUCO_MIP_36h12"); assert same(det.detect(mip, (K, D, (640, 480)), 0.187), want_mip)
+    ex(imgs[1]); det.setDictionary("ARUCO"); assert same(det.detect(imgs[1], (K, D, (640, 480)), 0.187), want[1])
+    ref.setCornerRefinementMethod(2); want_none = ref.detect(imgs[2], (K, D, (640, 480)), 0.187); ref.setCornerRefinementMethod(1)
+    ex(imgs[2]); det.setCornerRefinementMethod(2); assert same(det.detect(imgs[2], (K, D, (640, 480)), 0.187), want_none)
+    det.setCornerRefinementMethod(1)
+    ex(imgs[2]); assert same(det.detect(imgs[2], (K, D, (640, 480)), 0.187), want[2])
     ex.pair_detector(None)
     ex(imgs[0]); assert same(det.detect(imgs[0], (K, D, (640, 480)), 0.187), want[0])
