@@ -1095,6 +1095,8 @@ void aruco_unpair_notice(orbfe_aruco* h)
     if (h) h->spec.pending = false;
 }
 
+int aruco_device_of(const orbfe_aruco* h) { return h ? h->device : -1; }
+
 } // namespace orbfe
 
 // The modes whose frames go one at a time (THRES_AUTO_FIXED and the automatic size estimation carry state from frame to frame and

@@ -689,7 +689,7 @@ int orbfe_extract_batch(orbfe_extractor* h, const uint8_t* imgs, int nframes, si
     if ((rc = h->d_desc.ensure((size_t)cap * nframes * 32))) return rc;
     if ((rc = h->d_nout.ensure((size_t)nframes * 4))) return rc;
     // page-locked staging: [frames in, row pitch dpitch] then [n per frame | flag | keypoints | descriptors] out
-    const size_t o_n = align_up((int)(dframe * nframes), 256), o_flag = o_n + (size_t)align_up(nframes * 4, 64), o_kps = o_flag + 64;
+    const size_t o_n = (dframe * (size_t)nframes + 255) / 256 * 256, o_flag = o_n + ((size_t)nframes * 4 + 63) / 64 * 64, o_kps = o_flag + 64; // (size_t: a batch of 2 GiB and more)
     const size_t o_desc = o_kps + (size_t)cap * nframes * sizeof(orbfe_keypoint), o_end = o_desc + (size_t)cap * nframes * 32;
     if ((rc = h->pinned.ensure(o_end))) return rc;
     uint8_t* hp = h->pinned.as<uint8_t>();
@@ -707,8 +707,9 @@ int orbfe_extract_batch(orbfe_extractor* h, const uint8_t* imgs, int nframes, si
         if (spec) { // the paired detector starts on the same device copy, on its own stream, next to the launches below
             if (!h->ev_up) ORBFE_HIP(hipEventCreateWithFlags(&h->ev_up, hipEventDisableTiming));
             ORBFE_HIP(hipEventRecord(h->ev_up, s));
-            int rcs = aruco_speculate(h->paired, h->d_in.as<uint8_t>(), dframe, rows, cols, dpitch, h->ev_up, hp, dpitch);
-            if (rcs) return rcs;
+            // a frame the detector refuses, or a workspace it cannot get, is the detector's own call's business: the extraction runs
+            // "as if nothing had been started" (orbfe.h), and aruco_speculate() leaves no speculation pending when it fails
+            if (aruco_speculate(h->paired, h->d_in.as<uint8_t>(), dframe, rows, cols, dpitch, h->ev_up, hp, dpitch) != ORBFE_OK) (void)hipGetLastError();
         }
         int rc2 = h->run_device(h->d_in.as<uint8_t>(), nframes, dframe, rows, cols, dpitch, h->d_kps.as<orbfe_keypoint>(),
                                 h->d_desc.as<uint8_t>(), cap, h->d_nout.as<int32_t>(), s, /*flag_word*/ 1);
@@ -856,6 +857,8 @@ int orbfe_extractor_set_aux_stream(orbfe_extractor* h, void* stream)
 int orbfe_extractor_pair_detector(orbfe_extractor* h, orbfe_aruco* detector)
 {
     if (!h) return fail(ORBFE_ERR_INVALID, "null handle");
+    if (detector && aruco_device_of(detector) != h->device)   // the detector is started on the extractor's device copy of the frame
+        return fail(ORBFE_ERR_INVALID, "orbfe_extractor_pair_detector: extractor on device %d, detector on device %d", h->device, aruco_device_of(detector));
     if (h->paired) { aruco_speculation_wait(h->paired); aruco_unpair_notice(h->paired); }
     h->paired = detector;
     return ORBFE_OK;

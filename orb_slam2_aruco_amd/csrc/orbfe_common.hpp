@@ -127,6 +127,7 @@ int aruco_speculate(orbfe_aruco* a, const uint8_t* d_img, size_t dframe, int row
                     const uint8_t* host_copy, size_t host_pitch);
 void aruco_speculation_wait(orbfe_aruco* a); // until the detector no longer reads the extractor's copy of the image
 void aruco_unpair_notice(orbfe_aruco* a);
+int aruco_device_of(const orbfe_aruco* a);   // the HIP device the detector was created on
 
 // Scratch of the entry points that have no handle (matching, poses, keyframe records): one workspace per calling thread,
 // HIP device and stream.  A buffer allocated on one GPU is never handed to a kernel on another, two asynchronous calls

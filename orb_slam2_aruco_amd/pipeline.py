@@ -376,6 +376,7 @@ class FrontEndPipeline:
     def status(self):
         """Capacity flags of the last batch of every engine (synchronises): dict, all zero = results complete."""
         out = {"extractor_overflow": 0, "search_init_overflow": 0, "aruco_flagged_frames": 0, "aruco_flags": 0}
+        self.flush()                 # the newest batch's matching may still be held back (defer_post)
         if self.use_orb:
             out["extractor_overflow"] = max(e.batch_status() for e in self.exs)
             ovf = ctypes.c_int32(0)
@@ -413,11 +414,13 @@ class FrontEndPipeline:
 
     # ------------------------------------------------------------------------------------------------------------
     def read_records(self, cur):
-        """Result set `cur` as host arrays (after synchronize())."""
+        """Result set `cur` as host arrays (flushes the held-back post-work and synchronises)."""
+        self.synchronize()
         return self.layout.unpack(self.recs[cur].cpu().numpy())
 
     def read_matches(self):
         """Matching outputs of the newest batch: dict of (B-1, cap) arrays + nmatches (B-1)."""
+        self.synchronize()           # the newest batch's matching is enqueued one step late (defer_post): flush before reading
         g = lambda t: t.cpu().numpy()
         return {"best_idx": g(self.d_bidx), "best_dist": g(self.d_bdist), "second_dist": g(self.d_sdist),
                 "matches12": g(self.d_m12), "nmatches": g(self.d_nm)}
