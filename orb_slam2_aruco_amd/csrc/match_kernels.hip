@@ -1374,7 +1374,7 @@ static int sfi_launch(const orbfe_keypoint* d_kps, const uint8_t* d_desc, const 
     int rc;
     // grid records: nl0 | nq | cursor (ints), then sorted, xy, ang, desc, query per frame
     if ((rc = w.csr_cnt.ensure((size_t)nframes * (2 + SFI_CURSOR_PAD) * 4 + 64)) || (rc = w.csr_idx.ensure(F * (4 + 8 + 4 + 32 + 8 + 2) + 256)) ||
-        (rc = w.csr_dist.ensure((size_t)npairs * pool_cap * 4 + 512)) ||   // + slack: k_sfi_accept prefetches a row's next 64 entries unconditionally (the last pair's last row reads up to 63 entries past its pool) (rc = w.scratch.ensure((size_t)npairs * SFI_MAXL0 * 4)))
+        (rc = w.csr_dist.ensure((size_t)npairs * pool_cap * 4 + 512 /* k_sfi_accept prefetches a row's next 64 entries unconditionally: up to 63 past the last pool */)) || (rc = w.scratch.ensure((size_t)npairs * SFI_MAXL0 * 4)))
         return rc;
     if (!w.sfi_overflow.p) {
         if ((rc = w.sfi_overflow.ensure(16))) return rc;
