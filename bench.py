@@ -49,8 +49,6 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C2", choices=sorted(CONFIGS), help="SURVEY 8d configuration (default: the one "
                     "BASELINE.json's metric is quoted on)")
-    ap.add_argument("--splits", type=int, default=1, help="process a batch as this many sub-batches on separate handles and "
-                    "streams (their latency-bound and VALU-bound kernels overlap)")
     ap.add_argument("--frames", type=int, default=None, help="frames per step per GPU (overrides the configuration)")
     ap.add_argument("--rows", type=int, default=None)
     ap.add_argument("--cols", type=int, default=None)
@@ -381,7 +379,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    backend = os.environ.get("ORBFE_BENCH_BACKEND") or "nccl"
+    # The batch's gather runs INSIDE the library over RCCL (orbfe_pipeline_comm_init: ncclCommInitRank, ncclSend / ncclRecv on the
+    # pipeline's matching stream).  torch.distributed is only the rendezvous: a gloo group carries the 128-byte RCCL id to the ranks,
+    # the barriers and the max of the elapsed times.  ORBFE_BENCH_BACKEND=gloo (test hook of a one-GPU box, where several ranks share a
+    # device and RCCL cannot run) gathers the record sets through gloo from the host after every step instead.
+    backend = os.environ.get("ORBFE_BENCH_BACKEND") or "rccl"
     multi = world > 1 or args.force_gather          # the gather branch runs (RCCL with world size 1 under --force-gather)
     if multi and "RANK" not in os.environ:          # --force-gather started without torchrun
         os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK=str(local_rank))
@@ -389,13 +391,11 @@ def main():
         if "MASTER_PORT" not in os.environ:
             os.environ["MASTER_PORT"] = str(free_port())
     if multi:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        dist.init_process_group("gloo")
 
     from orb_slam2_aruco_amd import binding, sharding
-    from orb_slam2_aruco_amd.pipeline import FrontEndPipeline, RecordLayout, valid_records
+    from orb_slam2_aruco_amd import pipeline as pipeline_mod
+    from orb_slam2_aruco_amd.pipeline import FrontEndPipeline, valid_records
     L = binding.load()
     version = L.orbfe_version().decode()
     import hashlib
@@ -413,53 +413,44 @@ def main():
             skips[key] = int(os.environ[env])
     if "+ablation" in version:
         skips["library"] = version
-    if os.environ.get("ORBFE_MATCH_TWICE"):      # sensitivity study: the matching launched twice (more work, but not the workload)
-        skips["match_twice"] = 1
     # every ORBFE_* variable that is set is recorded; the ones that change which kernels run or how they are scheduled make the
-    # line a diagnostic (value null) unless they spell the default
+    # line a diagnostic (value null) unless they spell the default.  The list of variables and defaults comes from the library
+    # (orbfe_pipeline_env_defaults), so it cannot drift from the getenv calls; a variable the library does not list, or one whose
+    # default depends on the frame size, makes the line a diagnostic whatever it is set to.
     env_set = {k: v for k, v in sorted(os.environ.items()) if k.startswith("ORBFE_")}
-    harmless = {"ORBFE_BENCH_DEVICE", "ORBFE_BENCH_BACKEND", "ORBFE_LIB", "ORBFE_BENCH_SELF_LAUNCHED"}   # (ORBFE_GATHER_NOOP is not: it makes the line a diagnostic)
-    defaults = {"ORBFE_ORIENT_PAIR": "1", "ORBFE_FAST0": "0", "ORBFE_EARLY_SHARED": "0", "ORBFE_ARUCO_VIS": "0", "ORBFE_ARUCO_FORCE_GLOBAL": "0", "ORBFE_STREAM_PRIO": "0,0,0", "ORBFE_ENGINE_SETS_ARUCO": "1", "ORBFE_PHASE_PIN": "2", "ORBFE_DET_PIN": "4", "ORBFE_BLUR_LEND": "match", "ORBFE_LEND_ALL": "1", "ORBFE_RECORD_SETS": "4", "ORBFE_GATHER_STREAM": "match", "ORBFE_DET_NOFORK": "0",
-                "ORBFE_BLUR_PLACE": "1", "ORBFE_ARUCO_RELAY_CHUNK": "0", "ORBFE_OCC_FAST": "0", "ORBFE_OCC_BLUR": "0",
-                "ORBFE_OCC_ORIENT": "0", "ORBFE_ARUCO_TILED": "auto", "ORBFE_ARUCO_TILE_W": "0", "ORBFE_ARUCO_TPW": "0"}
-    defaults["ORBFE_DET_NOFORK"] = "1" if args.rows * args.cols <= 640 * 480 else "0"    # pipeline.py: by frame size
-    env_nondefault = {k: v for k, v in env_set.items() if k not in harmless and defaults.get(k) != v}
+    harmless = {"ORBFE_BENCH_DEVICE", "ORBFE_BENCH_BACKEND", "ORBFE_LIB", "ORBFE_BENCH_SELF_LAUNCHED"}
+    defaults = pipeline_mod.env_defaults()
+    env_nondefault = {k: v for k, v in env_set.items() if k not in harmless and (defaults.get(k) in (None, "size") or defaults[k] != v)}
     B, rows, cols = args.frames, args.rows, args.cols
     use_aruco, use_orb = not args.no_aruco, not args.no_orb
 
     frames_np = make_stream(args, rank)
-    gather = None
-    pipe = FrontEndPipeline(B, rows, cols, args.nfeatures, args.nlevels, args.dictionary, device=local_rank,
-                            marker_capacity=args.marker_capacity, use_orb=use_orb, use_aruco=use_aruco, splits=args.splits)
-    if os.environ.get("ORBFE_PG_ONLY"):      # diagnostic: the process group is initialised, the pipeline runs without its gather branch
-        gather_off = True
-    else:
-        gather_off = False
-    if multi and not gather_off:
-        # gloo moves CPU tensors: the test hook stages the record set through the host (the RCCL path gathers in place)
-        gather = sharding.RecordGather(pipe.recs[0] if backend == "nccl" else pipe.recs[0].cpu())
-        if os.environ.get("ORBFE_GATHER_NOOP"):       # diagnostic: the gather branch's events and waits without the collective
-            pipe.gather = lambda t: None
-        elif backend == "nccl":
-            pipe.gather = gather
-        else:
-            pipe.gather = lambda t: gather(t.cpu())
+    mkpipe = lambda: FrontEndPipeline(B, rows, cols, args.nfeatures, args.nlevels, args.dictionary, device=local_rank,
+                                      marker_capacity=args.marker_capacity, use_orb=use_orb, use_aruco=use_aruco)
+    pipe = mkpipe()
+    gloo_gather = None
+    if multi and backend == "rccl":
+        uid = [pipeline_mod.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        pipe.comm_init(uid[0], rank, world, 0)
+    elif multi:
+        gloo_gather = sharding.RecordGather(torch.zeros(pipe.layout.nbytes, dtype=torch.uint8))
     # resident input: R copies of the stream at different time offsets, one per step in rotation, so that no step finds its
     # frames in the 256 MiB Infinity Cache (copy r = the stream rolled by r * B / R frames)
     pitch = pipe.pitch
     R = args.resident_batches or max(1, min(8, (256 << 20) // (B * rows * pitch) + 2))
     shifts = [(r * B) // R for r in range(R)]
     d_batches = [pipe.upload(np.roll(frames_np, -s, axis=0)) for s in shifts]
-    ex, det = pipe.ex, pipe.det
-    ex.enable_kernel_timing(False)
-    if args.no_orb:  # diagnostics still want the level geometry
-        lay = pipe.layout
-        ex.extract_batch_device(d_batches[0].data_ptr(), B, rows * pitch, rows, cols, pitch, pipe.rec_ptr[0] + lay.kps,
-                                pipe.rec_ptr[0] + lay.desc, pipe.cap, pipe.rec_ptr[0] + lay.n, ctypes.c_void_p(pipe.stream.cuda_stream))
+
+    def step(r):
+        cur = pipe.step(d_batches[r])
+        if gloo_gather is not None:                 # the test hook: the record set through the host and gloo, every step
+            gloo_gather(torch.from_numpy(pipe.record_bytes(cur)))
+        return cur
 
     pipe.warmup(d_batches[0], args.warmup)
     for r in range(1, R):           # touch every resident copy once
-        pipe.step(d_batches[r])
+        step(r)
     pipe.synchronize()
     for key, v in late_skips:
         binding.debug_control(key, v)
@@ -472,16 +463,18 @@ def main():
         d.enable_kernel_timing(True)
     pipe.reset_timing_history()
     last = (0, 0)
+    r_hist = [R - 1]                # the resident copy each step ran on (the step before the timed region ran on the last one)
     t0 = time.perf_counter()
     for i in range(args.steps):
         r = i % R
-        last = (pipe.step(d_batches[r]), r)
-    pipe.flush()                               # the last batch's matching / gather (held back one step, see FrontEndPipeline.step)
+        last = (step(r), r)
+        r_hist.append(r)
+    pipe.flush()                               # the last batch's matching / gather (held back one step, see orbfe_pipeline_step)
     t_enq = time.perf_counter() - t0           # host time to enqueue all steps (the GPU runs behind it)
+    pipe.synchronize()
     torch.cuda.synchronize()
     if multi:
         dist.barrier()
-    torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     status = pipe.status()
     if any(status.values()):
@@ -489,79 +482,98 @@ def main():
     # HIP-event timings of the timed steps' launches (events recorded on the launch stream every step, no synchronisation in
     # between): the per-stage MEDIAN over the timed steps (the newest 64), not one step's events
     ex_last, det_last = pipe.last_engines()
-    orb_us = ex_last.kernel_times_us(median=True)
+    orb_us = ex_last.kernel_times_us(median=True) if use_orb else np.zeros(0, np.float32)
     aruco_us = det_last.kernel_times_us(median=True) if use_aruco else np.zeros(0, np.float32)
-    orb_us_last = ex_last.kernel_times_us()
+    orb_us_last = ex_last.kernel_times_us() if use_orb else np.zeros(0, np.float32)
     aruco_us_last = det_last.kernel_times_us() if use_aruco else np.zeros(0, np.float32)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if multi:
-        if backend == "nccl":
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        else:
-            tc = t.cpu(); dist.all_reduce(tc, op=dist.ReduceOp.MAX); t = tc
-    elapsed = float(t.item())
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
     total_frames = B * args.steps * world
     cur, r_last = last
     rec = pipe.read_records(cur)
     matches = pipe.read_matches() if use_orb else None
     last_frames = np.roll(frames_np, -shifts[r_last], axis=0)       # host images of the last timed step's batch
-
-    # ---- the stages ALONE on the GPU (outside the clock): each engine by itself, three batches, median of its HIP events.  In the
-    # timed pipeline a stage's launch time is stretched by whatever else shares the chip -- two extractor batches, the detector and
-    # the matching are in flight together -- so the in-pipeline figure says how long the launch was resident, this one what it costs.
-    match_med = pipe.matching_times_us(median=True) if use_orb else (0.0, 0.0)      # in the pipeline: before the history is reset below
+    prev_last = np.roll(frames_np, -shifts[r_hist[-2]], axis=0)[B - 1]   # the frame in front of it in the stream the pipeline saw
+    match_med = pipe.matching_times_us(median=True) if use_orb else (0.0, 0.0)
     match_last = pipe.matching_times_us() if use_orb else (0.0, 0.0)
+    gather_us = pipe.gather_times_us() if (multi and backend == "rccl") else None
+    gathered = [valid_records(pipe.gathered(r), use_orb) for r in range(world)] if (multi and backend == "rccl" and rank == 0) else None
+    if gloo_gather is not None and rank == 0:
+        gathered = [valid_records(pipe.layout.unpack(b.numpy()), use_orb) for b in gloo_gather.blocks]
+
+    # ---- the stages ALONE on the GPU (outside the clock): each engine by itself on a stream of its own, three batches, median of its
+    # HIP events.  In the timed pipeline a stage's launch time is stretched by whatever else shares the chip -- two extractor batches,
+    # the detector and the matching are in flight together -- so the in-pipeline figure says how long the launch was resident, this
+    # one what it costs.  (Engines of a second pipeline object: the timed one may hold an RCCL communicator.)
     alone = {}
     if not multi and not skips:
         lay = pipe.layout
+        cap, mcap = pipe.cap, pipe.mcap
+        st = torch.cuda.Stream(dev)
+        sp = ctypes.c_void_p(st.cuda_stream)
+        scratch = torch.zeros(lay.nbytes, dtype=torch.uint8, device=dev)
+        base = scratch.data_ptr()
         torch.cuda.synchronize()
         if use_orb:
             ex0 = pipe.ex
             ex0.enable_kernel_timing(True)          # clears the history
             for _ in range(3):
-                ex0.extract_batch_device(d_batches[r_last].data_ptr(), B, rows * pitch, rows, cols, pitch, pipe.rec_ptr[cur] + lay.kps,
-                                         pipe.rec_ptr[cur] + lay.desc, pipe.cap, pipe.rec_ptr[cur] + lay.n, ctypes.c_void_p(pipe.stream.cuda_stream))
+                ex0.extract_batch_device(d_batches[r_last].data_ptr(), B, rows * pitch, rows, cols, pitch, base + lay.kps + cap * 28,
+                                         base + lay.desc + cap * 32, cap, base + lay.n + 4, sp)
                 torch.cuda.synchronize()
             t = ex0.kernel_times_us(median=True)
             alone.update({nm: float(v) for nm, v in zip(binding.ORBextractor.stage_names(len(t)), t)})
-            pipe.reset_timing_history()
+            outs = [torch.zeros((B, cap), dtype=torch.int32, device=dev) for _ in range(4)]
+            d_nm = torch.zeros(B, dtype=torch.int32, device=dev)
+            tk, ts = [], []
             for _ in range(3):
-                pipe.enqueue_matching(cur)
+                e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                e[0].record(st)
+                binding._check(L, L.orbfe_knn2_batch_device(base + lay.desc, base + lay.n, cap * 32, cap, base + lay.desc + cap * 32, base + lay.n + 4,
+                                                            cap * 32, cap, B, 256, outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), sp),
+                               "orbfe_knn2_batch_device")
+                e[1].record(st)
+                binding._check(L, L.orbfe_search_for_initialization_batch_device(base + lay.kps, base + lay.desc, base + lay.n, cap, B, cols, rows,
+                                                                                 None, 100, 0.9, 1, outs[3].data_ptr(), d_nm.data_ptr(), sp),
+                               "orbfe_search_for_initialization_batch_device")
+                e[2].record(st)
                 torch.cuda.synchronize()
-            alone["knn2"], alone["search_init"] = pipe.matching_times_us(median=True)
+                tk.append(e[0].elapsed_time(e[1]) * 1000.0); ts.append(e[1].elapsed_time(e[2]) * 1000.0)
+            alone["knn2"], alone["search_init"] = float(np.median(tk)), float(np.median(ts))
         if use_aruco:
             det0 = pipe.det
             det0.enable_kernel_timing(True)
             for _ in range(3):
-                det0.detect_batch_device(d_batches[r_last].data_ptr(), B, rows * pitch, rows, cols, pitch, pipe.rec_ptr[cur] + lay.mk,
-                                         pipe.mcap, pipe.rec_ptr[cur] + lay.nmk, ctypes.c_void_p(pipe.stream2.cuda_stream))
+                det0.detect_batch_device(d_batches[r_last].data_ptr(), B, rows * pitch, rows, cols, pitch, base + lay.mk, mcap, base + lay.nmk, sp)
                 torch.cuda.synchronize()
             t = det0.kernel_times_us(median=True)
             alone.update({"aruco_" + nm: float(v) for nm, v in zip(binding.MarkerDetector.STAGES, t)})
+        del scratch
 
-    # ---- multi-GPU: rank 0 checks every gathered block of the last step against that rank's own stream, recomputed here
+    # ---- multi-GPU: rank 0 checks every gathered block of the last step against that rank's own stream, recomputed here (on a second
+    # pipeline without a communicator)
     gather_check = None
-    if multi and rank == 0 and not os.environ.get("ORBFE_GATHER_NOOP") and not gather_off:
-        blocks = gather.blocks
-        lay = pipe.layout
+    if multi and rank == 0:
         checked = []
+        chk = None
         for r in range(world):
-            got = valid_records(lay.unpack(blocks[r].cpu().numpy()), use_orb)
+            got = gathered[r]
             if r == 0:
                 want = valid_records(rec, use_orb)
             else:
-                other = np.roll(make_stream(args, r), -shifts[r_last], axis=0)
-                d_other = pipe.upload(other)
-                pipe.gather = None
-                c2 = pipe.step(d_other)
-                pipe.synchronize()
-                want = valid_records(pipe.read_records(c2), use_orb)
+                chk = chk or mkpipe()
+                d_other = chk.upload(np.roll(make_stream(args, r), -shifts[r_last], axis=0))
+                want = valid_records(chk.read_records(chk.step(d_other)), use_orb)
                 del d_other
             assert got == want, "gathered records of rank %d differ from that rank's stream recomputed on rank 0" % r
             checked.append(r)
+        del chk
         gather_check = {"ranks": checked, "frames_per_rank": B, "what": "n, keypoints, descriptors, marker ids / corners / poses of "
-                        "every frame, byte for byte"}
+                        "every frame, byte for byte", "transport": "RCCL send / recv inside liborbfe (orbfe_pipeline_comm_init)" if backend == "rccl"
+                        else "gloo from the host (test hook)"}
 
     if rank == 0:
         stages = {nm: float(v) for nm, v in zip(binding.ORBextractor.stage_names(len(orb_us)), orb_us)}   # blur7 runs on a second stream
@@ -575,7 +587,12 @@ def main():
             for nm, v in zip(binding.MarkerDetector.STAGES, aruco_us_last):
                 stages_last["aruco_" + nm] = float(v)
         # algorithmic bytes per frame of each stage (DESIGN.md "roofline": the terms of SURVEY 8d's B_orb / B_aruco)
-        sizes = ex.level_sizes()
+        if pipe.ex is not None:
+            sizes = pipe.ex.level_sizes()
+        else:   # --no-orb: the level geometry from an extractor of its own (one frame through it)
+            ex_geo = binding.ORBextractor(args.nfeatures, 1.2, args.nlevels, 20, 7, device=local_rank)
+            ex_geo(last_frames[0])
+            sizes = ex_geo.level_sizes()
         P = [w * h for (w, h) in sizes]
         sumP, P0 = sum(P), P[0]
         N = float(rec["n"].mean()) if use_orb else 0.0
@@ -588,7 +605,7 @@ def main():
             alg.update(binding.MarkerDetector.algorithmic_bytes(rows, cols))
             alg["aruco_decode"] = Ncand * 2 * 35 * 35
             alg["aruco_finalize"] = Ncand * 36
-        fl = lambda k: B if k in ("knn2", "search_init") else pipe.bounds[1] - pipe.bounds[0]   # frames one launch covers
+        fl = lambda k: B                                        # frames (or frame pairs) one launch covers
         # counters are NOT measured in this run: they come from the committed rocprofv3 --pmc profile of this configuration
         # (tools/pmc.py + tools/make_profiles.py) and carry that profile's id; a custom size reports none
         pmc = load_profile("pmc_stage", args.config) if not (args.custom or args.reduced) else None
@@ -647,7 +664,7 @@ def main():
             b_aruco = (10.0 / 3.0) * rows * cols if use_aruco else 0.0
             b_match = (2 * N * 32 + N * 12) if use_orb else 0.0
             fused_bytes = (b_orb + b_aruco) * B
-            fused_bytes_m = fused_bytes + b_match * (B - 1)
+            fused_bytes_m = fused_bytes + b_match * B
             step_bytes = sum(alg.get(k, 0) * B for k in stages)
             mk = lambda nbytes: {"algorithmic_bytes_per_step": nbytes, "GBps": nbytes / step_s / 1e9,
                                  "frac": nbytes / step_s / 1e9 / HBM_PEAK_GBPS}
@@ -679,7 +696,8 @@ def main():
             pairs = sorted({0, B // 2, B - 2}) if B >= 2 else []
             verified = pipeline_check.check_against_oracle(O, last_frames, fids, rec, matches, args.nfeatures, args.nlevels,
                                                            args.dictionary, cols, rows, pipe.cam_K, pipe.cam_D,
-                                                           use_orb=use_orb, use_aruco=use_aruco, pairs=pairs)
+                                                           use_orb=use_orb, use_aruco=use_aruco, pairs=pairs,
+                                                           prev_last=prev_last if use_orb and args.steps + R > 1 else None)
         cpu = None
         if world == 1 and args.cpu_frames > 0 and not skips:
             cpu = cpu_baseline(args, frames_np)
@@ -701,10 +719,11 @@ def main():
                                       " + ArUco detect incl. IPPE marker poses" if use_aruco else " (ArUco leg DISABLED: diagnostic run)"),
                        "frames_per_step_per_gpu": B, "mean_keypoints_per_frame": N, "marker_records_per_frame": pipe.mcap,
                        "result_record_bytes_per_step_per_gpu": pipe.layout.nbytes, "resident_batches": R,
-                       "sub_batches": pipe.S, "engine_sets": pipe.D, "engine_phase_lock_stage": pipe.phase_pin if pipe.D > 1 else 0,
-                       "detector_pyramid_in_line": bool(getattr(pipe, "det_nofork", False)), "detector_phase_stage": getattr(pipe, "det_pin", 0), "aruco_big_frame_kernel": pipe.big_frames, "library": version,
+                       "engine_sets": pipe.D, "record_sets": pipe.R, "engine_phase_lock_stage": pipe.phase_pin, "matching_deferred_one_step": pipe.defer_post,
+                       "detector_pyramid_in_line": pipe.det_nofork, "detector_phase_stage": pipe.det_pin, "aruco_big_frame_kernel": pipe.big_frames,
+                       "host": "C++ (orbfe_pipeline_* in liborbfe.so); Python only marshals", "library": version,
                        "library_sha16": lib_sha16, "env": env_set, "env_nondefault": env_nondefault or None,
-                       "parallelism": "stream-per-gpu x%d, %s" % (world, ("%s gather to rank 0" % ("RCCL" if backend == "nccl" else backend))
+                       "parallelism": "stream-per-gpu x%d, %s" % (world, ("%s gather to rank 0" % ("RCCL" if backend == "rccl" else backend))
                                                                   if multi else "no collective (one rank)")},
             "roofline": roof, "cpu_baseline": cpu, "verified_frames": verified, "skips": skips or None,
             "stage_us": stages, "stage_us_last_step": stages_last, "host_enqueue_ms_per_step": 1000.0 * t_enq / args.steps,
@@ -713,7 +732,7 @@ def main():
             out["diagnostic_frames_per_s"] = total_frames / elapsed
         if gather_check:
             out["gather_check"] = gather_check
-            out["gather_us"] = pipe.gather_times_us()
+            out["gather_us"] = gather_us
         if c5:
             out["c5_match"] = c5
         line = json.dumps(out)

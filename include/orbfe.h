@@ -629,6 +629,96 @@ int orbfe_aruco_detect_poses_bgr(orbfe_aruco* h, const uint8_t* bgr, int rows, i
 int orbfe_corner_subpix(const uint8_t* img, int rows, int cols, size_t step, float* pts, int n, int win, int max_iters, double eps,
                         int device);
 
+/* ------------------------------------------------------------------ the batched-video mode -- */
+/* What the reference's Tracking thread does per frame -- ORBextractor::operator() (Frame.cc:200-206), MarkerDetector::detect(image,
+ * camera, 0.187) (Frame.cc:142), frame t matched against t-1 (Tracking.cc:531-532: all-pairs knn2 + SearchForInitialization) -- for
+ * a STREAM of same-sized frames handed over in batches resident on the device (BASELINE north_star).  The pipeline
+ * owns the engines (two extractor sets that alternate batches, phase-locked; one detector), its HIP streams and events, `record_sets`
+ * result sets in rotation, and -- on N > 1 ranks -- the batch's one collective: the gather of the record set to rank `dst` by RCCL
+ * send / recv on the pipeline's matching stream.  orbfe_pipeline_step only ENQUEUES (a few hundred microseconds of host time per
+ * 300-frame batch) and returns the record set the batch is written to; a batch's matching (and gather) is enqueued one step late
+ * where that shortens the step (frames up to 640 x 480), so call orbfe_pipeline_flush before waiting for the newest batch.
+ *
+ * A record set is ONE contiguous device buffer (orbfe_record_layout), array by array over the frames; the keypoint arrays carry one
+ * slot in front of the batch (`halo` = 1): the last frame of the previous batch, so that the first frame of a batch is matched
+ * against its predecessor in the stream too.  Frame f of the batch is slot f + halo.  Matching outputs of the newest batch: pair p
+ * = slot p (queries, F1) against slot p + 1 (train, F2), p = 0 .. frames - 1; pair 0 is the pair across the batch boundary (no
+ * keypoints on the F1 side for the first batch of a stream). */
+typedef struct orbfe_pipeline orbfe_pipeline;
+typedef struct orbfe_pipeline_config {
+    int32_t frames, rows, cols;        /* frames per batch; frame size */
+    int32_t nfeatures, nlevels;        /* ORBextractor(nfeatures, scale_factor, nlevels, ini_th_fast, min_th_fast) */
+    float scale_factor;
+    int32_t ini_th_fast, min_th_fast;
+    char dictionary[32];               /* MarkerDetector::setDictionary */
+    int32_t device;
+    int32_t marker_capacity;           /* marker (+ pose) records per frame in a record set (<= orbfe_aruco_max_markers) */
+    int32_t use_orb, use_aruco;        /* 0 leaves an engine out (diagnostics) */
+    float marker_size;                 /* metres (Frame.cc:131: 0.187) */
+    float K[4], dist[12];              /* camera of the marker poses FOR THIS FRAME SIZE (orbfe_camera_resize), ndist coefficients */
+    int32_t ndist;
+    int32_t window_size;               /* SearchForInitialization: 100 */
+    float nnratio;                     /* 0.9 */
+    int32_t check_orientation;         /* 1 */
+    /* scheduling; -1 = the measured default for the frame size: extractor engine sets, result sets in rotation,
+     * phase lock of the engine sets (orbfe_extractor_follow stage), stage of the extractor's previous batch the detector's batch starts
+     * behind, matching enqueued one step late, the detector's /2 pyramid in line on its stream */
+    int32_t engine_sets, record_sets, phase_pin, det_pin, defer_post, det_nofork;
+} orbfe_pipeline_config;
+typedef struct orbfe_record_layout {
+    int32_t frames, capacity, marker_capacity, halo;
+    uint64_t off_kps, off_desc, off_n;                 /* (frames + halo) x capacity x 28 B | x 32 B | (frames + halo) x int32 */
+    uint64_t off_markers, off_nmarkers, off_poses;     /* frames x marker_capacity x 36 B | frames x int32 | frames x marker_capacity x 56 B */
+    uint64_t nbytes;
+} orbfe_record_layout;
+
+/* the defaults of BASELINE configs[1]: nfeatures 1000, 8 levels, 1.2, FAST 20 / 7, "ARUCO", 64 marker records, both engines, marker
+ * size 0.187, TUM1 camera (Examples/Monocular/TUM1.yaml) rescaled from 1280 x 720 (Frame.cc:132), window 100, ratio 0.9; scheduling -1 */
+int orbfe_pipeline_config_default(orbfe_pipeline_config* cfg, int frames, int rows, int cols);
+orbfe_pipeline* orbfe_pipeline_create(const orbfe_pipeline_config* cfg);
+void orbfe_pipeline_destroy(orbfe_pipeline* p);
+int orbfe_pipeline_layout(const orbfe_pipeline* p, orbfe_record_layout* out);
+/* One batch: d_imgs = frames x rows x pitch bytes on the pipeline's device (pitch >= cols; frames only have to stay valid until the
+ * step's engines are done -- orbfe_pipeline_input_done).  *record_set = index of the set the batch is written to. */
+int orbfe_pipeline_step(orbfe_pipeline* p, const uint8_t* d_imgs, size_t pitch, int32_t* record_set);
+int orbfe_pipeline_flush(orbfe_pipeline* p);                 /* enqueue the held-back post-work (matching, gather) of the newest batch */
+int orbfe_pipeline_synchronize(orbfe_pipeline* p);           /* flush + wait for everything enqueued */
+/* flush + wait until the engines of the batch written to `record_set` have read their frames (the input buffer may be reused) */
+int orbfe_pipeline_input_done(orbfe_pipeline* p, int record_set);
+/* capacity flags since the last call (synchronises): out[0] extractor overflow, [1] SearchForInitialization pool overflow (the pool
+ * has been grown: repeat), [2] frames the detector flagged, [3] the union of their flags.  All zero = results complete. */
+int orbfe_pipeline_status(orbfe_pipeline* p, int32_t out[4]);
+int orbfe_pipeline_set_big_frames(orbfe_pipeline* p, int on); /* orbfe_aruco_set_big_frames on the pipeline's detector */
+/* device pointers: record set `set`; the matching outputs of the newest batch ([frames][capacity] each, nmatches [frames]) */
+int orbfe_pipeline_records(orbfe_pipeline* p, int set, uint8_t** d_records);
+int orbfe_pipeline_matches(orbfe_pipeline* p, int32_t** d_best_idx, int32_t** d_best_dist, int32_t** d_second_dist, int32_t** d_matches12,
+                           int32_t** d_nmatches);
+/* a new stream: the next batch has no predecessor (the halo slots are emptied) */
+int orbfe_pipeline_reset_stream(orbfe_pipeline* p);
+/* the engines (for their debug entry points / kernel timers): extractor of engine set `set` (NULL past the last), the detector */
+orbfe_extractor* orbfe_pipeline_extractor(orbfe_pipeline* p, int set);
+orbfe_aruco* orbfe_pipeline_detector(orbfe_pipeline* p);
+int orbfe_pipeline_engine_sets(const orbfe_pipeline* p, int32_t* engine_sets, int32_t* record_sets, int32_t* phase_pin, int32_t* det_pin,
+                               int32_t* defer_post, int32_t* det_nofork);
+/* launch timing of the matching / gather (HIP events on the matching stream; off by default).  timing_us: medians over the steps
+ * since timing was switched on (the newest 64): out[0] knn2, [1] SearchForInitialization, [2] gather (0 without one); last != 0: the
+ * newest step's instead.  Synchronises. */
+int orbfe_pipeline_enable_timing(orbfe_pipeline* p, int on);
+int orbfe_pipeline_timing_us(orbfe_pipeline* p, int last, float out[3]);
+/* The ORBFE_* environment variables the pipeline and the engines read, with their defaults, as "NAME=default;NAME=default;..."
+ * ("size" = decided by the frame size): what bench.py checks the environment against. */
+const char* orbfe_pipeline_env_defaults(void);
+
+/* Multi-GPU (one process per GPU): the batch's gather over RCCL (librccl is opened at run time; ORBFE_ERR_HIP when it is missing).
+ * Either hand over a communicator the application owns (set_comm; ncclComm_t as void*), or let the pipeline create one:
+ * comm_unique_id on one rank (ncclGetUniqueId, 128 bytes), the bytes sent to all ranks by the application's own means, then
+ * comm_init on every rank (ncclCommInitRank).  From then on every batch's record set is gathered to rank `dst` behind the batch's
+ * matching: `dst` receives block r of rank r (its own too) in buffers allocated once; orbfe_pipeline_gathered returns block r of the
+ * newest gather on dst.  world == 1 runs the same branch with a send / recv to itself. */
+int orbfe_pipeline_comm_unique_id(uint8_t id[128]);
+int orbfe_pipeline_comm_init(orbfe_pipeline* p, const uint8_t id[128], int rank, int world, int dst);
+int orbfe_pipeline_set_comm(orbfe_pipeline* p, void* nccl_comm, int rank, int world, int dst);
+int orbfe_pipeline_gathered(orbfe_pipeline* p, int rank, uint8_t** d_block);
 
 #ifdef __cplusplus
 }

@@ -46,6 +46,12 @@ SYMBOLS = [
     "orbfe_search_by_projection_batch_status", "orbfe_release_stream_scratch", "orbfe_search_by_projection_last_frame", "orbfe_search_by_projection_best", "orbfe_search_by_projection_keyframe", "orbfe_fuse_search", "orbfe_fuse_search_batch_device", "orbfe_project_map_points", "orbfe_search_by_sim3", "orbfe_search_by_projection_sim3",
     "orbfe_keyframe_features_pack", "orbfe_keyframe_features_unpack", "orbfe_keyframe_features_pack_device",
     "orbfe_keyframe_features_unpack_device",
+    # the batched-video mode (csrc/pipeline.hip; ctypes prototypes in pipeline.py)
+    "orbfe_pipeline_config_default", "orbfe_pipeline_create", "orbfe_pipeline_destroy", "orbfe_pipeline_layout", "orbfe_pipeline_step",
+    "orbfe_pipeline_flush", "orbfe_pipeline_synchronize", "orbfe_pipeline_input_done", "orbfe_pipeline_status", "orbfe_pipeline_set_big_frames",
+    "orbfe_pipeline_records", "orbfe_pipeline_matches", "orbfe_pipeline_reset_stream", "orbfe_pipeline_extractor", "orbfe_pipeline_detector",
+    "orbfe_pipeline_engine_sets", "orbfe_pipeline_enable_timing", "orbfe_pipeline_timing_us", "orbfe_pipeline_env_defaults",
+    "orbfe_pipeline_comm_unique_id", "orbfe_pipeline_comm_init", "orbfe_pipeline_set_comm", "orbfe_pipeline_gathered",
 ]
 
 _lib = None
@@ -198,10 +204,21 @@ class ORBextractor:
             raise OrbfeError("orbfe_extractor_create: " + self.L.orbfe_last_error().decode())
         self.capacity = self.L.orbfe_extractor_max_keypoints(self.h)
 
+    @classmethod
+    def wrap(cls, handle, nlevels):
+        """A non-owning view of an extractor another object owns (the engines of an orbfe_pipeline)."""
+        self = cls.__new__(cls)
+        self.L = load()
+        self.nlevels = nlevels
+        self.h = handle
+        self._borrowed = True
+        self.capacity = self.L.orbfe_extractor_max_keypoints(self.h)
+        return self
+
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and not getattr(self, "_borrowed", False):
             self.L.orbfe_extractor_destroy(self.h)
-            self.h = None
+        self.h = None
 
     # reference getters (ORBextractor.h:63-83)
     def GetLevels(self):
@@ -788,10 +805,21 @@ class MarkerDetector:
         self.capacity = self.L.orbfe_aruco_max_markers(self.h)
         self._shape = None
 
+    @classmethod
+    def wrap(cls, handle):
+        """A non-owning view of a detector another object owns (the detector of an orbfe_pipeline)."""
+        self = cls.__new__(cls)
+        self.L = load()
+        self.h = handle
+        self._borrowed = True
+        self.capacity = self.L.orbfe_aruco_max_markers(self.h)
+        self._shape = None
+        return self
+
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and not getattr(self, "_borrowed", False):
             self.L.orbfe_aruco_destroy(self.h)
-            self.h = None
+        self.h = None
 
     DM_NORMAL, DM_FAST, DM_VIDEO_FAST = 0, 1, 2              # aruco::DetectionMode (markerdetector.h:60)
     CORNER_SUBPIX, CORNER_LINES, CORNER_NONE = 0, 1, 2       # aruco::CornerRefinementMethod (:62)

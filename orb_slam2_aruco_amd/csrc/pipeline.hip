@@ -1,0 +1,572 @@
+// pipeline.hip -- host side of the batched-video mode (orbfe_pipeline_*, include/orbfe.h): the schedule of one stream of frames on
+// one GPU, and the batch's gather over RCCL.
+//
+// Reference call sites this stands for: Frame::Frame (src/Frame.cc:91 -> :200-206 ORBextractor::operator(), :142
+// MarkerDetector::detect with poses) once per frame, and Tracking's frame-to-frame matching (src/Tracking.cc:531-532).  Here a batch
+// of B frames resident in HBM goes through the library's device-pointer entry points on HIP streams the pipeline owns:
+//
+//   extractor set d (batch i % D):  orbfe_extract_batch_device                                   stream ex[d]   (its blur lent st_match)
+//   detector:                       orbfe_aruco_detect_batch_device + orbfe_marker_poses_...     stream st_det
+//   matching of batch i - 1 (or i): orbfe_knn2_batch_device + orbfe_search_for_initialization_batch_device, then the gather of the
+//                                   record set (ncclSend / ncclRecv), then the halo for the next batch       stream st_match
+//
+// What the measurements of rounds 2 - 3 settled is encoded as defaults: two extractor engine sets alternating
+// batches, phase-locked behind each other's quadtree; the detector's batch behind the resize chain of the extractor's previous batch;
+// four record sets in rotation; a batch's matching enqueued one step late (frames up to 640 x 480); the detector's /2 pyramid in
+// line (the same); the gather on the matching stream (a fifth active stream costs 9 % of the step by itself).
+#include <dlfcn.h>
+
+#include <cstdlib>
+#include <memory>
+#include <mutex>
+
+#include "orbfe_common.hpp"
+
+using namespace orbfe;
+
+namespace {
+
+// ---- RCCL, opened at run time (the library has no link-time dependency on it; a process that already holds a copy -- PyTorch's --
+// gets that one)
+struct Id128 { char internal[128]; }; // ncclUniqueId
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(Id128*) = nullptr;
+    int (*CommInitRank)(void**, int, Id128, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+
+Rccl* rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = {"librccl.so.1", "librccl.so"};
+        for (const char* n : names)
+            if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+        for (const char* n : names)
+            if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (!r.lib) return;
+        auto sym = [&](const char* n) { return dlsym(r.lib, n); };
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+        r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
+        r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+        if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.GroupStart || !r.GroupEnd || !r.Send || !r.Recv) r.lib = nullptr;
+    });
+    return r.lib ? &r : nullptr;
+}
+#define ORBFE_NCCL(call)                                                                                                             \
+    do {                                                                                                                             \
+        const int e_ = (call);                                                                                                       \
+        if (e_ != 0) return fail(ORBFE_ERR_HIP, "%s failed: %s", #call, R->GetErrorString ? R->GetErrorString(e_) : "RCCL error");   \
+    } while (0)
+constexpr int NCCL_UINT8 = 1; // ncclUint8 (rccl.h: ncclInt8 = 0, ncclUint8 = 1)
+
+size_t up256(size_t v) { return (v + 255) / 256 * 256; }
+int env_or(const char* name, int v) { const char* e = getenv(name); return e && *e ? atoi(e) : v; }
+
+// the last frame of one record set -> the halo slot of another (keypoints, descriptors, count), one launch
+__global__ void k_copy_halo(const uint32_t* __restrict__ src_kps, uint32_t* __restrict__ dst_kps, const uint32_t* __restrict__ src_desc,
+                            uint32_t* __restrict__ dst_desc, const int32_t* __restrict__ src_n, int32_t* __restrict__ dst_n, int cap)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *dst_n = *src_n;
+    if (i < cap * 7) dst_kps[i] = src_kps[i];
+    if (i < cap * 8) dst_desc[i] = src_desc[i];
+}
+
+} // namespace
+
+struct orbfe_pipeline {
+    orbfe_pipeline_config cfg{};
+    int B = 0, rows = 0, cols = 0, cap = 0, mcap = 0, R = 0, D = 0;
+    int phase_pin = 0, det_pin = 0;
+    bool defer_post = false, det_nofork = false, use_orb = true, use_aruco = true;
+    std::vector<orbfe_extractor*> ex;
+    orbfe_aruco* det = nullptr;
+    std::vector<hipStream_t> st_ex;
+    hipStream_t st_det = nullptr, st_match = nullptr;
+    orbfe_record_layout lay{};
+    std::vector<uint8_t*> recs;
+    int32_t *d_bidx = nullptr, *d_bdist = nullptr, *d_sdist = nullptr, *d_m12 = nullptr, *d_nm = nullptr;
+    std::vector<hipEvent_t> ex_done, det_done, match_done, gather_done;
+    bool timing = false;
+    static constexpr int HIST = 64;
+    hipEvent_t match_ev[HIST][3] = {}, gather_ev[HIST][2] = {};
+    long match_steps = 0, gather_steps = 0;
+    long step_no = 0;
+    int pending = -1;
+    // gather
+    void* comm = nullptr;
+    bool own_comm = false;
+    int rank = 0, world = 0, dst = 0;
+    uint8_t* blocks = nullptr; // on dst: world x lay.nbytes
+
+    ~orbfe_pipeline()
+    {
+        (void)hipSetDevice(cfg.device);
+        (void)hipDeviceSynchronize();
+        if (own_comm && comm) { if (Rccl* R_ = rccl()) (void)R_->CommDestroy(comm); }
+        for (auto e : ex) if (e) orbfe_extractor_destroy(e);
+        if (det) orbfe_aruco_destroy(det);
+        for (auto r : recs) if (r) (void)hipFree(r);
+        for (void* p : {(void*)d_bidx, (void*)d_bdist, (void*)d_sdist, (void*)d_m12, (void*)d_nm, (void*)blocks}) if (p) (void)hipFree(p);
+        for (auto* v : {&ex_done, &det_done, &match_done, &gather_done}) for (auto e : *v) if (e) (void)hipEventDestroy(e);
+        for (auto& t : match_ev) for (auto e : t) if (e) (void)hipEventDestroy(e);
+        for (auto& t : gather_ev) for (auto e : t) if (e) (void)hipEventDestroy(e);
+        for (auto s : st_ex) if (s) (void)hipStreamDestroy(s);
+        if (st_det) (void)hipStreamDestroy(st_det);
+        if (st_match) (void)hipStreamDestroy(st_match);
+    }
+
+    uint8_t* slot_kps(int set, int slot) const { return recs[set] + lay.off_kps + (size_t)slot * cap * sizeof(orbfe_keypoint); }
+    uint8_t* slot_desc(int set, int slot) const { return recs[set] + lay.off_desc + (size_t)slot * cap * 32; }
+    int32_t* slot_n(int set, int slot) const { return reinterpret_cast<int32_t*>(recs[set] + lay.off_n) + slot; }
+
+    int enqueue_matching(int cur)
+    {
+        hipEvent_t* e = timing ? match_ev[match_steps % HIST] : nullptr;
+        if (timing) {
+            for (int k = 0; k < 3; k++) if (!e[k]) ORBFE_HIP(hipEventCreate(&e[k]));
+            match_steps++;
+            ORBFE_HIP(hipEventRecord(e[0], st_match));
+        }
+        int rc;
+        // pair p = slot p (F1: the halo for p = 0) against slot p + 1 (F2), B pairs
+        if ((rc = orbfe_knn2_batch_device(slot_desc(cur, 0), slot_n(cur, 0), (size_t)cap * 32, cap, slot_desc(cur, 1), slot_n(cur, 1), (size_t)cap * 32, cap,
+                                          B, 256, d_bidx, d_bdist, d_sdist, st_match)))
+            return rc;
+        if (timing) ORBFE_HIP(hipEventRecord(e[1], st_match));
+        if ((rc = orbfe_search_for_initialization_batch_device(reinterpret_cast<const orbfe_keypoint*>(slot_kps(cur, 0)), slot_desc(cur, 0), slot_n(cur, 0), cap, B,
+                                                               cols, rows, nullptr, cfg.window_size, cfg.nnratio, cfg.check_orientation, d_m12, d_nm, st_match)))
+            return rc;
+        if (timing) ORBFE_HIP(hipEventRecord(e[2], st_match));
+        return ORBFE_OK;
+    }
+
+    int enqueue_gather(int cur)
+    {
+        Rccl* R = rccl();
+        if (!R) return fail(ORBFE_ERR_HIP, "librccl is not available");
+        hipEvent_t* e = timing ? gather_ev[gather_steps % HIST] : nullptr;
+        if (timing) {
+            for (int k = 0; k < 2; k++) if (!e[k]) ORBFE_HIP(hipEventCreate(&e[k]));
+            gather_steps++;
+            ORBFE_HIP(hipEventRecord(e[0], st_match));
+        }
+        const size_t nb = (size_t)lay.nbytes;
+        ORBFE_NCCL(R->GroupStart());
+        if (rank == dst) {
+            for (int r = 0; r < world; r++) {
+                if (r == rank && world > 1) continue;
+                ORBFE_NCCL(R->Recv(blocks + (size_t)r * nb, nb, NCCL_UINT8, r, comm, st_match));
+            }
+            if (world == 1) ORBFE_NCCL(R->Send(recs[cur], nb, NCCL_UINT8, dst, comm, st_match)); // the one-GPU box: the same kernels, to itself
+        } else
+            ORBFE_NCCL(R->Send(recs[cur], nb, NCCL_UINT8, dst, comm, st_match));
+        ORBFE_NCCL(R->GroupEnd());
+        if (rank == dst && world > 1) ORBFE_HIP(hipMemcpyAsync(blocks + (size_t)rank * nb, recs[cur], nb, hipMemcpyDeviceToDevice, st_match));
+        if (timing) ORBFE_HIP(hipEventRecord(e[1], st_match));
+        ORBFE_HIP(hipEventRecord(gather_done[cur], st_match));
+        return ORBFE_OK;
+    }
+
+    // what follows a batch's engines: its matching, its gather, and the halo of the next record set
+    int enqueue_post(int cur)
+    {
+        int rc;
+        if (use_orb) {
+            ORBFE_HIP(hipStreamWaitEvent(st_match, ex_done[cur], 0));
+            if ((rc = enqueue_matching(cur))) return rc;
+        }
+        if (comm) {
+            if (use_aruco) ORBFE_HIP(hipStreamWaitEvent(st_match, det_done[cur], 0));
+            if ((rc = enqueue_gather(cur))) return rc;
+        }
+        if (use_orb) {
+            // the stream goes on: the batch's last frame becomes the halo of the set the NEXT batch is written to (that set's halo was
+            // last read by the matching of R batches ago, earlier on this stream).  Only then may this set be written again.
+            const int nxt = (cur + 1) % R;
+            hipLaunchKernelGGL(k_copy_halo, dim3((cap * 8 + 255) / 256), dim3(256), 0, st_match, reinterpret_cast<const uint32_t*>(slot_kps(cur, B)),
+                               reinterpret_cast<uint32_t*>(slot_kps(nxt, 0)), reinterpret_cast<const uint32_t*>(slot_desc(cur, B)),
+                               reinterpret_cast<uint32_t*>(slot_desc(nxt, 0)), slot_n(cur, B), slot_n(nxt, 0), cap);
+            ORBFE_HIP(hipEventRecord(match_done[cur], st_match));
+        }
+        return ORBFE_OK;
+    }
+};
+
+const char* orbfe_pipeline_env_defaults(void)
+{
+    // one list for the pipeline and the engines: bench.py marks a line as diagnostic when one of these is set to something else
+    return "ORBFE_ENGINE_SETS=size;ORBFE_RECORD_SETS=4;ORBFE_PHASE_PIN=2;ORBFE_DET_PIN=4;ORBFE_DEFER_POST=size;ORBFE_DET_NOFORK=size;"
+           "ORBFE_ORIENT_PAIR=1;ORBFE_FAST0=0;ORBFE_ARUCO_VIS=0;ORBFE_ARUCO_FORCE_GLOBAL=0;ORBFE_ARUCO_RELAY_CHUNK=0;ORBFE_ARUCO_RELAY_WIDE=1;"
+           "ORBFE_ARUCO_SMALL_SEPARATE=size;ORBFE_ARUCO_TILED=size;ORBFE_ARUCO_TILE_W=0;ORBFE_ARUCO_TPW=0;ORBFE_GRAPH=0;"
+           "ORBFE_OCC_FAST=0;ORBFE_OCC_BLUR=0;ORBFE_OCC_ORIENT=0;ORBFE_BLUR_PLACE=1";
+}
+
+int orbfe_pipeline_config_default(orbfe_pipeline_config* c, int frames, int rows, int cols)
+{
+    if (!c || frames < 1 || rows < 1 || cols < 1) return fail(ORBFE_ERR_INVALID, "orbfe_pipeline_config_default: invalid argument");
+    memset(c, 0, sizeof(*c));
+    c->frames = frames; c->rows = rows; c->cols = cols;
+    c->nfeatures = 1000; c->nlevels = 8; c->scale_factor = 1.2f; c->ini_th_fast = 20; c->min_th_fast = 7;
+    snprintf(c->dictionary, sizeof(c->dictionary), "ARUCO");
+    c->device = 0; c->marker_capacity = 64; c->use_orb = 1; c->use_aruco = 1;
+    c->marker_size = 0.187f; // Frame.cc:131
+    const float tum1[4] = {517.306408f, 516.469215f, 318.643040f, 255.313989f}; // Examples/Monocular/TUM1.yaml
+    const float d5[5] = {0.262383f, -0.953104f, -0.005358f, 0.002628f, 1.163314f};
+    orbfe_camera_resize(tum1, 1280, 720, cols, rows, c->K); // the detector is handed CamSize 1280 x 720 (Frame.cc:132)
+    for (int i = 0; i < 5; i++) c->dist[i] = d5[i];
+    c->ndist = 5;
+    c->window_size = 100; c->nnratio = 0.9f; c->check_orientation = 1;
+    c->engine_sets = c->record_sets = c->phase_pin = c->det_pin = c->defer_post = c->det_nofork = -1;
+    return ORBFE_OK;
+}
+
+orbfe_pipeline* orbfe_pipeline_create(const orbfe_pipeline_config* cfg)
+{
+    if (!cfg || cfg->frames < 1 || cfg->rows < 1 || cfg->cols < 1 || (!cfg->use_orb && !cfg->use_aruco)) {
+        fail(ORBFE_ERR_INVALID, "orbfe_pipeline_create: invalid configuration");
+        return nullptr;
+    }
+    if (use_device(cfg->device)) return nullptr;
+    std::unique_ptr<orbfe_pipeline> p(new orbfe_pipeline());
+    p->cfg = *cfg;
+    p->cfg.dictionary[sizeof(p->cfg.dictionary) - 1] = 0;
+    const int B = p->B = cfg->frames, rows = p->rows = cfg->rows, cols = p->cols = cfg->cols;
+    p->use_orb = cfg->use_orb != 0; p->use_aruco = cfg->use_aruco != 0;
+    const bool vga = (size_t)rows * cols <= (size_t)640 * 480;
+    // defaults by frame size, each overridable by the configuration and, for measurements, by the environment
+    auto pick = [&](int cfgv, const char* env, int dflt) { return env_or(env, cfgv >= 0 ? cfgv : dflt); };
+    // two extractor sets up to 1280 x 720 (1.4955 against 1.5288 ms per C2 step; 1920 x 1080 loses: 4.84 -> 5.00)
+    p->D = std::max(1, pick(cfg->engine_sets, "ORBFE_ENGINE_SETS", (size_t)rows * cols <= (size_t)1280 * 720 ? 2 : 1));
+    if (!p->use_orb) p->D = 1;
+    p->R = std::max(2, pick(cfg->record_sets, "ORBFE_RECORD_SETS", 4));
+    p->phase_pin = pick(cfg->phase_pin, "ORBFE_PHASE_PIN", 2);
+    p->det_pin = pick(cfg->det_pin, "ORBFE_DET_PIN", 4);
+    p->defer_post = pick(cfg->defer_post, "ORBFE_DEFER_POST", vga ? 1 : 0) != 0;
+    p->det_nofork = pick(cfg->det_nofork, "ORBFE_DET_NOFORK", vga ? 1 : 0) != 0;
+    auto bail = [&](const char* what) -> orbfe_pipeline* {
+        if (what) { std::string m = g_err; fail(ORBFE_ERR_HIP, "orbfe_pipeline_create: %s (%s)", what, m.c_str()); }
+        return nullptr;
+    };
+    auto mkstream = [&](hipStream_t* s) { return hipStreamCreateWithFlags(s, hipStreamNonBlocking) == hipSuccess; };
+    if (!mkstream(&p->st_det) || !mkstream(&p->st_match)) return bail("stream");
+    p->st_ex.assign((size_t)p->D, nullptr);
+    for (auto& s : p->st_ex) if (!mkstream(&s)) return bail("stream");
+    if (p->use_orb) {
+        for (int d = 0; d < p->D; d++) {
+            orbfe_extractor* e = orbfe_extractor_create(cfg->nfeatures, cfg->scale_factor, cfg->nlevels, cfg->ini_th_fast, cfg->min_th_fast, cfg->device);
+            if (!e) return nullptr;
+            p->ex.push_back(e);
+            // every set's blur on the matching stream (1.4466 against 1.4873 ms with the handles' own fork streams, which share hardware
+            // queues with the busy ones)
+            if (!env_or("ORBFE_NO_LEND", 0)) orbfe_extractor_set_aux_stream(e, p->st_match);
+        }
+        if (p->phase_pin && p->D > 1)
+            for (int d = 0; d < p->D; d++) orbfe_extractor_follow(p->ex[d], p->ex[(d + p->D - 1) % p->D], p->phase_pin);
+        if (getenv("ORBFE_BLUR_PLACE"))
+            for (auto e : p->ex) orbfe_extractor_debug_kernel_times(e, nullptr, 20 + atoi(getenv("ORBFE_BLUR_PLACE")));
+        p->cap = orbfe_extractor_max_keypoints(p->ex[0]);
+    } else
+        p->cap = 1;
+    if (p->use_aruco) {
+        p->det = orbfe_aruco_create(p->cfg.dictionary, cfg->device);
+        if (!p->det) return nullptr;
+        p->mcap = std::min(orbfe_aruco_max_markers(p->det), std::max(1, cfg->marker_capacity));
+        if (p->det_nofork) orbfe_aruco_set_aux_stream(p->det, p->st_det);
+    }
+    orbfe_record_layout& L = p->lay;
+    L.frames = B; L.capacity = p->cap; L.marker_capacity = p->mcap; L.halo = 1;
+    L.off_kps = 0;
+    L.off_desc = up256((size_t)(B + 1) * p->cap * sizeof(orbfe_keypoint));
+    L.off_n = L.off_desc + up256((size_t)(B + 1) * p->cap * 32);
+    L.off_markers = L.off_n + up256((size_t)(B + 1) * 4);
+    L.off_nmarkers = L.off_markers + up256((size_t)B * p->mcap * sizeof(orbfe_marker));
+    L.off_poses = L.off_nmarkers + up256((size_t)B * 4);
+    L.nbytes = L.off_poses + up256((size_t)B * p->mcap * sizeof(orbfe_marker_pose));
+    p->recs.assign((size_t)p->R, nullptr);
+    for (auto& r : p->recs) {
+        if (hipMalloc(&r, L.nbytes) != hipSuccess || hipMemset(r, 0, L.nbytes) != hipSuccess) return bail("record sets");
+    }
+    const size_t mb = (size_t)B * p->cap * 4;
+    if (hipMalloc(&p->d_bidx, mb) != hipSuccess || hipMalloc(&p->d_bdist, mb) != hipSuccess || hipMalloc(&p->d_sdist, mb) != hipSuccess ||
+        hipMalloc(&p->d_m12, mb) != hipSuccess || hipMalloc(&p->d_nm, (size_t)B * 4) != hipSuccess)
+        return bail("matching outputs");
+    (void)hipMemset(p->d_bidx, 0, mb); (void)hipMemset(p->d_bdist, 0, mb); (void)hipMemset(p->d_sdist, 0, mb); (void)hipMemset(p->d_m12, 0, mb);
+    (void)hipMemset(p->d_nm, 0, (size_t)B * 4);
+    for (auto* v : {&p->ex_done, &p->det_done, &p->match_done, &p->gather_done}) {
+        v->assign((size_t)p->R, nullptr);
+        for (auto& e : *v) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return bail("events");
+    }
+    if (hipDeviceSynchronize() != hipSuccess) return bail("synchronize");
+    return p.release();
+}
+
+void orbfe_pipeline_destroy(orbfe_pipeline* p) { delete p; }
+
+int orbfe_pipeline_layout(const orbfe_pipeline* p, orbfe_record_layout* out)
+{
+    if (!p || !out) return fail(ORBFE_ERR_INVALID, "orbfe_pipeline_layout: null argument");
+    *out = p->lay;
+    return ORBFE_OK;
+}
+
+int orbfe_pipeline_step(orbfe_pipeline* p, const uint8_t* d_imgs, size_t pitch, int32_t* record_set)
+{
+    if (!p || !d_imgs || pitch < (size_t)p->cols) return fail(ORBFE_ERR_INVALID, "orbfe_pipeline_step: invalid argument");
+    int rc = use_device(p->cfg.device);
+    if (rc) return rc;
+    const long i = p->step_no++;
+    const int cur = (int)(i % p->R), eset = (int)(i % p->D), B = p->B, rows = p->rows, cols = p->cols;
+    const size_t fstride = (size_t)rows * pitch;
+    uint8_t* base = p->recs[cur];
+    if (record_set) *record_set = cur;
+    auto enqueue_detector = [&]() -> int {
+        if (!p->use_aruco) return ORBFE_OK;
+        // the detector only depends on the resident frames and on its own previous batch: it is not joined with the extractor per step
+        if (p->comm && i >= p->R) ORBFE_HIP(hipStreamWaitEvent(p->st_det, p->gather_done[cur], 0)); // batch i - R has left this record set
+        if (p->det_pin && p->use_orb) {
+            const long j = p->det_pin >= 10 ? i : i - 1; // + 10: a stage of THIS batch's extractor, which is then enqueued first
+            if (j >= 0 && (rc = orbfe_extractor_stage_wait(p->ex[(size_t)(j % p->D)], p->det_pin % 10, p->st_det))) return rc;
+        }
+        orbfe_marker* mk = reinterpret_cast<orbfe_marker*>(base + p->lay.off_markers);
+        int32_t* nmk = reinterpret_cast<int32_t*>(base + p->lay.off_nmarkers);
+        if ((rc = orbfe_aruco_detect_batch_device(p->det, d_imgs, B, fstride, rows, cols, pitch, mk, p->mcap, nmk, p->st_det))) return rc;
+        // detect(image, CameraParameters, 0.187): every marker gets its IPPE pose (markerdetector_impl.cpp:8720-8780)
+        if ((rc = orbfe_marker_poses_batch_device(mk, nmk, p->mcap, B, p->cfg.marker_size, p->cfg.K, p->cfg.dist, p->cfg.ndist,
+                                                  reinterpret_cast<orbfe_marker_pose*>(base + p->lay.off_poses), p->st_det)))
+            return rc;
+        ORBFE_HIP(hipEventRecord(p->det_done[cur], p->st_det));
+        return ORBFE_OK;
+    };
+    auto enqueue_extractor = [&]() -> int {
+        if (!p->use_orb) return ORBFE_OK;
+        hipStream_t st = p->st_ex[(size_t)eset];
+        if (i >= p->R) {
+            ORBFE_HIP(hipStreamWaitEvent(st, p->match_done[cur], 0)); // the matching of batch i - R has read this record set
+            if (p->comm) ORBFE_HIP(hipStreamWaitEvent(st, p->gather_done[cur], 0));
+        }
+        if ((rc = orbfe_extract_batch_device(p->ex[(size_t)eset], d_imgs, B, fstride, rows, cols, pitch, reinterpret_cast<orbfe_keypoint*>(p->slot_kps(cur, 1)),
+                                             p->slot_desc(cur, 1), p->cap, p->slot_n(cur, 1), st)))
+            return rc;
+        ORBFE_HIP(hipEventRecord(p->ex_done[cur], st));
+        return ORBFE_OK;
+    };
+    if (p->det_pin >= 10) { if ((rc = enqueue_extractor()) || (rc = enqueue_detector())) return rc; }
+    else if ((rc = enqueue_detector()) || (rc = enqueue_extractor())) return rc;
+    // What follows a batch's engines goes onto the matching stream, which also carries the extractors' blur (lent).  Enqueued right
+    // away, the matching of batch i (which waits for the whole extractor chain of batch i) would sit IN FRONT of the blur of batch
+    // i + 1 on that stream, and the descriptors of batch i + 1 wait for that blur.  So the post-work of batch i is enqueued one step
+    // late, behind the blur of batch i + 1 (C2 1.4924 -> 1.4759 ms; 1280 x 720 loses 1.5 %: off there).
+    if (p->defer_post) {
+        if (p->pending >= 0 && (rc = p->enqueue_post(p->pending))) return rc;
+        p->pending = cur;
+    } else if ((rc = p->enqueue_post(cur)))
+        return rc;
+    return ORBFE_OK;
+}
+
+int orbfe_pipeline_flush(orbfe_pipeline* p)
+{
+    if (!p) return fail(ORBFE_ERR_INVALID, "null handle");
+    int rc = use_device(p->cfg.device);
+    if (rc) return rc;
+    if (p->pending >= 0) {
+        const int cur = p->pending;
+        p->pending = -1;
+        if ((rc = p->enqueue_post(cur))) return rc;
+    }
+    return ORBFE_OK;
+}
+
+int orbfe_pipeline_synchronize(orbfe_pipeline* p)
+{
+    int rc = orbfe_pipeline_flush(p);
+    if (rc) return rc;
+    for (auto s : p->st_ex) ORBFE_HIP(hipStreamSynchronize(s));
+    ORBFE_HIP(hipStreamSynchronize(p->st_det));
+    ORBFE_HIP(hipStreamSynchronize(p->st_match));
+    return ORBFE_OK;
+}
+
+int orbfe_pipeline_input_done(orbfe_pipeline* p, int set)
+{
+    if (!p || set < 0 || set >= p->R) return fail(ORBFE_ERR_INVALID, "orbfe_pipeline_input_done: invalid argument");
+    int rc = use_device(p->cfg.device);
+    if (rc) return rc;
+    if (p->use_orb) ORBFE_HIP(hipEventSynchronize(p->ex_done[(size_t)set]));
+    if (p->use_aruco) ORBFE_HIP(hipEventSynchronize(p->det_done[(size_t)set]));
+    return ORBFE_OK;
+}
+
+int orbfe_pipeline_status(orbfe_pipeline* p, int32_t out[4])
+{
+    if (!p || !out) return fail(ORBFE_ERR_INVALID, "orbfe_pipeline_status: null argument");
+    int rc = orbfe_pipeline_synchronize(p);
+    if (rc) return rc;
+    out[0] = out[1] = out[2] = out[3] = 0;
+    for (auto e : p->ex) {
+        int32_t o = 0;
+        if ((rc = orbfe_extractor_batch_status(e, &o))) return rc;
+        out[0] = std::max(out[0], o);
+    }
+    if (p->use_orb) {
+        int32_t o = 0;
+        rc = orbfe_search_for_initialization_batch_status(p->st_match, &o);
+        if (rc && rc != ORBFE_ERR_CAPACITY) return rc;
+        out[1] = o;
+    }
+    if (p->det) {
+        int32_t n = 0, fl = 0;
+        if ((rc = orbfe_aruco_batch_status(p->det, &n, &fl))) return rc;
+        out[2] = n; out[3] = fl;
+    }
+    return ORBFE_OK;
+}
+
+int orbfe_pipeline_set_big_frames(orbfe_pipeline* p, int on)
+{
+    if (!p) return fail(ORBFE_ERR_INVALID, "null handle");
+    return p->det ? orbfe_aruco_set_big_frames(p->det, on) : ORBFE_OK;
+}
+
+int orbfe_pipeline_records(orbfe_pipeline* p, int set, uint8_t** d_records)
+{
+    if (!p || !d_records || set < 0 || set >= p->R) return fail(ORBFE_ERR_INVALID, "orbfe_pipeline_records: invalid argument");
+    *d_records = p->recs[(size_t)set];
+    return ORBFE_OK;
+}
+
+int orbfe_pipeline_matches(orbfe_pipeline* p, int32_t** bi, int32_t** bd, int32_t** sd, int32_t** m12, int32_t** nm)
+{
+    if (!p) return fail(ORBFE_ERR_INVALID, "null handle");
+    if (bi) *bi = p->d_bidx;
+    if (bd) *bd = p->d_bdist;
+    if (sd) *sd = p->d_sdist;
+    if (m12) *m12 = p->d_m12;
+    if (nm) *nm = p->d_nm;
+    return ORBFE_OK;
+}
+
+int orbfe_pipeline_reset_stream(orbfe_pipeline* p)
+{
+    int rc = orbfe_pipeline_synchronize(p);
+    if (rc) return rc;
+    for (int s = 0; s < p->R; s++) ORBFE_HIP(hipMemset(p->slot_n(s, 0), 0, 4));
+    return ORBFE_OK;
+}
+
+orbfe_extractor* orbfe_pipeline_extractor(orbfe_pipeline* p, int set) { return p && set >= 0 && set < (int)p->ex.size() ? p->ex[(size_t)set] : nullptr; }
+orbfe_aruco* orbfe_pipeline_detector(orbfe_pipeline* p) { return p ? p->det : nullptr; }
+
+int orbfe_pipeline_engine_sets(const orbfe_pipeline* p, int32_t* engine_sets, int32_t* record_sets, int32_t* phase_pin, int32_t* det_pin,
+                               int32_t* defer_post, int32_t* det_nofork)
+{
+    if (!p) return fail(ORBFE_ERR_INVALID, "null handle");
+    if (engine_sets) *engine_sets = p->D;
+    if (record_sets) *record_sets = p->R;
+    if (phase_pin) *phase_pin = p->D > 1 ? p->phase_pin : 0;
+    if (det_pin) *det_pin = p->det_pin;
+    if (defer_post) *defer_post = p->defer_post;
+    if (det_nofork) *det_nofork = p->det_nofork;
+    return ORBFE_OK;
+}
+
+int orbfe_pipeline_enable_timing(orbfe_pipeline* p, int on)
+{
+    if (!p) return fail(ORBFE_ERR_INVALID, "null handle");
+    p->timing = on != 0;
+    p->match_steps = p->gather_steps = 0;
+    return ORBFE_OK;
+}
+
+int orbfe_pipeline_timing_us(orbfe_pipeline* p, int last, float out[3])
+{
+    if (!p || !out) return fail(ORBFE_ERR_INVALID, "orbfe_pipeline_timing_us: null argument");
+    int rc = orbfe_pipeline_synchronize(p);
+    if (rc) return rc;
+    out[0] = out[1] = out[2] = 0.f;
+    auto med = [](std::vector<float>& v) {
+        if (v.empty()) return 0.f;
+        std::sort(v.begin(), v.end());
+        const size_t m = v.size();
+        return (m & 1) ? v[m / 2] : 0.5f * (v[m / 2 - 1] + v[m / 2]);
+    };
+    constexpr long H = orbfe_pipeline::HIST;
+    std::vector<float> a, b, g;
+    const long nm = std::min(p->match_steps, H), ng = std::min(p->gather_steps, H);
+    for (long k = last ? std::max(0L, nm - 1) : 0; k < nm; k++) {
+        hipEvent_t* e = p->match_ev[last ? (p->match_steps - 1) % H : k];
+        float t0 = 0, t1 = 0;
+        if (hipEventElapsedTime(&t0, e[0], e[1]) == hipSuccess && hipEventElapsedTime(&t1, e[1], e[2]) == hipSuccess) { a.push_back(t0 * 1000.f); b.push_back(t1 * 1000.f); }
+    }
+    for (long k = last ? std::max(0L, ng - 1) : 0; k < ng; k++) {
+        hipEvent_t* e = p->gather_ev[last ? (p->gather_steps - 1) % H : k];
+        float t0 = 0;
+        if (hipEventElapsedTime(&t0, e[0], e[1]) == hipSuccess) g.push_back(t0 * 1000.f);
+    }
+    (void)hipGetLastError();
+    out[0] = med(a); out[1] = med(b); out[2] = med(g);
+    return ORBFE_OK;
+}
+
+// ---- multi-GPU
+int orbfe_pipeline_comm_unique_id(uint8_t id[128])
+{
+    Rccl* R = rccl();
+    if (!R || !id) return fail(ORBFE_ERR_HIP, "orbfe_pipeline_comm_unique_id: librccl is not available");
+    Id128 u{};
+    ORBFE_NCCL(R->GetUniqueId(&u));
+    memcpy(id, u.internal, 128);
+    return ORBFE_OK;
+}
+
+static int attach_comm(orbfe_pipeline* p, void* comm, bool own, int rank, int world, int dst)
+{
+    if (p->step_no) { int rc = orbfe_pipeline_synchronize(p); if (rc) return rc; }
+    p->comm = comm; p->own_comm = own; p->rank = rank; p->world = world; p->dst = dst;
+    if (rank == dst && !p->blocks) ORBFE_HIP(hipMalloc(&p->blocks, (size_t)world * p->lay.nbytes));
+    return ORBFE_OK;
+}
+
+int orbfe_pipeline_comm_init(orbfe_pipeline* p, const uint8_t id[128], int rank, int world, int dst)
+{
+    Rccl* R = rccl();
+    if (!R) return fail(ORBFE_ERR_HIP, "orbfe_pipeline_comm_init: librccl is not available");
+    if (!p || !id || world < 1 || rank < 0 || rank >= world || dst < 0 || dst >= world || p->comm) return fail(ORBFE_ERR_INVALID, "orbfe_pipeline_comm_init: invalid argument");
+    int rc = use_device(p->cfg.device);
+    if (rc) return rc;
+    Id128 u{};
+    memcpy(u.internal, id, 128);
+    void* comm = nullptr;
+    ORBFE_NCCL(R->CommInitRank(&comm, world, u, rank));
+    return attach_comm(p, comm, true, rank, world, dst);
+}
+
+int orbfe_pipeline_set_comm(orbfe_pipeline* p, void* nccl_comm, int rank, int world, int dst)
+{
+    if (!rccl()) return fail(ORBFE_ERR_HIP, "orbfe_pipeline_set_comm: librccl is not available");
+    if (!p || !nccl_comm || world < 1 || rank < 0 || rank >= world || dst < 0 || dst >= world || p->comm) return fail(ORBFE_ERR_INVALID, "orbfe_pipeline_set_comm: invalid argument");
+    int rc = use_device(p->cfg.device);
+    if (rc) return rc;
+    return attach_comm(p, nccl_comm, false, rank, world, dst);
+}
+
+int orbfe_pipeline_gathered(orbfe_pipeline* p, int rank, uint8_t** d_block)
+{
+    if (!p || !d_block || !p->comm || p->rank != p->dst || rank < 0 || rank >= p->world) return fail(ORBFE_ERR_INVALID, "orbfe_pipeline_gathered: not the destination rank, or no communicator");
+    *d_block = p->blocks + (size_t)rank * p->lay.nbytes;
+    return ORBFE_OK;
+}

@@ -1,15 +1,9 @@
-"""Host side of the batched-video mode (BASELINE north_star): one B-frame batch resident in HBM goes through
-
-    ORBextractor::operator()          (Frame.cc:200-206)  -> orbfe_extract_batch_device
-    MarkerDetector::detect(img, cam, 0.187) (Frame.cc:142) -> orbfe_aruco_detect_batch_device + orbfe_marker_poses_batch_device
-    frame t vs t-1 descriptor matching (ORBmatcher)        -> orbfe_knn2_batch_device + orbfe_search_for_initialization_batch_device
-
-on three HIP streams, into fixed-capacity result records.  bench.py times exactly this class and the GPU tests check exactly
-this class against the oracle, so the tested code is the benchmarked code.  torch is plumbing here (device buffers, streams,
-events, torch.distributed); every computation is a call into liborbfe.so.
-"""
-import ctypes
-import os
+"""Python face of the batched-video mode (BASELINE north_star).  The mode itself -- engines, HIP streams, events,
+record sets in rotation, the phase locks, the deferred matching, the RCCL gather -- is C++ inside liborbfe.so
+(csrc/pipeline.hip: orbfe_pipeline_*); this class only marshals arguments for bench.py and the GPU tests, so the tested code is
+the benchmarked code and a C++ application gets the same mode from include/orbfe.h (tests/pipeline_driver.cpp runs it without
+Python).  torch is used for one thing here: the resident input batch (upload)."""
+import ctypes as C
 
 import numpy as np
 
@@ -20,43 +14,42 @@ TUM1_DIST = [0.262383, -0.953104, -0.005358, 0.002628, 1.163314]
 MARKER_SIZE = 0.187                                             # Frame.cc:131
 
 
-def _up(v):
-    return (v + 255) // 256 * 256
+class PipelineConfig(C.Structure):
+    """orbfe_pipeline_config (include/orbfe.h)."""
+    _fields_ = [("frames", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32), ("nfeatures", C.c_int32), ("nlevels", C.c_int32),
+                ("scale_factor", C.c_float), ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32), ("dictionary", C.c_char * 32),
+                ("device", C.c_int32), ("marker_capacity", C.c_int32), ("use_orb", C.c_int32), ("use_aruco", C.c_int32),
+                ("marker_size", C.c_float), ("K", C.c_float * 4), ("dist", C.c_float * 12), ("ndist", C.c_int32),
+                ("window_size", C.c_int32), ("nnratio", C.c_float), ("check_orientation", C.c_int32),
+                ("engine_sets", C.c_int32), ("record_sets", C.c_int32), ("phase_pin", C.c_int32), ("det_pin", C.c_int32),
+                ("defer_post", C.c_int32), ("det_nofork", C.c_int32)]
 
 
-def _stream(torch, dev, priority=0):
-    """A non-blocking HIP stream of the given priority (-1 high, 0 normal, 1 low; torch's pool only has 0 and -1) as a torch stream."""
-    if priority == 0:
-        return torch.cuda.Stream(dev)
-    hip = ctypes.CDLL("libamdhip64.so")
-    h = ctypes.c_void_p()
-    with torch.cuda.device(dev):
-        rc = hip.hipStreamCreateWithPriority(ctypes.byref(h), ctypes.c_uint(1), ctypes.c_int(priority))   # hipStreamNonBlocking
-    if rc != 0:
-        raise RuntimeError("hipStreamCreateWithPriority: %d" % rc)
-    return torch.cuda.ExternalStream(h.value, device=dev)
+class RecordLayoutC(C.Structure):
+    """orbfe_record_layout (include/orbfe.h)."""
+    _fields_ = [("frames", C.c_int32), ("capacity", C.c_int32), ("marker_capacity", C.c_int32), ("halo", C.c_int32),
+                ("off_kps", C.c_uint64), ("off_desc", C.c_uint64), ("off_n", C.c_uint64), ("off_markers", C.c_uint64),
+                ("off_nmarkers", C.c_uint64), ("off_poses", C.c_uint64), ("nbytes", C.c_uint64)]
 
 
 class RecordLayout:
-    """One result set = ONE contiguous buffer, the record SURVEY 8e gathers, array by array over the B frames:
-    {kp[B][cap] x 28 B | desc[B][cap] x 32 B | n_kp[B] | markers[B][mcap] x 36 B | n_mk[B] | poses[B][mcap] x 56 B}."""
+    """One result set = ONE contiguous buffer, the record SURVEY 8e gathers, array by array over the frames:
+    {kp[B + 1][cap] x 28 B | desc[B + 1][cap] x 32 B | n_kp[B + 1] | markers[B][mcap] x 36 B | n_mk[B] | poses[B][mcap] x 56 B};
+    slot 0 of the keypoint arrays is the halo: the last frame of the previous batch of the stream."""
 
-    def __init__(self, B, cap, mcap):
-        self.B, self.cap, self.mcap = B, cap, mcap
-        self.kps = 0
-        self.desc = _up(B * cap * 28)
-        self.n = self.desc + _up(B * cap * 32)
-        self.mk = self.n + _up(B * 4)
-        self.nmk = self.mk + _up(B * mcap * 36)
-        self.pose = self.nmk + _up(B * 4)
-        self.nbytes = self.pose + _up(B * mcap * 56)
+    def __init__(self, c):
+        self.B, self.cap, self.mcap, self.halo = c.frames, c.capacity, c.marker_capacity, c.halo
+        self.kps, self.desc, self.n = int(c.off_kps), int(c.off_desc), int(c.off_n)
+        self.mk, self.nmk, self.pose = int(c.off_markers), int(c.off_nmarkers), int(c.off_poses)
+        self.nbytes = int(c.nbytes)
 
     def unpack(self, buf):
-        """bytes of one record set (numpy uint8) -> dict of per-frame arrays (views)."""
-        B, cap, mcap = self.B, self.cap, self.mcap
-        out = {"n": buf[self.n:self.n + B * 4].view(np.int32),
-               "kps": buf[self.kps:self.kps + B * cap * 28].view(binding.KP_DTYPE).reshape(B, cap),
-               "desc": buf[self.desc:self.desc + B * cap * 32].reshape(B, cap, 32)}
+        """bytes of one record set (numpy uint8) -> dict of per-frame arrays (views); "halo_*" = the slot in front of the batch."""
+        B, cap, mcap, h = self.B, self.cap, self.mcap, self.halo
+        n = buf[self.n:self.n + (B + h) * 4].view(np.int32)
+        kps = buf[self.kps:self.kps + (B + h) * cap * 28].view(binding.KP_DTYPE).reshape(B + h, cap)
+        desc = buf[self.desc:self.desc + (B + h) * cap * 32].reshape(B + h, cap, 32)
+        out = {"n": n[h:], "kps": kps[h:], "desc": desc[h:], "halo_n": n[:h], "halo_kps": kps[:h], "halo_desc": desc[:h]}
         if mcap:
             out["nmk"] = buf[self.nmk:self.nmk + B * 4].view(np.int32)
             out["markers"] = buf[self.mk:self.mk + B * mcap * 36].view(binding.MARKER_DTYPE).reshape(B, mcap)
@@ -77,371 +70,249 @@ def valid_records(rec, use_orb=True):
     return out
 
 
-class FrontEndPipeline:
-    """Extractor, detector and matching of one stream of frames on one GPU.
+_hip = None
 
-    step(d_imgs) enqueues one batch (B frames, rows x pitch bytes each, resident on the device) and returns at once; result
-    set i % R (R = 4) receives batch i, so the matching of batch i (third stream) -- and on N > 1 its gather (communication
-    stream) -- overlap with the engines of batch i + 1.  The engines are joined where their results meet: before the
-    gather and in synchronize()."""
+
+def _hiprt():
+    global _hip
+    if _hip is None:
+        _hip = C.CDLL("libamdhip64.so")
+        _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        _hip.hipMemcpy.restype = C.c_int
+    return _hip
+
+
+def device_bytes(ptr, nbytes):
+    """nbytes at device address ptr -> numpy uint8 (blocking hipMemcpy, device to host)."""
+    out = np.empty(nbytes, np.uint8)
+    rc = _hiprt().hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), nbytes, 2)
+    if rc != 0:
+        raise RuntimeError("hipMemcpy D2H: %d" % rc)
+    return out
+
+
+def _setup(L):
+    if getattr(L, "_pipeline_ready", False):
+        return
+    vp, i32p = C.c_void_p, C.POINTER(C.c_int32)
+    L.orbfe_pipeline_config_default.argtypes = [C.POINTER(PipelineConfig), C.c_int, C.c_int, C.c_int]
+    L.orbfe_pipeline_create.argtypes = [C.POINTER(PipelineConfig)]
+    L.orbfe_pipeline_create.restype = vp
+    L.orbfe_pipeline_destroy.argtypes = [vp]
+    L.orbfe_pipeline_destroy.restype = None
+    L.orbfe_pipeline_layout.argtypes = [vp, C.POINTER(RecordLayoutC)]
+    L.orbfe_pipeline_step.argtypes = [vp, vp, C.c_size_t, i32p]
+    for f in ("flush", "synchronize", "reset_stream"):
+        getattr(L, "orbfe_pipeline_" + f).argtypes = [vp]
+    L.orbfe_pipeline_input_done.argtypes = [vp, C.c_int]
+    L.orbfe_pipeline_status.argtypes = [vp, C.POINTER(C.c_int32 * 4)]
+    L.orbfe_pipeline_set_big_frames.argtypes = [vp, C.c_int]
+    L.orbfe_pipeline_records.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.orbfe_pipeline_matches.argtypes = [vp] + [C.POINTER(vp)] * 5
+    L.orbfe_pipeline_extractor.argtypes = [vp, C.c_int]
+    L.orbfe_pipeline_extractor.restype = vp
+    L.orbfe_pipeline_detector.argtypes = [vp]
+    L.orbfe_pipeline_detector.restype = vp
+    L.orbfe_pipeline_engine_sets.argtypes = [vp] + [i32p] * 6
+    L.orbfe_pipeline_enable_timing.argtypes = [vp, C.c_int]
+    L.orbfe_pipeline_timing_us.argtypes = [vp, C.c_int, C.POINTER(C.c_float * 3)]
+    L.orbfe_pipeline_env_defaults.restype = C.c_char_p
+    L.orbfe_pipeline_comm_unique_id.argtypes = [C.POINTER(C.c_uint8 * 128)]
+    L.orbfe_pipeline_comm_init.argtypes = [vp, C.POINTER(C.c_uint8 * 128), C.c_int, C.c_int, C.c_int]
+    L.orbfe_pipeline_set_comm.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int]
+    L.orbfe_pipeline_gathered.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L._pipeline_ready = True
+
+
+def env_defaults():
+    """{ORBFE_* variable: default} as the library states them (orbfe_pipeline_env_defaults): "size" = decided by the frame size."""
+    L = binding.load()
+    _setup(L)
+    return dict(kv.split("=", 1) for kv in L.orbfe_pipeline_env_defaults().decode().split(";") if kv)
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through the library (128 bytes): rank 0 calls it and hands the bytes to every rank."""
+    L = binding.load()
+    _setup(L)
+    buf = (C.c_uint8 * 128)()
+    binding._check(L, L.orbfe_pipeline_comm_unique_id(C.byref(buf)), "orbfe_pipeline_comm_unique_id")
+    return bytes(buf)
+
+
+class FrontEndPipeline:
+    """Extractor, detector and matching of one stream of frames on one GPU (orbfe_pipeline_*).
+
+    step(d_imgs) enqueues one batch (B frames, rows x pitch bytes each, resident on the device) and returns at once with the
+    record set the batch is written to; flush() / synchronize() before reading the newest batch (its matching is held back one
+    step for frames up to 640 x 480)."""
 
     def __init__(self, frames, rows, cols, nfeatures=1000, nlevels=8, dictionary="ARUCO", device=0, marker_capacity=64,
-                 use_orb=True, use_aruco=True, splits=1, gather=None, lend_aux_stream=True, engine_sets=None, record_sets=4, gather_stream="match", phase_pin=2):
-        import torch
-        self.torch = torch
-        self.L = binding.load()
+                 use_orb=True, use_aruco=True, engine_sets=None, record_sets=None, phase_pin=None, det_pin=None, defer_post=None,
+                 det_nofork=None):
+        self.L = L = binding.load()
+        _setup(L)
         self.B, self.rows, self.cols = frames, rows, cols
         self.pitch = (cols + 63) // 64 * 64
         self.use_orb, self.use_aruco = use_orb, use_aruco
         self.device = device
-        self.dev = dev = torch.device("cuda", device)
-        B = frames
-        S = self.S = max(1, min(splits, B // 2))
-        self.bounds = [B * k // S for k in range(S + 1)]          # sub-batch k = frames bounds[k] .. bounds[k+1]
-        # Engine sets: consecutive batches alternate between D sets of extractor handles and streams (a set owns its pyramid, candidate
-        # and keypoint workspaces), so that batch i + 1's resize / FAST run next to batch i's quadtree / descriptors -- the tail of the
-        # extractor chain is latency-bound (quadtree 116 us + descriptors 350 us in the pipeline for 140 us of VALU issue) and leaves
-        # issue slots free.  Round 2 measured two sets as a loss (2.02 against 1.89 ms, when the detector chain with its 540 us
-        # k_decode and the 640 us k_search_init set the step); with those split up (round 3) two EXTRACTOR sets win: 1.4955 against
-        # 1.5288 ms per C2 step (four interleaved runs each), a second detector set still loses (1.628).  Default: 2 / 1.
-        # Frames of more than a megapixel (1920 x 1080: 4.84 against 5.00 ms per 100-frame step) keep one set: a single batch of
-        # them keeps the chip busy through the extractor's tail, and the second set's workspace traffic costs more than it hides.
-        if engine_sets is None:
-            engine_sets = 2 if rows * cols <= 1280 * 720 else 1
-        D = self.D = max(1, int(os.environ.get("ORBFE_ENGINE_SETS", engine_sets)))
-        DA = self.DA = max(1, int(os.environ.get("ORBFE_ENGINE_SETS_ARUCO", 1)))
-        self.ex_sets = [[binding.ORBextractor(nfeatures, 1.2, nlevels, 20, 7, device=device) for _ in range(S)] for _ in range(D)]
-        self.exs = [e for es in self.ex_sets for e in es]
-        self.ex = self.exs[0]
-        # Phase lock of the engine sets (ORBFE_PHASE_PIN = stage 1 .. 3, 0 = free running): set d's batches start behind that stage of
-        # set d - 1's latest batch, round the ring.  Free running, the two sets' chains drift into whatever phase the contention of
-        # the moment leaves them in: the step time was bimodal from run to run (1.38 / 1.52 ms with the blur on the sets' own
-        # streams) and got LONGER when kernels got cheaper (the address-arithmetic rewrite of round 3 -- fewer instructions, k_blur7
-        # at 64 registers -- took the free-running step 1.42 -> 1.49 ms).  Behind the other set's QUADTREE (stage 2) batch i + 1's
-        # resize / FAST run next to batch i's blur join and descriptors, every step: C2 1.49 -> 1.355 ms (1.33 - 1.39 over eight
-        # interleaved runs; the old kernels under the same lock: 1.40), C3 4.19 -> 3.95; behind FAST (1) 1.45, behind the
-        # descriptors (3) 1.47.
-        self.phase_pin = int(os.environ.get("ORBFE_PHASE_PIN", phase_pin))
-        # The detector's phase (ORBFE_DET_PIN = stage of the extractor's PREVIOUS batch its batch starts behind; + 10: of the current
-        # batch; 0 = free running).  Free running the C2 step spread over 1.31 - 1.39 ms from run to run (two attractors); behind the
-        # previous batch's RESIZE CHAIN (4) 1.329 - 1.367 with the mean a little lower (1.3435 against 1.3495, twelve interleaved runs
-        # each; C3 3.98 against 4.00, gather branch 1.375 against 1.392).  Behind its FAST (1) 1.357, behind the current batch's
-        # stages (11 / 12 / 14) 1.348 / 1.381 / 1.365.
-        self.det_pin = int(os.environ.get("ORBFE_DET_PIN", 4))
-        if self.phase_pin and D > 1 and S == 1:
-            for d in range(D):
-                self.ex_sets[d][0].follow(self.ex_sets[(d - 1) % D][0], self.phase_pin)
-        if os.environ.get("ORBFE_BLUR_PLACE"):            # A/B of the blur's fork point: 0 after FAST, 1 before FAST, 2 no fork
-            for e in self.exs:
-                e.L.orbfe_extractor_debug_kernel_times(e.h, None, 20 + int(os.environ["ORBFE_BLUR_PLACE"]))
-        if os.environ.get("ORBFE_NO_LEND"):
-            lend_aux_stream = False
-        self.cap = cap = self.ex.capacity
-        self.det_sets = [[binding.MarkerDetector(dictionary, device=device) for _ in range(S)] for _ in range(DA)] if use_aruco else []
-        self.dets = [d for ds in self.det_sets for d in ds]
-        self.det = self.dets[0] if use_aruco else None
-        # marker records per frame in the result set (the detector clamps a frame's count to it; its own limit is 256 candidates)
-        self.mcap = mcap = min(self.det.capacity, marker_capacity) if use_aruco else 0
-        self.layout = lay = RecordLayout(B, cap, mcap)
-        # camera of the reference's monocular example; the detector is handed CamSize 1280x720 (Frame.cc:132), so the matrix
-        # is rescaled to the frame size before the marker poses (markerdetector_impl.cpp:1110-1172)
-        self.cam_K = binding.camera_resize(np.array(TUM1_K, np.float32), (1280, 720), (cols, rows)) if use_aruco else None
-        self.cam_D = np.array(TUM1_DIST, np.float32)
-        # Result sets in rotation: batch i writes set i % R.  A set is reused only when the matching (and, on N > 1, the gather) of the
-        # batch that last wrote it is done, which ties every engine to the slowest one R batches back.  With two sets the gather
-        # branch cost 12 % (the detector, 1.05 ms per batch, may run ahead of the extractor chain, 1.47 ms, by less than two
-        # batches); four sets (80 MB per rank) take the coupling out: 1.65 -> see profiles/r03_record_sets.txt.
-        R = self.R = max(2, int(os.environ.get("ORBFE_RECORD_SETS", record_sets)))
-        self.recs = [torch.zeros(lay.nbytes, dtype=torch.uint8, device=dev) for _ in range(R)]
-        self.rec_ptr = [r.data_ptr() for r in self.recs]
-        z = lambda *shape: torch.zeros(shape, dtype=torch.int32, device=dev)
-        # matching outputs of the newest batch: pair p = frame p (queries / F1) against frame p + 1 (train / F2)
-        self.d_bidx, self.d_bdist, self.d_sdist, self.d_m12 = z(B - 1, cap), z(B - 1, cap), z(B - 1, cap), z(B - 1, cap)
-        self.d_nm = z(B - 1)
-        # three HIP streams: the ORB extractor, the ArUco detector, the matching.  The first two only read the resident
-        # frames; the matching of batch i reads result set i % 2 while batch i+1 is extracted into the other set.
-        # So the latency-bound kernels (contours, quadtree, SearchForInitialization) overlap with the VALU-bound ones.
-        # None of them is the null stream: work on the legacy default stream synchronises implicitly with every blocking
-        # stream of the process (measured: 2.30 ms per C2 step with the extractor on the null stream, 2.01 ms on its own).
-        prio = [int(v) for v in os.environ.get("ORBFE_STREAM_PRIO", "0,0,0").split(",")]   # experiment: extractor, detector, matching
-        self.stream, self.stream2, self.stream3 = (_stream(torch, dev, p) for p in prio)
-        self.sp3 = ctypes.c_void_p(self.stream3.cuda_stream)
-        self.orb_stream_sets = [[self.stream] + [torch.cuda.Stream(dev) for _ in range(S - 1)]] + \
-                               [[torch.cuda.Stream(dev) for _ in range(S)] for _ in range(D - 1)]
-        self.aru_stream_sets = [[self.stream2] + [torch.cuda.Stream(dev) for _ in range(S - 1)]] + \
-                               [[torch.cuda.Stream(dev) for _ in range(S)] for _ in range(DA - 1)]
-        self.orb_streams, self.aru_streams = self.orb_stream_sets[0], self.aru_stream_sets[0]
-        self.last_set = self.last_aset = 0
-        if S == 1 and D > 1 and lend_aux_stream and os.environ.get("ORBFE_LEND_ALL", "1") != "0":
-            # every set's blur on the matching stream (1.4466 against 1.4873 ms with the handles' own fork streams, which share
-            # hardware queues with the busy ones)
-            # (experiment ORBFE_BLUR_LEND = det / other: the blur on the detector's stream / on the OTHER extractor set's stream)
-            lend = os.environ.get("ORBFE_BLUR_LEND", "match")
-            for d, es in enumerate(self.ex_sets):
-                for e in es:
-                    if lend == "det" and use_aruco:
-                        e.set_aux_stream(ctypes.c_void_p(self.aru_stream_sets[0][0].cuda_stream))
-                    elif lend == "other":
-                        e.set_aux_stream(ctypes.c_void_p(self.orb_stream_sets[(d + 1) % D][0].cuda_stream))
-                    else:
-                        e.set_aux_stream(self.sp3)
-        if S == 1 and D == 1 and lend_aux_stream:
-            # ROCm maps streams onto 4 hardware queues, and two busy streams on one queue serialise.  The extractor's forked
-            # launch (the blur) is lent the matching stream; measured against the handle's own fork stream and against one
-            # shared fork stream for both engines: 2.02 vs 2.12 vs 2.14 ms per step.
-            self.ex.set_aux_stream(self.sp3)
-            # The fourth queue: the detector's /2 pyramid (~100 us per batch) and the extractor's FAST of level 0 (~120 us), both
-            # wanted at the start of a batch and both independent of everything else, share one stream -- a fifth stream would
-            # share a hardware queue with a busy one (measured: FAST of level 0 ran behind the whole detector chain).
-            # Experiment (ORBFE_FAST0=1 ORBFE_EARLY_SHARED=1): no gain, off by default.
-            if use_aruco and use_orb and os.environ.get("ORBFE_EARLY_SHARED", "0") != "0":
-                self.stream4 = torch.cuda.Stream(dev)
-                self.sp4 = ctypes.c_void_p(self.stream4.cuda_stream)
-                self.det.set_aux_stream(self.sp4)
-                self.ex.set_early_stream(self.sp4)
-        # The detector's /2 pyramid in line on the detector's stream instead of forked onto the handle's second stream: one active
-        # stream fewer.  Measured as "no gain" while the engine sets were free-running; under the phase lock, frames up to VGA size:
-        # C2 1.360 -> 1.320 ms (six interleaved runs each, 1.305 - 1.335), the gather branch 1.393 -> 1.364; 1280 x 720 loses (3.99 ->
-        # 4.05: the pyramid there is 0.3 ms of HBM-bound work worth hiding), 1920 x 1080 does not care.
-        self.det_nofork = os.environ.get("ORBFE_DET_NOFORK", "1" if rows * cols <= 640 * 480 else "0") != "0"
-        if use_aruco and S == 1 and self.det_nofork:
-            for dset, sset in zip(self.det_sets, self.aru_stream_sets):
-                dset[0].set_aux_stream(ctypes.c_void_p(sset[0].cuda_stream))
-        ev = lambda **kw: torch.cuda.Event(**kw)
-        self.ex_done = [[ev() for _ in range(S)] for _ in range(R)]
-        self.det_done = [[ev() for _ in range(S)] for _ in range(R)]
-        self.match_done = [ev() for _ in range(R)]
-        self.gather_done = [ev() for _ in range(R)]
-        # around the matching launches (their stream); one event triple per step, the newest 64 steps kept for the median
-        self.match_evs = [[ev(enable_timing=True) for _ in range(3)] for _ in range(64)]
-        self.match_ev = self.match_evs[0]
-        self.match_steps = 0
-        self.gather_evs = [[ev(enable_timing=True) for _ in range(2)] for _ in range(64)]
-        self.gather_steps = 0
-        # The batch's gather needs a stream.  ROCm runs the process's streams on four hardware queues and the engines use four
-        # (extractor sets, detector, matching + blur, the detector's /2 pyramid): a stream of its own for the collective is a fifth
-        # ACTIVE one, and that alone -- one event record per batch on it, the collective replaced by a no-op, no waits -- costs the
-        # C2 step 9 % (1.50 -> 1.63 ms; profiles/r03_gather_stream.txt).  So the gather is issued on a stream that exists anyway:
-        # "match" (default): behind this batch's matching, which has waited for the extractor already; "det": behind the
-        # detector's poses; "comm": the separate stream (the round-2 arrangement).
-        which = os.environ.get("ORBFE_GATHER_STREAM", gather_stream)
-        self.comm_stream = {"match": self.stream3, "det": self.stream2}.get(which) or torch.cuda.Stream(dev)
-        self.gather_stream_name = which
-        self.gather = gather            # sharding.RecordGather or None (single GPU)
+        cfg = PipelineConfig()
+        binding._check(L, L.orbfe_pipeline_config_default(C.byref(cfg), frames, rows, cols), "orbfe_pipeline_config_default")
+        cfg.nfeatures, cfg.nlevels, cfg.device, cfg.marker_capacity = nfeatures, nlevels, device, marker_capacity
+        cfg.dictionary = dictionary.encode()
+        cfg.use_orb, cfg.use_aruco = int(use_orb), int(use_aruco)
+        for name, v in (("engine_sets", engine_sets), ("record_sets", record_sets), ("phase_pin", phase_pin), ("det_pin", det_pin),
+                        ("defer_post", defer_post), ("det_nofork", det_nofork)):
+            if v is not None:
+                setattr(cfg, name, int(v))
+        self.cfg = cfg
+        self.cam_K = np.array(list(cfg.K), np.float32)
+        self.cam_D = np.array(list(cfg.dist)[:cfg.ndist], np.float32)
+        self.h = L.orbfe_pipeline_create(C.byref(cfg))
+        if not self.h:
+            raise binding.OrbfeError("orbfe_pipeline_create: " + L.orbfe_last_error().decode())
+        lc = RecordLayoutC()
+        binding._check(L, L.orbfe_pipeline_layout(self.h, C.byref(lc)), "orbfe_pipeline_layout")
+        self.layout = RecordLayout(lc)
+        self.cap, self.mcap = lc.capacity, lc.marker_capacity
+        v = [C.c_int32(0) for _ in range(6)]
+        binding._check(L, L.orbfe_pipeline_engine_sets(self.h, *[C.byref(x) for x in v]), "orbfe_pipeline_engine_sets")
+        self.D, self.R, self.phase_pin, self.det_pin = v[0].value, v[1].value, v[2].value, v[3].value
+        self.defer_post, self.det_nofork = bool(v[4].value), bool(v[5].value)
+        # the engines, for their kernel timers and debug entry points (owned by the pipeline)
+        self.exs = [binding.ORBextractor.wrap(L.orbfe_pipeline_extractor(self.h, d), nlevels) for d in range(self.D)] if use_orb else []
+        self.ex = self.exs[0] if self.exs else None
+        dh = L.orbfe_pipeline_detector(self.h)
+        self.det = binding.MarkerDetector.wrap(dh) if dh else None
+        self.dets = [self.det] if self.det else []
+        self.rec_ptr = []
+        for s in range(self.R):
+            p = C.c_void_p()
+            binding._check(L, L.orbfe_pipeline_records(self.h, s, C.byref(p)), "orbfe_pipeline_records")
+            self.rec_ptr.append(p.value)
         self.step_no = 0
-        self.pending = None
-        # (measured: C2 1.4924 -> 1.4759 ms, five interleaved runs each; 1280 x 720: 4.40 -> 4.46, so only for frames up to VGA size)
-        self.defer_post = os.environ.get("ORBFE_DEFER_POST", "1" if rows * cols <= 640 * 480 else "0") != "0"
         self.big_frames = False
+        self.world = 0
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orbfe_pipeline_destroy(self.h)
+            self.h = None
 
     # ------------------------------------------------------------------------------------------------------------
     def upload(self, frames_u8):
-        """(B, rows, cols) uint8 host frames -> resident device batch with 64-byte aligned rows."""
-        torch = self.torch
-        d = torch.zeros((len(frames_u8), self.rows, self.pitch), dtype=torch.uint8, device=self.dev)
-        d[:, :, :self.cols] = torch.from_numpy(np.ascontiguousarray(frames_u8)).to(self.dev)
-        torch.cuda.synchronize(self.dev)     # the engines run on their own streams, not on the one that filled the batch
+        """(B, rows, cols) uint8 host frames -> resident device batch with 64-byte aligned rows (a torch tensor: keep it alive)."""
+        import torch
+        dev = torch.device("cuda", self.device)
+        d = torch.zeros((len(frames_u8), self.rows, self.pitch), dtype=torch.uint8, device=dev)
+        d[:, :, :self.cols] = torch.from_numpy(np.ascontiguousarray(frames_u8)).to(dev)
+        torch.cuda.synchronize(dev)     # the engines run on the pipeline's streams, not on the one that filled the batch
         return d
 
-    def step(self, d_imgs):
-        """Enqueue one batch; returns the result-set index (0 / 1) it writes."""
-        L, lay, S, B = self.L, self.layout, self.S, self.B
-        rows, cols, pitch, cap, mcap = self.rows, self.cols, self.pitch, self.cap, self.mcap
-        i = self.step_no
+    def step_ptr(self, ptr, pitch=None):
+        cur = C.c_int32(0)
+        binding._check(self.L, self.L.orbfe_pipeline_step(self.h, C.c_void_p(ptr), pitch or self.pitch, C.byref(cur)), "orbfe_pipeline_step")
         self.step_no += 1
-        cur = i % self.R
-        eset = self.last_set = i % self.D
-        aset = self.last_aset = i % self.DA
-        exs, dets = self.ex_sets[eset], (self.det_sets[aset] if self.use_aruco else [])
-        orb_streams, aru_streams = self.orb_stream_sets[eset], self.aru_stream_sets[aset]
-        base = self.rec_ptr[cur]
-        img0 = d_imgs.data_ptr()
-        multi = self.gather is not None
-        def enqueue_detector():
-            if self.use_aruco:
-                # the detector streams only depend on the (resident) input frames and on their own previous batch, so they are
-                # not joined with the ORB streams per step: consecutive batches of the two engines pipeline freely.
-                for k in range(S):
-                    f0, nf = self.bounds[k], self.bounds[k + 1] - self.bounds[k]
-                    st = aru_streams[k]
-                    if multi and i >= self.R:
-                        st.wait_event(self.gather_done[cur])         # batch i-R has left this record set
-                    sp = ctypes.c_void_p(st.cuda_stream)
-                    if self.det_pin and self.use_orb:
-                        # experiment (ORBFE_DET_PIN = stage, + 10: of THIS batch's extractor, which is then enqueued first): the detector's
-                        # batch starts behind a stage of the extractor's previous / current batch
-                        j = i if self.det_pin >= 10 else i - 1
-                        if j >= 0:
-                            binding._check(L, L.orbfe_extractor_stage_wait(self.ex_sets[j % self.D][k].h, self.det_pin % 10, sp), "stage_wait")
-                    dets[k].detect_batch_device(img0 + f0 * rows * pitch, nf, rows * pitch, rows, cols, pitch,
-                                                     base + lay.mk + f0 * mcap * 36, mcap, base + lay.nmk + f0 * 4, sp)
-                    # detect(image, CameraParameters, 0.187): every marker gets its IPPE pose (markerdetector_impl.cpp:8720-8780)
-                    binding._check(L, L.orbfe_marker_poses_batch_device(
-                        base + lay.mk + f0 * mcap * 36, base + lay.nmk + f0 * 4, mcap, nf, MARKER_SIZE,
-                        self.cam_K.ctypes.data_as(ctypes.c_void_p), self.cam_D.ctypes.data_as(ctypes.c_void_p), len(self.cam_D),
-                        base + lay.pose + f0 * mcap * 56, sp), "orbfe_marker_poses_batch_device")
-                    self.det_done[cur][k].record(st)
+        return cur.value
 
-        def enqueue_extractor():
-            if self.use_orb:
-                for k in range(S):
-                    f0, nf = self.bounds[k], self.bounds[k + 1] - self.bounds[k]
-                    st = orb_streams[k]
-                    if i >= self.R:
-                        st.wait_event(self.match_done[cur])          # the matching of batch i-2 has read this record set
-                        if multi:
-                            st.wait_event(self.gather_done[cur])
-                    exs[k].extract_batch_device(img0 + f0 * rows * pitch, nf, rows * pitch, rows, cols, pitch,
-                                                     base + lay.kps + f0 * cap * 28, base + lay.desc + f0 * cap * 32, cap,
-                                                     base + lay.n + f0 * 4, ctypes.c_void_p(st.cuda_stream))
-                    self.ex_done[cur][k].record(st)
-
-        if self.det_pin >= 10:
-            enqueue_extractor(); enqueue_detector()
-        else:
-            enqueue_detector(); enqueue_extractor()
-        # What follows a batch's engines -- its matching and, on N > 1, its gather -- goes onto the matching stream, which also
-        # carries the extractor's blur (lent).  Enqueued right away, the matching of batch i (which waits for the whole extractor
-        # chain of batch i) would sit IN FRONT of the blur of batch i + 1 on that stream, and the descriptors of batch i + 1 wait
-        # for that blur: descriptors(i) -> matching(i) -> blur(i+1) -> descriptors(i+1), one after the other, although the second
-        # extractor set has long been ready.  So the post-work of batch i is enqueued one step late, behind the blur of batch i + 1.
-        if self.defer_post:
-            if self.pending is not None:
-                self._enqueue_post(self.pending)
-            self.pending = cur
-        else:
-            self._enqueue_post(cur)
-        return cur
+    def step(self, d_imgs):
+        """Enqueue one batch; returns the record set it writes."""
+        return self.step_ptr(d_imgs.data_ptr())
 
     def flush(self):
-        """Enqueue the post-work (matching, gather) of the newest batch if it is still held back; call before synchronising."""
-        if self.pending is not None:
-            self._enqueue_post(self.pending)
-            self.pending = None
+        binding._check(self.L, self.L.orbfe_pipeline_flush(self.h), "orbfe_pipeline_flush")
 
-    def _enqueue_post(self, cur):
-        S = self.S
-        multi = self.gather is not None
-        if self.use_orb:
-            for k in range(S):
-                self.stream3.wait_event(self.ex_done[cur][k])
-            self.enqueue_matching(cur)
-            if os.environ.get("ORBFE_MATCH_TWICE"):      # sensitivity study only (tools/sensitivity.sh): the matching launched twice
-                self.enqueue_matching(cur)
-        if multi:
-            # the batch's one collective (SURVEY 8e): it waits for the engines of THIS batch and runs while the next batches are
-            # computed into the other record sets (on which stream: see __init__)
-            with self.torch.cuda.stream(self.comm_stream):
-                for k in range(S):
-                    if self.use_orb:
-                        self.comm_stream.wait_event(self.ex_done[cur][k])
-                    if self.use_aruco:
-                        self.comm_stream.wait_event(self.det_done[cur][k])
-                ge = self.gather_evs[self.gather_steps % len(self.gather_evs)]
-                self.gather_steps += 1
-                ge[0].record(self.comm_stream)
-                self.gather(self.recs[cur])
-                ge[1].record(self.comm_stream)
-                self.gather_done[cur].record(self.comm_stream)
-        return cur
+    def synchronize(self):
+        binding._check(self.L, self.L.orbfe_pipeline_synchronize(self.h), "orbfe_pipeline_synchronize")
 
-    def enqueue_matching(self, cur):
-        """Frame t vs t-1 over result set `cur` on the matching stream: all-pairs knn2 + one SearchForInitialization-style
-        windowed pass."""
-        L, lay, B, cap = self.L, self.layout, self.B, self.cap
-        base = self.rec_ptr[cur]
-        e = self.match_ev = self.match_evs[self.match_steps % len(self.match_evs)]
-        self.match_steps += 1
-        e[0].record(self.stream3)
-        binding._check(L, L.orbfe_knn2_batch_device(base + lay.desc, base + lay.n, cap * 32, cap,
-                                                    base + lay.desc + cap * 32, base + lay.n + 4, cap * 32, cap,
-                                                    B - 1, 256, self.d_bidx.data_ptr(), self.d_bdist.data_ptr(),
-                                                    self.d_sdist.data_ptr(), self.sp3), "orbfe_knn2_batch_device")
-        e[1].record(self.stream3)
-        binding._check(L, L.orbfe_search_for_initialization_batch_device(
-            base + lay.kps, base + lay.desc, base + lay.n, cap, B - 1, self.cols, self.rows, None, 100, 0.9, 1,
-            self.d_m12.data_ptr(), self.d_nm.data_ptr(), self.sp3), "orbfe_search_for_initialization_batch_device")
-        e[2].record(self.stream3)
-        self.match_done[cur].record(self.stream3)
+    def input_done(self, cur):
+        binding._check(self.L, self.L.orbfe_pipeline_input_done(self.h, cur), "orbfe_pipeline_input_done")
+
+    def reset_stream(self):
+        binding._check(self.L, self.L.orbfe_pipeline_reset_stream(self.h), "orbfe_pipeline_reset_stream")
 
     def last_engines(self):
         """(extractor, detector) handles that ran the most recent step (their launch timers describe that step)."""
-        return self.ex_sets[self.last_set][0], (self.det_sets[self.last_aset][0] if self.use_aruco else None)
+        return (self.exs[(self.step_no - 1) % self.D] if self.exs else None), self.det
 
-    def synchronize(self):
-        self.flush()
-        self.torch.cuda.synchronize(self.dev)
+    # ------------------------------------------------------------------------------------------------------------
+    def comm_init(self, unique_id, rank, world, dst=0):
+        """The batch's gather over RCCL: every rank calls this with rank 0's comm_unique_id() bytes (ncclCommInitRank inside)."""
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        binding._check(self.L, self.L.orbfe_pipeline_comm_init(self.h, C.byref(buf), rank, world, dst), "orbfe_pipeline_comm_init")
+        self.world, self.rank, self.dst = world, rank, dst
+
+    def gathered(self, rank):
+        """On the destination rank, after synchronize(): the record set rank `rank` sent with the newest batch, unpacked."""
+        p = C.c_void_p()
+        binding._check(self.L, self.L.orbfe_pipeline_gathered(self.h, rank, C.byref(p)), "orbfe_pipeline_gathered")
+        return self.layout.unpack(device_bytes(p.value, self.layout.nbytes))
 
     # ------------------------------------------------------------------------------------------------------------
     def status(self):
-        """Capacity flags of the last batch of every engine (synchronises): dict, all zero = results complete."""
-        out = {"extractor_overflow": 0, "search_init_overflow": 0, "aruco_flagged_frames": 0, "aruco_flags": 0}
-        self.flush()                 # the newest batch's matching may still be held back (defer_post)
-        if self.use_orb:
-            out["extractor_overflow"] = max(e.batch_status() for e in self.exs)
-            ovf = ctypes.c_int32(0)
-            binding._check(self.L, self.L.orbfe_search_for_initialization_batch_status(self.sp3, ctypes.byref(ovf)),
-                           "orbfe_search_for_initialization_batch_status")
-            out["search_init_overflow"] = ovf.value
-        for d in self.dets:
-            n, fl = d.batch_status()
-            out["aruco_flagged_frames"] += n
-            out["aruco_flags"] |= fl
-        return out
+        """Capacity flags since the last call (flushes and synchronises): dict, all zero = results complete."""
+        out = (C.c_int32 * 4)()
+        binding._check(self.L, self.L.orbfe_pipeline_status(self.h, C.byref(out)), "orbfe_pipeline_status")
+        return {"extractor_overflow": out[0], "search_init_overflow": out[1], "aruco_flagged_frames": out[2], "aruco_flags": out[3]}
 
     def warmup(self, d_imgs, steps):
-        """Untimed steps; afterwards the capacity flags are asked once: frames with more long contours than the LDS-resident
-        contour kernels hold (large, busy images) switch the detector to its big-frame kernel, and a SearchForInitialization
-        candidate overflow has grown the scratch, so the steps are repeated once."""
+        """Untimed steps; afterwards the capacity flags are asked once: frames with more long contours than the contour kernels
+        hold (large, busy images) switch the detector to its big-frame kernel, and a SearchForInitialization candidate overflow
+        has grown the scratch, so the steps are repeated once."""
         for _ in range(max(steps, 1)):
             self.step(d_imgs)
-        self.synchronize()
         st = self.status()
         again = False
         if st["aruco_flagged_frames"]:
-            for d in self.dets:
-                d.set_big_frames(True)
+            binding._check(self.L, self.L.orbfe_pipeline_set_big_frames(self.h, 1), "orbfe_pipeline_set_big_frames")
             self.big_frames = again = True
         if st["search_init_overflow"]:
             again = True
         if again:
             for _ in range(max(steps, 1)):
                 self.step(d_imgs)
-            self.synchronize()
             st = self.status()
         if any(st.values()):
             raise binding.OrbfeError("front-end capacity exceeded at this frame size: %r" % (st,))
 
     # ------------------------------------------------------------------------------------------------------------
+    def record_bytes(self, cur):
+        """Result set `cur` as raw bytes (flushes and synchronises)."""
+        self.synchronize()
+        return device_bytes(self.rec_ptr[cur], self.layout.nbytes)
+
     def read_records(self, cur):
         """Result set `cur` as host arrays (flushes the held-back post-work and synchronises)."""
-        self.synchronize()
-        return self.layout.unpack(self.recs[cur].cpu().numpy())
+        return self.layout.unpack(self.record_bytes(cur))
 
     def read_matches(self):
-        """Matching outputs of the newest batch: dict of (B-1, cap) arrays + nmatches (B-1)."""
-        self.synchronize()           # the newest batch's matching is enqueued one step late (defer_post): flush before reading
-        g = lambda t: t.cpu().numpy()
-        return {"best_idx": g(self.d_bidx), "best_dist": g(self.d_bdist), "second_dist": g(self.d_sdist),
-                "matches12": g(self.d_m12), "nmatches": g(self.d_nm)}
+        """Matching outputs of the newest batch: dict of (B, cap) arrays + nmatches (B); row p = slot p (F1) against slot p + 1
+        (F2) of the record set, i.e. row 0 = the last frame of the previous batch against frame 0, row p = frame p - 1 against p."""
+        self.synchronize()
+        ptrs = [C.c_void_p() for _ in range(5)]
+        binding._check(self.L, self.L.orbfe_pipeline_matches(self.h, *[C.byref(p) for p in ptrs]), "orbfe_pipeline_matches")
+        B, cap = self.B, self.cap
+        g = lambda p, n, shape: device_bytes(p.value, n * 4).view(np.int32).reshape(shape)
+        return {"best_idx": g(ptrs[0], B * cap, (B, cap)), "best_dist": g(ptrs[1], B * cap, (B, cap)), "second_dist": g(ptrs[2], B * cap, (B, cap)),
+                "matches12": g(ptrs[3], B * cap, (B, cap)), "nmatches": g(ptrs[4], B, (B,))}
+
+    def enable_timing(self, on=True):
+        binding._check(self.L, self.L.orbfe_pipeline_enable_timing(self.h, int(on)), "orbfe_pipeline_enable_timing")
 
     def reset_timing_history(self):
-        self.match_steps = 0
-        self.gather_steps = 0
+        self.enable_timing(True)
+
+    def _timing(self, last):
+        out = (C.c_float * 3)()
+        binding._check(self.L, self.L.orbfe_pipeline_timing_us(self.h, int(last), C.byref(out)), "orbfe_pipeline_timing_us")
+        return float(out[0]), float(out[1]), float(out[2])
 
     def matching_times_us(self, median=False):
-        """(knn2, SearchForInitialization) launch times of the newest step, or their medians over the steps since
-        reset_timing_history() (the newest 64); after synchronize()."""
-        if not median:
-            e = self.match_ev
-            return e[0].elapsed_time(e[1]) * 1000.0, e[1].elapsed_time(e[2]) * 1000.0
-        n = min(self.match_steps, len(self.match_evs))
-        t = np.array([[e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2])] for e in self.match_evs[:n]]) * 1000.0
-        return float(np.median(t[:, 0])), float(np.median(t[:, 1]))
+        """(knn2, SearchForInitialization) launch times of the newest step, or their medians over the steps since timing was
+        switched on (the newest 64); synchronises."""
+        t = self._timing(not median)
+        return t[0], t[1]
 
     def gather_times_us(self):
-        """Median duration of the batch gather on the communication stream over the steps since reset_timing_history()."""
-        n = min(self.gather_steps, len(self.gather_evs))
-        if n == 0:
-            return None
-        return float(np.median([e[0].elapsed_time(e[1]) for e in self.gather_evs[:n]]) * 1000.0)
+        """Median duration of the batch gather on the matching stream over the steps since timing was switched on."""
+        return self._timing(False)[2] or None

@@ -5,7 +5,8 @@ A resident batch goes through orb_slam2_aruco_amd.pipeline.FrontEndPipeline -- t
 + aruco detect_batch_device + marker poses + orbfe_knn2_batch_device + orbfe_search_for_initialization_batch_device with
 bench.py's arguments -- and EVERY frame's records and EVERY pair's best_idx / best_dist / second_dist / matches12 / nmatches are
 compared with the oracle (ORBmatcher.cc:409-524 for the windowed pass).  Several steps run back to back on rotated copies of
-the stream, as in the bench, so the double-buffered result sets and the cross-step stream dependencies are exercised too."""
+the stream, as in the bench, so the result sets in rotation, the cross-step stream dependencies and the halo slot (the pair across the batch boundary) are
+exercised too."""
 import os, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, HERE)
@@ -37,12 +38,13 @@ assert not any(pipe.status().values()), pipe.status()
 rec = pipe.read_records(cur)
 matches = pipe.read_matches()
 host = np.roll(frames, -shifts[order[-1]], axis=0)
-res = pipeline_check.check_against_oracle(oracle, host, list(range(B)), rec, matches, cfg["nfeatures"], cfg["nlevels"], cfg["dictionary"],
-                                          cols, rows, pipe.cam_K, pipe.cam_D, pairs=list(range(B - 1)))
-assert res["pairs_checked"] == B - 1 and res["keypoints_checked"] > 100 * B and res["markers_checked"] > 0, res
-# the other result set still holds the step before: spot-check it (double buffering must not have been overwritten)
-rec_prev = pipe.read_records(1 - cur)
 host_prev = np.roll(frames, -shifts[order[-2]], axis=0)
+# every pair inside the batch, and the pair across the batch boundary: the previous step's last frame against this step's first
+res = pipeline_check.check_against_oracle(oracle, host, list(range(B)), rec, matches, cfg["nfeatures"], cfg["nlevels"], cfg["dictionary"],
+                                          cols, rows, pipe.cam_K, pipe.cam_D, pairs=list(range(B - 1)), prev_last=host_prev[B - 1])
+assert res["pairs_checked"] == B - 1 and res["boundary_pair_checked"] and res["keypoints_checked"] > 100 * B and res["markers_checked"] > 0, res
+# the other result set still holds the step before: spot-check it (double buffering must not have been overwritten)
+rec_prev = pipe.read_records((cur - 1) % pipe.R)
 pipeline_check.check_against_oracle(oracle, host_prev, [0, B - 1], rec_prev, None, cfg["nfeatures"], cfg["nlevels"], cfg["dictionary"],
                                     cols, rows, pipe.cam_K, pipe.cam_D)
 print("ok", res["keypoints_checked"], res["markers_checked"], res["pairs_checked"])

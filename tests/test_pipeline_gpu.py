@@ -126,3 +126,41 @@ def test_bench_c4_eight_ranks_on_one_gpu(tmp_path):
     assert d["n_gpus"] == 8 and d["gather_check"]["ranks"] == list(range(8)) and d["gather_check"]["frames_per_rank"] == 8
     assert d["config"]["workload"].startswith("C4 at 8 frames per step: 8-frame 1280x720") and "ARUCO_MIP_25h7" in d["config"]["workload"]
     assert d["value"] > 0 and d["verified_frames"]["frames"] == [0, 4, 7]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("force_gather", [0, 1])
+def test_pipeline_from_cpp_without_python(tmp_path, force_gather):
+    """The batched-video mode is C++ inside liborbfe.so (orbfe_pipeline_*): tests/pipeline_driver.cpp -- hipcc, include/orbfe.h, no
+    Python, no PyTorch -- runs a 24-frame batch three times and writes the record set and the match counts; the Python wrapper run on
+    the same frames the same way must give the same bytes (keypoints, descriptors, markers, poses of every frame; the halo slot; the
+    match count of every pair incl. the one across the batch boundary).  force_gather = 1: with an RCCL communicator of one rank
+    created by the library (orbfe_pipeline_comm_unique_id / _comm_init); the record set read back is the gathered block."""
+    import numpy as np
+    from orb_slam2_aruco_amd import synth, binding
+    from orb_slam2_aruco_amd.pipeline import FrontEndPipeline, valid_records
+    B, rows, cols = 24, 480, 640
+    frames = synth.stream(rows, cols, B, 4242, "ARUCO", n_markers=4)
+    raw = tmp_path / "frames.u8"
+    frames.tofile(raw)
+    exe = tmp_path / "pipeline_driver"
+    libdir = os.path.dirname(binding.LIB_PATH)
+    r = subprocess.run(["hipcc", "-O2", "-std=c++17", "-Wall", "-Werror", os.path.join(HERE, "pipeline_driver.cpp"), "-o", str(exe), "-L" + libdir, "-lorbfe",
+                        "-Wl,-rpath," + libdir], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = tmp_path / "records.bin"
+    r = subprocess.run([str(exe), str(raw), str(B), str(rows), str(cols), "3", str(out), str(force_gather)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok frames 24 " in r.stdout, r.stdout + r.stderr[-2000:]      # (RCCL prints its version banner first)
+    pipe = FrontEndPipeline(B, rows, cols)
+    d = pipe.upload(frames)
+    for _ in range(3):
+        cur = pipe.step(d)
+    rec = pipe.read_records(cur)
+    nm = pipe.read_matches()["nmatches"]
+    blob = np.fromfile(out, np.uint8)
+    got = pipe.layout.unpack(blob[:pipe.layout.nbytes])
+    got_nm = blob[pipe.layout.nbytes:].view(np.int32)
+    assert valid_records(got) == valid_records(rec)
+    assert int(got["halo_n"][0]) == int(rec["halo_n"][0]) == int(rec["n"][B - 1]) > 0      # the stream went on: the previous step's last frame
+    assert np.array_equal(got_nm, nm) and nm[0] > 0 and nm[1:].sum() > 0
+    assert "keypoints %d " % int(rec["n"].sum()) in r.stdout
