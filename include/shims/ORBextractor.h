@@ -53,6 +53,15 @@ public:
         _descriptors.create(n, 32, CV_8U);              // :1068
         cv::Mat descriptors = _descriptors.getMat();
         for (int i = 0; i < n; i++) std::copy(desc.begin() + (size_t)i * 32, desc.begin() + (size_t)(i + 1) * 32, descriptors.ptr(i));
+        if (keep_pyramid_) { // ComputePyramid's result (:1107-1132) read back from the device, level by level (without the 19-pixel borders)
+            mvImagePyramid.resize(nlevels_);
+            for (int l = 0; l < nlevels_; l++) {
+                int w = 0, hgt = 0;
+                if (orbfe_extractor_debug_level_size(h_, l, &w, &hgt) != ORBFE_OK) throw std::runtime_error(orbfe_last_error());
+                mvImagePyramid[l].create(hgt, w, CV_8UC1);
+                if (orbfe_extractor_debug_level_image(h_, 0, l, 0, mvImagePyramid[l].data) != ORBFE_OK) throw std::runtime_error(orbfe_last_error());
+            }
+        }
     }
 
     int inline GetLevels() { return nlevels_; }
@@ -62,8 +71,10 @@ public:
     std::vector<float> inline GetScaleSigmaSquares() { return table(orbfe_extractor_get_scale_sigma_squares); }
     std::vector<float> inline GetInverseScaleSigmaSquares() { return table(orbfe_extractor_get_inverse_scale_sigma_squares); }
 
-    // only read by the stereo code path (Frame.cc:456, :546-563), which the monocular system never runs: left empty
+    // Only read by the stereo code path (Frame.cc:456, :546-563), which the monocular system never runs: left empty unless asked for
+    // -- keepImagePyramid(true) makes operator() read the levels back from the device (eight copies per frame: not for the hot path).
     std::vector<cv::Mat> mvImagePyramid;
+    void keepImagePyramid(bool on) { keep_pyramid_ = on; if (!on) mvImagePyramid.clear(); }
 
     orbfe_extractor* handle() { return h_; } // for the batched-video entry points (orbfe_extract_batch_device)
 
@@ -76,6 +87,7 @@ private:
     }
     orbfe_extractor* h_;
     int cap_ = 0, nlevels_ = 0;
+    bool keep_pyramid_ = false;
 };
 
 } // namespace ORB_SLAM2

@@ -2,7 +2,7 @@
 record sets in rotation, the phase locks, the deferred matching, the RCCL gather -- is C++ inside liborbfe.so
 (csrc/pipeline.hip: orbfe_pipeline_*); this class only marshals arguments for bench.py and the GPU tests, so the tested code is
 the benchmarked code and a C++ application gets the same mode from include/orbfe.h (tests/pipeline_driver.cpp runs it without
-Python).  torch is used for one thing here: the resident input batch (upload)."""
+Python).  No PyTorch here: device memory comes from the HIP runtime through ctypes."""
 import ctypes as C
 
 import numpy as np
@@ -80,6 +80,36 @@ def _hiprt():
         _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         _hip.hipMemcpy.restype = C.c_int
     return _hip
+
+
+class DeviceBatch:
+    """A resident input batch: hipMalloc'd frames with 64-byte aligned rows (freed with the object)."""
+
+    def __init__(self, frames_u8, pitch, device=0):
+        hip = _hiprt()
+        f = np.ascontiguousarray(frames_u8, np.uint8)
+        B, rows, cols = f.shape
+        self.shape, self.pitch, self.nbytes = (B, rows, pitch), pitch, B * rows * pitch
+        hip.hipSetDevice(device)
+        p = C.c_void_p()
+        if hip.hipMalloc(C.byref(p), C.c_size_t(self.nbytes)) != 0:
+            raise RuntimeError("hipMalloc of %d bytes failed" % self.nbytes)
+        self.ptr = p.value
+        hip.hipMemset(C.c_void_p(self.ptr), 0, C.c_size_t(self.nbytes))
+        # hipMemcpy2D(dst, dpitch, src, spitch, width, height, hipMemcpyHostToDevice = 1): one row of every frame per line
+        rc = hip.hipMemcpy2D(C.c_void_p(self.ptr), C.c_size_t(pitch), f.ctypes.data_as(C.c_void_p), C.c_size_t(cols), C.c_size_t(cols),
+                             C.c_size_t(B * rows), 1)
+        if rc != 0:
+            raise RuntimeError("hipMemcpy2D H2D: %d" % rc)
+        hip.hipDeviceSynchronize()
+
+    def data_ptr(self):
+        return self.ptr
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            _hiprt().hipFree(C.c_void_p(self.ptr))
+            self.ptr = None
 
 
 def device_bytes(ptr, nbytes):
@@ -201,13 +231,8 @@ class FrontEndPipeline:
 
     # ------------------------------------------------------------------------------------------------------------
     def upload(self, frames_u8):
-        """(B, rows, cols) uint8 host frames -> resident device batch with 64-byte aligned rows (a torch tensor: keep it alive)."""
-        import torch
-        dev = torch.device("cuda", self.device)
-        d = torch.zeros((len(frames_u8), self.rows, self.pitch), dtype=torch.uint8, device=dev)
-        d[:, :, :self.cols] = torch.from_numpy(np.ascontiguousarray(frames_u8)).to(dev)
-        torch.cuda.synchronize(dev)     # the engines run on the pipeline's streams, not on the one that filled the batch
-        return d
+        """(B, rows, cols) uint8 host frames -> resident device batch with 64-byte aligned rows (keep the object alive while it is used)."""
+        return DeviceBatch(frames_u8, self.pitch, self.device)
 
     def step_ptr(self, ptr, pitch=None):
         cur = C.c_int32(0)

@@ -173,6 +173,34 @@ def scene(h, w, seed, dictionary="ARUCO", n_markers=4, side_range=(40, 120), noi
     return np.clip(np.rint(img), 0, 255).astype(np.uint8), truth
 
 
+def paste_markers(image_u8, seed, dictionary="ARUCO", n_markers=3, side_range=(40, 110)):
+    """Markers of `dictionary` warped into a given grey image (a photograph: tests/natural_cases.py) the way scene() places them on
+    its synthetic background.  Returns (uint8 image, list of (id, 4x2 corner array))."""
+    rng = np.random.default_rng(seed)
+    img = np.asarray(image_u8, np.float64).copy()
+    h, w = img.shape
+    nbits, codes = dictionary_codes(dictionary)
+    ids = rng.choice(len(codes), size=n_markers, replace=False)
+    truth, placed = [], []
+    for mid in ids:
+        for _ in range(50):
+            side = float(rng.uniform(*side_range))
+            half = side * 0.95
+            cx = float(rng.uniform(half + 0.03 * w, w - half - 0.03 * w))
+            cy = float(rng.uniform(half + 0.03 * h, h - half - 0.03 * h))
+            if all((cx - px) ** 2 + (cy - py) ** 2 > (half + ph) ** 2 for px, py, ph in placed):
+                break
+        else:
+            continue
+        placed.append((cx, cy, half))
+        m = render_marker(dictionary, int(mid), 8, quiet=1)
+        S = m.shape[0]
+        quad = _tilted_quad(cx, cy, side, rng)
+        _warp_into(img, m, _homography([(8, 8), (S - 8, 8), (S - 8, S - 8), (8, S - 8)], quad))
+        truth.append((int(mid), np.array(quad, np.float64)))
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8), truth
+
+
 def stream(h, w, n_frames, seed_base, dictionary="ARUCO", n_markers=4, noise_sigma=2.0):
     """A video-like stream: one larger scene viewed under a smoothly drifting homography.
 

@@ -47,7 +47,26 @@ def modes():
     print("wrote aruco_modes_seq.npz")
 
 
+def natural():
+    """Photographs (tests/natural_cases.py): the oracle's keypoints / descriptors / markers per case as counts and SHA-256."""
+    import json
+    import natural_cases as N
+    out = {}
+    for case in N.CASES:
+        img, ids = N.build(case)
+        k, d = O.OrbOracle(case[3], 1.2, 8, 20, 7).extract(img)
+        m = O.ArucoOracle(case[4]).detect(img)
+        out[case[0]] = dict(N.digest(k, d, m), image_sum=int(img.astype(np.int64).sum()), pasted_ids=sorted(int(i) for i in ids),
+                            detected_ids=[int(i) for i in m["id"]])
+        print(case[0], out[case[0]])
+    json.dump(out, open(os.path.join(OUT, "natural_images.json"), "w"), indent=1, sort_keys=True)
+    print("wrote natural_images.json")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "natural":
+        os.makedirs(OUT, exist_ok=True)
+        return natural()
     if len(sys.argv) > 1 and sys.argv[1] == "modes":   # only the fixture of the detector modes (the others stay byte for byte)
         os.makedirs(OUT, exist_ok=True)
         return modes()

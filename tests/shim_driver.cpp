@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <set>
 #include <string>
 #include <vector>
@@ -219,6 +220,162 @@ int main(int argc, char** argv)
         for (auto& m : dup) added += m.mObservations.count(&KF) ? 1 : 0;
         res.push_back(replaced);
         res.push_back(added);
+    }
+    // ---- the members that need FeatureVectors or a second keyframe: both SearchByBoW variants, SearchForTriangulation, SearchBySim3,
+    // SearchByProjection(pKF, Scw, ...), Fuse(pKF, Scw, ...).  argv[6] = a vocabulary in DBoW2's text format (tests/voc_cases.py).
+    if (argc > 6) {
+        orbfe_vocabulary* voc = orbfe_vocabulary_load_text(argv[6], 0);
+        if (!voc) { fprintf(stderr, "vocabulary: %s\n", orbfe_last_error()); return 20; }
+        auto featvec = [&](const cv::Mat& desc, int n, DBoW2::FeatureVector& fv) { // Frame::ComputeBoW (Frame.cc:348-355): transform(.., 4)
+            std::vector<uint32_t> bw(n), fn(n), ff(n);
+            std::vector<double> bv(n);
+            std::vector<int32_t> fo(n + 1);
+            int32_t nb = 0, nf = 0;
+            if (orbfe_vocabulary_transform(voc, desc.data, n, 4, NULL, NULL, NULL, bw.data(), bv.data(), &nb, fn.data(), fo.data(), ff.data(), &nf)) return false;
+            fv.clear();
+            for (int i = 0; i < nf; i++) fv[fn[i]] = std::vector<unsigned int>(ff.begin() + fo[i], ff.begin() + fo[i + 1]);
+            return true;
+        };
+        if (!featvec(L.mDescriptors, L.N, KF.mFeatVec) || !featvec(C.mDescriptors, C.N, C.mFeatVec)) return 21;
+        // the second keyframe: frame 1 seen from a pure translation (every derived pose quantity is then exact in float), its own map
+        // points back-projected from its keypoints
+        KeyFrame KF2;
+        KF2.N = C.N; KF2.mvKeys = C.mvKeys; KF2.mvKeysUn = C.mvKeysUn; KF2.mDescriptors = C.mDescriptors; KF2.mFeatVec = C.mFeatVec;
+        KF2.fx = Frame::fx; KF2.fy = Frame::fy; KF2.cx = Frame::cx; KF2.cy = Frame::cy;
+        KF2.mnMinX = 0; KF2.mnMinY = 0; KF2.mnMaxX = cols; KF2.mnMaxY = rows;
+        KF2.mnScaleLevels = C.mnScaleLevels; KF2.mfScaleFactor = C.mfScaleFactor; KF2.mfLogScaleFactor = C.mfLogScaleFactor;
+        KF2.mvScaleFactors = C.mvScaleFactors; KF2.mvLevelSigma2 = C.mvLevelSigma2; KF2.mvInvLevelSigma2 = C.mvInvLevelSigma2;
+        const float t2[3] = {0.004f, -0.006f, 0.01f};
+        KF2.Rcw = mat32(3, 3, {1, 0, 0, 0, 1, 0, 0, 0, 1}); KF2.tcw = mat32(3, 1, {t2[0], t2[1], t2[2]}); KF2.Ow = mat32(3, 1, {-t2[0], -t2[1], -t2[2]});
+        std::vector<MapPoint> mps2(C.N);
+        std::vector<float> x3b(3 * (size_t)C.N), dminb(C.N), dmaxb(C.N);
+        KF2.mvpMapPoints.assign(C.N, (MapPoint*)NULL);
+        for (int i = 0; i < C.N; i++) {
+            const float z = 1.0f + 0.1f * (float)(i % 50);
+            const float Xc = (C.mvKeysUn[i].pt.x - Frame::cx) / Frame::fx * z, Yc = (C.mvKeysUn[i].pt.y - Frame::cy) / Frame::fy * z;
+            const float X = Xc - t2[0], Y = Yc - t2[1], Z = z - t2[2]; // world = camera - tcw (R = I)
+            mps2[i].mWorldPos = mat32(3, 1, {X, Y, Z});
+            const float d = sqrt(Xc * Xc + Yc * Yc + z * z);
+            mps2[i].mNormal = mat32(3, 1, {Xc / d, Yc / d, z / d});
+            mps2[i].mDescriptor = C.mDescriptors.row(i);
+            mps2[i].mfMaxDistance = d * C.mvScaleFactors[C.mvKeysUn[i].octave];
+            mps2[i].mfMinDistance = mps2[i].mfMaxDistance / C.mvScaleFactors[C.mnScaleLevels - 1];
+            x3b[3 * i] = X; x3b[3 * i + 1] = Y; x3b[3 * i + 2] = Z;
+            dminb[i] = mps2[i].mfMinDistance; dmaxb[i] = mps2[i].mfMaxDistance;
+            if (i % 4 != 0) KF2.mvpMapPoints[i] = &mps2[i];
+        }
+        dump("x3b", x3b); dump("dminb", dminb); dump("dmaxb", dmaxb);
+        KF.mvpMapPoints = L.mvpMapPoints; // (SearchByProjection(F, local) and Fuse above changed frame 0's / the keyframe's points)
+        for (int i = 0; i < L.N; i++) KF.mvpMapPoints[i] = (i % 9 != 0) ? &mps[i] : NULL;
+        for (auto& m : mps) { m.mbBad = false; m.mObservations.clear(); }
+        std::vector<int> kfmp(L.N);
+        for (int i = 0; i < L.N; i++) kfmp[i] = KF.mvpMapPoints[i] != NULL;
+        dump("kf1_has_mp", kfmp);
+        {   // Tracking::TrackReferenceKeyFrame (Tracking.cc:946): SearchByBoW(pKF, F, vpMapPointMatches)
+            ORBmatcher m07(0.7f, true);
+            std::vector<MapPoint*> got;
+            res.push_back(m07.SearchByBoW(&KF, C, got));
+            std::vector<int> idx(C.N, -1);
+            for (int i = 0; i < C.N; i++) idx[i] = got[i] ? (int)(got[i] - mps.data()) : -1;
+            dump("bow_kf_f", idx);
+        }
+        {   // LoopClosing::ComputeSim3 (LoopClosing.cc:286): SearchByBoW(pKF1, pKF2, vpMatches12)
+            ORBmatcher m075(0.75f, true);
+            std::vector<MapPoint*> got;
+            res.push_back(m075.SearchByBoW(&KF, &KF2, got));
+            std::vector<int> idx(L.N, -1);
+            for (int i = 0; i < L.N; i++) idx[i] = got[i] ? (int)(got[i] - mps2.data()) : -1;
+            dump("bow_kf_kf", idx);
+        }
+        {   // LocalMapping::CreateNewMapPoints (LocalMapping.cc:287): SearchForTriangulation(pKF1, pKF2, F12, pairs, false) on keyframes
+            // most of whose keypoints have no map point yet
+            // (the second view: the same keypoints seen after a pure translation -- a point at any depth then lies on the epipolar line
+            // through its own pixel, so the epipolar gate has something to accept, which two unrelated synthetic frames do not give it)
+            KeyFrame A = KF, B2 = KF;
+            const float t3[3] = {0.05f, 0.0f, 0.001f};
+            B2.tcw = mat32(3, 1, {t3[0], t3[1], t3[2]}); B2.Ow = mat32(3, 1, {-t3[0], -t3[1], -t3[2]});
+            for (int i = 0; i < A.N; i++) if (i % 3) A.mvpMapPoints[i] = NULL;
+            for (int i = 0; i < B2.N; i++) if (i % 3 != 1) B2.mvpMapPoints[i] = NULL;
+            // F12 = K1^-T [t12]x R12 K2^-1 (LocalMapping::ComputeF12) for R12 = I, t12 = -t3, written out
+            const float fx = Frame::fx, fy = Frame::fy, cx0 = Frame::cx, cy0 = Frame::cy, tx = -t3[0], ty = -t3[1], tz = -t3[2];
+            const float E[9] = {0, -tz, ty, tz, 0, -tx, -ty, tx, 0};
+            const float Ki[9] = {1 / fx, 0, -cx0 / fx, 0, 1 / fy, -cy0 / fy, 0, 0, 1};
+            float EK[9], F12a[9];
+            for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { float v = 0; for (int k = 0; k < 3; k++) v += E[3 * r + k] * Ki[3 * k + c]; EK[3 * r + c] = v; }
+            for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { float v = 0; for (int k = 0; k < 3; k++) v += Ki[3 * k + r] * EK[3 * k + c]; F12a[3 * r + c] = v; }
+            dump("F12", F12a, 9);
+            cv::Mat F12 = mat32(3, 3, {F12a[0], F12a[1], F12a[2], F12a[3], F12a[4], F12a[5], F12a[6], F12a[7], F12a[8]});
+            std::vector<std::pair<size_t, size_t> > pairs;
+            ORBmatcher m06(0.6f, false);
+            res.push_back(m06.SearchForTriangulation(&A, &B2, F12, pairs, false));
+            std::vector<int> flat;
+            for (auto& pr : pairs) { flat.push_back((int)pr.first); flat.push_back((int)pr.second); }
+            dump("triangulation", flat);
+        }
+        {   // LoopClosing::ComputeSim3 (LoopClosing.cc:322): SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, 7.5)
+            std::vector<MapPoint*> m12(L.N, (MapPoint*)NULL);
+            for (int i = 0; i < L.N && i < C.N; i += 13) if (KF2.mvpMapPoints[i]) { m12[i] = KF2.mvpMapPoints[i]; mps2[i].mObservations[&KF2] = i; } // already matched
+            std::vector<int> pre(L.N);
+            for (int i = 0; i < L.N; i++) pre[i] = m12[i] ? (int)(m12[i] - mps2.data()) : -1;
+            dump("sim3_pre", pre);
+            cv::Mat R12 = mat32(3, 3, {1, 0, 0, 0, 1, 0, 0, 0, 1}), t12 = mat32(3, 1, {-t2[0], -t2[1], -t2[2]});
+            const float s12 = 1.0f;
+            res.push_back(matcher.SearchBySim3(&KF, &KF2, m12, s12, R12, t12, 7.5f));
+            std::vector<int> idx(L.N);
+            for (int i = 0; i < L.N; i++) idx[i] = m12[i] ? (int)(m12[i] - mps2.data()) : -1;
+            dump("sim3", idx);
+            for (auto& m : mps2) m.mObservations.clear();
+        }
+        // the two Scw members look at a keyframe through a similarity that is ALMOST the keyframe's own pose (frame 0 seen from 0.5 mm
+        // to the side, scale 1): loop-closure candidates then project next to the keypoints they came from, as they do after a good Sim3
+        const float ts[3] = {0.0005f, -0.0003f, 0.0f};
+        cv::Mat Scws = mat32(4, 4, {1, 0, 0, ts[0], 0, 1, 0, ts[1], 0, 0, 1, ts[2], 0, 0, 0, 1});
+        std::vector<MapPoint> mps3(mps.begin(), mps.end()); // the keyframe's own points (other objects than the candidates)
+        KeyFrame KF3 = KF;
+        for (int i = 0; i < KF3.N; i++) KF3.mvpMapPoints[i] = (i % 4 != 0) ? &mps3[i] : NULL;
+        {   // LoopClosing::ComputeSim3 (LoopClosing.cc:372): SearchByProjection(mpCurrentKF, mScw, vpLoopMapPoints, vpMatched, 10)
+            std::vector<MapPoint*> pts;
+            for (auto& m : mps) pts.push_back(&m);
+            std::vector<MapPoint*> matched(KF3.N, (MapPoint*)NULL);
+            for (int i = 0; i < KF3.N; i += 17) matched[i] = &mps[i];
+            std::vector<int> pre(KF3.N);
+            for (int i = 0; i < KF3.N; i++) pre[i] = matched[i] ? (int)(matched[i] - mps.data()) : -1;
+            dump("proj_sim3_pre", pre);
+            res.push_back(matcher.SearchByProjection(&KF3, Scws, pts, matched, 10));
+            std::vector<int> idx(KF3.N);
+            for (int i = 0; i < KF3.N; i++) idx[i] = matched[i] ? (int)(matched[i] - mps.data()) : -1;
+            dump("proj_sim3", idx);
+        }
+        {   // LoopClosing::SearchAndFuse (LoopClosing.cc:700): Fuse(pKF, Scw, vpLoopMapPoints, 4, vpReplacePoints)
+            std::vector<MapPoint*> pts;
+            for (auto& m : mps) pts.push_back(&m);
+            std::vector<MapPoint*> rep(pts.size(), (MapPoint*)NULL);
+            res.push_back(matcher.Fuse(&KF3, Scws, pts, 4.0f, rep));
+            std::vector<int> idx(pts.size());
+            int added = 0;
+            for (size_t i = 0; i < pts.size(); i++) {
+                // a replacement names a point of the keyframe -- or, when an earlier candidate was added at that keypoint, that candidate (-2)
+                idx[i] = !rep[i] ? -1 : (rep[i] >= mps3.data() && rep[i] < mps3.data() + mps3.size()) ? (int)(rep[i] - mps3.data()) : -2;
+                added += mps[i].mObservations.count(&KF3) ? 1 : 0;
+            }
+            dump("fuse_scw_replace", idx);
+            res.push_back(added);
+        }
+        orbfe_vocabulary_destroy(voc);
+    }
+    {   // ORBextractor::mvImagePyramid (ORBextractor.h:85) is filled on request: keepImagePyramid(true), then operator()
+        ORBextractor ex2(1000, 1.2f, 8, 20, 7);
+        ex2.keepImagePyramid(true);
+        cv::Mat im(rows, cols, CV_8UC1, raw.data(), (size_t)cols);
+        std::vector<cv::KeyPoint> k;
+        cv::Mat d;
+        ex2(im, cv::Mat(), k, d);
+        if ((int)ex2.mvImagePyramid.size() != 8 || ex2.mvImagePyramid[0].rows != rows || ex2.mvImagePyramid[0].cols != cols) return 30;
+        std::vector<int> dims;
+        for (auto& m : ex2.mvImagePyramid) { dims.push_back(m.cols); dims.push_back(m.rows); }
+        dump("pyr_dims", dims);
+        dump("pyr_level3", ex2.mvImagePyramid[3].data, (size_t)ex2.mvImagePyramid[3].rows * ex2.mvImagePyramid[3].cols);
+        if (memcmp(ex2.mvImagePyramid[0].data, raw.data(), (size_t)rows * cols) != 0) return 31;
     }
     dump("results", res);
     printf("ok %d frames, %d keypoints in frame 0\n", nframes, F[0].N);

@@ -1,12 +1,13 @@
-"""The shims on the GPU: tests/shim_driver.cpp calls ORBextractor::operator(), aruco::MarkerDetector::detect and five ORBmatcher
-members the way Frame / Tracking / LocalMapping do; every result must equal the same call made through the ctypes binding (whose
-results the other GPU tests compare with the oracle)."""
+"""The shims on the GPU: tests/shim_driver.cpp calls ORBextractor::operator(), aruco::MarkerDetector::detect and ALL ELEVEN ORBmatcher
+members (ORBmatcher.h:44-83) the way Frame / Tracking / LocalMapping / LoopClosing do; every result must equal the same call made
+through the ctypes binding (whose results the other GPU tests compare with the oracle)."""
 import subprocess
 
 import numpy as np
 import pytest
 
 import shim_build
+import voc_cases
 from orb_slam2_aruco_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -17,7 +18,10 @@ def test_shims_equal_the_binding(orbfe, oracle, tmp_path):
     s = synth.stream(480, 640, 2, 1000)
     s.tofile(tmp_path / "frames.raw")
     pre = str(tmp_path / "o")
-    r = subprocess.run([exe, str(tmp_path / "frames.raw"), "480", "640", "2", pre], capture_output=True, text=True, timeout=600)
+    voc = voc_cases.make(k=8, L=4, seed=5, irregular=False)
+    voc_cases.write_text(voc, str(tmp_path / "voc.txt"))
+    r = subprocess.run([exe, str(tmp_path / "frames.raw"), "480", "640", "2", pre, str(tmp_path / "voc.txt")], capture_output=True, text=True,
+                       timeout=600)
     assert r.returncode == 0 and r.stdout.startswith("ok"), (r.returncode, r.stdout, r.stderr[-2000:])
     ld = lambda name, dt: np.fromfile(pre + "_" + name + ".bin", dt)
     # ---- ORBextractor::operator()
@@ -89,3 +93,76 @@ def test_shims_equal_the_binding(orbfe, oracle, tmp_path):
     isg = ex.GetInverseScaleSigmaSquares()
     bi, bd = orbfe.fuse_search(k0, d0, 640, 480, x3, None, dmin, dmax, nrm, d0, I34, np.zeros(3, np.float32), K4, sf, isg, logsf, 3.0, 5.99)
     assert res[5] == int((bd <= 50).sum()) and res[5] > 300 and res[6] > 0 and res[7] > 0
+
+    # ---- the members that need FeatureVectors or a second keyframe (results 8 ..): the same calls through the binding
+    V = orbfe.ORBVocabulary()
+    V.loadFromTextFile(str(tmp_path / "voc.txt"))
+    fv0, fv1 = V.transform(d0)["fv"], V.transform(d1)["fv"]
+    x3b, dminb, dmaxb = ld("x3b", np.float32).reshape(-1, 3), ld("dminb", np.float32), ld("dmaxb", np.float32)
+    idx1 = np.arange(len(k1))
+    has1 = ld("kf1_has_mp", np.int32).astype(np.uint8)
+    has2 = (idx1 % 4 != 0).astype(np.uint8)
+    # SearchByBoW(pKF, F, vpMapPointMatches), nnratio 0.7: vpMapPointMatches[i2] = the keyframe's point of match21[i2]
+    n, m12, m21 = orbfe.search_by_bow(k0, d0, fv0, k1, d1, fv1, valid1=has1, nnratio=0.7, accept_max=50, factor=30 / 360.0)
+    assert res[8] == n and n > 30 and np.array_equal(ld("bow_kf_f", np.int32), m21)
+    # SearchByBoW(pKF1, pKF2, vpMatches12), nnratio 0.75: vpMatches12[i1] = the second keyframe's point of match12[i1]
+    n, m12, m21 = orbfe.search_by_bow(k0, d0, fv0, k1, d1, fv1, valid1=has1, valid2=has2, nnratio=0.75, accept_max=49, factor=1 / 30.0)
+    assert res[9] == n and n > 20 and np.array_equal(ld("bow_kf_kf", np.int32), m12)
+    # SearchForTriangulation(pKF1, pKF2, F12, pairs, false): keypoints WITHOUT a map point on either side
+    t2 = np.array([0.004, -0.006, 0.01], np.float32)
+    F12 = ld("F12", np.float32)
+    c2 = np.array([0.05, 0.0, 0.001], np.float32)         # camera centre of keyframe 1 (the origin) in the second view: R * 0 + t
+    ep = (np.float32(517.3) * c2[0] * (np.float32(1.0) / c2[2]) + np.float32(318.6), np.float32(516.5) * c2[1] * (np.float32(1.0) / c2[2]) + np.float32(255.3))
+    hasA = ((idx % 3 == 0) & (has1 == 1)).astype(np.uint8)
+    hasB = ((idx % 3 == 1) & (has1 == 1)).astype(np.uint8)
+    n, m12 = orbfe.search_for_triangulation(k0, d0, fv0, k0, d0, fv0, F12, ep, sf, ex.GetScaleSigmaSquares(), has_mp1=hasA, has_mp2=hasB,
+                                            check_orientation=False)
+    tri = ld("triangulation", np.int32).reshape(-1, 2)
+    assert res[10] == n == len(tri) and n > 10
+    assert np.array_equal(tri[:, 0], np.flatnonzero(m12 >= 0)) and np.array_equal(tri[:, 1], m12[m12 >= 0])
+    # SearchBySim3(pKF1, pKF2, vpMatches12, 1, I, -t2, 7.5): the pre-matched points are left out on both sides
+    pm = ld("sim3_pre", np.int32)
+    v1 = (has1 == 1) & (pm < 0)
+    v2 = (has2 == 1)
+    v2[pm[pm >= 0]] = False
+    I34 = np.eye(3, 4, dtype=np.float32)
+    T2w = I34.copy(); T2w[:, 3] = t2
+    S12 = I34.copy(); S12[:, 3] = -t2
+    S21 = I34.copy(); S21[:, 3] = t2
+    kfa = dict(kps=k0, desc=d0, p3Dw=x3, valid=v1.astype(np.uint8), min_dist=dmin, max_dist=dmax, mp_desc=d0)
+    kfb = dict(kps=k1, desc=d1, p3Dw=x3b, valid=v2.astype(np.uint8), min_dist=dminb, max_dist=dmaxb, mp_desc=d1)
+    n, m12 = orbfe.search_by_sim3(kfa, kfb, 640, 480, I34, T2w, S12, S21, K4, sf, logsf, 7.5, 100)
+    want = pm.copy(); want[m12 >= 0] = m12[m12 >= 0]
+    assert res[11] == n and n > 20 and np.array_equal(ld("sim3", np.int32), want)
+    # SearchByProjection(pKF, Scw, vpPoints, vpMatched, 10) and Fuse(pKF, Scw, vpPoints, 4, vpReplacePoint): frame 0 as the keyframe, seen
+    # through a similarity 0.5 mm off its own pose; the candidates are frame 0's own map points (other objects than the keyframe's)
+    ts = np.array([0.0005, -0.0003, 0.0], np.float32)
+    Ts = I34.copy(); Ts[:, 3] = ts
+    pm = ld("proj_sim3_pre", np.int32)
+    valid = np.ones(len(k0), np.uint8); valid[pm[pm >= 0]] = 0          # spAlreadyFound
+    n, m = orbfe.search_by_projection_sim3(k0, d0, 640, 480, (pm >= 0).astype(np.uint8), x3, valid, dmin, dmax, nrm, d0, Ts, -ts, K4, sf, logsf, 10)
+    want = pm.copy(); want[m >= 0] = m[m >= 0]
+    assert res[12] == n and n > 300 and np.array_equal(ld("proj_sim3", np.int32), want)
+    has3 = (idx % 4 != 0)
+    bi, bd = orbfe.fuse_search(k0, d0, 640, 480, x3, None, dmin, dmax, nrm, d0, Ts, -ts, K4, sf, isg, logsf, 4.0, 0.0)
+    hit = bd <= 50
+    rep = ld("fuse_scw_replace", np.int32)
+    assert res[13] == int(hit.sum()) and res[13] > 300
+    # the bookkeeping in candidate order: a hit on a keypoint with a point names it as the replacement; the first hit on a keypoint
+    # without one adds itself there, later hits on that keypoint find it (-2 in the driver's dump)
+    want_rep, taken_kp, added = np.full(len(k0), -1, np.int32), set(), 0
+    for i in np.flatnonzero(hit):
+        j = int(bi[i])
+        if has3[j]:
+            want_rep[i] = j
+        elif j in taken_kp:
+            want_rep[i] = -2
+        else:
+            taken_kp.add(j); added += 1
+    assert np.array_equal(rep, want_rep) and (rep >= 0).sum() > 200 and res[14] == added > 50
+    # ---- ORBextractor::mvImagePyramid on request
+    dims = ld("pyr_dims", np.int32).reshape(-1, 2)
+    assert [tuple(x) for x in dims] == ex.level_sizes()
+    o = oracle.OrbOracle(1000, 1.2, 8, 20, 7)
+    o.extract(s[0])
+    assert np.array_equal(ld("pyr_level3", np.uint8).reshape(dims[3][1], dims[3][0]), o.level_image(3))
