@@ -60,6 +60,8 @@ def parse():
                     "offsets), one per step in rotation; 0 = as many as exceed the 256 MiB Infinity Cache (at most 8)")
     ap.add_argument("--cpu-frames", type=int, default=None, help="frames timed on the host for cpu_baseline (0 = skip)")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-run check against the oracle")
+    ap.add_argument("--no-extras", action="store_true", help="default configuration only: skip the records appended after the clock "
+                    "(single-frame latency, short C3 / C5 legs)")
     ap.add_argument("--no-aruco", action="store_true", help="diagnostic only: drop the ArUco leg (value becomes null)")
     ap.add_argument("--no-orb", action="store_true", help="diagnostic only: drop the ORB + matching legs (value becomes null)")
     ap.add_argument("--force-gather", action="store_true", help="with --gpus 1: still initialise the RCCL process group (world size 1) "
@@ -90,7 +92,9 @@ def make_stream(args, rank):
             return np.load(path)
         except Exception:
             pass
-    s = synth.stream(args.rows, args.cols, args.frames, seed, args.dictionary, n_markers=args.n_markers)
+    # (rendered by a pool of processes: 300 frames of 1280 x 720 take a minute on one core)
+    s = synth.stream(args.rows, args.cols, args.frames, seed, args.dictionary, n_markers=args.n_markers,
+                     workers=max(1, min(16, (os.cpu_count() or 1) // max(1, int(os.environ.get("WORLD_SIZE", "1"))))))
     try:
         np.save(path + ".tmp.npy", s)
         os.replace(path + ".tmp.npy", path)
@@ -229,21 +233,26 @@ def c5_match_leg(binding, torch, dev, O):
 
 
 def latency_mode(args):
-    """The drop-in mode the reference's sequential Tracking thread uses (Frame.cc:91,142; Tracking.cc:531): ONE frame per
-    call through the host-pointer ABI (H2D + kernels + D2H + sync inside each call), median of 200 calls."""
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    out = latency_record(args, make_stream(args, 0)[:max(16, min(64, args.frames))])
+    print(json.dumps(out))
+    if args.out:
+        open(args.out, "w").write(json.dumps(out) + "\n")
+
+
+def latency_record(args, frames, calls=200):
+    """The drop-in mode the reference's sequential Tracking thread uses (Frame.cc:91,142; Tracking.cc:531): ONE frame per
+    call through the host-pointer ABI (H2D + kernels + D2H + sync inside each call), median of `calls` calls."""
     from orb_slam2_aruco_amd import binding
     from orb_slam2_aruco_amd.pipeline import TUM1_K, TUM1_DIST, MARKER_SIZE
-    frames = make_stream(args, 0)[:max(16, min(64, args.frames))]
     ex = binding.ORBextractor(args.nfeatures, 1.2, args.nlevels, 20, 7)
     det = binding.MarkerDetector(args.dictionary)
     mt = binding.ORBmatcher(0.9, True)
     K = binding.camera_resize(np.array(TUM1_K, np.float32), (1280, 720), (args.cols, args.rows))
     D = np.array(TUM1_DIST, np.float32)
     cam = (K, D, (args.cols, args.rows))
-    calls = 200
 
     def run(paired):
         ex.pair_detector(det if paired else None)
@@ -301,9 +310,62 @@ def latency_mode(args):
         out["cpu_baseline"] = {"value": med(c_ex) + med(c_det) + med(c_sfi), "unit": "ms", "cores": 1, "kind": "port",
                                "sample": "%d frames, oracle/ single thread" % len(c_ex),
                                "median_ms": {"extract": med(c_ex), "aruco_detect+poses": med(c_det), "search_for_initialization": med(c_sfi)}}
-    print(json.dumps(out))
-    if args.out:
-        open(args.out, "w").write(json.dumps(out) + "\n")
+    return out
+
+
+def fused_bytes_per_frame(level_sizes, N, rows, cols, use_orb=True, use_aruco=True):
+    """SURVEY 8d's contract: the compulsory traffic of a FUSED pipeline, per frame:
+    B_orb = 3 * sumP - P0 + 1321 * N,  B_aruco = 3.33 * W * H,  B_match = (Q + T) * 32 + Q * 12 (frame t vs t - 1)."""
+    P = [w * h for (w, h) in level_sizes]
+    b_orb = (3 * sum(P) - P[0] + 1321 * N) if use_orb else 0.0
+    b_aruco = (10.0 / 3.0) * rows * cols if use_aruco else 0.0
+    b_match = (2 * N * 32 + N * 12) if use_orb else 0.0
+    return b_orb, b_aruco, b_match
+
+
+def extra_leg(name, device, steps=5, warmup=2):
+    """A short leg of another BASELINE configuration after the clock of the default run (the driver's record should
+    carry C3 and C5 too): the configuration's full batch when the box has the cores to render its stream in seconds, else a reduced
+    one (said in the record); ms per step, frames/s, the fused-bytes fraction of the HBM peak, two frames + a pair against the oracle."""
+    from orb_slam2_aruco_amd.pipeline import FrontEndPipeline
+    cfg = dict(CONFIGS[name])
+    full = (os.cpu_count() or 1) >= 32
+    if not full:
+        cfg["frames"] = {"C3": 96, "C5": 32}.get(name, cfg["frames"])
+    a = argparse.Namespace(**cfg)
+    t0 = time.perf_counter()
+    frames_np = make_stream(a, 0)
+    t_stream = time.perf_counter() - t0
+    B, rows, cols = a.frames, a.rows, a.cols
+    pipe = FrontEndPipeline(B, rows, cols, a.nfeatures, a.nlevels, a.dictionary, device=device)
+    batches = [pipe.upload(frames_np), pipe.upload(np.roll(frames_np, -(B // 2), axis=0))]
+    pipe.warmup(batches[0], warmup)
+    pipe.step(batches[1])
+    pipe.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        cur = pipe.step(batches[i % 2])
+    pipe.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    st = pipe.status()
+    if any(st.values()):
+        return {"workload": name, "error": "capacity flags %r" % (st,)}
+    r_last = (steps - 1) % 2
+    rec, matches = pipe.read_records(cur), pipe.read_matches()
+    host = frames_np if r_last == 0 else np.roll(frames_np, -(B // 2), axis=0)
+    prev = (frames_np if r_last == 1 else np.roll(frames_np, -(B // 2), axis=0))[B - 1]
+    import pipeline_check  # tests/
+    ver = pipeline_check.check_against_oracle(oracle_module(), host, [0, B - 1], rec, matches, a.nfeatures, a.nlevels, a.dictionary, cols, rows,
+                                              pipe.cam_K, pipe.cam_D, pairs=[0], prev_last=prev)
+    N = float(rec["n"].mean())
+    b_orb, b_aruco, b_match = fused_bytes_per_frame(pipe.ex.level_sizes(), N, rows, cols)
+    fused = (b_orb + b_aruco) * B
+    return {"workload": "%s%s: %d-frame %dx%d stream, nFeatures=%d, %d levels, %s" % (name, "" if full else " at a reduced batch", B, cols, rows, a.nfeatures,
+                                                                                 a.nlevels, a.dictionary),
+            "full_batch": full, "frames_per_step": B, "steps": steps, "ms_per_step": 1000.0 * dt, "frames_per_s": B / dt,
+            "fused": {"algorithmic_bytes_per_step": fused, "GBps": fused / dt / 1e9, "frac": fused / dt / 1e9 / HBM_PEAK_GBPS},
+            "mean_keypoints_per_frame": N, "verified_frames": ver, "aruco_big_frame_kernel": pipe.big_frames,
+            "stream_render_s": t_stream}
 
 
 def free_port():
@@ -660,9 +722,7 @@ def main():
             step_s = elapsed / args.steps
             # SURVEY 8d's contract: the compulsory traffic of a FUSED pipeline, per frame
             #   B_orb = 3 * sumP - P0 + 1321 * N,   B_aruco = 3.33 * W * H,   B_match = (Q + T) * 32 + Q * 12 (frame t vs t-1)
-            b_orb = (3 * sumP - P0 + 1321 * N) if use_orb else 0.0
-            b_aruco = (10.0 / 3.0) * rows * cols if use_aruco else 0.0
-            b_match = (2 * N * 32 + N * 12) if use_orb else 0.0
+            b_orb, b_aruco, b_match = fused_bytes_per_frame(sizes, N, rows, cols, use_orb, use_aruco)
             fused_bytes = (b_orb + b_aruco) * B
             fused_bytes_m = fused_bytes + b_match * B
             step_bytes = sum(alg.get(k, 0) * B for k in stages)
@@ -735,6 +795,24 @@ def main():
             out["gather_us"] = gather_us
         if c5:
             out["c5_match"] = c5
+        # ---- after the clock, default run only: the drop-in latency and short legs of the other configurations, so that the
+        # driver's record carries them and not only the builder's profile files
+        # (not in the measurement scripts' runs: those pass --no-verify / --cpu-frames 0)
+        if (args.config == "C2" and not args.custom and not args.reduced and not multi and not invalid and not args.no_extras
+                and not args.no_verify and args.cpu_frames > 0):
+            del d_batches
+            pipe = None
+            extras = {}
+            try:
+                extras["latency"] = latency_record(argparse.Namespace(**dict(vars(args), cpu_frames=0)), frames_np[:64], calls=200)
+            except Exception as e:      # an extra must not take the headline line with it
+                extras["latency"] = {"error": repr(e)}
+            for leg in ("C3", "C5"):
+                try:
+                    extras[leg] = extra_leg(leg, local_rank)
+                except Exception as e:
+                    extras[leg] = {"workload": leg, "error": repr(e)}
+            out["extras"] = extras
         line = json.dumps(out)
         print(line)
         if args.out:

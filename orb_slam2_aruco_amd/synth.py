@@ -201,11 +201,29 @@ def paste_markers(image_u8, seed, dictionary="ARUCO", n_markers=3, side_range=(4
     return np.clip(np.rint(img), 0, 255).astype(np.uint8), truth
 
 
-def stream(h, w, n_frames, seed_base, dictionary="ARUCO", n_markers=4, noise_sigma=2.0):
+def _stream_chunk(args):
+    """Worker of stream(workers > 1): frames [i0, i1) of the stream, rendered in a process of their own."""
+    h, w, n_frames, seed_base, dictionary, n_markers, noise_sigma, i0, i1 = args
+    return i0, stream(h, w, n_frames, seed_base, dictionary, n_markers, noise_sigma, only=range(i0, i1))[i0:i1].copy()
+
+
+def stream(h, w, n_frames, seed_base, dictionary="ARUCO", n_markers=4, noise_sigma=2.0, workers=1, only=None):
     """A video-like stream: one larger scene viewed under a smoothly drifting homography.
 
     Frame i adds noise seeded with seed_base + i.  Returns uint8 array (n_frames, h, w).
+    workers > 1: the frames are rendered by that many processes (forkserver: safe next to an initialised HIP runtime; only for
+    callers whose main module is import-safe, e.g. bench.py) -- every frame is a function of (seed_base, i, n_frames) alone, so the
+    result is the same bytes.  only = the frame indices to render (the rest of the array is left unset).
     """
+    if workers > 1 and n_frames >= 2 * workers:
+        import multiprocessing as mp
+        chunks = [(h, w, n_frames, seed_base, dictionary, n_markers, noise_sigma, n_frames * k // workers, n_frames * (k + 1) // workers)
+                  for k in range(workers)]
+        out = np.empty((n_frames, h, w), np.uint8)
+        with mp.get_context("forkserver").Pool(workers) as pool:
+            for i0, part in pool.imap_unordered(_stream_chunk, chunks):
+                out[i0:i0 + len(part)] = part
+        return out
     margin = 0.25
     H0, W0 = int(h * (1 + 2 * margin)), int(w * (1 + 2 * margin))
     base, _ = scene(H0, W0, seed_base, dictionary, n_markers=n_markers * 2,
@@ -213,7 +231,8 @@ def stream(h, w, n_frames, seed_base, dictionary="ARUCO", n_markers=4, noise_sig
     base = base.astype(np.float64)
     out = np.empty((n_frames, h, w), np.uint8)
     ys, xs = np.meshgrid(np.arange(h) + 0.5, np.arange(w) + 0.5, indexing="ij")
-    for i in range(n_frames):
+
+    def frame(i):   # a function of (seed_base, i, n_frames) alone
         t = i / max(1, n_frames - 1)
         ang = np.deg2rad(6.0 * np.sin(2 * np.pi * t))
         sc = 1.0 + 0.06 * np.sin(2 * np.pi * t * 0.7)
@@ -236,6 +255,9 @@ def stream(h, w, n_frames, seed_base, dictionary="ARUCO", n_markers=4, noise_sig
         if noise_sigma > 0:
             val = val + rng.normal(0.0, noise_sigma, val.shape)
         out[i] = np.clip(np.rint(val), 0, 255).astype(np.uint8)
+
+    for i in (range(n_frames) if only is None else only):
+        frame(i)
     return out
 
 
