@@ -69,6 +69,8 @@ def parse():
     ap.add_argument("--launch-check", action="store_true", help="only start the ranks, count them over gloo and print n_gpus (no GPU "
                     "needed: the CPU test of the --gpus N launcher)")
     ap.add_argument("--latency", action="store_true", help="single-frame latency through the host-pointer ABI instead")
+    ap.add_argument("--from-host", action="store_true", help="frames start in page-locked HOST memory and the record sets end there: upload, "
+                    "engines and read-back overlapped by the pipeline (orbfe_pipeline_step_host); a separate metric, never the headline value")
     ap.add_argument("--out", default=None, help="also write the JSON line to this file")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
@@ -313,6 +315,58 @@ def latency_record(args, frames, calls=200):
     return out
 
 
+def from_host_mode(args):
+    """The PCIe-inclusive rate: the stream sits in page-locked host memory (4 rotating copies), every batch is uploaded by the
+    pipeline's copy stream ahead of the engines and its record set copied back behind its matching (orbfe_pipeline_step_host)."""
+    from orb_slam2_aruco_amd.pipeline import FrontEndPipeline, PinnedFrames
+    B, rows, cols = args.frames, args.rows, args.cols
+    frames_np = make_stream(args, 0)
+    pipe = FrontEndPipeline(B, rows, cols, args.nfeatures, args.nlevels, args.dictionary, marker_capacity=args.marker_capacity)
+    R = 4
+    shifts = [(r * B) // R for r in range(R)]
+    host = [PinnedFrames(np.roll(frames_np, -s, axis=0)) for s in shifts]
+    d0 = pipe.upload(frames_np)
+    pipe.warmup(d0, args.warmup)                    # resident warm-up (capacity flags, scratch sizes)
+    for r in range(R):
+        pipe.step_host(host[r])
+    pipe.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        cur = pipe.step_host(host[i % R])
+    pipe.flush()
+    t_enq = time.perf_counter() - t0
+    pipe.synchronize()
+    dt = time.perf_counter() - t0
+    st = pipe.status()
+    if any(st.values()):
+        raise SystemExit("front-end capacity exceeded: %r" % (st,))
+    rec = pipe.host_records(cur)                    # what arrived in host memory
+    matches = pipe.read_matches()
+    r_last, r_prev = (args.steps - 1) % R, (args.steps - 2) % R
+    verified = None
+    if not args.no_verify:
+        O = oracle_module()          # (puts tests/ on the path)
+        import pipeline_check  # tests/
+        fids = sorted({0, B // 2, B - 1})
+        verified = pipeline_check.check_against_oracle(O, np.roll(frames_np, -shifts[r_last], axis=0), fids, rec, matches, args.nfeatures,
+                                                       args.nlevels, args.dictionary, cols, rows, pipe.cam_K, pipe.cam_D, pairs=sorted({0, B // 2, B - 2}),
+                                                       prev_last=np.roll(frames_np, -shifts[r_prev], axis=0)[B - 1])
+    in_bytes, out_bytes = B * rows * cols, pipe.layout.nbytes
+    out = {"metric": "frames/s incl. PCIe both ways (frames from page-locked host memory, record sets back to it; %dx%d mono)" % (cols, rows),
+           "value": B * args.steps / dt, "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
+           "higher_is_better": True, "dtype": "u8", "data": "synthetic",
+           "config": {"workload": "%s from host: %d-frame %dx%d batches in page-locked memory, nFeatures=%d, %d levels, %s" % (
+               args.config, B, cols, rows, args.nfeatures, args.nlevels, args.dictionary), "host_input_copies": R,
+               "device_input_ring": 3, "record_sets": pipe.R},
+           "pcie": {"h2d_bytes_per_step": in_bytes, "d2h_bytes_per_step": out_bytes, "h2d_GBps": in_bytes * args.steps / dt / 1e9,
+                    "d2h_GBps": out_bytes * args.steps / dt / 1e9,
+                    "note": "achieved = bytes moved / wall time of the timed steps; both directions run concurrently with the engines"},
+           "host_enqueue_ms_per_step": 1000.0 * t_enq / args.steps, "verified_frames": verified}
+    print(json.dumps(out))
+    if args.out:
+        open(args.out, "w").write(json.dumps(out) + "\n")
+
+
 def fused_bytes_per_frame(level_sizes, N, rows, cols, use_orb=True, use_aruco=True):
     """SURVEY 8d's contract: the compulsory traffic of a FUSED pipeline, per frame:
     B_orb = 3 * sumP - P0 + 1321 * N,  B_aruco = 3.33 * W * H,  B_match = (Q + T) * 32 + Q * 12 (frame t vs t - 1)."""
@@ -354,8 +408,9 @@ def extra_leg(name, device, steps=5, warmup=2):
     rec, matches = pipe.read_records(cur), pipe.read_matches()
     host = frames_np if r_last == 0 else np.roll(frames_np, -(B // 2), axis=0)
     prev = (frames_np if r_last == 1 else np.roll(frames_np, -(B // 2), axis=0))[B - 1]
+    O = oracle_module()              # (puts tests/ on the path)
     import pipeline_check  # tests/
-    ver = pipeline_check.check_against_oracle(oracle_module(), host, [0, B - 1], rec, matches, a.nfeatures, a.nlevels, a.dictionary, cols, rows,
+    ver = pipeline_check.check_against_oracle(O, host, [0, B - 1], rec, matches, a.nfeatures, a.nlevels, a.dictionary, cols, rows,
                                               pipe.cam_K, pipe.cam_D, pairs=[0], prev_last=prev)
     N = float(rec["n"].mean())
     b_orb, b_aruco, b_match = fused_bytes_per_frame(pipe.ex.level_sizes(), N, rows, cols)
@@ -418,6 +473,8 @@ def main():
     args = parse()
     if args.latency:
         return latency_mode(args)
+    if args.from_host:
+        return from_host_mode(args)
     # --gpus N is the number of ranks.  Under torchrun (WORLD_SIZE set) it must agree with the launcher; without it and N > 1 this
     # process launches the N ranks itself, so that the plain command `python bench.py --gpus N` measures N GPUs.
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:

@@ -681,6 +681,15 @@ int orbfe_pipeline_layout(const orbfe_pipeline* p, orbfe_record_layout* out);
 /* One batch: d_imgs = frames x rows x pitch bytes on the pipeline's device (pitch >= cols; frames only have to stay valid until the
  * step's engines are done -- orbfe_pipeline_input_done).  *record_set = index of the set the batch is written to. */
 int orbfe_pipeline_step(orbfe_pipeline* p, const uint8_t* d_imgs, size_t pitch, int32_t* record_set);
+/* The same with the frames in HOST memory (rows of `step` bytes, frames contiguous; page-locked -- orbfe_host_alloc -- for the copy to
+ * overlap): the pipeline uploads the batch into a ring of three device buffers on a copy stream of its own, ahead of the engines,
+ * and copies every batch's record set back to page-locked host memory on a second copy stream behind the batch's post-work; both
+ * overlap with the engines of the neighbouring batches.  h_imgs must stay valid until the upload is done (orbfe_pipeline_input_done).
+ * orbfe_pipeline_host_records: the host copy of record set `set` (waits for its copy; valid until the set is written again, R steps on). */
+int orbfe_pipeline_step_host(orbfe_pipeline* p, const uint8_t* h_imgs, size_t step, int32_t* record_set);
+int orbfe_pipeline_host_records(orbfe_pipeline* p, int set, const uint8_t** h_records);
+void* orbfe_host_alloc(size_t bytes);                        /* page-locked host memory (hipHostMalloc) / NULL */
+void orbfe_host_free(void* p);
 int orbfe_pipeline_flush(orbfe_pipeline* p);                 /* enqueue the held-back post-work (matching, gather) of the newest batch */
 int orbfe_pipeline_synchronize(orbfe_pipeline* p);           /* flush + wait for everything enqueued */
 /* flush + wait until the engines of the batch written to `record_set` have read their frames (the input buffer may be reused) */

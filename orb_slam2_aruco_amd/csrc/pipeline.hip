@@ -106,6 +106,20 @@ struct orbfe_pipeline {
     long match_steps = 0, gather_steps = 0;
     long step_no = 0;
     int pending = -1;
+    // frames from host memory (orbfe_pipeline_step_host): a ring of device input buffers filled on a copy stream ahead of the engines,
+    // every record set copied back to page-locked host memory on a second copy stream behind the batch's post-work
+    static constexpr int NIN = 3;
+    bool host_mode = false;
+    hipStream_t st_h2d = nullptr, st_h2d2 = nullptr, st_d2h = nullptr;   // two upload streams: two SDMA engines (one carried 34 GB/s)
+    hipEvent_t in_ready2[NIN] = {};
+    int h2d_split = 1;
+    uint8_t* d_in[NIN] = {};
+    size_t in_pitch = 0;
+    hipEvent_t in_ready[NIN] = {}, in_used_ex[NIN] = {}, in_used_det[NIN] = {};
+    long in_uses[NIN] = {};
+    std::vector<uint8_t*> h_recs;
+    std::vector<hipEvent_t> rb_done;
+    std::vector<char> rb_valid;
     // gather
     void* comm = nullptr;
     bool own_comm = false;
@@ -124,6 +138,14 @@ struct orbfe_pipeline {
         for (auto* v : {&ex_done, &det_done, &match_done, &gather_done}) for (auto e : *v) if (e) (void)hipEventDestroy(e);
         for (auto& t : match_ev) for (auto e : t) if (e) (void)hipEventDestroy(e);
         for (auto& t : gather_ev) for (auto e : t) if (e) (void)hipEventDestroy(e);
+        for (auto b : d_in) if (b) (void)hipFree(b);
+        for (auto h : h_recs) if (h) (void)hipHostFree(h);
+        for (auto e : rb_done) if (e) (void)hipEventDestroy(e);
+        for (int k = 0; k < NIN; k++) for (hipEvent_t e : {in_ready[k], in_used_ex[k], in_used_det[k]}) if (e) (void)hipEventDestroy(e);
+        for (auto e : in_ready2) if (e) (void)hipEventDestroy(e);
+        if (st_h2d) (void)hipStreamDestroy(st_h2d);
+        if (st_h2d2) (void)hipStreamDestroy(st_h2d2);
+        if (st_d2h) (void)hipStreamDestroy(st_d2h);
         for (auto s : st_ex) if (s) (void)hipStreamDestroy(s);
         if (st_det) (void)hipStreamDestroy(st_det);
         if (st_match) (void)hipStreamDestroy(st_match);
@@ -201,6 +223,14 @@ struct orbfe_pipeline {
                                reinterpret_cast<uint32_t*>(slot_kps(nxt, 0)), reinterpret_cast<const uint32_t*>(slot_desc(cur, B)),
                                reinterpret_cast<uint32_t*>(slot_desc(nxt, 0)), slot_n(cur, B), slot_n(nxt, 0), cap);
             ORBFE_HIP(hipEventRecord(match_done[cur], st_match));
+        }
+        if (host_mode) { // the record set back to the host, behind everything that writes or reads it on the device
+            if (use_orb) ORBFE_HIP(hipStreamWaitEvent(st_d2h, match_done[cur], 0));
+            if (use_aruco) ORBFE_HIP(hipStreamWaitEvent(st_d2h, det_done[cur], 0));
+            if (comm) ORBFE_HIP(hipStreamWaitEvent(st_d2h, gather_done[cur], 0));
+            ORBFE_HIP(hipMemcpyAsync(h_recs[(size_t)cur], recs[(size_t)cur], lay.nbytes, hipMemcpyDeviceToHost, st_d2h));
+            ORBFE_HIP(hipEventRecord(rb_done[(size_t)cur], st_d2h));
+            rb_valid[(size_t)cur] = 1;
         }
         return ORBFE_OK;
     }
@@ -323,11 +353,92 @@ int orbfe_pipeline_layout(const orbfe_pipeline* p, orbfe_record_layout* out)
     return ORBFE_OK;
 }
 
+static int step_impl(orbfe_pipeline* p, const uint8_t* d_imgs, size_t pitch, int32_t* record_set, int in_slot);
+
 int orbfe_pipeline_step(orbfe_pipeline* p, const uint8_t* d_imgs, size_t pitch, int32_t* record_set)
 {
     if (!p || !d_imgs || pitch < (size_t)p->cols) return fail(ORBFE_ERR_INVALID, "orbfe_pipeline_step: invalid argument");
     int rc = use_device(p->cfg.device);
     if (rc) return rc;
+    return step_impl(p, d_imgs, pitch, record_set, -1);
+}
+
+static int host_mode_init(orbfe_pipeline* p)
+{
+    if (p->host_mode) return ORBFE_OK;
+    p->in_pitch = ((size_t)p->cols + 63) / 64 * 64;
+    if (hipStreamCreateWithFlags(&p->st_h2d, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&p->st_d2h, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&p->st_h2d2, hipStreamNonBlocking) != hipSuccess)
+        return fail(ORBFE_ERR_HIP, "orbfe_pipeline_step_host: streams");
+    p->h2d_split = env_or("ORBFE_H2D_SPLIT", 1);   // (measured: 34.3 GB/s with one upload stream, 34.2 with two -- the link, not the copy engine)
+    for (int k = 0; k < orbfe_pipeline::NIN; k++) {
+        ORBFE_HIP(hipMalloc(&p->d_in[k], (size_t)p->B * p->rows * p->in_pitch));
+        ORBFE_HIP(hipMemset(p->d_in[k], 0, (size_t)p->B * p->rows * p->in_pitch));
+        ORBFE_HIP(hipEventCreateWithFlags(&p->in_ready[k], hipEventDisableTiming));
+        ORBFE_HIP(hipEventCreateWithFlags(&p->in_ready2[k], hipEventDisableTiming));
+        ORBFE_HIP(hipEventCreateWithFlags(&p->in_used_ex[k], hipEventDisableTiming));
+        ORBFE_HIP(hipEventCreateWithFlags(&p->in_used_det[k], hipEventDisableTiming));
+    }
+    p->h_recs.assign((size_t)p->R, nullptr);
+    p->rb_done.assign((size_t)p->R, nullptr);
+    p->rb_valid.assign((size_t)p->R, 0);
+    for (int k = 0; k < p->R; k++) {
+        ORBFE_HIP(hipHostMalloc((void**)&p->h_recs[(size_t)k], p->lay.nbytes, hipHostMallocDefault));
+        ORBFE_HIP(hipEventCreateWithFlags(&p->rb_done[(size_t)k], hipEventDisableTiming));
+    }
+    p->host_mode = true;
+    return ORBFE_OK;
+}
+
+int orbfe_pipeline_step_host(orbfe_pipeline* p, const uint8_t* h_imgs, size_t step, int32_t* record_set)
+{
+    if (!p || !h_imgs || step < (size_t)p->cols) return fail(ORBFE_ERR_INVALID, "orbfe_pipeline_step_host: invalid argument");
+    int rc = use_device(p->cfg.device);
+    if (rc) return rc;
+    if ((rc = host_mode_init(p))) return rc;
+    const int slot = (int)(p->step_no % orbfe_pipeline::NIN);
+    // the slot's previous batch (NIN steps ago) must have been read by its engines
+    if (p->in_uses[slot]) {
+        if (p->use_orb) ORBFE_HIP(hipStreamWaitEvent(p->st_h2d, p->in_used_ex[slot], 0));
+        if (p->use_aruco) ORBFE_HIP(hipStreamWaitEvent(p->st_h2d, p->in_used_det[slot], 0));
+    }
+    const size_t nrows = (size_t)p->B * p->rows, half = p->h2d_split > 1 ? nrows / 2 : nrows;
+    ORBFE_HIP(hipMemcpy2DAsync(p->d_in[slot], p->in_pitch, h_imgs, step, (size_t)p->cols, half, hipMemcpyHostToDevice, p->st_h2d));
+    ORBFE_HIP(hipEventRecord(p->in_ready[slot], p->st_h2d));
+    if (half < nrows) { // the second half of the batch on the second upload stream
+        if (p->in_uses[slot]) {
+            if (p->use_orb) ORBFE_HIP(hipStreamWaitEvent(p->st_h2d2, p->in_used_ex[slot], 0));
+            if (p->use_aruco) ORBFE_HIP(hipStreamWaitEvent(p->st_h2d2, p->in_used_det[slot], 0));
+        }
+        ORBFE_HIP(hipMemcpy2DAsync(p->d_in[slot] + half * p->in_pitch, p->in_pitch, h_imgs + half * step, step, (size_t)p->cols, nrows - half, hipMemcpyHostToDevice, p->st_h2d2));
+        ORBFE_HIP(hipEventRecord(p->in_ready2[slot], p->st_h2d2));
+    }
+    p->in_uses[slot]++;
+    return step_impl(p, p->d_in[slot], p->in_pitch, record_set, slot);
+}
+
+int orbfe_pipeline_host_records(orbfe_pipeline* p, int set, const uint8_t** h_records)
+{
+    if (!p || !h_records || !p->host_mode || set < 0 || set >= p->R || !p->rb_valid[(size_t)set])
+        return fail(ORBFE_ERR_INVALID, "orbfe_pipeline_host_records: no host copy of that record set (orbfe_pipeline_step_host, then flush)");
+    int rc = use_device(p->cfg.device);
+    if (rc) return rc;
+    ORBFE_HIP(hipEventSynchronize(p->rb_done[(size_t)set]));
+    *h_records = p->h_recs[(size_t)set];
+    return ORBFE_OK;
+}
+
+void* orbfe_host_alloc(size_t bytes)
+{
+    void* q = nullptr;
+    if (hipHostMalloc(&q, bytes, hipHostMallocDefault) != hipSuccess) { fail(ORBFE_ERR_HIP, "orbfe_host_alloc: %zu bytes of page-locked memory", bytes); return nullptr; }
+    return q;
+}
+void orbfe_host_free(void* q) { if (q) (void)hipHostFree(q); }
+
+static int step_impl(orbfe_pipeline* p, const uint8_t* d_imgs, size_t pitch, int32_t* record_set, int in_slot)
+{
+    int rc;
     const long i = p->step_no++;
     const int cur = (int)(i % p->R), eset = (int)(i % p->D), B = p->B, rows = p->rows, cols = p->cols;
     const size_t fstride = (size_t)rows * pitch;
@@ -337,6 +448,8 @@ int orbfe_pipeline_step(orbfe_pipeline* p, const uint8_t* d_imgs, size_t pitch, 
         if (!p->use_aruco) return ORBFE_OK;
         // the detector only depends on the resident frames and on its own previous batch: it is not joined with the extractor per step
         if (p->comm && i >= p->R) ORBFE_HIP(hipStreamWaitEvent(p->st_det, p->gather_done[cur], 0)); // batch i - R has left this record set
+        if (p->host_mode && p->rb_valid[(size_t)cur]) ORBFE_HIP(hipStreamWaitEvent(p->st_det, p->rb_done[(size_t)cur], 0)); // ... and has been copied to the host
+        if (in_slot >= 0) { ORBFE_HIP(hipStreamWaitEvent(p->st_det, p->in_ready[in_slot], 0)); if (p->h2d_split > 1) ORBFE_HIP(hipStreamWaitEvent(p->st_det, p->in_ready2[in_slot], 0)); }
         if (p->det_pin && p->use_orb) {
             const long j = p->det_pin >= 10 ? i : i - 1; // + 10: a stage of THIS batch's extractor, which is then enqueued first
             if (j >= 0 && (rc = orbfe_extractor_stage_wait(p->ex[(size_t)(j % p->D)], p->det_pin % 10, p->st_det))) return rc;
@@ -349,6 +462,7 @@ int orbfe_pipeline_step(orbfe_pipeline* p, const uint8_t* d_imgs, size_t pitch, 
                                                   reinterpret_cast<orbfe_marker_pose*>(base + p->lay.off_poses), p->st_det)))
             return rc;
         ORBFE_HIP(hipEventRecord(p->det_done[cur], p->st_det));
+        if (in_slot >= 0) ORBFE_HIP(hipEventRecord(p->in_used_det[in_slot], p->st_det));
         return ORBFE_OK;
     };
     auto enqueue_extractor = [&]() -> int {
@@ -358,10 +472,13 @@ int orbfe_pipeline_step(orbfe_pipeline* p, const uint8_t* d_imgs, size_t pitch, 
             ORBFE_HIP(hipStreamWaitEvent(st, p->match_done[cur], 0)); // the matching of batch i - R has read this record set
             if (p->comm) ORBFE_HIP(hipStreamWaitEvent(st, p->gather_done[cur], 0));
         }
+        if (p->host_mode && p->rb_valid[(size_t)cur]) ORBFE_HIP(hipStreamWaitEvent(st, p->rb_done[(size_t)cur], 0));
+        if (in_slot >= 0) { ORBFE_HIP(hipStreamWaitEvent(st, p->in_ready[in_slot], 0)); if (p->h2d_split > 1) ORBFE_HIP(hipStreamWaitEvent(st, p->in_ready2[in_slot], 0)); }
         if ((rc = orbfe_extract_batch_device(p->ex[(size_t)eset], d_imgs, B, fstride, rows, cols, pitch, reinterpret_cast<orbfe_keypoint*>(p->slot_kps(cur, 1)),
                                              p->slot_desc(cur, 1), p->cap, p->slot_n(cur, 1), st)))
             return rc;
         ORBFE_HIP(hipEventRecord(p->ex_done[cur], st));
+        if (in_slot >= 0) ORBFE_HIP(hipEventRecord(p->in_used_ex[in_slot], st));
         return ORBFE_OK;
     };
     if (p->det_pin >= 10) { if ((rc = enqueue_extractor()) || (rc = enqueue_detector())) return rc; }
@@ -398,6 +515,7 @@ int orbfe_pipeline_synchronize(orbfe_pipeline* p)
     for (auto s : p->st_ex) ORBFE_HIP(hipStreamSynchronize(s));
     ORBFE_HIP(hipStreamSynchronize(p->st_det));
     ORBFE_HIP(hipStreamSynchronize(p->st_match));
+    if (p->host_mode) { ORBFE_HIP(hipStreamSynchronize(p->st_h2d)); ORBFE_HIP(hipStreamSynchronize(p->st_h2d2)); ORBFE_HIP(hipStreamSynchronize(p->st_d2h)); }
     return ORBFE_OK;
 }
 

@@ -151,7 +151,33 @@ def _setup(L):
     L.orbfe_pipeline_comm_init.argtypes = [vp, C.POINTER(C.c_uint8 * 128), C.c_int, C.c_int, C.c_int]
     L.orbfe_pipeline_set_comm.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int]
     L.orbfe_pipeline_gathered.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.orbfe_pipeline_step_host.argtypes = [vp, vp, C.c_size_t, i32p]
+    L.orbfe_pipeline_host_records.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.orbfe_host_alloc.argtypes = [C.c_size_t]
+    L.orbfe_host_alloc.restype = vp
+    L.orbfe_host_free.argtypes = [vp]
+    L.orbfe_host_free.restype = None
     L._pipeline_ready = True
+
+
+class PinnedFrames:
+    """A batch of frames in page-locked host memory (orbfe_host_alloc): .array is the (B, rows, cols) uint8 view."""
+
+    def __init__(self, frames_u8):
+        self.L = binding.load()
+        _setup(self.L)
+        f = np.ascontiguousarray(frames_u8, np.uint8)
+        self.ptr = self.L.orbfe_host_alloc(f.nbytes)
+        if not self.ptr:
+            raise binding.OrbfeError("orbfe_host_alloc: " + self.L.orbfe_last_error().decode())
+        self.array = np.ctypeslib.as_array((C.c_uint8 * f.nbytes).from_address(self.ptr)).reshape(f.shape)
+        self.array[...] = f
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            self.array = None
+            self.L.orbfe_host_free(self.ptr)
+            self.ptr = None
 
 
 def env_defaults():
@@ -243,6 +269,22 @@ class FrontEndPipeline:
     def step(self, d_imgs):
         """Enqueue one batch; returns the record set it writes."""
         return self.step_ptr(d_imgs.data_ptr())
+
+    def step_host(self, pinned):
+        """Enqueue one batch whose frames are in host memory (a PinnedFrames, or any C-contiguous (B, rows, cols) uint8 array): the
+        pipeline uploads it on its own copy stream and copies the record set back (host_records)."""
+        arr = pinned.array if isinstance(pinned, PinnedFrames) else pinned
+        cur = C.c_int32(0)
+        binding._check(self.L, self.L.orbfe_pipeline_step_host(self.h, C.c_void_p(arr.ctypes.data), arr.strides[1], C.byref(cur)), "orbfe_pipeline_step_host")
+        self.step_no += 1
+        return cur.value
+
+    def host_records(self, cur):
+        """The host copy of record set `cur` (after step_host + flush; waits for its copy), unpacked."""
+        p = C.c_void_p()
+        binding._check(self.L, self.L.orbfe_pipeline_host_records(self.h, cur, C.byref(p)), "orbfe_pipeline_host_records")
+        buf = np.ctypeslib.as_array((C.c_uint8 * self.layout.nbytes).from_address(p.value))
+        return self.layout.unpack(buf.copy())
 
     def flush(self):
         binding._check(self.L, self.L.orbfe_pipeline_flush(self.h), "orbfe_pipeline_flush")

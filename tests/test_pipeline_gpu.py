@@ -164,3 +164,19 @@ def test_pipeline_from_cpp_without_python(tmp_path, force_gather):
     assert int(got["halo_n"][0]) == int(rec["halo_n"][0]) == int(rec["n"][B - 1]) > 0      # the stream went on: the previous step's last frame
     assert np.array_equal(got_nm, nm) and nm[0] > 0 and nm[1:].sum() > 0
     assert "keypoints %d " % int(rec["n"].sum()) in r.stdout
+
+
+@pytest.mark.gpu
+def test_bench_from_host_overlaps_upload_and_readback(tmp_path):
+    """bench.py --from-host: the frames start in page-locked host memory and the record sets end there (orbfe_pipeline_step_host: a ring
+    of device input buffers on a copy stream, read-back on another); the records that arrived on the host are checked against the
+    oracle, incl. the pair across the batch boundary."""
+    import json
+    out = tmp_path / "fh.json"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--from-host", "--frames", "24", "--steps", "7", "--warmup", "1",
+                        "--out", str(out)], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads(out.read_text())
+    assert d["value"] > 0 and d["pcie"]["h2d_GBps"] > 0 and d["pcie"]["d2h_GBps"] > 0
+    v = d["verified_frames"]
+    assert v["frames"] == [0, 12, 23] and v["pairs"] == [0, 12, 22] and v["boundary_pair_checked"] and v["keypoints_checked"] > 2500
