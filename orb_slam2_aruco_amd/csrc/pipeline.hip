@@ -93,8 +93,9 @@ struct orbfe_pipeline {
     int phase_pin = 0, det_pin = 0;
     bool defer_post = false, det_nofork = false, use_orb = true, use_aruco = true;
     std::vector<orbfe_extractor*> ex;
-    orbfe_aruco* det = nullptr;
-    std::vector<hipStream_t> st_ex;
+    orbfe_aruco* det = nullptr;               // detector of engine set 0 (= dets[0])
+    std::vector<orbfe_aruco*> dets;           // ORBFE_ENGINE_SETS_ARUCO detector sets alternate batches (measurement switch; default 1)
+    std::vector<hipStream_t> st_ex, st_dets;
     hipStream_t st_det = nullptr, st_match = nullptr;
     orbfe_record_layout lay{};
     std::vector<uint8_t*> recs;
@@ -132,7 +133,8 @@ struct orbfe_pipeline {
         (void)hipDeviceSynchronize();
         if (own_comm && comm) { if (Rccl* R_ = rccl()) (void)R_->CommDestroy(comm); }
         for (auto e : ex) if (e) orbfe_extractor_destroy(e);
-        if (det) orbfe_aruco_destroy(det);
+        for (auto d : dets) if (d) orbfe_aruco_destroy(d);
+        for (size_t k = 1; k < st_dets.size(); k++) if (st_dets[k]) (void)hipStreamDestroy(st_dets[k]);
         for (auto r : recs) if (r) (void)hipFree(r);
         for (void* p : {(void*)d_bidx, (void*)d_bdist, (void*)d_sdist, (void*)d_m12, (void*)d_nm, (void*)blocks}) if (p) (void)hipFree(p);
         for (auto* v : {&ex_done, &det_done, &match_done, &gather_done}) for (auto e : *v) if (e) (void)hipEventDestroy(e);
@@ -239,7 +241,7 @@ struct orbfe_pipeline {
 const char* orbfe_pipeline_env_defaults(void)
 {
     // one list for the pipeline and the engines: bench.py marks a line as diagnostic when one of these is set to something else
-    return "ORBFE_ENGINE_SETS=size;ORBFE_RECORD_SETS=4;ORBFE_PHASE_PIN=2;ORBFE_DET_PIN=4;ORBFE_DEFER_POST=size;ORBFE_DET_NOFORK=size;"
+    return "ORBFE_ENGINE_SETS=size;ORBFE_ENGINE_SETS_ARUCO=1;ORBFE_RECORD_SETS=4;ORBFE_PHASE_PIN=2;ORBFE_DET_PIN=4;ORBFE_DEFER_POST=size;ORBFE_DET_NOFORK=size;"
            "ORBFE_ORIENT_PAIR=1;ORBFE_FAST0=0;ORBFE_ARUCO_VIS=0;ORBFE_ARUCO_FORCE_GLOBAL=0;ORBFE_ARUCO_RELAY_CHUNK=0;ORBFE_ARUCO_RELAY_WIDE=1;"
            "ORBFE_ARUCO_SMALL_SEPARATE=size;ORBFE_ARUCO_TILED=size;ORBFE_ARUCO_TILE_W=0;ORBFE_ARUCO_TPW=0;ORBFE_GRAPH=0;"
            "ORBFE_OCC_FAST=0;ORBFE_OCC_BLUR=0;ORBFE_OCC_ORIENT=0;ORBFE_BLUR_PLACE=1";
@@ -312,10 +314,18 @@ orbfe_pipeline* orbfe_pipeline_create(const orbfe_pipeline_config* cfg)
     } else
         p->cap = 1;
     if (p->use_aruco) {
-        p->det = orbfe_aruco_create(p->cfg.dictionary, cfg->device);
-        if (!p->det) return nullptr;
+        const int DA = std::max(1, env_or("ORBFE_ENGINE_SETS_ARUCO", 1));
+        for (int d = 0; d < DA; d++) {
+            orbfe_aruco* a = orbfe_aruco_create(p->cfg.dictionary, cfg->device);
+            if (!a) return nullptr;
+            p->dets.push_back(a);
+            hipStream_t sd = p->st_det;
+            if (d > 0 && !mkstream(&sd)) return bail("stream");
+            p->st_dets.push_back(sd);
+            if (p->det_nofork) orbfe_aruco_set_aux_stream(a, sd);
+        }
+        p->det = p->dets[0];
         p->mcap = std::min(orbfe_aruco_max_markers(p->det), std::max(1, cfg->marker_capacity));
-        if (p->det_nofork) orbfe_aruco_set_aux_stream(p->det, p->st_det);
     }
     orbfe_record_layout& L = p->lay;
     L.frames = B; L.capacity = p->cap; L.marker_capacity = p->mcap; L.halo = 1;
@@ -446,23 +456,26 @@ static int step_impl(orbfe_pipeline* p, const uint8_t* d_imgs, size_t pitch, int
     if (record_set) *record_set = cur;
     auto enqueue_detector = [&]() -> int {
         if (!p->use_aruco) return ORBFE_OK;
+        const size_t aset = (size_t)(i % (long)p->dets.size());
+        orbfe_aruco* det_i = p->dets[aset];
+        hipStream_t st_det_i = p->st_dets[aset];
         // the detector only depends on the resident frames and on its own previous batch: it is not joined with the extractor per step
-        if (p->comm && i >= p->R) ORBFE_HIP(hipStreamWaitEvent(p->st_det, p->gather_done[cur], 0)); // batch i - R has left this record set
-        if (p->host_mode && p->rb_valid[(size_t)cur]) ORBFE_HIP(hipStreamWaitEvent(p->st_det, p->rb_done[(size_t)cur], 0)); // ... and has been copied to the host
-        if (in_slot >= 0) { ORBFE_HIP(hipStreamWaitEvent(p->st_det, p->in_ready[in_slot], 0)); if (p->h2d_split > 1) ORBFE_HIP(hipStreamWaitEvent(p->st_det, p->in_ready2[in_slot], 0)); }
+        if (p->comm && i >= p->R) ORBFE_HIP(hipStreamWaitEvent(st_det_i, p->gather_done[cur], 0)); // batch i - R has left this record set
+        if (p->host_mode && p->rb_valid[(size_t)cur]) ORBFE_HIP(hipStreamWaitEvent(st_det_i, p->rb_done[(size_t)cur], 0)); // ... and has been copied to the host
+        if (in_slot >= 0) { ORBFE_HIP(hipStreamWaitEvent(st_det_i, p->in_ready[in_slot], 0)); if (p->h2d_split > 1) ORBFE_HIP(hipStreamWaitEvent(st_det_i, p->in_ready2[in_slot], 0)); }
         if (p->det_pin && p->use_orb) {
             const long j = p->det_pin >= 10 ? i : i - 1; // + 10: a stage of THIS batch's extractor, which is then enqueued first
-            if (j >= 0 && (rc = orbfe_extractor_stage_wait(p->ex[(size_t)(j % p->D)], p->det_pin % 10, p->st_det))) return rc;
+            if (j >= 0 && (rc = orbfe_extractor_stage_wait(p->ex[(size_t)(j % p->D)], p->det_pin % 10, st_det_i))) return rc;
         }
         orbfe_marker* mk = reinterpret_cast<orbfe_marker*>(base + p->lay.off_markers);
         int32_t* nmk = reinterpret_cast<int32_t*>(base + p->lay.off_nmarkers);
-        if ((rc = orbfe_aruco_detect_batch_device(p->det, d_imgs, B, fstride, rows, cols, pitch, mk, p->mcap, nmk, p->st_det))) return rc;
+        if ((rc = orbfe_aruco_detect_batch_device(det_i, d_imgs, B, fstride, rows, cols, pitch, mk, p->mcap, nmk, st_det_i))) return rc;
         // detect(image, CameraParameters, 0.187): every marker gets its IPPE pose (markerdetector_impl.cpp:8720-8780)
         if ((rc = orbfe_marker_poses_batch_device(mk, nmk, p->mcap, B, p->cfg.marker_size, p->cfg.K, p->cfg.dist, p->cfg.ndist,
-                                                  reinterpret_cast<orbfe_marker_pose*>(base + p->lay.off_poses), p->st_det)))
+                                                  reinterpret_cast<orbfe_marker_pose*>(base + p->lay.off_poses), st_det_i)))
             return rc;
-        ORBFE_HIP(hipEventRecord(p->det_done[cur], p->st_det));
-        if (in_slot >= 0) ORBFE_HIP(hipEventRecord(p->in_used_det[in_slot], p->st_det));
+        ORBFE_HIP(hipEventRecord(p->det_done[cur], st_det_i));
+        if (in_slot >= 0) ORBFE_HIP(hipEventRecord(p->in_used_det[in_slot], st_det_i));
         return ORBFE_OK;
     };
     auto enqueue_extractor = [&]() -> int {
@@ -514,6 +527,7 @@ int orbfe_pipeline_synchronize(orbfe_pipeline* p)
     if (rc) return rc;
     for (auto s : p->st_ex) ORBFE_HIP(hipStreamSynchronize(s));
     ORBFE_HIP(hipStreamSynchronize(p->st_det));
+    for (auto sd : p->st_dets) ORBFE_HIP(hipStreamSynchronize(sd));
     ORBFE_HIP(hipStreamSynchronize(p->st_match));
     if (p->host_mode) { ORBFE_HIP(hipStreamSynchronize(p->st_h2d)); ORBFE_HIP(hipStreamSynchronize(p->st_h2d2)); ORBFE_HIP(hipStreamSynchronize(p->st_d2h)); }
     return ORBFE_OK;
@@ -546,10 +560,10 @@ int orbfe_pipeline_status(orbfe_pipeline* p, int32_t out[4])
         if (rc && rc != ORBFE_ERR_CAPACITY) return rc;
         out[1] = o;
     }
-    if (p->det) {
+    for (auto d : p->dets) {
         int32_t n = 0, fl = 0;
-        if ((rc = orbfe_aruco_batch_status(p->det, &n, &fl))) return rc;
-        out[2] = n; out[3] = fl;
+        if ((rc = orbfe_aruco_batch_status(d, &n, &fl))) return rc;
+        out[2] += n; out[3] |= fl;
     }
     return ORBFE_OK;
 }
@@ -557,7 +571,8 @@ int orbfe_pipeline_status(orbfe_pipeline* p, int32_t out[4])
 int orbfe_pipeline_set_big_frames(orbfe_pipeline* p, int on)
 {
     if (!p) return fail(ORBFE_ERR_INVALID, "null handle");
-    return p->det ? orbfe_aruco_set_big_frames(p->det, on) : ORBFE_OK;
+    for (auto d : p->dets) { int rc = orbfe_aruco_set_big_frames(d, on); if (rc) return rc; }
+    return ORBFE_OK;
 }
 
 int orbfe_pipeline_records(orbfe_pipeline* p, int set, uint8_t** d_records)
