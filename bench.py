@@ -377,7 +377,7 @@ def fused_bytes_per_frame(level_sizes, N, rows, cols, use_orb=True, use_aruco=Tr
     return b_orb, b_aruco, b_match
 
 
-def extra_leg(name, device, steps=5, warmup=2):
+def extra_leg(name, device, steps=10, warmup=3):
     """A short leg of another BASELINE configuration after the clock of the default run (the driver's record should
     carry C3 and C5 too): the configuration's full batch when the box has the cores to render its stream in seconds, else a reduced
     one (said in the record); ms per step, frames/s, the fused-bytes fraction of the HBM peak, two frames + a pair against the oracle."""

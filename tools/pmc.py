@@ -14,6 +14,8 @@ GROUPS = [
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "gpurun_out", "pmc")
 args = sys.argv[1:]
+import shutil
+shutil.rmtree(out, ignore_errors=True)      # rocprofv3 adds a directory per run: counters of an earlier configuration must not be averaged in
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 env = dict(os.environ, TMPDIR="/tmp")
 for gi, grp in enumerate(GROUPS):
