@@ -82,3 +82,21 @@ def test_host_scalar_helpers_need_no_device():
     ok = lambda y2, s2: L.orbfe_epipolar_distance_ok(10.0, 20.0, 55.0, y2, F.ctypes.data_as(vp), s2)
     assert ok(20.0, 1.0) == 1 and ok(21.9, 1.0) == 1 and ok(22.0, 1.0) == 0 and ok(23.0, 1.44) == 0 and ok(22.3, 1.44) == 1
     assert L.orbfe_epipolar_distance_ok(1.0, 2.0, 3.0, 4.0, np.zeros(9, np.float32).ctypes.data_as(vp), 1.0) == 0   # den == 0
+
+
+def test_every_environment_switch_of_the_library_is_in_its_own_list():
+    """bench.py decides from orbfe_pipeline_env_defaults() whether an ORBFE_* variable makes its line a diagnostic; the list is kept
+    next to the getenv calls, and this test keeps the two from drifting apart."""
+    import ctypes as C
+    from orb_slam2_aruco_amd import binding
+    L = binding.load()
+    L.orbfe_pipeline_env_defaults.restype = C.c_char_p
+    listed = {kv.split("=")[0] for kv in L.orbfe_pipeline_env_defaults().decode().split(";") if kv}
+    read = set()
+    csrc = os.path.join(ROOT, "orb_slam2_aruco_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".hpp")):
+            txt = open(os.path.join(csrc, f)).read()
+            read |= set(re.findall(r'(?:getenv|env_int|env_or|pick)\((?:[^"()]*,\s*)?"(ORBFE_[A-Z0-9_]+)"', txt))
+    assert read, "no getenv calls found: the pattern is stale"
+    assert read <= listed, sorted(read - listed)
