@@ -377,50 +377,28 @@ def fused_bytes_per_frame(level_sizes, N, rows, cols, use_orb=True, use_aruco=Tr
     return b_orb, b_aruco, b_match
 
 
-def extra_leg(name, device, steps=10, warmup=3):
+def extra_leg(name, steps=10):
     """A short leg of another BASELINE configuration after the clock of the default run (the driver's record should
-    carry C3 and C5 too): the configuration's full batch when the box has the cores to render its stream in seconds, else a reduced
-    one (said in the record); ms per step, frames/s, the fused-bytes fraction of the HBM peak, two frames + a pair against the oracle."""
-    from orb_slam2_aruco_amd.pipeline import FrontEndPipeline
-    cfg = dict(CONFIGS[name])
+    carry C3 and C5 too): bench.py itself on that configuration in a process of its own -- in this one a dozen HIP streams have come
+    and gone, and new pipelines were measured 10 - 25 % slower (hardware queue assignment) --, its full batch when the box has the
+    cores to render the stream in seconds, else a reduced one (said in the record)."""
+    import subprocess
+    import tempfile
     full = (os.cpu_count() or 1) >= 32
+    cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--steps", str(steps), "--cpu-frames", "0", "--no-extras"]
     if not full:
-        cfg["frames"] = {"C3": 96, "C5": 32}.get(name, cfg["frames"])
-    a = argparse.Namespace(**cfg)
-    t0 = time.perf_counter()
-    frames_np = make_stream(a, 0)
-    t_stream = time.perf_counter() - t0
-    B, rows, cols = a.frames, a.rows, a.cols
-    pipe = FrontEndPipeline(B, rows, cols, a.nfeatures, a.nlevels, a.dictionary, device=device)
-    batches = [pipe.upload(frames_np), pipe.upload(np.roll(frames_np, -(B // 2), axis=0))]
-    pipe.warmup(batches[0], warmup)
-    pipe.step(batches[1])
-    pipe.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        cur = pipe.step(batches[i % 2])
-    pipe.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    st = pipe.status()
-    if any(st.values()):
-        return {"workload": name, "error": "capacity flags %r" % (st,)}
-    r_last = (steps - 1) % 2
-    rec, matches = pipe.read_records(cur), pipe.read_matches()
-    host = frames_np if r_last == 0 else np.roll(frames_np, -(B // 2), axis=0)
-    prev = (frames_np if r_last == 1 else np.roll(frames_np, -(B // 2), axis=0))[B - 1]
-    O = oracle_module()              # (puts tests/ on the path)
-    import pipeline_check  # tests/
-    ver = pipeline_check.check_against_oracle(O, host, [0, B - 1], rec, matches, a.nfeatures, a.nlevels, a.dictionary, cols, rows,
-                                              pipe.cam_K, pipe.cam_D, pairs=[0], prev_last=prev)
-    N = float(rec["n"].mean())
-    b_orb, b_aruco, b_match = fused_bytes_per_frame(pipe.ex.level_sizes(), N, rows, cols)
-    fused = (b_orb + b_aruco) * B
-    return {"workload": "%s%s: %d-frame %dx%d stream, nFeatures=%d, %d levels, %s" % (name, "" if full else " at a reduced batch", B, cols, rows, a.nfeatures,
-                                                                                 a.nlevels, a.dictionary),
-            "full_batch": full, "frames_per_step": B, "steps": steps, "ms_per_step": 1000.0 * dt, "frames_per_s": B / dt,
-            "fused": {"algorithmic_bytes_per_step": fused, "GBps": fused / dt / 1e9, "frac": fused / dt / 1e9 / HBM_PEAK_GBPS},
-            "mean_keypoints_per_frame": N, "verified_frames": ver, "aruco_big_frame_kernel": pipe.big_frames,
-            "stream_render_s": t_stream}
+        cmd += ["--frames", str({"C3": 96, "C5": 32}[name])]
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "leg.json")
+        r = subprocess.run(cmd + ["--out", out], capture_output=True, text=True, timeout=600)
+        if r.returncode != 0 or not os.path.exists(out):
+            return {"workload": name, "error": (r.stderr or r.stdout)[-400:]}
+        d = json.load(open(out))
+    return {"workload": d["config"]["workload"], "full_batch": full, "frames_per_step": d["config"]["frames_per_step_per_gpu"], "steps": d["steps"],
+            "ms_per_step": d["ms_per_step"], "frames_per_s": d["value"] if d["value"] else d.get("diagnostic_frames_per_s"),
+            "fused": d["roofline"]["step"]["fused"] if d.get("roofline") else None, "verified_frames": d["verified_frames"],
+            "mean_keypoints_per_frame": d["config"]["mean_keypoints_per_frame"], "aruco_big_frame_kernel": d["config"]["aruco_big_frame_kernel"],
+            "c5_match": d.get("c5_match")}
 
 
 def free_port():
@@ -870,7 +848,7 @@ def main():
                 extras["latency"] = {"error": repr(e)}
             for leg in ("C3", "C5"):
                 try:
-                    extras[leg] = extra_leg(leg, local_rank)
+                    extras[leg] = extra_leg(leg)
                 except Exception as e:
                     extras[leg] = {"workload": leg, "error": repr(e)}
             out["extras"] = extras
