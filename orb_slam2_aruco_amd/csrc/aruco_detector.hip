@@ -86,6 +86,11 @@ struct orbfe_aruco {
     int tiled = getenv("ORBFE_ARUCO_TILED") ? (atoi(getenv("ORBFE_ARUCO_TILED")) ? 1 : 0) : -1;
     bool tiled_off = false;    // set while a batch is redone by the relay kernels
     bool tiled_ran = false;    // the last batch took the tiled path
+    // the walks of the tiled path by BANDS of cell rows, a workgroup of eight waves each (k_ct_band), instead of a wave per tile
+    // (k_ct_walk): -1 = by frame / batch size, 0 / 1 forced; ORBFE_ARUCO_BAND_ROWS = cell rows per band (0: what fits ~44 KB of LDS, at most 8)
+    int banded = getenv("ORBFE_ARUCO_BANDED") ? (atoi(getenv("ORBFE_ARUCO_BANDED")) ? 1 : 0) : -1;
+    int band_rows_env = getenv("ORBFE_ARUCO_BAND_ROWS") ? atoi(getenv("ORBFE_ARUCO_BAND_ROWS")) : 0;
+    DevBuf d_ctmlist;
     int tile_w_env = getenv("ORBFE_ARUCO_TILE_W") ? atoi(getenv("ORBFE_ARUCO_TILE_W")) : 0;
     int tpw_env = getenv("ORBFE_ARUCO_TPW") ? atoi(getenv("ORBFE_ARUCO_TPW")) : 0;
     int ct_segcap = 0, ct_hbits = 0, ct_lcap = 0, ct_items_per_frame = 0, ct_tiles_max = 0;
@@ -142,7 +147,7 @@ struct orbfe_aruco {
     {
         for (DevBuf* b : {&d_codes, &d_levels, &d_tabs, &d_bits, &d_pyr, &d_candq, &d_pool, &d_kept, &d_rects,
                           &d_counts, &d_candidx, &d_ncand, &d_result, &d_gpad, &d_in, &d_out, &d_nout, &d_segs, &d_tailkeys, &d_tailoff, &d_small, &d_hint, &d_rstate, &d_lut, &d_twork, &d_trect, &d_tctr, &d_dwork, &d_dctr, &d_ditems, &d_dhist, &d_dpatch, &d_vis, &d_poses, &d_scodes, &d_sids,
-                          &d_msrc, &d_red, &d_mhist, &d_masks, &d_bgr, &d_bits2, &d_ctseg, &d_cthtab, &d_ctelem, &d_ctstate, &d_ctitemsA, &d_ctitemsB, &d_cttiles})
+                          &d_msrc, &d_red, &d_mhist, &d_masks, &d_bgr, &d_bits2, &d_ctseg, &d_cthtab, &d_ctelem, &d_ctstate, &d_ctitemsA, &d_ctitemsB, &d_cttiles, &d_ctmlist})
             b->release();
         if (own_stream) (void)hipStreamDestroy(own_stream);
         if (aux_stream) (void)hipStreamDestroy(aux_stream);
@@ -345,7 +350,8 @@ struct orbfe_aruco {
             if ((rc = d_ctseg.ensure((size_t)5 * ct_segcap * 4 * B)) || (rc = d_cthtab.ensure(((size_t)8 << ct_hbits) * B)) ||
                 (rc = d_ctelem.ensure(elem_words * 8 * B)) || (rc = d_ctstate.ensure((size_t)CT_STATE_INTS * 4 * B)) ||
                 (rc = d_ctitemsA.ensure((size_t)ct_items_per_frame * 16 * B)) || (rc = d_ctitemsB.ensure((size_t)ct_items_per_frame * 8 * B)) ||
-                (rc = d_cttiles.ensure((size_t)ct_tiles_max * 8 * B)))
+                (rc = d_cttiles.ensure((size_t)ct_tiles_max * 8 * B)) ||
+                (rc = d_ctmlist.ensure((size_t)CTB_MCAP * 4 * ((rows + 31) / 32) * B)))   // (one list per band; at most one band per cell row)
                 return rc;
             ct_dirty = true;
         }
@@ -500,6 +506,19 @@ struct orbfe_aruco {
                     ORBFE_HIP(hipMemsetAsync(d_cthtab.p, 0, ((size_t)8 << ct_hbits) * B, s));
                 }
                 ct_dirty = true;
+                const bool use_band = banded > 0 || (banded < 0 && B > 32);
+                if (use_band) {
+                    const int pw = (cols + 2 + 31) / 32, crows = (rows + 31) / 32;
+                    int rb = band_rows_env > 0 ? band_rows_env : std::max(1, std::min(8, (int)((44 * 1024 / (pw * 4) - 3) / 32)));
+                    rb = std::max(1, std::min(rb, crows));
+                    const int nb = (crows + rb - 1) / rb;
+                    const size_t blds = ctb_lds_bytes(cols, rb);
+                    { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(k_ct_band), blds); if (rc_lds_) return rc_lds_; }
+                    hipLaunchKernelGGL(k_ct_band, dim3(nb, B), dim3(CTB_THREADS), blds, s, d_bits.as<uint32_t>(), bits_fu32, wpr, cols, rows, 70,
+                                       d_lut.as<uint16_t>(), rb, cw, ncols, d_ctmlist.as<uint32_t>(), CTB_MCAP, d_cthtab.as<unsigned long long>(), ct_hbits,
+                                       d_ctseg.as<uint32_t>(), (size_t)5 * ct_segcap, ct_segcap, d_ctstate.as<int32_t>(), d_pool.as<uint32_t>(), pool_fu32,
+                                       (int)pool_fu32, relay_kcap, d_tailkeys.as<unsigned long long>(), d_tailoff.as<int32_t>());
+                } else
                 hipLaunchKernelGGL(k_ct_walk, dim3(walk_wgs), dim3(CTW_THREADS), wlds, s, d_bits.as<uint32_t>(), bits_fu32, wpr, cols, rows, 70,
                                    d_lut.as<uint16_t>(), cw, ncols, nbands, total_tiles, d_cthtab.as<unsigned long long>(), ct_hbits,
                                    d_ctseg.as<uint32_t>(), (size_t)5 * ct_segcap, ct_segcap, d_ctstate.as<int32_t>(), d_pool.as<uint32_t>(), pool_fu32,

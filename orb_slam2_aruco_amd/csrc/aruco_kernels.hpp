@@ -183,6 +183,15 @@ __global__ void k_upsample_corners(ImgView src0, ImgView pyr, const ArLevel* lev
 #define CTW_MAX_CW 480           // tile width limit: the marker pixels of all relay columns of a tile (31 x (cw / 32 + 1)) fit the queue
 #define CT_STATE_INTS 8          // per frame: segments, kept small borders, pool words in use, flags, start candidates
 #define CTL_THREADS 1024
+#define CTB_THREADS 512          // k_ct_band: eight waves per band
+#define CTB_MCAP 8192            // marker pixels per (frame, band) its list holds
+#ifndef CTB_STEPS
+#define CTB_STEPS 2
+#endif
+inline size_t ctb_lds_bytes(int W, int rb) { return ((size_t)((W + 2 + 31) >> 5) * (32 * rb + 3) + 2) * 4 + 16; }   // the band's rows of the padded bit image
+__global__ void k_ct_band(const uint32_t* gbits, size_t bits_fstride, int wpr_g, int W, int H, int min_len, const uint16_t* lut_g, int rb, int cw_p,
+                          int ncols_p, uint32_t* mlist, int mcap, unsigned long long* htab, int hbits, uint32_t* seg, size_t seg_fstride, int segcap,
+                          int32_t* ctstate, uint32_t* pool, size_t pool_fstride, int pool_cap, int kcap, unsigned long long* tail_keys, int32_t* tail_off);
 inline int ctw_wave_lds_bytes(int cw) { return (2 * (CTW_ROWS * ((cw >> 5) + 2) + 2) * 4 + CTW_QCAP * 2 + CTW_FCAP * 24 + 15) & ~15; }   // two tile slots, queue, finished segments
 inline int ctp_wave_lds_bytes(int cw) { return ((CTW_ROWS * ((cw >> 5) + 2) + 2) * 4 + 15) & ~15; }                                           // k_ct_points: one tile
 __global__ void k_ct_walk(const uint32_t* gbits, size_t bits_fstride, int wpr_g, int W, int H, int min_len, const uint16_t* lut_g, int cw, int ncols,

@@ -386,15 +386,20 @@ def test_small_border_phase_inside_and_outside_the_relay_kernel(mode):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("mode,tile_w,tpw", [("0", "0", "0"), ("1", "0", "0"), ("1", "64", "4"), ("1", "480", "1")])
-def test_tiled_and_one_workgroup_contour_paths(mode, tile_w, tpw):
+@pytest.mark.parametrize("mode,tile_w,tpw,banded,band_rows", [("0", "0", "0", "0", "0"), ("1", "0", "0", "0", "0"), ("1", "64", "4", "0", "0"),
+                                                              ("1", "480", "1", "0", "0"), ("1", "0", "0", "1", "0"), ("1", "96", "0", "1", "1"),
+                                                              ("1", "0", "0", "1", "3")])
+def test_tiled_and_one_workgroup_contour_paths(mode, tile_w, tpw, banded, band_rows):
     """The contour stage has two formulations of the same relay segments: one workgroup per frame out of one LDS image
     (k_contours_relay*: what full batches of frames up to 1280 x 720 run) and tiles of whole grid cells, a wave each
     (aruco_tiles.hip: 1920 x 1080 and batches of up to 32 frames by default).  ORBFE_ARUCO_TILED=0 / 1 forces one or the other for
     every batch; narrow tiles with four tiles per wave (the waves are persistent and overlap their tiles) and the widest tiles are run
-    too.  The contour, detector-mode and full-HD tests must pass every way."""
+    too, and the walks by bands of cell rows, a workgroup each (k_ct_band: what full batches of the tiled path run), with the default
+    band height, with one cell row per band (every relay row is a band boundary) and with three.  The contour, detector-mode and
+    full-HD tests must pass every way."""
     import os, subprocess, sys
-    env = dict(os.environ, ORBFE_ARUCO_TILED=mode, ORBFE_ARUCO_TILE_W=tile_w, ORBFE_ARUCO_TPW=tpw)
+    env = dict(os.environ, ORBFE_ARUCO_TILED=mode, ORBFE_ARUCO_TILE_W=tile_w, ORBFE_ARUCO_TPW=tpw, ORBFE_ARUCO_BANDED=banded,
+               ORBFE_ARUCO_BAND_ROWS=band_rows)
     here = os.path.abspath(__file__)
     r = subprocess.run([sys.executable, "-m", "pytest", here, os.path.join(os.path.dirname(here), "test_aruco_modes_gpu.py"), "-q", "-x", "-k",
                         "structured_binary or relay_and_legacy or dense_frame or detect_matches_oracle or lds_boundary or tail_kernel or full_hd "
