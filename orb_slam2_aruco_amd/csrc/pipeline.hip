@@ -241,7 +241,7 @@ struct orbfe_pipeline {
 const char* orbfe_pipeline_env_defaults(void)
 {
     // one list for the pipeline and the engines: bench.py marks a line as diagnostic when one of these is set to something else
-    return "ORBFE_ENGINE_SETS=size;ORBFE_ENGINE_SETS_ARUCO=1;ORBFE_RECORD_SETS=4;ORBFE_PHASE_PIN=2;ORBFE_DET_PIN=4;ORBFE_DEFER_POST=size;ORBFE_DET_NOFORK=size;"
+    return "ORBFE_ENGINE_SETS=2;ORBFE_ENGINE_SETS_ARUCO=1;ORBFE_RECORD_SETS=4;ORBFE_PHASE_PIN=2;ORBFE_DET_PIN=4;ORBFE_DEFER_POST=size;ORBFE_DET_NOFORK=size;"
            "ORBFE_ORIENT_PAIR=1;ORBFE_FAST0=0;ORBFE_ARUCO_VIS=0;ORBFE_ARUCO_FORCE_GLOBAL=0;ORBFE_ARUCO_RELAY_CHUNK=0;ORBFE_ARUCO_RELAY_WIDE=1;"
            "ORBFE_ARUCO_SMALL_SEPARATE=size;ORBFE_ARUCO_TILED=size;ORBFE_ARUCO_TILE_W=0;ORBFE_ARUCO_TPW=0;ORBFE_ARUCO_BANDED=size;ORBFE_ARUCO_BAND_ROWS=0;ORBFE_GRAPH=0;"
            "ORBFE_OCC_FAST=0;ORBFE_OCC_BLUR=0;ORBFE_OCC_ORIENT=0;ORBFE_BLUR_PLACE=1;ORBFE_NO_LEND=0;ORBFE_H2D_SPLIT=1;ORBFE_GRAPH_VERBOSE=0";
@@ -281,8 +281,9 @@ orbfe_pipeline* orbfe_pipeline_create(const orbfe_pipeline_config* cfg)
     const bool vga = (size_t)rows * cols <= (size_t)640 * 480;
     // defaults by frame size, each overridable by the configuration and, for measurements, by the environment
     auto pick = [&](int cfgv, const char* env, int dflt) { return env_or(env, cfgv >= 0 ? cfgv : dflt); };
-    // two extractor sets up to 1280 x 720 (1.4955 against 1.5288 ms per C2 step; 1920 x 1080 loses: 4.84 -> 5.00)
-    p->D = std::max(1, pick(cfg->engine_sets, "ORBFE_ENGINE_SETS", (size_t)rows * cols <= (size_t)1280 * 720 ? 2 : 1));
+    // two extractor sets (1.4955 against 1.5288 ms per C2 step in round 3; 1920 x 1080 lost then, 4.84 -> 5.00, while its contour
+    // stage held whole CUs -- with the banded contour kernels it gains: 3.58 against 3.64 ms, three interleaved runs each)
+    p->D = std::max(1, pick(cfg->engine_sets, "ORBFE_ENGINE_SETS", 2));
     if (!p->use_orb) p->D = 1;
     p->R = std::max(2, pick(cfg->record_sets, "ORBFE_RECORD_SETS", 4));
     p->phase_pin = pick(cfg->phase_pin, "ORBFE_PHASE_PIN", 2);
