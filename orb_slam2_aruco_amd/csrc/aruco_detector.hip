@@ -94,7 +94,9 @@ struct orbfe_aruco {
     int tile_w_env = getenv("ORBFE_ARUCO_TILE_W") ? atoi(getenv("ORBFE_ARUCO_TILE_W")) : 0;
     int tpw_env = getenv("ORBFE_ARUCO_TPW") ? atoi(getenv("ORBFE_ARUCO_TPW")) : 0;
     int ct_segcap = 0, ct_hbits = 0, ct_lcap = 0, ct_items_per_frame = 0, ct_tiles_max = 0;
-    bool ct_dirty = true;      // the per-frame counters of k_ct_walk may be non-zero (first use; a batch abandoned before k_ct_lists)
+    bool ct_dirty = true;      // the per-frame counters of the walk kernel may be non-zero (first use; a batch abandoned before k_ct_lists)
+    unsigned ct_gen = 0;       // generation tag of the hash table's entries (16 bits; the table is cleared when it wraps and before first use)
+    bool ct_tab_dirty = true;
     DevBuf d_ctseg, d_cthtab, d_ctelem, d_ctstate, d_ctitemsA, d_ctitemsB, d_cttiles;
     bool relay_global = false; // k_contours_relay8g: the bit image stays in HBM (it does not fit LDS)
     int relay_tbits = 0;       // hash-table size of k_contours_relay (0: the kernel cannot run at this image size)
@@ -313,7 +315,7 @@ struct orbfe_aruco {
             ct_segcap = std::min(sc, 65535);
             ct_hbits = 1;
             while ((1 << ct_hbits) < 2 * sc) ct_hbits++;
-            ct_lcap = std::min(ct_segcap, large ? 8192 : 4096);
+            ct_lcap = std::min(ct_segcap, large ? 16384 : 4096);   // list elements k_ct_lists keeps in LDS (8 B each)
             ct_items_per_frame = std::max(4096, ct_segcap / 4);
             ct_tiles_max = ((rows_ + 31) / 32) * ((cols_ + 31) / 32);
         }
@@ -353,7 +355,7 @@ struct orbfe_aruco {
                 (rc = d_cttiles.ensure((size_t)ct_tiles_max * 8 * B)) ||
                 (rc = d_ctmlist.ensure((size_t)CTB_MCAP * 4 * ((rows + 31) / 32) * B)))   // (one list per band; at most one band per cell row)
                 return rc;
-            ct_dirty = true;
+            ct_dirty = true; ct_tab_dirty = true;
         }
         if (!d_hint.p) {
             if ((rc = d_hint.ensure(16))) return rc;
@@ -497,14 +499,14 @@ struct orbfe_aruco {
                 const int tpw = tpw_env > 0 ? tpw_env : (B <= 32 ? 1 : 2);
                 const int walk_wgs = std::max(1, std::min((total_tiles / tpw + CTW_THREADS / 64 - 1) / (CTW_THREADS / 64), 256 * 8));
                 const int ntiles = ncols * nbands;
-                const size_t llds = (((size_t)ntiles + 1) * 4 + 15) / 16 * 16 + (size_t)ct_lcap * 10 + 16;
+                const size_t llds = (((size_t)ntiles + 1) * 4 + 15) / 16 * 16 + (size_t)ct_lcap * 8 + 16;
                 { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(k_ct_walk), (size_t)wlds); if (rc_lds_) return rc_lds_; }
                 { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(k_ct_points), (size_t)plds); if (rc_lds_) return rc_lds_; }
                 { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(k_ct_lists), llds); if (rc_lds_) return rc_lds_; }
-                if (ct_dirty) {   // first use, or a batch abandoned between k_ct_walk and k_ct_lists (which leaves both empty)
-                    ORBFE_HIP(hipMemsetAsync(d_ctstate.p, 0, (size_t)CT_STATE_INTS * 4 * B, s));
-                    ORBFE_HIP(hipMemsetAsync(d_cthtab.p, 0, ((size_t)8 << ct_hbits) * B, s));
-                }
+                if (ct_dirty) ORBFE_HIP(hipMemsetAsync(d_ctstate.p, 0, (size_t)CT_STATE_INTS * 4 * B, s)); // first use, or a batch abandoned before k_ct_lists (which leaves them at zero)
+                ct_gen = (ct_gen + 1) & 0xffffu;
+                if (ct_gen == 0) { ct_gen = 1; ct_tab_dirty = true; }
+                if (ct_tab_dirty) { ORBFE_HIP(hipMemsetAsync(d_cthtab.p, 0, d_cthtab.bytes, s)); ct_tab_dirty = false; }
                 ct_dirty = true;
                 const bool use_band = banded > 0 || (banded < 0 && B > 32);
                 if (use_band) {
@@ -515,16 +517,16 @@ struct orbfe_aruco {
                     const size_t blds = ctb_lds_bytes(cols, rb);
                     { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(k_ct_band), blds); if (rc_lds_) return rc_lds_; }
                     hipLaunchKernelGGL(k_ct_band, dim3(nb, B), dim3(CTB_THREADS), blds, s, d_bits.as<uint32_t>(), bits_fu32, wpr, cols, rows, 70,
-                                       d_lut.as<uint16_t>(), rb, cw, ncols, d_ctmlist.as<uint32_t>(), CTB_MCAP, d_cthtab.as<unsigned long long>(), ct_hbits,
+                                       d_lut.as<uint16_t>(), rb, cw, ncols, d_ctmlist.as<uint32_t>(), CTB_MCAP, d_cthtab.as<unsigned long long>(), ct_hbits, ct_gen,
                                        d_ctseg.as<uint32_t>(), (size_t)5 * ct_segcap, ct_segcap, d_ctstate.as<int32_t>(), d_pool.as<uint32_t>(), pool_fu32,
                                        (int)pool_fu32, relay_kcap, d_tailkeys.as<unsigned long long>(), d_tailoff.as<int32_t>());
                 } else
                 hipLaunchKernelGGL(k_ct_walk, dim3(walk_wgs), dim3(CTW_THREADS), wlds, s, d_bits.as<uint32_t>(), bits_fu32, wpr, cols, rows, 70,
-                                   d_lut.as<uint16_t>(), cw, ncols, nbands, total_tiles, d_cthtab.as<unsigned long long>(), ct_hbits,
+                                   d_lut.as<uint16_t>(), cw, ncols, nbands, total_tiles, d_cthtab.as<unsigned long long>(), ct_hbits, ct_gen,
                                    d_ctseg.as<uint32_t>(), (size_t)5 * ct_segcap, ct_segcap, d_ctstate.as<int32_t>(), d_pool.as<uint32_t>(), pool_fu32,
                                    (int)pool_fu32, relay_kcap, d_tailkeys.as<unsigned long long>(), d_tailoff.as<int32_t>(), wave_bytes);
-                hipLaunchKernelGGL(k_ct_lists, dim3(B), dim3(ct_lcap > 4096 ? 1024 : 512), llds, s, d_ctseg.as<uint32_t>(), (size_t)5 * ct_segcap, ct_segcap,
-                                   d_ctstate.as<int32_t>(), d_cthtab.as<unsigned long long>(), ct_hbits, d_ctelem.as<unsigned long long>(), ct_lcap, 70,
+                hipLaunchKernelGGL(k_ct_lists, dim3(B), dim3(1024), llds, s, d_ctseg.as<uint32_t>(), (size_t)5 * ct_segcap, ct_segcap,
+                                   d_ctstate.as<int32_t>(), d_cthtab.as<unsigned long long>(), ct_hbits, ct_gen, d_ctelem.as<unsigned long long>(), ct_lcap, 70,
                                    (int)pool_fu32, relay_kcap, d_tailkeys.as<unsigned long long>(), d_tailoff.as<int32_t>(), d_counts.as<int32_t>(),
                                    d_rstate.as<int32_t>(), d_ctitemsA.as<uint4>(), d_ctitemsB.as<uint2>(), ct_items_per_frame, d_cttiles.as<int2>(), ntiles);
                 if (hipPeekAtLastError() == hipSuccess) ct_dirty = false;

@@ -190,15 +190,15 @@ __global__ void k_upsample_corners(ImgView src0, ImgView pyr, const ArLevel* lev
 #endif
 inline size_t ctb_lds_bytes(int W, int rb) { return ((size_t)((W + 2 + 31) >> 5) * (32 * rb + 3) + 2) * 4 + 16; }   // the band's rows of the padded bit image
 __global__ void k_ct_band(const uint32_t* gbits, size_t bits_fstride, int wpr_g, int W, int H, int min_len, const uint16_t* lut_g, int rb, int cw_p,
-                          int ncols_p, uint32_t* mlist, int mcap, unsigned long long* htab, int hbits, uint32_t* seg, size_t seg_fstride, int segcap,
+                          int ncols_p, uint32_t* mlist, int mcap, unsigned long long* htab, int hbits, unsigned gen, uint32_t* seg, size_t seg_fstride, int segcap,
                           int32_t* ctstate, uint32_t* pool, size_t pool_fstride, int pool_cap, int kcap, unsigned long long* tail_keys, int32_t* tail_off);
 inline int ctw_wave_lds_bytes(int cw) { return (2 * (CTW_ROWS * ((cw >> 5) + 2) + 2) * 4 + CTW_QCAP * 2 + CTW_FCAP * 24 + 15) & ~15; }   // two tile slots, queue, finished segments
 inline int ctp_wave_lds_bytes(int cw) { return ((CTW_ROWS * ((cw >> 5) + 2) + 2) * 4 + 15) & ~15; }                                           // k_ct_points: one tile
 __global__ void k_ct_walk(const uint32_t* gbits, size_t bits_fstride, int wpr_g, int W, int H, int min_len, const uint16_t* lut_g, int cw, int ncols,
-                          int nbands, int total_tiles, unsigned long long* htab, int hbits, uint32_t* seg, size_t seg_fstride,
+                          int nbands, int total_tiles, unsigned long long* htab, int hbits, unsigned gen, uint32_t* seg, size_t seg_fstride,
                           int segcap, int32_t* ctstate, uint32_t* pool, size_t pool_fstride, int pool_cap, int kcap, unsigned long long* tail_keys,
                           int32_t* tail_off, int wave_bytes);
-__global__ void k_ct_lists(const uint32_t* seg, size_t seg_fstride, int segcap, int32_t* ctstate, unsigned long long* htab, int hbits,
+__global__ void k_ct_lists(const uint32_t* seg, size_t seg_fstride, int segcap, int32_t* ctstate, const unsigned long long* htab, int hbits, unsigned gen,
                            unsigned long long* gelem, int lcap, int min_len, int pool_cap, int kcap, unsigned long long* tail_keys, int32_t* tail_off,
                            int32_t* counts, int32_t* rstate, uint4* itemsA, uint2* itemsB, int ipf, int2* tile_items, int ntiles);
 __global__ void k_ct_points(const uint32_t* gbits, size_t bits_fstride, int wpr_g, int W, int H, const uint16_t* lut_g, int cw, int ncols, int nbands,

@@ -36,21 +36,61 @@ __device__ __forceinline__ bool ct_is_marker(unsigned e, int x, int y)
     return (e & g) != 0;
 }
 
+// The frame's hash table: start state -> segment id, entries {key : 32 | id : 16 | generation : 16}.  An entry of another generation
+// (an earlier batch) counts as free, so nothing has to be emptied between batches; the host clears the table when the 16-bit
+// generation wraps (and before first use).  Returns false when no slot was found within 128 probes (the table is too full).
+__device__ __forceinline__ bool ct_hash_insert(unsigned long long* __restrict__ ht, int hbits, uint32_t key, int id, unsigned gen, int32_t* flags)
+{
+    const uint32_t hmask = (1u << hbits) - 1u;
+    uint32_t h = (key * 0x9E3779B1u) >> (32 - hbits);
+    const unsigned long long ent = (unsigned long long)key | ((unsigned long long)(uint32_t)id << 32) | ((unsigned long long)gen << 48);
+    unsigned long long seen = 0ull;
+    for (int p = 0; p < 128;) {
+        const unsigned long long old = atomicCAS(&ht[h], seen, ent);
+        if (old == seen) return true;
+        if ((unsigned)(old >> 48) != gen || old == 0ull) { seen = old; continue; } // a free slot after all (stale entry): take it
+        if ((uint32_t)old == key) { atomicOr(flags, RL_FLAG_BUG); return true; }   // a state owned twice
+        h = (h + 1) & hmask; seen = 0ull; p++;
+    }
+    return false;
+}
+__device__ __forceinline__ int ct_hash_find(const unsigned long long* __restrict__ ht, int hbits, uint32_t key, unsigned gen)
+{
+    const uint32_t hmask = (1u << hbits) - 1u;
+    uint32_t h = (key * 0x9E3779B1u) >> (32 - hbits);
+    for (int p = 0; p < 128; p++) {
+        const unsigned long long v = ht[h];
+        if ((unsigned)(v >> 48) != gen || v == 0ull) return -1; // free: the key is not there
+        if ((uint32_t)v == key) return (int)((v >> 32) & 0xffffu);
+        h = (h + 1) & hmask;
+    }
+    return -1;
+}
+
 // A tile of the padded bit image (pixel (x, y) = bit x + 1 of row y + 1) into wave-private LDS: words j0 - 1 .. j0 + TW - 2 of the
 // rows y0 - 1 .. y0 + 33, + two spare words for ring8()'s funnel loads.
 __device__ __forceinline__ void ct_load_tile(uint32_t* tile, const uint32_t* __restrict__ gb, int wpr_g, int H, int y0, int j0, int TW, int lane)
 {
     const int nwords = CTW_ROWS * TW;
-    for (int i = lane; i < nwords; i += 64) {
-        const int r = i / TW, k = i - r * TW, py = y0 - 1 + r, j = j0 - 1 + k; // word j of padded row py
-        uint32_t v = 0;
-        if (py >= 1 && py <= H && j >= 0) {
-            const uint32_t* row = gb + (size_t)(py - 1) * wpr_g;
-            const uint32_t cur = j < wpr_g ? row[j] : 0u;
-            const uint32_t prv = (j >= 1 && j - 1 < wpr_g) ? row[j - 1] : 0u;
-            v = (cur << 1) | (prv >> 31);
+    const float inv_tw = 1.0f / (float)TW;
+    for (int i0 = 0; i0 < nwords; i0 += 256) { // four words per lane per trip: their eight loads are in flight together
+        uint32_t cur[4], prv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + u * 64 + lane;
+            const int r = (int)(((float)i + 0.5f) * inv_tw), k = i - r * TW, py = y0 - 1 + r, j = j0 - 1 + k; // word j of padded row py (exact: i < 2^16)
+            cur[u] = 0; prv[u] = 0;
+            if (i < nwords && py >= 1 && py <= H && j >= 0) {
+                const uint32_t* row = gb + (size_t)(py - 1) * wpr_g;
+                if (j < wpr_g) cur[u] = row[j];
+                if (j >= 1 && j - 1 < wpr_g) prv[u] = row[j - 1];
+            }
         }
-        tile[i] = v;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + u * 64 + lane;
+            if (i < nwords) tile[i] = (cur[u] << 1) | (prv[u] >> 31);
+        }
     }
     if (lane < 2) tile[nwords + lane] = 0;
 }
@@ -67,7 +107,7 @@ __device__ __forceinline__ void ct_load_tile(uint32_t* tile, const uint32_t* __r
 __global__ __launch_bounds__(CTW_THREADS) void k_ct_walk(
     const uint32_t* __restrict__ gbits, size_t bits_fstride, int wpr_g, int W, int H, int min_len, const uint16_t* __restrict__ lut_g,
     int cw /* tile width in pixels: a multiple of 32, <= CTW_MAX_CW */, int ncols, int nbands, int total_tiles /* of the batch */,
-    unsigned long long* __restrict__ htab, int hbits, uint32_t* __restrict__ seg, size_t seg_fstride, int segcap,
+    unsigned long long* __restrict__ htab, int hbits, unsigned gen, uint32_t* __restrict__ seg, size_t seg_fstride, int segcap,
     int32_t* __restrict__ ctstate, uint32_t* __restrict__ pool, size_t pool_fstride, int pool_cap, int kcap,
     unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off, int wave_bytes)
 {
@@ -91,7 +131,6 @@ __global__ __launch_bounds__(CTW_THREADS) void k_ct_walk(
     uint32_t* f_off = fin + 4 * CTW_FCAP;
     uint32_t* f_frm = fin + 5 * CTW_FCAP;
     const int stage0 = pool_cap >> 2;
-    const uint32_t hmask = (1u << hbits) - 1u;
 
     // the two tile slots (wave-uniform): frame, tile number inside the frame, what to add to tile coordinates, neighbours
     int sl_f0 = 0, sl_f1 = 0, sl_tile0 = 0, sl_tile1 = 0, sl_ox0 = 0, sl_ox1 = 0, sl_oy0 = 0, sl_oy1 = 0, sl_right0 = 0, sl_right1 = 0, sl_lower0 = 0, sl_lower1 = 0;
@@ -133,18 +172,8 @@ __global__ __launch_bounds__(CTW_THREADS) void k_ct_walk(
                     const uint32_t key = f_key[lane];
                     sg[id] = key; sg[segcap + id] = f_nxt[lane]; sg[2 * segcap + id] = f_len[lane];
                     sg[3 * segcap + id] = f_mn[lane]; sg[4 * segcap + id] = f_off[lane];
-                    // start state -> id: the frame's hash table (k_ct_lists resolves the end states with it, then empties it again)
-                    unsigned long long* ht = htab + ((size_t)lf << hbits);
-                    uint32_t h = (key * 0x9E3779B1u) >> (32 - hbits);
-                    const unsigned long long ent = (unsigned long long)key | ((unsigned long long)(uint32_t)id << 32);
-                    int p = 0;
-                    for (; p < 128; p++) {
-                        const unsigned long long old = atomicCAS(&ht[h], 0ull, ent);
-                        if (old == 0ull) break;
-                        if ((uint32_t)old == key) { atomicOr(&st[3], RL_FLAG_BUG); break; } // a state owned twice
-                        h = (h + 1) & hmask;
-                    }
-                    if (p == 128) atomicOr(&st[3], RL_FLAG_TABLE);
+                    // start state -> id: the frame's hash table (k_ct_lists resolves the end states with it)
+                    if (!ct_hash_insert(htab + ((size_t)lf << hbits), hbits, key, id, gen, &st[3])) atomicOr(&st[3], RL_FLAG_TABLE);
                 }
             }
             rem &= ~grp;
@@ -402,7 +431,7 @@ __global__ __launch_bounds__(CTW_THREADS) void k_ct_walk(
 __global__ __launch_bounds__(CTB_THREADS) void k_ct_band(
     const uint32_t* __restrict__ gbits, size_t bits_fstride, int wpr_g, int W, int H, int min_len, const uint16_t* __restrict__ lut_g,
     int rb /* cell rows per band */, int cw_p, int ncols_p /* tiling of k_ct_points: tiles of one cell row x cw_p columns */,
-    uint32_t* __restrict__ mlist, int mcap /* marker pixels per (frame, band) */, unsigned long long* __restrict__ htab, int hbits,
+    uint32_t* __restrict__ mlist, int mcap /* marker pixels per (frame, band) */, unsigned long long* __restrict__ htab, int hbits, unsigned gen,
     uint32_t* __restrict__ seg, size_t seg_fstride, int segcap, int32_t* __restrict__ ctstate, uint32_t* __restrict__ pool,
     size_t pool_fstride, int pool_cap, int kcap, unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off)
 {
@@ -487,7 +516,6 @@ __global__ __launch_bounds__(CTB_THREADS) void k_ct_band(
     uint32_t* f_off = fin + 4 * CTW_FCAP;
     uint32_t* sg = seg + (size_t)f * seg_fstride;
     unsigned long long* ht = htab + ((size_t)f << hbits);
-    const uint32_t hmask = (1u << hbits) - 1u;
     int fcnt = 0;
     auto flush = [&]() {
         int base = 0;
@@ -499,16 +527,7 @@ __global__ __launch_bounds__(CTB_THREADS) void k_ct_band(
                 const uint32_t key = f_key[lane];
                 sg[id] = key; sg[segcap + id] = f_nxt[lane]; sg[2 * segcap + id] = f_len[lane];
                 sg[3 * segcap + id] = f_mn[lane]; sg[4 * segcap + id] = f_off[lane];
-                uint32_t h = (key * 0x9E3779B1u) >> (32 - hbits);
-                const unsigned long long ent = (unsigned long long)key | ((unsigned long long)(uint32_t)id << 32);
-                int p = 0;
-                for (; p < 128; p++) {
-                    const unsigned long long old = atomicCAS(&ht[h], 0ull, ent);
-                    if (old == 0ull) break;
-                    if ((uint32_t)old == key) { atomicOr(&st[3], RL_FLAG_BUG); break; }
-                    h = (h + 1) & hmask;
-                }
-                if (p == 128) atomicOr(&st[3], RL_FLAG_TABLE);
+                if (!ct_hash_insert(ht, hbits, key, id, gen, &st[3])) atomicOr(&st[3], RL_FLAG_TABLE);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -689,13 +708,13 @@ __device__ __forceinline__ unsigned long long ct_pack(CtElem e) { return (unsign
 __device__ __forceinline__ CtElem ct_unpack(unsigned long long u) { return CtElem{(uint32_t)u, (uint16_t)(u >> 32), (uint16_t)(u >> 48)}; }
 
 template <bool LDSL> struct CtStore;
-template <> struct CtStore<true> {
+template <> struct CtStore<true> { // the elements in LDS; the original next ids (written once, read once, in id order) in HBM
     unsigned long long* e;
     uint16_t* nx;
     __device__ __forceinline__ CtElem ld(int i) const { return ct_unpack(e[i]); }
     __device__ __forceinline__ void st(int i, CtElem v) const { e[i] = ct_pack(v); }
-    __device__ __forceinline__ int ldn(int i) const { return nx[i]; }
-    __device__ __forceinline__ void stn(int i, int v) const { nx[i] = (uint16_t)v; }
+    __device__ __forceinline__ int ldn(int i) const { return __hip_atomic_load(nx + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    __device__ __forceinline__ void stn(int i, int v) const { __hip_atomic_store(nx + i, (uint16_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 };
 // a frame with more segments than the LDS arrays hold (noise): the same lists in HBM / L2.  Only this workgroup touches them, and
 // its waves share one CU's vector cache, so workgroup scope is enough (an agent-scope release is an L2 write-back on this part)
@@ -712,7 +731,7 @@ template <> struct CtStore<false> {
 
 template <bool LDSL>
 __device__ __forceinline__ void ct_lists_frame(const CtStore<LDSL> S, int f, int nseg, int nk0, int pool0, int ncand, const uint32_t* __restrict__ sg,
-                                               int segcap, unsigned long long* __restrict__ ht, int hbits, int min_len, int pool_cap,
+                                               int segcap, const unsigned long long* __restrict__ ht, int hbits, unsigned gen, int min_len, int pool_cap,
                                                int kcap, unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off,
                                                int32_t* __restrict__ counts, int32_t* __restrict__ rstate, uint4* __restrict__ itA,
                                                uint2* __restrict__ itB, int ipf, int2* __restrict__ tile_items, int ntiles,
@@ -731,34 +750,15 @@ __device__ __forceinline__ void ct_lists_frame(const CtStore<LDSL> S, int f, int
     if (tid == 0) { *s_flags = 0; *s_nkept = nk0; *s_pool = pool0; s_ch[0] = s_ch[1] = s_ch[2] = 0; }
     for (int i = tid; i <= ntiles; i += NT) s_tcur[i] = 0;
     __syncthreads();
-    // ---- end states -> segment ids: k_ct_walk entered every segment's start state into the frame's hash table
-    const uint32_t hmask = (1u << hbits) - 1u;
+    // ---- end states -> segment ids: the walk kernel entered every segment's start state into the frame's hash table
     for (int i = tid; i < nseg; i += NT) {
-        const uint32_t key = g_nxt[i];
-        uint32_t h = (key * 0x9E3779B1u) >> (32 - hbits);
-        int nx = -1;
-        for (int p = 0; p < 128; p++) {
-            const unsigned long long v = ht[h];
-            if ((uint32_t)v == key) { nx = (int)(v >> 32); break; }
-            if (v == 0ull) break;
-            h = (h + 1) & hmask;
-        }
+        int nx = ct_hash_find(ht, hbits, g_nxt[i], gen);
         if (nx < 0 || nx >= nseg) { atomicOr(s_flags, RL_FLAG_BUG); nx = i; } // a segment that ends at a state nobody owns
         S.stn(i, nx);
         S.st(i, CtElem{g_mn[i], (uint16_t)nx, (uint16_t)i});
     }
     __threadfence_block();
     __syncthreads();
-    // the table is left empty for the next batch: every segment takes its own entry out again (all lookups are done)
-    for (int i = tid; i < nseg; i += NT) {
-        const uint32_t key = g_key[i];
-        uint32_t h = (key * 0x9E3779B1u) >> (32 - hbits);
-        for (int p = 0; p < 128; p++) {
-            const unsigned long long v = ht[h];
-            if ((uint32_t)v == key) { ht[h] = 0ull; break; }
-            h = (h + 1) & hmask; // (an emptied slot in between does not end the search: the entry is there)
-        }
-    }
     // ---- (e1) the border's smallest start state by pointer doubling round the cyclic list.  A round in which no value changes
     // ends it: values then do not decrease along the jumps, the jumps of any element lead into a loop whose windows tile the whole
     // cycle, so the loop's common value is the cycle's minimum and every value on the way to it is squeezed between.
@@ -888,11 +888,11 @@ __device__ __forceinline__ void ct_lists_frame(const CtStore<LDSL> S, int f, int
 }
 
 __global__ __launch_bounds__(CTL_THREADS) void k_ct_lists(const uint32_t* __restrict__ seg, size_t seg_fstride, int segcap, int32_t* __restrict__ ctstate,
-                                                          unsigned long long* __restrict__ htab, int hbits, unsigned long long* __restrict__ gelem,
-                                                          int lcap, int min_len, int pool_cap, int kcap, unsigned long long* __restrict__ tail_keys,
-                                                          int32_t* __restrict__ tail_off, int32_t* __restrict__ counts, int32_t* __restrict__ rstate,
-                                                          uint4* __restrict__ itemsA, uint2* __restrict__ itemsB, int ipf,
-                                                          int2* __restrict__ tile_items, int ntiles)
+                                                          const unsigned long long* __restrict__ htab, int hbits, unsigned gen,
+                                                          unsigned long long* __restrict__ gelem, int lcap, int min_len, int pool_cap, int kcap,
+                                                          unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off,
+                                                          int32_t* __restrict__ counts, int32_t* __restrict__ rstate, uint4* __restrict__ itemsA,
+                                                          uint2* __restrict__ itemsB, int ipf, int2* __restrict__ tile_items, int ntiles)
 {
     extern __shared__ __align__(16) unsigned char ctl_smem[];
     __shared__ int s_sh[8];
@@ -902,28 +902,27 @@ __global__ __launch_bounds__(CTL_THREADS) void k_ct_lists(const uint32_t* __rest
     int32_t* st = ctstate + (size_t)f * CT_STATE_INTS;
     if (tid < 5) s_in[tid] = st[tid];
     __syncthreads();
-    if (tid < 5) st[tid] = 0; // the counters of k_ct_walk are left at zero for the next batch
+    if (tid < 5) st[tid] = 0; // the counters of the walk kernel are left at zero for the next batch
     const int nseg = s_in[0], nk0 = s_in[1], pool0 = s_in[2], ncand = s_in[4];
     int flags = s_in[3];
     if (nseg > segcap) flags |= RL_FLAG_TABLE; // more segments than the frame's list holds: the host redoes the frame on a coarser grid
-    unsigned long long* ht = htab + ((size_t)f << hbits);
     if (flags) {
-        // (the hash table may hold anything now: emptied whole)
-        for (int i = tid; i < (1 << hbits); i += (int)blockDim.x) ht[i] = 0ull;
         if (tid == 0) { counts[f * 4 + 0] = 0; counts[f * 4 + 1] = 0; counts[f * 4 + 2] = flags; counts[f * 4 + 3] = 0; }
         return;
     }
     const uint32_t* sg = seg + (size_t)f * seg_fstride;
+    const unsigned long long* ht = htab + ((size_t)f << hbits);
     int* s_tcur = reinterpret_cast<int*>(ctl_smem);
     unsigned char* lists = ctl_smem + (((size_t)ntiles + 1) * 4 + 15) / 16 * 16;
+    unsigned long long* ge = gelem + (size_t)f * ((size_t)segcap + ((size_t)segcap + 3) / 4);
+    uint16_t* gnx = reinterpret_cast<uint16_t*>(ge + segcap);
     if (nseg <= lcap) {
-        CtStore<true> S{reinterpret_cast<unsigned long long*>(lists), reinterpret_cast<uint16_t*>(lists + (size_t)lcap * 8)};
-        ct_lists_frame<true>(S, f, nseg, nk0, pool0, ncand, sg, segcap, ht, hbits, min_len, pool_cap, kcap, tail_keys, tail_off, counts, rstate, itemsA,
+        CtStore<true> S{reinterpret_cast<unsigned long long*>(lists), gnx};
+        ct_lists_frame<true>(S, f, nseg, nk0, pool0, ncand, sg, segcap, ht, hbits, gen, min_len, pool_cap, kcap, tail_keys, tail_off, counts, rstate, itemsA,
                              itemsB, ipf, tile_items, ntiles, s_sh, s_tcur);
     } else {
-        unsigned long long* ge = gelem + (size_t)f * ((size_t)segcap + ((size_t)segcap + 3) / 4);
-        CtStore<false> S{ge, reinterpret_cast<uint16_t*>(ge + segcap)};
-        ct_lists_frame<false>(S, f, nseg, nk0, pool0, ncand, sg, segcap, ht, hbits, min_len, pool_cap, kcap, tail_keys, tail_off, counts, rstate, itemsA,
+        CtStore<false> S{ge, gnx};
+        ct_lists_frame<false>(S, f, nseg, nk0, pool0, ncand, sg, segcap, ht, hbits, gen, min_len, pool_cap, kcap, tail_keys, tail_off, counts, rstate, itemsA,
                               itemsB, ipf, tile_items, ntiles, s_sh, s_tcur);
     }
 }
