@@ -77,17 +77,18 @@ struct orbfe_aruco {
     // idle, so the many small workgroups of the separate kernel shorten the call: 0.62 -> 0.57 ms for one 640 x 480 frame; a full
     // batch issues more instructions that way and the pipeline is bound by those: 1.85 -> 1.98 ms per C2 step), 0 / 1 = forced
     int small_separate_mode = getenv("ORBFE_ARUCO_SMALL_SEPARATE") ? atoi(getenv("ORBFE_ARUCO_SMALL_SEPARATE")) : -1;
-    // the tiled relay formulation (aruco_tiles.hip: k_ct_walk / k_ct_lists / k_ct_points).  -1 = by frame and batch size: frames whose
-    // bit image does not fit LDS next to the relay kernel's tables (1920 x 1080: 100-frame step 4.88 -> 3.75 ms) and batches of up to
-    // 32 frames (a frame's walks spread over ~40 CUs instead of one); full batches of LDS-resident frames keep the one-workgroup relay
-    // kernels, which issue a third fewer instructions for the same borders (640 x 480: 1.32 against 1.50 ms per step, 1280 x 720: 4.0
-    // against 4.2).  ORBFE_ARUCO_TILED = 0 / 1 forces it off / on for every batch (tests, A/B); ORBFE_ARUCO_TILE_W = tile width in
-    // pixels, ORBFE_ARUCO_TPW = tiles per wave: measurement switches.
+    // the tiled relay formulation (aruco_tiles.hip: k_ct_band or k_ct_walk / k_ct_lists / k_ct_points).  -1 = by frame and batch size:
+    // frames for which the one-workgroup relay kernel needs its 8192-slot table and a CU to itself (1280 x 720: 300-frame step 4.09 -
+    // 4.13 -> 3.96 - 4.07 ms) or whose bit image does not fit LDS at all (1920 x 1080: 100-frame step 4.88 -> 3.41 ms), and batches of
+    // up to 32 frames (a frame's walks spread over ~40 CUs instead of one); full batches of 640 x 480 frames keep the one-workgroup
+    // kernel, whose single launch costs the pipeline less than band + lists + points (1.32 - 1.34 against 1.45 - 1.62 ms per step).
+    // ORBFE_ARUCO_TILED = 0 / 1 forces it off / on for every batch (tests, A/B); ORBFE_ARUCO_TILE_W = tile width in pixels,
+    // ORBFE_ARUCO_TPW = tiles per wave of k_ct_walk: measurement switches.
     int tiled = getenv("ORBFE_ARUCO_TILED") ? (atoi(getenv("ORBFE_ARUCO_TILED")) ? 1 : 0) : -1;
     bool tiled_off = false;    // set while a batch is redone by the relay kernels
     bool tiled_ran = false;    // the last batch took the tiled path
     // the walks of the tiled path by BANDS of cell rows, a workgroup of eight waves each (k_ct_band), instead of a wave per tile
-    // (k_ct_walk): -1 = by frame / batch size, 0 / 1 forced; ORBFE_ARUCO_BAND_ROWS = cell rows per band (0: what fits ~44 KB of LDS, at most 8)
+    // (k_ct_walk): -1 = by frame / batch size, 0 / 1 forced; ORBFE_ARUCO_BAND_ROWS = cell rows per band (0: what fits ~36 KB of LDS, at most 8)
     int banded = getenv("ORBFE_ARUCO_BANDED") ? (atoi(getenv("ORBFE_ARUCO_BANDED")) ? 1 : 0) : -1;
     int band_rows_env = getenv("ORBFE_ARUCO_BAND_ROWS") ? atoi(getenv("ORBFE_ARUCO_BAND_ROWS")) : 0;
     DevBuf d_ctmlist;
@@ -479,7 +480,7 @@ struct orbfe_aruco {
         ORBFE_HIP(hipGetLastError());
         auto kfn = big ? k_contours_t<false> : k_contours_t<true>;
         { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(kfn), (size_t)(lds)); if (rc_lds_) return rc_lds_; }
-        const bool use_tiled = (tiled > 0 || (tiled < 0 && (relay_global || !relay_tbits || B <= 32))) && !tiled_off && !force_legacy && !big_mode;
+        const bool use_tiled = (tiled > 0 || (tiled < 0 && (relay_global || !relay_tbits || relay_tbits > 12 || B <= 32))) && !tiled_off && !force_legacy && !big_mode;
         tiled_ran = use_tiled;
         const bool relay = (relay_tbits || use_tiled) && !force_legacy && !big_mode;
         for (int r_ = 0; relay && r_ < ORBFE_REPS_ARUCO(1); r_++) {
@@ -511,7 +512,7 @@ struct orbfe_aruco {
                 const bool use_band = banded > 0 || (banded < 0 && B > 32);
                 if (use_band) {
                     const int pw = (cols + 2 + 31) / 32, crows = (rows + 31) / 32;
-                    int rb = band_rows_env > 0 ? band_rows_env : std::max(1, std::min(8, (int)((44 * 1024 / (pw * 4) - 3) / 32)));
+                    int rb = band_rows_env > 0 ? band_rows_env : std::max(1, std::min(8, (int)((36 * 1024 / (pw * 4) - 3) / 32)));
                     rb = std::max(1, std::min(rb, crows));
                     const int nb = (crows + rb - 1) / rb;
                     const size_t blds = ctb_lds_bytes(cols, rb);
@@ -525,7 +526,7 @@ struct orbfe_aruco {
                                    d_lut.as<uint16_t>(), cw, ncols, nbands, total_tiles, d_cthtab.as<unsigned long long>(), ct_hbits, ct_gen,
                                    d_ctseg.as<uint32_t>(), (size_t)5 * ct_segcap, ct_segcap, d_ctstate.as<int32_t>(), d_pool.as<uint32_t>(), pool_fu32,
                                    (int)pool_fu32, relay_kcap, d_tailkeys.as<unsigned long long>(), d_tailoff.as<int32_t>(), wave_bytes);
-                hipLaunchKernelGGL(k_ct_lists, dim3(B), dim3(1024), llds, s, d_ctseg.as<uint32_t>(), (size_t)5 * ct_segcap, ct_segcap,
+                hipLaunchKernelGGL(k_ct_lists, dim3(B), dim3(ct_lcap > 4096 ? 1024 : 512), llds, s, d_ctseg.as<uint32_t>(), (size_t)5 * ct_segcap, ct_segcap,
                                    d_ctstate.as<int32_t>(), d_cthtab.as<unsigned long long>(), ct_hbits, ct_gen, d_ctelem.as<unsigned long long>(), ct_lcap, 70,
                                    (int)pool_fu32, relay_kcap, d_tailkeys.as<unsigned long long>(), d_tailoff.as<int32_t>(), d_counts.as<int32_t>(),
                                    d_rstate.as<int32_t>(), d_ctitemsA.as<uint4>(), d_ctitemsB.as<uint2>(), ct_items_per_frame, d_cttiles.as<int2>(), ntiles);
