@@ -94,11 +94,11 @@ struct orbfe_aruco {
     DevBuf d_ctmlist;
     int tile_w_env = getenv("ORBFE_ARUCO_TILE_W") ? atoi(getenv("ORBFE_ARUCO_TILE_W")) : 0;
     int tpw_env = getenv("ORBFE_ARUCO_TPW") ? atoi(getenv("ORBFE_ARUCO_TPW")) : 0;
-    int ct_segcap = 0, ct_hbits = 0, ct_lcap = 0, ct_items_per_frame = 0, ct_tiles_max = 0;
+    int ct_segcap = 0, ct_hbits = 0, ct_lcap = 0, ct_items_per_frame = 0, ct_code_slots = 0;
     bool ct_dirty = true;      // the per-frame counters of the walk kernel may be non-zero (first use; a batch abandoned before k_ct_lists)
     unsigned ct_gen = 0;       // generation tag of the hash table's entries (16 bits; the table is cleared when it wraps and before first use)
     bool ct_tab_dirty = true;
-    DevBuf d_ctseg, d_cthtab, d_ctelem, d_ctstate, d_ctitemsA, d_ctitemsB, d_cttiles;
+    DevBuf d_ctseg, d_cthtab, d_ctelem, d_ctstate, d_ctitemsA, d_ctitemsB, d_ctnitems, d_ctcodes;
     bool relay_global = false; // k_contours_relay8g: the bit image stays in HBM (it does not fit LDS)
     int relay_tbits = 0;       // hash-table size of k_contours_relay (0: the kernel cannot run at this image size)
     bool force_legacy = false; // debug: always use k_contours_t
@@ -150,7 +150,7 @@ struct orbfe_aruco {
     {
         for (DevBuf* b : {&d_codes, &d_levels, &d_tabs, &d_bits, &d_pyr, &d_candq, &d_pool, &d_kept, &d_rects,
                           &d_counts, &d_candidx, &d_ncand, &d_result, &d_gpad, &d_in, &d_out, &d_nout, &d_segs, &d_tailkeys, &d_tailoff, &d_small, &d_hint, &d_rstate, &d_lut, &d_twork, &d_trect, &d_tctr, &d_dwork, &d_dctr, &d_ditems, &d_dhist, &d_dpatch, &d_vis, &d_poses, &d_scodes, &d_sids,
-                          &d_msrc, &d_red, &d_mhist, &d_masks, &d_bgr, &d_bits2, &d_ctseg, &d_cthtab, &d_ctelem, &d_ctstate, &d_ctitemsA, &d_ctitemsB, &d_cttiles, &d_ctmlist})
+                          &d_msrc, &d_red, &d_mhist, &d_masks, &d_bgr, &d_bits2, &d_ctseg, &d_cthtab, &d_ctelem, &d_ctstate, &d_ctitemsA, &d_ctitemsB, &d_ctnitems, &d_ctcodes, &d_ctmlist})
             b->release();
         if (own_stream) (void)hipStreamDestroy(own_stream);
         if (aux_stream) (void)hipStreamDestroy(aux_stream);
@@ -318,7 +318,9 @@ struct orbfe_aruco {
             while ((1 << ct_hbits) < 2 * sc) ct_hbits++;
             ct_lcap = std::min(ct_segcap, large ? 16384 : 4096);   // list elements k_ct_lists keeps in LDS (8 B each)
             ct_items_per_frame = std::max(4096, ct_segcap / 4);
-            ct_tiles_max = ((rows_ + 31) / 32) * ((cols_ + 31) / 32);
+            // chain-code slots per frame: every started segment walk draws one (a shared grid line is walked from both sides), and the
+            // waves draw them in chunks
+            ct_code_slots = ct_segcap + ct_segcap / 2 + 4096;
         }
         rows = rows_; cols = cols_;
         pyr_rows = prows; pyr_cols = pcols;
@@ -350,10 +352,10 @@ struct orbfe_aruco {
             return rc;
         if (tiled != 0) {
             const size_t elem_words = (size_t)ct_segcap + ((size_t)ct_segcap + 3) / 4; // u64 elements + u16 next ids, per frame
-            if ((rc = d_ctseg.ensure((size_t)5 * ct_segcap * 4 * B)) || (rc = d_cthtab.ensure(((size_t)8 << ct_hbits) * B)) ||
+            if ((rc = d_ctseg.ensure((size_t)6 * ct_segcap * 4 * B)) || (rc = d_cthtab.ensure(((size_t)8 << ct_hbits) * B)) ||
                 (rc = d_ctelem.ensure(elem_words * 8 * B)) || (rc = d_ctstate.ensure((size_t)CT_STATE_INTS * 4 * B)) ||
                 (rc = d_ctitemsA.ensure((size_t)ct_items_per_frame * 16 * B)) || (rc = d_ctitemsB.ensure((size_t)ct_items_per_frame * 8 * B)) ||
-                (rc = d_cttiles.ensure((size_t)ct_tiles_max * 8 * B)) ||
+                (rc = d_ctnitems.ensure((size_t)4 * B)) || (rc = d_ctcodes.ensure((size_t)ct_code_slots * CT_CODE_WORDS * 4 * B)) ||
                 (rc = d_ctmlist.ensure((size_t)CTB_MCAP * 4 * ((rows + 31) / 32) * B)))   // (one list per band; at most one band per cell row)
                 return rc;
             ct_dirty = true; ct_tab_dirty = true;
@@ -494,15 +496,12 @@ struct orbfe_aruco {
                 const int cw = std::min(CTW_MAX_CW, std::max(32, ((cols + ncols0 - 1) / ncols0 + 31) / 32 * 32));
                 const int ncols = (cols + cw - 1) / cw, nbands = (rows + 31) / 32;
                 const int wave_bytes = ctw_wave_lds_bytes(cw), wlds = wave_bytes * (CTW_THREADS / 64);
-                const int pwave_bytes = ctp_wave_lds_bytes(cw), plds = pwave_bytes * (CTW_THREADS / 64);
-                const int wgs_pf = (ncols * nbands + CTW_THREADS / 64 - 1) / (CTW_THREADS / 64);
                 const int total_tiles = ncols * nbands * B;
                 const int tpw = tpw_env > 0 ? tpw_env : (B <= 32 ? 1 : 2);
                 const int walk_wgs = std::max(1, std::min((total_tiles / tpw + CTW_THREADS / 64 - 1) / (CTW_THREADS / 64), 256 * 8));
-                const int ntiles = ncols * nbands;
-                const size_t llds = (((size_t)ntiles + 1) * 4 + 15) / 16 * 16 + (size_t)ct_lcap * 8 + 16;
+                const size_t llds = (size_t)ct_lcap * 8 + 16;
+                const size_t codes_f = (size_t)ct_code_slots * CT_CODE_WORDS;
                 { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(k_ct_walk), (size_t)wlds); if (rc_lds_) return rc_lds_; }
-                { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(k_ct_points), (size_t)plds); if (rc_lds_) return rc_lds_; }
                 { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(k_ct_lists), llds); if (rc_lds_) return rc_lds_; }
                 if (ct_dirty) ORBFE_HIP(hipMemsetAsync(d_ctstate.p, 0, (size_t)CT_STATE_INTS * 4 * B, s)); // first use, or a batch abandoned before k_ct_lists (which leaves them at zero)
                 ct_gen = (ct_gen + 1) & 0xffffu;
@@ -518,22 +517,23 @@ struct orbfe_aruco {
                     const size_t blds = ctb_lds_bytes(cols, rb);
                     { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(k_ct_band), blds); if (rc_lds_) return rc_lds_; }
                     hipLaunchKernelGGL(k_ct_band, dim3(nb, B), dim3(CTB_THREADS), blds, s, d_bits.as<uint32_t>(), bits_fu32, wpr, cols, rows, 70,
-                                       d_lut.as<uint16_t>(), rb, cw, ncols, d_ctmlist.as<uint32_t>(), CTB_MCAP, d_cthtab.as<unsigned long long>(), ct_hbits, ct_gen,
-                                       d_ctseg.as<uint32_t>(), (size_t)5 * ct_segcap, ct_segcap, d_ctstate.as<int32_t>(), d_pool.as<uint32_t>(), pool_fu32,
-                                       (int)pool_fu32, relay_kcap, d_tailkeys.as<unsigned long long>(), d_tailoff.as<int32_t>());
+                                       d_lut.as<uint16_t>(), rb, d_ctmlist.as<uint32_t>(), CTB_MCAP, d_cthtab.as<unsigned long long>(), ct_hbits, ct_gen,
+                                       d_ctseg.as<uint32_t>(), (size_t)6 * ct_segcap, ct_segcap, d_ctstate.as<int32_t>(), d_pool.as<uint32_t>(), pool_fu32,
+                                       (int)pool_fu32, relay_kcap, d_tailkeys.as<unsigned long long>(), d_tailoff.as<int32_t>(), d_ctcodes.as<uint32_t>(),
+                                       codes_f, ct_code_slots);
                 } else
                 hipLaunchKernelGGL(k_ct_walk, dim3(walk_wgs), dim3(CTW_THREADS), wlds, s, d_bits.as<uint32_t>(), bits_fu32, wpr, cols, rows, 70,
                                    d_lut.as<uint16_t>(), cw, ncols, nbands, total_tiles, d_cthtab.as<unsigned long long>(), ct_hbits, ct_gen,
-                                   d_ctseg.as<uint32_t>(), (size_t)5 * ct_segcap, ct_segcap, d_ctstate.as<int32_t>(), d_pool.as<uint32_t>(), pool_fu32,
-                                   (int)pool_fu32, relay_kcap, d_tailkeys.as<unsigned long long>(), d_tailoff.as<int32_t>(), wave_bytes);
-                hipLaunchKernelGGL(k_ct_lists, dim3(B), dim3(ct_lcap > 4096 ? 1024 : 512), llds, s, d_ctseg.as<uint32_t>(), (size_t)5 * ct_segcap, ct_segcap,
+                                   d_ctseg.as<uint32_t>(), (size_t)6 * ct_segcap, ct_segcap, d_ctstate.as<int32_t>(), d_pool.as<uint32_t>(), pool_fu32,
+                                   (int)pool_fu32, relay_kcap, d_tailkeys.as<unsigned long long>(), d_tailoff.as<int32_t>(), wave_bytes,
+                                   d_ctcodes.as<uint32_t>(), codes_f, ct_code_slots);
+                hipLaunchKernelGGL(k_ct_lists, dim3(B), dim3(ct_lcap > 4096 ? 1024 : 512), llds, s, d_ctseg.as<uint32_t>(), (size_t)6 * ct_segcap, ct_segcap,
                                    d_ctstate.as<int32_t>(), d_cthtab.as<unsigned long long>(), ct_hbits, ct_gen, d_ctelem.as<unsigned long long>(), ct_lcap, 70,
                                    (int)pool_fu32, relay_kcap, d_tailkeys.as<unsigned long long>(), d_tailoff.as<int32_t>(), d_counts.as<int32_t>(),
-                                   d_rstate.as<int32_t>(), d_ctitemsA.as<uint4>(), d_ctitemsB.as<uint2>(), ct_items_per_frame, d_cttiles.as<int2>(), ntiles);
+                                   d_rstate.as<int32_t>(), d_ctitemsA.as<uint4>(), d_ctitemsB.as<uint2>(), ct_items_per_frame, d_ctnitems.as<int32_t>());
                 if (hipPeekAtLastError() == hipSuccess) ct_dirty = false;
-                hipLaunchKernelGGL(k_ct_points, dim3(xcd_grid(wgs_pf * B)), dim3(CTW_THREADS), plds, s, d_bits.as<uint32_t>(), bits_fu32, wpr, cols, rows,
-                                   d_lut.as<uint16_t>(), cw, ncols, nbands, wgs_pf, wgs_pf * B, d_counts.as<int32_t>(), d_ctitemsA.as<uint4>(),
-                                   d_ctitemsB.as<uint2>(), ct_items_per_frame, d_cttiles.as<int2>(), d_pool.as<uint32_t>(), pool_fu32, pwave_bytes);
+                hipLaunchKernelGGL(k_ct_points, dim3(ct_items_per_frame >= 8192 ? 32 : 8, B), dim3(256), 0, s, d_ctitemsA.as<uint4>(), d_ctitemsB.as<uint2>(),
+                                   ct_items_per_frame, d_ctnitems.as<int32_t>(), d_ctcodes.as<uint32_t>(), codes_f, d_pool.as<uint32_t>(), pool_fu32);
             } else {
             const size_t rlds = relay_lds_bytes(relay_global ? 0 : lds_bits_words, relay_kcap, relay_tbits);
             // A workgroup of the large-frame kernels takes a CU's whole LDS, so a launch of >= 256 frames shuts every kernel that

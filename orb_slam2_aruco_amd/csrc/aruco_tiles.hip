@@ -109,7 +109,8 @@ __global__ __launch_bounds__(CTW_THREADS) void k_ct_walk(
     int cw /* tile width in pixels: a multiple of 32, <= CTW_MAX_CW */, int ncols, int nbands, int total_tiles /* of the batch */,
     unsigned long long* __restrict__ htab, int hbits, unsigned gen, uint32_t* __restrict__ seg, size_t seg_fstride, int segcap,
     int32_t* __restrict__ ctstate, uint32_t* __restrict__ pool, size_t pool_fstride, int pool_cap, int kcap,
-    unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off, int wave_bytes)
+    unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off, int wave_bytes, uint32_t* __restrict__ codes, size_t codes_fstride,
+    int code_slots)
 {
     extern __shared__ __align__(16) unsigned char ctw_smem[];
     __shared__ __align__(16) uint16_t s_lut[2048];
@@ -130,6 +131,7 @@ __global__ __launch_bounds__(CTW_THREADS) void k_ct_walk(
     uint32_t* f_mn = fin + 3 * CTW_FCAP;
     uint32_t* f_off = fin + 4 * CTW_FCAP;
     uint32_t* f_frm = fin + 5 * CTW_FCAP;
+    uint32_t* f_slot = fin + 6 * CTW_FCAP;
     const int stage0 = pool_cap >> 2;
 
     // the two tile slots (wave-uniform): frame, tile number inside the frame, what to add to tile coordinates, neighbours
@@ -139,18 +141,24 @@ __global__ __launch_bounds__(CTW_THREADS) void k_ct_walk(
     int phase = 3, it0 = 0;    // enumeration state of the current tile: phases 0 .. 2, 3 = done
     int head = 0, total = 0, qphase = 0, fcnt = 0, ncand_w = 0;
     bool more = true;
+    // chain-code slots: the wave draws CTW_CHUNK of them at a time from the arena of a tile slot's frame
+    int ch_base0 = 0, ch_base1 = 0, ch_used0 = CTW_CHUNK, ch_used1 = CTW_CHUNK;
 
     // per lane
     int x = 0, y = 0, s = 0, n = 0;   // walk state, tile coordinates
     unsigned ring = 0;
     bool busy = false;
     int kind = 0;               // 0 segment, 1 small outer, 2 small hole
-    unsigned a = 0;             // grid-active directions of the lane's marker pixel whose states are still to be walked
+    unsigned a = 0;             // grid-active directions of the lane's marker pixel whose states are still to be walked; bit 8: the
+                                // walk filled its chain-code slot and goes on as a new segment from the state it is in
+    uint32_t skey = 0;          // start state of the segment being walked
     int sx = 0, sy = 0, s0 = 0; // start pixel and state of the walk (the marker pixel of a segment)
     uint32_t mn = 0xffffffffu, mnoff = 0;
     bool allbot = false, allright = false;
     int lslot = 0;              // the slot of the lane's tile
     const uint32_t* lbits = tiles; // = tiles + lslot * slot_words
+    uint32_t code = 0;          // the segment walk's directions, 3 bits a step: the word being filled, its fill, words written, the walk's slot
+    int cpos = 0, cwi = 0, cslot = -1;
 
     auto flush = [&]() {
         // the list may hold segments of two frames: one atomic per frame
@@ -171,7 +179,7 @@ __global__ __launch_bounds__(CTW_THREADS) void k_ct_walk(
                     uint32_t* sg = seg + (size_t)lf * seg_fstride;
                     const uint32_t key = f_key[lane];
                     sg[id] = key; sg[segcap + id] = f_nxt[lane]; sg[2 * segcap + id] = f_len[lane];
-                    sg[3 * segcap + id] = f_mn[lane]; sg[4 * segcap + id] = f_off[lane];
+                    sg[3 * segcap + id] = f_mn[lane]; sg[4 * segcap + id] = f_off[lane]; sg[5 * segcap + id] = f_slot[lane];
                     // start state -> id: the frame's hash table (k_ct_lists resolves the end states with it)
                     if (!ct_hash_insert(htab + ((size_t)lf << hbits), hbits, key, id, gen, &st[3])) atomicOr(&st[3], RL_FLAG_TABLE);
                 }
@@ -193,6 +201,7 @@ __global__ __launch_bounds__(CTW_THREADS) void k_ct_walk(
                 else {
                     const int fno = next_tile / tpf, tno = next_tile - fno * tpf, band = tno / ncols, col = tno - band * ncols;
                     next_tile += nwaves;
+                    if (fno != (o ? sl_f1 : sl_f0)) { if (o) ch_used1 = CTW_CHUNK; else ch_used0 = CTW_CHUNK; } // the slot's chunk is another frame's
                     if (o) { sl_f1 = fno; sl_tile1 = tno; sl_ox1 = col * cw - 32; sl_oy1 = band * 32 - 1; sl_right1 = (col + 1) * cw < W; sl_lower1 = (band + 1) * 32 < H; }
                     else { sl_f0 = fno; sl_tile0 = tno; sl_ox0 = col * cw - 32; sl_oy0 = band * 32 - 1; sl_right0 = (col + 1) * cw < W; sl_lower0 = (band + 1) * 32 < H; }
                     ct_load_tile(tiles + o * slot_words, gbits + (size_t)fno * bits_fstride, wpr_g, H, band * 32, (col * cw) >> 5, TW, lane);
@@ -308,20 +317,46 @@ __global__ __launch_bounds__(CTW_THREADS) void k_ct_walk(
             __builtin_amdgcn_wave_barrier(); // reads of the queue stay in front of the next refill's writes
         }
         // ---- the next state of a lane's marker pixel: the first foreground direction clockwise from a grid-active direction
-        if (!busy && a) {
-            const BitImage im{lbits, TW, 0, 0};
-            const unsigned ring0 = ring8(im, sx, sy);
-            const int d = __ffs((int)a) - 1;
-            const unsigned rr = ((ring0 | (ring0 << 8)) >> d) & 0xffu;
-            s0 = (d + 31 - __clz((int)rr)) & 7;
-            const unsigned e = s_lut[(ring0 << 3) | (unsigned)s0];
-            // the state's run, its 4-neighbour directions E, N, W, S (table bits 9, 7, 8, 10): all of them are this state's
-            a &= ~(((e >> 9) & 1u) | (((e >> 7) & 1u) << 2) | (((e >> 8) & 1u) << 4) | (((e >> 10) & 1u) << 6) | (1u << d));
-            kind = 0;
-            x = sx; y = sy; s = s0; n = 0; ring = ring0;
+        const bool starting = !busy && a;
+        if (starting) {
+            if (a & 0x100u) a &= ~0x100u; // x, y, s, ring stay
+            else {
+                const BitImage im{lbits, TW, 0, 0};
+                const unsigned ring0 = ring8(im, sx, sy);
+                const int d = __ffs((int)a) - 1;
+                const unsigned rr = ((ring0 | (ring0 << 8)) >> d) & 0xffu;
+                s0 = (d + 31 - __clz((int)rr)) & 7;
+                const unsigned e = s_lut[(ring0 << 3) | (unsigned)s0];
+                // the state's run, its 4-neighbour directions E, N, W, S (table bits 9, 7, 8, 10): all of them are this state's
+                a &= ~(((e >> 9) & 1u) | (((e >> 7) & 1u) << 2) | (((e >> 8) & 1u) << 4) | (((e >> 10) & 1u) << 6) | (1u << d));
+                kind = 0;
+                x = sx; y = sy; s = s0; ring = ring0;
+            }
+            skey = relay_key(x, y, s); n = 0;
             mn = 0xffffffffu; mnoff = 0;
-            allbot = sy == 33; allright = sx == cw + 32;
+            allbot = y == 33; allright = x == cw + 32;
+            code = 0; cpos = 0; cwi = 0;
             busy = true;
+        }
+        if (__any(starting)) { // their chain-code slots (wave-uniform bookkeeping: outside the branch)
+#pragma unroll
+            for (int o = 0; o < 2; o++) {
+                const bool me = starting && lslot == o;
+                const unsigned long long sm = __ballot(me);
+                if (!sm) continue;
+                const int ns = (int)__popcll(sm);
+                int used = o ? ch_used1 : ch_used0, cb = o ? ch_base1 : ch_base0;
+                if (used + ns > CTW_CHUNK) {
+                    const int leader = (int)__builtin_ctzll(sm);
+                    int nb = 0;
+                    if (lane == leader) nb = atomicAdd(&ctstate[(size_t)(o ? sl_f1 : sl_f0) * CT_STATE_INTS + 5], CTW_CHUNK);
+                    cb = __builtin_amdgcn_readlane(nb, leader);
+                    used = 0;
+                }
+                if (me) { cslot = cb + used + ctl_lane_prefix(sm); if (cslot >= code_slots) cslot = -1; }
+                used += ns;
+                if (o) { ch_used1 = used; ch_base1 = cb; } else { ch_used0 = used; ch_base0 = cb; }
+            }
         }
         if (!__any(busy)) {
             if (head >= total && phase >= 3 && !more && !__any(a != 0)) break;
@@ -338,8 +373,8 @@ __global__ __launch_bounds__(CTW_THREADS) void k_ct_walk(
                 const bool at_marker = (e & (((y & 31) == 1 ? 8u : 0u) | ((x & 31) == 0 ? 16u : 0u))) != 0;
                 bool stop;
                 if (kind == 0) {
-                    stop = n > 0 && at_marker;
-                    if (stop) { finished = true; endkey = relay_key(x, y, s); }
+                    stop = (n > 0 && at_marker) || n == CT_CODE_STEPS;
+                    if (stop) { finished = true; endkey = relay_key(x, y, s); if (!at_marker) a |= 0x100u; } // (a full slot: the segment is cut here)
                     else if (e & 0x60u) {
                         const uint32_t k = relay_key(x, y, s);
                         if (k < mn) { mn = k; mnoff = (uint32_t)n | ((((e >> 5) & 3u) == 2u ? 1u : 0u) << 31); }
@@ -361,7 +396,14 @@ __global__ __launch_bounds__(CTW_THREADS) void k_ct_walk(
                     else {
                         x = nx; y = ny; s = (int)((e + 4u) & 7u); n++;
                         ring = ring8(im, nx, ny);
-                        if (kind == 0) { allbot = allbot && ny == 33; allright = allright && nx == cw + 32; }
+                        if (kind == 0) {
+                            allbot = allbot && ny == 33; allright = allright && nx == cw + 32;
+                            code |= (e & 7u) << cpos; cpos += 3;
+                            if (cpos == 30) {
+                                if (cwi < CT_CODE_WORDS && cslot >= 0) codes[(size_t)CT_SLOT(sl_f, lslot) * codes_fstride + (size_t)cslot * CT_CODE_WORDS + cwi] = code;
+                                cwi++; code = 0; cpos = 0;
+                            }
+                        }
                         else if (nx == sx && ny == sy && s == s0) {
                             busy = false;
                             if (n > min_len) {
@@ -405,8 +447,11 @@ __global__ __launch_bounds__(CTW_THREADS) void k_ct_walk(
             if (mine) {
                 const int i = fcnt + ctl_lane_prefix(om);
                 const uint32_t koff = ((uint32_t)CT_SLOT(sl_oy, lslot) << 16) + ((uint32_t)CT_SLOT(sl_ox, lslot) << 3); // tile -> frame, for a state key
-                f_key[i] = relay_key(sx, sy, s0) + koff; f_nxt[i] = endkey + koff; f_len[i] = (uint32_t)n | ((uint32_t)CT_SLOT(sl_tile, lslot) << 16);
-                f_mn[i] = mn == 0xffffffffu ? mn : mn + koff; f_off[i] = mnoff; f_frm[i] = (uint32_t)CT_SLOT(sl_f, lslot);
+                f_key[i] = skey + koff; f_nxt[i] = endkey + koff; f_len[i] = (uint32_t)n;
+                f_mn[i] = mn == 0xffffffffu ? mn : mn + koff; f_off[i] = mnoff; f_frm[i] = (uint32_t)CT_SLOT(sl_f, lslot); f_slot[i] = (uint32_t)cslot;
+                // the last, partly filled word of its chain code; a full arena goes to the host's fallback
+                if (cpos && cwi < CT_CODE_WORDS && cslot >= 0) codes[(size_t)CT_SLOT(sl_f, lslot) * codes_fstride + (size_t)cslot * CT_CODE_WORDS + cwi] = code;
+                if (cslot < 0) atomicOr(&ctstate[(size_t)CT_SLOT(sl_f, lslot) * CT_STATE_INTS + 3], RL_FLAG_TABLE);
             }
             fcnt += nf;
             __builtin_amdgcn_wave_barrier();
@@ -430,15 +475,18 @@ __global__ __launch_bounds__(CTW_THREADS) void k_ct_walk(
 // closed cell: the cell whose closed rectangle ends at or after them).
 __global__ __launch_bounds__(CTB_THREADS) void k_ct_band(
     const uint32_t* __restrict__ gbits, size_t bits_fstride, int wpr_g, int W, int H, int min_len, const uint16_t* __restrict__ lut_g,
-    int rb /* cell rows per band */, int cw_p, int ncols_p /* tiling of k_ct_points: tiles of one cell row x cw_p columns */,
-    uint32_t* __restrict__ mlist, int mcap /* marker pixels per (frame, band) */, unsigned long long* __restrict__ htab, int hbits, unsigned gen,
+    int rb /* cell rows per band */, uint32_t* __restrict__ mlist, int mcap /* marker pixels per (frame, band) */, unsigned long long* __restrict__ htab, int hbits, unsigned gen,
     uint32_t* __restrict__ seg, size_t seg_fstride, int segcap, int32_t* __restrict__ ctstate, uint32_t* __restrict__ pool,
-    size_t pool_fstride, int pool_cap, int kcap, unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off)
+    size_t pool_fstride, int pool_cap, int kcap, unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off,
+    uint32_t* __restrict__ codes, size_t codes_fstride, int code_slots)
 {
     extern __shared__ __align__(16) unsigned char ctb_smem[];
     __shared__ __align__(16) uint16_t s_lut[2048];
     __shared__ int s_nm, s_next_d, s_next_c, s_ncand;
     __shared__ uint32_t s_fin[CTB_THREADS / 64][6 * CTW_FCAP];
+    // the wave's first chunk of chain-code slots (the round trip hides behind (a))
+    int ch_base = 0, ch_used = 0;
+    if ((threadIdx.x & 63) == 0) ch_base = atomicAdd(&ctstate[(size_t)blockIdx.y * CT_STATE_INTS + 5], CTB_CHUNK);
     __builtin_amdgcn_s_setprio(2);
     const int tid = threadIdx.x, lane = tid & 63, wid = wave_id(), NT = CTB_THREADS;
     const int band = blockIdx.x, f = blockIdx.y, nbands = gridDim.x;
@@ -514,7 +562,10 @@ __global__ __launch_bounds__(CTB_THREADS) void k_ct_band(
     uint32_t* f_len = fin + 2 * CTW_FCAP;
     uint32_t* f_mn = fin + 3 * CTW_FCAP;
     uint32_t* f_off = fin + 4 * CTW_FCAP;
+    uint32_t* f_slot = fin + 5 * CTW_FCAP;
     uint32_t* sg = seg + (size_t)f * seg_fstride;
+    uint32_t* cf = codes + (size_t)f * codes_fstride;
+    ch_base = __builtin_amdgcn_readfirstlane(ch_base);
     unsigned long long* ht = htab + ((size_t)f << hbits);
     int fcnt = 0;
     auto flush = [&]() {
@@ -526,7 +577,7 @@ __global__ __launch_bounds__(CTB_THREADS) void k_ct_band(
             if (id < segcap) {
                 const uint32_t key = f_key[lane];
                 sg[id] = key; sg[segcap + id] = f_nxt[lane]; sg[2 * segcap + id] = f_len[lane];
-                sg[3 * segcap + id] = f_mn[lane]; sg[4 * segcap + id] = f_off[lane];
+                sg[3 * segcap + id] = f_mn[lane]; sg[4 * segcap + id] = f_off[lane]; sg[5 * segcap + id] = f_slot[lane];
                 if (!ct_hash_insert(ht, hbits, key, id, gen, &st[3])) atomicOr(&st[3], RL_FLAG_TABLE);
             }
         }
@@ -536,11 +587,13 @@ __global__ __launch_bounds__(CTB_THREADS) void k_ct_band(
     // ---- (d) segments first (the longer walks), then (c) small borders; a wave goes from one to the other without a barrier.
     // A lane draws a marker pixel and walks its states one after the other; every trip advances each busy lane by CTB_STEPS steps.
     {
-        int x = 0, y = 0, s = 0, n = 0, sx = 0, sy = 0, s0 = 0, mx = 0, my = 0;
-        unsigned ring = 0, a = 0;
-        uint32_t mn = 0xffffffffu, mnoff = 0;
+        int x = 0, y = 0, s = 0, n = 0, sx = 0, sy = 0, cpos = 0, cwi = 0, cslot = -1;
+        unsigned ring = 0, a = 0; // a: the marker pixel's grid-active directions still to be walked; bit 8: the walk filled its chain-code slot and
+                                  // goes on as a new segment from the state it is in
+        uint32_t mn = 0xffffffffu, mnoff = 0, code = 0, skey = 0; // code: the walk's directions, 3 bits a step -- the word being filled; skey: its start state
         bool busy = false, drained = false, allbot = false;
         for (;;) {
+            bool starting = false;
             if (!busy) {
                 if (!a && !drained) {
                     const int i = atomicAdd(&s_next_d, 1);
@@ -553,16 +606,35 @@ __global__ __launch_bounds__(CTB_THREADS) void k_ct_band(
                     }
                 }
                 if (a) { // the next state of the lane's marker pixel: the first foreground direction clockwise from a grid-active direction
-                    const unsigned ring0 = ring8(im, sx, sy);
-                    const int d = __ffs((int)a) - 1;
-                    const unsigned rr = ((ring0 | (ring0 << 8)) >> d) & 0xffu;
-                    s0 = (d + 31 - __clz((int)rr)) & 7;
-                    const unsigned e = s_lut[(ring0 << 3) | (unsigned)s0];
-                    a &= ~(((e >> 9) & 1u) | (((e >> 7) & 1u) << 2) | (((e >> 8) & 1u) << 4) | (((e >> 10) & 1u) << 6) | (1u << d));
-                    x = sx; y = sy; s = s0; n = 0; ring = ring0; mx = sx; my = sy;
+                    if (a & 0x100u) a &= ~0x100u; // x, y, s, ring stay
+                    else {
+                        const unsigned ring0 = ring8(im, sx, sy);
+                        const int d = __ffs((int)a) - 1;
+                        const unsigned rr = ((ring0 | (ring0 << 8)) >> d) & 0xffu;
+                        const int s0 = (d + 31 - __clz((int)rr)) & 7;
+                        const unsigned e = s_lut[(ring0 << 3) | (unsigned)s0];
+                        a &= ~(((e >> 9) & 1u) | (((e >> 7) & 1u) << 2) | (((e >> 8) & 1u) << 4) | (((e >> 10) & 1u) << 6) | (1u << d));
+                        x = sx; y = sy; s = s0; ring = ring0;
+                    }
+                    skey = relay_key(x, y, s); n = 0;
                     mn = 0xffffffffu; mnoff = 0;
-                    allbot = sy == y1;
-                    busy = true;
+                    allbot = y == y1;
+                    code = 0; cpos = 0; cwi = 0;
+                    busy = true; starting = true;
+                }
+            }
+            {   // chain-code slots of the walks that start (wave-uniform bookkeeping: outside the branch)
+                const unsigned long long sm = __ballot(starting);
+                if (sm) {
+                    const int ns = (int)__popcll(sm);
+                    if (ch_used + ns > CTB_CHUNK) {
+                        int nb = 0;
+                        if (lane == 0) nb = atomicAdd(&st[5], CTB_CHUNK);
+                        ch_base = __builtin_amdgcn_readfirstlane(nb);
+                        ch_used = 0;
+                    }
+                    if (starting) { cslot = ch_base + ch_used + ctl_lane_prefix(sm); if (cslot >= code_slots) cslot = -1; }
+                    ch_used += ns;
                 }
             }
             if (!__any(busy || !drained || a != 0)) break;
@@ -573,6 +645,7 @@ __global__ __launch_bounds__(CTB_THREADS) void k_ct_band(
                 if (busy) {
                     const unsigned e = s_lut[(ring << 3) | (unsigned)s];
                     if (n > 0 && ct_is_marker(e, x, y)) { finished = true; endkey = relay_key(x, y, s); busy = false; }
+                    else if (n == CT_CODE_STEPS) { finished = true; endkey = relay_key(x, y, s); busy = false; a |= 0x100u; } // a full slot: the segment is cut here
                     else {
                         if (e & 0x60u) {
                             const uint32_t k = relay_key(x, y, s);
@@ -583,8 +656,12 @@ __global__ __launch_bounds__(CTB_THREADS) void k_ct_band(
                         else {
                             x += (int)((e >> 11) & 3u) - 1; y = ny; s = (int)((e + 4u) & 7u); n++;
                             ring = ring8(im, x, y);
-                            mx = max(mx, x); my = max(my, y);
                             allbot = allbot && ny == y1;
+                            code |= (e & 7u) << cpos; cpos += 3;
+                            if (cpos == 30) {
+                                if (cwi < CT_CODE_WORDS && cslot >= 0) cf[(size_t)cslot * CT_CODE_WORDS + cwi] = code;
+                                cwi++; code = 0; cpos = 0;
+                            }
                         }
                     }
                 }
@@ -596,8 +673,10 @@ __global__ __launch_bounds__(CTB_THREADS) void k_ct_band(
                 if (fcnt + nf > CTW_FCAP) flush();
                 if (mine) {
                     const int i = fcnt + ctl_lane_prefix(om);
-                    const int tile = ((my - 1) >> 5) * ncols_p + (((mx - 1) >> 5) << 5) / cw_p; // the closed cell that holds the segment
-                    f_key[i] = relay_key(sx, sy, s0); f_nxt[i] = endkey; f_len[i] = (uint32_t)n | ((uint32_t)tile << 16); f_mn[i] = mn; f_off[i] = mnoff;
+                    f_key[i] = skey; f_nxt[i] = endkey; f_len[i] = (uint32_t)n; f_mn[i] = mn; f_off[i] = mnoff; f_slot[i] = (uint32_t)cslot;
+                    // the last, partly filled word of its chain code; a full arena goes to the host's fallback
+                    if (cpos && cwi < CT_CODE_WORDS && cslot >= 0) cf[(size_t)cslot * CT_CODE_WORDS + cwi] = code;
+                    if (cslot < 0) atomicOr(&st[3], RL_FLAG_TABLE);
                 }
                 fcnt += nf;
                 __builtin_amdgcn_wave_barrier();
@@ -734,21 +813,21 @@ __device__ __forceinline__ void ct_lists_frame(const CtStore<LDSL> S, int f, int
                                                int segcap, const unsigned long long* __restrict__ ht, int hbits, unsigned gen, int min_len, int pool_cap,
                                                int kcap, unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off,
                                                int32_t* __restrict__ counts, int32_t* __restrict__ rstate, uint4* __restrict__ itA,
-                                               uint2* __restrict__ itB, int ipf, int2* __restrict__ tile_items, int ntiles,
-                                               int* s_sh /* 8 ints of LDS */, int* s_tcur /* ntiles + 1 ints of LDS */)
+                                               uint2* __restrict__ itB, int ipf, int32_t* __restrict__ nitems, int* s_sh /* 8 ints of LDS */)
 {
     const int tid = threadIdx.x, NT = (int)blockDim.x;
     const uint32_t* g_key = sg;
     const uint32_t* g_nxt = sg + segcap;
-    const uint32_t* g_len = sg + 2 * (size_t)segcap; // length | tile << 16
+    const uint32_t* g_len = sg + 2 * (size_t)segcap;
     const uint32_t* g_mn = sg + 3 * (size_t)segcap;
     const uint32_t* g_off = sg + 4 * (size_t)segcap;
+    const uint32_t* g_slot = sg + 5 * (size_t)segcap; // the chain code of the segment's walk
     int* s_flags = s_sh + 0;
     int* s_nkept = s_sh + 1;
     int* s_pool = s_sh + 2;
     int* s_ch = s_sh + 3; // three flags in rotation
-    if (tid == 0) { *s_flags = 0; *s_nkept = nk0; *s_pool = pool0; s_ch[0] = s_ch[1] = s_ch[2] = 0; }
-    for (int i = tid; i <= ntiles; i += NT) s_tcur[i] = 0;
+    int* s_nit = s_sh + 6;
+    if (tid == 0) { *s_flags = 0; *s_nkept = nk0; *s_pool = pool0; s_ch[0] = s_ch[1] = s_ch[2] = 0; *s_nit = 0; }
     __syncthreads();
     // ---- end states -> segment ids: the walk kernel entered every segment's start state into the frame's hash table
     for (int i = tid; i < nseg; i += NT) {
@@ -783,7 +862,7 @@ __device__ __forceinline__ void ct_lists_frame(const CtStore<LDSL> S, int f, int
         CtElem E = S.ld(i);
         const int nx = S.ldn(i);
         const CtElem N = S.ld(nx); // (its arg is final, whatever else the element holds by now)
-        E.v = g_len[i] & 0xffffu;
+        E.v = g_len[i];
         E.jmp = (N.arg == nx) ? (uint16_t)CT_NIL : (uint16_t)nx;
         S.st(i, E);
     }
@@ -837,52 +916,41 @@ __device__ __forceinline__ void ct_lists_frame(const CtStore<LDSL> S, int f, int
     int flags = *s_flags;
     if (*s_nkept > kcap) flags |= 2;
     if (flags) {
-        if (tid == 0) { counts[f * 4 + 0] = 0; counts[f * 4 + 1] = 0; counts[f * 4 + 2] = flags; counts[f * 4 + 3] = 0; }
+        if (tid == 0) { counts[f * 4 + 0] = 0; counts[f * 4 + 1] = 0; counts[f * 4 + 2] = flags; counts[f * 4 + 3] = 0; nitems[f] = 0; }
         return;
     }
-    // ---- (f2) one copy item per segment of a kept border, grouped by the tile that walked the segment (k_ct_points: a wave per
-    // tile).  Counting sort: segments per tile, exclusive scan, scatter.  Segment i starts (n - val[i]) points after the list head;
-    // the border starts `minoff` points into the head segment, so everything shifts down by minoff and the head's first points
-    // wrap to the end.
-    for (int i = tid; i < nseg; i += NT) {
-        const CtElem E = S.ld(i);
-        if (S.ld(E.arg).jmp != CT_NIL) atomicAdd(&s_tcur[g_len[i] >> 16], 1);
-    }
-    __syncthreads();
-    if (tid < 64) { // exclusive scan over the tiles by one wave; s_tcur[t] becomes the tile's write cursor
-        int run = 0;
-        for (int t0 = 0; t0 < ntiles; t0 += 64) {
-            const int t = t0 + tid;
-            const int c = t < ntiles ? s_tcur[t] : 0;
-            const int incl = wave_incl_scan_add(c);
-            if (t < ntiles) {
-                s_tcur[t] = run + incl - c;
-                tile_items[(size_t)f * ntiles + t] = make_int2(run + incl - c, (run + incl <= ipf) ? c : 0);
-            }
-            run += __builtin_amdgcn_readlane(incl, 63);
-        }
-        if (tid == 0) { s_tcur[ntiles] = run; if (run > ipf) atomicOr(s_flags, 4); } // more kept segments than the frame's item list holds: reported like a full pool
-    }
-    __syncthreads();
-    if (s_tcur[ntiles] <= ipf) {
+    // ---- (f2) one copy item per segment of a kept border (k_ct_points: a lane per item decodes the segment's chain code to its
+    // final place).  Segment i starts (n - val[i]) points after the list head; the border starts `minoff` points into the head
+    // segment, so everything shifts down by minoff and the head's first points wrap to the end.
+    {
         uint4* A = itA + (size_t)f * ipf;
         uint2* B2 = itB + (size_t)f * ipf;
-        for (int i = tid; i < nseg; i += NT) {
-            const CtElem E = S.ld(i);
-            const CtElem G = S.ld(E.arg);
-            if (G.jmp == CT_NIL) continue;
-            const int k = G.jmp, n = (int)G.v;
-            const int base = __hip_atomic_load(tail_off + (size_t)f * kcap + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const int dst = base + (n - (int)E.v) - (int)(g_off[E.arg] & 0x7fffffffu);
-            const uint32_t lt = g_len[i];
-            const int q = atomicAdd(&s_tcur[lt >> 16], 1);
-            A[q] = make_uint4(g_key[i], (uint32_t)dst, lt & 0xffffu, (uint32_t)base);
-            B2[q] = make_uint2((uint32_t)n, 0u);
+        const int lane = tid & 63;
+        for (int i0 = 0; i0 < nseg; i0 += NT) {
+            const int i = i0 + tid;
+            CtElem E{0, 0, 0}, G{0, CT_NIL, 0};
+            if (i < nseg) { E = S.ld(i); G = S.ld(E.arg); }
+            const bool kept = G.jmp != CT_NIL;
+            const unsigned long long km = __ballot(kept);
+            if (!km) continue;
+            int q0 = 0;
+            if (lane == 0) q0 = atomicAdd(s_nit, (int)__popcll(km));
+            const int q = __builtin_amdgcn_readfirstlane(q0) + ctl_lane_prefix(km);
+            if (kept && q < ipf) {
+                const int k = G.jmp, n = (int)G.v;
+                const int base = __hip_atomic_load(tail_off + (size_t)f * kcap + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int dst = base + (n - (int)E.v) - (int)(g_off[E.arg] & 0x7fffffffu);
+                A[q] = make_uint4(g_key[i], (uint32_t)dst, g_len[i], (uint32_t)base);
+                B2[q] = make_uint2((uint32_t)n, g_slot[i]);
+            }
         }
     }
     __syncthreads();
     if (tid == 0) {
-        counts[f * 4 + 0] = *s_nkept; counts[f * 4 + 1] = 0; counts[f * 4 + 2] = *s_flags; counts[f * 4 + 3] = ncand;
+        const int nit = *s_nit;
+        const int fl = *s_flags | (nit > ipf ? 4 : 0); // more kept segments than the frame's item list holds: reported like a full pool
+        counts[f * 4 + 0] = fl ? 0 : *s_nkept; counts[f * 4 + 1] = 0; counts[f * 4 + 2] = fl; counts[f * 4 + 3] = fl ? 0 : ncand;
+        nitems[f] = fl ? 0 : nit;
         rstate[f * 2 + 0] = 30; rstate[f * 2 + 1] = *s_pool;
     }
 }
@@ -892,7 +960,7 @@ __global__ __launch_bounds__(CTL_THREADS) void k_ct_lists(const uint32_t* __rest
                                                           unsigned long long* __restrict__ gelem, int lcap, int min_len, int pool_cap, int kcap,
                                                           unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off,
                                                           int32_t* __restrict__ counts, int32_t* __restrict__ rstate, uint4* __restrict__ itemsA,
-                                                          uint2* __restrict__ itemsB, int ipf, int2* __restrict__ tile_items, int ntiles)
+                                                          uint2* __restrict__ itemsB, int ipf, int32_t* __restrict__ nitems)
 {
     extern __shared__ __align__(16) unsigned char ctl_smem[];
     __shared__ int s_sh[8];
@@ -900,82 +968,75 @@ __global__ __launch_bounds__(CTL_THREADS) void k_ct_lists(const uint32_t* __rest
     __builtin_amdgcn_s_setprio(2);
     const int tid = threadIdx.x, f = blockIdx.x;
     int32_t* st = ctstate + (size_t)f * CT_STATE_INTS;
-    if (tid < 5) s_in[tid] = st[tid];
+    if (tid < 6) s_in[tid] = st[tid];
     __syncthreads();
-    if (tid < 5) st[tid] = 0; // the counters of the walk kernel are left at zero for the next batch
+    if (tid < 6) st[tid] = 0; // the counters of the walk kernel are left at zero for the next batch
     const int nseg = s_in[0], nk0 = s_in[1], pool0 = s_in[2], ncand = s_in[4];
     int flags = s_in[3];
     if (nseg > segcap) flags |= RL_FLAG_TABLE; // more segments than the frame's list holds: the host redoes the frame on a coarser grid
     if (flags) {
-        if (tid == 0) { counts[f * 4 + 0] = 0; counts[f * 4 + 1] = 0; counts[f * 4 + 2] = flags; counts[f * 4 + 3] = 0; }
+        if (tid == 0) { counts[f * 4 + 0] = 0; counts[f * 4 + 1] = 0; counts[f * 4 + 2] = flags; counts[f * 4 + 3] = 0; nitems[f] = 0; }
         return;
     }
     const uint32_t* sg = seg + (size_t)f * seg_fstride;
     const unsigned long long* ht = htab + ((size_t)f << hbits);
-    int* s_tcur = reinterpret_cast<int*>(ctl_smem);
-    unsigned char* lists = ctl_smem + (((size_t)ntiles + 1) * 4 + 15) / 16 * 16;
     unsigned long long* ge = gelem + (size_t)f * ((size_t)segcap + ((size_t)segcap + 3) / 4);
     uint16_t* gnx = reinterpret_cast<uint16_t*>(ge + segcap);
     if (nseg <= lcap) {
-        CtStore<true> S{reinterpret_cast<unsigned long long*>(lists), gnx};
+        CtStore<true> S{reinterpret_cast<unsigned long long*>(ctl_smem), gnx};
         ct_lists_frame<true>(S, f, nseg, nk0, pool0, ncand, sg, segcap, ht, hbits, gen, min_len, pool_cap, kcap, tail_keys, tail_off, counts, rstate, itemsA,
-                             itemsB, ipf, tile_items, ntiles, s_sh, s_tcur);
+                             itemsB, ipf, nitems, s_sh);
     } else {
         CtStore<false> S{ge, gnx};
         ct_lists_frame<false>(S, f, nseg, nk0, pool0, ncand, sg, segcap, ht, hbits, gen, min_len, pool_cap, kcap, tail_keys, tail_off, counts, rstate, itemsA,
-                              itemsB, ipf, tile_items, ntiles, s_sh, s_tcur);
+                              itemsB, ipf, nitems, s_sh);
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// (f2): a wave per tile, the grid of k_ct_walk again.  The tile's copy items -- the segments of kept borders it walked -- are walked
-// once more out of LDS, a lane each, their points going straight to their final place.
-__global__ __launch_bounds__(CTW_THREADS) void k_ct_points(
-    const uint32_t* __restrict__ gbits, size_t bits_fstride, int wpr_g, int W, int H, const uint16_t* __restrict__ lut_g, int cw, int ncols,
-    int nbands, int wgs_per_frame, int total_wgs, const int32_t* __restrict__ counts, const uint4* __restrict__ itemsA,
-    const uint2* __restrict__ itemsB, int ipf, const int2* __restrict__ tile_items, uint32_t* __restrict__ pool, size_t pool_fstride, int wave_bytes)
+// (f2): sixteen lanes per copy item -- a segment of a kept border.  The walk kernel recorded the segment's directions (3 bits a step,
+// ten steps a word, CT_CODE_WORDS words in the slot the walk drew from the frame's arena), so point o is the start pixel plus the
+// sum of the first o direction vectors: no bit image, no step table.  Lane j of a group holds word j of the code (one 64-byte
+// load); per pass the group's lanes take sixteen consecutive steps, fetch their word from the lane that holds it, and a scan over
+// the row of 16 lanes (DPP) of the packed steps (dx + 1 | dy + 1 << 16) gives every lane its point, which goes straight to its
+// final place in the pool: a group writes 64 consecutive bytes.  (A lane per item writing its points one after the other was
+// bound by the address units -- 64 cache lines per store instruction -- and no faster than walking the segments again out of an LDS
+// tile, which is what this kernel did first: 1920 x 1080 batch 157 / 130 us)
+__global__ __launch_bounds__(256) void k_ct_points(const uint4* __restrict__ itemsA, const uint2* __restrict__ itemsB, int ipf,
+                                                   const int32_t* __restrict__ nitems, const uint32_t* __restrict__ codes, size_t codes_fstride,
+                                                   uint32_t* __restrict__ pool, size_t pool_fstride)
 {
-    extern __shared__ __align__(16) unsigned char ctw_smem[];
-    __shared__ __align__(16) uint16_t s_lut[2048];
-    __builtin_amdgcn_s_setprio(2);
-    const int tid = threadIdx.x, lane = tid & 63, wid = wave_id();
-    int bx, f;
-    if (!xcd_remap(wgs_per_frame, total_wgs, bx, f)) return;
-    const int ntiles = nbands * ncols, tile0 = bx * (CTW_THREADS / 64);
-    if (counts[f * 4 + 2]) return; // the frame was given up
-    // (a workgroup none of whose tiles has an item -- most of them on a quiet frame -- leaves before the step table is loaded)
-    int any = 0;
-    if (tid < CTW_THREADS / 64 && tile0 + tid < ntiles) any = tile_items[(size_t)f * ntiles + tile0 + tid].y;
-    if (!__syncthreads_or(any)) return;
-    reinterpret_cast<uint4*>(s_lut)[tid] = reinterpret_cast<const uint4*>(lut_g)[tid];
-    __syncthreads();
-    const int tile_id = tile0 + wid;
-    if (tile_id >= ntiles) return;
-    const int2 ti = tile_items[(size_t)f * ntiles + tile_id];
-    if (ti.y <= 0) return;
-    const int band = tile_id / ncols, col = tile_id - band * ncols;
-    const RelayTile t = relay_tile(W, H, 32, cw, band, col);
-    const int nw = cw >> 5, TW = nw + 2, j0 = t.x0 >> 5;
-    uint32_t* tile = reinterpret_cast<uint32_t*>(ctw_smem + (size_t)wid * wave_bytes);
-    ct_load_tile(tile, gbits + (size_t)f * bits_fstride, wpr_g, H, t.y0, j0, TW, lane);
-    __builtin_amdgcn_wave_barrier();
-    const BitImage im{tile - (t.y0 - 1) * TW - (j0 - 1), TW, W, H};
+    const int f = blockIdx.y;
+    const int ni = nitems[f];
+    const int tid = threadIdx.x, j = tid & 15, gb = tid & 48;
     uint32_t* pl = pool + (size_t)f * pool_fstride;
-    const uint4* A = itemsA + (size_t)f * ipf + ti.x;
-    const uint2* B2 = itemsB + (size_t)f * ipf + ti.x;
-    for (int i = lane; i < ti.y; i += 64) {
-        const uint4 a = A[i];
-        const int n = (int)B2[i].x;
-        RelayWalk w2;
-        relay_walk_from_key(im, w2, a.x);
-        const int len = (int)a.z, base = (int)a.w;
-        int pdst = (int)a.y;
-        for (int o = 0; o < len; o++, pdst++) {
-            pl[pdst < base ? pdst + n : pdst] = relay_point(w2);
-            const unsigned e = s_lut[(w2.ring << 3) | (unsigned)w2.s];
-            w2.x += (int)((e >> 11) & 3u) - 1; w2.y += (int)((e >> 13) & 3u) - 1;
-            w2.s = (int)((e + 4u) & 7u);
-            w2.ring = ring8(im, w2.x, w2.y);
+    const uint32_t* cf = codes + (size_t)f * codes_fstride;
+    constexpr uint32_t DXP = (2u) | (2u << 2) | (1u << 4) | (0u << 6) | (0u << 8) | (0u << 10) | (1u << 12) | (2u << 14); // dir_dx() + 1, dir_dy() + 1
+    constexpr uint32_t DYP = (1u) | (0u << 2) | (0u << 4) | (0u << 6) | (1u << 8) | (2u << 10) | (2u << 12) | (2u << 14);
+    for (int i0 = (int)blockIdx.x * 16; i0 < ni; i0 += (int)gridDim.x * 16) {
+        const int i = i0 + (tid >> 4);
+        int len = 0, n = 0, base = 0, pdst = 0;
+        uint32_t pos = 0, myw = 0;
+        if (i < ni) {
+            const uint4 a = itemsA[(size_t)f * ipf + i];
+            const uint2 b = itemsB[(size_t)f * ipf + i];
+            n = (int)b.x; len = (int)a.z; base = (int)a.w; pdst = (int)a.y;
+            pos = (((a.x >> 3) & 0x1fffu) - 1u) | (((a.x >> 16) - 1u) << 16); // padded -> image coordinates, x | y << 16
+            myw = cf[(size_t)b.y * CT_CODE_WORDS + j];
+        }
+        for (int it = 0; __any(it * 16 < len); it++) {
+            const int o = it * 16 + j;
+            const int wi = (o * 205) >> 11, r = o - wi * 10; // o / 10, o % 10 (o < 176)
+            const uint32_t w = (uint32_t)__builtin_amdgcn_ds_bpermute((gb + min(wi, CT_CODE_WORDS - 1)) << 2, (int)myw);
+            const uint32_t d = (w >> (3 * r)) & 7u;
+            const uint32_t v = ((DXP >> (2 * d)) & 3u) | (((DYP >> (2 * d)) & 3u) << 16);
+            const uint32_t incl = (uint32_t)row16_incl_scan_add((int)v);
+            if (o < len) {
+                int idx = pdst + o;
+                if (idx < base) idx += n;
+                pl[idx] = pos + (incl - v) - (uint32_t)j * 0x10001u; // exact as one integer: both halves stay in [0, 65535]
+            }
+            pos += (uint32_t)__builtin_amdgcn_ds_bpermute((gb + 15) << 2, (int)incl) - 16u * 0x10001u;
         }
     }
 }

@@ -33,6 +33,12 @@ __device__ __forceinline__ int wave_incl_scan_add(int v)
 #undef ORBFE_STEP
     return v;
 }
+// inclusive scan inside each row of 16 lanes
+__device__ __forceinline__ int row16_incl_scan_add(int v)
+{
+    v += ORBFE_DPP(0, v, 0x111, 0xf); v += ORBFE_DPP(0, v, 0x112, 0xf); v += ORBFE_DPP(0, v, 0x114, 0xf); v += ORBFE_DPP(0, v, 0x118, 0xf);
+    return v;
+}
 __device__ __forceinline__ int wave_sum(int v) { return __builtin_amdgcn_readlane(wave_incl_scan_add(v), 63); }
 
 __device__ __forceinline__ int wave_max(int v)

@@ -121,7 +121,7 @@ def test_dense_frame_coarsens_the_relay_grid(orbfe, oracle):
         assert np.array_equal(got[f]["id"], want["id"])
 
 
-@pytest.mark.parametrize("pattern", ["spiral", "comb", "checker", "frame"])
+@pytest.mark.parametrize("pattern", ["spiral", "comb", "serpent", "checker", "frame"])
 def test_structured_binary_patterns(orbfe, oracle, pattern):
     """Long thin borders, borders between grid lines and one-pixel structures (the relay kernel's corner cases)."""
     img = np.full((240, 320), 200, np.uint8)
@@ -135,6 +135,13 @@ def test_structured_binary_patterns(orbfe, oracle, pattern):
         for x in range(34, 62, 4):
             img[35:62, x:x + 2] = 20
         img[60:62, 34:60] = 20
+    elif pattern == "serpent":     # the comb with a stem across a grid column: one segment of several hundred states between two grid
+        for x in range(34, 62, 4):  # markers (the tiled path records a segment's directions in slots of 160 steps and cuts it when one is full)
+            img[35:62, x:x + 2] = 20
+        img[60:62, 20:60] = 20
+        for y in range(100, 128, 4):  # and one across a grid row
+            img[y:y + 2, 100:126] = 20
+        img[90:126, 124:126] = 20
     elif pattern == "checker":
         yy, xx = np.mgrid[0:240, 0:320]
         img[((yy // 6 + xx // 6) % 2 == 0) & (yy > 30) & (yy < 200) & (xx > 40) & (xx < 280)] = 20
