@@ -508,10 +508,13 @@ struct orbfe_aruco {
                 if (ct_gen == 0) { ct_gen = 1; ct_tab_dirty = true; }
                 if (ct_tab_dirty) { ORBFE_HIP(hipMemsetAsync(d_cthtab.p, 0, d_cthtab.bytes, s)); ct_tab_dirty = false; }
                 ct_dirty = true;
-                const bool use_band = banded > 0 || (banded < 0 && B > 32);
+                // bands for full batches (eight waves level each other's load through the band's ticket counters) and, one cell row each, for
+                // up to four frames (single-frame call 0.385 -> 0.355 ms: the waves of a band share its start candidates, where a wave of
+                // k_ct_walk has its tile's to itself); a wave per tile in between
+                const bool use_band = banded > 0 || (banded < 0 && (B > 32 || B <= 4));
                 if (use_band) {
                     const int pw = (cols + 2 + 31) / 32, crows = (rows + 31) / 32;
-                    int rb = band_rows_env > 0 ? band_rows_env : std::max(1, std::min(8, (int)((36 * 1024 / (pw * 4) - 3) / 32)));
+                    int rb = band_rows_env > 0 ? band_rows_env : B <= 4 ? 1 : std::max(1, std::min(8, (int)((36 * 1024 / (pw * 4) - 3) / 32)));
                     rb = std::max(1, std::min(rb, crows));
                     const int nb = (crows + rb - 1) / rb;
                     const size_t blds = ctb_lds_bytes(cols, rb);
