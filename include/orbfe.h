@@ -690,6 +690,13 @@ int orbfe_pipeline_step_host(orbfe_pipeline* p, const uint8_t* h_imgs, size_t st
 int orbfe_pipeline_host_records(orbfe_pipeline* p, int set, const uint8_t** h_records);
 void* orbfe_host_alloc(size_t bytes);                        /* page-locked host memory (hipHostMalloc) / NULL */
 void orbfe_host_free(void* p);
+/* Device memory for a caller without a HIP toolchain of its own (the Python wrapper, a host language over FFI): zeroed memory on
+ * `device` / NULL, a blocking upload of `nrows` rows of `width` bytes (source rows `spitch` apart, destination rows `dpitch`), a
+ * blocking download of `bytes`.  The pointers are ordinary HIP device pointers of the library's runtime. */
+void* orbfe_device_alloc(int device, size_t bytes);
+void orbfe_device_free(void* d);
+int orbfe_device_upload_rows(void* d_dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t nrows);
+int orbfe_device_download(void* dst, const void* d_src, size_t bytes);
 int orbfe_pipeline_flush(orbfe_pipeline* p);                 /* enqueue the held-back post-work (matching, gather) of the newest batch */
 int orbfe_pipeline_synchronize(orbfe_pipeline* p);           /* flush + wait for everything enqueued */
 /* flush + wait until the engines of the batch written to `record_set` have read their frames (the input buffer may be reused) */

@@ -53,6 +53,7 @@ SYMBOLS = [
     "orbfe_pipeline_engine_sets", "orbfe_pipeline_enable_timing", "orbfe_pipeline_timing_us", "orbfe_pipeline_env_defaults",
     "orbfe_pipeline_comm_unique_id", "orbfe_pipeline_comm_init", "orbfe_pipeline_set_comm", "orbfe_pipeline_gathered",
     "orbfe_pipeline_step_host", "orbfe_pipeline_host_records", "orbfe_host_alloc", "orbfe_host_free",
+    "orbfe_device_alloc", "orbfe_device_free", "orbfe_device_upload_rows", "orbfe_device_download",
 ]
 
 _lib = None
@@ -967,6 +968,11 @@ class MarkerDetector:
     def set_tiled_contours(self, mode):
         """Debug: the tiled contour path (aruco_tiles.hip) None = by frame / batch size (default), True = every batch, False = never."""
         self.L.orbfe_aruco_debug_kernel_times(self.h, None, 4 if mode is None else 5 if mode else 6)
+
+    def contour_retries(self):
+        """Debug: how many batches of this detector were done again on the next contour path (tiled -> one workgroup -> single walker)
+        because a frame exceeded a capacity of the one they ran on."""
+        return int(self.L.orbfe_aruco_debug_kernel_times(self.h, None, 7))
 
     def rects(self, frame=0):
         out = np.zeros(self.capacity, RECT_DTYPE)

@@ -87,6 +87,7 @@ struct orbfe_aruco {
     int tiled = getenv("ORBFE_ARUCO_TILED") ? (atoi(getenv("ORBFE_ARUCO_TILED")) ? 1 : 0) : -1;
     bool tiled_off = false;    // set while a batch is redone by the relay kernels
     bool tiled_ran = false;    // the last batch took the tiled path
+    int n_escalations = 0;     // batches done again on the next contour path (debug query 7: the tests assert 0 for ordinary frames)
     // the walks of the tiled path by BANDS of cell rows, a workgroup of eight waves each (k_ct_band), instead of a wave per tile
     // (k_ct_walk): -1 = by frame / batch size, 0 / 1 forced; ORBFE_ARUCO_BAND_ROWS = cell rows per band (0: what fits ~36 KB of LDS, at most 8)
     int banded = getenv("ORBFE_ARUCO_BANDED") ? (atoi(getenv("ORBFE_ARUCO_BANDED")) ? 1 : 0) : -1;
@@ -94,7 +95,7 @@ struct orbfe_aruco {
     DevBuf d_ctmlist;
     int tile_w_env = getenv("ORBFE_ARUCO_TILE_W") ? atoi(getenv("ORBFE_ARUCO_TILE_W")) : 0;
     int tpw_env = getenv("ORBFE_ARUCO_TPW") ? atoi(getenv("ORBFE_ARUCO_TPW")) : 0;
-    int ct_segcap = 0, ct_hbits = 0, ct_lcap = 0, ct_items_per_frame = 0, ct_code_slots = 0;
+    int ct_segcap = 0, ct_hbits = 0, ct_lcap = 0, ct_items_per_frame = 0;
     bool ct_dirty = true;      // the per-frame counters of the walk kernel may be non-zero (first use; a batch abandoned before k_ct_lists)
     unsigned ct_gen = 0;       // generation tag of the hash table's entries (16 bits; the table is cleared when it wraps and before first use)
     bool ct_tab_dirty = true;
@@ -138,8 +139,8 @@ struct orbfe_aruco {
     {
         if (big_mode || force_legacy) return false;
         const bool was_tiled = tiled_ran;
-        if (was_tiled && (flags_or & RL_FALLBACK_FLAGS) && relay_tbits) { tiled_off = true; return true; }
-        if (flags_or & (2 | 4 | (was_tiled ? RL_FALLBACK_FLAGS : 0))) { big_mode = true; return true; }
+        if (was_tiled && (flags_or & RL_FALLBACK_FLAGS) && relay_tbits) { tiled_off = true; n_escalations++; return true; }
+        if (flags_or & (2 | 4 | (was_tiled ? RL_FALLBACK_FLAGS : 0))) { big_mode = true; n_escalations++; return true; }
         return false;
     }
     bool stateful() const { return thres_method == 1 || auto_size || tracking_min > 0; } // a frame's result depends on the frames before it
@@ -318,9 +319,6 @@ struct orbfe_aruco {
             while ((1 << ct_hbits) < 2 * sc) ct_hbits++;
             ct_lcap = std::min(ct_segcap, large ? 16384 : 4096);   // list elements k_ct_lists keeps in LDS (8 B each)
             ct_items_per_frame = std::max(4096, ct_segcap / 4);
-            // chain-code slots per frame: every started segment walk draws one (a shared grid line is walked from both sides), and the
-            // waves draw them in chunks
-            ct_code_slots = ct_segcap + ct_segcap / 2 + 4096;
         }
         rows = rows_; cols = cols_;
         pyr_rows = prows; pyr_cols = pcols;
@@ -352,10 +350,10 @@ struct orbfe_aruco {
             return rc;
         if (tiled != 0) {
             const size_t elem_words = (size_t)ct_segcap + ((size_t)ct_segcap + 3) / 4; // u64 elements + u16 next ids, per frame
-            if ((rc = d_ctseg.ensure((size_t)6 * ct_segcap * 4 * B)) || (rc = d_cthtab.ensure(((size_t)8 << ct_hbits) * B)) ||
+            if ((rc = d_ctseg.ensure((size_t)5 * ct_segcap * 4 * B)) || (rc = d_cthtab.ensure(((size_t)8 << ct_hbits) * B)) ||
                 (rc = d_ctelem.ensure(elem_words * 8 * B)) || (rc = d_ctstate.ensure((size_t)CT_STATE_INTS * 4 * B)) ||
                 (rc = d_ctitemsA.ensure((size_t)ct_items_per_frame * 16 * B)) || (rc = d_ctitemsB.ensure((size_t)ct_items_per_frame * 8 * B)) ||
-                (rc = d_ctnitems.ensure((size_t)4 * B)) || (rc = d_ctcodes.ensure((size_t)ct_code_slots * CT_CODE_WORDS * 4 * B)) ||
+                (rc = d_ctnitems.ensure((size_t)4 * B)) || (rc = d_ctcodes.ensure((size_t)ct_segcap * CT_CODE_WORDS * 4 * B)) ||
                 (rc = d_ctmlist.ensure((size_t)CTB_MCAP * 4 * ((rows + 31) / 32) * B)))   // (one list per band; at most one band per cell row)
                 return rc;
             ct_dirty = true; ct_tab_dirty = true;
@@ -500,7 +498,6 @@ struct orbfe_aruco {
                 const int tpw = tpw_env > 0 ? tpw_env : (B <= 32 ? 1 : 2);
                 const int walk_wgs = std::max(1, std::min((total_tiles / tpw + CTW_THREADS / 64 - 1) / (CTW_THREADS / 64), 256 * 8));
                 const size_t llds = (size_t)ct_lcap * 8 + 16;
-                const size_t codes_f = (size_t)ct_code_slots * CT_CODE_WORDS;
                 { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(k_ct_walk), (size_t)wlds); if (rc_lds_) return rc_lds_; }
                 { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(k_ct_lists), llds); if (rc_lds_) return rc_lds_; }
                 if (ct_dirty) ORBFE_HIP(hipMemsetAsync(d_ctstate.p, 0, (size_t)CT_STATE_INTS * 4 * B, s)); // first use, or a batch abandoned before k_ct_lists (which leaves them at zero)
@@ -521,22 +518,21 @@ struct orbfe_aruco {
                     { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(k_ct_band), blds); if (rc_lds_) return rc_lds_; }
                     hipLaunchKernelGGL(k_ct_band, dim3(nb, B), dim3(CTB_THREADS), blds, s, d_bits.as<uint32_t>(), bits_fu32, wpr, cols, rows, 70,
                                        d_lut.as<uint16_t>(), rb, d_ctmlist.as<uint32_t>(), CTB_MCAP, d_cthtab.as<unsigned long long>(), ct_hbits, ct_gen,
-                                       d_ctseg.as<uint32_t>(), (size_t)6 * ct_segcap, ct_segcap, d_ctstate.as<int32_t>(), d_pool.as<uint32_t>(), pool_fu32,
-                                       (int)pool_fu32, relay_kcap, d_tailkeys.as<unsigned long long>(), d_tailoff.as<int32_t>(), d_ctcodes.as<uint32_t>(),
-                                       codes_f, ct_code_slots);
+                                       d_ctseg.as<uint32_t>(), (size_t)5 * ct_segcap, ct_segcap, d_ctstate.as<int32_t>(), d_pool.as<uint32_t>(), pool_fu32,
+                                       (int)pool_fu32, relay_kcap, d_tailkeys.as<unsigned long long>(), d_tailoff.as<int32_t>(), d_ctcodes.as<uint4>());
                 } else
                 hipLaunchKernelGGL(k_ct_walk, dim3(walk_wgs), dim3(CTW_THREADS), wlds, s, d_bits.as<uint32_t>(), bits_fu32, wpr, cols, rows, 70,
                                    d_lut.as<uint16_t>(), cw, ncols, nbands, total_tiles, d_cthtab.as<unsigned long long>(), ct_hbits, ct_gen,
-                                   d_ctseg.as<uint32_t>(), (size_t)6 * ct_segcap, ct_segcap, d_ctstate.as<int32_t>(), d_pool.as<uint32_t>(), pool_fu32,
+                                   d_ctseg.as<uint32_t>(), (size_t)5 * ct_segcap, ct_segcap, d_ctstate.as<int32_t>(), d_pool.as<uint32_t>(), pool_fu32,
                                    (int)pool_fu32, relay_kcap, d_tailkeys.as<unsigned long long>(), d_tailoff.as<int32_t>(), wave_bytes,
-                                   d_ctcodes.as<uint32_t>(), codes_f, ct_code_slots);
-                hipLaunchKernelGGL(k_ct_lists, dim3(B), dim3(ct_lcap > 4096 ? 1024 : 512), llds, s, d_ctseg.as<uint32_t>(), (size_t)6 * ct_segcap, ct_segcap,
+                                   d_ctcodes.as<uint4>());
+                hipLaunchKernelGGL(k_ct_lists, dim3(B), dim3(ct_lcap > 4096 ? 1024 : 512), llds, s, d_ctseg.as<uint32_t>(), (size_t)5 * ct_segcap, ct_segcap,
                                    d_ctstate.as<int32_t>(), d_cthtab.as<unsigned long long>(), ct_hbits, ct_gen, d_ctelem.as<unsigned long long>(), ct_lcap, 70,
                                    (int)pool_fu32, relay_kcap, d_tailkeys.as<unsigned long long>(), d_tailoff.as<int32_t>(), d_counts.as<int32_t>(),
                                    d_rstate.as<int32_t>(), d_ctitemsA.as<uint4>(), d_ctitemsB.as<uint2>(), ct_items_per_frame, d_ctnitems.as<int32_t>());
                 if (hipPeekAtLastError() == hipSuccess) ct_dirty = false;
                 hipLaunchKernelGGL(k_ct_points, dim3(ct_items_per_frame >= 8192 ? 32 : 8, B), dim3(256), 0, s, d_ctitemsA.as<uint4>(), d_ctitemsB.as<uint2>(),
-                                   ct_items_per_frame, d_ctnitems.as<int32_t>(), d_ctcodes.as<uint32_t>(), codes_f, d_pool.as<uint32_t>(), pool_fu32);
+                                   ct_items_per_frame, d_ctnitems.as<int32_t>(), d_ctcodes.as<uint32_t>(), ct_segcap, d_pool.as<uint32_t>(), pool_fu32);
             } else {
             const size_t rlds = relay_lds_bytes(relay_global ? 0 : lds_bits_words, relay_kcap, relay_tbits);
             // A workgroup of the large-frame kernels takes a CU's whole LDS, so a launch of >= 256 frames shuts every kernel that
@@ -1516,7 +1512,9 @@ int orbfe_aruco_set_aux_stream(orbfe_aruco* h, void* stream)
 int orbfe_aruco_debug_kernel_times(orbfe_aruco* h, float* out_us, int capacity)
 {
     if (!h) return fail(ORBFE_ERR_INVALID, "null handle");
-    if (!out_us) { // control codes: 0/1 kernel timing off/on, 2/3 force the legacy contour kernel on/off, 4/5/6 tiled contour path by size / always / never
+    if (!out_us) { // control codes: 0/1 kernel timing off/on, 2/3 force the legacy contour kernel on/off, 4/5/6 tiled contour path by size / always / never,
+                   // 7 returns the number of batches that were done again on the next contour path
+        if (capacity == 7) return h->n_escalations;
         if (capacity == 2 || capacity == 3) h->force_legacy = capacity == 2;
         else if (capacity >= 4 && capacity <= 6) h->tiled = capacity == 4 ? -1 : capacity == 5 ? 1 : 0; // (the workspace of the tiled path exists unless ORBFE_ARUCO_TILED=0)
         else { h->timer.enabled = capacity != 0; h->timer.reset_history(); }

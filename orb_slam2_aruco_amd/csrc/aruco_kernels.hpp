@@ -181,12 +181,11 @@ __global__ void k_upsample_corners(ImgView src0, ImgView pyr, const ArLevel* lev
 #define CTW_TAKE 256             // enumeration items per refill of the queue (halved while they do not fit)
 #endif
 #define CTW_MAX_CW 480           // tile width limit: the marker pixels of all relay columns of a tile (31 x (cw / 32 + 1)) fit the queue
-#define CT_STATE_INTS 8          // per frame: segments, kept small borders, pool words in use, flags, start candidates, chain-code slots handed out
-#define CT_CODE_WORDS 16         // chain-code slot of a segment walk: 10 steps of 3 bits per word; a walk that fills its slot ends the segment there and
-                                 // goes on as the next one
+#define CT_STATE_INTS 8          // per frame: segments, kept small borders, pool words in use, flags, start candidates
+#define CT_CODE_WORDS 4          // chain code of a segment: 10 steps of 3 bits per word, kept in registers while the segment is walked and written with
+                                 // its record (16 bytes); a walk that fills it ends the segment there and goes on as the next one
 #define CT_CODE_STEPS (10 * CT_CODE_WORDS)
-#define CTB_CHUNK 128            // slots a wave of k_ct_band draws from the frame's arena at a time
-#define CTW_CHUNK 64             // ... a wave of k_ct_walk, per tile slot (>= 64: one draw serves every lane of the wave)
+#define CTB_FCAP 32              // finished segments a wave of k_ct_band collects before it appends them to the frame's list
 #define CTL_THREADS 1024
 #define CTB_THREADS 512          // k_ct_band: eight waves per band
 #define CTB_MCAP 8192            // marker pixels per (frame, band) its list holds
@@ -197,17 +196,17 @@ inline size_t ctb_lds_bytes(int W, int rb) { return ((size_t)((W + 2 + 31) >> 5)
 __global__ void k_ct_band(const uint32_t* gbits, size_t bits_fstride, int wpr_g, int W, int H, int min_len, const uint16_t* lut_g, int rb,
                           uint32_t* mlist, int mcap, unsigned long long* htab, int hbits, unsigned gen, uint32_t* seg, size_t seg_fstride, int segcap,
                           int32_t* ctstate, uint32_t* pool, size_t pool_fstride, int pool_cap, int kcap, unsigned long long* tail_keys, int32_t* tail_off,
-                          uint32_t* codes, size_t codes_fstride, int code_slots);
-inline int ctw_wave_lds_bytes(int cw) { return (2 * (CTW_ROWS * ((cw >> 5) + 2) + 2) * 4 + CTW_QCAP * 2 + CTW_FCAP * 28 + 15) & ~15; }   // two tile slots, queue, finished segments
+                          uint4* codes);
+inline int ctw_wave_lds_bytes(int cw) { return (2 * (CTW_ROWS * ((cw >> 5) + 2) + 2) * 4 + CTW_QCAP * 2 + CTW_FCAP * 40 + 15) & ~15; }   // two tile slots, queue, finished segments
 __global__ void k_ct_walk(const uint32_t* gbits, size_t bits_fstride, int wpr_g, int W, int H, int min_len, const uint16_t* lut_g, int cw, int ncols,
                           int nbands, int total_tiles, unsigned long long* htab, int hbits, unsigned gen, uint32_t* seg, size_t seg_fstride,
                           int segcap, int32_t* ctstate, uint32_t* pool, size_t pool_fstride, int pool_cap, int kcap, unsigned long long* tail_keys,
-                          int32_t* tail_off, int wave_bytes, uint32_t* codes, size_t codes_fstride, int code_slots);
+                          int32_t* tail_off, int wave_bytes, uint4* codes);
 __global__ void k_ct_lists(const uint32_t* seg, size_t seg_fstride, int segcap, int32_t* ctstate, const unsigned long long* htab, int hbits, unsigned gen,
                            unsigned long long* gelem, int lcap, int min_len, int pool_cap, int kcap, unsigned long long* tail_keys, int32_t* tail_off,
                            int32_t* counts, int32_t* rstate, uint4* itemsA, uint2* itemsB, int ipf, int32_t* nitems);
 __global__ void k_ct_points(const uint4* itemsA, const uint2* itemsB, int ipf, const int32_t* nitems, const uint32_t* codes,
-                            size_t codes_fstride, uint32_t* pool, size_t pool_fstride);
+                            int segcap, uint32_t* pool, size_t pool_fstride);
 
 // LDS of k_contours_relay: region R (bit image | list arrays) followed by the marker keys
 __host__ __device__ inline size_t relay_region_bytes(int lds_bits_words, int kcap, int tbits)

@@ -109,8 +109,7 @@ __global__ __launch_bounds__(CTW_THREADS) void k_ct_walk(
     int cw /* tile width in pixels: a multiple of 32, <= CTW_MAX_CW */, int ncols, int nbands, int total_tiles /* of the batch */,
     unsigned long long* __restrict__ htab, int hbits, unsigned gen, uint32_t* __restrict__ seg, size_t seg_fstride, int segcap,
     int32_t* __restrict__ ctstate, uint32_t* __restrict__ pool, size_t pool_fstride, int pool_cap, int kcap,
-    unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off, int wave_bytes, uint32_t* __restrict__ codes, size_t codes_fstride,
-    int code_slots)
+    unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off, int wave_bytes, uint4* __restrict__ codes /* segcap per frame */)
 {
     extern __shared__ __align__(16) unsigned char ctw_smem[];
     __shared__ __align__(16) uint16_t s_lut[2048];
@@ -122,7 +121,8 @@ __global__ __launch_bounds__(CTW_THREADS) void k_ct_walk(
     int next_tile = (int)blockIdx.x * (CTW_THREADS / 64) + wid;
     if (next_tile >= total_tiles) return;
     const int nw = cw >> 5, TW = nw + 2, slot_words = CTW_ROWS * TW + 2;
-    uint32_t* tiles = reinterpret_cast<uint32_t*>(ctw_smem + (size_t)wid * wave_bytes);
+    uint4* f_code = reinterpret_cast<uint4*>(ctw_smem + (size_t)wid * wave_bytes); // (first: 16-byte aligned)
+    uint32_t* tiles = reinterpret_cast<uint32_t*>(f_code + CTW_FCAP);
     uint16_t* queue = reinterpret_cast<uint16_t*>(tiles + 2 * slot_words);
     uint32_t* fin = reinterpret_cast<uint32_t*>(queue + CTW_QCAP);
     uint32_t* f_key = fin;
@@ -131,7 +131,6 @@ __global__ __launch_bounds__(CTW_THREADS) void k_ct_walk(
     uint32_t* f_mn = fin + 3 * CTW_FCAP;
     uint32_t* f_off = fin + 4 * CTW_FCAP;
     uint32_t* f_frm = fin + 5 * CTW_FCAP;
-    uint32_t* f_slot = fin + 6 * CTW_FCAP;
     const int stage0 = pool_cap >> 2;
 
     // the two tile slots (wave-uniform): frame, tile number inside the frame, what to add to tile coordinates, neighbours
@@ -141,8 +140,6 @@ __global__ __launch_bounds__(CTW_THREADS) void k_ct_walk(
     int phase = 3, it0 = 0;    // enumeration state of the current tile: phases 0 .. 2, 3 = done
     int head = 0, total = 0, qphase = 0, fcnt = 0, ncand_w = 0;
     bool more = true;
-    // chain-code slots: the wave draws CTW_CHUNK of them at a time from the arena of a tile slot's frame
-    int ch_base0 = 0, ch_base1 = 0, ch_used0 = CTW_CHUNK, ch_used1 = CTW_CHUNK;
 
     // per lane
     int x = 0, y = 0, s = 0, n = 0;   // walk state, tile coordinates
@@ -157,8 +154,8 @@ __global__ __launch_bounds__(CTW_THREADS) void k_ct_walk(
     bool allbot = false, allright = false;
     int lslot = 0;              // the slot of the lane's tile
     const uint32_t* lbits = tiles; // = tiles + lslot * slot_words
-    uint32_t code = 0;          // the segment walk's directions, 3 bits a step: the word being filled, its fill, words written, the walk's slot
-    int cpos = 0, cwi = 0, cslot = -1;
+    uint32_t code = 0, cd0 = 0, cd1 = 0, cd2 = 0; // the segment walk's directions, 3 bits a step: the word being filled and the full ones
+    int cpos = 0, cwi = 0;                        // fill of the word, number of full words
 
     auto flush = [&]() {
         // the list may hold segments of two frames: one atomic per frame
@@ -179,7 +176,8 @@ __global__ __launch_bounds__(CTW_THREADS) void k_ct_walk(
                     uint32_t* sg = seg + (size_t)lf * seg_fstride;
                     const uint32_t key = f_key[lane];
                     sg[id] = key; sg[segcap + id] = f_nxt[lane]; sg[2 * segcap + id] = f_len[lane];
-                    sg[3 * segcap + id] = f_mn[lane]; sg[4 * segcap + id] = f_off[lane]; sg[5 * segcap + id] = f_slot[lane];
+                    sg[3 * segcap + id] = f_mn[lane]; sg[4 * segcap + id] = f_off[lane];
+                    codes[(size_t)lf * segcap + id] = f_code[lane];
                     // start state -> id: the frame's hash table (k_ct_lists resolves the end states with it)
                     if (!ct_hash_insert(htab + ((size_t)lf << hbits), hbits, key, id, gen, &st[3])) atomicOr(&st[3], RL_FLAG_TABLE);
                 }
@@ -201,7 +199,6 @@ __global__ __launch_bounds__(CTW_THREADS) void k_ct_walk(
                 else {
                     const int fno = next_tile / tpf, tno = next_tile - fno * tpf, band = tno / ncols, col = tno - band * ncols;
                     next_tile += nwaves;
-                    if (fno != (o ? sl_f1 : sl_f0)) { if (o) ch_used1 = CTW_CHUNK; else ch_used0 = CTW_CHUNK; } // the slot's chunk is another frame's
                     if (o) { sl_f1 = fno; sl_tile1 = tno; sl_ox1 = col * cw - 32; sl_oy1 = band * 32 - 1; sl_right1 = (col + 1) * cw < W; sl_lower1 = (band + 1) * 32 < H; }
                     else { sl_f0 = fno; sl_tile0 = tno; sl_ox0 = col * cw - 32; sl_oy0 = band * 32 - 1; sl_right0 = (col + 1) * cw < W; sl_lower0 = (band + 1) * 32 < H; }
                     ct_load_tile(tiles + o * slot_words, gbits + (size_t)fno * bits_fstride, wpr_g, H, band * 32, (col * cw) >> 5, TW, lane);
@@ -319,7 +316,10 @@ __global__ __launch_bounds__(CTW_THREADS) void k_ct_walk(
         // ---- the next state of a lane's marker pixel: the first foreground direction clockwise from a grid-active direction
         const bool starting = !busy && a;
         if (starting) {
-            if (a & 0x100u) a &= ~0x100u; // x, y, s, ring stay
+            // The piece after a cut is this tile's whatever line it runs on: a neighbour can only come to its start state by walking the
+            // CT_CODE_STEPS states in front of it, and states that both tiles hold lie on one grid line -- at most 33 in a row.
+            const bool after_cut = (a & 0x100u) != 0;
+            if (after_cut) a &= ~0x100u; // x, y, s, ring stay
             else {
                 const BitImage im{lbits, TW, 0, 0};
                 const unsigned ring0 = ring8(im, sx, sy);
@@ -334,29 +334,9 @@ __global__ __launch_bounds__(CTW_THREADS) void k_ct_walk(
             }
             skey = relay_key(x, y, s); n = 0;
             mn = 0xffffffffu; mnoff = 0;
-            allbot = y == 33; allright = x == cw + 32;
+            allbot = !after_cut && y == 33; allright = !after_cut && x == cw + 32;
             code = 0; cpos = 0; cwi = 0;
             busy = true;
-        }
-        if (__any(starting)) { // their chain-code slots (wave-uniform bookkeeping: outside the branch)
-#pragma unroll
-            for (int o = 0; o < 2; o++) {
-                const bool me = starting && lslot == o;
-                const unsigned long long sm = __ballot(me);
-                if (!sm) continue;
-                const int ns = (int)__popcll(sm);
-                int used = o ? ch_used1 : ch_used0, cb = o ? ch_base1 : ch_base0;
-                if (used + ns > CTW_CHUNK) {
-                    const int leader = (int)__builtin_ctzll(sm);
-                    int nb = 0;
-                    if (lane == leader) nb = atomicAdd(&ctstate[(size_t)(o ? sl_f1 : sl_f0) * CT_STATE_INTS + 5], CTW_CHUNK);
-                    cb = __builtin_amdgcn_readlane(nb, leader);
-                    used = 0;
-                }
-                if (me) { cslot = cb + used + ctl_lane_prefix(sm); if (cslot >= code_slots) cslot = -1; }
-                used += ns;
-                if (o) { ch_used1 = used; ch_base1 = cb; } else { ch_used0 = used; ch_base0 = cb; }
-            }
         }
         if (!__any(busy)) {
             if (head >= total && phase >= 3 && !more && !__any(a != 0)) break;
@@ -399,10 +379,7 @@ __global__ __launch_bounds__(CTW_THREADS) void k_ct_walk(
                         if (kind == 0) {
                             allbot = allbot && ny == 33; allright = allright && nx == cw + 32;
                             code |= (e & 7u) << cpos; cpos += 3;
-                            if (cpos == 30) {
-                                if (cwi < CT_CODE_WORDS && cslot >= 0) codes[(size_t)CT_SLOT(sl_f, lslot) * codes_fstride + (size_t)cslot * CT_CODE_WORDS + cwi] = code;
-                                cwi++; code = 0; cpos = 0;
-                            }
+                            if (cpos == 30) { cd0 = cwi == 0 ? code : cd0; cd1 = cwi == 1 ? code : cd1; cd2 = cwi == 2 ? code : cd2; cwi++; if (cwi < CT_CODE_WORDS) { code = 0; cpos = 0; } }
                         }
                         else if (nx == sx && ny == sy && s == s0) {
                             busy = false;
@@ -448,10 +425,8 @@ __global__ __launch_bounds__(CTW_THREADS) void k_ct_walk(
                 const int i = fcnt + ctl_lane_prefix(om);
                 const uint32_t koff = ((uint32_t)CT_SLOT(sl_oy, lslot) << 16) + ((uint32_t)CT_SLOT(sl_ox, lslot) << 3); // tile -> frame, for a state key
                 f_key[i] = skey + koff; f_nxt[i] = endkey + koff; f_len[i] = (uint32_t)n;
-                f_mn[i] = mn == 0xffffffffu ? mn : mn + koff; f_off[i] = mnoff; f_frm[i] = (uint32_t)CT_SLOT(sl_f, lslot); f_slot[i] = (uint32_t)cslot;
-                // the last, partly filled word of its chain code; a full arena goes to the host's fallback
-                if (cpos && cwi < CT_CODE_WORDS && cslot >= 0) codes[(size_t)CT_SLOT(sl_f, lslot) * codes_fstride + (size_t)cslot * CT_CODE_WORDS + cwi] = code;
-                if (cslot < 0) atomicOr(&ctstate[(size_t)CT_SLOT(sl_f, lslot) * CT_STATE_INTS + 3], RL_FLAG_TABLE);
+                f_mn[i] = mn == 0xffffffffu ? mn : mn + koff; f_off[i] = mnoff; f_frm[i] = (uint32_t)CT_SLOT(sl_f, lslot);
+                f_code[i] = make_uint4(cwi == 0 ? code : cd0, cwi == 1 ? code : cd1, cwi == 2 ? code : cd2, cwi >= 3 ? code : 0u); // (the word being filled is word cwi)
             }
             fcnt += nf;
             __builtin_amdgcn_wave_barrier();
@@ -478,15 +453,12 @@ __global__ __launch_bounds__(CTB_THREADS) void k_ct_band(
     int rb /* cell rows per band */, uint32_t* __restrict__ mlist, int mcap /* marker pixels per (frame, band) */, unsigned long long* __restrict__ htab, int hbits, unsigned gen,
     uint32_t* __restrict__ seg, size_t seg_fstride, int segcap, int32_t* __restrict__ ctstate, uint32_t* __restrict__ pool,
     size_t pool_fstride, int pool_cap, int kcap, unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off,
-    uint32_t* __restrict__ codes, size_t codes_fstride, int code_slots)
+    uint4* __restrict__ codes /* segcap per frame */)
 {
     extern __shared__ __align__(16) unsigned char ctb_smem[];
     __shared__ __align__(16) uint16_t s_lut[2048];
     __shared__ int s_nm, s_next_d, s_next_c, s_ncand;
-    __shared__ uint32_t s_fin[CTB_THREADS / 64][6 * CTW_FCAP];
-    // the wave's first chunk of chain-code slots (the round trip hides behind (a))
-    int ch_base = 0, ch_used = 0;
-    if ((threadIdx.x & 63) == 0) ch_base = atomicAdd(&ctstate[(size_t)blockIdx.y * CT_STATE_INTS + 5], CTB_CHUNK);
+    __shared__ __align__(16) uint32_t s_fin[CTB_THREADS / 64][9 * CTB_FCAP];
     __builtin_amdgcn_s_setprio(2);
     const int tid = threadIdx.x, lane = tid & 63, wid = wave_id(), NT = CTB_THREADS;
     const int band = blockIdx.x, f = blockIdx.y, nbands = gridDim.x;
@@ -557,15 +529,14 @@ __global__ __launch_bounds__(CTB_THREADS) void k_ct_band(
     if (nmark > mcap) { if (tid == 0) atomicOr(&st[3], RL_FLAG_TABLE); return; } // more marker pixels than the band's list holds (noise): redone by the host
     const int stage0 = pool_cap >> 2;
     uint32_t* fin = s_fin[wid];
-    uint32_t* f_key = fin;
-    uint32_t* f_nxt = fin + CTW_FCAP;
-    uint32_t* f_len = fin + 2 * CTW_FCAP;
-    uint32_t* f_mn = fin + 3 * CTW_FCAP;
-    uint32_t* f_off = fin + 4 * CTW_FCAP;
-    uint32_t* f_slot = fin + 5 * CTW_FCAP;
+    uint4* f_code = reinterpret_cast<uint4*>(fin);
+    uint32_t* f_key = fin + 4 * CTB_FCAP;
+    uint32_t* f_nxt = fin + 5 * CTB_FCAP;
+    uint32_t* f_len = fin + 6 * CTB_FCAP;
+    uint32_t* f_mn = fin + 7 * CTB_FCAP;
+    uint32_t* f_off = fin + 8 * CTB_FCAP;
     uint32_t* sg = seg + (size_t)f * seg_fstride;
-    uint32_t* cf = codes + (size_t)f * codes_fstride;
-    ch_base = __builtin_amdgcn_readfirstlane(ch_base);
+    uint4* cf = codes + (size_t)f * segcap;
     unsigned long long* ht = htab + ((size_t)f << hbits);
     int fcnt = 0;
     auto flush = [&]() {
@@ -577,7 +548,8 @@ __global__ __launch_bounds__(CTB_THREADS) void k_ct_band(
             if (id < segcap) {
                 const uint32_t key = f_key[lane];
                 sg[id] = key; sg[segcap + id] = f_nxt[lane]; sg[2 * segcap + id] = f_len[lane];
-                sg[3 * segcap + id] = f_mn[lane]; sg[4 * segcap + id] = f_off[lane]; sg[5 * segcap + id] = f_slot[lane];
+                sg[3 * segcap + id] = f_mn[lane]; sg[4 * segcap + id] = f_off[lane];
+                cf[id] = f_code[lane];
                 if (!ct_hash_insert(ht, hbits, key, id, gen, &st[3])) atomicOr(&st[3], RL_FLAG_TABLE);
             }
         }
@@ -587,13 +559,13 @@ __global__ __launch_bounds__(CTB_THREADS) void k_ct_band(
     // ---- (d) segments first (the longer walks), then (c) small borders; a wave goes from one to the other without a barrier.
     // A lane draws a marker pixel and walks its states one after the other; every trip advances each busy lane by CTB_STEPS steps.
     {
-        int x = 0, y = 0, s = 0, n = 0, sx = 0, sy = 0, cpos = 0, cwi = 0, cslot = -1;
+        int x = 0, y = 0, s = 0, n = 0, sx = 0, sy = 0, cpos = 0, cwi = 0;
         unsigned ring = 0, a = 0; // a: the marker pixel's grid-active directions still to be walked; bit 8: the walk filled its chain-code slot and
                                   // goes on as a new segment from the state it is in
-        uint32_t mn = 0xffffffffu, mnoff = 0, code = 0, skey = 0; // code: the walk's directions, 3 bits a step -- the word being filled; skey: its start state
+        uint32_t mn = 0xffffffffu, mnoff = 0, skey = 0; // skey: the walk's start state
+        uint32_t code = 0, cd0 = 0, cd1 = 0, cd2 = 0;   // its directions, 3 bits a step: the word being filled (cpos bits in it) and the cwi full ones
         bool busy = false, drained = false, allbot = false;
         for (;;) {
-            bool starting = false;
             if (!busy) {
                 if (!a && !drained) {
                     const int i = atomicAdd(&s_next_d, 1);
@@ -606,7 +578,11 @@ __global__ __launch_bounds__(CTB_THREADS) void k_ct_band(
                     }
                 }
                 if (a) { // the next state of the lane's marker pixel: the first foreground direction clockwise from a grid-active direction
-                    if (a & 0x100u) a &= ~0x100u; // x, y, s, ring stay
+                    // The piece after a cut is this band's whatever row it runs on: the neighbour can only come to its start state by
+                    // walking the CT_CODE_STEPS states in front of it, and states that both bands hold lie on one relay row -- at most 33
+                    // in a row (a relay column ends the segment).
+                    const bool after_cut = (a & 0x100u) != 0;
+                    if (after_cut) a &= ~0x100u; // x, y, s, ring stay
                     else {
                         const unsigned ring0 = ring8(im, sx, sy);
                         const int d = __ffs((int)a) - 1;
@@ -618,23 +594,9 @@ __global__ __launch_bounds__(CTB_THREADS) void k_ct_band(
                     }
                     skey = relay_key(x, y, s); n = 0;
                     mn = 0xffffffffu; mnoff = 0;
-                    allbot = y == y1;
+                    allbot = !after_cut && y == y1;
                     code = 0; cpos = 0; cwi = 0;
-                    busy = true; starting = true;
-                }
-            }
-            {   // chain-code slots of the walks that start (wave-uniform bookkeeping: outside the branch)
-                const unsigned long long sm = __ballot(starting);
-                if (sm) {
-                    const int ns = (int)__popcll(sm);
-                    if (ch_used + ns > CTB_CHUNK) {
-                        int nb = 0;
-                        if (lane == 0) nb = atomicAdd(&st[5], CTB_CHUNK);
-                        ch_base = __builtin_amdgcn_readfirstlane(nb);
-                        ch_used = 0;
-                    }
-                    if (starting) { cslot = ch_base + ch_used + ctl_lane_prefix(sm); if (cslot >= code_slots) cslot = -1; }
-                    ch_used += ns;
+                    busy = true;
                 }
             }
             if (!__any(busy || !drained || a != 0)) break;
@@ -658,27 +620,24 @@ __global__ __launch_bounds__(CTB_THREADS) void k_ct_band(
                             ring = ring8(im, x, y);
                             allbot = allbot && ny == y1;
                             code |= (e & 7u) << cpos; cpos += 3;
-                            if (cpos == 30) {
-                                if (cwi < CT_CODE_WORDS && cslot >= 0) cf[(size_t)cslot * CT_CODE_WORDS + cwi] = code;
-                                cwi++; code = 0; cpos = 0;
-                            }
+                            if (cpos == 30) { cd0 = cwi == 0 ? code : cd0; cd1 = cwi == 1 ? code : cd1; cd2 = cwi == 2 ? code : cd2; cwi++; if (cwi < CT_CODE_WORDS) { code = 0; cpos = 0; } }
                         }
                     }
                 }
             }
             const bool mine = finished && !(lower && allbot);
-            const unsigned long long om = __ballot(mine);
-            if (om) {
-                const int nf = (int)__popcll(om);
-                if (fcnt + nf > CTW_FCAP) flush();
-                if (mine) {
-                    const int i = fcnt + ctl_lane_prefix(om);
-                    f_key[i] = skey; f_nxt[i] = endkey; f_len[i] = (uint32_t)n; f_mn[i] = mn; f_off[i] = mnoff; f_slot[i] = (uint32_t)cslot;
-                    // the last, partly filled word of its chain code; a full arena goes to the host's fallback
-                    if (cpos && cwi < CT_CODE_WORDS && cslot >= 0) cf[(size_t)cslot * CT_CODE_WORDS + cwi] = code;
-                    if (cslot < 0) atomicOr(&st[3], RL_FLAG_TABLE);
+            unsigned long long om = __ballot(mine);
+            while (om) { // into the wave's list; what does not fit goes in after the list has been appended to the frame's (one pass almost always)
+                if (fcnt == CTB_FCAP) flush();
+                const int rank = ctl_lane_prefix(om), room = CTB_FCAP - fcnt;
+                const bool put = mine && ((om >> lane) & 1ull) && rank < room;
+                if (put) {
+                    const int i = fcnt + rank;
+                    f_key[i] = skey; f_nxt[i] = endkey; f_len[i] = (uint32_t)n; f_mn[i] = mn; f_off[i] = mnoff;
+                    f_code[i] = make_uint4(cwi == 0 ? code : cd0, cwi == 1 ? code : cd1, cwi == 2 ? code : cd2, cwi >= 3 ? code : 0u); // (the word being filled is word cwi)
                 }
-                fcnt += nf;
+                fcnt += min((int)__popcll(om), room);
+                om &= ~__ballot(put);
                 __builtin_amdgcn_wave_barrier();
             }
         }
@@ -821,7 +780,6 @@ __device__ __forceinline__ void ct_lists_frame(const CtStore<LDSL> S, int f, int
     const uint32_t* g_len = sg + 2 * (size_t)segcap;
     const uint32_t* g_mn = sg + 3 * (size_t)segcap;
     const uint32_t* g_off = sg + 4 * (size_t)segcap;
-    const uint32_t* g_slot = sg + 5 * (size_t)segcap; // the chain code of the segment's walk
     int* s_flags = s_sh + 0;
     int* s_nkept = s_sh + 1;
     int* s_pool = s_sh + 2;
@@ -941,7 +899,7 @@ __device__ __forceinline__ void ct_lists_frame(const CtStore<LDSL> S, int f, int
                 const int base = __hip_atomic_load(tail_off + (size_t)f * kcap + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const int dst = base + (n - (int)E.v) - (int)(g_off[E.arg] & 0x7fffffffu);
                 A[q] = make_uint4(g_key[i], (uint32_t)dst, g_len[i], (uint32_t)base);
-                B2[q] = make_uint2((uint32_t)n, g_slot[i]);
+                B2[q] = make_uint2((uint32_t)n, (uint32_t)i);
             }
         }
     }
@@ -968,9 +926,9 @@ __global__ __launch_bounds__(CTL_THREADS) void k_ct_lists(const uint32_t* __rest
     __builtin_amdgcn_s_setprio(2);
     const int tid = threadIdx.x, f = blockIdx.x;
     int32_t* st = ctstate + (size_t)f * CT_STATE_INTS;
-    if (tid < 6) s_in[tid] = st[tid];
+    if (tid < 5) s_in[tid] = st[tid];
     __syncthreads();
-    if (tid < 6) st[tid] = 0; // the counters of the walk kernel are left at zero for the next batch
+    if (tid < 5) st[tid] = 0; // the counters of the walk kernel are left at zero for the next batch
     const int nseg = s_in[0], nk0 = s_in[1], pool0 = s_in[2], ncand = s_in[4];
     int flags = s_in[3];
     if (nseg > segcap) flags |= RL_FLAG_TABLE; // more segments than the frame's list holds: the host redoes the frame on a coarser grid
@@ -995,22 +953,22 @@ __global__ __launch_bounds__(CTL_THREADS) void k_ct_lists(const uint32_t* __rest
 
 // ---------------------------------------------------------------------------------------------------------------------
 // (f2): sixteen lanes per copy item -- a segment of a kept border.  The walk kernel recorded the segment's directions (3 bits a step,
-// ten steps a word, CT_CODE_WORDS words in the slot the walk drew from the frame's arena), so point o is the start pixel plus the
-// sum of the first o direction vectors: no bit image, no step table.  Lane j of a group holds word j of the code (one 64-byte
-// load); per pass the group's lanes take sixteen consecutive steps, fetch their word from the lane that holds it, and a scan over
-// the row of 16 lanes (DPP) of the packed steps (dx + 1 | dy + 1 << 16) gives every lane its point, which goes straight to its
-// final place in the pool: a group writes 64 consecutive bytes.  (A lane per item writing its points one after the other was
-// bound by the address units -- 64 cache lines per store instruction -- and no faster than walking the segments again out of an LDS
-// tile, which is what this kernel did first: 1920 x 1080 batch 157 / 130 us)
+// ten steps a word, CT_CODE_WORDS words next to the segment's record), so point o is the start pixel plus the sum of the first o
+// direction vectors: no bit image, no step table.  Lane j < 4 of a group holds word j of the code (one 16-byte load for the group);
+// per pass the group's lanes take sixteen consecutive steps, fetch their word from the lane that holds it, and a scan over the row of
+// 16 lanes (DPP) of the packed steps (dx + 1 | dy + 1 << 16) gives every lane its point, which goes straight to its final place in
+// the pool: a group writes 64 consecutive bytes.  (A lane per item writing its points one after the other was bound by the address
+// units -- 64 cache lines per store instruction -- and no faster than walking the segments again out of an LDS tile, which is what
+// this kernel did first: 1920 x 1080 batch 157 / 130 us)
 __global__ __launch_bounds__(256) void k_ct_points(const uint4* __restrict__ itemsA, const uint2* __restrict__ itemsB, int ipf,
-                                                   const int32_t* __restrict__ nitems, const uint32_t* __restrict__ codes, size_t codes_fstride,
+                                                   const int32_t* __restrict__ nitems, const uint32_t* __restrict__ codes, int segcap,
                                                    uint32_t* __restrict__ pool, size_t pool_fstride)
 {
     const int f = blockIdx.y;
     const int ni = nitems[f];
     const int tid = threadIdx.x, j = tid & 15, gb = tid & 48;
     uint32_t* pl = pool + (size_t)f * pool_fstride;
-    const uint32_t* cf = codes + (size_t)f * codes_fstride;
+    const uint32_t* cf = codes + (size_t)f * segcap * CT_CODE_WORDS;
     constexpr uint32_t DXP = (2u) | (2u << 2) | (1u << 4) | (0u << 6) | (0u << 8) | (0u << 10) | (1u << 12) | (2u << 14); // dir_dx() + 1, dir_dy() + 1
     constexpr uint32_t DYP = (1u) | (0u << 2) | (0u << 4) | (0u << 6) | (1u << 8) | (2u << 10) | (2u << 12) | (2u << 14);
     for (int i0 = (int)blockIdx.x * 16; i0 < ni; i0 += (int)gridDim.x * 16) {
@@ -1022,11 +980,11 @@ __global__ __launch_bounds__(256) void k_ct_points(const uint4* __restrict__ ite
             const uint2 b = itemsB[(size_t)f * ipf + i];
             n = (int)b.x; len = (int)a.z; base = (int)a.w; pdst = (int)a.y;
             pos = (((a.x >> 3) & 0x1fffu) - 1u) | (((a.x >> 16) - 1u) << 16); // padded -> image coordinates, x | y << 16
-            myw = cf[(size_t)b.y * CT_CODE_WORDS + j];
+            myw = cf[(size_t)b.y * CT_CODE_WORDS + (j & (CT_CODE_WORDS - 1))];
         }
         for (int it = 0; __any(it * 16 < len); it++) {
             const int o = it * 16 + j;
-            const int wi = (o * 205) >> 11, r = o - wi * 10; // o / 10, o % 10 (o < 176)
+            const int wi = (o * 205) >> 11, r = o - wi * 10; // o / 10, o % 10 (o < 48)
             const uint32_t w = (uint32_t)__builtin_amdgcn_ds_bpermute((gb + min(wi, CT_CODE_WORDS - 1)) << 2, (int)myw);
             const uint32_t d = (w >> (3 * r)) & 7u;
             const uint32_t v = ((DXP >> (2 * d)) & 3u) | (((DYP >> (2 * d)) & 3u) << 16);

@@ -447,6 +447,30 @@ void* orbfe_host_alloc(size_t bytes)
 }
 void orbfe_host_free(void* q) { if (q) (void)hipHostFree(q); }
 
+void* orbfe_device_alloc(int device, size_t bytes)
+{
+    void* q = nullptr;
+    if (hipSetDevice(device) != hipSuccess || hipMalloc(&q, bytes ? bytes : 1) != hipSuccess || hipMemset(q, 0, bytes) != hipSuccess) {
+        if (q) (void)hipFree(q);
+        fail(ORBFE_ERR_HIP, "orbfe_device_alloc: %zu bytes on device %d", bytes, device);
+        return nullptr;
+    }
+    return q;
+}
+void orbfe_device_free(void* d) { if (d) (void)hipFree(d); }
+int orbfe_device_upload_rows(void* d_dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t nrows)
+{
+    if (!d_dst || !src || dpitch < width || spitch < width) return fail(ORBFE_ERR_INVALID, "orbfe_device_upload_rows: invalid argument");
+    ORBFE_HIP(hipMemcpy2D(d_dst, dpitch, src, spitch, width, nrows, hipMemcpyHostToDevice));
+    return ORBFE_OK;
+}
+int orbfe_device_download(void* dst, const void* d_src, size_t bytes)
+{
+    if (!dst || !d_src) return fail(ORBFE_ERR_INVALID, "orbfe_device_download: null argument");
+    ORBFE_HIP(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return ORBFE_OK;
+}
+
 static int step_impl(orbfe_pipeline* p, const uint8_t* d_imgs, size_t pitch, int32_t* record_set, int in_slot)
 {
     int rc;

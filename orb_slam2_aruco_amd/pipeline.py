@@ -70,54 +70,41 @@ def valid_records(rec, use_orb=True):
     return out
 
 
-_hip = None
-
-
-def _hiprt():
-    global _hip
-    if _hip is None:
-        _hip = C.CDLL("libamdhip64.so")
-        _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-        _hip.hipMemcpy.restype = C.c_int
-    return _hip
-
-
 class DeviceBatch:
-    """A resident input batch: hipMalloc'd frames with 64-byte aligned rows (freed with the object)."""
+    """A resident input batch: frames in device memory with rows `pitch` bytes apart (orbfe_device_alloc of the library -- the runtime the
+    pipeline itself uses; freed with the object)."""
 
     def __init__(self, frames_u8, pitch, device=0):
-        hip = _hiprt()
+        from . import binding
+        self.L = binding.load()
+        _setup(self.L)
         f = np.ascontiguousarray(frames_u8, np.uint8)
         B, rows, cols = f.shape
         self.shape, self.pitch, self.nbytes = (B, rows, pitch), pitch, B * rows * pitch
-        hip.hipSetDevice(device)
-        p = C.c_void_p()
-        if hip.hipMalloc(C.byref(p), C.c_size_t(self.nbytes)) != 0:
-            raise RuntimeError("hipMalloc of %d bytes failed" % self.nbytes)
-        self.ptr = p.value
-        hip.hipMemset(C.c_void_p(self.ptr), 0, C.c_size_t(self.nbytes))
-        # hipMemcpy2D(dst, dpitch, src, spitch, width, height, hipMemcpyHostToDevice = 1): one row of every frame per line
-        rc = hip.hipMemcpy2D(C.c_void_p(self.ptr), C.c_size_t(pitch), f.ctypes.data_as(C.c_void_p), C.c_size_t(cols), C.c_size_t(cols),
-                             C.c_size_t(B * rows), 1)
+        self.ptr = self.L.orbfe_device_alloc(device, self.nbytes)
+        if not self.ptr:
+            raise RuntimeError("orbfe_device_alloc of %d bytes failed: %s" % (self.nbytes, self.L.orbfe_last_error().decode()))
+        rc = self.L.orbfe_device_upload_rows(self.ptr, pitch, f.ctypes.data_as(C.c_void_p), cols, cols, B * rows)
         if rc != 0:
-            raise RuntimeError("hipMemcpy2D H2D: %d" % rc)
-        hip.hipDeviceSynchronize()
+            raise RuntimeError("orbfe_device_upload_rows: %s" % self.L.orbfe_last_error().decode())
 
     def data_ptr(self):
         return self.ptr
 
     def __del__(self):
         if getattr(self, "ptr", None):
-            _hiprt().hipFree(C.c_void_p(self.ptr))
+            self.L.orbfe_device_free(self.ptr)
             self.ptr = None
 
 
 def device_bytes(ptr, nbytes):
-    """nbytes at device address ptr -> numpy uint8 (blocking hipMemcpy, device to host)."""
+    """nbytes at device address ptr -> numpy uint8 (blocking copy, device to host)."""
+    from . import binding
+    L = binding.load()
+    _setup(L)
     out = np.empty(nbytes, np.uint8)
-    rc = _hiprt().hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), nbytes, 2)
-    if rc != 0:
-        raise RuntimeError("hipMemcpy D2H: %d" % rc)
+    if L.orbfe_device_download(out.ctypes.data_as(C.c_void_p), ptr, nbytes) != 0:
+        raise RuntimeError("orbfe_device_download: %s" % L.orbfe_last_error().decode())
     return out
 
 
@@ -157,6 +144,12 @@ def _setup(L):
     L.orbfe_host_alloc.restype = vp
     L.orbfe_host_free.argtypes = [vp]
     L.orbfe_host_free.restype = None
+    L.orbfe_device_alloc.argtypes = [C.c_int, C.c_size_t]
+    L.orbfe_device_alloc.restype = vp
+    L.orbfe_device_free.argtypes = [vp]
+    L.orbfe_device_free.restype = None
+    L.orbfe_device_upload_rows.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.c_size_t]
+    L.orbfe_device_download.argtypes = [vp, vp, C.c_size_t]
     L._pipeline_ready = True
 
 

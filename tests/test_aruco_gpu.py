@@ -416,6 +416,32 @@ def test_tiled_and_one_workgroup_contour_paths(mode, tile_w, tpw, banded, band_r
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("rows,cols,dict_name", [(480, 640, "ARUCO"), (720, 1280, "ARUCO_MIP_25h7"), (1080, 1920, "ARUCO")])
+def test_tiled_path_completes_on_stream_frames(orbfe, rows, cols, dict_name):
+    """A frame that exceeds a capacity of the tiled contour path is done again on the one-workgroup kernels -- silently, with the same
+    answer.  Ordinary frames must not take that road (a walk bug that flags frames would hide behind it): forty frames (bands of cell
+    rows), eight (a wave per tile) and one (one-row bands) with the tiled path forced, no retries, and the markers, border counts and
+    candidate rectangles of the default path (one-workgroup kernels for the 640 x 480 batch of forty)."""
+    nf = 40 if rows < 1080 else 34
+    imgs = synth.stream(rows, cols, nf, 4242, dict_name, n_markers=4)
+    ref = orbfe.MarkerDetector(dict_name)
+    want = ref.detect_batch(imgs)
+    wkeys = [(_rects_key(ref, f), ref.counts(f)) for f in range(nf)]
+    assert ref.contour_retries() == 0
+    det = orbfe.MarkerDetector(dict_name)
+    det.set_tiled_contours(True)
+    for lo, hi in ((0, nf), (3, 11), (5, 6)):
+        got = det.detect_batch(imgs[lo:hi])
+        for f in range(lo, hi):
+            (ca, la), cnt = wkeys[f]
+            cb, lb = _rects_key(det, f - lo)
+            c2 = det.counts(f - lo)
+            assert np.array_equal(got[f - lo], want[f]) and np.array_equal(ca, cb) and np.array_equal(la, lb)
+            assert (cnt["nkept"], cnt["nrect"], cnt["ncand"]) == (c2["nkept"], c2["nrect"], c2["ncand"])
+    assert det.contour_retries() == 0
+    assert sum(len(w) for w in want) > 0
+
+
 def test_detector_paired_with_an_extractor(orbfe, oracle):
     """orbfe_extractor_pair_detector: the extractor's one-frame call starts the paired detector on the image it uploads; the detector's
     call takes that work if it is handed the same image and runs normally otherwise.  Same results in every case: same image (with
