@@ -526,11 +526,33 @@ def main():
                                       marker_capacity=args.marker_capacity, use_orb=use_orb, use_aruco=use_aruco)
     pipe = mkpipe()
     gloo_gather = None
+    rccl_error = None
     if multi and backend == "rccl":
-        uid = [pipeline_mod.comm_unique_id() if rank == 0 else None]
+        # every rank must end up on the same transport: a rank whose ncclCommInitRank fails says so over the gloo group, and then all of
+        # them gather through gloo from the host (a diagnostic line, flagged in config.parallelism and gather_check.transport)
+        try:
+            uid = [pipeline_mod.comm_unique_id() if rank == 0 else None]
+        except Exception as e:  # noqa: BLE001
+            uid, rccl_error = [None], repr(e)
         dist.broadcast_object_list(uid, src=0)
-        pipe.comm_init(uid[0], rank, world, 0)
-    elif multi:
+        if uid[0] is not None and rccl_error is None:
+            try:
+                pipe.comm_init(uid[0], rank, world, 0)
+            except Exception as e:  # noqa: BLE001
+                rccl_error = repr(e)
+        elif rccl_error is None:
+            rccl_error = "rank 0 could not create the RCCL id"
+        bad = torch.tensor([1 if rccl_error else 0], dtype=torch.int32)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if int(bad.item()):
+            errs = [None] * world
+            dist.all_gather_object(errs, rccl_error)
+            rccl_error = "; ".join("rank %d: %s" % (r, e) for r, e in enumerate(errs) if e) or "unknown"
+            if rank == 0:
+                print("bench.py: RCCL communicator not available (%s): gathering through gloo from the host" % rccl_error, file=sys.stderr)
+            backend = "gloo"
+            pipe = mkpipe()          # (a pipeline without a communicator)
+    if multi and backend != "rccl":
         gloo_gather = sharding.RecordGather(torch.zeros(pipe.layout.nbytes, dtype=torch.uint8))
     # resident input: R copies of the stream at different time offsets, one per step in rotation, so that no step finds its
     # frames in the 256 MiB Infinity Cache (copy r = the stream rolled by r * B / R frames)
@@ -670,7 +692,7 @@ def main():
         del chk
         gather_check = {"ranks": checked, "frames_per_rank": B, "what": "n, keypoints, descriptors, marker ids / corners / poses of "
                         "every frame, byte for byte", "transport": "RCCL send / recv inside liborbfe (orbfe_pipeline_comm_init)" if backend == "rccl"
-                        else "gloo from the host (test hook)"}
+                        else "gloo from the host (test hook)" if not rccl_error else "gloo from the host: RCCL was not available (%s)" % rccl_error}
 
     if rank == 0:
         stages = {nm: float(v) for nm, v in zip(binding.ORBextractor.stage_names(len(orb_us)), orb_us)}   # blur7 runs on a second stream

@@ -81,6 +81,23 @@ def test_bench_gpus_2_plain_command_launches_two_ranks(tmp_path):
     assert d["n_gpus"] == 2 and d["gather_check"]["ranks"] == [0, 1] and d["value"] > 0
 
 
+@pytest.mark.gpu
+def test_bench_falls_back_to_gloo_when_rccl_refuses(tmp_path):
+    """Two ranks on ONE device with the default transport: ncclCommInitRank refuses (duplicate GPU), every rank reports it over the
+    gloo group, and all of them gather through gloo from the host -- the line stays valid, says which transport it used and why."""
+    import json
+    out = tmp_path / "bfb.json"
+    env = dict(os.environ, ORBFE_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "ORBFE_BENCH_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--frames", "16", "--steps", "3", "--warmup", "1",
+                        "--cpu-frames", "0", "--out", str(out)], capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = json.loads(out.read_text())
+    assert d["n_gpus"] == 2 and d["gather_check"]["ranks"] == [0, 1] and d["value"] > 0
+    assert "RCCL was not available" in d["gather_check"]["transport"] and "gloo" in d["config"]["parallelism"]
+
+
 def _free_port():
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
