@@ -556,6 +556,7 @@ __global__ __launch_bounds__(CTB_THREADS) void k_ct_band(
         __builtin_amdgcn_wave_barrier();
         fcnt = 0;
     };
+#ifndef CTB_EXPERIMENT_SKIP_D
     // ---- (d) segments first (the longer walks), then (c) small borders; a wave goes from one to the other without a barrier.
     // A lane draws a marker pixel and walks its states one after the other; every trip advances each busy lane by CTB_STEPS steps.
     {
@@ -643,6 +644,10 @@ __global__ __launch_bounds__(CTB_THREADS) void k_ct_band(
         }
     }
     if (fcnt) flush();
+#endif
+#ifdef CTB_EXPERIMENT_SKIP_C
+    return; // (timing experiment: the share of phase (c); results are wrong)
+#endif
     // ---- (c) small borders: a lane takes one 32-pixel word of start candidates at a time (rows y0 + 1 .. y1: every row of the frame
     // belongs to one band; a candidate on a relay row stops at its first state, which is a marker)
     {
