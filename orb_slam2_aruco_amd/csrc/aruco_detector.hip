@@ -318,6 +318,7 @@ struct orbfe_aruco {
             ct_hbits = 1;
             while ((1 << ct_hbits) < 2 * sc) ct_hbits++;
             ct_lcap = std::min(ct_segcap, large ? 16384 : 4096);   // list elements k_ct_lists keeps in LDS (8 B each)
+            if (getenv("ORBFE_ARUCO_LCAP") && atoi(getenv("ORBFE_ARUCO_LCAP")) > 0) ct_lcap = std::min(ct_segcap, atoi(getenv("ORBFE_ARUCO_LCAP"))); // (measurement switch)
             ct_items_per_frame = std::max(4096, ct_segcap / 4);
         }
         rows = rows_; cols = cols_;
