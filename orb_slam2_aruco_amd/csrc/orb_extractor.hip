@@ -536,11 +536,11 @@ struct orbfe_extractor {
                                nodecap, veccap);
             const size_t lds = qt_lds_bytes(keycap_lds, nodecap, veccap);
             { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(&k_distribute), (size_t)(lds)); if (rc_lds_) return rc_lds_; }
-            hipLaunchKernelGGL(k_distribute, dim3(force_general_quadtree ? nlevels * B : std::min(nlevels * B, 512)), dim3(64), lds, s, dg,
-                               d_slots.as<uint32_t>(), slots_fu32, d_cellcnt.as<int32_t>(), ncells_total, d_keys.as<uint32_t>(), keys_fu32,
+            hipLaunchKernelGGL(k_distribute, dim3(nlevels, B), dim3(64), lds, s, dg, d_slots.as<uint32_t>(), slots_fu32,
+                               d_cellcnt.as<int32_t>(), ncells_total, d_keys.as<uint32_t>(), keys_fu32,
                                d_lvlout.as<uint32_t>(), out_total, d_lvlcnt.as<int32_t>(), nlevels,
                                d_lvlncand.as<int32_t>(), keycap_lds, nodecap, veccap,
-                               force_general_quadtree ? nullptr : d_fallback.as<int32_t>(), nlevels * B);
+                               force_general_quadtree ? nullptr : d_fallback.as<int32_t>());
         }
         timer.mark(s, "distribute");
         if ((rc = stage_event(1))) return rc;

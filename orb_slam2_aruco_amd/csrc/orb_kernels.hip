@@ -511,15 +511,18 @@ __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlan
 
 // The workgroup is a single wave: LDS operations of one wave execute in order, so a compiler-level barrier is enough.
 #define QT_SYNC() __builtin_amdgcn_wave_barrier()
-__device__ void qt_distribute_one(const int level, const int f, const LevelGeom* __restrict__ geom, const uint32_t* __restrict__ slots,
-                                  size_t slots_fstride, const int32_t* __restrict__ cellcnt,
-                                  int ncells_total, uint32_t* __restrict__ keyscratch,
-                                  size_t keys_fstride, uint32_t* __restrict__ lvl_out,
-                                  int out_fstride, int32_t* __restrict__ lvl_cnt, int nlevels,
-                                  int32_t* __restrict__ lvl_ncand, int keycap_lds, int nodecap, int veccap)
+__global__ __launch_bounds__(64) void k_distribute(const LevelGeom* __restrict__ geom, const uint32_t* __restrict__ slots,
+                                                   size_t slots_fstride, const int32_t* __restrict__ cellcnt,
+                                                   int ncells_total, uint32_t* __restrict__ keyscratch,
+                                                   size_t keys_fstride, uint32_t* __restrict__ lvl_out,
+                                                   int out_fstride, int32_t* __restrict__ lvl_cnt, int nlevels,
+                                                   int32_t* __restrict__ lvl_ncand, int keycap_lds, int nodecap,
+                                                   int veccap, const int32_t* __restrict__ only_flagged)
 {
     extern __shared__ __align__(16) unsigned char qt_smem[];
     const int lane = threadIdx.x;
+    const int level = blockIdx.x, f = blockIdx.y;
+    if (only_flagged && !only_flagged[f * nlevels + level]) return; // the pyramid fast path already did this level
     const LevelGeom g = geom[level];
 
     // carve LDS
@@ -873,27 +876,6 @@ __device__ void qt_distribute_one(const int level, const int f, const LevelGeom*
 #ifdef ORBFE_QT_TIMING
     if (lane == 0) lvl_ncand[f * nlevels + level] = (int)((qt1 - qt0) >> 8) | ((int)((qt2 - qt1) >> 8) << 10) | ((int)((clock64() - qt2) >> 8) << 20);
 #endif
-}
-
-// The general quadtree as a launch: with `only_flagged` (the normal case: it redoes the levels the pyramid fast path gave up, usually
-// none) a few hundred workgroups go through the (frame, level) flags and do what they find; one workgroup per (frame, level) had
-// 2400 workgroups of a C2 batch wait for ~50 KB of LDS each just to read a zero flag -- 61 us on the extractor's chain.  Without the
-// flags (orbfe_extractor debug switch: every level by this kernel) the grid covers every item.
-__global__ __launch_bounds__(64) void k_distribute(const LevelGeom* __restrict__ geom, const uint32_t* __restrict__ slots,
-                                                   size_t slots_fstride, const int32_t* __restrict__ cellcnt,
-                                                   int ncells_total, uint32_t* __restrict__ keyscratch,
-                                                   size_t keys_fstride, uint32_t* __restrict__ lvl_out,
-                                                   int out_fstride, int32_t* __restrict__ lvl_cnt, int nlevels,
-                                                   int32_t* __restrict__ lvl_ncand, int keycap_lds, int nodecap,
-                                                   int veccap, const int32_t* __restrict__ only_flagged, int nitems /* frames x levels */)
-{
-    for (int idx = (int)blockIdx.x; idx < nitems; idx += (int)gridDim.x) {
-        if (only_flagged && !only_flagged[idx]) continue; // the pyramid fast path already did this level
-        const int f = idx / nlevels, level = idx - f * nlevels;
-        qt_distribute_one(level, f, geom, slots, slots_fstride, cellcnt, ncells_total, keyscratch, keys_fstride, lvl_out, out_fstride, lvl_cnt, nlevels,
-                          lvl_ncand, keycap_lds, nodecap, veccap);
-        QT_SYNC();
-    }
 }
 
 // ------------------------------------------------------------------------------------------------ quadtree, fast path

@@ -70,7 +70,7 @@ __global__ void k_fast_cells(ImgView src0, ImgView pyr, const LevelGeom* geom, c
 __global__ void k_distribute(const LevelGeom* geom, const uint32_t* slots, size_t slots_fstride,
                              const int32_t* cellcnt, int ncells_total, uint32_t* keyscratch, size_t keys_fstride,
                              uint32_t* lvl_out, int out_fstride, int32_t* lvl_cnt, int nlevels, int32_t* lvl_ncand,
-                             int keycap_lds, int nodecap, int veccap, const int32_t* only_flagged, int nitems);
+                             int keycap_lds, int nodecap, int veccap, const int32_t* only_flagged);
 #define QT_MAXROOTS 16   // root nodes of DistributeOctTree (nIni = round(width / height), ORBextractor.cc:544) the kernels hold
 #define QP_THREADS 256
 __global__ void k_distribute_pyr(const LevelGeom* geom, const uint32_t* slots, size_t slots_fstride,
