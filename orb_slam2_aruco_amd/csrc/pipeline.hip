@@ -241,7 +241,7 @@ struct orbfe_pipeline {
 const char* orbfe_pipeline_env_defaults(void)
 {
     // one list for the pipeline and the engines: bench.py marks a line as diagnostic when one of these is set to something else
-    return "ORBFE_ENGINE_SETS=2;ORBFE_ENGINE_SETS_ARUCO=1;ORBFE_RECORD_SETS=4;ORBFE_PHASE_PIN=2;ORBFE_DET_PIN=4;ORBFE_DEFER_POST=size;ORBFE_DET_NOFORK=size;"
+    return "ORBFE_ENGINE_SETS=2;ORBFE_ENGINE_SETS_ARUCO=1;ORBFE_RECORD_SETS=4;ORBFE_PHASE_PIN=size;ORBFE_DET_PIN=4;ORBFE_DEFER_POST=size;ORBFE_DET_NOFORK=size;"
            "ORBFE_ORIENT_PAIR=1;ORBFE_FAST0=0;ORBFE_ARUCO_VIS=0;ORBFE_ARUCO_FORCE_GLOBAL=0;ORBFE_ARUCO_RELAY_CHUNK=0;ORBFE_ARUCO_RELAY_WIDE=1;"
            "ORBFE_ARUCO_SMALL_SEPARATE=size;ORBFE_ARUCO_TILED=size;ORBFE_ARUCO_TILE_W=0;ORBFE_ARUCO_TPW=0;ORBFE_ARUCO_BANDED=size;ORBFE_ARUCO_BAND_ROWS=0;ORBFE_ARUCO_LCAP=0;ORBFE_GRAPH=0;"
            "ORBFE_OCC_FAST=0;ORBFE_OCC_BLUR=0;ORBFE_OCC_ORIENT=0;ORBFE_BLUR_PLACE=1;ORBFE_NO_LEND=0;ORBFE_H2D_SPLIT=1;ORBFE_GRAPH_VERBOSE=0";
@@ -286,7 +286,10 @@ orbfe_pipeline* orbfe_pipeline_create(const orbfe_pipeline_config* cfg)
     p->D = std::max(1, pick(cfg->engine_sets, "ORBFE_ENGINE_SETS", 2));
     if (!p->use_orb) p->D = 1;
     p->R = std::max(2, pick(cfg->record_sets, "ORBFE_RECORD_SETS", 4));
-    p->phase_pin = pick(cfg->phase_pin, "ORBFE_PHASE_PIN", 2);
+    // the extractor sets' lock: behind the other set's quadtree up to 1280 x 720; behind its FAST above (1920 x 1080 with the banded contour
+    // kernels, four runs each: 3.15 - 3.19 ms per step, no lock at all 3.16 - 3.18, behind the quadtree 3.33 - 3.37, tools/r04_pins35b.sh)
+    const bool above_720p = (size_t)rows * cols > (size_t)1280 * 720;
+    p->phase_pin = pick(cfg->phase_pin, "ORBFE_PHASE_PIN", above_720p ? 1 : 2);
     p->det_pin = pick(cfg->det_pin, "ORBFE_DET_PIN", 4);
     p->defer_post = pick(cfg->defer_post, "ORBFE_DEFER_POST", vga ? 1 : 0) != 0;
     p->det_nofork = pick(cfg->det_nofork, "ORBFE_DET_NOFORK", vga ? 1 : 0) != 0;
