@@ -191,6 +191,10 @@ extern "C" int proto_find_contours_relay(const uint8_t* img, int w, int h, int k
 // its segments and its small borders from its own pixels plus one pixel on every side -- the rest of the image is filled with
 // noise in the tile's copy, so a read outside that window shows up as a wrong result -- and only the cyclic lists are global.
 // cells = tile width in grid cells.  stats: [segments, tiles, abandoned segment walks, skipped (neighbour's) segments, borders, abandoned small walks]
+// pieces of at most g_cut states per recorded segment (0: whole segments); the kernels use 40 at K = 32
+static int g_cut = 0;
+extern "C" void proto_set_cut(int cut) { g_cut = cut; }
+
 extern "C" int proto_find_contours_tiled(const uint8_t* img, int w, int h, int kshift, int cells, int32_t* lengths,
                                          int max_contours, int32_t* points, int max_points, int64_t* stats)
 {
@@ -204,7 +208,8 @@ extern "C" int proto_find_contours_tiled(const uint8_t* img, int w, int h, int k
     struct M { uint32_t key, next_key, cmin; int minoff, len, next; std::vector<uint32_t> pts; };
     std::vector<M> mk;
     std::unordered_map<uint32_t, int> idx;
-    int64_t n_abandoned = 0, n_skipped = 0, n_small_abandoned = 0, ntiles = 0;
+    int64_t n_abandoned = 0, n_skipped = 0, n_small_abandoned = 0, ntiles = 0, n_virtual = 0;
+    int rule_err = 0;
     const int nbands = (h + K - 1) / K, ncols = (w + cw - 1) / cw;
     uint32_t lcg = 12345u;
     for (int band = 0; band < nbands; band++)
@@ -228,30 +233,46 @@ extern "C" int proto_find_contours_tiled(const uint8_t* img, int w, int h, int k
                     const unsigned ring = ring8(im, px, py);
                     if (!ring) continue;
                     relay_states_of_pixel(ring, grid_active(ring, px, py, kmask), [&](int s0) {
-                        M m{relay_key(px, py, s0), 0u, 0xffffffffu, 0, 0, -1, {}};
                         RelayWalk wk;
-                        relay_walk_from_key(im, wk, m.key);
-                        bool allbot = py == t.y1, allright = px == t.x1, inside = true;
+                        relay_walk_from_key(im, wk, relay_key(px, py, s0));
+                        // A walk is recorded in pieces of at most g_cut states (the kernels keep a piece's directions in four registers):
+                        // the piece after a cut starts at a state that is no marker, so only the tile that walked up to it knows it --
+                        // it is that tile's whatever line it runs on (a neighbour would have had to walk the g_cut states in front of
+                        // it, and states two tiles share lie on one grid line: at most K + 1 in a row, g_cut > K + 1).
+                        bool after_cut = false;
                         for (;;) {
-                            unsigned run;
-                            const int d = relay_examine(wk.ring, wk.s, &run);
-                            if (wk.n > 0 && (run & grid_active(wk.ring, wk.x, wk.y, kmask))) { m.next_key = relay_key(wk.x, wk.y, wk.s); break; }
-                            if (relay_start_class(wk.ring, run)) {
-                                const uint32_t k = relay_key(wk.x, wk.y, wk.s);
-                                if (k < m.cmin) { m.cmin = k; m.minoff = wk.n; }
+                            M m{relay_key(wk.x, wk.y, wk.s), 0u, 0xffffffffu, 0, 0, -1, {}};
+                            const int n0 = wk.n;
+                            bool allbot = !after_cut && wk.y == t.y1, allright = !after_cut && wk.x == t.x1, inside = true, cut_here = false;
+                            for (;;) {
+                                unsigned run;
+                                const int d = relay_examine(wk.ring, wk.s, &run);
+                                const int np = wk.n - n0;
+                                if (np > 0 && (run & grid_active(wk.ring, wk.x, wk.y, kmask))) { m.next_key = relay_key(wk.x, wk.y, wk.s); break; }
+                                if (g_cut > 0 && np == g_cut) { m.next_key = relay_key(wk.x, wk.y, wk.s); cut_here = true; break; }
+                                if (relay_start_class(wk.ring, run)) {
+                                    const uint32_t k = relay_key(wk.x, wk.y, wk.s);
+                                    if (k < m.cmin) { m.cmin = k; m.minoff = np; }
+                                }
+                                m.pts.push_back(relay_point(wk));
+                                const int nx = wk.x + dir_dx(d), ny = wk.y + dir_dy(d);
+                                if (!relay_tile_has(t, nx, ny)) { inside = false; break; } // a neighbour's segment
+                                relay_advance(im, wk, d);
+                                allbot = allbot && wk.y == t.y1; allright = allright && wk.x == t.x1;
                             }
-                            m.pts.push_back(relay_point(wk));
-                            const int nx = wk.x + dir_dx(d), ny = wk.y + dir_dy(d);
-                            if (!relay_tile_has(t, nx, ny)) { inside = false; break; } // a neighbour's segment
-                            relay_advance(im, wk, d);
-                            allbot = allbot && wk.y == t.y1; allright = allright && wk.x == t.x1;
+                            if (!inside) { if (after_cut) rule_err = -13; n_abandoned++; return; } // (a walk never leaves its tile after a cut)
+                            if (after_cut || relay_tile_owns(t, allbot, allright)) {
+                                m.len = wk.n - n0;
+                                if (after_cut) n_virtual++;
+                                if (idx.count(m.key)) idx[m.key] = -1; // owned twice: reported below
+                                else { idx[m.key] = (int)mk.size(); mk.push_back(std::move(m)); }
+                            } else {
+                                n_skipped++;
+                                if (cut_here) rule_err = -14; // (a piece that fills the code is never a neighbour's)
+                            }
+                            if (!cut_here) return;
+                            after_cut = true;
                         }
-                        if (!inside) { n_abandoned++; return; }
-                        if (!relay_tile_owns(t, allbot, allright)) { n_skipped++; return; }
-                        m.len = wk.n;
-                        if (idx.count(m.key)) { idx[m.key] = -1; return; } // owned twice: reported below
-                        idx[m.key] = (int)mk.size();
-                        mk.push_back(std::move(m));
                     });
                 }
             // ---- small borders from the start candidates strictly between the tile's relay rows
@@ -307,7 +328,9 @@ extern "C" int proto_find_contours_tiled(const uint8_t* img, int w, int h, int k
                 });
             }
         if (bad) return -10;
-        if (nstates != mk.size()) return -11;
+        if (rule_err) return rule_err;
+        for (auto& kv : idx) if (kv.second < 0) return -15; // a piece after a cut owned twice
+        if (nstates + (size_t)n_virtual != mk.size()) return -11;
     }
     for (auto& m : mk) {
         auto it = idx.find(m.next_key);
@@ -365,7 +388,7 @@ extern "C" int proto_find_contours_tiled(const uint8_t* img, int w, int h, int k
     }
     if (stats) {
         stats[0] = (int64_t)mk.size(); stats[1] = ntiles; stats[2] = n_abandoned; stats[3] = n_skipped;
-        stats[4] = (int64_t)found.size(); stats[5] = n_small_abandoned;
+        stats[4] = (int64_t)found.size(); stats[5] = n_small_abandoned; stats[6] = n_virtual;
     }
     return (int)found.size();
 }

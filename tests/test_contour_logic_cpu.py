@@ -29,14 +29,19 @@ def protos(tmp_path_factory):
     P.proto_find_contours_tiled.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                             C.c_int, C.c_void_p]
 
-    def make(fn, *extra):
+    P.proto_set_cut.argtypes = [C.c_int]
+    P.proto_set_cut.restype = None
+
+    def make(fn, *extra, cut=0):
         def run(b, stats=None):
             b = np.ascontiguousarray(b, np.uint8)
             lens = np.zeros(200000, np.int32)
             pts = np.zeros((3000000, 2), np.int32)
             st = np.zeros(8, np.int64)
+            P.proto_set_cut(cut)
             n = fn(b.ctypes.data, b.shape[1], b.shape[0], *extra, lens.ctypes.data, len(lens), pts.ctypes.data,
                    len(pts), st.ctypes.data)
+            P.proto_set_cut(0)
             assert n >= 0, n
             if stats is not None:
                 stats[:] = st
@@ -54,10 +59,15 @@ def protos(tmp_path_factory):
             "relay8": make(P.proto_find_contours_relay, 3), "relay32": make(P.proto_find_contours_relay, 5),
             "tiled4x1": make(P.proto_find_contours_tiled, 2, 1), "tiled4x3": make(P.proto_find_contours_tiled, 2, 3),
             "tiled8x2": make(P.proto_find_contours_tiled, 3, 2), "tiled16x1": make(P.proto_find_contours_tiled, 4, 1),
-            "tiled32x1": make(P.proto_find_contours_tiled, 5, 1), "tiled32x20": make(P.proto_find_contours_tiled, 5, 20)}
+            "tiled32x1": make(P.proto_find_contours_tiled, 5, 1), "tiled32x20": make(P.proto_find_contours_tiled, 5, 20),
+            # the same with recorded segments cut into pieces of at most `cut` states (> K + 1; the kernels: 40 at K = 32)
+            "tiled4x1c6": make(P.proto_find_contours_tiled, 2, 1, cut=6), "tiled4x3c7": make(P.proto_find_contours_tiled, 2, 3, cut=7),
+            "tiled8x2c10": make(P.proto_find_contours_tiled, 3, 2, cut=10), "tiled32x1c40": make(P.proto_find_contours_tiled, 5, 1, cut=40),
+            "tiled32x20c34": make(P.proto_find_contours_tiled, 5, 20, cut=34)}
 
 
-@pytest.fixture(params=["trace", "relay4", "relay8", "relay32", "tiled4x1", "tiled4x3", "tiled8x2", "tiled16x1", "tiled32x1", "tiled32x20"])
+@pytest.fixture(params=["trace", "relay4", "relay8", "relay32", "tiled4x1", "tiled4x3", "tiled8x2", "tiled16x1", "tiled32x1", "tiled32x20",
+                        "tiled4x1c6", "tiled4x3c7", "tiled8x2c10", "tiled32x1c40", "tiled32x20c34"])
 def proto(request, protos):
     return protos[request.param]
 
@@ -114,3 +124,36 @@ def test_tiles_see_shared_grid_lines_once(protos, oracle):
         b = (rng.random((32, 48)) < (0.2 + 0.12 * k)).astype(np.uint8) * 255
         for name in ("tiled4x1", "tiled4x3", "tiled8x2", "tiled16x1"):
             assert _same(oracle.find_contours(b), protos[name](b)), (k, name)
+
+
+def test_cut_segments_have_one_owner(protos, oracle):
+    """A recorded segment is cut into pieces of at most `cut` states (the kernels keep a piece's directions in four registers: 40
+    states at K = 32).  The piece after a cut starts at a state that is no marker, so it belongs to the tile that walked up to it,
+    whatever grid line it runs on: combs and serpents inside one cell and across shared lines, random textures -- the prototype
+    reports a piece owned twice, by nobody, or a walk that leaves its tile after a cut; the contours equal the sequential scan's
+    and pieces were cut at all (stats[6])."""
+    st = np.zeros(8, np.int64)
+    rng = np.random.default_rng(7)
+    total_cut = 0
+    for name, K in (("tiled4x1c6", 4), ("tiled4x3c7", 4), ("tiled8x2c10", 8), ("tiled32x1c40", 32), ("tiled32x20c34", 32)):
+        imgs = []
+        b = np.zeros((4 * K + 3, 5 * K + 2), np.uint8)               # a comb inside one cell with a stem across a grid column and a grid row
+        for x in range(K + 1, 2 * K - 1, 2):
+            b[K + 1:2 * K - 2, x] = 255
+        b[2 * K - 3, K - 3:2 * K - 1] = 255
+        b[2 * K - 3:2 * K + 2, K + 1] = 255
+        imgs.append(b)
+        b = np.zeros((3 * K + 1, 4 * K + 1), np.uint8)               # a serpent that runs along both sides of a shared grid row
+        for x in range(2, 4 * K - 2, 4):
+            b[K - 3:K + 2, x] = 255
+            b[K - 3 if (x // 4) % 2 else K + 1, x:x + 5] = 255
+        imgs.append(b)
+        for d in (0.35, 0.5, 0.65):
+            imgs.append((rng.random((3 * K + 5, 4 * K + 3)) < d).astype(np.uint8) * 255)
+        if K == 32:
+            img, _ = synth.scene(240, 320, 5, "ARUCO", 2, side_range=(40, 70))
+            imgs.append(oracle.adaptive_threshold(img, 3, 7))
+        for b in imgs:
+            assert _same(oracle.find_contours(b), protos[name](b, st)), (name, b.shape)
+            total_cut += int(st[6])
+    assert total_cut > 20
