@@ -15,6 +15,9 @@
 #include "aruco_kernels.hpp"
 #include "wave_dpp.hpp"
 
+#ifndef ORBFE_PRIO_DET_TAIL
+#define ORBFE_PRIO_DET_TAIL 0 // wave priority of the detector's short kernels behind the contours (k_tail_approx, k_tail_finish, k_decode_warp, k_decode_vote)
+#endif
 namespace orbfe {
 
 __device__ __forceinline__ int a_lane_prefix(unsigned long long mask)
@@ -1802,6 +1805,7 @@ __global__ __launch_bounds__(256) void k_tail_approx(int kcap, const uint4* __re
                                                      const uint32_t* __restrict__ pool, size_t pool_fstride, ArKept* __restrict__ kept_out,
                                                      int kept_cap, uint8_t* __restrict__ rectflag, int pts)
 {
+    if (ORBFE_PRIO_DET_TAIL) __builtin_amdgcn_s_setprio(ORBFE_PRIO_DET_TAIL);
     extern __shared__ __align__(16) unsigned char ta_smem[];
     const int lane = threadIdx.x & 63, wid = wave_id();
     ApPt* o = (ApPt*)ta_smem + wid * AP_OUT;
@@ -1895,6 +1899,7 @@ __global__ __launch_bounds__(64) void k_tail_finish(int kcap, const uint8_t* __r
                                                     int kept_cap, ArRect* __restrict__ rects_out, int rect_cap, int32_t* __restrict__ counts,
                                                     int32_t* __restrict__ ctr)
 {
+    if (ORBFE_PRIO_DET_TAIL) __builtin_amdgcn_s_setprio(ORBFE_PRIO_DET_TAIL);
     const int f = blockIdx.x, lane = threadIdx.x;
     if (f == 0 && lane == 0) { ctr[0] = 0; ctr[1] = 0; } // every consumer of this batch's work list is done: ready for the next batch
     const int flags = counts[f * 4 + 2];
@@ -2125,6 +2130,7 @@ __global__ __launch_bounds__(DC_WAVES * 64) void k_decode_warp(ImgView src0, Img
                                                                DcItem* __restrict__ items, uint16_t* __restrict__ hist,
                                                                uint8_t* __restrict__ patch)
 {
+    if (ORBFE_PRIO_DET_TAIL) __builtin_amdgcn_s_setprio(ORBFE_PRIO_DET_TAIL);
     __shared__ uint32_t s_hist[DC_WAVES][256];
     const int lane = threadIdx.x & 63, wid = wave_id();
     const int nitems = wctr[0];
@@ -2292,6 +2298,7 @@ __global__ __launch_bounds__(DC_WAVES * 64) void k_decode_vote(ImgView src0, Img
                                                                const DcItem* __restrict__ items, const uint8_t* __restrict__ patch,
                                                                int32_t* __restrict__ result /*per slot: id, nrot*/)
 {
+    if (ORBFE_PRIO_DET_TAIL) __builtin_amdgcn_s_setprio(ORBFE_PRIO_DET_TAIL);
     __shared__ int s_ones[DC_WAVES][64], s_tot[DC_WAVES][64];
     __shared__ uint8_t s_bits[DC_WAVES][64];
     __shared__ unsigned long long s_ids[DC_WAVES][4];
