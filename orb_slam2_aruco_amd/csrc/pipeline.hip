@@ -190,15 +190,19 @@ struct orbfe_pipeline {
         }
         const size_t nb = (size_t)lay.nbytes;
         ORBFE_NCCL(R->GroupStart());
+        int ge = 0; // the first error inside the group: the group is closed whatever happens
+        const char* gwhat = "";
         if (rank == dst) {
-            for (int r = 0; r < world; r++) {
+            for (int r = 0; r < world && !ge; r++) {
                 if (r == rank && world > 1) continue;
-                ORBFE_NCCL(R->Recv(blocks + (size_t)r * nb, nb, NCCL_UINT8, r, comm, st_match));
+                if ((ge = R->Recv(blocks + (size_t)r * nb, nb, NCCL_UINT8, r, comm, st_match))) gwhat = "ncclRecv";
             }
-            if (world == 1) ORBFE_NCCL(R->Send(recs[cur], nb, NCCL_UINT8, dst, comm, st_match)); // the one-GPU box: the same kernels, to itself
-        } else
-            ORBFE_NCCL(R->Send(recs[cur], nb, NCCL_UINT8, dst, comm, st_match));
-        ORBFE_NCCL(R->GroupEnd());
+            if (world == 1 && !ge && (ge = R->Send(recs[cur], nb, NCCL_UINT8, dst, comm, st_match))) gwhat = "ncclSend"; // the one-GPU box: the same kernels, to itself
+        } else if ((ge = R->Send(recs[cur], nb, NCCL_UINT8, dst, comm, st_match)))
+            gwhat = "ncclSend";
+        const int gend = R->GroupEnd();
+        if (ge) return fail(ORBFE_ERR_HIP, "%s failed: %s", gwhat, R->GetErrorString ? R->GetErrorString(ge) : "RCCL error");
+        if (gend) return fail(ORBFE_ERR_HIP, "ncclGroupEnd failed: %s", R->GetErrorString ? R->GetErrorString(gend) : "RCCL error");
         if (rank == dst && world > 1) ORBFE_HIP(hipMemcpyAsync(blocks + (size_t)rank * nb, recs[cur], nb, hipMemcpyDeviceToDevice, st_match));
         if (timing) ORBFE_HIP(hipEventRecord(e[1], st_match));
         ORBFE_HIP(hipEventRecord(gather_done[cur], st_match));
