@@ -42,6 +42,16 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* liborbfe.so is built with -fvisibility=hidden: what is declared between here and the matching pop is its whole dynamic symbol table */
+/* the four opaque handles (their members are not part of the ABI: declared before the push, so that the library's own definitions
+ * of them keep hidden visibility) */
+typedef struct orbfe_extractor orbfe_extractor;   /* ORB_SLAM2::ORBextractor */
+typedef struct orbfe_aruco orbfe_aruco;           /* aruco::MarkerDetector */
+typedef struct orbfe_vocabulary orbfe_vocabulary; /* DBoW2 ORBVocabulary */
+typedef struct orbfe_pipeline orbfe_pipeline;     /* the batched-video mode */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 /* status codes (0 = ok, <0 = error; orbfe_last_error() holds the message of the calling thread) */
 #define ORBFE_OK 0
@@ -69,7 +79,6 @@ const char* orbfe_version(void);
 int orbfe_device_count(void); /* number of usable HIP devices, 0 if none */
 
 /* ------------------------------------------------------------------ ORB extractor -- */
-typedef struct orbfe_extractor orbfe_extractor;
 
 /* ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST); device = HIP device ordinal. NULL on error. */
 orbfe_extractor* orbfe_extractor_create(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST,
@@ -394,7 +403,6 @@ int orbfe_distinctive_descriptors_device(const uint8_t* d_desc, const int32_t* d
  * KeyFrame::ComputeBoW use it (src/Frame.cc:348-355, src/KeyFrame.cc): transform(descriptors, BowVector, FeatureVector, 4).
  * The handle owns the tree in HBM.  scoring / weighting are DBoW2's enums (BowVector.h:37-55): weighting 0 TF_IDF, 1 TF,
  * 2 IDF, 3 BINARY; scoring 0 L1_NORM .. 5 DOT_PRODUCT (decides the normalisation, ScoringObject.h:74-91). */
-typedef struct orbfe_vocabulary orbfe_vocabulary;
 
 /* TemplatedVocabulary::loadFromTextFile (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1338-1425; System.cc loads
  * ORBvoc.txt with it): "k L scoring weighting" then one line per node "parent isLeaf d0..d31 weight".  An empty line --
@@ -509,7 +517,6 @@ int orbfe_keyframe_features_pack_device(const orbfe_keypoint* d_kps, const uint8
                                         int max_records_per_segment, uint8_t* d_file, void* stream);
 
 /* ------------------------------------------------------------------ ArUco marker detector -- */
-typedef struct orbfe_aruco orbfe_aruco;
 
 /* MarkerDetector + setDictionary(dict) + setDetectionMode(DM_NORMAL) +
  * setCornerRefinementMethod(CORNER_LINES): the configuration of src/Frame.cc:135-137. NULL on error. */
@@ -580,7 +587,8 @@ int orbfe_aruco_detect_batch_device(orbfe_aruco* h, const uint8_t* d_imgs, int n
  * following batches. */
 int orbfe_aruco_batch_status(orbfe_aruco* h, int32_t* nflagged, int32_t* flags_or);
 int orbfe_aruco_set_big_frames(orbfe_aruco* h, int on);
-/* stage read-back for parity tests: 0 = thresholded image (rows x cols bytes, 0/255) of `frame` */
+/* stage read-back for parity tests: 0 = thresholded image (rows x cols bytes, 0/255) of `frame`; 104 = the bit image the contour
+ * kernels read (the thresholded image minus the specks that cannot have a border of more than 70 points) */
 int orbfe_aruco_debug_image(orbfe_aruco* h, int frame, int stage, uint8_t* out);
 /* As orbfe_extractor_set_aux_stream, for the detector's forked launches (the /2 pyramid). */
 int orbfe_aruco_set_aux_stream(orbfe_aruco* h, void* stream);
@@ -644,7 +652,6 @@ int orbfe_corner_subpix(const uint8_t* img, int rows, int cols, size_t step, flo
  * against its predecessor in the stream too.  Frame f of the batch is slot f + halo.  Matching outputs of the newest batch: pair p
  * = slot p (queries, F1) against slot p + 1 (train, F2), p = 0 .. frames - 1; pair 0 is the pair across the batch boundary (no
  * keypoints on the F1 side for the first batch of a stream). */
-typedef struct orbfe_pipeline orbfe_pipeline;
 typedef struct orbfe_pipeline_config {
     int32_t frames, rows, cols;        /* frames per batch; frame size */
     int32_t nfeatures, nlevels;        /* ORBextractor(nfeatures, scale_factor, nlevels, ini_th_fast, min_th_fast) */
@@ -699,7 +706,8 @@ int orbfe_device_upload_rows(void* d_dst, size_t dpitch, const void* src, size_t
 int orbfe_device_download(void* dst, const void* d_src, size_t bytes);
 int orbfe_pipeline_flush(orbfe_pipeline* p);                 /* enqueue the held-back post-work (matching, gather) of the newest batch */
 int orbfe_pipeline_synchronize(orbfe_pipeline* p);           /* flush + wait for everything enqueued */
-/* flush + wait until the engines of the batch written to `record_set` have read their frames (the input buffer may be reused) */
+/* wait until the engines of the batch written to `record_set` have read their frames (the input buffer may be reused).  The engines
+ * of a step are enqueued by the step itself, so nothing has to be flushed first. */
 int orbfe_pipeline_input_done(orbfe_pipeline* p, int record_set);
 /* capacity flags since the last call (synchronises): out[0] extractor overflow, [1] SearchForInitialization pool overflow (the pool
  * has been grown: repeat), [2] frames the detector flagged, [3] the union of their flags.  All zero = results complete. */
@@ -729,13 +737,28 @@ const char* orbfe_pipeline_env_defaults(void);
  * Either hand over a communicator the application owns (set_comm; ncclComm_t as void*), or let the pipeline create one:
  * comm_unique_id on one rank (ncclGetUniqueId, 128 bytes), the bytes sent to all ranks by the application's own means, then
  * comm_init on every rank (ncclCommInitRank).  From then on every batch's record set is gathered to rank `dst` behind the batch's
- * matching: `dst` receives block r of rank r (its own too) in buffers allocated once; orbfe_pipeline_gathered returns block r of the
- * newest gather on dst.  world == 1 runs the same branch with a send / recv to itself. */
+ * matching.  `dst` receives block r of rank r (its own too) in buffers allocated once: ONE SET OF BLOCKS PER RECORD SET -- the batch
+ * written to record set s (orbfe_pipeline_step's *record_set) lands in block set s, which is written again record_sets batches later --
+ * so a consumer on `dst` (one Tracking thread per stream, src/Tracking.cc:163-190) reads batch i while the following batches arrive:
+ *     orbfe_pipeline_gathered_wait(p, s)          block until the gather of the batch last written to set s is complete (its deferred
+ *                                                 post-work is flushed first if it was still held back)
+ *     orbfe_pipeline_gathered_set(p, s, r, &ptr)  rank r's block of set s (device pointer, layout = orbfe_pipeline_layout)
+ *     orbfe_pipeline_gathered_release(p, s, st)   optional: the reads of set s enqueued on the consumer's HIP stream `st` so far (NULL: the
+ *                                                 null stream) must finish before the set is received into again; without it the set is
+ *                                                 simply overwritten record_sets batches later
+ * orbfe_pipeline_gathered(p, r, &ptr) = block r of the newest gather that was enqueued.  world == 1 runs the same branch with a send /
+ * recv to itself.  ORBFE_RCCL_LIB names a library to bind in place of librccl (tests/fake_rccl.cpp). */
 int orbfe_pipeline_comm_unique_id(uint8_t id[128]);
 int orbfe_pipeline_comm_init(orbfe_pipeline* p, const uint8_t id[128], int rank, int world, int dst);
 int orbfe_pipeline_set_comm(orbfe_pipeline* p, void* nccl_comm, int rank, int world, int dst);
 int orbfe_pipeline_gathered(orbfe_pipeline* p, int rank, uint8_t** d_block);
+int orbfe_pipeline_gathered_set(orbfe_pipeline* p, int record_set, int rank, uint8_t** d_block);
+int orbfe_pipeline_gathered_wait(orbfe_pipeline* p, int record_set);
+int orbfe_pipeline_gathered_release(orbfe_pipeline* p, int record_set, void* stream);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -52,6 +52,7 @@ SYMBOLS = [
     "orbfe_pipeline_records", "orbfe_pipeline_matches", "orbfe_pipeline_reset_stream", "orbfe_pipeline_extractor", "orbfe_pipeline_detector",
     "orbfe_pipeline_engine_sets", "orbfe_pipeline_enable_timing", "orbfe_pipeline_timing_us", "orbfe_pipeline_env_defaults",
     "orbfe_pipeline_comm_unique_id", "orbfe_pipeline_comm_init", "orbfe_pipeline_set_comm", "orbfe_pipeline_gathered",
+    "orbfe_pipeline_gathered_set", "orbfe_pipeline_gathered_wait", "orbfe_pipeline_gathered_release",
     "orbfe_pipeline_step_host", "orbfe_pipeline_host_records", "orbfe_host_alloc", "orbfe_host_free",
     "orbfe_device_alloc", "orbfe_device_free", "orbfe_device_upload_rows", "orbfe_device_download",
 ]
@@ -968,6 +969,17 @@ class MarkerDetector:
     def set_tiled_contours(self, mode):
         """Debug: the tiled contour path (aruco_tiles.hip) None = by frame / batch size (default), True = every batch, False = never."""
         self.L.orbfe_aruco_debug_kernel_times(self.h, None, 4 if mode is None else 5 if mode else 6)
+
+    def set_speck_passes(self, on=True):
+        """Debug: the speck passes between threshold and contours (k_speck_clean) on / off / None = by batch size (default: calls of up
+        to 32 frames); the results do not change."""
+        self.L.orbfe_aruco_debug_kernel_times(self.h, None, 10 if on is None else 8 if on else 9)
+
+    def contour_image(self, frame=0):
+        """Debug: the bit image the contour kernels of the last batch read (the thresholded image after the speck passes)."""
+        out = np.zeros(self._shape, np.uint8)
+        _check(self.L, self.L.orbfe_aruco_debug_image(self.h, frame, 104, _p(out)), "debug_image")
+        return out
 
     def contour_retries(self):
         """Debug: how many batches of this detector were done again on the next contour path (tiled -> one workgroup -> single walker)

@@ -65,9 +65,6 @@ struct orbfe_aruco {
     PoseCamera last_cam{};
     float last_size = 0.f;
     bool relay_wide = !(getenv("ORBFE_ARUCO_RELAY_WIDE") && !atoi(getenv("ORBFE_ARUCO_RELAY_WIDE")));
-    DevBuf d_vis;        // per frame: one bit per start candidate on a gridded border (relay kernels, phase (d) -> (c))
-    size_t vis_fu32 = 0;
-    int vis_mode = getenv("ORBFE_ARUCO_VIS") ? atoi(getenv("ORBFE_ARUCO_VIS")) : 0; // experiment, slower: see relay_frame
     DevBuf d_dwork, d_dctr, d_ditems, d_dhist, d_dpatch; // k_prefilter -> k_decode_warp / _otsu / _vote: the batch's candidates
     bool decode_dirty = false; // the decode work-list counter may be non-zero
     bool tail_dirty = false;   // the work-list counters may be non-zero (set while the tail's three launches are being enqueued)
@@ -100,6 +97,15 @@ struct orbfe_aruco {
     unsigned ct_gen = 0;       // generation tag of the hash table's entries (16 bits; the table is cleared when it wraps and before first use)
     bool ct_tab_dirty = true;
     DevBuf d_ctseg, d_cthtab, d_ctelem, d_ctstate, d_ctitemsA, d_ctitemsB, d_ctnitems, d_ctcodes;
+    // the speck passes between threshold and contours (k_speck_clean; aruco_trace.hpp "FEWER WALKS"): result-neutral.  -1 = by batch
+    // size: calls of up to 32 frames, where the detector's chain is the call's latency and a quarter fewer walks shorten it; a full batch
+    // inside the pipeline is bound by the instructions all engines issue and by the number of launches on the detector's chain, and
+    // there the extra launch costs more than the shorter walks give back (C2 step 1.40 - 1.46 against 1.34 - 1.38 ms).
+    // ORBFE_ARUCO_SPECKS = 0 / 1 or debug codes 9 / 8 force them off / on (tests, A/B); = 2: the passes run and are not used (measurement).
+    int specks = getenv("ORBFE_ARUCO_SPECKS") ? (atoi(getenv("ORBFE_ARUCO_SPECKS")) ? 1 : 0) : -1;
+    bool specks_unused = getenv("ORBFE_ARUCO_SPECKS") && atoi(getenv("ORBFE_ARUCO_SPECKS")) == 2;
+    bool specks_ran = false;   // the last batch's contour kernels read d_bitsc
+    DevBuf d_bitsc;
     bool relay_global = false; // k_contours_relay8g: the bit image stays in HBM (it does not fit LDS)
     int relay_tbits = 0;       // hash-table size of k_contours_relay (0: the kernel cannot run at this image size)
     bool force_legacy = false; // debug: always use k_contours_t
@@ -150,8 +156,8 @@ struct orbfe_aruco {
     ~orbfe_aruco()
     {
         for (DevBuf* b : {&d_codes, &d_levels, &d_tabs, &d_bits, &d_pyr, &d_candq, &d_pool, &d_kept, &d_rects,
-                          &d_counts, &d_candidx, &d_ncand, &d_result, &d_gpad, &d_in, &d_out, &d_nout, &d_segs, &d_tailkeys, &d_tailoff, &d_small, &d_hint, &d_rstate, &d_lut, &d_twork, &d_trect, &d_tctr, &d_dwork, &d_dctr, &d_ditems, &d_dhist, &d_dpatch, &d_vis, &d_poses, &d_scodes, &d_sids,
-                          &d_msrc, &d_red, &d_mhist, &d_masks, &d_bgr, &d_bits2, &d_ctseg, &d_cthtab, &d_ctelem, &d_ctstate, &d_ctitemsA, &d_ctitemsB, &d_ctnitems, &d_ctcodes, &d_ctmlist})
+                          &d_counts, &d_candidx, &d_ncand, &d_result, &d_gpad, &d_in, &d_out, &d_nout, &d_segs, &d_tailkeys, &d_tailoff, &d_small, &d_hint, &d_rstate, &d_lut, &d_twork, &d_trect, &d_tctr, &d_dwork, &d_dctr, &d_ditems, &d_dhist, &d_dpatch, &d_poses, &d_scodes, &d_sids,
+                          &d_msrc, &d_red, &d_mhist, &d_masks, &d_bgr, &d_bits2, &d_ctseg, &d_cthtab, &d_ctelem, &d_ctstate, &d_ctitemsA, &d_ctitemsB, &d_ctnitems, &d_ctcodes, &d_ctmlist, &d_bitsc})
             b->release();
         if (own_stream) (void)hipStreamDestroy(own_stream);
         if (aux_stream) (void)hipStreamDestroy(aux_stream);
@@ -337,7 +343,7 @@ struct orbfe_aruco {
     {
         if (B <= batch_cap) return ORBFE_OK;
         int rc;
-        if ((rc = d_bits.ensure(bits_fu32 * 4 * B)) || (rc = d_pyr.ensure(pyr_fbytes * B)) ||
+        if ((rc = d_bits.ensure(bits_fu32 * 4 * B)) || (rc = d_bitsc.ensure(bits_fu32 * 4 * B)) || (rc = d_pyr.ensure(pyr_fbytes * B)) ||
             (rc = d_candq.ensure(candq_fu32 * 4 * B)) || (rc = d_pool.ensure(pool_fu32 * 4 * B)) ||
             (rc = d_kept.ensure((size_t)AR_MAX_KEPT_BIG * sizeof(ArKept) * B)) ||
             (rc = d_rects.ensure((size_t)AR_MAX_RECTS * sizeof(ArRect) * B)) || (rc = d_counts.ensure((size_t)16 * B)) ||
@@ -369,8 +375,6 @@ struct orbfe_aruco {
                 (rc = d_dpatch.ensure(items * DC_PATCH_BYTES)))
                 return rc;
         }
-        vis_fu32 = (size_t)((cols + 2 + 31) >> 5) * (rows + 2) + 4;
-        if (vis_mode && (rc = d_vis.ensure(vis_fu32 * 4 * B))) return rc;
         if (!d_dctr.p) {   // k_finalize leaves the counter at zero for the next batch
             if ((rc = d_dctr.ensure(16))) return rc;
             ORBFE_HIP(hipMemset(d_dctr.p, 0, 16));
@@ -475,6 +479,16 @@ struct orbfe_aruco {
             else hipLaunchKernelGGL(k_adaptive_threshold<15>, tg, dim3(256), 0, s, srcW, cols, rows, win, thres_value, 1.0 / (win * win), bp, bits_fu32, wpr);
         }
         timer.mark(s, "threshold");
+        // the bit image the contour kernels read: after the speck passes, unless switched off or the frame is too wide for their LDS tile
+        const size_t spk_lds = speck_lds_bytes(cols);
+        specks_ran = (specks > 0 || (specks < 0 && B <= 32)) && spk_lds <= 150 * 1024;
+        if (specks_ran) {
+            { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(k_speck_clean), spk_lds); if (rc_lds_) return rc_lds_; }
+            hipLaunchKernelGGL(k_speck_clean, dim3((rows + SPK_ROWS - 1) / SPK_ROWS, B), dim3(SPK_THREADS), spk_lds, s, d_bits.as<uint32_t>(), bits_fu32, wpr,
+                               cols, rows, d_bitsc.as<uint32_t>());
+        }
+        if (specks_unused) specks_ran = false;
+        const uint32_t* cbits = specks_ran ? d_bitsc.as<uint32_t>() : d_bits.as<uint32_t>();
         const bool big = big_mode || !lds_bits_words;
         const int legacy_kcap = big ? AR_MAX_KEPT_BIG : AR_MAX_KEPT, legacy_ldsw = big ? 0 : lds_bits_words;
         const size_t lds = contours_lds_bytes(legacy_ldsw, legacy_kcap);
@@ -517,12 +531,12 @@ struct orbfe_aruco {
                     const int nb = (crows + rb - 1) / rb;
                     const size_t blds = ctb_lds_bytes(cols, rb);
                     { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(k_ct_band), blds); if (rc_lds_) return rc_lds_; }
-                    hipLaunchKernelGGL(k_ct_band, dim3(nb, B), dim3(CTB_THREADS), blds, s, d_bits.as<uint32_t>(), bits_fu32, wpr, cols, rows, 70,
+                    hipLaunchKernelGGL(k_ct_band, dim3(nb, B), dim3(CTB_THREADS), blds, s, cbits, bits_fu32, wpr, cols, rows, 70,
                                        d_lut.as<uint16_t>(), rb, d_ctmlist.as<uint32_t>(), CTB_MCAP, d_cthtab.as<unsigned long long>(), ct_hbits, ct_gen,
                                        d_ctseg.as<uint32_t>(), (size_t)5 * ct_segcap, ct_segcap, d_ctstate.as<int32_t>(), d_pool.as<uint32_t>(), pool_fu32,
                                        (int)pool_fu32, relay_kcap, d_tailkeys.as<unsigned long long>(), d_tailoff.as<int32_t>(), d_ctcodes.as<uint4>());
                 } else
-                hipLaunchKernelGGL(k_ct_walk, dim3(walk_wgs), dim3(CTW_THREADS), wlds, s, d_bits.as<uint32_t>(), bits_fu32, wpr, cols, rows, 70,
+                hipLaunchKernelGGL(k_ct_walk, dim3(walk_wgs), dim3(CTW_THREADS), wlds, s, cbits, bits_fu32, wpr, cols, rows, 70,
                                    d_lut.as<uint16_t>(), cw, ncols, nbands, total_tiles, d_cthtab.as<unsigned long long>(), ct_hbits, ct_gen,
                                    d_ctseg.as<uint32_t>(), (size_t)5 * ct_segcap, ct_segcap, d_ctstate.as<int32_t>(), d_pool.as<uint32_t>(), pool_fu32,
                                    (int)pool_fu32, relay_kcap, d_tailkeys.as<unsigned long long>(), d_tailoff.as<int32_t>(), wave_bytes,
@@ -544,7 +558,7 @@ struct orbfe_aruco {
             const int nb_ = std::min(chunk, B - f0);
             if (relay_global) {
                 { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(k_contours_relay8g), (size_t)(rlds)); if (rc_lds_) return rc_lds_; }
-                hipLaunchKernelGGL(k_contours_relay8g, dim3(nb_), dim3(RL_THREADS_BIG), rlds, s, d_bits.as<uint32_t>(), bits_fu32, wpr,
+                hipLaunchKernelGGL(k_contours_relay8g, dim3(nb_), dim3(RL_THREADS_BIG), rlds, s, cbits, bits_fu32, wpr,
                                    cols, rows, 0, 70, relay_kshift, relay_tbits, d_segs.as<RelaySeg>(),
                                    d_pool.as<uint32_t>(), pool_fu32, (int)pool_fu32, d_kept.as<ArKept>(), relay_kcap, relay_kcap,
                                    d_tailkeys.as<unsigned long long>(), d_tailoff.as<int32_t>(), d_counts.as<int32_t>(), d_hint.as<int32_t>(),
@@ -553,12 +567,12 @@ struct orbfe_aruco {
             const bool wide = relay_tbits <= 12 && B <= 32 && relay_wide;   // few frames: 16 waves per frame (see k_contours_relay_wide)
             auto rfn = relay_tbits > 12 ? k_contours_relay8 : wide ? k_contours_relay_wide : k_contours_relay;
             { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(rfn), (size_t)(rlds)); if (rc_lds_) return rc_lds_; }
-            hipLaunchKernelGGL(rfn, dim3(nb_), dim3(relay_tbits > 12 || wide ? RL_THREADS_BIG : RL_THREADS), rlds, s, d_bits.as<uint32_t>(), bits_fu32, wpr,
+            hipLaunchKernelGGL(rfn, dim3(nb_), dim3(relay_tbits > 12 || wide ? RL_THREADS_BIG : RL_THREADS), rlds, s, cbits, bits_fu32, wpr,
                                cols, rows, lds_bits_words, 70, relay_kshift, relay_tbits, d_segs.as<RelaySeg>(),
                                d_pool.as<uint32_t>(), pool_fu32, (int)pool_fu32, d_kept.as<ArKept>(), relay_kcap, relay_kcap,
                                d_tailkeys.as<unsigned long long>(), d_tailoff.as<int32_t>(), d_counts.as<int32_t>(), d_hint.as<int32_t>(),
                                d_small.as<uint4>(), d_rstate.as<int32_t>(), small_separate ? 1 : 0, d_lut.as<uint16_t>(), f0,
-                               vis_mode ? d_vis.as<uint32_t>() : nullptr, vis_fu32);
+                               d_candq.as<uint32_t>(), candq_fu32);
             }
             }
             // the borders that touch no grid line, for frames done with a grid by a relay kernel that leaves them out (the
@@ -568,7 +582,7 @@ struct orbfe_aruco {
             if (relay_global || small_separate) {
                 const int nwaves = ((cols >> RS_BLOCK_SHIFT) + 1) * ((rows >> relay_kshift) + 1); // blocks of the finest grid
                 hipLaunchKernelGGL(k_contours_small, dim3((nwaves + RS_THREADS / 64 - 1) / (RS_THREADS / 64), B), dim3(RS_THREADS), 0, s,
-                                   d_bits.as<uint32_t>(), bits_fu32, wpr, cols, rows, 70, d_lut.as<uint16_t>(), d_rstate.as<int32_t>(),
+                                   cbits, bits_fu32, wpr, cols, rows, 70, d_lut.as<uint16_t>(), d_rstate.as<int32_t>(),
                                    d_pool.as<uint32_t>(), pool_fu32, (int)pool_fu32, relay_kcap, d_tailkeys.as<unsigned long long>(),
                                    d_tailoff.as<int32_t>(), d_counts.as<int32_t>());
             }
@@ -593,7 +607,7 @@ struct orbfe_aruco {
             }
         }
         // the single-walker kernel: images whose bit image does not fit LDS next to the relay kernel's tables, or forced
-        if (!relay && !ORBFE_SKIP_ARUCO(1)) hipLaunchKernelGGL(kfn, dim3(B), dim3(CT_PROBE_THREADS), lds, s, d_bits.as<uint32_t>(), bits_fu32, wpr, cols, rows,
+        if (!relay && !ORBFE_SKIP_ARUCO(1)) hipLaunchKernelGGL(kfn, dim3(B), dim3(CT_PROBE_THREADS), lds, s, cbits, bits_fu32, wpr, cols, rows,
                            legacy_ldsw, 70, d_candq.as<uint32_t>(), candq_fu32, (int)candq_fu32,
                            d_pool.as<uint32_t>(), pool_fu32, (int)pool_fu32, d_kept.as<ArKept>(), legacy_kcap,
                            d_rects.as<ArRect>(), AR_MAX_RECTS, d_counts.as<int32_t>(), d_gpad.as<uint32_t>(),
@@ -1451,6 +1465,15 @@ int orbfe_aruco_debug_image(orbfe_aruco* h, int frame, int stage, uint8_t* out)
                 out[(size_t)y * h->cols + x] = ((bits[(size_t)y * h->wpr + (x >> 5)] >> (x & 31)) & 1) ? 255 : 0;
         return ORBFE_OK;
     }
+    if (stage == 104) { // the bit image the contour kernels of the last batch read (after the speck passes, if they ran)
+        std::vector<uint32_t> bits(h->bits_fu32);
+        ORBFE_HIP(hipMemcpy(bits.data(), (h->specks_ran ? h->d_bitsc : h->d_bits).as<uint32_t>() + (size_t)frame * h->bits_fu32, bits.size() * 4,
+                            hipMemcpyDeviceToHost));
+        for (int y = 0; y < h->rows; y++)
+            for (int x = 0; x < h->cols; x++)
+                out[(size_t)y * h->cols + x] = ((bits[(size_t)y * h->wpr + (x >> 5)] >> (x & 31)) & 1) ? 255 : 0;
+        return ORBFE_OK;
+    }
     if (stage >= 1 && stage < h->npyr + 1 && stage - 1 >= 1) { // pyramid level stage-1 (>= 1)
         const ArLevel& L = h->levels[stage - 1];
         ORBFE_HIP(hipMemcpy2D(out, L.w, h->d_pyr.as<uint8_t>() + (size_t)frame * h->pyr_fbytes + L.off, L.pitch, L.w, L.h,
@@ -1514,10 +1537,15 @@ int orbfe_aruco_debug_kernel_times(orbfe_aruco* h, float* out_us, int capacity)
 {
     if (!h) return fail(ORBFE_ERR_INVALID, "null handle");
     if (!out_us) { // control codes: 0/1 kernel timing off/on, 2/3 force the legacy contour kernel on/off, 4/5/6 tiled contour path by size / always / never,
-                   // 7 returns the number of batches that were done again on the next contour path
+                   // 7 returns the number of batches that were done again on the next contour path, 8 / 9 / 10 the speck passes on / off / by batch size
         if (capacity == 7) return h->n_escalations;
+        if (capacity == 8 || capacity == 9 || capacity == 10) { h->specks = capacity == 8 ? 1 : capacity == 9 ? 0 : -1; return 0; }   // the speck passes on / off / by batch size (default)
         if (capacity == 2 || capacity == 3) h->force_legacy = capacity == 2;
-        else if (capacity >= 4 && capacity <= 6) h->tiled = capacity == 4 ? -1 : capacity == 5 ? 1 : 0; // (the workspace of the tiled path exists unless ORBFE_ARUCO_TILED=0)
+        else if (capacity >= 4 && capacity <= 6) {
+            const int t = capacity == 4 ? -1 : capacity == 5 ? 1 : 0;
+            if (h->tiled == 0 && t != 0) h->batch_cap = 0;   // the tiled path's workspace is only allocated while it can run: allocate on the next batch
+            h->tiled = t;
+        }
         else { h->timer.enabled = capacity != 0; h->timer.reset_history(); }
         return 0;
     }

@@ -213,6 +213,90 @@ template __global__ void k_adaptive_threshold_t<7>(ImgView, int, int, int, uint3
 template __global__ void k_adaptive_threshold_t<11>(ImgView, int, int, int, uint32_t, uint32_t*, size_t, int, int, int, int);
 template __global__ void k_adaptive_threshold_t<15>(ImgView, int, int, int, uint32_t, uint32_t*, size_t, int, int, int, int);
 
+// ---------------------------------------------------------------------------------------- specks --------------
+// The speck passes of aruco_trace.hpp ("FEWER WALKS" (2)) between the threshold and the contour kernels: what they clear has no border
+// of more than 68 points and changes no other border, and on textured frames it is most of the start candidates and a fifth of the
+// grid markers the contour kernels would otherwise walk.  A workgroup owns SPK_ROWS rows of one frame at full width and holds them
+// with ORBFE_SPECK_REACH rows above and below (what the two passes together can depend on) in LDS, in the padded layout of the contour
+// kernels (pixel (x, y) = bit x + 1 of row y + 1; zero beyond the frame); every pass is three sweeps over the tile's words -- rim
+// masks of each row, anchors (empty rims), clear -- with a barrier between them.  HBM-bound byte work in principle (38 KB in, 38 KB
+// out per 640 x 480 frame); the sweeps are ~35 VALU + ~25 LDS instructions per word and pass.
+template <int WW, int HH>
+__device__ __forceinline__ void speck_pass_lds(uint32_t* P, uint32_t* Fm, uint32_t* Sm, uint32_t* An, int NR, int PWS, int tid)
+{
+    const int n = NR * PWS;
+    const float inv_pws = 1.0f / (float)PWS;
+    for (int i = tid; i < n; i += SPK_THREADS) {
+        const int r = (int)(((float)i + 0.5f) * inv_pws), j = i - __mul24(r, PWS);   // exact: i < 2^16
+        uint32_t f = 0, sd = 0;
+        if (j + 1 < PWS) speck_row_masks<WW>(P[i], P[i + 1], &f, &sd);              // (the last word of a row is the zero word)
+        Fm[i] = f; Sm[i] = sd;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += SPK_THREADS) {
+        const int r = (int)(((float)i + 0.5f) * inv_pws);
+        uint32_t a = 0;
+        if (r + HH + 1 < NR) {   // anchors whose rim leaves the tile decide nothing here: the rows they could clear are another workgroup's
+            uint32_t occ = Fm[i] | Fm[i + (HH + 1) * PWS];
+#pragma unroll
+            for (int k = 1; k <= HH; k++) occ |= Sm[i + k * PWS];
+            a = ~occ;
+        }
+        An[i] = a;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += SPK_THREADS) {
+        const int r = (int)(((float)i + 0.5f) * inv_pws), j = i - __mul24(r, PWS);
+        if (r < HH) continue;
+        uint32_t e = 0, el = 0;
+#pragma unroll
+        for (int dy = 1; dy <= HH; dy++) {
+            e |= An[i - dy * PWS];
+            if (j) el |= An[i - dy * PWS - 1];
+        }
+        P[i] &= ~speck_dilate<WW>(e, el);
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(SPK_THREADS) void k_speck_clean(const uint32_t* __restrict__ bits, size_t bits_fstride, int wpr_g, int W, int H,
+                                                             uint32_t* __restrict__ out)
+{
+    extern __shared__ __align__(16) uint32_t spk_smem[];
+    constexpr int RCH = ORBFE_SPECK_REACH, NR = SPK_ROWS + 2 * RCH;
+    const int tid = threadIdx.x, f = blockIdx.y, y0 = blockIdx.x * SPK_ROWS;       // image rows y0 .. y0 + SPK_ROWS - 1
+    const int pw = (W + 2 + 31) >> 5, PWS = pw + 1, n = NR * PWS;
+    uint32_t* P = spk_smem;
+    uint32_t* Fm = P + n;
+    uint32_t* Sm = Fm + n;
+    uint32_t* An = Sm + n;
+    const uint32_t* gb = bits + (size_t)f * bits_fstride;
+    const float inv_pws = 1.0f / (float)PWS;
+    for (int i = tid; i < n; i += SPK_THREADS) {
+        const int r = (int)(((float)i + 0.5f) * inv_pws), j = i - __mul24(r, PWS), py = y0 + 1 - RCH + r;   // word j of padded row py
+        uint32_t v = 0;
+        if (j < pw && py >= 1 && py <= H) {
+            const uint32_t* row = gb + (uint32_t)__mul24(py - 1, wpr_g);
+            const uint32_t cur = j < wpr_g ? row[j] : 0u;
+            const uint32_t prv = (j >= 1 && j - 1 < wpr_g) ? row[j - 1] : 0u;
+            v = (cur << 1) | (prv >> 31);
+        }
+        P[i] = v;
+    }
+    __syncthreads();
+    speck_pass_lds<ORBFE_SPECK_W1, ORBFE_SPECK_H1>(P, Fm, Sm, An, NR, PWS, tid);
+    speck_pass_lds<ORBFE_SPECK_W2, ORBFE_SPECK_H2>(P, Fm, Sm, An, NR, PWS, tid);
+    // the owned rows back in the threshold kernel's layout (pixel x = bit x of its row's words)
+    uint32_t* ob = out + (size_t)f * bits_fstride;
+    const float inv_wg = 1.0f / (float)wpr_g;
+    for (int i = tid; i < SPK_ROWS * wpr_g; i += SPK_THREADS) {
+        const int r = (int)(((float)i + 0.5f) * inv_wg), j = i - __mul24(r, wpr_g), y = y0 + r;
+        if (y >= H) break;
+        const uint32_t* row = P + __mul24(RCH + r, PWS);
+        ob[(uint32_t)__mul24(y, wpr_g) + j] = (row[j] >> 1) | (row[j + 1] << 31);
+    }
+}
+
 // exact 2x downscale = INTER_AREA 2x2 mean (what cv::resize(INTER_LINEAR) does for an exact factor of two)
 __global__ __launch_bounds__(256) void k_half_area(ImgView src, ImgView dst, int dw, int dh)
 {
@@ -638,8 +722,7 @@ __global__ __launch_bounds__(CT_PROBE_THREADS) void k_contours_t(const uint32_t*
                             const uint32_t cur_l = (cur << 1) | (wj ? row[wj - 1] >> 31 : 0u);
                             const uint32_t up_l = (upw << 1) | (wj ? up[wj - 1] >> 31 : 0u);
                             const uint32_t up_r = (upw >> 1) | (wj + 1 < wpr ? up[wj + 1] << 31 : 0u);
-                            m_outer = cur & ~cur_l & ~up_l & ~upw & ~up_r;
-                            m_hole = ~cur & cur_l & upw;
+                            start_candidate_masks(cur, cur_l, upw, up_l, up_r, ORBFE_CAND_FILTER != 0, &m_outer, &m_hole);
                         }
                     }
                     if (m_outer | m_hole) {
@@ -838,11 +921,11 @@ __device__ __forceinline__ int relay_frame(
     int small_elsewhere = 0 /* phase (c) of gridded frames is k_contours_small's */,
     const uint16_t* __restrict__ lut_g = nullptr /* the step table, built once per detector (k_relay_lut) */,
     int f0 = 0 /* first frame of this launch (a batch may be launched in chunks) */,
-    uint32_t* __restrict__ vis_g = nullptr /* per frame: one bit per start candidate that lies on a gridded border (see (d)) */,
-    size_t vis_fstride = 0)
+    uint32_t* __restrict__ candq_g = nullptr /* per frame: the start candidates of phase (c), listed before the walks (see (c)) */,
+    size_t candq_fstride = 0)
 {
     extern __shared__ __align__(16) unsigned char ct_smem[];
-    __shared__ int s_nmpix;
+    __shared__ int s_nmpix, s_qn;
     __shared__ int s_next, s_next_d, s_nkept, s_flags, s_ncand, s_nmark, s_nsmall, s_pool, s_changed[2];
     // grid spacing that fitted the marker table in the previous batch of this handle (video: it will fit again); saves the
     // enumeration passes that overflow at finer spacings.  The result does not depend on the spacing.
@@ -891,7 +974,7 @@ __device__ __forceinline__ int relay_frame(
     // A frame whose segments overflow the staging arenas or the copy list (one giant noisy component) is done again
     // from (a) without a grid: every border is then followed whole, straight into the pool.
     if (tid == 0) {
-        s_next = 0; s_next_d = 0; s_nkept = 0; s_flags = 0; s_ncand = 0; s_nmark = 0; s_nsmall = 0; s_pool = 0;
+        s_next = 0; s_next_d = 0; s_nkept = 0; s_flags = 0; s_ncand = 0; s_nmark = 0; s_nsmall = 0; s_pool = 0; s_qn = 0;
         s_changed[0] = 0; s_changed[1] = 0;
     }
     RL_STAMP();
@@ -907,11 +990,6 @@ __device__ __forceinline__ int relay_frame(
             v = (cur << 1) | (prv >> 31);
         }
         lbits[i] = v;
-    }
-    uint32_t* vis = vis_g ? vis_g + (size_t)f * vis_fstride : nullptr;
-    if (vis) {
-        for (int i = tid; i < wpr * prow; i += NT) vis[i] = 0u;
-        __threadfence(); // ahead of the atomics of (d), which execute in L2
     }
     if (tid < 2) lbits[wpr * prow + tid] = 0; // spare words read by ring8()'s funnel loads
     for (int i = tid; i < T; i += NT) hkey[i] = 0u;
@@ -1020,7 +1098,12 @@ __device__ __forceinline__ int relay_frame(
     // trips).  Without a grid every border is "small" and is followed whole here: a lane takes one 32-pixel word of start
     // candidates at a time; every loop iteration advances each busy lane by ONE step.  A walk stops at a proof that
     // the candidate is not canonical, or when the border closes; a closed border longer than min_len is queued.
-    auto phase_c = [&](const bool use_vis) {
+    // The candidates are LISTED first (round 5): every lane takes words of the frame, the run tests of aruco_trace.hpp decide on whole
+    // words, and what is left goes to the frame's queue in HBM (it stays in L2).  With the speck passes in front of this kernel three
+    // words in four have no candidate at all; drawn one word per loop trip, as until round 4, the empty words were 40 % of a wave's
+    // trips, each with the whole loop body behind it.  A walking lane fetches its next queue entry one trip ahead of needing it, so the
+    // L2 round trip is hidden behind a trip of walking.  A frame with more candidates than the queue holds (noise) draws words as before.
+    auto phase_c = [&]() {
     if (kshift >= 30 || !small_elsewhere) {
         RelayWalk wk;
         bool busy = false, drained = false;
@@ -1028,6 +1111,36 @@ __device__ __forceinline__ int relay_frame(
         int wj = 0, wy = 0, sx = 0, sy = 0, s0 = 0, is_hole = 0, start_key = 0, ncand_l = 0;
         const int nwords = wpr * H;
         const float inv_wpr = 1.0f / (float)wpr;
+        uint32_t* cq = candq_g ? candq_g + (size_t)f * candq_fstride : nullptr;
+        const int qcap = (int)min(candq_fstride, (size_t)1 << 30);
+        if (cq) {
+            for (int i = tid; i < nwords; i += NT) {
+                const int y = 1 + (int)(((float)i + 0.5f) * inv_wpr), j = i - __mul24(y - 1, wpr); // exact: i < 2^20
+                const uint32_t* row = lbits + __mul24(y, wpr);
+                const uint32_t* up = row - wpr;
+                const uint32_t cur = row[j], upw = up[j];
+                const uint32_t cur_l = (cur << 1) | (j ? row[j - 1] >> 31 : 0u);
+                const uint32_t up_l = (upw << 1) | (j ? up[j - 1] >> 31 : 0u);
+                const uint32_t up_r = (upw >> 1) | (j + 1 < wpr ? up[j + 1] << 31 : 0u);
+                uint32_t mo, mh;
+                start_candidate_masks(cur, cur_l, upw, up_l, up_r, ORBFE_CAND_FILTER != 0, &mo, &mh);
+                const int c = __popc(mo) + __popc(mh);
+                if (c) {
+                    int q = atomicAdd(&s_qn, c);
+                    if (q + c <= qcap) {
+                        const uint32_t hi = ((uint32_t)y << 13) | ((uint32_t)j << 5);   // x | y << 13 | hole << 26 (x, y < 8192)
+                        while (mo) { const int b = __ffs(mo) - 1; mo &= mo - 1; cq[q++] = hi | (uint32_t)b; }
+                        while (mh) { const int b = __ffs(mh) - 1; mh &= mh - 1; cq[q++] = hi | (uint32_t)b | (1u << 26); }
+                    }
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+        const int qn = cq ? s_qn : 0;
+        const bool listed = cq != nullptr && qn <= qcap;
+        uint32_t nxt = 0;
+        bool have = false;
 #ifdef ORBFE_CT_TIMING
         unsigned dbg_iters = 0;
 #endif
@@ -1035,6 +1148,25 @@ __device__ __forceinline__ int relay_frame(
 #ifdef ORBFE_CT_TIMING
             dbg_iters++;
 #endif
+            if (listed) {
+                if (!busy && have) {
+                    have = false;
+                    const int qx = (int)(nxt & 0x1fffu);
+                    wy = (int)((nxt >> 13) & 0x1fffu); is_hole = (int)(nxt >> 26);
+                    sx = qx - is_hole; sy = wy;
+                    start_key = wy * 65536 + qx;
+                    wk.x = sx; wk.y = sy; wk.n = 0;
+                    wk.ring = ring8(im, sx, sy);
+                    s0 = relay_start_dir(wk.ring, is_hole);
+                    wk.s = s0;
+                    busy = s0 >= 0; // single-pixel borders are never kept
+                }
+                if (!have && !drained) {
+                    const int i = atomicAdd(&s_next, 1);
+                    if (i >= qn) drained = true;
+                    else { nxt = cq[i]; have = true; }
+                }
+            } else
             for (int tries_ = 0; tries_ < RL_FETCH_TRIES; tries_++)   // (a lane that drew an empty word, or a one-pixel border, tries again at once)
             if (!busy && !drained && RL_GATE_OPEN(busy, drained)) {
                 if (!(m_outer | m_hole)) {
@@ -1049,13 +1181,7 @@ __device__ __forceinline__ int relay_frame(
                         const uint32_t cur_l = (cur << 1) | (wj ? row[wj - 1] >> 31 : 0u);
                         const uint32_t up_l = (upw << 1) | (wj ? up[wj - 1] >> 31 : 0u);
                         const uint32_t up_r = (upw >> 1) | (wj + 1 < wpr ? up[wj + 1] << 31 : 0u);
-                        m_outer = cur & ~cur_l & ~up_l & ~upw & ~up_r;
-                        m_hole = ~cur & cur_l & upw;
-                        if (use_vis) { // candidates on gridded borders: the segment walkers of (d) have been there
-                            const uint32_t seen = __hip_atomic_load(vis + i + wpr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            ncand_l += __popc((m_outer | m_hole) & seen); // the statistic counts every start candidate of the frame
-                            m_outer &= ~seen; m_hole &= ~seen;
-                        }
+                        start_candidate_masks(cur, cur_l, upw, up_l, up_r, ORBFE_CAND_FILTER != 0, &m_outer, &m_hole);
                     }
                 }
                 if (m_outer | m_hole) {
@@ -1074,7 +1200,7 @@ __device__ __forceinline__ int relay_frame(
                     busy = s0 >= 0; // single-pixel borders are never kept
                 }
             }
-            if (!__any(busy || !drained)) break;
+            if (!__any(busy || have || !drained)) break;
 #pragma unroll
             for (int u = 0; u < RL_STEPS_PER_ITER; u++) {
                 if (busy) {
@@ -1121,7 +1247,8 @@ __device__ __forceinline__ int relay_frame(
                 }
             }
         }
-        atomicAdd(&s_ncand, ncand_l);
+        if (listed) { if (tid == 0) s_ncand = qn; }
+        else atomicAdd(&s_ncand, ncand_l);
 #ifdef ORBFE_CT_TIMING
         if ((tid & 63) == 0) { atomicMax(&s_dbg_steps[3], dbg_iters); atomicAdd(&s_dbg_steps[4], dbg_iters); }
 #endif
@@ -1131,7 +1258,7 @@ __device__ __forceinline__ int relay_frame(
 
     // ---- (d) segments: table slot -> walk to the next grid marker.  The points go to the lane's staging arena (upper
     // part of the frame's pool); (f2) copies the segments of kept borders to their final place.
-    auto phase_d = [&](const bool mark) {
+    auto phase_d = [&]() {
     {
         RelayWalk wk;
         bool busy = false, drained = false;
@@ -1170,12 +1297,6 @@ __device__ __forceinline__ int relay_frame(
                             const uint32_t k = relay_key(wk.x, wk.y, wk.s);
                             const uint32_t hole = ((e >> 5) & 3u) == 2u ? 1u : 0u;
                             if (k < mn) { mn = k; mnoff = wk.n; mnhole = hole; }
-                            // a start state = exactly one start candidate of the raster scan: the pixel itself (outer pattern) or
-                            // its E neighbour (hole pattern).  It lies on a gridded border, so phase (c) need not walk from it.
-                            if (mark) {
-                                const int qx = wk.x + (int)hole;
-                                __hip_atomic_fetch_or(vis + wk.y * wpr + (qx >> 5), 1u << (qx & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            }
                         }
                         rl_advance(im, wk, e);
                     }
@@ -1184,23 +1305,13 @@ __device__ __forceinline__ int relay_frame(
         }
     }
     };
-    // Order of (c) and (d).  Default: (c) then (d) with no barrier between them ((d) depends on nothing (c) writes and has its own
-    // ticket counter; a wave that has drained the small borders goes straight on to the segments).  Experiment of round 3
-    // (ORBFE_ARUCO_VIS=1, profiles/r03_contour_candidate_plane.txt): (d) first, its walkers setting a bit in an HBM plane for every
-    // start candidate they pass, then (c) on the candidates that are left.  It removes a quarter of the candidates (11.8 k of
-    // 15.9 k remain on a 640 x 480 frame) and the 14 k steps of walks that end at a grid marker -- and is SLOWER: 553 against
-    // 399 us alone, C2 step 1.74 against 1.56 ms: every word fetch of (c) now waits for an L2 round trip, the two phases no longer
-    // overlap, and (c)'s time is set by its slowest wave (123 loop trips against a mean of 46), not by the number of walks.
-    const bool vis_mode = vis != nullptr && kshift < 30 && !small_elsewhere;
-    if (vis_mode) {
-        phase_d(true);
-        __threadfence();
-        __syncthreads();
-        phase_c(true);
-    } else {
-        phase_c(false);
-        phase_d(false);
-    }
+    // (c) then (d) with no barrier between them: (d) depends on nothing (c) writes and has its own ticket counter; a wave that has
+    // drained the small borders goes straight on to the segments.  (Round 3 tried (d) first, its walkers marking the start candidates
+    // they pass in an HBM plane so that (c) need not walk from them: a quarter fewer candidates, and slower -- 553 against 399 us
+    // alone, profiles/r03_contour_candidate_plane.txt -- because (c)'s time was set by its slowest wave and its word fetches, not by
+    // the number of walks.  The experiment's code went in round 5.)
+    phase_c();
+    phase_d();
     __syncthreads();
     if ((s_flags & 4) && kshift < 30) return 1; // staging arena full: again without a grid
     if (s_flags) { // capacity exceeded or an invariant broken: the frame is reported as failed (flags != 0)
@@ -1457,16 +1568,16 @@ __global__ __launch_bounds__(RL_THREADS) RL_VGPR_ATTR void k_contours_relay(
     int kshift, int tbits, RelaySeg* __restrict__ segs, uint32_t* __restrict__ pool, size_t pool_fstride, int pool_cap,
     ArKept* __restrict__ kept_out, int kept_cap, int kcap /*kept borders this kernel's LDS holds*/,
     unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off, int32_t* __restrict__ counts, int32_t* __restrict__ hint,
-    uint4* __restrict__ small_g, int32_t* __restrict__ rstate, int small_elsewhere, const uint16_t* __restrict__ lut_g, int f0, uint32_t* __restrict__ vis_g, size_t vis_fstride)
+    uint4* __restrict__ small_g, int32_t* __restrict__ rstate, int small_elsewhere, const uint16_t* __restrict__ lut_g, int f0, uint32_t* __restrict__ candq_g, size_t candq_fstride)
 {
     __builtin_amdgcn_s_setprio(2); // latency-bound: its few waves go first when a VALU-bound kernel shares the CU
     if (relay_frame<false, RL_SLOTS_PER_THREAD, RL_THREADS>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool,
                                                 pool_fstride, pool_cap, kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate,
-                                                nullptr, 0, small_elsewhere, lut_g, f0, vis_g, vis_fstride)) {
+                                                nullptr, 0, small_elsewhere, lut_g, f0, candq_g, candq_fstride)) {
         __syncthreads();
         relay_frame<true, RL_SLOTS_PER_THREAD, RL_THREADS>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool,
                                                pool_fstride, pool_cap, kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate,
-                                               nullptr, 0, small_elsewhere, lut_g, f0, vis_g, vis_fstride);
+                                               nullptr, 0, small_elsewhere, lut_g, f0, candq_g, candq_fstride);
     }
 }
 
@@ -1477,14 +1588,14 @@ __global__ __launch_bounds__(RL_THREADS_BIG) void k_contours_relay8(
     int kshift, int tbits, RelaySeg* __restrict__ segs, uint32_t* __restrict__ pool, size_t pool_fstride, int pool_cap,
     ArKept* __restrict__ kept_out, int kept_cap, int kcap, unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off,
     int32_t* __restrict__ counts, int32_t* __restrict__ hint, uint4* __restrict__ small_g, int32_t* __restrict__ rstate, int small_elsewhere,
-    const uint16_t* __restrict__ lut_g, int f0, uint32_t* __restrict__ vis_g, size_t vis_fstride)
+    const uint16_t* __restrict__ lut_g, int f0, uint32_t* __restrict__ candq_g, size_t candq_fstride)
 {
     __builtin_amdgcn_s_setprio(2);
     if (relay_frame<false, 8192 / RL_THREADS_BIG, RL_THREADS_BIG>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool, pool_fstride, pool_cap,
-                              kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate, nullptr, 0, small_elsewhere, lut_g, f0, vis_g, vis_fstride)) {
+                              kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate, nullptr, 0, small_elsewhere, lut_g, f0, candq_g, candq_fstride)) {
         __syncthreads();
         relay_frame<true, 8192 / RL_THREADS_BIG, RL_THREADS_BIG>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool, pool_fstride, pool_cap,
-                             kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate, nullptr, 0, small_elsewhere, lut_g, f0, vis_g, vis_fstride);
+                             kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate, nullptr, 0, small_elsewhere, lut_g, f0, candq_g, candq_fstride);
     }
 }
 
@@ -1497,14 +1608,14 @@ __global__ __launch_bounds__(RL_THREADS_BIG) void k_contours_relay_wide(
     int kshift, int tbits, RelaySeg* __restrict__ segs, uint32_t* __restrict__ pool, size_t pool_fstride, int pool_cap,
     ArKept* __restrict__ kept_out, int kept_cap, int kcap, unsigned long long* __restrict__ tail_keys, int32_t* __restrict__ tail_off,
     int32_t* __restrict__ counts, int32_t* __restrict__ hint, uint4* __restrict__ small_g, int32_t* __restrict__ rstate, int small_elsewhere,
-    const uint16_t* __restrict__ lut_g, int f0, uint32_t* __restrict__ vis_g, size_t vis_fstride)
+    const uint16_t* __restrict__ lut_g, int f0, uint32_t* __restrict__ candq_g, size_t candq_fstride)
 {
     __builtin_amdgcn_s_setprio(2);
     if (relay_frame<false, 4096 / RL_THREADS_BIG, RL_THREADS_BIG>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool, pool_fstride, pool_cap,
-                              kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate, nullptr, 0, small_elsewhere, lut_g, f0, vis_g, vis_fstride)) {
+                              kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate, nullptr, 0, small_elsewhere, lut_g, f0, candq_g, candq_fstride)) {
         __syncthreads();
         relay_frame<true, 4096 / RL_THREADS_BIG, RL_THREADS_BIG>(gbits, bits_fstride, wpr_g, W, H, lds_bits_words, min_len, kshift, tbits, segs, pool, pool_fstride, pool_cap,
-                             kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate, nullptr, 0, small_elsewhere, lut_g, f0, vis_g, vis_fstride);
+                             kept_out, kept_cap, kcap, tail_keys, tail_off, counts, hint, small_g, rstate, nullptr, 0, small_elsewhere, lut_g, f0, candq_g, candq_fstride);
     }
 }
 
@@ -1624,8 +1735,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_contours_small(
         const uint32_t cur_l = (cur << 1) | (row[-1] >> 31);
         const uint32_t up_l = (upw << 1) | (up[-1] >> 31);
         const uint32_t up_r = (upw >> 1) | (up[1] << 31);
-        m_outer = (k < NWB - 1) ? cur & ~cur_l & ~up_l & ~upw & ~up_r : 0u;
-        m_hole = ~cur & cur_l & upw;
+        start_candidate_masks(cur, cur_l, upw, up_l, up_r, ORBFE_CAND_FILTER != 0, &m_outer, &m_hole);
+        if (k == NWB - 1) m_outer = 0u;
         if (k == 0) m_hole &= ~1u;
         if (k == NWB - 1) m_hole &= 1u;
         if (wj == 0) { m_outer &= ~1u; m_hole &= ~3u; } // column 0 is the frame; a hole candidate at column 1 has no start pixel

@@ -34,6 +34,16 @@ __global__ void k_adaptive_threshold(ImgView src, int W, int H, int win, int C, 
 template <int WIN>
 __global__ void k_adaptive_threshold_t(ImgView src, int W, int H, int C, uint32_t magic, uint32_t* bits,
                                        size_t bits_fstride, int wpr, int ntx, int ntiles, int total);
+// the run tests on the start candidates of the contour kernels (aruco_trace.hpp "FEWER WALKS" (1)); a build parameter so that a
+// library without them can be measured next to the shipped one (tools/build_variant.sh); result-neutral
+#ifndef ORBFE_CAND_FILTER
+#define ORBFE_CAND_FILTER 1
+#endif
+// the speck passes ("FEWER WALKS" (2)): bit image -> the bit image the contour kernels are handed
+#define SPK_THREADS 256
+#define SPK_ROWS 48   // output rows per workgroup (+ ORBFE_SPECK_REACH above and below)
+static inline size_t speck_lds_bytes(int cols) { return (size_t)4 * (SPK_ROWS + 2 * ORBFE_SPECK_REACH) * (((cols + 2 + 31) >> 5) + 1) * 4; }
+__global__ void k_speck_clean(const uint32_t* bits, size_t bits_fstride, int wpr_g, int W, int H, uint32_t* out);
 __global__ void k_half_area(ImgView src, ImgView dst, int dw, int dh);
 __global__ void k_half_area4(ImgView src, ImgView dst, int dw4, int dh);
 template <bool LDS_BITS>
@@ -53,15 +63,15 @@ struct RelaySeg {
 __global__ void k_contours_relay(const uint32_t* gbits, size_t bits_fstride, int wpr_g, int W, int H,
                                  int lds_bits_words, int min_len, int kshift, int tbits, RelaySeg* segs, uint32_t* pool,
                                  size_t pool_fstride, int pool_cap, ArKept* kept_out, int kept_cap, int kcap,
-                                 unsigned long long* tail_keys, int32_t* tail_off, int32_t* counts, int32_t* hint, uint4* small_g, int32_t* rstate, int small_elsewhere, const uint16_t* lut_g, int f0, uint32_t* vis_g, size_t vis_fstride);
+                                 unsigned long long* tail_keys, int32_t* tail_off, int32_t* counts, int32_t* hint, uint4* small_g, int32_t* rstate, int small_elsewhere, const uint16_t* lut_g, int f0, uint32_t* candq_g, size_t candq_fstride);
 __global__ void k_contours_relay8(const uint32_t* gbits, size_t bits_fstride, int wpr_g, int W, int H,
                                  int lds_bits_words, int min_len, int kshift, int tbits, RelaySeg* segs, uint32_t* pool,
                                  size_t pool_fstride, int pool_cap, ArKept* kept_out, int kept_cap, int kcap,
-                                 unsigned long long* tail_keys, int32_t* tail_off, int32_t* counts, int32_t* hint, uint4* small_g, int32_t* rstate, int small_elsewhere, const uint16_t* lut_g, int f0, uint32_t* vis_g, size_t vis_fstride);
+                                 unsigned long long* tail_keys, int32_t* tail_off, int32_t* counts, int32_t* hint, uint4* small_g, int32_t* rstate, int small_elsewhere, const uint16_t* lut_g, int f0, uint32_t* candq_g, size_t candq_fstride);
 __global__ void k_contours_relay_wide(const uint32_t* gbits, size_t bits_fstride, int wpr_g, int W, int H,
                                  int lds_bits_words, int min_len, int kshift, int tbits, RelaySeg* segs, uint32_t* pool,
                                  size_t pool_fstride, int pool_cap, ArKept* kept_out, int kept_cap, int kcap,
-                                 unsigned long long* tail_keys, int32_t* tail_off, int32_t* counts, int32_t* hint, uint4* small_g, int32_t* rstate, int small_elsewhere, const uint16_t* lut_g, int f0, uint32_t* vis_g, size_t vis_fstride);
+                                 unsigned long long* tail_keys, int32_t* tail_off, int32_t* counts, int32_t* hint, uint4* small_g, int32_t* rstate, int small_elsewhere, const uint16_t* lut_g, int f0, uint32_t* candq_g, size_t candq_fstride);
 __global__ void k_contours_relay8g(const uint32_t* gbits, size_t bits_fstride, int wpr_g, int W, int H,
                                  int lds_bits_words, int min_len, int kshift, int tbits, RelaySeg* segs, uint32_t* pool,
                                  size_t pool_fstride, int pool_cap, ArKept* kept_out, int kept_cap, int kcap,

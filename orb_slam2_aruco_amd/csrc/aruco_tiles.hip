@@ -252,8 +252,8 @@ __global__ __launch_bounds__(CTW_THREADS) void k_ct_walk(
                             const uint32_t cur_l = (curw << 1) | (row[-1] >> 31);
                             const uint32_t up_l = (upw << 1) | (up[-1] >> 31);
                             const uint32_t up_r = (upw >> 1) | (up[1] << 31);
-                            const uint32_t mo = curw & ~cur_l & ~up_l & ~upw & ~up_r; // bit = the start pixel
-                            const uint32_t mh = ~curw & cur_l & upw;                  // bit = the hole's background pixel; the start pixel is one to the left
+                            uint32_t mo, mh;   // mo: bit = the start pixel; mh: bit = the hole's background pixel, the start pixel is one to the left
+                            start_candidate_masks(curw, cur_l, upw, up_l, up_r, ORBFE_CAND_FILTER != 0, &mo, &mh);
                             // the statistic counts every start candidate of the frame once: candidate pixels in (x0, x1]
                             stc = __popc((mo | mh) & (k == 0 ? ~1u : k == nw ? 1u : ~0u));
                             if (r < 31) { // walked here: start pixels in [x0, x1] (a candidate on a shared column is tried by both tiles)
@@ -671,8 +671,7 @@ __global__ __launch_bounds__(CTB_THREADS) void k_ct_band(
                         const uint32_t cur_l = (cur << 1) | (wj ? row[wj - 1] >> 31 : 0u);
                         const uint32_t up_l = (upw << 1) | (wj ? up[wj - 1] >> 31 : 0u);
                         const uint32_t up_r = (upw >> 1) | (wj + 1 < wpr ? up[wj + 1] << 31 : 0u);
-                        m_outer = cur & ~cur_l & ~up_l & ~upw & ~up_r;
-                        m_hole = ~cur & cur_l & upw;
+                        start_candidate_masks(cur, cur_l, upw, up_l, up_r, ORBFE_CAND_FILTER != 0, &m_outer, &m_hole);
                         ncand_l += __popc(m_outer) + __popc(m_hole);
                     }
                 }

@@ -168,6 +168,114 @@ ORBFE_HD bool hole_start_candidate(const BitImage& im, int px, int py)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// FEWER WALKS.  The detector keeps only borders of more than 70 points (markerdetector_impl.cpp:3046 / :3217), and on textured
+// frames nearly every start candidate belongs to a border that is dropped: specks of the thresholded texture and the ragged edges of
+// large regions (a 640 x 480 stream frame: 12.8 k candidates, 8.0 k of its 8.2 k components have at most 17 pixels).  Two exact
+// reductions, both decided on whole 32-pixel words:
+//
+// (1) RUN TESTS on the start candidates.  A candidate is the canonical start of a border only if its pixel is the raster-first pixel
+//     of its component (outer) / of its background region (hole).  Follow the row eastwards from the candidate along its run of
+//     foreground (background) pixels: a foreground pixel among the NW, N, NE neighbours of the run belongs to the same 8-connected
+//     component, a background pixel N of the run to the same 4-connected region -- both raster-smaller, so the candidate cannot be
+//     canonical and no walk is started.  Runs are cut at the word's end (a carry that leaves the word proves nothing: the walk decides).
+//     "The carry of start bit p through the run's good pixels stops on a bad pixel" is one addition; getting from the stop back to p
+//     is the same addition on the bit-reversed word.
+//
+// (2) SPECKS.  A border visits a pixel at most four times -- the visits of one border to a pixel p are states (p, s) with pairwise
+//     different runs, a run on a followed border is never empty (an empty run's predecessor has an empty run, or the cycle is the
+//     three-pixel loop inside a solid corner: tests/test_contour_logic_cpu.py), and the 8 neighbours of p hold at most four maximal
+//     background runs -- so a component of n pixels has no border, outer or hole, longer than 4 n points.  A w x h window whose
+//     one-pixel rim is empty isolates what is inside it from the rest of the frame; with w h <= 17 nothing inside can have a border
+//     of more than 68 points, and clearing the window changes no other border (a walk only ever examines its own component and the
+//     background region it follows).  speck_* below are one PASS for one window shape, on the padded bit image:
+//         anchor (ax, ay), ax >= 0: the rim's top-left corner; rim = columns ax and ax + w + 1, rows ay and ay + h + 1;
+//         empty rim -> pixels (ax + 1 .. ax + w, ay + 1 .. ay + h) are cleared;
+//     the image is taken as zero beyond its frame.  Passes are applied one after the other (what one clears opens rims for the next);
+//     a pixel of a pass's output depends on the input within w columns and h rows of it.
+ORBFE_HD uint32_t bitrev32(uint32_t v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __brev(v);
+#else
+    v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+    v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+    v = ((v >> 4) & 0x0f0f0f0fu) | ((v & 0x0f0f0f0fu) << 4);
+    v = ((v >> 8) & 0x00ff00ffu) | ((v & 0x00ff00ffu) << 8);
+    return (v >> 16) | (v << 16);
+#endif
+}
+
+// start bits of `starts` (a subset of `good`) whose run of consecutive `good` bits towards bit 31 ends on a bit of `bad`
+ORBFE_HD uint32_t run_ends_on(uint32_t starts, uint32_t good, uint32_t bad)
+{
+    const uint32_t land = (good + starts) & ~good & bad;                 // where a start's carry stopped, if that is a bad pixel
+    const uint32_t rg = bitrev32(good);
+    const uint32_t back = (rg + (bitrev32(land) << 1)) & ~rg;            // the carry back down the run stops one below its start
+    return bitrev32(back) << 1;
+}
+
+// Start candidates of one word of row y of the padded image (bit i = pixel 32 j + i): cur = the row's word, cur_l = the W neighbours of
+// its pixels, upw / up_l / up_r = their N / NW / NE neighbours.  *outer: pixels that may start an outer border; *hole: BACKGROUND pixels b
+// whose W neighbour may start a hole border (the start pixel is b - 1).  filter: apply the run tests (1) above.
+// valid: the pixels of the word the caller may look at (a tile: its window; the kernels hold whole words: all ones) -- a run is cut there too.
+ORBFE_HD void start_candidate_masks(uint32_t cur, uint32_t cur_l, uint32_t upw, uint32_t up_l, uint32_t up_r, bool filter, uint32_t* outer,
+                                    uint32_t* hole, uint32_t valid = 0xffffffffu)
+{
+    uint32_t mo = cur & ~cur_l & ~up_l & ~upw & ~up_r;
+    uint32_t mh = ~cur & cur_l & upw;
+    if (filter) {
+        // foreground with foreground above: not the first of its component.  (The NE neighbour of the word's last pixel lies in another
+        // word of the row above, which not every caller holds for every word it looks at: left out, so that all callers decide alike.)
+        const uint32_t bad_o = cur & (up_l | upw | (up_r & 0x7fffffffu)) & valid;
+        mo &= ~run_ends_on(mo, cur & ~bad_o & valid, bad_o);
+        const uint32_t bad_h = ~cur & ~upw & valid;                     // background with background above
+        mh &= ~run_ends_on(mh, ~cur & upw & valid, bad_h);
+    }
+    *outer = mo;
+    *hole = mh;
+}
+
+// ((hi : lo) >> k) & 0xffffffff, 0 <= k <= 31
+ORBFE_HD uint32_t funnel_shr(uint32_t hi, uint32_t lo, int k)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)k);
+#else
+    return (uint32_t)((((unsigned long long)hi << 32) | lo) >> k);
+#endif
+}
+// One row's contribution to the rims of the anchors in its word: bit a of *full = one of pixels a .. a + WW + 1 of the row is set (a rim's
+// top or bottom row), bit a of *side = pixel a or pixel a + WW + 1 is set (its two columns).  p = the word, pn = the next word of the row.
+template <int WW>
+ORBFE_HD void speck_row_masks(uint32_t p, uint32_t pn, uint32_t* full, uint32_t* side)
+{
+    uint32_t f = p, last = p;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 1; k <= WW + 1; k++) { last = funnel_shr(pn, p, k); f |= last; }
+    *full = f;
+    *side = p | last;
+}
+// pixels cleared in a word of a row: e = the anchors (empty rims) of the HH rows above it in this word, el = in the word before it
+template <int WW>
+ORBFE_HD uint32_t speck_dilate(uint32_t e, uint32_t el)
+{
+    uint32_t c = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int dx = 1; dx <= WW; dx++) c |= funnel_shr(e, el, 32 - dx);
+    return c;
+}
+// the window shapes of the two passes (w x h <= 17 each); vertical reach of both together
+#define ORBFE_SPECK_W1 3
+#define ORBFE_SPECK_H1 5
+#define ORBFE_SPECK_W2 5
+#define ORBFE_SPECK_H2 3
+#define ORBFE_SPECK_REACH (ORBFE_SPECK_H1 + ORBFE_SPECK_H2)
+
+// ------------------------------------------------------------------------------------------------------------------
 // Relay segments: the same borders, cut into short independent pieces (k_contours_relay, tests/proto_contours.cpp).
 //
 // A walk state is (pixel p, direction s of the previous border pixel).  One step searches counter-clockwise from s+1

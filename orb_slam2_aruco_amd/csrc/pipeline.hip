@@ -46,11 +46,15 @@ Rccl* rccl()
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
+        // ORBFE_RCCL_LIB: the library to bind instead of the system's librccl (tests/fake_rccl.cpp: the N > 1 branch of the gather
+        // between processes that share the one GPU of a test box)
+        const char* over = getenv("ORBFE_RCCL_LIB");
+        if (over && *over) r.lib = dlopen(over, RTLD_NOW | RTLD_LOCAL);
         const char* names[] = {"librccl.so.1", "librccl.so"};
         for (const char* n : names)
-            if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+            if (!r.lib && !(over && *over)) r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
         for (const char* n : names)
-            if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (!r.lib && !(over && *over)) r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         if (!r.lib) return;
         auto sym = [&](const char* n) { return dlsym(r.lib, n); };
         r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
@@ -125,7 +129,12 @@ struct orbfe_pipeline {
     void* comm = nullptr;
     bool own_comm = false;
     int rank = 0, world = 0, dst = 0;
-    uint8_t* blocks = nullptr; // on dst: world x lay.nbytes
+    uint8_t* blocks = nullptr; // on dst: R sets x world x lay.nbytes -- the batch written to record set s is received into block set s,
+                               // so a consumer reads batch i (orbfe_pipeline_gathered_wait / _set) while batch i + 1 .. i + R - 1 arrive
+    std::vector<hipEvent_t> gather_free;   // orbfe_pipeline_gathered_release: the consumer's reads of block set s (the next receive into it waits)
+    std::vector<char> gather_free_valid;
+    int last_gathered = -1;    // record set of the newest gather that was enqueued
+    bool failed = false;       // an enqueue failed half way: events of that step were never recorded; the handle refuses further steps
 
     ~orbfe_pipeline()
     {
@@ -137,7 +146,7 @@ struct orbfe_pipeline {
         for (size_t k = 1; k < st_dets.size(); k++) if (st_dets[k]) (void)hipStreamDestroy(st_dets[k]);
         for (auto r : recs) if (r) (void)hipFree(r);
         for (void* p : {(void*)d_bidx, (void*)d_bdist, (void*)d_sdist, (void*)d_m12, (void*)d_nm, (void*)blocks}) if (p) (void)hipFree(p);
-        for (auto* v : {&ex_done, &det_done, &match_done, &gather_done}) for (auto e : *v) if (e) (void)hipEventDestroy(e);
+        for (auto* v : {&ex_done, &det_done, &match_done, &gather_done, &gather_free}) for (auto e : *v) if (e) (void)hipEventDestroy(e);
         for (auto& t : match_ev) for (auto e : t) if (e) (void)hipEventDestroy(e);
         for (auto& t : gather_ev) for (auto e : t) if (e) (void)hipEventDestroy(e);
         for (auto b : d_in) if (b) (void)hipFree(b);
@@ -189,13 +198,18 @@ struct orbfe_pipeline {
             ORBFE_HIP(hipEventRecord(e[0], st_match));
         }
         const size_t nb = (size_t)lay.nbytes;
+        uint8_t* bset = blocks ? blocks + (size_t)cur * world * nb : nullptr;   // this batch's receive blocks (rank dst only)
+        if (rank == dst && gather_free_valid[(size_t)cur]) {   // a consumer said when it is done with the batch this set held before
+            ORBFE_HIP(hipStreamWaitEvent(st_match, gather_free[(size_t)cur], 0));
+            gather_free_valid[(size_t)cur] = 0;
+        }
         ORBFE_NCCL(R->GroupStart());
         int ge = 0; // the first error inside the group: the group is closed whatever happens
         const char* gwhat = "";
         if (rank == dst) {
             for (int r = 0; r < world && !ge; r++) {
                 if (r == rank && world > 1) continue;
-                if ((ge = R->Recv(blocks + (size_t)r * nb, nb, NCCL_UINT8, r, comm, st_match))) gwhat = "ncclRecv";
+                if ((ge = R->Recv(bset + (size_t)r * nb, nb, NCCL_UINT8, r, comm, st_match))) gwhat = "ncclRecv";
             }
             if (world == 1 && !ge && (ge = R->Send(recs[cur], nb, NCCL_UINT8, dst, comm, st_match))) gwhat = "ncclSend"; // the one-GPU box: the same kernels, to itself
         } else if ((ge = R->Send(recs[cur], nb, NCCL_UINT8, dst, comm, st_match)))
@@ -203,9 +217,10 @@ struct orbfe_pipeline {
         const int gend = R->GroupEnd();
         if (ge) return fail(ORBFE_ERR_HIP, "%s failed: %s", gwhat, R->GetErrorString ? R->GetErrorString(ge) : "RCCL error");
         if (gend) return fail(ORBFE_ERR_HIP, "ncclGroupEnd failed: %s", R->GetErrorString ? R->GetErrorString(gend) : "RCCL error");
-        if (rank == dst && world > 1) ORBFE_HIP(hipMemcpyAsync(blocks + (size_t)rank * nb, recs[cur], nb, hipMemcpyDeviceToDevice, st_match));
+        if (rank == dst && world > 1) ORBFE_HIP(hipMemcpyAsync(bset + (size_t)rank * nb, recs[cur], nb, hipMemcpyDeviceToDevice, st_match));
         if (timing) ORBFE_HIP(hipEventRecord(e[1], st_match));
         ORBFE_HIP(hipEventRecord(gather_done[cur], st_match));
+        last_gathered = cur;
         return ORBFE_OK;
     }
 
@@ -225,6 +240,9 @@ struct orbfe_pipeline {
             // the stream goes on: the batch's last frame becomes the halo of the set the NEXT batch is written to (that set's halo was
             // last read by the matching of R batches ago, earlier on this stream).  Only then may this set be written again.
             const int nxt = (cur + 1) % R;
+            // ... and in host mode the set's previous contents are still being copied to the host (the read-back stream reads the whole
+            // set, halo slot included): the write waits for that copy like the engines do
+            if (host_mode && rb_valid[(size_t)nxt]) ORBFE_HIP(hipStreamWaitEvent(st_match, rb_done[(size_t)nxt], 0));
             hipLaunchKernelGGL(k_copy_halo, dim3((cap * 8 + 255) / 256), dim3(256), 0, st_match, reinterpret_cast<const uint32_t*>(slot_kps(cur, B)),
                                reinterpret_cast<uint32_t*>(slot_kps(nxt, 0)), reinterpret_cast<const uint32_t*>(slot_desc(cur, B)),
                                reinterpret_cast<uint32_t*>(slot_desc(nxt, 0)), slot_n(cur, B), slot_n(nxt, 0), cap);
@@ -246,9 +264,9 @@ const char* orbfe_pipeline_env_defaults(void)
 {
     // one list for the pipeline and the engines: bench.py marks a line as diagnostic when one of these is set to something else
     return "ORBFE_ENGINE_SETS=2;ORBFE_ENGINE_SETS_ARUCO=1;ORBFE_RECORD_SETS=4;ORBFE_PHASE_PIN=size;ORBFE_DET_PIN=4;ORBFE_DEFER_POST=size;ORBFE_DET_NOFORK=size;"
-           "ORBFE_ORIENT_PAIR=1;ORBFE_FAST0=0;ORBFE_ARUCO_VIS=0;ORBFE_ARUCO_FORCE_GLOBAL=0;ORBFE_ARUCO_RELAY_CHUNK=0;ORBFE_ARUCO_RELAY_WIDE=1;"
-           "ORBFE_ARUCO_SMALL_SEPARATE=size;ORBFE_ARUCO_TILED=size;ORBFE_ARUCO_TILE_W=0;ORBFE_ARUCO_TPW=0;ORBFE_ARUCO_BANDED=size;ORBFE_ARUCO_BAND_ROWS=0;ORBFE_ARUCO_LCAP=0;ORBFE_GRAPH=0;"
-           "ORBFE_OCC_FAST=0;ORBFE_OCC_BLUR=0;ORBFE_OCC_ORIENT=0;ORBFE_BLUR_PLACE=1;ORBFE_NO_LEND=0;ORBFE_H2D_SPLIT=1;ORBFE_GRAPH_VERBOSE=0";
+           "ORBFE_ORIENT_PAIR=1;ORBFE_FAST0=0;ORBFE_ARUCO_FORCE_GLOBAL=0;ORBFE_ARUCO_RELAY_CHUNK=0;ORBFE_ARUCO_RELAY_WIDE=1;"
+           "ORBFE_ARUCO_SPECKS=size;ORBFE_ARUCO_SMALL_SEPARATE=size;ORBFE_ARUCO_TILED=size;ORBFE_ARUCO_TILE_W=0;ORBFE_ARUCO_TPW=0;ORBFE_ARUCO_BANDED=size;ORBFE_ARUCO_BAND_ROWS=0;ORBFE_ARUCO_LCAP=0;ORBFE_GRAPH=0;"
+           "ORBFE_OCC_FAST=0;ORBFE_OCC_BLUR=0;ORBFE_OCC_ORIENT=0;ORBFE_BLUR_PLACE=1;ORBFE_NO_LEND=0;ORBFE_H2D_SPLIT=1;ORBFE_GRAPH_VERBOSE=0;ORBFE_RCCL_LIB=";
 }
 
 int orbfe_pipeline_config_default(orbfe_pipeline_config* c, int frames, int rows, int cols)
@@ -384,25 +402,27 @@ int orbfe_pipeline_step(orbfe_pipeline* p, const uint8_t* d_imgs, size_t pitch, 
 static int host_mode_init(orbfe_pipeline* p)
 {
     if (p->host_mode) return ORBFE_OK;
+    // every resource is created once: a call that failed half way (host_mode still false) is continued, not repeated, by the next one
     p->in_pitch = ((size_t)p->cols + 63) / 64 * 64;
-    if (hipStreamCreateWithFlags(&p->st_h2d, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&p->st_d2h, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&p->st_h2d2, hipStreamNonBlocking) != hipSuccess)
-        return fail(ORBFE_ERR_HIP, "orbfe_pipeline_step_host: streams");
+    for (hipStream_t* st : {&p->st_h2d, &p->st_d2h, &p->st_h2d2})
+        if (!*st && hipStreamCreateWithFlags(st, hipStreamNonBlocking) != hipSuccess) return fail(ORBFE_ERR_HIP, "orbfe_pipeline_step_host: streams");
     p->h2d_split = env_or("ORBFE_H2D_SPLIT", 1);   // (measured: 34.3 GB/s with one upload stream, 34.2 with two -- the link, not the copy engine)
     for (int k = 0; k < orbfe_pipeline::NIN; k++) {
-        ORBFE_HIP(hipMalloc(&p->d_in[k], (size_t)p->B * p->rows * p->in_pitch));
-        ORBFE_HIP(hipMemset(p->d_in[k], 0, (size_t)p->B * p->rows * p->in_pitch));
-        ORBFE_HIP(hipEventCreateWithFlags(&p->in_ready[k], hipEventDisableTiming));
-        ORBFE_HIP(hipEventCreateWithFlags(&p->in_ready2[k], hipEventDisableTiming));
-        ORBFE_HIP(hipEventCreateWithFlags(&p->in_used_ex[k], hipEventDisableTiming));
-        ORBFE_HIP(hipEventCreateWithFlags(&p->in_used_det[k], hipEventDisableTiming));
+        if (!p->d_in[k]) {
+            ORBFE_HIP(hipMalloc(&p->d_in[k], (size_t)p->B * p->rows * p->in_pitch));
+            ORBFE_HIP(hipMemset(p->d_in[k], 0, (size_t)p->B * p->rows * p->in_pitch));
+        }
+        for (hipEvent_t* e : {&p->in_ready[k], &p->in_ready2[k], &p->in_used_ex[k], &p->in_used_det[k]})
+            if (!*e) ORBFE_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
-    p->h_recs.assign((size_t)p->R, nullptr);
-    p->rb_done.assign((size_t)p->R, nullptr);
-    p->rb_valid.assign((size_t)p->R, 0);
+    if (p->h_recs.empty()) {
+        p->h_recs.assign((size_t)p->R, nullptr);
+        p->rb_done.assign((size_t)p->R, nullptr);
+        p->rb_valid.assign((size_t)p->R, 0);
+    }
     for (int k = 0; k < p->R; k++) {
-        ORBFE_HIP(hipHostMalloc((void**)&p->h_recs[(size_t)k], p->lay.nbytes, hipHostMallocDefault));
-        ORBFE_HIP(hipEventCreateWithFlags(&p->rb_done[(size_t)k], hipEventDisableTiming));
+        if (!p->h_recs[(size_t)k]) ORBFE_HIP(hipHostMalloc((void**)&p->h_recs[(size_t)k], p->lay.nbytes, hipHostMallocDefault));
+        if (!p->rb_done[(size_t)k]) ORBFE_HIP(hipEventCreateWithFlags(&p->rb_done[(size_t)k], hipEventDisableTiming));
     }
     p->host_mode = true;
     return ORBFE_OK;
@@ -478,7 +498,19 @@ int orbfe_device_download(void* dst, const void* d_src, size_t bytes)
     return ORBFE_OK;
 }
 
+static int step_body(orbfe_pipeline* p, const uint8_t* d_imgs, size_t pitch, int32_t* record_set, int in_slot);
+
+// A step that fails half way leaves events of that batch unrecorded which later steps would wait for (and step_no already counts
+// it): the handle is marked and refuses further steps -- destroy it.
 static int step_impl(orbfe_pipeline* p, const uint8_t* d_imgs, size_t pitch, int32_t* record_set, int in_slot)
+{
+    if (p->failed) return fail(ORBFE_ERR_INVALID, "orbfe_pipeline_step: an earlier step of this pipeline failed while it was being enqueued; destroy the handle");
+    const int rc = step_body(p, d_imgs, pitch, record_set, in_slot);
+    if (rc) p->failed = true;
+    return rc;
+}
+
+static int step_body(orbfe_pipeline* p, const uint8_t* d_imgs, size_t pitch, int32_t* record_set, int in_slot)
 {
     int rc;
     const long i = p->step_no++;
@@ -492,6 +524,9 @@ static int step_impl(orbfe_pipeline* p, const uint8_t* d_imgs, size_t pitch, int
         orbfe_aruco* det_i = p->dets[aset];
         hipStream_t st_det_i = p->st_dets[aset];
         // the detector only depends on the resident frames and on its own previous batch: it is not joined with the extractor per step
+        // (several detector sets -- a measurement switch -- alternate streams: the batch that used this record set R steps ago ran on
+        // another one when the number of sets does not divide R)
+        if (p->dets.size() > 1 && i >= p->R) ORBFE_HIP(hipStreamWaitEvent(st_det_i, p->det_done[cur], 0));
         if (p->comm && i >= p->R) ORBFE_HIP(hipStreamWaitEvent(st_det_i, p->gather_done[cur], 0)); // batch i - R has left this record set
         if (p->host_mode && p->rb_valid[(size_t)cur]) ORBFE_HIP(hipStreamWaitEvent(st_det_i, p->rb_done[(size_t)cur], 0)); // ... and has been copied to the host
         if (in_slot >= 0) { ORBFE_HIP(hipStreamWaitEvent(st_det_i, p->in_ready[in_slot], 0)); if (p->h2d_split > 1) ORBFE_HIP(hipStreamWaitEvent(st_det_i, p->in_ready2[in_slot], 0)); }
@@ -548,7 +583,7 @@ int orbfe_pipeline_flush(orbfe_pipeline* p)
     if (p->pending >= 0) {
         const int cur = p->pending;
         p->pending = -1;
-        if ((rc = p->enqueue_post(cur))) return rc;
+        if ((rc = p->enqueue_post(cur))) { p->failed = true; return rc; }
     }
     return ORBFE_OK;
 }
@@ -702,7 +737,15 @@ static int attach_comm(orbfe_pipeline* p, void* comm, bool own, int rank, int wo
 {
     if (p->step_no) { int rc = orbfe_pipeline_synchronize(p); if (rc) return rc; }
     p->comm = comm; p->own_comm = own; p->rank = rank; p->world = world; p->dst = dst;
-    if (rank == dst && !p->blocks) ORBFE_HIP(hipMalloc(&p->blocks, (size_t)world * p->lay.nbytes));
+    if (rank == dst && !p->blocks) {
+        ORBFE_HIP(hipMalloc(&p->blocks, (size_t)p->R * world * p->lay.nbytes));
+        ORBFE_HIP(hipMemset(p->blocks, 0, (size_t)p->R * world * p->lay.nbytes));
+    }
+    if (p->gather_free.empty()) {
+        p->gather_free.assign((size_t)p->R, nullptr);
+        p->gather_free_valid.assign((size_t)p->R, 0);
+        for (auto& e : p->gather_free) ORBFE_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
     return ORBFE_OK;
 }
 
@@ -729,9 +772,37 @@ int orbfe_pipeline_set_comm(orbfe_pipeline* p, void* nccl_comm, int rank, int wo
     return attach_comm(p, nccl_comm, false, rank, world, dst);
 }
 
+int orbfe_pipeline_gathered_set(orbfe_pipeline* p, int set, int rank, uint8_t** d_block)
+{
+    if (!p || !d_block || !p->comm || p->rank != p->dst || !p->blocks || rank < 0 || rank >= p->world || set < 0 || set >= p->R)
+        return fail(ORBFE_ERR_INVALID, "orbfe_pipeline_gathered_set: not the destination rank, no communicator, or no such set / rank");
+    *d_block = p->blocks + ((size_t)set * p->world + (size_t)rank) * p->lay.nbytes;
+    return ORBFE_OK;
+}
+
 int orbfe_pipeline_gathered(orbfe_pipeline* p, int rank, uint8_t** d_block)
 {
-    if (!p || !d_block || !p->comm || p->rank != p->dst || rank < 0 || rank >= p->world) return fail(ORBFE_ERR_INVALID, "orbfe_pipeline_gathered: not the destination rank, or no communicator");
-    *d_block = p->blocks + (size_t)rank * p->lay.nbytes;
+    if (!p || p->last_gathered < 0) return fail(ORBFE_ERR_INVALID, "orbfe_pipeline_gathered: nothing has been gathered yet (a batch's gather is enqueued with its matching: step, or flush)");
+    return orbfe_pipeline_gathered_set(p, p->last_gathered, rank, d_block);
+}
+
+int orbfe_pipeline_gathered_wait(orbfe_pipeline* p, int set)
+{
+    if (!p || !p->comm || set < 0 || set >= p->R) return fail(ORBFE_ERR_INVALID, "orbfe_pipeline_gathered_wait: no communicator, or no such set");
+    int rc = use_device(p->cfg.device);
+    if (rc) return rc;
+    if (p->pending == set && (rc = orbfe_pipeline_flush(p))) return rc;   // the set's post-work (matching, gather) was still held back
+    ORBFE_HIP(hipEventSynchronize(p->gather_done[(size_t)set]));
+    return ORBFE_OK;
+}
+
+int orbfe_pipeline_gathered_release(orbfe_pipeline* p, int set, void* stream)
+{
+    if (!p || !p->comm || p->rank != p->dst || set < 0 || set >= p->R || p->gather_free.empty())
+        return fail(ORBFE_ERR_INVALID, "orbfe_pipeline_gathered_release: not the destination rank, no communicator, or no such set");
+    int rc = use_device(p->cfg.device);
+    if (rc) return rc;
+    ORBFE_HIP(hipEventRecord(p->gather_free[(size_t)set], reinterpret_cast<hipStream_t>(stream)));
+    p->gather_free_valid[(size_t)set] = 1;
     return ORBFE_OK;
 }

@@ -138,6 +138,9 @@ def _setup(L):
     L.orbfe_pipeline_comm_init.argtypes = [vp, C.POINTER(C.c_uint8 * 128), C.c_int, C.c_int, C.c_int]
     L.orbfe_pipeline_set_comm.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int]
     L.orbfe_pipeline_gathered.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.orbfe_pipeline_gathered_set.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
+    L.orbfe_pipeline_gathered_wait.argtypes = [vp, C.c_int]
+    L.orbfe_pipeline_gathered_release.argtypes = [vp, C.c_int, vp]
     L.orbfe_pipeline_step_host.argtypes = [vp, vp, C.c_size_t, i32p]
     L.orbfe_pipeline_host_records.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.orbfe_host_alloc.argtypes = [C.c_size_t]
@@ -307,6 +310,19 @@ class FrontEndPipeline:
         p = C.c_void_p()
         binding._check(self.L, self.L.orbfe_pipeline_gathered(self.h, rank, C.byref(p)), "orbfe_pipeline_gathered")
         return self.layout.unpack(device_bytes(p.value, self.layout.nbytes))
+
+    def gathered_set(self, record_set, rank, wait=True):
+        """On the destination rank: the block rank `rank` sent with the batch that was written to `record_set` (every record set has
+        receive blocks of its own, so this batch stays readable while the following ones arrive); wait: until that gather is done."""
+        if wait:
+            binding._check(self.L, self.L.orbfe_pipeline_gathered_wait(self.h, record_set), "orbfe_pipeline_gathered_wait")
+        p = C.c_void_p()
+        binding._check(self.L, self.L.orbfe_pipeline_gathered_set(self.h, record_set, rank, C.byref(p)), "orbfe_pipeline_gathered_set")
+        return self.layout.unpack(device_bytes(p.value, self.layout.nbytes))
+
+    def gathered_release(self, record_set, stream=None):
+        """The consumer's reads of `record_set`'s blocks enqueued on `stream` so far must finish before the set is received into again."""
+        binding._check(self.L, self.L.orbfe_pipeline_gathered_release(self.h, record_set, stream), "orbfe_pipeline_gathered_release")
 
     # ------------------------------------------------------------------------------------------------------------
     def status(self):

@@ -11,14 +11,89 @@
 
 using namespace orbfe;
 
+// ---- the two reductions of aruco_trace.hpp "FEWER WALKS", switchable so that the tests can run every formulation with and without
+static int g_filter = 0, g_clean = 0;
+extern "C" void proto_set_reductions(int filter_candidates, int clean_specks) { g_filter = filter_candidates; g_clean = clean_specks; }
+
+// one pass of the speck window on a padded bit image of `prow` rows x wpr words (+ 2 spare words), zero beyond its frame
+template <int WW, int HH>
+static void speck_pass(std::vector<uint32_t>& bits, int wpr, int prow)
+{
+    const int pad = HH + 1, nr = prow + 2 * pad;   // rows -pad .. prow + pad - 1 of the zero-extended image
+    auto P = [&](int r, int j) -> uint32_t { return (r >= 0 && r < prow && j >= 0 && j < wpr) ? bits[(size_t)r * wpr + j] : 0u; };
+    std::vector<uint32_t> full((size_t)nr * wpr), side((size_t)nr * wpr), an((size_t)nr * wpr, 0u);
+    for (int r = -pad; r < prow + pad; r++)
+        for (int j = 0; j < wpr; j++) speck_row_masks<WW>(P(r, j), P(r, j + 1), &full[(size_t)(r + pad) * wpr + j], &side[(size_t)(r + pad) * wpr + j]);
+    for (int r = -pad; r + HH + 1 < prow + pad; r++)   // anchor rows whose rim lies in the extended range (the others only see zero rows)
+        for (int j = 0; j < wpr; j++) {
+            uint32_t occ = full[(size_t)(r + pad) * wpr + j] | full[(size_t)(r + pad + HH + 1) * wpr + j];
+            for (int k = 1; k <= HH; k++) occ |= side[(size_t)(r + pad + k) * wpr + j];
+            an[(size_t)(r + pad) * wpr + j] = ~occ;
+        }
+    for (int r = 0; r < prow; r++)
+        for (int j = 0; j < wpr; j++) {
+            uint32_t e = 0, el = 0;
+            for (int dy = 1; dy <= HH; dy++) {
+                e |= an[(size_t)(r - dy + pad) * wpr + j];
+                if (j) el |= an[(size_t)(r - dy + pad) * wpr + j - 1];
+            }
+            bits[(size_t)r * wpr + j] &= ~speck_dilate<WW>(e, el);
+        }
+}
+
+static std::vector<uint32_t> padded_bits(const uint8_t* img, int w, int h)
+{
+    const int wpr = (w + 2 + 31) / 32;
+    std::vector<uint32_t> bits((size_t)wpr * (h + 2) + 2, 0); // + spare words for ring8's funnel read
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+            if (img[(size_t)y * w + x]) bits[(size_t)(y + 1) * wpr + ((x + 1) >> 5)] |= 1u << ((x + 1) & 31);
+    if (g_clean) {
+        speck_pass<ORBFE_SPECK_W1, ORBFE_SPECK_H1>(bits, wpr, h + 2);
+        speck_pass<ORBFE_SPECK_W2, ORBFE_SPECK_H2>(bits, wpr, h + 2);
+    }
+    return bits;
+}
+
+// the bit image the contour kernels are handed (after the speck passes), as bytes
+extern "C" void proto_speck_clean(const uint8_t* img, int w, int h, uint8_t* out)
+{
+    const int keep = g_clean;
+    g_clean = 1;
+    const std::vector<uint32_t> bits = padded_bits(img, w, h);
+    g_clean = keep;
+    const int wpr = (w + 2 + 31) / 32;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) out[(size_t)y * w + x] = (bits[(size_t)(y + 1) * wpr + ((x + 1) >> 5)] >> ((x + 1) & 31)) & 1u;
+}
+
+// start candidate at padded pixel (px, py): 0 outer, 1 hole (px is the background pixel), -1 none; through the word masks when filtered
+static int start_candidate(const BitImage& im, int px, int py, int vx0 = 0, int vx1 = 1 << 20)   // [vx0, vx1]: the columns the caller may look at
+{
+    if (!g_filter) {
+        if (outer_start_candidate(im, px, py)) return 0;
+        if (px >= 2 && hole_start_candidate(im, px, py)) return 1;
+        return -1;
+    }
+    const int j = px >> 5;
+    const uint32_t* row = im.bits + (size_t)py * im.wpr;
+    const uint32_t* up = row - im.wpr;
+    const uint32_t cur = row[j], upw = up[j];
+    const uint32_t cur_l = (cur << 1) | (j ? row[j - 1] >> 31 : 0u), up_l = (upw << 1) | (j ? up[j - 1] >> 31 : 0u);
+    const uint32_t up_r = (upw >> 1) | (j + 1 < im.wpr ? up[j + 1] << 31 : 0u);
+    uint32_t mo, mh, valid = 0;
+    for (int b = 0; b < 32; b++) if (j * 32 + b >= vx0 && j * 32 + b <= vx1) valid |= 1u << b;
+    start_candidate_masks(cur, cur_l, upw, up_l, up_r, true, &mo, &mh, valid);
+    if ((mo >> (px & 31)) & 1u) return 0;
+    if ((mh >> (px & 31)) & 1u) return 1;
+    return -1;
+}
+
 extern "C" int proto_find_contours(const uint8_t* img, int w, int h, int32_t* lengths, int max_contours,
                                    int32_t* points, int max_points, int64_t* work_steps)
 {
     const int wpr = (w + 2 + 31) / 32;
-    std::vector<uint32_t> bits((size_t)wpr * (h + 2) + 2, 0); // + spare word for ring8's funnel read
-    for (int y = 0; y < h; y++)
-        for (int x = 0; x < w; x++)
-            if (img[(size_t)y * w + x]) bits[(size_t)(y + 1) * wpr + ((x + 1) >> 5)] |= 1u << ((x + 1) & 31);
+    const std::vector<uint32_t> bits = padded_bits(img, w, h);
     BitImage im{bits.data(), wpr, w, h};
     struct C { int key; std::vector<uint32_t> pts; };
     std::vector<C> found;
@@ -26,9 +101,7 @@ extern "C" int proto_find_contours(const uint8_t* img, int w, int h, int32_t* le
     int64_t steps = 0;
     for (int py = 1; py <= h; py++)
         for (int px = 1; px <= w; px++) {
-            int is_hole = -1;
-            if (outer_start_candidate(im, px, py)) is_hole = 0;
-            else if (px >= 2 && hole_start_candidate(im, px, py)) is_hole = 1;
+            const int is_hole = start_candidate(im, px, py);
             if (is_hole < 0) continue;
             int n = trace_border(im, px - is_hole, py, is_hole, tmp.data(), (int)tmp.size(), 1 << 30);
             if (n < 0) continue;
@@ -57,10 +130,7 @@ extern "C" int proto_find_contours_relay(const uint8_t* img, int w, int h, int k
                                          int max_contours, int32_t* points, int max_points, int64_t* stats)
 {
     const int wpr = (w + 2 + 31) / 32, kmask = (1 << kshift) - 1;
-    std::vector<uint32_t> bits((size_t)wpr * (h + 2) + 2, 0);
-    for (int y = 0; y < h; y++)
-        for (int x = 0; x < w; x++)
-            if (img[(size_t)y * w + x]) bits[(size_t)(y + 1) * wpr + ((x + 1) >> 5)] |= 1u << ((x + 1) & 31);
+    const std::vector<uint32_t> bits = padded_bits(img, w, h);
     BitImage im{bits.data(), wpr, w, h};
     struct C { int key; std::vector<uint32_t> pts; };
     std::vector<C> found;
@@ -84,9 +154,7 @@ extern "C" int proto_find_contours_relay(const uint8_t* img, int w, int h, int k
     int64_t small_steps = 0;
     for (int py = 1; py <= h; py++)
         for (int px = 1; px <= w; px++) {
-            int is_hole = -1;
-            if (outer_start_candidate(im, px, py)) is_hole = 0;
-            else if (px >= 2 && hole_start_candidate(im, px, py)) is_hole = 1;
+            const int is_hole = start_candidate(im, px, py);
             if (is_hole < 0) continue;
             const int sx = px - is_hole, sy = py, start_key = py * 65536 + px;
             RelayWalk wk;
@@ -199,10 +267,7 @@ extern "C" int proto_find_contours_tiled(const uint8_t* img, int w, int h, int k
                                          int max_contours, int32_t* points, int max_points, int64_t* stats)
 {
     const int wpr = (w + 2 + 31) / 32, K = 1 << kshift, kmask = K - 1, cw = cells * K;
-    std::vector<uint32_t> bits((size_t)wpr * (h + 2) + 2, 0);
-    for (int y = 0; y < h; y++)
-        for (int x = 0; x < w; x++)
-            if (img[(size_t)y * w + x]) bits[(size_t)(y + 1) * wpr + ((x + 1) >> 5)] |= 1u << ((x + 1) & 31);
+    const std::vector<uint32_t> bits = padded_bits(img, w, h);
     struct C { int key; std::vector<uint32_t> pts; };
     std::vector<C> found;
     struct M { uint32_t key, next_key, cmin; int minoff, len, next; std::vector<uint32_t> pts; };
@@ -278,9 +343,9 @@ extern "C" int proto_find_contours_tiled(const uint8_t* img, int w, int h, int k
             // ---- small borders from the start candidates strictly between the tile's relay rows
             for (int py = std::max(1, t.y0 + 1); py <= std::min(h, t.y1 - 1); py++)
                 for (int px = std::max(1, t.x0); px <= std::min(w, t.x1 + 1); px++) { // px: the candidate pixel; the start pixel is px - is_hole
-                    int is_hole = -1;
-                    if (px <= t.x1 && outer_start_candidate(im, px, py)) is_hole = 0;
-                    else if (px >= 2 && px - 1 >= t.x0 && hole_start_candidate(im, px, py)) is_hole = 1;
+                    int is_hole = start_candidate(im, px, py, t.x0 - 1, t.x1 + 1);
+                    if (is_hole == 0 && px > t.x1) is_hole = -1;
+                    if (is_hole == 1 && px - 1 < t.x0) is_hole = -1;
                     if (is_hole < 0) continue;
                     const int sx = px - is_hole, sy = py, start_key = py * 65536 + px;
                     RelayWalk wk;

@@ -488,3 +488,69 @@ def test_detector_paired_with_an_extractor(orbfe, oracle):
     ex(imgs[2]); assert same(det.detect(imgs[2], (K, D, (640, 480)), 0.187), want[2])
     ex.pair_detector(None)
     ex(imgs[0]); assert same(det.detect(imgs[0], (K, D, (640, 480)), 0.187), want[0])
+
+
+# ---- the speck passes between threshold and contours (csrc/aruco_kernels.hip k_speck_clean; aruco_trace.hpp "FEWER WALKS")
+def _proto_speck_clean(tmp_path_factory):
+    import ctypes as C
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path_factory.mktemp("proto") / "libproto.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, os.path.join(root, "tests", "proto_contours.cpp")])
+    P = C.CDLL(so)
+    P.proto_speck_clean.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    P.proto_speck_clean.restype = None
+
+    def clean(b):
+        b = np.ascontiguousarray(b, np.uint8)
+        out = np.zeros_like(b)
+        P.proto_speck_clean(b.ctypes.data, b.shape[1], b.shape[0], out.ctypes.data)
+        return out * 255
+    return clean
+
+
+@pytest.mark.parametrize("rows,cols", [(480, 640), (427, 641), (97, 129), (720, 1280), (1080, 1920), (48, 64), (49, 95)])
+def test_speck_passes_equal_the_cpu_twin(orbfe, tmp_path_factory, rows, cols):
+    """The bit image the contour kernels read = the CPU twin's passes (tests/proto_contours.cpp, itself checked against the pixel-wise
+    definition and the oracle in test_contour_logic_cpu.py) on the thresholded image, for frame sizes whose band / word geometry differs
+    (rows not a multiple of the band height, widths of 32 k - 1 / + 1 pixels, one band), on a batch (every frame)."""
+    clean = _proto_speck_clean(tmp_path_factory)
+    n = 3 if rows * cols <= 1280 * 720 else 1
+    imgs = synth.stream(rows, cols, n, 77, "ARUCO", n_markers=2 if rows >= 200 else 0)
+    det = orbfe.MarkerDetector("ARUCO")
+    det.detect_batch(imgs)
+    removed = 0
+    for f in range(n):
+        th, got = det.thresholded(f), det.contour_image(f)
+        assert np.array_equal(got, clean(th)), (rows, cols, f)
+        removed += int(np.count_nonzero(th) - np.count_nonzero(got))
+    assert removed > 0
+    det.set_speck_passes(False)
+    det.detect_batch(imgs)
+    assert np.array_equal(det.contour_image(0), det.thresholded(0))
+
+
+def test_speck_passes_change_no_result(orbfe):
+    """Rectangle candidates (order, corners, contour lengths), kept-border counts and markers with and without the passes, on every
+    contour path; with them far fewer start candidates are walked."""
+    imgs = synth.stream(480, 640, 6, 4321, "ARUCO", n_markers=4)
+    ref = orbfe.MarkerDetector("ARUCO")
+    ref.set_speck_passes(False)
+    want = ref.detect_batch(imgs)
+    wkeys = [(_rects_key(ref, f), ref.counts(f)) for f in range(len(imgs))]
+    for mode in ("default", "tiled", "legacy"):
+        det = orbfe.MarkerDetector("ARUCO")
+        if mode == "tiled":
+            det.set_tiled_contours(True)
+        if mode == "legacy":
+            det.force_legacy_contours(True)
+        got = det.detect_batch(imgs)
+        for f in range(len(imgs)):
+            (ca, la), cnt = wkeys[f]
+            cb, lb = _rects_key(det, f)
+            c2 = det.counts(f)
+            assert np.array_equal(got[f], want[f]) and np.array_equal(ca, cb) and np.array_equal(la, lb), (mode, f)
+            assert (cnt["nkept"], cnt["nrect"]) == (c2["nkept"], c2["nrect"]) and c2["flags"] == 0
+            assert c2["ncand"] * 2 < cnt["ncand"], (mode, f, c2["ncand"], cnt["ncand"])
+    assert sum(len(w) for w in want) > 0

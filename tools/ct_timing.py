@@ -8,6 +8,9 @@ rows, cols = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (480
 dic = sys.argv[3] if len(sys.argv) > 3 else "ARUCO"
 imgs = synth.stream(rows, cols, 300 if rows == 480 else 40, 1000, dic)[::38 if rows == 480 else 5][:8].copy()
 det = binding.MarkerDetector(dic)
+det.set_tiled_contours(False)      # the one-workgroup relay kernel (a batch of eight frames would take the tiled path)
+if os.environ.get("CT_SPECKS") == "0":
+    det.set_speck_passes(False)
 for legacy in (False, True):
     det.force_legacy_contours(legacy)
     det.detect_batch(imgs)
