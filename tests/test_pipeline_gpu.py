@@ -197,3 +197,112 @@ def test_bench_from_host_overlaps_upload_and_readback(tmp_path):
     assert d["value"] > 0 and d["pcie"]["h2d_GBps"] > 0 and d["pcie"]["d2h_GBps"] > 0
     v = d["verified_frames"]
     assert v["frames"] == [0, 12, 23] and v["pairs"] == [0, 12, 22] and v["boundary_pair_checked"] and v["keypoints_checked"] > 2500
+
+
+def _build_driver_and_fake_rccl(tmp_path):
+    from orb_slam2_aruco_amd import binding
+    libdir = os.path.dirname(binding.LIB_PATH)
+    exe, fake = tmp_path / "pipeline_driver", tmp_path / "libfake_rccl.so"
+    r = subprocess.run(["hipcc", "-O2", "-std=c++17", "-Wall", "-Werror", os.path.join(HERE, "pipeline_driver.cpp"), "-o", str(exe), "-L" + libdir, "-lorbfe",
+                        "-Wl,-rpath," + libdir], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run(["hipcc", "-O2", "-std=c++17", "-Wall", "-Werror", "-shared", "-fPIC", os.path.join(HERE, "fake_rccl.cpp"), "-o", str(fake), "-lrt"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return exe, fake
+
+
+def _two_rank_streams(tmp_path, B, rows, cols, nb):
+    from orb_slam2_aruco_amd import synth
+    raws = []
+    for r in range(2):
+        frames = synth.stream(rows, cols, B * nb, 900 + 1000 * r, "ARUCO", n_markers=3)
+        raw = tmp_path / ("frames%d.u8" % r)
+        frames.tofile(raw)
+        raws.append(raw)
+    return raws
+
+
+@pytest.mark.gpu
+def test_gather_between_two_processes_on_one_gpu(tmp_path):
+    """The N > 1 branch of the gather in C++, with a peer: two processes of tests/pipeline_driver.cpp on device 0, the library's RCCL entry
+    points bound to tests/fake_rccl.cpp (ORBFE_RCCL_LIB; shared-memory mailboxes).  Rank 1 sends every batch's record set, rank 0 receives
+    it next to its own (receive loop, own-block copy); six steps over three different batches with four record sets, so the sets and their
+    receive blocks rotate and wrap; rank 0 reads the blocks of batch s while batch s + 1 is in flight (orbfe_pipeline_gathered_wait / _set /
+    _release).  Every block of every step must equal, over the defined part of the records, what that rank computes for that step
+    on its own (the same driver without a communicator, synchronised and read back after every step)."""
+    import numpy as np
+    from orb_slam2_aruco_amd.pipeline import FrontEndPipeline, valid_records
+    B, rows, cols, nb, steps = 6, 480, 640, 3, 6
+    exe, fake = _build_driver_and_fake_rccl(tmp_path)
+    raws = _two_rank_streams(tmp_path, B, rows, cols, nb)
+    for r in range(2):   # what each rank's record sets must be, step by step
+        q = subprocess.run(list(map(str, [exe, raws[r], B, rows, cols, steps, tmp_path / ("ref%d" % r), "gather", 0, 1, "-", 1])), capture_output=True, text=True, timeout=600)
+        assert q.returncode == 0 and "ok rank 0 of 1" in q.stdout, q.stdout + q.stderr[-2000:]
+    env = dict(os.environ, ORBFE_RCCL_LIB=str(fake), FAKE_RCCL_TIMEOUT_S="120")
+    idf = tmp_path / "comm.id"
+    procs = [subprocess.Popen(list(map(str, [exe, raws[r], B, rows, cols, steps, tmp_path / "got", "gather", r, 2, idf])), env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for r in range(2):
+        assert procs[r].returncode == 0 and ("ok rank %d of 2" % r) in outs[r][0], outs[r][0] + outs[r][1][-2000:]
+    lay = FrontEndPipeline(B, rows, cols).layout
+    nkp = 0
+    for s in range(steps):
+        for r in range(2):
+            got = lay.unpack(np.fromfile(tmp_path / ("got.step%d.rank%d" % (s, r)), np.uint8))
+            want = lay.unpack(np.fromfile(tmp_path / ("ref%d.own.step%d" % (r, s)), np.uint8))
+            assert valid_records(got) == valid_records(want), (s, r)
+            assert int(got["halo_n"][0]) == int(want["halo_n"][0]) and got["halo_kps"][0, :int(got["halo_n"][0])].tobytes() == want["halo_kps"][0, :int(want["halo_n"][0])].tobytes()
+            nkp += int(got["n"].sum())
+        # the two ranks' streams differ, and so do consecutive batches of one rank: a block in the wrong place would not go unnoticed
+        a = lay.unpack(np.fromfile(tmp_path / ("got.step%d.rank0" % s), np.uint8))
+        b = lay.unpack(np.fromfile(tmp_path / ("got.step%d.rank1" % s), np.uint8))
+        assert valid_records(a) != valid_records(b)
+        if s:
+            prev = lay.unpack(np.fromfile(tmp_path / ("got.step%d.rank1" % (s - 1)), np.uint8))
+            assert valid_records(prev) != valid_records(b)
+    assert nkp > 2 * steps * B * 100
+
+
+@pytest.mark.gpu
+def test_gather_error_paths_fail_loudly_and_do_not_hang(tmp_path):
+    """A send that fails inside the RCCL group (the stub's second ncclSend on rank 1): that rank's step returns an error that names the
+    call, the group having been closed; rank 0, whose peer never delivers, gets the stub's time-out through ncclGroupEnd as an error of
+    its step instead of waiting for ever.  Both processes end by themselves."""
+    B, rows, cols, nb, steps = 6, 480, 640, 2, 4
+    exe, fake = _build_driver_and_fake_rccl(tmp_path)
+    raws = _two_rank_streams(tmp_path, B, rows, cols, nb)
+    env = dict(os.environ, ORBFE_RCCL_LIB=str(fake), FAKE_RCCL_TIMEOUT_S="10")
+    idf = tmp_path / "comm.id"
+    procs = [subprocess.Popen(list(map(str, [exe, raws[r], B, rows, cols, steps, tmp_path / "got", "gather", r, 2, idf])),
+                              env=dict(env, FAKE_RCCL_FAIL_SEND_AT="2") if r == 1 else env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert procs[1].returncode != 0 and "ncclSend failed" in outs[1][1] and "injected failure" in outs[1][1], outs[1]
+    assert procs[0].returncode != 0 and "timed out waiting for a peer" in outs[0][1], outs[0]
+
+
+@pytest.mark.gpu
+def test_pipeline_from_a_directory_of_pgm_frames(tmp_path):
+    """Frames from disk: tests/pipeline_driver.cpp reads a directory of binary PGM files in name order (the reference reads its video
+    frame by frame, Examples/Monocular/mono_cvcam.cc:128-148) and runs them in batches; the records equal those of the same frames
+    handed over as one raw blob."""
+    import numpy as np
+    from orb_slam2_aruco_amd import synth
+    B, rows, cols = 8, 480, 640
+    exe, _ = _build_driver_and_fake_rccl(tmp_path)
+    frames = synth.stream(rows, cols, 2 * B, 77, "ARUCO", n_markers=2)
+    d = tmp_path / "seq"
+    d.mkdir()
+    for i, f in enumerate(frames):
+        with open(d / ("%06d.pgm" % i), "wb") as fh:
+            fh.write(b"P5\n# frame %d\n%d %d\n255\n" % (i, cols, rows) + f.tobytes())
+    raw = tmp_path / "frames.u8"
+    frames.tofile(raw)
+    outs = []
+    for src, name in ((d, "a.bin"), (raw, "b.bin")):
+        r = subprocess.run(list(map(str, [exe, src, B, rows, cols, 4, tmp_path / name])), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "ok frames 8 " in r.stdout, r.stdout + r.stderr[-2000:]
+        outs.append(np.fromfile(tmp_path / name, np.uint8))
+    assert np.array_equal(outs[0], outs[1]) and outs[0].size > 0
