@@ -18,6 +18,7 @@ import argparse
 import ctypes
 import json
 import os
+import socket
 import sys
 import time
 
@@ -530,10 +531,21 @@ def main():
     if multi and backend == "rccl":
         # every rank must end up on the same transport: a rank whose ncclCommInitRank fails says so over the gloo group, and then all of
         # them gather through gloo from the host (a diagnostic line, flagged in config.parallelism and gather_check.transport)
+        # Before the collective ncclCommInitRank (in which the healthy ranks would wait for ever for one that cannot join): every rank
+        # says over gloo whether it can open librccl and which device it sits on; a missing library or two ranks on one device (RCCL
+        # refuses that) sends all of them to the fallback together.
         try:
-            uid = [pipeline_mod.comm_unique_id() if rank == 0 else None]
+            my_uid = pipeline_mod.comm_unique_id()      # (opens librccl; only rank 0's id is used)
+            pre = None
         except Exception as e:  # noqa: BLE001
-            uid, rccl_error = [None], repr(e)
+            my_uid, pre = None, repr(e)
+        seats = [None] * world
+        dist.all_gather_object(seats, (socket.gethostname(), int(local_rank), pre))
+        if any(p_ for _, _, p_ in seats):
+            rccl_error = "; ".join("rank %d: %s" % (r_, p_) for r_, (_, _, p_) in enumerate(seats) if p_)
+        elif len({(h_, d_) for h_, d_, _ in seats}) < world:
+            rccl_error = "ranks share a device: %s" % ", ".join("rank %d on %s:%d" % (r_, h_, d_) for r_, (h_, d_, _) in enumerate(seats))
+        uid = [my_uid if rank == 0 and rccl_error is None else None]
         dist.broadcast_object_list(uid, src=0)
         if uid[0] is not None and rccl_error is None:
             try:
@@ -801,9 +813,20 @@ def main():
             roof["counters_from"] = {"pmc_stage": prof_id(pmc), "traffic": prof_id(traffic),
                                      "note": "traffic / valu_us / lane_utilisation are read from committed profiles of this "
                                              "configuration, not measured in this run; launch_us and ms_per_step are this run's"}
+            # the counters describe the library they were measured on: when that is not the library this run loaded, the record
+            # says so and the headline roofline entry carries no counter-derived number (the per-stage table keeps them, tagged)
+            prof_shas = {d.get("_library_sha16") for d in (pmc, traffic) if d}
+            stale = bool(prof_shas) and prof_shas != {lib_sha16}
+            roof["counters_stale"] = stale
+            if stale:
+                roof["counters_from"]["stale"] = "profiled library %s != this run's library %s: re-run tools/profile_round.sh" % (
+                    ", ".join(sorted(x or "?" for x in prof_shas)), lib_sha16)
+                for k_ in ("traffic", "valu_us", "valu_frac"):
+                    roof[k_] = None
             roof["launch_us_is"] = "median over the %d timed steps (newest 64)" % args.steps
 
-        invalid = bool(skips) or args.no_aruco or args.no_orb or bool(env_nondefault)
+        # (a multi-GPU line whose gather fell back to gloo from the host measures another transport and another schedule: diagnostic)
+        invalid = bool(skips) or args.no_aruco or args.no_orb or bool(env_nondefault) or bool(rccl_error)
         verified = None
         if not args.no_verify and not skips:
             # outside the clock: frames {0, B/2, B-1} and pairs {0, B/2, B-2} of the LAST timed step against the oracle

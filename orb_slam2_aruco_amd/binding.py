@@ -971,9 +971,8 @@ class MarkerDetector:
         self.L.orbfe_aruco_debug_kernel_times(self.h, None, 4 if mode is None else 5 if mode else 6)
 
     def set_speck_passes(self, on=True):
-        """Debug: the speck passes between threshold and contours (k_speck_clean) on / off / None = by batch size (default: calls of up
-        to 32 frames); the results do not change."""
-        self.L.orbfe_aruco_debug_kernel_times(self.h, None, 10 if on is None else 8 if on else 9)
+        """Debug: the speck passes between threshold and contours (k_speck_clean) on / off (default); the results do not change."""
+        self.L.orbfe_aruco_debug_kernel_times(self.h, None, 8 if on else 9)
 
     def contour_image(self, frame=0):
         """Debug: the bit image the contour kernels of the last batch read (the thresholded image after the speck passes)."""

@@ -97,12 +97,13 @@ struct orbfe_aruco {
     unsigned ct_gen = 0;       // generation tag of the hash table's entries (16 bits; the table is cleared when it wraps and before first use)
     bool ct_tab_dirty = true;
     DevBuf d_ctseg, d_cthtab, d_ctelem, d_ctstate, d_ctitemsA, d_ctitemsB, d_ctnitems, d_ctcodes;
-    // the speck passes between threshold and contours (k_speck_clean; aruco_trace.hpp "FEWER WALKS"): result-neutral.  -1 = by batch
-    // size: calls of up to 32 frames, where the detector's chain is the call's latency and a quarter fewer walks shorten it; a full batch
-    // inside the pipeline is bound by the instructions all engines issue and by the number of launches on the detector's chain, and
-    // there the extra launch costs more than the shorter walks give back (C2 step 1.40 - 1.46 against 1.34 - 1.38 ms).
-    // ORBFE_ARUCO_SPECKS = 0 / 1 or debug codes 9 / 8 force them off / on (tests, A/B); = 2: the passes run and are not used (measurement).
-    int specks = getenv("ORBFE_ARUCO_SPECKS") ? (atoi(getenv("ORBFE_ARUCO_SPECKS")) ? 1 : 0) : -1;
+    // the speck passes between threshold and contours (k_speck_clean; aruco_trace.hpp "FEWER WALKS" (2)): result-neutral, OFF by default.
+    // They take a quarter of the contour stage's work away (300 x 640 x 480 alone: 472 -> 411 us, the pass itself included) -- and as a
+    // launch of their own on the detector's chain they cost the pipeline more than that: C2 step 1.40 - 1.46 against 1.34 - 1.38 ms,
+    // single-frame detect 0.357 against 0.358 ms (profiles/r05_contour_reductions_ab.txt).  Kept, tested on every
+    // contour path, for the day the passes run inside a kernel that holds the bit image anyway.  ORBFE_ARUCO_SPECKS = 1 or debug
+    // code 8 switch them on; = 2: the passes run and the contour kernels read the thresholded image (measurement).
+    int specks = getenv("ORBFE_ARUCO_SPECKS") ? (atoi(getenv("ORBFE_ARUCO_SPECKS")) ? 1 : 0) : 0;
     bool specks_unused = getenv("ORBFE_ARUCO_SPECKS") && atoi(getenv("ORBFE_ARUCO_SPECKS")) == 2;
     bool specks_ran = false;   // the last batch's contour kernels read d_bitsc
     DevBuf d_bitsc;
@@ -481,7 +482,7 @@ struct orbfe_aruco {
         timer.mark(s, "threshold");
         // the bit image the contour kernels read: after the speck passes, unless switched off or the frame is too wide for their LDS tile
         const size_t spk_lds = speck_lds_bytes(cols);
-        specks_ran = (specks > 0 || (specks < 0 && B <= 32)) && spk_lds <= 150 * 1024;
+        specks_ran = specks > 0 && spk_lds <= 150 * 1024;
         if (specks_ran) {
             { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(k_speck_clean), spk_lds); if (rc_lds_) return rc_lds_; }
             hipLaunchKernelGGL(k_speck_clean, dim3((rows + SPK_ROWS - 1) / SPK_ROWS, B), dim3(SPK_THREADS), spk_lds, s, d_bits.as<uint32_t>(), bits_fu32, wpr,
@@ -1537,9 +1538,9 @@ int orbfe_aruco_debug_kernel_times(orbfe_aruco* h, float* out_us, int capacity)
 {
     if (!h) return fail(ORBFE_ERR_INVALID, "null handle");
     if (!out_us) { // control codes: 0/1 kernel timing off/on, 2/3 force the legacy contour kernel on/off, 4/5/6 tiled contour path by size / always / never,
-                   // 7 returns the number of batches that were done again on the next contour path, 8 / 9 / 10 the speck passes on / off / by batch size
+                   // 7 returns the number of batches that were done again on the next contour path, 8 / 9 the speck passes on / off
         if (capacity == 7) return h->n_escalations;
-        if (capacity == 8 || capacity == 9 || capacity == 10) { h->specks = capacity == 8 ? 1 : capacity == 9 ? 0 : -1; return 0; }   // the speck passes on / off / by batch size (default)
+        if (capacity == 8 || capacity == 9) { h->specks = capacity == 8 ? 1 : 0; return 0; }   // the speck passes on / off (default)
         if (capacity == 2 || capacity == 3) h->force_legacy = capacity == 2;
         else if (capacity >= 4 && capacity <= 6) {
             const int t = capacity == 4 ? -1 : capacity == 5 ? 1 : 0;

@@ -1,9 +1,11 @@
-"""Multi-GPU plumbing: frames / streams are independent, so they shard across ranks with no data-path
-collective; the single collective is the gather of fixed-capacity result records to rank 0 (RCCL on GPU tensors,
-gloo in the CPU tests).  torch.distributed is plumbing here, not part of the product library.
+"""Stream-to-rank assignment of the multi-GPU mode, and bench.py's gloo transport.
 
-bench.py and pipeline.FrontEndPipeline gather through RecordGather, tests/test_multigpu_cpu.py runs the same class (and
-gather_records, which is built on it) with gloo on the CPU."""
+Frames / streams are independent, so they shard across ranks with no data-path collective: `stream_seed` / `frames_of_rank` say which
+rank owns what (bench.py, the tests).  The PRODUCT gather -- every batch's record set to rank 0 over RCCL -- is C++ inside the library
+(csrc/pipeline.hip: orbfe_pipeline_comm_init / _gathered_set / _gathered_wait; two processes with a peer: tests/fake_rccl.cpp).
+`RecordGather` / `gather_records` are NOT that path: they are the torch.distributed.gather bench.py uses when the records have to go
+through gloo from the host -- its test hook for N ranks on a one-GPU box (ORBFE_BENCH_BACKEND=gloo) and the fallback when RCCL cannot
+be initialised (then the line is a diagnostic) -- and what tests/test_multigpu_cpu.py runs with gloo on the CPU."""
 import torch
 import torch.distributed as dist
 
