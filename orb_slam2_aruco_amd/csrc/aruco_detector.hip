@@ -146,7 +146,10 @@ struct orbfe_aruco {
     {
         if (big_mode || force_legacy) return false;
         const bool was_tiled = tiled_ran;
-        if (was_tiled && (flags_or & RL_FALLBACK_FLAGS) && relay_tbits) { tiled_off = true; n_escalations++; return true; }
+        // from the tiled path any exceeded capacity (segment lists, kept borders, pool) goes to the one-workgroup relay kernels first:
+        // they coarsen their grid and follow what is left whole, and get through frames of dense noise that neither the tiles nor the
+        // single-walker kernel's per-lane arenas hold (480 x 640 with +-40 grey levels of noise: 203 kept borders, no flag)
+        if (was_tiled && (flags_or & (2 | 4 | RL_FALLBACK_FLAGS)) && relay_tbits) { tiled_off = true; n_escalations++; return true; }
         if (flags_or & (2 | 4 | (was_tiled ? RL_FALLBACK_FLAGS : 0))) { big_mode = true; n_escalations++; return true; }
         return false;
     }

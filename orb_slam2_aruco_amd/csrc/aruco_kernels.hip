@@ -758,13 +758,18 @@ __global__ __launch_bounds__(CT_PROBE_THREADS) void k_contours_t(const uint32_t*
                     busy = false;
                     if (st == 1 && t.n > min_len) { // only reachable in the long phase (CT_PROBE < min_len)
                         const int k = atomicAdd(&s_nkept, 1);
-                        if (wp + t.n > arena) atomicOr(&s_flags, 4);
-                        else if (k < kept_cap) {
+                        if (k < kept_cap) {
+                            // Every slot that was counted gets a key: a border whose points did not fit the lane's arena is flagged
+                            // (the frame is reported as incomplete) and entered with length 0, which the tail skips.  (Until round 5
+                            // its slot stayed unwritten and the tail sorted, and then followed, whatever the LDS held there: a
+                            // memory fault on frames of dense noise in big-frame mode.)
+                            const bool fits = wp + t.n <= arena;
+                            if (!fits) atomicOr(&s_flags, 4);
                             // discovery order = raster order of the transition pixel; findContours returns the reverse
                             kkey[k] = ((unsigned long long)(0xffffffffu - (uint32_t)(qy * 65536 + qx)) << 32) |
-                                      ((unsigned long long)(t.n & 0x7ffff) << 13) | ((unsigned)k << 1) | (unsigned)t.is_hole;
-                            off_u[k] = tid * arena + wp;
-                            wp += t.n;
+                                      ((unsigned long long)((fits ? t.n : 0) & 0x7ffff) << 13) | ((unsigned)k << 1) | (unsigned)t.is_hole;
+                            off_u[k] = fits ? tid * arena + wp : 0;
+                            if (fits) wp += t.n;
                         }
                     }
                 } else if (!storing && t.n >= CT_PROBE) {

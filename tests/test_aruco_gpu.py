@@ -555,3 +555,26 @@ def test_speck_passes_change_no_result(orbfe):
             assert (cnt["nkept"], cnt["nrect"]) == (c2["nkept"], c2["nrect"]) and c2["flags"] == 0
             assert c2["ncand"] * 2 < cnt["ncand"], (mode, f, c2["ncand"], cnt["ncand"])     # (both counts are after the run tests)
     assert sum(len(w) for w in want) > 0
+
+
+def test_dense_noise_frame_in_a_small_batch(orbfe, oracle):
+    """A frame with +-40 grey levels of noise in a three-frame call: the tiled path's segment lists overflow, the call is redone on the
+    one-workgroup relay kernels (which get through it) and the markers of all three frames equal the oracle's.  Forced onto the
+    single-walker kernel in big-frame mode the same frame exceeds the per-lane arenas: a capacity error, loudly -- until round 5 a
+    kept-border slot that was counted but never written sent the tail to an address made of stale LDS (GPU memory fault)."""
+    imgs = synth.stream(480, 640, 3, 77, "ARUCO", n_markers=2)
+    rng = np.random.default_rng(480)
+    imgs[-1] = np.clip(imgs[-1].astype(np.int32) + rng.integers(-40, 40, imgs[-1].shape), 0, 255).astype(np.uint8)
+    det = orbfe.MarkerDetector("ARUCO")
+    got = det.detect_batch(imgs)
+    assert det.contour_retries() >= 1
+    for f in range(3):
+        want = oracle.ArucoOracle("ARUCO").detect(imgs[f])
+        assert np.array_equal(got[f]["id"], want["id"]) and np.allclose(got[f]["corners"], want["corners"], atol=1e-3), f
+    big = orbfe.MarkerDetector("ARUCO")
+    big.L.orbfe_aruco_set_big_frames(big.h, 1)
+    try:
+        out = big.detect_batch(imgs)
+        assert all(np.array_equal(out[f]["id"], got[f]["id"]) for f in range(3))
+    except orbfe.OrbfeError as e:
+        assert "capacity" in str(e)
