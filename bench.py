@@ -95,9 +95,12 @@ def make_stream(args, rank):
             return np.load(path)
         except Exception:
             pass
-    # (rendered by a pool of processes: 300 frames of 1280 x 720 take a minute on one core)
-    s = synth.stream(args.rows, args.cols, args.frames, seed, args.dictionary, n_markers=args.n_markers,
-                     workers=max(1, min(16, (os.cpu_count() or 1) // max(1, int(os.environ.get("WORLD_SIZE", "1"))))))
+    # (rendered by a pool of processes: 300 frames of 1280 x 720 take a minute on one core -- but in this process when a profiler is
+    # attached: the pool's forkserver children inherit rocprofv3's preloaded tool and never come back, which is how a profile run that
+    # did not find the stream cached hung for as long as it was given)
+    profiled = any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    workers = 1 if profiled else max(1, min(16, (os.cpu_count() or 1) // max(1, int(os.environ.get("WORLD_SIZE", "1")))))
+    s = synth.stream(args.rows, args.cols, args.frames, seed, args.dictionary, n_markers=args.n_markers, workers=workers)
     try:
         np.save(path + ".tmp.npy", s)
         os.replace(path + ".tmp.npy", path)
@@ -341,6 +344,7 @@ def from_host_mode(args):
     st = pipe.status()
     if any(st.values()):
         raise SystemExit("front-end capacity exceeded: %r" % (st,))
+    up_us, rb_us = pipe.host_copy_us()
     rec = pipe.host_records(cur)                    # what arrived in host memory
     matches = pipe.read_matches()
     r_last, r_prev = (args.steps - 1) % R, (args.steps - 2) % R
@@ -361,6 +365,8 @@ def from_host_mode(args):
                "device_input_ring": 3, "record_sets": pipe.R},
            "pcie": {"h2d_bytes_per_step": in_bytes, "d2h_bytes_per_step": out_bytes, "h2d_GBps": in_bytes * args.steps / dt / 1e9,
                     "d2h_GBps": out_bytes * args.steps / dt / 1e9,
+                    "upload_us": up_us, "upload_GBps_while_copying": in_bytes / (up_us * 1e-6) / 1e9 if up_us > 0 else None,
+                    "readback_us": rb_us, "readback_GBps_while_copying": out_bytes / (rb_us * 1e-6) / 1e9 if rb_us > 0 else None,
                     "note": "achieved = bytes moved / wall time of the timed steps; both directions run concurrently with the engines"},
            "host_enqueue_ms_per_step": 1000.0 * t_enq / args.steps, "verified_frames": verified}
     print(json.dumps(out))

@@ -695,6 +695,9 @@ int orbfe_pipeline_step(orbfe_pipeline* p, const uint8_t* d_imgs, size_t pitch, 
  * orbfe_pipeline_host_records: the host copy of record set `set` (waits for its copy; valid until the set is written again, R steps on). */
 int orbfe_pipeline_step_host(orbfe_pipeline* p, const uint8_t* h_imgs, size_t step, int32_t* record_set);
 int orbfe_pipeline_host_records(orbfe_pipeline* p, int set, const uint8_t** h_records);
+/* after steps from host memory: out[0] = microseconds the newest uploads took on the copy stream (mean over the input ring), out[1] =
+ * the newest read-back of a record set.  Synchronises. */
+int orbfe_pipeline_host_copy_us(orbfe_pipeline* p, float out[2]);
 void* orbfe_host_alloc(size_t bytes);                        /* page-locked host memory (hipHostMalloc) / NULL */
 void orbfe_host_free(void* p);
 /* Device memory for a caller without a HIP toolchain of its own (the Python wrapper, a host language over FFI): zeroed memory on

@@ -118,6 +118,7 @@ struct orbfe_pipeline {
     hipStream_t st_h2d = nullptr, st_h2d2 = nullptr, st_d2h = nullptr;   // two upload streams: two SDMA engines (one carried 34 GB/s)
     hipEvent_t in_ready2[NIN] = {};
     int h2d_split = 1;
+    hipEvent_t up_t0[NIN] = {}, up_t1[NIN] = {}, rb_t0 = nullptr, rb_t1 = nullptr;   // timing of the newest upload per slot / read-back
     uint8_t* d_in[NIN] = {};
     size_t in_pitch = 0;
     hipEvent_t in_ready[NIN] = {}, in_used_ex[NIN] = {}, in_used_det[NIN] = {};
@@ -154,6 +155,7 @@ struct orbfe_pipeline {
         for (auto e : rb_done) if (e) (void)hipEventDestroy(e);
         for (int k = 0; k < NIN; k++) for (hipEvent_t e : {in_ready[k], in_used_ex[k], in_used_det[k]}) if (e) (void)hipEventDestroy(e);
         for (auto e : in_ready2) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : {up_t0[0], up_t0[1], up_t0[2], up_t1[0], up_t1[1], up_t1[2], rb_t0, rb_t1}) if (e) (void)hipEventDestroy(e);
         if (st_h2d) (void)hipStreamDestroy(st_h2d);
         if (st_h2d2) (void)hipStreamDestroy(st_h2d2);
         if (st_d2h) (void)hipStreamDestroy(st_d2h);
@@ -252,7 +254,10 @@ struct orbfe_pipeline {
             if (use_orb) ORBFE_HIP(hipStreamWaitEvent(st_d2h, match_done[cur], 0));
             if (use_aruco) ORBFE_HIP(hipStreamWaitEvent(st_d2h, det_done[cur], 0));
             if (comm) ORBFE_HIP(hipStreamWaitEvent(st_d2h, gather_done[cur], 0));
+            if (!rb_t0) { ORBFE_HIP(hipEventCreate(&rb_t0)); ORBFE_HIP(hipEventCreate(&rb_t1)); }
+            ORBFE_HIP(hipEventRecord(rb_t0, st_d2h));
             ORBFE_HIP(hipMemcpyAsync(h_recs[(size_t)cur], recs[(size_t)cur], lay.nbytes, hipMemcpyDeviceToHost, st_d2h));
+            ORBFE_HIP(hipEventRecord(rb_t1, st_d2h));
             ORBFE_HIP(hipEventRecord(rb_done[(size_t)cur], st_d2h));
             rb_valid[(size_t)cur] = 1;
         }
@@ -404,8 +409,15 @@ static int host_mode_init(orbfe_pipeline* p)
     if (p->host_mode) return ORBFE_OK;
     // every resource is created once: a call that failed half way (host_mode still false) is continued, not repeated, by the next one
     p->in_pitch = ((size_t)p->cols + 63) / 64 * 64;
+    // The copy streams must not share a hardware queue with an engine's stream: the runtime multiplexes the streams of one priority
+    // onto GPU_MAX_HW_QUEUES (4) queues, the pipeline has four engine streams already, and an upload queued behind an extractor chain
+    // waited for it -- the copy engine idle 1.1 ms of every 2.8 ms step.  Streams of another priority come from a pool of their own:
+    // C2 from host memory 107 k frames/s with plain copy streams, 152 k with lowest-priority ones (137 k with highest; 156 k with plain
+    // streams and GPU_MAX_HW_QUEUES=8), round 5.
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     for (hipStream_t* st : {&p->st_h2d, &p->st_d2h, &p->st_h2d2})
-        if (!*st && hipStreamCreateWithFlags(st, hipStreamNonBlocking) != hipSuccess) return fail(ORBFE_ERR_HIP, "orbfe_pipeline_step_host: streams");
+        if (!*st && hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_lo) != hipSuccess) return fail(ORBFE_ERR_HIP, "orbfe_pipeline_step_host: streams");
     p->h2d_split = env_or("ORBFE_H2D_SPLIT", 1);   // (measured: 34.3 GB/s with one upload stream, 34.2 with two -- the link, not the copy engine)
     for (int k = 0; k < orbfe_pipeline::NIN; k++) {
         if (!p->d_in[k]) {
@@ -441,14 +453,23 @@ int orbfe_pipeline_step_host(orbfe_pipeline* p, const uint8_t* h_imgs, size_t st
         if (p->use_aruco) ORBFE_HIP(hipStreamWaitEvent(p->st_h2d, p->in_used_det[slot], 0));
     }
     const size_t nrows = (size_t)p->B * p->rows, half = p->h2d_split > 1 ? nrows / 2 : nrows;
-    ORBFE_HIP(hipMemcpy2DAsync(p->d_in[slot], p->in_pitch, h_imgs, step, (size_t)p->cols, half, hipMemcpyHostToDevice, p->st_h2d));
+    auto upload = [&](uint8_t* dst, const uint8_t* src, size_t rows_, hipStream_t st) -> hipError_t {
+        // rows that lie back to back on both sides are one linear copy.  (A copy kernel of the pipeline's own reading the mapped host
+        // pointer -- 57 GB/s alone like hipMemcpyAsync, tools/h2d_bw.hip -- was measured inside the pipeline too: 30.5 against 34.3 GB/s.)
+        if (step == (size_t)p->cols && p->in_pitch == (size_t)p->cols) return hipMemcpyAsync(dst, src, rows_ * step, hipMemcpyHostToDevice, st);
+        return hipMemcpy2DAsync(dst, p->in_pitch, src, step, (size_t)p->cols, rows_, hipMemcpyHostToDevice, st);
+    };
+    if (!p->up_t0[slot]) { ORBFE_HIP(hipEventCreate(&p->up_t0[slot])); ORBFE_HIP(hipEventCreate(&p->up_t1[slot])); }
+    ORBFE_HIP(hipEventRecord(p->up_t0[slot], p->st_h2d));
+    ORBFE_HIP(upload(p->d_in[slot], h_imgs, half, p->st_h2d));
+    ORBFE_HIP(hipEventRecord(p->up_t1[slot], p->st_h2d));
     ORBFE_HIP(hipEventRecord(p->in_ready[slot], p->st_h2d));
     if (half < nrows) { // the second half of the batch on the second upload stream
         if (p->in_uses[slot]) {
             if (p->use_orb) ORBFE_HIP(hipStreamWaitEvent(p->st_h2d2, p->in_used_ex[slot], 0));
             if (p->use_aruco) ORBFE_HIP(hipStreamWaitEvent(p->st_h2d2, p->in_used_det[slot], 0));
         }
-        ORBFE_HIP(hipMemcpy2DAsync(p->d_in[slot] + half * p->in_pitch, p->in_pitch, h_imgs + half * step, step, (size_t)p->cols, nrows - half, hipMemcpyHostToDevice, p->st_h2d2));
+        ORBFE_HIP(upload(p->d_in[slot] + half * p->in_pitch, h_imgs + half * step, nrows - half, p->st_h2d2));
         ORBFE_HIP(hipEventRecord(p->in_ready2[slot], p->st_h2d2));
     }
     p->in_uses[slot]++;
@@ -463,6 +484,24 @@ int orbfe_pipeline_host_records(orbfe_pipeline* p, int set, const uint8_t** h_re
     if (rc) return rc;
     ORBFE_HIP(hipEventSynchronize(p->rb_done[(size_t)set]));
     *h_records = p->h_recs[(size_t)set];
+    return ORBFE_OK;
+}
+
+int orbfe_pipeline_host_copy_us(orbfe_pipeline* p, float out[2])
+{
+    if (!p || !out || !p->host_mode) return fail(ORBFE_ERR_INVALID, "orbfe_pipeline_host_copy_us: no step from host memory yet");
+    int rc = orbfe_pipeline_synchronize(p);
+    if (rc) return rc;
+    out[0] = out[1] = 0.f;
+    int n = 0;
+    for (int k = 0; k < orbfe_pipeline::NIN; k++) {
+        float ms = 0.f;
+        if (p->up_t0[k] && hipEventElapsedTime(&ms, p->up_t0[k], p->up_t1[k]) == hipSuccess) { out[0] += ms * 1000.f; n++; }
+    }
+    if (n) out[0] /= (float)n;
+    float ms = 0.f;
+    if (p->rb_t0 && hipEventElapsedTime(&ms, p->rb_t0, p->rb_t1) == hipSuccess) out[1] = ms * 1000.f;
+    (void)hipGetLastError();
     return ORBFE_OK;
 }
 

@@ -143,6 +143,7 @@ def _setup(L):
     L.orbfe_pipeline_gathered_release.argtypes = [vp, C.c_int, vp]
     L.orbfe_pipeline_step_host.argtypes = [vp, vp, C.c_size_t, i32p]
     L.orbfe_pipeline_host_records.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.orbfe_pipeline_host_copy_us.argtypes = [vp, C.POINTER(C.c_float * 2)]
     L.orbfe_host_alloc.argtypes = [C.c_size_t]
     L.orbfe_host_alloc.restype = vp
     L.orbfe_host_free.argtypes = [vp]
@@ -310,6 +311,12 @@ class FrontEndPipeline:
         p = C.c_void_p()
         binding._check(self.L, self.L.orbfe_pipeline_gathered(self.h, rank, C.byref(p)), "orbfe_pipeline_gathered")
         return self.layout.unpack(device_bytes(p.value, self.layout.nbytes))
+
+    def host_copy_us(self):
+        """(upload, read-back) durations in microseconds of the newest steps from host memory, measured on the copy streams."""
+        out = (C.c_float * 2)()
+        binding._check(self.L, self.L.orbfe_pipeline_host_copy_us(self.h, C.byref(out)), "orbfe_pipeline_host_copy_us")
+        return float(out[0]), float(out[1])
 
     def gathered_set(self, record_set, rank, wait=True):
         """On the destination rank: the block rank `rank` sent with the batch that was written to `record_set` (every record set has

@@ -3,6 +3,7 @@ OUT=$(realpath -m "$1"); shift
 R=$(cd "$(dirname "$0")/.." && pwd)
 export TMPDIR=/tmp
 rm -rf /tmp/kstats_prof
+python $R/bench.py --cpu-frames 0 --no-verify --no-extras --steps 1 --warmup 0 "$@" > /dev/null 2>&1   # (the synthetic stream is rendered by a process pool on first use: not under the profiler)
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kstats_prof -- python $R/bench.py --cpu-frames 0 --no-verify "$@" > /dev/null 2>&1 )
 cp $(find /tmp/kstats_prof -name '*kernel_stats.csv' | head -1) $OUT
 python - "$OUT" <<'PY'
