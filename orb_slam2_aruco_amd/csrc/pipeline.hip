@@ -335,6 +335,8 @@ orbfe_pipeline* orbfe_pipeline_create(const orbfe_pipeline_config* cfg)
             p->ex.push_back(e);
             // every set's blur on the matching stream (1.4466 against 1.4873 ms with the handles' own fork streams, which share hardware
             // queues with the busy ones)
+            // (round 5: the blur of all sets on ONE extra stream with a hardware queue of its own -- lowest / highest stream priority --
+            // 1.59 / 1.69 ms against 1.35: what the lending buys is that blur and matching do NOT run next to each other)
             if (!env_or("ORBFE_NO_LEND", 0)) orbfe_extractor_set_aux_stream(e, p->st_match);
         }
         if (p->phase_pin && p->D > 1)

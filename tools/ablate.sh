@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/.."
 mkdir -p build
 ( cd orb_slam2_aruco_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
-    -shared -DORBFE_ABLATION -o ../../build/liborbfe_ablate.so orb_kernels.hip orb_extractor.hip match_kernels.hip aruco_kernels.hip \
+    -shared -DORBFE_ABLATION -o ../../build/liborbfe_ablate.so orb_kernels.hip orb_extractor.hip match_kernels.hip aruco_kernels.hip aruco_tiles.hip aruco_modes.hip pipeline.hip \
     aruco_detector.hip bow_vocabulary.hip keyframe_io.hip )
 export ORBFE_LIB=$PWD/build/liborbfe_ablate.so
 run() { python bench.py --cpu-frames 0 --no-verify 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('%-28s %.3f ms' % ('$1', d['ms_per_step']))"; }
