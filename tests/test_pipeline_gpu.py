@@ -83,8 +83,9 @@ def test_bench_gpus_2_plain_command_launches_two_ranks(tmp_path):
 
 @pytest.mark.gpu
 def test_bench_falls_back_to_gloo_when_rccl_refuses(tmp_path):
-    """Two ranks on ONE device with the default transport: ncclCommInitRank refuses (duplicate GPU), every rank reports it over the
-    gloo group, and all of them gather through gloo from the host -- the line stays valid, says which transport it used and why."""
+    """Two ranks on ONE device with the default transport: RCCL cannot be used (duplicate GPU) -- the ranks find that out over the gloo
+    group BEFORE the collective ncclCommInitRank, all of them gather through gloo from the host, the gathered records are still checked,
+    and the line is a DIAGNOSTIC (value null, diagnostic_frames_per_s): another transport and schedule than the one the metric names."""
     import json
     out = tmp_path / "bfb.json"
     env = dict(os.environ, ORBFE_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -94,8 +95,9 @@ def test_bench_falls_back_to_gloo_when_rccl_refuses(tmp_path):
                         "--cpu-frames", "0", "--out", str(out)], capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     d = json.loads(out.read_text())
-    assert d["n_gpus"] == 2 and d["gather_check"]["ranks"] == [0, 1] and d["value"] > 0
+    assert d["n_gpus"] == 2 and d["gather_check"]["ranks"] == [0, 1] and d["value"] is None and d["diagnostic_frames_per_s"] > 0
     assert "RCCL was not available" in d["gather_check"]["transport"] and "gloo" in d["config"]["parallelism"]
+    assert "share a device" in d["gather_check"]["transport"]
 
 
 def _free_port():

@@ -46,7 +46,7 @@ stage = {
     "orient_describe": named("k_orient_describe", "k_orient_describe2"), "knn2": named("k_knn2_mfma", "k_knn2_tiles", "k_knn2_merge"),
     "search_init": named("k_search_init", "k_sfi_grid", "k_sfi_rows", "k_sfi_accept"),
     "aruco_threshold": named("k_adaptive_threshold_t", "k_adaptive_threshold"), "aruco_pyramid": named("k_half_area", "k_half_area4", "k_resize_level"),
-    "aruco_contours": [k for k in s if k.startswith("k_contours") or k.startswith("k_tail_") or k.startswith("k_ct_")],
+    "aruco_contours": [k for k in s if k.startswith("k_contours") or k.startswith("k_tail_") or k.startswith("k_ct_") or k.startswith("k_speck")],
     "aruco_decode": named("k_prefilter", "k_decode", "k_decode_warp", "k_decode_otsu", "k_decode_vote"), "aruco_finalize": named("k_finalize", "k_marker_poses"),
 }
 traffic = {"_note": "HBM-side bytes per launch (%s batch) = (FETCH_SIZE / f_read + WRITE_SIZE / f_write) * 1024 from separate rocprofv3 --pmc "
