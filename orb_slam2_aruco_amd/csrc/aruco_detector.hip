@@ -1112,14 +1112,16 @@ int aruco_speculate(orbfe_aruco* h, const uint8_t* d_img, size_t dframe, int row
     hipStream_t s = h->own_stream;
     ORBFE_HIP(hipStreamWaitEvent(s, uploaded, 0));
     if ((rc = h->run_device(d_img, 1, dframe, rows, cols, dpitch, h->d_out.as<orbfe_marker>(), AR_MAX_RECTS, h->d_nout.as<int32_t>(), s))) return rc;
-    ORBFE_HIP(hipMemcpyAsync(hp + o.n, h->d_nout.p, 4, hipMemcpyDeviceToHost, s));
-    ORBFE_HIP(hipMemcpyAsync(hp + o.cnt, h->d_counts.p, 16, hipMemcpyDeviceToHost, s));
-    ORBFE_HIP(hipMemcpyAsync(hp + o.mk, h->d_out.p, (size_t)AR_MAX_RECTS * sizeof(orbfe_marker), hipMemcpyDeviceToHost, s));
+    OutPack op;   // (one launch for the call's results: orbfe_common.hpp)
+    op.add(hp + o.n, h->d_nout.p, 4);
+    op.add(hp + o.cnt, h->d_counts.p, 16);
+    op.add(hp + o.mk, h->d_out.p, (size_t)AR_MAX_RECTS * sizeof(orbfe_marker));
     if (pose) {
         hipLaunchKernelGGL(k_marker_poses, dim3((AR_MAX_RECTS + 63) / 64, 1), dim3(64), 0, s, h->d_out.as<orbfe_marker>(), h->d_nout.as<int32_t>(),
                            AR_MAX_RECTS, h->last_size, h->last_cam, h->d_poses.as<orbfe_marker_pose>());
-        ORBFE_HIP(hipMemcpyAsync(hp + o.ps, h->d_poses.p, (size_t)AR_MAX_RECTS * sizeof(orbfe_marker_pose), hipMemcpyDeviceToHost, s));
+        op.add(hp + o.ps, h->d_poses.p, (size_t)AR_MAX_RECTS * sizeof(orbfe_marker_pose));
     }
+    if ((rc = op.flush<1>(s))) return rc;
     h->spec.pending = true; h->spec.rows = rows; h->spec.cols = cols; h->spec.host_copy = host_copy; h->spec.host_pitch = host_pitch;
     h->spec.has_pose = pose; h->spec.cam = h->last_cam; h->spec.size = h->last_size;
     return ORBFE_OK;
@@ -1343,13 +1345,21 @@ static int detect_batch_impl(orbfe_aruco* h, const uint8_t* imgs, int nframes, s
         rc = h->run_device(h->d_in.as<uint8_t>(), nframes, dframe, rows, cols, dpitch, h->d_out.as<orbfe_marker>(),
                            AR_MAX_RECTS, h->d_nout.as<int32_t>(), s);
         if (rc) { h->big_mode = user_big_mode; h->tiled_off = false; return rc; }
-        ORBFE_HIP(hipMemcpyAsync(hp + o_n, h->d_nout.p, (size_t)nframes * 4, hipMemcpyDeviceToHost, s));
-        ORBFE_HIP(hipMemcpyAsync(hp + o_cnt, h->d_counts.p, (size_t)nframes * 16, hipMemcpyDeviceToHost, s));
-        ORBFE_HIP(hipMemcpyAsync(hp + o_mk, h->d_out.p, (size_t)AR_MAX_RECTS * nframes * sizeof(orbfe_marker), hipMemcpyDeviceToHost, s));
-        if (cam) {
+        if (cam)
             hipLaunchKernelGGL(k_marker_poses, dim3((AR_MAX_RECTS + 63) / 64, nframes), dim3(64), 0, s, h->d_out.as<orbfe_marker>(),
                                h->d_nout.as<int32_t>(), AR_MAX_RECTS, marker_size, *cam, h->d_poses.as<orbfe_marker_pose>());
-            ORBFE_HIP(hipMemcpyAsync(hp + o_ps, h->d_poses.p, (size_t)AR_MAX_RECTS * nframes * sizeof(orbfe_marker_pose), hipMemcpyDeviceToHost, s));
+        if (nframes <= 16) {   // a frame or a few: the results in one launch that writes the staging buffer (OutPack, orbfe_common.hpp)
+            OutPack op;
+            op.add(hp + o_n, h->d_nout.p, (size_t)nframes * 4);
+            op.add(hp + o_cnt, h->d_counts.p, (size_t)nframes * 16);
+            op.add(hp + o_mk, h->d_out.p, (size_t)AR_MAX_RECTS * nframes * sizeof(orbfe_marker));
+            if (cam) op.add(hp + o_ps, h->d_poses.p, (size_t)AR_MAX_RECTS * nframes * sizeof(orbfe_marker_pose));
+            if ((rc = op.flush<2>(s))) { h->big_mode = user_big_mode; h->tiled_off = false; return rc; }
+        } else {
+            ORBFE_HIP(hipMemcpyAsync(hp + o_n, h->d_nout.p, (size_t)nframes * 4, hipMemcpyDeviceToHost, s));
+            ORBFE_HIP(hipMemcpyAsync(hp + o_cnt, h->d_counts.p, (size_t)nframes * 16, hipMemcpyDeviceToHost, s));
+            ORBFE_HIP(hipMemcpyAsync(hp + o_mk, h->d_out.p, (size_t)AR_MAX_RECTS * nframes * sizeof(orbfe_marker), hipMemcpyDeviceToHost, s));
+            if (cam) ORBFE_HIP(hipMemcpyAsync(hp + o_ps, h->d_poses.p, (size_t)AR_MAX_RECTS * nframes * sizeof(orbfe_marker_pose), hipMemcpyDeviceToHost, s));
         }
         ORBFE_HIP(hipStreamSynchronize(s));
         int flags_or = 0;

@@ -1569,21 +1569,31 @@ int orbfe_search_for_initialization(const orbfe_keypoint* kps1, const uint8_t* d
     const int32_t nn[2] = {n1, n2};
     memcpy(hp + i_nk, nn, 8);
     memcpy(hp + i_prev, prev_matched, (size_t)n1 * 8);
-    ORBFE_HIP(hipMemcpyAsync(w.kps.p, hp + i_kps, 2 * kb, hipMemcpyHostToDevice, s));
-    ORBFE_HIP(hipMemcpyAsync(w.desc.p, hp + i_desc, 2 * db, hipMemcpyHostToDevice, s));
-    ORBFE_HIP(hipMemcpyAsync(w.nk.p, hp + i_nk, 8, hipMemcpyHostToDevice, s));
+    // the call's four inputs in one launch that reads the page-locked staging buffer, its four results in another (OutPack,
+    // orbfe_common.hpp: every small copy would be a blit kernel of its own)
+    {
+        OutPack ip;
+        ip.add(w.kps.p, hp + i_kps, 2 * kb);
+        ip.add(w.desc.p, hp + i_desc, 2 * db);
+        ip.add(w.nk.p, hp + i_nk, 8);
+        if ((rc = ip.flush<3>(s))) return rc;
+    }
     for (int attempt = 0;; attempt++) {
         // the device copy of prev_matched is only overwritten by a run that did not overflow
-        ORBFE_HIP(hipMemcpyAsync(w.prev.p, hp + i_prev, (size_t)n1 * 8, hipMemcpyHostToDevice, s));
+        { OutPack ip; ip.add(w.prev.p, hp + i_prev, (size_t)n1 * 8); if ((rc = ip.flush<3>(s))) return rc; }
         rc = sfi_launch(w.kps.as<orbfe_keypoint>(), w.desc.as<uint8_t>(), w.nk.as<int32_t>(), cap, 1, frame_bounds(cols, rows, bounds),
                         window_size, nnratio, check_orientation, w.prev.as<float>(), w.prev.as<float>(),
                         w.m12.as<int32_t>(), w.nm.as<int32_t>(), s, w);
         if (rc) return rc;
         // results and flags: copies queued behind the kernels, one wait
-        ORBFE_HIP(hipMemcpyAsync(hp + o_m12, w.m12.p, (size_t)n1 * 4, hipMemcpyDeviceToHost, s));
-        ORBFE_HIP(hipMemcpyAsync(hp + o_prev, w.prev.p, (size_t)n1 * 8, hipMemcpyDeviceToHost, s));
-        ORBFE_HIP(hipMemcpyAsync(hp + o_nm, w.nm.p, 4, hipMemcpyDeviceToHost, s));
-        ORBFE_HIP(hipMemcpyAsync(hp + o_flags, w.sfi_overflow.p, 8, hipMemcpyDeviceToHost, s));
+        {
+            OutPack op;
+            op.add(hp + o_m12, w.m12.p, (size_t)n1 * 4);
+            op.add(hp + o_prev, w.prev.p, (size_t)n1 * 8);
+            op.add(hp + o_nm, w.nm.p, 4);
+            op.add(hp + o_flags, w.sfi_overflow.p, 8);
+            if ((rc = op.flush<3>(s))) return rc;
+        }
         ORBFE_HIP(hipStreamSynchronize(s));
         const int32_t* fl = reinterpret_cast<const int32_t*>(hp + o_flags);
         if (!fl[0] && !fl[1]) break;

@@ -714,7 +714,16 @@ int orbfe_extract_batch(orbfe_extractor* h, const uint8_t* imgs, int nframes, si
         int rc2 = h->run_device(h->d_in.as<uint8_t>(), nframes, dframe, rows, cols, dpitch, h->d_kps.as<orbfe_keypoint>(),
                                 h->d_desc.as<uint8_t>(), cap, h->d_nout.as<int32_t>(), s, /*flag_word*/ 1);
         if (rc2) return rc2;
-        // the results: four copies queued behind the kernels, one wait (blocking copies cost a round trip each: 4 x ~40 us per frame)
+        // the results: queued behind the kernels, one wait (blocking copies cost a round trip each: 4 x ~40 us per frame).  A single
+        // frame's four arrays go out in one launch that writes the page-locked staging buffer (OutPack); a batch by the copy engine.
+        if ((size_t)cap * nframes * 60 <= ((size_t)1 << 20)) {
+            OutPack op;
+            op.add(hp + o_n, h->d_nout.p, (size_t)nframes * 4);
+            op.add(hp + o_flag, h->d_overflow.as<int32_t>() + 1, 4);
+            op.add(hp + o_kps, h->d_kps.p, (size_t)cap * nframes * sizeof(orbfe_keypoint));
+            op.add(hp + o_desc, h->d_desc.p, (size_t)cap * nframes * 32);
+            return op.flush<0>(s);
+        }
         ORBFE_HIP(hipMemcpyAsync(hp + o_n, h->d_nout.p, (size_t)nframes * 4, hipMemcpyDeviceToHost, s));
         ORBFE_HIP(hipMemcpyAsync(hp + o_flag, h->d_overflow.as<int32_t>() + 1, 4, hipMemcpyDeviceToHost, s));
         ORBFE_HIP(hipMemcpyAsync(hp + o_kps, h->d_kps.p, (size_t)cap * nframes * sizeof(orbfe_keypoint), hipMemcpyDeviceToHost, s));

@@ -116,6 +116,40 @@ struct PinnedBuf {
     template <class T> T* as() const { return (T*)p; }
 };
 
+// The small results of a host-pointer call (counts, flags, a few KB of markers, 60 KB of keypoints) go to the caller's page-locked
+// staging buffer by ONE launch that writes the mapped host memory, instead of one hipMemcpyAsync per array: the runtime turns every
+// small device-to-host copy into a blit kernel of its own (rocprofv3: twelve __amd_rocclr_copyBuffer launches per frame of the drop-in
+// path, ~5 us each plus the gaps between them).  Items are 4-byte aligned, sizes multiples of 4.
+struct PackItem { const uint32_t* src; uint32_t* dst; uint32_t words; };
+struct PackList { PackItem it[8]; int n; };
+template <int TAG>
+__global__ __launch_bounds__(256) void k_pack_out(PackList L)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x, nt = gridDim.x * 256u;
+    for (int k = 0; k < L.n; k++)
+        for (uint32_t i = t; i < L.it[k].words; i += nt) L.it[k].dst[i] = L.it[k].src[i];
+}
+struct OutPack {
+    PackList L{};
+    size_t total = 0;
+    void add(void* host_dst, const void* dev_src, size_t bytes)
+    {
+        if (!bytes) return;
+        L.it[L.n++] = PackItem{(const uint32_t*)dev_src, (uint32_t*)host_dst, (uint32_t)(bytes / 4)};
+        total += bytes;
+    }
+    // host_dst pointers are page-locked memory of this process (hipHostMalloc: the same address on the device)
+    template <int TAG> int flush(hipStream_t s)
+    {
+        if (!L.n) return ORBFE_OK;
+        const int wgs = (int)std::min<size_t>(32, (total / 4 + 1023) / 1024 + 1);
+        hipLaunchKernelGGL(k_pack_out<TAG>, dim3(wgs), dim3(256), 0, s, L);
+        ORBFE_HIP(hipGetLastError());
+        L.n = 0; total = 0;
+        return ORBFE_OK;
+    }
+};
+
 // ---- a detector paired with an extractor (orbfe_extractor_pair_detector): the drop-in path calls ORBextractor::operator() and
 // MarkerDetector::detect on the SAME image one after the other (Frame.cc:91 -> :142); the extractor's call uploads the image once
 // and starts the detector on it on the detector's own stream, next to its own launches; the detector's call finds its work done if

@@ -1,7 +1,7 @@
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_lat -- python $GRAFT_REPO_ROOT/bench.py --latency --cpu-frames 0 > $GRAFT_REPO_ROOT/gpurun_out/r03_latency_prof.json 2>/dev/null
+rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_lat -- python $GRAFT_REPO_ROOT/bench.py --latency --cpu-frames 0 > $GRAFT_REPO_ROOT/gpurun_out/latency_prof.json 2>/dev/null
 cd $GRAFT_REPO_ROOT
-cat gpurun_out/r03_latency_prof.json | cut -c1-600
+cat gpurun_out/latency_prof.json | cut -c1-600
 for f in $(find gpurun_out/prof_lat -name '*stats.csv'); do echo $f; head -40 $f | cut -c1-140; done
 python - <<'PY'
 import csv, glob
