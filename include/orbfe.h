@@ -160,7 +160,7 @@ int orbfe_extractor_set_early_stream(orbfe_extractor* h, void* stream);
  * other == NULL: free running.
  * Two engine sets that follow each other run a fixed half-period apart instead of in whatever phase contention leaves them
  * (bench.py: measured).  stage + 10 * g adds a second gate: the handle's FAST waits for stage g of `other` (with stage
- * % 10 == 0 the resize chain starts freely; measured slower in every combination).  `other` must outlive the
+ * % 10 == 0 the resize chain starts freely; measured slower in every combination, docs/history/DESIGN_rounds_1-4.md §6b).  `other` must outlive the
  * relation.  Results do not depend on it. */
 int orbfe_extractor_follow(orbfe_extractor* h, orbfe_extractor* other, int stage);
 /* The same relation for any other work of the pipeline: whatever is enqueued on `stream` after this call starts behind stage 1 .. 4
