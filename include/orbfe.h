@@ -148,12 +148,11 @@ int orbfe_extractor_debug_level_keypoints(orbfe_extractor* h, int frame, int lev
  * loaded stream (bench.py: the matching stream) can lend it instead -- ROCm maps streams onto a few hardware queues, and
  * two busy streams on one queue serialise.  NULL restores the internal stream.  Ordering is by events either way. */
 int orbfe_extractor_set_aux_stream(orbfe_extractor* h, void* stream);
-/* A second fork (experimental, enabled with ORBFE_FAST0=1; it did not shorten the batched step): level 0 of the pyramid is the
+/* A second fork (experimental; it did not shorten the batched step; naming a stream switches it on): level 0 of the pyramid is the
  * caller's image, so its FAST cells (a third of all pixels) can be searched from the start of the batch, next to the resize chain
- * instead of behind it.  By default on the handle's second stream; an application whose
+ * instead of behind it, on the stream named here.  An application whose
  * streams already fill the hardware queues (ROCm has four; a fifth stream shares one and queues behind whatever runs there) names
- * a stream with little work at the start of a batch instead -- bench.py: the one that carries the detector's /2 pyramid.  NULL
- * restores the default.  Ordering is by events either way. */
+ * a stream with little work at the start of a batch.  NULL switches the early launch off again (the default).  Ordering is by events either way. */
 int orbfe_extractor_set_early_stream(orbfe_extractor* h, void* stream);
 /* Phase lock between the extractor handles of a pipeline (device-pointer batches): every batch of `h` starts behind a stage of the
  * latest batch enqueued on `other` -- stage 1 = its FAST, 2 = its quadtree, 3 = its descriptors, 4 = its resize chain (FAST starts); 0 or

@@ -49,7 +49,6 @@ struct orbfe_aruco {
     DevBuf d_rstate, d_lut; // k_contours_relay -> k_contours_small: per-frame grid shift and pool fill; the walks' step table
     DevBuf d_segs, d_tailkeys, d_tailoff, d_small, d_hint; // d_hint: the relay kernel's grid spacing of the previous batch
     int relay_kshift = 5;      // initial grid spacing (log2) of k_contours_relay
-    int relay_chunk = getenv("ORBFE_ARUCO_RELAY_CHUNK") ? atoi(getenv("ORBFE_ARUCO_RELAY_CHUNK")) : 1 << 30;   // frames per launch of the large-frame relay kernels
     PinnedBuf pinned; // staging of the host-pointer entry points
     DevBuf d_poses;   // orbfe_aruco_detect_poses
     // speculation for a paired extractor (orbfe_extractor_pair_detector; orbfe_common.hpp)
@@ -313,9 +312,7 @@ struct orbfe_aruco {
         // frames whose bit image does not fit LDS: the relay formulation with the bit image in HBM (k_contours_relay8g)
         // (and room for as many kept borders as the single-walker kernel's big-frame mode: busy 1920 x 1080 frames have > 1024)
         // (also frames whose bit image fits LDS for the single-walker kernel but not next to a marker table)
-        // experiment (ORBFE_ARUCO_FORCE_GLOBAL=1): the HBM-image formulation also for frames that would fit LDS -- its workgroups are
-        // 45 KB instead of 151 KB (1280 x 720), so the extractor's kernels can share their CUs
-        if (getenv("ORBFE_ARUCO_FORCE_GLOBAL") && atoi(getenv("ORBFE_ARUCO_FORCE_GLOBAL")) && large) relay_tbits = 0;
+        // (round 2: the HBM-image formulation also for frames that fit LDS -- 45 KB workgroups instead of 151 KB -- was slower, 5.50 against 4.62 ms at C3)
         relay_global = !relay_tbits && relay_lds_bytes(0, AR_MAX_KEPT_BIG, 13) + rl_static <= 160 * 1024;
         relay_kcap = RL_KCAP;
         if (relay_global) { relay_tbits = 13; relay_kshift = 5; relay_kcap = AR_MAX_KEPT_BIG; }
@@ -554,10 +551,10 @@ struct orbfe_aruco {
                                    ct_items_per_frame, d_ctnitems.as<int32_t>(), d_ctcodes.as<uint32_t>(), ct_segcap, d_pool.as<uint32_t>(), pool_fu32);
             } else {
             const size_t rlds = relay_lds_bytes(relay_global ? 0 : lds_bits_words, relay_kcap, relay_tbits);
-            // A workgroup of the large-frame kernels takes a CU's whole LDS, so a launch of >= 256 frames shuts every kernel that
-            // needs LDS (FAST, the descriptors) out of the chip for as long as it runs: such batches go in chunks of relay_chunk frames
+            // (round 2 launched the large-frame kernels, whose workgroups take a CU's whole LDS, in chunks of N frames: no gain at 128 / 192,
+            // worse below -- profiles/r02_relay_chunks.txt; one launch since round 5)
             const bool small_separate = small_separate_mode < 0 ? B <= 32 : small_separate_mode != 0;
-            const int chunk = (relay_global || relay_tbits > 12) ? std::max(1, std::min(B, relay_chunk)) : B;
+            const int chunk = B;
             for (int f0 = 0; f0 < B; f0 += chunk) {
             const int nb_ = std::min(chunk, B - f0);
             if (relay_global) {

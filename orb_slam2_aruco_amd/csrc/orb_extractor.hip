@@ -107,7 +107,7 @@ struct orbfe_extractor {
     // FAST of level 0 from the start of the batch, next to the resize chain: 0 off (default), 1 on the handle's second stream (or the one
     // named by orbfe_extractor_set_early_stream), 2 on the lent one.  Measured in round 3 (profiles/r03_fast0_early.txt): the launch
     // does overlap the resize chain, but the C2 step does not move (1.5365 ms either way) -- the chip was issue-bound there already
-    int fast0_mode = env_int("ORBFE_FAST0", 0);
+    int fast0_mode = 0; // (set by orbfe_extractor_set_early_stream)
     int rows = 0, cols = 0; // geometry currently built
     int batch_cap = 0;
     std::vector<LevelGeom> geom;
@@ -126,15 +126,9 @@ struct orbfe_extractor {
     // k_orient_describe2 (two keypoints per wave: 227 instead of 342 VALU instructions per keypoint, 238 instead of 256 us alone at C2)
     // is NOT the default: with the detector running the C2 step was 1.62 ms with it and 1.61 without (four interleaved runs each)
     bool orient_pair = env_int("ORBFE_ORIENT_PAIR", 1) != 0; // two keypoints per wave: the default since round 3 (C2 step 1.564 -> 1.543 ms, four interleaved runs each)
-    int occ_fast = env_int("ORBFE_OCC_FAST", 0), occ_blur = env_int("ORBFE_OCC_BLUR", 0), occ_orient = env_int("ORBFE_OCC_ORIENT", 0);
     static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
-    static size_t occ_lds(int per_cu, size_t static_bytes, size_t needed)
-    {
-        if (per_cu <= 0) return needed;
-        const size_t want = (size_t)160 * 1024 / per_cu;
-        const size_t dyn = want > static_bytes + 256 ? want - static_bytes - 256 : 0;
-        return dyn > needed ? dyn : needed;
-    }
+    // (rounds 2 - 3 capped the VALU-bound kernels' workgroups per CU with an LDS request they did not use -- ORBFE_OCC_FAST / _BLUR /
+    // _ORIENT -- so that the detector's 65 - 77 KB workgroups always found room: noise at best, slower when tighter; the switches went in round 5)
     bool force_general_quadtree = false; // test hook: run the general kernel for every level
     int force_pyramid_depth = 0;         // test hook: shallow count pyramid so that levels fall back
     DevBuf d_in, d_kps, d_desc, d_nout; // staging for the host-pointer entry points
@@ -430,7 +424,7 @@ struct orbfe_extractor {
             auto a16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
             const size_t lds = 4 * (a16((size_t)roi_pitch * roi_rows) + a16((size_t)map_pitch * map_rows) +
                                     a16((size_t)list_cap * 2));
-            const size_t lds_fast = occ_lds(occ_fast, 0, lds);
+            const size_t lds_fast = lds;
             { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(&k_fast_cells), (size_t)(lds_fast)); if (rc_lds_) return rc_lds_; }
             const int nx = (cell_end - cell_base + 3) / 4;
             for (int r_ = 0; r_ < ORBFE_REPS_ORB(1); r_++) hipLaunchKernelGGL(k_fast_cells, dim3(xcd_grid(nx * B)), dim3(256), lds_fast, st, src0, pyr, dg,
@@ -488,7 +482,7 @@ struct orbfe_extractor {
             ORBFE_HIP(hipEventRecord(ev_fork, s));
             ORBFE_HIP(hipStreamWaitEvent(aux_stream, ev_fork, 0));
             timer.mark(aux_stream, "blur7 starts", true);
-            const size_t lds_blur = occ_lds(occ_blur, 64 * 74 * 2 /* k_blur7: 64 columns x BL_CP u16 */, 0);
+            const size_t lds_blur = 0;
             if (lds_blur) {
                 int rc_lds_ = gaussian_ed ? ensure_dyn_lds(reinterpret_cast<const void*>(&k_blur7<true>), lds_blur)
                                           : ensure_dyn_lds(reinterpret_cast<const void*>(&k_blur7<false>), lds_blur);
@@ -562,7 +556,7 @@ struct orbfe_extractor {
         const int kcap_ = std::min(capacity, max_keypoints());
         const int okx = orient_pair ? (kcap_ + 7) / 8 : (kcap_ + 3) / 4;   // workgroups per frame: 4 waves of one or two keypoints
         auto ofn = orient_pair ? k_orient_describe2 : k_orient_describe;
-        const size_t lds_orient = occ_lds(occ_orient, orient_pair ? 8 * (31 * 36 + 12) : 4 * (31 * 36 + 12 + 37 * 40 + 8), 0);
+        const size_t lds_orient = 0;
         if (lds_orient) { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(ofn), lds_orient); if (rc_lds_) return rc_lds_; }
         for (int r_ = 0; r_ < ORBFE_REPS_ORB(4); r_++) hipLaunchKernelGGL(ofn, dim3(xcd_grid(okx * B)), dim3(256), lds_orient, s, src0, pyr, blur, dg,
                            d_flatkv.as<uint32_t>(), d_flatlvl.as<uint8_t>(), d_n, nlevels, d_pattern.as<uint32_t>(),
@@ -896,6 +890,7 @@ int orbfe_extractor_set_early_stream(orbfe_extractor* h, void* stream)
 {
     if (!h) return fail(ORBFE_ERR_INVALID, "null handle");
     h->user_early = (hipStream_t)stream;
+    h->fast0_mode = stream ? 1 : 0;   // naming a stream switches the early launch on, NULL off
     return ORBFE_OK;
 }
 

@@ -115,9 +115,7 @@ struct orbfe_pipeline {
     // every record set copied back to page-locked host memory on a second copy stream behind the batch's post-work
     static constexpr int NIN = 3;
     bool host_mode = false;
-    hipStream_t st_h2d = nullptr, st_h2d2 = nullptr, st_d2h = nullptr;   // two upload streams: two SDMA engines (one carried 34 GB/s)
-    hipEvent_t in_ready2[NIN] = {};
-    int h2d_split = 1;
+    hipStream_t st_h2d = nullptr, st_d2h = nullptr;
     hipEvent_t up_t0[NIN] = {}, up_t1[NIN] = {}, rb_t0 = nullptr, rb_t1 = nullptr;   // timing of the newest upload per slot / read-back
     uint8_t* d_in[NIN] = {};
     size_t in_pitch = 0;
@@ -154,10 +152,8 @@ struct orbfe_pipeline {
         for (auto h : h_recs) if (h) (void)hipHostFree(h);
         for (auto e : rb_done) if (e) (void)hipEventDestroy(e);
         for (int k = 0; k < NIN; k++) for (hipEvent_t e : {in_ready[k], in_used_ex[k], in_used_det[k]}) if (e) (void)hipEventDestroy(e);
-        for (auto e : in_ready2) if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : {up_t0[0], up_t0[1], up_t0[2], up_t1[0], up_t1[1], up_t1[2], rb_t0, rb_t1}) if (e) (void)hipEventDestroy(e);
         if (st_h2d) (void)hipStreamDestroy(st_h2d);
-        if (st_h2d2) (void)hipStreamDestroy(st_h2d2);
         if (st_d2h) (void)hipStreamDestroy(st_d2h);
         for (auto s : st_ex) if (s) (void)hipStreamDestroy(s);
         if (st_det) (void)hipStreamDestroy(st_det);
@@ -269,9 +265,9 @@ const char* orbfe_pipeline_env_defaults(void)
 {
     // one list for the pipeline and the engines: bench.py marks a line as diagnostic when one of these is set to something else
     return "ORBFE_ENGINE_SETS=2;ORBFE_ENGINE_SETS_ARUCO=1;ORBFE_RECORD_SETS=4;ORBFE_PHASE_PIN=size;ORBFE_DET_PIN=4;ORBFE_DEFER_POST=size;ORBFE_DET_NOFORK=size;"
-           "ORBFE_ORIENT_PAIR=1;ORBFE_FAST0=0;ORBFE_ARUCO_FORCE_GLOBAL=0;ORBFE_ARUCO_RELAY_CHUNK=0;ORBFE_ARUCO_RELAY_WIDE=1;"
+           "ORBFE_ORIENT_PAIR=1;ORBFE_ARUCO_RELAY_WIDE=1;"
            "ORBFE_ARUCO_SPECKS=0;ORBFE_ARUCO_SMALL_SEPARATE=size;ORBFE_ARUCO_TILED=size;ORBFE_ARUCO_TILE_W=0;ORBFE_ARUCO_TPW=0;ORBFE_ARUCO_BANDED=size;ORBFE_ARUCO_BAND_ROWS=0;ORBFE_ARUCO_LCAP=0;ORBFE_GRAPH=0;"
-           "ORBFE_OCC_FAST=0;ORBFE_OCC_BLUR=0;ORBFE_OCC_ORIENT=0;ORBFE_BLUR_PLACE=1;ORBFE_NO_LEND=0;ORBFE_H2D_SPLIT=1;ORBFE_GRAPH_VERBOSE=0;ORBFE_RCCL_LIB=";
+           "ORBFE_NO_LEND=0;ORBFE_GRAPH_VERBOSE=0;ORBFE_RCCL_LIB=";
 }
 
 int orbfe_pipeline_config_default(orbfe_pipeline_config* c, int frames, int rows, int cols)
@@ -341,8 +337,6 @@ orbfe_pipeline* orbfe_pipeline_create(const orbfe_pipeline_config* cfg)
         }
         if (p->phase_pin && p->D > 1)
             for (int d = 0; d < p->D; d++) orbfe_extractor_follow(p->ex[d], p->ex[(d + p->D - 1) % p->D], p->phase_pin);
-        if (getenv("ORBFE_BLUR_PLACE"))
-            for (auto e : p->ex) orbfe_extractor_debug_kernel_times(e, nullptr, 20 + atoi(getenv("ORBFE_BLUR_PLACE")));
         p->cap = orbfe_extractor_max_keypoints(p->ex[0]);
     } else
         p->cap = 1;
@@ -418,15 +412,14 @@ static int host_mode_init(orbfe_pipeline* p)
     // streams and GPU_MAX_HW_QUEUES=8), round 5.
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    for (hipStream_t* st : {&p->st_h2d, &p->st_d2h, &p->st_h2d2})
+    for (hipStream_t* st : {&p->st_h2d, &p->st_d2h})
         if (!*st && hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_lo) != hipSuccess) return fail(ORBFE_ERR_HIP, "orbfe_pipeline_step_host: streams");
-    p->h2d_split = env_or("ORBFE_H2D_SPLIT", 1);   // (measured: 34.3 GB/s with one upload stream, 34.2 with two -- the link, not the copy engine)
     for (int k = 0; k < orbfe_pipeline::NIN; k++) {
         if (!p->d_in[k]) {
             ORBFE_HIP(hipMalloc(&p->d_in[k], (size_t)p->B * p->rows * p->in_pitch));
             ORBFE_HIP(hipMemset(p->d_in[k], 0, (size_t)p->B * p->rows * p->in_pitch));
         }
-        for (hipEvent_t* e : {&p->in_ready[k], &p->in_ready2[k], &p->in_used_ex[k], &p->in_used_det[k]})
+        for (hipEvent_t* e : {&p->in_ready[k], &p->in_used_ex[k], &p->in_used_det[k]})
             if (!*e) ORBFE_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
     if (p->h_recs.empty()) {
@@ -454,26 +447,16 @@ int orbfe_pipeline_step_host(orbfe_pipeline* p, const uint8_t* h_imgs, size_t st
         if (p->use_orb) ORBFE_HIP(hipStreamWaitEvent(p->st_h2d, p->in_used_ex[slot], 0));
         if (p->use_aruco) ORBFE_HIP(hipStreamWaitEvent(p->st_h2d, p->in_used_det[slot], 0));
     }
-    const size_t nrows = (size_t)p->B * p->rows, half = p->h2d_split > 1 ? nrows / 2 : nrows;
-    auto upload = [&](uint8_t* dst, const uint8_t* src, size_t rows_, hipStream_t st) -> hipError_t {
-        // rows that lie back to back on both sides are one linear copy.  (A copy kernel of the pipeline's own reading the mapped host
-        // pointer -- 57 GB/s alone like hipMemcpyAsync, tools/h2d_bw.hip -- was measured inside the pipeline too: 30.5 against 34.3 GB/s.)
-        if (step == (size_t)p->cols && p->in_pitch == (size_t)p->cols) return hipMemcpyAsync(dst, src, rows_ * step, hipMemcpyHostToDevice, st);
-        return hipMemcpy2DAsync(dst, p->in_pitch, src, step, (size_t)p->cols, rows_, hipMemcpyHostToDevice, st);
-    };
+    const size_t nrows = (size_t)p->B * p->rows;
     if (!p->up_t0[slot]) { ORBFE_HIP(hipEventCreate(&p->up_t0[slot])); ORBFE_HIP(hipEventCreate(&p->up_t1[slot])); }
     ORBFE_HIP(hipEventRecord(p->up_t0[slot], p->st_h2d));
-    ORBFE_HIP(upload(p->d_in[slot], h_imgs, half, p->st_h2d));
+    // rows that lie back to back on both sides are one linear copy.  (Measured and gone: the batch in two halves on two copy streams,
+    // 34.2 against 34.3 GB/s while the copy stream still shared a hardware queue; a copy kernel of the pipeline's own reading the
+    // mapped host pointer -- 57 GB/s alone like hipMemcpyAsync, tools/h2d_bw.hip -- 30.5 against 34.3 GB/s.)
+    if (step == (size_t)p->cols && p->in_pitch == (size_t)p->cols) ORBFE_HIP(hipMemcpyAsync(p->d_in[slot], h_imgs, nrows * step, hipMemcpyHostToDevice, p->st_h2d));
+    else ORBFE_HIP(hipMemcpy2DAsync(p->d_in[slot], p->in_pitch, h_imgs, step, (size_t)p->cols, nrows, hipMemcpyHostToDevice, p->st_h2d));
     ORBFE_HIP(hipEventRecord(p->up_t1[slot], p->st_h2d));
     ORBFE_HIP(hipEventRecord(p->in_ready[slot], p->st_h2d));
-    if (half < nrows) { // the second half of the batch on the second upload stream
-        if (p->in_uses[slot]) {
-            if (p->use_orb) ORBFE_HIP(hipStreamWaitEvent(p->st_h2d2, p->in_used_ex[slot], 0));
-            if (p->use_aruco) ORBFE_HIP(hipStreamWaitEvent(p->st_h2d2, p->in_used_det[slot], 0));
-        }
-        ORBFE_HIP(upload(p->d_in[slot] + half * p->in_pitch, h_imgs + half * step, nrows - half, p->st_h2d2));
-        ORBFE_HIP(hipEventRecord(p->in_ready2[slot], p->st_h2d2));
-    }
     p->in_uses[slot]++;
     return step_impl(p, p->d_in[slot], p->in_pitch, record_set, slot);
 }
@@ -570,7 +553,7 @@ static int step_body(orbfe_pipeline* p, const uint8_t* d_imgs, size_t pitch, int
         if (p->dets.size() > 1 && i >= p->R) ORBFE_HIP(hipStreamWaitEvent(st_det_i, p->det_done[cur], 0));
         if (p->comm && i >= p->R) ORBFE_HIP(hipStreamWaitEvent(st_det_i, p->gather_done[cur], 0)); // batch i - R has left this record set
         if (p->host_mode && p->rb_valid[(size_t)cur]) ORBFE_HIP(hipStreamWaitEvent(st_det_i, p->rb_done[(size_t)cur], 0)); // ... and has been copied to the host
-        if (in_slot >= 0) { ORBFE_HIP(hipStreamWaitEvent(st_det_i, p->in_ready[in_slot], 0)); if (p->h2d_split > 1) ORBFE_HIP(hipStreamWaitEvent(st_det_i, p->in_ready2[in_slot], 0)); }
+        if (in_slot >= 0) { ORBFE_HIP(hipStreamWaitEvent(st_det_i, p->in_ready[in_slot], 0)); }
         if (p->det_pin && p->use_orb) {
             const long j = p->det_pin >= 10 ? i : i - 1; // + 10: a stage of THIS batch's extractor, which is then enqueued first
             if (j >= 0 && (rc = orbfe_extractor_stage_wait(p->ex[(size_t)(j % p->D)], p->det_pin % 10, st_det_i))) return rc;
@@ -594,7 +577,7 @@ static int step_body(orbfe_pipeline* p, const uint8_t* d_imgs, size_t pitch, int
             if (p->comm) ORBFE_HIP(hipStreamWaitEvent(st, p->gather_done[cur], 0));
         }
         if (p->host_mode && p->rb_valid[(size_t)cur]) ORBFE_HIP(hipStreamWaitEvent(st, p->rb_done[(size_t)cur], 0));
-        if (in_slot >= 0) { ORBFE_HIP(hipStreamWaitEvent(st, p->in_ready[in_slot], 0)); if (p->h2d_split > 1) ORBFE_HIP(hipStreamWaitEvent(st, p->in_ready2[in_slot], 0)); }
+        if (in_slot >= 0) { ORBFE_HIP(hipStreamWaitEvent(st, p->in_ready[in_slot], 0)); }
         if ((rc = orbfe_extract_batch_device(p->ex[(size_t)eset], d_imgs, B, fstride, rows, cols, pitch, reinterpret_cast<orbfe_keypoint*>(p->slot_kps(cur, 1)),
                                              p->slot_desc(cur, 1), p->cap, p->slot_n(cur, 1), st)))
             return rc;
@@ -637,7 +620,7 @@ int orbfe_pipeline_synchronize(orbfe_pipeline* p)
     ORBFE_HIP(hipStreamSynchronize(p->st_det));
     for (auto sd : p->st_dets) ORBFE_HIP(hipStreamSynchronize(sd));
     ORBFE_HIP(hipStreamSynchronize(p->st_match));
-    if (p->host_mode) { ORBFE_HIP(hipStreamSynchronize(p->st_h2d)); ORBFE_HIP(hipStreamSynchronize(p->st_h2d2)); ORBFE_HIP(hipStreamSynchronize(p->st_d2h)); }
+    if (p->host_mode) { ORBFE_HIP(hipStreamSynchronize(p->st_h2d)); ORBFE_HIP(hipStreamSynchronize(p->st_d2h)); }
     return ORBFE_OK;
 }
 

@@ -13,8 +13,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _run(script, *argv, timeout=600):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", script), *map(str, argv)], capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+def _run(script, *argv, timeout=600, env=None):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", script), *map(str, argv)], capture_output=True, text=True, timeout=timeout, cwd=ROOT,
+                       env=dict(os.environ, **env) if env else None)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     return r.stdout
 
@@ -29,6 +30,17 @@ def test_detector_on_random_frames_dictionaries_and_rates():
     out = _run("stress_aruco.py", 100, 405)
     m = re.search(r"(\d+) cases, (\d+) mismatches", out)
     assert m and int(m.group(1)) == 100 and int(m.group(2)) == 0, out[-3000:]
+
+
+def test_detector_with_the_speck_passes_on_random_frames():
+    """The same random frames (other seed) and the detector-mode sequences with the speck passes switched on (ORBFE_ARUCO_SPECKS=1: off
+    by default, a shipped switch): what they clear never changes a marker, a corner or a rectangle candidate."""
+    out = _run("stress_aruco.py", 100, 505, env={"ORBFE_ARUCO_SPECKS": "1"})
+    m = re.search(r"(\d+) cases, (\d+) mismatches", out)
+    assert m and int(m.group(1)) == 100 and int(m.group(2)) == 0, out[-3000:]
+    out = _run("stress_modes.py", 20, 506, env={"ORBFE_ARUCO_SPECKS": "1"})
+    m = re.search(r"(\d+) mismatches", out)
+    assert m and int(m.group(1)) == 0, out[-3000:]
 
 
 def test_detector_modes_on_random_sequences():
