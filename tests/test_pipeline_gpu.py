@@ -308,3 +308,20 @@ def test_pipeline_from_a_directory_of_pgm_frames(tmp_path):
         assert r.returncode == 0 and "ok frames 8 " in r.stdout, r.stdout + r.stderr[-2000:]
         outs.append(np.fromfile(tmp_path / name, np.uint8))
     assert np.array_equal(outs[0], outs[1]) and outs[0].size > 0
+
+
+
+@pytest.mark.gpu
+def test_from_host_with_two_record_sets_keeps_the_halo_slot_intact(tmp_path):
+    """with two record sets the halo write of batch i (slot 0 of the set batch i + 1 is written to) must wait for the host
+    copy of that set's previous contents, which reads the whole set, halo included.  bench.py --from-host checks exactly the host copies
+    -- keypoints, markers, the pair across the batch boundary (halo_n / halo_desc) -- against the oracle; here with ORBFE_RECORD_SETS=2."""
+    import json
+    out = tmp_path / "fh2.json"
+    env = dict(os.environ, ORBFE_RECORD_SETS="2")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--from-host", "--frames", "24", "--steps", "9", "--warmup", "1",
+                        "--out", str(out)], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads(out.read_text())
+    v = d["verified_frames"]
+    assert d["config"]["record_sets"] == 2 and v["frames"] == [0, 12, 23] and v["boundary_pair_checked"] and v["keypoints_checked"] > 2500
