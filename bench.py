@@ -579,7 +579,17 @@ def main():
     shifts = [(r * B) // R for r in range(R)]
     d_batches = [pipe.upload(np.roll(frames_np, -s, axis=0)) for s in shifts]
 
+    # experiment hook (tools/ballast.hip, tools/sweeps.md): a kernel that keeps ONE resource of the chip busy next to every step
+    ballast = None
+    if os.environ.get("ORBFE_BENCH_BALLAST"):
+        kind, iters = os.environ["ORBFE_BENCH_BALLAST"].split(":")
+        bl = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "build", "libballast.so"))
+        bl.ballast_last_us.restype = ctypes.c_float
+        ballast = (bl, kind.encode(), int(iters))
+
     def step(r):
+        if ballast:
+            ballast[0].ballast_launch(ballast[1], ballast[2])
         cur = pipe.step(d_batches[r])
         if gloo_gather is not None:                 # the test hook: the record set through the host and gloo, every step
             gloo_gather(torch.from_numpy(pipe.record_bytes(cur)))
@@ -832,7 +842,7 @@ def main():
             roof["launch_us_is"] = "median over the %d timed steps (newest 64)" % args.steps
 
         # (a multi-GPU line whose gather fell back to gloo from the host measures another transport and another schedule: diagnostic)
-        invalid = bool(skips) or args.no_aruco or args.no_orb or bool(env_nondefault) or bool(rccl_error)
+        invalid = bool(skips) or args.no_aruco or args.no_orb or bool(env_nondefault) or bool(rccl_error) or bool(ballast)
         verified = None
         if not args.no_verify and not skips:
             # outside the clock: frames {0, B/2, B-1} and pairs {0, B/2, B-2} of the LAST timed step against the oracle
@@ -876,6 +886,14 @@ def main():
         }
         if invalid:
             out["diagnostic_frames_per_s"] = total_frames / elapsed
+        if ballast:      # its duration next to the last step, and alone
+            in_pipe = float(ballast[0].ballast_last_us())
+            torch.cuda.synchronize()
+            alone = []
+            for _ in range(5):
+                ballast[0].ballast_launch(ballast[1], ballast[2])
+                alone.append(float(ballast[0].ballast_last_us()))
+            out["ballast"] = {"kind": ballast[1].decode(), "iterations": ballast[2], "us_next_to_a_step": in_pipe, "us_alone": sorted(alone)[2]}
         if gather_check:
             out["gather_check"] = gather_check
             out["gather_us"] = gather_us

@@ -974,6 +974,10 @@ class MarkerDetector:
         """Debug: the speck passes between threshold and contours (k_speck_clean) on / off (default); the results do not change."""
         self.L.orbfe_aruco_debug_kernel_times(self.h, None, 8 if on else 9)
 
+    def set_speck_passes_in_kernel(self, on=True):
+        """Debug: the speck passes inside the one-workgroup relay kernels (full batches of frames whose bit image fits LDS) on (default) / off."""
+        self.L.orbfe_aruco_debug_kernel_times(self.h, None, 10 if on else 11)
+
     def contour_image(self, frame=0):
         """Debug: the bit image the contour kernels of the last batch read (the thresholded image after the speck passes)."""
         out = np.zeros(self._shape, np.uint8)

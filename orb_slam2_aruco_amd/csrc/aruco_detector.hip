@@ -96,14 +96,16 @@ struct orbfe_aruco {
     unsigned ct_gen = 0;       // generation tag of the hash table's entries (16 bits; the table is cleared when it wraps and before first use)
     bool ct_tab_dirty = true;
     DevBuf d_ctseg, d_cthtab, d_ctelem, d_ctstate, d_ctitemsA, d_ctitemsB, d_ctnitems, d_ctcodes;
-    // the speck passes between threshold and contours (k_speck_clean; aruco_trace.hpp "FEWER WALKS" (2)): result-neutral, OFF by default.
-    // They take a quarter of the contour stage's work away (300 x 640 x 480 alone: 472 -> 411 us, the pass itself included) -- and as a
-    // launch of their own on the detector's chain they cost the pipeline more than that: C2 step 1.40 - 1.46 against 1.34 - 1.38 ms,
-    // single-frame detect 0.357 against 0.358 ms (profiles/r05_contour_reductions_ab.txt).  Kept, tested on every
-    // contour path, for the day the passes run inside a kernel that holds the bit image anyway.  ORBFE_ARUCO_SPECKS = 1 or debug
-    // code 8 switch them on; = 2: the passes run and the contour kernels read the thresholded image (measurement).
-    int specks = getenv("ORBFE_ARUCO_SPECKS") ? (atoi(getenv("ORBFE_ARUCO_SPECKS")) ? 1 : 0) : 0;
-    bool specks_unused = getenv("ORBFE_ARUCO_SPECKS") && atoi(getenv("ORBFE_ARUCO_SPECKS")) == 2;
+    // The speck passes (aruco_trace.hpp "FEWER WALKS" (2)): result-neutral, a quarter of the contour stage's start candidates and walks
+    // gone.  Two places to run them:
+    //   inside the one-workgroup relay kernels, on the bit image they hold in LDS anyway (speck_pass_frame) -- the DEFAULT for the
+    //     batches that take those kernels (more than 32 frames whose image fits LDS): contour stage of 300 x 640 x 480 alone 462 -> 440 us;
+    //   as a launch of their own between threshold and contours (k_speck_clean), for every contour path: 462 -> 408 us alone, but one
+    //     more launch on the detector's chain costs the pipeline more than that (C2 step 1.40 - 1.46 against 1.34 - 1.38 ms, single-
+    //     frame detect 0.357 against 0.358 ms; profiles/r05_contour_reductions_ab.txt): off by default.
+    // ORBFE_ARUCO_SPECKS = 0: neither; = 1: the launch (and then not inside).  Debug codes 8 / 9: the launch on / off, 10 / 11: inside.
+    int specks = getenv("ORBFE_ARUCO_SPECKS") && atoi(getenv("ORBFE_ARUCO_SPECKS")) == 1 ? 1 : 0;
+    bool specks_inkernel = !getenv("ORBFE_ARUCO_SPECKS") || !*getenv("ORBFE_ARUCO_SPECKS");
     bool specks_ran = false;   // the last batch's contour kernels read d_bitsc
     DevBuf d_bitsc;
     bool relay_global = false; // k_contours_relay8g: the bit image stays in HBM (it does not fit LDS)
@@ -281,7 +283,8 @@ struct orbfe_aruco {
         }
         npyr = (int)levels.size();
         pyr_fbytes = off + 64;
-        candq_fu32 = (size_t)rows_ * cols_ / 16 + 64; // HBM overflow of the LDS long-walk queue
+        // HBM overflow of the single-walker kernel's long-walk queue / the relay kernels' start-candidate queue, + their speck scratch
+        candq_fu32 = ((size_t)relay_queue_words(cols_, rows_) + speck_frame_scratch_words(cols_, rows_) + 63) / 64 * 64;
         pool_fu32 = (size_t)CT_THREADS * std::max(4096, rows_ * cols_ / 48); // one private arena per lane of k_contours
         const int pw = (cols_ + 2 + 31) / 32;
         const size_t padded_words = (size_t)pw * (rows_ + 2) + 2; // + spare words for ring8()
@@ -488,7 +491,6 @@ struct orbfe_aruco {
             hipLaunchKernelGGL(k_speck_clean, dim3((rows + SPK_ROWS - 1) / SPK_ROWS, B), dim3(SPK_THREADS), spk_lds, s, d_bits.as<uint32_t>(), bits_fu32, wpr,
                                cols, rows, d_bitsc.as<uint32_t>());
         }
-        if (specks_unused) specks_ran = false;
         const uint32_t* cbits = specks_ran ? d_bitsc.as<uint32_t>() : d_bits.as<uint32_t>();
         const bool big = big_mode || !lds_bits_words;
         const int legacy_kcap = big ? AR_MAX_KEPT_BIG : AR_MAX_KEPT, legacy_ldsw = big ? 0 : lds_bits_words;
@@ -572,7 +574,7 @@ struct orbfe_aruco {
                                cols, rows, lds_bits_words, 70, relay_kshift, relay_tbits, d_segs.as<RelaySeg>(),
                                d_pool.as<uint32_t>(), pool_fu32, (int)pool_fu32, d_kept.as<ArKept>(), relay_kcap, relay_kcap,
                                d_tailkeys.as<unsigned long long>(), d_tailoff.as<int32_t>(), d_counts.as<int32_t>(), d_hint.as<int32_t>(),
-                               d_small.as<uint4>(), d_rstate.as<int32_t>(), small_separate ? 1 : 0, d_lut.as<uint16_t>(), f0,
+                               d_small.as<uint4>(), d_rstate.as<int32_t>(), (small_separate ? 1 : 0) | (specks_inkernel && !specks_ran && !small_separate ? 2 : 0), d_lut.as<uint16_t>(), f0,
                                d_candq.as<uint32_t>(), candq_fu32);
             }
             }
@@ -1551,6 +1553,7 @@ int orbfe_aruco_debug_kernel_times(orbfe_aruco* h, float* out_us, int capacity)
                    // 7 returns the number of batches that were done again on the next contour path, 8 / 9 the speck passes on / off
         if (capacity == 7) return h->n_escalations;
         if (capacity == 8 || capacity == 9) { h->specks = capacity == 8 ? 1 : 0; return 0; }   // the speck passes on / off (default)
+        if (capacity == 10 || capacity == 11) { h->specks_inkernel = capacity == 10; return 0; }   // ... inside the relay kernels on (default) / off
         if (capacity == 2 || capacity == 3) h->force_legacy = capacity == 2;
         else if (capacity >= 4 && capacity <= 6) {
             const int t = capacity == 4 ? -1 : capacity == 5 ? 1 : 0;

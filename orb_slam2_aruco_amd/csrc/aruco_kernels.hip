@@ -896,6 +896,58 @@ __device__ __forceinline__ void rl_advance(const BitImage& im, RelayWalk& w, uns
     w.ring = ring8(im, w.x, w.y);
 }
 
+// One speck pass (aruco_trace.hpp "FEWER WALKS" (2)) on a frame's padded bit image where the relay kernel holds it anyway -- in LDS --
+// instead of as a launch of its own between threshold and contours (k_speck_clean), which cost the pipeline more than the shorter
+// walks gave back.  Same function of the image as k_speck_clean and the CPU twin.  The rim masks and anchors of the whole frame go
+// through scratch in HBM (it stays in L2; every array is written once and read afterwards, by other waves of the workgroup behind a
+// barrier), so the image can be cleared in place: nothing reads P between the sweep that computes the anchors and the one that clears.
+// scr: 3 arrays of speck_frame_rows(H, HH) x wpr words; row index = padded row + HH + 1.
+template <int WW, int HH, int NT>
+__device__ __forceinline__ void speck_pass_frame(uint32_t* P, int wpr, int prow, uint32_t* __restrict__ scr, int tid)
+{
+    const int nr = prow + 2 * (HH + 1), n = nr * wpr;
+    uint32_t* Fm = scr;
+    uint32_t* Sm = scr + n;
+    uint32_t* An = scr + 2 * n;
+    const float inv_wpr = 1.0f / (float)wpr;
+    for (int i = tid; i < n; i += NT) {
+        const int rr = (int)(((float)i + 0.5f) * inv_wpr), j = i - __mul24(rr, wpr), r = rr - (HH + 1);   // exact: i < 2^20
+        uint32_t f = 0, sd = 0;
+        if (r >= 0 && r < prow) {
+            const uint32_t* row = P + __mul24(r, wpr);
+            speck_row_masks<WW>(row[j], j + 1 < wpr ? row[j + 1] : 0u, &f, &sd);
+        }
+        Fm[i] = f; Sm[i] = sd;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int i = tid; i < n; i += NT) {
+        const int rr = (int)(((float)i + 0.5f) * inv_wpr);
+        uint32_t a = 0;
+        if (rr + HH + 1 < nr) {
+            uint32_t occ = Fm[i] | Fm[i + (HH + 1) * wpr];
+#pragma unroll
+            for (int k = 1; k <= HH; k++) occ |= Sm[i + k * wpr];
+            a = ~occ;
+        }
+        An[i] = a;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int i = tid; i < prow * wpr; i += NT) {
+        const int r = (int)(((float)i + 0.5f) * inv_wpr), j = i - __mul24(r, wpr);
+        const uint32_t* a = An + __mul24(r + HH + 1, wpr) + j;
+        uint32_t e = 0, el = 0;
+#pragma unroll
+        for (int dy = 1; dy <= HH; dy++) {
+            e |= a[-dy * wpr];
+            if (j) el |= a[-dy * wpr - 1];
+        }
+        P[i] &= ~speck_dilate<WW>(e, el);
+    }
+    __syncthreads();
+}
+
 #ifndef RL_FETCH_GATE
 #define RL_FETCH_GATE 1
 #endif
@@ -1003,6 +1055,12 @@ __device__ __forceinline__ int relay_frame(
     if (GBITS) __threadfence_block(); // the padded image was written to HBM: visible to the workgroup's other waves
     __syncthreads();
     const BitImage im{lbits, wpr, W, H};
+    if (!GBITS && (small_elsewhere & 2) && candq_g) {   // the speck passes on the image in LDS (see speck_pass_frame)
+        uint32_t* scr = candq_g + (size_t)f * candq_fstride + relay_queue_words(W, H);
+        speck_pass_frame<ORBFE_SPECK_W1, ORBFE_SPECK_H1, RL_NT>(lbits, wpr, prow, scr, tid);
+        speck_pass_frame<ORBFE_SPECK_W2, ORBFE_SPECK_H2, RL_NT>(lbits, wpr, prow, scr + 3 * (size_t)wpr * speck_frame_rows(H, ORBFE_SPECK_H1), tid);
+    }
+    small_elsewhere &= 1;
     RL_STAMP();
 
     // ---- (b) grid markers: relay rows word by word, relay columns in chunks of 32 rows.  If they do not fit the table
@@ -1117,7 +1175,7 @@ __device__ __forceinline__ int relay_frame(
         const int nwords = wpr * H;
         const float inv_wpr = 1.0f / (float)wpr;
         uint32_t* cq = candq_g ? candq_g + (size_t)f * candq_fstride : nullptr;
-        const int qcap = (int)min(candq_fstride, (size_t)1 << 30);
+        const int qcap = relay_queue_words(W, H);
         if (cq) {
             for (int i = tid; i < nwords; i += NT) {
                 const int y = 1 + (int)(((float)i + 0.5f) * inv_wpr), j = i - __mul24(y - 1, wpr); // exact: i < 2^20

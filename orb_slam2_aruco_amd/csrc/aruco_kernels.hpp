@@ -44,6 +44,15 @@ __global__ void k_adaptive_threshold_t(ImgView src, int W, int H, int C, uint32_
 #define SPK_ROWS 48   // output rows per workgroup (+ ORBFE_SPECK_REACH above and below)
 static inline size_t speck_lds_bytes(int cols) { return (size_t)4 * (SPK_ROWS + 2 * ORBFE_SPECK_REACH) * (((cols + 2 + 31) >> 5) + 1) * 4; }
 __global__ void k_speck_clean(const uint32_t* bits, size_t bits_fstride, int wpr_g, int W, int H, uint32_t* out);
+// Per-frame scratch of the relay kernels behind the long-walk queue words of d_candq: [start-candidate queue | rim masks and anchors
+// of the two speck passes when they run inside the kernel (speck_pass_frame): 3 arrays a pass, each (padded rows + 2 * (H + 1)) rows]
+__host__ __device__ inline int relay_queue_words(int W, int H) { return (W * H) / 16 + 64; }
+__host__ __device__ inline int speck_frame_rows(int H, int HH) { return H + 2 + 2 * (HH + 1); }
+__host__ __device__ inline size_t speck_frame_scratch_words(int W, int H)
+{
+    const size_t pw = (size_t)((W + 2 + 31) >> 5);
+    return 3 * pw * (size_t)speck_frame_rows(H, ORBFE_SPECK_H1) + 3 * pw * (size_t)speck_frame_rows(H, ORBFE_SPECK_H2);
+}
 __global__ void k_half_area(ImgView src, ImgView dst, int dw, int dh);
 __global__ void k_half_area4(ImgView src, ImgView dst, int dw4, int dh);
 template <bool LDS_BITS>

@@ -91,7 +91,7 @@ struct orbfe_extractor {
         mix((uint64_t)(uintptr_t)d_pyr.p); mix((uint64_t)(uintptr_t)d_blur.p); mix((uint64_t)(uintptr_t)d_slots.p); mix((uint64_t)(uintptr_t)d_keys.p);
         mix((uint64_t)(uintptr_t)d_flatkv.p); mix((uint64_t)(uintptr_t)d_lvlout.p); mix((uint64_t)(uintptr_t)user_aux); mix((uint64_t)(uintptr_t)user_early);
         mix((uint64_t)gaussian_ed); mix((uint64_t)force_general_quadtree); mix((uint64_t)force_pyramid_depth); mix((uint64_t)blur_place);
-        mix((uint64_t)fast0_mode); mix((uint64_t)orient_pair); mix((uint64_t)batch_cap);
+        mix((uint64_t)fast0_mode); mix((uint64_t)batch_cap);
         return k | 1ull;
     }
     hipStream_t user_aux = nullptr; // orbfe_extractor_set_aux_stream: run the blur there instead of on aux_stream
@@ -125,7 +125,6 @@ struct orbfe_extractor {
     // so that the other engine's latency-bound kernels (8 waves and 50-77 KB of LDS per workgroup) always find room on every CU
     // k_orient_describe2 (two keypoints per wave: 227 instead of 342 VALU instructions per keypoint, 238 instead of 256 us alone at C2)
     // is NOT the default: with the detector running the C2 step was 1.62 ms with it and 1.61 without (four interleaved runs each)
-    bool orient_pair = env_int("ORBFE_ORIENT_PAIR", 1) != 0; // two keypoints per wave: the default since round 3 (C2 step 1.564 -> 1.543 ms, four interleaved runs each)
     static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
     // (rounds 2 - 3 capped the VALU-bound kernels' workgroups per CU with an LDS request they did not use -- ORBFE_OCC_FAST / _BLUR /
     // _ORIENT -- so that the detector's 65 - 77 KB workgroups always found room: noise at best, slower when tighter; the switches went in round 5)
@@ -418,7 +417,8 @@ struct orbfe_extractor {
         auto launch_fast = [&](hipStream_t st, int cell_base, int cell_end) -> int {
             if (cell_end <= cell_base) return ORBFE_OK;
             // LDS per wave: ROI (cell + 6), score map (cell + 2), one u16 list of cell pixels
-            const int roi_pitch = align_up(max_wcell + 6 + 4, 4) + 8, roi_rows = max_hcell + 6; // +1 byte shift, +2 dwords read past a row (8-pixel groups)
+            // +1 byte shift, +2 dwords read past a row (8-pixel groups); rows are staged in 16-byte chunks
+            const int roi_pitch = align_up(max_wcell + 6 + 4 + 8, 16), roi_rows = max_hcell + 6;
             const int map_pitch = max_wcell + 2, map_rows = max_hcell + 2;
             const int list_cap = max_wcell * max_hcell;
             auto a16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
@@ -554,8 +554,8 @@ struct orbfe_extractor {
         } else
             ORBFE_HIP(hipStreamWaitEvent(s, ev_join, 0));
         const int kcap_ = std::min(capacity, max_keypoints());
-        const int okx = orient_pair ? (kcap_ + 7) / 8 : (kcap_ + 3) / 4;   // workgroups per frame: 4 waves of one or two keypoints
-        auto ofn = orient_pair ? k_orient_describe2 : k_orient_describe;
+        const int okx = (kcap_ + 7) / 8;   // workgroups per frame: 4 waves of two keypoints
+        auto ofn = k_orient_describe2;
         const size_t lds_orient = 0;
         if (lds_orient) { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(ofn), lds_orient); if (rc_lds_) return rc_lds_; }
         for (int r_ = 0; r_ < ORBFE_REPS_ORB(4); r_++) hipLaunchKernelGGL(ofn, dim3(xcd_grid(okx * B)), dim3(256), lds_orient, s, src0, pyr, blur, dg,

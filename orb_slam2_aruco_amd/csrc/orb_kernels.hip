@@ -6,7 +6,7 @@
 //   k_distribute        x 1            DistributeOctTree, one wave per (frame, level)           (:539-763)
 //   k_level_offsets     x 1            per-frame level prefix sums / keypoint totals            (:1059-1062)
 //   k_blur7             x 1            7x7 sigma-2 integer Gaussian of every level              (:1085-1086)
-//   k_orient_describe   x 1            IC_Angle + steered BRIEF, one wave per keypoint          (:77-147)
+//   k_orient_describe2  x 1            IC_Angle + steered BRIEF, two keypoints per wave         (:77-147)
 //
 // Data layout in HBM (per extractor handle, frame-major): see DESIGN.md "ORB extractor: layout".
 #include "orb_kernels.hpp"
@@ -228,13 +228,14 @@ __device__ __forceinline__ uint32_t compass_pass2(u16x2 v, u16x2 r0, u16x2 r4, u
     return as_u32(ph) | as_u32(pl);
 }
 
-// cornerScore<16> on pairs P[k] = (d[k], d[k+8]): max over the 16 arcs of 9 of min(d) (and of min(-d)), minus 1.
-// The differences are 9-bit integers, and gfx950 has three-input packed f16 minimum / maximum (v_pk_minimum3_f16,
-// v_pk_maximum3_f16) but no three-input packed integer ones.  An integer |d| <= 255 read as f16 BITS is the denormal d * 2^-24:
-// differences of two such values are exact, their order is the order of the integers, and the bits of a positive result are
-// the integer again -- so the whole network runs on packed f16 without a single conversion (the kernel's f16 denormal
-// mode is the default "preserve").  min over 9 consecutive = min3 of (min3 of 3) at offsets 0, 3, 6: 16 + 16 instructions
-// for all 16 arcs of both polarities, and the half swaps a wrapped index needs are operand selects of the instruction.
+// cornerScore<16> on pairs P[k] = (r[k], r[k+8]) of RING VALUES: the score is max over the 16 arcs of 9 of min(v - r) (and of
+// min(r - v)), minus 1 = max(v - (smallest arc maximum), (largest arc minimum) - v) - 1, so the network runs on the pixels as loaded
+// and the centre comes in once at the end (the eight subtractions d = v - r in front of it were 8 of ~86 instructions per trip).
+// gfx950 has three-input packed f16 minimum / maximum (v_pk_minimum3_f16, v_pk_maximum3_f16) but no three-input packed integer ones.
+// An integer 0 .. 255 read as f16 BITS is the denormal r * 2^-24: the order of such values is the order of the integers, their
+// differences are exact, and the bits of a positive result are the integer again -- so the whole network runs on packed f16 without
+// a single conversion (the kernel's f16 denormal mode is the default "preserve").  min over 9 consecutive = min3 of (min3 of 3) at
+// offsets 0, 3, 6: 16 + 16 instructions for all 16 arcs of both kinds, and the half swaps a wrapped index needs are operand selects.
 //   SW bit i: operand i is taken with its halves swapped
 template <int SW> __device__ __forceinline__ uint32_t hmin3(uint32_t a, uint32_t b, uint32_t c)
 {
@@ -252,21 +253,15 @@ template <int SW> __device__ __forceinline__ uint32_t hmax3(uint32_t a, uint32_t
     else asm("v_pk_maximum3_f16 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
-// (a.lo - b.lo, a.hi - b.hi) on f16 bits
-__device__ __forceinline__ uint32_t hsub2(uint32_t a, uint32_t b)
+// v2 = the centre pixel in both halves
+__device__ __forceinline__ int fast_score16_h(const uint32_t P[8], uint32_t v2)
 {
-    uint32_t r;
-    asm("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ int fast_score16_h(const uint32_t P[8])
-{
-    uint32_t n3[8], x3[8]; // (m3[k], m3[k+8]),  m3[k] = min / max of d[k], d[k+1], d[k+2]
+    uint32_t n3[8], x3[8]; // (m3[k], m3[k+8]),  m3[k] = min / max of r[k], r[k+1], r[k+2]
 #pragma unroll
     for (int k = 0; k < 6; k++) { n3[k] = hmin3<0>(P[k], P[k + 1], P[k + 2]); x3[k] = hmax3<0>(P[k], P[k + 1], P[k + 2]); }
     n3[6] = hmin3<4>(P[6], P[7], P[0]); x3[6] = hmax3<4>(P[6], P[7], P[0]);
     n3[7] = hmin3<6>(P[7], P[0], P[1]); x3[7] = hmax3<6>(P[7], P[0], P[1]);
-    uint32_t n9[8], x9[8]; // m9[k] = min / max of m3[k], m3[k+3], m3[k+6] = of d[k] .. d[k+8]
+    uint32_t n9[8], x9[8]; // m9[k] = min / max of m3[k], m3[k+3], m3[k+6] = of r[k] .. r[k+8]
     n9[0] = hmin3<0>(n3[0], n3[3], n3[6]); x9[0] = hmax3<0>(x3[0], x3[3], x3[6]);
     n9[1] = hmin3<0>(n3[1], n3[4], n3[7]); x9[1] = hmax3<0>(x3[1], x3[4], x3[7]);
     n9[2] = hmin3<4>(n3[2], n3[5], n3[0]); x9[2] = hmax3<4>(x3[2], x3[5], x3[0]);
@@ -275,11 +270,13 @@ __device__ __forceinline__ int fast_score16_h(const uint32_t P[8])
     n9[5] = hmin3<6>(n3[5], n3[0], n3[3]); x9[5] = hmax3<6>(x3[5], x3[0], x3[3]);
     n9[6] = hmin3<6>(n3[6], n3[1], n3[4]); x9[6] = hmax3<6>(x3[6], x3[1], x3[4]);
     n9[7] = hmin3<6>(n3[7], n3[2], n3[5]); x9[7] = hmax3<6>(x3[7], x3[2], x3[5]);
-    // brightest arc = max of the 16 minima; darkest arc = min of the 16 maxima
+    // darkest ring arc against the centre: the largest arc minimum; brightest: the smallest arc maximum
     const uint32_t bn = hmax3<0>(hmax3<0>(n9[0], n9[1], n9[2]), hmax3<0>(n9[3], n9[4], n9[5]), hmax3<0>(n9[6], n9[7], n9[7]));
     const uint32_t bx = hmin3<0>(hmin3<0>(x9[0], x9[1], x9[2]), hmin3<0>(x9[3], x9[4], x9[5]), hmin3<0>(x9[6], x9[7], x9[7]));
-    uint32_t m;
-    asm("v_pk_max_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(m) : "v"(bn), "v"(bx)); // (max(bn, -bx)) per half
+    uint32_t da, db, m;
+    asm("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(da) : "v"(bn), "v"(v2)); // (largest arc minimum) - v per half
+    asm("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(db) : "v"(v2), "v"(bx)); // v - (smallest arc maximum)
+    asm("v_pk_max_f16 %0, %1, %2" : "=v"(m) : "v"(da), "v"(db));
     uint32_t sres;
     asm("v_pk_max_f16 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(sres) : "v"(m));    // low half: max of the two halves
     return (int)(short)(sres & 0xffffu) - 1; // the bits of a positive denormal are the integer; anything else is far below any threshold
@@ -330,34 +327,35 @@ __global__ __launch_bounds__(256) void k_fast_cells(ImgView src0, ImgView pyr, c
     const int pitch = (level == 0) ? src0.pitch : g.pitch;
     const int SP = roi_pitch, MP = map_pitch;
 
-    // stage the ROI (columns -1 .. w-1: the one-byte shift) with unaligned dword loads, 8 in flight per lane.  A lane keeps its
-    // dword column and takes every (64 / ndw)-th row: its image and LDS offsets advance by constants (uniform base + 32-bit lane
-    // offset, one addition each per load -- the flat (row, dword) numbering cost a wrap test, three selects and a 64-bit
-    // multiply-add per item: 115 of the kernel's ~890 VALU instructions per wave); the 64 % ndw lanes left over idle here.
+    // stage the ROI (columns -1 .. w-1: the one-byte shift) with unaligned 16-byte loads, two in flight per lane.  A lane keeps its
+    // chunk column and takes every (64 / n16)-th row: its image and LDS offsets advance by constants (uniform base + 32-bit lane offset).
+    // (Until round 5 the unit was a dword, 8 in flight: 87 of the kernel's ~780 VALU instructions per wave were this loop's address
+    // arithmetic; a row is three chunks, so a 36-row ROI is two loads per lane.)  roi_pitch is a multiple of 16 and covers the chunks.
     {
-        typedef uint32_t u32_unaligned __attribute__((aligned(1)));
-        const int ndw = (w + 4) >> 2;
-        const int rpi = 64 / ndw;                      // rows per trip of the wave
-        const int y0 = (int)(((float)lane + 0.5f) * (1.0f / (float)ndw)), c = lane - __mul24(y0, ndw); // exact: lane < 64
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        typedef u32x4 u32x4_unaligned __attribute__((aligned(1)));
+        const int n16 = (w + 16) >> 4;
+        const int rpi = 64 / n16;                      // rows per trip of the wave
+        const int y0 = (int)(((float)lane + 0.5f) * (1.0f / (float)n16)), c = lane - __mul24(y0, n16); // exact: lane < 64
         const uint8_t* roi = img + (size_t)iniY * pitch + iniX - 1;
-        // (24-bit multiplies fold into v_mad_u32_u24 with the column offset)
-        uint32_t go = (uint32_t)(__mul24(y0, pitch) + 4 * c), so_ = (uint32_t)(__mul24(y0, SP) + 4 * c);
+        uint32_t go = (uint32_t)(__mul24(y0, pitch) + 16 * c), so_ = (uint32_t)(__mul24(y0, SP) + 16 * c);
         const uint32_t gstep = (uint32_t)(rpi * pitch), sstep = (uint32_t)(rpi * SP);
         // no predicates (a load under a condition becomes a branch with a wait behind it): a row past the end -- and with it the
-        // lanes left over -- takes the ROI's last row, i.e. loads and stores that row's dword once more
-        const uint32_t go_last = (uint32_t)((h - 1) * pitch + 4 * c), so_last = (uint32_t)((h - 1) * SP + 4 * c);
-        for (int r0 = 0; r0 < h; r0 += 8 * rpi) {
-            uint32_t v[8], so[8];
+        // lanes left over -- takes the ROI's last row, i.e. loads and stores that row's chunk once more
+        const uint32_t go_last = (uint32_t)((h - 1) * pitch + 16 * c), so_last = (uint32_t)((h - 1) * SP + 16 * c);
+        for (int r0 = 0; r0 < h; r0 += 2 * rpi) {
+            u32x4 v[2];
+            uint32_t so[2];
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
+            for (int k = 0; k < 2; k++) {
                 const bool in = r0 + k * rpi + y0 < h;
                 const uint32_t g_ = in ? go + (uint32_t)k * gstep : go_last;
                 so[k] = in ? so_ + (uint32_t)k * sstep : so_last;
-                v[k] = *reinterpret_cast<const u32_unaligned*>(roi + g_);
+                v[k] = *reinterpret_cast<const u32x4_unaligned*>(roi + g_);
             }
 #pragma unroll
-            for (int k = 0; k < 8; k++) *reinterpret_cast<uint32_t*>(simg + so[k]) = v[k];
-            go += 8 * gstep; so_ += 8 * sstep;
+            for (int k = 0; k < 2; k++) *reinterpret_cast<u32x4*>(simg + so[k]) = v[k];
+            go += 2 * gstep; so_ += 2 * sstep;
         }
     }
     for (int i = lane; i < (int)(map_bytes / 4); i += 64) reinterpret_cast<uint32_t*>(smap)[i] = 0;
@@ -427,16 +425,17 @@ __global__ __launch_bounds__(256) void k_fast_cells(ImgView src0, ImgView pyr, c
                 const uint8_t* c = simg + __mul24(yx >> 8, SP) + (yx & 255) + (3 * SP + 4);
                 const uint32_t v = c[0];
                 const uint32_t v2 = v | (v << 16);
-                uint32_t P[8]; // (d[k], d[k+8]) as f16 bits, d = v - ring pixel
-                P[0] = hsub2(v2, (uint32_t)c[3 * SP + 0] | ((uint32_t)c[-3 * SP + 0] << 16));
-                P[1] = hsub2(v2, (uint32_t)c[3 * SP + 1] | ((uint32_t)c[-3 * SP - 1] << 16));
-                P[2] = hsub2(v2, (uint32_t)c[2 * SP + 2] | ((uint32_t)c[-2 * SP - 2] << 16));
-                P[3] = hsub2(v2, (uint32_t)c[1 * SP + 3] | ((uint32_t)c[-1 * SP - 3] << 16));
-                P[4] = hsub2(v2, (uint32_t)c[3] | ((uint32_t)c[-3] << 16));
-                P[5] = hsub2(v2, (uint32_t)c[-1 * SP + 3] | ((uint32_t)c[1 * SP - 3] << 16));
-                P[6] = hsub2(v2, (uint32_t)c[-2 * SP + 2] | ((uint32_t)c[2 * SP - 2] << 16));
-                P[7] = hsub2(v2, (uint32_t)c[-3 * SP + 1] | ((uint32_t)c[3 * SP - 1] << 16));
-                score = fast_score16_h(P);
+                uint32_t P[8]; // ring pixels (r[k], r[k+8]) as f16 bits
+                // (a d16 byte load per half would join the pairs for free, but with SRAM ECC -- gfx950 -- a d16 load clears the other half)
+                P[0] = (uint32_t)c[3 * SP + 0] | ((uint32_t)c[-3 * SP + 0] << 16);
+                P[1] = (uint32_t)c[3 * SP + 1] | ((uint32_t)c[-3 * SP - 1] << 16);
+                P[2] = (uint32_t)c[2 * SP + 2] | ((uint32_t)c[-2 * SP - 2] << 16);
+                P[3] = (uint32_t)c[1 * SP + 3] | ((uint32_t)c[-1 * SP - 3] << 16);
+                P[4] = (uint32_t)c[3] | ((uint32_t)c[-3] << 16);
+                P[5] = (uint32_t)c[-1 * SP + 3] | ((uint32_t)c[1 * SP - 3] << 16);
+                P[6] = (uint32_t)c[-2 * SP + 2] | ((uint32_t)c[2 * SP - 2] << 16);
+                P[7] = (uint32_t)c[-3 * SP + 1] | ((uint32_t)c[3 * SP - 1] << 16);
+                score = fast_score16_h(P, v2);
                 corner = score >= t;
             }
             const unsigned long long m = __ballot(corner);
@@ -1442,164 +1441,22 @@ template __global__ void k_blur7<false>(ImgView, ImgView, ImgView, const LevelGe
 template __global__ void k_blur7<true>(ImgView, ImgView, ImgView, const LevelGeom*, const uint32_t*, int, int);
 
 // ------------------------------------------------------------------------------------------------ describe --
-// One wave per keypoint: IC_Angle on the un-blurred level (:77-104), then the 256 steered BRIEF tests on the
-// blurred level (:108-147), then the final record (octave, size, scaled coordinates; :837-847, :1095-1101).
-__global__ __launch_bounds__(256) void k_orient_describe(ImgView src0, ImgView pyr, ImgView blur,
-                                                         const LevelGeom* __restrict__ geom,
-                                                         const uint32_t* __restrict__ flat_kv,
-                                                         const uint8_t* __restrict__ flat_lvl,
-                                                         const int32_t* __restrict__ n_out, int nlevels,
-                                                         const uint32_t* __restrict__ pattern32 /*256 x (x0,y0,x1,y1) i8*/,
-                                                         const uint4* __restrict__ icw /*31 rows x 4 uint4: IC_Angle weights*/,
-                                                         orbfe_keypoint* __restrict__ kps,
-                                                         uint8_t* __restrict__ desc, int capacity, int nx, int total)
-{
-    // The kernel is bound by VALU issue, so everything that is the same for the whole wave sits in scalar registers (the
-    // keypoint, its level, every base address), the IC_Angle row weights come precomputed from the host and index arithmetic is incremental.  (The pattern as a float4
-    // table saves 32 conversions per lane but quadruples the table traffic of every wave: slower.)  (Letting four lanes of one wave do fastAtan2 + sin / cos for the four
-    // keypoints of the workgroup removes another 25 % of the instructions but costs two workgroup barriers around a serial
-    // f64 chain: measured 290 instead of 265 us.)
-    const int lane = threadIdx.x & 63, wid = wave_id();
-    int bx, f;
-    if (!xcd_remap(nx, total, bx, f)) return;
-    __shared__ __align__(16) uint8_t s_pat[4][31 * 36 + 12];
-    __shared__ __align__(16) uint8_t s_win[4][37 * 40 + 8];
-    const int oidx = bx * 4 + wid; // flat index over the frame's keypoints (levels concatenated ascending)
-    if (oidx >= n_out[f]) return;
-    const uint32_t kv = (uint32_t)__builtin_amdgcn_readfirstlane((int)flat_kv[(size_t)f * capacity + oidx]);
-    const int level = __builtin_amdgcn_readfirstlane((int)flat_lvl[(size_t)f * capacity + oidx]);
-    const LevelGeom g = geom[level];
-    const int kx = (int)(kv & 0xfff) + 16, ky = (int)((kv >> 12) & 0xfff) + 16; // += minBorder (:843-844)
-    const int score = kv >> 24;
-    const int ax = (kx - 18) & ~3, xoff = (kx - 18) - ax;
-    uint32_t wv[6], pat[4];
-    int m10 = 0, m01 = 0;
-    {
-        const uint8_t* img = (level == 0) ? src0.base + (size_t)f * src0.fstride
-                                          : pyr.base + (size_t)f * pyr.fstride + g.img_off;
-        const int pitch = (level == 0) ? src0.pitch : g.pitch;
-        // ---- all global loads of the keypoint up front (one round trip): the 37 x 37 blurred window of the descriptor (rows of
-        // 40 bytes from the 4-byte-aligned column at or below kx - 18), the lane's four pattern tests, the 31 x 31 patch of
-        // IC_Angle (rows of 36 bytes from the aligned column at or below kx - 15).  (row, dword) of a lane's item advance by a
-        // constant step per item (64 = 6 * 10 + 4 = 7 * 9 + 1), so there is one division per lane, not one per item.
-        const uint8_t* bimg = blur.base + (size_t)f * blur.fstride + g.blur_off + (off24(ky - 18, g.bpitch) + (uint32_t)ax);
-        {
-            int r = lane / 10, c = lane - r * 10;
-#pragma unroll
-            for (int k = 0; k < 6; k++) {
-                const bool in = k * 64 + lane < 370;
-                wv[k] = *reinterpret_cast<const uint32_t*>(bimg + (off24(in ? r : 36, g.bpitch) + (uint32_t)(4 * (in ? c : 9)))); // 32-bit offset off a uniform base
-                r += 6; c += 4;
-                if (c >= 10) { c -= 10; r++; }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) pat[j] = pattern32[j * 64 + lane];
-        // the row weights of IC_Angle (lane = patch row) come with the same round trip
-        const int wrow = min(lane, 30);
-        const uint4 wa = icw[wrow * 4 + 0], wb = icw[wrow * 4 + 1], oa = icw[wrow * 4 + 2], ob = icw[wrow * 4 + 3];
-        const int axp = (kx - 15) & ~3, xo = (kx - 15) - axp;
-        const uint8_t* pimg = img + (off24(ky - 15, pitch) + (uint32_t)axp);
-        uint32_t v[5];
-        {
-            int r = lane / 9, c = lane - r * 9;
-#pragma unroll
-            for (int k = 0; k < 5; k++) {
-                const bool in = k * 64 + lane < 279;
-                // level 0 is the caller's buffer: no alignment is assumed there (gfx950 global loads may be unaligned)
-                typedef uint32_t u32_unaligned __attribute__((aligned(1)));
-                v[k] = *reinterpret_cast<const u32_unaligned*>(pimg + (off24(in ? r : 30, pitch) + (uint32_t)(4 * (in ? c : 8))));
-                r += 7; c += 1;
-                if (c >= 9) { c -= 9; r++; }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            const int idx = k * 64 + lane;
-            if (idx < 279) reinterpret_cast<uint32_t*>(s_pat[wid])[idx] = v[k];
-        }
-        __builtin_amdgcn_wave_barrier();
-        // ---- IC_Angle: lane = patch row v = lane - 15 (lanes 0..30): the row's 31 bytes as eight dwords re-cut at the byte offset
-        // xo, m10 = sum (i - 15) I = dot(I, i) - 15 dot(I, 1) and m01 = v dot(I, 1) over the row's part of the circular patch
-        // (umax, ORBextractor.cc:454-469), with the two weight vectors of the row (byte index i, ones; zero outside |u| <= umax(|v|))
-        if (lane < 31) {
-            const uint32_t* rw = reinterpret_cast<const uint32_t*>(s_pat[wid] + lane * 36);
-            uint32_t d[9];
-#pragma unroll
-            for (int q = 0; q < 9; q++) d[q] = rw[q];
-            uint32_t e[8];
-#pragma unroll
-            for (int q = 0; q < 8; q++) e[q] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], xo);
-            uint32_t A = 0, B = 0;
-            A = bl_dot4(e[0], wa.x, A); A = bl_dot4(e[1], wa.y, A); A = bl_dot4(e[2], wa.z, A); A = bl_dot4(e[3], wa.w, A);
-            A = bl_dot4(e[4], wb.x, A); A = bl_dot4(e[5], wb.y, A); A = bl_dot4(e[6], wb.z, A); A = bl_dot4(e[7], wb.w, A);
-            B = bl_dot4(e[0], oa.x, B); B = bl_dot4(e[1], oa.y, B); B = bl_dot4(e[2], oa.z, B); B = bl_dot4(e[3], oa.w, B);
-            B = bl_dot4(e[4], ob.x, B); B = bl_dot4(e[5], ob.y, B); B = bl_dot4(e[6], ob.z, B); B = bl_dot4(e[7], ob.w, B);
-            m10 = (int)A - 15 * (int)B;
-            m01 = (lane - 15) * (int)B;
-        }
-        m10 = wave_sum(m10);
-        m01 = wave_sum(m01);
-#pragma unroll
-        for (int k = 0; k < 6; k++) {
-            const int idx = k * 64 + lane;
-            if (idx < 370) reinterpret_cast<uint32_t*>(s_win[wid])[idx] = wv[k];
-        }
-    }
-    const float angle = orbfe_fast_atan2((float)m01, (float)m10);
-    const float factorPI = (float)(3.14159265358979323846 / 180.f);
-    float a, b;
-    orbfe_sincosf(angle * factorPI, &b, &a); // a = cos, b = sin
-    __builtin_amdgcn_wave_barrier();
-
-    // ---- steered BRIEF on the staged window
-    // The rotation is separate multiplies and adds (the reference is compiled without fused multiply-add) on packed f32: the two
-    // points of a test side by side, (x0, x1) (b, b) + (y0, y1) (a, a), six v_pk_* instead of twelve scalar operations.  cvRound
-    // is "add 1.5 * 2^23": the sum is rounded to an integer by the adder (to nearest even, like cvRound), and its low mantissa
-    // bits are that integer plus 2^22; row * 40 + column is then one 24-bit multiply-add on the raw bits, the constants folded
-    // into the window's base address.
-    typedef float v2f __attribute__((ext_vector_type(2)));
-    constexpr uint32_t MAGIC_BITS = 0x4B400000u;                                      // 12582912.0f = 1.5 * 2^23
-    constexpr uint32_t IDX_BIAS = (MAGIC_BITS & 0xffffffu) * 40u + MAGIC_BITS;         // what the raw-bit multiply-add carries along
-    const uint8_t* bc = s_win[wid] + 18 * 40 + 18 + xoff;
-    const v2f aa = {a, a}, bb = {b, b}, magic = {12582912.0f, 12582912.0f};
-    unsigned long long words[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const uint32_t pp = pat[j];
-        const v2f X = {(float)(signed char)(pp & 0xff), (float)(signed char)((pp >> 16) & 0xff)};
-        const v2f Y = {(float)(signed char)((pp >> 8) & 0xff), (float)(signed char)(pp >> 24)};
-        const v2f R = (X * bb + Y * aa) + magic;   // rows of the two points (-ffp-contract=off: no fused multiply-add)
-        const v2f C = (X * aa - Y * bb) + magic;   // columns
-        const uint32_t i0 = __umul24(__float_as_uint(R.x), 40u) + __float_as_uint(C.x) - IDX_BIAS;
-        const uint32_t i1 = __umul24(__float_as_uint(R.y), 40u) + __float_as_uint(C.y) - IDX_BIAS;
-        const int t0 = bc[(int)i0], t1 = bc[(int)i1];
-        words[j] = __ballot(t0 < t1);
-    }
-    if (lane < 4) {
-        unsigned long long wd = lane == 0 ? words[0] : lane == 1 ? words[1] : lane == 2 ? words[2] : words[3];
-        reinterpret_cast<unsigned long long*>(desc + ((size_t)f * capacity + oidx) * 32)[lane] = wd;
-    }
-    if (lane == 0) {
-        orbfe_keypoint kp;
-        float px = (float)kx, py = (float)ky;
-        if (level != 0) { px = __fmul_rn(px, g.scale); py = __fmul_rn(py, g.scale); }
-        kp.x = px; kp.y = py;
-        kp.size = g.kp_size;
-        kp.angle = angle;
-        kp.response = (float)score;
-        kp.octave = level;
-        kp.class_id = -1;
-        kps[(size_t)f * capacity + oidx] = kp;
-    }
-}
-
-// Two keypoints per wave.  A third of k_orient_describe's instructions do not depend on the lane: fastAtan2 and sin / cos of the one
+// IC_Angle on the un-blurred level (:77-104), then the 256 steered BRIEF tests on the blurred level (:108-147), then the final record.
+// Two keypoints per wave.  A third of the instructions of one keypoint do not depend on the lane: fastAtan2 and sin / cos of the one
 // angle, and IC_Angle uses 31 lanes.  Here lanes 0..31 belong to keypoint A and 32..63 to keypoint B for those parts -- the patch rows
 // of both in one pass, the two moment sums out of one scan (lanes 31 and 63), one fastAtan2 / sincos sequence for both angles -- and
-// the loads and the 256 tests run per keypoint on all 64 lanes as before.  An odd last keypoint is paired with itself.
-// 66 registers would cost the eighth wave per SIMD: the kernel waits on three dependent global round trips per keypoint pair, so
-// occupancy is what hides them (C2 step 1.531 -> 1.519 ms, three interleaved runs each)
+// the loads and the 256 tests run per keypoint on all 64 lanes.  An odd last keypoint is paired with itself.
+//
+// What the kernel runs at is the CU's vector memory path, not instruction issue (round 5, tools/ext_alone.py with parts compiled out:
+// 452 us alone at C2, 449 without the trigonometry, 431 without the 256 tests, 243 without the image loads; the C2 step 1.39 -> 1.26 ms
+// without the image loads, unchanged without the arithmetic).  The texture addresser takes a wave's load FOUR LANES A CLOCK whatever
+// the width: 16 clocks for 256 bytes as dwords, 16 clocks for 1 KB as 16-byte lanes.  So:
+//   - the 37 x 40-byte window and the 31 x 36-byte patch are fetched as (row, 16-byte chunk) items, three chunks a row: two loads
+//     each (they were 6 + 5 dword loads: 24 vector memory instructions per wave for the images, now 8);
+//   - the two tables every wave needs -- the IC_Angle row weights (64 bytes a lane) and the test pattern -- come through LDS, fetched
+//     once per workgroup (8 loads per wave before);
+//   - the keypoint records are fetched WITH the frame's count, not behind it (one round trip less in a wave's life).
+// 66 registers would cost the eighth wave per SIMD, and occupancy is what hides the round trips.
 #ifndef OD2_ATTR
 #define OD2_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))
 #endif
@@ -1615,74 +1472,82 @@ __global__ __launch_bounds__(256) OD2_ATTR void k_orient_describe2(ImgView src0,
     const int lane = threadIdx.x & 63, wid = wave_id();
     int bx, f;
     if (!xcd_remap(nx, total, bx, f)) return;
-    constexpr int PATB = 31 * 36 + 12, WINB = 37 * 40 + 8;
+    constexpr int PROW = 40, PATB = 31 * PROW + 8, WINB = 37 * 40 + 8;   // (rows of 8-byte multiples: the chunks go in as 8-byte stores)
     // LDS per wave: the two IC_Angle patches; once the moments are summed the same bytes hold one descriptor window at a time
-    // (9 KB per workgroup: the footprint matters, an LDS request of 23 KB on k_orient_describe cost the C2 step 50 us)
+    // (13 KB per workgroup with the tables: the footprint matters, an LDS request of 23 KB cost the C2 step 50 us in round 3)
     static_assert(2 * PATB >= WINB, "the window overlays the patches");
     __shared__ __align__(16) uint8_t s_pat[4][2][PATB];
-    const int nk = n_out[f];
+    __shared__ uint4 s_icw[31 * 4];
+    __shared__ uint32_t s_pattern[256];
+    if (threadIdx.x < 31 * 4) s_icw[threadIdx.x] = icw[threadIdx.x];
+    s_pattern[threadIdx.x] = pattern32[threadIdx.x];
+    __syncthreads();
     const int o0 = (bx * 4 + wid) * 2;
+    // (the grid only covers slots below the capacity, whatever they hold)
+    const size_t slot0 = (size_t)f * capacity + min(o0, capacity - 1), slot1 = (size_t)f * capacity + min(o0 + 1, capacity - 1);
+    const uint32_t kv_pre[2] = {flat_kv[slot0], flat_kv[slot1]};
+    const int lvl_pre[2] = {flat_lvl[slot0], flat_lvl[slot1]};
+    const int nk = n_out[f];
     if (o0 >= nk) return;
     const bool two = o0 + 1 < nk;
     const int half = lane >> 5, r = lane & 31;
-    typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef u32x4 u32x4_unaligned __attribute__((aligned(1)));   // level 0 is the caller's buffer: no alignment is assumed there
     int kx[2], ky[2], level[2], score[2], xoff[2], xo[2];
-    uint32_t wv[2][6], v[2][5], pat[4];
+    u32x4 wv[2][2], v[2][2];
+    uint32_t pat[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) pat[j] = pattern32[j * 64 + lane];
+    for (int j = 0; j < 4; j++) pat[j] = s_pattern[j * 64 + lane];
     const int wrow = min(r, 30);
-    const uint4 wa = icw[wrow * 4 + 0], wb = icw[wrow * 4 + 1], oa = icw[wrow * 4 + 2], ob = icw[wrow * 4 + 3];
+    const uint4 wa = s_icw[wrow * 4 + 0], wb = s_icw[wrow * 4 + 1], oa = s_icw[wrow * 4 + 2], ob = s_icw[wrow * 4 + 3];
+    // item i = lane + 64 k (k = 0, 1) is chunk i % 3 of row i / 3 -- the same for the window, the patch and both keypoints; the items
+    // past the last row (37 x 3 = 111, 31 x 3 = 93) repeat that row's chunk: the same bytes to the same place once more
+    const int r0 = (lane * 171) >> 9, c0 = 16 * (lane - 3 * r0);                   // lane / 3 (exact below 171)
+    const int r1f = ((lane + 64) * 171) >> 9, c1 = 16 * (lane + 64 - 3 * r1f);
+    const int wr1 = min(r1f, 36), pr1 = min(r1f, 30);
 #pragma unroll
     for (int h = 0; h < 2; h++) {
-        const int oidx = (h == 1 && two) ? o0 + 1 : o0;
-        const uint32_t kv = (uint32_t)__builtin_amdgcn_readfirstlane((int)flat_kv[(size_t)f * capacity + oidx]);
-        level[h] = __builtin_amdgcn_readfirstlane((int)flat_lvl[(size_t)f * capacity + oidx]);
+        const int hs = (h == 1 && two) ? 1 : 0;
+        const uint32_t kv = (uint32_t)__builtin_amdgcn_readfirstlane((int)kv_pre[hs]);
+        level[h] = __builtin_amdgcn_readfirstlane(lvl_pre[hs]);
         const LevelGeom& g = geom[level[h]];
-        kx[h] = (int)(kv & 0xfff) + 16; ky[h] = (int)((kv >> 12) & 0xfff) + 16;
+        kx[h] = (int)(kv & 0xfff) + 16; ky[h] = (int)((kv >> 12) & 0xfff) + 16;   // += minBorder (:843-844)
         score[h] = kv >> 24;
         const int ax = (kx[h] - 18) & ~3;
         xoff[h] = (kx[h] - 18) - ax;
         const uint8_t* img = (level[h] == 0) ? src0.base + (size_t)f * src0.fstride : pyr.base + (size_t)f * pyr.fstride + g.img_off;
         const int pitch = (level[h] == 0) ? src0.pitch : g.pitch;
         const int bpitch = g.bpitch;
+        // rows ky - 18 .. ky + 18 of the blurred level from the 4-byte-aligned column at or below kx - 18: 48 bytes a row (40 used; a
+        // row's last chunk may end up to 9 bytes past the level's width: the next row, or the slack behind the last one)
         const uint8_t* bimg = blur.base + (size_t)f * blur.fstride + g.blur_off + (off24(ky[h] - 18, bpitch) + (uint32_t)ax);
-        {
-            int rr = lane / 10, c = lane - rr * 10;
-#pragma unroll
-            for (int k = 0; k < 6; k++) {
-                const bool in = k * 64 + lane < 370;
-                wv[h][k] = *reinterpret_cast<const uint32_t*>(bimg + (off24(in ? rr : 36, bpitch) + (uint32_t)(4 * (in ? c : 9))));
-                rr += 6; c += 4;
-                if (c >= 10) { c -= 10; rr++; }
-            }
-        }
+        wv[h][0] = *reinterpret_cast<const u32x4_unaligned*>(bimg + (uint32_t)(__mul24(r0, bpitch) + c0));
+        wv[h][1] = *reinterpret_cast<const u32x4_unaligned*>(bimg + (uint32_t)(__mul24(wr1, bpitch) + c1));
+        // rows ky - 15 .. ky + 15 of the level itself from the aligned column at or below kx - 15 (36 bytes used)
         const int axp = (kx[h] - 15) & ~3;
         xo[h] = (kx[h] - 15) - axp;
         const uint8_t* pimg = img + (off24(ky[h] - 15, pitch) + (uint32_t)axp);
-        {
-            int rr = lane / 9, c = lane - rr * 9;
-#pragma unroll
-            for (int k = 0; k < 5; k++) {
-                const bool in = k * 64 + lane < 279;
-                v[h][k] = *reinterpret_cast<const u32_unaligned*>(pimg + (off24(in ? rr : 30, pitch) + (uint32_t)(4 * (in ? c : 8))));
-                rr += 7; c += 1;
-                if (c >= 9) { c -= 9; rr++; }
-            }
-        }
+        v[h][0] = *reinterpret_cast<const u32x4_unaligned*>(pimg + (uint32_t)(__mul24(r0, pitch) + c0));
+        v[h][1] = *reinterpret_cast<const u32x4_unaligned*>(pimg + (uint32_t)(__mul24(pr1, pitch) + c1));
     }
+    // a chunk goes into its 40-byte LDS row as 8-byte halves; the second half of a row's last chunk would be the next row's first bytes
+    auto put_chunk = [&](uint8_t* base, int row, int c, const u32x4& q) {
+        uint2* d = reinterpret_cast<uint2*>(base + row * 40 + c);
+        d[0] = make_uint2(q.x, q.y);
+        if (c != 32) d[1] = make_uint2(q.z, q.w);
+    };
 #pragma unroll
     for (int h = 0; h < 2; h++) {
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            const int idx = k * 64 + lane;
-            if (idx < 279) reinterpret_cast<uint32_t*>(s_pat[wid][h])[idx] = v[h][k];
-        }
+        put_chunk(&s_pat[wid][h][0], r0, c0, v[h][0]);
+        put_chunk(&s_pat[wid][h][0], pr1, c1, v[h][1]);
     }
     __builtin_amdgcn_wave_barrier();
-    // ---- IC_Angle of both keypoints: lane = (keypoint, patch row)
+    // ---- IC_Angle of both keypoints: lane = (keypoint, patch row v = r - 15): the row's 31 bytes as eight dwords re-cut at the byte
+    // offset xo, m10 = sum (i - 15) I = dot(I, i) - 15 dot(I, 1) and m01 = v dot(I, 1) over the row's part of the circular patch
+    // (umax, ORBextractor.cc:454-469), with the two weight vectors of the row (byte index i, ones; zero outside |u| <= umax(|v|))
     int m10 = 0, m01 = 0;
     if (r < 31) {
-        const uint32_t* rw = reinterpret_cast<const uint32_t*>(&s_pat[wid][0][0] + half * PATB + r * 36);
+        const uint32_t* rw = reinterpret_cast<const uint32_t*>(&s_pat[wid][0][0] + half * PATB + r * PROW);
         const int sh = half ? xo[1] : xo[0];
         uint32_t d[9];
 #pragma unroll
@@ -1706,10 +1571,15 @@ __global__ __launch_bounds__(256) OD2_ATTR void k_orient_describe2(ImgView src0,
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     float a, b;
     orbfe_sincosf(angle * factorPI, &b, &a); // a = cos, b = sin
-    // ---- steered BRIEF, one keypoint after the other on all lanes (see k_orient_describe for the arithmetic)
+    // ---- steered BRIEF on the staged window, one keypoint after the other on all lanes
+    // The rotation is separate multiplies and adds (the reference is compiled without fused multiply-add) on packed f32: the two
+    // points of a test side by side, (x0, x1) (b, b) + (y0, y1) (a, a), six v_pk_* instead of twelve scalar operations.  cvRound
+    // is "add 1.5 * 2^23": the sum is rounded to an integer by the adder (to nearest even, like cvRound), and its low mantissa
+    // bits are that integer plus 2^22; row * 40 + column is then one 24-bit multiply-add on the raw bits, the constants folded
+    // into the window's base address.  (The pattern as a float4 table saves 32 conversions per lane but quadruples the table: slower.)
     typedef float v2f __attribute__((ext_vector_type(2)));
-    constexpr uint32_t MAGIC_BITS = 0x4B400000u;
-    constexpr uint32_t IDX_BIAS = (MAGIC_BITS & 0xffffffu) * 40u + MAGIC_BITS;
+    constexpr uint32_t MAGIC_BITS = 0x4B400000u;                                      // 12582912.0f = 1.5 * 2^23
+    constexpr uint32_t IDX_BIAS = (MAGIC_BITS & 0xffffffu) * 40u + MAGIC_BITS;         // what the raw-bit multiply-add carries along
     const v2f magic = {12582912.0f, 12582912.0f};
 #pragma unroll
     for (int h = 0; h < 2; h++) {
@@ -1718,11 +1588,8 @@ __global__ __launch_bounds__(256) OD2_ATTR void k_orient_describe2(ImgView src0,
         const v2f aa = {ah, ah}, bb = {bh, bh};
         uint8_t* win = &s_pat[wid][0][0];
         __builtin_amdgcn_wave_barrier();   // the patches (h = 0) / the first window (h = 1) have been read
-#pragma unroll
-        for (int k = 0; k < 6; k++) {
-            const int idx = k * 64 + lane;
-            if (idx < 370) reinterpret_cast<uint32_t*>(win)[idx] = wv[h][k];
-        }
+        put_chunk(win, r0, c0, wv[h][0]);
+        put_chunk(win, wr1, c1, wv[h][1]);
         __builtin_amdgcn_wave_barrier();
         const uint8_t* bc = win + 18 * 40 + 18 + xoff[h];
         unsigned long long words[4];
@@ -1731,8 +1598,8 @@ __global__ __launch_bounds__(256) OD2_ATTR void k_orient_describe2(ImgView src0,
             const uint32_t pp = pat[j];
             const v2f X = {(float)(signed char)(pp & 0xff), (float)(signed char)((pp >> 16) & 0xff)};
             const v2f Y = {(float)(signed char)((pp >> 8) & 0xff), (float)(signed char)(pp >> 24)};
-            const v2f R = (X * bb + Y * aa) + magic;
-            const v2f C = (X * aa - Y * bb) + magic;
+            const v2f R = (X * bb + Y * aa) + magic;   // rows of the two points (-ffp-contract=off: no fused multiply-add)
+            const v2f C = (X * aa - Y * bb) + magic;   // columns
             const uint32_t i0 = __umul24(__float_as_uint(R.x), 40u) + __float_as_uint(C.x) - IDX_BIAS;
             const uint32_t i1 = __umul24(__float_as_uint(R.y), 40u) + __float_as_uint(C.y) - IDX_BIAS;
             const int t0 = bc[(int)i0], t1 = bc[(int)i1];
@@ -1744,6 +1611,7 @@ __global__ __launch_bounds__(256) OD2_ATTR void k_orient_describe2(ImgView src0,
                 reinterpret_cast<unsigned long long*>(desc + ((size_t)f * capacity + o0 + h) * 32)[lane] = wd;
             }
             if (lane == h * 32) {
+                // the final record (octave, size, scaled coordinates; :837-847, :1095-1101)
                 const LevelGeom& g = geom[level[h]];
                 orbfe_keypoint kp;
                 float px = (float)kx[h], py = (float)ky[h];

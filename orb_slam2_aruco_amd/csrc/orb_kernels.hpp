@@ -92,10 +92,6 @@ __global__ void k_level_offsets(const int32_t* lvl_cnt, int32_t* lvl_off, int32_
                                 int out_fstride, uint32_t* flat_kv, uint8_t* flat_lvl);
 template <bool ED> __global__ void k_blur7(ImgView src0, ImgView pyr, ImgView blur, const LevelGeom* geom, const uint32_t* strips, int nx,
                         int total);
-__global__ void k_orient_describe(ImgView src0, ImgView pyr, ImgView blur, const LevelGeom* geom,
-                                  const uint32_t* flat_kv, const uint8_t* flat_lvl, const int32_t* n_out, int nlevels,
-                                  const uint32_t* pattern32, const uint4* icw, orbfe_keypoint* kps, uint8_t* desc,
-                                  int capacity, int nx, int total);
 __global__ void k_orient_describe2(ImgView src0, ImgView pyr, ImgView blur, const LevelGeom* geom,
                                   const uint32_t* flat_kv, const uint8_t* flat_lvl, const int32_t* n_out, int nlevels,
                                   const uint32_t* pattern32, const uint4* icw, orbfe_keypoint* kps, uint8_t* desc,

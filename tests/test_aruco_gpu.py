@@ -425,6 +425,7 @@ def test_tiled_path_completes_on_stream_frames(orbfe, rows, cols, dict_name):
     nf = 40 if rows < 1080 else 34
     imgs = synth.stream(rows, cols, nf, 4242, dict_name, n_markers=4)
     ref = orbfe.MarkerDetector(dict_name)
+    ref.set_speck_passes_in_kernel(False)      # (so that the numbers of start candidates are comparable)
     want = ref.detect_batch(imgs)
     wkeys = [(_rects_key(ref, f), ref.counts(f)) for f in range(nf)]
     assert ref.contour_retries() == 0
@@ -555,6 +556,35 @@ def test_speck_passes_change_no_result(orbfe):
             assert (cnt["nkept"], cnt["nrect"]) == (c2["nkept"], c2["nrect"]) and c2["flags"] == 0
             assert c2["ncand"] * 2 < cnt["ncand"], (mode, f, c2["ncand"], cnt["ncand"])     # (both counts are after the run tests)
     assert sum(len(w) for w in want) > 0
+
+
+def test_speck_passes_inside_the_relay_kernels(orbfe):
+    """Full batches of frames whose bit image fits LDS go to the one-workgroup relay kernels, which run the speck passes on the image
+    they hold (speck_pass_frame) -- by default.  Same function of the image as the launch of its own: the same number of start
+    candidates per frame as with k_speck_clean in front of the same kernels, fewer than half of what they walk without the passes
+    (clean frames; fewer on noisy ones),
+    and rectangles, kept borders and markers are those of the run without."""
+    imgs = synth.stream(480, 640, 40, 2468, "ARUCO", n_markers=4)
+    rng = np.random.default_rng(2468)
+    for f in range(1, 40, 2):      # every other frame with sensor noise: specks everywhere, also touching the markers' borders
+        imgs[f] = np.clip(imgs[f].astype(np.int32) + rng.integers(-12, 13, imgs[f].shape), 0, 255).astype(np.uint8)
+    runs = {}
+    for mode in ("inside", "launch", "none"):
+        det = orbfe.MarkerDetector("ARUCO")
+        det.set_speck_passes_in_kernel(mode == "inside")
+        det.set_speck_passes(mode == "launch")
+        out = det.detect_batch(imgs)
+        runs[mode] = (out, [(_rects_key(det, f), det.counts(f)) for f in range(len(imgs))])
+        assert det.contour_retries() == 0
+    for f in range(len(imgs)):
+        (c0, l0), n0 = runs["none"][1][f]
+        for mode in ("inside", "launch"):
+            (c1, l1), n1 = runs[mode][1][f]
+            assert np.array_equal(runs[mode][0][f], runs["none"][0][f]) and np.array_equal(c0, c1) and np.array_equal(l0, l1), (mode, f)
+            assert (n0["nkept"], n0["nrect"]) == (n1["nkept"], n1["nrect"]) and n1["flags"] == 0
+        assert runs["inside"][1][f][1]["ncand"] == runs["launch"][1][f][1]["ncand"], f
+        assert runs["inside"][1][f][1]["ncand"] * (2 if f % 2 == 0 else 1) < n0["ncand"], f     # (noise makes blobs larger than a window too)
+    assert sum(len(w) for w in runs["none"][0]) > 0
 
 
 def test_dense_noise_frame_in_a_small_batch(orbfe, oracle):

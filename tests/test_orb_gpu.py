@@ -166,18 +166,6 @@ def test_gaussian_tap_variants(orbfe, oracle):
         ex.set_gaussian_taps(2)
 
 
-@pytest.mark.parametrize("pair", ["0", "1"])
-def test_both_descriptor_kernels(pair):
-    """k_orient_describe2 (two keypoints per wave share fastAtan2 / sincos and the IC_Angle pass; the default since round 3) and
-    k_orient_describe (ORBFE_ORIENT_PAIR=0: one keypoint per wave) must give the same keypoints and descriptors: the end-to-end
-    cases of this file in a process with the switch set either way."""
-    import os, subprocess, sys
-    env = dict(os.environ, ORBFE_ORIENT_PAIR=pair)
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "stages_and_end_to_end"],
-                       env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-
-
 def test_hipgraph_replay_of_the_host_pointer_call():
     """ORBFE_GRAPH=1: from the third call with one frame size on, orbfe_extract replays its upload, launches and result copies as a
     hipGraph captured inside the library.  The end-to-end cases (several frames of one size through one handle) in a process with the
