@@ -417,8 +417,7 @@ struct orbfe_extractor {
         auto launch_fast = [&](hipStream_t st, int cell_base, int cell_end) -> int {
             if (cell_end <= cell_base) return ORBFE_OK;
             // LDS per wave: ROI (cell + 6), score map (cell + 2), one u16 list of cell pixels
-            // +1 byte shift, +2 dwords read past a row (8-pixel groups); rows are staged in 16-byte chunks
-            const int roi_pitch = align_up(max_wcell + 6 + 4 + 8, 16), roi_rows = max_hcell + 6;
+            const int roi_pitch = align_up(max_wcell + 6 + 4, 4) + 8, roi_rows = max_hcell + 6; // +1 byte shift, +2 dwords read past a row (8-pixel groups)
             const int map_pitch = max_wcell + 2, map_rows = max_hcell + 2;
             const int list_cap = max_wcell * max_hcell;
             auto a16 = [](size_t v) { return (v + 15) & ~(size_t)15; };

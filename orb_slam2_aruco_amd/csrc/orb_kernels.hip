@@ -327,35 +327,36 @@ __global__ __launch_bounds__(256) void k_fast_cells(ImgView src0, ImgView pyr, c
     const int pitch = (level == 0) ? src0.pitch : g.pitch;
     const int SP = roi_pitch, MP = map_pitch;
 
-    // stage the ROI (columns -1 .. w-1: the one-byte shift) with unaligned 16-byte loads, two in flight per lane.  A lane keeps its
-    // chunk column and takes every (64 / n16)-th row: its image and LDS offsets advance by constants (uniform base + 32-bit lane offset).
-    // (Until round 5 the unit was a dword, 8 in flight: 87 of the kernel's ~780 VALU instructions per wave were this loop's address
-    // arithmetic; a row is three chunks, so a 36-row ROI is two loads per lane.)  roi_pitch is a multiple of 16 and covers the chunks.
+    // stage the ROI (columns -1 .. w-1: the one-byte shift) with unaligned dword loads, 8 in flight per lane.  A lane keeps its
+    // dword column and takes every (64 / ndw)-th row: its image and LDS offsets advance by constants (uniform base + 32-bit lane
+    // offset, one addition each per load -- the flat (row, dword) numbering cost a wrap test, three selects and a 64-bit
+    // multiply-add per item: 115 of the kernel's ~890 VALU instructions per wave); the 64 % ndw lanes left over idle here.
+    // (16-byte chunks, three to a row and two loads a lane, save 42 of these instructions and are no faster at 640 x 480 -- and 3 % slower
+    // alone, 18 % in the pipeline, at 1920 x 1080, where the step then loses 3.5 %: unaligned 16-byte lanes straddle sectors)
     {
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        typedef u32x4 u32x4_unaligned __attribute__((aligned(1)));
-        const int n16 = (w + 16) >> 4;
-        const int rpi = 64 / n16;                      // rows per trip of the wave
-        const int y0 = (int)(((float)lane + 0.5f) * (1.0f / (float)n16)), c = lane - __mul24(y0, n16); // exact: lane < 64
+        typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+        const int ndw = (w + 4) >> 2;
+        const int rpi = 64 / ndw;                      // rows per trip of the wave
+        const int y0 = (int)(((float)lane + 0.5f) * (1.0f / (float)ndw)), c = lane - __mul24(y0, ndw); // exact: lane < 64
         const uint8_t* roi = img + (size_t)iniY * pitch + iniX - 1;
-        uint32_t go = (uint32_t)(__mul24(y0, pitch) + 16 * c), so_ = (uint32_t)(__mul24(y0, SP) + 16 * c);
+        // (24-bit multiplies fold into v_mad_u32_u24 with the column offset)
+        uint32_t go = (uint32_t)(__mul24(y0, pitch) + 4 * c), so_ = (uint32_t)(__mul24(y0, SP) + 4 * c);
         const uint32_t gstep = (uint32_t)(rpi * pitch), sstep = (uint32_t)(rpi * SP);
         // no predicates (a load under a condition becomes a branch with a wait behind it): a row past the end -- and with it the
-        // lanes left over -- takes the ROI's last row, i.e. loads and stores that row's chunk once more
-        const uint32_t go_last = (uint32_t)((h - 1) * pitch + 16 * c), so_last = (uint32_t)((h - 1) * SP + 16 * c);
-        for (int r0 = 0; r0 < h; r0 += 2 * rpi) {
-            u32x4 v[2];
-            uint32_t so[2];
+        // lanes left over -- takes the ROI's last row, i.e. loads and stores that row's dword once more
+        const uint32_t go_last = (uint32_t)((h - 1) * pitch + 4 * c), so_last = (uint32_t)((h - 1) * SP + 4 * c);
+        for (int r0 = 0; r0 < h; r0 += 8 * rpi) {
+            uint32_t v[8], so[8];
 #pragma unroll
-            for (int k = 0; k < 2; k++) {
+            for (int k = 0; k < 8; k++) {
                 const bool in = r0 + k * rpi + y0 < h;
                 const uint32_t g_ = in ? go + (uint32_t)k * gstep : go_last;
                 so[k] = in ? so_ + (uint32_t)k * sstep : so_last;
-                v[k] = *reinterpret_cast<const u32x4_unaligned*>(roi + g_);
+                v[k] = *reinterpret_cast<const u32_unaligned*>(roi + g_);
             }
 #pragma unroll
-            for (int k = 0; k < 2; k++) *reinterpret_cast<u32x4*>(simg + so[k]) = v[k];
-            go += 2 * gstep; so_ += 2 * sstep;
+            for (int k = 0; k < 8; k++) *reinterpret_cast<uint32_t*>(simg + so[k]) = v[k];
+            go += 8 * gstep; so_ += 8 * sstep;
         }
     }
     for (int i = lane; i < (int)(map_bytes / 4); i += 64) reinterpret_cast<uint32_t*>(smap)[i] = 0;
