@@ -975,7 +975,7 @@ class MarkerDetector:
         self.L.orbfe_aruco_debug_kernel_times(self.h, None, 8 if on else 9)
 
     def set_speck_passes_in_kernel(self, on=True):
-        """Debug: the speck passes inside the one-workgroup relay kernels (full batches of frames whose bit image fits LDS) on (default) / off."""
+        """Debug: the speck passes inside the one-workgroup relay kernels (full batches of frames whose bit image fits LDS) on / off (default)."""
         self.L.orbfe_aruco_debug_kernel_times(self.h, None, 10 if on else 11)
 
     def contour_image(self, frame=0):

@@ -97,15 +97,18 @@ struct orbfe_aruco {
     bool ct_tab_dirty = true;
     DevBuf d_ctseg, d_cthtab, d_ctelem, d_ctstate, d_ctitemsA, d_ctitemsB, d_ctnitems, d_ctcodes;
     // The speck passes (aruco_trace.hpp "FEWER WALKS" (2)): result-neutral, a quarter of the contour stage's start candidates and walks
-    // gone.  Two places to run them:
-    //   inside the one-workgroup relay kernels, on the bit image they hold in LDS anyway (speck_pass_frame) -- the DEFAULT for the
-    //     batches that take those kernels (more than 32 frames whose image fits LDS): contour stage of 300 x 640 x 480 alone 462 -> 440 us;
-    //   as a launch of their own between threshold and contours (k_speck_clean), for every contour path: 462 -> 408 us alone, but one
-    //     more launch on the detector's chain costs the pipeline more than that (C2 step 1.40 - 1.46 against 1.34 - 1.38 ms, single-
-    //     frame detect 0.357 against 0.358 ms; profiles/r05_contour_reductions_ab.txt): off by default.
-    // ORBFE_ARUCO_SPECKS = 0: neither; = 1: the launch (and then not inside).  Debug codes 8 / 9: the launch on / off, 10 / 11: inside.
+    // gone -- and OFF by default, because neither way of running them pays in the pipeline:
+    //   = 1: as a launch of their own between threshold and contours (k_speck_clean), for every contour path: the contour stage of
+    //     300 x 640 x 480 alone 462 -> 408 us, but one more launch on the detector's chain costs the pipeline more than that (C2 step
+    //     1.40 - 1.46 against 1.34 - 1.38 ms, single-frame detect 0.357 against 0.358 ms; profiles/r05_contour_reductions_ab.txt);
+    //   = 2: inside the one-workgroup relay kernels, on the bit image they hold in LDS anyway (speck_pass_frame; batches of more than
+    //     32 frames whose image fits LDS): 462 -> 440 us alone and 140 -> 120 us of VALU issue, the C2 step unchanged (1.343 against
+    //     1.333 ms, four interleaved runs) -- and the rim masks and anchors of a frame (120 KB) go through scratch in HBM, which
+    //     doubles the stage's HBM traffic (148 -> 268 MB per step).
+    // ORBFE_ARUCO_SPECKS = 0 (default) / 1 / 2.  Debug codes 8 / 9: the launch on / off, 10 / 11: inside.  Tested either way
+    // (tests/test_aruco_gpu.py, tests/test_stress_gpu.py).
     int specks = getenv("ORBFE_ARUCO_SPECKS") && atoi(getenv("ORBFE_ARUCO_SPECKS")) == 1 ? 1 : 0;
-    bool specks_inkernel = !getenv("ORBFE_ARUCO_SPECKS") || !*getenv("ORBFE_ARUCO_SPECKS");
+    bool specks_inkernel = getenv("ORBFE_ARUCO_SPECKS") && atoi(getenv("ORBFE_ARUCO_SPECKS")) == 2;
     bool specks_ran = false;   // the last batch's contour kernels read d_bitsc
     DevBuf d_bitsc;
     bool relay_global = false; // k_contours_relay8g: the bit image stays in HBM (it does not fit LDS)
@@ -1553,7 +1556,7 @@ int orbfe_aruco_debug_kernel_times(orbfe_aruco* h, float* out_us, int capacity)
                    // 7 returns the number of batches that were done again on the next contour path, 8 / 9 the speck passes on / off
         if (capacity == 7) return h->n_escalations;
         if (capacity == 8 || capacity == 9) { h->specks = capacity == 8 ? 1 : 0; return 0; }   // the speck passes on / off (default)
-        if (capacity == 10 || capacity == 11) { h->specks_inkernel = capacity == 10; return 0; }   // ... inside the relay kernels on (default) / off
+        if (capacity == 10 || capacity == 11) { h->specks_inkernel = capacity == 10; return 0; }   // ... inside the relay kernels on / off (default)
         if (capacity == 2 || capacity == 3) h->force_legacy = capacity == 2;
         else if (capacity >= 4 && capacity <= 6) {
             const int t = capacity == 4 ? -1 : capacity == 5 ? 1 : 0;

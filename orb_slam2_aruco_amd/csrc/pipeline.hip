@@ -266,7 +266,7 @@ const char* orbfe_pipeline_env_defaults(void)
     // one list for the pipeline and the engines: bench.py marks a line as diagnostic when one of these is set to something else
     return "ORBFE_ENGINE_SETS=2;ORBFE_ENGINE_SETS_ARUCO=1;ORBFE_RECORD_SETS=4;ORBFE_PHASE_PIN=size;ORBFE_DET_PIN=4;ORBFE_DEFER_POST=size;ORBFE_DET_NOFORK=size;"
            "ORBFE_ARUCO_RELAY_WIDE=1;"
-           "ORBFE_ARUCO_SPECKS=;ORBFE_ARUCO_SMALL_SEPARATE=size;ORBFE_ARUCO_TILED=size;ORBFE_ARUCO_TILE_W=0;ORBFE_ARUCO_TPW=0;ORBFE_ARUCO_BANDED=size;ORBFE_ARUCO_BAND_ROWS=0;ORBFE_ARUCO_LCAP=0;ORBFE_GRAPH=0;"
+           "ORBFE_ARUCO_SPECKS=0;ORBFE_ARUCO_SMALL_SEPARATE=size;ORBFE_ARUCO_TILED=size;ORBFE_ARUCO_TILE_W=0;ORBFE_ARUCO_TPW=0;ORBFE_ARUCO_BANDED=size;ORBFE_ARUCO_BAND_ROWS=0;ORBFE_ARUCO_LCAP=0;ORBFE_GRAPH=0;"
            "ORBFE_NO_LEND=0;ORBFE_GRAPH_VERBOSE=0;ORBFE_RCCL_LIB=";
 }
 

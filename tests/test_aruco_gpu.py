@@ -425,7 +425,6 @@ def test_tiled_path_completes_on_stream_frames(orbfe, rows, cols, dict_name):
     nf = 40 if rows < 1080 else 34
     imgs = synth.stream(rows, cols, nf, 4242, dict_name, n_markers=4)
     ref = orbfe.MarkerDetector(dict_name)
-    ref.set_speck_passes_in_kernel(False)      # (so that the numbers of start candidates are comparable)
     want = ref.detect_batch(imgs)
     wkeys = [(_rects_key(ref, f), ref.counts(f)) for f in range(nf)]
     assert ref.contour_retries() == 0
@@ -559,8 +558,8 @@ def test_speck_passes_change_no_result(orbfe):
 
 
 def test_speck_passes_inside_the_relay_kernels(orbfe):
-    """Full batches of frames whose bit image fits LDS go to the one-workgroup relay kernels, which run the speck passes on the image
-    they hold (speck_pass_frame) -- by default.  Same function of the image as the launch of its own: the same number of start
+    """Full batches of frames whose bit image fits LDS go to the one-workgroup relay kernels, which can run the speck passes on the image
+    they hold (speck_pass_frame; ORBFE_ARUCO_SPECKS=2).  Same function of the image as the launch of its own: the same number of start
     candidates per frame as with k_speck_clean in front of the same kernels, fewer than half of what they walk without the passes
     (clean frames; fewer on noisy ones),
     and rectangles, kept borders and markers are those of the run without."""

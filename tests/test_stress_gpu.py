@@ -34,7 +34,7 @@ def test_detector_on_random_frames_dictionaries_and_rates():
 
 def test_detector_with_the_speck_passes_on_random_frames():
     """The same random frames (other seed) and the detector-mode sequences with the speck passes as a launch of their own (ORBFE_ARUCO_SPECKS=1: a
-    shipped switch; by default they run inside the relay kernels of full batches, tests/test_aruco_gpu.py): what they clear never changes a marker, a corner or a rectangle candidate."""
+    shipped switch, off by default; inside the relay kernels of full batches: tests/test_aruco_gpu.py): what they clear never changes a marker, a corner or a rectangle candidate."""
     out = _run("stress_aruco.py", 100, 505, env={"ORBFE_ARUCO_SPECKS": "1"})
     m = re.search(r"(\d+) cases, (\d+) mismatches", out)
     assert m and int(m.group(1)) == 100 and int(m.group(2)) == 0, out[-3000:]
