@@ -109,6 +109,11 @@ struct orbfe_aruco {
     // (tests/test_aruco_gpu.py, tests/test_stress_gpu.py).
     int specks = getenv("ORBFE_ARUCO_SPECKS") && atoi(getenv("ORBFE_ARUCO_SPECKS")) == 1 ? 1 : 0;
     bool specks_inkernel = getenv("ORBFE_ARUCO_SPECKS") && atoi(getenv("ORBFE_ARUCO_SPECKS")) == 2;
+    orbfe_extractor* gate_ex = nullptr;   // aruco_set_contours_gate()
+    int gate_stage = 0;
+    hipEvent_t ev_contours = nullptr;   // behind the contour kernels (+ approxPolyDP) of the newest batch: aruco_contours_wait()
+    bool contours_recorded = false;
+    bool thr_v2 = !(getenv("ORBFE_ARUCO_THR_V2") && atoi(getenv("ORBFE_ARUCO_THR_V2")) == 0);   // k_threshold_pyr (measurement switch; debug code 12 / 13)
     bool specks_ran = false;   // the last batch's contour kernels read d_bitsc
     DevBuf d_bitsc;
     bool relay_global = false; // k_contours_relay8g: the bit image stays in HBM (it does not fit LDS)
@@ -171,6 +176,7 @@ struct orbfe_aruco {
         if (aux_stream) (void)hipStreamDestroy(aux_stream);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
+        if (ev_contours) (void)hipEventDestroy(ev_contours);
     }
 
     int set_dictionary(const char* name)
@@ -437,12 +443,36 @@ struct orbfe_aruco {
         ImgView pyr{d_pyr.as<uint8_t>(), d_pyr.as<uint8_t>(), pyr_fbytes, 0};
         timer.begin();
         timer.mark(s, "start");
-        // the /2 pyramid is only needed by k_decode: it runs on a second stream next to threshold + contours
+        // The threshold kernel of the batched configuration writes the pyramid levels its 64 x 64 tiles hold whole (k_threshold_pyr): the
+        // exact halvings, at most four, when the pyramid starts from the thresholded frame itself and n v + K stays within 16 bits
+        int nfuse = 0;
+        uint32_t thr_kk = 0;
+        {
+            const long n2 = (long)win * win, K = n2 * thres_value - n2 / 2;
+            const bool adaptive = !(mr && mr->fixed_thr >= 0);
+            if (adaptive && thr_v2 && th_magic && (win == 5 || win == 7 || win == 11 || win == 15) && K >= 0 && n2 * 255 + K <= 65535) {
+                thr_kk = (uint32_t)K | ((uint32_t)K << 16);
+                nfuse = -1;   // the kernel applies, with no level so far
+                if (!reduced)
+                    for (int p = 1; p < npyr && p <= 4; p++) {
+                        if (!lvl_exact[p] || levels[p].pitch % 4 != 0 || levels[p].pitch < 4 * ((levels[p].w + 3) / 4)) break;
+                        nfuse = p;
+                    }
+            }
+        }
+        const bool thr_pyr = nfuse != 0;
+        if (nfuse < 0) nfuse = 0;
+        // the /2 pyramid is only needed by k_decode: it runs on a second stream next to threshold + contours (what the threshold kernel
+        // leaves of it: behind that kernel, in line)
         hipStream_t aux_stream = user_aux ? user_aux : this->aux_stream;
-        ORBFE_HIP(hipEventRecord(ev_fork, s));
-        ORBFE_HIP(hipStreamWaitEvent(aux_stream, ev_fork, 0));
+        if (nfuse) aux_stream = s;
+        else {
+            ORBFE_HIP(hipEventRecord(ev_fork, s));
+            ORBFE_HIP(hipStreamWaitEvent(aux_stream, ev_fork, 0));
+        }
         timer.mark(aux_stream, "pyramid starts", true);
-        for (int p = 1; p < npyr; p++) {
+        auto rest_of_pyramid = [&](int first) -> int {
+        for (int p = first; p < npyr; p++) {
             const ArLevel& L = levels[p];
             const ArLevel& Lp = levels[p - 1];
             ImgView sv = (p == 1) ? src0 : ImgView{pyr.base + Lp.off, nullptr, pyr_fbytes, Lp.pitch};
@@ -459,8 +489,11 @@ struct orbfe_aruco {
                                    Lp.w, Lp.h, dw4, L.h, scale_x, scale_y, L.w);
             }
         }
+        return ORBFE_OK;
+        };
+        if (!nfuse && (rc = rest_of_pyramid(1))) return rc;
         timer.mark(aux_stream, "pyramid");
-        ORBFE_HIP(hipEventRecord(ev_join, aux_stream));
+        if (!nfuse) ORBFE_HIP(hipEventRecord(ev_join, aux_stream));
         int enlarge_k = win;   // detectEnclosedMarkers: the candidates grow by half the adaptive window, or half the erosion size
         for (int r_ = 0; r_ < ORBFE_REPS_ARUCO(8); r_++) {
             const dim3 tg((cols + 63) / 64, (rows + 63) / 64, B);
@@ -478,6 +511,15 @@ struct orbfe_aruco {
                     hipLaunchKernelGGL(k_erode_cross_xor, dim3((wpr * rows + 255) / 256, B), dim3(256), 0, s, d_bits2.as<uint32_t>(), bp, bits_fu32, wpr, cols, rows, k / 2);
                 } else
                     hipLaunchKernelGGL(k_fixed_threshold, dim3((wpr * rows + 255) / 256, B), dim3(256), 0, s, srcW, cols, rows, mr->fixed_thr, bp, bits_fu32, wpr);
+            } else if (thr_pyr) {
+                ThrPyr P{};
+                P.n = nfuse;
+                for (int p = 1; p <= nfuse; p++) { P.w[p - 1] = levels[p].w; P.h[p - 1] = levels[p].h; P.pitch[p - 1] = levels[p].pitch; P.off[p - 1] = levels[p].off; }
+                if (win == 5) hipLaunchKernelGGL(k_threshold_pyr<5>, tg1, dim3(256), 0, s, srcW, cols, rows, thr_kk, bp, bits_fu32, wpr, ntx, ntl, ntl * B, pyr, P);
+                else if (win == 7) hipLaunchKernelGGL(k_threshold_pyr<7>, tg1, dim3(256), 0, s, srcW, cols, rows, thr_kk, bp, bits_fu32, wpr, ntx, ntl, ntl * B, pyr, P);
+                else if (win == 11) hipLaunchKernelGGL(k_threshold_pyr<11>, tg1, dim3(256), 0, s, srcW, cols, rows, thr_kk, bp, bits_fu32, wpr, ntx, ntl, ntl * B, pyr, P);
+                else hipLaunchKernelGGL(k_threshold_pyr<15>, tg1, dim3(256), 0, s, srcW, cols, rows, thr_kk, bp, bits_fu32, wpr, ntx, ntl, ntl * B, pyr, P);
+                if (nfuse && r_ == 0 && (rc = rest_of_pyramid(nfuse + 1))) return rc;
             } else if (th_magic && win == 5) hipLaunchKernelGGL(k_adaptive_threshold_t<5>, tg1, dim3(256), 0, s, srcW, cols, rows, thres_value, th_magic, bp, bits_fu32, wpr, ntx, ntl, ntl * B);
             else if (th_magic && win == 7) hipLaunchKernelGGL(k_adaptive_threshold_t<7>, tg1, dim3(256), 0, s, srcW, cols, rows, thres_value, th_magic, bp, bits_fu32, wpr, ntx, ntl, ntl * B);
             else if (th_magic && win == 11) hipLaunchKernelGGL(k_adaptive_threshold_t<11>, tg1, dim3(256), 0, s, srcW, cols, rows, thres_value, th_magic, bp, bits_fu32, wpr, ntx, ntl, ntl * B);
@@ -504,6 +546,15 @@ struct orbfe_aruco {
         const bool use_tiled = (tiled > 0 || (tiled < 0 && (relay_global || !relay_tbits || relay_tbits > 12 || B <= 32))) && !tiled_off && !force_legacy && !big_mode;
         tiled_ran = use_tiled;
         const bool relay = (relay_tbits || use_tiled) && !force_legacy && !big_mode;
+        // the border walks -- the LDS-latency-bound kernels of the chain -- are enqueued: aruco_contours_wait() waits for this point
+        bool walks_marked = false;
+        auto walks_done = [&]() -> int {
+            if (!ev_contours) ORBFE_HIP(hipEventCreateWithFlags(&ev_contours, hipEventDisableTiming));
+            ORBFE_HIP(hipEventRecord(ev_contours, s));
+            contours_recorded = walks_marked = true;
+            return ORBFE_OK;
+        };
+        if (gate_ex && gate_stage && (rc = orbfe_extractor_stage_wait(gate_ex, gate_stage, s))) return rc;
         for (int r_ = 0; relay && r_ < ORBFE_REPS_ARUCO(1); r_++) {
             if (use_tiled) {
                 // Tile width and waves.  k_ct_walk's waves are persistent and overlap their tiles, so a wave wants several tiles (its
@@ -593,6 +644,7 @@ struct orbfe_aruco {
                                    d_tailoff.as<int32_t>(), d_counts.as<int32_t>());
             }
             } // (the relay kernels)
+            if ((rc = walks_done())) return rc;
             // (g): sort + rank per frame, approxPolyDP by persistent waves over the whole batch's borders, rectangles per frame
             {
                 const int pts = RT_PTS;   // LDS point buffer per wave; longer borders are read from the pool
@@ -619,6 +671,7 @@ struct orbfe_aruco {
                            d_rects.as<ArRect>(), AR_MAX_RECTS, d_counts.as<int32_t>(), d_gpad.as<uint32_t>(),
                            gpad_fu32, 0);
         timer.mark(s, "contours");
+        if (!walks_marked && (rc = walks_done())) return rc;   // (the single-walker kernel: walks and approxPolyDP are one launch)
         ORBFE_HIP(hipGetLastError());
         if (enclosed)   // enlargeMarkerCandidate on every rectangle, before prefilterCandidates sees them (:3560-3590)
             hipLaunchKernelGGL(k_enlarge_candidates, dim3(B), dim3(AR_MAX_RECTS), 0, s, d_rects.as<ArRect>(), AR_MAX_RECTS, d_counts.as<int32_t>(),
@@ -628,7 +681,7 @@ struct orbfe_aruco {
         hipLaunchKernelGGL(k_prefilter, dim3(B), dim3(256), 0, s, d_rects.as<ArRect>(), AR_MAX_RECTS,
                            d_counts.as<int32_t>(), cols, rows, win, d_candidx.as<int32_t>(), d_ncand.as<int32_t>(),
                            d_dwork.as<uint32_t>(), d_dctr.as<int32_t>());
-        ORBFE_HIP(hipStreamWaitEvent(s, ev_join, 0));
+        if (!nfuse) ORBFE_HIP(hipStreamWaitEvent(s, ev_join, 0));
         {
             // the batch's candidates as one work list: a wave per candidate (persistent: 32 candidates per frame is more than the
             // streams here produce, a busier batch loops), 64 candidates per Otsu wave
@@ -1140,6 +1193,12 @@ void aruco_unpair_notice(orbfe_aruco* h)
 }
 
 int aruco_device_of(const orbfe_aruco* h) { return h ? h->device : -1; }
+void aruco_set_contours_gate(orbfe_aruco* h, orbfe_extractor* ex, int stage) { if (h) { h->gate_ex = ex; h->gate_stage = ex ? stage : 0; } }
+int aruco_contours_wait(orbfe_aruco* h, hipStream_t stream)
+{
+    if (h && h->contours_recorded) ORBFE_HIP(hipStreamWaitEvent(stream, h->ev_contours, 0));
+    return ORBFE_OK;
+}
 
 } // namespace orbfe
 
@@ -1556,7 +1615,8 @@ int orbfe_aruco_debug_kernel_times(orbfe_aruco* h, float* out_us, int capacity)
                    // 7 returns the number of batches that were done again on the next contour path, 8 / 9 the speck passes on / off
         if (capacity == 7) return h->n_escalations;
         if (capacity == 8 || capacity == 9) { h->specks = capacity == 8 ? 1 : 0; return 0; }   // the speck passes on / off (default)
-        if (capacity == 10 || capacity == 11) { h->specks_inkernel = capacity == 10; return 0; }   // ... inside the relay kernels on / off (default)
+        if (capacity == 10 || capacity == 11) { h->specks_inkernel = capacity == 10; return 0; }
+        if (capacity == 12 || capacity == 13) { h->thr_v2 = capacity == 12; return 0; }   // the threshold kernel with the fused pyramid on (default) / off   // ... inside the relay kernels on / off (default)
         if (capacity == 2 || capacity == 3) h->force_legacy = capacity == 2;
         else if (capacity >= 4 && capacity <= 6) {
             const int t = capacity == 4 ? -1 : capacity == 5 ? 1 : 0;

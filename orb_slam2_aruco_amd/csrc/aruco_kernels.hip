@@ -213,6 +213,194 @@ template __global__ void k_adaptive_threshold_t<7>(ImgView, int, int, int, uint3
 template __global__ void k_adaptive_threshold_t<11>(ImgView, int, int, int, uint32_t, uint32_t*, size_t, int, int, int, int);
 template __global__ void k_adaptive_threshold_t<15>(ImgView, int, int, int, uint32_t, uint32_t*, size_t, int, int, int, int);
 
+// The threshold kernel of the batched path (round 6): the same horizontal pass, then
+//   vertical:   TWO row strips per lane on packed 16-bit lanes.  A wave owns rows 8 w .. 8 w + 7 (low halves) and 8 w + 32 .. 8 w + 39
+//               (high halves) of the tile; the box sums lie in LDS as (row q, row q + 32) pairs, so one ds_read_b32 feeds both strips,
+//               the sliding window is one v_pk_add_u16 + one v_pk_sub_u16 for 128 pixels, and "mean >= v + C", i.e.
+//               s + n/2 >= n (v + C) with n = WIN^2, is v_pk_mad_u16 (n v + K, K = n C - n/2 >= 0: the host checks the range) and one
+//               saturating v_pk_sub_u16 whose halves are zero where the pixel is set.  The two ballots of a row go into lanes k and 8 + k of
+//               two registers (v_writelane) and the 16 rows of a wave leave in ONE store instruction -- the per-row store of
+//               k_adaptive_threshold_t (address arithmetic on every lane for a store two lanes execute) was half of its vertical pass.
+//               12 -> ~5.5 instructions per 64 pixels and row.
+//   pyramid:    the detector's /2 pyramid (buildPyramid, markerdetector_impl.cpp:1299-1488; exact halving = the 2 x 2 mean) from the
+//               tile's own pixels, which are in LDS anyway: a 64 x 64 tile holds its 32 x 32, 16 x 16, 8 x 8 and 4 x 4 descendants whole.
+//               Four launches (k_half_area4) and a second read of every frame less on the detector's chain.
+typedef unsigned short th_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t th_quad(uint32_t r0, uint32_t r1) // two outputs (16-bit lanes) from one dword of each source row
+{
+    const uint32_t sum = (r0 & 0x00ff00ffu) + ((r0 >> 8) & 0x00ff00ffu) + (r1 & 0x00ff00ffu) + ((r1 >> 8) & 0x00ff00ffu) + 0x00020002u;
+    return (sum >> 2) & 0x00ff00ffu;
+}
+__device__ __forceinline__ uint32_t th_half4(uint2 a0, uint2 a1) // four outputs from eight pixels of two rows
+{
+    return __builtin_amdgcn_perm(th_quad(a0.y, a1.y), th_quad(a0.x, a1.x), 0x06040200u);
+}
+template <int WIN>
+__global__ __launch_bounds__(256) void k_threshold_pyr(ImgView src, int W, int H, uint32_t kk /* K | K << 16 */,
+                                                       uint32_t* __restrict__ bits, size_t bits_fstride, int wpr, int ntx, int ntiles,
+                                                       int total, ImgView pyr, ThrPyr P)
+{
+    constexpr int R = WIN / 2, NDW = R <= 3 ? 3 : 5, LEAD = R <= 3 ? 4 : 8; // window = bytes x - LEAD .. x - LEAD + 4 NDW - 1
+    constexpr int ROWS = 64 + 2 * R, QP = (32 + 2 * R) | 1;                   // pairs per LDS column: an odd number of dwords
+    __shared__ __align__(16) uint32_t shp[64 * QP];                           // (sum of row q, sum of row q + 32) of a column
+    __shared__ __align__(16) uint32_t spx[64][16];
+    __shared__ __align__(16) uint32_t l1[32][8];
+    __shared__ __align__(16) uint32_t l2[16][4];
+    __shared__ __align__(16) uint32_t l3[8][2];
+    int tile, f;
+    if (!xcd_remap(ntiles, total, tile, f)) return;
+    const int tyi = tile / ntx;
+    const int tx0 = (tile - tyi * ntx) * 64, ty0 = tyi * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint8_t* img = src.base + (size_t)f * src.fstride;
+    constexpr int NIT = (ROWS * 16 + 255) / 256;
+    uint32_t w[NIT][NDW];
+#pragma unroll
+    for (int k = 0; k < NIT; k++) {
+        const int it = tid + 256 * k;
+        const int rr = it >> 4, x = tx0 + 4 * (it & 15);
+#pragma unroll
+        for (int j = 0; j < NDW; j++) w[k][j] = 0;
+        if (rr < ROWS) {
+            const uint8_t* row = img + (uint32_t)__mul24(min(max(ty0 + rr - R, 0), H - 1), src.pitch); // BORDER_REPLICATE
+            if (x >= LEAD && x - LEAD + 4 * NDW <= W) {
+#pragma unroll
+                for (int j = 0; j < NDW; j++) w[k][j] = reinterpret_cast<const u32_unaligned_t*>(row + x - LEAD)[j];
+            } else {
+                // the window crosses the left or right image border: see k_adaptive_threshold_t
+                const uint32_t first = reinterpret_cast<const u32_unaligned_t*>(row)[0];
+                const uint32_t last = reinterpret_cast<const u32_unaligned_t*>(row + W - 4)[0];
+#pragma unroll
+                for (int j = 0; j < NDW; j++) {
+                    const int q = x - LEAD + 4 * j, n_in = W - q;
+                    if (q < 0) w[k][j] = __builtin_amdgcn_perm(0u, first, 0x00000000u);
+                    else if (n_in >= 4) w[k][j] = reinterpret_cast<const u32_unaligned_t*>(row + q)[0];
+                    else w[k][j] = __builtin_amdgcn_perm(0u, last, n_in <= 1 ? 0x03030303u : n_in == 2 ? 0x03030302u : 0x03030201u);
+                }
+            }
+        }
+    }
+    uint16_t* shh = reinterpret_cast<uint16_t*>(shp);
+#pragma unroll
+    for (int k = 0; k < NIT; k++) {
+        const int it = tid + 256 * k;
+        const int rr = it >> 4, c = 4 * (it & 15);
+        if (rr < ROWS) {
+            uint32_t sum[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                constexpr uint32_t ONES = 0x01010101u;
+                const int a = LEAD + i - R;
+                uint32_t acc = 0;
+#pragma unroll
+                for (int q = 0; q < (WIN + 3) / 4; q++) {
+                    const int b = a + 4 * q, j = b >> 2, sft = b & 3;                 // window bytes b .. b+3
+                    const uint32_t hi = j + 1 < NDW ? w[k][j + 1] : 0u;
+                    const uint32_t v = sft ? __builtin_amdgcn_alignbyte(hi, w[k][j], sft) : w[k][j];
+                    const int left = WIN - 4 * q;                                       // bytes still to add
+                    acc = bl_dot4_a(v, left >= 4 ? ONES : (ONES >> (8 * (4 - left))), acc);
+                }
+                sum[i] = acc;
+            }
+            // row rr is the low half of pair rr and the high half of pair rr - 32 (rows 32 .. 32 + 2 R - 1 are both)
+            if (rr < 32 + 2 * R) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) shh[((c + i) * QP + rr) * 2] = (uint16_t)sum[i];
+            }
+            if (rr >= 32) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) shh[((c + i) * QP + rr - 32) * 2 + 1] = (uint16_t)sum[i];
+            }
+            if (rr >= R && rr < 64 + R) spx[rr - R][it & 15] = w[k][LEAD / 4]; // the tile's own pixels x .. x+3
+        }
+    }
+    __syncthreads();
+    // vertical: lane = column, wave = rows 8 wid .. + 7 (low halves) and 8 wid + 32 .. + 39 (high halves)
+    {
+        const int c = lane, r0 = 8 * wid;
+        const uint32_t* hp = &shp[c * QP + r0];
+        uint32_t v[8 + 2 * R];
+#pragma unroll
+        for (int k = 0; k < 8 + 2 * R; k++) v[k] = hp[k];
+        th_u16x2 s = __builtin_bit_cast(th_u16x2, v[0]);
+#pragma unroll
+        for (int k = 1; k < WIN; k++) s += __builtin_bit_cast(th_u16x2, v[k]);
+        const unsigned long long xm = __ballot(tx0 + c < W);
+        const uint8_t* px = reinterpret_cast<const uint8_t*>(&spx[r0][0]) + c;
+        const th_u16x2 nn = {(unsigned short)(WIN * WIN), (unsigned short)(WIN * WIN)}, kv = __builtin_bit_cast(th_u16x2, kk);
+        uint32_t mlo = 0, mhi = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t pp = (uint32_t)px[k * 64] | ((uint32_t)px[(k + 32) * 64] << 16);
+            const th_u16x2 rhs = __builtin_bit_cast(th_u16x2, pp) * nn + kv;               // n v + K <= 65535 (host)
+            const uint32_t d = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(rhs, s)); // half == 0 <=> s >= n v + K
+            const unsigned long long ma = __ballot((d & 0xffffu) == 0u) & xm, mb = __ballot(d < 0x10000u) & xm;
+            // (this compiler has no writelane builtin; the ballots are scalar registers already)
+            asm("v_writelane_b32 %0, %1, %2" : "+v"(mlo) : "s"((uint32_t)ma), "n"(k));
+            asm("v_writelane_b32 %0, %1, %2" : "+v"(mhi) : "s"((uint32_t)(ma >> 32)), "n"(k));
+            asm("v_writelane_b32 %0, %1, %2" : "+v"(mlo) : "s"((uint32_t)mb), "n"(8 + k));
+            asm("v_writelane_b32 %0, %1, %2" : "+v"(mhi) : "s"((uint32_t)(mb >> 32)), "n"(8 + k));
+            if (k < 7) s = s + __builtin_bit_cast(th_u16x2, v[k + WIN]) - __builtin_bit_cast(th_u16x2, v[k]);
+        }
+        if (lane < 16) {
+            const int y = ty0 + r0 + 32 * (lane >> 3) + (lane & 7), word = tx0 >> 5;
+            if (y < H) {
+                uint32_t* o = bits + (size_t)f * bits_fstride + (uint32_t)(__mul24(y, wpr) + word);
+                o[0] = mlo;
+                if (word + 1 < wpr) o[1] = mhi;
+            }
+        }
+    }
+    // the /2 pyramid of the tile (uniform branches: P is a kernel argument)
+    if (P.n >= 1) {
+        uint8_t* pf = pyr.base_w + (size_t)f * pyr.fstride;
+        {
+            const int j = tid >> 3, d = tid & 7;
+            const uint2 a0 = *reinterpret_cast<const uint2*>(&spx[2 * j][2 * d]), a1 = *reinterpret_cast<const uint2*>(&spx[2 * j + 1][2 * d]);
+            const uint32_t o = th_half4(a0, a1);
+            l1[j][d] = o;
+            const int y = (ty0 >> 1) + j, x = (tx0 >> 1) + 4 * d;
+            if (y < P.h[0] && x < P.w[0]) *reinterpret_cast<uint32_t*>(pf + P.off[0] + (uint32_t)(__mul24(y, P.pitch[0]) + x)) = o;
+        }
+        if (P.n >= 2) {
+            __syncthreads();
+            if (tid < 64) {
+                const int j = tid >> 2, d = tid & 3;
+                const uint2 a0 = *reinterpret_cast<const uint2*>(&l1[2 * j][2 * d]), a1 = *reinterpret_cast<const uint2*>(&l1[2 * j + 1][2 * d]);
+                const uint32_t o = th_half4(a0, a1);
+                l2[j][d] = o;
+                const int y = (ty0 >> 2) + j, x = (tx0 >> 2) + 4 * d;
+                if (y < P.h[1] && x < P.w[1]) *reinterpret_cast<uint32_t*>(pf + P.off[1] + (uint32_t)(__mul24(y, P.pitch[1]) + x)) = o;
+            }
+        }
+        if (P.n >= 3) {
+            __syncthreads();
+            if (tid < 16) {
+                const int j = tid >> 1, d = tid & 1;
+                const uint2 a0 = *reinterpret_cast<const uint2*>(&l2[2 * j][2 * d]), a1 = *reinterpret_cast<const uint2*>(&l2[2 * j + 1][2 * d]);
+                const uint32_t o = th_half4(a0, a1);
+                l3[j][d] = o;
+                const int y = (ty0 >> 3) + j, x = (tx0 >> 3) + 4 * d;
+                if (y < P.h[2] && x < P.w[2]) *reinterpret_cast<uint32_t*>(pf + P.off[2] + (uint32_t)(__mul24(y, P.pitch[2]) + x)) = o;
+            }
+        }
+        if (P.n >= 4) {
+            __syncthreads();
+            if (tid < 4) {
+                const int j = tid;
+                const uint2 a0 = *reinterpret_cast<const uint2*>(&l3[2 * j][0]), a1 = *reinterpret_cast<const uint2*>(&l3[2 * j + 1][0]);
+                const uint32_t o = th_half4(a0, a1);
+                const int y = (ty0 >> 4) + j, x = tx0 >> 4;
+                if (y < P.h[3] && x < P.w[3]) *reinterpret_cast<uint32_t*>(pf + P.off[3] + (uint32_t)(__mul24(y, P.pitch[3]) + x)) = o;
+            }
+        }
+    }
+}
+template __global__ void k_threshold_pyr<5>(ImgView, int, int, uint32_t, uint32_t*, size_t, int, int, int, int, ImgView, ThrPyr);
+template __global__ void k_threshold_pyr<7>(ImgView, int, int, uint32_t, uint32_t*, size_t, int, int, int, int, ImgView, ThrPyr);
+template __global__ void k_threshold_pyr<11>(ImgView, int, int, uint32_t, uint32_t*, size_t, int, int, int, int, ImgView, ThrPyr);
+template __global__ void k_threshold_pyr<15>(ImgView, int, int, uint32_t, uint32_t*, size_t, int, int, int, int, ImgView, ThrPyr);
+
 // ---------------------------------------------------------------------------------------- specks --------------
 // The speck passes of aruco_trace.hpp ("FEWER WALKS" (2)) between the threshold and the contour kernels: what they clear has no border
 // of more than 68 points and changes no other border, and on textured frames it is most of the start candidates and a fifth of the

@@ -34,6 +34,11 @@ __global__ void k_adaptive_threshold(ImgView src, int W, int H, int win, int C, 
 template <int WIN>
 __global__ void k_adaptive_threshold_t(ImgView src, int W, int H, int C, uint32_t magic, uint32_t* bits,
                                        size_t bits_fstride, int wpr, int ntx, int ntiles, int total);
+// threshold + the /2 pyramid levels a 64 x 64 tile holds whole (levels 1 .. n <= 4 of the detector's pyramid), one launch
+struct ThrPyr { int n; int w[4], h[4], pitch[4]; long long off[4]; };
+template <int WIN>
+__global__ void k_threshold_pyr(ImgView src, int W, int H, uint32_t kk, uint32_t* bits, size_t bits_fstride, int wpr, int ntx, int ntiles,
+                                int total, ImgView pyr, ThrPyr P);
 // the run tests on the start candidates of the contour kernels (aruco_trace.hpp "FEWER WALKS" (1)); a build parameter so that a
 // library without them can be measured next to the shipped one (tools/build_variant.sh); result-neutral
 #ifndef ORBFE_CAND_FILTER

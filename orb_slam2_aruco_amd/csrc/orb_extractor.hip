@@ -99,6 +99,7 @@ struct orbfe_extractor {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork0 = nullptr, ev_join0 = nullptr;
     // orbfe_extractor_follow: this handle's batches start behind a stage of ANOTHER handle's latest batch (two engine sets of a
     // pipeline hold a fixed phase that way instead of whatever the contention of the moment settles on)
+    orbfe_aruco* fast_gate = nullptr;    // extractor_set_fast_gate(): FAST waits until this detector's newest batch has left its contour kernels
     orbfe_extractor* follow = nullptr;
     int follow_stage = 0;                // 1 = the other's FAST, 2 = its quadtree, 3 = its descriptors (the whole batch), 4 = its resize chain
     int follow_fast_stage = 0;           // a second gate in front of this handle's FAST (0 = none): the resize chain may run earlier
@@ -118,7 +119,7 @@ struct orbfe_extractor {
     std::vector<size_t> tab_off; // per level >= 1: offsets (in ints) of xofs, xalpha, yofs, ybeta in d_tabs
     DevBuf d_geom, d_cellinfo, d_tiles, d_tabs, d_pattern, d_umax;
     DevBuf d_pyr, d_blur, d_slots, d_cellcnt, d_keys, d_lvlout, d_lvlcnt, d_lvloff, d_lvlncand, d_overflow, d_fallback,
-        d_flatkv, d_flatlvl;
+        d_flatkv, d_flatlvl, d_worklist;
     int blur_place = 1;                  // where the blur is forked: 1 in front of FAST (default), 0 after FAST, 2 no fork (main stream, before orient)
     bool gaussian_ed = false;            // orbfe_extractor_set_gaussian_taps: 18 34 48 56 48 34 18 instead of 18 34 49 55 49 34 18
     // workgroups per CU the VALU-bound kernels may occupy (0 = what the hardware allows): the launch asks for LDS it does not use
@@ -139,7 +140,7 @@ struct orbfe_extractor {
     {
         for (DevBuf* b : {&d_geom, &d_cellinfo, &d_tiles, &d_tabs, &d_pattern, &d_umax, &d_pyr, &d_blur, &d_slots,
                           &d_cellcnt, &d_keys, &d_lvlout, &d_lvlcnt, &d_lvloff, &d_lvlncand, &d_overflow, &d_fallback, &d_flatkv,
-                          &d_flatlvl, &d_in,
+                          &d_flatlvl, &d_worklist, &d_in,
                           &d_kps, &d_desc, &d_nout})
             b->release();
         if (own_stream) (void)hipStreamDestroy(own_stream);
@@ -387,6 +388,10 @@ struct orbfe_extractor {
         if ((rc = d_lvloff.ensure((size_t)nlevels * 4 * B))) return rc;
         if ((rc = d_lvlncand.ensure((size_t)nlevels * 4 * B))) return rc;
         if ((rc = d_fallback.ensure((size_t)nlevels * 4 * B))) return rc;
+        // work list of the levels the count-pyramid quadtree gives up on: [0] = their number (zeroed here, and by k_level_offsets behind
+        // every batch), [4 ..] = frame * nlevels + level
+        if ((rc = d_worklist.ensure(((size_t)nlevels * B + 4) * 4))) return rc;
+        ORBFE_HIP(hipMemset(d_worklist.p, 0, 16));
         if (!d_overflow.p) { // zeroed here and whenever it is read: no memset launch per batch
             if ((rc = d_overflow.ensure(16))) return rc;
             ORBFE_HIP(hipMemset(d_overflow.p, 0, 16));
@@ -502,6 +507,7 @@ struct orbfe_extractor {
         if (blur_place == 1) { int rcb = launch_blur(); if (rcb) return rcb; }
         if (follow && follow != this && follow->stage_recorded && follow_fast_stage >= 1 && follow_fast_stage <= 4)
             ORBFE_HIP(hipStreamWaitEvent(s, follow->ev_stage[follow_fast_stage - 1], 0));
+        if (fast_gate && (rc = aruco_contours_wait(fast_gate, s))) return rc;   // (orbfe_pipeline: FAST behind the detector's border walks)
         if ((rc = launch_fast(s, fast0 ? ncells_l0 : 0, ncells_total))) return rc;
         timer.mark(s, "fast_cells");
         if (fast0) ORBFE_HIP(hipStreamWaitEvent(s, ev_join0, 0));
@@ -523,17 +529,24 @@ struct orbfe_extractor {
             const int D = force_pyramid_depth ? force_pyramid_depth : max_ini <= 4 ? 5 : 4;
             const size_t lds_p = qp_lds_bytes(max_ini, D, nodecap, veccap);
             { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(&k_distribute_pyr), (size_t)(lds_p)); if (rc_lds_) return rc_lds_; }
-            for (int r_ = 0; r_ < ORBFE_REPS_ORB(2); r_++) hipLaunchKernelGGL(k_distribute_pyr, dim3(nlevels, B), dim3(QP_THREADS), lds_p, s, dg, d_slots.as<uint32_t>(),
+            const int by_level = 0;   // (frames x levels, every frame's level 0 first: 1.419 against 1.420 ms per C2 step, ten interleaved runs each)
+            for (int r_ = 0; r_ < ORBFE_REPS_ORB(2); r_++) hipLaunchKernelGGL(k_distribute_pyr, by_level ? dim3(B, nlevels) : dim3(nlevels, B), dim3(QP_THREADS), lds_p, s, dg, d_slots.as<uint32_t>(),
                                slots_fu32, d_cellcnt.as<int32_t>(), ncells_total, d_lvlout.as<uint32_t>(), out_total,
                                d_lvlcnt.as<int32_t>(), nlevels, d_lvlncand.as<int32_t>(), d_fallback.as<int32_t>(), D,
-                               nodecap, veccap);
-            const size_t lds = qt_lds_bytes(keycap_lds, nodecap, veccap);
-            { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(&k_distribute), (size_t)(lds)); if (rc_lds_) return rc_lds_; }
-            hipLaunchKernelGGL(k_distribute, dim3(nlevels, B), dim3(64), lds, s, dg, d_slots.as<uint32_t>(), slots_fu32,
+                               nodecap, veccap, d_worklist.as<int32_t>() + 4, d_worklist.as<int32_t>(), by_level);
+            // (the work-list launch keeps its keys in the HBM scratch: a workgroup that asks for 50 KB of LDS it will almost never use
+            //  waits for the CU's other tenants -- 87 us behind the detector's threshold kernel, with an EMPTY list)
+            const int qcap = force_general_quadtree ? keycap_lds : 0;
+            const size_t lds = qt_lds_bytes(qcap, nodecap, veccap);
+            { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(&k_distribute), qt_lds_bytes(keycap_lds, nodecap, veccap)); if (rc_lds_) return rc_lds_; }
+            // the general kernel drains the work list with a small grid (a launch of nlevels x B workgroups of this much LDS that found
+            // nothing to do cost the chain 73 us); the test hook runs it for every level, a workgroup each
+            const dim3 qgrid = force_general_quadtree ? dim3(nlevels, B) : dim3(std::min(nlevels * B, 128));
+            hipLaunchKernelGGL(k_distribute, qgrid, dim3(64), lds, s, dg, d_slots.as<uint32_t>(), slots_fu32,
                                d_cellcnt.as<int32_t>(), ncells_total, d_keys.as<uint32_t>(), keys_fu32,
                                d_lvlout.as<uint32_t>(), out_total, d_lvlcnt.as<int32_t>(), nlevels,
-                               d_lvlncand.as<int32_t>(), keycap_lds, nodecap, veccap,
-                               force_general_quadtree ? nullptr : d_fallback.as<int32_t>());
+                               d_lvlncand.as<int32_t>(), qcap, nodecap, veccap,
+                               force_general_quadtree ? nullptr : d_worklist.as<int32_t>() + 4, d_worklist.as<int32_t>());
         }
         timer.mark(s, "distribute");
         if ((rc = stage_event(1))) return rc;
@@ -543,7 +556,7 @@ struct orbfe_extractor {
         }
         hipLaunchKernelGGL(k_level_offsets, dim3(B), dim3(256), 0, s, d_lvlcnt.as<int32_t>(), d_lvloff.as<int32_t>(),
                            d_n, nlevels, B, capacity, d_overflow.as<int32_t>() + flag_word, dg, d_lvlout.as<uint32_t>(), out_total,
-                           d_flatkv.as<uint32_t>(), d_flatlvl.as<uint8_t>());
+                           d_flatkv.as<uint32_t>(), d_flatlvl.as<uint8_t>(), d_worklist.as<int32_t>());
         if (blur_place == 2) { // no fork: the blur runs in the main stream between the quadtree and the descriptors
             hipStream_t keep = aux_stream;
             aux_stream = s;
@@ -567,6 +580,8 @@ struct orbfe_extractor {
         return ORBFE_OK;
     }
 };
+
+namespace orbfe { void extractor_set_fast_gate(orbfe_extractor* h, orbfe_aruco* det) { if (h) h->fast_gate = det; } }
 
 extern "C" {
 

@@ -511,18 +511,15 @@ __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlan
 
 // The workgroup is a single wave: LDS operations of one wave execute in order, so a compiler-level barrier is enough.
 #define QT_SYNC() __builtin_amdgcn_wave_barrier()
-__global__ __launch_bounds__(64) void k_distribute(const LevelGeom* __restrict__ geom, const uint32_t* __restrict__ slots,
-                                                   size_t slots_fstride, const int32_t* __restrict__ cellcnt,
-                                                   int ncells_total, uint32_t* __restrict__ keyscratch,
-                                                   size_t keys_fstride, uint32_t* __restrict__ lvl_out,
-                                                   int out_fstride, int32_t* __restrict__ lvl_cnt, int nlevels,
-                                                   int32_t* __restrict__ lvl_ncand, int keycap_lds, int nodecap,
-                                                   int veccap, const int32_t* __restrict__ only_flagged)
+// One (frame, level) of the general kernel; `qt_smem` is the workgroup's dynamic LDS (qt_lds_bytes()).
+__device__ __forceinline__ void qt_general_level(unsigned char* qt_smem, int level, int f, const LevelGeom* __restrict__ geom,
+                                                 const uint32_t* __restrict__ slots, size_t slots_fstride,
+                                                 const int32_t* __restrict__ cellcnt, int ncells_total,
+                                                 uint32_t* __restrict__ keyscratch, size_t keys_fstride,
+                                                 uint32_t* __restrict__ lvl_out, int out_fstride, int32_t* __restrict__ lvl_cnt,
+                                                 int nlevels, int32_t* __restrict__ lvl_ncand, int keycap_lds, int nodecap, int veccap)
 {
-    extern __shared__ __align__(16) unsigned char qt_smem[];
     const int lane = threadIdx.x;
-    const int level = blockIdx.x, f = blockIdx.y;
-    if (only_flagged && !only_flagged[f * nlevels + level]) return; // the pyramid fast path already did this level
     const LevelGeom g = geom[level];
 
     // carve LDS
@@ -878,6 +875,37 @@ __global__ __launch_bounds__(64) void k_distribute(const LevelGeom* __restrict__
 #endif
 }
 
+// The general kernel is the fall-back of k_distribute_pyr: on ordinary frames no level needs it.  As a grid of one workgroup per
+// (level, frame) -- 2400 workgroups of ~60 KB of LDS each at C2 -- the launch that did NOTHING still took 73 us on average in the
+// pipeline (4 .. 170; 11 alone: every workgroup waits for 60 KB of LDS on a CU the other engines' kernels fill), on the extractor's
+// critical chain between the quadtree and the descriptors.  Now the fast path appends the levels it gives up on to a work list, and a
+// small grid of workgroups drains it (an empty list costs one launch of `gridDim.x` idle waves).  worklist == nullptr: every
+// (level, frame) pair, one workgroup each (the test hook that runs the general kernel for everything).
+__global__ __launch_bounds__(64) void k_distribute(const LevelGeom* __restrict__ geom, const uint32_t* __restrict__ slots,
+                                                   size_t slots_fstride, const int32_t* __restrict__ cellcnt,
+                                                   int ncells_total, uint32_t* __restrict__ keyscratch,
+                                                   size_t keys_fstride, uint32_t* __restrict__ lvl_out,
+                                                   int out_fstride, int32_t* __restrict__ lvl_cnt, int nlevels,
+                                                   int32_t* __restrict__ lvl_ncand, int keycap_lds, int nodecap,
+                                                   int veccap, const int32_t* __restrict__ worklist,
+                                                   const int32_t* __restrict__ worklist_n)
+{
+    extern __shared__ __align__(16) unsigned char qt_smem[];
+    if (!worklist) {
+        qt_general_level(qt_smem, blockIdx.x, blockIdx.y, geom, slots, slots_fstride, cellcnt, ncells_total, keyscratch, keys_fstride,
+                         lvl_out, out_fstride, lvl_cnt, nlevels, lvl_ncand, keycap_lds, nodecap, veccap);
+        return;
+    }
+    const int n = *worklist_n;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const int fl = worklist[i];
+        const int f = fl / nlevels;
+        qt_general_level(qt_smem, fl - f * nlevels, f, geom, slots, slots_fstride, cellcnt, ncells_total, keyscratch, keys_fstride,
+                         lvl_out, out_fstride, lvl_cnt, nlevels, lvl_ncand, keycap_lds, nodecap, veccap);
+        QT_SYNC(); // the next item reuses the LDS
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ quadtree, fast path
 // DistributeOctTree without moving keypoints.  A node's rectangle depends only on its path from the root (DivideNode
 // halves with ceil, :483-484), so every candidate has a fixed cell at every depth.  One pass over the candidates builds,
@@ -903,7 +931,8 @@ __global__ __launch_bounds__(QP_THREADS) void k_distribute_pyr(const LevelGeom* 
                                                        int ncells_total, uint32_t* __restrict__ lvl_out, int out_fstride,
                                                        int32_t* __restrict__ lvl_cnt, int nlevels,
                                                        int32_t* __restrict__ lvl_ncand, int32_t* __restrict__ fallback,
-                                                       int D, int nodecap, int veccap)
+                                                       int D, int nodecap, int veccap, int32_t* __restrict__ worklist,
+                                                       int32_t* __restrict__ worklist_n, int by_level)
 {
 #ifndef ORBFE_PRIO_QT
 #define ORBFE_PRIO_QT 2
@@ -914,7 +943,9 @@ __global__ __launch_bounds__(QP_THREADS) void k_distribute_pyr(const LevelGeom* 
     // QP_THREADS threads build the leaf counts (the only part that is parallel over candidates), then one wave runs the
     // tree logic
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int level = blockIdx.x, f = blockIdx.y;
+    // by_level: grid (frames, levels) -- every frame's level 0, the level with the most candidates and the longest workgroups, is
+    // dispatched first and the short ones fill the tail; else grid (levels, frames)
+    const int level = by_level ? blockIdx.y : blockIdx.x, f = by_level ? blockIdx.x : blockIdx.y;
     const LevelGeom g = geom[level];
     const int nIni = g.nIni;
     // depth d cells live at cnt[off(d) + root * 4^d + code]; off(d) = 4 * nIni * (4^d - 1) / 3 rounded so that every
@@ -1206,7 +1237,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_distribute_pyr(const LevelGeom* 
         }
     }
     if (deep) {
-        if (lane == 0) fallback[fl_idx] = 1;
+        if (lane == 0) { fallback[fl_idx] = 1; worklist[atomicAdd(worklist_n, 1)] = fl_idx; } // k_distribute redoes this level
         return;
     }
 
@@ -1234,11 +1265,13 @@ __global__ __launch_bounds__(256) void k_level_offsets(const int32_t* __restrict
                                                        int capacity, int32_t* __restrict__ overflow,
                                                        const LevelGeom* __restrict__ geom,
                                                        const uint32_t* __restrict__ lvl_out, int out_fstride,
-                                                       uint32_t* __restrict__ flat_kv, uint8_t* __restrict__ flat_lvl)
+                                                       uint32_t* __restrict__ flat_kv, uint8_t* __restrict__ flat_lvl,
+                                                       int32_t* __restrict__ worklist_n)
 {
     __builtin_amdgcn_s_setprio(2); // latency-bound: its few waves go first when a VALU-bound kernel shares the CU
     const int f = blockIdx.x, tid = threadIdx.x;
     if (f >= nframes) return;
+    if (f == 0 && tid == 0) *worklist_n = 0; // the quadtree's work list (k_distribute has drained it) is empty for the next batch
     int acc = 0;
     for (int l = 0; l < nlevels; l++) {
         const int c = lvl_cnt[f * nlevels + l];

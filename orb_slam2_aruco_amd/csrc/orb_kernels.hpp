@@ -70,13 +70,13 @@ __global__ void k_fast_cells(ImgView src0, ImgView pyr, const LevelGeom* geom, c
 __global__ void k_distribute(const LevelGeom* geom, const uint32_t* slots, size_t slots_fstride,
                              const int32_t* cellcnt, int ncells_total, uint32_t* keyscratch, size_t keys_fstride,
                              uint32_t* lvl_out, int out_fstride, int32_t* lvl_cnt, int nlevels, int32_t* lvl_ncand,
-                             int keycap_lds, int nodecap, int veccap, const int32_t* only_flagged);
+                             int keycap_lds, int nodecap, int veccap, const int32_t* worklist, const int32_t* worklist_n);
 #define QT_MAXROOTS 16   // root nodes of DistributeOctTree (nIni = round(width / height), ORBextractor.cc:544) the kernels hold
 #define QP_THREADS 256
 __global__ void k_distribute_pyr(const LevelGeom* geom, const uint32_t* slots, size_t slots_fstride,
                                  const int32_t* cellcnt, int ncells_total, uint32_t* lvl_out, int out_fstride,
                                  int32_t* lvl_cnt, int nlevels, int32_t* lvl_ncand, int32_t* fallback, int D,
-                                 int nodecap, int veccap);
+                                 int nodecap, int veccap, int32_t* worklist, int32_t* worklist_n, int by_level);
 
 inline size_t qp_lds_bytes(int nIni, int D, int nodecap, int veccap)
 {
@@ -89,7 +89,7 @@ inline size_t qp_lds_bytes(int nIni, int D, int nodecap, int veccap)
 }
 __global__ void k_level_offsets(const int32_t* lvl_cnt, int32_t* lvl_off, int32_t* n_out, int nlevels, int nframes,
                                 int capacity, int32_t* overflow, const LevelGeom* geom, const uint32_t* lvl_out,
-                                int out_fstride, uint32_t* flat_kv, uint8_t* flat_lvl);
+                                int out_fstride, uint32_t* flat_kv, uint8_t* flat_lvl, int32_t* worklist_n);
 template <bool ED> __global__ void k_blur7(ImgView src0, ImgView pyr, ImgView blur, const LevelGeom* geom, const uint32_t* strips, int nx,
                         int total);
 __global__ void k_orient_describe2(ImgView src0, ImgView pyr, ImgView blur, const LevelGeom* geom,

@@ -132,15 +132,19 @@ __global__ __launch_bounds__(256) void k_pack_out(PackList L)
 struct OutPack {
     PackList L{};
     size_t total = 0;
+    bool bad = false;   // an item that does not fit the contract: flush() fails instead of dropping bytes or writing past the list
     void add(void* host_dst, const void* dev_src, size_t bytes)
     {
         if (!bytes) return;
+        if (L.n >= (int)(sizeof(L.it) / sizeof(L.it[0])) || (bytes & 3) || ((uintptr_t)host_dst & 3) || ((uintptr_t)dev_src & 3) ||
+            bytes / 4 > 0xffffffffull) { bad = true; return; }
         L.it[L.n++] = PackItem{(const uint32_t*)dev_src, (uint32_t*)host_dst, (uint32_t)(bytes / 4)};
         total += bytes;
     }
     // host_dst pointers are page-locked memory of this process (hipHostMalloc: the same address on the device)
     template <int TAG> int flush(hipStream_t s)
     {
+        if (bad) { bad = false; L.n = 0; total = 0; return fail(ORBFE_ERR_INVALID, "OutPack: more than 8 items, or an item that is not 4-byte aligned / sized"); }
         if (!L.n) return ORBFE_OK;
         const int wgs = (int)std::min<size_t>(32, (total / 4 + 1023) / 1024 + 1);
         hipLaunchKernelGGL(k_pack_out<TAG>, dim3(wgs), dim3(256), 0, s, L);
@@ -162,6 +166,11 @@ int aruco_speculate(orbfe_aruco* a, const uint8_t* d_img, size_t dframe, int row
 void aruco_speculation_wait(orbfe_aruco* a); // until the detector no longer reads the extractor's copy of the image
 void aruco_unpair_notice(orbfe_aruco* a);
 int aruco_device_of(const orbfe_aruco* a);   // the HIP device the detector was created on
+// Scheduling hook of the batched pipeline (csrc/pipeline.hip): `stream` waits until the detector's newest batch has left its contour
+// kernels (the LDS-latency-bound part of its chain, the one FAST stretches most and is stretched by); nothing if no batch ran yet.
+int aruco_contours_wait(orbfe_aruco* a, hipStream_t stream);
+void aruco_set_contours_gate(orbfe_aruco* a, orbfe_extractor* ex, int stage);   // the border walks of the NEXT batch behind that stage of `ex` (orbfe_extractor_stage_wait); nullptr / 0: off
+void extractor_set_fast_gate(orbfe_extractor* h, orbfe_aruco* det);   // FAST of every batch of `h` behind aruco_contours_wait(det) (nullptr: off)
 
 // Scratch of the entry points that have no handle (matching, poses, keyframe records): one workspace per calling thread,
 // HIP device and stream.  A buffer allocated on one GPU is never handed to a kernel on another, two asynchronous calls

@@ -94,8 +94,8 @@ __global__ void k_copy_halo(const uint32_t* __restrict__ src_kps, uint32_t* __re
 struct orbfe_pipeline {
     orbfe_pipeline_config cfg{};
     int B = 0, rows = 0, cols = 0, cap = 0, mcap = 0, R = 0, D = 0;
-    int phase_pin = 0, det_pin = 0;
-    bool defer_post = false, det_nofork = false, use_orb = true, use_aruco = true;
+    int phase_pin = 0, det_pin = 0, contour_pin = 0;
+    bool defer_post = false, det_nofork = false, use_orb = true, use_aruco = true, fast_gate = false;
     std::vector<orbfe_extractor*> ex;
     orbfe_aruco* det = nullptr;               // detector of engine set 0 (= dets[0])
     std::vector<orbfe_aruco*> dets;           // ORBFE_ENGINE_SETS_ARUCO detector sets alternate batches (measurement switch; default 1)
@@ -266,7 +266,7 @@ const char* orbfe_pipeline_env_defaults(void)
     // one list for the pipeline and the engines: bench.py marks a line as diagnostic when one of these is set to something else
     return "ORBFE_ENGINE_SETS=2;ORBFE_ENGINE_SETS_ARUCO=1;ORBFE_RECORD_SETS=4;ORBFE_PHASE_PIN=size;ORBFE_DET_PIN=4;ORBFE_DEFER_POST=size;ORBFE_DET_NOFORK=size;"
            "ORBFE_ARUCO_RELAY_WIDE=1;"
-           "ORBFE_ARUCO_SPECKS=0;ORBFE_ARUCO_SMALL_SEPARATE=size;ORBFE_ARUCO_TILED=size;ORBFE_ARUCO_TILE_W=0;ORBFE_ARUCO_TPW=0;ORBFE_ARUCO_BANDED=size;ORBFE_ARUCO_BAND_ROWS=0;ORBFE_ARUCO_LCAP=0;ORBFE_GRAPH=0;"
+           "ORBFE_ARUCO_SPECKS=0;ORBFE_ARUCO_THR_V2=1;ORBFE_FAST_GATE=0;ORBFE_CONTOUR_PIN=0;ORBFE_ARUCO_SMALL_SEPARATE=size;ORBFE_ARUCO_TILED=size;ORBFE_ARUCO_TILE_W=0;ORBFE_ARUCO_TPW=0;ORBFE_ARUCO_BANDED=size;ORBFE_ARUCO_BAND_ROWS=0;ORBFE_ARUCO_LCAP=0;ORBFE_GRAPH=0;"
            "ORBFE_NO_LEND=0;ORBFE_GRAPH_VERBOSE=0;ORBFE_RCCL_LIB=";
 }
 
@@ -352,6 +352,12 @@ orbfe_pipeline* orbfe_pipeline_create(const orbfe_pipeline_config* cfg)
             if (p->det_nofork) orbfe_aruco_set_aux_stream(a, sd);
         }
         p->det = p->dets[0];
+        // The step's critical cycle, made explicit (round 6): threshold(i + 1) behind FAST(i) (ORBFE_DET_PIN=1), the border walks behind the
+        // threshold, FAST(i + 1) behind the border walks (ORBFE_FAST_GATE=1).  FAST and the relay contour kernel are each other's worst
+        // neighbours (LDS latency), and left to themselves the two chains drift in and out of the alignment that keeps them apart.
+        p->contour_pin = env_or("ORBFE_CONTOUR_PIN", 0);
+        p->fast_gate = env_or("ORBFE_FAST_GATE", 0) != 0 && p->use_orb && p->dets.size() == 1;
+        if (p->fast_gate) for (auto e : p->ex) extractor_set_fast_gate(e, p->det);
         p->mcap = std::min(orbfe_aruco_max_markers(p->det), std::max(1, cfg->marker_capacity));
     }
     orbfe_record_layout& L = p->lay;
@@ -558,6 +564,8 @@ static int step_body(orbfe_pipeline* p, const uint8_t* d_imgs, size_t pitch, int
             const long j = p->det_pin >= 10 ? i : i - 1; // + 10: a stage of THIS batch's extractor, which is then enqueued first
             if (j >= 0 && (rc = orbfe_extractor_stage_wait(p->ex[(size_t)(j % p->D)], p->det_pin % 10, st_det_i))) return rc;
         }
+        // ... and its border walks behind a stage of the extractor's previous batch (ORBFE_CONTOUR_PIN; 1 = its FAST)
+        aruco_set_contours_gate(det_i, (p->contour_pin && p->use_orb && i >= 1) ? p->ex[(size_t)((i - 1) % p->D)] : nullptr, p->contour_pin);
         orbfe_marker* mk = reinterpret_cast<orbfe_marker*>(base + p->lay.off_markers);
         int32_t* nmk = reinterpret_cast<int32_t*>(base + p->lay.off_nmarkers);
         if ((rc = orbfe_aruco_detect_batch_device(det_i, d_imgs, B, fstride, rows, cols, pitch, mk, p->mcap, nmk, st_det_i))) return rc;
