@@ -623,6 +623,14 @@ def main():
     if multi:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("ORBFE_BENCH_WAVE_TIMING"):      # diagnosis build (-DORBFE_WAVE_TIMING, tools/wave_timing.sh): where the waves' lives went
+        wt = (ctypes.c_ulonglong * 64)()
+        if binding.load().orbfe_timing_read(wt, 1) == 0:
+            for kid, name in enumerate(("orient_describe", "fast_cells")):
+                row = [wt[kid * 16 + k] for k in range(16)]
+                if row[15]:
+                    print("wave_timing %s: waves %d, clocks per wave by phase %s, total %.0f" % (
+                        name, row[15], [round(v / row[15]) for v in row[:8]], sum(row[:8]) / row[15]), file=sys.stderr)
     status = pipe.status()
     if any(status.values()):
         raise SystemExit("front-end capacity exceeded during the timed run: results incomplete, no number reported (%r)" % (status,))

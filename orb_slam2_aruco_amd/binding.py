@@ -974,6 +974,10 @@ class MarkerDetector:
         """Debug: the speck passes between threshold and contours (k_speck_clean) on / off (default); the results do not change."""
         self.L.orbfe_aruco_debug_kernel_times(self.h, None, 8 if on else 9)
 
+    def set_threshold_pyramid_kernel(self, on=True):
+        """k_threshold_pyr (threshold + the /2 pyramid levels a tile holds, the default where it applies) / k_adaptive_threshold_t + k_half_area4."""
+        self.L.orbfe_aruco_debug_kernel_times(self.h, None, 12 if on else 13)
+
     def set_speck_passes_in_kernel(self, on=True):
         """Debug: the speck passes inside the one-workgroup relay kernels (full batches of frames whose bit image fits LDS) on / off (default)."""
         self.L.orbfe_aruco_debug_kernel_times(self.h, None, 10 if on else 11)

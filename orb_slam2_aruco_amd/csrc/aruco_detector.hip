@@ -109,11 +109,7 @@ struct orbfe_aruco {
     // (tests/test_aruco_gpu.py, tests/test_stress_gpu.py).
     int specks = getenv("ORBFE_ARUCO_SPECKS") && atoi(getenv("ORBFE_ARUCO_SPECKS")) == 1 ? 1 : 0;
     bool specks_inkernel = getenv("ORBFE_ARUCO_SPECKS") && atoi(getenv("ORBFE_ARUCO_SPECKS")) == 2;
-    orbfe_extractor* gate_ex = nullptr;   // aruco_set_contours_gate()
-    int gate_stage = 0;
-    hipEvent_t ev_contours = nullptr;   // behind the contour kernels (+ approxPolyDP) of the newest batch: aruco_contours_wait()
-    bool contours_recorded = false;
-    bool thr_v2 = !(getenv("ORBFE_ARUCO_THR_V2") && atoi(getenv("ORBFE_ARUCO_THR_V2")) == 0);   // k_threshold_pyr (measurement switch; debug code 12 / 13)
+    bool thr_v2 = true;   // k_threshold_pyr where it applies (debug code 12 / 13: the tests run both threshold kernels)
     bool specks_ran = false;   // the last batch's contour kernels read d_bitsc
     DevBuf d_bitsc;
     bool relay_global = false; // k_contours_relay8g: the bit image stays in HBM (it does not fit LDS)
@@ -176,7 +172,6 @@ struct orbfe_aruco {
         if (aux_stream) (void)hipStreamDestroy(aux_stream);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
-        if (ev_contours) (void)hipEventDestroy(ev_contours);
     }
 
     int set_dictionary(const char* name)
@@ -546,15 +541,6 @@ struct orbfe_aruco {
         const bool use_tiled = (tiled > 0 || (tiled < 0 && (relay_global || !relay_tbits || relay_tbits > 12 || B <= 32))) && !tiled_off && !force_legacy && !big_mode;
         tiled_ran = use_tiled;
         const bool relay = (relay_tbits || use_tiled) && !force_legacy && !big_mode;
-        // the border walks -- the LDS-latency-bound kernels of the chain -- are enqueued: aruco_contours_wait() waits for this point
-        bool walks_marked = false;
-        auto walks_done = [&]() -> int {
-            if (!ev_contours) ORBFE_HIP(hipEventCreateWithFlags(&ev_contours, hipEventDisableTiming));
-            ORBFE_HIP(hipEventRecord(ev_contours, s));
-            contours_recorded = walks_marked = true;
-            return ORBFE_OK;
-        };
-        if (gate_ex && gate_stage && (rc = orbfe_extractor_stage_wait(gate_ex, gate_stage, s))) return rc;
         for (int r_ = 0; relay && r_ < ORBFE_REPS_ARUCO(1); r_++) {
             if (use_tiled) {
                 // Tile width and waves.  k_ct_walk's waves are persistent and overlap their tiles, so a wave wants several tiles (its
@@ -644,7 +630,6 @@ struct orbfe_aruco {
                                    d_tailoff.as<int32_t>(), d_counts.as<int32_t>());
             }
             } // (the relay kernels)
-            if ((rc = walks_done())) return rc;
             // (g): sort + rank per frame, approxPolyDP by persistent waves over the whole batch's borders, rectangles per frame
             {
                 const int pts = RT_PTS;   // LDS point buffer per wave; longer borders are read from the pool
@@ -671,7 +656,6 @@ struct orbfe_aruco {
                            d_rects.as<ArRect>(), AR_MAX_RECTS, d_counts.as<int32_t>(), d_gpad.as<uint32_t>(),
                            gpad_fu32, 0);
         timer.mark(s, "contours");
-        if (!walks_marked && (rc = walks_done())) return rc;   // (the single-walker kernel: walks and approxPolyDP are one launch)
         ORBFE_HIP(hipGetLastError());
         if (enclosed)   // enlargeMarkerCandidate on every rectangle, before prefilterCandidates sees them (:3560-3590)
             hipLaunchKernelGGL(k_enlarge_candidates, dim3(B), dim3(AR_MAX_RECTS), 0, s, d_rects.as<ArRect>(), AR_MAX_RECTS, d_counts.as<int32_t>(),
@@ -1193,12 +1177,7 @@ void aruco_unpair_notice(orbfe_aruco* h)
 }
 
 int aruco_device_of(const orbfe_aruco* h) { return h ? h->device : -1; }
-void aruco_set_contours_gate(orbfe_aruco* h, orbfe_extractor* ex, int stage) { if (h) { h->gate_ex = ex; h->gate_stage = ex ? stage : 0; } }
-int aruco_contours_wait(orbfe_aruco* h, hipStream_t stream)
-{
-    if (h && h->contours_recorded) ORBFE_HIP(hipStreamWaitEvent(stream, h->ev_contours, 0));
-    return ORBFE_OK;
-}
+
 
 } // namespace orbfe
 

@@ -99,7 +99,6 @@ struct orbfe_extractor {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork0 = nullptr, ev_join0 = nullptr;
     // orbfe_extractor_follow: this handle's batches start behind a stage of ANOTHER handle's latest batch (two engine sets of a
     // pipeline hold a fixed phase that way instead of whatever the contention of the moment settles on)
-    orbfe_aruco* fast_gate = nullptr;    // extractor_set_fast_gate(): FAST waits until this detector's newest batch has left its contour kernels
     orbfe_extractor* follow = nullptr;
     int follow_stage = 0;                // 1 = the other's FAST, 2 = its quadtree, 3 = its descriptors (the whole batch), 4 = its resize chain
     int follow_fast_stage = 0;           // a second gate in front of this handle's FAST (0 = none): the resize chain may run earlier
@@ -296,7 +295,7 @@ struct orbfe_extractor {
                 const int sw = geom[l - 1].w, sh = geom[l - 1].h, dw = g.w, dh = g.h;
                 const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
                 const int dwp = align_up(dw, 4);
-                std::vector<int> xofs(dwp), xal(dwp), yofs(dh), ybe(dh);
+                std::vector<int> xofs(dwp), xal(dwp), ytab((size_t)dh * 4);   // ytab: per row {source row, the row below (both clipped), b0 << 12, b1 << 12}
                 for (int dx = 0; dx < dw; dx++) {
                     float fx = (float)((dx + 0.5) * scale_x - 0.5);
                     int sx = orbfe_floor_d(fx);
@@ -321,14 +320,18 @@ struct orbfe_extractor {
                     int sy = orbfe_floor_d(fy);
                     fy -= sy;
                     const int b0 = (short)orbfe_round_f((1.f - fy) * 2048.f), b1 = (short)orbfe_round_f(fy * 2048.f);
-                    yofs[dy] = sy;
-                    ybe[dy] = (b0 & 0xffff) | (b1 << 16);
+                    // rows are NOT clamped like columns: cv::resize keeps the fractional weight and clips the row index
+                    ytab[(size_t)dy * 4 + 0] = std::min(std::max(sy, 0), sh - 1);
+                    ytab[(size_t)dy * 4 + 1] = std::min(std::max(sy + 1, 0), sh - 1);
+                    ytab[(size_t)dy * 4 + 2] = (b0 & 0xffff) << 12;
+                    ytab[(size_t)dy * 4 + 3] = (b1 & 0xffff) << 12;
                 }
                 while (tabs.size() % 4) tabs.push_back(0); // k_resize_tab loads xofs/xal as int4
                 tab_off[l * 4 + 0] = tabs.size(); tabs.insert(tabs.end(), xofs.begin(), xofs.end());
                 tab_off[l * 4 + 1] = tabs.size(); tabs.insert(tabs.end(), xal.begin(), xal.end());
-                tab_off[l * 4 + 2] = tabs.size(); tabs.insert(tabs.end(), yofs.begin(), yofs.end());
-                tab_off[l * 4 + 3] = tabs.size(); tabs.insert(tabs.end(), ybe.begin(), ybe.end());
+                while (tabs.size() % 4) tabs.push_back(0); // ... and ytab as int4
+                tab_off[l * 4 + 2] = tabs.size(); tabs.insert(tabs.end(), ytab.begin(), ytab.end());
+                tab_off[l * 4 + 3] = 0;
             }
         }
         rows = rows_; cols = cols_;
@@ -462,8 +465,8 @@ struct orbfe_extractor {
                 const int* tb = d_tabs.as<int>();
                 const int nx = (nthreads + 255) / 256;
                 hipLaunchKernelGGL(k_resize_tab, dim3(xcd_grid(nx * B)), dim3(256), 0, s, sv, dv, gp.w, gp.h, dw4,
-                                   g.h, nthreads, tb + tab_off[l * 4 + 0], tb + tab_off[l * 4 + 1], tb + tab_off[l * 4 + 2],
-                                   tb + tab_off[l * 4 + 3], nx, nx * B);
+                                   g.h, nthreads, tb + tab_off[l * 4 + 0], tb + tab_off[l * 4 + 1],
+                                   reinterpret_cast<const int4*>(tb + tab_off[l * 4 + 2]), nx, nx * B);
             } else {
                 dim3 grid((dw4 + 63) / 64, (g.h + 7) / 8, B);
                 const double scale_x = 1. / ((double)g.w / gp.w), scale_y = 1. / ((double)g.h / gp.h);
@@ -482,24 +485,21 @@ struct orbfe_extractor {
         // codes 20..22 switch, ORBFE_BLUR_PLACE in the bench.
         hipStream_t aux_stream = user_aux ? user_aux : this->aux_stream;
         if (blur_place == 2) aux_stream = s;
+        // strips [first, first + count) of the strip list (level-major: level 0's strips come first)
+        auto blur_strips = [&](int first, int count) {
+            if (count <= 0) return;
+            if (gaussian_ed)
+                hipLaunchKernelGGL(k_blur7<true>, dim3(xcd_grid(count * B)), dim3(256), 0, aux_stream, src0, pyr, blur, dg,
+                                   d_tiles.as<uint32_t>() + first, count, count * B);
+            else
+                hipLaunchKernelGGL(k_blur7<false>, dim3(xcd_grid(count * B)), dim3(256), 0, aux_stream, src0, pyr, blur, dg,
+                                   d_tiles.as<uint32_t>() + first, count, count * B);
+        };
         auto launch_blur = [&]() -> int {
             ORBFE_HIP(hipEventRecord(ev_fork, s));
             ORBFE_HIP(hipStreamWaitEvent(aux_stream, ev_fork, 0));
             timer.mark(aux_stream, "blur7 starts", true);
-            const size_t lds_blur = 0;
-            if (lds_blur) {
-                int rc_lds_ = gaussian_ed ? ensure_dyn_lds(reinterpret_cast<const void*>(&k_blur7<true>), lds_blur)
-                                          : ensure_dyn_lds(reinterpret_cast<const void*>(&k_blur7<false>), lds_blur);
-                if (rc_lds_) return rc_lds_;
-            }
-            for (int r_ = 0; r_ < ORBFE_REPS_ORB(8); r_++) {
-                if (gaussian_ed)
-                    hipLaunchKernelGGL(k_blur7<true>, dim3(xcd_grid(ntiles * B)), dim3(256), lds_blur, aux_stream, src0, pyr, blur, dg,
-                                       d_tiles.as<uint32_t>(), ntiles, ntiles * B);
-                else
-                    hipLaunchKernelGGL(k_blur7<false>, dim3(xcd_grid(ntiles * B)), dim3(256), lds_blur, aux_stream, src0, pyr, blur, dg,
-                                       d_tiles.as<uint32_t>(), ntiles, ntiles * B);
-            }
+            for (int r_ = 0; r_ < ORBFE_REPS_ORB(8); r_++) blur_strips(0, ntiles);
             timer.mark(aux_stream, "blur7");
             ORBFE_HIP(hipEventRecord(ev_join, aux_stream));
             return ORBFE_OK;
@@ -507,7 +507,6 @@ struct orbfe_extractor {
         if (blur_place == 1) { int rcb = launch_blur(); if (rcb) return rcb; }
         if (follow && follow != this && follow->stage_recorded && follow_fast_stage >= 1 && follow_fast_stage <= 4)
             ORBFE_HIP(hipStreamWaitEvent(s, follow->ev_stage[follow_fast_stage - 1], 0));
-        if (fast_gate && (rc = aruco_contours_wait(fast_gate, s))) return rc;   // (orbfe_pipeline: FAST behind the detector's border walks)
         if ((rc = launch_fast(s, fast0 ? ncells_l0 : 0, ncells_total))) return rc;
         timer.mark(s, "fast_cells");
         if (fast0) ORBFE_HIP(hipStreamWaitEvent(s, ev_join0, 0));
@@ -565,23 +564,43 @@ struct orbfe_extractor {
             if (rcb) return rcb;
         } else
             ORBFE_HIP(hipStreamWaitEvent(s, ev_join, 0));
-        const int kcap_ = std::min(capacity, max_keypoints());
-        const int okx = (kcap_ + 7) / 8;   // workgroups per frame: 4 waves of two keypoints
-        auto ofn = k_orient_describe2;
-        const size_t lds_orient = 0;
-        if (lds_orient) { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(ofn), lds_orient); if (rc_lds_) return rc_lds_; }
-        for (int r_ = 0; r_ < ORBFE_REPS_ORB(4); r_++) hipLaunchKernelGGL(ofn, dim3(xcd_grid(okx * B)), dim3(256), lds_orient, s, src0, pyr, blur, dg,
-                           d_flatkv.as<uint32_t>(), d_flatlvl.as<uint8_t>(), d_n, nlevels, d_pattern.as<uint32_t>(),
-                           d_umax.as<uint4>(), d_kps_out, d_desc_out, capacity, okx, okx * B);
-        timer.mark(s, "orient_describe");
-        if ((rc = stage_event(2))) return rc;
         stage_recorded = true;
+        // the descriptors: here, or -- extractor_defer_describe(), the batched pipeline -- when the caller says so (describe_deferred())
+        late = Late{true, src0, B, capacity, d_kps_out, d_desc_out, d_n, s};
+        if (defer_describe) return ORBFE_OK;
+        return describe_deferred(nullptr, 0);
+    }
+
+    // k_orient_describe2 of the newest batch, behind stage `gate_stage` of `gate`'s newest batch if one is named
+    struct Late { bool pending; ImgView src0; int B, capacity; orbfe_keypoint* kps; uint8_t* desc; int32_t* n; hipStream_t s; };
+    Late late{};
+    bool defer_describe = false;
+    int describe_deferred(orbfe_extractor* gate, int gate_stage)
+    {
+        if (!late.pending) return ORBFE_OK;
+        late.pending = false;
+        hipStream_t s = late.s;
+        if (gate && gate != this && gate->stage_recorded && gate_stage >= 1 && gate_stage <= 4)
+            ORBFE_HIP(hipStreamWaitEvent(s, gate->ev_stage[gate_stage - 1], 0));
+        ImgView pyr{d_pyr.as<uint8_t>(), d_pyr.as<uint8_t>(), pyr_fbytes, 0};
+        ImgView blur{d_blur.as<uint8_t>(), d_blur.as<uint8_t>(), blur_fbytes, 0};
+        const int kcap_ = std::min(late.capacity, max_keypoints());
+        const int okx = (kcap_ + 7) / 8;   // workgroups per frame: 4 waves of two keypoints
+        for (int r_ = 0; r_ < ORBFE_REPS_ORB(4); r_++) hipLaunchKernelGGL(k_orient_describe2, dim3(xcd_grid(okx * late.B)), dim3(256), 0, s, late.src0, pyr, blur, d_geom.as<LevelGeom>(),
+                           d_flatkv.as<uint32_t>(), d_flatlvl.as<uint8_t>(), late.n, nlevels, d_pattern.as<uint32_t>(),
+                           d_umax.as<uint4>(), late.kps, late.desc, late.capacity, okx, okx * late.B);
+        timer.mark(s, "orient_describe");
+        if (!ev_stage[2]) ORBFE_HIP(hipEventCreateWithFlags(&ev_stage[2], hipEventDisableTiming));
+        ORBFE_HIP(hipEventRecord(ev_stage[2], s));
         ORBFE_HIP(hipGetLastError());
         return ORBFE_OK;
     }
 };
 
-namespace orbfe { void extractor_set_fast_gate(orbfe_extractor* h, orbfe_aruco* det) { if (h) h->fast_gate = det; } }
+namespace orbfe {
+void extractor_defer_describe(orbfe_extractor* h, bool on) { if (h) h->defer_describe = on; }
+int extractor_describe_now(orbfe_extractor* h, orbfe_extractor* gate, int gate_stage) { return h ? h->describe_deferred(gate, gate_stage) : ORBFE_OK; }
+}
 
 extern "C" {
 

@@ -29,6 +29,30 @@ __device__ __forceinline__ int lane_prefix(unsigned long long mask)
     return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
 }
 
+// Diagnosis build only (-DORBFE_WAVE_TIMING, tools/wave_timing.sh): where a wave's life goes, summed over all waves of a kernel.
+// WT_MARK(kernel, slot) adds the shader clocks since the previous mark of this wave to g_wt[kernel][slot] (slot 15 counts waves).
+#ifdef ORBFE_WAVE_TIMING
+// (2048 copies of every counter, picked by workgroup: one word takes ~90 atomics a microsecond, the kernels retire thousands of waves in that time)
+__device__ unsigned long long g_wt[4][16][2048];
+#define WT_BEGIN() long long wt_prev_ = clock64()
+#define WT_MARK(kid, slot) do { const long long t_ = clock64(); if ((threadIdx.x & 63) == 0) atomicAdd(&g_wt[kid][slot][(blockIdx.x * 4 + (threadIdx.x >> 6)) & 2047], (unsigned long long)(t_ - wt_prev_)); wt_prev_ = clock64(); } while (0)
+#define WT_COUNT(kid) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_wt[kid][15][(blockIdx.x * 4 + (threadIdx.x >> 6)) & 2047], 1ull); } while (0)
+} // namespace orbfe
+extern "C" __attribute__((visibility("default"))) int orbfe_timing_read(unsigned long long* out, int reset)
+{
+    static unsigned long long h[4][16][2048];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(orbfe::g_wt), sizeof(h)) != hipSuccess) return -1;
+    for (int k = 0; k < 4; k++) for (int s = 0; s < 16; s++) { unsigned long long t = 0; for (int i = 0; i < 2048; i++) t += h[k][s][i]; out[k * 16 + s] = t; }
+    if (reset) { for (auto& a : h) for (auto& b : a) for (auto& c : b) c = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(orbfe::g_wt), h, sizeof(h)); }
+    return 0;
+}
+namespace orbfe {
+#else
+#define WT_BEGIN()
+#define WT_MARK(kid, slot)
+#define WT_COUNT(kid)
+#endif
+
 // ------------------------------------------------------------------------------------------------ resize --
 // One thread = 4 horizontally adjacent output pixels x 2 rows (two aligned u32 stores).  The cv::resize coefficient
 // arithmetic (double/float) is evaluated per thread with exactly the host formulas -- contraction is
@@ -119,8 +143,7 @@ __device__ __forceinline__ uint32_t rs_wmul(uint32_t bs, uint32_t hm)
 
 __global__ __launch_bounds__(256) void k_resize_tab(ImgView src, ImgView dst, int sw, int sh, int dw4, int dh,
                                                     int nthreads, const int* __restrict__ xofs,
-                                                    const int* __restrict__ xal, const int* __restrict__ yofs,
-                                                    const int* __restrict__ ybe, int nx, int total)
+                                                    const int* __restrict__ xal, const int4* __restrict__ ytab, int nx, int total)
 {
 #ifndef ORBFE_PRIO_RESIZE
 #define ORBFE_PRIO_RESIZE 2
@@ -135,8 +158,10 @@ __global__ __launch_bounds__(256) void k_resize_tab(ImgView src, ImgView dst, in
     const int t = bx * 256 + threadIdx.x;
     if (t >= nthreads) return;
     const int rg = t / dw4, x4 = t - rg * dw4;
+    // uniform bases + 32-bit lane offsets (a per-lane 64-bit pointer costs a v_lshl_add_u64 per row and load)
     const uint8_t* S = src.base + (size_t)f * src.fstride;
-    uint8_t* D = dst.base_w + (size_t)f * dst.fstride + (size_t)x4 * 4;
+    uint8_t* D = dst.base_w + (size_t)f * dst.fstride;
+    const uint32_t xo = (uint32_t)x4 * 4u;
     const int4 sx = *reinterpret_cast<const int4*>(xofs + x4 * 4);
     const int4 al = *reinterpret_cast<const int4*>(xal + x4 * 4);
     const int w0 = min(sx.x, sw - 8);
@@ -153,32 +178,32 @@ __global__ __launch_bounds__(256) void k_resize_tab(ImgView src, ImgView dst, in
 #pragma unroll
     for (int r0 = 0; r0 < RS_ROWS; r0 += 4) {
         unsigned long long wt[4], wb[4];
-        int bb[4];
+        uint32_t b0s[4], b1s[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) { // all loads of four rows in flight before the first use
             const int dy = min(dy0 + r0 + r, dh - 1);
-            const int sy = yofs[dy];
-            bb[r] = ybe[dy];
-            // rows are NOT clamped like columns: cv::resize keeps the fractional weight and clips the row index
-            wt[r] = *reinterpret_cast<const u64_unaligned*>(S + (off24(min(max(sy, 0), sh - 1), src.pitch) + (uint32_t)w0));
-            wb[r] = *reinterpret_cast<const u64_unaligned*>(S + (off24(min(max(sy + 1, 0), sh - 1), src.pitch) + (uint32_t)w0));
+            // a row's entry: the two source rows (clipped -- cv::resize keeps the fractional weight and clips the row index -- by the
+            // host) and the two weights shifted for rs_wmul: one 16-byte load; the clamps and the unpacking were 8 of 64 instructions a row
+            const int4 ye = ytab[dy];
+            b0s[r] = (uint32_t)ye.z; b1s[r] = (uint32_t)ye.w;
+            wt[r] = *reinterpret_cast<const u64_unaligned*>(S + (off24(ye.x, src.pitch) + (uint32_t)w0));
+            wb[r] = *reinterpret_cast<const u64_unaligned*>(S + (off24(ye.y, src.pitch) + (uint32_t)w0));
         }
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int dy = dy0 + r0 + r;
             if (dy >= dh) break;
-            const uint32_t b0s = ((uint32_t)bb[r] & 0xffffu) << 12, b1s = ((uint32_t)bb[r] >> 16) << 12;
             const uint32_t tl = (uint32_t)wt[r], th = (uint32_t)(wt[r] >> 32), bl = (uint32_t)wb[r], bh = (uint32_t)(wb[r] >> 32);
             uint32_t packed = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const uint32_t h0 = hdot(__builtin_amdgcn_perm(th, tl, sel[k]), a[k]);
                 const uint32_t h1 = hdot(__builtin_amdgcn_perm(bh, bl, sel[k]), a[k]);
-                // (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2
-                const uint32_t v = (rs_wmul(b0s, h0 & ~15u) + rs_wmul(b1s, h1 & ~15u) + 2u) >> 2;
-                packed |= (v & 0xffu) << (8 * k);
+                // (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2: at most 255 (a pixel's weights add up to 2048 both ways)
+                const uint32_t v = (rs_wmul(b0s[r], h0 & ~15u) + rs_wmul(b1s[r], h1 & ~15u) + 2u) >> 2;
+                packed |= v << (8 * k);
             }
-            *reinterpret_cast<uint32_t*>(D + off24(dy, dst.pitch)) = packed;
+            *reinterpret_cast<uint32_t*>(D + (off24(dy, dst.pitch) + xo)) = packed;
         }
     }
 }
@@ -299,10 +324,12 @@ __global__ __launch_bounds__(256) void k_fast_cells(ImgView src0, ImgView pyr, c
     __builtin_amdgcn_s_setprio(ORBFE_PRIO_FAST); // (experiment: 1.53 against 1.36 ms per C2 step at priority 1)
 #endif
     const int lane = threadIdx.x & 63, wid = wave_id();
+    WT_BEGIN();
     int bx, f;
     if (!xcd_remap(nx, total, bx, f)) return;
     const int cell = cell_base + bx * 4 + wid;
     if (cell >= cell_end) return;
+    WT_COUNT(1);
     const size_t roi_bytes = ((size_t)roi_pitch * roi_rows + 15) & ~(size_t)15;
     const size_t map_bytes = ((size_t)map_pitch * map_rows + 15) & ~(size_t)15;
     const size_t per_wave = roi_bytes + map_bytes + (((size_t)list_cap * 2 + 15) & ~(size_t)15);
@@ -361,6 +388,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(ImgView src0, ImgView pyr, c
     }
     for (int i = lane; i < (int)(map_bytes / 4); i += 64) reinterpret_cast<uint32_t*>(smap)[i] = 0;
     __builtin_amdgcn_wave_barrier();
+    WT_MARK(1, 0);   // cell record, geometry, ROI loads, LDS stores
 
     const int G = (aw + 7) >> 3, nitems = G * ah; // 8-pixel groups per active row
     const float inv_G = 1.0f / (float)G;
@@ -414,6 +442,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(ImgView src0, ImgView pyr, c
             n1 += __builtin_amdgcn_readlane(incl, 63);
         }
         __builtin_amdgcn_wave_barrier();
+        WT_MARK(1, 1);   // prefilter + compaction
         // ---- 2: exact score of the survivors; corners (score >= t) into the score map, list compacted in place
         // (order-preserving; writes trail reads)
         nlist = 0;
@@ -448,6 +477,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(ImgView src0, ImgView pyr, c
             nlist += __popcll(m);
         }
         __builtin_amdgcn_wave_barrier();
+        WT_MARK(1, 2);   // scores
         // ---- 3: strict 3x3 maximum inside the cell
         keepbits = 0;
         int nkeep = 0;
@@ -464,6 +494,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(ImgView src0, ImgView pyr, c
             keepbits |= (unsigned long long)keep << k;
             nkeep += __popcll(__ballot(keep));
         }
+        WT_MARK(1, 3);   // NMS
         if (nkeep > 0 || pass_no == 1) break;
         // nothing at iniThFAST: wipe the scores and try again at minThFAST
         for (int e = lane; e < nlist; e += 64) {
@@ -489,6 +520,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(ImgView src0, ImgView pyr, c
         nout += __popcll(m);
     }
     if (lane == 0) *cnt_out = nout;
+    WT_MARK(1, 4);   // write-out
 }
 
 // ------------------------------------------------------------------------------------------------ quadtree --
@@ -1439,22 +1471,32 @@ __global__ __launch_bounds__(256) BL_ATTR void k_blur7(ImgView src0, ImgView pyr
         if (more) bl_load_rows(img, pitch, g, tx0, tyb + 64 - 3, 6, nrr_next, tid, 4, w); // rows 6.. of the next tile
         // ---- vertical pass: one thread = 4 adjacent columns x 4 consecutive rows, stored as four aligned dwords
         if (4 * q < nrows_out && x < g.bpitch) {
-            uint32_t out[4] = {0, 0, 0, 0};
+            // sat_u8(sum >> 16) of four columns into one dword per row: the high halves of two columns' sums side by side (v_perm), both
+            // saturated and packed by ONE v_sat_pk_u8_i16 (sum >> 16 <= 257), the two column pairs joined by a v_perm: 20 instructions for the
+            // 16 pixels where shift / min / shift-or per pixel took 48
+            uint32_t out[4], qp[2][4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t* hp = reinterpret_cast<const uint32_t*>(&sh[(c4 + j) * BL_CP + 4 * q]);
-                const uint32_t d0 = hp[0], d1 = hp[1], d2 = hp[2], d3 = hp[3], d4 = hp[4];
-                const uint32_t a01 = __builtin_amdgcn_alignbit(d1, d0, 16), a12 = __builtin_amdgcn_alignbit(d2, d1, 16);
-                const uint32_t a23 = __builtin_amdgcn_alignbit(d3, d2, 16), a34 = __builtin_amdgcn_alignbit(d4, d3, 16);
-                const uint32_t o0 = bl_dot2(d0, V01, bl_dot2(d1, V23, bl_dot2(d2, V45, bl_dot2(d3, V6, 32768u))));
-                const uint32_t o1 = bl_dot2(a01, V01, bl_dot2(a12, V23, bl_dot2(a23, V45, bl_dot2(a34, V6, 32768u))));
-                const uint32_t o2 = bl_dot2(d1, V01, bl_dot2(d2, V23, bl_dot2(d3, V45, bl_dot2(d4, V6, 32768u))));
-                const uint32_t o3 = bl_dot2(a12, V01, bl_dot2(a23, V23, bl_dot2(a34, V45, bl_dot2(d4, V6H, 32768u))));
-                out[0] |= min(o0 >> 16, 255u) << (8 * j);
-                out[1] |= min(o1 >> 16, 255u) << (8 * j);
-                out[2] |= min(o2 >> 16, 255u) << (8 * j);
-                out[3] |= min(o3 >> 16, 255u) << (8 * j);
+            for (int jp = 0; jp < 2; jp++) {
+                uint32_t o[2][4];
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++) {
+                    const uint32_t* hp = reinterpret_cast<const uint32_t*>(&sh[(c4 + 2 * jp + jj) * BL_CP + 4 * q]);
+                    const uint32_t d0 = hp[0], d1 = hp[1], d2 = hp[2], d3 = hp[3], d4 = hp[4];
+                    const uint32_t a01 = __builtin_amdgcn_alignbit(d1, d0, 16), a12 = __builtin_amdgcn_alignbit(d2, d1, 16);
+                    const uint32_t a23 = __builtin_amdgcn_alignbit(d3, d2, 16), a34 = __builtin_amdgcn_alignbit(d4, d3, 16);
+                    o[jj][0] = bl_dot2(d0, V01, bl_dot2(d1, V23, bl_dot2(d2, V45, bl_dot2(d3, V6, 32768u))));
+                    o[jj][1] = bl_dot2(a01, V01, bl_dot2(a12, V23, bl_dot2(a23, V45, bl_dot2(a34, V6, 32768u))));
+                    o[jj][2] = bl_dot2(d1, V01, bl_dot2(d2, V23, bl_dot2(d3, V45, bl_dot2(d4, V6, 32768u))));
+                    o[jj][3] = bl_dot2(a12, V01, bl_dot2(a23, V23, bl_dot2(a34, V45, bl_dot2(d4, V6H, 32768u))));
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const uint32_t pr = __builtin_amdgcn_perm(o[1][r], o[0][r], 0x07060302u);   // (sum of column 2 jp) >> 16 | (column 2 jp + 1) >> 16 << 16
+                    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(qp[jp][r]) : "v"(pr));
+                }
             }
+#pragma unroll
+            for (int r = 0; r < 4; r++) out[r] = __builtin_amdgcn_perm(qp[1][r], qp[0][r], 0x05040100u);
             const int y0 = tyb + 4 * q;
 #pragma unroll
             for (int j = 0; j < 4; j++)
@@ -1504,6 +1546,7 @@ __global__ __launch_bounds__(256) OD2_ATTR void k_orient_describe2(ImgView src0,
                                                           uint8_t* __restrict__ desc, int capacity, int nx, int total)
 {
     const int lane = threadIdx.x & 63, wid = wave_id();
+    WT_BEGIN();
     int bx, f;
     if (!xcd_remap(nx, total, bx, f)) return;
     constexpr int PROW = 40, PATB = 31 * PROW + 8, WINB = 37 * 40 + 8;   // (rows of 8-byte multiples: the chunks go in as 8-byte stores)
@@ -1522,7 +1565,9 @@ __global__ __launch_bounds__(256) OD2_ATTR void k_orient_describe2(ImgView src0,
     const uint32_t kv_pre[2] = {flat_kv[slot0], flat_kv[slot1]};
     const int lvl_pre[2] = {flat_lvl[slot0], flat_lvl[slot1]};
     const int nk = n_out[f];
+    WT_MARK(0, 0);   // tables, barrier, records
     if (o0 >= nk) return;
+    WT_COUNT(0);
     const bool two = o0 + 1 < nk;
     const int half = lane >> 5, r = lane & 31;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -1564,6 +1609,7 @@ __global__ __launch_bounds__(256) OD2_ATTR void k_orient_describe2(ImgView src0,
         v[h][0] = *reinterpret_cast<const u32x4_unaligned*>(pimg + (uint32_t)(__mul24(r0, pitch) + c0));
         v[h][1] = *reinterpret_cast<const u32x4_unaligned*>(pimg + (uint32_t)(__mul24(pr1, pitch) + c1));
     }
+    WT_MARK(0, 1);   // geometry, addresses, loads issued
     // a chunk goes into its 40-byte LDS row as 8-byte halves; the second half of a row's last chunk would be the next row's first bytes
     auto put_chunk = [&](uint8_t* base, int row, int c, const u32x4& q) {
         uint2* d = reinterpret_cast<uint2*>(base + row * 40 + c);
@@ -1576,6 +1622,7 @@ __global__ __launch_bounds__(256) OD2_ATTR void k_orient_describe2(ImgView src0,
         put_chunk(&s_pat[wid][h][0], pr1, c1, v[h][1]);
     }
     __builtin_amdgcn_wave_barrier();
+    WT_MARK(0, 2);   // patches arrived and stored
     // ---- IC_Angle of both keypoints: lane = (keypoint, patch row v = r - 15): the row's 31 bytes as eight dwords re-cut at the byte
     // offset xo, m10 = sum (i - 15) I = dot(I, i) - 15 dot(I, 1) and m01 = v dot(I, 1) over the row's part of the circular patch
     // (umax, ORBextractor.cc:454-469), with the two weight vectors of the row (byte index i, ones; zero outside |u| <= umax(|v|))
@@ -1605,6 +1652,7 @@ __global__ __launch_bounds__(256) OD2_ATTR void k_orient_describe2(ImgView src0,
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     float a, b;
     orbfe_sincosf(angle * factorPI, &b, &a); // a = cos, b = sin
+    WT_MARK(0, 3);   // IC_Angle, atan2, sincos
     // ---- steered BRIEF on the staged window, one keypoint after the other on all lanes
     // The rotation is separate multiplies and adds (the reference is compiled without fused multiply-add) on packed f32: the two
     // points of a test side by side, (x0, x1) (b, b) + (y0, y1) (a, a), six v_pk_* instead of twelve scalar operations.  cvRound
@@ -1639,6 +1687,7 @@ __global__ __launch_bounds__(256) OD2_ATTR void k_orient_describe2(ImgView src0,
             const int t0 = bc[(int)i0], t1 = bc[(int)i1];
             words[j] = __ballot(t0 < t1);
         }
+        WT_MARK(0, 4 + h);   // window stored (h = 0: arrived), 256 tests
         if (h == 0 || two) {
             if (lane < 4) {
                 unsigned long long wd = lane == 0 ? words[0] : lane == 1 ? words[1] : lane == 2 ? words[2] : words[3];

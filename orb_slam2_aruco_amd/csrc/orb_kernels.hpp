@@ -62,7 +62,7 @@ __global__ void k_resize_level(ImgView src, ImgView dst, int sw, int sh, int dw4
                                double scale_y, int dw);
 #define RS_ROWS 8
 __global__ void k_resize_tab(ImgView src, ImgView dst, int sw, int sh, int dw4, int dh, int nthreads, const int* xofs,
-                             const int* xal, const int* yofs, const int* ybe, int nx, int total);
+                             const int* xal, const int4* ytab, int nx, int total);
 __global__ void k_fast_cells(ImgView src0, ImgView pyr, const LevelGeom* geom, const uint32_t* cellinfo,
                              uint32_t* slots, size_t slots_fstride, int32_t* cellcnt, int ncells_total, int iniTh,
                              int minTh, int roi_pitch, int roi_rows, int map_pitch, int map_rows, int list_cap, int nx, int total,

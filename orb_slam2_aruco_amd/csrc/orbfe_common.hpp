@@ -166,11 +166,10 @@ int aruco_speculate(orbfe_aruco* a, const uint8_t* d_img, size_t dframe, int row
 void aruco_speculation_wait(orbfe_aruco* a); // until the detector no longer reads the extractor's copy of the image
 void aruco_unpair_notice(orbfe_aruco* a);
 int aruco_device_of(const orbfe_aruco* a);   // the HIP device the detector was created on
-// Scheduling hook of the batched pipeline (csrc/pipeline.hip): `stream` waits until the detector's newest batch has left its contour
-// kernels (the LDS-latency-bound part of its chain, the one FAST stretches most and is stretched by); nothing if no batch ran yet.
-int aruco_contours_wait(orbfe_aruco* a, hipStream_t stream);
-void aruco_set_contours_gate(orbfe_aruco* a, orbfe_extractor* ex, int stage);   // the border walks of the NEXT batch behind that stage of `ex` (orbfe_extractor_stage_wait); nullptr / 0: off
-void extractor_set_fast_gate(orbfe_extractor* h, orbfe_aruco* det);   // FAST of every batch of `h` behind aruco_contours_wait(det) (nullptr: off)
+// The batched pipeline enqueues a batch's descriptor kernel itself, one step late: behind the NEXT batch's resize chain (gate / gate_stage
+// as in orbfe_extractor_stage_wait), so that the two kernels that live on the vector memory path do not run next to each other.
+void extractor_defer_describe(orbfe_extractor* h, bool on);
+int extractor_describe_now(orbfe_extractor* h, orbfe_extractor* gate, int gate_stage);   // FAST of every batch of `h` behind aruco_contours_wait(det) (nullptr: off)
 
 // Scratch of the entry points that have no handle (matching, poses, keyframe records): one workspace per calling thread,
 // HIP device and stream.  A buffer allocated on one GPU is never handed to a kernel on another, two asynchronous calls

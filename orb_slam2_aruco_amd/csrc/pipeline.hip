@@ -94,8 +94,8 @@ __global__ void k_copy_halo(const uint32_t* __restrict__ src_kps, uint32_t* __re
 struct orbfe_pipeline {
     orbfe_pipeline_config cfg{};
     int B = 0, rows = 0, cols = 0, cap = 0, mcap = 0, R = 0, D = 0;
-    int phase_pin = 0, det_pin = 0, contour_pin = 0;
-    bool defer_post = false, det_nofork = false, use_orb = true, use_aruco = true, fast_gate = false;
+    int phase_pin = 0, det_pin = 0;
+    bool defer_post = false, det_nofork = false, use_orb = true, use_aruco = true;
     std::vector<orbfe_extractor*> ex;
     orbfe_aruco* det = nullptr;               // detector of engine set 0 (= dets[0])
     std::vector<orbfe_aruco*> dets;           // ORBFE_ENGINE_SETS_ARUCO detector sets alternate batches (measurement switch; default 1)
@@ -222,6 +222,21 @@ struct orbfe_pipeline {
         return ORBFE_OK;
     }
 
+    // ORBFE_DESCRIBE_LATE: the descriptor kernel of the batch whose front part (pyramid, FAST, quadtree) was enqueued last, behind the
+    // resize chain of the batch on engine set `gate_set` (-1: no gate -- the flush)
+    bool describe_late = false;
+    int late_set = -1, late_cur = -1, late_in_slot = -1;
+    int finish_describe(int gate_set)
+    {
+        if (late_set < 0) return ORBFE_OK;
+        int rc = extractor_describe_now(ex[(size_t)late_set], gate_set >= 0 ? ex[(size_t)gate_set] : nullptr, 4);
+        if (rc) return rc;
+        ORBFE_HIP(hipEventRecord(ex_done[late_cur], st_ex[(size_t)late_set]));
+        if (late_in_slot >= 0) ORBFE_HIP(hipEventRecord(in_used_ex[late_in_slot], st_ex[(size_t)late_set]));
+        late_set = -1;
+        return ORBFE_OK;
+    }
+
     // what follows a batch's engines: its matching, its gather, and the halo of the next record set
     int enqueue_post(int cur)
     {
@@ -266,7 +281,7 @@ const char* orbfe_pipeline_env_defaults(void)
     // one list for the pipeline and the engines: bench.py marks a line as diagnostic when one of these is set to something else
     return "ORBFE_ENGINE_SETS=2;ORBFE_ENGINE_SETS_ARUCO=1;ORBFE_RECORD_SETS=4;ORBFE_PHASE_PIN=size;ORBFE_DET_PIN=4;ORBFE_DEFER_POST=size;ORBFE_DET_NOFORK=size;"
            "ORBFE_ARUCO_RELAY_WIDE=1;"
-           "ORBFE_ARUCO_SPECKS=0;ORBFE_ARUCO_THR_V2=1;ORBFE_FAST_GATE=0;ORBFE_CONTOUR_PIN=0;ORBFE_ARUCO_SMALL_SEPARATE=size;ORBFE_ARUCO_TILED=size;ORBFE_ARUCO_TILE_W=0;ORBFE_ARUCO_TPW=0;ORBFE_ARUCO_BANDED=size;ORBFE_ARUCO_BAND_ROWS=0;ORBFE_ARUCO_LCAP=0;ORBFE_GRAPH=0;"
+           "ORBFE_ARUCO_SPECKS=0;ORBFE_DESCRIBE_LATE=size;ORBFE_ARUCO_SMALL_SEPARATE=size;ORBFE_ARUCO_TILED=size;ORBFE_ARUCO_TILE_W=0;ORBFE_ARUCO_TPW=0;ORBFE_ARUCO_BANDED=size;ORBFE_ARUCO_BAND_ROWS=0;ORBFE_ARUCO_LCAP=0;ORBFE_GRAPH=0;"
            "ORBFE_NO_LEND=0;ORBFE_GRAPH_VERBOSE=0;ORBFE_RCCL_LIB=";
 }
 
@@ -337,6 +352,13 @@ orbfe_pipeline* orbfe_pipeline_create(const orbfe_pipeline_config* cfg)
         }
         if (p->phase_pin && p->D > 1)
             for (int d = 0; d < p->D; d++) orbfe_extractor_follow(p->ex[d], p->ex[(d + p->D - 1) % p->D], p->phase_pin);
+        // A batch's descriptor kernel one step late, behind the NEXT batch's resize chain (round 6).  Both live on the CU's vector memory
+        // path -- unaligned 8- and 16-byte lane loads -- and next to each other the resize chain, which is on the step's critical chain,
+        // took 400 - 450 us (200 alone); next to FAST, which is VALU-bound, the descriptors cost less than they gave back at 640 x 480:
+        // 1.308 against 1.338 ms per C2 step (twelve interleaved runs each; resize 294 - 336 us, FAST 810 - 890 instead of 610 - 690);
+        // 1280 x 720 3.895 against 3.870 and 1920 x 1080 3.265 against 3.262: off above 640 x 480.
+        p->describe_late = pick(-1, "ORBFE_DESCRIBE_LATE", vga ? 1 : 0) != 0 && p->D > 1;
+        if (p->describe_late) { p->defer_post = true; for (auto e : p->ex) extractor_defer_describe(e, true); }
         p->cap = orbfe_extractor_max_keypoints(p->ex[0]);
     } else
         p->cap = 1;
@@ -352,12 +374,6 @@ orbfe_pipeline* orbfe_pipeline_create(const orbfe_pipeline_config* cfg)
             if (p->det_nofork) orbfe_aruco_set_aux_stream(a, sd);
         }
         p->det = p->dets[0];
-        // The step's critical cycle, made explicit (round 6): threshold(i + 1) behind FAST(i) (ORBFE_DET_PIN=1), the border walks behind the
-        // threshold, FAST(i + 1) behind the border walks (ORBFE_FAST_GATE=1).  FAST and the relay contour kernel are each other's worst
-        // neighbours (LDS latency), and left to themselves the two chains drift in and out of the alignment that keeps them apart.
-        p->contour_pin = env_or("ORBFE_CONTOUR_PIN", 0);
-        p->fast_gate = env_or("ORBFE_FAST_GATE", 0) != 0 && p->use_orb && p->dets.size() == 1;
-        if (p->fast_gate) for (auto e : p->ex) extractor_set_fast_gate(e, p->det);
         p->mcap = std::min(orbfe_aruco_max_markers(p->det), std::max(1, cfg->marker_capacity));
     }
     orbfe_record_layout& L = p->lay;
@@ -564,8 +580,6 @@ static int step_body(orbfe_pipeline* p, const uint8_t* d_imgs, size_t pitch, int
             const long j = p->det_pin >= 10 ? i : i - 1; // + 10: a stage of THIS batch's extractor, which is then enqueued first
             if (j >= 0 && (rc = orbfe_extractor_stage_wait(p->ex[(size_t)(j % p->D)], p->det_pin % 10, st_det_i))) return rc;
         }
-        // ... and its border walks behind a stage of the extractor's previous batch (ORBFE_CONTOUR_PIN; 1 = its FAST)
-        aruco_set_contours_gate(det_i, (p->contour_pin && p->use_orb && i >= 1) ? p->ex[(size_t)((i - 1) % p->D)] : nullptr, p->contour_pin);
         orbfe_marker* mk = reinterpret_cast<orbfe_marker*>(base + p->lay.off_markers);
         int32_t* nmk = reinterpret_cast<int32_t*>(base + p->lay.off_nmarkers);
         if ((rc = orbfe_aruco_detect_batch_device(det_i, d_imgs, B, fstride, rows, cols, pitch, mk, p->mcap, nmk, st_det_i))) return rc;
@@ -589,6 +603,12 @@ static int step_body(orbfe_pipeline* p, const uint8_t* d_imgs, size_t pitch, int
         if ((rc = orbfe_extract_batch_device(p->ex[(size_t)eset], d_imgs, B, fstride, rows, cols, pitch, reinterpret_cast<orbfe_keypoint*>(p->slot_kps(cur, 1)),
                                              p->slot_desc(cur, 1), p->cap, p->slot_n(cur, 1), st)))
             return rc;
+        if (p->describe_late) {
+            // the PREVIOUS batch's descriptors now, behind this batch's resize chain; this batch's at the next step (or the flush)
+            if ((rc = p->finish_describe(eset))) return rc;
+            p->late_set = eset; p->late_cur = cur; p->late_in_slot = in_slot;
+            return ORBFE_OK;
+        }
         ORBFE_HIP(hipEventRecord(p->ex_done[cur], st));
         if (in_slot >= 0) ORBFE_HIP(hipEventRecord(p->in_used_ex[in_slot], st));
         return ORBFE_OK;
@@ -612,6 +632,7 @@ int orbfe_pipeline_flush(orbfe_pipeline* p)
     if (!p) return fail(ORBFE_ERR_INVALID, "null handle");
     int rc = use_device(p->cfg.device);
     if (rc) return rc;
+    if ((rc = p->finish_describe(-1))) { p->failed = true; return rc; }
     if (p->pending >= 0) {
         const int cur = p->pending;
         p->pending = -1;

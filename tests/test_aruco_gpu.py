@@ -607,3 +607,28 @@ def test_dense_noise_frame_in_a_small_batch(orbfe, oracle):
         assert all(np.array_equal(out[f]["id"], got[f]["id"]) for f in range(3))
     except orbfe.OrbfeError as e:
         assert "capacity" in str(e)
+
+
+@pytest.mark.parametrize("rows,cols", [(480, 640), (427, 641), (720, 1280), (1080, 1920), (96, 130), (64, 64)])
+def test_threshold_kernels_agree_and_the_fused_pyramid_is_the_pyramid(orbfe, oracle, rows, cols):
+    """k_threshold_pyr (round 6: packed 16-bit vertical pass, ballots through v_writelane, the /2 pyramid levels a 64 x 64 tile holds
+    written by the same launch) against k_adaptive_threshold_t + k_half_area4: the bit image, every pyramid level and the markers are
+    the same, on frame sizes with partial tiles, odd widths, inexact deeper levels and all four window sizes' neighbours."""
+    n = 2 if rows * cols <= 1280 * 720 else 1
+    imgs = synth.stream(rows, cols, n, 99, "ARUCO", n_markers=3 if rows >= 200 else 0)
+    a, b = orbfe.MarkerDetector("ARUCO"), orbfe.MarkerDetector("ARUCO")
+    b.set_threshold_pyramid_kernel(False)
+    ma, mb = a.detect_batch(imgs), b.detect_batch(imgs)
+    for f in range(n):
+        assert np.array_equal(a.thresholded(f), b.thresholded(f)), (rows, cols, f)
+        win = max(3, int(15 * float(cols) / 1920.)) | 1
+        assert np.array_equal(a.thresholded(f), oracle.adaptive_threshold(imgs[f], win, 7)), (rows, cols, f)   # (window: markerdetector_impl.cpp:3765-3809)
+        lvl = 1
+        while True:
+            la, lb = a.pyramid_level(lvl, f), b.pyramid_level(lvl, f)
+            if la is None or lb is None:
+                assert la is None and lb is None
+                break
+            assert np.array_equal(la, lb), (rows, cols, f, lvl)
+            lvl += 1
+        assert np.array_equal(ma[f], mb[f])
