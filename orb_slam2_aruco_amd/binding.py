@@ -341,6 +341,10 @@ class ORBextractor:
     def enable_kernel_timing(self, on=True):
         self.L.orbfe_extractor_debug_kernel_times(self.h, None, int(on))
 
+    def set_blur_on_matrix_cores(self, on=True):
+        """k_blur7_mfma (default) / k_blur7: the tests run both."""
+        self.L.orbfe_extractor_debug_kernel_times(self.h, None, 23 if on else 24)
+
     def force_general_quadtree(self, on=True):
         """Test hook: bypass the count-pyramid fast path of DistributeOctTree."""
         self.L.orbfe_extractor_debug_kernel_times(self.h, None, 2 if on else 3)

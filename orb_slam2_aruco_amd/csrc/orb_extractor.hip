@@ -137,7 +137,7 @@ struct orbfe_extractor {
 
     ~orbfe_extractor()
     {
-        for (DevBuf* b : {&d_geom, &d_cellinfo, &d_tiles, &d_tabs, &d_pattern, &d_umax, &d_pyr, &d_blur, &d_slots,
+        for (DevBuf* b : {&d_geom, &d_cellinfo, &d_tiles, &d_tabs, &d_pattern, &d_umax, &d_bstrips, &d_btabs, &d_btab2, &d_pyr, &d_blur, &d_slots,
                           &d_cellcnt, &d_keys, &d_lvlout, &d_lvlcnt, &d_lvloff, &d_lvlncand, &d_overflow, &d_fallback, &d_flatkv,
                           &d_flatlvl, &d_worklist, &d_in,
                           &d_kps, &d_desc, &d_nout})
@@ -377,6 +377,82 @@ struct orbfe_extractor {
         return ORBFE_OK;
     }
 
+    // Tables of k_blur7_mfma for the geometry and the taps in force: the strips (level-major), per strip the two pass-1 tap matrices in the
+    // B-operand layout of v_mfma_i32_32x32x32_i8 (lane (n, half) holds B[16 half + i][n], i = 0 .. 15, as 16 bytes), BORDER_REFLECT_101
+    // folded in, and the two pass-2 matrices whose K index runs over a block's rows in the order pass 1 leaves them in a lane's registers.
+    DevBuf d_bstrips, d_btabs, d_btab2;
+    int n_bstrips = 0, blur_tabs_ed = -1, blur_tabs_rows = 0, blur_tabs_cols = 0;
+    bool blur_mfma_ok = false;
+    bool blur_mfma = true;               // test hook (debug code 23 / 24): k_blur7 instead
+    int build_blur_tables()
+    {
+        if (blur_tabs_ed == (int)gaussian_ed && blur_tabs_rows == rows && blur_tabs_cols == cols) return ORBFE_OK;
+        static const int T0[7] = {18, 34, 49, 55, 49, 34, 18}, T1[7] = {18, 34, 48, 56, 48, 34, 18};
+        const int* t = gaussian_ed ? T1 : T0;
+        std::vector<BlurStrip> st;
+        std::vector<uint8_t> tabs;
+        bool ok = true;
+        auto refl = [](int p, int n) { while (p < 0 || p >= n) p = (p < 0) ? -p : 2 * (n - 1) - p; return p; };
+        for (int l = 0; l < nlevels && ok; l++) {
+            const int w = geom[l].w, rowbytes = l == 0 ? w : geom[l].pitch;
+            if (w < 48 || rowbytes < 16) { ok = false; break; }
+            for (int X = 0; X < w; X += 32) {
+                BlurStrip S{};
+                S.level = l; S.x0 = X; S.tab = (int)(tabs.size() / 1024);
+                auto cl = [&](int c) { return std::min(std::max(c, 0), rowbytes - 16); };
+                S.c0 = cl(X - 4); S.c1 = cl(X + 12); S.c2 = cl(X + 28);
+                const int cs[3] = {S.c0, S.c1, S.c2};
+                // weight of input column xin for output column n
+                std::vector<int> W((size_t)w * 32, 0);
+                for (int n = 0; n < 32; n++) {
+                    if (X + n >= w) continue;
+                    for (int u = 0; u < 7; u++) W[(size_t)refl(X + n + u - 3, w) * 32 + n] += t[u];
+                }
+                std::vector<int> owner((size_t)w, -1);
+                for (int x = 0; x < w; x++)
+                    for (int pz = 0; pz < 3 && owner[x] < 0; pz++)
+                        if (x >= cs[pz] && x < cs[pz] + 16) owner[x] = pz;
+                for (int x = 0; x < w && ok; x++)
+                    for (int n = 0; n < 32; n++)
+                        if (W[(size_t)x * 32 + n] && (owner[x] < 0 || W[(size_t)x * 32 + n] > 127)) ok = false;
+                const size_t base = tabs.size();
+                tabs.resize(base + 2048, 0);
+                for (int ab = 0; ab < 2; ab++)
+                    for (int lane = 0; lane < 64; lane++) {
+                        const int n = lane & 31, half = lane >> 5;
+                        const int piece = ab == 0 ? half : (half == 0 ? 2 : -1);
+                        if (piece < 0) continue;
+                        for (int i = 0; i < 16; i++) {
+                            const int x = cs[piece] + i;
+                            if (x < 0 || x >= w || owner[x] != piece) continue;
+                            tabs[base + (size_t)ab * 1024 + (size_t)lane * 16 + i] = (uint8_t)(int8_t)W[(size_t)x * 32 + n];
+                        }
+                    }
+                st.push_back(S);
+            }
+        }
+        blur_mfma_ok = ok && !st.empty();
+        blur_tabs_ed = (int)gaussian_ed; blur_tabs_rows = rows; blur_tabs_cols = cols;
+        if (!blur_mfma_ok) return ORBFE_OK;   // (k_blur7 does such a geometry)
+        std::vector<uint8_t> t2(2048, 0);
+        for (int ab = 0; ab < 2; ab++)
+            for (int lane = 0; lane < 64; lane++) {
+                const int n = lane & 31, half = lane >> 5;
+                for (int i = 0; i < 16; i++) {
+                    const int q = 4 * half + (i & 3) + 8 * (i >> 2);
+                    const int u = ab == 0 ? q - n - 1 : q - n + 31;
+                    if (u >= 0 && u <= 6) t2[(size_t)ab * 1024 + (size_t)lane * 16 + i] = (uint8_t)t[u];
+                }
+            }
+        n_bstrips = (int)st.size();
+        int rc;
+        if ((rc = d_bstrips.ensure(st.size() * sizeof(BlurStrip))) || (rc = d_btabs.ensure(tabs.size())) || (rc = d_btab2.ensure(t2.size()))) return rc;
+        ORBFE_HIP(hipMemcpy(d_bstrips.p, st.data(), st.size() * sizeof(BlurStrip), hipMemcpyHostToDevice));
+        ORBFE_HIP(hipMemcpy(d_btabs.p, tabs.data(), tabs.size(), hipMemcpyHostToDevice));
+        ORBFE_HIP(hipMemcpy(d_btab2.p, t2.data(), t2.size(), hipMemcpyHostToDevice));
+        return ORBFE_OK;
+    }
+
     int ensure_workspace(int B)
     {
         if (B <= batch_cap) return ORBFE_OK;
@@ -412,6 +488,7 @@ struct orbfe_extractor {
         int rc;
         if ((rc = build_geometry(rows_, cols_))) return rc;
         if ((rc = ensure_workspace(B))) return rc;
+        if ((rc = build_blur_tables())) return rc;
         ImgView src0{d_imgs, nullptr, frame_stride, (int)step};
         ImgView pyr{d_pyr.as<uint8_t>(), d_pyr.as<uint8_t>(), pyr_fbytes, 0};
         ImgView blur{d_blur.as<uint8_t>(), d_blur.as<uint8_t>(), blur_fbytes, 0};
@@ -499,7 +576,14 @@ struct orbfe_extractor {
             ORBFE_HIP(hipEventRecord(ev_fork, s));
             ORBFE_HIP(hipStreamWaitEvent(aux_stream, ev_fork, 0));
             timer.mark(aux_stream, "blur7 starts", true);
-            for (int r_ = 0; r_ < ORBFE_REPS_ORB(8); r_++) blur_strips(0, ntiles);
+            for (int r_ = 0; r_ < ORBFE_REPS_ORB(8); r_++) {
+                if (blur_mfma && blur_mfma_ok) {   // the matrix-core kernel (a wave per 32-column strip, four to a workgroup)
+                    const int T = gaussian_ed ? 256 : 257, nxb = (n_bstrips + 3) / 4;
+                    hipLaunchKernelGGL(k_blur7_mfma, dim3(xcd_grid(nxb * B)), dim3(256), 0, aux_stream, src0, pyr, blur, dg, d_bstrips.as<BlurStrip>(),
+                                       d_btabs.as<uint4>(), d_btab2.as<uint4>(), 128 * T * T + 32768, n_bstrips, nxb, nxb * B);
+                } else
+                    blur_strips(0, ntiles);
+            }
             timer.mark(aux_stream, "blur7");
             ORBFE_HIP(hipEventRecord(ev_join, aux_stream));
             return ORBFE_OK;
@@ -935,6 +1019,7 @@ int orbfe_extractor_debug_kernel_times(orbfe_extractor* h, float* out_us, int ca
         else if (capacity == 3) h->force_general_quadtree = false;
         else if (capacity >= 10 && capacity <= 16) h->force_pyramid_depth = capacity - 10; // 10 = default depth
         else if (capacity >= 20 && capacity <= 22) h->blur_place = capacity - 20;
+        else if (capacity == 23 || capacity == 24) h->blur_mfma = capacity == 23;   // the blur on the matrix cores (default) / k_blur7
         else { h->timer.enabled = capacity != 0; h->timer.reset_history(); }
         return 0;
     }

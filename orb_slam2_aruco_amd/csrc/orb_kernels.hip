@@ -1516,6 +1516,111 @@ __global__ __launch_bounds__(256) BL_ATTR void k_blur7(ImgView src0, ImgView pyr
 template __global__ void k_blur7<false>(ImgView, ImgView, ImgView, const LevelGeom*, const uint32_t*, int, int);
 template __global__ void k_blur7<true>(ImgView, ImgView, ImgView, const LevelGeom*, const uint32_t*, int, int);
 
+// The same blur on the matrix cores (round 6).  The pipeline is bound by vector-ALU issue (the twelve stages issue 985 us of VALU work in
+// a 1.3 ms step) while the matrix pipe idles; a 7-tap filter is a banded (Toeplitz) matrix, and v_mfma_i32_32x32x32_i8 does 32 K integer
+// multiply-adds exactly in the time of eight VALU instructions.  One WAVE walks a 32-column strip of a level from top to bottom in blocks
+// of 32 rows:
+//   pass 1  H = P x T1: A = the block's pixels minus 128 (signed bytes; lane = row, 16 consecutive bytes of it: one unaligned 16-byte
+//           load), B = the strip's tap matrix.  32 outputs need 38 inputs: two K blocks, i.e. three 16-byte pieces of the row (the
+//           third one only feeds the second block's first seven columns).  BORDER_REFLECT_101 in x is folded into the tap matrix by the
+//           host (a reflected tap adds its weight to the column it lands on), in y it is the lane's row index.  With 128 as the
+//           accumulator's start value H'' = H - 128 T + 128 lies in [-32768, 32767] (T = the taps' sum, 257 or 256).
+//   planes  the accumulator layout of pass 1 -- lane = output column, registers = 16 rows -- IS the A layout of pass 2 (lane = row of A,
+//           16 values along K), with K = image row in the registers' order; the tap matrix of pass 2 is built in that order.  An
+//           accumulator is split into its high byte and its low byte minus 128 (both signed bytes): 7 instructions per 4 values.
+//   pass 2  out^T = H^T x T2 for the two byte planes, over this block and the previous one (an output row reaches 3 rows into the next
+//           block): four MFMA; S = (hi << 8) + lo with every constant (the 128s, the rounding 32768) in lo's start value.
+//   store   lane = output row, four registers = four consecutive pixels: v_perm + v_sat_pk_u8_i16 as in k_blur7.
+// ~100 VALU instructions per 32 x 32 pixels (6.4 lane operations a pixel; k_blur7: 16) and six MFMA; no LDS, no barrier.
+typedef int bm_v4i __attribute__((ext_vector_type(4)));
+typedef int bm_v16i __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void k_blur7_mfma(ImgView src0, ImgView pyr, ImgView blur, const LevelGeom* __restrict__ geom,
+                                                    const BlurStrip* __restrict__ strips, const uint4* __restrict__ tabs,
+                                                    const uint4* __restrict__ tab2, int K2, int nstrips, int nx, int total)
+{
+    constexpr int BM_PP = 9;   // dwords per row of a wave's 32 x 32-byte output patch (odd: the rows fall on different banks)
+    __shared__ uint32_t s_patch[4][32 * BM_PP];
+    const int lane = threadIdx.x & 63, wid = wave_id();
+    int bx, f;
+    if (!xcd_remap(nx, total, bx, f)) return;
+    const int si = bx * 4 + wid;
+    if (si >= nstrips) return;
+    uint32_t* patch = s_patch[wid];
+    const BlurStrip S = strips[si];
+    const LevelGeom& g = geom[S.level];
+    const int r = lane & 31, half = lane >> 5;
+    const uint8_t* img = (S.level == 0) ? src0.base + (size_t)f * src0.fstride : pyr.base + (size_t)f * pyr.fstride + g.img_off;
+    const int pitch = (S.level == 0) ? src0.pitch : g.pitch;
+    uint8_t* D = blur.base_w + (size_t)f * blur.fstride + g.blur_off;
+    const int h = g.h, wst = (g.w + 3) & ~3, bpitch = g.bpitch;
+    const bm_v4i B1a = __builtin_bit_cast(bm_v4i, tabs[(size_t)S.tab * 64 + lane]), B1b = __builtin_bit_cast(bm_v4i, tabs[(size_t)(S.tab + 1) * 64 + lane]);
+    const bm_v4i B2a = __builtin_bit_cast(bm_v4i, tab2[lane]), B2b = __builtin_bit_cast(bm_v4i, tab2[64 + lane]);
+    const uint32_t ca = (uint32_t)(half ? S.c1 : S.c0), cb = (uint32_t)S.c2;   // K block a: pieces 0 | 1 by half; K block b: piece 2 (its second half has no weight)
+    typedef uint32_t bm_u32x4 __attribute__((ext_vector_type(4)));
+    typedef bm_u32x4 bm_u32x4_unaligned __attribute__((aligned(1)));   // (level 0 is the caller's buffer: no alignment is assumed)
+    const int nblk = ((h + 31) >> 5) + 1;
+    auto load_rows = [&](int j, bm_u32x4& pa, bm_u32x4& pb) {
+        const uint32_t ro = off24(reflect101(32 * j - 4 + r, h), pitch);
+        pa = *reinterpret_cast<const bm_u32x4_unaligned*>(img + (ro + ca));
+        pb = *reinterpret_cast<const bm_u32x4_unaligned*>(img + (ro + cb));
+    };
+    bm_u32x4 na, nb;
+    load_rows(0, na, nb);
+    bm_v4i ph = {0, 0, 0, 0}, pl = {0, 0, 0, 0};
+    for (int j = 0; j < nblk; j++) {
+        const bm_u32x4 qa = na, qb = nb;
+        if (j + 1 < nblk) load_rows(j + 1, na, nb);   // the next block's rows are in flight while this one is worked on
+        constexpr uint32_t SGN = 0x80808080u;
+        const bm_v4i A1a = {(int)(qa.x ^ SGN), (int)(qa.y ^ SGN), (int)(qa.z ^ SGN), (int)(qa.w ^ SGN)};
+        const bm_v4i A1b = {(int)(qb.x ^ SGN), (int)(qb.y ^ SGN), (int)(qb.z ^ SGN), (int)(qb.w ^ SGN)};
+        bm_v16i acc = {128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128};
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1a, B1a, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1b, B1b, acc, 0, 0, 0);
+        // planes: byte 1 (the signed high byte) and byte 0 minus 128 of four accumulators into one register each
+        bm_v4i nh, nl;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t a0 = (uint32_t)acc[4 * q], a1 = (uint32_t)acc[4 * q + 1], a2 = (uint32_t)acc[4 * q + 2], a3 = (uint32_t)acc[4 * q + 3];
+            const uint32_t h01 = __builtin_amdgcn_perm(a1, a0, 0x0c0c0501u), h23 = __builtin_amdgcn_perm(a3, a2, 0x05010c0cu);
+            const uint32_t l01 = __builtin_amdgcn_perm(a1, a0, 0x0c0c0400u), l23 = __builtin_amdgcn_perm(a3, a2, 0x04000c0cu);
+            nh[q] = (int)(h01 | h23);
+            nl[q] = (int)((l01 | l23) ^ SGN);
+        }
+        if (j >= 1) {
+            bm_v16i ah = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            bm_v16i al = {K2, K2, K2, K2, K2, K2, K2, K2, K2, K2, K2, K2, K2, K2, K2, K2};
+            ah = __builtin_amdgcn_mfma_i32_32x32x32_i8(ph, B2a, ah, 0, 0, 0);
+            ah = __builtin_amdgcn_mfma_i32_32x32x32_i8(nh, B2b, ah, 0, 0, 0);
+            al = __builtin_amdgcn_mfma_i32_32x32x32_i8(pl, B2a, al, 0, 0, 0);
+            al = __builtin_amdgcn_mfma_i32_32x32x32_i8(nl, B2b, al, 0, 0, 0);
+            // the tile through the wave's LDS patch: written in the accumulators' layout (lane = row, four pixels a register group), read
+            // back with lanes along x -- a store instruction then covers 8 rows x 32 bytes instead of 32 rows x 8 bytes (stored straight
+            // from the accumulators the kernel was bound by its partial-line stores: 400 us next to FAST, 227 without them)
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                uint32_t s4[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) s4[k] = ((uint32_t)ah[4 * q + k] << 8) + (uint32_t)al[4 * q + k];
+                uint32_t p01, p23;
+                const uint32_t pr01 = __builtin_amdgcn_perm(s4[1], s4[0], 0x07060302u), pr23 = __builtin_amdgcn_perm(s4[3], s4[2], 0x07060302u);
+                asm("v_sat_pk_u8_i16 %0, %1" : "=v"(p01) : "v"(pr01));
+                asm("v_sat_pk_u8_i16 %0, %1" : "=v"(p23) : "v"(pr23));
+                patch[r * BM_PP + half + 2 * q] = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int x = S.x0 + 4 * (lane & 7);
+#pragma unroll
+            for (int it = 0; it < 4; it++) {
+                const int rr = (lane >> 3) + 8 * it, y = 32 * (j - 1) + rr;
+                const uint32_t v = patch[rr * BM_PP + (lane & 7)];
+                if (y < h && x < wst) *reinterpret_cast<uint32_t*>(D + (off24(y, bpitch) + (uint32_t)x)) = v;
+            }
+        }
+        ph = nh; pl = nl;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ describe --
 // IC_Angle on the un-blurred level (:77-104), then the 256 steered BRIEF tests on the blurred level (:108-147), then the final record.
 // Two keypoints per wave.  A third of the instructions of one keypoint do not depend on the lane: fastAtan2 and sin / cos of the one

@@ -90,6 +90,11 @@ inline size_t qp_lds_bytes(int nIni, int D, int nodecap, int veccap)
 __global__ void k_level_offsets(const int32_t* lvl_cnt, int32_t* lvl_off, int32_t* n_out, int nlevels, int nframes,
                                 int capacity, int32_t* overflow, const LevelGeom* geom, const uint32_t* lvl_out,
                                 int out_fstride, uint32_t* flat_kv, uint8_t* flat_lvl, int32_t* worklist_n);
+// k_blur7_mfma: a 32-column strip of a level per wave; c0 / c1 / c2 = byte columns of the three 16-byte pieces of a row it loads, tab =
+// index (units of 64 uint4) of the strip's two pass-1 tap matrices in operand layout (orb_extractor.hip: build_blur_tables)
+struct BlurStrip { int level, x0, c0, c1, c2, tab; };
+__global__ void k_blur7_mfma(ImgView src0, ImgView pyr, ImgView blur, const LevelGeom* geom, const BlurStrip* strips, const uint4* tabs,
+                             const uint4* tab2, int K2, int nstrips, int nx, int total);
 template <bool ED> __global__ void k_blur7(ImgView src0, ImgView pyr, ImgView blur, const LevelGeom* geom, const uint32_t* strips, int nx,
                         int total);
 __global__ void k_orient_describe2(ImgView src0, ImgView pyr, ImgView blur, const LevelGeom* geom,
