@@ -107,7 +107,10 @@ struct orbfe_aruco {
     //     doubles the stage's HBM traffic (148 -> 268 MB per step).
     // ORBFE_ARUCO_SPECKS = 0 (default) / 1 / 2.  Debug codes 8 / 9: the launch on / off, 10 / 11: inside.  Tested either way
     // (tests/test_aruco_gpu.py, tests/test_stress_gpu.py).
-    int specks = getenv("ORBFE_ARUCO_SPECKS") && atoi(getenv("ORBFE_ARUCO_SPECKS")) == 1 ? 1 : 0;
+    // the speck passes as a launch between threshold and contours: -1 = where they pay (full batches on the one-workgroup relay kernels:
+    // 1.246 against 1.263 ms per C2 step with them, round 6; on the tiled paths 3.99 against 3.74 ms at 1280 x 720, 3.53 against 3.21 at
+    // 1920 x 1080), 0 / 1 = never / wherever their tile fits LDS (ORBFE_ARUCO_SPECKS, debug codes 8 / 9)
+    int specks = !getenv("ORBFE_ARUCO_SPECKS") ? -1 : atoi(getenv("ORBFE_ARUCO_SPECKS")) == 1 ? 1 : 0;
     bool specks_inkernel = getenv("ORBFE_ARUCO_SPECKS") && atoi(getenv("ORBFE_ARUCO_SPECKS")) == 2;
     bool thr_v2 = true;   // k_threshold_pyr where it applies (debug code 12 / 13: the tests run both threshold kernels)
     bool specks_ran = false;   // the last batch's contour kernels read d_bitsc
@@ -288,7 +291,8 @@ struct orbfe_aruco {
         npyr = (int)levels.size();
         pyr_fbytes = off + 64;
         // HBM overflow of the single-walker kernel's long-walk queue / the relay kernels' start-candidate queue, + their speck scratch
-        candq_fu32 = ((size_t)relay_queue_words(cols_, rows_) + speck_frame_scratch_words(cols_, rows_) + 63) / 64 * 64;
+        // (the speck scratch -- four times the queue at 640 x 480 -- only where the in-kernel passes are switched on)
+        candq_fu32 = ((size_t)relay_queue_words(cols_, rows_) + (specks_inkernel ? speck_frame_scratch_words(cols_, rows_) : 0) + 63) / 64 * 64;
         pool_fu32 = (size_t)CT_THREADS * std::max(4096, rows_ * cols_ / 48); // one private arena per lane of k_contours
         const int pw = (cols_ + 2 + 31) / 32;
         const size_t padded_words = (size_t)pw * (rows_ + 2) + 2; // + spare words for ring8()
@@ -351,7 +355,7 @@ struct orbfe_aruco {
     {
         if (B <= batch_cap) return ORBFE_OK;
         int rc;
-        if ((rc = d_bits.ensure(bits_fu32 * 4 * B)) || (rc = d_bitsc.ensure(bits_fu32 * 4 * B)) || (rc = d_pyr.ensure(pyr_fbytes * B)) ||
+        if ((rc = d_bits.ensure(bits_fu32 * 4 * B)) || (rc = d_pyr.ensure(pyr_fbytes * B)) ||   // (d_bitsc: when the speck launch runs)
             (rc = d_candq.ensure(candq_fu32 * 4 * B)) || (rc = d_pool.ensure(pool_fu32 * 4 * B)) ||
             (rc = d_kept.ensure((size_t)AR_MAX_KEPT_BIG * sizeof(ArKept) * B)) ||
             (rc = d_rects.ensure((size_t)AR_MAX_RECTS * sizeof(ArRect) * B)) || (rc = d_counts.ensure((size_t)16 * B)) ||
@@ -523,15 +527,6 @@ struct orbfe_aruco {
             else hipLaunchKernelGGL(k_adaptive_threshold<15>, tg, dim3(256), 0, s, srcW, cols, rows, win, thres_value, 1.0 / (win * win), bp, bits_fu32, wpr);
         }
         timer.mark(s, "threshold");
-        // the bit image the contour kernels read: after the speck passes, unless switched off or the frame is too wide for their LDS tile
-        const size_t spk_lds = speck_lds_bytes(cols);
-        specks_ran = specks > 0 && spk_lds <= 150 * 1024;
-        if (specks_ran) {
-            { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(k_speck_clean), spk_lds); if (rc_lds_) return rc_lds_; }
-            hipLaunchKernelGGL(k_speck_clean, dim3((rows + SPK_ROWS - 1) / SPK_ROWS, B), dim3(SPK_THREADS), spk_lds, s, d_bits.as<uint32_t>(), bits_fu32, wpr,
-                               cols, rows, d_bitsc.as<uint32_t>());
-        }
-        const uint32_t* cbits = specks_ran ? d_bitsc.as<uint32_t>() : d_bits.as<uint32_t>();
         const bool big = big_mode || !lds_bits_words;
         const int legacy_kcap = big ? AR_MAX_KEPT_BIG : AR_MAX_KEPT, legacy_ldsw = big ? 0 : lds_bits_words;
         const size_t lds = contours_lds_bytes(legacy_ldsw, legacy_kcap);
@@ -541,6 +536,17 @@ struct orbfe_aruco {
         const bool use_tiled = (tiled > 0 || (tiled < 0 && (relay_global || !relay_tbits || relay_tbits > 12 || B <= 32))) && !tiled_off && !force_legacy && !big_mode;
         tiled_ran = use_tiled;
         const bool relay = (relay_tbits || use_tiled) && !force_legacy && !big_mode;
+        // the bit image the contour kernels read: after the speck passes, unless switched off or the frame is too wide for their LDS tile
+        const size_t spk_lds = speck_lds_bytes(cols);
+        specks_ran = (specks > 0 || (specks < 0 && relay && !use_tiled && !relay_global && B > 32)) && spk_lds <= 150 * 1024;
+        if (specks_ran) {
+            if ((rc = d_bitsc.ensure(bits_fu32 * 4 * batch_cap))) return rc;
+            { int rc_lds_ = ensure_dyn_lds(reinterpret_cast<const void*>(k_speck_clean), spk_lds); if (rc_lds_) return rc_lds_; }
+            hipLaunchKernelGGL(k_speck_clean, dim3((rows + SPK_ROWS - 1) / SPK_ROWS, B), dim3(SPK_THREADS), spk_lds, s, d_bits.as<uint32_t>(), bits_fu32, wpr,
+                               cols, rows, d_bitsc.as<uint32_t>());
+        }
+        const uint32_t* cbits = specks_ran ? d_bitsc.as<uint32_t>() : d_bits.as<uint32_t>();
+
         for (int r_ = 0; relay && r_ < ORBFE_REPS_ARUCO(1); r_++) {
             if (use_tiled) {
                 // Tile width and waves.  k_ct_walk's waves are persistent and overlap their tiles, so a wave wants several tiles (its
@@ -1594,7 +1600,7 @@ int orbfe_aruco_debug_kernel_times(orbfe_aruco* h, float* out_us, int capacity)
                    // 7 returns the number of batches that were done again on the next contour path, 8 / 9 the speck passes on / off
         if (capacity == 7) return h->n_escalations;
         if (capacity == 8 || capacity == 9) { h->specks = capacity == 8 ? 1 : 0; return 0; }   // the speck passes on / off (default)
-        if (capacity == 10 || capacity == 11) { h->specks_inkernel = capacity == 10; return 0; }
+        if (capacity == 10 || capacity == 11) { h->specks_inkernel = capacity == 10; h->rows = h->cols = 0; return 0; }   // (the queue's size depends on it: geometry rebuilt)
         if (capacity == 12 || capacity == 13) { h->thr_v2 = capacity == 12; return 0; }   // the threshold kernel with the fused pyramid on (default) / off   // ... inside the relay kernels on / off (default)
         if (capacity == 2 || capacity == 3) h->force_legacy = capacity == 2;
         else if (capacity >= 4 && capacity <= 6) {

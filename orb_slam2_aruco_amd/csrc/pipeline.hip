@@ -281,7 +281,7 @@ const char* orbfe_pipeline_env_defaults(void)
     // one list for the pipeline and the engines: bench.py marks a line as diagnostic when one of these is set to something else
     return "ORBFE_ENGINE_SETS=2;ORBFE_ENGINE_SETS_ARUCO=1;ORBFE_RECORD_SETS=4;ORBFE_PHASE_PIN=size;ORBFE_DET_PIN=4;ORBFE_DEFER_POST=size;ORBFE_DET_NOFORK=size;"
            "ORBFE_ARUCO_RELAY_WIDE=1;"
-           "ORBFE_ARUCO_SPECKS=0;ORBFE_DESCRIBE_LATE=size;ORBFE_ARUCO_SMALL_SEPARATE=size;ORBFE_ARUCO_TILED=size;ORBFE_ARUCO_TILE_W=0;ORBFE_ARUCO_TPW=0;ORBFE_ARUCO_BANDED=size;ORBFE_ARUCO_BAND_ROWS=0;ORBFE_ARUCO_LCAP=0;ORBFE_GRAPH=0;"
+           "ORBFE_ARUCO_SPECKS=size;ORBFE_DESCRIBE_LATE=1;ORBFE_ARUCO_SMALL_SEPARATE=size;ORBFE_ARUCO_TILED=size;ORBFE_ARUCO_TILE_W=0;ORBFE_ARUCO_TPW=0;ORBFE_ARUCO_BANDED=size;ORBFE_ARUCO_BAND_ROWS=0;ORBFE_ARUCO_LCAP=0;ORBFE_GRAPH=0;"
            "ORBFE_NO_LEND=0;ORBFE_GRAPH_VERBOSE=0;ORBFE_RCCL_LIB=";
 }
 
@@ -355,9 +355,10 @@ orbfe_pipeline* orbfe_pipeline_create(const orbfe_pipeline_config* cfg)
         // A batch's descriptor kernel one step late, behind the NEXT batch's resize chain (round 6).  Both live on the CU's vector memory
         // path -- unaligned 8- and 16-byte lane loads -- and next to each other the resize chain, which is on the step's critical chain,
         // took 400 - 450 us (200 alone); next to FAST, which is VALU-bound, the descriptors cost less than they gave back at 640 x 480:
-        // 1.308 against 1.338 ms per C2 step (twelve interleaved runs each; resize 294 - 336 us, FAST 810 - 890 instead of 610 - 690);
-        // 1280 x 720 3.895 against 3.870 and 1920 x 1080 3.265 against 3.262: off above 640 x 480.
-        p->describe_late = pick(-1, "ORBFE_DESCRIBE_LATE", vga ? 1 : 0) != 0 && p->D > 1;
+        // 1.308 against 1.338 ms per C2 step (twelve interleaved runs each; resize 294 - 336 us, FAST 810 - 890 instead of 610 - 690).
+        // With the blur on the matrix cores (k_blur7_mfma) FAST has the vector ALUs more to itself and every size gains: C2 1.265
+        // against 1.327, 1280 x 720 3.70 against 3.74, 1920 x 1080 3.13 against 3.21 ms.
+        p->describe_late = pick(-1, "ORBFE_DESCRIBE_LATE", 1) != 0 && p->D > 1;
         if (p->describe_late) { p->defer_post = true; for (auto e : p->ex) extractor_defer_describe(e, true); }
         p->cap = orbfe_extractor_max_keypoints(p->ex[0]);
     } else

@@ -425,9 +425,14 @@ def test_tiled_path_completes_on_stream_frames(orbfe, rows, cols, dict_name):
     nf = 40 if rows < 1080 else 34
     imgs = synth.stream(rows, cols, nf, 4242, dict_name, n_markers=4)
     ref = orbfe.MarkerDetector(dict_name)
+    ref.set_speck_passes(False)          # (the start-candidate counts below are those of the thresholded image as it is)
     want = ref.detect_batch(imgs)
     wkeys = [(_rects_key(ref, f), ref.counts(f)) for f in range(nf)]
     assert ref.contour_retries() == 0
+    dflt = orbfe.MarkerDetector(dict_name)   # the shipped default: the speck passes run in front of the one-workgroup kernels of a full batch
+    got_dflt = dflt.detect_batch(imgs)
+    for f in range(nf):
+        assert np.array_equal(got_dflt[f], want[f]) and (dflt.counts(f)["nkept"], dflt.counts(f)["nrect"]) == (wkeys[f][1]["nkept"], wkeys[f][1]["nrect"])
     det = orbfe.MarkerDetector(dict_name)
     det.set_tiled_contours(True)
     for lo, hi in ((0, nf), (3, 11), (5, 6)):
