@@ -978,6 +978,10 @@ class MarkerDetector:
         """Debug: the speck passes between threshold and contours (k_speck_clean) on / off (default); the results do not change."""
         self.L.orbfe_aruco_debug_kernel_times(self.h, None, 8 if on else 9)
 
+    def set_threshold_on_matrix_cores(self, on=True):
+        """k_threshold_mfma (default where it applies: windows up to 11) / the dot-product kernels."""
+        self.L.orbfe_aruco_debug_kernel_times(self.h, None, 14 if on else 15)
+
     def set_threshold_pyramid_kernel(self, on=True):
         """k_threshold_pyr (threshold + the /2 pyramid levels a tile holds, the default where it applies) / k_adaptive_threshold_t + k_half_area4."""
         self.L.orbfe_aruco_debug_kernel_times(self.h, None, 12 if on else 13)

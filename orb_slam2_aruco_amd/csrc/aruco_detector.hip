@@ -112,6 +112,80 @@ struct orbfe_aruco {
     // 1920 x 1080), 0 / 1 = never / wherever their tile fits LDS (ORBFE_ARUCO_SPECKS, debug codes 8 / 9)
     int specks = !getenv("ORBFE_ARUCO_SPECKS") ? -1 : atoi(getenv("ORBFE_ARUCO_SPECKS")) == 1 ? 1 : 0;
     bool specks_inkernel = getenv("ORBFE_ARUCO_SPECKS") && atoi(getenv("ORBFE_ARUCO_SPECKS")) == 2;
+    bool thr_mfma = true;   // k_threshold_mfma where it applies (windows up to 11; debug code 14 / 15)
+    DevBuf d_tstrips, d_ttabs, d_ttab2;
+    int n_tstrips = 0, ttab_rows = 0, ttab_cols = 0, ttab_win = 0, ttab_rb = 0;
+    bool thr_mfma_ok = false;
+    // Tables of k_threshold_mfma: per 32-column strip the pass-1 matrices (box K blocks a / b, selection a / b) in the B-operand layout of
+    // v_mfma_i32_32x32x32_i8, BORDER_REPLICATE folded in; the pass-2 matrices (box over the previous / this block, centre x -WIN^2).
+    int build_threshold_tables()
+    {
+        if (ttab_rows == rows && ttab_cols == cols && ttab_win == win) return ORBFE_OK;
+        ttab_rows = rows; ttab_cols = cols; ttab_win = win;
+        const int R = win / 2, n2 = win * win, W = cols, rb = R <= 3 ? 4 : 8;
+        thr_mfma_ok = false;
+        if (n2 > 127 || W < 48) return ORBFE_OK;
+        std::vector<ThrStrip> st;
+        std::vector<uint8_t> tabs;
+        bool ok = true;
+        for (int X = 0; X < W; X += 32) {
+            ThrStrip S{};
+            S.x0 = X; S.tab = (int)(tabs.size() / 1024);
+            auto cl = [&](int c) { return std::min(std::max(c, 0), W - 16); };
+            S.c0 = cl(X - rb); S.c1 = cl(X - rb + 16); S.c2 = cl(X - rb + 32);
+            const int cs[3] = {S.c0, S.c1, S.c2};
+            std::vector<int> Wb((size_t)W * 32, 0), Wi((size_t)W * 32, 0);
+            for (int n = 0; n < 32; n++) {
+                if (X + n >= W) continue;
+                for (int u = -R; u <= R; u++) Wb[(size_t)std::min(std::max(X + n + u, 0), W - 1) * 32 + n] += 1;
+                Wi[(size_t)(X + n) * 32 + n] = 1;
+            }
+            std::vector<int> owner((size_t)W, -1);
+            for (int x = 0; x < W; x++)
+                for (int pz = 0; pz < 3 && owner[x] < 0; pz++)
+                    if (x >= cs[pz] && x < cs[pz] + 16) owner[x] = pz;
+            for (int x = 0; x < W && ok; x++)
+                for (int n = 0; n < 32; n++)
+                    if (Wb[(size_t)x * 32 + n] && owner[x] < 0) ok = false;
+            const size_t base = tabs.size();
+            tabs.resize(base + 4096, 0);
+            for (int m = 0; m < 4; m++)   // box a, box b, selection a, selection b
+                for (int lane = 0; lane < 64; lane++) {
+                    const int n = lane & 31, half = lane >> 5, ab = m & 1;
+                    const int piece = ab == 0 ? half : (half == 0 ? 2 : -1);
+                    if (piece < 0) continue;
+                    for (int i = 0; i < 16; i++) {
+                        const int x = cs[piece] + i;
+                        if (x < 0 || x >= W || owner[x] != piece) continue;
+                        tabs[base + (size_t)m * 1024 + (size_t)lane * 16 + i] = (uint8_t)(int8_t)((m < 2 ? Wb : Wi)[(size_t)x * 32 + n]);
+                    }
+                }
+            st.push_back(S);
+        }
+        if (!ok || st.empty()) return ORBFE_OK;
+        std::vector<uint8_t> t2(4096, 0);
+        for (int m = 0; m < 4; m++)   // box over the previous block, over this block, centre in the previous block, in this block
+            for (int lane = 0; lane < 64; lane++) {
+                const int n = lane & 31, half = lane >> 5;
+                for (int i = 0; i < 16; i++) {
+                    const int q = 4 * half + (i & 3) + 8 * (i >> 2);
+                    const int d = ((m & 1) ? 32 : 0) + q - rb - n;   // the row's offset from the output row
+                    int v = 0;
+                    if (m < 2) v = (d >= -R && d <= R) ? 1 : 0;
+                    else v = d == 0 ? -n2 : 0;
+                    t2[(size_t)m * 1024 + (size_t)lane * 16 + i] = (uint8_t)(int8_t)v;
+                }
+            }
+        n_tstrips = (int)st.size();
+        ttab_rb = rb;
+        int rc;
+        if ((rc = d_tstrips.ensure(st.size() * sizeof(ThrStrip))) || (rc = d_ttabs.ensure(tabs.size())) || (rc = d_ttab2.ensure(t2.size()))) return rc;
+        ORBFE_HIP(hipMemcpy(d_tstrips.p, st.data(), st.size() * sizeof(ThrStrip), hipMemcpyHostToDevice));
+        ORBFE_HIP(hipMemcpy(d_ttabs.p, tabs.data(), tabs.size(), hipMemcpyHostToDevice));
+        ORBFE_HIP(hipMemcpy(d_ttab2.p, t2.data(), t2.size(), hipMemcpyHostToDevice));
+        thr_mfma_ok = true;
+        return ORBFE_OK;
+    }
     bool thr_v2 = true;   // k_threshold_pyr where it applies (debug code 12 / 13: the tests run both threshold kernels)
     bool specks_ran = false;   // the last batch's contour kernels read d_bitsc
     DevBuf d_bitsc;
@@ -169,7 +243,7 @@ struct orbfe_aruco {
     {
         for (DevBuf* b : {&d_codes, &d_levels, &d_tabs, &d_bits, &d_pyr, &d_candq, &d_pool, &d_kept, &d_rects,
                           &d_counts, &d_candidx, &d_ncand, &d_result, &d_gpad, &d_in, &d_out, &d_nout, &d_segs, &d_tailkeys, &d_tailoff, &d_small, &d_hint, &d_rstate, &d_lut, &d_twork, &d_trect, &d_tctr, &d_dwork, &d_dctr, &d_ditems, &d_dhist, &d_dpatch, &d_poses, &d_scodes, &d_sids,
-                          &d_msrc, &d_red, &d_mhist, &d_masks, &d_bgr, &d_bits2, &d_ctseg, &d_cthtab, &d_ctelem, &d_ctstate, &d_ctitemsA, &d_ctitemsB, &d_ctnitems, &d_ctcodes, &d_ctmlist, &d_bitsc})
+                          &d_msrc, &d_red, &d_mhist, &d_masks, &d_bgr, &d_bits2, &d_ctseg, &d_cthtab, &d_ctelem, &d_ctstate, &d_ctitemsA, &d_ctitemsB, &d_ctnitems, &d_ctcodes, &d_ctmlist, &d_bitsc, &d_tstrips, &d_ttabs, &d_ttab2})
             b->release();
         if (own_stream) (void)hipStreamDestroy(own_stream);
         if (aux_stream) (void)hipStreamDestroy(aux_stream);
@@ -446,10 +520,15 @@ struct orbfe_aruco {
         // exact halvings, at most four, when the pyramid starts from the thresholded frame itself and n v + K stays within 16 bits
         int nfuse = 0;
         uint32_t thr_kk = 0;
+        bool use_thr_mfma = false;
         {
             const long n2 = (long)win * win, K = n2 * thres_value - n2 / 2;
             const bool adaptive = !(mr && mr->fixed_thr >= 0);
-            if (adaptive && thr_v2 && th_magic && (win == 5 || win == 7 || win == 11 || win == 15) && K >= 0 && n2 * 255 + K <= 65535) {
+            if (adaptive && thr_mfma && th_magic && K > -(1 << 20) && K < (1 << 20)) {
+                if ((rc = build_threshold_tables())) return rc;
+                use_thr_mfma = thr_mfma_ok;
+            }
+            if (!use_thr_mfma && adaptive && thr_v2 && th_magic && (win == 5 || win == 7 || win == 11 || win == 15) && K >= 0 && n2 * 255 + K <= 65535) {
                 thr_kk = (uint32_t)K | ((uint32_t)K << 16);
                 nfuse = -1;   // the kernel applies, with no level so far
                 if (!reduced)
@@ -510,6 +589,10 @@ struct orbfe_aruco {
                     hipLaunchKernelGGL(k_erode_cross_xor, dim3((wpr * rows + 255) / 256, B), dim3(256), 0, s, d_bits2.as<uint32_t>(), bp, bits_fu32, wpr, cols, rows, k / 2);
                 } else
                     hipLaunchKernelGGL(k_fixed_threshold, dim3((wpr * rows + 255) / 256, B), dim3(256), 0, s, srcW, cols, rows, mr->fixed_thr, bp, bits_fu32, wpr);
+            } else if (use_thr_mfma) {
+                const int n2 = win * win, nxs = (n_tstrips + 3) / 4;
+                hipLaunchKernelGGL(k_threshold_mfma, dim3(xcd_grid(nxs * B)), dim3(256), 0, s, srcW, cols, rows, ttab_rb, -(n2 * thres_value - n2 / 2),
+                                   d_tstrips.as<ThrStrip>(), d_ttabs.as<uint4>(), d_ttab2.as<uint4>(), bp, bits_fu32, wpr, n_tstrips, nxs, nxs * B);
             } else if (thr_pyr) {
                 ThrPyr P{};
                 P.n = nfuse;
@@ -1601,6 +1684,7 @@ int orbfe_aruco_debug_kernel_times(orbfe_aruco* h, float* out_us, int capacity)
         if (capacity == 7) return h->n_escalations;
         if (capacity == 8 || capacity == 9) { h->specks = capacity == 8 ? 1 : 0; return 0; }   // the speck passes on / off (default)
         if (capacity == 10 || capacity == 11) { h->specks_inkernel = capacity == 10; h->rows = h->cols = 0; return 0; }   // (the queue's size depends on it: geometry rebuilt)
+        if (capacity == 14 || capacity == 15) { h->thr_mfma = capacity == 14; return 0; }   // the threshold on the matrix cores on (default) / off
         if (capacity == 12 || capacity == 13) { h->thr_v2 = capacity == 12; return 0; }   // the threshold kernel with the fused pyramid on (default) / off   // ... inside the relay kernels on / off (default)
         if (capacity == 2 || capacity == 3) h->force_legacy = capacity == 2;
         else if (capacity >= 4 && capacity <= 6) {

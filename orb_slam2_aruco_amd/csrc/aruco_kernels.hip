@@ -401,6 +401,101 @@ template __global__ void k_threshold_pyr<7>(ImgView, int, int, uint32_t, uint32_
 template __global__ void k_threshold_pyr<11>(ImgView, int, int, uint32_t, uint32_t*, size_t, int, int, int, int, ImgView, ThrPyr);
 template __global__ void k_threshold_pyr<15>(ImgView, int, int, uint32_t, uint32_t*, size_t, int, int, int, int, ImgView, ThrPyr);
 
+// The adaptive threshold on the matrix cores (round 6; the pipeline is bound by vector-ALU issue, see k_blur7_mfma in orb_kernels.hip,
+// whose structure this is): a wave walks a 32-column strip of the frame in blocks of 32 rows;
+//   pass 1  row sums of the WIN-pixel box (pixels minus 128 x a band matrix of ones, BORDER_REPLICATE folded into the matrix in x, the
+//           lane's row index clamped in y), and -- one more MFMA with a selection matrix -- the block's own pixels TRANSPOSED into the
+//           layout pass 2 reads (lane = column, bytes = rows);
+//   pass 2  column sums of the row sums' two byte planes over this block and the previous one, plus the centre pixels times -WIN^2:
+//           the accumulator is  box sum - n v - (n C - n / 2),  n = WIN^2, whose sign is the pixel ("mean >= v + C");
+//   bits    the sign bytes of four accumulators gathered by v_perm and one multiplication, a lane's 16 bits spread to their places in
+//           the row's word, the two halves of a row joined by one cross-lane read: a 32-bit word of the bit image per row and block.
+// Windows up to 11 (n <= 121 fits a signed byte); ~8 lane operations a pixel where the dot-product kernels issue ~25.
+typedef int tm_v4i __attribute__((ext_vector_type(4)));
+typedef int tm_v16i __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void k_threshold_mfma(ImgView src, int W, int H, int rb /* rows a block starts above 32 j */, int kinit,
+                                                        const ThrStrip* __restrict__ strips, const uint4* __restrict__ tabs,
+                                                        const uint4* __restrict__ tab2, uint32_t* __restrict__ bits, size_t bits_fstride,
+                                                        int wpr, int nstrips, int nx, int total)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int bx, f;
+    if (!xcd_remap(nx, total, bx, f)) return;
+    const int si = bx * 4 + wid;
+    if (si >= nstrips) return;
+    const ThrStrip S = strips[si];
+    const int r = lane & 31, half = lane >> 5;
+    const uint8_t* img = src.base + (size_t)f * src.fstride;
+    // pass-1 matrices of the strip: box (K blocks a, b), selection (a, b); pass-2 matrices: box (previous block, this block), centre (prev, this)
+    const tm_v4i Ba = __builtin_bit_cast(tm_v4i, tabs[(size_t)S.tab * 64 + lane]), Bb = __builtin_bit_cast(tm_v4i, tabs[(size_t)(S.tab + 1) * 64 + lane]);
+    const tm_v4i Ia = __builtin_bit_cast(tm_v4i, tabs[(size_t)(S.tab + 2) * 64 + lane]), Ib = __builtin_bit_cast(tm_v4i, tabs[(size_t)(S.tab + 3) * 64 + lane]);
+    const tm_v4i V2a = __builtin_bit_cast(tm_v4i, tab2[lane]), V2b = __builtin_bit_cast(tm_v4i, tab2[64 + lane]);
+    const tm_v4i C2a = __builtin_bit_cast(tm_v4i, tab2[128 + lane]), C2b = __builtin_bit_cast(tm_v4i, tab2[192 + lane]);
+    const uint32_t ca = (uint32_t)(half ? S.c1 : S.c0), cb = (uint32_t)S.c2;
+    typedef uint32_t tm_u32x4 __attribute__((ext_vector_type(4)));
+    typedef tm_u32x4 tm_u32x4_unaligned __attribute__((aligned(1)));
+    const int nblk = ((H + 31) >> 5) + 1;
+    auto load_rows = [&](int j, tm_u32x4& pa, tm_u32x4& pb) {
+        const uint32_t ro = (uint32_t)__mul24(min(max(32 * j - rb + r, 0), H - 1), src.pitch);   // BORDER_REPLICATE
+        pa = *reinterpret_cast<const tm_u32x4_unaligned*>(img + (ro + ca));
+        pb = *reinterpret_cast<const tm_u32x4_unaligned*>(img + (ro + cb));
+    };
+    tm_u32x4 na, nb;
+    load_rows(0, na, nb);
+    tm_v4i ph = {0, 0, 0, 0}, pl = {0, 0, 0, 0}, pc = {0, 0, 0, 0};
+    // where a lane's 16 sign bits go in the row's word: pixel 4 half + 8 q + k
+    const uint32_t valid = (S.x0 + 32 <= W) ? 0xffffffffu : ((1u << (W - S.x0)) - 1u);
+    uint32_t* brow = bits + (size_t)f * bits_fstride + (S.x0 >> 5);
+    for (int j = 0; j < nblk; j++) {
+        const tm_u32x4 qa = na, qb = nb;
+        if (j + 1 < nblk) load_rows(j + 1, na, nb);
+        constexpr uint32_t SGN = 0x80808080u;
+        const tm_v4i A1a = {(int)(qa.x ^ SGN), (int)(qa.y ^ SGN), (int)(qa.z ^ SGN), (int)(qa.w ^ SGN)};
+        const tm_v4i A1b = {(int)(qb.x ^ SGN), (int)(qb.y ^ SGN), (int)(qb.z ^ SGN), (int)(qb.w ^ SGN)};
+        tm_v16i acc = {128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128};
+        tm_v16i sel = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1a, Ba, acc, 0, 0, 0);
+        sel = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1a, Ia, sel, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1b, Bb, acc, 0, 0, 0);
+        sel = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1b, Ib, sel, 0, 0, 0);
+        tm_v4i nh, nl, nc;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t a0 = (uint32_t)acc[4 * q], a1 = (uint32_t)acc[4 * q + 1], a2 = (uint32_t)acc[4 * q + 2], a3 = (uint32_t)acc[4 * q + 3];
+            nh[q] = (int)(__builtin_amdgcn_perm(a1, a0, 0x0c0c0501u) | __builtin_amdgcn_perm(a3, a2, 0x05010c0cu));
+            nl[q] = (int)((__builtin_amdgcn_perm(a1, a0, 0x0c0c0400u) | __builtin_amdgcn_perm(a3, a2, 0x04000c0cu)) ^ SGN);
+            const uint32_t c0 = (uint32_t)sel[4 * q], c1 = (uint32_t)sel[4 * q + 1], c2 = (uint32_t)sel[4 * q + 2], c3 = (uint32_t)sel[4 * q + 3];
+            nc[q] = (int)(__builtin_amdgcn_perm(c1, c0, 0x0c0c0400u) | __builtin_amdgcn_perm(c3, c2, 0x04000c0cu));   // (pixel - 128: one signed byte)
+        }
+        if (j >= 1) {
+            tm_v16i ah = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            tm_v16i al = {kinit, kinit, kinit, kinit, kinit, kinit, kinit, kinit, kinit, kinit, kinit, kinit, kinit, kinit, kinit, kinit};
+            ah = __builtin_amdgcn_mfma_i32_32x32x32_i8(ph, V2a, ah, 0, 0, 0);
+            al = __builtin_amdgcn_mfma_i32_32x32x32_i8(pl, V2a, al, 0, 0, 0);
+            ah = __builtin_amdgcn_mfma_i32_32x32x32_i8(nh, V2b, ah, 0, 0, 0);
+            al = __builtin_amdgcn_mfma_i32_32x32x32_i8(nl, V2b, al, 0, 0, 0);
+            al = __builtin_amdgcn_mfma_i32_32x32x32_i8(pc, C2a, al, 0, 0, 0);
+            al = __builtin_amdgcn_mfma_i32_32x32x32_i8(nc, C2b, al, 0, 0, 0);
+            uint32_t wbits = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                uint32_t t4[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) t4[k] = ((uint32_t)ah[4 * q + k] << 8) + (uint32_t)al[4 * q + k];
+                // sign bytes of the four sums side by side, their top bits to a nibble (bit k = pixel k is OFF)
+                const uint32_t sg = (__builtin_amdgcn_perm(t4[1], t4[0], 0x0c0c0703u) | __builtin_amdgcn_perm(t4[3], t4[2], 0x07030c0cu)) & SGN;
+                const uint32_t nib = (sg * 0x00204081u) >> 28;
+                wbits |= nib << (8 * q);
+            }
+            wbits <<= 4 * half;
+            wbits |= (uint32_t)__shfl_xor((int)wbits, 32);
+            const int y = 32 * (j - 1) + r;
+            if (half == 0 && y < H) brow[(uint32_t)__mul24(y, wpr)] = ~wbits & valid;
+        }
+        ph = nh; pl = nl; pc = nc;
+    }
+}
+
 // ---------------------------------------------------------------------------------------- specks --------------
 // The speck passes of aruco_trace.hpp ("FEWER WALKS" (2)) between the threshold and the contour kernels: what they clear has no border
 // of more than 68 points and changes no other border, and on textured frames it is most of the start candidates and a fifth of the

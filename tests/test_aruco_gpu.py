@@ -621,19 +621,22 @@ def test_threshold_kernels_agree_and_the_fused_pyramid_is_the_pyramid(orbfe, ora
     the same, on frame sizes with partial tiles, odd widths, inexact deeper levels and all four window sizes' neighbours."""
     n = 2 if rows * cols <= 1280 * 720 else 1
     imgs = synth.stream(rows, cols, n, 99, "ARUCO", n_markers=3 if rows >= 200 else 0)
-    a, b = orbfe.MarkerDetector("ARUCO"), orbfe.MarkerDetector("ARUCO")
-    b.set_threshold_pyramid_kernel(False)
-    ma, mb = a.detect_batch(imgs), b.detect_batch(imgs)
+    a, b, c = orbfe.MarkerDetector("ARUCO"), orbfe.MarkerDetector("ARUCO"), orbfe.MarkerDetector("ARUCO")
+    a.set_threshold_on_matrix_cores(False)                                        # a: k_threshold_pyr
+    b.set_threshold_on_matrix_cores(False); b.set_threshold_pyramid_kernel(False)  # b: k_adaptive_threshold_t + k_half_area4
+    ma, mb, mc = a.detect_batch(imgs), b.detect_batch(imgs), c.detect_batch(imgs)  # c: k_threshold_mfma (round 6's default) + k_half_area4
     for f in range(n):
         assert np.array_equal(a.thresholded(f), b.thresholded(f)), (rows, cols, f)
+        assert np.array_equal(c.thresholded(f), b.thresholded(f)), (rows, cols, f)
+        assert np.array_equal(mc[f], mb[f])
         win = max(3, int(15 * float(cols) / 1920.)) | 1
         assert np.array_equal(a.thresholded(f), oracle.adaptive_threshold(imgs[f], win, 7)), (rows, cols, f)   # (window: markerdetector_impl.cpp:3765-3809)
         lvl = 1
         while True:
-            la, lb = a.pyramid_level(lvl, f), b.pyramid_level(lvl, f)
+            la, lb, lc = a.pyramid_level(lvl, f), b.pyramid_level(lvl, f), c.pyramid_level(lvl, f)
             if la is None or lb is None:
-                assert la is None and lb is None
+                assert la is None and lb is None and lc is None
                 break
-            assert np.array_equal(la, lb), (rows, cols, f, lvl)
+            assert np.array_equal(la, lb) and np.array_equal(lc, lb), (rows, cols, f, lvl)
             lvl += 1
         assert np.array_equal(ma[f], mb[f])
