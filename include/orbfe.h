@@ -587,7 +587,9 @@ int orbfe_aruco_detect_batch_device(orbfe_aruco* h, const uint8_t* d_imgs, int n
 int orbfe_aruco_batch_status(orbfe_aruco* h, int32_t* nflagged, int32_t* flags_or);
 int orbfe_aruco_set_big_frames(orbfe_aruco* h, int on);
 /* stage read-back for parity tests: 0 = thresholded image (rows x cols bytes, 0/255) of `frame`; 104 = the bit image the contour
- * kernels read (the thresholded image minus the specks that cannot have a border of more than 70 points) */
+ * kernels read from HBM: the thresholded image minus the specks that cannot have a border of more than 70 points where the speck
+ * passes ran as a launch (the default in front of the one-workgroup kernels of a full batch), the thresholded image itself otherwise
+ * -- also when the passes run INSIDE the relay kernels (ORBFE_ARUCO_SPECKS=2): their cleaned image only ever exists in LDS */
 int orbfe_aruco_debug_image(orbfe_aruco* h, int frame, int stage, uint8_t* out);
 /* As orbfe_extractor_set_aux_stream, for the detector's forked launches (the /2 pyramid). */
 int orbfe_aruco_set_aux_stream(orbfe_aruco* h, void* stream);
@@ -697,6 +699,10 @@ int orbfe_pipeline_host_records(orbfe_pipeline* p, int set, const uint8_t** h_re
 /* after steps from host memory: out[0] = microseconds the newest uploads took on the copy stream (mean over the input ring), out[1] =
  * the newest read-back of a record set.  Synchronises. */
 int orbfe_pipeline_host_copy_us(orbfe_pipeline* p, float out[2]);
+/* The HIP stream priority of the upload / read-back streams of orbfe_pipeline_step_host and the range the device offers (numerically
+ * larger = lower).  They are created with the LOWEST one so that they come out of another pool of hardware queues than the engines'
+ * streams; lowest == highest means the device has no second pool and uploads queue behind the engines (a warning is printed once). */
+int orbfe_pipeline_copy_stream_priority(orbfe_pipeline* p, int* priority, int* lowest, int* highest);
 void* orbfe_host_alloc(size_t bytes);                        /* page-locked host memory (hipHostMalloc) / NULL */
 void orbfe_host_free(void* p);
 /* Device memory for a caller without a HIP toolchain of its own (the Python wrapper, a host language over FFI): zeroed memory on
@@ -743,11 +749,15 @@ const char* orbfe_pipeline_env_defaults(void);
  * written to record set s (orbfe_pipeline_step's *record_set) lands in block set s, which is written again record_sets batches later --
  * so a consumer on `dst` (one Tracking thread per stream, src/Tracking.cc:163-190) reads batch i while the following batches arrive:
  *     orbfe_pipeline_gathered_wait(p, s)          block until the gather of the batch last written to set s is complete (its deferred
- *                                                 post-work is flushed first if it was still held back)
+ *                                                 post-work is flushed first if it was still held back); ORBFE_ERR_INVALID while no batch has
+ *                                                 been gathered into s yet
+ *     orbfe_pipeline_gathered_batch(p, s, &b)     which batch (step number of this pipeline, from 0) the newest gather into set s carries:
+ *                                                 a consumer that expects batch i and reads b = i + record_sets has been overtaken
  *     orbfe_pipeline_gathered_set(p, s, r, &ptr)  rank r's block of set s (device pointer, layout = orbfe_pipeline_layout)
  *     orbfe_pipeline_gathered_release(p, s, st)   optional: the reads of set s enqueued on the consumer's HIP stream `st` so far (NULL: the
  *                                                 null stream) must finish before the set is received into again; without it the set is
- *                                                 simply overwritten record_sets batches later
+ *                                                 simply overwritten record_sets batches later.  Call it BEFORE the step that writes set s
+ *                                                 again is enqueued: a release that comes later delays the gather after that one instead
  * orbfe_pipeline_gathered(p, r, &ptr) = block r of the newest gather that was enqueued.  world == 1 runs the same branch with a send /
  * recv to itself.  ORBFE_RCCL_LIB names a library to bind in place of librccl (tests/fake_rccl.cpp). */
 int orbfe_pipeline_comm_unique_id(uint8_t id[128]);
@@ -757,6 +767,7 @@ int orbfe_pipeline_gathered(orbfe_pipeline* p, int rank, uint8_t** d_block);
 int orbfe_pipeline_gathered_set(orbfe_pipeline* p, int record_set, int rank, uint8_t** d_block);
 int orbfe_pipeline_gathered_wait(orbfe_pipeline* p, int record_set);
 int orbfe_pipeline_gathered_release(orbfe_pipeline* p, int record_set, void* stream);
+int orbfe_pipeline_gathered_batch(orbfe_pipeline* p, int record_set, long long* batch);
 
 #if defined(__GNUC__) || defined(__clang__)
 #pragma GCC visibility pop

@@ -95,6 +95,7 @@ struct orbfe_pipeline {
     orbfe_pipeline_config cfg{};
     int B = 0, rows = 0, cols = 0, cap = 0, mcap = 0, R = 0, D = 0;
     int phase_pin = 0, det_pin = 0;
+    std::vector<long long> set_batch;      // per record set: the batch that was written to it last
     bool defer_post = false, det_nofork = false, use_orb = true, use_aruco = true;
     std::vector<orbfe_extractor*> ex;
     orbfe_aruco* det = nullptr;               // detector of engine set 0 (= dets[0])
@@ -115,6 +116,7 @@ struct orbfe_pipeline {
     // every record set copied back to page-locked host memory on a second copy stream behind the batch's post-work
     static constexpr int NIN = 3;
     bool host_mode = false;
+    int copy_stream_priority = 0;   // of the upload / read-back streams (the lowest the device offers; orbfe_pipeline_copy_stream_priority)
     hipStream_t st_h2d = nullptr, st_d2h = nullptr;
     hipEvent_t up_t0[NIN] = {}, up_t1[NIN] = {}, rb_t0 = nullptr, rb_t1 = nullptr;   // timing of the newest upload per slot / read-back
     uint8_t* d_in[NIN] = {};
@@ -133,6 +135,7 @@ struct orbfe_pipeline {
     std::vector<hipEvent_t> gather_free;   // orbfe_pipeline_gathered_release: the consumer's reads of block set s (the next receive into it waits)
     std::vector<char> gather_free_valid;
     int last_gathered = -1;    // record set of the newest gather that was enqueued
+    std::vector<long long> gather_batch;   // per record set: the batch (step number, from 0) whose gather was enqueued into it last; -1 = none yet
     bool failed = false;       // an enqueue failed half way: events of that step were never recorded; the handle refuses further steps
 
     ~orbfe_pipeline()
@@ -219,6 +222,7 @@ struct orbfe_pipeline {
         if (timing) ORBFE_HIP(hipEventRecord(e[1], st_match));
         ORBFE_HIP(hipEventRecord(gather_done[cur], st_match));
         last_gathered = cur;
+        if (gather_batch.size() == (size_t)R) gather_batch[(size_t)cur] = set_batch[(size_t)cur];
         return ORBFE_OK;
     }
 
@@ -434,7 +438,13 @@ static int host_mode_init(orbfe_pipeline* p)
     // C2 from host memory 107 k frames/s with plain copy streams, 152 k with lowest-priority ones (137 k with highest; 156 k with plain
     // streams and GPU_MAX_HW_QUEUES=8), round 5.
     int prio_lo = 0, prio_hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess || prio_lo == prio_hi) {
+        // no second priority: the copy streams come out of the engines' pool of hardware queues again (107 k instead of 152 k frames/s)
+        (void)hipGetLastError();
+        fprintf(stderr, "orbfe_pipeline_step_host: this device offers one stream priority only; uploads will share hardware queues with the engines\n");
+        prio_lo = prio_hi = 0;
+    }
+    p->copy_stream_priority = prio_lo;
     for (hipStream_t* st : {&p->st_h2d, &p->st_d2h})
         if (!*st && hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_lo) != hipSuccess) return fail(ORBFE_ERR_HIP, "orbfe_pipeline_step_host: streams");
     for (int k = 0; k < orbfe_pipeline::NIN; k++) {
@@ -492,6 +502,17 @@ int orbfe_pipeline_host_records(orbfe_pipeline* p, int set, const uint8_t** h_re
     if (rc) return rc;
     ORBFE_HIP(hipEventSynchronize(p->rb_done[(size_t)set]));
     *h_records = p->h_recs[(size_t)set];
+    return ORBFE_OK;
+}
+
+int orbfe_pipeline_copy_stream_priority(orbfe_pipeline* p, int* priority, int* lowest, int* highest)
+{
+    if (!p || !priority) return fail(ORBFE_ERR_INVALID, "orbfe_pipeline_copy_stream_priority: null argument");
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
+    *priority = p->host_mode ? p->copy_stream_priority : lo;
+    if (lowest) *lowest = lo;
+    if (highest) *highest = hi;
     return ORBFE_OK;
 }
 
@@ -565,6 +586,8 @@ static int step_body(orbfe_pipeline* p, const uint8_t* d_imgs, size_t pitch, int
     const size_t fstride = (size_t)rows * pitch;
     uint8_t* base = p->recs[cur];
     if (record_set) *record_set = cur;
+    if (p->set_batch.size() != (size_t)p->R) { p->set_batch.assign((size_t)p->R, -1); p->gather_batch.assign((size_t)p->R, -1); }
+    p->set_batch[(size_t)cur] = i;
     auto enqueue_detector = [&]() -> int {
         if (!p->use_aruco) return ORBFE_OK;
         const size_t aset = (size_t)(i % (long)p->dets.size());
@@ -846,7 +869,16 @@ int orbfe_pipeline_gathered_wait(orbfe_pipeline* p, int set)
     int rc = use_device(p->cfg.device);
     if (rc) return rc;
     if (p->pending == set && (rc = orbfe_pipeline_flush(p))) return rc;   // the set's post-work (matching, gather) was still held back
+    if (p->gather_batch.size() != (size_t)p->R || p->gather_batch[(size_t)set] < 0)
+        return fail(ORBFE_ERR_INVALID, "orbfe_pipeline_gathered_wait: no batch has been gathered into record set %d yet", set);
     ORBFE_HIP(hipEventSynchronize(p->gather_done[(size_t)set]));
+    return ORBFE_OK;
+}
+
+int orbfe_pipeline_gathered_batch(orbfe_pipeline* p, int set, long long* batch)
+{
+    if (!p || !batch || !p->comm || set < 0 || set >= p->R) return fail(ORBFE_ERR_INVALID, "orbfe_pipeline_gathered_batch: no communicator, or no such set");
+    *batch = p->gather_batch.size() == (size_t)p->R ? p->gather_batch[(size_t)set] : -1;
     return ORBFE_OK;
 }
 

@@ -141,6 +141,8 @@ def _setup(L):
     L.orbfe_pipeline_gathered_set.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
     L.orbfe_pipeline_gathered_wait.argtypes = [vp, C.c_int]
     L.orbfe_pipeline_gathered_release.argtypes = [vp, C.c_int, vp]
+    L.orbfe_pipeline_gathered_batch.argtypes = [vp, C.c_int, C.POINTER(C.c_longlong)]
+    L.orbfe_pipeline_copy_stream_priority.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.orbfe_pipeline_step_host.argtypes = [vp, vp, C.c_size_t, i32p]
     L.orbfe_pipeline_host_records.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.orbfe_pipeline_host_copy_us.argtypes = [vp, C.POINTER(C.c_float * 2)]
@@ -326,6 +328,18 @@ class FrontEndPipeline:
         p = C.c_void_p()
         binding._check(self.L, self.L.orbfe_pipeline_gathered_set(self.h, record_set, rank, C.byref(p)), "orbfe_pipeline_gathered_set")
         return self.layout.unpack(device_bytes(p.value, self.layout.nbytes))
+
+    def gathered_batch(self, record_set):
+        """The batch (step number, from 0) the newest gather into this record set carries; -1 before the first."""
+        b = C.c_longlong(-1)
+        binding._check(self.L, self.L.orbfe_pipeline_gathered_batch(self.h, record_set, C.byref(b)), "orbfe_pipeline_gathered_batch")
+        return int(b.value)
+
+    def copy_stream_priority(self):
+        """(priority of the host-mode copy streams, lowest, highest) of the device's stream priority range."""
+        a, lo, hi = C.c_int(0), C.c_int(0), C.c_int(0)
+        binding._check(self.L, self.L.orbfe_pipeline_copy_stream_priority(self.h, C.byref(a), C.byref(lo), C.byref(hi)), "orbfe_pipeline_copy_stream_priority")
+        return a.value, lo.value, hi.value
 
     def gathered_release(self, record_set, stream=None):
         """The consumer's reads of `record_set`'s blocks enqueued on `stream` so far must finish before the set is received into again."""
