@@ -768,6 +768,15 @@ int orbfe_pipeline_gathered_set(orbfe_pipeline* p, int record_set, int rank, uin
 int orbfe_pipeline_gathered_wait(orbfe_pipeline* p, int record_set);
 int orbfe_pipeline_gathered_release(orbfe_pipeline* p, int record_set, void* stream);
 int orbfe_pipeline_gathered_batch(orbfe_pipeline* p, int record_set, long long* batch);
+/* The transport operations one batch's gather consists of on rank `rank`, in issue order (csrc/gather_plan.hpp: the function the
+ * pipeline itself executes with ncclRecv / ncclSend / a device copy).  Host logic only -- no device is touched -- so the N-rank control
+ * flow (who receives what into which of the rotating blocks) can be driven over any transport: tests/test_multigpu_cpu.py runs it
+ * between two gloo ranks on the CPU.  Returns the number of operations written to ops[0 .. capacity), or ORBFE_ERR_INVALID. */
+#define ORBFE_GATHER_RECV 0      /* receive rank `peer`'s record set into the block buffer at byte `offset` */
+#define ORBFE_GATHER_SEND 1      /* send this rank's record set to rank `peer` */
+#define ORBFE_GATHER_COPY_OWN 2  /* this rank's own record set into the block buffer at byte `offset` */
+typedef struct orbfe_gather_op { int32_t kind, peer; unsigned long long offset; } orbfe_gather_op;
+int orbfe_pipeline_gather_plan(int rank, int world, int dst, int record_set, int record_sets, size_t nbytes, orbfe_gather_op* ops, int capacity);
 
 #if defined(__GNUC__) || defined(__clang__)
 #pragma GCC visibility pop

@@ -52,7 +52,7 @@ SYMBOLS = [
     "orbfe_pipeline_records", "orbfe_pipeline_matches", "orbfe_pipeline_reset_stream", "orbfe_pipeline_extractor", "orbfe_pipeline_detector",
     "orbfe_pipeline_engine_sets", "orbfe_pipeline_enable_timing", "orbfe_pipeline_timing_us", "orbfe_pipeline_env_defaults",
     "orbfe_pipeline_comm_unique_id", "orbfe_pipeline_comm_init", "orbfe_pipeline_set_comm", "orbfe_pipeline_gathered",
-    "orbfe_pipeline_host_copy_us", "orbfe_pipeline_gathered_set", "orbfe_pipeline_gathered_wait", "orbfe_pipeline_gathered_release", "orbfe_pipeline_gathered_batch", "orbfe_pipeline_copy_stream_priority",
+    "orbfe_pipeline_host_copy_us", "orbfe_pipeline_gathered_set", "orbfe_pipeline_gathered_wait", "orbfe_pipeline_gathered_release", "orbfe_pipeline_gathered_batch", "orbfe_pipeline_copy_stream_priority", "orbfe_pipeline_gather_plan",
     "orbfe_pipeline_step_host", "orbfe_pipeline_host_records", "orbfe_host_alloc", "orbfe_host_free",
     "orbfe_device_alloc", "orbfe_device_free", "orbfe_device_upload_rows", "orbfe_device_download",
 ]

@@ -21,6 +21,7 @@
 #include <mutex>
 
 #include "orbfe_common.hpp"
+#include "gather_plan.hpp"
 
 using namespace orbfe;
 
@@ -199,30 +200,31 @@ struct orbfe_pipeline {
             ORBFE_HIP(hipEventRecord(e[0], st_match));
         }
         const size_t nb = (size_t)lay.nbytes;
-        uint8_t* bset = blocks ? blocks + (size_t)cur * world * nb : nullptr;   // this batch's receive blocks (rank dst only)
-        if (rank == dst && gather_free_valid[(size_t)cur]) {   // a consumer said when it is done with the batch this set held before
+                if (rank == dst && gather_free_valid[(size_t)cur]) {   // a consumer said when it is done with the batch this set held before
             ORBFE_HIP(hipStreamWaitEvent(st_match, gather_free[(size_t)cur], 0));
             gather_free_valid[(size_t)cur] = 0;
         }
+        // the batch's operations (csrc/gather_plan.hpp: the same function tests/test_multigpu_cpu.py drives over gloo): the messages inside
+        // one group, the copy of the own block behind it
+        std::vector<orbfe_gather_op> ops((size_t)world + 2);
+        const int nops = gather_plan(rank, world, dst, cur, this->R, nb, ops.data(), (int)ops.size());
+        if (nops < 0) return fail(ORBFE_ERR_INVALID, "orbfe_pipeline: no gather plan for rank %d of %d", rank, world);
         ORBFE_NCCL(R->GroupStart());
         int ge = 0; // the first error inside the group: the group is closed whatever happens
         const char* gwhat = "";
-        if (rank == dst) {
-            for (int r = 0; r < world && !ge; r++) {
-                if (r == rank && world > 1) continue;
-                if ((ge = R->Recv(bset + (size_t)r * nb, nb, NCCL_UINT8, r, comm, st_match))) gwhat = "ncclRecv";
-            }
-            if (world == 1 && !ge && (ge = R->Send(recs[cur], nb, NCCL_UINT8, dst, comm, st_match))) gwhat = "ncclSend"; // the one-GPU box: the same kernels, to itself
-        } else if ((ge = R->Send(recs[cur], nb, NCCL_UINT8, dst, comm, st_match)))
-            gwhat = "ncclSend";
+        for (int k = 0; k < nops && !ge; k++) {
+            if (ops[(size_t)k].kind == ORBFE_GATHER_RECV) { if ((ge = R->Recv(blocks + ops[(size_t)k].offset, nb, NCCL_UINT8, ops[(size_t)k].peer, comm, st_match))) gwhat = "ncclRecv"; }
+            else if (ops[(size_t)k].kind == ORBFE_GATHER_SEND) { if ((ge = R->Send(recs[cur], nb, NCCL_UINT8, ops[(size_t)k].peer, comm, st_match))) gwhat = "ncclSend"; }
+        }
         const int gend = R->GroupEnd();
         if (ge) return fail(ORBFE_ERR_HIP, "%s failed: %s", gwhat, R->GetErrorString ? R->GetErrorString(ge) : "RCCL error");
         if (gend) return fail(ORBFE_ERR_HIP, "ncclGroupEnd failed: %s", R->GetErrorString ? R->GetErrorString(gend) : "RCCL error");
-        if (rank == dst && world > 1) ORBFE_HIP(hipMemcpyAsync(bset + (size_t)rank * nb, recs[cur], nb, hipMemcpyDeviceToDevice, st_match));
+        for (int k = 0; k < nops; k++)
+            if (ops[(size_t)k].kind == ORBFE_GATHER_COPY_OWN) ORBFE_HIP(hipMemcpyAsync(blocks + ops[(size_t)k].offset, recs[cur], nb, hipMemcpyDeviceToDevice, st_match));
         if (timing) ORBFE_HIP(hipEventRecord(e[1], st_match));
         ORBFE_HIP(hipEventRecord(gather_done[cur], st_match));
         last_gathered = cur;
-        if (gather_batch.size() == (size_t)R) gather_batch[(size_t)cur] = set_batch[(size_t)cur];
+        if (gather_batch.size() == (size_t)this->R) gather_batch[(size_t)cur] = set_batch[(size_t)cur];
         return ORBFE_OK;
     }
 
@@ -873,6 +875,13 @@ int orbfe_pipeline_gathered_wait(orbfe_pipeline* p, int set)
         return fail(ORBFE_ERR_INVALID, "orbfe_pipeline_gathered_wait: no batch has been gathered into record set %d yet", set);
     ORBFE_HIP(hipEventSynchronize(p->gather_done[(size_t)set]));
     return ORBFE_OK;
+}
+
+int orbfe_pipeline_gather_plan(int rank, int world, int dst, int record_set, int record_sets, size_t nbytes, orbfe_gather_op* ops, int capacity)
+{
+    const int n = gather_plan(rank, world, dst, record_set, record_sets, nbytes, ops, capacity);
+    if (n < 0) return fail(ORBFE_ERR_INVALID, "orbfe_pipeline_gather_plan: invalid rank / world / dst / record set, or capacity below world + 1");
+    return n;
 }
 
 int orbfe_pipeline_gathered_batch(orbfe_pipeline* p, int set, long long* batch)

@@ -3,9 +3,11 @@
 Frames / streams are independent, so they shard across ranks with no data-path collective: `stream_seed` / `frames_of_rank` say which
 rank owns what (bench.py, the tests).  The PRODUCT gather -- every batch's record set to rank 0 over RCCL -- is C++ inside the library
 (csrc/pipeline.hip: orbfe_pipeline_comm_init / _gathered_set / _gathered_wait; two processes with a peer: tests/fake_rccl.cpp).
-`RecordGather` / `gather_records` are NOT that path: they are the torch.distributed.gather bench.py uses when the records have to go
-through gloo from the host -- its test hook for N ranks on a one-GPU box (ORBFE_BENCH_BACKEND=gloo) and the fallback when RCCL cannot
-be initialised (then the line is a diagnostic) -- and what tests/test_multigpu_cpu.py runs with gloo on the CPU."""
+`gather_plan` / `run_gather_plan` drive that path's own control flow -- which rank receives what into which of the rotating blocks, from
+orbfe_pipeline_gather_plan, the function the library executes -- over torch.distributed point-to-point operations: tests/test_multigpu_cpu.py
+runs it between two gloo ranks without a GPU.  `RecordGather` / `gather_records` are NOT the product path: they are the
+torch.distributed.gather bench.py uses when the records have to go through gloo from the host -- its test hook for N ranks on a one-GPU
+box (ORBFE_BENCH_BACKEND=gloo) and the fallback when RCCL cannot be initialised (then the line is a diagnostic)."""
 import torch
 import torch.distributed as dist
 
@@ -49,3 +51,45 @@ def gather_records(tensors, dst=0):
     if dist.get_rank() != dst:
         return None
     return [[out[k][r] for k in range(len(tensors))] for r in range(dist.get_world_size())]
+
+
+# ---- the library's own gather plan over any transport -------------------------------------------------------------------------------
+import ctypes as _C
+
+
+class _GatherOp(_C.Structure):
+    _fields_ = [("kind", _C.c_int32), ("peer", _C.c_int32), ("offset", _C.c_ulonglong)]
+
+
+GATHER_RECV, GATHER_SEND, GATHER_COPY_OWN = 0, 1, 2
+
+
+def gather_plan(rank, world, dst, record_set, record_sets, nbytes):
+    """The operations of one batch's gather on `rank`, from the LIBRARY (orbfe_pipeline_gather_plan = csrc/gather_plan.hpp, the function
+    csrc/pipeline.hip executes over RCCL): a list of (kind, peer, byte offset into dst's block buffer).  No device is touched."""
+    from . import binding
+    L = binding.load()
+    L.orbfe_pipeline_gather_plan.argtypes = [_C.c_int, _C.c_int, _C.c_int, _C.c_int, _C.c_int, _C.c_size_t, _C.POINTER(_GatherOp), _C.c_int]
+    ops = (_GatherOp * (world + 2))()
+    n = L.orbfe_pipeline_gather_plan(rank, world, dst, record_set, record_sets, nbytes, ops, world + 2)
+    if n < 0:
+        raise ValueError("orbfe_pipeline_gather_plan: %s" % L.orbfe_last_error().decode())
+    return [(ops[i].kind, ops[i].peer, ops[i].offset) for i in range(n)]
+
+
+def run_gather_plan(plan, record, blocks):
+    """Execute a plan with torch.distributed point-to-point operations (any backend): `record` = this rank's record set (1-D uint8),
+    `blocks` = dst's block buffer (1-D uint8, record_sets x world blocks) or None.  The messages of a batch form one group, as in the
+    library (ncclGroupStart .. ncclGroupEnd): all are posted before any is waited for."""
+    nb = record.numel()
+    reqs = []
+    for kind, peer, off in plan:
+        if kind == GATHER_RECV:
+            reqs.append(dist.irecv(blocks[off:off + nb], src=peer))
+        elif kind == GATHER_SEND:
+            reqs.append(dist.isend(record, dst=peer))
+    for r in reqs:
+        r.wait()
+    for kind, peer, off in plan:
+        if kind == GATHER_COPY_OWN:
+            blocks[off:off + nb].copy_(record)
