@@ -112,7 +112,7 @@ struct orbfe_aruco {
     // 1920 x 1080), 0 / 1 = never / wherever their tile fits LDS (ORBFE_ARUCO_SPECKS, debug codes 8 / 9)
     int specks = !getenv("ORBFE_ARUCO_SPECKS") ? -1 : atoi(getenv("ORBFE_ARUCO_SPECKS")) == 1 ? 1 : 0;
     bool specks_inkernel = getenv("ORBFE_ARUCO_SPECKS") && atoi(getenv("ORBFE_ARUCO_SPECKS")) == 2;
-    bool thr_mfma = true;   // k_threshold_mfma where it applies (windows up to 11; debug code 14 / 15)
+    bool thr_mfma = true;   // k_threshold_mfma where it applies (windows up to 15; debug code 14 / 15)
     DevBuf d_tstrips, d_ttabs, d_ttab2;
     int n_tstrips = 0, ttab_rows = 0, ttab_cols = 0, ttab_win = 0, ttab_rb = 0;
     bool thr_mfma_ok = false;
@@ -124,7 +124,7 @@ struct orbfe_aruco {
         ttab_rows = rows; ttab_cols = cols; ttab_win = win;
         const int R = win / 2, n2 = win * win, W = cols, rb = R <= 3 ? 4 : 8;
         thr_mfma_ok = false;
-        if (n2 > 127 || W < 48) return ORBFE_OK;
+        if (n2 > 240 || R > 7 || W < 48) return ORBFE_OK;
         std::vector<ThrStrip> st;
         std::vector<uint8_t> tabs;
         bool ok = true;
@@ -163,8 +163,9 @@ struct orbfe_aruco {
             st.push_back(S);
         }
         if (!ok || st.empty()) return ORBFE_OK;
-        std::vector<uint8_t> t2(4096, 0);
-        for (int m = 0; m < 4; m++)   // box over the previous block, over this block, centre in the previous block, in this block
+        std::vector<uint8_t> t2(6144, 0);
+        const int cw1 = n2 <= 127 ? n2 : 113, cw2 = n2 - cw1;   // the centre's weight -n2 in one signed byte, or in two
+        for (int m = 0; m < 6; m++)   // box over the previous block, over this block, centre in the previous block, in this block (x 2)
             for (int lane = 0; lane < 64; lane++) {
                 const int n = lane & 31, half = lane >> 5;
                 for (int i = 0; i < 16; i++) {
@@ -172,7 +173,7 @@ struct orbfe_aruco {
                     const int d = ((m & 1) ? 32 : 0) + q - rb - n;   // the row's offset from the output row
                     int v = 0;
                     if (m < 2) v = (d >= -R && d <= R) ? 1 : 0;
-                    else v = d == 0 ? -n2 : 0;
+                    else v = d == 0 ? -(m < 4 ? cw1 : cw2) : 0;
                     t2[(size_t)m * 1024 + (size_t)lane * 16 + i] = (uint8_t)(int8_t)v;
                 }
             }
@@ -592,7 +593,7 @@ struct orbfe_aruco {
             } else if (use_thr_mfma) {
                 const int n2 = win * win, nxs = (n_tstrips + 3) / 4;
                 hipLaunchKernelGGL(k_threshold_mfma, dim3(xcd_grid(nxs * B)), dim3(256), 0, s, srcW, cols, rows, ttab_rb, -(n2 * thres_value - n2 / 2),
-                                   d_tstrips.as<ThrStrip>(), d_ttabs.as<uint4>(), d_ttab2.as<uint4>(), bp, bits_fu32, wpr, n_tstrips, nxs, nxs * B);
+                                   d_tstrips.as<ThrStrip>(), d_ttabs.as<uint4>(), d_ttab2.as<uint4>(), bp, bits_fu32, wpr, n_tstrips, nxs, nxs * B, n2 > 127 ? 1 : 0);
             } else if (thr_pyr) {
                 ThrPyr P{};
                 P.n = nfuse;

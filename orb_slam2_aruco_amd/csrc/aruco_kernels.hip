@@ -410,13 +410,14 @@ template __global__ void k_threshold_pyr<15>(ImgView, int, int, uint32_t, uint32
 //           the accumulator is  box sum - n v - (n C - n / 2),  n = WIN^2, whose sign is the pixel ("mean >= v + C");
 //   bits    the sign bytes of four accumulators gathered by v_perm and one multiplication, a lane's 16 bits spread to their places in
 //           the row's word, the two halves of a row joined by one cross-lane read: a 32-bit word of the bit image per row and block.
-// Windows up to 11 (n <= 121 fits a signed byte); ~8 lane operations a pixel where the dot-product kernels issue ~25.
+// Windows up to 15 (WIN^2 above 127: the centre's weight in two matrices); ~8 lane operations a pixel where the dot-product kernels
+// issue ~25.
 typedef int tm_v4i __attribute__((ext_vector_type(4)));
 typedef int tm_v16i __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(256) void k_threshold_mfma(ImgView src, int W, int H, int rb /* rows a block starts above 32 j */, int kinit,
                                                         const ThrStrip* __restrict__ strips, const uint4* __restrict__ tabs,
                                                         const uint4* __restrict__ tab2, uint32_t* __restrict__ bits, size_t bits_fstride,
-                                                        int wpr, int nstrips, int nx, int total)
+                                                        int wpr, int nstrips, int nx, int total, int two_centre)
 {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     int bx, f;
@@ -431,6 +432,8 @@ __global__ __launch_bounds__(256) void k_threshold_mfma(ImgView src, int W, int 
     const tm_v4i Ia = __builtin_bit_cast(tm_v4i, tabs[(size_t)(S.tab + 2) * 64 + lane]), Ib = __builtin_bit_cast(tm_v4i, tabs[(size_t)(S.tab + 3) * 64 + lane]);
     const tm_v4i V2a = __builtin_bit_cast(tm_v4i, tab2[lane]), V2b = __builtin_bit_cast(tm_v4i, tab2[64 + lane]);
     const tm_v4i C2a = __builtin_bit_cast(tm_v4i, tab2[128 + lane]), C2b = __builtin_bit_cast(tm_v4i, tab2[192 + lane]);
+    // windows of 13 and 15 pixels: -WIN^2 does not fit a signed byte, the centre takes two matrices (-113 and the rest)
+    const tm_v4i C3a = __builtin_bit_cast(tm_v4i, tab2[256 + lane]), C3b = __builtin_bit_cast(tm_v4i, tab2[320 + lane]);
     const uint32_t ca = (uint32_t)(half ? S.c1 : S.c0), cb = (uint32_t)S.c2;
     typedef uint32_t tm_u32x4 __attribute__((ext_vector_type(4)));
     typedef tm_u32x4 tm_u32x4_unaligned __attribute__((aligned(1)));
@@ -476,6 +479,10 @@ __global__ __launch_bounds__(256) void k_threshold_mfma(ImgView src, int W, int 
             al = __builtin_amdgcn_mfma_i32_32x32x32_i8(nl, V2b, al, 0, 0, 0);
             al = __builtin_amdgcn_mfma_i32_32x32x32_i8(pc, C2a, al, 0, 0, 0);
             al = __builtin_amdgcn_mfma_i32_32x32x32_i8(nc, C2b, al, 0, 0, 0);
+            if (two_centre) {
+                al = __builtin_amdgcn_mfma_i32_32x32x32_i8(pc, C3a, al, 0, 0, 0);
+                al = __builtin_amdgcn_mfma_i32_32x32x32_i8(nc, C3b, al, 0, 0, 0);
+            }
             uint32_t wbits = 0;
 #pragma unroll
             for (int q = 0; q < 4; q++) {

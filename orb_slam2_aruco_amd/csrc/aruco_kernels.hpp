@@ -38,7 +38,7 @@ __global__ void k_adaptive_threshold_t(ImgView src, int W, int H, int C, uint32_
 // (units of 64 uint4) of the strip's four pass-1 matrices (aruco_detector.hip: build_threshold_tables)
 struct ThrStrip { int x0, c0, c1, c2, tab; };
 __global__ void k_threshold_mfma(ImgView src, int W, int H, int rb, int kinit, const ThrStrip* strips, const uint4* tabs, const uint4* tab2,
-                                 uint32_t* bits, size_t bits_fstride, int wpr, int nstrips, int nx, int total);
+                                 uint32_t* bits, size_t bits_fstride, int wpr, int nstrips, int nx, int total, int two_centre);
 // threshold + the /2 pyramid levels a 64 x 64 tile holds whole (levels 1 .. n <= 4 of the detector's pyramid), one launch
 struct ThrPyr { int n; int w[4], h[4], pitch[4]; long long off[4]; };
 template <int WIN>

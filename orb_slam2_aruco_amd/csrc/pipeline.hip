@@ -162,6 +162,8 @@ struct orbfe_pipeline {
         for (auto s : st_ex) if (s) (void)hipStreamDestroy(s);
         if (st_det) (void)hipStreamDestroy(st_det);
         if (st_match) (void)hipStreamDestroy(st_match);
+        if (st_gather) (void)hipStreamDestroy(st_gather);
+        if (ev_gather_fork) (void)hipEventDestroy(ev_gather_fork);
     }
 
     uint8_t* slot_kps(int set, int slot) const { return recs[set] + lay.off_kps + (size_t)slot * cap * sizeof(orbfe_keypoint); }
@@ -189,19 +191,30 @@ struct orbfe_pipeline {
         return ORBFE_OK;
     }
 
+    // ORBFE_GATHER_STREAM=1: the gather's RCCL kernels on a stream of the LOWEST priority (another pool of hardware queues than the four
+    // engine streams, like the host mode's copy streams) behind the batch's matching, instead of on the matching stream itself
+    hipStream_t st_gather = nullptr;
+    hipEvent_t ev_gather_fork = nullptr;
     int enqueue_gather(int cur)
     {
+        hipStream_t sg = st_match;
+        if (st_gather) {
+            if (!ev_gather_fork) ORBFE_HIP(hipEventCreateWithFlags(&ev_gather_fork, hipEventDisableTiming));
+            ORBFE_HIP(hipEventRecord(ev_gather_fork, st_match));
+            ORBFE_HIP(hipStreamWaitEvent(st_gather, ev_gather_fork, 0));
+            sg = st_gather;
+        }
         Rccl* R = rccl();
         if (!R) return fail(ORBFE_ERR_HIP, "librccl is not available");
         hipEvent_t* e = timing ? gather_ev[gather_steps % HIST] : nullptr;
         if (timing) {
             for (int k = 0; k < 2; k++) if (!e[k]) ORBFE_HIP(hipEventCreate(&e[k]));
             gather_steps++;
-            ORBFE_HIP(hipEventRecord(e[0], st_match));
+            ORBFE_HIP(hipEventRecord(e[0], sg));
         }
         const size_t nb = (size_t)lay.nbytes;
                 if (rank == dst && gather_free_valid[(size_t)cur]) {   // a consumer said when it is done with the batch this set held before
-            ORBFE_HIP(hipStreamWaitEvent(st_match, gather_free[(size_t)cur], 0));
+            ORBFE_HIP(hipStreamWaitEvent(sg, gather_free[(size_t)cur], 0));
             gather_free_valid[(size_t)cur] = 0;
         }
         // the batch's operations (csrc/gather_plan.hpp: the same function tests/test_multigpu_cpu.py drives over gloo): the messages inside
@@ -213,16 +226,16 @@ struct orbfe_pipeline {
         int ge = 0; // the first error inside the group: the group is closed whatever happens
         const char* gwhat = "";
         for (int k = 0; k < nops && !ge; k++) {
-            if (ops[(size_t)k].kind == ORBFE_GATHER_RECV) { if ((ge = R->Recv(blocks + ops[(size_t)k].offset, nb, NCCL_UINT8, ops[(size_t)k].peer, comm, st_match))) gwhat = "ncclRecv"; }
-            else if (ops[(size_t)k].kind == ORBFE_GATHER_SEND) { if ((ge = R->Send(recs[cur], nb, NCCL_UINT8, ops[(size_t)k].peer, comm, st_match))) gwhat = "ncclSend"; }
+            if (ops[(size_t)k].kind == ORBFE_GATHER_RECV) { if ((ge = R->Recv(blocks + ops[(size_t)k].offset, nb, NCCL_UINT8, ops[(size_t)k].peer, comm, sg))) gwhat = "ncclRecv"; }
+            else if (ops[(size_t)k].kind == ORBFE_GATHER_SEND) { if ((ge = R->Send(recs[cur], nb, NCCL_UINT8, ops[(size_t)k].peer, comm, sg))) gwhat = "ncclSend"; }
         }
         const int gend = R->GroupEnd();
         if (ge) return fail(ORBFE_ERR_HIP, "%s failed: %s", gwhat, R->GetErrorString ? R->GetErrorString(ge) : "RCCL error");
         if (gend) return fail(ORBFE_ERR_HIP, "ncclGroupEnd failed: %s", R->GetErrorString ? R->GetErrorString(gend) : "RCCL error");
         for (int k = 0; k < nops; k++)
-            if (ops[(size_t)k].kind == ORBFE_GATHER_COPY_OWN) ORBFE_HIP(hipMemcpyAsync(blocks + ops[(size_t)k].offset, recs[cur], nb, hipMemcpyDeviceToDevice, st_match));
-        if (timing) ORBFE_HIP(hipEventRecord(e[1], st_match));
-        ORBFE_HIP(hipEventRecord(gather_done[cur], st_match));
+            if (ops[(size_t)k].kind == ORBFE_GATHER_COPY_OWN) ORBFE_HIP(hipMemcpyAsync(blocks + ops[(size_t)k].offset, recs[cur], nb, hipMemcpyDeviceToDevice, sg));
+        if (timing) ORBFE_HIP(hipEventRecord(e[1], sg));
+        ORBFE_HIP(hipEventRecord(gather_done[cur], sg));
         last_gathered = cur;
         if (gather_batch.size() == (size_t)this->R) gather_batch[(size_t)cur] = set_batch[(size_t)cur];
         return ORBFE_OK;
@@ -288,7 +301,7 @@ const char* orbfe_pipeline_env_defaults(void)
     return "ORBFE_ENGINE_SETS=2;ORBFE_ENGINE_SETS_ARUCO=1;ORBFE_RECORD_SETS=4;ORBFE_PHASE_PIN=size;ORBFE_DET_PIN=4;ORBFE_DEFER_POST=size;ORBFE_DET_NOFORK=size;"
            "ORBFE_ARUCO_RELAY_WIDE=1;"
            "ORBFE_ARUCO_SPECKS=size;ORBFE_DESCRIBE_LATE=1;ORBFE_ARUCO_SMALL_SEPARATE=size;ORBFE_ARUCO_TILED=size;ORBFE_ARUCO_TILE_W=0;ORBFE_ARUCO_TPW=0;ORBFE_ARUCO_BANDED=size;ORBFE_ARUCO_BAND_ROWS=0;ORBFE_ARUCO_LCAP=0;ORBFE_GRAPH=0;"
-           "ORBFE_NO_LEND=0;ORBFE_GRAPH_VERBOSE=0;ORBFE_RCCL_LIB=";
+           "ORBFE_GATHER_STREAM=0;ORBFE_NO_LEND=0;ORBFE_GRAPH_VERBOSE=0;ORBFE_RCCL_LIB=";
 }
 
 int orbfe_pipeline_config_default(orbfe_pipeline_config* c, int frames, int rows, int cols)
@@ -343,6 +356,11 @@ orbfe_pipeline* orbfe_pipeline_create(const orbfe_pipeline_config* cfg)
     };
     auto mkstream = [&](hipStream_t* s) { return hipStreamCreateWithFlags(s, hipStreamNonBlocking) == hipSuccess; };
     if (!mkstream(&p->st_det) || !mkstream(&p->st_match)) return bail("stream");
+    if (env_or("ORBFE_GATHER_STREAM", 0)) {
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
+        if (hipStreamCreateWithPriority(&p->st_gather, hipStreamNonBlocking, lo) != hipSuccess) return bail("stream");
+    }
     p->st_ex.assign((size_t)p->D, nullptr);
     for (auto& s : p->st_ex) if (!mkstream(&s)) return bail("stream");
     if (p->use_orb) {
@@ -675,6 +693,7 @@ int orbfe_pipeline_synchronize(orbfe_pipeline* p)
     ORBFE_HIP(hipStreamSynchronize(p->st_det));
     for (auto sd : p->st_dets) ORBFE_HIP(hipStreamSynchronize(sd));
     ORBFE_HIP(hipStreamSynchronize(p->st_match));
+    if (p->st_gather) ORBFE_HIP(hipStreamSynchronize(p->st_gather));
     if (p->host_mode) { ORBFE_HIP(hipStreamSynchronize(p->st_h2d)); ORBFE_HIP(hipStreamSynchronize(p->st_d2h)); }
     return ORBFE_OK;
 }

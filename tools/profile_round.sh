@@ -37,9 +37,17 @@ python tools/gather_stream.py $(find $O/prof_fg -name '*kernel_trace.csv' | head
 rm -rf $O/prof_fg
 # the RCCL branch on the hardware that is there (world size 1), and C4 as far as one GPU runs it (8 gloo ranks on device 0, 8 frames each)
 python bench.py --gpus 1 --force-gather --cpu-frames 0 --out $O/${TAG}_bench_rccl_world1_force_gather.json > $O/bench_fg.log 2>&1
+# ... and with the gather's kernels on a lowest-priority stream of their own (another pool of hardware queues): interleaved with the plain runs
+for r in 1 2 3 4; do
+  for v in "plain=" "forcegather=" "gatherstream=ORBFE_GATHER_STREAM=1"; do
+    n=${v%%=*}; e=${v#*=}; a="--gpus 1 --cpu-frames 0 --no-verify --no-extras"; [ "$n" != plain ] && a="$a --force-gather"
+    env $e python bench.py $a 2>/dev/null | python -c "import sys, json; d = json.loads(sys.stdin.readline()); print('$n', round(d['ms_per_step'], 4))"
+  done
+done | sort | awk '{s[$1] += $2; n[$1]++; a[$1] = a[$1] " " $2} END {for (k in s) printf "%-14s mean %.4f :%s\n", k, s[k] / n[k], a[k]}' > $O/${TAG}_gather_stream_ab.txt 2>&1
 PORT=$((20000 + RANDOM % 20000))
 ORBFE_BENCH_DEVICE=0 ORBFE_BENCH_BACKEND=gloo OMP_NUM_THREADS=2 python bench.py --gpus 8 --config C4 --frames 8 --steps 3 --warmup 1 --cpu-frames 0 \
     --out $O/${TAG}_bench_c4_8ranks_gloo_one_gpu.json > $O/bench_c4.log 2>&1
 python tools/timeline.py > $O/${TAG}_timeline_full.txt 2>&1
+bash tools/wave_timing.sh > $O/${TAG}_wave_timing.txt 2>&1
 rm -rf $O/prof gpurun_out/pmc gpurun_out/tl
 tail -c 400 $O/bench_c2.log
