@@ -486,6 +486,8 @@ struct orbfe_extractor {
         // flag_word: 0 = the sticky flag of the device-pointer batches (orbfe_extractor_batch_status), 1 = the host-pointer entry
         // points' own word (they own their whole call, so a device batch's unread flag must not fail them)
         int rc;
+        // a batch whose descriptors are still owed (the pipeline defers them by a step) gets them before its buffers are used again
+        if (late.pending && (rc = describe_deferred(nullptr, 0))) return rc;
         if ((rc = build_geometry(rows_, cols_))) return rc;
         if ((rc = ensure_workspace(B))) return rc;
         if ((rc = build_blur_tables())) return rc;

@@ -383,7 +383,7 @@ orbfe_pipeline* orbfe_pipeline_create(const orbfe_pipeline_config* cfg)
         // With the blur on the matrix cores (k_blur7_mfma) FAST has the vector ALUs more to itself and every size gains: C2 1.265
         // against 1.327, 1280 x 720 3.70 against 3.74, 1920 x 1080 3.13 against 3.21 ms.
         p->describe_late = pick(-1, "ORBFE_DESCRIBE_LATE", 1) != 0 && p->D > 1;
-        if (p->describe_late) { p->defer_post = true; for (auto e : p->ex) extractor_defer_describe(e, true); }
+        if (p->describe_late) p->defer_post = true;
         p->cap = orbfe_extractor_max_keypoints(p->ex[0]);
     } else
         p->cap = 1;
@@ -644,9 +644,12 @@ static int step_body(orbfe_pipeline* p, const uint8_t* d_imgs, size_t pitch, int
         }
         if (p->host_mode && p->rb_valid[(size_t)cur]) ORBFE_HIP(hipStreamWaitEvent(st, p->rb_done[(size_t)cur], 0));
         if (in_slot >= 0) { ORBFE_HIP(hipStreamWaitEvent(st, p->in_ready[in_slot], 0)); }
-        if ((rc = orbfe_extract_batch_device(p->ex[(size_t)eset], d_imgs, B, fstride, rows, cols, pitch, reinterpret_cast<orbfe_keypoint*>(p->slot_kps(cur, 1)),
-                                             p->slot_desc(cur, 1), p->cap, p->slot_n(cur, 1), st)))
-            return rc;
+        // (the deferral is the pipeline's, call by call: anybody else who calls the handle's entry points gets the whole extraction)
+        extractor_defer_describe(p->ex[(size_t)eset], p->describe_late);
+        rc = orbfe_extract_batch_device(p->ex[(size_t)eset], d_imgs, B, fstride, rows, cols, pitch, reinterpret_cast<orbfe_keypoint*>(p->slot_kps(cur, 1)),
+                                        p->slot_desc(cur, 1), p->cap, p->slot_n(cur, 1), st);
+        extractor_defer_describe(p->ex[(size_t)eset], false);
+        if (rc) return rc;
         if (p->describe_late) {
             // the PREVIOUS batch's descriptors now, behind this batch's resize chain; this batch's at the next step (or the flush)
             if ((rc = p->finish_describe(eset))) return rc;

@@ -15,7 +15,7 @@ for r in $(seq $R); do
     env $envs timeout -k 5 300 python bench.py --cpu-frames 0 --no-verify --no-extras $ARGS 2>/dev/null | STAGES=${STAGES:-0} python -c "
 import sys, json, os
 try:
-    d = json.loads(sys.stdin.readline())
+    d = [json.loads(l) for l in sys.stdin if l.startswith('{')][-1]
     print('$name %.4f' % d['ms_per_step'], json.dumps({k: round(v) for k, v in (d.get('stage_us') or {}).items()}) if os.environ['STAGES'] == '1' else '')
 except Exception as e:
     print('$name nan', repr(e))"

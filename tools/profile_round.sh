@@ -41,7 +41,7 @@ python bench.py --gpus 1 --force-gather --cpu-frames 0 --out $O/${TAG}_bench_rcc
 for r in 1 2 3 4; do
   for v in "plain=" "forcegather=" "gatherstream=ORBFE_GATHER_STREAM=1"; do
     n=${v%%=*}; e=${v#*=}; a="--gpus 1 --cpu-frames 0 --no-verify --no-extras"; [ "$n" != plain ] && a="$a --force-gather"
-    env $e python bench.py $a 2>/dev/null | python -c "import sys, json; d = json.loads(sys.stdin.readline()); print('$n', round(d['ms_per_step'], 4))"
+    env $e python bench.py $a 2>/dev/null | python -c "import sys, json; d = [json.loads(l) for l in sys.stdin if l.startswith('{')][-1]; print('$n', round(d['ms_per_step'], 4))"
   done
 done | sort | awk '{s[$1] += $2; n[$1]++; a[$1] = a[$1] " " $2} END {for (k in s) printf "%-14s mean %.4f :%s\n", k, s[k] / n[k], a[k]}' > $O/${TAG}_gather_stream_ab.txt 2>&1
 PORT=$((20000 + RANDOM % 20000))
