@@ -445,6 +445,10 @@ __global__ __launch_bounds__(256) void k_threshold_mfma(ImgView src, int W, int 
     };
     tm_u32x4 na, nb;
     load_rows(0, na, nb);
+    // (the accumulators' start values as operands of their own: no moves per block)
+    const tm_v16i c128 = {128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128};
+    const tm_v16i ckin = {kinit, kinit, kinit, kinit, kinit, kinit, kinit, kinit, kinit, kinit, kinit, kinit, kinit, kinit, kinit, kinit};
+    const tm_v16i czero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     tm_v4i ph = {0, 0, 0, 0}, pl = {0, 0, 0, 0}, pc = {0, 0, 0, 0};
     // where a lane's 16 sign bits go in the row's word: pixel 4 half + 8 q + k
     const uint32_t valid = (S.x0 + 32 <= W) ? 0xffffffffu : ((1u << (W - S.x0)) - 1u);
@@ -455,10 +459,8 @@ __global__ __launch_bounds__(256) void k_threshold_mfma(ImgView src, int W, int 
         constexpr uint32_t SGN = 0x80808080u;
         const tm_v4i A1a = {(int)(qa.x ^ SGN), (int)(qa.y ^ SGN), (int)(qa.z ^ SGN), (int)(qa.w ^ SGN)};
         const tm_v4i A1b = {(int)(qb.x ^ SGN), (int)(qb.y ^ SGN), (int)(qb.z ^ SGN), (int)(qb.w ^ SGN)};
-        tm_v16i acc = {128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128};
-        tm_v16i sel = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1a, Ba, acc, 0, 0, 0);
-        sel = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1a, Ia, sel, 0, 0, 0);
+        tm_v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1a, Ba, c128, 0, 0, 0);
+        tm_v16i sel = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1a, Ia, czero, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1b, Bb, acc, 0, 0, 0);
         sel = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1b, Ib, sel, 0, 0, 0);
         tm_v4i nh, nl, nc;
@@ -471,10 +473,8 @@ __global__ __launch_bounds__(256) void k_threshold_mfma(ImgView src, int W, int 
             nc[q] = (int)(__builtin_amdgcn_perm(c1, c0, 0x0c0c0400u) | __builtin_amdgcn_perm(c3, c2, 0x04000c0cu));   // (pixel - 128: one signed byte)
         }
         if (j >= 1) {
-            tm_v16i ah = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            tm_v16i al = {kinit, kinit, kinit, kinit, kinit, kinit, kinit, kinit, kinit, kinit, kinit, kinit, kinit, kinit, kinit, kinit};
-            ah = __builtin_amdgcn_mfma_i32_32x32x32_i8(ph, V2a, ah, 0, 0, 0);
-            al = __builtin_amdgcn_mfma_i32_32x32x32_i8(pl, V2a, al, 0, 0, 0);
+            tm_v16i ah = __builtin_amdgcn_mfma_i32_32x32x32_i8(ph, V2a, czero, 0, 0, 0);
+            tm_v16i al = __builtin_amdgcn_mfma_i32_32x32x32_i8(pl, V2a, ckin, 0, 0, 0);
             ah = __builtin_amdgcn_mfma_i32_32x32x32_i8(nh, V2b, ah, 0, 0, 0);
             al = __builtin_amdgcn_mfma_i32_32x32x32_i8(nl, V2b, al, 0, 0, 0);
             al = __builtin_amdgcn_mfma_i32_32x32x32_i8(pc, C2a, al, 0, 0, 0);

@@ -1567,14 +1567,18 @@ __global__ __launch_bounds__(256) void k_blur7_mfma(ImgView src0, ImgView pyr, I
     bm_u32x4 na, nb;
     load_rows(0, na, nb);
     bm_v4i ph = {0, 0, 0, 0}, pl = {0, 0, 0, 0};
+    // the accumulators' start values as operands of their own (srcC != vdst): kept in registers for the whole strip instead of sixteen
+    // moves per accumulator and block
+    const bm_v16i c128 = {128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128};
+    const bm_v16i ck2 = {K2, K2, K2, K2, K2, K2, K2, K2, K2, K2, K2, K2, K2, K2, K2, K2};
+    const bm_v16i czero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int j = 0; j < nblk; j++) {
         const bm_u32x4 qa = na, qb = nb;
         if (j + 1 < nblk) load_rows(j + 1, na, nb);   // the next block's rows are in flight while this one is worked on
         constexpr uint32_t SGN = 0x80808080u;
         const bm_v4i A1a = {(int)(qa.x ^ SGN), (int)(qa.y ^ SGN), (int)(qa.z ^ SGN), (int)(qa.w ^ SGN)};
         const bm_v4i A1b = {(int)(qb.x ^ SGN), (int)(qb.y ^ SGN), (int)(qb.z ^ SGN), (int)(qb.w ^ SGN)};
-        bm_v16i acc = {128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128};
-        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1a, B1a, acc, 0, 0, 0);
+        bm_v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1a, B1a, c128, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1b, B1b, acc, 0, 0, 0);
         // planes: byte 1 (the signed high byte) and byte 0 minus 128 of four accumulators into one register each
         bm_v4i nh, nl;
@@ -1587,11 +1591,9 @@ __global__ __launch_bounds__(256) void k_blur7_mfma(ImgView src0, ImgView pyr, I
             nl[q] = (int)((l01 | l23) ^ SGN);
         }
         if (j >= 1) {
-            bm_v16i ah = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            bm_v16i al = {K2, K2, K2, K2, K2, K2, K2, K2, K2, K2, K2, K2, K2, K2, K2, K2};
-            ah = __builtin_amdgcn_mfma_i32_32x32x32_i8(ph, B2a, ah, 0, 0, 0);
+            bm_v16i ah = __builtin_amdgcn_mfma_i32_32x32x32_i8(ph, B2a, czero, 0, 0, 0);
+            bm_v16i al = __builtin_amdgcn_mfma_i32_32x32x32_i8(pl, B2a, ck2, 0, 0, 0);
             ah = __builtin_amdgcn_mfma_i32_32x32x32_i8(nh, B2b, ah, 0, 0, 0);
-            al = __builtin_amdgcn_mfma_i32_32x32x32_i8(pl, B2a, al, 0, 0, 0);
             al = __builtin_amdgcn_mfma_i32_32x32x32_i8(nl, B2b, al, 0, 0, 0);
             // the tile through the wave's LDS patch: written in the accumulators' layout (lane = row, four pixels a register group), read
             // back with lanes along x -- a store instruction then covers 8 rows x 32 bytes instead of 32 rows x 8 bytes (stored straight
