@@ -626,7 +626,7 @@ def main():
     if os.environ.get("ORBFE_BENCH_WAVE_TIMING"):      # diagnosis build (-DORBFE_WAVE_TIMING, tools/wave_timing.sh): where the waves' lives went
         wt = (ctypes.c_ulonglong * 64)()
         if binding.load().orbfe_timing_read(wt, 1) == 0:
-            for kid, name in enumerate(("orient_describe", "fast_cells")):
+            for kid, name in enumerate(("orient_describe", "fast_cells", "distribute_pyr levels >= 1 (wave 0)", "distribute_pyr level 0 (wave 0)")):
                 row = [wt[kid * 16 + k] for k in range(16)]
                 if row[15]:
                     print("wave_timing %s: waves %d, clocks per wave by phase %s, total %.0f" % (

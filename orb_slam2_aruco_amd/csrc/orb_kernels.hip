@@ -978,6 +978,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_distribute_pyr(const LevelGeom* 
     // by_level: grid (frames, levels) -- every frame's level 0, the level with the most candidates and the longest workgroups, is
     // dispatched first and the short ones fill the tail; else grid (levels, frames)
     const int level = by_level ? blockIdx.y : blockIdx.x, f = by_level ? blockIdx.x : blockIdx.y;
+    WT_BEGIN();
     const LevelGeom g = geom[level];
     const int nIni = g.nIni;
     // depth d cells live at cnt[off(d) + root * 4^d + code]; off(d) = 4 * nIni * (4^d - 1) / 3 rounded so that every
@@ -1048,6 +1049,8 @@ __global__ __launch_bounds__(QP_THREADS) void k_distribute_pyr(const LevelGeom* 
     if (lane == 0) atomicAdd(&s_ncand, n);
     __syncthreads();
     if (wid != 0) return;
+    WT_MARK(2 + (level == 0), 0);   // candidates -> leaf counts (all four waves), barrier
+    WT_COUNT(2 + (level == 0));
     n = s_ncand;
     if (lane == 0) { lvl_ncand[fl_idx] = n; fallback[fl_idx] = 0; }
     if (n == 0) {
@@ -1064,6 +1067,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_distribute_pyr(const LevelGeom* 
         QT_SYNC();
     }
 
+    WT_MARK(2 + (level == 0), 1);   // count pyramid
     // ---- initial list: non-empty roots in order (:546-585); seq counts every root
     int L = 0, seq = nIni;
     const int N = g.quota;
@@ -1151,6 +1155,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_distribute_pyr(const LevelGeom* 
         L = total_ch + nkeep;
         { uint32_t* t; t = cA; cA = cB; cB = t; t = iA; iA = iB; iB = t; t = sA; sA = sB; sB = t; }
         QT_SYNC();
+        WT_MARK(2 + (level == 0), 2);   // passes of the first loop
         if (L >= N || L == prevSize) {
             finish = true;
         } else if (L + nToExpand * 3 > N) {
@@ -1268,6 +1273,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_distribute_pyr(const LevelGeom* 
             }
         }
     }
+    WT_MARK(2 + (level == 0), 3);   // priority rounds (sort + split)
     if (deep) {
         if (lane == 0) { fallback[fl_idx] = 1; worklist[atomicAdd(worklist_n, 1)] = fl_idx; } // k_distribute redoes this level
         return;
@@ -1288,6 +1294,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_distribute_pyr(const LevelGeom* 
         }
     }
     if (lane == 0) lvl_cnt[fl_idx] = L;
+    WT_MARK(2 + (level == 0), 4);   // best keypoint per node
 }
 
 // per-frame level offsets (ascending-level concatenation, :1076-1104), totals, and a flat (keypoint, level) list so that
