@@ -295,6 +295,7 @@ def latency_record(args, frames, calls=200):
            # -- same image -- finds its work done.  Identical results (tests/test_shims_gpu.py, test_aruco_gpu.py)
            "paired": {"value": med(p_all), "median_ms": {"orbfe_extract": med(p_ex), "orbfe_aruco_detect+poses": med(p_det),
                                                           "orbfe_search_for_initialization": med(p_sfi)}}}
+    out["c_abi"] = latency_from_cpp(args, frames, K, calls)
     if args.cpu_frames > 0:
         O = oracle_module()
         orb, aru = O.OrbOracle(args.nfeatures, 1.2, args.nlevels, 20, 7), O.ArucoOracle(args.dictionary)
@@ -317,6 +318,30 @@ def latency_record(args, frames, calls=200):
                                "sample": "%d frames, oracle/ single thread" % len(c_ex),
                                "median_ms": {"extract": med(c_ex), "aruco_detect+poses": med(c_det), "search_for_initialization": med(c_sfi)}}
     return out
+
+
+def latency_from_cpp(args, frames, K, calls):
+    """The same call sequence from C++ (tools/latency_driver.cpp, compiled here with g++ against include/orbfe.h): the library's own
+    latency, without the ctypes marshalling the Python loop above includes."""
+    import subprocess
+    import tempfile
+    from orb_slam2_aruco_amd import binding
+    root = os.path.dirname(os.path.abspath(__file__))
+    libdir = os.path.dirname(os.path.abspath(binding.LIB_PATH))
+    try:
+        with tempfile.TemporaryDirectory() as td:
+            exe, raw = os.path.join(td, "latency_driver"), os.path.join(td, "frames.u8")
+            libname = os.path.basename(binding.LIB_PATH)
+            subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(root, "tools", "latency_driver.cpp"), "-o", exe, "-L" + libdir,
+                            "-l:" + libname, "-Wl,-rpath," + libdir], check=True, capture_output=True, text=True)
+            np.ascontiguousarray(frames, np.uint8).tofile(raw)
+            r = subprocess.run([exe, raw, str(len(frames)), str(args.rows), str(args.cols), str(calls), str(args.nfeatures), str(args.nlevels),
+                                args.dictionary] + ["%.9g" % float(v) for v in K], check=True, capture_output=True, text=True, timeout=300)
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            d["what"] = "tools/latency_driver.cpp: the same three calls per frame from C++ through include/orbfe.h (no Python in the loop)"
+            return d
+    except Exception as e:  # noqa: BLE001
+        return {"error": (getattr(e, "stderr", None) or repr(e))[-400:]}
 
 
 def from_host_mode(args):

@@ -301,7 +301,7 @@ const char* orbfe_pipeline_env_defaults(void)
     return "ORBFE_ENGINE_SETS=2;ORBFE_ENGINE_SETS_ARUCO=1;ORBFE_RECORD_SETS=4;ORBFE_PHASE_PIN=size;ORBFE_DET_PIN=4;ORBFE_DEFER_POST=size;ORBFE_DET_NOFORK=size;"
            "ORBFE_ARUCO_RELAY_WIDE=1;"
            "ORBFE_ARUCO_SPECKS=size;ORBFE_DESCRIBE_LATE=1;ORBFE_ARUCO_SMALL_SEPARATE=size;ORBFE_ARUCO_TILED=size;ORBFE_ARUCO_TILE_W=0;ORBFE_ARUCO_TPW=0;ORBFE_ARUCO_BANDED=size;ORBFE_ARUCO_BAND_ROWS=0;ORBFE_ARUCO_LCAP=0;ORBFE_GRAPH=0;"
-           "ORBFE_GATHER_STREAM=0;ORBFE_NO_LEND=0;ORBFE_GRAPH_VERBOSE=0;ORBFE_RCCL_LIB=";
+           "ORBFE_GATHER_STREAM=0;ORBFE_CU_DET=0;ORBFE_CU_EX=0;ORBFE_NO_LEND=0;ORBFE_GRAPH_VERBOSE=0;ORBFE_RCCL_LIB=";
 }
 
 int orbfe_pipeline_config_default(orbfe_pipeline_config* c, int frames, int rows, int cols)
@@ -355,14 +355,24 @@ orbfe_pipeline* orbfe_pipeline_create(const orbfe_pipeline_config* cfg)
         return nullptr;
     };
     auto mkstream = [&](hipStream_t* s) { return hipStreamCreateWithFlags(s, hipStreamNonBlocking) == hipSuccess; };
-    if (!mkstream(&p->st_det) || !mkstream(&p->st_match)) return bail("stream");
+    // CU partition (measurement switch, round 6): ORBFE_CU_DET = K gives the detector's stream the first K compute units of the
+    // enumeration (the driver deals mask bits round-robin over the eight XCDs, so K / 8 of every XCD); ORBFE_CU_EX = 1 gives the
+    // extractor sets' streams the complement, 2 also the matching stream.  Off by default: see tools/sweeps.md.
+    const int cu_det = env_or("ORBFE_CU_DET", 0), cu_ex = env_or("ORBFE_CU_EX", 0);
+    auto mkmasked = [&](hipStream_t* s, int first, int last) {
+        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = first; i < last && i < 256; i++) mask[i >> 5] |= 1u << (i & 31);
+        return hipExtStreamCreateWithCUMask(s, 8, mask) == hipSuccess;
+    };
+    if (cu_det > 0 ? !mkmasked(&p->st_det, 0, cu_det) : !mkstream(&p->st_det)) return bail("stream");
+    if (cu_det > 0 && cu_ex >= 2 ? !mkmasked(&p->st_match, cu_det, 256) : !mkstream(&p->st_match)) return bail("stream");
     if (env_or("ORBFE_GATHER_STREAM", 0)) {
         int lo = 0, hi = 0;
         if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
         if (hipStreamCreateWithPriority(&p->st_gather, hipStreamNonBlocking, lo) != hipSuccess) return bail("stream");
     }
     p->st_ex.assign((size_t)p->D, nullptr);
-    for (auto& s : p->st_ex) if (!mkstream(&s)) return bail("stream");
+    for (auto& s : p->st_ex) if (cu_det > 0 && cu_ex ? !mkmasked(&s, cu_det, 256) : !mkstream(&s)) return bail("stream");
     if (p->use_orb) {
         for (int d = 0; d < p->D; d++) {
             orbfe_extractor* e = orbfe_extractor_create(cfg->nfeatures, cfg->scale_factor, cfg->nlevels, cfg->ini_th_fast, cfg->min_th_fast, cfg->device);
