@@ -979,8 +979,9 @@ class MarkerDetector:
         self.L.orbfe_aruco_debug_kernel_times(self.h, None, 8 if on else 9)
 
     def set_threshold_on_matrix_cores(self, on=True):
-        """k_threshold_mfma (default where it applies: windows up to 11) / the dot-product kernels."""
-        self.L.orbfe_aruco_debug_kernel_times(self.h, None, 14 if on else 15)
+        """True: k_threshold_mfma wherever it applies (windows up to 15); False: the dot-product kernels; None: the default rule -- the
+        matrix-core kernel for calls of 8 frames and more, k_threshold_pyr (one launch instead of five) for the drop-in call's few."""
+        self.L.orbfe_aruco_debug_kernel_times(self.h, None, 16 if on is None else 14 if on else 15)
 
     def set_threshold_pyramid_kernel(self, on=True):
         """k_threshold_pyr (threshold + the /2 pyramid levels a tile holds, the default where it applies) / k_adaptive_threshold_t + k_half_area4."""

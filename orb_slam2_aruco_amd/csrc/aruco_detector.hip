@@ -113,6 +113,7 @@ struct orbfe_aruco {
     int specks = !getenv("ORBFE_ARUCO_SPECKS") ? -1 : atoi(getenv("ORBFE_ARUCO_SPECKS")) == 1 ? 1 : 0;
     bool specks_inkernel = getenv("ORBFE_ARUCO_SPECKS") && atoi(getenv("ORBFE_ARUCO_SPECKS")) == 2;
     bool thr_mfma = true;   // k_threshold_mfma where it applies (windows up to 15; debug code 14 / 15)
+    bool thr_mfma_auto = true; // ... but k_threshold_pyr for calls of fewer than 8 frames (debug code 14 forces the matrix-core kernel, 16 = this rule again)
     DevBuf d_tstrips, d_ttabs, d_ttab2;
     int n_tstrips = 0, ttab_rows = 0, ttab_cols = 0, ttab_win = 0, ttab_rb = 0;
     bool thr_mfma_ok = false;
@@ -525,11 +526,15 @@ struct orbfe_aruco {
         {
             const long n2 = (long)win * win, K = n2 * thres_value - n2 / 2;
             const bool adaptive = !(mr && mr->fixed_thr >= 0);
-            if (adaptive && thr_mfma && th_magic && K > -(1 << 20) && K < (1 << 20)) {
+            const bool fused_ok = adaptive && thr_v2 && th_magic && (win == 5 || win == 7 || win == 11 || win == 15) && K >= 0 && n2 * 255 + K <= 65535;
+            // A call of a few frames (the drop-in call: one) is a chain of launches that each wait for the one before: there the kernel that
+            // also writes the pyramid (one launch instead of five) is the shorter chain -- detect 0.333 -> 0.303 ms per 640 x 480 frame;
+            // a batch has the pyramid next to the contour kernels on a stream of its own and takes the matrix-core kernel
+            if (adaptive && thr_mfma && th_magic && K > -(1 << 20) && K < (1 << 20) && !(fused_ok && !reduced && B < 8 && thr_mfma_auto)) {
                 if ((rc = build_threshold_tables())) return rc;
                 use_thr_mfma = thr_mfma_ok;
             }
-            if (!use_thr_mfma && adaptive && thr_v2 && th_magic && (win == 5 || win == 7 || win == 11 || win == 15) && K >= 0 && n2 * 255 + K <= 65535) {
+            if (!use_thr_mfma && fused_ok) {
                 thr_kk = (uint32_t)K | ((uint32_t)K << 16);
                 nfuse = -1;   // the kernel applies, with no level so far
                 if (!reduced)
@@ -1685,7 +1690,8 @@ int orbfe_aruco_debug_kernel_times(orbfe_aruco* h, float* out_us, int capacity)
         if (capacity == 7) return h->n_escalations;
         if (capacity == 8 || capacity == 9) { h->specks = capacity == 8 ? 1 : 0; return 0; }   // the speck passes on / off (default)
         if (capacity == 10 || capacity == 11) { h->specks_inkernel = capacity == 10; h->rows = h->cols = 0; return 0; }   // (the queue's size depends on it: geometry rebuilt)
-        if (capacity == 14 || capacity == 15) { h->thr_mfma = capacity == 14; return 0; }   // the threshold on the matrix cores on (default) / off
+        if (capacity == 14 || capacity == 15) { h->thr_mfma = capacity == 14; h->thr_mfma_auto = false; return 0; }
+        if (capacity == 16) { h->thr_mfma = true; h->thr_mfma_auto = true; return 0; }   // the threshold on the matrix cores on (default) / off
         if (capacity == 12 || capacity == 13) { h->thr_v2 = capacity == 12; return 0; }   // the threshold kernel with the fused pyramid on (default) / off   // ... inside the relay kernels on / off (default)
         if (capacity == 2 || capacity == 3) h->force_legacy = capacity == 2;
         else if (capacity >= 4 && capacity <= 6) {

@@ -624,7 +624,8 @@ def test_threshold_kernels_agree_and_the_fused_pyramid_is_the_pyramid(orbfe, ora
     a, b, c = orbfe.MarkerDetector("ARUCO"), orbfe.MarkerDetector("ARUCO"), orbfe.MarkerDetector("ARUCO")
     a.set_threshold_on_matrix_cores(False)                                        # a: k_threshold_pyr
     b.set_threshold_on_matrix_cores(False); b.set_threshold_pyramid_kernel(False)  # b: k_adaptive_threshold_t + k_half_area4
-    ma, mb, mc = a.detect_batch(imgs), b.detect_batch(imgs), c.detect_batch(imgs)  # c: k_threshold_mfma (round 6's default) + k_half_area4
+    c.set_threshold_on_matrix_cores(True)                                         # c: k_threshold_mfma (a batch's default; calls of fewer than 8 frames
+    ma, mb, mc = a.detect_batch(imgs), b.detect_batch(imgs), c.detect_batch(imgs)  #    take k_threshold_pyr unless told otherwise) + k_half_area4
     for f in range(n):
         assert np.array_equal(a.thresholded(f), b.thresholded(f)), (rows, cols, f)
         assert np.array_equal(c.thresholded(f), b.thresholded(f)), (rows, cols, f)
