@@ -972,6 +972,7 @@ __global__ __launch_bounds__(QP_THREADS) void k_distribute_pyr(const LevelGeom* 
     __builtin_amdgcn_s_setprio(ORBFE_PRIO_QT); // latency-bound: its few waves go first when a VALU-bound kernel shares the CU
     extern __shared__ __align__(16) unsigned char qp_smem[];
     __shared__ int s_ncand;
+    __shared__ int s_wtot[QP_THREADS / 64];
     // QP_THREADS threads build the leaf counts (the only part that is parallel over candidates), then one wave runs the
     // tree logic
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -1013,36 +1014,68 @@ __global__ __launch_bounds__(QP_THREADS) void k_distribute_pyr(const LevelGeom* 
     const uint32_t* cslots = slots + (size_t)f * slots_fstride + g.slot_off;
     const int H = g.maxBY - 16;
     int n = 0;
-    for (int c0 = wid * 64; c0 < g.ncells; c0 += QP_THREADS) {
-        const int c = c0 + lane;
-        const int k_cnt = (c < g.ncells) ? ccnt[c] : 0;
+    // The pass runs a THREAD PER CANDIDATE: a lane per cell walking its cell's slots ran for as many trips as the fullest of a wave's 64
+    // cells has candidates (20 - 100) with a seventh of the lanes at work, and the wave that held the textured cells kept the other three
+    // waiting -- 60 % of the workgroup's life (tools/wave_timing.sh), on the extractor's critical chain.  Per 1024 cells: the counts are
+    // scanned over the workgroup, every cell writes (cell << 10 | slot) of its candidates to the LDS the tree logic uses later (in
+    // windows of its capacity), and the 256 threads read the candidates from their slots, four in flight each.
+    uint32_t* clist = reinterpret_cast<uint32_t*>(vec);
+    const int lcap = (int)(((unsigned char*)cnt32 - (unsigned char*)vec) / 4);
+    constexpr int QP_CPT = 4;   // cells a thread: a level of up to 1024 cells (every level up to 1280 x 720's level 1) is one round of barriers
+    for (int cbase = 0; cbase < g.ncells; cbase += QP_THREADS * QP_CPT) {
+        const int cfirst = cbase + tid * QP_CPT;
+        int kc[QP_CPT], k_cnt = 0;
+#pragma unroll
+        for (int j = 0; j < QP_CPT; j++) kc[j] = ccnt[min(cfirst + j, g.ncells - 1)];
+#pragma unroll
+        for (int j = 0; j < QP_CPT; j++) { kc[j] = cfirst + j < g.ncells ? kc[j] : 0; k_cnt += kc[j]; }
         n += k_cnt;
-        const int mx = wave_max(k_cnt);
-        const uint32_t* sl = cslots + (size_t)c * g.cell_cap;
-        for (int k0 = 0; k0 < mx; k0 += 4) {
-            uint32_t kv[4];
+        int wtotal;
+        int excl = wave_excl_scan(k_cnt, lane, wtotal);
+        if (lane == 0) s_wtot[wid] = wtotal;
+        __syncthreads();
+        int total = 0;
 #pragma unroll
-            for (int k = 0; k < 4; k++) kv[k] = (k0 + k < k_cnt) ? sl[k0 + k] : 0u;
+        for (int w = 0; w < QP_THREADS / 64; w++) { const int t = s_wtot[w]; excl += w < wid ? t : 0; total += t; }
+        if (total == 0) __syncthreads();   // (the totals are rewritten for the next cells)
+        for (int base = 0; base < total; base += lcap) {
+            int e = excl;
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (k0 + k >= k_cnt) continue;
-                const int x = kv[k] & 0xfff, y = (kv[k] >> 12) & 0xfff;
-                const int r = (int)__fdiv_rn((float)x, g.hX);
-                int x0 = (int)(g.hX * (float)r), x1 = (int)(g.hX * (float)(r + 1)), y0 = 0, y1 = H;
-                uint32_t code = 0;
-                for (int d = 0; d < D; d++) {
-                    const int xm = x0 + ((x1 - x0 + 1) >> 1), ym = y0 + ((y1 - y0 + 1) >> 1); // ceil(float(w)/2)
-                    const int qx = x >= xm, qy = y >= ym;
-                    code = (code << 2) | (uint32_t)(qx + 2 * qy);
-                    x0 = qx ? xm : x0; x1 = qx ? x1 : xm;
-                    y0 = qy ? ym : y0; y1 = qy ? y1 : ym;
-                }
-                const uint32_t leaf = ((uint32_t)r << (2 * D)) + code;
-                const uint32_t ci = (uint32_t)off(D) + leaf;
-                atomicAdd(&cnt32[ci >> 1], (ci & 1) ? 0x10000u : 1u);
-                const uint32_t ord = ((uint32_t)c << 10) | (uint32_t)(k0 + k); // vToDistributeKeys order = (cell, slot): the keypoint itself
-                atomicMax(&best[leaf], ((kv[k] >> 24) << 22) | (0x3fffffu - ord)); // is read back from its slot at the end
+            for (int j = 0; j < QP_CPT; j++) {
+                const int k_end = min(kc[j], base + lcap - e);
+                for (int k = max(0, base - e); k < k_end; k++) clist[e + k - base] = ((uint32_t)(cfirst + j) << 10) | (uint32_t)k;
+                e += kc[j];
             }
+            __syncthreads();
+            const int m = min(lcap, total - base);
+            for (int i0 = 0; i0 < m; i0 += 4 * QP_THREADS) {
+                uint32_t ord[4], kv[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) ord[j] = clist[min(i0 + QP_THREADS * j + tid, m - 1)];
+#pragma unroll
+                for (int j = 0; j < 4; j++) kv[j] = cslots[(size_t)(ord[j] >> 10) * g.cell_cap + (ord[j] & 1023u)];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (i0 + QP_THREADS * j + tid >= m) continue;
+                    const int x = kv[j] & 0xfff, y = (kv[j] >> 12) & 0xfff;
+                    const int r = (int)__fdiv_rn((float)x, g.hX);
+                    int x0 = (int)(g.hX * (float)r), x1 = (int)(g.hX * (float)(r + 1)), y0 = 0, y1 = H;
+                    uint32_t code = 0;
+                    for (int d = 0; d < D; d++) {
+                        const int xm = x0 + ((x1 - x0 + 1) >> 1), ym = y0 + ((y1 - y0 + 1) >> 1); // ceil(float(w)/2)
+                        const int qx = x >= xm, qy = y >= ym;
+                        code = (code << 2) | (uint32_t)(qx + 2 * qy);
+                        x0 = qx ? xm : x0; x1 = qx ? x1 : xm;
+                        y0 = qy ? ym : y0; y1 = qy ? y1 : ym;
+                    }
+                    const uint32_t leaf = ((uint32_t)r << (2 * D)) + code;
+                    const uint32_t ci = (uint32_t)off(D) + leaf;
+                    atomicAdd(&cnt32[ci >> 1], (ci & 1) ? 0x10000u : 1u);
+                    // ord: vToDistributeKeys order = (cell, slot); the keypoint itself is read back from its slot at the end
+                    atomicMax(&best[leaf], ((kv[j] >> 24) << 22) | (0x3fffffu - ord[j]));
+                }
+            }
+            __syncthreads();   // the next window, the next 256 cells or the tree logic reuse the list
         }
     }
     n = wave_sum(n);
