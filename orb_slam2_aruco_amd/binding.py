@@ -987,6 +987,10 @@ class MarkerDetector:
         """k_threshold_pyr (threshold + the /2 pyramid levels a tile holds, the default where it applies) / k_adaptive_threshold_t + k_half_area4."""
         self.L.orbfe_aruco_debug_kernel_times(self.h, None, 12 if on else 13)
 
+    def set_half_pyramid_kernel(self, on=True):
+        """k_half_pyr (the leading exact /2 levels in one launch, default) / one k_half_area4 launch a level."""
+        self.L.orbfe_aruco_debug_kernel_times(self.h, None, 18 if on else 19)
+
     def set_speck_passes_in_kernel(self, on=True):
         """Debug: the speck passes inside the one-workgroup relay kernels (full batches of frames whose bit image fits LDS) on / off (default)."""
         self.L.orbfe_aruco_debug_kernel_times(self.h, None, 10 if on else 11)

@@ -112,6 +112,7 @@ struct orbfe_aruco {
     // 1920 x 1080), 0 / 1 = never / wherever their tile fits LDS (ORBFE_ARUCO_SPECKS, debug codes 8 / 9)
     int specks = !getenv("ORBFE_ARUCO_SPECKS") ? -1 : atoi(getenv("ORBFE_ARUCO_SPECKS")) == 1 ? 1 : 0;
     bool specks_inkernel = getenv("ORBFE_ARUCO_SPECKS") && atoi(getenv("ORBFE_ARUCO_SPECKS")) == 2;
+    bool half_pyr = true;   // the leading exact pyramid levels in one launch (k_half_pyr; debug code 18 / 19 = on / off)
     bool thr_mfma = true;   // k_threshold_mfma where it applies (windows up to 15; debug code 14 / 15)
     bool thr_mfma_auto = true; // ... but k_threshold_pyr for calls of fewer than 8 frames (debug code 14 forces the matrix-core kernel, 16 = this rule again)
     DevBuf d_tstrips, d_ttabs, d_ttab2;
@@ -556,6 +557,27 @@ struct orbfe_aruco {
         }
         timer.mark(aux_stream, "pyramid starts", true);
         auto rest_of_pyramid = [&](int first) -> int {
+        if (first == 1 && half_pyr) {
+            // the leading exact halvings in one launch (k_half_pyr): four from 16 x 16 source blocks, or three from 8 x 8
+            for (int nf = 4; nf >= 3 && first == 1; nf--) {
+                const int bs = 1 << nf;
+                bool ok = npyr > nf && levels[0].w % bs == 0 && levels[0].h % bs == 0 && src0.pitch % (bs == 16 ? 16 : 8) == 0 &&
+                          src0.fstride % (bs == 16 ? 16 : 8) == 0 && ((uintptr_t)src0.base & (bs == 16 ? 15 : 7)) == 0 && pyr_fbytes % 8 == 0;
+                for (int p = 1; ok && p <= nf; p++) {
+                    const int al = bs >> p;   // bytes a thread stores per row of level p
+                    ok = lvl_exact[p] && levels[p].w == levels[0].w >> p && levels[p].h == levels[0].h >> p && levels[p].pitch % al == 0 &&
+                         levels[p].off % al == 0 && levels[p].pitch >= levels[p].w;
+                }
+                if (!ok) continue;
+                HalfPyrDst P{};
+                P.base = pyr.base_w; P.fstride = pyr_fbytes;
+                for (int p = 1; p <= nf; p++) { P.off[p - 1] = (uint32_t)levels[p].off; P.pitch[p - 1] = levels[p].pitch; }
+                const int bw = levels[0].w / bs, nblocks = bw * (levels[0].h / bs);
+                if (nf == 4) hipLaunchKernelGGL(k_half_pyr<4>, dim3((nblocks + 255) / 256, B), dim3(256), 0, aux_stream, src0, P, bw, nblocks);
+                else hipLaunchKernelGGL(k_half_pyr<3>, dim3((nblocks + 255) / 256, B), dim3(256), 0, aux_stream, src0, P, bw, nblocks);
+                first = nf + 1;
+            }
+        }
         for (int p = first; p < npyr; p++) {
             const ArLevel& L = levels[p];
             const ArLevel& Lp = levels[p - 1];
@@ -1691,7 +1713,8 @@ int orbfe_aruco_debug_kernel_times(orbfe_aruco* h, float* out_us, int capacity)
         if (capacity == 8 || capacity == 9) { h->specks = capacity == 8 ? 1 : 0; return 0; }   // the speck passes on / off (default)
         if (capacity == 10 || capacity == 11) { h->specks_inkernel = capacity == 10; h->rows = h->cols = 0; return 0; }   // (the queue's size depends on it: geometry rebuilt)
         if (capacity == 14 || capacity == 15) { h->thr_mfma = capacity == 14; h->thr_mfma_auto = false; return 0; }
-        if (capacity == 16) { h->thr_mfma = true; h->thr_mfma_auto = true; return 0; }   // the threshold on the matrix cores on (default) / off
+        if (capacity == 16) { h->thr_mfma = true; h->thr_mfma_auto = true; return 0; }
+        if (capacity == 18 || capacity == 19) { h->half_pyr = capacity == 18; return 0; }   // k_half_pyr on (default) / off   // the threshold on the matrix cores on (default) / off
         if (capacity == 12 || capacity == 13) { h->thr_v2 = capacity == 12; return 0; }   // the threshold kernel with the fused pyramid on (default) / off   // ... inside the relay kernels on / off (default)
         if (capacity == 2 || capacity == 3) h->force_legacy = capacity == 2;
         else if (capacity >= 4 && capacity <= 6) {

@@ -65,6 +65,9 @@ __host__ __device__ inline size_t speck_frame_scratch_words(int W, int H)
 }
 __global__ void k_half_area(ImgView src, ImgView dst, int dw, int dh);
 __global__ void k_half_area4(ImgView src, ImgView dst, int dw4, int dh);
+// levels 1 .. NF of the /2 pyramid from the source in one launch (NF = 4: 16 x 16 source blocks, 16-byte aligned rows; NF = 3: 8 x 8, 8-byte)
+struct HalfPyrDst { uint8_t* base; size_t fstride; uint32_t off[4]; int pitch[4]; };
+template <int NF> __global__ void k_half_pyr(ImgView src, HalfPyrDst P, int bw, int nblocks);
 template <bool LDS_BITS>
 __global__ void k_contours_t(const uint32_t* gbits, size_t bits_fstride, int wpr_g, int W, int H, int lds_bits_words,
                            int min_len, uint32_t* candq, size_t candq_fstride, int candq_cap, uint32_t* pool,

@@ -623,7 +623,8 @@ def test_threshold_kernels_agree_and_the_fused_pyramid_is_the_pyramid(orbfe, ora
     imgs = synth.stream(rows, cols, n, 99, "ARUCO", n_markers=3 if rows >= 200 else 0)
     a, b, c = orbfe.MarkerDetector("ARUCO"), orbfe.MarkerDetector("ARUCO"), orbfe.MarkerDetector("ARUCO")
     a.set_threshold_on_matrix_cores(False)                                        # a: k_threshold_pyr
-    b.set_threshold_on_matrix_cores(False); b.set_threshold_pyramid_kernel(False)  # b: k_adaptive_threshold_t + k_half_area4
+    b.set_threshold_on_matrix_cores(False); b.set_threshold_pyramid_kernel(False)  # b: k_adaptive_threshold_t + k_half_area4 a level
+    b.set_half_pyramid_kernel(False)                                              #    (c's pyramid: k_half_pyr, the leading exact levels in one launch)
     c.set_threshold_on_matrix_cores(True)                                         # c: k_threshold_mfma (a batch's default; calls of fewer than 8 frames
     ma, mb, mc = a.detect_batch(imgs), b.detect_batch(imgs), c.detect_batch(imgs)  #    take k_threshold_pyr unless told otherwise) + k_half_area4
     for f in range(n):
