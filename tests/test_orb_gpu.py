@@ -105,6 +105,21 @@ def test_clustered_keypoints(orbfe, oracle):
     assert np.array_equal(k, ok) and np.array_equal(d, od)
 
 
+@pytest.mark.parametrize("rows,cols,nf,nl", [(480, 640, 1000, 8), (1080, 1920, 4000, 12)])
+def test_dense_noise_thousands_of_candidates_a_level(orbfe, oracle, rows, cols, nf, nl):
+    """Uniform noise: every cell is full of FAST corners.  The quadtree's count pass (a thread per candidate, round 6) then takes a
+    level's candidates in several windows of its LDS list and, at 1920 x 1080, the cells of level 0 in several rounds."""
+    img = np.random.default_rng(rows).integers(0, 256, (rows, cols), dtype=np.uint8)
+    ex = orbfe.ORBextractor(nf, 1.2, nl, 20, 7)
+    k, d = ex(img)
+    assert len(ex.level_keypoints(0, 0, 0)) > 4000      # the candidates of level 0 (before the quadtree)
+    ok, od = oracle.OrbOracle(nf, 1.2, nl, 20, 7).extract(img)
+    assert np.array_equal(k, ok) and np.array_equal(d, od)
+    ex.force_general_quadtree(True)
+    k2, d2 = ex(img)
+    assert np.array_equal(k2, ok) and np.array_equal(d2, od)
+
+
 @pytest.mark.parametrize("rows,cols,nf,nl,seed,dic,K", [
     (720, 1280, 2000, 8, 3, "ARUCO_MIP_25h7", 6),      # BASELINE configs[2]
     (1080, 1920, 4000, 12, 4, "ARUCO_MIP_36h12", 6),   # BASELINE configs[4] (extraction part)
