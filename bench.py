@@ -655,7 +655,8 @@ def main():
                 row = [wt[kid * 16 + k] for k in range(16)]
                 if row[15]:
                     print("wave_timing %s: waves %d, clocks per wave by phase %s, total %.0f" % (
-                        name, row[15], [round(v / row[15]) for v in row[:8]], sum(row[:8]) / row[15]), file=sys.stderr)
+                        name, row[15], [round(v / row[15]) for v in row[:8]], sum(row[:8]) / row[15]) +
+                          (", second passes %.3f of the waves" % (row[14] / row[15]) if row[14] else ""), file=sys.stderr)
     status = pipe.status()
     if any(status.values()):
         raise SystemExit("front-end capacity exceeded during the timed run: results incomplete, no number reported (%r)" % (status,))

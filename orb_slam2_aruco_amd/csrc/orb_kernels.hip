@@ -37,6 +37,7 @@ __device__ unsigned long long g_wt[4][16][2048];
 #define WT_BEGIN() long long wt_prev_ = clock64()
 #define WT_MARK(kid, slot) do { const long long t_ = clock64(); if ((threadIdx.x & 63) == 0) atomicAdd(&g_wt[kid][slot][(blockIdx.x * 4 + (threadIdx.x >> 6)) & 2047], (unsigned long long)(t_ - wt_prev_)); wt_prev_ = clock64(); } while (0)
 #define WT_COUNT(kid) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_wt[kid][15][(blockIdx.x * 4 + (threadIdx.x >> 6)) & 2047], 1ull); } while (0)
+#define WT_RETRY(kid) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_wt[kid][14][(blockIdx.x * 4 + (threadIdx.x >> 6)) & 2047], 1ull); } while (0)   // (FAST: cells that went to minThFAST)
 } // namespace orbfe
 extern "C" __attribute__((visibility("default"))) int orbfe_timing_read(unsigned long long* out, int reset)
 {
@@ -51,6 +52,7 @@ namespace orbfe {
 #define WT_BEGIN()
 #define WT_MARK(kid, slot)
 #define WT_COUNT(kid)
+#define WT_RETRY(kid)
 #endif
 
 // ------------------------------------------------------------------------------------------------ resize --
@@ -496,6 +498,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(ImgView src0, ImgView pyr, c
         }
         WT_MARK(1, 3);   // NMS
         if (nkeep > 0 || pass_no == 1) break;
+        WT_RETRY(1);
         // nothing at iniThFAST: wipe the scores and try again at minThFAST
         for (int e = lane; e < nlist; e += 64) {
             const int yx = slist[e];
