@@ -12,7 +12,7 @@ calib = json.load(open(cal)) if os.path.exists(cal) else {}
 # dominant global access width of each kernel (bytes per lane): reads, writes -- from the kernel sources
 WIDTH = {"k_orient_describe2": (4, 16), "k_decode_warp": (1, 1), "k_decode_vote": (1, 4), "k_decode_otsu": (16, 4), "k_sfi_rows": (16, 4), "k_sfi_accept": (16, 4),
          "k_sfi_grid": (16, 16), "k_resize_tab": (8, 4), "k_resize_level": (1, 4), "k_fast_cells": (4, 4), "k_blur7": (4, 4), "k_orient_describe": (4, 16),
-         "k_adaptive_threshold": (4, 8), "k_half_area4": (8, 4), "k_half_area": (1, 1), "k_knn2_mfma": (16, 4), "k_search_init": (16, 4), "k_contours_relay": (4, 4),
+         "k_adaptive_threshold": (4, 8), "k_half_area4": (8, 4), "k_half_pyr": (16, 8), "k_half_area": (1, 1), "k_knn2_mfma": (16, 4), "k_search_init": (16, 4), "k_contours_relay": (4, 4),
          "k_contours_small": (4, 4), "k_ct_walk": (4, 4), "k_ct_lists": (4, 8), "k_ct_points": (4, 4), "k_tail_prep": (8, 16), "k_tail_approx": (4, 4), "k_tail_finish": (4, 4), "k_decode": (1, 4), "k_distribute_pyr": (4, 4),
          "k_blur7_mfma": (16, 4), "k_threshold_mfma": (16, 4), "k_threshold_pyr": (4, 8), "k_speck_clean": (4, 4)}
 names = {1: "unsigned char", 4: "unsigned int", 8: "HIP_vector_type<unsigned int, 2u>", 16: "HIP_vector_type<unsigned int, 4u>"}
@@ -46,7 +46,7 @@ stage = {
     "distribute": named("k_distribute_pyr", "k_distribute", "k_level_offsets"), "blur7": named("k_blur7", "k_blur7_mfma"),
     "orient_describe": named("k_orient_describe", "k_orient_describe2"), "knn2": named("k_knn2_mfma", "k_knn2_tiles", "k_knn2_merge"),
     "search_init": named("k_search_init", "k_sfi_grid", "k_sfi_rows", "k_sfi_accept"),
-    "aruco_threshold": named("k_adaptive_threshold_t", "k_adaptive_threshold", "k_threshold_pyr", "k_threshold_mfma"), "aruco_pyramid": named("k_half_area", "k_half_area4", "k_resize_level"),
+    "aruco_threshold": named("k_adaptive_threshold_t", "k_adaptive_threshold", "k_threshold_pyr", "k_threshold_mfma"), "aruco_pyramid": named("k_half_area", "k_half_area4", "k_half_pyr", "k_resize_level"),
     "aruco_contours": [k for k in s if k.startswith("k_contours") or k.startswith("k_tail_") or k.startswith("k_ct_") or k.startswith("k_speck")],
     "aruco_decode": named("k_prefilter", "k_decode", "k_decode_warp", "k_decode_otsu", "k_decode_vote"), "aruco_finalize": named("k_finalize", "k_marker_poses"),
 }
