@@ -1406,18 +1406,33 @@ __device__ __forceinline__ int relay_frame(
     RL_STAMP();
     // ---- (a) padded bit image into LDS: pixel (x, y) -> bit x+1 of row y+1
     const float inv_wpr_a = 1.0f / (float)wpr;
-    for (int i = tid; i < wpr * prow; i += NT) {
-        const int py = (int)(((float)i + 0.5f) * inv_wpr_a), j = i - __mul24(py, wpr); // exact: i < 2^20 (an integer division by a runtime value is ~25 instructions)
-        uint32_t v = 0;
-        if (py >= 1 && py <= H) {
-            const uint32_t* row = gb + (uint32_t)__mul24(py - 1, wpr_g);
-            const uint32_t cur = j < wpr_g ? row[j] : 0u;
-            const uint32_t prv = (j >= 1 && j - 1 < wpr_g) ? row[j - 1] : 0u;
-            v = (cur << 1) | (prv >> 31);
+    // four words a thread and trip, their eight loads in flight together and none under a predicate (clamped addresses, the value
+    // masked afterwards): a load behind a condition is a branch with a full wait, and the image was twenty serial round trips --
+    // 22 k clocks of a frame's 560 k, twice (here and again in (f2))
+    auto load_padded_bits = [&]() {
+        const int nw = wpr * prow;
+        for (int i0 = 0; i0 < nw; i0 += 4 * NT) {
+            uint32_t cur[4], prv[4];
+            bool in[4], hasp[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int i = min(i0 + k * NT + tid, nw - 1);
+                const int py = (int)(((float)i + 0.5f) * inv_wpr_a), j = i - __mul24(py, wpr); // exact: i < 2^20 (an integer division by a runtime value is ~25 instructions)
+                const uint32_t* row = gb + (uint32_t)__mul24(min(max(py - 1, 0), H - 1), wpr_g);
+                in[k] = py >= 1 && py <= H && j < wpr_g;
+                hasp[k] = py >= 1 && py <= H && j >= 1 && j - 1 < wpr_g;
+                cur[k] = row[min(j, wpr_g - 1)];
+                prv[k] = row[min(max(j - 1, 0), wpr_g - 1)];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int i = i0 + k * NT + tid;
+                if (i < nw) lbits[i] = ((in[k] ? cur[k] : 0u) << 1) | ((hasp[k] ? prv[k] : 0u) >> 31);
+            }
         }
-        lbits[i] = v;
-    }
-    if (tid < 2) lbits[wpr * prow + tid] = 0; // spare words read by ring8()'s funnel loads
+        if (tid < 2) lbits[nw + tid] = 0; // spare words read by ring8()'s funnel loads
+    };
+    load_padded_bits();
     for (int i = tid; i < T; i += NT) hkey[i] = 0u;
     if (lut_g) for (int i = tid; i < 1024; i += NT) reinterpret_cast<uint32_t*>(s_lut)[i] = reinterpret_cast<const uint32_t*>(lut_g)[i];
     else for (int i = tid; i < 2048; i += NT) s_lut[i] = rl_lut_entry((unsigned)i >> 3, i & 7);
@@ -1498,9 +1513,13 @@ __device__ __forceinline__ int relay_frame(
         __syncthreads();
         if (s_nmpix > mcap && tid == 0) atomicOr(&s_flags, RL_FLAG_TABLE); // cannot fit the table either
         const int npx = min(s_nmpix, mcap);
-        for (int i = tid; i < npx; i += NT) {
-            const uint32_t v = mlist[i];
-            add((int)(v & 0xffffu), (int)(v >> 16));
+        for (int i0 = 0; i0 < npx; i0 += 4 * NT) {   // (four list entries a thread in flight: the list is in HBM)
+            uint32_t v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = mlist[min(i0 + k * NT + tid, npx - 1)];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (i0 + k * NT + tid < npx) add((int)(v[k] & 0xffffu), (int)(v[k] >> 16));
         }
         if (nm) atomicAdd(&s_nmark, nm);
     }
@@ -1753,12 +1772,19 @@ __device__ __forceinline__ int relay_frame(
     RL_STAMP();
 
     // the bit image is dead: its space now holds the list arrays, loaded from the segment records
+    {
+        // (the records' fields as unconditional loads of every slot of the thread, all in flight together: under `if (hkey[i])` each
+        //  was a branch with a wait for HBM behind it)
+        uint32_t r_mn[RL_SLOTS], r_nxt[RL_SLOTS];
 #pragma unroll
-    for (int q = 0; q < RL_SLOTS; q++) {
-        const int i = tid + q * NT;
-        if (i < T && hkey[i]) {
-            const RelaySeg r = sg[i];
-            cmin[i] = r.mn; jmp[i] = (uint16_t)r.nxt; arg[i] = (uint16_t)i;
+        for (int q = 0; q < RL_SLOTS; q++) {
+            const int i = min(tid + q * NT, T - 1);
+            r_mn[q] = sg[i].mn; r_nxt[q] = sg[i].nxt;
+        }
+#pragma unroll
+        for (int q = 0; q < RL_SLOTS; q++) {
+            const int i = tid + q * NT;
+            if (i < T && hkey[i]) { cmin[i] = r_mn[q]; jmp[i] = (uint16_t)r_nxt[q]; arg[i] = (uint16_t)i; }
         }
     }
     __syncthreads();
@@ -1898,21 +1924,29 @@ __device__ __forceinline__ int relay_frame(
         int e_dst[RL_SLOTS], e_len[RL_SLOTS], e_base[RL_SLOTS], e_n[RL_SLOTS];
         uint32_t e_key[RL_SLOTS];
         int mine = 0;
+        int e_g[RL_SLOTS], e_k[RL_SLOTS];
+        uint32_t r_len[RL_SLOTS], g_moff[RL_SLOTS];
 #pragma unroll
-        for (int q = 0; q < RL_SLOTS; q++) {
+        for (int q = 0; q < RL_SLOTS; q++) {   // what the lists say (LDS) ...
             const int i = tid + q * NT;
-            e_len[q] = 0;
-            if (i < T && hkey[i]) {
-                const int g = arg[i];
-                const int k = jmp[g];
-                if (k != RL_NIL) {
-                    const RelaySeg r = sg[i];
-                    const int n = (int)val[g];
-                    e_base[q] = off_u[k];
-                    e_dst[q] = off_u[k] + (n - (int)val[i]) - (int)(sg[g].minoff & 0x7fffffffu);
-                    e_len[q] = (int)r.len; e_n[q] = n; e_key[q] = hkey[i];
-                    mine++;
-                }
+            e_len[q] = 0; e_g[q] = 0; e_k[q] = RL_NIL;
+            if (i < T && hkey[i]) { e_g[q] = arg[i]; e_k[q] = jmp[e_g[q]]; }
+        }
+#pragma unroll
+        for (int q = 0; q < RL_SLOTS; q++) {   // ... the two record fields of every slot (HBM), unconditional and in flight together ...
+            r_len[q] = sg[min(tid + q * NT, T - 1)].len;
+            g_moff[q] = sg[e_g[q]].minoff;
+        }
+#pragma unroll
+        for (int q = 0; q < RL_SLOTS; q++) {   // ... the entries
+            const int i = tid + q * NT;
+            if (e_k[q] != RL_NIL) {
+                const int g = e_g[q], k = e_k[q];
+                const int n = (int)val[g];
+                e_base[q] = off_u[k];
+                e_dst[q] = off_u[k] + (n - (int)val[i]) - (int)(g_moff[q] & 0x7fffffffu);
+                e_len[q] = (int)r_len[q]; e_n[q] = n; e_key[q] = hkey[i];
+                mine++;
             }
         }
         // the kept borders (sort key, pool offset) go to k_tail_prep now: their arrays are about to be overwritten by the bit image
@@ -1926,20 +1960,7 @@ __device__ __forceinline__ int relay_frame(
         if (tid == 0) s_next = 0;
         __syncthreads(); // every read of the marker keys and of the list arrays done
         const int ebase = mine ? atomicAdd(&s_next, mine) : 0;
-        if (!GBITS) { // (a) again: the padded bit image
-            for (int i = tid; i < wpr * prow; i += NT) {
-                const int py = (int)(((float)i + 0.5f) * inv_wpr_a), j = i - __mul24(py, wpr);
-                uint32_t v = 0;
-                if (py >= 1 && py <= H) {
-                    const uint32_t* row = gb + (uint32_t)__mul24(py - 1, wpr_g);
-                    const uint32_t cur = j < wpr_g ? row[j] : 0u;
-                    const uint32_t prv = (j >= 1 && j - 1 < wpr_g) ? row[j - 1] : 0u;
-                    v = (cur << 1) | (prv >> 31);
-                }
-                lbits[i] = v;
-            }
-            if (tid < 2) lbits[wpr * prow + tid] = 0;
-        }
+        if (!GBITS) load_padded_bits(); // (a) again: the padded bit image
         __syncthreads();
         const int E = s_next;
         // the list: key, first destination, length, border base, border length -- five words per entry in the marker keys' space
