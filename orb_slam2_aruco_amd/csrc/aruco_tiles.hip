@@ -478,16 +478,26 @@ __global__ __launch_bounds__(CTB_THREADS) void k_ct_band(
     {
         const float inv_wpr = 1.0f / (float)wpr;
         const int nwords = wpr * nrows;
-        for (int i = tid; i < nwords; i += NT) {
-            const int r = (int)(((float)i + 0.5f) * inv_wpr), j = i - __mul24(r, wpr), py = y0 - 1 + r; // exact: i < 2^20
-            uint32_t v = 0;
-            if (py >= 1 && py <= H) {
-                const uint32_t* row = gb + (uint32_t)__mul24(py - 1, wpr_g);
-                const uint32_t cur = j < wpr_g ? row[j] : 0u;
-                const uint32_t prv = (j >= 1 && j - 1 < wpr_g) ? row[j - 1] : 0u;
-                v = (cur << 1) | (prv >> 31);
+        // (four words a thread and trip, their eight loads unconditional -- clamped addresses, masked values -- and in flight together, as
+        //  in k_contours_relay: under their predicates a band of eight cell rows was twenty serial round trips)
+        for (int i0 = 0; i0 < nwords; i0 += 4 * NT) {
+            uint32_t cur[4], prv[4];
+            bool in[4], hasp[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int i = min(i0 + k * NT + tid, nwords - 1);
+                const int r = (int)(((float)i + 0.5f) * inv_wpr), j = i - __mul24(r, wpr), py = y0 - 1 + r; // exact: i < 2^20
+                const uint32_t* row = gb + (uint32_t)__mul24(min(max(py - 1, 0), H - 1), wpr_g);
+                in[k] = py >= 1 && py <= H && j < wpr_g;
+                hasp[k] = py >= 1 && py <= H && j >= 1 && j - 1 < wpr_g;
+                cur[k] = row[min(j, wpr_g - 1)];
+                prv[k] = row[min(max(j - 1, 0), wpr_g - 1)];
             }
-            lbits[i] = v;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int i = i0 + k * NT + tid;
+                if (i < nwords) lbits[i] = ((in[k] ? cur[k] : 0u) << 1) | ((hasp[k] ? prv[k] : 0u) >> 31);
+            }
         }
         if (tid < 2) lbits[nwords + tid] = 0; // spare words read by ring8()'s funnel loads
     }
