@@ -2677,11 +2677,14 @@ __device__ __forceinline__ int dc_warp_pixel(const double* Mi, int y, int xx, co
     sy = sy < -32768 ? -32768 : sy > 32767 ? 32767 : sy;
     const int ax = X & 31, ay = Y & 31;
     const int w00 = (32 - ax) * (32 - ay) * 32, w01 = ax * (32 - ay) * 32, w10 = (32 - ax) * ay * 32, w11 = ax * ay * 32;
-    auto px = [&](int px_, int py_) -> int {
-        if (px_ < 0 || py_ < 0 || px_ >= LW || py_ >= LH) return 0;
-        return img[(size_t)py_ * pitch + px_];
-    };
-    int v = px(sx, sy) * w00 + px(sx + 1, sy) * w01 + px(sx, sy + 1) * w10 + px(sx + 1, sy + 1) * w11;
+    // the four neighbours as unconditional loads (clamped coordinates, the value masked afterwards): under `if (inside)` each was a
+    // branch with a wait for memory behind it -- four serial round trips a pixel, twenty pixels a lane
+    const bool x0in = sx >= 0 && sx < LW, x1in = sx + 1 >= 0 && sx + 1 < LW, y0in = sy >= 0 && sy < LH, y1in = sy + 1 >= 0 && sy + 1 < LH;
+    const int cx0 = min(max(sx, 0), LW - 1), cx1 = min(max(sx + 1, 0), LW - 1);
+    const uint8_t* r0 = img + (size_t)min(max(sy, 0), LH - 1) * pitch;
+    const uint8_t* r1 = img + (size_t)min(max(sy + 1, 0), LH - 1) * pitch;
+    const int p00 = r0[cx0], p01 = r0[cx1], p10 = r1[cx0], p11 = r1[cx1];
+    int v = (x0in && y0in ? p00 : 0) * w00 + (x1in && y0in ? p01 : 0) * w01 + (x0in && y1in ? p10 : 0) * w10 + (x1in && y1in ? p11 : 0) * w11;
     v = (v + (1 << 14)) >> 15;
     return v > 255 ? 255 : v;
 }
@@ -2765,11 +2768,22 @@ __global__ __launch_bounds__(DC_WAVES * 64) void k_decode_warp(ImgView src0, Img
             const uint8_t* img = (lvl == 0) ? src0.base + (size_t)f * src0.fstride : pyr.base + (size_t)f * pyr.fstride + L.off;
             const int pitch = (lvl == 0) ? src0.pitch : L.pitch;
             uint8_t* po = patch + (size_t)it * DC_PXCAP;
-            for (int i = lane; i < S * S; i += 64) {
-                const int y = i / S, xx = i - y * S;
-                const int v = dc_warp_pixel(Mi, y, xx, img, pitch, L.w, L.h);
-                atomicAdd(&h[v], 1u);
-                if (keep_px) po[i] = (uint8_t)v;
+            for (int i0 = 0; i0 < S * S; i0 += 4 * 64) {   // four pixels a lane and trip: sixteen loads in flight
+                int vv[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int i = min(i0 + 64 * k + lane, S * S - 1);
+                    const int y = i / S, xx = i - y * S;
+                    vv[k] = dc_warp_pixel(Mi, y, xx, img, pitch, L.w, L.h);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int i = i0 + 64 * k + lane;
+                    if (i < S * S) {
+                        atomicAdd(&h[vv[k]], 1u);
+                        if (keep_px) po[i] = (uint8_t)vv[k];
+                    }
+                }
             }
             __builtin_amdgcn_wave_barrier();
             // the histogram as u16 (a bin holds at most S * S pixels; the host refuses S > 255) and its first moment, which is a sum
@@ -2895,7 +2909,7 @@ __global__ __launch_bounds__(DC_WAVES * 64) void k_decode_vote(ImgView src0, Img
             const int my = (int)__fdiv_rn(__fmul_rn((float)n, (float)y), (float)S);
             const int mx = (int)__fdiv_rn(__fmul_rn((float)n, (float)xx), (float)S);
             // the patch k_decode_warp kept; a warp size whose patch does not fit is warped again (per pixel three f64 multiply-adds,
-            // an f64 division and four dependent byte loads)
+            // an f64 division and four byte loads)
             const int v = keep_px ? (int)px[i] : dc_warp_pixel(Mi, y, xx, img, pitch, L.w, L.h);
             if (v > th) atomicAdd(&s_ones[wid][my * n + mx], 1);
             atomicAdd(&s_tot[wid][my * n + mx], 1);
