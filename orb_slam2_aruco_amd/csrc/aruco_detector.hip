@@ -555,6 +555,7 @@ struct orbfe_aruco {
             ORBFE_HIP(hipEventRecord(ev_fork, s));
             ORBFE_HIP(hipStreamWaitEvent(aux_stream, ev_fork, 0));
         }
+        bool finish_in_prefilter = false;   // k_tail_finish's work inside k_prefilter (set where the tail kernels are launched)
         timer.mark(aux_stream, "pyramid starts", true);
         auto rest_of_pyramid = [&](int first) -> int {
         if (first == 1 && half_pyr) {
@@ -761,9 +762,13 @@ struct orbfe_aruco {
                                    d_twork.as<uint4>(), (size_t)relay_kcap * B, d_tctr.as<int32_t>());
                 hipLaunchKernelGGL(k_tail_approx, dim3(tail_wgs), dim3(256), alds, s, relay_kcap, d_twork.as<uint4>(), (size_t)relay_kcap * B, d_tctr.as<int32_t>(),
                                    d_pool.as<uint32_t>(), pool_fu32, d_kept.as<ArKept>(), relay_kcap, d_trect.as<uint8_t>(), pts);
-                hipLaunchKernelGGL(k_tail_finish, dim3(B), dim3(64), 0, s, relay_kcap, d_trect.as<uint8_t>(), d_kept.as<ArKept>(), relay_kcap,
-                                   d_rects.as<ArRect>(), AR_MAX_RECTS, d_counts.as<int32_t>(), d_tctr.as<int32_t>());
-                if (hipPeekAtLastError() == hipSuccess) tail_dirty = false;   // k_tail_finish leaves the list lengths at zero
+                // (the rectangle lists: a launch of their own only when the enclosed-marker pass sits between them and k_prefilter)
+                finish_in_prefilter = !enclosed;
+                if (!finish_in_prefilter) {
+                    hipLaunchKernelGGL(k_tail_finish, dim3(B), dim3(64), 0, s, relay_kcap, d_trect.as<uint8_t>(), d_kept.as<ArKept>(), relay_kcap,
+                                       d_rects.as<ArRect>(), AR_MAX_RECTS, d_counts.as<int32_t>(), d_tctr.as<int32_t>());
+                    if (hipPeekAtLastError() == hipSuccess) tail_dirty = false;   // k_tail_finish leaves the list lengths at zero
+                }
             }
         }
         // the single-walker kernel: images whose bit image does not fit LDS next to the relay kernel's tables, or forced
@@ -779,9 +784,14 @@ struct orbfe_aruco {
                                (int)(float(enlarge_k) / 2.));
         if (decode_dirty) ORBFE_HIP(hipMemsetAsync(d_dctr.p, 0, 16, s));   // a previous batch was abandoned between prefilter and finalize
         decode_dirty = true;
-        hipLaunchKernelGGL(k_prefilter, dim3(B), dim3(256), 0, s, d_rects.as<ArRect>(), AR_MAX_RECTS,
-                           d_counts.as<int32_t>(), cols, rows, win, d_candidx.as<int32_t>(), d_ncand.as<int32_t>(),
-                           d_dwork.as<uint32_t>(), d_dctr.as<int32_t>());
+        {
+            TailFinish tf{};
+            if (finish_in_prefilter) tf = TailFinish{relay_kcap, d_trect.as<uint8_t>(), d_kept.as<ArKept>(), relay_kcap, d_tctr.as<int32_t>()};
+            hipLaunchKernelGGL(k_prefilter, dim3(B), dim3(256), 0, s, d_rects.as<ArRect>(), AR_MAX_RECTS,
+                               d_counts.as<int32_t>(), cols, rows, win, d_candidx.as<int32_t>(), d_ncand.as<int32_t>(),
+                               d_dwork.as<uint32_t>(), d_dctr.as<int32_t>(), tf);
+            if (finish_in_prefilter && hipPeekAtLastError() == hipSuccess) tail_dirty = false;   // (it leaves the tail's list lengths at zero)
+        }
         if (!nfuse) ORBFE_HIP(hipStreamWaitEvent(s, ev_join, 0));
         {
             // the batch's candidates as one work list: a wave per candidate (persistent: 32 candidates per frame is more than the
@@ -832,18 +842,38 @@ struct orbfe_aruco {
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Marker pose (reference detect :8720-8780 -> Marker::calculateExtrinsics, and Frame.cc:170): one lane per marker record.
+// Marker pose (reference detect :8720-8780 -> Marker::calculateExtrinsics, and Frame.cc:170): TWO lanes per marker record, one per IPPE
+// solution -- both compute the homography and the two rotations (the same instructions on both lanes), then each its own translation,
+// reprojection error (Rodrigues with a double sine and cosine, four distorted projections) and rotation vector; the pair exchanges
+// seven floats.  The same operations on the same values as one lane doing both; the kernel is one serial chain of double arithmetic
+// at the end of the detector's launches, and this takes 40 % off it.  32 markers per 64-thread workgroup.
 __global__ __launch_bounds__(64) void k_marker_poses(const orbfe_marker* __restrict__ markers, const int32_t* __restrict__ d_n,
                                                     int capacity, float marker_size, PoseCamera cam,
                                                     orbfe_marker_pose* __restrict__ poses)
 {
-    const int f = blockIdx.y, i = blockIdx.x * 64 + threadIdx.x;
+    const int f = blockIdx.y, lane = threadIdx.x, i = blockIdx.x * 32 + (lane >> 1), which = lane & 1;
     const int n = d_n ? min(d_n[f], capacity) : capacity;
-    if (i >= n) return;
+    if (i >= n) return;   // (both lanes of a pair: the exchange below is between lanes of one pair)
     const orbfe_marker m = markers[(size_t)f * capacity + i];
-    orbfe_marker_pose out;
-    pose::solve_marker(m.corners, marker_size, cam, &out);
-    poses[(size_t)f * capacity + i] = out;
+    float e, r[3], t[3];
+    pose::solve_marker_half(m.corners, marker_size, cam, which, &e, r, t);
+    // the partner's solution
+    const float eo = __shfl_xor(e, 1);
+    float ro[3], to[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { ro[k] = __shfl_xor(r[k], 1); to[k] = __shfl_xor(t[k], 1); }
+    if (which == 0) {
+        const bool a_first = e < eo; // ippe.cpp:786 (this lane holds solution a)
+        orbfe_marker_pose out;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            out.rvec[k] = a_first ? r[k] : ro[k]; out.tvec[k] = a_first ? t[k] : to[k];
+            out.rvec2[k] = a_first ? ro[k] : r[k]; out.tvec2[k] = a_first ? to[k] : t[k];
+        }
+        out.err[0] = a_first ? e : eo;
+        out.err[1] = a_first ? eo : e;
+        poses[(size_t)f * capacity + i] = out;
+    }
 }
 
 static int pose_camera(const float* K4, const float* dist, int ndist, float marker_size, PoseCamera& c, const char* who)
@@ -1273,7 +1303,7 @@ int aruco_speculate(orbfe_aruco* h, const uint8_t* d_img, size_t dframe, int row
     op.add(hp + o.cnt, h->d_counts.p, 16);
     op.add(hp + o.mk, h->d_out.p, (size_t)AR_MAX_RECTS * sizeof(orbfe_marker));
     if (pose) {
-        hipLaunchKernelGGL(k_marker_poses, dim3((AR_MAX_RECTS + 63) / 64, 1), dim3(64), 0, s, h->d_out.as<orbfe_marker>(), h->d_nout.as<int32_t>(),
+        hipLaunchKernelGGL(k_marker_poses, dim3((AR_MAX_RECTS + 31) / 32, 1), dim3(64), 0, s, h->d_out.as<orbfe_marker>(), h->d_nout.as<int32_t>(),
                            AR_MAX_RECTS, h->last_size, h->last_cam, h->d_poses.as<orbfe_marker_pose>());
         op.add(hp + o.ps, h->d_poses.p, (size_t)AR_MAX_RECTS * sizeof(orbfe_marker_pose));
     }
@@ -1421,7 +1451,7 @@ static int detect_frames_modes(orbfe_aruco* h, const uint8_t* imgs, int nframes,
         if (n > capacity) return fail(ORBFE_ERR_CAPACITY, "frame %d has %d markers, capacity is %d", f, n, capacity);
         if (n) memcpy(out + (size_t)f * capacity, mk, (size_t)n * sizeof(orbfe_marker));
         if (n && cam) {
-            hipLaunchKernelGGL(k_marker_poses, dim3((AR_MAX_RECTS + 63) / 64, 1), dim3(64), 0, s, h->d_out.as<orbfe_marker>(), h->d_nout.as<int32_t>(),
+            hipLaunchKernelGGL(k_marker_poses, dim3((AR_MAX_RECTS + 31) / 32, 1), dim3(64), 0, s, h->d_out.as<orbfe_marker>(), h->d_nout.as<int32_t>(),
                                AR_MAX_RECTS, marker_size, *cam, h->d_poses.as<orbfe_marker_pose>());
             ORBFE_HIP(hipMemcpyAsync(hp + o_ps, h->d_poses.p, (size_t)n * sizeof(orbfe_marker_pose), hipMemcpyDeviceToHost, s));
             ORBFE_HIP(hipStreamSynchronize(s));
@@ -1467,7 +1497,7 @@ static int detect_batch_impl(orbfe_aruco* h, const uint8_t* imgs, int nframes, s
             uint8_t* hp = h->pinned.as<uint8_t>();
             const bool pose_ready = cam && h->spec.has_pose && h->spec.size == marker_size && same_camera(h->spec.cam, *cam);
             if (cam && !pose_ready) { // same markers, another camera: only the poses are still to do
-                hipLaunchKernelGGL(k_marker_poses, dim3((AR_MAX_RECTS + 63) / 64, 1), dim3(64), 0, s, h->d_out.as<orbfe_marker>(),
+                hipLaunchKernelGGL(k_marker_poses, dim3((AR_MAX_RECTS + 31) / 32, 1), dim3(64), 0, s, h->d_out.as<orbfe_marker>(),
                                    h->d_nout.as<int32_t>(), AR_MAX_RECTS, marker_size, *cam, h->d_poses.as<orbfe_marker_pose>());
                 ORBFE_HIP(hipMemcpyAsync(hp + o.ps, h->d_poses.p, (size_t)AR_MAX_RECTS * sizeof(orbfe_marker_pose), hipMemcpyDeviceToHost, s));
             }
@@ -1503,7 +1533,7 @@ static int detect_batch_impl(orbfe_aruco* h, const uint8_t* imgs, int nframes, s
                            AR_MAX_RECTS, h->d_nout.as<int32_t>(), s);
         if (rc) { h->big_mode = user_big_mode; h->tiled_off = false; return rc; }
         if (cam)
-            hipLaunchKernelGGL(k_marker_poses, dim3((AR_MAX_RECTS + 63) / 64, nframes), dim3(64), 0, s, h->d_out.as<orbfe_marker>(),
+            hipLaunchKernelGGL(k_marker_poses, dim3((AR_MAX_RECTS + 31) / 32, nframes), dim3(64), 0, s, h->d_out.as<orbfe_marker>(),
                                h->d_nout.as<int32_t>(), AR_MAX_RECTS, marker_size, *cam, h->d_poses.as<orbfe_marker_pose>());
         if (nframes <= 16) {   // a frame or a few: the results in one launch that writes the staging buffer (OutPack, orbfe_common.hpp)
             OutPack op;
@@ -1752,7 +1782,7 @@ int orbfe_marker_poses_batch_device(const orbfe_marker* d_markers, const int32_t
     int rc = pose_camera(K4, dist, ndist, marker_size, c, "orbfe_marker_poses_batch_device");
     if (rc) return rc;
     if (nframes == 0 || capacity == 0) return ORBFE_OK;
-    hipLaunchKernelGGL(k_marker_poses, dim3((capacity + 63) / 64, nframes), dim3(64), 0, (hipStream_t)stream, d_markers, d_n,
+    hipLaunchKernelGGL(k_marker_poses, dim3((capacity + 31) / 32, nframes), dim3(64), 0, (hipStream_t)stream, d_markers, d_n,
                        capacity, marker_size, c, d_poses);
     ORBFE_HIP(hipGetLastError());
     return ORBFE_OK;
@@ -1774,7 +1804,7 @@ int orbfe_marker_poses(const orbfe_marker* markers, int n, float marker_size, co
     const size_t o_p = (mb + 63) / 64 * 64;
     memcpy(hp, markers, mb);
     ORBFE_HIP(hipMemcpyAsync(w.markers.p, hp, mb, hipMemcpyHostToDevice, w.stream));
-    hipLaunchKernelGGL(k_marker_poses, dim3((n + 63) / 64, 1), dim3(64), 0, w.stream, w.markers.as<orbfe_marker>(), (const int32_t*)nullptr,
+    hipLaunchKernelGGL(k_marker_poses, dim3((n + 31) / 32, 1), dim3(64), 0, w.stream, w.markers.as<orbfe_marker>(), (const int32_t*)nullptr,
                        n, marker_size, c, w.poses.as<orbfe_marker_pose>());
     ORBFE_HIP(hipGetLastError());
     ORBFE_HIP(hipMemcpyAsync(hp + o_p, w.poses.p, pb, hipMemcpyDeviceToHost, w.stream));

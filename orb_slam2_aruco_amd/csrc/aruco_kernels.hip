@@ -2459,12 +2459,11 @@ __global__ __launch_bounds__(256) void k_tail_approx(int kcap, const uint4* __re
     }
 }
 
-__global__ __launch_bounds__(64) void k_tail_finish(int kcap, const uint8_t* __restrict__ rectflag, const ArKept* __restrict__ kept_out,
-                                                    int kept_cap, ArRect* __restrict__ rects_out, int rect_cap, int32_t* __restrict__ counts,
-                                                    int32_t* __restrict__ ctr)
+// the 4-gons of a frame's kept borders -> its rectangle list (one wave)
+__device__ __forceinline__ void tail_finish_frame(int f, int lane, int kcap, const uint8_t* __restrict__ rectflag, const ArKept* __restrict__ kept_out,
+                                                  int kept_cap, ArRect* __restrict__ rects_out, int rect_cap, int32_t* __restrict__ counts,
+                                                  int32_t* __restrict__ ctr)
 {
-    if (ORBFE_PRIO_DET_TAIL) __builtin_amdgcn_s_setprio(ORBFE_PRIO_DET_TAIL);
-    const int f = blockIdx.x, lane = threadIdx.x;
     if (f == 0 && lane == 0) { ctr[0] = 0; ctr[1] = 0; } // every consumer of this batch's work list is done: ready for the next batch
     const int flags = counts[f * 4 + 2];
     if (flags) return; // the relay kernel reported the frame as failed
@@ -2491,6 +2490,13 @@ __global__ __launch_bounds__(64) void k_tail_finish(int kcap, const uint8_t* __r
         if (nr > rect_cap) counts[f * 4 + 2] = flags | 8;
     }
 }
+__global__ __launch_bounds__(64) void k_tail_finish(int kcap, const uint8_t* __restrict__ rectflag, const ArKept* __restrict__ kept_out,
+                                                    int kept_cap, ArRect* __restrict__ rects_out, int rect_cap, int32_t* __restrict__ counts,
+                                                    int32_t* __restrict__ ctr)
+{
+    if (ORBFE_PRIO_DET_TAIL) __builtin_amdgcn_s_setprio(ORBFE_PRIO_DET_TAIL);
+    tail_finish_frame(blockIdx.x, threadIdx.x, kcap, rectflag, kept_out, kept_cap, rects_out, rect_cap, counts, ctr);
+}
 
 // ---------------------------------------------------------------------------------------- prefilter -----------
 __device__ __forceinline__ int ar_perimeter(const float c[4][2])
@@ -2505,15 +2511,20 @@ __device__ __forceinline__ int ar_perimeter(const float c[4][2])
 }
 
 // prefilterCandidates: one workgroup (256 threads) per frame
-__global__ __launch_bounds__(256) void k_prefilter(ArRect* __restrict__ rects, int rect_cap, const int32_t* __restrict__ counts,
+__global__ __launch_bounds__(256) void k_prefilter(ArRect* __restrict__ rects, int rect_cap, int32_t* __restrict__ counts,
                                                    int W, int H, int too_near, int32_t* __restrict__ cand_idx,
-                                                   int32_t* __restrict__ ncand_out, uint32_t* __restrict__ work, int32_t* __restrict__ wctr)
+                                                   int32_t* __restrict__ ncand_out, uint32_t* __restrict__ work, int32_t* __restrict__ wctr, TailFinish tf)
 {
     __builtin_amdgcn_s_setprio(2); // latency-bound: its few waves go first when a VALU-bound kernel shares the CU
     __shared__ int s_rm[AR_MAX_RECTS];
     __shared__ int s_per[AR_MAX_RECTS];
     const int f = blockIdx.x, tid = threadIdx.x;
-    const int n = counts[f * 4 + 1];
+    if (tf.rectflag) {   // the rectangle list first (k_tail_finish's work, one wave: a launch less on the detector's chain)
+        if (tid < 64) tail_finish_frame(f, tid, tf.kcap, tf.rectflag, tf.kept, tf.kept_cap, rects, rect_cap, counts, tf.ctr);
+        __threadfence_block();
+        __syncthreads();
+    }
+    const int n = *(volatile int32_t*)&counts[f * 4 + 1];
     ArRect* R = rects + (size_t)f * rect_cap;
     for (int i = tid; i < n; i += 256) {
         ArRect r = R[i];

@@ -109,8 +109,10 @@ __global__ void k_tail_approx(int kcap, const uint4* work, size_t work_half, con
                               int kept_cap, uint8_t* rectflag, int pts);
 __global__ void k_tail_finish(int kcap, const uint8_t* rectflag, const ArKept* kept_out, int kept_cap, ArRect* rects_out, int rect_cap,
                               int32_t* counts, int32_t* ctr);
-__global__ void k_prefilter(ArRect* rects, int rect_cap, const int32_t* counts, int W, int H, int too_near,
-                            int32_t* cand_idx, int32_t* ncand_out, uint32_t* work, int32_t* wctr);
+// what k_tail_finish does, when k_prefilter does it in front of its own work (rectflag == nullptr: k_tail_finish ran as a launch)
+struct TailFinish { int kcap; const uint8_t* rectflag; const ArKept* kept; int kept_cap; int32_t* ctr; };
+__global__ void k_prefilter(ArRect* rects, int rect_cap, int32_t* counts, int W, int H, int too_near,
+                            int32_t* cand_idx, int32_t* ncand_out, uint32_t* work, int32_t* wctr, TailFinish tf);
 struct DcItem { // one rectangle candidate between the decode kernels
     double Mi[9]; // inverse homography of the warp
     int lvl, ok;  // pyramid level; 0 = singular system

@@ -317,4 +317,34 @@ __device__ inline void solve_marker(const float corners[4][2], float marker_size
     out->err[1] = a_first ? eb : ea;
 }
 
+// One of the two solutions (which = 0: a, 1: b) of solve_marker(), for a kernel that gives a marker two lanes: the shared part -- the
+// normalised corners, the homography, both rotations -- then this solution's translation, reprojection error and rotation vector.
+// The same operations on the same values as solve_marker() performs for that solution.
+__device__ inline void solve_marker_half(const float corners[4][2], float marker_size, const PoseCamera& c, int which, float* err, float rvec[3],
+                                         float tvec[3])
+{
+    const float hs = marker_size / 2.f; // marker.cpp:360
+    const float obj[4][2] = {{-hs, hs}, {hs, hs}, {hs, -hs}, {-hs, -hs}};
+    V2 img[4], can[4];
+    double xb = 0, yb = 0;
+    for (int i = 0; i < 4; i++) {
+        img[i] = normalise_point(corners[i][0], corners[i][1], c);
+        xb += (double)obj[i][0]; yb += (double)obj[i][1];
+    }
+    xb = xb / 4.0; yb = yb / 4.0;
+    for (int i = 0; i < 4; i++) can[i] = {(double)obj[i][0] - xb, (double)obj[i][1] - yb};
+    double H[9];
+    homography4(can, img, H);
+    const double j00 = H[0] - H[6] * H[2], j01 = H[1] - H[7] * H[2], j10 = H[3] - H[6] * H[5], j11 = H[4] - H[7] * H[5];
+    double Ra[9], Rb[9], R[9], t[3];
+    rotations(j00, j01, j10, j11, H[2], H[5], Ra, Rb);
+    for (int i = 0; i < 9; i++) R[i] = which ? Rb[i] : Ra[i];
+    translation(can, img, R, t);
+    for (int i = 0; i < 3; i++) t[i] = R[3 * i] * -xb + R[3 * i + 1] * -yb + t[i]; // the canonical frame is the centred one (MCenter, ippe.cpp:707-722)
+    *err = reprojection_error(obj, corners, c, R, t);
+    double r[3];
+    rot2vec(R, r);
+    for (int i = 0; i < 3; i++) { rvec[i] = (float)r[i]; tvec[i] = (float)t[i]; }
+}
+
 } // namespace pose

@@ -1576,11 +1576,12 @@ int orbfe_search_for_initialization(const orbfe_keypoint* kps1, const uint8_t* d
         ip.add(w.kps.p, hp + i_kps, 2 * kb);
         ip.add(w.desc.p, hp + i_desc, 2 * db);
         ip.add(w.nk.p, hp + i_nk, 8);
+        ip.add(w.prev.p, hp + i_prev, (size_t)n1 * 8);   // (with the other inputs: one launch less on the call's chain)
         if ((rc = ip.flush<3>(s))) return rc;
     }
     for (int attempt = 0;; attempt++) {
-        // the device copy of prev_matched is only overwritten by a run that did not overflow
-        { OutPack ip; ip.add(w.prev.p, hp + i_prev, (size_t)n1 * 8); if ((rc = ip.flush<3>(s))) return rc; }
+        // the device copy of prev_matched is only overwritten by a run that did not overflow: a second attempt uploads it again
+        if (attempt) { OutPack ip; ip.add(w.prev.p, hp + i_prev, (size_t)n1 * 8); if ((rc = ip.flush<3>(s))) return rc; }
         rc = sfi_launch(w.kps.as<orbfe_keypoint>(), w.desc.as<uint8_t>(), w.nk.as<int32_t>(), cap, 1, frame_bounds(cols, rows, bounds),
                         window_size, nnratio, check_orientation, w.prev.as<float>(), w.prev.as<float>(),
                         w.m12.as<int32_t>(), w.nm.as<int32_t>(), s, w);
