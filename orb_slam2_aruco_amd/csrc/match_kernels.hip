@@ -642,22 +642,38 @@ __global__ __launch_bounds__(64) void k_sfi_accept(const orbfe_keypoint* __restr
     const unsigned long long t_2 = wall_clock64();
 #endif
     int nmatches = 0;
-    for (int q0 = 0; q0 < nq; q0 += 64) {
-        const int q = q0 + lane;
-        bool held = false;
-        if (q < nq) {
-            const int r = s_held[q];
-            held = r != NIL;
-            if (held) m12[qi[q]] = (int)(G.sorted[g2 + r] & 0xffff);
-            if (check_ori && s_acc[q] != NIL) {
-                float rot = k1[qi[q]].angle - G.ang[g2 + s_acc[q]];
+    for (int q0 = 0; q0 < nq; q0 += 4 * 64) {   // four queries a lane and trip: their index, match and angle loads in flight together
+        int rr[4], ra[4], qidx[4];
+        bool in[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int q = q0 + 64 * k + lane, qc = min(q, nq - 1);
+            in[k] = q < nq;
+            rr[k] = s_held[qc]; ra[k] = s_acc[qc];
+            qidx[k] = qi[qc];
+        }
+        uint32_t srt[4];
+        float a1[4], a2[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            srt[k] = G.sorted[g2 + (rr[k] != NIL ? rr[k] : 0)];
+            a1[k] = k1[qidx[k]].angle;
+            a2[k] = G.ang[g2 + (ra[k] != NIL ? ra[k] : 0)];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int q = q0 + 64 * k + lane;
+            const bool held = in[k] && rr[k] != NIL;
+            if (held) m12[qidx[k]] = (int)(srt[k] & 0xffff);
+            if (in[k] && check_ori && ra[k] != NIL) {
+                float rot = a1[k] - a2[k];
                 if (rot < 0.0f) rot += 360.0f;
                 int bin = (int)roundf(__fmul_rn(rot, factor));
                 if (bin == 30) bin = 0;
                 s_rotbin[q] = (signed char)bin; // rotHist[bin].push_back(i1): stays even if un-matched later
             }
+            nmatches += (int)__popcll(__ballot(held));
         }
-        nmatches += (int)__popcll(__ballot(held));
     }
     __threadfence_block();
     if (check_ori) {
@@ -675,26 +691,46 @@ __global__ __launch_bounds__(64) void k_sfi_accept(const orbfe_keypoint* __restr
         if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
         else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
         int removed = 0;
-        for (int q0 = 0; q0 < nq; q0 += 64) {
-            const int q = q0 + lane;
-            bool rm = false;
-            if (q < nq) {
-                const int bin = s_rotbin[q];
-                rm = bin >= 0 && bin != ind1 && bin != ind2 && bin != ind3 && s_held[q] != NIL;
-                if (rm) m12[qi[q]] = -1;
+        for (int q0 = 0; q0 < nq; q0 += 4 * 64) {
+            int qidx[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) qidx[k] = qi[min(q0 + 64 * k + lane, nq - 1)];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int q = q0 + 64 * k + lane;
+                bool rm = false;
+                if (q < nq) {
+                    const int bin = s_rotbin[q];
+                    rm = bin >= 0 && bin != ind1 && bin != ind2 && bin != ind3 && s_held[q] != NIL;
+                    if (rm) m12[qidx[k]] = -1;
+                }
+                removed += (int)__popcll(__ballot(rm));
             }
-            removed += (int)__popcll(__ballot(rm));
         }
         nmatches -= removed;
     }
     __threadfence_block();
     if (prevo)
-        for (int i = lane; i < n1; i += 64) {
-            float x = prev ? prev[2 * i] : k1[i].x, y = prev ? prev[2 * i + 1] : k1[i].y;
-            const int m = m12[i];
-            if (m >= 0) { x = k2[m].x; y = k2[m].y; }
-            prevo[2 * i] = x;
-            prevo[2 * i + 1] = y;
+        for (int i0 = 0; i0 < n1; i0 += 4 * 64) {   // four entries a lane, their loads in flight together (they were a round trip each:
+            float x[4], y[4];                        //   the match, then the keypoint it names, sixteen times over for one pair)
+            int m[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int i = min(i0 + 64 * k + lane, n1 - 1);
+                x[k] = prev ? prev[2 * i] : k1[i].x; y[k] = prev ? prev[2 * i + 1] : k1[i].y;
+                m[k] = m12[i];
+            }
+            float mx[4], my[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const int mm = max(m[k], 0); mx[k] = k2[mm].x; my[k] = k2[mm].y; }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int i = i0 + 64 * k + lane;
+                if (i < n1) {
+                    prevo[2 * i] = m[k] >= 0 ? mx[k] : x[k];
+                    prevo[2 * i + 1] = m[k] >= 0 ? my[k] : y[k];
+                }
+            }
         }
     if (lane == 0) nmatches_out[p] = nmatches;
 #ifdef ORBFE_SFI_TIMING
