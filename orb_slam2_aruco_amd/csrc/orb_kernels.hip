@@ -1706,6 +1706,17 @@ __global__ __launch_bounds__(256) OD2_ATTR void k_orient_describe2(ImgView src0,
     __shared__ __align__(16) uint8_t s_pat[4][2][PATB];
     __shared__ uint4 s_icw[31 * 4];
     __shared__ uint32_t s_pattern[256];
+#if OD2_LDS_PAD > 0
+    // LDS the kernel asks for and never uses.  13 KB of its own let eight workgroups of it -- every wave slot -- sit on a CU; with 8 KB
+    // more there are seven, and in the batched pipeline, where this kernel runs next to FAST for a whole step, that is worth 2 % of the
+    // C2 step: 1.174 against 1.198 ms over eight interleaved runs each (1.163 - 1.181 against 1.185 - 1.196 in four more series);
+    // + 4 KB changes nothing, + 12 KB gains half of it, + 16 KB and more lose (1.196 ... 1.31); 1280 x 720 and 1920 x 1080 do not care
+    // (3.50 / 3.51, 2.81 / 2.83).  The same cap by registers (amdgpu_waves_per_eu(7, 7)) loses 4 %, the same 8 KB as dynamic LDS of
+    // the launch gains nothing (12 KB: 1.2 %) -- tools/sweeps.md has the tables; alone the kernel takes 231 us either way.
+    __shared__ uint32_t s_pad[OD2_LDS_PAD / 4];
+    if (nlevels < 0) s_pad[threadIdx.x] = 1;                             // (never: keeps the array)
+    if (nlevels < -1) kps[0].x = (float)s_pad[threadIdx.x ^ 1];
+#endif
     if (threadIdx.x < 31 * 4) s_icw[threadIdx.x] = icw[threadIdx.x];
     s_pattern[threadIdx.x] = pattern32[threadIdx.x];
     __syncthreads();

@@ -97,6 +97,9 @@ __global__ void k_blur7_mfma(ImgView src0, ImgView pyr, ImgView blur, const Leve
                              const uint4* tab2, int K2, int nstrips, int nx, int total);
 template <bool ED> __global__ void k_blur7(ImgView src0, ImgView pyr, ImgView blur, const LevelGeom* geom, const uint32_t* strips, int nx,
                         int total);
+#ifndef OD2_LDS_PAD
+#define OD2_LDS_PAD 8192   // k_orient_describe2: unused LDS that caps its workgroups at seven a CU (see the kernel)
+#endif
 __global__ void k_orient_describe2(ImgView src0, ImgView pyr, ImgView blur, const LevelGeom* geom,
                                   const uint32_t* flat_kv, const uint8_t* flat_lvl, const int32_t* n_out, int nlevels,
                                   const uint32_t* pattern32, const uint4* icw, orbfe_keypoint* kps, uint8_t* desc,
